@@ -1,0 +1,64 @@
+"""Deterministic synthetic read generator: counter-based splitmix64 so that the
+same reads can be produced by C (fermi_amd/host/synth.c), numpy (here) or a kernel.
+
+rnd(seed, stream, i) = the i-th output of splitmix64 seeded with  seed ^ (stream * K)
+  genome base i      : 1 + (rnd(seed,1,i) >> 62)                          (nt6: A=1 C=2 G=3 T=4)
+  read r position    : rnd(seed,2,r) % (G - L + 1)
+  read r strand      : rnd(seed,3,r) >> 63          (1 = reverse complement of the genome window)
+  read r base j error: u = rnd(seed,4,r*L+j); substitute iff (u >> 32) < floor(err * 2^32),
+                       new base = 1 + ((old - 1) + 1 + (u & 0xffffffff) % 3) % 4
+Genome length G = N * L / coverage (integer division).
+"""
+import numpy as np
+
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+_K = np.uint64(0xD1B54A32D192ED03)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+DEFAULT_SEED = 20260928
+
+
+def rnd(seed, stream, idx):
+    """Vectorised splitmix64 output number `idx` (array) of stream `stream`."""
+    with np.errstate(over="ignore"):
+        s = np.uint64(seed) ^ (np.uint64(stream) * _K)
+        z = s + (np.asarray(idx, dtype=np.uint64) + np.uint64(1)) * _GOLD
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+def genome(seed, n_reads, read_len=100, coverage=30):
+    g = n_reads * read_len // coverage
+    if g < read_len:
+        g = read_len
+    return (1 + (rnd(seed, 1, np.arange(g, dtype=np.uint64)) >> np.uint64(62))).astype(np.uint8)
+
+
+def reads(seed, n_reads, read_len=100, coverage=30, err=0.0, start=0, count=None):
+    """Return uint8 [count, read_len] nt6 reads `start .. start+count` of the n_reads-read set."""
+    if count is None:
+        count = n_reads - start
+    gen = genome(seed, n_reads, read_len, coverage)
+    G = gen.shape[0]
+    r = np.arange(start, start + count, dtype=np.uint64)
+    pos = (rnd(seed, 2, r) % np.uint64(G - read_len + 1)).astype(np.int64)
+    strand = (rnd(seed, 3, r) >> np.uint64(63)).astype(bool)
+    win = gen[pos[:, None] + np.arange(read_len)[None, :]]
+    rc = (5 - win)[:, ::-1]
+    out = np.where(strand[:, None], rc, win).astype(np.uint8)
+    if err > 0:
+        thr = np.uint64(int(err * 4294967296.0))
+        u = rnd(seed, 4, (r[:, None] * np.uint64(read_len) + np.arange(read_len, dtype=np.uint64)[None, :]))
+        hit = (u >> np.uint64(32)) < thr
+        sub = (1 + ((out.astype(np.uint64) - 1) + 1 + (u & np.uint64(0xFFFFFFFF)) % np.uint64(3)) % 4).astype(np.uint8)
+        out = np.where(hit, sub, out)
+    return np.ascontiguousarray(out)
+
+
+def to_fastq(reads_nt6, path, qual="I"):
+    tab = np.frombuffer(b"$ACGTN", dtype=np.uint8)
+    with open(path, "wb") as fp:
+        for i, r in enumerate(reads_nt6):
+            s = tab[r].tobytes()
+            fp.write(b"@r%d\n%s\n+\n%s\n" % (i, s, qual.encode() * len(s)))
