@@ -1,0 +1,39 @@
+# Top-level build: the HIP library (gfx950 only), the C host library / CLI, and the oracle.
+#   make            -> fermi_amd/lib/libfmdhip.so  fermi_amd/lib/libfmdhost.so  oracle/liboracle.so
+#   make ref        -> oracle/_ref/ (only where /root/reference exists)
+HIPCC    ?= hipcc
+ARCH     ?= gfx950
+HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value
+CC        = gcc
+CFLAGS    = -O2 -g -Wall -fPIC -std=gnu11
+
+HIP_SRCS  = $(wildcard fermi_amd/csrc/*.hip)
+HIP_HDRS  = $(wildcard fermi_amd/csrc/*.h) include/fmd_hip.h
+HIP_OBJS  = $(patsubst fermi_amd/csrc/%.hip,build/%.o,$(HIP_SRCS))
+HOST_SRCS = $(wildcard fermi_amd/host/*.c)
+HOST_HDRS = $(wildcard fermi_amd/host/*.h) include/fmd_hip.h
+
+all: fermi_amd/lib/libfmdhip.so host oracle
+
+build/%.o: fermi_amd/csrc/%.hip $(HIP_HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+fermi_amd/lib/libfmdhip.so: $(HIP_OBJS)
+	@mkdir -p fermi_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJS) -o $@
+
+host: fermi_amd/lib/libfmdhost.so
+fermi_amd/lib/libfmdhost.so: $(HOST_SRCS) $(HOST_HDRS)
+	@mkdir -p fermi_amd/lib
+	@if [ -n "$(HOST_SRCS)" ]; then $(CC) $(CFLAGS) -shared -Iinclude $(HOST_SRCS) -o $@ -lpthread -lm -lz; fi
+
+oracle:
+	$(MAKE) -s -C oracle oracle
+ref:
+	$(MAKE) -s -C oracle ref
+
+clean:
+	rm -rf build fermi_amd/lib/*.so
+	$(MAKE) -s -C oracle clean
+.PHONY: all host oracle ref clean

@@ -1,0 +1,199 @@
+"""ctypes view of the C ABI in include/fmd_hip.h (libfmdhip.so) -- the product path.
+
+Names mirror the reference's C API (rld.h:45-58, fermi.h:61-103): `rld_restore` -> DevIndex.open,
+`rld_rank1a` -> rank1a, `rld_rank2a` -> rank2a, `fm6_extend` -> extend, `fm_backward_search` ->
+backward_search, `fm_retrieve` -> retrieve.  Everything here runs on the GPU; there is no CPU
+fallback -- if the library or a device is missing the calls raise FmdError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfmdhip.so")
+INTV_DT = np.dtype([("x", "<u8", 3), ("info", "<u8")])  # fmd_intv_t == fmintv_t (fermi.h:13-16)
+NONE64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+# every symbol include/fmd_hip.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "fmd_strerror", "fmd_last_hip_error", "fmd_device_count",
+    "fmd_dev_open_file", "fmd_dev_open_rld", "fmd_dev_open_rle6", "fmd_dev_open_bwt", "fmd_dev_open_bwt_dev",
+    "fmd_dev_close", "fmd_dev_info", "fmd_dev_sync",
+    "fmd_rank1a_dev", "fmd_rank2a_dev", "fmd_rank1a_batch", "fmd_rank2a_batch",
+    "fmd_extend_dev", "fmd_extend_batch", "fmd_bsearch_dev", "fmd_bsearch_batch",
+    "fmd_retrieve_dev", "fmd_retrieve_batch", "fmd_probe_gather",
+]
+
+
+class FmdError(RuntimeError):
+    pass
+
+
+class Info(C.Structure):
+    _fields_ = [("cnt", C.c_uint64 * 7), ("mcnt", C.c_uint64 * 7), ("n_blocks", C.c_uint64),
+                ("hbm_bytes", C.c_uint64), ("device", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libfmdhip.so; raises FmdError (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FmdError("libfmdhip.so is not built (%s); run `make` or __graft_entry__.build()" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, sz, u64p = C.c_void_p, C.c_size_t, C.c_void_p
+        L.fmd_strerror.restype = C.c_char_p; L.fmd_strerror.argtypes = [C.c_int]
+        L.fmd_last_hip_error.restype = C.c_char_p
+        L.fmd_device_count.restype = C.c_int
+        L.fmd_dev_open_file.argtypes = [C.c_int, C.c_char_p, C.POINTER(vp)]
+        L.fmd_dev_open_rld.argtypes = [C.c_int, vp, C.c_uint64, vp, C.POINTER(vp)]
+        L.fmd_dev_open_rle6.argtypes = [C.c_int, vp, C.c_uint64, C.POINTER(vp)]
+        L.fmd_dev_open_bwt.argtypes = [C.c_int, vp, C.c_uint64, C.POINTER(vp)]
+        L.fmd_dev_open_bwt_dev.argtypes = [C.c_int, vp, C.c_uint64, C.POINTER(vp)]
+        L.fmd_dev_close.restype = None; L.fmd_dev_close.argtypes = [vp]
+        L.fmd_dev_info.argtypes = [vp, C.POINTER(Info)]
+        L.fmd_dev_sync.argtypes = [vp, vp]
+        L.fmd_rank1a_dev.argtypes = [vp, vp, sz, u64p, u64p, vp]
+        L.fmd_rank2a_dev.argtypes = [vp, vp, sz, u64p, u64p, u64p, u64p]
+        L.fmd_rank1a_batch.argtypes = [vp, sz, u64p, u64p, vp]
+        L.fmd_rank2a_batch.argtypes = [vp, sz, u64p, u64p, u64p, u64p]
+        L.fmd_extend_dev.argtypes = [vp, vp, sz, vp, vp, vp]
+        L.fmd_extend_batch.argtypes = [vp, sz, vp, vp, vp]
+        L.fmd_bsearch_dev.argtypes = [vp, vp, sz, vp, u64p, u64p, u64p, u64p]
+        L.fmd_bsearch_batch.argtypes = [vp, sz, vp, u64p, u64p, u64p, u64p]
+        L.fmd_retrieve_dev.argtypes = [vp, vp, sz, u64p, vp, C.c_uint32, vp, u64p]
+        L.fmd_retrieve_batch.argtypes = [vp, sz, u64p, vp, C.c_uint32, vp, u64p]
+        L.fmd_probe_gather.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_float)]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        L = lib()
+        msg = L.fmd_strerror(rc).decode()
+        if rc == -6:
+            msg += ": " + L.fmd_last_hip_error().decode()
+        raise FmdError("libfmdhip: %s (%d)" % (msg, rc))
+
+
+def device_count():
+    return lib().fmd_device_count()
+
+
+def _ptr(a):
+    return a.ctypes.data
+
+
+def flatten_reads(seqs):
+    """list/2-D array of nt6 reads -> (uint8 concatenation padded to 8 bytes, uint64 offsets[n+1])"""
+    if isinstance(seqs, np.ndarray) and seqs.ndim == 2:
+        n, ln = seqs.shape
+        off = np.arange(n + 1, dtype=np.uint64) * np.uint64(ln)
+        flat = np.ascontiguousarray(seqs, dtype=np.uint8).reshape(-1)
+    else:
+        lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+        off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        np.cumsum(lens, out=off[1:])
+        flat = np.concatenate([np.asarray(s, dtype=np.uint8) for s in seqs]) if len(seqs) else np.zeros(0, np.uint8)
+    pad = (-len(flat)) % 8 + 8
+    return np.concatenate([flat, np.zeros(pad, dtype=np.uint8)]), off
+
+
+class DevIndex:
+    """An FMD index resident in one GPU's HBM (fmd_dev_t)."""
+
+    def __init__(self, handle):
+        self.h = handle
+        info = Info()
+        check(lib().fmd_dev_info(self.h, C.byref(info)))
+        self.cnt = np.array(info.cnt[:], dtype=np.uint64)
+        self.mcnt = np.array(info.mcnt[:], dtype=np.uint64)
+        self.n_blocks = int(info.n_blocks)
+        self.hbm_bytes = int(info.hbm_bytes)
+        self.device = int(info.device)
+        self.n = int(self.mcnt[0])
+
+    # ---- rld_restore (rld.c:288) and friends
+    @classmethod
+    def open(cls, fn, device=0):
+        h = C.c_void_p()
+        check(lib().fmd_dev_open_file(device, fn.encode(), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_bwt(cls, bwt, device=0):
+        bwt = np.ascontiguousarray(bwt, dtype=np.uint8)
+        h = C.c_void_p()
+        check(lib().fmd_dev_open_bwt(device, _ptr(bwt), len(bwt), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_bwt_dev(cls, d_ptr, n, device=0):
+        h = C.c_void_p()
+        check(lib().fmd_dev_open_bwt_dev(device, d_ptr, n, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_rle6(cls, runs, device=0):
+        runs = np.ascontiguousarray(runs, dtype=np.uint8)
+        h = C.c_void_p()
+        check(lib().fmd_dev_open_rle6(device, _ptr(runs), len(runs), C.byref(h)))
+        return cls(h)
+
+    def close(self):  # rld_destroy (rld.c:81)
+        if self.h:
+            lib().fmd_dev_close(self.h)
+            self.h = None
+
+    def sync(self, stream=None):
+        check(lib().fmd_dev_sync(self.h, stream))
+
+    # ---- host-array forms
+    def rank1a(self, ks):
+        ks = np.ascontiguousarray(ks, dtype=np.uint64)
+        ok = np.zeros((len(ks), 6), dtype=np.uint64); sym = np.zeros(len(ks), dtype=np.int8)
+        check(lib().fmd_rank1a_batch(self.h, len(ks), _ptr(ks), _ptr(ok), _ptr(sym)))
+        return ok, sym
+
+    def rank2a(self, ks, ls):
+        ks = np.ascontiguousarray(ks, dtype=np.uint64); ls = np.ascontiguousarray(ls, dtype=np.uint64)
+        ok = np.zeros((len(ks), 6), dtype=np.uint64); ol = np.zeros((len(ks), 6), dtype=np.uint64)
+        check(lib().fmd_rank2a_batch(self.h, len(ks), _ptr(ks), _ptr(ls), _ptr(ok), _ptr(ol)))
+        return ok, ol
+
+    def extend(self, iks, is_back):
+        iks = np.ascontiguousarray(iks, dtype=INTV_DT); is_back = np.ascontiguousarray(is_back, dtype=np.uint8)
+        out = np.zeros((len(iks), 6), dtype=INTV_DT)
+        check(lib().fmd_extend_batch(self.h, len(iks), _ptr(iks), _ptr(is_back), _ptr(out)))
+        return out
+
+    def backward_search(self, seqs):
+        flat, off = flatten_reads(seqs)
+        n = len(off) - 1
+        cnt = np.zeros(n, dtype=np.uint64); beg = np.zeros(n, dtype=np.uint64); end = np.zeros(n, dtype=np.uint64)
+        check(lib().fmd_bsearch_batch(self.h, n, _ptr(flat), _ptr(off), _ptr(cnt), _ptr(beg), _ptr(end)))
+        return cnt, beg, end
+
+    def retrieve(self, xs, stride=256):
+        """fm_retrieve for each x, returned in READ order (the C ABI returns it reversed, as
+        exact.c:59 does; this wrapper applies the callers' seq_reverse, unitig.c:285)."""
+        xs = np.ascontiguousarray(xs, dtype=np.uint64)
+        seqs = np.zeros((len(xs), stride), dtype=np.uint8); ln = np.zeros(len(xs), dtype=np.uint32)
+        rank = np.zeros(len(xs), dtype=np.uint64)
+        check(lib().fmd_retrieve_batch(self.h, len(xs), _ptr(xs), _ptr(seqs), stride, _ptr(ln), _ptr(rank)))
+        out = np.zeros_like(seqs)
+        for i in range(len(xs)):
+            l = min(int(ln[i]), stride)
+            out[i, :l] = seqs[i, :l][::-1]
+        return out, ln.astype(np.int32), rank
+
+
+def probe_gather(ws_bytes, line_bytes, n_access, iters=3, device=0):
+    ms = C.c_float(0)
+    check(lib().fmd_probe_gather(device, ws_bytes, line_bytes, n_access, iters, C.byref(ms)))
+    return ms.value

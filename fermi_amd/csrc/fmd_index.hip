@@ -1,0 +1,435 @@
+// fmd_index.hip -- index residency: upload a fermi .fmd (RLD\2 or RLE\6) or a plain BWT and
+// transcode it ON THE GPU into the fixed-stride rank-block layout of fmd_wave.h.
+// Replaces rld_restore / rld_restore_mmap / rld_destroy (rld.c:288, :327, :81) for the device.
+#include <hipcub/hipcub.hpp>
+#include <stdlib.h>
+#include <string.h>
+#include <atomic>
+#include "fmd_internal.h"
+
+// ---------------------------------------------------------------------------------- errors
+static thread_local char g_hip_err[256] = "";
+void fmd_set_hip_error(hipError_t e, const char *what)
+{
+    snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s", what, hipGetErrorString(e));
+}
+extern "C" const char *fmd_last_hip_error(void) { return g_hip_err; }
+extern "C" const char *fmd_strerror(int code)
+{
+    switch (code) {
+    case FMD_OK: return "ok";
+    case FMD_E_NODEV: return "no usable HIP device (libfmdhip has no CPU fallback)";
+    case FMD_E_ARG: return "bad argument";
+    case FMD_E_FORMAT: return "not a fermi .fmd (RLD\\2 with asize 6 / sbits 3, or RLE\\6)";
+    case FMD_E_IO: return "file I/O failed";
+    case FMD_E_NOMEM: return "out of host or device memory";
+    case FMD_E_HIP: return "HIP runtime error (see fmd_last_hip_error)";
+    case FMD_E_OVERFLOW: return "fixed-capacity device list overflowed";
+    default: return "unknown error";
+    }
+}
+extern "C" int fmd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------- transcode: plain BWT
+// one thread per 32-position chunk
+__global__ void k_bwt_to_planes(const uint8_t *__restrict__ bwt, uint64_t n, uint4 *__restrict__ blocks, uint64_t n_chunks)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const uint64_t p0 = c * 32;
+    uint32_t a = 0, b = 0, d = 0;
+    if (p0 + 32 <= n) {
+        const uint4 *src = (const uint4 *)(bwt + p0); // hipMalloc'd + 32-byte stride: aligned
+        const uint4 v0 = src[0], v1 = src[1];
+        const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t s = (w[i] >> (8 * j)) & 7;
+                a |= (s & 1) << (4 * i + j); b |= ((s >> 1) & 1) << (4 * i + j); d |= ((s >> 2) & 1) << (4 * i + j);
+            }
+    } else {
+        for (int i = 0; i < 32 && p0 + i < n; ++i) {
+            const uint32_t s = bwt[p0 + i] & 7;
+            a |= (s & 1) << i; b |= ((s >> 1) & 1) << i; d |= ((s >> 2) & 1) << i;
+        }
+    }
+    uint4 *dst = blocks + c; // chunk c of the flat chunk array == blocks[c>>3] chunk c&7
+    dst->x = a; dst->y = b; dst->z = d;
+}
+
+// --------------------------------------------------------- transcode: scatter of (sym,len) runs
+// OR `len` copies of symbol `sym` into the planes starting at BWT position `pos`.
+__device__ __forceinline__ void fmd_or_run(uint32_t *words, uint64_t pos, uint64_t len, uint32_t sym)
+{
+    if (sym == 0) return; // '$' = all-zero planes
+    uint64_t p = pos, end = pos + len;
+    while (p < end) {
+        const uint32_t bit = (uint32_t)p & 31;
+        const uint64_t take = (end - p < 32 - bit) ? end - p : 32 - bit;
+        const uint32_t m = (take == 32 ? 0xffffffffu : ((1u << take) - 1u)) << bit;
+        uint32_t *w = words + (p >> 5) * 4; // chunk = 4 words
+        if (take == 32) {                   // whole word is ours
+            if (sym & 1) w[0] = m;
+            if (sym & 2) w[1] = m;
+            if (sym & 4) w[2] = m;
+        } else {
+            if (sym & 1) atomicOr(w + 0, m);
+            if (sym & 2) atomicOr(w + 1, m);
+            if (sym & 4) atomicOr(w + 2, m);
+        }
+        p += take;
+    }
+}
+
+// RLE\6 stream: byte = len<<3 | sym, len 1..31 (ropebwt.c:132-136; reader rld.c:295-308)
+__global__ void k_rle6_len(const uint8_t *__restrict__ runs, uint64_t n, uint64_t *__restrict__ len)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) len[i] = runs[i] >> 3;
+}
+__global__ void k_rle6_scatter(const uint8_t *__restrict__ runs, uint64_t n, const uint64_t *__restrict__ start,
+                               uint32_t *__restrict__ words, uint64_t *__restrict__ sym_total)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t l = runs[i] >> 3, c = runs[i] & 7;
+    if (l) fmd_or_run(words, start[i], l, c);
+    if (i == n - 1) *sym_total = start[i] + l;
+}
+
+// RLD\2 payload (rld.c:111-175 writer; rld.h:77-94 decoder): 64-byte blocks, header = counts of
+// the PREVIOUS block as 7 x u16 or (bit 31 of the first u32 set) 7 x u32, then MSB-first
+// Elias-delta run codes.
+__device__ __forceinline__ uint64_t rld_hdr_size(const uint64_t *blk)
+{
+    const uint32_t w0 = (uint32_t)blk[0];
+    return (w0 >> 31) ? (w0 & 0x7fffffffu) : (w0 & 0xffffu);
+}
+__global__ void k_rld_sizes(const uint64_t *__restrict__ w, uint64_t n_rld_blocks, uint64_t *__restrict__ size)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n_rld_blocks) size[b] = rld_hdr_size(w + (b + 1) * 8); // next header describes block b
+}
+__device__ __forceinline__ uint64_t rld_peek(const uint64_t *w, uint32_t bit /*0..511*/)
+{
+    const uint32_t i = bit >> 6, off = bit & 63;
+    if (i >= 8) return 0;
+    uint64_t x = w[i] << off;
+    if (off && i + 1 < 8) x |= w[i + 1] >> (64 - off);
+    return x;
+}
+__global__ void k_rld_scatter(const uint64_t *__restrict__ w, uint64_t n_rld_blocks, const uint64_t *__restrict__ start,
+                              uint32_t *__restrict__ words, uint64_t *__restrict__ sym_total)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_rld_blocks) return;
+    const uint64_t *blk = w + b * 8;
+    uint32_t bit = (((uint32_t)blk[0] >> 31) ? 4u : 2u) * 64u;
+    uint64_t pos = start[b];
+    for (;;) {
+        const uint64_t x = rld_peek(blk, bit);
+        uint64_t len; uint32_t sym;
+        if (x >> 63) { len = 1; sym = (uint32_t)(x >> 60) & 7; bit += 4; }
+        else {
+            const int z = x ? __clzll((long long)x) : 64;
+            if (z >= 6) break;                                   // zero padding: block exhausted
+            const int gw = 2 * z + 1, nlow = (int)(x >> (64 - gw)) - 1;
+            len = ((x << gw) >> (64 - nlow)) | (1ull << nlow);
+            sym = (uint32_t)((x << (gw + nlow)) >> 61);
+            bit += (uint32_t)(gw + nlow + 3);
+        }
+        fmd_or_run(words, pos, len, sym);
+        pos += len;
+    }
+    if (b == n_rld_blocks - 1) *sym_total = pos;
+}
+
+// -------------------------------------------------------------- per-block symbol counts + meta
+__global__ void k_block_counts(const uint4 *__restrict__ blocks, uint64_t n_blocks, uint64_t *__restrict__ bc)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    uint32_t n[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint4 v = blocks[b * 8 + c];
+        n[0] += __builtin_popcount(~v.z & ~v.y & ~v.x); n[1] += __builtin_popcount(~v.z & ~v.y & v.x);
+        n[2] += __builtin_popcount(~v.z & v.y & ~v.x);  n[3] += __builtin_popcount(~v.z & v.y & v.x);
+        n[4] += __builtin_popcount(v.z & ~v.y & ~v.x);  n[5] += __builtin_popcount(v.z & ~v.y & v.x);
+    }
+#pragma unroll
+    for (int s = 0; s < 6; ++s) bc[(uint64_t)s * n_blocks + b] = n[s];
+}
+__global__ void k_write_meta(uint4 *__restrict__ blocks, uint64_t n_blocks, const uint64_t *__restrict__ acc)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    uint64_t a[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) a[s] = acc[(uint64_t)s * n_blocks + b];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) blocks[b * 8 + s].w = (uint32_t)a[s];
+    blocks[b * 8 + 6].w = (uint32_t)((a[0] >> 32) & 0xff) | (uint32_t)((a[1] >> 32) & 0xff) << 8 |
+                          (uint32_t)((a[2] >> 32) & 0xff) << 16 | (uint32_t)((a[3] >> 32) & 0xff) << 24;
+    blocks[b * 8 + 7].w = (uint32_t)((a[4] >> 32) & 0xff) | (uint32_t)((a[5] >> 32) & 0xff) << 8;
+}
+
+// --------------------------------------------------------------------------------- host side
+static int scan_u64(uint64_t *d_in, uint64_t *d_out, uint64_t n, hipStream_t st)
+{
+    void *tmp = nullptr; size_t tmp_bytes = 0;
+    FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_in, d_out, (size_t)n, st));
+    FMD_HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, d_in, d_out, (size_t)n, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    hipFree(tmp);
+    FMD_HIP_TRY(e); FMD_HIP_TRY(e2);
+    return FMD_OK;
+}
+
+static inline unsigned nblk(uint64_t n, unsigned t) { return (unsigned)((n + t - 1) / t); }
+
+static int dev_alloc_index(int device, uint64_t n_sym, fmd_dev **out)
+{
+    int ndev = fmd_device_count();
+    if (ndev <= 0 || device < 0 || device >= ndev) return FMD_E_NODEV;
+    if (n_sym == 0 || n_sym >= (1ull << 40)) return FMD_E_ARG; // 40-bit absolute counts
+    FMD_HIP_TRY(hipSetDevice(device));
+    fmd_dev *h = (fmd_dev *)calloc(1, sizeof(fmd_dev));
+    if (!h) return FMD_E_NOMEM;
+    hipDeviceProp_t prop;
+    FMD_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    h->device = device;
+    h->n_cu = prop.multiProcessorCount;
+    h->n_blocks = (n_sym + FMD_BLK_SYMS - 1) / FMD_BLK_SYMS + 1; // +1 pad block
+    h->bytes = h->n_blocks * 128;
+    hipError_t e = hipMalloc((void **)&h->blocks, h->bytes);
+    if (e != hipSuccess) { fmd_set_hip_error(e, "hipMalloc(index)"); free(h); return FMD_E_NOMEM; }
+    e = hipMalloc((void **)&h->queues, FMD_N_QUEUES * sizeof(uint32_t));
+    if (e != hipSuccess) { fmd_set_hip_error(e, "hipMalloc(queues)"); hipFree(h->blocks); free(h); return FMD_E_NOMEM; }
+    hipMemset(h->blocks, 0, h->bytes);
+    hipMemset(h->queues, 0, FMD_N_QUEUES * sizeof(uint32_t));
+    *out = h;
+    return FMD_OK;
+}
+
+// counts -> scan -> meta; also fills cnt/mcnt from the device counts
+static int finish_index(fmd_dev *h)
+{
+    const uint64_t nb = h->n_blocks;
+    uint64_t *bc = nullptr, *acc = nullptr;
+    FMD_HIP_TRY(hipMalloc((void **)&bc, 6 * nb * 8));
+    hipError_t e = hipMalloc((void **)&acc, 6 * nb * 8);
+    if (e != hipSuccess) { hipFree(bc); fmd_set_hip_error(e, "hipMalloc(scan)"); return FMD_E_NOMEM; }
+    k_block_counts<<<nblk(nb, 256), 256>>>(h->blocks, nb, bc);
+    int rc = FMD_OK;
+    for (int s = 0; s < 6 && rc == FMD_OK; ++s) rc = scan_u64(bc + s * nb, acc + s * nb, nb, 0);
+    if (rc == FMD_OK) {
+        k_write_meta<<<nblk(nb, 256), 256>>>(h->blocks, nb, acc);
+        // marginal counts = prefix at the pad block (positions past the end are '$'-coded zeros:
+        // correct mcnt[1] for them)
+        uint64_t last[6];
+        for (int s = 0; s < 6; ++s)
+            hipMemcpy(&last[s], acc + s * nb + (nb - 1), 8, hipMemcpyDeviceToHost);
+        const uint64_t pad = (nb - 1) * FMD_BLK_SYMS - h->mcnt[0];
+        last[0] -= pad;
+        h->mcnt[1] = last[0];
+        for (int s = 1; s < 6; ++s) h->mcnt[s + 1] = last[s];
+        h->cnt[0] = 0;
+        for (int s = 1; s < 7; ++s) h->cnt[s] = h->cnt[s - 1] + h->mcnt[s];
+        e = hipDeviceSynchronize();
+        if (e != hipSuccess) { fmd_set_hip_error(e, "transcode"); rc = FMD_E_HIP; }
+        else if (h->cnt[6] != h->mcnt[0]) rc = FMD_E_FORMAT;
+    }
+    hipFree(bc); hipFree(acc);
+    return rc;
+}
+
+extern "C" int fmd_dev_open_bwt_dev(int device, const uint8_t *d_bwt, uint64_t n, fmd_dev_t **out)
+{
+    if (!d_bwt || !out) return FMD_E_ARG;
+    fmd_dev *h = nullptr;
+    int rc = dev_alloc_index(device, n, &h);
+    if (rc) return rc;
+    h->mcnt[0] = n;
+    const uint64_t n_chunks = (n + 31) / 32;
+    k_bwt_to_planes<<<nblk(n_chunks, 256), 256>>>(d_bwt, n, h->blocks, n_chunks);
+    rc = finish_index(h);
+    if (rc) { fmd_dev_close(h); return rc; }
+    *out = h;
+    return FMD_OK;
+}
+
+extern "C" int fmd_dev_open_bwt(int device, const uint8_t *bwt, uint64_t n, fmd_dev_t **out)
+{
+    if (!bwt || !out) return FMD_E_ARG;
+    if (fmd_device_count() <= 0) return FMD_E_NODEV;
+    FMD_HIP_TRY(hipSetDevice(device));
+    uint8_t *d = nullptr;
+    FMD_HIP_TRY(hipMalloc((void **)&d, n + 64));
+    hipError_t e = hipMemcpy(d, bwt, n, hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? fmd_dev_open_bwt_dev(device, d, n, out) : FMD_E_HIP;
+    hipFree(d);
+    return rc;
+}
+
+extern "C" int fmd_dev_open_rle6(int device, const uint8_t *runs, uint64_t n_bytes, fmd_dev_t **out)
+{
+    if (!runs || !out || n_bytes == 0) return FMD_E_ARG;
+    if (fmd_device_count() <= 0) return FMD_E_NODEV;
+    FMD_HIP_TRY(hipSetDevice(device));
+    uint8_t *d_runs = nullptr; uint64_t *d_len = nullptr, *d_start = nullptr, *d_tot = nullptr;
+    int rc = FMD_OK;
+    fmd_dev *h = nullptr;
+    uint64_t n_sym = 0;
+    FMD_HIP_TRY(hipMalloc((void **)&d_runs, n_bytes));
+    if (hipMalloc((void **)&d_len, n_bytes * 8) != hipSuccess || hipMalloc((void **)&d_start, n_bytes * 8) != hipSuccess ||
+        hipMalloc((void **)&d_tot, 8) != hipSuccess) { rc = FMD_E_NOMEM; goto done; }
+    hipMemcpy(d_runs, runs, n_bytes, hipMemcpyHostToDevice);
+    k_rle6_len<<<nblk(n_bytes, 256), 256>>>(d_runs, n_bytes, d_len);
+    rc = scan_u64(d_len, d_start, n_bytes, 0);
+    if (rc) goto done;
+    { // total = start[last] + len[last]
+        uint64_t a, b;
+        hipMemcpy(&a, d_start + n_bytes - 1, 8, hipMemcpyDeviceToHost);
+        hipMemcpy(&b, d_len + n_bytes - 1, 8, hipMemcpyDeviceToHost);
+        n_sym = a + b;
+    }
+    rc = dev_alloc_index(device, n_sym, &h);
+    if (rc) goto done;
+    h->mcnt[0] = n_sym;
+    k_rle6_scatter<<<nblk(n_bytes, 256), 256>>>(d_runs, n_bytes, d_start, (uint32_t *)h->blocks, d_tot);
+    rc = finish_index(h);
+done:
+    hipFree(d_runs); hipFree(d_len); hipFree(d_start); hipFree(d_tot);
+    if (rc) { if (h) fmd_dev_close(h); return rc; }
+    *out = h;
+    return FMD_OK;
+}
+
+extern "C" int fmd_dev_open_rld(int device, const uint64_t *payload, uint64_t n_words, const uint64_t mcnt[7], fmd_dev_t **out)
+{
+    if (!payload || !out || !mcnt || n_words < 10) return FMD_E_ARG;
+    if (fmd_device_count() <= 0) return FMD_E_NODEV;
+    FMD_HIP_TRY(hipSetDevice(device));
+    // blocks 0 .. last/8-1 carry payload; the block at word `last` is header-only (rld.h:64)
+    const uint64_t n_rld = n_words / 8;
+    if (n_rld == 0) return FMD_E_FORMAT;
+    uint64_t *d_w = nullptr, *d_size = nullptr, *d_start = nullptr, *d_tot = nullptr;
+    int rc = FMD_OK;
+    fmd_dev *h = nullptr;
+    FMD_HIP_TRY(hipMalloc((void **)&d_w, (n_rld + 1) * 64));
+    if (hipMalloc((void **)&d_size, n_rld * 8) != hipSuccess || hipMalloc((void **)&d_start, n_rld * 8) != hipSuccess ||
+        hipMalloc((void **)&d_tot, 8) != hipSuccess) { rc = FMD_E_NOMEM; goto done; }
+    hipMemset(d_w, 0, (n_rld + 1) * 64);
+    hipMemcpy(d_w, payload, n_words * 8, hipMemcpyHostToDevice);
+    k_rld_sizes<<<nblk(n_rld, 256), 256>>>(d_w, n_rld, d_size);
+    rc = scan_u64(d_size, d_start, n_rld, 0);
+    if (rc) goto done;
+    rc = dev_alloc_index(device, mcnt[0], &h);
+    if (rc) goto done;
+    h->mcnt[0] = mcnt[0];
+    k_rld_scatter<<<nblk(n_rld, 64), 64>>>(d_w, n_rld, d_start, (uint32_t *)h->blocks, d_tot);
+    {
+        uint64_t tot = 0;
+        hipMemcpy(&tot, d_tot, 8, hipMemcpyDeviceToHost);
+        if (tot != mcnt[0]) { rc = FMD_E_FORMAT; goto done; }
+    }
+    rc = finish_index(h);
+    if (rc == FMD_OK)
+        for (int s = 1; s < 7; ++s) if (h->mcnt[s] != mcnt[s]) rc = FMD_E_FORMAT; // header vs decoded stream
+done:
+    hipFree(d_w); hipFree(d_size); hipFree(d_start); hipFree(d_tot);
+    if (rc) { if (h) fmd_dev_close(h); return rc; }
+    *out = h;
+    return FMD_OK;
+}
+
+// .fmd file: header = "RLD\2", u32 asize<<16|sbits, u64 0, u64 n_bytes, u64 n_frames, u64 mcnt[1..6]
+// (rld.c:242-263); anything else is treated as a raw run-length byte stream after a 4-byte
+// magic, as rld_restore does (rld.c:295-308).
+extern "C" int fmd_dev_open_file(int device, const char *fn, fmd_dev_t **out)
+{
+    if (!fn || !out) return FMD_E_ARG;
+    FILE *fp = fopen(fn, "rb");
+    if (!fp) return FMD_E_IO;
+    char magic[4];
+    int rc;
+    if (fread(magic, 1, 4, fp) != 4) { fclose(fp); return FMD_E_FORMAT; }
+    if (memcmp(magic, "RLD\2", 4) == 0) {
+        uint32_t a; uint64_t hdr[3], mcnt[7];
+        if (fread(&a, 4, 1, fp) != 1 || fread(hdr, 8, 3, fp) != 3 || fread(mcnt + 1, 8, 6, fp) != 6) { fclose(fp); return FMD_E_FORMAT; }
+        if ((a >> 16) != 6 || (a & 0xffff) != 3 || (hdr[1] & 7)) { fclose(fp); return FMD_E_FORMAT; }
+        mcnt[0] = 0;
+        for (int s = 1; s < 7; ++s) mcnt[0] += mcnt[s];
+        const uint64_t n_words = hdr[1] / 8;
+        uint64_t *w = (uint64_t *)malloc(n_words * 8 + 64);
+        if (!w) { fclose(fp); return FMD_E_NOMEM; }
+        if (fread(w, 8, n_words, fp) != n_words) { free(w); fclose(fp); return FMD_E_IO; }
+        fclose(fp); // the rank frames that follow are not needed: the device layout has none
+        rc = fmd_dev_open_rld(device, w, n_words, mcnt, out);
+        free(w);
+        return rc;
+    } else {
+        fseek(fp, 0, SEEK_END);
+        const long sz = ftell(fp);
+        if (sz <= 4) { fclose(fp); return FMD_E_FORMAT; }
+        fseek(fp, 4, SEEK_SET);
+        uint8_t *buf = (uint8_t *)malloc((size_t)sz - 4);
+        if (!buf) { fclose(fp); return FMD_E_NOMEM; }
+        if (fread(buf, 1, (size_t)sz - 4, fp) != (size_t)sz - 4) { free(buf); fclose(fp); return FMD_E_IO; }
+        fclose(fp);
+        rc = fmd_dev_open_rle6(device, buf, (uint64_t)sz - 4, out);
+        free(buf);
+        return rc;
+    }
+}
+
+extern "C" void fmd_dev_close(fmd_dev_t *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    hipFree(h->blocks);
+    hipFree(h->queues);
+    free(h);
+}
+
+extern "C" int fmd_dev_info(const fmd_dev_t *h, fmd_info_t *info)
+{
+    if (!h || !info) return FMD_E_ARG;
+    memcpy(info->cnt, h->cnt, sizeof(h->cnt));
+    memcpy(info->mcnt, h->mcnt, sizeof(h->mcnt));
+    info->n_blocks = h->n_blocks;
+    info->hbm_bytes = h->bytes;
+    info->device = h->device;
+    return FMD_OK;
+}
+
+extern "C" int fmd_dev_sync(const fmd_dev_t *h, void *stream)
+{
+    if (!h) return FMD_E_ARG;
+    FMD_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return FMD_OK;
+}
+
+uint32_t *fmd_next_queue(fmd_dev *h, hipStream_t stream)
+{
+    const uint32_t i = __atomic_fetch_add(&h->queue_next, 1u, __ATOMIC_RELAXED) % FMD_N_QUEUES;
+    hipMemsetAsync(h->queues + i, 0, sizeof(uint32_t), stream);
+    return h->queues + i;
+}
+
+int fmd_grid_for(const fmd_dev *h, size_t n_items)
+{
+    const size_t waves_needed = (n_items + 63) / 64;
+    const size_t resident = (size_t)h->n_cu * 10; // 16 KiB LDS per wave -> 10 waves per CU
+    size_t g = waves_needed < resident ? waves_needed : resident;
+    return (int)(g ? g : 1);
+}

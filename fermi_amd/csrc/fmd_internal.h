@@ -1,0 +1,46 @@
+// fmd_internal.h -- host-side internals shared by the .hip translation units of libfmdhip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/fmd_hip.h"
+#include "fmd_wave.h"
+
+struct fmd_dev {
+    int device;
+    int n_cu;                 // compute units on this GPU
+    uint64_t n_blocks;        // rank blocks incl. one trailing pad block
+    uint64_t bytes;           // HBM bytes held
+    uint4 *blocks;            // device
+    uint64_t cnt[7], mcnt[7];
+    uint32_t *queues;         // device ring of work-queue heads for the persistent kernels
+    uint32_t queue_next;      // host-side ring cursor (atomic)
+};
+#define FMD_N_QUEUES 256
+
+void fmd_set_hip_error(hipError_t e, const char *what);
+
+#define FMD_HIP_TRY(expr)                                       \
+    do {                                                        \
+        hipError_t e__ = (expr);                                \
+        if (e__ != hipSuccess) {                                \
+            fmd_set_hip_error(e__, #expr);                      \
+            return e__ == hipErrorOutOfMemory ? FMD_E_NOMEM : FMD_E_HIP; \
+        }                                                       \
+    } while (0)
+
+static inline FmdIndexView fmd_view(const fmd_dev *h)
+{
+    FmdIndexView v;
+    v.blocks = h->blocks;
+    for (int i = 0; i < 7; ++i) v.cnt[i] = h->cnt[i];
+    v.n_sym = h->mcnt[0];
+    v.n_seq = h->mcnt[1];
+    return v;
+}
+
+// next zeroed work-queue head for a persistent launch on `stream`
+uint32_t *fmd_next_queue(fmd_dev *h, hipStream_t stream);
+
+// persistent-grid size: waves (= 64-thread workgroups) to launch for n items
+int fmd_grid_for(const fmd_dev *h, size_t n_items);

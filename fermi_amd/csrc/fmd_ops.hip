@@ -1,0 +1,378 @@
+// fmd_ops.hip -- batched rank / extend / backward-search / retrieve kernels on the wave engine
+// of fmd_wave.h, and their C-ABI entry points (include/fmd_hip.h).
+//
+// Every kernel runs 64-thread workgroups (one wavefront, 16 KiB LDS); lane = one query/search.
+#include <stdlib.h>
+#include <string.h>
+#include "fmd_internal.h"
+
+#define NONE64 (~0ull)
+
+// ------------------------------------------------------------------------------ rank kernels
+// rld_rank1a (rld.c:424-446)
+__global__ __launch_bounds__(64) void k_rank1a(FmdIndexView ix, size_t n, const uint64_t *__restrict__ d_k,
+                                               uint64_t *__restrict__ d_ok, int8_t *__restrict__ d_sym)
+{
+    FMD_DECLARE_WAVE_LDS();
+    const int lane = fmd_lane();
+    const size_t stride = (size_t)gridDim.x * 64;
+    for (size_t base = (size_t)blockIdx.x * 64; base < n; base += stride) {
+        const size_t i = base + lane;
+        const uint64_t k = i < n ? d_k[i] : NONE64;
+        const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, k, NONE64);
+        if (i < n) {
+            uint64_t ok[6] = {0, 0, 0, 0, 0, 0};
+            int sym = -1;
+            if (r.hk) sym = fmd_block_rank6<true>(r.bk, r.t, r.nk, ok);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) d_ok[i * 6 + c] = ok[c];
+            if (d_sym) d_sym[i] = (int8_t)sym;
+        }
+    }
+}
+
+// rld_rank2a (rld.c:457-492)
+__global__ __launch_bounds__(64) void k_rank2a(FmdIndexView ix, size_t n, const uint64_t *__restrict__ d_k,
+                                               const uint64_t *__restrict__ d_l, uint64_t *__restrict__ d_ok,
+                                               uint64_t *__restrict__ d_ol)
+{
+    FMD_DECLARE_WAVE_LDS();
+    const int lane = fmd_lane();
+    const size_t stride = (size_t)gridDim.x * 64;
+    for (size_t base = (size_t)blockIdx.x * 64; base < n; base += stride) {
+        const size_t i = base + lane;
+        const uint64_t k = i < n ? d_k[i] : NONE64, l = i < n ? d_l[i] : NONE64;
+        const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, k, l);
+        if (i < n) {
+            uint64_t ok[6] = {0, 0, 0, 0, 0, 0}, ol[6] = {0, 0, 0, 0, 0, 0};
+            if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, ok);
+            if (r.hl) fmd_block_rank6<false>(r.bl, r.t, r.nl, ol);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { d_ok[i * 6 + c] = ok[c]; d_ol[i * 6 + c] = ol[c]; }
+        }
+    }
+}
+
+// fm6_extend (exact.c:72-88): one rank2a on strand o = !is_back, then the running sum over the
+// other strand in the fixed order $,T,G,C,A,N.
+__device__ __forceinline__ void fmd_extend_finish(const FmdIndexView &ix, const uint64_t x[3], int is_back,
+                                                  const uint64_t tk[6], const uint64_t tl[6], fmd_intv_t ok[6])
+{
+    uint64_t a[6], b[6], s[6];   // a: coordinate on the searched strand, b: on the other strand
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { a[c] = ix.cnt[c] + tk[c]; s[c] = tl[c] - tk[c]; }
+    uint64_t acc = is_back ? x[1] : x[0];
+    b[0] = acc; acc += s[0];
+    b[4] = acc; acc += s[4];
+    b[3] = acc; acc += s[3];
+    b[2] = acc; acc += s[2];
+    b[1] = acc; acc += s[1];
+    b[5] = acc;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        ok[c].x[0] = is_back ? a[c] : b[c];
+        ok[c].x[1] = is_back ? b[c] : a[c];
+        ok[c].x[2] = s[c];
+        ok[c].info = 0;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_extend(FmdIndexView ix, size_t n, const fmd_intv_t *__restrict__ d_ik,
+                                               const uint8_t *__restrict__ d_is_back, fmd_intv_t *__restrict__ d_ok)
+{
+    FMD_DECLARE_WAVE_LDS();
+    const int lane = fmd_lane();
+    const size_t stride = (size_t)gridDim.x * 64;
+    for (size_t base = (size_t)blockIdx.x * 64; base < n; base += stride) {
+        const size_t i = base + lane;
+        uint64_t x[3] = {0, 0, 0};
+        int is_back = 0;
+        uint64_t k = NONE64, l = NONE64;
+        if (i < n) {
+            x[0] = d_ik[i].x[0]; x[1] = d_ik[i].x[1]; x[2] = d_ik[i].x[2];
+            is_back = d_is_back[i] != 0;
+            const uint64_t a = is_back ? x[0] : x[1];
+            k = a - 1; l = a - 1 + x[2];
+        }
+        const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, k, l);
+        if (i < n) {
+            uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tl[6] = {0, 0, 0, 0, 0, 0};
+            if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
+            if (r.hl) fmd_block_rank6<false>(r.bl, r.t, r.nl, tl);
+            fmd_intv_t ok[6];
+            fmd_extend_finish(ix, x, is_back, tk, tl, ok);
+            uint4 *dst = (uint4 *)(d_ok + i * 6);
+            const uint4 *src = (const uint4 *)ok;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) dst[c] = src[c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------- fm_backward_search
+// exact.c:7-23.  Persistent waves; a lane that finishes its read (hit or early miss) pulls the
+// next read index from a global queue: ballot -> one atomicAdd per wave -> prefix popcount, so the
+// wave keeps 64 live SA intervals.
+__global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const uint8_t *__restrict__ seqs,
+                                                const uint64_t *__restrict__ off, uint64_t *__restrict__ d_cnt,
+                                                uint64_t *__restrict__ d_beg, uint64_t *__restrict__ d_end,
+                                                uint32_t *__restrict__ queue)
+{
+    FMD_DECLARE_WAVE_LDS();
+    const int lane = fmd_lane();
+    size_t rid = (size_t)-1;      // read being searched by this lane
+    uint64_t sbase = 0;           // off[rid]
+    int pos = -1;                 // next base to prepend
+    uint64_t k = 0, l = 0;
+    uint32_t cache = 0;           // 4 bases of the read around pos
+    bool live = false, exhausted = false;
+
+    for (;;) {
+        // ---- refill finished lanes from the queue
+        const uint64_t want = __ballot(!live && !exhausted);
+        if (want) {
+            uint32_t first = 0;
+            if (lane == 0) first = atomicAdd(queue, (uint32_t)__popcll(want));
+            first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+            if (!live && !exhausted) {
+                const size_t my = (size_t)first + __popcll(want & ((1ull << lane) - 1));
+                if (my < n) {
+                    rid = my; sbase = off[my];
+                    const int len = (int)(off[my + 1] - sbase);
+                    if (len <= 0) { d_cnt[my] = 0; d_beg[my] = 0; d_end[my] = 0; }
+                    else {
+                        const int c = seqs[sbase + len - 1];
+                        k = ix.cnt[c]; l = ix.cnt[c + 1] - 1;
+                        pos = len - 2;
+                        live = true;
+                        if (pos >= 0) cache = *(const uint32_t *)(seqs + ((sbase + pos) & ~3ull));
+                    }
+                } else exhausted = true;
+            }
+        }
+        if (__ballot(live) == 0) break;
+
+        // ---- retire lanes that have consumed their whole read (len == 1 lands here directly)
+        if (live && pos < 0) {
+            const bool hit = k <= l;
+            d_cnt[rid] = hit ? l - k + 1 : 0; d_beg[rid] = hit ? k : 0; d_end[rid] = hit ? l : 0;
+            live = false;
+        }
+        // ---- one backward step for every live lane: rank21(k-1, l, c)
+        int c = 0;
+        uint64_t qk = NONE64, ql = NONE64;
+        if (live) {
+            const uint64_t a = sbase + pos;
+            c = (int)((cache >> (8 * (a & 3))) & 0xff);
+            qk = k - 1; ql = l;
+        }
+        const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, qk, ql);
+        if (live) {
+            const uint64_t ok = r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, c) : 0;
+            const uint64_t ol = fmd_block_rank1(r.bl, r.t, r.nl, c);
+            k = ix.cnt[c] + ok;
+            l = ix.cnt[c] + ol - 1;
+            --pos;
+            if (k > l || pos < 0) {
+                const bool hit = k <= l;
+                d_cnt[rid] = hit ? l - k + 1 : 0; d_beg[rid] = hit ? k : 0; d_end[rid] = hit ? l : 0;
+                live = false;
+            } else if (((sbase + pos) & 3) == 3) {
+                cache = *(const uint32_t *)(seqs + ((sbase + pos) & ~3ull));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ fm_retrieve
+// exact.c:59-70: LF-walk from row x until '$'.  One dependent rank1a per base.
+__global__ __launch_bounds__(64) void k_retrieve(FmdIndexView ix, size_t n, const uint64_t *__restrict__ d_x,
+                                                 uint8_t *__restrict__ d_seqs, uint32_t stride,
+                                                 uint32_t *__restrict__ d_len, uint64_t *__restrict__ d_rank,
+                                                 uint32_t *__restrict__ queue)
+{
+    FMD_DECLARE_WAVE_LDS();
+    const int lane = fmd_lane();
+    size_t rid = 0;
+    uint64_t k = 0;
+    uint32_t len = 0;
+    bool live = false, exhausted = false;
+    for (;;) {
+        const uint64_t want = __ballot(!live && !exhausted);
+        if (want) {
+            uint32_t first = 0;
+            if (lane == 0) first = atomicAdd(queue, (uint32_t)__popcll(want));
+            first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+            if (!live && !exhausted) {
+                const size_t my = (size_t)first + __popcll(want & ((1ull << lane) - 1));
+                if (my < n) { rid = my; k = d_x[my]; len = 0; live = true; }
+                else exhausted = true;
+            }
+        }
+        if (__ballot(live) == 0) break;
+        const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, live ? k : NONE64, NONE64);
+        if (live) {
+            uint64_t ok[6];
+            const int c = fmd_block_rank6<true>(r.bk, r.t, r.nk, ok);
+            k = ix.cnt[c] + ok[c] - 1;
+            if (c == 0) { d_len[rid] = len; d_rank[rid] = k; live = false; }
+            else {
+                if (len < stride) d_seqs[rid * (size_t)stride + len] = (uint8_t)c;
+                ++len;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- host entry
+static inline hipStream_t S(void *s) { return (hipStream_t)s; }
+
+#define FMD_CHECK_LAUNCH()                                              \
+    do {                                                                \
+        hipError_t e__ = hipGetLastError();                             \
+        if (e__ != hipSuccess) { fmd_set_hip_error(e__, "kernel launch"); return FMD_E_HIP; } \
+    } while (0)
+
+extern "C" int fmd_rank1a_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_k, uint64_t *d_ok, int8_t *d_sym)
+{
+    if (!h || (n && (!d_k || !d_ok))) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    k_rank1a<<<fmd_grid_for(h, n), 64, 0, S(stream)>>>(fmd_view(h), n, d_k, d_ok, d_sym);
+    FMD_CHECK_LAUNCH();
+    return FMD_OK;
+}
+
+extern "C" int fmd_rank2a_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_k, const uint64_t *d_l,
+                              uint64_t *d_ok, uint64_t *d_ol)
+{
+    if (!h || (n && (!d_k || !d_l || !d_ok || !d_ol))) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    k_rank2a<<<fmd_grid_for(h, n), 64, 0, S(stream)>>>(fmd_view(h), n, d_k, d_l, d_ok, d_ol);
+    FMD_CHECK_LAUNCH();
+    return FMD_OK;
+}
+
+extern "C" int fmd_extend_dev(fmd_dev_t *h, void *stream, size_t n, const fmd_intv_t *d_ik, const uint8_t *d_is_back,
+                              fmd_intv_t *d_ok)
+{
+    if (!h || (n && (!d_ik || !d_is_back || !d_ok))) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    k_extend<<<fmd_grid_for(h, n), 64, 0, S(stream)>>>(fmd_view(h), n, d_ik, d_is_back, d_ok);
+    FMD_CHECK_LAUNCH();
+    return FMD_OK;
+}
+
+extern "C" int fmd_bsearch_dev(fmd_dev_t *h, void *stream, size_t n, const uint8_t *d_seqs, const uint64_t *d_off,
+                               uint64_t *d_cnt, uint64_t *d_beg, uint64_t *d_end)
+{
+    if (!h || (n && (!d_seqs || !d_off || !d_cnt || !d_beg || !d_end))) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    if (n >= 0xffffff00ull) return FMD_E_ARG; // 32-bit queue head
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    uint32_t *q = fmd_next_queue(h, S(stream));
+    k_bsearch<<<fmd_grid_for(h, n), 64, 0, S(stream)>>>(fmd_view(h), n, d_seqs, d_off, d_cnt, d_beg, d_end, q);
+    FMD_CHECK_LAUNCH();
+    return FMD_OK;
+}
+
+extern "C" int fmd_retrieve_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_x, uint8_t *d_seqs, uint32_t stride,
+                                uint32_t *d_len, uint64_t *d_rank)
+{
+    if (!h || (n && (!d_x || !d_seqs || !d_len || !d_rank || stride == 0))) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    if (n >= 0xffffff00ull) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    uint32_t *q = fmd_next_queue(h, S(stream));
+    k_retrieve<<<fmd_grid_for(h, n), 64, 0, S(stream)>>>(fmd_view(h), n, d_x, d_seqs, stride, d_len, d_rank, q);
+    FMD_CHECK_LAUNCH();
+    return FMD_OK;
+}
+
+// ---- host-pointer convenience forms: copy in, run, copy out, synchronise --------------------
+struct DevBuf {
+    void *p = nullptr;
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? FMD_OK : FMD_E_NOMEM; }
+    ~DevBuf() { if (p) hipFree(p); }
+};
+#define TRY_RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
+extern "C" int fmd_rank1a_batch(fmd_dev_t *h, size_t n, const uint64_t *k, uint64_t *ok, int8_t *sym)
+{
+    if (!h || (n && (!k || !ok))) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    DevBuf dk, dok, ds;
+    TRY_RC(dk.alloc(n * 8)); TRY_RC(dok.alloc(n * 48)); TRY_RC(ds.alloc(n));
+    FMD_HIP_TRY(hipMemcpy(dk.p, k, n * 8, hipMemcpyHostToDevice));
+    TRY_RC(fmd_rank1a_dev(h, nullptr, n, (uint64_t *)dk.p, (uint64_t *)dok.p, (int8_t *)ds.p));
+    FMD_HIP_TRY(hipMemcpy(ok, dok.p, n * 48, hipMemcpyDeviceToHost));
+    if (sym) FMD_HIP_TRY(hipMemcpy(sym, ds.p, n, hipMemcpyDeviceToHost));
+    return FMD_OK;
+}
+
+extern "C" int fmd_rank2a_batch(fmd_dev_t *h, size_t n, const uint64_t *k, const uint64_t *l, uint64_t *ok, uint64_t *ol)
+{
+    if (!h || (n && (!k || !l || !ok || !ol))) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    DevBuf dk, dl, dok, dol;
+    TRY_RC(dk.alloc(n * 8)); TRY_RC(dl.alloc(n * 8)); TRY_RC(dok.alloc(n * 48)); TRY_RC(dol.alloc(n * 48));
+    FMD_HIP_TRY(hipMemcpy(dk.p, k, n * 8, hipMemcpyHostToDevice));
+    FMD_HIP_TRY(hipMemcpy(dl.p, l, n * 8, hipMemcpyHostToDevice));
+    TRY_RC(fmd_rank2a_dev(h, nullptr, n, (uint64_t *)dk.p, (uint64_t *)dl.p, (uint64_t *)dok.p, (uint64_t *)dol.p));
+    FMD_HIP_TRY(hipMemcpy(ok, dok.p, n * 48, hipMemcpyDeviceToHost));
+    FMD_HIP_TRY(hipMemcpy(ol, dol.p, n * 48, hipMemcpyDeviceToHost));
+    return FMD_OK;
+}
+
+extern "C" int fmd_extend_batch(fmd_dev_t *h, size_t n, const fmd_intv_t *ik, const uint8_t *is_back, fmd_intv_t *ok)
+{
+    if (!h || (n && (!ik || !is_back || !ok))) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    DevBuf di, db, dok;
+    TRY_RC(di.alloc(n * 32)); TRY_RC(db.alloc(n)); TRY_RC(dok.alloc(n * 192));
+    FMD_HIP_TRY(hipMemcpy(di.p, ik, n * 32, hipMemcpyHostToDevice));
+    FMD_HIP_TRY(hipMemcpy(db.p, is_back, n, hipMemcpyHostToDevice));
+    TRY_RC(fmd_extend_dev(h, nullptr, n, (fmd_intv_t *)di.p, (uint8_t *)db.p, (fmd_intv_t *)dok.p));
+    FMD_HIP_TRY(hipMemcpy(ok, dok.p, n * 192, hipMemcpyDeviceToHost));
+    return FMD_OK;
+}
+
+extern "C" int fmd_bsearch_batch(fmd_dev_t *h, size_t n, const uint8_t *seqs, const uint64_t *off,
+                                 uint64_t *cnt, uint64_t *beg, uint64_t *end)
+{
+    if (!h || (n && (!seqs || !off || !cnt || !beg || !end))) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    const size_t total = off[n];
+    DevBuf ds, doff, dc, dbg, den;
+    TRY_RC(ds.alloc(total + 8)); TRY_RC(doff.alloc((n + 1) * 8)); TRY_RC(dc.alloc(n * 8)); TRY_RC(dbg.alloc(n * 8)); TRY_RC(den.alloc(n * 8));
+    FMD_HIP_TRY(hipMemcpy(ds.p, seqs, total, hipMemcpyHostToDevice));
+    FMD_HIP_TRY(hipMemcpy(doff.p, off, (n + 1) * 8, hipMemcpyHostToDevice));
+    TRY_RC(fmd_bsearch_dev(h, nullptr, n, (uint8_t *)ds.p, (uint64_t *)doff.p, (uint64_t *)dc.p, (uint64_t *)dbg.p, (uint64_t *)den.p));
+    FMD_HIP_TRY(hipMemcpy(cnt, dc.p, n * 8, hipMemcpyDeviceToHost));
+    FMD_HIP_TRY(hipMemcpy(beg, dbg.p, n * 8, hipMemcpyDeviceToHost));
+    FMD_HIP_TRY(hipMemcpy(end, den.p, n * 8, hipMemcpyDeviceToHost));
+    return FMD_OK;
+}
+
+extern "C" int fmd_retrieve_batch(fmd_dev_t *h, size_t n, const uint64_t *x, uint8_t *seqs, uint32_t stride,
+                                  uint32_t *len, uint64_t *rank)
+{
+    if (!h || (n && (!x || !seqs || !len || !rank || !stride))) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    DevBuf dx, ds, dl, dr;
+    TRY_RC(dx.alloc(n * 8)); TRY_RC(ds.alloc(n * (size_t)stride)); TRY_RC(dl.alloc(n * 4)); TRY_RC(dr.alloc(n * 8));
+    FMD_HIP_TRY(hipMemcpy(dx.p, x, n * 8, hipMemcpyHostToDevice));
+    FMD_HIP_TRY(hipMemset(ds.p, 0, n * (size_t)stride));
+    TRY_RC(fmd_retrieve_dev(h, nullptr, n, (uint64_t *)dx.p, (uint8_t *)ds.p, stride, (uint32_t *)dl.p, (uint64_t *)dr.p));
+    FMD_HIP_TRY(hipMemcpy(seqs, ds.p, n * (size_t)stride, hipMemcpyDeviceToHost));
+    FMD_HIP_TRY(hipMemcpy(len, dl.p, n * 4, hipMemcpyDeviceToHost));
+    FMD_HIP_TRY(hipMemcpy(rank, dr.p, n * 8, hipMemcpyDeviceToHost));
+    return FMD_OK;
+}

@@ -1,0 +1,110 @@
+/* include/fmd_hip.h -- C ABI of libfmdhip.so, the MI355X (gfx950) implementation of fermi's
+ * FMD-index hot path.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * This is the drop-in boundary: each entry point is the batched, device-side
+ * replacement of one function of the reference's internal C API (rld.h:45-58, fermi.h:61-103,
+ * unitig.c:77/93, correct.c:35), cited per declaration.  A reference maintainer binds these
+ * from cmd.c / unitig.c / correct.c exactly as shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 (FMD_OK) or a negative FMD_E_* code; fmd_strerror() names it.
+ *   - fmd_dev_t is an opaque handle to an index resident in one GPU's HBM (read-only after
+ *     open, like the reference's `const rld_t*`; safe to share between host threads).
+ *   - `*_dev` entry points take DEVICE pointers and a hipStream_t (as void*; NULL = default
+ *     stream), enqueue work and return without synchronising.  They allocate nothing.
+ *   - `*_batch` entry points take HOST pointers: copy in, run the `_dev` path, copy out, sync.
+ *   - nt6 alphabet everywhere: $=0 A=1 C=2 G=3 T=4 N=5 (seq.c:12-21).
+ *   - There is NO CPU fallback behind these symbols: without a GPU they return FMD_E_NODEV.
+ */
+#ifndef FMD_HIP_H
+#define FMD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMD_OK          0
+#define FMD_E_NODEV    (-1)  /* no usable HIP device */
+#define FMD_E_ARG      (-2)  /* bad argument */
+#define FMD_E_FORMAT   (-3)  /* not an RLD\2 (asize 6, sbits 3) or RLE\6 file */
+#define FMD_E_IO       (-4)  /* file could not be read/written */
+#define FMD_E_NOMEM    (-5)  /* host or device allocation failed */
+#define FMD_E_HIP      (-6)  /* a HIP runtime call failed; see fmd_last_hip_error() */
+#define FMD_E_OVERFLOW (-7)  /* a fixed-capacity device list overflowed for some item */
+
+/* bi-interval; identical layout to fmintv_t (fermi.h:13-16) */
+typedef struct {
+    uint64_t x[3]; /* [0] SA start of W, [1] SA start of revcomp(W), [2] size */
+    uint64_t info;
+} fmd_intv_t;
+
+typedef struct fmd_dev fmd_dev_t;
+
+typedef struct {
+    uint64_t cnt[7];     /* cnt[c] = # symbols < c, cnt[6] = total      (rld.c:282-284) */
+    uint64_t mcnt[7];    /* mcnt[0] = total, mcnt[1..6] = # of $ACGTN   (rld.c:233)     */
+    uint64_t n_blocks;   /* 128-byte device blocks                                      */
+    uint64_t hbm_bytes;  /* device bytes held by the index                              */
+    int device;
+} fmd_info_t;
+
+const char *fmd_strerror(int code);
+const char *fmd_last_hip_error(void);
+int fmd_device_count(void);
+
+/* ---- index residency: replaces rld_restore / rld_restore_mmap / rld_destroy -------------
+ * (rld.c:288, :327, :81).  The on-disk .fmd is unchanged; the GPU transcodes it at upload
+ * into fixed-stride 128-byte rank blocks (DESIGN.md "HBM layout"). */
+int fmd_dev_open_file(int device, const char *fn, fmd_dev_t **out);            /* RLD\2 or RLE\6 */
+int fmd_dev_open_rld(int device, const uint64_t *payload, uint64_t n_words,
+                     const uint64_t mcnt[7], fmd_dev_t **out);                  /* RLD\2 payload words (rld.c:242-263) */
+int fmd_dev_open_rle6(int device, const uint8_t *runs, uint64_t n_bytes, fmd_dev_t **out); /* len<<3|sym bytes (ropebwt.c:132) */
+int fmd_dev_open_bwt(int device, const uint8_t *bwt, uint64_t n, fmd_dev_t **out);          /* plain nt6 BWT string, host */
+int fmd_dev_open_bwt_dev(int device, const uint8_t *d_bwt, uint64_t n, fmd_dev_t **out);    /* same, already in HBM */
+void fmd_dev_close(fmd_dev_t *h);
+int fmd_dev_info(const fmd_dev_t *h, fmd_info_t *info);
+int fmd_dev_sync(const fmd_dev_t *h, void *stream);
+
+/* ---- rank: rld_rank1a (rld.c:424) / rld_rank2a (rld.c:457) -------------------------------
+ * ok/ol: n rows of 6 counts ($ACGTN) of BWT[0..k] inclusive; k == UINT64_MAX gives zeros.
+ * sym (may be NULL): BWT[k], -1 for k == UINT64_MAX. */
+int fmd_rank1a_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_k, uint64_t *d_ok, int8_t *d_sym);
+int fmd_rank2a_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_k, const uint64_t *d_l,
+                   uint64_t *d_ok, uint64_t *d_ol);
+int fmd_rank1a_batch(fmd_dev_t *h, size_t n, const uint64_t *k, uint64_t *ok, int8_t *sym);
+int fmd_rank2a_batch(fmd_dev_t *h, size_t n, const uint64_t *k, const uint64_t *l, uint64_t *ok, uint64_t *ol);
+
+/* ---- fm6_extend (exact.c:72-88): n bi-intervals -> n x 6 bi-intervals (info = 0) --------- */
+int fmd_extend_dev(fmd_dev_t *h, void *stream, size_t n, const fmd_intv_t *d_ik, const uint8_t *d_is_back,
+                   fmd_intv_t *d_ok);
+int fmd_extend_batch(fmd_dev_t *h, size_t n, const fmd_intv_t *ik, const uint8_t *is_back, fmd_intv_t *ok);
+
+/* ---- fm_backward_search (exact.c:7-23) ---------------------------------------------------
+ * Read i is seqs[off[i] .. off[i+1]) in nt6.  cnt[i] = occurrences (0 = miss; beg/end are then
+ * written as 0, where the reference leaves them untouched). */
+int fmd_bsearch_dev(fmd_dev_t *h, void *stream, size_t n, const uint8_t *d_seqs, const uint64_t *d_off,
+                    uint64_t *d_cnt, uint64_t *d_beg, uint64_t *d_end);
+int fmd_bsearch_batch(fmd_dev_t *h, size_t n, const uint8_t *seqs, const uint64_t *off,
+                      uint64_t *cnt, uint64_t *beg, uint64_t *end);
+
+/* ---- fm_retrieve (exact.c:59-70): LF-walk from row x[i] until '$' --------------------------
+ * Row i of seqs (stride bytes) receives the sequence REVERSED, exactly as fm_retrieve emits it
+ * (callers seq_reverse it, unitig.c:285); len[i] = its length (bases beyond `stride` are
+ * dropped, len still counts them); rank[i] = the returned sentinel rank. */
+int fmd_retrieve_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_x, uint8_t *d_seqs, uint32_t stride,
+                     uint32_t *d_len, uint64_t *d_rank);
+int fmd_retrieve_batch(fmd_dev_t *h, size_t n, const uint64_t *x, uint8_t *seqs, uint32_t stride,
+                       uint32_t *len, uint64_t *rank);
+
+/* ---- diagnostics: random-gather ceiling of this GPU (DESIGN.md "practical roofline") -----
+ * Reads n_access random aligned lines of `line_bytes` (64/128/256) from a working set of
+ * ws_bytes with the same LDS-DMA gather the rank kernels use; returns milliseconds. */
+int fmd_probe_gather(int device, uint64_t ws_bytes, uint32_t line_bytes, uint64_t n_access, int iters, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

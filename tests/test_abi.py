@@ -1,0 +1,57 @@
+"""CPU: the C-ABI library loads, exports every symbol include/fmd_hip.h declares, and fails
+loudly (no CPU fallback) when there is no GPU.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from fermi_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "fmd_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(fmd_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_and_binding_lists_agree():
+    assert _declared_symbols() == sorted(api.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    L = api.lib()
+    for s in _declared_symbols():
+        assert hasattr(L, s), s
+
+
+def test_strerror_covers_codes():
+    L = api.lib()
+    for code in range(0, -8, -1):
+        assert L.fmd_strerror(code)
+
+
+def test_no_cpu_fallback_without_gpu():
+    if api.device_count() > 0:
+        pytest.skip("a GPU is present")
+    bwt = np.array([1, 2, 3, 0], dtype=np.uint8)
+    with pytest.raises(api.FmdError, match="no usable HIP device"):
+        api.DevIndex.from_bwt(bwt)
+    with pytest.raises(api.FmdError):
+        api.DevIndex.open(os.path.join(ROOT, "tests", "golden", "tiny.fmd"))
+
+
+def test_product_does_not_reference_oracle():
+    """The product tree must never import, link or dlopen anything under oracle/."""
+    bad = []
+    for base in ("fermi_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".py", ".c", ".h", ".hip", ".cpp")):
+                    txt = open(os.path.join(dp, fn), errors="ignore").read()
+                    if re.search(r"liboracle|orcbind|oracle/|fmd_oracle|libfermi_ref", txt):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad

@@ -1,0 +1,148 @@
+"""GPU: the HIP path (through the C ABI) against the golden vectors and the oracle.
+Integer/index work: the bar is bit-exact."""
+import numpy as np
+import pytest
+
+import orcbind
+from fermi_amd import synth
+
+pytestmark = pytest.mark.gpu
+U64 = np.uint64
+NONE = U64(0xFFFFFFFFFFFFFFFF)
+
+
+@pytest.fixture(scope="module")
+def tiny_dev(gpu, gold):
+    d = gpu.DevIndex.open(gold.path("tiny.fmd"))
+    yield d
+    d.close()
+
+
+@pytest.mark.parametrize("name", ["tiny", "special", "dup32"])
+def test_open_rld_counts_and_rank1a_golden(gpu, gold, name):
+    v = gold.npz(name + "_vectors.npz")
+    d = gpu.DevIndex.open(gold.path(name + ".fmd"))
+    ok, sym = d.rank1a(v["rank1a_k"])
+    assert np.array_equal(ok, v["rank1a_ok"])
+    assert np.array_equal(sym, v["rank1a_sym"])
+    d.close()
+
+
+def test_three_loaders_give_one_index(gpu, gold, oracle_lib):
+    """RLD\\2 file, RLE\\6 file and the plain BWT string transcode to the same device index."""
+    o = orcbind.OrcIndex(gold.path("tiny.fmd"))
+    bwt = o.decode_all()
+    ks = np.arange(o.n, dtype=U64)
+    want, wsym = o.rank1a(ks)
+    for d in (gpu.DevIndex.open(gold.path("tiny.fmd")), gpu.DevIndex.open(gold.path("tiny.rle.fmd")), gpu.DevIndex.from_bwt(bwt)):
+        assert np.array_equal(d.cnt, o.cnt) and np.array_equal(d.mcnt, o.mcnt)
+        ok, sym = d.rank1a(ks)  # chkbwt -r equivalent (cmd.c:90-105): every position
+        assert np.array_equal(ok, want) and np.array_equal(sym, wsym)
+        d.close()
+    o.close()
+
+
+def test_rank2a_golden(tiny_dev, gold):
+    v = gold.npz("tiny_vectors.npz")
+    ok, ol = tiny_dev.rank2a(v["rank2a_k"], v["rank2a_l"])
+    assert np.array_equal(ok, v["rank2a_ok"]) and np.array_equal(ol, v["rank2a_ol"])
+
+
+def test_extend_golden(gpu, tiny_dev, gold):
+    v = gold.npz("tiny_vectors.npz")
+    ik = v["ext_ik"].copy().view(gpu.INTV_DT).reshape(-1)
+    out = tiny_dev.extend(ik, v["ext_back"])
+    assert np.array_equal(out.view(U64).reshape(-1, 24), v["ext_ok"])
+
+
+def test_backward_search_golden(tiny_dev, gold):
+    v = gold.npz("tiny_vectors.npz")
+    cnt, beg, end = tiny_dev.backward_search(v["bs_reads"])
+    assert np.array_equal(cnt, v["bs_cnt"])
+    hit = cnt > 0
+    assert np.array_equal(beg[hit], v["bs_beg"][hit]) and np.array_equal(end[hit], v["bs_end"][hit])
+    assert not beg[~hit].any() and not end[~hit].any()
+    short = [v["bs_short"][i, :v["bs_short_len"][i]] for i in range(len(v["bs_short_len"]))]
+    cnt, beg, end = tiny_dev.backward_search(short)  # ragged, incl. length-1 queries
+    assert np.array_equal(cnt, v["bs_short_cnt"])
+    hit = cnt > 0
+    assert np.array_equal(beg[hit], v["bs_short_beg"][hit]) and np.array_equal(end[hit], v["bs_short_end"][hit])
+
+
+@pytest.mark.parametrize("name,stride", [("tiny", 128), ("special", 64)])
+def test_retrieve_golden(gpu, gold, name, stride):
+    v = gold.npz(name + "_vectors.npz")
+    d = gpu.DevIndex.open(gold.path(name + ".fmd"))
+    seqs, ln, rank = d.retrieve(v["ret_x"], stride=stride)
+    assert np.array_equal(ln, v["ret_len"]) and np.array_equal(rank, v["ret_rank"])
+    assert np.array_equal(seqs, v["ret_seq"])
+    d.close()
+
+
+def test_empty_and_edge_inputs(gpu, tiny_dev):
+    ok, sym = tiny_dev.rank1a(np.zeros(0, dtype=U64))
+    assert ok.shape == (0, 6)
+    ok, sym = tiny_dev.rank1a(np.array([NONE, 0, tiny_dev.n - 1], dtype=U64))
+    assert not ok[0].any() and sym[0] == -1
+    assert ok[2].sum() == tiny_dev.n and np.array_equal(ok[2], tiny_dev.mcnt[1:])
+    cnt, beg, end = tiny_dev.backward_search([np.array([], dtype=np.uint8), np.array([1], dtype=np.uint8)])
+    assert cnt[0] == 0 and cnt[1] == tiny_dev.mcnt[2]
+
+
+def test_random_batches_vs_oracle(gpu, tiny_dev, tiny_oracle):
+    """10^6 random rank2a / extend queries, oracle beside the GPU."""
+    rng = np.random.default_rng(42)
+    n = tiny_dev.n
+    m = 1_000_000
+    k = rng.integers(0, n, m).astype(U64)
+    l = np.minimum(k + rng.integers(0, 1000, m).astype(U64), U64(n - 1))
+    k[::1000] = NONE
+    ok, ol = tiny_dev.rank2a(k, l)
+    wk, wl = tiny_oracle.rank2a(k, l)
+    assert np.array_equal(ok, wk) and np.array_equal(ol, wl)
+    ik = np.zeros(m, dtype=gpu.INTV_DT)
+    size = rng.integers(0, 300, m).astype(U64)
+    x0 = rng.integers(0, n, m).astype(U64)
+    x1 = rng.integers(0, n, m).astype(U64)
+    ik["x"][:, 0] = np.minimum(x0, U64(n) - size); ik["x"][:, 1] = np.minimum(x1, U64(n) - size); ik["x"][:, 2] = size
+    back = rng.integers(0, 2, m).astype(np.uint8)
+    got = tiny_dev.extend(ik, back)
+    want = tiny_oracle.extend(ik, back)
+    assert np.array_equal(got.view(U64), want.view(U64))
+
+
+def test_synthetic_index_properties(gpu, oracle_lib):
+    """Size-independent properties on a bigger synthetic index (5k reads, BWT by brute-force suffix sorting
+    encoder's input): every indexed read is found, with itself inside its interval; retrieve
+    inverts; mutated reads agree with the oracle."""
+    N = 5000
+    reads = synth.reads(synth.DEFAULT_SEED, N)
+    # BWT via sorting all suffixes on the host (small N): text = r $ revcomp(r) $ ...
+    both = np.empty((2 * N, 101), dtype=np.uint8)
+    both[0::2, :100] = reads
+    both[1::2, :100] = (5 - reads)[:, ::-1]
+    both[:, 100] = 0
+    text = both.reshape(-1)
+    # suffix keys: pad each suffix to its own sentinel, ties broken by sequence id
+    from test_build_host import bwt_by_sorting
+    bwt = bwt_by_sorting(both)
+    d = gpu.DevIndex.from_bwt(bwt)
+    o = orcbind.OrcIndex(bwt=bwt)
+    assert np.array_equal(d.cnt, o.cnt)
+    cnt, beg, end = d.backward_search(reads)
+    assert (cnt >= 1).all()
+    wc, wb, we = o.backward_search(reads[:2000])
+    assert np.array_equal(cnt[:2000], wc) and np.array_equal(beg[:2000], wb) and np.array_equal(end[:2000], we)
+    ids = np.arange(0, 2 * N, 7, dtype=U64)
+    seqs, ln, rank = d.retrieve(ids, stride=128)
+    assert (ln == 100).all()
+    assert np.array_equal(seqs[:, :100], both[ids.astype(np.int64), :100])
+    ws, wl, wr = o.retrieve(ids[:500], stride=128)
+    assert np.array_equal(rank[:500], wr)
+    miss = synth.reads(synth.DEFAULT_SEED, N, err=0.03)[:3000]
+    c1, b1, e1 = d.backward_search(miss)
+    c2, b2, e2 = o.backward_search(miss)
+    assert np.array_equal(c1, c2)
+    h = c1 > 0
+    assert np.array_equal(b1[h], b2[h]) and np.array_equal(e1[h], e2[h])
+    d.close(); o.close()
