@@ -23,6 +23,7 @@ ABI_SYMBOLS = [
     "fmd_rank1a_dev", "fmd_rank2a_dev", "fmd_rank1a_batch", "fmd_rank2a_batch",
     "fmd_extend_dev", "fmd_extend_batch", "fmd_bsearch_dev", "fmd_bsearch_batch",
     "fmd_retrieve_dev", "fmd_retrieve_batch", "fmd_probe_gather",
+    "fmd_build_bwt", "fmd_build_bwt_dev", "fmd_dev_free", "fmd_bwt_to_rle6", "fmd_host_free",
 ]
 
 
@@ -67,6 +68,11 @@ def lib():
         L.fmd_bsearch_batch.argtypes = [vp, sz, vp, u64p, u64p, u64p, u64p]
         L.fmd_retrieve_dev.argtypes = [vp, vp, sz, u64p, vp, C.c_uint32, vp, u64p]
         L.fmd_retrieve_batch.argtypes = [vp, sz, u64p, vp, C.c_uint32, vp, u64p]
+        L.fmd_build_bwt.argtypes = [C.c_int, sz, vp, u64p, vp, C.POINTER(C.c_uint64)]
+        L.fmd_build_bwt_dev.argtypes = [C.c_int, vp, sz, vp, u64p, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64)]
+        L.fmd_dev_free.restype = None; L.fmd_dev_free.argtypes = [vp]
+        L.fmd_bwt_to_rle6.argtypes = [C.c_int, vp, C.c_uint64, C.POINTER(vp), C.POINTER(C.c_uint64)]
+        L.fmd_host_free.restype = None; L.fmd_host_free.argtypes = [vp]
         L.fmd_probe_gather.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_float)]
         _lib = L
     return _lib
@@ -191,6 +197,17 @@ class DevIndex:
             l = min(int(ln[i]), stride)
             out[i, :l] = seqs[i, :l][::-1]
         return out, ln.astype(np.int32), rank
+
+
+def build_bwt(seqs, device=0):
+    """`fermi build` BWT of a read collection (list or 2-D array of nt6 reads), computed on the GPU."""
+    flat, off = flatten_reads(seqs)
+    n = len(off) - 1
+    bwt = np.zeros(2 * (int(off[n]) + n), dtype=np.uint8)
+    n_sym = C.c_uint64(0)
+    check(lib().fmd_build_bwt(device, n, _ptr(flat), _ptr(off), _ptr(bwt), C.byref(n_sym)))
+    assert n_sym.value == len(bwt)
+    return bwt
 
 
 def probe_gather(ws_bytes, line_bytes, n_access, iters=3, device=0):

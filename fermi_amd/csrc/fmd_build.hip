@@ -1,0 +1,211 @@
+// fmd_build.hip -- FMD-index construction on the GPU (the `fermi build` BWT, cmd.c:378-484 +
+// build.c:11-50, as plumbing for benchmarks and as a drop-in for index construction of short
+// reads).  The indexed text is, per read in input order,  read $ revcomp(read) $  and sentinels
+// compare by sequence id (ksa.c:54), so the BWT is the sort of all suffixes "sequence tail up to
+// and including its own $", ties broken by sequence id.  Short reads make that a fixed number
+// of stable LSD radix passes over 21-symbol (63-bit) key chunks: ceil((maxlen+1)/21) passes of
+// hipcub::DeviceRadixSort over (key, text position) pairs -- HBM-streaming work the MI355X does
+// in about a second for 2e9 suffixes, instead of SA-IS + merging on the host.
+#include <hipcub/hipcub.hpp>
+#include <stdlib.h>
+#include "fmd_internal.h"
+
+// text[T_s ..] for sequence s = 2r (forward) / 2r+1 (reverse complement); one thread per read base
+__global__ void k_build_text(size_t n_reads, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ off,
+                             uint8_t *__restrict__ text)
+{
+    // one 64-thread group per read
+    const size_t r = blockIdx.x;
+    if (r >= n_reads) return;
+    const uint64_t o = off[r], len = off[r + 1] - o;
+    const uint64_t t0 = 2 * (o + r); // both strands of all earlier reads, each with its '$'
+    for (uint64_t i = threadIdx.x; i < len; i += blockDim.x) {
+        const uint8_t c = reads[o + i];
+        text[t0 + i] = c;
+        text[t0 + len + 1 + (len - 1 - i)] = (c >= 1 && c <= 4) ? (uint8_t)(5 - c) : c;
+    }
+    if (threadIdx.x == 0) { text[t0 + len] = 0; text[t0 + 2 * len + 1] = 0; }
+}
+
+// distance from text position t to the '$' closing its sequence
+struct RemUniform { uint32_t len1; __device__ uint32_t operator()(uint64_t t) const { return len1 - 1 - (uint32_t)(t % len1); } };
+struct RemRagged {   // binary search over sequence ends (position of each '$'), n_seq entries
+    const uint64_t *send; uint64_t n_seq;
+    __device__ uint32_t operator()(uint64_t t) const {
+        uint64_t lo = 0, hi = n_seq - 1;
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (send[mid] < t) lo = mid + 1; else hi = mid; }
+        return (uint32_t)(send[lo] - t);
+    }
+};
+
+template <class Rem>
+__global__ void k_chunk_keys(const uint8_t *__restrict__ text, uint64_t n, const uint32_t *__restrict__ order, int chunk,
+                             Rem rem, uint64_t *__restrict__ keys)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t t = order ? order[i] : i;
+    const uint32_t r = rem(t), o0 = 21u * (uint32_t)chunk;
+    uint64_t key = 0;
+    if (o0 <= r) {
+        const uint32_t m = r - o0 + 1 < 21 ? r - o0 + 1 : 21; // symbols up to and including the '$'
+        for (uint32_t j = 0; j < m; ++j) key |= (uint64_t)text[t + o0 + j] << (3 * (20 - j));
+    }
+    keys[i] = key;
+}
+
+__global__ void k_iota32(uint32_t *a, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = (uint32_t)i;
+}
+
+__global__ void k_emit_bwt(const uint8_t *__restrict__ text, const uint32_t *__restrict__ order, uint64_t n, uint8_t *__restrict__ bwt)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t t = order[i];
+    bwt[i] = t ? text[t - 1] : 0; // text[t-1] is '$' (=0) exactly when t starts a sequence
+}
+
+__global__ void k_seq_ends(size_t n_reads, const uint64_t *__restrict__ off, uint64_t *__restrict__ send)
+{
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint64_t o = off[r], len = off[r + 1] - o, t0 = 2 * (o + r);
+    send[2 * r] = t0 + len; send[2 * r + 1] = t0 + 2 * len + 1;
+}
+
+static inline unsigned nblk(uint64_t n, unsigned t) { return (unsigned)((n + t - 1) / t); }
+
+struct DevPtr { void *p = nullptr; ~DevPtr() { if (p) hipFree(p); } };
+#define DALLOC(buf, bytes) do { hipError_t e__ = hipMalloc(&(buf).p, (bytes) ? (bytes) : 16); \
+    if (e__ != hipSuccess) { fmd_set_hip_error(e__, "hipMalloc(" #buf ")"); return FMD_E_NOMEM; } } while (0)
+
+extern "C" void fmd_dev_free(void *d_ptr) { if (d_ptr) hipFree(d_ptr); }
+
+extern "C" int fmd_build_bwt_dev(int device, void *stream_, size_t n_reads, const uint8_t *d_reads, const uint64_t *d_off,
+                                 uint64_t total_bases, uint32_t max_len, int uniform_len, uint8_t **d_bwt_out, uint64_t *n_sym_out)
+{
+    if (!d_reads || !d_off || !d_bwt_out || !n_sym_out || n_reads == 0 || max_len == 0) return FMD_E_ARG;
+    if (fmd_device_count() <= 0) return FMD_E_NODEV;
+    FMD_HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream_;
+    const uint64_t n = 2 * (total_bases + n_reads);
+    if (n >= 0xffffffffull) return FMD_E_ARG; // 32-bit suffix ids in this version
+    DevPtr text, keys_a, keys_b, ord_a, ord_b, send, tmp;
+    uint8_t *bwt = nullptr;
+    DALLOC(text, n + 64);
+    DALLOC(keys_a, n * 8); DALLOC(keys_b, n * 8); DALLOC(ord_a, n * 4); DALLOC(ord_b, n * 4);
+    k_build_text<<<(unsigned)n_reads, 64, 0, st>>>(n_reads, d_reads, d_off, (uint8_t *)text.p);
+    RemRagged rr{nullptr, 2 * n_reads};
+    if (!uniform_len) {
+        DALLOC(send, 2 * n_reads * 8);
+        k_seq_ends<<<nblk(n_reads, 256), 256, 0, st>>>(n_reads, d_off, (uint64_t *)send.p);
+        rr.send = (const uint64_t *)send.p;
+    }
+    size_t tmp_bytes = 0;
+    FMD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p,
+                                                  (uint32_t *)ord_a.p, (uint32_t *)ord_b.p, (size_t)n, 0, 63, st));
+    DALLOC(tmp, tmp_bytes);
+    const int n_chunks = (int)((max_len + 1 + 20) / 21);
+    uint32_t *cur = (uint32_t *)ord_a.p, *nxt = (uint32_t *)ord_b.p;
+    k_iota32<<<nblk(n, 256), 256, 0, st>>>(cur, n); // text order = sequence-id order: the tie-break
+    for (int c = n_chunks - 1; c >= 0; --c) {
+        if (uniform_len) k_chunk_keys<<<nblk(n, 256), 256, 0, st>>>((const uint8_t *)text.p, n, cur, c, RemUniform{max_len + 1}, (uint64_t *)keys_a.p);
+        else k_chunk_keys<<<nblk(n, 256), 256, 0, st>>>((const uint8_t *)text.p, n, cur, c, rr, (uint64_t *)keys_a.p);
+        FMD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, cur, nxt,
+                                                      (size_t)n, 0, 63, st));
+        uint32_t *t = cur; cur = nxt; nxt = t;
+    }
+    FMD_HIP_TRY(hipMalloc((void **)&bwt, n + 64));
+    k_emit_bwt<<<nblk(n, 256), 256, 0, st>>>((const uint8_t *)text.p, cur, n, bwt);
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { hipFree(bwt); fmd_set_hip_error(e, "build"); return FMD_E_HIP; }
+    *d_bwt_out = bwt; *n_sym_out = n;
+    return FMD_OK;
+}
+
+// Host-pointer form.  reads = nt6 bases of all reads back to back (no sentinels), off[n+1].
+// bwt must hold 2 * (off[n] + n) bytes.
+extern "C" int fmd_build_bwt(int device, size_t n_reads, const uint8_t *reads, const uint64_t *off, uint8_t *bwt, uint64_t *n_sym)
+{
+    if (!reads || !off || !bwt || !n_sym || n_reads == 0) return FMD_E_ARG;
+    if (fmd_device_count() <= 0) return FMD_E_NODEV;
+    FMD_HIP_TRY(hipSetDevice(device));
+    uint32_t max_len = 0; int uniform = 1;
+    for (size_t i = 0; i < n_reads; ++i) {
+        const uint64_t l = off[i + 1] - off[i];
+        if (l == 0 || l > 0xfffffff0ull) return FMD_E_ARG;
+        if (l > max_len) max_len = (uint32_t)l;
+        if (l != off[1] - off[0]) uniform = 0;
+    }
+    DevPtr dr, doff;
+    DALLOC(dr, off[n_reads] + 64); DALLOC(doff, (n_reads + 1) * 8);
+    FMD_HIP_TRY(hipMemcpy(dr.p, reads, off[n_reads], hipMemcpyHostToDevice));
+    FMD_HIP_TRY(hipMemcpy(doff.p, off, (n_reads + 1) * 8, hipMemcpyHostToDevice));
+    uint8_t *d_bwt = nullptr;
+    int rc = fmd_build_bwt_dev(device, nullptr, n_reads, (uint8_t *)dr.p, (uint64_t *)doff.p, off[n_reads], max_len, uniform, &d_bwt, n_sym);
+    if (rc) return rc;
+    hipError_t e = hipMemcpy(bwt, d_bwt, *n_sym, hipMemcpyDeviceToHost);
+    hipFree(d_bwt);
+    FMD_HIP_TRY(e);
+    return FMD_OK;
+}
+
+// ---------------------------------------------------------------- BWT (device) -> RLE\6 bytes
+// `len<<3 | sym`, len <= 31, long runs split: the stream `fermi ropebwt -b` writes
+// (ropebwt.c:132-136) and rld_restore re-encodes (rld.c:295-308).
+__global__ void k_run_bytes(const uint32_t *__restrict__ run_len, uint64_t n_runs, uint64_t *__restrict__ nb)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_runs) nb[i] = (run_len[i] + 30) / 31;
+}
+__global__ void k_run_emit(const uint8_t *__restrict__ run_sym, const uint32_t *__restrict__ run_len, uint64_t n_runs,
+                           const uint64_t *__restrict__ start, uint8_t *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_runs) return;
+    uint32_t l = run_len[i];
+    uint8_t *p = out + start[i];
+    const uint8_t c = run_sym[i];
+    for (; l > 31; l -= 31) *p++ = (uint8_t)(31 << 3 | c);
+    *p = (uint8_t)(l << 3 | c);
+}
+
+extern "C" int fmd_bwt_to_rle6(int device, const uint8_t *d_bwt, uint64_t n, uint8_t **h_rle6, uint64_t *n_bytes)
+{
+    if (!d_bwt || !h_rle6 || !n_bytes || n == 0) return FMD_E_ARG;
+    if (fmd_device_count() <= 0) return FMD_E_NODEV;
+    FMD_HIP_TRY(hipSetDevice(device));
+    DevPtr sym, len, nruns, tmp, nb, start, out;
+    DALLOC(sym, n); DALLOC(len, n * 4); DALLOC(nruns, 8);
+    size_t tb = 0;
+    FMD_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb, d_bwt, (uint8_t *)sym.p, (uint32_t *)len.p, (uint64_t *)nruns.p, (size_t)n));
+    DALLOC(tmp, tb);
+    FMD_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(tmp.p, tb, d_bwt, (uint8_t *)sym.p, (uint32_t *)len.p, (uint64_t *)nruns.p, (size_t)n));
+    uint64_t n_runs = 0;
+    FMD_HIP_TRY(hipMemcpy(&n_runs, nruns.p, 8, hipMemcpyDeviceToHost));
+    DALLOC(nb, n_runs * 8); DALLOC(start, n_runs * 8);
+    k_run_bytes<<<nblk(n_runs, 256), 256>>>((uint32_t *)len.p, n_runs, (uint64_t *)nb.p);
+    { // exclusive scan
+        DevPtr t2; size_t b2 = 0;
+        FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, (uint64_t *)nb.p, (uint64_t *)start.p, (size_t)n_runs));
+        DALLOC(t2, b2);
+        FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(t2.p, b2, (uint64_t *)nb.p, (uint64_t *)start.p, (size_t)n_runs));
+        FMD_HIP_TRY(hipDeviceSynchronize());
+    }
+    uint64_t a = 0, b = 0;
+    FMD_HIP_TRY(hipMemcpy(&a, (uint64_t *)start.p + n_runs - 1, 8, hipMemcpyDeviceToHost));
+    FMD_HIP_TRY(hipMemcpy(&b, (uint64_t *)nb.p + n_runs - 1, 8, hipMemcpyDeviceToHost));
+    const uint64_t total = a + b;
+    DALLOC(out, total);
+    k_run_emit<<<nblk(n_runs, 256), 256>>>((uint8_t *)sym.p, (uint32_t *)len.p, n_runs, (uint64_t *)start.p, (uint8_t *)out.p);
+    uint8_t *h = (uint8_t *)malloc(total);
+    if (!h) return FMD_E_NOMEM;
+    hipError_t e = hipMemcpy(h, out.p, total, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { free(h); fmd_set_hip_error(e, "copy rle6"); return FMD_E_HIP; }
+    *h_rle6 = h; *n_bytes = total;
+    return FMD_OK;
+}
+extern "C" void fmd_host_free(void *p) { free(p); }

@@ -1,0 +1,31 @@
+/* fmd_host.h -- host-side C helpers of the MI355X FMD path (plain C, no GPU code).
+ * File formats follow the reference byte for byte so that files are interchangeable with fermi:
+ *   RLD\2 container  rld.c:242-263 (layout), rld.c:111-175 (block/run encoding), rld.c:186-224 (frames)
+ *   RLE\6 stream     ropebwt.c:132-136
+ */
+#ifndef FMD_HOST_H
+#define FMD_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Encode a run-length byte stream (`len<<3 | sym`, len 1..31, adjacent equal symbols are
+ * merged like rld_enc does, rld.c:177-184) into an RLD\2 .fmd file.  Returns 0 or -errno. */
+int fmdh_write_rld_from_rle6(const uint8_t *runs, uint64_t n_bytes, const char *path);
+/* Write the same stream as an RLE\6 .fmd (what `fermi ropebwt -b` emits). */
+int fmdh_write_rle6(const uint8_t *runs, uint64_t n_bytes, const char *path);
+/* Plain BWT string (nt6 bytes) -> RLD\2 file. */
+int fmdh_write_rld_from_bwt(const uint8_t *bwt, uint64_t n, const char *path);
+
+/* nt6 conversion table (seq.c:12-21) and helpers */
+extern const uint8_t fmdh_nt6[256];
+/* cmd.c:457-463: an even-length read equal to its own reverse complement loses its last base.
+ * Returns the (possibly reduced) length. */
+uint32_t fmdh_trim_palindrome(const uint8_t *s, uint32_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

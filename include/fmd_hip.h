@@ -99,6 +99,22 @@ int fmd_retrieve_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_x, 
 int fmd_retrieve_batch(fmd_dev_t *h, size_t n, const uint64_t *x, uint8_t *seqs, uint32_t stride,
                        uint32_t *len, uint64_t *rank);
 
+/* ---- index construction: the BWT `fermi build` computes (cmd.c:378-484, build.c:11-50) ------
+ * reads: nt6 bases of all reads back to back, NO sentinels; read i = reads[off[i], off[i+1]).
+ * The text indexed is  read $ revcomp(read) $  per read in input order, sentinels ordered by
+ * sequence id (ksa.c:54).  Palindrome trimming (cmd.c:457-463) is the caller's job
+ * (fermi_amd/host).  bwt (host) must hold 2*(off[n]+n) bytes.  The _dev form returns a device
+ * buffer the caller releases with fmd_dev_free(); uniform_len != 0 asserts all reads have
+ * max_len bases. */
+int fmd_build_bwt(int device, size_t n_reads, const uint8_t *reads, const uint64_t *off, uint8_t *bwt, uint64_t *n_sym);
+int fmd_build_bwt_dev(int device, void *stream, size_t n_reads, const uint8_t *d_reads, const uint64_t *d_off,
+                      uint64_t total_bases, uint32_t max_len, int uniform_len, uint8_t **d_bwt, uint64_t *n_sym);
+void fmd_dev_free(void *d_ptr);
+/* device BWT -> host RLE\6 byte stream (`len<<3|sym`, ropebwt.c:132-136); *h_rle6 is malloc'ed,
+ * release with fmd_host_free().  Prefix it with "RLE\6" and it is a .fmd the reference loads. */
+int fmd_bwt_to_rle6(int device, const uint8_t *d_bwt, uint64_t n, uint8_t **h_rle6, uint64_t *n_bytes);
+void fmd_host_free(void *p);
+
 /* ---- diagnostics: random-gather ceiling of this GPU (DESIGN.md "practical roofline") -----
  * Reads n_access random aligned lines of `line_bytes` (64/128/256) from a working set of
  * ws_bytes with the same LDS-DMA gather the rank kernels use; returns milliseconds. */

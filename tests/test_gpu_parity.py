@@ -146,3 +146,31 @@ def test_synthetic_index_properties(gpu, oracle_lib):
     h = c1 > 0
     assert np.array_equal(b1[h], b2[h]) and np.array_equal(e1[h], e2[h])
     d.close(); o.close()
+
+
+def test_gpu_build_equals_fermi_build(gpu, gold, oracle_lib, tmp_path):
+    """GPU suffix-sort construction == `fermi build` BWT; the .fmd written from it is the same file."""
+    from fermi_amd import hostlib
+    import ctypes as C
+    for name in ("tiny", "special"):
+        reads = gold.fastq_nt6(name + ".fq.gz")
+        reads = [r[:hostlib.trim_palindrome(r)] for r in reads]  # cmd.c:457-463
+        bwt = gpu.build_bwt(reads)
+        o = orcbind.OrcIndex(gold.path(name + ".fmd"))
+        assert np.array_equal(bwt, o.decode_all()), name
+        o.close()
+        out = str(tmp_path / (name + ".fmd"))
+        hostlib.write_rld_from_bwt(bwt, out)
+        assert open(out, "rb").read() == open(gold.path(name + ".fmd"), "rb").read()
+    # device BWT -> RLE\6 stream -> RLD file (the bench's path)
+    reads = np.array(gold.fastq_nt6("tiny.fq.gz"), dtype=np.uint8)
+    d = gpu.DevIndex.from_bwt(bwt_tiny := gpu.build_bwt(reads))
+    import torch
+    t = torch.from_numpy(bwt_tiny).cuda()
+    p, nb = C.c_void_p(), C.c_uint64()
+    gpu.check(gpu.lib().fmd_bwt_to_rle6(0, t.data_ptr(), t.numel(), C.byref(p), C.byref(nb)))
+    out = str(tmp_path / "viarle.fmd")
+    hostlib.write_rld_from_rle6_ptr(p, nb.value, out)
+    gpu.lib().fmd_host_free(p)
+    assert open(out, "rb").read() == open(gold.path("tiny.fmd"), "rb").read()
+    d.close()

@@ -1,0 +1,45 @@
+"""CPU: the product's own .fmd writers (fermi_amd/host/rld_writer.c) are byte-identical to the
+files `fermi build` / `fermi ropebwt` wrote (golden), incl. 32-bit block headers."""
+import subprocess
+import os
+
+import numpy as np
+import pytest
+
+import orcbind
+from fermi_amd import hostlib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build_host():
+    subprocess.check_call(["make", "-s", "-C", ROOT, "host"])
+
+
+def test_rle6_to_rld_is_fermi_build_output(gold, tmp_path):
+    runs = np.frombuffer(open(gold.path("tiny.rle.fmd"), "rb").read()[4:], dtype=np.uint8)
+    out = str(tmp_path / "t.fmd")
+    hostlib.write_rld_from_rle6(runs, out)
+    assert open(out, "rb").read() == open(gold.path("tiny.fmd"), "rb").read()
+    out2 = str(tmp_path / "t.rle.fmd")
+    hostlib.write_rle6(runs, out2)
+    assert open(out2, "rb").read() == open(gold.path("tiny.rle.fmd"), "rb").read()
+
+
+@pytest.mark.parametrize("name", ["tiny", "special", "dup32"])
+def test_bwt_to_rld_roundtrip(oracle_lib, gold, tmp_path, name):
+    o = orcbind.OrcIndex(gold.path(name + ".fmd"))
+    out = str(tmp_path / "b.fmd")
+    hostlib.write_rld_from_bwt(o.decode_all(), out)
+    assert open(out, "rb").read() == open(gold.path(name + ".fmd"), "rb").read()
+    o.close()
+
+
+def test_trim_palindrome():
+    nt = {"A": 1, "C": 2, "G": 3, "T": 4, "N": 5}
+    f = lambda s: hostlib.trim_palindrome(np.array([nt[c] for c in s], dtype=np.uint8))
+    assert f("AACCGGTT") == 7          # even length, own reverse complement (cmd.c:457-463)
+    assert f("AACCGGTA") == 8
+    assert f("ACGTA") == 5             # odd length never trimmed
+    assert f("ANNT") == 4
