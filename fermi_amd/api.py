@@ -24,6 +24,7 @@ ABI_SYMBOLS = [
     "fmd_extend_dev", "fmd_extend_batch", "fmd_bsearch_dev", "fmd_bsearch_batch",
     "fmd_retrieve_dev", "fmd_retrieve_batch", "fmd_probe_gather",
     "fmd_build_bwt", "fmd_build_bwt_dev", "fmd_dev_free", "fmd_bwt_to_rle6", "fmd_host_free",
+    "fmd_dev_malloc", "fmd_memcpy_h2d", "fmd_memcpy_d2h",
 ]
 
 
@@ -45,6 +46,10 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise FmdError("libfmdhip.so is not built (%s); run `make` or __graft_entry__.build()" % LIB_PATH)
+        try:  # one process, one HIP runtime: if torch is going to be used, its bundled
+            import torch  # noqa: F401  libamdhip64 must be the copy that gets loaded (same soname)
+        except Exception:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, sz, u64p = C.c_void_p, C.c_size_t, C.c_void_p
         L.fmd_strerror.restype = C.c_char_p; L.fmd_strerror.argtypes = [C.c_int]
@@ -73,6 +78,9 @@ def lib():
         L.fmd_dev_free.restype = None; L.fmd_dev_free.argtypes = [vp]
         L.fmd_bwt_to_rle6.argtypes = [C.c_int, vp, C.c_uint64, C.POINTER(vp), C.POINTER(C.c_uint64)]
         L.fmd_host_free.restype = None; L.fmd_host_free.argtypes = [vp]
+        L.fmd_dev_malloc.argtypes = [C.c_int, sz, C.POINTER(vp)]
+        L.fmd_memcpy_h2d.argtypes = [vp, vp, sz, vp]
+        L.fmd_memcpy_d2h.argtypes = [vp, vp, sz, vp]
         L.fmd_probe_gather.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_float)]
         _lib = L
     return _lib

@@ -412,6 +412,28 @@ extern "C" int fmd_dev_info(const fmd_dev_t *h, fmd_info_t *info)
     return FMD_OK;
 }
 
+extern "C" int fmd_dev_malloc(int device, size_t bytes, void **d_ptr)
+{
+    if (!d_ptr) return FMD_E_ARG;
+    if (fmd_device_count() <= 0) return FMD_E_NODEV;
+    FMD_HIP_TRY(hipSetDevice(device));
+    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 16);
+    if (e != hipSuccess) { fmd_set_hip_error(e, "hipMalloc"); return FMD_E_NOMEM; }
+    return FMD_OK;
+}
+extern "C" int fmd_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream)
+{
+    FMD_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    FMD_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return FMD_OK;
+}
+extern "C" int fmd_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream)
+{
+    FMD_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    FMD_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return FMD_OK;
+}
+
 extern "C" int fmd_dev_sync(const fmd_dev_t *h, void *stream)
 {
     if (!h) return FMD_E_ARG;

@@ -110,6 +110,11 @@ int fmd_build_bwt(int device, size_t n_reads, const uint8_t *reads, const uint64
 int fmd_build_bwt_dev(int device, void *stream, size_t n_reads, const uint8_t *d_reads, const uint64_t *d_off,
                       uint64_t total_bases, uint32_t max_len, int uniform_len, uint8_t **d_bwt, uint64_t *n_sym);
 void fmd_dev_free(void *d_ptr);
+/* device memory for C hosts (the reference has no device; these are what a cgo/C caller uses to
+ * stage batches): plain hipMalloc / hipMemcpyAsync behind the ABI. */
+int fmd_dev_malloc(int device, size_t bytes, void **d_ptr);
+int fmd_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int fmd_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
 /* device BWT -> host RLE\6 byte stream (`len<<3|sym`, ropebwt.c:132-136); *h_rle6 is malloc'ed,
  * release with fmd_host_free().  Prefix it with "RLE\6" and it is a .fmd the reference loads. */
 int fmd_bwt_to_rle6(int device, const uint8_t *d_bwt, uint64_t n, uint8_t **h_rle6, uint64_t *n_bytes);

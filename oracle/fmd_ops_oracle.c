@@ -445,6 +445,7 @@ static void *bs_worker(void *d)
         j->cnt[i] = orc_backward_search(j->e, j->len, j->seqs + i * (size_t)j->len, &b, &en);
         j->beg[i] = b; j->end[i] = en;
     }
+    orc_counters_flush();
     return 0;
 }
 

@@ -43,6 +43,7 @@ typedef struct {
  * counters of rank calls; orc_counters_read() returns and clears the calling thread's. */
 typedef struct { uint64_t rank1a, rank2a, rank2a_spill; } orc_counters_t;
 orc_counters_t orc_counters_read(void);
+void orc_counters_flush(void);
 
 /* ---- container (rld.c:265-346) ---- */
 orc_rld_t *orc_rld_load(const char *fn);          /* accepts "RLD\2" and raw "RLE\6" streams */

@@ -16,10 +16,23 @@
 
 static __thread orc_counters_t tl_counters;
 
-orc_counters_t orc_counters_read(void)
+static orc_counters_t g_counters; /* totals handed over by finished worker threads */
+
+void orc_counters_flush(void) /* called by batch workers before they exit */
 {
-    orc_counters_t c = tl_counters;
+    __atomic_fetch_add(&g_counters.rank1a, tl_counters.rank1a, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&g_counters.rank2a, tl_counters.rank2a, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&g_counters.rank2a_spill, tl_counters.rank2a_spill, __ATOMIC_RELAXED);
     memset(&tl_counters, 0, sizeof(tl_counters));
+}
+
+orc_counters_t orc_counters_read(void) /* calling thread's + flushed workers'; clears both */
+{
+    orc_counters_t c;
+    orc_counters_flush();
+    c.rank1a = __atomic_exchange_n(&g_counters.rank1a, 0, __ATOMIC_RELAXED);
+    c.rank2a = __atomic_exchange_n(&g_counters.rank2a, 0, __ATOMIC_RELAXED);
+    c.rank2a_spill = __atomic_exchange_n(&g_counters.rank2a_spill, 0, __ATOMIC_RELAXED);
     return c;
 }
 

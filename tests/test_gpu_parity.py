@@ -165,10 +165,12 @@ def test_gpu_build_equals_fermi_build(gpu, gold, oracle_lib, tmp_path):
     # device BWT -> RLE\6 stream -> RLD file (the bench's path)
     reads = np.array(gold.fastq_nt6("tiny.fq.gz"), dtype=np.uint8)
     d = gpu.DevIndex.from_bwt(bwt_tiny := gpu.build_bwt(reads))
-    import torch
-    t = torch.from_numpy(bwt_tiny).cuda()
+    dp = C.c_void_p()
+    gpu.check(gpu.lib().fmd_dev_malloc(0, len(bwt_tiny), C.byref(dp)))
+    gpu.check(gpu.lib().fmd_memcpy_h2d(dp, bwt_tiny.ctypes.data, len(bwt_tiny), None))
     p, nb = C.c_void_p(), C.c_uint64()
-    gpu.check(gpu.lib().fmd_bwt_to_rle6(0, t.data_ptr(), t.numel(), C.byref(p), C.byref(nb)))
+    gpu.check(gpu.lib().fmd_bwt_to_rle6(0, dp, len(bwt_tiny), C.byref(p), C.byref(nb)))
+    gpu.lib().fmd_dev_free(dp)
     out = str(tmp_path / "viarle.fmd")
     hostlib.write_rld_from_rle6_ptr(p, nb.value, out)
     gpu.lib().fmd_host_free(p)
