@@ -207,6 +207,13 @@ def main():
                                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                                "kernel": "k_bsearch", "kernel_ms": kern_ms, "rank_queries_per_read": qpr,
                                "algorithmic_bytes_per_read": qpr * BYTES_PER_RANK_QUERY}
+            try:  # HBM bytes per launch measured by the separate rocprofv3 --pmc passes (profiles/)
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("k_bsearch@%d" % n_reads)
+                if pmc and err == 0:
+                    out["roofline"]["traffic"] = (pmc["fetch_kb"] * pmc["fetch_calibration"] + pmc["write_kb"]) * 1024.0
+                    out["roofline"]["traffic_source"] = pmc["source"]
+            except Exception:
+                pass
             base, parity = cpu_baseline(fmd_path, q_host, cpu_sample, g_cnt, g_beg, g_end)
             out["cpu_baseline"] = base
             out["parity_vs_cpu_on_sample"] = "bit-exact" if parity else "MISMATCH"
