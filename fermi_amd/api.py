@@ -14,6 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfmdhip.so")
 INTV_DT = np.dtype([("x", "<u8", 3), ("info", "<u8")])  # fmd_intv_t == fmintv_t (fermi.h:13-16)
 NONE64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+OVLP_DT = np.dtype([("rank", "<u8"), ("k", "<u8", 3), ("len", "<i4"), ("status", "<i4"), ("n_ovlp", "<i4"),
+                    ("rbeg", "<i4"), ("ext_len", "<i4"), ("n_nei", "<i4"), ("flags", "<u4"), ("reserved", "<u4")])
+OVLP_F_FORKED, OVLP_F_OVERFLOW, OVLP_F_FIXED = 1, 2, 4
 
 # every symbol include/fmd_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
@@ -25,6 +28,7 @@ ABI_SYMBOLS = [
     "fmd_retrieve_dev", "fmd_retrieve_batch", "fmd_probe_gather",
     "fmd_build_bwt", "fmd_build_bwt_dev", "fmd_dev_free", "fmd_bwt_to_rle6", "fmd_host_free",
     "fmd_dev_malloc", "fmd_memcpy_h2d", "fmd_memcpy_d2h",
+    "fmd_ovlp_work_bytes", "fmd_ovlp_dev", "fmd_ovlp_batch",
 ]
 
 
@@ -81,6 +85,9 @@ def lib():
         L.fmd_dev_malloc.argtypes = [C.c_int, sz, C.POINTER(vp)]
         L.fmd_memcpy_h2d.argtypes = [vp, vp, sz, vp]
         L.fmd_memcpy_d2h.argtypes = [vp, vp, sz, vp]
+        L.fmd_ovlp_work_bytes.restype = sz; L.fmd_ovlp_work_bytes.argtypes = [sz, C.c_uint32, C.c_int]
+        L.fmd_ovlp_dev.argtypes = [vp, vp, sz, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint32, vp, sz]
+        L.fmd_ovlp_batch.argtypes = [vp, sz, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint32]
         L.fmd_probe_gather.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_float)]
         _lib = L
     return _lib
@@ -205,6 +212,19 @@ class DevIndex:
             l = min(int(ln[i]), stride)
             out[i, :l] = seqs[i, :l][::-1]
         return out, ln.astype(np.int32), rank
+
+
+def _ovlp(self, ids, min_match, max_len=100, max_nei=4):
+    """Per-id overlap records (see include/fmd_hip.h): (rec[OVLP_DT], nei[n, max_nei, INTV_DT], seq[n, 2*max_len])."""
+    ids = np.ascontiguousarray(ids, dtype=np.uint64)
+    n = len(ids)
+    stride = 2 * ((max_len + 3) // 4 * 4)
+    rec = np.zeros(n, dtype=OVLP_DT); nei = np.zeros((n, max_nei), dtype=INTV_DT); seq = np.zeros((n, stride), dtype=np.uint8)
+    check(lib().fmd_ovlp_batch(self.h, n, _ptr(ids), min_match, max_len, max_nei, _ptr(rec), _ptr(nei), _ptr(seq), stride))
+    return rec, nei, seq
+
+
+DevIndex.overlap = _ovlp
 
 
 def build_bwt(seqs, device=0):

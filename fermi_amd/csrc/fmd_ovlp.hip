@@ -1,0 +1,448 @@
+// fmd_ovlp.hip -- all-vs-all overlap discovery for unitig construction: the read-only front half
+// of unitig1 (unitig.c:274-300) for a batch of sequence ids, one lane per read-strand:
+//     fm_retrieve (exact.c:59)  ->  fm6_is_contained / overlap_intv (unitig.c:38-91)
+//                               ->  fm6_get_nei (unitig.c:93-179, used = sorted = NULL)
+// Three phase-uniform persistent kernels on the wave engine (fmd_wave.h); candidate interval lists
+// travel between phases through an HBM work area.  Every lane free-runs its own search and posts
+// one rank2a request per wave step; finished lanes refill from a queue (ballot compaction).
+#include <stdlib.h>
+#include <string.h>
+#include "fmd_internal.h"
+
+#define NONE64 (~0ull)
+
+__device__ __forceinline__ int comp6(int c) { return (c >= 1 && c <= 4) ? 5 - c : c; }
+
+template <class T>
+__device__ __forceinline__ T sel6(int c, T a0, T a1, T a2, T a3, T a4, T a5)
+{
+    T r = a0;
+    r = c == 1 ? a1 : r; r = c == 2 ? a2 : r; r = c == 3 ? a3 : r; r = c == 4 ? a4 : r; r = c == 5 ? a5 : r;
+    return r;
+}
+
+// queue refill shared by the persistent kernels: returns the item index for lanes that asked
+__device__ __forceinline__ size_t fmd_queue_take(uint32_t *queue, bool want)
+{
+    const uint64_t m = __ballot(want);
+    if (m == 0) return (size_t)-1;
+    uint32_t first = 0;
+    if (fmd_lane() == 0) first = atomicAdd(queue, (uint32_t)__popcll(m));
+    first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+    return want ? (size_t)first + __popcll(m & ((1ull << fmd_lane()) - 1)) : (size_t)-1;
+}
+
+// ---------------------------------------------------------------------------- phase 0: retrieve
+// fm_retrieve (exact.c:59-70); writes the sequence REVERSED into srev and rank/len into rec.
+__global__ __launch_bounds__(64) void k_ovl_retrieve(FmdIndexView ix, size_t n, const uint64_t *__restrict__ ids,
+                                                     uint8_t *__restrict__ srev, uint32_t stride_r,
+                                                     fmd_ovlp_rec_t *__restrict__ rec, uint32_t *__restrict__ queue)
+{
+    FMD_DECLARE_WAVE_LDS();
+    size_t sid = 0;
+    uint64_t k = 0;
+    uint32_t len = 0, pack = 0;
+    bool live = false, exhausted = false;
+    for (;;) {
+        const size_t my = fmd_queue_take(queue, !live && !exhausted);
+        if (!live && !exhausted) {
+            if (my < n) { sid = my; k = ids[my]; len = 0; pack = 0; live = true; }
+            else exhausted = true;
+        }
+        if (__ballot(live) == 0) break;
+        const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, live ? k : NONE64, NONE64);
+        if (live) {
+            uint64_t ok[6];
+            const int c = fmd_block_rank6<true>(r.bk, r.t, r.nk, ok);
+            k = ix.cnt[c] + ok[c] - 1;
+            if (c == 0) {
+                if ((len & 3) && len < stride_r) *(uint32_t *)(srev + sid * (size_t)stride_r + (len & ~3u)) = pack;
+                fmd_ovlp_rec_t *o = rec + sid;
+                o->rank = k; o->k[0] = o->k[1] = o->k[2] = 0;
+                o->len = (int32_t)len; o->status = 0; o->n_ovlp = 0; o->rbeg = -1; o->ext_len = 0; o->n_nei = 0; o->flags = 0; o->reserved = 0;
+                live = false;
+            } else {
+                pack |= (uint32_t)c << (8 * (len & 3));
+                ++len;
+                if ((len & 3) == 0) { // four bases per store
+                    if (len <= stride_r) *(uint32_t *)(srev + sid * (size_t)stride_r + len - 4) = pack;
+                    pack = 0;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------- phase A: overlap_intv + fm6_is_contained
+// unitig.c:38-64 (at5 = 0, inc_sentinel = 0, j = len-1) then unitig.c:83-90.
+// The candidate list is written back to front so that it ends up in the reversed order the
+// reference produces with fm_reverse_fmivec (longest overlap first): entries [cap-n, cap).
+__global__ __launch_bounds__(64) void k_ovl_intv(FmdIndexView ix, size_t n, int min_match, const uint8_t *__restrict__ srev,
+                                                 uint32_t stride_r, uint32_t cap, fmd_intv_t *__restrict__ listA,
+                                                 fmd_ovlp_rec_t *__restrict__ rec, uint8_t *__restrict__ seq_out,
+                                                 uint32_t seq_stride, uint32_t *__restrict__ queue)
+{
+    FMD_DECLARE_WAVE_LDS();
+    size_t sid = 0;
+    int L = 0, jr = 0, depth = 0, phase = 0, ret = 0;
+    uint32_t npush = 0, cache = 0;
+    uint64_t x0 = 0, x1 = 0, sz = 0;
+    bool live = false, exhausted = false;
+    for (;;) {
+        const size_t my = fmd_queue_take(queue, !live && !exhausted);
+        if (!live && !exhausted) {
+            if (my < n) {
+                sid = my; L = rec[my].len;
+                if (L > (int)stride_r) { rec[my].flags |= FMD_OVLP_F_OVERFLOW; }     // longer than the caller's max_len
+                else if (L <= min_match) { rec[my].status = -1; }                      // too short (unitig.c:288)
+                else {
+                    const uint8_t *s = srev + sid * (size_t)stride_r;
+                    cache = *(const uint32_t *)s;
+                    const int c = cache & 0xff;
+                    x0 = ix.cnt[c]; x1 = ix.cnt[comp6(c)]; sz = ix.cnt[c + 1] - ix.cnt[c];
+                    if ((uint32_t)(L - 1) < seq_stride) seq_out[sid * (size_t)seq_stride + L - 1] = (uint8_t)c;
+                    jr = 1; depth = 1; npush = 0; ret = 0; phase = L > 1 ? 0 : 1; live = true;
+                }
+            } else exhausted = true;
+        }
+        if (__ballot(live) == 0) break;
+        // request: backward extension in phases 0/1, forward in phase 2
+        uint64_t qk = NONE64, ql = NONE64;
+        if (live) { const uint64_t a = phase == 2 ? x1 : x0; qk = a - 1; ql = a - 1 + sz; }
+        const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, qk, ql);
+        if (live) {
+            uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tl[6] = {0, 0, 0, 0, 0, 0};
+            if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
+            if (r.hl) fmd_block_rank6<false>(r.bl, r.t, r.nl, tl);
+            uint64_t s[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) s[c] = tl[c] - tk[c];
+            if (phase == 0) {
+                if ((jr & 3) == 0) cache = *(const uint32_t *)(srev + sid * (size_t)stride_r + jr);
+                const int c = (cache >> (8 * (jr & 3))) & 0xff;
+                const uint64_t sc = sel6(c, s[0], s[1], s[2], s[3], s[4], s[5]);
+                const int j = L - 1 - jr; // position of this base in read order
+                if ((uint32_t)j < seq_stride) seq_out[sid * (size_t)seq_stride + j] = (uint8_t)c;
+                if (sc == 0) phase = 1; // cannot be extended (unitig.c:50)
+                else {
+                    if (depth >= min_match && s[0]) { // a read starts here: keep the current interval
+                        if (npush < cap) {
+                            fmd_intv_t *e = listA + sid * (size_t)cap + (cap - 1 - npush);
+                            uint4 *q = (uint4 *)e;
+                            q[0] = make_uint4((uint32_t)x0, (uint32_t)(x0 >> 32), (uint32_t)x1, (uint32_t)(x1 >> 32));
+                            q[1] = make_uint4((uint32_t)sz, (uint32_t)(sz >> 32), (uint32_t)(j + 1), 0u);
+                        } else rec[sid].flags |= FMD_OVLP_F_OVERFLOW;
+                        ++npush;
+                    }
+                    // ik = ok[c] (backward): x0 from rank, x1 = running sum in the order $,T,G,C,A,N
+                    const uint64_t tkc = sel6(c, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
+                    x0 = sel6(c, ix.cnt[0], ix.cnt[1], ix.cnt[2], ix.cnt[3], ix.cnt[4], ix.cnt[5]) + tkc;
+                    uint64_t before = 0;             // sizes ordered before c: 0 <4 <3 <2 <1 <5
+                    if (c != 0) before += s[0];
+                    if (c == 3 || c == 2 || c == 1 || c == 5) before += s[4];
+                    if (c == 2 || c == 1 || c == 5) before += s[3];
+                    if (c == 1 || c == 5) before += s[2];
+                    if (c == 5) before += s[1];
+                    x1 += before; sz = sc;
+                    ++jr; ++depth;
+                    if (jr == L) phase = 1;
+                }
+            } else if (phase == 1) { // extend by '$' on the left: left-contained if the size shrinks
+                if (sz != s[0]) ret = -1;
+                x0 = tk[0]; sz = s[0]; // ok[0]: x[0] = cnt[0] + tk[0], x[1] unchanged
+                phase = 2;
+            } else {                 // extend by '$' on the right
+                if (sz != s[0]) ret = -1;
+                fmd_ovlp_rec_t *o = rec + sid;
+                o->k[0] = x0; o->k[1] = tk[0]; o->k[2] = s[0];
+                o->status = ret < 0 ? -3 : 0; // contained (unitig.c:292)
+                o->n_ovlp = (int32_t)npush;
+                live = false;
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------- phase B: fm6_get_nei
+enum { ST_IDLE = 0, ST_PICK, ST_EXT, ST_E0, ST_C, ST_FIX1, ST_FIX2 };
+
+struct I3 { uint64_t x0, x1, sz; };
+
+__device__ __forceinline__ void load_entry(const fmd_intv_t *e, uint64_t &x0, uint64_t &x1, uint64_t &sz, uint64_t &info)
+{
+    const uint4 *q = (const uint4 *)e;
+    const uint4 a = q[0], b = q[1];
+    x0 = (uint64_t)a.y << 32 | a.x; x1 = (uint64_t)a.w << 32 | a.z;
+    sz = (uint64_t)b.y << 32 | b.x; info = (uint64_t)b.w << 32 | b.z;
+}
+__device__ __forceinline__ void store_entry(fmd_intv_t *e, uint64_t x0, uint64_t x1, uint64_t sz, uint64_t info)
+{
+    uint4 *q = (uint4 *)e;
+    q[0] = make_uint4((uint32_t)x0, (uint32_t)(x0 >> 32), (uint32_t)x1, (uint32_t)(x1 >> 32));
+    q[1] = make_uint4((uint32_t)sz, (uint32_t)(sz >> 32), (uint32_t)info, (uint32_t)(info >> 32));
+}
+
+__global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int min_match, const uint8_t *__restrict__ srev,
+                                                uint32_t stride_r, uint32_t cap, fmd_intv_t *__restrict__ listA,
+                                                fmd_intv_t *__restrict__ listB, fmd_ovlp_rec_t *__restrict__ rec,
+                                                fmd_intv_t *__restrict__ nei_out, uint32_t max_nei,
+                                                uint8_t *__restrict__ seq_out, uint32_t seq_stride, uint32_t *__restrict__ queue)
+{
+    FMD_DECLARE_WAVE_LDS();
+    // per-lane search state
+    size_t sid = 0;
+    int st = ST_IDLE, ori_l = 0, cur_l = 0, cpend = 0, first_c = 0, masked_cat = -2, cat_j = 0, fix_i = 0, rbeg = -1;
+    uint32_t prev_n = 0, curr_n = 0, j = 0, n_nei = 0, flags = 0;
+    bool unsorted = false, exhausted = false, prev_is_a = true;
+    fmd_intv_t *prev = nullptr, *curr = nullptr;
+    uint64_t last_key = 0;
+    uint64_t px0 = 0, px1 = 0, psz = 0, pinfo = 0;   // interval being extended
+    I3 o0 = {0, 0, 0}, oc1 = {0, 0, 0}, oc2 = {0, 0, 0}, oc3 = {0, 0, 0}, oc4 = {0, 0, 0}; // its children
+    uint64_t nx0 = 0, nsz = 0;                        // first neighbour (fork fix-up)
+
+    for (;;) {
+        // ---- refill
+        const size_t my = fmd_queue_take(queue, st == ST_IDLE && !exhausted);
+        if (st == ST_IDLE && !exhausted) {
+            if (my < n) {
+                const fmd_ovlp_rec_t *o = rec + my;
+                if (o->status == 0 && o->n_ovlp > 0 && !(o->flags & FMD_OVLP_F_OVERFLOW)) {
+                    sid = my; ori_l = cur_l = o->len;
+                    prev_n = (uint32_t)o->n_ovlp; curr_n = 0; j = 0;
+                    prev = listA + sid * (size_t)cap + (cap - prev_n);
+                    curr = listB + sid * (size_t)cap; prev_is_a = true;
+                    n_nei = 0; flags = 0; masked_cat = -2; unsorted = false; last_key = 0; rbeg = -1;
+                    st = ST_PICK;
+                }
+            } else exhausted = true;
+        }
+        // ---- bookkeeping that needs no rank: pick the next interval / finish a round / finish
+        while (st == ST_PICK) {
+            if (j < prev_n) {
+                load_entry(prev + j, px0, px1, psz, pinfo);
+                cat_j = (int)(pinfo >> 36);
+                if (cat_j == masked_cat) { ++j; continue; }
+                st = ST_EXT;
+            } else if (curr_n) { // end of a round (unitig.c:137-153)
+                if ((uint32_t)cur_l < seq_stride) seq_out[sid * (size_t)seq_stride + cur_l] = (uint8_t)comp6(first_c);
+                ++cur_l;
+                if (unsorted) { // ks_introsort by info; keys are unique so any sort gives the same order
+                    for (uint32_t a = 1; a < curr_n; ++a) {
+                        uint64_t ax0, ax1, asz, ainf;
+                        load_entry(curr + a, ax0, ax1, asz, ainf);
+                        uint32_t b = a;
+                        while (b > 0) {
+                            uint64_t bx0, bx1, bsz, binf;
+                            load_entry(curr + b - 1, bx0, bx1, bsz, binf);
+                            if (binf <= ainf) break;
+                            store_entry(curr + b, bx0, bx1, bsz, binf);
+                            --b;
+                        }
+                        store_entry(curr + b, ax0, ax1, asz, ainf);
+                    }
+                }
+                uint32_t last = 0, cat0 = 0; // recompute the categories (unitig.c:143-151)
+                for (uint32_t a = 0; a < curr_n; ++a) {
+                    uint64_t *pinf = &curr[a].info;
+                    const uint64_t inf = *pinf;
+                    const uint32_t hi = (uint32_t)(inf >> 32);
+                    if (a == 0) last = hi;
+                    else if (hi != last) { last = hi; cat0 = a; }
+                    *pinf = (inf & 0xffffffffull) | (uint64_t)cat0 << 36;
+                }
+                if (cat0 != 0) flags |= FMD_OVLP_F_FORKED;
+                prev_is_a = !prev_is_a; // both lists start at index 0 of their areas from now on
+                prev = (prev_is_a ? listA : listB) + sid * (size_t)cap;
+                curr = (prev_is_a ? listB : listA) + sid * (size_t)cap;
+                prev_n = curr_n; curr_n = 0; j = 0; masked_cat = -2; unsorted = false; last_key = 0;
+            } else { // all paths closed (unitig.c:154-178)
+                fmd_ovlp_rec_t *o = rec + sid;
+                bool need_fix = false;
+                if (n_nei) {
+                    uint64_t a, b, c, inf;
+                    load_entry(nei_out + sid * (size_t)max_nei, a, b, c, inf);
+                    rbeg = ori_l - (int)(uint32_t)inf;
+                    if (n_nei == 1 && (flags & FMD_OVLP_F_FORKED) && !(flags & FMD_OVLP_F_FIXED) && rbeg < ori_l) {
+                        nx0 = a; nsz = c;   // contained reads made a fake fork: re-derive the appended bases
+                        o0.x0 = 0; o0.x1 = 0; o0.sz = ix.cnt[1]; // fm6_set_intv(e, 0, ok0)
+                        fix_i = rbeg;
+                        need_fix = true;
+                    }
+                }
+                if (need_fix) { st = ST_FIX1; break; }
+                if (n_nei > 1) cur_l = ori_l;
+                o->rbeg = n_nei ? rbeg : -1;
+                o->ext_len = cur_l - ori_l; o->n_nei = (int32_t)n_nei; o->flags |= flags;
+                st = ST_IDLE;
+            }
+        }
+        if (__ballot(st != ST_IDLE) == 0) { if (__ballot(!exhausted) == 0) break; else continue; }
+
+        // ---- one rank2a request per lane
+        uint64_t qk = NONE64, ql = NONE64;
+        if (st == ST_EXT) { qk = px1 - 1; ql = px1 - 1 + psz; }                    // forward: strand x[1]
+        else if (st == ST_E0) { qk = o0.x0 - 1; ql = o0.x0 - 1 + o0.sz; }          // backward: strand x[0]
+        else if (st == ST_C) {
+            const uint64_t a = cpend == 1 ? oc1.x0 : cpend == 2 ? oc2.x0 : cpend == 3 ? oc3.x0 : oc4.x0;
+            const uint64_t z = cpend == 1 ? oc1.sz : cpend == 2 ? oc2.sz : cpend == 3 ? oc3.sz : oc4.sz;
+            qk = a - 1; ql = a - 1 + z;
+        } else if (st == ST_FIX1 || st == ST_FIX2) { qk = o0.x1 - 1; ql = o0.x1 - 1 + o0.sz; }
+        const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, qk, ql);
+
+        // ---- consume
+        if (st == ST_EXT || st == ST_FIX1 || st == ST_FIX2) {
+            uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tl[6] = {0, 0, 0, 0, 0, 0};
+            if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
+            if (r.hl) fmd_block_rank6<false>(r.bl, r.t, r.nl, tl);
+            uint64_t s[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) s[c] = tl[c] - tk[c];
+            // forward extension (exact.c:72-88, is_back = 0): x[1] from rank, x[0] running sum
+            const uint64_t base0 = st == ST_EXT ? px0 : o0.x0;
+            I3 k0, k1, k2, k3, k4;
+            k0.x0 = base0;            k0.x1 = ix.cnt[0] + tk[0]; k0.sz = s[0];
+            k4.x0 = k0.x0 + s[0];     k4.x1 = ix.cnt[4] + tk[4]; k4.sz = s[4];
+            k3.x0 = k4.x0 + s[4];     k3.x1 = ix.cnt[3] + tk[3]; k3.sz = s[3];
+            k2.x0 = k3.x0 + s[3];     k2.x1 = ix.cnt[2] + tk[2]; k2.sz = s[2];
+            k1.x0 = k2.x0 + s[2];     k1.x1 = ix.cnt[1] + tk[1]; k1.sz = s[1];
+            if (st == ST_EXT) {
+                o0 = k0; oc1 = k1; oc2 = k2; oc3 = k3; oc4 = k4;
+                if (o0.sz && cur_l != ori_l) st = ST_E0;   // some reads end here (unitig.c:111)
+                else {
+                    cpend = oc1.sz ? 1 : oc2.sz ? 2 : oc3.sz ? 3 : oc4.sz ? 4 : 0;
+                    if (cpend) st = ST_C; else { ++j; st = ST_PICK; }
+                }
+            } else if (st == ST_FIX1) { // unitig.c:160-163
+                const int b = srev[sid * (size_t)stride_r + (ori_l - 1 - fix_i)];
+                const int c = comp6(b);
+                o0 = c == 1 ? k1 : c == 2 ? k2 : c == 3 ? k3 : c == 4 ? k4 : k0;
+                if (c == 5) { o0.x0 = k1.x0 + s[1]; o0.x1 = ix.cnt[5] + tk[5]; o0.sz = s[5]; }
+                ++fix_i;
+                if (fix_i == ori_l) { st = ori_l < cur_l ? ST_FIX2 : ST_PICK; flags |= FMD_OVLP_F_FIXED; }
+            } else { // ST_FIX2: unitig.c:164-175
+                int cnt_ok = 0, c0 = -1;
+#define FMD_FIX_TRY(c, kc) if (kc.sz && kc.x0 <= nx0 && kc.x0 + kc.sz >= nx0 + nsz) { ++cnt_ok; c0 = c; }
+                FMD_FIX_TRY(1, k1) FMD_FIX_TRY(2, k2) FMD_FIX_TRY(3, k3) FMD_FIX_TRY(4, k4)
+#undef FMD_FIX_TRY
+                bool stop = (cnt_ok == 0 && k0.sz != 0);
+                if (!stop && c0 > 0) {
+                    if ((uint32_t)fix_i < seq_stride) seq_out[sid * (size_t)seq_stride + fix_i] = (uint8_t)comp6(c0);
+                    o0 = c0 == 1 ? k1 : c0 == 2 ? k2 : c0 == 3 ? k3 : k4;
+                    ++fix_i;
+                    if (fix_i == cur_l) stop = true;
+                } else stop = true;
+                if (stop) { cur_l = fix_i; st = ST_PICK; }
+            }
+        } else if (st == ST_E0 || st == ST_C) {
+            // fm6_extend0 (exact.c:90-98), backward: only the '$' child matters
+            const uint64_t t0k = r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, 0) : 0;
+            const uint64_t t0l = r.hl ? fmd_block_rank1(r.bl, r.t, r.nl, 0) : 0;
+            const uint64_t e0sz = t0l - t0k;
+            if (st == ST_E0) {
+                bool is_nei = false;
+                if (e0sz && o0.sz == psz && psz == e0sz) { // bounded by sentinels on both sides and not contained
+                    if (n_nei < max_nei)
+                        store_entry(nei_out + sid * (size_t)max_nei + n_nei, t0k, o0.x1, e0sz, (uint64_t)ori_l - (pinfo & 0xffffffffull));
+                    else flags |= FMD_OVLP_F_OVERFLOW;
+                    ++n_nei;
+                    masked_cat = cat_j; // mask out the other intervals of this category
+                    is_nei = true;
+                }
+                if (is_nei) { ++j; st = ST_PICK; }
+                else {
+                    cpend = oc1.sz ? 1 : oc2.sz ? 2 : oc3.sz ? 3 : oc4.sz ? 4 : 0;
+                    if (cpend) st = ST_C; else { ++j; st = ST_PICK; }
+                }
+            } else {
+                if (e0sz) { // left end bounded by a sentinel: keep the child (unitig.c:128-135)
+                    const I3 ch = cpend == 1 ? oc1 : cpend == 2 ? oc2 : cpend == 3 ? oc3 : oc4;
+                    const uint64_t key = (pinfo & 0xfffffff0ffffffffull) | (uint64_t)cpend << 32;
+                    if (curr_n < cap) {
+                        store_entry(curr + curr_n, ch.x0, ch.x1, ch.sz, key);
+                        if (curr_n == 0) first_c = cpend;
+                        else if (key < last_key) unsorted = true;
+                        last_key = key;
+                        ++curr_n;
+                    } else { flags |= FMD_OVLP_F_OVERFLOW; }
+                }
+                int nc = 0;
+                if (cpend < 2 && oc2.sz) nc = 2; else if (cpend < 3 && oc3.sz) nc = 3; else if (cpend < 4 && oc4.sz) nc = 4;
+                if (nc) cpend = nc; else { ++j; st = ST_PICK; }
+            }
+        }
+        // an overflowing strand is abandoned; the host re-runs it with larger capacities
+        if (st != ST_IDLE && (flags & FMD_OVLP_F_OVERFLOW)) {
+            fmd_ovlp_rec_t *o = rec + sid;
+            o->flags |= FMD_OVLP_F_OVERFLOW; o->n_nei = 0; o->rbeg = -1; o->ext_len = 0;
+            st = ST_IDLE;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- host entry
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+extern "C" size_t fmd_ovlp_work_bytes(size_t n, uint32_t max_len, int min_match)
+{
+    const size_t stride_r = align_up((size_t)max_len, 4);
+    const size_t cap = fmd_ovlp_list_cap(max_len, min_match);
+    return align_up(n * stride_r, 256) + 2 * align_up(n * cap * sizeof(fmd_intv_t), 256) + 256;
+}
+
+extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_t *d_ids, int min_match, uint32_t max_len,
+                            uint32_t max_nei, fmd_ovlp_rec_t *d_rec, fmd_intv_t *d_nei, uint8_t *d_seq, uint32_t seq_stride,
+                            void *d_work, size_t work_bytes)
+{
+    if (!h || (n && (!d_ids || !d_rec || !d_nei || !d_seq || !d_work)) || max_len == 0 || max_nei == 0 || min_match < 0) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    if (n >= 0xffffff00ull || work_bytes < fmd_ovlp_work_bytes(n, max_len, min_match)) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream_;
+    const uint32_t stride_r = (uint32_t)align_up(max_len, 4);
+    const uint32_t cap = fmd_ovlp_list_cap(max_len, min_match);
+    uint8_t *srev = (uint8_t *)d_work;
+    fmd_intv_t *listA = (fmd_intv_t *)((uint8_t *)d_work + align_up(n * (size_t)stride_r, 256));
+    fmd_intv_t *listB = (fmd_intv_t *)((uint8_t *)listA + align_up(n * (size_t)cap * sizeof(fmd_intv_t), 256));
+    const FmdIndexView ix = fmd_view(h);
+    const int grid = fmd_grid_for(h, n);
+    uint32_t *q0 = fmd_next_queue(h, st), *q1 = fmd_next_queue(h, st), *q2 = fmd_next_queue(h, st);
+    k_ovl_retrieve<<<grid, 64, 0, st>>>(ix, n, d_ids, srev, stride_r, d_rec, q0);
+    k_ovl_intv<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, d_rec, d_seq, seq_stride, q1);
+    k_ovl_nei<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, listB, d_rec, d_nei, max_nei, d_seq, seq_stride, q2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fmd_set_hip_error(e, "overlap kernels"); return FMD_E_HIP; }
+    return FMD_OK;
+}
+
+struct DevBuf2 {
+    void *p = nullptr;
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? FMD_OK : FMD_E_NOMEM; }
+    ~DevBuf2() { if (p) hipFree(p); }
+};
+
+extern "C" int fmd_ovlp_batch(fmd_dev_t *h, size_t n, const uint64_t *ids, int min_match, uint32_t max_len, uint32_t max_nei,
+                              fmd_ovlp_rec_t *rec, fmd_intv_t *nei, uint8_t *seq, uint32_t seq_stride)
+{
+    if (!h || (n && (!ids || !rec || !nei || !seq))) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    const size_t chunk = 1u << 20; // strands per pass: bounds the HBM work area
+    const size_t m = n < chunk ? n : chunk;
+    const size_t wb = fmd_ovlp_work_bytes(m, max_len, min_match);
+    DevBuf2 di, dr, dn, ds, dw;
+    if (di.alloc(m * 8) || dr.alloc(m * sizeof(fmd_ovlp_rec_t)) || dn.alloc(m * max_nei * sizeof(fmd_intv_t)) ||
+        ds.alloc(m * (size_t)seq_stride) || dw.alloc(wb)) return FMD_E_NOMEM;
+    for (size_t o = 0; o < n; o += m) {
+        const size_t c = n - o < m ? n - o : m;
+        FMD_HIP_TRY(hipMemcpy(di.p, ids + o, c * 8, hipMemcpyHostToDevice));
+        FMD_HIP_TRY(hipMemset(ds.p, 0, c * (size_t)seq_stride));
+        FMD_HIP_TRY(hipMemset(dn.p, 0, c * max_nei * sizeof(fmd_intv_t)));
+        int rc = fmd_ovlp_dev(h, nullptr, c, (uint64_t *)di.p, min_match, max_len, max_nei, (fmd_ovlp_rec_t *)dr.p,
+                              (fmd_intv_t *)dn.p, (uint8_t *)ds.p, seq_stride, dw.p, wb);
+        if (rc) return rc;
+        FMD_HIP_TRY(hipMemcpy(rec + o, dr.p, c * sizeof(fmd_ovlp_rec_t), hipMemcpyDeviceToHost));
+        FMD_HIP_TRY(hipMemcpy(nei + o * max_nei, dn.p, c * max_nei * sizeof(fmd_intv_t), hipMemcpyDeviceToHost));
+        FMD_HIP_TRY(hipMemcpy(seq + o * (size_t)seq_stride, ds.p, c * (size_t)seq_stride, hipMemcpyDeviceToHost));
+    }
+    return FMD_OK;
+}

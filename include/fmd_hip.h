@@ -99,6 +99,46 @@ int fmd_retrieve_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_x, 
 int fmd_retrieve_batch(fmd_dev_t *h, size_t n, const uint64_t *x, uint8_t *seqs, uint32_t stride,
                        uint32_t *len, uint64_t *rank);
 
+/* ---- overlap discovery for unitig construction --------------------------------------------
+ * One record per sequence id: the read-only front half of unitig1 (unitig.c:274-300), i.e.
+ *   fm_retrieve (exact.c:59) + seq_reverse + fm6_is_contained (unitig.c:77) +
+ *   fm6_get_nei(beg = 0, used = NULL, sorted = NULL) (unitig.c:93)
+ * which SURVEY.md (fact 3) shows is a pure function of (index, id) and is exactly what the
+ * deterministic `fermi unitig -t1` walk consumes.  `rank`, k[0] and k[1] are in the coordinate
+ * system of the reference's used/bend/visited bitmaps (unitig.c:289, 299). */
+#define FMD_OVLP_SHORT      (-1)  /* len <= min_match (unitig.c:288) */
+#define FMD_OVLP_CONTAINED  (-3)  /* fm6_is_contained < 0 (unitig.c:292) */
+#define FMD_OVLP_F_FORKED   1u    /* more than one category survived a round (unitig.c:152) */
+#define FMD_OVLP_F_OVERFLOW 2u    /* a capacity (max_len, list, max_nei) was exceeded: record invalid, re-run larger */
+#define FMD_OVLP_F_FIXED    4u    /* the fake-fork fix-up of unitig.c:158-176 ran */
+typedef struct {
+    uint64_t rank;     /* fm_retrieve's return value */
+    uint64_t k[3];     /* *intv of fm6_is_contained: bi-interval of `$read$` */
+    int32_t len;       /* sequence length */
+    int32_t status;    /* 0, FMD_OVLP_SHORT or FMD_OVLP_CONTAINED */
+    int32_t n_ovlp;    /* candidate intervals from overlap_intv (unitig.c:47-58) */
+    int32_t rbeg;      /* fm6_get_nei's return value; -1 = no overlap */
+    int32_t ext_len;   /* bases fm6_get_nei appended to the sequence */
+    int32_t n_nei;     /* irreducible neighbours found */
+    uint32_t flags;    /* FMD_OVLP_F_* */
+    uint32_t reserved;
+} fmd_ovlp_rec_t;      /* 64 bytes */
+/* capacity of the per-strand candidate lists kept in the work area */
+static inline uint32_t fmd_ovlp_list_cap(uint32_t max_len, int min_match)
+{
+    uint32_t d = max_len > (uint32_t)min_match ? max_len - (uint32_t)min_match : 1;
+    return 2 * d < 16 ? 16 : 2 * d;
+}
+size_t fmd_ovlp_work_bytes(size_t n, uint32_t max_len, int min_match);
+/* d_nei: n x max_nei neighbours {x[0], x[1], x[2] of `$neighbour$`, info = overlap length};
+ * d_seq: n rows of seq_stride bytes = the sequence in read order followed by the ext_len appended
+ * bases (seq_stride >= 2*max_len is always enough). */
+int fmd_ovlp_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_ids, int min_match, uint32_t max_len,
+                 uint32_t max_nei, fmd_ovlp_rec_t *d_rec, fmd_intv_t *d_nei, uint8_t *d_seq, uint32_t seq_stride,
+                 void *d_work, size_t work_bytes);
+int fmd_ovlp_batch(fmd_dev_t *h, size_t n, const uint64_t *ids, int min_match, uint32_t max_len, uint32_t max_nei,
+                   fmd_ovlp_rec_t *rec, fmd_intv_t *nei, uint8_t *seq, uint32_t seq_stride);
+
 /* ---- index construction: the BWT `fermi build` computes (cmd.c:378-484, build.c:11-50) ------
  * reads: nt6 bases of all reads back to back, NO sentinels; read i = reads[off[i], off[i+1]).
  * The text indexed is  read $ revcomp(read) $  per read in input order, sentinels ordered by

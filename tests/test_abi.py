@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "fmd_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    hdr = re.sub(r"static inline[^{]*\{.*?\n\}", "", hdr, flags=re.S)  # header-only helpers are not exports
     return sorted(set(re.findall(r"\b(fmd_[a-z0-9_]+)\s*\(", hdr)))
 
 

@@ -176,3 +176,54 @@ def test_gpu_build_equals_fermi_build(gpu, gold, oracle_lib, tmp_path):
     gpu.lib().fmd_host_free(p)
     assert open(out, "rb").read() == open(gold.path("tiny.fmd"), "rb").read()
     d.close()
+
+
+def _check_overlap_records(gpu, gold, name, key, max_len):
+    recs = gold.json_gz(name + "_overlap.json.gz")[key]
+    mm = int(key[1:])
+    d = gpu.DevIndex.open(gold.path(name + ".fmd"))
+    ids = np.array([r["id"] for r in recs], dtype=U64)
+    rec, nei, seq = d.overlap(ids, mm, max_len=max_len, max_nei=8)
+    n_nei = n_fork = 0
+    for i, want in enumerate(recs):
+        g = rec[i]
+        assert not (g["flags"] & gpu.OVLP_F_OVERFLOW), want
+        assert g["rank"] == want["rank"] and g["len"] == want["len"], (i, g, want)
+        if want.get("status") == -1:
+            assert g["status"] == -1
+            continue
+        assert tuple(int(v) for v in g["k"]) == tuple(want["intv"]), (i, g, want)
+        assert (g["status"] == -3) == (want["contained"] < 0)
+        assert g["n_ovlp"] == want["n_ovlp"]
+        if want["contained"] < 0 or want["n_ovlp"] == 0:
+            assert g["n_nei"] == 0 and g["rbeg"] == -1
+            continue
+        assert g["rbeg"] == want["rbeg"], (i, g, want)
+        assert g["n_nei"] == len(want["nei"]), (i, g, want)
+        got_nei = [(int(e["x"][0]), int(e["x"][1]), int(e["x"][2]), int(e["info"])) for e in nei[i, :g["n_nei"]]]
+        assert got_nei == [tuple(x) for x in want["nei"]], (i, got_nei, want)
+        ext = bytes(seq[i, g["len"]:g["len"] + g["ext_len"]])
+        assert ext.hex() == want["ext"], (i, ext.hex(), want)
+        n_nei += g["n_nei"]; n_fork += int(bool(g["flags"] & gpu.OVLP_F_FORKED))
+    assert n_nei > 0
+    d.close()
+    return n_fork
+
+
+@pytest.mark.parametrize("name,key,max_len", [("tiny", "l50", 100), ("tiny", "l30", 100), ("special", "l20", 60)])
+def test_overlap_records_golden(gpu, gold, name, key, max_len):
+    """Per-read overlap records (fm_retrieve + fm6_is_contained + fm6_get_nei) vs the reference."""
+    _check_overlap_records(gpu, gold, name, key, max_len)
+
+
+def test_overlap_sequences_and_capacity_flags(gpu, gold):
+    d = gpu.DevIndex.open(gold.path("tiny.fmd"))
+    ids = np.arange(0, 400, dtype=U64)
+    rec, nei, seq = d.overlap(ids, 50, max_len=100)
+    want, ln, _ = d.retrieve(ids, stride=128)
+    for i in range(len(ids)):
+        assert np.array_equal(seq[i, :100], want[i, :100])
+    # a max_len smaller than the reads must raise the overflow flag, not corrupt anything
+    rec2, _, _ = d.overlap(ids[:64], 50, max_len=64)
+    assert ((rec2["flags"] & gpu.OVLP_F_OVERFLOW) != 0).all()
+    d.close()
