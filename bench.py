@@ -89,6 +89,133 @@ def rank_queries_per_read(reads_host, fmd_path, sample=20000):
     return (c["rank1a"] + c["rank2a"] + c["rank2a_spill"]) / n
 
 
+REF_OVLP_DT = np.dtype([("rank", "<u8"), ("k0", "<u8"), ("k1", "<u8"), ("len", "<i4"), ("status", "<i4"), ("n_ovlp", "<i4"),
+                        ("rbeg", "<i4"), ("ext_len", "<i4"), ("n_nei", "<i4"), ("nei", "<u8", (4, 3))])  # oracle/ref_driver.c
+
+
+def overlap_cpu_baseline(fmd_path, ids, min_match, g_rec, g_nei):
+    """fm_retrieve + fm6_is_contained + fm6_get_nei per sequence id on the host cores (the
+    reference itself when oracle/_ref travelled, else our C port), and the parity check."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    cores = os.cpu_count() or 1
+    n = len(ids)
+    ids = np.ascontiguousarray(ids, dtype=np.uint64)
+    drv = os.path.join(ROOT, "oracle", "_ref", "libref_driver.so")
+    if os.path.exists(drv):
+        L = C.CDLL(drv)
+        L.refdrv_load.restype = C.c_void_p; L.refdrv_load.argtypes = [C.c_char_p]
+        L.refdrv_free.argtypes = [C.c_void_p]
+        L.refdrv_overlap.restype = C.c_double
+        L.refdrv_overlap.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        e = L.refdrv_load(fmd_path.encode())
+        assert e
+        rec = np.zeros(n, dtype=REF_OVLP_DT)
+        n1 = min(n, 20_000)
+        t1 = L.refdrv_overlap(e, n1, ids.ctypes.data, min_match, rec.ctypes.data, 1)
+        tall = L.refdrv_overlap(e, n, ids.ctypes.data, min_match, rec.ctypes.data, cores)
+        L.refdrv_free(e)
+        kind = "reference"
+        ok = (np.array_equal(rec["rank"], g_rec["rank"]) and np.array_equal(rec["k0"], g_rec["k"][:, 0]) and
+              np.array_equal(rec["k1"], g_rec["k"][:, 1]) and np.array_equal(rec["len"], g_rec["len"]) and
+              np.array_equal(rec["status"], g_rec["status"]) and np.array_equal(rec["n_ovlp"], g_rec["n_ovlp"]) and
+              np.array_equal(rec["rbeg"], g_rec["rbeg"]) and np.array_equal(rec["ext_len"], g_rec["ext_len"]) and
+              np.array_equal(rec["n_nei"], g_rec["n_nei"]))
+        for j in range(min(4, g_nei.shape[1])):
+            m = rec["n_nei"] > j
+            ok = ok and np.array_equal(rec["nei"][m, j, 0], g_nei["x"][m, j, 0]) and np.array_equal(rec["nei"][m, j, 1], g_nei["x"][m, j, 1]) \
+                and np.array_equal(rec["nei"][m, j, 2], g_nei["info"][m, j])
+    else:
+        import orcbind
+        o = orcbind.OrcIndex(fmd_path)
+        n1 = min(n, 20_000)
+        t0 = time.time(); o.overlap_batch(ids[:n1], min_match, 100, g_nei.shape[1], 1); t1 = time.time() - t0
+        t0 = time.time(); rec, nei, _ = o.overlap_batch(ids, min_match, 100, g_nei.shape[1], cores); tall = time.time() - t0
+        o.close()
+        kind = "port"
+        ok = rec.tobytes() == g_rec.tobytes() and nei.tobytes() == g_nei.tobytes()
+    return {"value": n / 2.0 / tall, "unit": "reads/s", "cores": cores, "kind": kind,
+            "sample": "sequence ids 0..%d (both strands of %d reads), all %d host threads (1 thread: %.0f reads/s)"
+                      % (n - 1, n // 2, cores, n1 / 2.0 / t1)}, bool(ok)
+
+
+def overlap_rank_queries_per_strand(fmd_path, min_match, sample=4000):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orcbind
+    o = orcbind.OrcIndex(fmd_path)
+    o.counters()
+    o.overlap_batch(np.arange(sample, dtype=np.uint64), min_match, 100, 4, 1)
+    c = o.counters()
+    o.close()
+    return c, (c["rank1a"] + c["rank2a"] + c["rank2a_spill"]) / sample
+
+
+def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world, rank, fmd_path):
+    """Overlap discovery for ALL 2N sequence ids: one step = retrieve +
+    is_contained + get_nei for every strand, in HBM-bounded batches."""
+    min_match = int(os.environ.get("FMD_BENCH_MINMATCH", "50"))
+    n_ids = 2 * n_reads
+    batch = min(n_ids, int(os.environ.get("FMD_BENCH_OVLP_BATCH", "4000000")))
+    max_nei, stride = 4, 2 * L
+    ids = torch.arange(n_ids, dtype=torch.int64, device=dev)
+    rec = torch.zeros(n_ids * 64, dtype=torch.uint8, device=dev)
+    nei = torch.zeros(n_ids * max_nei * 32, dtype=torch.uint8, device=dev)
+    seq = torch.zeros(n_ids * stride, dtype=torch.uint8, device=dev)
+    wb = api.lib().fmd_ovlp_work_bytes(batch, L, min_match)
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream()
+    sh = C.c_void_p(stream.cuda_stream)
+
+    def step():
+        for o in range(0, n_ids, batch):
+            c = min(batch, n_ids - o)
+            api.check(api.lib().fmd_ovlp_dev(index.h, sh, c, ids.data_ptr() + o * 8, min_match, L, max_nei,
+                                             rec.data_ptr() + o * 64, nei.data_ptr() + o * max_nei * 32,
+                                             seq.data_ptr() + o * stride, stride, work.data_ptr(), wb))
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    w0 = time.perf_counter()
+    for a, b in evs:
+        a.record(stream); step(); b.record(stream)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - w0
+    if dist:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    if rank != 0:
+        return None
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    g_rec = rec.cpu().numpy().view(api.OVLP_DT)
+    out = {"metric": "reads/sec through unitig overlap discovery (retrieve + is_contained + get_nei, both strands)",
+           "value": n_reads * world * steps / wall, "unit": "reads/s", "strands_per_s": n_ids * world * steps / wall,
+           "ms_per_step": wall / steps * 1e3, "min_match": min_match, "batch_strands": batch,
+           "overflow_records": int(((g_rec["flags"] & api.OVLP_F_OVERFLOW) != 0).sum()),
+           "contained": int((g_rec["status"] == -3).sum()), "with_neighbour": int((g_rec["n_nei"] > 0).sum())}
+    if world == 1:
+        cnts, qps = overlap_rank_queries_per_strand(fmd_path, min_match)
+        alg = qps * BYTES_PER_RANK_QUERY * n_ids
+        ach = alg / (kern_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": None, "kernel": "k_ovl_retrieve + k_ovl_intv + k_ovl_nei (one step = %d batches)" % ((n_ids + batch - 1) // batch),
+                           "kernel_ms": kern_ms, "rank_queries_per_strand": qps, "algorithmic_bytes_per_read": 2 * qps * BYTES_PER_RANK_QUERY,
+                           "oracle_counters_on_sample": cnts}
+        ns = min(n_ids, int(os.environ.get("FMD_BENCH_CPU_SAMPLE_OVLP", "400000")))
+        g_nei = nei.cpu().numpy().view(api.INTV_DT).reshape(n_ids, max_nei)
+        base, ok = overlap_cpu_baseline(fmd_path, np.arange(ns, dtype=np.uint64), min_match, g_rec[:ns], g_nei[:ns])
+        out["cpu_baseline"] = base
+        out["parity_vs_cpu_on_sample"] = "bit-exact" if ok else "MISMATCH"
+        out["speedup_vs_cpu_all_cores"] = out["value"] / base["value"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,6 +312,10 @@ def main():
         wall = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
+    ovl = None
+    if os.environ.get("FMD_BENCH_OVERLAP", "1") != "0":
+        ovl = bench_overlap(torch, api, index, dev, n_reads, L, max(1, min(args.steps, 2)), min(args.warmup, 1), dist, world, rank, fmd_path)
+
     if rank == 0:
         g_cnt = cnt.cpu().numpy().view(np.uint64); g_beg = beg.cpu().numpy().view(np.uint64); g_end = end.cpu().numpy().view(np.uint64)
         total_reads = n_reads * world * args.steps
@@ -218,6 +349,8 @@ def main():
             out["cpu_baseline"] = base
             out["parity_vs_cpu_on_sample"] = "bit-exact" if parity else "MISMATCH"
             out["speedup_vs_cpu_all_cores"] = value / base["value"]
+        if ovl:
+            out["overlap_discovery"] = ovl
         print(json.dumps(out), flush=True)
         if fmd_path and os.path.exists(fmd_path):
             os.remove(fmd_path)

@@ -45,3 +45,67 @@ void orc_retrieve_batch(const orc_rld_t *e, size_t n, const uint64_t *x, uint8_t
         orc_reverse(l < stride ? l : stride, s);
     }
 }
+
+/* Per-id overlap records, same layout as fmd_ovlp_rec_t / fmd_intv_t of include/fmd_hip.h
+ * (restated here so that the oracle does not include product headers). */
+typedef struct {
+    uint64_t rank, k[3];
+    int32_t len, status, n_ovlp, rbeg, ext_len, n_nei;
+    uint32_t flags, reserved;
+} orc_ovlp_rec_t;
+
+typedef struct { const orc_rld_t *e; size_t n; const uint64_t *ids; int min_match; uint32_t max_nei;
+                 orc_ovlp_rec_t *rec; orc_intv_t *nei; uint8_t *seq; uint32_t seq_stride; int start, step; } ovj_t;
+
+static void *ov_worker(void *d)
+{
+    ovj_t *w = (ovj_t *)d;
+    orc_intv_v a0 = {0, 0, 0}, a1 = {0, 0, 0}, nei = {0, 0, 0};
+    orc_str_t s = {0, 0, 0};
+    size_t i, j;
+    s.m = 65536; s.s = (uint8_t *)malloc(s.m);
+    for (i = (size_t)w->start; i < w->n; i += (size_t)w->step) {
+        orc_ovlp_rec_t *r = &w->rec[i];
+        orc_intv_t intv;
+        int len = 0, ret;
+        memset(r, 0, sizeof(*r));
+        r->rbeg = -1;
+        r->rank = (uint64_t)orc_retrieve(w->e, w->ids[i], s.s, (int)s.m - 1, &len);
+        orc_reverse(len, s.s);
+        s.n = (size_t)len; s.s[len] = 0;
+        r->len = len;
+        if (w->seq) memcpy(w->seq + i * (size_t)w->seq_stride, s.s, (size_t)len < w->seq_stride ? (size_t)len : w->seq_stride);
+        if (len <= w->min_match) { r->status = -1; continue; }
+        a0.n = a1.n = nei.n = 0;
+        ret = orc_is_contained(w->e, w->min_match, s.s, len, &intv, &a0);
+        r->k[0] = intv.x[0]; r->k[1] = intv.x[1]; r->k[2] = intv.x[2];
+        r->n_ovlp = (int32_t)a0.n;
+        if (ret < 0) { r->status = -3; continue; }
+        if (a0.n) {
+            r->rbeg = orc_get_nei(w->e, w->min_match, 0, &s, &nei, &a0, &a1);
+            r->ext_len = (int32_t)s.n - len;
+            r->n_nei = (int32_t)nei.n;
+            for (j = 0; j < nei.n && j < w->max_nei; ++j) w->nei[i * w->max_nei + j] = nei.a[j];
+            if (w->seq)
+                for (j = (size_t)len; j < s.n && j < w->seq_stride; ++j) w->seq[i * (size_t)w->seq_stride + j] = s.s[j];
+        }
+    }
+    free(a0.a); free(a1.a); free(nei.a); free(s.s);
+    orc_counters_flush();
+    return 0;
+}
+
+void orc_overlap_batch(const orc_rld_t *e, size_t n, const uint64_t *ids, int min_match, uint32_t max_nei,
+                       void *rec, orc_intv_t *nei, uint8_t *seq, uint32_t seq_stride, int n_threads)
+{
+    pthread_t *tid = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    ovj_t *w = (ovj_t *)calloc((size_t)n_threads, sizeof(ovj_t));
+    int t;
+    for (t = 0; t < n_threads; ++t) {
+        ovj_t x = {e, n, ids, min_match, max_nei, (orc_ovlp_rec_t *)rec, nei, seq, seq_stride, t, n_threads};
+        w[t] = x;
+        pthread_create(&tid[t], 0, ov_worker, &w[t]);
+    }
+    for (t = 0; t < n_threads; ++t) pthread_join(tid[t], 0);
+    free(tid); free(w);
+}

@@ -208,6 +208,37 @@ def main():
                         rank1a_k=ks, rank1a_ok=ok, rank1a_sym=sym)
     R.close()
 
+    # ---- fixture 4: repeat -- a genome with near-identical repeats and ragged reads: forks
+    # (several irreducible neighbours), contained reads and the fake-fork fix-up (unitig.c:158-176)
+    rng = np.random.default_rng(123)
+    unit = rng.integers(1, 5, 400)
+
+    def mut(u, k):
+        u = u.copy(); idx = rng.choice(len(u), k, replace=False); u[idx] = 1 + (u[idx] + rng.integers(0, 3, k)) % 4
+        return u
+    g = np.concatenate([rng.integers(1, 5, 500), unit, rng.integers(1, 5, 300), mut(unit, 3), rng.integers(1, 5, 400),
+                        mut(unit, 1), rng.integers(1, 5, 500), unit[:200], rng.integers(1, 5, 300)])
+    rp = []
+    for i in range(1500):
+        L = int(rng.integers(40, 81)); p0 = int(rng.integers(0, len(g) - L)); r = g[p0:p0 + L]
+        if rng.integers(0, 2):
+            r = (5 - r)[::-1]
+        rp.append(r.astype(np.uint8))
+    fq4 = os.path.join(TMP, "repeat.fq")
+    write_fq(ascii_reads(rp), fq4)
+    with gzip.open(os.path.join(HERE, "repeat.fq.gz"), "wb", 9) as f:
+        f.write(open(fq4, "rb").read())
+    run([FERMI, "build", "-fo", os.path.join(HERE, "repeat.fmd"), fq4])
+    R = refbind.RefIndex(os.path.join(HERE, "repeat.fmd"))
+    ov = {"l20": overlap_table(R, int(R.mcnt[1]), 20, range(int(R.mcnt[1]))),
+          "l35": overlap_table(R, int(R.mcnt[1]), 35, range(0, int(R.mcnt[1]), 3))}
+    with gzip.open(os.path.join(HERE, "repeat_overlap.json.gz"), "wt") as f:
+        json.dump(ov, f)
+    R.close()
+    run([FERMI, "unitig", "-l20", "-t1", os.path.join(HERE, "repeat.fmd")], os.path.join(TMP, "repeat.mag"))
+    with gzip.open(os.path.join(HERE, "repeat.mag.gz"), "wb", 9) as f:
+        f.write(open(os.path.join(TMP, "repeat.mag"), "rb").read())
+
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith((".fmd", ".gz", ".npz")):
             man["files"][fn] = {"md5": md5(os.path.join(HERE, fn)), "bytes": os.path.getsize(os.path.join(HERE, fn))}

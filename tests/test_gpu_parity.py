@@ -210,7 +210,8 @@ def _check_overlap_records(gpu, gold, name, key, max_len):
     return n_fork
 
 
-@pytest.mark.parametrize("name,key,max_len", [("tiny", "l50", 100), ("tiny", "l30", 100), ("special", "l20", 60)])
+@pytest.mark.parametrize("name,key,max_len", [("tiny", "l50", 100), ("tiny", "l30", 100), ("special", "l20", 60),
+                                              ("repeat", "l20", 80), ("repeat", "l35", 80)])
 def test_overlap_records_golden(gpu, gold, name, key, max_len):
     """Per-read overlap records (fm_retrieve + fm6_is_contained + fm6_get_nei) vs the reference."""
     _check_overlap_records(gpu, gold, name, key, max_len)

@@ -134,7 +134,7 @@ def test_exact_cli_text(tiny_oracle, gold):
         assert b"\n".join(out) + b"\n" == want[i], i
 
 
-@pytest.mark.parametrize("name,key", [("tiny", "l50"), ("tiny", "l30"), ("special", "l20")])
+@pytest.mark.parametrize("name,key", [("tiny", "l50"), ("tiny", "l30"), ("special", "l20"), ("repeat", "l20"), ("repeat", "l35")])
 def test_overlap_records_golden(oracle_lib, gold, name, key):
     """Per-read overlap records = fm_retrieve + fm6_is_contained + fm6_get_nei (unitig.c:77,93)."""
     recs = gold.json_gz(name + "_overlap.json.gz")[key]
