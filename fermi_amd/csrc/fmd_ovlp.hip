@@ -164,9 +164,28 @@ __global__ __launch_bounds__(64) void k_ovl_intv(FmdIndexView ix, size_t n, int 
 }
 
 // --------------------------------------------------------------------- phase B: fm6_get_nei
+// unitig.c:93-179.  Latency is the enemy here (three dependent rank2a per candidate interval), so
+// nothing but the rank fetch is allowed on a wave step's critical path:
+//   * the next candidate interval is prefetched into registers while the current one is extended
+//     (its load completes under the same s_waitcnt as the rank-block gather);
+//   * the first child pushed in a round and the first neighbour stay in registers;
+//   * categories (unitig.c:143-151) are assigned while pushing, because children are pushed in
+//     sorted order unless a category forks; the stored entry keeps the original sort key in the
+//     spare top 16 bits of its size word, and only a round that saw an out-of-order push takes
+//     the slow path (sort + recompute), exactly as ks_introsort + the recompute loop would.
 enum { ST_IDLE = 0, ST_PICK, ST_EXT, ST_E0, ST_C, ST_FIX1, ST_FIX2 };
 
 struct I3 { uint64_t x0, x1, sz; };
+// field-wise select (keeps the candidates in registers; a struct ternary chain goes through scratch)
+__device__ __forceinline__ I3 pick5(int c, const I3 &a0, const I3 &a1, const I3 &a2, const I3 &a3, const I3 &a4)
+{
+    I3 r;
+    r.x0 = sel6(c, a0.x0, a1.x0, a2.x0, a3.x0, a4.x0, a0.x0);
+    r.x1 = sel6(c, a0.x1, a1.x1, a2.x1, a3.x1, a4.x1, a0.x1);
+    r.sz = sel6(c, a0.sz, a1.sz, a2.sz, a3.sz, a4.sz, a0.sz);
+    return r;
+}
+#define FMD_SZ_MASK 0xffffffffffffull
 
 __device__ __forceinline__ void load_entry(const fmd_intv_t *e, uint64_t &x0, uint64_t &x1, uint64_t &sz, uint64_t &info)
 {
@@ -191,14 +210,16 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
     FMD_DECLARE_WAVE_LDS();
     // per-lane search state
     size_t sid = 0;
-    int st = ST_IDLE, ori_l = 0, cur_l = 0, cpend = 0, first_c = 0, masked_cat = -2, cat_j = 0, fix_i = 0, rbeg = -1;
-    uint32_t prev_n = 0, curr_n = 0, j = 0, n_nei = 0, flags = 0;
-    bool unsorted = false, exhausted = false, prev_is_a = true;
+    int st = ST_IDLE, ori_l = 0, cur_l = 0, cpend = 0, first_c = 0, masked_cat = -2, cat_j = 0, fix_i = 0;
+    uint32_t prev_n = 0, curr_n = 0, j = 0, n_nei = 0, flags = 0, cat0 = 0, last_hi = 0;
+    bool unsorted = false, exhausted = false, prev_is_a = true, e_valid = false;
     fmd_intv_t *prev = nullptr, *curr = nullptr;
     uint64_t last_key = 0;
+    uint64_t ex0 = 0, ex1 = 0, esz = 0, einfo = 0;   // prefetched prev[j]
+    uint64_t fx0 = 0, fx1 = 0, fsz = 0, finfo = 0;   // first child pushed this round (= next round's prev[0])
     uint64_t px0 = 0, px1 = 0, psz = 0, pinfo = 0;   // interval being extended
     I3 o0 = {0, 0, 0}, oc1 = {0, 0, 0}, oc2 = {0, 0, 0}, oc3 = {0, 0, 0}, oc4 = {0, 0, 0}; // its children
-    uint64_t nx0 = 0, nsz = 0;                        // first neighbour (fork fix-up)
+    uint64_t nx0 = 0, nsz = 0, ninfo = 0;             // first neighbour
 
     for (;;) {
         // ---- refill
@@ -211,7 +232,8 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
                     prev_n = (uint32_t)o->n_ovlp; curr_n = 0; j = 0;
                     prev = listA + sid * (size_t)cap + (cap - prev_n);
                     curr = listB + sid * (size_t)cap; prev_is_a = true;
-                    n_nei = 0; flags = 0; masked_cat = -2; unsorted = false; last_key = 0; rbeg = -1;
+                    n_nei = 0; flags = 0; masked_cat = -2; unsorted = false; last_key = 0; cat0 = 0;
+                    e_valid = false;
                     st = ST_PICK;
                 }
             } else exhausted = true;
@@ -219,57 +241,58 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
         // ---- bookkeeping that needs no rank: pick the next interval / finish a round / finish
         while (st == ST_PICK) {
             if (j < prev_n) {
-                load_entry(prev + j, px0, px1, psz, pinfo);
-                cat_j = (int)(pinfo >> 36);
-                if (cat_j == masked_cat) { ++j; continue; }
+                if (!e_valid) { load_entry(prev + j, ex0, ex1, esz, einfo); esz &= FMD_SZ_MASK; }
+                cat_j = (int)(einfo >> 36);
+                if (cat_j == masked_cat) { ++j; e_valid = false; continue; }
+                px0 = ex0; px1 = ex1; psz = esz; pinfo = einfo;
                 st = ST_EXT;
+                e_valid = j + 1 < prev_n;
+                if (e_valid) { load_entry(prev + j + 1, ex0, ex1, esz, einfo); esz &= FMD_SZ_MASK; } // lands under the rank fetch
             } else if (curr_n) { // end of a round (unitig.c:137-153)
                 if ((uint32_t)cur_l < seq_stride) seq_out[sid * (size_t)seq_stride + cur_l] = (uint8_t)comp6(first_c);
                 ++cur_l;
-                if (unsorted) { // ks_introsort by info; keys are unique so any sort gives the same order
+                if (unsorted) { // slow path: ks_introsort by the original keys, then recompute the categories
                     for (uint32_t a = 1; a < curr_n; ++a) {
                         uint64_t ax0, ax1, asz, ainf;
                         load_entry(curr + a, ax0, ax1, asz, ainf);
+                        const uint64_t akey = (asz >> 48) << 32 | (ainf & 0xffffffffull);
                         uint32_t b = a;
                         while (b > 0) {
                             uint64_t bx0, bx1, bsz, binf;
                             load_entry(curr + b - 1, bx0, bx1, bsz, binf);
-                            if (binf <= ainf) break;
+                            if (((bsz >> 48) << 32 | (binf & 0xffffffffull)) <= akey) break;
                             store_entry(curr + b, bx0, bx1, bsz, binf);
                             --b;
                         }
                         store_entry(curr + b, ax0, ax1, asz, ainf);
                     }
-                }
-                uint32_t last = 0, cat0 = 0; // recompute the categories (unitig.c:143-151)
-                for (uint32_t a = 0; a < curr_n; ++a) {
-                    uint64_t *pinf = &curr[a].info;
-                    const uint64_t inf = *pinf;
-                    const uint32_t hi = (uint32_t)(inf >> 32);
-                    if (a == 0) last = hi;
-                    else if (hi != last) { last = hi; cat0 = a; }
-                    *pinf = (inf & 0xffffffffull) | (uint64_t)cat0 << 36;
+                    uint32_t last = 0; cat0 = 0;
+                    for (uint32_t a = 0; a < curr_n; ++a) {
+                        uint64_t ax0, ax1, asz, ainf;
+                        load_entry(curr + a, ax0, ax1, asz, ainf);
+                        const uint32_t hi = (uint32_t)(asz >> 48);
+                        if (a == 0) last = hi; else if (hi != last) { last = hi; cat0 = a; }
+                        ainf = (ainf & 0xffffffffull) | (uint64_t)cat0 << 36;
+                        curr[a].info = ainf;
+                        if (a == 0) { fx0 = ax0; fx1 = ax1; fsz = asz & FMD_SZ_MASK; finfo = ainf; }
+                    }
                 }
                 if (cat0 != 0) flags |= FMD_OVLP_F_FORKED;
                 prev_is_a = !prev_is_a; // both lists start at index 0 of their areas from now on
                 prev = (prev_is_a ? listA : listB) + sid * (size_t)cap;
                 curr = (prev_is_a ? listB : listA) + sid * (size_t)cap;
-                prev_n = curr_n; curr_n = 0; j = 0; masked_cat = -2; unsorted = false; last_key = 0;
+                prev_n = curr_n; curr_n = 0; j = 0; masked_cat = -2; unsorted = false; last_key = 0; cat0 = 0;
+                ex0 = fx0; ex1 = fx1; esz = fsz; einfo = finfo; e_valid = true;
             } else { // all paths closed (unitig.c:154-178)
                 fmd_ovlp_rec_t *o = rec + sid;
-                bool need_fix = false;
-                if (n_nei) {
-                    uint64_t a, b, c, inf;
-                    load_entry(nei_out + sid * (size_t)max_nei, a, b, c, inf);
-                    rbeg = ori_l - (int)(uint32_t)inf;
-                    if (n_nei == 1 && (flags & FMD_OVLP_F_FORKED) && !(flags & FMD_OVLP_F_FIXED) && rbeg < ori_l) {
-                        nx0 = a; nsz = c;   // contained reads made a fake fork: re-derive the appended bases
-                        o0.x0 = 0; o0.x1 = 0; o0.sz = ix.cnt[1]; // fm6_set_intv(e, 0, ok0)
-                        fix_i = rbeg;
-                        need_fix = true;
-                    }
+                const int rbeg = ori_l - (int)(uint32_t)ninfo;
+                if (n_nei == 1 && (flags & FMD_OVLP_F_FORKED) && !(flags & FMD_OVLP_F_FIXED) && rbeg < ori_l) {
+                    // contained reads made a fake fork: re-derive the appended bases (unitig.c:158-176)
+                    o0.x0 = 0; o0.x1 = 0; o0.sz = ix.cnt[1]; // fm6_set_intv(e, 0, ok0)
+                    fix_i = rbeg;
+                    st = ST_FIX1;
+                    break;
                 }
-                if (need_fix) { st = ST_FIX1; break; }
                 if (n_nei > 1) cur_l = ori_l;
                 o->rbeg = n_nei ? rbeg : -1;
                 o->ext_len = cur_l - ori_l; o->n_nei = (int32_t)n_nei; o->flags |= flags;
@@ -315,7 +338,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
             } else if (st == ST_FIX1) { // unitig.c:160-163
                 const int b = srev[sid * (size_t)stride_r + (ori_l - 1 - fix_i)];
                 const int c = comp6(b);
-                o0 = c == 1 ? k1 : c == 2 ? k2 : c == 3 ? k3 : c == 4 ? k4 : k0;
+                o0 = pick5(c, k0, k1, k2, k3, k4);
                 if (c == 5) { o0.x0 = k1.x0 + s[1]; o0.x1 = ix.cnt[5] + tk[5]; o0.sz = s[5]; }
                 ++fix_i;
                 if (fix_i == ori_l) { st = ori_l < cur_l ? ST_FIX2 : ST_PICK; flags |= FMD_OVLP_F_FIXED; }
@@ -327,7 +350,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
                 bool stop = (cnt_ok == 0 && k0.sz != 0);
                 if (!stop && c0 > 0) {
                     if ((uint32_t)fix_i < seq_stride) seq_out[sid * (size_t)seq_stride + fix_i] = (uint8_t)comp6(c0);
-                    o0 = c0 == 1 ? k1 : c0 == 2 ? k2 : c0 == 3 ? k3 : k4;
+                    o0 = pick5(c0, k0, k1, k2, k3, k4);
                     ++fix_i;
                     if (fix_i == cur_l) stop = true;
                 } else stop = true;
@@ -341,8 +364,9 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
             if (st == ST_E0) {
                 bool is_nei = false;
                 if (e0sz && o0.sz == psz && psz == e0sz) { // bounded by sentinels on both sides and not contained
-                    if (n_nei < max_nei)
-                        store_entry(nei_out + sid * (size_t)max_nei + n_nei, t0k, o0.x1, e0sz, (uint64_t)ori_l - (pinfo & 0xffffffffull));
+                    const uint64_t inf = (uint64_t)ori_l - (pinfo & 0xffffffffull);
+                    if (n_nei == 0) { nx0 = t0k; nsz = e0sz; ninfo = inf; }
+                    if (n_nei < max_nei) store_entry(nei_out + sid * (size_t)max_nei + n_nei, t0k, o0.x1, e0sz, inf);
                     else flags |= FMD_OVLP_F_OVERFLOW;
                     ++n_nei;
                     masked_cat = cat_j; // mask out the other intervals of this category
@@ -355,13 +379,19 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
                 }
             } else {
                 if (e0sz) { // left end bounded by a sentinel: keep the child (unitig.c:128-135)
-                    const I3 ch = cpend == 1 ? oc1 : cpend == 2 ? oc2 : cpend == 3 ? oc3 : oc4;
+                    const I3 ch = pick5(cpend, oc1, oc1, oc2, oc3, oc4);
                     const uint64_t key = (pinfo & 0xfffffff0ffffffffull) | (uint64_t)cpend << 32;
+                    const uint32_t hi = (uint32_t)(key >> 32);  // old category << 4 | base
                     if (curr_n < cap) {
-                        store_entry(curr + curr_n, ch.x0, ch.x1, ch.sz, key);
-                        if (curr_n == 0) first_c = cpend;
-                        else if (key < last_key) unsorted = true;
+                        if (curr_n == 0) { first_c = cpend; cat0 = 0; last_hi = hi; }
+                        else {
+                            if (key < last_key) unsorted = true;
+                            if (hi != last_hi) { cat0 = curr_n; last_hi = hi; }
+                        }
                         last_key = key;
+                        const uint64_t inf = (key & 0xffffffffull) | (uint64_t)cat0 << 36;
+                        store_entry(curr + curr_n, ch.x0, ch.x1, ch.sz | (uint64_t)hi << 48, inf);
+                        if (curr_n == 0) { fx0 = ch.x0; fx1 = ch.x1; fsz = ch.sz; finfo = inf; }
                         ++curr_n;
                     } else { flags |= FMD_OVLP_F_OVERFLOW; }
                 }
@@ -396,6 +426,7 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
     if (!h || (n && (!d_ids || !d_rec || !d_nei || !d_seq || !d_work)) || max_len == 0 || max_nei == 0 || min_match < 0) return FMD_E_ARG;
     if (n == 0) return FMD_OK;
     if (n >= 0xffffff00ull || work_bytes < fmd_ovlp_work_bytes(n, max_len, min_match)) return FMD_E_ARG;
+    if (fmd_ovlp_list_cap(max_len, min_match) >= 4096) return FMD_E_ARG; // category index is packed in 12 bits
     FMD_HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream_;
     const uint32_t stride_r = (uint32_t)align_up(max_len, 4);
