@@ -3,7 +3,7 @@
 #   make ref        -> oracle/_ref/ (only where /root/reference exists)
 HIPCC    ?= hipcc
 ARCH     ?= gfx950
-HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value
+HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value $(EXTRA)
 CC        = gcc
 CFLAGS    = -O2 -g -Wall -fPIC -std=gnu11
 
@@ -32,6 +32,12 @@ oracle:
 	$(MAKE) -s -C oracle oracle
 ref:
 	$(MAKE) -s -C oracle ref
+
+# A/B variant of the HIP library: make variant NAME=nt EXTRA=-DFMD_GLDS_AUX=2  -> fermi_amd/lib/libfmdhip_nt.so
+variant:
+	@mkdir -p build/$(NAME)
+	for f in $(HIP_SRCS); do $(HIPCC) $(HIPFLAGS) -c $$f -o build/$(NAME)/$$(basename $$f .hip).o || exit 1; done
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC build/$(NAME)/*.o -o fermi_amd/lib/libfmdhip_$(NAME).so
 
 clean:
 	rm -rf build fermi_amd/lib/*.so

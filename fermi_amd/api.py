@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfmdhip.so")
+LIB_PATH = os.environ.get("FMD_HIP_LIB") or os.path.join(_HERE, "lib", "libfmdhip.so")  # FMD_HIP_LIB: A/B builds
 INTV_DT = np.dtype([("x", "<u8", 3), ("info", "<u8")])  # fmd_intv_t == fmintv_t (fermi.h:13-16)
 NONE64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 OVLP_DT = np.dtype([("rank", "<u8"), ("k", "<u8", 3), ("len", "<i4"), ("status", "<i4"), ("n_ovlp", "<i4"),

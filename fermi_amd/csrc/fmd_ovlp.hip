@@ -100,7 +100,21 @@ __global__ __launch_bounds__(64) void k_ovl_intv(FmdIndexView ix, size_t n, int 
                     cache = *(const uint32_t *)s;
                     const int c = cache & 0xff;
                     x0 = ix.cnt[c]; x1 = ix.cnt[comp6(c)]; sz = ix.cnt[c + 1] - ix.cnt[c];
-                    if ((uint32_t)(L - 1) < seq_stride) seq_out[sid * (size_t)seq_stride + L - 1] = (uint8_t)c;
+                    {   // sequence in read order for the caller: one burst of dword stores (the row is
+                        // srev byte-reversed), so the line is written once instead of L partial writes
+                        uint8_t *dst = seq_out + sid * (size_t)seq_stride;
+                        const int nw = (L + 3) >> 2;
+                        for (int w = 0; w < nw; ++w) {
+                            // read-order bytes 4w..4w+3 = srev[L-1-4w], srev[L-2-4w], ...
+                            uint32_t v = 0;
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                const int i = 4 * w + b;
+                                if (i < L) v |= (uint32_t)s[L - 1 - i] << (8 * b);
+                            }
+                            if ((uint32_t)(4 * w + 3) < seq_stride) *(uint32_t *)(dst + 4 * w) = v;
+                        }
+                    }
                     jr = 1; depth = 1; npush = 0; ret = 0; phase = L > 1 ? 0 : 1; live = true;
                 }
             } else exhausted = true;
@@ -122,7 +136,6 @@ __global__ __launch_bounds__(64) void k_ovl_intv(FmdIndexView ix, size_t n, int 
                 const int c = (cache >> (8 * (jr & 3))) & 0xff;
                 const uint64_t sc = sel6(c, s[0], s[1], s[2], s[3], s[4], s[5]);
                 const int j = L - 1 - jr; // position of this base in read order
-                if ((uint32_t)j < seq_stride) seq_out[sid * (size_t)seq_stride + j] = (uint8_t)c;
                 if (sc == 0) phase = 1; // cannot be extended (unitig.c:50)
                 else {
                     if (depth >= min_match && s[0]) { // a read starts here: keep the current interval
@@ -215,7 +228,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
     bool unsorted = false, exhausted = false, prev_is_a = true, e_valid = false;
     fmd_intv_t *prev = nullptr, *curr = nullptr;
     uint64_t last_key = 0;
-    uint64_t ex0 = 0, ex1 = 0, esz = 0, einfo = 0;   // prefetched prev[j]
+    uint4 ea = make_uint4(0, 0, 0, 0), eb = make_uint4(0, 0, 0, 0); // prefetched prev[j], raw (decoded at pick time)
     uint64_t fx0 = 0, fx1 = 0, fsz = 0, finfo = 0;   // first child pushed this round (= next round's prev[0])
     uint64_t px0 = 0, px1 = 0, psz = 0, pinfo = 0;   // interval being extended
     I3 o0 = {0, 0, 0}, oc1 = {0, 0, 0}, oc2 = {0, 0, 0}, oc3 = {0, 0, 0}, oc4 = {0, 0, 0}; // its children
@@ -241,13 +254,14 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
         // ---- bookkeeping that needs no rank: pick the next interval / finish a round / finish
         while (st == ST_PICK) {
             if (j < prev_n) {
-                if (!e_valid) { load_entry(prev + j, ex0, ex1, esz, einfo); esz &= FMD_SZ_MASK; }
-                cat_j = (int)(einfo >> 36);
+                if (!e_valid) { const uint4 *q = (const uint4 *)(prev + j); ea = q[0]; eb = q[1]; }
+                cat_j = (int)(eb.w >> 4);                    // info >> 36
                 if (cat_j == masked_cat) { ++j; e_valid = false; continue; }
-                px0 = ex0; px1 = ex1; psz = esz; pinfo = einfo;
+                px0 = (uint64_t)ea.y << 32 | ea.x; px1 = (uint64_t)ea.w << 32 | ea.z;
+                psz = ((uint64_t)eb.y << 32 | eb.x) & FMD_SZ_MASK; pinfo = (uint64_t)eb.w << 32 | eb.z;
                 st = ST_EXT;
                 e_valid = j + 1 < prev_n;
-                if (e_valid) { load_entry(prev + j + 1, ex0, ex1, esz, einfo); esz &= FMD_SZ_MASK; } // lands under the rank fetch
+                if (e_valid) { const uint4 *q = (const uint4 *)(prev + j + 1); ea = q[0]; eb = q[1]; } // lands under the rank fetch
             } else if (curr_n) { // end of a round (unitig.c:137-153)
                 if ((uint32_t)cur_l < seq_stride) seq_out[sid * (size_t)seq_stride + cur_l] = (uint8_t)comp6(first_c);
                 ++cur_l;
@@ -282,7 +296,8 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
                 prev = (prev_is_a ? listA : listB) + sid * (size_t)cap;
                 curr = (prev_is_a ? listB : listA) + sid * (size_t)cap;
                 prev_n = curr_n; curr_n = 0; j = 0; masked_cat = -2; unsorted = false; last_key = 0; cat0 = 0;
-                ex0 = fx0; ex1 = fx1; esz = fsz; einfo = finfo; e_valid = true;
+                ea = make_uint4((uint32_t)fx0, (uint32_t)(fx0 >> 32), (uint32_t)fx1, (uint32_t)(fx1 >> 32));
+                eb = make_uint4((uint32_t)fsz, (uint32_t)(fsz >> 32), (uint32_t)finfo, (uint32_t)(finfo >> 32)); e_valid = true;
             } else { // all paths closed (unitig.c:154-178)
                 fmd_ovlp_rec_t *o = rec + sid;
                 const int rbeg = ori_l - (int)(uint32_t)ninfo;

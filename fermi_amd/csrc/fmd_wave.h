@@ -28,6 +28,11 @@
 #define FMD_BLK_U4 8            // uint4 per block
 #define FMD_WAVE_LDS_U4 1024    // 2 slots x 64 lanes x 8 uint4 = 16 KiB per wave
 
+// cache policy of the rank-block gather (global_load_lds aux bits: 0 = default, 2 = nt "stream")
+#ifndef FMD_GLDS_AUX
+#define FMD_GLDS_AUX 0
+#endif
+
 typedef __attribute__((address_space(3))) void fmd_lds_void;
 typedef const __attribute__((address_space(1))) void fmd_glb_void;
 
@@ -57,7 +62,7 @@ __device__ __forceinline__ void fmd_fetch_round(const FmdIndexView &ix, uint4 *l
         if ((need_mask >> ((lane & ~7) | R)) & 1) {
             const int t = (R & 3) | (((g >> 1) & 1) << 2);  // = fmd_chunk_xor(8g+R)
             const uint4 *src = ix.blocks + (size_t)sb * FMD_BLK_U4 + (j ^ t);
-            __builtin_amdgcn_global_load_lds((fmd_glb_void *)src, (fmd_lds_void *)(lds + SLOT * 512 + R * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((fmd_glb_void *)src, (fmd_lds_void *)(lds + SLOT * 512 + R * 64), 16, 0, FMD_GLDS_AUX);
         }
     }
 }
