@@ -28,6 +28,7 @@ ABI_SYMBOLS = [
     "fmd_retrieve_dev", "fmd_retrieve_batch", "fmd_probe_gather",
     "fmd_build_bwt", "fmd_build_bwt_dev", "fmd_dev_free", "fmd_bwt_to_rle6", "fmd_host_free",
     "fmd_dev_malloc", "fmd_memcpy_h2d", "fmd_memcpy_d2h",
+    "fmd_kmer_work_bytes", "fmd_kmer_collect_dev", "fmd_kmer_collect",
     "fmd_ovlp_work_bytes", "fmd_ovlp_dev", "fmd_ovlp_batch",
 ]
 
@@ -88,6 +89,9 @@ def lib():
         L.fmd_ovlp_work_bytes.restype = sz; L.fmd_ovlp_work_bytes.argtypes = [sz, C.c_uint32, C.c_int]
         L.fmd_ovlp_dev.argtypes = [vp, vp, sz, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint32, vp, sz]
         L.fmd_ovlp_batch.argtypes = [vp, sz, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint32]
+        L.fmd_kmer_work_bytes.restype = sz; L.fmd_kmer_work_bytes.argtypes = [C.c_uint64]
+        L.fmd_kmer_collect_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, sz, C.c_uint64, vp, vp, vp, vp]
+        L.fmd_kmer_collect.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64), vp]
         L.fmd_probe_gather.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_float)]
         _lib = L
     return _lib
@@ -225,6 +229,24 @@ def _ovlp(self, ids, min_match, max_len=100, max_nei=4):
 
 
 DevIndex.overlap = _ovlp
+
+
+def _kmer_collect(self, w, min_occ, suf_len=None):
+    """fm6_traverse + ec_collect over all buckets: (bucket u32[], key u32[], val u8[], cnt[2])."""
+    if suf_len is None:
+        suf_len = w - 15 if w > 15 else 1   # compute_SUF (correct.c:319)
+    b, k, v, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+    cnt = (C.c_int64 * 2)()
+    check(lib().fmd_kmer_collect(self.h, w, min_occ, suf_len, C.byref(b), C.byref(k), C.byref(v), C.byref(n), cnt))
+    m = n.value
+    out = (np.frombuffer(C.string_at(b, m * 4), dtype=np.uint32).copy(), np.frombuffer(C.string_at(k, m * 4), dtype=np.uint32).copy(),
+           np.frombuffer(C.string_at(v, m), dtype=np.uint8).copy(), [cnt[0], cnt[1]])
+    for p in (b, k, v):
+        lib().fmd_host_free(p)
+    return out
+
+
+DevIndex.kmer_collect = _kmer_collect
 
 
 def build_bwt(seqs, device=0):

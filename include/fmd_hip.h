@@ -139,6 +139,19 @@ int fmd_ovlp_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_ids, in
 int fmd_ovlp_batch(fmd_dev_t *h, size_t n, const uint64_t *ids, int min_match, uint32_t max_len, uint32_t max_nei,
                    fmd_ovlp_rec_t *rec, fmd_intv_t *nei, uint8_t *seq, uint32_t seq_stride);
 
+/* ---- k-mer harvest of `fermi correct`: fm6_traverse (exact.c:141) + ec_collect (correct.c:35-87)
+ * over ALL 4^suf_len suffix buckets (what worker1 does, correct.c:272-279).  Emits one
+ * (bucket, key, val) triple per solid k-mer: bucket = index into `solid[]` (correct.c:346-349),
+ * key/val exactly what kh_put/kh_val store (correct.c:71-75).  The order of triples is
+ * unspecified (the reference's own order is hash-table iteration order).  w <= 27, w - suf_len <= 15.
+ * d_status (4 x u64): [0] #triples, [1] non-zero = cap overflowed (re-run larger), [2] cnt[0],
+ * [3] cnt[1] (correct.c:64-69). */
+size_t fmd_kmer_work_bytes(uint64_t cap);
+int fmd_kmer_collect_dev(fmd_dev_t *h, void *stream, int w, int min_occ, int suf_len, void *d_work, size_t work_bytes,
+                         uint64_t cap, uint32_t *d_bucket, uint32_t *d_key, uint8_t *d_val, uint64_t *d_status);
+int fmd_kmer_collect(fmd_dev_t *h, int w, int min_occ, int suf_len, uint32_t **bucket, uint32_t **key, uint8_t **val,
+                     uint64_t *n, int64_t cnt[2]);   /* outputs malloc'ed: fmd_host_free() */
+
 /* ---- index construction: the BWT `fermi build` computes (cmd.c:378-484, build.c:11-50) ------
  * reads: nt6 bases of all reads back to back, NO sentinels; read i = reads[off[i], off[i+1]).
  * The text indexed is  read $ revcomp(read) $  per read in input order, sentinels ordered by

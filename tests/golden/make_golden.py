@@ -239,6 +239,27 @@ def main():
     with gzip.open(os.path.join(HERE, "repeat.mag.gz"), "wb", 9) as f:
         f.write(open(os.path.join(TMP, "repeat.mag"), "rb").read())
 
+    # ---- solid k-mer tables of `correct` phase 1 (correct.c:35-87, 341-356), dumped through
+    # oracle/ref_ec_harness.c which compiles the reference's own correct.c
+    import ctypes as C
+    Lec = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_ec.so"))
+    Lec.refec_collect.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                  C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p]
+    kv = {}
+    for (w, mo) in [(17, 3), (21, 3), (23, 2)]:
+        sl = w - 15 if w > 15 else 1
+        b, k, v, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+        cnt = (C.c_int64 * 2)()
+        assert Lec.refec_collect(os.path.join(HERE, "tiny.fmd").encode(), w, mo, sl, C.byref(b), C.byref(k), C.byref(v), C.byref(n), cnt) == 0
+        m = n.value
+        B = np.frombuffer(C.string_at(b, m * 4), dtype=np.uint32); K = np.frombuffer(C.string_at(k, m * 4), dtype=np.uint32)
+        V = np.frombuffer(C.string_at(v, m), dtype=np.uint8)
+        o = np.lexsort([V, K, B])
+        tag = "w%d_o%d" % (w, mo)
+        kv[tag + "_bucket"], kv[tag + "_key"], kv[tag + "_val"] = B[o], K[o], V[o]
+        kv[tag + "_cnt"] = np.array(list(cnt), dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "tiny_solid.npz"), **kv)
+
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith((".fmd", ".gz", ".npz")):
             man["files"][fn] = {"md5": md5(os.path.join(HERE, fn)), "bytes": os.path.getsize(os.path.join(HERE, fn))}

@@ -228,3 +228,14 @@ def test_overlap_sequences_and_capacity_flags(gpu, gold):
     rec2, _, _ = d.overlap(ids[:64], 50, max_len=64)
     assert ((rec2["flags"] & gpu.OVLP_F_OVERFLOW) != 0).all()
     d.close()
+
+
+@pytest.mark.parametrize("w,mo", [(17, 3), (21, 3), (23, 2)])
+def test_kmer_collect_golden(tiny_dev, gold, w, mo):
+    """fm6_traverse + ec_collect (correct.c:35-87): sorted multiset of (bucket, key, val) and cnt[]."""
+    v = gold.npz("tiny_solid.npz")
+    tag = "w%d_o%d" % (w, mo)
+    B, K, V, cnt = tiny_dev.kmer_collect(w, mo)
+    o = np.lexsort([V, K, B])
+    assert np.array_equal(B[o], v[tag + "_bucket"]) and np.array_equal(K[o], v[tag + "_key"]) and np.array_equal(V[o], v[tag + "_val"])
+    assert cnt == list(v[tag + "_cnt"])

@@ -169,3 +169,17 @@ def test_rle6_and_encoder_roundtrip(oracle_lib, gold, tmp_path):
         e2.dump(str(tmp_path / "b.fmd"))
         assert open(tmp_path / "b.fmd", "rb").read() == open(gold.path(name + ".fmd"), "rb").read(), name
         e.close(); e2.close()
+
+
+@pytest.mark.parametrize("w,mo", [(17, 3), (21, 3), (23, 2)])
+def test_ec_collect_golden(tiny_oracle, gold, w, mo):
+    """The `solid` k-mer tables (correct.c:35-87) as a sorted multiset of (bucket, key, val)."""
+    v = gold.npz("tiny_solid.npz")
+    tag = "w%d_o%d" % (w, mo)
+    sl = w - 15 if w > 15 else 1
+    out, cnt = tiny_oracle.ec_collect(w, mo, sl)
+    B = np.concatenate([np.full(len(k), i, dtype=np.uint32) for i, (k, _) in enumerate(out)])
+    K = np.concatenate([k for k, _ in out]); V = np.concatenate([x for _, x in out])
+    o = np.lexsort([V, K, B])
+    assert np.array_equal(B[o], v[tag + "_bucket"]) and np.array_equal(K[o], v[tag + "_key"]) and np.array_equal(V[o], v[tag + "_val"])
+    assert list(cnt) == list(v[tag + "_cnt"])
