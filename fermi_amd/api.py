@@ -28,6 +28,7 @@ ABI_SYMBOLS = [
     "fmd_retrieve_dev", "fmd_retrieve_batch", "fmd_probe_gather",
     "fmd_build_bwt", "fmd_build_bwt_dev", "fmd_dev_free", "fmd_bwt_to_rle6", "fmd_host_free",
     "fmd_dev_malloc", "fmd_memcpy_h2d", "fmd_memcpy_d2h",
+    "fmd_smem_work_bytes", "fmd_smem_dev", "fmd_smem_batch",
     "fmd_kmer_work_bytes", "fmd_kmer_collect_dev", "fmd_kmer_collect",
     "fmd_ovlp_work_bytes", "fmd_ovlp_dev", "fmd_ovlp_batch",
 ]
@@ -92,6 +93,9 @@ def lib():
         L.fmd_kmer_work_bytes.restype = sz; L.fmd_kmer_work_bytes.argtypes = [C.c_uint64]
         L.fmd_kmer_collect_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, sz, C.c_uint64, vp, vp, vp, vp]
         L.fmd_kmer_collect.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64), vp]
+        L.fmd_smem_work_bytes.restype = sz; L.fmd_smem_work_bytes.argtypes = [sz, C.c_uint32]
+        L.fmd_smem_dev.argtypes = [vp, vp, sz, vp, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, sz]
+        L.fmd_smem_batch.argtypes = [vp, sz, vp, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp]
         L.fmd_probe_gather.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_float)]
         _lib = L
     return _lib
@@ -247,6 +251,21 @@ def _kmer_collect(self, w, min_occ, suf_len=None):
 
 
 DevIndex.kmer_collect = _kmer_collect
+
+
+def _smem(self, seqs, self_match=0, max_mem=32):
+    """fm6_smem for each read: list of INTV_DT arrays (one per read)."""
+    flat, off = flatten_reads(seqs)
+    n = len(off) - 1
+    max_len = int(np.max(np.diff(off))) if n else 1
+    mem = np.zeros((n, max_mem), dtype=INTV_DT); n_mem = np.zeros(n, dtype=np.uint32)
+    check(lib().fmd_smem_batch(self.h, n, _ptr(flat), _ptr(off), self_match, max(max_len, 1), max_mem, _ptr(mem), _ptr(n_mem)))
+    if (n_mem >> 31).any():
+        raise FmdError("smem: capacity exceeded for %d reads (raise max_mem)" % int((n_mem >> 31).sum()))
+    return [mem[i, :n_mem[i]].copy() for i in range(n)]
+
+
+DevIndex.smem = _smem
 
 
 def build_bwt(seqs, device=0):

@@ -99,6 +99,17 @@ int fmd_retrieve_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_x, 
 int fmd_retrieve_batch(fmd_dev_t *h, size_t n, const uint64_t *x, uint8_t *seqs, uint32_t stride,
                        uint32_t *len, uint64_t *rank);
 
+/* ---- super-maximal exact matches: fm6_smem (smem.c:397-410) = repeated fm6_smem1_core
+ * (smem.c:13-80); what `fermi exact [-s]` prints (cmd.c:319-327, smem.c:412-418).
+ * mem: n rows of max_mem intervals in the reference's order; info = leftclosed<<63 | beg<<32 | end
+ * (FM_MASK30 fields, smem.c:63).  n_mem[i] = number of SMEMs of read i; bit 31 set = the read was
+ * longer than max_len or produced more than max_mem SMEMs (row invalid: re-run larger). */
+size_t fmd_smem_work_bytes(size_t n, uint32_t max_len);
+int fmd_smem_dev(fmd_dev_t *h, void *stream, size_t n, const uint8_t *d_seqs, const uint64_t *d_off, int self_match,
+                 uint32_t max_len, uint32_t max_mem, fmd_intv_t *d_mem, uint32_t *d_n_mem, void *d_work, size_t work_bytes);
+int fmd_smem_batch(fmd_dev_t *h, size_t n, const uint8_t *seqs, const uint64_t *off, int self_match, uint32_t max_len,
+                   uint32_t max_mem, fmd_intv_t *mem, uint32_t *n_mem);
+
 /* ---- overlap discovery for unitig construction --------------------------------------------
  * One record per sequence id: the read-only front half of unitig1 (unitig.c:274-300), i.e.
  *   fm_retrieve (exact.c:59) + seq_reverse + fm6_is_contained (unitig.c:77) +

@@ -239,3 +239,22 @@ def test_kmer_collect_golden(tiny_dev, gold, w, mo):
     o = np.lexsort([V, K, B])
     assert np.array_equal(B[o], v[tag + "_bucket"]) and np.array_equal(K[o], v[tag + "_key"]) and np.array_equal(V[o], v[tag + "_val"])
     assert cnt == list(v[tag + "_cnt"])
+
+
+@pytest.mark.parametrize("sm", [0, 1])
+def test_smem_golden(tiny_dev, gold, sm):
+    """fm6_smem (smem.c:397) on indexed and noisy reads, both self_match settings."""
+    v = gold.npz("tiny_vectors.npz")
+    off = v["smem%d_off" % sm]
+    got = tiny_dev.smem(v["smem%d_reads" % sm], sm, max_mem=64)
+    for i, m in enumerate(got):
+        assert np.array_equal(m.view(U64).reshape(-1, 4), v["smem%d_mem" % sm][off[i]:off[i + 1]]), i
+
+
+def test_smem_vs_oracle_ragged(gpu, tiny_dev, tiny_oracle):
+    rng = np.random.default_rng(7)
+    reads = synth.reads(synth.DEFAULT_SEED, 2000, coverage=20, err=0.02)
+    qs = [r[int(rng.integers(0, 50)):][:int(rng.integers(1, 100))] for r in reads[:600]]
+    got = tiny_dev.smem(qs, 0, max_mem=64)
+    for q, m in zip(qs, got):
+        assert m.tobytes() == tiny_oracle.smem(q, 0).tobytes()
