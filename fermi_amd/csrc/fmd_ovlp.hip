@@ -7,30 +7,12 @@
 // one rank2a request per wave step; finished lanes refill from a queue (ballot compaction).
 #include <stdlib.h>
 #include <string.h>
-#include "fmd_internal.h"
+#include "fmd_ovlp_common.h"
 
-#define NONE64 (~0ull)
-
-__device__ __forceinline__ int comp6(int c) { return (c >= 1 && c <= 4) ? 5 - c : c; }
-
-template <class T>
-__device__ __forceinline__ T sel6(int c, T a0, T a1, T a2, T a3, T a4, T a5)
-{
-    T r = a0;
-    r = c == 1 ? a1 : r; r = c == 2 ? a2 : r; r = c == 3 ? a3 : r; r = c == 4 ? a4 : r; r = c == 5 ? a5 : r;
-    return r;
-}
-
-// queue refill shared by the persistent kernels: returns the item index for lanes that asked
-__device__ __forceinline__ size_t fmd_queue_take(uint32_t *queue, bool want)
-{
-    const uint64_t m = __ballot(want);
-    if (m == 0) return (size_t)-1;
-    uint32_t first = 0;
-    if (fmd_lane() == 0) first = atomicAdd(queue, (uint32_t)__popcll(m));
-    first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
-    return want ? (size_t)first + __popcll(m & ((1ull << fmd_lane()) - 1)) : (size_t)-1;
-}
+void fmd_launch_nei_grp(int G, int grid, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
+                        const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
+                        uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n);
+void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, const fmd_intv_t *listA, uint32_t cap, FmdOvlClasses cl);
 
 // ---------------------------------------------------------------------------- phase 0: retrieve
 // fm_retrieve (exact.c:59-70); writes the sequence REVERSED into srev and rank/len into rec.
@@ -198,29 +180,17 @@ __device__ __forceinline__ I3 pick5(int c, const I3 &a0, const I3 &a1, const I3 
     r.sz = sel6(c, a0.sz, a1.sz, a2.sz, a3.sz, a4.sz, a0.sz);
     return r;
 }
-#define FMD_SZ_MASK 0xffffffffffffull
 
-__device__ __forceinline__ void load_entry(const fmd_intv_t *e, uint64_t &x0, uint64_t &x1, uint64_t &sz, uint64_t &info)
-{
-    const uint4 *q = (const uint4 *)e;
-    const uint4 a = q[0], b = q[1];
-    x0 = (uint64_t)a.y << 32 | a.x; x1 = (uint64_t)a.w << 32 | a.z;
-    sz = (uint64_t)b.y << 32 | b.x; info = (uint64_t)b.w << 32 | b.z;
-}
-__device__ __forceinline__ void store_entry(fmd_intv_t *e, uint64_t x0, uint64_t x1, uint64_t sz, uint64_t info)
-{
-    uint4 *q = (uint4 *)e;
-    q[0] = make_uint4((uint32_t)x0, (uint32_t)(x0 >> 32), (uint32_t)x1, (uint32_t)(x1 >> 32));
-    q[1] = make_uint4((uint32_t)sz, (uint32_t)(sz >> 32), (uint32_t)info, (uint32_t)(info >> 32));
-}
 
 __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int min_match, const uint8_t *__restrict__ srev,
                                                 uint32_t stride_r, uint32_t cap, fmd_intv_t *__restrict__ listA,
                                                 fmd_intv_t *__restrict__ listB, fmd_ovlp_rec_t *__restrict__ rec,
                                                 fmd_intv_t *__restrict__ nei_out, uint32_t max_nei,
-                                                uint8_t *__restrict__ seq_out, uint32_t seq_stride, uint32_t *__restrict__ queue)
+                                                uint8_t *__restrict__ seq_out, uint32_t seq_stride, uint32_t *__restrict__ queue,
+                                                const uint32_t *__restrict__ work_list, const uint32_t *__restrict__ work_n)
 {
     FMD_DECLARE_WAVE_LDS();
+    if (work_list) n = *work_n;   // only the strands the group kernels could not take
     // per-lane search state
     size_t sid = 0;
     int st = ST_IDLE, ori_l = 0, cur_l = 0, cpend = 0, first_c = 0, masked_cat = -2, cat_j = 0, fix_i = 0;
@@ -239,9 +209,10 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
         const size_t my = fmd_queue_take(queue, st == ST_IDLE && !exhausted);
         if (st == ST_IDLE && !exhausted) {
             if (my < n) {
-                const fmd_ovlp_rec_t *o = rec + my;
+                const size_t strand = work_list ? (size_t)work_list[my] : my;
+                const fmd_ovlp_rec_t *o = rec + strand;
                 if (o->status == 0 && o->n_ovlp > 0 && !(o->flags & FMD_OVLP_F_OVERFLOW)) {
-                    sid = my; ori_l = cur_l = o->len;
+                    sid = strand; ori_l = cur_l = o->len;
                     prev_n = (uint32_t)o->n_ovlp; curr_n = 0; j = 0;
                     prev = listA + sid * (size_t)cap + (cap - prev_n);
                     curr = listB + sid * (size_t)cap; prev_is_a = true;
@@ -431,7 +402,7 @@ extern "C" size_t fmd_ovlp_work_bytes(size_t n, uint32_t max_len, int min_match)
 {
     const size_t stride_r = align_up((size_t)max_len, 4);
     const size_t cap = fmd_ovlp_list_cap(max_len, min_match);
-    return align_up(n * stride_r, 256) + 2 * align_up(n * cap * sizeof(fmd_intv_t), 256) + 256;
+    return align_up(n * stride_r, 256) + 2 * align_up(n * cap * sizeof(fmd_intv_t), 256) + align_up(n * 20 + 64, 256) + 256;
 }
 
 extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_t *d_ids, int min_match, uint32_t max_len,
@@ -454,7 +425,23 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
     uint32_t *q0 = fmd_next_queue(h, st), *q1 = fmd_next_queue(h, st), *q2 = fmd_next_queue(h, st);
     k_ovl_retrieve<<<grid, 64, 0, st>>>(ix, n, d_ids, srev, stride_r, d_rec, q0);
     k_ovl_intv<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, d_rec, d_seq, seq_stride, q1);
-    k_ovl_nei<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, listB, d_rec, d_nei, max_nei, d_seq, seq_stride, q2);
+    if (getenv("FMD_OVLP_SLOW_ONLY")) { // A/B switch: everything through the lane-per-strand kernel
+        k_ovl_nei<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, listB, d_rec, d_nei, max_nei, d_seq, seq_stride, q2, nullptr, nullptr);
+    } else {
+        // work lists: [n16, n32, nslow, pad...] then l16 (2 words per strand), l32 (2), lslow (1)
+        uint32_t *cls = (uint32_t *)((uint8_t *)listB + align_up(n * (size_t)cap * sizeof(fmd_intv_t), 256));
+        FmdOvlClasses cl;
+        cl.n16 = cls; cl.n32 = cls + 1; cl.nslow = cls + 2;
+        cl.l16 = cls + 16; cl.l32 = cl.l16 + 2 * n; cl.lslow = cl.l32 + 2 * n;
+        FMD_HIP_TRY(hipMemsetAsync(cls, 0, 64, st));
+        fmd_launch_classify(st, n, d_rec, listA, cap, cl);
+        // one lane per candidate interval: 4 strands (<= 16 candidates) or 2 strands (<= 32) per wave
+        const int ggrid = h->n_cu * 4; // 34 KiB LDS per wave
+        fmd_launch_nei_grp(16, ggrid, st, ix, cl.l16, cl.n16, cap, listA, d_rec, d_nei, max_nei, d_seq, seq_stride, cl.lslow, cl.nslow);
+        fmd_launch_nei_grp(32, ggrid, st, ix, cl.l32, cl.n32, cap, listA, d_rec, d_nei, max_nei, d_seq, seq_stride, cl.lslow, cl.nslow);
+        // the rest (too many candidates, wide intervals, fake forks, neighbour overflow): lane per strand
+        k_ovl_nei<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, listB, d_rec, d_nei, max_nei, d_seq, seq_stride, q2, cl.lslow, cl.nslow);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "overlap kernels"); return FMD_E_HIP; }
     return FMD_OK;
