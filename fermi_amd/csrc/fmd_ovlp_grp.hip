@@ -30,44 +30,60 @@ __global__ void k_ovl_classify(size_t n, const fmd_ovlp_rec_t *__restrict__ rec,
                                FmdOvlClasses cl)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const fmd_ovlp_rec_t *o = rec + i;
-    if (o->status != 0 || o->n_ovlp <= 0 || (o->flags & FMD_OVLP_F_OVERFLOW)) return;
-    const uint32_t m = (uint32_t)o->n_ovlp;
-    // the widest candidate is the last one (shortest overlap): it must fit a rank block so that
-    // the six '$' boundaries of a lane live in at most two adjacent blocks
-    uint64_t x0, x1, sz, inf;
-    load_entry(listA + i * (size_t)cap + (cap - 1), x0, x1, sz, inf);
-    int cls = (sz >= 255 || o->len >= 65535) ? 2 : (m <= 16 ? 0 : (m <= 32 ? 1 : 2));
-    uint32_t *cnt = cls == 0 ? cl.n16 : cls == 1 ? cl.n32 : cl.nslow;
-    uint32_t *lst = cls == 0 ? cl.l16 : cls == 1 ? cl.l32 : cl.lslow;
-    const uint32_t k = atomicAdd(cnt, 1u);
-    if (cls == 2) lst[k] = (uint32_t)i;
-    else { lst[2 * k] = (uint32_t)i; lst[2 * k + 1] = m | (uint32_t)o->len << 16; }
+    int cls = -1;
+    uint32_t m = 0, len = 0;
+    if (i < n) {
+        const fmd_ovlp_rec_t *o = rec + i;
+        if (o->status == 0 && o->n_ovlp > 0 && !(o->flags & FMD_OVLP_F_OVERFLOW)) {
+            m = (uint32_t)o->n_ovlp; len = (uint32_t)o->len;
+            // the widest candidate is the last one (shortest overlap): the group kernels count
+            // symbols of BWT[x, x+size) through a 64-position window
+            uint64_t x0, x1, sz, inf;
+            load_entry(listA + i * (size_t)cap + (cap - 1), x0, x1, sz, inf);
+            cls = (sz > 63 || len >= 65535) ? 2 : (m <= 16 ? 0 : (m <= 32 ? 1 : 2));
+        }
+    }
+    // one atomic per wave and class (4 M single-lane atomics on three words cost 40 ms)
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const uint64_t mk = __ballot(cls == c);
+        if (mk == 0) continue;
+        uint32_t *cnt = c == 0 ? cl.n16 : c == 1 ? cl.n32 : cl.nslow;
+        uint32_t first = 0;
+        if (lane == __ffsll((long long)mk) - 1) first = atomicAdd(cnt, (uint32_t)__popcll(mk));
+        first = (uint32_t)__shfl((int)first, __ffsll((long long)mk) - 1);
+        if (cls == c) {
+            const uint32_t k = first + __popcll(mk & ((1ull << lane) - 1));
+            if (c == 2) cl.lslow[k] = (uint32_t)i;
+            else { uint32_t *lst = c == 0 ? cl.l16 : cl.l32; lst[2 * k] = (uint32_t)i; lst[2 * k + 1] = m | len << 16; }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------ the kernel
 __device__ __forceinline__ uint64_t bits_below(int j) { return j >= 64 ? ~0ull : ((1ull << j) - 1); }
 
-// '$' indicator words of a block image and its absolute '$' count
-__device__ __forceinline__ void dollar_words(const uint4 *blk, int t, uint32_t w[8], uint64_t &abs0)
+// Chunk (three bit-plane words) holding global 32-position word `gw`, from the lane's block images:
+// slot SK holds block blk_k, slot SL holds blk_l when has_l.  Words of other blocks read as zero
+// (they are masked out by the callers' range masks).
+template <int SK, int SL>
+__device__ __forceinline__ uint4 grp_chunk(const uint4 *lds, int lane, int t, uint32_t blk_k, uint32_t blk_l, bool has_l, uint64_t gw)
 {
-    uint32_t lo = 0, hi = 0;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const uint4 v = blk[c ^ t];
-        w[c] = ~v.x & ~v.y & ~v.z;
-        if (c == 0) lo = v.w;
-        if (c == 6) hi = v.w & 0xff;
-    }
-    abs0 = (uint64_t)hi << 32 | lo;
+    const uint32_t blk = (uint32_t)(gw >> 3);
+    const bool in_k = blk == blk_k, in_l = has_l && blk == blk_l;
+    uint4 v = lds[fmd_lds_base(lane, in_k ? SK : SL) + (((int)gw & 7) ^ t)];
+    if (!in_k && !in_l) v = make_uint4(0, 0, 0, 0);
+    return v;
 }
-__device__ __forceinline__ uint64_t rank0_words(const uint32_t w[8], uint64_t abs0, uint32_t npos)
+__device__ __forceinline__ uint64_t win64(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t sh)
 {
-    uint32_t n = 0;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) n += __builtin_popcount(w[c] & fmd_mask32((int)npos - 32 * c));
-    return abs0 + n;
+    const uint64_t lo = ((uint64_t)w1 << 32 | w0) >> sh;
+    return sh ? lo | (uint64_t)w2 << (64 - sh) : lo;
+}
+__device__ __forceinline__ uint64_t range64(uint32_t a, uint32_t b) // bits [a, b), b <= 64
+{
+    return bits_below((int)b) & ~bits_below((int)a);
 }
 
 template <int G>
@@ -139,46 +155,42 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
         fmd_fetch_slot<3>(ix, lds, blb, b_sep);
         fmd_fetch_wait();
 
-        uint64_t s[6] = {0, 0, 0, 0, 0, 0}, tk[6] = {0, 0, 0, 0, 0, 0};
+        // Every interval here has size <= 63 (k_ovl_classify), so "rank2a" is a count over a 64-position
+        // window of the planes read straight from the lane's LDS block images:
+        //   forward extension: symbols of BWT[x1, x1+size)          -> sizes of the six children
+        //   sentinel tests   : '$' in the child sub-ranges of BWT[x0, x0+size)  (extend0 of unitig.c:112/:129)
+        // Absolute ranks are needed only for the coordinates that survive: x[1] of the kept child
+        // (one rank of one symbol) and the two coordinates of a neighbour.
+        uint64_t s[6] = {0, 0, 0, 0, 0, 0};
         bool is_nei = false;
         uint32_t cm = 0;                    // children c = 1..4 that survive the sentinel test
-        uint64_t e0x0 = 0;                  // x[0] of the `$...$` interval when this lane is a neighbour
+        const int t = fmd_chunk_xor(lane);
         if (live) {
-            const int t = fmd_chunk_xor(lane);
-            uint64_t tl[6];
-            fmd_block_rank6<false>(lds + fmd_lds_base(lane, 0), t, ((uint32_t)ke & 255) + 1, tk);
-            fmd_block_rank6<false>(lds + fmd_lds_base(lane, e_sep ? 1 : 0), t, ((uint32_t)le & 255) + 1, tl);
-#pragma unroll
-            for (int c = 0; c < 6; ++c) s[c] = tl[c] - tk[c];
-            // '$' ranks at the child boundaries of the x[0] range, order $,T,G,C,A (exact.c:81-86)
-            uint32_t wk[8], wl[8];
-            uint64_t ak, al;
-            dollar_words(lds + fmd_lds_base(lane, 2), t, wk, ak);
-            if (b_sep) dollar_words(lds + fmd_lds_base(lane, 3), t, wl, al);
-            else {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) wl[c] = wk[c];
-                al = ak;
+            {   // window of BWT[x1 ...]
+                const uint64_t gw = x1 >> 5; const uint32_t sh = (uint32_t)x1 & 31;
+                const uint4 a = grp_chunk<0, 1>(lds, lane, t, bke, ble, e_sep, gw), b = grp_chunk<0, 1>(lds, lane, t, bke, ble, e_sep, gw + 1),
+                            c = grp_chunk<0, 1>(lds, lane, t, bke, ble, e_sep, gw + 2);
+                // x1 itself may sit in the block after ke's (ke = x1-1 is the last position of a block)
+                const uint64_t m = bits_below((int)sz);
+                const uint64_t X = win64(a.x, b.x, c.x, sh), Y = win64(a.y, b.y, c.y, sh), Z = win64(a.z, b.z, c.z, sh);
+                const uint64_t lo = ~Z & m, hi = Z & ~Y & m;
+                s[0] = __popcll(lo & ~Y & ~X); s[1] = __popcll(lo & ~Y & X); s[2] = __popcll(lo & Y & ~X); s[3] = __popcll(lo & Y & X);
+                s[4] = __popcll(hi & ~X); s[5] = sz - (s[0] + s[1] + s[2] + s[3] + s[4]);
             }
-            uint64_t b = kb, R[6];
-            const uint64_t step[5] = {s[0], s[4], s[3], s[2], s[1]};
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const bool in_k = (uint32_t)(b >> FMD_BLK_SHIFT) == bkb;
-                uint32_t w[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) w[c] = in_k ? wk[c] : wl[c];
-                R[i] = rank0_words(w, in_k ? ak : al, ((uint32_t)b & 255) + 1);
-                if (i < 5) b += step[i];
+            {   // '$' of BWT[x0 ...], children laid out in the order $,T,G,C,A (exact.c:81-86)
+                const uint64_t gw = x0 >> 5; const uint32_t sh = (uint32_t)x0 & 31;
+                const uint4 a = grp_chunk<2, 3>(lds, lane, t, bkb, blb, b_sep, gw), b = grp_chunk<2, 3>(lds, lane, t, bkb, blb, b_sep, gw + 1),
+                            c = grp_chunk<2, 3>(lds, lane, t, bkb, blb, b_sep, gw + 2);
+                const uint64_t D = win64(~a.x & ~a.y & ~a.z, ~b.x & ~b.y & ~b.z, ~c.x & ~c.y & ~c.z, sh);
+                const uint32_t o1 = (uint32_t)s[0], o2 = o1 + (uint32_t)s[4], o3 = o2 + (uint32_t)s[3], o4 = o3 + (uint32_t)s[2], o5 = o4 + (uint32_t)s[1];
+                const uint64_t e0sz = __popcll(D & range64(0, o1));
+                // unitig.c:111-122: a read ends here, bounded by sentinels on both sides, not contained
+                is_nei = round > 0 && s[0] && e0sz && s[0] == sz && sz == e0sz;
+                if (s[4] && (D & range64(o1, o2))) cm |= 1u << 4;
+                if (s[3] && (D & range64(o2, o3))) cm |= 1u << 3;
+                if (s[2] && (D & range64(o3, o4))) cm |= 1u << 2;
+                if (s[1] && (D & range64(o4, o5))) cm |= 1u << 1;
             }
-            const uint64_t e0sz = R[1] - R[0];
-            // unitig.c:111-122: a read ends here, bounded by sentinels on both sides, not contained
-            is_nei = round > 0 && s[0] && e0sz && s[0] == sz && sz == e0sz;
-            e0x0 = R[0];
-            if (s[4] && R[2] != R[1]) cm |= 1u << 4;
-            if (s[3] && R[3] != R[2]) cm |= 1u << 3;
-            if (s[2] && R[4] != R[3]) cm |= 1u << 2;
-            if (s[1] && R[5] != R[4]) cm |= 1u << 1;
         }
 
         // ---- the reference's sequential loop over the list, as prefix logic on group ballots
@@ -192,9 +204,11 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
         const uint32_t newnei_g = (uint32_t)(__ballot(new_nei) >> gbase) & GM;
         if (!keep) cm = 0;
         // neighbours, in list order (unitig.c:119-121)
-        if (new_nei) {
+        if (new_nei) { // ok0 of unitig.c:112: x[0] = rank of '$' before x0, x[1] = cnt[0] + rank of '$' before x1
             const uint32_t k = n_nei + __popc(newnei_g & (uint32_t)bits_below(j));
-            if (k < max_nei) store_entry(nei_out + sid * (size_t)max_nei + k, e0x0, ix.cnt[0] + tk[0], sz, (uint64_t)ori_l - pos);
+            const uint64_t r0 = fmd_block_rank1(lds + fmd_lds_base(lane, 2), t, ((uint32_t)kb & 255) + 1, 0);
+            const uint64_t r1 = fmd_block_rank1(lds + fmd_lds_base(lane, 0), t, ((uint32_t)ke & 255) + 1, 0);
+            if (k < max_nei) store_entry(nei_out + sid * (size_t)max_nei + k, r0, ix.cnt[0] + r1, sz, (uint64_t)ori_l - pos);
         }
         if (active && n_nei == 0 && newnei_g) { // info of nei[0] decides rbeg (unitig.c:157)
             const int src = gbase + __ffs((int)newnei_g) - 1;
@@ -215,8 +229,19 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
         const int p1 = before, p2 = p1 + __popc(c1 & same_m), p3 = p2 + __popc(c2 & same_m), p4 = p3 + __popc(c3 & same_m);
         const bool too_many = n_new > G;
         bool forked_now = false;
-        // x[0] of the children: running sum $,T,G,C,A; x[1] = cnt[c] + tk[c]
+        // x[0] of the children: running sum $,T,G,C,A; x[1] = cnt[c] + rank_c(x1 - 1): one rank of ONE
+        // symbol per surviving child (a second child only exists where the read set forks)
         const uint64_t cx0_4 = x0 + s[0], cx0_3 = cx0_4 + s[4], cx0_2 = cx0_3 + s[3], cx0_1 = cx0_2 + s[2];
+        uint64_t tk[5] = {0, 0, 0, 0, 0};
+        {
+            uint32_t todo = too_many ? 0u : cm;
+            while (__ballot(todo != 0)) {
+                const int c = todo ? __ffs((int)todo) - 1 : 0;
+                const uint64_t r = fmd_block_rank1(lds + fmd_lds_base(lane, 0), t, ((uint32_t)ke & 255) + 1, c);
+                if (todo) { tk[1] = c == 1 ? r : tk[1]; tk[2] = c == 2 ? r : tk[2]; tk[3] = c == 3 ? r : tk[3]; tk[4] = c == 4 ? r : tk[4]; }
+                todo &= todo - 1;
+            }
+        }
         if (!too_many) {
 #define GRP_PUSH(c, pc, cmask, cx0)                                                                     \
             if ((cm >> c) & 1) {                                                                        \
