@@ -436,7 +436,7 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
         FMD_HIP_TRY(hipMemsetAsync(cls, 0, 64, st));
         fmd_launch_classify(st, n, d_rec, listA, cap, cl);
         // one lane per candidate interval: 4 strands (<= 16 candidates) or 2 strands (<= 32) per wave
-        const int ggrid = h->n_cu * 4; // 34 KiB LDS per wave
+        const int ggrid = h->n_cu * 7; // 22.5 KiB LDS per wave
         fmd_launch_nei_grp(16, ggrid, st, ix, cl.l16, cl.n16, cap, listA, d_rec, d_nei, max_nei, d_seq, seq_stride, cl.lslow, cl.nslow);
         fmd_launch_nei_grp(32, ggrid, st, ix, cl.l32, cl.n32, cap, listA, d_rec, d_nei, max_nei, d_seq, seq_stride, cl.lslow, cl.nslow);
         // the rest (too many candidates, wide intervals, fake forks, neighbour overflow): lane per strand

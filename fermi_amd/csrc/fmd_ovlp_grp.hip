@@ -20,9 +20,14 @@
 // to k_ovl_nei through the `slow` work list; nothing is approximated.
 #include "fmd_ovlp_common.h"
 
-// LDS: 4 block slots per lane (EXT k/l, B k/l) + staging
-#define GRP_SLOTS_U4 (4 * 512)
+// LDS per wave: one block slot per lane for the k side of the forward extension (slot 0) and of
+// the sentinel window (slot 1); the l sides, needed only when a range straddles a block boundary
+// (~11 % of the lanes each), share a small compacted pool; then the re-pack staging area.
+#define GRP_POOL 32                          // spill blocks per wave step
+#define GRP_SLOTS_U4 (2 * 512)
+#define GRP_POOL_U4 (GRP_POOL * 8)
 #define GRP_STAGE_U4 128
+#define GRP_LDS_U4 (GRP_SLOTS_U4 + GRP_POOL_U4 + GRP_STAGE_U4 + GRP_POOL / 4)
 
 // ---------------------------------------------------------------------------- classification
 // one thread per strand: work lists for the three get_nei kernels
@@ -67,12 +72,12 @@ __device__ __forceinline__ uint64_t bits_below(int j) { return j >= 64 ? ~0ull :
 // Chunk (three bit-plane words) holding global 32-position word `gw`, from the lane's block images:
 // slot SK holds block blk_k, slot SL holds blk_l when has_l.  Words of other blocks read as zero
 // (they are masked out by the callers' range masks).
-template <int SK, int SL>
-__device__ __forceinline__ uint4 grp_chunk(const uint4 *lds, int lane, int t, uint32_t blk_k, uint32_t blk_l, bool has_l, uint64_t gw)
+__device__ __forceinline__ uint4 grp_chunk(const uint4 *img_k, int t_k, const uint4 *img_l, int t_l, uint32_t blk_k, uint32_t blk_l,
+                                           bool has_l, uint64_t gw)
 {
     const uint32_t blk = (uint32_t)(gw >> 3);
     const bool in_k = blk == blk_k, in_l = has_l && blk == blk_l;
-    uint4 v = lds[fmd_lds_base(lane, in_k ? SK : SL) + (((int)gw & 7) ^ t)];
+    uint4 v = in_k ? img_k[((int)gw & 7) ^ t_k] : img_l[((int)gw & 7) ^ t_l];
     if (!in_k && !in_l) v = make_uint4(0, 0, 0, 0);
     return v;
 }
@@ -92,8 +97,9 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
                                                     fmd_intv_t *__restrict__ nei_out, uint32_t max_nei, uint8_t *__restrict__ seq_out,
                                                     uint32_t seq_stride, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_n)
 {
-    __shared__ uint4 lds[GRP_SLOTS_U4 + GRP_STAGE_U4];
-    uint4 *stage = lds + GRP_SLOTS_U4;
+    __shared__ uint4 lds[GRP_LDS_U4];
+    uint4 *pool = lds + GRP_SLOTS_U4, *stage = pool + GRP_POOL_U4;
+    uint32_t *pool_blk = (uint32_t *)(stage + GRP_STAGE_U4);
     constexpr int S = 64 / G;
     constexpr uint32_t GM = G == 32 ? 0xffffffffu : 0xffffu;
     const int lane = fmd_lane(), g = lane / G, j = lane % G, gbase = g * G;
@@ -150,10 +156,35 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
         const uint32_t bkb = (uint32_t)(kb >> FMD_BLK_SHIFT), blb = (uint32_t)(lb >> FMD_BLK_SHIFT);
         const bool e_sep = live && ble != bke, b_sep = live && blb != bkb;
         fmd_fetch_slot<0>(ix, lds, bke, live);
-        fmd_fetch_slot<1>(ix, lds, ble, e_sep);
-        fmd_fetch_slot<2>(ix, lds, bkb, live);
-        fmd_fetch_slot<3>(ix, lds, blb, b_sep);
+        fmd_fetch_slot<1>(ix, lds, bkb, live);
+        // straddling ranges: compact the extra blocks into the pool (ballot prefix), 8 per instruction
+        const uint64_t me = __ballot(e_sep), mb = __ballot(b_sep);
+        const int n_e = __popcll(me), n_spill = n_e + __popcll(mb);
+        const uint64_t lt64 = (1ull << lane) - 1;
+        const int pe = __popcll(me & lt64), pb = n_e + __popcll(mb & lt64);
+        if (n_spill) {
+            if (e_sep && pe < GRP_POOL) pool_blk[pe] = ble;
+            if (b_sep && pb < GRP_POOL) pool_blk[pb] = blb;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int n_fetch = n_spill < GRP_POOL ? n_spill : GRP_POOL;
+            for (int r = 0; r * 8 < n_fetch; ++r) {
+                const int slot = r * 8 + (lane >> 3);
+                if (slot < n_fetch) {
+                    const uint32_t blk = pool_blk[slot];
+                    const uint4 *src = ix.blocks + (size_t)blk * FMD_BLK_U4 + ((lane & 7) ^ (slot & 7));
+                    __builtin_amdgcn_global_load_lds((fmd_glb_void *)src, (fmd_lds_void *)(pool + r * 64), 16, 0, FMD_GLDS_AUX);
+                }
+            }
+        }
+        // a lane whose spill block did not fit the pool cannot be computed this way: its strand goes
+        // to the lane-per-strand kernel (practically never: the pool holds 32, the mean need is ~14)
+        const bool unserved = (e_sep && pe >= GRP_POOL) || (b_sep && pb >= GRP_POOL);
+        const uint32_t unserved_g = (uint32_t)(__ballot(unserved) >> gbase) & GM;
         fmd_fetch_wait();
+        const int t = fmd_chunk_xor(lane);
+        const uint4 *img_e = lds + fmd_lds_base(lane, 0), *img_b = lds + fmd_lds_base(lane, 1);
+        const uint4 *img_el = pool + (e_sep ? (pe & (GRP_POOL - 1)) : 0) * 8, *img_bl = pool + (b_sep ? (pb & (GRP_POOL - 1)) : 0) * 8;
+        const int t_el = pe & 7, t_bl = pb & 7;
 
         // Every interval here has size <= 63 (k_ovl_classify), so "rank2a" is a count over a 64-position
         // window of the planes read straight from the lane's LDS block images:
@@ -164,12 +195,11 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
         uint64_t s[6] = {0, 0, 0, 0, 0, 0};
         bool is_nei = false;
         uint32_t cm = 0;                    // children c = 1..4 that survive the sentinel test
-        const int t = fmd_chunk_xor(lane);
         if (live) {
             {   // window of BWT[x1 ...]
                 const uint64_t gw = x1 >> 5; const uint32_t sh = (uint32_t)x1 & 31;
-                const uint4 a = grp_chunk<0, 1>(lds, lane, t, bke, ble, e_sep, gw), b = grp_chunk<0, 1>(lds, lane, t, bke, ble, e_sep, gw + 1),
-                            c = grp_chunk<0, 1>(lds, lane, t, bke, ble, e_sep, gw + 2);
+                const uint4 a = grp_chunk(img_e, t, img_el, t_el, bke, ble, e_sep, gw), b = grp_chunk(img_e, t, img_el, t_el, bke, ble, e_sep, gw + 1),
+                            c = grp_chunk(img_e, t, img_el, t_el, bke, ble, e_sep, gw + 2);
                 // x1 itself may sit in the block after ke's (ke = x1-1 is the last position of a block)
                 const uint64_t m = bits_below((int)sz);
                 const uint64_t X = win64(a.x, b.x, c.x, sh), Y = win64(a.y, b.y, c.y, sh), Z = win64(a.z, b.z, c.z, sh);
@@ -179,8 +209,8 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
             }
             {   // '$' of BWT[x0 ...], children laid out in the order $,T,G,C,A (exact.c:81-86)
                 const uint64_t gw = x0 >> 5; const uint32_t sh = (uint32_t)x0 & 31;
-                const uint4 a = grp_chunk<2, 3>(lds, lane, t, bkb, blb, b_sep, gw), b = grp_chunk<2, 3>(lds, lane, t, bkb, blb, b_sep, gw + 1),
-                            c = grp_chunk<2, 3>(lds, lane, t, bkb, blb, b_sep, gw + 2);
+                const uint4 a = grp_chunk(img_b, t, img_bl, t_bl, bkb, blb, b_sep, gw), b = grp_chunk(img_b, t, img_bl, t_bl, bkb, blb, b_sep, gw + 1),
+                            c = grp_chunk(img_b, t, img_bl, t_bl, bkb, blb, b_sep, gw + 2);
                 const uint64_t D = win64(~a.x & ~a.y & ~a.z, ~b.x & ~b.y & ~b.z, ~c.x & ~c.y & ~c.z, sh);
                 const uint32_t o1 = (uint32_t)s[0], o2 = o1 + (uint32_t)s[4], o3 = o2 + (uint32_t)s[3], o4 = o3 + (uint32_t)s[2], o5 = o4 + (uint32_t)s[1];
                 const uint64_t e0sz = __popcll(D & range64(0, o1));
@@ -206,8 +236,8 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
         // neighbours, in list order (unitig.c:119-121)
         if (new_nei) { // ok0 of unitig.c:112: x[0] = rank of '$' before x0, x[1] = cnt[0] + rank of '$' before x1
             const uint32_t k = n_nei + __popc(newnei_g & (uint32_t)bits_below(j));
-            const uint64_t r0 = fmd_block_rank1(lds + fmd_lds_base(lane, 2), t, ((uint32_t)kb & 255) + 1, 0);
-            const uint64_t r1 = fmd_block_rank1(lds + fmd_lds_base(lane, 0), t, ((uint32_t)ke & 255) + 1, 0);
+            const uint64_t r0 = fmd_block_rank1(img_b, t, ((uint32_t)kb & 255) + 1, 0);
+            const uint64_t r1 = fmd_block_rank1(img_e, t, ((uint32_t)ke & 255) + 1, 0);
             if (k < max_nei) store_entry(nei_out + sid * (size_t)max_nei + k, r0, ix.cnt[0] + r1, sz, (uint64_t)ori_l - pos);
         }
         if (active && n_nei == 0 && newnei_g) { // info of nei[0] decides rbeg (unitig.c:157)
@@ -237,7 +267,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
             uint32_t todo = too_many ? 0u : cm;
             while (__ballot(todo != 0)) {
                 const int c = todo ? __ffs((int)todo) - 1 : 0;
-                const uint64_t r = fmd_block_rank1(lds + fmd_lds_base(lane, 0), t, ((uint32_t)ke & 255) + 1, c);
+                const uint64_t r = fmd_block_rank1(img_e, t, ((uint32_t)ke & 255) + 1, c);
                 if (todo) { tk[1] = c == 1 ? r : tk[1]; tk[2] = c == 2 ? r : tk[2]; tk[3] = c == 3 ? r : tk[3]; tk[4] = c == 4 ? r : tk[4]; }
                 todo &= todo - 1;
             }
@@ -266,7 +296,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging writes done before the re-pack reads
         if (active) {
             if (fork_g) flags |= FMD_OVLP_F_FORKED;
-            if (too_many || n_nei > max_nei) { // hand the strand to the lane-per-strand kernel
+            if (too_many || n_nei > max_nei || unserved_g) { // hand the strand to the lane-per-strand kernel
                 if (j == 0) { const uint32_t k = atomicAdd(slow_n, 1u); slow_list[k] = sid; }
                 active = false; alive = false;
             } else if (n_new > 0) { // next round (unitig.c:137-153)
