@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64) void k_ovl_intv(FmdIndexView ix, size_t n, int 
                             fmd_intv_t *e = listA + sid * (size_t)cap + (cap - 1 - npush);
                             uint4 *q = (uint4 *)e;
                             q[0] = make_uint4((uint32_t)x0, (uint32_t)(x0 >> 32), (uint32_t)x1, (uint32_t)(x1 >> 32));
-                            q[1] = make_uint4((uint32_t)sz, (uint32_t)(sz >> 32), (uint32_t)(j + 1), 0u);
+                            q[1] = make_uint4((uint32_t)sz, (uint32_t)(sz >> 32), (uint32_t)depth, 0u); // info = depth; start = len - depth
                         } else rec[sid].flags |= FMD_OVLP_F_OVERFLOW;
                         ++npush;
                     }
@@ -155,6 +155,140 @@ __global__ __launch_bounds__(64) void k_ovl_intv(FmdIndexView ix, size_t n, int 
                 live = false;
             }
         }
+    }
+}
+
+// ------------------------------------------------- phases 0+A fused: LF-walk + overlap_intv in one pass
+// fm_retrieve walks the rows k_i of the suffixes "last i bases $" of the sequence; overlap_intv
+// extends the interval I_i of "last i bases" backward.  k_i lies INSIDE I_i, so once I_i is
+// narrower than a rank block the LF step and the extension read the SAME block: one gather per
+// base instead of two (while I_i is still wide -- the first ~log4(n) bases, blocks that live in
+// L2 -- the LF step takes a gather of its own).  The base found by the LF step is the base the
+// extension needs; when it is '$' the same ranks are fm6_is_contained's left test (unitig.c:83-85).
+// Candidates are pushed with info = depth (their start is len - depth, known only at the end).
+enum { WK_IDLE = 0, WK_LF, WK_EXT, WK_BOTH, WK_RIGHT };
+
+__global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, const uint64_t *__restrict__ ids, int min_match,
+                                                 uint8_t *__restrict__ srev, uint32_t stride_r, uint32_t cap,
+                                                 fmd_intv_t *__restrict__ listA, fmd_ovlp_rec_t *__restrict__ rec,
+                                                 uint8_t *__restrict__ seq_out, uint32_t seq_stride, uint32_t *__restrict__ queue)
+{
+    FMD_DECLARE_WAVE_LDS();
+    size_t sid = 0;
+    int st = WK_IDLE, c_pend = 0, ret = 0;
+    uint32_t depth = 0, npush = 0, pack = 0, flags = 0;
+    uint64_t k = 0, x0 = 0, x1 = 0, sz = 0;
+    bool exhausted = false;
+    for (;;) {
+        const size_t my = fmd_queue_take(queue, st == WK_IDLE && !exhausted);
+        if (st == WK_IDLE && !exhausted) {
+            if (my < n) { sid = my; k = ids[my]; depth = 0; npush = 0; pack = 0; flags = 0; ret = 0; st = WK_LF; }
+            else exhausted = true;
+        }
+        if (__ballot(st != WK_IDLE) == 0) break;
+
+        // ---- requests.  WK_LF: block of k only.  WK_EXT / WK_BOTH: the two ends of I's backward
+        //      extension (k sits in one of them for WK_BOTH).  WK_RIGHT: forward '$' extension.
+        uint64_t qk = NONE64, ql = NONE64;
+        if (st == WK_LF) qk = k;
+        else if (st == WK_EXT || st == WK_BOTH) { qk = x0 - 1; ql = x0 - 1 + sz; }
+        else if (st == WK_RIGHT) { qk = x1 - 1; ql = x1 - 1 + sz; }
+        const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, qk, ql);
+        if (st == WK_IDLE) continue;
+
+        int c = c_pend;
+        bool have_base = st == WK_EXT;
+        if (st == WK_LF || st == WK_BOTH) { // LF step at row k: base = BWT[k], k' = cnt[c] + rank_c(k) - 1
+            const bool in_k = st == WK_LF || (uint32_t)(k >> FMD_BLK_SHIFT) == (uint32_t)((x0 - 1) >> FMD_BLK_SHIFT);
+            const uint4 *img = in_k ? r.bk : r.bl;
+            const uint32_t off = (uint32_t)k & 255;
+            const uint4 v = img[(int)(off >> 5) ^ r.t];
+            const uint32_t bit = off & 31;
+            c = (int)(((v.x >> bit) & 1) | ((v.y >> bit) & 1) << 1 | ((v.z >> bit) & 1) << 2);
+            k = ix.cnt[c] + fmd_block_rank1(img, r.t, off + 1, c) - 1;
+            have_base = true;
+            if (st == WK_LF && depth > 0) { c_pend = c; st = WK_EXT; continue; } // the extension needs its own gather
+        }
+        if (depth == 0) { // first LF step: the last base of the sequence, or an empty sequence
+            if (c == 0) {
+                fmd_ovlp_rec_t *o = rec + sid;
+                o->rank = k; o->k[0] = o->k[1] = o->k[2] = 0; o->len = 0; o->status = -1; o->n_ovlp = 0; o->rbeg = -1;
+                o->ext_len = 0; o->n_nei = 0; o->flags = 0; o->reserved = 0;
+                st = WK_IDLE;
+                continue;
+            }
+            x0 = ix.cnt[c]; x1 = ix.cnt[comp6(c)]; sz = ix.cnt[c + 1] - ix.cnt[c];
+            pack = (uint32_t)c; depth = 1;
+        } else if (st == WK_EXT || st == WK_BOTH) {
+            uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tl[6] = {0, 0, 0, 0, 0, 0};
+            if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
+            if (r.hl) fmd_block_rank6<false>(r.bl, r.t, r.nl, tl);
+            uint64_t s[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) s[a] = tl[a] - tk[a];
+            if (c != 0) { // one more base: overlap_intv's loop body (unitig.c:47-59)
+                const uint64_t sc = sel6(c, s[0], s[1], s[2], s[3], s[4], s[5]);
+                // (sc == 0 cannot happen: the sequence itself is in the index)
+                if ((int)depth >= min_match && s[0]) {
+                    if (npush < cap) store_entry(listA + sid * (size_t)cap + (cap - 1 - npush), x0, x1, sz, (uint64_t)depth);
+                    else flags |= FMD_OVLP_F_OVERFLOW;
+                    ++npush;
+                }
+                x0 = sel6(c, ix.cnt[0], ix.cnt[1], ix.cnt[2], ix.cnt[3], ix.cnt[4], ix.cnt[5]) + sel6(c, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
+                uint64_t before = 0;             // sizes ordered before c: 0 <4 <3 <2 <1 <5
+                if (c != 0) before += s[0];
+                if (c == 3 || c == 2 || c == 1 || c == 5) before += s[4];
+                if (c == 2 || c == 1 || c == 5) before += s[3];
+                if (c == 1 || c == 5) before += s[2];
+                if (c == 5) before += s[1];
+                x1 += before; sz = sc;
+                pack |= (uint32_t)c << (8 * (depth & 3));
+                ++depth;
+                if ((depth & 3) == 0) {
+                    if (depth <= stride_r) *(uint32_t *)(srev + sid * (size_t)stride_r + depth - 4) = pack;
+                    pack = 0;
+                }
+            } else { // '$': the sequence is complete (len = depth); these ranks are the left test of fm6_is_contained
+                if ((depth & 3) && depth < stride_r) *(uint32_t *)(srev + sid * (size_t)stride_r + (depth & ~3u)) = pack;
+                fmd_ovlp_rec_t *o = rec + sid;
+                o->rank = k; o->len = (int32_t)depth; o->rbeg = -1; o->ext_len = 0; o->n_nei = 0; o->reserved = 0;
+                o->k[0] = o->k[1] = o->k[2] = 0; o->n_ovlp = 0;
+                if (depth > stride_r) { o->status = 0; o->flags = FMD_OVLP_F_OVERFLOW; st = WK_IDLE; continue; } // longer than max_len
+                if ((int)depth <= min_match) { o->status = -1; o->flags = 0; st = WK_IDLE; continue; }         // too short (unitig.c:288)
+                {   // the sequence in read order for the caller: srev byte-reversed, one burst
+                    const uint8_t *sr = srev + sid * (size_t)stride_r;
+                    uint8_t *dst = seq_out + sid * (size_t)seq_stride;
+                    const int L = (int)depth, nw = (L + 3) >> 2;
+                    for (int w = 0; w < nw; ++w) {
+                        uint32_t v = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) { const int i = 4 * w + b; if (i < L) v |= (uint32_t)sr[L - 1 - i] << (8 * b); }
+                        if ((uint32_t)(4 * w + 3) < seq_stride) *(uint32_t *)(dst + 4 * w) = v;
+                    }
+                }
+                if (sz != s[0]) ret = -1;          // left-contained
+                x0 = tk[0]; sz = s[0];             // ok[0]: x[0] = cnt[0] + tk[0], x[1] unchanged
+                st = WK_RIGHT;
+                continue;
+            }
+        } else if (st == WK_RIGHT) { // extend by '$' on the right (unitig.c:86-89)
+            const uint64_t t0k = r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, 0) : 0;
+            const uint64_t t0l = r.hl ? fmd_block_rank1(r.bl, r.t, r.nl, 0) : 0;
+            if (sz != t0l - t0k) ret = -1;
+            fmd_ovlp_rec_t *o = rec + sid;
+            o->k[0] = x0; o->k[1] = t0k; o->k[2] = t0l - t0k;
+            o->status = ret < 0 ? -3 : 0;
+            o->n_ovlp = (int32_t)npush;
+            o->flags = flags;
+            st = WK_IDLE;
+            continue;
+        }
+        // next base: can the LF step share the extension's gather?
+        {
+            const uint32_t bk_ = (uint32_t)((x0 - 1) >> FMD_BLK_SHIFT), bl_ = (uint32_t)((x0 - 1 + sz) >> FMD_BLK_SHIFT), bq = (uint32_t)(k >> FMD_BLK_SHIFT);
+            st = (bq == bk_ || bq == bl_) ? WK_BOTH : WK_LF;
+        }
+        (void)have_base;
     }
 }
 
@@ -230,6 +364,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
                 if (cat_j == masked_cat) { ++j; e_valid = false; continue; }
                 px0 = (uint64_t)ea.y << 32 | ea.x; px1 = (uint64_t)ea.w << 32 | ea.z;
                 psz = ((uint64_t)eb.y << 32 | eb.x) & FMD_SZ_MASK; pinfo = (uint64_t)eb.w << 32 | eb.z;
+                if (cur_l == ori_l) pinfo = (uint64_t)ori_l - pinfo; // round 0: the walk stored the suffix depth, unitig.c:53 wants the start
                 st = ST_EXT;
                 e_valid = j + 1 < prev_n;
                 if (e_valid) { const uint4 *q = (const uint4 *)(prev + j + 1); ea = q[0]; eb = q[1]; } // lands under the rank fetch
@@ -423,8 +558,11 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
     const FmdIndexView ix = fmd_view(h);
     const int grid = fmd_grid_for(h, n);
     uint32_t *q0 = fmd_next_queue(h, st), *q1 = fmd_next_queue(h, st), *q2 = fmd_next_queue(h, st);
-    k_ovl_retrieve<<<grid, 64, 0, st>>>(ix, n, d_ids, srev, stride_r, d_rec, q0);
-    k_ovl_intv<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, d_rec, d_seq, seq_stride, q1);
+    if (getenv("FMD_OVLP_UNFUSED")) { // A/B switch: separate LF-walk and overlap_intv passes
+        k_ovl_retrieve<<<grid, 64, 0, st>>>(ix, n, d_ids, srev, stride_r, d_rec, q0);
+        k_ovl_intv<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, d_rec, d_seq, seq_stride, q1);
+    } else
+        k_ovl_walk<<<grid, 64, 0, st>>>(ix, n, d_ids, min_match, srev, stride_r, cap, listA, d_rec, d_seq, seq_stride, q0);
     if (getenv("FMD_OVLP_SLOW_ONLY")) { // A/B switch: everything through the lane-per-strand kernel
         k_ovl_nei<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, listB, d_rec, d_nei, max_nei, d_seq, seq_stride, q2, nullptr, nullptr);
     } else {

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
             sid = d_sid; ori_l = (int)(d_meta >> 16); round = 0; n_nei = 0; flags = 0; nei0_info = 0;
             alive = (uint32_t)j < m;
             x0 = (uint64_t)pa.y << 32 | pa.x; x1 = (uint64_t)pa.w << 32 | pa.z;
-            sz = ((uint64_t)pb.y << 32 | pb.x) & FMD_SZ_MASK; pos = pb.z; cat = 0;
+            sz = ((uint64_t)pb.y << 32 | pb.x) & FMD_SZ_MASK; pos = (uint32_t)ori_l - pb.z; cat = 0; // stored info = suffix depth
             active = true;
             pf = 0; idx += n_groups;
         }
