@@ -33,7 +33,7 @@ __device__ __forceinline__ void km_extend_back(const FmdIndexView &ix, uint4 *ld
     for (int c = 0; c < 6; ++c) tk[c] = 0;
     if (active) {
         if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
-        if (r.hl) fmd_block_rank6<false>(r.bl, r.t, r.nl, tl);
+        if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
     }
 #pragma unroll
     for (int c = 0; c < 6; ++c) s[c] = tl[c] - tk[c];

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64) void k_rank2a(FmdIndexView ix, size_t n, const 
         if (i < n) {
             uint64_t ok[6] = {0, 0, 0, 0, 0, 0}, ol[6] = {0, 0, 0, 0, 0, 0};
             if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, ok);
-            if (r.hl) fmd_block_rank6<false>(r.bl, r.t, r.nl, ol);
+            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, ol);
 #pragma unroll
             for (int c = 0; c < 6; ++c) { d_ok[i * 6 + c] = ok[c]; d_ol[i * 6 + c] = ol[c]; }
         }
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64) void k_extend(FmdIndexView ix, size_t n, const 
         if (i < n) {
             uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tl[6] = {0, 0, 0, 0, 0, 0};
             if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
-            if (r.hl) fmd_block_rank6<false>(r.bl, r.t, r.nl, tl);
+            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
             fmd_intv_t ok[6];
             fmd_extend_finish(ix, x, is_back, tk, tl, ok);
             uint4 *dst = (uint4 *)(d_ok + i * 6);
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const
         const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, qk, ql);
         if (live) {
             const uint64_t ok = r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, c) : 0;
-            const uint64_t ol = fmd_block_rank1(r.bl, r.t, r.nl, c);
+            const uint64_t ol = fmd_block_rank1(r.bl, r.tl, r.nl, c);
             k = ix.cnt[c] + ok;
             l = ix.cnt[c] + ol - 1;
             --pos;

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64) void k_ovl_intv(FmdIndexView ix, size_t n, int 
         if (live) {
             uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tl[6] = {0, 0, 0, 0, 0, 0};
             if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
-            if (r.hl) fmd_block_rank6<false>(r.bl, r.t, r.nl, tl);
+            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
             uint64_t s[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) s[c] = tl[c] - tk[c];
@@ -202,10 +202,11 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             const bool in_k = st == WK_LF || (uint32_t)(k >> FMD_BLK_SHIFT) == (uint32_t)((x0 - 1) >> FMD_BLK_SHIFT);
             const uint4 *img = in_k ? r.bk : r.bl;
             const uint32_t off = (uint32_t)k & 255;
-            const uint4 v = img[(int)(off >> 5) ^ r.t];
+            const int tt = in_k ? r.t : r.tl;
+            const uint4 v = img[(int)(off >> 5) ^ tt];
             const uint32_t bit = off & 31;
             c = (int)(((v.x >> bit) & 1) | ((v.y >> bit) & 1) << 1 | ((v.z >> bit) & 1) << 2);
-            k = ix.cnt[c] + fmd_block_rank1(img, r.t, off + 1, c) - 1;
+            k = ix.cnt[c] + fmd_block_rank1(img, tt, off + 1, c) - 1;
             have_base = true;
             if (st == WK_LF && depth > 0) { c_pend = c; st = WK_EXT; continue; } // the extension needs its own gather
         }
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
         } else if (st == WK_EXT || st == WK_BOTH) {
             uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tl[6] = {0, 0, 0, 0, 0, 0};
             if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
-            if (r.hl) fmd_block_rank6<false>(r.bl, r.t, r.nl, tl);
+            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
             uint64_t s[6];
 #pragma unroll
             for (int a = 0; a < 6; ++a) s[a] = tl[a] - tk[a];
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             }
         } else if (st == WK_RIGHT) { // extend by '$' on the right (unitig.c:86-89)
             const uint64_t t0k = r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, 0) : 0;
-            const uint64_t t0l = r.hl ? fmd_block_rank1(r.bl, r.t, r.nl, 0) : 0;
+            const uint64_t t0l = r.hl ? fmd_block_rank1(r.bl, r.tl, r.nl, 0) : 0;
             if (sz != t0l - t0k) ret = -1;
             fmd_ovlp_rec_t *o = rec + sid;
             o->k[0] = x0; o->k[1] = t0k; o->k[2] = t0l - t0k;
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
         if (st == ST_EXT || st == ST_FIX1 || st == ST_FIX2) {
             uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tl[6] = {0, 0, 0, 0, 0, 0};
             if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
-            if (r.hl) fmd_block_rank6<false>(r.bl, r.t, r.nl, tl);
+            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
             uint64_t s[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) s[c] = tl[c] - tk[c];
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
         } else if (st == ST_E0 || st == ST_C) {
             // fm6_extend0 (exact.c:90-98), backward: only the '$' child matters
             const uint64_t t0k = r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, 0) : 0;
-            const uint64_t t0l = r.hl ? fmd_block_rank1(r.bl, r.t, r.nl, 0) : 0;
+            const uint64_t t0l = r.hl ? fmd_block_rank1(r.bl, r.tl, r.nl, 0) : 0;
             const uint64_t e0sz = t0l - t0k;
             if (st == ST_E0) {
                 bool is_nei = false;

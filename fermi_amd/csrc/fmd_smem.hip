@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
         if (st != SM_IDLE) {
             uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tl[6] = {0, 0, 0, 0, 0, 0};
             if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
-            if (r.hl) fmd_block_rank6<false>(r.bl, r.t, r.nl, tl);
+            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
             uint64_t s[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) s[c] = tl[c] - tk[c];

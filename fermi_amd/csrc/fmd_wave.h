@@ -152,12 +152,20 @@ __device__ __forceinline__ uint64_t fmd_block_rank1(const uint4 *blk, int t, uin
 // rank2: every lane posts k and l (positions, either may be UINT64_MAX = "none").
 // Fetches both sides (the l-side only when it lives in another block), then returns the lane's
 // LDS block pointers.  All 64 lanes must call this together.
+//
+// The k side is a dense slot (one block per lane, 8 cooperative rounds).  The l side is needed by
+// few lanes once the SA intervals are narrow (the two ends of [k, l] usually share a block), so
+// those lanes are compacted with a ballot prefix into a 32-block pool and fetched 8 per wave
+// instruction: at most 4 instructions instead of 8 rounds of swizzle + address arithmetic.  Wide
+// intervals (every lane straddles: the first few bases of a search) fall back to a dense l slot.
 struct FmdRank2 {
     const uint4 *bk, *bl;  // lane-owned block images in LDS
-    int t;
+    int t, tl;             // chunk XOR of each image
     uint32_t nk, nl;       // positions to count in each
     bool hk, hl;           // side present
 };
+
+#define FMD_POOL_BLOCKS 32
 
 __device__ __forceinline__ FmdRank2 fmd_wave_rank2_fetch(const FmdIndexView &ix, uint4 *lds, uint64_t k, uint64_t l)
 {
@@ -167,10 +175,31 @@ __device__ __forceinline__ FmdRank2 fmd_wave_rank2_fetch(const FmdIndexView &ix,
     const uint32_t blk_k = (uint32_t)(k >> FMD_BLK_SHIFT), blk_l = (uint32_t)(l >> FMD_BLK_SHIFT);
     const bool l_sep = r.hl && !(r.hk && blk_k == blk_l);
     fmd_fetch_slot<0>(ix, lds, blk_k, r.hk);
-    fmd_fetch_slot<1>(ix, lds, blk_l, l_sep);
     r.t = fmd_chunk_xor(q);
     r.bk = lds + fmd_lds_base(q, 0);
-    r.bl = lds + fmd_lds_base(q, l_sep ? 1 : 0);
+    r.bl = r.bk; r.tl = r.t;
+    const uint64_t m = __ballot(l_sep);
+    if (m) {
+        const int n_sep = __popcll(m);
+        if (n_sep <= FMD_POOL_BLOCKS) { // compact pool in the first half of slot 1; block ids after it
+            uint4 *pool = lds + 512;
+            uint32_t *ids = (uint32_t *)(pool + FMD_POOL_BLOCKS * 8);
+            const int p = __popcll(m & ((1ull << q) - 1));
+            if (l_sep) ids[p] = blk_l;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int rr = 0; rr * 8 < n_sep; ++rr) {
+                const int slot = rr * 8 + (q >> 3);
+                if (slot < n_sep) {
+                    const uint4 *src = ix.blocks + (size_t)ids[slot] * FMD_BLK_U4 + ((q & 7) ^ (slot & 7));
+                    __builtin_amdgcn_global_load_lds((fmd_glb_void *)src, (fmd_lds_void *)(pool + rr * 64), 16, 0, FMD_GLDS_AUX);
+                }
+            }
+            if (l_sep) { r.bl = pool + p * 8; r.tl = p & 7; }
+        } else {
+            fmd_fetch_slot<1>(ix, lds, blk_l, l_sep);
+            if (l_sep) r.bl = lds + fmd_lds_base(q, 1);
+        }
+    }
     r.nk = ((uint32_t)k & (FMD_BLK_SYMS - 1)) + 1;
     r.nl = ((uint32_t)l & (FMD_BLK_SYMS - 1)) + 1;
     fmd_fetch_wait();
