@@ -10,10 +10,10 @@ CFLAGS    = -O2 -g -Wall -fPIC -std=gnu11
 HIP_SRCS  = $(wildcard fermi_amd/csrc/*.hip)
 HIP_HDRS  = $(wildcard fermi_amd/csrc/*.h) include/fmd_hip.h
 HIP_OBJS  = $(patsubst fermi_amd/csrc/%.hip,build/%.o,$(HIP_SRCS))
-HOST_SRCS = $(wildcard fermi_amd/host/*.c)
+HOST_SRCS = $(filter-out fermi_amd/host/main.c,$(wildcard fermi_amd/host/*.c))
 HOST_HDRS = $(wildcard fermi_amd/host/*.h) include/fmd_hip.h
 
-all: fermi_amd/lib/libfmdhip.so host oracle
+all: fermi_amd/lib/libfmdhip.so host cli oracle
 
 build/%.o: fermi_amd/csrc/%.hip $(HIP_HDRS)
 	@mkdir -p build
@@ -24,9 +24,14 @@ fermi_amd/lib/libfmdhip.so: $(HIP_OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJS) -o $@
 
 host: fermi_amd/lib/libfmdhost.so
-fermi_amd/lib/libfmdhost.so: $(HOST_SRCS) $(HOST_HDRS)
+fermi_amd/lib/libfmdhost.so: $(HOST_SRCS) $(HOST_HDRS) fermi_amd/lib/libfmdhip.so
 	@mkdir -p fermi_amd/lib
-	@if [ -n "$(HOST_SRCS)" ]; then $(CC) $(CFLAGS) -shared -Iinclude $(HOST_SRCS) -o $@ -lpthread -lm -lz; fi
+	$(CC) $(CFLAGS) -shared -Iinclude $(HOST_SRCS) -o $@ -Lfermi_amd/lib -lfmdhip -Wl,-rpath,'$$ORIGIN' -lpthread -lm
+
+cli: fermi_amd/bin/fermi-amd
+fermi_amd/bin/fermi-amd: fermi_amd/host/main.c fermi_amd/lib/libfmdhost.so fermi_amd/lib/libfmdhip.so
+	@mkdir -p fermi_amd/bin
+	$(CC) $(CFLAGS) -Iinclude -Ifermi_amd/host fermi_amd/host/main.c -o $@ -Lfermi_amd/lib -lfmdhost -lfmdhip -Wl,-rpath,'$$ORIGIN/../lib'
 
 oracle:
 	$(MAKE) -s -C oracle oracle
@@ -42,4 +47,4 @@ variant:
 clean:
 	rm -rf build fermi_amd/lib/*.so
 	$(MAKE) -s -C oracle clean
-.PHONY: all host oracle ref clean
+.PHONY: all host cli oracle ref clean variant

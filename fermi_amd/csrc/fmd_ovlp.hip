@@ -531,6 +531,110 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
     }
 }
 
+// ------------------------------------------------------------ phase C: check_left_simple
+// unitig.c:186-204 for the edge (strand -> its unique neighbour): collect, walking the neighbour
+// forward from its first base, the reads that END inside it with >= min_match bases (its left
+// neighbours), then pull them back over the strand's bases left of the overlap; any of them that
+// neither ends nor continues with the strand's base is a backward bifurcation.  A pure function of
+// the strand once its neighbour is unique, so the deterministic host walk reads it from the table:
+// rec.reserved = 0 (check_left_simple returns 0), 1 (returns -1), 2 (not applicable).
+enum { CL_IDLE = 0, CL_FWD, CL_PICK, CL_BWD };
+
+__global__ __launch_bounds__(64) void k_ovl_cls(FmdIndexView ix, size_t n, int min_match, uint32_t cap, fmd_intv_t *__restrict__ listA,
+                                                fmd_intv_t *__restrict__ listB, fmd_ovlp_rec_t *__restrict__ rec,
+                                                const uint8_t *__restrict__ seq, uint32_t seq_stride, uint32_t *__restrict__ queue)
+{
+    FMD_DECLARE_WAVE_LDS();
+    size_t sid = 0;
+    int st = CL_IDLE, rbeg = 0, s_l = 0, depth = 0, i = 0;
+    uint32_t prev_n = 0, curr_n = 0, j = 0;
+    uint64_t x0 = 0, x1 = 0, sz = 0;
+    fmd_intv_t *prev = nullptr, *curr = nullptr;
+    const uint8_t *s = nullptr;
+    bool exhausted = false;
+    for (;;) {
+        const size_t my = fmd_queue_take(queue, st == CL_IDLE && !exhausted);
+        if (st == CL_IDLE && !exhausted) {
+            if (my < n) {
+                fmd_ovlp_rec_t *o = rec + my;
+                if (o->status == 0 && o->n_nei == 1 && o->rbeg >= 0 && !(o->flags & FMD_OVLP_F_OVERFLOW) &&
+                    (uint32_t)(o->len + o->ext_len) <= seq_stride) {
+                    sid = my; rbeg = o->rbeg; s_l = o->len + o->ext_len;
+                    s = seq + sid * (size_t)seq_stride;
+                    const int c = s[rbeg];
+                    x0 = ix.cnt[c]; x1 = ix.cnt[comp6(c)]; sz = ix.cnt[c + 1] - ix.cnt[c];
+                    depth = 1; prev = listA + sid * (size_t)cap; curr = listB + sid * (size_t)cap; prev_n = curr_n = 0;
+                    if (rbeg + 1 < s_l) st = CL_FWD;
+                    else { o->reserved = 0; } // a one-base neighbour cannot collect anything
+                } else o->reserved = 2;
+            } else exhausted = true;
+        }
+        while (st == CL_PICK) {
+            if (j < prev_n) { uint64_t inf; load_entry(prev + j, x0, x1, sz, inf); st = CL_BWD; }
+            else { // next base to the left (unitig.c:194-202)
+                fmd_intv_t *t = prev; prev = curr; curr = t;
+                prev_n = curr_n; curr_n = 0; j = 0; --i;
+                if (i < 0 || prev_n == 0) { rec[sid].reserved = 0; st = CL_IDLE; }
+            }
+        }
+        if (__ballot(st != CL_IDLE) == 0) { if (__ballot(!exhausted) == 0) break; else continue; }
+        uint64_t qk = NONE64, ql = NONE64;
+        if (st == CL_FWD) { qk = x1 - 1; ql = x1 - 1 + sz; }
+        else if (st == CL_BWD) { qk = x0 - 1; ql = x0 - 1 + sz; }
+        const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, qk, ql);
+        if (st == CL_IDLE) continue;
+        uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tl[6] = {0, 0, 0, 0, 0, 0};
+        if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
+        if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
+        uint64_t sc[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) sc[a] = tl[a] - tk[a];
+        if (st == CL_FWD) { // overlap_intv(at5 = 1, inc_sentinel = 1), unitig.c:38-64
+            const int c = comp6(s[rbeg + depth]);
+            const uint64_t szc = sel6(c, sc[0], sc[1], sc[2], sc[3], sc[4], sc[5]);
+            bool end_fwd = szc == 0;
+            if (!end_fwd) {
+                if (depth >= min_match && sc[0]) {
+                    if (prev_n < cap) store_entry(prev + prev_n, x0, ix.cnt[0] + tk[0], sc[0], 0);
+                    ++prev_n;
+                }
+                // ik = ok[c] (forward): x[1] from rank, x[0] running sum in the order $,T,G,C,A,N
+                uint64_t before = 0;
+                if (c != 0) before += sc[0];
+                if (c == 3 || c == 2 || c == 1 || c == 5) before += sc[4];
+                if (c == 2 || c == 1 || c == 5) before += sc[3];
+                if (c == 1 || c == 5) before += sc[2];
+                if (c == 5) before += sc[1];
+                x1 = sel6(c, ix.cnt[0], ix.cnt[1], ix.cnt[2], ix.cnt[3], ix.cnt[4], ix.cnt[5]) + sel6(c, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
+                x0 += before; sz = szc;
+                ++depth;
+                end_fwd = rbeg + depth == s_l;
+            }
+            if (end_fwd) {
+                if (prev_n > cap) { rec[sid].flags |= FMD_OVLP_F_OVERFLOW; rec[sid].reserved = 2; st = CL_IDLE; }
+                else if (prev_n == 0 || rbeg == 0) { rec[sid].reserved = 0; st = CL_IDLE; }
+                else { i = rbeg - 1; j = 0; curr_n = 0; st = CL_PICK; }
+            }
+        } else { // CL_BWD: one collected interval against base s[i] (unitig.c:196-200)
+            const int c = s[i];
+            const uint64_t szc = sel6(c, sc[0], sc[1], sc[2], sc[3], sc[4], sc[5]);
+            if (sc[0] + szc != sz) { rec[sid].reserved = 1; st = CL_IDLE; } // potential backward bifurcation
+            else {
+                uint64_t before = 0;
+                if (c != 0) before += sc[0];
+                if (c == 3 || c == 2 || c == 1 || c == 5) before += sc[4];
+                if (c == 2 || c == 1 || c == 5) before += sc[3];
+                if (c == 1 || c == 5) before += sc[2];
+                if (c == 5) before += sc[1];
+                const uint64_t nx0 = sel6(c, ix.cnt[0], ix.cnt[1], ix.cnt[2], ix.cnt[3], ix.cnt[4], ix.cnt[5]) + sel6(c, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
+                if (curr_n < cap) store_entry(curr + curr_n, nx0, x1 + before, szc, 0);
+                ++curr_n; ++j;
+                st = CL_PICK;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------- host entry
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -580,6 +684,10 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
         fmd_launch_nei_grp(32, ggrid, st, ix, cl.l32, cl.n32, cap, listA, d_rec, d_nei, max_nei, d_seq, seq_stride, cl.lslow, cl.nslow);
         // the rest (too many candidates, wide intervals, fake forks, neighbour overflow): lane per strand
         k_ovl_nei<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, listB, d_rec, d_nei, max_nei, d_seq, seq_stride, q2, cl.lslow, cl.nslow);
+    }
+    {   // check_left_simple for every strand with a unique neighbour (the lists' HBM areas are free again)
+        uint32_t *q3 = fmd_next_queue(h, st);
+        k_ovl_cls<<<grid, 64, 0, st>>>(ix, n, min_match, cap, listA, listB, d_rec, d_seq, seq_stride, q3);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "overlap kernels"); return FMD_E_HIP; }

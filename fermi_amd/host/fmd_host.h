@@ -7,6 +7,8 @@
 #define FMD_HOST_H
 #include <stddef.h>
 #include <stdint.h>
+#include <stdio.h>
+#include "fmd_hip.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -24,6 +26,20 @@ extern const uint8_t fmdh_nt6[256];
 /* cmd.c:457-463: an even-length read equal to its own reverse complement loses its last base.
  * Returns the (possibly reduced) length. */
 uint32_t fmdh_trim_palindrome(const uint8_t *s, uint32_t len);
+
+/* ---- `fermi unitig` on top of the GPU overlap table (unitig.c:227-362, mag.c:149-174) ---- */
+typedef struct {
+    uint64_t n;                  /* rows = sequence ids 0 .. n-1 */
+    uint32_t max_nei, seq_stride;
+    const fmd_ovlp_rec_t *rec;   /* n */
+    const fmd_intv_t *nei;       /* n * max_nei */
+    const uint8_t *seq;          /* n * seq_stride: sequence then appended bases */
+} fmdh_ovlp_table_t;
+/* Replays the single-threaded walk and writes the MAG records `fermi unitig -t1` prints. */
+int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, FILE *out);
+/* Whole command: open the .fmd on `device`, build the table on the GPU (capacities grown until no
+ * record overflows), walk, print.  `fermi unitig -l min_match <fn>` (cmd.c:184-216). */
+int fmdh_unitig(const char *fmd_path, int device, int min_match, FILE *out);
 
 #ifdef __cplusplus
 }

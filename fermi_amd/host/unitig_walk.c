@@ -1,0 +1,215 @@
+/* unitig_walk.c -- the deterministic `fermi unitig -t1` walk, replayed on the host over the per-read
+ * overlap table the GPU computed (include/fmd_hip.h: fmd_ovlp_*).
+ *
+ * In the reference, unitig_core (unitig.c:319-362) seeds from every odd sequence id, and
+ * unitig1 / unitig_unidir (unitig.c:227-317) extend a seed through unique irreducible overlaps.
+ * Everything in that walk that touches the FM-index is a pure function of one read-strand:
+ *   fm_retrieve + fm6_is_contained            -> rec.rank, rec.len, rec.k[], rec.status, seq
+ *   fm6_get_nei on the terminal read          -> rec.rbeg, nei[], appended bases (seq tail)
+ *   check_left_simple on the edge to the unique neighbour -> rec.reserved
+ *   check_left's second look (get_nei on the reverse strand of the neighbour) -> that strand's n_nei
+ * so the walk itself is bookkeeping: the used / bend / visited bitmaps (unitig.c:15-36, 238-253,
+ * 337-339), coverage strings and the MAG record printer (mag.c:149-174).  With one thread the
+ * reference is deterministic and this reproduces its output byte for byte.
+ * (Marks that the reference puts on CONTAINED reads -- unitig.c:124, :197 -- are not replayed: a
+ * contained seed is rejected with or without them, unitig.c:282-292.)
+ */
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "fmd_host.h"
+
+typedef struct { char *s; size_t l, m; } str_t;
+
+static int str_reserve(str_t *s, size_t need)
+{
+    if (need <= s->m) return 0;
+    size_t m = s->m ? s->m : 256;
+    while (m < need) m <<= 1;
+    char *p = (char *)realloc(s->s, m);
+    if (!p) return -ENOMEM;
+    s->s = p; s->m = m;
+    return 0;
+}
+
+static inline int bit_get(const uint64_t *b, uint64_t x) { return (int)(b[x >> 6] >> (x & 63) & 1); }
+static inline void bit_set(uint64_t *b, uint64_t x) { b[x >> 6] |= 1ull << (x & 63); }
+
+typedef struct {
+    const fmdh_ovlp_table_t *t;
+    uint64_t n_seq;
+    int min_match;
+    uint64_t *used, *bend, *visited;
+    uint32_t *row_of;           /* `$read$` interval start -> a sequence id with that interval */
+    /* the neighbour list left behind by the last try_right (unitig.c:181-184) */
+    const fmd_intv_t *nei; int n_nei;
+} walk_t;
+
+static inline const fmd_ovlp_rec_t *REC(const walk_t *w, uint64_t row) { return &w->t->rec[row]; }
+static inline const fmd_intv_t *NEI(const walk_t *w, uint64_t row) { return w->t->nei + row * w->t->max_nei; }
+static inline const uint8_t *SEQ(const walk_t *w, uint64_t row) { return w->t->seq + row * (size_t)w->t->seq_stride; }
+
+static void mark_used(walk_t *w, const uint64_t x[3]) /* set_bits, unitig.c:22-36 (sorted == NULL) */
+{
+    uint64_t k;
+    for (k = 0; k < x[2]; ++k) { bit_set(w->used, x[0] + k); bit_set(w->used, x[1] + k); }
+}
+
+/* check_left (unitig.c:206-225) for the edge row -> its unique neighbour */
+static int check_left(const walk_t *w, uint64_t row)
+{
+    const fmd_ovlp_rec_t *r = REC(w, row);
+    if (r->reserved == 0) return 0;
+    /* the back fork may be due to a contained read: look right from the reverse strand of the
+     * neighbour; more than one irreducible overlap there confirms the bifurcation */
+    uint32_t row2 = w->row_of[NEI(w, row)[0].x[1]];
+    if (row2 == 0xffffffffu) return -1;
+    return REC(w, row2)->n_nei > 1 ? -1 : 0;
+}
+
+/* unitig_unidir, unitig.c:227-262.  `cur` = table row of the read at the right end of s. */
+static int unidir(walk_t *w, uint64_t cur, str_t *s, str_t *cov, int beg0, uint64_t k0, uint64_t *end, int *is_loop)
+{
+    int beg = beg0, ori_l = (int)s->l, n_reads = 0, i;
+    *is_loop = 0;
+    for (;;) {
+        const fmd_ovlp_rec_t *r = REC(w, cur);
+        int rbeg;
+        w->nei = NEI(w, cur); w->n_nei = r->n_nei;
+        if (r->status != 0 || r->rbeg < 0) { w->n_nei = r->status == 0 ? r->n_nei : 0; break; }   /* try_right < 0 */
+        rbeg = beg + r->rbeg;
+        if (r->n_nei > 1) { bit_set(w->bend, *end); break; }                     /* forward bifurcation */
+        {   /* the bases fm6_get_nei appended (unitig.c:139) */
+            if (str_reserve(s, (size_t)ori_l + r->ext_len + 1)) return -1;
+            memcpy(s->s + ori_l, SEQ(w, cur) + r->len, (size_t)r->ext_len);
+            s->l = (size_t)ori_l + r->ext_len;
+        }
+        uint64_t k = w->nei[0].x[0];
+        if (k == *end) break;                                                    /* b>>c>>a><a */
+        if (bit_get(w->bend, k) || check_left(w, cur) < 0) { bit_set(w->bend, k); break; } /* backward bifurcation */
+        if (k == k0) { *is_loop = 1; break; }                                    /* a>>b>>c>>a */
+        if (w->nei[0].x[1] == *end) { w->n_nei = 0; break; }                     /* b>>c>>a>>a: cut the last link */
+        *end = w->nei[0].x[1];
+        mark_used(w, w->nei[0].x);
+        ++n_reads;
+        if (str_reserve(cov, s->l + 1)) return -1;
+        cov->l = s->l;
+        for (i = rbeg; i < ori_l; ++i) if (cov->s[i] != '~') ++cov->s[i];
+        for (i = ori_l; i < (int)s->l; ++i) cov->s[i] = '"';
+        beg = rbeg; ori_l = (int)s->l;
+        {
+            uint32_t nxt = w->row_of[w->nei[0].x[0]];
+            if (nxt == 0xffffffffu) break; /* cannot happen: a neighbour is a non-contained read */
+            cur = nxt;
+        }
+    }
+    s->l = cov->l = (size_t)ori_l;
+    return n_reads;
+}
+
+static void revcomp6(size_t l, char *s)
+{
+    size_t i;
+    for (i = 0; i < l >> 1; ++i) {
+        int a = s[i], b = s[l - 1 - i];
+        s[i] = (char)((b >= 1 && b <= 4) ? 5 - b : b);
+        s[l - 1 - i] = (char)((a >= 1 && a <= 4) ? 5 - a : a);
+    }
+    if (l & 1) { int a = s[i]; s[i] = (char)((a >= 1 && a <= 4) ? 5 - a : a); }
+}
+static void reverse(size_t l, char *s)
+{
+    size_t i;
+    for (i = 0; i < l >> 1; ++i) { char t = s[i]; s[i] = s[l - 1 - i]; s[l - 1 - i] = t; }
+}
+
+typedef struct { uint64_t x, y; } link_t;
+
+static int put_links(str_t *o, const link_t *a, int n)
+{
+    int k;
+    if (str_reserve(o, o->l + 32 * (size_t)(n + 1) + 8)) return -1;
+    o->s[o->l++] = '\t';
+    for (k = 0; k < n; ++k) o->l += (size_t)sprintf(o->s + o->l, "%lld,%d;", (long long)a[k].x, (int)(int32_t)a[k].y);
+    if (n == 0) o->s[o->l++] = '.';
+    return 0;
+}
+
+int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, FILE *out)
+{
+    walk_t w;
+    str_t s = {0, 0, 0}, cov = {0, 0, 0}, o = {0, 0, 0};
+    link_t *nei[2];
+    uint64_t i, j, nw = (n_seq + 63) / 64;
+    int rc = 0;
+    memset(&w, 0, sizeof(w));
+    w.t = t; w.n_seq = n_seq; w.min_match = min_match;
+    w.used = (uint64_t *)calloc(nw, 8); w.bend = (uint64_t *)calloc(nw, 8); w.visited = (uint64_t *)calloc(nw, 8);
+    w.row_of = (uint32_t *)malloc(n_seq * 4);
+    nei[0] = (link_t *)malloc(t->max_nei * sizeof(link_t)); nei[1] = (link_t *)malloc((t->max_nei + 1) * sizeof(link_t));
+    if (!w.used || !w.bend || !w.visited || !w.row_of || !nei[0] || !nei[1]) { rc = -ENOMEM; goto done; }
+    memset(w.row_of, 0xff, n_seq * 4);
+    for (i = t->n; i-- > 0;) { /* smallest id wins */
+        const fmd_ovlp_rec_t *r = &t->rec[i];
+        if (r->status == 0 && !(r->flags & FMD_OVLP_F_OVERFLOW) && r->k[0] < n_seq) w.row_of[r->k[0]] = (uint32_t)i;
+    }
+    /* unitig_core with start = 0, step = 1 (unitig.c:333-334): seeds are the odd sequence ids */
+    for (j = 0; j <= n_seq >> 2; ++j) {
+        for (i = j << 2 | 1; i < (j << 2) + 4 && i < n_seq; i += 2) {
+            const fmd_ovlp_rec_t *r = &t->rec[i];
+            uint64_t end[2];
+            int n_nei[2] = {0, 0}, n_reads, is_loop = 0, seed_len, k, done_loop = 0;
+            /* ---- unitig1 (unitig.c:274-317) */
+            if (r->flags & FMD_OVLP_F_OVERFLOW) { rc = -ERANGE; goto done; }
+            if (r->len <= min_match) continue;                       /* too short */
+            if (bit_get(w.used, r->rank)) continue;                  /* used */
+            mark_used(&w, r->k);
+            if (r->status != 0) continue;                            /* contained */
+            seed_len = r->len;
+            if (str_reserve(&s, (size_t)seed_len + 1) || str_reserve(&cov, (size_t)seed_len + 1)) { rc = -ENOMEM; goto done; }
+            memcpy(s.s, SEQ(&w, i), (size_t)seed_len); s.l = (size_t)seed_len;
+            memset(cov.s, '"', (size_t)seed_len); cov.l = (size_t)seed_len;
+            n_reads = 1;
+            end[0] = r->k[1]; end[1] = r->k[0];
+            if (r->n_ovlp) { /* left-wards extension of the unitig = right-wards of this strand */
+                int m = unidir(&w, i, &s, &cov, 0, r->k[0], &end[0], &is_loop);
+                if (m < 0) { rc = -ENOMEM; goto done; }
+                n_reads += m;
+                for (k = 0; k < w.n_nei; ++k) { nei[0][k].x = w.nei[k].x[0]; nei[0][k].y = w.nei[k].info; }
+                n_nei[0] = w.n_nei;
+                if (is_loop) { nei[1][0].x = end[0]; nei[1][0].y = w.nei[0].info; n_nei[1] = 1; done_loop = 1; }
+            }
+            if (!done_loop) { /* the other direction, from the reverse strand of the seed (unitig.c:310-315) */
+                int m;
+                revcomp6(s.l, s.s); reverse(cov.l, cov.s);
+                m = unidir(&w, i ^ 1, &s, &cov, (int)s.l - seed_len, r->k[1], &end[1], &is_loop);
+                if (m < 0) { rc = -ENOMEM; goto done; }
+                n_reads += m;
+                for (k = 0; k < w.n_nei; ++k) { nei[1][k].x = w.nei[k].x[0]; nei[1][k].y = w.nei[k].info; }
+                n_nei[1] = w.n_nei;
+            }
+            /* ---- unitig_core: keep each unitig once (unitig.c:336-339) */
+            if (bit_get(w.visited, end[0])) continue;
+            bit_set(w.visited, end[0]);
+            if (bit_get(w.visited, end[1])) continue;
+            bit_set(w.visited, end[1]);
+            /* ---- mag_v_write (mag.c:149-174) */
+            o.l = 0;
+            if (str_reserve(&o, 2 * s.l + 128)) { rc = -ENOMEM; goto done; }
+            o.l += (size_t)sprintf(o.s + o.l, "@%lld:%lld\t%d", (long long)end[0], (long long)end[1], n_reads);
+            if (put_links(&o, nei[0], n_nei[0]) || put_links(&o, nei[1], n_nei[1])) { rc = -ENOMEM; goto done; }
+            if (str_reserve(&o, o.l + 2 * s.l + 8)) { rc = -ENOMEM; goto done; }
+            o.s[o.l++] = '\n';
+            for (k = 0; k < (int)s.l; ++k) o.s[o.l++] = "ACGT"[(int)s.s[k] - 1];
+            memcpy(o.s + o.l, "\n+\n", 3); o.l += 3;
+            memcpy(o.s + o.l, cov.s, s.l); o.l += s.l;
+            o.s[o.l++] = '\n';
+            if (fwrite(o.s, 1, o.l, out) != o.l) { rc = -EIO; goto done; }
+        }
+    }
+done:
+    free(w.used); free(w.bend); free(w.visited); free(w.row_of); free(nei[0]); free(nei[1]);
+    free(s.s); free(cov.s); free(o.s);
+    return rc;
+}

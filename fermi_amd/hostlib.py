@@ -20,6 +20,12 @@ def lib():
         L.fmdh_write_rld_from_bwt.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p]
         L.fmdh_trim_palindrome.restype = C.c_uint32
         L.fmdh_trim_palindrome.argtypes = [C.c_void_p, C.c_uint32]
+        class Table(C.Structure):
+            _fields_ = [("n", C.c_uint64), ("max_nei", C.c_uint32), ("seq_stride", C.c_uint32),
+                        ("rec", C.c_void_p), ("nei", C.c_void_p), ("seq", C.c_void_p)]
+        L.Table = Table
+        L.fmdh_unitig_walk.argtypes = [C.POINTER(Table), C.c_uint64, C.c_int, C.c_void_p]
+        L.fmdh_unitig.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -51,3 +57,33 @@ def write_rld_from_bwt(bwt, path):
 def trim_palindrome(seq):
     seq = np.ascontiguousarray(seq, dtype=np.uint8)
     return int(lib().fmdh_trim_palindrome(seq.ctypes.data, len(seq)))
+
+
+_libc = C.CDLL(None)
+_libc.fopen.restype = C.c_void_p
+_libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+_libc.fclose.argtypes = [C.c_void_p]
+
+
+def unitig_walk(rec, nei, seq, n_seq, min_match, out_path):
+    """Replay the `fermi unitig -t1` walk over a per-id overlap table; writes MAG records to out_path."""
+    L = lib()
+    rec = np.ascontiguousarray(rec); nei = np.ascontiguousarray(nei); seq = np.ascontiguousarray(seq)
+    t = L.Table(len(rec), nei.shape[1], seq.shape[1], rec.ctypes.data, nei.ctypes.data, seq.ctypes.data)
+    fp = _libc.fopen(out_path.encode(), b"wb")
+    try:
+        _chk(L.fmdh_unitig_walk(C.byref(t), n_seq, min_match, fp), "unitig_walk")
+    finally:
+        _libc.fclose(fp)
+
+
+def unitig(fmd_path, min_match, out_path, device=0):
+    """`fermi-amd unitig -l min_match fmd_path > out_path` (GPU)."""
+    L = lib()
+    fp = _libc.fopen(out_path.encode(), b"wb")
+    try:
+        rc = L.fmdh_unitig(fmd_path.encode(), device, min_match, fp)
+    finally:
+        _libc.fclose(fp)
+    if rc:
+        raise RuntimeError("fmdh_unitig failed")

@@ -132,7 +132,8 @@ typedef struct {
     int32_t ext_len;   /* bases fm6_get_nei appended to the sequence */
     int32_t n_nei;     /* irreducible neighbours found */
     uint32_t flags;    /* FMD_OVLP_F_* */
-    uint32_t reserved;
+    uint32_t reserved; /* check_left_simple (unitig.c:186) for the edge to the unique neighbour:
+                          0 = passes, 1 = potential backward bifurcation (-1), 2 = not applicable */
 } fmd_ovlp_rec_t;      /* 64 bytes */
 /* capacity of the per-strand candidate lists kept in the work area */
 static inline uint32_t fmd_ovlp_list_cap(uint32_t max_len, int min_match)

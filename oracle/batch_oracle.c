@@ -69,7 +69,7 @@ static void *ov_worker(void *d)
         orc_intv_t intv;
         int len = 0, ret;
         memset(r, 0, sizeof(*r));
-        r->rbeg = -1;
+        r->rbeg = -1; r->reserved = 2;
         r->rank = (uint64_t)orc_retrieve(w->e, w->ids[i], s.s, (int)s.m - 1, &len);
         orc_reverse(len, s.s);
         s.n = (size_t)len; s.s[len] = 0;
@@ -88,6 +88,10 @@ static void *ov_worker(void *d)
             for (j = 0; j < nei.n && j < w->max_nei; ++j) w->nei[i * w->max_nei + j] = nei.a[j];
             if (w->seq)
                 for (j = (size_t)len; j < s.n && j < w->seq_stride; ++j) w->seq[i * (size_t)w->seq_stride + j] = s.s[j];
+            /* rec.reserved: check_left_simple for the edge to a unique neighbour (0 / 1), else 2 */
+            r->reserved = 2;
+            if (nei.n == 1 && r->rbeg >= 0)
+                r->reserved = orc_check_left_simple(w->e, w->min_match, 0, r->rbeg, s.s, (int)s.n) < 0 ? 1 : 0;
         }
     }
     free(a0.a); free(a1.a); free(nei.a); free(s.s);

@@ -376,6 +376,29 @@ int orc_get_nei(const orc_rld_t *e, int min_match, int beg, orc_str_t *s, orc_in
     return rbeg;
 }
 
+
+/* unitig.c:186-204 (check_left_simple) with used == NULL: 0, or -1 on a potential backward
+ * bifurcation.  s = unitig so far (len bases), the terminal read starts at beg, its neighbour at rbeg. */
+int orc_check_left_simple(const orc_rld_t *e, int min_match, int beg, int rbeg, const uint8_t *s, int len)
+{
+    orc_intv_v a = {0, 0, 0}, b = {0, 0, 0}, *prev = &a, *curr = &b, *t;
+    orc_intv_t ok[6];
+    int i, ret = 0;
+    size_t j;
+    overlap_intv(e, len, s, min_match, rbeg, 1, prev, 1);
+    for (i = rbeg - 1; i >= beg && ret == 0; --i) {
+        for (j = 0, curr->n = 0; j < prev->n; ++j) {
+            orc_intv_t *p = &prev->a[j];
+            orc_extend(e, p, ok, 1);
+            if (ok[0].x[2] + ok[s[i]].x[2] != p->x[2]) { ret = -1; break; }
+            vec_push(curr, &ok[s[i]]);
+        }
+        t = curr; curr = prev; prev = t;
+    }
+    free(a.a); free(b.a);
+    return ret;
+}
+
 /* ---- correct.c:35-87 -------------------------------------------------------------------- */
 
 void orc_ec_collect(const orc_rld_t *e, int w, int min_occ, int suf_len, const orc_intv_t *suf_intv,

@@ -258,3 +258,27 @@ def test_smem_vs_oracle_ragged(gpu, tiny_dev, tiny_oracle):
     got = tiny_dev.smem(qs, 0, max_mem=64)
     for q, m in zip(qs, got):
         assert m.tobytes() == tiny_oracle.smem(q, 0).tobytes()
+
+
+@pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20)])
+def test_unitig_cli_equals_fermi_unitig_t1(gpu, gold, tmp_path, name, mm):
+    """`fermi-amd unitig -l mm x.fmd` (GPU overlap table + host walk) == `fermi unitig -t1` bytes."""
+    import subprocess, os
+    from fermi_amd import hostlib
+    out = str(tmp_path / "o.mag")
+    hostlib.unitig(gold.path(name + ".fmd"), mm, out)
+    assert open(out, "rb").read() == gold.text_gz(name + ".mag.gz")
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fermi_amd", "bin", "fermi-amd")
+    if os.path.exists(exe):
+        got = subprocess.run([exe, "unitig", "-l%d" % mm, "-t4", gold.path(name + ".fmd")], stdout=subprocess.PIPE, check=True).stdout
+        assert got == gold.text_gz(name + ".mag.gz")
+
+
+def test_check_left_flags_vs_oracle(gpu, gold, oracle_lib):
+    for name, mm, ml in (("tiny", 50, 100), ("repeat", 20, 80), ("special", 20, 60)):
+        d = gpu.DevIndex.open(gold.path(name + ".fmd")); o = orcbind.OrcIndex(gold.path(name + ".fmd"))
+        ids = np.arange(int(o.mcnt[1]), dtype=U64)
+        g = d.overlap(ids, mm, max_len=ml, max_nei=8); w = o.overlap_batch(ids, mm, max_len=ml, max_nei=8)
+        assert np.array_equal(g[0]["reserved"], w[0]["reserved"]), name
+        assert g[0].tobytes() == w[0].tobytes() and g[1].tobytes() == w[1].tobytes(), name
+        d.close(); o.close()

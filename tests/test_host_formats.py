@@ -43,3 +43,19 @@ def test_trim_palindrome():
     assert f("AACCGGTA") == 8
     assert f("ACGTA") == 5             # odd length never trimmed
     assert f("ANNT") == 4
+
+
+@pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20)])
+def test_unitig_walk_reproduces_fermi_unitig_t1(oracle_lib, gold, tmp_path, name, mm):
+    """Host walk (fermi_amd/host/unitig_walk.c) over the per-read table == `fermi unitig -t1`
+    output, byte for byte.  The table here comes from the oracle (CPU); the GPU test feeds the
+    same walk from fmd_ovlp_*."""
+    o = orcbind.OrcIndex(gold.path(name + ".fmd"))
+    n_seq = int(o.mcnt[1])
+    rec, nei, seq = o.overlap_batch(np.arange(n_seq, dtype=np.uint64), mm, max_len=100, max_nei=8, n_threads=4)
+    out = str(tmp_path / "o.mag")
+    hostlib.unitig_walk(rec, nei, seq, n_seq, mm, out)
+    got = open(out, "rb").read()
+    want = gold.text_gz(name + ".mag.gz")
+    assert got == want
+    o.close()

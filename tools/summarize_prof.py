@@ -50,7 +50,7 @@ for k, v in pr.items():
 for sub in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
     a = pmc(sub)
     for k, v in a.items():
-        if k.startswith(("k_bsearch", "k_ovl", "k_retrieve", "k_smem", "k_kmer")):
+        if any(t in k for t in ("k_bsearch", "k_ovl", "k_retrieve", "k_smem", "k_kmer")):
             for c, vals in v.items():
                 m = sum(vals) / len(vals)
                 extra = ""
