@@ -26,7 +26,7 @@ fermi_amd/lib/libfmdhip.so: $(HIP_OBJS)
 host: fermi_amd/lib/libfmdhost.so
 fermi_amd/lib/libfmdhost.so: $(HOST_SRCS) $(HOST_HDRS) fermi_amd/lib/libfmdhip.so
 	@mkdir -p fermi_amd/lib
-	$(CC) $(CFLAGS) -shared -Iinclude $(HOST_SRCS) -o $@ -Lfermi_amd/lib -lfmdhip -Wl,-rpath,'$$ORIGIN' -lpthread -lm
+	$(CC) $(CFLAGS) -shared -Iinclude $(HOST_SRCS) -o $@ -Lfermi_amd/lib -lfmdhip -Wl,-rpath,'$$ORIGIN' -lpthread -lm -lz
 
 cli: fermi_amd/bin/fermi-amd
 fermi_amd/bin/fermi-amd: fermi_amd/host/main.c fermi_amd/lib/libfmdhost.so fermi_amd/lib/libfmdhip.so

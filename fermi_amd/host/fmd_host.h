@@ -41,6 +41,26 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
  * record overflows), walk, print.  `fermi unitig -l min_match <fn>` (cmd.c:184-216). */
 int fmdh_unitig(const char *fmd_path, int device, int min_match, FILE *out);
 
+/* ---- FASTA/FASTQ input (kseq.h semantics) ---- */
+typedef struct fmdh_seqio fmdh_seqio_t;
+fmdh_seqio_t *fmdh_seq_open(const char *fn);           /* "-" = stdin; gzip transparent */
+int fmdh_seq_read(fmdh_seqio_t *io);                   /* length, -1 = end of file, -2 = bad quality */
+const char *fmdh_seq_name(const fmdh_seqio_t *io);
+char *fmdh_seq_bases(fmdh_seqio_t *io);
+char *fmdh_seq_qual(fmdh_seqio_t *io);                 /* NULL for FASTA */
+void fmdh_seq_close(fmdh_seqio_t *io);
+
+/* `fermi exact [-s] <idx> <src.fa>` (cmd.c:292-331) */
+int fmdh_exact(const char *fmd_path, const char *fa_path, int device, int self_match, FILE *out);
+
+/* `fermi correct` (cmd.c:253-291, correct.c:305-456); defaults = cmd.c:258 */
+typedef struct { int w, min_occ, keep_bad, is_paired, trim_l, step; float max_corr; } fmdh_ecopt_t; /* = fmecopt_t, fermi.h:26-29 */
+int fmdh_correct(const char *fmd_path, const char *fq_path, int device, fmdh_ecopt_t *opt, FILE *out);
+int fmdh_correct_kmer(uint64_t n_symbols);                                   /* automatic k, correct.c:313-318 */
+/* phase 2 only (ec_fix, correct.c:121-256) against an already harvested (bucket, key, val) table */
+int fmdh_correct_reads(const fmdh_ecopt_t *opt, int suf_len, uint64_t n, const uint32_t *bucket, const uint32_t *key,
+                       const uint8_t *val, const char *fq_path, FILE *out);
+
 #ifdef __cplusplus
 }
 #endif

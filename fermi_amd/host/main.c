@@ -28,12 +28,61 @@ static int main_unitig(int argc, char *argv[]) /* cmd.c:184-216 */
     return fmdh_unitig(argv[optind], device, min_match, stdout);
 }
 
+static int main_exact(int argc, char *argv[]) /* cmd.c:292-331 */
+{
+    int c, self_match = 0, device = 0;
+    while ((c = getopt(argc, argv, "Msg:")) >= 0) {
+        switch (c) {
+        case 'M': break;
+        case 's': self_match = 1; break;
+        case 'g': device = atoi(optarg); break;
+        }
+    }
+    if (optind + 2 > argc) { fprintf(stderr, "Usage: fermi-amd exact [-s] [-g GPU] <idxbase.fmd> <src.fa>\n"); return 1; }
+    return fmdh_exact(argv[optind], argv[optind + 1], device, self_match, stdout);
+}
+
+static int main_correct(int argc, char *argv[]) /* cmd.c:253-291 */
+{
+    int c, device = 0;
+    fmdh_ecopt_t opt;
+    opt.w = -1; opt.min_occ = 3; opt.keep_bad = 0; opt.is_paired = 0; opt.max_corr = 0.3f; opt.trim_l = 0; opt.step = 5;
+    while ((c = getopt(argc, argv, "MKt:k:v:O:pC:l:s:g:")) >= 0) {
+        switch (c) {
+        case 'M': case 't': case 'v': break;   /* mmap / threads / verbosity: no effect on the output */
+        case 'K': opt.keep_bad = 1; break;
+        case 'k': opt.w = atoi(optarg); break;
+        case 'O': opt.min_occ = atoi(optarg); break;
+        case 'p': opt.is_paired = 1; break;
+        case 'C': opt.max_corr = (float)atof(optarg); break;
+        case 'l': opt.trim_l = atoi(optarg); break;
+        case 's': opt.step = atoi(optarg); break;
+        case 'g': device = atoi(optarg); break;
+        }
+    }
+    if (optind + 2 > argc) {
+        fprintf(stderr, "\nUsage:   fermi-amd correct [options] <reads.fmd> <reads.fq>\n\n");
+        fprintf(stderr, "Options: -k INT      k-mer length; -1 for auto [%d]\n", opt.w);
+        fprintf(stderr, "         -O INT      minimum (k+1)-mer occurrences [%d]\n", opt.min_occ);
+        fprintf(stderr, "         -C FLOAT    max fraction of corrected bases [%.2f]\n", opt.max_corr);
+        fprintf(stderr, "         -l INT      trim read down to INT bp; 0 to disable [0]\n");
+        fprintf(stderr, "         -s INT      step size for the jumping heuristic; 0 to disable [%d]\n", opt.step);
+        fprintf(stderr, "         -K          keep bad/unfixable reads\n");
+        fprintf(stderr, "         -p          paired-end reads (interleaved)\n");
+        fprintf(stderr, "         -g INT      GPU to use [0]\n\n");
+        return 1;
+    }
+    return fmdh_correct(argv[optind], argv[optind + 1], device, &opt, stdout);
+}
+
 int main(int argc, char *argv[])
 {
     if (argc < 2) {
         fprintf(stderr, "\nProgram: fermi-amd (FMD-index hot path of fermi on AMD MI355X)\n\n");
         fprintf(stderr, "Usage:   fermi-amd <command> [arguments]\n\n");
-        fprintf(stderr, "Command: unitig     construct unitigs (fermi unitig)\n\n");
+        fprintf(stderr, "Command: unitig     construct unitigs (fermi unitig)\n");
+        fprintf(stderr, "         correct    error correction (fermi correct)\n");
+        fprintf(stderr, "         exact      find super-maximal exact matches (fermi exact)\n\n");
         return 1;
     }
     if (fmd_device_count() <= 0) {
@@ -41,6 +90,8 @@ int main(int argc, char *argv[])
         return 1;
     }
     if (strcmp(argv[1], "unitig") == 0) return main_unitig(argc - 1, argv + 1);
+    if (strcmp(argv[1], "exact") == 0) return main_exact(argc - 1, argv + 1);
+    if (strcmp(argv[1], "correct") == 0) return main_correct(argc - 1, argv + 1);
     fprintf(stderr, "[E::main] unrecognized command `%s'\n", argv[1]);
     return 1;
 }

@@ -1,0 +1,79 @@
+/* seqio.c -- FASTA/FASTQ reader (plain or gzip) with the record semantics of the reader fermi uses
+ * (kseq.h:171-210): a record starts at '>' or '@'; the name ends at the first white space; the
+ * sequence may span lines and ends at the next '>', '@' or '+'; after '+' the quality has as many
+ * characters as the sequence. */
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+#include "fmd_host.h"
+
+struct fmdh_seqio {
+    gzFile fp;
+    unsigned char buf[1 << 16];
+    int beg, end, eof, last_char;
+    char *name, *seq, *qual;
+    size_t name_l, name_m, seq_l, seq_m, qual_l, qual_m;
+};
+
+static int io_getc(fmdh_seqio_t *io)
+{
+    if (io->beg >= io->end) {
+        if (io->eof) return -1;
+        io->beg = 0;
+        io->end = gzread(io->fp, io->buf, sizeof(io->buf));
+        if (io->end <= 0) { io->eof = 1; io->end = 0; return -1; }
+    }
+    return io->buf[io->beg++];
+}
+static void put(char **s, size_t *l, size_t *m, int c)
+{
+    if (*l + 2 > *m) { *m = *m ? *m << 1 : 256; *s = (char *)realloc(*s, *m); }
+    (*s)[(*l)++] = (char)c; (*s)[*l] = 0;
+}
+
+fmdh_seqio_t *fmdh_seq_open(const char *fn)
+{
+    fmdh_seqio_t *io = (fmdh_seqio_t *)calloc(1, sizeof(*io));
+    io->fp = strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(0, "r");
+    if (!io->fp) { free(io); return 0; }
+    put(&io->name, &io->name_l, &io->name_m, 0); io->name_l = 0;
+    put(&io->seq, &io->seq_l, &io->seq_m, 0); io->seq_l = 0;
+    put(&io->qual, &io->qual_l, &io->qual_m, 0); io->qual_l = 0;
+    return io;
+}
+void fmdh_seq_close(fmdh_seqio_t *io)
+{
+    if (!io) return;
+    gzclose(io->fp); free(io->name); free(io->seq); free(io->qual); free(io);
+}
+const char *fmdh_seq_name(const fmdh_seqio_t *io) { return io->name; }
+char *fmdh_seq_bases(fmdh_seqio_t *io) { return io->seq; }
+char *fmdh_seq_qual(fmdh_seqio_t *io) { return io->qual_l ? io->qual : 0; }
+
+int fmdh_seq_read(fmdh_seqio_t *io) /* sequence length, -1 at end of file, -2 on a truncated quality */
+{
+    int c;
+    if (io->last_char == 0) {
+        while ((c = io_getc(io)) != -1 && c != '>' && c != '@') {}
+        if (c == -1) return -1;
+        io->last_char = c;
+    }
+    io->name_l = io->seq_l = io->qual_l = 0; io->name[0] = io->seq[0] = io->qual[0] = 0;
+    while ((c = io_getc(io)) != -1 && c != ' ' && c != '\t' && c != '\n' && c != '\r') put(&io->name, &io->name_l, &io->name_m, c);
+    if (c == -1 && io->name_l == 0) return -1;
+    if (c != '\n') while ((c = io_getc(io)) != -1 && c != '\n') {} /* comment */
+    while ((c = io_getc(io)) != -1 && c != '>' && c != '+' && c != '@') {
+        if (c == '\n' || c == '\r') continue;
+        put(&io->seq, &io->seq_l, &io->seq_m, c);
+        while ((c = io_getc(io)) != -1 && c != '\n') if (c != '\r') put(&io->seq, &io->seq_l, &io->seq_m, c);
+    }
+    if (c == '>' || c == '@') io->last_char = c;
+    if (c != '+') { if (c == -1) io->last_char = 0; return (int)io->seq_l; }
+    while ((c = io_getc(io)) != -1 && c != '\n') {}
+    if (c == -1) return -2;
+    while (io->qual_l < io->seq_l && (c = io_getc(io)) != -1)
+        if (c != '\n' && c != '\r') put(&io->qual, &io->qual_l, &io->qual_m, c);
+    io->last_char = 0;
+    if (io->qual_l != io->seq_l) return -2;
+    return (int)io->seq_l;
+}

@@ -284,3 +284,23 @@ def test_check_left_flags_vs_oracle(gpu, gold, oracle_lib):
             assert np.array_equal(g[0][f], w[0][f]), (name, f)
         assert g[1].tobytes() == w[1].tobytes(), name
         d.close(); o.close()
+
+
+def _cli(*args):
+    import subprocess, os
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fermi_amd", "bin", "fermi-amd")
+    assert os.path.exists(exe), "fermi-amd is not built (make cli)"
+    return subprocess.run([exe] + list(args), stdout=subprocess.PIPE, check=True).stdout
+
+
+def test_exact_cli_equals_fermi_exact(gpu, gold, tmp_path):
+    """`fermi-amd exact [-s]` == `fermi exact [-s]` bytes (SMEMs on the GPU, printing on the host)."""
+    fq = str(tmp_path / "tiny.fq")
+    open(fq, "wb").write(gold.text_gz("tiny.fq.gz"))
+    assert _cli("exact", gold.path("tiny.fmd"), fq) == gold.text_gz("tiny.exact.gz")
+    assert _cli("exact", "-s", gold.path("tiny.fmd"), gold.path("tiny.fq.gz")) == gold.text_gz("tiny.exact_s.gz")
+
+
+def test_correct_cli_equals_fermi_correct(gpu, gold):
+    """`fermi-amd correct` == `fermi correct -t1` bytes: GPU k-mer harvest + host ec_fix."""
+    assert _cli("correct", "-t4", gold.path("tiny.fmd"), gold.path("tiny.fq.gz")) == gold.text_gz("tiny.ec.fq.gz")
