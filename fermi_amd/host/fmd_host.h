@@ -53,6 +53,9 @@ void fmdh_seq_close(fmdh_seqio_t *io);
 /* `fermi exact [-s] <idx> <src.fa>` (cmd.c:292-331) */
 int fmdh_exact(const char *fmd_path, const char *fa_path, int device, int self_match, FILE *out);
 
+/* `fermi build -o out.fmd <in.fa>` (cmd.c:378-484); no_fr = trim palindromes (default 1) */
+int fmdh_build(const char *fa_path, const char *out_path, int device, int max_len, int no_fr);
+
 /* `fermi correct` (cmd.c:253-291, correct.c:305-456); defaults = cmd.c:258 */
 typedef struct { int w, min_occ, keep_bad, is_paired, trim_l, step; float max_corr; } fmdh_ecopt_t; /* = fmecopt_t, fermi.h:26-29 */
 int fmdh_correct(const char *fmd_path, const char *fq_path, int device, fmdh_ecopt_t *opt, FILE *out);

@@ -28,6 +28,38 @@ static int main_unitig(int argc, char *argv[]) /* cmd.c:184-216 */
     return fmdh_unitig(argv[optind], device, min_match, stdout);
 }
 
+static int main_build(int argc, char *argv[]) /* cmd.c:378-484 */
+{
+    int c, force = 0, max_len = 0x7fffffff, no_fr = 1, device = 0;
+    const char *out = "-";
+    while ((c = getopt(argc, argv, "fb:o:i:s:l:Og:")) >= 0) {
+        switch (c) {
+        case 'f': force = 1; break;
+        case 'o': out = optarg; break;
+        case 'l': max_len = atoi(optarg); break;
+        case 'O': no_fr = 0; break;
+        case 's': break;   /* symbols per SA-IS block: the GPU sorts everything at once */
+        case 'g': device = atoi(optarg); break;
+        case 'b': if (atoi(optarg) != 3) { fprintf(stderr, "[E::%s] only -b 3 is supported\n", __func__); return 1; } break;
+        case 'i': fprintf(stderr, "[E::%s] -i (append to an index) is not supported\n", __func__); return 1;
+        }
+    }
+    if (argc == optind) {
+        fprintf(stderr, "\nUsage:   fermi-amd build [options] <in.fa>\n\n");
+        fprintf(stderr, "Options: -f        force to overwrite the output file (effective with -o)\n");
+        fprintf(stderr, "         -l INT    trim read down to INT bp [inf]\n");
+        fprintf(stderr, "         -o FILE   output file name [stdout]\n");
+        fprintf(stderr, "         -O        do not trim 1bp for reads whose forward and reverse are identical\n");
+        fprintf(stderr, "         -g INT    GPU to use [0]\n\n");
+        return 1;
+    }
+    if (strcmp(out, "-") && !force) {
+        FILE *fp = fopen(out, "rb");
+        if (fp) { fclose(fp); fprintf(stderr, "[E::%s] File `%s' exists. Please use `-f' to overwrite.\n", __func__, out); return 1; }
+    }
+    return fmdh_build(argv[optind], out, device, max_len, no_fr);
+}
+
 static int main_exact(int argc, char *argv[]) /* cmd.c:292-331 */
 {
     int c, self_match = 0, device = 0;
@@ -80,7 +112,8 @@ int main(int argc, char *argv[])
     if (argc < 2) {
         fprintf(stderr, "\nProgram: fermi-amd (FMD-index hot path of fermi on AMD MI355X)\n\n");
         fprintf(stderr, "Usage:   fermi-amd <command> [arguments]\n\n");
-        fprintf(stderr, "Command: unitig     construct unitigs (fermi unitig)\n");
+        fprintf(stderr, "Command: build      generate the FMD-index (fermi build)\n");
+        fprintf(stderr, "         unitig     construct unitigs (fermi unitig)\n");
         fprintf(stderr, "         correct    error correction (fermi correct)\n");
         fprintf(stderr, "         exact      find super-maximal exact matches (fermi exact)\n\n");
         return 1;
@@ -90,6 +123,7 @@ int main(int argc, char *argv[])
         return 1;
     }
     if (strcmp(argv[1], "unitig") == 0) return main_unitig(argc - 1, argv + 1);
+    if (strcmp(argv[1], "build") == 0) return main_build(argc - 1, argv + 1);
     if (strcmp(argv[1], "exact") == 0) return main_exact(argc - 1, argv + 1);
     if (strcmp(argv[1], "correct") == 0) return main_correct(argc - 1, argv + 1);
     fprintf(stderr, "[E::main] unrecognized command `%s'\n", argv[1]);

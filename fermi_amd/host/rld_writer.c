@@ -150,7 +150,7 @@ static int finish_and_dump(writer_t *s, const char *path)
         for (k = 1; k < n_frames; ++k)
             if (frame[k * 7] == 0) memcpy(frame + k * 7, frame + (k - 1) * 7, 56);
     }
-    fp = fopen(path, "wb");
+    fp = strcmp(path, "-") ? fopen(path, "wb") : stdout; /* "-" = stdout, like rld_dump (rld.c:248) */
     if (!fp) { free(frame); return -errno; }
     {
         const uint32_t a = 6u << 16 | 3u;
@@ -161,7 +161,7 @@ static int finish_and_dump(writer_t *s, const char *path)
         fwrite(frame, 56, n_frames, fp);
     }
     rc = ferror(fp) ? -EIO : 0;
-    fclose(fp);
+    if (fp != stdout) fclose(fp); else fflush(fp);
     free(frame);
     return rc;
 }

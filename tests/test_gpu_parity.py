@@ -304,3 +304,11 @@ def test_exact_cli_equals_fermi_exact(gpu, gold, tmp_path):
 def test_correct_cli_equals_fermi_correct(gpu, gold):
     """`fermi-amd correct` == `fermi correct -t1` bytes: GPU k-mer harvest + host ec_fix."""
     assert _cli("correct", "-t4", gold.path("tiny.fmd"), gold.path("tiny.fq.gz")) == gold.text_gz("tiny.ec.fq.gz")
+
+
+@pytest.mark.parametrize("name", ["tiny", "special", "repeat"])
+def test_build_cli_equals_fermi_build(gpu, gold, tmp_path, name):
+    """`fermi-amd build -fo x.fmd reads.fq` writes the file `fermi build` wrote, byte for byte."""
+    out = str(tmp_path / "x.fmd")
+    _cli("build", "-fo", out, gold.path(name + ".fq.gz"))
+    assert open(out, "rb").read() == open(gold.path(name + ".fmd"), "rb").read()
