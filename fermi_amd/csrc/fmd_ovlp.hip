@@ -197,8 +197,29 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
         if (st == WK_IDLE) continue;
 
         int c = c_pend;
-        bool have_base = st == WK_EXT;
-        if (st == WK_LF || st == WK_BOTH) { // LF step at row k: base = BWT[k], k' = cnt[c] + rank_c(k) - 1
+        // Narrow interval (size <= 63, i.e. all but the first ~log4(n) bases): everything comes from ONE
+        // 64-position window of BWT[x0, x0+size) read out of the lane's block image -- the six child
+        // sizes, the base at row k (k lies inside the window) and rank_c(k) -- plus ONE absolute rank
+        // of ONE symbol, rank_c(x0-1).  ~150 VALU instead of two full six-symbol block ranks (~600).
+        const bool narrow = st == WK_BOTH && sz <= 63;
+        uint64_t ws[6] = {0, 0, 0, 0, 0, 0}, wtk = 0;
+        if (narrow) {
+            const uint32_t bk_ = (uint32_t)((x0 - 1) >> FMD_BLK_SHIFT), bl_ = (uint32_t)((x0 - 1 + sz) >> FMD_BLK_SHIFT);
+            const bool sep = bl_ != bk_;
+            const uint64_t gw = x0 >> 5; const uint32_t sh = (uint32_t)x0 & 31;
+            const uint4 a = grp_chunk(r.bk, r.t, r.bl, r.tl, bk_, bl_, sep, gw), b = grp_chunk(r.bk, r.t, r.bl, r.tl, bk_, bl_, sep, gw + 1),
+                        cc = grp_chunk(r.bk, r.t, r.bl, r.tl, bk_, bl_, sep, gw + 2);
+            const uint64_t m = bits_below((int)sz);
+            const uint64_t X = win64(a.x, b.x, cc.x, sh), Y = win64(a.y, b.y, cc.y, sh), Z = win64(a.z, b.z, cc.z, sh);
+            const uint64_t lo = ~Z & m, hi = Z & ~Y & m;
+            const uint64_t M0 = lo & ~Y & ~X, M1 = lo & ~Y & X, M2 = lo & Y & ~X, M3 = lo & Y & X, M4 = hi & ~X, M5 = hi & X;
+            ws[0] = __popcll(M0); ws[1] = __popcll(M1); ws[2] = __popcll(M2); ws[3] = __popcll(M3); ws[4] = __popcll(M4); ws[5] = __popcll(M5);
+            const uint32_t o = (uint32_t)(k - x0);                       // row k inside the window
+            c = (int)(((X >> o) & 1) | ((Y >> o) & 1) << 1 | ((Z >> o) & 1) << 2);
+            wtk = fmd_block_rank1(r.bk, r.t, r.nk, c);                    // rank_c(x0 - 1)
+            const uint64_t Mc = sel6(c, M0, M1, M2, M3, M4, M5);
+            k = ix.cnt[c] + wtk + __popcll(Mc & bits_below((int)o + 1)) - 1;
+        } else if (st == WK_LF || st == WK_BOTH) { // LF step at row k: base = BWT[k], k' = cnt[c] + rank_c(k) - 1
             const bool in_k = st == WK_LF || (uint32_t)(k >> FMD_BLK_SHIFT) == (uint32_t)((x0 - 1) >> FMD_BLK_SHIFT);
             const uint4 *img = in_k ? r.bk : r.bl;
             const uint32_t off = (uint32_t)k & 255;
@@ -207,7 +228,6 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             const uint32_t bit = off & 31;
             c = (int)(((v.x >> bit) & 1) | ((v.y >> bit) & 1) << 1 | ((v.z >> bit) & 1) << 2);
             k = ix.cnt[c] + fmd_block_rank1(img, tt, off + 1, c) - 1;
-            have_base = true;
             if (st == WK_LF && depth > 0) { c_pend = c; st = WK_EXT; continue; } // the extension needs its own gather
         }
         if (depth == 0) { // first LF step: the last base of the sequence, or an empty sequence
@@ -221,12 +241,17 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             x0 = ix.cnt[c]; x1 = ix.cnt[comp6(c)]; sz = ix.cnt[c + 1] - ix.cnt[c];
             pack = (uint32_t)c; depth = 1;
         } else if (st == WK_EXT || st == WK_BOTH) {
-            uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tl[6] = {0, 0, 0, 0, 0, 0};
-            if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
-            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
-            uint64_t s[6];
+            uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, s[6];
+            if (narrow) { // only tk[c] is ever read below
 #pragma unroll
-            for (int a = 0; a < 6; ++a) s[a] = tl[a] - tk[a];
+                for (int a = 0; a < 6; ++a) { s[a] = ws[a]; tk[a] = wtk; }
+            } else {
+                uint64_t tl[6] = {0, 0, 0, 0, 0, 0};
+                if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
+                if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
+#pragma unroll
+                for (int a = 0; a < 6; ++a) s[a] = tl[a] - tk[a];
+            }
             if (c != 0) { // one more base: overlap_intv's loop body (unitig.c:47-59)
                 const uint64_t sc = sel6(c, s[0], s[1], s[2], s[3], s[4], s[5]);
                 // (sc == 0 cannot happen: the sequence itself is in the index)
@@ -289,7 +314,6 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             const uint32_t bk_ = (uint32_t)((x0 - 1) >> FMD_BLK_SHIFT), bl_ = (uint32_t)((x0 - 1 + sz) >> FMD_BLK_SHIFT), bq = (uint32_t)(k >> FMD_BLK_SHIFT);
             st = (bq == bk_ || bq == bl_) ? WK_BOTH : WK_LF;
         }
-        (void)have_base;
     }
 }
 

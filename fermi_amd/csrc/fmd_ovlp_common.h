@@ -40,6 +40,32 @@ __device__ __forceinline__ void store_entry(fmd_intv_t *e, uint64_t x0, uint64_t
     q[1] = make_uint4((uint32_t)sz, (uint32_t)(sz >> 32), (uint32_t)info, (uint32_t)(info >> 32));
 }
 
+// ---- 64-position window over a lane's block images (used when an SA interval is narrower than 64)
+__device__ __forceinline__ uint64_t bits_below(int j) { return j >= 64 ? ~0ull : ((1ull << j) - 1); }
+
+// Chunk (three bit-plane words) holding global 32-position word `gw`, from the lane's block images:
+// slot SK holds block blk_k, slot SL holds blk_l when has_l.  Words of other blocks read as zero
+// (they are masked out by the callers' range masks).
+__device__ __forceinline__ uint4 grp_chunk(const uint4 *img_k, int t_k, const uint4 *img_l, int t_l, uint32_t blk_k, uint32_t blk_l,
+                                           bool has_l, uint64_t gw)
+{
+    const uint32_t blk = (uint32_t)(gw >> 3);
+    const bool in_k = blk == blk_k, in_l = has_l && blk == blk_l;
+    uint4 v = in_k ? img_k[((int)gw & 7) ^ t_k] : img_l[((int)gw & 7) ^ t_l];
+    if (!in_k && !in_l) v = make_uint4(0, 0, 0, 0);
+    return v;
+}
+__device__ __forceinline__ uint64_t win64(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t sh)
+{
+    const uint64_t lo = ((uint64_t)w1 << 32 | w0) >> sh;
+    return sh ? lo | (uint64_t)w2 << (64 - sh) : lo;
+}
+__device__ __forceinline__ uint64_t range64(uint32_t a, uint32_t b) // bits [a, b), b <= 64
+{
+    return bits_below((int)b) & ~bits_below((int)a);
+}
+
+
 // work list of strand indices for one get_nei kernel class: [0] = count, then the indices
 struct FmdOvlClasses {
     uint32_t *n16, *l16;     // strands with <= 16 candidates and small intervals

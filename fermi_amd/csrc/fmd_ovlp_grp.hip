@@ -67,30 +67,6 @@ __global__ void k_ovl_classify(size_t n, const fmd_ovlp_rec_t *__restrict__ rec,
 }
 
 // ------------------------------------------------------------------------------ the kernel
-__device__ __forceinline__ uint64_t bits_below(int j) { return j >= 64 ? ~0ull : ((1ull << j) - 1); }
-
-// Chunk (three bit-plane words) holding global 32-position word `gw`, from the lane's block images:
-// slot SK holds block blk_k, slot SL holds blk_l when has_l.  Words of other blocks read as zero
-// (they are masked out by the callers' range masks).
-__device__ __forceinline__ uint4 grp_chunk(const uint4 *img_k, int t_k, const uint4 *img_l, int t_l, uint32_t blk_k, uint32_t blk_l,
-                                           bool has_l, uint64_t gw)
-{
-    const uint32_t blk = (uint32_t)(gw >> 3);
-    const bool in_k = blk == blk_k, in_l = has_l && blk == blk_l;
-    uint4 v = in_k ? img_k[((int)gw & 7) ^ t_k] : img_l[((int)gw & 7) ^ t_l];
-    if (!in_k && !in_l) v = make_uint4(0, 0, 0, 0);
-    return v;
-}
-__device__ __forceinline__ uint64_t win64(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t sh)
-{
-    const uint64_t lo = ((uint64_t)w1 << 32 | w0) >> sh;
-    return sh ? lo | (uint64_t)w2 << (64 - sh) : lo;
-}
-__device__ __forceinline__ uint64_t range64(uint32_t a, uint32_t b) // bits [a, b), b <= 64
-{
-    return bits_below((int)b) & ~bits_below((int)a);
-}
-
 template <int G>
 __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
                                                     uint32_t cap, const fmd_intv_t *__restrict__ listA, fmd_ovlp_rec_t *__restrict__ rec,
