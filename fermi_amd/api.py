@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "fmd_dev_malloc", "fmd_memcpy_h2d", "fmd_memcpy_d2h",
     "fmd_smem_work_bytes", "fmd_smem_dev", "fmd_smem_batch",
     "fmd_kmer_work_bytes", "fmd_kmer_collect_dev", "fmd_kmer_collect",
-    "fmd_ovlp_work_bytes", "fmd_ovlp_dev", "fmd_ovlp_batch",
+    "fmd_ovlp_work_bytes", "fmd_ovlp_dev", "fmd_ovlp_batch", "fmd_ovlp_check_left_dev",
 ]
 
 
@@ -89,7 +89,8 @@ def lib():
         L.fmd_memcpy_d2h.argtypes = [vp, vp, sz, vp]
         L.fmd_ovlp_work_bytes.restype = sz; L.fmd_ovlp_work_bytes.argtypes = [sz, C.c_uint32, C.c_int]
         L.fmd_ovlp_dev.argtypes = [vp, vp, sz, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint32, vp, sz]
-        L.fmd_ovlp_batch.argtypes = [vp, sz, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint32]
+        L.fmd_ovlp_batch.argtypes = [vp, sz, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint32, C.c_int]
+        L.fmd_ovlp_check_left_dev.argtypes = [vp, vp, sz, C.c_int, C.c_uint32, vp, vp, C.c_uint32, vp, sz]
         L.fmd_kmer_work_bytes.restype = sz; L.fmd_kmer_work_bytes.argtypes = [C.c_uint64]
         L.fmd_kmer_collect_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, sz, C.c_uint64, vp, vp, vp, vp]
         L.fmd_kmer_collect.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64), vp]
@@ -222,13 +223,13 @@ class DevIndex:
         return out, ln.astype(np.int32), rank
 
 
-def _ovlp(self, ids, min_match, max_len=100, max_nei=4):
+def _ovlp(self, ids, min_match, max_len=100, max_nei=4, check_left=True):
     """Per-id overlap records (see include/fmd_hip.h): (rec[OVLP_DT], nei[n, max_nei, INTV_DT], seq[n, 2*max_len])."""
     ids = np.ascontiguousarray(ids, dtype=np.uint64)
     n = len(ids)
     stride = 2 * ((max_len + 3) // 4 * 4)
     rec = np.zeros(n, dtype=OVLP_DT); nei = np.zeros((n, max_nei), dtype=INTV_DT); seq = np.zeros((n, stride), dtype=np.uint8)
-    check(lib().fmd_ovlp_batch(self.h, n, _ptr(ids), min_match, max_len, max_nei, _ptr(rec), _ptr(nei), _ptr(seq), stride))
+    check(lib().fmd_ovlp_batch(self.h, n, _ptr(ids), min_match, max_len, max_nei, _ptr(rec), _ptr(nei), _ptr(seq), stride, int(check_left)))
     return rec, nei, seq
 
 

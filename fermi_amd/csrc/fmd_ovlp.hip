@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void k_ovl_retrieve(FmdIndexView ix, size_t n, 
                 if ((len & 3) && len < stride_r) *(uint32_t *)(srev + sid * (size_t)stride_r + (len & ~3u)) = pack;
                 fmd_ovlp_rec_t *o = rec + sid;
                 o->rank = k; o->k[0] = o->k[1] = o->k[2] = 0;
-                o->len = (int32_t)len; o->status = 0; o->n_ovlp = 0; o->rbeg = -1; o->ext_len = 0; o->n_nei = 0; o->flags = 0; o->reserved = 0;
+                o->len = (int32_t)len; o->status = 0; o->n_ovlp = 0; o->rbeg = -1; o->ext_len = 0; o->n_nei = 0; o->flags = 0; o->reserved = 2;
                 live = false;
             } else {
                 pack |= (uint32_t)c << (8 * (len & 3));
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             if (c == 0) {
                 fmd_ovlp_rec_t *o = rec + sid;
                 o->rank = k; o->k[0] = o->k[1] = o->k[2] = 0; o->len = 0; o->status = -1; o->n_ovlp = 0; o->rbeg = -1;
-                o->ext_len = 0; o->n_nei = 0; o->flags = 0; o->reserved = 0;
+                o->ext_len = 0; o->n_nei = 0; o->flags = 0; o->reserved = 2;
                 st = WK_IDLE;
                 continue;
             }
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             } else { // '$': the sequence is complete (len = depth); these ranks are the left test of fm6_is_contained
                 if ((depth & 3) && depth < stride_r) *(uint32_t *)(srev + sid * (size_t)stride_r + (depth & ~3u)) = pack;
                 fmd_ovlp_rec_t *o = rec + sid;
-                o->rank = k; o->len = (int32_t)depth; o->rbeg = -1; o->ext_len = 0; o->n_nei = 0; o->reserved = 0;
+                o->rank = k; o->len = (int32_t)depth; o->rbeg = -1; o->ext_len = 0; o->n_nei = 0; o->reserved = 2;
                 o->k[0] = o->k[1] = o->k[2] = 0; o->n_ovlp = 0;
                 if (depth > stride_r) { o->status = 0; o->flags = FMD_OVLP_F_OVERFLOW; st = WK_IDLE; continue; } // longer than max_len
                 if ((int)depth <= min_match) { o->status = -1; o->flags = 0; st = WK_IDLE; continue; }         // too short (unitig.c:288)
@@ -709,12 +709,29 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
         // the rest (too many candidates, wide intervals, fake forks, neighbour overflow): lane per strand
         k_ovl_nei<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, listB, d_rec, d_nei, max_nei, d_seq, seq_stride, q2, cl.lslow, cl.nslow);
     }
-    {   // check_left_simple for every strand with a unique neighbour (the lists' HBM areas are free again)
-        uint32_t *q3 = fmd_next_queue(h, st);
-        k_ovl_cls<<<grid, 64, 0, st>>>(ix, n, min_match, cap, listA, listB, d_rec, d_seq, seq_stride, q3);
-    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "overlap kernels"); return FMD_E_HIP; }
+    return FMD_OK;
+}
+
+// check_left_simple (unitig.c:186-204) for every strand of a finished fmd_ovlp_dev batch that has a
+// unique neighbour; writes rec.reserved.  Same buffers and work area as the fmd_ovlp_dev call.
+extern "C" int fmd_ovlp_check_left_dev(fmd_dev_t *h, void *stream_, size_t n, int min_match, uint32_t max_len, fmd_ovlp_rec_t *d_rec,
+                                       const uint8_t *d_seq, uint32_t seq_stride, void *d_work, size_t work_bytes)
+{
+    if (!h || (n && (!d_rec || !d_seq || !d_work)) || max_len == 0) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    if (work_bytes < fmd_ovlp_work_bytes(n, max_len, min_match)) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream_;
+    const uint32_t stride_r = (uint32_t)align_up(max_len, 4);
+    const uint32_t cap = fmd_ovlp_list_cap(max_len, min_match);
+    fmd_intv_t *listA = (fmd_intv_t *)((uint8_t *)d_work + align_up(n * (size_t)stride_r, 256));
+    fmd_intv_t *listB = (fmd_intv_t *)((uint8_t *)listA + align_up(n * (size_t)cap * sizeof(fmd_intv_t), 256));
+    uint32_t *q = fmd_next_queue(h, st);
+    k_ovl_cls<<<fmd_grid_for(h, n), 64, 0, st>>>(fmd_view(h), n, min_match, cap, listA, listB, d_rec, d_seq, seq_stride, q);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fmd_set_hip_error(e, "k_ovl_cls"); return FMD_E_HIP; }
     return FMD_OK;
 }
 
@@ -725,7 +742,7 @@ struct DevBuf2 {
 };
 
 extern "C" int fmd_ovlp_batch(fmd_dev_t *h, size_t n, const uint64_t *ids, int min_match, uint32_t max_len, uint32_t max_nei,
-                              fmd_ovlp_rec_t *rec, fmd_intv_t *nei, uint8_t *seq, uint32_t seq_stride)
+                              fmd_ovlp_rec_t *rec, fmd_intv_t *nei, uint8_t *seq, uint32_t seq_stride, int with_check_left)
 {
     if (!h || (n && (!ids || !rec || !nei || !seq))) return FMD_E_ARG;
     if (n == 0) return FMD_OK;
@@ -744,6 +761,10 @@ extern "C" int fmd_ovlp_batch(fmd_dev_t *h, size_t n, const uint64_t *ids, int m
         int rc = fmd_ovlp_dev(h, nullptr, c, (uint64_t *)di.p, min_match, max_len, max_nei, (fmd_ovlp_rec_t *)dr.p,
                               (fmd_intv_t *)dn.p, (uint8_t *)ds.p, seq_stride, dw.p, wb);
         if (rc) return rc;
+        if (with_check_left) {
+            rc = fmd_ovlp_check_left_dev(h, nullptr, c, min_match, max_len, (fmd_ovlp_rec_t *)dr.p, (uint8_t *)ds.p, seq_stride, dw.p, wb);
+            if (rc) return rc;
+        }
         FMD_HIP_TRY(hipMemcpy(rec + o, dr.p, c * sizeof(fmd_ovlp_rec_t), hipMemcpyDeviceToHost));
         FMD_HIP_TRY(hipMemcpy(nei + o * max_nei, dn.p, c * max_nei * sizeof(fmd_intv_t), hipMemcpyDeviceToHost));
         FMD_HIP_TRY(hipMemcpy(seq + o * (size_t)seq_stride, ds.p, c * (size_t)seq_stride, hipMemcpyDeviceToHost));

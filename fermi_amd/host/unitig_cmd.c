@@ -28,7 +28,7 @@ int fmdh_unitig(const char *fmd_path, int device, int min_match, FILE *out)
         nei = (fmd_intv_t *)calloc(n * max_nei, sizeof(*nei));
         seq = (uint8_t *)calloc(n, stride);
         if (!nei || !seq) { rc = 1; goto done; }
-        rc = fmd_ovlp_batch(d, n, ids, min_match, max_len, max_nei, rec, nei, seq, stride);
+        rc = fmd_ovlp_batch(d, n, ids, min_match, max_len, max_nei, rec, nei, seq, stride, /*check_left*/1);
         if (rc) { fprintf(stderr, "[E::%s] overlap discovery failed: %s\n", __func__, fmd_strerror(rc)); rc = 1; goto done; }
         for (uint64_t i = 0; i < n; ++i) n_over += (rec[i].flags & FMD_OVLP_F_OVERFLOW) != 0;
         if (n_over == 0) {

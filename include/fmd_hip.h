@@ -148,8 +148,13 @@ size_t fmd_ovlp_work_bytes(size_t n, uint32_t max_len, int min_match);
 int fmd_ovlp_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_ids, int min_match, uint32_t max_len,
                  uint32_t max_nei, fmd_ovlp_rec_t *d_rec, fmd_intv_t *d_nei, uint8_t *d_seq, uint32_t seq_stride,
                  void *d_work, size_t work_bytes);
+/* Optional second step over the same buffers: check_left_simple (unitig.c:186-204) for every
+ * strand with a unique neighbour -> rec.reserved (the unitig walk needs it; plain overlap
+ * discovery does not, and records of fmd_ovlp_dev alone carry reserved = 2). */
+int fmd_ovlp_check_left_dev(fmd_dev_t *h, void *stream, size_t n, int min_match, uint32_t max_len, fmd_ovlp_rec_t *d_rec,
+                            const uint8_t *d_seq, uint32_t seq_stride, void *d_work, size_t work_bytes);
 int fmd_ovlp_batch(fmd_dev_t *h, size_t n, const uint64_t *ids, int min_match, uint32_t max_len, uint32_t max_nei,
-                   fmd_ovlp_rec_t *rec, fmd_intv_t *nei, uint8_t *seq, uint32_t seq_stride);
+                   fmd_ovlp_rec_t *rec, fmd_intv_t *nei, uint8_t *seq, uint32_t seq_stride, int with_check_left);
 
 /* ---- k-mer harvest of `fermi correct`: fm6_traverse (exact.c:141) + ec_collect (correct.c:35-87)
  * over ALL 4^suf_len suffix buckets (what worker1 does, correct.c:272-279).  Emits one
