@@ -128,8 +128,8 @@ def overlap_cpu_baseline(fmd_path, ids, min_match, g_rec, g_nei):
         import orcbind
         o = orcbind.OrcIndex(fmd_path)
         n1 = min(n, 20_000)
-        t0 = time.time(); o.overlap_batch(ids[:n1], min_match, 100, g_nei.shape[1], 1); t1 = time.time() - t0
-        t0 = time.time(); rec, nei, _ = o.overlap_batch(ids, min_match, 100, g_nei.shape[1], cores); tall = time.time() - t0
+        t0 = time.time(); o.overlap_batch(ids[:n1], min_match, 100, g_nei.shape[1], 1, check_left=False); t1 = time.time() - t0
+        t0 = time.time(); rec, nei, _ = o.overlap_batch(ids, min_match, 100, g_nei.shape[1], cores, check_left=False); tall = time.time() - t0
         o.close()
         kind = "port"
         ok = rec.tobytes() == g_rec.tobytes() and nei.tobytes() == g_nei.tobytes()
@@ -143,7 +143,7 @@ def overlap_rank_queries_per_strand(fmd_path, min_match, sample=4000):
     import orcbind
     o = orcbind.OrcIndex(fmd_path)
     o.counters()
-    o.overlap_batch(np.arange(sample, dtype=np.uint64), min_match, 100, 4, 1)
+    o.overlap_batch(np.arange(sample, dtype=np.uint64), min_match, 100, 4, 1, check_left=False)
     c = o.counters()
     o.close()
     return c, (c["rank1a"] + c["rank2a"] + c["rank2a_spill"]) / sample

@@ -55,7 +55,7 @@ typedef struct {
 } orc_ovlp_rec_t;
 
 typedef struct { const orc_rld_t *e; size_t n; const uint64_t *ids; int min_match; uint32_t max_nei;
-                 orc_ovlp_rec_t *rec; orc_intv_t *nei; uint8_t *seq; uint32_t seq_stride; int start, step; } ovj_t;
+                 orc_ovlp_rec_t *rec; orc_intv_t *nei; uint8_t *seq; uint32_t seq_stride; int start, step, with_cls; } ovj_t;
 
 static void *ov_worker(void *d)
 {
@@ -90,7 +90,7 @@ static void *ov_worker(void *d)
                 for (j = (size_t)len; j < s.n && j < w->seq_stride; ++j) w->seq[i * (size_t)w->seq_stride + j] = s.s[j];
             /* rec.reserved: check_left_simple for the edge to a unique neighbour (0 / 1), else 2 */
             r->reserved = 2;
-            if (nei.n == 1 && r->rbeg >= 0)
+            if (w->with_cls && nei.n == 1 && r->rbeg >= 0)
                 r->reserved = orc_check_left_simple(w->e, w->min_match, 0, r->rbeg, s.s, (int)s.n) < 0 ? 1 : 0;
         }
     }
@@ -100,13 +100,13 @@ static void *ov_worker(void *d)
 }
 
 void orc_overlap_batch(const orc_rld_t *e, size_t n, const uint64_t *ids, int min_match, uint32_t max_nei,
-                       void *rec, orc_intv_t *nei, uint8_t *seq, uint32_t seq_stride, int n_threads)
+                       void *rec, orc_intv_t *nei, uint8_t *seq, uint32_t seq_stride, int n_threads, int with_check_left)
 {
     pthread_t *tid = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
     ovj_t *w = (ovj_t *)calloc((size_t)n_threads, sizeof(ovj_t));
     int t;
     for (t = 0; t < n_threads; ++t) {
-        ovj_t x = {e, n, ids, min_match, max_nei, (orc_ovlp_rec_t *)rec, nei, seq, seq_stride, t, n_threads};
+        ovj_t x = {e, n, ids, min_match, max_nei, (orc_ovlp_rec_t *)rec, nei, seq, seq_stride, t, n_threads, with_check_left};
         w[t] = x;
         pthread_create(&tid[t], 0, ov_worker, &w[t]);
     }

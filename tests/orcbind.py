@@ -63,7 +63,7 @@ def lib():
         L.orc_is_contained.argtypes = [P, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(IntvV)]
         L.orc_get_nei.restype = C.c_int
         L.orc_get_nei.argtypes = [P, C.c_int, C.c_int, C.POINTER(StrT), C.POINTER(IntvV), C.POINTER(IntvV), C.POINTER(IntvV)]
-        L.orc_overlap_batch.argtypes = [P, C.c_size_t, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+        L.orc_overlap_batch.argtypes = [P, C.c_size_t, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int]
         L.orc_ec_collect.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(SolidT)]
         _lib = L
     return _lib
@@ -193,7 +193,7 @@ class OrcIndex:
                 _libc.free(p)
         return rec
 
-    def overlap_batch(self, ids, min_match, max_len=100, max_nei=4, n_threads=1):
+    def overlap_batch(self, ids, min_match, max_len=100, max_nei=4, n_threads=1, check_left=True):
         """Array form of overlap(): same (rec, nei, seq) triple as fermi_amd.api.DevIndex.overlap."""
         from fermi_amd.api import OVLP_DT
         ids = np.ascontiguousarray(ids, dtype=np.uint64)
@@ -201,7 +201,7 @@ class OrcIndex:
         stride = 2 * ((max_len + 3) // 4 * 4)
         rec = np.zeros(n, dtype=OVLP_DT); nei = np.zeros((n, max_nei), dtype=INTV_DT); seq = np.zeros((n, stride), dtype=np.uint8)
         self.L.orc_overlap_batch(self.e, n, ids.ctypes.data, min_match, max_nei, rec.ctypes.data, nei.ctypes.data,
-                                 seq.ctypes.data, stride, n_threads)
+                                 seq.ctypes.data, stride, n_threads, int(check_left))
         return rec, nei, seq
 
     def ec_collect(self, w, min_occ, suf_len):
