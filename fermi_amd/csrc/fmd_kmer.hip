@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64) void k_kmer_level(FmdIndexView ix, int d, int s
 {
     FMD_DECLARE_WAVE_LDS();
     const int lane = fmd_lane();
-    const uint64_t n = ctr[d];
+    const uint64_t n = ctr[d] < cap ? ctr[d] : cap;   // an overflowing level counted more than it stored
     const uint64_t thr = (d + 1 <= suf_len) ? 1 : (uint64_t)min_occ; // exact.c:159 vs correct.c:78
     const uint64_t stride = (uint64_t)gridDim.x * 64;
     for (uint64_t base = (uint64_t)blockIdx.x * 64; base < n; base += stride) {
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64) void k_kmer_emit(FmdIndexView ix, int w, int su
 {
     FMD_DECLARE_WAVE_LDS();
     const int lane = fmd_lane();
-    const uint64_t n = ctr[w];
+    const uint64_t n = ctr[w] < cap ? ctr[w] : cap;
     const uint64_t stride = (uint64_t)gridDim.x * 64;
     for (uint64_t base = (uint64_t)blockIdx.x * 64; base < n; base += stride) {
         const uint64_t i = base + lane;
