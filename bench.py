@@ -207,6 +207,13 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
                            "traffic": None, "kernel": "k_ovl_retrieve + k_ovl_intv + k_ovl_nei (one step = %d batches)" % ((n_ids + batch - 1) // batch),
                            "kernel_ms": kern_ms, "rank_queries_per_strand": qps, "algorithmic_bytes_per_read": 2 * qps * BYTES_PER_RANK_QUERY,
                            "oracle_counters_on_sample": cnts}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("overlap@%d" % n_reads)
+            if pmc and min_match == 50 and batch == 4000000:
+                out["roofline"]["traffic"] = (pmc["fetch_kb"] * pmc["fetch_calibration"] + pmc["write_kb"]) * 1024.0
+                out["roofline"]["traffic_source"] = pmc["source"]
+        except Exception:
+            pass
         ns = min(n_ids, int(os.environ.get("FMD_BENCH_CPU_SAMPLE_OVLP", "400000")))
         g_nei = nei.cpu().numpy().view(api.INTV_DT).reshape(n_ids, max_nei)
         base, ok = overlap_cpu_baseline(fmd_path, np.arange(ns, dtype=np.uint64), min_match, g_rec[:ns], g_nei[:ns])
