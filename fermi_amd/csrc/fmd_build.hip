@@ -82,6 +82,86 @@ struct DevPtr { void *p = nullptr; ~DevPtr() { if (p) hipFree(p); } };
 #define DALLOC(buf, bytes) do { hipError_t e__ = hipMalloc(&(buf).p, (bytes) ? (bytes) : 16); \
     if (e__ != hipSuccess) { fmd_set_hip_error(e__, "hipMalloc(" #buf ")"); return FMD_E_NOMEM; } } while (0)
 
+
+// ------------------------------------------------------------------ >= 2^32 symbols: bucketed
+// Same ordering, sorted one first-symbol bucket at a time with 64-bit text positions: the suffixes
+// starting with '$' are already in order (sequence id = text order), the others take the LSD passes
+// inside their bucket only.  Peak memory = text + 48 bytes per suffix of the largest bucket.
+struct IsSym { const uint8_t *text; uint8_t c; __device__ bool operator()(const uint64_t &t) const { return text[t] == c; } };
+
+template <class Rem>
+__global__ void k_chunk_keys64(const uint8_t *__restrict__ text, uint64_t m, const uint64_t *__restrict__ ids, int chunk, Rem rem,
+                               uint64_t *__restrict__ keys)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint64_t t = ids[i];
+    const uint32_t r = rem(t), o0 = 21u * (uint32_t)chunk;
+    uint64_t key = 0;
+    if (o0 <= r) {
+        const uint32_t mm = r - o0 + 1 < 21 ? r - o0 + 1 : 21;
+        for (uint32_t j = 0; j < mm; ++j) key |= (uint64_t)text[t + o0 + j] << (3 * (20 - j));
+    }
+    keys[i] = key;
+}
+__global__ void k_emit_bwt64(const uint8_t *__restrict__ text, const uint64_t *__restrict__ ids, uint64_t m, uint8_t *__restrict__ bwt)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint64_t t = ids[i];
+    bwt[i] = t ? text[t - 1] : 0;
+}
+
+static int build_bucketed(hipStream_t st, const uint8_t *text, uint64_t n, uint32_t max_len, int uniform_len, RemRagged rr, uint8_t *bwt)
+{
+    DevPtr cnt;
+    DALLOC(cnt, 8);
+    const int n_chunks = (int)((max_len + 1 + 20) / 21);
+    uint64_t done = 0;
+    for (int c = 0; c < 6; ++c) {
+        // positions of this bucket, ascending
+        size_t tb = 0;
+        hipcub::CountingInputIterator<uint64_t> it(0);
+        IsSym op{text, (uint8_t)c};
+        FMD_HIP_TRY(hipcub::DeviceSelect::If(nullptr, tb, it, (uint64_t *)nullptr, (uint64_t *)cnt.p, (int64_t)n, op, st));
+        // upper bound of the bucket size is not known before selecting: count first
+        uint64_t m = 0;
+        {
+            DevPtr tmp, out;
+            DALLOC(tmp, tb);
+            // count only: select into a scratch of full size would be wasteful; use a reduce via select on a discard iterator
+            hipcub::DiscardOutputIterator<uint64_t> discard;
+            FMD_HIP_TRY(hipcub::DeviceSelect::If(tmp.p, tb, it, discard, (uint64_t *)cnt.p, (int64_t)n, op, st));
+            FMD_HIP_TRY(hipMemcpyAsync(&m, cnt.p, 8, hipMemcpyDeviceToHost, st));
+            FMD_HIP_TRY(hipStreamSynchronize(st));
+        }
+        if (m == 0) continue;
+        DevPtr ids_a, ids_b, keys_a, keys_b, tmp, stmp;
+        DALLOC(ids_a, m * 8);
+        DALLOC(tmp, tb);
+        FMD_HIP_TRY(hipcub::DeviceSelect::If(tmp.p, tb, it, (uint64_t *)ids_a.p, (uint64_t *)cnt.p, (int64_t)n, op, st));
+        uint64_t *cur = (uint64_t *)ids_a.p;
+        if (c != 0) {
+            DALLOC(ids_b, m * 8); DALLOC(keys_a, m * 8); DALLOC(keys_b, m * 8);
+            size_t sb = 0;
+            FMD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sb, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, (uint64_t *)ids_a.p,
+                                                          (uint64_t *)ids_b.p, (size_t)m, 0, 63, st));
+            DALLOC(stmp, sb);
+            uint64_t *nxt = (uint64_t *)ids_b.p;
+            for (int ch = n_chunks - 1; ch >= 0; --ch) {
+                if (uniform_len) k_chunk_keys64<<<nblk(m, 256), 256, 0, st>>>(text, m, cur, ch, RemUniform{max_len + 1}, (uint64_t *)keys_a.p);
+                else k_chunk_keys64<<<nblk(m, 256), 256, 0, st>>>(text, m, cur, ch, rr, (uint64_t *)keys_a.p);
+                FMD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(stmp.p, sb, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, cur, nxt, (size_t)m, 0, 63, st));
+                uint64_t *t = cur; cur = nxt; nxt = t;
+            }
+        }
+        k_emit_bwt64<<<nblk(m, 256), 256, 0, st>>>(text, cur, m, bwt + done);
+        FMD_HIP_TRY(hipStreamSynchronize(st));
+        done += m;
+    }
+    return done == n ? FMD_OK : FMD_E_HIP;
+}
+
 extern "C" void fmd_dev_free(void *d_ptr) { if (d_ptr) hipFree(d_ptr); }
 
 extern "C" int fmd_build_bwt_dev(int device, void *stream_, size_t n_reads, const uint8_t *d_reads, const uint64_t *d_off,
@@ -92,11 +172,10 @@ extern "C" int fmd_build_bwt_dev(int device, void *stream_, size_t n_reads, cons
     FMD_HIP_TRY(hipSetDevice(device));
     hipStream_t st = (hipStream_t)stream_;
     const uint64_t n = 2 * (total_bases + n_reads);
-    if (n >= 0xffffffffull) return FMD_E_ARG; // 32-bit suffix ids in this version
+    const bool bucketed = n >= 0xffffffffull || getenv("FMD_BUILD_BUCKETED") != nullptr; // 32-bit suffix ids in the one-shot path
     DevPtr text, keys_a, keys_b, ord_a, ord_b, send, tmp;
     uint8_t *bwt = nullptr;
     DALLOC(text, n + 64);
-    DALLOC(keys_a, n * 8); DALLOC(keys_b, n * 8); DALLOC(ord_a, n * 4); DALLOC(ord_b, n * 4);
     k_build_text<<<(unsigned)n_reads, 64, 0, st>>>(n_reads, d_reads, d_off, (uint8_t *)text.p);
     RemRagged rr{nullptr, 2 * n_reads};
     if (!uniform_len) {
@@ -104,6 +183,14 @@ extern "C" int fmd_build_bwt_dev(int device, void *stream_, size_t n_reads, cons
         k_seq_ends<<<nblk(n_reads, 256), 256, 0, st>>>(n_reads, d_off, (uint64_t *)send.p);
         rr.send = (const uint64_t *)send.p;
     }
+    if (bucketed) {
+        FMD_HIP_TRY(hipMalloc((void **)&bwt, n + 64));
+        int rc = build_bucketed(st, (const uint8_t *)text.p, n, max_len, uniform_len, rr, bwt);
+        if (rc) { hipFree(bwt); return rc; }
+        *d_bwt_out = bwt; *n_sym_out = n;
+        return FMD_OK;
+    }
+    DALLOC(keys_a, n * 8); DALLOC(keys_b, n * 8); DALLOC(ord_a, n * 4); DALLOC(ord_b, n * 4);
     size_t tmp_bytes = 0;
     FMD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p,
                                                   (uint32_t *)ord_a.p, (uint32_t *)ord_b.p, (size_t)n, 0, 63, st));
@@ -178,34 +265,46 @@ extern "C" int fmd_bwt_to_rle6(int device, const uint8_t *d_bwt, uint64_t n, uin
     if (!d_bwt || !h_rle6 || !n_bytes || n == 0) return FMD_E_ARG;
     if (fmd_device_count() <= 0) return FMD_E_NODEV;
     FMD_HIP_TRY(hipSetDevice(device));
-    DevPtr sym, len, nruns, tmp, nb, start, out;
-    DALLOC(sym, n); DALLOC(len, n * 4); DALLOC(nruns, 8);
-    size_t tb = 0;
-    FMD_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb, d_bwt, (uint8_t *)sym.p, (uint32_t *)len.p, (uint64_t *)nruns.p, (size_t)n));
-    DALLOC(tmp, tb);
-    FMD_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(tmp.p, tb, d_bwt, (uint8_t *)sym.p, (uint32_t *)len.p, (uint64_t *)nruns.p, (size_t)n));
-    uint64_t n_runs = 0;
-    FMD_HIP_TRY(hipMemcpy(&n_runs, nruns.p, 8, hipMemcpyDeviceToHost));
-    DALLOC(nb, n_runs * 8); DALLOC(start, n_runs * 8);
-    k_run_bytes<<<nblk(n_runs, 256), 256>>>((uint32_t *)len.p, n_runs, (uint64_t *)nb.p);
-    { // exclusive scan
-        DevPtr t2; size_t b2 = 0;
-        FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, (uint64_t *)nb.p, (uint64_t *)start.p, (size_t)n_runs));
-        DALLOC(t2, b2);
-        FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(t2.p, b2, (uint64_t *)nb.p, (uint64_t *)start.p, (size_t)n_runs));
-        FMD_HIP_TRY(hipDeviceSynchronize());
+    // chunks of 2^30 symbols: a run cut at a chunk border just becomes two adjacent runs of the same
+    // symbol, which every reader of this stream merges (rld_enc, rld.c:177-184)
+    const uint64_t CH = 1ull << 30;
+    uint8_t *h = nullptr; uint64_t h_n = 0, h_cap = 0;
+    for (uint64_t o = 0; o < n; o += CH) {
+        const uint64_t m = n - o < CH ? n - o : CH;
+        DevPtr sym, len, nruns, tmp, nb, start, out;
+        DALLOC(sym, m); DALLOC(len, m * 4); DALLOC(nruns, 8);
+        size_t tb = 0;
+        FMD_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb, d_bwt + o, (uint8_t *)sym.p, (uint32_t *)len.p, (uint64_t *)nruns.p, (int)m));
+        DALLOC(tmp, tb);
+        FMD_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(tmp.p, tb, d_bwt + o, (uint8_t *)sym.p, (uint32_t *)len.p, (uint64_t *)nruns.p, (int)m));
+        uint64_t n_runs = 0;
+        FMD_HIP_TRY(hipMemcpy(&n_runs, nruns.p, 8, hipMemcpyDeviceToHost));
+        DALLOC(nb, n_runs * 8); DALLOC(start, n_runs * 8);
+        k_run_bytes<<<nblk(n_runs, 256), 256>>>((uint32_t *)len.p, n_runs, (uint64_t *)nb.p);
+        {
+            DevPtr t2; size_t b2 = 0;
+            FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, (uint64_t *)nb.p, (uint64_t *)start.p, (size_t)n_runs));
+            DALLOC(t2, b2);
+            FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(t2.p, b2, (uint64_t *)nb.p, (uint64_t *)start.p, (size_t)n_runs));
+            FMD_HIP_TRY(hipDeviceSynchronize());
+        }
+        uint64_t a = 0, b = 0;
+        FMD_HIP_TRY(hipMemcpy(&a, (uint64_t *)start.p + n_runs - 1, 8, hipMemcpyDeviceToHost));
+        FMD_HIP_TRY(hipMemcpy(&b, (uint64_t *)nb.p + n_runs - 1, 8, hipMemcpyDeviceToHost));
+        const uint64_t total = a + b;
+        DALLOC(out, total);
+        k_run_emit<<<nblk(n_runs, 256), 256>>>((uint8_t *)sym.p, (uint32_t *)len.p, n_runs, (uint64_t *)start.p, (uint8_t *)out.p);
+        if (h_n + total > h_cap) {
+            h_cap = (h_n + total) * (o + m < n ? 2 : 1) + 64;
+            uint8_t *nh = (uint8_t *)realloc(h, h_cap);
+            if (!nh) { free(h); return FMD_E_NOMEM; }
+            h = nh;
+        }
+        hipError_t e = hipMemcpy(h + h_n, out.p, total, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { free(h); fmd_set_hip_error(e, "copy rle6"); return FMD_E_HIP; }
+        h_n += total;
     }
-    uint64_t a = 0, b = 0;
-    FMD_HIP_TRY(hipMemcpy(&a, (uint64_t *)start.p + n_runs - 1, 8, hipMemcpyDeviceToHost));
-    FMD_HIP_TRY(hipMemcpy(&b, (uint64_t *)nb.p + n_runs - 1, 8, hipMemcpyDeviceToHost));
-    const uint64_t total = a + b;
-    DALLOC(out, total);
-    k_run_emit<<<nblk(n_runs, 256), 256>>>((uint8_t *)sym.p, (uint32_t *)len.p, n_runs, (uint64_t *)start.p, (uint8_t *)out.p);
-    uint8_t *h = (uint8_t *)malloc(total);
-    if (!h) return FMD_E_NOMEM;
-    hipError_t e = hipMemcpy(h, out.p, total, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) { free(h); fmd_set_hip_error(e, "copy rle6"); return FMD_E_HIP; }
-    *h_rle6 = h; *n_bytes = total;
+    *h_rle6 = h; *n_bytes = h_n;
     return FMD_OK;
 }
 extern "C" void fmd_host_free(void *p) { free(p); }

@@ -312,3 +312,17 @@ def test_build_cli_equals_fermi_build(gpu, gold, tmp_path, name):
     out = str(tmp_path / "x.fmd")
     _cli("build", "-fo", out, gold.path(name + ".fq.gz"))
     assert open(out, "rb").read() == open(gold.path(name + ".fmd"), "rb").read()
+
+
+def test_bucketed_builder_equals_one_shot(gpu, gold, oracle_lib, monkeypatch):
+    """The >= 2^32-symbol construction path (per-first-symbol buckets, 64-bit positions), forced on
+    small inputs, gives the same BWT as `fermi build`."""
+    from fermi_amd import hostlib
+    monkeypatch.setenv("FMD_BUILD_BUCKETED", "1")
+    for name in ("tiny", "special", "repeat"):
+        reads = gold.fastq_nt6(name + ".fq.gz")
+        reads = [r[:hostlib.trim_palindrome(r)] for r in reads]
+        bwt = gpu.build_bwt(reads)
+        o = orcbind.OrcIndex(gold.path(name + ".fmd"))
+        assert np.array_equal(bwt, o.decode_all()), name
+        o.close()
