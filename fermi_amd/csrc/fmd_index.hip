@@ -455,3 +455,14 @@ int fmd_grid_for(const fmd_dev *h, size_t n_items)
     size_t g = waves_needed < resident ? waves_needed : resident;
     return (int)(g ? g : 1);
 }
+
+int fmd_grid_for_lds(const fmd_dev *h, size_t n_items, size_t lds_bytes)
+{
+    const size_t waves_needed = (n_items + 63) / 64;
+    size_t per_cu = (160 * 1024) / (lds_bytes ? lds_bytes : 1);
+    if (per_cu > 16) per_cu = 16;
+    if (per_cu < 1) per_cu = 1;
+    const size_t resident = (size_t)h->n_cu * per_cu;
+    size_t g = waves_needed < resident ? waves_needed : resident;
+    return (int)(g ? g : 1);
+}

@@ -44,3 +44,5 @@ uint32_t *fmd_next_queue(fmd_dev *h, hipStream_t stream);
 
 // persistent-grid size: waves (= 64-thread workgroups) to launch for n items
 int fmd_grid_for(const fmd_dev *h, size_t n_items);
+// same for a kernel that uses lds_bytes of LDS per 64-thread workgroup (160 KiB per CU)
+int fmd_grid_for_lds(const fmd_dev *h, size_t n_items, size_t lds_bytes);

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const
                                                 uint64_t *__restrict__ d_beg, uint64_t *__restrict__ d_end,
                                                 uint32_t *__restrict__ queue)
 {
-    FMD_DECLARE_WAVE_LDS();
+    FMD_DECLARE_COMPACT_LDS();
     const int lane = fmd_lane();
     size_t rid = (size_t)-1;      // read being searched by this lane
     uint64_t sbase = 0;           // off[rid]
@@ -166,9 +166,10 @@ __global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const
             c = (int)((cache >> (8 * (a & 3))) & 0xff);
             qk = k - 1; ql = l;
         }
-        const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, qk, ql);
+        FmdRank2c r = fmd_wave_rank2_fetch_compact(ix, fmd_lds, qk, ql);
+        const uint64_t ok = (live && r.hk) ? fmd_block_rank1(r.bk, r.t, r.nk, c) : 0;
+        fmd_wave_l_ready(ix, fmd_lds, r); // only while the intervals are wide (more than 32 lanes straddle)
         if (live) {
-            const uint64_t ok = r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, c) : 0;
             const uint64_t ol = fmd_block_rank1(r.bl, r.tl, r.nl, c);
             k = ix.cnt[c] + ok;
             l = ix.cnt[c] + ol - 1;
@@ -273,7 +274,7 @@ extern "C" int fmd_bsearch_dev(fmd_dev_t *h, void *stream, size_t n, const uint8
     if (n >= 0xffffff00ull) return FMD_E_ARG; // 32-bit queue head
     FMD_HIP_TRY(hipSetDevice(h->device));
     uint32_t *q = fmd_next_queue(h, S(stream));
-    k_bsearch<<<fmd_grid_for(h, n), 64, 0, S(stream)>>>(fmd_view(h), n, d_seqs, d_off, d_cnt, d_beg, d_end, q);
+    k_bsearch<<<fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16), 64, 0, S(stream)>>>(fmd_view(h), n, d_seqs, d_off, d_cnt, d_beg, d_end, q);
     FMD_CHECK_LAUNCH();
     return FMD_OK;
 }

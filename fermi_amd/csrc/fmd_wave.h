@@ -205,3 +205,71 @@ __device__ __forceinline__ FmdRank2 fmd_wave_rank2_fetch(const FmdIndexView &ix,
     fmd_fetch_wait();
     return r;
 }
+
+
+// ---- compact engine: 12.4 KiB of LDS per wave (13 waves per CU instead of 10) -----------------
+// More waves = more lines in flight, which is what these latency-bound searches need (DESIGN.md
+// section 4).  Dense slot for the k side + the 32-block pool for the l side.  When more than 32
+// lanes straddle (only while the SA intervals are still wide: the first ~log4(n) bases, whose
+// blocks sit in L2) the step becomes two-phase: the caller consumes the k side, calls
+// fmd_wave_l_ready(), which re-uses the dense slot for the l blocks, then consumes the l side.
+#define FMD_COMPACT_LDS_U4 (512 + FMD_POOL_BLOCKS * 8 + FMD_POOL_BLOCKS / 4)
+#define FMD_DECLARE_COMPACT_LDS() __shared__ uint4 fmd_lds[FMD_COMPACT_LDS_U4]
+
+struct FmdRank2c {
+    const uint4 *bk, *bl;
+    int t, tl;
+    uint32_t nk, nl, blk_l;
+    bool hk, hl, l_sep;
+    bool two_phase;        // wave-uniform: bl is not valid until fmd_wave_l_ready()
+};
+
+__device__ __forceinline__ FmdRank2c fmd_wave_rank2_fetch_compact(const FmdIndexView &ix, uint4 *lds, uint64_t k, uint64_t l)
+{
+    const int q = fmd_lane();
+    FmdRank2c r;
+    r.hk = k != ~0ull; r.hl = l != ~0ull;
+    const uint32_t blk_k = (uint32_t)(k >> FMD_BLK_SHIFT);
+    r.blk_l = (uint32_t)(l >> FMD_BLK_SHIFT);
+    r.l_sep = r.hl && !(r.hk && blk_k == r.blk_l);
+    fmd_fetch_slot<0>(ix, lds, blk_k, r.hk);
+    r.t = fmd_chunk_xor(q);
+    r.bk = lds + fmd_lds_base(q, 0);
+    r.bl = r.bk; r.tl = r.t;
+    r.two_phase = false;
+    const uint64_t m = __ballot(r.l_sep);
+    if (m) {
+        const int n_sep = __popcll(m);
+        if (n_sep <= FMD_POOL_BLOCKS) {
+            uint4 *pool = lds + 512;
+            uint32_t *ids = (uint32_t *)(pool + FMD_POOL_BLOCKS * 8);
+            const int p = __popcll(m & ((1ull << q) - 1));
+            if (r.l_sep) ids[p] = r.blk_l;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int rr = 0; rr * 8 < n_sep; ++rr) {
+                const int slot = rr * 8 + (q >> 3);
+                if (slot < n_sep) {
+                    const uint4 *src = ix.blocks + (size_t)ids[slot] * FMD_BLK_U4 + ((q & 7) ^ (slot & 7));
+                    __builtin_amdgcn_global_load_lds((fmd_glb_void *)src, (fmd_lds_void *)(pool + rr * 64), 16, 0, FMD_GLDS_AUX);
+                }
+            }
+            if (r.l_sep) { r.bl = pool + p * 8; r.tl = p & 7; }
+        } else r.two_phase = true;
+    }
+    r.nk = ((uint32_t)k & (FMD_BLK_SYMS - 1)) + 1;
+    r.nl = ((uint32_t)l & (FMD_BLK_SYMS - 1)) + 1;
+    fmd_fetch_wait();
+    return r;
+}
+
+// Second phase of a two-phase step (no-op otherwise).  All 64 lanes together, after every lane
+// has finished reading its k-side image: lanes whose l side lives in another block get it in the
+// dense slot; the others keep their k block, which is also their l block.
+__device__ __forceinline__ void fmd_wave_l_ready(const FmdIndexView &ix, uint4 *lds, FmdRank2c &r)
+{
+    if (!r.two_phase) return;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // k-side LDS reads have returned
+    fmd_fetch_slot<0>(ix, lds, r.blk_l, r.l_sep);
+    fmd_fetch_wait();
+    r.bl = r.bk; r.tl = r.t;
+}
