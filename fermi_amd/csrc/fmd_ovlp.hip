@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
                                                  fmd_intv_t *__restrict__ listA, fmd_ovlp_rec_t *__restrict__ rec,
                                                  uint8_t *__restrict__ seq_out, uint32_t seq_stride, uint32_t *__restrict__ queue)
 {
-    FMD_DECLARE_WAVE_LDS();
+    FMD_DECLARE_COMPACT_LDS();
     size_t sid = 0;
     int st = WK_IDLE, c_pend = 0, ret = 0;
     uint32_t depth = 0, npush = 0, pack = 0, flags = 0;
@@ -193,8 +193,22 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
         if (st == WK_LF) qk = k;
         else if (st == WK_EXT || st == WK_BOTH) { qk = x0 - 1; ql = x0 - 1 + sz; }
         else if (st == WK_RIGHT) { qk = x1 - 1; ql = x1 - 1 + sz; }
-        const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, qk, ql);
-        if (st == WK_IDLE) continue;
+        FmdRank2c r = fmd_wave_rank2_fetch_compact(ix, fmd_lds, qk, ql);
+        // two-phase step (more than 32 lanes straddle: wide intervals): the k-side ranks are taken now,
+        // the l-side after fmd_wave_l_ready(); a narrow lane whose window straddles sits this step out
+        uint64_t tk2[6] = {0, 0, 0, 0, 0, 0};
+        const bool wide_ext = st == WK_EXT || (st == WK_BOTH && sz > 63);
+        bool skip = false;
+        if (r.two_phase) {
+            if (wide_ext && r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk2);
+            if (st == WK_RIGHT && r.hk) tk2[0] = fmd_block_rank1(r.bk, r.t, r.nk, 0);
+            skip = st == WK_BOTH && (sz <= 63 || (uint32_t)(k >> FMD_BLK_SHIFT) != (uint32_t)((x0 - 1) >> FMD_BLK_SHIFT)) && r.l_sep;
+            if (st == WK_BOTH && sz > 63 && !skip) skip = true; // wide WK_BOTH never shares a gather in two-phase steps
+            if (skip && st == WK_BOTH && sz > 63) st = WK_LF;   // take the LF step on its own next time
+        }
+        const bool was_two_phase = r.two_phase;
+        fmd_wave_l_ready(ix, fmd_lds, r);
+        if (st == WK_IDLE || skip) continue;
 
         int c = c_pend;
         // Narrow interval (size <= 63, i.e. all but the first ~log4(n) bases): everything comes from ONE
@@ -247,7 +261,10 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
                 for (int a = 0; a < 6; ++a) { s[a] = ws[a]; tk[a] = wtk; }
             } else {
                 uint64_t tl[6] = {0, 0, 0, 0, 0, 0};
-                if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
+                if (was_two_phase) {
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) tk[a] = tk2[a];
+                } else if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
                 if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
 #pragma unroll
                 for (int a = 0; a < 6; ++a) s[a] = tl[a] - tk[a];
@@ -298,7 +315,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
                 continue;
             }
         } else if (st == WK_RIGHT) { // extend by '$' on the right (unitig.c:86-89)
-            const uint64_t t0k = r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, 0) : 0;
+            const uint64_t t0k = was_two_phase ? tk2[0] : (r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, 0) : 0);
             const uint64_t t0l = r.hl ? fmd_block_rank1(r.bl, r.tl, r.nl, 0) : 0;
             if (sz != t0l - t0k) ret = -1;
             fmd_ovlp_rec_t *o = rec + sid;
@@ -691,7 +708,7 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
         k_ovl_retrieve<<<grid, 64, 0, st>>>(ix, n, d_ids, srev, stride_r, d_rec, q0);
         k_ovl_intv<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, d_rec, d_seq, seq_stride, q1);
     } else
-        k_ovl_walk<<<grid, 64, 0, st>>>(ix, n, d_ids, min_match, srev, stride_r, cap, listA, d_rec, d_seq, seq_stride, q0);
+        k_ovl_walk<<<fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16), 64, 0, st>>>(ix, n, d_ids, min_match, srev, stride_r, cap, listA, d_rec, d_seq, seq_stride, q0);
     if (getenv("FMD_OVLP_SLOW_ONLY")) { // A/B switch: everything through the lane-per-strand kernel
         k_ovl_nei<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, listB, d_rec, d_nei, max_nei, d_seq, seq_stride, q2, nullptr, nullptr);
     } else {
