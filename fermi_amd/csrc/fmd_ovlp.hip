@@ -117,7 +117,6 @@ __global__ __launch_bounds__(64) void k_ovl_intv(FmdIndexView ix, size_t n, int 
                 if ((jr & 3) == 0) cache = *(const uint32_t *)(srev + sid * (size_t)stride_r + jr);
                 const int c = (cache >> (8 * (jr & 3))) & 0xff;
                 const uint64_t sc = sel6(c, s[0], s[1], s[2], s[3], s[4], s[5]);
-                const int j = L - 1 - jr; // position of this base in read order
                 if (sc == 0) phase = 1; // cannot be extended (unitig.c:50)
                 else {
                     if (depth >= min_match && s[0]) { // a read starts here: keep the current interval
