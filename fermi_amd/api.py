@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "fmd_dev_malloc", "fmd_memcpy_h2d", "fmd_memcpy_d2h",
     "fmd_smem_work_bytes", "fmd_smem_dev", "fmd_smem_batch",
     "fmd_kmer_work_bytes", "fmd_kmer_collect_dev", "fmd_kmer_collect",
-    "fmd_ovlp_work_bytes", "fmd_ovlp_dev", "fmd_ovlp_batch", "fmd_ovlp_check_left_dev",
+    "fmd_ovlp_work_bytes", "fmd_ovlp_dev", "fmd_ovlp_batch", "fmd_ovlp_check_left_dev", "fmd_seqinfo_dev", "fmd_seqinfo_batch",
 ]
 
 
@@ -97,6 +97,8 @@ def lib():
         L.fmd_smem_work_bytes.restype = sz; L.fmd_smem_work_bytes.argtypes = [sz, C.c_uint32]
         L.fmd_smem_dev.argtypes = [vp, vp, sz, vp, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, sz]
         L.fmd_smem_batch.argtypes = [vp, sz, vp, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp]
+        L.fmd_seqinfo_dev.argtypes = [vp, vp, sz, u64p, C.c_uint32, vp, vp, C.c_uint32, vp, sz]
+        L.fmd_seqinfo_batch.argtypes = [vp, sz, u64p, C.c_uint32, vp]
         L.fmd_probe_gather.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_float)]
         _lib = L
     return _lib

@@ -170,7 +170,8 @@ enum { WK_IDLE = 0, WK_LF, WK_EXT, WK_BOTH, WK_RIGHT };
 __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, const uint64_t *__restrict__ ids, int min_match,
                                                  uint8_t *__restrict__ srev, uint32_t stride_r, uint32_t cap,
                                                  fmd_intv_t *__restrict__ listA, fmd_ovlp_rec_t *__restrict__ rec,
-                                                 uint8_t *__restrict__ seq_out, uint32_t seq_stride, uint32_t *__restrict__ queue)
+                                                 uint8_t *__restrict__ seq_out, uint32_t seq_stride, uint32_t *__restrict__ queue,
+                                                 int info_only)
 {
     FMD_DECLARE_COMPACT_LDS();
     size_t sid = 0;
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             if (c != 0) { // one more base: overlap_intv's loop body (unitig.c:47-59)
                 const uint64_t sc = sel6(c, s[0], s[1], s[2], s[3], s[4], s[5]);
                 // (sc == 0 cannot happen: the sequence itself is in the index)
-                if ((int)depth >= min_match && s[0]) {
+                if (!info_only && (int)depth >= min_match && s[0]) {
                     if (npush < cap) store_entry(listA + sid * (size_t)cap + (cap - 1 - npush), x0, x1, sz, (uint64_t)depth);
                     else flags |= FMD_OVLP_F_OVERFLOW;
                     ++npush;
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
                 o->rank = k; o->len = (int32_t)depth; o->rbeg = -1; o->ext_len = 0; o->n_nei = 0; o->reserved = 2;
                 o->k[0] = o->k[1] = o->k[2] = 0; o->n_ovlp = 0;
                 if (depth > stride_r) { o->status = 0; o->flags = FMD_OVLP_F_OVERFLOW; st = WK_IDLE; continue; } // longer than max_len
-                if ((int)depth <= min_match) { o->status = -1; o->flags = 0; st = WK_IDLE; continue; }         // too short (unitig.c:288)
+                if (!info_only && (int)depth <= min_match) { o->status = -1; o->flags = 0; st = WK_IDLE; continue; } // too short (unitig.c:288)
                 {   // the sequence in read order for the caller: srev byte-reversed, one burst
                     const uint8_t *sr = srev + sid * (size_t)stride_r;
                     uint8_t *dst = seq_out + sid * (size_t)seq_stride;
@@ -707,7 +708,7 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
         k_ovl_retrieve<<<grid, 64, 0, st>>>(ix, n, d_ids, srev, stride_r, d_rec, q0);
         k_ovl_intv<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, d_rec, d_seq, seq_stride, q1);
     } else
-        k_ovl_walk<<<fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16), 64, 0, st>>>(ix, n, d_ids, min_match, srev, stride_r, cap, listA, d_rec, d_seq, seq_stride, q0);
+        k_ovl_walk<<<fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16), 64, 0, st>>>(ix, n, d_ids, min_match, srev, stride_r, cap, listA, d_rec, d_seq, seq_stride, q0, 0);
     if (getenv("FMD_OVLP_SLOW_ONLY")) { // A/B switch: everything through the lane-per-strand kernel
         k_ovl_nei<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, listB, d_rec, d_nei, max_nei, d_seq, seq_stride, q2, nullptr, nullptr);
     } else {
@@ -751,6 +752,29 @@ extern "C" int fmd_ovlp_check_left_dev(fmd_dev_t *h, void *stream_, size_t n, in
     return FMD_OK;
 }
 
+// fm6_retrieve (exact.c:100-127) for a batch of sequence ids: rank, `$read$` bi-interval and
+// containment of each sequence, i.e. the walk phase alone with no length threshold.  What
+// fm6_seqsort (seqsort.c:12-35) needs.  rec.status = -3 when contained on either side.
+extern "C" int fmd_seqinfo_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_t *d_ids, uint32_t max_len, fmd_ovlp_rec_t *d_rec,
+                               uint8_t *d_seq, uint32_t seq_stride, void *d_work, size_t work_bytes)
+{
+    if (!h || (n && (!d_ids || !d_rec || !d_seq || !d_work)) || max_len == 0) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    if (n >= 0xffffff00ull || work_bytes < fmd_ovlp_work_bytes(n, max_len, (int)max_len - 1)) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream_;
+    const uint32_t stride_r = (uint32_t)align_up(max_len, 4);
+    const uint32_t cap = fmd_ovlp_list_cap(max_len, (int)max_len - 1);
+    uint8_t *srev = (uint8_t *)d_work;
+    fmd_intv_t *listA = (fmd_intv_t *)((uint8_t *)d_work + align_up(n * (size_t)stride_r, 256));
+    uint32_t *q0 = fmd_next_queue(h, st);
+    k_ovl_walk<<<fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16), 64, 0, st>>>(fmd_view(h), n, d_ids, 0, srev, stride_r, cap, listA, d_rec,
+                                                                             d_seq, seq_stride, q0, 1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fmd_set_hip_error(e, "k_ovl_walk"); return FMD_E_HIP; }
+    return FMD_OK;
+}
+
 struct DevBuf2 {
     void *p = nullptr;
     int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? FMD_OK : FMD_E_NOMEM; }
@@ -784,6 +808,27 @@ extern "C" int fmd_ovlp_batch(fmd_dev_t *h, size_t n, const uint64_t *ids, int m
         FMD_HIP_TRY(hipMemcpy(rec + o, dr.p, c * sizeof(fmd_ovlp_rec_t), hipMemcpyDeviceToHost));
         FMD_HIP_TRY(hipMemcpy(nei + o * max_nei, dn.p, c * max_nei * sizeof(fmd_intv_t), hipMemcpyDeviceToHost));
         FMD_HIP_TRY(hipMemcpy(seq + o * (size_t)seq_stride, ds.p, c * (size_t)seq_stride, hipMemcpyDeviceToHost));
+    }
+    return FMD_OK;
+}
+
+extern "C" int fmd_seqinfo_batch(fmd_dev_t *h, size_t n, const uint64_t *ids, uint32_t max_len, fmd_ovlp_rec_t *rec)
+{
+    if (!h || (n && (!ids || !rec))) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    const size_t chunk = 1u << 21;
+    const size_t m = n < chunk ? n : chunk;
+    const uint32_t stride = (uint32_t)align_up(max_len, 4);
+    const size_t wb = fmd_ovlp_work_bytes(m, max_len, (int)max_len - 1);
+    DevBuf2 di, dr, ds, dw;
+    if (di.alloc(m * 8) || dr.alloc(m * sizeof(fmd_ovlp_rec_t)) || ds.alloc(m * (size_t)stride) || dw.alloc(wb)) return FMD_E_NOMEM;
+    for (size_t o = 0; o < n; o += m) {
+        const size_t c = n - o < m ? n - o : m;
+        FMD_HIP_TRY(hipMemcpy(di.p, ids + o, c * 8, hipMemcpyHostToDevice));
+        int rc = fmd_seqinfo_dev(h, nullptr, c, (uint64_t *)di.p, max_len, (fmd_ovlp_rec_t *)dr.p, (uint8_t *)ds.p, stride, dw.p, wb);
+        if (rc) return rc;
+        FMD_HIP_TRY(hipMemcpy(rec + o, dr.p, c * sizeof(fmd_ovlp_rec_t), hipMemcpyDeviceToHost));
     }
     return FMD_OK;
 }

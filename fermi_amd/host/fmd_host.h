@@ -36,10 +36,12 @@ typedef struct {
     const uint8_t *seq;          /* n * seq_stride: sequence then appended bases */
 } fmdh_ovlp_table_t;
 /* Replays the single-threaded walk and writes the MAG records `fermi unitig -t1` prints. */
-int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, FILE *out);
+int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, const uint64_t *sorted /* or NULL */, FILE *out);
 /* Whole command: open the .fmd on `device`, build the table on the GPU (capacities grown until no
  * record overflows), walk, print.  `fermi unitig -l min_match <fn>` (cmd.c:184-216). */
-int fmdh_unitig(const char *fmd_path, int device, int min_match, FILE *out);
+int fmdh_unitig(const char *fmd_path, int device, int min_match, const char *rank_file /* -r, or NULL */, FILE *out);
+/* `fermi seqsort <reads.fmd>` (seqsort.c:37-70): *sorted is malloc'ed, n = mcnt[1] entries */
+int fmdh_seqsort(const char *fmd_path, int device, uint64_t **sorted, uint64_t *n);
 
 /* ---- FASTA/FASTQ input (kseq.h semantics) ---- */
 typedef struct fmdh_seqio fmdh_seqio_t;

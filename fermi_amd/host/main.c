@@ -9,23 +9,37 @@
 static int main_unitig(int argc, char *argv[]) /* cmd.c:184-216 */
 {
     int c, min_match = 30, device = 0;
+    const char *rank_file = 0;
     while ((c = getopt(argc, argv, "Ml:t:r:g:")) >= 0) {
         switch (c) {
         case 'l': min_match = atoi(optarg); break;
         case 'M': break;                 /* mmap: meaningless for a device-resident index */
         case 't': break;                 /* threads: the walk is the deterministic -t1 walk */
         case 'g': device = atoi(optarg); break;
-        case 'r': fprintf(stderr, "[E::%s] -r (rank file) is not supported yet\n", __func__); return 1;
+        case 'r': rank_file = optarg; break;
         }
     }
     if (optind + 1 > argc) {
         fprintf(stderr, "\nUsage:   fermi-amd unitig [options] <reads.fmd>\n\n");
         fprintf(stderr, "Options: -l INT      min match [%d]\n", min_match);
         fprintf(stderr, "         -t INT      number of threads [ignored: output is that of -t1]\n");
+        fprintf(stderr, "         -r FILE     rank file [null]\n");
         fprintf(stderr, "         -g INT      GPU to use [0]\n\n");
         return 1;
     }
-    return fmdh_unitig(argv[optind], device, min_match, stdout);
+    return fmdh_unitig(argv[optind], device, min_match, rank_file, stdout);
+}
+
+static int main_seqsort(int argc, char *argv[]) /* cmd.c:486-505 */
+{
+    int c, device = 0;
+    uint64_t *sorted = 0, n = 0;
+    while ((c = getopt(argc, argv, "t:g:")) >= 0) if (c == 'g') device = atoi(optarg);
+    if (optind == argc) { fprintf(stderr, "Usage: fermi-amd seqsort [-g GPU] <reads.fmd>\n"); return 1; }
+    if (fmdh_seqsort(argv[optind], device, &sorted, &n)) return 1;
+    fwrite(sorted, 8, n, stdout);
+    free(sorted);
+    return 0;
 }
 
 static int main_build(int argc, char *argv[]) /* cmd.c:378-484 */
@@ -113,6 +127,7 @@ int main(int argc, char *argv[])
         fprintf(stderr, "\nProgram: fermi-amd (FMD-index hot path of fermi on AMD MI355X)\n\n");
         fprintf(stderr, "Usage:   fermi-amd <command> [arguments]\n\n");
         fprintf(stderr, "Command: build      generate the FMD-index (fermi build)\n");
+        fprintf(stderr, "         seqsort    rank -> read index map for `unitig -r` (fermi seqsort)\n");
         fprintf(stderr, "         unitig     construct unitigs (fermi unitig)\n");
         fprintf(stderr, "         correct    error correction (fermi correct)\n");
         fprintf(stderr, "         exact      find super-maximal exact matches (fermi exact)\n\n");
@@ -124,6 +139,7 @@ int main(int argc, char *argv[])
     }
     if (strcmp(argv[1], "unitig") == 0) return main_unitig(argc - 1, argv + 1);
     if (strcmp(argv[1], "build") == 0) return main_build(argc - 1, argv + 1);
+    if (strcmp(argv[1], "seqsort") == 0) return main_seqsort(argc - 1, argv + 1);
     if (strcmp(argv[1], "exact") == 0) return main_exact(argc - 1, argv + 1);
     if (strcmp(argv[1], "correct") == 0) return main_correct(argc - 1, argv + 1);
     fprintf(stderr, "[E::main] unrecognized command `%s'\n", argv[1]);

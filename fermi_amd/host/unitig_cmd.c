@@ -6,7 +6,7 @@
 #include <string.h>
 #include "fmd_host.h"
 
-int fmdh_unitig(const char *fmd_path, int device, int min_match, FILE *out)
+int fmdh_unitig(const char *fmd_path, int device, int min_match, const char *rank_file, FILE *out)
 {
     fmd_dev_t *d = 0;
     fmd_info_t info;
@@ -19,7 +19,14 @@ int fmdh_unitig(const char *fmd_path, int device, int min_match, FILE *out)
     fmd_ovlp_rec_t *rec = (fmd_ovlp_rec_t *)malloc(n * sizeof(*rec));
     fmd_intv_t *nei = 0;
     uint8_t *seq = 0;
+    uint64_t *sorted = 0;
     if (!ids || !rec) { rc = 1; goto done; }
+    if (rank_file) { /* load_sorted, cmd.c:173-182 */
+        FILE *fp = fopen(rank_file, "rb");
+        sorted = (uint64_t *)malloc(n * 8);
+        if (!fp || !sorted || fread(sorted, 8, n, fp) != n) { fprintf(stderr, "[E::%s] cannot read the rank file `%s'\n", __func__, rank_file); if (fp) fclose(fp); rc = 1; goto done; }
+        fclose(fp);
+    }
     for (uint64_t i = 0; i < n; ++i) ids[i] = i;
     for (int attempt = 0; attempt < 8; ++attempt) { /* grow the capacities until no record overflows */
         const uint32_t stride = 2 * ((max_len + 3) / 4 * 4);
@@ -33,7 +40,7 @@ int fmdh_unitig(const char *fmd_path, int device, int min_match, FILE *out)
         for (uint64_t i = 0; i < n; ++i) n_over += (rec[i].flags & FMD_OVLP_F_OVERFLOW) != 0;
         if (n_over == 0) {
             fmdh_ovlp_table_t t = {n, max_nei, stride, rec, nei, seq};
-            rc = fmdh_unitig_walk(&t, n, min_match, out);
+            rc = fmdh_unitig_walk(&t, n, min_match, sorted, out);
             if (rc) { fprintf(stderr, "[E::%s] walk failed: %s\n", __func__, strerror(-rc)); rc = 1; }
             goto done;
         }
@@ -42,7 +49,7 @@ int fmdh_unitig(const char *fmd_path, int device, int min_match, FILE *out)
     fprintf(stderr, "[E::%s] capacities exhausted\n", __func__);
     rc = 1;
 done:
-    free(ids); free(rec); free(nei); free(seq);
+    free(ids); free(rec); free(nei); free(seq); free(sorted);
     fmd_dev_close(d);
     return rc;
 }

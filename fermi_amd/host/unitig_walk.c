@@ -14,6 +14,7 @@
  * (Marks that the reference puts on CONTAINED reads -- unitig.c:124, :197 -- are not replayed: a
  * contained seed is rejected with or without them, unitig.c:282-292.)
  */
+#define _GNU_SOURCE
 #include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -42,6 +43,7 @@ typedef struct {
     int min_match;
     uint64_t *used, *bend, *visited;
     uint32_t *row_of;           /* `$read$` interval start -> a sequence id with that interval */
+    const uint64_t *sorted;     /* optional rank -> (sequence id << 2 | flags) map of `unitig -r` (unitig.c:22-29) */
     /* the neighbour list left behind by the last try_right (unitig.c:181-184) */
     const fmd_intv_t *nei; int n_nei;
 } walk_t;
@@ -53,7 +55,8 @@ static inline const uint8_t *SEQ(const walk_t *w, uint64_t row) { return w->t->s
 static void mark_used(walk_t *w, const uint64_t x[3]) /* set_bits, unitig.c:22-36 (sorted == NULL) */
 {
     uint64_t k;
-    for (k = 0; k < x[2]; ++k) { bit_set(w->used, x[0] + k); bit_set(w->used, x[1] + k); }
+    if (w->sorted) for (k = 0; k < x[2]; ++k) { bit_set(w->used, w->sorted[x[0] + k] >> 2); bit_set(w->used, w->sorted[x[1] + k] >> 2); }
+    else for (k = 0; k < x[2]; ++k) { bit_set(w->used, x[0] + k); bit_set(w->used, x[1] + k); }
 }
 
 /* check_left (unitig.c:206-225) for the edge row -> its unique neighbour */
@@ -136,7 +139,7 @@ static int put_links(str_t *o, const link_t *a, int n)
     return 0;
 }
 
-int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, FILE *out)
+int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, const uint64_t *sorted, FILE *out)
 {
     walk_t w;
     str_t s = {0, 0, 0}, cov = {0, 0, 0}, o = {0, 0, 0};
@@ -144,7 +147,7 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
     uint64_t i, j, nw = (n_seq + 63) / 64;
     int rc = 0;
     memset(&w, 0, sizeof(w));
-    w.t = t; w.n_seq = n_seq; w.min_match = min_match;
+    w.t = t; w.n_seq = n_seq; w.min_match = min_match; w.sorted = sorted;
     w.used = (uint64_t *)calloc(nw, 8); w.bend = (uint64_t *)calloc(nw, 8); w.visited = (uint64_t *)calloc(nw, 8);
     w.row_of = (uint32_t *)malloc(n_seq * 4);
     nei[0] = (link_t *)malloc(t->max_nei * sizeof(link_t)); nei[1] = (link_t *)malloc((t->max_nei + 1) * sizeof(link_t));
@@ -162,8 +165,9 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
             int n_nei[2] = {0, 0}, n_reads, is_loop = 0, seed_len, k, done_loop = 0;
             /* ---- unitig1 (unitig.c:274-317) */
             if (r->flags & FMD_OVLP_F_OVERFLOW) { rc = -ERANGE; goto done; }
+            if (sorted && bit_get(w.used, i)) continue;              /* used (unitig.c:282: by sequence id with -r) */
             if (r->len <= min_match) continue;                       /* too short */
-            if (bit_get(w.used, r->rank)) continue;                  /* used */
+            if (!sorted && bit_get(w.used, r->rank)) continue;       /* used (unitig.c:289: by rank) */
             mark_used(&w, r->k);
             if (r->status != 0) continue;                            /* contained */
             seed_len = r->len;
@@ -205,7 +209,11 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
             memcpy(o.s + o.l, "\n+\n", 3); o.l += 3;
             memcpy(o.s + o.l, cov.s, s.l); o.l += s.l;
             o.s[o.l++] = '\n';
-            if (fwrite(o.s, 1, o.l, out) != o.l) { rc = -EIO; goto done; }
+            {   /* the reference prints the record with fputs (unitig.c:354): a base that is not A/C/G/T
+                 * becomes "ACGT"[4] = NUL (mag.c:168) and cuts the record there.  Reproduced as is. */
+                size_t wl = strnlen(o.s, o.l);
+                if (fwrite(o.s, 1, wl, out) != wl) { rc = -EIO; goto done; }
+            }
         }
     }
 done:

@@ -24,8 +24,8 @@ def lib():
             _fields_ = [("n", C.c_uint64), ("max_nei", C.c_uint32), ("seq_stride", C.c_uint32),
                         ("rec", C.c_void_p), ("nei", C.c_void_p), ("seq", C.c_void_p)]
         L.Table = Table
-        L.fmdh_unitig_walk.argtypes = [C.POINTER(Table), C.c_uint64, C.c_int, C.c_void_p]
-        L.fmdh_unitig.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+        L.fmdh_unitig_walk.argtypes = [C.POINTER(Table), C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+        L.fmdh_unitig.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_void_p]
         class EcOpt(C.Structure):
             _fields_ = [("w", C.c_int), ("min_occ", C.c_int), ("keep_bad", C.c_int), ("is_paired", C.c_int), ("trim_l", C.c_int),
                         ("step", C.c_int), ("max_corr", C.c_float)]
@@ -71,14 +71,15 @@ _libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
 _libc.fclose.argtypes = [C.c_void_p]
 
 
-def unitig_walk(rec, nei, seq, n_seq, min_match, out_path):
+def unitig_walk(rec, nei, seq, n_seq, min_match, out_path, sorted_map=None):
     """Replay the `fermi unitig -t1` walk over a per-id overlap table; writes MAG records to out_path."""
     L = lib()
     rec = np.ascontiguousarray(rec); nei = np.ascontiguousarray(nei); seq = np.ascontiguousarray(seq)
     t = L.Table(len(rec), nei.shape[1], seq.shape[1], rec.ctypes.data, nei.ctypes.data, seq.ctypes.data)
     fp = _libc.fopen(out_path.encode(), b"wb")
     try:
-        _chk(L.fmdh_unitig_walk(C.byref(t), n_seq, min_match, fp), "unitig_walk")
+        sm = None if sorted_map is None else np.ascontiguousarray(sorted_map, dtype=np.uint64)
+        _chk(L.fmdh_unitig_walk(C.byref(t), n_seq, min_match, None if sm is None else sm.ctypes.data, fp), "unitig_walk")
     finally:
         _libc.fclose(fp)
 
@@ -88,7 +89,7 @@ def unitig(fmd_path, min_match, out_path, device=0):
     L = lib()
     fp = _libc.fopen(out_path.encode(), b"wb")
     try:
-        rc = L.fmdh_unitig(fmd_path.encode(), device, min_match, fp)
+        rc = L.fmdh_unitig(fmd_path.encode(), device, min_match, None, fp)
     finally:
         _libc.fclose(fp)
     if rc:

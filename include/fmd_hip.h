@@ -169,6 +169,13 @@ int fmd_kmer_collect_dev(fmd_dev_t *h, void *stream, int w, int min_occ, int suf
 int fmd_kmer_collect(fmd_dev_t *h, int w, int min_occ, int suf_len, uint32_t **bucket, uint32_t **key, uint8_t **val,
                      uint64_t *n, int64_t cnt[2]);   /* outputs malloc'ed: fmd_host_free() */
 
+/* ---- fm6_retrieve (exact.c:100-127) in bulk: rank, `$read$` bi-interval and containment of each
+ * sequence id (rec.rank, rec.k[], rec.status = -3 when contained, rec.len); no length threshold,
+ * no overlap search.  This is what fm6_seqsort (seqsort.c:12-35) consumes. */
+int fmd_seqinfo_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_ids, uint32_t max_len, fmd_ovlp_rec_t *d_rec,
+                    uint8_t *d_seq, uint32_t seq_stride, void *d_work, size_t work_bytes); /* work: fmd_ovlp_work_bytes(n, max_len, max_len-1) */
+int fmd_seqinfo_batch(fmd_dev_t *h, size_t n, const uint64_t *ids, uint32_t max_len, fmd_ovlp_rec_t *rec);
+
 /* ---- index construction: the BWT `fermi build` computes (cmd.c:378-484, build.c:11-50) ------
  * reads: nt6 bases of all reads back to back, NO sentinels; read i = reads[off[i], off[i+1]).
  * The text indexed is  read $ revcomp(read) $  per read in input order, sentinels ordered by

@@ -260,8 +260,20 @@ def main():
         kv[tag + "_cnt"] = np.array(list(cnt), dtype=np.int64)
     np.savez_compressed(os.path.join(HERE, "tiny_solid.npz"), **kv)
 
+    # ---- seqsort + `unitig -r` (seqsort.c:37-70, unitig.c:22-29, 282): rank files and the MAGs they give
+    for name, mm in (("tiny", 50), ("repeat", 20), ("special", 20)):
+        rank = os.path.join(HERE, name + ".rank")
+        with open(rank, "wb") as fo:
+            subprocess.check_call([FERMI, "seqsort", os.path.join(HERE, name + ".fmd")], stdout=fo, stderr=subprocess.DEVNULL)
+        run([FERMI, "unitig", "-l%d" % mm, "-t1", "-r", rank, os.path.join(HERE, name + ".fmd")], os.path.join(TMP, name + ".r.mag"))
+        with gzip.open(os.path.join(HERE, name + ".r.mag.gz"), "wb", 9) as f:
+            f.write(open(os.path.join(TMP, name + ".r.mag"), "rb").read())
+    run([FERMI, "unitig", "-l20", "-t1", os.path.join(HERE, "special.fmd")], os.path.join(TMP, "special.mag"))
+    with gzip.open(os.path.join(HERE, "special.mag.gz"), "wb", 9) as f:
+        f.write(open(os.path.join(TMP, "special.mag"), "rb").read())
+
     for fn in sorted(os.listdir(HERE)):
-        if fn.endswith((".fmd", ".gz", ".npz")):
+        if fn.endswith((".fmd", ".gz", ".npz", ".rank")):
             man["files"][fn] = {"md5": md5(os.path.join(HERE, fn)), "bytes": os.path.getsize(os.path.join(HERE, fn))}
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(man, f, indent=1, sort_keys=True)

@@ -326,3 +326,14 @@ def test_bucketed_builder_equals_one_shot(gpu, gold, oracle_lib, monkeypatch):
         o = orcbind.OrcIndex(gold.path(name + ".fmd"))
         assert np.array_equal(bwt, o.decode_all()), name
         o.close()
+
+
+@pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20), ("special", 20)])
+def test_seqsort_and_unitig_r_cli(gpu, gold, tmp_path, name, mm):
+    """`fermi-amd seqsort` == `fermi seqsort` bytes; `fermi-amd unitig -r` == `fermi unitig -t1 -r` bytes."""
+    rank = _cli("seqsort", gold.path(name + ".fmd"))
+    assert rank == open(gold.path(name + ".rank"), "rb").read()
+    rf = str(tmp_path / "x.rank")
+    open(rf, "wb").write(rank)
+    assert _cli("unitig", "-l%d" % mm, "-r", rf, gold.path(name + ".fmd")) == gold.text_gz(name + ".r.mag.gz")
+    assert _cli("unitig", "-l%d" % mm, gold.path(name + ".fmd")) == gold.text_gz(name + ".mag.gz")

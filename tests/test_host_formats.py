@@ -45,7 +45,7 @@ def test_trim_palindrome():
     assert f("ANNT") == 4
 
 
-@pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20)])
+@pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20), ("special", 20)])
 def test_unitig_walk_reproduces_fermi_unitig_t1(oracle_lib, gold, tmp_path, name, mm):
     """Host walk (fermi_amd/host/unitig_walk.c) over the per-read table == `fermi unitig -t1`
     output, byte for byte.  The table here comes from the oracle (CPU); the GPU test feeds the
@@ -70,3 +70,17 @@ def test_correct_phase2_reproduces_fermi_correct(gold, tmp_path):
     out = str(tmp_path / "ec.fq")
     hostlib.correct_reads(17, 3, v["w17_o3_bucket"], v["w17_o3_key"], v["w17_o3_val"], gold.path("tiny.fq.gz"), out)
     assert open(out, "rb").read() == gold.text_gz("tiny.ec.fq.gz")
+
+
+@pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20), ("special", 20)])
+def test_unitig_walk_with_rank_file(oracle_lib, gold, tmp_path, name, mm):
+    """`unitig -r rank`: the used bitmap is indexed through the seqsort map (unitig.c:22-29, 282)."""
+    o = orcbind.OrcIndex(gold.path(name + ".fmd"))
+    n_seq = int(o.mcnt[1])
+    rec, nei, seq = o.overlap_batch(np.arange(n_seq, dtype=np.uint64), mm, max_len=100, max_nei=8, n_threads=4)
+    sm = np.fromfile(gold.path(name + ".rank"), dtype=np.uint64)
+    assert len(sm) == n_seq
+    out = str(tmp_path / "o.mag")
+    hostlib.unitig_walk(rec, nei, seq, n_seq, mm, out, sorted_map=sm)
+    assert open(out, "rb").read() == gold.text_gz(name + ".r.mag.gz")
+    o.close()
