@@ -190,6 +190,22 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
+    # ---- N > 1: the one exchange of the real pipeline -- gather of per-id records on rank 0 over
+    # RCCL (fermi_amd/dist.py).  Outside the timed region; every rank holds the same table here, so
+    # rank 0 can check what it received against its own copy.
+    gather_note = None
+    if dist:
+        try:
+            from fermi_amd import dist as fdist
+            m = min(n_ids, 200000)
+            mine = fdist.shard_ids(m, rank, world).astype(np.int64)
+            local = rec.view(torch.uint8).reshape(n_ids, 64)[torch.from_numpy(mine).to(dev)].cpu().numpy().view(api.OVLP_DT).reshape(-1)
+            got = fdist.gather_rows(local, m, rank, world, dist, device=dev)
+            if rank == 0:
+                want = rec.view(torch.uint8).reshape(n_ids, 64)[:m].cpu().numpy().view(api.OVLP_DT).reshape(-1)
+                gather_note = "ok (%d records from %d ranks, identical to rank 0's table)" % (m, world) if got.tobytes() == want.tobytes() else "MISMATCH"
+        except Exception as ex:  # never let the optional check take the benchmark line down
+            gather_note = "failed: %r" % (ex,)
     if rank != 0:
         return None
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
@@ -199,6 +215,8 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
            "ms_per_step": wall / steps * 1e3, "min_match": min_match, "batch_strands": batch,
            "overflow_records": int(((g_rec["flags"] & api.OVLP_F_OVERFLOW) != 0).sum()),
            "contained": int((g_rec["status"] == -3).sum()), "with_neighbour": int((g_rec["n_nei"] > 0).sum())}
+    if gather_note:
+        out["record_gather_rccl"] = gather_note
     if world == 1:
         cnts, qps = overlap_rank_queries_per_strand(fmd_path, min_match)
         alg = qps * BYTES_PER_RANK_QUERY * n_ids
