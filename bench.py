@@ -241,6 +241,129 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
     return out
 
 
+def smem_cpu_baseline(fmd_path, reads, max_mem, g_mem, g_nmem):
+    """fm6_smem (smem.c:397) per read on the host cores: the compiled reference when oracle/_ref
+    travelled, else our C port; also the parity check of the GPU output on that sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    cores = os.cpu_count() or 1
+    n, L = reads.shape
+    q = np.ascontiguousarray(reads)
+    INTV = np.dtype([("x", "<u8", (3,)), ("info", "<u8")])
+    mem = np.zeros((n, max_mem), dtype=INTV); n_mem = np.zeros(n, dtype=np.uint32)
+    drv = os.path.join(ROOT, "oracle", "_ref", "libref_driver.so")
+    n1 = min(n, 10_000)
+    if os.path.exists(drv):
+        Lb = C.CDLL(drv)
+        Lb.refdrv_load.restype = C.c_void_p; Lb.refdrv_load.argtypes = [C.c_char_p]
+        Lb.refdrv_free.argtypes = [C.c_void_p]
+        Lb.refdrv_smem.restype = C.c_double
+        Lb.refdrv_smem.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
+        e = Lb.refdrv_load(fmd_path.encode())
+        assert e
+        t1 = Lb.refdrv_smem(e, n1, L, q.ctypes.data, 0, max_mem, mem.ctypes.data, n_mem.ctypes.data, 1)
+        tall = Lb.refdrv_smem(e, n, L, q.ctypes.data, 0, max_mem, mem.ctypes.data, n_mem.ctypes.data, cores)
+        Lb.refdrv_free(e)
+        kind = "reference"
+    else:
+        import orcbind
+        o = orcbind.OrcIndex(fmd_path)
+        t0 = time.time(); o.smem_batch(q[:n1], 0, max_mem, 1); t1 = time.time() - t0
+        t0 = time.time(); mem, n_mem = o.smem_batch(q, 0, max_mem, cores); tall = time.time() - t0
+        o.close()
+        kind = "port"
+    ok = np.array_equal(n_mem, g_nmem)
+    if ok:
+        for j in range(max_mem):
+            m = n_mem > j
+            ok = ok and mem[m, j].tobytes() == g_mem[m, j].tobytes()
+    return {"value": n / tall, "unit": "reads/s", "cores": cores, "kind": kind,
+            "sample": "first %d reads of the batch, all %d host threads (1 thread: %.0f reads/s)" % (n, cores, n1 / t1)}, bool(ok)
+
+
+def bench_smem(torch, api, workload, dev, local_rank, n_reads, L, steps, warmup, dist, world, rank):
+    """fm6_smem (what `fermi exact` runs) of every read against the index
+    of the same reads, reads carrying 1 % substitutions.  One step = all reads."""
+    err = float(os.environ.get("FMD_BENCH_SMEM_ERR", "0.01"))
+    max_mem = 8
+    t0 = time.time()
+    reads = workload.synth_reads_host(n_reads, L, 30, err)
+    rd = workload.ReadsOnDevice(reads, dev)
+    d_bwt, n_sym = workload.build_bwt_on_device(rd, local_rank)
+    torch.cuda.synchronize()
+    fmd_path = None
+    if rank == 0 and world == 1:
+        fmd_path = os.path.join(tempfile.gettempdir(), "fmd_bench_smem_%d_%d.fmd" % (n_reads, os.getpid()))
+        workload.write_fmd_from_device_bwt(d_bwt, n_sym, fmd_path, local_rank)
+    index = api.DevIndex.from_bwt_dev(d_bwt, n_sym, local_rank)
+    api.lib().fmd_dev_free(d_bwt)
+    if rank == 0:
+        log("smem setup: %d reads at e=%g, index of %d symbols, %.1fs" % (n_reads, err, n_sym, time.time() - t0))
+    batch = min(n_reads, int(os.environ.get("FMD_BENCH_SMEM_BATCH", str(n_reads))))
+    mem = torch.zeros(n_reads * max_mem * 32, dtype=torch.uint8, device=dev)
+    n_mem = torch.zeros(n_reads, dtype=torch.int32, device=dev)
+    wb = api.lib().fmd_smem_work_bytes(batch, L)
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream()
+    sh = C.c_void_p(stream.cuda_stream)
+
+    def step():
+        for o in range(0, n_reads, batch):
+            c = min(batch, n_reads - o)
+            api.check(api.lib().fmd_smem_dev(index.h, sh, c, rd.flat.data_ptr(), rd.off.data_ptr() + o * 8, 0, L, max_mem,
+                                             mem.data_ptr() + o * max_mem * 32, n_mem.data_ptr() + o * 4, work.data_ptr(), wb))
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    w0 = time.perf_counter()
+    for a, b in evs:
+        a.record(stream); step(); b.record(stream)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - w0
+    if dist:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    out = None
+    if rank == 0:
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        g_nmem = n_mem.cpu().numpy().view(np.uint32)
+        out = {"metric": "reads/sec through fm6_smem (fermi exact), reads with %g substitutions against their own index" % err,
+               "value": n_reads * world * steps / wall, "unit": "reads/s", "ms_per_step": wall / steps * 1e3,
+               "smems": int((g_nmem & 0x7fffffff).sum()), "overflow_reads": int((g_nmem >> 31).sum()), "index_symbols": n_sym}
+        if world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import orcbind
+            o = orcbind.OrcIndex(fmd_path)
+            o.counters()
+            ns = 4000
+            o.smem_batch(reads[:ns], 0, max_mem, 1)
+            cn = o.counters()
+            o.close()
+            qpr = (cn["rank1a"] + cn["rank2a"] + cn["rank2a_spill"]) / ns
+            ach = qpr * BYTES_PER_RANK_QUERY * n_reads / (kern_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "k_smem", "kernel_ms": kern_ms, "rank_queries_per_read": qpr,
+                               "algorithmic_bytes_per_read": qpr * BYTES_PER_RANK_QUERY, "oracle_counters_on_sample": cn}
+            ns = min(n_reads, int(os.environ.get("FMD_BENCH_CPU_SAMPLE_SMEM", "400000")))
+            INTV = np.dtype([("x", "<u8", (3,)), ("info", "<u8")])
+            g_mem = mem[: ns * max_mem * 32].cpu().numpy().view(INTV).reshape(ns, max_mem)
+            base, ok = smem_cpu_baseline(fmd_path, reads[:ns], max_mem, g_mem, g_nmem[:ns])
+            out["cpu_baseline"] = base
+            out["parity_vs_cpu_on_sample"] = "bit-exact" if ok else "MISMATCH"
+            out["speedup_vs_cpu_all_cores"] = out["value"] / base["value"]
+        if fmd_path and os.path.exists(fmd_path):
+            os.remove(fmd_path)
+    index.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -341,6 +464,10 @@ def main():
     if os.environ.get("FMD_BENCH_OVERLAP", "1") != "0":
         ovl = bench_overlap(torch, api, index, dev, n_reads, L, max(1, min(args.steps, 2)), min(args.warmup, 1), dist, world, rank, fmd_path)
 
+    sm = None
+    if os.environ.get("FMD_BENCH_SMEM", "1") != "0":
+        sm = bench_smem(torch, api, workload, dev, local_rank, n_reads, L, max(1, min(args.steps, 2)), min(args.warmup, 1), dist, world, rank)
+
     if rank == 0:
         g_cnt = cnt.cpu().numpy().view(np.uint64); g_beg = beg.cpu().numpy().view(np.uint64); g_end = end.cpu().numpy().view(np.uint64)
         total_reads = n_reads * world * args.steps
@@ -376,6 +503,8 @@ def main():
             out["speedup_vs_cpu_all_cores"] = value / base["value"]
         if ovl:
             out["overlap_discovery"] = ovl
+        if sm:
+            out["smem"] = sm
         print(json.dumps(out), flush=True)
         if fmd_path and os.path.exists(fmd_path):
             os.remove(fmd_path)

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const
                                                 uint32_t *__restrict__ queue)
 {
     FMD_DECLARE_COMPACT_LDS();
-    const int lane = fmd_lane();
+
     size_t rid = (size_t)-1;      // read being searched by this lane
     uint64_t sbase = 0;           // off[rid]
     int pos = -1;                 // next base to prepend
@@ -127,15 +127,13 @@ __global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const
     uint32_t cache = 0;           // 4 bases of the read around pos
     bool live = false, exhausted = false;
 
+    FmdTickets tk_;
+    fmd_tickets_init(tk_, queue);
     for (;;) {
         // ---- refill finished lanes from the queue
-        const uint64_t want = __ballot(!live && !exhausted);
-        if (want) {
-            uint32_t first = 0;
-            if (lane == 0) first = atomicAdd(queue, (uint32_t)__popcll(want));
-            first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+        {
+            const size_t my = fmd_tickets_take(tk_, queue, !live && !exhausted);
             if (!live && !exhausted) {
-                const size_t my = (size_t)first + __popcll(want & ((1ull << lane) - 1));
                 if (my < n) {
                     rid = my; sbase = off[my];
                     const int len = (int)(off[my + 1] - sbase);
@@ -193,19 +191,17 @@ __global__ __launch_bounds__(64) void k_retrieve(FmdIndexView ix, size_t n, cons
                                                  uint32_t *__restrict__ queue)
 {
     FMD_DECLARE_WAVE_LDS();
-    const int lane = fmd_lane();
+
     size_t rid = 0;
     uint64_t k = 0;
     uint32_t len = 0;
     bool live = false, exhausted = false;
+    FmdTickets tk_;
+    fmd_tickets_init(tk_, queue);
     for (;;) {
-        const uint64_t want = __ballot(!live && !exhausted);
-        if (want) {
-            uint32_t first = 0;
-            if (lane == 0) first = atomicAdd(queue, (uint32_t)__popcll(want));
-            first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+        {
+            const size_t my = fmd_tickets_take(tk_, queue, !live && !exhausted);
             if (!live && !exhausted) {
-                const size_t my = (size_t)first + __popcll(want & ((1ull << lane) - 1));
                 if (my < n) { rid = my; k = d_x[my]; len = 0; live = true; }
                 else exhausted = true;
             }

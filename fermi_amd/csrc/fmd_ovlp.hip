@@ -25,8 +25,10 @@ __global__ __launch_bounds__(64) void k_ovl_retrieve(FmdIndexView ix, size_t n, 
     uint64_t k = 0;
     uint32_t len = 0, pack = 0;
     bool live = false, exhausted = false;
+    FmdTickets tk_;
+    fmd_tickets_init(tk_, queue);
     for (;;) {
-        const size_t my = fmd_queue_take(queue, !live && !exhausted);
+        const size_t my = fmd_tickets_take(tk_, queue, !live && !exhausted);
         if (!live && !exhausted) {
             if (my < n) { sid = my; k = ids[my]; len = 0; pack = 0; live = true; }
             else exhausted = true;
@@ -70,8 +72,10 @@ __global__ __launch_bounds__(64) void k_ovl_intv(FmdIndexView ix, size_t n, int 
     uint32_t npush = 0, cache = 0;
     uint64_t x0 = 0, x1 = 0, sz = 0;
     bool live = false, exhausted = false;
+    FmdTickets tk_;
+    fmd_tickets_init(tk_, queue);
     for (;;) {
-        const size_t my = fmd_queue_take(queue, !live && !exhausted);
+        const size_t my = fmd_tickets_take(tk_, queue, !live && !exhausted);
         if (!live && !exhausted) {
             if (my < n) {
                 sid = my; L = rec[my].len;
@@ -179,8 +183,10 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
     uint32_t depth = 0, npush = 0, pack = 0, flags = 0;
     uint64_t k = 0, x0 = 0, x1 = 0, sz = 0;
     bool exhausted = false;
+    FmdTickets tk_;
+    fmd_tickets_init(tk_, queue);
     for (;;) {
-        const size_t my = fmd_queue_take(queue, st == WK_IDLE && !exhausted);
+        const size_t my = fmd_tickets_take(tk_, queue, st == WK_IDLE && !exhausted);
         if (st == WK_IDLE && !exhausted) {
             if (my < n) { sid = my; k = ids[my]; depth = 0; npush = 0; pack = 0; flags = 0; ret = 0; st = WK_LF; }
             else exhausted = true;
@@ -380,9 +386,11 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
     I3 o0 = {0, 0, 0}, oc1 = {0, 0, 0}, oc2 = {0, 0, 0}, oc3 = {0, 0, 0}, oc4 = {0, 0, 0}; // its children
     uint64_t nx0 = 0, nsz = 0, ninfo = 0;             // first neighbour
 
+    FmdTickets tk_;
+    fmd_tickets_init(tk_, queue);
     for (;;) {
         // ---- refill
-        const size_t my = fmd_queue_take(queue, st == ST_IDLE && !exhausted);
+        const size_t my = fmd_tickets_take(tk_, queue, st == ST_IDLE && !exhausted);
         if (st == ST_IDLE && !exhausted) {
             if (my < n) {
                 const size_t strand = work_list ? (size_t)work_list[my] : my;
@@ -593,8 +601,10 @@ __global__ __launch_bounds__(64) void k_ovl_cls(FmdIndexView ix, size_t n, int m
     fmd_intv_t *prev = nullptr, *curr = nullptr;
     const uint8_t *s = nullptr;
     bool exhausted = false;
+    FmdTickets tk_;
+    fmd_tickets_init(tk_, queue);
     for (;;) {
-        const size_t my = fmd_queue_take(queue, st == CL_IDLE && !exhausted);
+        const size_t my = fmd_tickets_take(tk_, queue, st == CL_IDLE && !exhausted);
         if (st == CL_IDLE && !exhausted) {
             if (my < n) {
                 fmd_ovlp_rec_t *o = rec + my;

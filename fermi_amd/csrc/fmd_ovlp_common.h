@@ -15,17 +15,6 @@ __device__ __forceinline__ T sel6(int c, T a0, T a1, T a2, T a3, T a4, T a5)
     return r;
 }
 
-// queue refill shared by the persistent kernels: returns the item index for lanes that asked
-__device__ __forceinline__ size_t fmd_queue_take(uint32_t *queue, bool want)
-{
-    const uint64_t m = __ballot(want);
-    if (m == 0) return (size_t)-1;
-    uint32_t first = 0;
-    if (fmd_lane() == 0) first = atomicAdd(queue, (uint32_t)__popcll(m));
-    first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
-    return want ? (size_t)first + __popcll(m & ((1ull << fmd_lane()) - 1)) : (size_t)-1;
-}
-
 __device__ __forceinline__ void load_entry(const fmd_intv_t *e, uint64_t &x0, uint64_t &x1, uint64_t &sz, uint64_t &info)
 {
     const uint4 *q = (const uint4 *)e;

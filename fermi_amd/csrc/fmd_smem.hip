@@ -1,13 +1,14 @@
 // fmd_smem.hip -- super-maximal exact matches: fm6_smem1_core (smem.c:13-80) driven as fm6_smem
 // does (smem.c:397-410), i.e. what `fermi exact` prints (cmd.c:319-327).  One lane per read on the
-// wave engine; the forward sweep is a chain of forward extensions, the backward sweep walks the
-// whole candidate list once per base.  Candidate lists live in an HBM work area (two lists of
-// 2*max_len+2 entries per read); SMEMs are written to the caller's array in the reference's order.
+// compact wave engine (13 waves/CU); the forward sweep is a chain of forward extensions, the
+// backward sweep walks the whole candidate list once per base.  Candidate lists live in an HBM work
+// area owned by the persistent LANE (two lists of 2*max_len+2 entries, reused read after read, so the
+// area does not grow with the batch); SMEMs are written to the caller's array in the reference's order.
 #include <stdlib.h>
 #include <string.h>
 #include "fmd_internal.h"
+#include "fmd_ovlp_common.h"
 
-#define NONE64 (~0ull)
 #define MASK30 0x3fffffffull
 
 __device__ __forceinline__ int s_comp6(int c) { return (c >= 1 && c <= 4) ? 5 - c : c; }
@@ -36,38 +37,48 @@ __device__ __forceinline__ void s_store(fmd_intv_t *e, uint64_t x0, uint64_t x1,
 
 enum { SM_IDLE = 0, SM_START, SM_BEGIN_BWD, SM_BWD_PICK, SM_FWD, SM_FWD_END, SM_BWD };
 
+#define SMEM_LDS_BYTES (FMD_COMPACT_LDS_U4 * 16)
+#define SMEM_MAX_WAVES 4096   // the candidate lists belong to the persistent lane, not to the read
+
 __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ off,
                                              int self_match, uint32_t cap, fmd_intv_t *__restrict__ work, uint32_t max_mem,
-                                             fmd_intv_t *__restrict__ mem_out, uint32_t *__restrict__ n_mem_out, uint32_t *__restrict__ queue)
+                                             fmd_intv_t *__restrict__ mem_out, uint32_t *__restrict__ n_mem_out, uint32_t *__restrict__ queue,
+                                             int refill_min)
 {
-    FMD_DECLARE_WAVE_LDS();
+    FMD_DECLARE_COMPACT_LDS();
     size_t rid = 0;
     const uint8_t *q = nullptr;
     int st = SM_IDLE, len = 0, x = 0, i = 0, ret = 0;
     uint32_t prev_n = 0, curr_n = 0, j = 0, n_mem = 0, call_base = 0;
-    fmd_intv_t *la = nullptr, *lb = nullptr, *prev = nullptr, *curr = nullptr;
+    // two candidate lists of `cap` entries per lane (HBM; this lane's area is reused read after read)
+    fmd_intv_t *const la = work + ((size_t)blockIdx.x * 64 + fmd_lane()) * 2 * (size_t)cap, *const lb = la + cap;
+    fmd_intv_t *prev = nullptr, *curr = nullptr;
     uint64_t kx0 = 0, kx1 = 0, ksz = 0, kinfo = 0;   // ik (forward sweep) / p (backward sweep)
     uint64_t last_curr_sz = 0, last_mem_beg = 0;
+    uint64_t sbase = 0;                              // off[rid]
+    uint32_t cw = 0; uint64_t cw_at = ~0ull;         // four bases of the read around the position in use
+    uint4 pfa = make_uint4(0, 0, 0, 0), pfb = pfa;   // prev[j + 1], fetched under the gather of prev[j]
+    bool have_pf = false;
     bool exhausted = false, overflow = false;
 
+    FmdTickets tk_;
+    fmd_tickets_init(tk_, queue);
     for (;;) {
         // ---- refill
-        const uint64_t want = __ballot(st == SM_IDLE && !exhausted);
-        if (want) {
-            uint32_t first = 0;
-            if (fmd_lane() == 0) first = atomicAdd(queue, (uint32_t)__popcll(want));
-            first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
-            if (st == SM_IDLE && !exhausted) {
-                const size_t my = (size_t)first + __popcll(want & ((1ull << fmd_lane()) - 1));
-                if (my < n) {
-                    rid = my; q = seqs + off[my]; len = (int)(off[my + 1] - off[my]);
-                    la = work + rid * 2 * (size_t)cap; lb = la + cap;
-                    n_mem = 0; overflow = false; x = 0;
-                    if (len <= 0) n_mem_out[rid] = 0;
-                    else if (2 * (uint32_t)len + 2 > cap) n_mem_out[rid] = 0x80000000u; // longer than max_len
-                    else st = SM_START;
-                } else exhausted = true;
-            }
+        // Reads are taken in groups of at least refill_min lanes: a new read starts with ~log4(n) steps on
+        // wide intervals (two six-symbol block ranks), and a wave pays for that code path whenever ONE
+        // lane is in it; starting reads together keeps most steps free of it.
+        const uint64_t idle = __ballot(st == SM_IDLE);
+        const bool take = !exhausted && (__popcll(idle) >= refill_min || idle == ~0ull);
+        const size_t my = fmd_tickets_take(tk_, queue, st == SM_IDLE && take);
+        if (st == SM_IDLE && take) {
+            if (my < n) {
+                rid = my; sbase = off[my]; q = seqs + sbase; len = (int)(off[my + 1] - sbase); cw_at = ~0ull;
+                n_mem = 0; overflow = false; x = 0;
+                if (len <= 0) n_mem_out[rid] = 0;
+                else if (2 * (uint32_t)len + 2 > cap) n_mem_out[rid] = 0x80000000u; // longer than max_len
+                else st = SM_START;
+            } else exhausted = true;
         }
         // ---- transitions that need no rank
         bool again = st == SM_START || st == SM_BEGIN_BWD || st == SM_BWD_PICK;
@@ -91,14 +102,20 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
                 uint64_t t0, t1, t2, t3;
                 s_load(prev, t0, t1, t2, t3);
                 ret = (int)t3;
-                curr = lb; curr_n = 0; j = 0; i = x - 1; last_mem_beg = 0;
+                curr = lb; curr_n = 0; j = 0; i = x - 1; last_mem_beg = 0; have_pf = false;
                 st = SM_BWD_PICK; again = true;
             } else if (st == SM_BWD_PICK) {
-                if (j < prev_n) { s_load(prev + j, kx0, kx1, ksz, kinfo); st = SM_BWD; }
-                else if (curr_n != 0 && i != -1) { // next base to the left (smem.c:76-77)
+                if (j < prev_n) {
+                    if (have_pf) {
+                        kx0 = (uint64_t)pfa.y << 32 | pfa.x; kx1 = (uint64_t)pfa.w << 32 | pfa.z;
+                        ksz = (uint64_t)pfb.y << 32 | pfb.x; kinfo = (uint64_t)pfb.w << 32 | pfb.z;
+                    } else s_load(prev + j, kx0, kx1, ksz, kinfo);
+                    have_pf = false;
+                    st = SM_BWD;
+                } else if (curr_n != 0 && i != -1) { // next base to the left (smem.c:76-77)
                     prev = curr; prev_n = curr_n;
                     curr = (prev == lb) ? la : lb; // lists start at index 0 of their areas from now on
-                    curr_n = 0; j = 0; --i; again = true;
+                    curr_n = 0; j = 0; --i; have_pf = false; again = true;
                 } else { // this call is over: fm_reverse_fmivec(mem) (smem.c:79), then the next start (smem.c:404-409)
                     if (n_mem <= max_mem)
                         for (uint32_t a = call_base, b = n_mem; a + 1 < b; ++a) {
@@ -116,77 +133,122 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
         }
         if (__ballot(st != SM_IDLE) == 0) { if (__ballot(!exhausted) == 0) break; else continue; }
 
-        // ---- rank2a request
-        uint64_t qk = NONE64, ql = NONE64;
+        // ---- rank2a request: the two ends of the extension of [a, a + size)
+        const bool act = st != SM_IDLE;
         const bool fwd = st == SM_FWD || st == SM_FWD_END;
-        if (st != SM_IDLE) { const uint64_t a = fwd ? kx1 : kx0; qk = a - 1; ql = a - 1 + ksz; }
-        const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, qk, ql);
-        if (st != SM_IDLE) {
-            uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tl[6] = {0, 0, 0, 0, 0, 0};
-            if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
-            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
-            uint64_t s[6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) s[c] = tl[c] - tk[c];
-            // other-strand coordinate of child c: running sum in the order $,T,G,C,A,N (exact.c:81-86)
-            const uint64_t base = fwd ? kx0 : kx1;
-            const uint64_t r0 = base, r4 = r0 + s[0], r3 = r4 + s[4], r2 = r3 + s[3], r1 = r2 + s[2], r5 = r1 + s[1];
+        const uint64_t a0 = fwd ? kx1 : kx0;
+        // the symbol this step moves to (FWD_END only looks at '$'); the read is touched one aligned
+        // word per four bases, and that load rides under the gather as well
+        int c = 0;
+        if (st == SM_FWD || (st == SM_BWD && i >= 0)) {
+            const uint64_t a = sbase + (uint64_t)i;
+            if ((a & ~3ull) != cw_at) { cw_at = a & ~3ull; cw = *(const uint32_t *)(seqs + cw_at); }
+        }
+        if (st == SM_BWD && j + 1 < prev_n) { // next list entry rides under this gather
+            const uint4 *pq = (const uint4 *)(prev + j + 1);
+            pfa = pq[0]; pfb = pq[1]; have_pf = true;
+        }
+        FmdRank2c r = fmd_wave_rank2_fetch_compact(ix, fmd_lds, act ? a0 - 1 : NONE64, act ? a0 - 1 + ksz : NONE64);
+        if (st == SM_FWD || (st == SM_BWD && i >= 0)) c = (int)((cw >> (8 * ((sbase + (uint64_t)i) & 3))) & 0xff);
+        if (st == SM_FWD) c = s_comp6(c);
+        // narrow interval: everything comes from one 64-position window; a lane whose window straddles
+        // two blocks in a two-phase step (the dense slot is reused for the l side) takes the general path
+        const bool narrow = act && ksz <= 63 && !(r.two_phase && r.l_sep);
+        uint64_t tk[6] = {0, 0, 0, 0, 0, 0};
+        if (r.two_phase && act && !narrow && r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
+        const bool was_two_phase = r.two_phase;
+        fmd_wave_l_ready(ix, fmd_lds, r);
+        if (!act) continue;
 
-            if (st == SM_FWD) {
-                const int c = s_comp6(q[i]);
-                const uint64_t sc = s_sel6(c, s[0], s[1], s[2], s[3], s[4], s[5]);
-                if (sc != ksz) { // change of the interval size (smem.c:25-31)
-                    if (ksz != s[0]) { s_store(la + (cap - 1 - curr_n), kx0, kx1, ksz, kinfo); ++curr_n; }
-                    if (!self_match && s[0]) { s_store(la + (cap - 1 - curr_n), r0, ix.cnt[0] + tk[0], s[0], (uint64_t)i); ++curr_n; }
-                }
-                if ((!self_match && sc == 0) || (self_match && sc < 2)) st = SM_BEGIN_BWD; // cannot be extended
-                else {
-                    kx1 = s_sel6(c, ix.cnt[0], ix.cnt[1], ix.cnt[2], ix.cnt[3], ix.cnt[4], ix.cnt[5]) +
-                          s_sel6(c, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
-                    kx0 = s_sel6(c, r0, r1, r2, r3, r4, r5); ksz = sc; kinfo = (uint64_t)(i + 1);
-                    ++i;
-                    if (i == len) { // reached the end: always push (smem.c:35-37)
-                        s_store(la + (cap - 1 - curr_n), kx0, kx1, ksz, kinfo); ++curr_n;
-                        st = self_match ? SM_BEGIN_BWD : SM_FWD_END;
-                    }
-                }
-            } else if (st == SM_FWD_END) { // is the last interval terminated by a sentinel? (smem.c:38-43)
-                if (s[0]) { s_store(la + (cap - 1 - curr_n), r0, ix.cnt[0] + tk[0], s[0], (uint64_t)len); ++curr_n; }
-                st = SM_BEGIN_BWD;
-            } else { // SM_BWD: one interval of the list against base q[i] (smem.c:53-74)
-                const int c = i < 0 ? 0 : q[i];
-                const uint64_t sc = s_sel6(c, s[0], s[1], s[2], s[3], s[4], s[5]);
-                const bool fl_match = s[0] && kx1 < ix.n_seq;
-                const bool cont = self_match ? sc > 1 : sc != 0;
-                if (!cont || fl_match || i == -1) {
-                    if (curr_n == 0 || fl_match) {
-                        if (fl_match || n_mem == call_base || (uint64_t)(i + 1) < last_mem_beg) { // skip contained matches
-                            const uint64_t inf = kinfo | (uint64_t)(s[0] != 0) << 63 | (uint64_t)(i + 1) << 32;
-                            if (n_mem < max_mem) s_store(mem_out + rid * (size_t)max_mem + n_mem, kx0, kx1, ksz, inf);
-                            else overflow = true;
-                            ++n_mem;
-                            last_mem_beg = (uint64_t)(i + 1);
-                        }
-                    }
-                }
-                if (cont && (kx1 < ix.n_seq || curr_n == 0 || sc != last_curr_sz)) {
-                    const uint64_t nx0 = s_sel6(c, ix.cnt[0], ix.cnt[1], ix.cnt[2], ix.cnt[3], ix.cnt[4], ix.cnt[5]) +
-                                         s_sel6(c, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
-                    const uint64_t nx1 = s_sel6(c, r0, r1, r2, r3, r4, r5);
-                    s_store(curr + curr_n, nx0, nx1, sc, kinfo);
-                    last_curr_sz = sc;
-                    ++curr_n;
-                }
-                ++j;
-                st = SM_BWD_PICK;
+        uint64_t s[6], tkc, tk0;
+        bool have_tk0 = false;
+        if (narrow) { // all six child sizes from one 64-position window of BWT[a, a + size), one absolute rank
+            const uint32_t bk_ = (uint32_t)((a0 - 1) >> FMD_BLK_SHIFT), bl_ = (uint32_t)((a0 - 1 + ksz) >> FMD_BLK_SHIFT);
+            const bool sep = bl_ != bk_;
+            const uint64_t gw = a0 >> 5; const uint32_t sh = (uint32_t)a0 & 31;
+            const uint4 wa = grp_chunk(r.bk, r.t, r.bl, r.tl, bk_, bl_, sep, gw), wb = grp_chunk(r.bk, r.t, r.bl, r.tl, bk_, bl_, sep, gw + 1),
+                        wc = grp_chunk(r.bk, r.t, r.bl, r.tl, bk_, bl_, sep, gw + 2);
+            const uint64_t m = (1ull << (int)ksz) - 1;
+            const uint64_t X = win64(wa.x, wb.x, wc.x, sh), Y = win64(wa.y, wb.y, wc.y, sh), Z = win64(wa.z, wb.z, wc.z, sh);
+            const uint64_t lo = ~Z & m, hi = Z & ~Y & m;
+            s[0] = __popcll(lo & ~Y & ~X); s[1] = __popcll(lo & ~Y & X); s[2] = __popcll(lo & Y & ~X); s[3] = __popcll(lo & Y & X);
+            s[4] = __popcll(hi & ~X); s[5] = __popcll(hi & X);
+            tkc = r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, c) : 0;
+            tk0 = tkc; have_tk0 = c == 0;
+        } else {
+            uint64_t tl[6] = {0, 0, 0, 0, 0, 0};
+            if (!was_two_phase && r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
+            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
+#pragma unroll
+            for (int b = 0; b < 6; ++b) s[b] = tl[b] - tk[b];
+            tkc = s_sel6(c, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
+            tk0 = tk[0]; have_tk0 = true;
+        }
+        const uint64_t sc = s_sel6(c, s[0], s[1], s[2], s[3], s[4], s[5]);
+        // other-strand coordinate of child c: running sum in the order $,T,G,C,A,N (exact.c:81-86)
+        const uint64_t base = fwd ? kx0 : kx1;
+        uint64_t before = 0;
+        if (c != 0) before += s[0];
+        if (c == 3 || c == 2 || c == 1 || c == 5) before += s[4];
+        if (c == 2 || c == 1 || c == 5) before += s[3];
+        if (c == 1 || c == 5) before += s[2];
+        if (c == 5) before += s[1];
+        const uint64_t rc = base + before;                 // child c
+        const uint64_t nxc = ix.cnt[c] + tkc;              // its coordinate on the extended strand
+        // the '$' child of a forward extension (pushed by the forward sweep when !self_match)
+        if ((st == SM_FWD || st == SM_FWD_END) && !self_match && s[0] && !have_tk0) tk0 = r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, 0) : 0;
+
+        if (st == SM_FWD) {
+            if (sc != ksz) { // change of the interval size (smem.c:25-31)
+                if (ksz != s[0]) { s_store(la + (cap - 1 - curr_n), kx0, kx1, ksz, kinfo); ++curr_n; }
+                if (!self_match && s[0]) { s_store(la + (cap - 1 - curr_n), base, ix.cnt[0] + tk0, s[0], (uint64_t)i); ++curr_n; }
             }
+            if ((!self_match && sc == 0) || (self_match && sc < 2)) st = SM_BEGIN_BWD; // cannot be extended
+            else {
+                kx1 = nxc; kx0 = rc; ksz = sc; kinfo = (uint64_t)(i + 1);
+                ++i;
+                if (i == len) { // reached the end: always push (smem.c:35-37)
+                    s_store(la + (cap - 1 - curr_n), kx0, kx1, ksz, kinfo); ++curr_n;
+                    st = self_match ? SM_BEGIN_BWD : SM_FWD_END;
+                }
+            }
+        } else if (st == SM_FWD_END) { // is the last interval terminated by a sentinel? (smem.c:38-43)
+            if (s[0]) { s_store(la + (cap - 1 - curr_n), base, ix.cnt[0] + tk0, s[0], (uint64_t)len); ++curr_n; }
+            st = SM_BEGIN_BWD;
+        } else { // SM_BWD: one interval of the list against base q[i] (smem.c:53-74)
+            const bool fl_match = s[0] && kx1 < ix.n_seq;
+            const bool cont = self_match ? sc > 1 : sc != 0;
+            if (!cont || fl_match || i == -1) {
+                if (curr_n == 0 || fl_match) {
+                    if (fl_match || n_mem == call_base || (uint64_t)(i + 1) < last_mem_beg) { // skip contained matches
+                        const uint64_t inf = kinfo | (uint64_t)(s[0] != 0) << 63 | (uint64_t)(i + 1) << 32;
+                        if (n_mem < max_mem) s_store(mem_out + rid * (size_t)max_mem + n_mem, kx0, kx1, ksz, inf);
+                        else overflow = true;
+                        ++n_mem;
+                        last_mem_beg = (uint64_t)(i + 1);
+                    }
+                }
+            }
+            if (cont && (kx1 < ix.n_seq || curr_n == 0 || sc != last_curr_sz)) {
+                s_store(curr + curr_n, nxc, rc, sc, kinfo);
+                last_curr_sz = sc;
+                ++curr_n;
+            }
+            ++j;
+            st = SM_BWD_PICK;
         }
     }
 }
 
+static size_t smem_lanes(size_t n)
+{
+    const size_t waves = (n + 63) / 64;
+    return (waves < SMEM_MAX_WAVES ? waves : SMEM_MAX_WAVES) * 64;
+}
+
 extern "C" size_t fmd_smem_work_bytes(size_t n, uint32_t max_len)
 {
-    return n * 2 * (size_t)(2 * max_len + 2) * sizeof(fmd_intv_t) + 256;
+    return smem_lanes(n) * 2 * (size_t)(2 * max_len + 2) * sizeof(fmd_intv_t) + 256;
 }
 
 extern "C" int fmd_smem_dev(fmd_dev_t *h, void *stream_, size_t n, const uint8_t *d_seqs, const uint64_t *d_off, int self_match,
@@ -194,12 +256,15 @@ extern "C" int fmd_smem_dev(fmd_dev_t *h, void *stream_, size_t n, const uint8_t
 {
     if (!h || (n && (!d_seqs || !d_off || !d_mem || !d_n_mem || !d_work)) || max_len == 0 || max_mem == 0) return FMD_E_ARG;
     if (n == 0) return FMD_OK;
-    if (n >= 0xffffff00ull || work_bytes < fmd_smem_work_bytes(n, max_len)) return FMD_E_ARG;
+    if (n >= 0xffffff00ull || work_bytes < fmd_smem_work_bytes(n, max_len) || ((uintptr_t)d_seqs & 3)) return FMD_E_ARG;
     FMD_HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream_;
     uint32_t *q = fmd_next_queue(h, st);
-    k_smem<<<fmd_grid_for(h, n), 64, 0, st>>>(fmd_view(h), n, d_seqs, d_off, self_match ? 1 : 0, 2 * max_len + 2,
-                                              (fmd_intv_t *)d_work, max_mem, d_mem, d_n_mem, q);
+    int grid = fmd_grid_for_lds(h, n, SMEM_LDS_BYTES);
+    if (grid > SMEM_MAX_WAVES) grid = SMEM_MAX_WAVES;
+    static const int refill_min = getenv("FMD_SMEM_REFILL") ? atoi(getenv("FMD_SMEM_REFILL")) : 8;
+    k_smem<<<grid, 64, 0, st>>>(fmd_view(h), n, d_seqs, d_off, self_match ? 1 : 0, 2 * max_len + 2,
+                                (fmd_intv_t *)d_work, max_mem, d_mem, d_n_mem, q, refill_min);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "k_smem"); return FMD_E_HIP; }
     return FMD_OK;

@@ -85,7 +85,8 @@ __device__ __forceinline__ int fmd_lds_base(int q, int slot) { return slot * 512
 
 __device__ __forceinline__ uint32_t fmd_mask32(int rem) // low `rem` bits set, rem clamped to [0,32]
 {
-    return rem >= 32 ? 0xffffffffu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+    const int r = rem < 0 ? 0 : (rem > 32 ? 32 : rem);      // v_med3_i32
+    return (uint32_t)(1ull << r) - 1u;                      // r = 32: low word of 2^32 is 0 -> all ones
 }
 
 // Counts of all six symbols in BWT[0..k] from the lane's block image; npos = (k & 255) + 1.
@@ -93,27 +94,30 @@ __device__ __forceinline__ uint32_t fmd_mask32(int rem) // low `rem` bits set, r
 template <bool WANT_SYM>
 __device__ __forceinline__ int fmd_block_rank6(const uint4 *blk, int t, uint32_t npos, uint64_t out[6])
 {
-    uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0, n4 = 0, meta[8];
+    // five popcounts per chunk instead of six symbol masks: with x = |X|, y = |Y|, z = |Z|, xy = |X&Y|,
+    // xz = |X&Z| over the counted positions (Y and Z are never set together: codes 6, 7 do not occur)
+    //   T = z - xz, N = xz, G = xy, C = y - xy, A = x - xy - xz, $ = npos - (x + y + z - xy - xz)
+    uint32_t cx = 0, cy = 0, cz = 0, cxy = 0, cxz = 0, meta[8];
     uint32_t s0 = 0, s1 = 0, s2 = 0;
     const uint32_t off = npos - 1;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const uint4 v = blk[c ^ t];
         const uint32_t m = fmd_mask32((int)npos - 32 * c);
-        const uint32_t lo = ~v.z & m;           // symbols 0..3
-        const uint32_t a = lo & ~v.y, b = lo & v.y;
-        n0 += __builtin_popcount(a & ~v.x);     // $ 000
-        n1 += __builtin_popcount(a & v.x);      // A 001
-        n2 += __builtin_popcount(b & ~v.x);     // C 010
-        n3 += __builtin_popcount(b & v.x);      // G 011
-        n4 += __builtin_popcount(v.z & m & ~v.y & ~v.x); // T 100
+        const uint32_t xm = v.x & m;
+        cx += __builtin_popcount(xm);
+        cy += __builtin_popcount(v.y & m);
+        cz += __builtin_popcount(v.z & m);
+        cxy += __builtin_popcount(xm & v.y);
+        cxz += __builtin_popcount(xm & v.z);
         meta[c] = v.w;
         if (WANT_SYM) {
             const bool here = (off >> 5) == (uint32_t)c;
             s0 = here ? v.x : s0; s1 = here ? v.y : s1; s2 = here ? v.z : s2;
         }
     }
-    const uint32_t n5 = npos - (n0 + n1 + n2 + n3 + n4); // N 101 (positions past the BWT end are never counted)
+    const uint32_t n5 = cxz, n4 = cz - cxz, n3 = cxy, n2 = cy - cxy, n1 = cx - cxy - cxz;
+    const uint32_t n0 = npos - (n1 + n2 + n3 + n4 + n5); // positions past the BWT end are never counted
     out[0] = ((uint64_t)(meta[6] & 0xff) << 32 | meta[0]) + n0;
     out[1] = ((uint64_t)((meta[6] >> 8) & 0xff) << 32 | meta[1]) + n1;
     out[2] = ((uint64_t)((meta[6] >> 16) & 0xff) << 32 | meta[2]) + n2;
@@ -143,6 +147,47 @@ __device__ __forceinline__ uint64_t fmd_block_rank1(const uint4 *blk, int t, uin
         if (j == 7) hi = (c >= 4) ? (v.w >> (8 * (c - 4))) & 0xff : hi;
     }
     return ((uint64_t)hi << 32 | lo) + n;
+}
+
+// ---- work queue of the persistent kernels --------------------------------------------------------
+// Items are handed out by ONE device-wide counter.  A wave does not pay an atomic round trip (which
+// crosses the fabric: the counter is shared by all XCDs) every time a lane finishes: it holds a
+// small pool of tickets and reserves the next chunk as soon as it starts on the current one, so
+// the atomic's latency hides behind ~FMD_TICKET_CHUNK finished searches.  Lanes that want an item
+// get consecutive tickets by ballot prefix; a ticket >= n means the queue is drained.
+#define FMD_TICKET_CHUNK 16
+struct FmdTickets {
+    uint32_t cur, end;   // wave-uniform: tickets [cur, end) are ours
+    uint32_t nxt;        // lane 0: first ticket of the chunk reserved ahead (atomic may still be in flight)
+};
+
+__device__ __forceinline__ void fmd_tickets_init(FmdTickets &t, uint32_t *queue)
+{
+    uint32_t v = 0;
+    if (fmd_lane() == 0) v = atomicAdd(queue, 64u + FMD_TICKET_CHUNK); // one item per lane to start with + the chunk ahead
+    v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    t.cur = v; t.end = v + 64; t.nxt = v + 64;
+}
+
+// All 64 lanes call this together; returns the item of each lane that asked, (size_t)-1 otherwise.
+__device__ __forceinline__ size_t fmd_tickets_take(FmdTickets &t, uint32_t *queue, bool want)
+{
+    const uint64_t m = __ballot(want);
+    if (m == 0) return (size_t)-1;
+    const uint32_t p = (uint32_t)__popcll(m & ((1ull << fmd_lane()) - 1)), need = (uint32_t)__popcll(m);
+    uint32_t served = 0;
+    size_t res = (size_t)-1;
+    for (;;) {
+        const uint32_t avail = t.end - t.cur, k = avail < need - served ? avail : need - served;
+        if (want && p - served < k) res = (size_t)t.cur + (p - served);
+        t.cur += k; served += k;
+        if (served == need) break;
+        t.cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.nxt); t.end = t.cur + FMD_TICKET_CHUNK;
+        uint32_t v = 0;
+        if (fmd_lane() == 0) v = atomicAdd(queue, (uint32_t)FMD_TICKET_CHUNK);
+        t.nxt = v;
+    }
+    return res;
 }
 
 // The per-wave LDS area.  Kernels are launched with 64-thread workgroups (one wave each), so no

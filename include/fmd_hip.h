@@ -103,7 +103,9 @@ int fmd_retrieve_batch(fmd_dev_t *h, size_t n, const uint64_t *x, uint8_t *seqs,
  * (smem.c:13-80); what `fermi exact [-s]` prints (cmd.c:319-327, smem.c:412-418).
  * mem: n rows of max_mem intervals in the reference's order; info = leftclosed<<63 | beg<<32 | end
  * (FM_MASK30 fields, smem.c:63).  n_mem[i] = number of SMEMs of read i; bit 31 set = the read was
- * longer than max_len or produced more than max_mem SMEMs (row invalid: re-run larger). */
+ * longer than max_len or produced more than max_mem SMEMs (row invalid: re-run larger).
+ * d_seqs: 4-byte aligned and readable up to the next multiple of 4 past off[n] (the kernels read
+ * the sequences one aligned word at a time); same for fmd_bsearch_dev. */
 size_t fmd_smem_work_bytes(size_t n, uint32_t max_len);
 int fmd_smem_dev(fmd_dev_t *h, void *stream, size_t n, const uint8_t *d_seqs, const uint64_t *d_off, int self_match,
                  uint32_t max_len, uint32_t max_mem, fmd_intv_t *d_mem, uint32_t *d_n_mem, void *d_work, size_t work_bytes);

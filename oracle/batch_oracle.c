@@ -113,3 +113,36 @@ void orc_overlap_batch(const orc_rld_t *e, size_t n, const uint64_t *ids, int mi
     for (t = 0; t < n_threads; ++t) pthread_join(tid[t], 0);
     free(tid); free(w);
 }
+
+/* fm6_smem (smem.c:397-410) for n fixed-length reads, start/step threads; mem[i*max_mem ..) gets the
+ * first max_mem SMEMs of read i and n_mem[i] their true count -- the layout fmd_smem_dev writes. */
+typedef struct { const orc_rld_t *e; size_t n; int len; const uint8_t *seqs; int self_match; uint32_t max_mem; orc_intv_t *mem; uint32_t *n_mem; int start, step; } smj_t;
+static void *sm_worker(void *d)
+{
+    smj_t *w = (smj_t *)d;
+    orc_intv_v v = {0, 0, 0};
+    size_t i, j;
+    for (i = (size_t)w->start; i < w->n; i += (size_t)w->step) {
+        v.n = 0;
+        orc_smem(w->e, w->len, w->seqs + i * (size_t)w->len, &v, w->self_match);
+        w->n_mem[i] = (uint32_t)v.n;
+        for (j = 0; j < v.n && j < w->max_mem; ++j) w->mem[i * w->max_mem + j] = v.a[j];
+    }
+    free(v.a);
+    orc_counters_flush();
+    return 0;
+}
+void orc_smem_batch(const orc_rld_t *e, size_t n, int len, const uint8_t *seqs, int self_match, uint32_t max_mem,
+                    orc_intv_t *mem, uint32_t *n_mem, int n_threads)
+{
+    pthread_t *tid = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    smj_t *w = (smj_t *)calloc((size_t)n_threads, sizeof(smj_t));
+    int t;
+    for (t = 0; t < n_threads; ++t) {
+        smj_t x = {e, n, len, seqs, self_match, max_mem, mem, n_mem, t, n_threads};
+        w[t] = x;
+        pthread_create(&tid[t], 0, sm_worker, &w[t]);
+    }
+    for (t = 0; t < n_threads; ++t) pthread_join(tid[t], 0);
+    free(tid); free(w);
+}

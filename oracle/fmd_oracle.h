@@ -71,6 +71,8 @@ orc_intv_t *orc_traverse(const orc_rld_t *e, int depth);                        
 /* ---- SMEM (smem.c:13-80, 104, 397) ---- */
 int orc_smem1(const orc_rld_t *e, int len, const uint8_t *q, int x, orc_intv_v *mem, int self_match);
 int orc_smem(const orc_rld_t *e, int len, const uint8_t *q, orc_intv_v *mem, int self_match);
+void orc_smem_batch(const orc_rld_t *e, size_t n, int len, const uint8_t *seqs, int self_match, uint32_t max_mem,
+                    orc_intv_t *mem, uint32_t *n_mem, int n_threads);
 
 /* ---- overlap discovery (unitig.c:38-179), used == NULL / sorted == NULL form ---- */
 typedef struct { size_t n, m; uint8_t *s; } orc_str_t;

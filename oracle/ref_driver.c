@@ -121,3 +121,37 @@ double refdrv_overlap(void *e, size_t n, const uint64_t *ids, int min_match, voi
     free(tid); free(w);
     return t0;
 }
+
+/* fm6_smem (smem.c:397) per read; same output layout as fmd_smem_dev. */
+int fm6_smem(const struct __rld_t *e, int len, const uint8_t *q, fmintv_v *mem, int self_match); /* smem.c:397 */
+typedef struct { const struct __rld_t *e; size_t n; int len; const uint8_t *seqs; int self_match; uint32_t max_mem; fmintv_t *mem; uint32_t *n_mem; int start, step; } sm_t;
+static void *sm_worker(void *d)
+{
+    sm_t *w = (sm_t *)d;
+    fmintv_v v = {0, 0, 0};
+    size_t i, j;
+    for (i = (size_t)w->start; i < w->n; i += (size_t)w->step) {
+        v.n = 0;
+        fm6_smem(w->e, w->len, w->seqs + i * (size_t)w->len, &v, w->self_match);
+        w->n_mem[i] = (uint32_t)v.n;
+        for (j = 0; j < v.n && j < w->max_mem; ++j) w->mem[i * w->max_mem + j] = v.a[j];
+    }
+    free(v.a);
+    return 0;
+}
+double refdrv_smem(void *e, size_t n, int len, const uint8_t *seqs, int self_match, uint32_t max_mem, void *mem, uint32_t *n_mem, int n_threads)
+{
+    pthread_t *tid = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    sm_t *w = (sm_t *)calloc((size_t)n_threads, sizeof(sm_t));
+    int t;
+    double t0 = now();
+    for (t = 0; t < n_threads; ++t) {
+        sm_t x = {(const struct __rld_t *)e, n, len, seqs, self_match, max_mem, (fmintv_t *)mem, n_mem, t, n_threads};
+        w[t] = x;
+        pthread_create(&tid[t], 0, sm_worker, &w[t]);
+    }
+    for (t = 0; t < n_threads; ++t) pthread_join(tid[t], 0);
+    t0 = now() - t0;
+    free(tid); free(w);
+    return t0;
+}

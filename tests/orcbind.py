@@ -59,6 +59,7 @@ def lib():
         L.orc_backward_search_batch.argtypes = [P, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_traverse.restype = C.c_void_p; L.orc_traverse.argtypes = [P, C.c_int]
         L.orc_smem.restype = C.c_int; L.orc_smem.argtypes = [P, C.c_int, C.c_void_p, C.POINTER(IntvV), C.c_int]
+        L.orc_smem_batch.argtypes = [P, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_is_contained.restype = C.c_int
         L.orc_is_contained.argtypes = [P, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(IntvV)]
         L.orc_get_nei.restype = C.c_int
@@ -203,6 +204,14 @@ class OrcIndex:
         self.L.orc_overlap_batch(self.e, n, ids.ctypes.data, min_match, max_nei, rec.ctypes.data, nei.ctypes.data,
                                  seq.ctypes.data, stride, n_threads, int(check_left))
         return rec, nei, seq
+
+    def smem_batch(self, seqs, self_match=0, max_mem=32, n_threads=1):
+        """fm6_smem over an (n, len) uint8 array: (mem[n, max_mem] INTV_DT, n_mem[n]) as fmd_smem_dev writes them."""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        n, ln = seqs.shape
+        mem = np.zeros((n, max_mem), dtype=INTV_DT); n_mem = np.zeros(n, dtype=np.uint32)
+        self.L.orc_smem_batch(self.e, n, ln, seqs.ctypes.data, self_match, max_mem, mem.ctypes.data, n_mem.ctypes.data, n_threads)
+        return mem, n_mem
 
     def ec_collect(self, w, min_occ, suf_len):
         top = self.traverse(suf_len)

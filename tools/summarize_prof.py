@@ -47,7 +47,7 @@ for k, v in pr.items():
         known = (1 << 27) * 128
         cal = known / (kb * 1024.0)
         print("calibration: k_probe FETCH_SIZE = %.0f KB per launch for %d known bytes -> true/reported = %.3f\n" % (kb, known, cal))
-for sub in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
+for sub in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq", "pmc_inst"):
     a = pmc(sub)
     for k, v in a.items():
         if any(t in k for t in ("k_bsearch", "k_ovl", "k_retrieve", "k_smem", "k_kmer")):
