@@ -280,11 +280,11 @@ def smem_cpu_baseline(fmd_path, reads, max_mem, g_mem, g_nmem):
             "sample": "first %d reads of the batch, all %d host threads (1 thread: %.0f reads/s)" % (n, cores, n1 / t1)}, bool(ok)
 
 
-def bench_smem(torch, api, workload, dev, local_rank, n_reads, L, steps, warmup, dist, world, rank):
-    """SURVEY.md 8(d) config 3a: fm6_smem (what `fermi exact` runs) of every read against the index
-    of the same reads, reads carrying 1 % substitutions.  One step = all reads."""
+def bench_raw_reads(torch, api, workload, dev, local_rank, n_reads, L, steps, warmup, dist, world, rank):
+    """the index of reads that carry 1 % substitutions (what `fermi exact`
+    and `fermi correct` see before error correction).  Built once, used by the SMEM leg and the
+    k-mer harvest leg."""
     err = float(os.environ.get("FMD_BENCH_SMEM_ERR", "0.01"))
-    max_mem = 8
     t0 = time.time()
     reads = workload.synth_reads_host(n_reads, L, 30, err)
     rd = workload.ReadsOnDevice(reads, dev)
@@ -292,12 +292,155 @@ def bench_smem(torch, api, workload, dev, local_rank, n_reads, L, steps, warmup,
     torch.cuda.synchronize()
     fmd_path = None
     if rank == 0 and world == 1:
-        fmd_path = os.path.join(tempfile.gettempdir(), "fmd_bench_smem_%d_%d.fmd" % (n_reads, os.getpid()))
+        fmd_path = os.path.join(tempfile.gettempdir(), "fmd_bench_raw_%d_%d.fmd" % (n_reads, os.getpid()))
         workload.write_fmd_from_device_bwt(d_bwt, n_sym, fmd_path, local_rank)
     index = api.DevIndex.from_bwt_dev(d_bwt, n_sym, local_rank)
     api.lib().fmd_dev_free(d_bwt)
     if rank == 0:
-        log("smem setup: %d reads at e=%g, index of %d symbols, %.1fs" % (n_reads, err, n_sym, time.time() - t0))
+        log("raw-read index: %d reads at e=%g, %d symbols, %.1fs" % (n_reads, err, n_sym, time.time() - t0))
+    sm = km = None
+    try:
+        if os.environ.get("FMD_BENCH_SMEM", "1") != "0":
+            sm = bench_smem(torch, api, index, rd, reads, err, n_sym, fmd_path, dev, n_reads, L, steps, warmup, dist, world, rank)
+        if os.environ.get("FMD_BENCH_KMER", "1") != "0":
+            km = bench_kmer(torch, api, index, n_sym, fmd_path, dev, n_reads, steps, warmup, dist, world, rank)
+    finally:
+        if fmd_path and os.path.exists(fmd_path):
+            os.remove(fmd_path)
+        index.close()
+    return sm, km
+
+
+def kmer_cpu_baseline(fmd_path, w, min_occ, suf_len, n_buckets, g_trip):
+    """fm6_traverse + ec_collect (correct.c:35-87) over the first n_buckets suffix buckets on the host
+    cores: the reference's own static function through oracle/_ref/libref_ec.so when it travelled,
+    else our C port.  Parity = identical (bucket, key, val) multisets for those buckets."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    cores = os.cpu_count() or 1
+    drv = os.path.join(ROOT, "oracle", "_ref", "libref_ec.so")
+    n1 = max(1, n_buckets // 128)
+
+    def pack(B, K, V):
+        return np.sort(B.astype(np.uint64) << np.uint64(40) | K.astype(np.uint64) << np.uint64(8) | V.astype(np.uint64))
+    if os.path.exists(drv):
+        Lb = C.CDLL(drv)
+        Lb.refec_range.argtypes = [C.c_char_p] + [C.c_int] * 6 + [C.c_void_p] * 5
+        Lb.refec_free.argtypes = [C.c_void_p]
+
+        def run(b1, thr):
+            pb, pk, pv, n, secs = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_double()
+            rc = Lb.refec_range(fmd_path.encode(), w, min_occ, suf_len, 0, b1, thr, C.byref(pb), C.byref(pk), C.byref(pv), C.byref(n), C.byref(secs))
+            assert rc == 0
+            m = n.value
+            B = np.ctypeslib.as_array(C.cast(pb, C.POINTER(C.c_uint32)), (max(m, 1),))[:m].copy()
+            K = np.ctypeslib.as_array(C.cast(pk, C.POINTER(C.c_uint32)), (max(m, 1),))[:m].copy()
+            V = np.ctypeslib.as_array(C.cast(pv, C.POINTER(C.c_uint8)), (max(m, 1),))[:m].copy()
+            for p_ in (pb, pk, pv):
+                Lb.refec_free(p_)
+            return B, K, V, secs.value
+        kind = "reference"
+    else:
+        import orcbind
+        o = orcbind.OrcIndex(fmd_path)
+
+        def run(b1, thr):
+            return o.ec_range(w, min_occ, suf_len, 0, b1, thr)
+        kind = "port"
+    B1, _, _, t1 = run(n1, 1)
+    B, K, V, tall = run(n_buckets, cores)
+    ok = np.array_equal(pack(B, K, V), g_trip)
+    return {"value": len(B) / tall, "unit": "solid k-mers/s", "cores": cores, "kind": kind,
+            "sample": "suffix buckets 0..%d of %d (%d solid k-mers), all %d host threads (1 thread: %.0f k-mers/s)"
+                      % (n_buckets - 1, 1 << (2 * suf_len), len(B), cores, len(B1) / t1)}, bool(ok)
+
+
+def bench_kmer(torch, api, index, n_sym, fmd_path, dev, n_reads, steps, warmup, dist, world, rank):
+    """The k-mer harvest of `fermi correct` (fm6_traverse + ec_collect, correct.c:341-356) with the
+    reference's automatic k (correct.c:313-319) and -O 3.  One step = the whole index."""
+    import math
+    w = int(os.environ.get("FMD_BENCH_KMER_W", str(min(27, int(math.log(n_sym) / math.log(4) + 8.499)))))
+    min_occ, suf_len = 3, (w - 15 if w > 15 else 1)
+    cap = int(os.environ.get("FMD_BENCH_KMER_CAP", str(max(1 << 22, 1 << int(math.ceil(math.log2(n_sym / 30.0 * 1.5)))))))
+    lib = api.lib()
+    stream = torch.cuda.current_stream()
+    sh = C.c_void_p(stream.cuda_stream)
+    status = torch.zeros(4, dtype=torch.int64, device=dev)
+    while True:
+        wb = lib.fmd_kmer_work_bytes(cap)
+        work = torch.empty(wb, dtype=torch.uint8, device=dev)
+        ob = torch.empty(cap, dtype=torch.int32, device=dev); ok_ = torch.empty(cap, dtype=torch.int32, device=dev)
+        ov = torch.empty(cap, dtype=torch.uint8, device=dev)
+
+        def step():
+            api.check(lib.fmd_kmer_collect_dev(index.h, sh, w, min_occ, suf_len, work.data_ptr(), wb, cap, ob.data_ptr(), ok_.data_ptr(), ov.data_ptr(), status.data_ptr()))
+        step()
+        torch.cuda.synchronize()
+        st = status.cpu().numpy().view(np.uint64)
+        if st[1] == 0:
+            break
+        del work, ob, ok_, ov
+        cap *= 2
+        log("k-mer harvest: frontier overflow, retrying with cap %d" % cap)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    w0 = time.perf_counter()
+    for a, b in evs:
+        a.record(stream); step(); b.record(stream)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - w0
+    if dist:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    if rank != 0:
+        return None
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    st = status.cpu().numpy().view(np.uint64)
+    n_out = int(st[0])
+    ctr = work[: 72 * 8].cpu().numpy().view(np.uint64)
+    nodes = int(ctr[68])                     # trie nodes expanded = backward extensions (one rank2a each), counted by the kernels
+    out = {"metric": "solid k-mers/sec through fm6_traverse + ec_collect (fermi correct, k=%d, -O%d)" % (w, min_occ),
+           "value": n_out * world * steps / wall, "unit": "solid k-mers/s", "ms_per_step": wall / steps * 1e3,
+           "solid_kmers": n_out, "informative": int(st[3]), "extensions": nodes, "extensions_per_s": nodes * world * steps / wall,
+           "k": w, "suf_len": suf_len, "frontier_cap": cap}
+    if world == 1:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orcbind
+        o = orcbind.OrcIndex(fmd_path)
+        o.counters()
+        o.ec_range(w, min_occ, suf_len, 0, 16, 1)
+        cn = o.counters()
+        o.close()
+        spill = cn["rank2a_spill"] / max(cn["rank2a"], 1)
+        alg = nodes * (1.0 + spill) * BYTES_PER_RANK_QUERY
+        ach = alg / (kern_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "kernel": "k_kmer_level x %d + k_kmer_emit" % (w - 1), "kernel_ms": kern_ms,
+                           "rank_queries": nodes * (1.0 + spill), "rank2a_spill_rate_on_oracle_sample": spill,
+                           "oracle_counters_on_sample": cn}
+        nb = min(1 << (2 * suf_len), int(os.environ.get("FMD_BENCH_CPU_SAMPLE_KMER", "8192")))
+        gb = ob[:n_out].cpu().numpy().view(np.uint32); gk = ok_[:n_out].cpu().numpy().view(np.uint32); gv = ov[:n_out].cpu().numpy()
+        m = gb < nb
+        g_trip = np.sort(gb[m].astype(np.uint64) << np.uint64(40) | gk[m].astype(np.uint64) << np.uint64(8) | gv[m].astype(np.uint64))
+        base, ok = kmer_cpu_baseline(fmd_path, w, min_occ, suf_len, nb, g_trip)
+        out["cpu_baseline"] = base
+        out["parity_vs_cpu_on_sample"] = "bit-exact" if ok else "MISMATCH"
+        out["speedup_vs_cpu_all_cores"] = out["value"] / base["value"]
+    return out
+
+
+def bench_smem(torch, api, index, rd, reads, err, n_sym, fmd_path, dev, n_reads, L, steps, warmup, dist, world, rank):
+    """SURVEY.md 8(d) config 3a: fm6_smem (what `fermi exact` runs) of every read against the index
+    of the same reads, reads carrying 1 % substitutions.  One step = all reads."""
+    max_mem = 8
     batch = min(n_reads, int(os.environ.get("FMD_BENCH_SMEM_BATCH", str(n_reads))))
     mem = torch.zeros(n_reads * max_mem * 32, dtype=torch.uint8, device=dev)
     n_mem = torch.zeros(n_reads, dtype=torch.int32, device=dev)
@@ -358,9 +501,6 @@ def bench_smem(torch, api, workload, dev, local_rank, n_reads, L, steps, warmup,
             out["cpu_baseline"] = base
             out["parity_vs_cpu_on_sample"] = "bit-exact" if ok else "MISMATCH"
             out["speedup_vs_cpu_all_cores"] = out["value"] / base["value"]
-        if fmd_path and os.path.exists(fmd_path):
-            os.remove(fmd_path)
-    index.close()
     return out
 
 
@@ -464,9 +604,9 @@ def main():
     if os.environ.get("FMD_BENCH_OVERLAP", "1") != "0":
         ovl = bench_overlap(torch, api, index, dev, n_reads, L, max(1, min(args.steps, 2)), min(args.warmup, 1), dist, world, rank, fmd_path)
 
-    sm = None
-    if os.environ.get("FMD_BENCH_SMEM", "1") != "0":
-        sm = bench_smem(torch, api, workload, dev, local_rank, n_reads, L, max(1, min(args.steps, 2)), min(args.warmup, 1), dist, world, rank)
+    sm = km = None
+    if os.environ.get("FMD_BENCH_SMEM", "1") != "0" or os.environ.get("FMD_BENCH_KMER", "1") != "0":
+        sm, km = bench_raw_reads(torch, api, workload, dev, local_rank, n_reads, L, max(1, min(args.steps, 2)), min(args.warmup, 1), dist, world, rank)
 
     if rank == 0:
         g_cnt = cnt.cpu().numpy().view(np.uint64); g_beg = beg.cpu().numpy().view(np.uint64); g_end = end.cpu().numpy().view(np.uint64)
@@ -505,6 +645,8 @@ def main():
             out["overlap_discovery"] = ovl
         if sm:
             out["smem"] = sm
+        if km:
+            out["kmer_harvest"] = km
         print(json.dumps(out), flush=True)
         if fmd_path and os.path.exists(fmd_path):
             os.remove(fmd_path)

@@ -12,52 +12,93 @@
 // best (correct.c:71-73).
 #include <stdlib.h>
 #include <string.h>
+#include <hipcub/hipcub.hpp>
 #include "fmd_internal.h"
 
 #define NONE64 (~0ull)
 
 // counters in device memory: [0..63] frontier sizes per depth, [64] #output, [65] overflow flag,
-// [66] cnt[0] (k-mers kept), [67] cnt[1] (informative ones), correct.c:64-69
+// [66] cnt[0] (k-mers kept), [67] cnt[1] (informative ones), correct.c:64-69, [68] extensions
 #define KM_OUT 64
 #define KM_OVF 65
 #define KM_CNT0 66
 #define KM_CNT1 67
+#define KM_EXT 68      // backward extensions done (= trie nodes expanded), all levels
 #define KM_WORDS 72
 
 __device__ __forceinline__ void km_extend_back(const FmdIndexView &ix, uint4 *lds, bool active, uint64_t x0, uint64_t sz,
                                                uint64_t tk[6], uint64_t s[6])
 {
-    const FmdRank2 r = fmd_wave_rank2_fetch(ix, lds, active ? x0 - 1 : NONE64, active ? x0 - 1 + sz : NONE64);
+    FmdRank2c r = fmd_wave_rank2_fetch_compact(ix, lds, active ? x0 - 1 : NONE64, active ? x0 - 1 + sz : NONE64);
     uint64_t tl[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int c = 0; c < 6; ++c) tk[c] = 0;
-    if (active) {
-        if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
-        if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
-    }
+    if (active && r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
+    fmd_wave_l_ready(ix, lds, r);
+    if (active && r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
 #pragma unroll
     for (int c = 0; c < 6; ++c) s[c] = tl[c] - tk[c];
 }
 
+// Output space of a level is handed out in chunks of `ch` entries per wave: ONE device-wide atomic
+// per chunk instead of one per 64 nodes (a single counter serialises at ~10^8 atomics/s, which
+// capped the first version of this kernel at a twelfth of the gather rate).  A wave zero-fills
+// what it leaves unused of its last chunk (size 0 = hole; the next level skips holes), so a
+// frontier is "children + at most one partial chunk per wave".
+struct KmChunk { unsigned long long base; uint32_t fill, ch; bool have; };
+
+__device__ __forceinline__ void km_zero_fill(fmd_intv_t *out, uint64_t cap, const KmChunk &k)
+{
+    if (!k.have) return;
+    for (uint64_t e = k.base + k.fill + fmd_lane(); e < k.base + k.ch; e += 64)
+        if (e < cap) { uint4 *q = (uint4 *)(out + e); q[0] = make_uint4(0, 0, 0, 0); q[1] = make_uint4(0, 0, 0, 0); }
+}
+
+// first output slot for `tot` new entries of this wave (wave-uniform)
+__device__ __forceinline__ unsigned long long km_reserve(fmd_intv_t *out, uint64_t cap, KmChunk &k, uint32_t tot, unsigned long long *ctr_next)
+{
+    if (!k.have || k.fill + tot > k.ch) {
+        km_zero_fill(out, cap, k);
+        unsigned long long first = 0;
+        if (fmd_lane() == 0) first = atomicAdd(ctr_next, (unsigned long long)k.ch);
+        k.base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
+                 (unsigned int)__builtin_amdgcn_readfirstlane((int)first);
+        k.fill = 0; k.have = true;
+    }
+    const unsigned long long o = k.base + k.fill;
+    k.fill += tot;
+    return o;
+}
+
 // one trie level: nodes at depth d -> children at depth d+1
 __global__ __launch_bounds__(64) void k_kmer_level(FmdIndexView ix, int d, int suf_len, int min_occ, const fmd_intv_t *__restrict__ in,
-                                                   fmd_intv_t *__restrict__ out, uint64_t cap, unsigned long long *__restrict__ ctr)
+                                                   fmd_intv_t *__restrict__ out, uint64_t cap, uint32_t ch, unsigned long long *__restrict__ ctr)
 {
-    FMD_DECLARE_WAVE_LDS();
+    FMD_DECLARE_COMPACT_LDS();
     const int lane = fmd_lane();
     const uint64_t n = ctr[d] < cap ? ctr[d] : cap;   // an overflowing level counted more than it stored
     const uint64_t thr = (d + 1 <= suf_len) ? 1 : (uint64_t)min_occ; // exact.c:159 vs correct.c:78
     const uint64_t stride = (uint64_t)gridDim.x * 64;
+    KmChunk ck; ck.base = 0; ck.fill = 0; ck.ch = ch; ck.have = false;
+    uint32_t n_ext = 0;
+    uint4 na = make_uint4(0, 0, 0, 0), nb = na;       // the entry of the next iteration, loaded one gather ahead
+    {
+        const uint64_t i0 = (uint64_t)blockIdx.x * 64 + lane;
+        if (i0 < n) { const uint4 *q = (const uint4 *)(in + i0); na = q[0]; nb = q[1]; }
+    }
     for (uint64_t base = (uint64_t)blockIdx.x * 64; base < n; base += stride) {
-        const uint64_t i = base + lane;
-        const bool act = i < n;
-        uint64_t x0 = 0, x1 = 0, sz = 0, K = 0;
-        if (act) {
-            const uint4 *q = (const uint4 *)(in + i);
-            const uint4 a = q[0], b = q[1];
-            x0 = (uint64_t)a.y << 32 | a.x; x1 = (uint64_t)a.w << 32 | a.z;
-            sz = (uint64_t)b.y << 32 | b.x; K = (uint64_t)b.w << 32 | b.z;
+        const uint4 a = na, b = nb;
+        const uint64_t x0 = (uint64_t)a.y << 32 | a.x, x1 = (uint64_t)a.w << 32 | a.z;
+        const uint64_t sz = (uint64_t)b.y << 32 | b.x, K = (uint64_t)b.w << 32 | b.z;
+        const bool act = base + lane < n && sz != 0;
+        {
+            const uint64_t i1 = base + stride + lane;
+            na = make_uint4(0, 0, 0, 0); nb = na;
+            if (i1 < n) { const uint4 *q = (const uint4 *)(in + i1); na = q[0]; nb = q[1]; }
         }
+        const uint64_t m_act = __ballot(act);
+        if (m_act == 0) continue;                     // a run of holes
+        n_ext += (uint32_t)__popcll(m_act);
         uint64_t tk[6], s[6];
         km_extend_back(ix, fmd_lds, act, x0, sz, tk, s);
         // children c = 1..4 (ambiguous bases are skipped, correct.c:77); x[1] = running sum in
@@ -66,10 +107,7 @@ __global__ __launch_bounds__(64) void k_kmer_level(FmdIndexView ix, int d, int s
         const uint64_t m1 = __ballot(has1), m2 = __ballot(has2), m3 = __ballot(has3), m4 = __ballot(has4);
         const uint32_t tot = (uint32_t)(__popcll(m1) + __popcll(m2) + __popcll(m3) + __popcll(m4));
         if (tot == 0) continue;
-        unsigned long long first = 0;
-        if (lane == 0) first = atomicAdd(&ctr[d + 1], (unsigned long long)tot);
-        first = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
-                (unsigned int)__builtin_amdgcn_readfirstlane((int)first);
+        const unsigned long long first = km_reserve(out, cap, ck, tot, &ctr[d + 1]);
         const uint64_t lt = (1ull << lane) - 1;
         uint64_t o1 = first + __popcll(m1 & lt);
         uint64_t o2 = first + __popcll(m1) + __popcll(m2 & lt);
@@ -88,27 +126,42 @@ __global__ __launch_bounds__(64) void k_kmer_level(FmdIndexView ix, int d, int s
         KM_PUSH(1, has1, o1, x1_1) KM_PUSH(2, has2, o2, x1_2) KM_PUSH(3, has3, o3, x1_3) KM_PUSH(4, has4, o4, x1_4)
 #undef KM_PUSH
     }
+    km_zero_fill(out, cap, ck);
+    if (lane == 0 && n_ext) atomicAdd(&ctr[KM_EXT], (unsigned long long)n_ext);
 }
 
-// nodes at depth w: pick the most frequent next base and emit (bucket, key, val), correct.c:56-75
+// nodes at depth w: pick the most frequent next base and emit (bucket, key, val), correct.c:56-75.
+// No atomics in the loop: node i writes slot i of the raw arrays (flag 0 = nothing kept); the host
+// entry compacts them with hipCUB.  cnt[0]/cnt[1] are summed per wave and added once.
 __global__ __launch_bounds__(64) void k_kmer_emit(FmdIndexView ix, int w, int suf_len, int min_occ, const fmd_intv_t *__restrict__ in,
-                                                  uint32_t *__restrict__ o_bucket, uint32_t *__restrict__ o_key,
-                                                  uint8_t *__restrict__ o_val, uint64_t cap, unsigned long long *__restrict__ ctr)
+                                                  uint32_t *__restrict__ r_bucket, uint32_t *__restrict__ r_key,
+                                                  uint8_t *__restrict__ r_val, uint8_t *__restrict__ r_flag, uint64_t cap,
+                                                  unsigned long long *__restrict__ ctr)
 {
-    FMD_DECLARE_WAVE_LDS();
+    FMD_DECLARE_COMPACT_LDS();
     const int lane = fmd_lane();
     const uint64_t n = ctr[w] < cap ? ctr[w] : cap;
     const uint64_t stride = (uint64_t)gridDim.x * 64;
+    uint32_t n_keep = 0, n_inf = 0, n_ext = 0;
+    uint4 na = make_uint4(0, 0, 0, 0), nb = na;
+    {
+        const uint64_t i0 = (uint64_t)blockIdx.x * 64 + lane;
+        if (i0 < n) { const uint4 *q = (const uint4 *)(in + i0); na = q[0]; nb = q[1]; }
+    }
     for (uint64_t base = (uint64_t)blockIdx.x * 64; base < n; base += stride) {
         const uint64_t i = base + lane;
-        const bool act = i < n;
-        uint64_t x0 = 0, sz = 0, K = 0;
-        if (act) {
-            const uint4 *q = (const uint4 *)(in + i);
-            const uint4 a = q[0], b = q[1];
-            x0 = (uint64_t)a.y << 32 | a.x;
-            sz = (uint64_t)b.y << 32 | b.x; K = (uint64_t)b.w << 32 | b.z;
+        const uint4 a = na, b = nb;
+        const uint64_t x0 = (uint64_t)a.y << 32 | a.x;
+        const uint64_t sz = (uint64_t)b.y << 32 | b.x, K = (uint64_t)b.w << 32 | b.z;
+        const bool act = i < n && sz != 0;
+        {
+            const uint64_t i1 = i + stride;
+            na = make_uint4(0, 0, 0, 0); nb = na;
+            if (i1 < n) { const uint4 *q = (const uint4 *)(in + i1); na = q[0]; nb = q[1]; }
         }
+        const uint64_t m_act = __ballot(act);
+        if (m_act == 0) continue;
+        n_ext += (uint32_t)__popcll(m_act);
         uint64_t tk[6], s[6];
         km_extend_back(ix, fmd_lds, act, x0, sz, tk, s);
         uint64_t mx = 0; int max_c = 6;
@@ -119,30 +172,73 @@ __global__ __launch_bounds__(64) void k_kmer_emit(FmdIndexView ix, int w, int su
         double r = rest == 0 ? (double)mx : (double)mx / (double)rest;   // IEEE double divide, as on the host
         if (r > 31.) r = 31.;
         const bool informative = keep && rest <= 7 && r >= (double)min_occ;
-        const uint64_t mk = __ballot(keep), mi = __ballot(informative);
-        if (mk == 0) continue;
-        unsigned long long first = 0;
-        if (lane == 0) {
-            first = atomicAdd(&ctr[KM_OUT], (unsigned long long)__popcll(mk));
-            atomicAdd(&ctr[KM_CNT0], (unsigned long long)__popcll(mk));
-            if (mi) atomicAdd(&ctr[KM_CNT1], (unsigned long long)__popcll(mi));
-        }
-        first = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
-                (unsigned int)__builtin_amdgcn_readfirstlane((int)first);
-        if (keep) {
-            const uint64_t o = first + __popcll(mk & ((1ull << lane) - 1));
-            if (o < cap) {
-                o_bucket[o] = (uint32_t)(K & ((1ull << (2 * suf_len)) - 1));
-                o_key[o] = (uint32_t)(K >> (2 * suf_len)) << 2 | (uint32_t)(max_c - 1);
-                o_val[o] = (uint8_t)((int)(r + .499) << 3 | (int)(rest < 7 ? rest : 7));
-            } else ctr[KM_OVF] = 1;
+        n_keep += (uint32_t)__popcll(__ballot(keep)); n_inf += (uint32_t)__popcll(__ballot(informative));
+        if (i < n) {
+            r_flag[i] = keep ? 1 : 0;
+            if (keep) {
+                r_bucket[i] = (uint32_t)(K & ((1ull << (2 * suf_len)) - 1));
+                r_key[i] = (uint32_t)(K >> (2 * suf_len)) << 2 | (uint32_t)(max_c - 1);
+                r_val[i] = (uint8_t)((int)(r + .499) << 3 | (int)(rest < 7 ? rest : 7));
+            }
         }
     }
+    if (lane == 0 && n_ext) atomicAdd(&ctr[KM_EXT], (unsigned long long)n_ext);
+    if (lane == 0 && n_keep) {
+        atomicAdd(&ctr[KM_CNT0], (unsigned long long)n_keep);
+        if (n_inf) atomicAdd(&ctr[KM_CNT1], (unsigned long long)n_inf);
+    }
+}
+
+// ---- compaction of the raw emit arrays: tile counts -> exclusive scan -> scatter ----------------
+#define KM_TILE 2048   // items per 256-thread block, 8 per thread
+
+__device__ __forceinline__ uint32_t km_tile_prefix(uint32_t mine, uint32_t *lds, uint32_t &total) // exclusive scan over 256 threads
+{
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t v = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)v, o); if (lane >= o) v += u; }
+    if (lane == 63) lds[wv] = v;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int i = 0; i < wv; ++i) before += lds[i];
+    total = lds[0] + lds[1] + lds[2] + lds[3];
+    return before + v - mine;
+}
+
+__global__ __launch_bounds__(256) void k_km_count(const uint8_t *__restrict__ flag, uint64_t cap, unsigned long long *__restrict__ tile_cnt)
+{
+    __shared__ uint32_t lds[4];
+    const uint64_t i = (uint64_t)blockIdx.x * KM_TILE + threadIdx.x * 8;
+    uint32_t c = 0;
+    if (i + 8 <= cap) c = (uint32_t)__popcll(*(const uint64_t *)(flag + i) & 0x0101010101010101ull);
+    else for (uint64_t j = i; j < cap; ++j) c += flag[j] & 1;
+    uint32_t total;
+    km_tile_prefix(c, lds, total);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void k_km_scatter(const uint8_t *__restrict__ flag, uint64_t cap, const unsigned long long *__restrict__ tile_off,
+                                                    const unsigned long long *__restrict__ tile_cnt, uint64_t n_tiles,
+                                                    const uint32_t *__restrict__ r_bucket, const uint32_t *__restrict__ r_key, const uint8_t *__restrict__ r_val,
+                                                    uint32_t *__restrict__ o_bucket, uint32_t *__restrict__ o_key, uint8_t *__restrict__ o_val,
+                                                    unsigned long long *__restrict__ ctr)
+{
+    __shared__ uint32_t lds[4];
+    const uint64_t i = (uint64_t)blockIdx.x * KM_TILE + threadIdx.x * 8;
+    uint64_t f = 0;
+    if (i + 8 <= cap) f = *(const uint64_t *)(flag + i) & 0x0101010101010101ull;
+    else for (uint64_t j = i; j < cap; ++j) f |= (uint64_t)(flag[j] & 1) << (8 * (j - i));
+    uint32_t total;
+    uint64_t o = tile_off[blockIdx.x] + km_tile_prefix((uint32_t)__popcll(f), lds, total);
+    for (int j = 0; j < 8; ++j)
+        if ((f >> (8 * j)) & 1) { o_bucket[o] = r_bucket[i + j]; o_key[o] = r_key[i + j]; o_val[o] = r_val[i + j]; ++o; }
+    if (blockIdx.x == n_tiles - 1 && threadIdx.x == 0) ctr[KM_OUT] = tile_off[blockIdx.x] + tile_cnt[blockIdx.x];
 }
 
 extern "C" size_t fmd_kmer_work_bytes(uint64_t cap_frontier)
 {
-    return 2 * cap_frontier * sizeof(fmd_intv_t) + KM_WORDS * 8 + 512;
+    return 2 * cap_frontier * sizeof(fmd_intv_t) + KM_WORDS * 8 + 512 + (4u << 20);
 }
 
 // d_status (device, 4 x u64): [0] number of (bucket,key,val) triples, [1] overflow flag (then the
@@ -151,13 +247,14 @@ extern "C" int fmd_kmer_collect_dev(fmd_dev_t *h, void *stream_, int w, int min_
                                     uint64_t cap, uint32_t *d_bucket, uint32_t *d_key, uint8_t *d_val, uint64_t *d_status)
 {
     if (!h || !d_work || !d_bucket || !d_key || !d_val || !d_status) return FMD_E_ARG;
-    if (w < 2 || w > 27 || suf_len < 1 || suf_len >= w || min_occ < 1 || w - suf_len > 15 || cap < 4) return FMD_E_ARG; // MAX_KMER 27 (correct.c:303)
+    if (w < 2 || w > 27 || suf_len < 1 || suf_len >= w || min_occ < 1 || w - suf_len > 15 || cap < (1u << 16)) return FMD_E_ARG; // MAX_KMER 27 (correct.c:303)
     if (work_bytes < fmd_kmer_work_bytes(cap)) return FMD_E_ARG;
     FMD_HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream_;
     unsigned long long *ctr = (unsigned long long *)d_work;
     fmd_intv_t *fa = (fmd_intv_t *)(((uintptr_t)((uint8_t *)d_work + KM_WORDS * 8) + 255) & ~(uintptr_t)255);
     fmd_intv_t *fb = fa + cap;
+    uint8_t *tail = (uint8_t *)(fb + cap);                       // 4 MiB: scan scratch
     FMD_HIP_TRY(hipMemsetAsync(ctr, 0, KM_WORDS * 8, st));
     // depth 1: the four single-base intervals (exact.c:153-155: fm6_set_intv for the root)
     fmd_intv_t seed[4]; unsigned long long n1 = 0;
@@ -171,13 +268,30 @@ extern "C" int fmd_kmer_collect_dev(fmd_dev_t *h, void *stream_, int w, int min_
     FMD_HIP_TRY(hipMemcpyAsync(ctr + 1, &n1, 8, hipMemcpyHostToDevice, st));
     FMD_HIP_TRY(hipStreamSynchronize(st)); // seed[] is a stack buffer
     const FmdIndexView ix = fmd_view(h);
-    const int grid = h->n_cu * 10;
+    const int grid = fmd_grid_for_lds(h, cap, FMD_COMPACT_LDS_U4 * 16);
+    // chunk of output slots a wave reserves per atomic: as large as the capacity comfortably allows
+    // (at most one partial chunk per wave is wasted per level), at least one iteration's worth (256)
+    uint32_t ch = 1024;
+    while (ch > 256 && (uint64_t)grid * ch * 8 > cap) ch >>= 1;
     fmd_intv_t *in = fa, *out = fb;
     for (int d = 1; d < w; ++d) {
-        k_kmer_level<<<grid, 64, 0, st>>>(ix, d, suf_len, min_occ, in, out, cap, ctr);
+        k_kmer_level<<<grid, 64, 0, st>>>(ix, d, suf_len, min_occ, in, out, cap, ch, ctr);
         fmd_intv_t *t = in; in = out; out = t;
     }
-    k_kmer_emit<<<grid, 64, 0, st>>>(ix, w, suf_len, min_occ, in, d_bucket, d_key, d_val, cap, ctr);
+    // raw (uncompacted) triples + flags live in the frontier buffer that is free now: 10 of its 32 bytes per slot
+    uint32_t *r_bucket = (uint32_t *)out, *r_key = r_bucket + cap;
+    uint8_t *r_val = (uint8_t *)(r_key + cap), *r_flag = r_val + cap;
+    const uint64_t n_tiles = (cap + KM_TILE - 1) / KM_TILE;
+    unsigned long long *tile_cnt = (unsigned long long *)(((uintptr_t)(r_flag + cap) + 255) & ~(uintptr_t)255), *tile_off = tile_cnt + n_tiles;
+    if ((uint8_t *)(tile_off + n_tiles) > (uint8_t *)out + cap * sizeof(fmd_intv_t)) return FMD_E_ARG;
+    FMD_HIP_TRY(hipMemsetAsync(r_flag, 0, cap, st));
+    k_kmer_emit<<<grid, 64, 0, st>>>(ix, w, suf_len, min_occ, in, r_bucket, r_key, r_val, r_flag, cap, ctr);
+    k_km_count<<<(unsigned)n_tiles, 256, 0, st>>>(r_flag, cap, tile_cnt);
+    size_t tmp_bytes = 0;
+    FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, tile_cnt, tile_off, (size_t)n_tiles, st));
+    if (tmp_bytes > (4u << 20)) return FMD_E_ARG;
+    FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tail, tmp_bytes, tile_cnt, tile_off, (size_t)n_tiles, st));
+    k_km_scatter<<<(unsigned)n_tiles, 256, 0, st>>>(r_flag, cap, tile_off, tile_cnt, n_tiles, r_bucket, r_key, r_val, d_bucket, d_key, d_val, ctr);
     FMD_HIP_TRY(hipMemcpyAsync(d_status, ctr + KM_OUT, 4 * 8, hipMemcpyDeviceToDevice, st));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "kmer kernels"); return FMD_E_HIP; }
@@ -190,7 +304,7 @@ extern "C" int fmd_kmer_collect(fmd_dev_t *h, int w, int min_occ, int suf_len, u
 {
     if (!h || !bucket || !key || !val || !n || !cnt) return FMD_E_ARG;
     FMD_HIP_TRY(hipSetDevice(h->device));
-    uint64_t cap = 1u << 20;
+    uint64_t cap = 1u << 22;
     for (int attempt = 0; attempt < 16; ++attempt, cap *= 4) {
         void *work = nullptr, *db = nullptr, *dk = nullptr, *dv = nullptr, *ds = nullptr;
         const size_t wb = fmd_kmer_work_bytes(cap);

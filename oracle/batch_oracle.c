@@ -146,3 +146,60 @@ void orc_smem_batch(const orc_rld_t *e, size_t n, int len, const uint8_t *seqs, 
     for (t = 0; t < n_threads; ++t) pthread_join(tid[t], 0);
     free(tid); free(w);
 }
+
+/* ec_collect (correct.c:35-87) over suffix buckets [b0, b1), start/step threads (worker1,
+ * correct.c:272-279); triples (bucket, key, val) concatenated in unspecified order. */
+#include <time.h>
+typedef struct { const orc_rld_t *e; int w, min_occ, suf_len; const orc_intv_t *top; int b0, b1, start, step;
+                 uint32_t *B, *K; uint8_t *V; uint64_t n, m; } ecj_t;
+static void *ec_worker(void *d)
+{
+    ecj_t *w = (ecj_t *)d;
+    int b;
+    for (b = w->b0 + w->start; b < w->b1; b += w->step) {
+        orc_solid_t so;
+        size_t i;
+        memset(&so, 0, sizeof(so));
+        orc_ec_collect(w->e, w->w, w->min_occ, w->suf_len, &w->top[b], &so);
+        for (i = 0; i < so.n; ++i) {
+            if (w->n == w->m) {
+                w->m = w->m ? w->m << 1 : 1024;
+                w->B = (uint32_t *)realloc(w->B, w->m * 4); w->K = (uint32_t *)realloc(w->K, w->m * 4); w->V = (uint8_t *)realloc(w->V, w->m);
+            }
+            w->B[w->n] = (uint32_t)b; w->K[w->n] = so.key[i]; w->V[w->n] = so.val[i]; ++w->n;
+        }
+        free(so.key); free(so.val);
+    }
+    orc_counters_flush();
+    return 0;
+}
+int orc_ec_range(const orc_rld_t *e, int w, int min_occ, int suf_len, int b0, int b1, int n_threads, uint32_t **o_bucket,
+                 uint32_t **o_key, uint8_t **o_val, uint64_t *o_n, double *secs)
+{
+    orc_intv_t *top = orc_traverse(e, suf_len);
+    pthread_t *tid = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    ecj_t *ws = (ecj_t *)calloc((size_t)n_threads, sizeof(ecj_t));
+    uint64_t n = 0, off = 0;
+    struct timespec t0, t1;
+    int t;
+    if (b1 > (1 << (2 * suf_len))) b1 = 1 << (2 * suf_len);
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (t = 0; t < n_threads; ++t) {
+        ws[t].e = e; ws[t].w = w; ws[t].min_occ = min_occ; ws[t].suf_len = suf_len; ws[t].top = top;
+        ws[t].b0 = b0; ws[t].b1 = b1; ws[t].start = t; ws[t].step = n_threads;
+        pthread_create(&tid[t], 0, ec_worker, &ws[t]);
+    }
+    for (t = 0; t < n_threads; ++t) pthread_join(tid[t], 0);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    *secs = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    for (t = 0; t < n_threads; ++t) n += ws[t].n;
+    *o_bucket = (uint32_t *)malloc(n * 4 + 4); *o_key = (uint32_t *)malloc(n * 4 + 4); *o_val = (uint8_t *)malloc(n + 4);
+    for (t = 0; t < n_threads; ++t) {
+        memcpy(*o_bucket + off, ws[t].B, ws[t].n * 4); memcpy(*o_key + off, ws[t].K, ws[t].n * 4); memcpy(*o_val + off, ws[t].V, ws[t].n);
+        off += ws[t].n;
+        free(ws[t].B); free(ws[t].K); free(ws[t].V);
+    }
+    *o_n = n;
+    free(tid); free(ws); free(top);
+    return 0;
+}

@@ -71,6 +71,8 @@ orc_intv_t *orc_traverse(const orc_rld_t *e, int depth);                        
 /* ---- SMEM (smem.c:13-80, 104, 397) ---- */
 int orc_smem1(const orc_rld_t *e, int len, const uint8_t *q, int x, orc_intv_v *mem, int self_match);
 int orc_smem(const orc_rld_t *e, int len, const uint8_t *q, orc_intv_v *mem, int self_match);
+int orc_ec_range(const orc_rld_t *e, int w, int min_occ, int suf_len, int b0, int b1, int n_threads, uint32_t **o_bucket,
+                 uint32_t **o_key, uint8_t **o_val, uint64_t *o_n, double *secs);
 void orc_smem_batch(const orc_rld_t *e, size_t n, int len, const uint8_t *seqs, int self_match, uint32_t max_mem,
                     orc_intv_t *mem, uint32_t *n_mem, int n_threads);
 

@@ -60,6 +60,7 @@ def lib():
         L.orc_traverse.restype = C.c_void_p; L.orc_traverse.argtypes = [P, C.c_int]
         L.orc_smem.restype = C.c_int; L.orc_smem.argtypes = [P, C.c_int, C.c_void_p, C.POINTER(IntvV), C.c_int]
         L.orc_smem_batch.argtypes = [P, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_ec_range.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_is_contained.restype = C.c_int
         L.orc_is_contained.argtypes = [P, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(IntvV)]
         L.orc_get_nei.restype = C.c_int
@@ -212,6 +213,19 @@ class OrcIndex:
         mem = np.zeros((n, max_mem), dtype=INTV_DT); n_mem = np.zeros(n, dtype=np.uint32)
         self.L.orc_smem_batch(self.e, n, ln, seqs.ctypes.data, self_match, max_mem, mem.ctypes.data, n_mem.ctypes.data, n_threads)
         return mem, n_mem
+
+    def ec_range(self, w, min_occ, suf_len, b0, b1, n_threads=1):
+        """ec_collect over suffix buckets [b0, b1): (bucket, key, val, seconds)."""
+        pb, pk, pv = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n, secs = C.c_uint64(), C.c_double()
+        self.L.orc_ec_range(self.e, w, min_occ, suf_len, b0, b1, n_threads, C.byref(pb), C.byref(pk), C.byref(pv), C.byref(n), C.byref(secs))
+        m = n.value
+        B = np.zeros(m, dtype=np.uint32); K = np.zeros(m, dtype=np.uint32); V = np.zeros(m, dtype=np.uint8)
+        if m:
+            C.memmove(B.ctypes.data, pb, m * 4); C.memmove(K.ctypes.data, pk, m * 4); C.memmove(V.ctypes.data, pv, m)
+        for p in (pb, pk, pv):
+            _libc.free(p)
+        return B, K, V, secs.value
 
     def ec_collect(self, w, min_occ, suf_len):
         top = self.traverse(suf_len)
