@@ -247,6 +247,39 @@ static int fix_read(const fmdh_ecopt_t *opt, const solid_t *solid, char *seq, ch
     return info;
 }
 
+/* ec_fix worker threads (correct.c:281-290, `-t`): read i of a batch goes to thread i mod T; every
+ * read is corrected independently against the read-only table, so the output does not depend on T */
+#include <pthread.h>
+static int g_fix_threads = 1;
+void fmdh_correct_set_threads(int n) { g_fix_threads = n > 0 ? n : 1; }
+
+typedef struct { const fmdh_ecopt_t *opt; const solid_t *solid; char **seqs, **quals; int *info; size_t nb; int start, step; uint64_t n_query; } fixjob_t;
+static void *fix_worker(void *d)
+{
+    fixjob_t *w = (fixjob_t *)d;
+    fix_t fa; memset(&fa, 0, sizeof(fa));
+    char *buf = 0; size_t buf_m = 0, i;
+    for (i = (size_t)w->start; i < w->nb; i += (size_t)w->step)
+        w->info[i] = fix_read(w->opt, w->solid, w->seqs[i], w->quals[i], &fa, &buf, &buf_m, &w->n_query);
+    free(fa.heap); free(fa.stack); free(buf);
+    return 0;
+}
+static void fix_batch(const fmdh_ecopt_t *opt, const solid_t *solid, char **seqs, char **quals, int *info, size_t nb, uint64_t *n_query)
+{
+    int T = g_fix_threads, t;
+    if ((size_t)T > nb) T = nb ? (int)nb : 1;
+    pthread_t *tid = (pthread_t *)calloc((size_t)T, sizeof(pthread_t));
+    fixjob_t *w = (fixjob_t *)calloc((size_t)T, sizeof(fixjob_t));
+    for (t = 0; t < T; ++t) {
+        w[t].opt = opt; w[t].solid = solid; w[t].seqs = seqs; w[t].quals = quals; w[t].info = info; w[t].nb = nb; w[t].start = t; w[t].step = T;
+        if (t + 1 < T) pthread_create(&tid[t], 0, fix_worker, &w[t]);
+    }
+    fix_worker(&w[T - 1]);
+    for (t = 0; t + 1 < T; ++t) pthread_join(tid[t], 0);
+    for (t = 0; t < T; ++t) *n_query += w[t].n_query;
+    free(tid); free(w);
+}
+
 /* Phase 2 alone: correct the reads of fq_path against a harvested table (opt->w must be set). */
 int fmdh_correct_reads(const fmdh_ecopt_t *opt, int suf_len, uint64_t n, const uint32_t *bucket, const uint32_t *key, const uint8_t *val,
                        const char *fq_path, FILE *out)
@@ -259,15 +292,12 @@ int fmdh_correct_reads(const fmdh_ecopt_t *opt, int suf_len, uint64_t n, const u
     if (!io) { fprintf(stderr, "[E::%s] cannot open `%s'\n", __func__, fq_path); solid_free(&solid); return 1; }
     char **seqs = (char **)calloc(BATCH_SIZE, sizeof(char *)), **quals = (char **)calloc(BATCH_SIZE, sizeof(char *));
     int *info = (int *)calloc(BATCH_SIZE, sizeof(int));
-    fix_t fa; memset(&fa, 0, sizeof(fa));
-    char *buf = 0; size_t buf_m = 0;
     uint64_t id = 0, pre_id = 0, n_query = 0;
     size_t nb = 0;
     for (;;) {
         int ret = fmdh_seq_read(io);
         if (ret < 0 || (id && id % BATCH_SIZE == 0)) {
-            size_t i;
-            for (i = 0; i < nb; ++i) info[i] = fix_read(opt, &solid, seqs[i], quals[i], &fa, &buf, &buf_m, &n_query);
+            fix_batch(opt, &solid, seqs, quals, info, nb, &n_query);
             for (uint64_t k = pre_id; k < id; ++k) {
                 const size_t a = (size_t)(k - pre_id);
                 int is_bad = 0;
@@ -295,7 +325,7 @@ int fmdh_correct_reads(const fmdh_ecopt_t *opt, int suf_len, uint64_t n, const u
         } else quals[nb] = strdup(fmdh_seq_qual(io));
         ++nb; ++id;
     }
-    free(seqs); free(quals); free(info); free(fa.heap); free(fa.stack); free(buf);
+    free(seqs); free(quals); free(info);
     fmdh_seq_close(io);
     solid_free(&solid);
     return 0;

@@ -95,7 +95,8 @@ static int main_correct(int argc, char *argv[]) /* cmd.c:253-291 */
     opt.w = -1; opt.min_occ = 3; opt.keep_bad = 0; opt.is_paired = 0; opt.max_corr = 0.3f; opt.trim_l = 0; opt.step = 5;
     while ((c = getopt(argc, argv, "MKt:k:v:O:pC:l:s:g:")) >= 0) {
         switch (c) {
-        case 'M': case 't': case 'v': break;   /* mmap / threads / verbosity: no effect on the output */
+        case 'M': case 'v': break;             /* mmap / verbosity: no effect on the output */
+        case 't': fmdh_correct_set_threads(atoi(optarg)); break; /* ec_fix workers, as correct.c:281-290 */
         case 'K': opt.keep_bad = 1; break;
         case 'k': opt.w = atoi(optarg); break;
         case 'O': opt.min_occ = atoi(optarg); break;
@@ -113,6 +114,7 @@ static int main_correct(int argc, char *argv[]) /* cmd.c:253-291 */
         fprintf(stderr, "         -C FLOAT    max fraction of corrected bases [%.2f]\n", opt.max_corr);
         fprintf(stderr, "         -l INT      trim read down to INT bp; 0 to disable [0]\n");
         fprintf(stderr, "         -s INT      step size for the jumping heuristic; 0 to disable [%d]\n", opt.step);
+        fprintf(stderr, "         -t INT      number of host threads for the correction pass [1]\n");
         fprintf(stderr, "         -K          keep bad/unfixable reads\n");
         fprintf(stderr, "         -p          paired-end reads (interleaved)\n");
         fprintf(stderr, "         -g INT      GPU to use [0]\n\n");
