@@ -35,6 +35,9 @@ __device__ __forceinline__ void s_store(fmd_intv_t *e, uint64_t x0, uint64_t x1,
     q[1] = make_uint4((uint32_t)sz, (uint32_t)(sz >> 32), (uint32_t)info, (uint32_t)(info >> 32));
 }
 
+// forward-sweep push (the list is written back to front); a full list marks the item as overflowed
+#define SM_PUSH_FWD(a_, b_, c_, d_) do { if (curr_n < cap) { s_store(la + (cap - 1 - curr_n), a_, b_, c_, d_); ++curr_n; } else overflow = true; } while (0)
+
 enum { SM_IDLE = 0, SM_START, SM_BEGIN_BWD, SM_BWD_PICK, SM_FWD, SM_FWD_END, SM_BWD };
 
 #define SMEM_LDS_BYTES (FMD_COMPACT_LDS_U4 * 16)
@@ -43,12 +46,12 @@ enum { SM_IDLE = 0, SM_START, SM_BEGIN_BWD, SM_BWD_PICK, SM_FWD, SM_FWD_END, SM_
 __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ off,
                                              int self_match, uint32_t cap, fmd_intv_t *__restrict__ work, uint32_t max_mem,
                                              fmd_intv_t *__restrict__ mem_out, uint32_t *__restrict__ n_mem_out, uint32_t *__restrict__ queue,
-                                             int refill_min)
+                                             int refill_min, const fmd_smem_win_t *__restrict__ wins)
 {
     FMD_DECLARE_COMPACT_LDS();
     size_t rid = 0;
     const uint8_t *q = nullptr;
-    int st = SM_IDLE, len = 0, x = 0, i = 0, ret = 0;
+    int st = SM_IDLE, len = 0, x = 0, i = 0, ret = 0, stop = 0;
     uint32_t prev_n = 0, curr_n = 0, j = 0, n_mem = 0, call_base = 0;
     // two candidate lists of `cap` entries per lane (HBM; this lane's area is reused read after read)
     fmd_intv_t *const la = work + ((size_t)blockIdx.x * 64 + fmd_lane()) * 2 * (size_t)cap, *const lb = la + cap;
@@ -73,10 +76,14 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
         const size_t my = fmd_tickets_take(tk_, queue, st == SM_IDLE && take);
         if (st == SM_IDLE && take) {
             if (my < n) {
-                rid = my; sbase = off[my]; q = seqs + sbase; len = (int)(off[my + 1] - sbase); cw_at = ~0ull;
-                n_mem = 0; overflow = false; x = 0;
-                if (len <= 0) n_mem_out[rid] = 0;
-                else if (2 * (uint32_t)len + 2 > cap) n_mem_out[rid] = 0x80000000u; // longer than max_len
+                rid = my; cw_at = ~0ull; n_mem = 0; overflow = false;
+                if (wins) { // a window of a long sequence: start positions [start, stop) of the fm6_smem chain
+                    const fmd_smem_win_t wn = wins[my];
+                    sbase = wn.seq_off; len = (int)wn.seq_len; x = (int)wn.start; stop = (int)(wn.stop < wn.seq_len ? wn.stop : wn.seq_len);
+                } else { sbase = off[my]; len = (int)(off[my + 1] - sbase); x = 0; stop = len; }
+                q = seqs + sbase;
+                if (len <= 0 || x >= stop) n_mem_out[rid] = 0;
+                else if (!wins && 2 * (uint32_t)len + 2 > cap) n_mem_out[rid] = 0x80000000u; // longer than max_len
                 else st = SM_START;
             } else exhausted = true;
         }
@@ -93,7 +100,7 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
                     st = SM_IDLE;
                 } else if (i < len) st = SM_FWD;
                 else { // x is the last base: push the interval (smem.c:35-37); list is written back to front
-                    s_store(la + (cap - 1 - curr_n), kx0, kx1, ksz, kinfo); ++curr_n;
+                    SM_PUSH_FWD(kx0, kx1, ksz, kinfo);
                     st = self_match ? SM_BEGIN_BWD : SM_FWD_END;
                     again = st == SM_BEGIN_BWD;
                 }
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
                             s_store(pa, b0, b1, b2, b3); s_store(pb, a0, a1, a2, a3);
                         }
                     x = ret;
-                    if (x < len) { st = SM_START; again = true; }
+                    if (x < stop) { st = SM_START; again = true; }
                     else { n_mem_out[rid] = n_mem | (overflow ? 0x80000000u : 0); st = SM_IDLE; }
                 }
             }
@@ -200,20 +207,20 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
 
         if (st == SM_FWD) {
             if (sc != ksz) { // change of the interval size (smem.c:25-31)
-                if (ksz != s[0]) { s_store(la + (cap - 1 - curr_n), kx0, kx1, ksz, kinfo); ++curr_n; }
-                if (!self_match && s[0]) { s_store(la + (cap - 1 - curr_n), base, ix.cnt[0] + tk0, s[0], (uint64_t)i); ++curr_n; }
+                if (ksz != s[0]) SM_PUSH_FWD(kx0, kx1, ksz, kinfo);
+                if (!self_match && s[0]) SM_PUSH_FWD(base, ix.cnt[0] + tk0, s[0], (uint64_t)i);
             }
             if ((!self_match && sc == 0) || (self_match && sc < 2)) st = SM_BEGIN_BWD; // cannot be extended
             else {
                 kx1 = nxc; kx0 = rc; ksz = sc; kinfo = (uint64_t)(i + 1);
                 ++i;
                 if (i == len) { // reached the end: always push (smem.c:35-37)
-                    s_store(la + (cap - 1 - curr_n), kx0, kx1, ksz, kinfo); ++curr_n;
+                    SM_PUSH_FWD(kx0, kx1, ksz, kinfo);
                     st = self_match ? SM_BEGIN_BWD : SM_FWD_END;
                 }
             }
         } else if (st == SM_FWD_END) { // is the last interval terminated by a sentinel? (smem.c:38-43)
-            if (s[0]) { s_store(la + (cap - 1 - curr_n), base, ix.cnt[0] + tk0, s[0], (uint64_t)len); ++curr_n; }
+            if (s[0]) SM_PUSH_FWD(base, ix.cnt[0] + tk0, s[0], (uint64_t)len);
             st = SM_BEGIN_BWD;
         } else { // SM_BWD: one interval of the list against base q[i] (smem.c:53-74)
             const bool fl_match = s[0] && kx1 < ix.n_seq;
@@ -264,9 +271,34 @@ extern "C" int fmd_smem_dev(fmd_dev_t *h, void *stream_, size_t n, const uint8_t
     if (grid > SMEM_MAX_WAVES) grid = SMEM_MAX_WAVES;
     static const int refill_min = getenv("FMD_SMEM_REFILL") ? atoi(getenv("FMD_SMEM_REFILL")) : 8;
     k_smem<<<grid, 64, 0, st>>>(fmd_view(h), n, d_seqs, d_off, self_match ? 1 : 0, 2 * max_len + 2,
-                                (fmd_intv_t *)d_work, max_mem, d_mem, d_n_mem, q, refill_min);
+                                (fmd_intv_t *)d_work, max_mem, d_mem, d_n_mem, q, refill_min, nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "k_smem"); return FMD_E_HIP; }
+    return FMD_OK;
+}
+
+// Windows of long sequences (contigs): item i runs the fm6_smem chain (smem.c:397-410, = fm6_miter_next,
+// smem.c:96-102) over the start positions [start, stop) of the sequence at d_seqs + seq_off.  Every
+// fm6_smem1_core call is a pure function of (sequence, x) and the chain from any start position
+// reaches every SMEM that begins at or after it, so the union over a partition into windows is
+// the SMEM set of the whole sequence; an SMEM that covers a window boundary can be reported by
+// both windows (the caller sorts by start and drops duplicates).  max_len bounds the length of a
+// match (the longest sequence in the index + 1).
+extern "C" int fmd_smem_win_dev(fmd_dev_t *h, void *stream_, size_t n, const uint8_t *d_seqs, const fmd_smem_win_t *d_wins, int self_match,
+                                uint32_t max_len, uint32_t max_mem, fmd_intv_t *d_mem, uint32_t *d_n_mem, void *d_work, size_t work_bytes)
+{
+    if (!h || (n && (!d_seqs || !d_wins || !d_mem || !d_n_mem || !d_work)) || max_len == 0 || max_mem == 0) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    if (n >= 0xffffff00ull || work_bytes < fmd_smem_work_bytes(n, max_len) || ((uintptr_t)d_seqs & 3)) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream_;
+    uint32_t *q = fmd_next_queue(h, st);
+    int grid = fmd_grid_for_lds(h, n, SMEM_LDS_BYTES);
+    if (grid > SMEM_MAX_WAVES) grid = SMEM_MAX_WAVES;
+    k_smem<<<grid, 64, 0, st>>>(fmd_view(h), n, d_seqs, nullptr, self_match ? 1 : 0, 2 * max_len + 2,
+                                (fmd_intv_t *)d_work, max_mem, d_mem, d_n_mem, q, 1, d_wins);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fmd_set_hip_error(e, "k_smem (windows)"); return FMD_E_HIP; }
     return FMD_OK;
 }
 
@@ -286,6 +318,25 @@ extern "C" int fmd_smem_batch(fmd_dev_t *h, size_t n, const uint8_t *seqs, const
     FMD_HIP_TRY(hipMemcpy(doff.p, off, (n + 1) * 8, hipMemcpyHostToDevice));
     FMD_HIP_TRY(hipMemset(dm.p, 0, n * (size_t)max_mem * sizeof(fmd_intv_t)));
     int rc = fmd_smem_dev(h, nullptr, n, (uint8_t *)ds.p, (uint64_t *)doff.p, self_match, max_len, max_mem, (fmd_intv_t *)dm.p, (uint32_t *)dn.p, dw.p, wb);
+    if (rc) return rc;
+    FMD_HIP_TRY(hipMemcpy(mem, dm.p, n * (size_t)max_mem * sizeof(fmd_intv_t), hipMemcpyDeviceToHost));
+    FMD_HIP_TRY(hipMemcpy(n_mem, dn.p, n * 4, hipMemcpyDeviceToHost));
+    return FMD_OK;
+}
+
+extern "C" int fmd_smem_win_batch(fmd_dev_t *h, size_t n, const uint8_t *seqs, uint64_t seq_bytes, const fmd_smem_win_t *wins, int self_match,
+                                  uint32_t max_len, uint32_t max_mem, fmd_intv_t *mem, uint32_t *n_mem)
+{
+    if (!h || (n && (!seqs || !wins || !mem || !n_mem))) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    SBuf ds, dwin, dm, dn, dw;
+    const size_t wb = fmd_smem_work_bytes(n, max_len);
+    if (ds.alloc(seq_bytes + 8) || dwin.alloc(n * sizeof(fmd_smem_win_t)) || dm.alloc(n * (size_t)max_mem * sizeof(fmd_intv_t)) || dn.alloc(n * 4) || dw.alloc(wb))
+        return FMD_E_NOMEM;
+    FMD_HIP_TRY(hipMemcpy(ds.p, seqs, seq_bytes, hipMemcpyHostToDevice));
+    FMD_HIP_TRY(hipMemcpy(dwin.p, wins, n * sizeof(fmd_smem_win_t), hipMemcpyHostToDevice));
+    int rc = fmd_smem_win_dev(h, nullptr, n, (uint8_t *)ds.p, (fmd_smem_win_t *)dwin.p, self_match, max_len, max_mem, (fmd_intv_t *)dm.p, (uint32_t *)dn.p, dw.p, wb);
     if (rc) return rc;
     FMD_HIP_TRY(hipMemcpy(mem, dm.p, n * (size_t)max_mem * sizeof(fmd_intv_t), hipMemcpyDeviceToHost));
     FMD_HIP_TRY(hipMemcpy(n_mem, dn.p, n * 4, hipMemcpyDeviceToHost));

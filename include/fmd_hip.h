@@ -109,6 +109,16 @@ int fmd_retrieve_batch(fmd_dev_t *h, size_t n, const uint64_t *x, uint8_t *seqs,
 size_t fmd_smem_work_bytes(size_t n, uint32_t max_len);
 int fmd_smem_dev(fmd_dev_t *h, void *stream, size_t n, const uint8_t *d_seqs, const uint64_t *d_off, int self_match,
                  uint32_t max_len, uint32_t max_mem, fmd_intv_t *d_mem, uint32_t *d_n_mem, void *d_work, size_t work_bytes);
+/* The same chain over WINDOWS of long sequences (what fm6_miter_next does over a contig in `fermi
+ * remap`, smem.c:96-102, :151): item i = start positions [start, stop) of the sequence of seq_len
+ * bases at seqs + seq_off.  The union over a partition of a sequence into windows is its SMEM set;
+ * an SMEM covering a window boundary may be reported by both windows.  max_len = longest match
+ * possible (longest sequence in the index + 1). */
+typedef struct { uint64_t seq_off; uint32_t seq_len, start, stop, reserved; } fmd_smem_win_t;
+int fmd_smem_win_dev(fmd_dev_t *h, void *stream, size_t n, const uint8_t *d_seqs, const fmd_smem_win_t *d_wins, int self_match,
+                     uint32_t max_len, uint32_t max_mem, fmd_intv_t *d_mem, uint32_t *d_n_mem, void *d_work, size_t work_bytes);
+int fmd_smem_win_batch(fmd_dev_t *h, size_t n, const uint8_t *seqs, uint64_t seq_bytes, const fmd_smem_win_t *wins, int self_match,
+                       uint32_t max_len, uint32_t max_mem, fmd_intv_t *mem, uint32_t *n_mem);
 int fmd_smem_batch(fmd_dev_t *h, size_t n, const uint8_t *seqs, const uint64_t *off, int self_match, uint32_t max_len,
                    uint32_t max_mem, fmd_intv_t *mem, uint32_t *n_mem);
 

@@ -337,3 +337,20 @@ def test_seqsort_and_unitig_r_cli(gpu, gold, tmp_path, name, mm):
     open(rf, "wb").write(rank)
     assert _cli("unitig", "-l%d" % mm, "-r", rf, gold.path(name + ".fmd")) == gold.text_gz(name + ".r.mag.gz")
     assert _cli("unitig", "-l%d" % mm, gold.path(name + ".fmd")) == gold.text_gz(name + ".mag.gz")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window", [64, 256, 1000])
+def test_smem_windows_of_contigs_vs_oracle(gpu, tiny_dev, tiny_oracle, gold, window):
+    """fm6_miter_next over a long sequence (`fermi remap`, smem.c:96-102, :151) cut into windows: the
+    merged window results are the chain's SMEMs, for unitigs of the fixture and for a chimera."""
+    import gzip
+    lines = gzip.open(gold.path("tiny.mag.gz"), "rt").read().split("\n")
+    contigs = [l for l in lines[1::4] if len(l) > 300][:6]
+    nt6 = {c: i for i, c in enumerate("$ACGTN")}
+    seqs = [np.array([nt6[c] for c in s], dtype=np.uint8) for s in contigs]
+    seqs.append(np.concatenate([seqs[0][:333], seqs[1][100:471][::-1], seqs[2][5:300]]))   # breaks inside matches
+    for s in seqs:
+        want = tiny_oracle.smem(s, 0)
+        got = tiny_dev.smem_windows(s, window=window, max_len=128)
+        assert got.tobytes() == want.tobytes(), (len(s), len(got), len(want))
