@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "fmd_retrieve_dev", "fmd_retrieve_batch", "fmd_probe_gather",
     "fmd_build_bwt", "fmd_build_bwt_dev", "fmd_dev_free", "fmd_bwt_to_rle6", "fmd_host_free",
     "fmd_dev_malloc", "fmd_memcpy_h2d", "fmd_memcpy_d2h",
-    "fmd_smem_work_bytes", "fmd_smem_dev", "fmd_smem_batch", "fmd_smem_win_dev", "fmd_smem_win_batch",
+    "fmd_smem_work_bytes", "fmd_smem_dev", "fmd_smem_batch", "fmd_smem_win_dev", "fmd_smem_win_batch", "fmd_reach_dev", "fmd_reach_batch",
     "fmd_kmer_work_bytes", "fmd_kmer_collect_dev", "fmd_kmer_collect",
     "fmd_ovlp_work_bytes", "fmd_ovlp_dev", "fmd_ovlp_batch", "fmd_ovlp_check_left_dev", "fmd_seqinfo_dev", "fmd_seqinfo_batch",
 ]
@@ -97,6 +97,8 @@ def lib():
         L.fmd_smem_work_bytes.restype = sz; L.fmd_smem_work_bytes.argtypes = [sz, C.c_uint32]
         L.fmd_smem_dev.argtypes = [vp, vp, sz, vp, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, sz]
         L.fmd_smem_batch.argtypes = [vp, sz, vp, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp]
+        L.fmd_reach_dev.argtypes = [vp, vp, sz, vp, vp]
+        L.fmd_reach_batch.argtypes = [vp, sz, vp, vp]
         L.fmd_smem_win_dev.argtypes = [vp, vp, sz, vp, vp, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, sz]
         L.fmd_smem_win_batch.argtypes = [vp, sz, vp, C.c_uint64, vp, C.c_int, C.c_uint32, C.c_uint32, vp, vp]
         L.fmd_seqinfo_dev.argtypes = [vp, vp, sz, u64p, C.c_uint32, vp, vp, C.c_uint32, vp, sz]
@@ -275,31 +277,41 @@ DevIndex.smem = _smem
 SMEM_WIN_DT = np.dtype([("seq_off", "<u8"), ("seq_len", "<u4"), ("start", "<u4"), ("stop", "<u4"), ("reserved", "<u4")])
 
 
-def _smem_windows(self, seq, window=256, max_len=256, self_match=0):
-    """All SMEMs of one long sequence (the chain fm6_miter_next walks over a contig), computed in
-    windows of `window` start positions, merged: sorted by start, duplicates across window
-    boundaries dropped.  max_len = longest possible match (longest indexed sequence + 1)."""
+def _reach(self, seqs_zero_terminated):
+    """len[p] = longest prefix of buffer[p..] (up to the next 0 byte) that occurs in the index."""
+    buf = np.ascontiguousarray(seqs_zero_terminated, dtype=np.uint8)
+    out = np.zeros(len(buf), dtype=np.uint32)
+    check(lib().fmd_reach_batch(self.h, len(buf), _ptr(buf), _ptr(out)))
+    return out
+
+
+DevIndex.reach = _reach
+
+
+def _smem_chain(self, seq, max_len=256, self_match=0, full_only=False):
+    """fm6_smem of one long sequence, exactly as the reference walks it: reach -> chain positions ->
+    one fm6_smem1_core item per position, results concatenated in chain order."""
     seq = np.ascontiguousarray(seq, dtype=np.uint8)
     L = len(seq)
-    n = (L + window - 1) // window
-    wins = np.zeros(n, dtype=SMEM_WIN_DT)
-    wins["seq_len"] = L; wins["start"] = np.arange(n) * window; wins["stop"] = np.minimum(wins["start"] + window, L)
-    max_mem = window + max_len + 2
     flat = np.zeros(L + 8, dtype=np.uint8); flat[:L] = seq
+    reach = self.reach(flat[:L + 1])
+    pos = []
+    x = 0
+    while x < L:
+        pos.append(x)
+        x += int(reach[x]) if reach[x] else 1
+    n = len(pos)
+    wins = np.zeros(n, dtype=SMEM_WIN_DT)
+    wins["seq_len"] = L; wins["start"] = pos; wins["stop"] = np.array(pos) + 1; wins["reserved"] = 1 if full_only else 0
+    max_mem = 2 * max_len + 2
     mem = np.zeros((n, max_mem), dtype=INTV_DT); n_mem = np.zeros(n, dtype=np.uint32)
     check(lib().fmd_smem_win_batch(self.h, n, _ptr(flat), L, _ptr(wins), self_match, max_len, max_mem, _ptr(mem), _ptr(n_mem)))
     if (n_mem >> 31).any():
-        raise FmdError("smem_windows: capacity exceeded in %d windows" % int((n_mem >> 31).sum()))
-    allm = np.concatenate([mem[i, :n_mem[i]] for i in range(n)]) if n else np.zeros(0, dtype=INTV_DT)
-    beg = (allm["info"] >> np.uint64(32)) & np.uint64(0x3fffffff)
-    order = np.argsort(beg, kind="stable")
-    allm = allm[order]
-    keep = np.ones(len(allm), dtype=bool)
-    keep[1:] = allm["info"][1:] != allm["info"][:-1]
-    return allm[keep]
+        raise FmdError("smem_chain: capacity exceeded in %d calls" % int((n_mem >> 31).sum()))
+    return np.concatenate([mem[i, :n_mem[i]] for i in range(n)]) if n else np.zeros(0, dtype=INTV_DT)
 
 
-DevIndex.smem_windows = _smem_windows
+DevIndex.smem_chain = _smem_chain
 
 
 def build_bwt(seqs, device=0):

@@ -183,6 +183,62 @@ __global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const
     }
 }
 
+// ------------------------------------------------------------------------------ forward reach
+// For every position p of a buffer of zero-terminated nt6 sequences: the length of the longest
+// prefix of seqs[p..] (up to the terminator) that occurs in the index.  This is the value
+// fm6_smem1_core returns (smem.c:46: the end of its forward sweep), so x -> x + reach[x] is the chain
+// fm6_miter_next / fm6_smem walk (smem.c:96-102, :404-409) -- computed here for ALL positions at once
+// so that the chain itself becomes a pointer chase and every call on it an independent work item.
+// A forward extension of W by c is a backward extension of revcomp(W) by comp(c): plain backward
+// search on the reverse strand's interval, one single-symbol rank pair per base.
+__global__ __launch_bounds__(64) void k_reach(FmdIndexView ix, size_t n, const uint8_t *__restrict__ seqs, uint32_t *__restrict__ out_len,
+                                              uint32_t *__restrict__ queue)
+{
+    FMD_DECLARE_COMPACT_LDS();
+    size_t p = 0, i = 0;
+    uint64_t k = 0, l = 0;
+    uint32_t cw = 0; size_t cw_at = (size_t)-1;
+    bool live = false, exhausted = false;
+    FmdTickets tk_;
+    fmd_tickets_init(tk_, queue);
+    for (;;) {
+        {
+            const size_t my = fmd_tickets_take(tk_, queue, !live && !exhausted);
+            if (!live && !exhausted) {
+                if (my < n) {
+                    p = my;
+                    cw_at = p & ~(size_t)3; cw = *(const uint32_t *)(seqs + cw_at);
+                    const int c = (int)((cw >> (8 * (p & 3))) & 0xff);
+                    const int cc = (c >= 1 && c <= 4) ? 5 - c : c;
+                    if (c == 0 || c > 5) out_len[p] = 0;
+                    else {
+                        k = ix.cnt[cc]; l = ix.cnt[cc + 1] - 1;
+                        if (k > l) out_len[p] = 0;        // a base the index does not contain
+                        else { i = p + 1; live = true; }
+                    }
+                } else exhausted = true;
+            }
+        }
+        if (__ballot(live) == 0) { if (__ballot(!exhausted) == 0) break; else continue; }
+        int cc = 0;
+        if (live) {
+            if ((i & ~(size_t)3) != cw_at) { cw_at = i & ~(size_t)3; cw = *(const uint32_t *)(seqs + cw_at); }
+            const int c = (int)((cw >> (8 * (i & 3))) & 0xff);
+            cc = (c >= 1 && c <= 4) ? 5 - c : c;
+            if (c == 0 || c > 5) { out_len[p] = (uint32_t)(i - p); live = false; } // terminator
+        }
+        FmdRank2c r = fmd_wave_rank2_fetch_compact(ix, fmd_lds, live ? k - 1 : NONE64, live ? l : NONE64);
+        const uint64_t ok = (live && r.hk) ? fmd_block_rank1(r.bk, r.t, r.nk, cc) : 0;
+        fmd_wave_l_ready(ix, fmd_lds, r);
+        if (live) {
+            const uint64_t ol = fmd_block_rank1(r.bl, r.tl, r.nl, cc);
+            k = ix.cnt[cc] + ok; l = ix.cnt[cc] + ol - 1;
+            if (k > l) { out_len[p] = (uint32_t)(i - p); live = false; }
+            else ++i;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ fm_retrieve
 // exact.c:59-70: LF-walk from row x until '$'.  One dependent rank1a per base.
 __global__ __launch_bounds__(64) void k_retrieve(FmdIndexView ix, size_t n, const uint64_t *__restrict__ d_x,
@@ -275,6 +331,18 @@ extern "C" int fmd_bsearch_dev(fmd_dev_t *h, void *stream, size_t n, const uint8
     return FMD_OK;
 }
 
+extern "C" int fmd_reach_dev(fmd_dev_t *h, void *stream, size_t n_bytes, const uint8_t *d_seqs, uint32_t *d_len)
+{
+    if (!h || (n_bytes && (!d_seqs || !d_len)) || ((uintptr_t)d_seqs & 3)) return FMD_E_ARG;
+    if (n_bytes == 0) return FMD_OK;
+    if (n_bytes >= 0xffffff00ull) return FMD_E_ARG; // 32-bit queue head
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    uint32_t *q = fmd_next_queue(h, S(stream));
+    k_reach<<<fmd_grid_for_lds(h, n_bytes, FMD_COMPACT_LDS_U4 * 16), 64, 0, S(stream)>>>(fmd_view(h), n_bytes, d_seqs, d_len, q);
+    FMD_CHECK_LAUNCH();
+    return FMD_OK;
+}
+
 extern "C" int fmd_retrieve_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_x, uint8_t *d_seqs, uint32_t stride,
                                 uint32_t *d_len, uint64_t *d_rank)
 {
@@ -354,6 +422,20 @@ extern "C" int fmd_bsearch_batch(fmd_dev_t *h, size_t n, const uint8_t *seqs, co
     FMD_HIP_TRY(hipMemcpy(cnt, dc.p, n * 8, hipMemcpyDeviceToHost));
     FMD_HIP_TRY(hipMemcpy(beg, dbg.p, n * 8, hipMemcpyDeviceToHost));
     FMD_HIP_TRY(hipMemcpy(end, den.p, n * 8, hipMemcpyDeviceToHost));
+    return FMD_OK;
+}
+
+extern "C" int fmd_reach_batch(fmd_dev_t *h, size_t n_bytes, const uint8_t *seqs, uint32_t *len)
+{
+    if (!h || (n_bytes && (!seqs || !len))) return FMD_E_ARG;
+    if (n_bytes == 0) return FMD_OK;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    DevBuf ds, dl;
+    TRY_RC(ds.alloc(n_bytes + 8)); TRY_RC(dl.alloc(n_bytes * 4));
+    FMD_HIP_TRY(hipMemset((uint8_t *)ds.p + (n_bytes & ~(size_t)3), 0, 8 + (n_bytes & 3))); // zero terminator after the last sequence
+    FMD_HIP_TRY(hipMemcpy(ds.p, seqs, n_bytes, hipMemcpyHostToDevice));
+    TRY_RC(fmd_reach_dev(h, nullptr, n_bytes, (uint8_t *)ds.p, (uint32_t *)dl.p));
+    FMD_HIP_TRY(hipMemcpy(len, dl.p, n_bytes * 4, hipMemcpyDeviceToHost));
     return FMD_OK;
 }
 

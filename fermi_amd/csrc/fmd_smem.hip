@@ -52,7 +52,9 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
     size_t rid = 0;
     const uint8_t *q = nullptr;
     int st = SM_IDLE, len = 0, x = 0, i = 0, ret = 0, stop = 0;
-    uint32_t prev_n = 0, curr_n = 0, j = 0, n_mem = 0, call_base = 0;
+    uint32_t prev_n = 0, curr_n = 0, j = 0, n_mem = 0, call_base = 0;   // SMEMs found (the algorithm's count)
+    uint32_t n_out = 0, out_base = 0;                                    // SMEMs written (full_only drops some)
+    bool full_only = false;
     // two candidate lists of `cap` entries per lane (HBM; this lane's area is reused read after read)
     fmd_intv_t *const la = work + ((size_t)blockIdx.x * 64 + fmd_lane()) * 2 * (size_t)cap, *const lb = la + cap;
     fmd_intv_t *prev = nullptr, *curr = nullptr;
@@ -76,10 +78,11 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
         const size_t my = fmd_tickets_take(tk_, queue, st == SM_IDLE && take);
         if (st == SM_IDLE && take) {
             if (my < n) {
-                rid = my; cw_at = ~0ull; n_mem = 0; overflow = false;
+                rid = my; cw_at = ~0ull; n_mem = 0; n_out = 0; overflow = false; full_only = false;
                 if (wins) { // a window of a long sequence: start positions [start, stop) of the fm6_smem chain
                     const fmd_smem_win_t wn = wins[my];
                     sbase = wn.seq_off; len = (int)wn.seq_len; x = (int)wn.start; stop = (int)(wn.stop < wn.seq_len ? wn.stop : wn.seq_len);
+                    full_only = (wn.reserved & FMD_SMEM_WIN_F_FULL) != 0;
                 } else { sbase = off[my]; len = (int)(off[my + 1] - sbase); x = 0; stop = len; }
                 q = seqs + sbase;
                 if (len <= 0 || x >= stop) n_mem_out[rid] = 0;
@@ -94,9 +97,9 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
             if (st == SM_START) { // fm6_smem1_core prologue (smem.c:19-21)
                 const int c = q[x];
                 kx0 = ix.cnt[c]; kx1 = ix.cnt[s_comp6(c)]; ksz = ix.cnt[c + 1] - ix.cnt[c]; kinfo = (uint64_t)(x + 1);
-                curr_n = 0; call_base = n_mem; i = x + 1;
+                curr_n = 0; call_base = n_mem; out_base = n_out; i = x + 1;
                 if (ksz == 0) { // the reference dereferences an empty list here (undefined); stop this read
-                    n_mem_out[rid] = n_mem | (overflow ? 0x80000000u : 0);
+                    n_mem_out[rid] = n_out | (overflow ? 0x80000000u : 0);
                     st = SM_IDLE;
                 } else if (i < len) st = SM_FWD;
                 else { // x is the last base: push the interval (smem.c:35-37); list is written back to front
@@ -124,8 +127,8 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
                     curr = (prev == lb) ? la : lb; // lists start at index 0 of their areas from now on
                     curr_n = 0; j = 0; --i; have_pf = false; again = true;
                 } else { // this call is over: fm_reverse_fmivec(mem) (smem.c:79), then the next start (smem.c:404-409)
-                    if (n_mem <= max_mem)
-                        for (uint32_t a = call_base, b = n_mem; a + 1 < b; ++a) {
+                    if (n_out <= max_mem)
+                        for (uint32_t a = out_base, b = n_out; a + 1 < b; ++a) {
                             --b;
                             fmd_intv_t *pa = mem_out + rid * (size_t)max_mem + a, *pb = mem_out + rid * (size_t)max_mem + b;
                             uint64_t a0, a1, a2, a3, b0, b1, b2, b3;
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
                         }
                     x = ret;
                     if (x < stop) { st = SM_START; again = true; }
-                    else { n_mem_out[rid] = n_mem | (overflow ? 0x80000000u : 0); st = SM_IDLE; }
+                    else { n_mem_out[rid] = n_out | (overflow ? 0x80000000u : 0); st = SM_IDLE; }
                 }
             }
         }
@@ -229,8 +232,11 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
                 if (curr_n == 0 || fl_match) {
                     if (fl_match || n_mem == call_base || (uint64_t)(i + 1) < last_mem_beg) { // skip contained matches
                         const uint64_t inf = kinfo | (uint64_t)(s[0] != 0) << 63 | (uint64_t)(i + 1) << 32;
-                        if (n_mem < max_mem) s_store(mem_out + rid * (size_t)max_mem + n_mem, kx0, kx1, ksz, inf);
-                        else overflow = true;
+                        if (!full_only || fl_match) { // fl_match: closed by a sentinel on both sides = a whole sequence of the index
+                            if (n_out < max_mem) s_store(mem_out + rid * (size_t)max_mem + n_out, kx0, kx1, ksz, inf);
+                            else overflow = true;
+                            ++n_out;
+                        }
                         ++n_mem;
                         last_mem_beg = (uint64_t)(i + 1);
                     }
@@ -278,12 +284,10 @@ extern "C" int fmd_smem_dev(fmd_dev_t *h, void *stream_, size_t n, const uint8_t
 }
 
 // Windows of long sequences (contigs): item i runs the fm6_smem chain (smem.c:397-410, = fm6_miter_next,
-// smem.c:96-102) over the start positions [start, stop) of the sequence at d_seqs + seq_off.  Every
-// fm6_smem1_core call is a pure function of (sequence, x) and the chain from any start position
-// reaches every SMEM that begins at or after it, so the union over a partition into windows is
-// the SMEM set of the whole sequence; an SMEM that covers a window boundary can be reported by
-// both windows (the caller sorts by start and drops duplicates).  max_len bounds the length of a
-// match (the longest sequence in the index + 1).
+// smem.c:96-102) from `start` while x < stop over the sequence at d_seqs + seq_off.  Every
+// fm6_smem1_core call is a pure function of (sequence, x); the calls the reference makes are those at
+// the positions of the chain from 0 (x -> x + reach[x], fmd_reach_dev), one item each.  max_len bounds
+// the length of a match (the longest sequence in the index + 1).
 extern "C" int fmd_smem_win_dev(fmd_dev_t *h, void *stream_, size_t n, const uint8_t *d_seqs, const fmd_smem_win_t *d_wins, int self_match,
                                 uint32_t max_len, uint32_t max_mem, fmd_intv_t *d_mem, uint32_t *d_n_mem, void *d_work, size_t work_bytes)
 {

@@ -50,10 +50,24 @@ int fmdh_seq_read(fmdh_seqio_t *io);                   /* length, -1 = end of fi
 const char *fmdh_seq_name(const fmdh_seqio_t *io);
 char *fmdh_seq_bases(fmdh_seqio_t *io);
 char *fmdh_seq_qual(fmdh_seqio_t *io);                 /* NULL for FASTA */
+const char *fmdh_seq_comment(const fmdh_seqio_t *io);  /* NULL when the header has none */
 void fmdh_seq_close(fmdh_seqio_t *io);
 
 /* `fermi exact [-s] <idx> <src.fa>` (cmd.c:292-331) */
 int fmdh_exact(const char *fmd_path, const char *fa_path, int device, int self_match, FILE *out);
+
+/* `fermi remap [-l skip] [-c min_pcv] [-D max_dist] [-r rank] <reads.fmd> <contigs.fq>` (cmd.c:218-251,
+ * smem.c:114-394): coverage of every contig by the reads that match it full length, paired-end
+ * coverage when a rank file is given; prints what `fermi remap -t1` prints. */
+typedef struct { int skip, min_pcv, max_dist; } fmdh_remapopt_t;
+int fmdh_remap(const char *fmd_path, const char *contig_path, int device, const fmdh_remapopt_t *opt, const char *rank_file, FILE *out);
+/* the per-contig part alone (paircov + printing, smem.c:139-303) over the contig's full-length matches,
+ * sorted by start (state = fmdh_remap_new(); one state per run: the pair table lives across contigs) */
+typedef struct fmdh_remap_state fmdh_remap_state_t;
+fmdh_remap_state_t *fmdh_remap_new(const fmdh_remapopt_t *opt, const uint64_t *sorted /* or NULL */, uint64_t n_seq);
+void fmdh_remap_contig(fmdh_remap_state_t *st, const char *name, const char *comment, int len, uint8_t *nt6 /* len + 1 bytes, overwritten */,
+                       const fmd_intv_t *mem, size_t n_mem, FILE *out);
+void fmdh_remap_finish(fmdh_remap_state_t *st, FILE *err); /* the `avg = .. std = .. cap = ..` line, then frees st */
 
 /* `fermi build -o out.fmd <in.fa>` (cmd.c:378-484); no_fr = trim palindromes (default 1) */
 int fmdh_build(const char *fa_path, const char *out_path, int device, int max_len, int no_fr);

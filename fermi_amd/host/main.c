@@ -123,6 +123,34 @@ static int main_correct(int argc, char *argv[]) /* cmd.c:253-291 */
     return fmdh_correct(argv[optind], argv[optind + 1], device, &opt, stdout);
 }
 
+static int main_remap(int argc, char *argv[]) /* cmd.c:218-251 */
+{
+    int c, device = 0;
+    fmdh_remapopt_t opt;
+    const char *rank_file = 0;
+    opt.skip = 50; opt.min_pcv = 0; opt.max_dist = 1000;
+    while ((c = getopt(argc, argv, "Ml:t:c:r:D:g:")) >= 0) {
+        switch (c) {
+        case 'l': opt.skip = atoi(optarg); break;
+        case 'c': opt.min_pcv = atoi(optarg); break;
+        case 'D': opt.max_dist = atoi(optarg); break;
+        case 'r': rank_file = optarg; break;
+        case 'M': case 't': break; /* mmap / threads: the output is that of -t1 (contigs in input order) */
+        case 'g': device = atoi(optarg); break;
+        }
+    }
+    if (optind + 2 > argc) {
+        fprintf(stderr, "\nUsage:   fermi-amd remap [options] <reads.fmd> <contigs.fq>\n\n");
+        fprintf(stderr, "Options: -l INT      skip ending INT bases of a read pair [%d]\n", opt.skip);
+        fprintf(stderr, "         -c INT      minimum paired-end coverage [%d]\n", opt.min_pcv);
+        fprintf(stderr, "         -D INT      maximum insert size (external distance) [%d]\n", opt.max_dist);
+        fprintf(stderr, "         -r FILE     rank [null]\n");
+        fprintf(stderr, "         -g INT      GPU to use [0]\n\n");
+        return 1;
+    }
+    return fmdh_remap(argv[optind], argv[optind + 1], device, &opt, rank_file, stdout);
+}
+
 int main(int argc, char *argv[])
 {
     if (argc < 2) {
@@ -132,7 +160,8 @@ int main(int argc, char *argv[])
         fprintf(stderr, "         seqsort    rank -> read index map for `unitig -r` (fermi seqsort)\n");
         fprintf(stderr, "         unitig     construct unitigs (fermi unitig)\n");
         fprintf(stderr, "         correct    error correction (fermi correct)\n");
-        fprintf(stderr, "         exact      find super-maximal exact matches (fermi exact)\n\n");
+        fprintf(stderr, "         exact      find super-maximal exact matches (fermi exact)\n");
+        fprintf(stderr, "         remap      coverage of contigs by the reads, paired-end breaks (fermi remap)\n\n");
         return 1;
     }
     if (fmd_device_count() <= 0) {
@@ -144,6 +173,7 @@ int main(int argc, char *argv[])
     if (strcmp(argv[1], "seqsort") == 0) return main_seqsort(argc - 1, argv + 1);
     if (strcmp(argv[1], "exact") == 0) return main_exact(argc - 1, argv + 1);
     if (strcmp(argv[1], "correct") == 0) return main_correct(argc - 1, argv + 1);
+    if (strcmp(argv[1], "remap") == 0) return main_remap(argc - 1, argv + 1);
     fprintf(stderr, "[E::main] unrecognized command `%s'\n", argv[1]);
     return 1;
 }

@@ -11,8 +11,8 @@ struct fmdh_seqio {
     gzFile fp;
     unsigned char buf[1 << 16];
     int beg, end, eof, last_char;
-    char *name, *seq, *qual;
-    size_t name_l, name_m, seq_l, seq_m, qual_l, qual_m;
+    char *name, *seq, *qual, *comment;
+    size_t name_l, name_m, seq_l, seq_m, qual_l, qual_m, comment_l, comment_m;
 };
 
 static int io_getc(fmdh_seqio_t *io)
@@ -39,16 +39,18 @@ fmdh_seqio_t *fmdh_seq_open(const char *fn)
     put(&io->name, &io->name_l, &io->name_m, 0); io->name_l = 0;
     put(&io->seq, &io->seq_l, &io->seq_m, 0); io->seq_l = 0;
     put(&io->qual, &io->qual_l, &io->qual_m, 0); io->qual_l = 0;
+    put(&io->comment, &io->comment_l, &io->comment_m, 0); io->comment_l = 0;
     return io;
 }
 void fmdh_seq_close(fmdh_seqio_t *io)
 {
     if (!io) return;
-    gzclose(io->fp); free(io->name); free(io->seq); free(io->qual); free(io);
+    gzclose(io->fp); free(io->name); free(io->seq); free(io->qual); free(io->comment); free(io);
 }
 const char *fmdh_seq_name(const fmdh_seqio_t *io) { return io->name; }
 char *fmdh_seq_bases(fmdh_seqio_t *io) { return io->seq; }
 char *fmdh_seq_qual(fmdh_seqio_t *io) { return io->qual_l ? io->qual : 0; }
+const char *fmdh_seq_comment(const fmdh_seqio_t *io) { return io->comment_l ? io->comment : 0; } /* rest of the header line (kseq.h:183) */
 
 int fmdh_seq_read(fmdh_seqio_t *io) /* sequence length, -1 at end of file, -2 on a truncated quality */
 {
@@ -58,10 +60,13 @@ int fmdh_seq_read(fmdh_seqio_t *io) /* sequence length, -1 at end of file, -2 on
         if (c == -1) return -1;
         io->last_char = c;
     }
-    io->name_l = io->seq_l = io->qual_l = 0; io->name[0] = io->seq[0] = io->qual[0] = 0;
+    io->name_l = io->seq_l = io->qual_l = io->comment_l = 0; io->name[0] = io->seq[0] = io->qual[0] = io->comment[0] = 0;
     while ((c = io_getc(io)) != -1 && c != ' ' && c != '\t' && c != '\n' && c != '\r') put(&io->name, &io->name_l, &io->name_m, c);
     if (c == -1 && io->name_l == 0) return -1;
-    if (c != '\n') while ((c = io_getc(io)) != -1 && c != '\n') {} /* comment */
+    if (c != '\n') { /* comment: the rest of the line, a trailing CR dropped (kseq.h:135) */
+        while ((c = io_getc(io)) != -1 && c != '\n') put(&io->comment, &io->comment_l, &io->comment_m, c);
+        if (io->comment_l > 1 && io->comment[io->comment_l - 1] == '\r') io->comment[--io->comment_l] = 0;
+    }
     while ((c = io_getc(io)) != -1 && c != '>' && c != '+' && c != '@') {
         if (c == '\n' || c == '\r') continue;
         put(&io->seq, &io->seq_l, &io->seq_m, c);

@@ -32,6 +32,14 @@ def lib():
         L.EcOpt = EcOpt
         L.fmdh_correct_reads.argtypes = [C.POINTER(EcOpt), C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p]
         L.fmdh_correct_kmer.argtypes = [C.c_uint64]
+        class RemapOpt(C.Structure):
+            _fields_ = [("skip", C.c_int), ("min_pcv", C.c_int), ("max_dist", C.c_int)]
+        L.RemapOpt = RemapOpt
+        L.fmdh_remap_new.restype = C.c_void_p
+        L.fmdh_remap_new.argtypes = [C.POINTER(RemapOpt), C.c_void_p, C.c_uint64]
+        L.fmdh_remap_contig.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.fmdh_remap_finish.argtypes = [C.c_void_p, C.c_void_p]
+        L.fmdh_remap.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(RemapOpt), C.c_char_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -110,3 +118,22 @@ def correct_reads(w, min_occ, bucket, key, val, fq_path, out_path, step=5, max_c
         _libc.fclose(fp)
     if rc:
         raise RuntimeError("fmdh_correct_reads failed")
+
+
+def remap_contigs(contigs, mems, n_seq, out_path, err_path, skip=50, min_pcv=0, max_dist=1000, sorted_map=None):
+    """The host part of `fermi remap` (paircov + printing) over precomputed SMEM lists.
+    contigs: list of (name, comment or None, nt6 array); mems: one INTV_DT array per contig, sorted by start."""
+    L = lib()
+    opt = L.RemapOpt(skip, min_pcv, max_dist)
+    sm = None if sorted_map is None else np.ascontiguousarray(sorted_map, dtype=np.uint64)
+    st = L.fmdh_remap_new(C.byref(opt), None if sm is None else sm.ctypes.data, n_seq)
+    fp = _libc.fopen(out_path.encode(), b"wb"); fe = _libc.fopen(err_path.encode(), b"wb")
+    try:
+        for (name, comment, seq), m in zip(contigs, mems):
+            buf = np.zeros(len(seq) + 1, dtype=np.uint8); buf[:len(seq)] = seq
+            m = np.ascontiguousarray(m)
+            L.fmdh_remap_contig(st, name.encode(), None if comment is None else comment.encode(), len(seq), buf.ctypes.data,
+                                m.ctypes.data, len(m), fp)
+        L.fmdh_remap_finish(st, fe)
+    finally:
+        _libc.fclose(fp); _libc.fclose(fe)

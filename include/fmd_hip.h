@@ -99,6 +99,16 @@ int fmd_retrieve_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_x, 
 int fmd_retrieve_batch(fmd_dev_t *h, size_t n, const uint64_t *x, uint8_t *seqs, uint32_t stride,
                        uint32_t *len, uint64_t *rank);
 
+/* ---- forward reach ("matching statistics") --------------------------------------------------
+ * seqs: n_bytes of nt6 sequences, each followed by at least one 0 byte (the _dev form: 4-byte
+ * aligned, a 0 byte at or after seqs[n_bytes - 1], readable to the next multiple of 4).  len[p] = length of
+ * the longest prefix of seqs[p ..] (up to its terminator) that occurs in the index; 0 at terminators and
+ * at bases the index does not contain.  x -> x + len[x] is the chain of start positions that
+ * fm6_miter_next / fm6_smem walk (smem.c:46, :96-102, :404-409): with it, every fm6_smem1_core call
+ * of a long sequence is known up front and independent (fmd_smem_win_* with stop = start + 1). */
+int fmd_reach_dev(fmd_dev_t *h, void *stream, size_t n_bytes, const uint8_t *d_seqs, uint32_t *d_len);
+int fmd_reach_batch(fmd_dev_t *h, size_t n_bytes, const uint8_t *seqs, uint32_t *len);
+
 /* ---- super-maximal exact matches: fm6_smem (smem.c:397-410) = repeated fm6_smem1_core
  * (smem.c:13-80); what `fermi exact [-s]` prints (cmd.c:319-327, smem.c:412-418).
  * mem: n rows of max_mem intervals in the reference's order; info = leftclosed<<63 | beg<<32 | end
@@ -114,7 +124,8 @@ int fmd_smem_dev(fmd_dev_t *h, void *stream, size_t n, const uint8_t *d_seqs, co
  * bases at seqs + seq_off.  The union over a partition of a sequence into windows is its SMEM set;
  * an SMEM covering a window boundary may be reported by both windows.  max_len = longest match
  * possible (longest sequence in the index + 1). */
-typedef struct { uint64_t seq_off; uint32_t seq_len, start, stop, reserved; } fmd_smem_win_t;
+typedef struct { uint64_t seq_off; uint32_t seq_len, start, stop, reserved /* flags */; } fmd_smem_win_t;
+#define FMD_SMEM_WIN_F_FULL 1u   /* keep only matches closed by a sentinel on both sides (what remap consumes) */
 int fmd_smem_win_dev(fmd_dev_t *h, void *stream, size_t n, const uint8_t *d_seqs, const fmd_smem_win_t *d_wins, int self_match,
                      uint32_t max_len, uint32_t max_mem, fmd_intv_t *d_mem, uint32_t *d_n_mem, void *d_work, size_t work_bytes);
 int fmd_smem_win_batch(fmd_dev_t *h, size_t n, const uint8_t *seqs, uint64_t seq_bytes, const fmd_smem_win_t *wins, int self_match,

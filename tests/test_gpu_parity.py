@@ -339,18 +339,67 @@ def test_seqsort_and_unitig_r_cli(gpu, gold, tmp_path, name, mm):
     assert _cli("unitig", "-l%d" % mm, gold.path(name + ".fmd")) == gold.text_gz(name + ".mag.gz")
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("window", [64, 256, 1000])
-def test_smem_windows_of_contigs_vs_oracle(gpu, tiny_dev, tiny_oracle, gold, window):
-    """fm6_miter_next over a long sequence (`fermi remap`, smem.c:96-102, :151) cut into windows: the
-    merged window results are the chain's SMEMs, for unitigs of the fixture and for a chimera."""
+def _contigs_nt6(path):
     import gzip
-    lines = gzip.open(gold.path("tiny.mag.gz"), "rt").read().split("\n")
-    contigs = [l for l in lines[1::4] if len(l) > 300][:6]
+    lines = gzip.open(path, "rt").read().split("\n")
     nt6 = {c: i for i, c in enumerate("$ACGTN")}
-    seqs = [np.array([nt6[c] for c in s], dtype=np.uint8) for s in contigs]
-    seqs.append(np.concatenate([seqs[0][:333], seqs[1][100:471][::-1], seqs[2][5:300]]))   # breaks inside matches
-    for s in seqs:
-        want = tiny_oracle.smem(s, 0)
-        got = tiny_dev.smem_windows(s, window=window, max_len=128)
+    return [np.array([nt6[c] for c in s], dtype=np.uint8) for s in lines[1::4] if s]
+
+
+@pytest.mark.gpu
+def test_smem_chain_of_contigs_vs_oracle(gpu, gold, oracle_lib):
+    """fm6_smem over long sequences the way `fermi remap` walks them (fm6_miter_next, smem.c:96-102):
+    forward reach of every position -> chain of start positions -> one fm6_smem1_core work item per
+    position == the sequential chain of the oracle, for unitigs, the genome, a chimera, a reverse strand."""
+    from fermi_amd import api
+    d = api.DevIndex.open(gold.path("pairs.fmd"))
+    o = orcbind.OrcIndex(gold.path("pairs.fmd"))
+    for s in _contigs_nt6(gold.path("pairs_contigs.fq.gz")):
+        want = o.smem(s, 0)
+        got = d.smem_chain(s, max_len=64)
         assert got.tobytes() == want.tobytes(), (len(s), len(got), len(want))
+        full = d.smem_chain(s, max_len=64, full_only=True)
+        keep = ((want["info"] >> np.uint64(63)) != 0) & (want["x"][:, 1] < o.mcnt[1])
+        assert full.tobytes() == want[keep].tobytes()
+    o.close(); d.close()
+
+
+def test_reach_vs_oracle_backward_search(gpu, gold, oracle_lib):
+    """fmd_reach: longest indexed prefix at every position == the longest hit of fm_backward_search on
+    the reverse complement (checked position by position on a chimera with a foreign insert)."""
+    from fermi_amd import api
+    d = api.DevIndex.open(gold.path("pairs.fmd"))
+    o = orcbind.OrcIndex(gold.path("pairs.fmd"))
+    s = _contigs_nt6(gold.path("pairs_contigs.fq.gz"))[3][:700].copy()
+    s[300:310] = np.array([1, 1, 1, 1, 1, 1, 1, 1, 1, 1], dtype=np.uint8)
+    buf = np.concatenate([s, [0], s[:50], [0, 0, 0]]).astype(np.uint8)
+    got = d.reach(buf)
+    for p in range(len(buf)):
+        if buf[p] == 0:
+            assert got[p] == 0
+            continue
+        e = p
+        while buf[e] != 0:
+            e += 1
+        want = 0
+        for m in range(1, min(e - p, 70) + 1):       # matches are monotone: stop at the first miss
+            q = (5 - buf[p:p + m])[::-1].copy()
+            cnt, _, _ = o.backward_search(q[None, :])
+            if cnt[0] == 0:
+                break
+            want = m
+        assert got[p] == want, (p, got[p], want)
+    o.close(); d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,args", [("u", []), ("p", ["-l", "20", "-D", "600", "-r", "RANK"]),
+                                       ("c", ["-l", "20", "-D", "600", "-c", "2", "-r", "RANK"]), ("d", ["-D", "310", "-c", "1", "-t", "3", "-r", "RANK"])])
+def test_remap_cli_equals_fermi_remap(gpu, gold, mode, args):
+    """`fermi-amd remap` == `fermi remap -t1` bytes (stdout) and its insert-size line (stderr)."""
+    import json, os, subprocess
+    args = [gold.path("pairs.rank") if a == "RANK" else a for a in args]
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fermi_amd", "bin", "fermi-amd")
+    p = subprocess.run([exe, "remap"] + args + [gold.path("pairs.fmd"), gold.path("pairs_contigs.fq.gz")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    assert p.stdout == gold.text_gz("pairs.remap_%s.gz" % mode)
+    assert [l for l in p.stderr.decode().split("\n") if "fm6_remap" in l] == json.load(open(gold.path("pairs.remap_stderr.json")))[mode]

@@ -89,3 +89,39 @@ def test_unitig_walk_with_rank_file(oracle_lib, gold, tmp_path, name, mm):
     hostlib.unitig_walk(rec, nei, seq, n_seq, mm, out, sorted_map=sm)
     assert open(out, "rb").read() == gold.text_gz(name + ".r.mag.gz")
     o.close()
+
+
+def _read_contigs(path):
+    """(name, comment, nt6) per record, with kseq's header split (name = up to the first white space)."""
+    import gzip
+    lines = gzip.open(path, "rt").read().split("\n")
+    tab = np.full(256, 5, dtype=np.uint8)
+    for i, c in enumerate("$ACGTN"):
+        tab[ord(c)] = i; tab[ord(c.lower())] = i
+    out = []
+    for h, s in zip(lines[0::4], lines[1::4]):
+        if not h:
+            continue
+        h = h[1:]
+        k = next((i for i, c in enumerate(h) if c.isspace()), len(h))
+        out.append((h[:k], h[k + 1:] if k < len(h) and h[k + 1:] else None, tab[np.frombuffer(s.encode(), dtype=np.uint8)]))
+    return out
+
+
+@pytest.mark.parametrize("mode,kw", [("u", dict()), ("p", dict(skip=20, max_dist=600, rank=True)),
+                                     ("c", dict(skip=20, max_dist=600, min_pcv=2, rank=True)), ("d", dict(max_dist=310, min_pcv=1, rank=True))])
+def test_remap_host_part_reproduces_fermi_remap(oracle_lib, gold, tmp_path, mode, kw):
+    """paircov + pair table + mask_pcv + printers (fermi_amd/host/remap_cmd.c) over the SMEM chain of
+    each contig == `fermi remap -t1` bytes, incl. the UR:Z order (bucket order of the pair table, which
+    lives across contigs) and the insert-size line on stderr."""
+    import json
+    o = orcbind.OrcIndex(gold.path("pairs.fmd"))
+    contigs = _read_contigs(gold.path("pairs_contigs.fq.gz"))
+    mems = [o.smem(c[2], 0) for c in contigs]
+    kw = dict(kw)
+    sm = np.fromfile(gold.path("pairs.rank"), dtype=np.uint64) if kw.pop("rank", False) else None
+    out, err = str(tmp_path / "o"), str(tmp_path / "e")
+    hostlib.remap_contigs(contigs, mems, int(o.mcnt[1]), out, err, sorted_map=sm, **kw)
+    o.close()
+    assert open(out, "rb").read() == gold.text_gz("pairs.remap_%s.gz" % mode)
+    assert open(err).read().strip() == json.load(open(gold.path("pairs.remap_stderr.json")))[mode][0]

@@ -45,5 +45,34 @@ for name, a_args, r_args in [
     tr = run([REF] + r_args, T + "/b." + name)
     r = same(T + "/a." + name, T + "/b." + name); ok &= r
     print("%-8s: identical=%s  fermi-amd %.1fs  fermi(-t1) %.1fs  (%d bytes)" % (name, r, ta, tr, os.path.getsize(T + "/b." + name)), flush=True)
+
+# ---- paired-end part: seqsort, unitig -r, remap (smem.c:114-394) on a paired read set made from the
+# same genome (FR pairs, insert ~ N(300, 30), every other read reverse-complemented, same error rate)
+import numpy as np  # noqa: E402
+g = synth.genome(synth.DEFAULT_SEED, n, 100, 30)
+rng = np.random.default_rng(7)
+npairs = n // 2
+ins = np.clip(rng.normal(300, 30, npairs).astype(np.int64), 200, 500)
+pos = rng.integers(0, len(g) - 500, npairs)
+pr = np.empty((2 * npairs, 100), dtype=np.uint8)
+idx = np.arange(100)
+pr[0::2] = g[pos[:, None] + idx[None, :]]
+pr[1::2] = (5 - g[(pos + ins)[:, None] - 1 - idx[None, :]])
+if err > 0:
+    m = rng.random(pr.shape) < err
+    pr[m] = 1 + (pr[m] - 1 + rng.integers(1, 4, int(m.sum()))) % 4
+synth.to_fastq(pr, T + "/p.fq")
+run([AMD, "build", "-fo", T + "/p.fmd", T + "/p.fq"], T + "/p.log")
+for name, a_args, r_args in [
+        ("seqsort", ["seqsort", T + "/p.fmd"], ["seqsort", "-t8", T + "/p.fmd"]),
+        ("unitig-r", ["unitig", "-l50", "-r", T + "/a.seqsort", T + "/p.fmd"], ["unitig", "-l50", "-t1", "-r", T + "/b.seqsort", T + "/p.fmd"]),
+        ("remap-u", ["remap", T + "/p.fmd", T + "/b.unitig-r"], ["remap", T + "/p.fmd", T + "/b.unitig-r"]),
+        ("remap-p", ["remap", "-r", T + "/b.seqsort", T + "/p.fmd", T + "/b.unitig-r"], ["remap", "-r", T + "/b.seqsort", T + "/p.fmd", T + "/b.unitig-r"]),
+        ("remap-c", ["remap", "-c", "2", "-D", "420", "-r", T + "/b.seqsort", T + "/p.fmd", T + "/b.unitig-r"],
+         ["remap", "-c", "2", "-D", "420", "-r", T + "/b.seqsort", T + "/p.fmd", T + "/b.unitig-r"])]:
+    ta = run([AMD] + a_args, T + "/a." + name)
+    tr = run([REF] + r_args, T + "/b." + name)
+    r = same(T + "/a." + name, T + "/b." + name); ok &= r
+    print("%-8s: identical=%s  fermi-amd %.1fs  fermi(-t1) %.1fs  (%d bytes)" % (name, r, ta, tr, os.path.getsize(T + "/b." + name)), flush=True)
 print("ALL IDENTICAL" if ok else "MISMATCH")
 sys.exit(0 if ok else 1)
