@@ -392,6 +392,69 @@ extern "C" int fmd_dev_open_file(int device, const char *fn, fmd_dev_t **out)
     }
 }
 
+// ---- inspection: what `fermi chkbwt -p / -r` and the tests need --------------------------------
+// one thread per 32-position chunk: the plane words back into one nt6 byte per position
+__global__ void k_planes_to_bwt(const uint4 *__restrict__ blocks, uint64_t first, uint64_t n, uint8_t *__restrict__ out)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // chunk relative to first/32
+    const uint64_t p0 = (first & ~31ull) + c * 32;
+    if (p0 >= first + n) return;
+    const uint4 v = blocks[p0 >> 5];
+    for (int i = 0; i < 32; ++i) {
+        const uint64_t p = p0 + i;
+        if (p >= first && p < first + n) out[p - first] = (uint8_t)(((v.x >> i) & 1) | ((v.y >> i) & 1) << 1 | ((v.z >> i) & 1) << 2);
+    }
+}
+
+extern "C" int fmd_dev_export_bwt(fmd_dev_t *h, uint64_t first, uint64_t n, uint8_t *bwt)
+{
+    if (!h || (n && !bwt) || first > h->mcnt[0] || n > h->mcnt[0] - first) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    uint8_t *d = nullptr;
+    FMD_HIP_TRY(hipMalloc((void **)&d, n));
+    const uint64_t n_chunks = (first + n + 31) / 32 - first / 32;
+    k_planes_to_bwt<<<nblk(n_chunks, 256), 256>>>(h->blocks, first, n, d);
+    hipError_t e = hipMemcpy(bwt, d, n, hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) { fmd_set_hip_error(e, "export"); return FMD_E_HIP; }
+    return FMD_OK;
+}
+
+// rank self-check (chkbwt -r, cmd.c:86-101): for every position k the six counts of BWT[0..k] taken
+// from the block's absolute counts + popcounts must equal those of k-1 plus the symbol at k, and the
+// last position must give the marginal counts.  One thread per position, blocks read in order.
+__global__ void k_check_rank(FmdIndexView ix, unsigned long long *__restrict__ bad /* [0] count, [1] first position */)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ix.n_sym) return;
+    uint64_t a[6], b[6] = {0, 0, 0, 0, 0, 0};
+    const uint4 *blk = ix.blocks + (k >> FMD_BLK_SHIFT) * FMD_BLK_U4;
+    const int c = fmd_block_rank6<true>(blk, 0, ((uint32_t)k & (FMD_BLK_SYMS - 1)) + 1, a);
+    if (k) { const uint4 *pb = ix.blocks + ((k - 1) >> FMD_BLK_SHIFT) * FMD_BLK_U4; fmd_block_rank6<false>(pb, 0, ((uint32_t)(k - 1) & (FMD_BLK_SYMS - 1)) + 1, b); }
+    bool ok = c >= 0 && c < 6;
+    for (int j = 0; j < 6; ++j) ok = ok && a[j] == b[j] + (j == c ? 1u : 0u);
+    if (k == ix.n_sym - 1) for (int j = 0; j < 6; ++j) ok = ok && a[j] == ix.cnt[j + 1] - ix.cnt[j];
+    if (!ok) { atomicAdd(&bad[0], 1ull); atomicMin(&bad[1], (unsigned long long)k); }
+}
+
+extern "C" int fmd_dev_check_rank(fmd_dev_t *h, uint64_t *n_bad, uint64_t *first_bad)
+{
+    if (!h || !n_bad || !first_bad) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    unsigned long long *d = nullptr, init[2] = {0, ~0ull}, res[2];
+    FMD_HIP_TRY(hipMalloc((void **)&d, 16));
+    FMD_HIP_TRY(hipMemcpy(d, init, 16, hipMemcpyHostToDevice));
+    const uint64_t n = h->mcnt[0];
+    if ((n + 255) / 256 > 0x7fffffffull) { hipFree(d); return FMD_E_ARG; } // one thread per position: 5.5e11 symbols at most
+    if (n) k_check_rank<<<(unsigned)((n + 255) / 256), 256>>>(fmd_view(h), d);
+    hipError_t e = hipMemcpy(res, d, 16, hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) { fmd_set_hip_error(e, "check_rank"); return FMD_E_HIP; }
+    *n_bad = res[0]; *first_bad = res[1];
+    return FMD_OK;
+}
+
 extern "C" void fmd_dev_close(fmd_dev_t *h)
 {
     if (!h) return;

@@ -56,6 +56,10 @@ void fmdh_seq_close(fmdh_seqio_t *io);
 /* `fermi exact [-s] <idx> <src.fa>` (cmd.c:292-331) */
 int fmdh_exact(const char *fmd_path, const char *fa_path, int device, int self_match, FILE *out);
 
+/* `fermi chkbwt [-p] [-r] <idx>` (cmd.c:47-130) and `fermi unpack [-i INT]... <idx>` (cmd.c:132-171) */
+int fmdh_chkbwt(const char *fmd_path, int device, int plain, int check_rank, FILE *out);
+int fmdh_unpack(const char *fmd_path, int device, int n_list, const uint64_t *list /* or NULL: all */, FILE *out);
+
 /* `fermi remap [-l skip] [-c min_pcv] [-D max_dist] [-r rank] <reads.fmd> <contigs.fq>` (cmd.c:218-251,
  * smem.c:114-394): coverage of every contig by the reads that match it full length, paired-end
  * coverage when a rank file is given; prints what `fermi remap -t1` prints. */

@@ -123,6 +123,51 @@ static int main_correct(int argc, char *argv[]) /* cmd.c:253-291 */
     return fmdh_correct(argv[optind], argv[optind + 1], device, &opt, stdout);
 }
 
+static int main_chkbwt(int argc, char *argv[]) /* cmd.c:47-130 */
+{
+    int c, plain = 0, check_rank = 0, device = 0;
+    while ((c = getopt(argc, argv, "pMrg:")) >= 0) {
+        switch (c) {
+        case 'p': plain = 1; break;
+        case 'r': check_rank = 1; break;
+        case 'M': break;
+        case 'g': device = atoi(optarg); break;
+        }
+    }
+    if (argc == optind) {
+        fprintf(stderr, "\nUsage:   fermi-amd chkbwt [options] <idxbase.fmd>\n\n");
+        fprintf(stderr, "Options: -r        check rank\n");
+        fprintf(stderr, "         -p        print the BWT to the stdout\n");
+        fprintf(stderr, "         -g INT    GPU to use [0]\n\n");
+        return 1;
+    }
+    return fmdh_chkbwt(argv[optind], device, plain, check_rank, stdout);
+}
+
+static int main_unpack(int argc, char *argv[]) /* cmd.c:142-171 */
+{
+    int c, n = 0, m = 0, device = 0, rc;
+    uint64_t *list = 0;
+    while ((c = getopt(argc, argv, "Mi:g:")) >= 0) {
+        switch (c) {
+        case 'i':
+            if (n == m) { m = m ? m << 1 : 16; list = (uint64_t *)realloc(list, 8 * (size_t)m); }
+            list[n++] = (uint64_t)atol(optarg);
+            break;
+        case 'M': break;
+        case 'g': device = atoi(optarg); break;
+        }
+    }
+    if (argc == optind) {
+        fprintf(stderr, "\nUsage:   fermi-amd unpack [-i index] [-g GPU] <seqs.fmd>\n\n");
+        fprintf(stderr, "Options: -i INT    index of the read to output, starting from 0 [null]\n\n");
+        return 1;
+    }
+    rc = fmdh_unpack(argv[optind], device, n, list, stdout);
+    free(list);
+    return rc;
+}
+
 static int main_remap(int argc, char *argv[]) /* cmd.c:218-251 */
 {
     int c, device = 0;
@@ -161,6 +206,8 @@ int main(int argc, char *argv[])
         fprintf(stderr, "         unitig     construct unitigs (fermi unitig)\n");
         fprintf(stderr, "         correct    error correction (fermi correct)\n");
         fprintf(stderr, "         exact      find super-maximal exact matches (fermi exact)\n");
+        fprintf(stderr, "         chkbwt     print / check the BWT held on the GPU (fermi chkbwt)\n");
+        fprintf(stderr, "         unpack     print the indexed sequences (fermi unpack)\n");
         fprintf(stderr, "         remap      coverage of contigs by the reads, paired-end breaks (fermi remap)\n\n");
         return 1;
     }
@@ -174,6 +221,8 @@ int main(int argc, char *argv[])
     if (strcmp(argv[1], "exact") == 0) return main_exact(argc - 1, argv + 1);
     if (strcmp(argv[1], "correct") == 0) return main_correct(argc - 1, argv + 1);
     if (strcmp(argv[1], "remap") == 0) return main_remap(argc - 1, argv + 1);
+    if (strcmp(argv[1], "chkbwt") == 0) return main_chkbwt(argc - 1, argv + 1);
+    if (strcmp(argv[1], "unpack") == 0) return main_unpack(argc - 1, argv + 1);
     fprintf(stderr, "[E::main] unrecognized command `%s'\n", argv[1]);
     return 1;
 }

@@ -99,6 +99,14 @@ int fmd_retrieve_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_x, 
 int fmd_retrieve_batch(fmd_dev_t *h, size_t n, const uint64_t *x, uint8_t *seqs, uint32_t stride,
                        uint32_t *len, uint64_t *rank);
 
+/* ---- inspection (`fermi chkbwt`, cmd.c:47-130) ------------------------------------------------
+ * export: BWT[first, first+n) as nt6 bytes, decoded from the device layout (chkbwt -p).
+ * check_rank: the device layout's rank of every position against the symbols themselves (chkbwt -r):
+ * n_bad = positions whose six counts are not those of the previous position plus the symbol there (or,
+ * at the last position, not the marginal counts); first_bad = the smallest of them. */
+int fmd_dev_export_bwt(fmd_dev_t *h, uint64_t first, uint64_t n, uint8_t *bwt);
+int fmd_dev_check_rank(fmd_dev_t *h, uint64_t *n_bad, uint64_t *first_bad);
+
 /* ---- forward reach ("matching statistics") --------------------------------------------------
  * seqs: n_bytes of nt6 sequences, each followed by at least one 0 byte (the _dev form: 4-byte
  * aligned, a 0 byte at or after seqs[n_bytes - 1], readable to the next multiple of 4).  len[p] = length of

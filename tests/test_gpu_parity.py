@@ -403,3 +403,25 @@ def test_remap_cli_equals_fermi_remap(gpu, gold, mode, args):
     p = subprocess.run([exe, "remap"] + args + [gold.path("pairs.fmd"), gold.path("pairs_contigs.fq.gz")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
     assert p.stdout == gold.text_gz("pairs.remap_%s.gz" % mode)
     assert [l for l in p.stderr.decode().split("\n") if "fm6_remap" in l] == json.load(open(gold.path("pairs.remap_stderr.json")))[mode]
+
+
+def test_unpack_cli_equals_fermi_unpack(gpu, gold):
+    """`fermi-amd unpack` == `fermi unpack` bytes (every sequence + its rank), and the -i selection."""
+    want = gold.text_gz("tiny.unpack.gz")
+    assert _cli("unpack", gold.path("tiny.fmd")) == want
+    lines = want.split(b"\n")
+    assert _cli("unpack", "-i", "5", "-i", "99999999", "-i", "0", "-i", "3999", gold.path("tiny.fmd")) == b"\n".join([lines[5], lines[0], lines[3999]]) + b"\n"
+
+
+@pytest.mark.parametrize("name", ["tiny", "special", "dup32", "pairs"])
+def test_chkbwt_cli(gpu, gold, oracle_lib, name):
+    """`fermi-amd chkbwt -p` prints the BWT `fermi chkbwt -p` prints (decoded back from the device
+    planes), and -r (rank self-check on the GPU) passes."""
+    import hashlib, json
+    e = orcbind.OrcIndex(gold.path(name + ".fmd"))
+    want = np.frombuffer(b"$ACGTN", dtype=np.uint8)[e.decode_all()].tobytes() + b"\n"
+    e.close()
+    got = _cli("chkbwt", "-r", "-p", gold.path(name + ".fmd"))
+    assert got == want
+    if name == "tiny":
+        assert hashlib.md5(got).hexdigest() == json.load(open(gold.path("MANIFEST.json")))["tiny_bwt_md5"]
