@@ -75,7 +75,10 @@ def main():
     err["p"] = run([FERMI, "remap", "-l", "20", "-D", "600", "-r", rank, fmd, cfq], os.path.join(TMP, "pairs.remap_p"))
     err["c"] = run([FERMI, "remap", "-l", "20", "-D", "600", "-c", "2", "-r", rank, fmd, cfq], os.path.join(TMP, "pairs.remap_c"))
     err["d"] = run([FERMI, "remap", "-D", "310", "-c", "1", "-r", rank, fmd, cfq], os.path.join(TMP, "pairs.remap_d"))   # default -l50, tight insert cap
-    for name in ("pairs.fq", "pairs_contigs.fq", "pairs.remap_u", "pairs.remap_p", "pairs.remap_c", "pairs.remap_d"):
+    # `fermi exact` with long queries (contigs against the read index), both self_match settings
+    run([FERMI, "exact", fmd, cfq], os.path.join(TMP, "pairs.exact_contigs"))
+    run([FERMI, "exact", "-s", fmd, cfq], os.path.join(TMP, "pairs.exact_s_contigs"))
+    for name in ("pairs.fq", "pairs_contigs.fq", "pairs.remap_u", "pairs.remap_p", "pairs.remap_c", "pairs.remap_d", "pairs.exact_contigs", "pairs.exact_s_contigs"):
         with gzip.open(os.path.join(HERE, name + ".gz"), "wb", 9) as f:
             f.write(open(os.path.join(TMP, name), "rb").read())
     json.dump({k: [l for l in v.split("\n") if "fm6_remap" in l] for k, v in err.items()}, open(os.path.join(HERE, "pairs.remap_stderr.json"), "w"), indent=1)

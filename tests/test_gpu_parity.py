@@ -425,3 +425,10 @@ def test_chkbwt_cli(gpu, gold, oracle_lib, name):
     assert got == want
     if name == "tiny":
         assert hashlib.md5(got).hexdigest() == json.load(open(gold.path("MANIFEST.json")))["tiny_bwt_md5"]
+
+
+@pytest.mark.parametrize("flag,name", [([], "pairs.exact_contigs.gz"), (["-s"], "pairs.exact_s_contigs.gz")])
+def test_exact_cli_long_queries(gpu, gold, flag, name):
+    """`fermi-amd exact [-s]` with queries longer than the per-read path handles (contigs against a read
+    index): reach + chain work items (or, with -s, one chain-walking item) == `fermi exact` bytes."""
+    assert _cli("exact", *flag, gold.path("pairs.fmd"), gold.path("pairs_contigs.fq.gz")) == gold.text_gz(name)
