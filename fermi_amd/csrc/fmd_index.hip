@@ -60,7 +60,7 @@ __global__ void k_bwt_to_planes(const uint8_t *__restrict__ bwt, uint64_t n, uin
             a |= (s & 1) << i; b |= ((s >> 1) & 1) << i; d |= ((s >> 2) & 1) << i;
         }
     }
-    uint4 *dst = blocks + c; // chunk c of the flat chunk array == blocks[c>>3] chunk c&7
+    uint4 *dst = blocks + fmd_word_u4(c); // 32-position word c -> its block and chunk
     dst->x = a; dst->y = b; dst->z = d;
 }
 
@@ -74,7 +74,7 @@ __device__ __forceinline__ void fmd_or_run(uint32_t *words, uint64_t pos, uint64
         const uint32_t bit = (uint32_t)p & 31;
         const uint64_t take = (end - p < 32 - bit) ? end - p : 32 - bit;
         const uint32_t m = (take == 32 ? 0xffffffffu : ((1u << take) - 1u)) << bit;
-        uint32_t *w = words + (p >> 5) * 4; // chunk = 4 words
+        uint32_t *w = words + fmd_word_u4(p >> 5) * 4; // chunk = 4 words
         if (take == 32) {                   // whole word is ours
             if (sym & 1) w[0] = m;
             if (sym & 2) w[1] = m;
@@ -158,8 +158,8 @@ __global__ void k_block_counts(const uint4 *__restrict__ blocks, uint64_t n_bloc
     if (b >= n_blocks) return;
     uint32_t n[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const uint4 v = blocks[b * 8 + c];
+    for (int c = 0; c < FMD_BLK_CHUNKS; ++c) {
+        const uint4 v = blocks[b * FMD_BLK_U4 + c];
         n[0] += __builtin_popcount(~v.z & ~v.y & ~v.x); n[1] += __builtin_popcount(~v.z & ~v.y & v.x);
         n[2] += __builtin_popcount(~v.z & v.y & ~v.x);  n[3] += __builtin_popcount(~v.z & v.y & v.x);
         n[4] += __builtin_popcount(v.z & ~v.y & ~v.x);  n[5] += __builtin_popcount(v.z & ~v.y & v.x);
@@ -174,11 +174,20 @@ __global__ void k_write_meta(uint4 *__restrict__ blocks, uint64_t n_blocks, cons
     uint64_t a[6];
 #pragma unroll
     for (int s = 0; s < 6; ++s) a[s] = acc[(uint64_t)s * n_blocks + b];
+#if FMD_BLK64
+    // meta_0..2 in the .w of the three plane chunks, meta_3..6 = the fourth uint4 (fmd_wave.h)
+    blocks[b * 4 + 0].w = (uint32_t)a[0]; blocks[b * 4 + 1].w = (uint32_t)a[1]; blocks[b * 4 + 2].w = (uint32_t)a[2];
+    blocks[b * 4 + 3] = make_uint4((uint32_t)a[3], (uint32_t)a[4],
+                                   (uint32_t)((a[0] >> 32) & 0xff) | (uint32_t)((a[1] >> 32) & 0xff) << 8 |
+                                   (uint32_t)((a[2] >> 32) & 0xff) << 16 | (uint32_t)((a[3] >> 32) & 0xff) << 24,
+                                   (uint32_t)((a[4] >> 32) & 0xff));
+#else
 #pragma unroll
     for (int s = 0; s < 6; ++s) blocks[b * 8 + s].w = (uint32_t)a[s];
     blocks[b * 8 + 6].w = (uint32_t)((a[0] >> 32) & 0xff) | (uint32_t)((a[1] >> 32) & 0xff) << 8 |
                           (uint32_t)((a[2] >> 32) & 0xff) << 16 | (uint32_t)((a[3] >> 32) & 0xff) << 24;
     blocks[b * 8 + 7].w = (uint32_t)((a[4] >> 32) & 0xff) | (uint32_t)((a[5] >> 32) & 0xff) << 8;
+#endif
 }
 
 // --------------------------------------------------------------------------------- host side
@@ -209,7 +218,7 @@ static int dev_alloc_index(int device, uint64_t n_sym, fmd_dev **out)
     h->device = device;
     h->n_cu = prop.multiProcessorCount;
     h->n_blocks = (n_sym + FMD_BLK_SYMS - 1) / FMD_BLK_SYMS + 1; // +1 pad block
-    h->bytes = h->n_blocks * 128;
+    h->bytes = h->n_blocks * FMD_BLK_BYTES;
     hipError_t e = hipMalloc((void **)&h->blocks, h->bytes);
     if (e != hipSuccess) { fmd_set_hip_error(e, "hipMalloc(index)"); free(h); return FMD_E_NOMEM; }
     e = hipMalloc((void **)&h->queues, FMD_N_QUEUES * sizeof(uint32_t));
@@ -399,7 +408,7 @@ __global__ void k_planes_to_bwt(const uint4 *__restrict__ blocks, uint64_t first
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // chunk relative to first/32
     const uint64_t p0 = (first & ~31ull) + c * 32;
     if (p0 >= first + n) return;
-    const uint4 v = blocks[p0 >> 5];
+    const uint4 v = blocks[fmd_word_u4(p0 >> 5)];
     for (int i = 0; i < 32; ++i) {
         const uint64_t p = p0 + i;
         if (p >= first && p < first + n) out[p - first] = (uint8_t)(((v.x >> i) & 1) | ((v.y >> i) & 1) << 1 | ((v.z >> i) & 1) << 2);
@@ -429,9 +438,10 @@ __global__ void k_check_rank(FmdIndexView ix, unsigned long long *__restrict__ b
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ix.n_sym) return;
     uint64_t a[6], b[6] = {0, 0, 0, 0, 0, 0};
-    const uint4 *blk = ix.blocks + (k >> FMD_BLK_SHIFT) * FMD_BLK_U4;
-    const int c = fmd_block_rank6<true>(blk, 0, ((uint32_t)k & (FMD_BLK_SYMS - 1)) + 1, a);
-    if (k) { const uint4 *pb = ix.blocks + ((k - 1) >> FMD_BLK_SHIFT) * FMD_BLK_U4; fmd_block_rank6<false>(pb, 0, ((uint32_t)(k - 1) & (FMD_BLK_SYMS - 1)) + 1, b); }
+    uint32_t bn, off;
+    fmd_split(k, bn, off);
+    const int c = fmd_block_rank6<true>(ix.blocks + (size_t)bn * FMD_BLK_U4, 0, off + 1, a, bn);
+    if (k) { fmd_split(k - 1, bn, off); fmd_block_rank6<false>(ix.blocks + (size_t)bn * FMD_BLK_U4, 0, off + 1, b, bn); }
     bool ok = c >= 0 && c < 6;
     for (int j = 0; j < 6; ++j) ok = ok && a[j] == b[j] + (j == c ? 1u : 0u);
     if (k == ix.n_sym - 1) for (int j = 0; j < 6; ++j) ok = ok && a[j] == ix.cnt[j + 1] - ix.cnt[j];
@@ -514,7 +524,9 @@ uint32_t *fmd_next_queue(fmd_dev *h, hipStream_t stream)
 int fmd_grid_for(const fmd_dev *h, size_t n_items)
 {
     const size_t waves_needed = (n_items + 63) / 64;
-    const size_t resident = (size_t)h->n_cu * 10; // 16 KiB LDS per wave -> 10 waves per CU
+    size_t per_cu = (160 * 1024) / (FMD_WAVE_LDS_U4 * 16);  // two dense slots per wave: 10 waves per CU with 128-byte blocks
+    if (per_cu > 16) per_cu = 16;
+    const size_t resident = (size_t)h->n_cu * per_cu;
     size_t g = waves_needed < resident ? waves_needed : resident;
     return (int)(g ? g : 1);
 }

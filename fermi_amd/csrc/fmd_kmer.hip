@@ -33,9 +33,9 @@ __device__ __forceinline__ void km_extend_back(const FmdIndexView &ix, uint4 *ld
     uint64_t tl[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int c = 0; c < 6; ++c) tk[c] = 0;
-    if (active && r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
+    if (active && r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk, r.blk_k);
     fmd_wave_l_ready(ix, lds, r);
-    if (active && r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
+    if (active && r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl, r.blk_l);
 #pragma unroll
     for (int c = 0; c < 6; ++c) s[c] = tl[c] - tk[c];
 }

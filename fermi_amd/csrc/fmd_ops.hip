@@ -23,7 +23,7 @@ __global__ __launch_bounds__(64) void k_rank1a(FmdIndexView ix, size_t n, const 
         if (i < n) {
             uint64_t ok[6] = {0, 0, 0, 0, 0, 0};
             int sym = -1;
-            if (r.hk) sym = fmd_block_rank6<true>(r.bk, r.t, r.nk, ok);
+            if (r.hk) sym = fmd_block_rank6<true>(r.bk, r.t, r.nk, ok, r.blk_k);
 #pragma unroll
             for (int c = 0; c < 6; ++c) d_ok[i * 6 + c] = ok[c];
             if (d_sym) d_sym[i] = (int8_t)sym;
@@ -45,8 +45,8 @@ __global__ __launch_bounds__(64) void k_rank2a(FmdIndexView ix, size_t n, const 
         const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, k, l);
         if (i < n) {
             uint64_t ok[6] = {0, 0, 0, 0, 0, 0}, ol[6] = {0, 0, 0, 0, 0, 0};
-            if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, ok);
-            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, ol);
+            if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, ok, r.blk_k);
+            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, ol, r.blk_l);
 #pragma unroll
             for (int c = 0; c < 6; ++c) { d_ok[i * 6 + c] = ok[c]; d_ol[i * 6 + c] = ol[c]; }
         }
@@ -97,8 +97,8 @@ __global__ __launch_bounds__(64) void k_extend(FmdIndexView ix, size_t n, const 
         const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, k, l);
         if (i < n) {
             uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tl[6] = {0, 0, 0, 0, 0, 0};
-            if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
-            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
+            if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk, r.blk_k);
+            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl, r.blk_l);
             fmd_intv_t ok[6];
             fmd_extend_finish(ix, x, is_back, tk, tl, ok);
             uint4 *dst = (uint4 *)(d_ok + i * 6);
@@ -165,10 +165,10 @@ __global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const
             qk = k - 1; ql = l;
         }
         FmdRank2c r = fmd_wave_rank2_fetch_compact(ix, fmd_lds, qk, ql);
-        const uint64_t ok = (live && r.hk) ? fmd_block_rank1(r.bk, r.t, r.nk, c) : 0;
+        const uint64_t ok = (live && r.hk) ? fmd_block_rank1(r.bk, r.t, r.nk, c, r.blk_k) : 0;
         fmd_wave_l_ready(ix, fmd_lds, r); // only while the intervals are wide (more than 32 lanes straddle)
         if (live) {
-            const uint64_t ol = fmd_block_rank1(r.bl, r.tl, r.nl, c);
+            const uint64_t ol = fmd_block_rank1(r.bl, r.tl, r.nl, c, r.blk_l);
             k = ix.cnt[c] + ok;
             l = ix.cnt[c] + ol - 1;
             --pos;
@@ -228,10 +228,10 @@ __global__ __launch_bounds__(64) void k_reach(FmdIndexView ix, size_t n, const u
             if (c == 0 || c > 5) { out_len[p] = (uint32_t)(i - p); live = false; } // terminator
         }
         FmdRank2c r = fmd_wave_rank2_fetch_compact(ix, fmd_lds, live ? k - 1 : NONE64, live ? l : NONE64);
-        const uint64_t ok = (live && r.hk) ? fmd_block_rank1(r.bk, r.t, r.nk, cc) : 0;
+        const uint64_t ok = (live && r.hk) ? fmd_block_rank1(r.bk, r.t, r.nk, cc, r.blk_k) : 0;
         fmd_wave_l_ready(ix, fmd_lds, r);
         if (live) {
-            const uint64_t ol = fmd_block_rank1(r.bl, r.tl, r.nl, cc);
+            const uint64_t ol = fmd_block_rank1(r.bl, r.tl, r.nl, cc, r.blk_l);
             k = ix.cnt[cc] + ok; l = ix.cnt[cc] + ol - 1;
             if (k > l) { out_len[p] = (uint32_t)(i - p); live = false; }
             else ++i;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64) void k_retrieve(FmdIndexView ix, size_t n, cons
         const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, live ? k : NONE64, NONE64);
         if (live) {
             uint64_t ok[6];
-            const int c = fmd_block_rank6<true>(r.bk, r.t, r.nk, ok);
+            const int c = fmd_block_rank6<true>(r.bk, r.t, r.nk, ok, r.blk_k);
             k = ix.cnt[c] + ok[c] - 1;
             if (c == 0) { d_len[rid] = len; d_rank[rid] = k; live = false; }
             else {

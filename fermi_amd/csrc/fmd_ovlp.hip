@@ -13,6 +13,7 @@ void fmd_launch_nei_grp(int G, int grid, hipStream_t st, const FmdIndexView &ix,
                         const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
                         uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n);
 void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, const fmd_intv_t *listA, uint32_t cap, FmdOvlClasses cl);
+int fmd_grp_waves_per_cu(void);
 
 // ---------------------------------------------------------------------------- phase 0: retrieve
 // fm_retrieve (exact.c:59-70); writes the sequence REVERSED into srev and rank/len into rec.
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(64) void k_ovl_retrieve(FmdIndexView ix, size_t n, 
         const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, live ? k : NONE64, NONE64);
         if (live) {
             uint64_t ok[6];
-            const int c = fmd_block_rank6<true>(r.bk, r.t, r.nk, ok);
+            const int c = fmd_block_rank6<true>(r.bk, r.t, r.nk, ok, r.blk_k);
             k = ix.cnt[c] + ok[c] - 1;
             if (c == 0) {
                 if ((len & 3) && len < stride_r) *(uint32_t *)(srev + sid * (size_t)stride_r + (len & ~3u)) = pack;
@@ -112,8 +113,8 @@ __global__ __launch_bounds__(64) void k_ovl_intv(FmdIndexView ix, size_t n, int 
         const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, qk, ql);
         if (live) {
             uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tl[6] = {0, 0, 0, 0, 0, 0};
-            if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
-            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
+            if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk, r.blk_k);
+            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl, r.blk_l);
             uint64_t s[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) s[c] = tl[c] - tk[c];
@@ -206,11 +207,13 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
         const bool wide_ext = st == WK_EXT || (st == WK_BOTH && sz > 63);
         bool skip = false;
         if (r.two_phase) {
-            if (wide_ext && r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk2);
-            if (st == WK_RIGHT && r.hk) tk2[0] = fmd_block_rank1(r.bk, r.t, r.nk, 0);
-            skip = st == WK_BOTH && (sz <= 63 || (uint32_t)(k >> FMD_BLK_SHIFT) != (uint32_t)((x0 - 1) >> FMD_BLK_SHIFT)) && r.l_sep;
+            if (wide_ext && r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk2, r.blk_k);
+            if (st == WK_RIGHT && r.hk) tk2[0] = fmd_block_rank1(r.bk, r.t, r.nk, 0, r.blk_k);
+            skip = st == WK_BOTH && (sz <= 63 || fmd_blk_of(k) != r.blk_k) && r.l_sep;
             if (st == WK_BOTH && sz > 63 && !skip) skip = true; // wide WK_BOTH never shares a gather in two-phase steps
-            if (skip && st == WK_BOTH && sz > 63) st = WK_LF;   // take the LF step on its own next time
+            if (skip && st == WK_BOTH) st = WK_LF;   // take the LF step on its own next time, then the extension through the
+                                                     // general path (a lane that merely waited could wait forever: the same
+                                                     // lanes straddle again next step)
         }
         const bool was_two_phase = r.two_phase;
         fmd_wave_l_ready(ix, fmd_lds, r);
@@ -224,11 +227,9 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
         const bool narrow = st == WK_BOTH && sz <= 63;
         uint64_t ws[6] = {0, 0, 0, 0, 0, 0}, wtk = 0;
         if (narrow) {
-            const uint32_t bk_ = (uint32_t)((x0 - 1) >> FMD_BLK_SHIFT), bl_ = (uint32_t)((x0 - 1 + sz) >> FMD_BLK_SHIFT);
-            const bool sep = bl_ != bk_;
-            const uint64_t gw = x0 >> 5; const uint32_t sh = (uint32_t)x0 & 31;
-            const uint4 a = grp_chunk(r.bk, r.t, r.bl, r.tl, bk_, bl_, sep, gw), b = grp_chunk(r.bk, r.t, r.bl, r.tl, bk_, bl_, sep, gw + 1),
-                        cc = grp_chunk(r.bk, r.t, r.bl, r.tl, bk_, bl_, sep, gw + 2);
+            const uint32_t sh = (uint32_t)x0 & 31;
+            uint4 a, b, cc;
+            grp_window(r.bk, r.t, r.bl, r.tl, r.blk_k, r.blk_l, r.hk, r.l_sep, x0, a, b, cc);
             const uint64_t m = bits_below((int)sz);
             const uint64_t X = win64(a.x, b.x, cc.x, sh), Y = win64(a.y, b.y, cc.y, sh), Z = win64(a.z, b.z, cc.z, sh);
             const uint64_t lo = ~Z & m, hi = Z & ~Y & m;
@@ -236,18 +237,19 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             ws[0] = __popcll(M0); ws[1] = __popcll(M1); ws[2] = __popcll(M2); ws[3] = __popcll(M3); ws[4] = __popcll(M4); ws[5] = __popcll(M5);
             const uint32_t o = (uint32_t)(k - x0);                       // row k inside the window
             c = (int)(((X >> o) & 1) | ((Y >> o) & 1) << 1 | ((Z >> o) & 1) << 2);
-            wtk = fmd_block_rank1(r.bk, r.t, r.nk, c);                    // rank_c(x0 - 1)
+            wtk = fmd_block_rank1(r.bk, r.t, r.nk, c, r.blk_k);                    // rank_c(x0 - 1)
             const uint64_t Mc = sel6(c, M0, M1, M2, M3, M4, M5);
             k = ix.cnt[c] + wtk + __popcll(Mc & bits_below((int)o + 1)) - 1;
         } else if (st == WK_LF || st == WK_BOTH) { // LF step at row k: base = BWT[k], k' = cnt[c] + rank_c(k) - 1
-            const bool in_k = st == WK_LF || (uint32_t)(k >> FMD_BLK_SHIFT) == (uint32_t)((x0 - 1) >> FMD_BLK_SHIFT);
+            uint32_t kb_, off;
+            fmd_split(k, kb_, off);
+            const bool in_k = st == WK_LF || kb_ == r.blk_k;
             const uint4 *img = in_k ? r.bk : r.bl;
-            const uint32_t off = (uint32_t)k & 255;
             const int tt = in_k ? r.t : r.tl;
             const uint4 v = img[(int)(off >> 5) ^ tt];
             const uint32_t bit = off & 31;
             c = (int)(((v.x >> bit) & 1) | ((v.y >> bit) & 1) << 1 | ((v.z >> bit) & 1) << 2);
-            k = ix.cnt[c] + fmd_block_rank1(img, tt, off + 1, c) - 1;
+            k = ix.cnt[c] + fmd_block_rank1(img, tt, off + 1, c, kb_) - 1;
             if (st == WK_LF && depth > 0) { c_pend = c; st = WK_EXT; continue; } // the extension needs its own gather
         }
         if (depth == 0) { // first LF step: the last base of the sequence, or an empty sequence
@@ -270,8 +272,8 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
                 if (was_two_phase) {
 #pragma unroll
                     for (int a = 0; a < 6; ++a) tk[a] = tk2[a];
-                } else if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
-                if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
+                } else if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk, r.blk_k);
+                if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl, r.blk_l);
 #pragma unroll
                 for (int a = 0; a < 6; ++a) s[a] = tl[a] - tk[a];
             }
@@ -321,8 +323,8 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
                 continue;
             }
         } else if (st == WK_RIGHT) { // extend by '$' on the right (unitig.c:86-89)
-            const uint64_t t0k = was_two_phase ? tk2[0] : (r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, 0) : 0);
-            const uint64_t t0l = r.hl ? fmd_block_rank1(r.bl, r.tl, r.nl, 0) : 0;
+            const uint64_t t0k = was_two_phase ? tk2[0] : (r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, 0, r.blk_k) : 0);
+            const uint64_t t0l = r.hl ? fmd_block_rank1(r.bl, r.tl, r.nl, 0, r.blk_l) : 0;
             if (sz != t0l - t0k) ret = -1;
             fmd_ovlp_rec_t *o = rec + sid;
             o->k[0] = x0; o->k[1] = t0k; o->k[2] = t0l - t0k;
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
         }
         // next base: can the LF step share the extension's gather?
         {
-            const uint32_t bk_ = (uint32_t)((x0 - 1) >> FMD_BLK_SHIFT), bl_ = (uint32_t)((x0 - 1 + sz) >> FMD_BLK_SHIFT), bq = (uint32_t)(k >> FMD_BLK_SHIFT);
+            const uint32_t bk_ = fmd_blk_of(x0 - 1), bl_ = fmd_blk_of(x0 - 1 + sz), bq = fmd_blk_of(k);
             st = (bq == bk_ || bq == bl_) ? WK_BOTH : WK_LF;
         }
     }
@@ -486,8 +488,8 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
         // ---- consume
         if (st == ST_EXT || st == ST_FIX1 || st == ST_FIX2) {
             uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tl[6] = {0, 0, 0, 0, 0, 0};
-            if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
-            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
+            if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk, r.blk_k);
+            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl, r.blk_l);
             uint64_t s[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) s[c] = tl[c] - tk[c];
@@ -529,8 +531,8 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
             }
         } else if (st == ST_E0 || st == ST_C) {
             // fm6_extend0 (exact.c:90-98), backward: only the '$' child matters
-            const uint64_t t0k = r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, 0) : 0;
-            const uint64_t t0l = r.hl ? fmd_block_rank1(r.bl, r.tl, r.nl, 0) : 0;
+            const uint64_t t0k = r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, 0, r.blk_k) : 0;
+            const uint64_t t0l = r.hl ? fmd_block_rank1(r.bl, r.tl, r.nl, 0, r.blk_l) : 0;
             const uint64_t e0sz = t0l - t0k;
             if (st == ST_E0) {
                 bool is_nei = false;
@@ -635,8 +637,8 @@ __global__ __launch_bounds__(64) void k_ovl_cls(FmdIndexView ix, size_t n, int m
         const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, qk, ql);
         if (st == CL_IDLE) continue;
         uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tl[6] = {0, 0, 0, 0, 0, 0};
-        if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
-        if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
+        if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk, r.blk_k);
+        if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl, r.blk_l);
         uint64_t sc[6];
 #pragma unroll
         for (int a = 0; a < 6; ++a) sc[a] = tl[a] - tk[a];
@@ -730,7 +732,7 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
         FMD_HIP_TRY(hipMemsetAsync(cls, 0, 64, st));
         fmd_launch_classify(st, n, d_rec, listA, cap, cl);
         // one lane per candidate interval: 4 strands (<= 16 candidates) or 2 strands (<= 32) per wave
-        const int ggrid = h->n_cu * 7; // 22.5 KiB LDS per wave
+        const int ggrid = h->n_cu * fmd_grp_waves_per_cu();
         fmd_launch_nei_grp(16, ggrid, st, ix, cl.l16, cl.n16, cap, listA, d_rec, d_nei, max_nei, d_seq, seq_stride, cl.lslow, cl.nslow);
         fmd_launch_nei_grp(32, ggrid, st, ix, cl.l32, cl.n32, cap, listA, d_rec, d_nei, max_nei, d_seq, seq_stride, cl.lslow, cl.nslow);
         // the rest (too many candidates, wide intervals, fake forks, neighbour overflow): lane per strand

@@ -32,17 +32,27 @@ __device__ __forceinline__ void store_entry(fmd_intv_t *e, uint64_t x0, uint64_t
 // ---- 64-position window over a lane's block images (used when an SA interval is narrower than 64)
 __device__ __forceinline__ uint64_t bits_below(int j) { return j >= 64 ? ~0ull : ((1ull << j) - 1); }
 
-// Chunk (three bit-plane words) holding global 32-position word `gw`, from the lane's block images:
-// slot SK holds block blk_k, slot SL holds blk_l when has_l.  Words of other blocks read as zero
-// (they are masked out by the callers' range masks).
-__device__ __forceinline__ uint4 grp_chunk(const uint4 *img_k, int t_k, const uint4 *img_l, int t_l, uint32_t blk_k, uint32_t blk_l,
-                                           bool has_l, uint64_t gw)
+// The three 32-position chunks (bit-plane words) that cover BWT[pos, pos + 64), from the lane's block
+// images: img_k holds block blk_k (when has_k), img_l holds blk_l (when has_l).  Words of other blocks
+// read as zero (they are masked out by the callers' range masks).
+__device__ __forceinline__ uint4 grp_pick(const uint4 *img_k, int t_k, const uint4 *img_l, int t_l, uint32_t blk_k, uint32_t blk_l,
+                                          bool has_k, bool has_l, uint32_t blk, uint32_t ch)
 {
-    const uint32_t blk = (uint32_t)(gw >> 3);
-    const bool in_k = blk == blk_k, in_l = has_l && blk == blk_l;
-    uint4 v = in_k ? img_k[((int)gw & 7) ^ t_k] : img_l[((int)gw & 7) ^ t_l];
+    const bool in_k = has_k && blk == blk_k, in_l = has_l && blk == blk_l;
+    uint4 v = in_k ? img_k[(int)ch ^ t_k] : img_l[(int)ch ^ t_l];
     if (!in_k && !in_l) v = make_uint4(0, 0, 0, 0);
     return v;
+}
+__device__ __forceinline__ void grp_window(const uint4 *img_k, int t_k, const uint4 *img_l, int t_l, uint32_t blk_k, uint32_t blk_l,
+                                           bool has_k, bool has_l, uint64_t pos, uint4 &a, uint4 &b, uint4 &c)
+{
+    uint32_t blk, ch;
+    fmd_word_split(pos >> 5, blk, ch);
+    a = grp_pick(img_k, t_k, img_l, t_l, blk_k, blk_l, has_k, has_l, blk, ch);
+    if (++ch == FMD_BLK_CHUNKS) { ch = 0; ++blk; }
+    b = grp_pick(img_k, t_k, img_l, t_l, blk_k, blk_l, has_k, has_l, blk, ch);
+    if (++ch == FMD_BLK_CHUNKS) { ch = 0; ++blk; }
+    c = grp_pick(img_k, t_k, img_l, t_l, blk_k, blk_l, has_k, has_l, blk, ch);
 }
 __device__ __forceinline__ uint64_t win64(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t sh)
 {

@@ -23,9 +23,9 @@
 // LDS per wave: one block slot per lane for the k side of the forward extension (slot 0) and of
 // the sentinel window (slot 1); the l sides, needed only when a range straddles a block boundary
 // (~11 % of the lanes each), share a small compacted pool; then the re-pack staging area.
-#define GRP_POOL 32                          // spill blocks per wave step
-#define GRP_SLOTS_U4 (2 * 512)
-#define GRP_POOL_U4 (GRP_POOL * 8)
+#define GRP_POOL (32 * 8 / FMD_BLK_U4)       // spill blocks per wave step (4 KiB)
+#define GRP_SLOTS_U4 (2 * FMD_SLOT_U4)
+#define GRP_POOL_U4 (GRP_POOL * FMD_BLK_U4)
 #define GRP_STAGE_U4 128
 #define GRP_LDS_U4 (GRP_SLOTS_U4 + GRP_POOL_U4 + GRP_STAGE_U4 + GRP_POOL / 4)
 
@@ -128,8 +128,8 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
         const bool live = active && alive;
         const uint64_t ke = live ? x1 - 1 : NONE64, le = live ? x1 - 1 + sz : NONE64;
         const uint64_t kb = live ? x0 - 1 : NONE64, lb = live ? x0 - 1 + sz : NONE64; // x0 >= mcnt[1] > 0 for base strings
-        const uint32_t bke = (uint32_t)(ke >> FMD_BLK_SHIFT), ble = (uint32_t)(le >> FMD_BLK_SHIFT);
-        const uint32_t bkb = (uint32_t)(kb >> FMD_BLK_SHIFT), blb = (uint32_t)(lb >> FMD_BLK_SHIFT);
+        uint32_t bke, ble, bkb, blb, oke, okb, o_;
+        fmd_split(ke, bke, oke); fmd_split(le, ble, o_); fmd_split(kb, bkb, okb); fmd_split(lb, blb, o_);
         const bool e_sep = live && ble != bke, b_sep = live && blb != bkb;
         fmd_fetch_slot<0>(ix, lds, bke, live);
         fmd_fetch_slot<1>(ix, lds, bkb, live);
@@ -143,14 +143,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
             if (b_sep && pb < GRP_POOL) pool_blk[pb] = blb;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int n_fetch = n_spill < GRP_POOL ? n_spill : GRP_POOL;
-            for (int r = 0; r * 8 < n_fetch; ++r) {
-                const int slot = r * 8 + (lane >> 3);
-                if (slot < n_fetch) {
-                    const uint32_t blk = pool_blk[slot];
-                    const uint4 *src = ix.blocks + (size_t)blk * FMD_BLK_U4 + ((lane & 7) ^ (slot & 7));
-                    __builtin_amdgcn_global_load_lds((fmd_glb_void *)src, (fmd_lds_void *)(pool + r * 64), 16, 0, FMD_GLDS_AUX);
-                }
-            }
+            fmd_fetch_pool(ix, pool, pool_blk, n_fetch);
         }
         // a lane whose spill block did not fit the pool cannot be computed this way: its strand goes
         // to the lane-per-strand kernel (practically never: the pool holds 32, the mean need is ~14)
@@ -159,8 +152,8 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
         fmd_fetch_wait();
         const int t = fmd_chunk_xor(lane);
         const uint4 *img_e = lds + fmd_lds_base(lane, 0), *img_b = lds + fmd_lds_base(lane, 1);
-        const uint4 *img_el = pool + (e_sep ? (pe & (GRP_POOL - 1)) : 0) * 8, *img_bl = pool + (b_sep ? (pb & (GRP_POOL - 1)) : 0) * 8;
-        const int t_el = pe & 7, t_bl = pb & 7;
+        const uint4 *img_el = pool + (e_sep ? (pe & (GRP_POOL - 1)) : 0) * FMD_BLK_U4, *img_bl = pool + (b_sep ? (pb & (GRP_POOL - 1)) : 0) * FMD_BLK_U4;
+        const int t_el = pe & FMD_GRP_MASK, t_bl = pb & FMD_GRP_MASK;
 
         // Every interval here has size <= 63 (k_ovl_classify), so "rank2a" is a count over a 64-position
         // window of the planes read straight from the lane's LDS block images:
@@ -173,9 +166,9 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
         uint32_t cm = 0;                    // children c = 1..4 that survive the sentinel test
         if (live) {
             {   // window of BWT[x1 ...]
-                const uint64_t gw = x1 >> 5; const uint32_t sh = (uint32_t)x1 & 31;
-                const uint4 a = grp_chunk(img_e, t, img_el, t_el, bke, ble, e_sep, gw), b = grp_chunk(img_e, t, img_el, t_el, bke, ble, e_sep, gw + 1),
-                            c = grp_chunk(img_e, t, img_el, t_el, bke, ble, e_sep, gw + 2);
+                const uint32_t sh = (uint32_t)x1 & 31;
+                uint4 a, b, c;
+                grp_window(img_e, t, img_el, t_el, bke, ble, true, e_sep, x1, a, b, c);
                 // x1 itself may sit in the block after ke's (ke = x1-1 is the last position of a block)
                 const uint64_t m = bits_below((int)sz);
                 const uint64_t X = win64(a.x, b.x, c.x, sh), Y = win64(a.y, b.y, c.y, sh), Z = win64(a.z, b.z, c.z, sh);
@@ -184,9 +177,9 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
                 s[4] = __popcll(hi & ~X); s[5] = sz - (s[0] + s[1] + s[2] + s[3] + s[4]);
             }
             {   // '$' of BWT[x0 ...], children laid out in the order $,T,G,C,A (exact.c:81-86)
-                const uint64_t gw = x0 >> 5; const uint32_t sh = (uint32_t)x0 & 31;
-                const uint4 a = grp_chunk(img_b, t, img_bl, t_bl, bkb, blb, b_sep, gw), b = grp_chunk(img_b, t, img_bl, t_bl, bkb, blb, b_sep, gw + 1),
-                            c = grp_chunk(img_b, t, img_bl, t_bl, bkb, blb, b_sep, gw + 2);
+                const uint32_t sh = (uint32_t)x0 & 31;
+                uint4 a, b, c;
+                grp_window(img_b, t, img_bl, t_bl, bkb, blb, true, b_sep, x0, a, b, c);
                 const uint64_t D = win64(~a.x & ~a.y & ~a.z, ~b.x & ~b.y & ~b.z, ~c.x & ~c.y & ~c.z, sh);
                 const uint32_t o1 = (uint32_t)s[0], o2 = o1 + (uint32_t)s[4], o3 = o2 + (uint32_t)s[3], o4 = o3 + (uint32_t)s[2], o5 = o4 + (uint32_t)s[1];
                 const uint64_t e0sz = __popcll(D & range64(0, o1));
@@ -212,8 +205,8 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
         // neighbours, in list order (unitig.c:119-121)
         if (new_nei) { // ok0 of unitig.c:112: x[0] = rank of '$' before x0, x[1] = cnt[0] + rank of '$' before x1
             const uint32_t k = n_nei + __popc(newnei_g & (uint32_t)bits_below(j));
-            const uint64_t r0 = fmd_block_rank1(img_b, t, ((uint32_t)kb & 255) + 1, 0);
-            const uint64_t r1 = fmd_block_rank1(img_e, t, ((uint32_t)ke & 255) + 1, 0);
+            const uint64_t r0 = fmd_block_rank1(img_b, t, okb + 1, 0, bkb);
+            const uint64_t r1 = fmd_block_rank1(img_e, t, oke + 1, 0, bke);
             if (k < max_nei) store_entry(nei_out + sid * (size_t)max_nei + k, r0, ix.cnt[0] + r1, sz, (uint64_t)ori_l - pos);
         }
         if (active && n_nei == 0 && newnei_g) { // info of nei[0] decides rbeg (unitig.c:157)
@@ -243,7 +236,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
             uint32_t todo = too_many ? 0u : cm;
             while (__ballot(todo != 0)) {
                 const int c = todo ? __ffs((int)todo) - 1 : 0;
-                const uint64_t r = fmd_block_rank1(img_e, t, ((uint32_t)ke & 255) + 1, c);
+                const uint64_t r = fmd_block_rank1(img_e, t, oke + 1, c, bke);
                 if (todo) { tk[1] = c == 1 ? r : tk[1]; tk[2] = c == 2 ? r : tk[2]; tk[3] = c == 3 ? r : tk[3]; tk[4] = c == 4 ? r : tk[4]; }
                 todo &= todo - 1;
             }
@@ -308,6 +301,11 @@ void fmd_launch_nei_grp(int G, int grid, hipStream_t st, const FmdIndexView &ix,
 {
     if (G == 16) k_ovl_nei_grp<16><<<grid, 64, 0, st>>>(ix, list, list_n, cap, listA, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n);
     else k_ovl_nei_grp<32><<<grid, 64, 0, st>>>(ix, list, list_n, cap, listA, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n);
+}
+int fmd_grp_waves_per_cu(void) // LDS-bound residency of k_ovl_nei_grp (22.5 KiB per wave with 128-byte blocks)
+{
+    int w = (160 * 1024) / (GRP_LDS_U4 * 16);
+    return w > 12 ? 12 : w;
 }
 void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, const fmd_intv_t *listA, uint32_t cap, FmdOvlClasses cl)
 {

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
         // two blocks in a two-phase step (the dense slot is reused for the l side) takes the general path
         const bool narrow = act && ksz <= 63 && !(r.two_phase && r.l_sep);
         uint64_t tk[6] = {0, 0, 0, 0, 0, 0};
-        if (r.two_phase && act && !narrow && r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
+        if (r.two_phase && act && !narrow && r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk, r.blk_k);
         const bool was_two_phase = r.two_phase;
         fmd_wave_l_ready(ix, fmd_lds, r);
         if (!act) continue;
@@ -173,22 +173,20 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
         uint64_t s[6], tkc, tk0;
         bool have_tk0 = false;
         if (narrow) { // all six child sizes from one 64-position window of BWT[a, a + size), one absolute rank
-            const uint32_t bk_ = (uint32_t)((a0 - 1) >> FMD_BLK_SHIFT), bl_ = (uint32_t)((a0 - 1 + ksz) >> FMD_BLK_SHIFT);
-            const bool sep = bl_ != bk_;
-            const uint64_t gw = a0 >> 5; const uint32_t sh = (uint32_t)a0 & 31;
-            const uint4 wa = grp_chunk(r.bk, r.t, r.bl, r.tl, bk_, bl_, sep, gw), wb = grp_chunk(r.bk, r.t, r.bl, r.tl, bk_, bl_, sep, gw + 1),
-                        wc = grp_chunk(r.bk, r.t, r.bl, r.tl, bk_, bl_, sep, gw + 2);
+            const uint32_t sh = (uint32_t)a0 & 31;
+            uint4 wa, wb, wc;
+            grp_window(r.bk, r.t, r.bl, r.tl, r.blk_k, r.blk_l, r.hk, r.l_sep, a0, wa, wb, wc);
             const uint64_t m = (1ull << (int)ksz) - 1;
             const uint64_t X = win64(wa.x, wb.x, wc.x, sh), Y = win64(wa.y, wb.y, wc.y, sh), Z = win64(wa.z, wb.z, wc.z, sh);
             const uint64_t lo = ~Z & m, hi = Z & ~Y & m;
             s[0] = __popcll(lo & ~Y & ~X); s[1] = __popcll(lo & ~Y & X); s[2] = __popcll(lo & Y & ~X); s[3] = __popcll(lo & Y & X);
             s[4] = __popcll(hi & ~X); s[5] = __popcll(hi & X);
-            tkc = r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, c) : 0;
+            tkc = r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, c, r.blk_k) : 0;
             tk0 = tkc; have_tk0 = c == 0;
         } else {
             uint64_t tl[6] = {0, 0, 0, 0, 0, 0};
-            if (!was_two_phase && r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk);
-            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl);
+            if (!was_two_phase && r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk, r.blk_k);
+            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl, r.blk_l);
 #pragma unroll
             for (int b = 0; b < 6; ++b) s[b] = tl[b] - tk[b];
             tkc = s_sel6(c, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
@@ -206,7 +204,7 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
         const uint64_t rc = base + before;                 // child c
         const uint64_t nxc = ix.cnt[c] + tkc;              // its coordinate on the extended strand
         // the '$' child of a forward extension (pushed by the forward sweep when !self_match)
-        if ((st == SM_FWD || st == SM_FWD_END) && !self_match && s[0] && !have_tk0) tk0 = r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, 0) : 0;
+        if ((st == SM_FWD || st == SM_FWD_END) && !self_match && s[0] && !have_tk0) tk0 = r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, 0, r.blk_k) : 0;
 
         if (st == SM_FWD) {
             if (sc != ksz) { // change of the interval size (smem.c:25-31)

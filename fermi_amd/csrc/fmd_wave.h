@@ -23,10 +23,37 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define FMD_BLK_SHIFT 8
+// Second geometry (-DFMD_BLK64=1): 64-byte rank blocks of 96 positions.  Random 64-byte gathers run
+// 30-36 % more lines per second than 128-byte ones on MI355X (profiles/r1_bsearch/gather_probe.txt)
+// and a line costs half the LDS landing space.  Block b = 4 x uint4 = BWT[96b, 96b+96):
+//     u4[j], j = 0..2 = { p0, p1, p2, meta_j } for positions [32j, 32j+32)
+//     u4[3]           = { meta_3, meta_4, meta_5, meta_6 }
+//     meta_0..4 = low 32 bits of the absolute count of $,A,C,G,T before the block,
+//     meta_5 = bits 32..39 of the counts of $,A,C,G, meta_6 & 0xff = those of T;
+//     the count of N is 96b minus the other five.
+// Still one aligned fetch per rank, self-contained (no superblock table); 5.33 bits/symbol.
+#ifndef FMD_BLK64
+#define FMD_BLK64 0
+#endif
+#if FMD_BLK64
+#define FMD_BLK_SYMS 96u
+#define FMD_BLK_U4 4            // uint4 per block
+#define FMD_BLK_CHUNKS 3        // 32-position plane chunks per block
+#define FMD_GRP_SHIFT 2         // 4 lanes x 16 B fetch one block
+#else
 #define FMD_BLK_SYMS 256u
 #define FMD_BLK_U4 8            // uint4 per block
-#define FMD_WAVE_LDS_U4 1024    // 2 slots x 64 lanes x 8 uint4 = 16 KiB per wave
+#define FMD_BLK_CHUNKS 8
+#define FMD_GRP_SHIFT 3         // 8 lanes x 16 B fetch one block
+#endif
+#define FMD_BLK_BYTES (FMD_BLK_U4 * 16)
+#define FMD_GRP_MASK ((1 << FMD_GRP_SHIFT) - 1)
+#define FMD_BLK_PER_INST (64 >> FMD_GRP_SHIFT)   // blocks moved by one 64-lane global_load_lds
+#define FMD_SLOT_U4 (64 * FMD_BLK_U4)            // dense slot: one block per lane
+// blocks of the compacted l-side pool: as many bytes either way; with 64-byte blocks it holds one
+// block per lane, so the dense fallback / two-phase step is never needed there
+#define FMD_POOL_BLOCKS (32 * 8 / FMD_BLK_U4)
+#define FMD_WAVE_LDS_U4 (2 * FMD_SLOT_U4 + FMD_POOL_BLOCKS / 4)   // 2 slots (+ ids): 16 KiB (8 KiB) per wave
 
 // cache policy of the rank-block gather (global_load_lds aux bits: 0 = default, 2 = nt "stream")
 #ifndef FMD_GLDS_AUX
@@ -45,16 +72,63 @@ struct FmdIndexView {            // passed by value as a kernel argument (lives 
 
 __device__ __forceinline__ int fmd_lane() { return (int)(threadIdx.x & 63); }
 
+// position -> (block, offset inside the block)
+#if FMD_BLK64
+__device__ __forceinline__ uint64_t fmd_div3(uint64_t w) // w < 2^43 (32-position word index)
+{
+    // 2^32 = 3K + 1 with K = 0x55555555:  w = hi*2^32 + lo = 3*hi*K + (hi + lo);  hi + lo = c*2^32 + sl likewise
+    const uint32_t hi = (uint32_t)(w >> 32), lo = (uint32_t)w;
+    const uint64_t s = (uint64_t)hi + lo;
+    const uint32_t c = (uint32_t)(s >> 32), sl = (uint32_t)s;
+    return (uint64_t)(hi + c) * 0x55555555ull + (__umulhi(sl + c, 0xAAAAAAABu) >> 1);
+}
+__device__ __forceinline__ void fmd_word_split(uint64_t w, uint32_t &blk, uint32_t &ch) // 32-position word -> block, chunk
+{
+    const uint64_t q = fmd_div3(w);
+    blk = (uint32_t)q; ch = (uint32_t)(w - 3 * q);
+}
+__device__ __forceinline__ void fmd_split(uint64_t k, uint32_t &blk, uint32_t &off)
+{
+    uint32_t ch;
+    fmd_word_split(k >> 5, blk, ch);
+    off = ch * 32 + ((uint32_t)k & 31);
+}
+#else
+__device__ __forceinline__ void fmd_word_split(uint64_t w, uint32_t &blk, uint32_t &ch) { blk = (uint32_t)(w >> 3); ch = (uint32_t)w & 7; }
+__device__ __forceinline__ void fmd_split(uint64_t k, uint32_t &blk, uint32_t &off) { blk = (uint32_t)(k >> 8); off = (uint32_t)k & 255; }
+#endif
+__device__ __forceinline__ uint32_t fmd_blk_of(uint64_t k) { uint32_t b, o; fmd_split(k, b, o); return b; }
+// uint4 index of 32-position word w in the block array (transcode kernels)
+__device__ __forceinline__ uint64_t fmd_word_u4(uint64_t w) { uint32_t b, c; fmd_word_split(w, b, c); return (uint64_t)b * FMD_BLK_U4 + c; }
+
 // XOR applied to the chunk index inside a block's LDS image so that the eight ds_read_b128 of a
 // lane-owned block are bank-conflict free (the b128 lane groups are {0-3,12-15,20-27}, ... --
 // MI355X_MICROARCH.md LDS table; lanes of one group whose blocks start on the same 128-B
 // half-row get distinct 16-byte slots).
+#if FMD_BLK64
+// 64-byte images: slot of chunk j of lane q = 4*((q>>2)&3) + (j ^ t) mod 16; the four quads of a b128
+// lane group have distinct (q>>2)&3, so t = q & 3 separates the lanes of a quad.
+__device__ __forceinline__ int fmd_chunk_xor(int q) { return q & 3; }
+#else
 __device__ __forceinline__ int fmd_chunk_xor(int q) { return (q & 3) | (((q >> 4) & 1) << 2); }
+#endif
 
-// One cooperative round: group g fetches the block of lane 8g+R for slot SLOT.
+// One cooperative round: lane group g fetches the block of lane (g << FMD_GRP_SHIFT) + R for slot SLOT
+// (8 lanes x 16 B for a 128-byte block, 4 lanes for a 64-byte one).
 template <int SLOT, int R>
 __device__ __forceinline__ void fmd_fetch_round(const FmdIndexView &ix, uint4 *lds, uint32_t blk, uint64_t need_mask)
 {
+#if FMD_BLK64
+    if ((need_mask >> R) & 0x1111111111111111ull) {          // wave-uniform: anybody in this round?
+        const int lane = fmd_lane();
+        const int j = lane & 3;
+        const uint32_t sb = (uint32_t)__builtin_amdgcn_ds_swizzle((int)blk, (R << 5) | 0x1C); // blk of lane 4g+R
+        if ((need_mask >> ((lane & ~3) | R)) & 1) {
+            const uint4 *src = ix.blocks + (size_t)sb * FMD_BLK_U4 + (j ^ R);  // R = fmd_chunk_xor(4g+R)
+            __builtin_amdgcn_global_load_lds((fmd_glb_void *)src, (fmd_lds_void *)(lds + SLOT * FMD_SLOT_U4 + R * 64), 16, 0, FMD_GLDS_AUX);
+        }
+    }
+#else
     if ((need_mask >> R) & 0x0101010101010101ull) {          // wave-uniform: anybody in this round?
         const int lane = fmd_lane();
         const int g = lane >> 3, j = lane & 7;
@@ -62,9 +136,10 @@ __device__ __forceinline__ void fmd_fetch_round(const FmdIndexView &ix, uint4 *l
         if ((need_mask >> ((lane & ~7) | R)) & 1) {
             const int t = (R & 3) | (((g >> 1) & 1) << 2);  // = fmd_chunk_xor(8g+R)
             const uint4 *src = ix.blocks + (size_t)sb * FMD_BLK_U4 + (j ^ t);
-            __builtin_amdgcn_global_load_lds((fmd_glb_void *)src, (fmd_lds_void *)(lds + SLOT * 512 + R * 64), 16, 0, FMD_GLDS_AUX);
+            __builtin_amdgcn_global_load_lds((fmd_glb_void *)src, (fmd_lds_void *)(lds + SLOT * FMD_SLOT_U4 + R * 64), 16, 0, FMD_GLDS_AUX);
         }
     }
+#endif
 }
 
 template <int SLOT>
@@ -74,14 +149,33 @@ __device__ __forceinline__ void fmd_fetch_slot(const FmdIndexView &ix, uint4 *ld
     if (m == 0) return;
     fmd_fetch_round<SLOT, 0>(ix, lds, blk, m); fmd_fetch_round<SLOT, 1>(ix, lds, blk, m);
     fmd_fetch_round<SLOT, 2>(ix, lds, blk, m); fmd_fetch_round<SLOT, 3>(ix, lds, blk, m);
+#if !FMD_BLK64
     fmd_fetch_round<SLOT, 4>(ix, lds, blk, m); fmd_fetch_round<SLOT, 5>(ix, lds, blk, m);
     fmd_fetch_round<SLOT, 6>(ix, lds, blk, m); fmd_fetch_round<SLOT, 7>(ix, lds, blk, m);
+#endif
 }
 
 __device__ __forceinline__ void fmd_fetch_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // uint4 index (inside the wave's LDS area) of chunk 0^t of the block fetched for lane q, slot s
-__device__ __forceinline__ int fmd_lds_base(int q, int slot) { return slot * 512 + (q & 7) * 64 + (q >> 3) * 8; }
+__device__ __forceinline__ int fmd_lds_base(int q, int slot)
+{
+    return slot * FMD_SLOT_U4 + (q & FMD_GRP_MASK) * 64 + (q >> FMD_GRP_SHIFT) * FMD_BLK_U4;
+}
+
+// Pool of compacted blocks (ballot-prefix slots): `n` block ids in ids[], FMD_BLK_PER_INST per wave
+// instruction, written to pool; the lane that owns pool slot p reads pool + p * FMD_BLK_U4 with XOR p.
+__device__ __forceinline__ void fmd_fetch_pool(const FmdIndexView &ix, uint4 *pool, const uint32_t *ids, int n)
+{
+    const int q = fmd_lane();
+    for (int rr = 0; rr * FMD_BLK_PER_INST < n; ++rr) {
+        const int slot = rr * FMD_BLK_PER_INST + (q >> FMD_GRP_SHIFT);
+        if (slot < n) {
+            const uint4 *src = ix.blocks + (size_t)ids[slot] * FMD_BLK_U4 + ((q & FMD_GRP_MASK) ^ (slot & FMD_GRP_MASK));
+            __builtin_amdgcn_global_load_lds((fmd_glb_void *)src, (fmd_lds_void *)(pool + rr * 64), 16, 0, FMD_GLDS_AUX);
+        }
+    }
+}
 
 __device__ __forceinline__ uint32_t fmd_mask32(int rem) // low `rem` bits set, rem clamped to [0,32]
 {
@@ -89,10 +183,11 @@ __device__ __forceinline__ uint32_t fmd_mask32(int rem) // low `rem` bits set, r
     return (uint32_t)(1ull << r) - 1u;                      // r = 32: low word of 2^32 is 0 -> all ones
 }
 
-// Counts of all six symbols in BWT[0..k] from the lane's block image; npos = (k & 255) + 1.
-// WANT_SYM also returns BWT[k].
+// Counts of all six symbols in BWT[0..k] from the lane's block image; npos = offset of k in its block + 1,
+// blk = the block's number (the 64-byte layout derives the count of N from it).  WANT_SYM also
+// returns BWT[k].
 template <bool WANT_SYM>
-__device__ __forceinline__ int fmd_block_rank6(const uint4 *blk, int t, uint32_t npos, uint64_t out[6])
+__device__ __forceinline__ int fmd_block_rank6(const uint4 *blk, int t, uint32_t npos, uint64_t out[6], uint32_t blk_no)
 {
     // five popcounts per chunk instead of six symbol masks: with x = |X|, y = |Y|, z = |Z|, xy = |X&Y|,
     // xz = |X&Z| over the counted positions (Y and Z are never set together: codes 6, 7 do not occur)
@@ -101,7 +196,7 @@ __device__ __forceinline__ int fmd_block_rank6(const uint4 *blk, int t, uint32_t
     uint32_t s0 = 0, s1 = 0, s2 = 0;
     const uint32_t off = npos - 1;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < FMD_BLK_CHUNKS; ++c) {
         const uint4 v = blk[c ^ t];
         const uint32_t m = fmd_mask32((int)npos - 32 * c);
         const uint32_t xm = v.x & m;
@@ -118,12 +213,25 @@ __device__ __forceinline__ int fmd_block_rank6(const uint4 *blk, int t, uint32_t
     }
     const uint32_t n5 = cxz, n4 = cz - cxz, n3 = cxy, n2 = cy - cxy, n1 = cx - cxy - cxz;
     const uint32_t n0 = npos - (n1 + n2 + n3 + n4 + n5); // positions past the BWT end are never counted
+#if FMD_BLK64
+    {
+        const uint4 mv = blk[3 ^ t];
+        meta[3] = mv.x; meta[4] = mv.y; meta[5] = mv.z; meta[6] = mv.w;
+    }
+    const uint64_t b0 = ((uint64_t)(meta[5] & 0xff) << 32 | meta[0]), b1 = ((uint64_t)((meta[5] >> 8) & 0xff) << 32 | meta[1]);
+    const uint64_t b2 = ((uint64_t)((meta[5] >> 16) & 0xff) << 32 | meta[2]), b3 = ((uint64_t)(meta[5] >> 24) << 32 | meta[3]);
+    const uint64_t b4 = ((uint64_t)(meta[6] & 0xff) << 32 | meta[4]);
+    out[0] = b0 + n0; out[1] = b1 + n1; out[2] = b2 + n2; out[3] = b3 + n3; out[4] = b4 + n4;
+    out[5] = (uint64_t)blk_no * FMD_BLK_SYMS - (b0 + b1 + b2 + b3 + b4) + n5;
+#else
+    (void)blk_no;
     out[0] = ((uint64_t)(meta[6] & 0xff) << 32 | meta[0]) + n0;
     out[1] = ((uint64_t)((meta[6] >> 8) & 0xff) << 32 | meta[1]) + n1;
     out[2] = ((uint64_t)((meta[6] >> 16) & 0xff) << 32 | meta[2]) + n2;
     out[3] = ((uint64_t)(meta[6] >> 24) << 32 | meta[3]) + n3;
     out[4] = ((uint64_t)(meta[7] & 0xff) << 32 | meta[4]) + n4;
     out[5] = ((uint64_t)((meta[7] >> 8) & 0xff) << 32 | meta[5]) + n5;
+#endif
     if (WANT_SYM) {
         const uint32_t bit = off & 31;
         return (int)(((s0 >> bit) & 1) | ((s1 >> bit) & 1) << 1 | ((s2 >> bit) & 1) << 2);
@@ -133,10 +241,31 @@ __device__ __forceinline__ int fmd_block_rank6(const uint4 *blk, int t, uint32_t
 
 // Count of ONE symbol c (per-lane value 0..5) in BWT[0..k]: what fm_backward_search needs
 // (rld_rank11, rld.c:448).
-__device__ __forceinline__ uint64_t fmd_block_rank1(const uint4 *blk, int t, uint32_t npos, int c)
+__device__ __forceinline__ uint64_t fmd_block_rank1(const uint4 *blk, int t, uint32_t npos, int c, uint32_t blk_no)
 {
     const uint32_t x0 = (c & 1) ? 0u : ~0u, x1 = (c & 2) ? 0u : ~0u, x2 = (c & 4) ? 0u : ~0u;
     uint32_t n = 0, lo = 0, hi = 0;
+#if FMD_BLK64
+    uint32_t m0 = 0, m1 = 0, m2 = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const uint4 v = blk[j ^ t];
+        const uint32_t m = fmd_mask32((int)npos - 32 * j);
+        n += __builtin_popcount((v.x ^ x0) & (v.y ^ x1) & (v.z ^ x2) & m);
+        if (j == 0) m0 = v.w; else if (j == 1) m1 = v.w; else m2 = v.w;
+    }
+    const uint4 mv = blk[3 ^ t];
+    if (c < 5) {
+        lo = c == 0 ? m0 : c == 1 ? m1 : c == 2 ? m2 : c == 3 ? mv.x : mv.y;
+        hi = c < 4 ? (mv.z >> (8 * c)) & 0xff : mv.w & 0xff;
+        return ((uint64_t)hi << 32 | lo) + n;
+    }
+    // N: everything before the block that is none of the other five
+    const uint64_t five = ((uint64_t)(mv.z & 0xff) << 32 | m0) + ((uint64_t)((mv.z >> 8) & 0xff) << 32 | m1) +
+                          ((uint64_t)((mv.z >> 16) & 0xff) << 32 | m2) + ((uint64_t)(mv.z >> 24) << 32 | mv.x) + ((uint64_t)(mv.w & 0xff) << 32 | mv.y);
+    return (uint64_t)blk_no * FMD_BLK_SYMS - five + n;
+#else
+    (void)blk_no;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const uint4 v = blk[j ^ t];
@@ -147,6 +276,7 @@ __device__ __forceinline__ uint64_t fmd_block_rank1(const uint4 *blk, int t, uin
         if (j == 7) hi = (c >= 4) ? (v.w >> (8 * (c - 4))) & 0xff : hi;
     }
     return ((uint64_t)hi << 32 | lo) + n;
+#endif
 }
 
 // ---- work queue of the persistent kernels --------------------------------------------------------
@@ -207,64 +337,58 @@ struct FmdRank2 {
     const uint4 *bk, *bl;  // lane-owned block images in LDS
     int t, tl;             // chunk XOR of each image
     uint32_t nk, nl;       // positions to count in each
+    uint32_t blk_k, blk_l; // block numbers
     bool hk, hl;           // side present
 };
-
-#define FMD_POOL_BLOCKS 32
 
 __device__ __forceinline__ FmdRank2 fmd_wave_rank2_fetch(const FmdIndexView &ix, uint4 *lds, uint64_t k, uint64_t l)
 {
     const int q = fmd_lane();
     FmdRank2 r;
     r.hk = k != ~0ull; r.hl = l != ~0ull;
-    const uint32_t blk_k = (uint32_t)(k >> FMD_BLK_SHIFT), blk_l = (uint32_t)(l >> FMD_BLK_SHIFT);
-    const bool l_sep = r.hl && !(r.hk && blk_k == blk_l);
-    fmd_fetch_slot<0>(ix, lds, blk_k, r.hk);
+    uint32_t ok_, ol_;
+    fmd_split(k, r.blk_k, ok_); fmd_split(l, r.blk_l, ol_);
+    const bool l_sep = r.hl && !(r.hk && r.blk_k == r.blk_l);
+    fmd_fetch_slot<0>(ix, lds, r.blk_k, r.hk);
     r.t = fmd_chunk_xor(q);
     r.bk = lds + fmd_lds_base(q, 0);
     r.bl = r.bk; r.tl = r.t;
     const uint64_t m = __ballot(l_sep);
     if (m) {
         const int n_sep = __popcll(m);
-        if (n_sep <= FMD_POOL_BLOCKS) { // compact pool in the first half of slot 1; block ids after it
-            uint4 *pool = lds + 512;
-            uint32_t *ids = (uint32_t *)(pool + FMD_POOL_BLOCKS * 8);
+        if (n_sep <= FMD_POOL_BLOCKS) { // compact pool in slot 1; block ids after the two slots
+            uint4 *pool = lds + FMD_SLOT_U4;
+            uint32_t *ids = (uint32_t *)(lds + 2 * FMD_SLOT_U4);
             const int p = __popcll(m & ((1ull << q) - 1));
-            if (l_sep) ids[p] = blk_l;
+            if (l_sep) ids[p] = r.blk_l;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            for (int rr = 0; rr * 8 < n_sep; ++rr) {
-                const int slot = rr * 8 + (q >> 3);
-                if (slot < n_sep) {
-                    const uint4 *src = ix.blocks + (size_t)ids[slot] * FMD_BLK_U4 + ((q & 7) ^ (slot & 7));
-                    __builtin_amdgcn_global_load_lds((fmd_glb_void *)src, (fmd_lds_void *)(pool + rr * 64), 16, 0, FMD_GLDS_AUX);
-                }
-            }
-            if (l_sep) { r.bl = pool + p * 8; r.tl = p & 7; }
+            fmd_fetch_pool(ix, pool, ids, n_sep);
+            if (l_sep) { r.bl = pool + p * FMD_BLK_U4; r.tl = p & FMD_GRP_MASK; }
         } else {
-            fmd_fetch_slot<1>(ix, lds, blk_l, l_sep);
+            fmd_fetch_slot<1>(ix, lds, r.blk_l, l_sep);
             if (l_sep) r.bl = lds + fmd_lds_base(q, 1);
         }
     }
-    r.nk = ((uint32_t)k & (FMD_BLK_SYMS - 1)) + 1;
-    r.nl = ((uint32_t)l & (FMD_BLK_SYMS - 1)) + 1;
+    r.nk = ok_ + 1; r.nl = ol_ + 1;
     fmd_fetch_wait();
     return r;
 }
 
 
-// ---- compact engine: 12.4 KiB of LDS per wave (13 waves per CU instead of 10) -----------------
+// ---- compact engine: dense slot + pool (12.4 KiB of LDS per wave with 128-byte blocks: 13 waves per
+// CU instead of 10; 6.3 KiB with 64-byte blocks) ----------------------------------------------------
 // More waves = more lines in flight, which is what these latency-bound searches need (DESIGN.md
 // section 4).  Dense slot for the k side + the 32-block pool for the l side.  When more than 32
 // lanes straddle (only while the SA intervals are still wide: the first ~log4(n) bases, whose
 // blocks sit in L2) the step becomes two-phase: the caller consumes the k side, calls
 // fmd_wave_l_ready(), which re-uses the dense slot for the l blocks, then consumes the l side.
-#define FMD_COMPACT_LDS_U4 (512 + FMD_POOL_BLOCKS * 8 + FMD_POOL_BLOCKS / 4)
+#define FMD_COMPACT_LDS_U4 (FMD_SLOT_U4 + FMD_POOL_BLOCKS * FMD_BLK_U4 + FMD_POOL_BLOCKS / 4)
 #define FMD_DECLARE_COMPACT_LDS() __shared__ uint4 fmd_lds[FMD_COMPACT_LDS_U4]
 
 struct FmdRank2c {
     const uint4 *bk, *bl;
     int t, tl;
-    uint32_t nk, nl, blk_l;
+    uint32_t nk, nl, blk_k, blk_l;
     bool hk, hl, l_sep;
     bool two_phase;        // wave-uniform: bl is not valid until fmd_wave_l_ready()
 };
@@ -274,10 +398,10 @@ __device__ __forceinline__ FmdRank2c fmd_wave_rank2_fetch_compact(const FmdIndex
     const int q = fmd_lane();
     FmdRank2c r;
     r.hk = k != ~0ull; r.hl = l != ~0ull;
-    const uint32_t blk_k = (uint32_t)(k >> FMD_BLK_SHIFT);
-    r.blk_l = (uint32_t)(l >> FMD_BLK_SHIFT);
-    r.l_sep = r.hl && !(r.hk && blk_k == r.blk_l);
-    fmd_fetch_slot<0>(ix, lds, blk_k, r.hk);
+    uint32_t ok_, ol_;
+    fmd_split(k, r.blk_k, ok_); fmd_split(l, r.blk_l, ol_);
+    r.l_sep = r.hl && !(r.hk && r.blk_k == r.blk_l);
+    fmd_fetch_slot<0>(ix, lds, r.blk_k, r.hk);
     r.t = fmd_chunk_xor(q);
     r.bk = lds + fmd_lds_base(q, 0);
     r.bl = r.bk; r.tl = r.t;
@@ -286,23 +410,16 @@ __device__ __forceinline__ FmdRank2c fmd_wave_rank2_fetch_compact(const FmdIndex
     if (m) {
         const int n_sep = __popcll(m);
         if (n_sep <= FMD_POOL_BLOCKS) {
-            uint4 *pool = lds + 512;
-            uint32_t *ids = (uint32_t *)(pool + FMD_POOL_BLOCKS * 8);
+            uint4 *pool = lds + FMD_SLOT_U4;
+            uint32_t *ids = (uint32_t *)(pool + FMD_POOL_BLOCKS * FMD_BLK_U4);
             const int p = __popcll(m & ((1ull << q) - 1));
             if (r.l_sep) ids[p] = r.blk_l;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            for (int rr = 0; rr * 8 < n_sep; ++rr) {
-                const int slot = rr * 8 + (q >> 3);
-                if (slot < n_sep) {
-                    const uint4 *src = ix.blocks + (size_t)ids[slot] * FMD_BLK_U4 + ((q & 7) ^ (slot & 7));
-                    __builtin_amdgcn_global_load_lds((fmd_glb_void *)src, (fmd_lds_void *)(pool + rr * 64), 16, 0, FMD_GLDS_AUX);
-                }
-            }
-            if (r.l_sep) { r.bl = pool + p * 8; r.tl = p & 7; }
+            fmd_fetch_pool(ix, pool, ids, n_sep);
+            if (r.l_sep) { r.bl = pool + p * FMD_BLK_U4; r.tl = p & FMD_GRP_MASK; }
         } else r.two_phase = true;
     }
-    r.nk = ((uint32_t)k & (FMD_BLK_SYMS - 1)) + 1;
-    r.nl = ((uint32_t)l & (FMD_BLK_SYMS - 1)) + 1;
+    r.nk = ok_ + 1; r.nl = ol_ + 1;
     fmd_fetch_wait();
     return r;
 }
