@@ -30,6 +30,17 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
 BYTES_PER_RANK_QUERY = 128     # one rank block + its counts
 
 
+def pmc_traffic(key):
+    """HBM bytes per launch/step measured by the separate rocprofv3 --pmc passes (profiles/pmc_traffic.json)."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key)
+        if pmc:
+            return (pmc["fetch_kb"] * pmc["fetch_calibration"] + pmc["write_kb"]) * 1024.0, pmc["source"]
+    except Exception:
+        pass
+    return None, None
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -422,7 +433,8 @@ def bench_kmer(torch, api, index, n_sym, fmd_path, dev, n_reads, steps, warmup, 
         spill = cn["rank2a_spill"] / max(cn["rank2a"], 1)
         alg = nodes * (1.0 + spill) * BYTES_PER_RANK_QUERY
         ach = alg / (kern_ms * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+        tr, src = pmc_traffic("kmer@%d" % n_reads)
+        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src,
                            "kernel": "k_kmer_level x %d + k_kmer_emit" % (w - 1), "kernel_ms": kern_ms,
                            "rank_queries": nodes * (1.0 + spill), "rank2a_spill_rate_on_oracle_sample": spill,
                            "oracle_counters_on_sample": cn}
@@ -491,7 +503,8 @@ def bench_smem(torch, api, index, rd, reads, err, n_sym, fmd_path, dev, n_reads,
             o.close()
             qpr = (cn["rank1a"] + cn["rank2a"] + cn["rank2a_spill"]) / ns
             ach = qpr * BYTES_PER_RANK_QUERY * n_reads / (kern_ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            tr, src = pmc_traffic("smem@%d" % n_reads) if err == 0.01 else (None, None)
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src,
                                "kernel": "k_smem", "kernel_ms": kern_ms, "rank_queries_per_read": qpr,
                                "algorithmic_bytes_per_read": qpr * BYTES_PER_RANK_QUERY, "oracle_counters_on_sample": cn}
             ns = min(n_reads, int(os.environ.get("FMD_BENCH_CPU_SAMPLE_SMEM", "400000")))

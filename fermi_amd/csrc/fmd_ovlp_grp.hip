@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
         const int t = fmd_chunk_xor(lane);
         const uint4 *img_e = lds + fmd_lds_base(lane, 0), *img_b = lds + fmd_lds_base(lane, 1);
         const uint4 *img_el = pool + (e_sep ? (pe & (GRP_POOL - 1)) : 0) * FMD_BLK_U4, *img_bl = pool + (b_sep ? (pb & (GRP_POOL - 1)) : 0) * FMD_BLK_U4;
-        const int t_el = pe & FMD_GRP_MASK, t_bl = pb & FMD_GRP_MASK;
+        const int t_el = fmd_pool_xor(pe & (GRP_POOL - 1)), t_bl = fmd_pool_xor(pb & (GRP_POOL - 1));
 
         // Every interval here has size <= 63 (k_ovl_classify), so "rank2a" is a count over a 64-position
         // window of the planes read straight from the lane's LDS block images:

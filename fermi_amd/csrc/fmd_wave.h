@@ -33,7 +33,7 @@
 //     the count of N is 96b minus the other five.
 // Still one aligned fetch per rank, self-contained (no superblock table); 5.33 bits/symbol.
 #ifndef FMD_BLK64
-#define FMD_BLK64 0
+#define FMD_BLK64 1   // the shipped geometry (A/B: make variant NAME=128 EXTRA=-DFMD_BLK64=0)
 #endif
 #if FMD_BLK64
 #define FMD_BLK_SYMS 96u
@@ -163,15 +163,22 @@ __device__ __forceinline__ int fmd_lds_base(int q, int slot)
     return slot * FMD_SLOT_U4 + (q & FMD_GRP_MASK) * 64 + (q >> FMD_GRP_SHIFT) * FMD_BLK_U4;
 }
 
+// chunk XOR of pool slot p: 16 consecutive slots use the 16 distinct (quad, chunk) 16-byte slot classes
+#if FMD_BLK64
+__device__ __forceinline__ int fmd_pool_xor(int p) { return (p ^ (p >> 2)) & 3; }
+#else
+__device__ __forceinline__ int fmd_pool_xor(int p) { return p & 7; }
+#endif
+
 // Pool of compacted blocks (ballot-prefix slots): `n` block ids in ids[], FMD_BLK_PER_INST per wave
-// instruction, written to pool; the lane that owns pool slot p reads pool + p * FMD_BLK_U4 with XOR p.
+// instruction, written to pool; the lane that owns pool slot p reads pool + p * FMD_BLK_U4 with XOR fmd_pool_xor(p).
 __device__ __forceinline__ void fmd_fetch_pool(const FmdIndexView &ix, uint4 *pool, const uint32_t *ids, int n)
 {
     const int q = fmd_lane();
     for (int rr = 0; rr * FMD_BLK_PER_INST < n; ++rr) {
         const int slot = rr * FMD_BLK_PER_INST + (q >> FMD_GRP_SHIFT);
         if (slot < n) {
-            const uint4 *src = ix.blocks + (size_t)ids[slot] * FMD_BLK_U4 + ((q & FMD_GRP_MASK) ^ (slot & FMD_GRP_MASK));
+            const uint4 *src = ix.blocks + (size_t)ids[slot] * FMD_BLK_U4 + ((q & FMD_GRP_MASK) ^ fmd_pool_xor(slot));
             __builtin_amdgcn_global_load_lds((fmd_glb_void *)src, (fmd_lds_void *)(pool + rr * 64), 16, 0, FMD_GLDS_AUX);
         }
     }
@@ -363,7 +370,7 @@ __device__ __forceinline__ FmdRank2 fmd_wave_rank2_fetch(const FmdIndexView &ix,
             if (l_sep) ids[p] = r.blk_l;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             fmd_fetch_pool(ix, pool, ids, n_sep);
-            if (l_sep) { r.bl = pool + p * FMD_BLK_U4; r.tl = p & FMD_GRP_MASK; }
+            if (l_sep) { r.bl = pool + p * FMD_BLK_U4; r.tl = fmd_pool_xor(p); }
         } else {
             fmd_fetch_slot<1>(ix, lds, r.blk_l, l_sep);
             if (l_sep) r.bl = lds + fmd_lds_base(q, 1);
@@ -416,7 +423,7 @@ __device__ __forceinline__ FmdRank2c fmd_wave_rank2_fetch_compact(const FmdIndex
             if (r.l_sep) ids[p] = r.blk_l;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             fmd_fetch_pool(ix, pool, ids, n_sep);
-            if (r.l_sep) { r.bl = pool + p * FMD_BLK_U4; r.tl = p & FMD_GRP_MASK; }
+            if (r.l_sep) { r.bl = pool + p * FMD_BLK_U4; r.tl = fmd_pool_xor(p); }
         } else r.two_phase = true;
     }
     r.nk = ok_ + 1; r.nl = ol_ + 1;

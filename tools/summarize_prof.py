@@ -43,8 +43,8 @@ pr = pmc("pmc_probe")
 for k, v in pr.items():
     if "k_probe" in k and "FETCH_SIZE" in v:
         kb = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"])
-        # probe_gather(iters=1) launches twice (warm-up + timed), each reading 2^27 lines of 128 B
-        known = (1 << 27) * 128
+        # probe_gather(iters=1) launches twice (warm-up + timed), each reading 2^27 lines of PROBE_LINE bytes
+        known = (1 << 27) * int(os.environ.get("PROBE_LINE", "128"))
         cal = known / (kb * 1024.0)
         print("calibration: k_probe FETCH_SIZE = %.0f KB per launch for %d known bytes -> true/reported = %.3f\n" % (kb, known, cal))
 for sub in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq", "pmc_inst"):
