@@ -38,6 +38,10 @@ class FmdError(RuntimeError):
     pass
 
 
+# status codes of include/fmd_hip.h
+FMD_OK, FMD_E_NODEV, FMD_E_ARG, FMD_E_FORMAT, FMD_E_IO, FMD_E_NOMEM, FMD_E_HIP, FMD_E_OVERFLOW = 0, -1, -2, -3, -4, -5, -6, -7
+
+
 class Info(C.Structure):
     _fields_ = [("cnt", C.c_uint64 * 7), ("mcnt", C.c_uint64 * 7), ("n_blocks", C.c_uint64),
                 ("hbm_bytes", C.c_uint64), ("device", C.c_int)]

@@ -1,24 +1,24 @@
 // fmd_wave.h -- HBM layout of the FMD index and the per-wavefront rank engine (gfx950 only).
 //
-// HBM layout ("rank block"): the BWT string is cut into fixed runs of 256 positions.  Block b
-// (128 bytes, one L2 line) covers BWT[256b, 256b+256) as 8 chunks of 16 bytes; chunk j holds
-// positions [32j, 32j+32) as three bit-planes of the nt6 symbol plus one meta word:
-//     chunk j = { p0, p1, p2, meta_j }        bit i of p0/p1/p2 = bit 0/1/2 of symbol 32j+i
-//     meta_0..5 = low 32 bits of the absolute count of $,A,C,G,T,N in BWT[0, 256b)
-//     meta_6    = bits 32..39 of the counts of $,A,C,G  (one byte each)
-//     meta_7    = bits 32..39 of the counts of T,N      (low two bytes)
-// so rank(k) -- rld_rank1a in the reference (rld.c:424) -- is ONE aligned 128-byte fetch of
-// block k>>8 plus masked popcounts: no frame lookup, no header walk (rld.c:352), no sequential
-// Elias-delta decode (rld.h:77).  4 bits/symbol: 70 GB for the 1.4e11-symbol human-35x index,
-// which is what 288 GB of HBM3E per GPU is for.
+// HBM layout ("rank block"): the BWT string is cut into fixed runs of positions; a block holds the
+// nt6 symbols of its run as three bit-planes per 32 positions plus the absolute symbol counts before
+// it, so rank(k) -- rld_rank1a in the reference (rld.c:424) -- is ONE aligned fetch of the block k
+// falls into plus masked popcounts: no frame lookup, no header walk (rld.c:352), no sequential
+// Elias-delta decode (rld.h:77).  Two geometries share all the code below (FMD_BLK64):
+//   * 64 bytes / 96 positions (shipped; described where FMD_BLK64 is defined), 5.33 bits/symbol;
+//   * 128 bytes / 256 positions, one L2 line, 4 bits/symbol: 8 chunks of 16 bytes,
+//       chunk j = { p0, p1, p2, meta_j }        bit i of p0/p1/p2 = bit 0/1/2 of symbol 32j+i
+//       meta_0..5 = low 32 bits of the absolute count of $,A,C,G,T,N before the block,
+//       meta_6 / meta_7 = bits 32..39 of those counts (one byte each).
+// 70-94 GB for the 1.4e11-symbol human-35x index, which is what 288 GB of HBM3E per GPU is for.
 //
 // Wave engine: a wavefront owns 64 searches, one per lane.  Per step every lane posts up to two
 // block numbers (k-side, l-side).  The 64 lanes then fetch those blocks COOPERATIVELY: in round
-// r each 8-lane group g streams the 128-byte block of lane 8g+r with one 16-byte
-// global_load_lds_dwordx4 per lane (8 whole lines per wave instruction, fully coalesced, LDS-DMA,
-// no VGPR round trip).  After one s_waitcnt every lane reads ITS block back from LDS with eight
-// ds_read_b128 and counts all symbols itself.  LDS is the transpose between "coalesced by line"
-// and "one search per lane".  16 KiB LDS per wave (64 lanes x 2 slots x 128 B).
+// r each 4-lane (8-lane) group g streams the block of its lane number r with one 16-byte
+// global_load_lds_dwordx4 per lane (16 or 8 whole blocks per wave instruction, fully coalesced,
+// LDS-DMA, no VGPR round trip).  After one s_waitcnt every lane reads ITS block back from LDS with
+// ds_read_b128 and counts the symbols itself.  LDS is the transpose between "coalesced by line"
+// and "one search per lane".
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

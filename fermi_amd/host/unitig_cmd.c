@@ -4,15 +4,21 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include "fmd_host.h"
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
 int fmdh_unitig(const char *fmd_path, int device, int min_match, const char *rank_file, FILE *out)
 {
     fmd_dev_t *d = 0;
     fmd_info_t info;
+    const int timing = getenv("FMD_TIMING") != 0; /* phase times on stderr */
+    double t0 = now_s(), t1;
     int rc = fmd_dev_open_file(device, fmd_path, &d);
     if (rc) { fprintf(stderr, "[E::%s] cannot load `%s': %s\n", __func__, fmd_path, fmd_strerror(rc)); return 1; }
     fmd_dev_info(d, &info);
+    if (timing) { t1 = now_s(); fprintf(stderr, "[M::%s] index load + transcode: %.3f s\n", __func__, t1 - t0); t0 = t1; }
     const uint64_t n = info.mcnt[1];
     uint32_t max_len = 128, max_nei = 4;
     uint64_t *ids = (uint64_t *)malloc(n * 8);
@@ -38,9 +44,11 @@ int fmdh_unitig(const char *fmd_path, int device, int min_match, const char *ran
         rc = fmd_ovlp_batch(d, n, ids, min_match, max_len, max_nei, rec, nei, seq, stride, /*check_left*/1);
         if (rc) { fprintf(stderr, "[E::%s] overlap discovery failed: %s\n", __func__, fmd_strerror(rc)); rc = 1; goto done; }
         for (uint64_t i = 0; i < n; ++i) n_over += (rec[i].flags & FMD_OVLP_F_OVERFLOW) != 0;
+        if (timing) { t1 = now_s(); fprintf(stderr, "[M::%s] overlap table of %llu sequences (GPU + copies): %.3f s\n", __func__, (unsigned long long)n, t1 - t0); t0 = t1; }
         if (n_over == 0) {
             fmdh_ovlp_table_t t = {n, max_nei, stride, rec, nei, seq};
             rc = fmdh_unitig_walk(&t, n, min_match, sorted, out);
+            if (timing) { t1 = now_s(); fprintf(stderr, "[M::%s] walk + output: %.3f s\n", __func__, t1 - t0); t0 = t1; }
             if (rc) { fprintf(stderr, "[E::%s] walk failed: %s\n", __func__, strerror(-rc)); rc = 1; }
             goto done;
         }

@@ -87,6 +87,19 @@ def test_empty_and_edge_inputs(gpu, tiny_dev):
     assert ok[2].sum() == tiny_dev.n and np.array_equal(ok[2], tiny_dev.mcnt[1:])
     cnt, beg, end = tiny_dev.backward_search([np.array([], dtype=np.uint8), np.array([1], dtype=np.uint8)])
     assert cnt[0] == 0 and cnt[1] == tiny_dev.mcnt[2]
+    # the newer entry points: nothing to do is not an error, impossible arguments are
+    import ctypes as C
+    L = gpu.lib()
+    assert L.fmd_reach_batch(tiny_dev.h, 0, None, None) == 0
+    assert L.fmd_smem_win_batch(tiny_dev.h, 0, None, 0, None, 0, 64, 8, None, None) == 0
+    assert L.fmd_reach_batch(tiny_dev.h, 16, None, None) == gpu.FMD_E_ARG
+    assert L.fmd_dev_export_bwt(tiny_dev.h, tiny_dev.n, 1, None) == gpu.FMD_E_ARG          # past the end
+    buf = np.zeros(3, dtype=np.uint8)
+    assert L.fmd_dev_export_bwt(tiny_dev.h, tiny_dev.n - 3, 3, buf.ctypes.data) == 0 and (buf < 6).all()
+    r = tiny_dev.reach(np.array([0, 0, 5, 0, 1, 2, 0], dtype=np.uint8))                    # terminators, an N alone, a 2-mer
+    assert r[0] == r[1] == r[3] == r[6] == 0 and r[2] == 0 and r[4] in (1, 2) and r[5] == 1
+    bad, first = C.c_uint64(), C.c_uint64()
+    assert L.fmd_dev_check_rank(tiny_dev.h, C.byref(bad), C.byref(first)) == 0 and bad.value == 0
 
 
 def test_random_batches_vs_oracle(gpu, tiny_dev, tiny_oracle):
