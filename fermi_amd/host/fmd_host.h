@@ -34,6 +34,11 @@ typedef struct {
     const fmd_ovlp_rec_t *rec;   /* n */
     const fmd_intv_t *nei;       /* n * max_nei */
     const uint8_t *seq;          /* n * seq_stride: sequence then appended bases */
+    /* optional: the few rows whose lists did not fit the capacities above, recomputed with roomier ones */
+    const uint32_t *side_of;     /* n entries: index into the side arrays, 0xffffffff = not there; or NULL */
+    uint32_t side_max_nei, side_stride;
+    const fmd_intv_t *side_nei;  /* n_side * side_max_nei */
+    const uint8_t *side_seq;     /* n_side * side_stride */
 } fmdh_ovlp_table_t;
 /* Replays the single-threaded walk and writes the MAG records `fermi unitig -t1` prints. */
 int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, const uint64_t *sorted /* or NULL */, FILE *out);

@@ -49,8 +49,18 @@ typedef struct {
 } walk_t;
 
 static inline const fmd_ovlp_rec_t *REC(const walk_t *w, uint64_t row) { return &w->t->rec[row]; }
-static inline const fmd_intv_t *NEI(const walk_t *w, uint64_t row) { return w->t->nei + row * w->t->max_nei; }
-static inline const uint8_t *SEQ(const walk_t *w, uint64_t row) { return w->t->seq + row * (size_t)w->t->seq_stride; }
+static inline const fmd_intv_t *NEI(const walk_t *w, uint64_t row)
+{
+    const fmdh_ovlp_table_t *t = w->t;
+    if (t->side_of && t->side_of[row] != 0xffffffffu) return t->side_nei + (size_t)t->side_of[row] * t->side_max_nei;
+    return t->nei + row * t->max_nei;
+}
+static inline const uint8_t *SEQ(const walk_t *w, uint64_t row)
+{
+    const fmdh_ovlp_table_t *t = w->t;
+    if (t->side_of && t->side_of[row] != 0xffffffffu) return t->side_seq + (size_t)t->side_of[row] * t->side_stride;
+    return t->seq + row * (size_t)t->seq_stride;
+}
 
 static void mark_used(walk_t *w, const uint64_t x[3]) /* set_bits, unitig.c:22-36 (sorted == NULL) */
 {
@@ -150,7 +160,8 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
     w.t = t; w.n_seq = n_seq; w.min_match = min_match; w.sorted = sorted;
     w.used = (uint64_t *)calloc(nw, 8); w.bend = (uint64_t *)calloc(nw, 8); w.visited = (uint64_t *)calloc(nw, 8);
     w.row_of = (uint32_t *)malloc(n_seq * 4);
-    nei[0] = (link_t *)malloc(t->max_nei * sizeof(link_t)); nei[1] = (link_t *)malloc((t->max_nei + 1) * sizeof(link_t));
+    const uint32_t cap_nei = t->side_of && t->side_max_nei > t->max_nei ? t->side_max_nei : t->max_nei;
+    nei[0] = (link_t *)malloc(cap_nei * sizeof(link_t)); nei[1] = (link_t *)malloc((cap_nei + 1) * sizeof(link_t));
     if (!w.used || !w.bend || !w.visited || !w.row_of || !nei[0] || !nei[1]) { rc = -ENOMEM; goto done; }
     memset(w.row_of, 0xff, n_seq * 4);
     for (i = t->n; i-- > 0;) { /* smallest id wins */

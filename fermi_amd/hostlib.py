@@ -22,7 +22,9 @@ def lib():
         L.fmdh_trim_palindrome.argtypes = [C.c_void_p, C.c_uint32]
         class Table(C.Structure):
             _fields_ = [("n", C.c_uint64), ("max_nei", C.c_uint32), ("seq_stride", C.c_uint32),
-                        ("rec", C.c_void_p), ("nei", C.c_void_p), ("seq", C.c_void_p)]
+                        ("rec", C.c_void_p), ("nei", C.c_void_p), ("seq", C.c_void_p),
+                        ("side_of", C.c_void_p), ("side_max_nei", C.c_uint32), ("side_stride", C.c_uint32),
+                        ("side_nei", C.c_void_p), ("side_seq", C.c_void_p)]
         L.Table = Table
         L.fmdh_unitig_walk.argtypes = [C.POINTER(Table), C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
         L.fmdh_unitig.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_void_p]
@@ -83,7 +85,7 @@ def unitig_walk(rec, nei, seq, n_seq, min_match, out_path, sorted_map=None):
     """Replay the `fermi unitig -t1` walk over a per-id overlap table; writes MAG records to out_path."""
     L = lib()
     rec = np.ascontiguousarray(rec); nei = np.ascontiguousarray(nei); seq = np.ascontiguousarray(seq)
-    t = L.Table(len(rec), nei.shape[1], seq.shape[1], rec.ctypes.data, nei.ctypes.data, seq.ctypes.data)
+    t = L.Table(len(rec), nei.shape[1], seq.shape[1], rec.ctypes.data, nei.ctypes.data, seq.ctypes.data, None, 0, 0, None, None)
     fp = _libc.fopen(out_path.encode(), b"wb")
     try:
         sm = None if sorted_map is None else np.ascontiguousarray(sorted_map, dtype=np.uint64)
