@@ -298,7 +298,45 @@ extern "C" int fmd_kmer_collect_dev(fmd_dev_t *h, void *stream_, int w, int min_
     return FMD_OK;
 }
 
-// Host form: grows the capacity until nothing overflows; outputs are malloc'ed (fmd_host_free).
+// (bucket, key) packed into one sortable word and back: the host form returns the triples sorted, so
+// the consumer's per-bucket tables need no sorting of their own
+__global__ void k_km_pack(uint64_t n, const uint32_t *__restrict__ bucket, const uint32_t *__restrict__ key, uint64_t *__restrict__ k64)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) k64[i] = (uint64_t)bucket[i] << 32 | key[i];
+}
+__global__ void k_km_unpack(uint64_t n, const uint64_t *__restrict__ k64, uint32_t *__restrict__ bucket, uint32_t *__restrict__ key)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { bucket[i] = (uint32_t)(k64[i] >> 32); key[i] = (uint32_t)k64[i]; }
+}
+
+// sorts the m triples in (db, dk, dv) by (bucket, key) in place; a no-op for m beyond hipCUB's item count
+static int km_sort_triples(uint64_t m, int suf_len, uint32_t *db, uint32_t *dk, uint8_t *dv)
+{
+    if (m < 2 || m > 0x7fffffffull) return FMD_OK;
+    uint64_t *ka = nullptr, *kb = nullptr; uint8_t *vb = nullptr; void *tmp = nullptr;
+    size_t tmp_bytes = 0;
+    int rc = FMD_OK;
+    if (hipMalloc((void **)&ka, m * 8) != hipSuccess || hipMalloc((void **)&kb, m * 8) != hipSuccess || hipMalloc((void **)&vb, m) != hipSuccess) rc = FMD_E_NOMEM;
+    if (rc == FMD_OK) {
+        const unsigned nb = (unsigned)((m + 255) / 256);
+        k_km_pack<<<nb, 256>>>(m, db, dk, ka);
+        const int end_bit = 32 + 2 * suf_len;
+        if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ka, kb, dv, vb, (int)m, 0, end_bit) != hipSuccess ||
+            hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16) != hipSuccess) rc = FMD_E_NOMEM;
+        else if (hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, ka, kb, dv, vb, (int)m, 0, end_bit) != hipSuccess) rc = FMD_E_HIP;
+        else {
+            k_km_unpack<<<nb, 256>>>(m, kb, db, dk);
+            if (hipMemcpy(dv, vb, m, hipMemcpyDeviceToDevice) != hipSuccess) rc = FMD_E_HIP;
+        }
+    }
+    hipFree(ka); hipFree(kb); hipFree(vb); hipFree(tmp);
+    return rc;
+}
+
+// Host form: grows the capacity until nothing overflows; outputs are malloc'ed (fmd_host_free) and
+// sorted by (bucket, key).
 extern "C" int fmd_kmer_collect(fmd_dev_t *h, int w, int min_occ, int suf_len, uint32_t **bucket, uint32_t **key, uint8_t **val,
                                 uint64_t *n, int64_t cnt[2])
 {
@@ -314,6 +352,10 @@ extern "C" int fmd_kmer_collect(fmd_dev_t *h, int w, int min_occ, int suf_len, u
         uint64_t status[4] = {0, 0, 0, 0};
         if (rc == FMD_OK) rc = fmd_kmer_collect_dev(h, nullptr, w, min_occ, suf_len, work, wb, cap, (uint32_t *)db, (uint32_t *)dk, (uint8_t *)dv, (uint64_t *)ds);
         if (rc == FMD_OK && hipMemcpy(status, ds, 32, hipMemcpyDeviceToHost) != hipSuccess) rc = FMD_E_HIP;
+        if (rc == FMD_OK && status[1] == 0) {
+            hipFree(work); work = nullptr;   // the frontier buffers are not needed any more; the sort wants the room
+            rc = km_sort_triples(status[0], suf_len, (uint32_t *)db, (uint32_t *)dk, (uint8_t *)dv);
+        }
         if (rc == FMD_OK && status[1] == 0) {
             const uint64_t m = status[0];
             *bucket = (uint32_t *)malloc(m * 4 + 4); *key = (uint32_t *)malloc(m * 4 + 4); *val = (uint8_t *)malloc(m + 4);

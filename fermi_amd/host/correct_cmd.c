@@ -337,10 +337,15 @@ int fmdh_correct_kmer(uint64_t n_symbols) /* the automatic k-mer length, correct
     return w >= MAX_KMER ? MAX_KMER : w;
 }
 
+#include <time.h>
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
 int fmdh_correct(const char *fmd_path, const char *fq_path, int device, fmdh_ecopt_t *opt, FILE *out)
 {
     fmd_dev_t *d = 0;
     fmd_info_t finfo;
+    const int timing = getenv("FMD_TIMING") != 0; /* phase times on stderr */
+    double t0 = now_s(), t1;
     int rc = fmd_dev_open_file(device, fmd_path, &d);
     if (rc) { fprintf(stderr, "[E::%s] cannot load `%s': %s\n", __func__, fmd_path, fmd_strerror(rc)); return 1; }
     fmd_dev_info(d, &finfo);
@@ -348,10 +353,13 @@ int fmdh_correct(const char *fmd_path, const char *fq_path, int device, fmdh_eco
     const int suf_len = opt->w > 15 ? opt->w - 15 : 1; /* correct.c:319 */
     /* phase 1 on the GPU */
     uint32_t *bucket = 0, *key = 0; uint8_t *val = 0; uint64_t n = 0; int64_t cnt[2];
+    if (timing) { t1 = now_s(); fprintf(stderr, "[M::%s] index load + transcode: %.3f s\n", __func__, t1 - t0); t0 = t1; }
     rc = fmd_kmer_collect(d, opt->w, opt->min_occ, suf_len, &bucket, &key, &val, &n, cnt);
     fmd_dev_close(d);
     if (rc) { fprintf(stderr, "[E::%s] k-mer harvest failed: %s\n", __func__, fmd_strerror(rc)); return 1; }
+    if (timing) { t1 = now_s(); fprintf(stderr, "[M::%s] harvest of %llu solid %d-mers (GPU + copy): %.3f s\n", __func__, (unsigned long long)n, opt->w + 1, t1 - t0); t0 = t1; }
     rc = fmdh_correct_reads(opt, suf_len, n, bucket, key, val, fq_path, out);
+    if (timing) { t1 = now_s(); fprintf(stderr, "[M::%s] table build + correction + output: %.3f s\n", __func__, t1 - t0); t0 = t1; }
     fmd_host_free(bucket); fmd_host_free(key); fmd_host_free(val);
     return rc;
 }

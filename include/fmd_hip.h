@@ -191,7 +191,8 @@ int fmd_ovlp_batch(fmd_dev_t *h, size_t n, const uint64_t *ids, int min_match, u
  * over ALL 4^suf_len suffix buckets (what worker1 does, correct.c:272-279).  Emits one
  * (bucket, key, val) triple per solid k-mer: bucket = index into `solid[]` (correct.c:346-349),
  * key/val exactly what kh_put/kh_val store (correct.c:71-75).  The order of triples is
- * unspecified (the reference's own order is hash-table iteration order).  w <= 27, w - suf_len <= 15.
+ * unspecified for the _dev form (the reference's own order is hash-table iteration order); the host
+ * form returns them sorted by (bucket, key).  w <= 27, w - suf_len <= 15.
  * d_status (4 x u64): [0] #triples, [1] non-zero = cap overflowed (re-run larger), [2] cnt[0],
  * [3] cnt[1] (correct.c:64-69). */
 size_t fmd_kmer_work_bytes(uint64_t cap);
