@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
         if (narrow) {
             const uint32_t sh = (uint32_t)x0 & 31;
             uint4 a, b, cc;
-            grp_window(r.bk, r.t, r.bl, r.tl, r.blk_k, r.blk_l, r.hk, r.l_sep, x0, a, b, cc);
+            grp_window(r.bk, r.t, r.bl, r.tl, r.blk_k, r.blk_l, r.hk, r.l_sep, r.blk_k, r.nk - 1, a, b, cc); // window at x0 = (x0 - 1) + 1
             const uint64_t m = bits_below((int)sz);
             const uint64_t X = win64(a.x, b.x, cc.x, sh), Y = win64(a.y, b.y, cc.y, sh), Z = win64(a.z, b.z, cc.z, sh);
             const uint64_t lo = ~Z & m, hi = Z & ~Y & m;

@@ -43,11 +43,13 @@ __device__ __forceinline__ uint4 grp_pick(const uint4 *img_k, int t_k, const uin
     if (!in_k && !in_l) v = make_uint4(0, 0, 0, 0);
     return v;
 }
+// The window starts one position after `p`, whose block and offset (blk_p, off_p) the caller already has
+// (p = the k side of the rank pair that brought the images in): no second division.
 __device__ __forceinline__ void grp_window(const uint4 *img_k, int t_k, const uint4 *img_l, int t_l, uint32_t blk_k, uint32_t blk_l,
-                                           bool has_k, bool has_l, uint64_t pos, uint4 &a, uint4 &b, uint4 &c)
+                                           bool has_k, bool has_l, uint32_t blk_p, uint32_t off_p, uint4 &a, uint4 &b, uint4 &c)
 {
-    uint32_t blk, ch;
-    fmd_word_split(pos >> 5, blk, ch);
+    uint32_t blk = blk_p, ch = (off_p + 1) >> 5;
+    if (off_p + 1 == FMD_BLK_SYMS) { ++blk; ch = 0; }
     a = grp_pick(img_k, t_k, img_l, t_l, blk_k, blk_l, has_k, has_l, blk, ch);
     if (++ch == FMD_BLK_CHUNKS) { ch = 0; ++blk; }
     b = grp_pick(img_k, t_k, img_l, t_l, blk_k, blk_l, has_k, has_l, blk, ch);

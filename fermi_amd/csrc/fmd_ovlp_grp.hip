@@ -126,10 +126,11 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
 
         // ---- one round: forward extension + the six '$' boundaries, all from one gather
         const bool live = active && alive;
-        const uint64_t ke = live ? x1 - 1 : NONE64, le = live ? x1 - 1 + sz : NONE64;
-        const uint64_t kb = live ? x0 - 1 : NONE64, lb = live ? x0 - 1 + sz : NONE64; // x0 >= mcnt[1] > 0 for base strings
-        uint32_t bke, ble, bkb, blb, oke, okb, o_;
-        fmd_split(ke, bke, oke); fmd_split(le, ble, o_); fmd_split(kb, bkb, okb); fmd_split(lb, blb, o_);
+        const uint64_t ke = live ? x1 - 1 : NONE64, kb = live ? x0 - 1 : NONE64; // x0 >= mcnt[1] > 0 for base strings
+        // the l sides lie at most 63 positions after the k sides: same block or the next one
+        uint32_t bke, bkb, oke, okb;
+        fmd_split(ke, bke, oke); fmd_split(kb, bkb, okb);
+        const uint32_t ble = bke + (oke + (uint32_t)sz >= FMD_BLK_SYMS), blb = bkb + (okb + (uint32_t)sz >= FMD_BLK_SYMS);
         const bool e_sep = live && ble != bke, b_sep = live && blb != bkb;
         fmd_fetch_slot<0>(ix, lds, bke, live);
         fmd_fetch_slot<1>(ix, lds, bkb, live);
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
             {   // window of BWT[x1 ...]
                 const uint32_t sh = (uint32_t)x1 & 31;
                 uint4 a, b, c;
-                grp_window(img_e, t, img_el, t_el, bke, ble, true, e_sep, x1, a, b, c);
+                grp_window(img_e, t, img_el, t_el, bke, ble, true, e_sep, bke, oke, a, b, c);
                 // x1 itself may sit in the block after ke's (ke = x1-1 is the last position of a block)
                 const uint64_t m = bits_below((int)sz);
                 const uint64_t X = win64(a.x, b.x, c.x, sh), Y = win64(a.y, b.y, c.y, sh), Z = win64(a.z, b.z, c.z, sh);
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
             {   // '$' of BWT[x0 ...], children laid out in the order $,T,G,C,A (exact.c:81-86)
                 const uint32_t sh = (uint32_t)x0 & 31;
                 uint4 a, b, c;
-                grp_window(img_b, t, img_bl, t_bl, bkb, blb, true, b_sep, x0, a, b, c);
+                grp_window(img_b, t, img_bl, t_bl, bkb, blb, true, b_sep, bkb, okb, a, b, c);
                 const uint64_t D = win64(~a.x & ~a.y & ~a.z, ~b.x & ~b.y & ~b.z, ~c.x & ~c.y & ~c.z, sh);
                 const uint32_t o1 = (uint32_t)s[0], o2 = o1 + (uint32_t)s[4], o3 = o2 + (uint32_t)s[3], o4 = o3 + (uint32_t)s[2], o5 = o4 + (uint32_t)s[1];
                 const uint64_t e0sz = __popcll(D & range64(0, o1));

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
         if (narrow) { // all six child sizes from one 64-position window of BWT[a, a + size), one absolute rank
             const uint32_t sh = (uint32_t)a0 & 31;
             uint4 wa, wb, wc;
-            grp_window(r.bk, r.t, r.bl, r.tl, r.blk_k, r.blk_l, r.hk, r.l_sep, a0, wa, wb, wc);
+            grp_window(r.bk, r.t, r.bl, r.tl, r.blk_k, r.blk_l, r.hk, r.l_sep, r.blk_k, r.nk - 1, wa, wb, wc); // window at a0 = (a0 - 1) + 1
             const uint64_t m = (1ull << (int)ksz) - 1;
             const uint64_t X = win64(wa.x, wb.x, wc.x, sh), Y = win64(wa.y, wb.y, wc.y, sh), Z = win64(wa.z, wb.z, wc.z, sh);
             const uint64_t lo = ~Z & m, hi = Z & ~Y & m;
