@@ -210,6 +210,7 @@ static int dev_alloc_index(int device, uint64_t n_sym, fmd_dev **out)
     int ndev = fmd_device_count();
     if (ndev <= 0 || device < 0 || device >= ndev) return FMD_E_NODEV;
     if (n_sym == 0 || n_sym >= (1ull << 40)) return FMD_E_ARG; // 40-bit absolute counts
+    if ((n_sym + FMD_BLK_SYMS - 1) / FMD_BLK_SYMS + 1 >= 0xffffffffull) return FMD_E_ARG; // 32-bit block numbers
     FMD_HIP_TRY(hipSetDevice(device));
     fmd_dev *h = (fmd_dev *)calloc(1, sizeof(fmd_dev));
     if (!h) return FMD_E_NOMEM;
