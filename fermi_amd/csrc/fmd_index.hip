@@ -190,6 +190,59 @@ __global__ void k_write_meta(uint4 *__restrict__ blocks, uint64_t n_blocks, cons
 #endif
 }
 
+// ------------------------------------------------------------------ prefix table (FmdIndexView::ptab)
+// level d from level d-1: the string c S (c prepended) is one backward extension of S by c.
+// thread = index of the new string; its top two bits are c - 1.
+__global__ void k_ptab_level(FmdIndexView ix, int d, const uint4 *__restrict__ prev, uint4 *__restrict__ next)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1ull << (2 * d))) return;
+    const int c = (int)(i >> (2 * (d - 1))) + 1;
+    uint64_t k, l;
+    if (d == 1) { k = ix.cnt[c]; l = ix.cnt[c + 1] - 1; }
+    else {
+        const uint4 e = prev[i & ((1ull << (2 * (d - 1))) - 1)];
+        k = (uint64_t)e.y << 32 | e.x; l = (uint64_t)e.w << 32 | e.z;
+        if (k <= l) { // rank_c(k - 1), rank_c(l)  (k >= 1: position 0 holds a sentinel suffix)
+            uint32_t b, o;
+            fmd_split(k - 1, b, o);
+            const uint64_t rk = fmd_block_rank1(ix.blocks + (size_t)b * FMD_BLK_U4, 0, o + 1, c, b);
+            fmd_split(l, b, o);
+            const uint64_t rl = fmd_block_rank1(ix.blocks + (size_t)b * FMD_BLK_U4, 0, o + 1, c, b);
+            k = ix.cnt[c] + rk; l = ix.cnt[c] + rl - 1;
+        }
+    }
+    if (k > l) { k = 1; l = 0; }
+    next[i] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), (uint32_t)l, (uint32_t)(l >> 32));
+}
+
+static int build_ptab(fmd_dev *h)
+{
+    // as deep as keeps the table well below the index: 4^d <= n/8, at most 12 (268 MB), at least 2
+    int d = 2;
+    while (d < 12 && (1ull << (2 * (d + 1))) <= h->mcnt[0] / 8) ++d;
+    if (getenv("FMD_PTAB_DEPTH")) { d = atoi(getenv("FMD_PTAB_DEPTH")); if (d < 1) return FMD_OK; if (d > 13) d = 13; }
+    uint4 *a = nullptr, *b = nullptr;
+    const uint64_t n = 1ull << (2 * d);
+    FMD_HIP_TRY(hipMalloc((void **)&a, n * 16));
+    if (hipMalloc((void **)&b, (n / 4 ? n / 4 : 1) * 16) != hipSuccess) { hipFree(a); return FMD_E_NOMEM; }
+    // levels alternate between b (odd distance from the last) and a, so that level d lands in a
+    FmdIndexView ix = fmd_view(h);
+    uint4 *cur = nullptr;
+    for (int lv = 1; lv <= d; ++lv) {
+        uint4 *dst = ((d - lv) & 1) ? b : a;
+        const uint64_t m = 1ull << (2 * lv);
+        k_ptab_level<<<(unsigned)((m + 255) / 256), 256>>>(ix, lv, cur, dst);
+        cur = dst;
+    }
+    hipError_t e = hipDeviceSynchronize();
+    hipFree(b);
+    if (e != hipSuccess) { hipFree(a); fmd_set_hip_error(e, "prefix table"); return FMD_E_HIP; }
+    h->ptab = a; h->ptab_d = d;
+    h->bytes += n * 16;
+    return FMD_OK;
+}
+
 // --------------------------------------------------------------------------------- host side
 static int scan_u64(uint64_t *d_in, uint64_t *d_out, uint64_t n, hipStream_t st)
 {
@@ -259,6 +312,7 @@ static int finish_index(fmd_dev *h)
         else if (h->cnt[6] != h->mcnt[0]) rc = FMD_E_FORMAT;
     }
     hipFree(bc); hipFree(acc);
+    if (rc == FMD_OK) rc = build_ptab(h);
     return rc;
 }
 
@@ -471,6 +525,7 @@ extern "C" void fmd_dev_close(fmd_dev_t *h)
     if (!h) return;
     hipSetDevice(h->device);
     hipFree(h->blocks);
+    hipFree(h->ptab);
     hipFree(h->queues);
     free(h);
 }

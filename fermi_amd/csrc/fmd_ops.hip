@@ -139,11 +139,37 @@ __global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const
                     const int len = (int)(off[my + 1] - sbase);
                     if (len <= 0) { d_cnt[my] = 0; d_beg[my] = 0; d_end[my] = 0; }
                     else {
-                        const int c = seqs[sbase + len - 1];
-                        k = ix.cnt[c]; l = ix.cnt[c + 1] - 1;
-                        pos = len - 2;
-                        live = true;
-                        if (pos >= 0) cache = *(const uint32_t *)(seqs + ((sbase + pos) & ~3ull));
+                        // the last ptab_d bases in one table look-up (the top of the search tree, two lines
+                        // per step while the interval is wider than a block), when they are all A/C/G/T
+                        const int D = ix.ptab_d;
+                        bool from_table = false;
+                        if (ix.ptab && len >= D) {
+                            const uint64_t beg = sbase + (uint64_t)(len - D), end = sbase + (uint64_t)len;
+                            uint64_t idx = 0; bool acgt = true;
+                            for (uint64_t a = beg & ~3ull; a < end; a += 4) {
+                                const uint32_t w = *(const uint32_t *)(seqs + a);
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) {
+                                    const uint32_t c = (w >> (8 * b)) & 0xff;
+                                    if (a + b >= beg && a + b < end) { acgt = acgt && c >= 1 && c <= 4; idx = idx << 2 | ((c - 1) & 3); }
+                                }
+                            }
+                            if (acgt) {
+                                const uint4 e = ix.ptab[idx];
+                                k = (uint64_t)e.y << 32 | e.x; l = (uint64_t)e.w << 32 | e.z;
+                                pos = len - D - 1;
+                                from_table = true;
+                                if (k > l) { d_cnt[my] = 0; d_beg[my] = 0; d_end[my] = 0; } // already a miss
+                                else live = true;
+                            }
+                        }
+                        if (!from_table) {
+                            const int c = seqs[sbase + len - 1];
+                            k = ix.cnt[c]; l = ix.cnt[c + 1] - 1;
+                            pos = len - 2;
+                            live = true;
+                        }
+                        if (live && pos >= 0) cache = *(const uint32_t *)(seqs + ((sbase + pos) & ~3ull));
                     }
                 } else exhausted = true;
             }
@@ -212,9 +238,31 @@ __global__ __launch_bounds__(64) void k_reach(FmdIndexView ix, size_t n, const u
                     const int cc = (c >= 1 && c <= 4) ? 5 - c : c;
                     if (c == 0 || c > 5) out_len[p] = 0;
                     else {
-                        k = ix.cnt[cc]; l = ix.cnt[cc + 1] - 1;
-                        if (k > l) out_len[p] = 0;        // a base the index does not contain
-                        else { i = p + 1; live = true; }
+                        // first ptab_d symbols in one look-up when that many A/C/G/T follow and all of them match
+                        // (the sweep consumes comp(q[p]), comp(q[p+1]), ..: the table string read backwards)
+                        const int D = ix.ptab_d;
+                        bool from_table = false;
+                        if (ix.ptab) {
+                            uint64_t idx = 0; bool acgt = true;
+                            for (size_t a = p & ~(size_t)3; a < p + (size_t)D && acgt; a += 4) {
+                                const uint32_t w = *(const uint32_t *)(seqs + a);
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) {
+                                    const uint32_t x = (w >> (8 * b)) & 0xff;
+                                    if (a + b >= p && a + b < p + (size_t)D) { acgt = acgt && x >= 1 && x <= 4; idx |= (uint64_t)((4 - x) & 3) << (2 * (a + b - p)); }
+                                }
+                            }
+                            if (acgt) {
+                                const uint4 e = ix.ptab[idx];
+                                const uint64_t tk = (uint64_t)e.y << 32 | e.x, tl = (uint64_t)e.w << 32 | e.z;
+                                if (tk <= tl) { k = tk; l = tl; i = p + (size_t)D; live = true; from_table = true; }
+                            }
+                        }
+                        if (!from_table) {
+                            k = ix.cnt[cc]; l = ix.cnt[cc + 1] - 1;
+                            if (k > l) out_len[p] = 0;        // a base the index does not contain
+                            else { i = p + 1; live = true; }
+                        }
                     }
                 } else exhausted = true;
             }

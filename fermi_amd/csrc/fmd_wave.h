@@ -68,6 +68,10 @@ struct FmdIndexView {            // passed by value as a kernel argument (lives 
     uint64_t cnt[7];             // C array: cnt[c] = # symbols < c (rld.c:282-284)
     uint64_t n_sym;              // mcnt[0]
     uint64_t n_seq;              // mcnt[1] = number of sentinels
+    // SA intervals of all ACGT strings of ptab_d bases: entry = {k lo, k hi, l lo, l hi} (k > l: absent),
+    // index of s_0 s_1 .. s_{d-1} = sum (s_j - 1) << 2(d-1-j).  Lets a search start ptab_d bases in.
+    const uint4 *ptab;
+    int ptab_d;
 };
 
 __device__ __forceinline__ int fmd_lane() { return (int)(threadIdx.x & 63); }
