@@ -184,12 +184,18 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
     uint32_t depth = 0, npush = 0, pack = 0, flags = 0;
     uint64_t k = 0, x0 = 0, x1 = 0, sz = 0;
     bool exhausted = false;
+    // The first ptab_d bases need no interval arithmetic when nothing can be pushed that early
+    // (min_match >= ptab_d): LF steps only (one line each instead of three), the bi-interval then comes
+    // from the prefix table -- forward string for x[0] and the size, reverse complement for x[1].
+    const bool tab_ok = ix.ptab != nullptr && (info_only || min_match >= ix.ptab_d) && ix.ptab_d >= 2;
+    bool tab = false;
+    uint32_t tfw = 0, trv = 0;
     FmdTickets tk_;
     fmd_tickets_init(tk_, queue);
     for (;;) {
         const size_t my = fmd_tickets_take(tk_, queue, st == WK_IDLE && !exhausted);
         if (st == WK_IDLE && !exhausted) {
-            if (my < n) { sid = my; k = ids[my]; depth = 0; npush = 0; pack = 0; flags = 0; ret = 0; st = WK_LF; }
+            if (my < n) { sid = my; k = ids[my]; depth = 0; npush = 0; pack = 0; flags = 0; ret = 0; st = WK_LF; tab = tab_ok; }
             else exhausted = true;
         }
         if (__ballot(st != WK_IDLE) == 0) break;
@@ -250,6 +256,29 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             const uint32_t bit = off & 31;
             c = (int)(((v.x >> bit) & 1) | ((v.y >> bit) & 1) << 1 | ((v.z >> bit) & 1) << 2);
             k = ix.cnt[c] + fmd_block_rank1(img, tt, off + 1, c, kb_) - 1;
+            if (st == WK_LF && depth > 0 && tab) { // still inside the prefix table: no extension, just collect the base
+                if (c < 1 || c > 4) { // the sequence ends, or an ambiguous base: start over on the ordinary path
+                    k = ids[sid]; depth = 0; pack = 0; tab = false;
+                    continue;
+                }
+                tfw |= (uint32_t)(c - 1) << (2 * depth); trv = trv << 2 | (uint32_t)(4 - c);
+                pack |= (uint32_t)c << (8 * (depth & 3));
+                ++depth;
+                if ((depth & 3) == 0) {
+                    if (depth <= stride_r) *(uint32_t *)(srev + sid * (size_t)stride_r + depth - 4) = pack;
+                    pack = 0;
+                }
+                if ((int)depth == ix.ptab_d) {
+                    const uint4 ef = ix.ptab[tfw], er = ix.ptab[trv];
+                    x0 = (uint64_t)ef.y << 32 | ef.x;
+                    sz = ((uint64_t)ef.w << 32 | ef.z) - x0 + 1;   // never empty: the sequence is in the index
+                    x1 = (uint64_t)er.y << 32 | er.x;
+                    tab = false;
+                    const uint32_t bk_ = fmd_blk_of(x0 - 1), bl_ = fmd_blk_of(x0 - 1 + sz), bq = fmd_blk_of(k);
+                    st = (bq == bk_ || bq == bl_) ? WK_BOTH : WK_LF;
+                }
+                continue;
+            }
             if (st == WK_LF && depth > 0) { c_pend = c; st = WK_EXT; continue; } // the extension needs its own gather
         }
         if (depth == 0) { // first LF step: the last base of the sequence, or an empty sequence
@@ -262,6 +291,8 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             }
             x0 = ix.cnt[c]; x1 = ix.cnt[comp6(c)]; sz = ix.cnt[c + 1] - ix.cnt[c];
             pack = (uint32_t)c; depth = 1;
+            if (c > 4) tab = false;
+            tfw = (uint32_t)(c - 1) & 3; trv = (uint32_t)(4 - c) & 3;
         } else if (st == WK_EXT || st == WK_BOTH) {
             uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, s[6];
             if (narrow) { // only tk[c] is ever read below
@@ -338,6 +369,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
         {
             const uint32_t bk_ = fmd_blk_of(x0 - 1), bl_ = fmd_blk_of(x0 - 1 + sz), bq = fmd_blk_of(k);
             st = (bq == bk_ || bq == bl_) ? WK_BOTH : WK_LF;
+            if (tab) st = WK_LF;   // inside the prefix table there is no extension to share a gather with
         }
     }
 }
