@@ -591,7 +591,8 @@ int fmd_grid_for_lds(const fmd_dev *h, size_t n_items, size_t lds_bytes)
 {
     const size_t waves_needed = (n_items + 63) / 64;
     size_t per_cu = (160 * 1024) / (lds_bytes ? lds_bytes : 1);
-    if (per_cu > 16) per_cu = 16;
+    static const size_t cap = getenv("FMD_WAVES_PER_CU") ? (size_t)atoi(getenv("FMD_WAVES_PER_CU")) : 16;
+    if (per_cu > cap) per_cu = cap;
     if (per_cu < 1) per_cu = 1;
     const size_t resident = (size_t)h->n_cu * per_cu;
     size_t g = waves_needed < resident ? waves_needed : resident;

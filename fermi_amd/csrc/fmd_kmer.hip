@@ -14,8 +14,8 @@
 #include <string.h>
 #include <hipcub/hipcub.hpp>
 #include "fmd_internal.h"
+#include "fmd_ovlp_common.h"
 
-#define NONE64 (~0ull)
 
 // counters in device memory: [0..63] frontier sizes per depth, [64] #output, [65] overflow flag,
 // [66] cnt[0] (k-mers kept), [67] cnt[1] (informative ones), correct.c:64-69, [68] extensions
@@ -26,18 +26,44 @@
 #define KM_EXT 68      // backward extensions done (= trie nodes expanded), all levels
 #define KM_WORDS 72
 
+// One backward extension per lane.  Narrow intervals (size <= 63: every level below ~log4(n)) take the
+// child sizes from one 64-position window of the lane's block image(s); the absolute rank tk[c] is then
+// computed only for the children that are kept (usually one) -- or not at all (k_kmer_emit needs sizes
+// only).  Wide intervals: two six-symbol block ranks.
+template <bool NEED_TK>
 __device__ __forceinline__ void km_extend_back(const FmdIndexView &ix, uint4 *lds, bool active, uint64_t x0, uint64_t sz,
-                                               uint64_t tk[6], uint64_t s[6])
+                                               uint64_t thr, uint64_t tk[6], uint64_t s[6])
 {
     FmdRank2c r = fmd_wave_rank2_fetch_compact(ix, lds, active ? x0 - 1 : NONE64, active ? x0 - 1 + sz : NONE64);
+    const bool narrow = active && sz <= 63 && !(r.two_phase && r.l_sep);
     uint64_t tl[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int c = 0; c < 6; ++c) tk[c] = 0;
-    if (active && r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk, r.blk_k);
+    for (int c = 0; c < 6; ++c) { tk[c] = 0; s[c] = 0; }
+    if (active && !narrow && r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk, r.blk_k);
     fmd_wave_l_ready(ix, lds, r);
-    if (active && r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl, r.blk_l);
+    if (narrow) {
+        uint4 a, b, c;
+        grp_window(r.bk, r.t, r.bl, r.tl, r.blk_k, r.blk_l, r.hk, r.l_sep, r.blk_k, r.nk - 1, a, b, c); // window at x0 = (x0 - 1) + 1
+        const uint32_t sh = (uint32_t)x0 & 31;
+        const uint64_t m = (1ull << (int)sz) - 1;
+        const uint64_t X = win64(a.x, b.x, c.x, sh), Y = win64(a.y, b.y, c.y, sh), Z = win64(a.z, b.z, c.z, sh);
+        const uint64_t lo = ~Z & m, hi = Z & ~Y & m;
+        s[0] = __popcll(lo & ~Y & ~X); s[1] = __popcll(lo & ~Y & X); s[2] = __popcll(lo & Y & ~X); s[3] = __popcll(lo & Y & X);
+        s[4] = __popcll(hi & ~X); s[5] = __popcll(hi & X);
+        if (NEED_TK) {
+            uint32_t todo = (s[1] >= thr ? 2u : 0u) | (s[2] >= thr ? 4u : 0u) | (s[3] >= thr ? 8u : 0u) | (s[4] >= thr ? 16u : 0u);
+            while (__ballot(todo != 0)) {
+                const int cc = todo ? __ffs((int)todo) - 1 : 1;
+                const uint64_t v = r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, cc, r.blk_k) : 0;
+                if (todo) { tk[1] = cc == 1 ? v : tk[1]; tk[2] = cc == 2 ? v : tk[2]; tk[3] = cc == 3 ? v : tk[3]; tk[4] = cc == 4 ? v : tk[4]; }
+                todo &= todo - 1;
+            }
+        }
+    } else if (active) {
+        if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl, r.blk_l);
 #pragma unroll
-    for (int c = 0; c < 6; ++c) s[c] = tl[c] - tk[c];
+        for (int c = 0; c < 6; ++c) s[c] = tl[c] - tk[c];
+    }
 }
 
 // Output space of a level is handed out in chunks of `ch` entries per wave: ONE device-wide atomic
@@ -100,7 +126,7 @@ __global__ __launch_bounds__(64) void k_kmer_level(FmdIndexView ix, int d, int s
         if (m_act == 0) continue;                     // a run of holes
         n_ext += (uint32_t)__popcll(m_act);
         uint64_t tk[6], s[6];
-        km_extend_back(ix, fmd_lds, act, x0, sz, tk, s);
+        km_extend_back<true>(ix, fmd_lds, act, x0, sz, thr, tk, s);
         // children c = 1..4 (ambiguous bases are skipped, correct.c:77); x[1] = running sum in
         // the order $,T,G,C,A (exact.c:81-86)
         const bool has1 = act && s[1] >= thr, has2 = act && s[2] >= thr, has3 = act && s[3] >= thr, has4 = act && s[4] >= thr;
@@ -163,7 +189,7 @@ __global__ __launch_bounds__(64) void k_kmer_emit(FmdIndexView ix, int w, int su
         if (m_act == 0) continue;
         n_ext += (uint32_t)__popcll(m_act);
         uint64_t tk[6], s[6];
-        km_extend_back(ix, fmd_lds, act, x0, sz, tk, s);
+        km_extend_back<false>(ix, fmd_lds, act, x0, sz, 0, tk, s);
         uint64_t mx = 0; int max_c = 6;
 #pragma unroll
         for (int c = 1; c <= 4; ++c) if (s[c] > mx) { mx = s[c]; max_c = c; }
