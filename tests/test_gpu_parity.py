@@ -445,3 +445,30 @@ def test_exact_cli_long_queries(gpu, gold, flag, name):
     """`fermi-amd exact [-s]` with queries longer than the per-read path handles (contigs against a read
     index): reach + chain work items (or, with -s, one chain-walking item) == `fermi exact` bytes."""
     assert _cli("exact", *flag, gold.path("pairs.fmd"), gold.path("pairs_contigs.fq.gz")) == gold.text_gz(name)
+
+
+@pytest.mark.parametrize("name", ["tiny", "special"])
+def test_backward_search_around_the_prefix_table(gpu, gold, oracle_lib, name):
+    """Queries shorter than, equal to and longer than the prefix-table depth, with ambiguous bases and
+    sentinels' neighbours in every position of the table window, hits and misses: == the oracle."""
+    from fermi_amd import api
+    d = api.DevIndex.open(gold.path(name + ".fmd"))
+    o = orcbind.OrcIndex(gold.path(name + ".fmd"))
+    rng = np.random.default_rng(5)
+    seqs, _, _ = o.retrieve(np.arange(0, 400, dtype=np.uint64), 128)
+    base = [s[:40][::-1].copy() for s in seqs if (s[:40] != 0).all()][:200]
+    for L in [1, 2, 3, 5, 7, 8, 9, 11, 12, 13, 16, 25, 40]:
+        qs = []
+        for b in base:
+            q = b[len(b) - L:].copy()
+            r = rng.integers(0, 4)
+            if r == 1: q[rng.integers(0, L)] = 5                                  # an N somewhere
+            elif r == 2: q[rng.integers(0, L)] = 1 + (q[rng.integers(0, L)] % 4)  # a (possible) mismatch
+            qs.append(q)
+        qs = np.array(qs, dtype=np.uint8)
+        cnt, beg, end = d.backward_search(qs)
+        wc, wb, we = o.backward_search(qs)
+        hit = wc > 0
+        assert np.array_equal(cnt, wc), L
+        assert np.array_equal(beg[hit], wb[hit]) and np.array_equal(end[hit], we[hit]), L
+    o.close(); d.close()
