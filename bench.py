@@ -618,6 +618,7 @@ def main():
     ovl = None
     if os.environ.get("FMD_BENCH_OVERLAP", "1") != "0":
         ovl = bench_overlap(torch, api, index, dev, n_reads, L, max(1, min(args.steps, 2)), min(args.warmup, 1), dist, world, rank, fmd_path)
+        torch.cuda.empty_cache()   # the 128 GB work area goes back to HIP: the library allocates outside torch's cache
 
     sm = km = None
     if os.environ.get("FMD_BENCH_SMEM", "1") != "0" or os.environ.get("FMD_BENCH_KMER", "1") != "0":
