@@ -211,6 +211,7 @@ int main(int argc, char *argv[])
         fprintf(stderr, "         remap      coverage of contigs by the reads, paired-end breaks (fermi remap)\n\n");
         return 1;
     }
+    setvbuf(stdout, 0, _IOFBF, 4 << 20); /* the outputs are hundreds of MB of short lines */
     if (fmd_device_count() <= 0) {
         fprintf(stderr, "[E::main] %s\n", fmd_strerror(FMD_E_NODEV));
         return 1;
