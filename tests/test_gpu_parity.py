@@ -472,3 +472,54 @@ def test_backward_search_around_the_prefix_table(gpu, gold, oracle_lib, name):
         assert np.array_equal(cnt, wc), L
         assert np.array_equal(beg[hit], wb[hit]) and np.array_equal(end[hit], we[hit]), L
     o.close(); d.close()
+
+
+def test_large_index_properties(gpu):
+    """Size-independent properties at a size the oracle would not finish in seconds (300 k reads, 6*10^7
+    symbols, index built on the GPU; the prefix table is 12 deep here like at the bench size):
+      * every read is found by backward search;
+      * fm_retrieve inverts the index: sequence id 2i is read i, 2i+1 its reverse complement, the ranks are a
+        permutation of the sentinels;
+      * overlap records: rank/len agree with retrieve, the `$read$` interval of a strand and of its
+        reverse strand mirror each other (x[0] <-> x[1]), and unique irreducible overlaps are mutual:
+        if b is the only right neighbour of a with overlap o, then a^1 follows b^1 with the same o;
+      * the table-free kernels (FMD_OVLP_UNFUSED path) give the same records."""
+    import os
+    N, L = 300_000, 100
+    reads = synth.reads(synth.DEFAULT_SEED, N)
+    bwt = gpu.build_bwt(reads)
+    d = gpu.DevIndex.from_bwt(bwt)
+    assert d.n == 2 * N * (L + 1)
+    cnt, beg, end = d.backward_search(reads)
+    assert (cnt >= 1).all()
+    ids = np.arange(2 * N, dtype=U64)
+    seqs, ln, rank = d.retrieve(ids, stride=128)
+    assert (ln == L).all()
+    assert np.array_equal(seqs[0::2, :L], reads)
+    assert np.array_equal(seqs[1::2, :L], (5 - reads)[:, ::-1])
+    assert np.array_equal(np.sort(rank), np.arange(2 * N, dtype=U64))
+    assert (end - beg + 1 == cnt).all()
+    rec, nei, seq = d.overlap(ids, 50, L, 4, check_left=False)
+    assert np.array_equal(rec["rank"], rank) and (rec["len"] == L).all()
+    ok = rec["status"] == 0
+    a = np.where(ok)[0]
+    assert np.array_equal(rec["k"][a, 0], rec["k"][a ^ 1, 1]) and np.array_equal(rec["k"][a, 2], rec["k"][a ^ 1, 2])
+    # mutual unique overlaps: map `$read$` interval starts back to sequence ids
+    row_of = np.full(2 * N, -1, dtype=np.int64)
+    row_of[rec["k"][a, 0].astype(np.int64)] = a
+    u = np.where(ok & (rec["n_nei"] == 1))[0]
+    b = row_of[nei["x"][u, 0, 0].astype(np.int64)]
+    good = b >= 0
+    u, b = u[good], b[good]
+    back = (rec["n_nei"][b ^ 1] == 1) & ok[b ^ 1] & (rec["k"][u, 2] == 1) & (rec["k"][b, 2] == 1)   # duplicated reads share a row
+    u, b = u[back], b[back]
+    assert len(u) > N // 2
+    assert np.array_equal(row_of[nei["x"][b ^ 1, 0, 0].astype(np.int64)], u ^ 1)
+    assert np.array_equal(nei["info"][b ^ 1, 0], nei["info"][u, 0])
+    os.environ["FMD_OVLP_UNFUSED"] = "1"
+    try:
+        rec2, nei2, seq2 = d.overlap(ids[:200_000], 50, L, 4, check_left=False)
+    finally:
+        del os.environ["FMD_OVLP_UNFUSED"]
+    assert rec2.tobytes() == rec[:200_000].tobytes() and nei2.tobytes() == nei[:200_000].tobytes() and seq2.tobytes() == seq[:200_000].tobytes()
+    d.close()
