@@ -523,3 +523,29 @@ def test_large_index_properties(gpu):
         del os.environ["FMD_OVLP_UNFUSED"]
     assert rec2.tobytes() == rec[:200_000].tobytes() and nei2.tobytes() == nei[:200_000].tobytes() and seq2.tobytes() == seq[:200_000].tobytes()
     d.close()
+
+
+def test_kmer_harvest_cross_checked_by_backward_search(gpu):
+    """Two independent kernels must agree at a size beyond the oracle: every (k+1)-mer the harvest calls
+    solid occurs at least min_occ times according to backward search, its k-mer prefix at least as often,
+    and no k-mer is reported twice (100 k reads with 1 % errors, index built on the GPU)."""
+    N, L, w, min_occ = 100_000, 100, 19, 3
+    reads = synth.reads(synth.DEFAULT_SEED, N, err=0.01)
+    d = gpu.DevIndex.from_bwt(gpu.build_bwt(reads))
+    suf = w - 15
+    b, k, v, cnt = d.kmer_collect(w, min_occ, suf)
+    assert len(b) == cnt[0] and len(b) > N
+    K = (k.astype(np.uint64) >> np.uint64(2)) << np.uint64(2 * suf) | b.astype(np.uint64)
+    assert len(np.unique(K)) == len(K)
+    sel = np.random.default_rng(1).choice(len(K), 200_000, replace=False)
+    Ks, best = K[sel], (k[sel] & 3).astype(np.uint8)
+    kmer = np.empty((len(sel), w + 1), dtype=np.uint8)
+    kmer[:, 0] = best + 1                                                        # the base the table predicts, to the left
+    for dd in range(w):
+        kmer[:, w - dd] = ((Ks >> np.uint64(2 * dd)) & np.uint64(3)).astype(np.uint8) + 1   # base_0 = rightmost
+    c1, _, _ = d.backward_search(kmer)
+    c0, _, _ = d.backward_search(np.ascontiguousarray(kmer[:, 1:]))
+    assert (c1 >= min_occ).all() and (c0 >= c1).all()
+    # the stored ratio code: max / rest, capped at 31, rounded (correct.c:67-75) -- rest = k-mer count - best - '$' - N >= 0
+    assert ((v[sel] >> 3) >= 1).all()
+    d.close()
