@@ -483,6 +483,7 @@ def test_large_index_properties(gpu):
       * overlap records: rank/len agree with retrieve, the `$read$` interval of a strand and of its
         reverse strand mirror each other (x[0] <-> x[1]), and unique irreducible overlaps are mutual:
         if b is the only right neighbour of a with overlap o, then a^1 follows b^1 with the same o;
+      * an indexed read is its own single, sentinel-closed SMEM with the multiplicity backward search reports;
       * the table-free kernels (FMD_OVLP_UNFUSED path) give the same records."""
     import os
     N, L = 300_000, 100
@@ -516,6 +517,12 @@ def test_large_index_properties(gpu):
     assert len(u) > N // 2
     assert np.array_equal(row_of[nei["x"][b ^ 1, 0, 0].astype(np.int64)], u ^ 1)
     assert np.array_equal(nei["info"][b ^ 1, 0], nei["info"][u, 0])
+    # an indexed, error-free read is its own single SMEM, closed by sentinels on both sides, as often as it occurs
+    mems = d.smem(reads[:50_000], 0, max_mem=8)
+    assert all(len(m) == 1 for m in mems)
+    m0 = np.concatenate(mems)
+    assert (m0["info"] == np.uint64(1 << 63 | L)).all() and (m0["x"][:, 1] < np.uint64(2 * N)).all()
+    assert np.array_equal(m0["x"][:, 2], cnt[:50_000])
     os.environ["FMD_OVLP_UNFUSED"] = "1"
     try:
         rec2, nei2, seq2 = d.overlap(ids[:200_000], 50, L, 4, check_left=False)
