@@ -556,3 +556,38 @@ def test_kmer_harvest_cross_checked_by_backward_search(gpu):
     # the stored ratio code: max / rest, capped at 31, rounded (correct.c:67-75) -- rest = k-mer count - best - '$' - N >= 0
     assert ((v[sel] >> 3) >= 1).all()
     d.close()
+
+
+@pytest.mark.parametrize("L,cov,mm,err", [(300, 40, 100, 0.0), (251, 60, 60, 0.003), (150, 25, 31, 0.01)])
+def test_overlap_longer_reads_vs_oracle(gpu, oracle_lib, L, cov, mm, err):
+    """Reads longer than the bench's 100 bp, deep coverage: candidate lists beyond 32 entries (the
+    lane-per-strand kernel), list capacities in the hundreds, intervals wider than the 64-position window
+    late into the walk -- every record, neighbour and sequence equals the oracle's."""
+    N = 3000
+    reads = synth.reads(synth.DEFAULT_SEED + L, N, L, cov, err)
+    bwt = gpu.build_bwt(reads)
+    d = gpu.DevIndex.from_bwt(bwt)
+    o = orcbind.OrcIndex(bwt=bwt)
+    ids = np.arange(2 * N, dtype=U64)
+
+    def compare(idl, max_len, max_nei):
+        rec, nei, seq = d.overlap(idl, mm, max_len, max_nei, check_left=True)
+        wrec, wnei, wseq = o.overlap_batch(idl, mm, max_len, max_nei, 4, check_left=True)
+        over = (rec["flags"] & gpu.OVLP_F_OVERFLOW) != 0       # capacity exceeded: the caller runs these again, larger
+        g = ~over
+        for f in ("rank", "k", "len", "status", "n_ovlp", "rbeg", "ext_len", "n_nei", "reserved"):
+            assert np.array_equal(rec[f][g], wrec[f][g]), f
+        for j in range(max_nei):
+            m = g & (wrec["n_nei"] > j)
+            assert nei[m, j].tobytes() == wnei[m, j].tobytes(), j
+        used = (wrec["len"] + np.maximum(wrec["ext_len"], 0)).astype(np.int64)
+        for i in np.where(g & (wrec["status"] == 0))[0][::7]:
+            assert np.array_equal(seq[i, :used[i]], wseq[i, :used[i]]), i
+        return rec, over
+    rec, over = compare(ids, L, 8)
+    if over.any():
+        assert over.sum() < len(ids) // 4
+        rec2, over2 = compare(ids[over], 2 * L, 64)
+        assert not over2.any()
+    assert (rec["n_ovlp"] > 32).sum() > 0 or cov < 40
+    d.close(); o.close()
