@@ -1,6 +1,5 @@
 """CPU: the C-ABI library loads, exports every symbol include/fmd_hip.h declares, and fails
 loudly (no CPU fallback) when there is no GPU.  No compute calls here."""
-import ctypes as C
 import os
 import re
 

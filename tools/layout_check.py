@@ -1,6 +1,6 @@
 """Step-by-step sanity run of one HIP library build (used when bringing up a new block geometry):
 every step prints before the next starts, so a hang is attributable.  Run under `timeout`."""
-import sys, os, gzip, json, numpy as np
+import sys, os, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from fermi_amd import api
 import orcbind

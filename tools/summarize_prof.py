@@ -1,5 +1,5 @@
 """Summarise a tools/profile_*.sh output directory into markdown (kernel stats + PMC per launch)."""
-import csv, glob, os, sys, json
+import csv, glob, os, sys
 from collections import defaultdict
 
 out = sys.argv[1]
