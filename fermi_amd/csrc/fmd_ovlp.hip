@@ -770,6 +770,16 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
         // the rest (too many candidates, wide intervals, fake forks, neighbour overflow): lane per strand
         k_ovl_nei<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, listB, d_rec, d_nei, max_nei, d_seq, seq_stride, q2, cl.lslow, cl.nslow);
     }
+#ifdef GRP_STATS
+    if (!getenv("FMD_OVLP_SLOW_ONLY")) {
+        uint32_t hs[16];
+        uint32_t *cls = (uint32_t *)((uint8_t *)listB + align_up(n * (size_t)cap * sizeof(fmd_intv_t), 256));
+        hipStreamSynchronize(st);
+        hipMemcpy(hs, cls, 64, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[grp stats] n16 %u n32 %u nslow %u | wave rounds %u, live lanes %u (%.1f %%), lanes of groups holding a strand %u (%.1f %%)\n",
+                hs[0], hs[1], hs[2], hs[10], hs[11], 100.0 * hs[11] / (64.0 * hs[10]), hs[12], 100.0 * hs[12] / (64.0 * hs[10]));
+    }
+#endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "overlap kernels"); return FMD_E_HIP; }
     return FMD_OK;

@@ -126,6 +126,9 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
 
         // ---- one round: forward extension + the six '$' boundaries, all from one gather
         const bool live = active && alive;
+#ifdef GRP_STATS
+        { const uint32_t nl = (uint32_t)__popcll(__ballot(live)); if (lane == 0) { atomicAdd(slow_n + 8, 1u); atomicAdd(slow_n + 9, nl); atomicAdd(slow_n + 10, (uint32_t)__popcll(act_m)); } }
+#endif
         const uint64_t ke = live ? x1 - 1 : NONE64, kb = live ? x0 - 1 : NONE64; // x0 >= mcnt[1] > 0 for base strings
         // the l sides lie at most 63 positions after the k sides: same block or the next one
         uint32_t bke, bkb, oke, okb;
