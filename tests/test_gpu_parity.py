@@ -591,3 +591,92 @@ def test_overlap_longer_reads_vs_oracle(gpu, oracle_lib, L, cov, mm, err):
         assert not over2.any()
     assert (rec["n_ovlp"] > 32).sum() > 0 or cov < 40
     d.close(); o.close()
+
+
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_fuzz_small_read_sets(gpu, oracle_lib, tmp_path, seed):
+    """Differential fuzzing over small, nasty read sets -- ragged lengths from 3 bases up (shorter than the
+    prefix table is deep), Ns, exact duplicates, reverse-complement palindromes, both strands: GPU
+    construction against `fermi build` (when the compiled reference travelled), then rank, backward search,
+    overlap discovery, check_left, SMEM (both modes), the k-mer harvest and the SMEM chain of a long
+    chimeric query, all against the oracle on the same index."""
+    import os, subprocess
+    from fermi_amd import hostlib
+    rng = np.random.default_rng(1000 + seed)
+    G = int(rng.integers(300, 1500))
+    genome = rng.integers(1, 5, G).astype(np.uint8)
+    reads = []
+    for _ in range(int(rng.integers(150, 500))):
+        L = int(rng.integers(3, 81)) if rng.random() < 0.8 else int(rng.integers(3, 14))
+        p = int(rng.integers(0, G - L))
+        r = genome[p:p + L].copy()
+        if rng.random() < 0.5:
+            r = (5 - r)[::-1].copy()
+        if rng.random() < 0.05:
+            r[int(rng.integers(0, L))] = 5
+        reads.append(r)
+    for _ in range(6):                                    # duplicates and palindromes
+        reads.append(reads[int(rng.integers(0, len(reads)))].copy())
+        x = genome[int(rng.integers(0, G - 12)):][:int(rng.integers(2, 12))]
+        reads.append(np.concatenate([x, (5 - x)[::-1]]))
+    tab = np.frombuffer(b"$ACGTN", dtype=np.uint8)
+    fq = str(tmp_path / "f.fq")
+    with open(fq, "w") as f:
+        for i, r in enumerate(reads):
+            f.write("@r%d\n%s\n+\n%s\n" % (i, tab[r].tobytes().decode(), "I" * len(r)))
+    trimmed = [r[:hostlib.trim_palindrome(r)] for r in reads]   # cmd.c:457-463
+    bwt = gpu.build_bwt(trimmed)
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "fermi")
+    if os.path.exists(ref):
+        fmd = str(tmp_path / "f.fmd")
+        subprocess.run([ref, "build", "-fo", fmd, fq], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        e = orcbind.OrcIndex(fmd)
+        assert np.array_equal(bwt, e.decode_all())
+        e.close()
+    d = gpu.DevIndex.from_bwt(bwt)
+    o = orcbind.OrcIndex(bwt=bwt)
+    n, n_seq = d.n, int(o.mcnt[1])
+    k = rng.integers(0, n, 20000).astype(U64); l = np.minimum(k + rng.integers(0, 200, 20000).astype(U64), U64(n - 1))
+    k[::97] = NONE
+    gk, gl = d.rank2a(k, l); wk, wl = o.rank2a(k, l)
+    assert np.array_equal(gk, wk) and np.array_equal(gl, wl)
+    # backward search: the reads, mutated copies, by length
+    qs = [r.copy() for r in trimmed] + [r.copy() for r in trimmed[:200]]
+    for q in qs[len(trimmed):]:
+        q[int(rng.integers(0, len(q)))] = int(rng.integers(1, 6))
+    cnt, beg, end = d.backward_search(qs)
+    for Lq in sorted({len(q) for q in qs}):
+        idx = [i for i, q in enumerate(qs) if len(q) == Lq]
+        wc, wb, we = o.backward_search(np.array([qs[i] for i in idx], dtype=np.uint8))
+        assert np.array_equal(cnt[idx], wc), Lq
+        h = wc > 0
+        assert np.array_equal(beg[idx][h], wb[h]) and np.array_equal(end[idx][h], we[h]), Lq
+    # overlap discovery + check_left, short minimum so that short reads overlap too
+    ids = np.arange(n_seq, dtype=U64)
+    for mm in (5, 13):
+        rec, nei, seq = d.overlap(ids, mm, 80, 16, check_left=True)
+        wrec, wnei, wseq = o.overlap_batch(ids, mm, 80, 16, 2, check_left=True)
+        g = (rec["flags"] & gpu.OVLP_F_OVERFLOW) == 0
+        assert g.sum() > n_seq // 2
+        for f in ("rank", "k", "len", "status", "n_ovlp", "rbeg", "ext_len", "n_nei", "reserved"):
+            assert np.array_equal(rec[f][g], wrec[f][g]), (mm, f)
+        for j in range(16):
+            m = g & (wrec["n_nei"] > j)
+            assert nei[m, j].tobytes() == wnei[m, j].tobytes(), (mm, j)
+    # SMEM, both modes, reads and mutated reads
+    for sm in (0, 1):
+        got = d.smem(qs[:300] + qs[len(trimmed):], sm, max_mem=128)
+        for q, m in zip(qs[:300] + qs[len(trimmed):], got):
+            assert m.tobytes() == o.smem(q, sm).tobytes(), sm
+    # k-mer harvest
+    for (w, mo) in ((7, 2), (11, 1)):
+        B, K, V, c2 = d.kmer_collect(w, mo, 1)
+        per_bucket, wc2 = o.ec_collect(w, mo, 1)
+        wB = np.concatenate([np.full(len(kv[0]), b, dtype=np.uint32) for b, kv in enumerate(per_bucket)])
+        wK = np.concatenate([kv[0] for kv in per_bucket]); wV = np.concatenate([kv[1] for kv in per_bucket])
+        a, b_ = np.lexsort([V, K, B]), np.lexsort([wV, wK, wB])
+        assert np.array_equal(B[a], wB[b_]) and np.array_equal(K[a], wK[b_]) and np.array_equal(V[a], wV[b_]) and list(c2) == list(wc2), (w, mo)
+    # the chain over a long chimeric query
+    long_q = np.concatenate([t for t in trimmed[:40] if (t <= 4).all()] + [genome[:200]])
+    assert d.smem_chain(long_q, max_len=128).tobytes() == o.smem(long_q, 0).tobytes()
+    d.close(); o.close()
