@@ -680,3 +680,61 @@ def test_fuzz_small_read_sets(gpu, oracle_lib, tmp_path, seed):
     long_q = np.concatenate([t for t in trimmed[:40] if (t <= 4).all()] + [genome[:200]])
     assert d.smem_chain(long_q, max_len=128).tobytes() == o.smem(long_q, 0).tobytes()
     d.close(); o.close()
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_fuzz_cli_against_reference_binary(gpu, tmp_path, seed):
+    """Whole commands on random small read sets against the compiled reference (when it travelled):
+    build, seqsort, unitig (with and without -r), exact (-s too), correct, remap (three option sets).
+    A command the reference itself cannot finish on an input (abort, time-out) is skipped for that input."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref, amd = os.path.join(root, "oracle", "_ref", "fermi"), os.path.join(root, "fermi_amd", "bin", "fermi-amd")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/fermi is not here")
+    rng = np.random.default_rng(7000 + seed)
+    G = int(rng.integers(800, 4000))
+    genome = rng.integers(1, 5, G).astype(np.uint8)
+    if seed % 3 == 0:                                   # a repeat, so that forks and bubbles appear
+        genome[G // 2:G // 2 + 150] = genome[50:200]
+    tab = np.frombuffer(b"$ACGTN", dtype=np.uint8)
+    Lmax = int(rng.integers(36, 90))
+    fq = str(tmp_path / "r.fq")
+    with open(fq, "w") as f:
+        for i in range(int(G * rng.integers(15, 40) / Lmax)):
+            L = Lmax if rng.random() < 0.7 else int(rng.integers(25, Lmax + 1))
+            p = int(rng.integers(0, G - L))
+            r = genome[p:p + L].copy()
+            if rng.random() < 0.5:
+                r = (5 - r)[::-1].copy()
+            if rng.random() < 0.3:
+                j = int(rng.integers(0, L)); r[j] = 1 + (r[j] + int(rng.integers(0, 3))) % 4
+            f.write("@r%d\n%s\n+\n%s\n" % (i, tab[r].tobytes().decode(), "".join(chr(33 + int(q)) for q in rng.integers(5, 41, L))))
+
+    def run(exe, args, out):
+        try:
+            with open(out, "wb") as fo:
+                p = subprocess.run([exe] + args, stdout=fo, stderr=subprocess.DEVNULL, timeout=60)
+            return p.returncode == 0
+        except subprocess.TimeoutExpired:
+            return False
+    T = str(tmp_path)
+    assert run(ref, ["build", "-fo", T + "/b.fmd", fq], T + "/b.log") and run(amd, ["build", "-fo", T + "/a.fmd", fq], T + "/a.log")
+    assert open(T + "/a.fmd", "rb").read() == open(T + "/b.fmd", "rb").read()
+    mm = str(int(rng.integers(12, 24)))
+    cmds = [("seqsort", ["seqsort", T + "/b.fmd"], None),
+            ("unitig", ["unitig", "-l", mm, T + "/b.fmd"], ["unitig", "-l", mm, "-t1", T + "/b.fmd"]),
+            ("unitig-r", ["unitig", "-l", mm, "-r", T + "/b.seqsort", T + "/b.fmd"], ["unitig", "-l", mm, "-t1", "-r", T + "/b.seqsort", T + "/b.fmd"]),
+            ("exact", ["exact", T + "/b.fmd", fq], None), ("exact-s", ["exact", "-s", T + "/b.fmd", fq], None),
+            ("correct", ["correct", "-k", "13", "-t", "3", T + "/b.fmd", fq], ["correct", "-k", "13", "-t1", T + "/b.fmd", fq]),
+            ("remap-u", ["remap", T + "/b.fmd", T + "/b.unitig"], None),
+            ("remap-p", ["remap", "-l", "10", "-D", "400", "-r", T + "/b.seqsort", T + "/b.fmd", T + "/b.unitig"], None),
+            ("remap-c", ["remap", "-l", "10", "-D", "400", "-c", "1", "-r", T + "/b.seqsort", T + "/b.fmd", T + "/b.unitig"], None)]
+    compared = 0
+    for name, a_args, r_args in cmds:
+        if not run(ref, r_args or a_args, T + "/b." + name):
+            continue                                    # the reference itself gives up on this input
+        assert run(amd, a_args, T + "/a." + name), name
+        assert open(T + "/a." + name, "rb").read() == open(T + "/b." + name, "rb").read(), name
+        compared += 1
+    assert compared >= 5
