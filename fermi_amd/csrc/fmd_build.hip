@@ -14,17 +14,17 @@
 __global__ void k_build_text(size_t n_reads, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ off,
                              uint8_t *__restrict__ text)
 {
-    // one 64-thread group per read
-    const size_t r = blockIdx.x;
-    if (r >= n_reads) return;
-    const uint64_t o = off[r], len = off[r + 1] - o;
-    const uint64_t t0 = 2 * (o + r); // both strands of all earlier reads, each with its '$'
-    for (uint64_t i = threadIdx.x; i < len; i += blockDim.x) {
-        const uint8_t c = reads[o + i];
-        text[t0 + i] = c;
-        text[t0 + len + 1 + (len - 1 - i)] = (c >= 1 && c <= 4) ? (uint8_t)(5 - c) : c;
+    // one 64-thread group per read (grid-stride: the grid is capped)
+    for (size_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+        const uint64_t o = off[r], len = off[r + 1] - o;
+        const uint64_t t0 = 2 * (o + r); // both strands of all earlier reads, each with its '$'
+        for (uint64_t i = threadIdx.x; i < len; i += blockDim.x) {
+            const uint8_t c = reads[o + i];
+            text[t0 + i] = c;
+            text[t0 + len + 1 + (len - 1 - i)] = (c >= 1 && c <= 4) ? (uint8_t)(5 - c) : c;
+        }
+        if (threadIdx.x == 0) { text[t0 + len] = 0; text[t0 + 2 * len + 1] = 0; }
     }
-    if (threadIdx.x == 0) { text[t0 + len] = 0; text[t0 + 2 * len + 1] = 0; }
 }
 
 // distance from text position t to the '$' closing its sequence
@@ -42,41 +42,46 @@ template <class Rem>
 __global__ void k_chunk_keys(const uint8_t *__restrict__ text, uint64_t n, const uint32_t *__restrict__ order, int chunk,
                              Rem rem, uint64_t *__restrict__ keys)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t t = order ? order[i] : i;
-    const uint32_t r = rem(t), o0 = 21u * (uint32_t)chunk;
-    uint64_t key = 0;
-    if (o0 <= r) {
-        const uint32_t m = r - o0 + 1 < 21 ? r - o0 + 1 : 21; // symbols up to and including the '$'
-        for (uint32_t j = 0; j < m; ++j) key |= (uint64_t)text[t + o0 + j] << (3 * (20 - j));
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t t = order ? order[i] : i;
+        const uint32_t r = rem(t), o0 = 21u * (uint32_t)chunk;
+        uint64_t key = 0;
+        if (o0 <= r) {
+            const uint32_t m = r - o0 + 1 < 21 ? r - o0 + 1 : 21; // symbols up to and including the '$'
+            for (uint32_t j = 0; j < m; ++j) key |= (uint64_t)text[t + o0 + j] << (3 * (20 - j));
+        }
+        keys[i] = key;
     }
-    keys[i] = key;
 }
 
 __global__ void k_iota32(uint32_t *a, uint64_t n)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) a[i] = (uint32_t)i;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) a[i] = (uint32_t)i;
 }
 
 __global__ void k_emit_bwt(const uint8_t *__restrict__ text, const uint32_t *__restrict__ order, uint64_t n, uint8_t *__restrict__ bwt)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t t = order[i];
-    bwt[i] = t ? text[t - 1] : 0; // text[t-1] is '$' (=0) exactly when t starts a sequence
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t t = order[i];
+        bwt[i] = t ? text[t - 1] : 0; // text[t-1] is '$' (=0) exactly when t starts a sequence
+    }
 }
 
 __global__ void k_seq_ends(size_t n_reads, const uint64_t *__restrict__ off, uint64_t *__restrict__ send)
 {
-    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
-    const uint64_t o = off[r], len = off[r + 1] - o, t0 = 2 * (o + r);
-    send[2 * r] = t0 + len; send[2 * r + 1] = t0 + 2 * len + 1;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t o = off[r], len = off[r + 1] - o, t0 = 2 * (o + r);
+        send[2 * r] = t0 + len; send[2 * r + 1] = t0 + 2 * len + 1;
+    }
 }
 
-static inline unsigned nblk(uint64_t n, unsigned t) { return (unsigned)((n + t - 1) / t); }
+// blocks for n items, t threads each: at most 2^31 threads per launch (the dispatch packet counts work-items in 32
+// bits; the kernels above loop with a grid stride)
+static inline unsigned nblk(uint64_t n, unsigned t)
+{
+    const uint64_t b = (n + t - 1) / t, cap = (1ull << 31) / t;
+    return (unsigned)(b < cap ? (b ? b : 1) : cap);
+}
 
 struct DevPtr { void *p = nullptr; ~DevPtr() { if (p) hipFree(p); } };
 #define DALLOC(buf, bytes) do { hipError_t e__ = hipMalloc(&(buf).p, (bytes) ? (bytes) : 16); \
@@ -93,23 +98,23 @@ template <class Rem>
 __global__ void k_chunk_keys64(const uint8_t *__restrict__ text, uint64_t m, const uint64_t *__restrict__ ids, int chunk, Rem rem,
                                uint64_t *__restrict__ keys)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const uint64_t t = ids[i];
-    const uint32_t r = rem(t), o0 = 21u * (uint32_t)chunk;
-    uint64_t key = 0;
-    if (o0 <= r) {
-        const uint32_t mm = r - o0 + 1 < 21 ? r - o0 + 1 : 21;
-        for (uint32_t j = 0; j < mm; ++j) key |= (uint64_t)text[t + o0 + j] << (3 * (20 - j));
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t t = ids[i];
+        const uint32_t r = rem(t), o0 = 21u * (uint32_t)chunk;
+        uint64_t key = 0;
+        if (o0 <= r) {
+            const uint32_t mm = r - o0 + 1 < 21 ? r - o0 + 1 : 21;
+            for (uint32_t j = 0; j < mm; ++j) key |= (uint64_t)text[t + o0 + j] << (3 * (20 - j));
+        }
+        keys[i] = key;
     }
-    keys[i] = key;
 }
 __global__ void k_emit_bwt64(const uint8_t *__restrict__ text, const uint64_t *__restrict__ ids, uint64_t m, uint8_t *__restrict__ bwt)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const uint64_t t = ids[i];
-    bwt[i] = t ? text[t - 1] : 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t t = ids[i];
+        bwt[i] = t ? text[t - 1] : 0;
+    }
 }
 
 static int build_bucketed(hipStream_t st, const uint8_t *text, uint64_t n, uint32_t max_len, int uniform_len, RemRagged rr, uint8_t *bwt)
@@ -176,7 +181,7 @@ extern "C" int fmd_build_bwt_dev(int device, void *stream_, size_t n_reads, cons
     DevPtr text, keys_a, keys_b, ord_a, ord_b, send, tmp;
     uint8_t *bwt = nullptr;
     DALLOC(text, n + 64);
-    k_build_text<<<(unsigned)n_reads, 64, 0, st>>>(n_reads, d_reads, d_off, (uint8_t *)text.p);
+    k_build_text<<<(unsigned)(n_reads < (1u << 24) ? n_reads : (1u << 24)), 64, 0, st>>>(n_reads, d_reads, d_off, (uint8_t *)text.p);
     RemRagged rr{nullptr, 2 * n_reads};
     if (!uniform_len) {
         DALLOC(send, 2 * n_reads * 8);
@@ -245,19 +250,18 @@ extern "C" int fmd_build_bwt(int device, size_t n_reads, const uint8_t *reads, c
 // (ropebwt.c:132-136) and rld_restore re-encodes (rld.c:295-308).
 __global__ void k_run_bytes(const uint32_t *__restrict__ run_len, uint64_t n_runs, uint64_t *__restrict__ nb)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_runs) nb[i] = (run_len[i] + 30) / 31;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_runs; i += (uint64_t)gridDim.x * blockDim.x) nb[i] = (run_len[i] + 30) / 31;
 }
 __global__ void k_run_emit(const uint8_t *__restrict__ run_sym, const uint32_t *__restrict__ run_len, uint64_t n_runs,
                            const uint64_t *__restrict__ start, uint8_t *__restrict__ out)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_runs) return;
-    uint32_t l = run_len[i];
-    uint8_t *p = out + start[i];
-    const uint8_t c = run_sym[i];
-    for (; l > 31; l -= 31) *p++ = (uint8_t)(31 << 3 | c);
-    *p = (uint8_t)(l << 3 | c);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_runs; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t l = run_len[i];
+        uint8_t *p = out + start[i];
+        const uint8_t c = run_sym[i];
+        for (; l > 31; l -= 31) *p++ = (uint8_t)(31 << 3 | c);
+        *p = (uint8_t)(l << 3 | c);
+    }
 }
 
 extern "C" int fmd_bwt_to_rle6(int device, const uint8_t *d_bwt, uint64_t n, uint8_t **h_rle6, uint64_t *n_bytes)

@@ -39,29 +39,29 @@ extern "C" int fmd_device_count(void)
 // one thread per 32-position chunk
 __global__ void k_bwt_to_planes(const uint8_t *__restrict__ bwt, uint64_t n, uint4 *__restrict__ blocks, uint64_t n_chunks)
 {
-    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_chunks) return;
-    const uint64_t p0 = c * 32;
-    uint32_t a = 0, b = 0, d = 0;
-    if (p0 + 32 <= n) {
-        const uint4 *src = (const uint4 *)(bwt + p0); // hipMalloc'd + 32-byte stride: aligned
-        const uint4 v0 = src[0], v1 = src[1];
-        const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p0 = c * 32;
+        uint32_t a = 0, b = 0, d = 0;
+        if (p0 + 32 <= n) {
+            const uint4 *src = (const uint4 *)(bwt + p0); // hipMalloc'd + 32-byte stride: aligned
+            const uint4 v0 = src[0], v1 = src[1];
+            const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t s = (w[i] >> (8 * j)) & 7;
-                a |= (s & 1) << (4 * i + j); b |= ((s >> 1) & 1) << (4 * i + j); d |= ((s >> 2) & 1) << (4 * i + j);
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t s = (w[i] >> (8 * j)) & 7;
+                    a |= (s & 1) << (4 * i + j); b |= ((s >> 1) & 1) << (4 * i + j); d |= ((s >> 2) & 1) << (4 * i + j);
+                }
+        } else {
+            for (int i = 0; i < 32 && p0 + i < n; ++i) {
+                const uint32_t s = bwt[p0 + i] & 7;
+                a |= (s & 1) << i; b |= ((s >> 1) & 1) << i; d |= ((s >> 2) & 1) << i;
             }
-    } else {
-        for (int i = 0; i < 32 && p0 + i < n; ++i) {
-            const uint32_t s = bwt[p0 + i] & 7;
-            a |= (s & 1) << i; b |= ((s >> 1) & 1) << i; d |= ((s >> 2) & 1) << i;
         }
+        uint4 *dst = blocks + fmd_word_u4(c); // 32-position word c -> its block and chunk
+        dst->x = a; dst->y = b; dst->z = d;
     }
-    uint4 *dst = blocks + fmd_word_u4(c); // 32-position word c -> its block and chunk
-    dst->x = a; dst->y = b; dst->z = d;
 }
 
 // --------------------------------------------------------- transcode: scatter of (sym,len) runs
@@ -91,17 +91,16 @@ __device__ __forceinline__ void fmd_or_run(uint32_t *words, uint64_t pos, uint64
 // RLE\6 stream: byte = len<<3 | sym, len 1..31 (ropebwt.c:132-136; reader rld.c:295-308)
 __global__ void k_rle6_len(const uint8_t *__restrict__ runs, uint64_t n, uint64_t *__restrict__ len)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) len[i] = runs[i] >> 3;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) len[i] = runs[i] >> 3;
 }
 __global__ void k_rle6_scatter(const uint8_t *__restrict__ runs, uint64_t n, const uint64_t *__restrict__ start,
                                uint32_t *__restrict__ words, uint64_t *__restrict__ sym_total)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t l = runs[i] >> 3, c = runs[i] & 7;
-    if (l) fmd_or_run(words, start[i], l, c);
-    if (i == n - 1) *sym_total = start[i] + l;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t l = runs[i] >> 3, c = runs[i] & 7;
+        if (l) fmd_or_run(words, start[i], l, c);
+        if (i == n - 1) *sym_total = start[i] + l;
+    }
 }
 
 // RLD\2 payload (rld.c:111-175 writer; rld.h:77-94 decoder): 64-byte blocks, header = counts of
@@ -114,8 +113,7 @@ __device__ __forceinline__ uint64_t rld_hdr_size(const uint64_t *blk)
 }
 __global__ void k_rld_sizes(const uint64_t *__restrict__ w, uint64_t n_rld_blocks, uint64_t *__restrict__ size)
 {
-    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < n_rld_blocks) size[b] = rld_hdr_size(w + (b + 1) * 8); // next header describes block b
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_rld_blocks; b += (uint64_t)gridDim.x * blockDim.x) size[b] = rld_hdr_size(w + (b + 1) * 8); // next header describes block b
 }
 __device__ __forceinline__ uint64_t rld_peek(const uint64_t *w, uint32_t bit /*0..511*/)
 {
@@ -128,66 +126,73 @@ __device__ __forceinline__ uint64_t rld_peek(const uint64_t *w, uint32_t bit /*0
 __global__ void k_rld_scatter(const uint64_t *__restrict__ w, uint64_t n_rld_blocks, const uint64_t *__restrict__ start,
                               uint32_t *__restrict__ words, uint64_t *__restrict__ sym_total)
 {
-    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_rld_blocks) return;
-    const uint64_t *blk = w + b * 8;
-    uint32_t bit = (((uint32_t)blk[0] >> 31) ? 4u : 2u) * 64u;
-    uint64_t pos = start[b];
-    for (;;) {
-        const uint64_t x = rld_peek(blk, bit);
-        uint64_t len; uint32_t sym;
-        if (x >> 63) { len = 1; sym = (uint32_t)(x >> 60) & 7; bit += 4; }
-        else {
-            const int z = x ? __clzll((long long)x) : 64;
-            if (z >= 6) break;                                   // zero padding: block exhausted
-            const int gw = 2 * z + 1, nlow = (int)(x >> (64 - gw)) - 1;
-            len = ((x << gw) >> (64 - nlow)) | (1ull << nlow);
-            sym = (uint32_t)((x << (gw + nlow)) >> 61);
-            bit += (uint32_t)(gw + nlow + 3);
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_rld_blocks; b += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t *blk = w + b * 8;
+        uint32_t bit = (((uint32_t)blk[0] >> 31) ? 4u : 2u) * 64u;
+        uint64_t pos = start[b];
+        for (;;) {
+            const uint64_t x = rld_peek(blk, bit);
+            uint64_t len; uint32_t sym;
+            if (x >> 63) { len = 1; sym = (uint32_t)(x >> 60) & 7; bit += 4; }
+            else {
+                const int z = x ? __clzll((long long)x) : 64;
+                if (z >= 6) break;                                   // zero padding: block exhausted
+                const int gw = 2 * z + 1, nlow = (int)(x >> (64 - gw)) - 1;
+                len = ((x << gw) >> (64 - nlow)) | (1ull << nlow);
+                sym = (uint32_t)((x << (gw + nlow)) >> 61);
+                bit += (uint32_t)(gw + nlow + 3);
+            }
+            fmd_or_run(words, pos, len, sym);
+            pos += len;
         }
-        fmd_or_run(words, pos, len, sym);
-        pos += len;
+        if (b == n_rld_blocks - 1) *sym_total = pos;
     }
-    if (b == n_rld_blocks - 1) *sym_total = pos;
 }
 
 // -------------------------------------------------------------- per-block symbol counts + meta
-__global__ void k_block_counts(const uint4 *__restrict__ blocks, uint64_t n_blocks, uint64_t *__restrict__ bc)
-{
-    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_blocks) return;
-    uint32_t n[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int c = 0; c < FMD_BLK_CHUNKS; ++c) {
-        const uint4 v = blocks[b * FMD_BLK_U4 + c];
-        n[0] += __builtin_popcount(~v.z & ~v.y & ~v.x); n[1] += __builtin_popcount(~v.z & ~v.y & v.x);
-        n[2] += __builtin_popcount(~v.z & v.y & ~v.x);  n[3] += __builtin_popcount(~v.z & v.y & v.x);
-        n[4] += __builtin_popcount(v.z & ~v.y & ~v.x);  n[5] += __builtin_popcount(v.z & ~v.y & v.x);
-    }
-#pragma unroll
-    for (int s = 0; s < 6; ++s) bc[(uint64_t)s * n_blocks + b] = n[s];
-}
-__global__ void k_write_meta(uint4 *__restrict__ blocks, uint64_t n_blocks, const uint64_t *__restrict__ acc)
-{
-    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_blocks) return;
-    uint64_t a[6];
-#pragma unroll
-    for (int s = 0; s < 6; ++s) a[s] = acc[(uint64_t)s * n_blocks + b];
+// Counts fit a byte for 96-position blocks and a 16-bit word for 256-position ones; the six running
+// sums are then taken one symbol at a time through ONE 8-byte-per-block buffer, so finishing an index
+// costs 20 (14) bytes per block on top of the index itself -- the 1.4e11-symbol index (1.5e9 blocks)
+// must fit next to its own 94 GB.
 #if FMD_BLK64
-    // meta_0..2 in the .w of the three plane chunks, meta_3..6 = the fourth uint4 (fmd_wave.h)
-    blocks[b * 4 + 0].w = (uint32_t)a[0]; blocks[b * 4 + 1].w = (uint32_t)a[1]; blocks[b * 4 + 2].w = (uint32_t)a[2];
-    blocks[b * 4 + 3] = make_uint4((uint32_t)a[3], (uint32_t)a[4],
-                                   (uint32_t)((a[0] >> 32) & 0xff) | (uint32_t)((a[1] >> 32) & 0xff) << 8 |
-                                   (uint32_t)((a[2] >> 32) & 0xff) << 16 | (uint32_t)((a[3] >> 32) & 0xff) << 24,
-                                   (uint32_t)((a[4] >> 32) & 0xff));
+typedef uint8_t fmd_bc_t;
 #else
-#pragma unroll
-    for (int s = 0; s < 6; ++s) blocks[b * 8 + s].w = (uint32_t)a[s];
-    blocks[b * 8 + 6].w = (uint32_t)((a[0] >> 32) & 0xff) | (uint32_t)((a[1] >> 32) & 0xff) << 8 |
-                          (uint32_t)((a[2] >> 32) & 0xff) << 16 | (uint32_t)((a[3] >> 32) & 0xff) << 24;
-    blocks[b * 8 + 7].w = (uint32_t)((a[4] >> 32) & 0xff) | (uint32_t)((a[5] >> 32) & 0xff) << 8;
+typedef uint16_t fmd_bc_t;
 #endif
+__global__ void k_block_counts(const uint4 *__restrict__ blocks, uint64_t n_blocks, fmd_bc_t *__restrict__ bc)
+{
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t n[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < FMD_BLK_CHUNKS; ++c) {
+            const uint4 v = blocks[b * FMD_BLK_U4 + c];
+            n[0] += __builtin_popcount(~v.z & ~v.y & ~v.x); n[1] += __builtin_popcount(~v.z & ~v.y & v.x);
+            n[2] += __builtin_popcount(~v.z & v.y & ~v.x);  n[3] += __builtin_popcount(~v.z & v.y & v.x);
+            n[4] += __builtin_popcount(v.z & ~v.y & ~v.x);  n[5] += __builtin_popcount(v.z & ~v.y & v.x);
+        }
+#pragma unroll
+        for (int s = 0; s < 6; ++s) bc[(uint64_t)s * n_blocks + b] = (fmd_bc_t)n[s];
+    }
+}
+// the count of symbol s before each block into its place in the block's meta words (fmd_wave.h)
+__global__ void k_write_meta_sym(uint4 *__restrict__ blocks, uint64_t n_blocks, const uint64_t *__restrict__ acc, int s)
+{
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t a = acc[b];
+        const uint32_t lo = (uint32_t)a, hi = (uint32_t)(a >> 32) & 0xff;
+    #if FMD_BLK64
+        // meta_0..2 in the .w of the three plane chunks, meta_3..6 = the fourth uint4; N is not stored
+        uint4 *m = blocks + b * 4;
+        if (s < 3) m[s].w = lo; else if (s == 3) m[3].x = lo; else if (s == 4) m[3].y = lo;
+        if (s < 4) m[3].z = (m[3].z & ~(0xffu << (8 * s))) | hi << (8 * s);
+        else if (s == 4) m[3].w = hi;
+    #else
+        uint4 *m = blocks + b * 8;
+        m[s].w = lo;
+        if (s < 4) m[6].w = (m[6].w & ~(0xffu << (8 * s))) | hi << (8 * s);
+        else m[7].w = (m[7].w & ~(0xffu << (8 * (s - 4)))) | hi << (8 * (s - 4));
+    #endif
+    }
 }
 
 // ------------------------------------------------------------------ prefix table (FmdIndexView::ptab)
@@ -203,10 +208,10 @@ __global__ void k_ptab_level(FmdIndexView ix, int d, const uint4 *__restrict__ p
     else {
         const uint4 e = prev[i & ((1ull << (2 * (d - 1))) - 1)];
         k = (uint64_t)e.y << 32 | e.x; l = (uint64_t)e.w << 32 | e.z;
-        if (k <= l) { // rank_c(k - 1), rank_c(l)  (k >= 1: position 0 holds a sentinel suffix)
+        if (k <= l) { // rank_c(k - 1), rank_c(l)  (k >= 1 in a real index: position 0 holds a sentinel suffix)
             uint32_t b, o;
-            fmd_split(k - 1, b, o);
-            const uint64_t rk = fmd_block_rank1(ix.blocks + (size_t)b * FMD_BLK_U4, 0, o + 1, c, b);
+            uint64_t rk = 0;
+            if (k) { fmd_split(k - 1, b, o); rk = fmd_block_rank1(ix.blocks + (size_t)b * FMD_BLK_U4, 0, o + 1, c, b); }
             fmd_split(l, b, o);
             const uint64_t rl = fmd_block_rank1(ix.blocks + (size_t)b * FMD_BLK_U4, 0, o + 1, c, b);
             k = ix.cnt[c] + rk; l = ix.cnt[c] + rl - 1;
@@ -244,6 +249,20 @@ static int build_ptab(fmd_dev *h)
 }
 
 // --------------------------------------------------------------------------------- host side
+struct FmdWiden { __host__ __device__ uint64_t operator()(fmd_bc_t v) const { return (uint64_t)v; } };
+static int scan_counts(const fmd_bc_t *d_in, uint64_t *d_out, uint64_t n, hipStream_t st)
+{
+    hipcub::TransformInputIterator<uint64_t, FmdWiden, const fmd_bc_t *> in(d_in, FmdWiden());
+    void *tmp = nullptr; size_t tmp_bytes = 0;
+    FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, in, d_out, (size_t)n, st));
+    FMD_HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, in, d_out, (size_t)n, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    hipFree(tmp);
+    FMD_HIP_TRY(e); FMD_HIP_TRY(e2);
+    return FMD_OK;
+}
+
 static int scan_u64(uint64_t *d_in, uint64_t *d_out, uint64_t n, hipStream_t st)
 {
     void *tmp = nullptr; size_t tmp_bytes = 0;
@@ -256,7 +275,13 @@ static int scan_u64(uint64_t *d_in, uint64_t *d_out, uint64_t n, hipStream_t st)
     return FMD_OK;
 }
 
-static inline unsigned nblk(uint64_t n, unsigned t) { return (unsigned)((n + t - 1) / t); }
+// blocks for n items, t threads each: at most 2^31 threads per launch (the dispatch packet counts work-items in 32
+// bits; the kernels above loop with a grid stride)
+static inline unsigned nblk(uint64_t n, unsigned t)
+{
+    const uint64_t b = (n + t - 1) / t, cap = (1ull << 31) / t;
+    return (unsigned)(b < cap ? (b ? b : 1) : cap);
+}
 
 static int dev_alloc_index(int device, uint64_t n_sym, fmd_dev **out)
 {
@@ -287,20 +312,22 @@ static int dev_alloc_index(int device, uint64_t n_sym, fmd_dev **out)
 static int finish_index(fmd_dev *h)
 {
     const uint64_t nb = h->n_blocks;
-    uint64_t *bc = nullptr, *acc = nullptr;
-    FMD_HIP_TRY(hipMalloc((void **)&bc, 6 * nb * 8));
-    hipError_t e = hipMalloc((void **)&acc, 6 * nb * 8);
+    fmd_bc_t *bc = nullptr; uint64_t *acc = nullptr;
+    FMD_HIP_TRY(hipMalloc((void **)&bc, 6 * nb * sizeof(fmd_bc_t)));
+    hipError_t e = hipMalloc((void **)&acc, nb * 8);
     if (e != hipSuccess) { hipFree(bc); fmd_set_hip_error(e, "hipMalloc(scan)"); return FMD_E_NOMEM; }
     k_block_counts<<<nblk(nb, 256), 256>>>(h->blocks, nb, bc);
     int rc = FMD_OK;
-    for (int s = 0; s < 6 && rc == FMD_OK; ++s) rc = scan_u64(bc + s * nb, acc + s * nb, nb, 0);
+    uint64_t last[6] = {0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < 6 && rc == FMD_OK; ++s) { // one symbol at a time through the same buffer
+        rc = scan_counts(bc + (uint64_t)s * nb, acc, nb, 0);
+        if (rc != FMD_OK) break;
+        k_write_meta_sym<<<nblk(nb, 256), 256>>>(h->blocks, nb, acc, s);
+        // marginal count = prefix at the pad block
+        if (hipMemcpy(&last[s], acc + (nb - 1), 8, hipMemcpyDeviceToHost) != hipSuccess) rc = FMD_E_HIP;
+    }
     if (rc == FMD_OK) {
-        k_write_meta<<<nblk(nb, 256), 256>>>(h->blocks, nb, acc);
-        // marginal counts = prefix at the pad block (positions past the end are '$'-coded zeros:
-        // correct mcnt[1] for them)
-        uint64_t last[6];
-        for (int s = 0; s < 6; ++s)
-            hipMemcpy(&last[s], acc + s * nb + (nb - 1), 8, hipMemcpyDeviceToHost);
+        // positions past the end are '$'-coded zeros: correct mcnt[1] for them
         const uint64_t pad = (nb - 1) * FMD_BLK_SYMS - h->mcnt[0];
         last[0] -= pad;
         h->mcnt[1] = last[0];
@@ -490,17 +517,17 @@ extern "C" int fmd_dev_export_bwt(fmd_dev_t *h, uint64_t first, uint64_t n, uint
 // last position must give the marginal counts.  One thread per position, blocks read in order.
 __global__ void k_check_rank(FmdIndexView ix, unsigned long long *__restrict__ bad /* [0] count, [1] first position */)
 {
-    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= ix.n_sym) return;
-    uint64_t a[6], b[6] = {0, 0, 0, 0, 0, 0};
-    uint32_t bn, off;
-    fmd_split(k, bn, off);
-    const int c = fmd_block_rank6<true>(ix.blocks + (size_t)bn * FMD_BLK_U4, 0, off + 1, a, bn);
-    if (k) { fmd_split(k - 1, bn, off); fmd_block_rank6<false>(ix.blocks + (size_t)bn * FMD_BLK_U4, 0, off + 1, b, bn); }
-    bool ok = c >= 0 && c < 6;
-    for (int j = 0; j < 6; ++j) ok = ok && a[j] == b[j] + (j == c ? 1u : 0u);
-    if (k == ix.n_sym - 1) for (int j = 0; j < 6; ++j) ok = ok && a[j] == ix.cnt[j + 1] - ix.cnt[j];
-    if (!ok) { atomicAdd(&bad[0], 1ull); atomicMin(&bad[1], (unsigned long long)k); }
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < ix.n_sym; k += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t a[6], b[6] = {0, 0, 0, 0, 0, 0};
+        uint32_t bn, off;
+        fmd_split(k, bn, off);
+        const int c = fmd_block_rank6<true>(ix.blocks + (size_t)bn * FMD_BLK_U4, 0, off + 1, a, bn);
+        if (k) { fmd_split(k - 1, bn, off); fmd_block_rank6<false>(ix.blocks + (size_t)bn * FMD_BLK_U4, 0, off + 1, b, bn); }
+        bool ok = c >= 0 && c < 6;
+        for (int j = 0; j < 6; ++j) ok = ok && a[j] == b[j] + (j == c ? 1u : 0u);
+        if (k == ix.n_sym - 1) for (int j = 0; j < 6; ++j) ok = ok && a[j] == ix.cnt[j + 1] - ix.cnt[j];
+        if (!ok) { atomicAdd(&bad[0], 1ull); atomicMin(&bad[1], (unsigned long long)k); }
+    }
 }
 
 extern "C" int fmd_dev_check_rank(fmd_dev_t *h, uint64_t *n_bad, uint64_t *first_bad)
@@ -511,8 +538,7 @@ extern "C" int fmd_dev_check_rank(fmd_dev_t *h, uint64_t *n_bad, uint64_t *first
     FMD_HIP_TRY(hipMalloc((void **)&d, 16));
     FMD_HIP_TRY(hipMemcpy(d, init, 16, hipMemcpyHostToDevice));
     const uint64_t n = h->mcnt[0];
-    if ((n + 255) / 256 > 0x7fffffffull) { hipFree(d); return FMD_E_ARG; } // one thread per position: 5.5e11 symbols at most
-    if (n) k_check_rank<<<(unsigned)((n + 255) / 256), 256>>>(fmd_view(h), d);
+    if (n) k_check_rank<<<nblk(n, 256), 256>>>(fmd_view(h), d);
     hipError_t e = hipMemcpy(res, d, 16, hipMemcpyDeviceToHost);
     hipFree(d);
     if (e != hipSuccess) { fmd_set_hip_error(e, "check_rank"); return FMD_E_HIP; }
