@@ -654,6 +654,15 @@ def main():
                     out["roofline"]["traffic_source"] = pmc["source"]
             except Exception:
                 pass
+            try:  # the practical ceiling next to the spec peak: random 64-byte lines through the same gather machinery
+                if os.environ.get("FMD_BENCH_PROBE", "1") != "0":
+                    nl = 1 << 27
+                    pms = api.probe_gather(8 << 30, 64, nl, iters=3, device=local_rank)
+                    out["roofline"]["random_gather_probe"] = {"line_bytes": 64, "working_set_GiB": 8, "lines_per_s": nl / (pms * 1e-3),
+                                                              "GB_per_s": nl * 64 / (pms * 1e-3) / 1e9,
+                                                              "kernel_rank_queries_per_s": qpr * n_reads / (kern_ms * 1e-3)}
+            except Exception:
+                pass
             base, parity = cpu_baseline(fmd_path, q_host, cpu_sample, g_cnt, g_beg, g_end)
             out["cpu_baseline"] = base
             out["parity_vs_cpu_on_sample"] = "bit-exact" if parity else "MISMATCH"
