@@ -638,6 +638,9 @@ def main():
                                    "index (%.2f GB) + reads resident in HBM" % (n_reads, L, err, index.hbm_bytes / 1e9),
                        "reads_per_gpu": n_reads, "read_len": L, "index_symbols": n_sym, "parallelism": "replicated index, reads sharded x%d" % world},
             "hits": int((g_cnt > 0).sum()),
+            # untimed set-up, for the record: GPU suffix-sort construction and drop-in load of fermi's file
+            "index_build": {"symbols": n_sym, "gpu_bwt_seconds": t2 - t1, "symbols_per_s": n_sym / max(t2 - t1, 1e-9),
+                            "fmd_write_seconds": t3 - t2, "fmd_load_transcode_seconds": t4 - t3, "hbm_bytes": index.hbm_bytes},
         }
         if world == 1:
             qpr = rank_queries_per_read(q_host, fmd_path)
