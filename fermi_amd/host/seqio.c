@@ -15,20 +15,42 @@ struct fmdh_seqio {
     size_t name_l, name_m, seq_l, seq_m, qual_l, qual_m, comment_l, comment_m;
 };
 
-static int io_getc(fmdh_seqio_t *io)
+static int io_fill(fmdh_seqio_t *io) /* 0 at end of file */
 {
-    if (io->beg >= io->end) {
-        if (io->eof) return -1;
-        io->beg = 0;
-        io->end = gzread(io->fp, io->buf, sizeof(io->buf));
-        if (io->end <= 0) { io->eof = 1; io->end = 0; return -1; }
-    }
+    if (io->eof) return 0;
+    io->beg = 0;
+    io->end = gzread(io->fp, io->buf, sizeof(io->buf));
+    if (io->end <= 0) { io->eof = 1; io->end = 0; return 0; }
+    return 1;
+}
+static inline int io_getc(fmdh_seqio_t *io)
+{
+    if (io->beg >= io->end && !io_fill(io)) return -1;
     return io->buf[io->beg++];
 }
 static void put(char **s, size_t *l, size_t *m, int c)
 {
     if (*l + 2 > *m) { *m = *m ? *m << 1 : 256; *s = (char *)realloc(*s, *m); }
     (*s)[(*l)++] = (char)c; (*s)[*l] = 0;
+}
+/* append the rest of the current line (without its '\n'; a trailing CR is dropped) in bulk;
+ * returns -1 when the file ended before a newline and nothing was read */
+static int io_append_line(fmdh_seqio_t *io, char **s, size_t *l, size_t *m)
+{
+    int got = 0;
+    for (;;) {
+        if (io->beg >= io->end && !io_fill(io)) break;
+        const unsigned char *p = io->buf + io->beg, *nl = (const unsigned char *)memchr(p, '\n', (size_t)(io->end - io->beg));
+        const size_t k = nl ? (size_t)(nl - p) : (size_t)(io->end - io->beg);
+        if (*l + k + 2 > *m) { while (*l + k + 2 > *m) *m = *m ? *m << 1 : 256; *s = (char *)realloc(*s, *m); }
+        memcpy(*s + *l, p, k); *l += k;
+        got = 1;
+        io->beg += (int)k + (nl ? 1 : 0);
+        if (nl) break;
+    }
+    if (*l && (*s)[*l - 1] == '\r') --*l;
+    if (*s) (*s)[*l] = 0;
+    return got ? 0 : -1;
 }
 
 fmdh_seqio_t *fmdh_seq_open(const char *fn)
@@ -67,17 +89,16 @@ int fmdh_seq_read(fmdh_seqio_t *io) /* sequence length, -1 at end of file, -2 on
         while ((c = io_getc(io)) != -1 && c != '\n') put(&io->comment, &io->comment_l, &io->comment_m, c);
         if (io->comment_l > 1 && io->comment[io->comment_l - 1] == '\r') io->comment[--io->comment_l] = 0;
     }
-    while ((c = io_getc(io)) != -1 && c != '>' && c != '+' && c != '@') {
+    while ((c = io_getc(io)) != -1 && c != '>' && c != '+' && c != '@') { /* the first character of each line decides (kseq.h:186-191) */
         if (c == '\n' || c == '\r') continue;
         put(&io->seq, &io->seq_l, &io->seq_m, c);
-        while ((c = io_getc(io)) != -1 && c != '\n') if (c != '\r') put(&io->seq, &io->seq_l, &io->seq_m, c);
+        io_append_line(io, &io->seq, &io->seq_l, &io->seq_m);
     }
     if (c == '>' || c == '@') io->last_char = c;
     if (c != '+') { if (c == -1) io->last_char = 0; return (int)io->seq_l; }
     while ((c = io_getc(io)) != -1 && c != '\n') {}
     if (c == -1) return -2;
-    while (io->qual_l < io->seq_l && (c = io_getc(io)) != -1)
-        if (c != '\n' && c != '\r') put(&io->qual, &io->qual_l, &io->qual_m, c);
+    while (io->qual_l < io->seq_l && io_append_line(io, &io->qual, &io->qual_l, &io->qual_m) == 0) {} /* whole lines (kseq.h:206) */
     io->last_char = 0;
     if (io->qual_l != io->seq_l) return -2;
     return (int)io->seq_l;
