@@ -1,4 +1,4 @@
-// fmd_ovlp_common.h -- helpers shared by the overlap-discovery kernels
+// fmd_kernel_common.h -- small device helpers shared by the search kernels (overlap, SMEM, k-mer harvest)
 #pragma once
 #include "fmd_internal.h"
 

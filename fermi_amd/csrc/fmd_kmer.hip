@@ -14,7 +14,7 @@
 #include <string.h>
 #include <hipcub/hipcub.hpp>
 #include "fmd_internal.h"
-#include "fmd_ovlp_common.h"
+#include "fmd_kernel_common.h"
 
 
 // counters in device memory: [0..63] frontier sizes per depth, [64] #output, [65] overflow flag,

@@ -7,7 +7,7 @@
 // one rank2a request per wave step; finished lanes refill from a queue (ballot compaction).
 #include <stdlib.h>
 #include <string.h>
-#include "fmd_ovlp_common.h"
+#include "fmd_kernel_common.h"
 
 void fmd_launch_nei_grp(int G, int grid, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                         const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,

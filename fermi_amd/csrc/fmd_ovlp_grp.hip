@@ -18,7 +18,7 @@
 // Strands that do not fit the fast shape -- more than G candidates, an interval wider than a rank
 // block, more neighbours than max_nei, or the fake-fork fix-up of unitig.c:158-176 -- are handed
 // to k_ovl_nei through the `slow` work list; nothing is approximated.
-#include "fmd_ovlp_common.h"
+#include "fmd_kernel_common.h"
 
 // LDS per wave: one block slot per lane for the k side of the forward extension (slot 0) and of
 // the sentinel window (slot 1); the l sides, needed only when a range straddles a block boundary

@@ -7,36 +7,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include "fmd_internal.h"
-#include "fmd_ovlp_common.h"
-
-#define MASK30 0x3fffffffull
-
-__device__ __forceinline__ int s_comp6(int c) { return (c >= 1 && c <= 4) ? 5 - c : c; }
-
-template <class T>
-__device__ __forceinline__ T s_sel6(int c, T a0, T a1, T a2, T a3, T a4, T a5)
-{
-    T r = a0;
-    r = c == 1 ? a1 : r; r = c == 2 ? a2 : r; r = c == 3 ? a3 : r; r = c == 4 ? a4 : r; r = c == 5 ? a5 : r;
-    return r;
-}
-
-__device__ __forceinline__ void s_load(const fmd_intv_t *e, uint64_t &x0, uint64_t &x1, uint64_t &sz, uint64_t &info)
-{
-    const uint4 *q = (const uint4 *)e;
-    const uint4 a = q[0], b = q[1];
-    x0 = (uint64_t)a.y << 32 | a.x; x1 = (uint64_t)a.w << 32 | a.z;
-    sz = (uint64_t)b.y << 32 | b.x; info = (uint64_t)b.w << 32 | b.z;
-}
-__device__ __forceinline__ void s_store(fmd_intv_t *e, uint64_t x0, uint64_t x1, uint64_t sz, uint64_t info)
-{
-    uint4 *q = (uint4 *)e;
-    q[0] = make_uint4((uint32_t)x0, (uint32_t)(x0 >> 32), (uint32_t)x1, (uint32_t)(x1 >> 32));
-    q[1] = make_uint4((uint32_t)sz, (uint32_t)(sz >> 32), (uint32_t)info, (uint32_t)(info >> 32));
-}
+#include "fmd_kernel_common.h"
 
 // forward-sweep push (the list is written back to front); a full list marks the item as overflowed
-#define SM_PUSH_FWD(a_, b_, c_, d_) do { if (curr_n < cap) { s_store(la + (cap - 1 - curr_n), a_, b_, c_, d_); ++curr_n; } else overflow = true; } while (0)
+#define SM_PUSH_FWD(a_, b_, c_, d_) do { if (curr_n < cap) { store_entry(la + (cap - 1 - curr_n), a_, b_, c_, d_); ++curr_n; } else overflow = true; } while (0)
 
 enum { SM_IDLE = 0, SM_START, SM_BEGIN_BWD, SM_BWD_PICK, SM_FWD, SM_FWD_END, SM_BWD };
 
@@ -96,7 +70,7 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
             again = false;
             if (st == SM_START) { // fm6_smem1_core prologue (smem.c:19-21)
                 const int c = q[x];
-                kx0 = ix.cnt[c]; kx1 = ix.cnt[s_comp6(c)]; ksz = ix.cnt[c + 1] - ix.cnt[c]; kinfo = (uint64_t)(x + 1);
+                kx0 = ix.cnt[c]; kx1 = ix.cnt[comp6(c)]; ksz = ix.cnt[c + 1] - ix.cnt[c]; kinfo = (uint64_t)(x + 1);
                 curr_n = 0; call_base = n_mem; out_base = n_out; i = x + 1;
                 if (ksz == 0) { // the reference dereferences an empty list here (undefined); stop this read
                     n_mem_out[rid] = n_out | (overflow ? 0x80000000u : 0);
@@ -110,7 +84,7 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
             } else if (st == SM_BEGIN_BWD) { // the forward list, already reversed, becomes prev (smem.c:45-50)
                 prev = la + (cap - curr_n); prev_n = curr_n;
                 uint64_t t0, t1, t2, t3;
-                s_load(prev, t0, t1, t2, t3);
+                load_entry(prev, t0, t1, t2, t3);
                 ret = (int)t3;
                 curr = lb; curr_n = 0; j = 0; i = x - 1; last_mem_beg = 0; have_pf = false;
                 st = SM_BWD_PICK; again = true;
@@ -119,7 +93,7 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
                     if (have_pf) {
                         kx0 = (uint64_t)pfa.y << 32 | pfa.x; kx1 = (uint64_t)pfa.w << 32 | pfa.z;
                         ksz = (uint64_t)pfb.y << 32 | pfb.x; kinfo = (uint64_t)pfb.w << 32 | pfb.z;
-                    } else s_load(prev + j, kx0, kx1, ksz, kinfo);
+                    } else load_entry(prev + j, kx0, kx1, ksz, kinfo);
                     have_pf = false;
                     st = SM_BWD;
                 } else if (curr_n != 0 && i != -1) { // next base to the left (smem.c:76-77)
@@ -132,8 +106,8 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
                             --b;
                             fmd_intv_t *pa = mem_out + rid * (size_t)max_mem + a, *pb = mem_out + rid * (size_t)max_mem + b;
                             uint64_t a0, a1, a2, a3, b0, b1, b2, b3;
-                            s_load(pa, a0, a1, a2, a3); s_load(pb, b0, b1, b2, b3);
-                            s_store(pa, b0, b1, b2, b3); s_store(pb, a0, a1, a2, a3);
+                            load_entry(pa, a0, a1, a2, a3); load_entry(pb, b0, b1, b2, b3);
+                            store_entry(pa, b0, b1, b2, b3); store_entry(pb, a0, a1, a2, a3);
                         }
                     x = ret;
                     if (x < stop) { st = SM_START; again = true; }
@@ -160,7 +134,7 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
         }
         FmdRank2c r = fmd_wave_rank2_fetch_compact(ix, fmd_lds, act ? a0 - 1 : NONE64, act ? a0 - 1 + ksz : NONE64);
         if (st == SM_FWD || (st == SM_BWD && i >= 0)) c = (int)((cw >> (8 * ((sbase + (uint64_t)i) & 3))) & 0xff);
-        if (st == SM_FWD) c = s_comp6(c);
+        if (st == SM_FWD) c = comp6(c);
         // narrow interval: everything comes from one 64-position window; a lane whose window straddles
         // two blocks in a two-phase step (the dense slot is reused for the l side) takes the general path
         const bool narrow = act && ksz <= 63 && !(r.two_phase && r.l_sep);
@@ -189,10 +163,10 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
             if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl, r.blk_l);
 #pragma unroll
             for (int b = 0; b < 6; ++b) s[b] = tl[b] - tk[b];
-            tkc = s_sel6(c, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
+            tkc = sel6(c, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
             tk0 = tk[0]; have_tk0 = true;
         }
-        const uint64_t sc = s_sel6(c, s[0], s[1], s[2], s[3], s[4], s[5]);
+        const uint64_t sc = sel6(c, s[0], s[1], s[2], s[3], s[4], s[5]);
         // other-strand coordinate of child c: running sum in the order $,T,G,C,A,N (exact.c:81-86)
         const uint64_t base = fwd ? kx0 : kx1;
         uint64_t before = 0;
@@ -231,7 +205,7 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
                     if (fl_match || n_mem == call_base || (uint64_t)(i + 1) < last_mem_beg) { // skip contained matches
                         const uint64_t inf = kinfo | (uint64_t)(s[0] != 0) << 63 | (uint64_t)(i + 1) << 32;
                         if (!full_only || fl_match) { // fl_match: closed by a sentinel on both sides = a whole sequence of the index
-                            if (n_out < max_mem) s_store(mem_out + rid * (size_t)max_mem + n_out, kx0, kx1, ksz, inf);
+                            if (n_out < max_mem) store_entry(mem_out + rid * (size_t)max_mem + n_out, kx0, kx1, ksz, inf);
                             else overflow = true;
                             ++n_out;
                         }
@@ -241,7 +215,7 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
                 }
             }
             if (cont && (kx1 < ix.n_seq || curr_n == 0 || sc != last_curr_sz)) {
-                s_store(curr + curr_n, nxc, rc, sc, kinfo);
+                store_entry(curr + curr_n, nxc, rc, sc, kinfo);
                 last_curr_sz = sc;
                 ++curr_n;
             }
