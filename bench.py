@@ -55,7 +55,7 @@ def cpu_baseline(fmd_path, reads_host, sample, gpu_cnt, gpu_beg, gpu_end):
     q = np.ascontiguousarray(reads_host[:n])
     cnt = np.zeros(n, dtype=np.uint64); beg = np.zeros(n, dtype=np.uint64); end = np.zeros(n, dtype=np.uint64)
     drv = os.path.join(ROOT, "oracle", "_ref", "libref_driver.so")
-    if os.path.exists(drv):
+    if os.path.exists(drv) and not os.environ.get("FMD_BENCH_FORCE_PORT"):
         L = C.CDLL(drv)
         L.refdrv_load.restype = C.c_void_p; L.refdrv_load.argtypes = [C.c_char_p]
         L.refdrv_free.argtypes = [C.c_void_p]
@@ -112,7 +112,7 @@ def overlap_cpu_baseline(fmd_path, ids, min_match, g_rec, g_nei):
     n = len(ids)
     ids = np.ascontiguousarray(ids, dtype=np.uint64)
     drv = os.path.join(ROOT, "oracle", "_ref", "libref_driver.so")
-    if os.path.exists(drv):
+    if os.path.exists(drv) and not os.environ.get("FMD_BENCH_FORCE_PORT"):
         L = C.CDLL(drv)
         L.refdrv_load.restype = C.c_void_p; L.refdrv_load.argtypes = [C.c_char_p]
         L.refdrv_free.argtypes = [C.c_void_p]
@@ -266,7 +266,7 @@ def smem_cpu_baseline(fmd_path, reads, max_mem, g_mem, g_nmem):
     mem = np.zeros((n, max_mem), dtype=INTV); n_mem = np.zeros(n, dtype=np.uint32)
     drv = os.path.join(ROOT, "oracle", "_ref", "libref_driver.so")
     n1 = min(n, 10_000)
-    if os.path.exists(drv):
+    if os.path.exists(drv) and not os.environ.get("FMD_BENCH_FORCE_PORT"):
         Lb = C.CDLL(drv)
         Lb.refdrv_load.restype = C.c_void_p; Lb.refdrv_load.argtypes = [C.c_char_p]
         Lb.refdrv_free.argtypes = [C.c_void_p]
@@ -336,7 +336,7 @@ def kmer_cpu_baseline(fmd_path, w, min_occ, suf_len, n_buckets, g_trip):
 
     def pack(B, K, V):
         return np.sort(B.astype(np.uint64) << np.uint64(40) | K.astype(np.uint64) << np.uint64(8) | V.astype(np.uint64))
-    if os.path.exists(drv):
+    if os.path.exists(drv) and not os.environ.get("FMD_BENCH_FORCE_PORT"):
         Lb = C.CDLL(drv)
         Lb.refec_range.argtypes = [C.c_char_p] + [C.c_int] * 6 + [C.c_void_p] * 5
         Lb.refec_free.argtypes = [C.c_void_p]
