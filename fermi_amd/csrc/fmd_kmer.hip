@@ -96,31 +96,51 @@ __device__ __forceinline__ unsigned long long km_reserve(fmd_intv_t *out, uint64
     return o;
 }
 
+// Which frontier slots a workgroup walks.  Consecutive workgroups land on different XCDs (8 of them, each
+// with its own L2), while consecutive frontier entries are children of neighbouring nodes and touch
+// neighbouring rank blocks: give every XCD one contiguous eighth of the frontier so that this locality
+// stays inside one L2.
+struct KmRange { uint64_t beg, end, stride; };
+__device__ __forceinline__ KmRange km_range(uint64_t n, int xcd_aware)
+{
+    KmRange r;
+    if (xcd_aware && (gridDim.x & 7) == 0) {
+        const uint32_t x = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+        const uint64_t seg = ((n + 7) / 8 + 63) & ~63ull;
+        r.beg = (uint64_t)x * seg + (uint64_t)slot * 64;
+        r.end = (uint64_t)(x + 1) * seg < n ? (uint64_t)(x + 1) * seg : n;
+        r.stride = (uint64_t)per * 64;
+    } else { r.beg = (uint64_t)blockIdx.x * 64; r.end = n; r.stride = (uint64_t)gridDim.x * 64; }
+    return r;
+}
+
 // one trie level: nodes at depth d -> children at depth d+1
 __global__ __launch_bounds__(64) void k_kmer_level(FmdIndexView ix, int d, int suf_len, int min_occ, const fmd_intv_t *__restrict__ in,
-                                                   fmd_intv_t *__restrict__ out, uint64_t cap, uint32_t ch, unsigned long long *__restrict__ ctr)
+                                                   fmd_intv_t *__restrict__ out, uint64_t cap, uint32_t ch, unsigned long long *__restrict__ ctr,
+                                                   int xcd_aware)
 {
     FMD_DECLARE_COMPACT_LDS();
     const int lane = fmd_lane();
     const uint64_t n = ctr[d] < cap ? ctr[d] : cap;   // an overflowing level counted more than it stored
     const uint64_t thr = (d + 1 <= suf_len) ? 1 : (uint64_t)min_occ; // exact.c:159 vs correct.c:78
-    const uint64_t stride = (uint64_t)gridDim.x * 64;
+    const KmRange rg = km_range(n, xcd_aware);
+    const uint64_t stride = rg.stride;
     KmChunk ck; ck.base = 0; ck.fill = 0; ck.ch = ch; ck.have = false;
     uint32_t n_ext = 0;
     uint4 na = make_uint4(0, 0, 0, 0), nb = na;       // the entry of the next iteration, loaded one gather ahead
     {
-        const uint64_t i0 = (uint64_t)blockIdx.x * 64 + lane;
-        if (i0 < n) { const uint4 *q = (const uint4 *)(in + i0); na = q[0]; nb = q[1]; }
+        const uint64_t i0 = rg.beg + lane;
+        if (i0 < rg.end) { const uint4 *q = (const uint4 *)(in + i0); na = q[0]; nb = q[1]; }
     }
-    for (uint64_t base = (uint64_t)blockIdx.x * 64; base < n; base += stride) {
+    for (uint64_t base = rg.beg; base < rg.end; base += stride) {
         const uint4 a = na, b = nb;
         const uint64_t x0 = (uint64_t)a.y << 32 | a.x, x1 = (uint64_t)a.w << 32 | a.z;
         const uint64_t sz = (uint64_t)b.y << 32 | b.x, K = (uint64_t)b.w << 32 | b.z;
-        const bool act = base + lane < n && sz != 0;
+        const bool act = base + lane < rg.end && sz != 0;
         {
             const uint64_t i1 = base + stride + lane;
             na = make_uint4(0, 0, 0, 0); nb = na;
-            if (i1 < n) { const uint4 *q = (const uint4 *)(in + i1); na = q[0]; nb = q[1]; }
+            if (i1 < rg.end) { const uint4 *q = (const uint4 *)(in + i1); na = q[0]; nb = q[1]; }
         }
         const uint64_t m_act = __ballot(act);
         if (m_act == 0) continue;                     // a run of holes
@@ -162,28 +182,29 @@ __global__ __launch_bounds__(64) void k_kmer_level(FmdIndexView ix, int d, int s
 __global__ __launch_bounds__(64) void k_kmer_emit(FmdIndexView ix, int w, int suf_len, int min_occ, const fmd_intv_t *__restrict__ in,
                                                   uint32_t *__restrict__ r_bucket, uint32_t *__restrict__ r_key,
                                                   uint8_t *__restrict__ r_val, uint8_t *__restrict__ r_flag, uint64_t cap,
-                                                  unsigned long long *__restrict__ ctr)
+                                                  unsigned long long *__restrict__ ctr, int xcd_aware)
 {
     FMD_DECLARE_COMPACT_LDS();
     const int lane = fmd_lane();
     const uint64_t n = ctr[w] < cap ? ctr[w] : cap;
-    const uint64_t stride = (uint64_t)gridDim.x * 64;
+    const KmRange rg = km_range(n, xcd_aware);
+    const uint64_t stride = rg.stride;
     uint32_t n_keep = 0, n_inf = 0, n_ext = 0;
     uint4 na = make_uint4(0, 0, 0, 0), nb = na;
     {
-        const uint64_t i0 = (uint64_t)blockIdx.x * 64 + lane;
-        if (i0 < n) { const uint4 *q = (const uint4 *)(in + i0); na = q[0]; nb = q[1]; }
+        const uint64_t i0 = rg.beg + lane;
+        if (i0 < rg.end) { const uint4 *q = (const uint4 *)(in + i0); na = q[0]; nb = q[1]; }
     }
-    for (uint64_t base = (uint64_t)blockIdx.x * 64; base < n; base += stride) {
+    for (uint64_t base = rg.beg; base < rg.end; base += stride) {
         const uint64_t i = base + lane;
         const uint4 a = na, b = nb;
         const uint64_t x0 = (uint64_t)a.y << 32 | a.x;
         const uint64_t sz = (uint64_t)b.y << 32 | b.x, K = (uint64_t)b.w << 32 | b.z;
-        const bool act = i < n && sz != 0;
+        const bool act = i < rg.end && sz != 0;
         {
             const uint64_t i1 = i + stride;
             na = make_uint4(0, 0, 0, 0); nb = na;
-            if (i1 < n) { const uint4 *q = (const uint4 *)(in + i1); na = q[0]; nb = q[1]; }
+            if (i1 < rg.end) { const uint4 *q = (const uint4 *)(in + i1); na = q[0]; nb = q[1]; }
         }
         const uint64_t m_act = __ballot(act);
         if (m_act == 0) continue;
@@ -199,7 +220,7 @@ __global__ __launch_bounds__(64) void k_kmer_emit(FmdIndexView ix, int w, int su
         if (r > 31.) r = 31.;
         const bool informative = keep && rest <= 7 && r >= (double)min_occ;
         n_keep += (uint32_t)__popcll(__ballot(keep)); n_inf += (uint32_t)__popcll(__ballot(informative));
-        if (i < n) {
+        if (i < rg.end) {
             r_flag[i] = keep ? 1 : 0;
             if (keep) {
                 r_bucket[i] = (uint32_t)(K & ((1ull << (2 * suf_len)) - 1));
@@ -297,11 +318,12 @@ extern "C" int fmd_kmer_collect_dev(fmd_dev_t *h, void *stream_, int w, int min_
     const int grid = fmd_grid_for_lds(h, cap, FMD_COMPACT_LDS_U4 * 16);
     // chunk of output slots a wave reserves per atomic: as large as the capacity comfortably allows
     // (at most one partial chunk per wave is wasted per level), at least one iteration's worth (256)
+    static const int xcd_aware = getenv("FMD_KMER_XCD") ? atoi(getenv("FMD_KMER_XCD")) : 1;
     uint32_t ch = 1024;
     while (ch > 256 && (uint64_t)grid * ch * 8 > cap) ch >>= 1;
     fmd_intv_t *in = fa, *out = fb;
     for (int d = 1; d < w; ++d) {
-        k_kmer_level<<<grid, 64, 0, st>>>(ix, d, suf_len, min_occ, in, out, cap, ch, ctr);
+        k_kmer_level<<<grid, 64, 0, st>>>(ix, d, suf_len, min_occ, in, out, cap, ch, ctr, xcd_aware);
         fmd_intv_t *t = in; in = out; out = t;
     }
     // raw (uncompacted) triples + flags live in the frontier buffer that is free now: 10 of its 32 bytes per slot
@@ -311,7 +333,7 @@ extern "C" int fmd_kmer_collect_dev(fmd_dev_t *h, void *stream_, int w, int min_
     unsigned long long *tile_cnt = (unsigned long long *)(((uintptr_t)(r_flag + cap) + 255) & ~(uintptr_t)255), *tile_off = tile_cnt + n_tiles;
     if ((uint8_t *)(tile_off + n_tiles) > (uint8_t *)out + cap * sizeof(fmd_intv_t)) return FMD_E_ARG;
     FMD_HIP_TRY(hipMemsetAsync(r_flag, 0, cap, st));
-    k_kmer_emit<<<grid, 64, 0, st>>>(ix, w, suf_len, min_occ, in, r_bucket, r_key, r_val, r_flag, cap, ctr);
+    k_kmer_emit<<<grid, 64, 0, st>>>(ix, w, suf_len, min_occ, in, r_bucket, r_key, r_val, r_flag, cap, ctr, xcd_aware);
     k_km_count<<<(unsigned)n_tiles, 256, 0, st>>>(r_flag, cap, tile_cnt);
     size_t tmp_bytes = 0;
     FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, tile_cnt, tile_off, (size_t)n_tiles, st));
