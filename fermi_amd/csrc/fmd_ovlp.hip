@@ -841,7 +841,12 @@ extern "C" int fmd_ovlp_batch(fmd_dev_t *h, size_t n, const uint64_t *ids, int m
     if (!h || (n && (!ids || !rec || !nei || !seq))) return FMD_E_ARG;
     if (n == 0) return FMD_OK;
     FMD_HIP_TRY(hipSetDevice(h->device));
-    const size_t chunk = 1u << 20; // strands per pass: bounds the HBM work area
+    // strands per pass: as many as keep the HBM work area (two candidate lists per strand: 6.4 kB at 100 bp,
+    // -l50) around 32 GB, between 2^16 and 2^22
+    const size_t per_strand = fmd_ovlp_work_bytes(1u << 16, max_len, min_match) >> 16;
+    size_t chunk = ((size_t)32 << 30) / (per_strand ? per_strand : 1);
+    if (chunk > (4u << 20)) chunk = 4u << 20;
+    if (chunk < (1u << 16)) chunk = 1u << 16;
     const size_t m = n < chunk ? n : chunk;
     const size_t wb = fmd_ovlp_work_bytes(m, max_len, min_match);
     DevBuf2 di, dr, dn, ds, dw;
