@@ -281,51 +281,133 @@ static void fix_batch(const fmdh_ecopt_t *opt, const solid_t *solid, char **seqs
 }
 
 /* Phase 2 alone: correct the reads of fq_path against a harvested table (opt->w must be set). */
+/* Three-stage pipeline over batches of BATCH_SIZE reads (correct.c:372-441 reads, corrects and prints one
+ * batch after the other): the caller's thread parses batch k+1 while the fix workers are on batch k and a
+ * writer thread prints batch k-1.  A ring of three batches; each slot goes free -> filled -> fixed -> free. */
+typedef struct {
+    char *buf; size_t buf_l, buf_m;      /* sequences and qualities of the batch, back to back, NUL-terminated */
+    size_t *off;                         /* 2 * nb offsets into buf */
+    char **seqs, **quals; int *info;
+    size_t nb; uint64_t pre_id;
+    int last, state;                     /* state: 0 free, 1 filled, 2 fixed */
+} ecbatch_t;
+typedef struct {
+    const fmdh_ecopt_t *opt; const solid_t *solid; FILE *out;
+    ecbatch_t b[3];
+    pthread_mutex_t mu; pthread_cond_t cv;
+    uint64_t n_query;
+} ecpipe_t;
+
+static void pipe_wait(ecpipe_t *p, ecbatch_t *b, int want)
+{
+    pthread_mutex_lock(&p->mu);
+    while (b->state != want) pthread_cond_wait(&p->cv, &p->mu);
+    pthread_mutex_unlock(&p->mu);
+}
+static void pipe_set(ecpipe_t *p, ecbatch_t *b, int st)
+{
+    pthread_mutex_lock(&p->mu);
+    b->state = st;
+    pthread_cond_broadcast(&p->cv);
+    pthread_mutex_unlock(&p->mu);
+}
+static void *pipe_fixer(void *d)
+{
+    ecpipe_t *p = (ecpipe_t *)d;
+    for (unsigned k = 0;; ++k) {
+        ecbatch_t *b = &p->b[k % 3];
+        pipe_wait(p, b, 1);
+        for (size_t i = 0; i < b->nb; ++i) { b->seqs[i] = b->buf + b->off[2 * i]; b->quals[i] = b->buf + b->off[2 * i + 1]; }
+        fix_batch(p->opt, p->solid, b->seqs, b->quals, b->info, b->nb, &p->n_query);
+        const int last = b->last;
+        pipe_set(p, b, 2);
+        if (last) return 0;
+    }
+}
+static void *pipe_writer(void *d)
+{
+    ecpipe_t *p = (ecpipe_t *)d;
+    const fmdh_ecopt_t *opt = p->opt;
+    FILE *out = p->out;
+    char hdr[64];
+    for (unsigned kb = 0;; ++kb) {
+        ecbatch_t *b = &p->b[kb % 3];
+        pipe_wait(p, b, 2);
+        const int *info = b->info;
+        for (size_t a = 0; a < b->nb; ++a) {
+            const uint64_t k = b->pre_id + a;
+            int is_bad = 0;
+            if (opt->is_paired) { /* a pair is bad when either end is (correct.c:401-410, one thread) */
+                if (info[a] >> 16 & 1) is_bad = 1;
+                else if (k & 1) { if (a >= 1 && (info[a - 1] >> 16 & 1)) is_bad = 1; }
+                else if (a + 1 < b->nb && (info[a + 1] >> 16 & 1)) is_bad = 1;
+            } else if (info[a] >> 16 & 1) is_bad = 1;
+            if (!is_bad || opt->keep_bad) {
+                int tmp = (int)strlen(b->seqs[a]);
+                if (opt->trim_l && opt->trim_l < tmp) tmp = opt->trim_l;
+                const int hl = snprintf(hdr, sizeof(hdr), "@%lld%c%d%c%d\n", (long long)(opt->is_paired ? k >> 1 : k), opt->is_paired ? ' ' : '_',
+                                        info[a] & 0xffff, opt->is_paired ? ' ' : '_', info[a] >> 18);
+                fwrite(hdr, 1, (size_t)hl, out);
+                fwrite(b->seqs[a], 1, (size_t)tmp, out); fwrite("\n+\n", 1, 3, out); fwrite(b->quals[a], 1, (size_t)tmp, out); fputc('\n', out);
+            }
+        }
+        const int last = b->last;
+        pipe_set(p, b, 0);
+        if (last) return 0;
+    }
+}
+static void batch_put(ecbatch_t *b, const char *s, size_t l, size_t slot)
+{
+    if (b->buf_l + l + 1 > b->buf_m) { while (b->buf_l + l + 1 > b->buf_m) b->buf_m = b->buf_m ? b->buf_m << 1 : 1 << 20; b->buf = (char *)realloc(b->buf, b->buf_m); }
+    b->off[slot] = b->buf_l;
+    memcpy(b->buf + b->buf_l, s, l); b->buf[b->buf_l + l] = 0;
+    b->buf_l += l + 1;
+}
+
 int fmdh_correct_reads(const fmdh_ecopt_t *opt, int suf_len, uint64_t n, const uint32_t *bucket, const uint32_t *key, const uint8_t *val,
                        const char *fq_path, FILE *out)
 {
     solid_t solid;
     memset(&solid, 0, sizeof(solid));
     if (solid_build(&solid, suf_len, n, bucket, key, val)) { fprintf(stderr, "[E::%s] out of memory\n", __func__); return 1; }
-    /* batches of BATCH_SIZE reads, output in input order (correct.c:372-441) */
     fmdh_seqio_t *io = fmdh_seq_open(fq_path);
     if (!io) { fprintf(stderr, "[E::%s] cannot open `%s'\n", __func__, fq_path); solid_free(&solid); return 1; }
-    char **seqs = (char **)calloc(BATCH_SIZE, sizeof(char *)), **quals = (char **)calloc(BATCH_SIZE, sizeof(char *));
-    int *info = (int *)calloc(BATCH_SIZE, sizeof(int));
-    uint64_t id = 0, pre_id = 0, n_query = 0;
-    size_t nb = 0;
-    for (;;) {
-        int ret = fmdh_seq_read(io);
-        if (ret < 0 || (id && id % BATCH_SIZE == 0)) {
-            fix_batch(opt, &solid, seqs, quals, info, nb, &n_query);
-            for (uint64_t k = pre_id; k < id; ++k) {
-                const size_t a = (size_t)(k - pre_id);
-                int is_bad = 0;
-                if (opt->is_paired) { /* a pair is bad when either end is (correct.c:401-410, one thread) */
-                    if (info[a] >> 16 & 1) is_bad = 1;
-                    else if (k & 1) { if (a >= 1 && (info[a - 1] >> 16 & 1)) is_bad = 1; }
-                    else if (a + 1 < nb && (info[a + 1] >> 16 & 1)) is_bad = 1;
-                } else if (info[a] >> 16 & 1) is_bad = 1;
-                if (!is_bad || opt->keep_bad) {
-                    int tmp = (int)strlen(seqs[a]);
-                    if (opt->trim_l && opt->trim_l < tmp) tmp = opt->trim_l;
-                    fprintf(out, "@%lld%c%d%c%d\n", (long long)(opt->is_paired ? k >> 1 : k), opt->is_paired ? ' ' : '_', info[a] & 0xffff,
-                            opt->is_paired ? ' ' : '_', info[a] >> 18);
-                    fwrite(seqs[a], 1, (size_t)tmp, out); fputs("\n+\n", out); fwrite(quals[a], 1, (size_t)tmp, out); fputc('\n', out);
-                }
-                free(seqs[a]); free(quals[a]);
-            }
-            nb = 0; pre_id = id;
-        }
-        if (ret < 0) break;
-        seqs[nb] = strdup(fmdh_seq_bases(io));
-        if (fmdh_seq_qual(io) == 0) { /* no quality: phred 15 (correct.c:431-436) */
-            quals[nb] = (char *)malloc((size_t)ret + 1);
-            memset(quals[nb], 33 + 15, (size_t)ret); quals[nb][ret] = 0;
-        } else quals[nb] = strdup(fmdh_seq_qual(io));
-        ++nb; ++id;
+    ecpipe_t p;
+    memset(&p, 0, sizeof(p));
+    p.opt = opt; p.solid = &solid; p.out = out;
+    pthread_mutex_init(&p.mu, 0); pthread_cond_init(&p.cv, 0);
+    for (int i = 0; i < 3; ++i) {
+        p.b[i].off = (size_t *)malloc(2 * BATCH_SIZE * sizeof(size_t));
+        p.b[i].seqs = (char **)malloc(BATCH_SIZE * sizeof(char *)); p.b[i].quals = (char **)malloc(BATCH_SIZE * sizeof(char *));
+        p.b[i].info = (int *)malloc(BATCH_SIZE * sizeof(int));
     }
-    free(seqs); free(quals); free(info);
+    pthread_t t_fix, t_out;
+    pthread_create(&t_fix, 0, pipe_fixer, &p);
+    pthread_create(&t_out, 0, pipe_writer, &p);
+    uint64_t id = 0;
+    char *q15 = 0; size_t q15_m = 0;
+    for (unsigned kb = 0;; ++kb) { /* batches of BATCH_SIZE reads, output in input order */
+        ecbatch_t *b = &p.b[kb % 3];
+        pipe_wait(&p, b, 0);
+        b->nb = 0; b->buf_l = 0; b->pre_id = id; b->last = 0;
+        while (b->nb < BATCH_SIZE) {
+            const int ret = fmdh_seq_read(io);
+            if (ret < 0) { b->last = 1; break; }
+            batch_put(b, fmdh_seq_bases(io), (size_t)ret, 2 * b->nb);
+            if (fmdh_seq_qual(io) == 0) { /* no quality: phred 15 (correct.c:431-436) */
+                if ((size_t)ret + 1 > q15_m) { q15_m = (size_t)ret * 2 + 64; q15 = (char *)realloc(q15, q15_m); memset(q15, 33 + 15, q15_m); }
+                batch_put(b, q15, (size_t)ret, 2 * b->nb + 1);
+            } else batch_put(b, fmdh_seq_qual(io), (size_t)ret, 2 * b->nb + 1);
+            ++b->nb; ++id;
+        }
+        const int last = b->last;
+        pipe_set(&p, b, 1);
+        if (last) break;
+    }
+    pthread_join(t_fix, 0); pthread_join(t_out, 0);
+    for (int i = 0; i < 3; ++i) { free(p.b[i].buf); free(p.b[i].off); free(p.b[i].seqs); free(p.b[i].quals); free(p.b[i].info); }
+    free(q15);
+    pthread_mutex_destroy(&p.mu); pthread_cond_destroy(&p.cv);
     fmdh_seq_close(io);
     solid_free(&solid);
     return 0;
