@@ -67,9 +67,15 @@ __device__ __forceinline__ uint64_t range64(uint32_t a, uint32_t b) // bits [a, 
 }
 
 
-// work list of strand indices for one get_nei kernel class: [0] = count, then the indices
+// Work lists of the get_nei kernels.  A strand with m candidate intervals goes to the group kernel with
+// the smallest group size G >= m (one lane per candidate, 64 / G strands per wave); the sizes are chosen
+// so that 64 / G groups leave at most 4 lanes unused.
+#define FMD_GRP_CLASSES 5
+__device__ __host__ __forceinline__ constexpr int fmd_grp_size(int k) { return k == 0 ? 8 : k == 1 ? 12 : k == 2 ? 16 : k == 3 ? 21 : 32; }
+#define FMD_CLS_CNT_STRIDE 32              // counters sit on separate 128-byte lines
+#define FMD_CLS_HEADER_U32 256             // the counter area in front of the lists
 struct FmdOvlClasses {
-    uint32_t *n16, *l16;     // strands with <= 16 candidates and small intervals
-    uint32_t *n32, *l32;     // 17..32 candidates
-    uint32_t *nslow, *lslow; // everything else, plus strands the group kernels hand back
+    uint32_t *cnt;                    // [k * FMD_CLS_CNT_STRIDE] = strands of class k, [FMD_GRP_CLASSES * ...] = strands of the slow list
+    uint32_t *lst[FMD_GRP_CLASSES];   // two words per strand: index, candidates | length << 16
+    uint32_t *lslow;                  // everything else, plus strands the group kernels hand back
 };

@@ -9,7 +9,7 @@
 #include <string.h>
 #include "fmd_kernel_common.h"
 
-void fmd_launch_nei_grp(int G, int grid, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
+void fmd_launch_nei_grp(int cls, int grid, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                         const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
                         uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n);
 void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, const fmd_intv_t *listA, uint32_t cap, FmdOvlClasses cl);
@@ -727,7 +727,7 @@ extern "C" size_t fmd_ovlp_work_bytes(size_t n, uint32_t max_len, int min_match)
 {
     const size_t stride_r = align_up((size_t)max_len, 4);
     const size_t cap = fmd_ovlp_list_cap(max_len, min_match);
-    return align_up(n * stride_r, 256) + 2 * align_up(n * cap * sizeof(fmd_intv_t), 256) + align_up(n * 20 + 64, 256) + 256;
+    return align_up(n * stride_r, 256) + 2 * align_up(n * cap * sizeof(fmd_intv_t), 256) + align_up(n * (8 * FMD_GRP_CLASSES + 4) + 4 * FMD_CLS_HEADER_U32, 256) + 256;
 }
 
 extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_t *d_ids, int min_match, uint32_t max_len,
@@ -756,28 +756,31 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
     if (getenv("FMD_OVLP_SLOW_ONLY")) { // A/B switch: everything through the lane-per-strand kernel
         k_ovl_nei<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, listB, d_rec, d_nei, max_nei, d_seq, seq_stride, q2, nullptr, nullptr);
     } else {
-        // work lists: [n16, n32, nslow, pad...] then l16 (2 words per strand), l32 (2), lslow (1)
+        // work lists: 16 counters, then one list per group class (2 words per strand) and the slow list (1)
         uint32_t *cls = (uint32_t *)((uint8_t *)listB + align_up(n * (size_t)cap * sizeof(fmd_intv_t), 256));
         FmdOvlClasses cl;
-        cl.n16 = cls; cl.n32 = cls + 1; cl.nslow = cls + 2;
-        cl.l16 = cls + 16; cl.l32 = cl.l16 + 2 * n; cl.lslow = cl.l32 + 2 * n;
-        FMD_HIP_TRY(hipMemsetAsync(cls, 0, 64, st));
+        cl.cnt = cls;
+        for (int k = 0; k < FMD_GRP_CLASSES; ++k) cl.lst[k] = cls + FMD_CLS_HEADER_U32 + 2 * n * k;
+        cl.lslow = cls + FMD_CLS_HEADER_U32 + 2 * n * FMD_GRP_CLASSES;
+        uint32_t *n_slow = cl.cnt + FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE;
+        FMD_HIP_TRY(hipMemsetAsync(cls, 0, 4 * FMD_CLS_HEADER_U32, st));
         fmd_launch_classify(st, n, d_rec, listA, cap, cl);
-        // one lane per candidate interval: 4 strands (<= 16 candidates) or 2 strands (<= 32) per wave
+        // one lane per candidate interval, 64 / G strands per wave
         const int ggrid = h->n_cu * fmd_grp_waves_per_cu();
-        fmd_launch_nei_grp(16, ggrid, st, ix, cl.l16, cl.n16, cap, listA, d_rec, d_nei, max_nei, d_seq, seq_stride, cl.lslow, cl.nslow);
-        fmd_launch_nei_grp(32, ggrid, st, ix, cl.l32, cl.n32, cap, listA, d_rec, d_nei, max_nei, d_seq, seq_stride, cl.lslow, cl.nslow);
+        for (int k = 0; k < FMD_GRP_CLASSES; ++k)
+            fmd_launch_nei_grp(k, ggrid, st, ix, cl.lst[k], cl.cnt + k * FMD_CLS_CNT_STRIDE, cap, listA, d_rec, d_nei, max_nei, d_seq, seq_stride, cl.lslow, n_slow);
         // the rest (too many candidates, wide intervals, fake forks, neighbour overflow): lane per strand
-        k_ovl_nei<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, listB, d_rec, d_nei, max_nei, d_seq, seq_stride, q2, cl.lslow, cl.nslow);
+        k_ovl_nei<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, listB, d_rec, d_nei, max_nei, d_seq, seq_stride, q2, cl.lslow, n_slow);
     }
 #ifdef GRP_STATS
     if (!getenv("FMD_OVLP_SLOW_ONLY")) {
-        uint32_t hs[16];
+        uint32_t hs[FMD_CLS_HEADER_U32];
         uint32_t *cls = (uint32_t *)((uint8_t *)listB + align_up(n * (size_t)cap * sizeof(fmd_intv_t), 256));
         hipStreamSynchronize(st);
-        hipMemcpy(hs, cls, 64, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[grp stats] n16 %u n32 %u nslow %u | wave rounds %u, live lanes %u (%.1f %%), lanes of groups holding a strand %u (%.1f %%)\n",
-                hs[0], hs[1], hs[2], hs[10], hs[11], 100.0 * hs[11] / (64.0 * hs[10]), hs[12], 100.0 * hs[12] / (64.0 * hs[10]));
+        hipMemcpy(hs, cls, sizeof(hs), hipMemcpyDeviceToHost);
+        const uint32_t *g = hs + FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE + 8;
+        fprintf(stderr, "[grp stats] classes %u %u %u %u %u slow %u | wave rounds %u, live lanes %u (%.1f %%), lanes of groups holding a strand %u (%.1f %%)\n",
+                hs[0], hs[32], hs[64], hs[96], hs[128], hs[160], g[0], g[1], 100.0 * g[1] / (64.0 * g[0]), g[2], 100.0 * g[2] / (64.0 * g[0]));
     }
 #endif
     hipError_t e = hipGetLastError();

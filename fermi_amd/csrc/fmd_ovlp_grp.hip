@@ -30,11 +30,15 @@
 #define GRP_LDS_U4 (GRP_SLOTS_U4 + GRP_POOL_U4 + GRP_STAGE_U4 + GRP_POOL / 4)
 
 // ---------------------------------------------------------------------------- classification
-// one thread per strand: work lists for the three get_nei kernels
-__global__ void k_ovl_classify(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, const fmd_intv_t *__restrict__ listA, uint32_t cap,
-                               FmdOvlClasses cl)
+// one thread per strand: work lists for the get_nei kernels.  Positions come from a block-wide count
+// (ballots per wave, LDS across the 16 waves) and ONE atomic per block and class, each counter on
+// its own 128-byte line: per-wave atomics on adjacent words cost 7-15 ms per 2*10^7 strands.
+#define CLS_THREADS 1024
+__global__ __launch_bounds__(CLS_THREADS) void k_ovl_classify(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, const fmd_intv_t *__restrict__ listA,
+                                                              uint32_t cap, FmdOvlClasses cl)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t wcnt[CLS_THREADS / 64][FMD_GRP_CLASSES + 1], base[FMD_GRP_CLASSES + 1];
+    const size_t i = (size_t)blockIdx.x * CLS_THREADS + threadIdx.x;
     int cls = -1;
     uint32_t m = 0, len = 0;
     if (i < n) {
@@ -45,24 +49,31 @@ __global__ void k_ovl_classify(size_t n, const fmd_ovlp_rec_t *__restrict__ rec,
             // symbols of BWT[x, x+size) through a 64-position window
             uint64_t x0, x1, sz, inf;
             load_entry(listA + i * (size_t)cap + (cap - 1), x0, x1, sz, inf);
-            cls = (sz > 63 || len >= 65535) ? 2 : (m <= 16 ? 0 : (m <= 32 ? 1 : 2));
+            cls = FMD_GRP_CLASSES;
+            if (sz <= 63 && len < 65535)
+#pragma unroll
+                for (int k = FMD_GRP_CLASSES - 1; k >= 0; --k) if (m <= (uint32_t)fmd_grp_size(k)) cls = k;
         }
     }
-    // one atomic per wave and class (4 M single-lane atomics on three words cost 40 ms)
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t in_wave = 0;                      // lanes of this wave before me in my class
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c <= FMD_GRP_CLASSES; ++c) {
         const uint64_t mk = __ballot(cls == c);
-        if (mk == 0) continue;
-        uint32_t *cnt = c == 0 ? cl.n16 : c == 1 ? cl.n32 : cl.nslow;
-        uint32_t first = 0;
-        if (lane == __ffsll((long long)mk) - 1) first = atomicAdd(cnt, (uint32_t)__popcll(mk));
-        first = (uint32_t)__shfl((int)first, __ffsll((long long)mk) - 1);
-        if (cls == c) {
-            const uint32_t k = first + __popcll(mk & ((1ull << lane) - 1));
-            if (c == 2) cl.lslow[k] = (uint32_t)i;
-            else { uint32_t *lst = c == 0 ? cl.l16 : cl.l32; lst[2 * k] = (uint32_t)i; lst[2 * k + 1] = m | len << 16; }
-        }
+        if (lane == 0) wcnt[wave][c] = (uint32_t)__popcll(mk);
+        if (cls == c) in_wave = (uint32_t)__popcll(mk & ((1ull << lane) - 1));
+    }
+    __syncthreads();
+    if (threadIdx.x <= FMD_GRP_CLASSES) {      // exclusive scan over the waves, then the block's slice of the list
+        uint32_t tot = 0;
+        for (int w = 0; w < CLS_THREADS / 64; ++w) { const uint32_t v = wcnt[w][threadIdx.x]; wcnt[w][threadIdx.x] = tot; tot += v; }
+        base[threadIdx.x] = tot ? atomicAdd(cl.cnt + threadIdx.x * FMD_CLS_CNT_STRIDE, tot) : 0;
+    }
+    __syncthreads();
+    if (cls >= 0) {
+        const uint32_t k = base[cls] + wcnt[wave][cls] + in_wave;
+        if (cls == FMD_GRP_CLASSES) cl.lslow[k] = (uint32_t)i;
+        else { uint32_t *lst = cl.lst[cls]; lst[2 * k] = (uint32_t)i; lst[2 * k + 1] = m | len << 16; }
     }
 }
 
@@ -77,11 +88,11 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
     uint4 *pool = lds + GRP_SLOTS_U4, *stage = pool + GRP_POOL_U4;
     uint32_t *pool_blk = (uint32_t *)(stage + GRP_STAGE_U4);
     constexpr int S = 64 / G;
-    constexpr uint32_t GM = G == 32 ? 0xffffffffu : 0xffffu;
+    constexpr uint32_t GM = G == 32 ? 0xffffffffu : (1u << G) - 1;
     const int lane = fmd_lane(), g = lane / G, j = lane % G, gbase = g * G;
     const uint32_t N = *list_n;
     const uint32_t n_groups = gridDim.x * S;
-    uint32_t idx = blockIdx.x * S + g;                   // position of this group's next strand in the list
+    uint32_t idx = g < S ? blockIdx.x * S + g : 0xffffffffu; // position of this group's next strand in the list (lanes past S * G idle)
 
     // group-uniform strand state (identical in all lanes of the group)
     bool active = false;
@@ -299,12 +310,19 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
 }
 
 // explicit instantiations + launcher used by fmd_ovlp.hip
-void fmd_launch_nei_grp(int G, int grid, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
+void fmd_launch_nei_grp(int cls, int grid, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                         const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
                         uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n)
 {
-    if (G == 16) k_ovl_nei_grp<16><<<grid, 64, 0, st>>>(ix, list, list_n, cap, listA, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n);
-    else k_ovl_nei_grp<32><<<grid, 64, 0, st>>>(ix, list, list_n, cap, listA, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n);
+#define GRP_LAUNCH(K) k_ovl_nei_grp<fmd_grp_size(K)><<<grid, 64, 0, st>>>(ix, list, list_n, cap, listA, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n)
+    switch (cls) {
+    case 0: GRP_LAUNCH(0); break;
+    case 1: GRP_LAUNCH(1); break;
+    case 2: GRP_LAUNCH(2); break;
+    case 3: GRP_LAUNCH(3); break;
+    default: GRP_LAUNCH(4); break;
+    }
+#undef GRP_LAUNCH
 }
 int fmd_grp_waves_per_cu(void) // LDS-bound residency of k_ovl_nei_grp (22.5 KiB per wave with 128-byte blocks)
 {
@@ -313,5 +331,5 @@ int fmd_grp_waves_per_cu(void) // LDS-bound residency of k_ovl_nei_grp (22.5 KiB
 }
 void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, const fmd_intv_t *listA, uint32_t cap, FmdOvlClasses cl)
 {
-    k_ovl_classify<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(n, rec, listA, cap, cl);
+    k_ovl_classify<<<(unsigned)((n + CLS_THREADS - 1) / CLS_THREADS), CLS_THREADS, 0, st>>>(n, rec, listA, cap, cl);
 }
