@@ -9,11 +9,10 @@
 #include <string.h>
 #include "fmd_kernel_common.h"
 
-void fmd_launch_nei_grp(int cls, int grid, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
+void fmd_launch_nei_grp(int cls, int n_cu, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                         const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
                         uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n);
 void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, const fmd_intv_t *listA, uint32_t cap, FmdOvlClasses cl);
-int fmd_grp_waves_per_cu(void);
 
 // ---------------------------------------------------------------------------- phase 0: retrieve
 // fm_retrieve (exact.c:59-70); writes the sequence REVERSED into srev and rank/len into rec.
@@ -766,9 +765,8 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
         FMD_HIP_TRY(hipMemsetAsync(cls, 0, 4 * FMD_CLS_HEADER_U32, st));
         fmd_launch_classify(st, n, d_rec, listA, cap, cl);
         // one lane per candidate interval, 64 / G strands per wave
-        const int ggrid = h->n_cu * fmd_grp_waves_per_cu();
         for (int k = 0; k < FMD_GRP_CLASSES; ++k)
-            fmd_launch_nei_grp(k, ggrid, st, ix, cl.lst[k], cl.cnt + k * FMD_CLS_CNT_STRIDE, cap, listA, d_rec, d_nei, max_nei, d_seq, seq_stride, cl.lslow, n_slow);
+            fmd_launch_nei_grp(k, h->n_cu, st, ix, cl.lst[k], cl.cnt + k * FMD_CLS_CNT_STRIDE, cap, listA, d_rec, d_nei, max_nei, d_seq, seq_stride, cl.lslow, n_slow);
         // the rest (too many candidates, wide intervals, fake forks, neighbour overflow): lane per strand
         k_ovl_nei<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, listB, d_rec, d_nei, max_nei, d_seq, seq_stride, q2, cl.lslow, n_slow);
     }

@@ -217,13 +217,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
         const bool keep = live && (nei_g & in_cat_upto_j) == 0;                                 // not masked, not a neighbour
         const uint32_t newnei_g = (uint32_t)(__ballot(new_nei) >> gbase) & GM;
         if (!keep) cm = 0;
-        // neighbours, in list order (unitig.c:119-121)
-        if (new_nei) { // ok0 of unitig.c:112: x[0] = rank of '$' before x0, x[1] = cnt[0] + rank of '$' before x1
-            const uint32_t k = n_nei + __popc(newnei_g & (uint32_t)bits_below(j));
-            const uint64_t r0 = fmd_block_rank1(img_b, t, okb + 1, 0, bkb);
-            const uint64_t r1 = fmd_block_rank1(img_e, t, oke + 1, 0, bke);
-            if (k < max_nei) store_entry(nei_out + sid * (size_t)max_nei + k, r0, ix.cnt[0] + r1, sz, (uint64_t)ori_l - pos);
-        }
+        const uint32_t nei_k = n_nei + __popc(newnei_g & (uint32_t)bits_below(j)); // neighbours in list order (unitig.c:119-121)
         if (active && n_nei == 0 && newnei_g) { // info of nei[0] decides rbeg (unitig.c:157)
             const int src = gbase + __ffs((int)newnei_g) - 1;
             nei0_info = (uint64_t)ori_l - (uint32_t)__shfl((int)pos, src);
@@ -244,29 +238,36 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
         const bool too_many = n_new > G;
         bool forked_now = false;
         // x[0] of the children: running sum $,T,G,C,A; x[1] = cnt[c] + rank_c(x1 - 1): one rank of ONE
-        // symbol per surviving child (a second child only exists where the read set forks)
+        // symbol per surviving child (a second child only exists where the read set forks).  A new
+        // neighbour (unitig.c:112, :119-121) needs two ranks of '$' instead: x[0] = rank of '$' before x0,
+        // x[1] = cnt[0] + rank of '$' before x1.  Both kinds share one loop so that the rank code runs
+        // once per wave step when nothing forks and no neighbour is found, twice otherwise.
         const uint64_t cx0_4 = x0 + s[0], cx0_3 = cx0_4 + s[4], cx0_2 = cx0_3 + s[3], cx0_1 = cx0_2 + s[2];
-        uint64_t tk[5] = {0, 0, 0, 0, 0};
         {
             uint32_t todo = too_many ? 0u : cm;
-            while (__ballot(todo != 0)) {
+            int nei_todo = new_nei ? 2 : 0;
+            uint64_t nei_r1 = 0;
+            while (__ballot(todo != 0 || nei_todo != 0)) {
+                const bool on_b = nei_todo == 1;
                 const int c = todo ? __ffs((int)todo) - 1 : 0;
-                const uint64_t r = fmd_block_rank1(img_e, t, oke + 1, c, bke);
-                if (todo) { tk[1] = c == 1 ? r : tk[1]; tk[2] = c == 2 ? r : tk[2]; tk[3] = c == 3 ? r : tk[3]; tk[4] = c == 4 ? r : tk[4]; }
-                todo &= todo - 1;
+                const uint64_t r = fmd_block_rank1(on_b ? img_b : img_e, t, (on_b ? okb : oke) + 1, c, on_b ? bkb : bke);
+                if (todo) {
+                    const int pc = c == 1 ? p1 : c == 2 ? p2 : c == 3 ? p3 : p4;
+                    const uint32_t cmask = c == 1 ? c1 : c == 2 ? c2 : c == 3 ? c3 : c4;
+                    const uint64_t cx0 = c == 1 ? cx0_1 : c == 2 ? cx0_2 : c == 3 ? cx0_3 : cx0_4;
+                    const uint64_t sc = c == 1 ? s[1] : c == 2 ? s[2] : c == 3 ? s[3] : s[4];
+                    const uint64_t nx1 = (c == 1 ? ix.cnt[1] : c == 2 ? ix.cnt[2] : c == 3 ? ix.cnt[3] : ix.cnt[4]) + r;
+                    const int d = pc + __popc(cmask & lt_m);
+                    stage[2 * (gbase + d)] = make_uint4((uint32_t)cx0, (uint32_t)(cx0 >> 32), (uint32_t)nx1, (uint32_t)(nx1 >> 32));
+                    stage[2 * (gbase + d) + 1] = make_uint4((uint32_t)sc, (uint32_t)(sc >> 32), pos, (uint32_t)pc);
+                    forked_now |= pc != 0;
+                    todo &= todo - 1;
+                } else if (nei_todo == 2) { nei_r1 = r; nei_todo = 1; }
+                else if (nei_todo == 1) {
+                    if (nei_k < max_nei) store_entry(nei_out + sid * (size_t)max_nei + nei_k, r, ix.cnt[0] + nei_r1, sz, (uint64_t)ori_l - pos);
+                    nei_todo = 0;
+                }
             }
-        }
-        if (!too_many) {
-#define GRP_PUSH(c, pc, cmask, cx0)                                                                     \
-            if ((cm >> c) & 1) {                                                                        \
-                const int d = pc + __popc(cmask & lt_m);                                                \
-                const uint64_t nx1 = ix.cnt[c] + tk[c];                                                 \
-                stage[2 * (gbase + d)] = make_uint4((uint32_t)(cx0), (uint32_t)((cx0) >> 32), (uint32_t)nx1, (uint32_t)(nx1 >> 32)); \
-                stage[2 * (gbase + d) + 1] = make_uint4((uint32_t)s[c], (uint32_t)(s[c] >> 32), pos, (uint32_t)pc); \
-                forked_now |= pc != 0;                                                                  \
-            }
-            GRP_PUSH(1, p1, c1, cx0_1) GRP_PUSH(2, p2, c2, cx0_2) GRP_PUSH(3, p3, c3, cx0_3) GRP_PUSH(4, p4, c4, cx0_4)
-#undef GRP_PUSH
         }
         const uint32_t fork_g = (uint32_t)(__ballot(forked_now) >> gbase) & GM;
         // base appended this round = base of the first child in push order (unitig.c:138-139)
@@ -309,12 +310,31 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
     }
 }
 
-// explicit instantiations + launcher used by fmd_ovlp.hip
-void fmd_launch_nei_grp(int cls, int grid, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
+// launcher used by fmd_ovlp.hip.  The strands of a work list are dealt to the groups round-robin, so
+// the grid must be exactly the resident set: a block that has to wait for a slot starts when the others
+// are done and then works alone through a full share (11 blocks per CU computed from 160 KiB / 14.25 KiB
+// ran 17 % slower than 10: LDS is handed out in 1280-byte granules).  Ask the runtime.
+template <int G>
+static int grp_blocks_per_cu(void)
+{
+    static int cached = 0;
+    if (!cached) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ovl_nei_grp<G>, 64, 0) != hipSuccess || nb < 1) nb = 1;
+        const int by_lds = (160 * 1024) / (((GRP_LDS_U4 * 16 + 1279) / 1280) * 1280);
+        if (nb > by_lds) nb = by_lds;
+        const char *e = getenv("FMD_GRP_WAVES"); // A/B knob: fewer resident waves per CU
+        if (e && atoi(e) > 0 && atoi(e) < nb) nb = atoi(e);
+        if (getenv("FMD_DEBUG_OCC")) fprintf(stderr, "[occupancy] k_ovl_nei_grp<%d>: %d blocks per CU\n", G, nb);
+        cached = nb;
+    }
+    return cached;
+}
+void fmd_launch_nei_grp(int cls, int n_cu, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                         const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
                         uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n)
 {
-#define GRP_LAUNCH(K) k_ovl_nei_grp<fmd_grp_size(K)><<<grid, 64, 0, st>>>(ix, list, list_n, cap, listA, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n)
+#define GRP_LAUNCH(K) k_ovl_nei_grp<fmd_grp_size(K)><<<n_cu * grp_blocks_per_cu<fmd_grp_size(K)>(), 64, 0, st>>>(ix, list, list_n, cap, listA, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n)
     switch (cls) {
     case 0: GRP_LAUNCH(0); break;
     case 1: GRP_LAUNCH(1); break;
@@ -323,11 +343,6 @@ void fmd_launch_nei_grp(int cls, int grid, hipStream_t st, const FmdIndexView &i
     default: GRP_LAUNCH(4); break;
     }
 #undef GRP_LAUNCH
-}
-int fmd_grp_waves_per_cu(void) // LDS-bound residency of k_ovl_nei_grp (22.5 KiB per wave with 128-byte blocks)
-{
-    int w = (160 * 1024) / (GRP_LDS_U4 * 16);
-    return w > 12 ? 12 : w;
 }
 void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, const fmd_intv_t *listA, uint32_t cap, FmdOvlClasses cl)
 {
