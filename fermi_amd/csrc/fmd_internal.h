@@ -49,3 +49,20 @@ uint32_t *fmd_next_queue(fmd_dev *h, hipStream_t stream);
 int fmd_grid_for(const fmd_dev *h, size_t n_items);
 // same for a kernel that uses lds_bytes of LDS per 64-thread workgroup (160 KiB per CU)
 int fmd_grid_for_lds(const fmd_dev *h, size_t n_items, size_t lds_bytes);
+
+// Resident 64-thread workgroups per CU of `kernel` with lds_bytes of static LDS, for kernels that deal
+// their work statically (round-robin or by ranges): a workgroup beyond the resident set would start when
+// the others are done and then work through a full share alone.  The runtime's occupancy query, bounded by
+// the LDS granule (1280 bytes on gfx950: 160 KiB / 128) and by `cap`.
+#include <stdlib.h>
+template <typename K>
+static inline int fmd_resident_per_cu(K kernel, size_t lds_bytes, int cap, const char *name)
+{
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 64, 0) != hipSuccess || nb < 1) nb = 1;
+    const int by_lds = lds_bytes ? (int)((160 * 1024) / (((lds_bytes + 1279) / 1280) * 1280)) : nb;
+    if (nb > by_lds) nb = by_lds;
+    if (nb > cap) nb = cap;
+    if (getenv("FMD_DEBUG_OCC")) fprintf(stderr, "[occupancy] %s: %d workgroups per CU\n", name, nb);
+    return nb;
+}

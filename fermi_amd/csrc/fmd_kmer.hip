@@ -315,7 +315,15 @@ extern "C" int fmd_kmer_collect_dev(fmd_dev_t *h, void *stream_, int w, int min_
     FMD_HIP_TRY(hipMemcpyAsync(ctr + 1, &n1, 8, hipMemcpyHostToDevice, st));
     FMD_HIP_TRY(hipStreamSynchronize(st)); // seed[] is a stack buffer
     const FmdIndexView ix = fmd_view(h);
-    const int grid = fmd_grid_for_lds(h, cap, FMD_COMPACT_LDS_U4 * 16);
+    // both kernels walk the frontier by static ranges: the grid is the smaller of the two resident sets
+    static int per_cu = 0;
+    if (!per_cu) {
+        const int a = fmd_resident_per_cu(k_kmer_level, FMD_COMPACT_LDS_U4 * 16, 16, "k_kmer_level");
+        const int b = fmd_resident_per_cu(k_kmer_emit, FMD_COMPACT_LDS_U4 * 16, 16, "k_kmer_emit");
+        per_cu = a < b ? a : b;
+    }
+    int grid = fmd_grid_for_lds(h, cap, FMD_COMPACT_LDS_U4 * 16);
+    if (grid > h->n_cu * per_cu) grid = h->n_cu * per_cu;
     // chunk of output slots a wave reserves per atomic: as large as the capacity comfortably allows
     // (at most one partial chunk per wave is wasted per level), at least one iteration's worth (256)
     static const int xcd_aware = getenv("FMD_KMER_XCD") ? atoi(getenv("FMD_KMER_XCD")) : 1;

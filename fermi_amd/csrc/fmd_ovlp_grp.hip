@@ -319,13 +319,9 @@ static int grp_blocks_per_cu(void)
 {
     static int cached = 0;
     if (!cached) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ovl_nei_grp<G>, 64, 0) != hipSuccess || nb < 1) nb = 1;
-        const int by_lds = (160 * 1024) / (((GRP_LDS_U4 * 16 + 1279) / 1280) * 1280);
-        if (nb > by_lds) nb = by_lds;
+        int nb = fmd_resident_per_cu(k_ovl_nei_grp<G>, GRP_LDS_U4 * 16, 16, "k_ovl_nei_grp");
         const char *e = getenv("FMD_GRP_WAVES"); // A/B knob: fewer resident waves per CU
         if (e && atoi(e) > 0 && atoi(e) < nb) nb = atoi(e);
-        if (getenv("FMD_DEBUG_OCC")) fprintf(stderr, "[occupancy] k_ovl_nei_grp<%d>: %d blocks per CU\n", G, nb);
         cached = nb;
     }
     return cached;
