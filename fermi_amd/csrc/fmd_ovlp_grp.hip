@@ -22,12 +22,16 @@
 
 // LDS per wave: one block slot per lane for the k side of the forward extension (slot 0) and of
 // the sentinel window (slot 1); the l sides, needed only when a range straddles a block boundary
-// (~11 % of the lanes each), share a small compacted pool; then the re-pack staging area.
+// (~17 % of the lanes each: a first-round candidate is the whole interval of the overlap string),
+// share a compacted pool.  The re-pack staging area (2 KiB) reuses the pool: the last pool read
+// of a round (the windows) is issued before the first staging write and LDS serves a wave in order.
+// 12.25 KiB -> 12 waves per CU (LDS comes in 1280-byte granules).
 #define GRP_POOL (32 * 8 / FMD_BLK_U4)       // spill blocks per wave step (4 KiB)
 #define GRP_SLOTS_U4 (2 * FMD_SLOT_U4)
 #define GRP_POOL_U4 (GRP_POOL * FMD_BLK_U4)
 #define GRP_STAGE_U4 128
-#define GRP_LDS_U4 (GRP_SLOTS_U4 + GRP_POOL_U4 + GRP_STAGE_U4 + GRP_POOL / 4)
+#define GRP_LDS_U4 (GRP_SLOTS_U4 + GRP_POOL_U4 + GRP_POOL / 4)
+static_assert(GRP_STAGE_U4 <= GRP_POOL_U4, "staging area must fit the pool it reuses");
 
 // ---------------------------------------------------------------------------- classification
 // one thread per strand: work lists for the get_nei kernels.  Positions come from a block-wide count
@@ -85,8 +89,8 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
                                                     uint32_t seq_stride, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_n)
 {
     __shared__ uint4 lds[GRP_LDS_U4];
-    uint4 *pool = lds + GRP_SLOTS_U4, *stage = pool + GRP_POOL_U4;
-    uint32_t *pool_blk = (uint32_t *)(stage + GRP_STAGE_U4);
+    uint4 *pool = lds + GRP_SLOTS_U4, *stage = pool;
+    uint32_t *pool_blk = (uint32_t *)(pool + GRP_POOL_U4);
     constexpr int S = 64 / G;
     constexpr uint32_t GM = G == 32 ? 0xffffffffu : (1u << G) - 1;
     const int lane = fmd_lane(), g = lane / G, j = lane % G, gbase = g * G;
