@@ -171,6 +171,18 @@ __global__ __launch_bounds__(64) void k_ovl_intv(FmdIndexView ix, size_t n, int 
 // Candidates are pushed with info = depth (their start is len - depth, known only at the end).
 enum { WK_IDLE = 0, WK_LF, WK_EXT, WK_BOTH, WK_RIGHT };
 
+// every 4th base: the word moves into its place of the 16-byte group; every 16th: one store
+#define WALK_STASH_WORD()                                                                                  \
+    do {                                                                                                   \
+        const uint32_t wq_ = (depth >> 2) & 3;                                                             \
+        if (wq_ == 1) pk0 = pack; else if (wq_ == 2) pk1 = pack; else if (wq_ == 3) pk2 = pack;            \
+        else {                                                                                             \
+            if (depth <= stride_r) *(uint4 *)(srev + sid * (size_t)stride_r + depth - 16) = make_uint4(pk0, pk1, pk2, pack); \
+            pk0 = pk1 = pk2 = 0;                                                                           \
+        }                                                                                                  \
+        pack = 0;                                                                                          \
+    } while (0)
+
 __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, const uint64_t *__restrict__ ids, int min_match,
                                                  uint8_t *__restrict__ srev, uint32_t stride_r, uint32_t cap,
                                                  fmd_intv_t *__restrict__ listA, fmd_ovlp_rec_t *__restrict__ rec,
@@ -181,6 +193,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
     size_t sid = 0;
     int st = WK_IDLE, c_pend = 0, ret = 0;
     uint32_t depth = 0, npush = 0, pack = 0, flags = 0;
+    uint32_t pk0 = 0, pk1 = 0, pk2 = 0;   // the stash is written 16 bases at a time (one 16-byte store per lane instead of four words)
     uint64_t k = 0, x0 = 0, x1 = 0, sz = 0;
     bool exhausted = false;
     // The first ptab_d bases need no interval arithmetic when nothing can be pushed that early
@@ -194,7 +207,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
     for (;;) {
         const size_t my = fmd_tickets_take(tk_, queue, st == WK_IDLE && !exhausted);
         if (st == WK_IDLE && !exhausted) {
-            if (my < n) { sid = my; k = ids[my]; depth = 0; npush = 0; pack = 0; flags = 0; ret = 0; st = WK_LF; tab = tab_ok; }
+            if (my < n) { sid = my; k = ids[my]; depth = 0; npush = 0; pack = 0; pk0 = pk1 = pk2 = 0; flags = 0; ret = 0; st = WK_LF; tab = tab_ok; }
             else exhausted = true;
         }
         if (__ballot(st != WK_IDLE) == 0) break;
@@ -257,16 +270,13 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             k = ix.cnt[c] + fmd_block_rank1(img, tt, off + 1, c, kb_) - 1;
             if (st == WK_LF && depth > 0 && tab) { // still inside the prefix table: no extension, just collect the base
                 if (c < 1 || c > 4) { // the sequence ends, or an ambiguous base: start over on the ordinary path
-                    k = ids[sid]; depth = 0; pack = 0; tab = false;
+                    k = ids[sid]; depth = 0; pack = 0; pk0 = pk1 = pk2 = 0; tab = false;
                     continue;
                 }
                 tfw |= (uint32_t)(c - 1) << (2 * depth); trv = trv << 2 | (uint32_t)(4 - c);
                 pack |= (uint32_t)c << (8 * (depth & 3));
                 ++depth;
-                if ((depth & 3) == 0) {
-                    if (depth <= stride_r) *(uint32_t *)(srev + sid * (size_t)stride_r + depth - 4) = pack;
-                    pack = 0;
-                }
+                if ((depth & 3) == 0) WALK_STASH_WORD();
                 if ((int)depth == ix.ptab_d) {
                     const uint4 ef = ix.ptab[tfw], er = ix.ptab[trv];
                     x0 = (uint64_t)ef.y << 32 | ef.x;
@@ -325,28 +335,19 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
                 x1 += before; sz = sc;
                 pack |= (uint32_t)c << (8 * (depth & 3));
                 ++depth;
-                if ((depth & 3) == 0) {
-                    if (depth <= stride_r) *(uint32_t *)(srev + sid * (size_t)stride_r + depth - 4) = pack;
-                    pack = 0;
-                }
+                if ((depth & 3) == 0) WALK_STASH_WORD();
             } else { // '$': the sequence is complete (len = depth); these ranks are the left test of fm6_is_contained
-                if ((depth & 3) && depth < stride_r) *(uint32_t *)(srev + sid * (size_t)stride_r + (depth & ~3u)) = pack;
+                if ((depth & 15) && depth <= stride_r) // the last, partial group of 16 (stride_r is a multiple of 16)
+                {   // completed words of the group sit in pk0..2, a partial word in pack; everything past it is zero
+                    const uint32_t wq = (depth >> 2) & 3;
+                    *(uint4 *)(srev + sid * (size_t)stride_r + (depth & ~15u)) = make_uint4(wq == 0 ? pack : pk0, wq == 1 ? pack : pk1, wq == 2 ? pack : pk2, wq == 3 ? pack : 0u);
+                }
                 fmd_ovlp_rec_t *o = rec + sid;
                 o->rank = k; o->len = (int32_t)depth; o->rbeg = -1; o->ext_len = 0; o->n_nei = 0; o->reserved = 2;
                 o->k[0] = o->k[1] = o->k[2] = 0; o->n_ovlp = 0;
                 if (depth > stride_r) { o->status = 0; o->flags = FMD_OVLP_F_OVERFLOW; st = WK_IDLE; continue; } // longer than max_len
                 if (!info_only && (int)depth <= min_match) { o->status = -1; o->flags = 0; st = WK_IDLE; continue; } // too short (unitig.c:288)
-                {   // the sequence in read order for the caller: srev byte-reversed, one burst
-                    const uint8_t *sr = srev + sid * (size_t)stride_r;
-                    uint8_t *dst = seq_out + sid * (size_t)seq_stride;
-                    const int L = (int)depth, nw = (L + 3) >> 2;
-                    for (int w = 0; w < nw; ++w) {
-                        uint32_t v = 0;
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) { const int i = 4 * w + b; if (i < L) v |= (uint32_t)sr[L - 1 - i] << (8 * b); }
-                        if ((uint32_t)(4 * w + 3) < seq_stride) *(uint32_t *)(dst + 4 * w) = v;
-                    }
-                }
+                // (the caller's copy in read order is made by k_ovl_seq_out: a lane doing it here holds up the other 63)
                 if (sz != s[0]) ret = -1;          // left-contained
                 x0 = tk[0]; sz = s[0];             // ok[0]: x[0] = cnt[0] + tk[0], x[1] unchanged
                 st = WK_RIGHT;
@@ -370,6 +371,33 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             st = (bq == bk_ || bq == bl_) ? WK_BOTH : WK_LF;
             if (tab) st = WK_LF;   // inside the prefix table there is no extension to share a gather with
         }
+    }
+}
+
+#undef WALK_STASH_WORD
+
+// The caller's copy of every sequence in read order: the stash holds it last base first.  One thread
+// per output word; the same conditions under which a record describes a complete sequence
+// (k_ovl_walk: not empty, not longer than max_len, longer than min_match unless info_only).
+__global__ void k_ovl_seq_out(size_t n, uint32_t words, const uint8_t *__restrict__ srev, uint32_t stride_r, const fmd_ovlp_rec_t *__restrict__ rec,
+                              int min_match, int info_only, uint8_t *__restrict__ seq_out, uint32_t seq_stride)
+{
+    const size_t total = n * (size_t)words, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const size_t sid = i / words;
+        const uint32_t w = (uint32_t)(i - sid * words);
+        const int L = rec[sid].len;
+        if (L <= 0 || (uint32_t)L > stride_r || (!info_only && L <= min_match) || (int)(4 * w) >= L || 4 * w + 3 >= seq_stride) continue;
+        const uint8_t *sr = srev + sid * (size_t)stride_r;
+        // output bytes 4w..4w+3 = stash bytes a+3..a with a = L - 4 - 4w: an unaligned word, byte-swapped
+        const int a = L - 4 - (int)(4 * w);
+        uint32_t v;
+        if (a >= 0) {
+            const uint32_t *q = (const uint32_t *)(sr + (a & ~3));
+            const uint64_t two = (a & 3) ? ((uint64_t)q[1] << 32 | q[0]) : q[0];
+            v = __builtin_bswap32((uint32_t)(two >> (8 * (a & 3))));
+        } else v = __builtin_bswap32(*(const uint32_t *)sr << (8 * -a)); // the first 4 + a bases of the stash, the rest of the word zero
+        *(uint32_t *)(seq_out + sid * (size_t)seq_stride + 4 * w) = v;
     }
 }
 
@@ -721,10 +749,19 @@ __global__ __launch_bounds__(64) void k_ovl_cls(FmdIndexView ix, size_t n, int m
 
 // ------------------------------------------------------------------------------- host entry
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static void launch_seq_out(hipStream_t st, size_t n, uint32_t max_len, const uint8_t *srev, uint32_t stride_r, const fmd_ovlp_rec_t *rec, int min_match,
+                           int info_only, uint8_t *seq_out, uint32_t seq_stride)
+{
+    const uint32_t words = (max_len + 3) / 4;
+    const size_t total = n * (size_t)words;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > (1u << 22)) blocks = 1u << 22;
+    k_ovl_seq_out<<<(unsigned)blocks, 256, 0, st>>>(n, words, srev, stride_r, rec, min_match, info_only, seq_out, seq_stride);
+}
 
 extern "C" size_t fmd_ovlp_work_bytes(size_t n, uint32_t max_len, int min_match)
 {
-    const size_t stride_r = align_up((size_t)max_len, 4);
+    const size_t stride_r = align_up((size_t)max_len, 16);
     const size_t cap = fmd_ovlp_list_cap(max_len, min_match);
     return align_up(n * stride_r, 256) + 2 * align_up(n * cap * sizeof(fmd_intv_t), 256) + align_up(n * (8 * FMD_GRP_CLASSES + 4) + 4 * FMD_CLS_HEADER_U32, 256) + 256;
 }
@@ -739,7 +776,7 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
     if (fmd_ovlp_list_cap(max_len, min_match) >= 4096) return FMD_E_ARG; // category index is packed in 12 bits
     FMD_HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream_;
-    const uint32_t stride_r = (uint32_t)align_up(max_len, 4);
+    const uint32_t stride_r = (uint32_t)align_up(max_len, 16);
     const uint32_t cap = fmd_ovlp_list_cap(max_len, min_match);
     uint8_t *srev = (uint8_t *)d_work;
     fmd_intv_t *listA = (fmd_intv_t *)((uint8_t *)d_work + align_up(n * (size_t)stride_r, 256));
@@ -750,8 +787,10 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
     if (getenv("FMD_OVLP_UNFUSED")) { // A/B switch: separate LF-walk and overlap_intv passes
         k_ovl_retrieve<<<grid, 64, 0, st>>>(ix, n, d_ids, srev, stride_r, d_rec, q0);
         k_ovl_intv<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, d_rec, d_seq, seq_stride, q1);
-    } else
+    } else {
         k_ovl_walk<<<fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16), 64, 0, st>>>(ix, n, d_ids, min_match, srev, stride_r, cap, listA, d_rec, d_seq, seq_stride, q0, 0);
+        launch_seq_out(st, n, max_len, srev, stride_r, d_rec, min_match, 0, d_seq, seq_stride);
+    }
     if (getenv("FMD_OVLP_SLOW_ONLY")) { // A/B switch: everything through the lane-per-strand kernel
         k_ovl_nei<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, listB, d_rec, d_nei, max_nei, d_seq, seq_stride, q2, nullptr, nullptr);
     } else {
@@ -796,7 +835,7 @@ extern "C" int fmd_ovlp_check_left_dev(fmd_dev_t *h, void *stream_, size_t n, in
     if (work_bytes < fmd_ovlp_work_bytes(n, max_len, min_match)) return FMD_E_ARG;
     FMD_HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream_;
-    const uint32_t stride_r = (uint32_t)align_up(max_len, 4);
+    const uint32_t stride_r = (uint32_t)align_up(max_len, 16);
     const uint32_t cap = fmd_ovlp_list_cap(max_len, min_match);
     fmd_intv_t *listA = (fmd_intv_t *)((uint8_t *)d_work + align_up(n * (size_t)stride_r, 256));
     fmd_intv_t *listB = (fmd_intv_t *)((uint8_t *)listA + align_up(n * (size_t)cap * sizeof(fmd_intv_t), 256));
@@ -818,13 +857,14 @@ extern "C" int fmd_seqinfo_dev(fmd_dev_t *h, void *stream_, size_t n, const uint
     if (n >= 0xffffff00ull || work_bytes < fmd_ovlp_work_bytes(n, max_len, (int)max_len - 1)) return FMD_E_ARG;
     FMD_HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream_;
-    const uint32_t stride_r = (uint32_t)align_up(max_len, 4);
+    const uint32_t stride_r = (uint32_t)align_up(max_len, 16);
     const uint32_t cap = fmd_ovlp_list_cap(max_len, (int)max_len - 1);
     uint8_t *srev = (uint8_t *)d_work;
     fmd_intv_t *listA = (fmd_intv_t *)((uint8_t *)d_work + align_up(n * (size_t)stride_r, 256));
     uint32_t *q0 = fmd_next_queue(h, st);
     k_ovl_walk<<<fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16), 64, 0, st>>>(fmd_view(h), n, d_ids, 0, srev, stride_r, cap, listA, d_rec,
                                                                              d_seq, seq_stride, q0, 1);
+    launch_seq_out(st, n, max_len, srev, stride_r, d_rec, 0, 1, d_seq, seq_stride);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "k_ovl_walk"); return FMD_E_HIP; }
     return FMD_OK;
