@@ -236,7 +236,7 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
         alg = qps * BYTES_PER_RANK_QUERY * n_ids
         ach = alg / (kern_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": None, "kernel": "k_ovl_walk + k_ovl_classify + k_ovl_nei_grp<16> + k_ovl_nei_grp<32> + k_ovl_nei (one step = %d batches of %d strands)" % ((n_ids + batch - 1) // batch, batch),
+                           "traffic": None, "kernel": "k_ovl_walk + k_ovl_seq_out + k_ovl_classify + k_ovl_nei_grp<8|12|16|21|32> + k_ovl_nei (one step = %d batches of %d strands)" % ((n_ids + batch - 1) // batch, batch),
                            "kernel_ms": kern_ms, "rank_queries_per_strand": qps, "algorithmic_bytes_per_read": 2 * qps * BYTES_PER_RANK_QUERY,
                            "oracle_counters_on_sample": cnts}
         try:
