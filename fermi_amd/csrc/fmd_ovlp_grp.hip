@@ -3,8 +3,8 @@
 // fm6_get_nei advances a list of candidate intervals (one per read that might overlap the strand)
 // by one base per round.  The lane-per-strand kernel (k_ovl_nei, fmd_ovlp.hip) keeps those lists
 // in HBM and pays for it: profiles/r1_ovlp showed 154 GB of traffic per 4 M-strand launch against
-// 53 GB of rank blocks.  Here a strand owns a group of G = 16 or 32 lanes and its candidate list
-// IS the group's registers:
+// 53 GB of rank blocks.  Here a strand owns a group of G lanes (G = 8, 12, 16, 21 or 32: the smallest
+// that holds its candidates, fmd_grp_size) and its candidate list IS the group's registers:
 //   * one wave step = one round of every resident strand (64/G of them): each live lane extends
 //     its interval forward (rank2a on the x[1] strand) and, from the SAME step, answers the
 //     backward `$` tests of unitig.c:112 and :129 for ok[0] and all four children: they are ranks
@@ -12,11 +12,11 @@
 //     (two if the range straddles) whose address is known before the extension returns;
 //   * the sequential semantics of the reference's loop (first neighbour of a category masks the
 //     rest of it; children ordered by old category, base, start) are prefix computations on
-//     group ballots; children are re-packed through a 2 KiB LDS staging area;
+//     group ballots; children are re-packed through a 2 KiB LDS staging area (it reuses the spill pool);
 //   * the next strand of every group is prefetched (descriptor, then candidates) under the rank
 //     gathers of the current one.
-// Strands that do not fit the fast shape -- more than G candidates, an interval wider than a rank
-// block, more neighbours than max_nei, or the fake-fork fix-up of unitig.c:158-176 -- are handed
+// Strands that do not fit the fast shape -- more than 32 candidates, an interval wider than 63,
+// more neighbours than max_nei, or the fake-fork fix-up of unitig.c:158-176 -- are handed
 // to k_ovl_nei through the `slow` work list; nothing is approximated.
 #include "fmd_kernel_common.h"
 
