@@ -58,8 +58,9 @@ __device__ __forceinline__ void grp_window(const uint4 *img_k, int t_k, const ui
 }
 __device__ __forceinline__ uint64_t win64(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t sh)
 {
-    const uint64_t lo = ((uint64_t)w1 << 32 | w0) >> sh;
-    return sh ? lo | (uint64_t)w2 << (64 - sh) : lo;
+    // two funnel shifts (v_alignbit_b32: low word of {hi, lo} >> sh, sh in 0..31)
+    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+    return (uint64_t)hi << 32 | lo;
 }
 __device__ __forceinline__ uint64_t range64(uint32_t a, uint32_t b) // bits [a, b), b <= 64
 {

@@ -154,11 +154,10 @@ __global__ __launch_bounds__(64) void k_kmer_level(FmdIndexView ix, int d, int s
         const uint32_t tot = (uint32_t)(__popcll(m1) + __popcll(m2) + __popcll(m3) + __popcll(m4));
         if (tot == 0) continue;
         const unsigned long long first = km_reserve(out, cap, ck, tot, &ctr[d + 1]);
-        const uint64_t lt = (1ull << lane) - 1;
-        uint64_t o1 = first + __popcll(m1 & lt);
-        uint64_t o2 = first + __popcll(m1) + __popcll(m2 & lt);
-        uint64_t o3 = first + __popcll(m1) + __popcll(m2) + __popcll(m3 & lt);
-        uint64_t o4 = first + __popcll(m1) + __popcll(m2) + __popcll(m3) + __popcll(m4 & lt);
+        uint64_t o1 = first + fmd_below(m1);
+        uint64_t o2 = first + __popcll(m1) + fmd_below(m2);
+        uint64_t o3 = first + __popcll(m1) + __popcll(m2) + fmd_below(m3);
+        uint64_t o4 = first + __popcll(m1) + __popcll(m2) + __popcll(m3) + fmd_below(m4);
         const uint64_t x1_4 = x1 + s[0], x1_3 = x1_4 + s[4], x1_2 = x1_3 + s[3], x1_1 = x1_2 + s[2];
 #define KM_PUSH(c, has, o, x1c)                                                                   \
         if (has) {                                                                                \

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(CLS_THREADS) void k_ovl_classify(size_t n, const fm
     for (int c = 0; c <= FMD_GRP_CLASSES; ++c) {
         const uint64_t mk = __ballot(cls == c);
         if (lane == 0) wcnt[wave][c] = (uint32_t)__popcll(mk);
-        if (cls == c) in_wave = (uint32_t)__popcll(mk & ((1ull << lane) - 1));
+        if (cls == c) in_wave = (uint32_t)fmd_below(mk);
     }
     __syncthreads();
     if (threadIdx.x <= FMD_GRP_CLASSES) {      // exclusive scan over the waves, then the block's slice of the list
@@ -155,8 +155,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
         // straddling ranges: compact the extra blocks into the pool (ballot prefix), 8 per instruction
         const uint64_t me = __ballot(e_sep), mb = __ballot(b_sep);
         const int n_e = __popcll(me), n_spill = n_e + __popcll(mb);
-        const uint64_t lt64 = (1ull << lane) - 1;
-        const int pe = __popcll(me & lt64), pb = n_e + __popcll(mb & lt64);
+        const int pe = fmd_below(me), pb = n_e + fmd_below(mb);
         if (n_spill) {
             if (e_sep && pe < GRP_POOL) pool_blk[pe] = ble;
             if (b_sep && pb < GRP_POOL) pool_blk[pb] = blb;
@@ -180,34 +179,36 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
         //   sentinel tests   : '$' in the child sub-ranges of BWT[x0, x0+size)  (extend0 of unitig.c:112/:129)
         // Absolute ranks are needed only for the coordinates that survive: x[1] of the kept child
         // (one rank of one symbol) and the two coordinates of a neighbour.
-        uint64_t s[6] = {0, 0, 0, 0, 0, 0};
+        uint32_t s[6] = {0, 0, 0, 0, 0, 0};   // child sizes (<= 63)
         bool is_nei = false;
         uint32_t cm = 0;                    // children c = 1..4 that survive the sentinel test
         if (live) {
+            const uint32_t sz32 = (uint32_t)sz;
             {   // window of BWT[x1 ...]
                 const uint32_t sh = (uint32_t)x1 & 31;
                 uint4 a, b, c;
                 grp_window(img_e, t, img_el, t_el, bke, ble, true, e_sep, bke, oke, a, b, c);
                 // x1 itself may sit in the block after ke's (ke = x1-1 is the last position of a block)
-                const uint64_t m = bits_below((int)sz);
+                const uint64_t m = (1ull << sz32) - 1;
                 const uint64_t X = win64(a.x, b.x, c.x, sh), Y = win64(a.y, b.y, c.y, sh), Z = win64(a.z, b.z, c.z, sh);
                 const uint64_t lo = ~Z & m, hi = Z & ~Y & m;
                 s[0] = __popcll(lo & ~Y & ~X); s[1] = __popcll(lo & ~Y & X); s[2] = __popcll(lo & Y & ~X); s[3] = __popcll(lo & Y & X);
-                s[4] = __popcll(hi & ~X); s[5] = sz - (s[0] + s[1] + s[2] + s[3] + s[4]);
+                s[4] = __popcll(hi & ~X); s[5] = sz32 - (s[0] + s[1] + s[2] + s[3] + s[4]);
             }
             {   // '$' of BWT[x0 ...], children laid out in the order $,T,G,C,A (exact.c:81-86)
                 const uint32_t sh = (uint32_t)x0 & 31;
                 uint4 a, b, c;
                 grp_window(img_b, t, img_bl, t_bl, bkb, blb, true, b_sep, bkb, okb, a, b, c);
-                const uint64_t D = win64(~a.x & ~a.y & ~a.z, ~b.x & ~b.y & ~b.z, ~c.x & ~c.y & ~c.z, sh);
-                const uint32_t o1 = (uint32_t)s[0], o2 = o1 + (uint32_t)s[4], o3 = o2 + (uint32_t)s[3], o4 = o3 + (uint32_t)s[2], o5 = o4 + (uint32_t)s[1];
-                const uint64_t e0sz = __popcll(D & range64(0, o1));
+                const uint64_t D = win64(~(a.x | a.y | a.z), ~(b.x | b.y | b.z), ~(c.x | c.y | c.z), sh);
+                // sub-range [o_k, o_k+1) of the window = 2^o_k+1 - 2^o_k (all offsets <= 63)
+                const uint64_t B1 = 1ull << s[0], B2 = B1 << s[4], B3 = B2 << s[3], B4 = B3 << s[2], B5 = B4 << s[1];
+                const uint32_t e0sz = (uint32_t)__popcll(D & (B1 - 1));
                 // unitig.c:111-122: a read ends here, bounded by sentinels on both sides, not contained
-                is_nei = round > 0 && s[0] && e0sz && s[0] == sz && sz == e0sz;
-                if (s[4] && (D & range64(o1, o2))) cm |= 1u << 4;
-                if (s[3] && (D & range64(o2, o3))) cm |= 1u << 3;
-                if (s[2] && (D & range64(o3, o4))) cm |= 1u << 2;
-                if (s[1] && (D & range64(o4, o5))) cm |= 1u << 1;
+                is_nei = round > 0 && s[0] && s[0] == sz32 && e0sz == sz32;
+                if (s[4] && (D & (B2 - B1))) cm |= 1u << 4;
+                if (s[3] && (D & (B3 - B2))) cm |= 1u << 3;
+                if (s[2] && (D & (B4 - B3))) cm |= 1u << 2;
+                if (s[1] && (D & (B5 - B4))) cm |= 1u << 1;
             }
         }
 
@@ -259,11 +260,11 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
                     const int pc = c == 1 ? p1 : c == 2 ? p2 : c == 3 ? p3 : p4;
                     const uint32_t cmask = c == 1 ? c1 : c == 2 ? c2 : c == 3 ? c3 : c4;
                     const uint64_t cx0 = c == 1 ? cx0_1 : c == 2 ? cx0_2 : c == 3 ? cx0_3 : cx0_4;
-                    const uint64_t sc = c == 1 ? s[1] : c == 2 ? s[2] : c == 3 ? s[3] : s[4];
+                    const uint32_t sc = c == 1 ? s[1] : c == 2 ? s[2] : c == 3 ? s[3] : s[4];
                     const uint64_t nx1 = (c == 1 ? ix.cnt[1] : c == 2 ? ix.cnt[2] : c == 3 ? ix.cnt[3] : ix.cnt[4]) + r;
                     const int d = pc + __popc(cmask & lt_m);
                     stage[2 * (gbase + d)] = make_uint4((uint32_t)cx0, (uint32_t)(cx0 >> 32), (uint32_t)nx1, (uint32_t)(nx1 >> 32));
-                    stage[2 * (gbase + d) + 1] = make_uint4((uint32_t)sc, (uint32_t)(sc >> 32), pos, (uint32_t)pc);
+                    stage[2 * (gbase + d) + 1] = make_uint4(sc, 0u, pos, (uint32_t)pc);
                     forked_now |= pc != 0;
                     todo &= todo - 1;
                 } else if (nei_todo == 2) { nei_r1 = r; nei_todo = 1; }

@@ -75,6 +75,11 @@ struct FmdIndexView {            // passed by value as a kernel argument (lives 
 };
 
 __device__ __forceinline__ int fmd_lane() { return (int)(threadIdx.x & 63); }
+// number of set bits of a wave-uniform mask below this lane (v_mbcnt_lo/hi: two instructions)
+__device__ __forceinline__ int fmd_below(uint64_t mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
 
 // position -> (block, offset inside the block)
 #if FMD_BLK64
@@ -370,7 +375,7 @@ __device__ __forceinline__ FmdRank2 fmd_wave_rank2_fetch(const FmdIndexView &ix,
         if (n_sep <= FMD_POOL_BLOCKS) { // compact pool in slot 1; block ids after the two slots
             uint4 *pool = lds + FMD_SLOT_U4;
             uint32_t *ids = (uint32_t *)(lds + 2 * FMD_SLOT_U4);
-            const int p = __popcll(m & ((1ull << q) - 1));
+            const int p = fmd_below(m);
             if (l_sep) ids[p] = r.blk_l;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             fmd_fetch_pool(ix, pool, ids, n_sep);
@@ -423,7 +428,7 @@ __device__ __forceinline__ FmdRank2c fmd_wave_rank2_fetch_compact(const FmdIndex
         if (n_sep <= FMD_POOL_BLOCKS) {
             uint4 *pool = lds + FMD_SLOT_U4;
             uint32_t *ids = (uint32_t *)(pool + FMD_POOL_BLOCKS * FMD_BLK_U4);
-            const int p = __popcll(m & ((1ull << q) - 1));
+            const int p = fmd_below(m);
             if (r.l_sep) ids[p] = r.blk_l;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             fmd_fetch_pool(ix, pool, ids, n_sep);
