@@ -23,15 +23,19 @@
 // LDS per wave: one block slot per lane for the k side of the forward extension (slot 0) and of
 // the sentinel window (slot 1); the l sides, needed only when a range straddles a block boundary
 // (~17 % of the lanes each: a first-round candidate is the whole interval of the overlap string),
-// share a compacted pool.  The re-pack staging area (2 KiB) reuses the pool: the last pool read
-// of a round (the windows) is issued before the first staging write and LDS serves a wave in order.
-// 12.25 KiB -> 12 waves per CU (LDS comes in 1280-byte granules).
-#define GRP_POOL (32 * 8 / FMD_BLK_U4)       // spill blocks per wave step (4 KiB)
+// share a compacted pool of 30 blocks; a wave step that needs more (0.2 % of them) takes the pool
+// in several passes.  One 2 KiB region holds the pool (1920 bytes), the block numbers to fetch
+// (128 bytes) and -- later in the step, when the windows have been read -- the re-pack staging
+// area.  10 KiB per wave = 8 LDS granules -> 16 waves per CU.
+#ifndef GRP_POOL
+#define GRP_POOL 30                          // spill blocks per pass (-DGRP_POOL=4 stresses the multi-pass path in the tests)
+#endif
 #define GRP_SLOTS_U4 (2 * FMD_SLOT_U4)
-#define GRP_POOL_U4 (GRP_POOL * FMD_BLK_U4)
+#define GRP_REGION_U4 128
 #define GRP_STAGE_U4 128
-#define GRP_LDS_U4 (GRP_SLOTS_U4 + GRP_POOL_U4 + GRP_POOL / 4)
-static_assert(GRP_STAGE_U4 <= GRP_POOL_U4, "staging area must fit the pool it reuses");
+#define GRP_LDS_U4 (GRP_SLOTS_U4 + GRP_REGION_U4)
+static_assert(GRP_POOL * FMD_BLK_U4 + 8 <= GRP_REGION_U4 && GRP_STAGE_U4 <= GRP_REGION_U4, "pool + 32 block numbers, and the staging area, share the region");
+static_assert(FMD_BLK_U4 == 4, "the group kernels are laid out for the 64-byte block geometry");
 
 // ---------------------------------------------------------------------------- classification
 // one thread per strand: work lists for the get_nei kernels.  Positions come from a block-wide count
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
 {
     __shared__ uint4 lds[GRP_LDS_U4];
     uint4 *pool = lds + GRP_SLOTS_U4, *stage = pool;
-    uint32_t *pool_blk = (uint32_t *)(pool + GRP_POOL_U4);
+    uint32_t *pool_blk = (uint32_t *)(pool + GRP_REGION_U4 - 8);
     constexpr int S = 64 / G;
     constexpr uint32_t GM = G == 32 ? 0xffffffffu : (1u << G) - 1;
     const int lane = fmd_lane(), g = lane / G, j = lane % G, gbase = g * G;
@@ -152,31 +156,47 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
         const bool e_sep = live && ble != bke, b_sep = live && blb != bkb;
         fmd_fetch_slot<0>(ix, lds, bke, live);
         fmd_fetch_slot<1>(ix, lds, bkb, live);
-        // straddling ranges: compact the extra blocks into the pool (ballot prefix), 8 per instruction
+        // straddling ranges: compact the extra blocks into the pool (ballot prefix), 16 per instruction,
+        // GRP_POOL per pass.  Every interval here has size <= 63 (k_ovl_classify), so "rank2a" is a count
+        // over a 64-position window of the planes read straight from the lane's LDS block images:
+        //   forward extension: symbols of BWT[x1, x1+size)          -> sizes of the six children
+        //   sentinel tests   : '$' in the child sub-ranges of BWT[x0, x0+size)  (extend0 of unitig.c:112/:129)
+        // A lane reads its windows in the pass that brings its spill block(s), or in the first one.
         const uint64_t me = __ballot(e_sep), mb = __ballot(b_sep);
         const int n_e = __popcll(me), n_spill = n_e + __popcll(mb);
         const int pe = fmd_below(me), pb = n_e + fmd_below(mb);
-        if (n_spill) {
-            if (e_sep && pe < GRP_POOL) pool_blk[pe] = ble;
-            if (b_sep && pb < GRP_POOL) pool_blk[pb] = blb;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const int n_fetch = n_spill < GRP_POOL ? n_spill : GRP_POOL;
-            fmd_fetch_pool(ix, pool, pool_blk, n_fetch);
-        }
-        // a lane whose spill block did not fit the pool cannot be computed this way: its strand goes
-        // to the lane-per-strand kernel (practically never: the pool holds 32, the mean need is ~14)
-        const bool unserved = (e_sep && pe >= GRP_POOL) || (b_sep && pb >= GRP_POOL);
-        const uint32_t unserved_g = (uint32_t)(__ballot(unserved) >> gbase) & GM;
-        fmd_fetch_wait();
         const int t = fmd_chunk_xor(lane);
         const uint4 *img_e = lds + fmd_lds_base(lane, 0), *img_b = lds + fmd_lds_base(lane, 1);
-        const uint4 *img_el = pool + (e_sep ? (pe & (GRP_POOL - 1)) : 0) * FMD_BLK_U4, *img_bl = pool + (b_sep ? (pb & (GRP_POOL - 1)) : 0) * FMD_BLK_U4;
-        const int t_el = fmd_pool_xor(pe & (GRP_POOL - 1)), t_bl = fmd_pool_xor(pb & (GRP_POOL - 1));
+        uint64_t X = 0, Y = 0, Z = 0, D = 0;
+        bool need_e = live, need_b = live;
+        for (int base = 0;; base += GRP_POOL) {
+            const int re = pe - base, rb = pb - base;
+            const bool in_e = e_sep && re >= 0 && re < GRP_POOL, in_b = b_sep && rb >= 0 && rb < GRP_POOL;
+            const int n_here = n_spill - base < GRP_POOL ? n_spill - base : GRP_POOL;
+            if (n_here > 0) {
+                if (in_e) pool_blk[re] = ble;
+                if (in_b) pool_blk[rb] = blb;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                fmd_fetch_pool(ix, pool, pool_blk, n_here);
+            }
+            fmd_fetch_wait();
+            if (need_e && (!e_sep || in_e)) {   // window of BWT[x1 ...]; x1 may sit in the block after ke's (ke = x1-1)
+                uint4 a, b, c;
+                grp_window(img_e, t, pool + (in_e ? re : 0) * FMD_BLK_U4, fmd_pool_xor(in_e ? re : 0), bke, ble, true, e_sep, bke, oke, a, b, c);
+                const uint32_t sh = (uint32_t)x1 & 31;
+                X = win64(a.x, b.x, c.x, sh); Y = win64(a.y, b.y, c.y, sh); Z = win64(a.z, b.z, c.z, sh);
+                need_e = false;
+            }
+            if (need_b && (!b_sep || in_b)) {   // '$' positions of BWT[x0 ...]
+                uint4 a, b, c;
+                grp_window(img_b, t, pool + (in_b ? rb : 0) * FMD_BLK_U4, fmd_pool_xor(in_b ? rb : 0), bkb, blb, true, b_sep, bkb, okb, a, b, c);
+                D = win64(~(a.x | a.y | a.z), ~(b.x | b.y | b.z), ~(c.x | c.y | c.z), (uint32_t)x0 & 31);
+                need_b = false;
+            }
+            if (base + GRP_POOL >= n_spill) break;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the windows are read before the next pass lands in the pool
+        }
 
-        // Every interval here has size <= 63 (k_ovl_classify), so "rank2a" is a count over a 64-position
-        // window of the planes read straight from the lane's LDS block images:
-        //   forward extension: symbols of BWT[x1, x1+size)          -> sizes of the six children
-        //   sentinel tests   : '$' in the child sub-ranges of BWT[x0, x0+size)  (extend0 of unitig.c:112/:129)
         // Absolute ranks are needed only for the coordinates that survive: x[1] of the kept child
         // (one rank of one symbol) and the two coordinates of a neighbour.
         uint32_t s[6] = {0, 0, 0, 0, 0, 0};   // child sizes (<= 63)
@@ -184,32 +204,20 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
         uint32_t cm = 0;                    // children c = 1..4 that survive the sentinel test
         if (live) {
             const uint32_t sz32 = (uint32_t)sz;
-            {   // window of BWT[x1 ...]
-                const uint32_t sh = (uint32_t)x1 & 31;
-                uint4 a, b, c;
-                grp_window(img_e, t, img_el, t_el, bke, ble, true, e_sep, bke, oke, a, b, c);
-                // x1 itself may sit in the block after ke's (ke = x1-1 is the last position of a block)
-                const uint64_t m = (1ull << sz32) - 1;
-                const uint64_t X = win64(a.x, b.x, c.x, sh), Y = win64(a.y, b.y, c.y, sh), Z = win64(a.z, b.z, c.z, sh);
-                const uint64_t lo = ~Z & m, hi = Z & ~Y & m;
-                s[0] = __popcll(lo & ~Y & ~X); s[1] = __popcll(lo & ~Y & X); s[2] = __popcll(lo & Y & ~X); s[3] = __popcll(lo & Y & X);
-                s[4] = __popcll(hi & ~X); s[5] = sz32 - (s[0] + s[1] + s[2] + s[3] + s[4]);
-            }
-            {   // '$' of BWT[x0 ...], children laid out in the order $,T,G,C,A (exact.c:81-86)
-                const uint32_t sh = (uint32_t)x0 & 31;
-                uint4 a, b, c;
-                grp_window(img_b, t, img_bl, t_bl, bkb, blb, true, b_sep, bkb, okb, a, b, c);
-                const uint64_t D = win64(~(a.x | a.y | a.z), ~(b.x | b.y | b.z), ~(c.x | c.y | c.z), sh);
-                // sub-range [o_k, o_k+1) of the window = 2^o_k+1 - 2^o_k (all offsets <= 63)
-                const uint64_t B1 = 1ull << s[0], B2 = B1 << s[4], B3 = B2 << s[3], B4 = B3 << s[2], B5 = B4 << s[1];
-                const uint32_t e0sz = (uint32_t)__popcll(D & (B1 - 1));
-                // unitig.c:111-122: a read ends here, bounded by sentinels on both sides, not contained
-                is_nei = round > 0 && s[0] && s[0] == sz32 && e0sz == sz32;
-                if (s[4] && (D & (B2 - B1))) cm |= 1u << 4;
-                if (s[3] && (D & (B3 - B2))) cm |= 1u << 3;
-                if (s[2] && (D & (B4 - B3))) cm |= 1u << 2;
-                if (s[1] && (D & (B5 - B4))) cm |= 1u << 1;
-            }
+            const uint64_t m = (1ull << sz32) - 1;
+            const uint64_t lo = ~Z & m, hi = Z & ~Y & m;
+            s[0] = __popcll(lo & ~Y & ~X); s[1] = __popcll(lo & ~Y & X); s[2] = __popcll(lo & Y & ~X); s[3] = __popcll(lo & Y & X);
+            s[4] = __popcll(hi & ~X); s[5] = sz32 - (s[0] + s[1] + s[2] + s[3] + s[4]);
+            // children of the x[0] range laid out in the order $,T,G,C,A (exact.c:81-86);
+            // sub-range [o_k, o_k+1) of the window = 2^o_k+1 - 2^o_k (all offsets <= 63)
+            const uint64_t B1 = 1ull << s[0], B2 = B1 << s[4], B3 = B2 << s[3], B4 = B3 << s[2], B5 = B4 << s[1];
+            const uint32_t e0sz = (uint32_t)__popcll(D & (B1 - 1));
+            // unitig.c:111-122: a read ends here, bounded by sentinels on both sides, not contained
+            is_nei = round > 0 && s[0] && s[0] == sz32 && e0sz == sz32;
+            if (s[4] && (D & (B2 - B1))) cm |= 1u << 4;
+            if (s[3] && (D & (B3 - B2))) cm |= 1u << 3;
+            if (s[2] && (D & (B4 - B3))) cm |= 1u << 2;
+            if (s[1] && (D & (B5 - B4))) cm |= 1u << 1;
         }
 
         // ---- the reference's sequential loop over the list, as prefix logic on group ballots
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging writes done before the re-pack reads
         if (active) {
             if (fork_g) flags |= FMD_OVLP_F_FORKED;
-            if (too_many || n_nei > max_nei || unserved_g) { // hand the strand to the lane-per-strand kernel
+            if (too_many || n_nei > max_nei) { // hand the strand to the lane-per-strand kernel
                 if (j == 0) { const uint32_t k = atomicAdd(slow_n, 1u); slow_list[k] = sid; }
                 active = false; alive = false;
             } else if (n_new > 0) { // next round (unitig.c:137-153)
