@@ -553,6 +553,10 @@ extern "C" void fmd_dev_close(fmd_dev_t *h)
     hipFree(h->blocks);
     hipFree(h->ptab);
     hipFree(h->queues);
+    if (h->aux_ready) {
+        hipStreamDestroy(h->aux_stream);
+        for (int i = 0; i <= FMD_OVLP_MAX_PARTS; ++i) hipEventDestroy(h->aux_ev[i]);
+    }
     free(h);
 }
 

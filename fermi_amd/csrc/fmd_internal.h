@@ -6,6 +6,7 @@
 #include "../../include/fmd_hip.h"
 #include "fmd_wave.h"
 
+#define FMD_OVLP_MAX_PARTS 8
 struct fmd_dev {
     int device;
     int n_cu;                 // compute units on this GPU
@@ -17,6 +18,11 @@ struct fmd_dev {
     int ptab_d;
     uint32_t *queues;         // device ring of work-queue heads for the persistent kernels
     uint32_t queue_next;      // host-side ring cursor (atomic)
+    // second stream + events of the pipelined overlap batch (fmd_ovlp_dev), created on first use;
+    // aux_busy (atomic) lets one call at a time use them, a concurrent call takes the serial path
+    hipStream_t aux_stream;
+    hipEvent_t aux_ev[FMD_OVLP_MAX_PARTS + 1];
+    int aux_ready, aux_busy;
 };
 #define FMD_N_QUEUES 256
 

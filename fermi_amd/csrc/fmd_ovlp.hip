@@ -9,7 +9,7 @@
 #include <string.h>
 #include "fmd_kernel_common.h"
 
-void fmd_launch_nei_grp(int cls, int n_cu, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
+void fmd_launch_nei_grp(int cls, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                         const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
                         uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n);
 void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, const fmd_intv_t *listA, uint32_t cap, FmdOvlClasses cl);
@@ -763,7 +763,114 @@ extern "C" size_t fmd_ovlp_work_bytes(size_t n, uint32_t max_len, int min_match)
 {
     const size_t stride_r = align_up((size_t)max_len, 16);
     const size_t cap = fmd_ovlp_list_cap(max_len, min_match);
-    return align_up(n * stride_r, 256) + 2 * align_up(n * cap * sizeof(fmd_intv_t), 256) + align_up(n * (8 * FMD_GRP_CLASSES + 4) + 4 * FMD_CLS_HEADER_U32, 256) + 256;
+    return align_up(n * stride_r, 256) + 2 * align_up(n * cap * sizeof(fmd_intv_t), 256) +
+           align_up(n * (8 * FMD_GRP_CLASSES + 4) + 4 * FMD_CLS_HEADER_U32 * FMD_OVLP_MAX_PARTS, 256) + 256;
+}
+
+// The buffers of one fmd_ovlp_dev call; the two phases below work on the strands [b, b + np) of it.
+struct OvlBatch {
+    fmd_dev *h; FmdIndexView ix;
+    const uint64_t *ids; int min_match; uint32_t max_len, max_nei, stride_r, cap, seq_stride;
+    uint8_t *srev; fmd_intv_t *listA, *listB; uint32_t *cls;
+    fmd_ovlp_rec_t *rec; fmd_intv_t *nei; uint8_t *seq;
+};
+
+// phase A: LF-walk + overlap_intv + fm6_is_contained, then the read-order copy.  per_cu > 0 bounds the
+// resident waves per CU (pipelined batches leave room for phase B of the previous part).
+static void ovl_phase_a(const OvlBatch &o, hipStream_t st, size_t b, size_t np, int per_cu)
+{
+    uint8_t *srev = o.srev + b * (size_t)o.stride_r;
+    fmd_intv_t *listA = o.listA + b * (size_t)o.cap;
+    uint8_t *seq = o.seq + b * (size_t)o.seq_stride;
+    uint32_t *q0 = fmd_next_queue(o.h, st), *q1 = fmd_next_queue(o.h, st);
+    if (getenv("FMD_OVLP_UNFUSED")) { // A/B switch: separate LF-walk and overlap_intv passes
+        const int grid = fmd_grid_for(o.h, np);
+        k_ovl_retrieve<<<grid, 64, 0, st>>>(o.ix, np, o.ids + b, srev, o.stride_r, o.rec + b, q0);
+        k_ovl_intv<<<grid, 64, 0, st>>>(o.ix, np, o.min_match, srev, o.stride_r, o.cap, listA, o.rec + b, seq, o.seq_stride, q1);
+        return;
+    }
+    int grid = fmd_grid_for_lds(o.h, np, FMD_COMPACT_LDS_U4 * 16);
+    if (per_cu > 0 && grid > o.h->n_cu * per_cu) grid = o.h->n_cu * per_cu;
+    k_ovl_walk<<<grid, 64, 0, st>>>(o.ix, np, o.ids + b, o.min_match, srev, o.stride_r, o.cap, listA, o.rec + b, seq, o.seq_stride, q0, 0);
+    launch_seq_out(st, np, o.max_len, srev, o.stride_r, o.rec + b, o.min_match, 0, seq, o.seq_stride);
+}
+
+// phase B: fm6_get_nei.  `part` selects the counter header of this part's work lists.
+static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, int part, int per_cu)
+{
+    uint8_t *srev = o.srev + b * (size_t)o.stride_r;
+    fmd_intv_t *listA = o.listA + b * (size_t)o.cap, *listB = o.listB + b * (size_t)o.cap;
+    fmd_ovlp_rec_t *rec = o.rec + b;
+    fmd_intv_t *nei = o.nei + b * (size_t)o.max_nei;
+    uint8_t *seq = o.seq + b * (size_t)o.seq_stride;
+    const int grid = fmd_grid_for(o.h, np);
+    uint32_t *q2 = fmd_next_queue(o.h, st);
+    if (getenv("FMD_OVLP_SLOW_ONLY")) { // A/B switch: everything through the lane-per-strand kernel
+        k_ovl_nei<<<grid, 64, 0, st>>>(o.ix, np, o.min_match, srev, o.stride_r, o.cap, listA, listB, rec, nei, o.max_nei, seq, o.seq_stride, q2, nullptr, nullptr);
+        return FMD_OK;
+    }
+    // work lists: the counter header, then one list per group class (2 words per strand) and the slow list (1)
+    uint32_t *cls = o.cls + (size_t)part * FMD_CLS_HEADER_U32 + b * (2 * FMD_GRP_CLASSES + 1);
+    FmdOvlClasses cl;
+    cl.cnt = cls;
+    for (int k = 0; k < FMD_GRP_CLASSES; ++k) cl.lst[k] = cls + FMD_CLS_HEADER_U32 + 2 * np * k;
+    cl.lslow = cls + FMD_CLS_HEADER_U32 + 2 * np * FMD_GRP_CLASSES;
+    uint32_t *n_slow = cl.cnt + FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE;
+    FMD_HIP_TRY(hipMemsetAsync(cls, 0, 4 * FMD_CLS_HEADER_U32, st));
+    fmd_launch_classify(st, np, rec, listA, o.cap, cl);
+    // one lane per candidate interval, 64 / G strands per wave
+    for (int k = 0; k < FMD_GRP_CLASSES; ++k)
+        fmd_launch_nei_grp(k, o.h->n_cu, per_cu, st, o.ix, cl.lst[k], cl.cnt + k * FMD_CLS_CNT_STRIDE, o.cap, listA, rec, nei, o.max_nei, seq, o.seq_stride, cl.lslow, n_slow);
+    // the rest (too many candidates, wide intervals, fake forks, neighbour overflow): lane per strand
+    k_ovl_nei<<<grid, 64, 0, st>>>(o.ix, np, o.min_match, srev, o.stride_r, o.cap, listA, listB, rec, nei, o.max_nei, seq, o.seq_stride, q2, cl.lslow, n_slow);
+#ifdef GRP_STATS
+    {
+        uint32_t hs[FMD_CLS_HEADER_U32];
+        hipStreamSynchronize(st);
+        hipMemcpy(hs, cls, sizeof(hs), hipMemcpyDeviceToHost);
+        const uint32_t *g = hs + FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE + 8;
+        fprintf(stderr, "[grp stats] classes %u %u %u %u %u slow %u | wave rounds %u, live lanes %u (%.1f %%), lanes of groups holding a strand %u (%.1f %%)\n",
+                hs[0], hs[32], hs[64], hs[96], hs[128], hs[160], g[0], g[1], 100.0 * g[1] / (64.0 * g[0]), g[2], 100.0 * g[2] / (64.0 * g[0]));
+    }
+#endif
+    return FMD_OK;
+}
+
+// Pipelined batches.  Phase A is bound by the memory system's request rate and leaves the VALUs idle;
+// phase B waits on dependent gathers with few requests in flight.  A large batch is cut into parts and
+// phase B of part p runs on a second stream beside phase A of part p+1, each with a share of the
+// CU's wave slots (LDS: 6 x 8.75 KiB + 10 x 10 KiB <= 160 KiB; get_nei needs the waves, the walk
+// still issues 85 % of its requests with 6).  FMD_OVLP_PIPE="parts,walk_per_cu,
+// grp_per_cu" overrides the split; parts = 1 is the serial order.
+static void ovl_pipe_config(size_t n, int &parts, int &walk_cu, int &grp_cu)
+{
+    parts = n >= (1u << 21) ? 4 : 1; walk_cu = 6; grp_cu = 10;
+    const char *e = getenv("FMD_OVLP_PIPE");
+    if (e) {
+        int a = 0, b = 0, c = 0;
+        const int k = sscanf(e, "%d,%d,%d", &a, &b, &c);
+        if (k >= 1 && a >= 1) parts = a < FMD_OVLP_MAX_PARTS ? a : FMD_OVLP_MAX_PARTS;
+        if (k >= 2 && b >= 1) walk_cu = b;
+        if (k >= 3 && c >= 1) grp_cu = c;
+    }
+    if (getenv("FMD_OVLP_UNFUSED") || getenv("FMD_OVLP_SLOW_ONLY")) parts = 1;
+}
+static bool ovl_aux_acquire(fmd_dev *h)
+{
+    int expect = 0;
+    if (!__atomic_compare_exchange_n(&h->aux_busy, &expect, 1, false, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED)) return false;
+    if (!h->aux_ready) {
+        bool ok = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) == hipSuccess; // must not synchronise with the null stream
+        int made = 0;
+        for (; ok && made <= FMD_OVLP_MAX_PARTS; ++made) ok = hipEventCreateWithFlags(&h->aux_ev[made], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            for (int i = 0; i < made - 1; ++i) hipEventDestroy(h->aux_ev[i]);
+            __atomic_store_n(&h->aux_busy, 0, __ATOMIC_RELEASE);
+            return false;
+        }
+        h->aux_ready = 1;
+    }
+    return true;
 }
 
 extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_t *d_ids, int min_match, uint32_t max_len,
@@ -776,50 +883,43 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
     if (fmd_ovlp_list_cap(max_len, min_match) >= 4096) return FMD_E_ARG; // category index is packed in 12 bits
     FMD_HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream_;
-    const uint32_t stride_r = (uint32_t)align_up(max_len, 16);
-    const uint32_t cap = fmd_ovlp_list_cap(max_len, min_match);
-    uint8_t *srev = (uint8_t *)d_work;
-    fmd_intv_t *listA = (fmd_intv_t *)((uint8_t *)d_work + align_up(n * (size_t)stride_r, 256));
-    fmd_intv_t *listB = (fmd_intv_t *)((uint8_t *)listA + align_up(n * (size_t)cap * sizeof(fmd_intv_t), 256));
-    const FmdIndexView ix = fmd_view(h);
-    const int grid = fmd_grid_for(h, n);
-    uint32_t *q0 = fmd_next_queue(h, st), *q1 = fmd_next_queue(h, st), *q2 = fmd_next_queue(h, st);
-    if (getenv("FMD_OVLP_UNFUSED")) { // A/B switch: separate LF-walk and overlap_intv passes
-        k_ovl_retrieve<<<grid, 64, 0, st>>>(ix, n, d_ids, srev, stride_r, d_rec, q0);
-        k_ovl_intv<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, d_rec, d_seq, seq_stride, q1);
+    OvlBatch o;
+    o.h = h; o.ix = fmd_view(h);
+    o.ids = d_ids; o.min_match = min_match; o.max_len = max_len; o.max_nei = max_nei; o.seq_stride = seq_stride;
+    o.stride_r = (uint32_t)align_up(max_len, 16);
+    o.cap = fmd_ovlp_list_cap(max_len, min_match);
+    o.srev = (uint8_t *)d_work;
+    o.listA = (fmd_intv_t *)((uint8_t *)d_work + align_up(n * (size_t)o.stride_r, 256));
+    o.listB = (fmd_intv_t *)((uint8_t *)o.listA + align_up(n * (size_t)o.cap * sizeof(fmd_intv_t), 256));
+    o.cls = (uint32_t *)((uint8_t *)o.listB + align_up(n * (size_t)o.cap * sizeof(fmd_intv_t), 256));
+    o.rec = d_rec; o.nei = d_nei; o.seq = d_seq;
+
+    int parts, walk_cu, grp_cu;
+    ovl_pipe_config(n, parts, walk_cu, grp_cu);
+    if (parts > 1 && !ovl_aux_acquire(h)) parts = 1;   // the second stream is in use by another call: serial order
+    int rc = FMD_OK;
+    if (parts == 1) {
+        ovl_phase_a(o, st, 0, n, 0);
+        rc = ovl_phase_b(o, st, 0, n, 0, 0);
     } else {
-        k_ovl_walk<<<fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16), 64, 0, st>>>(ix, n, d_ids, min_match, srev, stride_r, cap, listA, d_rec, d_seq, seq_stride, q0, 0);
-        launch_seq_out(st, n, max_len, srev, stride_r, d_rec, min_match, 0, d_seq, seq_stride);
+        hipStream_t s2 = h->aux_stream;
+        // Equal parts: get_nei is the slower phase while the two run side by side, so the last part --
+        // whose get_nei has the GPU to itself -- should not be smaller than the others.
+        const size_t per = ((n + parts - 1) / parts + 63) & ~(size_t)63;
+        int p = 0;
+        for (size_t b = 0; b < n && rc == FMD_OK; b += per, ++p) {
+            const size_t np = n - b < per ? n - b : per;
+            const bool last = b + per >= n;
+            ovl_phase_a(o, st, b, np, p == 0 ? 0 : walk_cu);         // the first part has the GPU to itself
+            hipEventRecord(h->aux_ev[p], st);
+            hipStreamWaitEvent(s2, h->aux_ev[p], 0);
+            rc = ovl_phase_b(o, s2, b, np, p, last ? 0 : grp_cu);      // so has the last phase B
+        }
+        hipEventRecord(h->aux_ev[FMD_OVLP_MAX_PARTS], s2);
+        hipStreamWaitEvent(st, h->aux_ev[FMD_OVLP_MAX_PARTS], 0);       // the caller's stream owns the results again
+        __atomic_store_n(&h->aux_busy, 0, __ATOMIC_RELEASE);
     }
-    if (getenv("FMD_OVLP_SLOW_ONLY")) { // A/B switch: everything through the lane-per-strand kernel
-        k_ovl_nei<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, listB, d_rec, d_nei, max_nei, d_seq, seq_stride, q2, nullptr, nullptr);
-    } else {
-        // work lists: 16 counters, then one list per group class (2 words per strand) and the slow list (1)
-        uint32_t *cls = (uint32_t *)((uint8_t *)listB + align_up(n * (size_t)cap * sizeof(fmd_intv_t), 256));
-        FmdOvlClasses cl;
-        cl.cnt = cls;
-        for (int k = 0; k < FMD_GRP_CLASSES; ++k) cl.lst[k] = cls + FMD_CLS_HEADER_U32 + 2 * n * k;
-        cl.lslow = cls + FMD_CLS_HEADER_U32 + 2 * n * FMD_GRP_CLASSES;
-        uint32_t *n_slow = cl.cnt + FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE;
-        FMD_HIP_TRY(hipMemsetAsync(cls, 0, 4 * FMD_CLS_HEADER_U32, st));
-        fmd_launch_classify(st, n, d_rec, listA, cap, cl);
-        // one lane per candidate interval, 64 / G strands per wave
-        for (int k = 0; k < FMD_GRP_CLASSES; ++k)
-            fmd_launch_nei_grp(k, h->n_cu, st, ix, cl.lst[k], cl.cnt + k * FMD_CLS_CNT_STRIDE, cap, listA, d_rec, d_nei, max_nei, d_seq, seq_stride, cl.lslow, n_slow);
-        // the rest (too many candidates, wide intervals, fake forks, neighbour overflow): lane per strand
-        k_ovl_nei<<<grid, 64, 0, st>>>(ix, n, min_match, srev, stride_r, cap, listA, listB, d_rec, d_nei, max_nei, d_seq, seq_stride, q2, cl.lslow, n_slow);
-    }
-#ifdef GRP_STATS
-    if (!getenv("FMD_OVLP_SLOW_ONLY")) {
-        uint32_t hs[FMD_CLS_HEADER_U32];
-        uint32_t *cls = (uint32_t *)((uint8_t *)listB + align_up(n * (size_t)cap * sizeof(fmd_intv_t), 256));
-        hipStreamSynchronize(st);
-        hipMemcpy(hs, cls, sizeof(hs), hipMemcpyDeviceToHost);
-        const uint32_t *g = hs + FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE + 8;
-        fprintf(stderr, "[grp stats] classes %u %u %u %u %u slow %u | wave rounds %u, live lanes %u (%.1f %%), lanes of groups holding a strand %u (%.1f %%)\n",
-                hs[0], hs[32], hs[64], hs[96], hs[128], hs[160], g[0], g[1], 100.0 * g[1] / (64.0 * g[0]), g[2], 100.0 * g[2] / (64.0 * g[0]));
-    }
-#endif
+    if (rc != FMD_OK) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "overlap kernels"); return FMD_E_HIP; }
     return FMD_OK;

@@ -593,6 +593,39 @@ def test_overlap_longer_reads_vs_oracle(gpu, oracle_lib, L, cov, mm, err):
     d.close(); o.close()
 
 
+@pytest.mark.parametrize("pipe", ["3,9,7", "8,2,2", "5,16,16"])
+def test_overlap_pipelined_parts_equal_serial(gpu, oracle_lib, monkeypatch, pipe):
+    """fmd_ovlp_dev cuts a large batch into parts and runs get_nei of one part on a second stream beside
+    the walk of the next (FMD_OVLP_PIPE = parts, waves per CU of either phase; the default engages above
+    2^21 strands).  Forced here on a small batch with ragged part sizes: records, neighbours and
+    sequences equal the serial order byte for byte, and the oracle on a sample."""
+    N = 20000
+    reads = synth.reads(synth.DEFAULT_SEED + 77, N, 100, 30, 0.005)
+    bwt = gpu.build_bwt(reads)
+    d = gpu.DevIndex.from_bwt(bwt)
+    ids = np.arange(2 * N - 37, dtype=U64)
+    monkeypatch.setenv("FMD_OVLP_PIPE", "1")
+    rec0, nei0, seq0 = d.overlap(ids, 50, 100, 8, check_left=True)
+    monkeypatch.setenv("FMD_OVLP_PIPE", pipe)
+    for _ in range(2):   # twice: the second call reuses the stream and the events
+        rec1, nei1, seq1 = d.overlap(ids, 50, 100, 8, check_left=True)
+        assert rec1.tobytes() == rec0.tobytes()
+        m = rec0["n_nei"] > 0
+        for j in range(8):
+            mj = rec0["n_nei"] > j
+            assert nei1[mj, j].tobytes() == nei0[mj, j].tobytes()
+        used = (rec0["len"] + np.maximum(rec0["ext_len"], 0)).astype(np.int64)
+        for i in np.where(rec0["status"] == 0)[0][::11]:
+            assert np.array_equal(seq1[i, :used[i]], seq0[i, :used[i]]), i
+        assert m.sum() > N
+    o = orcbind.OrcIndex(bwt=bwt)
+    sub = ids[:3000]
+    wrec, wnei, wseq = o.overlap_batch(sub, 50, 100, 8, 4, check_left=True)
+    for f in ("rank", "k", "len", "status", "n_ovlp", "rbeg", "ext_len", "n_nei", "reserved"):
+        assert np.array_equal(rec1[f][:3000], wrec[f]), f
+    d.close(); o.close()
+
+
 @pytest.mark.parametrize("seed", list(range(40)))
 def test_fuzz_small_read_sets(gpu, oracle_lib, tmp_path, seed):
     """Differential fuzzing over small, nasty read sets -- ragged lengths from 3 bases up (shorter than the
