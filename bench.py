@@ -223,6 +223,21 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
     if rank != 0:
         return None
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    # Large batches run get_nei of one part beside the walk of the next on a second stream.
+    # Outside the timed region: the same step in serial order into fresh buffers must give the same bytes.
+    pipe_note = None
+    if batch >= (1 << 21) and "FMD_OVLP_PIPE" not in os.environ and world == 1:
+        keep = (rec, nei, seq)
+        rec, nei, seq = torch.zeros_like(rec), torch.zeros_like(nei), torch.zeros_like(seq)
+        os.environ["FMD_OVLP_PIPE"] = "1"
+        try:
+            step()
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["FMD_OVLP_PIPE"]
+        same = torch.equal(rec, keep[0]) and torch.equal(nei, keep[1]) and torch.equal(seq, keep[2])
+        pipe_note = "identical (records, neighbours, sequences of all %d strands)" % n_ids if same else "MISMATCH"
+        rec, nei, seq = keep
     g_rec = rec.cpu().numpy().view(api.OVLP_DT)
     out = {"metric": "reads/sec through unitig overlap discovery (retrieve + is_contained + get_nei, both strands)",
            "value": n_reads * world * steps / wall, "unit": "reads/s", "strands_per_s": n_ids * world * steps / wall,
@@ -231,6 +246,8 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
            "contained": int((g_rec["status"] == -3).sum()), "with_neighbour": int((g_rec["n_nei"] > 0).sum())}
     if gather_note:
         out["record_gather_rccl"] = gather_note
+    if pipe_note:
+        out["pipelined_vs_serial_order"] = pipe_note
     if world == 1:
         cnts, qps = overlap_rank_queries_per_strand(fmd_path, min_match)
         alg = qps * BYTES_PER_RANK_QUERY * n_ids

@@ -175,7 +175,10 @@ static inline uint32_t fmd_ovlp_list_cap(uint32_t max_len, int min_match)
 size_t fmd_ovlp_work_bytes(size_t n, uint32_t max_len, int min_match);
 /* d_nei: n x max_nei neighbours {x[0], x[1], x[2] of `$neighbour$`, info = overlap length};
  * d_seq: n rows of seq_stride bytes = the sequence in read order followed by the ext_len appended
- * bases (seq_stride >= 2*max_len is always enough). */
+ * bases (seq_stride >= 2*max_len is always enough).
+ * Stream order is the caller's: the call starts after the work already queued on `stream` and its results
+ * belong to `stream` when it returns, although a batch of 2^21 strands or more also runs kernels on a
+ * second, library-owned stream in between (joined by events, no host synchronisation). */
 int fmd_ovlp_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_ids, int min_match, uint32_t max_len,
                  uint32_t max_nei, fmd_ovlp_rec_t *d_rec, fmd_intv_t *d_nei, uint8_t *d_seq, uint32_t seq_stride,
                  void *d_work, size_t work_bytes);

@@ -7,4 +7,5 @@ for l in sys.stdin:
         for k in ("overlap_discovery", "smem", "kmer_harvest"):
             if k in d:
                 o = d[k]
-                print(k, "ms", round(o["ms_per_step"], 2), "frac", round(o["roofline"]["frac"], 3), "parity", o.get("parity_vs_cpu_on_sample"))
+                print(k, "ms", round(o["ms_per_step"], 2), "frac", round(o["roofline"]["frac"], 3), "parity", o.get("parity_vs_cpu_on_sample"),
+                      ("| pipelined vs serial: " + o["pipelined_vs_serial_order"]) if "pipelined_vs_serial_order" in o else "")
