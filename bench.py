@@ -693,6 +693,13 @@ def main():
             out["smem"] = sm
         if km:
             out["kmer_harvest"] = km
+        # `achieved` counts ALGORITHMIC bytes (the reference's accounting); where the PMC traffic
+        # of the same kernels is known, say next to it what actually moved
+        for leg in (out, ovl, sm, km):
+            r = leg.get("roofline") if leg else None
+            if r and r.get("traffic") and r.get("kernel_ms"):
+                r["traffic_GBps"] = r["traffic"] / (r["kernel_ms"] * 1e-3) / 1e9
+                r["traffic_frac_of_peak"] = r["traffic_GBps"] / r["peak"]
         print(json.dumps(out), flush=True)
         if fmd_path and os.path.exists(fmd_path):
             os.remove(fmd_path)
