@@ -907,16 +907,20 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
         // whose get_nei has the GPU to itself -- should not be smaller than the others.
         const size_t per = ((n + parts - 1) / parts + 63) & ~(size_t)63;
         int p = 0;
+        bool join_ok = true;
         for (size_t b = 0; b < n && rc == FMD_OK; b += per, ++p) {
             const size_t np = n - b < per ? n - b : per;
             const bool last = b + per >= n;
             ovl_phase_a(o, st, b, np, p == 0 ? 0 : walk_cu);         // the first part has the GPU to itself
-            hipEventRecord(h->aux_ev[p], st);
-            hipStreamWaitEvent(s2, h->aux_ev[p], 0);
+            if (hipEventRecord(h->aux_ev[p], st) != hipSuccess || hipStreamWaitEvent(s2, h->aux_ev[p], 0) != hipSuccess) { join_ok = false; break; }
             rc = ovl_phase_b(o, s2, b, np, p, last ? 0 : grp_cu);      // so has the last phase B
         }
-        hipEventRecord(h->aux_ev[FMD_OVLP_MAX_PARTS], s2);
-        hipStreamWaitEvent(st, h->aux_ev[FMD_OVLP_MAX_PARTS], 0);       // the caller's stream owns the results again
+        // the caller's stream owns the results again; if the hand-over itself failed, wait on the host
+        if (!join_ok || hipEventRecord(h->aux_ev[FMD_OVLP_MAX_PARTS], s2) != hipSuccess ||
+            hipStreamWaitEvent(st, h->aux_ev[FMD_OVLP_MAX_PARTS], 0) != hipSuccess) {
+            hipStreamSynchronize(s2);
+            if (!join_ok) { fmd_set_hip_error(hipGetLastError(), "overlap batch: event hand-over"); rc = FMD_E_HIP; }
+        }
         __atomic_store_n(&h->aux_busy, 0, __ATOMIC_RELEASE);
     }
     if (rc != FMD_OK) return rc;
