@@ -695,30 +695,50 @@ __global__ __launch_bounds__(64) void k_ovl_cls(FmdIndexView ix, size_t n, int m
         else if (st == CL_BWD) { qk = x0 - 1; ql = x0 - 1 + sz; }
         const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, qk, ql);
         if (st == CL_IDLE) continue;
-        uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tl[6] = {0, 0, 0, 0, 0, 0};
-        if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk, r.blk_k);
-        if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl, r.blk_l);
-        uint64_t sc[6];
+        // the symbol this step extends by: forward along the neighbour, or backward over the strand
+        const int c = st == CL_FWD ? comp6(s[rbeg + depth]) : s[i];
+        // Child sizes sc[], rank_c(k) and -- where a candidate may be pushed -- rank_$(k).  Narrow interval
+        // (all but the first ~log4(n) forward steps): one 64-position window of the lane's block image(s)
+        // and one or two single-symbol ranks instead of two six-symbol block ranks.
+        uint64_t sc[6], tkc, tk0 = 0;
+        if (sz <= 63) {
+            const uint64_t a0 = st == CL_FWD ? x1 : x0;
+            uint4 wa, wb, wc;
+            grp_window(r.bk, r.t, r.bl, r.tl, r.blk_k, r.blk_l, r.hk, r.hl && r.blk_l != r.blk_k, r.blk_k, r.nk - 1, wa, wb, wc); // window at a0 = (a0 - 1) + 1
+            const uint32_t sh = (uint32_t)a0 & 31;
+            const uint64_t m = (1ull << (int)sz) - 1;
+            const uint64_t X = win64(wa.x, wb.x, wc.x, sh), Y = win64(wa.y, wb.y, wc.y, sh), Z = win64(wa.z, wb.z, wc.z, sh);
+            const uint64_t lo = ~Z & m, hi = Z & ~Y & m;
+            sc[0] = __popcll(lo & ~Y & ~X); sc[1] = __popcll(lo & ~Y & X); sc[2] = __popcll(lo & Y & ~X); sc[3] = __popcll(lo & Y & X);
+            sc[4] = __popcll(hi & ~X); sc[5] = __popcll(hi & X);
+            tkc = fmd_block_rank1(r.bk, r.t, r.nk, c, r.blk_k);
+            if (st == CL_FWD && depth >= min_match && sc[0]) tk0 = fmd_block_rank1(r.bk, r.t, r.nk, 0, r.blk_k);
+        } else {
+            uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tl[6] = {0, 0, 0, 0, 0, 0};
+            if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk, r.blk_k);
+            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl, r.blk_l);
 #pragma unroll
-        for (int a = 0; a < 6; ++a) sc[a] = tl[a] - tk[a];
+            for (int a = 0; a < 6; ++a) sc[a] = tl[a] - tk[a];
+            tkc = sel6(c, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
+            tk0 = tk[0];
+        }
+        const uint64_t szc = sel6(c, sc[0], sc[1], sc[2], sc[3], sc[4], sc[5]);
+        // coordinate of child c on the strand that is not extended: running sum in the order $,T,G,C,A,N (exact.c:81-86)
+        uint64_t before = 0;
+        if (c != 0) before += sc[0];
+        if (c == 3 || c == 2 || c == 1 || c == 5) before += sc[4];
+        if (c == 2 || c == 1 || c == 5) before += sc[3];
+        if (c == 1 || c == 5) before += sc[2];
+        if (c == 5) before += sc[1];
+        const uint64_t nxc = sel6(c, ix.cnt[0], ix.cnt[1], ix.cnt[2], ix.cnt[3], ix.cnt[4], ix.cnt[5]) + tkc;
         if (st == CL_FWD) { // overlap_intv(at5 = 1, inc_sentinel = 1), unitig.c:38-64
-            const int c = comp6(s[rbeg + depth]);
-            const uint64_t szc = sel6(c, sc[0], sc[1], sc[2], sc[3], sc[4], sc[5]);
             bool end_fwd = szc == 0;
             if (!end_fwd) {
                 if (depth >= min_match && sc[0]) {
-                    if (prev_n < cap) store_entry(prev + prev_n, x0, ix.cnt[0] + tk[0], sc[0], 0);
+                    if (prev_n < cap) store_entry(prev + prev_n, x0, ix.cnt[0] + tk0, sc[0], 0);
                     ++prev_n;
                 }
-                // ik = ok[c] (forward): x[1] from rank, x[0] running sum in the order $,T,G,C,A,N
-                uint64_t before = 0;
-                if (c != 0) before += sc[0];
-                if (c == 3 || c == 2 || c == 1 || c == 5) before += sc[4];
-                if (c == 2 || c == 1 || c == 5) before += sc[3];
-                if (c == 1 || c == 5) before += sc[2];
-                if (c == 5) before += sc[1];
-                x1 = sel6(c, ix.cnt[0], ix.cnt[1], ix.cnt[2], ix.cnt[3], ix.cnt[4], ix.cnt[5]) + sel6(c, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
-                x0 += before; sz = szc;
+                x1 = nxc; x0 += before; sz = szc;   // ik = ok[c] (forward)
                 ++depth;
                 end_fwd = rbeg + depth == s_l;
             }
@@ -728,18 +748,9 @@ __global__ __launch_bounds__(64) void k_ovl_cls(FmdIndexView ix, size_t n, int m
                 else { i = rbeg - 1; j = 0; curr_n = 0; st = CL_PICK; }
             }
         } else { // CL_BWD: one collected interval against base s[i] (unitig.c:196-200)
-            const int c = s[i];
-            const uint64_t szc = sel6(c, sc[0], sc[1], sc[2], sc[3], sc[4], sc[5]);
             if (sc[0] + szc != sz) { rec[sid].reserved = 1; st = CL_IDLE; } // potential backward bifurcation
             else {
-                uint64_t before = 0;
-                if (c != 0) before += sc[0];
-                if (c == 3 || c == 2 || c == 1 || c == 5) before += sc[4];
-                if (c == 2 || c == 1 || c == 5) before += sc[3];
-                if (c == 1 || c == 5) before += sc[2];
-                if (c == 5) before += sc[1];
-                const uint64_t nx0 = sel6(c, ix.cnt[0], ix.cnt[1], ix.cnt[2], ix.cnt[3], ix.cnt[4], ix.cnt[5]) + sel6(c, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
-                if (curr_n < cap) store_entry(curr + curr_n, nx0, x1 + before, szc, 0);
+                if (curr_n < cap) store_entry(curr + curr_n, nxc, x1 + before, szc, 0);
                 ++curr_n; ++j;
                 st = CL_PICK;
             }
