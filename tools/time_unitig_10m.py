@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""`fermi-amd build` + `fermi-amd unitig -l50` on N error-free 100-bp reads with phase times (FMD_TIMING).
+Usage: python tools/time_unitig_10m.py [n_reads=10000000]"""
+import os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from fermi_amd import synth
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+AMD = os.path.join(ROOT, "fermi_amd", "bin", "fermi-amd")
+D = "/tmp/fmd_time_unitig"; os.makedirs(D, exist_ok=True)
+lut = np.frombuffer(b"$ACGTN", dtype=np.uint8)
+with open(D + "/r.fq", "wb") as fp:
+    for s in range(0, n, 1_000_000):
+        c = min(1_000_000, n - s)
+        r = lut[synth.reads(synth.DEFAULT_SEED, n, 100, 30, 0.0, start=s, count=c)]
+        fp.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (s + i, r[i].tobytes(), b"I" * 100) for i in range(c)))
+env = dict(os.environ, FMD_TIMING="1")
+for cmd, out in (([AMD, "build", "-fo", D + "/a.fmd", D + "/r.fq"], None), ([AMD, "unitig", "-l50", D + "/a.fmd"], D + "/a.mag")):
+    t = time.time()
+    p = subprocess.run(cmd, stdout=open(out, "wb") if out else subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
+    print(" ".join(cmd[1:3]), "%.1f s" % (time.time() - t), "rc", p.returncode)
+    print("\n".join(l for l in p.stderr.decode().splitlines() if "M::" in l))
+print("MAG bytes", os.path.getsize(D + "/a.mag"))
