@@ -38,7 +38,7 @@ static int solid_build(solid_t *t, int suf_len, uint64_t n, const uint32_t *buck
     uint64_t i, b;
     t->suf_len = suf_len; t->suf_num = 1ull << (2 * suf_len);
     t->off = (uint64_t *)calloc(t->suf_num + 1, 8);
-    t->key = (uint32_t *)malloc((n + 1) * 4); t->val = (uint8_t *)malloc(n + 1);
+    t->key = (uint32_t *)fmdh_big_alloc((n + 1) * 4); t->val = (uint8_t *)fmdh_big_alloc(n + 1);
     if (!t->off || !t->key || !t->val) return -1;
     for (i = 0; i < n; ++i) ++t->off[bucket[i] + 1];
     for (b = 0; b < t->suf_num; ++b) t->off[b + 1] += t->off[b];

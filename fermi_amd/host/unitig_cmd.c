@@ -22,7 +22,7 @@ int fmdh_unitig(const char *fmd_path, int device, int min_match, const char *ran
     const uint64_t n = info.mcnt[1];
     uint32_t max_len = 128, max_nei = 4;
     uint64_t *ids = (uint64_t *)malloc(n * 8);
-    fmd_ovlp_rec_t *rec = (fmd_ovlp_rec_t *)malloc(n * sizeof(*rec));
+    fmd_ovlp_rec_t *rec = (fmd_ovlp_rec_t *)fmdh_big_alloc(n * sizeof(*rec));
     fmd_intv_t *nei = 0;
     uint8_t *seq = 0;
     uint64_t *sorted = 0;
@@ -37,8 +37,8 @@ int fmdh_unitig(const char *fmd_path, int device, int min_match, const char *ran
     for (uint64_t i = 0; i < n; ++i) ids[i] = i;
     {
         const uint32_t stride = 2 * ((max_len + 3) / 4 * 4);
-        nei = (fmd_intv_t *)calloc(n * max_nei, sizeof(*nei));
-        seq = (uint8_t *)calloc(n, stride);
+        nei = (fmd_intv_t *)fmdh_big_alloc(n * max_nei * sizeof(*nei));
+        seq = (uint8_t *)fmdh_big_alloc(n * (size_t)stride);
         if (!nei || !seq) { rc = 1; goto done; }
         rc = fmd_ovlp_batch(d, n, ids, min_match, max_len, max_nei, rec, nei, seq, stride, /*check_left*/1);
         if (rc) { fprintf(stderr, "[E::%s] overlap discovery failed: %s\n", __func__, fmd_strerror(rc)); rc = 1; goto done; }

@@ -159,7 +159,7 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
     memset(&w, 0, sizeof(w));
     w.t = t; w.n_seq = n_seq; w.min_match = min_match; w.sorted = sorted;
     w.used = (uint64_t *)calloc(nw, 8); w.bend = (uint64_t *)calloc(nw, 8); w.visited = (uint64_t *)calloc(nw, 8);
-    w.row_of = (uint32_t *)malloc(n_seq * 4);
+    w.row_of = (uint32_t *)fmdh_big_alloc(n_seq * 4);
     const uint32_t cap_nei = t->side_of && t->side_max_nei > t->max_nei ? t->side_max_nei : t->max_nei;
     nei[0] = (link_t *)malloc(cap_nei * sizeof(link_t)); nei[1] = (link_t *)malloc((cap_nei + 1) * sizeof(link_t));
     if (!w.used || !w.bend || !w.visited || !w.row_of || !nei[0] || !nei[1]) { rc = -ENOMEM; goto done; }
