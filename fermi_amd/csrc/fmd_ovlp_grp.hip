@@ -31,11 +31,10 @@
 #define GRP_POOL 30                          // spill blocks per pass (-DGRP_POOL=4 stresses the multi-pass path in the tests)
 #endif
 #define GRP_SLOTS_U4 (2 * FMD_SLOT_U4)
-#define GRP_REGION_U4 128
 #define GRP_STAGE_U4 128
+#define GRP_REGION_U4 (GRP_POOL * FMD_BLK_U4 + 8 > GRP_STAGE_U4 ? GRP_POOL * FMD_BLK_U4 + 8 : GRP_STAGE_U4) // 128 with 64-byte blocks
 #define GRP_LDS_U4 (GRP_SLOTS_U4 + GRP_REGION_U4)
-static_assert(GRP_POOL * FMD_BLK_U4 + 8 <= GRP_REGION_U4 && GRP_STAGE_U4 <= GRP_REGION_U4, "pool + 32 block numbers, and the staging area, share the region");
-static_assert(FMD_BLK_U4 == 4, "the group kernels are laid out for the 64-byte block geometry");
+static_assert(GRP_POOL <= 32, "the region ends with 32 block numbers");
 
 // ---------------------------------------------------------------------------- classification
 // one thread per strand: work lists for the get_nei kernels.  Positions come from a block-wide count
