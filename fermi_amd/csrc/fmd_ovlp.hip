@@ -991,6 +991,19 @@ struct DevBuf2 {
     ~DevBuf2() { if (p) hipFree(p); }
 };
 
+// hipHostRegister for the lifetime of a scope; only for large arrays, silently skipped when it fails
+struct HostPin {
+    void *p;
+    HostPin(void *ptr, size_t bytes) : p(nullptr)
+    {
+        if (bytes >= ((size_t)64 << 20) && !getenv("FMD_NO_PIN") && hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess) p = ptr;
+        else (void)hipGetLastError();
+    }
+    ~HostPin() { if (p) hipHostUnregister(p); }
+    HostPin(const HostPin &) = delete;
+    HostPin &operator=(const HostPin &) = delete;
+};
+
 extern "C" int fmd_ovlp_batch(fmd_dev_t *h, size_t n, const uint64_t *ids, int min_match, uint32_t max_len, uint32_t max_nei,
                               fmd_ovlp_rec_t *rec, fmd_intv_t *nei, uint8_t *seq, uint32_t seq_stride, int with_check_left)
 {
@@ -1008,6 +1021,9 @@ extern "C" int fmd_ovlp_batch(fmd_dev_t *h, size_t n, const uint64_t *ids, int m
     DevBuf2 di, dr, dn, ds, dw;
     if (di.alloc(m * 8) || dr.alloc(m * sizeof(fmd_ovlp_rec_t)) || dn.alloc(m * max_nei * sizeof(fmd_intv_t)) ||
         ds.alloc(m * (size_t)seq_stride) || dw.alloc(wb)) return FMD_E_NOMEM;
+    // Gigabytes come back per call: pin the caller's arrays for its duration so the copies run at link speed
+    // instead of through the runtime's staging buffers (best effort; pageable copies otherwise).
+    HostPin pin_rec(rec, n * sizeof(fmd_ovlp_rec_t)), pin_nei(nei, n * max_nei * sizeof(fmd_intv_t)), pin_seq(seq, n * (size_t)seq_stride);
     for (size_t o = 0; o < n; o += m) {
         const size_t c = n - o < m ? n - o : m;
         FMD_HIP_TRY(hipMemcpy(di.p, ids + o, c * 8, hipMemcpyHostToDevice));
