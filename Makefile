@@ -13,7 +13,7 @@ HIP_OBJS  = $(patsubst fermi_amd/csrc/%.hip,build/%.o,$(HIP_SRCS))
 HOST_SRCS = $(filter-out fermi_amd/host/main.c,$(wildcard fermi_amd/host/*.c))
 HOST_HDRS = $(wildcard fermi_amd/host/*.h) include/fmd_hip.h
 
-all: fermi_amd/lib/libfmdhip.so host cli oracle
+all: fermi_amd/lib/libfmdhip.so fermi_amd/lib/libfmdhip_count.so host cli oracle
 
 build/%.o: fermi_amd/csrc/%.hip $(HIP_HDRS)
 	@mkdir -p build
@@ -22,6 +22,16 @@ build/%.o: fermi_amd/csrc/%.hip $(HIP_HDRS)
 fermi_amd/lib/libfmdhip.so: $(HIP_OBJS)
 	@mkdir -p fermi_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJS) -o $@
+
+# the same sources with the gathers instrumented (fmd_count_lines, fmd_wave.h): bench.py runs one step of every
+# leg through it to count the rank blocks the shipped kernels request (roofline.frac in DEVICE bytes)
+CNT_OBJS  = $(patsubst fermi_amd/csrc/%.hip,build/count/%.o,$(HIP_SRCS))
+build/count/%.o: fermi_amd/csrc/%.hip $(HIP_HDRS)
+	@mkdir -p build/count
+	$(HIPCC) $(HIPFLAGS) -DFMD_COUNT_LINES=1 -c $< -o $@
+fermi_amd/lib/libfmdhip_count.so: $(CNT_OBJS)
+	@mkdir -p fermi_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(CNT_OBJS) -o $@
 
 host: fermi_amd/lib/libfmdhost.so
 fermi_amd/lib/libfmdhost.so: $(HOST_SRCS) $(HOST_HDRS) fermi_amd/lib/libfmdhip.so

@@ -22,7 +22,7 @@ OVLP_F_FORKED, OVLP_F_OVERFLOW, OVLP_F_FIXED = 1, 2, 4
 ABI_SYMBOLS = [
     "fmd_strerror", "fmd_last_hip_error", "fmd_device_count",
     "fmd_dev_open_file", "fmd_dev_open_rld", "fmd_dev_open_rle6", "fmd_dev_open_bwt", "fmd_dev_open_bwt_dev",
-    "fmd_dev_close", "fmd_dev_info", "fmd_dev_sync",
+    "fmd_dev_close", "fmd_dev_info", "fmd_dev_sync", "fmd_dev_line_count",
     "fmd_rank1a_dev", "fmd_rank2a_dev", "fmd_rank1a_batch", "fmd_rank2a_batch",
     "fmd_extend_dev", "fmd_extend_batch", "fmd_bsearch_dev", "fmd_bsearch_batch",
     "fmd_retrieve_dev", "fmd_retrieve_batch", "fmd_probe_gather",
@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
     "fmd_smem_work_bytes", "fmd_smem_dev", "fmd_smem_batch", "fmd_smem_win_dev", "fmd_smem_win_batch", "fmd_reach_dev", "fmd_reach_batch", "fmd_dev_export_bwt", "fmd_dev_check_rank",
     "fmd_kmer_work_bytes", "fmd_kmer_collect_dev", "fmd_kmer_collect",
     "fmd_ovlp_work_bytes", "fmd_ovlp_dev", "fmd_ovlp_batch", "fmd_ovlp_check_left_dev", "fmd_seqinfo_dev", "fmd_seqinfo_batch",
+    "fmd_ovlp_pack_max_bytes", "fmd_ovlp_pack_work_bytes", "fmd_ovlp_pack_dev",
 ]
 
 
@@ -48,6 +49,74 @@ class Info(C.Structure):
 
 
 _lib = None
+_count_lib = None
+COUNT_LIB_PATH = os.path.join(_HERE, "lib", "libfmdhip_count.so")  # same sources, gathers instrumented (-DFMD_COUNT_LINES=1)
+
+
+def _configure(L):
+    """Prototypes of include/fmd_hip.h on a loaded library."""
+    vp, sz, u64p = C.c_void_p, C.c_size_t, C.c_void_p
+    L.fmd_strerror.restype = C.c_char_p; L.fmd_strerror.argtypes = [C.c_int]
+    L.fmd_last_hip_error.restype = C.c_char_p
+    L.fmd_device_count.restype = C.c_int
+    L.fmd_dev_open_file.argtypes = [C.c_int, C.c_char_p, C.POINTER(vp)]
+    L.fmd_dev_open_rld.argtypes = [C.c_int, vp, C.c_uint64, vp, C.POINTER(vp)]
+    L.fmd_dev_open_rle6.argtypes = [C.c_int, vp, C.c_uint64, C.POINTER(vp)]
+    L.fmd_dev_open_bwt.argtypes = [C.c_int, vp, C.c_uint64, C.POINTER(vp)]
+    L.fmd_dev_open_bwt_dev.argtypes = [C.c_int, vp, C.c_uint64, C.POINTER(vp)]
+    L.fmd_dev_close.restype = None; L.fmd_dev_close.argtypes = [vp]
+    L.fmd_dev_info.argtypes = [vp, C.POINTER(Info)]
+    L.fmd_dev_sync.argtypes = [vp, vp]
+    L.fmd_rank1a_dev.argtypes = [vp, vp, sz, u64p, u64p, vp]
+    L.fmd_rank2a_dev.argtypes = [vp, vp, sz, u64p, u64p, u64p, u64p]
+    L.fmd_rank1a_batch.argtypes = [vp, sz, u64p, u64p, vp]
+    L.fmd_rank2a_batch.argtypes = [vp, sz, u64p, u64p, u64p, u64p]
+    L.fmd_extend_dev.argtypes = [vp, vp, sz, vp, vp, vp]
+    L.fmd_extend_batch.argtypes = [vp, sz, vp, vp, vp]
+    L.fmd_bsearch_dev.argtypes = [vp, vp, sz, vp, u64p, u64p, u64p, u64p]
+    L.fmd_bsearch_batch.argtypes = [vp, sz, vp, u64p, u64p, u64p, u64p]
+    L.fmd_retrieve_dev.argtypes = [vp, vp, sz, u64p, vp, C.c_uint32, vp, u64p]
+    L.fmd_retrieve_batch.argtypes = [vp, sz, u64p, vp, C.c_uint32, vp, u64p]
+    L.fmd_build_bwt.argtypes = [C.c_int, sz, vp, u64p, vp, C.POINTER(C.c_uint64)]
+    L.fmd_build_bwt_dev.argtypes = [C.c_int, vp, sz, vp, u64p, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64)]
+    L.fmd_dev_free.restype = None; L.fmd_dev_free.argtypes = [vp]
+    L.fmd_bwt_to_rle6.argtypes = [C.c_int, vp, C.c_uint64, C.POINTER(vp), C.POINTER(C.c_uint64)]
+    L.fmd_host_free.restype = None; L.fmd_host_free.argtypes = [vp]
+    L.fmd_dev_malloc.argtypes = [C.c_int, sz, C.POINTER(vp)]
+    L.fmd_memcpy_h2d.argtypes = [vp, vp, sz, vp]
+    L.fmd_memcpy_d2h.argtypes = [vp, vp, sz, vp]
+    L.fmd_ovlp_work_bytes.restype = sz; L.fmd_ovlp_work_bytes.argtypes = [sz, C.c_uint32, C.c_int]
+    L.fmd_ovlp_dev.argtypes = [vp, vp, sz, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint32, vp, sz]
+    L.fmd_ovlp_batch.argtypes = [vp, sz, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint32, C.c_int]
+    L.fmd_ovlp_check_left_dev.argtypes = [vp, vp, sz, C.c_int, C.c_uint32, vp, vp, C.c_uint32, vp, sz]
+    L.fmd_kmer_work_bytes.restype = sz; L.fmd_kmer_work_bytes.argtypes = [C.c_uint64]
+    L.fmd_kmer_collect_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, sz, C.c_uint64, vp, vp, vp, vp]
+    L.fmd_kmer_collect.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64), vp]
+    L.fmd_smem_work_bytes.restype = sz; L.fmd_smem_work_bytes.argtypes = [sz, C.c_uint32]
+    L.fmd_smem_dev.argtypes = [vp, vp, sz, vp, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, sz]
+    L.fmd_smem_batch.argtypes = [vp, sz, vp, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp]
+    L.fmd_dev_export_bwt.argtypes = [vp, C.c_uint64, C.c_uint64, vp]
+    L.fmd_dev_check_rank.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.fmd_reach_dev.argtypes = [vp, vp, sz, vp, vp]
+    L.fmd_reach_batch.argtypes = [vp, sz, vp, vp]
+    L.fmd_smem_win_dev.argtypes = [vp, vp, sz, vp, vp, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, sz]
+    L.fmd_smem_win_batch.argtypes = [vp, sz, vp, C.c_uint64, vp, C.c_int, C.c_uint32, C.c_uint32, vp, vp]
+    L.fmd_seqinfo_dev.argtypes = [vp, vp, sz, u64p, C.c_uint32, vp, vp, C.c_uint32, vp, sz]
+    L.fmd_seqinfo_batch.argtypes = [vp, sz, u64p, C.c_uint32, vp]
+    L.fmd_probe_gather.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_float)]
+    L.fmd_dev_line_count.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
+    L.fmd_ovlp_pack_max_bytes.restype = sz; L.fmd_ovlp_pack_max_bytes.argtypes = [sz, C.c_uint32, C.c_uint32]
+    L.fmd_ovlp_pack_work_bytes.restype = sz; L.fmd_ovlp_pack_work_bytes.argtypes = [sz]
+    L.fmd_ovlp_pack_dev.argtypes = [vp, vp, sz, vp, vp, C.c_uint32, vp, C.c_uint32, vp, vp, vp, C.c_uint64, vp, sz]
+    return L
+
+
+def _load(path):
+    try:  # one process, one HIP runtime: if torch is going to be used, its bundled
+        import torch  # noqa: F401  libamdhip64 must be the copy that gets loaded (same soname)
+    except Exception:
+        pass
+    return _configure(C.CDLL(path))
 
 
 def lib():
@@ -56,62 +125,16 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise FmdError("libfmdhip.so is not built (%s); run `make` or __graft_entry__.build()" % LIB_PATH)
-        try:  # one process, one HIP runtime: if torch is going to be used, its bundled
-            import torch  # noqa: F401  libamdhip64 must be the copy that gets loaded (same soname)
-        except Exception:
-            pass
-        L = C.CDLL(LIB_PATH)
-        vp, sz, u64p = C.c_void_p, C.c_size_t, C.c_void_p
-        L.fmd_strerror.restype = C.c_char_p; L.fmd_strerror.argtypes = [C.c_int]
-        L.fmd_last_hip_error.restype = C.c_char_p
-        L.fmd_device_count.restype = C.c_int
-        L.fmd_dev_open_file.argtypes = [C.c_int, C.c_char_p, C.POINTER(vp)]
-        L.fmd_dev_open_rld.argtypes = [C.c_int, vp, C.c_uint64, vp, C.POINTER(vp)]
-        L.fmd_dev_open_rle6.argtypes = [C.c_int, vp, C.c_uint64, C.POINTER(vp)]
-        L.fmd_dev_open_bwt.argtypes = [C.c_int, vp, C.c_uint64, C.POINTER(vp)]
-        L.fmd_dev_open_bwt_dev.argtypes = [C.c_int, vp, C.c_uint64, C.POINTER(vp)]
-        L.fmd_dev_close.restype = None; L.fmd_dev_close.argtypes = [vp]
-        L.fmd_dev_info.argtypes = [vp, C.POINTER(Info)]
-        L.fmd_dev_sync.argtypes = [vp, vp]
-        L.fmd_rank1a_dev.argtypes = [vp, vp, sz, u64p, u64p, vp]
-        L.fmd_rank2a_dev.argtypes = [vp, vp, sz, u64p, u64p, u64p, u64p]
-        L.fmd_rank1a_batch.argtypes = [vp, sz, u64p, u64p, vp]
-        L.fmd_rank2a_batch.argtypes = [vp, sz, u64p, u64p, u64p, u64p]
-        L.fmd_extend_dev.argtypes = [vp, vp, sz, vp, vp, vp]
-        L.fmd_extend_batch.argtypes = [vp, sz, vp, vp, vp]
-        L.fmd_bsearch_dev.argtypes = [vp, vp, sz, vp, u64p, u64p, u64p, u64p]
-        L.fmd_bsearch_batch.argtypes = [vp, sz, vp, u64p, u64p, u64p, u64p]
-        L.fmd_retrieve_dev.argtypes = [vp, vp, sz, u64p, vp, C.c_uint32, vp, u64p]
-        L.fmd_retrieve_batch.argtypes = [vp, sz, u64p, vp, C.c_uint32, vp, u64p]
-        L.fmd_build_bwt.argtypes = [C.c_int, sz, vp, u64p, vp, C.POINTER(C.c_uint64)]
-        L.fmd_build_bwt_dev.argtypes = [C.c_int, vp, sz, vp, u64p, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64)]
-        L.fmd_dev_free.restype = None; L.fmd_dev_free.argtypes = [vp]
-        L.fmd_bwt_to_rle6.argtypes = [C.c_int, vp, C.c_uint64, C.POINTER(vp), C.POINTER(C.c_uint64)]
-        L.fmd_host_free.restype = None; L.fmd_host_free.argtypes = [vp]
-        L.fmd_dev_malloc.argtypes = [C.c_int, sz, C.POINTER(vp)]
-        L.fmd_memcpy_h2d.argtypes = [vp, vp, sz, vp]
-        L.fmd_memcpy_d2h.argtypes = [vp, vp, sz, vp]
-        L.fmd_ovlp_work_bytes.restype = sz; L.fmd_ovlp_work_bytes.argtypes = [sz, C.c_uint32, C.c_int]
-        L.fmd_ovlp_dev.argtypes = [vp, vp, sz, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint32, vp, sz]
-        L.fmd_ovlp_batch.argtypes = [vp, sz, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint32, C.c_int]
-        L.fmd_ovlp_check_left_dev.argtypes = [vp, vp, sz, C.c_int, C.c_uint32, vp, vp, C.c_uint32, vp, sz]
-        L.fmd_kmer_work_bytes.restype = sz; L.fmd_kmer_work_bytes.argtypes = [C.c_uint64]
-        L.fmd_kmer_collect_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, sz, C.c_uint64, vp, vp, vp, vp]
-        L.fmd_kmer_collect.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64), vp]
-        L.fmd_smem_work_bytes.restype = sz; L.fmd_smem_work_bytes.argtypes = [sz, C.c_uint32]
-        L.fmd_smem_dev.argtypes = [vp, vp, sz, vp, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, sz]
-        L.fmd_smem_batch.argtypes = [vp, sz, vp, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp]
-        L.fmd_dev_export_bwt.argtypes = [vp, C.c_uint64, C.c_uint64, vp]
-        L.fmd_dev_check_rank.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-        L.fmd_reach_dev.argtypes = [vp, vp, sz, vp, vp]
-        L.fmd_reach_batch.argtypes = [vp, sz, vp, vp]
-        L.fmd_smem_win_dev.argtypes = [vp, vp, sz, vp, vp, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, sz]
-        L.fmd_smem_win_batch.argtypes = [vp, sz, vp, C.c_uint64, vp, C.c_int, C.c_uint32, C.c_uint32, vp, vp]
-        L.fmd_seqinfo_dev.argtypes = [vp, vp, sz, u64p, C.c_uint32, vp, vp, C.c_uint32, vp, sz]
-        L.fmd_seqinfo_batch.argtypes = [vp, sz, u64p, C.c_uint32, vp]
-        L.fmd_probe_gather.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_float)]
-        _lib = L
+        _lib = _load(LIB_PATH)
     return _lib
+
+
+def count_lib():
+    """The instrumented build (measurement only: bench.py's device-byte model); None when it has not been built."""
+    global _count_lib
+    if _count_lib is None and os.path.exists(COUNT_LIB_PATH):
+        _count_lib = _load(COUNT_LIB_PATH)
+    return _count_lib
 
 
 def check(rc):
@@ -246,6 +269,42 @@ def _ovlp(self, ids, min_match, max_len=100, max_nei=4, check_left=True):
 
 
 DevIndex.overlap = _ovlp
+
+
+def _ovlp_pack(self, rec, nei, seq):
+    """fmd_ovlp_pack_dev over host copies of a finished batch: (prec[OVLP_DT], off[u64, n+1], var[u8])."""
+    L = lib()
+    n = len(rec)
+    max_nei, stride = nei.shape[1], seq.shape[1]
+    rec = np.ascontiguousarray(rec); nei = np.ascontiguousarray(nei); seq = np.ascontiguousarray(seq)
+    cap = L.fmd_ovlp_pack_max_bytes(n, max_nei, stride)
+    wb = L.fmd_ovlp_pack_work_bytes(n)
+    sizes = [max(rec.nbytes, 16), max(nei.nbytes, 16), max(seq.nbytes, 16), max(rec.nbytes, 16), (n + 1) * 8, max(cap, 16), wb]
+    ptrs = []
+    try:
+        for b in sizes:
+            p = C.c_void_p()
+            check(L.fmd_dev_malloc(self.device, b, C.byref(p)))
+            ptrs.append(p)
+        d_rec, d_nei, d_seq, d_prec, d_off, d_var, d_work = ptrs
+        for d, a in ((d_rec, rec), (d_nei, nei), (d_seq, seq)):
+            if a.nbytes:
+                check(L.fmd_memcpy_h2d(d, _ptr(a), a.nbytes, None))
+        check(L.fmd_ovlp_pack_dev(self.h, None, n, d_rec, d_nei, max_nei, d_seq, stride, d_prec, d_off, d_var, cap, d_work, wb))
+        prec = np.zeros(n, dtype=OVLP_DT); off = np.zeros(n + 1, dtype=np.uint64)
+        if n:
+            check(L.fmd_memcpy_d2h(_ptr(prec), d_prec, prec.nbytes, None))
+        check(L.fmd_memcpy_d2h(_ptr(off), d_off, off.nbytes, None))
+        var = np.zeros(int(off[n]), dtype=np.uint8)
+        if len(var):
+            check(L.fmd_memcpy_d2h(_ptr(var), d_var, var.nbytes, None))
+        return prec, off, var
+    finally:
+        for p in ptrs:
+            L.fmd_dev_free(p)
+
+
+DevIndex.overlap_pack = _ovlp_pack
 
 
 def _kmer_collect(self, w, min_occ, suf_len=None):

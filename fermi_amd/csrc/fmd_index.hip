@@ -302,8 +302,11 @@ static int dev_alloc_index(int device, uint64_t n_sym, fmd_dev **out)
     if (e != hipSuccess) { fmd_set_hip_error(e, "hipMalloc(index)"); free(h); return FMD_E_NOMEM; }
     e = hipMalloc((void **)&h->queues, FMD_N_QUEUES * sizeof(uint32_t));
     if (e != hipSuccess) { fmd_set_hip_error(e, "hipMalloc(queues)"); hipFree(h->blocks); free(h); return FMD_E_NOMEM; }
+    e = hipMalloc((void **)&h->stat, FMD_STAT_SLOTS * FMD_STAT_STRIDE * 8);
+    if (e != hipSuccess) { fmd_set_hip_error(e, "hipMalloc(stat)"); hipFree(h->queues); hipFree(h->blocks); free(h); return FMD_E_NOMEM; }
     hipMemset(h->blocks, 0, h->bytes);
     hipMemset(h->queues, 0, FMD_N_QUEUES * sizeof(uint32_t));
+    hipMemset(h->stat, 0, FMD_STAT_SLOTS * FMD_STAT_STRIDE * 8);
     *out = h;
     return FMD_OK;
 }
@@ -553,6 +556,7 @@ extern "C" void fmd_dev_close(fmd_dev_t *h)
     hipFree(h->blocks);
     hipFree(h->ptab);
     hipFree(h->queues);
+    hipFree(h->stat);
     if (h->aux_ready) {
         hipStreamDestroy(h->aux_stream);
         for (int i = 0; i <= FMD_OVLP_MAX_PARTS; ++i) hipEventDestroy(h->aux_ev[i]);
@@ -568,6 +572,23 @@ extern "C" int fmd_dev_info(const fmd_dev_t *h, fmd_info_t *info)
     info->n_blocks = h->n_blocks;
     info->hbm_bytes = h->bytes;
     info->device = h->device;
+    return FMD_OK;
+}
+
+// Rank blocks (and other random lines) the kernels launched on this handle have requested since the last reset.
+// The shipped library does not count (returns zeros and counting = 0); libfmdhip_count.so, the same sources built with
+// -DFMD_COUNT_LINES=1, does.  Synchronises the device.
+extern "C" int fmd_dev_line_count(fmd_dev_t *h, uint64_t lines[2], int reset, int *counting)
+{
+    if (!h || !lines) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    unsigned long long host[FMD_STAT_SLOTS * FMD_STAT_STRIDE];
+    FMD_HIP_TRY(hipDeviceSynchronize());
+    FMD_HIP_TRY(hipMemcpy(host, h->stat, sizeof(host), hipMemcpyDeviceToHost));
+    lines[0] = lines[1] = 0;
+    for (int i = 0; i < FMD_STAT_SLOTS; ++i) { lines[0] += host[i * FMD_STAT_STRIDE]; lines[1] += host[i * FMD_STAT_STRIDE + 1]; }
+    if (reset) FMD_HIP_TRY(hipMemset(h->stat, 0, sizeof(host)));
+    if (counting) *counting = FMD_COUNT_LINES;
     return FMD_OK;
 }
 

@@ -18,6 +18,7 @@ struct fmd_dev {
     int ptab_d;
     uint32_t *queues;         // device ring of work-queue heads for the persistent kernels
     uint32_t queue_next;      // host-side ring cursor (atomic)
+    unsigned long long *stat; // device: FMD_STAT_SLOTS x FMD_STAT_STRIDE line counters (written by the instrumented build only)
     // second stream + events of the pipelined overlap batch (fmd_ovlp_dev), created on first use;
     // aux_busy (atomic) lets one call at a time use them, a concurrent call takes the serial path
     hipStream_t aux_stream;
@@ -45,6 +46,7 @@ static inline FmdIndexView fmd_view(const fmd_dev *h)
     v.n_sym = h->mcnt[0];
     v.n_seq = h->mcnt[1];
     v.ptab = h->ptab; v.ptab_d = h->ptab_d;
+    v.stat = h->stat;
     return v;
 }
 

@@ -156,6 +156,7 @@ __global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const
                             }
                             if (acgt) {
                                 const uint4 e = ix.ptab[idx];
+                                fmd_count_lane(ix, 1, 1);
                                 k = (uint64_t)e.y << 32 | e.x; l = (uint64_t)e.w << 32 | e.z;
                                 pos = len - D - 1;
                                 from_table = true;
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(64) void k_reach(FmdIndexView ix, size_t n, const u
                             }
                             if (acgt) {
                                 const uint4 e = ix.ptab[idx];
+                                fmd_count_lane(ix, 1, 1);
                                 const uint64_t tk = (uint64_t)e.y << 32 | e.x, tl = (uint64_t)e.w << 32 | e.z;
                                 if (tk <= tl) { k = tk; l = tl; i = p + (size_t)D; live = true; from_table = true; }
                             }

@@ -279,6 +279,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
                 if ((depth & 3) == 0) WALK_STASH_WORD();
                 if ((int)depth == ix.ptab_d) {
                     const uint4 ef = ix.ptab[tfw], er = ix.ptab[trv];
+                    fmd_count_lane(ix, 2, 1);
                     x0 = (uint64_t)ef.y << 32 | ef.x;
                     sz = ((uint64_t)ef.w << 32 | ef.z) - x0 + 1;   // never empty: the sequence is in the index
                     x1 = (uint64_t)er.y << 32 | er.x;

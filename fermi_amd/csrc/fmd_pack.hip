@@ -1,0 +1,117 @@
+// fmd_pack.hip -- compact form of a finished overlap batch: what leaves the GPU.
+//
+// fmd_ovlp_dev works on fixed-stride rows (64-byte record, max_nei x 32-byte neighbours, seq_stride bytes of
+// sequence: 448 bytes per strand at the defaults).  That is the right shape for the kernels and the wrong one for
+// a link: the unitig walk (unitig.c:227-317, host) reads from a row its record, its n_nei neighbours (one, unless
+// the read set forks) and len + ext_len bases.  fmd_ovlp_pack_dev rewrites a batch as
+//     prec[i]        the record, unchanged except for FMD_OVLP_F_PACK4 in `flags`
+//     var + off[i]   min(n_nei, max_nei) neighbours (32 bytes each), then len + ext_len bases, 4 per byte
+//                    (2 per byte when the row holds a base other than A/C/G/T: FMD_OVLP_F_PACK4), padded to 8 bytes;
+//                    nothing at all for rows the walk never opens (status != 0 or an overflowed record)
+// ~125 bytes per strand on 100-bp reads.  The same rows travel over PCIe to the host walk (fmdh_ovlp_table_build)
+// and over xGMI to rank 0 in the multi-process form (the one RCCL exchange of the pipeline).
+#include <hipcub/hipcub.hpp>
+#include "fmd_kernel_common.h"
+
+// bytes of row i's variable part; *pack4 = the sequence needs 4 bits per base
+__device__ __forceinline__ uint32_t pack_row_bytes(const fmd_ovlp_rec_t &r, uint32_t max_nei, const uint8_t *seq, uint32_t seq_stride, bool &pack4)
+{
+    pack4 = false;
+    if (r.status != 0 || (r.flags & FMD_OVLP_F_OVERFLOW)) return 0;
+    uint32_t nb = (uint32_t)r.len + (uint32_t)r.ext_len;
+    if (nb > seq_stride) nb = seq_stride;
+    for (uint32_t j = 0; j < nb && !pack4; j += 4) { // rows are 4-byte aligned (the host entry checks seq_stride % 4 == 0)
+        const uint32_t w = *(const uint32_t *)(seq + j);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { const uint32_t c = (w >> (8 * b)) & 0xff; if (j + b < nb && (c < 1 || c > 4)) pack4 = true; }
+    }
+    const uint32_t nn = (uint32_t)r.n_nei < max_nei ? (uint32_t)r.n_nei : max_nei;
+    const uint32_t sb = pack4 ? (nb + 1) / 2 : (nb + 3) / 4;
+    return nn * 32 + ((sb + 7) & ~7u);
+}
+
+__global__ void k_pack_sizes(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, uint32_t max_nei, const uint8_t *__restrict__ seq, uint32_t seq_stride,
+                             uint64_t *__restrict__ sizes)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += step) {
+        bool p4;
+        sizes[i] = i < n ? pack_row_bytes(rec[i], max_nei, seq + i * (size_t)seq_stride, seq_stride, p4) : 0;
+    }
+}
+
+// one 8-lane group per row: record (64 bytes = 8 lanes x 8), neighbours, then the packed bases 8 bytes per lane
+__global__ void k_pack_rows(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, const fmd_intv_t *__restrict__ nei, uint32_t max_nei,
+                            const uint8_t *__restrict__ seq, uint32_t seq_stride, fmd_ovlp_rec_t *__restrict__ prec,
+                            const uint64_t *__restrict__ off, uint8_t *__restrict__ var, uint64_t var_cap)
+{
+    const size_t step = (size_t)gridDim.x * (blockDim.x >> 3);
+    const int l8 = threadIdx.x & 7;
+    for (size_t i = (size_t)blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3); i < n; i += step) {
+        const fmd_ovlp_rec_t r = rec[i];
+        const uint64_t o = off[i], sz = off[i + 1] - o;
+        const bool fits = o + sz <= var_cap;
+        uint32_t nb = (uint32_t)r.len + (uint32_t)r.ext_len;
+        if (nb > seq_stride) nb = seq_stride;
+        const uint32_t nn = (uint32_t)r.n_nei < max_nei ? (uint32_t)r.n_nei : max_nei;
+        bool pack4;
+        (void)pack_row_bytes(r, max_nei, seq + i * (size_t)seq_stride, seq_stride, pack4);
+        const uint32_t sb8 = sz ? (uint32_t)sz - nn * 32 : 0;          // padded sequence bytes
+        {   // the record: lane l8 copies word l8; flags live in word 7 (low half)
+            uint64_t w = ((const uint64_t *)(rec + i))[l8];
+            if (l8 == 7 && pack4) w |= (uint64_t)FMD_OVLP_F_PACK4;
+            ((uint64_t *)(prec + i))[l8] = w;
+        }
+        if (!sz || !fits) continue;
+        uint8_t *dst = var + o;
+        for (uint32_t w = l8; w < nn * 4; w += 8) ((uint64_t *)dst)[w] = ((const uint64_t *)(nei + i * (size_t)max_nei))[w];
+        dst += nn * 32;
+        const uint8_t *s = seq + i * (size_t)seq_stride;
+        for (uint32_t w = l8; w < sb8 / 8; w += 8) {   // output word w = bases [32w, 32w+32) (2-bit) or [16w, 16w+16) (4-bit)
+            uint64_t v = 0;
+            if (pack4) {
+                for (int b = 0; b < 16; ++b) { const uint32_t j = 16 * w + b; if (j < nb) v |= (uint64_t)(s[j] & 15) << (4 * b); }
+            } else {
+                for (int b = 0; b < 32; ++b) { const uint32_t j = 32 * w + b; if (j < nb) v |= (uint64_t)((s[j] - 1) & 3) << (2 * b); }
+            }
+            ((uint64_t *)dst)[w] = v;
+        }
+    }
+}
+
+extern "C" size_t fmd_ovlp_pack_max_bytes(size_t n, uint32_t max_nei, uint32_t seq_stride)
+{
+    return n * ((size_t)max_nei * 32 + (((size_t)seq_stride + 1) / 2 + 7) / 8 * 8);
+}
+
+extern "C" size_t fmd_ovlp_pack_work_bytes(size_t n)
+{
+    size_t tb = 0;
+    hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (uint64_t *)nullptr, (uint64_t *)nullptr, n + 1);
+    return (n + 1) * 8 + ((tb + 255) & ~(size_t)255) + 256;
+}
+
+extern "C" int fmd_ovlp_pack_dev(fmd_dev_t *h, void *stream_, size_t n, const fmd_ovlp_rec_t *d_rec, const fmd_intv_t *d_nei, uint32_t max_nei,
+                                 const uint8_t *d_seq, uint32_t seq_stride, fmd_ovlp_rec_t *d_prec, uint64_t *d_off, uint8_t *d_var, uint64_t var_cap,
+                                 void *d_work, size_t work_bytes)
+{
+    if (!h || (n && (!d_rec || !d_nei || !d_seq || !d_prec || !d_off || !d_var || !d_work)) || max_nei == 0 || (seq_stride & 3)) return FMD_E_ARG;
+    if (work_bytes < fmd_ovlp_pack_work_bytes(n)) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream_;
+    if (n == 0) { FMD_HIP_TRY(hipMemsetAsync(d_off, 0, 8, st)); return FMD_OK; }
+    uint64_t *sizes = (uint64_t *)d_work;
+    void *tmp = (uint8_t *)d_work + (((n + 1) * 8 + 255) & ~(size_t)255);
+    size_t tb = 0;
+    FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, sizes, d_off, n + 1, st));
+    size_t blocks = (n + 256) / 256;
+    if (blocks > (1u << 20)) blocks = 1u << 20;
+    k_pack_sizes<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, max_nei, d_seq, seq_stride, sizes);
+    FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tb, sizes, d_off, n + 1, st));
+    blocks = (n + 31) / 32;
+    if (blocks > (1u << 20)) blocks = 1u << 20;
+    k_pack_rows<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, d_nei, max_nei, d_seq, seq_stride, d_prec, d_off, d_var, var_cap);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fmd_set_hip_error(e, "overlap pack kernels"); return FMD_E_HIP; }
+    return FMD_OK;
+}

@@ -72,13 +72,42 @@ struct FmdIndexView {            // passed by value as a kernel argument (lives 
     // index of s_0 s_1 .. s_{d-1} = sum (s_j - 1) << 2(d-1-j).  Lets a search start ptab_d bases in.
     const uint4 *ptab;
     int ptab_d;
+    // 64 counters on separate 128-byte lines: rank blocks requested from the memory system by the gathers.
+    // Only the instrumented build (-DFMD_COUNT_LINES=1, libfmdhip_count.so) adds to them; bench.py runs one step
+    // of each leg through that build to price the shipped kernels in DEVICE bytes (64 bytes per block).
+    unsigned long long *stat;
 };
+
+#ifndef FMD_COUNT_LINES
+#define FMD_COUNT_LINES 0
+#endif
+#define FMD_STAT_SLOTS 64
+#define FMD_STAT_STRIDE 16   // u64 per slot = 128 bytes
+// kind 0 = 64-byte rank blocks, kind 1 = other random lines (prefix-table look-ups)
+__device__ __forceinline__ void fmd_count_lines(const FmdIndexView &ix, int n, int kind = 0)
+{
+#if FMD_COUNT_LINES
+    if (n > 0 && (threadIdx.x & 63) == 0) atomicAdd(ix.stat + (blockIdx.x & (FMD_STAT_SLOTS - 1)) * FMD_STAT_STRIDE + kind, (unsigned long long)n);
+#else
+    (void)ix; (void)n; (void)kind;
+#endif
+}
 
 __device__ __forceinline__ int fmd_lane() { return (int)(threadIdx.x & 63); }
 // number of set bits of a wave-uniform mask below this lane (v_mbcnt_lo/hi: two instructions)
 __device__ __forceinline__ int fmd_below(uint64_t mask)
 {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// per-LANE form (divergent call sites: the prefix-table look-up of one lane)
+__device__ __forceinline__ void fmd_count_lane(const FmdIndexView &ix, int n, int kind)
+{
+#if FMD_COUNT_LINES
+    atomicAdd(ix.stat + (blockIdx.x & (FMD_STAT_SLOTS - 1)) * FMD_STAT_STRIDE + kind, (unsigned long long)n);
+#else
+    (void)ix; (void)n; (void)kind;
+#endif
 }
 
 // position -> (block, offset inside the block)
@@ -156,6 +185,7 @@ __device__ __forceinline__ void fmd_fetch_slot(const FmdIndexView &ix, uint4 *ld
 {
     const uint64_t m = __ballot(need);
     if (m == 0) return;
+    fmd_count_lines(ix, __popcll(m));
     fmd_fetch_round<SLOT, 0>(ix, lds, blk, m); fmd_fetch_round<SLOT, 1>(ix, lds, blk, m);
     fmd_fetch_round<SLOT, 2>(ix, lds, blk, m); fmd_fetch_round<SLOT, 3>(ix, lds, blk, m);
 #if !FMD_BLK64
@@ -184,6 +214,7 @@ __device__ __forceinline__ int fmd_pool_xor(int p) { return p & 7; }
 __device__ __forceinline__ void fmd_fetch_pool(const FmdIndexView &ix, uint4 *pool, const uint32_t *ids, int n)
 {
     const int q = fmd_lane();
+    fmd_count_lines(ix, n);
     for (int rr = 0; rr * FMD_BLK_PER_INST < n; ++rr) {
         const int slot = rr * FMD_BLK_PER_INST + (q >> FMD_GRP_SHIFT);
         if (slot < n) {

@@ -62,3 +62,59 @@ def to_fastq(reads_nt6, path, qual="I"):
         for i, r in enumerate(reads_nt6):
             s = tab[r].tobytes()
             fp.write(b"@r%d\n%s\n+\n%s\n" % (i, s, qual.encode() * len(s)))
+
+
+# ---- the same generator on a GPU (torch int64 arithmetic wraps like uint64; shifts are made logical) ----
+def _i64(v):
+    v &= 0xFFFFFFFFFFFFFFFF
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _lsr(t, k):
+    return (t >> k) & ((1 << (64 - k)) - 1)
+
+
+def rnd_torch(seed, stream, idx):
+    """rnd() on a torch int64 tensor of indices; returns the 64-bit outputs as int64 bit patterns."""
+    s = _i64(int(seed) ^ (int(stream) * int(_K)))
+    z = (idx + 1) * _i64(int(_GOLD)) + s
+    z = (z ^ _lsr(z, 30)) * _i64(int(_M1))
+    z = (z ^ _lsr(z, 27)) * _i64(int(_M2))
+    return z ^ _lsr(z, 31)
+
+
+def _umod(u, m):
+    """(u as unsigned 64-bit) % m for 0 < m < 2^31, int64 tensors only."""
+    hi, lo = _lsr(u, 32), u & 0xFFFFFFFF
+    return ((hi % m) * ((1 << 32) % m) + lo) % m
+
+
+def reads_torch(seed, n_reads, read_len=100, coverage=30, err=0.0, device="cuda", chunk=2_000_000):
+    """reads() computed on `device`: uint8 [n_reads, read_len] tensor, identical to the numpy form."""
+    import torch
+    g = max(n_reads * read_len // coverage, read_len)
+    span = g - read_len + 1
+    if span >= (1 << 31):
+        raise ValueError("reads_torch: genome too long for the 32-bit split of the modulo; use reads()")
+    gen = torch.empty(g, dtype=torch.uint8, device=device)
+    for s in range(0, g, 1 << 26):
+        c = min(1 << 26, g - s)
+        gen[s:s + c] = (1 + _lsr(rnd_torch(seed, 1, torch.arange(s, s + c, dtype=torch.int64, device=device)), 62)).to(torch.uint8)
+    out = torch.empty((n_reads, read_len), dtype=torch.uint8, device=device)
+    ar = torch.arange(read_len, dtype=torch.int64, device=device)
+    thr = int(err * 4294967296.0)
+    for s in range(0, n_reads, chunk):
+        c = min(chunk, n_reads - s)
+        r = torch.arange(s, s + c, dtype=torch.int64, device=device)
+        pos = _umod(rnd_torch(seed, 2, r), span)
+        strand = _lsr(rnd_torch(seed, 3, r), 63).bool()
+        win = gen[pos[:, None] + ar[None, :]]
+        rc = (5 - win).flip(1)
+        o = torch.where(strand[:, None], rc, win)
+        if err > 0:
+            u = rnd_torch(seed, 4, r[:, None] * read_len + ar[None, :])
+            hit = _lsr(u, 32) < thr
+            sub = (1 + ((o.to(torch.int64) - 1) + 1 + (u & 0xFFFFFFFF) % 3) % 4).to(torch.uint8)
+            o = torch.where(hit, sub, o)
+        out[s:s + c] = o
+    return out

@@ -28,6 +28,18 @@ class ReadsOnDevice:
         self.off = (torch.arange(n + 1, dtype=torch.int64, device=device) * L)
         self.total = n * L
 
+    @classmethod
+    def synth(cls, n_reads, read_len, coverage, err, device, seed=synth.DEFAULT_SEED):
+        """The synthetic read set of SURVEY.md 8(d), generated in HBM (synth.reads_torch == synth.reads)."""
+        import torch
+        self = cls.__new__(cls)
+        self.n, self.L = n_reads, read_len
+        self.flat = torch.zeros(n_reads * read_len + 64, dtype=torch.uint8, device=device)
+        self.flat[: n_reads * read_len].view(n_reads, read_len).copy_(synth.reads_torch(seed, n_reads, read_len, coverage, err, device))
+        self.off = (torch.arange(n_reads + 1, dtype=torch.int64, device=device) * read_len)
+        self.total = n_reads * read_len
+        return self
+
 
 def build_bwt_on_device(rd, device_index=0, stream=None):
     """-> (device pointer of the BWT, n_sym); release with api.lib().fmd_dev_free."""

@@ -67,6 +67,11 @@ int fmd_dev_open_bwt_dev(int device, const uint8_t *d_bwt, uint64_t n, fmd_dev_t
 void fmd_dev_close(fmd_dev_t *h);
 int fmd_dev_info(const fmd_dev_t *h, fmd_info_t *info);
 int fmd_dev_sync(const fmd_dev_t *h, void *stream);
+/* measurement aid (no reference counterpart): lines[0] = 64-byte rank blocks, lines[1] = other random lines
+ * (prefix-table look-ups) that the kernels launched on this handle have requested since the last reset.  Only
+ * libfmdhip_count.so -- the same sources built with -DFMD_COUNT_LINES=1 -- counts (*counting = 1); the shipped
+ * library returns zeros and *counting = 0.  Synchronises the device. */
+int fmd_dev_line_count(fmd_dev_t *h, uint64_t lines[2], int reset, int *counting);
 
 /* ---- rank: rld_rank1a (rld.c:424) / rld_rank2a (rld.c:457) -------------------------------
  * ok/ol: n rows of 6 counts ($ACGTN) of BWT[0..k] inclusive; k == UINT64_MAX gives zeros.
@@ -153,6 +158,7 @@ int fmd_smem_batch(fmd_dev_t *h, size_t n, const uint8_t *seqs, const uint64_t *
 #define FMD_OVLP_F_FORKED   1u    /* more than one category survived a round (unitig.c:152) */
 #define FMD_OVLP_F_OVERFLOW 2u    /* a capacity (max_len, list, max_nei) was exceeded: record invalid, re-run larger */
 #define FMD_OVLP_F_FIXED    4u    /* the fake-fork fix-up of unitig.c:158-176 ran */
+#define FMD_OVLP_F_PACK4    8u    /* packed rows only (fmd_ovlp_pack_dev): the bases are stored 2 per byte, not 4 */
 typedef struct {
     uint64_t rank;     /* fm_retrieve's return value */
     uint64_t k[3];     /* *intv of fm6_is_contained: bi-interval of `$read$` */
@@ -189,6 +195,20 @@ int fmd_ovlp_check_left_dev(fmd_dev_t *h, void *stream, size_t n, int min_match,
                             const uint8_t *d_seq, uint32_t seq_stride, void *d_work, size_t work_bytes);
 int fmd_ovlp_batch(fmd_dev_t *h, size_t n, const uint64_t *ids, int min_match, uint32_t max_len, uint32_t max_nei,
                    fmd_ovlp_rec_t *rec, fmd_intv_t *nei, uint8_t *seq, uint32_t seq_stride, int with_check_left);
+
+/* ---- compact form of a finished batch: what leaves the GPU (PCIe to the host walk, xGMI to rank 0) ----------
+ * The walk (unitig.c:227-317) reads from a row its record, its n_nei neighbours and len + ext_len bases.  Row i becomes
+ *   d_prec[i]          the record (flags gains FMD_OVLP_F_PACK4 when the row holds a base other than A/C/G/T)
+ *   d_var + d_off[i]   min(n_nei, max_nei) neighbours (32 bytes each), then len + ext_len bases, 4 per byte as
+ *                      (base - 1) in 2 bits, first base in the low bits -- or nt6 codes 2 per byte with PACK4 --
+ *                      padded to 8 bytes; empty for rows with status != 0 or FMD_OVLP_F_OVERFLOW
+ * d_off has n + 1 entries; rows that would end past var_cap are not written (compare d_off[n] with var_cap;
+ * fmd_ovlp_pack_max_bytes is always enough).  seq_stride must be a multiple of 4. */
+size_t fmd_ovlp_pack_max_bytes(size_t n, uint32_t max_nei, uint32_t seq_stride);
+size_t fmd_ovlp_pack_work_bytes(size_t n);
+int fmd_ovlp_pack_dev(fmd_dev_t *h, void *stream, size_t n, const fmd_ovlp_rec_t *d_rec, const fmd_intv_t *d_nei, uint32_t max_nei,
+                      const uint8_t *d_seq, uint32_t seq_stride, fmd_ovlp_rec_t *d_prec, uint64_t *d_off, uint8_t *d_var, uint64_t var_cap,
+                      void *d_work, size_t work_bytes);
 
 /* ---- k-mer harvest of `fermi correct`: fm6_traverse (exact.c:141) + ec_collect (correct.c:35-87)
  * over ALL 4^suf_len suffix buckets (what worker1 does, correct.c:272-279).  Emits one

@@ -1,5 +1,5 @@
-"""CPU, world_size 2, gloo: the N>1 path -- id sharding (start/step interleave) and the single
-gather of per-id records on rank 0 -- with the record dtype the GPU path produces."""
+"""CPU, world_size 2, gloo: the N>1 path -- id sharding (start/step interleave) and the single gather of the
+packed per-id rows on rank 0 -- on records the ORACLE computed from the golden index (not synthetic rows)."""
 import os
 import socket
 
@@ -8,8 +8,10 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from fermi_amd import api
 from fermi_amd import dist as fdist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
 
 
 def _free_port():
@@ -17,28 +19,45 @@ def _free_port():
     return p
 
 
-def _fake_records(ids):
-    rec = np.zeros(len(ids), dtype=api.OVLP_DT)
-    rec["rank"] = ids * 7 + 1
-    rec["k"][:, 0] = ids; rec["k"][:, 1] = ids ^ 1; rec["k"][:, 2] = 1
-    rec["len"] = 100; rec["n_nei"] = (ids % 3).astype(np.int32)
-    nei = np.zeros((len(ids), 4), dtype=api.INTV_DT)
-    nei["x"][:, 0, 0] = ids + 5; nei["info"][:, 0] = 80 + ids % 17
-    return rec, nei
+def _oracle_rows(fmd, ids, min_match):
+    import sys
+    sys.path.insert(0, HERE)
+    import orcbind
+    import packref
+    o = orcbind.OrcIndex(fmd)
+    rec, nei, seq = o.overlap_batch(ids, min_match, 128, 4, 1, check_left=True)
+    o.close()
+    return packref.pack_rows(rec, nei, seq, 4)
 
 
-def _worker(rank, world, port, n_ids, q):
+def _worker(rank, world, port, fmd, n_ids, min_match, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ids = fdist.shard_ids(n_ids, rank, world)
-    rec, nei = _fake_records(ids)
-    g_rec = fdist.gather_rows(rec, n_ids, rank, world, dist)
-    g_nei = fdist.gather_rows(nei, n_ids, rank, world, dist)
+    prec, off, var = _oracle_rows(fmd, ids, min_match)
+    cap = len(var) + 64     # the device buffer is larger than what is used: only off[-1] bytes travel
+    var_t = torch.zeros(cap, dtype=torch.uint8); var_t[: len(var)] = torch.from_numpy(var)
+    got = fdist.gather_packed(torch.from_numpy(prec.view(np.uint8).reshape(-1).copy()), torch.from_numpy(off.astype(np.int64)), var_t,
+                              n_ids, rank, world, dist)
     if rank == 0:
-        want_rec, want_nei = _fake_records(np.arange(n_ids, dtype=np.uint64))
-        q.put(bool(g_rec.tobytes() == want_rec.tobytes() and g_nei.tobytes() == want_nei.tobytes()))
+        want_p, want_o, want_v = _oracle_rows(fmd, np.arange(n_ids, dtype=np.uint64), min_match)
+        ok = len(got) == world
+        for r in range(world):   # row i of the global table = arrays of rank i % world, index i // world
+            p, o_, v = got[r]
+            rows = np.arange(r, n_ids, world)
+            ok = ok and p.numpy().tobytes() == want_p[rows].tobytes()
+            lens = (o_[1:] - o_[:-1]).numpy()
+            ok = ok and np.array_equal(lens, (want_o[rows + 1] - want_o[rows]).astype(np.int64)) and int(o_[-1]) == v.numel()
+            for k in (0, len(rows) // 2, len(rows) - 1):
+                i = rows[k]
+                ok = ok and v[int(o_[k]):int(o_[k + 1])].numpy().tobytes() == want_v[int(want_o[i]):int(want_o[i + 1])].tobytes()
+            # all variable parts of this rank, back to back, through the same index arithmetic bench.py's check uses
+            pr, ln, vb = fdist.packed_rows(torch, got[r], torch.arange(len(rows), dtype=torch.int64))
+            want_cat = b"".join(want_v[int(want_o[i]):int(want_o[i + 1])].tobytes() for i in rows)
+            ok = ok and vb.numpy().tobytes() == want_cat
+        q.put(bool(ok))
     else:
-        assert g_rec is None and g_nei is None
+        assert got is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -47,17 +66,37 @@ def test_shard_ids_is_start_step_interleave():
     assert list(fdist.shard_ids(10, 1, 4)) == [1, 5, 9]
     allids = np.sort(np.concatenate([fdist.shard_ids(1001, r, 8) for r in range(8)]))
     assert np.array_equal(allids, np.arange(1001, dtype=np.uint64))
+    assert [fdist.shard_size(1001, r, 8) for r in range(8)] == [len(fdist.shard_ids(1001, r, 8)) for r in range(8)]
 
 
-def test_gather_records_world2_gloo():
+def test_packed_rows_roundtrip(oracle_lib):
+    import packref
+    fmd = os.path.join(GOLD, "special.fmd")   # ragged lengths, Ns, palindromes: both packings occur
+    import orcbind
+    o = orcbind.OrcIndex(fmd)
+    n = int(o.mcnt[1])
+    rec, nei, seq = o.overlap_batch(np.arange(n, dtype=np.uint64), 20, 128, 4, 1, check_left=True)
+    o.close()
+    prec, off, var = packref.pack_rows(rec, nei, seq, 4)
+    assert (prec["flags"] & packref.F_PACK4).any() and not (prec["flags"] & packref.F_PACK4).all()
+    for i in range(n):
+        ne, s = packref.unpack_row(prec[i], var[int(off[i]):int(off[i + 1])])
+        if rec[i]["status"] != 0:
+            assert len(s) == 0
+            continue
+        nb = rec[i]["len"] + rec[i]["ext_len"]
+        assert np.array_equal(s, seq[i, :nb]) and ne.tobytes() == nei[i, :min(rec[i]["n_nei"], 4)].tobytes()
+
+
+def test_gather_packed_records_world2_gloo(oracle_lib):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     n_ids = 1001  # odd: ranks hold different counts
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, n_ids, q)) for r in range(2)]
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, os.path.join(GOLD, "tiny.fmd"), n_ids, 50, q)) for r in range(2)]
     for p in ps:
         p.start()
-    ok = q.get(timeout=120)
+    ok = q.get(timeout=180)
     for p in ps:
         p.join(timeout=60)
         assert p.exitcode == 0

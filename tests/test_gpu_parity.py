@@ -230,6 +230,24 @@ def test_overlap_records_golden(gpu, gold, name, key, max_len):
     _check_overlap_records(gpu, gold, name, key, max_len)
 
 
+@pytest.mark.parametrize("name,mm,max_len", [("tiny", 50, 100), ("special", 20, 60), ("repeat", 20, 80)])
+def test_overlap_pack_equals_numpy_statement(gpu, gold, name, mm, max_len):
+    """fmd_ovlp_pack_dev (what leaves the GPU: PCIe to the host walk, xGMI to rank 0) against tests/packref.py, incl.
+    rows with Ns (4-bit form), contained/short rows (empty) and overflowed rows."""
+    import packref
+    d = gpu.DevIndex.open(gold.path(name + ".fmd"))
+    ids = np.arange(int(d.mcnt[1]), dtype=U64)
+    for ml in (max_len, max(8, max_len // 2)):   # the second pass overflows the longer reads
+        rec, nei, seq = d.overlap(ids, mm, max_len=ml)
+        prec, off, var = d.overlap_pack(rec, nei, seq)
+        wp, wo, wv = packref.pack_rows(rec, nei, seq, nei.shape[1])
+        assert prec.tobytes() == wp.tobytes() and np.array_equal(off, wo) and var.tobytes() == wv.tobytes()
+    r0, n0, s0 = d.overlap(ids[:0], mm, max_len=max_len)
+    p0, o0, v0 = d.overlap_pack(r0, n0, s0)
+    assert len(p0) == 0 and list(o0) == [0] and len(v0) == 0
+    d.close()
+
+
 def test_overlap_sequences_and_capacity_flags(gpu, gold):
     d = gpu.DevIndex.open(gold.path("tiny.fmd"))
     ids = np.arange(0, 400, dtype=U64)
