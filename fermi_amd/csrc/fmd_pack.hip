@@ -10,6 +10,9 @@
 //                    nothing at all for rows the walk never opens (status != 0 or an overflowed record)
 // ~125 bytes per strand on 100-bp reads.  The same rows travel over PCIe to the host walk (fmdh_ovlp_table_build)
 // and over xGMI to rank 0 in the multi-process form (the one RCCL exchange of the pipeline).
+#include <stdlib.h>
+#include <sys/mman.h>
+#include <vector>
 #include <hipcub/hipcub.hpp>
 #include "fmd_kernel_common.h"
 
@@ -114,4 +117,125 @@ extern "C" int fmd_ovlp_pack_dev(fmd_dev_t *h, void *stream_, size_t n, const fm
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "overlap pack kernels"); return FMD_E_HIP; }
     return FMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host form: the whole table of one shard of sequence ids, packed, pipelined.
+//
+// ids = first, first + step, ... (the reference's worker interleave, unitig.c:333, 398-399) or an explicit list.
+// Chunks of 2^chunk_shift rows go through  fmd_ovlp_dev -> fmd_ovlp_check_left_dev -> fmd_ovlp_pack_dev  on one
+// stream; the packed rows of chunk c cross PCIe on a second stream while chunk c+1 is computed (two sets of
+// packed buffers, one set of everything else).  ~125 bytes per strand leave the GPU instead of 448.
+__global__ void k_fill_ids(size_t n, uint64_t first, uint64_t step, uint64_t *ids)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) ids[i] = first + step * i;
+}
+
+namespace {
+struct DevMem {
+    void *p = nullptr;
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? FMD_OK : FMD_E_NOMEM; }
+    ~DevMem() { if (p) hipFree(p); }
+};
+struct Stream {
+    hipStream_t s = nullptr;
+    int make() { return hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess ? FMD_OK : FMD_E_HIP; }
+    ~Stream() { if (s) hipStreamDestroy(s); }
+};
+struct Event {
+    hipEvent_t e = nullptr;
+    int make() { return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess ? FMD_OK : FMD_E_HIP; }
+    ~Event() { if (e) hipEventDestroy(e); }
+};
+struct Pinned { // hipHostRegister for a scope (best effort: pageable copies otherwise)
+    void *p = nullptr;
+    void pin(void *ptr, size_t bytes) { if (bytes >= ((size_t)8 << 20) && !getenv("FMD_NO_PIN") && hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess) p = ptr; else (void)hipGetLastError(); }
+    ~Pinned() { if (p) hipHostUnregister(p); }
+};
+}
+
+extern "C" void fmd_ovlp_packed_free(uint8_t **chunks, size_t n_chunks)
+{
+    if (!chunks) return;
+    for (size_t c = 0; c < n_chunks; ++c) { free(chunks[c]); chunks[c] = nullptr; }
+}
+
+extern "C" int fmd_ovlp_packed_batch(fmd_dev_t *h, const uint64_t *ids, uint64_t first, uint64_t step, size_t n, int min_match, uint32_t max_len,
+                                     uint32_t max_nei, int with_check_left, fmd_ovlp_rec_t *rec, uint64_t *off, uint32_t chunk_shift, uint8_t **chunks)
+{
+    if (!h || (n && (!rec || !off || !chunks)) || chunk_shift < 10 || chunk_shift > 26 || max_len == 0 || max_nei == 0) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    const size_t CH = (size_t)1 << chunk_shift, m = n < CH ? n : CH, n_chunks = (n + CH - 1) / CH;
+    const uint32_t stride = 2 * ((max_len + 3) / 4 * 4);
+    const size_t wb0 = fmd_ovlp_work_bytes(m, max_len, min_match), wb1 = fmd_ovlp_pack_work_bytes(m), wb = wb0 > wb1 ? wb0 : wb1;
+    const size_t cap = fmd_ovlp_pack_max_bytes(m, max_nei, stride);
+    for (size_t c = 0; c < n_chunks; ++c) chunks[c] = nullptr;
+    DevMem d_ids, d_rec, d_nei, d_seq, d_work, d_prec[2], d_off[2], d_var[2];
+    Stream s_cmp, s_cpy;
+    Event done[2], copied[2];
+    if (d_ids.alloc(m * 8) || d_rec.alloc(m * sizeof(fmd_ovlp_rec_t)) || d_nei.alloc(m * max_nei * sizeof(fmd_intv_t)) || d_seq.alloc(m * (size_t)stride) ||
+        d_work.alloc(wb)) return FMD_E_NOMEM;
+    for (int k = 0; k < 2; ++k)
+        if (d_prec[k].alloc(m * sizeof(fmd_ovlp_rec_t)) || d_off[k].alloc((m + 1) * 8) || d_var[k].alloc(cap) || done[k].make() || copied[k].make()) return FMD_E_NOMEM;
+    if (s_cmp.make() || s_cpy.make()) return FMD_E_HIP;
+    Pinned pin_rec, pin_off;
+    pin_rec.pin(rec, n * sizeof(fmd_ovlp_rec_t));
+    pin_off.pin(off, n * 8);
+    uint64_t *tot = nullptr;            // pinned landing place of the two chunk totals
+    FMD_HIP_TRY(hipHostMalloc((void **)&tot, 2 * sizeof(uint64_t), hipHostMallocDefault));
+    int rc = FMD_OK;
+    std::vector<void *> registered;
+    auto fail = [&](int code) { rc = code; };
+    // chunk c: compute on s_cmp into set c & 1; its copy-out is issued one iteration later
+    for (size_t c = 0; c <= n_chunks && rc == FMD_OK; ++c) {
+        if (c < n_chunks) {
+            const int k = (int)(c & 1);
+            const size_t b = c * CH, nc = n - b < CH ? n - b : CH;
+            if (c >= 2 && hipStreamWaitEvent(s_cmp.s, copied[k].e, 0) != hipSuccess) { fail(FMD_E_HIP); break; } // set k has left the GPU
+            if (ids) { if (hipMemcpyAsync(d_ids.p, ids + b, nc * 8, hipMemcpyHostToDevice, s_cmp.s) != hipSuccess) { fail(FMD_E_HIP); break; } }
+            else k_fill_ids<<<1024, 256, 0, s_cmp.s>>>(nc, first + step * b, step, (uint64_t *)d_ids.p);
+            if (hipMemsetAsync(d_seq.p, 0, nc * (size_t)stride, s_cmp.s) != hipSuccess || hipMemsetAsync(d_nei.p, 0, nc * max_nei * sizeof(fmd_intv_t), s_cmp.s) != hipSuccess) { fail(FMD_E_HIP); break; }
+            rc = fmd_ovlp_dev(h, s_cmp.s, nc, (uint64_t *)d_ids.p, min_match, max_len, max_nei, (fmd_ovlp_rec_t *)d_rec.p, (fmd_intv_t *)d_nei.p, (uint8_t *)d_seq.p, stride, d_work.p, wb);
+            if (rc == FMD_OK && with_check_left)
+                rc = fmd_ovlp_check_left_dev(h, s_cmp.s, nc, min_match, max_len, (fmd_ovlp_rec_t *)d_rec.p, (uint8_t *)d_seq.p, stride, d_work.p, wb);
+            if (rc == FMD_OK)
+                rc = fmd_ovlp_pack_dev(h, s_cmp.s, nc, (fmd_ovlp_rec_t *)d_rec.p, (fmd_intv_t *)d_nei.p, max_nei, (uint8_t *)d_seq.p, stride,
+                                       (fmd_ovlp_rec_t *)d_prec[k].p, (uint64_t *)d_off[k].p, (uint8_t *)d_var[k].p, cap, d_work.p, wb);
+            if (rc != FMD_OK) break;
+            if (hipMemcpyAsync(tot + k, (uint64_t *)d_off[k].p + nc, 8, hipMemcpyDeviceToHost, s_cmp.s) != hipSuccess || hipEventRecord(done[k].e, s_cmp.s) != hipSuccess) { fail(FMD_E_HIP); break; }
+        }
+        if (c >= 1) { // copy chunk c - 1 out while chunk c runs
+            const size_t p = c - 1, b = p * CH, np = n - b < CH ? n - b : CH;
+            const int k = (int)(p & 1);
+            if (hipEventSynchronize(done[k].e) != hipSuccess) { fail(FMD_E_HIP); break; }
+            const uint64_t bytes = tot[k];
+            if (bytes > cap) { fail(FMD_E_OVERFLOW); break; }  // cannot happen: cap is the worst case
+            // 2 MiB-aligned, huge pages on request: the walk reads these rows at random
+            const size_t huge = (size_t)2 << 20, asz = ((bytes ? bytes : 1) + huge - 1) / huge * huge;
+            void *buf = nullptr;
+            if (posix_memalign(&buf, bytes >= 16 * huge ? huge : 64, bytes >= 16 * huge ? asz : (bytes ? bytes : 64))) { fail(FMD_E_NOMEM); break; }
+#ifdef MADV_HUGEPAGE
+            if (bytes >= 16 * huge) madvise(buf, asz, MADV_HUGEPAGE);
+#endif
+            chunks[p] = (uint8_t *)buf;
+            if (bytes >= ((size_t)8 << 20) && !getenv("FMD_NO_PIN") && hipHostRegister(buf, bytes, hipHostRegisterDefault) == hipSuccess) registered.push_back(buf);
+            else (void)hipGetLastError();
+            if (hipMemcpyAsync(rec + b, d_prec[k].p, np * sizeof(fmd_ovlp_rec_t), hipMemcpyDeviceToHost, s_cpy.s) != hipSuccess ||
+                hipMemcpyAsync(off + b, d_off[k].p, np * 8, hipMemcpyDeviceToHost, s_cpy.s) != hipSuccess ||
+                (bytes && hipMemcpyAsync(buf, d_var[k].p, bytes, hipMemcpyDeviceToHost, s_cpy.s) != hipSuccess) ||
+                hipEventRecord(copied[k].e, s_cpy.s) != hipSuccess) { fail(FMD_E_HIP); break; }
+        }
+    }
+    hipStreamSynchronize(s_cmp.s);
+    hipStreamSynchronize(s_cpy.s);
+    for (void *q : registered) hipHostUnregister(q);
+    hipHostFree(tot);
+    if (rc == FMD_OK) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { fmd_set_hip_error(e, "packed overlap batch"); rc = FMD_E_HIP; }
+    } else if (rc == FMD_E_HIP) fmd_set_hip_error(hipGetLastError(), "packed overlap batch");
+    if (rc != FMD_OK) fmd_ovlp_packed_free(chunks, n_chunks);
+    return rc;
 }

@@ -27,24 +27,57 @@ extern const uint8_t fmdh_nt6[256];
  * Returns the (possibly reduced) length. */
 uint32_t fmdh_trim_palindrome(const uint8_t *s, uint32_t len);
 
-/* ---- `fermi unitig` on top of the GPU overlap table (unitig.c:227-362, mag.c:149-174) ---- */
+/* ---- `fermi unitig` on top of the GPU overlap table (unitig.c:227-362, mag.c:149-174) ----
+ * The table holds one PACKED row per sequence id (include/fmd_hip.h, fmd_ovlp_pack_dev): the record, its neighbours
+ * and its bases.  It is kept in the shards it was computed in: with N GPUs, id i is row i / N of shard i % N (the
+ * reference's worker interleave, unitig.c:333, 398-399), so nothing is re-interleaved after the GPUs finish. */
 typedef struct {
-    uint64_t n;                  /* rows = sequence ids 0 .. n-1 */
-    uint32_t max_nei, seq_stride;
-    const fmd_ovlp_rec_t *rec;   /* n */
-    const fmd_intv_t *nei;       /* n * max_nei */
-    const uint8_t *seq;          /* n * seq_stride: sequence then appended bases */
-    /* optional: the few rows whose lists did not fit the capacities above, recomputed with roomier ones */
-    const uint32_t *side_of;     /* n entries: index into the side arrays, 0xffffffff = not there; or NULL */
-    uint32_t side_max_nei, side_stride;
-    const fmd_intv_t *side_nei;  /* n_side * side_max_nei */
-    const uint8_t *side_seq;     /* n_side * side_stride */
+    uint64_t n;                  /* rows */
+    fmd_ovlp_rec_t *rec;         /* n packed records */
+    uint64_t *off;               /* n: byte offset of the row's variable part inside chunk[row >> chunk_shift] */
+    uint8_t **chunk;             /* ceil(n / 2^chunk_shift) buffers (fmd_ovlp_packed_free) */
+    uint32_t chunk_shift, max_nei, seq_stride;
+} fmdh_ovlp_shard_t;
+typedef struct {
+    uint64_t n;                  /* sequence ids 0 .. n-1 */
+    int n_shards;
+    fmdh_ovlp_shard_t *shard;    /* n_shards */
+    /* the few rows whose lists did not fit the capacities of the first pass, recomputed with roomier ones */
+    uint32_t *side_of;           /* n entries: row in `side`, 0xffffffff = not there; or NULL */
+    fmdh_ovlp_shard_t side;
 } fmdh_ovlp_table_t;
+typedef struct { const fmd_ovlp_rec_t *rec; const fmd_intv_t *nei; const uint8_t *var; uint32_t max_nei; } fmdh_row_t;
+static inline fmdh_row_t fmdh_table_row(const fmdh_ovlp_table_t *t, uint64_t id)
+{
+    const fmdh_ovlp_shard_t *s;
+    uint64_t r;
+    fmdh_row_t x;
+    if (t->side_of && t->side_of[id] != 0xffffffffu) { s = &t->side; r = t->side_of[id]; }
+    else { s = &t->shard[id % (uint64_t)t->n_shards]; r = id / (uint64_t)t->n_shards; }
+    x.rec = &s->rec[r];
+    x.var = s->chunk[r >> s->chunk_shift] + s->off[r];
+    x.nei = (const fmd_intv_t *)x.var;
+    x.max_nei = s->max_nei;
+    return x;
+}
+/* bases [from, from + n) of a row (the sequence, then the bases fm6_get_nei appended), as nt6 codes */
+static inline void fmdh_row_bases(const fmdh_row_t *x, uint32_t from, uint32_t n, char *dst)
+{
+    uint32_t j;
+    for (j = 0; j < n; ++j) dst[j] = (char)fmd_ovlp_row_base(x->rec, x->max_nei, x->var, from + j);
+}
+/* Build the table of all n_seq sequence ids on the GPUs devices[0..n_dev): one host thread and one replica of the index
+ * per device, shard g = ids g, g + n_dev, ...; rows that overflow the capacities are recomputed (device 0) with the
+ * capacities doubled until they fit.  A device may be listed more than once (two replicas on one GPU). */
+int fmdh_ovlp_table_build(const char *fmd_path, int n_dev, const int *devices, int min_match, fmdh_ovlp_table_t *t, uint64_t *n_seq);
+void fmdh_ovlp_table_free(fmdh_ovlp_table_t *t);
 /* Replays the single-threaded walk and writes the MAG records `fermi unitig -t1` prints. */
 int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, const uint64_t *sorted /* or NULL */, FILE *out);
-/* Whole command: open the .fmd on `device`, build the table on the GPU (capacities grown until no
- * record overflows), walk, print.  `fermi unitig -l min_match <fn>` (cmd.c:184-216). */
-int fmdh_unitig(const char *fmd_path, int device, int min_match, const char *rank_file /* -r, or NULL */, FILE *out);
+/* Whole command: replicate the .fmd on the listed GPUs, build the table, walk, print.  `fermi unitig -l min_match <fn>`
+ * (cmd.c:184-216); the reference's fm6_unitig gives seeds i = j (mod n_threads) to worker j (unitig.c:394-404), here
+ * GPU g computes the rows of ids i = g (mod n_dev) and ONE deterministic walk consumes them (the output is that of -t1
+ * whatever n_dev is). */
+int fmdh_unitig(const char *fmd_path, int n_dev, const int *devices, int min_match, const char *rank_file /* -r, or NULL */, FILE *out);
 /* `fermi seqsort <reads.fmd>` (seqsort.c:37-70): *sorted is malloc'ed, n = mcnt[1] entries */
 int fmdh_seqsort(const char *fmd_path, int device, uint64_t **sorted, uint64_t *n);
 

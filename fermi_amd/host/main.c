@@ -6,28 +6,47 @@
 #include <unistd.h>
 #include "fmd_host.h"
 
+/* "-g 0,1,3": one entry per replica of the index (a GPU may be listed twice) */
+static int parse_gpu_list(const char *s, int *dev, int max)
+{
+    int n = 0;
+    while (*s && n < max) {
+        char *e;
+        long v = strtol(s, &e, 10);
+        if (e == s || v < 0) return -1;
+        dev[n++] = (int)v;
+        s = *e == ',' ? e + 1 : e;
+        if (*e && *e != ',') return -1;
+    }
+    return n;
+}
+
 static int main_unitig(int argc, char *argv[]) /* cmd.c:184-216 */
 {
-    int c, min_match = 30, device = 0;
+    int c, min_match = 30, n_dev = 1, devices[64] = {0};
     const char *rank_file = 0;
     while ((c = getopt(argc, argv, "Ml:t:r:g:")) >= 0) {
         switch (c) {
         case 'l': min_match = atoi(optarg); break;
         case 'M': break;                 /* mmap: meaningless for a device-resident index */
         case 't': break;                 /* threads: the walk is the deterministic -t1 walk */
-        case 'g': device = atoi(optarg); break;
+        case 'g': n_dev = parse_gpu_list(optarg, devices, 64); break;
         case 'r': rank_file = optarg; break;
         }
     }
+    if (n_dev < 1) { fprintf(stderr, "[E::%s] -g takes a comma-separated list of GPU numbers\n", __func__); return 1; }
+    for (c = 0; c < n_dev; ++c)
+        if (devices[c] >= fmd_device_count()) { fprintf(stderr, "[E::%s] GPU %d: this node has %d\n", __func__, devices[c], fmd_device_count()); return 1; }
     if (optind + 1 > argc) {
         fprintf(stderr, "\nUsage:   fermi-amd unitig [options] <reads.fmd>\n\n");
         fprintf(stderr, "Options: -l INT      min match [%d]\n", min_match);
         fprintf(stderr, "         -t INT      number of threads [ignored: output is that of -t1]\n");
         fprintf(stderr, "         -r FILE     rank file [null]\n");
-        fprintf(stderr, "         -g INT      GPU to use [0]\n\n");
+        fprintf(stderr, "         -g LIST     GPUs to use, e.g. 0,1,2,3: the index is replicated on each, GPU g computes the\n");
+        fprintf(stderr, "                     sequences i = g (mod #GPUs) as worker g of `fermi unitig -t` would seed them [0]\n\n");
         return 1;
     }
-    return fmdh_unitig(argv[optind], device, min_match, rank_file, stdout);
+    return fmdh_unitig(argv[optind], n_dev, devices, min_match, rank_file, stdout);
 }
 
 static int main_seqsort(int argc, char *argv[]) /* cmd.c:486-505 */

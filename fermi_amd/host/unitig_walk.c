@@ -16,6 +16,7 @@
  */
 #define _GNU_SOURCE
 #include <errno.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -48,18 +49,85 @@ typedef struct {
     const fmd_intv_t *nei; int n_nei;
 } walk_t;
 
-static inline const fmd_ovlp_rec_t *REC(const walk_t *w, uint64_t row) { return &w->t->rec[row]; }
-static inline const fmd_intv_t *NEI(const walk_t *w, uint64_t row)
+static inline fmdh_row_t ROW(const walk_t *w, uint64_t row) { return fmdh_table_row(w->t, row); }
+
+/* ---- output: records are formatted by the walk and written by a second thread (two buffers handed back and forth) */
+#define OUT_BUF ((size_t)8 << 20)
+typedef struct {
+    FILE *fp;
+    char *buf[2]; size_t len[2];
+    int fill;                    /* buffer the walk appends to */
+    int pending;                 /* buffer waiting to be written, or -1 */
+    int quit, err, threaded;
+    pthread_t tid; pthread_mutex_t mu; pthread_cond_t cv;
+} outq_t;
+static void *outq_main(void *p)
 {
-    const fmdh_ovlp_table_t *t = w->t;
-    if (t->side_of && t->side_of[row] != 0xffffffffu) return t->side_nei + (size_t)t->side_of[row] * t->side_max_nei;
-    return t->nei + row * t->max_nei;
+    outq_t *q = (outq_t *)p;
+    pthread_mutex_lock(&q->mu);
+    for (;;) {
+        while (q->pending < 0 && !q->quit) pthread_cond_wait(&q->cv, &q->mu);
+        if (q->pending < 0) break;
+        {
+            const int k = q->pending;
+            pthread_mutex_unlock(&q->mu);
+            if (fwrite(q->buf[k], 1, q->len[k], q->fp) != q->len[k]) q->err = 1;
+            pthread_mutex_lock(&q->mu);
+            q->len[k] = 0; q->pending = -1;
+            pthread_cond_broadcast(&q->cv);
+        }
+    }
+    pthread_mutex_unlock(&q->mu);
+    return 0;
 }
-static inline const uint8_t *SEQ(const walk_t *w, uint64_t row)
+static int outq_open(outq_t *q, FILE *fp)
 {
-    const fmdh_ovlp_table_t *t = w->t;
-    if (t->side_of && t->side_of[row] != 0xffffffffu) return t->side_seq + (size_t)t->side_of[row] * t->side_stride;
-    return t->seq + row * (size_t)t->seq_stride;
+    memset(q, 0, sizeof(*q));
+    q->fp = fp; q->pending = -1;
+    q->buf[0] = (char *)malloc(OUT_BUF); q->buf[1] = (char *)malloc(OUT_BUF);
+    if (!q->buf[0] || !q->buf[1]) { free(q->buf[0]); free(q->buf[1]); return -ENOMEM; }
+    pthread_mutex_init(&q->mu, 0); pthread_cond_init(&q->cv, 0);
+    q->threaded = pthread_create(&q->tid, 0, outq_main, q) == 0;   /* no thread: the walk writes itself */
+    return 0;
+}
+static void outq_flush(outq_t *q) /* hand the filled buffer over, continue in the other one */
+{
+    const int k = q->fill;
+    if (q->len[k] == 0) return;
+    if (!q->threaded) { if (fwrite(q->buf[k], 1, q->len[k], q->fp) != q->len[k]) q->err = 1; q->len[k] = 0; return; }
+    pthread_mutex_lock(&q->mu);
+    while (q->pending >= 0) pthread_cond_wait(&q->cv, &q->mu);     /* the other buffer is still being written */
+    q->pending = k; q->fill = k ^ 1;
+    pthread_cond_broadcast(&q->cv);
+    pthread_mutex_unlock(&q->mu);
+}
+static int outq_put(outq_t *q, const char *s, size_t l)
+{
+    if (l > OUT_BUF) { /* a record larger than a buffer (a chromosome-long unitig): drain, then write it directly */
+        outq_flush(q);
+        if (q->threaded) { pthread_mutex_lock(&q->mu); while (q->pending >= 0) pthread_cond_wait(&q->cv, &q->mu); pthread_mutex_unlock(&q->mu); }
+        if (fwrite(s, 1, l, q->fp) != l) q->err = 1;
+        return q->err ? -EIO : 0;
+    }
+    if (q->len[q->fill] + l > OUT_BUF) outq_flush(q);
+    memcpy(q->buf[q->fill] + q->len[q->fill], s, l);
+    q->len[q->fill] += l;
+    return q->err ? -EIO : 0;
+}
+static int outq_close(outq_t *q)
+{
+    outq_flush(q);
+    if (q->threaded) {
+        pthread_mutex_lock(&q->mu);
+        while (q->pending >= 0) pthread_cond_wait(&q->cv, &q->mu);
+        q->quit = 1;
+        pthread_cond_broadcast(&q->cv);
+        pthread_mutex_unlock(&q->mu);
+        pthread_join(q->tid, 0);
+    }
+    pthread_mutex_destroy(&q->mu); pthread_cond_destroy(&q->cv);
+    free(q->buf[0]); free(q->buf[1]);
+    return q->err ? -EIO : 0;
 }
 
 static void mark_used(walk_t *w, const uint64_t x[3]) /* set_bits, unitig.c:22-36 (sorted == NULL) */
@@ -72,13 +140,13 @@ static void mark_used(walk_t *w, const uint64_t x[3]) /* set_bits, unitig.c:22-3
 /* check_left (unitig.c:206-225) for the edge row -> its unique neighbour */
 static int check_left(const walk_t *w, uint64_t row)
 {
-    const fmd_ovlp_rec_t *r = REC(w, row);
-    if (r->reserved == 0) return 0;
+    const fmdh_row_t x = ROW(w, row);
+    if (x.rec->reserved == 0) return 0;
     /* the back fork may be due to a contained read: look right from the reverse strand of the
      * neighbour; more than one irreducible overlap there confirms the bifurcation */
-    uint32_t row2 = w->row_of[NEI(w, row)[0].x[1]];
+    uint32_t row2 = w->row_of[x.nei[0].x[1]];
     if (row2 == 0xffffffffu) return -1;
-    return REC(w, row2)->n_nei > 1 ? -1 : 0;
+    return ROW(w, row2).rec->n_nei > 1 ? -1 : 0;
 }
 
 /* unitig_unidir, unitig.c:227-262.  `cur` = table row of the read at the right end of s. */
@@ -87,15 +155,16 @@ static int unidir(walk_t *w, uint64_t cur, str_t *s, str_t *cov, int beg0, uint6
     int beg = beg0, ori_l = (int)s->l, n_reads = 0, i;
     *is_loop = 0;
     for (;;) {
-        const fmd_ovlp_rec_t *r = REC(w, cur);
+        const fmdh_row_t x = ROW(w, cur);
+        const fmd_ovlp_rec_t *r = x.rec;
         int rbeg;
-        w->nei = NEI(w, cur); w->n_nei = r->n_nei;
+        w->nei = x.nei; w->n_nei = r->n_nei;
         if (r->status != 0 || r->rbeg < 0) { w->n_nei = r->status == 0 ? r->n_nei : 0; break; }   /* try_right < 0 */
         rbeg = beg + r->rbeg;
         if (r->n_nei > 1) { bit_set(w->bend, *end); break; }                     /* forward bifurcation */
         {   /* the bases fm6_get_nei appended (unitig.c:139) */
             if (str_reserve(s, (size_t)ori_l + r->ext_len + 1)) return -1;
-            memcpy(s->s + ori_l, SEQ(w, cur) + r->len, (size_t)r->ext_len);
+            fmdh_row_bases(&x, (uint32_t)r->len, (uint32_t)r->ext_len, s->s + ori_l);
             s->l = (size_t)ori_l + r->ext_len;
         }
         uint64_t k = w->nei[0].x[0];
@@ -160,18 +229,25 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
     w.t = t; w.n_seq = n_seq; w.min_match = min_match; w.sorted = sorted;
     w.used = (uint64_t *)calloc(nw, 8); w.bend = (uint64_t *)calloc(nw, 8); w.visited = (uint64_t *)calloc(nw, 8);
     w.row_of = (uint32_t *)fmdh_big_alloc(n_seq * 4);
-    const uint32_t cap_nei = t->side_of && t->side_max_nei > t->max_nei ? t->side_max_nei : t->max_nei;
+    uint32_t cap_nei = t->side_of ? t->side.max_nei : 1;
+    outq_t oq;
+    int oq_open = 0, g;
+    for (g = 0; g < t->n_shards; ++g) if (t->shard[g].max_nei > cap_nei) cap_nei = t->shard[g].max_nei;
     nei[0] = (link_t *)malloc(cap_nei * sizeof(link_t)); nei[1] = (link_t *)malloc((cap_nei + 1) * sizeof(link_t));
     if (!w.used || !w.bend || !w.visited || !w.row_of || !nei[0] || !nei[1]) { rc = -ENOMEM; goto done; }
     memset(w.row_of, 0xff, n_seq * 4);
+    if (n_seq >= 0xffffffffull || t->n >= 0xffffffffull) { rc = -ERANGE; goto done; }   /* row_of holds 32-bit ids */
+    if ((rc = outq_open(&oq, out)) != 0) goto done;
+    oq_open = 1;
     for (i = t->n; i-- > 0;) { /* smallest id wins */
-        const fmd_ovlp_rec_t *r = &t->rec[i];
+        const fmd_ovlp_rec_t *r = fmdh_table_row(t, i).rec;
         if (r->status == 0 && !(r->flags & FMD_OVLP_F_OVERFLOW) && r->k[0] < n_seq) w.row_of[r->k[0]] = (uint32_t)i;
     }
     /* unitig_core with start = 0, step = 1 (unitig.c:333-334): seeds are the odd sequence ids */
     for (j = 0; j <= n_seq >> 2; ++j) {
         for (i = j << 2 | 1; i < (j << 2) + 4 && i < n_seq; i += 2) {
-            const fmd_ovlp_rec_t *r = &t->rec[i];
+            const fmdh_row_t seed = fmdh_table_row(t, i);
+            const fmd_ovlp_rec_t *r = seed.rec;
             uint64_t end[2];
             int n_nei[2] = {0, 0}, n_reads, is_loop = 0, seed_len, k, done_loop = 0;
             /* ---- unitig1 (unitig.c:274-317) */
@@ -183,7 +259,7 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
             if (r->status != 0) continue;                            /* contained */
             seed_len = r->len;
             if (str_reserve(&s, (size_t)seed_len + 1) || str_reserve(&cov, (size_t)seed_len + 1)) { rc = -ENOMEM; goto done; }
-            memcpy(s.s, SEQ(&w, i), (size_t)seed_len); s.l = (size_t)seed_len;
+            fmdh_row_bases(&seed, 0, (uint32_t)seed_len, s.s); s.l = (size_t)seed_len;
             memset(cov.s, '"', (size_t)seed_len); cov.l = (size_t)seed_len;
             n_reads = 1;
             end[0] = r->k[1]; end[1] = r->k[0];
@@ -223,11 +299,12 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
             {   /* the reference prints the record with fputs (unitig.c:354): a base that is not A/C/G/T
                  * becomes "ACGT"[4] = NUL (mag.c:168) and cuts the record there.  Reproduced as is. */
                 size_t wl = strnlen(o.s, o.l);
-                if (fwrite(o.s, 1, wl, out) != wl) { rc = -EIO; goto done; }
+                if ((rc = outq_put(&oq, o.s, wl)) != 0) goto done;
             }
         }
     }
 done:
+    if (oq_open) { const int e = outq_close(&oq); if (!rc) rc = e; }
     free(w.used); free(w.bend); free(w.visited); free(w.row_of); free(nei[0]); free(nei[1]);
     free(s.s); free(cov.s); free(o.s);
     return rc;

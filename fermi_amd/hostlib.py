@@ -20,14 +20,15 @@ def lib():
         L.fmdh_write_rld_from_bwt.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p]
         L.fmdh_trim_palindrome.restype = C.c_uint32
         L.fmdh_trim_palindrome.argtypes = [C.c_void_p, C.c_uint32]
+        class Shard(C.Structure):
+            _fields_ = [("n", C.c_uint64), ("rec", C.c_void_p), ("off", C.c_void_p), ("chunk", C.POINTER(C.c_void_p)),
+                        ("chunk_shift", C.c_uint32), ("max_nei", C.c_uint32), ("seq_stride", C.c_uint32)]
         class Table(C.Structure):
-            _fields_ = [("n", C.c_uint64), ("max_nei", C.c_uint32), ("seq_stride", C.c_uint32),
-                        ("rec", C.c_void_p), ("nei", C.c_void_p), ("seq", C.c_void_p),
-                        ("side_of", C.c_void_p), ("side_max_nei", C.c_uint32), ("side_stride", C.c_uint32),
-                        ("side_nei", C.c_void_p), ("side_seq", C.c_void_p)]
+            _fields_ = [("n", C.c_uint64), ("n_shards", C.c_int), ("shard", C.POINTER(Shard)), ("side_of", C.c_void_p), ("side", Shard)]
+        L.Shard = Shard
         L.Table = Table
         L.fmdh_unitig_walk.argtypes = [C.POINTER(Table), C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
-        L.fmdh_unitig.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_void_p]
+        L.fmdh_unitig.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_void_p]
         class EcOpt(C.Structure):
             _fields_ = [("w", C.c_int), ("min_occ", C.c_int), ("keep_bad", C.c_int), ("is_paired", C.c_int), ("trim_l", C.c_int),
                         ("step", C.c_int), ("max_corr", C.c_float)]
@@ -81,11 +82,22 @@ _libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
 _libc.fclose.argtypes = [C.c_void_p]
 
 
-def unitig_walk(rec, nei, seq, n_seq, min_match, out_path, sorted_map=None):
-    """Replay the `fermi unitig -t1` walk over a per-id overlap table; writes MAG records to out_path."""
+def unitig_walk(shards, n_seq, min_match, out_path, sorted_map=None, max_nei=4, seq_stride=256):
+    """Replay the `fermi unitig -t1` walk over a packed per-id overlap table kept in len(shards) shards -- id i = row
+    i // N of shard i % N; each shard = (prec[OVLP_DT], off[u64, n+1], var[u8]) as fmd_ovlp_pack_dev writes them.
+    Writes MAG records to out_path."""
     L = lib()
-    rec = np.ascontiguousarray(rec); nei = np.ascontiguousarray(nei); seq = np.ascontiguousarray(seq)
-    t = L.Table(len(rec), nei.shape[1], seq.shape[1], rec.ctypes.data, nei.ctypes.data, seq.ctypes.data, None, 0, 0, None, None)
+    keep = []
+    arr = (L.Shard * len(shards))()
+    n_total = 0
+    for k, (prec, off, var) in enumerate(shards):
+        prec = np.ascontiguousarray(prec); off = np.ascontiguousarray(off, dtype=np.uint64)
+        var = np.ascontiguousarray(var, dtype=np.uint8) if len(var) else np.zeros(8, np.uint8)
+        chunk = (C.c_void_p * 1)(var.ctypes.data)
+        keep += [prec, off, var, chunk]
+        arr[k] = L.Shard(len(prec), prec.ctypes.data, off.ctypes.data, chunk, 40, max_nei, seq_stride)   # one chunk: shift beyond any row count
+        n_total += len(prec)
+    t = L.Table(n_total, len(shards), arr, None, L.Shard())
     fp = _libc.fopen(out_path.encode(), b"wb")
     try:
         sm = None if sorted_map is None else np.ascontiguousarray(sorted_map, dtype=np.uint64)
@@ -94,12 +106,13 @@ def unitig_walk(rec, nei, seq, n_seq, min_match, out_path, sorted_map=None):
         _libc.fclose(fp)
 
 
-def unitig(fmd_path, min_match, out_path, device=0):
-    """`fermi-amd unitig -l min_match fmd_path > out_path` (GPU)."""
+def unitig(fmd_path, min_match, out_path, devices=(0,)):
+    """`fermi-amd unitig -l min_match -g d0,d1,.. fmd_path > out_path` (GPU)."""
     L = lib()
+    dev = (C.c_int * len(devices))(*devices)
     fp = _libc.fopen(out_path.encode(), b"wb")
     try:
-        rc = L.fmdh_unitig(fmd_path.encode(), device, min_match, None, fp)
+        rc = L.fmdh_unitig(fmd_path.encode(), len(devices), dev, min_match, None, fp)
     finally:
         _libc.fclose(fp)
     if rc:

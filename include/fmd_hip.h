@@ -210,6 +210,37 @@ int fmd_ovlp_pack_dev(fmd_dev_t *h, void *stream, size_t n, const fmd_ovlp_rec_t
                       const uint8_t *d_seq, uint32_t seq_stride, fmd_ovlp_rec_t *d_prec, uint64_t *d_off, uint8_t *d_var, uint64_t var_cap,
                       void *d_work, size_t work_bytes);
 
+/* Host form, pipelined: the packed table of one shard of sequence ids -- ids[0..n) when ids != NULL, else
+ * first, first + step, ... (the reference's worker interleave, unitig.c:333, 398-399).  Chunks of 2^chunk_shift rows
+ * are computed (fmd_ovlp_dev, fmd_ovlp_check_left_dev when asked, fmd_ovlp_pack_dev) while the previous chunk crosses
+ * PCIe.  rec[n], off[n] (byte offset of row i inside chunks[i >> chunk_shift]); chunks[] receives
+ * ceil(n / 2^chunk_shift) buffers the caller releases with fmd_ovlp_packed_free().  The end of row i's variable part
+ * follows from its record (fmd_ovlp_row_bytes). */
+int fmd_ovlp_packed_batch(fmd_dev_t *h, const uint64_t *ids, uint64_t first, uint64_t step, size_t n, int min_match, uint32_t max_len,
+                          uint32_t max_nei, int with_check_left, fmd_ovlp_rec_t *rec, uint64_t *off, uint32_t chunk_shift, uint8_t **chunks);
+void fmd_ovlp_packed_free(uint8_t **chunks, size_t n_chunks);
+/* layout of a packed row's variable part, from its (packed) record */
+static inline uint32_t fmd_ovlp_row_nei(const fmd_ovlp_rec_t *r, uint32_t max_nei)
+{
+    if (r->status != 0 || (r->flags & FMD_OVLP_F_OVERFLOW)) return 0;
+    return (uint32_t)r->n_nei < max_nei ? (uint32_t)r->n_nei : max_nei;
+}
+static inline uint32_t fmd_ovlp_row_bytes(const fmd_ovlp_rec_t *r, uint32_t max_nei, uint32_t seq_stride)
+{
+    uint32_t nb, sb;
+    if (r->status != 0 || (r->flags & FMD_OVLP_F_OVERFLOW)) return 0;
+    nb = (uint32_t)r->len + (uint32_t)r->ext_len;
+    if (nb > seq_stride) nb = seq_stride;
+    sb = (r->flags & FMD_OVLP_F_PACK4) ? (nb + 1) / 2 : (nb + 3) / 4;
+    return fmd_ovlp_row_nei(r, max_nei) * 32 + ((sb + 7) & ~7u);
+}
+/* base j of a packed row (nt6 code) */
+static inline int fmd_ovlp_row_base(const fmd_ovlp_rec_t *r, uint32_t max_nei, const uint8_t *var, uint32_t j)
+{
+    const uint8_t *s = var + fmd_ovlp_row_nei(r, max_nei) * 32;
+    return (r->flags & FMD_OVLP_F_PACK4) ? (s[j >> 1] >> (4 * (j & 1))) & 15 : ((s[j >> 2] >> (2 * (j & 3))) & 3) + 1;
+}
+
 /* ---- k-mer harvest of `fermi correct`: fm6_traverse (exact.c:141) + ec_collect (correct.c:35-87)
  * over ALL 4^suf_len suffix buckets (what worker1 does, correct.c:272-279).  Emits one
  * (bucket, key, val) triple per solid k-mer: bucket = index into `solid[]` (correct.c:346-349),

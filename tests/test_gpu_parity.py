@@ -305,6 +305,55 @@ def test_unitig_cli_equals_fermi_unitig_t1(gpu, gold, tmp_path, name, mm):
         assert got == gold.text_gz(name + ".mag.gz")
 
 
+@pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20), ("special", 20)])
+@pytest.mark.parametrize("n_rep", [2, 3])
+def test_unitig_sharded_over_replicas_equals_one_gpu(gpu, gold, tmp_path, name, mm, n_rep):
+    """`fermi-amd unitig -g a,b[,c]`: the index replicated n_rep times, replica g computing the rows of the ids
+    i = g (mod n_rep) on its own host thread (unitig.c:333, 398-399), one walk over the shards: the MAG must be the
+    single-GPU one, i.e. `fermi unitig -t1`'s.  Distinct GPUs when the box has them, else replicas on GPU 0."""
+    import subprocess, os
+    from fermi_amd import hostlib
+    n_gpu = gpu.device_count()
+    devs = tuple(g % n_gpu for g in range(n_rep))
+    out = str(tmp_path / "o.mag")
+    hostlib.unitig(gold.path(name + ".fmd"), mm, out, devices=devs)
+    assert open(out, "rb").read() == gold.text_gz(name + ".mag.gz")
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fermi_amd", "bin", "fermi-amd")
+    if os.path.exists(exe):
+        got = subprocess.run([exe, "unitig", "-l%d" % mm, "-g", ",".join(map(str, devs)), gold.path(name + ".fmd")], stdout=subprocess.PIPE, check=True).stdout
+        assert got == gold.text_gz(name + ".mag.gz")
+
+
+def test_packed_batch_equals_fixed_stride_batch(gpu, gold):
+    """fmd_ovlp_packed_batch (pipelined chunks, ids by first/step or explicit) == pack(fmd_ovlp_batch) row for row."""
+    import ctypes as C
+    import packref
+    d = gpu.DevIndex.open(gold.path("tiny.fmd"))
+    L = gpu.lib()
+    n_seq = int(d.mcnt[1])
+    for first, step, shift in ((0, 1, 10), (1, 3, 11), (2, 3, 20)):
+        ids = np.arange(first, n_seq, step, dtype=U64)
+        n = len(ids)
+        rec, nei, seq = d.overlap(ids, 50, max_len=128, max_nei=4)
+        wp, wo, wv = packref.pack_rows(rec, nei, seq, 4)
+        for explicit in (False, True):
+            prec = np.zeros(n, dtype=gpu.OVLP_DT); off = np.zeros(n, dtype=U64)
+            nc = (n + (1 << shift) - 1) >> shift
+            chunks = (C.c_void_p * nc)()
+            gpu.check(L.fmd_ovlp_packed_batch(d.h, ids.ctypes.data if explicit else None, first, step, n, 50, 128, 4, 1,
+                                              prec.ctypes.data, off.ctypes.data, shift, chunks))
+            assert prec.tobytes() == wp.tobytes()
+            for i in (list(range(0, n, 97)) + [n - 1]):
+                c = i >> shift
+                ln = int(wo[i + 1] - wo[i])
+                got = C.string_at(chunks[c] + int(off[i]), ln) if ln else b""
+                assert got == wv[int(wo[i]):int(wo[i + 1])].tobytes()
+                # offsets restart in every chunk
+                assert int(off[i]) == int(wo[i] - wo[c << shift])
+            L.fmd_ovlp_packed_free(chunks, nc)
+    d.close()
+
+
 def test_check_left_flags_vs_oracle(gpu, gold, oracle_lib):
     for name, mm, ml in (("tiny", 50, 100), ("repeat", 20, 80), ("special", 20, 60)):
         d = gpu.DevIndex.open(gold.path(name + ".fmd")); o = orcbind.OrcIndex(gold.path(name + ".fmd"))

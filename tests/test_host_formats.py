@@ -45,16 +45,23 @@ def test_trim_palindrome():
     assert f("ANNT") == 4
 
 
+def _packed_shards(rec, nei, seq, n_shards):
+    """The oracle's fixed-stride table as the packed shards the GPUs produce: id i = row i // N of shard i % N."""
+    import packref
+    return [packref.pack_rows(rec[g::n_shards], nei[g::n_shards], seq[g::n_shards], nei.shape[1]) for g in range(n_shards)]
+
+
 @pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20), ("special", 20)])
-def test_unitig_walk_reproduces_fermi_unitig_t1(oracle_lib, gold, tmp_path, name, mm):
-    """Host walk (fermi_amd/host/unitig_walk.c) over the per-read table == `fermi unitig -t1`
-    output, byte for byte.  The table here comes from the oracle (CPU); the GPU test feeds the
-    same walk from fmd_ovlp_*."""
+@pytest.mark.parametrize("n_shards", [1, 2, 3])
+def test_unitig_walk_reproduces_fermi_unitig_t1(oracle_lib, gold, tmp_path, name, mm, n_shards):
+    """Host walk (fermi_amd/host/unitig_walk.c) over the packed per-read table == `fermi unitig -t1` output, byte for
+    byte, however many shards (GPUs) the table was computed in.  The table here comes from the oracle (CPU); the GPU
+    tests feed the same walk from fmd_ovlp_packed_batch."""
     o = orcbind.OrcIndex(gold.path(name + ".fmd"))
     n_seq = int(o.mcnt[1])
     rec, nei, seq = o.overlap_batch(np.arange(n_seq, dtype=np.uint64), mm, max_len=100, max_nei=8, n_threads=4)
     out = str(tmp_path / "o.mag")
-    hostlib.unitig_walk(rec, nei, seq, n_seq, mm, out)
+    hostlib.unitig_walk(_packed_shards(rec, nei, seq, n_shards), n_seq, mm, out, max_nei=8, seq_stride=seq.shape[1])
     got = open(out, "rb").read()
     want = gold.text_gz(name + ".mag.gz")
     assert got == want
@@ -86,7 +93,7 @@ def test_unitig_walk_with_rank_file(oracle_lib, gold, tmp_path, name, mm):
     sm = np.fromfile(gold.path(name + ".rank"), dtype=np.uint64)
     assert len(sm) == n_seq
     out = str(tmp_path / "o.mag")
-    hostlib.unitig_walk(rec, nei, seq, n_seq, mm, out, sorted_map=sm)
+    hostlib.unitig_walk(_packed_shards(rec, nei, seq, 2), n_seq, mm, out, sorted_map=sm, max_nei=8, seq_stride=seq.shape[1])
     assert open(out, "rb").read() == gold.text_gz(name + ".r.mag.gz")
     o.close()
 
