@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("FMD_HIP_LIB") or os.path.join(_HERE, "lib", "libfmdhi
 INTV_DT = np.dtype([("x", "<u8", 3), ("info", "<u8")])  # fmd_intv_t == fmintv_t (fermi.h:13-16)
 NONE64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 OVLP_DT = np.dtype([("rank", "<u8"), ("k", "<u8", 3), ("len", "<i4"), ("status", "<i4"), ("n_ovlp", "<i4"),
-                    ("rbeg", "<i4"), ("ext_len", "<i4"), ("n_nei", "<i4"), ("flags", "<u4"), ("reserved", "<u4")])
+                    ("rbeg", "<i4"), ("ext_len", "<i4"), ("n_nei", "<i4"), ("flags", "<u4"), ("reserved", "<u2"), ("lfork", "<u2")])
 OVLP_F_FORKED, OVLP_F_OVERFLOW, OVLP_F_FIXED = 1, 2, 4
 
 # every symbol include/fmd_hip.h declares (tests check the library exports all of them)

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64) void k_ovl_retrieve(FmdIndexView ix, size_t n, 
                 if ((len & 3) && len < stride_r) *(uint32_t *)(srev + sid * (size_t)stride_r + (len & ~3u)) = pack;
                 fmd_ovlp_rec_t *o = rec + sid;
                 o->rank = k; o->k[0] = o->k[1] = o->k[2] = 0;
-                o->len = (int32_t)len; o->status = 0; o->n_ovlp = 0; o->rbeg = -1; o->ext_len = 0; o->n_nei = 0; o->flags = 0; o->reserved = 2;
+                o->len = (int32_t)len; o->status = 0; o->n_ovlp = 0; o->rbeg = -1; o->ext_len = 0; o->n_nei = 0; o->flags = 0; o->reserved = 2; o->lfork = 0;
                 live = false;
             } else {
                 pack |= (uint32_t)c << (8 * (len & 3));
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             if (c == 0) {
                 fmd_ovlp_rec_t *o = rec + sid;
                 o->rank = k; o->k[0] = o->k[1] = o->k[2] = 0; o->len = 0; o->status = -1; o->n_ovlp = 0; o->rbeg = -1;
-                o->ext_len = 0; o->n_nei = 0; o->flags = 0; o->reserved = 2;
+                o->ext_len = 0; o->n_nei = 0; o->flags = 0; o->reserved = 2; o->lfork = 0;
                 st = WK_IDLE;
                 continue;
             }
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
                     *(uint4 *)(srev + sid * (size_t)stride_r + (depth & ~15u)) = make_uint4(wq == 0 ? pack : pk0, wq == 1 ? pack : pk1, wq == 2 ? pack : pk2, wq == 3 ? pack : 0u);
                 }
                 fmd_ovlp_rec_t *o = rec + sid;
-                o->rank = k; o->len = (int32_t)depth; o->rbeg = -1; o->ext_len = 0; o->n_nei = 0; o->reserved = 2;
+                o->rank = k; o->len = (int32_t)depth; o->rbeg = -1; o->ext_len = 0; o->n_nei = 0; o->reserved = 2; o->lfork = 0;
                 o->k[0] = o->k[1] = o->k[2] = 0; o->n_ovlp = 0;
                 if (depth > stride_r) { o->status = 0; o->flags = FMD_OVLP_F_OVERFLOW; st = WK_IDLE; continue; } // longer than max_len
                 if (!info_only && (int)depth <= min_match) { o->status = -1; o->flags = 0; st = WK_IDLE; continue; } // too short (unitig.c:288)

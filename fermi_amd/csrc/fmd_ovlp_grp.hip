@@ -86,7 +86,7 @@ __global__ __launch_bounds__(CLS_THREADS) void k_ovl_classify(size_t n, const fm
 
 // ------------------------------------------------------------------------------ the kernel
 template <int G>
-__global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
+__global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
                                                     uint32_t cap, const fmd_intv_t *__restrict__ listA, fmd_ovlp_rec_t *__restrict__ rec,
                                                     fmd_intv_t *__restrict__ nei_out, uint32_t max_nei, uint8_t *__restrict__ seq_out,
                                                     uint32_t seq_stride, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_n)
@@ -104,6 +104,10 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
     // group-uniform strand state (identical in all lanes of the group)
     bool active = false;
     uint32_t sid = 0, n_nei = 0, flags = 0;
+    // bits 8..24 of `flags` hold lfork (FMD_LFORK_* of include/fmd_hip.h) while the strand is resident; bit 24 = closed
+#define LF_SHIFT 8
+#define LF_GET(f) (((f) >> LF_SHIFT) & 0x1ffffu)
+#define LF_SET(f, v) ((f) = ((f) & ~(0x1ffffu << LF_SHIFT)) | ((uint32_t)(v) << LF_SHIFT))
     int ori_l = 0, round = 0;
     uint64_t nei0_info = 0;
     // the lane's candidate
@@ -201,6 +205,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
         uint32_t s[6] = {0, 0, 0, 0, 0, 0};   // child sizes (<= 63)
         bool is_nei = false;
         uint32_t cm = 0;                    // children c = 1..4 that survive the sentinel test
+        uint32_t dm = 0;                    // the same before any masking, N included (check_left's view, lfork)
         if (live) {
             const uint32_t sz32 = (uint32_t)sz;
             const uint64_t m = (1ull << sz32) - 1;
@@ -217,11 +222,20 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
             if (s[3] && (D & (B3 - B2))) cm |= 1u << 3;
             if (s[2] && (D & (B4 - B3))) cm |= 1u << 2;
             if (s[1] && (D & (B5 - B4))) cm |= 1u << 1;
+            dm = cm | ((s[5] && (D & ((B5 << s[5]) - B5))) ? 1u << 5 : 0u); // reads that start here and go on with A/C/G/T or N
         }
 
         // ---- the reference's sequential loop over the list, as prefix logic on group ballots
         const uint32_t alive_g = (uint32_t)(__ballot(live) >> gbase) & GM;
         const int ncur = __popc(alive_g);
+        if (active && !(LF_GET(flags) & 0x10000u)) { // check_left's rounds (include/fmd_hip.h, FMD_LFORK_*): which bases do the reads that start inside X go on with?
+            uint32_t u = 0;
+#pragma unroll
+            for (int c = 1; c <= 5; ++c) if ((uint32_t)(__ballot((dm >> c) & 1) >> gbase) & GM) u |= 1u << c;
+            if (__popc(u) >= 2) LF_SET(flags, LF_GET(flags) | 0x18000u);             // two bases in round `round`: D, closed
+            else if (u == 0) LF_SET(flags, FMD_LFORK_ALL | 0x10000u);                 // every one of them ended
+            else LF_SET(flags, (uint32_t)(round + 1) | ((u & 32u) ? 0x10000u : 0u));  // consistent; an N child is not followed any further
+        }
         const uint32_t nei_g = (uint32_t)(__ballot(is_nei) >> gbase) & GM;
         const uint32_t head_g = (uint32_t)(__ballot(live && cat == j) >> gbase) & GM;   // first lane of each category
         const uint32_t in_cat_upto_j = (uint32_t)(bits_below(j + 1) & ~bits_below(cat));
@@ -306,6 +320,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
                     sz = (uint64_t)b.y << 32 | b.x; pos = b.z; cat = (int)b.w;
                 }
             } else { // every path is closed (unitig.c:154-178)
+                if (j == 0) rec[sid].lfork = (uint16_t)(LF_GET(flags) & 0xffffu);  // valid whatever happens to the record below
                 if (n_nei == 1 && (flags & FMD_OVLP_F_FORKED)) { // fake fork: the fix-up needs the slow kernel
                     if (j == 0) { const uint32_t k = atomicAdd(slow_n, 1u); slow_list[k] = sid; }
                 } else if (j == 0) {
@@ -313,7 +328,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei_grp(FmdIndexView ix, const uint3
                     o->rbeg = n_nei ? ori_l - (int)(uint32_t)nei0_info : -1;
                     o->ext_len = n_nei > 1 ? 0 : round;
                     o->n_nei = (int32_t)n_nei;
-                    o->flags |= flags;
+                    o->flags |= flags & 0xffu;
                 }
                 active = false; alive = false;
             }

@@ -11,6 +11,7 @@
 // ~125 bytes per strand on 100-bp reads.  The same rows travel over PCIe to the host walk (fmdh_ovlp_table_build)
 // and over xGMI to rank 0 in the multi-process form (the one RCCL exchange of the pipeline).
 #include <stdlib.h>
+#include <time.h>
 #include <sys/mman.h>
 #include <vector>
 #include <hipcub/hipcub.hpp>
@@ -167,6 +168,10 @@ extern "C" int fmd_ovlp_packed_batch(fmd_dev_t *h, const uint64_t *ids, uint64_t
     if (!h || (n && (!rec || !off || !chunks)) || chunk_shift < 10 || chunk_shift > 26 || max_len == 0 || max_nei == 0) return FMD_E_ARG;
     if (n == 0) return FMD_OK;
     FMD_HIP_TRY(hipSetDevice(h->device));
+    const bool timing = getenv("FMD_TIMING") != nullptr;
+    auto now = [] { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; };
+    const double t_begin = now();
+    double t_alloc = 0, t_wait = 0, t_host = 0;
     const size_t CH = (size_t)1 << chunk_shift, m = n < CH ? n : CH, n_chunks = (n + CH - 1) / CH;
     const uint32_t stride = 2 * ((max_len + 3) / 4 * 4);
     const size_t wb0 = fmd_ovlp_work_bytes(m, max_len, min_match), wb1 = fmd_ovlp_pack_work_bytes(m), wb = wb0 > wb1 ? wb0 : wb1;
@@ -185,6 +190,7 @@ extern "C" int fmd_ovlp_packed_batch(fmd_dev_t *h, const uint64_t *ids, uint64_t
     pin_off.pin(off, n * 8);
     uint64_t *tot = nullptr;            // pinned landing place of the two chunk totals
     FMD_HIP_TRY(hipHostMalloc((void **)&tot, 2 * sizeof(uint64_t), hipHostMallocDefault));
+    t_alloc = now() - t_begin;
     int rc = FMD_OK;
     std::vector<void *> registered;
     auto fail = [&](int code) { rc = code; };
@@ -209,7 +215,9 @@ extern "C" int fmd_ovlp_packed_batch(fmd_dev_t *h, const uint64_t *ids, uint64_t
         if (c >= 1) { // copy chunk c - 1 out while chunk c runs
             const size_t p = c - 1, b = p * CH, np = n - b < CH ? n - b : CH;
             const int k = (int)(p & 1);
+            double t0 = now();
             if (hipEventSynchronize(done[k].e) != hipSuccess) { fail(FMD_E_HIP); break; }
+            t_wait += now() - t0; t0 = now();
             const uint64_t bytes = tot[k];
             if (bytes > cap) { fail(FMD_E_OVERFLOW); break; }  // cannot happen: cap is the worst case
             // 2 MiB-aligned, huge pages on request: the walk reads these rows at random
@@ -226,10 +234,14 @@ extern "C" int fmd_ovlp_packed_batch(fmd_dev_t *h, const uint64_t *ids, uint64_t
                 hipMemcpyAsync(off + b, d_off[k].p, np * 8, hipMemcpyDeviceToHost, s_cpy.s) != hipSuccess ||
                 (bytes && hipMemcpyAsync(buf, d_var[k].p, bytes, hipMemcpyDeviceToHost, s_cpy.s) != hipSuccess) ||
                 hipEventRecord(copied[k].e, s_cpy.s) != hipSuccess) { fail(FMD_E_HIP); break; }
+            t_host += now() - t0;
         }
     }
     hipStreamSynchronize(s_cmp.s);
+    const double t_tail0 = now();
     hipStreamSynchronize(s_cpy.s);
+    if (timing) fprintf(stderr, "[M::%s] %zu rows in %zu chunks: device buffers + pinning %.3f s, waiting for kernels %.3f s, host allocation + copy issue %.3f s, last copy %.3f s, total %.3f s\n",
+                        __func__, n, n_chunks, t_alloc, t_wait, t_host, now() - t_tail0, now() - t_begin);
     for (void *q : registered) hipHostUnregister(q);
     hipHostFree(tot);
     if (rc == FMD_OK) {

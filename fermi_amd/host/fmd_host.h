@@ -45,7 +45,13 @@ typedef struct {
     /* the few rows whose lists did not fit the capacities of the first pass, recomputed with roomier ones */
     uint32_t *side_of;           /* n entries: row in `side`, 0xffffffff = not there; or NULL */
     fmdh_ovlp_shard_t side;
+    /* optional, filled by fmdh_ovlp_table_link(): */
+    uint32_t *row_of;            /* n entries: `$read$` interval start k[0] -> smallest id with that interval, 0xffffffff = none */
+    struct fmdh_link *link;      /* n entries */
 } fmdh_ovlp_table_t;
+/* what the walk needs to step from a row to the next without touching the neighbour list: rows of the unique
+ * neighbour and of its reverse strand (0xffffffff: none / more than one neighbour) */
+typedef struct fmdh_link { uint32_t nxt, rev; } fmdh_link_t;
 typedef struct { const fmd_ovlp_rec_t *rec; const fmd_intv_t *nei; const uint8_t *var; uint32_t max_nei; } fmdh_row_t;
 static inline fmdh_row_t fmdh_table_row(const fmdh_ovlp_table_t *t, uint64_t id)
 {
@@ -69,6 +75,11 @@ static inline void fmdh_row_bases(const fmdh_row_t *x, uint32_t from, uint32_t n
 /* Build the table of all n_seq sequence ids on the GPUs devices[0..n_dev): one host thread and one replica of the index
  * per device, shard g = ids g, g + n_dev, ...; rows that overflow the capacities are recomputed (device 0) with the
  * capacities doubled until they fit.  A device may be listed more than once (two replicas on one GPU). */
+/* One parallel pass over a complete table (n_threads host threads): row_of, link, and check_left_simple's verdict
+ * (unitig.c:186-204) for every row with a unique neighbour, decided from the lfork of the neighbour's reverse strand
+ * (include/fmd_hip.h) and written to rec.reserved (0 / 1).  Rows it cannot decide are returned in *undecided
+ * (malloc'ed ids, *n_undecided of them; rec.reserved stays 2): the caller runs fmd_ovlp_check_left on those. */
+int fmdh_ovlp_table_link(fmdh_ovlp_table_t *t, int n_threads, uint64_t **undecided, uint64_t *n_undecided);
 int fmdh_ovlp_table_build(const char *fmd_path, int n_dev, const int *devices, int min_match, fmdh_ovlp_table_t *t, uint64_t *n_seq);
 void fmdh_ovlp_table_free(fmdh_ovlp_table_t *t);
 /* Replays the single-threaded walk and writes the MAG records `fermi unitig -t1` prints. */

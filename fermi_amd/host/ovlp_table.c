@@ -31,7 +31,7 @@ static void shard_free(fmdh_ovlp_shard_t *s)
 
 /* rows of the ids  ids[0..n)  or  first, first + step, ...  with capacities (max_len, max_nei) */
 static int shard_fill(fmd_dev_t *d, fmdh_ovlp_shard_t *s, const uint64_t *ids, uint64_t first, uint64_t step, uint64_t n, int min_match,
-                      uint32_t max_len, uint32_t max_nei)
+                      uint32_t max_len, uint32_t max_nei, int with_cl)
 {
     const size_t nc = (size_t)((n + ((uint64_t)1 << TABLE_CHUNK_SHIFT) - 1) >> TABLE_CHUNK_SHIFT);
     memset(s, 0, sizeof(*s));
@@ -41,12 +41,110 @@ static int shard_fill(fmd_dev_t *d, fmdh_ovlp_shard_t *s, const uint64_t *ids, u
     s->chunk = (uint8_t **)calloc(nc ? nc : 1, sizeof(uint8_t *));
     if (!s->rec || !s->off || !s->chunk) { shard_free(s); return FMD_E_NOMEM; }
     {
-        const int rc = fmd_ovlp_packed_batch(d, ids, first, step, n, min_match, max_len, max_nei, /*check_left*/1, s->rec, s->off, s->chunk_shift, s->chunk);
+        const int rc = fmd_ovlp_packed_batch(d, ids, first, step, n, min_match, max_len, max_nei, with_cl, s->rec, s->off, s->chunk_shift, s->chunk);
         if (rc) { shard_free(s); return rc; }
     }
     return FMD_OK;
 }
 
+/* ------------------------------------------------------------------------------------------------ link pass */
+typedef struct {
+    fmdh_ovlp_table_t *t; uint64_t lo, hi; int phase;
+    uint64_t *und; uint64_t n_und, m_und; int rc;
+} lk_t;
+static inline fmd_ovlp_rec_t *row_rec_mut(fmdh_ovlp_table_t *t, uint64_t id)
+{
+    if (t->side_of && t->side_of[id] != 0xffffffffu) return &t->side.rec[t->side_of[id]];
+    return &t->shard[id % (uint64_t)t->n_shards].rec[id / (uint64_t)t->n_shards];
+}
+static void *lk_main(void *p)
+{
+    lk_t *w = (lk_t *)p;
+    fmdh_ovlp_table_t *t = w->t;
+    uint64_t i;
+    if (w->phase == 0) { /* row_of: the smallest id wins (identical reads share one interval) */
+        for (i = w->lo; i < w->hi; ++i) {
+            const fmd_ovlp_rec_t *r = row_rec_mut(t, i);
+            if (r->status == 0 && !(r->flags & FMD_OVLP_F_OVERFLOW) && r->k[0] < t->n) {
+                uint32_t *slot = &t->row_of[r->k[0]], cur = __atomic_load_n(slot, __ATOMIC_RELAXED);
+                while ((uint32_t)i < cur && !__atomic_compare_exchange_n(slot, &cur, (uint32_t)i, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+            }
+        }
+        return 0;
+    }
+    for (i = w->lo; i < w->hi; ++i) {
+        const fmdh_row_t x = fmdh_table_row(t, i);
+        fmd_ovlp_rec_t *r = row_rec_mut(t, i);
+        fmdh_link_t *l = &t->link[i];
+        l->nxt = l->rev = 0xffffffffu;
+        if (r->status != 0 || r->n_nei != 1 || r->rbeg < 0 || (r->flags & FMD_OVLP_F_OVERFLOW)) continue;
+        if (x.nei[0].x[0] < t->n) l->nxt = t->row_of[x.nei[0].x[0]];
+        if (x.nei[0].x[1] < t->n) l->rev = t->row_of[x.nei[0].x[1]];
+        if (r->reserved != 2) continue;                      /* the exact answer is already there */
+        {
+            int d = 1;
+            if (l->rev != 0xffffffffu) d = fmd_lfork_decide(row_rec_mut(t, l->rev)->lfork, r->rbeg);
+            if (getenv("FMD_CHECK_LEFT_EXACT")) d = 1;       /* A/B: every edge through fmd_ovlp_check_left_dev */
+            if (d != 1) r->reserved = d < 0 ? 1 : 0;
+            else {
+                if (w->n_und == w->m_und) {
+                    uint64_t m = w->m_und ? w->m_und << 1 : 1024, *q = (uint64_t *)realloc(w->und, m * 8);
+                    if (!q) { w->rc = -ENOMEM; return 0; }
+                    w->und = q; w->m_und = m;
+                }
+                w->und[w->n_und++] = i;
+            }
+        }
+    }
+    return 0;
+}
+
+int fmdh_ovlp_table_link(fmdh_ovlp_table_t *t, int n_threads, uint64_t **undecided, uint64_t *n_undecided)
+{
+    const uint64_t n = t->n;
+    lk_t *w;
+    pthread_t *tid;
+    char *started;
+    int k, phase, rc = 0;
+    uint64_t tot = 0;
+    if (undecided) *undecided = 0;
+    if (n_undecided) *n_undecided = 0;
+    if (n >= 0xffffffffull) return -ERANGE;
+    if (n_threads < 1) n_threads = 1;
+    if ((uint64_t)n_threads > n / 4096 + 1) n_threads = (int)(n / 4096 + 1);
+    free(t->row_of); free(t->link);
+    t->row_of = (uint32_t *)fmdh_big_alloc((n ? n : 1) * 4);
+    t->link = (fmdh_link_t *)fmdh_big_alloc((n ? n : 1) * sizeof(fmdh_link_t));
+    w = (lk_t *)calloc((size_t)n_threads, sizeof(lk_t));
+    tid = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    started = (char *)calloc((size_t)n_threads, 1);
+    if (!t->row_of || !t->link || !w || !tid || !started) { rc = -ENOMEM; goto done; }
+    memset(t->row_of, 0xff, n * 4);
+    for (phase = 0; phase < 2; ++phase) {
+        for (k = 0; k < n_threads; ++k) {
+            w[k].t = t; w[k].lo = n * (uint64_t)k / (uint64_t)n_threads; w[k].hi = n * (uint64_t)(k + 1) / (uint64_t)n_threads; w[k].phase = phase;
+            started[k] = k > 0 && pthread_create(&tid[k], 0, lk_main, &w[k]) == 0;
+        }
+        for (k = 0; k < n_threads; ++k) if (!started[k]) lk_main(&w[k]);   /* slice 0, and any slice whose thread could not be created */
+        for (k = 1; k < n_threads; ++k) if (started[k]) pthread_join(tid[k], 0);
+    }
+    for (k = 0; k < n_threads; ++k) { if (w[k].rc) rc = w[k].rc; tot += w[k].n_und; }
+    if (!rc && undecided && tot) {
+        uint64_t *u = (uint64_t *)malloc(tot * 8), o = 0;
+        if (!u) rc = -ENOMEM;
+        else {
+            for (k = 0; k < n_threads; ++k) { memcpy(u + o, w[k].und, w[k].n_und * 8); o += w[k].n_und; } /* slices are id ranges: already sorted */
+            *undecided = u;
+        }
+    }
+    if (!rc && n_undecided) *n_undecided = tot;
+done:
+    if (w) for (k = 0; k < n_threads; ++k) free(w[k].und);
+    free(w); free(tid); free(started);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------ build */
 typedef struct {
     const char *fmd_path; int device, g, n_dev, min_match; uint32_t max_len, max_nei;
     fmdh_ovlp_shard_t *shard; fmd_dev_t *dev; uint64_t n_seq; int rc; double t_load, t_rows;
@@ -64,7 +162,7 @@ static void *job_main(void *p)
     j->t_load = now_s() - t0; t0 = now_s();
     {
         const uint64_t n = j->n_seq > (uint64_t)j->g ? (j->n_seq - (uint64_t)j->g + (uint64_t)j->n_dev - 1) / (uint64_t)j->n_dev : 0;
-        j->rc = shard_fill(j->dev, j->shard, 0, (uint64_t)j->g, (uint64_t)j->n_dev, n, j->min_match, j->max_len, j->max_nei);
+        j->rc = shard_fill(j->dev, j->shard, 0, (uint64_t)j->g, (uint64_t)j->n_dev, n, j->min_match, j->max_len, j->max_nei, 0);
     }
     j->t_rows = now_s() - t0;
     if (j->g != 0) { fmd_dev_close(j->dev); j->dev = 0; }   /* replica 0 stays open for the overflow pass */
@@ -78,7 +176,7 @@ void fmdh_ovlp_table_free(fmdh_ovlp_table_t *t)
     for (g = 0; g < t->n_shards; ++g) shard_free(&t->shard[g]);
     free(t->shard);
     shard_free(&t->side);
-    free(t->side_of);
+    free(t->side_of); free(t->row_of); free(t->link);
     memset(t, 0, sizeof(*t));
 }
 
@@ -135,7 +233,7 @@ int fmdh_ovlp_table_build(const char *fmd_path, int n_dev, const int *devices, i
             if (attempt == 12) { fprintf(stderr, "[E::%s] %llu rows still overflow at max_len %u, max_nei %u\n", __func__, (unsigned long long)n_side, s_len, s_nei); rc = 1; goto done; }
             s_len *= 2; s_nei *= 2;
             shard_free(&t->side);
-            rc = shard_fill(jobs[0].dev, &t->side, ids, 0, 0, n_side, min_match, s_len, s_nei);
+            rc = shard_fill(jobs[0].dev, &t->side, ids, 0, 0, n_side, min_match, s_len, s_nei, 0);
             if (rc) { fprintf(stderr, "[E::%s] overflow pass: %s\n", __func__, fmd_strerror(rc)); rc = 1; goto done; }
             for (i = 0; i < n_side; ++i) n_over += (t->side.rec[i].flags & FMD_OVLP_F_OVERFLOW) != 0;
             if (n_over == 0) break;
@@ -143,6 +241,37 @@ int fmdh_ovlp_table_build(const char *fmd_path, int n_dev, const int *devices, i
         memset(t->side_of, 0xff, n_seq * 4);
         for (i = 0; i < n_side; ++i) t->side_of[ids[i]] = (uint32_t)i;
         if (timing) fprintf(stderr, "[M::%s] %llu rows again with capacities %u / %u: %.3f s\n", __func__, (unsigned long long)n_side, s_len, s_nei, now_s() - t1);
+    }
+    /* check_left_simple (unitig.c:186-204) of every edge: decided on the host from the lfork of the neighbour's reverse
+     * strand; the edges that field does not decide go through the exact kernel (fmd_ovlp_check_left_dev), alone */
+    {
+        uint64_t *und = 0, n_und = 0, k;
+        double t1 = now_s();
+        int nt = 16;
+        { const char *e = getenv("FMD_HOST_THREADS"); if (e && atoi(e) > 0) nt = atoi(e); }
+        rc = fmdh_ovlp_table_link(t, nt, &und, &n_und);
+        if (rc) { fprintf(stderr, "[E::%s] link pass: %s\n", __func__, strerror(-rc)); rc = 1; free(und); goto done; }
+        if (timing) fprintf(stderr, "[M::%s] link pass (%d threads): %.3f s, %llu edges left to the exact kernel\n", __func__, nt, now_s() - t1, (unsigned long long)n_und);
+        if (n_und) {
+            fmdh_ovlp_shard_t ex;
+            uint32_t s_len = max_len, s_nei = max_nei;
+            int attempt;
+            t1 = now_s();
+            memset(&ex, 0, sizeof(ex));
+            for (attempt = 0;; ++attempt) {   /* same capacity ladder as above: a row of the side table needs its capacities here too */
+                uint64_t n_over = 0;
+                rc = shard_fill(jobs[0].dev, &ex, und, 0, 0, n_und, min_match, s_len, s_nei, 1);
+                if (rc) { fprintf(stderr, "[E::%s] exact check_left pass: %s\n", __func__, fmd_strerror(rc)); rc = 1; free(und); goto done; }
+                for (k = 0; k < n_und; ++k) n_over += (ex.rec[k].flags & FMD_OVLP_F_OVERFLOW) != 0;
+                if (n_over == 0 || attempt == 12) break;
+                s_len *= 2; s_nei *= 2;
+                shard_free(&ex);
+            }
+            for (k = 0; k < n_und; ++k) row_rec_mut(t, und[k])->reserved = ex.rec[k].reserved;
+            shard_free(&ex);
+            if (timing) fprintf(stderr, "[M::%s] exact check_left of %llu rows: %.3f s\n", __func__, (unsigned long long)n_und, now_s() - t1);
+        }
+        free(und);
     }
     if (timing) fprintf(stderr, "[M::%s] table of %llu sequences on %d GPU(s): %.3f s\n", __func__, (unsigned long long)n_seq, n_dev, now_s() - t0);
 done:

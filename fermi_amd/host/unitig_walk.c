@@ -45,8 +45,9 @@ typedef struct {
     uint64_t *used, *bend, *visited;
     uint32_t *row_of;           /* `$read$` interval start -> a sequence id with that interval */
     const uint64_t *sorted;     /* optional rank -> (sequence id << 2 | flags) map of `unitig -r` (unitig.c:22-29) */
-    /* the neighbour list left behind by the last try_right (unitig.c:181-184) */
-    const fmd_intv_t *nei; int n_nei;
+    /* the neighbour list left behind by the last try_right (unitig.c:181-184): that of row `last` */
+    uint64_t last; int n_nei;
+    int err;
 } walk_t;
 
 static inline fmdh_row_t ROW(const walk_t *w, uint64_t row) { return fmdh_table_row(w->t, row); }
@@ -137,56 +138,110 @@ static void mark_used(walk_t *w, const uint64_t x[3]) /* set_bits, unitig.c:22-3
     else for (k = 0; k < x[2]; ++k) { bit_set(w->used, x[0] + k); bit_set(w->used, x[1] + k); }
 }
 
-/* check_left (unitig.c:206-225) for the edge row -> its unique neighbour */
-static int check_left(const walk_t *w, uint64_t row)
+/* Coverage string (unitig.c:251-255: '"' = one read, one more per read that covers the base, capped at '~').  Every
+ * accepted extension adds one read over [rbeg, new end): kept as a difference array over a base string and
+ * materialised when the string is needed -- min('~', base + reads) is the same whenever the cap is applied. */
+typedef struct { char *s; int32_t *d; size_t l, m; } cov_t;
+static int cov_reserve(cov_t *c, size_t need)
 {
-    const fmdh_row_t x = ROW(w, row);
-    if (x.rec->reserved == 0) return 0;
+    if (need <= c->m) return 0;
+    size_t m = c->m ? c->m : 256;
+    while (m < need) m <<= 1;
+    char *p = (char *)realloc(c->s, m);
+    if (!p) return -ENOMEM;
+    c->s = p;
+    int32_t *q = (int32_t *)realloc(c->d, m * sizeof(int32_t));
+    if (!q) return -ENOMEM;
+    c->d = q;
+    memset(c->s + c->m, '!', m - c->m);                   /* '!' = no read yet */
+    memset(c->d + c->m, 0, (m - c->m) * sizeof(int32_t));
+    c->m = m;
+    return 0;
+}
+static inline int cov_add(cov_t *c, size_t from, size_t to) /* one more read over [from, to) */
+{
+    if (cov_reserve(c, to + 2)) return -ENOMEM;
+    ++c->d[from]; --c->d[to];
+    if (to > c->l) c->l = to;
+    return 0;
+}
+static void cov_flush(cov_t *c, size_t l) /* materialise [0, l); everything beyond is dropped */
+{
+    size_t i;
+    int32_t run = 0;
+    for (i = 0; i < l; ++i) {
+        run += c->d[i]; c->d[i] = 0;
+        { const int v = c->s[i] + run; c->s[i] = (char)(v > '~' ? '~' : v); }
+    }
+    for (; i <= c->l && i < c->m; ++i) { c->d[i] = 0; c->s[i] = '!'; }
+    c->l = l;
+}
+
+static inline const fmd_ovlp_rec_t *REC(const walk_t *w, uint64_t row)
+{
+    const fmdh_ovlp_table_t *t = w->t;
+    if (t->side_of && t->side_of[row] != 0xffffffffu) return &t->side.rec[t->side_of[row]];
+    if (t->n_shards == 1) return &t->shard[0].rec[row];
+    return &t->shard[row % (uint64_t)t->n_shards].rec[row / (uint64_t)t->n_shards];
+}
+
+/* check_left (unitig.c:206-225) for the edge row -> its unique neighbour; rev = row of the neighbour's reverse strand */
+static int check_left(walk_t *w, const fmd_ovlp_rec_t *r, uint32_t rev)
+{
+    int cl = r->reserved;
+    if (cl == 2) { /* check_left_simple was not run on this row: the rounds of the neighbour's reverse strand decide it (include/fmd_hip.h) */
+        const int d = rev != 0xffffffffu ? fmd_lfork_decide(REC(w, rev)->lfork, r->rbeg) : 1;
+        if (d == 1) { w->err = -EDOM; return -1; }        /* the table is incomplete: fmdh_ovlp_table_link leaves no such row */
+        cl = d < 0;
+    }
+    if (cl == 0) return 0;
     /* the back fork may be due to a contained read: look right from the reverse strand of the
      * neighbour; more than one irreducible overlap there confirms the bifurcation */
-    uint32_t row2 = w->row_of[x.nei[0].x[1]];
-    if (row2 == 0xffffffffu) return -1;
-    return ROW(w, row2).rec->n_nei > 1 ? -1 : 0;
+    if (rev == 0xffffffffu) return -1;
+    return REC(w, rev)->n_nei > 1 ? -1 : 0;
 }
 
 /* unitig_unidir, unitig.c:227-262.  `cur` = table row of the read at the right end of s. */
-static int unidir(walk_t *w, uint64_t cur, str_t *s, str_t *cov, int beg0, uint64_t k0, uint64_t *end, int *is_loop)
+static int unidir(walk_t *w, uint64_t cur, str_t *s, cov_t *cov, int beg0, uint64_t k0, uint64_t *end, int *is_loop)
 {
-    int beg = beg0, ori_l = (int)s->l, n_reads = 0, i;
+    const fmdh_link_t *link = w->t->link;
+    int beg = beg0, ori_l = (int)s->l, n_reads = 0;
     *is_loop = 0;
     for (;;) {
-        const fmdh_row_t x = ROW(w, cur);
-        const fmd_ovlp_rec_t *r = x.rec;
+        const fmd_ovlp_rec_t *r = REC(w, cur);
+        uint64_t kx[3];
+        uint32_t nxt, rev;
         int rbeg;
-        w->nei = x.nei; w->n_nei = r->n_nei;
+        w->last = cur; w->n_nei = r->n_nei;                                      /* the list try_right leaves behind (unitig.c:181-184) */
         if (r->status != 0 || r->rbeg < 0) { w->n_nei = r->status == 0 ? r->n_nei : 0; break; }   /* try_right < 0 */
         rbeg = beg + r->rbeg;
         if (r->n_nei > 1) { bit_set(w->bend, *end); break; }                     /* forward bifurcation */
-        {   /* the bases fm6_get_nei appended (unitig.c:139) */
+        {
+            const fmdh_row_t x = ROW(w, cur);
+            if (link) { nxt = link[cur].nxt; rev = link[cur].rev; }
+            else { nxt = x.nei[0].x[0] < w->n_seq ? w->row_of[x.nei[0].x[0]] : 0xffffffffu; rev = x.nei[0].x[1] < w->n_seq ? w->row_of[x.nei[0].x[1]] : 0xffffffffu; }
+            /* the `$neighbour$` interval: the neighbour's own row has it (its record is the next one the walk reads anyway) */
+            if (nxt != 0xffffffffu) { const fmd_ovlp_rec_t *q = REC(w, nxt); kx[0] = q->k[0]; kx[1] = q->k[1]; kx[2] = q->k[2]; }
+            else { kx[0] = x.nei[0].x[0]; kx[1] = x.nei[0].x[1]; kx[2] = x.nei[0].x[2]; }
+            /* the bases fm6_get_nei appended (unitig.c:139) */
             if (str_reserve(s, (size_t)ori_l + r->ext_len + 1)) return -1;
             fmdh_row_bases(&x, (uint32_t)r->len, (uint32_t)r->ext_len, s->s + ori_l);
             s->l = (size_t)ori_l + r->ext_len;
         }
-        uint64_t k = w->nei[0].x[0];
-        if (k == *end) break;                                                    /* b>>c>>a><a */
-        if (bit_get(w->bend, k) || check_left(w, cur) < 0) { bit_set(w->bend, k); break; } /* backward bifurcation */
-        if (k == k0) { *is_loop = 1; break; }                                    /* a>>b>>c>>a */
-        if (w->nei[0].x[1] == *end) { w->n_nei = 0; break; }                     /* b>>c>>a>>a: cut the last link */
-        *end = w->nei[0].x[1];
-        mark_used(w, w->nei[0].x);
+        if (kx[0] == *end) break;                                                /* b>>c>>a><a */
+        if (bit_get(w->bend, kx[0]) || check_left(w, r, rev) < 0) { if (w->err) return -1; bit_set(w->bend, kx[0]); break; } /* backward bifurcation */
+        if (kx[0] == k0) { *is_loop = 1; break; }                                /* a>>b>>c>>a */
+        if (kx[1] == *end) { w->n_nei = 0; break; }                              /* b>>c>>a>>a: cut the last link */
+        *end = kx[1];
+        mark_used(w, kx);
         ++n_reads;
-        if (str_reserve(cov, s->l + 1)) return -1;
-        cov->l = s->l;
-        for (i = rbeg; i < ori_l; ++i) if (cov->s[i] != '~') ++cov->s[i];
-        for (i = ori_l; i < (int)s->l; ++i) cov->s[i] = '"';
+        if (cov_add(cov, (size_t)rbeg, s->l)) return -1;                          /* ++ over [rbeg, ori_l), '"' for the new bases */
         beg = rbeg; ori_l = (int)s->l;
-        {
-            uint32_t nxt = w->row_of[w->nei[0].x[0]];
-            if (nxt == 0xffffffffu) break; /* cannot happen: a neighbour is a non-contained read */
-            cur = nxt;
-        }
+        if (nxt == 0xffffffffu) break; /* cannot happen: a neighbour is a non-contained read */
+        cur = nxt;
     }
-    s->l = cov->l = (size_t)ori_l;
+    s->l = (size_t)ori_l;
+    cov_flush(cov, (size_t)ori_l);
     return n_reads;
 }
 
@@ -221,33 +276,35 @@ static int put_links(str_t *o, const link_t *a, int n)
 int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, const uint64_t *sorted, FILE *out)
 {
     walk_t w;
-    str_t s = {0, 0, 0}, cov = {0, 0, 0}, o = {0, 0, 0};
+    str_t s = {0, 0, 0}, o = {0, 0, 0};
+    cov_t cov = {0, 0, 0, 0};
     link_t *nei[2];
     uint64_t i, j, nw = (n_seq + 63) / 64;
     int rc = 0;
     memset(&w, 0, sizeof(w));
     w.t = t; w.n_seq = n_seq; w.min_match = min_match; w.sorted = sorted;
     w.used = (uint64_t *)calloc(nw, 8); w.bend = (uint64_t *)calloc(nw, 8); w.visited = (uint64_t *)calloc(nw, 8);
-    w.row_of = (uint32_t *)fmdh_big_alloc(n_seq * 4);
+    w.row_of = t->row_of ? t->row_of : (uint32_t *)fmdh_big_alloc((n_seq ? n_seq : 1) * 4);
     uint32_t cap_nei = t->side_of ? t->side.max_nei : 1;
     outq_t oq;
     int oq_open = 0, g;
     for (g = 0; g < t->n_shards; ++g) if (t->shard[g].max_nei > cap_nei) cap_nei = t->shard[g].max_nei;
     nei[0] = (link_t *)malloc(cap_nei * sizeof(link_t)); nei[1] = (link_t *)malloc((cap_nei + 1) * sizeof(link_t));
     if (!w.used || !w.bend || !w.visited || !w.row_of || !nei[0] || !nei[1]) { rc = -ENOMEM; goto done; }
-    memset(w.row_of, 0xff, n_seq * 4);
     if (n_seq >= 0xffffffffull || t->n >= 0xffffffffull) { rc = -ERANGE; goto done; }   /* row_of holds 32-bit ids */
     if ((rc = outq_open(&oq, out)) != 0) goto done;
     oq_open = 1;
-    for (i = t->n; i-- > 0;) { /* smallest id wins */
-        const fmd_ovlp_rec_t *r = fmdh_table_row(t, i).rec;
-        if (r->status == 0 && !(r->flags & FMD_OVLP_F_OVERFLOW) && r->k[0] < n_seq) w.row_of[r->k[0]] = (uint32_t)i;
+    if (!t->row_of) { /* not linked (fmdh_ovlp_table_link): build the row map here */
+        memset(w.row_of, 0xff, n_seq * 4);
+        for (i = t->n; i-- > 0;) { /* smallest id wins */
+            const fmd_ovlp_rec_t *r = REC(&w, i);
+            if (r->status == 0 && !(r->flags & FMD_OVLP_F_OVERFLOW) && r->k[0] < n_seq) w.row_of[r->k[0]] = (uint32_t)i;
+        }
     }
     /* unitig_core with start = 0, step = 1 (unitig.c:333-334): seeds are the odd sequence ids */
     for (j = 0; j <= n_seq >> 2; ++j) {
         for (i = j << 2 | 1; i < (j << 2) + 4 && i < n_seq; i += 2) {
-            const fmdh_row_t seed = fmdh_table_row(t, i);
-            const fmd_ovlp_rec_t *r = seed.rec;
+            const fmd_ovlp_rec_t *r = REC(&w, i);
             uint64_t end[2];
             int n_nei[2] = {0, 0}, n_reads, is_loop = 0, seed_len, k, done_loop = 0;
             /* ---- unitig1 (unitig.c:274-317) */
@@ -258,26 +315,31 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
             mark_used(&w, r->k);
             if (r->status != 0) continue;                            /* contained */
             seed_len = r->len;
-            if (str_reserve(&s, (size_t)seed_len + 1) || str_reserve(&cov, (size_t)seed_len + 1)) { rc = -ENOMEM; goto done; }
-            fmdh_row_bases(&seed, 0, (uint32_t)seed_len, s.s); s.l = (size_t)seed_len;
-            memset(cov.s, '"', (size_t)seed_len); cov.l = (size_t)seed_len;
+            if (str_reserve(&s, (size_t)seed_len + 1)) { rc = -ENOMEM; goto done; }
+            { const fmdh_row_t seed = fmdh_table_row(t, i); fmdh_row_bases(&seed, 0, (uint32_t)seed_len, s.s); }
+            s.l = (size_t)seed_len;
+            cov_flush(&cov, 0);
+            if (cov_add(&cov, 0, (size_t)seed_len)) { rc = -ENOMEM; goto done; }
             n_reads = 1;
             end[0] = r->k[1]; end[1] = r->k[0];
             if (r->n_ovlp) { /* left-wards extension of the unitig = right-wards of this strand */
                 int m = unidir(&w, i, &s, &cov, 0, r->k[0], &end[0], &is_loop);
-                if (m < 0) { rc = -ENOMEM; goto done; }
+                if (m < 0) { rc = w.err ? w.err : -ENOMEM; goto done; }
                 n_reads += m;
-                for (k = 0; k < w.n_nei; ++k) { nei[0][k].x = w.nei[k].x[0]; nei[0][k].y = w.nei[k].info; }
-                n_nei[0] = w.n_nei;
-                if (is_loop) { nei[1][0].x = end[0]; nei[1][0].y = w.nei[0].info; n_nei[1] = 1; done_loop = 1; }
+                { const fmd_intv_t *ln = fmdh_table_row(t, w.last).nei;
+                  for (k = 0; k < w.n_nei; ++k) { nei[0][k].x = ln[k].x[0]; nei[0][k].y = ln[k].info; }
+                  n_nei[0] = w.n_nei;
+                  if (is_loop) { nei[1][0].x = end[0]; nei[1][0].y = ln[0].info; n_nei[1] = 1; done_loop = 1; } }
             }
             if (!done_loop) { /* the other direction, from the reverse strand of the seed (unitig.c:310-315) */
                 int m;
-                revcomp6(s.l, s.s); reverse(cov.l, cov.s);
+                cov_flush(&cov, s.l);
+                revcomp6(s.l, s.s); reverse(s.l, cov.s);
                 m = unidir(&w, i ^ 1, &s, &cov, (int)s.l - seed_len, r->k[1], &end[1], &is_loop);
-                if (m < 0) { rc = -ENOMEM; goto done; }
+                if (m < 0) { rc = w.err ? w.err : -ENOMEM; goto done; }
                 n_reads += m;
-                for (k = 0; k < w.n_nei; ++k) { nei[1][k].x = w.nei[k].x[0]; nei[1][k].y = w.nei[k].info; }
+                { const fmd_intv_t *ln = fmdh_table_row(t, w.last).nei;
+                  for (k = 0; k < w.n_nei; ++k) { nei[1][k].x = ln[k].x[0]; nei[1][k].y = ln[k].info; } }
                 n_nei[1] = w.n_nei;
             }
             /* ---- unitig_core: keep each unitig once (unitig.c:336-339) */
@@ -305,7 +367,8 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
     }
 done:
     if (oq_open) { const int e = outq_close(&oq); if (!rc) rc = e; }
-    free(w.used); free(w.bend); free(w.visited); free(w.row_of); free(nei[0]); free(nei[1]);
-    free(s.s); free(cov.s); free(o.s);
+    free(w.used); free(w.bend); free(w.visited); if (w.row_of != t->row_of) free(w.row_of);
+    free(nei[0]); free(nei[1]);
+    free(s.s); free(cov.s); free(cov.d); free(o.s);
     return rc;
 }

@@ -24,7 +24,9 @@ def lib():
             _fields_ = [("n", C.c_uint64), ("rec", C.c_void_p), ("off", C.c_void_p), ("chunk", C.POINTER(C.c_void_p)),
                         ("chunk_shift", C.c_uint32), ("max_nei", C.c_uint32), ("seq_stride", C.c_uint32)]
         class Table(C.Structure):
-            _fields_ = [("n", C.c_uint64), ("n_shards", C.c_int), ("shard", C.POINTER(Shard)), ("side_of", C.c_void_p), ("side", Shard)]
+            _fields_ = [("n", C.c_uint64), ("n_shards", C.c_int), ("shard", C.POINTER(Shard)), ("side_of", C.c_void_p), ("side", Shard),
+                        ("row_of", C.c_void_p), ("link", C.c_void_p)]
+        L.fmdh_ovlp_table_link.argtypes = [C.POINTER(Table), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.Shard = Shard
         L.Table = Table
         L.fmdh_unitig_walk.argtypes = [C.POINTER(Table), C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
@@ -80,9 +82,11 @@ _libc = C.CDLL(None)
 _libc.fopen.restype = C.c_void_p
 _libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
 _libc.fclose.argtypes = [C.c_void_p]
+_libc.free.argtypes = [C.c_void_p]
+_libc.free.restype = None
 
 
-def unitig_walk(shards, n_seq, min_match, out_path, sorted_map=None, max_nei=4, seq_stride=256):
+def unitig_walk(shards, n_seq, min_match, out_path, sorted_map=None, max_nei=4, seq_stride=256, link=0, resolve=None):
     """Replay the `fermi unitig -t1` walk over a packed per-id overlap table kept in len(shards) shards -- id i = row
     i // N of shard i % N; each shard = (prec[OVLP_DT], off[u64, n+1], var[u8]) as fmd_ovlp_pack_dev writes them.
     Writes MAG records to out_path."""
@@ -97,13 +101,26 @@ def unitig_walk(shards, n_seq, min_match, out_path, sorted_map=None, max_nei=4, 
         keep += [prec, off, var, chunk]
         arr[k] = L.Shard(len(prec), prec.ctypes.data, off.ctypes.data, chunk, 40, max_nei, seq_stride)   # one chunk: shift beyond any row count
         n_total += len(prec)
-    t = L.Table(n_total, len(shards), arr, None, L.Shard())
+    t = L.Table(n_total, len(shards), arr, None, L.Shard(), None, None)
+    undecided = None
+    if link:   # the parallel link pass of the product path (rec.reserved of decided edges is written in place)
+        und, n_und = C.c_void_p(), C.c_uint64()
+        _chk(L.fmdh_ovlp_table_link(C.byref(t), link, C.byref(und), C.byref(n_und)), "table_link")
+        undecided = np.ctypeslib.as_array(C.cast(und, C.POINTER(C.c_uint64)), (n_und.value,)).copy() if n_und.value else np.zeros(0, np.uint64)
+        _libc.free(und)
+        if resolve is not None and len(undecided):   # the product runs fmd_ovlp_check_left on these ids (ovlp_table.c)
+            vals = resolve(undecided)
+            n_sh = len(shards)
+            for i, v in zip(undecided, vals):
+                keep[4 * int(i % n_sh)]["reserved"][int(i // n_sh)] = v
     fp = _libc.fopen(out_path.encode(), b"wb")
     try:
         sm = None if sorted_map is None else np.ascontiguousarray(sorted_map, dtype=np.uint64)
         _chk(L.fmdh_unitig_walk(C.byref(t), n_seq, min_match, None if sm is None else sm.ctypes.data, fp), "unitig_walk")
     finally:
         _libc.fclose(fp)
+        _libc.free(t.row_of); _libc.free(t.link)
+    return undecided
 
 
 def unitig(fmd_path, min_match, out_path, devices=(0,)):

@@ -169,9 +169,25 @@ typedef struct {
     int32_t ext_len;   /* bases fm6_get_nei appended to the sequence */
     int32_t n_nei;     /* irreducible neighbours found */
     uint32_t flags;    /* FMD_OVLP_F_* */
-    uint32_t reserved; /* check_left_simple (unitig.c:186) for the edge to the unique neighbour:
-                          0 = passes, 1 = potential backward bifurcation (-1), 2 = not applicable */
+    uint16_t reserved; /* check_left_simple (unitig.c:186) for the edge to the unique neighbour, when it was computed
+                          for this row (fmd_ovlp_check_left_dev): 0 = passes, 1 = potential backward bifurcation (-1);
+                          2 = not computed / not applicable */
+    uint16_t lfork;    /* what fm6_get_nei's rounds on THIS strand X say about check_left_simple on any edge S -> N whose
+                          neighbour N is the reverse complement of X (FMD_LFORK_*): the reads check_left_simple collects on
+                          N and pulls back over S are the candidates of X extended forward, round for round */
 } fmd_ovlp_rec_t;      /* 64 bytes */
+/* lfork = D << 15 | R:  rounds 0 .. R-1 saw every read that starts inside X with >= min_match bases either end or go on
+ * with one and the same base (R = FMD_LFORK_ALL: all of them ended, nothing can ever disagree); D = 1: round R has two
+ * different bases.  For an edge S -> N with rbeg = fm6_get_nei's return value on S (the walk's check_left_simple(beg = 0,
+ * rbeg), unitig.c:186-204 visits rounds 0 .. rbeg-1):   rbeg <= R  => 0;   D && R < rbeg  => -1;   otherwise not
+ * decided by this row (lfork = 0 decides nothing) and fmd_ovlp_check_left_dev has to be run on S. */
+#define FMD_LFORK_ALL 0x7fffu
+static inline int fmd_lfork_decide(uint16_t lfork, int rbeg) /* 0 / -1 as check_left_simple, 1 = undecided */
+{
+    const int r = lfork & 0x7fff;
+    if (rbeg <= r || r == (int)FMD_LFORK_ALL) return 0;
+    return (lfork & 0x8000) ? -1 : 1;
+}
 /* capacity of the per-strand candidate lists kept in the work area */
 static inline uint32_t fmd_ovlp_list_cap(uint32_t max_len, int min_match)
 {

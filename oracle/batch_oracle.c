@@ -51,7 +51,8 @@ void orc_retrieve_batch(const orc_rld_t *e, size_t n, const uint64_t *x, uint8_t
 typedef struct {
     uint64_t rank, k[3];
     int32_t len, status, n_ovlp, rbeg, ext_len, n_nei;
-    uint32_t flags, reserved;
+    uint32_t flags;
+    uint16_t reserved, lfork;   /* lfork: EXACT here (orc_left_fork); the product may know less (see include/fmd_hip.h) */
 } orc_ovlp_rec_t;
 
 typedef struct { const orc_rld_t *e; size_t n; const uint64_t *ids; int min_match; uint32_t max_nei;
@@ -81,6 +82,7 @@ static void *ov_worker(void *d)
         r->k[0] = intv.x[0]; r->k[1] = intv.x[1]; r->k[2] = intv.x[2];
         r->n_ovlp = (int32_t)a0.n;
         if (ret < 0) { r->status = -3; continue; }
+        r->lfork = (uint16_t)orc_left_fork(w->e, w->min_match, s.s, len);
         if (a0.n) {
             r->rbeg = orc_get_nei(w->e, w->min_match, 0, &s, &nei, &a0, &a1);
             r->ext_len = (int32_t)s.n - len;

@@ -399,6 +399,42 @@ int orc_check_left_simple(const orc_rld_t *e, int min_match, int beg, int rbeg, 
     return ret;
 }
 
+/* The lfork field of include/fmd_hip.h, EXACT: what check_left_simple (unitig.c:186-204) would meet on any edge whose
+ * neighbour is N = the reverse complement of the strand x (len bases), told round by round without knowing the other
+ * read.  The list is check_left_simple's own first step -- overlap_intv(N, from its first base, at5 = 1, sentinel
+ * children) -- and each round is its inner loop with the base taken from the reads instead of from s[i]:
+ *   round r passes iff every read of every interval either starts here (ok[0]) or goes on with one common base.
+ * Returns D << 15 | R: rounds 0..R-1 pass; D = 1: round R has two bases; R = 0x7fff, D = 0: every read ended. */
+unsigned orc_left_fork(const orc_rld_t *e, int min_match, const uint8_t *x, int len)
+{
+    orc_intv_v a = {0, 0, 0}, b = {0, 0, 0}, *prev = &a, *curr = &b, *t;
+    orc_intv_t ok[6];
+    uint8_t *n = (uint8_t *)malloc((size_t)len + 1);
+    unsigned res = 0x7fffu;
+    int i, r;
+    size_t j;
+    for (i = 0; i < len; ++i) { const int c = x[len - 1 - i]; n[i] = (uint8_t)((c >= 1 && c <= 4) ? 5 - c : c); }
+    overlap_intv(e, len, n, min_match, 0, 1, prev, 1);
+    for (r = 0; prev->n; ++r) {
+        unsigned u = 0;
+        int c, the = 0;
+        for (j = 0; j < prev->n; ++j) {
+            orc_extend(e, &prev->a[j], ok, 1);
+            for (c = 1; c <= 5; ++c) if (ok[c].x[2]) u |= 1u << c;
+        }
+        if (u & (u - 1)) { res = 0x8000u | (unsigned)r; break; }   /* two different bases */
+        if (u == 0) break;                                          /* every read ended: nothing left to disagree */
+        for (c = 1; c <= 5; ++c) if (u >> c & 1) the = c;
+        for (j = 0, curr->n = 0; j < prev->n; ++j) {
+            orc_extend(e, &prev->a[j], ok, 1);
+            if (ok[the].x[2]) vec_push(curr, &ok[the]);
+        }
+        t = curr; curr = prev; prev = t;
+    }
+    free(a.a); free(b.a); free(n);
+    return res;
+}
+
 /* ---- correct.c:35-87 -------------------------------------------------------------------- */
 
 void orc_ec_collect(const orc_rld_t *e, int w, int min_occ, int suf_len, const orc_intv_t *suf_intv,

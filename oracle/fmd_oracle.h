@@ -84,7 +84,8 @@ int orc_is_contained(const orc_rld_t *e, int min_match, const uint8_t *s, int le
 int orc_get_nei(const orc_rld_t *e, int min_match, int beg, orc_str_t *s, orc_intv_v *nei,
                 orc_intv_v *prev, orc_intv_v *curr);
 
-int orc_check_left_simple(const orc_rld_t *e, int min_match, int beg, int rbeg, const uint8_t *s, int len); /* unitig.c:186 */
+int orc_check_left_simple(const orc_rld_t *e, int min_match, int beg, int rbeg, const uint8_t *s, int len);
+unsigned orc_left_fork(const orc_rld_t *e, int min_match, const uint8_t *x, int len); /* unitig.c:186 */
 
 /* ---- k-mer harvest for `correct` (correct.c:35-87): appends (key,val) pairs ---- */
 typedef struct { size_t n, m; uint32_t *key; uint8_t *val; int64_t cnt[2]; } orc_solid_t;

@@ -354,6 +354,49 @@ def test_packed_batch_equals_fixed_stride_batch(gpu, gold):
     d.close()
 
 
+def _lfork_decide(lf, rbeg):
+    R, D = int(lf) & 0x7fff, int(lf) >> 15
+    if rbeg <= R or R == 0x7fff:
+        return 0
+    return -1 if D else 1
+
+
+@pytest.mark.parametrize("name,mm,ml", [("tiny", 50, 100), ("tiny", 30, 100), ("repeat", 20, 80), ("special", 20, 60)])
+def test_lfork_never_claims_more_than_the_truth_and_decides_check_left(gpu, gold, oracle_lib, name, mm, ml):
+    """rec.lfork (include/fmd_hip.h): what fm6_get_nei's rounds on strand X already tell about check_left_simple on
+    any edge whose neighbour is revcomp(X).  (1) the GPU's claim is implied by the oracle's exact value; (2) for every
+    edge of the fixture, deciding check_left_simple from the lfork of the neighbour's reverse strand gives what the
+    oracle's check_left_simple (unitig.c:186-204) returns -- or says `undecided`, never the wrong answer."""
+    d = gpu.DevIndex.open(gold.path(name + ".fmd")); o = orcbind.OrcIndex(gold.path(name + ".fmd"))
+    n = int(o.mcnt[1])
+    ids = np.arange(n, dtype=U64)
+    g_rec, g_nei, _ = d.overlap(ids, mm, max_len=ml, max_nei=8, check_left=True)
+    w_rec, w_nei, _ = o.overlap_batch(ids, mm, max_len=ml, max_nei=8)
+    Rg, Dg = g_rec["lfork"] & 0x7fff, g_rec["lfork"] >> 15
+    Ro, Do = w_rec["lfork"] & 0x7fff, w_rec["lfork"] >> 15
+    assert np.array_equal(Rg[Dg == 1], Ro[Dg == 1]) and (Do[Dg == 1] == 1).all()   # a fork the GPU reports is the first one
+    assert (Rg[Dg == 0] <= Ro[Dg == 0]).all()                                        # rounds it vouches for really pass (0x7fff = all)
+    assert (g_rec["lfork"][g_rec["status"] != 0] == 0).all()
+    row_of = {}
+    for i in range(n - 1, -1, -1):
+        if g_rec[i]["status"] == 0:
+            row_of[int(g_rec[i]["k"][0])] = i
+    edges = undecided = 0
+    for i in range(n):
+        r = w_rec[i]
+        if r["status"] == 0 and r["n_nei"] == 1 and r["rbeg"] >= 0 and r["reserved"] != 2:
+            row2 = row_of[int(w_nei[i, 0]["x"][1])]
+            dec = _lfork_decide(g_rec[row2]["lfork"], int(r["rbeg"]))
+            edges += 1
+            if dec == 1:
+                undecided += 1
+            else:
+                assert dec == (-1 if r["reserved"] == 1 else 0), (name, i)
+            assert _lfork_decide(w_rec[row2]["lfork"], int(r["rbeg"])) == (-1 if r["reserved"] == 1 else 0)   # the exact value decides every edge
+    assert edges > 100 and undecided <= 0.05 * edges, (edges, undecided)
+    d.close(); o.close()
+
+
 def test_check_left_flags_vs_oracle(gpu, gold, oracle_lib):
     for name, mm, ml in (("tiny", 50, 100), ("repeat", 20, 80), ("special", 20, 60)):
         d = gpu.DevIndex.open(gold.path(name + ".fmd")); o = orcbind.OrcIndex(gold.path(name + ".fmd"))

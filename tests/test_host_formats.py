@@ -68,6 +68,28 @@ def test_unitig_walk_reproduces_fermi_unitig_t1(oracle_lib, gold, tmp_path, name
     o.close()
 
 
+@pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20), ("special", 20)])
+@pytest.mark.parametrize("weaken", [0, 3])
+def test_unitig_walk_with_check_left_decided_by_the_link_pass(oracle_lib, gold, tmp_path, name, mm, weaken):
+    """The product path: check_left_simple is NOT run per row (rec.reserved = 2); fmdh_ovlp_table_link decides every edge
+    from the lfork of the neighbour's reverse strand (include/fmd_hip.h) on several threads, hands back the rows it cannot
+    decide, and the walk steps through the link array.  With the oracle's exact lfork nothing is left undecided; with
+    every `weaken`-th lfork blanked the rest goes to the exact answer.  MAG == `fermi unitig -t1` either way."""
+    o = orcbind.OrcIndex(gold.path(name + ".fmd"))
+    n_seq = int(o.mcnt[1])
+    rec, nei, seq = o.overlap_batch(np.arange(n_seq, dtype=np.uint64), mm, max_len=100, max_nei=8, n_threads=4)
+    exact = rec["reserved"].copy()
+    rec["reserved"] = 2
+    if weaken:
+        rec["lfork"][::weaken] = 0
+    out = str(tmp_path / "o.mag")
+    und = hostlib.unitig_walk(_packed_shards(rec, nei, seq, 2), n_seq, mm, out, max_nei=8, seq_stride=seq.shape[1], link=3,
+                              resolve=lambda ids: exact[ids.astype(np.int64)])
+    assert (len(und) == 0) if not weaken else (len(und) > 0)
+    assert open(out, "rb").read() == gold.text_gz(name + ".mag.gz")
+    o.close()
+
+
 @pytest.mark.parametrize("threads", [1, 5])
 def test_correct_phase2_reproduces_fermi_correct(gold, tmp_path, threads):
     """Host ec_fix (fermi_amd/host/correct_cmd.c) over the golden solid table == `fermi correct -t1`
