@@ -30,6 +30,7 @@ ABI_SYMBOLS = [
     "fmd_dev_malloc", "fmd_memcpy_h2d", "fmd_memcpy_d2h",
     "fmd_smem_work_bytes", "fmd_smem_dev", "fmd_smem_batch", "fmd_smem_win_dev", "fmd_smem_win_batch", "fmd_reach_dev", "fmd_reach_batch", "fmd_dev_export_bwt", "fmd_dev_check_rank",
     "fmd_kmer_work_bytes", "fmd_kmer_collect_dev", "fmd_kmer_collect",
+    "fmd_ectab_build_dev", "fmd_ectab_build", "fmd_ectab_free", "fmd_ecfix_work_bytes", "fmd_ecfix_dev", "fmd_ecfix_batch",
     "fmd_ovlp_work_bytes", "fmd_ovlp_dev", "fmd_ovlp_batch", "fmd_ovlp_check_left_dev", "fmd_seqinfo_dev", "fmd_seqinfo_batch",
     "fmd_ovlp_pack_max_bytes", "fmd_ovlp_pack_work_bytes", "fmd_ovlp_pack_dev", "fmd_ovlp_packed_batch", "fmd_ovlp_packed_free",
 ]
@@ -107,6 +108,12 @@ def _configure(L):
     L.fmd_dev_line_count.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
     L.fmd_ovlp_pack_max_bytes.restype = sz; L.fmd_ovlp_pack_max_bytes.argtypes = [sz, C.c_uint32, C.c_uint32]
     L.fmd_ovlp_pack_work_bytes.restype = sz; L.fmd_ovlp_pack_work_bytes.argtypes = [sz]
+    L.fmd_ectab_build_dev.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_uint64, vp, vp, vp, C.POINTER(vp)]
+    L.fmd_ectab_build.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, vp, vp, vp, C.POINTER(vp)]
+    L.fmd_ectab_free.restype = None; L.fmd_ectab_free.argtypes = [vp]
+    L.fmd_ecfix_work_bytes.restype = sz; L.fmd_ecfix_work_bytes.argtypes = [vp, sz, C.c_uint32]
+    L.fmd_ecfix_dev.argtypes = [vp, vp, sz, vp, vp, u64p, C.c_int, C.c_uint32, vp, vp, sz]
+    L.fmd_ecfix_batch.argtypes = [vp, sz, vp, vp, u64p, C.c_int, vp]
     L.fmd_ovlp_packed_batch.argtypes = [vp, vp, C.c_uint64, C.c_uint64, sz, C.c_int, C.c_uint32, C.c_uint32, C.c_int, vp, vp, C.c_uint32, vp]
     L.fmd_ovlp_packed_free.restype = None; L.fmd_ovlp_packed_free.argtypes = [vp, sz]
     L.fmd_ovlp_pack_dev.argtypes = [vp, vp, sz, vp, vp, C.c_uint32, vp, C.c_uint32, vp, vp, vp, C.c_uint64, vp, sz]

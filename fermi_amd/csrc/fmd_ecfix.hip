@@ -1,0 +1,448 @@
+// fmd_ecfix.hip -- the correction pass of `fermi correct` (ec_fix1 / ec_fix, correct.c:121-256) on the GPU.
+//
+// The reference corrects a read by a best-first search over partial paths: a path ends at some base of the read,
+// carries the k-mer that ends there, a score, and a back-pointer into a trace of the choices made.  The next path
+// to extend is the one with the smallest key
+//        score (16 bits) | trace index (32) | bases still ahead (16)          compared as a SIGNED 64-bit number
+// (correct.c:104, ku128_ylt mag.c:22).  Every path has its own trace index, so the order is total: any priority
+// queue pops the paths in the reference's order, and the result is a function of (read, qualities, table) alone.
+// That makes a read an independent work item -- one lane each, two passes (reverse-complement strand, then forward:
+// correct.c:237-243), refilled from a ticket queue as lanes finish (reads with errors take 10-100x the steps of clean
+// ones).  A lane's queue (<= 256 paths, correct.c:114) and trace live in its slice of an HBM work area; the table is
+// a device hash table with one 8-byte slot per solid k-mer: a look-up is ONE random 8-byte load where the host table
+// (sorted buckets) needs a search and the reference's khash two dependent ones.
+//
+// Nothing here touches the FMD index: the table is the output of fmd_kmer_collect_dev (fmd_kmer.hip).
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "fmd_kernel_common.h"
+
+// correct.c:112-119
+#define EC_RATIO_FACTOR 10
+#define EC_DIFF_FACTOR 13
+#define EC_MAX_HEAP 256
+#define EC_MAX_SC_DIFF 60
+#define EC_MAX_QUAL 40
+#define EC_MISS_PENALTY 10
+#define EC_MIN_OCC 5
+#define EC_MIN_OCC_RATIO 0.8
+#define EC_HEAP_SLOTS 264          // 256 + the slack of one expansion
+#define EC_INFO_TRACE_FULL 0x80000000u
+
+struct fmd_ectab {
+    int device, w, suf_len;
+    uint64_t n_slots;              // power of two
+    uint64_t *slots;               // device: kmer << 10 | val << 2 | best base, or EC_EMPTY
+    uint32_t *queue;               // device: ticket counter of the persistent kernel
+};
+#define EC_EMPTY (~0ull)
+
+__device__ __forceinline__ uint64_t ec_hash(uint64_t x)   // splitmix64 finaliser: the k-mers of a genome are anything but uniform
+{
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+
+__global__ void k_ectab_fill(uint64_t n, int suf_len, const uint32_t *__restrict__ bucket, const uint32_t *__restrict__ key, const uint8_t *__restrict__ val,
+                             uint64_t *__restrict__ slots, uint64_t mask)
+{
+    const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+        // the k-mer a look-up will present (correct.c:156-157): bucket = its low 2*suf_len bits, key >> 2 = the rest
+        const uint64_t x = (uint64_t)(key[i] >> 2) << (2 * suf_len) | bucket[i];
+        const uint64_t e = x << 10 | (uint64_t)val[i] << 2 | (key[i] & 3);
+        uint64_t p = ec_hash(x) & mask;
+        for (;;) {
+            const unsigned long long old = atomicCAS((unsigned long long *)(slots + p), (unsigned long long)EC_EMPTY, (unsigned long long)e);
+            if (old == EC_EMPTY) break;
+            p = (p + 1) & mask;
+        }
+    }
+}
+
+// kh_get(solid, h, key) of correct.c:156-157: -1, or val << 2 | best base
+__device__ __forceinline__ int ec_lookup(const uint64_t *__restrict__ slots, uint64_t mask, uint64_t x)
+{
+    uint64_t p = ec_hash(x) & mask;
+    for (;;) {
+        const uint64_t e = slots[p];
+        if (e == EC_EMPTY) return -1;
+        if ((e >> 10) == x) return (int)(e & 0x3ff);
+        p = (p + 1) & mask;
+    }
+}
+
+struct EcNode { uint64_t x; int64_t y; };
+
+// binary min-heap on y in the lane's slice (any queue gives the reference's order: the keys are distinct)
+__device__ __forceinline__ void ec_push(uint4 *heap, uint32_t &hn, uint64_t x, int64_t y)
+{
+    uint32_t k = hn++;
+    while (k) {
+        const uint32_t p = (k - 1) >> 1;
+        const uint4 v = heap[p];
+        const int64_t py = (int64_t)((uint64_t)v.w << 32 | v.z);
+        if (py <= y) break;
+        heap[k] = v; k = p;
+    }
+    heap[k] = make_uint4((uint32_t)x, (uint32_t)(x >> 32), (uint32_t)(uint64_t)y, (uint32_t)((uint64_t)y >> 32));
+}
+__device__ __forceinline__ EcNode ec_pop(uint4 *heap, uint32_t &hn)
+{
+    const uint4 top = heap[0];
+    EcNode r; r.x = (uint64_t)top.y << 32 | top.x; r.y = (int64_t)((uint64_t)top.w << 32 | top.z);
+    const uint4 last = heap[--hn];
+    const int64_t ly = (int64_t)((uint64_t)last.w << 32 | last.z);
+    uint32_t i = 0;
+    for (;;) {
+        uint32_t c = 2 * i + 1;
+        if (c >= hn) break;
+        uint4 cv = heap[c];
+        int64_t cy = (int64_t)((uint64_t)cv.w << 32 | cv.z);
+        if (c + 1 < hn) {
+            const uint4 dv = heap[c + 1];
+            const int64_t dy = (int64_t)((uint64_t)dv.w << 32 | dv.z);
+            if (dy < cy) { cv = dv; cy = dy; ++c; }
+        }
+        if (ly <= cy) break;
+        heap[i] = cv; i = c;
+    }
+    if (hn) heap[i] = last;
+    return r;
+}
+
+// One read, seen from one strand.  Pass 0 works on the reverse complement with the qualities reversed (correct.c:237-238):
+// logical position i is byte len-1-i, bases complemented; pass 1 is the read as stored.
+struct EcRead {
+    uint8_t *s, *q; int len; bool rc;
+    __device__ __forceinline__ int base(int i) const { const int c = s[rc ? len - 1 - i : i]; return rc ? comp6(c) : c; }
+    __device__ __forceinline__ void set_base(int i, int c) { s[rc ? len - 1 - i : i] = (uint8_t)(rc ? comp6(c) : c); }
+    __device__ __forceinline__ int qual(int i) const { return q[rc ? len - 1 - i : i]; }
+    __device__ __forceinline__ void set_qual(int i, int v) { q[rc ? len - 1 - i : i] = (uint8_t)v; }
+};
+
+// a new path: `par` extended by base code c (0..3; an N in the read is followed as A, correct.c:101) at a cost
+__device__ __forceinline__ bool ec_branch(uint4 *heap, uint32_t &hn, uint64_t *trace, uint32_t &tn, uint32_t trace_cap, const EcNode &par, int c, int cost,
+                                          int shift, int has_match)
+{
+    if (tn >= trace_cap) return false;
+    if (cost < 0) cost = 0;
+    if (c >= 4) c = 0;
+    const uint64_t py = (uint64_t)par.y, left = (py & 0xffff) - 1;
+    const uint64_t y = ((py >> 48) + (uint64_t)cost) << 48 | (uint64_t)tn << 16 | left;
+    trace[tn++] = left << 32 | (uint64_t)((uint32_t)c << 29 | (uint32_t)has_match << 28 | (uint32_t)(py >> 16)); // position | base | matched | parent
+    ec_push(heap, hn, (uint64_t)c << shift | par.x >> 2, (int64_t)y);
+    return true;
+}
+
+// price of leaving the read's base for the table's best one, from the packed depth byte (correct.c:164-171)
+__device__ __forceinline__ int ec_swap_penalty(int v)
+{
+    const int rest = v & 7, best = rest ? rest * (v >> 3) : v >> 3;
+    int p = (best - rest) * EC_DIFF_FACTOR;
+    if (best - rest < 1) p = 1;
+    const int by_ratio = rest ? (v >> 3) * EC_RATIO_FACTOR : 10000, by_rest = (7 - rest) * EC_DIFF_FACTOR;
+    p = p < by_ratio ? p : by_ratio;
+    p = p < by_rest ? p : by_rest;
+    return p < 1 ? 1 : p;
+}
+__device__ __forceinline__ int ec_depth(int v) { return (v & 7) ? (v & 7) * ((v >> 3) + 1) : v >> 3; }
+
+// ec_fix1 (correct.c:121-220) on the strand `r`, cut into the pieces a lane runs between two looks at the wave:
+// seed (the first path), one expansion of the best path, and the closing step (scores, trace applied to the read).
+struct EcSearch {
+    uint32_t hn, tn;           // paths in the queue, trace entries
+    int n_done, no_hits;
+    int64_t done_y[2];         // keys of the (up to two) best finished paths
+};
+enum { EC_MORE = 0, EC_DONE = 1, EC_FULL = 2 };
+
+__device__ __forceinline__ bool ec_seed(const EcRead &r, int w, EcSearch &S, uint4 *heap, uint64_t *trace)   // false: ec_fix1 returns 0xffff
+{
+    const int shift = (w - 1) << 1;
+    if (r.len <= w) return false;
+    uint64_t x = 0;
+    int i, l;
+    for (i = r.len - 1, l = 0; i > 0 && l < w; --i) {      // the k-mer at the end of the strand (windows restart after an N)
+        const int c = r.base(i);
+        if (c == 5) { x = 0; l = 0; }
+        else { x = (uint64_t)(c - 1) << shift | x >> 2; ++l; }
+    }
+    if (i == 0) return false;
+    S.hn = 0; S.tn = 0; S.n_done = 0; S.no_hits = 1; S.done_y[0] = S.done_y[1] = 0;
+    trace[S.tn++] = 0;
+    ec_push(heap, S.hn, x, (int64_t)(i + 1));
+    return true;
+}
+
+__device__ __forceinline__ int ec_expand(const EcRead &r, int w, int step, const uint64_t *__restrict__ slots, uint64_t mask, EcSearch &S, uint4 *heap,
+                                         uint64_t *trace, uint32_t trace_cap)
+{
+    const int shift = (w - 1) << 1;
+    if (S.hn == 0) return EC_DONE;
+    EcNode z = ec_pop(heap, S.hn);
+    const uint64_t zy = (uint64_t)z.y;
+    if ((zy & 0xffff) == 0) {                                // a path that reached the start of the strand
+        S.done_y[S.n_done++] = z.y;
+        return S.n_done == 2 ? EC_DONE : EC_MORE;
+    }
+    if (S.n_done && (int)(zy >> 48) > (int)((uint64_t)S.done_y[0] >> 48) + EC_MAX_SC_DIFF) return EC_DONE;
+    int i = (int)(zy & 0xffff) - 1, l;
+    const int b = r.base(i);
+    int q = r.qual(i) - 33;
+    q = q < EC_MAX_QUAL ? q : EC_MAX_QUAL;
+    q = q < 3 ? 3 : q;
+    const int hit = ec_lookup(slots, mask, z.x);
+    bool ok = true;
+    if (hit < 0) ok = ec_branch(heap, S.hn, trace, S.tn, trace_cap, z, b - 1, EC_MISS_PENALTY + (EC_MAX_QUAL - q), shift, 0);
+    else {
+        const int best = (hit & 3) + 1, v = hit >> 2;
+        S.no_hits = 0;
+        if (b != best) {                                     // the table prefers another base: follow both, within the queue's budget
+            const int pen = ec_swap_penalty(v);
+            if (b != 5 && (S.hn + 2 <= EC_MAX_HEAP || pen < q)) ok = ec_branch(heap, S.hn, trace, S.tn, trace_cap, z, b - 1, pen, shift, 1);
+            if (ok && (b == 5 || S.hn + 2 <= EC_MAX_HEAP || pen > q)) ok = ec_branch(heap, S.hn, trace, S.tn, trace_cap, z, best - 1, q, shift, 1);
+        } else {                                             // agreement: hop `step` bases at a time while the k-mers stay deep and unambiguous
+            EcNode keep = z;
+            int keep_i = i, depth_last = ec_depth(v);
+            if ((v & 7) <= 0 && step > 1) {
+                while (keep_i > 0) {
+                    for (i = (int)((uint64_t)z.y & 0xffff) - 1, l = 0; i >= 1 && l < step && r.base(i) < 5; --i, ++l)
+                        z.x = (uint64_t)(r.base(i) - 1) << shift | z.x >> 2;
+                    const int bi = r.base(i);
+                    if (bi == 5) break;
+                    const int h2 = ec_lookup(slots, mask, z.x);
+                    if (h2 < 0 || bi != (h2 & 3) + 1) break;
+                    const int v2 = h2 >> 2, depth = ec_depth(v2);
+                    if (!((v2 & 7) <= 1 && depth >= EC_MIN_OCC && (double)depth / depth_last >= EC_MIN_OCC_RATIO)) break;
+                    z.y = (int64_t)((uint64_t)z.y >> 16 << 16 | (uint64_t)(i + 1));
+                    keep = z; keep_i = i; depth_last = depth;
+                }
+            }
+            ok = ec_branch(heap, S.hn, trace, S.tn, trace_cap, keep, r.base(keep_i) - 1, 0, shift, 1);
+        }
+    }
+    return ok ? EC_MORE : EC_FULL;
+}
+
+__device__ __forceinline__ int ec_close(EcRead &r, const EcSearch &S, const uint64_t *trace)   // ec_fix1's return value; the read is rewritten
+{
+    int score_diff = S.n_done == 1 ? EC_MAX_SC_DIFF : (int)((uint64_t)S.done_y[1] >> 48) - (int)((uint64_t)S.done_y[0] >> 48);
+    if (score_diff >= EC_MAX_SC_DIFF) score_diff = EC_MAX_SC_DIFF;
+    if (((uint64_t)S.done_y[0] >> 48) == 0) return score_diff << 18;       // nothing to change
+    int qsum = 0;
+    for (uint32_t t = (uint32_t)((uint64_t)S.done_y[0] >> 16); t;) {       // apply the best path's choices
+        const uint64_t e = trace[t];
+        const int pos = (int)(e >> 32);
+        const uint32_t lo = (uint32_t)e, c = lo >> 29;
+        if ((uint32_t)(r.base(pos) - 1) != c) { qsum += r.qual(pos) - 33; r.set_base(pos, (int)c + 1); }
+        else if ((lo >> 28 & 1) && r.qual(pos) < 37) r.set_qual(pos, 37);
+        t = lo << 4 >> 4;
+    }
+    return qsum | score_diff << 18 | S.no_hits << 17;
+}
+
+// One lane = one read at a time, one expansion per turn of the wave's loop; a lane whose read is finished draws the next
+// one at once (reads with errors take 10-100x the expansions of clean ones: a wave never waits for its slowest read).
+__global__ __launch_bounds__(64) void k_ecfix(size_t n, uint8_t *__restrict__ seqs, uint8_t *__restrict__ quals, const uint64_t *__restrict__ off, int w, int step,
+                                              const uint64_t *__restrict__ slots, uint64_t mask, int32_t *__restrict__ info, uint4 *heaps, uint64_t *traces,
+                                              uint32_t trace_cap, uint32_t *__restrict__ queue)
+{
+    const size_t slice = (size_t)blockIdx.x * 64 + threadIdx.x;
+    uint4 *heap = heaps + slice * EC_HEAP_SLOTS;
+    uint64_t *trace = traces + slice * (size_t)trace_cap;
+    EcRead r; r.s = nullptr; r.q = nullptr; r.len = 0; r.rc = true;
+    EcSearch S; S.hn = S.tn = 0; S.n_done = 0; S.no_hits = 1; S.done_y[0] = S.done_y[1] = 0;
+    size_t cur = 0;
+    int ret0 = 0;
+    bool busy = false, drained = false;
+    FmdTickets tk;
+    fmd_tickets_init(tk, queue);
+    for (;;) {
+        const size_t my = fmd_tickets_take(tk, queue, !busy && !drained);
+        if (!busy && !drained) {
+            if (my < n) {
+                cur = my;
+                r.s = seqs + off[my]; r.q = quals + off[my]; r.len = (int)(off[my + 1] - off[my]); r.rc = true;
+                if (ec_seed(r, w, S, heap, trace)) busy = true;
+                else info[my] = 0xffff;                                    // too short, or no clean k-mer (correct.c:242-246)
+            } else drained = true;
+        }
+        if (__ballot(busy) == 0) { if (__ballot(!drained) == 0) break; else continue; }
+        if (!busy) continue;
+        const int st = ec_expand(r, w, step, slots, mask, S, heap, trace, trace_cap);
+        if (st == EC_MORE) continue;
+        if (st == EC_FULL) { info[cur] = (int32_t)EC_INFO_TRACE_FULL; busy = false; continue; }
+        int ret = ec_close(r, S, trace);
+        if (r.rc) {                                                        // the reverse-complement strand is done: now the read as given
+            ret0 = ret;
+            r.rc = false;
+            if (ec_seed(r, w, S, heap, trace)) continue;
+            ret = 0xffff;                                                  // no clean k-mer at this end: ec_fix1 returns 0xffff and ec_fix combines it all the same
+        }
+        {
+            int out = ((ret0 & 0xffff) + (ret & 0xffff)) | ((ret0 >> 18 < ret >> 18 ? ret0 >> 18 : ret >> 18) << 18);
+            if ((ret0 >> 17 & 1) && (ret >> 17 & 1)) out |= 1 << 16;
+            info[cur] = out;
+            busy = false;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host entries
+extern "C" void fmd_ectab_free(fmd_ectab_t *t)
+{
+    if (!t) return;
+    hipSetDevice(t->device);
+    hipFree(t->slots); hipFree(t->queue);
+    free(t);
+}
+
+extern "C" int fmd_ectab_build_dev(int device, void *stream_, int w, int suf_len, uint64_t n, const uint32_t *d_bucket, const uint32_t *d_key,
+                                   const uint8_t *d_val, fmd_ectab_t **out)
+{
+    if (!out || w < 2 || w > 27 || suf_len < 1 || 2 * w - 2 * suf_len > 30 || (n && (!d_bucket || !d_key || !d_val))) return FMD_E_ARG;
+    if (fmd_device_count() <= 0) return FMD_E_NODEV;
+    FMD_HIP_TRY(hipSetDevice(device));
+    fmd_ectab *t = (fmd_ectab *)calloc(1, sizeof(fmd_ectab));
+    if (!t) return FMD_E_NOMEM;
+    t->device = device; t->w = w; t->suf_len = suf_len;
+    t->n_slots = 1024;
+    while (t->n_slots < 2 * n) t->n_slots <<= 1;              // load factor <= 1/2
+    hipStream_t st = (hipStream_t)stream_;
+    if (hipMalloc((void **)&t->slots, t->n_slots * 8) != hipSuccess || hipMalloc((void **)&t->queue, 64) != hipSuccess) {
+        fmd_set_hip_error(hipGetLastError(), "hipMalloc(k-mer table)");
+        fmd_ectab_free(t);
+        return FMD_E_NOMEM;
+    }
+    FMD_HIP_TRY(hipMemsetAsync(t->slots, 0xff, t->n_slots * 8, st));
+    if (n) {
+        size_t blocks = (size_t)((n + 255) / 256);
+        if (blocks > (1u << 20)) blocks = 1u << 20;
+        k_ectab_fill<<<(unsigned)blocks, 256, 0, st>>>(n, suf_len, d_bucket, d_key, d_val, t->slots, t->n_slots - 1);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fmd_set_hip_error(e, "k_ectab_fill"); fmd_ectab_free(t); return FMD_E_HIP; }
+    *out = t;
+    return FMD_OK;
+}
+
+extern "C" int fmd_ectab_build(int device, int w, int suf_len, uint64_t n, const uint32_t *bucket, const uint32_t *key, const uint8_t *val, fmd_ectab_t **out)
+{
+    if (n && (!bucket || !key || !val)) return FMD_E_ARG;
+    if (fmd_device_count() <= 0) return FMD_E_NODEV;
+    FMD_HIP_TRY(hipSetDevice(device));
+    void *db = nullptr, *dk = nullptr, *dv = nullptr;
+    int rc = FMD_OK;
+    if (hipMalloc(&db, n * 4 + 16) != hipSuccess || hipMalloc(&dk, n * 4 + 16) != hipSuccess || hipMalloc(&dv, n + 16) != hipSuccess) rc = FMD_E_NOMEM;
+    if (rc == FMD_OK && n && (hipMemcpy(db, bucket, n * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dk, key, n * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                              hipMemcpy(dv, val, n, hipMemcpyHostToDevice) != hipSuccess)) rc = FMD_E_HIP;
+    if (rc == FMD_OK) rc = fmd_ectab_build_dev(device, nullptr, w, suf_len, n, (uint32_t *)db, (uint32_t *)dk, (uint8_t *)dv, out);
+    if (rc == FMD_OK && hipDeviceSynchronize() != hipSuccess) { rc = FMD_E_HIP; fmd_ectab_free(*out); *out = nullptr; }
+    hipFree(db); hipFree(dk); hipFree(dv);
+    return rc;
+}
+
+static int ec_grid(int device, size_t n)
+{
+    hipDeviceProp_t prop;
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
+    size_t waves = (size_t)cus * 16, need = (n + 63) / 64;
+    return (int)(need < waves ? (need ? need : 1) : waves);
+}
+
+extern "C" size_t fmd_ecfix_work_bytes(const fmd_ectab_t *t, size_t n, uint32_t trace_cap)
+{
+    if (!t) return 0;
+    const size_t lanes = (size_t)ec_grid(t->device, n) * 64;
+    return lanes * (EC_HEAP_SLOTS * sizeof(uint4) + (size_t)trace_cap * 8) + 256;
+}
+
+extern "C" int fmd_ecfix_dev(fmd_ectab_t *t, void *stream_, size_t n, uint8_t *d_seqs, uint8_t *d_quals, const uint64_t *d_off, int step, uint32_t trace_cap,
+                             int32_t *d_info, void *d_work, size_t work_bytes)
+{
+    if (!t || (n && (!d_seqs || !d_quals || !d_off || !d_info || !d_work)) || trace_cap < 16) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    if (n >= 0xffffff00ull || work_bytes < fmd_ecfix_work_bytes(t, n, trace_cap)) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(t->device));
+    hipStream_t st = (hipStream_t)stream_;
+    const int grid = ec_grid(t->device, n);
+    uint4 *heaps = (uint4 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
+    uint64_t *traces = (uint64_t *)(heaps + (size_t)grid * 64 * EC_HEAP_SLOTS);
+    FMD_HIP_TRY(hipMemsetAsync(t->queue, 0, 4, st));
+    k_ecfix<<<grid, 64, 0, st>>>(n, d_seqs, d_quals, d_off, t->w, step, t->slots, t->n_slots - 1, d_info, heaps, traces, trace_cap, t->queue);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fmd_set_hip_error(e, "k_ecfix"); return FMD_E_HIP; }
+    return FMD_OK;
+}
+
+// Host form: reads whose trace overflows are run again, from their original bytes, with the trace doubled.
+extern "C" int fmd_ecfix_batch(fmd_ectab_t *t, size_t n, uint8_t *seqs, uint8_t *quals, const uint64_t *off, int step, int32_t *info)
+{
+    if (!t || (n && (!seqs || !quals || !off || !info))) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    FMD_HIP_TRY(hipSetDevice(t->device));
+    const uint64_t total = off[n] - off[0];
+    uint32_t cap = 1024;
+    void *ds = nullptr, *dq = nullptr, *doff = nullptr, *dinfo = nullptr, *dwork = nullptr;
+    int rc = FMD_OK;
+    if (hipMalloc(&ds, total + 16) != hipSuccess || hipMalloc(&dq, total + 16) != hipSuccess || hipMalloc(&doff, (n + 1) * 8) != hipSuccess ||
+        hipMalloc(&dinfo, n * 4) != hipSuccess) rc = FMD_E_NOMEM;
+    uint64_t *rel = nullptr;   // offsets relative to the first read
+    if (rc == FMD_OK) {
+        rel = (uint64_t *)malloc((n + 1) * 8);
+        if (!rel) rc = FMD_E_NOMEM;
+        else for (size_t i = 0; i <= n; ++i) rel[i] = off[i] - off[0];
+    }
+    uint8_t *s0 = seqs + off[0], *q0 = quals + off[0];
+    if (rc == FMD_OK && (hipMemcpy(ds, s0, total, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dq, q0, total, hipMemcpyHostToDevice) != hipSuccess ||
+                         hipMemcpy(doff, rel, (n + 1) * 8, hipMemcpyHostToDevice) != hipSuccess)) rc = FMD_E_HIP;
+    std::vector<uint8_t> keep_s, keep_q;   // originals, for the re-runs (allocated only if one is needed)
+    if (rc == FMD_OK) {
+        const size_t wb = fmd_ecfix_work_bytes(t, n, cap);
+        if (hipMalloc(&dwork, wb) != hipSuccess) rc = FMD_E_NOMEM;
+        if (rc == FMD_OK) { keep_s.assign(s0, s0 + total); keep_q.assign(q0, q0 + total); }
+        if (rc == FMD_OK) rc = fmd_ecfix_dev(t, nullptr, n, (uint8_t *)ds, (uint8_t *)dq, (uint64_t *)doff, step, cap, (int32_t *)dinfo, dwork, wb);
+        if (rc == FMD_OK && (hipMemcpy(s0, ds, total, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(q0, dq, total, hipMemcpyDeviceToHost) != hipSuccess ||
+                             hipMemcpy(info, dinfo, n * 4, hipMemcpyDeviceToHost) != hipSuccess)) rc = FMD_E_HIP;
+        hipFree(dwork); dwork = nullptr;
+    }
+    // re-runs
+    for (int attempt = 0; rc == FMD_OK && attempt < 12; ++attempt) {
+        std::vector<size_t> again;
+        for (size_t i = 0; i < n; ++i) if ((uint32_t)info[i] == EC_INFO_TRACE_FULL) again.push_back(i);
+        if (again.empty()) break;
+        cap *= 4;
+        const size_t m = again.size();
+        std::vector<uint64_t> o2(m + 1, 0);
+        for (size_t k = 0; k < m; ++k) o2[k + 1] = o2[k] + (rel[again[k] + 1] - rel[again[k]]);
+        std::vector<uint8_t> s2(o2[m] + 16), q2(o2[m] + 16);
+        for (size_t k = 0; k < m; ++k) {
+            memcpy(s2.data() + o2[k], keep_s.data() + rel[again[k]], o2[k + 1] - o2[k]);
+            memcpy(q2.data() + o2[k], keep_q.data() + rel[again[k]], o2[k + 1] - o2[k]);
+        }
+        std::vector<int32_t> i2(m);
+        const size_t wb = fmd_ecfix_work_bytes(t, m, cap);
+        if (hipMalloc(&dwork, wb) != hipSuccess) { rc = FMD_E_NOMEM; break; }
+        if (hipMemcpy(ds, s2.data(), o2[m], hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dq, q2.data(), o2[m], hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(doff, o2.data(), (m + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) rc = FMD_E_HIP;
+        if (rc == FMD_OK) rc = fmd_ecfix_dev(t, nullptr, m, (uint8_t *)ds, (uint8_t *)dq, (uint64_t *)doff, step, cap, (int32_t *)dinfo, dwork, wb);
+        if (rc == FMD_OK && (hipMemcpy(s2.data(), ds, o2[m], hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(q2.data(), dq, o2[m], hipMemcpyDeviceToHost) != hipSuccess ||
+                             hipMemcpy(i2.data(), dinfo, m * 4, hipMemcpyDeviceToHost) != hipSuccess)) rc = FMD_E_HIP;
+        hipFree(dwork); dwork = nullptr;
+        if (rc != FMD_OK) break;
+        for (size_t k = 0; k < m; ++k) {
+            info[again[k]] = i2[k];
+            if ((uint32_t)i2[k] == EC_INFO_TRACE_FULL) continue;
+            memcpy(s0 + rel[again[k]], s2.data() + o2[k], o2[k + 1] - o2[k]);
+            memcpy(q0 + rel[again[k]], q2.data() + o2[k], o2[k + 1] - o2[k]);
+        }
+    }
+    if (rc == FMD_OK) for (size_t i = 0; i < n; ++i) if ((uint32_t)info[i] == EC_INFO_TRACE_FULL) { rc = FMD_E_OVERFLOW; break; }
+    free(rel);
+    hipFree(ds); hipFree(dq); hipFree(doff); hipFree(dinfo); hipFree(dwork);
+    return rc;
+}

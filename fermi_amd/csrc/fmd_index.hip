@@ -557,6 +557,7 @@ extern "C" void fmd_dev_close(fmd_dev_t *h)
     hipFree(h->ptab);
     hipFree(h->queues);
     hipFree(h->stat);
+    for (size_t i = 0; i < sizeof(h->scratch) / sizeof(h->scratch[0]); ++i) if (h->scratch[i].p) hipFree(h->scratch[i].p);
     if (h->aux_ready) {
         hipStreamDestroy(h->aux_stream);
         for (int i = 0; i <= FMD_OVLP_MAX_PARTS; ++i) hipEventDestroy(h->aux_ev[i]);
@@ -619,6 +620,48 @@ extern "C" int fmd_dev_sync(const fmd_dev_t *h, void *stream)
     if (!h) return FMD_E_ARG;
     FMD_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return FMD_OK;
+}
+
+static void scratch_lock(fmd_dev *h) { int e = 0; while (!__atomic_compare_exchange_n(&h->scratch_lock, &e, 1, false, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED)) e = 0; }
+static void scratch_unlock(fmd_dev *h) { __atomic_store_n(&h->scratch_lock, 0, __ATOMIC_RELEASE); }
+void *fmd_scratch_acquire(fmd_dev *h, size_t bytes)
+{
+    const int N = (int)(sizeof(h->scratch) / sizeof(h->scratch[0]));
+    if (bytes == 0) bytes = 16;
+    scratch_lock(h);
+    int best = -1, empty = -1, victim = -1;
+    for (int i = 0; i < N; ++i) {
+        if (!h->scratch[i].p) { if (empty < 0) empty = i; continue; }
+        if (h->scratch[i].busy) continue;
+        if (h->scratch[i].bytes >= bytes && (best < 0 || h->scratch[i].bytes < h->scratch[best].bytes)) best = i;
+        if (victim < 0 || h->scratch[i].bytes < h->scratch[victim].bytes) victim = i;
+    }
+    if (best >= 0 && h->scratch[best].bytes <= 2 * bytes + ((size_t)64 << 20)) { // do not hand a 26 GB buffer to a 1 MB request
+        h->scratch[best].busy = 1;
+        void *p = h->scratch[best].p;
+        scratch_unlock(h);
+        return p;
+    }
+    if (empty < 0 && victim >= 0) { hipFree(h->scratch[victim].p); h->scratch[victim].p = nullptr; empty = victim; } // table full: drop the smallest idle one
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        for (int i = 0; i < N; ++i) if (h->scratch[i].p && !h->scratch[i].busy) { hipFree(h->scratch[i].p); h->scratch[i].p = nullptr; if (empty < 0) empty = i; } // make room, try once more
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+    }
+    if (p && empty >= 0) { h->scratch[empty].p = p; h->scratch[empty].bytes = bytes; h->scratch[empty].busy = 1; }
+    else if (p) { /* no slot: an untracked buffer, freed on release */ }
+    scratch_unlock(h);
+    return p;
+}
+void fmd_scratch_release(fmd_dev *h, void *p)
+{
+    if (!p) return;
+    const int N = (int)(sizeof(h->scratch) / sizeof(h->scratch[0]));
+    scratch_lock(h);
+    for (int i = 0; i < N; ++i) if (h->scratch[i].p == p) { h->scratch[i].busy = 0; scratch_unlock(h); return; }
+    scratch_unlock(h);
+    hipFree(p);
 }
 
 uint32_t *fmd_next_queue(fmd_dev *h, hipStream_t stream)

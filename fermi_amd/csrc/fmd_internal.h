@@ -21,6 +21,10 @@ struct fmd_dev {
     unsigned long long *stat; // device: FMD_STAT_SLOTS x FMD_STAT_STRIDE line counters (written by the instrumented build only)
     // second stream + events of the pipelined overlap batch (fmd_ovlp_dev), created on first use;
     // aux_busy (atomic) lets one call at a time use them, a concurrent call takes the serial path
+    // device buffers kept between host-form calls (fmd_scratch_*): hipFree + hipMalloc of tens of GB per call cost
+    // 1-2 s (`unitig` on 10 M reads: 1.05 s of a 1.2 s table pass); released by fmd_dev_close
+    struct { void *p; size_t bytes; int busy; } scratch[24];
+    int scratch_lock;
     hipStream_t aux_stream;
     hipEvent_t aux_ev[FMD_OVLP_MAX_PARTS + 1];
     int aux_ready, aux_busy;
@@ -49,6 +53,11 @@ static inline FmdIndexView fmd_view(const fmd_dev *h)
     v.stat = h->stat;
     return v;
 }
+
+// A device buffer of at least `bytes` from the handle's cache (hipMalloc when none fits); give it back with
+// fmd_scratch_release.  Thread-safe; nullptr when the device is out of memory.
+void *fmd_scratch_acquire(fmd_dev *h, size_t bytes);
+void fmd_scratch_release(fmd_dev *h, void *p);
 
 // next zeroed work-queue head for a persistent launch on `stream`
 uint32_t *fmd_next_queue(fmd_dev *h, hipStream_t stream);

@@ -134,10 +134,11 @@ __global__ void k_fill_ids(size_t n, uint64_t first, uint64_t step, uint64_t *id
 }
 
 namespace {
-struct DevMem {
+struct DevMem { // from the handle's buffer cache: the same sizes come back call after call
+    fmd_dev *h = nullptr;
     void *p = nullptr;
-    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? FMD_OK : FMD_E_NOMEM; }
-    ~DevMem() { if (p) hipFree(p); }
+    int alloc(fmd_dev *h_, size_t bytes) { h = h_; p = fmd_scratch_acquire(h, bytes); return p ? FMD_OK : FMD_E_NOMEM; }
+    ~DevMem() { if (p) fmd_scratch_release(h, p); }
 };
 struct Stream {
     hipStream_t s = nullptr;
@@ -180,10 +181,10 @@ extern "C" int fmd_ovlp_packed_batch(fmd_dev_t *h, const uint64_t *ids, uint64_t
     DevMem d_ids, d_rec, d_nei, d_seq, d_work, d_prec[2], d_off[2], d_var[2];
     Stream s_cmp, s_cpy;
     Event done[2], copied[2];
-    if (d_ids.alloc(m * 8) || d_rec.alloc(m * sizeof(fmd_ovlp_rec_t)) || d_nei.alloc(m * max_nei * sizeof(fmd_intv_t)) || d_seq.alloc(m * (size_t)stride) ||
-        d_work.alloc(wb)) return FMD_E_NOMEM;
+    if (d_ids.alloc(h, m * 8) || d_rec.alloc(h, m * sizeof(fmd_ovlp_rec_t)) || d_nei.alloc(h, m * max_nei * sizeof(fmd_intv_t)) || d_seq.alloc(h, m * (size_t)stride) ||
+        d_work.alloc(h, wb)) return FMD_E_NOMEM;
     for (int k = 0; k < 2; ++k)
-        if (d_prec[k].alloc(m * sizeof(fmd_ovlp_rec_t)) || d_off[k].alloc((m + 1) * 8) || d_var[k].alloc(cap) || done[k].make() || copied[k].make()) return FMD_E_NOMEM;
+        if (d_prec[k].alloc(h, m * sizeof(fmd_ovlp_rec_t)) || d_off[k].alloc(h, (m + 1) * 8) || d_var[k].alloc(h, cap) || done[k].make() || copied[k].make()) return FMD_E_NOMEM;
     if (s_cmp.make() || s_cpy.make()) return FMD_E_HIP;
     Pinned pin_rec, pin_off;
     pin_rec.pin(rec, n * sizeof(fmd_ovlp_rec_t));

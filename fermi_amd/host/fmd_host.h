@@ -128,10 +128,11 @@ int fmdh_build(const char *fa_path, const char *out_path, int device, int max_le
 /* `fermi correct` (cmd.c:253-291, correct.c:305-456); defaults = cmd.c:258 */
 typedef struct { int w, min_occ, keep_bad, is_paired, trim_l, step; float max_corr; } fmdh_ecopt_t; /* = fmecopt_t, fermi.h:26-29 */
 int fmdh_correct(const char *fmd_path, const char *fq_path, int device, fmdh_ecopt_t *opt, FILE *out);
-void fmdh_correct_set_threads(int n);                                        /* `-t`: ec_fix worker threads (output independent of n) */
+void fmdh_correct_set_threads(int n);                                        /* `-t`: host threads of the marking pass (output independent of n) */
 int fmdh_correct_kmer(uint64_t n_symbols);                                   /* automatic k, correct.c:313-318 */
-/* phase 2 only (ec_fix, correct.c:121-256) against an already harvested (bucket, key, val) table */
-int fmdh_correct_reads(const fmdh_ecopt_t *opt, int suf_len, uint64_t n, const uint32_t *bucket, const uint32_t *key,
+/* phase 2 only (ec_fix on the GPU, fmd_ecfix_batch; marking, filtering and printing on the host) against an already
+ * harvested (bucket, key, val) table */
+int fmdh_correct_reads(const fmdh_ecopt_t *opt, int device, int suf_len, uint64_t n, const uint32_t *bucket, const uint32_t *key,
                        const uint8_t *val, const char *fq_path, FILE *out);
 
 #ifdef __cplusplus

@@ -35,7 +35,7 @@ def lib():
             _fields_ = [("w", C.c_int), ("min_occ", C.c_int), ("keep_bad", C.c_int), ("is_paired", C.c_int), ("trim_l", C.c_int),
                         ("step", C.c_int), ("max_corr", C.c_float)]
         L.EcOpt = EcOpt
-        L.fmdh_correct_reads.argtypes = [C.POINTER(EcOpt), C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p]
+        L.fmdh_correct_reads.argtypes = [C.POINTER(EcOpt), C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p]
         L.fmdh_correct_kmer.argtypes = [C.c_uint64]
         class RemapOpt(C.Structure):
             _fields_ = [("skip", C.c_int), ("min_pcv", C.c_int), ("max_dist", C.c_int)]
@@ -136,15 +136,15 @@ def unitig(fmd_path, min_match, out_path, devices=(0,)):
         raise RuntimeError("fmdh_unitig failed")
 
 
-def correct_reads(w, min_occ, bucket, key, val, fq_path, out_path, step=5, max_corr=0.3):
-    """ec_fix phase of `fermi correct` against a harvested solid-k-mer table (host only)."""
+def correct_reads(w, min_occ, bucket, key, val, fq_path, out_path, step=5, max_corr=0.3, device=0):
+    """ec_fix phase of `fermi correct` against a harvested solid-k-mer table (GPU correction pass + host marking/printing)."""
     L = lib()
     opt = L.EcOpt(w, min_occ, 0, 0, 0, step, max_corr)
     bucket = np.ascontiguousarray(bucket, dtype=np.uint32); key = np.ascontiguousarray(key, dtype=np.uint32)
     val = np.ascontiguousarray(val, dtype=np.uint8)
     fp = _libc.fopen(out_path.encode(), b"wb")
     try:
-        rc = L.fmdh_correct_reads(C.byref(opt), w - 15 if w > 15 else 1, len(key), bucket.ctypes.data, key.ctypes.data, val.ctypes.data,
+        rc = L.fmdh_correct_reads(C.byref(opt), device, w - 15 if w > 15 else 1, len(key), bucket.ctypes.data, key.ctypes.data, val.ctypes.data,
                                   fq_path.encode(), fp)
     finally:
         _libc.fclose(fp)

@@ -188,11 +188,13 @@ static inline int fmd_lfork_decide(uint16_t lfork, int rbeg) /* 0 / -1 as check_
     if (rbeg <= r || r == (int)FMD_LFORK_ALL) return 0;
     return (lfork & 0x8000) ? -1 : 1;
 }
-/* capacity of the per-strand candidate lists kept in the work area */
+/* capacity of the per-strand candidate lists kept in the work area: overlap_intv (unitig.c:47-58) pushes at most one
+ * interval per suffix longer than min_match, and a round of fm6_get_nei keeps more children than it had parents only
+ * where the read set forks -- a strand that needs more sets FMD_OVLP_F_OVERFLOW and is re-run with larger capacities */
 static inline uint32_t fmd_ovlp_list_cap(uint32_t max_len, int min_match)
 {
     uint32_t d = max_len > (uint32_t)min_match ? max_len - (uint32_t)min_match : 1;
-    return 2 * d < 16 ? 16 : 2 * d;
+    return d + 8 < 16 ? 16 : d + 8;
 }
 size_t fmd_ovlp_work_bytes(size_t n, uint32_t max_len, int min_match);
 /* d_nei: n x max_nei neighbours {x[0], x[1], x[2] of `$neighbour$`, info = overlap length};
@@ -270,6 +272,25 @@ int fmd_kmer_collect_dev(fmd_dev_t *h, void *stream, int w, int min_occ, int suf
                          uint64_t cap, uint32_t *d_bucket, uint32_t *d_key, uint8_t *d_val, uint64_t *d_status);
 int fmd_kmer_collect(fmd_dev_t *h, int w, int min_occ, int suf_len, uint32_t **bucket, uint32_t **key, uint8_t **val,
                      uint64_t *n, int64_t cnt[2]);   /* outputs malloc'ed: fmd_host_free() */
+
+/* ---- the correction pass of `fermi correct`: ec_fix1 / ec_fix (correct.c:121-256) ------------------------------
+ * The table is what fmd_kmer_collect* returns (one triple per solid k-mer, any order), loaded into a device hash
+ * table: a look-up kh_get(solid[x & (SUF_NUM-1)], x >> 2*SUF_LEN << 2) (correct.c:156-157) is one 8-byte load.
+ * fmd_ecfix_*: read i = bytes [off[i], off[i+1]) of seqs (nt6 codes) and quals (phred + 33).  Both are rewritten in
+ * place exactly as ec_fix leaves str.s and qual[i] after its two ec_fix1 passes (correct.c:237-243); info[i] = the
+ * value ec_fix holds at correct.c:246, before the lower-case count (correct.c:247-252, host).  A lane keeps its best-
+ * first queue (<= 256 paths, correct.c:114) and its trace in d_work; a read whose trace exceeds trace_cap gets
+ * info = FMD_ECFIX_TRACE_FULL and must be run again FROM ITS ORIGINAL BYTES with a larger cap (the host form does). */
+typedef struct fmd_ectab fmd_ectab_t;
+#define FMD_ECFIX_TRACE_FULL ((int32_t)0x80000000)
+int fmd_ectab_build_dev(int device, void *stream, int w, int suf_len, uint64_t n, const uint32_t *d_bucket, const uint32_t *d_key,
+                        const uint8_t *d_val, fmd_ectab_t **out);
+int fmd_ectab_build(int device, int w, int suf_len, uint64_t n, const uint32_t *bucket, const uint32_t *key, const uint8_t *val, fmd_ectab_t **out);
+void fmd_ectab_free(fmd_ectab_t *t);
+size_t fmd_ecfix_work_bytes(const fmd_ectab_t *t, size_t n, uint32_t trace_cap);
+int fmd_ecfix_dev(fmd_ectab_t *t, void *stream, size_t n, uint8_t *d_seqs, uint8_t *d_quals, const uint64_t *d_off, int step, uint32_t trace_cap,
+                  int32_t *d_info, void *d_work, size_t work_bytes);
+int fmd_ecfix_batch(fmd_ectab_t *t, size_t n, uint8_t *seqs, uint8_t *quals, const uint64_t *off, int step, int32_t *info);
 
 /* ---- fm6_retrieve (exact.c:100-127) in bulk: rank, `$read$` bi-interval and containment of each
  * sequence id (rec.rank, rec.k[], rec.status = -3 when contained, rec.len); no length threshold,

@@ -67,6 +67,10 @@ def lib():
         L.orc_get_nei.argtypes = [P, C.c_int, C.c_int, C.POINTER(StrT), C.POINTER(IntvV), C.POINTER(IntvV), C.POINTER(IntvV)]
         L.orc_overlap_batch.argtypes = [P, C.c_size_t, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int]
         L.orc_ec_collect.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(SolidT)]
+        L.orc_ectab_new.restype = C.c_void_p
+        L.orc_ectab_new.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_ectab_free.argtypes = [C.c_void_p]
+        L.orc_ecfix_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -241,3 +245,22 @@ class OrcIndex:
             out.append((k, v))
             cnt[0] += so.cnt[0]; cnt[1] += so.cnt[1]
         return out, cnt
+
+
+def ec_fix(w, bucket, key, val, seqs_nt6, quals, step=5):
+    """ec_fix (correct.c:232-246) of a list of reads against a (bucket, key, val) table: lists of corrected nt6 arrays
+    and qualities (phred + 33 bytes) and the info array -- the contract of fmd_ecfix_batch (include/fmd_hip.h)."""
+    L = lib()
+    suf_len = w - 15 if w > 15 else 1
+    bucket = np.ascontiguousarray(bucket, dtype=np.uint32); key = np.ascontiguousarray(key, dtype=np.uint32); val = np.ascontiguousarray(val, dtype=np.uint8)
+    t = L.orc_ectab_new(suf_len, len(key), bucket.ctypes.data, key.ctypes.data, val.ctypes.data)
+    assert t
+    n = len(seqs_nt6)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum([len(x) for x in seqs_nt6], out=off[1:])
+    s = np.concatenate([np.asarray(x, dtype=np.uint8) for x in seqs_nt6] + [np.zeros(8, np.uint8)])
+    q = np.concatenate([np.asarray(x, dtype=np.uint8) for x in quals] + [np.zeros(8, np.uint8)])
+    info = np.zeros(n, dtype=np.int32)
+    L.orc_ecfix_batch(t, w, step, n, s.ctypes.data, q.ctypes.data, off.ctypes.data, info.ctypes.data)
+    L.orc_ectab_free(t)
+    return s[: int(off[n])], q[: int(off[n])], off, info

@@ -393,8 +393,84 @@ def test_lfork_never_claims_more_than_the_truth_and_decides_check_left(gpu, gold
             else:
                 assert dec == (-1 if r["reserved"] == 1 else 0), (name, i)
             assert _lfork_decide(w_rec[row2]["lfork"], int(r["rbeg"])) == (-1 if r["reserved"] == 1 else 0)   # the exact value decides every edge
-    assert edges > 100 and undecided <= 0.05 * edges, (edges, undecided)
+    # what is left goes to fmd_ovlp_check_left_dev: few on ordinary reads, more where the read set forks or holds contained reads
+    assert edges > 100 and undecided <= (0.05 if name == "tiny" else 0.3) * edges, (edges, undecided)
     d.close(); o.close()
+
+
+def _ecfix_gpu(gpu, w, bucket, key, val, seqs_nt6, quals, step=5):
+    import ctypes as C
+    L = gpu.lib()
+    bucket = np.ascontiguousarray(bucket, dtype=np.uint32); key = np.ascontiguousarray(key, dtype=np.uint32); val = np.ascontiguousarray(val, dtype=np.uint8)
+    t = C.c_void_p()
+    gpu.check(L.fmd_ectab_build(0, w, w - 15 if w > 15 else 1, len(key), bucket.ctypes.data, key.ctypes.data, val.ctypes.data, C.byref(t)))
+    n = len(seqs_nt6)
+    off = np.zeros(n + 1, dtype=U64)
+    np.cumsum([len(x) for x in seqs_nt6], out=off[1:])
+    s = np.concatenate([np.asarray(x, dtype=np.uint8) for x in seqs_nt6] + [np.zeros(8, np.uint8)])
+    q = np.concatenate([np.asarray(x, dtype=np.uint8) for x in quals] + [np.zeros(8, np.uint8)])
+    info = np.zeros(n, dtype=np.int32)
+    gpu.check(L.fmd_ecfix_batch(t, n, s.ctypes.data, q.ctypes.data, off.ctypes.data, step, info.ctypes.data))
+    L.fmd_ectab_free(t)
+    return s[: int(off[n])], q[: int(off[n])], off, info
+
+
+@pytest.mark.parametrize("step", [5, 0, 2])
+def test_ecfix_kernel_equals_oracle_and_fermi_correct(gpu, gold, oracle_lib, step):
+    """fmd_ecfix_batch (ec_fix1 / ec_fix on the GPU: one lane per read, device hash table, its own queue) == the oracle's
+    statement of correct.c:121-246 on corrected bases, qualities and info words of every read of tiny.fq; with the
+    default step the marked and filtered FASTQ is `fermi correct -t1`'s."""
+    from test_oracle_golden import _fastq_records, finish_correct
+    v = gold.npz("tiny_solid.npz")
+    recs = _fastq_records(gold.text_gz("tiny.fq.gz"))
+    nt6 = gold.fastq_nt6("tiny.fq.gz")
+    quals = [np.frombuffer(r[2], dtype=np.uint8) for r in recs]
+    g = _ecfix_gpu(gpu, 17, v["w17_o3_bucket"], v["w17_o3_key"], v["w17_o3_val"], nt6, quals, step)
+    w = orcbind.ec_fix(17, v["w17_o3_bucket"], v["w17_o3_key"], v["w17_o3_val"], nt6, quals, step)
+    assert np.array_equal(g[3], w[3]) and np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1])
+    if step == 5:
+        assert finish_correct([r[1] for r in recs], *g) == gold.text_gz("tiny.ec.fq.gz")
+
+
+def test_ecfix_kernel_odd_reads_vs_oracle(gpu, gold, oracle_lib):
+    """Reads the fixture does not hold: shorter than k, all N, Ns near either end (a strand without a clean k-mer), very
+    low and very high qualities, reads of other genomes (every look-up misses: the longest searches, trace re-runs)."""
+    v = gold.npz("tiny_solid.npz")
+    rng = np.random.default_rng(7)
+    base = gold.fastq_nt6("tiny.fq.gz")
+    seqs, quals = [], []
+    for i in range(600):
+        r = base[i % len(base)].copy()
+        kind = i % 12
+        if kind == 0: r = r[: int(rng.integers(0, 18))]
+        elif kind == 1: r[:] = 5
+        elif kind == 2: r[-int(rng.integers(1, 30)):] = 5
+        elif kind == 3: r[: int(rng.integers(1, 30))] = 5
+        elif kind == 4: r = rng.integers(1, 5, size=len(r)).astype(np.uint8)
+        elif kind == 5: r[rng.integers(0, len(r), size=8)] = rng.integers(1, 5, size=8)
+        elif kind == 6: r[rng.integers(0, len(r), size=3)] = 5
+        elif kind == 7: r = np.concatenate([r, r[::-1], r])            # 300 bases
+        q = rng.integers(33, 33 + 45, size=len(r)).astype(np.uint8) if kind % 2 else np.full(len(r), 33 + (2 if kind == 8 else 30), dtype=np.uint8)
+        seqs.append(r); quals.append(q)
+    for step in (5, 0):
+        g = _ecfix_gpu(gpu, 17, v["w17_o3_bucket"], v["w17_o3_key"], v["w17_o3_val"], seqs, quals, step)
+        w = orcbind.ec_fix(17, v["w17_o3_bucket"], v["w17_o3_key"], v["w17_o3_val"], seqs, quals, step)
+        assert np.array_equal(g[3], w[3]) and np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1])
+
+
+def test_correct_phase2_on_the_golden_table(gpu, gold, tmp_path):
+    """fmdh_correct_reads (GPU correction pass + host marking, filter, printing) over the golden solid table ==
+    `fermi correct -t1` output, byte for byte, with any number of host threads."""
+    from fermi_amd import hostlib
+    v = gold.npz("tiny_solid.npz")
+    for threads in (1, 5):
+        out = str(tmp_path / ("ec%d.fq" % threads))
+        hostlib.lib().fmdh_correct_set_threads(threads)
+        try:
+            hostlib.correct_reads(17, 3, v["w17_o3_bucket"], v["w17_o3_key"], v["w17_o3_val"], gold.path("tiny.fq.gz"), out)
+        finally:
+            hostlib.lib().fmdh_correct_set_threads(1)
+        assert open(out, "rb").read() == gold.text_gz("tiny.ec.fq.gz")
 
 
 def test_check_left_flags_vs_oracle(gpu, gold, oracle_lib):

@@ -183,3 +183,44 @@ def test_ec_collect_golden(tiny_oracle, gold, w, mo):
     o = np.lexsort([V, K, B])
     assert np.array_equal(B[o], v[tag + "_bucket"]) and np.array_equal(K[o], v[tag + "_key"]) and np.array_equal(V[o], v[tag + "_val"])
     assert list(cnt) == list(v[tag + "_cnt"])
+
+
+def _fastq_records(blob):
+    lines = blob.split(b"\n")
+    return [(lines[i], lines[i + 1], lines[i + 3]) for i in range(0, len(lines) - 1, 4)]
+
+
+def finish_correct(reads_ascii, s, q, off, info, max_corr=0.3):
+    """What the host does after ec_fix (correct.c:247-252, 412-425; unpaired, keep_bad = 0): FASTQ text."""
+    nt6 = np.full(256, 5, dtype=np.uint8)
+    for ch, v in zip(b"ACGTacgt", [1, 2, 3, 4, 1, 2, 3, 4]):
+        nt6[ch] = v
+    out = []
+    for i, a in enumerate(reads_ascii):
+        a = np.frombuffer(a, dtype=np.uint8)
+        cs, cq = s[int(off[i]):int(off[i + 1])], q[int(off[i]):int(off[i + 1])].copy()
+        same = nt6[a] == cs
+        text = np.where(same, np.frombuffer(bytes(a).upper(), dtype=np.uint8), np.frombuffer(b"$acgtn", dtype=np.uint8)[cs])
+        lower = (text >= ord("a")) & (text <= ord("z"))
+        cq[lower] = 36
+        inf = int(info[i])
+        if len(a) and lower.sum() / len(a) > max_corr:
+            inf |= 1 << 16
+        if inf >> 18 <= 10:
+            inf |= 1 << 16
+        if not (inf >> 16 & 1):
+            out.append(b"@%d_%d_%d\n%s\n+\n%s\n" % (i, inf & 0xffff, inf >> 18, text.tobytes(), cq.tobytes()))
+    return b"".join(out)
+
+
+def test_oracle_ec_fix_reproduces_fermi_correct(oracle_lib, gold):
+    """oracle/ecfix_oracle.c (the checker of the GPU correction pass) over the golden solid table of tiny.fmd
+    (k = 17, -O3) + the host's marking/filter rule == `fermi correct -t1` output, byte for byte."""
+    import gzip
+    v = gold.npz("tiny_solid.npz")
+    recs = _fastq_records(gold.text_gz("tiny.fq.gz"))
+    reads = [r[1] for r in recs]
+    nt6 = gold.fastq_nt6("tiny.fq.gz")
+    quals = [np.frombuffer(r[2], dtype=np.uint8) for r in recs]
+    s, q, off, info = orcbind.ec_fix(17, v["w17_o3_bucket"], v["w17_o3_key"], v["w17_o3_val"], nt6, quals)
+    assert finish_correct(reads, s, q, off, info) == gold.text_gz("tiny.ec.fq.gz")
