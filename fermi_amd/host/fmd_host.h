@@ -120,7 +120,8 @@ typedef struct fmdh_remap_state fmdh_remap_state_t;
 fmdh_remap_state_t *fmdh_remap_new(const fmdh_remapopt_t *opt, const uint64_t *sorted /* or NULL */, uint64_t n_seq);
 void fmdh_remap_contig(fmdh_remap_state_t *st, const char *name, const char *comment, int len, uint8_t *nt6 /* len + 1 bytes, overwritten */,
                        const fmd_intv_t *mem, size_t n_mem, FILE *out);
-void fmdh_remap_finish(fmdh_remap_state_t *st, FILE *err); /* the `avg = .. std = .. cap = ..` line, then frees st */
+void fmdh_remap_finish(fmdh_remap_state_t *st, FILE *err);
+uint64_t fmdh_remap_table_resets(const fmdh_remap_state_t *st);  /* how often the pair table was started afresh (every 2^28 contig bases, smem.c:380) */ /* the `avg = .. std = .. cap = ..` line, then frees st */
 
 /* `fermi build -o out.fmd <in.fa>` (cmd.c:378-484); no_fr = trim palindromes (default 1) */
 int fmdh_build(const char *fa_path, const char *out_path, int device, int max_len, int no_fr);

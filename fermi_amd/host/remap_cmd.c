@@ -121,39 +121,84 @@ static void pm_del(pmap_t *h, uint32_t x)
     if (x != h->n_buckets && !PM_EITHER(h->flags, x)) { PM_SET_DEL(h->flags, x); --h->size; }
 }
 
-/* ---- per-contig work (smem.c:139-303) -------------------------------------------------------- */
-typedef struct { uint64_t x, y; } u128_t;
+/* ---- per-contig work (smem.c:139-303) --------------------------------------------------------
+ * Told in this file's own terms.  A "hit" is a read that matches the contig over its full length; it covers the span
+ * [beg, end) of the contig.  With a rank file every hit also names a sequence id, ids come in fours per read pair
+ * (two reads x two strands), and the pairing rule is: a hit on the forward strand of one mate WAITS in the pair book
+ * under the id its partner will show up with; a hit on the reverse strand looks its id up -- found and close enough,
+ * the two spans (trimmed by `skip` at both ends) add to the paired coverage and the waiting entry is closed; otherwise
+ * the hit is listed as unpaired.  What still waits when the contig ends is unpaired too and is listed in the book's
+ * bucket order.  Insert sizes of the closed pairs feed the avg / std / cap line. */
+typedef struct { int beg, end; } span_t;
+typedef struct { uint64_t id, where; } loose_t;            /* an unpaired hit: sequence id, packed span */
 struct fmdh_remap_state {
     fmdh_remapopt_t opt;
     const uint64_t *sorted;
     uint64_t n_seq;
-    pmap_t h;
-    uint64_t rec[3];
-    uint8_t *cov; size_t cov_m;          /* cov + pcv */
-    u128_t *unp; size_t unp_n, unp_m;
-    char *line; size_t line_l, line_m;
+    pmap_t book;                                           /* waiting forward-strand hits: id -> packed span */
+    uint64_t n_pairs, sum_isize, sum_isize2;               /* closed pairs (smem.c:171-173) */
+    uint64_t bases_since_reset, reset_bases;               /* the reference starts a new table every 2^28 contig bases (smem.c:380, :237) */
+    uint64_t n_resets;
+    uint8_t *depth; size_t depth_m;                        /* single + paired coverage of the current contig */
+    loose_t *loose; size_t n_loose, m_loose;
+    char *text; size_t text_l, text_m;                     /* output record under construction */
 };
+#define SPAN_MASK (MASK30 << 32 | MASK30)
+static inline span_t span_of(uint64_t info) { span_t s; s.beg = (int)(info >> 32 & MASK30); s.end = (int)(info & MASK30); return s; }
 
 fmdh_remap_state_t *fmdh_remap_new(const fmdh_remapopt_t *opt, const uint64_t *sorted, uint64_t n_seq)
 {
     fmdh_remap_state_t *st = (fmdh_remap_state_t *)calloc(1, sizeof(*st));
+    if (!st) return 0;
     st->opt = *opt; st->sorted = sorted; st->n_seq = n_seq;
-    if (sorted == 0) { st->opt.skip = -1; st->opt.min_pcv = 0; } /* no rank -> index map: nothing is broken (smem.c:233) */
+    st->reset_bases = (uint64_t)1 << 28;
+    { const char *e = getenv("FMD_REMAP_TABLE_BASES"); if (e && atoll(e) > 0) st->reset_bases = (uint64_t)atoll(e); } /* tests: force the restart */
+    if (sorted == 0) { st->opt.skip = -1; st->opt.min_pcv = 0; } /* no rank -> index map: nothing is paired, nothing is broken (smem.c:233) */
     return st;
 }
+uint64_t fmdh_remap_table_resets(const fmdh_remap_state_t *st) { return st->n_resets; }
 
-static void o_putc(fmdh_remap_state_t *st, int c)
+static void text_room(fmdh_remap_state_t *st, size_t more)
 {
-    if (st->line_l + 2 > st->line_m) { st->line_m = st->line_m ? st->line_m << 1 : 1024; st->line = (char *)realloc(st->line, st->line_m); }
-    st->line[st->line_l++] = (char)c;
+    if (st->text_l + more + 1 <= st->text_m) return;
+    while (st->text_l + more + 1 > st->text_m) st->text_m = st->text_m ? st->text_m << 1 : 4096;
+    st->text = (char *)realloc(st->text, st->text_m);
 }
-static void o_putsn(fmdh_remap_state_t *st, const char *s, size_t n) { for (size_t i = 0; i < n; ++i) o_putc(st, s[i]); }
-static void o_puts(fmdh_remap_state_t *st, const char *s) { o_putsn(st, s, strlen(s)); }
-static void o_putl(fmdh_remap_state_t *st, long long v) { char b[32]; snprintf(b, sizeof(b), "%lld", v); o_puts(st, b); }
-static void unp_push(fmdh_remap_state_t *st, uint64_t x, uint64_t y)
+static void text_bytes(fmdh_remap_state_t *st, const void *p, size_t n) { text_room(st, n); memcpy(st->text + st->text_l, p, n); st->text_l += n; }
+static void text_fmt(fmdh_remap_state_t *st, const char *fmt, long long a, long long b, long long c)
 {
-    if (st->unp_n == st->unp_m) { st->unp_m = st->unp_m ? st->unp_m << 1 : 16; st->unp = (u128_t *)realloc(st->unp, st->unp_m * sizeof(u128_t)); }
-    st->unp[st->unp_n].x = x; st->unp[st->unp_n].y = y; ++st->unp_n;
+    text_room(st, 96);
+    st->text_l += (size_t)snprintf(st->text + st->text_l, 96, fmt, a, b, c);
+}
+static void loose_add(fmdh_remap_state_t *st, uint64_t id, uint64_t where)
+{
+    if (st->n_loose == st->m_loose) { st->m_loose = st->m_loose ? st->m_loose << 1 : 16; st->loose = (loose_t *)realloc(st->loose, st->m_loose * sizeof(loose_t)); }
+    st->loose[st->n_loose].id = id; st->loose[st->n_loose].where = where; ++st->n_loose;
+}
+static inline void depth_add(uint8_t *d, int from, int to) { for (int j = from; j < to; ++j) if (d[j] < 255) ++d[j]; }
+
+/* one read of one hit against the pair book (smem.c:158-192) */
+static void book_visit(fmdh_remap_state_t *st, uint64_t id, uint64_t where, int len, uint8_t *paired)
+{
+    if (id & 1) { /* forward strand: wait for the mate, which will come with the id of this read's partner strand */
+        const uint32_t slot = pm_put(&st->book, id ^ 3);
+        st->book.vals[slot] = where;
+        return;
+    }
+    const uint32_t slot = pm_get(&st->book, id);
+    const int waiting = st->book.n_buckets && slot != st->book.n_buckets;
+    span_t both;                                            /* from the mate's start to this hit's end */
+    both.beg = waiting ? span_of(st->book.vals[slot]).beg : 0;
+    both.end = span_of(where).end;
+    if (!waiting || both.end - both.beg >= st->opt.max_dist) { loose_add(st, id ^ 1, where); return; }
+    {
+        const int isize = both.end - both.beg;
+        ++st->n_pairs; st->sum_isize += (uint64_t)isize; st->sum_isize2 += (uint64_t)(isize * isize);
+    }
+    both.beg += st->opt.skip; both.end -= st->opt.skip;
+    if (both.beg > both.end) { const int t = both.beg; both.beg = both.end; both.end = t; }
+    depth_add(paired, both.beg < 0 ? 0 : both.beg, both.end > len ? len : both.end);
+    pm_del(&st->book, slot);
 }
 
 /* Case = verdict of the paired coverage (smem.c:201-224): between the first and the last base
@@ -172,104 +217,92 @@ static void mask_pcv(int l, char *seq, const uint8_t *pcv, int skip, int min_pcv
     }
 }
 
-void fmdh_remap_contig(fmdh_remap_state_t *st, const char *name, const char *comment, int len, uint8_t *si, const fmd_intv_t *mem, size_t n_mem, FILE *out)
+/* the contig cut at its lower-case stretches, one FASTQ record per upper-case piece (smem.c:254-273) */
+static void print_pieces(fmdh_remap_state_t *st, const char *name, int len, const char *seq, const uint8_t *cov, int n_hits, FILE *out)
 {
-    const uint64_t mask = MASK30 << 32 | MASK30;
-    const int skip = st->opt.skip, min_pcv = st->opt.min_pcv, max_dist = st->opt.max_dist;
-    int n_supp = 0, j;
-    size_t m;
-    if ((size_t)(len + 1) * 2 > st->cov_m) { st->cov_m = (size_t)(len + 1) * 2; st->cov = (uint8_t *)realloc(st->cov, st->cov_m); }
-    memset(st->cov, 0, (size_t)(len + 1) * 2);
-    uint8_t *cov = st->cov, *pcv = st->cov + len + 1;
-    st->unp_n = 0;
-    if (st->h.n_buckets >= 256) pm_free(&st->h); /* smem.c:241-244 */
-    /* paircov (smem.c:139-199) over the full-length matches in the order the iterator yields them */
-    for (m = 0; m < n_mem; ++m) {
-        const fmd_intv_t *p = &mem[m];
-        if (!(p->info >> 63 && p->x[1] < st->n_seq)) continue;
-        const int end0 = (int)(p->info & MASK30);
-        for (j = (int)(p->info >> 32 & MASK30); j < end0; ++j) if (cov[j] < 255) ++cov[j];
-        ++n_supp;
-        if (skip <= 0 || st->sorted == 0) continue;
-        for (uint64_t l = 0; l < p->x[2]; ++l) {
-            const uint64_t k = st->sorted[p->x[1] + l] >> 2; /* x[1]: the interval of the reverse strand */
-            if ((k & 1) == 0) { /* reverse strand: look for the mate */
-                int beg = 0, end = 0, to_add = 0;
-                const uint32_t kk = pm_get(&st->h, k);
-                if (st->h.n_buckets && kk != st->h.n_buckets) {
-                    beg = (int)(st->h.vals[kk] >> 32);
-                    end = (int)(p->info & MASK30);
-                    if (end - beg < max_dist) { ++st->rec[0]; st->rec[1] += (uint64_t)(end - beg); st->rec[2] += (uint64_t)((end - beg) * (end - beg)); }
-                    else to_add = 1;
-                } else to_add = 1;
-                if (to_add) { unp_push(st, k ^ 1, p->info & mask); continue; }
-                beg += skip; end -= skip;
-                if (beg > end) { const int t = beg; beg = end; end = t; }
-                if (beg < 0) beg = 0;
-                if (end > len) end = len;
-                for (j = beg; j < end; ++j) if (pcv[j] < 255) ++pcv[j];
-                pm_del(&st->h, kk);
-            } else { /* forward strand: remember it */
-                const uint32_t kk = pm_put(&st->h, k ^ 3);
-                st->h.vals[kk] = p->info & mask;
-            }
+    int from = -1, piece = 0;
+    for (int j = 0; j <= len; ++j) {
+        const int up = j < len && isupper((unsigned char)seq[j]);
+        if (up && from < 0) from = j;
+        if (!up && from >= 0) {
+            st->text_l = 0;                       /* every maximal upper-case run is a piece */
+            text_bytes(st, "@", 1); text_bytes(st, name, strlen(name));
+            text_fmt(st, "_%lld\t%lld\t%lld\n", piece, j - from, n_hits);
+            text_bytes(st, seq + from, (size_t)(j - from)); text_bytes(st, "\n+\n", 3);
+            text_bytes(st, cov + from, (size_t)(j - from)); text_bytes(st, "\n", 1);
+            fwrite(st->text, 1, st->text_l, out);
+            ++piece;
+            from = -1;
         }
     }
-    for (uint32_t kk = 0; kk != st->h.n_buckets; ++kk)
-        if (!PM_EITHER(st->h.flags, kk)) unp_push(st, st->h.keys[kk] ^ 2, st->h.vals[kk]);
-    pm_clear(&st->h);
+}
 
-    for (j = 0; j < len; ++j) cov[j] = cov[j] + 33 < 126 ? (uint8_t)(cov[j] + 33) : 126;
-    si[len] = 0;
-    if (min_pcv > 0) { /* break the contig where the paired coverage is low (smem.c:254-273) */
-        int beg, k;
-        mask_pcv(len, (char *)si, pcv, skip, min_pcv);
-        for (j = 0; j < len; ++j) if (isupper(si[j])) break;
-        beg = j;
-        for (j = beg + 1, k = 0; j <= len; ++j) {
-            if ((islower(si[j]) || j == len) && isupper(si[j - 1])) {
-                st->line_l = 0;
-                o_putc(st, '@'); o_puts(st, name); o_putc(st, '_'); o_putl(st, k);
-                o_putc(st, '\t'); o_putl(st, j - beg); o_putc(st, '\t'); o_putl(st, n_supp); o_putc(st, '\n');
-                o_putsn(st, (char *)si + beg, (size_t)(j - beg)); o_putsn(st, "\n+\n", 3);
-                o_putsn(st, (char *)cov + beg, (size_t)(j - beg)); o_putc(st, '\n');
-                fwrite(st->line, 1, st->line_l, out);
-                ++k;
-            }
-            if (isupper(si[j]) && islower(si[j - 1])) beg = j;
-        }
-    } else {
-        st->line_l = 0;
-        o_putc(st, '@'); o_puts(st, name);
-        if (comment) { /* "<number> <rest>": the number is replaced by the support (smem.c:277-284) */
-            char *q;
-            strtol(comment, &q, 10);
-            if (q != comment && isspace((unsigned char)*q)) { o_putc(st, '\t'); o_putl(st, n_supp); o_putc(st, '\t'); o_puts(st, q + 1); }
-        }
-        if (st->unp_n) {
-            o_putsn(st, "\tUR:Z:", 6);
-            for (size_t u = 0; u < st->unp_n; ++u) {
-                o_putl(st, (long long)st->unp[u].x); o_putc(st, ',');
-                o_putl(st, (long long)(st->unp[u].y >> 32)); o_putc(st, ',');
-                o_putl(st, (long long)(st->unp[u].y << 32 >> 32)); o_putc(st, ';');
-            }
-        }
-        o_putc(st, '\n');
-        for (j = 0; j < len; ++j) si[j] = (uint8_t)"$ACGTN"[si[j]];
-        o_putsn(st, (char *)si, (size_t)len); o_putsn(st, "\n+\n", 3);
-        o_putsn(st, (char *)cov, (size_t)len); o_putc(st, '\n');
-        fwrite(st->line, 1, st->line_l, out);
+/* the whole contig, its support in the header, unpaired hits in a UR:Z tag (smem.c:275-300) */
+static void print_whole(fmdh_remap_state_t *st, const char *name, const char *comment, int len, uint8_t *bases, const uint8_t *cov, int n_hits, FILE *out)
+{
+    st->text_l = 0;
+    text_bytes(st, "@", 1); text_bytes(st, name, strlen(name));
+    if (comment) { /* "<number> <rest>": the number is replaced by the support (smem.c:277-284) */
+        char *rest;
+        strtol(comment, &rest, 10);
+        if (rest != comment && isspace((unsigned char)*rest)) { text_fmt(st, "\t%lld\t", n_hits, 0, 0); text_bytes(st, rest + 1, strlen(rest + 1)); }
     }
+    if (st->n_loose) {
+        text_bytes(st, "\tUR:Z:", 6);
+        for (size_t u = 0; u < st->n_loose; ++u)
+            text_fmt(st, "%lld,%lld,%lld;", (long long)st->loose[u].id, (long long)(st->loose[u].where >> 32), (long long)(st->loose[u].where << 32 >> 32));
+    }
+    text_bytes(st, "\n", 1);
+    for (int j = 0; j < len; ++j) bases[j] = (uint8_t)"$ACGTN"[bases[j]];
+    text_bytes(st, bases, (size_t)len); text_bytes(st, "\n+\n", 3);
+    text_bytes(st, cov, (size_t)len); text_bytes(st, "\n", 1);
+    fwrite(st->text, 1, st->text_l, out);
+}
+
+void fmdh_remap_contig(fmdh_remap_state_t *st, const char *name, const char *comment, int len, uint8_t *bases, const fmd_intv_t *mem, size_t n_mem, FILE *out)
+{
+    const int pairing = st->opt.skip > 0 && st->sorted != 0;
+    int n_hits = 0;
+    if ((size_t)(len + 1) * 2 > st->depth_m) { st->depth_m = (size_t)(len + 1) * 2; st->depth = (uint8_t *)realloc(st->depth, st->depth_m); }
+    memset(st->depth, 0, (size_t)(len + 1) * 2);
+    uint8_t *cov = st->depth, *paired = st->depth + len + 1;
+    st->n_loose = 0;
+    if (st->book.n_buckets >= 256) pm_free(&st->book);       /* a table that grew large is dropped before the next contig (smem.c:241-244) */
+    /* the hits, in the order the iterator yields them */
+    for (size_t m = 0; m < n_mem; ++m) {
+        const fmd_intv_t *hit = &mem[m];
+        if (!(hit->info >> 63) || hit->x[1] >= st->n_seq) continue;      /* closed by sentinels on both sides = a whole read */
+        const span_t sp = span_of(hit->info);
+        depth_add(cov, sp.beg, sp.end);
+        ++n_hits;
+        if (!pairing) continue;
+        for (uint64_t r = 0; r < hit->x[2]; ++r)                          /* x[1]: the interval of the reverse strand */
+            book_visit(st, st->sorted[hit->x[1] + r] >> 2, hit->info & SPAN_MASK, len, paired);
+    }
+    for (uint32_t slot = 0; slot != st->book.n_buckets; ++slot)           /* still waiting: unpaired, in bucket order */
+        if (!PM_EITHER(st->book.flags, slot)) loose_add(st, st->book.keys[slot] ^ 2, st->book.vals[slot]);
+    pm_clear(&st->book);
+
+    for (int j = 0; j < len; ++j) cov[j] = cov[j] + 33 < 126 ? (uint8_t)(cov[j] + 33) : 126;
+    bases[len] = 0;
+    if (st->opt.min_pcv > 0) {
+        mask_pcv(len, (char *)bases, paired, st->opt.skip, st->opt.min_pcv);
+        print_pieces(st, name, len, (const char *)bases, cov, n_hits, out);
+    } else print_whole(st, name, comment, len, bases, cov, n_hits, out);
+    /* the reference hands its contigs to paircov_all in batches of >= 2^28 bases and every batch starts with a new table
+     * (smem.c:237, :380): the batch ends with the contig that reaches the limit */
+    st->bases_since_reset += (uint64_t)len;
+    if (st->bases_since_reset >= st->reset_bases) { pm_free(&st->book); st->bases_since_reset = 0; ++st->n_resets; }
 }
 
 void fmdh_remap_finish(fmdh_remap_state_t *st, FILE *err)
 {
     if (err) { /* smem.c:383-387; the pipeline reads `cap` off this line */
-        const double avg = (double)st->rec[1] / (double)st->rec[0];
-        const double std = sqrt((double)st->rec[2] / (double)st->rec[0] - avg * avg);
+        const double avg = (double)st->sum_isize / (double)st->n_pairs;
+        const double std = sqrt((double)st->sum_isize2 / (double)st->n_pairs - avg * avg);
         fprintf(err, "[M::fm6_remap] avg = %.2f std = %.2f cap = %d\n", avg, std, (int)(avg + std * 2. + 1.499));
     }
-    pm_free(&st->h); free(st->cov); free(st->unp); free(st->line); free(st);
+    pm_free(&st->book); free(st->depth); free(st->loose); free(st->text); free(st);
 }
 
 /* ---- the command ----------------------------------------------------------------------------- */

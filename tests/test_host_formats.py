@@ -142,3 +142,28 @@ def test_remap_host_part_reproduces_fermi_remap(oracle_lib, gold, tmp_path, mode
     o.close()
     assert open(out, "rb").read() == gold.text_gz("pairs.remap_%s.gz" % mode)
     assert open(err).read().strip() == json.load(open(gold.path("pairs.remap_stderr.json")))[mode][0]
+
+
+def test_remap_pair_table_restarts_like_the_reference_batches(oracle_lib, gold, tmp_path, monkeypatch):
+    """The reference hands contigs to paircov_all in batches of >= 2^28 bases and every batch starts with a new pair
+    table (smem.c:237, :380).  The product keeps one table across its own GPU batches and must start it afresh at the
+    same places: forced here after every contig (FMD_REMAP_TABLE_BASES=1).  The table is empty between contigs, so only
+    the ORDER of the UR:Z entries may depend on its history: everything else, and the entries as a set, stay golden."""
+    o = orcbind.OrcIndex(gold.path("pairs.fmd"))
+    contigs = _read_contigs(gold.path("pairs_contigs.fq.gz"))
+    mems = [o.smem(c[2], 0) for c in contigs]
+    sm = np.fromfile(gold.path("pairs.rank"), dtype=np.uint64)
+    monkeypatch.setenv("FMD_REMAP_TABLE_BASES", "1")
+    out, err = str(tmp_path / "o.txt"), str(tmp_path / "e.txt")
+    hostlib.remap_contigs(contigs, mems, int(o.mcnt[1]), out, err, sorted_map=sm, skip=20, max_dist=600)
+    def canon(blob):
+        res = []
+        for line in blob.split(b"\n"):
+            if b"\tUR:Z:" in line:
+                head, tag = line.split(b"\tUR:Z:")
+                line = head + b"\tUR:Z:" + b";".join(sorted(tag.rstrip(b";").split(b";")))
+            res.append(line)
+        return res
+    got = open(out, "rb").read()
+    assert b"UR:Z:" in got and canon(got) == canon(gold.text_gz("pairs.remap_p.gz"))
+    o.close()
