@@ -272,7 +272,8 @@ extern "C" int fmd_bwt_to_rle6(int device, const uint8_t *d_bwt, uint64_t n, uin
     // chunks of 2^30 symbols: a run cut at a chunk border just becomes two adjacent runs of the same
     // symbol, which every reader of this stream merges (rld_enc, rld.c:177-184)
     const uint64_t CH = 1ull << 30;
-    uint8_t *h = nullptr; uint64_t h_n = 0, h_cap = 0;
+    struct HostBuf { uint8_t *p = nullptr; ~HostBuf() { free(p); } } hold;   // released to the caller on success only (FMD_HIP_TRY returns early)
+    uint8_t *&h = hold.p; uint64_t h_n = 0, h_cap = 0;
     for (uint64_t o = 0; o < n; o += CH) {
         const uint64_t m = n - o < CH ? n - o : CH;
         DevPtr sym, len, nruns, tmp, nb, start, out;
@@ -301,14 +302,15 @@ extern "C" int fmd_bwt_to_rle6(int device, const uint8_t *d_bwt, uint64_t n, uin
         if (h_n + total > h_cap) {
             h_cap = (h_n + total) * (o + m < n ? 2 : 1) + 64;
             uint8_t *nh = (uint8_t *)realloc(h, h_cap);
-            if (!nh) { free(h); return FMD_E_NOMEM; }
+            if (!nh) return FMD_E_NOMEM;
             h = nh;
         }
         hipError_t e = hipMemcpy(h + h_n, out.p, total, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { free(h); fmd_set_hip_error(e, "copy rle6"); return FMD_E_HIP; }
+        if (e != hipSuccess) { fmd_set_hip_error(e, "copy rle6"); return FMD_E_HIP; }
         h_n += total;
     }
     *h_rle6 = h; *n_bytes = h_n;
+    h = nullptr;
     return FMD_OK;
 }
 extern "C" void fmd_host_free(void *p) { free(p); }

@@ -123,8 +123,10 @@ __device__ __forceinline__ uint64_t rld_peek(const uint64_t *w, uint32_t bit /*0
     if (off && i + 1 < 8) x |= w[i + 1] >> (64 - off);
     return x;
 }
+// A run that would end past the symbol count of the header is not written: the file is corrupt or truncated, and
+// sym_total[1] tells the host (FMD_E_FORMAT) -- the decoded lengths are never trusted to stay inside the index.
 __global__ void k_rld_scatter(const uint64_t *__restrict__ w, uint64_t n_rld_blocks, const uint64_t *__restrict__ start,
-                              uint32_t *__restrict__ words, uint64_t *__restrict__ sym_total)
+                              uint32_t *__restrict__ words, uint64_t n_sym, uint64_t *__restrict__ sym_total)
 {
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_rld_blocks; b += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t *blk = w + b * 8;
@@ -142,10 +144,11 @@ __global__ void k_rld_scatter(const uint64_t *__restrict__ w, uint64_t n_rld_blo
                 sym = (uint32_t)((x << (gw + nlow)) >> 61);
                 bit += (uint32_t)(gw + nlow + 3);
             }
+            if (pos > n_sym || len > n_sym - pos) { sym_total[1] = 1; break; }
             fmd_or_run(words, pos, len, sym);
             pos += len;
         }
-        if (b == n_rld_blocks - 1) *sym_total = pos;
+        if (b == n_rld_blocks - 1) sym_total[0] = pos;
     }
 }
 
@@ -421,7 +424,8 @@ extern "C" int fmd_dev_open_rld(int device, const uint64_t *payload, uint64_t n_
     fmd_dev *h = nullptr;
     FMD_HIP_TRY(hipMalloc((void **)&d_w, (n_rld + 1) * 64));
     if (hipMalloc((void **)&d_size, n_rld * 8) != hipSuccess || hipMalloc((void **)&d_start, n_rld * 8) != hipSuccess ||
-        hipMalloc((void **)&d_tot, 8) != hipSuccess) { rc = FMD_E_NOMEM; goto done; }
+        hipMalloc((void **)&d_tot, 16) != hipSuccess) { rc = FMD_E_NOMEM; goto done; }
+    hipMemset(d_tot, 0, 16);
     hipMemset(d_w, 0, (n_rld + 1) * 64);
     hipMemcpy(d_w, payload, n_words * 8, hipMemcpyHostToDevice);
     k_rld_sizes<<<nblk(n_rld, 256), 256>>>(d_w, n_rld, d_size);
@@ -430,11 +434,11 @@ extern "C" int fmd_dev_open_rld(int device, const uint64_t *payload, uint64_t n_
     rc = dev_alloc_index(device, mcnt[0], &h);
     if (rc) goto done;
     h->mcnt[0] = mcnt[0];
-    k_rld_scatter<<<nblk(n_rld, 64), 64>>>(d_w, n_rld, d_start, (uint32_t *)h->blocks, d_tot);
+    k_rld_scatter<<<nblk(n_rld, 64), 64>>>(d_w, n_rld, d_start, (uint32_t *)h->blocks, mcnt[0], d_tot);
     {
-        uint64_t tot = 0;
-        hipMemcpy(&tot, d_tot, 8, hipMemcpyDeviceToHost);
-        if (tot != mcnt[0]) { rc = FMD_E_FORMAT; goto done; }
+        uint64_t tot[2] = {0, 0};
+        hipMemcpy(tot, d_tot, 16, hipMemcpyDeviceToHost);
+        if (tot[1] || tot[0] != mcnt[0]) { rc = FMD_E_FORMAT; goto done; }
     }
     rc = finish_index(h);
     if (rc == FMD_OK)
@@ -464,6 +468,13 @@ extern "C" int fmd_dev_open_file(int device, const char *fn, fmd_dev_t **out)
         mcnt[0] = 0;
         for (int s = 1; s < 7; ++s) mcnt[0] += mcnt[s];
         const uint64_t n_words = hdr[1] / 8;
+        {   // the header's payload size against the file itself, before anything is sized by it
+            const long at = ftell(fp);
+            fseek(fp, 0, SEEK_END);
+            const long sz = ftell(fp);
+            fseek(fp, at, SEEK_SET);
+            if (at < 0 || sz < at || hdr[1] > (uint64_t)(sz - at)) { fclose(fp); return FMD_E_FORMAT; }
+        }
         uint64_t *w = (uint64_t *)malloc(n_words * 8 + 64);
         if (!w) { fclose(fp); return FMD_E_NOMEM; }
         if (fread(w, 8, n_words, fp) != n_words) { free(w); fclose(fp); return FMD_E_IO; }

@@ -877,6 +877,8 @@ static bool ovl_aux_acquire(fmd_dev *h)
         for (; ok && made <= FMD_OVLP_MAX_PARTS; ++made) ok = hipEventCreateWithFlags(&h->aux_ev[made], hipEventDisableTiming) == hipSuccess;
         if (!ok) {
             for (int i = 0; i < made - 1; ++i) hipEventDestroy(h->aux_ev[i]);
+            if (h->aux_stream) { hipStreamDestroy(h->aux_stream); h->aux_stream = nullptr; }   // or every retry would leak a stream
+            (void)hipGetLastError();
             __atomic_store_n(&h->aux_busy, 0, __ATOMIC_RELEASE);
             return false;
         }

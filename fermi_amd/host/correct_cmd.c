@@ -93,83 +93,100 @@ static void *stage_gpu(void *d)
     }
 }
 
-/* correct.c:247-252 for the reads [lo, hi) of a batch: corrected bases in lower case with quality 36 ('$'), and the
- * "too many corrections / too close a second best" mark (bit 16 of info) */
-typedef struct { const fmdh_ecopt_t *opt; batch_t *b; size_t lo, hi; } markjob_t;
-static void *mark_main(void *d)
+/* What the reference does to a corrected read before printing it, on a slice [lo, hi) of a batch and in two passes
+ * because the pair rule looks at the neighbour's verdict:
+ *   pass 0 (correct.c:247-252): corrected bases in lower case with quality 36 ('$'); bit 16 of info = "too many
+ *          corrections / too close a second best";
+ *   pass 1 (correct.c:396-425): drop bad reads (a pair is bad when either end is), format the FASTQ records of the
+ *          slice into its own buffer -- the writer thread then has one fwrite per slice. */
+typedef struct { const fmdh_ecopt_t *opt; batch_t *b; size_t lo, hi; int pass; char *text; size_t text_l, text_m; int failed; } slice_t;
+static void *slice_main(void *d)
 {
-    markjob_t *w = (markjob_t *)d;
+    slice_t *w = (slice_t *)d;
     batch_t *b = w->b;
-    for (size_t i = w->lo; i < w->hi; ++i) {
-        char *a = b->ascii + b->off[i];
-        const uint8_t *s = b->nt6 + b->off[i];
-        uint8_t *q = b->qual + b->off[i];
-        const int l = (int)(b->off[i + 1] - b->off[i]);
-        int n_lower = 0, info = b->info[i];
-        for (int j = 0; j < l; ++j) {
-            a[j] = fmdh_nt6[(unsigned char)a[j]] == s[j] ? (char)toupper((unsigned char)a[j]) : "$acgtn"[s[j]];
-            if (islower((unsigned char)a[j])) { ++n_lower; q[j] = 36; }
+    const fmdh_ecopt_t *opt = w->opt;
+    if (w->pass == 0) {
+        for (size_t i = w->lo; i < w->hi; ++i) {
+            char *a = b->ascii + b->off[i];
+            const uint8_t *s = b->nt6 + b->off[i];
+            uint8_t *q = b->qual + b->off[i];
+            const int l = (int)(b->off[i + 1] - b->off[i]);
+            int n_lower = 0, info = b->info[i];
+            for (int j = 0; j < l; ++j) {
+                a[j] = fmdh_nt6[(unsigned char)a[j]] == s[j] ? (char)toupper((unsigned char)a[j]) : "$acgtn"[s[j]];
+                if (islower((unsigned char)a[j])) { ++n_lower; q[j] = 36; }
+            }
+            if ((double)n_lower / l > opt->max_corr) info |= 1 << 16;
+            if (info >> 18 <= 10) info |= 1 << 16;
+            b->info[i] = info;
         }
-        if ((double)n_lower / l > w->opt->max_corr) info |= 1 << 16;
-        if (info >> 18 <= 10) info |= 1 << 16;
-        b->info[i] = info;
+        return 0;
+    }
+    {
+        const size_t need = 2 * (size_t)(b->off[w->hi] - b->off[w->lo]) + (w->hi - w->lo) * 48 + 64;
+        if (need > w->text_m) { char *t = (char *)realloc(w->text, need); if (!t) { w->failed = 1; return 0; } w->text = t; w->text_m = need; }
+    }
+    w->text_l = 0;
+    for (size_t a = w->lo; a < w->hi; ++a) {
+        const uint64_t k = b->first_id + a;
+        const int32_t *info = b->info;
+        int is_bad = 0;
+        if (opt->is_paired) { /* batches hold whole pairs (BATCH_SIZE is even) */
+            if (info[a] >> 16 & 1) is_bad = 1;
+            else if (k & 1) { if (a >= 1 && (info[a - 1] >> 16 & 1)) is_bad = 1; }
+            else if (a + 1 < b->nb && (info[a + 1] >> 16 & 1)) is_bad = 1;
+        } else if (info[a] >> 16 & 1) is_bad = 1;
+        if (is_bad && !opt->keep_bad) continue;
+        int len = (int)(b->off[a + 1] - b->off[a]);
+        if (opt->trim_l && opt->trim_l < len) len = opt->trim_l;
+        char *o = w->text + w->text_l;
+        o += sprintf(o, "@%lld%c%d%c%d\n", (long long)(opt->is_paired ? k >> 1 : k), opt->is_paired ? ' ' : '_', info[a] & 0xffff, opt->is_paired ? ' ' : '_', info[a] >> 18);
+        memcpy(o, b->ascii + b->off[a], (size_t)len); o += len;
+        memcpy(o, "\n+\n", 3); o += 3;
+        memcpy(o, b->qual + b->off[a], (size_t)len); o += len;
+        *o++ = '\n';
+        w->text_l = (size_t)(o - w->text);
     }
     return 0;
 }
-static void mark_batch(const fmdh_ecopt_t *opt, batch_t *b)
-{
-    int T = g_host_threads, t;
-    if ((size_t)T > b->nb / 4096 + 1) T = (int)(b->nb / 4096 + 1);
-    markjob_t *w = (markjob_t *)calloc((size_t)T, sizeof(markjob_t));
-    pthread_t *tid = (pthread_t *)calloc((size_t)T, sizeof(pthread_t));
-    char *started = (char *)calloc((size_t)T, 1);
-    if (!w || !tid || !started) { markjob_t one = {opt, b, 0, b->nb}; mark_main(&one); free(w); free(tid); free(started); return; }
-    for (t = 0; t < T; ++t) {
-        w[t].opt = opt; w[t].b = b; w[t].lo = b->nb * (size_t)t / (size_t)T; w[t].hi = b->nb * (size_t)(t + 1) / (size_t)T;
-        started[t] = t > 0 && pthread_create(&tid[t], 0, mark_main, &w[t]) == 0;
-    }
-    for (t = 0; t < T; ++t) if (!started[t]) mark_main(&w[t]);
-    for (t = 1; t < T; ++t) if (started[t]) pthread_join(tid[t], 0);
-    free(w); free(tid); free(started);
-}
 
-/* stage 3: mark, filter, print (correct.c:396-425) */
+/* stage 3: mark, filter, format on g_host_threads threads; print in order */
+#define MAX_SLICES 64
 static void *stage_print(void *d)
 {
     pipe_t *p = (pipe_t *)d;
-    const fmdh_ecopt_t *opt = p->opt;
-    char hdr[64];
+    slice_t sl[MAX_SLICES];
+    pthread_t tid[MAX_SLICES];
+    char started[MAX_SLICES];
+    memset(sl, 0, sizeof(sl));
     for (unsigned kb = 0;; ++kb) {
         batch_t *b = &p->b[kb % 3];
         slot_wait(p, b, 2);
         const double t0 = now_s();
-        if (!p->failed) {
-            mark_batch(opt, b);
-            for (size_t a = 0; a < b->nb; ++a) {
-                const uint64_t k = b->first_id + a;
-                const int32_t *info = b->info;
-                int is_bad = 0;
-                if (opt->is_paired) { /* a pair is bad when either end is (correct.c:401-410; batches hold whole pairs) */
-                    if (info[a] >> 16 & 1) is_bad = 1;
-                    else if (k & 1) { if (a >= 1 && (info[a - 1] >> 16 & 1)) is_bad = 1; }
-                    else if (a + 1 < b->nb && (info[a + 1] >> 16 & 1)) is_bad = 1;
-                } else if (info[a] >> 16 & 1) is_bad = 1;
-                if (!is_bad || opt->keep_bad) {
-                    int len = (int)(b->off[a + 1] - b->off[a]);
-                    if (opt->trim_l && opt->trim_l < len) len = opt->trim_l;
-                    const int hl = snprintf(hdr, sizeof(hdr), "@%lld%c%d%c%d\n", (long long)(opt->is_paired ? k >> 1 : k), opt->is_paired ? ' ' : '_',
-                                            info[a] & 0xffff, opt->is_paired ? ' ' : '_', info[a] >> 18);
-                    fwrite(hdr, 1, (size_t)hl, p->out);
-                    fwrite(b->ascii + b->off[a], 1, (size_t)len, p->out); fwrite("\n+\n", 1, 3, p->out);
-                    fwrite(b->qual + b->off[a], 1, (size_t)len, p->out); fputc('\n', p->out);
+        if (!p->failed && b->nb) {
+            int T = g_host_threads < MAX_SLICES ? g_host_threads : MAX_SLICES, t, pass;
+            if ((size_t)T > b->nb / 4096 + 1) T = (int)(b->nb / 4096 + 1);
+            for (pass = 0; pass < 2; ++pass) {
+                for (t = 0; t < T; ++t) {
+                    sl[t].opt = p->opt; sl[t].b = b; sl[t].pass = pass;
+                    sl[t].lo = b->nb * (size_t)t / (size_t)T; sl[t].hi = b->nb * (size_t)(t + 1) / (size_t)T;
+                    started[t] = t > 0 && pthread_create(&tid[t], 0, slice_main, &sl[t]) == 0;
                 }
+                for (t = 0; t < T; ++t) if (!started[t]) slice_main(&sl[t]);
+                for (t = 1; t < T; ++t) if (started[t]) pthread_join(tid[t], 0);
+            }
+            for (t = 0; t < T; ++t) {
+                if (sl[t].failed) { fprintf(stderr, "[E::%s] out of memory\n", __func__); p->failed = 1; break; }
+                if (fwrite(sl[t].text, 1, sl[t].text_l, p->out) != sl[t].text_l) { fprintf(stderr, "[E::%s] write error\n", __func__); p->failed = 1; break; }
             }
         }
         const int last = b->last;
         p->t_write += now_s() - t0;
         slot_set(p, b, 0);
-        if (last) return 0;
+        if (last) break;
     }
+    for (int t = 0; t < MAX_SLICES; ++t) free(sl[t].text);
+    return 0;
 }
 
 /* Phase 2 alone: correct the reads of fq_path against a harvested table (opt->w must be set). */

@@ -150,10 +150,10 @@ int fmdh_exact(const char *fmd_path, const char *fa_path, int device, int self_m
     for (;;) {
         l = fmdh_seq_read(io);
         if (l < 0 || n == EXACT_BATCH) {
-            if (n && (rc = flush_batch(d, &info, self_match, n, names, bases, off, max_len, out)) != 0) break;
-            for (size_t i = 0; i < n; ++i) free(names[i]);
+            if (n) rc = flush_batch(d, &info, self_match, n, names, bases, off, max_len, out);
+            for (size_t i = 0; i < n; ++i) free(names[i]);     /* also when the batch failed */
             n = 0; tot = 0; max_len = 1;
-            if (l < 0) break;
+            if (rc || l < 0) break;
         }
         if (tot + (size_t)l + 8 > cap) { while (tot + (size_t)l + 8 > cap) cap <<= 1; bases = (uint8_t *)realloc(bases, cap); }
         const char *s = fmdh_seq_bases(io);
