@@ -151,7 +151,7 @@ def timed(torch, dist, dev, stream, step, steps, warmup):
     torch.cuda.synchronize()
     wall = time.perf_counter() - w0
     if dist:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     return wall, float(np.mean([a.elapsed_time(b) for a, b in evs]))
@@ -729,8 +729,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("FMD_BENCH_BACKEND", "nccl")       # "gloo" + FMD_BENCH_SHARE_GPU=1: the N > 1 path on a one-GPU box (tests)
+        if os.environ.get("FMD_BENCH_SHARE_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     assert api.device_count() > 0, "bench.py needs a GPU: libfmdhip has no CPU fallback"

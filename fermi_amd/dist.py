@@ -28,6 +28,11 @@ def gather_packed(prec, off, var, n_ids, rank, world, dist, dst=0):
     import torch
     if world == 1:
         return [(prec, off, var[: int(off[-1].item())])]
+    home = prec.device
+    if dist.get_backend() != "nccl" and prec.is_cuda:
+        # gloo moves host memory only: the one-GPU test form of the N > 1 path (bench.py FMD_BENCH_BACKEND=gloo) bounces
+        # through the host here; under nccl (RCCL) the device tensors below go peer to peer over xGMI as they are
+        prec, off, var = prec.cpu(), off.cpu(), var[: int(off[-1].item())].cpu()
     tot = off[-1:].clone()
     sizes = [torch.zeros(1, dtype=torch.int64, device=off.device) for _ in range(world)]
     dist.all_gather(sizes, tot)
@@ -48,6 +53,8 @@ def gather_packed(prec, off, var, n_ids, rank, world, dist, dst=0):
                 ops.append(dist.P2POp(dist.irecv, b[2], r))
         for w in (dist.batch_isend_irecv(ops) if ops else []):
             w.wait()
+        if bufs[0][0].device != home:
+            bufs = [tuple(t.to(home) for t in b) for b in bufs]
         return bufs
     mine = int(tot.item())
     ops = []

@@ -1,7 +1,12 @@
 /* seqio.c -- FASTA/FASTQ reader (plain or gzip) with the record semantics of the reader fermi uses
- * (kseq.h:171-210): a record starts at '>' or '@'; the name ends at the first white space; the
+ * (kseq.h:171-210): a record starts at '>' or '@'; the name ends at the first white space (isspace); the
  * sequence may span lines and ends at the next '>', '@' or '+'; after '+' the quality has as many
- * characters as the sequence. */
+ * characters as the sequence.  The corner cases follow that reader too, because `build`, `correct` and `remap`
+ * must see the bytes fermi sees: the first character of every sequence line is taken as it is -- the '\n' of a
+ * blank line included (it becomes an N and the next line continues the same "line") --, a CR before the line end is
+ * dropped only when more than one character has been collected, and one quality line is read even for an empty
+ * sequence. */
+#include <ctype.h>
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
@@ -48,7 +53,7 @@ static int io_append_line(fmdh_seqio_t *io, char **s, size_t *l, size_t *m)
         io->beg += (int)k + (nl ? 1 : 0);
         if (nl) break;
     }
-    if (*l && (*s)[*l - 1] == '\r') --*l;
+    if (*l > 1 && (*s)[*l - 1] == '\r') --*l;       /* kseq.h:135: only when more than one character is there */
     if (*s) (*s)[*l] = 0;
     return got ? 0 : -1;
 }
@@ -83,22 +88,21 @@ int fmdh_seq_read(fmdh_seqio_t *io) /* sequence length, -1 at end of file, -2 on
         io->last_char = c;
     }
     io->name_l = io->seq_l = io->qual_l = io->comment_l = 0; io->name[0] = io->seq[0] = io->qual[0] = io->comment[0] = 0;
-    while ((c = io_getc(io)) != -1 && c != ' ' && c != '\t' && c != '\n' && c != '\r') put(&io->name, &io->name_l, &io->name_m, c);
+    while ((c = io_getc(io)) != -1 && !isspace(c)) put(&io->name, &io->name_l, &io->name_m, c);
     if (c == -1 && io->name_l == 0) return -1;
     if (c != '\n') { /* comment: the rest of the line, a trailing CR dropped (kseq.h:135) */
         while ((c = io_getc(io)) != -1 && c != '\n') put(&io->comment, &io->comment_l, &io->comment_m, c);
         if (io->comment_l > 1 && io->comment[io->comment_l - 1] == '\r') io->comment[--io->comment_l] = 0;
     }
     while ((c = io_getc(io)) != -1 && c != '>' && c != '+' && c != '@') { /* the first character of each line decides (kseq.h:186-191) */
-        if (c == '\n' || c == '\r') continue;
-        put(&io->seq, &io->seq_l, &io->seq_m, c);
+        put(&io->seq, &io->seq_l, &io->seq_m, c);                              /* whatever it is */
         io_append_line(io, &io->seq, &io->seq_l, &io->seq_m);
     }
     if (c == '>' || c == '@') io->last_char = c;
     if (c != '+') { if (c == -1) io->last_char = 0; return (int)io->seq_l; }
     while ((c = io_getc(io)) != -1 && c != '\n') {}
     if (c == -1) return -2;
-    while (io->qual_l < io->seq_l && io_append_line(io, &io->qual, &io->qual_l, &io->qual_m) == 0) {} /* whole lines (kseq.h:206) */
+    while (io_append_line(io, &io->qual, &io->qual_l, &io->qual_m) == 0 && io->qual_l < io->seq_l) {} /* whole lines, at least one (kseq.h:206) */
     io->last_char = 0;
     if (io->qual_l != io->seq_l) return -2;
     return (int)io->seq_l;

@@ -1,0 +1,88 @@
+"""GPU, full size: BASELINE.json's configs at the sizes they name, inside `pytest -m gpu`.
+
+  configs[1], [2] and the single-GPU size class of [3]: 10 M x 100 bp reads -- index built on the GPU, backward search,
+      overlap discovery (+ check_left), SMEM and the k-mer harvest compared with the reference (oracle/_ref when it
+      travelled, the oracle otherwise) on RANDOM samples of the ids / reads / buckets, through bench.py's own legs
+      (the same code the driver times; 50 M is its default size, 10 M here keeps the test inside two minutes);
+  configs[0]: 1 M x 100 bp -- `fermi-amd build`, `unitig -l50` (one GPU and two replicas) and `correct` against the md5s of
+      the reference binary's output (tests/golden/md5_1m.json, made by tests/golden/make_md5_1m.py where
+      /root/reference exists).
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+AMD = os.path.join(ROOT, "fermi_amd", "bin", "fermi-amd")
+
+
+def _md5_stream(cmd, env=None):
+    h = hashlib.md5()
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+    n = 0
+    for blk in iter(lambda: p.stdout.read(1 << 24), b""):
+        h.update(blk); n += len(blk)
+    assert p.wait() == 0, cmd
+    return [h.hexdigest(), n]
+
+
+def test_10m_reads_every_leg_bit_exact_on_random_samples(gpu):
+    env = dict(os.environ, FMD_BENCH_READS="10000000", FMD_BENCH_BSEARCH_READS="10000000", FMD_BENCH_CPU_SAMPLE="200000",
+               FMD_BENCH_CPU_SAMPLE_OVLP="100000", FMD_BENCH_CPU_SAMPLE_SMEM="100000", FMD_BENCH_CPU_SAMPLE_KMER="2048", FMD_BENCH_PROBE="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    d = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert d["config"]["reads"] == 10_000_000 and d["overlap_discovery"]["strands_this_rank"] == 20_000_000
+    assert d["parity_vs_cpu_on_sample"] == "bit-exact"                                   # overlap records + neighbours, random ids
+    assert d["overlap_discovery"]["pipelined_vs_serial_order"].startswith("identical")
+    assert d["overlap_discovery"]["overflow_records"] == 0
+    assert d["check_left"]["parity_vs_oracle_on_sample"].startswith("bit-exact")
+    assert d["backward_search"]["parity_vs_cpu_on_sample"] == "bit-exact" and d["backward_search"]["hits"] == 10_000_000
+    assert d["smem"]["parity_vs_cpu_on_sample"] == "bit-exact" and d["smem"]["overflow_reads"] == 0
+    assert d["kmer_harvest"]["parity_vs_cpu_on_sample"] == "bit-exact"
+    for leg in (d, d["check_left"], d["backward_search"], d["smem"], d["kmer_harvest"]):
+        f = leg["roofline"]["frac"]
+        assert f is None or 0 < f <= 1.0, leg["roofline"]                               # a fraction is a fraction
+
+
+def test_1m_reads_cli_md5_equals_the_reference(gpu, tmp_path):
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_md5_1m as gen
+    want = json.load(open(os.path.join(HERE, "golden", "md5_1m.json")))
+    d = str(tmp_path)
+    gen.write_fastq(d + "/clean.fq", 0.0, False)
+    subprocess.check_call([AMD, "build", "-fo", d + "/clean.fmd", d + "/clean.fq"], stderr=subprocess.DEVNULL)
+    assert _md5_stream(["cat", d + "/clean.fmd"]) == want["clean_fmd"]                  # the .fmd `fermi build` writes, byte for byte
+    assert _md5_stream([AMD, "unitig", "-l50", d + "/clean.fmd"]) == want["unitig_l50_t1"]
+    assert _md5_stream([AMD, "unitig", "-l50", "-g", "0,0", d + "/clean.fmd"]) == want["unitig_l50_t1"]   # two replicas, sharded ids
+    assert _md5_stream([AMD, "unitig", "-l50", d + "/clean.fmd"], env=dict(os.environ, FMD_CHECK_LEFT_EXACT="1")) == want["unitig_l50_t1"]
+    gen.write_fastq(d + "/raw.fq", 0.01, True)
+    subprocess.check_call([AMD, "build", "-fo", d + "/raw.fmd", d + "/raw.fq"], stderr=subprocess.DEVNULL)
+    assert _md5_stream(["cat", d + "/raw.fmd"]) == want["raw_fmd"]
+    assert _md5_stream([AMD, "correct", "-t8", d + "/raw.fmd", d + "/raw.fq"]) == want["correct_t1"]
+    assert _md5_stream([AMD, "unitig", "-l50", d + "/raw.fmd"]) == want["unitig_raw_l50_t1"]   # reads with errors: forks, tips, back-bifurcations
+
+
+def test_bench_n2_path_sharded_ids_and_gather_on_one_gpu(gpu):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per GPU), here with both ranks on
+    GPU 0 and gloo instead of RCCL (FMD_BENCH_BACKEND / FMD_BENCH_SHARE_GPU): rank r computes the ids i = r (mod 2), the
+    packed rows are gathered on rank 0 inside the timed step, and rank 0 recomputes a sample of rank 1's rows."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, FMD_BENCH_READS="1000000", FMD_BENCH_BACKEND="gloo", FMD_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["reads"] == 1_000_000
+    assert d["overlap_discovery"]["strands_this_rank"] == 1_000_000            # half of the 2 * 10^6 ids
+    g = d["overlap_discovery"]["record_gather_rccl"]
+    assert g["check"].startswith("ok"), g
+    assert 64 < g["bytes_per_strand"] < 200

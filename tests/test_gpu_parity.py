@@ -928,7 +928,13 @@ def test_fuzz_cli_against_reference_binary(gpu, tmp_path, seed):
                 r = (5 - r)[::-1].copy()
             if rng.random() < 0.3:
                 j = int(rng.integers(0, L)); r[j] = 1 + (r[j] + int(rng.integers(0, 3))) % 4
-            f.write("@r%d\n%s\n+\n%s\n" % (i, tab[r].tobytes().decode(), "".join(chr(33 + int(q)) for q in rng.integers(5, 41, L))))
+            bases, quals = tab[r].tobytes().decode(), "".join(chr(33 + int(q)) for q in rng.integers(5, 41, L))
+            odd = int(rng.integers(0, 12)) if seed % 4 == 1 else 99    # records the reader's corner cases decide (kseq.h:171-210)
+            if odd == 0: f.write("@r%d\r\n%s\r\n+\r\n%s\r\n" % (i, bases, quals))                               # CR LF
+            elif odd == 1: f.write("@r%d\tlane 3\n%s\n%s\n+r%d\n%s\n%s\n" % (i, bases[:L // 2], bases[L // 2:], i, quals[:L // 3], quals[L // 3:]))  # wrapped lines, a comment
+            elif odd == 2: f.write(">r%d some text\n%s\n" % (i, bases))                                           # FASTA among FASTQ
+            elif odd == 3: f.write("@r%d\v1\n%s\n+\n%s\n" % (i, bases, quals))                                   # the name ends at ANY white space
+            else: f.write("@r%d\n%s\n+\n%s\n" % (i, bases, quals))
 
     def run(exe, args, out):
         try:
