@@ -30,9 +30,6 @@
 #ifndef GRP_POOL
 #define GRP_POOL 30                          // spill blocks per pass (-DGRP_POOL=4 stresses the multi-pass path in the tests)
 #endif
-#ifndef GRP_SHARED
-#define GRP_SHARED 1                         // A/B: -DGRP_SHARED=0 fetches one x[1] block per lane (the first version)
-#endif
 #define GRP_SLOTS_U4 (2 * FMD_SLOT_U4)
 #define GRP_STAGE_U4 128
 #define GRP_REGION_U4 (GRP_POOL * FMD_BLK_U4 + 8 > GRP_STAGE_U4 ? GRP_POOL * FMD_BLK_U4 + 8 : GRP_STAGE_U4) // 128 with 64-byte blocks
@@ -95,7 +92,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
                                                     uint32_t seq_stride, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_n)
 {
     __shared__ uint4 lds[GRP_LDS_U4];
-    uint4 *pool = lds + GRP_SLOTS_U4;
+    uint4 *pool = lds + GRP_SLOTS_U4, *stage = pool;
     uint32_t *pool_blk = (uint32_t *)(pool + GRP_REGION_U4 - 8);
     constexpr int S = 64 / G;
     constexpr uint32_t GM = G == 32 ? 0xffffffffu : (1u << G) - 1;
@@ -160,94 +157,47 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
         fmd_split(ke, bke, oke); fmd_split(kb, bkb, okb);
         const uint32_t ble = bke + (oke + (uint32_t)sz >= FMD_BLK_SYMS), blb = bkb + (okb + (uint32_t)sz >= FMD_BLK_SYMS);
         const bool e_sep = live && ble != bke, b_sep = live && blb != bkb;
-        // ---- category geometry (group ballots).  Live lanes are packed [0, ncur); a category = lanes [cat, cat_end).
-        const uint32_t alive_g = (uint32_t)(__ballot(live) >> gbase) & GM;
-        const int ncur = __popc(alive_g);
-        const uint32_t head_g = (uint32_t)(__ballot(live && cat == j) >> gbase) & GM;   // first lane of each category
-        const uint32_t later_heads = (cat + 1 >= 32) ? 0u : (head_g >> (cat + 1));
-        const int cat_end = later_heads ? cat + 1 + (__ffs((int)later_heads) - 1) : ncur;
-        const uint32_t before_m = (uint32_t)bits_below(cat), same_m = (uint32_t)(bits_below(cat_end) & ~bits_below(cat));
-        // The x[1] ranges of a category are NESTED: its intervals are those of suffixes of one string, longest first, and
-        // an extension by a common base keeps them nested (rank is monotone).  The last lane holds the widest (<= 63
-        // positions), so every window BWT[x1, x1+size) of the category lies in the block b of the last lane's x1 - 1 or in
-        // b + 1: the category fetches those ONE or TWO blocks once (compact pool) instead of one or two per lane.
-        const int last_l = gbase + (cat_end > 0 ? cat_end - 1 : 0);
-        const uint32_t b_cat = (uint32_t)__shfl((int)bke, last_l);
-        const bool is_last = live && lane == last_l;
-        const bool odd = live && !((bke == b_cat || bke == b_cat + 1) && (ble == b_cat || ble == b_cat + 1)); // never, by the argument above
-        const uint32_t w1_g = (uint32_t)(__ballot(live && (bke == b_cat + 1 || ble == b_cat + 1)) >> gbase) & GM;
-        const bool cat_b1 = (w1_g & same_m) != 0;                 // somebody in my category needs block b + 1
-        const uint64_t m0 = __ballot(is_last), m1 = __ballot(is_last && cat_b1), mb = __ballot(b_sep);
-        const int n_sh = __popcll(m0) + __popcll(m1);
-        const bool shared = GRP_SHARED && __ballot(odd) == 0 && n_sh + __popcll(mb) <= GRP_POOL;   // wave-uniform
-        const int t = fmd_chunk_xor(lane);
-        const uint4 *img_e = lds + fmd_lds_base(lane, 0), *img_b = lds + fmd_lds_base(lane, 1);
-        int t_e = t;
-        uint4 *stage = pool;               // re-pack staging area: the pool region, once the windows have been read ...
-        uint64_t X = 0, Y = 0, Z = 0, D = 0;
-        // Every interval here has size <= 63 (k_ovl_classify), so "rank2a" is a count over a 64-position window of the
-        // planes read straight from LDS block images:
+        fmd_fetch_slot<0>(ix, lds, bke, live);
+        fmd_fetch_slot<1>(ix, lds, bkb, live);
+        // straddling ranges: compact the extra blocks into the pool (ballot prefix), 16 per instruction,
+        // GRP_POOL per pass.  Every interval here has size <= 63 (k_ovl_classify), so "rank2a" is a count
+        // over a 64-position window of the planes read straight from the lane's LDS block images:
         //   forward extension: symbols of BWT[x1, x1+size)          -> sizes of the six children
         //   sentinel tests   : '$' in the child sub-ranges of BWT[x0, x0+size)  (extend0 of unitig.c:112/:129)
-        if (shared) {
-            const int i0 = fmd_below(m0) + fmd_below(m1);          // (at last lanes) pool slot of block b; b + 1 follows it
-            const int s0 = __shfl(i0, last_l);
-            const int rb = n_sh + fmd_below(mb);
-            const int n_req = n_sh + __popcll(mb);
-            if (is_last) { pool_blk[i0] = b_cat; if (cat_b1) pool_blk[i0 + 1] = b_cat + 1; }
-            if (b_sep) pool_blk[rb] = blb;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            fmd_fetch_slot<1>(ix, lds, bkb, live);
-            fmd_fetch_pool(ix, pool, pool_blk, n_req);
+        // A lane reads its windows in the pass that brings its spill block(s), or in the first one.
+        const uint64_t me = __ballot(e_sep), mb = __ballot(b_sep);
+        const int n_e = __popcll(me), n_spill = n_e + __popcll(mb);
+        const int pe = fmd_below(me), pb = n_e + fmd_below(mb);
+        const int t = fmd_chunk_xor(lane);
+        const uint4 *img_e = lds + fmd_lds_base(lane, 0), *img_b = lds + fmd_lds_base(lane, 1);
+        uint64_t X = 0, Y = 0, Z = 0, D = 0;
+        bool need_e = live, need_b = live;
+        for (int base = 0;; base += GRP_POOL) {
+            const int re = pe - base, rb = pb - base;
+            const bool in_e = e_sep && re >= 0 && re < GRP_POOL, in_b = b_sep && rb >= 0 && rb < GRP_POOL;
+            const int n_here = n_spill - base < GRP_POOL ? n_spill - base : GRP_POOL;
+            if (n_here > 0) {
+                if (in_e) pool_blk[re] = ble;
+                if (in_b) pool_blk[rb] = blb;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                fmd_fetch_pool(ix, pool, pool_blk, n_here);
+            }
             fmd_fetch_wait();
-            stage = lds;                   // ... here the pool holds the x[1] images the rank loop still reads: stage in the unused slot 0
-            if (live) {
-                const int se = s0 + (int)(bke - b_cat), sl = s0 + (int)(ble - b_cat);
-                img_e = pool + se * FMD_BLK_U4; t_e = fmd_pool_xor(se);
+            if (need_e && (!e_sep || in_e)) {   // window of BWT[x1 ...]; x1 may sit in the block after ke's (ke = x1-1)
                 uint4 a, b, c;
-                grp_window(img_e, t_e, pool + sl * FMD_BLK_U4, fmd_pool_xor(sl), bke, ble, true, e_sep, bke, oke, a, b, c);
+                grp_window(img_e, t, pool + (in_e ? re : 0) * FMD_BLK_U4, fmd_pool_xor(in_e ? re : 0), bke, ble, true, e_sep, bke, oke, a, b, c);
                 const uint32_t sh = (uint32_t)x1 & 31;
                 X = win64(a.x, b.x, c.x, sh); Y = win64(a.y, b.y, c.y, sh); Z = win64(a.z, b.z, c.z, sh);
-                grp_window(img_b, t, pool + (b_sep ? rb : 0) * FMD_BLK_U4, fmd_pool_xor(b_sep ? rb : 0), bkb, blb, true, b_sep, bkb, okb, a, b, c);
+                need_e = false;
+            }
+            if (need_b && (!b_sep || in_b)) {   // '$' positions of BWT[x0 ...]
+                uint4 a, b, c;
+                grp_window(img_b, t, pool + (in_b ? rb : 0) * FMD_BLK_U4, fmd_pool_xor(in_b ? rb : 0), bkb, blb, true, b_sep, bkb, okb, a, b, c);
                 D = win64(~(a.x | a.y | a.z), ~(b.x | b.y | b.z), ~(c.x | c.y | c.z), (uint32_t)x0 & 31);
+                need_b = false;
             }
-        } else {
-            // general form (more requests than the pool holds: 0.2 % of the wave steps): one x[1] block per lane in slot 0,
-            // straddling ranges through the pool, GRP_POOL per pass; a lane reads its windows in the pass that brings its
-            // spill block(s), or in the first one.
-            fmd_fetch_slot<0>(ix, lds, bke, live);
-            fmd_fetch_slot<1>(ix, lds, bkb, live);
-            const uint64_t me = __ballot(e_sep);
-            const int n_e = __popcll(me), n_spill = n_e + __popcll(mb);
-            const int pe = fmd_below(me), pb = n_e + fmd_below(mb);
-            bool need_e = live, need_b = live;
-            for (int base = 0;; base += GRP_POOL) {
-                const int re = pe - base, rb = pb - base;
-                const bool in_e = e_sep && re >= 0 && re < GRP_POOL, in_b = b_sep && rb >= 0 && rb < GRP_POOL;
-                const int n_here = n_spill - base < GRP_POOL ? n_spill - base : GRP_POOL;
-                if (n_here > 0) {
-                    if (in_e) pool_blk[re] = ble;
-                    if (in_b) pool_blk[rb] = blb;
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    fmd_fetch_pool(ix, pool, pool_blk, n_here);
-                }
-                fmd_fetch_wait();
-                if (need_e && (!e_sep || in_e)) {   // window of BWT[x1 ...]; x1 may sit in the block after ke's (ke = x1-1)
-                    uint4 a, b, c;
-                    grp_window(img_e, t, pool + (in_e ? re : 0) * FMD_BLK_U4, fmd_pool_xor(in_e ? re : 0), bke, ble, true, e_sep, bke, oke, a, b, c);
-                    const uint32_t sh = (uint32_t)x1 & 31;
-                    X = win64(a.x, b.x, c.x, sh); Y = win64(a.y, b.y, c.y, sh); Z = win64(a.z, b.z, c.z, sh);
-                    need_e = false;
-                }
-                if (need_b && (!b_sep || in_b)) {   // '$' positions of BWT[x0 ...]
-                    uint4 a, b, c;
-                    grp_window(img_b, t, pool + (in_b ? rb : 0) * FMD_BLK_U4, fmd_pool_xor(in_b ? rb : 0), bkb, blb, true, b_sep, bkb, okb, a, b, c);
-                    D = win64(~(a.x | a.y | a.z), ~(b.x | b.y | b.z), ~(c.x | c.y | c.z), (uint32_t)x0 & 31);
-                    need_b = false;
-                }
-                if (base + GRP_POOL >= n_spill) break;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the windows are read before the next pass lands in the pool
-            }
+            if (base + GRP_POOL >= n_spill) break;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the windows are read before the next pass lands in the pool
         }
 
         // Absolute ranks are needed only for the coordinates that survive: x[1] of the kept child
@@ -276,6 +226,8 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
         }
 
         // ---- the reference's sequential loop over the list, as prefix logic on group ballots
+        const uint32_t alive_g = (uint32_t)(__ballot(live) >> gbase) & GM;
+        const int ncur = __popc(alive_g);
         if (active && !(LF_GET(flags) & 0x10000u)) { // check_left's rounds (include/fmd_hip.h, FMD_LFORK_*): which bases do the reads that start inside X go on with?
             uint32_t u = 0;
 #pragma unroll
@@ -285,6 +237,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
             else LF_SET(flags, (uint32_t)(round + 1) | ((u & 32u) ? 0x10000u : 0u));  // consistent; an N child is not followed any further
         }
         const uint32_t nei_g = (uint32_t)(__ballot(is_nei) >> gbase) & GM;
+        const uint32_t head_g = (uint32_t)(__ballot(live && cat == j) >> gbase) & GM;   // first lane of each category
         const uint32_t in_cat_upto_j = (uint32_t)(bits_below(j + 1) & ~bits_below(cat));
         const bool new_nei = is_nei && (nei_g & in_cat_upto_j & (uint32_t)bits_below(j)) == 0; // first neighbour of its category
         const bool keep = live && (nei_g & in_cat_upto_j) == 0;                                 // not masked, not a neighbour
@@ -302,6 +255,9 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
         const uint32_t c1 = (uint32_t)(__ballot((cm >> 1) & 1) >> gbase) & GM, c2 = (uint32_t)(__ballot((cm >> 2) & 1) >> gbase) & GM;
         const uint32_t c3 = (uint32_t)(__ballot((cm >> 3) & 1) >> gbase) & GM, c4 = (uint32_t)(__ballot((cm >> 4) & 1) >> gbase) & GM;
         const int n_new = __popc(c1) + __popc(c2) + __popc(c3) + __popc(c4);
+        const uint32_t later_heads = (cat + 1 >= 32) ? 0u : (head_g >> (cat + 1));
+        const int cat_end = later_heads ? cat + 1 + (__ffs((int)later_heads) - 1) : ncur;
+        const uint32_t before_m = (uint32_t)bits_below(cat), same_m = (uint32_t)(bits_below(cat_end) & ~bits_below(cat));
         const uint32_t lt_m = same_m & (uint32_t)bits_below(j);
         const int before = __popc(c1 & before_m) + __popc(c2 & before_m) + __popc(c3 & before_m) + __popc(c4 & before_m);
         const int p1 = before, p2 = p1 + __popc(c1 & same_m), p3 = p2 + __popc(c2 & same_m), p4 = p3 + __popc(c3 & same_m);
@@ -320,7 +276,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
             while (__ballot(todo != 0 || nei_todo != 0)) {
                 const bool on_b = nei_todo == 1;
                 const int c = todo ? __ffs((int)todo) - 1 : 0;
-                const uint64_t r = fmd_block_rank1(on_b ? img_b : img_e, on_b ? t : t_e, (on_b ? okb : oke) + 1, c, on_b ? bkb : bke);
+                const uint64_t r = fmd_block_rank1(on_b ? img_b : img_e, t, (on_b ? okb : oke) + 1, c, on_b ? bkb : bke);
                 if (todo) {
                     const int pc = c == 1 ? p1 : c == 2 ? p2 : c == 3 ? p3 : p4;
                     const uint32_t cmask = c == 1 ? c1 : c == 2 ? c2 : c == 3 ? c3 : c4;

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""The bench legs with nothing around them, for the rocprofv3 --pmc passes (tools/pmc_collect.sh): K steps of each leg at
+bench.py's sizes, no warm-up, no checks, no instrumented build -- every launch of a leg's kernels in the profile belongs
+to one of its K steps.  Usage: python tools/pmc_legs.py [steps=2]"""
+import ctypes as C, math, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from fermi_amd import api, workload
+import bench
+
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+n_reads = int(os.environ.get("FMD_BENCH_READS", "50000000"))
+n_bs = int(os.environ.get("FMD_BENCH_BSEARCH_READS", "10000000"))
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+L = 100
+sh = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+lib = api.lib()
+
+
+def index_of(n, err):
+    rd = workload.ReadsOnDevice.synth(n, L, 30, err, dev)
+    d_bwt, n_sym = workload.build_bwt_on_device(rd, 0)
+    ix = api.DevIndex.from_bwt_dev(d_bwt, n_sym, 0)
+    lib.fmd_dev_free(d_bwt)
+    return rd, ix, n_sym
+
+
+# overlap (+ check_left) at n_reads, e = 0
+rd, ix, n_sym = index_of(n_reads, 0.0)
+del rd
+job = bench.OverlapJob(torch, api, ix, dev, 2 * n_reads, 0, 1, L, 50)
+for _ in range(K):
+    job.compute()
+torch.cuda.synchronize()
+for _ in range(K):
+    job.check_left()
+torch.cuda.synchronize()
+del job
+ix.close(); torch.cuda.empty_cache()
+# backward search at n_bs, e = 0
+rd, ix, _ = index_of(n_bs, 0.0)
+cnt = torch.zeros(n_bs, dtype=torch.int64, device=dev); beg = torch.zeros_like(cnt); end = torch.zeros_like(cnt)
+for _ in range(K):
+    api.check(lib.fmd_bsearch_dev(ix.h, sh, n_bs, rd.flat.data_ptr(), rd.off.data_ptr(), cnt.data_ptr(), beg.data_ptr(), end.data_ptr()))
+torch.cuda.synchronize()
+ix.close(); del rd, cnt, beg, end; torch.cuda.empty_cache()
+# SMEM + k-mer harvest at n_reads, e = 0.01
+rd, ix, n_sym = index_of(n_reads, 0.01)
+mem = torch.zeros(n_reads * 8 * 32, dtype=torch.uint8, device=dev); n_mem = torch.zeros(n_reads, dtype=torch.int32, device=dev)
+wb = lib.fmd_smem_work_bytes(n_reads, L); work = torch.empty(wb, dtype=torch.uint8, device=dev)
+for _ in range(K):
+    api.check(lib.fmd_smem_dev(ix.h, sh, n_reads, rd.flat.data_ptr(), rd.off.data_ptr(), 0, L, 8, mem.data_ptr(), n_mem.data_ptr(), work.data_ptr(), wb))
+torch.cuda.synchronize()
+del mem, n_mem, work, rd; torch.cuda.empty_cache()
+w = min(27, int(math.log(n_sym) / math.log(4) + 8.499)); suf = w - 15 if w > 15 else 1
+cap = max(1 << 22, 1 << int(math.ceil(math.log2(n_sym / 30.0 * 1.5))))
+wb = lib.fmd_kmer_work_bytes(cap); work = torch.empty(wb, dtype=torch.uint8, device=dev)
+ob = torch.empty(cap, dtype=torch.int32, device=dev); ok_ = torch.empty(cap, dtype=torch.int32, device=dev); ov = torch.empty(cap, dtype=torch.uint8, device=dev)
+st = torch.zeros(4, dtype=torch.int64, device=dev)
+for _ in range(K):
+    api.check(lib.fmd_kmer_collect_dev(ix.h, sh, w, 3, suf, work.data_ptr(), wb, cap, ob.data_ptr(), ok_.data_ptr(), ov.data_ptr(), st.data_ptr()))
+torch.cuda.synchronize()
+ix.close()
+print("pmc_legs: %d steps per leg at %d / %d reads" % (K, n_reads, n_bs))

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc passes of tools/pmc_legs.py -> profiles/pmc_traffic.json, keyed by leg@reads and stamped with the sha
+of the kernel sources they were measured on (bench.py prints roofline.traffic only when that sha is the tree's).
+FETCH_SIZE / WRITE_SIZE are KB (MI355X_MICROARCH.md, HBM section); FETCH_SIZE is calibrated on the gather probe (64-byte
+lines, known byte count), as that section prescribes for anything but wide streaming reads.
+Usage: python tools/pmc_to_json.py <dir with pmc_fetch/ pmc_write/ pmc_probe/> <steps> <n_reads> <n_bsearch_reads> <source label>"""
+import csv, glob, json, os, sys
+from collections import defaultdict
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+
+d, steps, n_reads, n_bs, label = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+LEGS = {"overlap@%d" % n_reads: ("k_ovl_walk", "k_ovl_seq_out", "k_ovl_classify", "k_ovl_nei_grp", "k_ovl_nei"),
+        "check_left@%d" % n_reads: ("k_ovl_cls",), "k_bsearch@%d" % n_bs: ("k_bsearch",), "smem@%d" % n_reads: ("k_smem",),
+        "kmer@%d" % n_reads: ("k_kmer_level", "k_kmer_emit")}
+
+
+def sums(sub, counter):
+    f = glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True)
+    acc = defaultdict(float)
+    if f:
+        for r in csv.DictReader(open(f[0])):
+            if r["Counter_Name"] == counter:
+                acc[r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]] += float(r["Counter_Value"])
+    return acc
+
+
+fetch, write, probe = sums("pmc_fetch", "FETCH_SIZE"), sums("pmc_write", "WRITE_SIZE"), sums("pmc_probe", "FETCH_SIZE")
+cal = 1.0
+if probe.get("k_probe"):
+    known = 2 * (1 << 27) * 64            # probe_once: warm-up + timed launch, 2^27 lines of 64 bytes each
+    cal = known / (probe["k_probe"] * 1024.0)
+out = {"_comment": "HBM bytes per bench step from rocprofv3 --pmc passes over tools/pmc_legs.py (tools/pmc_collect.sh): sum over the launches of a leg's "
+                   "kernels / steps.  KB units; FETCH_SIZE x fetch_calibration (gather probe, 64-byte lines: %.4f).  Valid for kernel sources with this sha only." % cal}
+for key, names in LEGS.items():
+    fk = sum(v for k, v in fetch.items() if k in names) / steps
+    wk = sum(v for k, v in write.items() if k in names) / steps
+    if fk:
+        out[key] = {"fetch_kb": fk, "write_kb": wk, "fetch_calibration": cal, "csrc_sha": bench.csrc_sha(), "source": label,
+                    "per_kernel_fetch_kb": {k: v / steps for k, v in fetch.items() if k in names}}
+json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1)[:3000])
