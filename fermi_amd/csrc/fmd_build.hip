@@ -8,6 +8,7 @@
 // in about a second for 2e9 suffixes, instead of SA-IS + merging on the host.
 #include <hipcub/hipcub.hpp>
 #include <stdlib.h>
+#include <vector>
 #include "fmd_internal.h"
 
 // text[T_s ..] for sequence s = 2r (forward) / 2r+1 (reverse complement); one thread per read base
@@ -89,10 +90,28 @@ struct DevPtr { void *p = nullptr; ~DevPtr() { if (p) hipFree(p); } };
 
 
 // ------------------------------------------------------------------ >= 2^32 symbols: bucketed
-// Same ordering, sorted one first-symbol bucket at a time with 64-bit text positions: the suffixes
-// starting with '$' are already in order (sequence id = text order), the others take the LSD passes
-// inside their bucket only.  Peak memory = text + 48 bytes per suffix of the largest bucket.
-struct IsSym { const uint8_t *text; uint8_t c; __device__ bool operator()(const uint64_t &t) const { return text[t] == c; } };
+// Same ordering, sorted one PREFIX bucket at a time with 64-bit text positions.  A bucket = the suffixes that share
+// their first `depth` symbols (a '$' ends the comparison: what follows it in the text belongs to the next sequence and
+// counts as zeros, exactly as in the chunk keys); buckets taken in increasing prefix order are contiguous in the BWT.
+// The suffixes starting with '$' are already in order (sequence id = text order); so is every bucket whose prefix holds
+// a '$' (all its suffixes are equal up to their '$': ties go by sequence id).  The others take the LSD passes inside
+// their bucket only.  Peak memory = text + BWT + 32 bytes per suffix of the largest bucket (+ the sort's scratch):
+// depth 1 carries 50 M x 100 bp reads, depth 2-3 the 2.5*10^8 x 100 bp (5*10^10 symbols) that one 288 GB GPU can hold
+// next to its own text and BWT.
+struct HasPrefix {
+    const uint8_t *text; uint64_t n; int depth; uint32_t code;   // code: 3 bits per symbol, first symbol on top
+    __device__ bool operator()(const uint64_t &t) const
+    {
+        uint32_t c = 0;
+        int j = 0;
+        for (; j < depth; ++j) {
+            const uint32_t x = t + (uint64_t)j < n ? text[t + j] : 0u;
+            c = c << 3 | x;
+            if (x == 0) { c <<= 3 * (depth - 1 - j); break; }
+        }
+        return c == code;
+    }
+};
 
 template <class Rem>
 __global__ void k_chunk_keys64(const uint8_t *__restrict__ text, uint64_t m, const uint64_t *__restrict__ ids, int chunk, Rem rem,
@@ -117,46 +136,72 @@ __global__ void k_emit_bwt64(const uint8_t *__restrict__ text, const uint64_t *_
     }
 }
 
-static int build_bucketed(hipStream_t st, const uint8_t *text, uint64_t n, uint32_t max_len, int uniform_len, RemRagged rr, uint8_t *bwt)
+// prefixes of `depth` symbols in increasing order: digits 0..5, nothing but zeros after a zero
+static void prefix_codes(int depth, std::vector<uint32_t> &out)
+{
+    std::vector<uint32_t> cur(1, 0u);
+    for (int j = 0; j < depth; ++j) {
+        std::vector<uint32_t> nxt;
+        for (uint32_t p : cur) {
+            const bool ended = j > 0 && ((p & 7u) == 0);          // the last symbol was '$' (or the prefix ended earlier)
+            if (ended) { nxt.push_back(p << 3); continue; }
+            for (uint32_t c = 0; c < 6; ++c) nxt.push_back(p << 3 | c);
+        }
+        cur.swap(nxt);
+    }
+    out.swap(cur);   // generated in increasing numeric order
+}
+
+static int build_bucketed(hipStream_t st, const uint8_t *text, uint64_t n, uint32_t max_len, int uniform_len, RemRagged rr, uint8_t *bwt, int depth)
 {
     DevPtr cnt;
     DALLOC(cnt, 8);
     const int n_chunks = (int)((max_len + 1 + 20) / 21);
-    uint64_t done = 0;
-    for (int c = 0; c < 6; ++c) {
-        // positions of this bucket, ascending
-        size_t tb = 0;
-        hipcub::CountingInputIterator<uint64_t> it(0);
-        IsSym op{text, (uint8_t)c};
+    std::vector<uint32_t> codes;
+    prefix_codes(depth, codes);
+    uint64_t done = 0, cap = 0;
+    DevPtr ids_a, ids_b, keys_a, keys_b, tmp, stmp;     // grown to the largest bucket met so far
+    size_t tb = 0, sb = 0;
+    hipcub::CountingInputIterator<uint64_t> it(0);
+    {
+        HasPrefix op{text, n, depth, 0};
         FMD_HIP_TRY(hipcub::DeviceSelect::If(nullptr, tb, it, (uint64_t *)nullptr, (uint64_t *)cnt.p, (int64_t)n, op, st));
-        // upper bound of the bucket size is not known before selecting: count first
+        DALLOC(tmp, tb);
+    }
+    for (uint32_t code : codes) {
+        HasPrefix op{text, n, depth, code};
+        bool has_end = false;                               // a '$' inside the prefix: the bucket is in order as it is
+        for (int j = 0; j < depth; ++j) if (((code >> (3 * (depth - 1 - j))) & 7u) == 0) has_end = true;
+        // size of the bucket first (selection into a discard iterator), then its positions, ascending
         uint64_t m = 0;
         {
-            DevPtr tmp, out;
-            DALLOC(tmp, tb);
-            // count only: select into a scratch of full size would be wasteful; use a reduce via select on a discard iterator
             hipcub::DiscardOutputIterator<uint64_t> discard;
             FMD_HIP_TRY(hipcub::DeviceSelect::If(tmp.p, tb, it, discard, (uint64_t *)cnt.p, (int64_t)n, op, st));
             FMD_HIP_TRY(hipMemcpyAsync(&m, cnt.p, 8, hipMemcpyDeviceToHost, st));
             FMD_HIP_TRY(hipStreamSynchronize(st));
         }
         if (m == 0) continue;
-        DevPtr ids_a, ids_b, keys_a, keys_b, tmp, stmp;
-        DALLOC(ids_a, m * 8);
-        DALLOC(tmp, tb);
+        if (m > cap) {                                      // grow: release first, the arrays are the bulk of the footprint
+            hipFree(ids_a.p); hipFree(ids_b.p); hipFree(keys_a.p); hipFree(keys_b.p); hipFree(stmp.p);
+            ids_a.p = ids_b.p = keys_a.p = keys_b.p = stmp.p = nullptr;
+            cap = m + m / 16;
+            DALLOC(ids_a, cap * 8); DALLOC(ids_b, cap * 8); DALLOC(keys_a, cap * 8); DALLOC(keys_b, cap * 8);
+            FMD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sb, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, (uint64_t *)ids_a.p,
+                                                          (uint64_t *)ids_b.p, (size_t)cap, 0, 63, st));
+            DALLOC(stmp, sb);
+        }
         FMD_HIP_TRY(hipcub::DeviceSelect::If(tmp.p, tb, it, (uint64_t *)ids_a.p, (uint64_t *)cnt.p, (int64_t)n, op, st));
         uint64_t *cur = (uint64_t *)ids_a.p;
-        if (c != 0) {
-            DALLOC(ids_b, m * 8); DALLOC(keys_a, m * 8); DALLOC(keys_b, m * 8);
-            size_t sb = 0;
-            FMD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sb, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, (uint64_t *)ids_a.p,
-                                                          (uint64_t *)ids_b.p, (size_t)m, 0, 63, st));
-            DALLOC(stmp, sb);
+        if (!has_end) {
             uint64_t *nxt = (uint64_t *)ids_b.p;
+            size_t sb_m = 0;
+            FMD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sb_m, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, cur, nxt, (size_t)m, 0, 63, st));
             for (int ch = n_chunks - 1; ch >= 0; --ch) {
                 if (uniform_len) k_chunk_keys64<<<nblk(m, 256), 256, 0, st>>>(text, m, cur, ch, RemUniform{max_len + 1}, (uint64_t *)keys_a.p);
                 else k_chunk_keys64<<<nblk(m, 256), 256, 0, st>>>(text, m, cur, ch, rr, (uint64_t *)keys_a.p);
-                FMD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(stmp.p, sb, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, cur, nxt, (size_t)m, 0, 63, st));
+                // the first `depth` symbols are equal inside a bucket: chunk 0 sorts on the bits below them only
+                const int end_bit = ch == 0 ? 63 - 3 * (depth < 21 ? depth : 21) : 63;
+                FMD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(stmp.p, sb_m, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, cur, nxt, (size_t)m, 0, end_bit, st));
                 uint64_t *t = cur; cur = nxt; nxt = t;
             }
         }
@@ -165,6 +210,23 @@ static int build_bucketed(hipStream_t st, const uint8_t *text, uint64_t n, uint3
         done += m;
     }
     return done == n ? FMD_OK : FMD_E_HIP;
+}
+
+// prefix depth of the bucketed builder: the shallowest whose largest bucket (estimated from the A/C/G/T share of the
+// text, with room for skew) fits the free memory next to text and BWT
+static int bucket_depth(uint64_t n)
+{
+    const char *e = getenv("FMD_BUILD_DEPTH");
+    if (e && atoi(e) >= 1 && atoi(e) <= 6) return atoi(e);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 3;
+    for (int d = 1; d <= 5; ++d) {
+        double share = 1.0;
+        for (int j = 0; j < d; ++j) share /= 4.0;
+        const double need = 34.0 * 1.6 * share * (double)n;     // 32 bytes per suffix + scratch, 1.6x the even share
+        if (need < 0.85 * (double)free_b) return d;
+    }
+    return 6;
 }
 
 extern "C" void fmd_dev_free(void *d_ptr) { if (d_ptr) hipFree(d_ptr); }
@@ -190,7 +252,7 @@ extern "C" int fmd_build_bwt_dev(int device, void *stream_, size_t n_reads, cons
     }
     if (bucketed) {
         FMD_HIP_TRY(hipMalloc((void **)&bwt, n + 64));
-        int rc = build_bucketed(st, (const uint8_t *)text.p, n, max_len, uniform_len, rr, bwt);
+        int rc = build_bucketed(st, (const uint8_t *)text.p, n, max_len, uniform_len, rr, bwt, bucket_depth(n));
         if (rc) { hipFree(bwt); return rc; }
         *d_bwt_out = bwt; *n_sym_out = n;
         return FMD_OK;

@@ -513,11 +513,18 @@ def test_build_cli_equals_fermi_build(gpu, gold, tmp_path, name):
     assert open(out, "rb").read() == open(gold.path(name + ".fmd"), "rb").read()
 
 
-def test_bucketed_builder_equals_one_shot(gpu, gold, oracle_lib, monkeypatch):
-    """The >= 2^32-symbol construction path (per-first-symbol buckets, 64-bit positions), forced on
-    small inputs, gives the same BWT as `fermi build`."""
+@pytest.mark.parametrize("depth", [1, 2, 3, 4])
+def test_bucketed_builder_equals_one_shot(gpu, gold, oracle_lib, monkeypatch, depth):
+    """The >= 2^32-symbol construction path (buckets by the first `depth` symbols, 64-bit positions), forced on
+    small inputs, gives the same BWT as `fermi build` -- ragged reads, Ns and sequences shorter than the prefix included."""
     from fermi_amd import hostlib
     monkeypatch.setenv("FMD_BUILD_BUCKETED", "1")
+    monkeypatch.setenv("FMD_BUILD_DEPTH", str(depth))
+    tiny_reads = [np.array(x, dtype=np.uint8) for x in ([1], [2, 2], [4, 5, 1], [3], [1, 2], [1])]   # tails shorter than any prefix
+    monkeypatch.delenv("FMD_BUILD_BUCKETED")
+    want_small = gpu.build_bwt(tiny_reads)                      # the one-shot builder (equal to `fermi build` on every fixture)
+    monkeypatch.setenv("FMD_BUILD_BUCKETED", "1")
+    assert np.array_equal(gpu.build_bwt(tiny_reads), want_small)
     for name in ("tiny", "special", "repeat"):
         reads = gold.fastq_nt6(name + ".fq.gz")
         reads = [r[:hostlib.trim_palindrome(r)] for r in reads]
