@@ -362,6 +362,23 @@ class OverlapJob:
             self.api.check(Lb.fmd_ovlp_check_left_dev(h, self.sh, c, self.min_match, self.L, self.rec.data_ptr() + o * 64,
                                                       self.seq.data_ptr() + o * self.stride, self.stride, self.work.data_ptr(), self.wb))
 
+    # ---- check_left as the product runs it on one GPU: verdicts from lfork (fmd_ovlp_link_dev), the exact kernel for the rest
+    def alloc_link(self):
+        torch = self.torch
+        self.row_of = torch.empty(self.n, dtype=torch.int32, device=self.dev)
+        self.link = torch.empty(2 * self.n, dtype=torch.int32, device=self.dev)
+        self.und = torch.empty(self.n, dtype=torch.int64, device=self.dev)
+        self.n_und = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.rec16 = self.rec.view(self.torch.int16).view(self.n, 32)
+
+    def check_left_linked(self, Lb=None, h=None):
+        Lb = Lb or self.api.lib()
+        h = h or self.index.h
+        self.rec16[:, 30] = 2                                   # rec.reserved: nothing decided yet
+        self.api.check(Lb.fmd_ovlp_link_dev(h, self.sh, self.n, self.rec.data_ptr(), self.nei.data_ptr(), 4 * self.max_nei,
+                                            self.row_of.data_ptr(), self.link.data_ptr(), self.und.data_ptr(), self.n_und.data_ptr()))
+        self.check_left(Lb, h)                                  # looks at the rows still at 2 only
+
     # ---- the one exchange (N > 1): packed rows of every rank -> rank 0, device to device
     def alloc_packed(self):
         torch, lib = self.torch, self.api.lib()
@@ -442,7 +459,7 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
         job.rec, job.nei, job.seq = keep
     ctr = Counter(api, fmd_path, local_rank)
     lines = ctr.run(job.compute)
-    cl_lines = ctr.run(job.check_left) if "check_left" in legs else None
+    cl_lines = None
     ctr.close()
     torch.cuda.synchronize()
     ok_rows = (g_rec["status"] == 0) & ((g_rec["flags"] & api.OVLP_F_OVERFLOW) == 0)
@@ -474,17 +491,23 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
     return out, job
 
 
-def bench_check_left(torch, api, job, n_reads, steps, warmup, fmd_path, ovl):
-    """check_left_simple (unitig.c:186-204) for every strand with a unique neighbour: the second pass the real `unitig`
-    needs over a finished batch (rec.reserved).  Timed against the discovery it follows."""
-    cl_lines = ovl.pop("_check_left_lines", None)
+def bench_check_left(torch, api, job, n_reads, steps, warmup, fmd_path, ovl, local_rank):
+    """check_left_simple (unitig.c:186-204) for every strand with a unique neighbour, as the product computes it on one GPU:
+    the verdict of almost every edge follows from the lfork field the discovery kernels already wrote for the neighbour's
+    reverse strand (fmd_ovlp_link_dev: two streaming kernels, which also build the walk's row map and links); the exact
+    kernel (fmd_ovlp_check_left_dev) runs on the edges that field leaves open.  Timed against the discovery it follows;
+    the exact kernel on EVERY edge (what round 1 shipped) is timed once beside it."""
+    ovl.pop("_check_left_lines", None)
     dev, stream = job.dev, job.stream
-    wall, kern_ms = timed(torch, None, dev, stream, job.check_left, steps, warmup)
+    job.alloc_link()
+    wall, kern_ms = timed(torch, None, dev, stream, job.check_left_linked, steps, warmup)
+    n_und = int(job.n_und.item())
     g_rec = job.rec.cpu().numpy().view(api.OVLP_DT)
     n_edges = int(((g_rec["status"] == 0) & (g_rec["n_nei"] == 1) & (g_rec["rbeg"] >= 0)).sum())
-    out = {"metric": "read-strands/sec through check_left_simple (unitig.c:186-204) over a finished overlap batch",
+    out = {"metric": "read-strands/sec through check_left_simple (unitig.c:186-204) over a finished overlap table: lfork verdicts + row map + links "
+                     "(fmd_ovlp_link_dev), exact kernel on the undecided edges",
            "value": job.n * steps / wall, "unit": "strands/s", "ms_per_step": wall / steps * 1e3, "edges_checked": n_edges,
-           "back_bifurcations": int((g_rec["reserved"] == 1).sum()),
+           "edges_left_to_the_exact_kernel": n_und, "back_bifurcations": int((g_rec["reserved"] == 1).sum()),
            "fraction_of_discovery_time": (wall / steps * 1e3) / ovl["ms_per_step"]}
     ns = 4000
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -496,12 +519,28 @@ def bench_check_left(torch, api, job, n_reads, steps, warmup, fmd_path, ovl):
     q = {k: c1[k] - c0[k] for k in c1}
     qps = (q["rank1a"] + q["rank2a"] + q["rank2a_spill"]) / float(ns)
     same = bool(np.array_equal(rec_o["reserved"], g_rec["reserved"][:ns]))
-    out["parity_vs_oracle_on_sample"] = "bit-exact (reserved flags of ids 0..%d)" % (ns - 1) if same else "MISMATCH"
-    io = job.n * (64 + 64 + 100)
-    dev_bytes = None if cl_lines is None else (cl_lines[0] + cl_lines[1]) * BLOCK_BYTES + io
-    out["roofline"] = roofline("k_ovl_cls", kern_ms, dev_bytes, {"rank_blocks": cl_lines and cl_lines[0], "stream_bytes": io,
-                                                                 "streams": "record read + write, sequence row read (candidate lists in HBM not modelled)"},
-                               qps * BYTES_PER_RANK_QUERY * job.n, "check_left@%d" % n_reads, {"rank_queries_per_strand": qps})
+    out["parity_vs_oracle_on_sample"] = "bit-exact (check_left_simple of ids 0..%d)" % (ns - 1) if same else "MISMATCH"
+    # device bytes of the linked form: rec read twice + reserved written, neighbour x0/x1 read, row map written + read twice, links written
+    io = job.n * (2 * 64 + 64 + 16 + 3 * 4 + 8) + n_und * 8
+    ctr = Counter(api, fmd_path, local_rank)
+    lines = ctr.run(job.check_left_linked)
+    ctr.close()
+    dev_bytes = None if lines is None else (lines[0] + lines[1]) * BLOCK_BYTES + io
+    out["roofline"] = roofline("k_link_rows + k_link_edges (+ k_ovl_cls on %d undecided edges)" % n_und, kern_ms, dev_bytes,
+                               {"rank_blocks": lines and lines[0], "stream_bytes": io,
+                                "streams": "records read twice + verdict written, neighbour coordinates, row map scatter + two gathers, links"},
+                               qps * BYTES_PER_RANK_QUERY * job.n, "check_left@%d" % n_reads,
+                               {"rank_queries_per_strand_in_the_reference": qps,
+                                "note": "streaming kernels: the rank work check_left_simple would redo was already done by fm6_get_nei's rounds on the neighbour's reverse strand"})
+    # the round-1 form for comparison: the exact kernel on every edge
+    job.rec16[:, 30] = 2
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream); job.check_left(); e1.record(stream)
+    torch.cuda.synchronize()
+    out["exact_kernel_on_every_edge_ms"] = e0.elapsed_time(e1)
+    g2 = job.rec.cpu().numpy().view(api.OVLP_DT)
+    out["lfork_verdicts_equal_exact_kernel"] = bool(np.array_equal(g2["reserved"], g_rec["reserved"]))
     return out
 
 
@@ -774,7 +813,7 @@ def main():
     ovl, job = bench_overlap(torch, api, index, dev, n_reads, L, args.steps, args.warmup, dist, world, rank, fmd_path, local_rank, legs)
     cl = None
     if rank == 0 and world == 1 and "check_left" in legs:
-        cl = bench_check_left(torch, api, job, n_reads, max(1, min(args.steps, 3)), min(args.warmup, 1), fmd_path, ovl)
+        cl = bench_check_left(torch, api, job, n_reads, max(1, min(args.steps, 3)), min(args.warmup, 1), fmd_path, ovl, local_rank)
     elif ovl:
         ovl.pop("_check_left_lines", None)
     hbm_index = index.hbm_bytes

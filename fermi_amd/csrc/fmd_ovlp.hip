@@ -670,7 +670,8 @@ __global__ __launch_bounds__(64) void k_ovl_cls(FmdIndexView ix, size_t n, int m
         if (st == CL_IDLE && !exhausted) {
             if (my < n) {
                 fmd_ovlp_rec_t *o = rec + my;
-                if (o->status == 0 && o->n_nei == 1 && o->rbeg >= 0 && !(o->flags & FMD_OVLP_F_OVERFLOW) &&
+                if (o->reserved != 2) {}   // decided already (fmd_ovlp_link_dev): only the rows still open are looked at
+                else if (o->status == 0 && o->n_nei == 1 && o->rbeg >= 0 && !(o->flags & FMD_OVLP_F_OVERFLOW) &&
                     (uint32_t)(o->len + o->ext_len) <= seq_stride) {
                     sid = my; rbeg = o->rbeg; s_l = o->len + o->ext_len;
                     s = seq + sid * (size_t)seq_stride;

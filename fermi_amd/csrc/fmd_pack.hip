@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <time.h>
 #include <sys/mman.h>
+#include <algorithm>
 #include <vector>
 #include <hipcub/hipcub.hpp>
 #include "fmd_kernel_common.h"
@@ -121,6 +122,70 @@ extern "C" int fmd_ovlp_pack_dev(fmd_dev_t *h, void *stream_, size_t n, const fm
 }
 
 // ------------------------------------------------------------------------------------------------
+// The link pass over a COMPLETE table resident on one device (rows = sequence ids 0 .. n-1): what the unitig walk needs
+// to step from a read to the next without touching neighbour lists, and check_left_simple's verdict for every edge
+// from the lfork of the neighbour's reverse strand (include/fmd_hip.h).  The host does the same over sharded tables
+// (fmdh_ovlp_table_link); on one GPU this is two streaming kernels instead of 0.4 s of host threads.
+//   row_of[k]  = smallest id whose `$read$` interval starts at k (identical reads share one interval), ~0 = none
+//   link[i]    = {row_of[nei.x0], row_of[nei.x1]} of the unique neighbour, {~0, ~0} otherwise
+//   rec[i].reserved: 0 / 1 where lfork decides the edge; 2 (untouched) elsewhere -- those ids are appended to und[]
+__device__ __forceinline__ int lfork_decide_dev(uint16_t lfork, int rbeg)   // fmd_lfork_decide of include/fmd_hip.h (a host inline there)
+{
+    const int r = lfork & 0x7fff;
+    if (rbeg <= r || r == (int)FMD_LFORK_ALL) return 0;
+    return (lfork & 0x8000) ? -1 : 1;
+}
+__global__ void k_link_rows(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, uint32_t *__restrict__ row_of)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+        const fmd_ovlp_rec_t *r = rec + i;
+        if (r->status == 0 && !(r->flags & FMD_OVLP_F_OVERFLOW) && r->k[0] < n) atomicMin(row_of + r->k[0], (uint32_t)i);
+    }
+}
+__global__ void k_link_edges(size_t n, fmd_ovlp_rec_t *__restrict__ rec, const uint64_t *__restrict__ nei_x01, uint32_t nei_stride,
+                             const uint32_t *__restrict__ row_of, fmd_ovlp_link_t *__restrict__ link, uint64_t *__restrict__ und,
+                             unsigned long long *__restrict__ n_und, int force_exact)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+        fmd_ovlp_rec_t *r = rec + i;
+        fmd_ovlp_link_t l; l.nxt = l.rev = 0xffffffffu;
+        if (r->status == 0 && r->n_nei == 1 && r->rbeg >= 0 && !(r->flags & FMD_OVLP_F_OVERFLOW)) {
+            const uint64_t x0 = nei_x01[i * (size_t)nei_stride], x1 = nei_x01[i * (size_t)nei_stride + 1];
+            if (x0 < n) l.nxt = row_of[x0];
+            if (x1 < n) l.rev = row_of[x1];
+            if (r->reserved == 2) {
+                int d = 1;
+                if (l.rev != 0xffffffffu && !force_exact) d = lfork_decide_dev(rec[l.rev].lfork, r->rbeg);
+                if (d != 1) r->reserved = (uint16_t)(d < 0 ? 1 : 0);
+                else und[atomicAdd(n_und, 1ull)] = i;
+            }
+        }
+        link[i] = l;
+    }
+}
+extern "C" int fmd_ovlp_link_dev(fmd_dev_t *h, void *stream_, size_t n, fmd_ovlp_rec_t *d_rec, const uint64_t *d_nei_x01, uint32_t nei_stride_u64,
+                                 uint32_t *d_row_of, fmd_ovlp_link_t *d_link, uint64_t *d_undecided, uint64_t *d_n_undecided)
+{
+    if (!h || (n && (!d_rec || !d_nei_x01 || !d_row_of || !d_link || !d_undecided || !d_n_undecided)) || nei_stride_u64 < 2) return FMD_E_ARG;
+    if (n >= 0xffffffffull) return FMD_E_ARG;                     // 32-bit row numbers
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream_;
+    FMD_HIP_TRY(hipMemsetAsync(d_n_undecided, 0, 8, st));
+    if (n == 0) return FMD_OK;
+    FMD_HIP_TRY(hipMemsetAsync(d_row_of, 0xff, n * 4, st));
+    size_t blocks = (n + 255) / 256;
+    if (blocks > (1u << 20)) blocks = 1u << 20;
+    k_link_rows<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, d_row_of);
+    k_link_edges<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, d_nei_x01, nei_stride_u64, d_row_of, d_link, d_undecided, (unsigned long long *)d_n_undecided,
+                                                  getenv("FMD_CHECK_LEFT_EXACT") != nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fmd_set_hip_error(e, "link kernels"); return FMD_E_HIP; }
+    return FMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Host form: the whole table of one shard of sequence ids, packed, pipelined.
 //
 // ids = first, first + step, ... (the reference's worker interleave, unitig.c:333, 398-399) or an explicit list.
@@ -163,8 +228,22 @@ extern "C" void fmd_ovlp_packed_free(uint8_t **chunks, size_t n_chunks)
     for (size_t c = 0; c < n_chunks; ++c) { free(chunks[c]); chunks[c] = nullptr; }
 }
 
-extern "C" int fmd_ovlp_packed_batch(fmd_dev_t *h, const uint64_t *ids, uint64_t first, uint64_t step, size_t n, int min_match, uint32_t max_len,
-                                     uint32_t max_nei, int with_check_left, fmd_ovlp_rec_t *rec, uint64_t *off, uint32_t chunk_shift, uint8_t **chunks)
+// rows of all chunks kept on the device for the link pass at the end (whole-table form only)
+struct KeepRows { fmd_ovlp_rec_t *rec; uint64_t *nei01; };
+__global__ void k_keep_nei01(size_t n, const fmd_intv_t *__restrict__ nei, uint32_t max_nei, uint64_t *__restrict__ out)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) { out[2 * i] = nei[i * (size_t)max_nei].x[0]; out[2 * i + 1] = nei[i * (size_t)max_nei].x[1]; }
+}
+__global__ void k_take_reserved(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, uint8_t *__restrict__ out)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) out[i] = (uint8_t)rec[i].reserved;
+}
+
+static int packed_batch_core(fmd_dev_t *h, const uint64_t *ids, uint64_t first, uint64_t step, size_t n, int min_match, uint32_t max_len,
+                             uint32_t max_nei, int with_check_left, fmd_ovlp_rec_t *rec, uint64_t *off, uint32_t chunk_shift, uint8_t **chunks,
+                             const KeepRows *keep, hipStream_t *stream_out)
 {
     if (!h || (n && (!rec || !off || !chunks)) || chunk_shift < 10 || chunk_shift > 26 || max_len == 0 || max_nei == 0) return FMD_E_ARG;
     if (n == 0) return FMD_OK;
@@ -211,6 +290,10 @@ extern "C" int fmd_ovlp_packed_batch(fmd_dev_t *h, const uint64_t *ids, uint64_t
                 rc = fmd_ovlp_pack_dev(h, s_cmp.s, nc, (fmd_ovlp_rec_t *)d_rec.p, (fmd_intv_t *)d_nei.p, max_nei, (uint8_t *)d_seq.p, stride,
                                        (fmd_ovlp_rec_t *)d_prec[k].p, (uint64_t *)d_off[k].p, (uint8_t *)d_var[k].p, cap, d_work.p, wb);
             if (rc != FMD_OK) break;
+            if (keep) { // the fixed-stride record and the first neighbour's coordinates stay on the device for the link pass
+                if (hipMemcpyAsync(keep->rec + b, d_rec.p, nc * sizeof(fmd_ovlp_rec_t), hipMemcpyDeviceToDevice, s_cmp.s) != hipSuccess) { fail(FMD_E_HIP); break; }
+                k_keep_nei01<<<1024, 256, 0, s_cmp.s>>>(nc, (const fmd_intv_t *)d_nei.p, max_nei, keep->nei01 + 2 * b);
+            }
             if (hipMemcpyAsync(tot + k, (uint64_t *)d_off[k].p + nc, 8, hipMemcpyDeviceToHost, s_cmp.s) != hipSuccess || hipEventRecord(done[k].e, s_cmp.s) != hipSuccess) { fail(FMD_E_HIP); break; }
         }
         if (c >= 1) { // copy chunk c - 1 out while chunk c runs
@@ -250,5 +333,53 @@ extern "C" int fmd_ovlp_packed_batch(fmd_dev_t *h, const uint64_t *ids, uint64_t
         if (e != hipSuccess) { fmd_set_hip_error(e, "packed overlap batch"); rc = FMD_E_HIP; }
     } else if (rc == FMD_E_HIP) fmd_set_hip_error(hipGetLastError(), "packed overlap batch");
     if (rc != FMD_OK) fmd_ovlp_packed_free(chunks, n_chunks);
+    (void)stream_out;
+    return rc;
+}
+
+extern "C" int fmd_ovlp_packed_batch(fmd_dev_t *h, const uint64_t *ids, uint64_t first, uint64_t step, size_t n, int min_match, uint32_t max_len,
+                                     uint32_t max_nei, int with_check_left, fmd_ovlp_rec_t *rec, uint64_t *off, uint32_t chunk_shift, uint8_t **chunks)
+{
+    return packed_batch_core(h, ids, first, step, n, min_match, max_len, max_nei, with_check_left, rec, off, chunk_shift, chunks, nullptr, nullptr);
+}
+
+// The whole table (ids 0 .. n-1) on ONE device: the packed rows as above, then the link pass on the device
+// (fmd_ovlp_link_dev) -- row_of[n], link[n], rec[i].reserved set to check_left_simple's verdict wherever lfork decides it,
+// and the ids it leaves open in *undecided (malloc'ed, fmd_host_free; *n_undecided of them, ascending).
+extern "C" int fmd_ovlp_packed_table(fmd_dev_t *h, size_t n, int min_match, uint32_t max_len, uint32_t max_nei, fmd_ovlp_rec_t *rec, uint64_t *off,
+                                     uint32_t chunk_shift, uint8_t **chunks, uint32_t *row_of, fmd_ovlp_link_t *link, uint64_t **undecided, uint64_t *n_undecided)
+{
+    if (!h || !undecided || !n_undecided || (n && (!rec || !off || !chunks || !row_of || !link))) return FMD_E_ARG;
+    *undecided = nullptr; *n_undecided = 0;
+    if (n == 0) return FMD_OK;
+    if (n >= 0xffffffffull) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    DevMem d_rec_all, d_nei01, d_row_of, d_link, d_und, d_nund, d_res;
+    if (d_rec_all.alloc(h, n * sizeof(fmd_ovlp_rec_t)) || d_nei01.alloc(h, n * 16) || d_row_of.alloc(h, n * 4) || d_link.alloc(h, n * sizeof(fmd_ovlp_link_t)) ||
+        d_und.alloc(h, n * 8) || d_nund.alloc(h, 8) || d_res.alloc(h, n)) return FMD_E_NOMEM;
+    KeepRows keep{(fmd_ovlp_rec_t *)d_rec_all.p, (uint64_t *)d_nei01.p};
+    int rc = packed_batch_core(h, nullptr, 0, 1, n, min_match, max_len, max_nei, 0, rec, off, chunk_shift, chunks, &keep, nullptr);
+    if (rc) return rc;
+    const size_t n_chunks = (n + ((size_t)1 << chunk_shift) - 1) >> chunk_shift;
+    rc = fmd_ovlp_link_dev(h, nullptr, n, keep.rec, keep.nei01, 2, (uint32_t *)d_row_of.p, (fmd_ovlp_link_t *)d_link.p, (uint64_t *)d_und.p, (uint64_t *)d_nund.p);
+    if (rc == FMD_OK) {
+        size_t blocks = (n + 255) / 256;
+        if (blocks > (1u << 20)) blocks = 1u << 20;
+        k_take_reserved<<<(unsigned)blocks, 256>>>(n, keep.rec, (uint8_t *)d_res.p);
+        std::vector<uint8_t> res(n);
+        uint64_t nu = 0;
+        if (hipMemcpy(row_of, d_row_of.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(link, d_link.p, n * sizeof(fmd_ovlp_link_t), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(res.data(), d_res.p, n, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&nu, d_nund.p, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = FMD_E_HIP;
+        if (rc == FMD_OK) {
+            for (size_t i = 0; i < n; ++i) rec[i].reserved = res[i];
+            if (nu) {
+                uint64_t *u = (uint64_t *)malloc(nu * 8);
+                if (!u) rc = FMD_E_NOMEM;
+                else if (hipMemcpy(u, d_und.p, nu * 8, hipMemcpyDeviceToHost) != hipSuccess) { free(u); rc = FMD_E_HIP; }
+                else { std::sort(u, u + nu); *undecided = u; *n_undecided = nu; }
+            }
+        }
+    }
+    if (rc != FMD_OK) { fmd_ovlp_packed_free(chunks, n_chunks); if (rc == FMD_E_HIP) fmd_set_hip_error(hipGetLastError(), "packed table: link pass"); }
     return rc;
 }

@@ -148,7 +148,29 @@ done:
 typedef struct {
     const char *fmd_path; int device, g, n_dev, min_match; uint32_t max_len, max_nei;
     fmdh_ovlp_shard_t *shard; fmd_dev_t *dev; uint64_t n_seq; int rc; double t_load, t_rows;
+    fmdh_ovlp_table_t *whole;          /* one GPU: the table itself, linked on the device (fmd_ovlp_packed_table) */
+    uint64_t *und, n_und;
 } job_t;
+
+/* one GPU holds every row: the link pass runs there too */
+static int table_fill_linked(fmd_dev_t *d, fmdh_ovlp_table_t *t, uint64_t n, int min_match, uint32_t max_len, uint32_t max_nei, uint64_t **und, uint64_t *n_und)
+{
+    fmdh_ovlp_shard_t *s = &t->shard[0];
+    const size_t nc = (size_t)((n + ((uint64_t)1 << TABLE_CHUNK_SHIFT) - 1) >> TABLE_CHUNK_SHIFT);
+    memset(s, 0, sizeof(*s));
+    s->n = n; s->chunk_shift = TABLE_CHUNK_SHIFT; s->max_nei = max_nei; s->seq_stride = 2 * ((max_len + 3) / 4 * 4);
+    s->rec = (fmd_ovlp_rec_t *)fmdh_big_alloc((n ? n : 1) * sizeof(fmd_ovlp_rec_t));
+    s->off = (uint64_t *)fmdh_big_alloc((n ? n : 1) * 8);
+    s->chunk = (uint8_t **)calloc(nc ? nc : 1, sizeof(uint8_t *));
+    t->row_of = (uint32_t *)fmdh_big_alloc((n ? n : 1) * 4);
+    t->link = (fmdh_link_t *)fmdh_big_alloc((n ? n : 1) * sizeof(fmdh_link_t));
+    if (!s->rec || !s->off || !s->chunk || !t->row_of || !t->link) { shard_free(s); free(t->row_of); free(t->link); t->row_of = 0; t->link = 0; return FMD_E_NOMEM; }
+    {
+        const int rc = fmd_ovlp_packed_table(d, n, min_match, max_len, max_nei, s->rec, s->off, s->chunk_shift, s->chunk, t->row_of, (fmd_ovlp_link_t *)t->link, und, n_und);
+        if (rc) { shard_free(s); free(t->row_of); free(t->link); t->row_of = 0; t->link = 0; return rc; }
+    }
+    return FMD_OK;
+}
 
 static void *job_main(void *p)
 {
@@ -160,8 +182,10 @@ static void *job_main(void *p)
     fmd_dev_info(j->dev, &info);
     j->n_seq = info.mcnt[1];
     j->t_load = now_s() - t0; t0 = now_s();
-    {
+    if (j->whole && j->n_seq < 0xffffffffull && !getenv("FMD_HOST_LINK")) j->rc = table_fill_linked(j->dev, j->whole, j->n_seq, j->min_match, j->max_len, j->max_nei, &j->und, &j->n_und);
+    else {
         const uint64_t n = j->n_seq > (uint64_t)j->g ? (j->n_seq - (uint64_t)j->g + (uint64_t)j->n_dev - 1) / (uint64_t)j->n_dev : 0;
+        j->whole = 0;
         j->rc = shard_fill(j->dev, j->shard, 0, (uint64_t)j->g, (uint64_t)j->n_dev, n, j->min_match, j->max_len, j->max_nei, 0);
     }
     j->t_rows = now_s() - t0;
@@ -199,7 +223,7 @@ int fmdh_ovlp_table_build(const char *fmd_path, int n_dev, const int *devices, i
     if (!jobs || !tid || !started || !t->shard) { free(jobs); free(tid); free(started); free(t->shard); t->shard = 0; return 1; }
     t->n_shards = n_dev;
     for (g = 0; g < n_dev; ++g) {
-        job_t x = {fmd_path, devices[g], g, n_dev, min_match, max_len, max_nei, &t->shard[g], 0, 0, 0, 0, 0};
+        job_t x = {fmd_path, devices[g], g, n_dev, min_match, max_len, max_nei, &t->shard[g], 0, 0, 0, 0, 0, n_dev == 1 ? t : 0, 0, 0};
         jobs[g] = x;
         if (g > 0) started[g] = pthread_create(&tid[g], 0, job_main, &jobs[g]) == 0;
     }
@@ -249,9 +273,15 @@ int fmdh_ovlp_table_build(const char *fmd_path, int n_dev, const int *devices, i
         double t1 = now_s();
         int nt = 16;
         { const char *e = getenv("FMD_HOST_THREADS"); if (e && atoi(e) > 0) nt = atoi(e); }
-        rc = fmdh_ovlp_table_link(t, nt, &und, &n_und);
-        if (rc) { fprintf(stderr, "[E::%s] link pass: %s\n", __func__, strerror(-rc)); rc = 1; free(und); goto done; }
-        if (timing) fprintf(stderr, "[M::%s] link pass (%d threads): %.3f s, %llu edges left to the exact kernel\n", __func__, nt, now_s() - t1, (unsigned long long)n_und);
+        if (jobs[0].whole && n_side == 0) { /* linked on the device already */
+            und = jobs[0].und; n_und = jobs[0].n_und; jobs[0].und = 0;
+            if (timing) fprintf(stderr, "[M::%s] link pass on the GPU (inside the table pass), %llu edges left to the exact kernel\n", __func__, (unsigned long long)n_und);
+        } else {
+            fmd_host_free(jobs[0].und); jobs[0].und = 0;    /* rows were replaced by the overflow pass: link again, here */
+            rc = fmdh_ovlp_table_link(t, nt, &und, &n_und);
+            if (rc) { fprintf(stderr, "[E::%s] link pass: %s\n", __func__, strerror(-rc)); rc = 1; free(und); goto done; }
+            if (timing) fprintf(stderr, "[M::%s] link pass (%d threads): %.3f s, %llu edges left to the exact kernel\n", __func__, nt, now_s() - t1, (unsigned long long)n_und);
+        }
         if (n_und) {
             fmdh_ovlp_shard_t ex;
             uint32_t s_len = max_len, s_nei = max_nei;

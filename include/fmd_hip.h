@@ -228,6 +228,17 @@ int fmd_ovlp_pack_dev(fmd_dev_t *h, void *stream, size_t n, const fmd_ovlp_rec_t
                       const uint8_t *d_seq, uint32_t seq_stride, fmd_ovlp_rec_t *d_prec, uint64_t *d_off, uint8_t *d_var, uint64_t var_cap,
                       void *d_work, size_t work_bytes);
 
+/* The link pass over a COMPLETE table on one device (rows = sequence ids 0 .. n-1, fixed-stride records): row_of[k] = the
+ * smallest id whose `$read$` interval starts at k; link[i] = rows of the unique neighbour of i and of its reverse strand
+ * (what the walk's `cur = neighbour` and check_left's second look need, unitig.c:206-262); rec[i].reserved = 0 / 1 where
+ * the lfork of the neighbour's reverse strand decides check_left_simple, left at 2 elsewhere -- those ids are appended
+ * to d_undecided (any order; n capacity) for fmd_ovlp_check_left_dev, which only looks at rows still at 2.
+ * d_nei_x01: x[0], x[1] of each row's first neighbour at d_nei_x01[i * nei_stride_u64] (a fmd_intv_t array: stride
+ * 4 * max_nei; a compact copy: 2). */
+typedef struct { uint32_t nxt, rev; } fmd_ovlp_link_t;
+int fmd_ovlp_link_dev(fmd_dev_t *h, void *stream, size_t n, fmd_ovlp_rec_t *d_rec, const uint64_t *d_nei_x01, uint32_t nei_stride_u64,
+                      uint32_t *d_row_of, fmd_ovlp_link_t *d_link, uint64_t *d_undecided, uint64_t *d_n_undecided);
+
 /* Host form, pipelined: the packed table of one shard of sequence ids -- ids[0..n) when ids != NULL, else
  * first, first + step, ... (the reference's worker interleave, unitig.c:333, 398-399).  Chunks of 2^chunk_shift rows
  * are computed (fmd_ovlp_dev, fmd_ovlp_check_left_dev when asked, fmd_ovlp_pack_dev) while the previous chunk crosses
@@ -237,6 +248,11 @@ int fmd_ovlp_pack_dev(fmd_dev_t *h, void *stream, size_t n, const fmd_ovlp_rec_t
 int fmd_ovlp_packed_batch(fmd_dev_t *h, const uint64_t *ids, uint64_t first, uint64_t step, size_t n, int min_match, uint32_t max_len,
                           uint32_t max_nei, int with_check_left, fmd_ovlp_rec_t *rec, uint64_t *off, uint32_t chunk_shift, uint8_t **chunks);
 void fmd_ovlp_packed_free(uint8_t **chunks, size_t n_chunks);
+/* The whole table (ids 0 .. n-1) on ONE device: the packed rows as above (no per-row check_left), then fmd_ovlp_link_dev on
+ * the device: row_of[n], link[n], rec[i].reserved = check_left_simple's verdict wherever lfork decides it; the ids it leaves
+ * open come back in *undecided (malloc'ed: fmd_host_free; ascending) for a fmd_ovlp_packed_batch(ids, with_check_left = 1). */
+int fmd_ovlp_packed_table(fmd_dev_t *h, size_t n, int min_match, uint32_t max_len, uint32_t max_nei, fmd_ovlp_rec_t *rec, uint64_t *off,
+                          uint32_t chunk_shift, uint8_t **chunks, uint32_t *row_of, fmd_ovlp_link_t *link, uint64_t **undecided, uint64_t *n_undecided);
 /* layout of a packed row's variable part, from its (packed) record */
 static inline uint32_t fmd_ovlp_row_nei(const fmd_ovlp_rec_t *r, uint32_t max_nei)
 {

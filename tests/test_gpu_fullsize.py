@@ -42,7 +42,7 @@ def test_10m_reads_every_leg_bit_exact_on_random_samples(gpu):
     assert d["parity_vs_cpu_on_sample"] == "bit-exact"                                   # overlap records + neighbours, random ids
     assert d["overlap_discovery"]["pipelined_vs_serial_order"].startswith("identical")
     assert d["overlap_discovery"]["overflow_records"] == 0
-    assert d["check_left"]["parity_vs_oracle_on_sample"].startswith("bit-exact")
+    assert d["check_left"]["parity_vs_oracle_on_sample"].startswith("bit-exact") and d["check_left"]["lfork_verdicts_equal_exact_kernel"]
     assert d["backward_search"]["parity_vs_cpu_on_sample"] == "bit-exact" and d["backward_search"]["hits"] == 10_000_000
     assert d["smem"]["parity_vs_cpu_on_sample"] == "bit-exact" and d["smem"]["overflow_reads"] == 0
     assert d["kmer_harvest"]["parity_vs_cpu_on_sample"] == "bit-exact"

@@ -34,8 +34,9 @@ job = bench.OverlapJob(torch, api, ix, dev, 2 * n_reads, 0, 1, L, 50)
 for _ in range(K):
     job.compute()
 torch.cuda.synchronize()
+job.alloc_link()
 for _ in range(K):
-    job.check_left()
+    job.check_left_linked()
 torch.cuda.synchronize()
 del job
 ix.close(); torch.cuda.empty_cache()
