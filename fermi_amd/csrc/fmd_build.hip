@@ -113,6 +113,27 @@ struct HasPrefix {
     }
 };
 
+// sizes of all prefix buckets in ONE pass over the text (a selection pass per bucket just to count cost as much as the
+// selection itself: 0.65 s per pass over 5*10^10 symbols, 156 buckets at depth 3)
+__global__ void k_prefix_hist(const uint8_t *__restrict__ text, uint64_t n, int depth, unsigned long long *__restrict__ hist)
+{
+    extern __shared__ unsigned int h_lds[];
+    const uint32_t bins = 1u << (3 * depth);
+    for (uint32_t i = threadIdx.x; i < bins; i += blockDim.x) h_lds[i] = 0;
+    __syncthreads();
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t c = 0;
+        for (int j = 0; j < depth; ++j) {
+            const uint32_t x = t + (uint64_t)j < n ? text[t + j] : 0u;
+            c = c << 3 | x;
+            if (x == 0) { c <<= 3 * (depth - 1 - j); break; }
+        }
+        atomicAdd(&h_lds[c], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < bins; i += blockDim.x) if (h_lds[i]) atomicAdd(&hist[i], (unsigned long long)h_lds[i]);
+}
+
 template <class Rem>
 __global__ void k_chunk_keys64(const uint8_t *__restrict__ text, uint64_t m, const uint64_t *__restrict__ ids, int chunk, Rem rem,
                                uint64_t *__restrict__ keys)
@@ -168,18 +189,21 @@ static int build_bucketed(hipStream_t st, const uint8_t *text, uint64_t n, uint3
         FMD_HIP_TRY(hipcub::DeviceSelect::If(nullptr, tb, it, (uint64_t *)nullptr, (uint64_t *)cnt.p, (int64_t)n, op, st));
         DALLOC(tmp, tb);
     }
+    std::vector<unsigned long long> sizes((size_t)1 << (3 * depth), 0ull);
+    {
+        DevPtr hist;
+        DALLOC(hist, sizes.size() * 8);
+        FMD_HIP_TRY(hipMemsetAsync(hist.p, 0, sizes.size() * 8, st));
+        // a block counts at most 2^32 - 1 positions per bin in LDS: grid-stride over n with 4096 blocks x 1024 threads is far below that
+        k_prefix_hist<<<4096, 1024, sizes.size() * 4, st>>>(text, n, depth, (unsigned long long *)hist.p);
+        FMD_HIP_TRY(hipMemcpyAsync(sizes.data(), hist.p, sizes.size() * 8, hipMemcpyDeviceToHost, st));
+        FMD_HIP_TRY(hipStreamSynchronize(st));
+    }
     for (uint32_t code : codes) {
         HasPrefix op{text, n, depth, code};
         bool has_end = false;                               // a '$' inside the prefix: the bucket is in order as it is
         for (int j = 0; j < depth; ++j) if (((code >> (3 * (depth - 1 - j))) & 7u) == 0) has_end = true;
-        // size of the bucket first (selection into a discard iterator), then its positions, ascending
-        uint64_t m = 0;
-        {
-            hipcub::DiscardOutputIterator<uint64_t> discard;
-            FMD_HIP_TRY(hipcub::DeviceSelect::If(tmp.p, tb, it, discard, (uint64_t *)cnt.p, (int64_t)n, op, st));
-            FMD_HIP_TRY(hipMemcpyAsync(&m, cnt.p, 8, hipMemcpyDeviceToHost, st));
-            FMD_HIP_TRY(hipStreamSynchronize(st));
-        }
+        const uint64_t m = sizes[code];                      // from the histogram; the positions follow, ascending
         if (m == 0) continue;
         if (m > cap) {                                      // grow: release first, the arrays are the bulk of the footprint
             hipFree(ids_a.p); hipFree(ids_b.p); hipFree(keys_a.p); hipFree(keys_b.p); hipFree(stmp.p);
@@ -217,16 +241,16 @@ static int build_bucketed(hipStream_t st, const uint8_t *text, uint64_t n, uint3
 static int bucket_depth(uint64_t n)
 {
     const char *e = getenv("FMD_BUILD_DEPTH");
-    if (e && atoi(e) >= 1 && atoi(e) <= 6) return atoi(e);
+    if (e && atoi(e) >= 1 && atoi(e) <= 4) return atoi(e);     // 8^4 histogram bins fit a workgroup's LDS
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 3;
-    for (int d = 1; d <= 5; ++d) {
+    for (int d = 1; d <= 3; ++d) {
         double share = 1.0;
         for (int j = 0; j < d; ++j) share /= 4.0;
         const double need = 34.0 * 1.6 * share * (double)n;     // 32 bytes per suffix + scratch, 1.6x the even share
         if (need < 0.85 * (double)free_b) return d;
     }
-    return 6;
+    return 4;
 }
 
 extern "C" void fmd_dev_free(void *d_ptr) { if (d_ptr) hipFree(d_ptr); }
