@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "fmd_rank1a_dev", "fmd_rank2a_dev", "fmd_rank1a_batch", "fmd_rank2a_batch",
     "fmd_extend_dev", "fmd_extend_batch", "fmd_bsearch_dev", "fmd_bsearch_batch",
     "fmd_retrieve_dev", "fmd_retrieve_batch", "fmd_probe_gather",
-    "fmd_build_bwt", "fmd_build_bwt_dev", "fmd_dev_free", "fmd_bwt_to_rle6", "fmd_host_free",
+    "fmd_build_bwt", "fmd_build_bwt_dev", "fmd_dev_free", "fmd_builder_new", "fmd_builder_add_dev", "fmd_builder_finish", "fmd_builder_free", "fmd_bwt_to_rle6", "fmd_host_free",
     "fmd_dev_malloc", "fmd_memcpy_h2d", "fmd_memcpy_d2h",
     "fmd_smem_work_bytes", "fmd_smem_dev", "fmd_smem_batch", "fmd_smem_win_dev", "fmd_smem_win_batch", "fmd_reach_dev", "fmd_reach_batch", "fmd_dev_export_bwt", "fmd_dev_check_rank",
     "fmd_kmer_work_bytes", "fmd_kmer_collect_dev", "fmd_kmer_collect",
@@ -81,6 +81,10 @@ def _configure(L):
     L.fmd_build_bwt.argtypes = [C.c_int, sz, vp, u64p, vp, C.POINTER(C.c_uint64)]
     L.fmd_build_bwt_dev.argtypes = [C.c_int, vp, sz, vp, u64p, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64)]
     L.fmd_dev_free.restype = None; L.fmd_dev_free.argtypes = [vp]
+    L.fmd_builder_new.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(vp)]
+    L.fmd_builder_add_dev.argtypes = [vp, vp, C.c_uint64, vp]
+    L.fmd_builder_finish.argtypes = [vp, C.POINTER(vp)]
+    L.fmd_builder_free.restype = None; L.fmd_builder_free.argtypes = [vp]
     L.fmd_bwt_to_rle6.argtypes = [C.c_int, vp, C.c_uint64, C.POINTER(vp), C.POINTER(C.c_uint64)]
     L.fmd_host_free.restype = None; L.fmd_host_free.argtypes = [vp]
     L.fmd_dev_malloc.argtypes = [C.c_int, sz, C.POINTER(vp)]
@@ -388,6 +392,35 @@ def _smem_chain(self, seq, max_len=256, self_match=0, full_only=False):
 
 
 DevIndex.smem_chain = _smem_chain
+
+
+def build_index_inplace(reads_2d, device=0, pieces=3):
+    """The index of equal-length reads through the in-place builder (fmd_builder_*: packed text, BWT slices written
+    straight into the device layout, reads appended in `pieces` calls) -> DevIndex."""
+    L = lib()
+    reads_2d = np.ascontiguousarray(reads_2d, dtype=np.uint8)
+    n, ln = reads_2d.shape
+    b = C.c_void_p()
+    check(L.fmd_builder_new(device, n, ln, C.byref(b)))
+    try:
+        step = max(1, (n + pieces - 1) // pieces)
+        for s in range(0, n, step):
+            part = reads_2d[s:s + step]
+            d = C.c_void_p()
+            check(L.fmd_dev_malloc(device, part.nbytes + 16, C.byref(d)))
+            try:
+                check(L.fmd_memcpy_h2d(d, _ptr(part), part.nbytes, None))
+                check(L.fmd_builder_add_dev(b, None, len(part), d))
+                check(L.fmd_memcpy_d2h(_ptr(np.zeros(1, np.uint8)), d, 1, None))   # the add kernel has read the piece before it is freed
+            finally:
+                L.fmd_dev_free(d)
+        h = C.c_void_p()
+        check(L.fmd_builder_finish(b, C.byref(h)))
+        b = None
+        return DevIndex(h)
+    finally:
+        if b:
+            L.fmd_builder_free(b)
 
 
 def build_bwt(seqs, device=0):

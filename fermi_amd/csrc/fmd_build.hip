@@ -98,45 +98,72 @@ struct DevPtr { void *p = nullptr; ~DevPtr() { if (p) hipFree(p); } };
 // their bucket only.  Peak memory = text + BWT + 32 bytes per suffix of the largest bucket (+ the sort's scratch):
 // depth 1 carries 50 M x 100 bp reads, depth 2-3 the 2.5*10^8 x 100 bp (5*10^10 symbols) that one 288 GB GPU can hold
 // next to its own text and BWT.
-struct HasPrefix {
-    const uint8_t *text; uint64_t n; int depth; uint32_t code;   // code: 3 bits per symbol, first symbol on top
-    __device__ bool operator()(const uint64_t &t) const
-    {
-        uint32_t c = 0;
-        int j = 0;
-        for (; j < depth; ++j) {
-            const uint32_t x = t + (uint64_t)j < n ? text[t + j] : 0u;
-            c = c << 3 | x;
-            if (x == 0) { c <<= 3 * (depth - 1 - j); break; }
-        }
-        return c == code;
-    }
-};
+// the text as the bucketed builder sees it: one byte per symbol, or two symbols per byte (the in-place index builder)
+struct Text8 { const uint8_t *p; __device__ __forceinline__ uint32_t operator[](uint64_t t) const { return p[t]; } };
+struct Text4 { const uint8_t *p; __device__ __forceinline__ uint32_t operator[](uint64_t t) const { return (p[t >> 1] >> (4 * (uint32_t)(t & 1))) & 15u; } };
 
+template <class Text>
+__device__ __forceinline__ uint32_t prefix_code(const Text &text, uint64_t n, int depth, uint64_t t)   // 3 bits per symbol, first symbol on top
+{
+    uint32_t c = 0;
+    for (int j = 0; j < depth; ++j) {
+        const uint32_t x = t + (uint64_t)j < n ? text[t + j] : 0u;
+        c = c << 3 | x;
+        if (x == 0) { c <<= 3 * (depth - 1 - j); break; }
+    }
+    return c;
+}
 // sizes of all prefix buckets in ONE pass over the text (a selection pass per bucket just to count cost as much as the
 // selection itself: 0.65 s per pass over 5*10^10 symbols, 156 buckets at depth 3)
-__global__ void k_prefix_hist(const uint8_t *__restrict__ text, uint64_t n, int depth, unsigned long long *__restrict__ hist)
+template <class Text>
+__global__ void k_prefix_hist(Text text, uint64_t n, int depth, unsigned long long *__restrict__ hist)
 {
     extern __shared__ unsigned int h_lds[];
     const uint32_t bins = 1u << (3 * depth);
     for (uint32_t i = threadIdx.x; i < bins; i += blockDim.x) h_lds[i] = 0;
     __syncthreads();
-    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t c = 0;
-        for (int j = 0; j < depth; ++j) {
-            const uint32_t x = t + (uint64_t)j < n ? text[t + j] : 0u;
-            c = c << 3 | x;
-            if (x == 0) { c <<= 3 * (depth - 1 - j); break; }
-        }
-        atomicAdd(&h_lds[c], 1u);
-    }
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x)
+        atomicAdd(&h_lds[prefix_code(text, n, depth, t)], 1u);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < bins; i += blockDim.x) if (h_lds[i]) atomicAdd(&hist[i], (unsigned long long)h_lds[i]);
 }
 
-template <class Rem>
-__global__ void k_chunk_keys64(const uint8_t *__restrict__ text, uint64_t m, const uint64_t *__restrict__ ids, int chunk, Rem rem,
-                               uint64_t *__restrict__ keys)
+// The positions of one bucket, ascending.  hipcub::DeviceSelect over a counting iterator takes 0.65 s per pass over 5*10^10
+// symbols (156 buckets at depth 3, ~800 at depth 4); here a wave owns a tile of 2^16 consecutive positions: it counts its
+// matches, an exclusive scan over the tiles gives every tile its place, and the wave writes its matches in order with
+// ballot prefixes -- two coalesced sweeps over the text per bucket.
+#define SEL_TILE_SHIFT 16
+template <class Text>
+__global__ void k_tile_count(Text text, uint64_t n, int depth, uint32_t code, uint64_t n_tiles, uint64_t *__restrict__ counts)
+{
+    const int lane = threadIdx.x & 63;
+    for (uint64_t tile = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < n_tiles; tile += (uint64_t)gridDim.x * (blockDim.x >> 6)) {
+        const uint64_t t0 = tile << SEL_TILE_SHIFT, t1 = t0 + (1ull << SEL_TILE_SHIFT) < n ? t0 + (1ull << SEL_TILE_SHIFT) : n;
+        uint32_t c = 0;
+        for (uint64_t t = t0 + (uint64_t)lane; t < t1; t += 64) c += prefix_code(text, n, depth, t) == code;
+        for (int o = 32; o; o >>= 1) c += __shfl_xor((int)c, o);
+        if (lane == 0) counts[tile] = c;
+    }
+}
+template <class Text>
+__global__ void k_tile_select(Text text, uint64_t n, int depth, uint32_t code, uint64_t n_tiles, const uint64_t *__restrict__ offset, uint64_t *__restrict__ ids)
+{
+    const int lane = threadIdx.x & 63;
+    for (uint64_t tile = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < n_tiles; tile += (uint64_t)gridDim.x * (blockDim.x >> 6)) {
+        const uint64_t t0 = tile << SEL_TILE_SHIFT, t1 = t0 + (1ull << SEL_TILE_SHIFT) < n ? t0 + (1ull << SEL_TILE_SHIFT) : n;
+        uint64_t base = offset[tile];
+        for (uint64_t tb = t0; tb < t1; tb += 64) {           // all 64 lanes take every turn: the ballot needs them
+            const uint64_t t = tb + (uint64_t)lane;
+            const bool hit = t < t1 && prefix_code(text, n, depth, t) == code;
+            const uint64_t m = __ballot(hit);
+            if (hit) ids[base + (uint64_t)__popcll(m & ((1ull << lane) - 1))] = t;
+            base += (uint64_t)__popcll(m);
+        }
+    }
+}
+
+template <class Text, class Rem>
+__global__ void k_chunk_keys64(Text text, uint64_t m, const uint64_t *__restrict__ ids, int chunk, Rem rem, uint64_t *__restrict__ keys)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t t = ids[i];
@@ -149,11 +176,12 @@ __global__ void k_chunk_keys64(const uint8_t *__restrict__ text, uint64_t m, con
         keys[i] = key;
     }
 }
-__global__ void k_emit_bwt64(const uint8_t *__restrict__ text, const uint64_t *__restrict__ ids, uint64_t m, uint8_t *__restrict__ bwt)
+template <class Text>
+__global__ void k_emit_bwt64(Text text, const uint64_t *__restrict__ ids, uint64_t m, uint8_t *__restrict__ bwt)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t t = ids[i];
-        bwt[i] = t ? text[t - 1] : 0;
+        bwt[i] = t ? (uint8_t)text[t - 1] : 0;   // text[t-1] is '$' (= 0) exactly when t starts a sequence
     }
 }
 
@@ -173,22 +201,22 @@ static void prefix_codes(int depth, std::vector<uint32_t> &out)
     out.swap(cur);   // generated in increasing numeric order
 }
 
-static int build_bucketed(hipStream_t st, const uint8_t *text, uint64_t n, uint32_t max_len, int uniform_len, RemRagged rr, uint8_t *bwt, int depth)
+// Sink(d_bwt_slice, first_position, m): the BWT symbols of positions [first, first + m), in a device buffer that is reused
+template <class Text, class Sink>
+static int build_bucketed(hipStream_t st, Text text, uint64_t n, uint32_t max_len, int uniform_len, RemRagged rr, int depth, uint8_t *bwt_direct, Sink sink)
 {
-    DevPtr cnt;
-    DALLOC(cnt, 8);
     const int n_chunks = (int)((max_len + 1 + 20) / 21);
     std::vector<uint32_t> codes;
     prefix_codes(depth, codes);
     uint64_t done = 0, cap = 0;
-    DevPtr ids_a, ids_b, keys_a, keys_b, tmp, stmp;     // grown to the largest bucket met so far
+    DevPtr ids_a, ids_b, keys_a, keys_b, tmp, stmp, slice;     // grown to the largest bucket met so far
     size_t tb = 0, sb = 0;
-    hipcub::CountingInputIterator<uint64_t> it(0);
-    {
-        HasPrefix op{text, n, depth, 0};
-        FMD_HIP_TRY(hipcub::DeviceSelect::If(nullptr, tb, it, (uint64_t *)nullptr, (uint64_t *)cnt.p, (int64_t)n, op, st));
-        DALLOC(tmp, tb);
-    }
+    const uint64_t n_tiles = (n + (1ull << SEL_TILE_SHIFT) - 1) >> SEL_TILE_SHIFT;
+    DevPtr tile_cnt, tile_off;
+    DALLOC(tile_cnt, n_tiles * 8); DALLOC(tile_off, n_tiles * 8);
+    FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (uint64_t *)tile_cnt.p, (uint64_t *)tile_off.p, (size_t)n_tiles, st));
+    DALLOC(tmp, tb);
+    const unsigned sel_grid = (unsigned)(n_tiles / 4 + 1 < 65536 ? n_tiles / 4 + 1 : 65536);
     std::vector<unsigned long long> sizes((size_t)1 << (3 * depth), 0ull);
     {
         DevPtr hist;
@@ -200,21 +228,23 @@ static int build_bucketed(hipStream_t st, const uint8_t *text, uint64_t n, uint3
         FMD_HIP_TRY(hipStreamSynchronize(st));
     }
     for (uint32_t code : codes) {
-        HasPrefix op{text, n, depth, code};
         bool has_end = false;                               // a '$' inside the prefix: the bucket is in order as it is
         for (int j = 0; j < depth; ++j) if (((code >> (3 * (depth - 1 - j))) & 7u) == 0) has_end = true;
         const uint64_t m = sizes[code];                      // from the histogram; the positions follow, ascending
         if (m == 0) continue;
         if (m > cap) {                                      // grow: release first, the arrays are the bulk of the footprint
-            hipFree(ids_a.p); hipFree(ids_b.p); hipFree(keys_a.p); hipFree(keys_b.p); hipFree(stmp.p);
-            ids_a.p = ids_b.p = keys_a.p = keys_b.p = stmp.p = nullptr;
+            hipFree(ids_a.p); hipFree(ids_b.p); hipFree(keys_a.p); hipFree(keys_b.p); hipFree(stmp.p); hipFree(slice.p);
+            ids_a.p = ids_b.p = keys_a.p = keys_b.p = stmp.p = slice.p = nullptr;
             cap = m + m / 16;
             DALLOC(ids_a, cap * 8); DALLOC(ids_b, cap * 8); DALLOC(keys_a, cap * 8); DALLOC(keys_b, cap * 8);
+            if (!bwt_direct) DALLOC(slice, cap + 64);
             FMD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sb, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, (uint64_t *)ids_a.p,
                                                           (uint64_t *)ids_b.p, (size_t)cap, 0, 63, st));
             DALLOC(stmp, sb);
         }
-        FMD_HIP_TRY(hipcub::DeviceSelect::If(tmp.p, tb, it, (uint64_t *)ids_a.p, (uint64_t *)cnt.p, (int64_t)n, op, st));
+        k_tile_count<<<sel_grid, 256, 0, st>>>(text, n, depth, code, n_tiles, (uint64_t *)tile_cnt.p);
+        FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, (uint64_t *)tile_cnt.p, (uint64_t *)tile_off.p, (size_t)n_tiles, st));
+        k_tile_select<<<sel_grid, 256, 0, st>>>(text, n, depth, code, n_tiles, (const uint64_t *)tile_off.p, (uint64_t *)ids_a.p);
         uint64_t *cur = (uint64_t *)ids_a.p;
         if (!has_end) {
             uint64_t *nxt = (uint64_t *)ids_b.p;
@@ -229,17 +259,24 @@ static int build_bucketed(hipStream_t st, const uint8_t *text, uint64_t n, uint3
                 uint64_t *t = cur; cur = nxt; nxt = t;
             }
         }
-        k_emit_bwt64<<<nblk(m, 256), 256, 0, st>>>(text, cur, m, bwt + done);
+        if (bwt_direct) k_emit_bwt64<<<nblk(m, 256), 256, 0, st>>>(text, cur, m, bwt_direct + done);
+        else {
+            k_emit_bwt64<<<nblk(m, 256), 256, 0, st>>>(text, cur, m, (uint8_t *)slice.p);
+            const int rc = sink((const uint8_t *)slice.p, done, m);
+            if (rc) return rc;
+        }
         FMD_HIP_TRY(hipStreamSynchronize(st));
         done += m;
     }
     return done == n ? FMD_OK : FMD_E_HIP;
 }
+struct NoSink { int operator()(const uint8_t *, uint64_t, uint64_t) const { return FMD_OK; } };
 
 // prefix depth of the bucketed builder: the shallowest whose largest bucket (estimated from the A/C/G/T share of the
 // text, with room for skew) fits the free memory next to text and BWT
-static int bucket_depth(uint64_t n)
+static int bucket_depth(uint64_t n, int fixed_bytes_per_symbol_already_allocated)
 {
+    (void)fixed_bytes_per_symbol_already_allocated;
     const char *e = getenv("FMD_BUILD_DEPTH");
     if (e && atoi(e) >= 1 && atoi(e) <= 4) return atoi(e);     // 8^4 histogram bins fit a workgroup's LDS
     size_t free_b = 0, total_b = 0;
@@ -276,7 +313,7 @@ extern "C" int fmd_build_bwt_dev(int device, void *stream_, size_t n_reads, cons
     }
     if (bucketed) {
         FMD_HIP_TRY(hipMalloc((void **)&bwt, n + 64));
-        int rc = build_bucketed(st, (const uint8_t *)text.p, n, max_len, uniform_len, rr, bwt, bucket_depth(n));
+        int rc = build_bucketed(st, Text8{(const uint8_t *)text.p}, n, max_len, uniform_len, rr, bucket_depth(n, 2), bwt, NoSink());
         if (rc) { hipFree(bwt); return rc; }
         *d_bwt_out = bwt; *n_sym_out = n;
         return FMD_OK;
@@ -301,6 +338,86 @@ extern "C" int fmd_build_bwt_dev(int device, void *stream_, size_t n_reads, cons
     hipError_t e = hipStreamSynchronize(st);
     if (e != hipSuccess) { hipFree(bwt); fmd_set_hip_error(e, "build"); return FMD_E_HIP; }
     *d_bwt_out = bwt; *n_sym_out = n;
+    return FMD_OK;
+}
+
+// ------------------------------------------------------------------ the index built in place (no byte BWT, packed text)
+// For read sets whose text + BWT do not fit next to the index (7*10^8 x 100 bp: 1.4*10^11 symbols, 141 GB each): the text
+// is kept 4 bits per symbol, and every bucket's slice of the BWT goes straight into the planes of the device index
+// (fmd_index_put_slice) instead of into a byte array.  Footprint = n/2 (text) + 0.67 n (index) + 34 bytes per suffix of
+// the largest bucket.  Reads of ONE length, appended in any number of calls so that they never have to sit in HBM together.
+struct fmd_builder {
+    int device; uint64_t n_reads, added; uint32_t len;
+    uint64_t n_sym;
+    uint8_t *text4;      // device: n_sym / 2 bytes (+ pad)
+};
+__global__ void k_text4_add(uint64_t n, uint32_t len, uint64_t first_read, const uint8_t *__restrict__ reads, uint8_t *__restrict__ text4)
+{
+    // one thread per PAIR of text positions of the added reads (a read's 2 * (len + 1) symbols start at an even position)
+    const uint64_t per = (uint64_t)len + 1, pairs = n * per;   // 2 * per symbols per read = per pairs
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / per, k = 2 * (i - r * per);     // symbols k, k + 1 of read r's block
+        const uint8_t *s = reads + r * (uint64_t)len;
+        uint32_t v[2];
+        for (int j = 0; j < 2; ++j) {
+            const uint64_t q = k + (uint64_t)j;                 // 0 .. 2 * len + 1
+            uint32_t c;
+            if (q < len) c = s[q];
+            else if (q == len || q == 2 * (uint64_t)len + 1) c = 0;
+            else { const uint32_t b = s[len - 1 - (q - len - 1)]; c = (b >= 1 && b <= 4) ? 5 - b : b; }
+            v[j] = c;
+        }
+        text4[(first_read + r) * per + (k >> 1)] = (uint8_t)(v[0] | v[1] << 4);
+    }
+}
+
+extern "C" void fmd_builder_free(fmd_builder_t *b)
+{
+    if (!b) return;
+    hipSetDevice(b->device);
+    hipFree(b->text4);
+    free(b);
+}
+extern "C" int fmd_builder_new(int device, uint64_t n_reads, uint32_t read_len, fmd_builder_t **out)
+{
+    if (!out || n_reads == 0 || read_len == 0 || read_len > 0xfffffff0u) return FMD_E_ARG;
+    if (fmd_device_count() <= 0) return FMD_E_NODEV;
+    FMD_HIP_TRY(hipSetDevice(device));
+    fmd_builder *b = (fmd_builder *)calloc(1, sizeof(fmd_builder));
+    if (!b) return FMD_E_NOMEM;
+    b->device = device; b->n_reads = n_reads; b->len = read_len; b->n_sym = 2 * n_reads * ((uint64_t)read_len + 1);
+    if (hipMalloc((void **)&b->text4, b->n_sym / 2 + 64) != hipSuccess) { fmd_set_hip_error(hipGetLastError(), "hipMalloc(text)"); free(b); return FMD_E_NOMEM; }
+    *out = b;
+    return FMD_OK;
+}
+extern "C" int fmd_builder_add_dev(fmd_builder_t *b, void *stream, uint64_t n, const uint8_t *d_reads)
+{
+    if (!b || (n && !d_reads) || b->added + n > b->n_reads) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    FMD_HIP_TRY(hipSetDevice(b->device));
+    k_text4_add<<<nblk(n * ((uint64_t)b->len + 1), 256), 256, 0, (hipStream_t)stream>>>(n, b->len, b->added, d_reads, b->text4);
+    b->added += n;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fmd_set_hip_error(e, "k_text4_add"); return FMD_E_HIP; }
+    return FMD_OK;
+}
+extern "C" int fmd_builder_finish(fmd_builder_t *b, fmd_dev_t **out)
+{
+    if (!b || !out || b->added != b->n_reads) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(b->device));
+    FMD_HIP_TRY(hipDeviceSynchronize());
+    fmd_dev *h = nullptr;
+    int rc = fmd_index_alloc(b->device, b->n_sym, &h);
+    if (rc) return rc;
+    const uint64_t n = b->n_sym;
+    hipStream_t st = nullptr;
+    RemRagged rr{nullptr, 2 * b->n_reads};
+    rc = build_bucketed(st, Text4{b->text4}, n, b->len, 1, rr, bucket_depth(n, 0), nullptr,
+                        [&](const uint8_t *slice, uint64_t first, uint64_t m) { return fmd_index_put_slice(h, st, slice, first, m); });
+    if (rc == FMD_OK) { hipFree(b->text4); b->text4 = nullptr; rc = fmd_index_finish(h); }   // the text goes before the count scratch comes
+    if (rc) { fmd_dev_close(h); return rc; }
+    fmd_builder_free(b);
+    *out = h;
     return FMD_OK;
 }
 

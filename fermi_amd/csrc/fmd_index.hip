@@ -349,6 +349,42 @@ static int finish_index(fmd_dev *h)
     return rc;
 }
 
+// for the in-place builder (fmd_build.hip): an empty index of n symbols, slices of the BWT OR-ed into its planes in any
+// number of calls (positions ascending, one slice after the other on one stream), then the counts
+int fmd_index_alloc(int device, uint64_t n_sym, fmd_dev **out)
+{
+    int rc = dev_alloc_index(device, n_sym, out);
+    if (rc == FMD_OK) (*out)->mcnt[0] = n_sym;
+    return rc;
+}
+int fmd_index_finish(fmd_dev *h) { return finish_index(h); }
+// one thread per 32-position word that the slice [first, first + m) touches; border words are shared with the
+// neighbouring slices, which are written before / after this launch on the same stream: plain OR
+__global__ void k_slice_to_planes(const uint8_t *__restrict__ slice, uint64_t first, uint64_t m, uint4 *__restrict__ blocks)
+{
+    const uint64_t w0 = first >> 5, w1 = (first + m - 1) >> 5;
+    for (uint64_t w = w0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w <= w1; w += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p0 = w << 5;
+        uint32_t a = 0, b = 0, d = 0;
+        for (int i = 0; i < 32; ++i) {
+            const uint64_t p = p0 + (uint64_t)i;
+            if (p < first || p >= first + m) continue;
+            const uint32_t s = slice[p - first] & 7;
+            a |= (s & 1) << i; b |= ((s >> 1) & 1) << i; d |= ((s >> 2) & 1) << i;
+        }
+        uint4 *dst = blocks + fmd_word_u4(w);
+        dst->x |= a; dst->y |= b; dst->z |= d;
+    }
+}
+int fmd_index_put_slice(fmd_dev *h, hipStream_t st, const uint8_t *d_slice, uint64_t first, uint64_t m)
+{
+    if (m == 0) return FMD_OK;
+    if (first + m > h->mcnt[0]) return FMD_E_ARG;
+    const uint64_t words = ((first + m - 1) >> 5) - (first >> 5) + 1;
+    k_slice_to_planes<<<nblk(words, 256), 256, 0, st>>>(d_slice, first, m, h->blocks);
+    return hipGetLastError() == hipSuccess ? FMD_OK : FMD_E_HIP;
+}
+
 extern "C" int fmd_dev_open_bwt_dev(int device, const uint8_t *d_bwt, uint64_t n, fmd_dev_t **out)
 {
     if (!d_bwt || !out) return FMD_E_ARG;

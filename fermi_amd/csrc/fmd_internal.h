@@ -59,6 +59,11 @@ static inline FmdIndexView fmd_view(const fmd_dev *h)
 void *fmd_scratch_acquire(fmd_dev *h, size_t bytes);
 void fmd_scratch_release(fmd_dev *h, void *p);
 
+// the in-place index builder's hooks into fmd_index.hip
+int fmd_index_alloc(int device, uint64_t n_sym, fmd_dev **out);
+int fmd_index_put_slice(fmd_dev *h, hipStream_t st, const uint8_t *d_slice, uint64_t first, uint64_t m);
+int fmd_index_finish(fmd_dev *h);
+
 // next zeroed work-queue head for a persistent launch on `stream`
 uint32_t *fmd_next_queue(fmd_dev *h, hipStream_t stream);
 

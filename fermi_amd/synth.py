@@ -84,27 +84,38 @@ def rnd_torch(seed, stream, idx):
 
 
 def _umod(u, m):
-    """(u as unsigned 64-bit) % m for 0 < m < 2^31, int64 tensors only."""
-    hi, lo = _lsr(u, 32), u & 0xFFFFFFFF
-    return ((hi % m) * ((1 << 32) % m) + lo) % m
+    """(u as unsigned 64-bit) % m for 0 < m < 2^47, int64 tensors only: Horner over the four 16-bit limbs."""
+    r = _lsr(u, 48) % m
+    for sh in (32, 16, 0):
+        r = (r * 65536 + (_lsr(u, sh) & 0xFFFF)) % m
+    return r
 
 
-def reads_torch(seed, n_reads, read_len=100, coverage=30, err=0.0, device="cuda", chunk=2_000_000):
-    """reads() computed on `device`: uint8 [n_reads, read_len] tensor, identical to the numpy form."""
+def genome_torch(seed, n_reads, read_len=100, coverage=30, device="cuda"):
     import torch
     g = max(n_reads * read_len // coverage, read_len)
-    span = g - read_len + 1
-    if span >= (1 << 31):
-        raise ValueError("reads_torch: genome too long for the 32-bit split of the modulo; use reads()")
     gen = torch.empty(g, dtype=torch.uint8, device=device)
     for s in range(0, g, 1 << 26):
         c = min(1 << 26, g - s)
         gen[s:s + c] = (1 + _lsr(rnd_torch(seed, 1, torch.arange(s, s + c, dtype=torch.int64, device=device)), 62)).to(torch.uint8)
-    out = torch.empty((n_reads, read_len), dtype=torch.uint8, device=device)
+    return gen
+
+
+def reads_torch(seed, n_reads, read_len=100, coverage=30, err=0.0, device="cuda", chunk=2_000_000, start=0, count=None, gen=None):
+    """reads() computed on `device`: uint8 [count, read_len] tensor (reads start .. start+count of the n_reads-read set),
+    identical to the numpy form.  gen: the genome from genome_torch(), to generate a large set piece by piece."""
+    import torch
+    if count is None:
+        count = n_reads - start
+    if gen is None:
+        gen = genome_torch(seed, n_reads, read_len, coverage, device)
+    span = gen.shape[0] - read_len + 1
+    out = torch.empty((count, read_len), dtype=torch.uint8, device=device)
     ar = torch.arange(read_len, dtype=torch.int64, device=device)
     thr = int(err * 4294967296.0)
-    for s in range(0, n_reads, chunk):
-        c = min(chunk, n_reads - s)
+    for s0 in range(0, count, chunk):
+        c = min(chunk, count - s0)
+        s = start + s0
         r = torch.arange(s, s + c, dtype=torch.int64, device=device)
         pos = _umod(rnd_torch(seed, 2, r), span)
         strand = _lsr(rnd_torch(seed, 3, r), 63).bool()
@@ -116,5 +127,5 @@ def reads_torch(seed, n_reads, read_len=100, coverage=30, err=0.0, device="cuda"
             hit = _lsr(u, 32) < thr
             sub = (1 + ((o.to(torch.int64) - 1) + 1 + (u & 0xFFFFFFFF) % 3) % 4).to(torch.uint8)
             o = torch.where(hit, sub, o)
-        out[s:s + c] = o
+        out[s0:s0 + c] = o
     return out

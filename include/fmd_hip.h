@@ -326,6 +326,16 @@ int fmd_build_bwt(int device, size_t n_reads, const uint8_t *reads, const uint64
 int fmd_build_bwt_dev(int device, void *stream, size_t n_reads, const uint8_t *d_reads, const uint64_t *d_off,
                       uint64_t total_bases, uint32_t max_len, int uniform_len, uint8_t **d_bwt, uint64_t *n_sym);
 void fmd_dev_free(void *d_ptr);
+/* The same index without the byte BWT, for read sets whose text + BWT do not fit next to the index (7*10^8 x 100 bp:
+ * 1.4*10^11 symbols): reads of ONE length appended in any number of calls (n x read_len nt6 bytes on the device, no
+ * sentinels; they need not stay resident), text kept 4 bits per symbol, BWT slices written straight into the device
+ * layout.  fmd_builder_finish releases the builder and returns the index fmd_dev_open_bwt_dev(fmd_build_bwt_dev(..))
+ * would return. */
+typedef struct fmd_builder fmd_builder_t;
+int fmd_builder_new(int device, uint64_t n_reads, uint32_t read_len, fmd_builder_t **out);
+int fmd_builder_add_dev(fmd_builder_t *b, void *stream, uint64_t n, const uint8_t *d_reads);
+int fmd_builder_finish(fmd_builder_t *b, fmd_dev_t **out);
+void fmd_builder_free(fmd_builder_t *b);
 /* device memory for C hosts (the reference has no device; these are what a cgo/C caller uses to
  * stage batches): plain hipMalloc / hipMemcpyAsync behind the ABI. */
 int fmd_dev_malloc(int device, size_t bytes, void **d_ptr);

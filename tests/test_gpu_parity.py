@@ -534,6 +534,32 @@ def test_bucketed_builder_equals_one_shot(gpu, gold, oracle_lib, monkeypatch, de
         o.close()
 
 
+@pytest.mark.parametrize("depth", [1, 2, 3, 4])
+def test_inplace_builder_gives_the_same_index(gpu, monkeypatch, depth):
+    """fmd_builder_* (text 4 bits per symbol, no byte BWT: every bucket's slice goes straight into the planes of the device
+    index, reads appended in pieces) == fmd_build_bwt + fmd_dev_open_bwt: the decoded BWT, the counts, the rank self-check
+    and a backward search of every read."""
+    import ctypes as C
+    monkeypatch.setenv("FMD_BUILD_DEPTH", str(depth))
+    for n, ln, err, seed in ((3000, 37, 0.02, 1), (501, 5, 0.0, 2), (2000, 100, 0.01, 3)):
+        reads = synth.reads(synth.DEFAULT_SEED + seed, n, ln, 20, err)
+        if seed == 1:
+            reads[::17, 3] = 5                                  # some Ns
+        a = gpu.build_index_inplace(reads, pieces=3)
+        want = gpu.build_bwt(reads)
+        got = np.zeros(a.n, dtype=np.uint8)
+        gpu.check(gpu.lib().fmd_dev_export_bwt(a.h, 0, a.n, got.ctypes.data))
+        assert a.n == len(want) and np.array_equal(got, want)
+        b = gpu.DevIndex.from_bwt(want)
+        assert np.array_equal(a.cnt, b.cnt) and np.array_equal(a.mcnt, b.mcnt)
+        bad, first = C.c_uint64(), C.c_uint64()
+        gpu.check(gpu.lib().fmd_dev_check_rank(a.h, C.byref(bad), C.byref(first)))
+        assert bad.value == 0
+        ca, cb = a.backward_search(reads), b.backward_search(reads)
+        assert all(np.array_equal(x, y) for x, y in zip(ca, cb)) and (ca[0] >= 1).all()
+        a.close(); b.close()
+
+
 @pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20), ("special", 20)])
 def test_seqsort_and_unitig_r_cli(gpu, gold, tmp_path, name, mm):
     """`fermi-amd seqsort` == `fermi seqsort` bytes; `fermi-amd unitig -r` == `fermi unitig -t1 -r` bytes."""

@@ -1,66 +1,133 @@
 #!/usr/bin/env python3
-"""Indexes beyond 2.6*10^10 symbols on one MI355X (task 7): synthetic N x 100 bp reads (30x, e = 0) generated in
-HBM, BWT built by the prefix-bucketed GPU builder, device-wide rank self-check (the `chkbwt -r` equivalent), backward
-search of a sample of the reads (every one must hit, interval size = its multiplicity >= 1), and overlap discovery on a
-random sample of sequence ids against the REFERENCE (oracle/_ref when it travelled, the oracle otherwise) through the
-.fmd the product writes.  Usage: python tools/scale_check.py [n_reads=250000000] [sample=20000]"""
+"""Indexes beyond 2.6*10^10 symbols on one MI355X (task 7; BASELINE config 5 = 7*10^8 x 100 bp): synthetic
+N x 100 bp reads (30x, e = 0) generated in HBM piece by piece, the index built by the prefix-bucketed GPU builder -- through
+the byte BWT (`bwt`: what fits text + BWT + index) or in place (`inplace`: packed text, BWT slices written straight into the
+device layout; the only form that carries 1.4*10^11 symbols) --, then
+  * the device-wide rank self-check (the `chkbwt -r` equivalent) over every position,
+  * backward search of a sample of the reads (every one must hit its own index),
+  * backward search and overlap discovery on random samples against the REFERENCE (oracle/_ref when it travelled, the oracle
+    otherwise) through the .fmd the product writes (skipped with `noref`),
+  * config 5's share of one GPU out of `share` (ids i = 0 mod share): one timed pass of overlap discovery on this index.
+Usage: python tools/scale_check.py [n_reads=250000000] [bwt|inplace] [sample=20000] [share=8] [noref]"""
 import ctypes as C, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
-from fermi_amd import api, workload
+from fermi_amd import api, hostlib, synth, workload
 import bench
 
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 250_000_000
-sample = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
+mode = sys.argv[2] if len(sys.argv) > 2 else "bwt"
+sample = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
+share = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+noref = "noref" in sys.argv[5:]
 L = 100
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 lib = api.lib()
-t0 = time.time()
-rd = workload.ReadsOnDevice.synth(n_reads, L, 30, 0.0, dev)
-torch.cuda.synchronize()
-print("reads in HBM: %d x %d bp, %.1f s" % (n_reads, L, time.time() - t0), flush=True)
-t0 = time.time()
-d_bwt, n_sym = workload.build_bwt_on_device(rd, 0)
-torch.cuda.synchronize()
-t_build = time.time() - t0
-free_b, total_b = torch.cuda.mem_get_info()
-print("GPU BWT build: %d symbols in %.1f s (%.2e symbols/s); HBM in use after the build %.1f GB" % (n_sym, t_build, n_sym / t_build, (total_b - free_b) / 1e9), flush=True)
-# a sample of the reads before they are released
+seed = synth.DEFAULT_SEED
 rng = np.random.default_rng(11)
-sel = np.sort(rng.choice(n_reads, min(sample, n_reads), replace=False))
-q = rd.flat[: n_reads * L].view(n_reads, L)[torch.from_numpy(sel).to(dev)].cpu().numpy()
-del rd
-torch.cuda.empty_cache()
+
+
+def hbm_used():
+    free_b, total_b = torch.cuda.mem_get_info()
+    return (total_b - free_b) / 1e9
+
+
+t0 = time.time()
+gen = synth.genome_torch(seed, n_reads, L, 30, dev)
+PIECE = 25_000_000
 fmd_path = os.path.join(tempfile.gettempdir(), "fmd_scale_%d.fmd" % n_reads)
-t0 = time.time()
-workload.write_fmd_from_device_bwt(d_bwt, n_sym, fmd_path, 0)
-print(".fmd written (GPU run-length pass + host RLD encoder): %.1f GB in %.1f s" % (os.path.getsize(fmd_path) / 1e9, time.time() - t0), flush=True)
-t0 = time.time()
-index = api.DevIndex.from_bwt_dev(d_bwt, n_sym, 0)
-lib.fmd_dev_free(d_bwt)
-print("device index: %.1f GB in HBM, %.1f s" % (index.hbm_bytes / 1e9, time.time() - t0), flush=True)
+if mode == "inplace":
+    b = C.c_void_p()
+    api.check(lib.fmd_builder_new(0, n_reads, L, C.byref(b)))
+    for s in range(0, n_reads, PIECE):
+        c = min(PIECE, n_reads - s)
+        piece = synth.reads_torch(seed, n_reads, L, 30, 0.0, dev, start=s, count=c, gen=gen)
+        api.check(lib.fmd_builder_add_dev(b, None, c, piece.data_ptr()))
+        torch.cuda.synchronize()
+        del piece
+    print("text in HBM (4 bits per symbol): %d reads, %.1f s, HBM in use %.1f GB" % (n_reads, time.time() - t0, hbm_used()), flush=True)
+    torch.cuda.empty_cache()
+    t0 = time.time()
+    h = C.c_void_p()
+    api.check(lib.fmd_builder_finish(b, C.byref(h)))
+    index = api.DevIndex(h)
+    n_sym = index.n
+    t_build = time.time() - t0
+    print("index built in place: %d symbols in %.1f s (%.2e symbols/s), %.1f GB in HBM, HBM in use %.1f GB" % (n_sym, t_build, n_sym / t_build, index.hbm_bytes / 1e9, hbm_used()), flush=True)
+    if not noref:   # the reference reads fermi's file: decode the BWT back from the device layout, encode RLD on the host
+        t0 = time.time()
+        bwt = np.empty(n_sym, dtype=np.uint8)
+        for o in range(0, n_sym, 1 << 30):
+            m = min(1 << 30, n_sym - o)
+            api.check(lib.fmd_dev_export_bwt(index.h, o, m, bwt.ctypes.data + o))
+        hostlib.write_rld_from_bwt(bwt, fmd_path)
+        del bwt
+        print(".fmd written (BWT decoded from the device layout + host RLD encoder): %.1f GB in %.1f s" % (os.path.getsize(fmd_path) / 1e9, time.time() - t0), flush=True)
+else:
+    rd = workload.ReadsOnDevice.__new__(workload.ReadsOnDevice)
+    rd.n, rd.L = n_reads, L
+    rd.flat = torch.zeros(n_reads * L + 64, dtype=torch.uint8, device=dev)
+    for s in range(0, n_reads, PIECE):
+        c = min(PIECE, n_reads - s)
+        rd.flat[s * L:(s + c) * L].view(c, L).copy_(synth.reads_torch(seed, n_reads, L, 30, 0.0, dev, start=s, count=c, gen=gen))
+    rd.off = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * L
+    rd.total = n_reads * L
+    torch.cuda.synchronize()
+    print("reads in HBM: %d x %d bp, %.1f s" % (n_reads, L, time.time() - t0), flush=True)
+    t0 = time.time()
+    d_bwt, n_sym = workload.build_bwt_on_device(rd, 0)
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+    print("GPU BWT build: %d symbols in %.1f s (%.2e symbols/s); HBM in use after the build %.1f GB" % (n_sym, t_build, n_sym / t_build, hbm_used()), flush=True)
+    del rd
+    torch.cuda.empty_cache()
+    if not noref:
+        t0 = time.time()
+        workload.write_fmd_from_device_bwt(d_bwt, n_sym, fmd_path, 0)
+        print(".fmd written (GPU run-length pass + host RLD encoder): %.1f GB in %.1f s" % (os.path.getsize(fmd_path) / 1e9, time.time() - t0), flush=True)
+    t0 = time.time()
+    index = api.DevIndex.from_bwt_dev(d_bwt, n_sym, 0)
+    lib.fmd_dev_free(d_bwt)
+    print("device index: %.1f GB in HBM, %.1f s" % (index.hbm_bytes / 1e9, time.time() - t0), flush=True)
+
 t0 = time.time()
 bad, first = C.c_uint64(), C.c_uint64()
 api.check(lib.fmd_dev_check_rank(index.h, C.byref(bad), C.byref(first)))
 print("rank self-check over all %d positions: %d bad (%.1f s)" % (n_sym, bad.value, time.time() - t0), flush=True)
 assert bad.value == 0
+# a spread sample of the reads: blocks of 1000 consecutive reads
+starts = np.sort(rng.choice(n_reads // 1000, max(1, sample // 1000), replace=False)) * 1000
+q = torch.cat([synth.reads_torch(seed, n_reads, L, 30, 0.0, dev, start=int(s), count=1000, gen=gen) for s in starts]).cpu().numpy()
+del gen
+torch.cuda.empty_cache()
 cnt, beg, end = index.backward_search(q)
 assert (cnt >= 1).all() and np.array_equal(end - beg + 1, cnt), "a read of the set does not hit its own index"
-print("backward search: all %d sampled reads hit (multiplicities 1..%d)" % (len(q), int(cnt.max())), flush=True)
-base, ok = bench.cpu_bsearch(fmd_path, q, cnt, beg, end)
-print("backward search vs %s on the sample: %s (%.0f reads/s on %d host threads)" % (base["kind"], "bit-exact" if ok else "MISMATCH", base["value"], base["cores"]), flush=True)
-assert ok
+print("backward search: all %d sampled reads hit their own index (multiplicities 1..%d)" % (len(q), int(cnt.max())), flush=True)
 ids = np.sort(rng.choice(2 * n_reads, min(sample, 2 * n_reads), replace=False)).astype(np.uint64)
-t0 = time.time()
 rec, nei, seq = index.overlap(ids, 50, max_len=100, max_nei=4, check_left=False)
-t_g = time.time() - t0
-base, ok = bench.cpu_overlap(fmd_path, ids, 50, rec, nei)
-print("overlap discovery vs %s on %d random sequence ids: %s (GPU host-form call %.2f s; reference %.0f reads/s on %d threads)"
-      % (base["kind"], len(ids), "bit-exact" if ok else "MISMATCH", t_g, base["value"], base["cores"]), flush=True)
-assert ok
+print("overlap discovery of %d random sequence ids: %d with a neighbour, %d contained, %d overflow" % (len(ids), int((rec["n_nei"] > 0).sum()), int((rec["status"] == -3).sum()),
+      int(((rec["flags"] & api.OVLP_F_OVERFLOW) != 0).sum())), flush=True)
+if not noref:
+    base, ok = bench.cpu_bsearch(fmd_path, q, cnt, beg, end)
+    print("backward search vs %s on the sample: %s (%.0f reads/s on %d host threads)" % (base["kind"], "bit-exact" if ok else "MISMATCH", base["value"], base["cores"]), flush=True)
+    assert ok
+    base, ok = bench.cpu_overlap(fmd_path, ids, 50, rec, nei)
+    print("overlap discovery vs %s on %d random sequence ids: %s (reference %.0f reads/s on %d threads)" % (base["kind"], len(ids), "bit-exact" if ok else "MISMATCH", base["value"], base["cores"]), flush=True)
+    assert ok
+    os.remove(fmd_path)
+# ---- one GPU's share of the sharded overlap discovery on this index (BASELINE configs[3] / [4]: ids i = 0 (mod share))
+job = bench.OverlapJob(torch, api, index, dev, 2 * n_reads, 0, share, L, 50)
+job.compute()                       # warm-up
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(job.stream); job.compute(); e1.record(job.stream)
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)
+g = job.rec.view(torch.int32).view(job.n, 16)
+print("share 1/%d of the overlap discovery on this index: %d strands in %.1f ms = %.3e strands/s = %.3e reads/s per GPU (%d overflow records, %d with a neighbour); HBM in use %.1f GB"
+      % (share, job.n, ms, job.n / ms * 1e3, job.n / 2 / ms * 1e3, int(((g[:, 14] & 2) != 0).sum().item()), int((g[:, 13] > 0).sum().item()), hbm_used()), flush=True)
 index.close()
-os.remove(fmd_path)
-print("scale check passed: %d reads, %d symbols" % (n_reads, n_sym))
+print("scale check passed: %d reads, %d symbols, %s builder" % (n_reads, n_sym, mode))
