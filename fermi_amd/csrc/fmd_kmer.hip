@@ -289,11 +289,22 @@ extern "C" size_t fmd_kmer_work_bytes(uint64_t cap_frontier)
 
 // d_status (device, 4 x u64): [0] number of (bucket,key,val) triples, [1] overflow flag (then the
 // result is incomplete: call again with a larger cap), [2] cnt[0], [3] cnt[1] of correct.c:64-69.
+// The same over the part of the trie whose k-mers END in one of the bases of seed_mask (bit c-1 = base c): the trie is a forest
+// rooted at the last base, so the four parts are disjoint, their union is the whole harvest and each needs about a quarter
+// of the frontier -- what carries indexes beyond 2.5*10^10 symbols, whose full frontiers (2 x 32 bytes per distinct k-mer)
+// do not fit next to the index.
+extern "C" int fmd_kmer_collect_part_dev(fmd_dev_t *h, void *stream_, int w, int min_occ, int suf_len, int seed_mask, void *d_work, size_t work_bytes,
+                                         uint64_t cap, uint32_t *d_bucket, uint32_t *d_key, uint8_t *d_val, uint64_t *d_status);
 extern "C" int fmd_kmer_collect_dev(fmd_dev_t *h, void *stream_, int w, int min_occ, int suf_len, void *d_work, size_t work_bytes,
                                     uint64_t cap, uint32_t *d_bucket, uint32_t *d_key, uint8_t *d_val, uint64_t *d_status)
 {
+    return fmd_kmer_collect_part_dev(h, stream_, w, min_occ, suf_len, 0xf, d_work, work_bytes, cap, d_bucket, d_key, d_val, d_status);
+}
+extern "C" int fmd_kmer_collect_part_dev(fmd_dev_t *h, void *stream_, int w, int min_occ, int suf_len, int seed_mask, void *d_work, size_t work_bytes,
+                                         uint64_t cap, uint32_t *d_bucket, uint32_t *d_key, uint8_t *d_val, uint64_t *d_status)
+{
     if (!h || !d_work || !d_bucket || !d_key || !d_val || !d_status) return FMD_E_ARG;
-    if (w < 2 || w > 27 || suf_len < 1 || suf_len >= w || min_occ < 1 || w - suf_len > 15 || cap < (1u << 16)) return FMD_E_ARG; // MAX_KMER 27 (correct.c:303)
+    if (w < 2 || w > 27 || suf_len < 1 || suf_len >= w || min_occ < 1 || w - suf_len > 15 || cap < (1u << 16) || !(seed_mask & 0xf)) return FMD_E_ARG; // MAX_KMER 27 (correct.c:303)
     if (work_bytes < fmd_kmer_work_bytes(cap)) return FMD_E_ARG;
     FMD_HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream_;
@@ -306,7 +317,7 @@ extern "C" int fmd_kmer_collect_dev(fmd_dev_t *h, void *stream_, int w, int min_
     fmd_intv_t seed[4]; unsigned long long n1 = 0;
     for (int c = 1; c <= 4; ++c) {
         const uint64_t sz = h->cnt[c + 1] - h->cnt[c];
-        if (sz == 0) continue;
+        if (sz == 0 || !((seed_mask >> (c - 1)) & 1)) continue;
         seed[n1].x[0] = h->cnt[c]; seed[n1].x[1] = h->cnt[5 - c]; seed[n1].x[2] = sz; seed[n1].info = (uint64_t)(c - 1);
         ++n1;
     }
@@ -390,22 +401,20 @@ static int km_sort_triples(uint64_t m, int suf_len, uint32_t *db, uint32_t *dk, 
     return rc;
 }
 
-// Host form: grows the capacity until nothing overflows; outputs are malloc'ed (fmd_host_free) and
-// sorted by (bucket, key).
-extern "C" int fmd_kmer_collect(fmd_dev_t *h, int w, int min_occ, int suf_len, uint32_t **bucket, uint32_t **key, uint8_t **val,
-                                uint64_t *n, int64_t cnt[2])
+// One part of the harvest (seed_mask) on the device with the capacity grown until nothing overflows; triples sorted by
+// (bucket, key) and appended to the host arrays.
+static int km_collect_part_host(fmd_dev_t *h, int w, int min_occ, int suf_len, int seed_mask, uint64_t cap0, uint32_t **bucket, uint32_t **key,
+                                uint8_t **val, uint64_t *n, uint64_t *m_alloc, int64_t cnt[2])
 {
-    if (!h || !bucket || !key || !val || !n || !cnt) return FMD_E_ARG;
-    FMD_HIP_TRY(hipSetDevice(h->device));
-    uint64_t cap = 1u << 22;
+    uint64_t cap = cap0;
     for (int attempt = 0; attempt < 16; ++attempt, cap *= 4) {
         void *work = nullptr, *db = nullptr, *dk = nullptr, *dv = nullptr, *ds = nullptr;
         const size_t wb = fmd_kmer_work_bytes(cap);
         int rc = FMD_OK;
         if (hipMalloc(&work, wb) != hipSuccess || hipMalloc(&db, cap * 4) != hipSuccess || hipMalloc(&dk, cap * 4) != hipSuccess ||
-            hipMalloc(&dv, cap) != hipSuccess || hipMalloc(&ds, 32) != hipSuccess) rc = FMD_E_NOMEM;
+            hipMalloc(&dv, cap) != hipSuccess || hipMalloc(&ds, 32) != hipSuccess) { (void)hipGetLastError(); rc = FMD_E_NOMEM; }
         uint64_t status[4] = {0, 0, 0, 0};
-        if (rc == FMD_OK) rc = fmd_kmer_collect_dev(h, nullptr, w, min_occ, suf_len, work, wb, cap, (uint32_t *)db, (uint32_t *)dk, (uint8_t *)dv, (uint64_t *)ds);
+        if (rc == FMD_OK) rc = fmd_kmer_collect_part_dev(h, nullptr, w, min_occ, suf_len, seed_mask, work, wb, cap, (uint32_t *)db, (uint32_t *)dk, (uint8_t *)dv, (uint64_t *)ds);
         if (rc == FMD_OK && hipMemcpy(status, ds, 32, hipMemcpyDeviceToHost) != hipSuccess) rc = FMD_E_HIP;
         if (rc == FMD_OK && status[1] == 0) {
             hipFree(work); work = nullptr;   // the frontier buffers are not needed any more; the sort wants the room
@@ -413,15 +422,47 @@ extern "C" int fmd_kmer_collect(fmd_dev_t *h, int w, int min_occ, int suf_len, u
         }
         if (rc == FMD_OK && status[1] == 0) {
             const uint64_t m = status[0];
-            *bucket = (uint32_t *)malloc(m * 4 + 4); *key = (uint32_t *)malloc(m * 4 + 4); *val = (uint8_t *)malloc(m + 4);
-            if (!*bucket || !*key || !*val) rc = FMD_E_NOMEM;
-            else if (m && (hipMemcpy(*bucket, db, m * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(*key, dk, m * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-                           hipMemcpy(*val, dv, m, hipMemcpyDeviceToHost) != hipSuccess)) rc = FMD_E_HIP;
-            *n = m; cnt[0] = (int64_t)status[2]; cnt[1] = (int64_t)status[3];
+            if (*n + m + 4 > *m_alloc) {
+                const uint64_t want = (*n + m) + (*n ? (*n + m) / 2 : 0) + 4;     // later parts are about as large as this one
+                uint32_t *nb = (uint32_t *)realloc(*bucket, want * 4), *nk = nb ? (uint32_t *)realloc(*key, want * 4) : nullptr;
+                if (nb) *bucket = nb;
+                if (nk) *key = nk;
+                uint8_t *nv = nk ? (uint8_t *)realloc(*val, want) : nullptr;
+                if (nv) *val = nv;
+                if (!nb || !nk || !nv) rc = FMD_E_NOMEM; else *m_alloc = want;
+            }
+            if (rc == FMD_OK && m && (hipMemcpy(*bucket + *n, db, m * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(*key + *n, dk, m * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                                      hipMemcpy(*val + *n, dv, m, hipMemcpyDeviceToHost) != hipSuccess)) rc = FMD_E_HIP;
+            if (rc == FMD_OK) { *n += m; cnt[0] += (int64_t)status[2]; cnt[1] += (int64_t)status[3]; }
         }
         hipFree(work); hipFree(db); hipFree(dk); hipFree(dv); hipFree(ds);
+        if (rc == FMD_E_NOMEM && attempt == 0 && cap0 > (1u << 22)) { cap = (1u << 22) / 4; continue; }   // the estimate did not fit: grow from the bottom instead
         if (rc != FMD_OK) return rc;
         if (status[1] == 0) return FMD_OK;
     }
     return FMD_E_OVERFLOW;
+}
+
+// Host form; outputs are malloc'ed (fmd_host_free).  One pass over the whole trie when its frontiers fit next to the index
+// (triples sorted by (bucket, key)), else the four parts by last base one after the other (each part sorted, parts
+// concatenated: the consumers -- fmd_ectab_build, multiset comparisons -- do not depend on the order).
+extern "C" int fmd_kmer_collect(fmd_dev_t *h, int w, int min_occ, int suf_len, uint32_t **bucket, uint32_t **key, uint8_t **val,
+                                uint64_t *n, int64_t cnt[2])
+{
+    if (!h || !bucket || !key || !val || !n || !cnt) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    *bucket = nullptr; *key = nullptr; *val = nullptr; *n = 0; cnt[0] = cnt[1] = 0;
+    // distinct k-mers of both strands ~ symbols / 30 at 30x; two frontiers of 32 bytes each + 9 bytes of output per slot
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)64 << 30;
+    const double est = (double)h->mcnt[0] / 20.0;
+    int parts = est * 73.0 > 0.8 * (double)free_b ? 4 : 1;
+    { const char *e = getenv("FMD_KMER_PARTS"); if (e && (atoi(e) == 1 || atoi(e) == 4)) parts = atoi(e); }
+    uint64_t m_alloc = 0;
+    int rc = FMD_OK;
+    for (int p = 0; p < parts && rc == FMD_OK; ++p)
+        rc = km_collect_part_host(h, w, min_occ, suf_len, parts == 1 ? 0xf : 1 << p, 1u << 22, bucket, key, val, n, &m_alloc, cnt);
+    if (rc != FMD_OK) { free(*bucket); free(*key); free(*val); *bucket = nullptr; *key = nullptr; *val = nullptr; *n = 0; }
+    else if (!*bucket) { *bucket = (uint32_t *)malloc(4); *key = (uint32_t *)malloc(4); *val = (uint8_t *)malloc(4); }
+    return rc;
 }

@@ -280,12 +280,16 @@ static inline int fmd_ovlp_row_base(const fmd_ovlp_rec_t *r, uint32_t max_nei, c
  * (bucket, key, val) triple per solid k-mer: bucket = index into `solid[]` (correct.c:346-349),
  * key/val exactly what kh_put/kh_val store (correct.c:71-75).  The order of triples is
  * unspecified for the _dev form (the reference's own order is hash-table iteration order); the host
- * form returns them sorted by (bucket, key).  w <= 27, w - suf_len <= 15.
+ * form returns them sorted by (bucket, key), or -- for an index whose frontiers do not fit beside it -- as four sorted parts.  w <= 27, w - suf_len <= 15.
  * d_status (4 x u64): [0] #triples, [1] non-zero = cap overflowed (re-run larger), [2] cnt[0],
  * [3] cnt[1] (correct.c:64-69). */
 size_t fmd_kmer_work_bytes(uint64_t cap);
 int fmd_kmer_collect_dev(fmd_dev_t *h, void *stream, int w, int min_occ, int suf_len, void *d_work, size_t work_bytes,
                          uint64_t cap, uint32_t *d_bucket, uint32_t *d_key, uint8_t *d_val, uint64_t *d_status);
+/* the part of the harvest whose k-mers end in a base of seed_mask (bit c-1 = nt6 base c; 0xf = all): the trie is a forest
+ * rooted at the last base, the parts are disjoint and each needs about a quarter of the frontier */
+int fmd_kmer_collect_part_dev(fmd_dev_t *h, void *stream, int w, int min_occ, int suf_len, int seed_mask, void *d_work, size_t work_bytes,
+                              uint64_t cap, uint32_t *d_bucket, uint32_t *d_key, uint8_t *d_val, uint64_t *d_status);
 int fmd_kmer_collect(fmd_dev_t *h, int w, int min_occ, int suf_len, uint32_t **bucket, uint32_t **key, uint8_t **val,
                      uint64_t *n, int64_t cnt[2]);   /* outputs malloc'ed: fmd_host_free() */
 

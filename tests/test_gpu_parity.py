@@ -272,6 +272,19 @@ def test_kmer_collect_golden(tiny_dev, gold, w, mo):
     assert cnt == list(v[tag + "_cnt"])
 
 
+def test_kmer_collect_in_four_parts_equals_one_pass(tiny_dev, monkeypatch):
+    """The harvest by last base (fmd_kmer_collect_part_dev: what carries indexes whose frontiers do not fit beside them)
+    gives the triples of the one-pass harvest, and the same informative / ambiguous counts."""
+    def pack(b, k, v):
+        return np.sort(b.astype(np.uint64) << np.uint64(40) | k.astype(np.uint64) << np.uint64(8) | v.astype(np.uint64))
+    for w, mo in ((17, 3), (23, 2)):
+        monkeypatch.setenv("FMD_KMER_PARTS", "1")
+        b1, k1, v1, c1 = tiny_dev.kmer_collect(w, mo)
+        monkeypatch.setenv("FMD_KMER_PARTS", "4")
+        b4, k4, v4, c4 = tiny_dev.kmer_collect(w, mo)
+        assert len(b1) > 1000 and np.array_equal(pack(b1, k1, v1), pack(b4, k4, v4)) and list(c1) == list(c4)
+
+
 @pytest.mark.parametrize("sm", [0, 1])
 def test_smem_golden(tiny_dev, gold, sm):
     """fm6_smem (smem.c:397) on indexed and noisy reads, both self_match settings."""
