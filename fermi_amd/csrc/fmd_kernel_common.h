@@ -29,6 +29,36 @@ __device__ __forceinline__ void store_entry(fmd_intv_t *e, uint64_t x0, uint64_t
     q[1] = make_uint4((uint32_t)sz, (uint32_t)(sz >> 32), (uint32_t)info, (uint32_t)(info >> 32));
 }
 
+// Candidate intervals of one strand (the list overlap_intv builds, unitig.c:38-64), as the walk leaves them for the get_nei kernels.
+// Wide form = store_entry(x0, x1, size, depth).  Narrow form (size <= 63, depth < 65536: every candidate the walk pushes from its
+// 64-position window path) carries two more facts about BWT[x0, x0 + size) that the walk has at hand when it pushes and that
+// fm6_get_nei would otherwise fetch the block of x0 for again: D = the positions of '$' in that range (bit i = BWT[x0 + i] is '$':
+// the reads that START with the candidate string, the sentinel tests of unitig.c:112/:129) and r0 = the number of '$' before x0
+// (x[0] of the neighbour interval, unitig.c:113).  Both follow a forward extension without touching memory (the child ranges are
+// sub-ranges of [x0, x0 + size)), so the unforked fast path of get_nei (k_ovl_nei_fast) never reads the x[0] side at all.
+//   q[0] = { x0 lo, x0 bits 32..39 | r0 bits 32..39 << 8 | depth << 16, x1 lo, x1 hi }     q[1] = { D lo, D hi, r0 lo, NARROW | size }
+#define FMD_CAND_NARROW 0x80000000u
+struct FmdCand { uint64_t x0, x1, sz, D, r0; uint32_t depth; bool narrow; };
+__device__ __forceinline__ FmdCand cand_decode(const uint4 a, const uint4 b)
+{
+    FmdCand c;
+    c.narrow = (b.w & FMD_CAND_NARROW) != 0;
+    c.x1 = (uint64_t)a.w << 32 | a.z;
+    if (c.narrow) {
+        c.x0 = (uint64_t)(a.y & 0xffu) << 32 | a.x; c.r0 = (uint64_t)((a.y >> 8) & 0xffu) << 32 | b.z; c.depth = a.y >> 16;
+        c.sz = b.w & 63u; c.D = (uint64_t)b.y << 32 | b.x;
+    } else {
+        c.x0 = (uint64_t)a.y << 32 | a.x; c.sz = ((uint64_t)b.y << 32 | b.x) & 0xffffffffffffull; c.depth = b.z; c.D = 0; c.r0 = 0;
+    }
+    return c;
+}
+__device__ __forceinline__ void cand_store_narrow(fmd_intv_t *e, uint64_t x0, uint64_t x1, uint32_t sz, uint32_t depth, uint64_t D, uint64_t r0)
+{
+    uint4 *q = (uint4 *)e;
+    q[0] = make_uint4((uint32_t)x0, ((uint32_t)(x0 >> 32) & 0xffu) | ((uint32_t)(r0 >> 32) & 0xffu) << 8 | depth << 16, (uint32_t)x1, (uint32_t)(x1 >> 32));
+    q[1] = make_uint4((uint32_t)D, (uint32_t)(D >> 32), (uint32_t)r0, FMD_CAND_NARROW | sz);
+}
+
 // ---- 64-position window over a lane's block images (used when an SA interval is narrower than 64)
 __device__ __forceinline__ uint64_t bits_below(int j) { return j >= 64 ? ~0ull : ((1ull << j) - 1); }
 
@@ -74,9 +104,14 @@ __device__ __forceinline__ uint64_t range64(uint32_t a, uint32_t b) // bits [a, 
 #define FMD_GRP_CLASSES 5
 __device__ __host__ __forceinline__ constexpr int fmd_grp_size(int k) { return k == 0 ? 8 : k == 1 ? 12 : k == 2 ? 16 : k == 3 ? 21 : 32; }
 #define FMD_CLS_CNT_STRIDE 32              // counters sit on separate 128-byte lines
-#define FMD_CLS_HEADER_U32 256             // the counter area in front of the lists
+#define FMD_CLS_HEADER_U32 512             // the counter area in front of the lists
+#define FMD_CLS_LISTS (3 * FMD_GRP_CLASSES + 1)                 // general lists, the slow list, fast lists (32-bit masks, 64-bit masks)
+#define FMD_CLS_WORDS_PER_STRAND (6 * FMD_GRP_CLASSES + 1)      // two words per entry of a group list, one for the slow list
 struct FmdOvlClasses {
-    uint32_t *cnt;                    // [k * FMD_CLS_CNT_STRIDE] = strands of class k, [FMD_GRP_CLASSES * ...] = strands of the slow list
+    // counters: [k * STRIDE] = strands of general class k, [CLASSES * STRIDE] = the slow list, [(CLASSES + 1 + k) * STRIDE] = fast class k,
+    // k >= CLASSES: the 64-bit variant of class k - CLASSES (+8 on that line: strands the fast kernel handed on to the general class)
+    uint32_t *cnt;
     uint32_t *lst[FMD_GRP_CLASSES];   // two words per strand: index, candidates | length << 16
     uint32_t *lslow;                  // everything else, plus strands the group kernels hand back
+    uint32_t *fast[2 * FMD_GRP_CLASSES];  // strands whose candidates are in the narrow form: k_ovl_nei_fast first (same two words)
 };

@@ -12,7 +12,11 @@
 void fmd_launch_nei_grp(int cls, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                         const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
                         uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n);
-void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, const fmd_intv_t *listA, uint32_t cap, FmdOvlClasses cl);
+int fmd_nei_fast_available(void);
+void fmd_launch_nei_fast(int cls, int wide, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
+                         const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
+                         uint32_t seq_stride, uint32_t *gen_list, uint32_t *gen_n, uint32_t *bail_n, uint32_t *slow_list, uint32_t *slow_n);
+void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, const fmd_intv_t *listA, uint32_t cap, FmdOvlClasses cl, int use_fast);
 
 // ---------------------------------------------------------------------------- phase 0: retrieve
 // fm_retrieve (exact.c:59-70); writes the sequence REVERSED into srev and rank/len into rec.
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
         // sizes, the base at row k (k lies inside the window) and rank_c(k) -- plus ONE absolute rank
         // of ONE symbol, rank_c(x0-1).  ~150 VALU instead of two full six-symbol block ranks (~600).
         const bool narrow = st == WK_BOTH && sz <= 63;
-        uint64_t ws[6] = {0, 0, 0, 0, 0, 0}, wtk = 0;
+        uint64_t ws[6] = {0, 0, 0, 0, 0, 0}, wtk = 0, wD = 0, wr0 = 0;  // wD, wr0: cand_store_narrow (fmd_kernel_common.h)
         if (narrow) {
             const uint32_t sh = (uint32_t)x0 & 31;
             uint4 a, b, cc;
@@ -255,7 +259,8 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             ws[0] = __popcll(M0); ws[1] = __popcll(M1); ws[2] = __popcll(M2); ws[3] = __popcll(M3); ws[4] = __popcll(M4); ws[5] = __popcll(M5);
             const uint32_t o = (uint32_t)(k - x0);                       // row k inside the window
             c = (int)(((X >> o) & 1) | ((Y >> o) & 1) << 1 | ((Z >> o) & 1) << 2);
-            wtk = fmd_block_rank1(r.bk, r.t, r.nk, c, r.blk_k);                    // rank_c(x0 - 1)
+            wtk = fmd_block_rank1z(r.bk, r.t, r.nk, c, r.blk_k, wr0);              // rank_c(x0 - 1), rank_$(x0 - 1)
+            wD = M0;
             const uint64_t Mc = sel6(c, M0, M1, M2, M3, M4, M5);
             k = ix.cnt[c] + wtk + __popcll(Mc & bits_below((int)o + 1)) - 1;
         } else if (st == WK_LF || st == WK_BOTH) { // LF step at row k: base = BWT[k], k' = cnt[c] + rank_c(k) - 1
@@ -322,8 +327,11 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
                 const uint64_t sc = sel6(c, s[0], s[1], s[2], s[3], s[4], s[5]);
                 // (sc == 0 cannot happen: the sequence itself is in the index)
                 if (!info_only && (int)depth >= min_match && s[0]) {
-                    if (npush < cap) store_entry(listA + sid * (size_t)cap + (cap - 1 - npush), x0, x1, sz, (uint64_t)depth);
-                    else flags |= FMD_OVLP_F_OVERFLOW;
+                    if (npush < cap) {
+                        fmd_intv_t *e = listA + sid * (size_t)cap + (cap - 1 - npush);
+                        if (narrow && depth < 65536u) cand_store_narrow(e, x0, x1, (uint32_t)sz, depth, wD, wr0);
+                        else store_entry(e, x0, x1, sz, (uint64_t)depth);
+                    } else flags |= FMD_OVLP_F_OVERFLOW;
                     ++npush;
                 }
                 x0 = sel6(c, ix.cnt[0], ix.cnt[1], ix.cnt[2], ix.cnt[3], ix.cnt[4], ix.cnt[5]) + sel6(c, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
@@ -472,11 +480,16 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
         while (st == ST_PICK) {
             if (j < prev_n) {
                 if (!e_valid) { const uint4 *q = (const uint4 *)(prev + j); ea = q[0]; eb = q[1]; }
-                cat_j = (int)(eb.w >> 4);                    // info >> 36
+                if (cur_l == ori_l) { // round 0: the walk's candidates (either form); it stored the suffix depth, unitig.c:53 wants the start
+                    const FmdCand cd = cand_decode(ea, eb);
+                    cat_j = 0;
+                    px0 = cd.x0; px1 = cd.x1; psz = cd.sz; pinfo = (uint64_t)ori_l - cd.depth;
+                } else {
+                    cat_j = (int)(eb.w >> 4);                    // info >> 36
+                    px0 = (uint64_t)ea.y << 32 | ea.x; px1 = (uint64_t)ea.w << 32 | ea.z;
+                    psz = ((uint64_t)eb.y << 32 | eb.x) & FMD_SZ_MASK; pinfo = (uint64_t)eb.w << 32 | eb.z;
+                }
                 if (cat_j == masked_cat) { ++j; e_valid = false; continue; }
-                px0 = (uint64_t)ea.y << 32 | ea.x; px1 = (uint64_t)ea.w << 32 | ea.z;
-                psz = ((uint64_t)eb.y << 32 | eb.x) & FMD_SZ_MASK; pinfo = (uint64_t)eb.w << 32 | eb.z;
-                if (cur_l == ori_l) pinfo = (uint64_t)ori_l - pinfo; // round 0: the walk stored the suffix depth, unitig.c:53 wants the start
                 st = ST_EXT;
                 e_valid = j + 1 < prev_n;
                 if (e_valid) { const uint4 *q = (const uint4 *)(prev + j + 1); ea = q[0]; eb = q[1]; } // lands under the rank fetch
@@ -777,7 +790,7 @@ extern "C" size_t fmd_ovlp_work_bytes(size_t n, uint32_t max_len, int min_match)
     const size_t stride_r = align_up((size_t)max_len, 16);
     const size_t cap = fmd_ovlp_list_cap(max_len, min_match);
     return align_up(n * stride_r, 256) + 2 * align_up(n * cap * sizeof(fmd_intv_t), 256) +
-           align_up(n * (8 * FMD_GRP_CLASSES + 4) + 4 * FMD_CLS_HEADER_U32 * FMD_OVLP_MAX_PARTS, 256) + 256;
+           align_up(n * (4 * FMD_CLS_WORDS_PER_STRAND) + 4 * FMD_CLS_HEADER_U32 * FMD_OVLP_MAX_PARTS, 256) + 256;
 }
 
 // The buffers of one fmd_ovlp_dev call; the two phases below work on the strands [b, b + np) of it.
@@ -809,7 +822,7 @@ static void ovl_phase_a(const OvlBatch &o, hipStream_t st, size_t b, size_t np, 
 }
 
 // phase B: fm6_get_nei.  `part` selects the counter header of this part's work lists.
-static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, int part, int per_cu)
+static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, int part, int per_cu, int fast_cu)
 {
     uint8_t *srev = o.srev + b * (size_t)o.stride_r;
     fmd_intv_t *listA = o.listA + b * (size_t)o.cap, *listB = o.listB + b * (size_t)o.cap;
@@ -822,20 +835,43 @@ static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, i
         k_ovl_nei<<<grid, 64, 0, st>>>(o.ix, np, o.min_match, srev, o.stride_r, o.cap, listA, listB, rec, nei, o.max_nei, seq, o.seq_stride, q2, nullptr, nullptr);
         return FMD_OK;
     }
-    // work lists: the counter header, then one list per group class (2 words per strand) and the slow list (1)
-    uint32_t *cls = o.cls + (size_t)part * FMD_CLS_HEADER_U32 + b * (2 * FMD_GRP_CLASSES + 1);
+    // work lists: the counter header, then one list per group class (2 words per strand), the slow list (1), one list per fast class (2)
+    uint32_t *cls = o.cls + (size_t)part * FMD_CLS_HEADER_U32 + b * FMD_CLS_WORDS_PER_STRAND;
     FmdOvlClasses cl;
     cl.cnt = cls;
     for (int k = 0; k < FMD_GRP_CLASSES; ++k) cl.lst[k] = cls + FMD_CLS_HEADER_U32 + 2 * np * k;
     cl.lslow = cls + FMD_CLS_HEADER_U32 + 2 * np * FMD_GRP_CLASSES;
+    for (int k = 0; k < 2 * FMD_GRP_CLASSES; ++k) cl.fast[k] = cl.lslow + np + 2 * np * k;
     uint32_t *n_slow = cl.cnt + FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE;
     FMD_HIP_TRY(hipMemsetAsync(cls, 0, 4 * FMD_CLS_HEADER_U32, st));
-    fmd_launch_classify(st, np, rec, listA, o.cap, cl);
+    // FMD_OVLP_FAST=0: A/B switch, every strand through the general group kernels
+    const char *ef = getenv("FMD_OVLP_FAST");
+    const int use_fast = fmd_nei_fast_available() && !(ef && atoi(ef) == 0);
+    fmd_launch_classify(st, np, rec, listA, o.cap, cl, use_fast);
+    // strands whose candidates the walk left in the narrow form: the unforked path (one lane per candidate, no x[0]-side fetch,
+    // one shared window per strand and round); whatever turns out not to be that simple moves on to the general list of its class
+    if (use_fast)
+        for (int k = 0; k < 2 * FMD_GRP_CLASSES; ++k) {
+            uint32_t *nk = cl.cnt + (FMD_GRP_CLASSES + 1 + k) * FMD_CLS_CNT_STRIDE;
+            const int kg = k % FMD_GRP_CLASSES;
+            fmd_launch_nei_fast(kg, k >= FMD_GRP_CLASSES, o.h->n_cu, fast_cu, st, o.ix, cl.fast[k], nk, o.cap, listA, rec, nei, o.max_nei, seq,
+                                o.seq_stride, cl.lst[kg], cl.cnt + kg * FMD_CLS_CNT_STRIDE, nk + 8, cl.lslow, n_slow);
+        }
     // one lane per candidate interval, 64 / G strands per wave
     for (int k = 0; k < FMD_GRP_CLASSES; ++k)
         fmd_launch_nei_grp(k, o.h->n_cu, per_cu, st, o.ix, cl.lst[k], cl.cnt + k * FMD_CLS_CNT_STRIDE, o.cap, listA, rec, nei, o.max_nei, seq, o.seq_stride, cl.lslow, n_slow);
     // the rest (too many candidates, wide intervals, fake forks, neighbour overflow): lane per strand
     k_ovl_nei<<<grid, 64, 0, st>>>(o.ix, np, o.min_match, srev, o.stride_r, o.cap, listA, listB, rec, nei, o.max_nei, seq, o.seq_stride, q2, cl.lslow, n_slow);
+    if (getenv("FMD_OVLP_STATS")) { // where the strands of this part went (synchronises: diagnostics only)
+        uint32_t hs[FMD_CLS_HEADER_U32];
+        hipStreamSynchronize(st);
+        hipMemcpy(hs, cls, sizeof(hs), hipMemcpyDeviceToHost);
+        uint32_t nf = 0, nb = 0, ng = 0;
+        for (int k = 0; k < 2 * FMD_GRP_CLASSES; ++k) { nf += hs[(FMD_GRP_CLASSES + 1 + k) * FMD_CLS_CNT_STRIDE]; nb += hs[(FMD_GRP_CLASSES + 1 + k) * FMD_CLS_CNT_STRIDE + 8]; }
+        for (int k = 0; k < FMD_GRP_CLASSES; ++k) ng += hs[k * FMD_CLS_CNT_STRIDE];
+        fprintf(stderr, "[M::fmd_ovlp] part of %zu strands: %u to the unforked path (%u of them handed on), %u through the general group kernels, %u through the lane-per-strand kernel\n",
+                np, nf, nb, ng, hs[FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE]);
+    }
 #ifdef GRP_STATS
     {
         uint32_t hs[FMD_CLS_HEADER_U32];
@@ -855,16 +891,17 @@ static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, i
 // CU's wave slots (LDS: 6 x 8.75 KiB + 10 x 10 KiB <= 160 KiB; get_nei needs the waves, the walk
 // still issues 85 % of its requests with 6).  FMD_OVLP_PIPE="parts,walk_per_cu,
 // grp_per_cu" overrides the split; parts = 1 is the serial order.
-static void ovl_pipe_config(size_t n, int &parts, int &walk_cu, int &grp_cu)
+static void ovl_pipe_config(size_t n, int &parts, int &walk_cu, int &grp_cu, int &fast_cu)
 {
-    parts = n >= (1u << 21) ? 4 : 1; walk_cu = 6; grp_cu = 10;
+    parts = n >= (1u << 21) ? 4 : 1; walk_cu = 6; grp_cu = 10; fast_cu = 0;
     const char *e = getenv("FMD_OVLP_PIPE");
     if (e) {
-        int a = 0, b = 0, c = 0;
-        const int k = sscanf(e, "%d,%d,%d", &a, &b, &c);
+        int a = 0, b = 0, c = 0, d = 0;
+        const int k = sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d);
         if (k >= 1 && a >= 1) parts = a < FMD_OVLP_MAX_PARTS ? a : FMD_OVLP_MAX_PARTS;
         if (k >= 2 && b >= 1) walk_cu = b;
         if (k >= 3 && c >= 1) grp_cu = c;
+        if (k >= 4 && d >= 1) fast_cu = d;
     }
     if (getenv("FMD_OVLP_UNFUSED") || getenv("FMD_OVLP_SLOW_ONLY")) parts = 1;
 }
@@ -909,13 +946,13 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
     o.cls = (uint32_t *)((uint8_t *)o.listB + align_up(n * (size_t)o.cap * sizeof(fmd_intv_t), 256));
     o.rec = d_rec; o.nei = d_nei; o.seq = d_seq;
 
-    int parts, walk_cu, grp_cu;
-    ovl_pipe_config(n, parts, walk_cu, grp_cu);
+    int parts, walk_cu, grp_cu, fast_cu;
+    ovl_pipe_config(n, parts, walk_cu, grp_cu, fast_cu);
     if (parts > 1 && !ovl_aux_acquire(h)) parts = 1;   // the second stream is in use by another call: serial order
     int rc = FMD_OK;
     if (parts == 1) {
         ovl_phase_a(o, st, 0, n, 0);
-        rc = ovl_phase_b(o, st, 0, n, 0, 0);
+        rc = ovl_phase_b(o, st, 0, n, 0, 0, 0);
     } else {
         hipStream_t s2 = h->aux_stream;
         // Equal parts: get_nei is the slower phase while the two run side by side, so the last part --
@@ -928,7 +965,7 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
             const bool last = b + per >= n;
             ovl_phase_a(o, st, b, np, p == 0 ? 0 : walk_cu);         // the first part has the GPU to itself
             if (hipEventRecord(h->aux_ev[p], st) != hipSuccess || hipStreamWaitEvent(s2, h->aux_ev[p], 0) != hipSuccess) { join_ok = false; break; }
-            rc = ovl_phase_b(o, s2, b, np, p, last ? 0 : grp_cu);      // so has the last phase B
+            rc = ovl_phase_b(o, s2, b, np, p, last ? 0 : grp_cu, last ? 0 : fast_cu);      // so has the last phase B
         }
         // the caller's stream owns the results again; if the hand-over itself failed, wait on the host
         if (!join_ok || hipEventRecord(h->aux_ev[FMD_OVLP_MAX_PARTS], s2) != hipSuccess ||

@@ -41,10 +41,11 @@ static_assert(GRP_POOL <= 32, "the region ends with 32 block numbers");
 // (ballots per wave, LDS across the 16 waves) and ONE atomic per block and class, each counter on
 // its own 128-byte line: per-wave atomics on adjacent words cost 7-15 ms per 2*10^7 strands.
 #define CLS_THREADS 1024
+#define CLS_LISTS FMD_CLS_LISTS            // general class k = k, slow = FMD_GRP_CLASSES, fast class k = FMD_GRP_CLASSES + 1 + k (+ FMD_GRP_CLASSES: 64-bit masks)
 __global__ __launch_bounds__(CLS_THREADS) void k_ovl_classify(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, const fmd_intv_t *__restrict__ listA,
-                                                              uint32_t cap, FmdOvlClasses cl)
+                                                              uint32_t cap, FmdOvlClasses cl, int use_fast)
 {
-    __shared__ uint32_t wcnt[CLS_THREADS / 64][FMD_GRP_CLASSES + 1], base[FMD_GRP_CLASSES + 1];
+    __shared__ uint32_t wcnt[CLS_THREADS / 64][CLS_LISTS], base[CLS_LISTS];
     const size_t i = (size_t)blockIdx.x * CLS_THREADS + threadIdx.x;
     int cls = -1;
     uint32_t m = 0, len = 0;
@@ -54,24 +55,27 @@ __global__ __launch_bounds__(CLS_THREADS) void k_ovl_classify(size_t n, const fm
             m = (uint32_t)o->n_ovlp; len = (uint32_t)o->len;
             // the widest candidate is the last one (shortest overlap): the group kernels count
             // symbols of BWT[x, x+size) through a 64-position window
-            uint64_t x0, x1, sz, inf;
-            load_entry(listA + i * (size_t)cap + (cap - 1), x0, x1, sz, inf);
+            const uint4 *q = (const uint4 *)(listA + i * (size_t)cap + (cap - 1));
+            const FmdCand w = cand_decode(q[0], q[1]);
             cls = FMD_GRP_CLASSES;
-            if (sz <= 63 && len < 65535)
+            if (w.sz <= 63 && len < 65535) {
 #pragma unroll
                 for (int k = FMD_GRP_CLASSES - 1; k >= 0; --k) if (m <= (uint32_t)fmd_grp_size(k)) cls = k;
+                // the widest candidate was pushed first; the fast kernel checks the others when it loads them
+                if (cls < FMD_GRP_CLASSES && w.narrow && use_fast) cls += FMD_GRP_CLASSES + 1 + (w.sz > 31 ? FMD_GRP_CLASSES : 0);
+            }
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t in_wave = 0;                      // lanes of this wave before me in my class
 #pragma unroll
-    for (int c = 0; c <= FMD_GRP_CLASSES; ++c) {
+    for (int c = 0; c < CLS_LISTS; ++c) {
         const uint64_t mk = __ballot(cls == c);
         if (lane == 0) wcnt[wave][c] = (uint32_t)__popcll(mk);
         if (cls == c) in_wave = (uint32_t)fmd_below(mk);
     }
     __syncthreads();
-    if (threadIdx.x <= FMD_GRP_CLASSES) {      // exclusive scan over the waves, then the block's slice of the list
+    if (threadIdx.x < CLS_LISTS) {             // exclusive scan over the waves, then the block's slice of the list
         uint32_t tot = 0;
         for (int w = 0; w < CLS_THREADS / 64; ++w) { const uint32_t v = wcnt[w][threadIdx.x]; wcnt[w][threadIdx.x] = tot; tot += v; }
         base[threadIdx.x] = tot ? atomicAdd(cl.cnt + threadIdx.x * FMD_CLS_CNT_STRIDE, tot) : 0;
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(CLS_THREADS) void k_ovl_classify(size_t n, const fm
     if (cls >= 0) {
         const uint32_t k = base[cls] + wcnt[wave][cls] + in_wave;
         if (cls == FMD_GRP_CLASSES) cl.lslow[k] = (uint32_t)i;
-        else { uint32_t *lst = cl.lst[cls]; lst[2 * k] = (uint32_t)i; lst[2 * k + 1] = m | len << 16; }
+        else { uint32_t *lst = cls < FMD_GRP_CLASSES ? cl.lst[cls] : cl.fast[cls - FMD_GRP_CLASSES - 1]; lst[2 * k] = (uint32_t)i; lst[2 * k + 1] = m | len << 16; }   // fast[5..9]: the 64-bit lists
     }
 }
 
@@ -125,8 +129,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
             const uint32_t m = d_meta & 0xffff;
             sid = d_sid; ori_l = (int)(d_meta >> 16); round = 0; n_nei = 0; flags = 0; nei0_info = 0;
             alive = (uint32_t)j < m;
-            x0 = (uint64_t)pa.y << 32 | pa.x; x1 = (uint64_t)pa.w << 32 | pa.z;
-            sz = ((uint64_t)pb.y << 32 | pb.x) & FMD_SZ_MASK; pos = (uint32_t)ori_l - pb.z; cat = 0; // stored info = suffix depth
+            { const FmdCand cd = cand_decode(pa, pb); x0 = cd.x0; x1 = cd.x1; sz = cd.sz; pos = (uint32_t)ori_l - cd.depth; cat = 0; } // stored: suffix depth
             active = true;
             pf = 0; idx += n_groups;
         }
@@ -337,6 +340,234 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
     }
 }
 
+// ---------------------------------------------------------------------- the unforked fast path
+// fm6_get_nei for the strands it is simple on -- on read sets deep enough to assemble, nearly all of them: every candidate is in
+// the narrow form (fmd_kernel_common.h: the walk left D and r0 with it), nothing has forked yet (one category) and, this round, the
+// reads that contain any candidate go on with ONE base or end.  Same lane-per-candidate groups as k_ovl_nei_grp, a fraction of
+// its work per round:
+//   * the x[0] side is never fetched: a child's range is a sub-range of its parent's, so D shifts and r0 counts along;
+//   * the x[1] ranges of a strand's candidates are NESTED (they are suffixes W_i of one string, longest first, and x[1] is the
+//     interval of revcomp(W_i), of which revcomp(W_j), j > i, is a prefix): one window -- the widest live candidate's, one or two
+//     blocks per strand and round through a 16-slot pool, ONE wave instruction -- serves every lane of the group, each lane
+//     counting its own sub-range [d, d + size) of it; the child's x[1] is rank_c(X1 - 1) + the c's before d, one absolute rank
+//     per group instead of per lane, and the neighbour's x[1] the same with '$';
+//   * lanes never move: without categories the list order is the lane order, so there is no re-pack through LDS;
+//   * the range masks are 32-bit words when the widest candidate has at most 31 occurrences (M = uint32_t), 64-bit otherwise.
+// The moment a strand leaves that regime (a second base or an N among the reads of any candidate, even one no read starts with;
+// a candidate in the wide form) it is appended to the general list of its class and k_ovl_nei_grp starts it over: nothing the fast
+// path wrote for it survives (records are written at the close only; neighbours and appended bases are rewritten).
+#if FMD_BLK64
+template <typename M> struct FastW;
+template <> struct FastW<uint32_t> {
+    static constexpr uint32_t MAXW = 31;
+    static __device__ __forceinline__ uint32_t below(uint32_t n) { return (1u << n) - 1u; }          // n <= 31
+    static __device__ __forceinline__ uint32_t popc(uint32_t v) { return (uint32_t)__popc(v); }
+    static __device__ __forceinline__ int top(uint32_t v) { return 31 - __clz((int)v); }
+    // bit-planes of BWT[96 b + o1, .. + 32) from the images of blocks b, b + 1 (4 uint4 each, chunk 3 of a block = its counts)
+    static __device__ __forceinline__ void window(const uint4 *img, uint32_t o1, uint32_t &X, uint32_t &Y, uint32_t &Z)
+    {
+        const uint32_t q = o1 >> 5, sh = o1 & 31;
+        const uint4 a = img[q + (q >= 3)], b = img[q + 1 + (q >= 2)];
+        X = __builtin_amdgcn_alignbit(b.x, a.x, sh); Y = __builtin_amdgcn_alignbit(b.y, a.y, sh); Z = __builtin_amdgcn_alignbit(b.z, a.z, sh);
+    }
+};
+template <> struct FastW<uint64_t> {
+    static constexpr uint32_t MAXW = 63;
+    static __device__ __forceinline__ uint64_t below(uint32_t n) { return (1ull << n) - 1ull; }       // n <= 63
+    static __device__ __forceinline__ uint32_t popc(uint64_t v) { return (uint32_t)__popcll(v); }
+    static __device__ __forceinline__ int top(uint64_t v) { return 63 - __clzll((long long)v); }
+    static __device__ __forceinline__ void window(const uint4 *img, uint32_t o1, uint64_t &X, uint64_t &Y, uint64_t &Z)
+    {
+        const uint32_t q = o1 >> 5, sh = o1 & 31;
+        const uint4 a = img[q + (q >= 3)], b = img[q + 1 + (q >= 2)], c = img[q + 2 + (q >= 1)];
+        X = win64(a.x, b.x, c.x, sh); Y = win64(a.y, b.y, c.y, sh); Z = win64(a.z, b.z, c.z, sh);
+    }
+};
+
+template <int G, typename M>
+__global__ __launch_bounds__(64, 5) void k_ovl_nei_fast(FmdIndexView ix, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
+                                                     uint32_t cap, const fmd_intv_t *__restrict__ listA, fmd_ovlp_rec_t *__restrict__ rec,
+                                                     fmd_intv_t *__restrict__ nei_out, uint32_t max_nei, uint8_t *__restrict__ seq_out,
+                                                     uint32_t seq_stride, uint32_t *__restrict__ gen_list, uint32_t *__restrict__ gen_n,
+                                                     uint32_t *__restrict__ bail_n, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_n)
+{
+    using W = FastW<M>;
+    constexpr int S = 64 / G;
+    // pool slots 2g, 2g+1 = the block(s) under group g's window, images side by side and unswizzled (the lanes of a group read ONE
+    // address: a broadcast); + the two slots the idle lanes past S * G would read
+    __shared__ uint4 pool[(FMD_BLK_PER_INST + 2) * FMD_BLK_U4];
+    static_assert(2 * S <= FMD_BLK_PER_INST, "one gather instruction per step");
+    constexpr uint32_t GM = G == 32 ? 0xffffffffu : (1u << G) - 1;
+    const int lane = fmd_lane(), g = lane / G, j = lane % G, gbase = g * G;
+    const uint32_t N = *list_n;
+    const uint32_t n_groups = gridDim.x * S;
+    uint32_t idx = g < S ? blockIdx.x * S + g : 0xffffffffu;
+    // this lane's part in the gather: chunk (lane & 3) of pool slot lane >> 2, which belongs to group f_src / G
+    const int f_slot = lane >> FMD_GRP_SHIFT, f_src = (f_slot >> 1) < S ? (f_slot >> 1) * G : 0;
+    const bool f_mine = (f_slot >> 1) < S;
+    const uint4 *img = pool + 2 * FMD_BLK_U4 * g;
+
+    // group-uniform strand state
+    bool active = false;
+    uint32_t sid = 0, meta = 0, n_nei = 0, lf = 0, nei0 = 0, szw = 1, round = 0;
+    uint64_t X1 = 1;                                              // start of the group's window = x[1] of the widest live candidate
+    // the lane's candidate: its range is [X1 + d, X1 + d + sz) on the x[1] side
+    bool alive = false;
+    uint32_t d = 0, sz = 0, pos = 0;
+    M D = 0;
+    uint64_t r0 = 0;
+    int pf = 0;
+    uint32_t d_sid = 0, d_meta = 0;
+    uint4 pa = make_uint4(0, 0, 0, 0), pb = make_uint4(0, 0, 0, 0);
+
+    for (;;) {
+        // ---- admission
+        if (!active && pf == 2) {
+            const uint32_t m = d_meta & 0xffff;
+            sid = d_sid; meta = d_meta; round = 0; n_nei = 0; lf = 0; nei0 = 0;
+            alive = (uint32_t)j < m;
+            const FmdCand cd = cand_decode(pa, pb);
+            const int wl = gbase + (int)m - 1;                   // the widest candidate is the last
+            const uint32_t wlo = (uint32_t)__shfl((int)(uint32_t)cd.x1, wl), whi = (uint32_t)__shfl((int)(uint32_t)(cd.x1 >> 32), wl);
+            X1 = (uint64_t)whi << 32 | wlo;
+            szw = (uint32_t)__shfl((int)(uint32_t)cd.sz, wl);
+            sz = (uint32_t)cd.sz; D = (M)cd.D; r0 = cd.r0; pos = (meta >> 16) - cd.depth;
+            d = (uint32_t)(cd.x1 - X1);
+            // every candidate in the narrow form and inside the widest one's range (nesting: see above)
+            const bool bad = alive && (!cd.narrow || cd.x1 < X1 || cd.x1 - X1 + cd.sz > szw || szw > W::MAXW || cd.sz == 0);
+            if ((uint32_t)(__ballot(bad) >> gbase) & GM) {
+                if (j == 0) { const uint32_t k = atomicAdd(gen_n, 1u); gen_list[2 * (size_t)k] = sid; gen_list[2 * (size_t)k + 1] = meta; atomicAdd(bail_n, 1u); }
+                alive = false;
+            } else active = true;
+            pf = 0; idx += n_groups;
+        }
+        // ---- prefetch pipeline (loads complete under the window gather below)
+        if (pf == 1) {
+            const uint32_t m = d_meta & 0xffff;
+            if ((uint32_t)j < m) { const uint4 *q = (const uint4 *)(listA + d_sid * (size_t)cap + (cap - m) + j); pa = q[0]; pb = q[1]; }
+            pf = 2;
+        } else if (pf == 0 && idx < N) {
+            d_sid = list[2 * (size_t)idx]; d_meta = list[2 * (size_t)idx + 1];
+            pf = 1;
+        }
+        const uint64_t act_m = __ballot(active);
+        if (act_m == 0) {
+            if (__ballot(pf != 0 || idx < N) == 0) break;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            continue;
+        }
+
+        // ---- the window of every resident strand: BWT[X1, X1 + szw), its block(s) into pool slots 2g (2g + 1)
+        uint32_t bke, oke;
+        fmd_split(X1 - 1, bke, oke);                              // x[1] >= cnt[1] > 0 for base strings
+        const uint32_t o1 = oke + 1;                              // offset of X1 in block bke (96: the first position of the next one)
+        const uint64_t sep_m = __ballot(active && o1 + szw > FMD_BLK_SYMS);
+#if FMD_COUNT_LINES
+        { uint64_t heads = 0; for (int q = 0; q < S; ++q) heads |= 1ull << (q * G); fmd_count_lines(ix, __popcll(act_m & heads) + __popcll(sep_m & heads)); }
+#endif
+        {
+            const uint32_t sb = (uint32_t)__shfl((int)bke, f_src);
+            if (f_mine && ((act_m >> f_src) & 1) && (!(f_slot & 1) || ((sep_m >> f_src) & 1))) {
+                const uint4 *from = ix.blocks + (size_t)(sb + (uint32_t)(f_slot & 1)) * FMD_BLK_U4 + (lane & FMD_GRP_MASK);
+                __builtin_amdgcn_global_load_lds((fmd_glb_void *)from, (fmd_lds_void *)pool, 16, 0, FMD_GLDS_AUX);
+            }
+        }
+        fmd_fetch_wait();
+        M X, Y, Z;
+        W::window(img, o1, X, Y, Z);   // (words of a block that was not fetched lie past the range and are masked out)
+        // the base the strand goes on with: every read of the window that does not end here must show the same one
+        const M mw = W::below(szw);
+        const M any = (X | Y | Z) & mw, xa = X & any, ya = Y & any, za = Z & any;
+        const int cs = (xa ? 1 : 0) | (ya ? 2 : 0) | (za ? 4 : 0);
+        const bool bail = active && ((xa && xa != any) || (ya && ya != any) || (za && za != any) || cs > 4);   // a second base, or N
+        // absolute ranks at X1 - 1: of that base (children) and of '$' (x[1] of a neighbour)
+        uint64_t Rz;
+        const uint64_t Rc = fmd_block_rank1z(img, 0, o1, cs, bke, Rz);
+
+        // ---- this lane's candidate
+        const bool live = active && alive;
+        const uint32_t nc = W::popc(any & (W::below(sz) << d)), nS = sz - nc;   // reads that go on with cs / that end here
+        const bool is_nei = live && round > 0 && nc == 0 && D == W::below(sz);  // unitig.c:111-122
+        const M Dc = (D >> nS) & W::below(nc);                                   // reads that start with the child string (unitig.c:129)
+        const bool has_child = live && Dc != 0;
+        const uint32_t nei_g = (uint32_t)(__ballot(is_nei) >> gbase) & GM, dm_g = (uint32_t)(__ballot(has_child) >> gbase) & GM;
+        const int f = nei_g ? __ffs((int)nei_g) - 1 : 64;       // the first neighbour masks the rest of the (only) category
+        const bool alive2 = has_child && j < f;
+        const uint32_t child_g = (uint32_t)(__ballot(alive2) >> gbase) & GM;
+
+        if (active) {
+            if (bail) {
+                if (j == 0) { const uint32_t k = atomicAdd(gen_n, 1u); gen_list[2 * (size_t)k] = sid; gen_list[2 * (size_t)k + 1] = meta; atomicAdd(bail_n, 1u); }
+                active = false; alive = false;
+            } else {
+                const uint32_t ori_l = meta >> 16;
+                if (!(lf & 0x10000u)) lf = dm_g ? round + 1 : (FMD_LFORK_ALL | 0x10000u);   // check_left's rounds (FMD_LFORK_*)
+                if (nei_g) {
+                    if (n_nei == 0) nei0 = ori_l - (uint32_t)__shfl((int)pos, gbase + f);   // info of nei[0] decides rbeg (unitig.c:157)
+                    if (is_nei && j == f && n_nei < max_nei)
+                        store_entry(nei_out + sid * (size_t)max_nei + n_nei, r0, ix.cnt[0] + Rz + (d - W::popc(any & W::below(d))), sz, (uint64_t)(ori_l - pos));
+                    ++n_nei;
+                }
+                if (n_nei > max_nei) { // more neighbours than the caller has room for: the lane-per-strand kernel reports it
+                    if (j == 0) { const uint32_t k = atomicAdd(slow_n, 1u); slow_list[k] = sid; }
+                    active = false; alive = false;
+                } else if (child_g) { // next round (unitig.c:137-153)
+                    if (j == 0 && ori_l + round < seq_stride) seq_out[sid * (size_t)seq_stride + ori_l + round] = (uint8_t)(5 - cs);   // comp6, cs in 1..4
+                    ++round;
+                    const int wl = gbase + 31 - __clz((int)child_g);                 // the widest child
+                    const uint32_t before = W::popc(any & W::below(d));               // cs's of the window before my range
+                    const uint32_t wb = (uint32_t)__shfl((int)before, wl);
+                    szw = (uint32_t)__shfl((int)nc, wl);
+                    X1 = (cs == 1 ? ix.cnt[1] : cs == 2 ? ix.cnt[2] : cs == 3 ? ix.cnt[3] : ix.cnt[4]) + Rc + wb;
+                    r0 += W::popc(D & W::below(nS));
+                    D = Dc; sz = nc; d = alive2 ? before - wb : 0u; alive = alive2;
+                } else { // every path is closed (unitig.c:154-178); nothing forked, so no fix-up
+                    if (j == 0) {
+                        fmd_ovlp_rec_t *o = rec + sid;
+                        o->lfork = (uint16_t)(lf & 0xffffu);
+                        o->rbeg = n_nei ? (int)(ori_l - nei0) : -1;
+                        o->ext_len = n_nei > 1 ? 0 : (int)round;
+                        o->n_nei = (int32_t)n_nei;
+                    }
+                    active = false; alive = false;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the images are read before the next gather lands in the pool
+    }
+}
+
+static inline int grp_cap(int resident, int cap) { return cap > 0 && cap < resident ? cap : resident; }
+template <int G, typename M>
+static int fast_blocks_per_cu(void)
+{
+    static int cached = 0;
+    if (!cached) cached = fmd_resident_per_cu(k_ovl_nei_fast<G, M>, sizeof(uint4) * (FMD_BLK_PER_INST + 2) * FMD_BLK_U4, 32, "k_ovl_nei_fast");
+    return cached;
+}
+#endif
+int fmd_nei_fast_available(void) { return FMD_BLK64 ? 1 : 0; }
+void fmd_launch_nei_fast(int cls, int wide, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
+                         const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
+                         uint32_t seq_stride, uint32_t *gen_list, uint32_t *gen_n, uint32_t *bail_n, uint32_t *slow_list, uint32_t *slow_n)
+{
+#if FMD_BLK64
+    const char *e = getenv("FMD_FAST_WAVES"); // A/B knob: resident waves per CU
+    if (e && atoi(e) > 0 && (per_cu_cap <= 0 || atoi(e) < per_cu_cap)) per_cu_cap = atoi(e);
+#define FAST_LAUNCH(K, M) k_ovl_nei_fast<fmd_grp_size(K), M><<<n_cu * grp_cap(fast_blocks_per_cu<fmd_grp_size(K), M>(), per_cu_cap), 64, 0, st>>>(ix, list, list_n, cap, listA, rec, nei_out, max_nei, seq_out, seq_stride, gen_list, gen_n, bail_n, slow_list, slow_n)
+#define FAST_LAUNCH2(K) do { if (wide) FAST_LAUNCH(K, uint64_t); else FAST_LAUNCH(K, uint32_t); } while (0)
+    switch (cls) {
+    case 0: FAST_LAUNCH2(0); break;
+    case 1: FAST_LAUNCH2(1); break;
+    case 2: FAST_LAUNCH2(2); break;
+    case 3: FAST_LAUNCH2(3); break;
+    default: FAST_LAUNCH2(4); break;
+    }
+#undef FAST_LAUNCH2
+#undef FAST_LAUNCH
+#endif
+}
+
 // launcher used by fmd_ovlp.hip.  The strands of a work list are dealt to the groups round-robin, so
 // the grid must be exactly the resident set: a block that has to wait for a slot starts when the others
 // are done and then works alone through a full share (11 blocks per CU computed from 160 KiB / 14.25 KiB
@@ -353,7 +584,6 @@ static int grp_blocks_per_cu(void)
     }
     return cached;
 }
-static inline int grp_cap(int resident, int cap) { return cap > 0 && cap < resident ? cap : resident; }
 void fmd_launch_nei_grp(int cls, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                         const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
                         uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n)
@@ -368,7 +598,7 @@ void fmd_launch_nei_grp(int cls, int n_cu, int per_cu_cap, hipStream_t st, const
     }
 #undef GRP_LAUNCH
 }
-void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, const fmd_intv_t *listA, uint32_t cap, FmdOvlClasses cl)
+void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, const fmd_intv_t *listA, uint32_t cap, FmdOvlClasses cl, int use_fast)
 {
-    k_ovl_classify<<<(unsigned)((n + CLS_THREADS - 1) / CLS_THREADS), CLS_THREADS, 0, st>>>(n, rec, listA, cap, cl);
+    k_ovl_classify<<<(unsigned)((n + CLS_THREADS - 1) / CLS_THREADS), CLS_THREADS, 0, st>>>(n, rec, listA, cap, cl, use_fast);
 }

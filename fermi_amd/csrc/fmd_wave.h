@@ -326,6 +326,36 @@ __device__ __forceinline__ uint64_t fmd_block_rank1(const uint4 *blk, int t, uin
 #endif
 }
 
+// fmd_block_rank1 of symbol c AND of '$' from the same three chunk reads (the walk's window path and k_ovl_nei_fast want both).
+__device__ __forceinline__ uint64_t fmd_block_rank1z(const uint4 *blk, int t, uint32_t npos, int c, uint32_t blk_no, uint64_t &rz)
+{
+#if FMD_BLK64
+    const uint32_t x0 = (c & 1) ? 0u : ~0u, x1 = (c & 2) ? 0u : ~0u, x2 = (c & 4) ? 0u : ~0u;
+    uint32_t n = 0, nz = 0, lo = 0, hi = 0, m0 = 0, m1 = 0, m2 = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const uint4 v = blk[j ^ t];
+        const uint32_t m = fmd_mask32((int)npos - 32 * j);
+        n += __builtin_popcount((v.x ^ x0) & (v.y ^ x1) & (v.z ^ x2) & m);
+        nz += __builtin_popcount(~(v.x | v.y | v.z) & m);
+        if (j == 0) m0 = v.w; else if (j == 1) m1 = v.w; else m2 = v.w;
+    }
+    const uint4 mv = blk[3 ^ t];
+    rz = ((uint64_t)(mv.z & 0xff) << 32 | m0) + nz;
+    if (c < 5) {
+        lo = c == 0 ? m0 : c == 1 ? m1 : c == 2 ? m2 : c == 3 ? mv.x : mv.y;
+        hi = c < 4 ? (mv.z >> (8 * c)) & 0xff : mv.w & 0xff;
+        return ((uint64_t)hi << 32 | lo) + n;
+    }
+    const uint64_t five = ((uint64_t)(mv.z & 0xff) << 32 | m0) + ((uint64_t)((mv.z >> 8) & 0xff) << 32 | m1) +
+                          ((uint64_t)((mv.z >> 16) & 0xff) << 32 | m2) + ((uint64_t)(mv.z >> 24) << 32 | mv.x) + ((uint64_t)(mv.w & 0xff) << 32 | mv.y);
+    return (uint64_t)blk_no * FMD_BLK_SYMS - five + n;
+#else
+    rz = fmd_block_rank1(blk, t, npos, 0, blk_no);
+    return fmd_block_rank1(blk, t, npos, c, blk_no);
+#endif
+}
+
 // ---- work queue of the persistent kernels --------------------------------------------------------
 // Items are handed out by ONE device-wide counter.  A wave does not pay an atomic round trip (which
 // crosses the fabric: the counter is shared by all XCDs) every time a lane finishes: it holds a

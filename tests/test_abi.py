@@ -55,3 +55,24 @@ def test_product_does_not_reference_oracle():
                     if re.search(r"liboracle|orcbind|oracle/|fmd_oracle|libfermi_ref", txt):
                         bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_no_kernel_spills_to_scratch():
+    """Every gfx950 kernel of the built library keeps its registers: no VGPR spills, no private segment (tools/kernel_resources.py reads
+    the code-object metadata of build/*.o).  A spilling k_ovl_nei_fast returned wrong neighbours for a few strands in 10^7 when it ran
+    beside the walk on a second stream (round 2), and a spilling kernel is never at the occupancy its launch bound names."""
+    import glob, sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as kr
+    objs = sorted(glob.glob(os.path.join(ROOT, "build", "*.o")))
+    if not objs or not os.path.exists(kr.LLVM + "/clang-offload-bundler"):
+        pytest.skip("no build/*.o here (the library was built elsewhere) or no LLVM tools")
+    seen = 0
+    for o in objs:
+        for k in kr.kernels_of(o):
+            seen += 1
+            name = kr.demangle(k["name"])
+            assert int(k.get("vgpr_spill_count", 0)) == 0, (os.path.basename(o), name, k)
+            if "rocprim" not in name:   # (the library sort's kernels keep small private arrays; ours have none)
+                assert int(k.get("private_segment_fixed_size", 0)) == 0, (os.path.basename(o), name, k)
+    assert seen > 40

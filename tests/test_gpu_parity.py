@@ -825,6 +825,52 @@ def test_overlap_longer_reads_vs_oracle(gpu, oracle_lib, L, cov, mm, err):
     d.close(); o.close()
 
 
+def _same_overlap(a, b, max_nei):
+    rec0, nei0, seq0 = a; rec1, nei1, seq1 = b
+    assert rec1.tobytes() == rec0.tobytes()
+    for j in range(max_nei):
+        mj = rec0["n_nei"] > j
+        assert nei1[mj, j].tobytes() == nei0[mj, j].tobytes(), j
+    used = (rec0["len"] + np.maximum(rec0["ext_len"], 0)).astype(np.int64)
+    for i in np.where(rec0["status"] == 0)[0]:
+        assert np.array_equal(seq1[i, :used[i]], seq0[i, :used[i]]), i
+
+
+@pytest.mark.parametrize("L,cov,mm,err,N", [(100, 30, 50, 0.0, 20000), (100, 30, 50, 0.01, 20000), (100, 60, 40, 0.003, 8000), (151, 12, 31, 0.02, 6000)])
+def test_unforked_fast_path_equals_general_group_kernels(gpu, oracle_lib, monkeypatch, capfd, L, cov, mm, err, N):
+    """k_ovl_nei_fast (candidates in the narrow form, no x[0]-side fetch, one shared window per strand and round; hands a strand
+    on to k_ovl_nei_grp the moment its reads show a second base) against the general group kernels alone (FMD_OVLP_FAST=0) and the
+    oracle: records incl. lfork, neighbours, appended bases.  Also: the fast path really ran, and with errors in the reads really
+    handed strands on."""
+    import re
+    reads = synth.reads(synth.DEFAULT_SEED + 5 * L + cov, N, L, cov, err)
+    bwt = gpu.build_bwt(reads)
+    d = gpu.DevIndex.from_bwt(bwt)
+    ids = np.arange(2 * N, dtype=U64)
+    monkeypatch.setenv("FMD_OVLP_STATS", "1")
+    capfd.readouterr()
+    fast = d.overlap(ids, mm, L, 8, check_left=True)
+    msg = capfd.readouterr().err
+    monkeypatch.delenv("FMD_OVLP_STATS")
+    monkeypatch.setenv("FMD_OVLP_FAST", "0")
+    general = d.overlap(ids, mm, L, 8, check_left=True)
+    monkeypatch.delenv("FMD_OVLP_FAST")
+    _same_overlap(general, fast, 8)
+    took = [(int(a), int(b)) for a, b in re.findall(r"(\d+) to the unforked path \((\d+) of them handed on\)", msg)]
+    assert took and sum(a for a, _ in took) > N // 2, msg
+    if err > 0:
+        assert sum(b for _, b in took) > 0, msg
+    o = orcbind.OrcIndex(bwt=bwt)
+    sub = ids[:4000]
+    wrec, wnei, wseq = o.overlap_batch(sub, mm, L, 8, 4, check_left=True)
+    for f in ("rank", "k", "len", "status", "n_ovlp", "rbeg", "ext_len", "n_nei", "reserved"):   # (lfork: the oracle's is exact, the product's may say less)
+        assert np.array_equal(fast[0][f][:4000], wrec[f]), f
+    for j in range(8):
+        mj = wrec["n_nei"] > j
+        assert fast[1][:4000][mj, j].tobytes() == wnei[mj, j].tobytes(), j
+    d.close(); o.close()
+
+
 @pytest.mark.parametrize("pipe", ["3,9,7", "8,2,2", "5,16,16"])
 def test_overlap_pipelined_parts_equal_serial(gpu, oracle_lib, monkeypatch, pipe):
     """fmd_ovlp_dev cuts a large batch into parts and runs get_nei of one part on a second stream beside

@@ -1,14 +1,22 @@
 #!/bin/bash
-# Run on the GPU box: kernel trace of the overlap-discovery leg of bench.py alone; prints the kernel table.
-OUT=gpurun_out/trace_ovl
-mkdir -p $OUT
-export TMPDIR=/tmp
-export FMD_BENCH_SMEM=0 FMD_BENCH_KMER=0 FMD_BENCH_PROBE=0 FMD_BENCH_CPU_SAMPLE=20000 FMD_BENCH_CPU_SAMPLE_OVLP=20000
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python bench.py --steps 2 --warmup 1 > $OUT/bench_traced.json 2> $OUT/bench_traced.err
-python - <<'PY'
-import csv, glob
-f = glob.glob("gpurun_out/trace_ovl/trace/**/*kernel_stats.csv", recursive=True)[0]
-for r in list(csv.DictReader(open(f)))[:16]:
-    if "ovl" in r["Name"]:
-        print("%-50s calls %3s avg %.3f ms" % (r["Name"][:50], r["Calls"], float(r["AverageNs"]) / 1e6))
-PY
+# Kernel timeline of overlap discovery under one or more settings (tools/ab_overlap.py syntax), rocprofv3 --kernel-trace.
+# usage: tools/trace_overlap.sh OUTDIR N_READS ERR SETTING [SETTING...]
+out=$(realpath -m "$1"); n=$2; err=$3; shift 3
+root=$(cd "$(dirname "$0")/.." && pwd)
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp
+i=0
+for cfg in "$@"; do
+    i=$((i + 1))
+    d=/tmp/prof_ovl_$$_$i
+    rm -rf $d
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o p -- python $root/tools/ab_overlap.py $n $err 3 -- "$cfg" > $out/run_$i.txt 2>&1
+    echo "== $cfg" >> $out/summary.txt
+    grep "ms per pass" $out/run_$i.txt >> $out/summary.txt
+    st=$(find $d -name "*kernel_stats.csv" | head -1)
+    tr=$(find $d -name "*kernel_trace.csv" | head -1)
+    [ -n "$st" ] && cp "$st" $out/kernel_stats_$i.csv
+    [ -n "$tr" ] && python $root/tools/trace_tail.py "$tr" > $out/timeline_$i.txt
+    rm -rf $d
+done
+cat $out/summary.txt
