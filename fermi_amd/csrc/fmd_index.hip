@@ -167,7 +167,7 @@ __global__ void k_block_counts(const uint4 *__restrict__ blocks, uint64_t n_bloc
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t n[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int c = 0; c < FMD_BLK_CHUNKS; ++c) {
+        for (int c = 0; c < FMD_BLK_OWN_CHUNKS; ++c) {   // (overlapped blocks: the look-ahead chunk belongs to the next block's count)
             const uint4 v = blocks[b * FMD_BLK_U4 + c];
             n[0] += __builtin_popcount(~v.z & ~v.y & ~v.x); n[1] += __builtin_popcount(~v.z & ~v.y & v.x);
             n[2] += __builtin_popcount(~v.z & v.y & ~v.x);  n[3] += __builtin_popcount(~v.z & v.y & v.x);
@@ -177,6 +177,19 @@ __global__ void k_block_counts(const uint4 *__restrict__ blocks, uint64_t n_bloc
         for (int s = 0; s < 6; ++s) bc[(uint64_t)s * n_blocks + b] = (fmd_bc_t)n[s];
     }
 }
+#if FMD_BLK_OVERLAP
+// overlapped blocks: the planes of the first chunk of block b + 1 repeated as the third chunk of block b (the transcoders write
+// every 32-position word once, into the block that owns it)
+__global__ void k_fill_lookahead(uint4 *__restrict__ blocks, uint64_t n_blocks)
+{
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += (uint64_t)gridDim.x * blockDim.x) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (b + 1 < n_blocks) v = blocks[(b + 1) * FMD_BLK_U4];
+        uint4 *dst = blocks + b * FMD_BLK_U4 + FMD_BLK_OWN_CHUNKS;
+        dst->x = v.x; dst->y = v.y; dst->z = v.z;
+    }
+}
+#endif
 // the count of symbol s before each block into its place in the block's meta words (fmd_wave.h)
 __global__ void k_write_meta_sym(uint4 *__restrict__ blocks, uint64_t n_blocks, const uint64_t *__restrict__ acc, int s)
 {
@@ -291,7 +304,7 @@ static int dev_alloc_index(int device, uint64_t n_sym, fmd_dev **out)
     int ndev = fmd_device_count();
     if (ndev <= 0 || device < 0 || device >= ndev) return FMD_E_NODEV;
     if (n_sym == 0 || n_sym >= (1ull << 40)) return FMD_E_ARG; // 40-bit absolute counts
-    if ((n_sym + FMD_BLK_SYMS - 1) / FMD_BLK_SYMS + 1 >= 0xffffffffull) return FMD_E_ARG; // 32-bit block numbers
+    if ((n_sym + FMD_BLK_STRIDE - 1) / FMD_BLK_STRIDE + 1 >= 0xffffffffull) return FMD_E_ARG; // 32-bit block numbers
     FMD_HIP_TRY(hipSetDevice(device));
     fmd_dev *h = (fmd_dev *)calloc(1, sizeof(fmd_dev));
     if (!h) return FMD_E_NOMEM;
@@ -299,7 +312,7 @@ static int dev_alloc_index(int device, uint64_t n_sym, fmd_dev **out)
     FMD_HIP_TRY(hipGetDeviceProperties(&prop, device));
     h->device = device;
     h->n_cu = prop.multiProcessorCount;
-    h->n_blocks = (n_sym + FMD_BLK_SYMS - 1) / FMD_BLK_SYMS + 1; // +1 pad block
+    h->n_blocks = (n_sym + FMD_BLK_STRIDE - 1) / FMD_BLK_STRIDE + 1; // +1 pad block
     h->bytes = h->n_blocks * FMD_BLK_BYTES;
     hipError_t e = hipMalloc((void **)&h->blocks, h->bytes);
     if (e != hipSuccess) { fmd_set_hip_error(e, "hipMalloc(index)"); free(h); return FMD_E_NOMEM; }
@@ -322,6 +335,9 @@ static int finish_index(fmd_dev *h)
     FMD_HIP_TRY(hipMalloc((void **)&bc, 6 * nb * sizeof(fmd_bc_t)));
     hipError_t e = hipMalloc((void **)&acc, nb * 8);
     if (e != hipSuccess) { hipFree(bc); fmd_set_hip_error(e, "hipMalloc(scan)"); return FMD_E_NOMEM; }
+#if FMD_BLK_OVERLAP
+    k_fill_lookahead<<<nblk(nb, 256), 256>>>(h->blocks, nb);
+#endif
     k_block_counts<<<nblk(nb, 256), 256>>>(h->blocks, nb, bc);
     int rc = FMD_OK;
     uint64_t last[6] = {0, 0, 0, 0, 0, 0};
@@ -334,7 +350,7 @@ static int finish_index(fmd_dev *h)
     }
     if (rc == FMD_OK) {
         // positions past the end are '$'-coded zeros: correct mcnt[1] for them
-        const uint64_t pad = (nb - 1) * FMD_BLK_SYMS - h->mcnt[0];
+        const uint64_t pad = (nb - 1) * FMD_BLK_STRIDE - h->mcnt[0];
         last[0] -= pad;
         h->mcnt[1] = last[0];
         for (int s = 1; s < 6; ++s) h->mcnt[s + 1] = last[s];

@@ -79,12 +79,22 @@ __device__ __forceinline__ void grp_window(const uint4 *img_k, int t_k, const ui
                                            bool has_k, bool has_l, uint32_t blk_p, uint32_t off_p, uint4 &a, uint4 &b, uint4 &c)
 {
     uint32_t blk = blk_p, ch = (off_p + 1) >> 5;
+#if FMD_BLK_OVERLAP
+    // 32-position words counted from the start of block blk_p: words 0..2 are its chunks, word q >= 3 is chunk q - 2 of the next block
+    if (ch >= FMD_BLK_CHUNKS) { ch -= FMD_BLK_OWN_CHUNKS; ++blk; }
+    a = grp_pick(img_k, t_k, img_l, t_l, blk_k, blk_l, has_k, has_l, blk, ch);
+    if (++ch == FMD_BLK_CHUNKS) { ch = FMD_BLK_CHUNKS - FMD_BLK_OWN_CHUNKS; ++blk; }
+    b = grp_pick(img_k, t_k, img_l, t_l, blk_k, blk_l, has_k, has_l, blk, ch);
+    if (++ch == FMD_BLK_CHUNKS) { ch = FMD_BLK_CHUNKS - FMD_BLK_OWN_CHUNKS; ++blk; }
+    c = grp_pick(img_k, t_k, img_l, t_l, blk_k, blk_l, has_k, has_l, blk, ch);
+#else
     if (off_p + 1 == FMD_BLK_SYMS) { ++blk; ch = 0; }
     a = grp_pick(img_k, t_k, img_l, t_l, blk_k, blk_l, has_k, has_l, blk, ch);
     if (++ch == FMD_BLK_CHUNKS) { ch = 0; ++blk; }
     b = grp_pick(img_k, t_k, img_l, t_l, blk_k, blk_l, has_k, has_l, blk, ch);
     if (++ch == FMD_BLK_CHUNKS) { ch = 0; ++blk; }
     c = grp_pick(img_k, t_k, img_l, t_l, blk_k, blk_l, has_k, has_l, blk, ch);
+#endif
 }
 __device__ __forceinline__ uint64_t win64(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t sh)
 {
@@ -105,6 +115,12 @@ __device__ __forceinline__ uint64_t range64(uint32_t a, uint32_t b) // bits [a, 
 __device__ __host__ __forceinline__ constexpr int fmd_grp_size(int k) { return k == 0 ? 8 : k == 1 ? 12 : k == 2 ? 16 : k == 3 ? 21 : 32; }
 #define FMD_CLS_CNT_STRIDE 32              // counters sit on separate 128-byte lines
 #define FMD_CLS_HEADER_U32 512             // the counter area in front of the lists
+// hand-over from k_ovl_nei_fast to k_ovl_nei_grp: list slots reserved FMD_FAST_CHUNK at a time, unused ones stay holes
+#define FMD_FAST_CHUNK 16
+#define FMD_FAST_MAX_WAVES 8192
+#define FMD_LIST_HOLE 0xffffffffu
+#define FMD_FAST_RESERVE (2 * FMD_FAST_MAX_WAVES * FMD_FAST_CHUNK)   // entries a general list may lose to holes (two fast kernels feed it)
+#define FMD_CLS_PART_U32 (FMD_CLS_HEADER_U32 + 2 * FMD_GRP_CLASSES * FMD_FAST_RESERVE)   // per part of a pipelined batch: counters + that room
 #define FMD_CLS_LISTS (3 * FMD_GRP_CLASSES + 1)                 // general lists, the slow list, fast lists (32-bit masks, 64-bit masks)
 #define FMD_CLS_WORDS_PER_STRAND (6 * FMD_GRP_CLASSES + 1)      // two words per entry of a group list, one for the slow list
 struct FmdOvlClasses {

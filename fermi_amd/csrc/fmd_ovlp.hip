@@ -174,6 +174,13 @@ __global__ __launch_bounds__(64) void k_ovl_intv(FmdIndexView ix, size_t n, int 
 // extension needs; when it is '$' the same ranks are fm6_is_contained's left test (unitig.c:83-85).
 // Candidates are pushed with info = depth (their start is len - depth, known only at the end).
 enum { WK_IDLE = 0, WK_LF, WK_EXT, WK_BOTH, WK_RIGHT };
+// can the LF step at row k be read from a block the backward extension of [x0, x0 + sz) brings in anyway (the block of x0 - 1, or
+// the block of its other end when that one does not reach it)?
+__device__ __forceinline__ bool walk_lf_shares(uint64_t k, uint64_t x0, uint64_t sz)
+{
+    uint32_t o;
+    return fmd_in_block(k, fmd_blk_of(x0 - 1), o) || fmd_in_block(k, fmd_blk_of(x0 - 1 + sz), o);
+}
 
 // every 4th base: the word moves into its place of the 16-byte group; every 16th: one store
 #define WALK_STASH_WORD()                                                                                  \
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
         if (r.two_phase) {
             if (wide_ext && r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk2, r.blk_k);
             if (st == WK_RIGHT && r.hk) tk2[0] = fmd_block_rank1(r.bk, r.t, r.nk, 0, r.blk_k);
-            skip = st == WK_BOTH && (sz <= 63 || fmd_blk_of(k) != r.blk_k) && r.l_sep;
+            { uint32_t ko_; skip = st == WK_BOTH && (sz <= 63 || !fmd_in_block(k, r.blk_k, ko_)) && r.l_sep; }
             if (st == WK_BOTH && sz > 63 && !skip) skip = true; // wide WK_BOTH never shares a gather in two-phase steps
             if (skip && st == WK_BOTH) st = WK_LF;   // take the LF step on its own next time, then the extension through the
                                                      // general path (a lane that merely waited could wait forever: the same
@@ -264,9 +271,9 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             const uint64_t Mc = sel6(c, M0, M1, M2, M3, M4, M5);
             k = ix.cnt[c] + wtk + __popcll(Mc & bits_below((int)o + 1)) - 1;
         } else if (st == WK_LF || st == WK_BOTH) { // LF step at row k: base = BWT[k], k' = cnt[c] + rank_c(k) - 1
-            uint32_t kb_, off;
-            fmd_split(k, kb_, off);
-            const bool in_k = st == WK_LF || kb_ == r.blk_k;
+            uint32_t kb_ = r.blk_k, off;
+            const bool in_k = fmd_in_block(k, r.blk_k, off);     // (WK_LF: the block asked for; WK_BOTH: one of the extension's two)
+            if (!in_k) { kb_ = r.blk_l; fmd_in_block(k, r.blk_l, off); }
             const uint4 *img = in_k ? r.bk : r.bl;
             const int tt = in_k ? r.t : r.tl;
             const uint4 v = img[(int)(off >> 5) ^ tt];
@@ -289,8 +296,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
                     sz = ((uint64_t)ef.w << 32 | ef.z) - x0 + 1;   // never empty: the sequence is in the index
                     x1 = (uint64_t)er.y << 32 | er.x;
                     tab = false;
-                    const uint32_t bk_ = fmd_blk_of(x0 - 1), bl_ = fmd_blk_of(x0 - 1 + sz), bq = fmd_blk_of(k);
-                    st = (bq == bk_ || bq == bl_) ? WK_BOTH : WK_LF;
+                    st = walk_lf_shares(k, x0, sz) ? WK_BOTH : WK_LF;
                 }
                 continue;
             }
@@ -376,8 +382,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
         }
         // next base: can the LF step share the extension's gather?
         {
-            const uint32_t bk_ = fmd_blk_of(x0 - 1), bl_ = fmd_blk_of(x0 - 1 + sz), bq = fmd_blk_of(k);
-            st = (bq == bk_ || bq == bl_) ? WK_BOTH : WK_LF;
+            st = walk_lf_shares(k, x0, sz) ? WK_BOTH : WK_LF;
             if (tab) st = WK_LF;   // inside the prefix table there is no extension to share a gather with
         }
     }
@@ -790,7 +795,7 @@ extern "C" size_t fmd_ovlp_work_bytes(size_t n, uint32_t max_len, int min_match)
     const size_t stride_r = align_up((size_t)max_len, 16);
     const size_t cap = fmd_ovlp_list_cap(max_len, min_match);
     return align_up(n * stride_r, 256) + 2 * align_up(n * cap * sizeof(fmd_intv_t), 256) +
-           align_up(n * (4 * FMD_CLS_WORDS_PER_STRAND) + 4 * FMD_CLS_HEADER_U32 * FMD_OVLP_MAX_PARTS, 256) + 256;
+           align_up(n * (4 * FMD_CLS_WORDS_PER_STRAND) + 4 * (size_t)FMD_CLS_PART_U32 * FMD_OVLP_MAX_PARTS, 256) + 256;
 }
 
 // The buffers of one fmd_ovlp_dev call; the two phases below work on the strands [b, b + np) of it.
@@ -836,11 +841,12 @@ static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, i
         return FMD_OK;
     }
     // work lists: the counter header, then one list per group class (2 words per strand), the slow list (1), one list per fast class (2)
-    uint32_t *cls = o.cls + (size_t)part * FMD_CLS_HEADER_U32 + b * FMD_CLS_WORDS_PER_STRAND;
+    // (a general list has room for every strand of the part + the holes the fast kernels' chunked hand-over may leave)
+    uint32_t *cls = o.cls + (size_t)part * FMD_CLS_PART_U32 + b * FMD_CLS_WORDS_PER_STRAND;
     FmdOvlClasses cl;
     cl.cnt = cls;
-    for (int k = 0; k < FMD_GRP_CLASSES; ++k) cl.lst[k] = cls + FMD_CLS_HEADER_U32 + 2 * np * k;
-    cl.lslow = cls + FMD_CLS_HEADER_U32 + 2 * np * FMD_GRP_CLASSES;
+    for (int k = 0; k < FMD_GRP_CLASSES; ++k) cl.lst[k] = cls + FMD_CLS_HEADER_U32 + (2 * np + 2 * (size_t)FMD_FAST_RESERVE) * k;
+    cl.lslow = cls + FMD_CLS_HEADER_U32 + (2 * np + 2 * (size_t)FMD_FAST_RESERVE) * FMD_GRP_CLASSES;
     for (int k = 0; k < 2 * FMD_GRP_CLASSES; ++k) cl.fast[k] = cl.lslow + np + 2 * np * k;
     uint32_t *n_slow = cl.cnt + FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE;
     FMD_HIP_TRY(hipMemsetAsync(cls, 0, 4 * FMD_CLS_HEADER_U32, st));
@@ -869,7 +875,7 @@ static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, i
         uint32_t nf = 0, nb = 0, ng = 0;
         for (int k = 0; k < 2 * FMD_GRP_CLASSES; ++k) { nf += hs[(FMD_GRP_CLASSES + 1 + k) * FMD_CLS_CNT_STRIDE]; nb += hs[(FMD_GRP_CLASSES + 1 + k) * FMD_CLS_CNT_STRIDE + 8]; }
         for (int k = 0; k < FMD_GRP_CLASSES; ++k) ng += hs[k * FMD_CLS_CNT_STRIDE];
-        fprintf(stderr, "[M::fmd_ovlp] part of %zu strands: %u to the unforked path (%u of them handed on), %u through the general group kernels, %u through the lane-per-strand kernel\n",
+        fprintf(stderr, "[M::fmd_ovlp] part of %zu strands: %u to the unforked path (%u of them handed on), %u slots of the general group kernels' lists (holes of the hand-over included), %u through the lane-per-strand kernel\n",
                 np, nf, nb, ng, hs[FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE]);
     }
 #ifdef GRP_STATS
@@ -880,20 +886,26 @@ static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, i
         const uint32_t *g = hs + FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE + 8;
         fprintf(stderr, "[grp stats] classes %u %u %u %u %u slow %u | wave rounds %u, live lanes %u (%.1f %%), lanes of groups holding a strand %u (%.1f %%)\n",
                 hs[0], hs[32], hs[64], hs[96], hs[128], hs[160], g[0], g[1], 100.0 * g[1] / (64.0 * g[0]), g[2], 100.0 * g[2] / (64.0 * g[0]));
+        for (int k = 0; k < 2 * FMD_GRP_CLASSES; ++k) {
+            const uint32_t *f = hs + (FMD_GRP_CLASSES + 1 + k) * FMD_CLS_CNT_STRIDE;
+            if (f[0]) fprintf(stderr, "[fast stats] G=%d %s: %u strands, %u handed on (%u) | wave rounds %u (%u with a second base), live lanes %.1f %%, lanes of groups holding a strand %.1f %%\n",
+                              fmd_grp_size(k % FMD_GRP_CLASSES), k >= FMD_GRP_CLASSES ? "64-bit" : "32-bit", f[0], f[8], f[9], f[10], f[13], 100.0 * f[11] / (64.0 * f[10]), 100.0 * f[12] / (64.0 * f[10]));
+        }
     }
 #endif
     return FMD_OK;
 }
 
-// Pipelined batches.  Phase A is bound by the memory system's request rate and leaves the VALUs idle;
-// phase B waits on dependent gathers with few requests in flight.  A large batch is cut into parts and
-// phase B of part p runs on a second stream beside phase A of part p+1, each with a share of the
-// CU's wave slots (LDS: 6 x 8.75 KiB + 10 x 10 KiB <= 160 KiB; get_nei needs the waves, the walk
-// still issues 85 % of its requests with 6).  FMD_OVLP_PIPE="parts,walk_per_cu,
-// grp_per_cu" overrides the split; parts = 1 is the serial order.
+// Pipelined batches (FMD_OVLP_PIPE="parts,walk_per_cu,grp_per_cu,fast_per_cu"; not the default any more).  A batch can be cut
+// into parts with phase B of part p on a second stream beside phase A of part p+1, each with a share of the CU's wave slots.  That
+// paid while get_nei was the general group kernel alone (92 ms of serial work in 82 on error-free reads).  With the unforked fast
+// path phase B is a quarter of a part and bound by instruction issue, the walk wants every wave slot it can get (it runs at the
+// memory system's rate of random lines), and the two side by side finish no sooner than one after the other -- 71 against 75 ms on
+// error-free reads with "4,8,8,8", 147 against 117 ms on reads with 1 % errors, whose long get_nei phase then starves the walk
+// (profiles/r2_ab/ab_fast_pipe.txt).  Default: the serial order.
 static void ovl_pipe_config(size_t n, int &parts, int &walk_cu, int &grp_cu, int &fast_cu)
 {
-    parts = n >= (1u << 21) ? 4 : 1; walk_cu = 6; grp_cu = 10; fast_cu = 0;
+    parts = 1; walk_cu = 8; grp_cu = 8; fast_cu = 8;
     const char *e = getenv("FMD_OVLP_PIPE");
     if (e) {
         int a = 0, b = 0, c = 0, d = 0;

@@ -134,6 +134,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
             pf = 0; idx += n_groups;
         }
         // ---- prefetch pipeline (loads complete under the rank gather below)
+        if (pf == 1 && d_sid == FMD_LIST_HOLE) { pf = 0; idx += n_groups; }   // an unused slot of a chunk the fast kernel reserved
         if (pf == 1) { // descriptor has arrived: fetch this lane's candidate
             const uint32_t m = d_meta & 0xffff;
             if ((uint32_t)j < m) { const uint4 *q = (const uint4 *)(listA + d_sid * (size_t)cap + (cap - m) + j); pa = q[0]; pb = q[1]; }
@@ -357,6 +358,15 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
 // a candidate in the wide form) it is appended to the general list of its class and k_ovl_nei_grp starts it over: nothing the fast
 // path wrote for it survives (records are written at the close only; neighbours and appended bases are rewritten).
 #if FMD_BLK64
+// uint4 index, in the two block images side by side (4 uint4 each), of the q-th 32-position word counted from the start of the first
+__device__ __forceinline__ uint32_t fast_word(uint32_t q)
+{
+#if FMD_BLK_OVERLAP
+    return q < 3 ? q : q + 2;          // words 3, 4 = chunks 1, 2 of the next block (word 2 is in both)
+#else
+    return q < 3 ? q : q + 1;          // words 3.. = chunks 0.. of the next block
+#endif
+}
 template <typename M> struct FastW;
 template <> struct FastW<uint32_t> {
     static constexpr uint32_t MAXW = 31;
@@ -367,7 +377,7 @@ template <> struct FastW<uint32_t> {
     static __device__ __forceinline__ void window(const uint4 *img, uint32_t o1, uint32_t &X, uint32_t &Y, uint32_t &Z)
     {
         const uint32_t q = o1 >> 5, sh = o1 & 31;
-        const uint4 a = img[q + (q >= 3)], b = img[q + 1 + (q >= 2)];
+        const uint4 a = img[fast_word(q)], b = img[fast_word(q + 1)];
         X = __builtin_amdgcn_alignbit(b.x, a.x, sh); Y = __builtin_amdgcn_alignbit(b.y, a.y, sh); Z = __builtin_amdgcn_alignbit(b.z, a.z, sh);
     }
 };
@@ -379,7 +389,7 @@ template <> struct FastW<uint64_t> {
     static __device__ __forceinline__ void window(const uint4 *img, uint32_t o1, uint64_t &X, uint64_t &Y, uint64_t &Z)
     {
         const uint32_t q = o1 >> 5, sh = o1 & 31;
-        const uint4 a = img[q + (q >= 3)], b = img[q + 1 + (q >= 2)], c = img[q + 2 + (q >= 1)];
+        const uint4 a = img[fast_word(q)], b = img[fast_word(q + 1)], c = img[fast_word(q + 2)];
         X = win64(a.x, b.x, c.x, sh); Y = win64(a.y, b.y, c.y, sh); Z = win64(a.z, b.z, c.z, sh);
     }
 };
@@ -419,8 +429,35 @@ __global__ __launch_bounds__(64, 5) void k_ovl_nei_fast(FmdIndexView ix, const u
     int pf = 0;
     uint32_t d_sid = 0, d_meta = 0;
     uint4 pa = make_uint4(0, 0, 0, 0), pb = make_uint4(0, 0, 0, 0);
+    // Strands handed on to the general kernel go to slots of its list that the wave reserves FMD_FAST_CHUNK at a time (one atomic on
+    // the list counter per chunk; one per strand serialises: 5*10^6 atomics on one address cost 45 ms on reads with 1 % errors);
+    // a chunk is filled with hole markers when it is reserved, k_ovl_nei_grp skips what stays a hole.
+    uint32_t res_cur = 0, res_end = 0, n_handed = 0;              // wave-uniform
+    bool hand_on = false;                                         // this group's strand leaves for the general kernel (set at j == 0 too)
 
     for (;;) {
+        {   // ---- hand-overs of the previous step / of the admission below
+            const uint64_t hm = __ballot(hand_on && j == 0);
+            if (hm) {
+                const uint32_t n = (uint32_t)__popcll(hm);
+                if (res_end - res_cur < n) {                      // a new chunk (what is left of the old one stays holes)
+                    uint32_t base = 0;
+                    if (lane == 0) { base = atomicAdd(gen_n, (uint32_t)FMD_FAST_CHUNK); atomicAdd(bail_n, n_handed); }   // (the count: diagnostics, FMD_OVLP_STATS)
+                    n_handed = 0;
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (lane < FMD_FAST_CHUNK) { gen_list[2 * (size_t)(base + lane)] = FMD_LIST_HOLE; gen_list[2 * (size_t)(base + lane) + 1] = 0; }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the markers land before the entries that replace them
+                    res_cur = base; res_end = base + FMD_FAST_CHUNK;
+                }
+                if (hand_on && j == 0) {
+                    const uint32_t k = res_cur + (uint32_t)fmd_below(hm);
+                    gen_list[2 * (size_t)k] = sid; gen_list[2 * (size_t)k + 1] = meta;
+                }
+                n_handed += n;
+                res_cur += n;
+                hand_on = false;
+            }
+        }
         // ---- admission
         if (!active && pf == 2) {
             const uint32_t m = d_meta & 0xffff;
@@ -435,10 +472,8 @@ __global__ __launch_bounds__(64, 5) void k_ovl_nei_fast(FmdIndexView ix, const u
             d = (uint32_t)(cd.x1 - X1);
             // every candidate in the narrow form and inside the widest one's range (nesting: see above)
             const bool bad = alive && (!cd.narrow || cd.x1 < X1 || cd.x1 - X1 + cd.sz > szw || szw > W::MAXW || cd.sz == 0);
-            if ((uint32_t)(__ballot(bad) >> gbase) & GM) {
-                if (j == 0) { const uint32_t k = atomicAdd(gen_n, 1u); gen_list[2 * (size_t)k] = sid; gen_list[2 * (size_t)k + 1] = meta; atomicAdd(bail_n, 1u); }
-                alive = false;
-            } else active = true;
+            if ((uint32_t)(__ballot(bad) >> gbase) & GM) { hand_on = true; alive = false; }   // (sid and meta stay until the hand-over above)
+            else active = true;
             pf = 0; idx += n_groups;
         }
         // ---- prefetch pipeline (loads complete under the window gather below)
@@ -452,11 +487,14 @@ __global__ __launch_bounds__(64, 5) void k_ovl_nei_fast(FmdIndexView ix, const u
         }
         const uint64_t act_m = __ballot(active);
         if (act_m == 0) {
-            if (__ballot(pf != 0 || idx < N) == 0) break;
+            if (__ballot(pf != 0 || idx < N || hand_on) == 0) { if (lane == 0 && n_handed) atomicAdd(bail_n, n_handed); break; }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             continue;
         }
 
+#ifdef GRP_STATS
+        { const uint32_t nl = (uint32_t)__popcll(__ballot(active && alive)); if (lane == 0) { atomicAdd(bail_n + 2, 1u); atomicAdd(bail_n + 3, nl); atomicAdd(bail_n + 4, (uint32_t)__popcll(act_m)); } }
+#endif
         // ---- the window of every resident strand: BWT[X1, X1 + szw), its block(s) into pool slots 2g (2g + 1)
         uint32_t bke, oke;
         fmd_split(X1 - 1, bke, oke);                              // x[1] >= cnt[1] > 0 for base strings
@@ -475,20 +513,50 @@ __global__ __launch_bounds__(64, 5) void k_ovl_nei_fast(FmdIndexView ix, const u
         fmd_fetch_wait();
         M X, Y, Z;
         W::window(img, o1, X, Y, Z);   // (words of a block that was not fetched lie past the range and are masked out)
-        // the base the strand goes on with: every read of the window that does not end here must show the same one
-        const M mw = W::below(szw);
+        // The base the strand goes on with.  Usually every read of the window that does not end here shows the same one; reads that
+        // show another (sequencing errors, repeats) matter only if one of them STARTS inside a candidate (a surviving child,
+        // unitig.c:126-134): the wave takes the longer way below only in steps where some strand sees a second base at all.
+        const bool live = active && alive;
+        const M mw = W::below(szw), mine = W::below(sz) << d;
         const M any = (X | Y | Z) & mw, xa = X & any, ya = Y & any, za = Z & any;
-        const int cs = (xa ? 1 : 0) | (ya ? 2 : 0) | (za ? 4 : 0);
-        const bool bail = active && ((xa && xa != any) || (ya && ya != any) || (za && za != any) || cs > 4);   // a second base, or N
+        int cs = (xa ? 1 : 0) | (ya ? 2 : 0) | (za ? 4 : 0);
+        M Cw = any;                                               // the positions of cs in the window
+        uint32_t nc = W::popc(any & mine), coff = sz - nc;        // reads of my range that go on with cs; children before it in x[0] order
+        const uint32_t nS = W::popc(~(X | Y | Z) & mw & mine);   // reads of my range that end here
+        bool bail = false;
+        if (__ballot(active && ((xa && xa != any) || (ya && ya != any) || (za && za != any) || cs > 4))) {
+#ifdef GRP_STATS
+            if (lane == 0) atomicAdd(bail_n + 5, 1u);
+#endif
+            // per base: how many reads of my range show it (order of the x[0] side: $ T G C A N), and does one start with it?
+            const M m1 = X & ~Y & ~Z & mw, m2 = ~X & Y & ~Z & mw, m3 = X & Y & ~Z & mw, m4 = ~X & ~Y & Z & mw, m5 = X & ~Y & Z & mw;
+            const uint32_t s1 = W::popc(m1 & mine), s2 = W::popc(m2 & mine), s3 = W::popc(m3 & mine), s4 = W::popc(m4 & mine), s5 = W::popc(m5 & mine);
+            const uint32_t o4 = nS, o3 = o4 + s4, o2 = o3 + s3, o1_ = o2 + s2, o5 = o1_ + s1;
+            uint32_t cm = 0;
+            if (live) {
+                if ((D >> o1_) & W::below(s1)) cm |= 2u;
+                if ((D >> o2) & W::below(s2)) cm |= 4u;
+                if ((D >> o3) & W::below(s3)) cm |= 8u;
+                if ((D >> o4) & W::below(s4)) cm |= 16u;
+                if ((D >> o5) & W::below(s5)) cm |= 32u;
+            }
+            uint32_t u = 0;
+#pragma unroll
+            for (int c = 1; c <= 5; ++c) if ((uint32_t)(__ballot((cm >> c) & 1) >> gbase) & GM) u |= 1u << c;
+            bail = active && (__popc(u) >= 2 || (u & 32u));     // a fork (or an N to follow): the general kernel's business
+            cs = u ? __ffs((int)u) - 1 : 0;
+            if (cs > 4) cs = 0;
+            Cw = cs == 1 ? m1 : cs == 2 ? m2 : cs == 3 ? m3 : cs == 4 ? m4 : (M)0;
+            nc = cs == 1 ? s1 : cs == 2 ? s2 : cs == 3 ? s3 : cs == 4 ? s4 : 0u;
+            coff = cs == 1 ? o1_ : cs == 2 ? o2 : cs == 3 ? o3 : o4;
+        }
         // absolute ranks at X1 - 1: of that base (children) and of '$' (x[1] of a neighbour)
         uint64_t Rz;
         const uint64_t Rc = fmd_block_rank1z(img, 0, o1, cs, bke, Rz);
 
         // ---- this lane's candidate
-        const bool live = active && alive;
-        const uint32_t nc = W::popc(any & (W::below(sz) << d)), nS = sz - nc;   // reads that go on with cs / that end here
-        const bool is_nei = live && round > 0 && nc == 0 && D == W::below(sz);  // unitig.c:111-122
-        const M Dc = (D >> nS) & W::below(nc);                                   // reads that start with the child string (unitig.c:129)
+        const bool is_nei = live && round > 0 && nS == sz && D == W::below(sz);   // unitig.c:111-122
+        const M Dc = (D >> coff) & W::below(nc);                                   // reads that start with the child string (unitig.c:129)
         const bool has_child = live && Dc != 0;
         const uint32_t nei_g = (uint32_t)(__ballot(is_nei) >> gbase) & GM, dm_g = (uint32_t)(__ballot(has_child) >> gbase) & GM;
         const int f = nei_g ? __ffs((int)nei_g) - 1 : 64;       // the first neighbour masks the rest of the (only) category
@@ -496,16 +564,14 @@ __global__ __launch_bounds__(64, 5) void k_ovl_nei_fast(FmdIndexView ix, const u
         const uint32_t child_g = (uint32_t)(__ballot(alive2) >> gbase) & GM;
 
         if (active) {
-            if (bail) {
-                if (j == 0) { const uint32_t k = atomicAdd(gen_n, 1u); gen_list[2 * (size_t)k] = sid; gen_list[2 * (size_t)k + 1] = meta; atomicAdd(bail_n, 1u); }
-                active = false; alive = false;
-            } else {
+            if (bail) { hand_on = true; active = false; alive = false; }
+            else {
                 const uint32_t ori_l = meta >> 16;
                 if (!(lf & 0x10000u)) lf = dm_g ? round + 1 : (FMD_LFORK_ALL | 0x10000u);   // check_left's rounds (FMD_LFORK_*)
                 if (nei_g) {
                     if (n_nei == 0) nei0 = ori_l - (uint32_t)__shfl((int)pos, gbase + f);   // info of nei[0] decides rbeg (unitig.c:157)
                     if (is_nei && j == f && n_nei < max_nei)
-                        store_entry(nei_out + sid * (size_t)max_nei + n_nei, r0, ix.cnt[0] + Rz + (d - W::popc(any & W::below(d))), sz, (uint64_t)(ori_l - pos));
+                        store_entry(nei_out + sid * (size_t)max_nei + n_nei, r0, ix.cnt[0] + Rz + W::popc(~(X | Y | Z) & W::below(d)), sz, (uint64_t)(ori_l - pos));
                     ++n_nei;
                 }
                 if (n_nei > max_nei) { // more neighbours than the caller has room for: the lane-per-strand kernel reports it
@@ -515,11 +581,11 @@ __global__ __launch_bounds__(64, 5) void k_ovl_nei_fast(FmdIndexView ix, const u
                     if (j == 0 && ori_l + round < seq_stride) seq_out[sid * (size_t)seq_stride + ori_l + round] = (uint8_t)(5 - cs);   // comp6, cs in 1..4
                     ++round;
                     const int wl = gbase + 31 - __clz((int)child_g);                 // the widest child
-                    const uint32_t before = W::popc(any & W::below(d));               // cs's of the window before my range
+                    const uint32_t before = W::popc(Cw & W::below(d));                // cs's of the window before my range
                     const uint32_t wb = (uint32_t)__shfl((int)before, wl);
                     szw = (uint32_t)__shfl((int)nc, wl);
                     X1 = (cs == 1 ? ix.cnt[1] : cs == 2 ? ix.cnt[2] : cs == 3 ? ix.cnt[3] : ix.cnt[4]) + Rc + wb;
-                    r0 += W::popc(D & W::below(nS));
+                    r0 += W::popc(D & W::below(coff));
                     D = Dc; sz = nc; d = alive2 ? before - wb : 0u; alive = alive2;
                 } else { // every path is closed (unitig.c:154-178); nothing forked, so no fix-up
                     if (j == 0) {
@@ -547,6 +613,7 @@ static int fast_blocks_per_cu(void)
 }
 #endif
 int fmd_nei_fast_available(void) { return FMD_BLK64 ? 1 : 0; }
+static inline int fast_grid(int waves) { return waves < FMD_FAST_MAX_WAVES ? waves : FMD_FAST_MAX_WAVES; }   // (the hand-over lists have room for this many waves' holes)
 void fmd_launch_nei_fast(int cls, int wide, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                          const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
                          uint32_t seq_stride, uint32_t *gen_list, uint32_t *gen_n, uint32_t *bail_n, uint32_t *slow_list, uint32_t *slow_n)
@@ -554,7 +621,7 @@ void fmd_launch_nei_fast(int cls, int wide, int n_cu, int per_cu_cap, hipStream_
 #if FMD_BLK64
     const char *e = getenv("FMD_FAST_WAVES"); // A/B knob: resident waves per CU
     if (e && atoi(e) > 0 && (per_cu_cap <= 0 || atoi(e) < per_cu_cap)) per_cu_cap = atoi(e);
-#define FAST_LAUNCH(K, M) k_ovl_nei_fast<fmd_grp_size(K), M><<<n_cu * grp_cap(fast_blocks_per_cu<fmd_grp_size(K), M>(), per_cu_cap), 64, 0, st>>>(ix, list, list_n, cap, listA, rec, nei_out, max_nei, seq_out, seq_stride, gen_list, gen_n, bail_n, slow_list, slow_n)
+#define FAST_LAUNCH(K, M) k_ovl_nei_fast<fmd_grp_size(K), M><<<fast_grid(n_cu * grp_cap(fast_blocks_per_cu<fmd_grp_size(K), M>(), per_cu_cap)), 64, 0, st>>>(ix, list, list_n, cap, listA, rec, nei_out, max_nei, seq_out, seq_stride, gen_list, gen_n, bail_n, slow_list, slow_n)
 #define FAST_LAUNCH2(K) do { if (wide) FAST_LAUNCH(K, uint64_t); else FAST_LAUNCH(K, uint32_t); } while (0)
     switch (cls) {
     case 0: FAST_LAUNCH2(0); break;

@@ -35,8 +35,17 @@
 #ifndef FMD_BLK64
 #define FMD_BLK64 1   // the shipped geometry (A/B: make variant NAME=128 EXTRA=-DFMD_BLK64=0)
 #endif
+// Overlapped blocks (FMD_BLK_OVERLAP, the shipped form of the 64-byte geometry): a block STARTS every 64 positions and holds the
+// symbols of 96 -- its third chunk repeats the first chunk of the next block.  The counts are those before position 64 b.  A rank
+// pair (k, l) -- the two ends of an SA interval, l - k <= a few dozen once a search is past its first bases -- is answered from the
+// ONE block of k whenever l < 64 b + 96, i.e. always for intervals up to 32 wide, where disjoint 96-position blocks needed a second
+// line for a fraction size/96 of the steps (12-16 % of all lines of backward search and overlap discovery at 30x); the block of a
+// position is a shift instead of a division by 96.  8 bits per symbol instead of 5.33: 141 GB for the 1.4e11-symbol index.
+#ifndef FMD_BLK_OVERLAP
+#define FMD_BLK_OVERLAP 0   // measured (profiles/r2_ab): +3-5 % on overlap discovery and backward search, -2 % on SMEM, 1.5 x the HBM: not shipped
+#endif
 #if FMD_BLK64
-#define FMD_BLK_SYMS 96u
+#define FMD_BLK_SYMS 96u        // positions whose symbols a block holds
 #define FMD_BLK_U4 4            // uint4 per block
 #define FMD_BLK_CHUNKS 3        // 32-position plane chunks per block
 #define FMD_GRP_SHIFT 2         // 4 lanes x 16 B fetch one block
@@ -45,6 +54,16 @@
 #define FMD_BLK_U4 8            // uint4 per block
 #define FMD_BLK_CHUNKS 8
 #define FMD_GRP_SHIFT 3         // 8 lanes x 16 B fetch one block
+#endif
+#if FMD_BLK_OVERLAP
+#if !FMD_BLK64
+#error "overlapped blocks are defined for the 64-byte geometry"
+#endif
+#define FMD_BLK_STRIDE 64u      // positions between the starts of consecutive blocks
+#define FMD_BLK_OWN_CHUNKS 2    // chunks a block counts as its own (the rest is look-ahead)
+#else
+#define FMD_BLK_STRIDE FMD_BLK_SYMS
+#define FMD_BLK_OWN_CHUNKS FMD_BLK_CHUNKS
 #endif
 #define FMD_BLK_BYTES (FMD_BLK_U4 * 16)
 #define FMD_GRP_MASK ((1 << FMD_GRP_SHIFT) - 1)
@@ -111,7 +130,10 @@ __device__ __forceinline__ void fmd_count_lane(const FmdIndexView &ix, int n, in
 }
 
 // position -> (block, offset inside the block)
-#if FMD_BLK64
+#if FMD_BLK_OVERLAP
+__device__ __forceinline__ void fmd_word_split(uint64_t w, uint32_t &blk, uint32_t &ch) { blk = (uint32_t)(w >> 1); ch = (uint32_t)w & 1; } // the OWN chunk of word w
+__device__ __forceinline__ void fmd_split(uint64_t k, uint32_t &blk, uint32_t &off) { blk = (uint32_t)(k >> 6); off = (uint32_t)k & 63; }
+#elif FMD_BLK64
 __device__ __forceinline__ uint64_t fmd_div3(uint64_t w) // w < 2^43 (32-position word index)
 {
     // 2^32 = 3K + 1 with K = 0x55555555:  w = hi*2^32 + lo = 3*hi*K + (hi + lo);  hi + lo = c*2^32 + sl likewise
@@ -136,6 +158,13 @@ __device__ __forceinline__ void fmd_word_split(uint64_t w, uint32_t &blk, uint32
 __device__ __forceinline__ void fmd_split(uint64_t k, uint32_t &blk, uint32_t &off) { blk = (uint32_t)(k >> 8); off = (uint32_t)k & 255; }
 #endif
 __device__ __forceinline__ uint32_t fmd_blk_of(uint64_t k) { uint32_t b, o; fmd_split(k, b, o); return b; }
+// Can position p be read from the image of block blk (its own positions, or -- overlapped blocks -- the look-ahead chunk)?  off = its offset there.
+__device__ __forceinline__ bool fmd_in_block(uint64_t p, uint32_t blk, uint32_t &off)
+{
+    const uint64_t o = p - (uint64_t)blk * FMD_BLK_STRIDE;     // wraps to a huge value when p lies before the block
+    off = (uint32_t)o;
+    return o < FMD_BLK_SYMS;
+}
 // uint4 index of 32-position word w in the block array (transcode kernels)
 __device__ __forceinline__ uint64_t fmd_word_u4(uint64_t w) { uint32_t b, c; fmd_word_split(w, b, c); return (uint64_t)b * FMD_BLK_U4 + c; }
 
@@ -269,7 +298,7 @@ __device__ __forceinline__ int fmd_block_rank6(const uint4 *blk, int t, uint32_t
     const uint64_t b2 = ((uint64_t)((meta[5] >> 16) & 0xff) << 32 | meta[2]), b3 = ((uint64_t)(meta[5] >> 24) << 32 | meta[3]);
     const uint64_t b4 = ((uint64_t)(meta[6] & 0xff) << 32 | meta[4]);
     out[0] = b0 + n0; out[1] = b1 + n1; out[2] = b2 + n2; out[3] = b3 + n3; out[4] = b4 + n4;
-    out[5] = (uint64_t)blk_no * FMD_BLK_SYMS - (b0 + b1 + b2 + b3 + b4) + n5;
+    out[5] = (uint64_t)blk_no * FMD_BLK_STRIDE - (b0 + b1 + b2 + b3 + b4) + n5;
 #else
     (void)blk_no;
     out[0] = ((uint64_t)(meta[6] & 0xff) << 32 | meta[0]) + n0;
@@ -310,7 +339,7 @@ __device__ __forceinline__ uint64_t fmd_block_rank1(const uint4 *blk, int t, uin
     // N: everything before the block that is none of the other five
     const uint64_t five = ((uint64_t)(mv.z & 0xff) << 32 | m0) + ((uint64_t)((mv.z >> 8) & 0xff) << 32 | m1) +
                           ((uint64_t)((mv.z >> 16) & 0xff) << 32 | m2) + ((uint64_t)(mv.z >> 24) << 32 | mv.x) + ((uint64_t)(mv.w & 0xff) << 32 | mv.y);
-    return (uint64_t)blk_no * FMD_BLK_SYMS - five + n;
+    return (uint64_t)blk_no * FMD_BLK_STRIDE - five + n;
 #else
     (void)blk_no;
 #pragma unroll
@@ -349,7 +378,7 @@ __device__ __forceinline__ uint64_t fmd_block_rank1z(const uint4 *blk, int t, ui
     }
     const uint64_t five = ((uint64_t)(mv.z & 0xff) << 32 | m0) + ((uint64_t)((mv.z >> 8) & 0xff) << 32 | m1) +
                           ((uint64_t)((mv.z >> 16) & 0xff) << 32 | m2) + ((uint64_t)(mv.z >> 24) << 32 | mv.x) + ((uint64_t)(mv.w & 0xff) << 32 | mv.y);
-    return (uint64_t)blk_no * FMD_BLK_SYMS - five + n;
+    return (uint64_t)blk_no * FMD_BLK_STRIDE - five + n;
 #else
     rz = fmd_block_rank1(blk, t, npos, 0, blk_no);
     return fmd_block_rank1(blk, t, npos, c, blk_no);
@@ -410,6 +439,17 @@ __device__ __forceinline__ size_t fmd_tickets_take(FmdTickets &t, uint32_t *queu
 // those lanes are compacted with a ballot prefix into a 32-block pool and fetched 8 per wave
 // instruction: at most 4 instructions instead of 8 rounds of swizzle + address arithmetic.  Wide
 // intervals (every lane straddles: the first few bases of a search) fall back to a dense l slot.
+// overlapped blocks: the l side of a rank pair is read from the block of the k side whenever that block reaches it
+__device__ __forceinline__ void fmd_l_from_k(bool both, uint64_t l, uint32_t blk_k, uint32_t &blk_l, uint32_t &off_l)
+{
+#if FMD_BLK_OVERLAP
+    uint32_t o;
+    if (both && blk_l != blk_k && fmd_in_block(l, blk_k, o)) { blk_l = blk_k; off_l = o; }
+#else
+    (void)both; (void)l; (void)blk_k; (void)blk_l; (void)off_l;
+#endif
+}
+
 struct FmdRank2 {
     const uint4 *bk, *bl;  // lane-owned block images in LDS
     int t, tl;             // chunk XOR of each image
@@ -425,6 +465,7 @@ __device__ __forceinline__ FmdRank2 fmd_wave_rank2_fetch(const FmdIndexView &ix,
     r.hk = k != ~0ull; r.hl = l != ~0ull;
     uint32_t ok_, ol_;
     fmd_split(k, r.blk_k, ok_); fmd_split(l, r.blk_l, ol_);
+    fmd_l_from_k(r.hk && r.hl, l, r.blk_k, r.blk_l, ol_);
     const bool l_sep = r.hl && !(r.hk && r.blk_k == r.blk_l);
     fmd_fetch_slot<0>(ix, lds, r.blk_k, r.hk);
     r.t = fmd_chunk_xor(q);
@@ -477,6 +518,7 @@ __device__ __forceinline__ FmdRank2c fmd_wave_rank2_fetch_compact(const FmdIndex
     r.hk = k != ~0ull; r.hl = l != ~0ull;
     uint32_t ok_, ol_;
     fmd_split(k, r.blk_k, ok_); fmd_split(l, r.blk_l, ol_);
+    fmd_l_from_k(r.hk && r.hl, l, r.blk_k, r.blk_l, ol_);
     r.l_sep = r.hl && !(r.hk && r.blk_k == r.blk_l);
     fmd_fetch_slot<0>(ix, lds, r.blk_k, r.hk);
     r.t = fmd_chunk_xor(q);
