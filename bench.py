@@ -490,7 +490,7 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
     dev_bytes = None if lines is None else (lines[0] + lines[1]) * BLOCK_BYTES + io
     cn = oracle_counters(fmd_path, lambda o: o.overlap_batch(np.arange(4000, dtype=np.uint64), min_match, 100, 4, 1, check_left=False))
     qps = (cn["rank1a"] + cn["rank2a"] + cn["rank2a_spill"]) / 4000.0
-    out["roofline"] = roofline("k_ovl_walk + k_ovl_seq_out + k_ovl_classify + k_ovl_nei_grp<8|12|16|21|32> + k_ovl_nei (one step = %d batches of %d strands)"
+    out["roofline"] = roofline("k_ovl_walk + k_ovl_seq_out + k_ovl_classify + k_ovl_nei_fast<G, M> + k_ovl_nei_grp<G> + k_ovl_nei (one step = %d batches of %d strands)"
                                % ((job.n + job.batch - 1) // job.batch, job.batch), kern_ms, dev_bytes,
                                {"rank_blocks": lines and lines[0], "prefix_table_lines": lines and lines[1], "stream_bytes": io, "streams": streams},
                                qps * BYTES_PER_RANK_QUERY * n_ids, "overlap@%d" % n_reads,
@@ -866,6 +866,13 @@ def main():
             if k in ovl:
                 out[k] = ovl.pop(k)
         out["overlap_discovery"] = ovl
+        # the bound that applies to a path made of random 64-byte lines is the rate of those, not the streaming peak: the bare gather
+        # probe of the backward-search leg (64-byte lines over 8 GiB) beside this leg's bytes
+        probe = (bs or {}).get("roofline", {}).get("random_gather_probe")
+        if probe and "roofline" in out:
+            r = out["roofline"]
+            r["random_gather_ceiling"] = {"probe_GBps": probe["GB_per_s"], "requested_bytes_frac_of_it": r["achieved"] / probe["GB_per_s"],
+                                          "traffic_frac_of_it": (r["traffic_GBps"] / probe["GB_per_s"]) if r.get("traffic_GBps") else None}
         if cl:
             out["check_left"] = cl
         if bs:
