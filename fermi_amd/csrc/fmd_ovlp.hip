@@ -821,6 +821,7 @@ static void ovl_phase_a(const OvlBatch &o, hipStream_t st, size_t b, size_t np, 
         return;
     }
     int grid = fmd_grid_for_lds(o.h, np, FMD_COMPACT_LDS_U4 * 16);
+    { const char *e = getenv("FMD_WALK_WAVES"); if (per_cu <= 0 && e && atoi(e) > 0) per_cu = atoi(e); }   // A/B knob: resident waves per CU
     if (per_cu > 0 && grid > o.h->n_cu * per_cu) grid = o.h->n_cu * per_cu;
     k_ovl_walk<<<grid, 64, 0, st>>>(o.ix, np, o.ids + b, o.min_match, srev, o.stride_r, o.cap, listA, o.rec + b, seq, o.seq_stride, q0, 0);
     launch_seq_out(st, np, o.max_len, srev, o.stride_r, o.rec + b, o.min_match, 0, seq, o.seq_stride);

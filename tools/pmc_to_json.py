@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 import bench
 
 d, steps, n_reads, n_bs, label = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-LEGS = {"overlap@%d" % n_reads: ("k_ovl_walk", "k_ovl_seq_out", "k_ovl_classify", "k_ovl_nei_grp", "k_ovl_nei"),
+LEGS = {"overlap@%d" % n_reads: ("k_ovl_walk", "k_ovl_seq_out", "k_ovl_classify", "k_ovl_nei_fast", "k_ovl_nei_grp", "k_ovl_nei"),
         "check_left@%d" % n_reads: ("k_link_rows", "k_link_edges", "k_ovl_cls"), "k_bsearch@%d" % n_bs: ("k_bsearch",), "smem@%d" % n_reads: ("k_smem",),
         "kmer@%d" % n_reads: ("k_kmer_level", "k_kmer_emit")}
 
