@@ -21,4 +21,10 @@ for cmd, out in (([AMD, "build", "-fo", D + "/a.fmd", D + "/r.fq"], None), ([AMD
     p = subprocess.run(cmd, stdout=open(out, "wb") if out else subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
     print(" ".join(cmd[1:3]), "%.1f s" % (time.time() - t), "rc", p.returncode)
     print("\n".join(l for l in p.stderr.decode().splitlines() if "M::" in l))
-print("MAG bytes", os.path.getsize(D + "/a.mag"))
+import hashlib
+print("MAG bytes", os.path.getsize(D + "/a.mag"), "md5", hashlib.md5(open(D + "/a.mag", "rb").read()).hexdigest())
+# A/B: the walk as a plain pointer chase (no skip-list prefetch), and on reads with 1 % errors (many short unitigs)
+t = time.time()
+p = subprocess.run([AMD, "unitig", "-l50", D + "/a.fmd"], stdout=open(D + "/b.mag", "wb"), stderr=subprocess.PIPE, env=dict(env, FMD_WALK_NO_JUMP="1"))
+print("unitig -l50 with FMD_WALK_NO_JUMP=1: %.1f s" % (time.time() - t), "md5", hashlib.md5(open(D + "/b.mag", "rb").read()).hexdigest())
+print("\n".join(l for l in p.stderr.decode().splitlines() if "walk" in l))
