@@ -74,6 +74,30 @@ static int batch_room(batch_t *b, size_t more)
     return 0;
 }
 
+/* ASCII -> nt6 of a byte range of a batch: the parser (one thread, the pipeline's critical stage) only copies; the codes the GPU
+ * wants are made here, on the `-t` host threads, when the batch reaches the second stage */
+typedef struct { batch_t *b; size_t lo, hi; } enc_t;
+static void *enc_main(void *d)
+{
+    enc_t *e = (enc_t *)d;
+    const unsigned char *a = (const unsigned char *)e->b->ascii;
+    uint8_t *o = e->b->nt6;
+    for (size_t i = e->lo; i < e->hi; ++i) o[i] = fmdh_nt6[a[i]];
+    return 0;
+}
+static void encode_batch(batch_t *b)
+{
+    int T = g_host_threads < 1 ? 1 : (g_host_threads > 64 ? 64 : g_host_threads), t;
+    pthread_t tid[64];
+    enc_t e[64];
+    int started[64];
+    if (b->bytes < ((size_t)1 << 20)) T = 1;
+    for (t = 0; t < T; ++t) { e[t].b = b; e[t].lo = b->bytes * (size_t)t / (size_t)T; e[t].hi = b->bytes * (size_t)(t + 1) / (size_t)T; }
+    for (t = 1; t < T; ++t) started[t] = pthread_create(&tid[t], 0, enc_main, &e[t]) == 0;
+    enc_main(&e[0]);
+    for (t = 1; t < T; ++t) { if (started[t]) pthread_join(tid[t], 0); else enc_main(&e[t]); }
+}
+
 /* stage 2: the GPU corrects a parsed batch in place (nt6 + qual) */
 static void *stage_gpu(void *d)
 {
@@ -82,6 +106,7 @@ static void *stage_gpu(void *d)
         batch_t *b = &p->b[k % 3];
         slot_wait(p, b, 1);
         const double t0 = now_s();
+        if (b->nb && !p->failed) encode_batch(b);
         if (b->nb && !p->failed) {
             const int rc = fmd_ecfix_batch(p->tab, b->nb, b->nt6, b->qual, b->off, p->opt->step, b->info);
             if (rc) { fprintf(stderr, "[E::%s] correction pass failed: %s\n", __func__, fmd_strerror(rc)); p->failed = 1; }
@@ -229,8 +254,7 @@ int fmdh_correct_reads(const fmdh_ecopt_t *opt, int device, int suf_len, uint64_
             if (len < 0) { b->last = 1; break; }
             if (batch_room(b, (size_t)len)) { fprintf(stderr, "[E::%s] out of memory\n", __func__); p.failed = 1; b->last = 1; break; }
             const char *s = fmdh_seq_bases(io), *q = fmdh_seq_qual(io);
-            memcpy(b->ascii + b->bytes, s, (size_t)len);
-            for (int j = 0; j < len; ++j) b->nt6[b->bytes + (size_t)j] = fmdh_nt6[(unsigned char)s[j]];
+            memcpy(b->ascii + b->bytes, s, (size_t)len);                  /* (nt6 codes: encode_batch, second stage) */
             if (q) memcpy(b->qual + b->bytes, q, (size_t)len);
             else memset(b->qual + b->bytes, 33 + 15, (size_t)len);      /* no quality: phred 15 (correct.c:431-436) */
             b->bytes += (size_t)len;
