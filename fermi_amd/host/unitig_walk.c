@@ -58,6 +58,7 @@ typedef struct {
  * offset has arrived, the variable part.  Hints only: where the walk stops or turns, a prefetch was wasted, nothing else. */
 #define JUMP_LOG 3
 #define JUMP_DIST (1 << JUMP_LOG)
+#define SEED_AHEAD 32           /* ids between a seed and the one whose first hop is prefetched */
 typedef struct { const fmdh_link_t *link; const uint32_t *src; uint32_t *dst; uint64_t n; int first, tid, nt; } jump_job_t;
 static void *jump_main(void *p)
 {
@@ -89,21 +90,25 @@ static uint32_t *build_jump(const fmdh_link_t *link, uint64_t n)
     free(b);
     return a;
 }
+/* (a row that the overflow pass replaced lives in the side table: its prefetch goes to the old place and is wasted) */
 static inline void prefetch_row_head(const walk_t *w, uint32_t row) /* what a visit reads first */
 {
     const fmdh_ovlp_table_t *t = w->t;
-    if (t->n_shards != 1 || t->side_of) return;        /* (the sharded / patched tables keep the plain chase) */
-    __builtin_prefetch(&t->shard[0].rec[row]);
-    __builtin_prefetch(&t->shard[0].off[row]);
-    __builtin_prefetch(&t->link[row]);
-    __builtin_prefetch(&w->jump[row]);
+    const fmdh_ovlp_shard_t *s = &t->shard[row % (uint32_t)t->n_shards];
+    const uint32_t r = row / (uint32_t)t->n_shards;
+    __builtin_prefetch(&s->rec[r]);
+    __builtin_prefetch(&s->off[r]);
+    if (t->link) __builtin_prefetch(&t->link[row]);
+    if (w->jump) __builtin_prefetch(&w->jump[row]);
+    if (t->side_of) __builtin_prefetch(&t->side_of[row]);
 }
 static inline void prefetch_row_var(const walk_t *w, uint32_t row)  /* once its offset is there */
 {
-    const fmdh_ovlp_shard_t *s = &w->t->shard[0];
-    if (w->t->n_shards != 1 || w->t->side_of) return;
-    __builtin_prefetch(s->chunk[row >> s->chunk_shift] + s->off[row]);
-    __builtin_prefetch(s->chunk[row >> s->chunk_shift] + s->off[row] + 64);
+    const fmdh_ovlp_table_t *t = w->t;
+    const fmdh_ovlp_shard_t *s = &t->shard[row % (uint32_t)t->n_shards];
+    const uint32_t r = row / (uint32_t)t->n_shards;
+    __builtin_prefetch(s->chunk[r >> s->chunk_shift] + s->off[r]);
+    __builtin_prefetch(s->chunk[r >> s->chunk_shift] + s->off[r] + 64);
 }
 
 static inline fmdh_row_t ROW(const walk_t *w, uint64_t row) { return fmdh_table_row(w->t, row); }
@@ -367,10 +372,17 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
             if (r->status == 0 && !(r->flags & FMD_OVLP_F_OVERFLOW) && r->k[0] < n_seq) w.row_of[r->k[0]] = (uint32_t)i;
         }
     }
-    if (t->link && t->n_shards == 1 && !t->side_of && !getenv("FMD_WALK_NO_JUMP")) w.jump = build_jump(t->link, t->n);   /* 0: the plain chase */
+    const int hints = t->link && !getenv("FMD_WALK_NO_JUMP");
+    if (hints) w.jump = build_jump(t->link, t->n);   /* 0: the plain chase */
     /* unitig_core with start = 0, step = 1 (unitig.c:333-334): seeds are the odd sequence ids */
     for (j = 0; j <= n_seq >> 2; ++j) {
         for (i = j << 2 | 1; i < (j << 2) + 4 && i < n_seq; i += 2) {
+            if (hints && i + SEED_AHEAD < t->n) {   /* short unitigs (reads with errors): the record of the first hop of a seed to come, both directions */
+                const uint64_t m = i + SEED_AHEAD;
+                const uint32_t a = t->link[m].nxt, b = t->link[m - 1].nxt;
+                if (a != 0xffffffffu) __builtin_prefetch(&t->shard[a % (uint32_t)t->n_shards].rec[a / (uint32_t)t->n_shards]);
+                if (b != 0xffffffffu) __builtin_prefetch(&t->shard[b % (uint32_t)t->n_shards].rec[b / (uint32_t)t->n_shards]);
+            }
             const fmd_ovlp_rec_t *r = REC(&w, i);
             uint64_t end[2];
             int n_nei[2] = {0, 0}, n_reads, is_loop = 0, seed_len, k, done_loop = 0;
