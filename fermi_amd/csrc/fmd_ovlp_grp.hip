@@ -431,7 +431,8 @@ __global__ __launch_bounds__(64, 5) void k_ovl_nei_fast(FmdIndexView ix, const u
     uint4 pa = make_uint4(0, 0, 0, 0), pb = make_uint4(0, 0, 0, 0);
     // Strands handed on to the general kernel go to slots of its list that the wave reserves FMD_FAST_CHUNK at a time (one atomic on
     // the list counter per chunk; one per strand serialises: 5*10^6 atomics on one address cost 45 ms on reads with 1 % errors);
-    // a chunk is filled with hole markers when it is reserved, k_ovl_nei_grp skips what stays a hole.
+    // a chunk is filled with hole markers when it is reserved, k_ovl_nei_grp skips what stays a hole -- at most FMD_FAST_CHUNK - 1
+    // slots per wave and launch, which is what FMD_FAST_RESERVE adds to the capacity of a general list.
     uint32_t res_cur = 0, res_end = 0, n_handed = 0;              // wave-uniform
     bool hand_on = false;                                         // this group's strand leaves for the general kernel (set at j == 0 too)
 
@@ -439,22 +440,22 @@ __global__ __launch_bounds__(64, 5) void k_ovl_nei_fast(FmdIndexView ix, const u
         {   // ---- hand-overs of the previous step / of the admission below
             const uint64_t hm = __ballot(hand_on && j == 0);
             if (hm) {
-                const uint32_t n = (uint32_t)__popcll(hm);
-                if (res_end - res_cur < n) {                      // a new chunk (what is left of the old one stays holes)
-                    uint32_t base = 0;
+                const uint32_t n = (uint32_t)__popcll(hm), room = res_end - res_cur;   // n <= 8 < FMD_FAST_CHUNK
+                uint32_t base = 0;
+                if (room < n) {   // the first `room` of them finish the old chunk, the rest start a new one: only a wave's LAST chunk keeps holes
                     if (lane == 0) { base = atomicAdd(gen_n, (uint32_t)FMD_FAST_CHUNK); atomicAdd(bail_n, n_handed); }   // (the count: diagnostics, FMD_OVLP_STATS)
                     n_handed = 0;
                     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                     if (lane < FMD_FAST_CHUNK) { gen_list[2 * (size_t)(base + lane)] = FMD_LIST_HOLE; gen_list[2 * (size_t)(base + lane) + 1] = 0; }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the markers land before the entries that replace them
-                    res_cur = base; res_end = base + FMD_FAST_CHUNK;
                 }
                 if (hand_on && j == 0) {
-                    const uint32_t k = res_cur + (uint32_t)fmd_below(hm);
+                    const uint32_t q = (uint32_t)fmd_below(hm), k = q < room ? res_cur + q : base + (q - room);
                     gen_list[2 * (size_t)k] = sid; gen_list[2 * (size_t)k + 1] = meta;
                 }
+                if (room < n) { res_cur = base + (n - room); res_end = base + FMD_FAST_CHUNK; }
+                else res_cur += n;
                 n_handed += n;
-                res_cur += n;
                 hand_on = false;
             }
         }
