@@ -90,6 +90,27 @@ def test_unitig_walk_with_check_left_decided_by_the_link_pass(oracle_lib, gold, 
     o.close()
 
 
+@pytest.mark.parametrize("n_shards", [1, 3])
+def test_unitig_walk_prefetch_hints_change_nothing(oracle_lib, gold, tmp_path, monkeypatch, n_shards):
+    """The walk's skip list over the links (unitig_walk.c: jump[] by pointer doubling, prefetches 8 rows ahead) only issues hints:
+    the MAG is the reference's with it (default, linked table) and without it (FMD_WALK_NO_JUMP=1), one shard or three."""
+    o = orcbind.OrcIndex(gold.path("tiny.fmd"))
+    n_seq = int(o.mcnt[1])
+    rec, nei, seq = o.overlap_batch(np.arange(n_seq, dtype=np.uint64), 50, max_len=100, max_nei=8, n_threads=4)
+    exact = rec["reserved"].copy()
+    rec["reserved"] = 2
+    outs = []
+    for no_jump in (False, True):
+        if no_jump:
+            monkeypatch.setenv("FMD_WALK_NO_JUMP", "1")
+        out = str(tmp_path / ("o%d.mag" % no_jump))
+        hostlib.unitig_walk(_packed_shards(rec.copy(), nei, seq, n_shards), n_seq, 50, out, max_nei=8, seq_stride=seq.shape[1], link=2,
+                            resolve=lambda ids: exact[ids.astype(np.int64)])
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] == gold.text_gz("tiny.mag.gz")
+    o.close()
+
+
 def test_correct_kmer_rule():
     assert hostlib.lib().fmdh_correct_kmer(404000) == 17       # correct.c:313-318
 
