@@ -836,7 +836,8 @@ def _same_overlap(a, b, max_nei):
         assert np.array_equal(seq1[i, :used[i]], seq0[i, :used[i]]), i
 
 
-@pytest.mark.parametrize("L,cov,mm,err,N", [(100, 30, 50, 0.0, 20000), (100, 30, 50, 0.01, 20000), (100, 60, 40, 0.003, 8000), (151, 12, 31, 0.02, 6000)])
+@pytest.mark.parametrize("L,cov,mm,err,N", [(100, 30, 50, 0.0, 20000), (100, 30, 50, 0.01, 20000), (100, 60, 40, 0.003, 8000), (151, 12, 31, 0.02, 6000),
+                                            (100, 80, 45, 0.0, 6000), (100, 80, 45, 0.005, 6000)])   # the last two: widest candidates of 32..63 occurrences, the 64-bit masks
 def test_unforked_fast_path_equals_general_group_kernels(gpu, oracle_lib, monkeypatch, capfd, L, cov, mm, err, N):
     """k_ovl_nei_fast (candidates in the narrow form, no x[0]-side fetch, one shared window per strand and round; hands a strand
     on to k_ovl_nei_grp the moment its reads show a second base) against the general group kernels alone (FMD_OVLP_FAST=0) and the
@@ -863,10 +864,12 @@ def test_unforked_fast_path_equals_general_group_kernels(gpu, oracle_lib, monkey
     o = orcbind.OrcIndex(bwt=bwt)
     sub = ids[:4000]
     wrec, wnei, wseq = o.overlap_batch(sub, mm, L, 8, 4, check_left=True)
+    ok = (fast[0]["flags"][:4000] & gpu.OVLP_F_OVERFLOW) == 0     # (more than max_nei neighbours: the caller runs those again, larger)
+    assert ok.sum() > 3900
     for f in ("rank", "k", "len", "status", "n_ovlp", "rbeg", "ext_len", "n_nei", "reserved"):   # (lfork: the oracle's is exact, the product's may say less)
-        assert np.array_equal(fast[0][f][:4000], wrec[f]), f
+        assert np.array_equal(fast[0][f][:4000][ok], wrec[f][ok]), f
     for j in range(8):
-        mj = wrec["n_nei"] > j
+        mj = ok & (wrec["n_nei"] > j)
         assert fast[1][:4000][mj, j].tobytes() == wnei[mj, j].tobytes(), j
     d.close(); o.close()
 
