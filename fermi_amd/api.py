@@ -331,8 +331,10 @@ def _kmer_collect(self, w, min_occ, suf_len=None):
     cnt = (C.c_int64 * 2)()
     check(lib().fmd_kmer_collect(self.h, w, min_occ, suf_len, C.byref(b), C.byref(k), C.byref(v), C.byref(n), cnt))
     m = n.value
-    out = (np.frombuffer(C.string_at(b, m * 4), dtype=np.uint32).copy(), np.frombuffer(C.string_at(k, m * 4), dtype=np.uint32).copy(),
-           np.frombuffer(C.string_at(v, m), dtype=np.uint8).copy(), [cnt[0], cnt[1]])
+
+    def take(p, ct, dt):   # (ctypes.string_at stops at 2^31 bytes; a 5*10^10-symbol index has 1.7*10^9 solid k-mers)
+        return np.ctypeslib.as_array((ct * max(m, 1)).from_address(p.value))[:m].astype(dt, copy=True) if m else np.zeros(0, dtype=dt)
+    out = (take(b, C.c_uint32, np.uint32), take(k, C.c_uint32, np.uint32), take(v, C.c_uint8, np.uint8), [cnt[0], cnt[1]])
     for p in (b, k, v):
         lib().fmd_host_free(p)
     return out

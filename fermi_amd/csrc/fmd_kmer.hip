@@ -406,8 +406,12 @@ static int km_sort_triples(uint64_t m, int suf_len, uint32_t *db, uint32_t *dk, 
 static int km_collect_part_host(fmd_dev_t *h, int w, int min_occ, int suf_len, int seed_mask, uint64_t cap0, uint32_t **bucket, uint32_t **key,
                                 uint8_t **val, uint64_t *n, uint64_t *m_alloc, int64_t cnt[2])
 {
-    uint64_t cap = cap0;
-    for (int attempt = 0; attempt < 16; ++attempt, cap *= 4) {
+    uint64_t cap = cap0, demand = 0;
+    for (int attempt = 0; attempt < 24; ++attempt) {
+        if (attempt) {   // grow by what the overflowed pass asked for (the widest level it counted, + a fifth), at least twice
+            const uint64_t by_demand = demand + demand / 5 + 1024;
+            cap = by_demand > 2 * cap ? by_demand : 2 * cap;
+        }
         void *work = nullptr, *db = nullptr, *dk = nullptr, *dv = nullptr, *ds = nullptr;
         const size_t wb = fmd_kmer_work_bytes(cap);
         int rc = FMD_OK;
@@ -416,6 +420,10 @@ static int km_collect_part_host(fmd_dev_t *h, int w, int min_occ, int suf_len, i
         uint64_t status[4] = {0, 0, 0, 0};
         if (rc == FMD_OK) rc = fmd_kmer_collect_part_dev(h, nullptr, w, min_occ, suf_len, seed_mask, work, wb, cap, (uint32_t *)db, (uint32_t *)dk, (uint8_t *)dv, (uint64_t *)ds);
         if (rc == FMD_OK && hipMemcpy(status, ds, 32, hipMemcpyDeviceToHost) != hipSuccess) rc = FMD_E_HIP;
+        if (rc == FMD_OK && status[1] != 0) {   // overflowed: the level counters (exact up to the first level that did not fit) say how much is needed
+            unsigned long long lv[KM_WORDS];
+            if (hipMemcpy(lv, work, sizeof(lv), hipMemcpyDeviceToHost) == hipSuccess) { demand = 0; for (int d = 1; d <= w && d < KM_WORDS; ++d) if (lv[d] > demand) demand = lv[d]; }
+        }
         if (rc == FMD_OK && status[1] == 0) {
             hipFree(work); work = nullptr;   // the frontier buffers are not needed any more; the sort wants the room
             rc = km_sort_triples(status[0], suf_len, (uint32_t *)db, (uint32_t *)dk, (uint8_t *)dv);
@@ -436,8 +444,7 @@ static int km_collect_part_host(fmd_dev_t *h, int w, int min_occ, int suf_len, i
             if (rc == FMD_OK) { *n += m; cnt[0] += (int64_t)status[2]; cnt[1] += (int64_t)status[3]; }
         }
         hipFree(work); hipFree(db); hipFree(dk); hipFree(dv); hipFree(ds);
-        if (rc == FMD_E_NOMEM && attempt == 0 && cap0 > (1u << 22)) { cap = (1u << 22) / 4; continue; }   // the estimate did not fit: grow from the bottom instead
-        if (rc != FMD_OK) return rc;
+        if (rc != FMD_OK) return rc;   // FMD_E_NOMEM: the caller cuts the harvest into more parts
         if (status[1] == 0) return FMD_OK;
     }
     return FMD_E_OVERFLOW;
@@ -460,8 +467,14 @@ extern "C" int fmd_kmer_collect(fmd_dev_t *h, int w, int min_occ, int suf_len, u
     { const char *e = getenv("FMD_KMER_PARTS"); if (e && (atoi(e) == 1 || atoi(e) == 4)) parts = atoi(e); }
     uint64_t m_alloc = 0;
     int rc = FMD_OK;
-    for (int p = 0; p < parts && rc == FMD_OK; ++p)
-        rc = km_collect_part_host(h, w, min_occ, suf_len, parts == 1 ? 0xf : 1 << p, 1u << 22, bucket, key, val, n, &m_alloc, cnt);
+    for (;;) {
+        for (int p = 0; p < parts && rc == FMD_OK; ++p)
+            rc = km_collect_part_host(h, w, min_occ, suf_len, parts == 1 ? 0xf : 1 << p, 1u << 22, bucket, key, val, n, &m_alloc, cnt);
+        if (rc != FMD_E_NOMEM || parts != 1) break;
+        // the frontiers of the whole trie did not fit beside the index after all: start over, a quarter at a time
+        free(*bucket); free(*key); free(*val); *bucket = nullptr; *key = nullptr; *val = nullptr; *n = 0; m_alloc = 0; cnt[0] = cnt[1] = 0;
+        parts = 4; rc = FMD_OK;
+    }
     if (rc != FMD_OK) { free(*bucket); free(*key); free(*val); *bucket = nullptr; *key = nullptr; *val = nullptr; *n = 0; }
     else if (!*bucket) { *bucket = (uint32_t *)malloc(4); *key = (uint32_t *)malloc(4); *val = (uint8_t *)malloc(4); }
     return rc;

@@ -8,7 +8,7 @@ device layout; the only form that carries 1.4*10^11 symbols) --, then
   * backward search and overlap discovery on random samples against the REFERENCE (oracle/_ref when it travelled, the oracle
     otherwise) through the .fmd the product writes (skipped with `noref`),
   * config 5's share of one GPU out of `share` (ids i = 0 mod share): one timed pass of overlap discovery on this index.
-Usage: python tools/scale_check.py [n_reads=250000000] [bwt|inplace] [sample=20000] [share=8] [noref]"""
+Usage: python tools/scale_check.py [n_reads=250000000] [bwt|inplace] [sample=20000] [share=8] [noref] [kmer]"""
 import ctypes as C, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -117,6 +117,21 @@ if not noref:
     base, ok = bench.cpu_overlap(fmd_path, ids, 50, rec, nei)
     print("overlap discovery vs %s on %d random sequence ids: %s (reference %.0f reads/s on %d threads)" % (base["kind"], len(ids), "bit-exact" if ok else "MISMATCH", base["value"], base["cores"]), flush=True)
     assert ok
+    if "kmer" in sys.argv[5:]:   # the harvest of `fermi correct` (fm6_traverse + ec_collect) over the whole index, host form (parts as the free HBM asks)
+        import math
+        w = min(27, int(math.log(n_sym) / math.log(4) + 8.499)); suf_len = w - 15 if w > 15 else 1
+        t0 = time.time()
+        kb, kk, kv, kc = index.kmer_collect(w, 3, suf_len)
+        t_h = time.time() - t0
+        print("k-mer harvest (k = %d, min_occ 3): %d solid %d-mers in %.1f s incl. the copy to the host (%.2e per s), %d informative; HBM in use %.1f GB"
+              % (w, len(kb), w - 1, t_h, len(kb) / t_h, kc[1], hbm_used()), flush=True)
+        nb = 256
+        m = kb < nb
+        trip = np.sort(kb[m].astype(np.uint64) << np.uint64(40) | kk[m].astype(np.uint64) << np.uint64(8) | kv[m].astype(np.uint64))
+        del kb, kk, kv
+        base, ok = bench.cpu_kmer(fmd_path, w, 3, suf_len, nb, trip)
+        print("k-mer harvest vs %s on suffix buckets 0..%d (%d triples): %s" % (base["kind"], nb - 1, len(trip), "bit-exact" if ok else "MISMATCH"), flush=True)
+        assert ok
     os.remove(fmd_path)
 # ---- one GPU's share of the sharded overlap discovery on this index (BASELINE configs[3] / [4]: ids i = 0 (mod share))
 job = bench.OverlapJob(torch, api, index, dev, 2 * n_reads, 0, share, L, 50)
