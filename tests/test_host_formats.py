@@ -111,6 +111,57 @@ def test_unitig_walk_prefetch_hints_change_nothing(oracle_lib, gold, tmp_path, m
     o.close()
 
 
+def _random_bwt(rng, n, mean_run, long_runs):
+    """nt6 symbols with geometric run lengths (mean `mean_run`) and a few very long runs (>= 2^15: the 32-bit block headers)"""
+    out, tot = [], 0
+    while tot < n:
+        k = int(rng.integers(2000, 8000))
+        lens = rng.geometric(1.0 / mean_run, k)
+        syms = rng.integers(0, 6, k).astype(np.uint8)
+        out.append(np.repeat(syms, lens)); tot += int(lens.sum())
+        if long_runs and rng.random() < 0.3:
+            L = int(rng.integers(1 << 15, 1 << 18))
+            out.append(np.full(L, int(rng.integers(0, 6)), dtype=np.uint8)); tot += L
+    return np.concatenate(out)[:n]
+
+
+def _to_rle6(bwt):
+    """the byte stream the GPU run-length pass emits: len << 3 | sym, len <= 31 (long runs in pieces)"""
+    edge = np.flatnonzero(np.diff(bwt)) + 1
+    start = np.concatenate(([0], edge)); ln = np.diff(np.concatenate((start, [len(bwt)])))
+    reps = (ln + 30) // 31
+    sym = np.repeat(bwt[start], reps)
+    piece = np.full(int(reps.sum()), 31, dtype=np.int64)
+    last = np.cumsum(reps) - 1
+    piece[last] = ln - 31 * (reps - 1)
+    return (piece.astype(np.uint8) << 3 | sym).astype(np.uint8)
+
+
+@pytest.mark.parametrize("mean_run,long_runs,chunk_words", [(1.3, False, 0), (6, True, 0), (40, True, 0), (2, False, 1024), (9, True, 4096), (3, True, 64)])
+def test_parallel_rld_encoder_writes_the_bytes_of_the_sequential_one(tmp_path, monkeypatch, mean_run, long_runs, chunk_words):
+    """rld_writer.c: speculative slices + stitch (several host threads) against the one-thread encoder, from a byte BWT and from an
+    RLE\\6 stream; short and long runs (16- and 32-bit block headers); with the chunk length of the format shrunk so that the
+    shortened last block of a chunk (rld.h:66) falls inside every slice (both encoders then write the same non-standard file)."""
+    rng = np.random.default_rng(int(mean_run * 10) + chunk_words)
+    bwt = _random_bwt(rng, 3_000_000, mean_run, long_runs)
+    rle = _to_rle6(bwt)
+    if chunk_words:
+        monkeypatch.setenv("FMD_RLD_TEST_CHUNK_WORDS", str(chunk_words))
+    want = {}
+    for threads in (1, 3, 16, 61):
+        monkeypatch.setenv("FMD_RLD_THREADS", str(threads))
+        for kind, arr, fn in (("bwt", bwt, hostlib.write_rld_from_bwt), ("rle6", rle, hostlib.write_rld_from_rle6)):
+            path = str(tmp_path / ("%s_%d.fmd" % (kind, threads)))
+            fn(arr, path)
+            got = open(path, "rb").read()
+            os.remove(path)
+            if threads == 1:
+                want[kind] = got
+            else:
+                assert got == want[kind], (kind, threads)
+    assert want["bwt"] == want["rle6"]
+
+
 def test_correct_kmer_rule():
     assert hostlib.lib().fmdh_correct_kmer(404000) == 17       # correct.c:313-318
 
