@@ -749,18 +749,61 @@ def bench_raw_reads(torch, api, workload, dev, local_rank, n_reads, L, steps, wa
     index = api.DevIndex.from_bwt_dev(d_bwt, n_sym, local_rank)
     api.lib().fmd_dev_free(d_bwt)
     log("raw-read index: %d reads at e=%g, %d symbols, %.1fs" % (n_reads, err, n_sym, time.time() - t0))
-    sm = km = None
+    sm = km = raw = None
     try:
         if "smem" in legs:
             sm = bench_smem(torch, api, index, rd, err, n_sym, fmd_path, dev, local_rank, n_reads, L, steps, warmup)
             torch.cuda.empty_cache()
         if "kmer" in legs:
             km = bench_kmer(torch, api, index, n_sym, fmd_path, dev, local_rank, n_reads, steps, warmup)
+            torch.cuda.empty_cache()
+        if "overlap" in legs and os.environ.get("FMD_BENCH_RAW_OVERLAP", "1") != "0":
+            raw = bench_overlap_raw(torch, api, index, dev, n_reads, L, err)
     finally:
         if os.path.exists(fmd_path):
             os.remove(fmd_path)
         index.close()
-    return sm, km
+    return sm, km, raw
+
+
+def bench_overlap_raw(torch, api, index, dev, n_reads, L, err):
+    """Not a BASELINE config: overlap discovery of one batch of strands on the RAW-read index (reads with errors fork; the fast
+    get_nei path hands the forked strands to the general group kernels), with the fast path and without, so that the headline --
+    measured on error-free reads, where every strand takes the fast path -- can be read for what it is."""
+    n_ids = min(2 * n_reads, 20_000_000)
+    job = OverlapJob(torch, api, index, dev, n_ids, 0, 1, L, 50)
+    out = {"what": "fm_retrieve + fm6_is_contained + fm6_get_nei (-l50) for the first %d sequence ids of the index of %d reads with %g substitutions per base" % (n_ids, n_reads, err)}
+    saved = os.environ.get("FMD_OVLP_FAST")
+    sums = {}
+    try:
+        for key, val in (("ms_with_the_fast_get_nei_path", None), ("ms_general_group_kernels_only", "0")):
+            if val is None:
+                os.environ.pop("FMD_OVLP_FAST", None)
+            else:
+                os.environ["FMD_OVLP_FAST"] = val
+            job.compute()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(job.stream)
+            for _ in range(2):
+                job.compute()
+            e1.record(job.stream)
+            torch.cuda.synchronize()
+            out[key] = e0.elapsed_time(e1) / 2
+            g = job.rec.view(torch.int32).view(job.n, 16)
+            sums[key] = (int(g[:, 11:14].to(torch.int64).sum().item()), int(job.nei.view(torch.int64).view(job.n, job.max_nei, 4)[:, 0].sum().item()))
+    finally:
+        if saved is None:
+            os.environ.pop("FMD_OVLP_FAST", None)
+        else:
+            os.environ["FMD_OVLP_FAST"] = saved
+    g = job.rec.view(torch.int32).view(job.n, 16)
+    out["strands"] = job.n
+    out["strands_per_s"] = job.n / out["ms_with_the_fast_get_nei_path"] * 1e3
+    out["with_neighbour"] = int((g[:, 13] > 0).sum().item())
+    out["forked"] = int(((g[:, 14] & 1) != 0).sum().item())
+    out["same_results_both_ways"] = len(set(sums.values())) == 1     # (sums of rbeg + ext_len + n_nei and of the first neighbours' intervals)
+    return out
 
 
 def main():
@@ -839,14 +882,14 @@ def main():
     if fmd_path and os.path.exists(fmd_path):
         os.remove(fmd_path)
 
-    bs = sm = km = None
+    bs = sm = km = raw_ovl = None
     if rank == 0 and world == 1:
         k2, w2 = max(1, min(args.steps, 5)), min(args.warmup, 1)
         if "bsearch" in legs:
             bs = bench_bsearch(torch, api, workload, dev, local_rank, k2, w2)
             torch.cuda.empty_cache()
         if "smem" in legs or "kmer" in legs:
-            sm, km = bench_raw_reads(torch, api, workload, dev, local_rank, n_reads, L, max(1, min(args.steps, 3)), w2, legs)
+            sm, km, raw_ovl = bench_raw_reads(torch, api, workload, dev, local_rank, n_reads, L, max(1, min(args.steps, 3)), w2, legs)
 
     if rank == 0:
         out = {
@@ -881,6 +924,8 @@ def main():
             out["smem"] = sm
         if km:
             out["kmer_harvest"] = km
+        if raw_ovl:
+            out["overlap_discovery_on_raw_reads"] = raw_ovl
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()
