@@ -483,7 +483,7 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
     n_neis = int(np.minimum(g_rec["n_nei"][ok_rows], job.max_nei).sum())
     n_ext = int(g_rec["ext_len"][ok_rows].sum())
     stride_r = (L + 15) // 16 * 16
-    streams = {"ids": 8 * n_ids, "stash_write_and_read": 2 * stride_r * n_ids, "sequence_rows_out": L * n_ids + 32 * n_ext,
+    streams = {"ids": 8 * n_ids, "tail_table": 0 if os.environ.get("FMD_TAIL_TABLE") == "0" else 8 * n_ids, "stash_write_and_read": 2 * stride_r * n_ids, "sequence_rows_out": L * n_ids + 32 * n_ext,
                "records_write_classify_read_result_write": 3 * 64 * n_ids, "work_lists": 16 * n_ids,
                "candidates_write_and_read": 2 * 32 * n_cand, "classify_widest_candidate": 64 * n_ids, "neighbours": 32 * n_neis}
     io = sum(streams.values())

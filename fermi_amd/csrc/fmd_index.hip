@@ -264,6 +264,40 @@ static int build_ptab(fmd_dev *h)
     return FMD_OK;
 }
 
+// ------------------------------------------------------------------ tail table (FmdIndexView::tail)
+#define FMD_TAIL_NONE (~0ull)
+static unsigned nblk(uint64_t n, unsigned per);
+__global__ void k_tail_table(FmdIndexView ix, int d, unsigned long long *__restrict__ tail)
+{
+    for (uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; id < ix.n_seq; id += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t k = id, tfw = 0;
+        bool ok = true;
+        for (int j = 0; j < d && ok; ++j) {   // the LF step of fm_retrieve (exact.c:63-66): base = BWT[k], k = cnt[c] + rank_c(k) - 1
+            uint32_t b, o;
+            uint64_t r[6];
+            fmd_split(k, b, o);
+            const int c = fmd_block_rank6<true>(ix.blocks + (size_t)b * FMD_BLK_U4, 0, o + 1, r, b);
+            if (c < 1 || c > 4) { ok = false; break; }
+            k = ix.cnt[c] + r[c] - 1;
+            tfw |= (uint64_t)(c - 1) << (2 * j);
+        }
+        tail[id] = ok ? (k | tfw << 40) : FMD_TAIL_NONE;
+    }
+}
+static int build_tail(fmd_dev *h)
+{
+    const char *e = getenv("FMD_TAIL_TABLE");
+    if ((e && atoi(e) == 0) || !h->ptab || h->ptab_d < 2 || h->ptab_d > 12 || h->mcnt[1] == 0) return FMD_OK;   // 24 bits of bases beside a 40-bit row
+    unsigned long long *t = nullptr;
+    if (hipMalloc((void **)&t, h->mcnt[1] * 8) != hipSuccess) { (void)hipGetLastError(); return FMD_OK; }   // no room: the walk takes its steps itself
+    k_tail_table<<<nblk(h->mcnt[1], 256), 256>>>(fmd_view(h), h->ptab_d, t);
+    hipError_t err = hipDeviceSynchronize();
+    if (err != hipSuccess) { hipFree(t); fmd_set_hip_error(err, "tail table"); return FMD_E_HIP; }
+    h->tail = t;
+    h->bytes += h->mcnt[1] * 8;
+    return FMD_OK;
+}
+
 // --------------------------------------------------------------------------------- host side
 struct FmdWiden { __host__ __device__ uint64_t operator()(fmd_bc_t v) const { return (uint64_t)v; } };
 static int scan_counts(const fmd_bc_t *d_in, uint64_t *d_out, uint64_t n, hipStream_t st)
@@ -362,6 +396,7 @@ static int finish_index(fmd_dev *h)
     }
     hipFree(bc); hipFree(acc);
     if (rc == FMD_OK) rc = build_ptab(h);
+    if (rc == FMD_OK) rc = build_tail(h);
     return rc;
 }
 
@@ -618,6 +653,7 @@ extern "C" void fmd_dev_close(fmd_dev_t *h)
     hipSetDevice(h->device);
     hipFree(h->blocks);
     hipFree(h->ptab);
+    hipFree(h->tail);
     hipFree(h->queues);
     hipFree(h->stat);
     for (size_t i = 0; i < sizeof(h->scratch) / sizeof(h->scratch[0]); ++i) if (h->scratch[i].p) hipFree(h->scratch[i].p);

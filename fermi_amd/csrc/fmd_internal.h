@@ -16,6 +16,7 @@ struct fmd_dev {
     uint64_t cnt[7], mcnt[7];
     uint4 *ptab;              // device: intervals of all strings of ptab_d bases (FmdIndexView)
     int ptab_d;
+    unsigned long long *tail;  // device: FmdIndexView::tail
     uint32_t *queues;         // device ring of work-queue heads for the persistent kernels
     uint32_t queue_next;      // host-side ring cursor (atomic)
     unsigned long long *stat; // device: FMD_STAT_SLOTS x FMD_STAT_STRIDE line counters (written by the instrumented build only)
@@ -49,7 +50,7 @@ static inline FmdIndexView fmd_view(const fmd_dev *h)
     for (int i = 0; i < 7; ++i) v.cnt[i] = h->cnt[i];
     v.n_sym = h->mcnt[0];
     v.n_seq = h->mcnt[1];
-    v.ptab = h->ptab; v.ptab_d = h->ptab_d;
+    v.ptab = h->ptab; v.ptab_d = h->ptab_d; v.tail = h->tail;
     v.stat = h->stat;
     return v;
 }

@@ -218,7 +218,28 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
     for (;;) {
         const size_t my = fmd_tickets_take(tk_, queue, st == WK_IDLE && !exhausted);
         if (st == WK_IDLE && !exhausted) {
-            if (my < n) { sid = my; k = ids[my]; depth = 0; npush = 0; pack = 0; pk0 = pk1 = pk2 = 0; flags = 0; ret = 0; st = WK_LF; tab = tab_ok; }
+            if (my < n) {
+                sid = my; k = ids[my]; depth = 0; npush = 0; pack = 0; pk0 = pk1 = pk2 = 0; flags = 0; ret = 0; st = WK_LF; tab = tab_ok;
+                // the first ptab_d LF steps were taken when the index was loaded (FmdIndexView::tail): pick the walk up behind them
+                const unsigned long long te = (tab_ok && ix.tail && k < ix.n_seq) ? ix.tail[k] : ~0ull;
+                if (te != ~0ull) {
+                    tfw = (uint32_t)(te >> 40); k = te & 0xffffffffffull;
+                    for (int jb = 0; jb < ix.ptab_d; ++jb) {   // the bases into the stash, as the steps would have put them
+                        pack |= (((tfw >> (2 * jb)) & 3u) + 1u) << (8 * (depth & 3));
+                        ++depth;
+                        if ((depth & 3) == 0) WALK_STASH_WORD();
+                    }
+                    // reverse complement of the ptab index: the 2-bit groups in reverse order, complemented
+                    { uint32_t r = __brev(~tfw) >> (32 - 2 * ix.ptab_d); trv = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1); }
+                    const uint4 ef = ix.ptab[tfw], er = ix.ptab[trv];
+                    fmd_count_lane(ix, 2, 1);
+                    x0 = (uint64_t)ef.y << 32 | ef.x;
+                    sz = ((uint64_t)ef.w << 32 | ef.z) - x0 + 1;
+                    x1 = (uint64_t)er.y << 32 | er.x;
+                    tab = false;
+                    st = walk_lf_shares(k, x0, sz) ? WK_BOTH : WK_LF;
+                }
+            }
             else exhausted = true;
         }
         if (__ballot(st != WK_IDLE) == 0) break;

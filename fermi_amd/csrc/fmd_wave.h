@@ -91,6 +91,11 @@ struct FmdIndexView {            // passed by value as a kernel argument (lives 
     // index of s_0 s_1 .. s_{d-1} = sum (s_j - 1) << 2(d-1-j).  Lets a search start ptab_d bases in.
     const uint4 *ptab;
     int ptab_d;
+    // Where the LF-walk of every sequence stands after its last ptab_d bases (tail[id], id = the sequence's sentinel row):
+    // row | the bases as a ptab index << 40; ~0 = shorter than that, or not A/C/G/T.  fm_retrieve (exact.c:59) begins with
+    // exactly these ptab_d dependent steps -- one DRAM line each, a ninth of all lines of overlap discovery -- for every
+    // sequence, every time; they are taken once, when the index is loaded (8 bytes per sequence; nullptr = not built).
+    const unsigned long long *tail;
     // 64 counters on separate 128-byte lines: rank blocks requested from the memory system by the gathers.
     // Only the instrumented build (-DFMD_COUNT_LINES=1, libfmdhip_count.so) adds to them; bench.py runs one step
     // of each leg through that build to price the shipped kernels in DEVICE bytes (64 bytes per block).
