@@ -349,7 +349,8 @@ class OverlapJob:
         self.n_ids, self.rank, self.world = n_ids, rank, world
         self.ids = torch.arange(rank, n_ids, world, dtype=torch.int64, device=dev)   # start/step interleave (unitig.c:333)
         self.n = int(self.ids.numel())
-        # strands per launch: the HBM work area is 6.4 kB per strand at 100 bp, -l50; 2*10^7 strands = 128 GB of the 288 GB
+        # strands per launch: the HBM work area is 3.95 kB per strand at 100 bp, -l50 (two candidate lists of 58 entries, the stash,
+        # the work lists); 2*10^7 strands = 79 GB of the 288 GB
         self.batch = max(1, min(self.n, int(os.environ.get("FMD_BENCH_OVLP_BATCH", "20000000"))))
         self.rec = torch.zeros(self.n * 64, dtype=torch.uint8, device=dev)
         self.nei = torch.zeros(self.n * self.max_nei * 32, dtype=torch.uint8, device=dev)
@@ -902,7 +903,7 @@ def main():
     hbm_index = index.hbm_bytes
     del job
     index.close()
-    torch.cuda.empty_cache()   # the 128 GB work area goes back to HIP: the library allocates outside torch's cache
+    torch.cuda.empty_cache()   # the 79 GB work area goes back to HIP: the library allocates outside torch's cache
     if fmd_path and os.path.exists(fmd_path):
         os.remove(fmd_path)
 
