@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "fmd_smem_work_bytes", "fmd_smem_dev", "fmd_smem_batch", "fmd_smem_win_dev", "fmd_smem_win_batch", "fmd_reach_dev", "fmd_reach_batch", "fmd_dev_export_bwt", "fmd_dev_check_rank",
     "fmd_kmer_work_bytes", "fmd_kmer_collect_dev", "fmd_kmer_collect_part_dev", "fmd_kmer_collect",
     "fmd_ectab_build_dev", "fmd_ectab_build", "fmd_ectab_free", "fmd_ecfix_work_bytes", "fmd_ecfix_dev", "fmd_ecfix_batch",
-    "fmd_ovlp_work_bytes", "fmd_ovlp_dev", "fmd_ovlp_batch", "fmd_ovlp_check_left_dev", "fmd_seqinfo_dev", "fmd_seqinfo_batch",
+    "fmd_ovlp_work_bytes", "fmd_ovlp_dev", "fmd_ovlp_sorted_work_bytes", "fmd_ovlp_sorted_dev", "fmd_ovlp_batch", "fmd_ovlp_check_left_dev", "fmd_seqinfo_dev", "fmd_seqinfo_batch",
     "fmd_ovlp_pack_max_bytes", "fmd_ovlp_pack_work_bytes", "fmd_ovlp_pack_dev", "fmd_ovlp_packed_batch", "fmd_ovlp_packed_free", "fmd_ovlp_link_dev", "fmd_ovlp_packed_table",
 ]
 
@@ -91,6 +91,8 @@ def _configure(L):
     L.fmd_memcpy_h2d.argtypes = [vp, vp, sz, vp]
     L.fmd_memcpy_d2h.argtypes = [vp, vp, sz, vp]
     L.fmd_ovlp_work_bytes.restype = sz; L.fmd_ovlp_work_bytes.argtypes = [sz, C.c_uint32, C.c_int]
+    L.fmd_ovlp_sorted_work_bytes.restype = sz; L.fmd_ovlp_sorted_work_bytes.argtypes = [sz, sz, C.c_uint32, C.c_int]
+    L.fmd_ovlp_sorted_dev.argtypes = [vp, vp, sz, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint32, vp, sz, sz]
     L.fmd_ovlp_dev.argtypes = [vp, vp, sz, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint32, vp, sz]
     L.fmd_ovlp_batch.argtypes = [vp, sz, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint32, C.c_int]
     L.fmd_ovlp_check_left_dev.argtypes = [vp, vp, sz, C.c_int, C.c_uint32, vp, vp, C.c_uint32, vp, sz]

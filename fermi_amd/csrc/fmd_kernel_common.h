@@ -131,3 +131,8 @@ struct FmdOvlClasses {
     uint32_t *lslow;                  // everything else, plus strands the group kernels hand back
     uint32_t *fast[2 * FMD_GRP_CLASSES];  // strands whose candidates are in the narrow form: k_ovl_nei_fast first (same two words)
 };
+
+// Two-pass walk of a sorted job (k_ovl_walk<WALK_HEAD / WALK_TAIL>, fmd_ovlp.hip): where a strand stands FMD_WALK_SPLIT bases in.
+#define FMD_WALK_SPLIT 32u            // a multiple of 16: the stash of a parked strand is two whole 16-byte groups
+struct FmdWalkPark { unsigned long long k, x0, x1, sz; uint4 s0, s1; };   // k = ~0: the sequence ended inside the head (its record was written there)
+static_assert(sizeof(FmdWalkPark) == 64, "one line per parked strand");

@@ -9,14 +9,18 @@
 #include <string.h>
 #include "fmd_kernel_common.h"
 
+// (gidx: slot of a sorted batch -> row of rec / nei_out / seq_out, fmd_ovlp_sorted_dev; nullptr = the slot is the row)
 void fmd_launch_nei_grp(int cls, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                         const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
-                        uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n);
+                        uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx);
 int fmd_nei_fast_available(void);
 void fmd_launch_nei_fast(int cls, int wide, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                          const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
-                         uint32_t seq_stride, uint32_t *gen_list, uint32_t *gen_n, uint32_t *bail_n, uint32_t *slow_list, uint32_t *slow_n);
-void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, const fmd_intv_t *listA, uint32_t cap, FmdOvlClasses cl, int use_fast);
+                         uint32_t seq_stride, uint32_t *gen_list, uint32_t *gen_n, uint32_t *bail_n, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx);
+void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, const fmd_intv_t *listA, uint32_t cap, FmdOvlClasses cl, int use_fast, const uint32_t *gidx);
+// fmd_ovlp_sort.hip: minimizer keys of the parked strands, then their rows sorted by key (-> vals_b)
+size_t fmd_park_sort_temp_bytes(size_t n);
+int fmd_park_sort(hipStream_t st, size_t n, const FmdWalkPark *park, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *tmp, size_t tmp_bytes);
 
 // ---------------------------------------------------------------------------- phase 0: retrieve
 // fm_retrieve (exact.c:59-70); writes the sequence REVERSED into srev and rank/len into rec.
@@ -194,14 +198,28 @@ __device__ __forceinline__ bool walk_lf_shares(uint64_t k, uint64_t x0, uint64_t
         pack = 0;                                                                                          \
     } while (0)
 
+// Two-pass form (WALK_HEAD + WALK_TAIL, the locality sort of fmd_ovlp_sorted_dev below).  Strands whose last bases lie next to each
+// other on the genome visit the SAME rank blocks (the interval of "g[a, e)" holds the interval of "g[a, e + d)"), d steps apart; in
+// id order they are never in flight together and every one of those visits is a DRAM miss.  WALK_HEAD takes every strand of the job
+// FMD_WALK_SPLIT bases in and parks it (FmdWalkPark: row, bi-interval, the bases so far); the strands are sorted by the minimizer of
+// those bases (k_ovl_park_keys), so that strands of one genomic window sit in neighbouring lanes; WALK_TAIL picks each strand up where
+// it was parked, in that order.  Nothing can be pushed before min_match >= FMD_WALK_SPLIT bases, so the two passes together make
+// exactly the steps of the one-pass walk and leave the same records, candidates and stash.
+enum { WALK_WHOLE = 0, WALK_HEAD = 1, WALK_TAIL = 2 };   // (FMD_WALK_SPLIT, FmdWalkPark: fmd_kernel_common.h)
+
+// MODE = WALK_HEAD: item = position in ids[] = row of park[] and rec[]; srev/stride_r address the stash inside park[].
+// MODE = WALK_TAIL: item = slot of the batch (rows of srev, listA), gidx[slot] = its row in park[], rec[] (and, for the kernels
+// that follow, nei[] and seq[]).
+template <int MODE>
 __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, const uint64_t *__restrict__ ids, int min_match,
                                                  uint8_t *__restrict__ srev, uint32_t stride_r, uint32_t cap,
                                                  fmd_intv_t *__restrict__ listA, fmd_ovlp_rec_t *__restrict__ rec,
                                                  uint8_t *__restrict__ seq_out, uint32_t seq_stride, uint32_t *__restrict__ queue,
-                                                 int info_only)
+                                                 int info_only, FmdWalkPark *__restrict__ park, const uint32_t *__restrict__ gidx)
 {
     FMD_DECLARE_COMPACT_LDS();
     size_t sid = 0;
+    size_t gs = 0;                        // the strand's row in rec[] (WALK_TAIL: gidx[sid], otherwise sid)
     int st = WK_IDLE, c_pend = 0, ret = 0;
     uint32_t depth = 0, npush = 0, pack = 0, flags = 0;
     uint32_t pk0 = 0, pk1 = 0, pk2 = 0;   // the stash is written 16 bases at a time (one 16-byte store per lane instead of four words)
@@ -218,8 +236,22 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
     for (;;) {
         const size_t my = fmd_tickets_take(tk_, queue, st == WK_IDLE && !exhausted);
         if (st == WK_IDLE && !exhausted) {
+            if (MODE == WALK_TAIL) {
+                if (my < n) {   // pick the strand up where WALK_HEAD parked it
+                    sid = my; gs = gidx[my];
+                    const FmdWalkPark *pp = park + gs;
+                    const uint4 a = ((const uint4 *)pp)[0], b = ((const uint4 *)pp)[1];
+                    k = (uint64_t)a.y << 32 | a.x; x0 = (uint64_t)a.w << 32 | a.z; x1 = (uint64_t)b.y << 32 | b.x; sz = (uint64_t)b.w << 32 | b.z;
+                    if (k != ~0ull) {
+                        uint4 *sr = (uint4 *)(srev + sid * (size_t)stride_r);
+                        sr[0] = pp->s0; sr[1] = pp->s1;
+                        depth = FMD_WALK_SPLIT; npush = 0; pack = 0; pk0 = pk1 = pk2 = 0; flags = 0; ret = 0; tab = false;
+                        st = walk_lf_shares(k, x0, sz) ? WK_BOTH : WK_LF;
+                    }
+                } else exhausted = true;
+            } else
             if (my < n) {
-                sid = my; k = ids[my]; depth = 0; npush = 0; pack = 0; pk0 = pk1 = pk2 = 0; flags = 0; ret = 0; st = WK_LF; tab = tab_ok;
+                sid = my; gs = my; k = ids[my]; depth = 0; npush = 0; pack = 0; pk0 = pk1 = pk2 = 0; flags = 0; ret = 0; st = WK_LF; tab = tab_ok;
                 // the first ptab_d LF steps were taken when the index was loaded (FmdIndexView::tail): pick the walk up behind them
                 const unsigned long long te = (tab_ok && ix.tail && k < ix.n_seq) ? ix.tail[k] : ~0ull;
                 if (te != ~0ull) {
@@ -325,9 +357,10 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
         }
         if (depth == 0) { // first LF step: the last base of the sequence, or an empty sequence
             if (c == 0) {
-                fmd_ovlp_rec_t *o = rec + sid;
+                fmd_ovlp_rec_t *o = rec + gs;
                 o->rank = k; o->k[0] = o->k[1] = o->k[2] = 0; o->len = 0; o->status = -1; o->n_ovlp = 0; o->rbeg = -1;
                 o->ext_len = 0; o->n_nei = 0; o->flags = 0; o->reserved = 2; o->lfork = 0;
+                if (MODE == WALK_HEAD) park[sid].k = ~0ull;
                 st = WK_IDLE;
                 continue;
             }
@@ -353,7 +386,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             if (c != 0) { // one more base: overlap_intv's loop body (unitig.c:47-59)
                 const uint64_t sc = sel6(c, s[0], s[1], s[2], s[3], s[4], s[5]);
                 // (sc == 0 cannot happen: the sequence itself is in the index)
-                if (!info_only && (int)depth >= min_match && s[0]) {
+                if (MODE != WALK_HEAD && !info_only && (int)depth >= min_match && s[0]) {
                     if (npush < cap) {
                         fmd_intv_t *e = listA + sid * (size_t)cap + (cap - 1 - npush);
                         if (narrow && depth < 65536u) cand_store_narrow(e, x0, x1, (uint32_t)sz, depth, wD, wr0);
@@ -378,9 +411,10 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
                     const uint32_t wq = (depth >> 2) & 3;
                     *(uint4 *)(srev + sid * (size_t)stride_r + (depth & ~15u)) = make_uint4(wq == 0 ? pack : pk0, wq == 1 ? pack : pk1, wq == 2 ? pack : pk2, wq == 3 ? pack : 0u);
                 }
-                fmd_ovlp_rec_t *o = rec + sid;
+                fmd_ovlp_rec_t *o = rec + gs;
                 o->rank = k; o->len = (int32_t)depth; o->rbeg = -1; o->ext_len = 0; o->n_nei = 0; o->reserved = 2; o->lfork = 0;
                 o->k[0] = o->k[1] = o->k[2] = 0; o->n_ovlp = 0;
+                if (MODE == WALK_HEAD) park[sid].k = ~0ull;   // ended inside the head: shorter than min_match, the record below is final
                 if (depth > stride_r) { o->status = 0; o->flags = FMD_OVLP_F_OVERFLOW; st = WK_IDLE; continue; } // longer than max_len
                 if (!info_only && (int)depth <= min_match) { o->status = -1; o->flags = 0; st = WK_IDLE; continue; } // too short (unitig.c:288)
                 // (the caller's copy in read order is made by k_ovl_seq_out: a lane doing it here holds up the other 63)
@@ -393,7 +427,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             const uint64_t t0k = was_two_phase ? tk2[0] : (r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, 0, r.blk_k) : 0);
             const uint64_t t0l = r.hl ? fmd_block_rank1(r.bl, r.tl, r.nl, 0, r.blk_l) : 0;
             if (sz != t0l - t0k) ret = -1;
-            fmd_ovlp_rec_t *o = rec + sid;
+            fmd_ovlp_rec_t *o = rec + gs;
             o->k[0] = x0; o->k[1] = t0k; o->k[2] = t0l - t0k;
             o->status = ret < 0 ? -3 : 0;
             o->n_ovlp = (int32_t)npush;
@@ -406,6 +440,12 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             st = walk_lf_shares(k, x0, sz) ? WK_BOTH : WK_LF;
             if (tab) st = WK_LF;   // inside the prefix table there is no extension to share a gather with
         }
+        if (MODE == WALK_HEAD && depth == FMD_WALK_SPLIT && !tab) {   // park the strand (its stash so far lies in park[sid].s0, s1 already)
+            uint4 *pp = (uint4 *)(park + sid);
+            pp[0] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), (uint32_t)x0, (uint32_t)(x0 >> 32));
+            pp[1] = make_uint4((uint32_t)x1, (uint32_t)(x1 >> 32), (uint32_t)sz, (uint32_t)(sz >> 32));
+            st = WK_IDLE;
+        }
     }
 }
 
@@ -415,13 +455,14 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
 // per output word; the same conditions under which a record describes a complete sequence
 // (k_ovl_walk: not empty, not longer than max_len, longer than min_match unless info_only).
 __global__ void k_ovl_seq_out(size_t n, uint32_t words, const uint8_t *__restrict__ srev, uint32_t stride_r, const fmd_ovlp_rec_t *__restrict__ rec,
-                              int min_match, int info_only, uint8_t *__restrict__ seq_out, uint32_t seq_stride)
+                              int min_match, int info_only, uint8_t *__restrict__ seq_out, uint32_t seq_stride, const uint32_t *__restrict__ gidx)
 {
     const size_t total = n * (size_t)words, step = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
         const size_t sid = i / words;
         const uint32_t w = (uint32_t)(i - sid * words);
-        const int L = rec[sid].len;
+        const size_t g = gidx ? (size_t)gidx[sid] : sid;   // the strand's row in rec[] and seq_out[] (sorted batches: fmd_ovlp_sorted_dev)
+        const int L = rec[g].len;
         if (L <= 0 || (uint32_t)L > stride_r || (!info_only && L <= min_match) || (int)(4 * w) >= L || 4 * w + 3 >= seq_stride) continue;
         const uint8_t *sr = srev + sid * (size_t)stride_r;
         // output bytes 4w..4w+3 = stash bytes a+3..a with a = L - 4 - 4w: an unaligned word, byte-swapped
@@ -432,7 +473,7 @@ __global__ void k_ovl_seq_out(size_t n, uint32_t words, const uint8_t *__restric
             const uint64_t two = (a & 3) ? ((uint64_t)q[1] << 32 | q[0]) : q[0];
             v = __builtin_bswap32((uint32_t)(two >> (8 * (a & 3))));
         } else v = __builtin_bswap32(*(const uint32_t *)sr << (8 * -a)); // the first 4 + a bases of the stash, the rest of the word zero
-        *(uint32_t *)(seq_out + sid * (size_t)seq_stride + 4 * w) = v;
+        *(uint32_t *)(seq_out + g * (size_t)seq_stride + 4 * w) = v;
     }
 }
 
@@ -465,12 +506,14 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
                                                 fmd_intv_t *__restrict__ listB, fmd_ovlp_rec_t *__restrict__ rec,
                                                 fmd_intv_t *__restrict__ nei_out, uint32_t max_nei,
                                                 uint8_t *__restrict__ seq_out, uint32_t seq_stride, uint32_t *__restrict__ queue,
-                                                const uint32_t *__restrict__ work_list, const uint32_t *__restrict__ work_n)
+                                                const uint32_t *__restrict__ work_list, const uint32_t *__restrict__ work_n,
+                                                const uint32_t *__restrict__ gidx)
 {
     FMD_DECLARE_WAVE_LDS();
     if (work_list) n = *work_n;   // only the strands the group kernels could not take
     // per-lane search state
-    size_t sid = 0;
+    size_t sid = 0;   // the strand's slot in the batch (rows of srev, listA, listB)
+    size_t gs = 0;    // its row in rec[], nei_out[], seq_out[] (gidx[sid] in a sorted batch, sid otherwise)
     int st = ST_IDLE, ori_l = 0, cur_l = 0, cpend = 0, first_c = 0, masked_cat = -2, cat_j = 0, fix_i = 0;
     uint32_t prev_n = 0, curr_n = 0, j = 0, n_nei = 0, flags = 0, cat0 = 0, last_hi = 0;
     bool unsorted = false, exhausted = false, prev_is_a = true, e_valid = false;
@@ -490,9 +533,10 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
         if (st == ST_IDLE && !exhausted) {
             if (my < n) {
                 const size_t strand = work_list ? (size_t)work_list[my] : my;
-                const fmd_ovlp_rec_t *o = rec + strand;
+                const size_t grow = gidx ? (size_t)gidx[strand] : strand;
+                const fmd_ovlp_rec_t *o = rec + grow;
                 if (o->status == 0 && o->n_ovlp > 0 && !(o->flags & FMD_OVLP_F_OVERFLOW)) {
-                    sid = strand; ori_l = cur_l = o->len;
+                    sid = strand; gs = grow; ori_l = cur_l = o->len;
                     prev_n = (uint32_t)o->n_ovlp; curr_n = 0; j = 0;
                     prev = listA + sid * (size_t)cap + (cap - prev_n);
                     curr = listB + sid * (size_t)cap; prev_is_a = true;
@@ -520,7 +564,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
                 e_valid = j + 1 < prev_n;
                 if (e_valid) { const uint4 *q = (const uint4 *)(prev + j + 1); ea = q[0]; eb = q[1]; } // lands under the rank fetch
             } else if (curr_n) { // end of a round (unitig.c:137-153)
-                if ((uint32_t)cur_l < seq_stride) seq_out[sid * (size_t)seq_stride + cur_l] = (uint8_t)comp6(first_c);
+                if ((uint32_t)cur_l < seq_stride) seq_out[gs * (size_t)seq_stride + cur_l] = (uint8_t)comp6(first_c);
                 ++cur_l;
                 if (unsorted) { // slow path: ks_introsort by the original keys, then recompute the categories
                     for (uint32_t a = 1; a < curr_n; ++a) {
@@ -556,7 +600,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
                 ea = make_uint4((uint32_t)fx0, (uint32_t)(fx0 >> 32), (uint32_t)fx1, (uint32_t)(fx1 >> 32));
                 eb = make_uint4((uint32_t)fsz, (uint32_t)(fsz >> 32), (uint32_t)finfo, (uint32_t)(finfo >> 32)); e_valid = true;
             } else { // all paths closed (unitig.c:154-178)
-                fmd_ovlp_rec_t *o = rec + sid;
+                fmd_ovlp_rec_t *o = rec + gs;
                 const int rbeg = ori_l - (int)(uint32_t)ninfo;
                 if (n_nei == 1 && (flags & FMD_OVLP_F_FORKED) && !(flags & FMD_OVLP_F_FIXED) && rbeg < ori_l) {
                     // contained reads made a fake fork: re-derive the appended bases (unitig.c:158-176)
@@ -621,7 +665,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
 #undef FMD_FIX_TRY
                 bool stop = (cnt_ok == 0 && k0.sz != 0);
                 if (!stop && c0 > 0) {
-                    if ((uint32_t)fix_i < seq_stride) seq_out[sid * (size_t)seq_stride + fix_i] = (uint8_t)comp6(c0);
+                    if ((uint32_t)fix_i < seq_stride) seq_out[gs * (size_t)seq_stride + fix_i] = (uint8_t)comp6(c0);
                     o0 = pick5(c0, k0, k1, k2, k3, k4);
                     ++fix_i;
                     if (fix_i == cur_l) stop = true;
@@ -638,7 +682,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
                 if (e0sz && o0.sz == psz && psz == e0sz) { // bounded by sentinels on both sides and not contained
                     const uint64_t inf = (uint64_t)ori_l - (pinfo & 0xffffffffull);
                     if (n_nei == 0) { nx0 = t0k; nsz = e0sz; ninfo = inf; }
-                    if (n_nei < max_nei) store_entry(nei_out + sid * (size_t)max_nei + n_nei, t0k, o0.x1, e0sz, inf);
+                    if (n_nei < max_nei) store_entry(nei_out + gs * (size_t)max_nei + n_nei, t0k, o0.x1, e0sz, inf);
                     else flags |= FMD_OVLP_F_OVERFLOW;
                     ++n_nei;
                     masked_cat = cat_j; // mask out the other intervals of this category
@@ -674,7 +718,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
         }
         // an overflowing strand is abandoned; the host re-runs it with larger capacities
         if (st != ST_IDLE && (flags & FMD_OVLP_F_OVERFLOW)) {
-            fmd_ovlp_rec_t *o = rec + sid;
+            fmd_ovlp_rec_t *o = rec + gs;
             o->flags |= FMD_OVLP_F_OVERFLOW; o->n_nei = 0; o->rbeg = -1; o->ext_len = 0;
             st = ST_IDLE;
         }
@@ -802,13 +846,13 @@ __global__ __launch_bounds__(64) void k_ovl_cls(FmdIndexView ix, size_t n, int m
 // ------------------------------------------------------------------------------- host entry
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static void launch_seq_out(hipStream_t st, size_t n, uint32_t max_len, const uint8_t *srev, uint32_t stride_r, const fmd_ovlp_rec_t *rec, int min_match,
-                           int info_only, uint8_t *seq_out, uint32_t seq_stride)
+                           int info_only, uint8_t *seq_out, uint32_t seq_stride, const uint32_t *gidx = nullptr)
 {
     const uint32_t words = (max_len + 3) / 4;
     const size_t total = n * (size_t)words;
     size_t blocks = (total + 255) / 256;
     if (blocks > (1u << 22)) blocks = 1u << 22;
-    k_ovl_seq_out<<<(unsigned)blocks, 256, 0, st>>>(n, words, srev, stride_r, rec, min_match, info_only, seq_out, seq_stride);
+    k_ovl_seq_out<<<(unsigned)blocks, 256, 0, st>>>(n, words, srev, stride_r, rec, min_match, info_only, seq_out, seq_stride, gidx);
 }
 
 extern "C" size_t fmd_ovlp_work_bytes(size_t n, uint32_t max_len, int min_match)
@@ -825,6 +869,9 @@ struct OvlBatch {
     const uint64_t *ids; int min_match; uint32_t max_len, max_nei, stride_r, cap, seq_stride;
     uint8_t *srev; fmd_intv_t *listA, *listB; uint32_t *cls;
     fmd_ovlp_rec_t *rec; fmd_intv_t *nei; uint8_t *seq;
+    // a batch taken from the sorted order of a larger job (fmd_ovlp_sorted_dev): slot t of the batch is row gidx[t] of rec, nei, seq and of
+    // park, where WALK_HEAD left it; nullptr: slot = row, the walk starts at the sentinel of ids[t]
+    const uint32_t *gidx; FmdWalkPark *park;
 };
 
 // phase A: LF-walk + overlap_intv + fm6_is_contained, then the read-order copy.  per_cu > 0 bounds the
@@ -833,8 +880,16 @@ static void ovl_phase_a(const OvlBatch &o, hipStream_t st, size_t b, size_t np, 
 {
     uint8_t *srev = o.srev + b * (size_t)o.stride_r;
     fmd_intv_t *listA = o.listA + b * (size_t)o.cap;
-    uint8_t *seq = o.seq + b * (size_t)o.seq_stride;
+    uint8_t *seq = o.gidx ? o.seq : o.seq + b * (size_t)o.seq_stride;
     uint32_t *q0 = fmd_next_queue(o.h, st), *q1 = fmd_next_queue(o.h, st);
+    if (o.gidx) {   // the second pass of a sorted job: every strand of the batch from where WALK_HEAD parked it
+        int grid = fmd_grid_for_lds(o.h, np, FMD_COMPACT_LDS_U4 * 16);
+        { const char *e = getenv("FMD_WALK_WAVES"); if (per_cu <= 0 && e && atoi(e) > 0) per_cu = atoi(e); }
+        if (per_cu > 0 && grid > o.h->n_cu * per_cu) grid = o.h->n_cu * per_cu;
+        k_ovl_walk<WALK_TAIL><<<grid, 64, 0, st>>>(o.ix, np, nullptr, o.min_match, srev, o.stride_r, o.cap, listA, o.rec, seq, o.seq_stride, q0, 0, o.park, o.gidx + b);
+        launch_seq_out(st, np, o.max_len, srev, o.stride_r, o.rec, o.min_match, 0, seq, o.seq_stride, o.gidx + b);
+        return;
+    }
     if (getenv("FMD_OVLP_UNFUSED")) { // A/B switch: separate LF-walk and overlap_intv passes
         const int grid = fmd_grid_for(o.h, np);
         k_ovl_retrieve<<<grid, 64, 0, st>>>(o.ix, np, o.ids + b, srev, o.stride_r, o.rec + b, q0);
@@ -844,7 +899,7 @@ static void ovl_phase_a(const OvlBatch &o, hipStream_t st, size_t b, size_t np, 
     int grid = fmd_grid_for_lds(o.h, np, FMD_COMPACT_LDS_U4 * 16);
     { const char *e = getenv("FMD_WALK_WAVES"); if (per_cu <= 0 && e && atoi(e) > 0) per_cu = atoi(e); }   // A/B knob: resident waves per CU
     if (per_cu > 0 && grid > o.h->n_cu * per_cu) grid = o.h->n_cu * per_cu;
-    k_ovl_walk<<<grid, 64, 0, st>>>(o.ix, np, o.ids + b, o.min_match, srev, o.stride_r, o.cap, listA, o.rec + b, seq, o.seq_stride, q0, 0);
+    k_ovl_walk<WALK_WHOLE><<<grid, 64, 0, st>>>(o.ix, np, o.ids + b, o.min_match, srev, o.stride_r, o.cap, listA, o.rec + b, seq, o.seq_stride, q0, 0, nullptr, nullptr);
     launch_seq_out(st, np, o.max_len, srev, o.stride_r, o.rec + b, o.min_match, 0, seq, o.seq_stride);
 }
 
@@ -853,13 +908,14 @@ static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, i
 {
     uint8_t *srev = o.srev + b * (size_t)o.stride_r;
     fmd_intv_t *listA = o.listA + b * (size_t)o.cap, *listB = o.listB + b * (size_t)o.cap;
-    fmd_ovlp_rec_t *rec = o.rec + b;
-    fmd_intv_t *nei = o.nei + b * (size_t)o.max_nei;
-    uint8_t *seq = o.seq + b * (size_t)o.seq_stride;
+    const uint32_t *gidx = o.gidx ? o.gidx + b : nullptr;
+    fmd_ovlp_rec_t *rec = gidx ? o.rec : o.rec + b;
+    fmd_intv_t *nei = gidx ? o.nei : o.nei + b * (size_t)o.max_nei;
+    uint8_t *seq = gidx ? o.seq : o.seq + b * (size_t)o.seq_stride;
     const int grid = fmd_grid_for(o.h, np);
     uint32_t *q2 = fmd_next_queue(o.h, st);
     if (getenv("FMD_OVLP_SLOW_ONLY")) { // A/B switch: everything through the lane-per-strand kernel
-        k_ovl_nei<<<grid, 64, 0, st>>>(o.ix, np, o.min_match, srev, o.stride_r, o.cap, listA, listB, rec, nei, o.max_nei, seq, o.seq_stride, q2, nullptr, nullptr);
+        k_ovl_nei<<<grid, 64, 0, st>>>(o.ix, np, o.min_match, srev, o.stride_r, o.cap, listA, listB, rec, nei, o.max_nei, seq, o.seq_stride, q2, nullptr, nullptr, gidx);
         return FMD_OK;
     }
     // work lists: the counter header, then one list per group class (2 words per strand), the slow list (1), one list per fast class (2)
@@ -875,7 +931,7 @@ static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, i
     // FMD_OVLP_FAST=0: A/B switch, every strand through the general group kernels
     const char *ef = getenv("FMD_OVLP_FAST");
     const int use_fast = fmd_nei_fast_available() && !(ef && atoi(ef) == 0);
-    fmd_launch_classify(st, np, rec, listA, o.cap, cl, use_fast);
+    fmd_launch_classify(st, np, rec, listA, o.cap, cl, use_fast, gidx);
     // strands whose candidates the walk left in the narrow form: the unforked path (one lane per candidate, no x[0]-side fetch,
     // one shared window per strand and round); whatever turns out not to be that simple moves on to the general list of its class
     if (use_fast)
@@ -883,13 +939,13 @@ static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, i
             uint32_t *nk = cl.cnt + (FMD_GRP_CLASSES + 1 + k) * FMD_CLS_CNT_STRIDE;
             const int kg = k % FMD_GRP_CLASSES;
             fmd_launch_nei_fast(kg, k >= FMD_GRP_CLASSES, o.h->n_cu, fast_cu, st, o.ix, cl.fast[k], nk, o.cap, listA, rec, nei, o.max_nei, seq,
-                                o.seq_stride, cl.lst[kg], cl.cnt + kg * FMD_CLS_CNT_STRIDE, nk + 8, cl.lslow, n_slow);
+                                o.seq_stride, cl.lst[kg], cl.cnt + kg * FMD_CLS_CNT_STRIDE, nk + 8, cl.lslow, n_slow, gidx);
         }
     // one lane per candidate interval, 64 / G strands per wave
     for (int k = 0; k < FMD_GRP_CLASSES; ++k)
-        fmd_launch_nei_grp(k, o.h->n_cu, per_cu, st, o.ix, cl.lst[k], cl.cnt + k * FMD_CLS_CNT_STRIDE, o.cap, listA, rec, nei, o.max_nei, seq, o.seq_stride, cl.lslow, n_slow);
+        fmd_launch_nei_grp(k, o.h->n_cu, per_cu, st, o.ix, cl.lst[k], cl.cnt + k * FMD_CLS_CNT_STRIDE, o.cap, listA, rec, nei, o.max_nei, seq, o.seq_stride, cl.lslow, n_slow, gidx);
     // the rest (too many candidates, wide intervals, fake forks, neighbour overflow): lane per strand
-    k_ovl_nei<<<grid, 64, 0, st>>>(o.ix, np, o.min_match, srev, o.stride_r, o.cap, listA, listB, rec, nei, o.max_nei, seq, o.seq_stride, q2, cl.lslow, n_slow);
+    k_ovl_nei<<<grid, 64, 0, st>>>(o.ix, np, o.min_match, srev, o.stride_r, o.cap, listA, listB, rec, nei, o.max_nei, seq, o.seq_stride, q2, cl.lslow, n_slow, gidx);
     if (getenv("FMD_OVLP_STATS")) { // where the strands of this part went (synchronises: diagnostics only)
         uint32_t hs[FMD_CLS_HEADER_U32];
         hipStreamSynchronize(st);
@@ -978,7 +1034,7 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
     o.listA = (fmd_intv_t *)((uint8_t *)d_work + align_up(n * (size_t)o.stride_r, 256));
     o.listB = (fmd_intv_t *)((uint8_t *)o.listA + align_up(n * (size_t)o.cap * sizeof(fmd_intv_t), 256));
     o.cls = (uint32_t *)((uint8_t *)o.listB + align_up(n * (size_t)o.cap * sizeof(fmd_intv_t), 256));
-    o.rec = d_rec; o.nei = d_nei; o.seq = d_seq;
+    o.rec = d_rec; o.nei = d_nei; o.seq = d_seq; o.gidx = nullptr; o.park = nullptr;
 
     int parts, walk_cu, grp_cu, fast_cu;
     ovl_pipe_config(n, parts, walk_cu, grp_cu, fast_cu);
@@ -1012,6 +1068,99 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
     if (rc != FMD_OK) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "overlap kernels"); return FMD_E_HIP; }
+    return FMD_OK;
+}
+
+// ---- the whole job in an order that keeps neighbours on the genome in flight together ---------------------------------------------
+// Work area of fmd_ovlp_sorted_dev: the parked strands (64 bytes each), two (key, row) arrays for the sort, the sort's own
+// temporary storage, and the work area of ONE batch of fmd_ovlp_dev.
+struct SortedLayout { size_t park, keys_a, keys_b, vals_a, vals_b, tmp, tmp_bytes, batch_area, total; };
+static SortedLayout sorted_layout(size_t n, size_t batch, uint32_t max_len, int min_match)
+{
+    SortedLayout L;
+    size_t o = 0;
+    L.park = o; o += align_up(n * sizeof(FmdWalkPark), 256);
+    L.keys_a = o; o += align_up(n * 4, 256);
+    L.keys_b = o; o += align_up(n * 4, 256);
+    L.vals_a = o; o += align_up(n * 4, 256);
+    L.vals_b = o; o += align_up(n * 4, 256);
+    L.tmp_bytes = fmd_park_sort_temp_bytes(n);
+    L.tmp = o; o += align_up(L.tmp_bytes, 256);
+    L.batch_area = o; o += fmd_ovlp_work_bytes(batch, max_len, min_match);
+    L.total = o;
+    return L;
+}
+extern "C" size_t fmd_ovlp_sorted_work_bytes(size_t n, size_t batch, uint32_t max_len, int min_match)
+{
+    if (batch == 0 || batch > n) batch = n;
+    return sorted_layout(n, batch, max_len, min_match).total;
+}
+// can the two-pass form be used at all?  (nothing may be pushed inside the head; a parked stash is two 16-byte groups of the row)
+static bool sorted_eligible(const fmd_dev *h, size_t n, int min_match, uint32_t max_len)
+{
+    const char *e = getenv("FMD_OVLP_SORT");   // A/B switch: 0 = batches in id order through the one-pass walk
+    if (e && atoi(e) == 0) return false;
+    return n < 0xffffff00ull && min_match >= (int)FMD_WALK_SPLIT && max_len >= FMD_WALK_SPLIT && h->ptab_d < (int)FMD_WALK_SPLIT && !getenv("FMD_OVLP_UNFUSED");
+}
+
+extern "C" int fmd_ovlp_sorted_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_t *d_ids, int min_match, uint32_t max_len,
+                                   uint32_t max_nei, fmd_ovlp_rec_t *d_rec, fmd_intv_t *d_nei, uint8_t *d_seq, uint32_t seq_stride,
+                                   void *d_work, size_t work_bytes, size_t batch)
+{
+    if (!h || (n && (!d_ids || !d_rec || !d_nei || !d_seq || !d_work)) || max_len == 0 || max_nei == 0 || min_match < 0) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    if (n >= 0xffffff00ull || fmd_ovlp_list_cap(max_len, min_match) >= 4096) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream_;
+    if (batch == 0 || batch > n) batch = n;
+    if (!sorted_eligible(h, n, min_match, max_len)) {   // the same strands in id order, batch by batch
+        if (work_bytes < fmd_ovlp_work_bytes(batch, max_len, min_match)) return FMD_E_ARG;
+        for (size_t b = 0; b < n; b += batch) {
+            const size_t np = n - b < batch ? n - b : batch;
+            const int rc = fmd_ovlp_dev(h, stream_, np, d_ids + b, min_match, max_len, max_nei, d_rec + b, d_nei + b * (size_t)max_nei,
+                                        d_seq + b * (size_t)seq_stride, seq_stride, d_work, work_bytes);
+            if (rc != FMD_OK) return rc;
+        }
+        return FMD_OK;
+    }
+    const SortedLayout L = sorted_layout(n, batch, max_len, min_match);
+    if (work_bytes < L.total) return FMD_E_ARG;
+    uint8_t *w = (uint8_t *)d_work;
+    FmdWalkPark *park = (FmdWalkPark *)(w + L.park);
+    uint32_t *sorted = (uint32_t *)(w + L.vals_b);
+    const FmdIndexView ix = fmd_view(h);
+    // pass 1: every strand FMD_WALK_SPLIT bases in (its stash so far goes into the second half of its park row)
+    {
+        uint32_t *q = fmd_next_queue(h, st);
+        int grid = fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16);
+        { const char *e = getenv("FMD_HEAD_WAVES"); if (e && atoi(e) > 0 && grid > h->n_cu * atoi(e)) grid = h->n_cu * atoi(e); }
+        k_ovl_walk<WALK_HEAD><<<grid, 64, 0, st>>>(ix, n, d_ids, min_match, (uint8_t *)park + 32, (uint32_t)sizeof(FmdWalkPark), 0, nullptr, d_rec,
+                                                nullptr, seq_stride, q, 0, park, nullptr);
+    }
+    // the order: rows sorted by the minimizer of the bases each strand has shown so far
+    {
+        const int rc = fmd_park_sort(st, n, park, (uint32_t *)(w + L.keys_a), (uint32_t *)(w + L.keys_b), (uint32_t *)(w + L.vals_a), sorted, w + L.tmp, L.tmp_bytes);
+        if (rc != FMD_OK) return rc;
+    }
+    // pass 2 + fm6_get_nei, batch by batch in that order
+    OvlBatch o;
+    o.h = h; o.ix = ix; o.ids = d_ids; o.min_match = min_match; o.max_len = max_len; o.max_nei = max_nei; o.seq_stride = seq_stride;
+    o.stride_r = (uint32_t)align_up(max_len, 16);
+    o.cap = fmd_ovlp_list_cap(max_len, min_match);
+    o.srev = w + L.batch_area;
+    o.listA = (fmd_intv_t *)(o.srev + align_up(batch * (size_t)o.stride_r, 256));
+    o.listB = (fmd_intv_t *)((uint8_t *)o.listA + align_up(batch * (size_t)o.cap * sizeof(fmd_intv_t), 256));
+    o.cls = (uint32_t *)((uint8_t *)o.listB + align_up(batch * (size_t)o.cap * sizeof(fmd_intv_t), 256));
+    o.rec = d_rec; o.nei = d_nei; o.seq = d_seq; o.park = park;
+    for (size_t b = 0; b < n; b += batch) {
+        const size_t np = n - b < batch ? n - b : batch;
+        o.gidx = sorted + b;
+        ovl_phase_a(o, st, 0, np, 0);
+        const int rc = ovl_phase_b(o, st, 0, np, 0, 0, 0);
+        if (rc != FMD_OK) return rc;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fmd_set_hip_error(e, "sorted overlap job"); return FMD_E_HIP; }
     return FMD_OK;
 }
 
@@ -1052,8 +1201,8 @@ extern "C" int fmd_seqinfo_dev(fmd_dev_t *h, void *stream_, size_t n, const uint
     uint8_t *srev = (uint8_t *)d_work;
     fmd_intv_t *listA = (fmd_intv_t *)((uint8_t *)d_work + align_up(n * (size_t)stride_r, 256));
     uint32_t *q0 = fmd_next_queue(h, st);
-    k_ovl_walk<<<fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16), 64, 0, st>>>(fmd_view(h), n, d_ids, 0, srev, stride_r, cap, listA, d_rec,
-                                                                             d_seq, seq_stride, q0, 1);
+    k_ovl_walk<WALK_WHOLE><<<fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16), 64, 0, st>>>(fmd_view(h), n, d_ids, 0, srev, stride_r, cap, listA, d_rec,
+                                                                                         d_seq, seq_stride, q0, 1, nullptr, nullptr);
     launch_seq_out(st, n, max_len, srev, stride_r, d_rec, 0, 1, d_seq, seq_stride);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "k_ovl_walk"); return FMD_E_HIP; }

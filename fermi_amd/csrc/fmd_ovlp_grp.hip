@@ -43,14 +43,14 @@ static_assert(GRP_POOL <= 32, "the region ends with 32 block numbers");
 #define CLS_THREADS 1024
 #define CLS_LISTS FMD_CLS_LISTS            // general class k = k, slow = FMD_GRP_CLASSES, fast class k = FMD_GRP_CLASSES + 1 + k (+ FMD_GRP_CLASSES: 64-bit masks)
 __global__ __launch_bounds__(CLS_THREADS) void k_ovl_classify(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, const fmd_intv_t *__restrict__ listA,
-                                                              uint32_t cap, FmdOvlClasses cl, int use_fast)
+                                                              uint32_t cap, FmdOvlClasses cl, int use_fast, const uint32_t *__restrict__ gidx)
 {
     __shared__ uint32_t wcnt[CLS_THREADS / 64][CLS_LISTS], base[CLS_LISTS];
     const size_t i = (size_t)blockIdx.x * CLS_THREADS + threadIdx.x;
     int cls = -1;
     uint32_t m = 0, len = 0;
     if (i < n) {
-        const fmd_ovlp_rec_t *o = rec + i;
+        const fmd_ovlp_rec_t *o = rec + (gidx ? (size_t)gidx[i] : i);   // (sorted batches: the record's row is not the slot, fmd_ovlp_sorted_dev)
         if (o->status == 0 && o->n_ovlp > 0 && !(o->flags & FMD_OVLP_F_OVERFLOW)) {
             m = (uint32_t)o->n_ovlp; len = (uint32_t)o->len;
             // the widest candidate is the last one (shortest overlap): the group kernels count
@@ -93,7 +93,8 @@ template <int G>
 __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
                                                     uint32_t cap, const fmd_intv_t *__restrict__ listA, fmd_ovlp_rec_t *__restrict__ rec,
                                                     fmd_intv_t *__restrict__ nei_out, uint32_t max_nei, uint8_t *__restrict__ seq_out,
-                                                    uint32_t seq_stride, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_n)
+                                                    uint32_t seq_stride, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_n,
+                                                    const uint32_t *__restrict__ gidx)
 {
     __shared__ uint4 lds[GRP_LDS_U4];
     uint4 *pool = lds + GRP_SLOTS_U4, *stage = pool;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
 
     // group-uniform strand state (identical in all lanes of the group)
     bool active = false;
-    uint32_t sid = 0, n_nei = 0, flags = 0;
+    uint32_t sid = 0, gs = 0, n_nei = 0, flags = 0;   // sid: the strand's slot in the batch (listA rows, work lists); gs: its row in rec / nei_out / seq_out
     // bits 8..24 of `flags` hold lfork (FMD_LFORK_* of include/fmd_hip.h) while the strand is resident; bit 24 = closed
 #define LF_SHIFT 8
 #define LF_GET(f) (((f) >> LF_SHIFT) & 0x1ffffu)
@@ -120,14 +121,14 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
     uint32_t pos = 0; int cat = 0;
     // prefetch pipeline: 0 empty, 1 descriptor in flight, 2 candidates in flight / ready
     int pf = 0;
-    uint32_t d_sid = 0, d_meta = 0;
+    uint32_t d_sid = 0, d_meta = 0, d_gs = 0;
     uint4 pa = make_uint4(0, 0, 0, 0), pb = make_uint4(0, 0, 0, 0);
 
     for (;;) {
         // ---- admission
         if (!active && pf == 2) {
             const uint32_t m = d_meta & 0xffff;
-            sid = d_sid; ori_l = (int)(d_meta >> 16); round = 0; n_nei = 0; flags = 0; nei0_info = 0;
+            sid = d_sid; gs = d_gs; ori_l = (int)(d_meta >> 16); round = 0; n_nei = 0; flags = 0; nei0_info = 0;
             alive = (uint32_t)j < m;
             { const FmdCand cd = cand_decode(pa, pb); x0 = cd.x0; x1 = cd.x1; sz = cd.sz; pos = (uint32_t)ori_l - cd.depth; cat = 0; } // stored: suffix depth
             active = true;
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
         if (pf == 1) { // descriptor has arrived: fetch this lane's candidate
             const uint32_t m = d_meta & 0xffff;
             if ((uint32_t)j < m) { const uint4 *q = (const uint4 *)(listA + d_sid * (size_t)cap + (cap - m) + j); pa = q[0]; pb = q[1]; }
+            d_gs = gidx ? gidx[d_sid] : d_sid;
             pf = 2;
         } else if (pf == 0 && idx < N) {
             d_sid = list[2 * (size_t)idx]; d_meta = list[2 * (size_t)idx + 1];
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
                     todo &= todo - 1;
                 } else if (nei_todo == 2) { nei_r1 = r; nei_todo = 1; }
                 else if (nei_todo == 1) {
-                    if (nei_k < max_nei) store_entry(nei_out + sid * (size_t)max_nei + nei_k, r, ix.cnt[0] + nei_r1, sz, (uint64_t)ori_l - pos);
+                    if (nei_k < max_nei) store_entry(nei_out + gs * (size_t)max_nei + nei_k, r, ix.cnt[0] + nei_r1, sz, (uint64_t)ori_l - pos);
                     nei_todo = 0;
                 }
             }
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
                 if (j == 0) { const uint32_t k = atomicAdd(slow_n, 1u); slow_list[k] = sid; }
                 active = false; alive = false;
             } else if (n_new > 0) { // next round (unitig.c:137-153)
-                if (j == 0 && (uint32_t)(ori_l + round) < seq_stride) seq_out[sid * (size_t)seq_stride + ori_l + round] = (uint8_t)comp6(first_c);
+                if (j == 0 && (uint32_t)(ori_l + round) < seq_stride) seq_out[gs * (size_t)seq_stride + ori_l + round] = (uint8_t)comp6(first_c);
                 ++round;
                 alive = j < n_new;
                 if (alive) {
@@ -324,11 +326,11 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
                     sz = (uint64_t)b.y << 32 | b.x; pos = b.z; cat = (int)b.w;
                 }
             } else { // every path is closed (unitig.c:154-178)
-                if (j == 0) rec[sid].lfork = (uint16_t)(LF_GET(flags) & 0xffffu);  // valid whatever happens to the record below
+                if (j == 0) rec[gs].lfork = (uint16_t)(LF_GET(flags) & 0xffffu);  // valid whatever happens to the record below
                 if (n_nei == 1 && (flags & FMD_OVLP_F_FORKED)) { // fake fork: the fix-up needs the slow kernel
                     if (j == 0) { const uint32_t k = atomicAdd(slow_n, 1u); slow_list[k] = sid; }
                 } else if (j == 0) {
-                    fmd_ovlp_rec_t *o = rec + sid;
+                    fmd_ovlp_rec_t *o = rec + gs;
                     o->rbeg = n_nei ? ori_l - (int)(uint32_t)nei0_info : -1;
                     o->ext_len = n_nei > 1 ? 0 : round;
                     o->n_nei = (int32_t)n_nei;
@@ -399,7 +401,8 @@ __global__ __launch_bounds__(64, 5) void k_ovl_nei_fast(FmdIndexView ix, const u
                                                      uint32_t cap, const fmd_intv_t *__restrict__ listA, fmd_ovlp_rec_t *__restrict__ rec,
                                                      fmd_intv_t *__restrict__ nei_out, uint32_t max_nei, uint8_t *__restrict__ seq_out,
                                                      uint32_t seq_stride, uint32_t *__restrict__ gen_list, uint32_t *__restrict__ gen_n,
-                                                     uint32_t *__restrict__ bail_n, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_n)
+                                                     uint32_t *__restrict__ bail_n, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_n,
+                                                     const uint32_t *__restrict__ gidx)
 {
     using W = FastW<M>;
     constexpr int S = 64 / G;
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(64, 5) void k_ovl_nei_fast(FmdIndexView ix, const u
 
     // group-uniform strand state
     bool active = false;
-    uint32_t sid = 0, meta = 0, n_nei = 0, lf = 0, nei0 = 0, szw = 1, round = 0;
+    uint32_t sid = 0, gs = 0, meta = 0, n_nei = 0, lf = 0, nei0 = 0, szw = 1, round = 0;   // sid: slot in the batch; gs: row in rec / nei_out / seq_out
     uint64_t X1 = 1;                                              // start of the group's window = x[1] of the widest live candidate
     // the lane's candidate: its range is [X1 + d, X1 + d + sz) on the x[1] side
     bool alive = false;
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(64, 5) void k_ovl_nei_fast(FmdIndexView ix, const u
     M D = 0;
     uint64_t r0 = 0;
     int pf = 0;
-    uint32_t d_sid = 0, d_meta = 0;
+    uint32_t d_sid = 0, d_meta = 0, d_gs = 0;
     uint4 pa = make_uint4(0, 0, 0, 0), pb = make_uint4(0, 0, 0, 0);
     // Strands handed on to the general kernel go to slots of its list that the wave reserves FMD_FAST_CHUNK at a time (one atomic on
     // the list counter per chunk; one per strand serialises: 5*10^6 atomics on one address cost 45 ms on reads with 1 % errors);
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(64, 5) void k_ovl_nei_fast(FmdIndexView ix, const u
         // ---- admission
         if (!active && pf == 2) {
             const uint32_t m = d_meta & 0xffff;
-            sid = d_sid; meta = d_meta; round = 0; n_nei = 0; lf = 0; nei0 = 0;
+            sid = d_sid; gs = d_gs; meta = d_meta; round = 0; n_nei = 0; lf = 0; nei0 = 0;
             alive = (uint32_t)j < m;
             const FmdCand cd = cand_decode(pa, pb);
             const int wl = gbase + (int)m - 1;                   // the widest candidate is the last
@@ -481,6 +484,7 @@ __global__ __launch_bounds__(64, 5) void k_ovl_nei_fast(FmdIndexView ix, const u
         if (pf == 1) {
             const uint32_t m = d_meta & 0xffff;
             if ((uint32_t)j < m) { const uint4 *q = (const uint4 *)(listA + d_sid * (size_t)cap + (cap - m) + j); pa = q[0]; pb = q[1]; }
+            d_gs = gidx ? gidx[d_sid] : d_sid;
             pf = 2;
         } else if (pf == 0 && idx < N) {
             d_sid = list[2 * (size_t)idx]; d_meta = list[2 * (size_t)idx + 1];
@@ -572,14 +576,14 @@ __global__ __launch_bounds__(64, 5) void k_ovl_nei_fast(FmdIndexView ix, const u
                 if (nei_g) {
                     if (n_nei == 0) nei0 = ori_l - (uint32_t)__shfl((int)pos, gbase + f);   // info of nei[0] decides rbeg (unitig.c:157)
                     if (is_nei && j == f && n_nei < max_nei)
-                        store_entry(nei_out + sid * (size_t)max_nei + n_nei, r0, ix.cnt[0] + Rz + W::popc(~(X | Y | Z) & W::below(d)), sz, (uint64_t)(ori_l - pos));
+                        store_entry(nei_out + gs * (size_t)max_nei + n_nei, r0, ix.cnt[0] + Rz + W::popc(~(X | Y | Z) & W::below(d)), sz, (uint64_t)(ori_l - pos));
                     ++n_nei;
                 }
                 if (n_nei > max_nei) { // more neighbours than the caller has room for: the lane-per-strand kernel reports it
                     if (j == 0) { const uint32_t k = atomicAdd(slow_n, 1u); slow_list[k] = sid; }
                     active = false; alive = false;
                 } else if (child_g) { // next round (unitig.c:137-153)
-                    if (j == 0 && ori_l + round < seq_stride) seq_out[sid * (size_t)seq_stride + ori_l + round] = (uint8_t)(5 - cs);   // comp6, cs in 1..4
+                    if (j == 0 && ori_l + round < seq_stride) seq_out[gs * (size_t)seq_stride + ori_l + round] = (uint8_t)(5 - cs);   // comp6, cs in 1..4
                     ++round;
                     const int wl = gbase + 31 - __clz((int)child_g);                 // the widest child
                     const uint32_t before = W::popc(Cw & W::below(d));                // cs's of the window before my range
@@ -590,7 +594,7 @@ __global__ __launch_bounds__(64, 5) void k_ovl_nei_fast(FmdIndexView ix, const u
                     D = Dc; sz = nc; d = alive2 ? before - wb : 0u; alive = alive2;
                 } else { // every path is closed (unitig.c:154-178); nothing forked, so no fix-up
                     if (j == 0) {
-                        fmd_ovlp_rec_t *o = rec + sid;
+                        fmd_ovlp_rec_t *o = rec + gs;
                         o->lfork = (uint16_t)(lf & 0xffffu);
                         o->rbeg = n_nei ? (int)(ori_l - nei0) : -1;
                         o->ext_len = n_nei > 1 ? 0 : (int)round;
@@ -617,12 +621,12 @@ int fmd_nei_fast_available(void) { return FMD_BLK64 ? 1 : 0; }
 static inline int fast_grid(int waves) { return waves < FMD_FAST_MAX_WAVES ? waves : FMD_FAST_MAX_WAVES; }   // (the hand-over lists have room for this many waves' holes)
 void fmd_launch_nei_fast(int cls, int wide, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                          const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
-                         uint32_t seq_stride, uint32_t *gen_list, uint32_t *gen_n, uint32_t *bail_n, uint32_t *slow_list, uint32_t *slow_n)
+                         uint32_t seq_stride, uint32_t *gen_list, uint32_t *gen_n, uint32_t *bail_n, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx)
 {
 #if FMD_BLK64
     const char *e = getenv("FMD_FAST_WAVES"); // A/B knob: resident waves per CU
     if (e && atoi(e) > 0 && (per_cu_cap <= 0 || atoi(e) < per_cu_cap)) per_cu_cap = atoi(e);
-#define FAST_LAUNCH(K, M) k_ovl_nei_fast<fmd_grp_size(K), M><<<fast_grid(n_cu * grp_cap(fast_blocks_per_cu<fmd_grp_size(K), M>(), per_cu_cap)), 64, 0, st>>>(ix, list, list_n, cap, listA, rec, nei_out, max_nei, seq_out, seq_stride, gen_list, gen_n, bail_n, slow_list, slow_n)
+#define FAST_LAUNCH(K, M) k_ovl_nei_fast<fmd_grp_size(K), M><<<fast_grid(n_cu * grp_cap(fast_blocks_per_cu<fmd_grp_size(K), M>(), per_cu_cap)), 64, 0, st>>>(ix, list, list_n, cap, listA, rec, nei_out, max_nei, seq_out, seq_stride, gen_list, gen_n, bail_n, slow_list, slow_n, gidx)
 #define FAST_LAUNCH2(K) do { if (wide) FAST_LAUNCH(K, uint64_t); else FAST_LAUNCH(K, uint32_t); } while (0)
     switch (cls) {
     case 0: FAST_LAUNCH2(0); break;
@@ -654,9 +658,9 @@ static int grp_blocks_per_cu(void)
 }
 void fmd_launch_nei_grp(int cls, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                         const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
-                        uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n)
+                        uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx)
 {
-#define GRP_LAUNCH(K) k_ovl_nei_grp<fmd_grp_size(K)><<<n_cu * grp_cap(grp_blocks_per_cu<fmd_grp_size(K)>(), per_cu_cap), 64, 0, st>>>(ix, list, list_n, cap, listA, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n)
+#define GRP_LAUNCH(K) k_ovl_nei_grp<fmd_grp_size(K)><<<n_cu * grp_cap(grp_blocks_per_cu<fmd_grp_size(K)>(), per_cu_cap), 64, 0, st>>>(ix, list, list_n, cap, listA, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n, gidx)
     switch (cls) {
     case 0: GRP_LAUNCH(0); break;
     case 1: GRP_LAUNCH(1); break;
@@ -666,7 +670,7 @@ void fmd_launch_nei_grp(int cls, int n_cu, int per_cu_cap, hipStream_t st, const
     }
 #undef GRP_LAUNCH
 }
-void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, const fmd_intv_t *listA, uint32_t cap, FmdOvlClasses cl, int use_fast)
+void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, const fmd_intv_t *listA, uint32_t cap, FmdOvlClasses cl, int use_fast, const uint32_t *gidx)
 {
-    k_ovl_classify<<<(unsigned)((n + CLS_THREADS - 1) / CLS_THREADS), CLS_THREADS, 0, st>>>(n, rec, listA, cap, cl, use_fast);
+    k_ovl_classify<<<(unsigned)((n + CLS_THREADS - 1) / CLS_THREADS), CLS_THREADS, 0, st>>>(n, rec, listA, cap, cl, use_fast, gidx);
 }

@@ -206,6 +206,18 @@ size_t fmd_ovlp_work_bytes(size_t n, uint32_t max_len, int min_match);
 int fmd_ovlp_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_ids, int min_match, uint32_t max_len,
                  uint32_t max_nei, fmd_ovlp_rec_t *d_rec, fmd_intv_t *d_nei, uint8_t *d_seq, uint32_t seq_stride,
                  void *d_work, size_t work_bytes);
+/* The same records for ALL n ids in one call, computed in an order that keeps neighbours on the genome in flight together
+ * (fm6_unitig hands its workers the ids in input order, unitig.c:394-404; any order gives the same records, and the order decides
+ * how often a rank block is found in cache).  Two strands whose last bases lie d positions apart on the genome visit the same rank
+ * blocks d steps apart; in input order each such visit is a DRAM miss.  Pass 1 takes every strand 32 bases in and parks it (64 bytes
+ * per strand); the strands are sorted by the minimizer of those 32 bases; pass 2 + fm6_get_nei then run batch by batch in that
+ * order and write row i of d_rec / d_nei / d_seq for ids[i] as fmd_ovlp_dev does -- byte for byte.  `batch` strands share the work
+ * area of one fmd_ovlp_dev call (0 = n); work_bytes >= fmd_ovlp_sorted_work_bytes(n, batch, ..).  Where the two-pass form does not
+ * apply (min_match < 32, FMD_OVLP_SORT=0) the batches are taken in id order. */
+size_t fmd_ovlp_sorted_work_bytes(size_t n, size_t batch, uint32_t max_len, int min_match);
+int fmd_ovlp_sorted_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_ids, int min_match, uint32_t max_len,
+                        uint32_t max_nei, fmd_ovlp_rec_t *d_rec, fmd_intv_t *d_nei, uint8_t *d_seq, uint32_t seq_stride,
+                        void *d_work, size_t work_bytes, size_t batch);
 /* Optional second step over the same buffers: check_left_simple (unitig.c:186-204) for every
  * strand with a unique neighbour -> rec.reserved (the unitig walk needs it; plain overlap
  * discovery does not, and records of fmd_ovlp_dev alone carry reserved = 2). */
