@@ -355,13 +355,24 @@ class OverlapJob:
         self.rec = torch.zeros(self.n * 64, dtype=torch.uint8, device=dev)
         self.nei = torch.zeros(self.n * self.max_nei * 32, dtype=torch.uint8, device=dev)
         self.seq = torch.zeros(self.n * self.stride, dtype=torch.uint8, device=dev)
-        self.wb = api.lib().fmd_ovlp_work_bytes(self.batch, L, min_match)
+        # the whole shard is ONE job (fmd_ovlp_sorted_dev): every strand 32 bases in, the strands sorted by the minimizer of those
+        # bases, the rest batch by batch in that order; the work area holds the parked strands (64 B each), the sort arrays and the
+        # work area of one batch
+        self.wb = api.lib().fmd_ovlp_sorted_work_bytes(self.n, self.batch, L, min_match)
         self.work = torch.empty(self.wb, dtype=torch.uint8, device=dev)
         self.stream = torch.cuda.current_stream()
         self.sh = C.c_void_p(self.stream.cuda_stream)
         self.packed = None
 
     def compute(self, Lb=None, h=None):
+        Lb = Lb or self.api.lib()
+        h = h or self.index.h
+        self.api.check(Lb.fmd_ovlp_sorted_dev(h, self.sh, self.n, self.ids.data_ptr(), self.min_match, self.L, self.max_nei,
+                                              self.rec.data_ptr(), self.nei.data_ptr(), self.seq.data_ptr(), self.stride,
+                                              self.work.data_ptr(), self.wb, self.batch))
+
+    def compute_in_id_order(self, Lb=None, h=None):
+        """The same strands batch by batch in id order through the one-pass walk (fmd_ovlp_dev): rounds 1-2's step, kept as the A/B."""
         Lb = Lb or self.api.lib()
         h = h or self.index.h
         for o in range(0, self.n, self.batch):
@@ -461,18 +472,31 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
         out["record_gather_rccl"] = {"ms_per_step_pack_plus_gather": g_ms, "bytes_received_by_rank0": tot,
                                      "bytes_per_strand": tot / max(1, n_ids - job.n), "check": gather_note}
         return out, job
-    # ---- N = 1: pipelined == serial order, device-byte model, CPU baseline
-    if job.batch >= (1 << 21) and "FMD_OVLP_PIPE" not in os.environ:
+    # ---- N = 1: the same strands in id order (the one-pass walk of rounds 1-2), same box, same run: time and bytes
+    if os.environ.get("FMD_BENCH_ID_ORDER_AB", "1") != "0":
         keep = (job.rec, job.nei, job.seq)
         job.rec, job.nei, job.seq = torch.zeros_like(job.rec), torch.zeros_like(job.nei), torch.zeros_like(job.seq)
-        os.environ["FMD_OVLP_PIPE"] = "4,8,8,8"   # the two-stream pipeline (no longer the default) against the serial order just timed
-        try:
-            job.compute()
-            torch.cuda.synchronize()
-        finally:
-            del os.environ["FMD_OVLP_PIPE"]
-        same = torch.equal(job.rec, keep[0]) and torch.equal(job.nei, keep[1]) and torch.equal(job.seq, keep[2])
-        out["pipelined_vs_serial_order"] = "identical (records, neighbours, sequences of all %d strands; FMD_OVLP_PIPE=4,8,8,8 against the default serial order)" % n_ids if same else "MISMATCH"
+        job.compute_in_id_order()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(job.stream)
+        for _ in range(2):
+            job.compute_in_id_order()
+        e1.record(job.stream)
+        torch.cuda.synchronize()
+        g0 = keep[0].view(torch.int32).view(job.n, 16)
+        same = torch.equal(job.rec, keep[0])
+        for o in range(0, job.n, 1 << 22):   # neighbours up to n_nei, sequence rows up to len + ext_len (in pieces: the masks are as large as the arrays)
+            e = min(job.n, o + (1 << 22))
+            nn = g0[o:e, 13].clamp(0, job.max_nei)
+            km = (torch.arange(job.max_nei, device=dev)[None, :] < nn[:, None])[:, :, None]
+            na, nb = keep[1].view(torch.int64).view(job.n, job.max_nei, 4)[o:e], job.nei.view(torch.int64).view(job.n, job.max_nei, 4)[o:e]
+            same = same and not bool(((na != nb) & km).any())
+            used = (g0[o:e, 8] + g0[o:e, 12].clamp(min=0)).clamp(0, job.stride)
+            sm = torch.arange(job.stride, device=dev)[None, :] < used[:, None]
+            same = same and not bool(((keep[2].view(job.n, job.stride)[o:e] != job.seq.view(job.n, job.stride)[o:e]) & sm).any())
+        out["id_order_one_pass_walk"] = {"ms_per_step": e0.elapsed_time(e1) / 2, "what": "fmd_ovlp_dev batch by batch over ids in input order (the step of rounds 1-2), 2 passes on this box right after the timed steps",
+                                         "same_results": "identical (records, neighbours, sequences + appended bases of all %d strands)" % n_ids if same else "MISMATCH"}
         job.rec, job.nei, job.seq = keep
     ctr = Counter(api, fmd_path, local_rank)
     lines = ctr.run(job.compute)
@@ -484,14 +508,16 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
     n_neis = int(np.minimum(g_rec["n_nei"][ok_rows], job.max_nei).sum())
     n_ext = int(g_rec["ext_len"][ok_rows].sum())
     stride_r = (L + 15) // 16 * 16
-    streams = {"ids": 8 * n_ids, "tail_table": 0 if os.environ.get("FMD_TAIL_TABLE") == "0" else 8 * n_ids, "stash_write_and_read": 2 * stride_r * n_ids, "sequence_rows_out": L * n_ids + 32 * n_ext,
+    streams = {"ids": 2 * 8 * n_ids, "tail_table": 0 if os.environ.get("FMD_TAIL_TABLE") == "0" else 2 * 8 * n_ids, "stash_write_and_read": 2 * stride_r * n_ids, "sequence_rows_out": L * n_ids + 32 * n_ext,
+               "head_admission_records_write_and_read": 2 * 32 * n_ids, "parked_strands_write_read_twice": 3 * 64 * n_ids,
+               "two_sorts_keys_and_rows": 2 * (2 * 8 + 4 * 2 * 8) * n_ids, "slot_to_row_map_reads": 4 * 4 * n_ids,
                "records_write_classify_read_result_write": 3 * 64 * n_ids, "work_lists": 16 * n_ids,
                "candidates_write_and_read": 2 * 32 * n_cand, "classify_widest_candidate": 64 * n_ids, "neighbours": 32 * n_neis}
     io = sum(streams.values())
     dev_bytes = None if lines is None else (lines[0] + lines[1]) * BLOCK_BYTES + io
     cn = oracle_counters(fmd_path, lambda o: o.overlap_batch(np.arange(4000, dtype=np.uint64), min_match, 100, 4, 1, check_left=False))
     qps = (cn["rank1a"] + cn["rank2a"] + cn["rank2a_spill"]) / 4000.0
-    out["roofline"] = roofline("k_ovl_walk + k_ovl_seq_out + k_ovl_classify + k_ovl_nei_fast<G, M> + k_ovl_nei_grp<G> + k_ovl_nei (one step = %d batches of %d strands)"
+    out["roofline"] = roofline("k_ovl_head_adm + k_ovl_walk<HEAD> + 2 radix sorts + per batch: k_ovl_walk<TAIL> + k_ovl_seq_out + k_ovl_classify + k_ovl_nei_fast<G, M> + k_ovl_nei_grp<G> + k_ovl_nei (one step = one job of %d batches of %d strands)"
                                % ((job.n + job.batch - 1) // job.batch, job.batch), kern_ms, dev_bytes,
                                {"rank_blocks": lines and lines[0], "prefix_table_lines": lines and lines[1], "stream_bytes": io, "streams": streams},
                                qps * BYTES_PER_RANK_QUERY * n_ids, "overlap@%d" % n_reads,
@@ -550,17 +576,19 @@ def bench_check_left(torch, api, job, n_reads, steps, warmup, fmd_path, ovl, loc
            "value": job.n * steps / wall, "unit": "strands/s", "ms_per_step": wall / steps * 1e3, "edges_checked": n_edges,
            "edges_left_to_the_exact_kernel": n_und, "back_bifurcations": int((g_rec["reserved"] == 1).sum()),
            "fraction_of_discovery_time": (wall / steps * 1e3) / ovl["ms_per_step"]}
-    ns = 4000
+    ns = min(job.n, 4000)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orcbind
+    sel = np.sort(np.random.default_rng(7).choice(job.n, ns, replace=False)).astype(np.uint64)
     o = orcbind.OrcIndex(fmd_path)
-    o.counters(); o.overlap_batch(np.arange(ns, dtype=np.uint64), job.min_match, 100, 4, 1, check_left=False); c0 = o.counters()
-    rec_o, _, _ = o.overlap_batch(np.arange(ns, dtype=np.uint64), job.min_match, 100, 4, 1, check_left=True); c1 = o.counters()
+    o.counters(); o.overlap_batch(sel, job.min_match, 100, 4, 1, check_left=False); c0 = o.counters()
+    rec_o, _, _ = o.overlap_batch(sel, job.min_match, 100, 4, 1, check_left=True); c1 = o.counters()
     o.close()
     q = {k: c1[k] - c0[k] for k in c1}
     qps = (q["rank1a"] + q["rank2a"] + q["rank2a_spill"]) / float(ns)
-    same = bool(np.array_equal(rec_o["reserved"], g_rec["reserved"][:ns]))
-    out["parity_vs_oracle_on_sample"] = "bit-exact (check_left_simple of ids 0..%d)" % (ns - 1) if same else "MISMATCH"
+    same = bool(np.array_equal(rec_o["reserved"], g_rec["reserved"][sel.astype(np.int64)]))
+    out["parity_vs_oracle_on_sample"] = ("bit-exact (check_left_simple of %d random ids, %d of them edges with a verdict, %d back-bifurcations)"
+                                         % (ns, int((rec_o["reserved"] != 2).sum()), int((rec_o["reserved"] == 1).sum()))) if same else "MISMATCH"
     # device bytes of the linked form: rec read twice + reserved written, neighbour x0/x1 read, row map written + read twice, links written
     io = job.n * (2 * 64 + 64 + 16 + 3 * 4 + 8) + n_und * 8
     ctr = Counter(api, fmd_path, local_rank)
@@ -783,7 +811,7 @@ def bench_raw_reads(torch, api, workload, dev, local_rank, n_reads, L, steps, wa
             km = bench_kmer(torch, api, index, n_sym, fmd_path, dev, local_rank, n_reads, steps, warmup)
             torch.cuda.empty_cache()
         if "overlap" in legs and os.environ.get("FMD_BENCH_RAW_OVERLAP", "1") != "0":
-            raw = bench_overlap_raw(torch, api, index, dev, n_reads, L, err)
+            raw = bench_overlap_raw(torch, api, index, dev, n_reads, L, err, fmd_path)
     finally:
         if os.path.exists(fmd_path):
             os.remove(fmd_path)
@@ -791,17 +819,18 @@ def bench_raw_reads(torch, api, workload, dev, local_rank, n_reads, L, steps, wa
     return sm, km, raw
 
 
-def bench_overlap_raw(torch, api, index, dev, n_reads, L, err):
-    """Not a BASELINE config: overlap discovery of one batch of strands on the RAW-read index (reads with errors fork; the fast
-    get_nei path hands the forked strands to the general group kernels), with the fast path and without, so that the headline --
-    measured on error-free reads, where every strand takes the fast path -- can be read for what it is."""
-    n_ids = min(2 * n_reads, 20_000_000)
+def bench_overlap_raw(torch, api, index, dev, n_reads, L, err, fmd_path):
+    """Not a BASELINE config: overlap discovery of ALL strands of the RAW-read index (reads with errors fork; the fast get_nei path
+    hands the forked strands to the general group kernels), with the fast path and without, so that the headline -- measured on
+    error-free reads, where every strand takes the fast path -- can be read for what it is.  Checked against the reference on
+    random ids (records + neighbours) and against the oracle's check_left_simple on random ids, where back-bifurcations exist."""
+    n_ids = 2 * n_reads
     job = OverlapJob(torch, api, index, dev, n_ids, 0, 1, L, 50)
-    out = {"what": "fm_retrieve + fm6_is_contained + fm6_get_nei (-l50) for the first %d sequence ids of the index of %d reads with %g substitutions per base" % (n_ids, n_reads, err)}
+    out = {"what": "fm_retrieve + fm6_is_contained + fm6_get_nei (-l50) for all %d sequence ids of the index of %d reads with %g substitutions per base, one sorted job" % (n_ids, n_reads, err)}
     saved = os.environ.get("FMD_OVLP_FAST")
     sums = {}
     try:
-        for key, val in (("ms_with_the_fast_get_nei_path", None), ("ms_general_group_kernels_only", "0")):
+        for key, val in (("ms_general_group_kernels_only", "0"), ("ms_with_the_fast_get_nei_path", None)):
             if val is None:
                 os.environ.pop("FMD_OVLP_FAST", None)
             else:
@@ -823,11 +852,55 @@ def bench_overlap_raw(torch, api, index, dev, n_reads, L, err):
         else:
             os.environ["FMD_OVLP_FAST"] = saved
     g = job.rec.view(torch.int32).view(job.n, 16)
+    ms = out["ms_with_the_fast_get_nei_path"]
     out["strands"] = job.n
-    out["strands_per_s"] = job.n / out["ms_with_the_fast_get_nei_path"] * 1e3
+    out["strands_per_s"] = job.n / ms * 1e3
+    out["reads_per_s"] = job.n / 2 / ms * 1e3
+    out["ms_per_20M_strands"] = ms * 2e7 / job.n
     out["with_neighbour"] = int((g[:, 13] > 0).sum().item())
     out["forked"] = int(((g[:, 14] & 1) != 0).sum().item())
     out["same_results_both_ways"] = len(set(sums.values())) == 1     # (sums of rbeg + ext_len + n_nei and of the first neighbours' intervals)
+    # ---- the results (fast path on) against the reference on random ids
+    g_rec = job.rec.cpu().numpy().view(api.OVLP_DT)
+    ns = min(n_ids, int(os.environ.get("FMD_BENCH_CPU_SAMPLE_OVLP_RAW", "100000")))
+    sel = np.sort(np.random.default_rng(5).choice(n_ids, ns, replace=False))
+    sel_d = torch.from_numpy(sel).to(dev)
+    g_nei_s = job.nei.view(n_ids, job.max_nei * 32)[sel_d].cpu().numpy().view(api.INTV_DT).reshape(ns, job.max_nei)
+    base, ok = cpu_overlap(fmd_path, sel, 50, g_rec[sel], g_nei_s)
+    out["cpu_baseline"] = base
+    out["parity_vs_cpu_on_sample"] = "bit-exact" if ok else "MISMATCH"
+    out["speedup_vs_cpu_all_cores"] = out["reads_per_s"] / base["value"]
+    # ---- check_left as the product runs it (lfork verdicts, exact kernel on the open edges) against the oracle's check_left_simple
+    job.alloc_link()
+    job.check_left_linked()
+    torch.cuda.synchronize()
+    g_rec = job.rec.cpu().numpy().view(api.OVLP_DT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orcbind
+    nc = min(n_ids, 4000)
+    selc = np.sort(np.random.default_rng(6).choice(n_ids, nc, replace=False)).astype(np.uint64)
+    o = orcbind.OrcIndex(fmd_path)
+    rec_o, _, _ = o.overlap_batch(selc, 50, 100, 4, usable_cpus(), check_left=True)
+    o.close()
+    same = bool(np.array_equal(rec_o["reserved"], g_rec["reserved"][selc.astype(np.int64)]))
+    out["check_left"] = {"edges_left_to_the_exact_kernel": int(job.n_und.item()), "back_bifurcations": int((g_rec["reserved"] == 1).sum()),
+                         "parity_vs_oracle_on_sample": ("bit-exact (check_left_simple of %d random ids: %d edges with a verdict, %d back-bifurcations among them)"
+                                                        % (nc, int((rec_o["reserved"] != 2).sum()), int((rec_o["reserved"] == 1).sum()))) if same else "MISMATCH"}
+    # ---- device bytes of one job (rank blocks counted by the instrumented build) over its time
+    ctr = Counter(api, fmd_path, index.device)
+    lines = ctr.run(job.compute)
+    ctr.close()
+    torch.cuda.synchronize()
+    ok_rows = (g_rec["status"] == 0) & ((g_rec["flags"] & api.OVLP_F_OVERFLOW) == 0)
+    n_cand = int(g_rec["n_ovlp"][ok_rows].sum())
+    io = n_ids * (16 + 16 + 2 * 112 + L + 3 * 64 + 16 + 64 + 64 + 3 * 64 + 80 + 16) + 2 * 32 * n_cand
+    dev_bytes = None if lines is None else (lines[0] + lines[1]) * BLOCK_BYTES + io
+    cn = oracle_counters(fmd_path, lambda oo: oo.overlap_batch(selc[:2000], 50, 100, 4, 1, check_left=False))
+    qps = (cn["rank1a"] + cn["rank2a"] + cn["rank2a_spill"]) / 2000.0
+    out["roofline"] = roofline("the sorted job on reads with errors (k_ovl_nei_grp<G> takes the forked strands)", ms, dev_bytes,
+                               {"rank_blocks": lines and lines[0], "prefix_table_lines": lines and lines[1], "stream_bytes": io,
+                                "streams": "as the headline's model (per strand: ids, tail, admission, parked state, sort arrays, stash, records, lists) + 64 B per candidate"},
+                               qps * BYTES_PER_RANK_QUERY * n_ids, "overlap_raw@%d" % n_reads, {"rank_queries_per_strand": qps})
     return out
 
 

@@ -289,6 +289,45 @@ def _ovlp(self, ids, min_match, max_len=100, max_nei=4, check_left=True):
 DevIndex.overlap = _ovlp
 
 
+def _ovlp_sorted(self, ids, min_match, max_len=100, max_nei=4, batch=0, check_left=False):
+    """fmd_ovlp_sorted_dev over device copies: the records of ALL ids from one job (every strand 32 bases in, the strands sorted by
+    the minimizer of those bases, the rest in that order, `batch` strands at a time).  Same arrays as overlap()."""
+    L = lib()
+    ids = np.ascontiguousarray(ids, dtype=np.uint64)
+    n = len(ids)
+    stride = 2 * ((max_len + 3) // 4 * 4)
+    rec = np.zeros(n, dtype=OVLP_DT); nei = np.zeros((n, max_nei), dtype=INTV_DT); seq = np.zeros((n, stride), dtype=np.uint8)
+    if n == 0:
+        return rec, nei, seq
+    wb = L.fmd_ovlp_sorted_work_bytes(n, batch, max_len, min_match)
+    ptrs = []
+    try:
+        for b in (ids.nbytes, rec.nbytes, nei.nbytes, seq.nbytes, wb):
+            p = C.c_void_p()
+            check(L.fmd_dev_malloc(self.device, max(b, 16), C.byref(p)))
+            ptrs.append(p)
+        d_ids, d_rec, d_nei, d_seq, d_work = ptrs
+        check(L.fmd_memcpy_h2d(d_ids, _ptr(ids), ids.nbytes, None))
+        for d, a in ((d_rec, rec), (d_nei, nei), (d_seq, seq)):   # zeroes: rows of short / contained strands are not written
+            check(L.fmd_memcpy_h2d(d, _ptr(a), a.nbytes, None))
+        check(L.fmd_ovlp_sorted_dev(self.h, None, n, d_ids, min_match, max_len, max_nei, d_rec, d_nei, d_seq, stride, d_work, wb, batch))
+        if check_left:
+            m = batch if 0 < batch < n else n
+            for o in range(0, n, m):
+                c = min(m, n - o)
+                check(L.fmd_ovlp_check_left_dev(self.h, None, c, min_match, max_len, C.c_void_p(d_rec.value + 64 * o), C.c_void_p(d_seq.value + stride * o), stride, d_work, wb))
+        check(L.fmd_dev_sync(self.h, None))
+        for d, a in ((d_rec, rec), (d_nei, nei), (d_seq, seq)):
+            check(L.fmd_memcpy_d2h(_ptr(a), d, a.nbytes, None))
+        return rec, nei, seq
+    finally:
+        for p in ptrs:
+            L.fmd_dev_free(p)
+
+
+DevIndex.overlap_sorted = _ovlp_sorted
+
+
 def _ovlp_pack(self, rec, nei, seq):
     """fmd_ovlp_pack_dev over host copies of a finished batch: (prec[OVLP_DT], off[u64, n+1], var[u8])."""
     L = lib()

@@ -34,9 +34,14 @@ struct fmd_ectab {
     int device, w, suf_len;
     uint64_t n_slots;              // power of two
     uint64_t *slots;               // device: kmer << 10 | val << 2 | best base, or EC_EMPTY
-    uint32_t *queue;               // device: ticket counter of the persistent kernel
+    uint32_t *queue;               // device: ticket counter of the persistent kernel (+ EC_FULL_FLAG)
+    void *buf[5]; size_t buf_bytes[5]; int buf_busy;   // device buffers of fmd_ecfix_batch, kept between calls (EcBuf)
 };
 #define EC_EMPTY (~0ull)
+// One triple encodes to EC_EMPTY itself: the 27-mer of 27 Ts (54 one bits) with the largest packed depths (255) and best base T.
+// k_ectab_fill does not store it -- it would read as an empty slot and the solid k-mer as a miss -- but raises queue[EC_FULL_FLAG],
+// and a look-up of that k-mer that runs into an empty slot answers from the flag.
+#define EC_FULL_FLAG 1
 
 __device__ __forceinline__ uint64_t ec_hash(uint64_t x)   // splitmix64 finaliser: the k-mers of a genome are anything but uniform
 {
@@ -46,13 +51,14 @@ __device__ __forceinline__ uint64_t ec_hash(uint64_t x)   // splitmix64 finalise
 }
 
 __global__ void k_ectab_fill(uint64_t n, int suf_len, const uint32_t *__restrict__ bucket, const uint32_t *__restrict__ key, const uint8_t *__restrict__ val,
-                             uint64_t *__restrict__ slots, uint64_t mask)
+                             uint64_t *__restrict__ slots, uint64_t mask, uint32_t *__restrict__ full_flag)
 {
     const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
         // the k-mer a look-up will present (correct.c:156-157): bucket = its low 2*suf_len bits, key >> 2 = the rest
         const uint64_t x = (uint64_t)(key[i] >> 2) << (2 * suf_len) | bucket[i];
         const uint64_t e = x << 10 | (uint64_t)val[i] << 2 | (key[i] & 3);
+        if (e == EC_EMPTY) { *full_flag = 1u; continue; }
         uint64_t p = ec_hash(x) & mask;
         for (;;) {
             const unsigned long long old = atomicCAS((unsigned long long *)(slots + p), (unsigned long long)EC_EMPTY, (unsigned long long)e);
@@ -63,12 +69,12 @@ __global__ void k_ectab_fill(uint64_t n, int suf_len, const uint32_t *__restrict
 }
 
 // kh_get(solid, h, key) of correct.c:156-157: -1, or val << 2 | best base
-__device__ __forceinline__ int ec_lookup(const uint64_t *__restrict__ slots, uint64_t mask, uint64_t x)
+__device__ __forceinline__ int ec_lookup(const uint64_t *__restrict__ slots, uint64_t mask, uint64_t x, bool full)
 {
     uint64_t p = ec_hash(x) & mask;
     for (;;) {
         const uint64_t e = slots[p];
-        if (e == EC_EMPTY) return -1;
+        if (e == EC_EMPTY) return (full && x == (EC_EMPTY >> 10)) ? 0x3ff : -1;
         if ((e >> 10) == x) return (int)(e & 0x3ff);
         p = (p + 1) & mask;
     }
@@ -177,7 +183,7 @@ __device__ __forceinline__ bool ec_seed(const EcRead &r, int w, EcSearch &S, uin
     return true;
 }
 
-__device__ __forceinline__ int ec_expand(const EcRead &r, int w, int step, const uint64_t *__restrict__ slots, uint64_t mask, EcSearch &S, uint4 *heap,
+__device__ __forceinline__ int ec_expand(const EcRead &r, int w, int step, const uint64_t *__restrict__ slots, uint64_t mask, bool full, EcSearch &S, uint4 *heap,
                                          uint64_t *trace, uint32_t trace_cap)
 {
     const int shift = (w - 1) << 1;
@@ -194,7 +200,7 @@ __device__ __forceinline__ int ec_expand(const EcRead &r, int w, int step, const
     int q = r.qual(i) - 33;
     q = q < EC_MAX_QUAL ? q : EC_MAX_QUAL;
     q = q < 3 ? 3 : q;
-    const int hit = ec_lookup(slots, mask, z.x);
+    const int hit = ec_lookup(slots, mask, z.x, full);
     bool ok = true;
     if (hit < 0) ok = ec_branch(heap, S.hn, trace, S.tn, trace_cap, z, b - 1, EC_MISS_PENALTY + (EC_MAX_QUAL - q), shift, 0);
     else {
@@ -213,7 +219,7 @@ __device__ __forceinline__ int ec_expand(const EcRead &r, int w, int step, const
                         z.x = (uint64_t)(r.base(i) - 1) << shift | z.x >> 2;
                     const int bi = r.base(i);
                     if (bi == 5) break;
-                    const int h2 = ec_lookup(slots, mask, z.x);
+                    const int h2 = ec_lookup(slots, mask, z.x, full);
                     if (h2 < 0 || bi != (h2 & 3) + 1) break;
                     const int v2 = h2 >> 2, depth = ec_depth(v2);
                     if (!((v2 & 7) <= 1 && depth >= EC_MIN_OCC && (double)depth / depth_last >= EC_MIN_OCC_RATIO)) break;
@@ -258,6 +264,7 @@ __global__ __launch_bounds__(64) void k_ecfix(size_t n, uint8_t *__restrict__ se
     size_t cur = 0;
     int ret0 = 0;
     bool busy = false, drained = false;
+    const bool full = queue[EC_FULL_FLAG] != 0;   // the one triple the table cannot hold (EC_FULL_FLAG)
     FmdTickets tk;
     fmd_tickets_init(tk, queue);
     for (;;) {
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(64) void k_ecfix(size_t n, uint8_t *__restrict__ se
         }
         if (__ballot(busy) == 0) { if (__ballot(!drained) == 0) break; else continue; }
         if (!busy) continue;
-        const int st = ec_expand(r, w, step, slots, mask, S, heap, trace, trace_cap);
+        const int st = ec_expand(r, w, step, slots, mask, full, S, heap, trace, trace_cap);
         if (st == EC_MORE) continue;
         if (st == EC_FULL) { info[cur] = (int32_t)EC_INFO_TRACE_FULL; busy = false; continue; }
         int ret = ec_close(r, S, trace);
@@ -297,6 +304,7 @@ extern "C" void fmd_ectab_free(fmd_ectab_t *t)
     if (!t) return;
     hipSetDevice(t->device);
     hipFree(t->slots); hipFree(t->queue);
+    for (int i = 0; i < 5; ++i) if (t->buf[i]) hipFree(t->buf[i]);
     free(t);
 }
 
@@ -318,10 +326,11 @@ extern "C" int fmd_ectab_build_dev(int device, void *stream_, int w, int suf_len
         return FMD_E_NOMEM;
     }
     FMD_HIP_TRY(hipMemsetAsync(t->slots, 0xff, t->n_slots * 8, st));
+    FMD_HIP_TRY(hipMemsetAsync(t->queue, 0, 64, st));
     if (n) {
         size_t blocks = (size_t)((n + 255) / 256);
         if (blocks > (1u << 20)) blocks = 1u << 20;
-        k_ectab_fill<<<(unsigned)blocks, 256, 0, st>>>(n, suf_len, d_bucket, d_key, d_val, t->slots, t->n_slots - 1);
+        k_ectab_fill<<<(unsigned)blocks, 256, 0, st>>>(n, suf_len, d_bucket, d_key, d_val, t->slots, t->n_slots - 1, t->queue + EC_FULL_FLAG);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "k_ectab_fill"); fmd_ectab_free(t); return FMD_E_HIP; }
@@ -379,7 +388,39 @@ extern "C" int fmd_ecfix_dev(fmd_ectab_t *t, void *stream_, size_t n, uint8_t *d
     return FMD_OK;
 }
 
-// Host form: reads whose trace overflows are run again, from their original bytes, with the trace doubled.
+// Device buffers of the host form, kept in the table handle between calls (`correct` calls it once per 10^6 reads: the work
+// area alone is 256 CUs x 16 waves x 64 lanes x ~12 KB).  One caller at a time owns them; a concurrent call allocates its own.
+struct EcBuf {
+    fmd_ectab *t; bool cached; void *p[5]; size_t bytes[5];
+    explicit EcBuf(fmd_ectab *t_) : t(t_), cached(false)
+    {
+        for (int i = 0; i < 5; ++i) { p[i] = nullptr; bytes[i] = 0; }
+        int expect = 0;
+        if (__atomic_compare_exchange_n(&t->buf_busy, &expect, 1, false, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED)) {
+            cached = true;
+            for (int i = 0; i < 5; ++i) { p[i] = t->buf[i]; bytes[i] = t->buf_bytes[i]; }
+        }
+    }
+    void *get(int i, size_t need)   // at least `need` bytes in buffer i (contents are not kept), nullptr when the device is out of memory
+    {
+        if (bytes[i] >= need && p[i]) return p[i];
+        if (p[i]) hipFree(p[i]);
+        p[i] = nullptr; bytes[i] = 0;
+        const size_t want = need + need / 8 + 256;
+        if (hipMalloc(&p[i], want) != hipSuccess) { (void)hipGetLastError(); p[i] = nullptr; return nullptr; }
+        bytes[i] = want;
+        return p[i];
+    }
+    ~EcBuf()
+    {
+        if (cached) {
+            for (int i = 0; i < 5; ++i) { t->buf[i] = p[i]; t->buf_bytes[i] = bytes[i]; }
+            __atomic_store_n(&t->buf_busy, 0, __ATOMIC_RELEASE);
+        } else for (int i = 0; i < 5; ++i) if (p[i]) hipFree(p[i]);
+    }
+};
+
+// Host form: reads whose trace overflows are run again, from their original bytes, with the trace four times as long.
 extern "C" int fmd_ecfix_batch(fmd_ectab_t *t, size_t n, uint8_t *seqs, uint8_t *quals, const uint64_t *off, int step, int32_t *info)
 {
     if (!t || (n && (!seqs || !quals || !off || !info))) return FMD_E_ARG;
@@ -387,62 +428,70 @@ extern "C" int fmd_ecfix_batch(fmd_ectab_t *t, size_t n, uint8_t *seqs, uint8_t 
     FMD_HIP_TRY(hipSetDevice(t->device));
     const uint64_t total = off[n] - off[0];
     uint32_t cap = 1024;
-    void *ds = nullptr, *dq = nullptr, *doff = nullptr, *dinfo = nullptr, *dwork = nullptr;
-    int rc = FMD_OK;
-    if (hipMalloc(&ds, total + 16) != hipSuccess || hipMalloc(&dq, total + 16) != hipSuccess || hipMalloc(&doff, (n + 1) * 8) != hipSuccess ||
-        hipMalloc(&dinfo, n * 4) != hipSuccess) rc = FMD_E_NOMEM;
-    uint64_t *rel = nullptr;   // offsets relative to the first read
-    if (rc == FMD_OK) {
-        rel = (uint64_t *)malloc((n + 1) * 8);
-        if (!rel) rc = FMD_E_NOMEM;
-        else for (size_t i = 0; i <= n; ++i) rel[i] = off[i] - off[0];
-    }
+    EcBuf B(t);
+    void *ds = B.get(0, total + 16), *dq = B.get(1, total + 16), *doff = B.get(2, (n + 1) * 8), *dinfo = B.get(3, n * 4);
+    if (!ds || !dq || !doff || !dinfo) return FMD_E_NOMEM;
+    std::vector<uint64_t> rel(n + 1);   // offsets relative to the first read
+    for (size_t i = 0; i <= n; ++i) rel[i] = off[i] - off[0];
     uint8_t *s0 = seqs + off[0], *q0 = quals + off[0];
-    if (rc == FMD_OK && (hipMemcpy(ds, s0, total, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dq, q0, total, hipMemcpyHostToDevice) != hipSuccess ||
-                         hipMemcpy(doff, rel, (n + 1) * 8, hipMemcpyHostToDevice) != hipSuccess)) rc = FMD_E_HIP;
-    std::vector<uint8_t> keep_s, keep_q;   // originals, for the re-runs (allocated only if one is needed)
-    if (rc == FMD_OK) {
+    FMD_HIP_TRY(hipMemcpy(ds, s0, total, hipMemcpyHostToDevice));
+    FMD_HIP_TRY(hipMemcpy(dq, q0, total, hipMemcpyHostToDevice));
+    FMD_HIP_TRY(hipMemcpy(doff, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    {
         const size_t wb = fmd_ecfix_work_bytes(t, n, cap);
-        if (hipMalloc(&dwork, wb) != hipSuccess) rc = FMD_E_NOMEM;
-        if (rc == FMD_OK) { keep_s.assign(s0, s0 + total); keep_q.assign(q0, q0 + total); }
-        if (rc == FMD_OK) rc = fmd_ecfix_dev(t, nullptr, n, (uint8_t *)ds, (uint8_t *)dq, (uint64_t *)doff, step, cap, (int32_t *)dinfo, dwork, wb);
-        if (rc == FMD_OK && (hipMemcpy(s0, ds, total, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(q0, dq, total, hipMemcpyDeviceToHost) != hipSuccess ||
-                             hipMemcpy(info, dinfo, n * 4, hipMemcpyDeviceToHost) != hipSuccess)) rc = FMD_E_HIP;
-        hipFree(dwork); dwork = nullptr;
+        void *dwork = B.get(4, wb);
+        if (!dwork) return FMD_E_NOMEM;
+        const int rc = fmd_ecfix_dev(t, nullptr, n, (uint8_t *)ds, (uint8_t *)dq, (uint64_t *)doff, step, cap, (int32_t *)dinfo, dwork, wb);
+        if (rc != FMD_OK) return rc;
     }
-    // re-runs
-    for (int attempt = 0; rc == FMD_OK && attempt < 12; ++attempt) {
-        std::vector<size_t> again;
-        for (size_t i = 0; i < n; ++i) if ((uint32_t)info[i] == EC_INFO_TRACE_FULL) again.push_back(i);
-        if (again.empty()) break;
+    FMD_HIP_TRY(hipMemcpy(info, dinfo, n * 4, hipMemcpyDeviceToHost));
+    // the reads to run again (rare: a trace of 1024 entries is enough for all but the most error-ridden reads): their ORIGINAL bytes
+    // are taken from the caller's arrays now, before the corrected batch is copied over them
+    std::vector<size_t> again;
+    for (size_t i = 0; i < n; ++i) if ((uint32_t)info[i] == EC_INFO_TRACE_FULL) again.push_back(i);
+    std::vector<uint64_t> ko(again.size() + 1, 0);
+    for (size_t k = 0; k < again.size(); ++k) ko[k + 1] = ko[k] + (rel[again[k] + 1] - rel[again[k]]);
+    std::vector<uint8_t> keep_s(ko.back() + 16), keep_q(ko.back() + 16);
+    for (size_t k = 0; k < again.size(); ++k) {
+        memcpy(keep_s.data() + ko[k], s0 + rel[again[k]], ko[k + 1] - ko[k]);
+        memcpy(keep_q.data() + ko[k], q0 + rel[again[k]], ko[k + 1] - ko[k]);
+    }
+    FMD_HIP_TRY(hipMemcpy(s0, ds, total, hipMemcpyDeviceToHost));
+    FMD_HIP_TRY(hipMemcpy(q0, dq, total, hipMemcpyDeviceToHost));
+    // re-runs: `todo` indexes `again` (and so the kept originals)
+    std::vector<size_t> todo(again.size());
+    for (size_t k = 0; k < todo.size(); ++k) todo[k] = k;
+    for (int attempt = 0; attempt < 12 && !todo.empty(); ++attempt) {
         cap *= 4;
-        const size_t m = again.size();
+        const size_t m = todo.size();
         std::vector<uint64_t> o2(m + 1, 0);
-        for (size_t k = 0; k < m; ++k) o2[k + 1] = o2[k] + (rel[again[k] + 1] - rel[again[k]]);
+        for (size_t k = 0; k < m; ++k) o2[k + 1] = o2[k] + (ko[todo[k] + 1] - ko[todo[k]]);
         std::vector<uint8_t> s2(o2[m] + 16), q2(o2[m] + 16);
         for (size_t k = 0; k < m; ++k) {
-            memcpy(s2.data() + o2[k], keep_s.data() + rel[again[k]], o2[k + 1] - o2[k]);
-            memcpy(q2.data() + o2[k], keep_q.data() + rel[again[k]], o2[k + 1] - o2[k]);
+            memcpy(s2.data() + o2[k], keep_s.data() + ko[todo[k]], o2[k + 1] - o2[k]);
+            memcpy(q2.data() + o2[k], keep_q.data() + ko[todo[k]], o2[k + 1] - o2[k]);
         }
         std::vector<int32_t> i2(m);
         const size_t wb = fmd_ecfix_work_bytes(t, m, cap);
-        if (hipMalloc(&dwork, wb) != hipSuccess) { rc = FMD_E_NOMEM; break; }
-        if (hipMemcpy(ds, s2.data(), o2[m], hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dq, q2.data(), o2[m], hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(doff, o2.data(), (m + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) rc = FMD_E_HIP;
-        if (rc == FMD_OK) rc = fmd_ecfix_dev(t, nullptr, m, (uint8_t *)ds, (uint8_t *)dq, (uint64_t *)doff, step, cap, (int32_t *)dinfo, dwork, wb);
-        if (rc == FMD_OK && (hipMemcpy(s2.data(), ds, o2[m], hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(q2.data(), dq, o2[m], hipMemcpyDeviceToHost) != hipSuccess ||
-                             hipMemcpy(i2.data(), dinfo, m * 4, hipMemcpyDeviceToHost) != hipSuccess)) rc = FMD_E_HIP;
-        hipFree(dwork); dwork = nullptr;
-        if (rc != FMD_OK) break;
+        void *dwork = B.get(4, wb);
+        if (!dwork) return FMD_E_NOMEM;
+        FMD_HIP_TRY(hipMemcpy(ds, s2.data(), o2[m], hipMemcpyHostToDevice));
+        FMD_HIP_TRY(hipMemcpy(dq, q2.data(), o2[m], hipMemcpyHostToDevice));
+        FMD_HIP_TRY(hipMemcpy(doff, o2.data(), (m + 1) * 8, hipMemcpyHostToDevice));
+        const int rc = fmd_ecfix_dev(t, nullptr, m, (uint8_t *)ds, (uint8_t *)dq, (uint64_t *)doff, step, cap, (int32_t *)dinfo, dwork, wb);
+        if (rc != FMD_OK) return rc;
+        FMD_HIP_TRY(hipMemcpy(s2.data(), ds, o2[m], hipMemcpyDeviceToHost));
+        FMD_HIP_TRY(hipMemcpy(q2.data(), dq, o2[m], hipMemcpyDeviceToHost));
+        FMD_HIP_TRY(hipMemcpy(i2.data(), dinfo, m * 4, hipMemcpyDeviceToHost));
+        std::vector<size_t> left;
         for (size_t k = 0; k < m; ++k) {
-            info[again[k]] = i2[k];
-            if ((uint32_t)i2[k] == EC_INFO_TRACE_FULL) continue;
-            memcpy(s0 + rel[again[k]], s2.data() + o2[k], o2[k + 1] - o2[k]);
-            memcpy(q0 + rel[again[k]], q2.data() + o2[k], o2[k + 1] - o2[k]);
+            const size_t i = again[todo[k]];
+            info[i] = i2[k];
+            if ((uint32_t)i2[k] == EC_INFO_TRACE_FULL) { left.push_back(todo[k]); continue; }
+            memcpy(s0 + rel[i], s2.data() + o2[k], o2[k + 1] - o2[k]);
+            memcpy(q0 + rel[i], q2.data() + o2[k], o2[k + 1] - o2[k]);
         }
+        todo.swap(left);
     }
-    if (rc == FMD_OK) for (size_t i = 0; i < n; ++i) if ((uint32_t)info[i] == EC_INFO_TRACE_FULL) { rc = FMD_E_OVERFLOW; break; }
-    free(rel);
-    hipFree(ds); hipFree(dq); hipFree(doff); hipFree(dinfo); hipFree(dwork);
-    return rc;
+    return todo.empty() ? FMD_OK : FMD_E_OVERFLOW;
 }

@@ -134,5 +134,9 @@ struct FmdOvlClasses {
 
 // Two-pass walk of a sorted job (k_ovl_walk<WALK_HEAD / WALK_TAIL>, fmd_ovlp.hip): where a strand stands FMD_WALK_SPLIT bases in.
 #define FMD_WALK_SPLIT 32u            // a multiple of 16: the stash of a parked strand is two whole 16-byte groups
-struct FmdWalkPark { unsigned long long k, x0, x1, sz; uint4 s0, s1; };   // k = ~0: the sequence ended inside the head (its record was written there)
+struct FmdWalkPark {                  // k = ~0: the sequence ended inside the head (its record was written there)
+    unsigned long long k, x0, x1, sz;  // LF row and bi-interval after FMD_WALK_SPLIT bases
+    uint4 bases;                       // those bases, last base of the sequence first, 4 bits each (nt6 codes)
+    uint4 pad;                         // (the row is one 64-byte line, written in one burst)
+};
 static_assert(sizeof(FmdWalkPark) == 64, "one line per parked strand");

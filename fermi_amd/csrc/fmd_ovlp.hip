@@ -21,6 +21,9 @@ void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, co
 // fmd_ovlp_sort.hip: minimizer keys of the parked strands, then their rows sorted by key (-> vals_b)
 size_t fmd_park_sort_temp_bytes(size_t n);
 int fmd_park_sort(hipStream_t st, size_t n, const FmdWalkPark *park, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *tmp, size_t tmp_bytes);
+// rows of ids[] sorted by the last bases of their sequences (the top `bits` bits of the tail-table entries) -> vals_b
+int fmd_tail_sort(hipStream_t st, size_t n, const uint64_t *ids, const unsigned long long *tail, uint64_t n_seq, int bits, uint32_t *keys_a, uint32_t *keys_b,
+                  uint32_t *vals_a, uint32_t *vals_b, void *tmp, size_t tmp_bytes);
 
 // ---------------------------------------------------------------------------- phase 0: retrieve
 // fm_retrieve (exact.c:59-70); writes the sequence REVERSED into srev and rank/len into rec.
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(64) void k_ovl_intv(FmdIndexView ix, size_t n, int 
 // L2 -- the LF step takes a gather of its own).  The base found by the LF step is the base the
 // extension needs; when it is '$' the same ranks are fm6_is_contained's left test (unitig.c:83-85).
 // Candidates are pushed with info = depth (their start is len - depth, known only at the end).
-enum { WK_IDLE = 0, WK_LF, WK_EXT, WK_BOTH, WK_RIGHT };
+enum { WK_IDLE = 0, WK_LF, WK_EXT, WK_BOTH, WK_RIGHT, WK_ADM1, WK_ADM2 };
 // can the LF step at row k be read from a block the backward extension of [x0, x0 + sz) brings in anyway (the block of x0 - 1, or
 // the block of its other end when that one does not reach it)?
 __device__ __forceinline__ bool walk_lf_shares(uint64_t k, uint64_t x0, uint64_t sz)
@@ -198,6 +201,21 @@ __device__ __forceinline__ bool walk_lf_shares(uint64_t k, uint64_t x0, uint64_t
         pack = 0;                                                                                          \
     } while (0)
 
+// one more base of the sequence (the one at position `depth` from its end).  WALK_HEAD keeps its 32 bases in the four stash registers,
+// 4 bits each (FmdWalkPark::bases), and never stores
+#define WALK_PUT_BASE(cc)                                                                                  \
+    do {                                                                                                   \
+        if (MODE == WALK_HEAD) {                                                                           \
+            const uint32_t v_ = (uint32_t)(cc) << (4 * (depth & 7)), w_ = depth >> 3;                      \
+            pk0 |= w_ == 0 ? v_ : 0u; pk1 |= w_ == 1 ? v_ : 0u; pk2 |= w_ == 2 ? v_ : 0u; pack |= w_ == 3 ? v_ : 0u; \
+            ++depth;                                                                                       \
+        } else {                                                                                           \
+            pack |= (uint32_t)(cc) << (8 * (depth & 3));                                                   \
+            ++depth;                                                                                       \
+            if ((depth & 3) == 0) WALK_STASH_WORD();                                                       \
+        }                                                                                                  \
+    } while (0)
+
 // Two-pass form (WALK_HEAD + WALK_TAIL, the locality sort of fmd_ovlp_sorted_dev below).  Strands whose last bases lie next to each
 // other on the genome visit the SAME rank blocks (the interval of "g[a, e)" holds the interval of "g[a, e + d)"), d steps apart; in
 // id order they are never in flight together and every one of those visits is a DRAM miss.  WALK_HEAD takes every strand of the job
@@ -207,15 +225,19 @@ __device__ __forceinline__ bool walk_lf_shares(uint64_t k, uint64_t x0, uint64_t
 // exactly the steps of the one-pass walk and leave the same records, candidates and stash.
 enum { WALK_WHOLE = 0, WALK_HEAD = 1, WALK_TAIL = 2 };   // (FMD_WALK_SPLIT, FmdWalkPark: fmd_kernel_common.h)
 
-// MODE = WALK_HEAD: item = position in ids[] = row of park[] and rec[]; srev/stride_r address the stash inside park[].
+// MODE = WALK_HEAD: item t = row gidx[t] (t when gidx is null) of ids[], park[] and rec[]; the first 32 bases stay in registers
+// and leave with the parked state in ONE 64-byte burst.  The items come sorted by the strands' last ptab_d bases (the
+// tail table has them, fmd_ovlp_sorted_dev): strands of one wave then share the prefix-table entries and the blocks of the first,
+// wide steps behind the table.
 // MODE = WALK_TAIL: item = slot of the batch (rows of srev, listA), gidx[slot] = its row in park[], rec[] (and, for the kernels
 // that follow, nei[] and seq[]).
 template <int MODE>
-__global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, const uint64_t *__restrict__ ids, int min_match,
+__global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, const uint64_t *__restrict__ ids, int min_match,
                                                  uint8_t *__restrict__ srev, uint32_t stride_r, uint32_t cap,
                                                  fmd_intv_t *__restrict__ listA, fmd_ovlp_rec_t *__restrict__ rec,
                                                  uint8_t *__restrict__ seq_out, uint32_t seq_stride, uint32_t *__restrict__ queue,
-                                                 int info_only, FmdWalkPark *__restrict__ park, const uint32_t *__restrict__ gidx)
+                                                 int info_only, FmdWalkPark *__restrict__ park, const uint32_t *__restrict__ gidx,
+                                                 const uint4 *__restrict__ adm)
 {
     FMD_DECLARE_COMPACT_LDS();
     size_t sid = 0;
@@ -231,35 +253,31 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
     const bool tab_ok = ix.ptab != nullptr && (info_only || min_match >= ix.ptab_d) && ix.ptab_d >= 2;
     bool tab = false;
     uint32_t tfw = 0, trv = 0;
+    uint4 adm_a = make_uint4(0, 0, 0, 0), adm_b = make_uint4(0, 0, 0, 0);   // WALK_HEAD: the admission record of a strand on its way in (WK_ADM1)
     FmdTickets tk_;
     fmd_tickets_init(tk_, queue);
     for (;;) {
         const size_t my = fmd_tickets_take(tk_, queue, st == WK_IDLE && !exhausted);
         if (st == WK_IDLE && !exhausted) {
+            // The two passes of a sorted job take a strand in over one (WALK_HEAD) or two (WALK_TAIL) wave steps: the loads are issued
+            // here and complete under the gather of the other lanes (WK_ADM1 / WK_ADM2 below).  A chain of dependent loads in front of
+            // the gather -- id, tail-table entry, two prefix-table entries, as the one-pass walk does it -- stalls all 64 lanes of a wave
+            // whose strands live 20 steps: k_ovl_head_adm resolves that chain for every strand beforehand, streaming.
             if (MODE == WALK_TAIL) {
-                if (my < n) {   // pick the strand up where WALK_HEAD parked it
-                    sid = my; gs = gidx[my];
-                    const FmdWalkPark *pp = park + gs;
-                    const uint4 a = ((const uint4 *)pp)[0], b = ((const uint4 *)pp)[1];
-                    k = (uint64_t)a.y << 32 | a.x; x0 = (uint64_t)a.w << 32 | a.z; x1 = (uint64_t)b.y << 32 | b.x; sz = (uint64_t)b.w << 32 | b.z;
-                    if (k != ~0ull) {
-                        uint4 *sr = (uint4 *)(srev + sid * (size_t)stride_r);
-                        sr[0] = pp->s0; sr[1] = pp->s1;
-                        depth = FMD_WALK_SPLIT; npush = 0; pack = 0; pk0 = pk1 = pk2 = 0; flags = 0; ret = 0; tab = false;
-                        st = walk_lf_shares(k, x0, sz) ? WK_BOTH : WK_LF;
-                    }
-                } else exhausted = true;
+                if (my < n) { sid = my; gs = gidx[my]; st = WK_ADM1; }
+                else exhausted = true;
+            } else if (MODE == WALK_HEAD) {
+                if (my < n) { sid = my; adm_a = adm[2 * my]; adm_b = adm[2 * my + 1]; st = WK_ADM1; }
+                else exhausted = true;
             } else
             if (my < n) {
-                sid = my; gs = my; k = ids[my]; depth = 0; npush = 0; pack = 0; pk0 = pk1 = pk2 = 0; flags = 0; ret = 0; st = WK_LF; tab = tab_ok;
+                sid = my; gs = my; k = ids[gs]; depth = 0; npush = 0; pack = 0; pk0 = pk1 = pk2 = 0; flags = 0; ret = 0; st = WK_LF; tab = tab_ok;
                 // the first ptab_d LF steps were taken when the index was loaded (FmdIndexView::tail): pick the walk up behind them
                 const unsigned long long te = (tab_ok && ix.tail && k < ix.n_seq) ? ix.tail[k] : ~0ull;
                 if (te != ~0ull) {
                     tfw = (uint32_t)(te >> 40); k = te & 0xffffffffffull;
                     for (int jb = 0; jb < ix.ptab_d; ++jb) {   // the bases into the stash, as the steps would have put them
-                        pack |= (((tfw >> (2 * jb)) & 3u) + 1u) << (8 * (depth & 3));
-                        ++depth;
-                        if ((depth & 3) == 0) WALK_STASH_WORD();
+                        WALK_PUT_BASE(((tfw >> (2 * jb)) & 3u) + 1u);
                     }
                     // reverse complement of the ptab index: the 2-bit groups in reverse order, complemented
                     { uint32_t r = __brev(~tfw) >> (32 - 2 * ix.ptab_d); trv = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1); }
@@ -300,6 +318,49 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
         const bool was_two_phase = r.two_phase;
         fmd_wave_l_ready(ix, fmd_lds, r);
         if (st == WK_IDLE || skip) continue;
+        if (MODE == WALK_HEAD && st == WK_ADM1) {   // the admission record has arrived (FmdHeadAdm, k_ovl_head_adm)
+            gs = adm_a.x;
+            depth = 0; npush = 0; pack = 0; pk0 = pk1 = pk2 = 0; flags = 0; ret = 0;
+            if (adm_b.w & 1u) {   // no tail-table entry: from the sentinel, on the ordinary path
+                k = (uint64_t)(adm_b.y & 0xffu) << 32 | adm_a.y; st = WK_LF; tab = tab_ok;
+            } else {
+                const uint32_t hi = adm_b.y;
+                k = (uint64_t)(hi & 0xffu) << 32 | adm_a.y; x0 = (uint64_t)((hi >> 8) & 0xffu) << 32 | adm_a.z;
+                x1 = (uint64_t)((hi >> 16) & 0xffu) << 32 | adm_a.w; sz = (uint64_t)(hi >> 24) << 32 | adm_b.x;
+                // the ptab_d bases of the tail as nibbles (2-bit code + 1): 8 per word
+                const uint32_t tf = adm_b.z;
+                uint32_t lo = tf & 0xffffu, up = tf >> 16;
+                lo = (lo | lo << 8) & 0x00ff00ffu; lo = (lo | lo << 4) & 0x0f0f0f0fu; lo = (lo | lo << 2) & 0x33333333u;
+                up = (up | up << 8) & 0x00ff00ffu; up = (up | up << 4) & 0x0f0f0f0fu; up = (up | up << 2) & 0x33333333u;
+                const int d = ix.ptab_d;
+                pk0 = (lo + 0x11111111u) & (d >= 8 ? ~0u : (1u << (4 * d)) - 1u);
+                pk1 = d > 8 ? (up + 0x11111111u) & (d >= 16 ? ~0u : (1u << (4 * (d - 8))) - 1u) : 0u;
+                depth = (uint32_t)d; tab = false;
+                st = walk_lf_shares(k, x0, sz) ? WK_BOTH : WK_LF;
+            }
+            continue;
+        }
+        if (MODE == WALK_TAIL && st == WK_ADM1) {   // the strand's row is known: fetch what WALK_HEAD parked there, straight into the
+            const uint4 *pp = (const uint4 *)(park + gs);   // registers the state will live in (the loads land under the next gather)
+            const uint4 a = pp[0], b = pp[1], cb = pp[2];
+            k = (uint64_t)a.y << 32 | a.x; x0 = (uint64_t)a.w << 32 | a.z; x1 = (uint64_t)b.y << 32 | b.x; sz = (uint64_t)b.w << 32 | b.z;
+            pk0 = cb.x; pk1 = cb.y; pk2 = cb.z; pack = cb.w;
+            st = WK_ADM2;
+            continue;
+        }
+        if (MODE == WALK_TAIL && st == WK_ADM2) {
+            st = WK_IDLE;
+            if (k != ~0ull) {   // (~0: the sequence ended inside the head)
+                uint4 *sr = (uint4 *)(srev + sid * (size_t)stride_r);   // the 32 bases into the stash, one per byte
+#define WALK_NIB4(v_) (((v_) & 0xfu) | ((v_) & 0xf0u) << 4 | ((v_) & 0xf00u) << 8 | ((v_) & 0xf000u) << 12)
+                sr[0] = make_uint4(WALK_NIB4(pk0), WALK_NIB4(pk0 >> 16), WALK_NIB4(pk1), WALK_NIB4(pk1 >> 16));
+                sr[1] = make_uint4(WALK_NIB4(pk2), WALK_NIB4(pk2 >> 16), WALK_NIB4(pack), WALK_NIB4(pack >> 16));
+#undef WALK_NIB4
+                depth = FMD_WALK_SPLIT; npush = 0; pack = 0; pk0 = pk1 = pk2 = 0; flags = 0; ret = 0; tab = false;
+                st = walk_lf_shares(k, x0, sz) ? WK_BOTH : WK_LF;
+            }
+            continue;
+        }
 
         int c = c_pend;
         // Narrow interval (size <= 63, i.e. all but the first ~log4(n) bases): everything comes from ONE
@@ -335,13 +396,11 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             k = ix.cnt[c] + fmd_block_rank1(img, tt, off + 1, c, kb_) - 1;
             if (st == WK_LF && depth > 0 && tab) { // still inside the prefix table: no extension, just collect the base
                 if (c < 1 || c > 4) { // the sequence ends, or an ambiguous base: start over on the ordinary path
-                    k = ids[sid]; depth = 0; pack = 0; pk0 = pk1 = pk2 = 0; tab = false;
+                    k = ids[gs]; depth = 0; pack = 0; pk0 = pk1 = pk2 = 0; tab = false;
                     continue;
                 }
                 tfw |= (uint32_t)(c - 1) << (2 * depth); trv = trv << 2 | (uint32_t)(4 - c);
-                pack |= (uint32_t)c << (8 * (depth & 3));
-                ++depth;
-                if ((depth & 3) == 0) WALK_STASH_WORD();
+                WALK_PUT_BASE(c);
                 if ((int)depth == ix.ptab_d) {
                     const uint4 ef = ix.ptab[tfw], er = ix.ptab[trv];
                     fmd_count_lane(ix, 2, 1);
@@ -360,12 +419,12 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
                 fmd_ovlp_rec_t *o = rec + gs;
                 o->rank = k; o->k[0] = o->k[1] = o->k[2] = 0; o->len = 0; o->status = -1; o->n_ovlp = 0; o->rbeg = -1;
                 o->ext_len = 0; o->n_nei = 0; o->flags = 0; o->reserved = 2; o->lfork = 0;
-                if (MODE == WALK_HEAD) park[sid].k = ~0ull;
+                if (MODE == WALK_HEAD) park[gs].k = ~0ull;
                 st = WK_IDLE;
                 continue;
             }
             x0 = ix.cnt[c]; x1 = ix.cnt[comp6(c)]; sz = ix.cnt[c + 1] - ix.cnt[c];
-            pack = (uint32_t)c; depth = 1;
+            WALK_PUT_BASE(c);   // (depth 0 -> 1)
             if (c > 4) tab = false;
             tfw = (uint32_t)(c - 1) & 3; trv = (uint32_t)(4 - c) & 3;
         } else if (st == WK_EXT || st == WK_BOTH) {
@@ -402,11 +461,9 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
                 if (c == 1 || c == 5) before += s[2];
                 if (c == 5) before += s[1];
                 x1 += before; sz = sc;
-                pack |= (uint32_t)c << (8 * (depth & 3));
-                ++depth;
-                if ((depth & 3) == 0) WALK_STASH_WORD();
+                WALK_PUT_BASE(c);
             } else { // '$': the sequence is complete (len = depth); these ranks are the left test of fm6_is_contained
-                if ((depth & 15) && depth <= stride_r) // the last, partial group of 16 (stride_r is a multiple of 16)
+                if (MODE != WALK_HEAD && (depth & 15) && depth <= stride_r) // the last, partial group of 16 (stride_r is a multiple of 16)
                 {   // completed words of the group sit in pk0..2, a partial word in pack; everything past it is zero
                     const uint32_t wq = (depth >> 2) & 3;
                     *(uint4 *)(srev + sid * (size_t)stride_r + (depth & ~15u)) = make_uint4(wq == 0 ? pack : pk0, wq == 1 ? pack : pk1, wq == 2 ? pack : pk2, wq == 3 ? pack : 0u);
@@ -414,7 +471,7 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
                 fmd_ovlp_rec_t *o = rec + gs;
                 o->rank = k; o->len = (int32_t)depth; o->rbeg = -1; o->ext_len = 0; o->n_nei = 0; o->reserved = 2; o->lfork = 0;
                 o->k[0] = o->k[1] = o->k[2] = 0; o->n_ovlp = 0;
-                if (MODE == WALK_HEAD) park[sid].k = ~0ull;   // ended inside the head: shorter than min_match, the record below is final
+                if (MODE == WALK_HEAD) park[gs].k = ~0ull;   // ended inside the head: shorter than min_match, the record below is final
                 if (depth > stride_r) { o->status = 0; o->flags = FMD_OVLP_F_OVERFLOW; st = WK_IDLE; continue; } // longer than max_len
                 if (!info_only && (int)depth <= min_match) { o->status = -1; o->flags = 0; st = WK_IDLE; continue; } // too short (unitig.c:288)
                 // (the caller's copy in read order is made by k_ovl_seq_out: a lane doing it here holds up the other 63)
@@ -440,16 +497,18 @@ __global__ __launch_bounds__(64) void k_ovl_walk(FmdIndexView ix, size_t n, cons
             st = walk_lf_shares(k, x0, sz) ? WK_BOTH : WK_LF;
             if (tab) st = WK_LF;   // inside the prefix table there is no extension to share a gather with
         }
-        if (MODE == WALK_HEAD && depth == FMD_WALK_SPLIT && !tab) {   // park the strand (its stash so far lies in park[sid].s0, s1 already)
-            uint4 *pp = (uint4 *)(park + sid);
+        if (MODE == WALK_HEAD && depth == FMD_WALK_SPLIT && !tab) {   // park the strand: one 64-byte line, written whole
+            uint4 *pp = (uint4 *)(park + gs);
             pp[0] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), (uint32_t)x0, (uint32_t)(x0 >> 32));
             pp[1] = make_uint4((uint32_t)x1, (uint32_t)(x1 >> 32), (uint32_t)sz, (uint32_t)(sz >> 32));
+            pp[2] = make_uint4(pk0, pk1, pk2, pack); pp[3] = make_uint4(0, 0, 0, 0);
             st = WK_IDLE;
         }
     }
 }
 
 #undef WALK_STASH_WORD
+#undef WALK_PUT_BASE
 
 // The caller's copy of every sequence in read order: the stash holds it last base first.  One thread
 // per output word; the same conditions under which a record describes a complete sequence
@@ -886,7 +945,7 @@ static void ovl_phase_a(const OvlBatch &o, hipStream_t st, size_t b, size_t np, 
         int grid = fmd_grid_for_lds(o.h, np, FMD_COMPACT_LDS_U4 * 16);
         { const char *e = getenv("FMD_WALK_WAVES"); if (per_cu <= 0 && e && atoi(e) > 0) per_cu = atoi(e); }
         if (per_cu > 0 && grid > o.h->n_cu * per_cu) grid = o.h->n_cu * per_cu;
-        k_ovl_walk<WALK_TAIL><<<grid, 64, 0, st>>>(o.ix, np, nullptr, o.min_match, srev, o.stride_r, o.cap, listA, o.rec, seq, o.seq_stride, q0, 0, o.park, o.gidx + b);
+        k_ovl_walk<WALK_TAIL><<<grid, 64, 0, st>>>(o.ix, np, nullptr, o.min_match, srev, o.stride_r, o.cap, listA, o.rec, seq, o.seq_stride, q0, 0, o.park, o.gidx + b, nullptr);
         launch_seq_out(st, np, o.max_len, srev, o.stride_r, o.rec, o.min_match, 0, seq, o.seq_stride, o.gidx + b);
         return;
     }
@@ -899,7 +958,7 @@ static void ovl_phase_a(const OvlBatch &o, hipStream_t st, size_t b, size_t np, 
     int grid = fmd_grid_for_lds(o.h, np, FMD_COMPACT_LDS_U4 * 16);
     { const char *e = getenv("FMD_WALK_WAVES"); if (per_cu <= 0 && e && atoi(e) > 0) per_cu = atoi(e); }   // A/B knob: resident waves per CU
     if (per_cu > 0 && grid > o.h->n_cu * per_cu) grid = o.h->n_cu * per_cu;
-    k_ovl_walk<WALK_WHOLE><<<grid, 64, 0, st>>>(o.ix, np, o.ids + b, o.min_match, srev, o.stride_r, o.cap, listA, o.rec + b, seq, o.seq_stride, q0, 0, nullptr, nullptr);
+    k_ovl_walk<WALK_WHOLE><<<grid, 64, 0, st>>>(o.ix, np, o.ids + b, o.min_match, srev, o.stride_r, o.cap, listA, o.rec + b, seq, o.seq_stride, q0, 0, nullptr, nullptr, nullptr);
     launch_seq_out(st, np, o.max_len, srev, o.stride_r, o.rec + b, o.min_match, 0, seq, o.seq_stride);
 }
 
@@ -1071,6 +1130,40 @@ extern "C" int fmd_ovlp_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_
     return FMD_OK;
 }
 
+// What WALK_HEAD needs to take a strand in, resolved for every strand beforehand by a streaming kernel (one thread per strand) instead
+// of a chain of four dependent loads in front of a wave's gather: item t of the head's order -> its row, and where its walk stands
+// behind the tail table (FmdIndexView::tail + two prefix-table entries; the items come sorted by tail, so neighbouring threads read
+// neighbouring entries).  32 bytes per strand:
+//   a = { row, k lo, x0 lo, x1 lo }   b = { size lo, k hi | x0 hi << 8 | x1 hi << 16 | size hi << 24, tail as a prefix-table index, flags }
+// flags bit 0: no tail-table entry (shorter than ptab_d bases, or a base that is not A/C/G/T among them): k = the sequence id, and
+// the walk starts at its sentinel.
+__global__ void k_ovl_head_adm(FmdIndexView ix, size_t n, const uint64_t *__restrict__ ids, const uint32_t *__restrict__ order, int use_tail,
+                               uint4 *__restrict__ adm)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += step) {
+        const uint32_t row = order ? order[t] : (uint32_t)t;
+        const uint64_t id = ids[row];
+        const unsigned long long te = (use_tail && id < ix.n_seq) ? ix.tail[id] : ~0ull;
+        uint4 a, b;
+        if (te != ~0ull) {
+            const uint32_t tfw = (uint32_t)(te >> 40);
+            const uint64_t k = te & 0xffffffffffull;
+            uint32_t r = __brev(~tfw) >> (32 - 2 * ix.ptab_d);   // reverse complement of the ptab index: the 2-bit groups in reverse order, complemented
+            const uint32_t trv = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+            const uint4 ef = ix.ptab[tfw], er = ix.ptab[trv];
+            fmd_count_lane(ix, 2, 1);
+            const uint64_t x0 = (uint64_t)ef.y << 32 | ef.x, sz = ((uint64_t)ef.w << 32 | ef.z) - x0 + 1, x1 = (uint64_t)er.y << 32 | er.x;
+            a = make_uint4(row, (uint32_t)k, (uint32_t)x0, (uint32_t)x1);
+            b = make_uint4((uint32_t)sz, (uint32_t)(k >> 32) | (uint32_t)(x0 >> 32) << 8 | (uint32_t)(x1 >> 32) << 16 | (uint32_t)(sz >> 32) << 24, tfw, 0u);
+        } else {
+            a = make_uint4(row, (uint32_t)id, 0u, 0u);
+            b = make_uint4(0u, (uint32_t)(id >> 32) & 0xffu, 0u, 1u);
+        }
+        adm[2 * t] = a; adm[2 * t + 1] = b;
+    }
+}
+
 // ---- the whole job in an order that keeps neighbours on the genome in flight together ---------------------------------------------
 // Work area of fmd_ovlp_sorted_dev: the parked strands (64 bytes each), two (key, row) arrays for the sort, the sort's own
 // temporary storage, and the work area of ONE batch of fmd_ovlp_dev.
@@ -1086,7 +1179,8 @@ static SortedLayout sorted_layout(size_t n, size_t batch, uint32_t max_len, int 
     L.vals_b = o; o += align_up(n * 4, 256);
     L.tmp_bytes = fmd_park_sort_temp_bytes(n);
     L.tmp = o; o += align_up(L.tmp_bytes, 256);
-    L.batch_area = o; o += fmd_ovlp_work_bytes(batch, max_len, min_match);
+    L.batch_area = o;   // (also the head's admission records, 32 bytes per strand of the job, while pass 1 runs)
+    { const size_t ba = fmd_ovlp_work_bytes(batch, max_len, min_match), ad = align_up(n * 32, 256); o += ba > ad ? ba : ad; }
     L.total = o;
     return L;
 }
@@ -1129,15 +1223,27 @@ extern "C" int fmd_ovlp_sorted_dev(fmd_dev_t *h, void *stream_, size_t n, const 
     FmdWalkPark *park = (FmdWalkPark *)(w + L.park);
     uint32_t *sorted = (uint32_t *)(w + L.vals_b);
     const FmdIndexView ix = fmd_view(h);
-    // pass 1: every strand FMD_WALK_SPLIT bases in (its stash so far goes into the second half of its park row)
+    // pass 1: every strand FMD_WALK_SPLIT bases in, the strands taken in the order of their last ptab_d bases (known from the tail table)
     {
+        const uint32_t *order1 = nullptr;
+        if (ix.tail && !getenv("FMD_HEAD_UNSORTED")) {
+            const int rc = fmd_tail_sort(st, n, d_ids, ix.tail, ix.n_seq, 2 * ix.ptab_d, (uint32_t *)(w + L.keys_a), (uint32_t *)(w + L.keys_b), (uint32_t *)(w + L.vals_a), sorted, w + L.tmp, L.tmp_bytes);
+            if (rc != FMD_OK) return rc;
+            order1 = sorted;
+        }
+        // (the admission records live in the batch area, which is idle until pass 2; 32 bytes per strand of the job)
+        uint4 *adm = (uint4 *)(w + L.batch_area);
+        const int use_tail = ix.tail != nullptr && ix.ptab != nullptr && min_match >= ix.ptab_d && ix.ptab_d >= 2;
+        size_t blocks = (n + 255) / 256;
+        if (blocks > (1u << 20)) blocks = 1u << 20;
+        k_ovl_head_adm<<<(unsigned)blocks, 256, 0, st>>>(ix, n, d_ids, order1, use_tail, adm);
         uint32_t *q = fmd_next_queue(h, st);
         int grid = fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16);
         { const char *e = getenv("FMD_HEAD_WAVES"); if (e && atoi(e) > 0 && grid > h->n_cu * atoi(e)) grid = h->n_cu * atoi(e); }
-        k_ovl_walk<WALK_HEAD><<<grid, 64, 0, st>>>(ix, n, d_ids, min_match, (uint8_t *)park + 32, (uint32_t)sizeof(FmdWalkPark), 0, nullptr, d_rec,
-                                                nullptr, seq_stride, q, 0, park, nullptr);
+        k_ovl_walk<WALK_HEAD><<<grid, 64, 0, st>>>(ix, n, d_ids, min_match, nullptr, (uint32_t)sizeof(FmdWalkPark), 0, nullptr, d_rec,
+                                                nullptr, seq_stride, q, 0, park, nullptr, adm);
     }
-    // the order: rows sorted by the minimizer of the bases each strand has shown so far
+    // the order of pass 2: rows sorted by the minimizer of the bases each strand has shown so far
     {
         const int rc = fmd_park_sort(st, n, park, (uint32_t *)(w + L.keys_a), (uint32_t *)(w + L.keys_b), (uint32_t *)(w + L.vals_a), sorted, w + L.tmp, L.tmp_bytes);
         if (rc != FMD_OK) return rc;
@@ -1202,7 +1308,7 @@ extern "C" int fmd_seqinfo_dev(fmd_dev_t *h, void *stream_, size_t n, const uint
     fmd_intv_t *listA = (fmd_intv_t *)((uint8_t *)d_work + align_up(n * (size_t)stride_r, 256));
     uint32_t *q0 = fmd_next_queue(h, st);
     k_ovl_walk<WALK_WHOLE><<<fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16), 64, 0, st>>>(fmd_view(h), n, d_ids, 0, srev, stride_r, cap, listA, d_rec,
-                                                                                         d_seq, seq_stride, q0, 1, nullptr, nullptr);
+                                                                                         d_seq, seq_stride, q0, 1, nullptr, nullptr, nullptr);
     launch_seq_out(st, n, max_len, srev, stride_r, d_rec, 0, 1, d_seq, seq_stride);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "k_ovl_walk"); return FMD_E_HIP; }

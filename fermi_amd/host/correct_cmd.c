@@ -40,7 +40,7 @@ typedef struct {
     const fmdh_ecopt_t *opt; fmd_ectab_t *tab; FILE *out;
     batch_t b[3];
     pthread_mutex_t mu; pthread_cond_t cv;
-    int failed;
+    int failed;               /* set by any of the three pipeline threads: atomic accesses only */
     double t_gpu, t_write;               /* busy time of the two worker stages (FMD_TIMING) */
 } pipe_t;
 
@@ -106,10 +106,10 @@ static void *stage_gpu(void *d)
         batch_t *b = &p->b[k % 3];
         slot_wait(p, b, 1);
         const double t0 = now_s();
-        if (b->nb && !p->failed) encode_batch(b);
-        if (b->nb && !p->failed) {
+        if (b->nb && !__atomic_load_n(&p->failed, __ATOMIC_RELAXED)) encode_batch(b);
+        if (b->nb && !__atomic_load_n(&p->failed, __ATOMIC_RELAXED)) {
             const int rc = fmd_ecfix_batch(p->tab, b->nb, b->nt6, b->qual, b->off, p->opt->step, b->info);
-            if (rc) { fprintf(stderr, "[E::%s] correction pass failed: %s\n", __func__, fmd_strerror(rc)); p->failed = 1; }
+            if (rc) { fprintf(stderr, "[E::%s] correction pass failed: %s\n", __func__, fmd_strerror(rc)); __atomic_store_n(&p->failed, 1, __ATOMIC_RELAXED); }
         }
         p->t_gpu += now_s() - t0;
         const int last = b->last;
@@ -188,7 +188,7 @@ static void *stage_print(void *d)
         batch_t *b = &p->b[kb % 3];
         slot_wait(p, b, 2);
         const double t0 = now_s();
-        if (!p->failed && b->nb) {
+        if (!__atomic_load_n(&p->failed, __ATOMIC_RELAXED) && b->nb) {
             int T = g_host_threads < MAX_SLICES ? g_host_threads : MAX_SLICES, t, pass;
             if ((size_t)T > b->nb / 4096 + 1) T = (int)(b->nb / 4096 + 1);
             for (pass = 0; pass < 2; ++pass) {
@@ -201,8 +201,8 @@ static void *stage_print(void *d)
                 for (t = 1; t < T; ++t) if (started[t]) pthread_join(tid[t], 0);
             }
             for (t = 0; t < T; ++t) {
-                if (sl[t].failed) { fprintf(stderr, "[E::%s] out of memory\n", __func__); p->failed = 1; break; }
-                if (fwrite(sl[t].text, 1, sl[t].text_l, p->out) != sl[t].text_l) { fprintf(stderr, "[E::%s] write error\n", __func__); p->failed = 1; break; }
+                if (sl[t].failed) { fprintf(stderr, "[E::%s] out of memory\n", __func__); __atomic_store_n(&p->failed, 1, __ATOMIC_RELAXED); break; }
+                if (fwrite(sl[t].text, 1, sl[t].text_l, p->out) != sl[t].text_l) { fprintf(stderr, "[E::%s] write error\n", __func__); __atomic_store_n(&p->failed, 1, __ATOMIC_RELAXED); break; }
             }
         }
         const int last = b->last;
@@ -233,14 +233,14 @@ int fmdh_correct_reads(const fmdh_ecopt_t *opt, int device, int suf_len, uint64_
     for (int i = 0; i < 3; ++i) {
         p.b[i].off = (uint64_t *)malloc((BATCH_SIZE + 1) * sizeof(uint64_t));
         p.b[i].info = (int32_t *)malloc(BATCH_SIZE * sizeof(int32_t));
-        if (!p.b[i].off || !p.b[i].info) p.failed = 1;
+        if (!p.b[i].off || !p.b[i].info) __atomic_store_n(&p.failed, 1, __ATOMIC_RELAXED);
     }
     pthread_t t_gpu, t_out;
     int have_gpu_thread = 0, have_out_thread = 0;
-    if (!p.failed) {
+    if (!__atomic_load_n(&p.failed, __ATOMIC_RELAXED)) {
         have_gpu_thread = pthread_create(&t_gpu, 0, stage_gpu, &p) == 0;
         have_out_thread = have_gpu_thread && pthread_create(&t_out, 0, stage_print, &p) == 0;
-        if (!have_gpu_thread || !have_out_thread) p.failed = 1;
+        if (!have_gpu_thread || !have_out_thread) __atomic_store_n(&p.failed, 1, __ATOMIC_RELAXED);
     }
     uint64_t id = 0;
     for (unsigned kb = 0; have_out_thread; ++kb) { /* batches of BATCH_SIZE reads, output in input order */
@@ -252,7 +252,7 @@ int fmdh_correct_reads(const fmdh_ecopt_t *opt, int device, int suf_len, uint64_
         while (b->nb < BATCH_SIZE) {
             const int len = fmdh_seq_read(io);
             if (len < 0) { b->last = 1; break; }
-            if (batch_room(b, (size_t)len)) { fprintf(stderr, "[E::%s] out of memory\n", __func__); p.failed = 1; b->last = 1; break; }
+            if (batch_room(b, (size_t)len)) { fprintf(stderr, "[E::%s] out of memory\n", __func__); __atomic_store_n(&p.failed, 1, __ATOMIC_RELAXED); b->last = 1; break; }
             const char *s = fmdh_seq_bases(io), *q = fmdh_seq_qual(io);
             memcpy(b->ascii + b->bytes, s, (size_t)len);                  /* (nt6 codes: encode_batch, second stage) */
             if (q) memcpy(b->qual + b->bytes, q, (size_t)len);
@@ -275,7 +275,7 @@ int fmdh_correct_reads(const fmdh_ecopt_t *opt, int device, int suf_len, uint64_
     pthread_mutex_destroy(&p.mu); pthread_cond_destroy(&p.cv);
     fmdh_seq_close(io);
     fmd_ectab_free(p.tab);
-    return p.failed ? 1 : 0;
+    return __atomic_load_n(&p.failed, __ATOMIC_RELAXED) ? 1 : 0;
 }
 
 int fmdh_correct_kmer(uint64_t n_symbols) /* the automatic k-mer length, correct.c:313-318 */

@@ -50,6 +50,7 @@ static int shard_fill(fmd_dev_t *d, fmdh_ovlp_shard_t *s, const uint64_t *ids, u
 /* ------------------------------------------------------------------------------------------------ link pass */
 typedef struct {
     fmdh_ovlp_table_t *t; uint64_t lo, hi; int phase;
+    int force_exact;          /* A/B (FMD_CHECK_LEFT_EXACT, read once by the caller): every edge through fmd_ovlp_check_left_dev */
     uint64_t *und; uint64_t n_und, m_und; int rc;
 } lk_t;
 static inline fmd_ovlp_rec_t *row_rec_mut(fmdh_ovlp_table_t *t, uint64_t id)
@@ -84,7 +85,7 @@ static void *lk_main(void *p)
         {
             int d = 1;
             if (l->rev != 0xffffffffu) d = fmd_lfork_decide(row_rec_mut(t, l->rev)->lfork, r->rbeg);
-            if (getenv("FMD_CHECK_LEFT_EXACT")) d = 1;       /* A/B: every edge through fmd_ovlp_check_left_dev */
+            if (w->force_exact) d = 1;
             if (d != 1) r->reserved = d < 0 ? 1 : 0;
             else {
                 if (w->n_und == w->m_und) {
@@ -108,6 +109,7 @@ int fmdh_ovlp_table_link(fmdh_ovlp_table_t *t, int n_threads, uint64_t **undecid
     int k, phase, rc = 0;
     uint64_t tot = 0;
     if (undecided) *undecided = 0;
+    const int force_exact = getenv("FMD_CHECK_LEFT_EXACT") != NULL;
     if (n_undecided) *n_undecided = 0;
     if (n >= 0xffffffffull) return -ERANGE;
     if (n_threads < 1) n_threads = 1;
@@ -122,7 +124,7 @@ int fmdh_ovlp_table_link(fmdh_ovlp_table_t *t, int n_threads, uint64_t **undecid
     memset(t->row_of, 0xff, n * 4);
     for (phase = 0; phase < 2; ++phase) {
         for (k = 0; k < n_threads; ++k) {
-            w[k].t = t; w[k].lo = n * (uint64_t)k / (uint64_t)n_threads; w[k].hi = n * (uint64_t)(k + 1) / (uint64_t)n_threads; w[k].phase = phase;
+            w[k].t = t; w[k].lo = n * (uint64_t)k / (uint64_t)n_threads; w[k].hi = n * (uint64_t)(k + 1) / (uint64_t)n_threads; w[k].phase = phase; w[k].force_exact = force_exact;
             started[k] = k > 0 && pthread_create(&tid[k], 0, lk_main, &w[k]) == 0;
         }
         for (k = 0; k < n_threads; ++k) if (!started[k]) lk_main(&w[k]);   /* slice 0, and any slice whose thread could not be created */
@@ -293,7 +295,11 @@ int fmdh_ovlp_table_build(const char *fmd_path, int n_dev, const int *devices, i
                 rc = shard_fill(jobs[0].dev, &ex, und, 0, 0, n_und, min_match, s_len, s_nei, 1);
                 if (rc) { fprintf(stderr, "[E::%s] exact check_left pass: %s\n", __func__, fmd_strerror(rc)); rc = 1; free(und); goto done; }
                 for (k = 0; k < n_und; ++k) n_over += (ex.rec[k].flags & FMD_OVLP_F_OVERFLOW) != 0;
-                if (n_over == 0 || attempt == 12) break;
+                if (n_over == 0) break;
+                if (attempt == 12) {   /* records that still overflow are invalid: their verdicts must not reach the table */
+                    fprintf(stderr, "[E::%s] exact check_left pass: %llu rows still overflow at max_len %u, max_nei %u\n", __func__, (unsigned long long)n_over, s_len, s_nei);
+                    rc = 1; shard_free(&ex); free(und); goto done;
+                }
                 s_len *= 2; s_nei *= 2;
                 shard_free(&ex);
             }

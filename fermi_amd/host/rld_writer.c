@@ -25,7 +25,7 @@
 #include "fmd_host.h"
 
 #define WORDS_PER_BLOCK 8u
-static uint64_t g_words_per_chunk = 1u << 23;   /* rld.h:66; FMD_RLD_TEST_CHUNK_WORDS shrinks it for the tests of the stitch (both encoders) */
+static uint64_t g_words_per_chunk = 1u << 23;   /* rld.h:66; set by encode() before the writers start (test hook: FMD_RLD_TEST_CHUNK_WORDS) */
 #define WORDS_PER_CHUNK g_words_per_chunk
 
 typedef struct {
@@ -199,7 +199,6 @@ static int writer_init(writer_t *s)
     s->held_sym = -1;
     if (grow(s, 2 * WORDS_PER_BLOCK)) return -ENOMEM;
     s->head = 0; s->cur = 2; s->cur_hw = 2; s->room = 64; s->last_usable = usable_tail(0); /* block 0: zero header */
-    { const char *e = getenv("FMD_RLD_TEST_CHUNK_WORDS"); g_words_per_chunk = e && atoll(e) >= 64 ? (uint64_t)atoll(e) / 8 * 8 : 1u << 23; }
     return 0;
 }
 
@@ -357,6 +356,10 @@ static int encode_parallel(const uint8_t *src, int is_bwt, uint64_t n, const cha
 static int encode(const uint8_t *src, int is_bwt, uint64_t n, const char *path)
 {
     int T = 16;
+    /* test hook, read ONCE before any writer thread starts: a shrunken chunk exercises the stitch at chunk ends.  The reference cannot
+     * load such a file (RLD_LSIZE, rld.h:66), so the product honours it only together with FMD_RLD_TEST_HOOKS=1. */
+    { const char *e = getenv("FMD_RLD_TEST_CHUNK_WORDS"), *on = getenv("FMD_RLD_TEST_HOOKS");
+      g_words_per_chunk = (on && atoi(on) == 1 && e && atoll(e) >= 64) ? (uint64_t)atoll(e) / 8 * 8 : 1u << 23; }
     { const char *e = getenv("FMD_HOST_THREADS"); if (e && atoi(e) > 0) T = atoi(e); }
     { const char *e = getenv("FMD_RLD_THREADS"); if (e && atoi(e) > 0) T = atoi(e); }   /* (tests: 1 = the one-thread encoder) */
     if (T > 256) T = 256;

@@ -40,13 +40,16 @@ def test_10m_reads_every_leg_bit_exact_on_random_samples(gpu):
     d = json.loads(p.stdout.decode().strip().splitlines()[-1])
     assert d["config"]["reads"] == 10_000_000 and d["overlap_discovery"]["strands_this_rank"] == 20_000_000
     assert d["parity_vs_cpu_on_sample"] == "bit-exact"                                   # overlap records + neighbours, random ids
-    assert d["overlap_discovery"]["pipelined_vs_serial_order"].startswith("identical")
+    assert d["overlap_discovery"]["id_order_one_pass_walk"]["same_results"].startswith("identical")   # the sorted job against the one-pass walk in id order: every strand
     assert d["overlap_discovery"]["overflow_records"] == 0
     assert d["check_left"]["parity_vs_oracle_on_sample"].startswith("bit-exact") and d["check_left"]["lfork_verdicts_equal_exact_kernel"]
     assert d["backward_search"]["parity_vs_cpu_on_sample"] == "bit-exact" and d["backward_search"]["hits"] == 10_000_000
     assert d["smem"]["parity_vs_cpu_on_sample"] == "bit-exact" and d["smem"]["overflow_reads"] == 0
     assert d["kmer_harvest"]["parity_vs_cpu_on_sample"] == "bit-exact"
-    for leg in (d, d["check_left"], d["backward_search"], d["smem"], d["kmer_harvest"]):
+    raw = d["overlap_discovery_on_raw_reads"]                                            # reads with 1 % errors: forks, the general group kernels
+    assert raw["parity_vs_cpu_on_sample"] == "bit-exact" and raw["same_results_both_ways"] and raw["forked"] > 0
+    assert raw["check_left"]["parity_vs_oracle_on_sample"].startswith("bit-exact") and raw["check_left"]["back_bifurcations"] > 0
+    for leg in (d, d["check_left"], d["backward_search"], d["smem"], d["kmer_harvest"], raw):
         f = leg["roofline"]["frac"]
         assert f is None or 0 < f <= 1.0, leg["roofline"]                               # a fraction is a fraction
 

@@ -146,6 +146,7 @@ def test_parallel_rld_encoder_writes_the_bytes_of_the_sequential_one(tmp_path, m
     bwt = _random_bwt(rng, 3_000_000, mean_run, long_runs)
     rle = _to_rle6(bwt)
     if chunk_words:
+        monkeypatch.setenv("FMD_RLD_TEST_HOOKS", "1")
         monkeypatch.setenv("FMD_RLD_TEST_CHUNK_WORDS", str(chunk_words))
     want = {}
     for threads in (1, 3, 16, 61):
