@@ -290,9 +290,10 @@ REF_OVLP_DT = np.dtype([("rank", "<u8"), ("k0", "<u8"), ("k1", "<u8"), ("len", "
                         ("rbeg", "<i4"), ("ext_len", "<i4"), ("n_nei", "<i4"), ("nei", "<u8", (4, 3))])  # oracle/ref_driver.c
 
 
-def cpu_overlap(fmd_path, ids, min_match, g_rec, g_nei):
+def cpu_overlap(fmd_path, ids, min_match, g_rec, g_nei, keep=None):
     """fm_retrieve + fm6_is_contained + fm6_get_nei per sequence id on the host cores (the reference itself when
-    oracle/_ref travelled, else our C port), and the parity check."""
+    oracle/_ref travelled, else our C port), and the parity check (over the rows of `keep` when given: rows that exceeded a
+    capacity carry FMD_OVLP_F_OVERFLOW instead of a result and are re-run larger by the caller)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     cores = usable_cpus()
     n = len(ids)
@@ -307,6 +308,8 @@ def cpu_overlap(fmd_path, ids, min_match, g_rec, g_nei):
         tall = L.refdrv_overlap(e, n, ids.ctypes.data, min_match, rec.ctypes.data, cores)
         L.refdrv_free(e)
         kind = "reference"
+        if keep is not None:
+            rec, g_rec, g_nei = rec[keep], g_rec[keep], g_nei[keep]
         ok = (np.array_equal(rec["rank"], g_rec["rank"]) and np.array_equal(rec["k0"], g_rec["k"][:, 0]) and
               np.array_equal(rec["k1"], g_rec["k"][:, 1]) and np.array_equal(rec["len"], g_rec["len"]) and
               np.array_equal(rec["status"], g_rec["status"]) and np.array_equal(rec["n_ovlp"], g_rec["n_ovlp"]) and
@@ -323,6 +326,8 @@ def cpu_overlap(fmd_path, ids, min_match, g_rec, g_nei):
         t0 = time.time(); rec, nei, _ = o.overlap_batch(ids, min_match, 100, g_nei.shape[1], cores, check_left=False); tall = time.time() - t0
         o.close()
         kind = "port"
+        if keep is not None:
+            rec, nei, g_rec, g_nei = rec[keep], nei[keep], g_rec[keep], g_nei[keep]
         g2 = g_rec.copy(); g2["reserved"] = rec["reserved"]; g2["lfork"] = rec["lfork"]
         ok = rec.tobytes() == g2.tobytes() and nei.tobytes() == g_nei.tobytes()
     return baseline_obj(n / 2.0 / tall, "reads/s", cores, kind,
@@ -866,9 +871,19 @@ def bench_overlap_raw(torch, api, index, dev, n_reads, L, err, fmd_path):
     sel = np.sort(np.random.default_rng(5).choice(n_ids, ns, replace=False))
     sel_d = torch.from_numpy(sel).to(dev)
     g_nei_s = job.nei.view(n_ids, job.max_nei * 32)[sel_d].cpu().numpy().view(api.INTV_DT).reshape(ns, job.max_nei)
-    base, ok = cpu_overlap(fmd_path, sel, 50, g_rec[sel], g_nei_s)
+    over = (g_rec["flags"][sel] & api.OVLP_F_OVERFLOW) != 0     # more than max_nei neighbours: flagged, not answered (the caller re-runs those larger)
+    base, ok = cpu_overlap(fmd_path, sel, 50, g_rec[sel], g_nei_s, keep=~over)
     out["cpu_baseline"] = base
     out["parity_vs_cpu_on_sample"] = "bit-exact" if ok else "MISMATCH"
+    out["overflow_records"] = int(((g_rec["flags"] & api.OVLP_F_OVERFLOW) != 0).sum())
+    if over.any():   # the flagged rows of the sample again with room for 64 neighbours, through the host form, against the reference too
+        ids_o = sel[over].astype(np.uint64)
+        r2, n2, _ = index.overlap(ids_o, 50, L, 64, check_left=False)
+        _, ok2 = cpu_overlap(fmd_path, ids_o, 50, r2, n2, keep=(r2["flags"] & api.OVLP_F_OVERFLOW) == 0)
+        out["overflow_rows_of_the_sample_rerun_with_64_neighbours"] = {"rows": int(over.sum()), "still_overflowing": int(((r2["flags"] & api.OVLP_F_OVERFLOW) != 0).sum()),
+                                                                      "parity_vs_cpu": "bit-exact" if ok2 else "MISMATCH"}
+        if not ok2:
+            out["parity_vs_cpu_on_sample"] = "MISMATCH"
     out["speedup_vs_cpu_all_cores"] = out["reads_per_s"] / base["value"]
     # ---- check_left as the product runs it (lfork verdicts, exact kernel on the open edges) against the oracle's check_left_simple
     job.alloc_link()
