@@ -185,6 +185,8 @@ enum { WK_IDLE = 0, WK_LF, WK_EXT, WK_BOTH, WK_RIGHT, WK_ADM1, WK_ADM2 };
 // the block of its other end when that one does not reach it)?
 __device__ __forceinline__ bool walk_lf_shares(uint64_t k, uint64_t x0, uint64_t sz)
 {
+    // k lies inside [x0, x0 + sz); a range of at most 64 positions touches two consecutive blocks at most -- those of its two ends
+    if (sz <= 63) return true;
     uint32_t o;
     return fmd_in_block(k, fmd_blk_of(x0 - 1), o) || fmd_in_block(k, fmd_blk_of(x0 - 1 + sz), o);
 }
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
                                                  fmd_intv_t *__restrict__ listA, fmd_ovlp_rec_t *__restrict__ rec,
                                                  uint8_t *__restrict__ seq_out, uint32_t seq_stride, uint32_t *__restrict__ queue,
                                                  int info_only, FmdWalkPark *__restrict__ park, const uint32_t *__restrict__ gidx,
-                                                 const uint4 *__restrict__ adm)
+                                                 const uint4 *__restrict__ adm, uint32_t tchunk)
 {
     FMD_DECLARE_COMPACT_LDS();
     size_t sid = 0;
@@ -255,9 +257,9 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
     uint32_t tfw = 0, trv = 0;
     uint4 adm_a = make_uint4(0, 0, 0, 0), adm_b = make_uint4(0, 0, 0, 0);   // WALK_HEAD: the admission record of a strand on its way in (WK_ADM1)
     FmdTickets tk_;
-    fmd_tickets_init(tk_, queue);
+    fmd_tickets_init(tk_, queue, tchunk & 0xffffffu, (MODE != WALK_WHOLE && (tchunk >> 24)) ? n : 0);   // (bit 24: guided chunks, the two passes of a sorted job)
     for (;;) {
-        const size_t my = fmd_tickets_take(tk_, queue, st == WK_IDLE && !exhausted);
+        const size_t my = fmd_tickets_take(tk_, queue, st == WK_IDLE && !exhausted, (MODE != WALK_WHOLE && (tchunk >> 24)) ? n : 0);
         if (st == WK_IDLE && !exhausted) {
             // The two passes of a sorted job take a strand in over one (WALK_HEAD) or two (WALK_TAIL) wave steps: the loads are issued
             // here and complete under the gather of the other lanes (WK_ADM1 / WK_ADM2 below).  A chain of dependent loads in front of
@@ -904,6 +906,18 @@ __global__ __launch_bounds__(64) void k_ovl_cls(FmdIndexView ix, size_t n, int m
 
 // ------------------------------------------------------------------------------- host entry
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+// tickets per atomic of a walk launch (FmdTickets::chunk): `dflt` for large launches, never more than a 64th of a wave's share
+// (the last chunks of a launch are worked off by fewer and fewer waves); the environment variable is the A/B knob
+static uint32_t walk_ticket_chunk(const char *env, uint32_t dflt, size_t n, int grid)
+{
+    const char *e = getenv(env);
+    uint32_t c = e && atoi(e) > 0 ? (uint32_t)atoi(e) : dflt;
+    const size_t share = n / (size_t)(grid > 0 ? grid : 1) / 64;
+    if (!e && c > share) c = (uint32_t)share;
+    if (c < FMD_TICKET_CHUNK) c = FMD_TICKET_CHUNK;
+    if (!getenv("FMD_TICKETS_FIXED")) c |= 1u << 24;   // guided chunks (fmd_wave.h); FMD_TICKETS_FIXED: the A/B switch
+    return c;
+}
 static void launch_seq_out(hipStream_t st, size_t n, uint32_t max_len, const uint8_t *srev, uint32_t stride_r, const fmd_ovlp_rec_t *rec, int min_match,
                            int info_only, uint8_t *seq_out, uint32_t seq_stride, const uint32_t *gidx = nullptr)
 {
@@ -945,7 +959,7 @@ static void ovl_phase_a(const OvlBatch &o, hipStream_t st, size_t b, size_t np, 
         int grid = fmd_grid_for_lds(o.h, np, FMD_COMPACT_LDS_U4 * 16);
         { const char *e = getenv("FMD_WALK_WAVES"); if (per_cu <= 0 && e && atoi(e) > 0) per_cu = atoi(e); }
         if (per_cu > 0 && grid > o.h->n_cu * per_cu) grid = o.h->n_cu * per_cu;
-        k_ovl_walk<WALK_TAIL><<<grid, 64, 0, st>>>(o.ix, np, nullptr, o.min_match, srev, o.stride_r, o.cap, listA, o.rec, seq, o.seq_stride, q0, 0, o.park, o.gidx + b, nullptr);
+        k_ovl_walk<WALK_TAIL><<<grid, 64, 0, st>>>(o.ix, np, nullptr, o.min_match, srev, o.stride_r, o.cap, listA, o.rec, seq, o.seq_stride, q0, 0, o.park, o.gidx + b, nullptr, walk_ticket_chunk("FMD_TAIL_TICKETS", 64, np, grid));
         launch_seq_out(st, np, o.max_len, srev, o.stride_r, o.rec, o.min_match, 0, seq, o.seq_stride, o.gidx + b);
         return;
     }
@@ -958,7 +972,7 @@ static void ovl_phase_a(const OvlBatch &o, hipStream_t st, size_t b, size_t np, 
     int grid = fmd_grid_for_lds(o.h, np, FMD_COMPACT_LDS_U4 * 16);
     { const char *e = getenv("FMD_WALK_WAVES"); if (per_cu <= 0 && e && atoi(e) > 0) per_cu = atoi(e); }   // A/B knob: resident waves per CU
     if (per_cu > 0 && grid > o.h->n_cu * per_cu) grid = o.h->n_cu * per_cu;
-    k_ovl_walk<WALK_WHOLE><<<grid, 64, 0, st>>>(o.ix, np, o.ids + b, o.min_match, srev, o.stride_r, o.cap, listA, o.rec + b, seq, o.seq_stride, q0, 0, nullptr, nullptr, nullptr);
+    k_ovl_walk<WALK_WHOLE><<<grid, 64, 0, st>>>(o.ix, np, o.ids + b, o.min_match, srev, o.stride_r, o.cap, listA, o.rec + b, seq, o.seq_stride, q0, 0, nullptr, nullptr, nullptr, walk_ticket_chunk("FMD_WALK_TICKETS", 64, np, grid));
     launch_seq_out(st, np, o.max_len, srev, o.stride_r, o.rec + b, o.min_match, 0, seq, o.seq_stride);
 }
 
@@ -1241,7 +1255,7 @@ extern "C" int fmd_ovlp_sorted_dev(fmd_dev_t *h, void *stream_, size_t n, const 
         int grid = fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16);
         { const char *e = getenv("FMD_HEAD_WAVES"); if (e && atoi(e) > 0 && grid > h->n_cu * atoi(e)) grid = h->n_cu * atoi(e); }
         k_ovl_walk<WALK_HEAD><<<grid, 64, 0, st>>>(ix, n, d_ids, min_match, nullptr, (uint32_t)sizeof(FmdWalkPark), 0, nullptr, d_rec,
-                                                nullptr, seq_stride, q, 0, park, nullptr, adm);
+                                                nullptr, seq_stride, q, 0, park, nullptr, adm, walk_ticket_chunk("FMD_HEAD_TICKETS", 256, n, grid));
     }
     // the order of pass 2: rows sorted by the minimizer of the bases each strand has shown so far
     {
@@ -1308,7 +1322,7 @@ extern "C" int fmd_seqinfo_dev(fmd_dev_t *h, void *stream_, size_t n, const uint
     fmd_intv_t *listA = (fmd_intv_t *)((uint8_t *)d_work + align_up(n * (size_t)stride_r, 256));
     uint32_t *q0 = fmd_next_queue(h, st);
     k_ovl_walk<WALK_WHOLE><<<fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16), 64, 0, st>>>(fmd_view(h), n, d_ids, 0, srev, stride_r, cap, listA, d_rec,
-                                                                                         d_seq, seq_stride, q0, 1, nullptr, nullptr, nullptr);
+                                                                                         d_seq, seq_stride, q0, 1, nullptr, nullptr, nullptr, FMD_TICKET_CHUNK);
     launch_seq_out(st, n, max_len, srev, stride_r, d_rec, 0, 1, d_seq, seq_stride);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "k_ovl_walk"); return FMD_E_HIP; }

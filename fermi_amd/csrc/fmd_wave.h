@@ -400,18 +400,34 @@ __device__ __forceinline__ uint64_t fmd_block_rank1z(const uint4 *blk, int t, ui
 struct FmdTickets {
     uint32_t cur, end;   // wave-uniform: tickets [cur, end) are ours
     uint32_t nxt;        // lane 0: first ticket of the chunk reserved ahead (atomic may still be in flight)
-};
+    uint32_t nxt_size;   // wave-uniform: its size
+    uint32_t chunk;      // largest chunk.  Atomics on ONE address serialise at ~14 ns each whatever the number of waves: a launch of
+                         // 10^8 short items (k_ovl_walk<WALK_HEAD>: 20 steps each) in chunks of 16 is 6*10^6 atomics = 85 ms of
+                         // counter time for 50 ms of work.  Kernels with many short items therefore take large chunks -- and, so that
+                         // the end of the launch is not worked off by a few waves holding the last large chunks, guided ones: a chunk
+                         // is 1/(2 * waves) of what is left of the n items when it is reserved, between FMD_TICKET_CHUNK and `chunk`
+};                       // (guided chunks: the caller passes the number of items of the launch to every call; 0 = every chunk is `chunk`)
 
-__device__ __forceinline__ void fmd_tickets_init(FmdTickets &t, uint32_t *queue)
+__device__ __forceinline__ uint32_t fmd_tickets_size(const FmdTickets &t, uint32_t at, size_t n_guided)
+{
+    if (n_guided == 0) return t.chunk;
+    const uint32_t n = (uint32_t)n_guided, rem = n > at ? n - at : 0u, g = rem / (2u * gridDim.x);
+    return g < FMD_TICKET_CHUNK ? FMD_TICKET_CHUNK : (g > t.chunk ? t.chunk : g);
+}
+
+// n_guided > 0: guided chunks over a launch of that many items (all waves of the grid take part)
+__device__ __forceinline__ void fmd_tickets_init(FmdTickets &t, uint32_t *queue, uint32_t chunk = FMD_TICKET_CHUNK, size_t n_guided = 0)
 {
     uint32_t v = 0;
-    if (fmd_lane() == 0) v = atomicAdd(queue, 64u + FMD_TICKET_CHUNK); // one item per lane to start with + the chunk ahead
+    t.chunk = chunk;
+    t.nxt_size = fmd_tickets_size(t, 64u * gridDim.x, n_guided);   // (where the queue stands once every wave has taken its first 64)
+    if (fmd_lane() == 0) v = atomicAdd(queue, 64u + t.nxt_size); // one item per lane to start with + the chunk ahead
     v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
     t.cur = v; t.end = v + 64; t.nxt = v + 64;
 }
 
 // All 64 lanes call this together; returns the item of each lane that asked, (size_t)-1 otherwise.
-__device__ __forceinline__ size_t fmd_tickets_take(FmdTickets &t, uint32_t *queue, bool want)
+__device__ __forceinline__ size_t fmd_tickets_take(FmdTickets &t, uint32_t *queue, bool want, size_t n_guided = 0)
 {
     const uint64_t m = __ballot(want);
     if (m == 0) return (size_t)-1;
@@ -423,9 +439,10 @@ __device__ __forceinline__ size_t fmd_tickets_take(FmdTickets &t, uint32_t *queu
         if (want && p - served < k) res = (size_t)t.cur + (p - served);
         t.cur += k; served += k;
         if (served == need) break;
-        t.cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.nxt); t.end = t.cur + FMD_TICKET_CHUNK;
+        t.cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.nxt); t.end = t.cur + t.nxt_size;
+        t.nxt_size = fmd_tickets_size(t, t.end, n_guided);
         uint32_t v = 0;
-        if (fmd_lane() == 0) v = atomicAdd(queue, (uint32_t)FMD_TICKET_CHUNK);
+        if (fmd_lane() == 0) v = atomicAdd(queue, t.nxt_size);
         t.nxt = v;
     }
     return res;
@@ -522,7 +539,14 @@ __device__ __forceinline__ FmdRank2c fmd_wave_rank2_fetch_compact(const FmdIndex
     FmdRank2c r;
     r.hk = k != ~0ull; r.hl = l != ~0ull;
     uint32_t ok_, ol_;
-    fmd_split(k, r.blk_k, ok_); fmd_split(l, r.blk_l, ol_);
+    fmd_split(k, r.blk_k, ok_);
+#if !FMD_BLK_OVERLAP
+    if (r.hk && r.hl && l - k < FMD_BLK_SYMS) {   // the two ends of a narrow interval: one division, not two
+        ol_ = ok_ + (uint32_t)(l - k); r.blk_l = r.blk_k;
+        if (ol_ >= FMD_BLK_SYMS) { ol_ -= FMD_BLK_SYMS; ++r.blk_l; }
+    } else
+#endif
+    fmd_split(l, r.blk_l, ol_);
     fmd_l_from_k(r.hk && r.hl, l, r.blk_k, r.blk_l, ol_);
     r.l_sep = r.hl && !(r.hk && r.blk_k == r.blk_l);
     fmd_fetch_slot<0>(ix, lds, r.blk_k, r.hk);
