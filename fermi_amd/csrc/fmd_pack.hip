@@ -260,8 +260,24 @@ static int packed_batch_core(fmd_dev_t *h, const uint64_t *ids, uint64_t first, 
     DevMem d_ids, d_rec, d_nei, d_seq, d_work, d_prec[2], d_off[2], d_var[2];
     Stream s_cmp, s_cpy;
     Event done[2], copied[2];
-    if (d_ids.alloc(h, m * 8) || d_rec.alloc(h, m * sizeof(fmd_ovlp_rec_t)) || d_nei.alloc(h, m * max_nei * sizeof(fmd_intv_t)) || d_seq.alloc(h, m * (size_t)stride) ||
-        d_work.alloc(h, wb)) return FMD_E_NOMEM;
+    // Large tables: ALL rows from one sorted job (fmd_ovlp_sorted_dev: the order that keeps neighbours on the genome in flight together)
+    // into fixed-stride arrays for the whole table, which the chunks are then packed from in id order.  Taken when those arrays + the
+    // job's work area fit beside what is in HBM already; otherwise chunk by chunk in id order, as before.
+    size_t sorted_batch = 0, sorted_wb = 0;
+    size_t sort_min = (size_t)1 << 21;   // below this a table has no locality to find (FMD_PACKED_SORT_MIN: tests force the path on small tables)
+    { const char *e = getenv("FMD_PACKED_SORT_MIN"); if (e && atoll(e) > 0) sort_min = (size_t)atoll(e); }
+    if (n >= sort_min && !getenv("FMD_PACKED_UNSORTED")) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        const size_t rows = n * (8 + sizeof(fmd_ovlp_rec_t) + max_nei * sizeof(fmd_intv_t) + (size_t)stride), pk = 2 * (m * sizeof(fmd_ovlp_rec_t) + (m + 1) * 8 + cap);
+        for (size_t bt = (size_t)1 << 24; bt >= ((size_t)1 << 12); bt >>= 1) {
+            const size_t b2 = bt < n ? bt : n, w2 = fmd_ovlp_sorted_work_bytes(n, b2, max_len, min_match);
+            if (rows + pk + (w2 > wb1 ? w2 : wb1) + ((size_t)2 << 30) <= free_b) { sorted_batch = b2; sorted_wb = w2 > wb1 ? w2 : wb1; break; }
+        }
+    }
+    const size_t mr = sorted_batch ? n : m;   // rows the fixed-stride arrays hold
+    if (d_ids.alloc(h, mr * 8) || d_rec.alloc(h, mr * sizeof(fmd_ovlp_rec_t)) || d_nei.alloc(h, mr * max_nei * sizeof(fmd_intv_t)) || d_seq.alloc(h, mr * (size_t)stride) ||
+        d_work.alloc(h, sorted_batch ? sorted_wb : wb)) return FMD_E_NOMEM;
     for (int k = 0; k < 2; ++k)
         if (d_prec[k].alloc(h, m * sizeof(fmd_ovlp_rec_t)) || d_off[k].alloc(h, (m + 1) * 8) || d_var[k].alloc(h, cap) || done[k].make() || copied[k].make()) return FMD_E_NOMEM;
     if (s_cmp.make() || s_cpy.make()) return FMD_E_HIP;
@@ -274,25 +290,42 @@ static int packed_batch_core(fmd_dev_t *h, const uint64_t *ids, uint64_t first, 
     int rc = FMD_OK;
     std::vector<void *> registered;
     auto fail = [&](int code) { rc = code; };
+    double t_job = 0;
+    if (sorted_batch) {   // every row of the table, once
+        const double t0 = now();
+        if (ids) { if (hipMemcpyAsync(d_ids.p, ids, n * 8, hipMemcpyHostToDevice, s_cmp.s) != hipSuccess) fail(FMD_E_HIP); }
+        else k_fill_ids<<<1024, 256, 0, s_cmp.s>>>(n, first, step, (uint64_t *)d_ids.p);
+        if (rc == FMD_OK && (hipMemsetAsync(d_seq.p, 0, n * (size_t)stride, s_cmp.s) != hipSuccess || hipMemsetAsync(d_nei.p, 0, n * max_nei * sizeof(fmd_intv_t), s_cmp.s) != hipSuccess)) fail(FMD_E_HIP);
+        if (rc == FMD_OK)
+            rc = fmd_ovlp_sorted_dev(h, s_cmp.s, n, (uint64_t *)d_ids.p, min_match, max_len, max_nei, (fmd_ovlp_rec_t *)d_rec.p, (fmd_intv_t *)d_nei.p, (uint8_t *)d_seq.p, stride,
+                                     d_work.p, sorted_wb, sorted_batch);
+        if (rc == FMD_OK && timing) { hipStreamSynchronize(s_cmp.s); t_job = now() - t0; }
+    }
     // chunk c: compute on s_cmp into set c & 1; its copy-out is issued one iteration later
     for (size_t c = 0; c <= n_chunks && rc == FMD_OK; ++c) {
         if (c < n_chunks) {
             const int k = (int)(c & 1);
             const size_t b = c * CH, nc = n - b < CH ? n - b : CH;
+            const size_t row0 = sorted_batch ? b : 0;   // the chunk's first row in the fixed-stride arrays
+            fmd_ovlp_rec_t *c_rec = (fmd_ovlp_rec_t *)d_rec.p + row0;
+            fmd_intv_t *c_nei = (fmd_intv_t *)d_nei.p + row0 * max_nei;
+            uint8_t *c_seq = (uint8_t *)d_seq.p + row0 * (size_t)stride;
             if (c >= 2 && hipStreamWaitEvent(s_cmp.s, copied[k].e, 0) != hipSuccess) { fail(FMD_E_HIP); break; } // set k has left the GPU
-            if (ids) { if (hipMemcpyAsync(d_ids.p, ids + b, nc * 8, hipMemcpyHostToDevice, s_cmp.s) != hipSuccess) { fail(FMD_E_HIP); break; } }
-            else k_fill_ids<<<1024, 256, 0, s_cmp.s>>>(nc, first + step * b, step, (uint64_t *)d_ids.p);
-            if (hipMemsetAsync(d_seq.p, 0, nc * (size_t)stride, s_cmp.s) != hipSuccess || hipMemsetAsync(d_nei.p, 0, nc * max_nei * sizeof(fmd_intv_t), s_cmp.s) != hipSuccess) { fail(FMD_E_HIP); break; }
-            rc = fmd_ovlp_dev(h, s_cmp.s, nc, (uint64_t *)d_ids.p, min_match, max_len, max_nei, (fmd_ovlp_rec_t *)d_rec.p, (fmd_intv_t *)d_nei.p, (uint8_t *)d_seq.p, stride, d_work.p, wb);
+            if (!sorted_batch) {
+                if (ids) { if (hipMemcpyAsync(d_ids.p, ids + b, nc * 8, hipMemcpyHostToDevice, s_cmp.s) != hipSuccess) { fail(FMD_E_HIP); break; } }
+                else k_fill_ids<<<1024, 256, 0, s_cmp.s>>>(nc, first + step * b, step, (uint64_t *)d_ids.p);
+                if (hipMemsetAsync(d_seq.p, 0, nc * (size_t)stride, s_cmp.s) != hipSuccess || hipMemsetAsync(d_nei.p, 0, nc * max_nei * sizeof(fmd_intv_t), s_cmp.s) != hipSuccess) { fail(FMD_E_HIP); break; }
+                rc = fmd_ovlp_dev(h, s_cmp.s, nc, (uint64_t *)d_ids.p, min_match, max_len, max_nei, c_rec, c_nei, c_seq, stride, d_work.p, wb);
+            }
             if (rc == FMD_OK && with_check_left)
-                rc = fmd_ovlp_check_left_dev(h, s_cmp.s, nc, min_match, max_len, (fmd_ovlp_rec_t *)d_rec.p, (uint8_t *)d_seq.p, stride, d_work.p, wb);
+                rc = fmd_ovlp_check_left_dev(h, s_cmp.s, nc, min_match, max_len, c_rec, c_seq, stride, d_work.p, sorted_batch ? sorted_wb : wb);
             if (rc == FMD_OK)
-                rc = fmd_ovlp_pack_dev(h, s_cmp.s, nc, (fmd_ovlp_rec_t *)d_rec.p, (fmd_intv_t *)d_nei.p, max_nei, (uint8_t *)d_seq.p, stride,
-                                       (fmd_ovlp_rec_t *)d_prec[k].p, (uint64_t *)d_off[k].p, (uint8_t *)d_var[k].p, cap, d_work.p, wb);
+                rc = fmd_ovlp_pack_dev(h, s_cmp.s, nc, c_rec, c_nei, max_nei, c_seq, stride,
+                                       (fmd_ovlp_rec_t *)d_prec[k].p, (uint64_t *)d_off[k].p, (uint8_t *)d_var[k].p, cap, d_work.p, sorted_batch ? sorted_wb : wb);
             if (rc != FMD_OK) break;
             if (keep) { // the fixed-stride record and the first neighbour's coordinates stay on the device for the link pass
-                if (hipMemcpyAsync(keep->rec + b, d_rec.p, nc * sizeof(fmd_ovlp_rec_t), hipMemcpyDeviceToDevice, s_cmp.s) != hipSuccess) { fail(FMD_E_HIP); break; }
-                k_keep_nei01<<<1024, 256, 0, s_cmp.s>>>(nc, (const fmd_intv_t *)d_nei.p, max_nei, keep->nei01 + 2 * b);
+                if (hipMemcpyAsync(keep->rec + b, c_rec, nc * sizeof(fmd_ovlp_rec_t), hipMemcpyDeviceToDevice, s_cmp.s) != hipSuccess) { fail(FMD_E_HIP); break; }
+                k_keep_nei01<<<1024, 256, 0, s_cmp.s>>>(nc, (const fmd_intv_t *)c_nei, max_nei, keep->nei01 + 2 * b);
             }
             if (hipMemcpyAsync(tot + k, (uint64_t *)d_off[k].p + nc, 8, hipMemcpyDeviceToHost, s_cmp.s) != hipSuccess || hipEventRecord(done[k].e, s_cmp.s) != hipSuccess) { fail(FMD_E_HIP); break; }
         }
@@ -324,8 +357,8 @@ static int packed_batch_core(fmd_dev_t *h, const uint64_t *ids, uint64_t first, 
     hipStreamSynchronize(s_cmp.s);
     const double t_tail0 = now();
     hipStreamSynchronize(s_cpy.s);
-    if (timing) fprintf(stderr, "[M::%s] %zu rows in %zu chunks: device buffers + pinning %.3f s, waiting for kernels %.3f s, host allocation + copy issue %.3f s, last copy %.3f s, total %.3f s\n",
-                        __func__, n, n_chunks, t_alloc, t_wait, t_host, now() - t_tail0, now() - t_begin);
+    if (timing) fprintf(stderr, "[M::%s] %zu rows in %zu chunks%s: device buffers + pinning %.3f s, sorted job %.3f s, waiting for kernels %.3f s, host allocation + copy issue %.3f s, last copy %.3f s, total %.3f s\n",
+                        __func__, n, n_chunks, sorted_batch ? " (all rows from one sorted job)" : " (chunk by chunk in id order)", t_alloc, t_job, t_wait, t_host, now() - t_tail0, now() - t_begin);
     for (void *q : registered) hipHostUnregister(q);
     hipHostFree(tot);
     if (rc == FMD_OK) {

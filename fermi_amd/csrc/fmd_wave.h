@@ -396,7 +396,9 @@ __device__ __forceinline__ uint64_t fmd_block_rank1z(const uint4 *blk, int t, ui
 // small pool of tickets and reserves the next chunk as soon as it starts on the current one, so
 // the atomic's latency hides behind ~FMD_TICKET_CHUNK finished searches.  Lanes that want an item
 // get consecutive tickets by ballot prefix; a ticket >= n means the queue is drained.
+#ifndef FMD_TICKET_CHUNK
 #define FMD_TICKET_CHUNK 16
+#endif
 struct FmdTickets {
     uint32_t cur, end;   // wave-uniform: tickets [cur, end) are ours
     uint32_t nxt;        // lane 0: first ticket of the chunk reserved ahead (atomic may still be in flight)

@@ -104,3 +104,44 @@ def test_sorted_job_below_the_split_takes_id_order(gpu):
     assert L.fmd_ovlp_sorted_work_bytes(10**6, 10**5, 100, 50) > L.fmd_ovlp_work_bytes(10**5, 100, 50) + 64 * 10**6
     assert L.fmd_ovlp_sorted_dev(d.h, None, 1000, 1, 50, 100, 4, 1, 1, 1, 200, 1, 4096, 0) == gpu.FMD_E_ARG
     d.close()
+
+
+@pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20)])
+@pytest.mark.parametrize("devs", [(0,), (0, 0, 0)])
+def test_unitig_from_a_sorted_table_equals_fermi_unitig_t1(gpu, gold, tmp_path, monkeypatch, name, mm, devs):
+    """The product's table (fmd_ovlp_packed_table / fmd_ovlp_packed_batch) takes large tables from one sorted job and packs the
+    chunks from it in id order; forced on the small fixtures here (FMD_PACKED_SORT_MIN), one GPU and three replicas (strided ids):
+    the MAG is `fermi unitig -t1`'s, byte for byte.  (-l20 is below the split: the job runs in id order inside.)"""
+    from fermi_amd import hostlib
+    monkeypatch.setenv("FMD_PACKED_SORT_MIN", "1")
+    out = str(tmp_path / "o.mag")
+    hostlib.unitig(gold.path(name + ".fmd"), mm, out, devices=devs)
+    assert open(out, "rb").read() == gold.text_gz(name + ".mag.gz")
+
+
+def test_packed_rows_from_a_sorted_job_equal_chunked_rows(gpu, monkeypatch):
+    """fmd_ovlp_packed_batch with explicit ids, with and without the sorted job behind it, small chunks: same records, offsets, bytes."""
+    import ctypes as C
+    N = 20000
+    reads = synth.reads(synth.DEFAULT_SEED + 12, N, 100, 30, 0.005)
+    d = gpu.DevIndex.from_bwt(gpu.build_bwt(reads))
+    L = gpu.lib()
+    ids = np.random.default_rng(4).permutation(2 * N)[: 2 * N - 77].astype(U64)
+    n, shift = len(ids), 13
+    nch = (n + (1 << shift) - 1) >> shift
+    res = []
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("FMD_PACKED_SORT_MIN", "1")
+        rec = np.zeros(n, dtype=gpu.OVLP_DT); off = np.zeros(n, dtype=U64)
+        chunks = (C.c_void_p * nch)()
+        gpu.check(L.fmd_ovlp_packed_batch(d.h, ids.ctypes.data, 0, 1, n, 50, 100, 4, 1, rec.ctypes.data, off.ctypes.data, shift, chunks))
+        var = []
+        for c in range(nch):
+            lo, hi = c << shift, min(n, (c + 1) << shift)
+            last = hi - 1
+            var.append(C.string_at(chunks[c], int(off[last])) if hi > lo else b"")   # (up to the start of the chunk's last row: its length follows from its record)
+        L.fmd_ovlp_packed_free(chunks, nch)
+        res.append((rec.tobytes(), off.tobytes(), var))
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and res[0][2] == res[1][2]
+    d.close()
