@@ -368,6 +368,7 @@ class OverlapJob:
         self.stream = torch.cuda.current_stream()
         self.sh = C.c_void_p(self.stream.cuda_stream)
         self.packed = None
+        self.gatherer = None
 
     def compute(self, Lb=None, h=None):
         Lb = Lb or self.api.lib()
@@ -428,10 +429,14 @@ class OverlapJob:
                                                         p["cap"], self.work.data_ptr(), self.wb))
 
     def gather(self, dist):
-        """-> on rank 0: list over ranks of (prec, off, var) device tensors (rank 0's own first); None elsewhere."""
+        """-> on rank 0: list over ranks of (prec, off, var) tensors (rank 0's own first); None elsewhere.  The receive buffers belong to
+        the PackedGather object: allocated in the first (warm-up) step, on the device or -- where the root's HBM cannot hold them -- in
+        pinned host memory, reused afterwards."""
         from fermi_amd import dist as fdist
+        if self.gatherer is None:
+            self.gatherer = fdist.PackedGather(self.torch, dist, self.n_ids, self.rank, self.world, timeout_s=int(os.environ.get("FMD_BENCH_GATHER_TIMEOUT", "120")))
         p = self.packed
-        return fdist.gather_packed(p["prec"], p["off"], p["var"], self.n_ids, self.rank, self.world, dist)
+        return self.gatherer(p["prec"], p["off"], p["var"])
 
 
 def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world, rank, fmd_path, local_rank, legs):
@@ -444,6 +449,8 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
         job.alloc_packed()
 
     def step():
+        if world > 1:
+            ec0 = torch.cuda.Event(enable_timing=True); ec0.record(job.stream)
         job.compute()
         if world > 1:   # the records leave the GPU they were computed on: pack, then the RCCL gather on rank 0
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -451,10 +458,12 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
             job.pack()
             gathered[0] = job.gather(dist)
             e1.record(job.stream)
-            gather_ms.append((e0, e1))
+            gather_ms.append((ec0, e0, e1))
     wall, kern_ms = timed(torch, dist, dev, job.stream, step, steps, warmup)
     out = None
-    g_ms = float(np.mean([a.elapsed_time(b) for a, b in gather_ms[-steps:]])) if gather_ms else None
+    g_ms = float(np.mean([a.elapsed_time(b) for _, a, b in gather_ms[-steps:]])) if gather_ms else None
+    if gather_ms:   # the discovery kernels of this rank alone (what its roofline is priced on)
+        kern_ms = float(np.mean([c.elapsed_time(a) for c, a, _ in gather_ms[-steps:]]))
 
     # ---- N > 1, outside the timed region: rank 0 recomputes a sample of ids itself and compares with what arrived
     gather_note = None
@@ -474,10 +483,14 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
            "contained": int((g_rec["status"] == -3).sum()), "with_neighbour": int((g_rec["n_nei"] > 0).sum())}
     if world > 1:
         tot = sum(int(t[0].numel() + t[2].numel() + t[1].numel() * 8) for t in gathered[0][1:])
-        out["record_gather_rccl"] = {"ms_per_step_pack_plus_gather": g_ms, "bytes_received_by_rank0": tot,
-                                     "bytes_per_strand": tot / max(1, n_ids - job.n), "check": gather_note}
-        return out, job
-    # ---- N = 1: the same strands in id order (the one-pass walk of rounds 1-2), same box, same run: time and bytes
+        out["record_gather_rccl"] = {"ms_per_step_pack_plus_gather": g_ms, "bytes_received_by_rank0": tot, "path": job.gatherer.path,
+                                     "bytes_per_strand": tot / max(1, n_ids - job.n), "check": gather_note,
+                                     "discovery_kernels_ms_per_step_on_rank0": kern_ms}
+        if not fmd_path:
+            return out, job
+    n_loc = job.n               # rows of this rank (all of them at N = 1); everything below is about rank 0's own shard
+    ids_host = job.ids.cpu().numpy().astype(np.uint64)
+    # ---- the same strands in id order (the one-pass walk of rounds 1-2), same box, same run: time and bytes
     if os.environ.get("FMD_BENCH_ID_ORDER_AB", "1") != "0":
         keep = (job.rec, job.nei, job.seq)
         job.rec, job.nei, job.seq = torch.zeros_like(job.rec), torch.zeros_like(job.nei), torch.zeros_like(job.seq)
@@ -501,7 +514,7 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
             sm = torch.arange(job.stride, device=dev)[None, :] < used[:, None]
             same = same and not bool(((keep[2].view(job.n, job.stride)[o:e] != job.seq.view(job.n, job.stride)[o:e]) & sm).any())
         out["id_order_one_pass_walk"] = {"ms_per_step": e0.elapsed_time(e1) / 2, "what": "fmd_ovlp_dev batch by batch over ids in input order (the step of rounds 1-2), 2 passes on this box right after the timed steps",
-                                         "same_results": "identical (records, neighbours, sequences + appended bases of all %d strands)" % n_ids if same else "MISMATCH"}
+                                         "same_results": "identical (records, neighbours, sequences + appended bases of all %d strands)" % n_loc if same else "MISMATCH"}
         job.rec, job.nei, job.seq = keep
     ctr = Counter(api, fmd_path, local_rank)
     lines = ctr.run(job.compute)
@@ -513,11 +526,11 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
     n_neis = int(np.minimum(g_rec["n_nei"][ok_rows], job.max_nei).sum())
     n_ext = int(g_rec["ext_len"][ok_rows].sum())
     stride_r = (L + 15) // 16 * 16
-    streams = {"ids": 2 * 8 * n_ids, "tail_table": 0 if os.environ.get("FMD_TAIL_TABLE") == "0" else 2 * 8 * n_ids, "stash_write_and_read": 2 * stride_r * n_ids, "sequence_rows_out": L * n_ids + 32 * n_ext,
-               "head_admission_records_write_and_read": 2 * 32 * n_ids, "parked_strands_write_read_twice": 3 * 64 * n_ids,
-               "two_sorts_keys_and_rows": 2 * (2 * 8 + 4 * 2 * 8) * n_ids, "slot_to_row_map_reads": 4 * 4 * n_ids,
-               "records_write_classify_read_result_write": 3 * 64 * n_ids, "work_lists": 16 * n_ids,
-               "candidates_write_and_read": 2 * 32 * n_cand, "classify_widest_candidate": 64 * n_ids, "neighbours": 32 * n_neis}
+    streams = {"ids": 2 * 8 * n_loc, "tail_table": 0 if os.environ.get("FMD_TAIL_TABLE") == "0" else 2 * 8 * n_loc, "stash_write_and_read": 2 * stride_r * n_loc, "sequence_rows_out": L * n_loc + 32 * n_ext,
+               "head_admission_records_write_and_read": 2 * 32 * n_loc, "parked_strands_write_read_twice": 3 * 64 * n_loc,
+               "two_sorts_keys_and_rows": 2 * (2 * 8 + 4 * 2 * 8) * n_loc, "slot_to_row_map_reads": 4 * 4 * n_loc,
+               "records_write_classify_read_result_write": 3 * 64 * n_loc, "work_lists": 16 * n_loc,
+               "candidates_write_and_read": 2 * 32 * n_cand, "classify_widest_candidate": 64 * n_loc, "neighbours": 32 * n_neis}
     io = sum(streams.values())
     dev_bytes = None if lines is None else (lines[0] + lines[1]) * BLOCK_BYTES + io
     cn = oracle_counters(fmd_path, lambda o: o.overlap_batch(np.arange(4000, dtype=np.uint64), min_match, 100, 4, 1, check_left=False))
@@ -525,13 +538,14 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
     out["roofline"] = roofline("k_ovl_head_adm + k_ovl_walk<HEAD> + 2 radix sorts + per batch: k_ovl_walk<TAIL> + k_ovl_seq_out + k_ovl_classify + k_ovl_nei_fast<G, M> + k_ovl_nei_grp<G> + k_ovl_nei (one step = one job of %d batches of %d strands)"
                                % ((job.n + job.batch - 1) // job.batch, job.batch), kern_ms, dev_bytes,
                                {"rank_blocks": lines and lines[0], "prefix_table_lines": lines and lines[1], "stream_bytes": io, "streams": streams},
-                               qps * BYTES_PER_RANK_QUERY * n_ids, "overlap@%d" % n_reads,
-                               {"rank_queries_per_strand": qps, "oracle_counters_on_sample": cn})
-    ns = min(n_ids, int(os.environ.get("FMD_BENCH_CPU_SAMPLE_OVLP", "400000")))
-    sel = np.sort(np.random.default_rng(2).choice(n_ids, ns, replace=False))
+                               qps * BYTES_PER_RANK_QUERY * n_loc, "overlap@%d" % n_reads if world == 1 else "overlap@%d/%d" % (n_reads, world),
+                               {"rank_queries_per_strand": qps, "oracle_counters_on_sample": cn,
+                                "scope": "rank 0's shard of %d strands, its discovery kernels alone" % n_loc if world > 1 else "all %d strands" % n_loc})
+    ns = min(n_loc, int(os.environ.get("FMD_BENCH_CPU_SAMPLE_OVLP", "400000")))
+    sel = np.sort(np.random.default_rng(2).choice(n_loc, ns, replace=False))
     sel_d = torch.from_numpy(sel).to(dev)
-    g_nei_s = job.nei.view(n_ids, job.max_nei * 32)[sel_d].cpu().numpy().view(api.INTV_DT).reshape(ns, job.max_nei)
-    base, ok = cpu_overlap(fmd_path, sel, min_match, g_rec[sel], g_nei_s)
+    g_nei_s = job.nei.view(n_loc, job.max_nei * 32)[sel_d].cpu().numpy().view(api.INTV_DT).reshape(ns, job.max_nei)
+    base, ok = cpu_overlap(fmd_path, ids_host[sel], min_match, g_rec[sel], g_nei_s)
     out["cpu_baseline"] = base
     out["parity_vs_cpu_on_sample"] = "bit-exact" if ok else "MISMATCH"
     out["speedup_vs_cpu_all_cores"] = out["value"] / base["value"]
@@ -539,7 +553,7 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
     # the reference's per-read functions hand their results to host code: the same discovery through the host form the CLI uses
     # (fmd_ovlp_packed_batch: chunks of 2^22 rows computed, packed and copied to host memory, copy of one chunk under the compute
     # of the next), wall clock, one batch.  Reported beside `value`, never as `value`.
-    if os.environ.get("FMD_BENCH_HOST_API", "1") != "0":
+    if os.environ.get("FMD_BENCH_HOST_API", "1") != "0" and world == 1:
         try:
             nb = min(n_ids, 20_000_000)
             h_rec = np.zeros(nb, dtype=api.OVLP_DT); h_off = np.zeros(nb, dtype=np.uint64)
@@ -951,6 +965,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     assert api.device_count() > 0, "bench.py needs a GPU: libfmdhip has no CPU fallback"
+    if dist:
+        from fermi_amd import dist as fdist
+        fdist.describe_fabric(torch, dist, rank, world)
 
     n_reads = int(os.environ.get("FMD_BENCH_READS", "50000000"))
     L = 100
@@ -966,7 +983,7 @@ def main():
     torch.cuda.synchronize()
     t2 = time.time()
     fmd_path = None
-    if rank == 0 and world == 1:
+    if rank == 0:   # (N > 1 too: rank 0 prices its own shard -- roofline, CPU baseline, parity -- as the N = 1 line does)
         fmd_path = os.path.join(tempfile.gettempdir(), "fmd_bench_%d_%d.fmd" % (n_reads, os.getpid()))
         workload.write_fmd_from_device_bwt(d_bwt, n_sym, fmd_path, local_rank)
     t3 = time.time()

@@ -30,15 +30,27 @@ def _oracle_rows(fmd, ids, min_match):
     return packref.pack_rows(rec, nei, seq, 4)
 
 
-def _worker(rank, world, port, fmd, n_ids, min_match, q):
+def _worker(rank, world, port, fmd, n_ids, min_match, q, mode="device"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ids = fdist.shard_ids(n_ids, rank, world)
     prec, off, var = _oracle_rows(fmd, ids, min_match)
     cap = len(var) + 64     # the device buffer is larger than what is used: only off[-1] bytes travel
     var_t = torch.zeros(cap, dtype=torch.uint8); var_t[: len(var)] = torch.from_numpy(var)
-    got = fdist.gather_packed(torch.from_numpy(prec.view(np.uint8).reshape(-1).copy()), torch.from_numpy(off.astype(np.int64)), var_t,
-                              n_ids, rank, world, dist)
+    # the gather object of bench.py: buffers allocated in the first step, reused in the second.  mode: the direct batched form,
+    # peer after peer through a staging buffer (what configs[4] needs on the root), or the padded all-gather a transport
+    # without batch_isend_irecv falls back to (the probe is made to fail on every rank)
+    g = fdist.PackedGather(torch, dist, n_ids, rank, world, force_path=None if mode == "fallback" else mode, timeout_s=120)
+    if mode == "fallback":
+        g._break_p2p = True
+    fdist.describe_fabric(torch, dist, rank, world)
+    args = (torch.from_numpy(prec.view(np.uint8).reshape(-1).copy()), torch.from_numpy(off.astype(np.int64)), var_t)
+    first = g(*args)
+    keep = None if first is None else [b[2].data_ptr() for b in first]
+    got = g(*args)
+    assert g.path == {"device": "device", "host-rounds": "host-rounds", "fallback": "all-gather"}[mode], g.path
+    if rank == 0 and mode != "fallback":
+        assert keep == [b[2].data_ptr() for b in got], "the receive buffers must be the first step's"
     if rank == 0:
         want_p, want_o, want_v = _oracle_rows(fmd, np.arange(n_ids, dtype=np.uint64), min_match)
         ok = len(got) == world
@@ -88,12 +100,16 @@ def test_packed_rows_roundtrip(oracle_lib):
         assert np.array_equal(s, seq[i, :nb]) and ne.tobytes() == nei[i, :min(rec[i]["n_nei"], 4)].tobytes()
 
 
-def test_gather_packed_records_world2_gloo(oracle_lib):
+import pytest
+
+
+@pytest.mark.parametrize("world,mode", [(2, "device"), (3, "host-rounds"), (2, "fallback")])
+def test_gather_packed_records_gloo(oracle_lib, world, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     n_ids = 1001  # odd: ranks hold different counts
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, os.path.join(GOLD, "tiny.fmd"), n_ids, 50, q)) for r in range(2)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, os.path.join(GOLD, "tiny.fmd"), n_ids, 50, q, mode)) for r in range(world)]
     for p in ps:
         p.start()
     ok = q.get(timeout=180)

@@ -1,0 +1,45 @@
+"""GPU, BASELINE.json configs[4] (700 M x 100 bp, human-35x scale: 1.4*10^11 symbols, one GPU's 1/8 share of the ids) and the
+builders that only sizes beyond 2^32 symbols exercise, inside `pytest -m gpu` (they were builder-run tool logs).
+
+  * 7*10^8 reads: the in-place builder (4-bit text + BWT slices ORed straight into the device layout, prefix buckets of depth 4),
+    the rank self-check over all 1.4*10^11 positions, sampled reads hit themselves, overlap discovery of random ids checked by what
+    the generator knows (sequences, the one neighbour and its overlap from the start positions, mutual edges, mirrored intervals),
+    the four-part k-mer harvest cross-checked by backward search, and the share i = 0 (mod 8) of the discovery timed.  ~10 minutes.
+  * 1.3*10^8 reads (2.6*10^10 symbols): the bucketed byte-BWT builder, the .fmd written by the product and loaded by the REFERENCE
+    (oracle/_ref when it travelled, the oracle otherwise): backward search and overlap discovery of 20 000 random reads / ids
+    bit-exact, plus the same generator properties.  ~3 minutes.
+Both run tools/scale_check.py (the log goes to gpurun_out/ when that directory exists)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _scale_check(tag, args, timeout):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scale_check.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+    txt = p.stdout.decode(errors="replace")
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        open(os.path.join(out, "pytest_scale_%s.txt" % tag), "w").write(txt)
+    assert p.returncode == 0 and "scale check passed" in txt, txt[-3000:]
+    return txt
+
+
+@pytest.mark.skipif(os.environ.get("FMD_TEST_SKIP_CFG5") == "1", reason="FMD_TEST_SKIP_CFG5=1")
+def test_config5_700m_reads_index_in_place_and_one_gpus_share(gpu):
+    import torch
+    free_b, total_b = torch.cuda.mem_get_info()
+    assert total_b > 250e9, "config 5 needs the 288 GB of an MI355X"
+    txt = _scale_check("700M", ["700000000", "inplace", "20000", "8", "noref", "kmer", "props"], 1500)
+    assert "141400000000 positions: 0 bad" in txt and "properties on" in txt and "cross-checked by backward search" in txt
+    assert "share 1/8 of the overlap discovery on this index: 175000000 strands" in txt and "(0 overflow records" in txt
+
+
+def test_130m_reads_bucketed_builder_fmd_and_reference(gpu):
+    txt = _scale_check("130M", ["130000000", "bwt", "20000", "8", "props"], 900)
+    assert "26260000000 positions: 0 bad" in txt and "properties on" in txt
+    assert "backward search vs" in txt and "overlap discovery vs" in txt and "MISMATCH" not in txt

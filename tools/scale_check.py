@@ -8,7 +8,12 @@ device layout; the only form that carries 1.4*10^11 symbols) --, then
   * backward search and overlap discovery on random samples against the REFERENCE (oracle/_ref when it travelled, the oracle
     otherwise) through the .fmd the product writes (skipped with `noref`),
   * config 5's share of one GPU out of `share` (ids i = 0 mod share): one timed pass of overlap discovery on this index.
-Usage: python tools/scale_check.py [n_reads=250000000] [bwt|inplace] [sample=20000] [share=8] [noref] [kmer]"""
+  * `props`: size-independent properties of the discovery on random ids, from what the GENERATOR knows (no reference needed):
+    the sequence rows are the generated reads (fm_retrieve inverts the index), a strand whose successor on the genome is unambiguous
+    has exactly that read as its one neighbour with the overlap the two start positions give, and the edge is mutual (the
+    successor's reverse strand is followed by the strand's reverse strand with the same overlap),
+  * `kmer` with `noref`: the harvest's solid k-mers cross-checked by backward search on a sample.
+Usage: python tools/scale_check.py [n_reads=250000000] [bwt|inplace] [sample=20000] [share=8] [noref] [kmer] [props]"""
 import ctypes as C, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -101,6 +106,38 @@ assert bad.value == 0
 # a spread sample of the reads: blocks of 1000 consecutive reads
 starts = np.sort(rng.choice(n_reads // 1000, max(1, sample // 1000), replace=False)) * 1000
 q = torch.cat([synth.reads_torch(seed, n_reads, L, 30, 0.0, dev, start=int(s), count=1000, gen=gen) for s in starts]).cpu().numpy()
+if "props" in sys.argv[5:]:
+    # ---- what the generator knows: where every read starts and which way round it is
+    G = gen.shape[0]
+    t0 = time.time()
+    pos = torch.empty(n_reads, dtype=torch.int64, device=dev); sbit = torch.empty(n_reads, dtype=torch.int8, device=dev)
+    for s0 in range(0, n_reads, 50_000_000):
+        r_ = torch.arange(s0, min(n_reads, s0 + 50_000_000), dtype=torch.int64, device=dev)
+        pos[s0:s0 + r_.numel()] = synth._umod(synth.rnd_torch(seed, 2, r_), G - L + 1)
+        sbit[s0:s0 + r_.numel()] = synth._lsr(synth.rnd_torch(seed, 3, r_), 63).to(torch.int8)
+    P, order = torch.sort(pos)
+    del pos
+    m = min(sample, n_reads - 4)
+    ii = torch.from_numpy(np.sort(rng.choice(n_reads - 4, m, replace=False)) + 2).to(dev)     # ranks in start order, away from the ends
+    d_next, d_prev = P[ii + 1] - P[ii], P[ii] - P[ii - 1]
+    # unambiguous successor on the + strand: the next start is 1..50 bases on, nobody shares this start or that one
+    okp = (d_next >= 1) & (d_next <= L - 50) & (P[ii + 2] != P[ii + 1]) & (d_prev >= 1)
+    okm = (d_prev >= 1) & (d_prev <= L - 50) & (P[ii - 2] != P[ii - 1]) & (d_next >= 1)
+    r_a = order[ii]
+    plus = lambda rr: 2 * rr + sbit[rr].to(torch.int64)          # the strand of read rr that reads like the genome
+    minus = lambda rr: 2 * rr + 1 - sbit[rr].to(torch.int64)
+    a_p, b_p, o_p = plus(r_a)[okp], plus(order[ii + 1])[okp], (L - d_next)[okp]
+    a_m, b_m, o_m = minus(r_a)[okm], minus(order[ii - 1])[okm], (L - d_prev)[okm]
+    A = torch.cat([a_p, a_m]).cpu().numpy().astype(np.uint64); B = torch.cat([b_p, b_m]).cpu().numpy().astype(np.uint64)
+    OV = torch.cat([o_p, o_m]).cpu().numpy()
+    # the reads themselves (for the retrieve check): strand A[i] as the generator makes it
+    ra = torch.from_numpy((A >> np.uint64(1)).astype(np.int64)).to(dev)
+    win = gen[synth._umod(synth.rnd_torch(seed, 2, ra), G - L + 1)[:, None] + torch.arange(L, device=dev)[None, :]]
+    fw = sbit[ra].to(torch.int64) == torch.from_numpy((A & np.uint64(1)).astype(np.int64)).to(dev)     # strand 2r + s reads like the genome
+    want_seq = torch.where(fw[:, None], win, (5 - win).flip(1)).cpu().numpy()
+    del P, order, sbit, win
+    torch.cuda.empty_cache()
+    print("generator: %d strands with an unambiguous successor among %d sampled reads (%.1f s)" % (len(A), m, time.time() - t0), flush=True)
 del gen
 torch.cuda.empty_cache()
 cnt, beg, end = index.backward_search(q)
@@ -110,6 +147,40 @@ ids = np.sort(rng.choice(2 * n_reads, min(sample, 2 * n_reads), replace=False)).
 rec, nei, seq = index.overlap(ids, 50, max_len=100, max_nei=4, check_left=False)
 print("overlap discovery of %d random sequence ids: %d with a neighbour, %d contained, %d overflow" % (len(ids), int((rec["n_nei"] > 0).sum()), int((rec["status"] == -3).sum()),
       int(((rec["flags"] & api.OVLP_F_OVERFLOW) != 0).sum())), flush=True)
+if "props" in sys.argv[5:]:
+    t0 = time.time()
+    all_ids = np.unique(np.concatenate([A, A ^ np.uint64(1), B, B ^ np.uint64(1)]))
+    prec, pnei, pseq = index.overlap(all_ids, 50, max_len=100, max_nei=4, check_left=False)
+    at = lambda x: np.searchsorted(all_ids, x)
+    ia, ia1, ib, ib1 = at(A), at(A ^ np.uint64(1)), at(B), at(B ^ np.uint64(1))
+    assert (prec["len"][ia] == L).all() and np.array_equal(pseq[ia, :L], want_seq), "fm_retrieve does not give the generated reads back"
+    assert (prec["status"][ia] == 0).all() and (prec["n_nei"][ia] == 1).all(), "a strand with an unambiguous successor must have exactly one neighbour"
+    assert np.array_equal(pnei["info"][ia, 0].astype(np.int64), OV.astype(np.int64)), "overlap length differs from what the start positions give"
+    assert np.array_equal(pnei["x"][ia, 0, 0], prec["k"][ib, 0]), "the neighbour is not the successor on the genome"
+    assert (prec["n_nei"][ib1] >= 1).all() and np.array_equal(pnei["x"][ib1, 0, 0], prec["k"][ia1, 0]) and np.array_equal(pnei["info"][ib1, 0].astype(np.int64), OV.astype(np.int64)), "the edge is not mutual"
+    assert np.array_equal(prec["k"][ia, 0], prec["k"][ia1, 1]) and np.array_equal(prec["k"][ia, 2], prec["k"][ia1, 2]), "`$read$` intervals of the two strands do not mirror each other"
+    print("properties on %d strands (+ their reverse strands, successors and the successors' reverse strands: %d ids): sequences = the generated reads, one neighbour = "
+          "the successor on the genome with the overlap the start positions give, edges mutual, strand intervals mirrored (%.1f s)" % (len(A), len(all_ids), time.time() - t0), flush=True)
+    del prec, pnei, pseq
+if noref and "kmer" in sys.argv[5:]:   # the harvest of `fermi correct` over the whole index, cross-checked by backward search
+    import math
+    w = min(27, int(math.log(n_sym) / math.log(4) + 8.499)); suf_len = w - 15 if w > 15 else 1
+    t0 = time.time()
+    kb, kk, kv, kc = index.kmer_collect(w, 3, suf_len)
+    t_h = time.time() - t0
+    print("k-mer harvest (k = %d, min_occ 3): %d solid %d-mers in %.1f s incl. the copy to the host (%.2e per s), %d informative; HBM in use %.1f GB"
+          % (w, len(kb), w - 1, t_h, len(kb) / t_h, kc[1], hbm_used()), flush=True)
+    sel = np.sort(rng.choice(len(kb), min(len(kb), 200_000), replace=False))
+    Ks = (kk[sel].astype(np.uint64) >> np.uint64(2)) << np.uint64(2 * suf_len) | kb[sel].astype(np.uint64)
+    km = np.empty((len(sel), w + 1), dtype=np.uint8)
+    km[:, 0] = (kk[sel] & 3).astype(np.uint8) + 1                                    # the base the table predicts, to the left
+    for dd in range(w):
+        km[:, w - dd] = ((Ks >> np.uint64(2 * dd)) & np.uint64(3)).astype(np.uint8) + 1
+    del kb, kk, kv
+    c1, _, _ = index.backward_search(km)
+    c0, _, _ = index.backward_search(np.ascontiguousarray(km[:, 1:]))
+    assert (c1 >= 3).all() and (c0 >= c1).all(), "a k-mer the harvest calls solid does not occur min_occ times"
+    print("k-mer harvest cross-checked by backward search on %d random solid k-mers: each occurs >= min_occ times with its predicted base" % len(sel), flush=True)
 if not noref:
     base, ok = bench.cpu_bsearch(fmd_path, q, cnt, beg, end)
     print("backward search vs %s on the sample: %s (%.0f reads/s on %d host threads)" % (base["kind"], "bit-exact" if ok else "MISMATCH", base["value"], base["cores"]), flush=True)
