@@ -479,3 +479,23 @@ extern "C" int fmd_kmer_collect(fmd_dev_t *h, int w, int min_occ, int suf_len, u
     else if (!*bucket) { *bucket = (uint32_t *)malloc(4); *key = (uint32_t *)malloc(4); *val = (uint8_t *)malloc(4); }
     return rc;
 }
+
+// The part of the harvest whose k-mers END in one of the bases of seed_mask (bit c-1 = base c), host form: what one GPU of several
+// computes when `fermi-amd correct -g a,b,..` shards the harvest -- the reference hands suffix buckets to its workers
+// (correct.c:346-356); here the trie is a forest rooted at the last base, so the shards are whole trees.  Same outputs as
+// fmd_kmer_collect (malloc'ed, fmd_host_free; cnt[] = the shard's own counts); the union over disjoint masks that cover 0xf is the
+// whole harvest.
+extern "C" int fmd_kmer_collect_seeds(fmd_dev_t *h, int w, int min_occ, int suf_len, int seed_mask, uint32_t **bucket, uint32_t **key, uint8_t **val,
+                                      uint64_t *n, int64_t cnt[2])
+{
+    if (!h || !bucket || !key || !val || !n || !cnt || (seed_mask & ~0xf)) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    *bucket = nullptr; *key = nullptr; *val = nullptr; *n = 0; cnt[0] = cnt[1] = 0;
+    uint64_t m_alloc = 0;
+    int rc = FMD_OK;
+    for (int p = 0; p < 4 && rc == FMD_OK; ++p)     // one tree at a time: a quarter of the frontier memory of the whole harvest
+        if ((seed_mask >> p) & 1) rc = km_collect_part_host(h, w, min_occ, suf_len, 1 << p, 1u << 22, bucket, key, val, n, &m_alloc, cnt);
+    if (rc != FMD_OK) { free(*bucket); free(*key); free(*val); *bucket = nullptr; *key = nullptr; *val = nullptr; *n = 0; }
+    else if (!*bucket) { *bucket = (uint32_t *)malloc(4); *key = (uint32_t *)malloc(4); *val = (uint8_t *)malloc(4); }
+    return rc;
+}

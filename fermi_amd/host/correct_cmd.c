@@ -37,7 +37,8 @@ typedef struct {
 } batch_t;
 
 typedef struct {
-    const fmdh_ecopt_t *opt; fmd_ectab_t *tab; FILE *out;
+    const fmdh_ecopt_t *opt; FILE *out;
+    fmd_ectab_t *tab[FMDH_MAX_GPUS]; int n_tab;   /* one copy of the table per GPU: a batch is split over them */
     batch_t b[3];
     pthread_mutex_t mu; pthread_cond_t cv;
     int failed;               /* set by any of the three pipeline threads: atomic accesses only */
@@ -98,6 +99,30 @@ static void encode_batch(batch_t *b)
     for (t = 1; t < T; ++t) { if (started[t]) pthread_join(tid[t], 0); else enc_main(&e[t]); }
 }
 
+/* one GPU's slice [lo, hi) of a batch */
+typedef struct { pipe_t *p; batch_t *b; int g; size_t lo, hi; int rc; } gslice_t;
+static void *gslice_main(void *d)
+{
+    gslice_t *s = (gslice_t *)d;
+    s->rc = s->hi > s->lo ? fmd_ecfix_batch(s->p->tab[s->g], s->hi - s->lo, s->b->nt6, s->b->qual, s->b->off + s->lo, s->p->opt->step, s->b->info + s->lo) : 0;
+    return 0;
+}
+/* ec_fix (correct.c:221-246) of a batch: reads are independent given the table, so with several GPUs each takes a contiguous share */
+static int fix_batch(pipe_t *p, batch_t *b)
+{
+    gslice_t sl[FMDH_MAX_GPUS];
+    pthread_t tid[FMDH_MAX_GPUS];
+    int started[FMDH_MAX_GPUS], g, rc = 0;
+    const int G = p->n_tab;
+    if (G == 1) return fmd_ecfix_batch(p->tab[0], b->nb, b->nt6, b->qual, b->off, p->opt->step, b->info);
+    for (g = 0; g < G; ++g) { sl[g].p = p; sl[g].b = b; sl[g].g = g; sl[g].lo = b->nb * (size_t)g / (size_t)G; sl[g].hi = b->nb * (size_t)(g + 1) / (size_t)G; sl[g].rc = 0; }
+    for (g = 1; g < G; ++g) started[g] = pthread_create(&tid[g], 0, gslice_main, &sl[g]) == 0;
+    gslice_main(&sl[0]);
+    for (g = 1; g < G; ++g) { if (started[g]) pthread_join(tid[g], 0); else gslice_main(&sl[g]); }
+    for (g = 0; g < G; ++g) if (sl[g].rc && !rc) rc = sl[g].rc;
+    return rc;
+}
+
 /* stage 2: the GPU corrects a parsed batch in place (nt6 + qual) */
 static void *stage_gpu(void *d)
 {
@@ -108,7 +133,7 @@ static void *stage_gpu(void *d)
         const double t0 = now_s();
         if (b->nb && !__atomic_load_n(&p->failed, __ATOMIC_RELAXED)) encode_batch(b);
         if (b->nb && !__atomic_load_n(&p->failed, __ATOMIC_RELAXED)) {
-            const int rc = fmd_ecfix_batch(p->tab, b->nb, b->nt6, b->qual, b->off, p->opt->step, b->info);
+            const int rc = fix_batch(p, b);
             if (rc) { fprintf(stderr, "[E::%s] correction pass failed: %s\n", __func__, fmd_strerror(rc)); __atomic_store_n(&p->failed, 1, __ATOMIC_RELAXED); }
         }
         p->t_gpu += now_s() - t0;
@@ -218,16 +243,28 @@ static void *stage_print(void *d)
 int fmdh_correct_reads(const fmdh_ecopt_t *opt, int device, int suf_len, uint64_t n, const uint32_t *bucket, const uint32_t *key, const uint8_t *val,
                        const char *fq_path, FILE *out)
 {
+    return fmdh_correct_reads_multi(opt, 1, &device, suf_len, n, bucket, key, val, fq_path, out);
+}
+
+static void free_tabs(pipe_t *p) { for (int g = 0; g < p->n_tab; ++g) fmd_ectab_free(p->tab[g]); p->n_tab = 0; }
+
+int fmdh_correct_reads_multi(const fmdh_ecopt_t *opt, int n_dev, const int *devices, int suf_len, uint64_t n, const uint32_t *bucket, const uint32_t *key,
+                             const uint8_t *val, const char *fq_path, FILE *out)
+{
     const int timing = getenv("FMD_TIMING") != 0;
     const double t_begin = now_s();
     double t_read = 0;
     pipe_t p;
     memset(&p, 0, sizeof(p));
-    int rc = fmd_ectab_build(device, opt->w, suf_len, n, bucket, key, val, &p.tab);
-    if (rc) { fprintf(stderr, "[E::%s] cannot load the k-mer table: %s\n", __func__, fmd_strerror(rc)); return 1; }
+    if (n_dev < 1 || n_dev > FMDH_MAX_GPUS) return 1;
+    for (int g = 0; g < n_dev; ++g) {   /* the whole table on every GPU (one 8-byte slot per solid k-mer) */
+        const int rc = fmd_ectab_build(devices[g], opt->w, suf_len, n, bucket, key, val, &p.tab[g]);
+        if (rc) { fprintf(stderr, "[E::%s] cannot load the k-mer table on GPU %d: %s\n", __func__, devices[g], fmd_strerror(rc)); free_tabs(&p); return 1; }
+        p.n_tab = g + 1;
+    }
     const double t_table = now_s() - t_begin;
     fmdh_seqio_t *io = fmdh_seq_open(fq_path);
-    if (!io) { fprintf(stderr, "[E::%s] cannot open `%s'\n", __func__, fq_path); fmd_ectab_free(p.tab); return 1; }
+    if (!io) { fprintf(stderr, "[E::%s] cannot open `%s'\n", __func__, fq_path); free_tabs(&p); return 1; }
     p.opt = opt; p.out = out;
     pthread_mutex_init(&p.mu, 0); pthread_cond_init(&p.cv, 0);
     for (int i = 0; i < 3; ++i) {
@@ -274,7 +311,7 @@ int fmdh_correct_reads(const fmdh_ecopt_t *opt, int device, int suf_len, uint64_
     for (int i = 0; i < 3; ++i) { free(p.b[i].ascii); free(p.b[i].nt6); free(p.b[i].qual); free(p.b[i].off); free(p.b[i].info); }
     pthread_mutex_destroy(&p.mu); pthread_cond_destroy(&p.cv);
     fmdh_seq_close(io);
-    fmd_ectab_free(p.tab);
+    free_tabs(&p);
     return __atomic_load_n(&p.failed, __ATOMIC_RELAXED) ? 1 : 0;
 }
 
@@ -282,6 +319,69 @@ int fmdh_correct_kmer(uint64_t n_symbols) /* the automatic k-mer length, correct
 {
     int w = (int)(log((double)n_symbols) / log(4) + 8.499);
     return w >= MAX_KMER ? MAX_KMER : w;
+}
+
+/* `correct -g a,b,..`: GPU g of G harvests the trees of the k-mer trie whose last base is c = g, g + G, .. (fm6_traverse + ec_collect are
+ * sharded over the reference's threads by suffix bucket, correct.c:346-356; the trie is a forest rooted at the last base, so whole
+ * trees are the natural shards: at most four GPUs harvest), every GPU then holds the whole table and corrects a contiguous share of
+ * each batch of reads.  Output bytes are those of one GPU. */
+typedef struct { const char *fmd_path; int device, w, min_occ, suf_len, seeds, rc; uint32_t *bucket, *key; uint8_t *val; uint64_t n; int64_t cnt[2]; uint64_t n_sym; } hv_t;
+static void *hv_main(void *d)
+{
+    hv_t *h = (hv_t *)d;
+    fmd_dev_t *dev = 0;
+    h->rc = fmd_dev_open_file(h->device, h->fmd_path, &dev);
+    if (h->rc) return 0;
+    h->rc = fmd_kmer_collect_seeds(dev, h->w, h->min_occ, h->suf_len, h->seeds, &h->bucket, &h->key, &h->val, &h->n, h->cnt);
+    fmd_dev_close(dev);
+    return 0;
+}
+
+int fmdh_correct_multi(const char *fmd_path, const char *fq_path, int n_dev, const int *devices, fmdh_ecopt_t *opt, FILE *out)
+{
+    if (n_dev < 1 || n_dev > FMDH_MAX_GPUS) return 1;
+    if (n_dev == 1) return fmdh_correct(fmd_path, fq_path, devices[0], opt, out);
+    const int timing = getenv("FMD_TIMING") != 0;
+    double t0 = now_s(), t1;
+    int rc, g;
+    if (opt->w < 0) {   /* the automatic k needs the symbol count (correct.c:313-318): read it from the header through one load */
+        fmd_dev_t *d = 0; fmd_info_t fi;
+        rc = fmd_dev_open_file(devices[0], fmd_path, &d);
+        if (rc) { fprintf(stderr, "[E::%s] cannot load `%s': %s\n", __func__, fmd_path, fmd_strerror(rc)); return 1; }
+        fmd_dev_info(d, &fi); fmd_dev_close(d);
+        opt->w = fmdh_correct_kmer(fi.mcnt[0]);
+    }
+    const int suf_len = opt->w > 15 ? opt->w - 15 : 1, H = n_dev < 4 ? n_dev : 4;
+    hv_t hv[4];
+    pthread_t tid[4];
+    int started[4];
+    memset(hv, 0, sizeof(hv));
+    for (g = 0; g < H; ++g) {
+        hv[g].fmd_path = fmd_path; hv[g].device = devices[g]; hv[g].w = opt->w; hv[g].min_occ = opt->min_occ; hv[g].suf_len = suf_len;
+        for (int c = g; c < 4; c += H) hv[g].seeds |= 1 << c;
+    }
+    for (g = 1; g < H; ++g) started[g] = pthread_create(&tid[g], 0, hv_main, &hv[g]) == 0;
+    hv_main(&hv[0]);
+    for (g = 1; g < H; ++g) { if (started[g]) pthread_join(tid[g], 0); else hv_main(&hv[g]); }
+    uint64_t n = 0, o = 0;
+    rc = 0;
+    for (g = 0; g < H; ++g) { if (hv[g].rc && !rc) rc = hv[g].rc; n += hv[g].n; }
+    uint32_t *bucket = 0, *key = 0; uint8_t *val = 0;
+    if (!rc) {
+        bucket = (uint32_t *)malloc((n ? n : 1) * 4); key = (uint32_t *)malloc((n ? n : 1) * 4); val = (uint8_t *)malloc(n ? n : 1);
+        if (!bucket || !key || !val) rc = FMD_E_NOMEM;
+        else for (g = 0; g < H; ++g) {
+            memcpy(bucket + o, hv[g].bucket, hv[g].n * 4); memcpy(key + o, hv[g].key, hv[g].n * 4); memcpy(val + o, hv[g].val, hv[g].n);
+            o += hv[g].n;
+        }
+    }
+    for (g = 0; g < H; ++g) { fmd_host_free(hv[g].bucket); fmd_host_free(hv[g].key); fmd_host_free(hv[g].val); }
+    if (rc) { fprintf(stderr, "[E::%s] k-mer harvest failed: %s\n", __func__, fmd_strerror(rc)); free(bucket); free(key); free(val); return 1; }
+    if (timing) { t1 = now_s(); fprintf(stderr, "[M::%s] index load + harvest of %llu solid %d-mers on %d GPUs (trees by last base): %.3f s\n", __func__, (unsigned long long)n, opt->w + 1, H, t1 - t0); t0 = t1; }
+    rc = fmdh_correct_reads_multi(opt, n_dev, devices, suf_len, n, bucket, key, val, fq_path, out);
+    if (timing) { t1 = now_s(); fprintf(stderr, "[M::%s] table upload + correction on %d GPUs + output: %.3f s\n", __func__, n_dev, t1 - t0); }
+    free(bucket); free(key); free(val);
+    return rc;
 }
 
 int fmdh_correct(const char *fmd_path, const char *fq_path, int device, fmdh_ecopt_t *opt, FILE *out)

@@ -1,6 +1,7 @@
 /* exact_cmd.c -- `fermi exact [-s] <idx> <src.fa>` (cmd.c:292-331): SMEMs of every query against
  * the index, found on the GPU (fmd_smem_batch), printed as the reference prints them
  * (cmd.c:320-327, fm6_write_smem smem.c:412-418). */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -82,9 +83,44 @@ static void print_query(const fmd_info_t *info, const char *name, int len, const
     fputs("//\n", out);
 }
 
-static int flush_batch(fmd_dev_t *d, const fmd_info_t *info, int self_match, size_t n, char **names, uint8_t *bases, uint64_t *off,
+/* one GPU's share [lo, hi) of the short queries of a batch (`exact -g a,b,..`: the reference hands reads to its threads the same way,
+ * smem.c:379-380; the index is replicated, results land in the batch's arrays, so the output order is the input order) */
+typedef struct { fmd_dev_t *d; const uint8_t *sb; const uint64_t *soff; size_t lo, hi; int self_match; uint32_t max_len, max_mem; fmd_intv_t *mem; uint32_t *n_mem; int rc; } xs_t;
+static void *xs_main(void *p)
+{
+    xs_t *x = (xs_t *)p;
+    const size_t m = x->hi - x->lo;
+    x->rc = 0;
+    if (m == 0) return 0;
+    uint64_t *o = (uint64_t *)malloc((m + 1) * 8);   /* offsets relative to the share's first base */
+    if (!o) { x->rc = FMD_E_NOMEM; return 0; }
+    for (size_t i = 0; i <= m; ++i) o[i] = x->soff[x->lo + i] - x->soff[x->lo];
+    x->rc = fmd_smem_batch(x->d, m, x->sb + x->soff[x->lo], o, x->self_match, x->max_len, x->max_mem, x->mem + x->lo * (size_t)x->max_mem, x->n_mem + x->lo);
+    free(o);
+    return 0;
+}
+static int smem_shares(fmd_dev_t **devs, int n_dev, size_t ns, const uint8_t *sb, const uint64_t *soff, int self_match, uint32_t max_len, uint32_t max_mem,
+                       fmd_intv_t *mem, uint32_t *n_mem)
+{
+    xs_t x[FMDH_MAX_GPUS];
+    pthread_t tid[FMDH_MAX_GPUS];
+    int started[FMDH_MAX_GPUS], g, rc = 0;
+    if (n_dev == 1) return fmd_smem_batch(devs[0], ns, sb, soff, self_match, max_len, max_mem, mem, n_mem);
+    for (g = 0; g < n_dev; ++g) {
+        x[g].d = devs[g]; x[g].sb = sb; x[g].soff = soff; x[g].lo = ns * (size_t)g / (size_t)n_dev; x[g].hi = ns * (size_t)(g + 1) / (size_t)n_dev;
+        x[g].self_match = self_match; x[g].max_len = max_len; x[g].max_mem = max_mem; x[g].mem = mem; x[g].n_mem = n_mem; x[g].rc = 0;
+    }
+    for (g = 1; g < n_dev; ++g) started[g] = pthread_create(&tid[g], 0, xs_main, &x[g]) == 0;
+    xs_main(&x[0]);
+    for (g = 1; g < n_dev; ++g) { if (started[g]) pthread_join(tid[g], 0); else xs_main(&x[g]); }
+    for (g = 0; g < n_dev; ++g) if (x[g].rc && !rc) rc = x[g].rc;
+    return rc;
+}
+
+static int flush_batch(fmd_dev_t **devs, int n_dev, const fmd_info_t *info, int self_match, size_t n, char **names, uint8_t *bases, uint64_t *off,
                        uint32_t max_len_all, FILE *out)
 {
+    fmd_dev_t *d = devs[0];   /* long queries (contigs) stay on the first GPU */
     /* short queries: one lane each (fmd_smem_batch); long ones: smem_long, one at a time */
     size_t ns = 0, i;
     uint32_t max_len = 1, max_mem = 64, long_max_len = 256;
@@ -108,7 +144,7 @@ static int flush_batch(fmd_dev_t *d, const fmd_info_t *info, int self_match, siz
         free(mem);
         mem = (fmd_intv_t *)malloc(ns * (size_t)max_mem * sizeof(*mem));
         if (!mem || !n_mem) { rc = 1; break; }
-        rc = fmd_smem_batch(d, ns, sb, soff, self_match, max_len, max_mem, mem, n_mem);
+        rc = smem_shares(devs, n_dev, ns, sb, soff, self_match, max_len, max_mem, mem, n_mem);
         if (rc) { fprintf(stderr, "[E::%s] %s\n", __func__, fmd_strerror(rc)); rc = 1; break; }
         for (i = 0; i < ns; ++i) over |= (int)(n_mem[i] >> 31);
         if (!over) break;
@@ -134,13 +170,25 @@ static int flush_batch(fmd_dev_t *d, const fmd_info_t *info, int self_match, siz
 
 int fmdh_exact(const char *fmd_path, const char *fa_path, int device, int self_match, FILE *out)
 {
-    fmd_dev_t *d = 0;
+    return fmdh_exact_multi(fmd_path, fa_path, 1, &device, self_match, out);
+}
+
+int fmdh_exact_multi(const char *fmd_path, const char *fa_path, int n_dev, const int *devices, int self_match, FILE *out)
+{
+    fmd_dev_t *devs[FMDH_MAX_GPUS];
     fmd_info_t info;
-    int rc = fmd_dev_open_file(device, fmd_path, &d), l;
-    if (rc) { fprintf(stderr, "[E::%s] cannot load `%s': %s\n", __func__, fmd_path, fmd_strerror(rc)); return 1; }
-    fmd_dev_info(d, &info);
+    int rc = 0, l, g;
+    if (n_dev < 1 || n_dev > FMDH_MAX_GPUS) return 1;
+    memset(devs, 0, sizeof(devs));
+    for (g = 0; g < n_dev && rc == 0; ++g) rc = fmd_dev_open_file(devices[g], fmd_path, &devs[g]);   /* the full index on every GPU */
+    if (rc) {
+        fprintf(stderr, "[E::%s] cannot load `%s': %s\n", __func__, fmd_path, fmd_strerror(rc));
+        for (g = 0; g < n_dev; ++g) if (devs[g]) fmd_dev_close(devs[g]);
+        return 1;
+    }
+    fmd_dev_info(devs[0], &info);
     fmdh_seqio_t *io = fmdh_seq_open(fa_path);
-    if (!io) { fprintf(stderr, "[E::%s] cannot open `%s'\n", __func__, fa_path); fmd_dev_close(d); return 1; }
+    if (!io) { fprintf(stderr, "[E::%s] cannot open `%s'\n", __func__, fa_path); for (g = 0; g < n_dev; ++g) fmd_dev_close(devs[g]); return 1; }
     char **names = (char **)calloc(EXACT_BATCH, sizeof(char *));
     uint64_t *off = (uint64_t *)malloc((EXACT_BATCH + 1) * 8);
     size_t n = 0, cap = 1 << 20, tot = 0;
@@ -150,7 +198,7 @@ int fmdh_exact(const char *fmd_path, const char *fa_path, int device, int self_m
     for (;;) {
         l = fmdh_seq_read(io);
         if (l < 0 || n == EXACT_BATCH) {
-            if (n) rc = flush_batch(d, &info, self_match, n, names, bases, off, max_len, out);
+            if (n) rc = flush_batch(devs, n_dev, &info, self_match, n, names, bases, off, max_len, out);
             for (size_t i = 0; i < n; ++i) free(names[i]);     /* also when the batch failed */
             n = 0; tot = 0; max_len = 1;
             if (rc || l < 0) break;
@@ -164,6 +212,6 @@ int fmdh_exact(const char *fmd_path, const char *fa_path, int device, int self_m
     }
     free(names); free(off); free(bases);
     fmdh_seq_close(io);
-    fmd_dev_close(d);
+    for (g = 0; g < n_dev; ++g) fmd_dev_close(devs[g]);
     return rc;
 }

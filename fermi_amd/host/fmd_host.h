@@ -129,6 +129,14 @@ int fmdh_build(const char *fa_path, const char *out_path, int device, int max_le
 /* `fermi correct` (cmd.c:253-291, correct.c:305-456); defaults = cmd.c:258 */
 typedef struct { int w, min_occ, keep_bad, is_paired, trim_l, step; float max_corr; } fmdh_ecopt_t; /* = fmecopt_t, fermi.h:26-29 */
 int fmdh_correct(const char *fmd_path, const char *fq_path, int device, fmdh_ecopt_t *opt, FILE *out);
+#define FMDH_MAX_GPUS 16
+/* `-g a,b,..`: the harvest sharded by the last base of the k-mer (whole trees of the trie, at most four GPUs), the table replicated,
+ * every batch of reads split over the GPUs; the output bytes are those of one GPU */
+int fmdh_correct_multi(const char *fmd_path, const char *fq_path, int n_dev, const int *devices, fmdh_ecopt_t *opt, FILE *out);
+int fmdh_correct_reads_multi(const fmdh_ecopt_t *opt, int n_dev, const int *devices, int suf_len, uint64_t n, const uint32_t *bucket, const uint32_t *key,
+                             const uint8_t *val, const char *fq_path, FILE *out);
+/* `exact -g a,b,..`: the index replicated, every batch of queries split over the GPUs, output in input order */
+int fmdh_exact_multi(const char *fmd_path, const char *fa_path, int n_dev, const int *devices, int self_match, FILE *out);
 void fmdh_correct_set_threads(int n);                                        /* `-t`: host threads of the marking pass (output independent of n) */
 int fmdh_correct_kmer(uint64_t n_symbols);                                   /* automatic k, correct.c:313-318 */
 /* phase 2 only (ec_fix on the GPU, fmd_ecfix_batch; marking, filtering and printing on the host) against an already

@@ -61,6 +61,23 @@ static int main_seqsort(int argc, char *argv[]) /* cmd.c:486-505 */
     return 0;
 }
 
+/* "-g 0,1,3" -> devices[]; returns the count (1 device, 0, when the option is absent) */
+static int parse_gpus(const char *arg, int *devices, int max)
+{
+    int n = 0;
+    const char *p = arg;
+    while (*p && n < max) {
+        char *q;
+        const long v = strtol(p, &q, 10);
+        if (q == p) break;
+        devices[n++] = (int)v;
+        p = *q == ',' ? q + 1 : q;
+        if (*q != ',') break;
+    }
+    if (n == 0) { devices[0] = 0; n = 1; }
+    return n;
+}
+
 static int main_build(int argc, char *argv[]) /* cmd.c:378-484 */
 {
     int c, force = 0, max_len = 0x7fffffff, no_fr = 1, device = 0;
@@ -95,21 +112,21 @@ static int main_build(int argc, char *argv[]) /* cmd.c:378-484 */
 
 static int main_exact(int argc, char *argv[]) /* cmd.c:292-331 */
 {
-    int c, self_match = 0, device = 0;
+    int c, self_match = 0, devices[FMDH_MAX_GPUS] = {0}, n_dev = 1;
     while ((c = getopt(argc, argv, "Msg:")) >= 0) {
         switch (c) {
         case 'M': break;
         case 's': self_match = 1; break;
-        case 'g': device = atoi(optarg); break;
+        case 'g': n_dev = parse_gpus(optarg, devices, FMDH_MAX_GPUS); break;
         }
     }
-    if (optind + 2 > argc) { fprintf(stderr, "Usage: fermi-amd exact [-s] [-g GPU] <idxbase.fmd> <src.fa>\n"); return 1; }
-    return fmdh_exact(argv[optind], argv[optind + 1], device, self_match, stdout);
+    if (optind + 2 > argc) { fprintf(stderr, "Usage: fermi-amd exact [-s] [-g GPU[,GPU..]] <idxbase.fmd> <src.fa>\n"); return 1; }
+    return fmdh_exact_multi(argv[optind], argv[optind + 1], n_dev, devices, self_match, stdout);
 }
 
 static int main_correct(int argc, char *argv[]) /* cmd.c:253-291 */
 {
-    int c, device = 0;
+    int c, devices[FMDH_MAX_GPUS] = {0}, n_dev = 1;
     fmdh_ecopt_t opt;
     opt.w = -1; opt.min_occ = 3; opt.keep_bad = 0; opt.is_paired = 0; opt.max_corr = 0.3f; opt.trim_l = 0; opt.step = 5;
     while ((c = getopt(argc, argv, "MKt:k:v:O:pC:l:s:g:")) >= 0) {
@@ -123,7 +140,7 @@ static int main_correct(int argc, char *argv[]) /* cmd.c:253-291 */
         case 'C': opt.max_corr = (float)atof(optarg); break;
         case 'l': opt.trim_l = atoi(optarg); break;
         case 's': opt.step = atoi(optarg); break;
-        case 'g': device = atoi(optarg); break;
+        case 'g': n_dev = parse_gpus(optarg, devices, FMDH_MAX_GPUS); break;
         }
     }
     if (optind + 2 > argc) {
@@ -136,10 +153,10 @@ static int main_correct(int argc, char *argv[]) /* cmd.c:253-291 */
         fprintf(stderr, "         -t INT      number of host threads for the correction pass [1]\n");
         fprintf(stderr, "         -K          keep bad/unfixable reads\n");
         fprintf(stderr, "         -p          paired-end reads (interleaved)\n");
-        fprintf(stderr, "         -g INT      GPU to use [0]\n\n");
+        fprintf(stderr, "         -g LIST     GPUs to use, e.g. 0,1,2,3: harvest by last base on up to four, reads of a batch split over all [0]\n\n");
         return 1;
     }
-    return fmdh_correct(argv[optind], argv[optind + 1], device, &opt, stdout);
+    return fmdh_correct_multi(argv[optind], argv[optind + 1], n_dev, devices, &opt, stdout);
 }
 
 static int main_chkbwt(int argc, char *argv[]) /* cmd.c:47-130 */

@@ -303,7 +303,12 @@ int fmd_kmer_collect_dev(fmd_dev_t *h, void *stream, int w, int min_occ, int suf
 int fmd_kmer_collect_part_dev(fmd_dev_t *h, void *stream, int w, int min_occ, int suf_len, int seed_mask, void *d_work, size_t work_bytes,
                               uint64_t cap, uint32_t *d_bucket, uint32_t *d_key, uint8_t *d_val, uint64_t *d_status);
 int fmd_kmer_collect(fmd_dev_t *h, int w, int min_occ, int suf_len, uint32_t **bucket, uint32_t **key, uint8_t **val,
-                     uint64_t *n, int64_t cnt[2]);   /* outputs malloc'ed: fmd_host_free() */
+                     uint64_t *n, int64_t cnt[2]);
+/* The same for the k-mers that END in one of the bases of seed_mask (bit c-1 = base c): one GPU's shard of a harvest spread over
+ * several (`fermi-amd correct -g`; the reference shards ec_collect over its threads by suffix bucket, correct.c:346-356).  Disjoint
+ * masks covering 0xf give, together, exactly the triples of fmd_kmer_collect. */
+int fmd_kmer_collect_seeds(fmd_dev_t *h, int w, int min_occ, int suf_len, int seed_mask, uint32_t **bucket, uint32_t **key, uint8_t **val,
+                           uint64_t *n, int64_t cnt[2]);   /* outputs malloc'ed: fmd_host_free() */
 
 /* ---- the correction pass of `fermi correct`: ec_fix1 / ec_fix (correct.c:121-256) ------------------------------
  * The table is what fmd_kmer_collect* returns (one triple per solid k-mer, any order), loaded into a device hash

@@ -69,6 +69,7 @@ def test_1m_reads_cli_md5_equals_the_reference(gpu, tmp_path):
     subprocess.check_call([AMD, "build", "-fo", d + "/raw.fmd", d + "/raw.fq"], stderr=subprocess.DEVNULL)
     assert _md5_stream(["cat", d + "/raw.fmd"]) == want["raw_fmd"]
     assert _md5_stream([AMD, "correct", "-t8", d + "/raw.fmd", d + "/raw.fq"]) == want["correct_t1"]
+    assert _md5_stream([AMD, "correct", "-t8", "-g", "0,0,0", d + "/raw.fmd", d + "/raw.fq"]) == want["correct_t1"]   # harvest by last base + batches split over three replicas
     assert _md5_stream([AMD, "unitig", "-l50", d + "/raw.fmd"]) == want["unitig_raw_l50_t1"]   # reads with errors: forks, tips, back-bifurcations
 
 

@@ -518,6 +518,19 @@ def test_correct_cli_equals_fermi_correct(gpu, gold):
     assert _cli("correct", "-t4", gold.path("tiny.fmd"), gold.path("tiny.fq.gz")) == gold.text_gz("tiny.ec.fq.gz")
 
 
+@pytest.mark.parametrize("n_rep", [2, 3, 5])
+def test_correct_and_exact_sharded_over_replicas(gpu, gold, n_rep):
+    """`correct -g a,b,..`: the harvest sharded by the k-mer's last base (whole trees of the trie, at most four GPUs), the table on
+    every GPU, each batch of reads split over the GPUs; `exact -g a,b,..`: the index on every GPU, each batch of queries split.
+    Replicas on GPU 0 where the box has one GPU (distinct GPUs where it has more): the bytes are the single-GPU ones, i.e. the
+    reference's."""
+    n_gpu = gpu.device_count()
+    devs = ",".join(str(g % n_gpu) for g in range(n_rep))
+    assert _cli("correct", "-t4", "-g", devs, gold.path("tiny.fmd"), gold.path("tiny.fq.gz")) == gold.text_gz("tiny.ec.fq.gz")
+    assert _cli("exact", "-g", devs, gold.path("tiny.fmd"), gold.path("tiny.fq.gz")) == gold.text_gz("tiny.exact.gz")
+    assert _cli("exact", "-s", "-g", devs, gold.path("tiny.fmd"), gold.path("tiny.fq.gz")) == gold.text_gz("tiny.exact_s.gz")
+
+
 @pytest.mark.parametrize("name", ["tiny", "special", "repeat"])
 def test_build_cli_equals_fermi_build(gpu, gold, tmp_path, name):
     """`fermi-amd build -fo x.fmd reads.fq` writes the file `fermi build` wrote, byte for byte."""
