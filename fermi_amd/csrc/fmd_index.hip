@@ -657,6 +657,10 @@ extern "C" void fmd_dev_close(fmd_dev_t *h)
     hipFree(h->queues);
     hipFree(h->stat);
     for (size_t i = 0; i < sizeof(h->scratch) / sizeof(h->scratch[0]); ++i) if (h->scratch[i].p) hipFree(h->scratch[i].p);
+    if (h->slow_ready) {
+        hipStreamDestroy(h->slow_stream);
+        for (int i = 0; i < 2; ++i) hipEventDestroy(h->slow_ev[i]);
+    }
     if (h->aux_ready) {
         hipStreamDestroy(h->aux_stream);
         for (int i = 0; i <= FMD_OVLP_MAX_PARTS; ++i) hipEventDestroy(h->aux_ev[i]);

@@ -29,6 +29,11 @@ struct fmd_dev {
     hipStream_t aux_stream;
     hipEvent_t aux_ev[FMD_OVLP_MAX_PARTS + 1];
     int aux_ready, aux_busy;
+    // side stream of fm6_get_nei's lane-per-strand kernel (k_ovl_nei on the strands k_ovl_classify sets aside runs beside the group
+    // kernels: a few long dependent chains, nothing to gain from having the GPU to itself); same ownership rule as aux_*
+    hipStream_t slow_stream;
+    hipEvent_t slow_ev[2];
+    int slow_ready, slow_busy;
 };
 #define FMD_N_QUEUES 256
 

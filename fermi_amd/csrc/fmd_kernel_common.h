@@ -122,7 +122,12 @@ __device__ __host__ __forceinline__ constexpr int fmd_grp_size(int k) { return k
 #define FMD_FAST_RESERVE (2 * FMD_FAST_MAX_WAVES * FMD_FAST_CHUNK)   // entries a general list may lose to holes (two fast kernels feed it)
 #define FMD_CLS_PART_U32 (FMD_CLS_HEADER_U32 + 2 * FMD_GRP_CLASSES * FMD_FAST_RESERVE)   // per part of a pipelined batch: counters + that room
 #define FMD_CLS_LISTS (3 * FMD_GRP_CLASSES + 1)                 // general lists, the slow list, fast lists (32-bit masks, 64-bit masks)
-#define FMD_CLS_WORDS_PER_STRAND (6 * FMD_GRP_CLASSES + 1)      // two words per entry of a group list, one for the slow list
+#define FMD_CLS_WORDS_PER_STRAND (6 * FMD_GRP_CLASSES + 3)      // two words per entry of a group list, one each for the slow list, the late slow list, the fix-up list
+// Counters on the slow list's 128-byte line: [0] strands k_ovl_classify sets aside (k_ovl_nei takes them at once, beside the group
+// kernels), [FMD_CLS_LATE_CNT] strands the fast / group kernels hand back later (a second k_ovl_nei launch behind them; this is the
+// counter those kernels get as `slow_n`), and FMD_CLS_FIX_CNT words behind THAT the fix-up list's.
+#define FMD_CLS_LATE_CNT 4
+#define FMD_CLS_FIX_CNT 16
 struct FmdOvlClasses {
     // counters: [k * STRIDE] = strands of general class k, [CLASSES * STRIDE] = the slow list, [(CLASSES + 1 + k) * STRIDE] = fast class k,
     // k >= CLASSES: the 64-bit variant of class k - CLASSES (+8 on that line: strands the fast kernel handed on to the general class)

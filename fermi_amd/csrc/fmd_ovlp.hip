@@ -12,7 +12,7 @@
 // (gidx: slot of a sorted batch -> row of rec / nei_out / seq_out, fmd_ovlp_sorted_dev; nullptr = the slot is the row)
 void fmd_launch_nei_grp(int cls, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                         const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
-                        uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx);
+                        uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx, size_t fix_off);
 int fmd_nei_fast_available(void);
 void fmd_launch_nei_fast(int cls, int wide, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                          const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
@@ -21,9 +21,6 @@ void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, co
 // fmd_ovlp_sort.hip: minimizer keys of the parked strands, then their rows sorted by key (-> vals_b)
 size_t fmd_park_sort_temp_bytes(size_t n);
 int fmd_park_sort(hipStream_t st, size_t n, const FmdWalkPark *park, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *tmp, size_t tmp_bytes);
-// rows of ids[] sorted by the last bases of their sequences (the top `bits` bits of the tail-table entries) -> vals_b
-int fmd_tail_sort(hipStream_t st, size_t n, const uint64_t *ids, const unsigned long long *tail, uint64_t n_seq, int bits, uint32_t *keys_a, uint32_t *keys_b,
-                  uint32_t *vals_a, uint32_t *vals_b, void *tmp, size_t tmp_bytes);
 
 // ---------------------------------------------------------------------------- phase 0: retrieve
 // fm_retrieve (exact.c:59-70); writes the sequence REVERSED into srev and rank/len into rec.
@@ -227,10 +224,8 @@ __device__ __forceinline__ bool walk_lf_shares(uint64_t k, uint64_t x0, uint64_t
 // exactly the steps of the one-pass walk and leave the same records, candidates and stash.
 enum { WALK_WHOLE = 0, WALK_HEAD = 1, WALK_TAIL = 2 };   // (FMD_WALK_SPLIT, FmdWalkPark: fmd_kernel_common.h)
 
-// MODE = WALK_HEAD: item t = row gidx[t] (t when gidx is null) of ids[], park[] and rec[]; the first 32 bases stay in registers
-// and leave with the parked state in ONE 64-byte burst.  The items come sorted by the strands' last ptab_d bases (the
-// tail table has them, fmd_ovlp_sorted_dev): strands of one wave then share the prefix-table entries and the blocks of the first,
-// wide steps behind the table.
+// MODE = WALK_HEAD: item t = admission record t (k_ovl_head_adm: the strand's row in ids[], park[] and rec[] and where its walk stands
+// behind the tail table); the first 32 bases stay in registers and leave with the parked state in ONE 64-byte burst.
 // MODE = WALK_TAIL: item = slot of the batch (rows of srev, listA), gidx[slot] = its row in park[], rec[] (and, for the kernels
 // that follow, nei[] and seq[]).
 template <int MODE>
@@ -786,6 +781,87 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
     }
 }
 
+// ------------------------------------------------------------ the fake-fork fix-up on its own
+// unitig.c:158-176 for strands the group kernels closed with ONE neighbour after a fork (contained reads made the fork): the record,
+// the neighbour and the appended bases are there as fm6_get_nei's loop leaves them; what remains is to walk the overlap string
+// forward from the empty interval (FIX1: ori_l - rbeg dependent steps) and then re-derive the appended bases as long as exactly one
+// child still contains the neighbour's interval (FIX2).  k_ovl_nei does the same at the end of its own pass -- after redoing the
+// whole of fm6_get_nei with lists in HBM, which is what this kernel spares the strands the group kernels had finished.
+__global__ __launch_bounds__(64) void k_ovl_fix(FmdIndexView ix, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
+                                                const uint8_t *__restrict__ srev, uint32_t stride_r, fmd_ovlp_rec_t *__restrict__ rec,
+                                                const fmd_intv_t *__restrict__ nei_out, uint32_t max_nei, uint8_t *__restrict__ seq_out, uint32_t seq_stride,
+                                                uint32_t *__restrict__ queue, const uint32_t *__restrict__ gidx)
+{
+    FMD_DECLARE_WAVE_LDS();
+    const size_t n = *list_n;
+    size_t sid = 0, gs = 0;
+    int st = 0, ori_l = 0, cur_l = 0, fix_i = 0;   // st: 0 idle, 1 = FIX1, 2 = FIX2
+    uint64_t x0 = 0, x1 = 0, sz = 0, nx0 = 0, nsz = 0;
+    bool exhausted = false;
+    FmdTickets tk_;
+    fmd_tickets_init(tk_, queue);
+    for (;;) {
+        const size_t my = fmd_tickets_take(tk_, queue, st == 0 && !exhausted);
+        if (st == 0 && !exhausted) {
+            if (my < n) {
+                sid = list[my]; gs = gidx ? (size_t)gidx[sid] : sid;
+                const fmd_ovlp_rec_t *o = rec + gs;
+                ori_l = o->len; cur_l = ori_l + o->ext_len; fix_i = o->rbeg;
+                const uint4 *q = (const uint4 *)(nei_out + gs * (size_t)max_nei);
+                const uint4 a = q[0], b = q[1];
+                nx0 = (uint64_t)a.y << 32 | a.x; nsz = (uint64_t)b.y << 32 | b.x;
+                x0 = 0; x1 = 0; sz = ix.cnt[1];                      // fm6_set_intv(e, 0, ok0)
+                if (fix_i >= 0 && fix_i < ori_l) st = 1;
+            } else exhausted = true;
+        }
+        if (__ballot(st != 0) == 0) { if (__ballot(!exhausted) == 0) break; else continue; }
+        const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, st ? x1 - 1 : NONE64, st ? x1 - 1 + sz : NONE64);   // forward: strand x[1]
+        if (st == 0) continue;
+        uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tl[6] = {0, 0, 0, 0, 0, 0}, s[6];
+        if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk, r.blk_k);
+        if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl, r.blk_l);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s[c] = tl[c] - tk[c];
+        // forward extension (exact.c:72-88, is_back = 0): x[1] from rank, x[0] running sum in the order $, T, G, C, A, N
+        I3 k0, k1, k2, k3, k4;
+        k0.x0 = x0;               k0.x1 = ix.cnt[0] + tk[0]; k0.sz = s[0];
+        k4.x0 = k0.x0 + s[0];     k4.x1 = ix.cnt[4] + tk[4]; k4.sz = s[4];
+        k3.x0 = k4.x0 + s[4];     k3.x1 = ix.cnt[3] + tk[3]; k3.sz = s[3];
+        k2.x0 = k3.x0 + s[3];     k2.x1 = ix.cnt[2] + tk[2]; k2.sz = s[2];
+        k1.x0 = k2.x0 + s[2];     k1.x1 = ix.cnt[1] + tk[1]; k1.sz = s[1];
+        bool done = false;
+        if (st == 1) { // unitig.c:160-163
+            const int b = srev[sid * (size_t)stride_r + (ori_l - 1 - fix_i)];
+            const int c = comp6(b);
+            I3 n3 = pick5(c, k0, k1, k2, k3, k4);
+            if (c == 5) { n3.x0 = k1.x0 + s[1]; n3.x1 = ix.cnt[5] + tk[5]; n3.sz = s[5]; }
+            x0 = n3.x0; x1 = n3.x1; sz = n3.sz;
+            ++fix_i;
+            if (fix_i == ori_l) { if (ori_l < cur_l) st = 2; else done = true; }
+        } else {       // unitig.c:164-175
+            int cnt_ok = 0, c0 = -1;
+#define FMD_FIX_TRY(c, kc) if (kc.sz && kc.x0 <= nx0 && kc.x0 + kc.sz >= nx0 + nsz) { ++cnt_ok; c0 = c; }
+            FMD_FIX_TRY(1, k1) FMD_FIX_TRY(2, k2) FMD_FIX_TRY(3, k3) FMD_FIX_TRY(4, k4)
+#undef FMD_FIX_TRY
+            bool stop = (cnt_ok == 0 && k0.sz != 0);
+            if (!stop && c0 > 0) {
+                if ((uint32_t)fix_i < seq_stride) seq_out[gs * (size_t)seq_stride + fix_i] = (uint8_t)comp6(c0);
+                const I3 n3 = pick5(c0, k0, k1, k2, k3, k4);
+                x0 = n3.x0; x1 = n3.x1; sz = n3.sz;
+                ++fix_i;
+                if (fix_i == cur_l) stop = true;
+            } else stop = true;
+            if (stop) { cur_l = fix_i; done = true; }
+        }
+        if (done) {
+            fmd_ovlp_rec_t *o = rec + gs;
+            o->ext_len = cur_l - ori_l;
+            o->flags |= FMD_OVLP_F_FIXED;
+            st = 0;
+        }
+    }
+}
+
 // ------------------------------------------------------------ phase C: check_left_simple
 // unitig.c:186-204 for the edge (strand -> its unique neighbour): collect, walking the neighbour
 // forward from its first base, the reads that END inside it with >= min_match bases (its left
@@ -976,6 +1052,7 @@ static void ovl_phase_a(const OvlBatch &o, hipStream_t st, size_t b, size_t np, 
     launch_seq_out(st, np, o.max_len, srev, o.stride_r, o.rec + b, o.min_match, 0, seq, o.seq_stride);
 }
 
+static bool ovl_slow_acquire(fmd_dev *h);
 // phase B: fm6_get_nei.  `part` selects the counter header of this part's work lists.
 static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, int part, int per_cu, int fast_cu)
 {
@@ -999,12 +1076,26 @@ static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, i
     for (int k = 0; k < FMD_GRP_CLASSES; ++k) cl.lst[k] = cls + FMD_CLS_HEADER_U32 + (2 * np + 2 * (size_t)FMD_FAST_RESERVE) * k;
     cl.lslow = cls + FMD_CLS_HEADER_U32 + (2 * np + 2 * (size_t)FMD_FAST_RESERVE) * FMD_GRP_CLASSES;
     for (int k = 0; k < 2 * FMD_GRP_CLASSES; ++k) cl.fast[k] = cl.lslow + np + 2 * np * k;
-    uint32_t *n_slow = cl.cnt + FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE;
+    uint32_t *lslow_late = cl.lslow + np + 2 * np * (size_t)(2 * FMD_GRP_CLASSES);   // strands the fast / group kernels hand back (behind the fast lists)
+    const size_t fix_off = np;                                                        // the fix-up list (fake forks the group kernels closed), behind that one
+    uint32_t *n_slow = cl.cnt + FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE, *n_late = n_slow + FMD_CLS_LATE_CNT;
     FMD_HIP_TRY(hipMemsetAsync(cls, 0, 4 * FMD_CLS_HEADER_U32, st));
     // FMD_OVLP_FAST=0: A/B switch, every strand through the general group kernels
     const char *ef = getenv("FMD_OVLP_FAST");
     const int use_fast = fmd_nei_fast_available() && !(ef && atoi(ef) == 0);
     fmd_launch_classify(st, np, rec, listA, o.cap, cl, use_fast, gidx);
+    // what classification sets aside (more than 32 candidates, a candidate wider than 63) goes through the lane-per-strand kernel NOW, on a
+    // side stream beside the group kernels: it is a handful of long dependent chains (10 ms per 2*10^7 strands of raw reads for 1 % of
+    // them), latency from end to end
+    bool side = false;
+    if (!getenv("FMD_OVLP_SLOW_SERIAL") && ovl_slow_acquire(o.h)) {
+        side = hipEventRecord(o.h->slow_ev[0], st) == hipSuccess && hipStreamWaitEvent(o.h->slow_stream, o.h->slow_ev[0], 0) == hipSuccess;
+        if (!side) { (void)hipGetLastError(); __atomic_store_n(&o.h->slow_busy, 0, __ATOMIC_RELEASE); }
+    }
+    {
+        hipStream_t ss = side ? o.h->slow_stream : st;
+        k_ovl_nei<<<grid, 64, 0, ss>>>(o.ix, np, o.min_match, srev, o.stride_r, o.cap, listA, listB, rec, nei, o.max_nei, seq, o.seq_stride, fmd_next_queue(o.h, ss), cl.lslow, n_slow, gidx);
+    }
     // strands whose candidates the walk left in the narrow form: the unforked path (one lane per candidate, no x[0]-side fetch,
     // one shared window per strand and round); whatever turns out not to be that simple moves on to the general list of its class
     if (use_fast)
@@ -1012,13 +1103,19 @@ static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, i
             uint32_t *nk = cl.cnt + (FMD_GRP_CLASSES + 1 + k) * FMD_CLS_CNT_STRIDE;
             const int kg = k % FMD_GRP_CLASSES;
             fmd_launch_nei_fast(kg, k >= FMD_GRP_CLASSES, o.h->n_cu, fast_cu, st, o.ix, cl.fast[k], nk, o.cap, listA, rec, nei, o.max_nei, seq,
-                                o.seq_stride, cl.lst[kg], cl.cnt + kg * FMD_CLS_CNT_STRIDE, nk + 8, cl.lslow, n_slow, gidx);
+                                o.seq_stride, cl.lst[kg], cl.cnt + kg * FMD_CLS_CNT_STRIDE, nk + 8, lslow_late, n_late, gidx);
         }
     // one lane per candidate interval, 64 / G strands per wave
     for (int k = 0; k < FMD_GRP_CLASSES; ++k)
-        fmd_launch_nei_grp(k, o.h->n_cu, per_cu, st, o.ix, cl.lst[k], cl.cnt + k * FMD_CLS_CNT_STRIDE, o.cap, listA, rec, nei, o.max_nei, seq, o.seq_stride, cl.lslow, n_slow, gidx);
+        fmd_launch_nei_grp(k, o.h->n_cu, per_cu, st, o.ix, cl.lst[k], cl.cnt + k * FMD_CLS_CNT_STRIDE, o.cap, listA, rec, nei, o.max_nei, seq, o.seq_stride, lslow_late, n_late, gidx, fix_off);
     // the rest (too many candidates, wide intervals, fake forks, neighbour overflow): lane per strand
-    k_ovl_nei<<<grid, 64, 0, st>>>(o.ix, np, o.min_match, srev, o.stride_r, o.cap, listA, listB, rec, nei, o.max_nei, seq, o.seq_stride, q2, cl.lslow, n_slow, gidx);
+    k_ovl_nei<<<grid, 64, 0, st>>>(o.ix, np, o.min_match, srev, o.stride_r, o.cap, listA, listB, rec, nei, o.max_nei, seq, o.seq_stride, q2, lslow_late, n_late, gidx);
+    // fake forks among the strands the group kernels finished: the fix-up alone
+    k_ovl_fix<<<grid, 64, 0, st>>>(o.ix, lslow_late + fix_off, n_late + FMD_CLS_FIX_CNT, srev, o.stride_r, rec, nei, o.max_nei, seq, o.seq_stride, fmd_next_queue(o.h, st), gidx);
+    if (side) {   // the caller's stream owns every row again (and the work area, which the next batch reuses)
+        if (hipEventRecord(o.h->slow_ev[1], o.h->slow_stream) != hipSuccess || hipStreamWaitEvent(st, o.h->slow_ev[1], 0) != hipSuccess) { (void)hipGetLastError(); hipStreamSynchronize(o.h->slow_stream); }
+        __atomic_store_n(&o.h->slow_busy, 0, __ATOMIC_RELEASE);
+    }
     if (getenv("FMD_OVLP_STATS")) { // where the strands of this part went (synchronises: diagnostics only)
         uint32_t hs[FMD_CLS_HEADER_U32];
         hipStreamSynchronize(st);
@@ -1027,14 +1124,14 @@ static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, i
         for (int k = 0; k < 2 * FMD_GRP_CLASSES; ++k) { nf += hs[(FMD_GRP_CLASSES + 1 + k) * FMD_CLS_CNT_STRIDE]; nb += hs[(FMD_GRP_CLASSES + 1 + k) * FMD_CLS_CNT_STRIDE + 8]; }
         for (int k = 0; k < FMD_GRP_CLASSES; ++k) ng += hs[k * FMD_CLS_CNT_STRIDE];
         fprintf(stderr, "[M::fmd_ovlp] part of %zu strands: %u to the unforked path (%u of them handed on), %u slots of the general group kernels' lists (holes of the hand-over included), %u through the lane-per-strand kernel\n",
-                np, nf, nb, ng, hs[FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE]);
+                np, nf, nb, ng, hs[FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE] + hs[FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE + FMD_CLS_LATE_CNT]);
     }
 #ifdef GRP_STATS
     {
         uint32_t hs[FMD_CLS_HEADER_U32];
         hipStreamSynchronize(st);
         hipMemcpy(hs, cls, sizeof(hs), hipMemcpyDeviceToHost);
-        const uint32_t *g = hs + FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE + 8;
+        const uint32_t *g = hs + FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE + FMD_CLS_LATE_CNT + 8;
         fprintf(stderr, "[grp stats] classes %u %u %u %u %u slow %u | wave rounds %u, live lanes %u (%.1f %%), lanes of groups holding a strand %u (%.1f %%)\n",
                 hs[0], hs[32], hs[64], hs[96], hs[128], hs[160], g[0], g[1], 100.0 * g[1] / (64.0 * g[0]), g[2], 100.0 * g[2] / (64.0 * g[0]));
         for (int k = 0; k < 2 * FMD_GRP_CLASSES; ++k) {
@@ -1067,6 +1164,25 @@ static void ovl_pipe_config(size_t n, int &parts, int &walk_cu, int &grp_cu, int
         if (k >= 4 && d >= 1) fast_cu = d;
     }
     if (getenv("FMD_OVLP_UNFUSED") || getenv("FMD_OVLP_SLOW_ONLY")) parts = 1;
+}
+static bool ovl_slow_acquire(fmd_dev *h)
+{
+    int expect = 0;
+    if (!__atomic_compare_exchange_n(&h->slow_busy, &expect, 1, false, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED)) return false;
+    if (!h->slow_ready) {
+        bool ok = hipStreamCreateWithFlags(&h->slow_stream, hipStreamNonBlocking) == hipSuccess;
+        int made = 0;
+        for (; ok && made < 2; ++made) ok = hipEventCreateWithFlags(&h->slow_ev[made], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            for (int i = 0; i < made - 1; ++i) hipEventDestroy(h->slow_ev[i]);
+            if (h->slow_stream) { hipStreamDestroy(h->slow_stream); h->slow_stream = nullptr; }
+            (void)hipGetLastError();
+            __atomic_store_n(&h->slow_busy, 0, __ATOMIC_RELEASE);
+            return false;
+        }
+        h->slow_ready = 1;
+    }
+    return true;
 }
 static bool ovl_aux_acquire(fmd_dev *h)
 {
@@ -1237,14 +1353,10 @@ extern "C" int fmd_ovlp_sorted_dev(fmd_dev_t *h, void *stream_, size_t n, const 
     FmdWalkPark *park = (FmdWalkPark *)(w + L.park);
     uint32_t *sorted = (uint32_t *)(w + L.vals_b);
     const FmdIndexView ix = fmd_view(h);
-    // pass 1: every strand FMD_WALK_SPLIT bases in, the strands taken in the order of their last ptab_d bases (known from the tail table)
+    // pass 1: every strand FMD_WALK_SPLIT bases in, in the caller's order.  (Taking the strands in the order of their last ptab_d bases --
+    // the tail table has them, one more radix sort -- makes this pass 7 % faster and costs what it saves: profiles/r3_locality.)
     {
         const uint32_t *order1 = nullptr;
-        if (ix.tail && !getenv("FMD_HEAD_UNSORTED")) {
-            const int rc = fmd_tail_sort(st, n, d_ids, ix.tail, ix.n_seq, 2 * ix.ptab_d, (uint32_t *)(w + L.keys_a), (uint32_t *)(w + L.keys_b), (uint32_t *)(w + L.vals_a), sorted, w + L.tmp, L.tmp_bytes);
-            if (rc != FMD_OK) return rc;
-            order1 = sorted;
-        }
         // (the admission records live in the batch area, which is idle until pass 2; 32 bytes per strand of the job)
         uint4 *adm = (uint4 *)(w + L.batch_area);
         const int use_tail = ix.tail != nullptr && ix.ptab != nullptr && min_match >= ix.ptab_d && ix.ptab_d >= 2;

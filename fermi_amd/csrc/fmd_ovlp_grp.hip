@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
                                                     uint32_t cap, const fmd_intv_t *__restrict__ listA, fmd_ovlp_rec_t *__restrict__ rec,
                                                     fmd_intv_t *__restrict__ nei_out, uint32_t max_nei, uint8_t *__restrict__ seq_out,
                                                     uint32_t seq_stride, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_n,
-                                                    const uint32_t *__restrict__ gidx)
+                                                    const uint32_t *__restrict__ gidx, size_t fix_off)
 {
     __shared__ uint4 lds[GRP_LDS_U4];
     uint4 *pool = lds + GRP_SLOTS_U4, *stage = pool;
@@ -313,7 +313,10 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging writes done before the re-pack reads
         if (active) {
             if (fork_g) flags |= FMD_OVLP_F_FORKED;
-            if (too_many || n_nei > max_nei) { // hand the strand to the lane-per-strand kernel
+            if (n_nei > max_nei) { // more neighbours than the caller has room for: the record says so (what k_ovl_nei would write after redoing
+                if (j == 0) rec[gs].flags |= FMD_OVLP_F_OVERFLOW;   // the strand: n_nei, rbeg, ext_len stay as the walk left them), the caller re-runs it larger
+                active = false; alive = false;
+            } else if (too_many) { // hand the strand to the lane-per-strand kernel
                 if (j == 0) { const uint32_t k = atomicAdd(slow_n, 1u); slow_list[k] = sid; }
                 active = false; alive = false;
             } else if (n_new > 0) { // next round (unitig.c:137-153)
@@ -326,15 +329,16 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
                     sz = (uint64_t)b.y << 32 | b.x; pos = b.z; cat = (int)b.w;
                 }
             } else { // every path is closed (unitig.c:154-178)
-                if (j == 0) rec[gs].lfork = (uint16_t)(LF_GET(flags) & 0xffffu);  // valid whatever happens to the record below
-                if (n_nei == 1 && (flags & FMD_OVLP_F_FORKED)) { // fake fork: the fix-up needs the slow kernel
-                    if (j == 0) { const uint32_t k = atomicAdd(slow_n, 1u); slow_list[k] = sid; }
-                } else if (j == 0) {
+                if (j == 0) {
                     fmd_ovlp_rec_t *o = rec + gs;
+                    o->lfork = (uint16_t)(LF_GET(flags) & 0xffffu);
                     o->rbeg = n_nei ? ori_l - (int)(uint32_t)nei0_info : -1;
                     o->ext_len = n_nei > 1 ? 0 : round;
                     o->n_nei = (int32_t)n_nei;
                     o->flags |= flags & 0xffu;
+                    // a fake fork (contained reads, unitig.c:158-176): the record stands as fm6_get_nei leaves it BEFORE the fix-up; k_ovl_fix
+                    // re-derives the appended bases from it (a lane walking ~60 dependent steps has no place in a group kernel)
+                    if (n_nei == 1 && (flags & FMD_OVLP_F_FORKED)) { const uint32_t k = atomicAdd(slow_n + FMD_CLS_FIX_CNT, 1u); slow_list[fix_off + k] = sid; }
                 }
                 active = false; alive = false;
             }
@@ -579,8 +583,8 @@ __global__ __launch_bounds__(64, 5) void k_ovl_nei_fast(FmdIndexView ix, const u
                         store_entry(nei_out + gs * (size_t)max_nei + n_nei, r0, ix.cnt[0] + Rz + W::popc(~(X | Y | Z) & W::below(d)), sz, (uint64_t)(ori_l - pos));
                     ++n_nei;
                 }
-                if (n_nei > max_nei) { // more neighbours than the caller has room for: the lane-per-strand kernel reports it
-                    if (j == 0) { const uint32_t k = atomicAdd(slow_n, 1u); slow_list[k] = sid; }
+                if (n_nei > max_nei) { // more neighbours than the caller has room for: flagged (as k_ovl_nei would after redoing the strand), re-run larger by the caller
+                    if (j == 0) rec[gs].flags |= FMD_OVLP_F_OVERFLOW;
                     active = false; alive = false;
                 } else if (child_g) { // next round (unitig.c:137-153)
                     if (j == 0 && ori_l + round < seq_stride) seq_out[gs * (size_t)seq_stride + ori_l + round] = (uint8_t)(5 - cs);   // comp6, cs in 1..4
@@ -658,9 +662,9 @@ static int grp_blocks_per_cu(void)
 }
 void fmd_launch_nei_grp(int cls, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                         const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
-                        uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx)
+                        uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx, size_t fix_off)
 {
-#define GRP_LAUNCH(K) k_ovl_nei_grp<fmd_grp_size(K)><<<n_cu * grp_cap(grp_blocks_per_cu<fmd_grp_size(K)>(), per_cu_cap), 64, 0, st>>>(ix, list, list_n, cap, listA, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n, gidx)
+#define GRP_LAUNCH(K) k_ovl_nei_grp<fmd_grp_size(K)><<<n_cu * grp_cap(grp_blocks_per_cu<fmd_grp_size(K)>(), per_cu_cap), 64, 0, st>>>(ix, list, list_n, cap, listA, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n, gidx, fix_off)
     switch (cls) {
     case 0: GRP_LAUNCH(0); break;
     case 1: GRP_LAUNCH(1); break;

@@ -70,28 +70,3 @@ int fmd_park_sort(hipStream_t st, size_t n, const FmdWalkPark *park, uint32_t *k
     FMD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (const uint32_t *)keys_a, keys_b, (const uint32_t *)vals_a, vals_b, n, 0, 32, st));
     return FMD_OK;
 }
-
-// ---- the order of pass 1: by the last ptab_d bases, which the tail table holds for every sequence (FmdIndexView::tail, bits 40..).
-// Strands with the same tail read the same two prefix-table entries and, for the first bases behind the table, the same rank blocks.
-__global__ void k_ovl_tail_keys(size_t n, const uint64_t *__restrict__ ids, const unsigned long long *__restrict__ tail, uint64_t n_seq,
-                                uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
-{
-    const size_t step = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
-        const uint64_t id = ids[i];
-        const unsigned long long te = id < n_seq ? tail[id] : ~0ull;
-        keys[i] = (uint32_t)(te >> 40);
-        vals[i] = (uint32_t)i;
-    }
-}
-
-int fmd_tail_sort(hipStream_t st, size_t n, const uint64_t *ids, const unsigned long long *tail, uint64_t n_seq, int bits, uint32_t *keys_a, uint32_t *keys_b,
-                  uint32_t *vals_a, uint32_t *vals_b, void *tmp, size_t tmp_bytes)
-{
-    size_t blocks = (n + 255) / 256;
-    if (blocks > (1u << 20)) blocks = 1u << 20;
-    k_ovl_tail_keys<<<(unsigned)blocks, 256, 0, st>>>(n, ids, tail, n_seq, keys_a, vals_a);
-    if (bits < 1 || bits > 24) bits = 24;   // (entries of sequences without a tail are all ones: they sort to the end)
-    FMD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (const uint32_t *)keys_a, keys_b, (const uint32_t *)vals_a, vals_b, n, 0, bits, st));
-    return FMD_OK;
-}

@@ -5,8 +5,8 @@ TAG=${1:-x}; N=${2:-50000000}; B=${3:-20000000}; shift 3
 OUT=gpurun_out/insts_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc -o t -- python tools/ab_sorted.py $N 0.0 $B 1 "$@" > $OUT/pmc.txt 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python tools/ab_sorted.py $N 0.0 $B 1 "$@" > $OUT/trace.txt 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc -o t -- python tools/ab_sorted.py $N ${ERR:-0.0} $B 1 "$@" > $OUT/pmc.txt 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python tools/ab_sorted.py $N ${ERR:-0.0} $B 1 "$@" > $OUT/trace.txt 2>&1
 find $OUT -name "*kernel_trace.csv" -delete
 python - $OUT <<'PY'
 import csv, glob, os, sys
