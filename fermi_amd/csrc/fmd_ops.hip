@@ -128,11 +128,11 @@ __global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const
     bool live = false, exhausted = false;
 
     FmdTickets tk_;
-    fmd_tickets_init(tk_, queue);
+    fmd_tickets_init(tk_, queue, 64, n);   // guided chunks (fmd_wave.h)
     for (;;) {
         // ---- refill finished lanes from the queue
         {
-            const size_t my = fmd_tickets_take(tk_, queue, !live && !exhausted);
+            const size_t my = fmd_tickets_take(tk_, queue, !live && !exhausted, n);
             if (!live && !exhausted) {
                 if (my < n) {
                     rid = my; sbase = off[my];

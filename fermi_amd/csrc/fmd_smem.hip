@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
     bool exhausted = false, overflow = false;
 
     FmdTickets tk_;
-    fmd_tickets_init(tk_, queue);
+    fmd_tickets_init(tk_, queue, 64, n);   // guided chunks of up to 64 reads: a launch of 5*10^7 reads in chunks of 16 is 3*10^6 atomics on one counter
     for (;;) {
         // ---- refill
         // Reads are taken in groups of at least refill_min lanes: a new read starts with ~log4(n) steps on
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
         // lane is in it; starting reads together keeps most steps free of it.
         const uint64_t idle = __ballot(st == SM_IDLE);
         const bool take = !exhausted && (__popcll(idle) >= refill_min || idle == ~0ull);
-        const size_t my = fmd_tickets_take(tk_, queue, st == SM_IDLE && take);
+        const size_t my = fmd_tickets_take(tk_, queue, st == SM_IDLE && take, n);
         if (st == SM_IDLE && take) {
             if (my < n) {
                 rid = my; cw_at = ~0ull; n_mem = 0; n_out = 0; overflow = false; full_only = false;

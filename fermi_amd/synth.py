@@ -35,11 +35,13 @@ def genome(seed, n_reads, read_len=100, coverage=30):
     return (1 + (rnd(seed, 1, np.arange(g, dtype=np.uint64)) >> np.uint64(62))).astype(np.uint8)
 
 
-def reads(seed, n_reads, read_len=100, coverage=30, err=0.0, start=0, count=None):
-    """Return uint8 [count, read_len] nt6 reads `start .. start+count` of the n_reads-read set."""
+def reads(seed, n_reads, read_len=100, coverage=30, err=0.0, start=0, count=None, gen=None):
+    """Return uint8 [count, read_len] nt6 reads `start .. start+count` of the n_reads-read set (gen: the genome from genome(),
+    to generate a large set piece by piece without recomputing it)."""
     if count is None:
         count = n_reads - start
-    gen = genome(seed, n_reads, read_len, coverage)
+    if gen is None:
+        gen = genome(seed, n_reads, read_len, coverage)
     G = gen.shape[0]
     r = np.arange(start, start + count, dtype=np.uint64)
     pos = (rnd(seed, 2, r) % np.uint64(G - read_len + 1)).astype(np.int64)

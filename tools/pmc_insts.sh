@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc -o t -- python tools/ab_sorted.py $N ${ERR:-0.0} $B 1 "$@" > $OUT/pmc.txt 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python tools/ab_sorted.py $N ${ERR:-0.0} $B 1 "$@" > $OUT/trace.txt 2>&1
 find $OUT -name "*kernel_trace.csv" -delete
-python - $OUT <<'PY'
+python - $OUT <<'PY' | tee $OUT/TABLE.txt
 import csv, glob, os, sys
 from collections import defaultdict
 out = sys.argv[1]
@@ -30,4 +30,4 @@ for k in sorted(acc, key=lambda k: -t.get(k, (0, 0))[0] * t.get(k, (0, 0))[1]):
     if t.get(k, (0, 0))[1] > 0.3:
         print("%-46s %5d %9.3f %11.4g %11.4g %11.4g %11.4g" % (k, t[k][0], t[k][1], m("SQ_INSTS_VALU"), m("SQ_INSTS_SALU"), m("SQ_INSTS_LDS"), m("SQ_INSTS_VMEM_RD")))
 PY
-grep -E "sorted job|id order|SAME|DIFF" $OUT/trace.txt
+grep -E "index:|sorted job|id order|SAME|DIFF" $OUT/trace.txt | tee -a $OUT/TABLE.txt
