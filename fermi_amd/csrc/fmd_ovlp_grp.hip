@@ -400,8 +400,11 @@ template <> struct FastW<uint64_t> {
     }
 };
 
+#ifndef FMD_FAST_LB
+#define FMD_FAST_LB 5      // waves per SIMD the register budget is cut for.  6 makes some instantiations spill: the build of the round-2 incident (tools/scratch_incident.py)
+#endif
 template <int G, typename M>
-__global__ __launch_bounds__(64, 5) void k_ovl_nei_fast(FmdIndexView ix, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
+__global__ __launch_bounds__(64, FMD_FAST_LB) void k_ovl_nei_fast(FmdIndexView ix, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
                                                      uint32_t cap, const fmd_intv_t *__restrict__ listA, fmd_ovlp_rec_t *__restrict__ rec,
                                                      fmd_intv_t *__restrict__ nei_out, uint32_t max_nei, uint8_t *__restrict__ seq_out,
                                                      uint32_t seq_stride, uint32_t *__restrict__ gen_list, uint32_t *__restrict__ gen_n,

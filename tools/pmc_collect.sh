@@ -9,6 +9,8 @@ export TMPDIR=/tmp
 NR=${FMD_BENCH_READS:-50000000}; NB=${FMD_BENCH_BSEARCH_READS:-10000000}
 timeout 1200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o legs -- python tools/pmc_legs.py $K > $OUT/pmc_fetch.log 2>&1
 timeout 1200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o legs -- python tools/pmc_legs.py $K > $OUT/pmc_write.log 2>&1
+PMC_LEGS=overlap_raw timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/raw_fetch -o legs -- python tools/pmc_legs.py $K > $OUT/raw_fetch.log 2>&1
+PMC_LEGS=overlap_raw timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/raw_write -o legs -- python tools/pmc_legs.py $K > $OUT/raw_write.log 2>&1
 PROBE_LINE=64 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_probe -o probe -- python tools/probe_once.py > $OUT/probe_once.txt 2>&1
 python tools/pmc_to_json.py $OUT $K $NR $NB "profiles/${TAG}_pmc (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/pmc_legs.py, $K steps per leg)" > $OUT/pmc_traffic_summary.txt 2>&1
 cp profiles/pmc_traffic.json $OUT/pmc_traffic.json

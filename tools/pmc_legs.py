@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The bench legs with nothing around them, for the rocprofv3 --pmc passes (tools/pmc_collect.sh): K steps of each leg at
 bench.py's sizes, no warm-up, no checks, no instrumented build -- every launch of a leg's kernels in the profile belongs
-to one of its K steps.  Usage: python tools/pmc_legs.py [steps=2]"""
+to one of its K steps.  PMC_LEGS=overlap_raw runs only overlap discovery on the raw-read index (the same kernels as the headline
+leg: it needs a profile of its own).  Usage: python tools/pmc_legs.py [steps=2]"""
 import ctypes as C, math, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -27,6 +28,16 @@ def index_of(n, err):
     return rd, ix, n_sym
 
 
+if os.environ.get("PMC_LEGS") == "overlap_raw":
+    rd, ix, n_sym = index_of(n_reads, 0.01)
+    del rd
+    job = bench.OverlapJob(torch, api, ix, dev, 2 * n_reads, 0, 1, L, 50)
+    for _ in range(K):
+        job.compute()
+    torch.cuda.synchronize()
+    ix.close()
+    print("pmc_legs: %d steps of overlap discovery on the raw-read index of %d reads" % (K, n_reads))
+    sys.exit(0)
 # overlap (+ check_left) at n_reads, e = 0
 rd, ix, n_sym = index_of(n_reads, 0.0)
 del rd

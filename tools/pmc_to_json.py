@@ -11,7 +11,10 @@ sys.path.insert(0, ROOT)
 import bench
 
 d, steps, n_reads, n_bs, label = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-LEGS = {"overlap@%d" % n_reads: ("k_ovl_walk", "k_ovl_seq_out", "k_ovl_classify", "k_ovl_nei_fast", "k_ovl_nei_grp", "k_ovl_nei"),
+OVL = ("k_ovl_head_adm", "k_ovl_walk", "k_ovl_park_keys", "k_ovl_seq_out", "k_ovl_classify", "k_ovl_nei_fast", "k_ovl_nei_grp", "k_ovl_nei", "k_ovl_fix")
+# (the two 32-bit radix sorts of the sorted job -- ~10 GB of streaming per 10^8 strands -- run in rocprim kernels whose names they
+# share with the sorts of the index build in the same profile: not in these sums)
+LEGS = {"overlap@%d" % n_reads: OVL,
         "check_left@%d" % n_reads: ("k_link_rows", "k_link_edges", "k_ovl_cls"), "k_bsearch@%d" % n_bs: ("k_bsearch",), "smem@%d" % n_reads: ("k_smem",),
         "kmer@%d" % n_reads: ("k_kmer_level", "k_kmer_emit")}
 
@@ -39,5 +42,10 @@ for key, names in LEGS.items():
     if fk:
         out[key] = {"fetch_kb": fk, "write_kb": wk, "fetch_calibration": cal, "csrc_sha": bench.csrc_sha(), "source": label,
                     "per_kernel_fetch_kb": {k: v / steps for k, v in fetch.items() if k in names}}
+fr, wr = sums("raw_fetch", "FETCH_SIZE"), sums("raw_write", "WRITE_SIZE")   # overlap discovery on the raw-read index: its own profile (same kernel names)
+fk = sum(v for k, v in fr.items() if k in OVL) / steps
+if fk:
+    out["overlap_raw@%d" % n_reads] = {"fetch_kb": fk, "write_kb": sum(v for k, v in wr.items() if k in OVL) / steps, "fetch_calibration": cal, "csrc_sha": bench.csrc_sha(),
+                                       "source": label, "per_kernel_fetch_kb": {k: v / steps for k, v in fr.items() if k in OVL}}
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
