@@ -220,7 +220,7 @@ __global__ void k_ptab_level(FmdIndexView ix, int d, const uint4 *__restrict__ p
     if (i >= (1ull << (2 * d))) return;
     const int c = (int)(i >> (2 * (d - 1))) + 1;
     uint64_t k, l;
-    if (d == 1) { k = fmd_cnt(ix, c); l = fmd_cnt(ix, c + 1) - 1; }
+    if (d == 1) { k = ix.cnt[c]; l = ix.cnt[c + 1] - 1; }
     else {
         const uint4 e = prev[i & ((1ull << (2 * (d - 1))) - 1)];
         k = (uint64_t)e.y << 32 | e.x; l = (uint64_t)e.w << 32 | e.z;
@@ -230,7 +230,7 @@ __global__ void k_ptab_level(FmdIndexView ix, int d, const uint4 *__restrict__ p
             if (k) { fmd_split(k - 1, b, o); rk = fmd_block_rank1(ix.blocks + (size_t)b * FMD_BLK_U4, 0, o + 1, c, b); }
             fmd_split(l, b, o);
             const uint64_t rl = fmd_block_rank1(ix.blocks + (size_t)b * FMD_BLK_U4, 0, o + 1, c, b);
-            k = fmd_cnt(ix, c) + rk; l = fmd_cnt(ix, c) + rl - 1;
+            k = ix.cnt[c] + rk; l = ix.cnt[c] + rl - 1;
         }
     }
     if (k > l) { k = 1; l = 0; }
@@ -278,7 +278,7 @@ __global__ void k_tail_table(FmdIndexView ix, int d, unsigned long long *__restr
             fmd_split(k, b, o);
             const int c = fmd_block_rank6<true>(ix.blocks + (size_t)b * FMD_BLK_U4, 0, o + 1, r, b);
             if (c < 1 || c > 4) { ok = false; break; }
-            k = fmd_cnt(ix, c) + r[c] - 1;
+            k = ix.cnt[c] + r[c] - 1;
             tfw |= (uint64_t)(c - 1) << (2 * j);
         }
         tail[id] = ok ? (k | tfw << 40) : FMD_TAIL_NONE;

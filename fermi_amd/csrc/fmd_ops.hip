@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const
                         }
                         if (!from_table) {
                             const int c = seqs[sbase + len - 1];
-                            k = fmd_cnt(ix, c); l = fmd_cnt(ix, c + 1) - 1;
+                            k = ix.cnt[c]; l = ix.cnt[c + 1] - 1;
                             pos = len - 2;
                             live = true;
                         }
@@ -196,8 +196,8 @@ __global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const
         fmd_wave_l_ready(ix, fmd_lds, r); // only while the intervals are wide (more than 32 lanes straddle)
         if (live) {
             const uint64_t ol = fmd_block_rank1(r.bl, r.tl, r.nl, c, r.blk_l);
-            k = fmd_cnt(ix, c) + ok;
-            l = fmd_cnt(ix, c) + ol - 1;
+            k = ix.cnt[c] + ok;
+            l = ix.cnt[c] + ol - 1;
             --pos;
             if (k > l || pos < 0) {
                 const bool hit = k <= l;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(64) void k_reach(FmdIndexView ix, size_t n, const u
                             }
                         }
                         if (!from_table) {
-                            k = fmd_cnt(ix, cc); l = fmd_cnt(ix, cc + 1) - 1;
+                            k = ix.cnt[cc]; l = ix.cnt[cc + 1] - 1;
                             if (k > l) out_len[p] = 0;        // a base the index does not contain
                             else { i = p + 1; live = true; }
                         }
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64) void k_reach(FmdIndexView ix, size_t n, const u
         fmd_wave_l_ready(ix, fmd_lds, r);
         if (live) {
             const uint64_t ol = fmd_block_rank1(r.bl, r.tl, r.nl, cc, r.blk_l);
-            k = fmd_cnt(ix, cc) + ok; l = fmd_cnt(ix, cc) + ol - 1;
+            k = ix.cnt[cc] + ok; l = ix.cnt[cc] + ol - 1;
             if (k > l) { out_len[p] = (uint32_t)(i - p); live = false; }
             else ++i;
         }
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64) void k_retrieve(FmdIndexView ix, size_t n, cons
         if (live) {
             uint64_t ok[6];
             const int c = fmd_block_rank6<true>(r.bk, r.t, r.nk, ok, r.blk_k);
-            k = fmd_cnt(ix, c) + ok[c] - 1;
+            k = ix.cnt[c] + ok[c] - 1;
             if (c == 0) { d_len[rid] = len; d_rank[rid] = k; live = false; }
             else {
                 if (len < stride) d_seqs[rid * (size_t)stride + len] = (uint8_t)c;

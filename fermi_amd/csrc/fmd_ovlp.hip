@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64) void k_ovl_retrieve(FmdIndexView ix, size_t n, 
         if (live) {
             uint64_t ok[6];
             const int c = fmd_block_rank6<true>(r.bk, r.t, r.nk, ok, r.blk_k);
-            k = fmd_cnt(ix, c) + ok[c] - 1;
+            k = ix.cnt[c] + ok[c] - 1;
             if (c == 0) {
                 if ((len & 3) && len < stride_r) *(uint32_t *)(srev + sid * (size_t)stride_r + (len & ~3u)) = pack;
                 fmd_ovlp_rec_t *o = rec + sid;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64) void k_ovl_intv(FmdIndexView ix, size_t n, int 
                     const uint8_t *s = srev + sid * (size_t)stride_r;
                     cache = *(const uint32_t *)s;
                     const int c = cache & 0xff;
-                    x0 = fmd_cnt(ix, c); x1 = fmd_cnt(ix, comp6(c)); sz = fmd_cnt(ix, c + 1) - fmd_cnt(ix, c);
+                    x0 = ix.cnt[c]; x1 = ix.cnt[comp6(c)]; sz = ix.cnt[c + 1] - ix.cnt[c];
                     {   // sequence in read order for the caller: one burst of dword stores (the row is
                         // srev byte-reversed), so the line is written once instead of L partial writes
                         uint8_t *dst = seq_out + sid * (size_t)seq_stride;
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
             wtk = fmd_block_rank1z(r.bk, r.t, r.nk, c, r.blk_k, wr0);              // rank_c(x0 - 1), rank_$(x0 - 1)
             wD = M0;
             const uint64_t Mc = sel6(c, M0, M1, M2, M3, M4, M5);
-            k = fmd_cnt(ix, c) + wtk + __popcll(Mc & bits_below((int)o + 1)) - 1;
+            k = ix.cnt[c] + wtk + __popcll(Mc & bits_below((int)o + 1)) - 1;
         } else if (st == WK_LF || st == WK_BOTH) { // LF step at row k: base = BWT[k], k' = cnt[c] + rank_c(k) - 1
             uint32_t kb_ = r.blk_k, off;
             const bool in_k = fmd_in_block(k, r.blk_k, off);     // (WK_LF: the block asked for; WK_BOTH: one of the extension's two)
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
             const uint4 v = img[(int)(off >> 5) ^ tt];
             const uint32_t bit = off & 31;
             c = (int)(((v.x >> bit) & 1) | ((v.y >> bit) & 1) << 1 | ((v.z >> bit) & 1) << 2);
-            k = fmd_cnt(ix, c) + fmd_block_rank1(img, tt, off + 1, c, kb_) - 1;
+            k = ix.cnt[c] + fmd_block_rank1(img, tt, off + 1, c, kb_) - 1;
             if (st == WK_LF && depth > 0 && tab) { // still inside the prefix table: no extension, just collect the base
                 if (c < 1 || c > 4) { // the sequence ends, or an ambiguous base: start over on the ordinary path
                     k = ids[gs]; depth = 0; pack = 0; pk0 = pk1 = pk2 = 0; tab = false;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
                 st = WK_IDLE;
                 continue;
             }
-            x0 = fmd_cnt(ix, c); x1 = fmd_cnt(ix, comp6(c)); sz = fmd_cnt(ix, c + 1) - fmd_cnt(ix, c);
+            x0 = ix.cnt[c]; x1 = ix.cnt[comp6(c)]; sz = ix.cnt[c + 1] - ix.cnt[c];
             WALK_PUT_BASE(c);   // (depth 0 -> 1)
             if (c > 4) tab = false;
             tfw = (uint32_t)(c - 1) & 3; trv = (uint32_t)(4 - c) & 3;
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(64) void k_ovl_cls(FmdIndexView ix, size_t n, int m
                     sid = my; rbeg = o->rbeg; s_l = o->len + o->ext_len;
                     s = seq + sid * (size_t)seq_stride;
                     const int c = s[rbeg];
-                    x0 = fmd_cnt(ix, c); x1 = fmd_cnt(ix, comp6(c)); sz = fmd_cnt(ix, c + 1) - fmd_cnt(ix, c);
+                    x0 = ix.cnt[c]; x1 = ix.cnt[comp6(c)]; sz = ix.cnt[c + 1] - ix.cnt[c];
                     depth = 1; prev = listA + sid * (size_t)cap; curr = listB + sid * (size_t)cap; prev_n = curr_n = 0;
                     if (rbeg + 1 < s_l) st = CL_FWD;
                     else { o->reserved = 0; } // a one-base neighbour cannot collect anything

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
             again = false;
             if (st == SM_START) { // fm6_smem1_core prologue (smem.c:19-21)
                 const int c = q[x];
-                kx0 = fmd_cnt(ix, c); kx1 = fmd_cnt(ix, comp6(c)); ksz = fmd_cnt(ix, c + 1) - fmd_cnt(ix, c); kinfo = (uint64_t)(x + 1);
+                kx0 = ix.cnt[c]; kx1 = ix.cnt[comp6(c)]; ksz = ix.cnt[c + 1] - ix.cnt[c]; kinfo = (uint64_t)(x + 1);
                 curr_n = 0; call_base = n_mem; out_base = n_out; i = x + 1;
                 if (ksz == 0) { // the reference dereferences an empty list here (undefined); stop this read
                     n_mem_out[rid] = n_out | (overflow ? 0x80000000u : 0);
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
         if (c == 1 || c == 5) before += s[2];
         if (c == 5) before += s[1];
         const uint64_t rc = base + before;                 // child c
-        const uint64_t nxc = fmd_cnt(ix, c) + tkc;              // its coordinate on the extended strand
+        const uint64_t nxc = ix.cnt[c] + tkc;              // its coordinate on the extended strand
         // the '$' child of a forward extension (pushed by the forward sweep when !self_match)
         if ((st == SM_FWD || st == SM_FWD_END) && !self_match && s[0] && !have_tk0) tk0 = r.hk ? fmd_block_rank1(r.bk, r.t, r.nk, 0, r.blk_k) : 0;
 

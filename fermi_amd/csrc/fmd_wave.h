@@ -117,17 +117,6 @@ __device__ __forceinline__ void fmd_count_lines(const FmdIndexView &ix, int n, i
 #endif
 }
 
-// cnt[c] for a per-LANE symbol c (0..6).  The view is a kernel argument and lives in SGPRs, which a lane cannot index: `ix.cnt[c]`
-// compiles to a load from the kernel-argument segment IN MEMORY with an s_waitcnt vmcnt(0) behind it -- a round trip to L2 in the
-// dependent chain of every step of every search (rounds 1-2 had it in k_bsearch, k_retrieve, k_smem and the walk).  Six selects instead.
-__device__ __forceinline__ uint64_t fmd_cnt(const FmdIndexView &ix, int c)
-{
-    uint64_t r = ix.cnt[0];
-    r = c == 1 ? ix.cnt[1] : r; r = c == 2 ? ix.cnt[2] : r; r = c == 3 ? ix.cnt[3] : r;
-    r = c == 4 ? ix.cnt[4] : r; r = c == 5 ? ix.cnt[5] : r; r = c == 6 ? ix.cnt[6] : r;
-    return r;
-}
-
 __device__ __forceinline__ int fmd_lane() { return (int)(threadIdx.x & 63); }
 // number of set bits of a wave-uniform mask below this lane (v_mbcnt_lo/hi: two instructions)
 __device__ __forceinline__ int fmd_below(uint64_t mask)
