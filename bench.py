@@ -20,7 +20,7 @@ the same sources, libfmdhip_count.so, in one extra untimed step) + the streams t
 the HIP-event time of the timed steps, over 8 TB/s.  The SURVEY 8(d) accounting (128 B per rank query of the
 REFERENCE's layout) is reported beside it as algorithmic_equivalent_GBps; it exceeds the peak because this layout
 needs far fewer bytes per query.  roofline.traffic = PMC bytes from profiles/pmc_traffic.json, printed only
-when that file was measured on these kernel sources (sha of fermi_amd/csrc) at this size.
+when that file was measured on these kernel sources (sha of the leg's files in fermi_amd/csrc) at this size.
 
 Knobs: FMD_BENCH_READS (50_000_000), FMD_BENCH_BSEARCH_READS (10_000_000), FMD_BENCH_LEGS
 (overlap,check_left,bsearch,smem,kmer), FMD_BENCH_CPU_SAMPLE* (bounded CPU samples).
@@ -48,13 +48,20 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def csrc_sha():
-    """Identity of the kernel sources: PMC figures are valid for exactly these."""
+# the sources a leg's kernels are compiled from (besides the headers and the index layout, which every kernel depends on)
+LEG_SOURCES = {"overlap": ("fmd_ovlp.hip", "fmd_ovlp_grp.hip", "fmd_ovlp_sort.hip"), "overlap_raw": ("fmd_ovlp.hip", "fmd_ovlp_grp.hip", "fmd_ovlp_sort.hip"),
+               "check_left": ("fmd_pack.hip", "fmd_ovlp.hip"), "k_bsearch": ("fmd_ops.hip",), "smem": ("fmd_smem.hip",), "kmer": ("fmd_kmer.hip",)}
+
+
+def csrc_sha(leg=None, read=None):
+    """Identity of the kernel sources PMC figures are valid for: the headers, the index layout and the files the leg's kernels
+    live in (all of fermi_amd/csrc when no leg is named).  `read(name) -> bytes` lets a tool hash another revision's files."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "fermi_amd", "csrc")
+    read = read or (lambda fn: open(os.path.join(d, fn), "rb").read())
     for fn in sorted(os.listdir(d)):
-        if fn.endswith((".hip", ".h")):
-            h.update(fn.encode()); h.update(open(os.path.join(d, fn), "rb").read())
+        if fn.endswith(".h") or fn == "fmd_index.hip" or (fn.endswith(".hip") and (leg is None or fn in LEG_SOURCES[leg])):
+            h.update(fn.encode()); h.update(read(fn))
     return h.hexdigest()[:16]
 
 
@@ -63,7 +70,7 @@ def pmc_traffic(key):
     None unless the entry was measured on the kernel sources of this tree."""
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key)
-        if pmc and pmc.get("csrc_sha") == csrc_sha():
+        if pmc and pmc.get("csrc_sha") == csrc_sha(key.split("@")[0]):
             return (pmc["fetch_kb"] * pmc["fetch_calibration"] + pmc["write_kb"]) * 1024.0, pmc["source"]
     except Exception:
         pass

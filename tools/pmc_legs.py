@@ -38,31 +38,36 @@ if os.environ.get("PMC_LEGS") == "overlap_raw":
     ix.close()
     print("pmc_legs: %d steps of overlap discovery on the raw-read index of %d reads" % (K, n_reads))
     sys.exit(0)
-# overlap (+ check_left) at n_reads, e = 0
-rd, ix, n_sym = index_of(n_reads, 0.0)
-del rd
-job = bench.OverlapJob(torch, api, ix, dev, 2 * n_reads, 0, 1, L, 50)
-for _ in range(K):
-    job.compute()
-torch.cuda.synchronize()
-job.alloc_link()
-for _ in range(K):
-    job.check_left_linked()
-torch.cuda.synchronize()
-del job
-ix.close(); torch.cuda.empty_cache()
-# backward search at n_bs, e = 0
-rd, ix, _ = index_of(n_bs, 0.0)
-cnt = torch.zeros(n_bs, dtype=torch.int64, device=dev); beg = torch.zeros_like(cnt); end = torch.zeros_like(cnt)
-for _ in range(K):
-    api.check(lib.fmd_bsearch_dev(ix.h, sh, n_bs, rd.flat.data_ptr(), rd.off.data_ptr(), cnt.data_ptr(), beg.data_ptr(), end.data_ptr()))
-torch.cuda.synchronize()
-ix.close(); del rd, cnt, beg, end; torch.cuda.empty_cache()
+ONLY = os.environ.get("PMC_LEGS")   # e.g. PMC_LEGS=smem,kmer: a partial re-collection after one leg's kernels changed
+want = lambda leg: not ONLY or leg in ONLY.split(",")
+if want("overlap") or want("check_left"):   # overlap (+ check_left) at n_reads, e = 0
+    rd, ix, n_sym = index_of(n_reads, 0.0)
+    del rd
+    job = bench.OverlapJob(torch, api, ix, dev, 2 * n_reads, 0, 1, L, 50)
+    for _ in range(K):
+        job.compute()
+    torch.cuda.synchronize()
+    job.alloc_link()
+    for _ in range(K):
+        job.check_left_linked()
+    torch.cuda.synchronize()
+    del job
+    ix.close(); torch.cuda.empty_cache()
+if want("k_bsearch"):   # backward search at n_bs, e = 0
+    rd, ix, _ = index_of(n_bs, 0.0)
+    cnt = torch.zeros(n_bs, dtype=torch.int64, device=dev); beg = torch.zeros_like(cnt); end = torch.zeros_like(cnt)
+    for _ in range(K):
+        api.check(lib.fmd_bsearch_dev(ix.h, sh, n_bs, rd.flat.data_ptr(), rd.off.data_ptr(), cnt.data_ptr(), beg.data_ptr(), end.data_ptr()))
+    torch.cuda.synchronize()
+    ix.close(); del rd, cnt, beg, end; torch.cuda.empty_cache()
+if not (want("smem") or want("kmer")):
+    print("pmc_legs: %d steps of %s" % (K, ONLY))
+    sys.exit(0)
 # SMEM + k-mer harvest at n_reads, e = 0.01
 rd, ix, n_sym = index_of(n_reads, 0.01)
 mem = torch.zeros(n_reads * 8 * 32, dtype=torch.uint8, device=dev); n_mem = torch.zeros(n_reads, dtype=torch.int32, device=dev)
 wb = lib.fmd_smem_work_bytes(n_reads, L); work = torch.empty(wb, dtype=torch.uint8, device=dev)
-for _ in range(K):
+for _ in range(K if want("smem") else 0):
     api.check(lib.fmd_smem_dev(ix.h, sh, n_reads, rd.flat.data_ptr(), rd.off.data_ptr(), 0, L, 8, mem.data_ptr(), n_mem.data_ptr(), work.data_ptr(), wb))
 torch.cuda.synchronize()
 del mem, n_mem, work, rd; torch.cuda.empty_cache()
@@ -71,7 +76,7 @@ cap = max(1 << 22, 1 << int(math.ceil(math.log2(n_sym / 30.0 * 1.5))))
 wb = lib.fmd_kmer_work_bytes(cap); work = torch.empty(wb, dtype=torch.uint8, device=dev)
 ob = torch.empty(cap, dtype=torch.int32, device=dev); ok_ = torch.empty(cap, dtype=torch.int32, device=dev); ov = torch.empty(cap, dtype=torch.uint8, device=dev)
 st = torch.zeros(4, dtype=torch.int64, device=dev)
-for _ in range(K):
+for _ in range(K if want("kmer") else 0):
     api.check(lib.fmd_kmer_collect_dev(ix.h, sh, w, 3, suf, work.data_ptr(), wb, cap, ob.data_ptr(), ok_.data_ptr(), ov.data_ptr(), st.data_ptr()))
 torch.cuda.synchronize()
 ix.close()

@@ -35,17 +35,25 @@ if probe.get("k_probe"):
     known = 2 * (1 << 27) * 64            # probe_once: warm-up + timed launch, 2^27 lines of 64 bytes each
     cal = known / (probe["k_probe"] * 1024.0)
 out = {"_comment": "HBM bytes per bench step from rocprofv3 --pmc passes over tools/pmc_legs.py (tools/pmc_collect.sh): sum over the launches of a leg's "
-                   "kernels / steps.  KB units; FETCH_SIZE x fetch_calibration (gather probe, 64-byte lines: %.4f).  Valid for kernel sources with this sha only." % cal}
+                   "kernels / steps.  KB units; FETCH_SIZE x fetch_calibration (gather probe, 64-byte lines: %.4f).  Every entry is valid for the kernel sources its csrc_sha names (the leg's files, bench.csrc_sha(leg))." % cal}
 for key, names in LEGS.items():
     fk = sum(v for k, v in fetch.items() if k in names) / steps
     wk = sum(v for k, v in write.items() if k in names) / steps
     if fk:
-        out[key] = {"fetch_kb": fk, "write_kb": wk, "fetch_calibration": cal, "csrc_sha": bench.csrc_sha(), "source": label,
+        out[key] = {"fetch_kb": fk, "write_kb": wk, "fetch_calibration": cal, "csrc_sha": bench.csrc_sha(key.split("@")[0]), "source": label,
                     "per_kernel_fetch_kb": {k: v / steps for k, v in fetch.items() if k in names}}
 fr, wr = sums("raw_fetch", "FETCH_SIZE"), sums("raw_write", "WRITE_SIZE")   # overlap discovery on the raw-read index: its own profile (same kernel names)
 fk = sum(v for k, v in fr.items() if k in OVL) / steps
 if fk:
-    out["overlap_raw@%d" % n_reads] = {"fetch_kb": fk, "write_kb": sum(v for k, v in wr.items() if k in OVL) / steps, "fetch_calibration": cal, "csrc_sha": bench.csrc_sha(),
+    out["overlap_raw@%d" % n_reads] = {"fetch_kb": fk, "write_kb": sum(v for k, v in wr.items() if k in OVL) / steps, "fetch_calibration": cal, "csrc_sha": bench.csrc_sha("overlap_raw"),
                                        "source": label, "per_kernel_fetch_kb": {k: v / steps for k, v in fr.items() if k in OVL}}
-json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+dst = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+try:   # a partial collection (PMC_LEGS=...) keeps the other legs' entries; each is valid for the sha it carries
+    old = json.load(open(dst))
+    for k, v in old.items():
+        if k not in out and isinstance(v, dict) and v.get("csrc_sha") == bench.csrc_sha(k.split("@")[0]):
+            out[k] = v
+except Exception:
+    pass
+json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
