@@ -1,43 +1,98 @@
 // fmd_smem.hip -- super-maximal exact matches: fm6_smem1_core (smem.c:13-80) driven as fm6_smem
 // does (smem.c:397-410), i.e. what `fermi exact` prints (cmd.c:319-327).  One lane per read on the
 // compact wave engine (13 waves/CU); the forward sweep is a chain of forward extensions, the
-// backward sweep walks the whole candidate list once per base.  Candidate lists live in an HBM work
+// backward sweep walks the candidate list once per base.  Candidate lists live in an HBM work
 // area owned by the persistent LANE (two lists of 2*max_len+2 entries, reused read after read, so the
 // area does not grow with the batch); SMEMs are written to the caller's array in the reference's order.
+//
+// The lists and the memory system.  One list entry is 32 bytes at an address no other lane is near, so
+// every push and every pick used to be a request of its own to the fabric -- a third of all requests
+// of this kernel, which runs at the fabric's request rate.  Now: (1) the last two entries pushed sit in
+// LDS (two 32-byte slots per lane) and go to HBM as ONE aligned 64-byte burst when a pair is complete;
+// the first entry of the backward sweep (the last one pushed) is taken from its slot; (2) picks fetch the
+// next entry NEEDED under the current gather; (3) the last round of the backward
+// sweep (i = -1) writes no list at all -- nobody reads `curr` after it (smem.c:52, :75) -- and skips
+// every entry that can no longer matter: once curr is non-empty, an entry that is not followed by a
+// sentinel (x[1] >= n_seq) can neither be a full-length match nor be kept (smem.c:61-62), so its
+// fm6_extend would be dead work.  Which entries are sentinel-closed is known when they are pushed: a
+// bit per entry in a 64-bit register (entries beyond the 64th are simply processed).
 #include <stdlib.h>
 #include <string.h>
 #include "fmd_internal.h"
 #include "fmd_kernel_common.h"
 
 // forward-sweep push (the list is written back to front); a full list marks the item as overflowed
-#define SM_PUSH_FWD(a_, b_, c_, d_) do { if (curr_n < cap) { store_entry(la + (cap - 1 - curr_n), a_, b_, c_, d_); ++curr_n; } else overflow = true; } while (0)
+#define SM_PUSH_FWD(a_, b_, c_, d_) do { if (curr_n < cap) { sm_push(la, slots, pend_e, cap - 1 - curr_n, a_, b_, c_, d_); fmask = fmask << 1 | (uint64_t)((b_) < ix.n_seq); ++curr_n; } else overflow = true; } while (0)
+
+#define SM_NONE 0xffffffffu
+// the two LDS slots of a lane (slot = entry index & 1), planes of 64 lanes x 16 bytes: no bank conflicts
+#define SM_SLOT(s_, p_) slots[(((s_) * 2 + (p_)) << 6) + fmd_lane()]
+
+__device__ __forceinline__ void sm_flush_single(fmd_intv_t *la, uint4 *slots, uint32_t &pend_e)
+{
+    uint4 *dst = (uint4 *)(la + pend_e);
+    const uint32_t s = pend_e & 1;
+    dst[0] = SM_SLOT(s, 0); dst[1] = SM_SLOT(s, 1);
+    pend_e = SM_NONE;
+}
+
+// entry e of the lane's area (la[e]; lb = la + cap) := (a, b, c, d).  It is written to its LDS slot; HBM gets it together with
+// its pair partner (e ^ 1) as one aligned 64-byte burst when that one was the push before, else when its slot is needed again.
+__device__ __forceinline__ void sm_push(fmd_intv_t *la, uint4 *slots, uint32_t &pend_e, uint32_t e, uint64_t a, uint64_t b, uint64_t c, uint64_t d)
+{
+    if (pend_e != SM_NONE && pend_e != (e ^ 1u)) sm_flush_single(la, slots, pend_e);
+    const uint32_t s = e & 1;
+    const uint4 v0 = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+    const uint4 v1 = make_uint4((uint32_t)c, (uint32_t)(c >> 32), (uint32_t)d, (uint32_t)(d >> 32));
+    SM_SLOT(s, 0) = v0; SM_SLOT(s, 1) = v1;
+    if (pend_e == (e ^ 1u)) {
+        const uint4 p0 = SM_SLOT(s ^ 1, 0), p1 = SM_SLOT(s ^ 1, 1);
+        uint4 *dm = (uint4 *)(la + e), *dp = (uint4 *)(la + (e ^ 1u));   // (addresses, not data, depend on which half this is)
+        dm[0] = v0; dm[1] = v1; dp[0] = p0; dp[1] = p1;
+        pend_e = SM_NONE;
+    } else pend_e = e;
+}
+
+// first entry at or after j that the last round still needs (bit = the entry is sentinel-closed; entries from the 64th on: all)
+__device__ __forceinline__ uint32_t sm_next_needed(uint32_t j, uint32_t n, uint64_t mask)
+{
+    if (j >= 64) return j;
+    const uint64_t rem = mask >> j;
+    if (rem) return j + (uint32_t)__builtin_ctzll(rem);
+    return n < 64 ? n : 64;
+}
 
 enum { SM_IDLE = 0, SM_START, SM_BEGIN_BWD, SM_BWD_PICK, SM_FWD, SM_FWD_END, SM_BWD };
 
-#define SMEM_LDS_BYTES (FMD_COMPACT_LDS_U4 * 16)
+#define SMEM_LDS_BYTES (FMD_COMPACT_LDS_U4 * 16 + 4 * 64 * 16)   // the engine + the two list slots per lane
 #define SMEM_MAX_WAVES 4096   // the candidate lists belong to the persistent lane, not to the read
 
-__global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ off,
+__global__ __launch_bounds__(64, 3) void k_smem(FmdIndexView ix, size_t n, const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ off,
                                              int self_match, uint32_t cap, fmd_intv_t *__restrict__ work, uint32_t max_mem,
                                              fmd_intv_t *__restrict__ mem_out, uint32_t *__restrict__ n_mem_out, uint32_t *__restrict__ queue,
-                                             int refill_min, const fmd_smem_win_t *__restrict__ wins)
+                                             int refill_min, const fmd_smem_win_t *__restrict__ wins, const uint32_t *__restrict__ mixed, int patience)
 {
+    // reads of one length (k_smem_mixed, same stream): the wave waits for ALL its lanes before it takes new reads -- while that works
+    bool patient = mixed && *mixed == 0;
+    int drain = 0;                               // wave steps since the first lane of the wave went idle
     FMD_DECLARE_COMPACT_LDS();
+    __shared__ uint4 slots[4 * 64];
     size_t rid = 0;
     const uint8_t *q = nullptr;
     int st = SM_IDLE, len = 0, x = 0, i = 0, ret = 0, stop = 0;
     uint32_t prev_n = 0, curr_n = 0, j = 0, n_mem = 0, call_base = 0;   // SMEMs found (the algorithm's count)
     uint32_t n_out = 0, out_base = 0;                                    // SMEMs written (full_only drops some)
     bool full_only = false;
-    // two candidate lists of `cap` entries per lane (HBM; this lane's area is reused read after read)
-    fmd_intv_t *const la = work + ((size_t)blockIdx.x * 64 + fmd_lane()) * 2 * (size_t)cap, *const lb = la + cap;
-    fmd_intv_t *prev = nullptr, *curr = nullptr;
+    // two candidate lists of `cap` entries per lane (HBM; this lane's area is reused read after read): la = entries [0, cap) of
+    // the area, lb = [cap, 2 cap).  prev / curr are entry indices into it.
+    fmd_intv_t *const la = work + ((size_t)blockIdx.x * 64 + fmd_lane()) * 2 * (size_t)cap;
+    uint32_t prev_e0 = 0, curr_e0 = 0, pend_e = SM_NONE, pf_e = SM_NONE;
+    uint64_t fmask = 0, kmask = 0, cmask = 0;        // sentinel-closed entries of the list being pushed / of prev / of curr
     uint64_t kx0 = 0, kx1 = 0, ksz = 0, kinfo = 0;   // ik (forward sweep) / p (backward sweep)
     uint64_t last_curr_sz = 0, last_mem_beg = 0;
     uint64_t sbase = 0;                              // off[rid]
     uint32_t cw = 0; uint64_t cw_at = ~0ull;         // four bases of the read around the position in use
-    uint4 pfa = make_uint4(0, 0, 0, 0), pfb = pfa;   // prev[j + 1], fetched under the gather of prev[j]
-    bool have_pf = false;
+    uint4 pfa = make_uint4(0, 0, 0, 0), pfb = pfa;   // entry pf_e of the area, fetched under a gather
     bool exhausted = false, overflow = false;
 
     FmdTickets tk_;
@@ -48,7 +103,9 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
         // wide intervals (two six-symbol block ranks), and a wave pays for that code path whenever ONE
         // lane is in it; starting reads together keeps most steps free of it.
         const uint64_t idle = __ballot(st == SM_IDLE);
-        const bool take = !exhausted && (__popcll(idle) >= refill_min || idle == ~0ull);
+        drain = idle ? drain + 1 : 0;
+        if (drain > patience) patient = false;   // the lanes' work differs too much (several calls per read, long backward sweeps): groups from now on
+        const bool take = !exhausted && ((!patient && __popcll(idle) >= refill_min) || idle == ~0ull);
         const size_t my = fmd_tickets_take(tk_, queue, st == SM_IDLE && take, n);
         if (st == SM_IDLE && take) {
             if (my < n) {
@@ -71,7 +128,7 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
             if (st == SM_START) { // fm6_smem1_core prologue (smem.c:19-21)
                 const int c = q[x];
                 kx0 = ix.cnt[c]; kx1 = ix.cnt[comp6(c)]; ksz = ix.cnt[c + 1] - ix.cnt[c]; kinfo = (uint64_t)(x + 1);
-                curr_n = 0; call_base = n_mem; out_base = n_out; i = x + 1;
+                curr_n = 0; call_base = n_mem; out_base = n_out; i = x + 1; fmask = 0; pend_e = SM_NONE;
                 if (ksz == 0) { // the reference dereferences an empty list here (undefined); stop this read
                     n_mem_out[rid] = n_out | (overflow ? 0x80000000u : 0);
                     st = SM_IDLE;
@@ -82,24 +139,35 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
                     again = st == SM_BEGIN_BWD;
                 }
             } else if (st == SM_BEGIN_BWD) { // the forward list, already reversed, becomes prev (smem.c:45-50)
-                prev = la + (cap - curr_n); prev_n = curr_n;
-                uint64_t t0, t1, t2, t3;
-                load_entry(prev, t0, t1, t2, t3);
-                ret = (int)t3;
-                curr = lb; curr_n = 0; j = 0; i = x - 1; last_mem_beg = 0; have_pf = false;
-                st = SM_BWD_PICK; again = true;
+                if (curr_n == 0) { // nothing was pushed (every occurrence of q[x] ends its sequence): the reference reads a[0] of an empty list; stop this read
+                    n_mem_out[rid] = n_out | (overflow ? 0x80000000u : 0);
+                    st = SM_IDLE;
+                } else {
+                    prev_e0 = cap - curr_n; prev_n = curr_n; kmask = fmask;
+                    { // prev[0] = the last entry pushed: still in its slot
+                        const uint4 a = SM_SLOT(prev_e0 & 1, 0), b = SM_SLOT(prev_e0 & 1, 1);
+                        kx0 = (uint64_t)a.y << 32 | a.x; kx1 = (uint64_t)a.w << 32 | a.z;
+                        ksz = (uint64_t)b.y << 32 | b.x; kinfo = (uint64_t)b.w << 32 | b.z;
+                    }
+                    ret = (int)kinfo;
+                    pend_e = SM_NONE;   // (the only entry that can still be waiting for its partner is that one)
+                    curr_e0 = cap; curr_n = 0; cmask = 0; j = 0; i = x - 1; last_mem_beg = 0; pf_e = SM_NONE;
+                    st = SM_BWD;
+                }
             } else if (st == SM_BWD_PICK) {
+                if (i == -1 && curr_n != 0) j = sm_next_needed(j, prev_n, kmask);
                 if (j < prev_n) {
-                    if (have_pf) {
+                    const uint32_t e = prev_e0 + j;
+                    if (e == pf_e) {
                         kx0 = (uint64_t)pfa.y << 32 | pfa.x; kx1 = (uint64_t)pfa.w << 32 | pfa.z;
                         ksz = (uint64_t)pfb.y << 32 | pfb.x; kinfo = (uint64_t)pfb.w << 32 | pfb.z;
-                    } else load_entry(prev + j, kx0, kx1, ksz, kinfo);
-                    have_pf = false;
+                    } else load_entry(la + e, kx0, kx1, ksz, kinfo);
                     st = SM_BWD;
                 } else if (curr_n != 0 && i != -1) { // next base to the left (smem.c:76-77)
-                    prev = curr; prev_n = curr_n;
-                    curr = (prev == lb) ? la : lb; // lists start at index 0 of their areas from now on
-                    curr_n = 0; j = 0; --i; have_pf = false; again = true;
+                    if (pend_e != SM_NONE) sm_flush_single(la, slots, pend_e);
+                    prev_e0 = curr_e0; prev_n = curr_n; kmask = cmask; cmask = 0;
+                    curr_e0 = prev_e0 == cap ? 0 : cap; // lists start at index 0 of their areas from now on
+                    curr_n = 0; j = 0; --i; pf_e = SM_NONE; again = true;
                 } else { // this call is over: fm_reverse_fmivec(mem) (smem.c:79), then the next start (smem.c:404-409)
                     if (n_out <= max_mem)
                         for (uint32_t a = out_base, b = n_out; a + 1 < b; ++a) {
@@ -128,9 +196,12 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
             const uint64_t a = sbase + (uint64_t)i;
             if ((a & ~3ull) != cw_at) { cw_at = a & ~3ull; cw = *(const uint32_t *)(seqs + cw_at); }
         }
-        if (st == SM_BWD && j + 1 < prev_n) { // next list entry rides under this gather
-            const uint4 *pq = (const uint4 *)(prev + j + 1);
-            pfa = pq[0]; pfb = pq[1]; have_pf = true;
+        if (st == SM_BWD) { // the next entry needed rides under this gather (last round: curr is non-empty after the first entry in all but odd cases)
+            const uint32_t jn = i == -1 ? sm_next_needed(j + 1, prev_n, kmask) : j + 1;
+            if (jn < prev_n) {
+                const uint4 *pq = (const uint4 *)(la + (prev_e0 + jn));
+                pfa = pq[0]; pfb = pq[1]; pf_e = prev_e0 + jn;
+            }
         }
         FmdRank2c r = fmd_wave_rank2_fetch_compact(ix, fmd_lds, act ? a0 - 1 : NONE64, act ? a0 - 1 + ksz : NONE64);
         if (st == SM_FWD || (st == SM_BWD && i >= 0)) c = (int)((cw >> (8 * ((sbase + (uint64_t)i) & 3))) & 0xff);
@@ -138,8 +209,13 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
         // narrow interval: everything comes from one 64-position window; a lane whose window straddles
         // two blocks in a two-phase step (the dense slot is reused for the l side) takes the general path
         const bool narrow = act && ksz <= 63 && !(r.two_phase && r.l_sep);
+        // the last round of a backward sweep (i = -1) extends by '$' alone: of the six counts of a wide interval it needs that one
+        const bool only0 = st == SM_BWD && i == -1;
         uint64_t tk[6] = {0, 0, 0, 0, 0, 0};
-        if (r.two_phase && act && !narrow && r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk, r.blk_k);
+        if (r.two_phase && act && !narrow && r.hk) {
+            if (only0) tk[0] = fmd_block_rank1(r.bk, r.t, r.nk, 0, r.blk_k);
+            else fmd_block_rank6<false>(r.bk, r.t, r.nk, tk, r.blk_k);
+        }
         const bool was_two_phase = r.two_phase;
         fmd_wave_l_ready(ix, fmd_lds, r);
         if (!act) continue;
@@ -159,8 +235,13 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
             tk0 = tkc; have_tk0 = c == 0;
         } else {
             uint64_t tl[6] = {0, 0, 0, 0, 0, 0};
-            if (!was_two_phase && r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk, r.blk_k);
-            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl, r.blk_l);
+            if (only0) {
+                if (!was_two_phase && r.hk) tk[0] = fmd_block_rank1(r.bk, r.t, r.nk, 0, r.blk_k);
+                if (r.hl) tl[0] = fmd_block_rank1(r.bl, r.tl, r.nl, 0, r.blk_l);
+            } else {
+                if (!was_two_phase && r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk, r.blk_k);
+                if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl, r.blk_l);
+            }
 #pragma unroll
             for (int b = 0; b < 6; ++b) s[b] = tl[b] - tk[b];
             tkc = sel6(c, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
@@ -215,7 +296,10 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
                 }
             }
             if (cont && (kx1 < ix.n_seq || curr_n == 0 || sc != last_curr_sz)) {
-                store_entry(curr + curr_n, nxc, rc, sc, kinfo);
+                if (i != -1) { // (nobody reads the list of the last round)
+                    sm_push(la, slots, pend_e, curr_e0 + curr_n, nxc, rc, sc, kinfo);
+                    if (curr_n < 64) cmask |= (uint64_t)(kx1 < ix.n_seq) << curr_n;
+                }
                 last_curr_sz = sc;
                 ++curr_n;
             }
@@ -223,6 +307,15 @@ __global__ __launch_bounds__(64) void k_smem(FmdIndexView ix, size_t n, const ui
             st = SM_BWD_PICK;
         }
     }
+}
+
+// *mixed := 1 when the n sequences do not all have the length of the first
+__global__ void k_smem_mixed(size_t n, const uint64_t *__restrict__ off, uint32_t *__restrict__ mixed)
+{
+    const uint64_t len0 = off[1] - off[0];
+    bool any = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) any |= off[i + 1] - off[i] != len0;
+    if (__ballot(any) && fmd_lane() == 0) *mixed = 1;
 }
 
 static size_t smem_lanes(size_t n)
@@ -247,9 +340,22 @@ extern "C" int fmd_smem_dev(fmd_dev_t *h, void *stream_, size_t n, const uint8_t
     uint32_t *q = fmd_next_queue(h, st);
     int grid = fmd_grid_for_lds(h, n, SMEM_LDS_BYTES);
     if (grid > SMEM_MAX_WAVES) grid = SMEM_MAX_WAVES;
-    static const int refill_min = getenv("FMD_SMEM_REFILL") ? atoi(getenv("FMD_SMEM_REFILL")) : 8;
+    // When do idle lanes take new reads?  Reads of ONE length that start together stay together: 64 forward sweeps in step, then 64
+    // backward sweeps, and a wave step pays for one of the two code paths (and for the wide-interval path only while every lane is
+    // on it) instead of for all of them -- worth more than the lanes that wait for the longest list of the wave (50 M x 100 bp:
+    // 204 ms against 221).  Reads of mixed lengths drift apart anyway and would only wait: groups of 8; and so would reads of one
+    // length whose work differs (self_match: nine calls per read, 471 ms against 377 for 2*10^7 reads), so a wave whose lanes
+    // do not all come back within `patience` steps of the first gives the waiting up for the rest of the launch.  The lengths are
+    // looked at on the device (one streaming pass over `off`); FMD_SMEM_REFILL=k fixes the group size (64: always wait).
+    const char *rf = getenv("FMD_SMEM_REFILL"), *pt = getenv("FMD_SMEM_PATIENCE");
+    uint32_t *uniform = (uint32_t *)((uint8_t *)d_work + fmd_smem_work_bytes(n, max_len) - 16);   // (inside the slack behind the lists)
+    if (!rf) {
+        FMD_HIP_TRY(hipMemsetAsync(uniform, 0, 4, st));
+        k_smem_mixed<<<512, 256, 0, st>>>(n, d_off, uniform);
+    }
     k_smem<<<grid, 64, 0, st>>>(fmd_view(h), n, d_seqs, d_off, self_match ? 1 : 0, 2 * max_len + 2,
-                                (fmd_intv_t *)d_work, max_mem, d_mem, d_n_mem, q, refill_min, nullptr);
+                                (fmd_intv_t *)(((uintptr_t)d_work + 63) & ~(uintptr_t)63), max_mem, d_mem, d_n_mem, q, rf ? atoi(rf) : 8, nullptr,
+                                rf ? nullptr : uniform, pt ? atoi(pt) : 96);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "k_smem"); return FMD_E_HIP; }
     return FMD_OK;
@@ -272,7 +378,7 @@ extern "C" int fmd_smem_win_dev(fmd_dev_t *h, void *stream_, size_t n, const uin
     int grid = fmd_grid_for_lds(h, n, SMEM_LDS_BYTES);
     if (grid > SMEM_MAX_WAVES) grid = SMEM_MAX_WAVES;
     k_smem<<<grid, 64, 0, st>>>(fmd_view(h), n, d_seqs, nullptr, self_match ? 1 : 0, 2 * max_len + 2,
-                                (fmd_intv_t *)d_work, max_mem, d_mem, d_n_mem, q, 1, d_wins);
+                                (fmd_intv_t *)(((uintptr_t)d_work + 63) & ~(uintptr_t)63), max_mem, d_mem, d_n_mem, q, 1, d_wins, nullptr, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "k_smem (windows)"); return FMD_E_HIP; }
     return FMD_OK;

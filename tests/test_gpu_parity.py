@@ -304,6 +304,37 @@ def test_smem_vs_oracle_ragged(gpu, tiny_dev, tiny_oracle):
         assert m.tobytes() == tiny_oracle.smem(q, 0).tobytes()
 
 
+@pytest.mark.parametrize("sm", [0, 1])
+def test_smem_lists_and_refill_policies(gpu, oracle_lib, monkeypatch, sm):
+    """k_smem's candidate lists (pairs of entries leave LDS as one burst; the last round of a backward sweep skips the entries that
+    cannot matter and writes no list) and its three ways of taking new reads (whole waves in step for reads of one length, groups
+    of 8 otherwise, one by one) give the oracle's SMEMs: 250-bp reads at 60x (lists of > 64 entries: beyond the per-entry bits),
+    exact reads (one call, last round only), reads with errors (several calls, backward sweeps over many bases), queries that
+    start in the middle of reads (x > 0 rounds), an N, and reads of mixed lengths."""
+    rng = np.random.default_rng(31 + sm)
+    reads = synth.reads(synth.DEFAULT_SEED + 77, 3000, 250, 60, 0.004)
+    reads[7][100] = 5                                                              # (an N that is in the index: fm6_smem of a symbol the index lacks reads an empty list)
+    bwt = gpu.build_bwt(reads)
+    d = gpu.DevIndex.from_bwt(bwt)
+    o = orcbind.OrcIndex(bwt=bwt)
+    uni = [reads[i].copy() for i in range(400)]
+    for r in uni[200:300]:
+        for _ in range(3):
+            r[rng.integers(0, len(r))] = rng.integers(1, 5)                        # errors: the forward sweep stops, more calls follow
+    mixed = [r[int(rng.integers(0, 120)):][: int(rng.integers(20, 250))] for r in uni]
+    want_u = [o.smem(q, sm).tobytes() for q in uni]
+    want_m = [o.smem(q, sm).tobytes() for q in mixed]
+    assert max(len(w) for w in want_u) >= 2 * 32
+    for env in ({}, {"FMD_SMEM_REFILL": "64"}, {"FMD_SMEM_REFILL": "1"}, {"FMD_SMEM_PATIENCE": "2"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        assert [m.tobytes() for m in d.smem(uni, sm, max_mem=256)] == want_u, env
+        assert [m.tobytes() for m in d.smem(mixed, sm, max_mem=256)] == want_m, env
+        for k in env:
+            monkeypatch.delenv(k)
+    d.close(); o.close()
+
+
 @pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20)])
 def test_unitig_cli_equals_fermi_unitig_t1(gpu, gold, tmp_path, name, mm):
     """`fermi-amd unitig -l mm x.fmd` (GPU overlap table + host walk) == `fermi unitig -t1` bytes."""
