@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "fmd_kmer_work_bytes", "fmd_kmer_collect_dev", "fmd_kmer_collect_part_dev", "fmd_kmer_collect", "fmd_kmer_collect_seeds",
     "fmd_ectab_build_dev", "fmd_ectab_build", "fmd_ectab_free", "fmd_ecfix_work_bytes", "fmd_ecfix_dev", "fmd_ecfix_batch",
     "fmd_ovlp_work_bytes", "fmd_ovlp_dev", "fmd_ovlp_sorted_work_bytes", "fmd_ovlp_sorted_dev", "fmd_ovlp_batch", "fmd_ovlp_check_left_dev", "fmd_seqinfo_dev", "fmd_seqinfo_batch",
-    "fmd_ovlp_pack_max_bytes", "fmd_ovlp_pack_work_bytes", "fmd_ovlp_pack_dev", "fmd_ovlp_packed_batch", "fmd_ovlp_packed_free", "fmd_ovlp_link_dev", "fmd_ovlp_packed_table",
+    "fmd_ovlp_pack_max_bytes", "fmd_ovlp_pack_work_bytes", "fmd_ovlp_pack_dev", "fmd_ovlp_packed_batch", "fmd_ovlp_packed_free", "fmd_table_alloc", "fmd_table_free", "fmd_ovlp_link_dev", "fmd_ovlp_packed_table",
 ]
 
 
@@ -126,6 +126,8 @@ def _configure(L):
     L.fmd_ovlp_link_dev.argtypes = [vp, vp, sz, vp, vp, C.c_uint32, vp, vp, vp, vp]
     L.fmd_ovlp_packed_table.argtypes = [vp, sz, C.c_int, C.c_uint32, C.c_uint32, vp, vp, C.c_uint32, vp, vp, vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
     L.fmd_ovlp_packed_free.restype = None; L.fmd_ovlp_packed_free.argtypes = [vp, sz]
+    L.fmd_table_alloc.restype = vp; L.fmd_table_alloc.argtypes = [sz]
+    L.fmd_table_free.restype = None; L.fmd_table_free.argtypes = [vp]
     L.fmd_ovlp_pack_dev.argtypes = [vp, vp, sz, vp, vp, C.c_uint32, vp, C.c_uint32, vp, vp, vp, C.c_uint64, vp, sz]
     return L
 

@@ -13,7 +13,13 @@
 #include <stdlib.h>
 #include <time.h>
 #include <sys/mman.h>
+#include <errno.h>
+#include <string.h>
+#include <unistd.h>
 #include <algorithm>
+#include <mutex>
+#include <string>
+#include <unordered_map>
 #include <vector>
 #include <hipcub/hipcub.hpp>
 #include "fmd_kernel_common.h"
@@ -222,10 +228,61 @@ struct Pinned { // hipHostRegister for a scope (best effort: pageable copies oth
 };
 }
 
+// ---- host memory of the tables (include/fmd_hip.h: fmd_table_alloc) --------------------------------------------------------
+static std::mutex g_tab_mu;
+static std::unordered_map<void *, size_t> g_tab_maps;   // blocks that are file pages: address -> mapped bytes
+
+extern "C" void *fmd_table_alloc(size_t bytes)
+{
+    const size_t huge = (size_t)2 << 20;
+    if (bytes == 0) bytes = 1;
+    const char *dir = getenv("FMD_TABLE_DIR"), *mn = getenv("FMD_TABLE_DIR_MIN");
+    const size_t dir_min = mn && atoll(mn) > 0 ? (size_t)atoll(mn) : 16 * huge;
+    if (dir && *dir && bytes >= dir_min) {
+        const size_t page = 4096, asz = (bytes + page - 1) / page * page;
+        std::string path = std::string(dir) + "/fmdtab.XXXXXX";
+        const int fd = mkstemp(&path[0]);
+        if (fd >= 0) {
+            unlink(path.c_str());
+            void *p = ftruncate(fd, (off_t)asz) == 0 ? mmap(nullptr, asz, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
+            close(fd);
+            if (p != MAP_FAILED) {
+#ifdef MADV_RANDOM
+                madvise(p, asz, MADV_RANDOM);   // the walk reads rows at random: no read-ahead
+#endif
+                std::lock_guard<std::mutex> lk(g_tab_mu);
+                g_tab_maps[p] = asz;
+                return p;
+            }
+        }
+        static bool warned = false;
+        if (!warned) { warned = true; fprintf(stderr, "[W::%s] FMD_TABLE_DIR=%s: no file pages (%s); anonymous memory instead\n", __func__, dir, strerror(errno)); }
+    }
+    if (bytes < 16 * huge) return malloc(bytes);
+    void *p = nullptr;
+    const size_t asz = (bytes + huge - 1) / huge * huge;
+    if (posix_memalign(&p, huge, asz)) return nullptr;
+#ifdef MADV_HUGEPAGE
+    madvise(p, asz, MADV_HUGEPAGE);   // first touch of 4 KiB pages costs more than the copy that fills a 9 GB table, and random reads miss the TLB less
+#endif
+    return p;
+}
+
+extern "C" void fmd_table_free(void *p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_tab_mu);
+        auto it = g_tab_maps.find(p);
+        if (it != g_tab_maps.end()) { munmap(p, it->second); g_tab_maps.erase(it); return; }
+    }
+    free(p);
+}
+
 extern "C" void fmd_ovlp_packed_free(uint8_t **chunks, size_t n_chunks)
 {
     if (!chunks) return;
-    for (size_t c = 0; c < n_chunks; ++c) { free(chunks[c]); chunks[c] = nullptr; }
+    for (size_t c = 0; c < n_chunks; ++c) { fmd_table_free(chunks[c]); chunks[c] = nullptr; }
 }
 
 // rows of all chunks kept on the device for the link pass at the end (whole-table form only)
@@ -337,13 +394,9 @@ static int packed_batch_core(fmd_dev_t *h, const uint64_t *ids, uint64_t first, 
             t_wait += now() - t0; t0 = now();
             const uint64_t bytes = tot[k];
             if (bytes > cap) { fail(FMD_E_OVERFLOW); break; }  // cannot happen: cap is the worst case
-            // 2 MiB-aligned, huge pages on request: the walk reads these rows at random
-            const size_t huge = (size_t)2 << 20, asz = ((bytes ? bytes : 1) + huge - 1) / huge * huge;
-            void *buf = nullptr;
-            if (posix_memalign(&buf, bytes >= 16 * huge ? huge : 64, bytes >= 16 * huge ? asz : (bytes ? bytes : 64))) { fail(FMD_E_NOMEM); break; }
-#ifdef MADV_HUGEPAGE
-            if (bytes >= 16 * huge) madvise(buf, asz, MADV_HUGEPAGE);
-#endif
+            // huge pages on request, or file pages under FMD_TABLE_DIR: the walk reads these rows at random
+            void *buf = fmd_table_alloc(bytes ? bytes : 64);
+            if (!buf) { fail(FMD_E_NOMEM); break; }
             chunks[p] = (uint8_t *)buf;
             if (bytes >= ((size_t)8 << 20) && !getenv("FMD_NO_PIN") && hipHostRegister(buf, bytes, hipHostRegisterDefault) == hipSuccess) registered.push_back(buf);
             else (void)hipGetLastError();

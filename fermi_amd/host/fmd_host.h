@@ -148,22 +148,10 @@ int fmdh_correct_reads(const fmdh_ecopt_t *opt, int device, int suf_len, uint64_
 }
 #endif
 
-/* Large tables that are filled once and then read at random (overlap table, solid k-mer table): huge pages
- * where the kernel grants them on request.  First touch of 4 KiB pages costs more than the copy that fills a
- * 9 GB table, and the random reads miss the TLB less (`unitig` on 10 M reads: 8.2 -> 6.4 s).  Contents are
- * undefined; release with free(). */
-#include <stdlib.h>
-#include <sys/mman.h>
-static inline void *fmdh_big_alloc(size_t bytes)
-{
-    const size_t huge = (size_t)2 << 20;
-    void *p = 0;
-    if (bytes < 16 * huge) return malloc(bytes ? bytes : 1);
-    if (posix_memalign(&p, huge, (bytes + huge - 1) / huge * huge)) return 0;
-#ifdef MADV_HUGEPAGE
-    madvise(p, (bytes + huge - 1) / huge * huge, MADV_HUGEPAGE);
-#endif
-    return p;
-}
+/* Large tables that are filled once and then read at random (overlap table, its links): fmd_table_alloc (include/fmd_hip.h) --
+ * huge pages where the kernel grants them on request (`unitig` on 10 M reads: 8.2 -> 6.4 s), file pages under FMD_TABLE_DIR.
+ * Contents are undefined; release with fmdh_big_free(). */
+#define fmdh_big_alloc(bytes) fmd_table_alloc(bytes)
+#define fmdh_big_free(p) fmd_table_free(p)
 
 #endif

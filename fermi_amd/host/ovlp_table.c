@@ -25,7 +25,7 @@ static void shard_free(fmdh_ovlp_shard_t *s)
         fmd_ovlp_packed_free(s->chunk, nc);
         free(s->chunk);
     }
-    free(s->rec); free(s->off);
+    fmdh_big_free(s->rec); fmdh_big_free(s->off);
     memset(s, 0, sizeof(*s));
 }
 
@@ -114,7 +114,7 @@ int fmdh_ovlp_table_link(fmdh_ovlp_table_t *t, int n_threads, uint64_t **undecid
     if (n >= 0xffffffffull) return -ERANGE;
     if (n_threads < 1) n_threads = 1;
     if ((uint64_t)n_threads > n / 4096 + 1) n_threads = (int)(n / 4096 + 1);
-    free(t->row_of); free(t->link);
+    fmdh_big_free(t->row_of); fmdh_big_free(t->link);
     t->row_of = (uint32_t *)fmdh_big_alloc((n ? n : 1) * 4);
     t->link = (fmdh_link_t *)fmdh_big_alloc((n ? n : 1) * sizeof(fmdh_link_t));
     w = (lk_t *)calloc((size_t)n_threads, sizeof(lk_t));
@@ -166,10 +166,10 @@ static int table_fill_linked(fmd_dev_t *d, fmdh_ovlp_table_t *t, uint64_t n, int
     s->chunk = (uint8_t **)calloc(nc ? nc : 1, sizeof(uint8_t *));
     t->row_of = (uint32_t *)fmdh_big_alloc((n ? n : 1) * 4);
     t->link = (fmdh_link_t *)fmdh_big_alloc((n ? n : 1) * sizeof(fmdh_link_t));
-    if (!s->rec || !s->off || !s->chunk || !t->row_of || !t->link) { shard_free(s); free(t->row_of); free(t->link); t->row_of = 0; t->link = 0; return FMD_E_NOMEM; }
+    if (!s->rec || !s->off || !s->chunk || !t->row_of || !t->link) { shard_free(s); fmdh_big_free(t->row_of); fmdh_big_free(t->link); t->row_of = 0; t->link = 0; return FMD_E_NOMEM; }
     {
         const int rc = fmd_ovlp_packed_table(d, n, min_match, max_len, max_nei, s->rec, s->off, s->chunk_shift, s->chunk, t->row_of, (fmd_ovlp_link_t *)t->link, und, n_und);
-        if (rc) { shard_free(s); free(t->row_of); free(t->link); t->row_of = 0; t->link = 0; return rc; }
+        if (rc) { shard_free(s); fmdh_big_free(t->row_of); fmdh_big_free(t->link); t->row_of = 0; t->link = 0; return rc; }
     }
     return FMD_OK;
 }
@@ -202,7 +202,7 @@ void fmdh_ovlp_table_free(fmdh_ovlp_table_t *t)
     for (g = 0; g < t->n_shards; ++g) shard_free(&t->shard[g]);
     free(t->shard);
     shard_free(&t->side);
-    free(t->side_of); free(t->row_of); free(t->link);
+    free(t->side_of); fmdh_big_free(t->row_of); fmdh_big_free(t->link);
     memset(t, 0, sizeof(*t));
 }
 

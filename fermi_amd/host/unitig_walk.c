@@ -75,7 +75,7 @@ static uint32_t *build_jump(const fmdh_link_t *link, uint64_t n)
     int nt = 16, lv, k;
     { const char *e = getenv("FMD_HOST_THREADS"); if (e && atoi(e) > 0) nt = atoi(e); }
     if (nt > 64) nt = 64;
-    if (!a || !b) { free(a); free(b); return 0; }
+    if (!a || !b) { fmdh_big_free(a); fmdh_big_free(b); return 0; }
     for (lv = 1; lv <= JUMP_LOG; ++lv) {   /* after level lv, a[] holds the row 2^lv links on */
         pthread_t tid[64];
         jump_job_t job[64];
@@ -87,7 +87,7 @@ static uint32_t *build_jump(const fmdh_link_t *link, uint64_t n)
         for (k = 1; k < nt; ++k) { if (started[k]) pthread_join(tid[k], 0); else jump_main(&job[k]); }
         if (lv > 1) { t = a; a = b; b = t; }
     }
-    free(b);
+    fmdh_big_free(b);
     return a;
 }
 /* (a row that the overflow pass replaced lives in the side table: its prefetch goes to the old place and is wasted) */
@@ -446,8 +446,8 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
     }
 done:
     if (oq_open) { const int e = outq_close(&oq); if (!rc) rc = e; }
-    free(w.used); free(w.bend); free(w.visited); if (w.row_of != t->row_of) free(w.row_of);
-    free(w.jump);
+    free(w.used); free(w.bend); free(w.visited); if (w.row_of != t->row_of) fmdh_big_free(w.row_of);
+    fmdh_big_free(w.jump);
     free(nei[0]); free(nei[1]);
     free(s.s); free(cov.s); free(cov.d); free(o.s);
     return rc;

@@ -260,6 +260,15 @@ int fmd_ovlp_link_dev(fmd_dev_t *h, void *stream, size_t n, fmd_ovlp_rec_t *d_re
 int fmd_ovlp_packed_batch(fmd_dev_t *h, const uint64_t *ids, uint64_t first, uint64_t step, size_t n, int min_match, uint32_t max_len,
                           uint32_t max_nei, int with_check_left, fmd_ovlp_rec_t *rec, uint64_t *off, uint32_t chunk_shift, uint8_t **chunks);
 void fmd_ovlp_packed_free(uint8_t **chunks, size_t n_chunks);
+/* Host memory for tables that are filled once and then read at random -- the chunks above come from here, and a caller that keeps
+ * rec / off / row_of / link for a whole .fmd (the reference keeps nothing of the kind: it recomputes, unitig.c:274-300) should too.
+ * Default: malloc; large blocks 2 MiB-aligned with transparent huge pages on request.  With FMD_TABLE_DIR=<dir> in the environment,
+ * blocks of FMD_TABLE_DIR_MIN bytes (default 32 MiB) and more are pages of unlinked files in <dir> (mmap, MAP_SHARED): the table of a
+ * large .fmd then lives in the page cache and on <dir>'s device instead of in anonymous memory, and `unitig` of BASELINE's 7*10^8
+ * reads (~ 190 GB of table) runs in whatever RAM the host has, at the speed of that device once the table no longer fits.
+ * fmd_table_free() accepts any pointer fmd_table_alloc() returned (and, like free(), NULL). */
+void *fmd_table_alloc(size_t bytes);
+void fmd_table_free(void *p);
 /* The whole table (ids 0 .. n-1) on ONE device: the packed rows as above (no per-row check_left), then fmd_ovlp_link_dev on
  * the device: row_of[n], link[n], rec[i].reserved = check_left_simple's verdict wherever lfork decides it; the ids it leaves
  * open come back in *undecided (malloc'ed: fmd_host_free; ascending) for a fmd_ovlp_packed_batch(ids, with_check_left = 1). */

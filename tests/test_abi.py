@@ -76,3 +76,33 @@ def test_no_kernel_spills_to_scratch():
             if "rocprim" not in name:   # (the library sort's kernels keep small private arrays; ours have none)
                 assert int(k.get("private_segment_fixed_size", 0)) == 0, (os.path.basename(o), name, k)
     assert seen > 40
+
+
+def test_table_memory_as_file_pages(tmp_path, monkeypatch):
+    """fmd_table_alloc: anonymous memory by default; with FMD_TABLE_DIR, blocks of FMD_TABLE_DIR_MIN bytes and more are pages of an
+    unlinked file in that directory (the streamed form of `unitig`'s table), smaller ones stay malloc'ed; fmd_table_free takes both."""
+    import ctypes as C
+    L = api.lib()
+
+    def mapped_files():
+        return [ln for ln in open("/proc/self/maps") if str(tmp_path) in ln]
+
+    a = L.fmd_table_alloc(1 << 20)
+    assert a and not mapped_files()
+    C.memset(a, 7, 1 << 20)
+    L.fmd_table_free(a)
+    monkeypatch.setenv("FMD_TABLE_DIR", str(tmp_path))
+    monkeypatch.setenv("FMD_TABLE_DIR_MIN", str(1 << 16))
+    small, big = L.fmd_table_alloc(1000), L.fmd_table_alloc((1 << 20) + 123)
+    assert small and big
+    m = mapped_files()
+    assert len(m) == 1 and "fmdtab." in m[0] and "(deleted)" in m[0] and not os.listdir(tmp_path)   # unlinked: nothing is left behind, whatever happens to the process
+    buf = (C.c_uint8 * ((1 << 20) + 123)).from_address(big)
+    buf[0] = 1; buf[(1 << 20) + 122] = 2
+    assert buf[0] == 1 and buf[(1 << 20) + 122] == 2 and buf[5000] == 0
+    L.fmd_table_free(big); L.fmd_table_free(small); L.fmd_table_free(None)
+    assert not mapped_files()
+    monkeypatch.setenv("FMD_TABLE_DIR", str(tmp_path / "missing"))                   # no such directory: anonymous memory, a warning, no failure
+    c = L.fmd_table_alloc(1 << 20)
+    assert c and not mapped_files()
+    L.fmd_table_free(c)

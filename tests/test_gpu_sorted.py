@@ -145,3 +145,17 @@ def test_packed_rows_from_a_sorted_job_equal_chunked_rows(gpu, monkeypatch):
         res.append((rec.tobytes(), off.tobytes(), var))
     assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and res[0][2] == res[1][2]
     d.close()
+
+
+@pytest.mark.parametrize("devs", [(0,), (0, 0)])
+def test_unitig_with_the_table_in_file_pages(gpu, gold, tmp_path, monkeypatch, devs):
+    """FMD_TABLE_DIR: chunks, records, offsets, row map and links of `unitig`'s table are pages of unlinked files (fmd_table_alloc), the
+    copies from the GPU land in them unpinned where the runtime will not register file pages; the MAG is `fermi unitig -t1`'s."""
+    from fermi_amd import hostlib
+    d = tmp_path / "pages"; d.mkdir()
+    monkeypatch.setenv("FMD_TABLE_DIR", str(d))
+    monkeypatch.setenv("FMD_TABLE_DIR_MIN", "1")
+    out = str(tmp_path / "o.mag")
+    hostlib.unitig(gold.path("tiny.fmd"), 50, out, devices=devs)
+    assert open(out, "rb").read() == gold.text_gz("tiny.mag.gz")
+    assert not list(d.iterdir())

@@ -28,3 +28,10 @@ t = time.time()
 p = subprocess.run([AMD, "unitig", "-l50", D + "/a.fmd"], stdout=open(D + "/b.mag", "wb"), stderr=subprocess.PIPE, env=dict(env, FMD_WALK_NO_JUMP="1"))
 print("unitig -l50 with FMD_WALK_NO_JUMP=1: %.1f s" % (time.time() - t), "md5", hashlib.md5(open(D + "/b.mag", "rb").read()).hexdigest())
 print("\n".join(l for l in p.stderr.decode().splitlines() if "walk" in l))
+# the streamed form of the table: every large block of it in file pages under FMD_TABLE_DIR (fmd_table_alloc), here a directory of /tmp
+os.makedirs(D + "/pages", exist_ok=True)
+t = time.time()
+p = subprocess.run([AMD, "unitig", "-l50", D + "/a.fmd"], stdout=open(D + "/c.mag", "wb"), stderr=subprocess.PIPE, env=dict(env, FMD_TABLE_DIR=D + "/pages"))
+print("unitig -l50 with FMD_TABLE_DIR=%s/pages (%s): %.1f s" % (D, subprocess.run(["df", "--output=fstype,avail", "-h", D + "/pages"], capture_output=True, text=True).stdout.split("\n")[1].strip(), time.time() - t),
+      "md5", hashlib.md5(open(D + "/c.mag", "rb").read()).hexdigest())
+print("\n".join(l for l in p.stderr.decode().splitlines() if "M::" in l))
