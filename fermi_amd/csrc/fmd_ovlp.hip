@@ -11,11 +11,11 @@
 
 // (gidx: slot of a sorted batch -> row of rec / nei_out / seq_out, fmd_ovlp_sorted_dev; nullptr = the slot is the row)
 void fmd_launch_nei_grp(int cls, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
-                        const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
+                        const fmd_intv_t *listA, const fmd_intv_t *listB, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
                         uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx, size_t fix_off);
 int fmd_nei_fast_available(void);
 void fmd_launch_nei_fast(int cls, int wide, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
-                         const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
+                         const fmd_intv_t *listA, fmd_intv_t *listB, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
                          uint32_t seq_stride, uint32_t *gen_list, uint32_t *gen_n, uint32_t *bail_n, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx);
 void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, const fmd_intv_t *listA, uint32_t cap, FmdOvlClasses cl, int use_fast, const uint32_t *gidx);
 // fmd_ovlp_sort.hip: minimizer keys of the parked strands, then their rows sorted by key (-> vals_b)
@@ -1102,12 +1102,12 @@ static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, i
         for (int k = 0; k < 2 * FMD_GRP_CLASSES; ++k) {
             uint32_t *nk = cl.cnt + (FMD_GRP_CLASSES + 1 + k) * FMD_CLS_CNT_STRIDE;
             const int kg = k % FMD_GRP_CLASSES;
-            fmd_launch_nei_fast(kg, k >= FMD_GRP_CLASSES, o.h->n_cu, fast_cu, st, o.ix, cl.fast[k], nk, o.cap, listA, rec, nei, o.max_nei, seq,
+            fmd_launch_nei_fast(kg, k >= FMD_GRP_CLASSES, o.h->n_cu, fast_cu, st, o.ix, cl.fast[k], nk, o.cap, listA, listB, rec, nei, o.max_nei, seq,
                                 o.seq_stride, cl.lst[kg], cl.cnt + kg * FMD_CLS_CNT_STRIDE, nk + 8, lslow_late, n_late, gidx);
         }
     // one lane per candidate interval, 64 / G strands per wave
     for (int k = 0; k < FMD_GRP_CLASSES; ++k)
-        fmd_launch_nei_grp(k, o.h->n_cu, per_cu, st, o.ix, cl.lst[k], cl.cnt + k * FMD_CLS_CNT_STRIDE, o.cap, listA, rec, nei, o.max_nei, seq, o.seq_stride, lslow_late, n_late, gidx, fix_off);
+        fmd_launch_nei_grp(k, o.h->n_cu, per_cu, st, o.ix, cl.lst[k], cl.cnt + k * FMD_CLS_CNT_STRIDE, o.cap, listA, listB, rec, nei, o.max_nei, seq, o.seq_stride, lslow_late, n_late, gidx, fix_off);
     // the rest (too many candidates, wide intervals, fake forks, neighbour overflow): lane per strand
     k_ovl_nei<<<grid, 64, 0, st>>>(o.ix, np, o.min_match, srev, o.stride_r, o.cap, listA, listB, rec, nei, o.max_nei, seq, o.seq_stride, q2, lslow_late, n_late, gidx);
     // fake forks among the strands the group kernels finished: the fix-up alone

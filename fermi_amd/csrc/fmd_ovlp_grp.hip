@@ -89,9 +89,18 @@ __global__ __launch_bounds__(CLS_THREADS) void k_ovl_classify(size_t n, const fm
 }
 
 // ------------------------------------------------------------------------------ the kernel
+// A lane's candidate is (x[1], size, D, r0, pos): D = the positions of '$' in BWT[x[0], x[0] + size) (the reads that START with the
+// candidate string: the sentinel tests of unitig.c:112 / :129), r0 = the number of '$' before x[0] (x[0] of a neighbour interval,
+// unitig.c:113).  Both follow an extension without touching memory -- the x[0] range of child c is the sub-range [o_c, o_c + s_c) of
+// its parent's, in the order $,T,G,C,A,N (exact.c:81-86): D shifts, r0 counts along -- so the x[0] side of the index is read ONCE per
+// candidate at most: by the walk for candidates it pushes in the narrow form (fmd_kernel_common.h), else in the candidate's first
+// round here.  x[0] itself is never needed.  (Round 2 fetched the x[0] block of every lane every round: a second dense slot, a second
+// window, a second spill list.)  It is also the state k_ovl_nei_fast holds when a strand stops being simple, so that kernel hands
+// its strands on where they stand (FMD_LIST_RESUME) instead of at round 0.
 template <int G>
 __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
-                                                    uint32_t cap, const fmd_intv_t *__restrict__ listA, fmd_ovlp_rec_t *__restrict__ rec,
+                                                    uint32_t cap, const fmd_intv_t *__restrict__ listA, const fmd_intv_t *__restrict__ listB,
+                                                    fmd_ovlp_rec_t *__restrict__ rec,
                                                     fmd_intv_t *__restrict__ nei_out, uint32_t max_nei, uint8_t *__restrict__ seq_out,
                                                     uint32_t seq_stride, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_n,
                                                     const uint32_t *__restrict__ gidx, size_t fix_off)
@@ -114,11 +123,11 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
 #define LF_GET(f) (((f) >> LF_SHIFT) & 0x1ffffu)
 #define LF_SET(f, v) ((f) = ((f) & ~(0x1ffffu << LF_SHIFT)) | ((uint32_t)(v) << LF_SHIFT))
     int ori_l = 0, round = 0;
-    uint64_t nei0_info = 0;
+    uint32_t nei0_info = 0;
     // the lane's candidate
-    bool alive = false;
-    uint64_t x0 = 0, x1 = 0, sz = 0;
-    uint32_t pos = 0; int cat = 0;
+    bool alive = false, need_d = false;   // need_d: D and r0 are still to be read from the index (a candidate the walk pushed in the wide form)
+    uint64_t x1 = 0, D = 0, r0 = 0;
+    uint32_t sz = 0, pos = 0; int cat = 0;
     // prefetch pipeline: 0 empty, 1 descriptor in flight, 2 candidates in flight / ready
     int pf = 0;
     uint32_t d_sid = 0, d_meta = 0, d_gs = 0;
@@ -127,18 +136,32 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
     for (;;) {
         // ---- admission
         if (!active && pf == 2) {
-            const uint32_t m = d_meta & 0xffff;
-            sid = d_sid; gs = d_gs; ori_l = (int)(d_meta >> 16); round = 0; n_nei = 0; flags = 0; nei0_info = 0;
+            const uint32_t m = d_meta & 0x7fffu;
+            sid = d_sid; gs = d_gs; ori_l = (int)(d_meta >> 16); flags = 0; cat = 0;
             alive = (uint32_t)j < m;
-            { const FmdCand cd = cand_decode(pa, pb); x0 = cd.x0; x1 = cd.x1; sz = cd.sz; pos = (uint32_t)ori_l - cd.depth; cat = 0; } // stored: suffix depth
+            if (d_meta & FMD_LIST_RESUME) { // the strand as k_ovl_nei_fast left it before round `round` (fmd_resume_*: every entry carries the strand's state)
+                uint32_t lf_; uint32_t rd_, nn_, n0_;
+                fmd_resume_decode(pa, pb, x1, sz, D, r0, pos, rd_, nn_, n0_, lf_);
+                round = (int)(uint32_t)__shfl((int)rd_, gbase); n_nei = (uint32_t)__shfl((int)nn_, gbase);   // (lanes past m hold no entry)
+                nei0_info = (uint32_t)__shfl((int)n0_, gbase); LF_SET(flags, (uint32_t)__shfl((int)lf_, gbase));
+                need_d = false;
+            } else {
+                const FmdCand cd = cand_decode(pa, pb);
+                x1 = cd.x1; sz = (uint32_t)cd.sz; pos = (uint32_t)ori_l - cd.depth; // stored: suffix depth
+                D = cd.D; r0 = cd.r0; need_d = alive && !cd.narrow;
+                round = 0; n_nei = 0; nei0_info = 0;
+            }
             active = true;
             pf = 0; idx += n_groups;
         }
         // ---- prefetch pipeline (loads complete under the rank gather below)
         if (pf == 1 && d_sid == FMD_LIST_HOLE) { pf = 0; idx += n_groups; }   // an unused slot of a chunk the fast kernel reserved
         if (pf == 1) { // descriptor has arrived: fetch this lane's candidate
-            const uint32_t m = d_meta & 0xffff;
-            if ((uint32_t)j < m) { const uint4 *q = (const uint4 *)(listA + d_sid * (size_t)cap + (cap - m) + j); pa = q[0]; pb = q[1]; }
+            const uint32_t m = d_meta & 0x7fffu;
+            if ((uint32_t)j < m) {
+                const uint4 *q = (const uint4 *)((d_meta & FMD_LIST_RESUME) ? listB + d_sid * (size_t)cap + j : listA + d_sid * (size_t)cap + (cap - m) + j);
+                pa = q[0]; pb = q[1];
+            }
             d_gs = gidx ? gidx[d_sid] : d_sid;
             pf = 2;
         } else if (pf == 0 && idx < N) {
@@ -152,34 +175,44 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
             continue;
         }
 
-        // ---- one round: forward extension + the six '$' boundaries, all from one gather
+        // ---- one round: forward extension (symbols of BWT[x1, x1 + size)) from one gather
         const bool live = active && alive;
 #ifdef GRP_STATS
         { const uint32_t nl = (uint32_t)__popcll(__ballot(live)); if (lane == 0) { atomicAdd(slow_n + 8, 1u); atomicAdd(slow_n + 9, nl); atomicAdd(slow_n + 10, (uint32_t)__popcll(act_m)); } }
 #endif
-        const uint64_t ke = live ? x1 - 1 : NONE64, kb = live ? x0 - 1 : NONE64; // x0 >= mcnt[1] > 0 for base strings
-        // the l sides lie at most 63 positions after the k sides: same block or the next one
-        uint32_t bke, bkb, oke, okb;
-        fmd_split(ke, bke, oke); fmd_split(kb, bkb, okb);
-        const uint32_t ble = bke + (oke + (uint32_t)sz >= FMD_BLK_SYMS), blb = bkb + (okb + (uint32_t)sz >= FMD_BLK_SYMS);
-        const bool e_sep = live && ble != bke, b_sep = live && blb != bkb;
+        const uint64_t ke = live ? x1 - 1 : NONE64;
+        // the l side lies at most 63 positions after the k side: same block or the next one
+        uint32_t bke, oke;
+        fmd_split(ke, bke, oke);
+        const uint32_t ble = bke + (oke + sz >= FMD_BLK_SYMS);
+        const bool e_sep = live && ble != bke;
+        // the x[0] side: only for candidates still without D / r0, i.e. in the first round of a candidate in the wide form
+        const bool nb = live && need_d;
+        const bool any_nb = __ballot(nb) != 0;
+        uint32_t bkb = 0, okb = 0, blb = 0, x0lo = 0;
+        bool b_sep = false;
+        if (any_nb) {
+            const uint64_t x0 = cand_decode(pa, pb).x0;   // (pa / pb still hold the entry: the prefetch of the next strand has only fetched its descriptor)
+            const uint64_t kb = nb ? x0 - 1 : NONE64;     // x0 >= mcnt[1] > 0 for base strings
+            fmd_split(kb, bkb, okb);
+            blb = bkb + (okb + sz >= FMD_BLK_SYMS);
+            b_sep = nb && blb != bkb; x0lo = (uint32_t)x0;
+        }
         fmd_fetch_slot<0>(ix, lds, bke, live);
-        fmd_fetch_slot<1>(ix, lds, bkb, live);
+        if (any_nb) fmd_fetch_slot<1>(ix, lds, bkb, nb);
         // straddling ranges: compact the extra blocks into the pool (ballot prefix), 16 per instruction,
         // GRP_POOL per pass.  Every interval here has size <= 63 (k_ovl_classify), so "rank2a" is a count
-        // over a 64-position window of the planes read straight from the lane's LDS block images:
-        //   forward extension: symbols of BWT[x1, x1+size)          -> sizes of the six children
-        //   sentinel tests   : '$' in the child sub-ranges of BWT[x0, x0+size)  (extend0 of unitig.c:112/:129)
+        // over a 64-position window of the planes read straight from the lane's LDS block images.
         // A lane reads its windows in the pass that brings its spill block(s), or in the first one.
         const uint64_t me = __ballot(e_sep), mb = __ballot(b_sep);
         const int n_e = __popcll(me), n_spill = n_e + __popcll(mb);
-        const int pe = fmd_below(me), pb = n_e + fmd_below(mb);
+        const int pe = fmd_below(me), pb_ = n_e + fmd_below(mb);
         const int t = fmd_chunk_xor(lane);
         const uint4 *img_e = lds + fmd_lds_base(lane, 0), *img_b = lds + fmd_lds_base(lane, 1);
-        uint64_t X = 0, Y = 0, Z = 0, D = 0;
-        bool need_e = live, need_b = live;
+        uint64_t X = 0, Y = 0, Z = 0;
+        bool need_e = live, need_b = nb;
         for (int base = 0;; base += GRP_POOL) {
-            const int re = pe - base, rb = pb - base;
+            const int re = pe - base, rb = pb_ - base;
             const bool in_e = e_sep && re >= 0 && re < GRP_POOL, in_b = b_sep && rb >= 0 && rb < GRP_POOL;
             const int n_here = n_spill - base < GRP_POOL ? n_spill - base : GRP_POOL;
             if (n_here > 0) {
@@ -196,34 +229,34 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
                 X = win64(a.x, b.x, c.x, sh); Y = win64(a.y, b.y, c.y, sh); Z = win64(a.z, b.z, c.z, sh);
                 need_e = false;
             }
-            if (need_b && (!b_sep || in_b)) {   // '$' positions of BWT[x0 ...]
+            if (need_b && (!b_sep || in_b)) {   // '$' positions of BWT[x0 ...] and the '$' before x0
                 uint4 a, b, c;
                 grp_window(img_b, t, pool + (in_b ? rb : 0) * FMD_BLK_U4, fmd_pool_xor(in_b ? rb : 0), bkb, blb, true, b_sep, bkb, okb, a, b, c);
-                D = win64(~(a.x | a.y | a.z), ~(b.x | b.y | b.z), ~(c.x | c.y | c.z), (uint32_t)x0 & 31);
-                need_b = false;
+                D = win64(~(a.x | a.y | a.z), ~(b.x | b.y | b.z), ~(c.x | c.y | c.z), x0lo & 31) & ((1ull << sz) - 1);
+                r0 = fmd_block_rank1(img_b, t, okb + 1, 0, bkb);
+                need_b = false; need_d = false;
             }
             if (base + GRP_POOL >= n_spill) break;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the windows are read before the next pass lands in the pool
         }
 
         // Absolute ranks are needed only for the coordinates that survive: x[1] of the kept child
-        // (one rank of one symbol) and the two coordinates of a neighbour.
+        // (one rank of one symbol) and x[1] of a neighbour (one of '$').
         uint32_t s[6] = {0, 0, 0, 0, 0, 0};   // child sizes (<= 63)
         bool is_nei = false;
         uint32_t cm = 0;                    // children c = 1..4 that survive the sentinel test
         uint32_t dm = 0;                    // the same before any masking, N included (check_left's view, lfork)
         if (live) {
-            const uint32_t sz32 = (uint32_t)sz;
-            const uint64_t m = (1ull << sz32) - 1;
+            const uint64_t m = (1ull << sz) - 1;
             const uint64_t lo = ~Z & m, hi = Z & ~Y & m;
             s[0] = __popcll(lo & ~Y & ~X); s[1] = __popcll(lo & ~Y & X); s[2] = __popcll(lo & Y & ~X); s[3] = __popcll(lo & Y & X);
-            s[4] = __popcll(hi & ~X); s[5] = sz32 - (s[0] + s[1] + s[2] + s[3] + s[4]);
+            s[4] = __popcll(hi & ~X); s[5] = sz - (s[0] + s[1] + s[2] + s[3] + s[4]);
             // children of the x[0] range laid out in the order $,T,G,C,A (exact.c:81-86);
             // sub-range [o_k, o_k+1) of the window = 2^o_k+1 - 2^o_k (all offsets <= 63)
             const uint64_t B1 = 1ull << s[0], B2 = B1 << s[4], B3 = B2 << s[3], B4 = B3 << s[2], B5 = B4 << s[1];
             const uint32_t e0sz = (uint32_t)__popcll(D & (B1 - 1));
             // unitig.c:111-122: a read ends here, bounded by sentinels on both sides, not contained
-            is_nei = round > 0 && s[0] && s[0] == sz32 && e0sz == sz32;
+            is_nei = round > 0 && s[0] && s[0] == sz && e0sz == sz;
             if (s[4] && (D & (B2 - B1))) cm |= 1u << 4;
             if (s[3] && (D & (B3 - B2))) cm |= 1u << 3;
             if (s[2] && (D & (B4 - B3))) cm |= 1u << 2;
@@ -252,7 +285,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
         const uint32_t nei_k = n_nei + __popc(newnei_g & (uint32_t)bits_below(j)); // neighbours in list order (unitig.c:119-121)
         if (active && n_nei == 0 && newnei_g) { // info of nei[0] decides rbeg (unitig.c:157)
             const int src = gbase + __ffs((int)newnei_g) - 1;
-            nei0_info = (uint64_t)ori_l - (uint32_t)__shfl((int)pos, src);
+            nei0_info = (uint32_t)ori_l - (uint32_t)__shfl((int)pos, src);
         }
         if (active) n_nei += __popc(newnei_g);
 
@@ -269,35 +302,32 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
         const int p1 = before, p2 = p1 + __popc(c1 & same_m), p3 = p2 + __popc(c2 & same_m), p4 = p3 + __popc(c3 & same_m);
         const bool too_many = n_new > G;
         bool forked_now = false;
-        // x[0] of the children: running sum $,T,G,C,A; x[1] = cnt[c] + rank_c(x1 - 1): one rank of ONE
-        // symbol per surviving child (a second child only exists where the read set forks).  A new
-        // neighbour (unitig.c:112, :119-121) needs two ranks of '$' instead: x[0] = rank of '$' before x0,
-        // x[1] = cnt[0] + rank of '$' before x1.  Both kinds share one loop so that the rank code runs
-        // once per wave step when nothing forks and no neighbour is found, twice otherwise.
-        const uint64_t cx0_4 = x0 + s[0], cx0_3 = cx0_4 + s[4], cx0_2 = cx0_3 + s[3], cx0_1 = cx0_2 + s[2];
+        // x[1] of a child = cnt[c] + rank_c(x1 - 1): one rank of ONE symbol per surviving child (a second child only exists where the
+        // read set forks); its D and r0 from the parent's: offsets of the children in the x[0] range, order $,T,G,C,A.  A new neighbour
+        // (unitig.c:112, :119-121) needs one rank of '$': x[0] = r0, x[1] = cnt[0] + rank of '$' before x1.  Both kinds share one loop
+        // so that the rank code runs once per wave step when nothing forks and no neighbour is found.
+        const uint32_t o4 = s[0], o3 = o4 + s[4], o2 = o3 + s[3], o1 = o2 + s[2];
         {
             uint32_t todo = too_many ? 0u : cm;
-            int nei_todo = new_nei ? 2 : 0;
-            uint64_t nei_r1 = 0;
-            while (__ballot(todo != 0 || nei_todo != 0)) {
-                const bool on_b = nei_todo == 1;
+            bool nei_todo = new_nei;
+            while (__ballot(todo != 0 || nei_todo)) {
                 const int c = todo ? __ffs((int)todo) - 1 : 0;
-                const uint64_t r = fmd_block_rank1(on_b ? img_b : img_e, t, (on_b ? okb : oke) + 1, c, on_b ? bkb : bke);
+                const uint64_t r = fmd_block_rank1(img_e, t, oke + 1, c, bke);
                 if (todo) {
                     const int pc = c == 1 ? p1 : c == 2 ? p2 : c == 3 ? p3 : p4;
                     const uint32_t cmask = c == 1 ? c1 : c == 2 ? c2 : c == 3 ? c3 : c4;
-                    const uint64_t cx0 = c == 1 ? cx0_1 : c == 2 ? cx0_2 : c == 3 ? cx0_3 : cx0_4;
+                    const uint32_t oc = c == 1 ? o1 : c == 2 ? o2 : c == 3 ? o3 : o4;
                     const uint32_t sc = c == 1 ? s[1] : c == 2 ? s[2] : c == 3 ? s[3] : s[4];
                     const uint64_t nx1 = (c == 1 ? ix.cnt[1] : c == 2 ? ix.cnt[2] : c == 3 ? ix.cnt[3] : ix.cnt[4]) + r;
+                    const uint64_t Dc = (D >> oc) & ((1ull << sc) - 1), r0c = r0 + (uint32_t)__popcll(D & ((1ull << oc) - 1));
                     const int d = pc + __popc(cmask & lt_m);
-                    stage[2 * (gbase + d)] = make_uint4((uint32_t)cx0, (uint32_t)(cx0 >> 32), (uint32_t)nx1, (uint32_t)(nx1 >> 32));
-                    stage[2 * (gbase + d) + 1] = make_uint4(sc, 0u, pos, (uint32_t)pc);
+                    stage[2 * (gbase + d)] = make_uint4((uint32_t)nx1, (uint32_t)(nx1 >> 32) | sc << 8 | (uint32_t)pc << 16, (uint32_t)Dc, (uint32_t)(Dc >> 32));
+                    stage[2 * (gbase + d) + 1] = make_uint4((uint32_t)r0c, (uint32_t)(r0c >> 32), pos, 0u);
                     forked_now |= pc != 0;
                     todo &= todo - 1;
-                } else if (nei_todo == 2) { nei_r1 = r; nei_todo = 1; }
-                else if (nei_todo == 1) {
-                    if (nei_k < max_nei) store_entry(nei_out + gs * (size_t)max_nei + nei_k, r, ix.cnt[0] + nei_r1, sz, (uint64_t)ori_l - pos);
-                    nei_todo = 0;
+                } else if (nei_todo) {
+                    if (nei_k < max_nei) store_entry(nei_out + gs * (size_t)max_nei + nei_k, r0, ix.cnt[0] + r, (uint64_t)sz, (uint64_t)((uint32_t)ori_l - pos));
+                    nei_todo = false;
                 }
             }
         }
@@ -325,14 +355,14 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
                 alive = j < n_new;
                 if (alive) {
                     const uint4 a = stage[2 * (gbase + j)], b = stage[2 * (gbase + j) + 1];
-                    x0 = (uint64_t)a.y << 32 | a.x; x1 = (uint64_t)a.w << 32 | a.z;
-                    sz = (uint64_t)b.y << 32 | b.x; pos = b.z; cat = (int)b.w;
+                    x1 = (uint64_t)(a.y & 0xffu) << 32 | a.x; sz = (a.y >> 8) & 0xffu; cat = (int)(a.y >> 16);
+                    D = (uint64_t)a.w << 32 | a.z; r0 = (uint64_t)b.y << 32 | b.x; pos = b.z;
                 }
             } else { // every path is closed (unitig.c:154-178)
                 if (j == 0) {
                     fmd_ovlp_rec_t *o = rec + gs;
                     o->lfork = (uint16_t)(LF_GET(flags) & 0xffffu);
-                    o->rbeg = n_nei ? ori_l - (int)(uint32_t)nei0_info : -1;
+                    o->rbeg = n_nei ? ori_l - (int)nei0_info : -1;
                     o->ext_len = n_nei > 1 ? 0 : round;
                     o->n_nei = (int32_t)n_nei;
                     o->flags |= flags & 0xffu;
@@ -405,7 +435,7 @@ template <> struct FastW<uint64_t> {
 #endif
 template <int G, typename M>
 __global__ __launch_bounds__(64, FMD_FAST_LB) void k_ovl_nei_fast(FmdIndexView ix, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
-                                                     uint32_t cap, const fmd_intv_t *__restrict__ listA, fmd_ovlp_rec_t *__restrict__ rec,
+                                                     uint32_t cap, const fmd_intv_t *__restrict__ listA, fmd_intv_t *__restrict__ listB, fmd_ovlp_rec_t *__restrict__ rec,
                                                      fmd_intv_t *__restrict__ nei_out, uint32_t max_nei, uint8_t *__restrict__ seq_out,
                                                      uint32_t seq_stride, uint32_t *__restrict__ gen_list, uint32_t *__restrict__ gen_n,
                                                      uint32_t *__restrict__ bail_n, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_n,
@@ -445,11 +475,22 @@ __global__ __launch_bounds__(64, FMD_FAST_LB) void k_ovl_nei_fast(FmdIndexView i
     // slots per wave and launch, which is what FMD_FAST_RESERVE adds to the capacity of a general list.
     uint32_t res_cur = 0, res_end = 0, n_handed = 0;              // wave-uniform
     bool hand_on = false;                                         // this group's strand leaves for the general kernel (set at j == 0 too)
+    bool resume = false;                                          // ... in the middle: with its state (FMD_LIST_RESUME), not from round 0
 
     for (;;) {
         {   // ---- hand-overs of the previous step / of the admission below
             const uint64_t hm = __ballot(hand_on && j == 0);
             if (hm) {
+                // a strand that leaves in the middle: its live candidates, packed in list order, into its row of listB
+                uint32_t meta_out = meta;
+                if (hand_on && resume) {
+                    const uint32_t ag = (uint32_t)(__ballot(alive) >> gbase) & GM, mp = (uint32_t)__popc(ag);
+                    if (mp <= cap && fmd_resume_fits(round, n_nei, nei0, 0u)) {   // (pos <= the strand's length < 65535: k_ovl_classify)
+                        if (alive) fmd_resume_encode((uint4 *)(listB + sid * (size_t)cap + __popc(ag & ((1u << j) - 1u))), X1 + d, sz, (uint64_t)D, r0, pos, round, n_nei, nei0, lf);
+                        meta_out = mp | FMD_LIST_RESUME | (meta & 0xffff0000u);
+                    }
+                    alive = false; resume = false;
+                }
                 const uint32_t n = (uint32_t)__popcll(hm), room = res_end - res_cur;   // n <= 8 < FMD_FAST_CHUNK
                 uint32_t base = 0;
                 if (room < n) {   // the first `room` of them finish the old chunk, the rest start a new one: only a wave's LAST chunk keeps holes
@@ -461,7 +502,7 @@ __global__ __launch_bounds__(64, FMD_FAST_LB) void k_ovl_nei_fast(FmdIndexView i
                 }
                 if (hand_on && j == 0) {
                     const uint32_t q = (uint32_t)fmd_below(hm), k = q < room ? res_cur + q : base + (q - room);
-                    gen_list[2 * (size_t)k] = sid; gen_list[2 * (size_t)k + 1] = meta;
+                    gen_list[2 * (size_t)k] = sid; gen_list[2 * (size_t)k + 1] = meta_out;
                 }
                 if (room < n) { res_cur = base + (n - room); res_end = base + FMD_FAST_CHUNK; }
                 else res_cur += n;
@@ -576,7 +617,7 @@ __global__ __launch_bounds__(64, FMD_FAST_LB) void k_ovl_nei_fast(FmdIndexView i
         const uint32_t child_g = (uint32_t)(__ballot(alive2) >> gbase) & GM;
 
         if (active) {
-            if (bail) { hand_on = true; active = false; alive = false; }
+            if (bail) { hand_on = true; resume = true; active = false; }   // (the candidates stay as they are until the hand-over at the top of the next step)
             else {
                 const uint32_t ori_l = meta >> 16;
                 if (!(lf & 0x10000u)) lf = dm_g ? round + 1 : (FMD_LFORK_ALL | 0x10000u);   // check_left's rounds (FMD_LFORK_*)
@@ -627,13 +668,13 @@ static int fast_blocks_per_cu(void)
 int fmd_nei_fast_available(void) { return FMD_BLK64 ? 1 : 0; }
 static inline int fast_grid(int waves) { return waves < FMD_FAST_MAX_WAVES ? waves : FMD_FAST_MAX_WAVES; }   // (the hand-over lists have room for this many waves' holes)
 void fmd_launch_nei_fast(int cls, int wide, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
-                         const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
+                         const fmd_intv_t *listA, fmd_intv_t *listB, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
                          uint32_t seq_stride, uint32_t *gen_list, uint32_t *gen_n, uint32_t *bail_n, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx)
 {
 #if FMD_BLK64
     const char *e = getenv("FMD_FAST_WAVES"); // A/B knob: resident waves per CU
     if (e && atoi(e) > 0 && (per_cu_cap <= 0 || atoi(e) < per_cu_cap)) per_cu_cap = atoi(e);
-#define FAST_LAUNCH(K, M) k_ovl_nei_fast<fmd_grp_size(K), M><<<fast_grid(n_cu * grp_cap(fast_blocks_per_cu<fmd_grp_size(K), M>(), per_cu_cap)), 64, 0, st>>>(ix, list, list_n, cap, listA, rec, nei_out, max_nei, seq_out, seq_stride, gen_list, gen_n, bail_n, slow_list, slow_n, gidx)
+#define FAST_LAUNCH(K, M) k_ovl_nei_fast<fmd_grp_size(K), M><<<fast_grid(n_cu * grp_cap(fast_blocks_per_cu<fmd_grp_size(K), M>(), per_cu_cap)), 64, 0, st>>>(ix, list, list_n, cap, listA, listB, rec, nei_out, max_nei, seq_out, seq_stride, gen_list, gen_n, bail_n, slow_list, slow_n, gidx)
 #define FAST_LAUNCH2(K) do { if (wide) FAST_LAUNCH(K, uint64_t); else FAST_LAUNCH(K, uint32_t); } while (0)
     switch (cls) {
     case 0: FAST_LAUNCH2(0); break;
@@ -664,10 +705,10 @@ static int grp_blocks_per_cu(void)
     return cached;
 }
 void fmd_launch_nei_grp(int cls, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
-                        const fmd_intv_t *listA, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
+                        const fmd_intv_t *listA, const fmd_intv_t *listB, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
                         uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx, size_t fix_off)
 {
-#define GRP_LAUNCH(K) k_ovl_nei_grp<fmd_grp_size(K)><<<n_cu * grp_cap(grp_blocks_per_cu<fmd_grp_size(K)>(), per_cu_cap), 64, 0, st>>>(ix, list, list_n, cap, listA, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n, gidx, fix_off)
+#define GRP_LAUNCH(K) k_ovl_nei_grp<fmd_grp_size(K)><<<n_cu * grp_cap(grp_blocks_per_cu<fmd_grp_size(K)>(), per_cu_cap), 64, 0, st>>>(ix, list, list_n, cap, listA, listB, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n, gidx, fix_off)
     switch (cls) {
     case 0: GRP_LAUNCH(0); break;
     case 1: GRP_LAUNCH(1); break;
