@@ -2,7 +2,8 @@
 """The sorted overlap job (fmd_ovlp_sorted_dev: park after 32 bases, minimizer sort, the rest in that order) against the same ids
 batch by batch in id order (fmd_ovlp_dev): HIP-event time of each over all 2N strands, and the records, neighbours and
 sequences compared byte for byte (neighbours up to n_nei, sequences up to len + ext_len).
-Usage: python tools/ab_sorted.py [n_reads=50000000] [err=0.0] [batch=20000000] [steps=2] [ENV=VAL ...]"""
+Usage: python tools/ab_sorted.py [n_reads=50000000] [err=0.0] [batch=20000000] [steps=2] [stride=1] [ENV=VAL ...]
+(stride s: the ids 0, s, 2s, ...: the shard of one rank of s)"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,6 +18,7 @@ n_reads = int(pos[0]) if len(pos) > 0 else 50_000_000
 err = float(pos[1]) if len(pos) > 1 else 0.0
 batch = int(pos[2]) if len(pos) > 2 else 20_000_000
 steps = int(pos[3]) if len(pos) > 3 else 2
+id_stride = int(pos[4]) if len(pos) > 4 else 1
 L, min_match, max_nei = 100, 50, 4
 stride = 2 * L
 dev = torch.device("cuda", 0)
@@ -28,10 +30,10 @@ del rd
 index = api.DevIndex.from_bwt_dev(d_bwt, n_sym, 0)
 lib.fmd_dev_free(d_bwt)
 torch.cuda.empty_cache()
-n = 2 * n_reads
+n = (2 * n_reads + id_stride - 1) // id_stride
 batch = min(batch, n)
 print("index: %d reads (e = %g), %d symbols, %.2f GB; %d strands, batches of %d" % (n_reads, err, n_sym, index.hbm_bytes / 1e9, n, batch), flush=True)
-ids = torch.arange(n, dtype=torch.int64, device=dev)
+ids = torch.arange(n, dtype=torch.int64, device=dev) * id_stride
 st = torch.cuda.current_stream()
 sh = C.c_void_p(st.cuda_stream)
 wb = lib.fmd_ovlp_sorted_work_bytes(n, batch, L, min_match)
