@@ -364,6 +364,11 @@ class OverlapJob:
         # strands per launch: the HBM work area is 3.95 kB per strand at 100 bp, -l50 (two candidate lists of 58 entries, the stash,
         # the work lists); 2*10^7 strands = 79 GB of the 288 GB
         self.batch = max(1, min(self.n, int(os.environ.get("FMD_BENCH_OVLP_BATCH", "20000000"))))
+        if "FMD_BENCH_OVLP_BATCH" not in os.environ:   # beside a large index (config 5: 141 GB) the rows of the shard and the job's work area must still fit
+            rows = self.n * (64 + self.max_nei * 32 + self.stride)
+            free_b = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+            while self.batch > 1_000_000 and rows + api.lib().fmd_ovlp_sorted_work_bytes(self.n, self.batch, L, min_match) + (6 << 30) > free_b:
+                self.batch //= 2
         self.rec = torch.zeros(self.n * 64, dtype=torch.uint8, device=dev)
         self.nei = torch.zeros(self.n * self.max_nei * 32, dtype=torch.uint8, device=dev)
         self.seq = torch.zeros(self.n * self.stride, dtype=torch.uint8, device=dev)

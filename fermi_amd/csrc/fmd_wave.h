@@ -42,7 +42,11 @@
 // line for a fraction size/96 of the steps (12-16 % of all lines of backward search and overlap discovery at 30x); the block of a
 // position is a shift instead of a division by 96.  8 bits per symbol instead of 5.33: 141 GB for the 1.4e11-symbol index.
 #ifndef FMD_BLK_OVERLAP
-#define FMD_BLK_OVERLAP 0   // measured (profiles/r2_ab): +3-5 % on overlap discovery and backward search, -2 % on SMEM, 1.5 x the HBM: not shipped
+#define FMD_BLK_OVERLAP 1   // round 2 (kernels bound by DRAM lines): 3-5 % for 1.5 x the HBM, not shipped.  Round 3 (the sorted walk is bound by the
+                            // fabric's REQUEST rate, every second line of a straddling pair a request of its own): overlap discovery -6 %, raw reads -3.5 %,
+                            // backward search -5.6 %, k-mer harvest -6 %, SMEM +-0 on one box (profiles/r3_locality/overlapped_blocks_all_legs.txt);
+                            // the index is 1.43 x the size (11.2 GB for 50 M reads, 141 GB for config 5: 288 GB of HBM are there to be used).
+                            // -DFMD_BLK_OVERLAP=0 builds the disjoint 96-position blocks (make variant NAME=disjoint EXTRA=-DFMD_BLK_OVERLAP=0)
 #endif
 #if FMD_BLK64
 #define FMD_BLK_SYMS 96u        // positions whose symbols a block holds
