@@ -124,19 +124,21 @@ __device__ __host__ __forceinline__ constexpr int fmd_grp_size(int k) { return k
 // k_ovl_nei, which these strands never reach without being started over from listA) one 32-byte entry per live candidate, in list
 // order.  Every entry also carries the strand's own state (round, neighbours so far, lfork, info of the first neighbour): the lanes
 // of a group read one entry each and nothing else.
-//   a = { x1 lo, x1 bits 32..39 | round << 8 | n_nei << 24, D lo, D hi }     b = { r0 lo, r0 bits 32..39 | nei0 << 8, size | pos << 16, lfork (17 bits) }
+//   a = { x1 lo, x1 bits 32..39 | round << 8 | n_nei << 24, D lo, D hi }     b = { r0 lo, r0 bits 32..39 | nei0 << 8, size | pos << 16, lfork (17 bits) | category << 17 | flags << 22 }
+// (category, flags: a strand k_ovl_nei_grp<G> passes on to a larger group size because a round leaves it more than G candidates)
 #define FMD_LIST_RESUME 0x8000u
-__device__ __forceinline__ void fmd_resume_encode(uint4 *e, uint64_t x1, uint32_t sz, uint64_t D, uint64_t r0, uint32_t pos, uint32_t round, uint32_t n_nei, uint32_t nei0, uint32_t lf)
+__device__ __forceinline__ void fmd_resume_encode(uint4 *e, uint64_t x1, uint32_t sz, uint64_t D, uint64_t r0, uint32_t pos, uint32_t round, uint32_t n_nei, uint32_t nei0, uint32_t lf,
+                                                  uint32_t cat = 0, uint32_t flags8 = 0)
 {
     e[0] = make_uint4((uint32_t)x1, ((uint32_t)(x1 >> 32) & 0xffu) | round << 8 | n_nei << 24, (uint32_t)D, (uint32_t)(D >> 32));
-    e[1] = make_uint4((uint32_t)r0, ((uint32_t)(r0 >> 32) & 0xffu) | nei0 << 8, sz | pos << 16, lf & 0x1ffffu);
+    e[1] = make_uint4((uint32_t)r0, ((uint32_t)(r0 >> 32) & 0xffu) | nei0 << 8, sz | pos << 16, (lf & 0x1ffffu) | cat << 17 | (flags8 & 0xffu) << 22);
 }
 __device__ __forceinline__ bool fmd_resume_fits(uint32_t round, uint32_t n_nei, uint32_t nei0, uint32_t pos) { return round < 65536u && n_nei < 256u && nei0 < 65536u && pos < 65536u; }
 __device__ __forceinline__ void fmd_resume_decode(const uint4 a, const uint4 b, uint64_t &x1, uint32_t &sz, uint64_t &D, uint64_t &r0, uint32_t &pos, uint32_t &round, uint32_t &n_nei,
-                                                  uint32_t &nei0, uint32_t &lf)
+                                                  uint32_t &nei0, uint32_t &lf, uint32_t &cat, uint32_t &flags8)
 {
     x1 = (uint64_t)(a.y & 0xffu) << 32 | a.x; round = (a.y >> 8) & 0xffffu; n_nei = a.y >> 24; D = (uint64_t)a.w << 32 | a.z;
-    r0 = (uint64_t)(b.y & 0xffu) << 32 | b.x; nei0 = b.y >> 8; sz = b.z & 0xffffu; pos = b.z >> 16; lf = b.w;
+    r0 = (uint64_t)(b.y & 0xffu) << 32 | b.x; nei0 = b.y >> 8; sz = b.z & 0xffffu; pos = b.z >> 16; lf = b.w & 0x1ffffu; cat = (b.w >> 17) & 31u; flags8 = (b.w >> 22) & 0xffu;
 }
 #define FMD_FAST_RESERVE (2 * FMD_FAST_MAX_WAVES * FMD_FAST_CHUNK)   // entries a general list may lose to holes (two fast kernels feed it)
 #define FMD_CLS_PART_U32 (FMD_CLS_HEADER_U32 + 2 * FMD_GRP_CLASSES * FMD_FAST_RESERVE)   // per part of a pipelined batch: counters + that room

@@ -11,7 +11,7 @@
 
 // (gidx: slot of a sorted batch -> row of rec / nei_out / seq_out, fmd_ovlp_sorted_dev; nullptr = the slot is the row)
 void fmd_launch_nei_grp(int cls, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
-                        const fmd_intv_t *listA, const fmd_intv_t *listB, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
+                        const fmd_intv_t *listA, fmd_intv_t *listB, const FmdOvlClasses &cl, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
                         uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx, size_t fix_off);
 int fmd_nei_fast_available(void);
 void fmd_launch_nei_fast(int cls, int wide, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
@@ -1107,7 +1107,7 @@ static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, i
         }
     // one lane per candidate interval, 64 / G strands per wave
     for (int k = 0; k < FMD_GRP_CLASSES; ++k)
-        fmd_launch_nei_grp(k, o.h->n_cu, per_cu, st, o.ix, cl.lst[k], cl.cnt + k * FMD_CLS_CNT_STRIDE, o.cap, listA, listB, rec, nei, o.max_nei, seq, o.seq_stride, lslow_late, n_late, gidx, fix_off);
+        fmd_launch_nei_grp(k, o.h->n_cu, per_cu, st, o.ix, cl.lst[k], cl.cnt + k * FMD_CLS_CNT_STRIDE, o.cap, listA, listB, cl, rec, nei, o.max_nei, seq, o.seq_stride, lslow_late, n_late, gidx, fix_off);
     // the rest (too many candidates, wide intervals, fake forks, neighbour overflow): lane per strand
     k_ovl_nei<<<grid, 64, 0, st>>>(o.ix, np, o.min_match, srev, o.stride_r, o.cap, listA, listB, rec, nei, o.max_nei, seq, o.seq_stride, q2, lslow_late, n_late, gidx);
     // fake forks among the strands the group kernels finished: the fix-up alone
@@ -1123,8 +1123,8 @@ static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, i
         uint32_t nf = 0, nb = 0, ng = 0;
         for (int k = 0; k < 2 * FMD_GRP_CLASSES; ++k) { nf += hs[(FMD_GRP_CLASSES + 1 + k) * FMD_CLS_CNT_STRIDE]; nb += hs[(FMD_GRP_CLASSES + 1 + k) * FMD_CLS_CNT_STRIDE + 8]; }
         for (int k = 0; k < FMD_GRP_CLASSES; ++k) ng += hs[k * FMD_CLS_CNT_STRIDE];
-        fprintf(stderr, "[M::fmd_ovlp] part of %zu strands: %u to the unforked path (%u of them handed on), %u slots of the general group kernels' lists (holes of the hand-over included), %u through the lane-per-strand kernel\n",
-                np, nf, nb, ng, hs[FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE] + hs[FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE + FMD_CLS_LATE_CNT]);
+        fprintf(stderr, "[M::fmd_ovlp] part of %zu strands: %u to the unforked path (%u of them handed on), %u slots of the general group kernels' lists (holes of the hand-over included), %u through the lane-per-strand kernel at once + %u handed back to it, %u fake forks fixed up\n",
+                np, nf, nb, ng, hs[FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE], hs[FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE + FMD_CLS_LATE_CNT], hs[FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE + FMD_CLS_LATE_CNT + FMD_CLS_FIX_CNT]);
     }
 #ifdef GRP_STATS
     {

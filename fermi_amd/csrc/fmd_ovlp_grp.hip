@@ -6,10 +6,10 @@
 // 53 GB of rank blocks.  Here a strand owns a group of G lanes (G = 8, 12, 16, 21 or 32: the smallest
 // that holds its candidates, fmd_grp_size) and its candidate list IS the group's registers:
 //   * one wave step = one round of every resident strand (64/G of them): each live lane extends
-//     its interval forward (rank2a on the x[1] strand) and, from the SAME step, answers the
-//     backward `$` tests of unitig.c:112 and :129 for ok[0] and all four children: they are ranks
-//     of '$' at the six child boundaries of the x[0] range [x0-1, x0-1+size], i.e. one more block
-//     (two if the range straddles) whose address is known before the extension returns;
+//     its interval forward (rank2a on the x[1] strand) and answers the backward `$` tests of
+//     unitig.c:112 and :129 for ok[0] and all four children from what it CARRIES: D, the '$'
+//     positions of BWT[x0, x0 + size), and r0, the '$' before x0 (see the kernel: the x[0] side of
+//     the index is read once per candidate at most);
 //   * the sequential semantics of the reference's loop (first neighbour of a category masks the
 //     rest of it; children ordered by old category, base, start) are prefix computations on
 //     group ballots; children are re-packed through a 2 KiB LDS staging area (it reuses the spill pool);
@@ -20,10 +20,9 @@
 // to k_ovl_nei through the `slow` work list; nothing is approximated.
 #include "fmd_kernel_common.h"
 
-// LDS per wave: one block slot per lane for the k side of the forward extension (slot 0) and of
-// the sentinel window (slot 1); the l sides, needed only when a range straddles a block boundary
-// (~17 % of the lanes each: a first-round candidate is the whole interval of the overlap string),
-// share a compacted pool of 30 blocks; a wave step that needs more (0.2 % of them) takes the pool
+// LDS per wave: one block slot per lane for the k side of the forward extension (slot 0) and, in the first round of
+// a candidate that came without D / r0, of its x[0] range (slot 1); the l sides, needed only when a range leaves its
+// block, share a compacted pool of 30 blocks; a wave step that needs more (0.2 % of them) takes the pool
 // in several passes.  One 2 KiB region holds the pool (1920 bytes), the block numbers to fetch
 // (128 bytes) and -- later in the step, when the windows have been read -- the re-pack staging
 // area.  10 KiB per wave = 8 LDS granules -> 16 waves per CU.
@@ -99,7 +98,7 @@ __global__ __launch_bounds__(CLS_THREADS) void k_ovl_classify(size_t n, const fm
 // its strands on where they stand (FMD_LIST_RESUME) instead of at round 0.
 template <int G>
 __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
-                                                    uint32_t cap, const fmd_intv_t *__restrict__ listA, const fmd_intv_t *__restrict__ listB,
+                                                    uint32_t cap, const fmd_intv_t *__restrict__ listA, fmd_intv_t *listB, FmdOvlClasses cl,
                                                     fmd_ovlp_rec_t *__restrict__ rec,
                                                     fmd_intv_t *__restrict__ nei_out, uint32_t max_nei, uint8_t *__restrict__ seq_out,
                                                     uint32_t seq_stride, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_n,
@@ -140,10 +139,11 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
             sid = d_sid; gs = d_gs; ori_l = (int)(d_meta >> 16); flags = 0; cat = 0;
             alive = (uint32_t)j < m;
             if (d_meta & FMD_LIST_RESUME) { // the strand as k_ovl_nei_fast left it before round `round` (fmd_resume_*: every entry carries the strand's state)
-                uint32_t lf_; uint32_t rd_, nn_, n0_;
-                fmd_resume_decode(pa, pb, x1, sz, D, r0, pos, rd_, nn_, n0_, lf_);
+                uint32_t lf_, rd_, nn_, n0_, ct_, fl_;
+                fmd_resume_decode(pa, pb, x1, sz, D, r0, pos, rd_, nn_, n0_, lf_, ct_, fl_);
                 round = (int)(uint32_t)__shfl((int)rd_, gbase); n_nei = (uint32_t)__shfl((int)nn_, gbase);   // (lanes past m hold no entry)
                 nei0_info = (uint32_t)__shfl((int)n0_, gbase); LF_SET(flags, (uint32_t)__shfl((int)lf_, gbase));
+                flags |= (uint32_t)__shfl((int)fl_, gbase); cat = (int)ct_;
                 need_d = false;
             } else {
                 const FmdCand cd = cand_decode(pa, pb);
@@ -267,14 +267,6 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
         // ---- the reference's sequential loop over the list, as prefix logic on group ballots
         const uint32_t alive_g = (uint32_t)(__ballot(live) >> gbase) & GM;
         const int ncur = __popc(alive_g);
-        if (active && !(LF_GET(flags) & 0x10000u)) { // check_left's rounds (include/fmd_hip.h, FMD_LFORK_*): which bases do the reads that start inside X go on with?
-            uint32_t u = 0;
-#pragma unroll
-            for (int c = 1; c <= 5; ++c) if ((uint32_t)(__ballot((dm >> c) & 1) >> gbase) & GM) u |= 1u << c;
-            if (__popc(u) >= 2) LF_SET(flags, LF_GET(flags) | 0x18000u);             // two bases in round `round`: D, closed
-            else if (u == 0) LF_SET(flags, FMD_LFORK_ALL | 0x10000u);                 // every one of them ended
-            else LF_SET(flags, (uint32_t)(round + 1) | ((u & 32u) ? 0x10000u : 0u));  // consistent; an N child is not followed any further
-        }
         const uint32_t nei_g = (uint32_t)(__ballot(is_nei) >> gbase) & GM;
         const uint32_t head_g = (uint32_t)(__ballot(live && cat == j) >> gbase) & GM;   // first lane of each category
         const uint32_t in_cat_upto_j = (uint32_t)(bits_below(j + 1) & ~bits_below(cat));
@@ -282,13 +274,6 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
         const bool keep = live && (nei_g & in_cat_upto_j) == 0;                                 // not masked, not a neighbour
         const uint32_t newnei_g = (uint32_t)(__ballot(new_nei) >> gbase) & GM;
         if (!keep) cm = 0;
-        const uint32_t nei_k = n_nei + __popc(newnei_g & (uint32_t)bits_below(j)); // neighbours in list order (unitig.c:119-121)
-        if (active && n_nei == 0 && newnei_g) { // info of nei[0] decides rbeg (unitig.c:157)
-            const int src = gbase + __ffs((int)newnei_g) - 1;
-            nei0_info = (uint32_t)ori_l - (uint32_t)__shfl((int)pos, src);
-        }
-        if (active) n_nei += __popc(newnei_g);
-
         // children: destination = #children of earlier categories + same category & smaller base
         //           + same category, same base, earlier lane  (= ks_introsort by info, unitig.c:140)
         const uint32_t c1 = (uint32_t)(__ballot((cm >> 1) & 1) >> gbase) & GM, c2 = (uint32_t)(__ballot((cm >> 2) & 1) >> gbase) & GM;
@@ -300,7 +285,25 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
         const uint32_t lt_m = same_m & (uint32_t)bits_below(j);
         const int before = __popc(c1 & before_m) + __popc(c2 & before_m) + __popc(c3 & before_m) + __popc(c4 & before_m);
         const int p1 = before, p2 = p1 + __popc(c1 & same_m), p3 = p2 + __popc(c2 & same_m), p4 = p3 + __popc(c3 & same_m);
-        const bool too_many = n_new > G;
+        // more children than the group has lanes: nothing of this round happens here (no neighbour is stored, no count moves) -- the
+        // strand goes, as it stands BEFORE the round, to the list of the smallest group size that holds them (its kernel runs after
+        // this one), or to the lane-per-strand kernel when there is none
+        const bool too_many = active && n_new > G;
+        const bool run = active && !too_many;
+        if (run && !(LF_GET(flags) & 0x10000u)) { // check_left's rounds (include/fmd_hip.h, FMD_LFORK_*): which bases do the reads that start inside X go on with?
+            uint32_t u = 0;
+#pragma unroll
+            for (int c = 1; c <= 5; ++c) if ((uint32_t)(__ballot((dm >> c) & 1) >> gbase) & GM) u |= 1u << c;
+            if (__popc(u) >= 2) LF_SET(flags, LF_GET(flags) | 0x18000u);             // two bases in round `round`: D, closed
+            else if (u == 0) LF_SET(flags, FMD_LFORK_ALL | 0x10000u);                 // every one of them ended
+            else LF_SET(flags, (uint32_t)(round + 1) | ((u & 32u) ? 0x10000u : 0u));  // consistent; an N child is not followed any further
+        }
+        const uint32_t nei_k = n_nei + __popc(newnei_g & (uint32_t)bits_below(j)); // neighbours in list order (unitig.c:119-121)
+        if (run && n_nei == 0 && newnei_g) { // info of nei[0] decides rbeg (unitig.c:157)
+            const int src = gbase + __ffs((int)newnei_g) - 1;
+            nei0_info = (uint32_t)ori_l - (uint32_t)__shfl((int)pos, src);
+        }
+        if (run) n_nei += __popc(newnei_g);
         bool forked_now = false;
         // x[1] of a child = cnt[c] + rank_c(x1 - 1): one rank of ONE symbol per surviving child (a second child only exists where the
         // read set forks); its D and r0 from the parent's: offsets of the children in the x[0] range, order $,T,G,C,A.  A new neighbour
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
         const uint32_t o4 = s[0], o3 = o4 + s[4], o2 = o3 + s[3], o1 = o2 + s[2];
         {
             uint32_t todo = too_many ? 0u : cm;
-            bool nei_todo = new_nei;
+            bool nei_todo = new_nei && !too_many;
             while (__ballot(todo != 0 || nei_todo)) {
                 const int c = todo ? __ffs((int)todo) - 1 : 0;
                 const uint64_t r = fmd_block_rank1(img_e, t, oke + 1, c, bke);
@@ -346,8 +349,17 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
             if (n_nei > max_nei) { // more neighbours than the caller has room for: the record says so (what k_ovl_nei would write after redoing
                 if (j == 0) rec[gs].flags |= FMD_OVLP_F_OVERFLOW;   // the strand: n_nei, rbeg, ext_len stay as the walk left them), the caller re-runs it larger
                 active = false; alive = false;
-            } else if (too_many) { // hand the strand to the lane-per-strand kernel
-                if (j == 0) { const uint32_t k = atomicAdd(slow_n, 1u); slow_list[k] = sid; }
+            } else if (too_many) {
+                int k2 = FMD_GRP_CLASSES;
+#pragma unroll
+                for (int k = FMD_GRP_CLASSES - 1; k >= 0; --k) if (fmd_grp_size(k) > G && n_new <= fmd_grp_size(k)) k2 = k;
+                if (k2 < FMD_GRP_CLASSES && fmd_resume_fits((uint32_t)round, n_nei, nei0_info, 0u) && (uint32_t)ncur <= cap) {
+                    if (alive) fmd_resume_encode((uint4 *)(listB + sid * (size_t)cap + j), x1, sz, D, r0, pos, (uint32_t)round, n_nei, nei0_info, LF_GET(flags), (uint32_t)cat, flags & 0xffu);
+                    if (j == 0) {
+                        const uint32_t k = atomicAdd(cl.cnt + k2 * FMD_CLS_CNT_STRIDE, 1u);
+                        cl.lst[k2][2 * (size_t)k] = sid; cl.lst[k2][2 * (size_t)k + 1] = (uint32_t)ncur | FMD_LIST_RESUME | (uint32_t)ori_l << 16;
+                    }
+                } else if (j == 0) { const uint32_t k = atomicAdd(slow_n, 1u); slow_list[k] = sid; }   // the lane-per-strand kernel starts it over
                 active = false; alive = false;
             } else if (n_new > 0) { // next round (unitig.c:137-153)
                 if (j == 0 && (uint32_t)(ori_l + round) < seq_stride) seq_out[gs * (size_t)seq_stride + ori_l + round] = (uint8_t)comp6(first_c);
@@ -705,10 +717,10 @@ static int grp_blocks_per_cu(void)
     return cached;
 }
 void fmd_launch_nei_grp(int cls, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
-                        const fmd_intv_t *listA, const fmd_intv_t *listB, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
+                        const fmd_intv_t *listA, fmd_intv_t *listB, const FmdOvlClasses &cl, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
                         uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx, size_t fix_off)
 {
-#define GRP_LAUNCH(K) k_ovl_nei_grp<fmd_grp_size(K)><<<n_cu * grp_cap(grp_blocks_per_cu<fmd_grp_size(K)>(), per_cu_cap), 64, 0, st>>>(ix, list, list_n, cap, listA, listB, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n, gidx, fix_off)
+#define GRP_LAUNCH(K) k_ovl_nei_grp<fmd_grp_size(K)><<<n_cu * grp_cap(grp_blocks_per_cu<fmd_grp_size(K)>(), per_cu_cap), 64, 0, st>>>(ix, list, list_n, cap, listA, listB, cl, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n, gidx, fix_off)
     switch (cls) {
     case 0: GRP_LAUNCH(0); break;
     case 1: GRP_LAUNCH(1); break;

@@ -1,6 +1,6 @@
 // fmd_smem.hip -- super-maximal exact matches: fm6_smem1_core (smem.c:13-80) driven as fm6_smem
 // does (smem.c:397-410), i.e. what `fermi exact` prints (cmd.c:319-327).  One lane per read on the
-// compact wave engine (13 waves/CU); the forward sweep is a chain of forward extensions, the
+// compact wave engine (12 waves/CU); the forward sweep is a chain of forward extensions, the
 // backward sweep walks the candidate list once per base.  Candidate lists live in an HBM work
 // area owned by the persistent LANE (two lists of 2*max_len+2 entries, reused read after read, so the
 // area does not grow with the batch); SMEMs are written to the caller's array in the reference's order.
