@@ -334,12 +334,28 @@ static void reverse(size_t l, char *s)
 
 typedef struct { uint64_t x, y; } link_t;
 
+/* decimal digits of v (what "%lld" prints) at p; returns the number of bytes.  A record of raw reads is one header of up to eight
+ * numbers over ~200 bytes of text, and printf's parser is most of what such a record costs. */
+static inline size_t put_ll(char *p, long long v)
+{
+    char t[24];
+    size_t n = 0, i;
+    unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+    do { t[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) t[n++] = '-';
+    for (i = 0; i < n; ++i) p[i] = t[n - 1 - i];
+    return n;
+}
+
 static int put_links(str_t *o, const link_t *a, int n)
 {
     int k;
     if (str_reserve(o, o->l + 32 * (size_t)(n + 1) + 8)) return -1;
     o->s[o->l++] = '\t';
-    for (k = 0; k < n; ++k) o->l += (size_t)sprintf(o->s + o->l, "%lld,%d;", (long long)a[k].x, (int)(int32_t)a[k].y);
+    for (k = 0; k < n; ++k) {
+        o->l += put_ll(o->s + o->l, (long long)a[k].x); o->s[o->l++] = ',';
+        o->l += put_ll(o->s + o->l, (long long)(int32_t)a[k].y); o->s[o->l++] = ';';
+    }
     if (n == 0) o->s[o->l++] = '.';
     return 0;
 }
@@ -429,7 +445,8 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
             /* ---- mag_v_write (mag.c:149-174) */
             o.l = 0;
             if (str_reserve(&o, 2 * s.l + 128)) { rc = -ENOMEM; goto done; }
-            o.l += (size_t)sprintf(o.s + o.l, "@%lld:%lld\t%d", (long long)end[0], (long long)end[1], n_reads);
+            o.s[o.l++] = '@'; o.l += put_ll(o.s + o.l, (long long)end[0]); o.s[o.l++] = ':'; o.l += put_ll(o.s + o.l, (long long)end[1]);
+            o.s[o.l++] = '\t'; o.l += put_ll(o.s + o.l, (long long)n_reads);
             if (put_links(&o, nei[0], n_nei[0]) || put_links(&o, nei[1], n_nei[1])) { rc = -ENOMEM; goto done; }
             if (str_reserve(&o, o.l + 2 * s.l + 8)) { rc = -ENOMEM; goto done; }
             o.s[o.l++] = '\n';
