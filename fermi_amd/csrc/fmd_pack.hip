@@ -223,7 +223,7 @@ struct Event {
 };
 struct Pinned { // hipHostRegister for a scope (best effort: pageable copies otherwise)
     void *p = nullptr;
-    void pin(void *ptr, size_t bytes) { if (bytes >= ((size_t)8 << 20) && !getenv("FMD_NO_PIN") && hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess) p = ptr; else (void)hipGetLastError(); }
+    void pin(void *ptr, size_t bytes) { if (bytes >= ((size_t)8 << 20) && !getenv("FMD_NO_PIN") && !getenv("FMD_TABLE_DIR") && hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess) p = ptr; else (void)hipGetLastError(); }   // (FMD_TABLE_DIR: the table is not to be held in RAM)
     ~Pinned() { if (p) hipHostUnregister(p); }
 };
 }
@@ -398,7 +398,8 @@ static int packed_batch_core(fmd_dev_t *h, const uint64_t *ids, uint64_t first, 
             void *buf = fmd_table_alloc(bytes ? bytes : 64);
             if (!buf) { fail(FMD_E_NOMEM); break; }
             chunks[p] = (uint8_t *)buf;
-            if (bytes >= ((size_t)8 << 20) && !getenv("FMD_NO_PIN") && hipHostRegister(buf, bytes, hipHostRegisterDefault) == hipSuccess) registered.push_back(buf);
+            // (file pages are not pinned: registering every chunk until the end of the pass would hold the whole table in RAM, which is what FMD_TABLE_DIR is there to avoid)
+            if (bytes >= ((size_t)8 << 20) && !getenv("FMD_NO_PIN") && !getenv("FMD_TABLE_DIR") && hipHostRegister(buf, bytes, hipHostRegisterDefault) == hipSuccess) registered.push_back(buf);
             else (void)hipGetLastError();
             if (hipMemcpyAsync(rec + b, d_prec[k].p, np * sizeof(fmd_ovlp_rec_t), hipMemcpyDeviceToHost, s_cpy.s) != hipSuccess ||
                 hipMemcpyAsync(off + b, d_off[k].p, np * 8, hipMemcpyDeviceToHost, s_cpy.s) != hipSuccess ||
