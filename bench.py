@@ -707,9 +707,10 @@ def bench_smem(torch, api, index, rd, err, n_sym, fmd_path, dev, local_rank, n_r
     cn = oracle_counters(fmd_path, lambda o: o.smem_batch(q[:ns], 0, max_mem, 1))
     qpr = (cn["rank1a"] + cn["rank2a"] + cn["rank2a_spill"]) / float(min(ns, len(q)))
     io = n_reads * (L + 4) + n_out * 32
-    dev_bytes = None if lines is None else (lines[0] + lines[1]) * BLOCK_BYTES + io
-    out["roofline"] = roofline("k_smem", kern_ms, dev_bytes, {"rank_blocks": lines and lines[0], "stream_bytes": io,
-                                                              "streams": "reads + SMEM rows out (the lane-owned candidate lists in HBM are not modelled)"},
+    # (k_smem's second counter is its candidate lists: 32-byte entries written to / picked from the lane-owned lists in HBM)
+    dev_bytes = None if lines is None else lines[0] * BLOCK_BYTES + lines[1] * 32 + io
+    out["roofline"] = roofline("k_smem", kern_ms, dev_bytes, {"rank_blocks": lines and lines[0], "list_entries_moved": lines and lines[1], "stream_bytes": io,
+                                                              "streams": "reads + SMEM rows out; the candidate lists: 32 B per entry written or picked (counted by the instrumented build, like the rank blocks)"},
                                qpr * BYTES_PER_RANK_QUERY * n_reads, "smem@%d" % n_reads, {"rank_queries_per_read": qpr, "oracle_counters_on_sample": cn})
     INTV = np.dtype([("x", "<u8", (3,)), ("info", "<u8")])
     g_mem = mem.view(n_reads, max_mem * 32)[sel_d].cpu().numpy().view(INTV).reshape(len(sel), max_mem)

@@ -22,14 +22,16 @@
 #include "fmd_kernel_common.h"
 
 // forward-sweep push (the list is written back to front); a full list marks the item as overflowed
-#define SM_PUSH_FWD(a_, b_, c_, d_) do { if (curr_n < cap) { sm_push(la, slots, pend_e, cap - 1 - curr_n, a_, b_, c_, d_); fmask = fmask << 1 | (uint64_t)((b_) < ix.n_seq); ++curr_n; } else overflow = true; } while (0)
+#define SM_PUSH_FWD(a_, b_, c_, d_) do { if (curr_n < cap) { sm_push(la, slots, pend_e, list_units, cap - 1 - curr_n, a_, b_, c_, d_); fmask = fmask << 1 | (uint64_t)((b_) < ix.n_seq); ++curr_n; } else overflow = true; } while (0)
 
 #define SM_NONE 0xffffffffu
 // the two LDS slots of a lane (slot = entry index & 1), planes of 64 lanes x 16 bytes: no bank conflicts
 #define SM_SLOT(s_, p_) slots[(((s_) * 2 + (p_)) << 6) + fmd_lane()]
 
-__device__ __forceinline__ void sm_flush_single(fmd_intv_t *la, uint4 *slots, uint32_t &pend_e)
+// (units: list entries moved to or from HBM, 32 bytes each -- read by the instrumented build only, dead code otherwise)
+__device__ __forceinline__ void sm_flush_single(fmd_intv_t *la, uint4 *slots, uint32_t &pend_e, uint32_t &units)
 {
+    ++units;
     uint4 *dst = (uint4 *)(la + pend_e);
     const uint32_t s = pend_e & 1;
     dst[0] = SM_SLOT(s, 0); dst[1] = SM_SLOT(s, 1);
@@ -38,9 +40,9 @@ __device__ __forceinline__ void sm_flush_single(fmd_intv_t *la, uint4 *slots, ui
 
 // entry e of the lane's area (la[e]; lb = la + cap) := (a, b, c, d).  It is written to its LDS slot; HBM gets it together with
 // its pair partner (e ^ 1) as one aligned 64-byte burst when that one was the push before, else when its slot is needed again.
-__device__ __forceinline__ void sm_push(fmd_intv_t *la, uint4 *slots, uint32_t &pend_e, uint32_t e, uint64_t a, uint64_t b, uint64_t c, uint64_t d)
+__device__ __forceinline__ void sm_push(fmd_intv_t *la, uint4 *slots, uint32_t &pend_e, uint32_t &units, uint32_t e, uint64_t a, uint64_t b, uint64_t c, uint64_t d)
 {
-    if (pend_e != SM_NONE && pend_e != (e ^ 1u)) sm_flush_single(la, slots, pend_e);
+    if (pend_e != SM_NONE && pend_e != (e ^ 1u)) sm_flush_single(la, slots, pend_e, units);
     const uint32_t s = e & 1;
     const uint4 v0 = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
     const uint4 v1 = make_uint4((uint32_t)c, (uint32_t)(c >> 32), (uint32_t)d, (uint32_t)(d >> 32));
@@ -49,7 +51,7 @@ __device__ __forceinline__ void sm_push(fmd_intv_t *la, uint4 *slots, uint32_t &
         const uint4 p0 = SM_SLOT(s ^ 1, 0), p1 = SM_SLOT(s ^ 1, 1);
         uint4 *dm = (uint4 *)(la + e), *dp = (uint4 *)(la + (e ^ 1u));   // (addresses, not data, depend on which half this is)
         dm[0] = v0; dm[1] = v1; dp[0] = p0; dp[1] = p1;
-        pend_e = SM_NONE;
+        pend_e = SM_NONE; units += 2;
     } else pend_e = e;
 }
 
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(64, 3) void k_smem(FmdIndexView ix, size_t n, const
     // two candidate lists of `cap` entries per lane (HBM; this lane's area is reused read after read): la = entries [0, cap) of
     // the area, lb = [cap, 2 cap).  prev / curr are entry indices into it.
     fmd_intv_t *const la = work + ((size_t)blockIdx.x * 64 + fmd_lane()) * 2 * (size_t)cap;
-    uint32_t prev_e0 = 0, curr_e0 = 0, pend_e = SM_NONE, pf_e = SM_NONE;
+    uint32_t prev_e0 = 0, curr_e0 = 0, pend_e = SM_NONE, pf_e = SM_NONE, list_units = 0;
     uint64_t fmask = 0, kmask = 0, cmask = 0;        // sentinel-closed entries of the list being pushed / of prev / of curr
     uint64_t kx0 = 0, kx1 = 0, ksz = 0, kinfo = 0;   // ik (forward sweep) / p (backward sweep)
     uint64_t last_curr_sz = 0, last_mem_beg = 0;
@@ -161,10 +163,10 @@ __global__ __launch_bounds__(64, 3) void k_smem(FmdIndexView ix, size_t n, const
                     if (e == pf_e) {
                         kx0 = (uint64_t)pfa.y << 32 | pfa.x; kx1 = (uint64_t)pfa.w << 32 | pfa.z;
                         ksz = (uint64_t)pfb.y << 32 | pfb.x; kinfo = (uint64_t)pfb.w << 32 | pfb.z;
-                    } else load_entry(la + e, kx0, kx1, ksz, kinfo);
+                    } else { load_entry(la + e, kx0, kx1, ksz, kinfo); ++list_units; }
                     st = SM_BWD;
                 } else if (curr_n != 0 && i != -1) { // next base to the left (smem.c:76-77)
-                    if (pend_e != SM_NONE) sm_flush_single(la, slots, pend_e);
+                    if (pend_e != SM_NONE) sm_flush_single(la, slots, pend_e, list_units);
                     prev_e0 = curr_e0; prev_n = curr_n; kmask = cmask; cmask = 0;
                     curr_e0 = prev_e0 == cap ? 0 : cap; // lists start at index 0 of their areas from now on
                     curr_n = 0; j = 0; --i; pf_e = SM_NONE; again = true;
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(64, 3) void k_smem(FmdIndexView ix, size_t n, const
         }
         if (__ballot(st != SM_IDLE) == 0) { if (__ballot(!exhausted) == 0) break; else continue; }
 
+
         // ---- rank2a request: the two ends of the extension of [a, a + size)
         const bool act = st != SM_IDLE;
         const bool fwd = st == SM_FWD || st == SM_FWD_END;
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(64, 3) void k_smem(FmdIndexView ix, size_t n, const
             const uint32_t jn = i == -1 ? sm_next_needed(j + 1, prev_n, kmask) : j + 1;
             if (jn < prev_n) {
                 const uint4 *pq = (const uint4 *)(la + (prev_e0 + jn));
-                pfa = pq[0]; pfb = pq[1]; pf_e = prev_e0 + jn;
+                pfa = pq[0]; pfb = pq[1]; pf_e = prev_e0 + jn; ++list_units;
             }
         }
         FmdRank2c r = fmd_wave_rank2_fetch_compact(ix, fmd_lds, act ? a0 - 1 : NONE64, act ? a0 - 1 + ksz : NONE64);
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(64, 3) void k_smem(FmdIndexView ix, size_t n, const
             }
             if (cont && (kx1 < ix.n_seq || curr_n == 0 || sc != last_curr_sz)) {
                 if (i != -1) { // (nobody reads the list of the last round)
-                    sm_push(la, slots, pend_e, curr_e0 + curr_n, nxc, rc, sc, kinfo);
+                    sm_push(la, slots, pend_e, list_units, curr_e0 + curr_n, nxc, rc, sc, kinfo);
                     if (curr_n < 64) cmask |= (uint64_t)(kx1 < ix.n_seq) << curr_n;
                 }
                 last_curr_sz = sc;
@@ -307,6 +310,9 @@ __global__ __launch_bounds__(64, 3) void k_smem(FmdIndexView ix, size_t n, const
             st = SM_BWD_PICK;
         }
     }
+#if FMD_COUNT_LINES
+    if (list_units) atomicAdd(ix.stat + (blockIdx.x & (FMD_STAT_SLOTS - 1)) * FMD_STAT_STRIDE + 1, (unsigned long long)list_units);   // kind 1 in this kernel: 32-byte list entries
+#endif
 }
 
 // *mixed := 1 when the n sequences do not all have the length of the first
