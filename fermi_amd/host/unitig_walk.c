@@ -113,6 +113,44 @@ static inline void prefetch_row_var(const walk_t *w, uint32_t row)  /* once its 
 
 static inline fmdh_row_t ROW(const walk_t *w, uint64_t row) { return fmdh_table_row(w->t, row); }
 
+/* Short unitigs (reads with errors: 10^8 of them at 50 M reads) leave the skip list nothing to look ahead along; what a seed will
+ * touch is known from the seeds' own links, which are read in id order.  Three stages, SEED_AHEAD ids apart, for the two first hops
+ * of a seed to come (from the seed's strand and from its reverse): the hop's record, offset, links and the record of the hop's
+ * reverse strand (check_left reads its lfork) -- then the hop's packed row and the heads of the SECOND hops -- then their rows. */
+static inline void seed_hint_head(const walk_t *w, uint32_t a)
+{
+    if (a == 0xffffffffu) return;
+    prefetch_row_head(w, a);
+}
+static inline void seed_hints(const walk_t *w, uint64_t i, int staged)
+{
+    const fmdh_ovlp_table_t *t = w->t;
+    int d;
+    if (!staged) {   /* (FMD_WALK_SEED_STAGES=0: the first hop's record only, as before) */
+        if (i + SEED_AHEAD < t->n) for (d = 0; d < 2; ++d) { const uint32_t a = t->link[i + SEED_AHEAD - (uint64_t)d].nxt; if (a != 0xffffffffu) __builtin_prefetch(&t->shard[a % (uint32_t)t->n_shards].rec[a / (uint32_t)t->n_shards]); }
+        return;
+    }
+    if (i + 3 * SEED_AHEAD < t->n)
+        for (d = 0; d < 2; ++d) {
+            const fmdh_link_t *l = &t->link[i + 3 * SEED_AHEAD - (uint64_t)d];
+            seed_hint_head(w, l->nxt);
+            if (l->rev != 0xffffffffu) __builtin_prefetch(&t->shard[l->rev % (uint32_t)t->n_shards].rec[l->rev / (uint32_t)t->n_shards]);
+        }
+    if (i + 2 * SEED_AHEAD < t->n)
+        for (d = 0; d < 2; ++d) {
+            const uint32_t a = t->link[i + 2 * SEED_AHEAD - (uint64_t)d].nxt;
+            if (a == 0xffffffffu) continue;
+            prefetch_row_var(w, a);
+            seed_hint_head(w, t->link[a].nxt);
+            if (t->link[a].rev != 0xffffffffu) __builtin_prefetch(&t->shard[t->link[a].rev % (uint32_t)t->n_shards].rec[t->link[a].rev / (uint32_t)t->n_shards]);
+        }
+    if (i + SEED_AHEAD < t->n)
+        for (d = 0; d < 2; ++d) {
+            const uint32_t a = t->link[i + SEED_AHEAD - (uint64_t)d].nxt;
+            if (a != 0xffffffffu && t->link[a].nxt != 0xffffffffu) prefetch_row_var(w, t->link[a].nxt);
+        }
+}
+
 /* ---- output: records are formatted by the walk and written by a second thread (two buffers handed back and forth) */
 #define OUT_BUF ((size_t)8 << 20)
 typedef struct {
@@ -390,15 +428,11 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
     }
     const int hints = t->link && !getenv("FMD_WALK_NO_JUMP");
     if (hints) w.jump = build_jump(t->link, t->n);   /* 0: the plain chase */
+    const int seed_stages = !(getenv("FMD_WALK_SEED_STAGES") && atoi(getenv("FMD_WALK_SEED_STAGES")) == 0);
     /* unitig_core with start = 0, step = 1 (unitig.c:333-334): seeds are the odd sequence ids */
     for (j = 0; j <= n_seq >> 2; ++j) {
         for (i = j << 2 | 1; i < (j << 2) + 4 && i < n_seq; i += 2) {
-            if (hints && i + SEED_AHEAD < t->n) {   /* short unitigs (reads with errors): the record of the first hop of a seed to come, both directions */
-                const uint64_t m = i + SEED_AHEAD;
-                const uint32_t a = t->link[m].nxt, b = t->link[m - 1].nxt;
-                if (a != 0xffffffffu) __builtin_prefetch(&t->shard[a % (uint32_t)t->n_shards].rec[a / (uint32_t)t->n_shards]);
-                if (b != 0xffffffffu) __builtin_prefetch(&t->shard[b % (uint32_t)t->n_shards].rec[b / (uint32_t)t->n_shards]);
-            }
+            if (hints) seed_hints(&w, i, seed_stages);
             const fmd_ovlp_rec_t *r = REC(&w, i);
             uint64_t end[2];
             int n_nei[2] = {0, 0}, n_reads, is_loop = 0, seed_len, k, done_loop = 0;
