@@ -7,6 +7,7 @@
 #define FMD_HOST_H
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>
 #include <stdio.h>
 #include "fmd_hip.h"
 #ifdef __cplusplus
@@ -69,8 +70,17 @@ static inline fmdh_row_t fmdh_table_row(const fmdh_ovlp_table_t *t, uint64_t id)
 /* bases [from, from + n) of a row (the sequence, then the bases fm6_get_nei appended), as nt6 codes */
 static inline void fmdh_row_bases(const fmdh_row_t *x, uint32_t from, uint32_t n, char *dst)
 {
-    uint32_t j;
-    for (j = 0; j < n; ++j) dst[j] = (char)fmd_ovlp_row_base(x->rec, x->max_nei, x->var, from + j);
+    uint32_t j = 0;
+    if (!(x->rec->flags & FMD_OVLP_F_PACK4)) {   /* 2 bits per base: four at a time once `from + j` is a multiple of four */
+        const uint8_t *s = x->var + fmd_ovlp_row_nei(x->rec, x->max_nei) * 32;
+        for (; j < n && ((from + j) & 3); ++j) dst[j] = (char)(((s[(from + j) >> 2] >> (2 * ((from + j) & 3))) & 3) + 1);
+        for (; j + 4 <= n; j += 4) {
+            const uint32_t b = s[(from + j) >> 2];
+            const uint32_t v = ((b & 3u) | (b & 0xcu) << 6 | (b & 0x30u) << 12 | (b & 0xc0u) << 18) + 0x01010101u;   /* little endian: base j in the low byte */
+            memcpy(dst + j, &v, 4);
+        }
+    }
+    for (; j < n; ++j) dst[j] = (char)fmd_ovlp_row_base(x->rec, x->max_nei, x->var, from + j);
 }
 /* Build the table of all n_seq sequence ids on the GPUs devices[0..n_dev): one host thread and one replica of the index
  * per device, shard g = ids g, g + n_dev, ...; rows that overflow the capacities are recomputed (device 0) with the

@@ -240,7 +240,7 @@ static void mark_used(walk_t *w, const uint64_t x[3]) /* set_bits, unitig.c:22-3
 /* Coverage string (unitig.c:251-255: '"' = one read, one more per read that covers the base, capped at '~').  Every
  * accepted extension adds one read over [rbeg, new end): kept as a difference array over a base string and
  * materialised when the string is needed -- min('~', base + reads) is the same whenever the cap is applied. */
-typedef struct { char *s; int32_t *d; size_t l, m; } cov_t;
+typedef struct { char *s; int32_t *d; size_t l, m; int dirty; } cov_t;   /* dirty: reads added since the last flush */
 static int cov_reserve(cov_t *c, size_t need)
 {
     if (need <= c->m) return 0;
@@ -262,18 +262,22 @@ static inline int cov_add(cov_t *c, size_t from, size_t to) /* one more read ove
     if (cov_reserve(c, to + 2)) return -ENOMEM;
     ++c->d[from]; --c->d[to];
     if (to > c->l) c->l = to;
+    c->dirty = 1;
     return 0;
 }
 static void cov_flush(cov_t *c, size_t l) /* materialise [0, l); everything beyond is dropped */
 {
-    size_t i;
+    size_t i, end;
     int32_t run = 0;
-    for (i = 0; i < l; ++i) {
-        run += c->d[i]; c->d[i] = 0;
-        { const int v = c->s[i] + run; c->s[i] = (char)(v > '~' ? '~' : v); }
-    }
-    for (; i <= c->l && i < c->m; ++i) { c->d[i] = 0; c->s[i] = '!'; }
-    c->l = l;
+    if (!c->dirty && l == c->l) return;                   /* nothing was added since this very flush */
+    if (c->dirty)
+        for (i = 0; i < l; ++i) {
+            run += c->d[i]; c->d[i] = 0;
+            { const int v = c->s[i] + run; c->s[i] = (char)(v > '~' ? '~' : v); }
+        }
+    end = c->l + 1 < c->m ? c->l + 1 : c->m;               /* [l, end): dropped */
+    if (end > l) { memset(c->d + l, 0, (end - l) * sizeof(int32_t)); memset(c->s + l, '!', end - l); }
+    c->l = l; c->dirty = 0;
 }
 
 static inline const fmd_ovlp_rec_t *REC(const walk_t *w, uint64_t row)
@@ -354,23 +358,81 @@ static int unidir(walk_t *w, uint64_t cur, str_t *s, cov_t *cov, int beg0, uint6
     return n_reads;
 }
 
-static void revcomp6(size_t l, char *s)
-{
-    size_t i;
-    for (i = 0; i < l >> 1; ++i) {
-        int a = s[i], b = s[l - 1 - i];
-        s[i] = (char)((b >= 1 && b <= 4) ? 5 - b : b);
-        s[l - 1 - i] = (char)((a >= 1 && a <= 4) ? 5 - a : a);
-    }
-    if (l & 1) { int a = s[i]; s[i] = (char)((a >= 1 && a <= 4) ? 5 - a : a); }
-}
+/* eight bytes at a time from both ends (byte swap), the middle byte by byte */
 static void reverse(size_t l, char *s)
 {
-    size_t i;
-    for (i = 0; i < l >> 1; ++i) { char t = s[i]; s[i] = s[l - 1 - i]; s[l - 1 - i] = t; }
+    size_t i = 0, j = l;
+    while (j - i >= 16) {
+        uint64_t a, b;
+        memcpy(&a, s + i, 8); memcpy(&b, s + j - 8, 8);
+        a = __builtin_bswap64(a); b = __builtin_bswap64(b);
+        memcpy(s + i, &b, 8); memcpy(s + j - 8, &a, 8);
+        i += 8; j -= 8;
+    }
+    for (; i + 1 < j; ++i, --j) { char t = s[i]; s[i] = s[j - 1]; s[j - 1] = t; }
+}
+/* reverse complement of nt6 codes: 1..4 -> 5 - v, 0 and 5 stay.  Words whose bytes are all 1..4 (nearly all) are complemented as
+ * 0x0505.. - w (no byte borrows); a word with a 0 or a 5 in it goes byte by byte. */
+static inline uint64_t comp6_word(uint64_t w)
+{
+    const uint64_t ones = 0x0101010101010101ull, five = 0x0505050505050505ull, x = w ^ five;
+    if ((((w - ones) & ~w) | ((x - ones) & ~x)) & 0x8080808080808080ull) {   /* some byte is 0 or 5 */
+        uint64_t r = 0; int k;
+        for (k = 0; k < 8; ++k) { const unsigned v = (unsigned)(w >> (8 * k)) & 0xff; r |= (uint64_t)((v >= 1 && v <= 4) ? 5 - v : v) << (8 * k); }
+        return r;
+    }
+    return five - w;
+}
+static void revcomp6(size_t l, char *s)
+{
+    size_t i = 0, j = l;
+    while (j - i >= 16) {
+        uint64_t a, b;
+        memcpy(&a, s + i, 8); memcpy(&b, s + j - 8, 8);
+        a = __builtin_bswap64(comp6_word(a)); b = __builtin_bswap64(comp6_word(b));
+        memcpy(s + i, &b, 8); memcpy(s + j - 8, &a, 8);
+        i += 8; j -= 8;
+    }
+    for (; i + 1 < j; ++i, --j) {
+        int a = s[i], b = s[j - 1];
+        s[i] = (char)((b >= 1 && b <= 4) ? 5 - b : b);
+        s[j - 1] = (char)((a >= 1 && a <= 4) ? 5 - a : a);
+    }
+    if (i < j) { int a = s[i]; s[i] = (char)((a >= 1 && a <= 4) ? 5 - a : a); }
 }
 
 typedef struct { uint64_t x, y; } link_t;
+
+/* nt6 codes -> the letters mag_v_write prints ("ACGT"[c - 1], mag.c:168: code 5 prints as NUL); returns non-zero if a NUL was
+ * written.  Sixteen bases per shuffle where the CPU has SSSE3 (a record of raw reads is half bases). */
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("ssse3"))) static int bases_to_text_ssse3(size_t n, const char *b, char *q)
+{
+    const __m128i lut = _mm_setr_epi8(0, 'A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0), five = _mm_set1_epi8(5);
+    size_t z = 0;
+    int cut = 0;
+    for (; z + 16 <= n; z += 16) {
+        const __m128i v = _mm_loadu_si128((const __m128i *)(b + z));
+        _mm_storeu_si128((__m128i *)(q + z), _mm_shuffle_epi8(lut, v));
+        cut |= _mm_movemask_epi8(_mm_cmpeq_epi8(v, five));
+    }
+    for (; z < n; ++z) { const int v = b[z]; q[z] = "ACGT"[v - 1]; cut |= v == 5; }
+    return cut;
+}
+#endif
+static int bases_to_text(size_t n, const char *b, char *q)
+{
+    size_t z;
+    int cut = 0;
+#if defined(__x86_64__)
+    static int have = -1;
+    if (have < 0) have = __builtin_cpu_supports("ssse3") ? 1 : 0;
+    if (have) return bases_to_text_ssse3(n, b, q);
+#endif
+    for (z = 0; z < n; ++z) { const int v = b[z]; q[z] = "ACGT"[v - 1]; cut |= v == 5; }
+    return cut;
+}
 
 /* decimal digits of v (what "%lld" prints) at p; returns the number of bytes.  A record of raw reads is one header of up to eight
  * numbers over ~200 bytes of text, and printf's parser is most of what such a record costs. */
@@ -430,8 +492,19 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
     if (hints) w.jump = build_jump(t->link, t->n);   /* 0: the plain chase */
     const int seed_stages = !(getenv("FMD_WALK_SEED_STAGES") && atoi(getenv("FMD_WALK_SEED_STAGES")) == 0);
     /* unitig_core with start = 0, step = 1 (unitig.c:333-334): seeds are the odd sequence ids */
+    /* FMD_WALK_PROFILE=1: where the walk's time goes (time-stamp counter around its sections; a diagnostic, printed to stderr) */
+    const int prof = getenv("FMD_WALK_PROFILE") != 0;
+    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, pn[2] = {0, 0}, pt = 0;
+#if defined(__x86_64__)
+#define PROF_T() (prof ? __builtin_ia32_rdtsc() : 0ull)
+#else
+#define PROF_T() 0ull
+#endif
+#define PROF_ADD(k_) do { if (prof) { const unsigned long long t_ = PROF_T(); pc[k_] += t_ - pt; pt = t_; } } while (0)
+    pt = PROF_T();
     for (j = 0; j <= n_seq >> 2; ++j) {
         for (i = j << 2 | 1; i < (j << 2) + 4 && i < n_seq; i += 2) {
+            PROF_ADD(0);                                             /* 0: seeds skipped or finished, hints, the tail of the previous record */
             if (hints) seed_hints(&w, i, seed_stages);
             const fmd_ovlp_rec_t *r = REC(&w, i);
             uint64_t end[2];
@@ -451,6 +524,8 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
             if (cov_add(&cov, 0, (size_t)seed_len)) { rc = -ENOMEM; goto done; }
             n_reads = 1;
             end[0] = r->k[1]; end[1] = r->k[0];
+            ++pn[0];
+            PROF_ADD(1);                                             /* 1: the seed's own row */
             if (r->n_ovlp) { /* left-wards extension of the unitig = right-wards of this strand */
                 int m = unidir(&w, i, &s, &cov, 0, r->k[0], &end[0], &is_loop);
                 if (m < 0) { rc = w.err ? w.err : -ENOMEM; goto done; }
@@ -460,10 +535,12 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
                   n_nei[0] = w.n_nei;
                   if (is_loop) { nei[1][0].x = end[0]; nei[1][0].y = ln[0].info; n_nei[1] = 1; done_loop = 1; } }
             }
+            PROF_ADD(2);                                             /* 2: the walk to the right */
             if (!done_loop) { /* the other direction, from the reverse strand of the seed (unitig.c:310-315) */
                 int m;
                 cov_flush(&cov, s.l);
                 revcomp6(s.l, s.s); reverse(s.l, cov.s);
+                PROF_ADD(3);                                         /* 3: turning the unitig round */
                 m = unidir(&w, i ^ 1, &s, &cov, (int)s.l - seed_len, r->k[1], &end[1], &is_loop);
                 if (m < 0) { rc = w.err ? w.err : -ENOMEM; goto done; }
                 n_reads += m;
@@ -471,6 +548,7 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
                   for (k = 0; k < w.n_nei; ++k) { nei[1][k].x = ln[k].x[0]; nei[1][k].y = ln[k].info; } }
                 n_nei[1] = w.n_nei;
             }
+            PROF_ADD(4);                                             /* 4: the walk to the left */
             /* ---- unitig_core: keep each unitig once (unitig.c:336-339) */
             if (bit_get(w.visited, end[0])) continue;
             bit_set(w.visited, end[0]);
@@ -484,16 +562,24 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
             if (put_links(&o, nei[0], n_nei[0]) || put_links(&o, nei[1], n_nei[1])) { rc = -ENOMEM; goto done; }
             if (str_reserve(&o, o.l + 2 * s.l + 8)) { rc = -ENOMEM; goto done; }
             o.s[o.l++] = '\n';
-            for (k = 0; k < (int)s.l; ++k) o.s[o.l++] = "ACGT"[(int)s.s[k] - 1];
+            const int cut = bases_to_text(s.l, s.s, o.s + o.l);      /* cut: a base that prints as NUL (see below) */
+            o.l += s.l;
             memcpy(o.s + o.l, "\n+\n", 3); o.l += 3;
             memcpy(o.s + o.l, cov.s, s.l); o.l += s.l;
             o.s[o.l++] = '\n';
             {   /* the reference prints the record with fputs (unitig.c:354): a base that is not A/C/G/T
                  * becomes "ACGT"[4] = NUL (mag.c:168) and cuts the record there.  Reproduced as is. */
-                size_t wl = strnlen(o.s, o.l);
+                size_t wl = cut ? strnlen(o.s, o.l) : o.l;
                 if ((rc = outq_put(&oq, o.s, wl)) != 0) goto done;
             }
+            ++pn[1];
+            PROF_ADD(5);                                             /* 5: formatting the record and handing it to the writer */
         }
+    }
+    if (prof) {
+        const double tot = (double)(pc[0] + pc[1] + pc[2] + pc[3] + pc[4] + pc[5]) + 1.0;
+        fprintf(stderr, "[M::%s] %llu seeds walked, %llu records written; shares of the walk's time: between seeds %.1f %%, the seed's row %.1f %%, walk to the right %.1f %%, turning round %.1f %%, walk to the left %.1f %%, formatting + hand-over %.1f %%\n",
+                __func__, pn[0], pn[1], 100 * pc[0] / tot, 100 * pc[1] / tot, 100 * pc[2] / tot, 100 * pc[3] / tot, 100 * pc[4] / tot, 100 * pc[5] / tot);
     }
 done:
     if (oq_open) { const int e = outq_close(&oq); if (!rc) rc = e; }
