@@ -4,9 +4,9 @@
 // compare by sequence id (ksa.c:54), so the BWT is the sort of all suffixes "sequence tail up to
 // and including its own $", ties broken by sequence id.  Short reads make that a fixed number
 // of stable LSD radix passes over 21-symbol (63-bit) key chunks: ceil((maxlen+1)/21) passes of
-// hipcub::DeviceRadixSort over (key, text position) pairs -- HBM-streaming work the MI355X does
+// rocPRIM's radix sort over (key, text position) pairs -- HBM-streaming work the MI355X does
 // in about a second for 2e9 suffixes, instead of SA-IS + merging on the host.
-#include <hipcub/hipcub.hpp>
+#include "fmd_prim.h"
 #include <stdlib.h>
 #include <vector>
 #include "fmd_internal.h"
@@ -128,7 +128,7 @@ __global__ void k_prefix_hist(Text text, uint64_t n, int depth, unsigned long lo
     for (uint32_t i = threadIdx.x; i < bins; i += blockDim.x) if (h_lds[i]) atomicAdd(&hist[i], (unsigned long long)h_lds[i]);
 }
 
-// The positions of one bucket, ascending.  hipcub::DeviceSelect over a counting iterator takes 0.65 s per pass over 5*10^10
+// The positions of one bucket, ascending.  a device-wide select over a counting iterator takes 0.65 s per pass over 5*10^10
 // symbols (156 buckets at depth 3, ~800 at depth 4); here a wave owns a tile of 2^16 consecutive positions: it counts its
 // matches, an exclusive scan over the tiles gives every tile its place, and the wave writes its matches in order with
 // ballot prefixes -- two coalesced sweeps over the text per bucket.
@@ -214,7 +214,7 @@ static int build_bucketed(hipStream_t st, Text text, uint64_t n, uint32_t max_le
     const uint64_t n_tiles = (n + (1ull << SEL_TILE_SHIFT) - 1) >> SEL_TILE_SHIFT;
     DevPtr tile_cnt, tile_off;
     DALLOC(tile_cnt, n_tiles * 8); DALLOC(tile_off, n_tiles * 8);
-    FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (uint64_t *)tile_cnt.p, (uint64_t *)tile_off.p, (size_t)n_tiles, st));
+    FMD_HIP_TRY(fmd_exclusive_sum(nullptr, tb, (uint64_t *)tile_cnt.p, (uint64_t *)tile_off.p, (size_t)n_tiles, st));
     DALLOC(tmp, tb);
     const unsigned sel_grid = (unsigned)(n_tiles / 4 + 1 < 65536 ? n_tiles / 4 + 1 : 65536);
     std::vector<unsigned long long> sizes((size_t)1 << (3 * depth), 0ull);
@@ -238,24 +238,24 @@ static int build_bucketed(hipStream_t st, Text text, uint64_t n, uint32_t max_le
             cap = m + m / 16;
             DALLOC(ids_a, cap * 8); DALLOC(ids_b, cap * 8); DALLOC(keys_a, cap * 8); DALLOC(keys_b, cap * 8);
             if (!bwt_direct) DALLOC(slice, cap + 64);
-            FMD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sb, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, (uint64_t *)ids_a.p,
+            FMD_HIP_TRY(fmd_sort_pairs(nullptr, sb, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, (uint64_t *)ids_a.p,
                                                           (uint64_t *)ids_b.p, (size_t)cap, 0, 63, st));
             DALLOC(stmp, sb);
         }
         k_tile_count<<<sel_grid, 256, 0, st>>>(text, n, depth, code, n_tiles, (uint64_t *)tile_cnt.p);
-        FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, (uint64_t *)tile_cnt.p, (uint64_t *)tile_off.p, (size_t)n_tiles, st));
+        FMD_HIP_TRY(fmd_exclusive_sum(tmp.p, tb, (uint64_t *)tile_cnt.p, (uint64_t *)tile_off.p, (size_t)n_tiles, st));
         k_tile_select<<<sel_grid, 256, 0, st>>>(text, n, depth, code, n_tiles, (const uint64_t *)tile_off.p, (uint64_t *)ids_a.p);
         uint64_t *cur = (uint64_t *)ids_a.p;
         if (!has_end) {
             uint64_t *nxt = (uint64_t *)ids_b.p;
             size_t sb_m = 0;
-            FMD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sb_m, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, cur, nxt, (size_t)m, 0, 63, st));
+            FMD_HIP_TRY(fmd_sort_pairs(nullptr, sb_m, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, cur, nxt, (size_t)m, 0, 63, st));
             for (int ch = n_chunks - 1; ch >= 0; --ch) {
                 if (uniform_len) k_chunk_keys64<<<nblk(m, 256), 256, 0, st>>>(text, m, cur, ch, RemUniform{max_len + 1}, (uint64_t *)keys_a.p);
                 else k_chunk_keys64<<<nblk(m, 256), 256, 0, st>>>(text, m, cur, ch, rr, (uint64_t *)keys_a.p);
                 // the first `depth` symbols are equal inside a bucket: chunk 0 sorts on the bits below them only
                 const int end_bit = ch == 0 ? 63 - 3 * (depth < 21 ? depth : 21) : 63;
-                FMD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(stmp.p, sb_m, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, cur, nxt, (size_t)m, 0, end_bit, st));
+                FMD_HIP_TRY(fmd_sort_pairs(stmp.p, sb_m, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, cur, nxt, (size_t)m, 0, end_bit, st));
                 uint64_t *t = cur; cur = nxt; nxt = t;
             }
         }
@@ -320,7 +320,7 @@ extern "C" int fmd_build_bwt_dev(int device, void *stream_, size_t n_reads, cons
     }
     DALLOC(keys_a, n * 8); DALLOC(keys_b, n * 8); DALLOC(ord_a, n * 4); DALLOC(ord_b, n * 4);
     size_t tmp_bytes = 0;
-    FMD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p,
+    FMD_HIP_TRY(fmd_sort_pairs(nullptr, tmp_bytes, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p,
                                                   (uint32_t *)ord_a.p, (uint32_t *)ord_b.p, (size_t)n, 0, 63, st));
     DALLOC(tmp, tmp_bytes);
     const int n_chunks = (int)((max_len + 1 + 20) / 21);
@@ -329,7 +329,7 @@ extern "C" int fmd_build_bwt_dev(int device, void *stream_, size_t n_reads, cons
     for (int c = n_chunks - 1; c >= 0; --c) {
         if (uniform_len) k_chunk_keys<<<nblk(n, 256), 256, 0, st>>>((const uint8_t *)text.p, n, cur, c, RemUniform{max_len + 1}, (uint64_t *)keys_a.p);
         else k_chunk_keys<<<nblk(n, 256), 256, 0, st>>>((const uint8_t *)text.p, n, cur, c, rr, (uint64_t *)keys_a.p);
-        FMD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, cur, nxt,
+        FMD_HIP_TRY(fmd_sort_pairs(tmp.p, tmp_bytes, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, cur, nxt,
                                                       (size_t)n, 0, 63, st));
         uint32_t *t = cur; cur = nxt; nxt = t;
     }
@@ -482,18 +482,18 @@ extern "C" int fmd_bwt_to_rle6(int device, const uint8_t *d_bwt, uint64_t n, uin
         DevPtr sym, len, nruns, tmp, nb, start, out;
         DALLOC(sym, m); DALLOC(len, m * 4); DALLOC(nruns, 8);
         size_t tb = 0;
-        FMD_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb, d_bwt + o, (uint8_t *)sym.p, (uint32_t *)len.p, (uint64_t *)nruns.p, (int)m));
+        FMD_HIP_TRY(fmd_run_length_encode(nullptr, tb, d_bwt + o, (unsigned)m, (uint8_t *)sym.p, (uint32_t *)len.p, (uint64_t *)nruns.p));
         DALLOC(tmp, tb);
-        FMD_HIP_TRY(hipcub::DeviceRunLengthEncode::Encode(tmp.p, tb, d_bwt + o, (uint8_t *)sym.p, (uint32_t *)len.p, (uint64_t *)nruns.p, (int)m));
+        FMD_HIP_TRY(fmd_run_length_encode(tmp.p, tb, d_bwt + o, (unsigned)m, (uint8_t *)sym.p, (uint32_t *)len.p, (uint64_t *)nruns.p));
         uint64_t n_runs = 0;
         FMD_HIP_TRY(hipMemcpy(&n_runs, nruns.p, 8, hipMemcpyDeviceToHost));
         DALLOC(nb, n_runs * 8); DALLOC(start, n_runs * 8);
         k_run_bytes<<<nblk(n_runs, 256), 256>>>((uint32_t *)len.p, n_runs, (uint64_t *)nb.p);
         {
             DevPtr t2; size_t b2 = 0;
-            FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, (uint64_t *)nb.p, (uint64_t *)start.p, (size_t)n_runs));
+            FMD_HIP_TRY(fmd_exclusive_sum(nullptr, b2, (uint64_t *)nb.p, (uint64_t *)start.p, (size_t)n_runs));
             DALLOC(t2, b2);
-            FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(t2.p, b2, (uint64_t *)nb.p, (uint64_t *)start.p, (size_t)n_runs));
+            FMD_HIP_TRY(fmd_exclusive_sum(t2.p, b2, (uint64_t *)nb.p, (uint64_t *)start.p, (size_t)n_runs));
             FMD_HIP_TRY(hipDeviceSynchronize());
         }
         uint64_t a = 0, b = 0;

@@ -1,7 +1,7 @@
 // fmd_index.hip -- index residency: upload a fermi .fmd (RLD\2 or RLE\6) or a plain BWT and
 // transcode it ON THE GPU into the fixed-stride rank-block layout of fmd_wave.h.
 // Replaces rld_restore / rld_restore_mmap / rld_destroy (rld.c:288, :327, :81) for the device.
-#include <hipcub/hipcub.hpp>
+#include "fmd_prim.h"
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
@@ -302,11 +302,11 @@ static int build_tail(fmd_dev *h)
 struct FmdWiden { __host__ __device__ uint64_t operator()(fmd_bc_t v) const { return (uint64_t)v; } };
 static int scan_counts(const fmd_bc_t *d_in, uint64_t *d_out, uint64_t n, hipStream_t st)
 {
-    hipcub::TransformInputIterator<uint64_t, FmdWiden, const fmd_bc_t *> in(d_in, FmdWiden());
+    rocprim::transform_iterator<const fmd_bc_t *, FmdWiden, uint64_t> in(d_in, FmdWiden());
     void *tmp = nullptr; size_t tmp_bytes = 0;
-    FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, in, d_out, (size_t)n, st));
+    FMD_HIP_TRY(fmd_exclusive_sum(nullptr, tmp_bytes, in, d_out, (size_t)n, st));
     FMD_HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-    hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, in, d_out, (size_t)n, st);
+    hipError_t e = fmd_exclusive_sum(tmp, tmp_bytes, in, d_out, (size_t)n, st);
     hipError_t e2 = hipStreamSynchronize(st);
     hipFree(tmp);
     FMD_HIP_TRY(e); FMD_HIP_TRY(e2);
@@ -316,9 +316,9 @@ static int scan_counts(const fmd_bc_t *d_in, uint64_t *d_out, uint64_t n, hipStr
 static int scan_u64(uint64_t *d_in, uint64_t *d_out, uint64_t n, hipStream_t st)
 {
     void *tmp = nullptr; size_t tmp_bytes = 0;
-    FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_in, d_out, (size_t)n, st));
+    FMD_HIP_TRY(fmd_exclusive_sum(nullptr, tmp_bytes, d_in, d_out, (size_t)n, st));
     FMD_HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-    hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, d_in, d_out, (size_t)n, st);
+    hipError_t e = fmd_exclusive_sum(tmp, tmp_bytes, d_in, d_out, (size_t)n, st);
     hipError_t e2 = hipStreamSynchronize(st);
     hipFree(tmp);
     FMD_HIP_TRY(e); FMD_HIP_TRY(e2);

@@ -12,7 +12,7 @@
 // best (correct.c:71-73).
 #include <stdlib.h>
 #include <string.h>
-#include <hipcub/hipcub.hpp>
+#include "fmd_prim.h"
 #include "fmd_internal.h"
 #include "fmd_kernel_common.h"
 
@@ -354,9 +354,9 @@ extern "C" int fmd_kmer_collect_part_dev(fmd_dev_t *h, void *stream_, int w, int
     k_kmer_emit<<<grid, 64, 0, st>>>(ix, w, suf_len, min_occ, in, r_bucket, r_key, r_val, r_flag, cap, ctr, xcd_aware);
     k_km_count<<<(unsigned)n_tiles, 256, 0, st>>>(r_flag, cap, tile_cnt);
     size_t tmp_bytes = 0;
-    FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, tile_cnt, tile_off, (size_t)n_tiles, st));
+    FMD_HIP_TRY(fmd_exclusive_sum(nullptr, tmp_bytes, tile_cnt, tile_off, (size_t)n_tiles, st));
     if (tmp_bytes > (4u << 20)) return FMD_E_ARG;
-    FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tail, tmp_bytes, tile_cnt, tile_off, (size_t)n_tiles, st));
+    FMD_HIP_TRY(fmd_exclusive_sum(tail, tmp_bytes, tile_cnt, tile_off, (size_t)n_tiles, st));
     k_km_scatter<<<(unsigned)n_tiles, 256, 0, st>>>(r_flag, cap, tile_off, tile_cnt, n_tiles, r_bucket, r_key, r_val, d_bucket, d_key, d_val, ctr);
     FMD_HIP_TRY(hipMemcpyAsync(d_status, ctr + KM_OUT, 4 * 8, hipMemcpyDeviceToDevice, st));
     hipError_t e = hipGetLastError();
@@ -389,9 +389,9 @@ static int km_sort_triples(uint64_t m, int suf_len, uint32_t *db, uint32_t *dk, 
         const unsigned nb = (unsigned)((m + 255) / 256);
         k_km_pack<<<nb, 256>>>(m, db, dk, ka);
         const int end_bit = 32 + 2 * suf_len;
-        if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ka, kb, dv, vb, (int)m, 0, end_bit) != hipSuccess ||
+        if (fmd_sort_pairs(nullptr, tmp_bytes, ka, kb, dv, vb, (int)m, 0, end_bit) != hipSuccess ||
             hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16) != hipSuccess) rc = FMD_E_NOMEM;
-        else if (hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, ka, kb, dv, vb, (int)m, 0, end_bit) != hipSuccess) rc = FMD_E_HIP;
+        else if (fmd_sort_pairs(tmp, tmp_bytes, ka, kb, dv, vb, (int)m, 0, end_bit) != hipSuccess) rc = FMD_E_HIP;
         else {
             k_km_unpack<<<nb, 256>>>(m, kb, db, dk);
             if (hipMemcpy(dv, vb, m, hipMemcpyDeviceToDevice) != hipSuccess) rc = FMD_E_HIP;

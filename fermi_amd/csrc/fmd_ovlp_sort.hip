@@ -9,7 +9,7 @@
 // the strand's end as the low bits of the key, so that strands sharing a minimizer are in genome order among themselves.
 // 3.5 strands per key at 30x; measured on the 50 M-read set: 100 M strands in 269 ms in this order, 254 ms in true genome order,
 // 367 ms in id order (profiles/r3_locality).
-#include <hipcub/hipcub.hpp>
+#include "fmd_prim.h"
 #include "fmd_kernel_common.h"
 
 #define PARK_K 16u                                   // bases per k-mer (2 bits each: one 32-bit word)
@@ -55,7 +55,7 @@ __global__ void k_ovl_park_keys(size_t n, const FmdWalkPark *__restrict__ park, 
 size_t fmd_park_sort_temp_bytes(size_t n)
 {
     size_t tb = 0;
-    if (hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 32, (hipStream_t)0) != hipSuccess) {
+    if (fmd_sort_pairs(nullptr, tb, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 32, (hipStream_t)0) != hipSuccess) {
         (void)hipGetLastError();
         tb = 16 * n + (1u << 20);   // more than any version of the sort has asked for
     }
@@ -67,6 +67,6 @@ int fmd_park_sort(hipStream_t st, size_t n, const FmdWalkPark *park, uint32_t *k
     size_t blocks = (n + 255) / 256;
     if (blocks > (1u << 20)) blocks = 1u << 20;
     k_ovl_park_keys<<<(unsigned)blocks, 256, 0, st>>>(n, park, keys_a, vals_a);
-    FMD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (const uint32_t *)keys_a, keys_b, (const uint32_t *)vals_a, vals_b, n, 0, 32, st));
+    FMD_HIP_TRY(fmd_sort_pairs(tmp, tmp_bytes, (const uint32_t *)keys_a, keys_b, (const uint32_t *)vals_a, vals_b, n, 0, 32, st));
     return FMD_OK;
 }

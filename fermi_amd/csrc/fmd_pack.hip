@@ -21,7 +21,7 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
-#include <hipcub/hipcub.hpp>
+#include "fmd_prim.h"
 #include "fmd_kernel_common.h"
 
 // bytes of row i's variable part; *pack4 = the sequence needs 4 bits per base
@@ -98,7 +98,7 @@ extern "C" size_t fmd_ovlp_pack_max_bytes(size_t n, uint32_t max_nei, uint32_t s
 extern "C" size_t fmd_ovlp_pack_work_bytes(size_t n)
 {
     size_t tb = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (uint64_t *)nullptr, (uint64_t *)nullptr, n + 1);
+    fmd_exclusive_sum(nullptr, tb, (uint64_t *)nullptr, (uint64_t *)nullptr, n + 1);
     return (n + 1) * 8 + ((tb + 255) & ~(size_t)255) + 256;
 }
 
@@ -114,11 +114,11 @@ extern "C" int fmd_ovlp_pack_dev(fmd_dev_t *h, void *stream_, size_t n, const fm
     uint64_t *sizes = (uint64_t *)d_work;
     void *tmp = (uint8_t *)d_work + (((n + 1) * 8 + 255) & ~(size_t)255);
     size_t tb = 0;
-    FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, sizes, d_off, n + 1, st));
+    FMD_HIP_TRY(fmd_exclusive_sum(nullptr, tb, sizes, d_off, n + 1, st));
     size_t blocks = (n + 256) / 256;
     if (blocks > (1u << 20)) blocks = 1u << 20;
     k_pack_sizes<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, max_nei, d_seq, seq_stride, sizes);
-    FMD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, tb, sizes, d_off, n + 1, st));
+    FMD_HIP_TRY(fmd_exclusive_sum(tmp, tb, sizes, d_off, n + 1, st));
     blocks = (n + 31) / 32;
     if (blocks > (1u << 20)) blocks = 1u << 20;
     k_pack_rows<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, d_nei, max_nei, d_seq, seq_stride, d_prec, d_off, d_var, var_cap);
@@ -242,9 +242,14 @@ extern "C" void *fmd_table_alloc(size_t bytes)
         const size_t page = 4096, asz = (bytes + page - 1) / page * page;
         std::string path = std::string(dir) + "/fmdtab.XXXXXX";
         const int fd = mkstemp(&path[0]);
+        int err = errno;   // (of the call that failed, for the warning below)
         if (fd >= 0) {
             unlink(path.c_str());
-            void *p = ftruncate(fd, (off_t)asz) == 0 ? mmap(nullptr, asz, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
+            // the space is RESERVED (posix_fallocate), not just promised (ftruncate): a device that fills up is an allocation
+            // failure here and the anonymous-memory fallback below, not a SIGBUS at first touch in the middle of the walk
+            void *p = MAP_FAILED;
+            err = posix_fallocate(fd, 0, (off_t)asz);
+            if (err == 0) { p = mmap(nullptr, asz, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0); if (p == MAP_FAILED) err = errno; }
             close(fd);
             if (p != MAP_FAILED) {
 #ifdef MADV_RANDOM
@@ -256,7 +261,7 @@ extern "C" void *fmd_table_alloc(size_t bytes)
             }
         }
         static bool warned = false;
-        if (!warned) { warned = true; fprintf(stderr, "[W::%s] FMD_TABLE_DIR=%s: no file pages (%s); anonymous memory instead\n", __func__, dir, strerror(errno)); }
+        if (!warned) { warned = true; fprintf(stderr, "[W::%s] FMD_TABLE_DIR=%s: no file pages (%s); anonymous memory instead\n", __func__, dir, strerror(err)); }
     }
     if (bytes < 16 * huge) return malloc(bytes);
     void *p = nullptr;
@@ -329,7 +334,9 @@ static int packed_batch_core(fmd_dev_t *h, const uint64_t *ids, uint64_t first, 
         const size_t rows = n * (8 + sizeof(fmd_ovlp_rec_t) + max_nei * sizeof(fmd_intv_t) + (size_t)stride), pk = 2 * (m * sizeof(fmd_ovlp_rec_t) + (m + 1) * 8 + cap);
         for (size_t bt = (size_t)1 << 24; bt >= ((size_t)1 << 12); bt >>= 1) {
             const size_t b2 = bt < n ? bt : n, w2 = fmd_ovlp_sorted_work_bytes(n, b2, max_len, min_match);
-            if (rows + pk + (w2 > wb1 ? w2 : wb1) + ((size_t)2 << 30) <= free_b) { sorted_batch = b2; sorted_wb = w2 > wb1 ? w2 : wb1; break; }
+            // (the area also serves the per-chunk steps that follow the job: check_left of a chunk of m rows needs wb0, the pack wb1)
+            const size_t w = w2 > wb ? w2 : wb;
+            if (rows + pk + w + ((size_t)2 << 30) <= free_b) { sorted_batch = b2; sorted_wb = w; break; }
         }
     }
     const size_t mr = sorted_batch ? n : m;   // rows the fixed-stride arrays hold

@@ -409,15 +409,15 @@ typedef struct { uint64_t x, y; } link_t;
 #include <immintrin.h>
 __attribute__((target("ssse3"))) static int bases_to_text_ssse3(size_t n, const char *b, char *q)
 {
-    const __m128i lut = _mm_setr_epi8(0, 'A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0), five = _mm_set1_epi8(5);
+    const __m128i lut = _mm_setr_epi8(0, 'A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0), zero = _mm_setzero_si128();
     size_t z = 0;
     int cut = 0;
     for (; z + 16 <= n; z += 16) {
-        const __m128i v = _mm_loadu_si128((const __m128i *)(b + z));
-        _mm_storeu_si128((__m128i *)(q + z), _mm_shuffle_epi8(lut, v));
-        cut |= _mm_movemask_epi8(_mm_cmpeq_epi8(v, five));
+        const __m128i t = _mm_shuffle_epi8(lut, _mm_loadu_si128((const __m128i *)(b + z)));
+        _mm_storeu_si128((__m128i *)(q + z), t);
+        cut |= _mm_movemask_epi8(_mm_cmpeq_epi8(t, zero));   /* any code that is not A/C/G/T (5 = N; 0 never occurs in a unitig) */
     }
-    for (; z < n; ++z) { const int v = b[z]; q[z] = "ACGT"[v - 1]; cut |= v == 5; }
+    for (; z < n; ++z) { const unsigned v = (unsigned char)b[z]; q[z] = v < 6 ? "\0ACGT"[v] : 0; cut |= q[z] == 0; }
     return cut;
 }
 #endif
@@ -430,7 +430,7 @@ static int bases_to_text(size_t n, const char *b, char *q)
     if (have < 0) have = __builtin_cpu_supports("ssse3") ? 1 : 0;
     if (have) return bases_to_text_ssse3(n, b, q);
 #endif
-    for (z = 0; z < n; ++z) { const int v = b[z]; q[z] = "ACGT"[v - 1]; cut |= v == 5; }
+    for (z = 0; z < n; ++z) { const unsigned v = (unsigned char)b[z]; q[z] = v < 6 ? "\0ACGT"[v] : 0; cut |= q[z] == 0; }
     return cut;
 }
 

@@ -211,7 +211,8 @@ int fmd_ovlp_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_ids, in
  * how often a rank block is found in cache).  Two strands whose last bases lie d positions apart on the genome visit the same rank
  * blocks d steps apart; in input order each such visit is a DRAM miss.  Pass 1 takes every strand 32 bases in and parks it (64 bytes
  * per strand); the strands are sorted by the minimizer of those 32 bases; pass 2 + fm6_get_nei then run batch by batch in that
- * order and write row i of d_rec / d_nei / d_seq for ids[i] as fmd_ovlp_dev does -- byte for byte.  `batch` strands share the work
+ * order and write row i of d_rec / d_nei / d_seq for ids[i] with the contents fmd_ovlp_dev gives them: the record in full, the first
+ * min(n_nei, max_nei) neighbours, the first len + ext_len bytes of the sequence row (bytes of a row beyond those are unspecified in both).  `batch` strands share the work
  * area of one fmd_ovlp_dev call (0 = n); work_bytes >= fmd_ovlp_sorted_work_bytes(n, batch, ..).  Where the two-pass form does not
  * apply (min_match < 32, FMD_OVLP_SORT=0) the batches are taken in id order. */
 size_t fmd_ovlp_sorted_work_bytes(size_t n, size_t batch, uint32_t max_len, int min_match);
