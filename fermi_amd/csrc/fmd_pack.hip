@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <time.h>
 #include <sys/mman.h>
+#include <fcntl.h>
 #include <errno.h>
 #include <string.h>
 #include <unistd.h>
