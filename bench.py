@@ -454,32 +454,92 @@ class OverlapJob:
 def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world, rank, fmd_path, local_rank, legs):
     min_match = int(os.environ.get("FMD_BENCH_MINMATCH", "50"))
     n_ids = 2 * n_reads
-    job = OverlapJob(torch, api, index, dev, n_ids, rank, world, L, min_match)
-    gathered = [None]
-    gather_ms = []
-    if world > 1:
-        job.alloc_packed()
+    # ---- N > 1: the step behind the C ABI (fmd_ovlp_dist_step): pass 1 on the id shard, [the parked strands all-to-all by key,] pass 2 in
+    # pieces whose rows are packed and sent to rank 0 under the compute of the next piece; transport = RCCL created through the C ABI
+    # (fmd_comm_rccl_*), or -- FMD_BENCH_BACKEND=gloo, the one-GPU test form -- torch.distributed through the fmd_comm_t callbacks.
+    # FMD_BENCH_COMM=torch: round 3's step (compute, pack, ONE gather through torch.distributed), kept as the fallback.
+    djob = comm = None
+    if world > 1 and os.environ.get("FMD_BENCH_COMM", "c") != "torch":
+        from fermi_amd import dist as fdist
+        ok = torch.ones(1, dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        try:
+            comm = fdist.RcclComm(api, dist, rank, world, local_rank) if dist.get_backend() == "nccl" else fdist.TorchComm(api, dist, rank, world)
+            djob = fdist.DistJob(api, index, comm, n_ids, min_match, L, 4, pieces=int(os.environ.get("FMD_BENCH_PIECES", "0")),
+                                 key_shard=int(os.environ.get("FMD_BENCH_KEY_SHARD", "1")), root=0, host_table=int(os.environ.get("FMD_BENCH_HOST_TABLE", "-1")),
+                                 batch=int(os.environ.get("FMD_BENCH_OVLP_BATCH", "0")))
+        except Exception as ex:
+            log("[rank %d] the C-ABI step is not available here (%r): falling back to the torch.distributed gather" % (rank, ex))
+            ok[0] = 0
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if djob:
+                djob.free()
+            djob = None
+    if djob is not None:
+        stream = torch.cuda.current_stream()
+        sh = C.c_void_p(stream.cuda_stream)
+        stats = []
+        wd = fdist.Watchdog(int(os.environ.get("FMD_BENCH_GATHER_TIMEOUT", "600")), "the N > 1 overlap step (fmd_ovlp_dist_step)")
 
-    def step():
-        if world > 1:
-            ec0 = torch.cuda.Event(enable_timing=True); ec0.record(job.stream)
+        def step():
+            with wd:
+                stats.append(djob.step(sh).as_dict())
+        wall, _ = timed(torch, dist, dev, stream, step, steps, warmup)
+        st = {k: (float(np.mean([x[k] for x in stats[-steps:]])) if isinstance(stats[-1][k], float) else stats[-1][k]) for k in stats[-1]}
+        kern_ms = st["head_ms"] + st["key_exchange_ms"] + st["tail_ms"]
+        gather_note = None
+        if rank == 0:
+            try:
+                gather_note = fdist.check_table(torch, api, index, djob, n_ids, min_match, L, 4, dev)
+            except Exception as ex:   # the check must not take the benchmark line down
+                gather_note = "check failed to run: %r" % (ex,)
+        tot_rx = st["bytes_received"]
+        djob.free()
+        if comm:
+            comm.free()
+        torch.cuda.empty_cache()
+        if rank != 0:
+            return None, None
+        # rank 0 prices its own id shard as the N = 1 line does: the same kernels over the ids 0, N, 2N, ... once more, untimed
+        job = OverlapJob(torch, api, index, dev, n_ids, rank, world, L, min_match)
         job.compute()
-        if world > 1:   # the records leave the GPU they were computed on: pack, then the RCCL gather on rank 0
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(job.stream)
-            job.pack()
-            gathered[0] = job.gather(dist)
-            e1.record(job.stream)
-            gather_ms.append((ec0, e0, e1))
-    wall, kern_ms = timed(torch, dist, dev, job.stream, step, steps, warmup)
+        torch.cuda.synchronize()
+        record_gather = {"path": "fmd_ovlp_dist_step (C ABI): %d pieces, %s, table %s" % (st["pieces"], "pass 2 sharded by minimizer key (one all-to-all of the parked strands)" if st["key_shard"] else "pass 2 on the id shard",
+                                                                                        "in pinned host memory" if st["on_host"] else "in rank 0's HBM"),
+                         "transport": "RCCL %d through fmd_comm_rccl_* (ncclAllGather + grouped ncclSend / ncclRecv)" % api.lib().fmd_comm_rccl_version() if dist.get_backend() == "nccl" else "torch.distributed/%s through the fmd_comm_t callbacks" % dist.get_backend(),
+                         "gather_exposed_ms": st["gather_exposed_ms"], "last_piece_pack_plus_send_ms": st["last_piece_pack_send_ms"],
+                         "rank0_ms": {"pass1_and_sort": st["head_ms"], "key_exchange_and_resort": st["key_exchange_ms"], "pass2_all_pieces": st["tail_ms"], "step_host_clock": st["step_ms"]},
+                         "bytes_received_by_rank0": tot_rx, "bytes_per_strand": tot_rx / max(1, n_ids - st["rows_computed"]), "check": gather_note,
+                         "key_rows_sent_by_rank0": st["key_rows_sent"], "discovery_kernels_ms_per_step_on_rank0": kern_ms}
+        gathered, g_ms, gather_ms = None, None, []
+    else:
+        job = OverlapJob(torch, api, index, dev, n_ids, rank, world, L, min_match)
+        record_gather = None
+        gathered = [None]
+        gather_ms = []
+        if world > 1:
+            job.alloc_packed()
+
+        def step():
+            if world > 1:
+                ec0 = torch.cuda.Event(enable_timing=True); ec0.record(job.stream)
+            job.compute()
+            if world > 1:   # the records leave the GPU they were computed on: pack, then the RCCL gather on rank 0
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(job.stream)
+                job.pack()
+                gathered[0] = job.gather(dist)
+                e1.record(job.stream)
+                gather_ms.append((ec0, e0, e1))
+        wall, kern_ms = timed(torch, dist, dev, job.stream, step, steps, warmup)
+        g_ms = float(np.mean([a.elapsed_time(b) for _, a, b in gather_ms[-steps:]])) if gather_ms else None
+        if gather_ms:   # the discovery kernels of this rank alone (what its roofline is priced on)
+            kern_ms = float(np.mean([c.elapsed_time(a) for c, a, _ in gather_ms[-steps:]]))
     out = None
-    g_ms = float(np.mean([a.elapsed_time(b) for _, a, b in gather_ms[-steps:]])) if gather_ms else None
-    if gather_ms:   # the discovery kernels of this rank alone (what its roofline is priced on)
-        kern_ms = float(np.mean([c.elapsed_time(a) for c, a, _ in gather_ms[-steps:]]))
 
     # ---- N > 1, outside the timed region: rank 0 recomputes a sample of ids itself and compares with what arrived
-    gather_note = None
-    if world > 1 and rank == 0:
+    if record_gather is None and world > 1 and rank == 0:
+        gather_note = None
         from fermi_amd import dist as fdist
         try:
             gather_note = fdist.check_gathered(torch, api, job, gathered[0], n_ids, world)
@@ -494,10 +554,13 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
            "overflow_records": int(((g_rec["flags"] & api.OVLP_F_OVERFLOW) != 0).sum()),
            "contained": int((g_rec["status"] == -3).sum()), "with_neighbour": int((g_rec["n_nei"] > 0).sum())}
     if world > 1:
-        tot = sum(int(t[0].numel() + t[2].numel() + t[1].numel() * 8) for t in gathered[0][1:])
-        out["record_gather_rccl"] = {"ms_per_step_pack_plus_gather": g_ms, "bytes_received_by_rank0": tot, "path": job.gatherer.path,
-                                     "bytes_per_strand": tot / max(1, n_ids - job.n), "check": gather_note,
-                                     "discovery_kernels_ms_per_step_on_rank0": kern_ms}
+        if record_gather is not None:
+            out["record_gather_rccl"] = record_gather
+        else:
+            tot = sum(int(t[0].numel() + t[2].numel() + t[1].numel() * 8) for t in gathered[0][1:])
+            out["record_gather_rccl"] = {"ms_per_step_pack_plus_gather": g_ms, "bytes_received_by_rank0": tot, "path": job.gatherer.path,
+                                         "bytes_per_strand": tot / max(1, n_ids - job.n), "check": gather_note,
+                                         "discovery_kernels_ms_per_step_on_rank0": kern_ms}
         if not fmd_path:
             return out, job
     n_loc = job.n               # rows of this rank (all of them at N = 1); everything below is about rank 0's own shard

@@ -33,6 +33,9 @@ ABI_SYMBOLS = [
     "fmd_ectab_build_dev", "fmd_ectab_build", "fmd_ectab_free", "fmd_ecfix_work_bytes", "fmd_ecfix_dev", "fmd_ecfix_batch",
     "fmd_ovlp_work_bytes", "fmd_ovlp_dev", "fmd_ovlp_sorted_work_bytes", "fmd_ovlp_sorted_dev", "fmd_ovlp_batch", "fmd_ovlp_check_left_dev", "fmd_seqinfo_dev", "fmd_seqinfo_batch",
     "fmd_ovlp_pack_max_bytes", "fmd_ovlp_pack_work_bytes", "fmd_ovlp_pack_dev", "fmd_ovlp_packed_batch", "fmd_ovlp_packed_free", "fmd_table_alloc", "fmd_table_free", "fmd_ovlp_link_dev", "fmd_ovlp_packed_table",
+    "fmd_ovlp_two_pass_ok", "fmd_ovlp_head_work_bytes", "fmd_ovlp_head_dev", "fmd_ovlp_tail_dev", "fmd_ovlp_pack_rows_dev",
+    "fmd_comm_rccl_unique_id", "fmd_comm_rccl_init", "fmd_comm_rccl_version", "fmd_comm_free",
+    "fmd_ovlp_dist_new", "fmd_ovlp_dist_step", "fmd_ovlp_dist_table", "fmd_ovlp_dist_local", "fmd_ovlp_dist_free",
 ]
 
 
@@ -129,6 +132,20 @@ def _configure(L):
     L.fmd_table_alloc.restype = vp; L.fmd_table_alloc.argtypes = [sz]
     L.fmd_table_free.restype = None; L.fmd_table_free.argtypes = [vp]
     L.fmd_ovlp_pack_dev.argtypes = [vp, vp, sz, vp, vp, C.c_uint32, vp, C.c_uint32, vp, vp, vp, C.c_uint64, vp, sz]
+    L.fmd_ovlp_two_pass_ok.argtypes = [vp, sz, C.c_int, C.c_uint32]
+    L.fmd_ovlp_head_work_bytes.restype = sz; L.fmd_ovlp_head_work_bytes.argtypes = [sz]
+    L.fmd_ovlp_head_dev.argtypes = [vp, vp, sz, u64p, C.c_int, C.c_uint32, vp, vp, vp, vp, vp, sz]
+    L.fmd_ovlp_tail_dev.argtypes = [vp, vp, sz, vp, vp, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint32, vp, sz]
+    L.fmd_ovlp_pack_rows_dev.argtypes = [vp, vp, sz, vp, vp, C.c_uint64, C.c_uint64, vp, vp, C.c_uint32, vp, C.c_uint32, vp, vp, vp, vp, C.c_uint64, vp, sz]
+    L.fmd_comm_rccl_unique_id.argtypes = [vp]
+    L.fmd_comm_rccl_init.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.fmd_comm_rccl_version.restype = C.c_int
+    L.fmd_comm_free.restype = None; L.fmd_comm_free.argtypes = [vp]
+    L.fmd_ovlp_dist_new.argtypes = [vp, vp, vp, C.POINTER(vp)]
+    L.fmd_ovlp_dist_step.argtypes = [vp, vp, vp]
+    L.fmd_ovlp_dist_table.argtypes = [vp, vp]
+    L.fmd_ovlp_dist_local.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint32)]
+    L.fmd_ovlp_dist_free.restype = None; L.fmd_ovlp_dist_free.argtypes = [vp]
     return L
 
 

@@ -1327,6 +1327,101 @@ static bool sorted_eligible(const fmd_dev *h, size_t n, int min_match, uint32_t 
     return n < 0xffffff00ull && min_match >= (int)FMD_WALK_SPLIT && max_len >= FMD_WALK_SPLIT && h->ptab_d < (int)FMD_WALK_SPLIT && !getenv("FMD_OVLP_UNFUSED");
 }
 
+// ---- the two halves of the sorted job as entry points of their own: a caller may do something between them (hand finished rows on
+// while the rest is being computed; exchange the parked strands between GPUs by key: fmd_ovlp_dist.hip) --------------------------------
+extern "C" int fmd_ovlp_two_pass_ok(const fmd_dev_t *h, size_t n, int min_match, uint32_t max_len)
+{
+    return h && sorted_eligible(h, n, min_match, max_len) && fmd_ovlp_list_cap(max_len, min_match) < 4096 ? 1 : 0;
+}
+// work area of the head: the admission records (32 bytes per strand), the unsorted (key, row) arrays, the sort's temporary storage
+struct HeadLayout { size_t adm, keys_a, vals_a, tmp, tmp_bytes, total; };
+static HeadLayout head_layout(size_t n)
+{
+    HeadLayout L;
+    size_t o = 0;
+    L.keys_a = o; o += align_up(n * 4, 256);
+    L.vals_a = o; o += align_up(n * 4, 256);
+    L.tmp_bytes = fmd_park_sort_temp_bytes(n);
+    L.tmp = o; o += align_up(L.tmp_bytes, 256);
+    L.adm = o; o += align_up(n * 32, 256);
+    L.total = o;
+    return L;
+}
+extern "C" size_t fmd_ovlp_head_work_bytes(size_t n) { return head_layout(n).total; }
+
+// pass 1 with the arrays where the caller wants them: park[n], the sorted keys and the order (row of the t-th strand in key order)
+static int ovl_head(fmd_dev *h, hipStream_t st, size_t n, const uint64_t *d_ids, int min_match, uint32_t seq_stride, fmd_ovlp_rec_t *d_rec, FmdWalkPark *park,
+                    uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_sorted, uint32_t *order, void *tmp, size_t tmp_bytes, uint4 *adm)
+{
+    const FmdIndexView ix = fmd_view(h);
+    // pass 1: every strand FMD_WALK_SPLIT bases in, in the caller's order.  (Taking the strands in the order of their last ptab_d bases --
+    // the tail table has them, one more radix sort -- makes this pass 7 % faster and costs what it saves: profiles/r3_locality.)
+    {
+        const uint32_t *order1 = nullptr;
+        const int use_tail = ix.tail != nullptr && ix.ptab != nullptr && min_match >= ix.ptab_d && ix.ptab_d >= 2;
+        size_t blocks = (n + 255) / 256;
+        if (blocks > (1u << 20)) blocks = 1u << 20;
+        k_ovl_head_adm<<<(unsigned)blocks, 256, 0, st>>>(ix, n, d_ids, order1, use_tail, adm);
+        uint32_t *q = fmd_next_queue(h, st);
+        int grid = fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16);
+        { const char *e = getenv("FMD_HEAD_WAVES"); if (e && atoi(e) > 0 && grid > h->n_cu * atoi(e)) grid = h->n_cu * atoi(e); }
+        k_ovl_walk<WALK_HEAD><<<grid, 64, 0, st>>>(ix, n, d_ids, min_match, nullptr, (uint32_t)sizeof(FmdWalkPark), 0, nullptr, d_rec,
+                                                nullptr, seq_stride, q, 0, park, nullptr, adm, walk_ticket_chunk("FMD_HEAD_TICKETS", 256, n, grid));
+    }
+    // the order of pass 2: rows sorted by the minimizer of the bases each strand has shown so far
+    return fmd_park_sort(st, n, park, keys_a, keys_sorted, vals_a, order, tmp, tmp_bytes);
+}
+
+extern "C" int fmd_ovlp_head_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_t *d_ids, int min_match, uint32_t max_len, fmd_ovlp_rec_t *d_rec,
+                                 void *d_park, uint32_t *d_keys, uint32_t *d_order, void *d_work, size_t work_bytes)
+{
+    if (!h || (n && (!d_ids || !d_rec || !d_park || !d_keys || !d_order || !d_work)) || max_len == 0 || min_match < 0) return FMD_E_ARG;
+    if (n == 0) return FMD_OK;
+    if (!fmd_ovlp_two_pass_ok(h, n, min_match, max_len)) return FMD_E_ARG;
+    const HeadLayout L = head_layout(n);
+    if (work_bytes < L.total) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    uint8_t *w = (uint8_t *)d_work;
+    const int rc = ovl_head(h, (hipStream_t)stream_, n, d_ids, min_match, 2 * max_len, d_rec, (FmdWalkPark *)d_park, (uint32_t *)(w + L.keys_a), (uint32_t *)(w + L.vals_a),
+                            d_keys, d_order, w + L.tmp, L.tmp_bytes, (uint4 *)(w + L.adm));
+    if (rc != FMD_OK) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fmd_set_hip_error(e, "sorted overlap job: head"); return FMD_E_HIP; }
+    return FMD_OK;
+}
+
+// pass 2 + fm6_get_nei for np parked strands: slot t of the call = row d_rows[t] of d_park, d_rec, d_nei and d_seq
+static int ovl_tail(fmd_dev *h, hipStream_t st, size_t np, const uint32_t *rows, FmdWalkPark *park, const uint64_t *d_ids, int min_match, uint32_t max_len, uint32_t max_nei,
+                    fmd_ovlp_rec_t *d_rec, fmd_intv_t *d_nei, uint8_t *d_seq, uint32_t seq_stride, uint8_t *area, size_t area_strands)
+{
+    OvlBatch o;
+    o.h = h; o.ix = fmd_view(h); o.ids = d_ids; o.min_match = min_match; o.max_len = max_len; o.max_nei = max_nei; o.seq_stride = seq_stride;
+    o.stride_r = (uint32_t)align_up(max_len, 16);
+    o.cap = fmd_ovlp_list_cap(max_len, min_match);
+    o.srev = area;
+    o.listA = (fmd_intv_t *)(o.srev + align_up(area_strands * (size_t)o.stride_r, 256));
+    o.listB = (fmd_intv_t *)((uint8_t *)o.listA + align_up(area_strands * (size_t)o.cap * sizeof(fmd_intv_t), 256));
+    o.cls = (uint32_t *)((uint8_t *)o.listB + align_up(area_strands * (size_t)o.cap * sizeof(fmd_intv_t), 256));
+    o.rec = d_rec; o.nei = d_nei; o.seq = d_seq; o.park = park;
+    o.gidx = rows;
+    ovl_phase_a(o, st, 0, np, 0);
+    return ovl_phase_b(o, st, 0, np, 0, 0, 0);
+}
+
+extern "C" int fmd_ovlp_tail_dev(fmd_dev_t *h, void *stream_, size_t np, const uint32_t *d_rows, void *d_park, int min_match, uint32_t max_len, uint32_t max_nei,
+                                 fmd_ovlp_rec_t *d_rec, fmd_intv_t *d_nei, uint8_t *d_seq, uint32_t seq_stride, void *d_work, size_t work_bytes)
+{
+    if (!h || (np && (!d_rows || !d_park || !d_rec || !d_nei || !d_seq || !d_work)) || max_len == 0 || max_nei == 0 || min_match < 0) return FMD_E_ARG;
+    if (np == 0) return FMD_OK;
+    if (np >= 0xffffff00ull || !fmd_ovlp_two_pass_ok(h, np, min_match, max_len) || work_bytes < fmd_ovlp_work_bytes(np, max_len, min_match)) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    const int rc = ovl_tail(h, (hipStream_t)stream_, np, d_rows, (FmdWalkPark *)d_park, nullptr, min_match, max_len, max_nei, d_rec, d_nei, d_seq, seq_stride, (uint8_t *)d_work, np);
+    if (rc != FMD_OK) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fmd_set_hip_error(e, "sorted overlap job: tail"); return FMD_E_HIP; }
+    return FMD_OK;
+}
+
 extern "C" int fmd_ovlp_sorted_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_t *d_ids, int min_match, uint32_t max_len,
                                    uint32_t max_nei, fmd_ovlp_rec_t *d_rec, fmd_intv_t *d_nei, uint8_t *d_seq, uint32_t seq_stride,
                                    void *d_work, size_t work_bytes, size_t batch)
@@ -1352,43 +1447,16 @@ extern "C" int fmd_ovlp_sorted_dev(fmd_dev_t *h, void *stream_, size_t n, const 
     uint8_t *w = (uint8_t *)d_work;
     FmdWalkPark *park = (FmdWalkPark *)(w + L.park);
     uint32_t *sorted = (uint32_t *)(w + L.vals_b);
-    const FmdIndexView ix = fmd_view(h);
-    // pass 1: every strand FMD_WALK_SPLIT bases in, in the caller's order.  (Taking the strands in the order of their last ptab_d bases --
-    // the tail table has them, one more radix sort -- makes this pass 7 % faster and costs what it saves: profiles/r3_locality.)
+    // (the admission records live in the batch area, which is idle until pass 2; 32 bytes per strand of the job)
     {
-        const uint32_t *order1 = nullptr;
-        // (the admission records live in the batch area, which is idle until pass 2; 32 bytes per strand of the job)
-        uint4 *adm = (uint4 *)(w + L.batch_area);
-        const int use_tail = ix.tail != nullptr && ix.ptab != nullptr && min_match >= ix.ptab_d && ix.ptab_d >= 2;
-        size_t blocks = (n + 255) / 256;
-        if (blocks > (1u << 20)) blocks = 1u << 20;
-        k_ovl_head_adm<<<(unsigned)blocks, 256, 0, st>>>(ix, n, d_ids, order1, use_tail, adm);
-        uint32_t *q = fmd_next_queue(h, st);
-        int grid = fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16);
-        { const char *e = getenv("FMD_HEAD_WAVES"); if (e && atoi(e) > 0 && grid > h->n_cu * atoi(e)) grid = h->n_cu * atoi(e); }
-        k_ovl_walk<WALK_HEAD><<<grid, 64, 0, st>>>(ix, n, d_ids, min_match, nullptr, (uint32_t)sizeof(FmdWalkPark), 0, nullptr, d_rec,
-                                                nullptr, seq_stride, q, 0, park, nullptr, adm, walk_ticket_chunk("FMD_HEAD_TICKETS", 256, n, grid));
-    }
-    // the order of pass 2: rows sorted by the minimizer of the bases each strand has shown so far
-    {
-        const int rc = fmd_park_sort(st, n, park, (uint32_t *)(w + L.keys_a), (uint32_t *)(w + L.keys_b), (uint32_t *)(w + L.vals_a), sorted, w + L.tmp, L.tmp_bytes);
+        const int rc = ovl_head(h, st, n, d_ids, min_match, seq_stride, d_rec, park, (uint32_t *)(w + L.keys_a), (uint32_t *)(w + L.vals_a), (uint32_t *)(w + L.keys_b), sorted,
+                                w + L.tmp, L.tmp_bytes, (uint4 *)(w + L.batch_area));
         if (rc != FMD_OK) return rc;
     }
     // pass 2 + fm6_get_nei, batch by batch in that order
-    OvlBatch o;
-    o.h = h; o.ix = ix; o.ids = d_ids; o.min_match = min_match; o.max_len = max_len; o.max_nei = max_nei; o.seq_stride = seq_stride;
-    o.stride_r = (uint32_t)align_up(max_len, 16);
-    o.cap = fmd_ovlp_list_cap(max_len, min_match);
-    o.srev = w + L.batch_area;
-    o.listA = (fmd_intv_t *)(o.srev + align_up(batch * (size_t)o.stride_r, 256));
-    o.listB = (fmd_intv_t *)((uint8_t *)o.listA + align_up(batch * (size_t)o.cap * sizeof(fmd_intv_t), 256));
-    o.cls = (uint32_t *)((uint8_t *)o.listB + align_up(batch * (size_t)o.cap * sizeof(fmd_intv_t), 256));
-    o.rec = d_rec; o.nei = d_nei; o.seq = d_seq; o.park = park;
     for (size_t b = 0; b < n; b += batch) {
         const size_t np = n - b < batch ? n - b : batch;
-        o.gidx = sorted + b;
-        ovl_phase_a(o, st, 0, np, 0);
-        const int rc = ovl_phase_b(o, st, 0, np, 0, 0, 0);
+        const int rc = ovl_tail(h, st, np, sorted + b, park, d_ids, min_match, max_len, max_nei, d_rec, d_nei, d_seq, seq_stride, w + L.batch_area, batch);
         if (rc != FMD_OK) return rc;
     }
     hipError_t e = hipGetLastError();

@@ -1,0 +1,662 @@
+// fmd_ovlp_dist.hip -- overlap discovery on N GPUs: the two exchange steps of the path and the transport behind the C ABI.
+//
+// The reference joins its N workers over ONE shared index for nothing (pthreads, unitig.c:394-404) and emits results as they are
+// found (unitig.c:353-354).  N GPUs hold N replicas of the index; two things move:
+//   (a) the finished rows, to the rank that runs the walk -- in PIECES: pass 2 runs batch by batch in the sorted order, and while
+//       batch p + 1 is computed the rows of batch p are packed on a second stream (fmd_ovlp_pack_rows_dev: ~137 bytes per strand
+//       with its id) and sent to the root, every peer over its own xGMI link (direct sends, no ring).  Only the LAST piece's pack +
+//       transfer cannot hide under compute;
+//   (b) optionally the parked strands between the two passes (64 bytes each), all-to-all by minimizer key range: pass 1 is sharded
+//       by id (the reference's worker interleave, unitig.c:333, 398-399), pass 2 by KEY, so that all strands of a genomic window
+//       meet on one GPU and the rank blocks they share are fetched once -- a rank then sees the coverage of the whole read set on
+//       1/N of the genome instead of 1/N of the coverage everywhere.
+// The transport is fmd_comm_t (include/fmd_hip.h): RCCL here (librccl is loaded on first use, so that a single-GPU host never needs
+// it), anything else through the two callbacks.
+#include <dlfcn.h>
+#include <string.h>
+#include <stdlib.h>
+#include <time.h>
+#include <vector>
+#include "fmd_kernel_common.h"
+#include "fmd_internal.h"
+
+// (fmd_ovlp_sort.hip)
+size_t fmd_park_sort_temp_bytes(size_t n);
+int fmd_park_sort(hipStream_t st, size_t n, const FmdWalkPark *park, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *tmp, size_t tmp_bytes);
+
+static inline double now_s() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ------------------------------------------------------------------------------------------------ RCCL transport
+namespace {
+typedef int ncclResult_t_;
+typedef struct { char internal[128]; } ncclUniqueId_;
+struct Rccl {
+    void *so = nullptr;
+    ncclResult_t_ (*GetVersion)(int *) = nullptr;
+    ncclResult_t_ (*GetUniqueId)(ncclUniqueId_ *) = nullptr;
+    ncclResult_t_ (*CommInitRank)(void **, int, ncclUniqueId_, int) = nullptr;
+    ncclResult_t_ (*CommDestroy)(void *) = nullptr;
+    ncclResult_t_ (*GroupStart)() = nullptr;
+    ncclResult_t_ (*GroupEnd)() = nullptr;
+    ncclResult_t_ (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    ncclResult_t_ (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    ncclResult_t_ (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t_) = nullptr;
+    bool ok = false;
+};
+const int kNcclUint8 = 1;   // ncclUint8 (rccl.h ncclDataType_t: ncclInt8 = 0, ncclUint8 = 1)
+Rccl &rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    const char *names[] = {getenv("FMD_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names) { if (nm && *nm && (r.so = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break; }
+    if (!r.so) return r;
+#define RSYM(f) *(void **)(&r.f) = dlsym(r.so, "nccl" #f)
+    RSYM(GetVersion); RSYM(GetUniqueId); RSYM(CommInitRank); RSYM(CommDestroy); RSYM(GroupStart); RSYM(GroupEnd); RSYM(Send); RSYM(Recv); RSYM(AllGather); RSYM(GetErrorString);
+#undef RSYM
+    r.ok = r.GetVersion && r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.AllGather;
+    return r;
+}
+struct RcclCtx { void *comm; int device; };
+int rccl_fail(ncclResult_t_ e, const char *what)
+{
+    Rccl &r = rccl();
+    fprintf(stderr, "[E::fmd_comm_rccl] %s: %s\n", what, r.GetErrorString ? r.GetErrorString(e) : "error");
+    return FMD_E_HIP;
+}
+int rccl_allgather(void *ctx, void *stream, const void *d_send, void *d_recv, size_t bytes)
+{
+    RcclCtx *c = (RcclCtx *)ctx;
+    const ncclResult_t_ e = rccl().AllGather(d_send, d_recv, bytes, kNcclUint8, c->comm, (hipStream_t)stream);
+    return e ? rccl_fail(e, "ncclAllGather") : FMD_OK;
+}
+int rccl_exchange(void *ctx, void *stream, int n_ops, const fmd_comm_op_t *ops)
+{
+    RcclCtx *c = (RcclCtx *)ctx;
+    Rccl &r = rccl();
+    if (n_ops <= 0) return FMD_OK;
+    ncclResult_t_ e = r.GroupStart();
+    if (e) return rccl_fail(e, "ncclGroupStart");
+    for (int i = 0; i < n_ops && !e; ++i) {
+        if (ops[i].bytes == 0) continue;
+        e = ops[i].is_recv ? r.Recv(ops[i].d_ptr, ops[i].bytes, kNcclUint8, ops[i].peer, c->comm, (hipStream_t)stream)
+                           : r.Send(ops[i].d_ptr, ops[i].bytes, kNcclUint8, ops[i].peer, c->comm, (hipStream_t)stream);
+    }
+    const ncclResult_t_ e2 = r.GroupEnd();
+    if (e) return rccl_fail(e, "ncclSend / ncclRecv");
+    return e2 ? rccl_fail(e2, "ncclGroupEnd") : FMD_OK;
+}
+void rccl_destroy(void *ctx)
+{
+    RcclCtx *c = (RcclCtx *)ctx;
+    if (c) { if (c->comm) rccl().CommDestroy(c->comm); delete c; }
+}
+}   // namespace
+
+extern "C" int fmd_comm_rccl_version(void)
+{
+    Rccl &r = rccl();
+    int v = 0;
+    if (!r.ok || r.GetVersion(&v)) return 0;
+    return v;
+}
+extern "C" int fmd_comm_rccl_unique_id(uint8_t id[FMD_COMM_ID_BYTES])
+{
+    Rccl &r = rccl();
+    if (!id) return FMD_E_ARG;
+    if (!r.ok) return FMD_E_NODEV;
+    ncclUniqueId_ u;
+    const ncclResult_t_ e = r.GetUniqueId(&u);
+    if (e) return rccl_fail(e, "ncclGetUniqueId");
+    memcpy(id, u.internal, FMD_COMM_ID_BYTES);
+    return FMD_OK;
+}
+extern "C" int fmd_comm_rccl_init(int device, int rank, int world, const uint8_t id[FMD_COMM_ID_BYTES], fmd_comm_t **out)
+{
+    if (!out || !id || world < 1 || rank < 0 || rank >= world) return FMD_E_ARG;
+    *out = nullptr;
+    Rccl &r = rccl();
+    if (!r.ok) return FMD_E_NODEV;
+    FMD_HIP_TRY(hipSetDevice(device));
+    ncclUniqueId_ u;
+    memcpy(u.internal, id, FMD_COMM_ID_BYTES);
+    void *comm = nullptr;
+    const ncclResult_t_ e = r.CommInitRank(&comm, world, u, rank);
+    if (e) return rccl_fail(e, "ncclCommInitRank");
+    fmd_comm_t *c = (fmd_comm_t *)calloc(1, sizeof(fmd_comm_t));
+    RcclCtx *x = new RcclCtx{comm, device};
+    c->rank = rank; c->world = world; c->ctx = x;
+    c->allgather = rccl_allgather; c->exchange = rccl_exchange; c->destroy = rccl_destroy;
+    *out = c;
+    return FMD_OK;
+}
+extern "C" void fmd_comm_free(fmd_comm_t *c)
+{
+    if (!c) return;
+    if (c->destroy) c->destroy(c->ctx);
+    if (c->destroy == rccl_destroy) free(c);
+}
+
+// ------------------------------------------------------------------------------------------------ key shard: kernels
+// Destination of a strand by its minimizer key: W equal ranges of the 32-bit key space (the keys are hashes: uniform); the two
+// special keys (0xffffffff: the strand ended inside the head; 0xfffffffe: no k-mer without an ambiguous base) stay where they are.
+__host__ __device__ static inline uint32_t ks_first_key(int p, int world) { return (uint32_t)((((uint64_t)p << 32) + (uint64_t)world - 1) / (uint64_t)world); }
+
+// counts[p], p < world: strands for rank p; counts[world]: strands that stay (special keys).  keys ascending.
+__global__ void k_ks_counts(size_t n, const uint32_t *__restrict__ keys, int world, unsigned long long *__restrict__ counts)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > world) return;
+    auto lower = [&](uint32_t v) { size_t lo = 0, hi = n; while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (keys[mid] < v) lo = mid + 1; else hi = mid; } return lo; };
+    const size_t a = p < world ? lower(ks_first_key(p, world)) : lower(0xfffffffeu);
+    const size_t b = p + 1 < world ? lower(ks_first_key(p + 1, world)) : (p + 1 == world ? lower(0xfffffffeu) : n);
+    counts[p] = (unsigned long long)(b - a);
+}
+// the parked strands in key order, each stamped with its sequence id (pad.x/y); a strand that ended inside the head carries what
+// its record needs (rank in x0, length in x1: k_ks_unpack rebuilds the record wherever the row ends up).  4 lanes per row.
+__global__ void k_ks_gather(size_t n, const uint32_t *__restrict__ order, const FmdWalkPark *__restrict__ park, const uint64_t *__restrict__ ids,
+                            const fmd_ovlp_rec_t *__restrict__ rec, FmdWalkPark *__restrict__ send)
+{
+    const size_t step = (size_t)gridDim.x * (blockDim.x >> 2);
+    const int l4 = threadIdx.x & 3;
+    for (size_t t = (size_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2); t < n; t += step) {
+        const size_t row = order[t];
+        uint4 v = ((const uint4 *)(park + row))[l4];
+        const uint4 a = l4 == 0 ? v : ((const uint4 *)(park + row))[0];
+        const bool ended = a.x == 0xffffffffu && a.y == 0xffffffffu;
+        if (l4 == 3) { const uint64_t id = ids[row]; v = make_uint4((uint32_t)id, (uint32_t)(id >> 32), 0u, 0u); }
+        if (ended && l4 == 0) { const uint64_t rk = rec[row].rank; v.z = (uint32_t)rk; v.w = (uint32_t)(rk >> 32); }
+        if (ended && l4 == 1) { v.x = (uint32_t)rec[row].len; v.y = 0; }
+        ((uint4 *)(send + t))[l4] = v;
+    }
+}
+// after the exchange: ids of the rows this rank now owns; final records of the ones that ended inside the head
+__global__ void k_ks_unpack(size_t m, const FmdWalkPark *__restrict__ park, uint64_t *__restrict__ ids, fmd_ovlp_rec_t *__restrict__ rec)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += step) {
+        const FmdWalkPark *p = park + j;
+        ids[j] = (uint64_t)p->pad.y << 32 | p->pad.x;
+        if (p->k == ~0ull) {   // what k_ovl_walk<WALK_HEAD> wrote for it on the rank that took it in (fmd_ovlp.hip)
+            fmd_ovlp_rec_t o;
+            o.rank = p->x0; o.k[0] = o.k[1] = o.k[2] = 0; o.len = (int32_t)p->x1; o.status = FMD_OVLP_SHORT; o.n_ovlp = 0; o.rbeg = -1;
+            o.ext_len = 0; o.n_nei = 0; o.flags = 0; o.reserved = 2; o.lfork = 0;
+            rec[j] = o;
+        }
+    }
+}
+__global__ void k_iota32(size_t n, uint32_t *v)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) v[i] = (uint32_t)i;
+}
+__global__ void k_fill_ids64(size_t n, uint64_t first, uint64_t step_, uint64_t *ids)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) ids[i] = first + step_ * i;
+}
+// root: a piece has arrived at rows [row0, row0 + np) of the table: where each row's variable part is, which row holds which id
+__global__ void k_place(size_t np, const uint32_t *__restrict__ pid, const uint64_t *__restrict__ off, uint64_t var_base, uint64_t row0,
+                        uint64_t *__restrict__ vaddr, uint32_t *__restrict__ row_of_id, uint64_t n_ids)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < np; t += step) {
+        vaddr[t] = var_base + off[t];
+        const uint32_t id = pid[t];
+        if (id < n_ids) row_of_id[id] = (uint32_t)(row0 + t);
+    }
+}
+static inline unsigned nblk(size_t n, unsigned per) { size_t b = (n + per - 1) / per; if (b > (1u << 20)) b = 1u << 20; return (unsigned)(b ? b : 1); }
+
+// ------------------------------------------------------------------------------------------------ the job object
+namespace {
+struct DBuf {   // device memory owned by the job
+    void *p = nullptr; size_t bytes = 0;
+    int need(size_t b) { if (b <= bytes) return FMD_OK; if (p) { hipFree(p); p = nullptr; bytes = 0; } if (hipMalloc(&p, b ? b : 16) != hipSuccess) { (void)hipGetLastError(); return FMD_E_NOMEM; } bytes = b; return FMD_OK; }
+    void drop() { if (p) hipFree(p); p = nullptr; bytes = 0; }
+};
+struct HBuf {   // pinned host memory owned by the job
+    void *p = nullptr; size_t bytes = 0;
+    int need(size_t b) { if (b <= bytes) return FMD_OK; if (p) { hipHostFree(p); p = nullptr; bytes = 0; } if (hipHostMalloc(&p, b ? b : 16, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return FMD_E_NOMEM; } bytes = b; return FMD_OK; }
+    void drop() { if (p) hipHostFree(p); p = nullptr; bytes = 0; }
+};
+struct Arena {  // variable parts at the root: large chunks, allocated when first needed, kept between steps
+    bool host = false;
+    size_t chunk_bytes = 0;
+    std::vector<void *> chunks;
+    size_t cur = 0, used = 0;   // chunk in use, bytes used in it
+    void reset() { cur = 0; used = 0; }
+    void *take(size_t bytes)
+    {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (bytes > chunk_bytes) return nullptr;
+        if (cur < chunks.size() && used + bytes > chunk_bytes) { ++cur; used = 0; }
+        if (cur >= chunks.size()) {
+            void *p = nullptr;
+            if ((host ? hipHostMalloc(&p, chunk_bytes, hipHostMallocDefault) : hipMalloc(&p, chunk_bytes)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            chunks.push_back(p);
+            cur = chunks.size() - 1; used = 0;
+        }
+        void *r = (uint8_t *)chunks[cur] + used;
+        used += bytes;
+        return r;
+    }
+    void shrink_last(size_t taken, size_t kept) { taken = (taken + 255) & ~(size_t)255; kept = (kept + 255) & ~(size_t)255; if (kept < taken && used >= taken - kept) used -= taken - kept; }
+    void drop() { for (void *p : chunks) { if (host) hipHostFree(p); else hipFree(p); } chunks.clear(); reset(); }
+};
+struct Stage { DBuf pid, prec, off, var, vaddr; };   // one piece of one peer on its way through HBM (host table), or this rank's piece on its way out
+}   // namespace
+
+struct fmd_ovlp_dist {
+    fmd_dev *h; fmd_comm_t *comm; fmd_ovlp_dist_cfg_t cfg;
+    int rank, world, two_pass, pieces, on_host;
+    uint32_t stride;
+    uint64_t n_home, cap_rows, n_rows;          // strands of pass 1; capacity / number of the rows this rank computes
+    size_t piece_max, var_cap_piece;
+    DBuf ids_home, ids_loc, park_home, park_send, park_loc, keys, order, rec, nei, seq, work, pack_work, cnt_dev, sizes_dev;
+    HBuf cnt_host, sizes_host;
+    Stage out[2];                               // this rank's piece on its way out (non-root: set 0; root with a host table: set p & 1)
+    std::vector<Stage> in[2];                   // root, host mode: staging per peer, two sets
+    // the table at the root
+    DBuf t_prec, t_ids, t_vaddr, t_row_of, t_off;   // (t_off: per peer (piece_max + 1) offsets of the piece being placed)
+    HBuf th_prec, th_ids, th_vaddr, th_row_of;
+    Arena var;
+    hipStream_t sm = nullptr, s3 = nullptr;
+    std::vector<hipEvent_t> done;               // piece p computed (compute stream)
+    hipEvent_t ev[8] = {};                      // timing + joins
+    hipEvent_t staged[2] = {}, drained[2] = {};
+    fmd_ovlp_dist_stats_t last;
+    const uint64_t *loc_ids;                    // ids of the rows this rank computed in the last step
+};
+
+static uint64_t shard_size(uint64_t n_ids, int r, int world) { return n_ids > (uint64_t)r ? (n_ids - (uint64_t)r + (uint64_t)world - 1) / (uint64_t)world : 0; }
+static uint64_t piece_begin(uint64_t rows, int p, int pieces) { return (uint64_t)((unsigned __int128)rows * (unsigned)p / (unsigned)pieces); }
+
+extern "C" void fmd_ovlp_dist_free(fmd_ovlp_dist_t *d)
+{
+    if (!d) return;
+    hipSetDevice(d->h->device);
+    hipDeviceSynchronize();
+    DBuf *bs[] = {&d->ids_home, &d->ids_loc, &d->park_home, &d->park_send, &d->park_loc, &d->keys, &d->order, &d->rec, &d->nei, &d->seq, &d->work, &d->pack_work, &d->cnt_dev,
+                  &d->sizes_dev, &d->t_prec, &d->t_ids, &d->t_vaddr, &d->t_row_of, &d->t_off, &d->out[0].pid, &d->out[0].prec, &d->out[0].off, &d->out[0].var, &d->out[0].vaddr, &d->out[1].pid, &d->out[1].prec, &d->out[1].off, &d->out[1].var, &d->out[1].vaddr};
+    for (DBuf *b : bs) b->drop();
+    for (int k = 0; k < 2; ++k) for (Stage &s : d->in[k]) { s.pid.drop(); s.prec.drop(); s.off.drop(); s.var.drop(); s.vaddr.drop(); }
+    HBuf *hs[] = {&d->cnt_host, &d->sizes_host, &d->th_prec, &d->th_ids, &d->th_vaddr, &d->th_row_of};
+    for (HBuf *b : hs) b->drop();
+    d->var.drop();
+    for (hipEvent_t e : d->done) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : d->ev) if (e) hipEventDestroy(e);
+    for (int k = 0; k < 2; ++k) { if (d->staged[k]) hipEventDestroy(d->staged[k]); if (d->drained[k]) hipEventDestroy(d->drained[k]); }
+    if (d->sm) hipStreamDestroy(d->sm);
+    if (d->s3) hipStreamDestroy(d->s3);
+    (void)hipGetLastError();
+    delete d;
+}
+
+extern "C" int fmd_ovlp_dist_new(fmd_dev_t *h, fmd_comm_t *comm, const fmd_ovlp_dist_cfg_t *cfg, fmd_ovlp_dist_t **out)
+{
+    if (!h || !comm || !cfg || !out || !comm->allgather || !comm->exchange || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world) return FMD_E_ARG;
+    if (cfg->n_ids == 0 || cfg->n_ids >= 0xffffff00ull || cfg->max_len == 0 || cfg->max_nei == 0 || cfg->min_match < 0 || cfg->root < 0 || cfg->root >= comm->world) return FMD_E_ARG;
+    *out = nullptr;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    fmd_ovlp_dist *d = new fmd_ovlp_dist();
+    d->h = h; d->comm = comm; d->cfg = *cfg; d->rank = comm->rank; d->world = comm->world;
+    d->stride = 2 * ((cfg->max_len + 3) / 4 * 4);
+    d->n_home = shard_size(cfg->n_ids, d->rank, d->world);
+    const uint64_t n_max = shard_size(cfg->n_ids, 0, d->world);   // the largest shard
+    d->two_pass = fmd_ovlp_two_pass_ok(h, (size_t)(n_max + n_max / 8 + 65536), cfg->min_match, cfg->max_len);
+    if (!d->two_pass) d->cfg.key_shard = 0;
+    if (d->world == 1) d->cfg.key_shard = 0;
+    // key shard: the keys are hashes, a rank's share of them is n / world +- a few sigma; room for 1/8 more, and a collective
+    // fall-back to the id shard for the step in which any rank would exceed it (a read set that is one repeat)
+    d->cap_rows = d->cfg.key_shard ? d->n_home + d->n_home / 8 + 65536 : d->n_home;
+    // pieces: the same number on every rank
+    {
+        const uint64_t bmax = cfg->batch ? cfg->batch : 20000000ull;
+        uint64_t P = cfg->pieces ? cfg->pieces : 4;
+        const uint64_t rows_max = d->cfg.key_shard ? n_max + n_max / 8 + 65536 : n_max;
+        if ((rows_max + P - 1) / P > bmax) P = (rows_max + bmax - 1) / bmax;
+        if (!cfg->pieces) while (P > 1 && n_max / P < 262144) --P;
+        if (P > 4096) P = 4096;
+        d->pieces = (int)P;
+        d->piece_max = (size_t)((rows_max + P - 1) / P + 1);
+    }
+    d->var_cap_piece = fmd_ovlp_pack_max_bytes(d->piece_max, cfg->max_nei, d->stride);
+    int rc = FMD_OK;
+#define NEED(buf, bytes) do { if (rc == FMD_OK) rc = (buf).need(bytes); } while (0)
+    NEED(d->ids_home, d->n_home * 8);
+    NEED(d->rec, d->cap_rows * sizeof(fmd_ovlp_rec_t));
+    NEED(d->nei, d->cap_rows * (size_t)cfg->max_nei * sizeof(fmd_intv_t));
+    NEED(d->seq, d->cap_rows * (size_t)d->stride);
+    NEED(d->order, d->cap_rows * 4);
+    if (d->two_pass) {
+        NEED(d->keys, d->cap_rows * 4);
+        NEED(d->park_home, d->n_home * sizeof(FmdWalkPark));
+        if (d->cfg.key_shard) { NEED(d->park_send, d->n_home * sizeof(FmdWalkPark)); NEED(d->park_loc, d->cap_rows * sizeof(FmdWalkPark)); NEED(d->ids_loc, d->cap_rows * 8); }
+    }
+    {
+        size_t wb = fmd_ovlp_work_bytes(d->piece_max, cfg->max_len, cfg->min_match);
+        if (d->two_pass) { const size_t hb = fmd_ovlp_head_work_bytes((size_t)d->cap_rows); if (hb > wb) wb = hb; }
+        NEED(d->work, wb);
+    }
+    NEED(d->pack_work, fmd_ovlp_pack_work_bytes(d->piece_max));
+    NEED(d->cnt_dev, (size_t)(d->world + 1) * 8 * (size_t)(d->world + 1));
+    NEED(d->sizes_dev, 16 * (size_t)(d->world + 1));
+    if (rc == FMD_OK) rc = d->cnt_host.need((size_t)(d->world + 1) * 8 * (size_t)(d->world + 1));
+    if (rc == FMD_OK) rc = d->sizes_host.need(16 * (size_t)(d->world + 1));
+    // where the table lives at the root
+    const bool root = d->rank == cfg->root;
+    d->on_host = 0;
+    if (root) {
+        const uint64_t n = cfg->n_ids;
+        const size_t table_dev = n * (sizeof(fmd_ovlp_rec_t) + 4 + 8 + 4) + n * (size_t)(cfg->max_nei * 8 + 72);   // fixed parts + a usual variable part
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        d->on_host = cfg->host_table > 0 || (cfg->host_table < 0 && table_dev + ((size_t)6 << 30) > free_b) ? 1 : 0;
+        NEED(d->t_row_of, n * 4);
+        if (!d->on_host) { NEED(d->t_prec, n * sizeof(fmd_ovlp_rec_t)); NEED(d->t_ids, n * 4); NEED(d->t_vaddr, n * 8); NEED(d->t_off, (size_t)d->world * (d->piece_max + 1) * 8); }
+        else {
+            if (rc == FMD_OK) rc = d->th_prec.need(n * sizeof(fmd_ovlp_rec_t));
+            if (rc == FMD_OK) rc = d->th_ids.need(n * 4);
+            if (rc == FMD_OK) rc = d->th_vaddr.need(n * 8);
+            if (rc == FMD_OK) rc = d->th_row_of.need(n * 4);
+            for (int k = 0; k < 2 && rc == FMD_OK; ++k) {
+                d->in[k].resize((size_t)d->world);
+                for (int q = 0; q < d->world && rc == FMD_OK; ++q) {
+                    Stage &s = d->in[k][(size_t)q];
+                    NEED(s.pid, d->piece_max * 4); NEED(s.prec, d->piece_max * sizeof(fmd_ovlp_rec_t)); NEED(s.off, (d->piece_max + 1) * 8); NEED(s.var, d->var_cap_piece); NEED(s.vaddr, d->piece_max * 8);
+                }
+            }
+        }
+        d->var.host = d->on_host != 0;
+        d->var.chunk_bytes = d->var_cap_piece > ((size_t)256 << 20) ? up256(d->var_cap_piece) : ((size_t)256 << 20);
+    }
+    for (int k = 0; k < (root && d->on_host ? 2 : (root ? 0 : 1)); ++k) { NEED(d->out[k].pid, d->piece_max * 4); NEED(d->out[k].prec, d->piece_max * sizeof(fmd_ovlp_rec_t)); NEED(d->out[k].off, (d->piece_max + 1) * 8); NEED(d->out[k].var, d->var_cap_piece); }
+#undef NEED
+    if (rc == FMD_OK) {
+        int lo = 0, hi = 0;
+        bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&d->sm, hipStreamNonBlocking, hi) == hipSuccess;   // the transfers first, when a slot frees up
+        if (!ok) { (void)hipGetLastError(); ok = hipStreamCreateWithFlags(&d->sm, hipStreamNonBlocking) == hipSuccess; }
+        ok = ok && hipStreamCreateWithFlags(&d->s3, hipStreamNonBlocking) == hipSuccess;
+        d->done.resize((size_t)d->pieces, nullptr);
+        for (int p = 0; p < d->pieces && ok; ++p) ok = hipEventCreateWithFlags(&d->done[(size_t)p], hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < 8 && ok; ++k) ok = hipEventCreate(&d->ev[k]) == hipSuccess;
+        for (int k = 0; k < 2 && ok; ++k) ok = hipEventCreateWithFlags(&d->staged[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&d->drained[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { fmd_set_hip_error(hipGetLastError(), "overlap job on N GPUs: streams and events"); rc = FMD_E_HIP; }
+    }
+    if (rc != FMD_OK) { fmd_ovlp_dist_free(d); return rc; }
+    k_fill_ids64<<<nblk(d->n_home, 256), 256>>>(d->n_home, (uint64_t)d->rank, (uint64_t)d->world, (uint64_t *)d->ids_home.p);
+    FMD_HIP_TRY(hipDeviceSynchronize());
+    memset(&d->last, 0, sizeof(d->last));
+    *out = d;
+    return FMD_OK;
+}
+
+// the all-to-all of the parked strands; on return park_loc / ids_loc / keys / order describe the rows this rank computes.
+// *fell_back = 1: some rank's share would not fit (decided the same way on every rank): the step runs on the id shard.
+static int key_exchange(fmd_ovlp_dist *d, hipStream_t sc, uint64_t *rows_out, std::vector<uint64_t> &rows_of_rank, int *fell_back, uint64_t *sent_rows)
+{
+    const int W = d->world, me = d->rank;
+    const size_t n = d->n_home;
+    unsigned long long *cnt = (unsigned long long *)d->cnt_dev.p;           // [W + 1] mine, then [W][W + 1] everybody's
+    k_ks_counts<<<(W + 1 + 63) / 64, 64, 0, sc>>>(n, (const uint32_t *)d->keys.p, W, cnt);
+    k_ks_gather<<<nblk(n, 64), 256, 0, sc>>>(n, (const uint32_t *)d->order.p, (const FmdWalkPark *)d->park_home.p, (const uint64_t *)d->ids_home.p,
+                                           (const fmd_ovlp_rec_t *)d->rec.p, (FmdWalkPark *)d->park_send.p);
+    int rc = d->comm->allgather(d->comm->ctx, sc, cnt, cnt + (W + 1), (size_t)(W + 1) * 8);
+    if (rc != FMD_OK) return rc;
+    uint64_t *mat = (uint64_t *)d->cnt_host.p;
+    FMD_HIP_TRY(hipMemcpyAsync(mat, cnt + (W + 1), (size_t)W * (W + 1) * 8, hipMemcpyDeviceToHost, sc));
+    FMD_HIP_TRY(hipStreamSynchronize(sc));
+    // rows every rank ends up with
+    *fell_back = 0;
+    for (int q = 0; q < W; ++q) {
+        uint64_t m = mat[(size_t)q * (W + 1) + W];
+        for (int s = 0; s < W; ++s) m += mat[(size_t)s * (W + 1) + q];
+        rows_of_rank[(size_t)q] = m;
+        const uint64_t nq = shard_size(d->cfg.n_ids, q, W), capq = nq + nq / 8 + 65536;
+        if (m > capq || (m + (uint64_t)d->pieces - 1) / (uint64_t)d->pieces + 1 > d->piece_max) *fell_back = 1;
+    }
+    if (*fell_back) return FMD_OK;
+    // my segments in park_send: [to 0 | to 1 | ... | to W-1 | special]; what I receive, in rank order, then my own special rows
+    std::vector<fmd_comm_op_t> ops;
+    uint64_t soff = 0, roff = 0;
+    FmdWalkPark *send = (FmdWalkPark *)d->park_send.p, *loc = (FmdWalkPark *)d->park_loc.p;
+    *sent_rows = 0;
+    for (int q = 0; q < W; ++q) {
+        const uint64_t sc_ = mat[(size_t)me * (W + 1) + q], rc_ = mat[(size_t)q * (W + 1) + me];
+        if (q == me) { if (sc_) FMD_HIP_TRY(hipMemcpyAsync(loc + roff, send + soff, sc_ * sizeof(FmdWalkPark), hipMemcpyDeviceToDevice, sc)); }
+        else {
+            if (sc_) { ops.push_back(fmd_comm_op_t{0, q, send + soff, (size_t)sc_ * sizeof(FmdWalkPark)}); *sent_rows += sc_; }
+            if (rc_) ops.push_back(fmd_comm_op_t{1, q, loc + roff, (size_t)rc_ * sizeof(FmdWalkPark)});
+        }
+        soff += sc_; roff += rc_;
+    }
+    { const uint64_t sp = mat[(size_t)me * (W + 1) + W]; if (sp) FMD_HIP_TRY(hipMemcpyAsync(loc + roff, send + soff, sp * sizeof(FmdWalkPark), hipMemcpyDeviceToDevice, sc)); roff += sp; }
+    rc = d->comm->exchange(d->comm->ctx, sc, (int)ops.size(), ops.data());
+    if (rc != FMD_OK) return rc;
+    const uint64_t m = roff;
+    *rows_out = m;
+    if (m) {
+        k_ks_unpack<<<nblk(m, 256), 256, 0, sc>>>(m, loc, (uint64_t *)d->ids_loc.p, (fmd_ovlp_rec_t *)d->rec.p);
+        // the order of pass 2 over the rows as they arrived (W sorted runs): the same sort again
+        uint8_t *w = (uint8_t *)d->work.p;
+        const size_t tb = fmd_park_sort_temp_bytes(m);
+        uint32_t *keys_a = (uint32_t *)w, *vals_a = (uint32_t *)(w + up256(m * 4));
+        void *tmp = w + 2 * up256(m * 4);
+        if (2 * up256(m * 4) + tb > d->work.bytes) return FMD_E_NOMEM;
+        rc = fmd_park_sort(sc, m, loc, keys_a, (uint32_t *)d->keys.p, vals_a, (uint32_t *)d->order.p, tmp, tb);
+    }
+    return rc;
+}
+
+extern "C" int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream_, fmd_ovlp_dist_stats_t *stats)
+{
+    if (!d) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(d->h->device));
+    hipStream_t sc = (hipStream_t)stream_, sm = d->sm, s3 = d->s3;
+    const fmd_ovlp_dist_cfg_t &cfg = d->cfg;
+    const int W = d->world, me = d->rank, root = cfg.root, P = d->pieces;
+    const bool is_root = me == root;
+    fmd_ovlp_dist_stats_t S;
+    memset(&S, 0, sizeof(S));
+    S.pieces = P; S.on_host = d->on_host; S.two_pass = d->two_pass;
+    const double t_begin = now_s();
+    int rc = FMD_OK;
+    FMD_HIP_TRY(hipEventRecord(d->ev[0], sc));
+    FMD_HIP_TRY(hipStreamWaitEvent(sm, d->ev[0], 0));
+    // ---- pass 1 on the id shard
+    uint64_t rows = d->n_home;
+    std::vector<uint64_t> rows_of_rank((size_t)W);
+    for (int q = 0; q < W; ++q) rows_of_rank[(size_t)q] = shard_size(cfg.n_ids, q, W);
+    FmdWalkPark *park = (FmdWalkPark *)d->park_home.p;
+    const uint64_t *row_ids = nullptr;          // nullptr: row j of this rank is id me + W * j
+    int key_shard = 0;
+    if (d->two_pass) {
+        if (d->n_home) rc = fmd_ovlp_head_dev(d->h, sc, (size_t)d->n_home, (const uint64_t *)d->ids_home.p, cfg.min_match, cfg.max_len, (fmd_ovlp_rec_t *)d->rec.p, park,
+                                              (uint32_t *)d->keys.p, (uint32_t *)d->order.p, d->work.p, d->work.bytes);
+        if (rc != FMD_OK) return rc;
+        FMD_HIP_TRY(hipEventRecord(d->ev[1], sc));
+        if (cfg.key_shard) {
+            int fell_back = 0;
+            uint64_t m = 0, sent = 0;
+            rc = key_exchange(d, sc, &m, rows_of_rank, &fell_back, &sent);
+            if (rc != FMD_OK) return rc;
+            if (!fell_back) { rows = m; park = (FmdWalkPark *)d->park_loc.p; row_ids = (const uint64_t *)d->ids_loc.p; key_shard = 1; S.key_rows_sent = sent; }
+            else for (int q = 0; q < W; ++q) rows_of_rank[(size_t)q] = shard_size(cfg.n_ids, q, W);
+        }
+    } else {
+        k_iota32<<<nblk(d->n_home, 256), 256, 0, sc>>>((size_t)d->n_home, (uint32_t *)d->order.p);
+        FMD_HIP_TRY(hipEventRecord(d->ev[1], sc));
+    }
+    FMD_HIP_TRY(hipEventRecord(d->ev[2], sc));
+    S.key_shard = key_shard;
+    d->n_rows = rows;
+    d->loc_ids = row_ids ? row_ids : (const uint64_t *)d->ids_home.p;
+    // ---- pass 2 + fm6_get_nei: every piece queued on the compute stream now; the loop below follows with pack + transfer
+    for (int p = 0; p < P && rc == FMD_OK; ++p) {
+        const uint64_t b = piece_begin(rows, p, P), np = piece_begin(rows, p + 1, P) - b;
+        if (np) {
+            if (d->two_pass)
+                rc = fmd_ovlp_tail_dev(d->h, sc, (size_t)np, (const uint32_t *)d->order.p + b, park, cfg.min_match, cfg.max_len, cfg.max_nei, (fmd_ovlp_rec_t *)d->rec.p,
+                                       (fmd_intv_t *)d->nei.p, (uint8_t *)d->seq.p, d->stride, d->work.p, d->work.bytes);
+            else
+                rc = fmd_ovlp_dev(d->h, sc, (size_t)np, (const uint64_t *)d->ids_home.p + b, cfg.min_match, cfg.max_len, cfg.max_nei, (fmd_ovlp_rec_t *)d->rec.p + b,
+                                  (fmd_intv_t *)d->nei.p + b * cfg.max_nei, (uint8_t *)d->seq.p + b * (size_t)d->stride, d->stride, d->work.p, d->work.bytes);
+        }
+        if (rc == FMD_OK && hipEventRecord(d->done[(size_t)p], sc) != hipSuccess) rc = FMD_E_HIP;
+    }
+    if (rc != FMD_OK) return rc;
+    FMD_HIP_TRY(hipEventRecord(d->ev[3], sc));
+    // ---- the pieces leave
+    std::vector<uint64_t> rowbase((size_t)W + 1, 0);
+    for (int q = 0; q < W; ++q) rowbase[(size_t)q + 1] = rowbase[(size_t)q] + rows_of_rank[(size_t)q];
+    if (is_root) { d->var.reset(); FMD_HIP_TRY(hipMemsetAsync(d->t_row_of.p, 0xff, cfg.n_ids * 4, sm)); }
+    unsigned long long *sz_dev = (unsigned long long *)d->sizes_dev.p;   // [2] mine = {rows, variable bytes}, then [W][2]
+    uint64_t *sz_host = (uint64_t *)d->sizes_host.p;
+    for (int p = 0; p < P; ++p) {
+        const uint64_t b = piece_begin(rows, p, P), np = piece_begin(rows, p + 1, P) - b;
+        const int k = p & 1;
+        FMD_HIP_TRY(hipStreamWaitEvent(sm, d->done[(size_t)p], 0));
+        if (p == P - 1) FMD_HIP_TRY(hipEventRecord(d->ev[4], sm));
+        // where this rank's piece is packed to: straight into the table (root, table in HBM) or into the out buffers
+        uint32_t *o_pid; fmd_ovlp_rec_t *o_prec; uint64_t *o_off; uint8_t *o_var; uint64_t o_cap;
+        const uint64_t my_row0 = rowbase[(size_t)me] + b;
+        if (is_root && !d->on_host) {
+            o_pid = (uint32_t *)d->t_ids.p + my_row0; o_prec = (fmd_ovlp_rec_t *)d->t_prec.p + my_row0; o_off = (uint64_t *)d->t_off.p + (size_t)me * (d->piece_max + 1);
+            o_cap = fmd_ovlp_pack_max_bytes((size_t)np, cfg.max_nei, d->stride);
+            o_var = (uint8_t *)d->var.take(o_cap ? o_cap : 256);
+            if (!o_var) return FMD_E_NOMEM;
+        } else {
+            Stage &os = d->out[is_root ? k : 0];
+            if (is_root) FMD_HIP_TRY(hipStreamWaitEvent(sm, d->drained[k], 0));   // (host table: set k -- the root's own piece and the peers' staging -- has left for the host)
+            o_pid = (uint32_t *)os.pid.p; o_prec = (fmd_ovlp_rec_t *)os.prec.p; o_off = (uint64_t *)os.off.p; o_var = (uint8_t *)os.var.p; o_cap = d->var_cap_piece;
+        }
+        rc = fmd_ovlp_pack_rows_dev(d->h, sm, (size_t)np, (const uint32_t *)d->order.p + b, row_ids, (uint64_t)me, (uint64_t)W, (const fmd_ovlp_rec_t *)d->rec.p, (const fmd_intv_t *)d->nei.p,
+                                    cfg.max_nei, (const uint8_t *)d->seq.p, d->stride, o_pid, o_prec, o_off, o_var, o_cap, d->pack_work.p, d->pack_work.bytes);
+        if (rc != FMD_OK) return rc;
+        // sizes of everybody's piece p
+        FMD_HIP_TRY(hipMemcpyAsync(sz_dev + 1, o_off + np, 8, hipMemcpyDeviceToDevice, sm));
+        { const unsigned long long npv = np; FMD_HIP_TRY(hipMemcpyAsync(sz_dev, &npv, 8, hipMemcpyHostToDevice, sm)); FMD_HIP_TRY(hipStreamSynchronize(sm)); }
+        if (W > 1) {
+            rc = d->comm->allgather(d->comm->ctx, sm, sz_dev, sz_dev + 2, 16);
+            if (rc != FMD_OK) return rc;
+            FMD_HIP_TRY(hipMemcpyAsync(sz_host, sz_dev + 2, (size_t)W * 16, hipMemcpyDeviceToHost, sm));
+        } else FMD_HIP_TRY(hipMemcpyAsync(sz_host, sz_dev, 16, hipMemcpyDeviceToHost, sm));
+        FMD_HIP_TRY(hipStreamSynchronize(sm));
+        S.rows_computed += np;
+        if (is_root && !d->on_host) d->var.shrink_last(o_cap ? o_cap : 256, sz_host[2 * me + 1] ? sz_host[2 * me + 1] : 256);   // (the worst case was reserved for the root's own piece)
+        if (!is_root) {
+            const uint64_t vb = sz_host[2 * me + 1];
+            fmd_comm_op_t ops[4] = {{0, root, o_pid, (size_t)np * 4}, {0, root, o_prec, (size_t)np * sizeof(fmd_ovlp_rec_t)}, {0, root, o_off, (size_t)(np + 1) * 8}, {0, root, o_var, (size_t)vb}};
+            if (np) { rc = d->comm->exchange(d->comm->ctx, sm, 4, ops); if (rc != FMD_OK) return rc; }
+            S.rows_sent += np; S.bytes_sent += np * (4 + sizeof(fmd_ovlp_rec_t)) + (np + 1) * 8 + vb;
+            continue;
+        }
+        // ---- root: receive every peer's piece p, place it
+        std::vector<fmd_comm_op_t> ops;
+        struct Placed { const uint32_t *pid; const uint64_t *off; uint64_t var_base, row0, np; uint64_t *vaddr_dst; Stage *st; uint64_t vb; };
+        std::vector<Placed> placed;
+        for (int q = 0; q < W; ++q) {
+            const uint64_t nq = sz_host[2 * q], vb = sz_host[2 * q + 1];
+            const uint64_t bq = piece_begin(rows_of_rank[(size_t)q], p, P);
+            if (nq != piece_begin(rows_of_rank[(size_t)q], p + 1, P) - bq) { fprintf(stderr, "[E::fmd_ovlp_dist_step] rank %d sends %llu rows in piece %d, %llu expected\n", q, (unsigned long long)nq, p, (unsigned long long)(piece_begin(rows_of_rank[(size_t)q], p + 1, P) - bq)); return FMD_E_ARG; }
+            if (!nq) continue;
+            const uint64_t row0 = rowbase[(size_t)q] + bq;
+            if (!d->on_host) {
+                uint64_t *offq = (uint64_t *)d->t_off.p + (size_t)q * (d->piece_max + 1);
+                uint8_t *vq = o_var;
+                if (q != me) {
+                    vq = (uint8_t *)d->var.take(vb ? vb : 256);
+                    if (!vq) return FMD_E_NOMEM;
+                    ops.push_back(fmd_comm_op_t{1, q, (uint32_t *)d->t_ids.p + row0, (size_t)nq * 4});
+                    ops.push_back(fmd_comm_op_t{1, q, (fmd_ovlp_rec_t *)d->t_prec.p + row0, (size_t)nq * sizeof(fmd_ovlp_rec_t)});
+                    ops.push_back(fmd_comm_op_t{1, q, offq, (size_t)(nq + 1) * 8});
+                    ops.push_back(fmd_comm_op_t{1, q, vq, (size_t)vb});
+                    S.bytes_received += nq * (4 + sizeof(fmd_ovlp_rec_t)) + (nq + 1) * 8 + vb;
+                }
+                placed.push_back(Placed{(const uint32_t *)d->t_ids.p + row0, offq, (uint64_t)(uintptr_t)vq, row0, nq, (uint64_t *)d->t_vaddr.p + row0, nullptr, vb});
+            } else {
+                Stage *st = &d->in[k][(size_t)q];
+                uint8_t *hv = (uint8_t *)d->var.take(vb ? vb : 256);   // the row's final place in pinned host memory
+                if (!hv) return FMD_E_NOMEM;
+                const uint32_t *pid_src; const uint64_t *off_src;
+                if (q != me) {
+                    ops.push_back(fmd_comm_op_t{1, q, st->pid.p, (size_t)nq * 4});
+                    ops.push_back(fmd_comm_op_t{1, q, st->prec.p, (size_t)nq * sizeof(fmd_ovlp_rec_t)});
+                    ops.push_back(fmd_comm_op_t{1, q, st->off.p, (size_t)(nq + 1) * 8});
+                    ops.push_back(fmd_comm_op_t{1, q, st->var.p, (size_t)vb});
+                    S.bytes_received += nq * (4 + sizeof(fmd_ovlp_rec_t)) + (nq + 1) * 8 + vb;
+                    pid_src = (const uint32_t *)st->pid.p; off_src = (const uint64_t *)st->off.p;
+                } else { pid_src = o_pid; off_src = o_off; }
+                placed.push_back(Placed{pid_src, off_src, (uint64_t)(uintptr_t)hv, row0, nq, (uint64_t *)st->vaddr.p, st, vb});
+            }
+        }
+        if (!ops.empty()) { rc = d->comm->exchange(d->comm->ctx, sm, (int)ops.size(), ops.data()); if (rc != FMD_OK) return rc; }
+        for (const Placed &pl : placed)
+            k_place<<<nblk(pl.np, 256), 256, 0, sm>>>((size_t)pl.np, pl.pid, pl.off, pl.var_base, pl.row0, pl.vaddr_dst, (uint32_t *)d->t_row_of.p, cfg.n_ids);
+        if (d->on_host) {   // staging set k -> the pinned table, on the copy stream
+            FMD_HIP_TRY(hipEventRecord(d->staged[k], sm));
+            FMD_HIP_TRY(hipStreamWaitEvent(s3, d->staged[k], 0));
+            for (const Placed &pl : placed) {
+                const bool mine = pl.pid == o_pid;
+                const void *src_prec = mine ? (const void *)o_prec : pl.st->prec.p, *src_var = mine ? (const void *)o_var : pl.st->var.p;
+                FMD_HIP_TRY(hipMemcpyAsync((uint32_t *)d->th_ids.p + pl.row0, pl.pid, pl.np * 4, hipMemcpyDeviceToHost, s3));
+                FMD_HIP_TRY(hipMemcpyAsync((fmd_ovlp_rec_t *)d->th_prec.p + pl.row0, src_prec, pl.np * sizeof(fmd_ovlp_rec_t), hipMemcpyDeviceToHost, s3));
+                FMD_HIP_TRY(hipMemcpyAsync((uint64_t *)d->th_vaddr.p + pl.row0, pl.vaddr_dst, pl.np * 8, hipMemcpyDeviceToHost, s3));
+                if (pl.vb) FMD_HIP_TRY(hipMemcpyAsync((void *)(uintptr_t)pl.var_base, src_var, pl.vb, hipMemcpyDeviceToHost, s3));
+            }
+            FMD_HIP_TRY(hipEventRecord(d->drained[k], s3));
+        }
+    }
+    FMD_HIP_TRY(hipEventRecord(d->ev[5], sm));
+    // ---- the end of this rank's part in the gather (the end of its compute is ev[3] on the compute stream)
+    FMD_HIP_TRY(hipStreamSynchronize(sm));
+    if (is_root && d->on_host) FMD_HIP_TRY(hipMemcpyAsync(d->th_row_of.p, d->t_row_of.p, cfg.n_ids * 4, hipMemcpyDeviceToHost, s3));
+    FMD_HIP_TRY(hipEventRecord(d->ev[6], s3));
+    FMD_HIP_TRY(hipStreamSynchronize(s3));
+    const double t_end = now_s();
+    FMD_HIP_TRY(hipStreamWaitEvent(sc, d->ev[5], 0));   // the caller's stream owns the table
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, d->ev[0], d->ev[1]) == hipSuccess) S.head_ms = ms;
+    if (hipEventElapsedTime(&ms, d->ev[1], d->ev[2]) == hipSuccess) S.key_exchange_ms = ms;
+    if (hipEventElapsedTime(&ms, d->ev[2], d->ev[3]) == hipSuccess) S.tail_ms = ms;
+    if (hipEventElapsedTime(&ms, d->ev[4], d->ev[5]) == hipSuccess) S.last_piece_pack_send_ms = ms;
+    (void)hipGetLastError();
+    // what of the gather did not hide under this rank's compute: from the end of its last kernel to the end of its last transfer
+    // (root with a host table: to the end of the last copy to the host)
+    if (hipEventElapsedTime(&ms, d->ev[3], d->ev[is_root && d->on_host ? 6 : 5]) == hipSuccess) S.gather_exposed_ms = ms > 0 ? ms : 0;
+    S.step_ms = (t_end - t_begin) * 1e3;
+    d->last = S;
+    if (stats) *stats = S;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fmd_set_hip_error(e, "overlap job on N GPUs"); return FMD_E_HIP; }
+    return FMD_OK;
+}
+
+extern "C" int fmd_ovlp_dist_table(fmd_ovlp_dist_t *d, fmd_ovlp_dist_table_t *t)
+{
+    if (!d || !t) return FMD_E_ARG;
+    memset(t, 0, sizeof(*t));
+    if (d->rank != d->cfg.root) return FMD_E_ARG;
+    t->on_host = d->on_host;
+    t->n_rows = d->cfg.n_ids;
+    if (d->on_host) { t->prec = (const fmd_ovlp_rec_t *)d->th_prec.p; t->ids = (const uint32_t *)d->th_ids.p; t->vaddr = (const uint64_t *)d->th_vaddr.p; t->row_of_id = (const uint32_t *)d->th_row_of.p; }
+    else { t->prec = (const fmd_ovlp_rec_t *)d->t_prec.p; t->ids = (const uint32_t *)d->t_ids.p; t->vaddr = (const uint64_t *)d->t_vaddr.p; t->row_of_id = (const uint32_t *)d->t_row_of.p; }
+    return FMD_OK;
+}
+
+extern "C" int fmd_ovlp_dist_local(fmd_ovlp_dist_t *d, uint64_t *n_rows, const uint64_t **d_ids, const fmd_ovlp_rec_t **d_rec, const fmd_intv_t **d_nei, const uint8_t **d_seq, uint32_t *seq_stride)
+{
+    if (!d) return FMD_E_ARG;
+    if (n_rows) *n_rows = d->n_rows;
+    if (d_ids) *d_ids = d->loc_ids;
+    if (d_rec) *d_rec = (const fmd_ovlp_rec_t *)d->rec.p;
+    if (d_nei) *d_nei = (const fmd_intv_t *)d->nei.p;
+    if (d_seq) *d_seq = (const uint8_t *)d->seq.p;
+    if (seq_stride) *seq_stride = d->stride;
+    return FMD_OK;
+}

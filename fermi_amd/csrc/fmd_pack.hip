@@ -42,26 +42,31 @@ __device__ __forceinline__ uint32_t pack_row_bytes(const fmd_ovlp_rec_t &r, uint
     return nn * 32 + ((sb + 7) & ~7u);
 }
 
+// (rows != nullptr: output row i is row rows[i] of the fixed-stride arrays -- a piece of a sorted job, fmd_ovlp_pack_rows_dev)
 __global__ void k_pack_sizes(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, uint32_t max_nei, const uint8_t *__restrict__ seq, uint32_t seq_stride,
-                             uint64_t *__restrict__ sizes)
+                             uint64_t *__restrict__ sizes, const uint32_t *__restrict__ rows)
 {
     const size_t step = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += step) {
         bool p4;
-        sizes[i] = i < n ? pack_row_bytes(rec[i], max_nei, seq + i * (size_t)seq_stride, seq_stride, p4) : 0;
+        const size_t r = i < n ? (rows ? (size_t)rows[i] : i) : 0;
+        sizes[i] = i < n ? pack_row_bytes(rec[r], max_nei, seq + r * (size_t)seq_stride, seq_stride, p4) : 0;
     }
 }
 
 // one 8-lane group per row: record (64 bytes = 8 lanes x 8), neighbours, then the packed bases 8 bytes per lane
 __global__ void k_pack_rows(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, const fmd_intv_t *__restrict__ nei, uint32_t max_nei,
                             const uint8_t *__restrict__ seq, uint32_t seq_stride, fmd_ovlp_rec_t *__restrict__ prec,
-                            const uint64_t *__restrict__ off, uint8_t *__restrict__ var, uint64_t var_cap)
+                            const uint64_t *__restrict__ off, uint8_t *__restrict__ var, uint64_t var_cap, const uint32_t *__restrict__ rows,
+                            const uint64_t *__restrict__ row_ids, uint64_t id_first, uint64_t id_step, uint32_t *__restrict__ pid)
 {
     const size_t step = (size_t)gridDim.x * (blockDim.x >> 3);
     const int l8 = threadIdx.x & 7;
-    for (size_t i = (size_t)blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3); i < n; i += step) {
+    for (size_t t = (size_t)blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3); t < n; t += step) {
+        const size_t i = rows ? (size_t)rows[t] : t;   // source row; everything written goes to row t
+        if (pid && l8 == 0) pid[t] = (uint32_t)(row_ids ? row_ids[i] : id_first + id_step * i);
         const fmd_ovlp_rec_t r = rec[i];
-        const uint64_t o = off[i], sz = off[i + 1] - o;
+        const uint64_t o = off[t], sz = off[t + 1] - o;
         const bool fits = o + sz <= var_cap;
         uint32_t nb = (uint32_t)r.len + (uint32_t)r.ext_len;
         if (nb > seq_stride) nb = seq_stride;
@@ -72,7 +77,7 @@ __global__ void k_pack_rows(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, co
         {   // the record: lane l8 copies word l8; flags live in word 7 (low half)
             uint64_t w = ((const uint64_t *)(rec + i))[l8];
             if (l8 == 7 && pack4) w |= (uint64_t)FMD_OVLP_F_PACK4;
-            ((uint64_t *)(prec + i))[l8] = w;
+            ((uint64_t *)(prec + t))[l8] = w;
         }
         if (!sz || !fits) continue;
         uint8_t *dst = var + o;
@@ -103,14 +108,13 @@ extern "C" size_t fmd_ovlp_pack_work_bytes(size_t n)
     return (n + 1) * 8 + ((tb + 255) & ~(size_t)255) + 256;
 }
 
-extern "C" int fmd_ovlp_pack_dev(fmd_dev_t *h, void *stream_, size_t n, const fmd_ovlp_rec_t *d_rec, const fmd_intv_t *d_nei, uint32_t max_nei,
-                                 const uint8_t *d_seq, uint32_t seq_stride, fmd_ovlp_rec_t *d_prec, uint64_t *d_off, uint8_t *d_var, uint64_t var_cap,
-                                 void *d_work, size_t work_bytes)
+static int pack_core(fmd_dev_t *h, hipStream_t st, size_t n, const uint32_t *d_rows, const uint64_t *d_row_ids, uint64_t id_first, uint64_t id_step,
+                     const fmd_ovlp_rec_t *d_rec, const fmd_intv_t *d_nei, uint32_t max_nei, const uint8_t *d_seq, uint32_t seq_stride, uint32_t *d_pid,
+                     fmd_ovlp_rec_t *d_prec, uint64_t *d_off, uint8_t *d_var, uint64_t var_cap, void *d_work, size_t work_bytes)
 {
     if (!h || (n && (!d_rec || !d_nei || !d_seq || !d_prec || !d_off || !d_var || !d_work)) || max_nei == 0 || (seq_stride & 3)) return FMD_E_ARG;
     if (work_bytes < fmd_ovlp_pack_work_bytes(n)) return FMD_E_ARG;
     FMD_HIP_TRY(hipSetDevice(h->device));
-    hipStream_t st = (hipStream_t)stream_;
     if (n == 0) { FMD_HIP_TRY(hipMemsetAsync(d_off, 0, 8, st)); return FMD_OK; }
     uint64_t *sizes = (uint64_t *)d_work;
     void *tmp = (uint8_t *)d_work + (((n + 1) * 8 + 255) & ~(size_t)255);
@@ -118,14 +122,29 @@ extern "C" int fmd_ovlp_pack_dev(fmd_dev_t *h, void *stream_, size_t n, const fm
     FMD_HIP_TRY(fmd_exclusive_sum(nullptr, tb, sizes, d_off, n + 1, st));
     size_t blocks = (n + 256) / 256;
     if (blocks > (1u << 20)) blocks = 1u << 20;
-    k_pack_sizes<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, max_nei, d_seq, seq_stride, sizes);
+    k_pack_sizes<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, max_nei, d_seq, seq_stride, sizes, d_rows);
     FMD_HIP_TRY(fmd_exclusive_sum(tmp, tb, sizes, d_off, n + 1, st));
     blocks = (n + 31) / 32;
     if (blocks > (1u << 20)) blocks = 1u << 20;
-    k_pack_rows<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, d_nei, max_nei, d_seq, seq_stride, d_prec, d_off, d_var, var_cap);
+    k_pack_rows<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, d_nei, max_nei, d_seq, seq_stride, d_prec, d_off, d_var, var_cap, d_rows, d_row_ids, id_first, id_step, d_pid);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "overlap pack kernels"); return FMD_E_HIP; }
     return FMD_OK;
+}
+
+extern "C" int fmd_ovlp_pack_dev(fmd_dev_t *h, void *stream_, size_t n, const fmd_ovlp_rec_t *d_rec, const fmd_intv_t *d_nei, uint32_t max_nei,
+                                 const uint8_t *d_seq, uint32_t seq_stride, fmd_ovlp_rec_t *d_prec, uint64_t *d_off, uint8_t *d_var, uint64_t var_cap,
+                                 void *d_work, size_t work_bytes)
+{
+    return pack_core(h, (hipStream_t)stream_, n, nullptr, nullptr, 0, 1, d_rec, d_nei, max_nei, d_seq, seq_stride, nullptr, d_prec, d_off, d_var, var_cap, d_work, work_bytes);
+}
+
+extern "C" int fmd_ovlp_pack_rows_dev(fmd_dev_t *h, void *stream_, size_t n, const uint32_t *d_rows, const uint64_t *d_row_ids, uint64_t id_first, uint64_t id_step,
+                                      const fmd_ovlp_rec_t *d_rec, const fmd_intv_t *d_nei, uint32_t max_nei, const uint8_t *d_seq, uint32_t seq_stride,
+                                      uint32_t *d_pid, fmd_ovlp_rec_t *d_prec, uint64_t *d_off, uint8_t *d_var, uint64_t var_cap, void *d_work, size_t work_bytes)
+{
+    if (n && (!d_rows || !d_pid)) return FMD_E_ARG;
+    return pack_core(h, (hipStream_t)stream_, n, d_rows, d_row_ids, id_first, id_step, d_rec, d_nei, max_nei, d_seq, seq_stride, d_pid, d_prec, d_off, d_var, var_cap, d_work, work_bytes);
 }
 
 // ------------------------------------------------------------------------------------------------

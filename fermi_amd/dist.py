@@ -47,6 +47,15 @@ class Watchdog:
             self.t.cancel()
         return False
 
+    def restart(self, seconds=None):
+        """Start the clock again (after a step that is slow but not a stall: pinning the root's receive buffers)."""
+        if self.t is not None:
+            self.t.cancel()
+            self.t = None
+        if seconds is not None:
+            self.seconds = seconds
+        self.__enter__()
+
 
 def describe_fabric(torch, dist, rank, world):
     """One stderr line per job about what carries the exchange (rank 0 only): backend, RCCL version, peer access between the GPUs."""
@@ -121,12 +130,15 @@ class PackedGather:
             # gloo moves host memory only: the one-GPU test form of the N > 1 path (bench.py FMD_BENCH_BACKEND=gloo) bounces
             # through the host here; under nccl (RCCL) the device tensors below go peer to peer over xGMI as they are
             prec, off, var = prec.cpu(), off.cpu(), var[: int(off[-1].item())].cpu()
-        with Watchdog(self.timeout_s, "the gather of the packed overlap records"):
+        with Watchdog(self.timeout_s, "the gather of the packed overlap records") as wd:
+            self._wd = wd
             tot = off[-1:].clone()
             sizes_t = [torch.zeros(1, dtype=torch.int64, device=off.device) for _ in range(world)]
             dist.all_gather(sizes_t, tot)
             sizes = [int(s.item()) for s in sizes_t]
             mine = sizes[rank]
+            if self.timeout_s:
+                wd.restart(self.timeout_s + int((sum(sizes) + 72 * self.n_ids) / 1e9) * (10 if self.bufs is None else 1))   # the first step also allocates (and may pin) the root's buffers
             if self.path is None:
                 # every rank takes the same decision: the root's choice (its free memory) is broadcast, and a transport whose
                 # batched point-to-point call does not work on ANY rank (probed once with 8 bytes) sends everybody to the all-gather
@@ -179,6 +191,9 @@ class PackedGather:
         host_rounds = self.path == "host-rounds"
         if self.bufs is None or any(self.bufs[r] is not None and self.bufs[r][2].numel() < sizes[r] for r in range(world)):
             self.bufs = self._alloc_root(sizes, prec, pinned_host=host_rounds)   # first step (or the sizes grew): allocated once, outside later steps
+            # (pinning ~163 GB of host memory takes minutes and is not a stall: the clock starts again here, with room for the bytes to come --
+            # the peers' clocks run on while they wait in their sends, so theirs is the same budget: timeout_s + 1 s per GB expected)
+            getattr(self, "_wd", Watchdog(0, "")).restart(self.timeout_s + int(sum(sizes) / 1e9))
             if host_rounds:
                 n_max = max(shard_size(self.n_ids, r, world) for r in range(world) if r != dst)
                 s_max = max(sizes[r] for r in range(world) if r != dst)
@@ -243,10 +258,10 @@ class PackedGather:
         return out
 
 
-def gather_packed(prec, off, var, n_ids, rank, world, dist, dst=0, force_path=None):
-    """One-shot form of PackedGather (tests; bench.py keeps a PackedGather across its steps)."""
+def gather_packed(prec, off, var, n_ids, rank, world, dist, dst=0, force_path=None, timeout_s=120):
+    """One-shot form of PackedGather (tests; bench.py keeps a PackedGather across its steps).  timeout_s = 0: no watchdog."""
     import torch
-    return PackedGather(torch, dist, n_ids, rank, world, dst, force_path)(prec, off, var)
+    return PackedGather(torch, dist, n_ids, rank, world, dst, force_path, timeout_s)(prec, off, var)
 
 
 def packed_rows(torch, bufs, rows):
@@ -297,3 +312,334 @@ def check_gathered(torch, api, job, gathered, n_ids, world, sample=200_000):
             return "MISMATCH (rows of rank %d)" % r
         n_checked += m
     return "ok: %d rows computed by ranks 1..%d recomputed on rank 0, packed bytes identical" % (n_checked, world - 1)
+
+
+# ======================================================================================================================
+# Round 4: the N > 1 step behind the C ABI (fmd_ovlp_dist_*, fmd_comm_t; fermi_amd/csrc/fmd_ovlp_dist.hip) -- pass 2 in pieces
+# whose rows leave under the compute of the next piece, and the optional key shard (one all-to-all of the parked strands).
+# Here: the ctypes view of those entry points, the two transports a Python host can hand them (RCCL created from a unique id that
+# travels through torch.distributed's store; torch.distributed itself through the fmd_comm_t callbacks -- gloo in the tests), and
+# `piecewise_exchange` / `key_shard_rows`: the same exchange logic over plain tensors, the twin the CPU tests run on rows the
+# oracle computed.
+import ctypes as C
+
+
+class CommOp(C.Structure):
+    _fields_ = [("is_recv", C.c_int), ("peer", C.c_int), ("d_ptr", C.c_void_p), ("bytes", C.c_size_t)]
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(CommOp))
+DESTROY_FN = C.CFUNCTYPE(None, C.c_void_p)
+
+
+class Comm(C.Structure):       # fmd_comm_t
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("ctx", C.c_void_p), ("allgather", ALLGATHER_FN), ("exchange", EXCHANGE_FN), ("destroy", DESTROY_FN)]
+
+
+class DistCfg(C.Structure):    # fmd_ovlp_dist_cfg_t
+    _fields_ = [("n_ids", C.c_uint64), ("min_match", C.c_int), ("max_len", C.c_uint32), ("max_nei", C.c_uint32), ("pieces", C.c_uint32),
+                ("key_shard", C.c_int), ("root", C.c_int), ("host_table", C.c_int), ("batch", C.c_size_t)]
+
+
+class DistStats(C.Structure):  # fmd_ovlp_dist_stats_t
+    _fields_ = [("head_ms", C.c_double), ("key_exchange_ms", C.c_double), ("tail_ms", C.c_double), ("last_piece_pack_send_ms", C.c_double),
+                ("gather_exposed_ms", C.c_double), ("step_ms", C.c_double), ("rows_computed", C.c_uint64), ("rows_sent", C.c_uint64),
+                ("bytes_sent", C.c_uint64), ("bytes_received", C.c_uint64), ("key_rows_sent", C.c_uint64),
+                ("pieces", C.c_int), ("on_host", C.c_int), ("key_shard", C.c_int), ("two_pass", C.c_int)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class DistTable(C.Structure):  # fmd_ovlp_dist_table_t
+    _fields_ = [("on_host", C.c_int), ("n_rows", C.c_uint64), ("prec", C.c_void_p), ("ids", C.c_void_p), ("vaddr", C.c_void_p), ("row_of_id", C.c_void_p)]
+
+
+class TorchComm:
+    """fmd_comm_t over torch.distributed through the two callbacks: the transport of the tests (gloo: device buffers bounce through
+    host arrays; the call synchronises the stream).  The product's transport is RcclComm."""
+
+    def __init__(self, api, dist, rank, world):
+        import numpy as np
+        import torch
+        self.api, self.dist, self.np, self.torch = api, dist, np, torch
+        self.lib = api.lib()
+        self._ag = ALLGATHER_FN(self._allgather)
+        self._ex = EXCHANGE_FN(self._exchange)
+        self._de = DESTROY_FN(lambda ctx: None)
+        self.c = Comm(rank, world, None, self._ag, self._ex, self._de)
+
+    def ptr(self):
+        return C.addressof(self.c)
+
+    def _d2h(self, d_ptr, n):
+        a = self.np.empty(n, dtype=self.np.uint8)
+        if n:
+            self.api.check(self.lib.fmd_memcpy_d2h(a.ctypes.data, d_ptr, n, None))
+        return a
+
+    def _h2d(self, d_ptr, a):
+        if a.size:
+            self.api.check(self.lib.fmd_memcpy_h2d(d_ptr, a.ctypes.data, a.size, None))
+
+    def _sync(self, stream):
+        self.torch.cuda.synchronize()
+
+    def _allgather(self, ctx, stream, d_send, d_recv, nbytes):
+        try:
+            self._sync(stream)
+            mine = self.torch.from_numpy(self._d2h(d_send, nbytes))
+            got = [self.torch.empty(nbytes, dtype=self.torch.uint8) for _ in range(self.c.world)]
+            self.dist.all_gather(got, mine)
+            self._h2d(d_recv, self.torch.cat(got).numpy())
+            self._sync(stream)
+            return 0
+        except Exception as ex:   # an exception must not cross the C frame
+            import sys
+            print("[fermi_amd.dist] TorchComm.allgather: %r" % (ex,), file=sys.stderr, flush=True)
+            return -6
+
+    def _exchange(self, ctx, stream, n_ops, ops):
+        try:
+            self._sync(stream)
+            reqs, recvs = [], []
+            for i in range(n_ops):
+                o = ops[i]
+                if o.bytes == 0:
+                    continue
+                if o.is_recv:
+                    t = self.torch.empty(o.bytes, dtype=self.torch.uint8)
+                    recvs.append((o.d_ptr, t))
+                    reqs.append(self.dist.irecv(t, o.peer))
+                else:
+                    reqs.append(self.dist.isend(self.torch.from_numpy(self._d2h(o.d_ptr, o.bytes)), o.peer))
+            for r in reqs:
+                r.wait()
+            for d_ptr, t in recvs:
+                self._h2d(d_ptr, t.numpy())
+            self._sync(stream)
+            return 0
+        except Exception as ex:
+            import sys
+            print("[fermi_amd.dist] TorchComm.exchange: %r" % (ex,), file=sys.stderr, flush=True)
+            return -6
+
+    def free(self):
+        pass
+
+
+class RcclComm:
+    """fmd_comm_rccl_init on this rank's device: rank 0 makes the unique id (ncclGetUniqueId), torch.distributed carries it."""
+
+    def __init__(self, api, dist, rank, world, device):
+        import torch
+        self.lib = api.lib()
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            api.check(self.lib.fmd_comm_rccl_unique_id(ident))
+        box = [bytes(ident)]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        api.check(self.lib.fmd_comm_rccl_init(device, rank, world, ident, C.byref(h)))
+        self.h = h
+        if world > 1:
+            torch.cuda.synchronize()
+
+    def ptr(self):
+        return self.h
+
+    def free(self):
+        if self.h:
+            self.lib.fmd_comm_free(self.h)
+            self.h = None
+
+
+class DistJob:
+    """fmd_ovlp_dist_t: one pass of overlap discovery over ids 0 .. n_ids-1 on `world` GPUs per step()."""
+
+    def __init__(self, api, index, comm, n_ids, min_match, max_len, max_nei=4, pieces=0, key_shard=0, root=0, host_table=-1, batch=0):
+        self.api, self.lib, self.comm = api, api.lib(), comm
+        self.cfg = DistCfg(n_ids, min_match, max_len, max_nei, pieces, key_shard, root, host_table, batch)
+        h = C.c_void_p()
+        api.check(self.lib.fmd_ovlp_dist_new(index.h, comm.ptr(), C.byref(self.cfg), C.byref(h)))
+        self.h = h
+        self.stats = DistStats()
+
+    def step(self, stream=None):
+        self.api.check(self.lib.fmd_ovlp_dist_step(self.h, stream, C.byref(self.stats)))
+        return self.stats
+
+    def table(self):
+        t = DistTable()
+        self.api.check(self.lib.fmd_ovlp_dist_table(self.h, C.byref(t)))
+        return t
+
+    def local(self):
+        n, ids, rec, nei, seq, stride = C.c_uint64(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint32()
+        self.api.check(self.lib.fmd_ovlp_dist_local(self.h, C.byref(n), C.byref(ids), C.byref(rec), C.byref(nei), C.byref(seq), C.byref(stride)))
+        return n.value, ids.value, rec.value, nei.value, seq.value, stride.value
+
+    def free(self):
+        if self.h:
+            self.lib.fmd_ovlp_dist_free(self.h)
+            self.h = None
+
+
+# ---- the same exchange logic over plain tensors (the twin the CPU tests run, gloo, on rows the oracle computed) ------------------
+def piece_begin(rows, p, pieces):
+    return rows * p // pieces
+
+
+def first_key(p, world):
+    """smallest 32-bit key that goes to rank p (fmd_ovlp_dist.hip: ks_first_key)."""
+    return ((p << 32) + world - 1) // world
+
+
+def key_dest(keys, rank, world):
+    """destination rank of every key (numpy uint32/uint64 array): W equal ranges; the two special keys stay on `rank`."""
+    import numpy as np
+    k = np.asarray(keys, dtype=np.uint64)
+    d = (k * np.uint64(world)) >> np.uint64(32)
+    # (k * W >> 32 == p  <=>  first_key(p) <= k < first_key(p + 1))
+    d = d.astype(np.int64)
+    d[k >= np.uint64(0xfffffffe)] = rank
+    return d
+
+
+def key_shard_rows(torch, dist, rank, world, park, keys):
+    """The all-to-all of the parked strands: park [n, 64] uint8 rows in ascending key order, keys [n] (numpy uint32, ascending).
+    -> (rows this rank owns afterwards [m, 64] in arrival order: rank 0's, rank 1's, ..., then its own special rows; counts matrix)."""
+    import numpy as np
+    dest = key_dest(keys, rank, world)
+    special = np.asarray(keys, dtype=np.uint64) >= np.uint64(0xfffffffe)
+    counts = np.array([int(((dest == q) & ~special).sum()) for q in range(world)] + [int(special.sum())], dtype=np.int64)
+    mat = [torch.zeros(world + 1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(mat, torch.from_numpy(counts))
+    mat = torch.stack(mat).numpy()
+    soff = np.concatenate([[0], np.cumsum(counts)])
+    reqs, got = [], [None] * world
+    for q in range(world):
+        seg = park[int(soff[q]):int(soff[q + 1])]
+        if q == rank:
+            got[q] = seg.clone()
+            continue
+        if len(seg):
+            reqs.append(dist.isend(seg.contiguous(), q))
+        rc = int(mat[q, rank])
+        got[q] = torch.empty((rc, park.shape[1]), dtype=park.dtype)
+        if rc:
+            reqs.append(dist.irecv(got[q], q))
+    for r in reqs:
+        r.wait()
+    got.append(park[int(soff[world]):int(soff[world + 1])].clone())
+    return torch.cat(got), mat
+
+
+def piecewise_exchange(torch, dist, rank, world, root, pieces, rows_of_rank, my_pieces):
+    """The gather in pieces: my_pieces = list over p of (pid int32 [np], prec uint8 [np * 64], off int64 [np + 1], var uint8 [bytes]) of
+    this rank's rows piece_begin(rows, p) .. piece_begin(rows, p + 1) in its computing order.  Per piece: an all-gather of
+    (rows, variable bytes), then every peer's four arrays straight to the root.
+    -> root: dict id -> (record bytes, variable-part bytes) of every row of the job; others: None."""
+    table = {} if rank == root else None
+    for p in range(pieces):
+        pid, prec, off, var = my_pieces[p]
+        mine = torch.tensor([len(pid), int(off[-1])], dtype=torch.int64)
+        sizes = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(sizes, mine)
+        if rank != root:
+            ops = []
+            if len(pid):
+                ops = [dist.P2POp(dist.isend, pid, root), dist.P2POp(dist.isend, prec, root), dist.P2POp(dist.isend, off, root)]
+                if int(off[-1]):
+                    ops.append(dist.P2POp(dist.isend, var[: int(off[-1])], root))
+            for w in (dist.batch_isend_irecv(ops) if ops else []):
+                w.wait()
+            continue
+        got, ops = {}, []
+        for q in range(world):
+            nq, vb = int(sizes[q][0]), int(sizes[q][1])
+            assert nq == piece_begin(rows_of_rank[q], p + 1, pieces) - piece_begin(rows_of_rank[q], p, pieces), "rank %d, piece %d: %d rows" % (q, p, nq)
+            if q == root:
+                got[q] = (pid, prec, off, var[:vb])
+                continue
+            b = (torch.empty(nq, dtype=torch.int32), torch.empty(nq * 64, dtype=torch.uint8), torch.empty(nq + 1, dtype=torch.int64), torch.empty(vb, dtype=torch.uint8))
+            got[q] = b
+            if nq:
+                ops += [dist.P2POp(dist.irecv, b[0], q), dist.P2POp(dist.irecv, b[1], q), dist.P2POp(dist.irecv, b[2], q)]
+                if vb:
+                    ops.append(dist.P2POp(dist.irecv, b[3], q))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        for q in range(world):   # placement: what k_place does at the root
+            qpid, qprec, qoff, qvar = got[q]
+            for t in range(len(qpid)):
+                table[int(qpid[t])] = (qprec[t * 64:(t + 1) * 64].numpy().tobytes(), qvar[int(qoff[t]):int(qoff[t + 1])].numpy().tobytes())
+    return table
+
+
+class _DevView:
+    """A device pointer as something torch.as_tensor() accepts (the CUDA array interface, which torch's ROCm build reads too)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def table_tensors(torch, t, n_ids, device):
+    """The root's table (fmd_ovlp_dist_table) as tensors: prec [n, 64] uint8, ids int32 [n], vaddr int64 [n], row_of_id int32 [n] --
+    views of the job's own memory (device or pinned host), valid until the next step."""
+    if t.on_host:
+        mk = lambda p, nb: torch.from_numpy(np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (nb,)))
+    else:
+        mk = lambda p, nb: torch.as_tensor(_DevView(p, nb), device=device)
+    return (mk(t.prec, n_ids * 64).view(n_ids, 64), mk(t.ids, n_ids * 4).view(torch.int32), mk(t.vaddr, n_ids * 8).view(torch.int64),
+            mk(t.row_of_id, n_ids * 4).view(torch.int32))
+
+
+def check_table(torch, api, index, djob, n_ids, min_match, max_len, max_nei, device, sample=200_000, var_sample=2_000):
+    """Rank 0, outside the timed region: every id present exactly once; a spread sample of ids recomputed here (fmd_ovlp_dev + fmd_ovlp_pack_dev)
+    and compared with the rows that arrived -- records of `sample` ids byte for byte, variable parts of `var_sample` of them byte for byte."""
+    lib = api.lib()
+    t = djob.table()
+    prec, ids, vaddr, row_of = table_tensors(torch, t, n_ids, device)
+    ro = row_of.to(device).to(torch.int64)
+    if int((ro < 0).sum().item()) or int((ro >= n_ids).sum().item()):
+        return "MISMATCH (ids without a row)"
+    if not torch.equal(ids.to(device)[ro].to(torch.int64), torch.arange(n_ids, dtype=torch.int64, device=device)):
+        return "MISMATCH (row_of_id does not invert ids)"
+    m = min(sample, n_ids)
+    sel = (torch.arange(m, dtype=torch.int64, device=device) * (n_ids // m)).contiguous()
+    stride = 2 * ((max_len + 3) // 4 * 4)
+    rec = torch.zeros(m * 64, dtype=torch.uint8, device=device); nei = torch.zeros(m * max_nei * 32, dtype=torch.uint8, device=device)
+    seq = torch.zeros(m * stride, dtype=torch.uint8, device=device)
+    wb = max(lib.fmd_ovlp_work_bytes(m, max_len, min_match), lib.fmd_ovlp_pack_work_bytes(m))
+    work = torch.empty(wb, dtype=torch.uint8, device=device)
+    api.check(lib.fmd_ovlp_dev(index.h, None, m, sel.data_ptr(), min_match, max_len, max_nei, rec.data_ptr(), nei.data_ptr(), seq.data_ptr(), stride, work.data_ptr(), wb))
+    cap = lib.fmd_ovlp_pack_max_bytes(m, max_nei, stride)
+    wp = torch.empty(m * 64, dtype=torch.uint8, device=device); wo = torch.zeros(m + 1, dtype=torch.int64, device=device); wv = torch.empty(cap, dtype=torch.uint8, device=device)
+    api.check(lib.fmd_ovlp_pack_dev(index.h, None, m, rec.data_ptr(), nei.data_ptr(), max_nei, seq.data_ptr(), stride, wp.data_ptr(), wo.data_ptr(), wv.data_ptr(), cap, work.data_ptr(), wb))
+    torch.cuda.synchronize()
+    rows = ro[sel]
+    got = prec[rows.to(prec.device)].to(device)
+    if not torch.equal(got.reshape(-1), wp):
+        return "MISMATCH (records)"
+    vs = min(var_sample, m)
+    pick = (torch.arange(vs, dtype=torch.int64) * (m // vs)).tolist()
+    wo_h, va_h = wo.cpu().numpy(), vaddr.to("cpu").numpy()
+    rows_h = rows.cpu().numpy()
+    for j in pick:
+        nb = int(wo_h[j + 1] - wo_h[j])
+        if nb == 0:
+            continue
+        addr = int(va_h[rows_h[j]])
+        if t.on_host:
+            g = bytes((C.c_uint8 * nb).from_address(addr))
+        else:
+            a = np.empty(nb, dtype=np.uint8)
+            api.check(lib.fmd_memcpy_d2h(a.ctypes.data, C.c_void_p(addr), nb, None))
+            g = a.tobytes()
+        if g != wv[int(wo_h[j]):int(wo_h[j + 1])].cpu().numpy().tobytes():
+            return "MISMATCH (variable part of id %d)" % int(sel[j].item())
+    return "ok: all %d ids present once; %d ids spread over every rank's rows recomputed on rank 0: records identical, variable parts of %d of them identical" % (n_ids, m, vs)

@@ -297,6 +297,94 @@ static inline int fmd_ovlp_row_base(const fmd_ovlp_rec_t *r, uint32_t max_nei, c
     return (r->flags & FMD_OVLP_F_PACK4) ? (s[j >> 1] >> (4 * (j & 1))) & 15 : ((s[j >> 2] >> (2 * (j & 3))) & 3) + 1;
 }
 
+/* ---- the sorted job in its two halves ----------------------------------------------------------------------------
+ * fmd_ovlp_sorted_dev = fmd_ovlp_head_dev, then fmd_ovlp_tail_dev over slices of d_order.  A caller that wants to do something
+ * between the two -- hand finished rows on while the rest is being computed, exchange the parked strands between GPUs by key
+ * (fmd_ovlp_dist_*) -- calls them itself.  fmd_ovlp_two_pass_ok: can this index / these parameters use the two-pass form at all
+ * (min_match >= 32, ...)?
+ * head: pass 1 of every strand (32 bases in), d_park[n] = 64 bytes per strand, d_keys[n] = the minimizer keys ascending,
+ *       d_order[n] = row of the t-th strand in that order; d_rec receives the final record of strands that end inside the head
+ *       (shorter than 32 bases: status FMD_OVLP_SHORT; their key is 0xffffffff).
+ * tail: pass 2 + fm6_get_nei for np parked strands, slot t of the call = row d_rows[t] of d_park, d_rec, d_nei, d_seq;
+ *       work_bytes >= fmd_ovlp_work_bytes(np, ..). */
+int fmd_ovlp_two_pass_ok(const fmd_dev_t *h, size_t n, int min_match, uint32_t max_len);
+size_t fmd_ovlp_head_work_bytes(size_t n);
+int fmd_ovlp_head_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_ids, int min_match, uint32_t max_len, fmd_ovlp_rec_t *d_rec,
+                      void *d_park, uint32_t *d_keys, uint32_t *d_order, void *d_work, size_t work_bytes);
+int fmd_ovlp_tail_dev(fmd_dev_t *h, void *stream, size_t np, const uint32_t *d_rows, void *d_park, int min_match, uint32_t max_len, uint32_t max_nei,
+                      fmd_ovlp_rec_t *d_rec, fmd_intv_t *d_nei, uint8_t *d_seq, uint32_t seq_stride, void *d_work, size_t work_bytes);
+/* fmd_ovlp_pack_dev for the rows d_rows[0..n) of the fixed-stride arrays, in that order ("a piece"): output row t is row d_rows[t];
+ * d_pid[t] = its sequence id: d_row_ids[d_rows[t]] when d_row_ids != NULL, else id_first + id_step * d_rows[t]. */
+int fmd_ovlp_pack_rows_dev(fmd_dev_t *h, void *stream, size_t n, const uint32_t *d_rows, const uint64_t *d_row_ids, uint64_t id_first, uint64_t id_step,
+                           const fmd_ovlp_rec_t *d_rec, const fmd_intv_t *d_nei, uint32_t max_nei, const uint8_t *d_seq, uint32_t seq_stride,
+                           uint32_t *d_pid, fmd_ovlp_rec_t *d_prec, uint64_t *d_off, uint8_t *d_var, uint64_t var_cap, void *d_work, size_t work_bytes);
+
+/* ---- N GPUs: the exchange steps of the overlap path behind the C ABI ---------------------------------------------
+ * The reference joins N workers over one shared index at no cost (pthreads, unitig.c:394-404); N GPUs hold N replicas of the index
+ * and the only data that has to move is (a) the finished rows, to the rank that runs the walk, and (b) -- optional -- the parked
+ * strands between pass 1 and pass 2, so that every GPU runs pass 2 on ONE RANGE OF MINIMIZER KEYS of the whole read set instead of on
+ * 1/N of the coverage everywhere (strands of one genomic window meet on one GPU and share rank blocks in cache).
+ *
+ * fmd_comm_t is the transport: two collective calls on DEVICE buffers, enqueued on a HIP stream.  fmd_comm_rccl_* is the one that
+ * ships (RCCL over xGMI: ncclAllGather; ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd -- direct, every peer on its own link to
+ * the root, no ring); a host may plug in its own (MPI, sockets; the tests plug in torch.distributed/gloo). */
+typedef struct { int is_recv, peer; void *d_ptr; size_t bytes; } fmd_comm_op_t;
+typedef struct fmd_comm {
+    int rank, world;
+    void *ctx;
+    /* every rank contributes `bytes` from d_send; d_recv receives world x bytes in rank order */
+    int (*allgather)(void *ctx, void *stream, const void *d_send, void *d_recv, size_t bytes);
+    /* one group of point-to-point transfers (matching sends and receives are posted by the peers in the same call) */
+    int (*exchange)(void *ctx, void *stream, int n_ops, const fmd_comm_op_t *ops);
+    void (*destroy)(void *ctx);
+} fmd_comm_t;
+#define FMD_COMM_ID_BYTES 128
+int fmd_comm_rccl_unique_id(uint8_t id[FMD_COMM_ID_BYTES]);                       /* ncclGetUniqueId: rank 0 calls, the host carries it to the others */
+int fmd_comm_rccl_init(int device, int rank, int world, const uint8_t id[FMD_COMM_ID_BYTES], fmd_comm_t **out);   /* ncclCommInitRank */
+int fmd_comm_rccl_version(void);                                                 /* ncclGetVersion; 0 = librccl not loadable */
+void fmd_comm_free(fmd_comm_t *c);                                               /* calls destroy(ctx) and frees c if fmd_comm_rccl_init made it */
+
+/* One pass of overlap discovery over the sequence ids 0 .. n_ids-1 on `world` GPUs, rank r on its own replica of the index:
+ *   pass 1 on the ids r, r + world, ... (the reference's worker interleave, unitig.c:333, 398-399);
+ *   key_shard: one all-to-all of the parked strands (64 bytes each) by minimizer key range;
+ *   pass 2 + fm6_get_nei in `pieces` batches of the sorted order; while batch p + 1 is computed, the rows of batch p are packed
+ *   on a second stream and sent to `root` (fmd_ovlp_pack_rows_dev; ids, records, offsets, variable parts).
+ * On return (stream-ordered on `stream` for the caller's later work; the call itself synchronises with the host between pieces)
+ * the root holds all n_ids rows: fmd_ovlp_dist_table().  The object keeps every buffer between steps. */
+typedef struct fmd_ovlp_dist fmd_ovlp_dist_t;
+typedef struct {
+    uint64_t n_ids;
+    int min_match;
+    uint32_t max_len, max_nei;
+    uint32_t pieces;        /* 0 = default (4, fewer for small shards) */
+    int key_shard;          /* 0 / 1; where the two-pass form does not apply (fmd_ovlp_two_pass_ok) the shard is computed in id order */
+    int root;
+    int host_table;         /* root: 0 = the table stays in HBM, 1 = in pinned host memory (pieces staged through HBM), -1 = by free HBM */
+    size_t batch;           /* 0 = a piece is one batch; else pieces are cut further so that no batch exceeds this many strands */
+} fmd_ovlp_dist_cfg_t;
+typedef struct {            /* of the last step, this rank; milliseconds from HIP events / the host clock */
+    double head_ms, key_exchange_ms, tail_ms;      /* compute stream: pass 1 + sort; the all-to-all and the re-sort; all pieces of pass 2 */
+    double last_piece_pack_send_ms;                /* comm stream: pack + transfer of the LAST piece (what cannot hide under compute) */
+    double gather_exposed_ms;                      /* HIP events: end of this rank's last compute kernel -> end of its part in the gather */
+    double step_ms;                                /* host clock, whole step */
+    uint64_t rows_computed, rows_sent, bytes_sent, bytes_received, key_rows_sent;
+    int pieces, on_host, key_shard, two_pass;
+} fmd_ovlp_dist_stats_t;
+typedef struct {            /* root only: the table of the last step */
+    int on_host;                  /* the arrays below are device (0) or pinned host (1) memory */
+    uint64_t n_rows;              /* = n_ids when the step is complete */
+    const fmd_ovlp_rec_t *prec;   /* records in arrival order (packed form: fmd_ovlp_pack_dev) */
+    const uint32_t *ids;          /* sequence id of each row */
+    const uint64_t *vaddr;        /* address of each row's variable part (same memory kind) */
+    const uint32_t *row_of_id;    /* n_ids entries: the row that holds sequence id i */
+} fmd_ovlp_dist_table_t;
+int fmd_ovlp_dist_new(fmd_dev_t *h, fmd_comm_t *comm, const fmd_ovlp_dist_cfg_t *cfg, fmd_ovlp_dist_t **out);
+int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream, fmd_ovlp_dist_stats_t *stats);
+int fmd_ovlp_dist_table(fmd_ovlp_dist_t *d, fmd_ovlp_dist_table_t *t);
+/* this rank's own fixed-stride rows of the last step (tests, parity samples): row j describes sequence id ids[j] */
+int fmd_ovlp_dist_local(fmd_ovlp_dist_t *d, uint64_t *n_rows, const uint64_t **d_ids, const fmd_ovlp_rec_t **d_rec, const fmd_intv_t **d_nei, const uint8_t **d_seq, uint32_t *seq_stride);
+void fmd_ovlp_dist_free(fmd_ovlp_dist_t *d);
+
 /* ---- k-mer harvest of `fermi correct`: fm6_traverse (exact.c:141) + ec_collect (correct.c:35-87)
  * over ALL 4^suf_len suffix buckets (what worker1 does, correct.c:272-279).  Emits one
  * (bucket, key, val) triple per solid k-mer: bucket = index into `solid[]` (correct.c:346-349),

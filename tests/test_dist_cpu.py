@@ -117,3 +117,91 @@ def test_gather_packed_records_gloo(oracle_lib, world, mode):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok
+
+
+# ---- round 4: the gather in pieces and the key shard (fermi_amd/dist.py: the twin of fmd_ovlp_dist_step's exchange logic) ----------
+def _fake_key(ids):
+    """a 32-bit hash of the id standing in for the minimizer key (the exchange only needs keys that scatter)"""
+    v = (np.asarray(ids, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(32)
+    v = v.astype(np.uint64)
+    v[np.asarray(ids) % 97 == 5] = 0xffffffff     # strands that ended inside the head: stay at home
+    v[np.asarray(ids) % 89 == 7] = 0xfffffffe     # no usable minimizer: stay at home
+    return v.astype(np.uint32)
+
+
+def _pieces_worker(rank, world, port, fmd, n_ids, min_match, pieces, key_shard, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, HERE)
+    home = fdist.shard_ids(n_ids, rank, world)
+    rows_of_rank = [fdist.shard_size(n_ids, r, world) for r in range(world)]
+    own = home
+    if key_shard:
+        keys = _fake_key(home)
+        order = np.argsort(keys, kind="stable")
+        park = np.zeros((len(home), 64), dtype=np.uint8)
+        park[:, 48:56] = home[:, None].view(np.uint8).reshape(len(home), 8)          # pad.x/y = the id, as k_ks_gather stamps it
+        got, mat = fdist.key_shard_rows(torch, dist, rank, world, torch.from_numpy(park[order]), keys[order])
+        own = got.numpy()[:, 48:56].copy().view(np.uint64).reshape(-1)
+        # every row this rank owns has a key in its range, or is one of its own special rows
+        k_own = _fake_key(own).astype(np.uint64)
+        lo, hi = fdist.first_key(rank, world), (fdist.first_key(rank + 1, world) if rank + 1 < world else 0xfffffffe)
+        sp = k_own >= 0xfffffffe
+        assert ((k_own[~sp] >= lo) & (k_own[~sp] < hi)).all() and (own[sp] % world == rank).all()
+        assert np.array_equal(fdist.key_dest(k_own[~sp], rank, world), np.full(int((~sp).sum()), rank))
+        cnt = torch.zeros(world, dtype=torch.int64); cnt[rank] = len(own)
+        dist.all_reduce(cnt)
+        rows_of_rank = [int(c) for c in cnt]
+        assert sum(rows_of_rank) == n_ids and int(mat.sum()) == n_ids
+    # this rank's rows in its computing order (a permutation: the sorted order of pass 2), cut into pieces
+    rng = np.random.default_rng(100 + rank)
+    comp = own[rng.permutation(len(own))]
+    prec, off, var = _oracle_rows(fmd, comp, min_match)
+    my = []
+    for p in range(pieces):
+        b, e = fdist.piece_begin(len(comp), p, pieces), fdist.piece_begin(len(comp), p + 1, pieces)
+        o = off[b:e + 1].astype(np.int64) - int(off[b])
+        my.append((torch.from_numpy(comp[b:e].astype(np.int32)), torch.from_numpy(prec[b:e].view(np.uint8).reshape(-1).copy()), torch.from_numpy(o),
+                   torch.from_numpy(var[int(off[b]):int(off[e])].copy())))
+    table = fdist.piecewise_exchange(torch, dist, rank, world, 0, pieces, rows_of_rank, my)
+    if rank == 0:
+        want_p, want_o, want_v = _oracle_rows(fmd, np.arange(n_ids, dtype=np.uint64), min_match)
+        ok = len(table) == n_ids
+        for i in range(n_ids):
+            r, v = table[i]
+            ok = ok and r == want_p[i].tobytes() and v == want_v[int(want_o[i]):int(want_o[i + 1])].tobytes()
+        q.put(bool(ok))
+    else:
+        assert table is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,pieces,key_shard", [(2, 4, 0), (3, 5, 0), (2, 3, 1), (3, 4, 1), (2, 1, 1)])
+def test_gather_in_pieces_and_key_shard_gloo(oracle_lib, world, pieces, key_shard):
+    """pieces x {id shard, key shard} at world 2 / 3: the root ends up with every id's packed row, byte for byte the oracle's --
+    i.e. key-shard rows == id-shard rows == the rows of one process."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    n_ids = 1001
+    ps = [ctx.Process(target=_pieces_worker, args=(r, world, port, os.path.join(GOLD, "tiny.fmd"), n_ids, 50, pieces, key_shard, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    ok = q.get(timeout=180)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
+
+
+def test_key_ranges_partition_the_key_space():
+    for world in (1, 2, 3, 7, 8):
+        ks = np.concatenate([np.arange(0, 1 << 12, dtype=np.uint64), np.random.default_rng(world).integers(0, 0xfffffffe, 20000, dtype=np.uint64),
+                             np.array([fdist.first_key(p, world) + d for p in range(world) for d in (-1, 0, 1) if 0 <= fdist.first_key(p, world) + d < 0xfffffffe], dtype=np.uint64)])
+        d = fdist.key_dest(ks, 0, world)
+        assert d.min() >= 0 and d.max() < world
+        for p in range(world):
+            hi = fdist.first_key(p + 1, world) if p + 1 < world else 0xfffffffe
+            assert ((d == p) == ((ks >= fdist.first_key(p, world)) & (ks < hi))).all()
