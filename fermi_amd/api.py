@@ -35,6 +35,7 @@ ABI_SYMBOLS = [
     "fmd_ovlp_pack_max_bytes", "fmd_ovlp_pack_work_bytes", "fmd_ovlp_pack_dev", "fmd_ovlp_packed_batch", "fmd_ovlp_packed_free", "fmd_table_alloc", "fmd_table_free", "fmd_ovlp_link_dev", "fmd_ovlp_packed_table",
     "fmd_ovlp_two_pass_ok", "fmd_ovlp_head_work_bytes", "fmd_ovlp_head_dev", "fmd_ovlp_tail_dev", "fmd_ovlp_pack_rows_dev",
     "fmd_comm_rccl_unique_id", "fmd_comm_rccl_init", "fmd_comm_rccl_version", "fmd_comm_free",
+    "fmd_ovlp_side_work_bytes", "fmd_ovlp_rerun_overflow_dev",
     "fmd_ovlp_dist_new", "fmd_ovlp_dist_step", "fmd_ovlp_dist_table", "fmd_ovlp_dist_local", "fmd_ovlp_dist_free",
 ]
 
@@ -137,6 +138,8 @@ def _configure(L):
     L.fmd_ovlp_head_dev.argtypes = [vp, vp, sz, u64p, C.c_int, C.c_uint32, vp, vp, vp, vp, vp, sz]
     L.fmd_ovlp_tail_dev.argtypes = [vp, vp, sz, vp, vp, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint32, vp, sz]
     L.fmd_ovlp_pack_rows_dev.argtypes = [vp, vp, sz, vp, vp, C.c_uint64, C.c_uint64, vp, vp, C.c_uint32, vp, C.c_uint32, vp, vp, vp, vp, C.c_uint64, vp, sz]
+    L.fmd_ovlp_side_work_bytes.restype = sz; L.fmd_ovlp_side_work_bytes.argtypes = [sz, C.c_uint32, C.c_int]
+    L.fmd_ovlp_rerun_overflow_dev.argtypes = [vp, vp, sz, vp, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp, C.c_uint32, vp, sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.fmd_comm_rccl_unique_id.argtypes = [vp]
     L.fmd_comm_rccl_init.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]
     L.fmd_comm_rccl_version.restype = C.c_int

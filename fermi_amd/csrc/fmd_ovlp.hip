@@ -1464,6 +1464,73 @@ extern "C" int fmd_ovlp_sorted_dev(fmd_dev_t *h, void *stream_, size_t n, const 
     return FMD_OK;
 }
 
+// ---- rows that exceeded a capacity: again, alone, larger -------------------------------------------------------------------------
+// fm6_get_nei has no capacities (kvec grows, unitig.c:93-179); here a row that needs more neighbours than max_nei, a longer candidate
+// list or more bases than max_len is flagged (FMD_OVLP_F_OVERFLOW) instead of answered.  This collects the ids of the flagged rows of
+// a finished job on the device and runs them through fmd_ovlp_dev with the capacities the caller names, into a side table; rows of
+// the side table that are still flagged are counted so that the caller can go one size up.
+__global__ void k_ovl_collect_overflow(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, const uint64_t *__restrict__ ids, uint64_t cap,
+                                       uint64_t *__restrict__ out_ids, uint32_t *__restrict__ out_rows, unsigned long long *__restrict__ counter)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x; i0 < n; i0 += step) {
+        const size_t i = i0 + threadIdx.x;
+        const bool hit = i < n && (rec[i].flags & FMD_OVLP_F_OVERFLOW) != 0;
+        const unsigned long long m = __ballot(hit);
+        if (m == 0) continue;
+        const int lane = threadIdx.x & 63;
+        unsigned long long base = 0;
+        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counter, (unsigned long long)__popcll(m));   // one atomic per wave that has any
+        base = __shfl(base, __ffsll((long long)m) - 1);
+        if (hit) {
+            const unsigned long long slot = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+            if (slot < cap) { out_ids[slot] = ids ? ids[i] : (uint64_t)i; if (out_rows) out_rows[slot] = (uint32_t)i; }
+        }
+    }
+}
+__global__ void k_ovl_count_overflow(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, unsigned long long *__restrict__ counter)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    unsigned long long c = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) c += (rec[i].flags & FMD_OVLP_F_OVERFLOW) != 0;
+    if (c) atomicAdd(counter, c);
+}
+extern "C" size_t fmd_ovlp_side_work_bytes(size_t side_cap, uint32_t max_len, int min_match)
+{
+    return 256 + fmd_ovlp_work_bytes(side_cap, max_len, min_match);
+}
+extern "C" int fmd_ovlp_rerun_overflow_dev(fmd_dev_t *h, void *stream_, size_t n, const uint64_t *d_ids, const fmd_ovlp_rec_t *d_rec, int min_match, uint32_t max_len,
+                                           uint32_t max_nei, uint64_t side_cap, uint64_t *d_side_ids, uint32_t *d_side_rows, fmd_ovlp_rec_t *d_side_rec, fmd_intv_t *d_side_nei,
+                                           uint8_t *d_side_seq, uint32_t side_stride, void *d_work, size_t work_bytes, uint64_t *n_side, uint64_t *n_still)
+{
+    if (!h || !n_side || !n_still || (n && !d_rec) || (side_cap && (!d_side_ids || !d_side_rec || !d_side_nei || !d_side_seq || !d_work)) || max_len == 0 || max_nei == 0) return FMD_E_ARG;
+    *n_side = 0; *n_still = 0;
+    if (n == 0) return FMD_OK;
+    if (work_bytes < fmd_ovlp_side_work_bytes(side_cap, max_len, min_match)) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream_;
+    unsigned long long *ctr = (unsigned long long *)d_work;   // [0] flagged rows of the job, [1] rows of the side table still flagged
+    FMD_HIP_TRY(hipMemsetAsync(ctr, 0, 16, st));
+    size_t blocks = (n + 255) / 256;
+    if (blocks > (1u << 16)) blocks = 1u << 16;
+    k_ovl_collect_overflow<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, d_ids, side_cap, d_side_ids, d_side_rows, ctr);
+    unsigned long long hc[2] = {0, 0};
+    FMD_HIP_TRY(hipMemcpyAsync(hc, ctr, 8, hipMemcpyDeviceToHost, st));
+    FMD_HIP_TRY(hipStreamSynchronize(st));
+    *n_side = hc[0];
+    if (hc[0] == 0) return FMD_OK;
+    if (hc[0] > side_cap) return FMD_E_OVERFLOW;    // (the caller's side table is too small: *n_side says how many rows there are)
+    const size_t k = (size_t)hc[0];
+    FMD_HIP_TRY(hipMemsetAsync(d_side_seq, 0, k * (size_t)side_stride, st));
+    const int rc = fmd_ovlp_dev(h, stream_, k, d_side_ids, min_match, max_len, max_nei, d_side_rec, d_side_nei, d_side_seq, side_stride, (uint8_t *)d_work + 256, work_bytes - 256);
+    if (rc != FMD_OK) return rc;
+    k_ovl_count_overflow<<<(unsigned)((k + 255) / 256 > 4096 ? 4096 : (k + 255) / 256), 256, 0, st>>>(k, d_side_rec, ctr + 1);
+    FMD_HIP_TRY(hipMemcpyAsync(hc + 1, ctr + 1, 8, hipMemcpyDeviceToHost, st));
+    FMD_HIP_TRY(hipStreamSynchronize(st));
+    *n_still = hc[1];
+    return FMD_OK;
+}
+
 // check_left_simple (unitig.c:186-204) for every strand of a finished fmd_ovlp_dev batch that has a
 // unique neighbour; writes rec.reserved.  Same buffers and work area as the fmd_ovlp_dev call.
 extern "C" int fmd_ovlp_check_left_dev(fmd_dev_t *h, void *stream_, size_t n, int min_match, uint32_t max_len, fmd_ovlp_rec_t *d_rec,

@@ -16,6 +16,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <time.h>
+#include <algorithm>
 #include <vector>
 #include "fmd_kernel_common.h"
 #include "fmd_internal.h"
@@ -142,18 +143,32 @@ extern "C" void fmd_comm_free(fmd_comm_t *c)
 }
 
 // ------------------------------------------------------------------------------------------------ key shard: kernels
-// Destination of a strand by its minimizer key: W equal ranges of the 32-bit key space (the keys are hashes: uniform); the two
-// special keys (0xffffffff: the strand ended inside the head; 0xfffffffe: no k-mer without an ambiguous base) stay where they are.
-__host__ __device__ static inline uint32_t ks_first_key(int p, int world) { return (uint32_t)((((uint64_t)p << 32) + (uint64_t)world - 1) / (uint64_t)world); }
-
-// counts[p], p < world: strands for rank p; counts[world]: strands that stay (special keys).  keys ascending.
-__global__ void k_ks_counts(size_t n, const uint32_t *__restrict__ keys, int world, unsigned long long *__restrict__ counts)
+// Destination of a strand by its minimizer key: W contiguous key ranges; the two special keys (0xffffffff: the strand ended inside
+// the head; 0xfffffffe: no k-mer without an ambiguous base) stay where they are.  A minimizer is the SMALLEST of 17 hashes, so the
+// keys crowd towards 0 (and a repeat-rich read set skews them further): the range boundaries are quantiles of the data -- every
+// rank's id shard is a uniform sample of the strands, so each takes the p/W quantiles of its own sorted keys, the ranks all-gather
+// them and everybody uses the median over the ranks.
+__device__ static inline size_t ks_lower(const uint32_t *keys, size_t n, uint32_t v)
+{
+    size_t lo = 0, hi = n;
+    while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (keys[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__global__ void k_ks_quantiles(size_t n, const uint32_t *__restrict__ keys, int world, uint32_t *__restrict__ out)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= world) return;
+    const size_t n_reg = ks_lower(keys, n, 0xfffffffeu);
+    out[p] = p == 0 || n_reg == 0 ? 0u : keys[(size_t)((unsigned __int128)n_reg * (unsigned)p / (unsigned)world)];
+}
+// counts[p], p < world: strands for rank p = keys in [split[p], split[p + 1]); counts[world]: strands that stay (special keys).
+// keys ascending; split[0] = 0, split[world] = 0xfffffffe.
+__global__ void k_ks_counts(size_t n, const uint32_t *__restrict__ keys, int world, const uint32_t *__restrict__ split, unsigned long long *__restrict__ counts)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p > world) return;
-    auto lower = [&](uint32_t v) { size_t lo = 0, hi = n; while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (keys[mid] < v) lo = mid + 1; else hi = mid; } return lo; };
-    const size_t a = p < world ? lower(ks_first_key(p, world)) : lower(0xfffffffeu);
-    const size_t b = p + 1 < world ? lower(ks_first_key(p + 1, world)) : (p + 1 == world ? lower(0xfffffffeu) : n);
+    const size_t a = ks_lower(keys, n, split[p]);
+    const size_t b = p < world ? ks_lower(keys, n, split[p + 1]) : n;
     counts[p] = (unsigned long long)(b - a);
 }
 // the parked strands in key order, each stamped with its sequence id (pad.x/y); a strand that ended inside the head carries what
@@ -257,8 +272,8 @@ struct fmd_ovlp_dist {
     uint32_t stride;
     uint64_t n_home, cap_rows, n_rows;          // strands of pass 1; capacity / number of the rows this rank computes
     size_t piece_max, var_cap_piece;
-    DBuf ids_home, ids_loc, park_home, park_send, park_loc, keys, order, rec, nei, seq, work, pack_work, cnt_dev, sizes_dev;
-    HBuf cnt_host, sizes_host;
+    DBuf ids_home, ids_loc, park_home, park_send, park_loc, keys, order, rec, nei, seq, work, pack_work, cnt_dev, sizes_dev, split_dev;
+    HBuf cnt_host, sizes_host, split_host;
     Stage out[2];                               // this rank's piece on its way out (non-root: set 0; root with a host table: set p & 1)
     std::vector<Stage> in[2];                   // root, host mode: staging per peer, two sets
     // the table at the root
@@ -274,18 +289,24 @@ struct fmd_ovlp_dist {
 };
 
 static uint64_t shard_size(uint64_t n_ids, int r, int world) { return n_ids > (uint64_t)r ? (n_ids - (uint64_t)r + (uint64_t)world - 1) / (uint64_t)world : 0; }
-static uint64_t piece_begin(uint64_t rows, int p, int pieces) { return (uint64_t)((unsigned __int128)rows * (unsigned)p / (unsigned)pieces); }
+// pieces shrink towards the end (P : P-1 : ... : 1 -- 40 / 30 / 20 / 10 % for four): what cannot hide under compute is the pack + transfer
+// of the LAST piece, so that one is the smallest
+static uint64_t piece_begin(uint64_t rows, int p, int pieces)
+{
+    const unsigned __int128 num = (unsigned __int128)(unsigned)p * (unsigned)(2 * pieces - p + 1), den = (unsigned __int128)(unsigned)pieces * (unsigned)(pieces + 1);
+    return (uint64_t)((unsigned __int128)rows * num / den);
+}
 
 extern "C" void fmd_ovlp_dist_free(fmd_ovlp_dist_t *d)
 {
     if (!d) return;
     hipSetDevice(d->h->device);
     hipDeviceSynchronize();
-    DBuf *bs[] = {&d->ids_home, &d->ids_loc, &d->park_home, &d->park_send, &d->park_loc, &d->keys, &d->order, &d->rec, &d->nei, &d->seq, &d->work, &d->pack_work, &d->cnt_dev,
+    DBuf *bs[] = {&d->ids_home, &d->ids_loc, &d->park_home, &d->park_send, &d->park_loc, &d->keys, &d->order, &d->rec, &d->nei, &d->seq, &d->work, &d->pack_work, &d->cnt_dev, &d->split_dev,
                   &d->sizes_dev, &d->t_prec, &d->t_ids, &d->t_vaddr, &d->t_row_of, &d->t_off, &d->out[0].pid, &d->out[0].prec, &d->out[0].off, &d->out[0].var, &d->out[0].vaddr, &d->out[1].pid, &d->out[1].prec, &d->out[1].off, &d->out[1].var, &d->out[1].vaddr};
     for (DBuf *b : bs) b->drop();
     for (int k = 0; k < 2; ++k) for (Stage &s : d->in[k]) { s.pid.drop(); s.prec.drop(); s.off.drop(); s.var.drop(); s.vaddr.drop(); }
-    HBuf *hs[] = {&d->cnt_host, &d->sizes_host, &d->th_prec, &d->th_ids, &d->th_vaddr, &d->th_row_of};
+    HBuf *hs[] = {&d->cnt_host, &d->sizes_host, &d->split_host, &d->th_prec, &d->th_ids, &d->th_vaddr, &d->th_row_of};
     for (HBuf *b : hs) b->drop();
     d->var.drop();
     for (hipEvent_t e : d->done) if (e) hipEventDestroy(e);
@@ -319,11 +340,11 @@ extern "C" int fmd_ovlp_dist_new(fmd_dev_t *h, fmd_comm_t *comm, const fmd_ovlp_
         const uint64_t bmax = cfg->batch ? cfg->batch : 20000000ull;
         uint64_t P = cfg->pieces ? cfg->pieces : 4;
         const uint64_t rows_max = d->cfg.key_shard ? n_max + n_max / 8 + 65536 : n_max;
-        if ((rows_max + P - 1) / P > bmax) P = (rows_max + bmax - 1) / bmax;
+        while (rows_max * 2 / (P + 1) + 2 > bmax && P < 4096) ++P;
         if (!cfg->pieces) while (P > 1 && n_max / P < 262144) --P;
         if (P > 4096) P = 4096;
         d->pieces = (int)P;
-        d->piece_max = (size_t)((rows_max + P - 1) / P + 1);
+        d->piece_max = (size_t)(rows_max * 2 / (P + 1) + 2);   // the first piece is the largest: 2 / (P + 1) of the rows
     }
     d->var_cap_piece = fmd_ovlp_pack_max_bytes(d->piece_max, cfg->max_nei, d->stride);
     int rc = FMD_OK;
@@ -346,6 +367,8 @@ extern "C" int fmd_ovlp_dist_new(fmd_dev_t *h, fmd_comm_t *comm, const fmd_ovlp_
     NEED(d->pack_work, fmd_ovlp_pack_work_bytes(d->piece_max));
     NEED(d->cnt_dev, (size_t)(d->world + 1) * 8 * (size_t)(d->world + 1));
     NEED(d->sizes_dev, 16 * (size_t)(d->world + 1));
+    NEED(d->split_dev, 4 * ((size_t)d->world * (d->world + 2) + 2));
+    if (rc == FMD_OK) rc = d->split_host.need(4 * ((size_t)d->world * (d->world + 2) + 2));
     if (rc == FMD_OK) rc = d->cnt_host.need((size_t)(d->world + 1) * 8 * (size_t)(d->world + 1));
     if (rc == FMD_OK) rc = d->sizes_host.need(16 * (size_t)(d->world + 1));
     // where the table lives at the root
@@ -403,10 +426,29 @@ static int key_exchange(fmd_ovlp_dist *d, hipStream_t sc, uint64_t *rows_out, st
     const int W = d->world, me = d->rank;
     const size_t n = d->n_home;
     unsigned long long *cnt = (unsigned long long *)d->cnt_dev.p;           // [W + 1] mine, then [W][W + 1] everybody's
-    k_ks_counts<<<(W + 1 + 63) / 64, 64, 0, sc>>>(n, (const uint32_t *)d->keys.p, W, cnt);
+    // the key ranges: everybody's quantiles, the median of each
+    uint32_t *q_dev = (uint32_t *)d->split_dev.p, *q_all = q_dev + W, *split_dev = q_all + (size_t)W * W;   // [W] mine, [W][W] everybody's, [W + 1] the boundaries
+    uint32_t *q_host = (uint32_t *)d->split_host.p, *split = q_host + (size_t)W * W;
+    k_ks_quantiles<<<(W + 63) / 64, 64, 0, sc>>>(n, (const uint32_t *)d->keys.p, W, q_dev);
+    int rc = d->comm->allgather(d->comm->ctx, sc, q_dev, q_all, (size_t)W * 4);
+    if (rc != FMD_OK) return rc;
+    FMD_HIP_TRY(hipMemcpyAsync(q_host, q_all, (size_t)W * W * 4, hipMemcpyDeviceToHost, sc));
+    FMD_HIP_TRY(hipStreamSynchronize(sc));
+    split[0] = 0; split[W] = 0xfffffffeu;
+    for (int p = 1; p < W; ++p) {
+        std::vector<uint32_t> v((size_t)W);
+        for (int r = 0; r < W; ++r) v[(size_t)r] = q_host[(size_t)r * W + p];
+        std::sort(v.begin(), v.end());
+        uint32_t m_ = v[(size_t)(W - 1) / 2];
+        if (m_ < split[p - 1]) m_ = split[p - 1];
+        if (m_ > 0xfffffffeu) m_ = 0xfffffffeu;
+        split[p] = m_;
+    }
+    FMD_HIP_TRY(hipMemcpyAsync(split_dev, split, (size_t)(W + 1) * 4, hipMemcpyHostToDevice, sc));
+    k_ks_counts<<<(W + 1 + 63) / 64, 64, 0, sc>>>(n, (const uint32_t *)d->keys.p, W, split_dev, cnt);
     k_ks_gather<<<nblk(n, 64), 256, 0, sc>>>(n, (const uint32_t *)d->order.p, (const FmdWalkPark *)d->park_home.p, (const uint64_t *)d->ids_home.p,
                                            (const fmd_ovlp_rec_t *)d->rec.p, (FmdWalkPark *)d->park_send.p);
-    int rc = d->comm->allgather(d->comm->ctx, sc, cnt, cnt + (W + 1), (size_t)(W + 1) * 8);
+    rc = d->comm->allgather(d->comm->ctx, sc, cnt, cnt + (W + 1), (size_t)(W + 1) * 8);
     if (rc != FMD_OK) return rc;
     uint64_t *mat = (uint64_t *)d->cnt_host.p;
     FMD_HIP_TRY(hipMemcpyAsync(mat, cnt + (W + 1), (size_t)W * (W + 1) * 8, hipMemcpyDeviceToHost, sc));
@@ -418,7 +460,7 @@ static int key_exchange(fmd_ovlp_dist *d, hipStream_t sc, uint64_t *rows_out, st
         for (int s = 0; s < W; ++s) m += mat[(size_t)s * (W + 1) + q];
         rows_of_rank[(size_t)q] = m;
         const uint64_t nq = shard_size(d->cfg.n_ids, q, W), capq = nq + nq / 8 + 65536;
-        if (m > capq || (m + (uint64_t)d->pieces - 1) / (uint64_t)d->pieces + 1 > d->piece_max) *fell_back = 1;
+        if (m > capq || piece_begin(m, 1, d->pieces) + 1 > d->piece_max) *fell_back = 1;
     }
     if (*fell_back) return FMD_OK;
     // my segments in park_send: [to 0 | to 1 | ... | to W-1 | special]; what I receive, in rank order, then my own special rows

@@ -490,30 +490,45 @@ class DistJob:
 
 # ---- the same exchange logic over plain tensors (the twin the CPU tests run, gloo, on rows the oracle computed) ------------------
 def piece_begin(rows, p, pieces):
-    return rows * p // pieces
+    """first row of piece p of `pieces`: the pieces shrink P : P-1 : ... : 1 (fmd_ovlp_dist.hip), the last one -- whose transfer nothing hides -- is the smallest."""
+    return rows * (p * (2 * pieces - p + 1)) // (pieces * (pieces + 1))
 
 
-def first_key(p, world):
-    """smallest 32-bit key that goes to rank p (fmd_ovlp_dist.hip: ks_first_key)."""
-    return ((p << 32) + world - 1) // world
+def local_quantiles(keys_sorted, world):
+    """the p / W quantiles (p = 0 .. W-1; 0 for p = 0) of this rank's regular keys (k_ks_quantiles)."""
+    k = np.asarray(keys_sorted, dtype=np.uint64)
+    n_reg = int(np.searchsorted(k, np.uint64(0xfffffffe), side="left"))
+    return np.array([0 if p == 0 or n_reg == 0 else int(k[n_reg * p // world]) for p in range(world)], dtype=np.int64)
 
 
-def key_dest(keys, rank, world):
-    """destination rank of every key (numpy uint32/uint64 array): W equal ranges; the two special keys stay on `rank`."""
-    import numpy as np
+def key_splitters(torch, dist, keys_sorted, world):
+    """The boundaries of the W key ranges, the same on every rank: split[0] = 0, split[W] = 0xfffffffe, split[p] = the median over the ranks of
+    their p / W quantiles (a minimizer is the smallest of 17 hashes: the keys crowd towards 0, equal ranges would not be equal shares)."""
+    mine = torch.from_numpy(local_quantiles(keys_sorted, world))
+    allq = [torch.zeros(world, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(allq, mine)
+    allq = torch.stack(allq).numpy()
+    split = [0]
+    for p in range(1, world):
+        m = int(np.sort(allq[:, p])[(world - 1) // 2])
+        split.append(min(max(m, split[-1]), 0xfffffffe))
+    split.append(0xfffffffe)
+    return np.array(split, dtype=np.uint64)
+
+
+def key_dest(keys, rank, split):
+    """destination rank of every key (numpy array): rank p takes [split[p], split[p + 1]); the two special keys stay on `rank`."""
     k = np.asarray(keys, dtype=np.uint64)
-    d = (k * np.uint64(world)) >> np.uint64(32)
-    # (k * W >> 32 == p  <=>  first_key(p) <= k < first_key(p + 1))
-    d = d.astype(np.int64)
+    d = (np.searchsorted(split, k, side="right") - 1).astype(np.int64)
     d[k >= np.uint64(0xfffffffe)] = rank
     return d
 
 
 def key_shard_rows(torch, dist, rank, world, park, keys):
     """The all-to-all of the parked strands: park [n, 64] uint8 rows in ascending key order, keys [n] (numpy uint32, ascending).
-    -> (rows this rank owns afterwards [m, 64] in arrival order: rank 0's, rank 1's, ..., then its own special rows; counts matrix)."""
-    import numpy as np
-    dest = key_dest(keys, rank, world)
+    -> (rows this rank owns afterwards [m, 64] in arrival order: rank 0's, rank 1's, ..., then its own special rows; counts matrix; the splitters)."""
+    split = key_splitters(torch, dist, keys, world)
+    dest = key_dest(keys, rank, split)
     special = np.asarray(keys, dtype=np.uint64) >= np.uint64(0xfffffffe)
     counts = np.array([int(((dest == q) & ~special).sum()) for q in range(world)] + [int(special.sum())], dtype=np.int64)
     mat = [torch.zeros(world + 1, dtype=torch.int64) for _ in range(world)]
@@ -535,7 +550,7 @@ def key_shard_rows(torch, dist, rank, world, park, keys):
     for r in reqs:
         r.wait()
     got.append(park[int(soff[world]):int(soff[world + 1])].clone())
-    return torch.cat(got), mat
+    return torch.cat(got), mat, split
 
 
 def piecewise_exchange(torch, dist, rank, world, root, pieces, rows_of_rank, my_pieces):

@@ -206,6 +206,7 @@ void fmdh_ovlp_table_free(fmdh_ovlp_table_t *t)
     memset(t, 0, sizeof(*t));
 }
 
+static int cmp_u64(const void *a, const void *b) { const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b; return x < y ? -1 : x > y; }
 int fmdh_ovlp_table_build(const char *fmd_path, int n_dev, const int *devices, int min_match, fmdh_ovlp_table_t *t, uint64_t *n_seq_out)
 {
     const int timing = getenv("FMD_TIMING") != 0;
@@ -214,7 +215,7 @@ int fmdh_ovlp_table_build(const char *fmd_path, int n_dev, const int *devices, i
     pthread_t *tid;
     char *started;
     uint64_t *ids = 0, n_side = 0, n_seq, i;
-    int g, rc = 0;
+    int g, rc = 0, too_long_hint = 0;
     double t0 = now_s();
     if (n_dev < 1 || !devices || !t) return 1;
     memset(t, 0, sizeof(*t));
@@ -244,20 +245,33 @@ int fmdh_ovlp_table_build(const char *fmd_path, int n_dev, const int *devices, i
     if (n_seq >= 0xffffffffull) { fprintf(stderr, "[E::%s] %llu sequences: the walk's row map holds 32-bit ids\n", __func__, (unsigned long long)n_seq); rc = 1; goto done; }
     /* the rows that did not fit (longer sequences, more neighbours, longer lists): again, alone, with the capacities
      * doubled until they do -- on the GPU; nothing falls back to the CPU */
-    for (i = 0; i < n_seq; ++i) n_side += (t->shard[i % (uint64_t)n_dev].rec[i / (uint64_t)n_dev].flags & FMD_OVLP_F_OVERFLOW) != 0;
+    {   /* one pass over the records: the flagged ids, and whether any of them is a sequence longer than max_len */
+        uint64_t cap_ids = 0;
+        int too_long = 0;
+        for (g = 0; g < n_dev; ++g) {
+            const fmd_ovlp_rec_t *r = t->shard[g].rec;
+            const uint64_t m = t->shard[g].n;
+            for (i = 0; i < m; ++i) if (r[i].flags & FMD_OVLP_F_OVERFLOW) {
+                if (n_side == cap_ids) { cap_ids = cap_ids ? 2 * cap_ids : 1 << 16; ids = (uint64_t *)realloc(ids, cap_ids * 8); if (!ids) { rc = 1; goto done; } }
+                ids[n_side++] = i * (uint64_t)n_dev + (uint64_t)g;
+                too_long |= (uint32_t)r[i].len > max_len;
+            }
+        }
+        too_long_hint = too_long;
+    }
     if (n_side) {
         uint32_t s_len = max_len, s_nei = max_nei;
-        uint64_t k = 0;
         int attempt;
         double t1 = now_s();
-        ids = (uint64_t *)malloc(n_side * 8);
         t->side_of = (uint32_t *)malloc(n_seq * 4);
         if (!ids || !t->side_of) { rc = 1; goto done; }
-        for (i = 0; i < n_seq; ++i) if (t->shard[i % (uint64_t)n_dev].rec[i / (uint64_t)n_dev].flags & FMD_OVLP_F_OVERFLOW) ids[k++] = i;
+        if (n_dev > 1) qsort(ids, n_side, 8, cmp_u64);   /* (one shard: ascending already) */
         for (attempt = 0;; ++attempt) {
             uint64_t n_over = 0;
             if (attempt == 12) { fprintf(stderr, "[E::%s] %llu rows still overflow at max_len %u, max_nei %u\n", __func__, (unsigned long long)n_side, s_len, s_nei); rc = 1; goto done; }
-            s_len *= 2; s_nei *= 2;
+            /* what overflows in practice is the neighbour list of a strand in a fork-rich corner (more than max_nei irreducible overlaps): room for
+             * four times as many at once, longer sequences / candidate lists only where a flagged record says so or the first attempt was not enough */
+            if (attempt == 0) { s_nei *= 4; if (too_long_hint) s_len *= 2; } else { s_len *= 2; s_nei *= 2; }
             shard_free(&t->side);
             rc = shard_fill(jobs[0].dev, &t->side, ids, 0, 0, n_side, min_match, s_len, s_nei, 0);
             if (rc) { fprintf(stderr, "[E::%s] overflow pass: %s\n", __func__, fmd_strerror(rc)); rc = 1; goto done; }

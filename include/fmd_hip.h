@@ -219,6 +219,17 @@ size_t fmd_ovlp_sorted_work_bytes(size_t n, size_t batch, uint32_t max_len, int 
 int fmd_ovlp_sorted_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_ids, int min_match, uint32_t max_len,
                         uint32_t max_nei, fmd_ovlp_rec_t *d_rec, fmd_intv_t *d_nei, uint8_t *d_seq, uint32_t seq_stride,
                         void *d_work, size_t work_bytes, size_t batch);
+/* Rows that exceeded a capacity, again, alone, larger.  fm6_get_nei has no capacities (its vectors grow, unitig.c:93-179); a row of the calls above
+ * that needs more than max_nei neighbours, a longer candidate list or more bases than max_len carries FMD_OVLP_F_OVERFLOW instead of a
+ * result.  This entry collects the flagged rows of a finished job on the device (d_side_ids[k] = their ids -- d_ids[i], or i when d_ids is
+ * NULL --, d_side_rows[k] = their rows, any order; d_side_rows may be NULL) and runs them through fmd_ovlp_dev with the capacities named
+ * here into the side arrays (row k of d_side_rec / d_side_nei [max_nei per row] / d_side_seq [side_stride per row]).  *n_side = rows
+ * collected (FMD_E_OVERFLOW when they exceed side_cap: nothing was run), *n_still = rows of the side table that are flagged again
+ * (call again on the side table with larger capacities).  Synchronises the stream twice (the counts come back to the host). */
+size_t fmd_ovlp_side_work_bytes(size_t side_cap, uint32_t max_len, int min_match);
+int fmd_ovlp_rerun_overflow_dev(fmd_dev_t *h, void *stream, size_t n, const uint64_t *d_ids, const fmd_ovlp_rec_t *d_rec, int min_match, uint32_t max_len,
+                                uint32_t max_nei, uint64_t side_cap, uint64_t *d_side_ids, uint32_t *d_side_rows, fmd_ovlp_rec_t *d_side_rec, fmd_intv_t *d_side_nei,
+                                uint8_t *d_side_seq, uint32_t side_stride, void *d_work, size_t work_bytes, uint64_t *n_side, uint64_t *n_still);
 /* Optional second step over the same buffers: check_left_simple (unitig.c:186-204) for every
  * strand with a unique neighbour -> rec.reserved (the unitig walk needs it; plain overlap
  * discovery does not, and records of fmd_ovlp_dev alone carry reserved = 2). */

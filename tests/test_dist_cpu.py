@@ -121,11 +121,15 @@ def test_gather_packed_records_gloo(oracle_lib, world, mode):
 
 # ---- round 4: the gather in pieces and the key shard (fermi_amd/dist.py: the twin of fmd_ovlp_dist_step's exchange logic) ----------
 def _fake_key(ids):
-    """a 32-bit hash of the id standing in for the minimizer key (the exchange only needs keys that scatter)"""
-    v = (np.asarray(ids, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(32)
-    v = v.astype(np.uint64)
-    v[np.asarray(ids) % 97 == 5] = 0xffffffff     # strands that ended inside the head: stay at home
-    v[np.asarray(ids) % 89 == 7] = 0xfffffffe     # no usable minimizer: stay at home
+    """a 32-bit key per id standing in for the minimizer key: the smallest of 17 hashes, as a minimizer is -- crowded towards 0, so that equal
+    key ranges would be very unequal shares (what the quantile splitters are there for)"""
+    ids = np.asarray(ids, dtype=np.uint64)
+    v = np.full(len(ids), 0xffffffff, dtype=np.uint64)
+    for j in range(17):
+        h = ((ids * np.uint64(17) + np.uint64(j)) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(32)
+        v = np.minimum(v, h)
+    v[ids % np.uint64(97) == 5] = 0xffffffff     # strands that ended inside the head: stay at home
+    v[ids % np.uint64(89) == 7] = 0xfffffffe     # no usable minimizer: stay at home
     return v.astype(np.uint32)
 
 
@@ -142,14 +146,15 @@ def _pieces_worker(rank, world, port, fmd, n_ids, min_match, pieces, key_shard, 
         order = np.argsort(keys, kind="stable")
         park = np.zeros((len(home), 64), dtype=np.uint8)
         park[:, 48:56] = home[:, None].view(np.uint8).reshape(len(home), 8)          # pad.x/y = the id, as k_ks_gather stamps it
-        got, mat = fdist.key_shard_rows(torch, dist, rank, world, torch.from_numpy(park[order]), keys[order])
+        got, mat, split = fdist.key_shard_rows(torch, dist, rank, world, torch.from_numpy(park[order]), keys[order])
         own = got.numpy()[:, 48:56].copy().view(np.uint64).reshape(-1)
-        # every row this rank owns has a key in its range, or is one of its own special rows
+        # every row this rank owns has a key in its range, or is one of its own special rows; the shares are near n / world although
+        # three quarters of the keys lie in the lowest eighth of the key space
         k_own = _fake_key(own).astype(np.uint64)
-        lo, hi = fdist.first_key(rank, world), (fdist.first_key(rank + 1, world) if rank + 1 < world else 0xfffffffe)
         sp = k_own >= 0xfffffffe
-        assert ((k_own[~sp] >= lo) & (k_own[~sp] < hi)).all() and (own[sp] % world == rank).all()
-        assert np.array_equal(fdist.key_dest(k_own[~sp], rank, world), np.full(int((~sp).sum()), rank))
+        assert ((k_own[~sp] >= split[rank]) & (k_own[~sp] < split[rank + 1])).all() and (own[sp] % world == rank).all()
+        assert np.array_equal(fdist.key_dest(k_own[~sp], rank, split), np.full(int((~sp).sum()), rank))
+        assert abs(len(own) - n_ids / world) < 0.15 * n_ids / world, (len(own), n_ids, world)
         cnt = torch.zeros(world, dtype=torch.int64); cnt[rank] = len(own)
         dist.all_reduce(cnt)
         rows_of_rank = [int(c) for c in cnt]
@@ -196,12 +201,14 @@ def test_gather_in_pieces_and_key_shard_gloo(oracle_lib, world, pieces, key_shar
     assert ok
 
 
-def test_key_ranges_partition_the_key_space():
+def test_key_splitters_partition_the_key_space():
     for world in (1, 2, 3, 7, 8):
-        ks = np.concatenate([np.arange(0, 1 << 12, dtype=np.uint64), np.random.default_rng(world).integers(0, 0xfffffffe, 20000, dtype=np.uint64),
-                             np.array([fdist.first_key(p, world) + d for p in range(world) for d in (-1, 0, 1) if 0 <= fdist.first_key(p, world) + d < 0xfffffffe], dtype=np.uint64)])
-        d = fdist.key_dest(ks, 0, world)
+        split = np.array([0] + sorted(np.random.default_rng(world).integers(1, 0xfffffffe, world - 1).tolist()) + [0xfffffffe], dtype=np.uint64)
+        ks = np.concatenate([np.arange(0, 1 << 12, dtype=np.uint64), np.random.default_rng(world + 9).integers(0, 0xfffffffe, 20000, dtype=np.uint64),
+                             np.array([int(b) + d for b in split for d in (-1, 0, 1) if 0 <= int(b) + d < 0xfffffffe], dtype=np.uint64)])
+        d = fdist.key_dest(ks, 0, split)
         assert d.min() >= 0 and d.max() < world
         for p in range(world):
-            hi = fdist.first_key(p + 1, world) if p + 1 < world else 0xfffffffe
-            assert ((d == p) == ((ks >= fdist.first_key(p, world)) & (ks < hi))).all()
+            assert ((d == p) == ((ks >= split[p]) & (ks < split[p + 1]))).all()
+        assert (fdist.key_dest(np.array([0xfffffffe, 0xffffffff], dtype=np.uint64), 5, split) == 5).all()
+    assert list(fdist.local_quantiles(np.array([3, 5, 9, 11, 0xfffffffe, 0xffffffff], dtype=np.uint32), 2)) == [0, 9]
