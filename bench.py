@@ -65,9 +65,61 @@ def csrc_sha(leg=None, read=None):
     return h.hexdigest()[:16]
 
 
+PMC_LIVE = {}     # leg key -> (bytes per step, source): measured by THIS run (pmc_in_run), preferred over the look-up below
+PROBE = {}        # the bare random-gather probe of this run (64-byte lines over 8 GiB): the ceiling that applies to a path made of random lines
+
+
+def pmc_in_run(fmd_path, n_reads, steps=2):
+    """roofline.traffic measured in the run that prints it: when rocprofv3 is on the box, two short child processes run `steps` steps of
+    the headline leg (tools/pmc_legs.py on the .fmd this run wrote) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate
+    passes, counters only, as MI355X_MICROARCH.md prescribes), a third runs the gather probe for the FETCH_SIZE calibration (known byte
+    count, 64-byte lines).  -> PMC_LIVE["overlap@n"], PMC_LIVE["check_left@n"]; on any failure the tracked look-up stays in place."""
+    import csv, glob, shutil, subprocess
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe or os.environ.get("FMD_BENCH_PMC", "1") == "0":
+        return "not run (%s)" % ("FMD_BENCH_PMC=0" if exe else "no rocprofv3 on this box")
+    t0 = time.time()
+    out = tempfile.mkdtemp(prefix="fmd_pmc_")
+    env = dict(os.environ, TMPDIR="/tmp", PMC_LEGS="overlap", PMC_FMD=fmd_path, FMD_BENCH_READS=str(n_reads), PROBE_LINE="64")
+    legs, probe = os.path.join(ROOT, "tools", "pmc_legs.py"), os.path.join(ROOT, "tools", "probe_once.py")
+    try:
+        for sub, ctr, script, args in (("f", "FETCH_SIZE", legs, [str(steps)]), ("w", "WRITE_SIZE", legs, [str(steps)]), ("p", "FETCH_SIZE", probe, [])):
+            r = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(out, sub), "-o", "x", "--", sys.executable, script] + args,
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+            if r.returncode != 0:
+                return "failed (%s pass: rc %d: %s)" % (ctr, r.returncode, r.stderr.decode(errors="replace")[-200:].replace("\n", " "))
+
+        def sums(sub, ctr):
+            acc = {}
+            for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == ctr:
+                        k = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+                        acc[k] = acc.get(k, 0.0) + float(row["Counter_Value"])
+            return acc
+        fetch, write, pr = sums("f", "FETCH_SIZE"), sums("w", "WRITE_SIZE"), sums("p", "FETCH_SIZE")
+        if not pr.get("k_probe") or not fetch:
+            return "failed (no counter rows)"
+        cal = 2 * (1 << 27) * 64 / (pr["k_probe"] * 1024.0)      # probe_once: warm-up + one launch, 2^27 lines of 64 bytes each
+        src = "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over %d steps of the leg on the index this run built; KB units, FETCH_SIZE x %.4f (gather probe, 64-byte lines, same run)" % (steps, cal)
+        OVL = ("k_ovl_head_adm", "k_ovl_walk", "k_ovl_park_keys", "k_ovl_seq_out", "k_ovl_classify", "k_ovl_nei_fast", "k_ovl_nei_grp", "k_ovl_nei", "k_ovl_fix")
+        for key, names in (("overlap@%d" % n_reads, OVL), ("check_left@%d" % n_reads, ("k_link_rows", "k_link_edges", "k_ovl_cls"))):
+            fk = sum(v for k, v in fetch.items() if k in names) / steps
+            wk = sum(v for k, v in write.items() if k in names) / steps
+            if fk:
+                PMC_LIVE[key] = ((fk * cal + wk) * 1024.0, src)
+        return "ok (%.0f s)" % (time.time() - t0)
+    except Exception as ex:
+        return "failed (%r)" % (ex,)
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def pmc_traffic(key):
-    """HBM bytes per step from the separate rocprofv3 --pmc passes (tools/pmc_pass.sh -> profiles/pmc_traffic.json);
-    None unless the entry was measured on the kernel sources of this tree."""
+    """HBM bytes per step: measured by this run when it could (pmc_in_run), else from the separate rocprofv3 --pmc passes of the builder
+    (tools/pmc_collect.sh -> profiles/pmc_traffic.json) -- None unless that entry was measured on the kernel sources of this tree."""
+    if key in PMC_LIVE:
+        return PMC_LIVE[key]
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key)
         if pmc and pmc.get("csrc_sha") == csrc_sha(key.split("@")[0]):
@@ -91,9 +143,8 @@ def usable_cpus():
 
 def roofline(kernel, kern_ms, device_bytes, model, alg_bytes, traffic_key, extra=None):
     """The roofline object of one leg.  device_bytes may be None (instrumented build missing)."""
-    tr, src = pmc_traffic(traffic_key)
     r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": kernel, "kernel_ms": kern_ms,
-         "achieved": None, "frac": None, "traffic": tr, "traffic_source": src,
+         "achieved": None, "frac": None, "traffic": None, "traffic_source": None, "_traffic_key": traffic_key,
          "achieved_definition": "device bytes (64 B x rank blocks requested, counted by the instrumented build of the same kernels, "
                                 "+ the streams they read/write) / HIP-event time of the timed steps",
          "device_bytes_model": model,
@@ -102,11 +153,21 @@ def roofline(kernel, kern_ms, device_bytes, model, alg_bytes, traffic_key, extra
     if device_bytes is not None:
         r["achieved"] = device_bytes / (kern_ms * 1e-3) / 1e9
         r["frac"] = r["achieved"] / HBM_PEAK_GBS
-    if tr:
-        r["traffic_GBps"] = tr / (kern_ms * 1e-3) / 1e9
-        r["traffic_frac_of_peak"] = r["traffic_GBps"] / HBM_PEAK_GBS
     if extra:
         r.update(extra)
+    return apply_traffic(r)
+
+
+def apply_traffic(r):
+    """(Re)fill the PMC fields of a roofline object from the best source there is now (the in-run pass comes after the legs it prices)."""
+    tr, src = pmc_traffic(r["_traffic_key"])
+    r["traffic"], r["traffic_source"] = tr, src
+    if tr:
+        r["traffic_GBps"] = tr / (r["kernel_ms"] * 1e-3) / 1e9
+        r["traffic_frac_of_peak"] = r["traffic_GBps"] / HBM_PEAK_GBS
+    if PROBE.get("GB_per_s"):   # the ceiling of a path whose unit of work is a random 64-byte line: the bare gather probe of this run
+        r["frac_of_random_gather_probe"] = {"probe_GBps": PROBE["GB_per_s"], "requested_bytes": r["achieved"] / PROBE["GB_per_s"] if r["achieved"] else None,
+                                            "traffic": r["traffic_GBps"] / PROBE["GB_per_s"] if tr else None}
     return r
 
 
@@ -255,13 +316,8 @@ def bench_bsearch(torch, api, workload, dev, local_rank, steps, warmup):
                                     "streams": "reads %d B + 3 x 8 B results per read" % L},
                                    qpr * BYTES_PER_RANK_QUERY * n_reads, "k_bsearch@%d" % n_reads,
                                    {"rank_queries_per_read": qpr})
-        try:
-            if os.environ.get("FMD_BENCH_PROBE", "1") != "0":
-                nl = 1 << 27
-                pms = api.probe_gather(8 << 30, 64, nl, iters=3, device=local_rank)
-                out["roofline"]["random_gather_probe"] = {"line_bytes": 64, "working_set_GiB": 8, "lines_per_s": nl / (pms * 1e-3), "GB_per_s": nl * 64 / (pms * 1e-3) / 1e9}
-        except Exception:
-            pass
+        if PROBE:
+            out["roofline"]["random_gather_probe"] = dict(PROBE)
         ns = min(n_reads, int(os.environ.get("FMD_BENCH_CPU_SAMPLE", "1000000")))
         sel = np.sort(np.random.default_rng(1).choice(n_reads, ns, replace=False))
         sel_d = torch.from_numpy(sel).to(dev)
@@ -1109,6 +1165,14 @@ def main():
         log("setup: synth in HBM %.1fs, GPU BWT build %.2fs (%d symbols), .fmd write %.1fs, index load+transcode %.2fs (%.2f GB in HBM)"
             % (t1 - t0, t2 - t1, n_sym, t3 - t2, t4 - t3, index.hbm_bytes / 1e9))
 
+    if rank == 0 and os.environ.get("FMD_BENCH_PROBE", "1") != "0":
+        try:
+            nl = 1 << 27
+            pms = api.probe_gather(8 << 30, 64, nl, iters=3, device=local_rank)
+            PROBE.update({"line_bytes": 64, "working_set_GiB": 8, "lines_per_s": nl / (pms * 1e-3), "GB_per_s": nl * 64 / (pms * 1e-3) / 1e9})
+        except Exception:
+            pass
+    keep_fmd = rank == 0 and world == 1 and fmd_path and os.environ.get("FMD_BENCH_PMC", "1") != "0"
     ovl, job = bench_overlap(torch, api, index, dev, n_reads, L, args.steps, args.warmup, dist, world, rank, fmd_path, local_rank, legs)
     cl = None
     if rank == 0 and world == 1 and "check_left" in legs:
@@ -1119,6 +1183,13 @@ def main():
     del job
     index.close()
     torch.cuda.empty_cache()   # the 79 GB work area goes back to HIP: the library allocates outside torch's cache
+    pmc_note = None
+    if keep_fmd and "roofline" in (ovl or {}):   # roofline.traffic measured in this run, now that the leg's memory is free again
+        pmc_note = pmc_in_run(fmd_path, n_reads)
+        log("in-run PMC pass: %s" % pmc_note)
+        apply_traffic(ovl["roofline"])
+        if cl and "roofline" in cl:
+            apply_traffic(cl["roofline"])
     if fmd_path and os.path.exists(fmd_path):
         os.remove(fmd_path)
 
@@ -1151,7 +1222,7 @@ def main():
         out["overlap_discovery"] = ovl
         # the bound that applies to a path made of random 64-byte lines is the rate of those, not the streaming peak: the bare gather
         # probe of the backward-search leg (64-byte lines over 8 GiB) beside this leg's bytes
-        probe = (bs or {}).get("roofline", {}).get("random_gather_probe")
+        probe = dict(PROBE) if PROBE else None
         if probe and "roofline" in out:
             r = out["roofline"]
             r["random_gather_ceiling"] = {"probe_GBps": probe["GB_per_s"], "requested_bytes_frac_of_it": r["achieved"] / probe["GB_per_s"],
@@ -1166,6 +1237,15 @@ def main():
             out["kmer_harvest"] = km
         if raw_ovl:
             out["overlap_discovery_on_raw_reads"] = raw_ovl
+        if pmc_note:
+            out["pmc_in_run"] = pmc_note
+
+        def strip(o):
+            if isinstance(o, dict):
+                o.pop("_traffic_key", None)
+                for v in o.values():
+                    strip(v)
+        strip(out)
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()

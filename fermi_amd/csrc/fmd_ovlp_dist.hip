@@ -204,6 +204,14 @@ __global__ void k_ks_unpack(size_t m, const FmdWalkPark *__restrict__ park, uint
         }
     }
 }
+// the parked strands into the order of pass 2 (row t = the t-th strand in key order): everything pass 2 and the pack touch per strand --
+// parked state, record, neighbours, sequence row -- is then addressed by position, sequentially, and a piece is a contiguous range of rows
+__global__ void k_park_permute(size_t m, const uint32_t *__restrict__ order, const FmdWalkPark *__restrict__ src, FmdWalkPark *__restrict__ dst)
+{
+    const size_t step = (size_t)gridDim.x * (blockDim.x >> 2);
+    const int l4 = threadIdx.x & 3;
+    for (size_t t = (size_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2); t < m; t += step) ((uint4 *)(dst + t))[l4] = ((const uint4 *)(src + order[t]))[l4];
+}
 __global__ void k_iota32(size_t n, uint32_t *v)
 {
     const size_t step = (size_t)gridDim.x * blockDim.x;
@@ -272,7 +280,7 @@ struct fmd_ovlp_dist {
     uint32_t stride;
     uint64_t n_home, cap_rows, n_rows;          // strands of pass 1; capacity / number of the rows this rank computes
     size_t piece_max, var_cap_piece;
-    DBuf ids_home, ids_loc, park_home, park_send, park_loc, keys, order, rec, nei, seq, work, pack_work, cnt_dev, sizes_dev, split_dev;
+    DBuf ids_home, ids_loc, park_home, park_send, park_loc, keys, order, iota, rec, nei, seq, work, pack_work, cnt_dev, sizes_dev, split_dev;
     HBuf cnt_host, sizes_host, split_host;
     Stage out[2];                               // this rank's piece on its way out (non-root: set 0; root with a host table: set p & 1)
     std::vector<Stage> in[2];                   // root, host mode: staging per peer, two sets
@@ -302,7 +310,7 @@ extern "C" void fmd_ovlp_dist_free(fmd_ovlp_dist_t *d)
     if (!d) return;
     hipSetDevice(d->h->device);
     hipDeviceSynchronize();
-    DBuf *bs[] = {&d->ids_home, &d->ids_loc, &d->park_home, &d->park_send, &d->park_loc, &d->keys, &d->order, &d->rec, &d->nei, &d->seq, &d->work, &d->pack_work, &d->cnt_dev, &d->split_dev,
+    DBuf *bs[] = {&d->ids_home, &d->ids_loc, &d->park_home, &d->park_send, &d->park_loc, &d->keys, &d->order, &d->iota, &d->rec, &d->nei, &d->seq, &d->work, &d->pack_work, &d->cnt_dev, &d->split_dev,
                   &d->sizes_dev, &d->t_prec, &d->t_ids, &d->t_vaddr, &d->t_row_of, &d->t_off, &d->out[0].pid, &d->out[0].prec, &d->out[0].off, &d->out[0].var, &d->out[0].vaddr, &d->out[1].pid, &d->out[1].prec, &d->out[1].off, &d->out[1].var, &d->out[1].vaddr};
     for (DBuf *b : bs) b->drop();
     for (int k = 0; k < 2; ++k) for (Stage &s : d->in[k]) { s.pid.drop(); s.prec.drop(); s.off.drop(); s.var.drop(); s.vaddr.drop(); }
@@ -354,10 +362,13 @@ extern "C" int fmd_ovlp_dist_new(fmd_dev_t *h, fmd_comm_t *comm, const fmd_ovlp_
     NEED(d->nei, d->cap_rows * (size_t)cfg->max_nei * sizeof(fmd_intv_t));
     NEED(d->seq, d->cap_rows * (size_t)d->stride);
     NEED(d->order, d->cap_rows * 4);
+    NEED(d->iota, d->cap_rows * 4);
     if (d->two_pass) {
         NEED(d->keys, d->cap_rows * 4);
         NEED(d->park_home, d->n_home * sizeof(FmdWalkPark));
-        if (d->cfg.key_shard) { NEED(d->park_send, d->n_home * sizeof(FmdWalkPark)); NEED(d->park_loc, d->cap_rows * sizeof(FmdWalkPark)); NEED(d->ids_loc, d->cap_rows * 8); }
+        NEED(d->park_send, d->cap_rows * sizeof(FmdWalkPark));    // the parked strands in the order of pass 2 (key shard: first the send buffer of the all-to-all)
+        NEED(d->ids_loc, d->cap_rows * 8);
+        if (d->cfg.key_shard) NEED(d->park_loc, d->cap_rows * sizeof(FmdWalkPark));
     }
     {
         size_t wb = fmd_ovlp_work_bytes(d->piece_max, cfg->max_len, cfg->min_match);
@@ -402,7 +413,9 @@ extern "C" int fmd_ovlp_dist_new(fmd_dev_t *h, fmd_comm_t *comm, const fmd_ovlp_
 #undef NEED
     if (rc == FMD_OK) {
         int lo = 0, hi = 0;
-        bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&d->sm, hipStreamNonBlocking, hi) == hipSuccess;   // the transfers first, when a slot frees up
+        // the second stream at the compute stream's priority: measured on one GPU (tools/dist_one_rank.py), 10^8 strands, pass 2 takes 242 ms beside
+        // the pack at equal priority (243 without any pack) and 265 ms when the pack's stream is the device's highest; FMD_DIST_HIGH_PRIORITY is the A/B knob
+        bool ok = getenv("FMD_DIST_HIGH_PRIORITY") && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&d->sm, hipStreamNonBlocking, hi) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); ok = hipStreamCreateWithFlags(&d->sm, hipStreamNonBlocking) == hipSuccess; }
         ok = ok && hipStreamCreateWithFlags(&d->s3, hipStreamNonBlocking) == hipSuccess;
         d->done.resize((size_t)d->pieces, nullptr);
@@ -413,6 +426,7 @@ extern "C" int fmd_ovlp_dist_new(fmd_dev_t *h, fmd_comm_t *comm, const fmd_ovlp_
     }
     if (rc != FMD_OK) { fmd_ovlp_dist_free(d); return rc; }
     k_fill_ids64<<<nblk(d->n_home, 256), 256>>>(d->n_home, (uint64_t)d->rank, (uint64_t)d->world, (uint64_t *)d->ids_home.p);
+    k_iota32<<<nblk(d->cap_rows, 256), 256>>>((size_t)d->cap_rows, (uint32_t *)d->iota.p);
     FMD_HIP_TRY(hipDeviceSynchronize());
     memset(&d->last, 0, sizeof(d->last));
     *out = d;
@@ -446,8 +460,6 @@ static int key_exchange(fmd_ovlp_dist *d, hipStream_t sc, uint64_t *rows_out, st
     }
     FMD_HIP_TRY(hipMemcpyAsync(split_dev, split, (size_t)(W + 1) * 4, hipMemcpyHostToDevice, sc));
     k_ks_counts<<<(W + 1 + 63) / 64, 64, 0, sc>>>(n, (const uint32_t *)d->keys.p, W, split_dev, cnt);
-    k_ks_gather<<<nblk(n, 64), 256, 0, sc>>>(n, (const uint32_t *)d->order.p, (const FmdWalkPark *)d->park_home.p, (const uint64_t *)d->ids_home.p,
-                                           (const fmd_ovlp_rec_t *)d->rec.p, (FmdWalkPark *)d->park_send.p);
     rc = d->comm->allgather(d->comm->ctx, sc, cnt, cnt + (W + 1), (size_t)(W + 1) * 8);
     if (rc != FMD_OK) return rc;
     uint64_t *mat = (uint64_t *)d->cnt_host.p;
@@ -483,14 +495,17 @@ static int key_exchange(fmd_ovlp_dist *d, hipStream_t sc, uint64_t *rows_out, st
     const uint64_t m = roff;
     *rows_out = m;
     if (m) {
-        k_ks_unpack<<<nblk(m, 256), 256, 0, sc>>>(m, loc, (uint64_t *)d->ids_loc.p, (fmd_ovlp_rec_t *)d->rec.p);
-        // the order of pass 2 over the rows as they arrived (W sorted runs): the same sort again
+        // the order of pass 2 over the rows as they arrived (W sorted runs): the same sort again, then the rows into that order (the send
+        // buffer is free again: the exchange precedes this on the stream)
         uint8_t *w = (uint8_t *)d->work.p;
         const size_t tb = fmd_park_sort_temp_bytes(m);
         uint32_t *keys_a = (uint32_t *)w, *vals_a = (uint32_t *)(w + up256(m * 4));
         void *tmp = w + 2 * up256(m * 4);
         if (2 * up256(m * 4) + tb > d->work.bytes) return FMD_E_NOMEM;
         rc = fmd_park_sort(sc, m, loc, keys_a, (uint32_t *)d->keys.p, vals_a, (uint32_t *)d->order.p, tmp, tb);
+        if (rc != FMD_OK) return rc;
+        k_park_permute<<<nblk(m, 64), 256, 0, sc>>>(m, (const uint32_t *)d->order.p, loc, send);
+        k_ks_unpack<<<nblk(m, 256), 256, 0, sc>>>(m, send, (uint64_t *)d->ids_loc.p, (fmd_ovlp_rec_t *)d->rec.p);
     }
     return rc;
 }
@@ -522,16 +537,23 @@ extern "C" int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream_, fmd_ovlp_di
                                               (uint32_t *)d->keys.p, (uint32_t *)d->order.p, d->work.p, d->work.bytes);
         if (rc != FMD_OK) return rc;
         FMD_HIP_TRY(hipEventRecord(d->ev[1], sc));
+        // the parked strands in key order, each with its id (and, if it ended inside the head, what its record needs): the send buffer of the
+        // all-to-all, and -- without one -- already the rows of pass 2
+        if (d->n_home)
+            k_ks_gather<<<nblk(d->n_home, 64), 256, 0, sc>>>((size_t)d->n_home, (const uint32_t *)d->order.p, (const FmdWalkPark *)d->park_home.p, (const uint64_t *)d->ids_home.p,
+                                                             (const fmd_ovlp_rec_t *)d->rec.p, (FmdWalkPark *)d->park_send.p);
+        int fell_back = 1;
         if (cfg.key_shard) {
-            int fell_back = 0;
             uint64_t m = 0, sent = 0;
             rc = key_exchange(d, sc, &m, rows_of_rank, &fell_back, &sent);
             if (rc != FMD_OK) return rc;
-            if (!fell_back) { rows = m; park = (FmdWalkPark *)d->park_loc.p; row_ids = (const uint64_t *)d->ids_loc.p; key_shard = 1; S.key_rows_sent = sent; }
+            if (!fell_back) { rows = m; key_shard = 1; S.key_rows_sent = sent; }
             else for (int q = 0; q < W; ++q) rows_of_rank[(size_t)q] = shard_size(cfg.n_ids, q, W);
         }
+        if (fell_back && d->n_home) k_ks_unpack<<<nblk(d->n_home, 256), 256, 0, sc>>>((size_t)d->n_home, (const FmdWalkPark *)d->park_send.p, (uint64_t *)d->ids_loc.p, (fmd_ovlp_rec_t *)d->rec.p);
+        park = (FmdWalkPark *)d->park_send.p;
+        row_ids = (const uint64_t *)d->ids_loc.p;
     } else {
-        k_iota32<<<nblk(d->n_home, 256), 256, 0, sc>>>((size_t)d->n_home, (uint32_t *)d->order.p);
         FMD_HIP_TRY(hipEventRecord(d->ev[1], sc));
     }
     FMD_HIP_TRY(hipEventRecord(d->ev[2], sc));
@@ -543,7 +565,7 @@ extern "C" int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream_, fmd_ovlp_di
         const uint64_t b = piece_begin(rows, p, P), np = piece_begin(rows, p + 1, P) - b;
         if (np) {
             if (d->two_pass)
-                rc = fmd_ovlp_tail_dev(d->h, sc, (size_t)np, (const uint32_t *)d->order.p + b, park, cfg.min_match, cfg.max_len, cfg.max_nei, (fmd_ovlp_rec_t *)d->rec.p,
+                rc = fmd_ovlp_tail_dev(d->h, sc, (size_t)np, (const uint32_t *)d->iota.p + b, park, cfg.min_match, cfg.max_len, cfg.max_nei, (fmd_ovlp_rec_t *)d->rec.p,
                                        (fmd_intv_t *)d->nei.p, (uint8_t *)d->seq.p, d->stride, d->work.p, d->work.bytes);
             else
                 rc = fmd_ovlp_dev(d->h, sc, (size_t)np, (const uint64_t *)d->ids_home.p + b, cfg.min_match, cfg.max_len, cfg.max_nei, (fmd_ovlp_rec_t *)d->rec.p + b,
@@ -559,7 +581,7 @@ extern "C" int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream_, fmd_ovlp_di
     if (is_root) { d->var.reset(); FMD_HIP_TRY(hipMemsetAsync(d->t_row_of.p, 0xff, cfg.n_ids * 4, sm)); }
     unsigned long long *sz_dev = (unsigned long long *)d->sizes_dev.p;   // [2] mine = {rows, variable bytes}, then [W][2]
     uint64_t *sz_host = (uint64_t *)d->sizes_host.p;
-    for (int p = 0; p < P; ++p) {
+    for (int p = 0; p < P && !(W == 1 && getenv("FMD_DIST_NO_PACK")); ++p) {   // (A/B knob: pass 2 alone)
         const uint64_t b = piece_begin(rows, p, P), np = piece_begin(rows, p + 1, P) - b;
         const int k = p & 1;
         FMD_HIP_TRY(hipStreamWaitEvent(sm, d->done[(size_t)p], 0));
@@ -577,7 +599,7 @@ extern "C" int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream_, fmd_ovlp_di
             if (is_root) FMD_HIP_TRY(hipStreamWaitEvent(sm, d->drained[k], 0));   // (host table: set k -- the root's own piece and the peers' staging -- has left for the host)
             o_pid = (uint32_t *)os.pid.p; o_prec = (fmd_ovlp_rec_t *)os.prec.p; o_off = (uint64_t *)os.off.p; o_var = (uint8_t *)os.var.p; o_cap = d->var_cap_piece;
         }
-        rc = fmd_ovlp_pack_rows_dev(d->h, sm, (size_t)np, (const uint32_t *)d->order.p + b, row_ids, (uint64_t)me, (uint64_t)W, (const fmd_ovlp_rec_t *)d->rec.p, (const fmd_intv_t *)d->nei.p,
+        rc = fmd_ovlp_pack_rows_dev(d->h, sm, (size_t)np, (const uint32_t *)d->iota.p + b, row_ids, (uint64_t)me, (uint64_t)W, (const fmd_ovlp_rec_t *)d->rec.p, (const fmd_intv_t *)d->nei.p,
                                     cfg.max_nei, (const uint8_t *)d->seq.p, d->stride, o_pid, o_prec, o_off, o_var, o_cap, d->pack_work.p, d->pack_work.bytes);
         if (rc != FMD_OK) return rc;
         // sizes of everybody's piece p
@@ -654,6 +676,7 @@ extern "C" int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream_, fmd_ovlp_di
             FMD_HIP_TRY(hipEventRecord(d->drained[k], s3));
         }
     }
+    if (W == 1 && getenv("FMD_DIST_NO_PACK")) { FMD_HIP_TRY(hipStreamWaitEvent(sm, d->done[(size_t)P - 1], 0)); FMD_HIP_TRY(hipEventRecord(d->ev[4], sm)); }
     FMD_HIP_TRY(hipEventRecord(d->ev[5], sm));
     // ---- the end of this rank's part in the gather (the end of its compute is ev[3] on the compute stream)
     FMD_HIP_TRY(hipStreamSynchronize(sm));

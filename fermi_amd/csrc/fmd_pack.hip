@@ -42,22 +42,76 @@ __device__ __forceinline__ uint32_t pack_row_bytes(const fmd_ovlp_rec_t &r, uint
     return nn * 32 + ((sb + 7) & ~7u);
 }
 
-// (rows != nullptr: output row i is row rows[i] of the fixed-stride arrays -- a piece of a sorted job, fmd_ovlp_pack_rows_dev)
-__global__ void k_pack_sizes(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, uint32_t max_nei, const uint8_t *__restrict__ seq, uint32_t seq_stride,
-                             uint64_t *__restrict__ sizes, const uint32_t *__restrict__ rows)
+// ---- the two pack kernels: 8 lanes per row, the sequence rows read 8 bytes per lane and step (coalesced 64-byte bursts), bases
+// compressed in registers (SWAR): the pack runs beside the discovery kernels of the next piece (fmd_ovlp_dist.hip) and must be light
+__device__ __forceinline__ uint64_t bytes_outside_1_4(uint64_t w)   // bit 7 of every byte that is not 1, 2, 3 or 4 (the others zero)
 {
-    const size_t step = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += step) {
-        bool p4;
-        const size_t r = i < n ? (rows ? (size_t)rows[i] : i) : 0;
-        sizes[i] = i < n ? pack_row_bytes(rec[r], max_nei, seq + r * (size_t)seq_stride, seq_stride, p4) : 0;
+    const uint64_t H = 0x8080808080808080ull, hi = w & 0xF8F8F8F8F8F8F8F8ull;          // any of bits 3..7 set: >= 8
+    const uint64_t big = ((hi | (hi << 1) | (hi << 2) | (hi << 3) | (hi << 4)) & H);      // -> bit 7 of such bytes
+    const uint64_t lo = w & 0x0707070707070707ull;                                      // low 3 bits: 0..7, no carries between bytes below
+    const uint64_t ge5 = ((lo + 0x0303030303030303ull) & 0x0808080808080808ull) << 4;    // b + 3 >= 8  <=>  b >= 5
+    const uint64_t zero = (~(lo + 0x0707070707070707ull) & 0x0808080808080808ull) << 4;  // b + 7 < 8   <=>  b == 0
+    return big | ge5 | zero;
+}
+__device__ __forceinline__ uint32_t squeeze2(uint64_t w)   // 8 bases (one per byte, codes 1..4) -> 16 bits, first base lowest: (b - 1) & 3 each
+{
+    uint64_t y = (w - 0x0101010101010101ull) & 0x0303030303030303ull;   // (bytes 1..4: no borrow crosses a byte; other bytes are masked by the caller)
+    y = (y | (y >> 6)) & 0x000F000F000F000Full;
+    y = (y | (y >> 12)) & 0x000000FF000000FFull;
+    y = (y | (y >> 24)) & 0xFFFFull;
+    return (uint32_t)y;
+}
+// sizes[t] = bytes of output row t's variable part, p4[t] = its sequence needs 4 bits per base.  (rows != nullptr: output row t is row
+// rows[t] of the fixed-stride arrays -- a piece of a sorted job, fmd_ovlp_pack_rows_dev)
+__global__ void k_pack_sizes(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, uint32_t max_nei, const uint8_t *__restrict__ seq, uint32_t seq_stride,
+                             uint64_t *__restrict__ sizes, uint8_t *__restrict__ p4, const uint32_t *__restrict__ rows)
+{
+    const size_t step = (size_t)gridDim.x * (blockDim.x >> 3);
+    const int l8 = threadIdx.x & 7;
+    for (size_t t0 = (size_t)blockIdx.x * (blockDim.x >> 3); t0 <= n; t0 += step) {   // (whole groups stay together for the shuffles)
+        const size_t t = t0 + (threadIdx.x >> 3);
+        uint64_t bad = 0, bytes = 0;
+        if (t < n) {
+            const size_t i = rows ? (size_t)rows[t] : t;
+            const int32_t status = rec[i].status; const uint32_t flags = rec[i].flags;
+            if (status == 0 && !(flags & FMD_OVLP_F_OVERFLOW)) {
+                uint32_t nb = (uint32_t)rec[i].len + (uint32_t)rec[i].ext_len;
+                if (nb > seq_stride) nb = seq_stride;
+                const uint8_t *s = seq + i * (size_t)seq_stride;
+                if (((uintptr_t)s & 7) == 0)
+                    for (uint32_t w = l8; 8 * w < nb; w += 8) {
+                        uint64_t v = *(const uint64_t *)(s + 8 * w);
+                        const uint32_t left = nb - 8 * w;
+                        if (left < 8) v = (v & ((1ull << (8 * left)) - 1)) | (0x0101010101010101ull << (8 * left));   // bytes past the end count as 'A'
+                        bad |= bytes_outside_1_4(v);
+                    }
+                else
+                    for (uint32_t j = l8; j < nb; j += 8) { const uint32_t c = s[j]; bad |= (uint64_t)(c < 1 || c > 4); }
+                bytes = 1;
+            }
+        }
+        uint32_t b32 = (uint32_t)((bad | (bad >> 32)) != 0);
+        b32 |= __shfl_xor(b32, 1); b32 |= __shfl_xor(b32, 2); b32 |= __shfl_xor(b32, 4);
+        if (l8 == 0 && t <= n) {
+            uint64_t sz = 0;
+            if (bytes) {
+                const size_t i = rows ? (size_t)rows[t] : t;
+                uint32_t nb = (uint32_t)rec[i].len + (uint32_t)rec[i].ext_len;
+                if (nb > seq_stride) nb = seq_stride;
+                const uint32_t nn = (uint32_t)rec[i].n_nei < max_nei ? (uint32_t)rec[i].n_nei : max_nei;
+                const uint32_t sb = b32 ? (nb + 1) / 2 : (nb + 3) / 4;
+                sz = nn * 32 + ((sb + 7) & ~7u);
+            }
+            sizes[t] = sz;
+            if (t < n) p4[t] = (uint8_t)(bytes ? b32 : 0);
+        }
     }
 }
 
 // one 8-lane group per row: record (64 bytes = 8 lanes x 8), neighbours, then the packed bases 8 bytes per lane
 __global__ void k_pack_rows(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, const fmd_intv_t *__restrict__ nei, uint32_t max_nei,
                             const uint8_t *__restrict__ seq, uint32_t seq_stride, fmd_ovlp_rec_t *__restrict__ prec,
-                            const uint64_t *__restrict__ off, uint8_t *__restrict__ var, uint64_t var_cap, const uint32_t *__restrict__ rows,
+                            const uint64_t *__restrict__ off, const uint8_t *__restrict__ p4, uint8_t *__restrict__ var, uint64_t var_cap, const uint32_t *__restrict__ rows,
                             const uint64_t *__restrict__ row_ids, uint64_t id_first, uint64_t id_step, uint32_t *__restrict__ pid)
 {
     const size_t step = (size_t)gridDim.x * (blockDim.x >> 3);
@@ -65,29 +119,45 @@ __global__ void k_pack_rows(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, co
     for (size_t t = (size_t)blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3); t < n; t += step) {
         const size_t i = rows ? (size_t)rows[t] : t;   // source row; everything written goes to row t
         if (pid && l8 == 0) pid[t] = (uint32_t)(row_ids ? row_ids[i] : id_first + id_step * i);
-        const fmd_ovlp_rec_t r = rec[i];
         const uint64_t o = off[t], sz = off[t + 1] - o;
         const bool fits = o + sz <= var_cap;
-        uint32_t nb = (uint32_t)r.len + (uint32_t)r.ext_len;
-        if (nb > seq_stride) nb = seq_stride;
-        const uint32_t nn = (uint32_t)r.n_nei < max_nei ? (uint32_t)r.n_nei : max_nei;
-        bool pack4;
-        (void)pack_row_bytes(r, max_nei, seq + i * (size_t)seq_stride, seq_stride, pack4);
-        const uint32_t sb8 = sz ? (uint32_t)sz - nn * 32 : 0;          // padded sequence bytes
+        const bool pack4 = p4[t] != 0;
+        uint64_t w7;
         {   // the record: lane l8 copies word l8; flags live in word 7 (low half)
             uint64_t w = ((const uint64_t *)(rec + i))[l8];
             if (l8 == 7 && pack4) w |= (uint64_t)FMD_OVLP_F_PACK4;
             ((uint64_t *)(prec + t))[l8] = w;
+            w7 = w;
         }
         if (!sz || !fits) continue;
+        // len, ext_len, n_nei from the record words the lanes hold: word 4 = len | status << 32, word 6 = ext_len | n_nei << 32
+        const int g0 = (int)(threadIdx.x & 63u & ~7u);
+        const uint64_t w4 = __shfl(w7, g0 + 4), w6 = __shfl(w7, g0 + 6);
+        uint32_t nb = (uint32_t)w4 + (uint32_t)w6;
+        if (nb > seq_stride) nb = seq_stride;
+        const uint32_t nnr = (uint32_t)(w6 >> 32);
+        const uint32_t nn = nnr < max_nei ? nnr : max_nei;
+        const uint32_t sb8 = (uint32_t)sz - nn * 32;          // padded sequence bytes
         uint8_t *dst = var + o;
         for (uint32_t w = l8; w < nn * 4; w += 8) ((uint64_t *)dst)[w] = ((const uint64_t *)(nei + i * (size_t)max_nei))[w];
         dst += nn * 32;
         const uint8_t *s = seq + i * (size_t)seq_stride;
+        const bool al = ((uintptr_t)s & 7) == 0;
         for (uint32_t w = l8; w < sb8 / 8; w += 8) {   // output word w = bases [32w, 32w+32) (2-bit) or [16w, 16w+16) (4-bit)
             uint64_t v = 0;
             if (pack4) {
                 for (int b = 0; b < 16; ++b) { const uint32_t j = 16 * w + b; if (j < nb) v |= (uint64_t)(s[j] & 15) << (4 * b); }
+            } else if (al) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t j = 32 * w + 8 * q;
+                    if (j < nb) {
+                        uint64_t x = *(const uint64_t *)(s + j);
+                        const uint32_t left = nb - j;
+                        if (left < 8) x = (x & ((1ull << (8 * left)) - 1)) | (0x0101010101010101ull << (8 * left));
+                        v |= (uint64_t)squeeze2(x) << (16 * q);
+                    }
+                }
             } else {
                 for (int b = 0; b < 32; ++b) { const uint32_t j = 32 * w + b; if (j < nb) v |= (uint64_t)((s[j] - 1) & 3) << (2 * b); }
             }
@@ -105,7 +175,7 @@ extern "C" size_t fmd_ovlp_pack_work_bytes(size_t n)
 {
     size_t tb = 0;
     fmd_exclusive_sum(nullptr, tb, (uint64_t *)nullptr, (uint64_t *)nullptr, n + 1);
-    return (n + 1) * 8 + ((tb + 255) & ~(size_t)255) + 256;
+    return (((n + 1) * 8 + 255) & ~(size_t)255) + ((tb + 255) & ~(size_t)255) + ((n + 255) & ~(size_t)255) + 256;   // sizes, the scan's storage, one flag byte per row
 }
 
 static int pack_core(fmd_dev_t *h, hipStream_t st, size_t n, const uint32_t *d_rows, const uint64_t *d_row_ids, uint64_t id_first, uint64_t id_step,
@@ -120,13 +190,14 @@ static int pack_core(fmd_dev_t *h, hipStream_t st, size_t n, const uint32_t *d_r
     void *tmp = (uint8_t *)d_work + (((n + 1) * 8 + 255) & ~(size_t)255);
     size_t tb = 0;
     FMD_HIP_TRY(fmd_exclusive_sum(nullptr, tb, sizes, d_off, n + 1, st));
-    size_t blocks = (n + 256) / 256;
+    uint8_t *p4 = (uint8_t *)tmp + ((tb + 255) & ~(size_t)255);
+    size_t blocks = (n + 1 + 31) / 32;
     if (blocks > (1u << 20)) blocks = 1u << 20;
-    k_pack_sizes<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, max_nei, d_seq, seq_stride, sizes, d_rows);
+    k_pack_sizes<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, max_nei, d_seq, seq_stride, sizes, p4, d_rows);
     FMD_HIP_TRY(fmd_exclusive_sum(tmp, tb, sizes, d_off, n + 1, st));
     blocks = (n + 31) / 32;
     if (blocks > (1u << 20)) blocks = 1u << 20;
-    k_pack_rows<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, d_nei, max_nei, d_seq, seq_stride, d_prec, d_off, d_var, var_cap, d_rows, d_row_ids, id_first, id_step, d_pid);
+    k_pack_rows<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, d_nei, max_nei, d_seq, seq_stride, d_prec, d_off, p4, d_var, var_cap, d_rows, d_row_ids, id_first, id_step, d_pid);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "overlap pack kernels"); return FMD_E_HIP; }
     return FMD_OK;
