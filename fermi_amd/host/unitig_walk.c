@@ -18,6 +18,7 @@
 #include <errno.h>
 #include <pthread.h>
 #include <stdio.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
 #include "fmd_host.h"
@@ -38,11 +39,25 @@ static int str_reserve(str_t *s, size_t need)
 static inline int bit_get(const uint64_t *b, uint64_t x) { return (int)(b[x >> 6] >> (x & 63) & 1); }
 static inline void bit_set(uint64_t *b, uint64_t x) { b[x >> 6] |= 1ull << (x & 63); }
 
+/* The three bitmaps of the walk (unitig.c:390-392) are its only state that outlives a seed.  A walk run SPECULATIVELY (the parallel
+ * driver at the end of this file) reads them through st_get and writes through st_set: reads that find a bit set in the shared maps
+ * are final (bits are never cleared); every other read is logged with the value it saw, writes go to a private overlay and a log, and
+ * the shared maps are only touched when the walk is committed in seed order. */
+enum { ST_USED = 0, ST_BEND = 1, ST_VIS = 2 };
+typedef struct {
+    uint64_t *keys; uint32_t cap, n;   /* overlay: open addressing, key + 1 stored (0 = empty) */
+    uint64_t *rlog; size_t n_r, m_r;   /* which << 62 | value << 61 | bit */
+    uint64_t *wlog; size_t n_w, m_w;   /* which << 62 | bit */
+    int err;
+    uint32_t budget;                   /* reads the walk in progress may still take in (SPEC_MAX_STEPS per seed) */
+} spec_t;
+
 typedef struct {
     const fmdh_ovlp_table_t *t;
     uint64_t n_seq;
     int min_match;
     uint64_t *used, *bend, *visited;
+    spec_t *sp;                 /* NULL: the maps are read and written directly (the sequential walk, and re-runs at commit) */
     uint32_t *row_of;           /* `$read$` interval start -> a sequence id with that interval */
     const uint64_t *sorted;     /* optional rank -> (sequence id << 2 | flags) map of `unitig -r` (unitig.c:22-29) */
     /* the neighbour list left behind by the last try_right (unitig.c:181-184): that of row `last` */
@@ -230,11 +245,60 @@ static int outq_close(outq_t *q)
     return q->err ? -EIO : 0;
 }
 
+static inline uint64_t *st_map(const walk_t *w, int which) { return which == ST_USED ? w->used : which == ST_BEND ? w->bend : w->visited; }
+static inline uint64_t ov_hash(uint64_t k) { k ^= k >> 31; k *= 0x9E3779B97F4A7C15ull; return k ^ (k >> 29); }
+static int ov_has(const spec_t *sp, uint64_t key)
+{
+    uint32_t h;
+    if (!sp->n) return 0;
+    for (h = (uint32_t)ov_hash(key) & (sp->cap - 1); sp->keys[h]; h = (h + 1) & (sp->cap - 1)) if (sp->keys[h] == key + 1) return 1;
+    return 0;
+}
+static int ov_add(spec_t *sp, uint64_t key) /* 1 = new */
+{
+    uint32_t h;
+    if (2 * (sp->n + 1) > sp->cap) {
+        const uint32_t ncap = sp->cap ? 2 * sp->cap : 1024;
+        uint64_t *nk = (uint64_t *)calloc(ncap, 8);
+        uint32_t i;
+        if (!nk) { sp->err = -ENOMEM; return 0; }
+        for (i = 0; i < sp->cap; ++i) if (sp->keys[i]) { uint32_t g = (uint32_t)ov_hash(sp->keys[i] - 1) & (ncap - 1); while (nk[g]) g = (g + 1) & (ncap - 1); nk[g] = sp->keys[i]; }
+        free(sp->keys); sp->keys = nk; sp->cap = ncap;
+    }
+    for (h = (uint32_t)ov_hash(key) & (sp->cap - 1); sp->keys[h]; h = (h + 1) & (sp->cap - 1)) if (sp->keys[h] == key + 1) return 0;
+    sp->keys[h] = key + 1; ++sp->n;
+    return 1;
+}
+static inline void log_push(uint64_t **a, size_t *n, size_t *m, uint64_t v, int *err)
+{
+    if (*n == *m) { const size_t nm = *m ? 2 * *m : 4096; uint64_t *q = (uint64_t *)realloc(*a, nm * 8); if (!q) { *err = -ENOMEM; return; } *a = q; *m = nm; }
+    (*a)[(*n)++] = v;
+}
+static inline int st_get(walk_t *w, int which, uint64_t x)
+{
+    spec_t *sp = w->sp;
+    if (bit_get(st_map(w, which), x)) return 1;              /* set in the shared map: final */
+    if (!sp) return 0;
+    {
+        const uint64_t key = (uint64_t)which << 62 | x;
+        const int v = ov_has(sp, key);                          /* set by an earlier walk of this chunk, not committed yet */
+        log_push(&sp->rlog, &sp->n_r, &sp->m_r, key | (uint64_t)v << 61, &sp->err);
+        return v;
+    }
+}
+static inline void st_set(walk_t *w, int which, uint64_t x)
+{
+    spec_t *sp = w->sp;
+    if (!sp) { bit_set(st_map(w, which), x); return; }
+    if (bit_get(st_map(w, which), x)) return;
+    { const uint64_t key = (uint64_t)which << 62 | x; if (ov_add(sp, key)) log_push(&sp->wlog, &sp->n_w, &sp->m_w, key, &sp->err); }
+}
+
 static void mark_used(walk_t *w, const uint64_t x[3]) /* set_bits, unitig.c:22-36 (sorted == NULL) */
 {
     uint64_t k;
-    if (w->sorted) for (k = 0; k < x[2]; ++k) { bit_set(w->used, w->sorted[x[0] + k] >> 2); bit_set(w->used, w->sorted[x[1] + k] >> 2); }
-    else for (k = 0; k < x[2]; ++k) { bit_set(w->used, x[0] + k); bit_set(w->used, x[1] + k); }
+    if (w->sorted) for (k = 0; k < x[2]; ++k) { st_set(w, ST_USED, w->sorted[x[0] + k] >> 2); st_set(w, ST_USED, w->sorted[x[1] + k] >> 2); }
+    else for (k = 0; k < x[2]; ++k) { st_set(w, ST_USED, x[0] + k); st_set(w, ST_USED, x[1] + k); }
 }
 
 /* Coverage string (unitig.c:251-255: '"' = one read, one more per read that covers the base, capped at '~').  Every
@@ -315,6 +379,7 @@ static int unidir(walk_t *w, uint64_t cur, str_t *s, cov_t *cov, int beg0, uint6
     for (q = 0; q < JUMP_DIST; ++q) ahead[q] = 0xffffffffu;
     *is_loop = 0;
     for (;; ++step) {
+        if (w->sp && w->sp->budget-- == 0) { w->err = -EAGAIN; return -1; }      /* too long to speculate on: this seed is walked at commit */
         if (w->jump) {
             const uint32_t far = w->jump[cur], mid = ahead[(step + JUMP_DIST / 2) % JUMP_DIST];   /* mid: noted JUMP_DIST / 2 steps ago */
             if (far != 0xffffffffu) prefetch_row_head(w, far);
@@ -328,7 +393,7 @@ static int unidir(walk_t *w, uint64_t cur, str_t *s, cov_t *cov, int beg0, uint6
         w->last = cur; w->n_nei = r->n_nei;                                      /* the list try_right leaves behind (unitig.c:181-184) */
         if (r->status != 0 || r->rbeg < 0) { w->n_nei = r->status == 0 ? r->n_nei : 0; break; }   /* try_right < 0 */
         rbeg = beg + r->rbeg;
-        if (r->n_nei > 1) { bit_set(w->bend, *end); break; }                     /* forward bifurcation */
+        if (r->n_nei > 1) { st_set(w, ST_BEND, *end); break; }                     /* forward bifurcation */
         {
             const fmdh_row_t x = ROW(w, cur);
             if (link) { nxt = link[cur].nxt; rev = link[cur].rev; }
@@ -342,7 +407,7 @@ static int unidir(walk_t *w, uint64_t cur, str_t *s, cov_t *cov, int beg0, uint6
             s->l = (size_t)ori_l + r->ext_len;
         }
         if (kx[0] == *end) break;                                                /* b>>c>>a><a */
-        if (bit_get(w->bend, kx[0]) || check_left(w, r, rev) < 0) { if (w->err) return -1; bit_set(w->bend, kx[0]); break; } /* backward bifurcation */
+        if (st_get(w, ST_BEND, kx[0]) || check_left(w, r, rev) < 0) { if (w->err) return -1; st_set(w, ST_BEND, kx[0]); break; } /* backward bifurcation */
         if (kx[0] == k0) { *is_loop = 1; break; }                                /* a>>b>>c>>a */
         if (kx[1] == *end) { w->n_nei = 0; break; }                              /* b>>c>>a>>a: cut the last link */
         *end = kx[1];
@@ -460,27 +525,328 @@ static int put_links(str_t *o, const link_t *a, int n)
     return 0;
 }
 
+/* ---- one seed: unitig1 (unitig.c:274-317), the visited test of unitig_core (unitig.c:336-339) and mag_v_write (mag.c:149-174).
+ * The buffers belong to the caller (one set per thread).  Returns 1 with the record in o->s[0 .. *wl), 0 when the seed yields nothing,
+ * < 0 on error. */
+typedef struct { str_t s, o; cov_t cov; link_t *nei[2]; uint32_t cap_nei; } seedbuf_t;
+static int seedbuf_init(seedbuf_t *b, uint32_t cap_nei)
+{
+    memset(b, 0, sizeof(*b));
+    b->cap_nei = cap_nei;
+    b->nei[0] = (link_t *)malloc(cap_nei * sizeof(link_t)); b->nei[1] = (link_t *)malloc((cap_nei + 1) * sizeof(link_t));
+    return b->nei[0] && b->nei[1] ? 0 : -ENOMEM;
+}
+static void seedbuf_free(seedbuf_t *b) { free(b->nei[0]); free(b->nei[1]); free(b->s.s); free(b->o.s); free(b->cov.s); free(b->cov.d); }
+
+static int walk_seed(walk_t *w, uint64_t i, seedbuf_t *b, size_t *wl)
+{
+    const fmdh_ovlp_table_t *t = w->t;
+    const uint64_t *sorted = w->sorted;
+    const int min_match = w->min_match;
+    str_t *s = &b->s, *o = &b->o;
+    cov_t *cov = &b->cov;
+    link_t **nei = b->nei;
+    const fmd_ovlp_rec_t *r = REC(w, i);
+    uint64_t end[2];
+    int n_nei[2] = {0, 0}, n_reads, is_loop = 0, seed_len, k, done_loop = 0;
+    if (r->flags & FMD_OVLP_F_OVERFLOW) return -ERANGE;
+    if (sorted && st_get(w, ST_USED, i)) return 0;              /* used (unitig.c:282: by sequence id with -r) */
+    if (r->len <= min_match) return 0;                          /* too short */
+    if (!sorted && st_get(w, ST_USED, r->rank)) return 0;       /* used (unitig.c:289: by rank) */
+    mark_used(w, r->k);
+    if (r->status != 0) return 0;                               /* contained */
+    seed_len = r->len;
+    if (str_reserve(s, (size_t)seed_len + 1)) return -ENOMEM;
+    { const fmdh_row_t seed = fmdh_table_row(t, i); fmdh_row_bases(&seed, 0, (uint32_t)seed_len, s->s); }
+    s->l = (size_t)seed_len;
+    cov_flush(cov, 0);
+    if (cov_add(cov, 0, (size_t)seed_len)) return -ENOMEM;
+    n_reads = 1;
+    end[0] = r->k[1]; end[1] = r->k[0];
+    if (r->n_ovlp) { /* left-wards extension of the unitig = right-wards of this strand */
+        int m = unidir(w, i, s, cov, 0, r->k[0], &end[0], &is_loop);
+        if (m < 0) return w->err ? w->err : -ENOMEM;
+        n_reads += m;
+        { const fmd_intv_t *ln = fmdh_table_row(t, w->last).nei;
+          for (k = 0; k < w->n_nei; ++k) { nei[0][k].x = ln[k].x[0]; nei[0][k].y = ln[k].info; }
+          n_nei[0] = w->n_nei;
+          if (is_loop) { nei[1][0].x = end[0]; nei[1][0].y = ln[0].info; n_nei[1] = 1; done_loop = 1; } }
+    }
+    if (!done_loop) { /* the other direction, from the reverse strand of the seed (unitig.c:310-315) */
+        int m;
+        cov_flush(cov, s->l);
+        revcomp6(s->l, s->s); reverse(s->l, cov->s);
+        m = unidir(w, i ^ 1, s, cov, (int)s->l - seed_len, r->k[1], &end[1], &is_loop);
+        if (m < 0) return w->err ? w->err : -ENOMEM;
+        n_reads += m;
+        { const fmd_intv_t *ln = fmdh_table_row(t, w->last).nei;
+          for (k = 0; k < w->n_nei; ++k) { nei[1][k].x = ln[k].x[0]; nei[1][k].y = ln[k].info; } }
+        n_nei[1] = w->n_nei;
+    }
+    /* ---- unitig_core: keep each unitig once (unitig.c:336-339) */
+    if (st_get(w, ST_VIS, end[0])) return 0;
+    st_set(w, ST_VIS, end[0]);
+    if (st_get(w, ST_VIS, end[1])) return 0;
+    st_set(w, ST_VIS, end[1]);
+    /* ---- mag_v_write (mag.c:149-174) */
+    o->l = 0;
+    if (str_reserve(o, 2 * s->l + 128)) return -ENOMEM;
+    o->s[o->l++] = '@'; o->l += put_ll(o->s + o->l, (long long)end[0]); o->s[o->l++] = ':'; o->l += put_ll(o->s + o->l, (long long)end[1]);
+    o->s[o->l++] = '\t'; o->l += put_ll(o->s + o->l, (long long)n_reads);
+    if (put_links(o, nei[0], n_nei[0]) || put_links(o, nei[1], n_nei[1])) return -ENOMEM;
+    if (str_reserve(o, o->l + 2 * s->l + 8)) return -ENOMEM;
+    o->s[o->l++] = '\n';
+    {
+        const int cut = bases_to_text(s->l, s->s, o->s + o->l);      /* cut: a base that prints as NUL (see below) */
+        o->l += s->l;
+        memcpy(o->s + o->l, "\n+\n", 3); o->l += 3;
+        memcpy(o->s + o->l, cov->s, s->l); o->l += s->l;
+        o->s[o->l++] = '\n';
+        /* the reference prints the record with fputs (unitig.c:354): a base that is not A/C/G/T
+         * becomes "ACGT"[4] = NUL (mag.c:168) and cuts the record there.  Reproduced as is. */
+        *wl = cut ? strnlen(o->s, o->l) : o->l;
+    }
+    return 1;
+}
+
+/* ---- the parallel driver ---------------------------------------------------------------------------------------------------------
+ * `fermi unitig -tN` hands the seeds to N threads that race on the bitmaps (unitig.c:319-362, 394-404): fast, and a different MAG on
+ * every run.  Here N threads give the MAG of -t1, byte for byte.  The seeds (odd ids, ascending) are cut into chunks; the chunks of a
+ * window are walked concurrently and SPECULATIVELY against the bitmaps as the previous window left them (st_get / st_set above: private
+ * overlay, read and write logs, the record formatted into the chunk's own buffer); then one thread commits the window in seed order:
+ * a walk whose logged reads still hold in the bitmaps as they are NOW did exactly what the sequential walk does at this point (the
+ * walk is a function of the table and of the bits it reads; reads that found a bit set are final because bits are never cleared) --
+ * its writes are applied and its record goes out; a walk that read something an earlier seed of the window has changed since is run
+ * again, directly, then and there.  With reads in sequencer order a window holds a few 10^5 of 10^8 reads, so two walks of one window
+ * rarely meet (the log says how often).  One long unitig (error-free reads: the whole genome from the first seed) is one walk and
+ * stays one thread's work. */
+#define CHUNK_SEEDS 2048
+#define SPEC_MAX_STEPS 1024   /* a speculative walk gives up after this many reads: a long unitig is few seeds' work however it is done, and every seed of the
+                               * first window would walk the whole of it (nothing is `used` yet in the bitmaps it sees) */
+typedef struct { uint32_t n_r, n_w; uint64_t out_len; int rc; } seedres_t;
+typedef struct {
+    walk_t w; spec_t sp; seedbuf_t b;
+    seedres_t res[CHUNK_SEEDS];
+    uint64_t q0, nq;            /* seeds q0 .. q0 + nq of the job (seed q = sequence id 2q + 1) */
+    char *out; size_t out_l, out_m;
+    volatile int pending;       /* slices of `out` the writer has not written yet */
+} chunk_t;
+typedef struct slice { const char *p; size_t l; chunk_t *owner; char *own; } slice_t;   /* own: malloc'ed copy the writer frees */
+#define SLICE_RING 4096
+typedef struct {
+    FILE *fp; slice_t ring[SLICE_RING]; size_t head, tail;   /* head: next to write, tail: next free */
+    int quit, err; pthread_t tid; pthread_mutex_t mu; pthread_cond_t cv;
+} sliceq_t;
+static void *sliceq_main(void *p)
+{
+    sliceq_t *q = (sliceq_t *)p;
+    pthread_mutex_lock(&q->mu);
+    for (;;) {
+        while (q->head == q->tail && !q->quit) pthread_cond_wait(&q->cv, &q->mu);
+        if (q->head == q->tail) break;
+        {
+            slice_t sl = q->ring[q->head % SLICE_RING];
+            pthread_mutex_unlock(&q->mu);
+            if (sl.l && fwrite(sl.p, 1, sl.l, q->fp) != sl.l) q->err = 1;
+            free(sl.own);
+            if (sl.owner) __atomic_fetch_sub(&sl.owner->pending, 1, __ATOMIC_RELEASE);
+            pthread_mutex_lock(&q->mu);
+            ++q->head;
+            pthread_cond_broadcast(&q->cv);
+        }
+    }
+    pthread_mutex_unlock(&q->mu);
+    return 0;
+}
+static void sliceq_put(sliceq_t *q, const char *p, size_t l, chunk_t *owner, char *own)
+{
+    if (owner) __atomic_fetch_add(&owner->pending, 1, __ATOMIC_RELAXED);
+    pthread_mutex_lock(&q->mu);
+    while (q->tail - q->head == SLICE_RING) pthread_cond_wait(&q->cv, &q->mu);
+    q->ring[q->tail % SLICE_RING] = (slice_t){p, l, owner, own};
+    ++q->tail;
+    pthread_cond_broadcast(&q->cv);
+    pthread_mutex_unlock(&q->mu);
+}
+typedef struct {
+    chunk_t *chunks; int n_chunks;          /* the chunks of the current window */
+    volatile int next;                      /* next chunk to claim */
+    int n_threads, phase_quit;
+    pthread_mutex_t mu; pthread_cond_t cv; int generation, running;
+    uint64_t n_seq;
+} pool_t;
+static void chunk_run(chunk_t *c, uint64_t n_seq)
+{
+    uint64_t k;
+    spec_t *sp = &c->sp;
+    while (__atomic_load_n(&c->pending, __ATOMIC_ACQUIRE) > 0) sched_yield();     /* its last window's records are still on their way out */
+    if (sp->n) { memset(sp->keys, 0, (size_t)sp->cap * 8); sp->n = 0; }
+    sp->n_r = sp->n_w = 0;
+    c->out_l = 0;
+    int gave_up = 0;
+    uint32_t spec_steps;
+    { const char *e = getenv("FMD_WALK_SPEC_STEPS"); spec_steps = e && atoi(e) > 0 ? (uint32_t)atoi(e) : SPEC_MAX_STEPS; }   /* (tests make it small) */
+    for (k = 0; k < c->nq; ++k) {
+        const uint64_t i = 2 * (c->q0 + k) + 1;
+        const size_t r0 = sp->n_r, w0 = sp->n_w;
+        size_t wl = 0;
+        int rc;
+        if (gave_up) { c->res[k].n_r = c->res[k].n_w = 0; c->res[k].out_len = 0; c->res[k].rc = -EAGAIN; continue; }   /* (walked at commit) */
+        sp->budget = spec_steps; c->w.err = 0;
+        if (c->w.jump && i < n_seq) seed_hints(&c->w, i, 1);
+        rc = i < n_seq ? walk_seed(&c->w, i, &c->b, &wl) : 0;
+        if (sp->err && rc >= 0) rc = sp->err;
+        /* a walk too long to speculate on: the seeds behind it in this chunk may lie on that very unitig (error-free reads: all of them do) and
+         * would each walk it again -- they wait for the commit, where the long walk has happened and marked its reads */
+        if (rc == -EAGAIN) gave_up = 1;
+        if (rc == 1) {
+            if (c->out_l + wl > c->out_m) { size_t m = c->out_m ? c->out_m : (size_t)1 << 20; char *q; while (m < c->out_l + wl) m <<= 1; q = (char *)realloc(c->out, m); if (!q) { rc = -ENOMEM; wl = 0; } else { c->out = q; c->out_m = m; } }
+            if (rc == 1) { memcpy(c->out + c->out_l, c->b.o.s, wl); c->out_l += wl; }
+        }
+        c->res[k].n_r = (uint32_t)(sp->n_r - r0); c->res[k].n_w = (uint32_t)(sp->n_w - w0); c->res[k].out_len = rc == 1 ? wl : 0; c->res[k].rc = rc;
+    }
+}
+static void *pool_main(void *p)
+{
+    pool_t *P = (pool_t *)p;
+    int gen = 0;
+    for (;;) {
+        pthread_mutex_lock(&P->mu);
+        while (P->generation == gen && !P->phase_quit) pthread_cond_wait(&P->cv, &P->mu);
+        if (P->phase_quit) { pthread_mutex_unlock(&P->mu); return 0; }
+        gen = P->generation;
+        pthread_mutex_unlock(&P->mu);
+        for (;;) {
+            const int k = __atomic_fetch_add(&P->next, 1, __ATOMIC_RELAXED);
+            if (k >= P->n_chunks) break;
+            chunk_run(&P->chunks[k], P->n_seq);
+        }
+        pthread_mutex_lock(&P->mu);
+        if (--P->running == 0) pthread_cond_broadcast(&P->cv);
+        pthread_mutex_unlock(&P->mu);
+    }
+}
+
+static int walk_threads(void)
+{
+    const char *e = getenv("FMD_WALK_THREADS");
+    int nt = 16;
+    if (e && atoi(e) > 0) nt = atoi(e);
+    else { e = getenv("FMD_HOST_THREADS"); if (e && atoi(e) > 0) nt = atoi(e); }
+    return nt > 256 ? 256 : nt;
+}
+
+static uint64_t chunk_seeds(void)   /* FMD_WALK_CHUNK: seeds per chunk (tests make it small, so that a fixture is many windows) */
+{
+    const char *e = getenv("FMD_WALK_CHUNK");
+    const long v = e ? atol(e) : 0;
+    return v > 0 && v < CHUNK_SEEDS ? (uint64_t)v : CHUNK_SEEDS;
+}
+static int walk_parallel(walk_t *w0, uint32_t cap_nei, FILE *out, int nt)
+{
+    const uint64_t n_seeds = w0->n_seq / 2;          /* odd ids below n_seq */
+    const uint64_t CS = chunk_seeds();
+    const int per_win = 4 * nt;
+    chunk_t *ch = (chunk_t *)calloc((size_t)2 * per_win, sizeof(chunk_t));   /* two windows' worth: a window's records leave while the next is walked */
+    pthread_t *tid = (pthread_t *)calloc((size_t)nt, sizeof(pthread_t));
+    pool_t P;
+    sliceq_t Q;
+    seedbuf_t mb;
+    walk_t wm = *w0;                                  /* the committing thread's own walk: direct mode */
+    int rc = 0, k, started = 0, q_open = 0, mb_ok = 0;
+    uint64_t q = 0, n_rerun = 0, n_walked = 0, win = 0;
+    const int timing = getenv("FMD_TIMING") != 0;
+    memset(&P, 0, sizeof(P)); memset(&Q, 0, sizeof(Q));
+    if (!ch || !tid) { rc = -ENOMEM; goto done; }
+    wm.sp = 0;
+    if ((rc = seedbuf_init(&mb, cap_nei)) != 0) goto done;
+    mb_ok = 1;
+    for (k = 0; k < 2 * per_win; ++k) { ch[k].w = *w0; ch[k].w.sp = &ch[k].sp; if ((rc = seedbuf_init(&ch[k].b, cap_nei)) != 0) goto done; }
+    Q.fp = out; pthread_mutex_init(&Q.mu, 0); pthread_cond_init(&Q.cv, 0);
+    if (pthread_create(&Q.tid, 0, sliceq_main, &Q) != 0) { rc = -EAGAIN; goto done; }
+    q_open = 1;
+    pthread_mutex_init(&P.mu, 0); pthread_cond_init(&P.cv, 0);
+    P.n_threads = nt; P.n_seq = w0->n_seq;
+    for (k = 0; k < nt - 1; ++k) { if (pthread_create(&tid[k], 0, pool_main, &P) != 0) break; ++started; }
+    for (win = 0; q < n_seeds + 1 && rc == 0; ++win) {
+        chunk_t *cw = ch + (win & 1) * per_win;
+        int nc = 0;
+        for (k = 0; k < per_win && q < n_seeds + 1; ++k, ++nc) { cw[k].q0 = q; cw[k].nq = n_seeds + 1 - q < CS ? n_seeds + 1 - q : CS; q += cw[k].nq; }
+        /* ---- the window's chunks, concurrently */
+        pthread_mutex_lock(&P.mu);
+        P.chunks = cw; P.n_chunks = nc; P.next = 0; P.running = started; ++P.generation;
+        pthread_cond_broadcast(&P.cv);
+        pthread_mutex_unlock(&P.mu);
+        for (;;) { const int c = __atomic_fetch_add(&P.next, 1, __ATOMIC_RELAXED); if (c >= nc) break; chunk_run(&cw[c], w0->n_seq); }
+        pthread_mutex_lock(&P.mu);
+        while (P.running > 0) pthread_cond_wait(&P.cv, &P.mu);
+        pthread_mutex_unlock(&P.mu);
+        /* ---- commit in seed order */
+        for (k = 0; k < nc && rc == 0; ++k) {
+            chunk_t *c = &cw[k];
+            const uint64_t *rl = c->sp.rlog, *wlg = c->sp.wlog;
+            size_t ro = 0, wo = 0, oo = 0, run_beg = 0, pf_r = 0, pf_w = 0;
+            uint64_t j;
+            for (j = 0; j < c->nq && rc == 0; ++j) {
+                const seedres_t *sr = &c->res[j];
+                size_t z;
+                int ok = sr->rc >= 0;
+                /* the bits the next seeds' logs name, on their way into the cache */
+                while (pf_r < c->sp.n_r && pf_r < ro + 64) { const uint64_t e = rl[pf_r++]; __builtin_prefetch(&st_map(&wm, (int)(e >> 62))[(e & ((1ull << 61) - 1)) >> 6]); }
+                while (pf_w < c->sp.n_w && pf_w < wo + 64) { const uint64_t e = wlg[pf_w++]; __builtin_prefetch(&st_map(&wm, (int)(e >> 62))[(e & ((1ull << 61) - 1)) >> 6]); }
+                for (z = 0; z < sr->n_r && ok; ++z) { const uint64_t e = rl[ro + z]; ok = bit_get(st_map(&wm, (int)(e >> 62)), e & ((1ull << 61) - 1)) == (int)(e >> 61 & 1); }
+                if (sr->n_r || sr->n_w) ++n_walked;
+                if (ok) {
+                    for (z = 0; z < sr->n_w; ++z) { const uint64_t e = wlg[wo + z]; bit_set(st_map(&wm, (int)(e >> 62)), e & ((1ull << 61) - 1)); }
+                } else {   /* something it read has changed (or it failed for want of memory): again, on the bitmaps as they are now */
+                    size_t wl = 0;
+                    const int r2 = walk_seed(&wm, 2 * (c->q0 + j) + 1, &mb, &wl);
+                    ++n_rerun;
+                    if (r2 < 0) { rc = r2; break; }
+                    if (oo > run_beg) sliceq_put(&Q, c->out + run_beg, oo - run_beg, c, 0);
+                    run_beg = oo + sr->out_len;
+                    if (r2 == 1) { char *cp = (char *)malloc(wl ? wl : 1); if (!cp) { rc = -ENOMEM; break; } memcpy(cp, mb.o.s, wl); sliceq_put(&Q, cp, wl, 0, cp); }
+                }
+                ro += sr->n_r; wo += sr->n_w; oo += sr->out_len;
+            }
+            if (rc == 0 && oo > run_beg) sliceq_put(&Q, c->out + run_beg, oo - run_beg, c, 0);
+        }
+        if (Q.err) rc = -EIO;
+    }
+    if (timing) fprintf(stderr, "[M::%s] %d threads, %llu windows of %d chunks x %d seeds: %llu seeds walked speculatively, %llu of them run again at commit\n", __func__, nt,
+                        (unsigned long long)win, per_win, (int)CS, (unsigned long long)n_walked, (unsigned long long)n_rerun);
+done:
+    if (started || P.generation) {
+        pthread_mutex_lock(&P.mu); P.phase_quit = 1; pthread_cond_broadcast(&P.cv); pthread_mutex_unlock(&P.mu);
+        for (k = 0; k < started; ++k) pthread_join(tid[k], 0);
+    }
+    if (q_open) {
+        pthread_mutex_lock(&Q.mu); Q.quit = 1; pthread_cond_broadcast(&Q.cv); pthread_mutex_unlock(&Q.mu);
+        pthread_join(Q.tid, 0);
+        if (Q.err && !rc) rc = -EIO;
+    }
+    if (ch) for (k = 0; k < 2 * per_win; ++k) { seedbuf_free(&ch[k].b); free(ch[k].sp.keys); free(ch[k].sp.rlog); free(ch[k].sp.wlog); free(ch[k].out); }
+    if (mb_ok) seedbuf_free(&mb);
+    free(ch); free(tid);
+    return rc;
+}
+
 int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, const uint64_t *sorted, FILE *out)
 {
     walk_t w;
-    str_t s = {0, 0, 0}, o = {0, 0, 0};
-    cov_t cov = {0, 0, 0, 0};
-    link_t *nei[2];
-    uint64_t i, j, nw = (n_seq + 63) / 64;
-    int rc = 0;
+    seedbuf_t b;
+    uint64_t i, nw = (n_seq + 63) / 64;
+    int rc = 0, b_ok = 0;
     memset(&w, 0, sizeof(w));
     w.t = t; w.n_seq = n_seq; w.min_match = min_match; w.sorted = sorted;
-    w.used = (uint64_t *)calloc(nw, 8); w.bend = (uint64_t *)calloc(nw, 8); w.visited = (uint64_t *)calloc(nw, 8);
+    w.used = (uint64_t *)calloc(nw + 1, 8); w.bend = (uint64_t *)calloc(nw + 1, 8); w.visited = (uint64_t *)calloc(nw + 1, 8);
     w.row_of = t->row_of ? t->row_of : (uint32_t *)fmdh_big_alloc((n_seq ? n_seq : 1) * 4);
     uint32_t cap_nei = t->side_of ? t->side.max_nei : 1;
     outq_t oq;
     int oq_open = 0, g;
     for (g = 0; g < t->n_shards; ++g) if (t->shard[g].max_nei > cap_nei) cap_nei = t->shard[g].max_nei;
-    nei[0] = (link_t *)malloc(cap_nei * sizeof(link_t)); nei[1] = (link_t *)malloc((cap_nei + 1) * sizeof(link_t));
-    if (!w.used || !w.bend || !w.visited || !w.row_of || !nei[0] || !nei[1]) { rc = -ENOMEM; goto done; }
+    if (!w.used || !w.bend || !w.visited || !w.row_of) { rc = -ENOMEM; goto done; }
     if (n_seq >= 0xffffffffull || t->n >= 0xffffffffull) { rc = -ERANGE; goto done; }   /* row_of holds 32-bit ids */
-    if ((rc = outq_open(&oq, out)) != 0) goto done;
-    oq_open = 1;
     if (!t->row_of) { /* not linked (fmdh_ovlp_table_link): build the row map here */
         memset(w.row_of, 0xff, n_seq * 4);
         for (i = t->n; i-- > 0;) { /* smallest id wins */
@@ -491,101 +857,27 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
     const int hints = t->link && !getenv("FMD_WALK_NO_JUMP");
     if (hints) w.jump = build_jump(t->link, t->n);   /* 0: the plain chase */
     const int seed_stages = !(getenv("FMD_WALK_SEED_STAGES") && atoi(getenv("FMD_WALK_SEED_STAGES")) == 0);
-    /* unitig_core with start = 0, step = 1 (unitig.c:333-334): seeds are the odd sequence ids */
-    /* FMD_WALK_PROFILE=1: where the walk's time goes (time-stamp counter around its sections; a diagnostic, printed to stderr) */
-    const int prof = getenv("FMD_WALK_PROFILE") != 0;
-    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, pn[2] = {0, 0}, pt = 0;
-#if defined(__x86_64__)
-#define PROF_T() (prof ? __builtin_ia32_rdtsc() : 0ull)
-#else
-#define PROF_T() 0ull
-#endif
-#define PROF_ADD(k_) do { if (prof) { const unsigned long long t_ = PROF_T(); pc[k_] += t_ - pt; pt = t_; } } while (0)
-    pt = PROF_T();
-    for (j = 0; j <= n_seq >> 2; ++j) {
-        for (i = j << 2 | 1; i < (j << 2) + 4 && i < n_seq; i += 2) {
-            PROF_ADD(0);                                             /* 0: seeds skipped or finished, hints, the tail of the previous record */
-            if (hints) seed_hints(&w, i, seed_stages);
-            const fmd_ovlp_rec_t *r = REC(&w, i);
-            uint64_t end[2];
-            int n_nei[2] = {0, 0}, n_reads, is_loop = 0, seed_len, k, done_loop = 0;
-            /* ---- unitig1 (unitig.c:274-317) */
-            if (r->flags & FMD_OVLP_F_OVERFLOW) { rc = -ERANGE; goto done; }
-            if (sorted && bit_get(w.used, i)) continue;              /* used (unitig.c:282: by sequence id with -r) */
-            if (r->len <= min_match) continue;                       /* too short */
-            if (!sorted && bit_get(w.used, r->rank)) continue;       /* used (unitig.c:289: by rank) */
-            mark_used(&w, r->k);
-            if (r->status != 0) continue;                            /* contained */
-            seed_len = r->len;
-            if (str_reserve(&s, (size_t)seed_len + 1)) { rc = -ENOMEM; goto done; }
-            { const fmdh_row_t seed = fmdh_table_row(t, i); fmdh_row_bases(&seed, 0, (uint32_t)seed_len, s.s); }
-            s.l = (size_t)seed_len;
-            cov_flush(&cov, 0);
-            if (cov_add(&cov, 0, (size_t)seed_len)) { rc = -ENOMEM; goto done; }
-            n_reads = 1;
-            end[0] = r->k[1]; end[1] = r->k[0];
-            ++pn[0];
-            PROF_ADD(1);                                             /* 1: the seed's own row */
-            if (r->n_ovlp) { /* left-wards extension of the unitig = right-wards of this strand */
-                int m = unidir(&w, i, &s, &cov, 0, r->k[0], &end[0], &is_loop);
-                if (m < 0) { rc = w.err ? w.err : -ENOMEM; goto done; }
-                n_reads += m;
-                { const fmd_intv_t *ln = fmdh_table_row(t, w.last).nei;
-                  for (k = 0; k < w.n_nei; ++k) { nei[0][k].x = ln[k].x[0]; nei[0][k].y = ln[k].info; }
-                  n_nei[0] = w.n_nei;
-                  if (is_loop) { nei[1][0].x = end[0]; nei[1][0].y = ln[0].info; n_nei[1] = 1; done_loop = 1; } }
-            }
-            PROF_ADD(2);                                             /* 2: the walk to the right */
-            if (!done_loop) { /* the other direction, from the reverse strand of the seed (unitig.c:310-315) */
-                int m;
-                cov_flush(&cov, s.l);
-                revcomp6(s.l, s.s); reverse(s.l, cov.s);
-                PROF_ADD(3);                                         /* 3: turning the unitig round */
-                m = unidir(&w, i ^ 1, &s, &cov, (int)s.l - seed_len, r->k[1], &end[1], &is_loop);
-                if (m < 0) { rc = w.err ? w.err : -ENOMEM; goto done; }
-                n_reads += m;
-                { const fmd_intv_t *ln = fmdh_table_row(t, w.last).nei;
-                  for (k = 0; k < w.n_nei; ++k) { nei[1][k].x = ln[k].x[0]; nei[1][k].y = ln[k].info; } }
-                n_nei[1] = w.n_nei;
-            }
-            PROF_ADD(4);                                             /* 4: the walk to the left */
-            /* ---- unitig_core: keep each unitig once (unitig.c:336-339) */
-            if (bit_get(w.visited, end[0])) continue;
-            bit_set(w.visited, end[0]);
-            if (bit_get(w.visited, end[1])) continue;
-            bit_set(w.visited, end[1]);
-            /* ---- mag_v_write (mag.c:149-174) */
-            o.l = 0;
-            if (str_reserve(&o, 2 * s.l + 128)) { rc = -ENOMEM; goto done; }
-            o.s[o.l++] = '@'; o.l += put_ll(o.s + o.l, (long long)end[0]); o.s[o.l++] = ':'; o.l += put_ll(o.s + o.l, (long long)end[1]);
-            o.s[o.l++] = '\t'; o.l += put_ll(o.s + o.l, (long long)n_reads);
-            if (put_links(&o, nei[0], n_nei[0]) || put_links(&o, nei[1], n_nei[1])) { rc = -ENOMEM; goto done; }
-            if (str_reserve(&o, o.l + 2 * s.l + 8)) { rc = -ENOMEM; goto done; }
-            o.s[o.l++] = '\n';
-            const int cut = bases_to_text(s.l, s.s, o.s + o.l);      /* cut: a base that prints as NUL (see below) */
-            o.l += s.l;
-            memcpy(o.s + o.l, "\n+\n", 3); o.l += 3;
-            memcpy(o.s + o.l, cov.s, s.l); o.l += s.l;
-            o.s[o.l++] = '\n';
-            {   /* the reference prints the record with fputs (unitig.c:354): a base that is not A/C/G/T
-                 * becomes "ACGT"[4] = NUL (mag.c:168) and cuts the record there.  Reproduced as is. */
-                size_t wl = cut ? strnlen(o.s, o.l) : o.l;
-                if ((rc = outq_put(&oq, o.s, wl)) != 0) goto done;
-            }
-            ++pn[1];
-            PROF_ADD(5);                                             /* 5: formatting the record and handing it to the writer */
-        }
+    {
+        const int nt = walk_threads();
+        if (nt > 1 && n_seq >= 4 * chunk_seeds()) { rc = walk_parallel(&w, cap_nei, out, nt); goto done; }
     }
-    if (prof) {
-        const double tot = (double)(pc[0] + pc[1] + pc[2] + pc[3] + pc[4] + pc[5]) + 1.0;
-        fprintf(stderr, "[M::%s] %llu seeds walked, %llu records written; shares of the walk's time: between seeds %.1f %%, the seed's row %.1f %%, walk to the right %.1f %%, turning round %.1f %%, walk to the left %.1f %%, formatting + hand-over %.1f %%\n",
-                __func__, pn[0], pn[1], 100 * pc[0] / tot, 100 * pc[1] / tot, 100 * pc[2] / tot, 100 * pc[3] / tot, 100 * pc[4] / tot, 100 * pc[5] / tot);
+    if ((rc = seedbuf_init(&b, cap_nei)) != 0) goto done;
+    b_ok = 1;
+    if ((rc = outq_open(&oq, out)) != 0) goto done;
+    oq_open = 1;
+    /* unitig_core with start = 0, step = 1 (unitig.c:333-334): seeds are the odd sequence ids */
+    for (i = 1; i < n_seq; i += 2) {
+        size_t wl = 0;
+        int r1;
+        if (hints) seed_hints(&w, i, seed_stages);
+        r1 = walk_seed(&w, i, &b, &wl);
+        if (r1 < 0) { rc = r1; goto done; }
+        if (r1 == 1 && (rc = outq_put(&oq, b.o.s, wl)) != 0) goto done;
     }
 done:
     if (oq_open) { const int e = outq_close(&oq); if (!rc) rc = e; }
     free(w.used); free(w.bend); free(w.visited); if (w.row_of != t->row_of) fmdh_big_free(w.row_of);
     fmdh_big_free(w.jump);
-    free(nei[0]); free(nei[1]);
-    free(s.s); free(cov.s); free(cov.d); free(o.s);
+    if (b_ok) seedbuf_free(&b);
     return rc;
 }

@@ -131,3 +131,61 @@ def reads_torch(seed, n_reads, read_len=100, coverage=30, err=0.0, device="cuda"
             o = torch.where(hit, sub, o)
         out[s0:s0 + c] = o
     return out
+
+
+# ---- a repeat-rich genome and ragged reads (what a real read set looks like to fm6_get_nei: repeats make forks and wide intervals,
+# substrings of other reads are contained, lengths differ) -- numpy only, deterministic from the seed -----------------------------
+def repeat_genome(seed, g_len, repeat_frac=0.05, min_len=300, max_len=5000, min_copies=2, max_copies=50):
+    """Random genome of g_len bases in which families of repeats (a segment of min_len..max_len bases pasted at min_copies..max_copies
+    random places, every other copy reverse-complemented) cover about repeat_frac of the positions."""
+    gen = (1 + (rnd(seed, 21, np.arange(g_len, dtype=np.uint64)) >> np.uint64(62))).astype(np.uint8)
+    covered, f = 0, 0
+    while covered < repeat_frac * g_len:
+        ln = int(min_len + rnd(seed, 22, f) % np.uint64(max_len - min_len + 1))
+        nc = int(min_copies + rnd(seed, 23, f) % np.uint64(max_copies - min_copies + 1))
+        ln = min(ln, g_len // 4)
+        seg = (1 + (rnd(seed, 24, np.uint64(f) * np.uint64(1 << 20) + np.arange(ln, dtype=np.uint64)) >> np.uint64(62))).astype(np.uint8)
+        for c in range(nc):
+            p = int(rnd(seed, 25, f * 64 + c) % np.uint64(g_len - ln + 1))
+            gen[p:p + ln] = seg if c % 2 == 0 else (5 - seg)[::-1]
+        covered += ln * nc
+        f += 1
+    return gen
+
+
+def ragged_reads(seed, n_reads, gen, min_len=70, max_len=150, err=0.01, dup_frac=0.01, sub_frac=0.01):
+    """n_reads reads of min_len..max_len bases at uniform positions and strands of `gen`, substitutions with probability err per
+    base; dup_frac of the reads are exact copies of an earlier read, sub_frac are proper substrings of one (1..20 bases trimmed
+    from each end: contained reads).  -> list of uint8 arrays (nt6)."""
+    G = len(gen)
+    r = np.arange(n_reads, dtype=np.uint64)
+    ln = (min_len + rnd(seed, 31, r) % np.uint64(max_len - min_len + 1)).astype(np.int64)
+    pos = (rnd(seed, 32, r) % (np.uint64(G) - ln.astype(np.uint64) + np.uint64(1))).astype(np.int64)
+    strand = (rnd(seed, 33, r) >> np.uint64(63)).astype(bool)
+    kind = rnd(seed, 34, r) % np.uint64(1000000)
+    is_dup = kind < np.uint64(int(dup_frac * 1e6))
+    is_sub = (~is_dup) & (kind < np.uint64(int((dup_frac + sub_frac) * 1e6)))
+    thr = np.uint64(int(err * 4294967296.0))
+    out = [None] * n_reads
+    CH = 200000
+    for s in range(0, n_reads, CH):
+        e = min(n_reads, s + CH)
+        idx = pos[s:e, None] + np.arange(max_len)[None, :]
+        win = gen[np.minimum(idx, G - 1)]
+        u = rnd(seed, 35, (r[s:e, None] * np.uint64(max_len) + np.arange(max_len, dtype=np.uint64)[None, :]))
+        hit = (u >> np.uint64(32)) < thr
+        sub = (1 + ((win.astype(np.uint64) - 1) + 1 + (u & np.uint64(0xFFFFFFFF)) % np.uint64(3)) % 4).astype(np.uint8)
+        win = np.where(hit, sub, win).astype(np.uint8)
+        for i in range(s, e):
+            w = win[i - s, :ln[i]]
+            out[i] = np.ascontiguousarray((5 - w)[::-1]) if strand[i] else w.copy()
+    back = (1 + rnd(seed, 36, r) % np.uint64(1000)).astype(np.int64)
+    t5 = (1 + rnd(seed, 37, r) % np.uint64(20)).astype(np.int64)
+    t3 = (1 + rnd(seed, 38, r) % np.uint64(20)).astype(np.int64)
+    for i in np.nonzero(is_dup | is_sub)[0]:
+        src = out[max(0, int(i) - int(back[i]))] if i > 0 else out[0]
+        if is_dup[i] or len(src) <= int(t5[i] + t3[i]) + 32:
+            out[i] = src.copy()
+        else:
+            out[i] = src[int(t5[i]): len(src) - int(t3[i])].copy()
+    return out

@@ -240,3 +240,25 @@ def test_remap_pair_table_restarts_like_the_reference_batches(oracle_lib, gold, 
     got = open(out, "rb").read()
     assert b"UR:Z:" in got and canon(got) == canon(gold.text_gz("pairs.remap_p.gz"))
     o.close()
+
+
+@pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20), ("special", 20)])
+@pytest.mark.parametrize("threads,chunk", [(1, 0), (3, 16), (16, 64), (8, 2048), (4, -32)])
+def test_parallel_walk_is_the_t1_walk(oracle_lib, gold, tmp_path, monkeypatch, name, mm, threads, chunk):
+    """fmdh_unitig_walk with N threads (speculative chunks of seeds, committed in seed order: unitig_walk.c) writes the bytes of
+    `fermi unitig -t1` whatever the number of threads and the chunk size -- chunks of 16 seeds make the fixtures hundreds of windows in
+    which walks of one window do meet (the repeat fixture: forks, bend marks, reads used by an earlier seed of the same window)."""
+    from fermi_amd import hostlib
+    monkeypatch.setenv("FMD_WALK_THREADS", str(threads))
+    monkeypatch.setenv("FMD_TIMING", "1")
+    if chunk:
+        monkeypatch.setenv("FMD_WALK_CHUNK", str(abs(chunk)))
+    if chunk < 0:   # walks of more than three reads are "too long to speculate on": the rest of their chunk waits for the commit
+        monkeypatch.setenv("FMD_WALK_SPEC_STEPS", "3")
+    o = orcbind.OrcIndex(gold.path(name + ".fmd"))
+    n_seq = int(o.mcnt[1])
+    rec, nei, seq = o.overlap_batch(np.arange(n_seq, dtype=np.uint64), mm, max_len=100, max_nei=8, n_threads=4)
+    o.close()
+    out = str(tmp_path / "o.mag")
+    hostlib.unitig_walk(_packed_shards(rec, nei, seq, 2), n_seq, mm, out, max_nei=8, seq_stride=seq.shape[1])
+    assert open(out, "rb").read() == gold.text_gz(name + ".mag.gz")
