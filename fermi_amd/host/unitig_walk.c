@@ -744,7 +744,7 @@ static uint64_t chunk_seeds(void)   /* FMD_WALK_CHUNK: seeds per chunk (tests ma
 }
 static int walk_parallel(walk_t *w0, uint32_t cap_nei, FILE *out, int nt)
 {
-    const uint64_t n_seeds = w0->n_seq / 2;          /* odd ids below n_seq */
+    const uint64_t n_seeds = w0->n_seq / 2;          /* odd ids below n_seq: seed q = id 2q + 1, q < n_seq / 2 */
     const uint64_t CS = chunk_seeds();
     const int per_win = 4 * nt;
     chunk_t *ch = (chunk_t *)calloc((size_t)2 * per_win, sizeof(chunk_t));   /* two windows' worth: a window's records leave while the next is walked */
@@ -768,10 +768,10 @@ static int walk_parallel(walk_t *w0, uint32_t cap_nei, FILE *out, int nt)
     pthread_mutex_init(&P.mu, 0); pthread_cond_init(&P.cv, 0);
     P.n_threads = nt; P.n_seq = w0->n_seq;
     for (k = 0; k < nt - 1; ++k) { if (pthread_create(&tid[k], 0, pool_main, &P) != 0) break; ++started; }
-    for (win = 0; q < n_seeds + 1 && rc == 0; ++win) {
+    for (win = 0; q < n_seeds && rc == 0; ++win) {
         chunk_t *cw = ch + (win & 1) * per_win;
         int nc = 0;
-        for (k = 0; k < per_win && q < n_seeds + 1; ++k, ++nc) { cw[k].q0 = q; cw[k].nq = n_seeds + 1 - q < CS ? n_seeds + 1 - q : CS; q += cw[k].nq; }
+        for (k = 0; k < per_win && q < n_seeds; ++k, ++nc) { cw[k].q0 = q; cw[k].nq = n_seeds - q < CS ? n_seeds - q : CS; q += cw[k].nq; }
         /* ---- the window's chunks, concurrently */
         pthread_mutex_lock(&P.mu);
         P.chunks = cw; P.n_chunks = nc; P.next = 0; P.running = started; ++P.generation;
