@@ -94,6 +94,10 @@ int fmdh_ovlp_table_build(const char *fmd_path, int n_dev, const int *devices, i
 void fmdh_ovlp_table_free(fmdh_ovlp_table_t *t);
 /* Replays the single-threaded walk and writes the MAG records `fermi unitig -t1` prints. */
 int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, const uint64_t *sorted /* or NULL */, FILE *out);
+/* flags: FMDH_WALK_FULL_RECORDS = a record that holds a base other than A/C/G/T is written whole, NUL included, as mag_g_print writes
+ * a graph (mag.c:176-188, fwrite) -- `fermi unitig` cuts it at the NUL (unitig.c:354, fputs), which is the default here */
+#define FMDH_WALK_FULL_RECORDS 1
+int fmdh_unitig_walk_opt(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, const uint64_t *sorted /* or NULL */, FILE *out, int flags);
 /* Whole command: replicate the .fmd on the listed GPUs, build the table, walk, print.  `fermi unitig -l min_match <fn>`
  * (cmd.c:184-216); the reference's fm6_unitig gives seeds i = j (mod n_threads) to worker j (unitig.c:394-404), here
  * GPU g computes the rows of ids i = g (mod n_dev) and ONE deterministic walk consumes them (the output is that of -t1
@@ -132,6 +136,19 @@ void fmdh_remap_contig(fmdh_remap_state_t *st, const char *name, const char *com
                        const fmd_intv_t *mem, size_t n_mem, FILE *out);
 void fmdh_remap_finish(fmdh_remap_state_t *st, FILE *err);
 uint64_t fmdh_remap_table_resets(const fmdh_remap_state_t *st);  /* how often the pair table was started afresh (every 2^28 contig bases, smem.c:380) */ /* the `avg = .. std = .. cap = ..` line, then frees st */
+
+/* ---- the in-memory API (fermi.h:119-123): reads in ONE buffer of l bytes, a NUL after every read, letters or nt6 codes.
+ * fmdh_api_unitig = fm6_api_unitig (unitig.c:413-434: fm6_build2 -- no palindrome trimming, build.c:52-70 --, then unitig_core with one
+ * thread) with the graph written as mag_g_print would print it before any cleaning (mag.c:149-174): the records of `fermi unitig`.
+ * min_match < 0: a third of the lower-quartile read length (unitig.c:418-421).  seq is converted to nt6 in place, as the reference does.
+ * fmdh_api_correct = fm6_api_correct (correct.c:464-511): k-mer harvest (k = kmer, or 19), ec_fix over every read; on return seq holds
+ * upper-case letters where a base was kept and lower-case ones where it was corrected, qual 36 ('$') under the corrected bases; qual may
+ * be NULL (quality 20 everywhere).  The reference leaves the jump heuristic's step uninitialised there (fmecopt_t opt on the stack,
+ * correct.c:471-474): it is a parameter here (the CLI default is 5, 0 switches the heuristic off). */
+int fmdh_api_unitig(int device, int min_match, int64_t l, char *seq, FILE *out);
+int fmdh_api_correct(int device, int kmer, int step, int64_t l, char *seq, char *qual);
+int fmdh_api_seqlen(int64_t l, const char *seq, double quantile);   /* fm6_api_seqlen, seq.c:430-446 */
+int fmdh_ovlp_table_build_dev(fmd_dev_t *dev, int min_match, fmdh_ovlp_table_t *t, uint64_t *n_seq_out);
 
 /* `fermi build -o out.fmd <in.fa>` (cmd.c:378-484); no_fr = trim palindromes (default 1) */
 int fmdh_build(const char *fa_path, const char *out_path, int device, int max_len, int no_fr);

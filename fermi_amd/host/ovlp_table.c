@@ -179,7 +179,7 @@ static void *job_main(void *p)
     job_t *j = (job_t *)p;
     fmd_info_t info;
     double t0 = now_s();
-    j->rc = fmd_dev_open_file(j->device, j->fmd_path, &j->dev);
+    if (!j->dev) j->rc = fmd_dev_open_file(j->device, j->fmd_path, &j->dev);   /* (fmdh_ovlp_table_build_dev: the caller's handle) */
     if (j->rc) return 0;
     fmd_dev_info(j->dev, &info);
     j->n_seq = info.mcnt[1];
@@ -207,7 +207,21 @@ void fmdh_ovlp_table_free(fmdh_ovlp_table_t *t)
 }
 
 static int cmp_u64(const void *a, const void *b) { const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b; return x < y ? -1 : x > y; }
+static int table_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_dev, const int *devices, int min_match, fmdh_ovlp_table_t *t, uint64_t *n_seq_out);
 int fmdh_ovlp_table_build(const char *fmd_path, int n_dev, const int *devices, int min_match, fmdh_ovlp_table_t *t, uint64_t *n_seq_out)
+{
+    return table_build_core(fmd_path, 0, n_dev, devices, min_match, t, n_seq_out);
+}
+/* the same table from an index that is already in a GPU's HBM (the in-memory API: no .fmd in between); the handle stays the caller's */
+int fmdh_ovlp_table_build_dev(fmd_dev_t *dev, int min_match, fmdh_ovlp_table_t *t, uint64_t *n_seq_out)
+{
+    fmd_info_t info;
+    int device;
+    if (!dev || fmd_dev_info(dev, &info)) return 1;
+    device = info.device;
+    return table_build_core("(memory)", dev, 1, &device, min_match, t, n_seq_out);
+}
+static int table_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_dev, const int *devices, int min_match, fmdh_ovlp_table_t *t, uint64_t *n_seq_out)
 {
     const int timing = getenv("FMD_TIMING") != 0;
     const uint32_t max_len = 128, max_nei = 4;
@@ -228,6 +242,7 @@ int fmdh_ovlp_table_build(const char *fmd_path, int n_dev, const int *devices, i
     for (g = 0; g < n_dev; ++g) {
         job_t x = {fmd_path, devices[g], g, n_dev, min_match, max_len, max_nei, &t->shard[g], 0, 0, 0, 0, 0, n_dev == 1 ? t : 0, 0, 0};
         jobs[g] = x;
+        if (g == 0 && preopened) jobs[g].dev = preopened;
         if (g > 0) started[g] = pthread_create(&tid[g], 0, job_main, &jobs[g]) == 0;
     }
     job_main(&jobs[0]);                                           /* shard 0 on the calling thread */
@@ -325,7 +340,7 @@ int fmdh_ovlp_table_build(const char *fmd_path, int n_dev, const int *devices, i
     }
     if (timing) fprintf(stderr, "[M::%s] table of %llu sequences on %d GPU(s): %.3f s\n", __func__, (unsigned long long)n_seq, n_dev, now_s() - t0);
 done:
-    for (g = 0; g < n_dev; ++g) if (jobs[g].dev) fmd_dev_close(jobs[g].dev);
+    for (g = 0; g < n_dev; ++g) if (jobs[g].dev && jobs[g].dev != preopened) fmd_dev_close(jobs[g].dev);
     free(ids); free(jobs); free(tid); free(started);
     if (rc) fmdh_ovlp_table_free(t);
     return rc;

@@ -57,6 +57,7 @@ typedef struct {
     uint64_t n_seq;
     int min_match;
     uint64_t *used, *bend, *visited;
+    int full_records;           /* records written whole (mag_g_print, mag.c:176-188: fwrite) instead of cut at a NUL (unitig.c:354: fputs) */
     spec_t *sp;                 /* NULL: the maps are read and written directly (the sequential walk, and re-runs at commit) */
     uint32_t *row_of;           /* `$read$` interval start -> a sequence id with that interval */
     const uint64_t *sorted;     /* optional rank -> (sequence id << 2 | flags) map of `unitig -r` (unitig.c:22-29) */
@@ -604,7 +605,7 @@ static int walk_seed(walk_t *w, uint64_t i, seedbuf_t *b, size_t *wl)
         o->s[o->l++] = '\n';
         /* the reference prints the record with fputs (unitig.c:354): a base that is not A/C/G/T
          * becomes "ACGT"[4] = NUL (mag.c:168) and cuts the record there.  Reproduced as is. */
-        *wl = cut ? strnlen(o->s, o->l) : o->l;
+        *wl = cut && !w->full_records ? strnlen(o->s, o->l) : o->l;
     }
     return 1;
 }
@@ -833,12 +834,16 @@ done:
 
 int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, const uint64_t *sorted, FILE *out)
 {
+    return fmdh_unitig_walk_opt(t, n_seq, min_match, sorted, out, 0);
+}
+int fmdh_unitig_walk_opt(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, const uint64_t *sorted, FILE *out, int flags)
+{
     walk_t w;
     seedbuf_t b;
     uint64_t i, nw = (n_seq + 63) / 64;
     int rc = 0, b_ok = 0;
     memset(&w, 0, sizeof(w));
-    w.t = t; w.n_seq = n_seq; w.min_match = min_match; w.sorted = sorted;
+    w.t = t; w.n_seq = n_seq; w.min_match = min_match; w.sorted = sorted; w.full_records = (flags & FMDH_WALK_FULL_RECORDS) != 0;
     w.used = (uint64_t *)calloc(nw + 1, 8); w.bend = (uint64_t *)calloc(nw + 1, 8); w.visited = (uint64_t *)calloc(nw + 1, 8);
     w.row_of = t->row_of ? t->row_of : (uint32_t *)fmdh_big_alloc((n_seq ? n_seq : 1) * 4);
     uint32_t cap_nei = t->side_of ? t->side.max_nei : 1;

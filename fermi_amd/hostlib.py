@@ -45,6 +45,9 @@ def lib():
         L.fmdh_remap_contig.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.fmdh_remap_finish.argtypes = [C.c_void_p, C.c_void_p]
         L.fmdh_remap.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(RemapOpt), C.c_char_p, C.c_void_p]
+        L.fmdh_api_unitig.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+        L.fmdh_api_correct.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+        L.fmdh_api_seqlen.argtypes = [C.c_int64, C.c_void_p, C.c_double]
         _lib = L
     return _lib
 
@@ -169,3 +172,29 @@ def remap_contigs(contigs, mems, n_seq, out_path, err_path, skip=50, min_pcv=0, 
         L.fmdh_remap_finish(st, fe)
     finally:
         _libc.fclose(fp); _libc.fclose(fe)
+
+
+def _read_buffer(reads):
+    """list of byte strings -> one buffer with a NUL after every read (what fm6_api_readseq returns, seq.c:385-408)"""
+    return np.frombuffer(b"".join(r + b"\0" for r in reads), dtype=np.uint8).copy()
+
+
+def api_unitig(reads, min_match, out_path, device=0):
+    """fm6_api_unitig (unitig.c:413-434) over reads held in memory: list of ASCII byte strings -> MAG text in out_path."""
+    L = lib()
+    buf = _read_buffer(reads)
+    fp = _libc.fopen(out_path.encode(), b"wb")
+    try:
+        if L.fmdh_api_unitig(device, min_match, len(buf), buf.ctypes.data, fp) != 0:
+            raise RuntimeError("fmdh_api_unitig failed")
+    finally:
+        _libc.fclose(fp)
+
+
+def api_correct(reads, quals, kmer, step=5, device=0):
+    """fm6_api_correct (correct.c:464-511): -> (corrected reads, qualities) as lists of byte strings (upper case = kept, lower = corrected)."""
+    L = lib()
+    s, q = _read_buffer(reads), _read_buffer(quals)
+    if L.fmdh_api_correct(device, kmer, step, len(s), s.ctypes.data, q.ctypes.data) != 0:
+        raise RuntimeError("fmdh_api_correct failed")
+    return s.tobytes().split(b"\0")[:-1], q.tobytes().split(b"\0")[:-1]
