@@ -184,6 +184,24 @@ static void *job_main(void *p)
     fmd_dev_info(j->dev, &info);
     j->n_seq = info.mcnt[1];
     j->t_load = now_s() - t0; t0 = now_s();
+    {   /* The capacity of the main pass follows the reads: the lengths of 8192 evenly spaced sequences (fm6_retrieve in bulk, a few ms), the
+         * longest of them rounded up to 32 -- 128 for reads of up to 128 bases.  A sequence longer than that is flagged by the main pass and
+         * computed in the overflow pass below, which costs a second look at the index: fine for stragglers, not for a third of the read set
+         * (reads of 70-150 bases under a fixed 128: 28 % of the rows went round again, and the ladder doubled their capacities out of memory). */
+        const uint64_t ns = j->n_seq < 8192 ? j->n_seq : 8192;
+        uint64_t *sid = (uint64_t *)malloc((ns ? ns : 1) * 8), k;
+        fmd_ovlp_rec_t *sr = (fmd_ovlp_rec_t *)malloc((ns ? ns : 1) * sizeof(fmd_ovlp_rec_t));
+        if (sid && sr && ns) {
+            int32_t mx = 0;
+            for (k = 0; k < ns; ++k) sid[k] = (uint64_t)((unsigned __int128)j->n_seq * k / ns);
+            if (fmd_seqinfo_batch(j->dev, (size_t)ns, sid, 1024, sr) == FMD_OK) {
+                for (k = 0; k < ns; ++k) if (sr[k].len > mx) mx = sr[k].len;
+                if (mx > 3000) mx = 3000;
+                if ((uint32_t)mx > j->max_len) j->max_len = ((uint32_t)mx + 31) / 32 * 32;
+            }
+        }
+        free(sid); free(sr);
+    }
     if (j->whole && j->n_seq < 0xffffffffull && !getenv("FMD_HOST_LINK")) j->rc = table_fill_linked(j->dev, j->whole, j->n_seq, j->min_match, j->max_len, j->max_nei, &j->und, &j->n_und);
     else {
         const uint64_t n = j->n_seq > (uint64_t)j->g ? (j->n_seq - (uint64_t)j->g + (uint64_t)j->n_dev - 1) / (uint64_t)j->n_dev : 0;
@@ -224,7 +242,8 @@ int fmdh_ovlp_table_build_dev(fmd_dev_t *dev, int min_match, fmdh_ovlp_table_t *
 static int table_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_dev, const int *devices, int min_match, fmdh_ovlp_table_t *t, uint64_t *n_seq_out)
 {
     const int timing = getenv("FMD_TIMING") != 0;
-    const uint32_t max_len = 128, max_nei = 4;
+    uint32_t max_len = 128, longest = 0;   /* (max_len: raised by the jobs' probe of the read lengths) */
+    const uint32_t max_nei = 4;
     job_t *jobs;
     pthread_t *tid;
     char *started;
@@ -254,6 +273,8 @@ static int table_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_de
     }
     if (rc) goto done;
     n_seq = jobs[0].n_seq;
+    max_len = jobs[0].max_len;
+    for (g = 1; g < n_dev; ++g) if (jobs[g].max_len > max_len) max_len = jobs[g].max_len;
     for (g = 1; g < n_dev; ++g) if (jobs[g].n_seq != n_seq) { fprintf(stderr, "[E::%s] the replicas disagree\n", __func__); rc = 1; goto done; }
     t->n = n_seq;
     if (n_seq_out) *n_seq_out = n_seq;
@@ -270,6 +291,7 @@ static int table_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_de
                 if (n_side == cap_ids) { cap_ids = cap_ids ? 2 * cap_ids : 1 << 16; ids = (uint64_t *)realloc(ids, cap_ids * 8); if (!ids) { rc = 1; goto done; } }
                 ids[n_side++] = i * (uint64_t)n_dev + (uint64_t)g;
                 too_long |= (uint32_t)r[i].len > max_len;
+                if (r[i].len > 0 && (uint32_t)r[i].len > longest) longest = (uint32_t)r[i].len;
             }
         }
         too_long_hint = too_long;
@@ -286,7 +308,9 @@ static int table_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_de
             if (attempt == 12) { fprintf(stderr, "[E::%s] %llu rows still overflow at max_len %u, max_nei %u\n", __func__, (unsigned long long)n_side, s_len, s_nei); rc = 1; goto done; }
             /* what overflows in practice is the neighbour list of a strand in a fork-rich corner (more than max_nei irreducible overlaps): room for
              * four times as many at once, longer sequences / candidate lists only where a flagged record says so or the first attempt was not enough */
-            if (attempt == 0) { s_nei *= 4; if (too_long_hint) s_len *= 2; } else { s_len *= 2; s_nei *= 2; }
+            if (attempt == 0) { s_nei *= 4; if (too_long_hint && longest > s_len) s_len = (longest + 31) / 32 * 32; }
+            else { s_nei *= 2; s_len = (s_len + s_len / 2 + 31) / 32 * 32; }     /* (the candidate lists' capacity follows max_len: fmd_ovlp_list_cap) */
+            if (s_len > 4000 + (uint32_t)min_match) s_len = 4000 + (uint32_t)min_match;   /* (lists of 4096 entries and more: not supported) */
             shard_free(&t->side);
             rc = shard_fill(jobs[0].dev, &t->side, ids, 0, 0, n_side, min_match, s_len, s_nei, 0);
             if (rc) { fprintf(stderr, "[E::%s] overflow pass: %s\n", __func__, fmd_strerror(rc)); rc = 1; goto done; }
@@ -315,7 +339,7 @@ static int table_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_de
         }
         if (n_und) {
             fmdh_ovlp_shard_t ex;
-            uint32_t s_len = max_len, s_nei = max_nei;
+            uint32_t s_len = max_len > longest ? max_len : (longest + 31) / 32 * 32, s_nei = max_nei;
             int attempt;
             t1 = now_s();
             memset(&ex, 0, sizeof(ex));
@@ -329,7 +353,8 @@ static int table_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_de
                     fprintf(stderr, "[E::%s] exact check_left pass: %llu rows still overflow at max_len %u, max_nei %u\n", __func__, (unsigned long long)n_over, s_len, s_nei);
                     rc = 1; shard_free(&ex); free(und); goto done;
                 }
-                s_len *= 2; s_nei *= 2;
+                s_nei *= 2; s_len = (s_len + s_len / 2 + 31) / 32 * 32;
+                if (s_len > 4000 + (uint32_t)min_match) s_len = 4000 + (uint32_t)min_match;
                 shard_free(&ex);
             }
             for (k = 0; k < n_und; ++k) row_rec_mut(t, und[k])->reserved = ex.rec[k].reserved;

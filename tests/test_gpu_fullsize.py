@@ -34,7 +34,7 @@ def _md5_stream(cmd, env=None):
 
 def test_10m_reads_every_leg_bit_exact_on_random_samples(gpu):
     env = dict(os.environ, FMD_BENCH_READS="10000000", FMD_BENCH_BSEARCH_READS="10000000", FMD_BENCH_CPU_SAMPLE="200000",
-               FMD_BENCH_CPU_SAMPLE_OVLP="100000", FMD_BENCH_CPU_SAMPLE_SMEM="100000", FMD_BENCH_CPU_SAMPLE_KMER="2048", FMD_BENCH_PROBE="0")
+               FMD_BENCH_CPU_SAMPLE_OVLP="100000", FMD_BENCH_CPU_SAMPLE_SMEM="100000", FMD_BENCH_CPU_SAMPLE_KMER="2048", FMD_BENCH_PROBE="0", FMD_BENCH_PMC="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     d = json.loads(p.stdout.decode().strip().splitlines()[-1])
@@ -48,6 +48,7 @@ def test_10m_reads_every_leg_bit_exact_on_random_samples(gpu):
     assert d["kmer_harvest"]["parity_vs_cpu_on_sample"] == "bit-exact"
     raw = d["overlap_discovery_on_raw_reads"]                                            # reads with 1 % errors: forks, the general group kernels
     assert raw["parity_vs_cpu_on_sample"] == "bit-exact" and raw["same_results_both_ways"] and raw["forked"] > 0
+    assert raw["overflow_records"] == 0 and raw["rows_completed_in_the_side_table"]["are_exactly_the_flagged_rows"]   # every row has its answer when the clock stops
     assert raw["check_left"]["parity_vs_oracle_on_sample"].startswith("bit-exact") and raw["check_left"]["back_bifurcations"] > 0
     for leg in (d, d["check_left"], d["backward_search"], d["smem"], d["kmer_harvest"], raw):
         f = leg["roofline"]["frac"]
@@ -90,3 +91,51 @@ def test_bench_n2_path_sharded_ids_and_gather_on_one_gpu(gpu):
     g = d["overlap_discovery"]["record_gather_rccl"]
     assert g["check"].startswith("ok"), g
     assert 64 < g["bytes_per_strand"] < 200
+
+
+def test_repeat_rich_ragged_2m_reads_md5_and_random_ids_vs_the_reference(gpu, oracle_lib, tmp_path):
+    """The read set a uniform random genome never gives: 2 M reads of 70-150 bp, 5 % of the genome in repeat families,
+    1 % substitutions, exact duplicates and proper substrings of other reads (tests/golden/make_md5_repeat.py, fermi_amd/synth.py).
+    `fermi-amd build`, `unitig -l50` and `correct` against the md5s of the reference binary's output; 10^5 random ids (records + neighbours)
+    against the reference's own functions and check_left_simple of 4 000 ids against the oracle where oracle/_ref travelled."""
+    import ctypes as C
+    import numpy as np
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_md5_repeat as gen
+    want = json.load(open(os.path.join(HERE, "golden", "md5_repeat.json")))
+    d = str(tmp_path)
+    reads = gen.make_reads()
+    assert len(reads) == want["n_reads"] and sum(len(r) for r in reads) == want["total_bases"]
+    gen.write_fastq(d + "/rep.fq", reads)
+    del reads
+    assert _md5_stream(["cat", d + "/rep.fq"]) == want["fastq"]
+    subprocess.check_call([AMD, "build", "-fo", d + "/rep.fmd", d + "/rep.fq"], stderr=subprocess.DEVNULL)
+    assert _md5_stream(["cat", d + "/rep.fmd"]) == want["fmd"]
+    p = subprocess.run([AMD, "unitig", "-l50", d + "/rep.fmd"], stdout=open(d + "/rep.mag", "wb"), stderr=subprocess.PIPE, env=dict(os.environ, FMD_TIMING="1", FMD_OVLP_STATS="1"))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    print("\n".join(l for l in p.stderr.decode().splitlines() if "M::" in l)[-6000:])      # the kernel mix of this read set (pytest -s; DESIGN.md quotes it)
+    assert _md5_stream(["cat", d + "/rep.mag"]) == want["unitig_l50_t1"]
+    assert _md5_stream([AMD, "unitig", "-l50", "-g", "0,0", d + "/rep.fmd"], env=dict(os.environ, FMD_WALK_THREADS="1")) == want["unitig_l50_t1"]   # two replicas, the sequential walk
+    assert _md5_stream([AMD, "correct", "-t16", d + "/rep.fmd", d + "/rep.fq"]) == want["correct_t1"]
+    # ---- random ids against the reference's own fm_retrieve + fm6_is_contained + fm6_get_nei
+    sys.path.insert(0, ROOT)
+    import bench
+    import orcbind
+    api = gpu
+    ix = api.DevIndex.open(d + "/rep.fmd")
+    n_ids = int(ix.mcnt[1])
+    sel = np.sort(np.random.default_rng(11).choice(n_ids, 100_000, replace=False)).astype(np.uint64)
+    rec, nei, _ = ix.overlap_sorted(sel, 50, 150, 16, 0)
+    keep = (rec["flags"] & api.OVLP_F_OVERFLOW) == 0
+    assert keep.mean() > 0.99
+    assert (rec["status"] == -3).sum() > 500 and (rec["n_nei"] > 4).sum() > 100 and (rec["flags"] & api.OVLP_F_FORKED).sum() > 1000   # contained reads, many neighbours, forks: all there
+    if bench.ref_driver() is not None:
+        _, ok = bench.cpu_overlap(d + "/rep.fmd", sel, 50, rec, nei, keep=keep)
+        assert ok, "records / neighbours of random ids differ from the reference"
+    sub = sel[::25]
+    r_cl, _, _ = ix.overlap_sorted(sub, 50, 150, 16, 0, check_left=True)
+    o = orcbind.OrcIndex(d + "/rep.fmd")
+    w_cl, _, _ = o.overlap_batch(sub, 50, 150, 16, 8, check_left=True)
+    o.close(); ix.close()
+    k2 = (r_cl["flags"] & api.OVLP_F_OVERFLOW) == 0
+    assert np.array_equal(r_cl["reserved"][k2], w_cl["reserved"][k2]) and (w_cl["reserved"] == 1).sum() > 10
