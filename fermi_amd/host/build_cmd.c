@@ -5,6 +5,7 @@
  * `fermi build`'s; -b (block size) other than 3 and -i (append to an index) are not supported. */
 #define _GNU_SOURCE
 #include <limits.h>
+#include <pthread.h>
 #include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -12,6 +13,31 @@
 #include "fmd_host.h"
 
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+/* a piece of a span parsed by seqpar.c: its reads clamped to max_len, converted to nt6 in place, palindromes trimmed, empty records dropped
+ * (what the loop of fmdh_build does to one read at a time); on return p->len[0 .. p->n) / p->bytes describe the reads that are left, packed */
+typedef struct { fmdh_ppart_t *p; int max_len, no_fr; } prep_t;
+static void *prep_main(void *d)
+{
+    prep_t *j = (prep_t *)d;
+    fmdh_ppart_t *p = j->p;
+    size_t i, src = 0, dst = 0, n = 0;
+    for (i = 0; i < p->n; ++i) {
+        const uint32_t l0 = p->len[i];
+        uint32_t l = l0 > (uint32_t)j->max_len ? (uint32_t)j->max_len : l0, k;
+        uint8_t *o = (uint8_t *)p->seq + dst;
+        const unsigned char *s = (const unsigned char *)p->seq + src;
+        src += l0;
+        if (l == 0) continue;
+        for (k = 0; k < l; ++k) o[k] = fmdh_nt6[s[k]];        /* (dst <= src: in place) */
+        if (j->no_fr) l = fmdh_trim_palindrome(o, l);
+        dst += l; p->len[n++] = l;
+    }
+    p->n = n; p->bytes = dst;
+    return 0;
+}
+typedef struct { uint8_t *dst; const fmdh_ppart_t *p; } cpy_t;
+static void *cpy_main(void *d) { cpy_t *c = (cpy_t *)d; memcpy(c->dst, c->p->seq, c->p->bytes); return 0; }
 
 int fmdh_build(const char *fa_path, const char *out_path, int device, int max_len, int no_fr)
 {
@@ -24,7 +50,34 @@ int fmdh_build(const char *fa_path, const char *out_path, int device, int max_le
     uint64_t *off = (uint64_t *)malloc((ncap + 1) * 8);
     int l, rc = 0;
     off[0] = 0;
-    while ((l = fmdh_seq_read(io)) >= 0) {
+    /* a plain file: spans of it parsed, encoded and trimmed by several threads (seqpar.c); gzip and stdin: the one reader below */
+    int pt = 16;
+    { const char *e = getenv("FMD_HOST_THREADS"); if (e && atoi(e) > 0) pt = atoi(e); }
+    fmdh_pseq_t *pr = fmdh_pseq_open(fa_path, pt, (size_t)512 << 20);
+    while (pr) {
+        fmdh_ppart_t *parts = 0;
+        int np = 0, k;
+        prep_t pj[64]; cpy_t cj[64]; pthread_t tid[64]; int st[64];
+        const int got = fmdh_pseq_next(pr, &parts, &np);
+        if (got <= 0) { if (got < 0) rc = 1; break; }
+        for (k = 0; k < np; ++k) { pj[k].p = &parts[k]; pj[k].max_len = max_len; pj[k].no_fr = no_fr; }
+        for (k = 1; k < np; ++k) st[k] = pthread_create(&tid[k], 0, prep_main, &pj[k]) == 0;
+        prep_main(&pj[0]);
+        for (k = 1; k < np; ++k) { if (st[k]) pthread_join(tid[k], 0); else prep_main(&pj[k]); }
+        size_t add_b = 0, add_n = 0;
+        for (k = 0; k < np; ++k) { add_b += parts[k].bytes; add_n += parts[k].n; }
+        if (tot + add_b + 8 > cap) { while (tot + add_b + 8 > cap) cap <<= 1; bases = (uint8_t *)realloc(bases, cap); }
+        if (n + add_n > ncap) { while (n + add_n > ncap) ncap <<= 1; off = (uint64_t *)realloc(off, (ncap + 1) * 8); }
+        if (!bases || !off) { rc = 1; break; }
+        { size_t o = tot; for (k = 0; k < np; ++k) { cj[k].dst = bases + o; cj[k].p = &parts[k]; o += parts[k].bytes; } }
+        for (k = 1; k < np; ++k) st[k] = pthread_create(&tid[k], 0, cpy_main, &cj[k]) == 0;
+        cpy_main(&cj[0]);
+        for (k = 1; k < np; ++k) { if (st[k]) pthread_join(tid[k], 0); else cpy_main(&cj[k]); }
+        for (k = 0; k < np; ++k) for (size_t i = 0; i < parts[k].n; ++i) { tot += parts[k].len[i]; off[++n] = tot; }
+    }
+    if (pr) fmdh_pseq_close(pr);
+    if (rc) { fprintf(stderr, "[E::%s] out of memory\n", __func__); fmdh_seq_close(io); free(bases); free(off); return 1; }
+    while (!pr && (l = fmdh_seq_read(io)) >= 0) {
         const char *s = fmdh_seq_bases(io);
         if (l > max_len) l = max_len;
         if (l == 0) continue; /* an empty record contributes nothing to the reference's index either */

@@ -31,7 +31,7 @@ typedef struct {
     char *ascii; uint8_t *nt6, *qual;    /* three parallel byte arrays: read i = bytes [off[i], off[i+1]) of each */
     uint64_t *off;                       /* nb + 1 */
     int32_t *info;
-    size_t nb, bytes, cap_bytes;
+    size_t nb, bytes, cap_bytes, cap_reads;
     uint64_t first_id;
     int last, state;                     /* state: 0 free, 1 parsed, 2 corrected */
 } batch_t;
@@ -72,6 +72,34 @@ static int batch_room(batch_t *b, size_t more)
     if (q) b->qual = q;
     if (!a || !n || !q) return -1;
     b->cap_bytes = m;
+    return 0;
+}
+
+static int batch_reads_room(batch_t *b, size_t n_reads)
+{
+    if (n_reads <= b->cap_reads) return 0;
+    size_t m = b->cap_reads ? b->cap_reads : BATCH_SIZE;
+    while (m < n_reads) m <<= 1;
+    uint64_t *o = (uint64_t *)realloc(b->off, (m + 1) * sizeof(uint64_t));
+    if (o) b->off = o;
+    int32_t *f = (int32_t *)realloc(b->info, m * sizeof(int32_t));
+    if (f) b->info = f;
+    if (!o || !f) return -1;
+    b->cap_reads = m;
+    return 0;
+}
+
+/* a piece of a span parsed by seqpar.c into its place in a batch (reads r0 .., bytes o0 ..): one thread per piece */
+typedef struct { batch_t *b; const fmdh_ppart_t *p; size_t r0, o0; } fill_t;
+static void *fill_main(void *d)
+{
+    fill_t *f = (fill_t *)d;
+    batch_t *b = f->b;
+    const fmdh_ppart_t *p = f->p;
+    size_t o = f->o0, i;
+    memcpy(b->ascii + o, p->seq, p->bytes);
+    for (i = 0; i < p->bytes; ++i) { const uint8_t q = (uint8_t)p->qual[i]; b->qual[o + i] = q ? q : 33 + 15; }   /* no quality: phred 15 (correct.c:431-436) */
+    for (i = 0; i < p->n; ++i) { o += p->len[i]; b->off[f->r0 + i + 1] = o; }
     return 0;
 }
 
@@ -267,11 +295,12 @@ int fmdh_correct_reads_multi(const fmdh_ecopt_t *opt, int n_dev, const int *devi
     if (!io) { fprintf(stderr, "[E::%s] cannot open `%s'\n", __func__, fq_path); free_tabs(&p); return 1; }
     p.opt = opt; p.out = out;
     pthread_mutex_init(&p.mu, 0); pthread_cond_init(&p.cv, 0);
-    for (int i = 0; i < 3; ++i) {
-        p.b[i].off = (uint64_t *)malloc((BATCH_SIZE + 1) * sizeof(uint64_t));
-        p.b[i].info = (int32_t *)malloc(BATCH_SIZE * sizeof(int32_t));
-        if (!p.b[i].off || !p.b[i].info) __atomic_store_n(&p.failed, 1, __ATOMIC_RELAXED);
-    }
+    for (int i = 0; i < 3; ++i) if (batch_reads_room(&p.b[i], BATCH_SIZE)) __atomic_store_n(&p.failed, 1, __ATOMIC_RELAXED);
+    /* a plain file is parsed by several threads (seqpar.c), a span of it per batch; gzip and stdin by the one reader below */
+    int pt = g_host_threads > 1 ? g_host_threads : 8;
+    { const char *e = getenv("FMD_HOST_THREADS"); if (e && atoi(e) > 0) pt = atoi(e); }
+    fmdh_pseq_t *pr = fmdh_pseq_open(fq_path, pt, (size_t)220 << 20);   /* (~10^6 reads of 100 bases: the reference's batch, correct.c:281) */
+    char *carry_s = 0, *carry_q = 0; size_t carry_l = 0; int have_carry = 0;   /* pairs: a batch holds whole pairs -- an odd read waits for the next batch */
     pthread_t t_gpu, t_out;
     int have_gpu_thread = 0, have_out_thread = 0;
     if (!__atomic_load_n(&p.failed, __ATOMIC_RELAXED)) {
@@ -286,7 +315,36 @@ int fmdh_correct_reads_multi(const fmdh_ecopt_t *opt, int n_dev, const int *devi
         const double t0 = now_s();
         b->nb = 0; b->bytes = 0; b->first_id = id; b->last = 0;
         b->off[0] = 0;
-        while (b->nb < BATCH_SIZE) {
+        if (pr) {
+            fmdh_ppart_t *parts = 0;
+            int np = 0, k;
+            const int got = fmdh_pseq_next(pr, &parts, &np);
+            if (got <= 0) { b->last = 1; if (got < 0) { fprintf(stderr, "[E::%s] out of memory\n", __func__); __atomic_store_n(&p.failed, 1, __ATOMIC_RELAXED); } np = 0; }
+            size_t tot_n = have_carry ? 1 : 0, tot_b = have_carry ? carry_l : 0;
+            for (k = 0; k < np; ++k) { tot_n += parts[k].n; tot_b += parts[k].bytes; }
+            if (batch_room(b, tot_b) || batch_reads_room(b, tot_n + 1)) { fprintf(stderr, "[E::%s] out of memory\n", __func__); __atomic_store_n(&p.failed, 1, __ATOMIC_RELAXED); b->last = 1; np = 0; tot_n = tot_b = 0; have_carry = 0; }
+            if (have_carry && tot_n) { memcpy(b->ascii, carry_s, carry_l); memcpy(b->qual, carry_q, carry_l); b->off[1] = carry_l; }
+            {
+                fill_t fl[64]; pthread_t ft[64]; int fs[64];
+                size_t r0 = have_carry ? 1 : 0, o0 = have_carry ? carry_l : 0;
+                for (k = 0; k < np; ++k) { fl[k].b = b; fl[k].p = &parts[k]; fl[k].r0 = r0; fl[k].o0 = o0; r0 += parts[k].n; o0 += parts[k].bytes; }
+                for (k = 1; k < np; ++k) fs[k] = pthread_create(&ft[k], 0, fill_main, &fl[k]) == 0;
+                if (np) fill_main(&fl[0]);
+                for (k = 1; k < np; ++k) { if (fs[k]) pthread_join(ft[k], 0); else fill_main(&fl[k]); }
+            }
+            have_carry = 0;
+            b->nb = tot_n; b->bytes = tot_b;
+            if (opt->is_paired && (b->nb & 1) && !b->last) {   /* the odd read at the end opens the next batch */
+                const size_t l = (size_t)(b->off[b->nb] - b->off[b->nb - 1]);
+                char *cs = (char *)realloc(carry_s, l + 1), *cq = (char *)realloc(carry_q, l + 1);
+                if (cs) carry_s = cs;
+                if (cq) carry_q = cq;
+                if (!cs || !cq) { __atomic_store_n(&p.failed, 1, __ATOMIC_RELAXED); b->last = 1; }
+                else { memcpy(carry_s, b->ascii + b->off[b->nb - 1], l); memcpy(carry_q, b->qual + b->off[b->nb - 1], l); carry_l = l; have_carry = 1; --b->nb; b->bytes -= l; }
+            }
+            id += b->nb;
+        }
+        while (!pr && b->nb < BATCH_SIZE) {
             const int len = fmdh_seq_read(io);
             if (len < 0) { b->last = 1; break; }
             if (batch_room(b, (size_t)len)) { fprintf(stderr, "[E::%s] out of memory\n", __func__); __atomic_store_n(&p.failed, 1, __ATOMIC_RELAXED); b->last = 1; break; }
@@ -311,6 +369,8 @@ int fmdh_correct_reads_multi(const fmdh_ecopt_t *opt, int n_dev, const int *devi
     for (int i = 0; i < 3; ++i) { free(p.b[i].ascii); free(p.b[i].nt6); free(p.b[i].qual); free(p.b[i].off); free(p.b[i].info); }
     pthread_mutex_destroy(&p.mu); pthread_cond_destroy(&p.cv);
     fmdh_seq_close(io);
+    fmdh_pseq_close(pr);
+    free(carry_s); free(carry_q);
     free_tabs(&p);
     return __atomic_load_n(&p.failed, __ATOMIC_RELAXED) ? 1 : 0;
 }

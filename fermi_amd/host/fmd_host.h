@@ -115,6 +115,19 @@ char *fmdh_seq_bases(fmdh_seqio_t *io);
 char *fmdh_seq_qual(fmdh_seqio_t *io);                 /* NULL for FASTA */
 const char *fmdh_seq_comment(const fmdh_seqio_t *io);  /* NULL when the header has none */
 void fmdh_seq_close(fmdh_seqio_t *io);
+fmdh_seqio_t *fmdh_seq_open_mem(const void *p, size_t n);   /* the same reader over bytes in memory */
+size_t fmdh_seq_mem_pos(const fmdh_seqio_t *io);
+int fmdh_seq_between_records(const fmdh_seqio_t *io);
+/* ---- seqpar.c: a plain (not compressed) FASTA/FASTQ FILE parsed by several threads, records in file order, the bytes fmdh_seq_read gives.
+ * The file is mapped; a span of it is cut at guessed record starts, every piece parsed by its own fmdh_seq reader, and a piece counts only
+ * if the piece before it ended exactly where it starts, between two records (the first piece starts where the previous span ended: no guess)
+ * -- otherwise the span is parsed again by one reader.  fmdh_pseq_open returns NULL for input that cannot be mapped (stdin, gzip): the
+ * caller then reads it with fmdh_seq_read as before. */
+typedef struct { char *seq, *qual; uint32_t *len; size_t n, bytes; int has_qual, bad; size_t m_bytes, m_n; } fmdh_ppart_t;   /* reads of a piece, back to back */
+typedef struct fmdh_pseq fmdh_pseq_t;
+fmdh_pseq_t *fmdh_pseq_open(const char *fn, int n_threads, size_t span_bytes);
+int fmdh_pseq_next(fmdh_pseq_t *r, fmdh_ppart_t **parts, int *n_parts);   /* 1 = parts[0 .. *n_parts) hold the next reads; 0 = end of file; -2 = truncated quality */
+void fmdh_pseq_close(fmdh_pseq_t *r);
 
 /* `fermi exact [-s] <idx> <src.fa>` (cmd.c:292-331) */
 int fmdh_exact(const char *fmd_path, const char *fa_path, int device, int self_match, FILE *out);

@@ -13,19 +13,24 @@
 #include "fmd_host.h"
 
 struct fmdh_seqio {
-    gzFile fp;
-    unsigned char buf[1 << 16];
-    int beg, end, eof, last_char;
+    gzFile fp;                  /* NULL: the bytes come from memory (fmdh_seq_open_mem) */
+    unsigned char own[1 << 16];
+    const unsigned char *buf;   /* own[], or the caller's memory */
+    size_t beg, end;
+    int eof, last_char;
     char *name, *seq, *qual, *comment;
     size_t name_l, name_m, seq_l, seq_m, qual_l, qual_m, comment_l, comment_m;
 };
 
 static int io_fill(fmdh_seqio_t *io) /* 0 at end of file */
 {
+    int k;
     if (io->eof) return 0;
+    if (!io->fp) { io->eof = 1; return 0; }     /* memory: everything was there from the start */
     io->beg = 0;
-    io->end = gzread(io->fp, io->buf, sizeof(io->buf));
-    if (io->end <= 0) { io->eof = 1; io->end = 0; return 0; }
+    k = gzread(io->fp, io->own, sizeof(io->own));
+    if (k <= 0) { io->eof = 1; io->end = 0; return 0; }
+    io->end = (size_t)k;
     return 1;
 }
 static inline int io_getc(fmdh_seqio_t *io)
@@ -50,7 +55,7 @@ static int io_append_line(fmdh_seqio_t *io, char **s, size_t *l, size_t *m)
         if (*l + k + 2 > *m) { while (*l + k + 2 > *m) *m = *m ? *m << 1 : 256; *s = (char *)realloc(*s, *m); }
         memcpy(*s + *l, p, k); *l += k;
         got = 1;
-        io->beg += (int)k + (nl ? 1 : 0);
+        io->beg += k + (nl ? 1 : 0);
         if (nl) break;
     }
     if (*l > 1 && (*s)[*l - 1] == '\r') --*l;       /* kseq.h:135: only when more than one character is there */
@@ -64,16 +69,33 @@ fmdh_seqio_t *fmdh_seq_open(const char *fn)
     io->fp = strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(0, "r");
     if (!io->fp) { free(io); return 0; }
     gzbuffer(io->fp, 1u << 20);   /* zlib's default is 8 KiB: 270 000 read() calls for a 2.2 GB FASTQ */
+    io->buf = io->own;
     put(&io->name, &io->name_l, &io->name_m, 0); io->name_l = 0;
     put(&io->seq, &io->seq_l, &io->seq_m, 0); io->seq_l = 0;
     put(&io->qual, &io->qual_l, &io->qual_m, 0); io->qual_l = 0;
     put(&io->comment, &io->comment_l, &io->comment_m, 0); io->comment_l = 0;
     return io;
 }
+/* the same reader over n bytes of memory (a slice of an mmap'ed file: seqpar.c parses slices concurrently) */
+fmdh_seqio_t *fmdh_seq_open_mem(const void *p, size_t n)
+{
+    fmdh_seqio_t *io = (fmdh_seqio_t *)calloc(1, sizeof(*io));
+    if (!io) return 0;
+    io->buf = (const unsigned char *)p; io->beg = 0; io->end = n;
+    put(&io->name, &io->name_l, &io->name_m, 0); io->name_l = 0;
+    put(&io->seq, &io->seq_l, &io->seq_m, 0); io->seq_l = 0;
+    put(&io->qual, &io->qual_l, &io->qual_m, 0); io->qual_l = 0;
+    put(&io->comment, &io->comment_l, &io->comment_m, 0); io->comment_l = 0;
+    return io;
+}
+/* memory readers: bytes consumed so far, and whether the reader stands between two records (nothing of the next one read yet) */
+size_t fmdh_seq_mem_pos(const fmdh_seqio_t *io) { return io->beg; }
+int fmdh_seq_between_records(const fmdh_seqio_t *io) { return io->last_char == 0; }
 void fmdh_seq_close(fmdh_seqio_t *io)
 {
     if (!io) return;
-    gzclose(io->fp); free(io->name); free(io->seq); free(io->qual); free(io->comment); free(io);
+    if (io->fp) gzclose(io->fp);
+    free(io->name); free(io->seq); free(io->qual); free(io->comment); free(io);
 }
 const char *fmdh_seq_name(const fmdh_seqio_t *io) { return io->name; }
 char *fmdh_seq_bases(fmdh_seqio_t *io) { return io->seq; }

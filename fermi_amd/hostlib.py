@@ -45,6 +45,18 @@ def lib():
         L.fmdh_remap_contig.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.fmdh_remap_finish.argtypes = [C.c_void_p, C.c_void_p]
         L.fmdh_remap.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(RemapOpt), C.c_char_p, C.c_void_p]
+        class PPart(C.Structure):
+            _fields_ = [("seq", C.c_void_p), ("qual", C.c_void_p), ("len", C.c_void_p), ("n", C.c_size_t), ("bytes", C.c_size_t), ("has_qual", C.c_int), ("bad", C.c_int),
+                        ("m_bytes", C.c_size_t), ("m_n", C.c_size_t)]
+        L.PPart = PPart
+        L.fmdh_seq_open.restype = C.c_void_p; L.fmdh_seq_open.argtypes = [C.c_char_p]
+        L.fmdh_seq_read.argtypes = [C.c_void_p]
+        L.fmdh_seq_bases.restype = C.c_void_p; L.fmdh_seq_bases.argtypes = [C.c_void_p]
+        L.fmdh_seq_qual.restype = C.c_void_p; L.fmdh_seq_qual.argtypes = [C.c_void_p]
+        L.fmdh_seq_close.restype = None; L.fmdh_seq_close.argtypes = [C.c_void_p]
+        L.fmdh_pseq_open.restype = C.c_void_p; L.fmdh_pseq_open.argtypes = [C.c_char_p, C.c_int, C.c_size_t]
+        L.fmdh_pseq_next.argtypes = [C.c_void_p, C.POINTER(C.POINTER(PPart)), C.POINTER(C.c_int)]
+        L.fmdh_pseq_close.restype = None; L.fmdh_pseq_close.argtypes = [C.c_void_p]
         L.fmdh_api_unitig.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
         L.fmdh_api_correct.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
         L.fmdh_api_seqlen.argtypes = [C.c_int64, C.c_void_p, C.c_double]
@@ -198,3 +210,42 @@ def api_correct(reads, quals, kmer, step=5, device=0):
     if L.fmdh_api_correct(device, kmer, step, len(s), s.ctypes.data, q.ctypes.data) != 0:
         raise RuntimeError("fmdh_api_correct failed")
     return s.tobytes().split(b"\0")[:-1], q.tobytes().split(b"\0")[:-1]
+
+
+def read_records_serial(path):
+    """[(bases, qualities or None)] as fmdh_seq_read gives them (seqio.c: the reader `build`, `correct`, `remap` use)."""
+    L = lib()
+    io = L.fmdh_seq_open(path.encode())
+    out = []
+    while True:
+        n = L.fmdh_seq_read(io)
+        if n < 0:
+            break
+        q = L.fmdh_seq_qual(io)
+        out.append((C.string_at(L.fmdh_seq_bases(io), n), C.string_at(q, n) if q else None))
+    L.fmdh_seq_close(io)
+    return out, n
+
+
+def read_records_parallel(path, threads, span):
+    """the same records through fmdh_pseq_* (seqpar.c); None if the input cannot be mapped (gzip, stdin)."""
+    L = lib()
+    r = L.fmdh_pseq_open(path.encode(), threads, span)
+    if not r:
+        return None
+    out = []
+    parts, n_parts = C.POINTER(L.PPart)(), C.c_int()
+    while L.fmdh_pseq_next(r, C.byref(parts), C.byref(n_parts)) == 1:
+        for k in range(n_parts.value):
+            p = parts[k]
+            lens = np.ctypeslib.as_array(C.cast(p.len, C.POINTER(C.c_uint32)), (max(p.n, 1),))[: p.n]
+            seq = C.string_at(p.seq, p.bytes) if p.bytes else b""
+            qual = C.string_at(p.qual, p.bytes) if p.bytes else b""
+            o = 0
+            for ln in lens:
+                ln = int(ln)
+                q = qual[o:o + ln]
+                out.append((seq[o:o + ln], q if p.has_qual and (ln == 0 or any(q)) else None))
+                o += ln
+    L.fmdh_pseq_close(r)
+    return out

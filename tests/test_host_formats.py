@@ -262,3 +262,43 @@ def test_parallel_walk_is_the_t1_walk(oracle_lib, gold, tmp_path, monkeypatch, n
     out = str(tmp_path / "o.mag")
     hostlib.unitig_walk(_packed_shards(rec, nei, seq, 2), n_seq, mm, out, max_nei=8, seq_stride=seq.shape[1])
     assert open(out, "rb").read() == gold.text_gz(name + ".mag.gz")
+
+
+def test_parallel_fastq_reader_gives_the_serial_reader_s_records(gold, tmp_path):
+    """seqpar.c: a plain file cut at guessed record starts, every piece parsed by its own reader, a piece kept only if the piece before it
+    ended exactly where it starts -- four-line FASTQ in parallel, anything else (multi-line records, FASTA, '@' opening a quality line, CRLF,
+    a truncated last record) through the verification's fall-back: the records are fmdh_seq_read's in every case."""
+    from fermi_amd import hostlib
+    tiny = gold.text_gz("tiny.fq.gz")
+    rng = np.random.default_rng(3)
+    files = {"tiny.fq": tiny, "special.fq": gold.text_gz("special.fq.gz")}
+    recs = tiny.split(b"\n")
+    # qualities that start with '@' and with '+', CRLF line ends
+    lines = list(recs)
+    for i in range(3, len(lines) - 1, 4):
+        if rng.random() < 0.3:
+            lines[i] = (b"@" if rng.random() < 0.5 else b"+") + lines[i][1:]
+    files["at_quals.fq"] = b"\n".join(lines)
+    files["crlf.fq"] = tiny.replace(b"\n", b"\r\n")
+    # multi-line FASTQ (sequence and quality wrapped at 60) and FASTA
+    ml, fa = [], []
+    for i in range(0, len(recs) - 1, 4):
+        s, q = recs[i + 1], recs[i + 3]
+        ml += [recs[i]] + [s[j:j + 60] for j in range(0, len(s), 60)] + [b"+"] + [q[j:j + 60] for j in range(0, len(q), 60)]
+        fa += [b">" + recs[i][1:]] + [s[j:j + 70] for j in range(0, len(s), 70)]
+    files["multiline.fq"] = b"\n".join(ml) + b"\n"
+    files["reads.fa"] = b"\n".join(fa) + b"\n"
+    files["truncated.fq"] = tiny[: len(tiny) - 37]
+    files["no_final_newline.fq"] = tiny.rstrip(b"\n")
+    for name, data in files.items():
+        path = str(tmp_path / name)
+        open(path, "wb").write(data)
+        want, _ = hostlib.read_records_serial(path)
+        assert len(want) > 100
+        for threads, span in ((2, 1 << 20), (7, 3 << 20), (16, 0), (5, 1 << 16)):
+            got = hostlib.read_records_parallel(path, threads, span)
+            assert got is not None and len(got) == len(want), (name, threads, span, len(got), len(want))
+            assert got == want, (name, threads, span)
+    gz = str(tmp_path / "tiny.fq.gz")
+    open(gz, "wb").write(open(gold.path("tiny.fq.gz"), "rb").read())
+    assert hostlib.read_records_parallel(gz, 4, 0) is None          # gzip: one zlib stream, one reader
