@@ -514,6 +514,8 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
     # pieces whose rows are packed and sent to rank 0 under the compute of the next piece; transport = RCCL created through the C ABI
     # (fmd_comm_rccl_*), or -- FMD_BENCH_BACKEND=gloo, the one-GPU test form -- torch.distributed through the fmd_comm_t callbacks.
     # FMD_BENCH_COMM=torch: round 3's step (compute, pack, ONE gather through torch.distributed), kept as the fallback.
+    # Key shard from four ranks up: at N = 2 every parked strand that leaves (half of them, 1.6 GB per rank at 5*10^7 reads) crosses the ONE link to
+    # the peer, which costs more than the 11 % pass 2 gains (profiles/r4_scale); at N = 8 it is 0.7 GB over seven links for 22 %.
     djob = comm = None
     if world > 1 and os.environ.get("FMD_BENCH_COMM", "c") != "torch":
         from fermi_amd import dist as fdist
@@ -521,7 +523,7 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
         try:
             comm = fdist.RcclComm(api, dist, rank, world, local_rank) if dist.get_backend() == "nccl" else fdist.TorchComm(api, dist, rank, world)
             djob = fdist.DistJob(api, index, comm, n_ids, min_match, L, 4, pieces=int(os.environ.get("FMD_BENCH_PIECES", "0")),
-                                 key_shard=int(os.environ.get("FMD_BENCH_KEY_SHARD", "1")), root=0, host_table=int(os.environ.get("FMD_BENCH_HOST_TABLE", "-1")),
+                                 key_shard=int(os.environ.get("FMD_BENCH_KEY_SHARD", "1" if world >= 4 else "0")), root=0, host_table=int(os.environ.get("FMD_BENCH_HOST_TABLE", "-1")),
                                  batch=int(os.environ.get("FMD_BENCH_OVLP_BATCH", "0")))
         except Exception as ex:
             log("[rank %d] the C-ABI step is not available here (%r): falling back to the torch.distributed gather" % (rank, ex))
