@@ -11,7 +11,7 @@ timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -4 > $OUT/pytest.lo
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1; tail -1 $OUT/smoke.txt
 tools/pmc_collect.sh $TAG 2 > $OUT/pmc_collect.log 2>&1; tail -3 $OUT/pmc_collect.log
 timeout 1800 python bench.py --steps $K --warmup $W > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
-timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/trace_$TAG -o bench -- python bench.py --steps 5 --warmup 2 > $OUT/bench_traced.json 2> $OUT/bench_traced.err
+FMD_BENCH_PMC=0 timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/trace_$TAG -o bench -- python bench.py --steps 5 --warmup 2 > $OUT/bench_traced.json 2> $OUT/bench_traced.err
 cp $(find /tmp/trace_$TAG -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
 python tools/trace_tail.py $(find /tmp/trace_$TAG -name "*kernel_trace.csv" | head -1) 400 > $OUT/overlap_timeline_tail.txt 2>/dev/null
 timeout 900 python tools/time_unitig_10m.py 10000000 > $OUT/time_unitig_10M.txt 2>&1; tail -3 $OUT/time_unitig_10M.txt
