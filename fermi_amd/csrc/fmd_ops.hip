@@ -124,8 +124,20 @@ __global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const
     uint64_t sbase = 0;           // off[rid]
     int pos = -1;                 // next base to prepend
     uint64_t k = 0, l = 0;
-    uint32_t cache = 0;           // 4 bases of the read around pos
+    // 16 bases of the read around pos: the four dwords of the 16-byte block of the read buffer that holds base pos, fetched together.  A lane
+    // reads its read backwards, one base per step; fetched one dword every fourth step (round 1-3), each of a line's 16 dwords was a request of
+    // its own, four steps after the last -- long enough for the random block traffic of the other waves to have pushed the line out of L2:
+    // the kernel fetched 1.18 x the bytes it asked for, 1 KB per read of refetched read lines (PMC).  Only dwords at or below
+    // pos are loaded (the bases above it are behind us), so nothing beyond what the contract makes readable is touched.
+    uint4 cq = make_uint4(0, 0, 0, 0);
     bool live = false, exhausted = false;
+#define BS_LOAD16(at_)                                                                                           \
+    do {                                                                                                         \
+        const uint64_t a_ = (at_), b_ = a_ & ~15ull, top_ = a_ & ~3ull;                                          \
+        const uint32_t *w_ = (const uint32_t *)(seqs + b_);                                                      \
+        cq.x = w_[0];                                                                                            \
+        cq.y = b_ + 4 <= top_ ? w_[1] : 0u; cq.z = b_ + 8 <= top_ ? w_[2] : 0u; cq.w = b_ + 12 <= top_ ? w_[3] : 0u; \
+    } while (0)
 
     FmdTickets tk_;
     fmd_tickets_init(tk_, queue, 64, n);   // guided chunks (fmd_wave.h)
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const
                             pos = len - 2;
                             live = true;
                         }
-                        if (live && pos >= 0) cache = *(const uint32_t *)(seqs + ((sbase + pos) & ~3ull));
+                        if (live && pos >= 0) BS_LOAD16(sbase + pos);
                     }
                 } else exhausted = true;
             }
@@ -188,7 +200,8 @@ __global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const
         uint64_t qk = NONE64, ql = NONE64;
         if (live) {
             const uint64_t a = sbase + pos;
-            c = (int)((cache >> (8 * (a & 3))) & 0xff);
+            const uint32_t wq = (uint32_t)(a >> 2) & 3u, cw_ = wq == 0 ? cq.x : wq == 1 ? cq.y : wq == 2 ? cq.z : cq.w;
+            c = (int)((cw_ >> (8 * (a & 3))) & 0xff);
             qk = k - 1; ql = l;
         }
         FmdRank2c r = fmd_wave_rank2_fetch_compact(ix, fmd_lds, qk, ql);
@@ -203,11 +216,12 @@ __global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const
                 const bool hit = k <= l;
                 d_cnt[rid] = hit ? l - k + 1 : 0; d_beg[rid] = hit ? k : 0; d_end[rid] = hit ? l : 0;
                 live = false;
-            } else if (((sbase + pos) & 3) == 3) {
-                cache = *(const uint32_t *)(seqs + ((sbase + pos) & ~3ull));
+            } else if (((sbase + pos) & 15) == 15) {
+                BS_LOAD16(sbase + pos);
             }
         }
     }
+#undef BS_LOAD16
 }
 
 // ------------------------------------------------------------------------------ forward reach
