@@ -522,17 +522,33 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
         ok = torch.ones(1, dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
         try:
             comm = fdist.RcclComm(api, dist, rank, world, local_rank) if dist.get_backend() == "nccl" else fdist.TorchComm(api, dist, rank, world)
-            djob = fdist.DistJob(api, index, comm, n_ids, min_match, L, 4, pieces=int(os.environ.get("FMD_BENCH_PIECES", "0")),
-                                 key_shard=int(os.environ.get("FMD_BENCH_KEY_SHARD", "1" if world >= 4 else "0")), root=0, host_table=int(os.environ.get("FMD_BENCH_HOST_TABLE", "-1")),
-                                 batch=int(os.environ.get("FMD_BENCH_OVLP_BATCH", "0")))
         except Exception as ex:
-            log("[rank %d] the C-ABI step is not available here (%r): falling back to the torch.distributed gather" % (rank, ex))
+            log("[rank %d] no transport for the C-ABI step here (%r): falling back to the torch.distributed gather" % (rank, ex))
             ok[0] = 0
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
-            if djob:
-                djob.free()
-            djob = None
+        if int(ok.item()):
+            # beside a large index (config 5: 153 GB) the job's buffers must still fit: smaller pieces until every rank has room
+            batches = [int(os.environ["FMD_BENCH_OVLP_BATCH"])] if "FMD_BENCH_OVLP_BATCH" in os.environ else [0, 10_000_000, 5_000_000, 2_500_000, 1_250_000]
+            for bt in batches:
+                ok[0] = 1
+                try:
+                    djob = fdist.DistJob(api, index, comm, n_ids, min_match, L, 4, pieces=int(os.environ.get("FMD_BENCH_PIECES", "0")),
+                                         key_shard=int(os.environ.get("FMD_BENCH_KEY_SHARD", "1" if world >= 4 else "0")), root=0,
+                                         host_table=int(os.environ.get("FMD_BENCH_HOST_TABLE", "-1")), batch=bt)
+                except Exception as ex:
+                    log("[rank %d] fmd_ovlp_dist_new with pieces of at most %s strands: %r" % (rank, bt or "2*10^7", ex))
+                    djob = None
+                    ok[0] = 0
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()):
+                    break
+                if djob:
+                    djob.free()
+                djob = None
+                torch.cuda.empty_cache()
+        if djob is None and comm is not None:
+            comm.free()
+            comm = None
     if djob is not None:
         stream = torch.cuda.current_stream()
         sh = C.c_void_p(stream.cuda_stream)
@@ -1248,6 +1264,10 @@ def main():
                 for v in o.values():
                     strip(v)
         strip(out)
+        try:   # what C libraries hold in their stdio buffers (this image's librccl prints a version banner to stdout) goes out BEFORE the line, not after it
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()

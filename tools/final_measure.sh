@@ -7,7 +7,7 @@ TAG=${1:-final}; K=${2:-20}; W=${3:-5}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -4 > $OUT/pytest.log; cat $OUT/pytest.log
+timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path\|amdgpu.ids" | tail -6 > $OUT/pytest.log; cat $OUT/pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1; tail -1 $OUT/smoke.txt
 tools/pmc_collect.sh $TAG 2 > $OUT/pmc_collect.log 2>&1; tail -3 $OUT/pmc_collect.log
 timeout 1800 python bench.py --steps $K --warmup $W > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
