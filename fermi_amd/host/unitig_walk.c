@@ -65,8 +65,6 @@ typedef struct {
     uint64_t last; int n_nei;
     int err;
     uint32_t *jump;             /* row JUMP_DIST accepted links ahead of each row (prefetch hints only; 0 = not built) */
-    struct asm_pipe *ap;        /* the second thread of a LONG walk (asm_*, below unidir's helpers); NULL = none yet */
-    int ap_allowed, asm_after;  /* direct-mode walkers only; accepted reads after which a walk goes onto two threads (FMD_WALK_ASM_AFTER: tests) */
 } walk_t;
 
 /* The walk is a pointer chase: the next row is known when link[row] has arrived, one DRAM miss (~90 ns) per read and nothing
@@ -371,113 +369,17 @@ static int check_left(walk_t *w, const fmd_ovlp_rec_t *r, uint32_t rev)
     return REC(w, rev)->n_nei > 1 ? -1 : 0;
 }
 
-/* ---- a LONG walk on two threads.  Error-free reads are one unitig: one chain of 10^8 reads, which no split of the seeds can share out.  What a step does
- * falls into two halves that only meet at the end of the walk: DECIDING (the record of the read, its link, the neighbour's interval, the bend / used maps,
- * check_left: does the walk go on, and to which row) and ASSEMBLING (the row's packed bases decoded behind the sequence, one more read in the coverage).
- * Past ASM_AFTER accepted reads the walk hands every accepted step to a second thread through a ring -- {row, where its bases go, how many, coverage range}
- * -- and only decides; the second thread sees the rows it will need a ring ahead of time and prefetches them itself.  The bytes are the same: the second
- * thread does to s and cov, in order, exactly what the loop would have done. */
-#define ASM_RING 4096
-#define ASM_AFTER 4096
-typedef struct { uint32_t row; int32_t ori_l, ext_len, len, rbeg, s_l; } asm_item_t;
-typedef struct asm_pipe {
-    asm_item_t ring[ASM_RING];
-    volatile uint64_t head, tail;          /* produced, consumed */
-    const fmdh_ovlp_table_t *t; str_t *s; cov_t *cov;
-    volatile int running, quit, err, idle;
-    pthread_t tid; pthread_mutex_t mu; pthread_cond_t cv;
-} asm_pipe_t;
-static void *asm_main(void *d)
-{
-    asm_pipe_t *p = (asm_pipe_t *)d;
-    for (;;) {
-        pthread_mutex_lock(&p->mu);
-        p->idle = 1; pthread_cond_broadcast(&p->cv);
-        while (!p->running && !p->quit) pthread_cond_wait(&p->cv, &p->mu);
-        p->idle = 0;
-        pthread_mutex_unlock(&p->mu);
-        if (p->quit) return 0;
-        for (;;) {
-            const uint64_t h = __atomic_load_n(&p->head, __ATOMIC_ACQUIRE);
-            uint64_t k = p->tail;
-            if (k == h) { if (!__atomic_load_n(&p->running, __ATOMIC_ACQUIRE) && k == __atomic_load_n(&p->head, __ATOMIC_ACQUIRE)) break; __builtin_ia32_pause(); continue; }
-            for (; k < h; ++k) {
-                const asm_item_t *it = &p->ring[k % ASM_RING];
-                if (k + 8 < h) {   /* the row eight steps on: its offset now, its packed bases a little later */
-                    const asm_item_t *f = &p->ring[(k + 8) % ASM_RING];
-                    const fmdh_ovlp_shard_t *sh = &p->t->shard[f->row % (uint32_t)p->t->n_shards];
-                    __builtin_prefetch(&sh->off[f->row / (uint32_t)p->t->n_shards]);
-                    __builtin_prefetch(&sh->rec[f->row / (uint32_t)p->t->n_shards]);
-                }
-                if (k + 4 < h) {
-                    const asm_item_t *f = &p->ring[(k + 4) % ASM_RING];
-                    const fmdh_ovlp_shard_t *sh = &p->t->shard[f->row % (uint32_t)p->t->n_shards];
-                    const uint32_t r = f->row / (uint32_t)p->t->n_shards;
-                    __builtin_prefetch(sh->chunk[r >> sh->chunk_shift] + sh->off[r]); __builtin_prefetch(sh->chunk[r >> sh->chunk_shift] + sh->off[r] + 64);
-                }
-                if (!p->err) {
-                    const fmdh_row_t x = fmdh_table_row(p->t, it->row);
-                    if (str_reserve(p->s, (size_t)it->s_l + 1)) p->err = -ENOMEM;
-                    else { fmdh_row_bases(&x, (uint32_t)it->len, (uint32_t)it->ext_len, p->s->s + it->ori_l); if (cov_add(p->cov, (size_t)it->rbeg, (size_t)it->s_l)) p->err = -ENOMEM; }
-                }
-                __atomic_store_n(&p->tail, k + 1, __ATOMIC_RELEASE);
-            }
-        }
-    }
-}
-static asm_pipe_t *asm_open(const fmdh_ovlp_table_t *t)
-{
-    asm_pipe_t *p = (asm_pipe_t *)calloc(1, sizeof(*p));
-    if (!p) return 0;
-    p->t = t;
-    pthread_mutex_init(&p->mu, 0); pthread_cond_init(&p->cv, 0);
-    if (pthread_create(&p->tid, 0, asm_main, p) != 0) { free(p); return 0; }
-    return p;
-}
-static void asm_close(asm_pipe_t *p)
-{
-    if (!p) return;
-    pthread_mutex_lock(&p->mu); p->quit = 1; pthread_cond_broadcast(&p->cv); pthread_mutex_unlock(&p->mu);
-    pthread_join(p->tid, 0);
-    pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv);
-    free(p);
-}
-static void asm_start(asm_pipe_t *p, str_t *s, cov_t *cov)
-{
-    pthread_mutex_lock(&p->mu);
-    while (!p->idle) pthread_cond_wait(&p->cv, &p->mu);
-    p->s = s; p->cov = cov; p->head = p->tail = 0; p->err = 0; p->running = 1;
-    pthread_cond_broadcast(&p->cv);
-    pthread_mutex_unlock(&p->mu);
-}
-static inline void asm_push(asm_pipe_t *p, asm_item_t it)
-{
-    const uint64_t h = p->head;
-    while (h - __atomic_load_n(&p->tail, __ATOMIC_ACQUIRE) >= ASM_RING) __builtin_ia32_pause();
-    p->ring[h % ASM_RING] = it;
-    __atomic_store_n(&p->head, h + 1, __ATOMIC_RELEASE);
-}
-static int asm_finish(asm_pipe_t *p)   /* the walk has ended: everything pushed is in s and cov when this returns */
-{
-    __atomic_store_n(&p->running, 0, __ATOMIC_RELEASE);
-    pthread_mutex_lock(&p->mu);
-    while (!p->idle) pthread_cond_wait(&p->cv, &p->mu);
-    pthread_mutex_unlock(&p->mu);
-    return p->err;
-}
-
 /* unitig_unidir, unitig.c:227-262.  `cur` = table row of the read at the right end of s. */
 static int unidir(walk_t *w, uint64_t cur, str_t *s, cov_t *cov, int beg0, uint64_t k0, uint64_t *end, int *is_loop)
 {
     const fmdh_link_t *link = w->t->link;
-    int beg = beg0, ori_l = (int)s->l, n_reads = 0, piped = 0, s_l = (int)s->l;
+    int beg = beg0, ori_l = (int)s->l, n_reads = 0;
     uint32_t ahead[JUMP_DIST];              /* ahead[i % JUMP_DIST] = the row step i + JUMP_DIST will visit, as far as known */
     uint64_t step = 0;
     int q;
     for (q = 0; q < JUMP_DIST; ++q) ahead[q] = 0xffffffffu;
     *is_loop = 0;
     for (;; ++step) {
-        if (!piped && w->ap_allowed && link && n_reads >= w->asm_after && (w->ap || (w->ap = asm_open(w->t)) != 0)) { asm_start(w->ap, s, cov); piped = 1; }
         if (w->sp && w->sp->budget-- == 0) { w->err = -EAGAIN; return -1; }      /* too long to speculate on: this seed is walked at commit */
         if (w->jump) {
             const uint32_t far = w->jump[cur], mid = ahead[(step + JUMP_DIST / 2) % JUMP_DIST];   /* mid: noted JUMP_DIST / 2 steps ago */
@@ -494,37 +396,29 @@ static int unidir(walk_t *w, uint64_t cur, str_t *s, cov_t *cov, int beg0, uint6
         rbeg = beg + r->rbeg;
         if (r->n_nei > 1) { st_set(w, ST_BEND, *end); break; }                     /* forward bifurcation */
         {
-            fmdh_row_t x;
-            int have_x = 0;
-            memset(&x, 0, sizeof(x));
-            if (!piped) { x = ROW(w, cur); have_x = 1; }    /* (piped: the row's variable part is the other thread's business) */
+            const fmdh_row_t x = ROW(w, cur);
             if (link) { nxt = link[cur].nxt; rev = link[cur].rev; }
             else { nxt = x.nei[0].x[0] < w->n_seq ? w->row_of[x.nei[0].x[0]] : 0xffffffffu; rev = x.nei[0].x[1] < w->n_seq ? w->row_of[x.nei[0].x[1]] : 0xffffffffu; }
             /* the `$neighbour$` interval: the neighbour's own row has it (its record is the next one the walk reads anyway) */
             if (nxt != 0xffffffffu) { const fmd_ovlp_rec_t *q = REC(w, nxt); kx[0] = q->k[0]; kx[1] = q->k[1]; kx[2] = q->k[2]; }
-            else { if (!have_x) x = ROW(w, cur); kx[0] = x.nei[0].x[0]; kx[1] = x.nei[0].x[1]; kx[2] = x.nei[0].x[2]; }
+            else { kx[0] = x.nei[0].x[0]; kx[1] = x.nei[0].x[1]; kx[2] = x.nei[0].x[2]; }
             /* the bases fm6_get_nei appended (unitig.c:139) */
-            s_l = ori_l + r->ext_len;
-            if (!piped) {
-                if (str_reserve(s, (size_t)s_l + 1)) return -1;
-                fmdh_row_bases(&x, (uint32_t)r->len, (uint32_t)r->ext_len, s->s + ori_l);
-                s->l = (size_t)s_l;
-            }
+            if (str_reserve(s, (size_t)ori_l + r->ext_len + 1)) return -1;
+            fmdh_row_bases(&x, (uint32_t)r->len, (uint32_t)r->ext_len, s->s + ori_l);
+            s->l = (size_t)ori_l + r->ext_len;
         }
         if (kx[0] == *end) break;                                                /* b>>c>>a><a */
-        if (st_get(w, ST_BEND, kx[0]) || check_left(w, r, rev) < 0) { if (w->err) { if (piped) asm_finish(w->ap); return -1; } st_set(w, ST_BEND, kx[0]); break; } /* backward bifurcation */
+        if (st_get(w, ST_BEND, kx[0]) || check_left(w, r, rev) < 0) { if (w->err) return -1; st_set(w, ST_BEND, kx[0]); break; } /* backward bifurcation */
         if (kx[0] == k0) { *is_loop = 1; break; }                                /* a>>b>>c>>a */
         if (kx[1] == *end) { w->n_nei = 0; break; }                              /* b>>c>>a>>a: cut the last link */
         *end = kx[1];
         mark_used(w, kx);
         ++n_reads;
-        if (piped) asm_push(w->ap, (asm_item_t){(uint32_t)cur, ori_l, r->ext_len, r->len, rbeg, s_l});   /* the other thread decodes the bases and counts the read */
-        else if (cov_add(cov, (size_t)rbeg, (size_t)s_l)) return -1;              /* ++ over [rbeg, ori_l), '"' for the new bases */
-        beg = rbeg; ori_l = s_l;
+        if (cov_add(cov, (size_t)rbeg, s->l)) return -1;                          /* ++ over [rbeg, ori_l), '"' for the new bases */
+        beg = rbeg; ori_l = (int)s->l;
         if (nxt == 0xffffffffu) break; /* cannot happen: a neighbour is a non-contained read */
         cur = nxt;
     }
-    if (piped && asm_finish(w->ap)) return -1;
     s->l = (size_t)ori_l;
     cov_flush(cov, (size_t)ori_l);
     return n_reads;
@@ -865,7 +759,7 @@ static int walk_parallel(walk_t *w0, uint32_t cap_nei, FILE *out, int nt)
     const int timing = getenv("FMD_TIMING") != 0;
     memset(&P, 0, sizeof(P)); memset(&Q, 0, sizeof(Q));
     if (!ch || !tid) { rc = -ENOMEM; goto done; }
-    wm.sp = 0; wm.ap_allowed = 1; wm.ap = 0;
+    wm.sp = 0;
     if ((rc = seedbuf_init(&mb, cap_nei)) != 0) goto done;
     mb_ok = 1;
     for (k = 0; k < 2 * per_win; ++k) { ch[k].w = *w0; ch[k].w.sp = &ch[k].sp; if ((rc = seedbuf_init(&ch[k].b, cap_nei)) != 0) goto done; }
@@ -934,7 +828,6 @@ done:
     }
     if (ch) for (k = 0; k < 2 * per_win; ++k) { seedbuf_free(&ch[k].b); free(ch[k].sp.keys); free(ch[k].sp.rlog); free(ch[k].sp.wlog); free(ch[k].out); }
     if (mb_ok) seedbuf_free(&mb);
-    asm_close(wm.ap);
     free(ch); free(tid);
     return rc;
 }
@@ -951,7 +844,6 @@ int fmdh_unitig_walk_opt(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_mat
     int rc = 0, b_ok = 0;
     memset(&w, 0, sizeof(w));
     w.t = t; w.n_seq = n_seq; w.min_match = min_match; w.sorted = sorted; w.full_records = (flags & FMDH_WALK_FULL_RECORDS) != 0;
-    { const char *e = getenv("FMD_WALK_ASM_AFTER"); w.asm_after = e ? atoi(e) : ASM_AFTER; }   /* (tests: 0 = from the first read on) */
     w.used = (uint64_t *)calloc(nw + 1, 8); w.bend = (uint64_t *)calloc(nw + 1, 8); w.visited = (uint64_t *)calloc(nw + 1, 8);
     w.row_of = t->row_of ? t->row_of : (uint32_t *)fmdh_big_alloc((n_seq ? n_seq : 1) * 4);
     uint32_t cap_nei = t->side_of ? t->side.max_nei : 1;
@@ -976,7 +868,6 @@ int fmdh_unitig_walk_opt(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_mat
     }
     if ((rc = seedbuf_init(&b, cap_nei)) != 0) goto done;
     b_ok = 1;
-    w.ap_allowed = walk_threads() > 1;   /* (FMD_WALK_THREADS=1: one thread means one thread) */
     if ((rc = outq_open(&oq, out)) != 0) goto done;
     oq_open = 1;
     /* unitig_core with start = 0, step = 1 (unitig.c:333-334): seeds are the odd sequence ids */
@@ -992,7 +883,6 @@ done:
     if (oq_open) { const int e = outq_close(&oq); if (!rc) rc = e; }
     free(w.used); free(w.bend); free(w.visited); if (w.row_of != t->row_of) fmdh_big_free(w.row_of);
     fmdh_big_free(w.jump);
-    asm_close(w.ap);
     if (b_ok) seedbuf_free(&b);
     return rc;
 }

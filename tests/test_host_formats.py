@@ -243,7 +243,7 @@ def test_remap_pair_table_restarts_like_the_reference_batches(oracle_lib, gold, 
 
 
 @pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20), ("special", 20)])
-@pytest.mark.parametrize("threads,chunk", [(1, 0), (3, 16), (16, 64), (8, 2048), (4, -32), (2, -2048)])
+@pytest.mark.parametrize("threads,chunk", [(1, 0), (3, 16), (16, 64), (8, 2048), (4, -32)])
 def test_parallel_walk_is_the_t1_walk(oracle_lib, gold, tmp_path, monkeypatch, name, mm, threads, chunk):
     """fmdh_unitig_walk with N threads (speculative chunks of seeds, committed in seed order: unitig_walk.c) writes the bytes of
     `fermi unitig -t1` whatever the number of threads and the chunk size -- chunks of 16 seeds make the fixtures hundreds of windows in
@@ -253,9 +253,8 @@ def test_parallel_walk_is_the_t1_walk(oracle_lib, gold, tmp_path, monkeypatch, n
     monkeypatch.setenv("FMD_TIMING", "1")
     if chunk:
         monkeypatch.setenv("FMD_WALK_CHUNK", str(abs(chunk)))
-    if chunk < 0:   # walks of more than three reads are "too long to speculate on": the rest of their chunk waits for the commit ...
+    if chunk < 0:   # walks of more than three reads are "too long to speculate on": the rest of their chunk waits for the commit
         monkeypatch.setenv("FMD_WALK_SPEC_STEPS", "3")
-        monkeypatch.setenv("FMD_WALK_ASM_AFTER", "0" if chunk == -2048 else "2")   # ... where every walk hands its reads to the assembling thread (from the first / third on)
     o = orcbind.OrcIndex(gold.path(name + ".fmd"))
     n_seq = int(o.mcnt[1])
     rec, nei, seq = o.overlap_batch(np.arange(n_seq, dtype=np.uint64), mm, max_len=100, max_nei=8, n_threads=4)
