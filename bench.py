@@ -78,6 +78,8 @@ def pmc_in_run(fmd_path, n_reads, steps=2):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not exe or os.environ.get("FMD_BENCH_PMC", "1") == "0":
         return "not run (%s)" % ("FMD_BENCH_PMC=0" if exe else "no rocprofv3 on this box")
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return "not run (this process is itself being profiled)"
     t0 = time.time()
     out = tempfile.mkdtemp(prefix="fmd_pmc_")
     env = dict(os.environ, TMPDIR="/tmp", PMC_LEGS="overlap", PMC_FMD=fmd_path, FMD_BENCH_READS=str(n_reads), PROBE_LINE="64")
@@ -85,7 +87,7 @@ def pmc_in_run(fmd_path, n_reads, steps=2):
     try:
         for sub, ctr, script, args in (("f", "FETCH_SIZE", legs, [str(steps)]), ("w", "WRITE_SIZE", legs, [str(steps)]), ("p", "FETCH_SIZE", probe, [])):
             r = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(out, sub), "-o", "x", "--", sys.executable, script] + args,
-                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=120)
             if r.returncode != 0:
                 return "failed (%s pass: rc %d: %s)" % (ctr, r.returncode, r.stderr.decode(errors="replace")[-200:].replace("\n", " "))
 
