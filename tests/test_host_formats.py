@@ -302,3 +302,25 @@ def test_parallel_fastq_reader_gives_the_serial_reader_s_records(gold, tmp_path)
     gz = str(tmp_path / "tiny.fq.gz")
     open(gz, "wb").write(open(gold.path("tiny.fq.gz"), "rb").read())
     assert hostlib.read_records_parallel(gz, 4, 0) is None          # gzip: one zlib stream, one reader
+
+
+@pytest.mark.parametrize("threads,chunk,spec", [(1, 0, 0), (4, 16, 0), (3, 16, 3), (16, 2048, 0)])
+def test_walks_that_close_on_themselves(oracle_lib, gold, tmp_path, monkeypatch, threads, chunk, spec):
+    """circle: two circular genomes tiled by reads (unitigs that come round to their own first read, unitig.c:247: the one piece of its own history a walk
+    needs) and a linear one, ids shuffled; `fermi unitig -l40 -t1`'s MAG from the sequential loop and from the speculative chunks, with walks that are
+    given up after three reads and run at commit among them (tests/golden/make_golden_circle.py made the fixture with the reference binary)."""
+    from fermi_amd import hostlib
+    monkeypatch.setenv("FMD_WALK_THREADS", str(threads))
+    if chunk:
+        monkeypatch.setenv("FMD_WALK_CHUNK", str(chunk))
+    if spec:
+        monkeypatch.setenv("FMD_WALK_SPEC_STEPS", str(spec))
+    o = orcbind.OrcIndex(gold.path("circle.fmd"))
+    n_seq = int(o.mcnt[1])
+    rec, nei, seq = o.overlap_batch(np.arange(n_seq, dtype=np.uint64), 40, max_len=100, max_nei=8, n_threads=4)
+    o.close()
+    assert (rec["status"] == 0).sum() > 2000
+    out = str(tmp_path / "o.mag")
+    hostlib.unitig_walk(_packed_shards(rec, nei, seq, 2), n_seq, 40, out, max_nei=8, seq_stride=seq.shape[1], link=3)
+    got = open(out, "rb").read()
+    assert got == gold.text_gz("circle.mag.gz") and got.count(b"\n@") + 1 == 3
