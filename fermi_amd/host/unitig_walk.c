@@ -19,11 +19,13 @@
 #include <pthread.h>
 #include <stdio.h>
 #include <sched.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 #include "fmd_host.h"
 
 typedef struct { char *s; size_t l, m; } str_t;
+static double wall_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
 static int str_reserve(str_t *s, size_t need)
 {
@@ -36,8 +38,9 @@ static int str_reserve(str_t *s, size_t need)
     return 0;
 }
 
-static inline int bit_get(const uint64_t *b, uint64_t x) { return (int)(b[x >> 6] >> (x & 63) & 1); }
-static inline void bit_set(uint64_t *b, uint64_t x) { b[x >> 6] |= 1ull << (x & 63); }
+/* (the bitmaps are read by the speculating threads while the committing thread writes them: word-sized relaxed atomics; ONE thread writes) */
+static inline int bit_get(const uint64_t *b, uint64_t x) { return (int)(__atomic_load_n(&b[x >> 6], __ATOMIC_RELAXED) >> (x & 63) & 1); }
+static inline void bit_set(uint64_t *b, uint64_t x) { __atomic_store_n(&b[x >> 6], b[x >> 6] | 1ull << (x & 63), __ATOMIC_RELAXED); }
 
 /* The three bitmaps of the walk (unitig.c:390-392) are its only state that outlives a seed.  A walk run SPECULATIVELY (the parallel
  * driver at the end of this file) reads them through st_get and writes through st_set: reads that find a bit set in the shared maps
@@ -756,6 +759,7 @@ static int walk_parallel(walk_t *w0, uint32_t cap_nei, FILE *out, int nt)
     walk_t wm = *w0;                                  /* the committing thread's own walk: direct mode */
     int rc = 0, k, started = 0, q_open = 0, mb_ok = 0;
     uint64_t q = 0, n_rerun = 0, n_walked = 0, win = 0;
+    double t_spec = 0, t_commit = 0;
     const int timing = getenv("FMD_TIMING") != 0;
     memset(&P, 0, sizeof(P)); memset(&Q, 0, sizeof(Q));
     if (!ch || !tid) { rc = -ENOMEM; goto done; }
@@ -769,19 +773,33 @@ static int walk_parallel(walk_t *w0, uint32_t cap_nei, FILE *out, int nt)
     pthread_mutex_init(&P.mu, 0); pthread_cond_init(&P.cv, 0);
     P.n_threads = nt; P.n_seq = w0->n_seq;
     for (k = 0; k < nt - 1; ++k) { if (pthread_create(&tid[k], 0, pool_main, &P) != 0) break; ++started; }
-    for (win = 0; q < n_seeds && rc == 0; ++win) {
-        chunk_t *cw = ch + (win & 1) * per_win;
-        int nc = 0;
-        for (k = 0; k < per_win && q < n_seeds; ++k, ++nc) { cw[k].q0 = q; cw[k].nq = n_seeds - q < CS ? n_seeds - q : CS; q += cw[k].nq; }
-        /* ---- the window's chunks, concurrently */
-        pthread_mutex_lock(&P.mu);
-        P.chunks = cw; P.n_chunks = nc; P.next = 0; P.running = started; ++P.generation;
-        pthread_cond_broadcast(&P.cv);
-        pthread_mutex_unlock(&P.mu);
-        for (;;) { const int c = __atomic_fetch_add(&P.next, 1, __ATOMIC_RELAXED); if (c >= nc) break; chunk_run(&cw[c], w0->n_seq); }
-        pthread_mutex_lock(&P.mu);
-        while (P.running > 0) pthread_cond_wait(&P.cv, &P.mu);
-        pthread_mutex_unlock(&P.mu);
+    /* Window w + 1 is walked (by the pool) WHILE window w is committed (by this thread): the walkers then see the bitmaps somewhere between "as window w - 1
+     * left them" and "as window w leaves them" -- any of which is fine, because a walk is only accepted if what it read still holds when ITS turn comes.
+     * The first window is walked by everybody. */
+    int nc_next = 0;
+    for (k = 0; k < per_win && q < n_seeds; ++k, ++nc_next) { ch[k].q0 = q; ch[k].nq = n_seeds - q < CS ? n_seeds - q : CS; q += ch[k].nq; }
+    pthread_mutex_lock(&P.mu);
+    P.chunks = ch; P.n_chunks = nc_next; P.next = 0; P.running = started; ++P.generation;
+    pthread_cond_broadcast(&P.cv);
+    pthread_mutex_unlock(&P.mu);
+    for (;;) { const int c = __atomic_fetch_add(&P.next, 1, __ATOMIC_RELAXED); if (c >= nc_next) break; chunk_run(&ch[c], w0->n_seq); }
+    pthread_mutex_lock(&P.mu);
+    while (P.running > 0) pthread_cond_wait(&P.cv, &P.mu);
+    pthread_mutex_unlock(&P.mu);
+    for (win = 0; nc_next > 0 && rc == 0; ++win) {
+        chunk_t *cw = ch + (win & 1) * per_win, *cn = ch + ((win + 1) & 1) * per_win;
+        const int nc = nc_next;
+        const double t_win0 = wall_s();
+        int async = 0;
+        nc_next = 0;
+        for (k = 0; k < per_win && q < n_seeds; ++k, ++nc_next) { cn[k].q0 = q; cn[k].nq = n_seeds - q < CS ? n_seeds - q : CS; q += cn[k].nq; }
+        if (nc_next && started > 0 && !getenv("FMD_WALK_NO_OVERLAP")) {   /* ---- the next window's chunks, concurrently with the commit below */
+            pthread_mutex_lock(&P.mu);
+            P.chunks = cn; P.n_chunks = nc_next; P.next = 0; P.running = started; ++P.generation;
+            pthread_cond_broadcast(&P.cv);
+            pthread_mutex_unlock(&P.mu);
+            async = 1;
+        }
         /* ---- commit in seed order */
         for (k = 0; k < nc && rc == 0; ++k) {
             chunk_t *c = &cw[k];
@@ -813,9 +831,25 @@ static int walk_parallel(walk_t *w0, uint32_t cap_nei, FILE *out, int nt)
             if (rc == 0 && oo > run_beg) sliceq_put(&Q, c->out + run_beg, oo - run_beg, c, 0);
         }
         if (Q.err) rc = -EIO;
+        t_commit += wall_s() - t_win0;
+        {
+            const double t1 = wall_s();
+            if (async) { pthread_mutex_lock(&P.mu); while (P.running > 0) pthread_cond_wait(&P.cv, &P.mu); pthread_mutex_unlock(&P.mu); }
+            else if (nc_next && rc == 0) {   /* (no pool, or FMD_WALK_NO_OVERLAP: one after the other, everybody walking) */
+                pthread_mutex_lock(&P.mu);
+                P.chunks = cn; P.n_chunks = nc_next; P.next = 0; P.running = started; ++P.generation;
+                pthread_cond_broadcast(&P.cv);
+                pthread_mutex_unlock(&P.mu);
+                for (;;) { const int c = __atomic_fetch_add(&P.next, 1, __ATOMIC_RELAXED); if (c >= nc_next) break; chunk_run(&cn[c], w0->n_seq); }
+                pthread_mutex_lock(&P.mu);
+                while (P.running > 0) pthread_cond_wait(&P.cv, &P.mu);
+                pthread_mutex_unlock(&P.mu);
+            }
+            t_spec += wall_s() - t1;      /* what of the walking did not hide under the commit */
+        }
     }
-    if (timing) fprintf(stderr, "[M::%s] %d threads, %llu windows of %d chunks x %d seeds: %llu seeds walked speculatively, %llu of them run again at commit\n", __func__, nt,
-                        (unsigned long long)win, per_win, (int)CS, (unsigned long long)n_walked, (unsigned long long)n_rerun);
+    if (timing) fprintf(stderr, "[M::%s] %d threads, %llu windows of %d chunks x %d seeds: %llu seeds walked speculatively, %llu of them run again at commit; commit %.3f s, waiting for the walkers of the next window after it %.3f s\n", __func__, nt,
+                        (unsigned long long)win, per_win, (int)CS, (unsigned long long)n_walked, (unsigned long long)n_rerun, t_commit, t_spec);
 done:
     if (started || P.generation) {
         pthread_mutex_lock(&P.mu); P.phase_quit = 1; pthread_cond_broadcast(&P.cv); pthread_mutex_unlock(&P.mu);
