@@ -29,7 +29,7 @@ static int main_unitig(int argc, char *argv[]) /* cmd.c:184-216 */
         switch (c) {
         case 'l': min_match = atoi(optarg); break;
         case 'M': break;                 /* mmap: meaningless for a device-resident index */
-        case 't': break;                 /* threads: the walk is the deterministic -t1 walk */
+        case 't': if (atoi(optarg) > 0) setenv("FMD_WALK_THREADS", optarg, 0); break;   /* host threads of the walk (unitig_walk.c); whatever the number, the MAG is -t1's */
         case 'g': n_dev = parse_gpu_list(optarg, devices, 64); break;
         case 'r': rank_file = optarg; break;
         }
@@ -40,7 +40,7 @@ static int main_unitig(int argc, char *argv[]) /* cmd.c:184-216 */
     if (optind + 1 > argc) {
         fprintf(stderr, "\nUsage:   fermi-amd unitig [options] <reads.fmd>\n\n");
         fprintf(stderr, "Options: -l INT      min match [%d]\n", min_match);
-        fprintf(stderr, "         -t INT      number of threads [ignored: output is that of -t1]\n");
+        fprintf(stderr, "         -t INT      host threads of the walk; the output is that of `fermi unitig -t1` whatever the number [16]\n");
         fprintf(stderr, "         -r FILE     rank file [null]\n");
         fprintf(stderr, "         -g LIST     GPUs to use, e.g. 0,1,2,3: the index is replicated on each, GPU g computes the\n");
         fprintf(stderr, "                     sequences i = g (mod #GPUs) as worker g of `fermi unitig -t` would seed them [0]\n\n");
