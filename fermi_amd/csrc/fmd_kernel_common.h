@@ -110,11 +110,13 @@ __device__ __forceinline__ uint64_t range64(uint32_t a, uint32_t b) // bits [a, 
 
 // Work lists of the get_nei kernels.  A strand with m candidate intervals goes to the group kernel with
 // the smallest group size G >= m (one lane per candidate, 64 / G strands per wave); the sizes are chosen
-// so that 64 / G groups leave at most 4 lanes unused.
-#define FMD_GRP_CLASSES 5
-__device__ __host__ __forceinline__ constexpr int fmd_grp_size(int k) { return k == 0 ? 8 : k == 1 ? 12 : k == 2 ? 16 : k == 3 ? 21 : 32; }
+// so that 64 / G groups leave at most 4 lanes unused.  G = 4 is there for reads with errors: an error cuts the overlaps a
+// strand has short, and 36 % of the strands of 30-fold reads with 1 % substitutions that have any candidate have at most four
+// (error-free: 0.1 %) -- in groups of 8 half of their lanes never hold anything.
+#define FMD_GRP_CLASSES 6
+__device__ __host__ __forceinline__ constexpr int fmd_grp_size(int k) { return k == 0 ? 4 : k == 1 ? 8 : k == 2 ? 12 : k == 3 ? 16 : k == 4 ? 21 : 32; }
 #define FMD_CLS_CNT_STRIDE 32              // counters sit on separate 128-byte lines
-#define FMD_CLS_HEADER_U32 512             // the counter area in front of the lists
+#define FMD_CLS_HEADER_U32 640             // the counter area in front of the lists (3 * FMD_GRP_CLASSES + 1 lines)
 // hand-over from k_ovl_nei_fast to k_ovl_nei_grp: list slots reserved FMD_FAST_CHUNK at a time, unused ones stay holes
 #define FMD_FAST_CHUNK 16
 #define FMD_FAST_MAX_WAVES 8192
@@ -142,6 +144,7 @@ __device__ __forceinline__ void fmd_resume_decode(const uint4 a, const uint4 b, 
 }
 #define FMD_FAST_RESERVE (2 * FMD_FAST_MAX_WAVES * FMD_FAST_CHUNK)   // entries a general list may lose to holes (two fast kernels feed it)
 #define FMD_CLS_PART_U32 (FMD_CLS_HEADER_U32 + 2 * FMD_GRP_CLASSES * FMD_FAST_RESERVE)   // per part of a pipelined batch: counters + that room
+static_assert((3 * FMD_GRP_CLASSES + 1) * FMD_CLS_CNT_STRIDE <= FMD_CLS_HEADER_U32, "one counter line per list");
 #define FMD_CLS_LISTS (3 * FMD_GRP_CLASSES + 1)                 // general lists, the slow list, fast lists (32-bit masks, 64-bit masks)
 #define FMD_CLS_WORDS_PER_STRAND (6 * FMD_GRP_CLASSES + 3)      // two words per entry of a group list, one each for the slow list, the late slow list, the fix-up list
 // Counters on the slow list's 128-byte line: [0] strands k_ovl_classify sets aside (k_ovl_nei takes them at once, beside the group

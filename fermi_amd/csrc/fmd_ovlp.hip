@@ -1132,8 +1132,8 @@ static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, i
         hipStreamSynchronize(st);
         hipMemcpy(hs, cls, sizeof(hs), hipMemcpyDeviceToHost);
         const uint32_t *g = hs + FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE + FMD_CLS_LATE_CNT + 8;
-        fprintf(stderr, "[grp stats] classes %u %u %u %u %u slow %u | wave rounds %u, live lanes %u (%.1f %%), lanes of groups holding a strand %u (%.1f %%)\n",
-                hs[0], hs[32], hs[64], hs[96], hs[128], hs[160], g[0], g[1], 100.0 * g[1] / (64.0 * g[0]), g[2], 100.0 * g[2] / (64.0 * g[0]));
+        fprintf(stderr, "[grp stats] classes %u %u %u %u %u %u slow %u | wave rounds %u, live lanes %u (%.1f %%), lanes of groups holding a strand %u (%.1f %%)\n",
+                hs[0], hs[32], hs[64], hs[96], hs[128], hs[160], hs[192], g[0], g[1], 100.0 * g[1] / (64.0 * g[0]), g[2], 100.0 * g[2] / (64.0 * g[0]));
         for (int k = 0; k < 2 * FMD_GRP_CLASSES; ++k) {
             const uint32_t *f = hs + (FMD_GRP_CLASSES + 1 + k) * FMD_CLS_CNT_STRIDE;
             if (f[0]) fprintf(stderr, "[fast stats] G=%d %s: %u strands, %u handed on (%u) | wave rounds %u (%u with a second base), live lanes %.1f %%, lanes of groups holding a strand %.1f %%\n",

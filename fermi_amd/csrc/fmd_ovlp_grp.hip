@@ -42,7 +42,7 @@ static_assert(GRP_POOL <= 32, "the region ends with 32 block numbers");
 #define CLS_THREADS 1024
 #define CLS_LISTS FMD_CLS_LISTS            // general class k = k, slow = FMD_GRP_CLASSES, fast class k = FMD_GRP_CLASSES + 1 + k (+ FMD_GRP_CLASSES: 64-bit masks)
 __global__ __launch_bounds__(CLS_THREADS) void k_ovl_classify(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, const fmd_intv_t *__restrict__ listA,
-                                                              uint32_t cap, FmdOvlClasses cl, int use_fast, const uint32_t *__restrict__ gidx)
+                                                              uint32_t cap, FmdOvlClasses cl, int use_fast, const uint32_t *__restrict__ gidx, int min_cls)
 {
     __shared__ uint32_t wcnt[CLS_THREADS / 64][CLS_LISTS], base[CLS_LISTS];
     const size_t i = (size_t)blockIdx.x * CLS_THREADS + threadIdx.x;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(CLS_THREADS) void k_ovl_classify(size_t n, const fm
             cls = FMD_GRP_CLASSES;
             if (w.sz <= 63 && len < 65535) {
 #pragma unroll
-                for (int k = FMD_GRP_CLASSES - 1; k >= 0; --k) if (m <= (uint32_t)fmd_grp_size(k)) cls = k;
+                for (int k = FMD_GRP_CLASSES - 1; k >= 0; --k) if (k >= min_cls && m <= (uint32_t)fmd_grp_size(k)) cls = k;
                 // the widest candidate was pushed first; the fast kernel checks the others when it loads them
                 if (cls < FMD_GRP_CLASSES && w.narrow && use_fast) cls += FMD_GRP_CLASSES + 1 + (w.sz > 31 ? FMD_GRP_CLASSES : 0);
             }
@@ -457,16 +457,16 @@ __global__ __launch_bounds__(64, FMD_FAST_LB) void k_ovl_nei_fast(FmdIndexView i
     constexpr int S = 64 / G;
     // pool slots 2g, 2g+1 = the block(s) under group g's window, images side by side and unswizzled (the lanes of a group read ONE
     // address: a broadcast); + the two slots the idle lanes past S * G would read
-    __shared__ uint4 pool[(FMD_BLK_PER_INST + 2) * FMD_BLK_U4];
-    static_assert(2 * S <= FMD_BLK_PER_INST, "one gather instruction per step");
+    // (G = 4: 16 strands per wave, 32 slots, two gather instructions per step -- the second one carries the groups 8..15)
+    constexpr int NI = (2 * S + FMD_BLK_PER_INST - 1) / FMD_BLK_PER_INST;
+    __shared__ uint4 pool[(NI * FMD_BLK_PER_INST + 2) * FMD_BLK_U4];
+    static_assert(NI <= 2 && S <= FMD_FAST_CHUNK, "a step hands on at most one chunk of strands");
     constexpr uint32_t GM = G == 32 ? 0xffffffffu : (1u << G) - 1;
     const int lane = fmd_lane(), g = lane / G, j = lane % G, gbase = g * G;
     const uint32_t N = *list_n;
     const uint32_t n_groups = gridDim.x * S;
     uint32_t idx = g < S ? blockIdx.x * S + g : 0xffffffffu;
-    // this lane's part in the gather: chunk (lane & 3) of pool slot lane >> 2, which belongs to group f_src / G
-    const int f_slot = lane >> FMD_GRP_SHIFT, f_src = (f_slot >> 1) < S ? (f_slot >> 1) * G : 0;
-    const bool f_mine = (f_slot >> 1) < S;
+    // this lane's part in gather instruction r: chunk (lane & 3) of pool slot 16 r + (lane >> 2), which belongs to group slot / 2
     const uint4 *img = pool + 2 * FMD_BLK_U4 * g;
 
     // group-uniform strand state
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(64, FMD_FAST_LB) void k_ovl_nei_fast(FmdIndexView i
                     }
                     alive = false; resume = false;
                 }
-                const uint32_t n = (uint32_t)__popcll(hm), room = res_end - res_cur;   // n <= 8 < FMD_FAST_CHUNK
+                const uint32_t n = (uint32_t)__popcll(hm), room = res_end - res_cur;   // n <= S <= FMD_FAST_CHUNK
                 uint32_t base = 0;
                 if (room < n) {   // the first `room` of them finish the old chunk, the rest start a new one: only a wave's LAST chunk keeps holes
                     if (lane == 0) { base = atomicAdd(gen_n, (uint32_t)FMD_FAST_CHUNK); atomicAdd(bail_n, n_handed); }   // (the count: diagnostics, FMD_OVLP_STATS)
@@ -568,11 +568,13 @@ __global__ __launch_bounds__(64, FMD_FAST_LB) void k_ovl_nei_fast(FmdIndexView i
 #if FMD_COUNT_LINES
         { uint64_t heads = 0; for (int q = 0; q < S; ++q) heads |= 1ull << (q * G); fmd_count_lines(ix, __popcll(act_m & heads) + __popcll(sep_m & heads)); }
 #endif
-        {
+#pragma unroll
+        for (int r = 0; r < NI; ++r) {
+            const int f_slot = r * FMD_BLK_PER_INST + (lane >> FMD_GRP_SHIFT), f_grp = f_slot >> 1, f_src = f_grp < S ? f_grp * G : 0;
             const uint32_t sb = (uint32_t)__shfl((int)bke, f_src);
-            if (f_mine && ((act_m >> f_src) & 1) && (!(f_slot & 1) || ((sep_m >> f_src) & 1))) {
+            if (f_grp < S && ((act_m >> f_src) & 1) && (!(f_slot & 1) || ((sep_m >> f_src) & 1))) {
                 const uint4 *from = ix.blocks + (size_t)(sb + (uint32_t)(f_slot & 1)) * FMD_BLK_U4 + (lane & FMD_GRP_MASK);
-                __builtin_amdgcn_global_load_lds((fmd_glb_void *)from, (fmd_lds_void *)pool, 16, 0, FMD_GLDS_AUX);
+                __builtin_amdgcn_global_load_lds((fmd_glb_void *)from, (fmd_lds_void *)(pool + r * FMD_BLK_PER_INST * FMD_BLK_U4), 16, 0, FMD_GLDS_AUX);
             }
         }
         fmd_fetch_wait();
@@ -673,7 +675,7 @@ template <int G, typename M>
 static int fast_blocks_per_cu(void)
 {
     static int cached = 0;
-    if (!cached) cached = fmd_resident_per_cu(k_ovl_nei_fast<G, M>, sizeof(uint4) * (FMD_BLK_PER_INST + 2) * FMD_BLK_U4, 32, "k_ovl_nei_fast");
+    if (!cached) cached = fmd_resident_per_cu(k_ovl_nei_fast<G, M>, sizeof(uint4) * ((2 * (64 / G) + FMD_BLK_PER_INST - 1) / FMD_BLK_PER_INST * FMD_BLK_PER_INST + 2) * FMD_BLK_U4, 32, "k_ovl_nei_fast");
     return cached;
 }
 #endif
@@ -693,7 +695,8 @@ void fmd_launch_nei_fast(int cls, int wide, int n_cu, int per_cu_cap, hipStream_
     case 1: FAST_LAUNCH2(1); break;
     case 2: FAST_LAUNCH2(2); break;
     case 3: FAST_LAUNCH2(3); break;
-    default: FAST_LAUNCH2(4); break;
+    case 4: FAST_LAUNCH2(4); break;
+    default: FAST_LAUNCH2(5); break;
     }
 #undef FAST_LAUNCH2
 #undef FAST_LAUNCH
@@ -726,11 +729,13 @@ void fmd_launch_nei_grp(int cls, int n_cu, int per_cu_cap, hipStream_t st, const
     case 1: GRP_LAUNCH(1); break;
     case 2: GRP_LAUNCH(2); break;
     case 3: GRP_LAUNCH(3); break;
-    default: GRP_LAUNCH(4); break;
+    case 4: GRP_LAUNCH(4); break;
+    default: GRP_LAUNCH(5); break;
     }
 #undef GRP_LAUNCH
 }
 void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, const fmd_intv_t *listA, uint32_t cap, FmdOvlClasses cl, int use_fast, const uint32_t *gidx)
 {
-    k_ovl_classify<<<(unsigned)((n + CLS_THREADS - 1) / CLS_THREADS), CLS_THREADS, 0, st>>>(n, rec, listA, cap, cl, use_fast, gidx);
+    const char *e = getenv("FMD_GRP4");   // A/B knob: FMD_GRP4=0 = no groups of 4 (round 3's classes)
+    k_ovl_classify<<<(unsigned)((n + CLS_THREADS - 1) / CLS_THREADS), CLS_THREADS, 0, st>>>(n, rec, listA, cap, cl, use_fast, gidx, e && atoi(e) == 0 ? 1 : 0);
 }

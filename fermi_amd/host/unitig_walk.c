@@ -71,6 +71,7 @@ typedef struct {
     uint64_t last; int n_nei;
     int err;
     uint32_t *jump;             /* row JUMP_DIST accepted links ahead of each row (prefetch hints only; 0 = not built) */
+    const struct hop *hop;      /* what a plain step of the walk reads, 32 bytes per row (hop_build below; 0 = not built) */
 } walk_t;
 
 /* The walk is a pointer chase: the next row is known when link[row] has arrived, one DRAM miss (~90 ns) per read and nothing
@@ -124,6 +125,7 @@ static inline void prefetch_row_head(const walk_t *w, uint32_t row) /* what a vi
     if (w->jump) __builtin_prefetch(&w->jump[row]);
     if (t->side_of) __builtin_prefetch(&t->side_of[row]);
 }
+
 static inline void prefetch_row_var(const walk_t *w, uint32_t row)  /* once its offset is there */
 {
     const fmdh_ovlp_table_t *t = w->t;
@@ -134,6 +136,84 @@ static inline void prefetch_row_var(const walk_t *w, uint32_t row)  /* once its 
 }
 
 static inline fmdh_row_t ROW(const walk_t *w, uint64_t row) { return fmdh_table_row(w->t, row); }
+
+/* A step of unidir() over the table reads the row's record, its offset, its link, its jump entry, two lines of its packed part (the appended
+ * bases), the record of the neighbour's reverse strand (check_left): seven lines from seven places, and a core keeps about a dozen misses
+ * in flight whatever the prefetch distance -- 61 ns per read on error-free reads (5*10^7 of them in a handful of unitigs: 3.05 s at the
+ * commit of `unitig` on 5*10^7 reads).  The PLAIN step -- one neighbour, check_left decided, a few appended bases: all but the last step of
+ * every walk -- needs 29 bytes of all that.  hop[row] holds them, written once by all host threads (the pass reads the table in row
+ * order; only the neighbour's records are random), and the walk then touches ONE line per read.  Rows that are not plain (no / several
+ * neighbours, an undecided edge, a row of the side table, more than 21 appended bases, intervals beyond 32 bits) have HOP_OK clear and
+ * take the general code below, which is also what FMD_WALK_NO_HOP=1 leaves (the A/B switch, and the tests' second opinion). */
+#define HOP_OK 1u
+#define HOP_CL 2u               /* check_left < 0: a backward bifurcation */
+#define HOP_MAX_EXT 21
+typedef struct hop {
+    uint32_t nxt, far;          /* the neighbour's row; the row JUMP_DIST links on (prefetch hint) */
+    uint32_t kx0, kx1;          /* k[0], k[1] of the neighbour's record: its `$read$` interval */
+    uint16_t rbeg; uint8_t ext_len, kx2;
+    uint8_t flags, pad[3];
+    uint64_t bases;             /* the appended bases (nt6 codes), 3 bits each, first one lowest */
+} hop_t;                        /* 32 bytes */
+typedef struct { const walk_t *w; hop_t *hop; uint64_t lo, hi; } hop_job_t;
+static inline const fmd_ovlp_rec_t *REC(const walk_t *w, uint64_t row);
+static void *hop_main(void *p)
+{
+    hop_job_t *j = (hop_job_t *)p;
+    const walk_t *w = j->w;
+    const fmdh_ovlp_table_t *t = w->t;
+    uint64_t i;
+    for (i = j->lo; i < j->hi; ++i) {
+        hop_t *h = &j->hop[i];
+        memset(h, 0, sizeof(*h));
+        h->nxt = t->link[i].nxt; h->far = w->jump ? w->jump[i] : 0xffffffffu;
+        if (i + 8 < j->hi && t->link[i + 8].nxt != 0xffffffffu) __builtin_prefetch(REC(w, t->link[i + 8].nxt));
+        if (i + 8 < j->hi && t->link[i + 8].rev != 0xffffffffu) __builtin_prefetch(REC(w, t->link[i + 8].rev));
+        if (t->side_of && t->side_of[i] != 0xffffffffu) continue;
+        const fmd_ovlp_rec_t *r = REC(w, i);
+        const uint32_t nxt = t->link[i].nxt, rev = t->link[i].rev;
+        if (r->status != 0 || r->rbeg < 0 || r->rbeg > 0xffff || r->n_nei != 1 || (r->flags & FMD_OVLP_F_OVERFLOW) || nxt == 0xffffffffu) continue;
+        if (r->ext_len < 0 || r->ext_len > HOP_MAX_EXT) continue;
+        const fmd_ovlp_rec_t *q = REC(w, nxt);
+        if (q->k[0] > 0xffffffffull || q->k[1] > 0xffffffffull || q->k[2] > 0xffull) continue;
+        int cl = r->reserved;                            /* check_left below, without its error exit: an undecided edge is not a plain step */
+        if (cl == 2) {
+            const int d = rev != 0xffffffffu ? fmd_lfork_decide(REC(w, rev)->lfork, r->rbeg) : 1;
+            if (d == 1) continue;
+            cl = d < 0;
+        }
+        if (cl != 0) cl = rev == 0xffffffffu ? 1 : REC(w, rev)->n_nei > 1;
+        {
+            char tmp[HOP_MAX_EXT + 3];
+            const fmdh_row_t x = ROW(w, i);
+            int k;
+            fmdh_row_bases(&x, (uint32_t)r->len, (uint32_t)r->ext_len, tmp);
+            for (k = 0; k < r->ext_len; ++k) h->bases |= (uint64_t)((unsigned char)tmp[k] & 7u) << (3 * k);
+        }
+        h->kx0 = (uint32_t)q->k[0]; h->kx1 = (uint32_t)q->k[1]; h->kx2 = (uint8_t)q->k[2];
+        h->rbeg = (uint16_t)r->rbeg; h->ext_len = (uint8_t)r->ext_len;
+        h->flags = (uint8_t)(HOP_OK | (cl ? HOP_CL : 0u));
+    }
+    return 0;
+}
+static hop_t *hop_build(const walk_t *w)
+{
+    const uint64_t n = w->t->n;
+    hop_t *hop = (hop_t *)fmdh_big_alloc((n ? n : 1) * sizeof(hop_t));
+    int nt = 16, k;
+    pthread_t tid[64];
+    hop_job_t job[64];
+    int started[64];
+    { const char *e = getenv("FMD_HOST_THREADS"); if (e && atoi(e) > 0) nt = atoi(e); }
+    if (nt > 64) nt = 64;
+    if ((uint64_t)nt > n / 4096 + 1) nt = (int)(n / 4096 + 1);
+    if (!hop) return 0;
+    for (k = 0; k < nt; ++k) job[k] = (hop_job_t){w, hop, n * (uint64_t)k / (uint64_t)nt, n * (uint64_t)(k + 1) / (uint64_t)nt};
+    for (k = 1; k < nt; ++k) started[k] = pthread_create(&tid[k], 0, hop_main, &job[k]) == 0;
+    hop_main(&job[0]);
+    for (k = 1; k < nt; ++k) { if (started[k]) pthread_join(tid[k], 0); else hop_main(&job[k]); }
+    return hop;
+}
 
 /* Short unitigs (reads with errors: 10^8 of them at 50 M reads) leave the skip list nothing to look ahead along; what a seed will
  * touch is known from the seeds' own links, which are read in id order.  Three stages, SEED_AHEAD ids apart, for the two first hops
@@ -387,6 +467,35 @@ static int unidir(walk_t *w, uint64_t cur, str_t *s, cov_t *cov, int beg0, uint6
     *is_loop = 0;
     for (;; ++step) {
         if (w->sp && w->sp->budget-- == 0) { w->err = -EAGAIN; return -1; }      /* too long to speculate on: this seed is walked at commit */
+        if (w->hop) {
+            const hop_t *h = &w->hop[cur];
+            {   /* hints: the line of the step JUMP_DIST links on; half way there, when that line has arrived, the bitmap words its step will test and set */
+                const uint32_t mid = ahead[(step + JUMP_DIST / 2) % JUMP_DIST];
+                if (h->far != 0xffffffffu) __builtin_prefetch(&w->hop[h->far]);
+                if (mid != 0xffffffffu) { const hop_t *m = &w->hop[mid]; __builtin_prefetch(&w->bend[m->kx0 >> 6]); __builtin_prefetch(&w->used[m->kx0 >> 6]); __builtin_prefetch(&w->used[m->kx1 >> 6]); }
+                ahead[step % JUMP_DIST] = h->far;
+            }
+            if (h->flags & HOP_OK) {                                             /* the plain step, from one line (see hop_t) */
+                uint64_t kx[3] = {h->kx0, h->kx1, h->kx2}, bs = h->bases;
+                const int ext = h->ext_len, rbeg = beg + (int)h->rbeg;
+                int k;
+                w->last = cur; w->n_nei = 1;
+                if (str_reserve(s, (size_t)ori_l + (size_t)ext + 1)) return -1;
+                for (k = 0; k < ext; ++k, bs >>= 3) s->s[ori_l + k] = (char)(bs & 7u);
+                s->l = (size_t)ori_l + (size_t)ext;
+                if (kx[0] == *end) break;
+                if (st_get(w, ST_BEND, kx[0]) || (h->flags & HOP_CL)) { st_set(w, ST_BEND, kx[0]); break; }
+                if (kx[0] == k0) { *is_loop = 1; break; }
+                if (kx[1] == *end) { w->n_nei = 0; break; }
+                *end = kx[1];
+                mark_used(w, kx);
+                ++n_reads;
+                if (cov_add(cov, (size_t)rbeg, s->l)) return -1;
+                beg = rbeg; ori_l = (int)s->l;
+                cur = h->nxt;
+                continue;
+            }
+        }
         if (w->jump) {
             const uint32_t far = w->jump[cur], mid = ahead[(step + JUMP_DIST / 2) % JUMP_DIST];   /* mid: noted JUMP_DIST / 2 steps ago */
             if (far != 0xffffffffu) prefetch_row_head(w, far);
@@ -915,6 +1024,11 @@ int fmdh_unitig_walk_opt(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_mat
     }
     const int hints = t->link && !getenv("FMD_WALK_NO_JUMP");
     if (hints) w.jump = build_jump(t->link, t->n);   /* 0: the plain chase */
+    if (t->link && !getenv("FMD_WALK_NO_HOP")) {
+        const double t0 = wall_s();
+        w.hop = hop_build(&w);                         /* 0: every step through the general code */
+        if (getenv("FMD_TIMING")) fprintf(stderr, "[M::%s] one line per plain step (hop[], %.1f GB): %.3f s\n", __func__, (double)t->n * sizeof(hop_t) / 1e9, wall_s() - t0);
+    }
     const int seed_stages = !(getenv("FMD_WALK_SEED_STAGES") && atoi(getenv("FMD_WALK_SEED_STAGES")) == 0);
     {
         const int nt = walk_threads();
@@ -936,7 +1050,7 @@ int fmdh_unitig_walk_opt(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_mat
 done:
     if (oq_open) { const int e = outq_close(&oq); if (!rc) rc = e; }
     free(w.used); free(w.bend); free(w.visited); if (w.row_of != t->row_of) fmdh_big_free(w.row_of);
-    fmdh_big_free(w.jump);
+    fmdh_big_free(w.jump); fmdh_big_free((void *)w.hop);
     if (b_ok) seedbuf_free(&b);
     return rc;
 }
