@@ -225,7 +225,8 @@ extern "C" int fmd_ovlp_pack_rows_dev(fmd_dev_t *h, void *stream_, size_t n, con
 // (fmdh_ovlp_table_link); on one GPU this is two streaming kernels instead of 0.4 s of host threads.
 //   row_of[k]  = smallest id whose `$read$` interval starts at k (identical reads share one interval), ~0 = none
 //   link[i]    = {row_of[nei.x0], row_of[nei.x1]} of the unique neighbour, {~0, ~0} otherwise
-//   rec[i].reserved: 0 / 1 where lfork decides the edge; 2 (untouched) elsewhere -- those ids are appended to und[]
+//   rec[i].reserved: 0 / 1 where lfork decides the edge; 2 (untouched) elsewhere -- those ids are appended to und[], and so are the
+//   rows whose neighbour has no row yet (flagged records)
 __device__ __forceinline__ int lfork_decide_dev(uint16_t lfork, int rbeg)   // fmd_lfork_decide of include/fmd_hip.h (a host inline there)
 {
     const int r = lfork & 0x7fff;
@@ -252,12 +253,16 @@ __global__ void k_link_edges(size_t n, fmd_ovlp_rec_t *__restrict__ rec, const u
             const uint64_t x0 = nei_x01[i * (size_t)nei_stride], x1 = nei_x01[i * (size_t)nei_stride + 1];
             if (x0 < n) l.nxt = row_of[x0];
             if (x1 < n) l.rev = row_of[x1];
+            // a neighbour without a row: its record is flagged (a capacity was exceeded) and the caller computes it again, larger -- the
+            // edge is reported with the undecided ones, and the caller links it when that row is there (host/ovlp_table.c: table_patch_links)
+            const bool miss = (x0 < n && l.nxt == 0xffffffffu) || (x1 < n && l.rev == 0xffffffffu);
+            int d = 0;
             if (r->reserved == 2) {
-                int d = 1;
+                d = 1;
                 if (l.rev != 0xffffffffu && !force_exact) d = lfork_decide_dev(rec[l.rev].lfork, r->rbeg);
                 if (d != 1) r->reserved = (uint16_t)(d < 0 ? 1 : 0);
-                else und[atomicAdd(n_und, 1ull)] = i;
             }
+            if (d == 1 || miss) und[atomicAdd(n_und, 1ull)] = i;
         }
         link[i] = l;
     }

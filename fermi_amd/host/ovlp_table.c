@@ -58,6 +58,23 @@ static inline fmd_ovlp_rec_t *row_rec_mut(fmdh_ovlp_table_t *t, uint64_t id)
     if (t->side_of && t->side_of[id] != 0xffffffffu) return &t->side.rec[t->side_of[id]];
     return &t->shard[id % (uint64_t)t->n_shards].rec[id / (uint64_t)t->n_shards];
 }
+/* link[i] and, where lfork decides it, rec[i].reserved of one row; 1 = the edge is left to the exact kernel */
+static inline int link_row(fmdh_ovlp_table_t *t, uint64_t i, int force_exact)
+{
+    const fmdh_row_t x = fmdh_table_row(t, i);
+    fmd_ovlp_rec_t *r = row_rec_mut(t, i);
+    fmdh_link_t *l = &t->link[i];
+    int d = 1;
+    l->nxt = l->rev = 0xffffffffu;
+    if (r->status != 0 || r->n_nei != 1 || r->rbeg < 0 || (r->flags & FMD_OVLP_F_OVERFLOW)) return 0;
+    if (x.nei[0].x[0] < t->n) l->nxt = t->row_of[x.nei[0].x[0]];
+    if (x.nei[0].x[1] < t->n) l->rev = t->row_of[x.nei[0].x[1]];
+    if (r->reserved != 2) return 0;                          /* the exact answer is already there */
+    if (l->rev != 0xffffffffu) d = fmd_lfork_decide(row_rec_mut(t, l->rev)->lfork, r->rbeg);
+    if (force_exact) d = 1;
+    if (d != 1) r->reserved = d < 0 ? 1 : 0;
+    return d == 1;
+}
 static void *lk_main(void *p)
 {
     lk_t *w = (lk_t *)p;
@@ -73,30 +90,15 @@ static void *lk_main(void *p)
         }
         return 0;
     }
-    for (i = w->lo; i < w->hi; ++i) {
-        const fmdh_row_t x = fmdh_table_row(t, i);
-        fmd_ovlp_rec_t *r = row_rec_mut(t, i);
-        fmdh_link_t *l = &t->link[i];
-        l->nxt = l->rev = 0xffffffffu;
-        if (r->status != 0 || r->n_nei != 1 || r->rbeg < 0 || (r->flags & FMD_OVLP_F_OVERFLOW)) continue;
-        if (x.nei[0].x[0] < t->n) l->nxt = t->row_of[x.nei[0].x[0]];
-        if (x.nei[0].x[1] < t->n) l->rev = t->row_of[x.nei[0].x[1]];
-        if (r->reserved != 2) continue;                      /* the exact answer is already there */
-        {
-            int d = 1;
-            if (l->rev != 0xffffffffu) d = fmd_lfork_decide(row_rec_mut(t, l->rev)->lfork, r->rbeg);
-            if (w->force_exact) d = 1;
-            if (d != 1) r->reserved = d < 0 ? 1 : 0;
-            else {
-                if (w->n_und == w->m_und) {
-                    uint64_t m = w->m_und ? w->m_und << 1 : 1024, *q = (uint64_t *)realloc(w->und, m * 8);
-                    if (!q) { w->rc = -ENOMEM; return 0; }
-                    w->und = q; w->m_und = m;
-                }
-                w->und[w->n_und++] = i;
+    for (i = w->lo; i < w->hi; ++i)
+        if (link_row(t, i, w->force_exact)) {
+            if (w->n_und == w->m_und) {
+                uint64_t m = w->m_und ? w->m_und << 1 : 1024, *q = (uint64_t *)realloc(w->und, m * 8);
+                if (!q) { w->rc = -ENOMEM; return 0; }
+                w->und = q; w->m_und = m;
             }
+            w->und[w->n_und++] = i;
         }
-    }
     return 0;
 }
 
@@ -144,6 +146,33 @@ done:
     if (w) for (k = 0; k < n_threads; ++k) free(w[k].und);
     free(w); free(tid); free(started);
     return rc;
+}
+
+/* One GPU linked the whole table (fmd_ovlp_packed_table) while the rows that exceeded a capacity were still flagged; they are in the side
+ * table now.  Nothing else changed, so nothing else is linked again: the side rows enter row_of (identical reads overflow together, so no
+ * entry that is there loses to one of them), and the rows of `ids` -- the side rows themselves and what the device reported: edges it could
+ * not decide and edges into a row that was not there -- get their links and verdicts the way fmdh_ovlp_table_link gives them to every row.
+ * (0.6 s of host threads over 10^8 rows for 6*10^5 that changed.)  ids: ascending, may repeat. */
+static int table_patch_links(fmdh_ovlp_table_t *t, const uint64_t *side_ids, uint64_t n_side, const uint64_t *dev_und, uint64_t n_dev_und, uint64_t **und_out, uint64_t *n_und_out)
+{
+    const int force_exact = getenv("FMD_CHECK_LEFT_EXACT") != NULL;
+    uint64_t a = 0, b = 0, last = ~0ull, n_und = 0, m_und = 0, *und = 0;
+    *und_out = 0; *n_und_out = 0;
+    for (a = 0; a < n_side; ++a) {
+        const fmd_ovlp_rec_t *r = &t->side.rec[a];
+        if (r->status == 0 && !(r->flags & FMD_OVLP_F_OVERFLOW) && r->k[0] < t->n && (uint32_t)side_ids[a] < t->row_of[r->k[0]]) t->row_of[r->k[0]] = (uint32_t)side_ids[a];
+    }
+    for (a = 0, b = 0; a < n_side || b < n_dev_und;) {   /* the two lists merged */
+        const uint64_t i = b >= n_dev_und || (a < n_side && side_ids[a] <= dev_und[b]) ? side_ids[a++] : dev_und[b++];
+        if (i == last) continue;
+        last = i;
+        if (link_row(t, i, force_exact)) {
+            if (n_und == m_und) { uint64_t m = m_und ? m_und << 1 : 1024, *q = (uint64_t *)realloc(und, m * 8); if (!q) { free(und); return -ENOMEM; } und = q; m_und = m; }
+            und[n_und++] = i;
+        }
+    }
+    *und_out = und; *n_und_out = n_und;
+    return 0;
 }
 
 /* ------------------------------------------------------------------------------------------------ build */
@@ -331,6 +360,12 @@ static int table_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_de
         if (jobs[0].whole && n_side == 0) { /* linked on the device already */
             und = jobs[0].und; n_und = jobs[0].n_und; jobs[0].und = 0;
             if (timing) fprintf(stderr, "[M::%s] link pass on the GPU (inside the table pass), %llu edges left to the exact kernel\n", __func__, (unsigned long long)n_und);
+        } else if (jobs[0].whole && !getenv("FMD_HOST_RELINK")) {   /* linked on the device, and a few rows were replaced since: those, and what pointed at them */
+            rc = table_patch_links(t, ids, n_side, jobs[0].und, jobs[0].n_und, &und, &n_und);
+            fmd_host_free(jobs[0].und); jobs[0].und = 0;
+            if (rc) { fprintf(stderr, "[E::%s] link patch: %s\n", __func__, strerror(-rc)); rc = 1; goto done; }
+            if (timing) fprintf(stderr, "[M::%s] link pass on the GPU (inside the table pass) + %llu rows linked again here: %.3f s, %llu edges left to the exact kernel\n", __func__,
+                                (unsigned long long)n_side, now_s() - t1, (unsigned long long)n_und);
         } else {
             fmd_host_free(jobs[0].und); jobs[0].und = 0;    /* rows were replaced by the overflow pass: link again, here */
             rc = fmdh_ovlp_table_link(t, nt, &und, &n_und);

@@ -73,6 +73,17 @@ typedef struct {
     uint32_t *jump;             /* row JUMP_DIST accepted links ahead of each row (prefetch hints only; 0 = not built) */
     const struct hop *hop;      /* what a plain step of the walk reads, 32 bytes per row (hop_build below; 0 = not built) */
 } walk_t;
+/* one entry of walk_t.hop (see hop_build) */
+#define HOP_OK 1u
+#define HOP_CL 2u               /* check_left < 0: a backward bifurcation */
+#define HOP_MAX_EXT 21
+typedef struct hop {
+    uint32_t nxt, far;          /* the neighbour's row; the row JUMP_DIST links on (prefetch hint) */
+    uint32_t kx0, kx1;          /* k[0], k[1] of the neighbour's record: its `$read$` interval */
+    uint16_t rbeg; uint8_t ext_len, kx2;
+    uint8_t flags, pad[3];
+    uint64_t bases;             /* the appended bases (nt6 codes), 3 bits each, first one lowest */
+} hop_t;                        /* 32 bytes */
 
 /* The walk is a pointer chase: the next row is known when link[row] has arrived, one DRAM miss (~90 ns) per read and nothing
  * to overlap it with -- 1.8 s per 10^7 reads.  A chase cannot be prefetched, a chase with a skip list can: jump[row] = the
@@ -124,13 +135,14 @@ static inline void prefetch_row_head(const walk_t *w, uint32_t row) /* what a vi
     if (t->link) __builtin_prefetch(&t->link[row]);
     if (w->jump) __builtin_prefetch(&w->jump[row]);
     if (t->side_of) __builtin_prefetch(&t->side_of[row]);
+    if (w->hop) __builtin_prefetch(&w->hop[row]);
 }
 
 static inline void prefetch_row_var(const walk_t *w, uint32_t row)  /* once its offset is there */
 {
     const fmdh_ovlp_table_t *t = w->t;
     const fmdh_ovlp_shard_t *s = &t->shard[row % (uint32_t)t->n_shards];
-    const uint32_t r = row / (uint32_t)t->n_shards;
+    const uint64_t r = row / (uint32_t)t->n_shards;   /* (64 bits: a table in one chunk has a chunk_shift beyond 32) */
     __builtin_prefetch(s->chunk[r >> s->chunk_shift] + s->off[r]);
     __builtin_prefetch(s->chunk[r >> s->chunk_shift] + s->off[r] + 64);
 }
@@ -145,16 +157,6 @@ static inline fmdh_row_t ROW(const walk_t *w, uint64_t row) { return fmdh_table_
  * order; only the neighbour's records are random), and the walk then touches ONE line per read.  Rows that are not plain (no / several
  * neighbours, an undecided edge, a row of the side table, more than 21 appended bases, intervals beyond 32 bits) have HOP_OK clear and
  * take the general code below, which is also what FMD_WALK_NO_HOP=1 leaves (the A/B switch, and the tests' second opinion). */
-#define HOP_OK 1u
-#define HOP_CL 2u               /* check_left < 0: a backward bifurcation */
-#define HOP_MAX_EXT 21
-typedef struct hop {
-    uint32_t nxt, far;          /* the neighbour's row; the row JUMP_DIST links on (prefetch hint) */
-    uint32_t kx0, kx1;          /* k[0], k[1] of the neighbour's record: its `$read$` interval */
-    uint16_t rbeg; uint8_t ext_len, kx2;
-    uint8_t flags, pad[3];
-    uint64_t bases;             /* the appended bases (nt6 codes), 3 bits each, first one lowest */
-} hop_t;                        /* 32 bytes */
 typedef struct { const walk_t *w; hop_t *hop; uint64_t lo, hi; } hop_job_t;
 static inline const fmd_ovlp_rec_t *REC(const walk_t *w, uint64_t row);
 static void *hop_main(void *p)
@@ -224,6 +226,14 @@ static inline void seed_hint_head(const walk_t *w, uint32_t a)
     if (a == 0xffffffffu) return;
     prefetch_row_head(w, a);
 }
+/* A seed that is `used` already returns at once (unitig.c:282, :289) and nothing of its rows is read: no hints for it.  On error-free reads that is
+ * every seed but a handful -- the genome is one walk -- and thirty wasted line fetches per seed were most of the walk's time there (2*10^6 reads on
+ * 8 cores: 1.26 s, of which 0.19 s inside walks).  The bit is read as it is NOW, without the speculative walk's logs: a hint decides nothing. */
+static inline const fmd_ovlp_rec_t *REC(const walk_t *w, uint64_t row);
+static inline int seed_is_used(const walk_t *w, uint64_t j)
+{
+    return w->sorted ? bit_get(w->used, j) : bit_get(w->used, REC(w, j)->rank);
+}
 static inline void seed_hints(const walk_t *w, uint64_t i, int staged)
 {
     const fmdh_ovlp_table_t *t = w->t;
@@ -232,13 +242,13 @@ static inline void seed_hints(const walk_t *w, uint64_t i, int staged)
         if (i + SEED_AHEAD < t->n) for (d = 0; d < 2; ++d) { const uint32_t a = t->link[i + SEED_AHEAD - (uint64_t)d].nxt; if (a != 0xffffffffu) __builtin_prefetch(&t->shard[a % (uint32_t)t->n_shards].rec[a / (uint32_t)t->n_shards]); }
         return;
     }
-    if (i + 3 * SEED_AHEAD < t->n)
+    if (i + 3 * SEED_AHEAD < t->n && !seed_is_used(w, i + 3 * SEED_AHEAD))
         for (d = 0; d < 2; ++d) {
             const fmdh_link_t *l = &t->link[i + 3 * SEED_AHEAD - (uint64_t)d];
             seed_hint_head(w, l->nxt);
             if (l->rev != 0xffffffffu) __builtin_prefetch(&t->shard[l->rev % (uint32_t)t->n_shards].rec[l->rev / (uint32_t)t->n_shards]);
         }
-    if (i + 2 * SEED_AHEAD < t->n)
+    if (i + 2 * SEED_AHEAD < t->n && !seed_is_used(w, i + 2 * SEED_AHEAD))
         for (d = 0; d < 2; ++d) {
             const uint32_t a = t->link[i + 2 * SEED_AHEAD - (uint64_t)d].nxt;
             if (a == 0xffffffffu) continue;
@@ -246,7 +256,7 @@ static inline void seed_hints(const walk_t *w, uint64_t i, int staged)
             seed_hint_head(w, t->link[a].nxt);
             if (t->link[a].rev != 0xffffffffu) __builtin_prefetch(&t->shard[t->link[a].rev % (uint32_t)t->n_shards].rec[t->link[a].rev / (uint32_t)t->n_shards]);
         }
-    if (i + SEED_AHEAD < t->n)
+    if (i + SEED_AHEAD < t->n && !seed_is_used(w, i + SEED_AHEAD))
         for (d = 0; d < 2; ++d) {
             const uint32_t a = t->link[i + SEED_AHEAD - (uint64_t)d].nxt;
             if (a != 0xffffffffu && t->link[a].nxt != 0xffffffffu) prefetch_row_var(w, t->link[a].nxt);
@@ -1005,6 +1015,7 @@ int fmdh_unitig_walk_opt(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_mat
     seedbuf_t b;
     uint64_t i, nw = (n_seq + 63) / 64;
     int rc = 0, b_ok = 0;
+    double t_begin = wall_s();
     memset(&w, 0, sizeof(w));
     w.t = t; w.n_seq = n_seq; w.min_match = min_match; w.sorted = sorted; w.full_records = (flags & FMDH_WALK_FULL_RECORDS) != 0;
     w.used = (uint64_t *)calloc(nw + 1, 8); w.bend = (uint64_t *)calloc(nw + 1, 8); w.visited = (uint64_t *)calloc(nw + 1, 8);
@@ -1023,7 +1034,9 @@ int fmdh_unitig_walk_opt(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_mat
         }
     }
     const int hints = t->link && !getenv("FMD_WALK_NO_JUMP");
+    t_begin = wall_s();
     if (hints) w.jump = build_jump(t->link, t->n);   /* 0: the plain chase */
+    if (getenv("FMD_TIMING") && hints) fprintf(stderr, "[M::%s] skip list over the links: %.3f s\n", __func__, wall_s() - t_begin);
     if (t->link && !getenv("FMD_WALK_NO_HOP")) {
         const double t0 = wall_s();
         w.hop = hop_build(&w);                         /* 0: every step through the general code */
@@ -1049,6 +1062,7 @@ int fmdh_unitig_walk_opt(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_mat
     }
 done:
     if (oq_open) { const int e = outq_close(&oq); if (!rc) rc = e; }
+    if (getenv("FMD_TIMING")) fprintf(stderr, "[M::%s] walk of %llu sequences: %.3f s\n", __func__, (unsigned long long)n_seq, wall_s() - t_begin);
     free(w.used); free(w.bend); free(w.visited); if (w.row_of != t->row_of) fmdh_big_free(w.row_of);
     fmdh_big_free(w.jump); fmdh_big_free((void *)w.hop);
     if (b_ok) seedbuf_free(&b);

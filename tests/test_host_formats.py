@@ -111,6 +111,29 @@ def test_unitig_walk_prefetch_hints_change_nothing(oracle_lib, gold, tmp_path, m
     o.close()
 
 
+@pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20), ("special", 20), ("circle", 40)])
+@pytest.mark.parametrize("threads", [1, 4])
+def test_one_line_per_plain_step_changes_nothing(oracle_lib, gold, tmp_path, monkeypatch, name, mm, threads):
+    """hop[] (unitig_walk.c: the 29 bytes a plain step of the walk needs, one 32-byte entry per row, built from the linked table by all host threads)
+    against the general code that reads the record, the link, the packed row and the reverse strand's record (FMD_WALK_NO_HOP=1): the same MAG, the
+    reference's, from the sequential loop and from the speculative chunks -- on the fixtures with forks, contained reads, bases other than A/C/G/T
+    (rows that are not plain steps) and unitigs that close on themselves."""
+    monkeypatch.setenv("FMD_WALK_THREADS", str(threads))
+    monkeypatch.setenv("FMD_WALK_CHUNK", "16")
+    o = orcbind.OrcIndex(gold.path(name + ".fmd"))
+    n_seq = int(o.mcnt[1])
+    rec, nei, seq = o.overlap_batch(np.arange(n_seq, dtype=np.uint64), mm, max_len=100, max_nei=8, n_threads=4)
+    outs = []
+    for no_hop in (False, True):
+        if no_hop:
+            monkeypatch.setenv("FMD_WALK_NO_HOP", "1")
+        out = str(tmp_path / ("o%d.mag" % no_hop))
+        hostlib.unitig_walk(_packed_shards(rec.copy(), nei, seq, 2), n_seq, mm, out, max_nei=8, seq_stride=seq.shape[1], link=3)
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] == gold.text_gz(name + ".mag.gz")
+    o.close()
+
+
 def _random_bwt(rng, n, mean_run, long_runs):
     """nt6 symbols with geometric run lengths (mean `mean_run`) and a few very long runs (>= 2^15: the 32-bit block headers)"""
     out, tot = [], 0
