@@ -72,6 +72,7 @@ typedef struct {
     int err;
     uint32_t *jump;             /* row JUMP_DIST accepted links ahead of each row (prefetch hints only; 0 = not built) */
     const struct hop *hop;      /* what a plain step of the walk reads, 32 bytes per row (hop_build below; 0 = not built) */
+    double t_uni, t_turn, t_text; uint64_t n_hops;   /* FMD_TIMING: seconds inside unidir, turning the string round, formatting the record; reads appended */
 } walk_t;
 /* one entry of walk_t.hop (see hop_build) */
 #define HOP_OK 1u
@@ -689,8 +690,10 @@ static int walk_seed(walk_t *w, uint64_t i, seedbuf_t *b, size_t *wl)
     if (cov_add(cov, 0, (size_t)seed_len)) return -ENOMEM;
     n_reads = 1;
     end[0] = r->k[1]; end[1] = r->k[0];
+    double p0 = wall_s(), p1;
     if (r->n_ovlp) { /* left-wards extension of the unitig = right-wards of this strand */
         int m = unidir(w, i, s, cov, 0, r->k[0], &end[0], &is_loop);
+        p1 = wall_s(); w->t_uni += p1 - p0; p0 = p1; w->n_hops += m > 0 ? (uint64_t)m : 0;
         if (m < 0) return w->err ? w->err : -ENOMEM;
         n_reads += m;
         { const fmd_intv_t *ln = fmdh_table_row(t, w->last).nei;
@@ -702,7 +705,9 @@ static int walk_seed(walk_t *w, uint64_t i, seedbuf_t *b, size_t *wl)
         int m;
         cov_flush(cov, s->l);
         revcomp6(s->l, s->s); reverse(s->l, cov->s);
+        p1 = wall_s(); w->t_turn += p1 - p0; p0 = p1;
         m = unidir(w, i ^ 1, s, cov, (int)s->l - seed_len, r->k[1], &end[1], &is_loop);
+        p1 = wall_s(); w->t_uni += p1 - p0; p0 = p1; w->n_hops += m > 0 ? (uint64_t)m : 0;
         if (m < 0) return w->err ? w->err : -ENOMEM;
         n_reads += m;
         { const fmd_intv_t *ln = fmdh_table_row(t, w->last).nei;
@@ -732,6 +737,7 @@ static int walk_seed(walk_t *w, uint64_t i, seedbuf_t *b, size_t *wl)
          * becomes "ACGT"[4] = NUL (mag.c:168) and cuts the record there.  Reproduced as is. */
         *wl = cut && !w->full_records ? strnlen(o->s, o->l) : o->l;
     }
+    w->t_text += wall_s() - p0;
     return 1;
 }
 
@@ -988,6 +994,8 @@ static int walk_parallel(walk_t *w0, uint32_t cap_nei, FILE *out, int nt)
     }
     if (timing) fprintf(stderr, "[M::%s] %d threads, %llu windows of %d chunks x %d seeds: %llu seeds walked speculatively, %llu of them run again at commit; commit %.3f s, waiting for the walkers of the next window after it %.3f s\n", __func__, nt,
                         (unsigned long long)win, per_win, (int)CS, (unsigned long long)n_walked, (unsigned long long)n_rerun, t_commit, t_spec);
+    if (timing) fprintf(stderr, "[M::%s] walks run at the commit: %llu reads appended in %.3f s, turning the strings round %.3f s, record text %.3f s\n", __func__,
+                        (unsigned long long)wm.n_hops, wm.t_uni, wm.t_turn, wm.t_text);
 done:
     if (started || P.generation) {
         pthread_mutex_lock(&P.mu); P.phase_quit = 1; pthread_cond_broadcast(&P.cv); pthread_mutex_unlock(&P.mu);
