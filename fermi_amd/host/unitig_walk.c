@@ -72,6 +72,7 @@ typedef struct {
     int err;
     uint32_t *jump;             /* row JUMP_DIST accepted links ahead of each row (prefetch hints only; 0 = not built) */
     const struct hop *hop;      /* what a plain step of the walk reads, 32 bytes per row (hop_build below; 0 = not built) */
+    int seed_hints;             /* the seeds' first hops are prefetched (a linked table, unless FMD_WALK_NO_JUMP) */
     double t_uni, t_turn, t_text; uint64_t n_hops;   /* FMD_TIMING: seconds inside unidir, turning the string round, formatting the record; reads appended */
 } walk_t;
 /* one entry of walk_t.hop (see hop_build) */
@@ -696,6 +697,7 @@ static int walk_seed(walk_t *w, uint64_t i, seedbuf_t *b, size_t *wl)
         p1 = wall_s(); w->t_uni += p1 - p0; p0 = p1; w->n_hops += m > 0 ? (uint64_t)m : 0;
         if (m < 0) return w->err ? w->err : -ENOMEM;
         n_reads += m;
+        if ((uint32_t)w->n_nei > b->cap_nei) return -ERANGE;   /* more neighbours than any row of this table holds: the row should have been flagged and computed again */
         { const fmd_intv_t *ln = fmdh_table_row(t, w->last).nei;
           for (k = 0; k < w->n_nei; ++k) { nei[0][k].x = ln[k].x[0]; nei[0][k].y = ln[k].info; }
           n_nei[0] = w->n_nei;
@@ -710,6 +712,7 @@ static int walk_seed(walk_t *w, uint64_t i, seedbuf_t *b, size_t *wl)
         p1 = wall_s(); w->t_uni += p1 - p0; p0 = p1; w->n_hops += m > 0 ? (uint64_t)m : 0;
         if (m < 0) return w->err ? w->err : -ENOMEM;
         n_reads += m;
+        if ((uint32_t)w->n_nei > b->cap_nei) return -ERANGE;
         { const fmd_intv_t *ln = fmdh_table_row(t, w->last).nei;
           for (k = 0; k < w->n_nei; ++k) { nei[1][k].x = ln[k].x[0]; nei[1][k].y = ln[k].info; } }
         n_nei[1] = w->n_nei;
@@ -831,7 +834,7 @@ static void chunk_run(chunk_t *c, uint64_t n_seq)
         int rc;
         if (gave_up) { c->res[k].n_r = c->res[k].n_w = 0; c->res[k].out_len = 0; c->res[k].rc = -EAGAIN; continue; }   /* (walked at commit) */
         sp->budget = spec_steps; c->w.err = 0;
-        if (c->w.jump && i < n_seq) seed_hints(&c->w, i, 1);
+        if (c->w.seed_hints && i < n_seq) seed_hints(&c->w, i, 1);
         rc = i < n_seq ? walk_seed(&c->w, i, &c->b, &wl) : 0;
         if (sp->err && rc >= 0) rc = sp->err;
         /* a walk too long to speculate on: the seeds behind it in this chunk may lie on that very unitig (error-free reads: all of them do) and
@@ -1043,9 +1046,33 @@ int fmdh_unitig_walk_opt(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_mat
     }
     const int hints = t->link && !getenv("FMD_WALK_NO_JUMP");
     t_begin = wall_s();
-    if (hints) w.jump = build_jump(t->link, t->n);   /* 0: the plain chase */
-    if (getenv("FMD_TIMING") && hints) fprintf(stderr, "[M::%s] skip list over the links: %.3f s\n", __func__, wall_s() - t_begin);
-    if (t->link && !getenv("FMD_WALK_NO_HOP")) {
+    w.seed_hints = hints;
+    /* The skip list and hop[] serve LONG walks (error-free or corrected reads: unitigs of 10^3 .. 10^7 reads, walked by one thread); on raw reads a
+     * walk is one to three steps from its seed, the seeds' own hints cover those, and 0.15 + 0.43 s of building the two per 10^8 rows buy nothing
+     * (measured: walk 4.4-5.2 s with, 4.1-4.7 s without, box noise larger than the difference).  Which it is shows in the links: the plain steps in a row
+     * from 2048 evenly spaced rows, 64 at most each.  FMD_WALK_LONG=0 / 1 overrides the verdict (tests: both ways on the same fixture). */
+    int long_walks = 0;
+    if (t->link && t->n) {
+        const uint64_t ns = t->n < 2048 ? t->n : 2048;
+        uint64_t k, tot = 0;
+        for (k = 0; k < ns; ++k) {
+            uint64_t cur = (uint64_t)((unsigned __int128)t->n * k / ns);
+            int len = 0;
+            while (len < 64) {
+                const fmd_ovlp_rec_t *r = REC(&w, cur);
+                if (r->status != 0 || r->rbeg < 0 || r->n_nei != 1 || t->link[cur].nxt == 0xffffffffu) break;
+                cur = t->link[cur].nxt; ++len;
+            }
+            tot += (uint64_t)len;
+        }
+        long_walks = tot >= 16 * ns;
+        { const char *e = getenv("FMD_WALK_LONG"); if (e) long_walks = atoi(e) != 0; }
+        if (getenv("FMD_TIMING")) fprintf(stderr, "[M::%s] %.1f plain steps in a row from a sampled row (of 64 at most): %s\n", __func__, (double)tot / (double)ns,
+                                          long_walks ? "long walks, skip list + one line per step" : "short walks, the seeds' hints only");
+    }
+    if (hints && long_walks) w.jump = build_jump(t->link, t->n);   /* 0: the plain chase */
+    if (getenv("FMD_TIMING") && w.jump) fprintf(stderr, "[M::%s] skip list over the links: %.3f s\n", __func__, wall_s() - t_begin);
+    if (t->link && long_walks && !getenv("FMD_WALK_NO_HOP")) {
         const double t0 = wall_s();
         w.hop = hop_build(&w);                         /* 0: every step through the general code */
         if (getenv("FMD_TIMING")) fprintf(stderr, "[M::%s] one line per plain step (hop[], %.1f GB): %.3f s\n", __func__, (double)t->n * sizeof(hop_t) / 1e9, wall_s() - t0);

@@ -100,6 +100,7 @@ def test_unitig_walk_prefetch_hints_change_nothing(oracle_lib, gold, tmp_path, m
     exact = rec["reserved"].copy()
     rec["reserved"] = 2
     outs = []
+    monkeypatch.setenv("FMD_WALK_LONG", "1")
     for no_jump in (False, True):
         if no_jump:
             monkeypatch.setenv("FMD_WALK_NO_JUMP", "1")
@@ -120,6 +121,7 @@ def test_one_line_per_plain_step_changes_nothing(oracle_lib, gold, tmp_path, mon
     (rows that are not plain steps) and unitigs that close on themselves."""
     monkeypatch.setenv("FMD_WALK_THREADS", str(threads))
     monkeypatch.setenv("FMD_WALK_CHUNK", "16")
+    monkeypatch.setenv("FMD_WALK_LONG", "1")   # (the walk builds hop[] and the skip list where a sample of the links shows long walks: here, always)
     o = orcbind.OrcIndex(gold.path(name + ".fmd"))
     n_seq = int(o.mcnt[1])
     rec, nei, seq = o.overlap_batch(np.arange(n_seq, dtype=np.uint64), mm, max_len=100, max_nei=8, n_threads=4)
