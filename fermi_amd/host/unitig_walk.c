@@ -73,6 +73,7 @@ typedef struct {
     uint32_t *jump;             /* row JUMP_DIST accepted links ahead of each row (prefetch hints only; 0 = not built) */
     const struct hop *hop;      /* what a plain step of the walk reads, 32 bytes per row (hop_build below; 0 = not built) */
     int seed_hints;             /* the seeds' first hops are prefetched (a linked table, unless FMD_WALK_NO_JUMP) */
+    int timing;                 /* FMD_TIMING: the clock is read around the sections of a walk (four times per seed that walks: not for free at 4*10^7 seeds) */
     double t_uni, t_turn, t_text; uint64_t n_hops;   /* FMD_TIMING: seconds inside unidir, turning the string round, formatting the record; reads appended */
 } walk_t;
 /* one entry of walk_t.hop (see hop_build) */
@@ -691,10 +692,11 @@ static int walk_seed(walk_t *w, uint64_t i, seedbuf_t *b, size_t *wl)
     if (cov_add(cov, 0, (size_t)seed_len)) return -ENOMEM;
     n_reads = 1;
     end[0] = r->k[1]; end[1] = r->k[0];
-    double p0 = wall_s(), p1;
+    const int tm = w->timing;
+    double p0 = tm ? wall_s() : 0, p1;
     if (r->n_ovlp) { /* left-wards extension of the unitig = right-wards of this strand */
         int m = unidir(w, i, s, cov, 0, r->k[0], &end[0], &is_loop);
-        p1 = wall_s(); w->t_uni += p1 - p0; p0 = p1; w->n_hops += m > 0 ? (uint64_t)m : 0;
+        if (tm) { p1 = wall_s(); w->t_uni += p1 - p0; p0 = p1; w->n_hops += m > 0 ? (uint64_t)m : 0; }
         if (m < 0) return w->err ? w->err : -ENOMEM;
         n_reads += m;
         if ((uint32_t)w->n_nei > b->cap_nei) return -ERANGE;   /* more neighbours than any row of this table holds: the row should have been flagged and computed again */
@@ -707,9 +709,9 @@ static int walk_seed(walk_t *w, uint64_t i, seedbuf_t *b, size_t *wl)
         int m;
         cov_flush(cov, s->l);
         revcomp6(s->l, s->s); reverse(s->l, cov->s);
-        p1 = wall_s(); w->t_turn += p1 - p0; p0 = p1;
+        if (tm) { p1 = wall_s(); w->t_turn += p1 - p0; p0 = p1; }
         m = unidir(w, i ^ 1, s, cov, (int)s->l - seed_len, r->k[1], &end[1], &is_loop);
-        p1 = wall_s(); w->t_uni += p1 - p0; p0 = p1; w->n_hops += m > 0 ? (uint64_t)m : 0;
+        if (tm) { p1 = wall_s(); w->t_uni += p1 - p0; p0 = p1; w->n_hops += m > 0 ? (uint64_t)m : 0; }
         if (m < 0) return w->err ? w->err : -ENOMEM;
         n_reads += m;
         if ((uint32_t)w->n_nei > b->cap_nei) return -ERANGE;
@@ -740,7 +742,7 @@ static int walk_seed(walk_t *w, uint64_t i, seedbuf_t *b, size_t *wl)
          * becomes "ACGT"[4] = NUL (mag.c:168) and cuts the record there.  Reproduced as is. */
         *wl = cut && !w->full_records ? strnlen(o->s, o->l) : o->l;
     }
-    w->t_text += wall_s() - p0;
+    if (tm) w->t_text += wall_s() - p0;
     return 1;
 }
 
@@ -1047,6 +1049,7 @@ int fmdh_unitig_walk_opt(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_mat
     const int hints = t->link && !getenv("FMD_WALK_NO_JUMP");
     t_begin = wall_s();
     w.seed_hints = hints;
+    w.timing = getenv("FMD_TIMING") != NULL;
     /* The skip list and hop[] serve LONG walks (error-free or corrected reads: unitigs of 10^3 .. 10^7 reads, walked by one thread); on raw reads a
      * walk is one to three steps from its seed, the seeds' own hints cover those, and 0.15 + 0.43 s of building the two per 10^8 rows buy nothing
      * (measured: walk 4.4-5.2 s with, 4.1-4.7 s without, box noise larger than the difference).  Which it is shows in the links: the plain steps in a row
