@@ -507,29 +507,63 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
 #undef WALK_STASH_WORD
 #undef WALK_PUT_BASE
 
-// The caller's copy of every sequence in read order: the stash holds it last base first.  One thread
-// per output word; the same conditions under which a record describes a complete sequence
-// (k_ovl_walk: not empty, not longer than max_len, longer than min_match unless info_only).
-__global__ void k_ovl_seq_out(size_t n, uint32_t words, const uint8_t *__restrict__ srev, uint32_t stride_r, const fmd_ovlp_rec_t *__restrict__ rec,
-                              int min_match, int info_only, uint8_t *__restrict__ seq_out, uint32_t seq_stride, const uint32_t *__restrict__ gidx)
+// The caller's copy of every sequence in read order: the stash holds it last base first.  One thread per 16 output bytes (four aligned
+// dwords of the stash, a fifth when the chunk starts between two, funnel-shifted and byte-swapped; the record's length is read once per
+// chunk, not once per word: 2.8 -> ms per 2*10^7 strands of 100 bases); the chunk that holds the sequence's last
+// bytes, and rows too short for a whole chunk, go word by word as before.  Same conditions under which a record describes a complete
+// sequence (k_ovl_walk: not empty, not longer than max_len, longer than min_match unless info_only).  Bytes of a row beyond the sequence
+// are written only inside the word that holds its last base (zeros), as before.
+__device__ __forceinline__ void seq_out_word(const uint8_t *sr, int L, uint32_t w, uint8_t *dst)
+{
+    // output bytes 4w..4w+3 = stash bytes a+3..a with a = L - 4 - 4w: an unaligned word, byte-swapped
+    const int a = L - 4 - (int)(4 * w);
+    uint32_t v;
+    if (a >= 0) {
+        const uint32_t *q = (const uint32_t *)(sr + (a & ~3));
+        const uint64_t two = (a & 3) ? ((uint64_t)q[1] << 32 | q[0]) : q[0];
+        v = __builtin_bswap32((uint32_t)(two >> (8 * (a & 3))));
+    } else v = __builtin_bswap32(*(const uint32_t *)sr << (8 * -a)); // the first 4 + a bases of the stash, the rest of the word zero
+    *(uint32_t *)(dst + 4 * w) = v;
+}
+__global__ void k_ovl_seq_out_words(size_t n, uint32_t words, const uint8_t *__restrict__ srev, uint32_t stride_r, const fmd_ovlp_rec_t *__restrict__ rec,
+                                    int min_match, int info_only, uint8_t *__restrict__ seq_out, uint32_t seq_stride, const uint32_t *__restrict__ gidx)
 {
     const size_t total = n * (size_t)words, step = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
         const size_t sid = i / words;
         const uint32_t w = (uint32_t)(i - sid * words);
-        const size_t g = gidx ? (size_t)gidx[sid] : sid;   // the strand's row in rec[] and seq_out[] (sorted batches: fmd_ovlp_sorted_dev)
+        const size_t g = gidx ? (size_t)gidx[sid] : sid;
         const int L = rec[g].len;
         if (L <= 0 || (uint32_t)L > stride_r || (!info_only && L <= min_match) || (int)(4 * w) >= L || 4 * w + 3 >= seq_stride) continue;
+        seq_out_word(srev + sid * (size_t)stride_r, L, w, seq_out + g * (size_t)seq_stride);
+    }
+}
+__global__ void k_ovl_seq_out(size_t n, uint32_t chunks, const uint8_t *__restrict__ srev, uint32_t stride_r, const fmd_ovlp_rec_t *__restrict__ rec,
+                              int min_match, int info_only, uint8_t *__restrict__ seq_out, uint32_t seq_stride, const uint32_t *__restrict__ gidx)
+{
+    const size_t total = n * (size_t)chunks, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const size_t sid = i / chunks;
+        const uint32_t c = (uint32_t)(i - sid * chunks), o = 16 * c;
+        const size_t g = gidx ? (size_t)gidx[sid] : sid;   // the strand's row in rec[] and seq_out[] (sorted batches: fmd_ovlp_sorted_dev)
+        const int L = rec[g].len;
+        if (L <= 0 || (uint32_t)L > stride_r || (!info_only && L <= min_match) || (int)o >= L) continue;
         const uint8_t *sr = srev + sid * (size_t)stride_r;
-        // output bytes 4w..4w+3 = stash bytes a+3..a with a = L - 4 - 4w: an unaligned word, byte-swapped
-        const int a = L - 4 - (int)(4 * w);
-        uint32_t v;
-        if (a >= 0) {
+        uint8_t *dst = seq_out + g * (size_t)seq_stride;
+        if ((int)o + 16 <= L && o + 16 <= seq_stride) {   // a whole chunk inside the sequence: stash bytes [a, a + 16), a >= 0
+            const int a = L - 16 - (int)o;
+            const uint32_t sh = 8 * ((uint32_t)a & 3);
             const uint32_t *q = (const uint32_t *)(sr + (a & ~3));
-            const uint64_t two = (a & 3) ? ((uint64_t)q[1] << 32 | q[0]) : q[0];
-            v = __builtin_bswap32((uint32_t)(two >> (8 * (a & 3))));
-        } else v = __builtin_bswap32(*(const uint32_t *)sr << (8 * -a)); // the first 4 + a bases of the stash, the rest of the word zero
-        *(uint32_t *)(seq_out + g * (size_t)seq_stride + 4 * w) = v;
+            const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = sh ? q[4] : 0u;   // (q[4] holds stash bytes below a + 16 <= L: inside the row)
+            const uint32_t d0 = sh ? (uint32_t)(((uint64_t)q1 << 32 | q0) >> sh) : q0, d1 = sh ? (uint32_t)(((uint64_t)q2 << 32 | q1) >> sh) : q1;
+            const uint32_t d2 = sh ? (uint32_t)(((uint64_t)q3 << 32 | q2) >> sh) : q2, d3 = sh ? (uint32_t)(((uint64_t)q4 << 32 | q3) >> sh) : q3;
+            uint32_t *out = (uint32_t *)(dst + o);
+            out[0] = __builtin_bswap32(d3); out[1] = __builtin_bswap32(d2); out[2] = __builtin_bswap32(d1); out[3] = __builtin_bswap32(d0);
+        } else {
+#pragma unroll
+            for (uint32_t w = 4 * c; w < 4 * c + 4; ++w)
+                if ((int)(4 * w) < L && 4 * w + 3 < seq_stride) seq_out_word(sr, L, w, dst);
+        }
     }
 }
 
@@ -997,11 +1031,18 @@ static uint32_t walk_ticket_chunk(const char *env, uint32_t dflt, size_t n, int 
 static void launch_seq_out(hipStream_t st, size_t n, uint32_t max_len, const uint8_t *srev, uint32_t stride_r, const fmd_ovlp_rec_t *rec, int min_match,
                            int info_only, uint8_t *seq_out, uint32_t seq_stride, const uint32_t *gidx = nullptr)
 {
-    const uint32_t words = (max_len + 3) / 4;
-    const size_t total = n * (size_t)words;
+    if (getenv("FMD_SEQ_OUT_WORDS")) {   // A/B switch: one thread per output word (round 3's kernel)
+        const uint32_t words = (max_len + 3) / 4;
+        size_t blocks = (n * (size_t)words + 255) / 256;
+        if (blocks > (1u << 22)) blocks = 1u << 22;
+        k_ovl_seq_out_words<<<(unsigned)blocks, 256, 0, st>>>(n, words, srev, stride_r, rec, min_match, info_only, seq_out, seq_stride, gidx);
+        return;
+    }
+    const uint32_t chunks = (max_len + 15) / 16;
+    const size_t total = n * (size_t)chunks;
     size_t blocks = (total + 255) / 256;
     if (blocks > (1u << 22)) blocks = 1u << 22;
-    k_ovl_seq_out<<<(unsigned)blocks, 256, 0, st>>>(n, words, srev, stride_r, rec, min_match, info_only, seq_out, seq_stride, gidx);
+    k_ovl_seq_out<<<(unsigned)blocks, 256, 0, st>>>(n, chunks, srev, stride_r, rec, min_match, info_only, seq_out, seq_stride, gidx);
 }
 
 extern "C" size_t fmd_ovlp_work_bytes(size_t n, uint32_t max_len, int min_match)
