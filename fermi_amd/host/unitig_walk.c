@@ -204,6 +204,12 @@ static void *hop_main(void *p)
 static hop_t *hop_build(const walk_t *w)
 {
     const uint64_t n = w->t->n;
+    /* 32 bytes per row on top of a table of 140: only where that much memory is plainly there (twice over, unless the blocks are file pages) --
+     * the walk is the same without it */
+    if (!getenv("FMD_TABLE_DIR")) {
+        const long pg = sysconf(_SC_PAGESIZE), av = sysconf(_SC_AVPHYS_PAGES);
+        if (pg > 0 && av > 0 && (double)av * (double)pg < 2.0 * (double)n * sizeof(hop_t)) return 0;
+    }
     hop_t *hop = (hop_t *)fmdh_big_alloc((n ? n : 1) * sizeof(hop_t));
     int nt = 16, k;
     pthread_t tid[64];
