@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Groups of 4 lanes for strands with at most four candidates (FMD_GRP4, fmd_kernel_common.h) against round 3's classes (8, 12, 16, 21, 32):
 the sorted overlap job over all strands of an index of reads with errors, HIP-event time each way, and the records, neighbours and
-sequences compared byte for byte.  Usage: python tools/ab_grp4.py [n_reads=50000000] [err=0.01] [steps=2] [only=0|1]
+sequences compared byte for byte.  Usage: python tools/ab_grp4.py [n_reads=50000000] [err=0.01] [steps=2] [only=0|1|-] [switch=FMD_GRP4]
 (only: that setting of FMD_GRP4 alone, steps + 1 passes, nothing compared -- the form tools/pmc_grp4.sh profiles)"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +12,8 @@ from fermi_amd import api, workload
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
 err = float(sys.argv[2]) if len(sys.argv) > 2 else 0.01
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-only = sys.argv[4] if len(sys.argv) > 4 else None
+only = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] != "-" else None
+VAR = sys.argv[5] if len(sys.argv) > 5 else "FMD_GRP4"   # the switch under test (FMD_GRP4, FMD_ROUTE_DOWN): 0 = without, 1 = with
 L, min_match, max_nei, batch = 100, 50, 4, 20_000_000
 stride = 2 * L
 dev = torch.device("cuda", 0)
@@ -56,15 +57,15 @@ def timed(bufs):
 
 
 if only is not None:
-    os.environ["FMD_GRP4"] = only
-    print("FMD_GRP4=%s: %.1f ms per pass over %d strands" % (only, timed(buffers()), n), flush=True)
+    os.environ[VAR] = only
+    print("%s=%s: %.1f ms per pass over %d strands" % (VAR, only, timed(buffers()), n), flush=True)
     index.close()
     sys.exit(0)
 A, B = buffers(), buffers()
 res = {}
 for rnd in range(2):   # (twice each way, alternating: clocks and caches settle)
-    for key, val, bufs in (("classes 8..32", "0", A), ("classes 4..32", "1", B)):
-        os.environ["FMD_GRP4"] = val
+    for key, val, bufs in ((VAR + "=0", "0", A), (VAR + "=1", "1", B)):
+        os.environ[VAR] = val
         res.setdefault(key, []).append(timed(bufs))
 for key, v in res.items():
     print("%-14s %s ms per pass over %d strands" % (key, " ".join("%8.1f" % t for t in v), n), flush=True)
