@@ -13,7 +13,11 @@ AMD = os.path.join(ROOT, "fermi_amd", "bin", "fermi-amd")
 D = "/tmp/fmd_ab_hop"; os.makedirs(D, exist_ok=True)
 lut = np.frombuffer(b"$ACGTN", dtype=np.uint8)
 env = dict(os.environ, FMD_TIMING="1")
-for err in (0.0, 0.01):
+ERRS = [float(x) for x in os.environ.get("AB_ERRS", "0,0.01").split(",")]
+MODES = [("as shipped", {}), ("FMD_WALK_NO_HOP=1", {"FMD_WALK_NO_HOP": "1"}), ("FMD_HOST_RELINK=1", {"FMD_HOST_RELINK": "1"})]
+if "AB_MODES" in os.environ:   # e.g. AB_MODES="FMD_WALK_NO_DEFER=1;FMD_WALK_NO_HOP=1" (as shipped always runs first)
+    MODES = [("as shipped", {})] + [(m, dict(kv.split("=", 1) for kv in m.split(","))) for m in os.environ["AB_MODES"].split(";") if m]
+for err in ERRS:
     with open(D + "/r.fq", "wb") as fp:
         for s in range(0, n, 1_000_000):
             c = min(1_000_000, n - s)
@@ -22,7 +26,7 @@ for err in (0.0, 0.01):
     subprocess.run([AMD, "build", "-fo", D + "/a.fmd", D + "/r.fq"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env, check=True)
     print("==== %d reads, e = %g" % (n, err), flush=True)
     for rep in range(2):
-        for name, extra in (("as shipped", {}), ("FMD_WALK_NO_HOP=1", {"FMD_WALK_NO_HOP": "1"}), ("FMD_HOST_RELINK=1", {"FMD_HOST_RELINK": "1"})):
+        for name, extra in MODES:
             if name.startswith("FMD_HOST") and err == 0.0:
                 continue
             t = time.time()
