@@ -19,7 +19,6 @@
 #include <unistd.h>
 #include <algorithm>
 #include <mutex>
-#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -367,27 +366,6 @@ extern "C" void *fmd_table_alloc(size_t bytes)
 #ifdef MADV_HUGEPAGE
     madvise(p, asz, MADV_HUGEPAGE);   // first touch of 4 KiB pages costs more than the copy that fills a 9 GB table, and random reads miss the TLB less
 #endif
-    // The pages of a big block are faulted in HERE, by several threads: left to the first user -- hipHostRegister, which pins page by page on one
-    // thread -- "device buffers + pinning" of a 10^8-row table took 0.3 s on a box that had huge pages to give and 1.0-2.2 s on one that did not.
-    if (asz >= ((size_t)256 << 20) && !getenv("FMD_NO_POPULATE")) {
-        int nt = 8;
-        { const char *e = getenv("FMD_HOST_THREADS"); if (e && atoi(e) > 0 && atoi(e) < nt) nt = atoi(e); }
-        const size_t per = (asz / (size_t)nt + huge - 1) / huge * huge;
-        std::vector<std::thread> th;
-        for (int k = 0; k < nt; ++k) {
-            const size_t lo = (size_t)k * per, hi = lo + per < asz ? lo + per : asz;
-            if (lo >= hi) break;
-            th.emplace_back([=] {
-                char *q = (char *)p + lo;
-                const size_t len = hi - lo;
-#ifdef MADV_POPULATE_WRITE
-                if (madvise(q, len, MADV_POPULATE_WRITE) == 0) return;
-#endif
-                for (size_t o = 0; o < len; o += 4096) ((volatile char *)q)[o] = 0;
-            });
-        }
-        for (auto &t : th) t.join();
-    }
     return p;
 }
 

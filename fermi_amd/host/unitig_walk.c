@@ -73,7 +73,6 @@ typedef struct {
     uint32_t *jump;             /* row JUMP_DIST accepted links ahead of each row (prefetch hints only; 0 = not built) */
     const struct hop *hop;      /* what a plain step of the walk reads, 32 bytes per row (hop_build below; 0 = not built) */
     int seed_hints;             /* the seeds' first hops are prefetched (a linked table, unless FMD_WALK_NO_JUMP) */
-    uint32_t *defer; uint32_t n_defer;   /* `used` marks of plain steps, set in bulk (defer_flush); 0 = set as the walk goes */
     int timing;                 /* FMD_TIMING: the clock is read around the sections of a walk (four times per seed that walks: not for free at 4*10^7 seeds) */
     double t_uni, t_turn, t_text; uint64_t n_hops;   /* FMD_TIMING: seconds inside unidir, turning the string round, formatting the record; reads appended */
 } walk_t;
@@ -475,30 +474,8 @@ static int check_left(walk_t *w, const fmd_ovlp_rec_t *r, uint32_t rev)
     return REC(w, rev)->n_nei > 1 ? -1 : 0;
 }
 
-/* Nothing inside a walk reads `used` (unitig.c:227-262 tests `bend` only; `used` decides which SEEDS walk), so the marks of a long walk's plain steps need
- * not be set as it goes: two random words of a 12 MB bitmap per read, competing for the core's dozen outstanding misses with the one line the next step
- * waits for.  They are noted and set in bulk, every DEFER_CAP / 2 reads and when the walk returns -- before anything looks at `used` again on this
- * thread; the speculative walkers of the next window see them a little later, which any state of the maps allows (walk_parallel). */
-#define DEFER_CAP 8192
-static void defer_flush(walk_t *w)
-{
-    uint32_t k;
-    const uint32_t n = w->n_defer;
-    for (k = 0; k < n; ++k) {
-        if (k + 16 < n) __builtin_prefetch(&w->used[w->defer[k + 16] >> 6], 1);
-        bit_set(w->used, w->defer[k]);
-    }
-    w->n_defer = 0;
-}
-static int unidir_core(walk_t *w, uint64_t cur, str_t *s, cov_t *cov, int beg0, uint64_t k0, uint64_t *end, int *is_loop);
 /* unitig_unidir, unitig.c:227-262.  `cur` = table row of the read at the right end of s. */
 static int unidir(walk_t *w, uint64_t cur, str_t *s, cov_t *cov, int beg0, uint64_t k0, uint64_t *end, int *is_loop)
-{
-    const int r = unidir_core(w, cur, s, cov, beg0, k0, end, is_loop);
-    if (w->n_defer) defer_flush(w);
-    return r;
-}
-static int unidir_core(walk_t *w, uint64_t cur, str_t *s, cov_t *cov, int beg0, uint64_t k0, uint64_t *end, int *is_loop)
 {
     const fmdh_link_t *link = w->t->link;
     int beg = beg0, ori_l = (int)s->l, n_reads = 0;
@@ -517,7 +494,7 @@ static int unidir_core(walk_t *w, uint64_t cur, str_t *s, cov_t *cov, int beg0, 
                 if (mid != 0xffffffffu) {
                     const hop_t *m = &w->hop[mid];
                     __builtin_prefetch(&w->bend[m->kx0 >> 6]);
-                    if (!w->defer || w->sp) { __builtin_prefetch(&w->used[m->kx0 >> 6]); __builtin_prefetch(&w->used[m->kx1 >> 6]); }
+                    __builtin_prefetch(&w->used[m->kx0 >> 6]); __builtin_prefetch(&w->used[m->kx1 >> 6]);
                 }
                 ahead[step % JUMP_DIST] = h->far;
             }
@@ -534,10 +511,7 @@ static int unidir_core(walk_t *w, uint64_t cur, str_t *s, cov_t *cov, int beg0, 
                 if (kx[0] == k0) { *is_loop = 1; break; }
                 if (kx[1] == *end) { w->n_nei = 0; break; }
                 *end = kx[1];
-                if (w->defer && !w->sp && kx[2] == 1) {
-                    if (w->n_defer + 2 > DEFER_CAP) defer_flush(w);
-                    w->defer[w->n_defer++] = (uint32_t)kx[0]; w->defer[w->n_defer++] = (uint32_t)kx[1];
-                } else mark_used(w, kx);
+                mark_used(w, kx);
                 ++n_reads;
                 if (cov_add(cov, (size_t)rbeg, s->l)) return -1;
                 beg = rbeg; ori_l = (int)s->l;
@@ -1114,7 +1088,6 @@ int fmdh_unitig_walk_opt(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_mat
     if (t->link && long_walks && !getenv("FMD_WALK_NO_HOP")) {
         const double t0 = wall_s();
         w.hop = hop_build(&w);                         /* 0: every step through the general code */
-        if (w.hop && !sorted && !getenv("FMD_WALK_NO_DEFER")) w.defer = (uint32_t *)malloc(DEFER_CAP * sizeof(uint32_t));   /* (-r marks by sequence id through `sorted`: as it goes) */
         if (getenv("FMD_TIMING")) fprintf(stderr, "[M::%s] one line per plain step (hop[], %.1f GB): %.3f s\n", __func__, (double)t->n * sizeof(hop_t) / 1e9, wall_s() - t0);
     }
     const int seed_stages = !(getenv("FMD_WALK_SEED_STAGES") && atoi(getenv("FMD_WALK_SEED_STAGES")) == 0);
@@ -1139,7 +1112,7 @@ done:
     if (oq_open) { const int e = outq_close(&oq); if (!rc) rc = e; }
     if (getenv("FMD_TIMING")) fprintf(stderr, "[M::%s] walk of %llu sequences: %.3f s\n", __func__, (unsigned long long)n_seq, wall_s() - t_begin);
     free(w.used); free(w.bend); free(w.visited); if (w.row_of != t->row_of) fmdh_big_free(w.row_of);
-    fmdh_big_free(w.jump); fmdh_big_free((void *)w.hop); free(w.defer);
+    fmdh_big_free(w.jump); fmdh_big_free((void *)w.hop);
     if (b_ok) seedbuf_free(&b);
     return rc;
 }
