@@ -5,6 +5,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
+#include <thread>
+#include <vector>
+#include <unistd.h>
+#include <sys/types.h>
 #include "fmd_internal.h"
 
 // ---------------------------------------------------------------------------------- errors
@@ -498,23 +502,17 @@ done:
     return FMD_OK;
 }
 
-extern "C" int fmd_dev_open_rld(int device, const uint64_t *payload, uint64_t n_words, const uint64_t mcnt[7], fmd_dev_t **out)
+// The payload words of an RLD\2 file, already in device memory ((n_words / 8 + 1) * 64 bytes, zero behind the payload): the index.  Frees d_w.
+static int open_rld_words_dev(int device, uint64_t *d_w, uint64_t n_words, const uint64_t mcnt[7], fmd_dev_t **out)
 {
-    if (!payload || !out || !mcnt || n_words < 10) return FMD_E_ARG;
-    if (fmd_device_count() <= 0) return FMD_E_NODEV;
-    FMD_HIP_TRY(hipSetDevice(device));
     // blocks 0 .. last/8-1 carry payload; the block at word `last` is header-only (rld.h:64)
     const uint64_t n_rld = n_words / 8;
-    if (n_rld == 0) return FMD_E_FORMAT;
-    uint64_t *d_w = nullptr, *d_size = nullptr, *d_start = nullptr, *d_tot = nullptr;
+    uint64_t *d_size = nullptr, *d_start = nullptr, *d_tot = nullptr;
     int rc = FMD_OK;
     fmd_dev *h = nullptr;
-    FMD_HIP_TRY(hipMalloc((void **)&d_w, (n_rld + 1) * 64));
     if (hipMalloc((void **)&d_size, n_rld * 8) != hipSuccess || hipMalloc((void **)&d_start, n_rld * 8) != hipSuccess ||
         hipMalloc((void **)&d_tot, 16) != hipSuccess) { rc = FMD_E_NOMEM; goto done; }
     hipMemset(d_tot, 0, 16);
-    hipMemset(d_w, 0, (n_rld + 1) * 64);
-    hipMemcpy(d_w, payload, n_words * 8, hipMemcpyHostToDevice);
     k_rld_sizes<<<nblk(n_rld, 256), 256>>>(d_w, n_rld, d_size);
     rc = scan_u64(d_size, d_start, n_rld, 0);
     if (rc) goto done;
@@ -535,6 +533,51 @@ done:
     if (rc) { if (h) fmd_dev_close(h); return rc; }
     *out = h;
     return FMD_OK;
+}
+
+extern "C" int fmd_dev_open_rld(int device, const uint64_t *payload, uint64_t n_words, const uint64_t mcnt[7], fmd_dev_t **out)
+{
+    if (!payload || !out || !mcnt || n_words < 10) return FMD_E_ARG;
+    if (fmd_device_count() <= 0) return FMD_E_NODEV;
+    FMD_HIP_TRY(hipSetDevice(device));
+    const uint64_t n_rld = n_words / 8;
+    if (n_rld == 0) return FMD_E_FORMAT;
+    uint64_t *d_w = nullptr;
+    FMD_HIP_TRY(hipMalloc((void **)&d_w, (n_rld + 1) * 64));
+    hipMemset(d_w, 0, (n_rld + 1) * 64);
+    hipMemcpy(d_w, payload, n_words * 8, hipMemcpyHostToDevice);
+    return open_rld_words_dev(device, d_w, n_words, mcnt, out);
+}
+
+// The payload of a large .fmd goes from the file to the device in pieces, several threads each reading a piece into its own pinned buffer and sending it
+// on its own stream: one fread into fresh memory and one pageable copy of the whole (2.5 GB for 5*10^7 raw reads) were most of "index load + transcode".
+static int upload_payload(int device, int fd, off_t at, uint64_t bytes, uint8_t *d_dst)
+{
+    size_t CH = (size_t)32 << 20;
+    { const char *e = getenv("FMD_LOAD_CHUNK"); if (e && atoll(e) >= 64) CH = (size_t)atoll(e) / 64 * 64; }   // (tests: many pieces of a small file)
+    const int T = 4;
+    std::atomic<uint64_t> next{0};
+    std::atomic<int> failed{0};
+    const uint64_t n_ch = (bytes + CH - 1) / CH;
+    auto work = [&]() {
+        void *stage = nullptr; hipStream_t st = nullptr;
+        if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&stage, CH, hipHostMallocDefault) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { failed = FMD_E_HIP; if (stage) hipHostFree(stage); return; }
+        for (;;) {
+            const uint64_t c = next.fetch_add(1);
+            if (c >= n_ch || failed) break;
+            const uint64_t off = c * CH, len = bytes - off < CH ? bytes - off : CH;
+            uint64_t got = 0;
+            while (got < len) { const ssize_t k = pread(fd, (char *)stage + got, len - got, at + (off_t)(off + got)); if (k <= 0) { failed = FMD_E_IO; break; } got += (uint64_t)k; }
+            if (failed) break;
+            if (hipMemcpyAsync(d_dst + off, stage, len, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { failed = FMD_E_HIP; break; }
+        }
+        hipStreamDestroy(st); hipHostFree(stage);
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < T && (uint64_t)k < n_ch; ++k) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    return failed.load();
 }
 
 // .fmd file: header = "RLD\2", u32 asize<<16|sbits, u64 0, u64 n_bytes, u64 n_frames, u64 mcnt[1..6]
@@ -562,13 +605,20 @@ extern "C" int fmd_dev_open_file(int device, const char *fn, fmd_dev_t **out)
             fseek(fp, at, SEEK_SET);
             if (at < 0 || sz < at || hdr[1] > (uint64_t)(sz - at)) { fclose(fp); return FMD_E_FORMAT; }
         }
-        uint64_t *w = (uint64_t *)malloc(n_words * 8 + 64);
-        if (!w) { fclose(fp); return FMD_E_NOMEM; }
-        if (fread(w, 8, n_words, fp) != n_words) { free(w); fclose(fp); return FMD_E_IO; }
-        fclose(fp); // the rank frames that follow are not needed: the device layout has none
-        rc = fmd_dev_open_rld(device, w, n_words, mcnt, out);
-        free(w);
-        return rc;
+        if (n_words < 10 || n_words / 8 == 0) { fclose(fp); return FMD_E_FORMAT; }
+        if (fmd_device_count() <= 0) { fclose(fp); return FMD_E_NODEV; }
+        if (hipSetDevice(device) != hipSuccess) { fclose(fp); fmd_set_hip_error(hipGetLastError(), "hipSetDevice"); return FMD_E_HIP; }
+        {
+            const uint64_t n_rld = n_words / 8;
+            const off_t at = (off_t)ftell(fp);
+            uint64_t *d_w = nullptr;
+            if (hipMalloc((void **)&d_w, (n_rld + 1) * 64) != hipSuccess) { fclose(fp); (void)hipGetLastError(); return FMD_E_NOMEM; }
+            hipMemset((uint8_t *)d_w + n_words * 8, 0, (n_rld + 1) * 64 - n_words * 8);   // behind the payload
+            rc = upload_payload(device, fileno(fp), at, n_words * 8, (uint8_t *)d_w);
+            fclose(fp); // the rank frames that follow are not needed: the device layout has none
+            if (rc) { hipFree(d_w); return rc; }
+            return open_rld_words_dev(device, d_w, n_words, mcnt, out);
+        }
     } else {
         fseek(fp, 0, SEEK_END);
         const long sz = ftell(fp);

@@ -42,6 +42,24 @@ def test_three_loaders_give_one_index(gpu, gold, oracle_lib):
     o.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny", "special", "dup32"])
+def test_fmd_file_uploaded_in_pieces_by_several_threads(gpu, gold, monkeypatch, name):
+    """fmd_dev_open_file sends the payload of an RLD\\2 file to the device in pieces (32 MiB each, four threads with a pinned buffer and a stream each): with
+    pieces of 4 KiB, 192 bytes and 64 bytes a fixture is hundreds of them, and the index is the one the single piece gives -- every position's rank."""
+    ref = gpu.DevIndex.open(gold.path(name + ".fmd"))
+    ks = np.arange(int(ref.mcnt[0]), dtype=U64)
+    want, wsym = ref.rank1a(ks)
+    for chunk in (4096, 192, 64):
+        monkeypatch.setenv("FMD_LOAD_CHUNK", str(chunk))
+        d = gpu.DevIndex.open(gold.path(name + ".fmd"))
+        assert np.array_equal(d.cnt, ref.cnt) and np.array_equal(d.mcnt, ref.mcnt)
+        ok, sym = d.rank1a(ks)
+        assert np.array_equal(ok, want) and np.array_equal(sym, wsym)
+        d.close()
+    ref.close()
+
+
 def test_rank2a_golden(tiny_dev, gold):
     v = gold.npz("tiny_vectors.npz")
     ok, ol = tiny_dev.rank2a(v["rank2a_k"], v["rank2a_l"])
