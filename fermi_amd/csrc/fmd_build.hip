@@ -472,38 +472,37 @@ extern "C" int fmd_bwt_to_rle6(int device, const uint8_t *d_bwt, uint64_t n, uin
     if (!d_bwt || !h_rle6 || !n_bytes || n == 0) return FMD_E_ARG;
     if (fmd_device_count() <= 0) return FMD_E_NODEV;
     FMD_HIP_TRY(hipSetDevice(device));
-    // chunks of 2^30 symbols: a run cut at a chunk border just becomes two adjacent runs of the same
-    // symbol, which every reader of this stream merges (rld_enc, rld.c:177-184)
-    const uint64_t CH = 1ull << 30;
+    // chunks of 2^28 symbols: a run cut at a chunk border just becomes two adjacent runs of the same
+    // symbol, which every reader of this stream merges (rld_enc, rld.c:177-184).  The device buffers are sized for the worst chunk (every
+    // symbol its own run) ONCE: allocating and releasing 22 GB per 2^30 symbols was 1 s per chunk, the kernels are milliseconds.
+    const uint64_t CH = 1ull << 28;
+    const uint64_t mx = n < CH ? n : CH;
     struct HostBuf { uint8_t *p = nullptr; ~HostBuf() { free(p); } } hold;   // released to the caller on success only (FMD_HIP_TRY returns early)
     uint8_t *&h = hold.p; uint64_t h_n = 0, h_cap = 0;
+    DevPtr sym, len, nruns, tmp, nb, start, out, t2;
+    DALLOC(sym, mx); DALLOC(len, mx * 4); DALLOC(nruns, 8); DALLOC(nb, mx * 8); DALLOC(start, mx * 8); DALLOC(out, mx);
+    size_t tb = 0, b2 = 0;
+    FMD_HIP_TRY(fmd_run_length_encode(nullptr, tb, d_bwt, (unsigned)mx, (uint8_t *)sym.p, (uint32_t *)len.p, (uint64_t *)nruns.p));
+    FMD_HIP_TRY(fmd_exclusive_sum(nullptr, b2, (uint64_t *)nb.p, (uint64_t *)start.p, (size_t)mx));
+    DALLOC(tmp, tb); DALLOC(t2, b2);
     for (uint64_t o = 0; o < n; o += CH) {
         const uint64_t m = n - o < CH ? n - o : CH;
-        DevPtr sym, len, nruns, tmp, nb, start, out;
-        DALLOC(sym, m); DALLOC(len, m * 4); DALLOC(nruns, 8);
-        size_t tb = 0;
-        FMD_HIP_TRY(fmd_run_length_encode(nullptr, tb, d_bwt + o, (unsigned)m, (uint8_t *)sym.p, (uint32_t *)len.p, (uint64_t *)nruns.p));
-        DALLOC(tmp, tb);
-        FMD_HIP_TRY(fmd_run_length_encode(tmp.p, tb, d_bwt + o, (unsigned)m, (uint8_t *)sym.p, (uint32_t *)len.p, (uint64_t *)nruns.p));
+        size_t tb1 = tb, b21 = b2;
+        FMD_HIP_TRY(fmd_run_length_encode(tmp.p, tb1, d_bwt + o, (unsigned)m, (uint8_t *)sym.p, (uint32_t *)len.p, (uint64_t *)nruns.p));
         uint64_t n_runs = 0;
         FMD_HIP_TRY(hipMemcpy(&n_runs, nruns.p, 8, hipMemcpyDeviceToHost));
-        DALLOC(nb, n_runs * 8); DALLOC(start, n_runs * 8);
+        if (n_runs == 0 || n_runs > m) return FMD_E_HIP;
         k_run_bytes<<<nblk(n_runs, 256), 256>>>((uint32_t *)len.p, n_runs, (uint64_t *)nb.p);
-        {
-            DevPtr t2; size_t b2 = 0;
-            FMD_HIP_TRY(fmd_exclusive_sum(nullptr, b2, (uint64_t *)nb.p, (uint64_t *)start.p, (size_t)n_runs));
-            DALLOC(t2, b2);
-            FMD_HIP_TRY(fmd_exclusive_sum(t2.p, b2, (uint64_t *)nb.p, (uint64_t *)start.p, (size_t)n_runs));
-            FMD_HIP_TRY(hipDeviceSynchronize());
-        }
+        FMD_HIP_TRY(fmd_exclusive_sum(t2.p, b21, (uint64_t *)nb.p, (uint64_t *)start.p, (size_t)n_runs));
         uint64_t a = 0, b = 0;
         FMD_HIP_TRY(hipMemcpy(&a, (uint64_t *)start.p + n_runs - 1, 8, hipMemcpyDeviceToHost));
         FMD_HIP_TRY(hipMemcpy(&b, (uint64_t *)nb.p + n_runs - 1, 8, hipMemcpyDeviceToHost));
         const uint64_t total = a + b;
-        DALLOC(out, total);
+        if (total > m) return FMD_E_HIP;                 // cannot happen: a run of l symbols is ceil(l / 31) <= l bytes
         k_run_emit<<<nblk(n_runs, 256), 256>>>((uint8_t *)sym.p, (uint32_t *)len.p, n_runs, (uint64_t *)start.p, (uint8_t *)out.p);
-        if (h_n + total > h_cap) {
-            h_cap = (h_n + total) * (o + m < n ? 2 : 1) + 64;
+        if (h_n + total > h_cap) {   // the first chunk's ratio for the whole stream + a fifth, then doubling
+            const uint64_t est = o == 0 ? (uint64_t)((double)total * ((double)n / (double)m) * 1.2) + 64 : (h_n + total) * 2 + 64;
+            h_cap = est > h_n + total ? est : h_n + total + 64;
             uint8_t *nh = (uint8_t *)realloc(h, h_cap);
             if (!nh) return FMD_E_NOMEM;
             h = nh;

@@ -91,16 +91,46 @@ int fmdh_build(const char *fa_path, const char *out_path, int device, int max_le
     if (n == 0) { fprintf(stderr, "[E::%s] no sequences\n", __func__); free(bases); free(off); return 1; }
     uint64_t n_sym = 0;
     const double t1 = now_s();
-    uint8_t *bwt = (uint8_t *)malloc(2 * (tot + n) + 64);
-    rc = fmd_build_bwt(device, n, bases, off, bwt, &n_sym);
-    const double t2 = now_s();
-    if (rc) fprintf(stderr, "[E::%s] BWT construction failed: %s\n", __func__, fmd_strerror(rc));
-    else {
-        rc = fmdh_write_rld_from_bwt(bwt, n_sym, out_path);
-        if (rc) fprintf(stderr, "[E::%s] cannot write `%s'\n", __func__, out_path);
+    double t2;
+    if (!getenv("FMD_BUILD_HOST_BWT")) {
+        /* The BWT stays on the device and leaves it as runs (`len << 3 | sym` bytes, fmd_bwt_to_rle6): a byte per symbol across PCIe and through the
+         * encoder's run finder was 10 GB each way for 5*10^7 reads; the runs are 0.8-2 GB, and the container written from them is the same file
+         * (neighbouring runs of one symbol are merged by every reader of that stream, rld_writer.c). */
+        void *d_reads = 0, *d_off = 0;
+        uint8_t *d_bwt = 0, *rle6 = 0;
+        uint64_t n_rle6 = 0;
+        uint32_t mx = 0; int uniform = 1;
+        size_t i;
+        for (i = 0; i < n; ++i) { const uint64_t ll = off[i + 1] - off[i]; if (ll > mx) mx = (uint32_t)ll; if (ll != off[1] - off[0]) uniform = 0; }
+        rc = fmd_dev_malloc(device, tot + 64, &d_reads);
+        if (!rc) rc = fmd_dev_malloc(device, (n + 1) * 8, &d_off);
+        if (!rc) rc = fmd_memcpy_h2d(d_reads, bases, tot, 0);
+        if (!rc) rc = fmd_memcpy_h2d(d_off, off, (n + 1) * 8, 0);
+        if (!rc) rc = fmd_build_bwt_dev(device, 0, n, (const uint8_t *)d_reads, (const uint64_t *)d_off, tot, mx, uniform, &d_bwt, &n_sym);
+        fmd_dev_free(d_reads); fmd_dev_free(d_off);
+        free(bases); bases = 0;                                    /* (5 GB the encoder does not need) */
+        if (!rc) rc = fmd_bwt_to_rle6(device, d_bwt, n_sym, &rle6, &n_rle6);
+        fmd_dev_free(d_bwt);
+        t2 = now_s();
+        if (rc) fprintf(stderr, "[E::%s] BWT construction failed: %s\n", __func__, fmd_strerror(rc));
+        else {
+            rc = fmdh_write_rld_from_rle6(rle6, n_rle6, out_path);
+            if (rc) fprintf(stderr, "[E::%s] cannot write `%s'\n", __func__, out_path);
+        }
+        fmd_host_free(rle6);
+    } else {   /* A/B: the byte BWT on the host (round 3) */
+        uint8_t *bwt = (uint8_t *)malloc(2 * (tot + n) + 64);
+        rc = bwt ? fmd_build_bwt(device, n, bases, off, bwt, &n_sym) : FMD_E_NOMEM;
+        t2 = now_s();
+        if (rc) fprintf(stderr, "[E::%s] BWT construction failed: %s\n", __func__, fmd_strerror(rc));
+        else {
+            rc = fmdh_write_rld_from_bwt(bwt, n_sym, out_path);
+            if (rc) fprintf(stderr, "[E::%s] cannot write `%s'\n", __func__, out_path);
+        }
+        free(bwt);
     }
     if (timing) fprintf(stderr, "[M::%s] %zu sequences, %llu symbols: read + encode %.3f s, BWT on the GPU (incl. copies) %.3f s, .fmd %.3f s\n", __func__, n,
                         (unsigned long long)n_sym, t1 - t0, t2 - t1, now_s() - t2);
-    free(bwt); free(bases); free(off);
+    free(bases); free(off);
     return rc ? 1 : 0;
 }

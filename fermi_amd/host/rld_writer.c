@@ -59,7 +59,7 @@ static int rec_push(writer_t *s, uint64_t pos0, uint64_t in0, unsigned hw)
     return 0;
 }
 
-static unsigned bit_length(uint64_t v) { unsigned n = 0; while (v) { ++n; v >>= 1; } return n; }
+static inline unsigned bit_length(uint64_t v) { return v ? 64u - (unsigned)__builtin_clzll(v) : 0u; }
 
 static int grow(writer_t *s, uint64_t need)
 {
@@ -218,6 +218,8 @@ static int run_next(runit_t *it, uint64_t *len, int *sym, uint64_t *in)
     return 1;
 }
 
+#include <time.h>
+static double rw_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static int encode_sequential(const uint8_t *src, int is_bwt, uint64_t n, const char *path)
 {
     writer_t s;
@@ -310,9 +312,11 @@ static int encode_parallel(const uint8_t *src, int is_bwt, uint64_t n, const cha
         cut = b;
     }
     sl[T - 1].end = n;
+    const double t_beg = rw_now();
     for (t = 1; t < T; ++t) started[t] = pthread_create(&tid[t], 0, slice_main, &sl[t]) == 0;
     slice_main(&sl[0]);
     for (t = 1; t < T; ++t) { if (started[t]) pthread_join(tid[t], 0); else slice_main(&sl[t]); }
+    const double t_sl = rw_now();
     for (t = 0; t < T && rc == 0; ++t) rc = sl[t].rc;
     if (rc == 0) rc = writer_init(&W);
     {   /* room for everything the slices wrote, so that the stitch does not realloc its way up */
@@ -347,7 +351,9 @@ static int encode_parallel(const uint8_t *src, int is_bwt, uint64_t n, const cha
         }
         free(sl[t].w.w); sl[t].w.w = 0; free(sl[t].w.rec); sl[t].w.rec = 0;
     }
+    const double t_st = rw_now();
     if (rc == 0) rc = finish_and_dump(&W, path);
+    if (getenv("FMD_TIMING")) fprintf(stderr, "[M::%s] %d slices encoded in %.3f s, stitched in %.3f s, frames + file %.3f s\n", __func__, T, t_sl - t_beg, t_st - t_sl, rw_now() - t_st);
     for (t = 0; t < T; ++t) { free(sl[t].w.w); free(sl[t].w.rec); }
     free(W.w); free(sl); free(tid); free(started);
     return rc;
