@@ -92,10 +92,11 @@ int fmdh_build(const char *fa_path, const char *out_path, int device, int max_le
     uint64_t n_sym = 0;
     const double t1 = now_s();
     double t2;
-    if (!getenv("FMD_BUILD_HOST_BWT")) {
-        /* The BWT stays on the device and leaves it as runs (`len << 3 | sym` bytes, fmd_bwt_to_rle6): a byte per symbol across PCIe and through the
-         * encoder's run finder was 10 GB each way for 5*10^7 reads; the runs are 0.8-2 GB, and the container written from them is the same file
-         * (neighbouring runs of one symbol are merged by every reader of that stream, rld_writer.c). */
+    if (getenv("FMD_BUILD_RUNS")) {
+        /* Opt-in (FMD_BUILD_RUNS=1): the BWT stays on the device and leaves it as runs (`len << 3 | sym` bytes, fmd_bwt_to_rle6) instead of a byte per
+         * symbol; the container written from them is the same file (neighbouring runs of one symbol are merged by every reader of that stream,
+         * rld_writer.c).  Measured (tools/ab_build.py, profiles/r4_e2e): 10^7 reads 3.5 s against 4.2 s, but at 5*10^7 the forty chunks of run-length
+         * encoding cost the BWT phase 1.6-5.8 s for 0.9-2.6 s saved in the writer -- not the default. */
         void *d_reads = 0, *d_off = 0;
         uint8_t *d_bwt = 0, *rle6 = 0;
         uint64_t n_rle6 = 0;
@@ -118,7 +119,7 @@ int fmdh_build(const char *fa_path, const char *out_path, int device, int max_le
             if (rc) fprintf(stderr, "[E::%s] cannot write `%s'\n", __func__, out_path);
         }
         fmd_host_free(rle6);
-    } else {   /* A/B: the byte BWT on the host (round 3) */
+    } else {   /* the byte BWT on the host */
         uint8_t *bwt = (uint8_t *)malloc(2 * (tot + n) + 64);
         rc = bwt ? fmd_build_bwt(device, n, bases, off, bwt, &n_sym) : FMD_E_NOMEM;
         t2 = now_s();

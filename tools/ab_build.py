@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""`fermi-amd build` on N 100-bp reads (error-free, then 1 % substitutions): as shipped (the BWT leaves the device as runs) against FMD_BUILD_HOST_BWT=1 (a byte
-per symbol to the host, round 3); phase times and the md5 of the .fmd each way.  Usage: python tools/ab_build.py [n_reads=10000000]"""
+"""`fermi-amd build` on N 100-bp reads (error-free, then 1 % substitutions): as shipped (a byte per symbol to the host) against FMD_BUILD_RUNS=1 (the BWT leaves
+the device as runs); phase times and the md5 of the .fmd each way.  Usage: python tools/ab_build.py [n_reads=10000000]"""
 import hashlib, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,7 +19,7 @@ for err in (0.0, 0.01):
             fp.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (s + i, r[i].tobytes(), b"I" * 100) for i in range(c)))
     print("==== %d reads, e = %g" % (n, err), flush=True)
     for rep in range(2):
-        for name, extra in (("as shipped", {}), ("FMD_BUILD_HOST_BWT=1", {"FMD_BUILD_HOST_BWT": "1"})):
+        for name, extra in (("as shipped", {}), ("FMD_BUILD_RUNS=1", {"FMD_BUILD_RUNS": "1"})):
             t = time.time()
             p = subprocess.run([AMD, "build", "-fo", D + "/a.fmd", D + "/r.fq"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(env, **extra))
             dt = time.time() - t
