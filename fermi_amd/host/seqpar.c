@@ -42,12 +42,16 @@ static int part_room(fmdh_ppart_t *p, size_t more)
 }
 
 /* parse [beg, stop_at): records that START before stop_at (the last one runs to its end); *end = where the reader stands afterwards */
-static void parse_range(const fmdh_pseq_t *r, size_t beg, size_t stop_at, fmdh_ppart_t *p, size_t *end, int *clean)
+static void parse_range(const fmdh_pseq_t *r, size_t beg, size_t stop_at, fmdh_ppart_t *dst, size_t *end, int *clean_out)
 {
+    /* the piece's counters change with every record and the pieces of a span sit side by side in one array (72 bytes each): the thread works on a
+     * copy of its own and stores it back once -- and likewise `clean`, whose neighbours belong to the other threads */
+    fmdh_ppart_t loc = *dst, *p = &loc;
+    int clean_v = 0, *clean = &clean_v;
     fmdh_seqio_t *io = fmdh_seq_open_mem(r->map + beg, r->size - beg);
     p->n = p->bytes = 0; p->has_qual = 0; p->bad = 0;
     *clean = 0; *end = beg;
-    if (!io) { p->bad = 1; return; }
+    if (!io) { p->bad = 1; *dst = loc; *clean_out = 0; return; }
     for (;;) {
         int len;
         if (fmdh_seq_between_records(io) && beg + fmdh_seq_mem_pos(io) >= stop_at) { *clean = 1; break; }
@@ -64,6 +68,7 @@ static void parse_range(const fmdh_pseq_t *r, size_t beg, size_t stop_at, fmdh_p
     }
     *end = beg + fmdh_seq_mem_pos(io);
     fmdh_seq_close(io);
+    *dst = loc; *clean_out = clean_v;
 }
 
 /* first guessed record start at or after x: a line starting with '@' whose line after next starts with '+' */
