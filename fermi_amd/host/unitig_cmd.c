@@ -33,6 +33,8 @@ int fmdh_unitig(const char *fmd_path, int n_dev, const int *devices, int min_mat
     if (timing) fprintf(stderr, "[M::%s] walk + output: %.3f s\n", __func__, now_s() - t0);
 done:
     free(sorted);
+    t0 = now_s();
     fmdh_ovlp_table_free(&t);
+    if (timing) fprintf(stderr, "[M::%s] table released: %.3f s\n", __func__, now_s() - t0);
     return rc;
 }

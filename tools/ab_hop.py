@@ -37,4 +37,4 @@ for err in ERRS:
                 for blk in iter(lambda: f.read(1 << 24), b""):
                     h.update(blk)
             print("-- %s: %.2f s, rc %d, MAG %d bytes md5 %s" % (name, dt, p.returncode, os.path.getsize(D + "/a.mag"), h.hexdigest()), flush=True)
-            print("\n".join("   " + l[:260] for l in p.stderr.decode().splitlines() if "M::" in l and ("table" in l or "walk" in l or "link" in l or "hop" in l or "rows again" in l or "packed_batch" in l)), flush=True)
+            print("\n".join("   " + l[:260] for l in p.stderr.decode().splitlines() if "M::" in l and ("table" in l or "walk" in l or "link" in l or "hop" in l or "rows again" in l or "packed_batch" in l or "main]" in l or "released" in l)), flush=True)
