@@ -407,10 +407,11 @@ static void mark_used(walk_t *w, const uint64_t x[3]) /* set_bits, unitig.c:22-3
     else for (k = 0; k < x[2]; ++k) { st_set(w, ST_USED, x[0] + k); st_set(w, ST_USED, x[1] + k); }
 }
 
-/* Coverage string (unitig.c:251-255: '"' = one read, one more per read that covers the base, capped at '~').  Every
- * accepted extension adds one read over [rbeg, new end): kept as a difference array over a base string and
- * materialised when the string is needed -- min('~', base + reads) is the same whenever the cap is applied. */
-typedef struct { char *s; int32_t *d; size_t l, m; int dirty; } cov_t;   /* dirty: reads added since the last flush */
+/* Coverage string (unitig.c:251-255: '"' = one read, one more per read that covers the base, capped at '~').  Every accepted extension adds one read
+ * over [rbeg, new end): a saturating byte increment over ~100 bytes, which the compiler turns into a handful of vector operations -- min('~', base + reads)
+ * is the same whenever the cap is applied.  (Rounds 2-4 kept a difference array and materialised it when the string was needed: a scalar prefix sum over the
+ * whole string, twice per seed, which on reads with errors -- 4*10^7 unitigs of one to three reads -- was a sixth of a walker's time.) */
+typedef struct { char *s; size_t l, m; } cov_t;
 static int cov_reserve(cov_t *c, size_t need)
 {
     if (need <= c->m) return 0;
@@ -419,35 +420,24 @@ static int cov_reserve(cov_t *c, size_t need)
     char *p = (char *)realloc(c->s, m);
     if (!p) return -ENOMEM;
     c->s = p;
-    int32_t *q = (int32_t *)realloc(c->d, m * sizeof(int32_t));
-    if (!q) return -ENOMEM;
-    c->d = q;
     memset(c->s + c->m, '!', m - c->m);                   /* '!' = no read yet */
-    memset(c->d + c->m, 0, (m - c->m) * sizeof(int32_t));
     c->m = m;
     return 0;
 }
 static inline int cov_add(cov_t *c, size_t from, size_t to) /* one more read over [from, to) */
 {
+    size_t i;
+    unsigned char *q;
     if (cov_reserve(c, to + 2)) return -ENOMEM;
-    ++c->d[from]; --c->d[to];
+    q = (unsigned char *)c->s;
+    for (i = from; i < to; ++i) { const unsigned char v = (unsigned char)(q[i] + 1); q[i] = v > '~' ? '~' : v; }
     if (to > c->l) c->l = to;
-    c->dirty = 1;
     return 0;
 }
-static void cov_flush(cov_t *c, size_t l) /* materialise [0, l); everything beyond is dropped */
+static void cov_flush(cov_t *c, size_t l) /* keep [0, l); everything beyond is dropped */
 {
-    size_t i, end;
-    int32_t run = 0;
-    if (!c->dirty && l == c->l) return;                   /* nothing was added since this very flush */
-    if (c->dirty)
-        for (i = 0; i < l; ++i) {
-            run += c->d[i]; c->d[i] = 0;
-            { const int v = c->s[i] + run; c->s[i] = (char)(v > '~' ? '~' : v); }
-        }
-    end = c->l + 1 < c->m ? c->l + 1 : c->m;               /* [l, end): dropped */
-    if (end > l) { memset(c->d + l, 0, (end - l) * sizeof(int32_t)); memset(c->s + l, '!', end - l); }
-    c->l = l; c->dirty = 0;
+    if (c->l > l) memset(c->s + l, '!', c->l - l);
+    c->l = l;
 }
 
 static inline const fmd_ovlp_rec_t *REC(const walk_t *w, uint64_t row)
@@ -675,7 +665,7 @@ static int seedbuf_init(seedbuf_t *b, uint32_t cap_nei)
     b->nei[0] = (link_t *)malloc(cap_nei * sizeof(link_t)); b->nei[1] = (link_t *)malloc((cap_nei + 1) * sizeof(link_t));
     return b->nei[0] && b->nei[1] ? 0 : -ENOMEM;
 }
-static void seedbuf_free(seedbuf_t *b) { free(b->nei[0]); free(b->nei[1]); free(b->s.s); free(b->o.s); free(b->cov.s); free(b->cov.d); }
+static void seedbuf_free(seedbuf_t *b) { free(b->nei[0]); free(b->nei[1]); free(b->s.s); free(b->o.s); free(b->cov.s); }
 
 static int walk_seed(walk_t *w, uint64_t i, seedbuf_t *b, size_t *wl)
 {
@@ -1110,6 +1100,8 @@ int fmdh_unitig_walk_opt(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_mat
     }
 done:
     if (oq_open) { const int e = outq_close(&oq); if (!rc) rc = e; }
+    if (getenv("FMD_TIMING") && w.n_hops + (uint64_t)(w.t_uni > 0)) fprintf(stderr, "[M::%s] walks of the sequential loop: %llu reads appended in %.3f s, turning the strings round %.3f s, record text %.3f s\n", __func__,
+                                                                              (unsigned long long)w.n_hops, w.t_uni, w.t_turn, w.t_text);
     if (getenv("FMD_TIMING")) fprintf(stderr, "[M::%s] walk of %llu sequences: %.3f s\n", __func__, (unsigned long long)n_seq, wall_s() - t_begin);
     free(w.used); free(w.bend); free(w.visited); if (w.row_of != t->row_of) fmdh_big_free(w.row_of);
     fmdh_big_free(w.jump); fmdh_big_free((void *)w.hop);
