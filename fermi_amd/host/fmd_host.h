@@ -60,6 +60,7 @@ static inline fmdh_row_t fmdh_table_row(const fmdh_ovlp_table_t *t, uint64_t id)
     uint64_t r;
     fmdh_row_t x;
     if (t->side_of && t->side_of[id] != 0xffffffffu) { s = &t->side; r = t->side_of[id]; }
+    else if (t->n_shards == 1) { s = &t->shard[0]; r = id; }
     else { s = &t->shard[id % (uint64_t)t->n_shards]; r = id / (uint64_t)t->n_shards; }
     x.rec = &s->rec[r];
     x.var = s->chunk[r >> s->chunk_shift] + s->off[r];

@@ -127,12 +127,20 @@ static uint32_t *build_jump(const fmdh_link_t *link, uint64_t n)
     fmdh_big_free(b);
     return a;
 }
+/* the record of a row for a prefetch (side-table rows go to the old place: a wasted hint).  One shard -- one GPU computed the table -- is the usual case and
+ * needs no division: two of them per hint, thirty hints per seed, were a third of the seed loop's time on reads with errors. */
+static inline const fmd_ovlp_rec_t *rec_addr(const fmdh_ovlp_table_t *t, uint32_t row)
+{
+    if (t->n_shards == 1) return &t->shard[0].rec[row];
+    return &t->shard[row % (uint32_t)t->n_shards].rec[row / (uint32_t)t->n_shards];
+}
 /* (a row that the overflow pass replaced lives in the side table: its prefetch goes to the old place and is wasted) */
 static inline void prefetch_row_head(const walk_t *w, uint32_t row) /* what a visit reads first */
 {
     const fmdh_ovlp_table_t *t = w->t;
-    const fmdh_ovlp_shard_t *s = &t->shard[row % (uint32_t)t->n_shards];
-    const uint32_t r = row / (uint32_t)t->n_shards;
+    const int one = t->n_shards == 1;
+    const fmdh_ovlp_shard_t *s = one ? &t->shard[0] : &t->shard[row % (uint32_t)t->n_shards];
+    const uint32_t r = one ? row : row / (uint32_t)t->n_shards;
     __builtin_prefetch(&s->rec[r]);
     __builtin_prefetch(&s->off[r]);
     if (t->link) __builtin_prefetch(&t->link[row]);
@@ -144,8 +152,9 @@ static inline void prefetch_row_head(const walk_t *w, uint32_t row) /* what a vi
 static inline void prefetch_row_var(const walk_t *w, uint32_t row)  /* once its offset is there */
 {
     const fmdh_ovlp_table_t *t = w->t;
-    const fmdh_ovlp_shard_t *s = &t->shard[row % (uint32_t)t->n_shards];
-    const uint64_t r = row / (uint32_t)t->n_shards;   /* (64 bits: a table in one chunk has a chunk_shift beyond 32) */
+    const int one = t->n_shards == 1;
+    const fmdh_ovlp_shard_t *s = one ? &t->shard[0] : &t->shard[row % (uint32_t)t->n_shards];
+    const uint64_t r = one ? row : row / (uint32_t)t->n_shards;   /* (64 bits: a table in one chunk has a chunk_shift beyond 32) */
     __builtin_prefetch(s->chunk[r >> s->chunk_shift] + s->off[r]);
     __builtin_prefetch(s->chunk[r >> s->chunk_shift] + s->off[r] + 64);
 }
@@ -248,14 +257,14 @@ static inline void seed_hints(const walk_t *w, uint64_t i, int staged)
     const fmdh_ovlp_table_t *t = w->t;
     int d;
     if (!staged) {   /* (FMD_WALK_SEED_STAGES=0: the first hop's record only, as before) */
-        if (i + SEED_AHEAD < t->n) for (d = 0; d < 2; ++d) { const uint32_t a = t->link[i + SEED_AHEAD - (uint64_t)d].nxt; if (a != 0xffffffffu) __builtin_prefetch(&t->shard[a % (uint32_t)t->n_shards].rec[a / (uint32_t)t->n_shards]); }
+        if (i + SEED_AHEAD < t->n) for (d = 0; d < 2; ++d) { const uint32_t a = t->link[i + SEED_AHEAD - (uint64_t)d].nxt; if (a != 0xffffffffu) __builtin_prefetch(rec_addr(t, a)); }
         return;
     }
     if (i + 3 * SEED_AHEAD < t->n && !seed_is_used(w, i + 3 * SEED_AHEAD))
         for (d = 0; d < 2; ++d) {
             const fmdh_link_t *l = &t->link[i + 3 * SEED_AHEAD - (uint64_t)d];
             seed_hint_head(w, l->nxt);
-            if (l->rev != 0xffffffffu) __builtin_prefetch(&t->shard[l->rev % (uint32_t)t->n_shards].rec[l->rev / (uint32_t)t->n_shards]);
+            if (l->rev != 0xffffffffu) __builtin_prefetch(rec_addr(t, l->rev));
         }
     if (i + 2 * SEED_AHEAD < t->n && !seed_is_used(w, i + 2 * SEED_AHEAD))
         for (d = 0; d < 2; ++d) {
@@ -263,7 +272,7 @@ static inline void seed_hints(const walk_t *w, uint64_t i, int staged)
             if (a == 0xffffffffu) continue;
             prefetch_row_var(w, a);
             seed_hint_head(w, t->link[a].nxt);
-            if (t->link[a].rev != 0xffffffffu) __builtin_prefetch(&t->shard[t->link[a].rev % (uint32_t)t->n_shards].rec[t->link[a].rev / (uint32_t)t->n_shards]);
+            if (t->link[a].rev != 0xffffffffu) __builtin_prefetch(rec_addr(t, t->link[a].rev));
         }
     if (i + SEED_AHEAD < t->n && !seed_is_used(w, i + SEED_AHEAD))
         for (d = 0; d < 2; ++d) {
