@@ -417,10 +417,14 @@ static void mark_used(walk_t *w, const uint64_t x[3]) /* set_bits, unitig.c:22-3
 }
 
 /* Coverage string (unitig.c:251-255: '"' = one read, one more per read that covers the base, capped at '~').  Every accepted extension adds one read
- * over [rbeg, new end): a saturating byte increment over ~100 bytes, which the compiler turns into a handful of vector operations -- min('~', base + reads)
- * is the same whenever the cap is applied.  (Rounds 2-4 kept a difference array and materialised it when the string was needed: a scalar prefix sum over the
- * whole string, twice per seed, which on reads with errors -- 4*10^7 unitigs of one to three reads -- was a sixth of a walker's time.) */
-typedef struct { char *s; size_t l, m; } cov_t;
+ * over [rbeg, new end) -- min('~', base + reads) is the same whenever the cap is applied, so there are two ways to add it and each walk gets the one
+ * that suits it.  The first COV_DIRECT reads of a walk are added at once: a saturating byte increment over ~100 bytes, a handful of vector operations
+ * (reads with errors: 4*10^7 unitigs of one to three reads; a difference array materialised by a scalar prefix sum over the whole string, twice per seed,
+ * was a sixth of a walker's time there).  A walk that goes on is a long one: from then on the reads go into a difference array (two integer updates per
+ * read instead of a hundred bytes: the genome-long walks of error-free reads measured 43 ns per read this way and 68 ns the other), materialised over the
+ * stretch they touched when the string is needed. */
+#define COV_DIRECT 8
+typedef struct { char *s; int32_t *d; size_t l, m, d_m, lo, hi; int n_add; } cov_t;   /* d: pending reads over [lo, hi) as differences (hi = 0: none) */
 static int cov_reserve(cov_t *c, size_t need)
 {
     if (need <= c->m) return 0;
@@ -435,18 +439,40 @@ static int cov_reserve(cov_t *c, size_t need)
 }
 static inline int cov_add(cov_t *c, size_t from, size_t to) /* one more read over [from, to) */
 {
-    size_t i;
-    unsigned char *q;
     if (cov_reserve(c, to + 2)) return -ENOMEM;
-    q = (unsigned char *)c->s;
-    for (i = from; i < to; ++i) { const unsigned char v = (unsigned char)(q[i] + 1); q[i] = v > '~' ? '~' : v; }
+    if (c->n_add < COV_DIRECT) {
+        unsigned char *q = (unsigned char *)c->s;
+        size_t i;
+        for (i = from; i < to; ++i) { const unsigned char v = (unsigned char)(q[i] + 1); q[i] = v > '~' ? '~' : v; }
+        ++c->n_add;
+    } else {
+        if (c->d_m < c->m) {
+            int32_t *q = (int32_t *)realloc(c->d, c->m * sizeof(int32_t));
+            if (!q) return -ENOMEM;
+            memset(q + c->d_m, 0, (c->m - c->d_m) * sizeof(int32_t));
+            c->d = q; c->d_m = c->m;
+        }
+        ++c->d[from]; --c->d[to];
+        if (c->hi == 0 || from < c->lo) c->lo = from;
+        if (to > c->hi) c->hi = to;
+    }
     if (to > c->l) c->l = to;
     return 0;
 }
-static void cov_flush(cov_t *c, size_t l) /* keep [0, l); everything beyond is dropped */
+static void cov_flush(cov_t *c, size_t l) /* materialise what is pending, keep [0, l); everything beyond is dropped */
 {
+    if (c->hi) {
+        size_t i;
+        int32_t run = 0;
+        for (i = c->lo; i < c->hi; ++i) {
+            run += c->d[i]; c->d[i] = 0;
+            { const int v = (unsigned char)c->s[i] + run; c->s[i] = (char)(v > '~' ? '~' : v); }
+        }
+        c->d[c->hi] = 0;                                    /* (the last read's closing -1) */
+        c->hi = c->lo = 0;
+    }
     if (c->l > l) memset(c->s + l, '!', c->l - l);
-    c->l = l;
+    c->l = l; c->n_add = 0;
 }
 
 static inline const fmd_ovlp_rec_t *REC(const walk_t *w, uint64_t row)
@@ -674,7 +700,7 @@ static int seedbuf_init(seedbuf_t *b, uint32_t cap_nei)
     b->nei[0] = (link_t *)malloc(cap_nei * sizeof(link_t)); b->nei[1] = (link_t *)malloc((cap_nei + 1) * sizeof(link_t));
     return b->nei[0] && b->nei[1] ? 0 : -ENOMEM;
 }
-static void seedbuf_free(seedbuf_t *b) { free(b->nei[0]); free(b->nei[1]); free(b->s.s); free(b->o.s); free(b->cov.s); }
+static void seedbuf_free(seedbuf_t *b) { free(b->nei[0]); free(b->nei[1]); free(b->s.s); free(b->o.s); free(b->cov.s); free(b->cov.d); }
 
 static int walk_seed(walk_t *w, uint64_t i, seedbuf_t *b, size_t *wl)
 {
