@@ -87,6 +87,60 @@ __global__ __launch_bounds__(CLS_THREADS) void k_ovl_classify(size_t n, const fm
     }
 }
 
+// ------------------------------------------------------------------------------ dealing the work list
+// The strands of a work list used to be dealt to the groups round-robin (group q: positions q, q + n_groups, ...): a group's share is then fixed at
+// the launch, the rounds a strand takes are not (1 .. 50 on reads with errors), and the kernel ends when the group with the longest share does --
+// 11 % of all group rounds of k_ovl_nei_grp and 10-17 % of k_ovl_nei_fast's were groups with nothing left (GRP_STATS, 10^7 reads with 1 % errors).
+// DYN: a wave reserves CHUNKS of consecutive positions from one counter (one atomic per chunk: atomics on one address serialise at ~14 ns; guided
+// sizes 16 .. FMD_DEAL_CHUNK, the first chunk of every wave without an atomic), a group asks when its prefetch slot is empty.  Consecutive positions still go to groups that run
+// at the same time, which is what the order of the list is for.  The counter is word 16 of the list counter's own 128-byte line (zeroed
+// with the header of the batch).  Returns the position for every lane of a group that asked (`want`: group-uniform), 0xffffffff otherwise and once
+// the list is dealt out (`dry`).
+#ifndef FMD_DEAL_CHUNK
+#define FMD_DEAL_CHUNK 64
+#endif
+#define FMD_DEAL_WORD 16
+static int nei_dyn(void)   // FMD_NEI_DYN=0: A/B switch, the work lists dealt round-robin as before
+{
+    const char *e = getenv("FMD_NEI_DYN");
+    return !(e && atoi(e) == 0);
+}
+struct FmdDeal { uint32_t cur, end; };   // wave-uniform: positions [cur, end) of the list are this wave's
+// a wave's FIRST chunk costs no atomic: wave w owns [w * c0, w * c0 + c0), the counter starts behind the last wave's.  c0 is one strand per group
+// for a list shorter than the grid (every strand starts at once, as in the round-robin deal; a wave without a strand leaves at once)
+template <int G>
+__device__ __forceinline__ uint32_t fmd_deal_first(uint32_t N)
+{
+    const uint32_t g = N / (2u * gridDim.x);
+    return g < (uint32_t)(64 / G) ? (uint32_t)(64 / G) : (g > (uint32_t)FMD_DEAL_CHUNK ? (uint32_t)FMD_DEAL_CHUNK : g);
+}
+template <int G>
+__device__ __forceinline__ void fmd_deal_init(FmdDeal &q, uint32_t N, bool &dry)
+{
+    const uint32_t c0 = fmd_deal_first<G>(N);
+    q.cur = blockIdx.x * c0; q.end = q.cur + c0;
+    dry = q.cur >= N;
+}
+template <int G>
+__device__ __forceinline__ uint32_t fmd_deal_next(FmdDeal &q, uint32_t *deal, uint32_t N, bool want, bool &dry)
+{
+    const int lane = fmd_lane(), gbase = lane / G * G;
+    const uint64_t m = __ballot(want && !dry && lane == gbase);
+    if (m == 0) return 0xffffffffu;
+    const uint32_t need = (uint32_t)__popcll(m), r = (uint32_t)__popcll(m & ((1ull << gbase) - 1)), avail = q.end - q.cur;   // r: this group's place among those that ask
+    uint32_t pos;
+    if (avail < need) {   // the rest of this chunk, then a new one: 1 / (2 * waves) of what is left of the list, between 16 (>= the groups of a wave) and FMD_DEAL_CHUNK
+        const uint32_t rem = N > q.end ? N - q.end : 0u, gsz = rem / (2u * gridDim.x), sz = gsz < 16u ? 16u : (gsz > (uint32_t)FMD_DEAL_CHUNK ? (uint32_t)FMD_DEAL_CHUNK : gsz);
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(deal, sz);
+        v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v) + gridDim.x * fmd_deal_first<G>(N);
+        pos = r < avail ? q.cur + r : v + (r - avail);
+        q.cur = v + (need - avail); q.end = v + sz;
+    } else { pos = q.cur + r; q.cur += need; }
+    if (q.cur >= N) dry = true;          // positions only grow: nothing is left for this wave (a position >= N is no strand: the caller tests)
+    return want ? pos : 0xffffffffu;
+}
+
 // ------------------------------------------------------------------------------ the kernel
 // A lane's candidate is (x[1], size, D, r0, pos): D = the positions of '$' in BWT[x[0], x[0] + size) (the reads that START with the
 // candidate string: the sentinel tests of unitig.c:112 / :129), r0 = the number of '$' before x[0] (x[0] of a neighbour interval,
@@ -96,13 +150,13 @@ __global__ __launch_bounds__(CLS_THREADS) void k_ovl_classify(size_t n, const fm
 // round here.  x[0] itself is never needed.  (Round 2 fetched the x[0] block of every lane every round: a second dense slot, a second
 // window, a second spill list.)  It is also the state k_ovl_nei_fast holds when a strand stops being simple, so that kernel hands
 // its strands on where they stand (FMD_LIST_RESUME) instead of at round 0.
-template <int G>
+template <int G, bool DYN>
 __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
                                                     uint32_t cap, const fmd_intv_t *__restrict__ listA, fmd_intv_t *listB, FmdOvlClasses cl,
                                                     fmd_ovlp_rec_t *__restrict__ rec,
                                                     fmd_intv_t *__restrict__ nei_out, uint32_t max_nei, uint8_t *__restrict__ seq_out,
                                                     uint32_t seq_stride, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_n,
-                                                    const uint32_t *__restrict__ gidx, size_t fix_off)
+                                                    const uint32_t *__restrict__ gidx, size_t fix_off, uint32_t *__restrict__ deal)
 {
     __shared__ uint4 lds[GRP_LDS_U4];
     uint4 *pool = lds + GRP_SLOTS_U4, *stage = pool;
@@ -112,7 +166,13 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
     const int lane = fmd_lane(), g = lane / G, j = lane % G, gbase = g * G;
     const uint32_t N = *list_n;
     const uint32_t n_groups = gridDim.x * S;
-    uint32_t idx = g < S ? blockIdx.x * S + g : 0xffffffffu; // position of this group's next strand in the list (lanes past S * G idle)
+    uint32_t idx = !DYN && g < S ? blockIdx.x * S + g : 0xffffffffu; // position of this group's next strand in the list (lanes past S * G idle)
+    // DYN: the positions are dealt out instead (fmd_deal_next below) -- dealt round-robin, a group's share of the list is fixed at the launch and
+    // the kernel ends when the group with the longest share does (rounds per strand: 1 .. 50), with 11 % of all group rounds idle on reads with errors
+    FmdDeal tk;
+    bool dry = !DYN;
+    if (N == 0) return;
+    if (DYN) { fmd_deal_init<G>(tk, N, dry); if (dry) return; }
 
     // group-uniform strand state (identical in all lanes of the group)
     bool active = false;
@@ -152,10 +212,11 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
                 round = 0; n_nei = 0; nei0_info = 0;
             }
             active = true;
-            pf = 0; idx += n_groups;
+            pf = 0; if (!DYN) idx += n_groups;
         }
         // ---- prefetch pipeline (loads complete under the rank gather below)
-        if (pf == 1 && d_sid == FMD_LIST_HOLE) { pf = 0; idx += n_groups; }   // an unused slot of a chunk the fast kernel reserved
+        if (pf == 1 && d_sid == FMD_LIST_HOLE) { pf = 0; if (!DYN) idx += n_groups; }   // an unused slot of a chunk the fast kernel reserved
+        if (DYN) idx = fmd_deal_next<G>(tk, deal, N, pf == 0 && g < S, dry);
         if (pf == 1) { // descriptor has arrived: fetch this lane's candidate
             const uint32_t m = d_meta & 0x7fffu;
             if ((uint32_t)j < m) {
@@ -170,7 +231,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
         }
         const uint64_t act_m = __ballot(active);
         if (act_m == 0) {
-            if (__ballot(pf != 0 || idx < N) == 0) break;
+            if (__ballot(pf != 0 || (!DYN && idx < N)) == 0 && dry) break;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // let the prefetches land
             continue;
         }
@@ -445,13 +506,13 @@ template <> struct FastW<uint64_t> {
 #ifndef FMD_FAST_LB
 #define FMD_FAST_LB 5      // waves per SIMD the register budget is cut for.  6 makes some instantiations spill: the build of the round-2 incident (tools/scratch_incident.py)
 #endif
-template <int G, typename M>
+template <int G, typename M, bool DYN>
 __global__ __launch_bounds__(64, FMD_FAST_LB) void k_ovl_nei_fast(FmdIndexView ix, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
                                                      uint32_t cap, const fmd_intv_t *__restrict__ listA, fmd_intv_t *__restrict__ listB, fmd_ovlp_rec_t *__restrict__ rec,
                                                      fmd_intv_t *__restrict__ nei_out, uint32_t max_nei, uint8_t *__restrict__ seq_out,
                                                      uint32_t seq_stride, uint32_t *__restrict__ gen_list, uint32_t *__restrict__ gen_n,
                                                      uint32_t *__restrict__ bail_n, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_n,
-                                                     const uint32_t *__restrict__ gidx)
+                                                     const uint32_t *__restrict__ gidx, uint32_t *__restrict__ deal)
 {
     using W = FastW<M>;
     constexpr int S = 64 / G;
@@ -465,7 +526,11 @@ __global__ __launch_bounds__(64, FMD_FAST_LB) void k_ovl_nei_fast(FmdIndexView i
     const int lane = fmd_lane(), g = lane / G, j = lane % G, gbase = g * G;
     const uint32_t N = *list_n;
     const uint32_t n_groups = gridDim.x * S;
-    uint32_t idx = g < S ? blockIdx.x * S + g : 0xffffffffu;
+    uint32_t idx = !DYN && g < S ? blockIdx.x * S + g : 0xffffffffu;
+    FmdDeal tk;                                                   // DYN: list positions dealt out as the groups ask (see k_ovl_nei_grp)
+    bool dry = !DYN;
+    if (N == 0) return;
+    if (DYN) { fmd_deal_init<G>(tk, N, dry); if (dry) return; }
     // this lane's part in gather instruction r: chunk (lane & 3) of pool slot 16 r + (lane >> 2), which belongs to group slot / 2
     const uint4 *img = pool + 2 * FMD_BLK_U4 * g;
 
@@ -538,9 +603,10 @@ __global__ __launch_bounds__(64, FMD_FAST_LB) void k_ovl_nei_fast(FmdIndexView i
             const bool bad = alive && (!cd.narrow || cd.x1 < X1 || cd.x1 - X1 + cd.sz > szw || szw > W::MAXW || cd.sz == 0);
             if ((uint32_t)(__ballot(bad) >> gbase) & GM) { hand_on = true; alive = false; }   // (sid and meta stay until the hand-over above)
             else active = true;
-            pf = 0; idx += n_groups;
+            pf = 0; if (!DYN) idx += n_groups;
         }
         // ---- prefetch pipeline (loads complete under the window gather below)
+        if (DYN) idx = fmd_deal_next<G>(tk, deal, N, pf == 0 && g < S, dry);
         if (pf == 1) {
             const uint32_t m = d_meta & 0xffff;
             if ((uint32_t)j < m) { const uint4 *q = (const uint4 *)(listA + d_sid * (size_t)cap + (cap - m) + j); pa = q[0]; pb = q[1]; }
@@ -552,7 +618,7 @@ __global__ __launch_bounds__(64, FMD_FAST_LB) void k_ovl_nei_fast(FmdIndexView i
         }
         const uint64_t act_m = __ballot(active);
         if (act_m == 0) {
-            if (__ballot(pf != 0 || idx < N || hand_on) == 0) { if (lane == 0 && n_handed) atomicAdd(bail_n, n_handed); break; }
+            if (__ballot(pf != 0 || (!DYN && idx < N) || hand_on) == 0 && dry) { if (lane == 0 && n_handed) atomicAdd(bail_n, n_handed); break; }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             continue;
         }
@@ -671,11 +737,11 @@ __global__ __launch_bounds__(64, FMD_FAST_LB) void k_ovl_nei_fast(FmdIndexView i
 }
 
 static inline int grp_cap(int resident, int cap) { return cap > 0 && cap < resident ? cap : resident; }
-template <int G, typename M>
+template <int G, typename M, bool DYN>
 static int fast_blocks_per_cu(void)
 {
     static int cached = 0;
-    if (!cached) cached = fmd_resident_per_cu(k_ovl_nei_fast<G, M>, sizeof(uint4) * ((2 * (64 / G) + FMD_BLK_PER_INST - 1) / FMD_BLK_PER_INST * FMD_BLK_PER_INST + 2) * FMD_BLK_U4, 32, "k_ovl_nei_fast");
+    if (!cached) cached = fmd_resident_per_cu(k_ovl_nei_fast<G, M, DYN>, sizeof(uint4) * ((2 * (64 / G) + FMD_BLK_PER_INST - 1) / FMD_BLK_PER_INST * FMD_BLK_PER_INST + 2) * FMD_BLK_U4, 32, "k_ovl_nei_fast");
     return cached;
 }
 #endif
@@ -688,7 +754,10 @@ void fmd_launch_nei_fast(int cls, int wide, int n_cu, int per_cu_cap, hipStream_
 #if FMD_BLK64
     const char *e = getenv("FMD_FAST_WAVES"); // A/B knob: resident waves per CU
     if (e && atoi(e) > 0 && (per_cu_cap <= 0 || atoi(e) < per_cu_cap)) per_cu_cap = atoi(e);
-#define FAST_LAUNCH(K, M) k_ovl_nei_fast<fmd_grp_size(K), M><<<fast_grid(n_cu * grp_cap(fast_blocks_per_cu<fmd_grp_size(K), M>(), per_cu_cap)), 64, 0, st>>>(ix, list, list_n, cap, listA, listB, rec, nei_out, max_nei, seq_out, seq_stride, gen_list, gen_n, bail_n, slow_list, slow_n, gidx)
+    const bool dyn = nei_dyn() != 0;
+    uint32_t *deal = (uint32_t *)list_n + FMD_DEAL_WORD;
+#define FAST_LAUNCH_(K, M, DY) k_ovl_nei_fast<fmd_grp_size(K), M, DY><<<fast_grid(n_cu * grp_cap(fast_blocks_per_cu<fmd_grp_size(K), M, DY>(), per_cu_cap)), 64, 0, st>>>(ix, list, list_n, cap, listA, listB, rec, nei_out, max_nei, seq_out, seq_stride, gen_list, gen_n, bail_n, slow_list, slow_n, gidx, deal)
+#define FAST_LAUNCH(K, M) do { if (dyn) FAST_LAUNCH_(K, M, true); else FAST_LAUNCH_(K, M, false); } while (0)
 #define FAST_LAUNCH2(K) do { if (wide) FAST_LAUNCH(K, uint64_t); else FAST_LAUNCH(K, uint32_t); } while (0)
     switch (cls) {
     case 0: FAST_LAUNCH2(0); break;
@@ -700,6 +769,7 @@ void fmd_launch_nei_fast(int cls, int wide, int n_cu, int per_cu_cap, hipStream_
     }
 #undef FAST_LAUNCH2
 #undef FAST_LAUNCH
+#undef FAST_LAUNCH_
 #endif
 }
 
@@ -707,12 +777,12 @@ void fmd_launch_nei_fast(int cls, int wide, int n_cu, int per_cu_cap, hipStream_
 // the grid must be exactly the resident set: a block that has to wait for a slot starts when the others
 // are done and then works alone through a full share (11 blocks per CU computed from 160 KiB / 14.25 KiB
 // ran 17 % slower than 10: LDS is handed out in 1280-byte granules).  Ask the runtime.
-template <int G>
+template <int G, bool DYN>
 static int grp_blocks_per_cu(void)
 {
     static int cached = 0;
     if (!cached) {
-        int nb = fmd_resident_per_cu(k_ovl_nei_grp<G>, GRP_LDS_U4 * 16, 16, "k_ovl_nei_grp");
+        int nb = fmd_resident_per_cu(k_ovl_nei_grp<G, DYN>, GRP_LDS_U4 * 16, 16, "k_ovl_nei_grp");
         const char *e = getenv("FMD_GRP_WAVES"); // A/B knob: fewer resident waves per CU
         if (e && atoi(e) > 0 && atoi(e) < nb) nb = atoi(e);
         cached = nb;
@@ -723,7 +793,10 @@ void fmd_launch_nei_grp(int cls, int n_cu, int per_cu_cap, hipStream_t st, const
                         const fmd_intv_t *listA, fmd_intv_t *listB, const FmdOvlClasses &cl, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
                         uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx, size_t fix_off)
 {
-#define GRP_LAUNCH(K) k_ovl_nei_grp<fmd_grp_size(K)><<<n_cu * grp_cap(grp_blocks_per_cu<fmd_grp_size(K)>(), per_cu_cap), 64, 0, st>>>(ix, list, list_n, cap, listA, listB, cl, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n, gidx, fix_off)
+    const bool dyn = nei_dyn() != 0;
+    uint32_t *deal = (uint32_t *)list_n + FMD_DEAL_WORD;
+#define GRP_LAUNCH_(K, DY) k_ovl_nei_grp<fmd_grp_size(K), DY><<<n_cu * grp_cap(grp_blocks_per_cu<fmd_grp_size(K), DY>(), per_cu_cap), 64, 0, st>>>(ix, list, list_n, cap, listA, listB, cl, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n, gidx, fix_off, deal)
+#define GRP_LAUNCH(K) do { if (dyn) GRP_LAUNCH_(K, true); else GRP_LAUNCH_(K, false); } while (0)
     switch (cls) {
     case 0: GRP_LAUNCH(0); break;
     case 1: GRP_LAUNCH(1); break;
@@ -733,6 +806,7 @@ void fmd_launch_nei_grp(int cls, int n_cu, int per_cu_cap, hipStream_t st, const
     default: GRP_LAUNCH(5); break;
     }
 #undef GRP_LAUNCH
+#undef GRP_LAUNCH_
 }
 void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, const fmd_intv_t *listA, uint32_t cap, FmdOvlClasses cl, int use_fast, const uint32_t *gidx)
 {
