@@ -39,8 +39,37 @@ struct RemRagged {   // binary search over sequence ends (position of each '$'),
     }
 };
 
+// ---- the 63-bit key of a chunk: up to 21 symbols from text position a, 3 bits each, the first one highest, zeros behind the `mm` that count.
+// Byte by byte that is 21 loads per suffix, and the key kernels took twice the time of the radix sorts they feed (9.6 s of the two 5*10^7-read
+// builds of a bench run against 5.2 s: profiles/r4_final2/kernel_stats.csv) although a suffix lies in one or two 64-byte lines.  A byte text is
+// read as four aligned 8-byte words instead -- the 21 symbols start anywhere in the first -- and eight symbols at a time go from bytes to 3-bit
+// fields in registers.  (`n` = symbols of the text: a window that would reach past it takes the byte loop, as does a text that is not 8-byte aligned.)
+__device__ __forceinline__ uint64_t key_bytes(const uint8_t *text, uint64_t a, uint32_t mm)
+{
+    uint64_t key = 0;
+    for (uint32_t j = 0; j < mm; ++j) key |= (uint64_t)text[a + j] << (3 * (20 - j));
+    return key;
+}
+__device__ __forceinline__ uint64_t squeeze3(uint64_t w)   // 8 symbols, one per byte, the FIRST in the lowest byte -> 24 bits, the first highest
+{
+    uint64_t y = __builtin_bswap64(w) & 0x0707070707070707ull;
+    y = (y | (y >> 5)) & 0x003F003F003F003Full;
+    y = (y | (y >> 10)) & 0x00000FFF00000FFFull;
+    return (y | (y >> 20)) & 0xFFFFFFull;
+}
+__device__ __forceinline__ uint64_t chunk_key(const uint8_t *text, uint64_t n, uint64_t a, uint32_t mm)
+{
+    if (a + 32 > n || ((uintptr_t)text & 7)) return key_bytes(text, a, mm);
+    const uint64_t *q = (const uint64_t *)(text + (a & ~7ull));
+    const uint32_t sh = 8 * (uint32_t)(a & 7);
+    const uint64_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = sh ? q[3] : 0;
+    const uint64_t w0 = sh ? q0 >> sh | q1 << (64 - sh) : q0, w1 = sh ? q1 >> sh | q2 << (64 - sh) : q1, w2 = sh ? q2 >> sh | q3 << (64 - sh) : q2;
+    const uint64_t key = squeeze3(w0) << 39 | squeeze3(w1) << 15 | squeeze3(w2) >> 9;
+    return mm >= 21 ? key : key & ~((1ull << (3 * (21 - mm))) - 1);
+}
+
 template <class Rem>
-__global__ void k_chunk_keys(const uint8_t *__restrict__ text, uint64_t n, const uint32_t *__restrict__ order, int chunk,
+__global__ void k_chunk_keys(const uint8_t *__restrict__ text, uint64_t n, uint64_t n_wide, const uint32_t *__restrict__ order, int chunk,
                              Rem rem, uint64_t *__restrict__ keys)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -49,7 +78,7 @@ __global__ void k_chunk_keys(const uint8_t *__restrict__ text, uint64_t n, const
         uint64_t key = 0;
         if (o0 <= r) {
             const uint32_t m = r - o0 + 1 < 21 ? r - o0 + 1 : 21; // symbols up to and including the '$'
-            for (uint32_t j = 0; j < m; ++j) key |= (uint64_t)text[t + o0 + j] << (3 * (20 - j));
+            key = chunk_key(text, n_wide, t + o0, m);
         }
         keys[i] = key;
     }
@@ -162,8 +191,16 @@ __global__ void k_tile_select(Text text, uint64_t n, int depth, uint32_t code, u
     }
 }
 
+template <class Text>
+__device__ __forceinline__ uint64_t text_key(Text text, uint64_t, uint64_t a, uint32_t mm)   // (4 bits per symbol: symbol by symbol)
+{
+    uint64_t key = 0;
+    for (uint32_t j = 0; j < mm; ++j) key |= (uint64_t)text[a + j] << (3 * (20 - j));
+    return key;
+}
+__device__ __forceinline__ uint64_t text_key(Text8 text, uint64_t n, uint64_t a, uint32_t mm) { return chunk_key(text.p, n, a, mm); }
 template <class Text, class Rem>
-__global__ void k_chunk_keys64(Text text, uint64_t m, const uint64_t *__restrict__ ids, int chunk, Rem rem, uint64_t *__restrict__ keys)
+__global__ void k_chunk_keys64(Text text, uint64_t n_text, uint64_t m, const uint64_t *__restrict__ ids, int chunk, Rem rem, uint64_t *__restrict__ keys)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t t = ids[i];
@@ -171,7 +208,7 @@ __global__ void k_chunk_keys64(Text text, uint64_t m, const uint64_t *__restrict
         uint64_t key = 0;
         if (o0 <= r) {
             const uint32_t mm = r - o0 + 1 < 21 ? r - o0 + 1 : 21;
-            for (uint32_t j = 0; j < mm; ++j) key |= (uint64_t)text[t + o0 + j] << (3 * (20 - j));
+            key = text_key(text, n_text, t + o0, mm);
         }
         keys[i] = key;
     }
@@ -250,9 +287,10 @@ static int build_bucketed(hipStream_t st, Text text, uint64_t n, uint32_t max_le
             uint64_t *nxt = (uint64_t *)ids_b.p;
             size_t sb_m = 0;
             FMD_HIP_TRY(fmd_sort_pairs(nullptr, sb_m, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, cur, nxt, (size_t)m, 0, 63, st));
+            const uint64_t n_wide = getenv("FMD_BUILD_KEY_BYTES") && atoi(getenv("FMD_BUILD_KEY_BYTES")) ? 0 : n;   // A/B switch: 0 = every key byte by byte (round 3)
             for (int ch = n_chunks - 1; ch >= 0; --ch) {
-                if (uniform_len) k_chunk_keys64<<<nblk(m, 256), 256, 0, st>>>(text, m, cur, ch, RemUniform{max_len + 1}, (uint64_t *)keys_a.p);
-                else k_chunk_keys64<<<nblk(m, 256), 256, 0, st>>>(text, m, cur, ch, rr, (uint64_t *)keys_a.p);
+                if (uniform_len) k_chunk_keys64<<<nblk(m, 256), 256, 0, st>>>(text, n_wide, m, cur, ch, RemUniform{max_len + 1}, (uint64_t *)keys_a.p);
+                else k_chunk_keys64<<<nblk(m, 256), 256, 0, st>>>(text, n_wide, m, cur, ch, rr, (uint64_t *)keys_a.p);
                 // the first `depth` symbols are equal inside a bucket: chunk 0 sorts on the bits below them only
                 const int end_bit = ch == 0 ? 63 - 3 * (depth < 21 ? depth : 21) : 63;
                 FMD_HIP_TRY(fmd_sort_pairs(stmp.p, sb_m, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, cur, nxt, (size_t)m, 0, end_bit, st));
@@ -326,9 +364,10 @@ extern "C" int fmd_build_bwt_dev(int device, void *stream_, size_t n_reads, cons
     const int n_chunks = (int)((max_len + 1 + 20) / 21);
     uint32_t *cur = (uint32_t *)ord_a.p, *nxt = (uint32_t *)ord_b.p;
     k_iota32<<<nblk(n, 256), 256, 0, st>>>(cur, n); // text order = sequence-id order: the tie-break
+    const uint64_t n_wide = getenv("FMD_BUILD_KEY_BYTES") && atoi(getenv("FMD_BUILD_KEY_BYTES")) ? 0 : n;   // A/B switch: 0 = every key byte by byte (round 3)
     for (int c = n_chunks - 1; c >= 0; --c) {
-        if (uniform_len) k_chunk_keys<<<nblk(n, 256), 256, 0, st>>>((const uint8_t *)text.p, n, cur, c, RemUniform{max_len + 1}, (uint64_t *)keys_a.p);
-        else k_chunk_keys<<<nblk(n, 256), 256, 0, st>>>((const uint8_t *)text.p, n, cur, c, rr, (uint64_t *)keys_a.p);
+        if (uniform_len) k_chunk_keys<<<nblk(n, 256), 256, 0, st>>>((const uint8_t *)text.p, n, n_wide, cur, c, RemUniform{max_len + 1}, (uint64_t *)keys_a.p);
+        else k_chunk_keys<<<nblk(n, 256), 256, 0, st>>>((const uint8_t *)text.p, n, n_wide, cur, c, rr, (uint64_t *)keys_a.p);
         FMD_HIP_TRY(fmd_sort_pairs(tmp.p, tmp_bytes, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, cur, nxt,
                                                       (size_t)n, 0, 63, st));
         uint32_t *t = cur; cur = nxt; nxt = t;
