@@ -1,3 +1,7 @@
+#!/bin/bash
+# Chunk sizes of the dealt-out get_nei work lists (FMD_DEAL_CHUNK, fmd_ovlp_grp.hip) and the group-occupancy counters with them.  Build the variants first:
+#   make variant NAME=dc32 EXTRA=-DFMD_DEAL_CHUNK=32; make variant NAME=dc128 EXTRA=-DFMD_DEAL_CHUNK=128; make variant NAME=stats EXTRA=-DGRP_STATS=1
+# then run this on the GPU box.  Separate processes: differences below ~2 % are box noise (profiles/r4_dyn/chunk_sizes.txt).
 mkdir -p gpurun_out/r4_dyn
 for e in 0.01 0; do
   for v in "" _dc32 _dc128; do
