@@ -936,6 +936,34 @@ def test_unforked_fast_path_equals_general_group_kernels(gpu, oracle_lib, monkey
     d.close(); o.close()
 
 
+@pytest.mark.parametrize("L,cov,mm,err,N", [(100, 30, 50, 0.01, 400000), (100, 30, 50, 0.0, 30000), (151, 12, 31, 0.02, 6000)])
+def test_dealt_out_work_lists_equal_the_round_robin_deal(gpu, oracle_lib, monkeypatch, L, cov, mm, err, N):
+    """The get_nei kernels take their strands from chunks of the work list handed out as the groups ask (fmd_deal_next) -- against the
+    round-robin shares of rounds 1-3 (FMD_NEI_DYN=0, read at every launch) and the oracle: records, neighbours, appended bases.  The
+    first set has more strands in its lists than the first chunks of the grid hold (8 * 10^5 strands: ~10^5 in the general list of the groups
+    of 8 against 32 768 first positions), so waves come back for chunks; the others fit the first chunks (one strand per group: the old deal)."""
+    reads = synth.reads(synth.DEFAULT_SEED + 11 * L + cov, N, L, cov, err)
+    bwt = gpu.build_bwt(reads)
+    d = gpu.DevIndex.from_bwt(bwt)
+    ids = np.arange(2 * N, dtype=U64)
+    dealt = d.overlap(ids, mm, L, 8, check_left=True)
+    monkeypatch.setenv("FMD_NEI_DYN", "0")
+    fixed = d.overlap(ids, mm, L, 8, check_left=True)
+    monkeypatch.delenv("FMD_NEI_DYN")
+    _same_overlap(fixed, dealt, 8)
+    o = orcbind.OrcIndex(bwt=bwt)
+    sub = ids[:3000]
+    wrec, wnei, wseq = o.overlap_batch(sub, mm, L, 8, 4, check_left=True)
+    ok = (dealt[0]["flags"][:3000] & gpu.OVLP_F_OVERFLOW) == 0
+    assert ok.sum() > 2900
+    for f in ("rank", "k", "len", "status", "n_ovlp", "rbeg", "ext_len", "n_nei", "reserved"):
+        assert np.array_equal(dealt[0][f][:3000][ok], wrec[f][ok]), f
+    for j in range(8):
+        mj = ok & (wrec["n_nei"] > j)
+        assert dealt[1][:3000][mj, j].tobytes() == wnei[mj, j].tobytes(), j
+    d.close(); o.close()
+
+
 @pytest.mark.parametrize("pipe", ["3,9,7", "8,2,2", "5,16,16"])
 def test_overlap_pipelined_parts_equal_serial(gpu, oracle_lib, monkeypatch, pipe):
     """fmd_ovlp_dev cuts a large batch into parts and runs get_nei of one part on a second stream beside
