@@ -113,6 +113,8 @@ static inline unsigned nblk(uint64_t n, unsigned t)
     return (unsigned)(b < cap ? (b ? b : 1) : cap);
 }
 
+#include <time.h>
+static double bt_now(hipStream_t st, bool on) { if (!on) return 0; hipStreamSynchronize(st); struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 struct DevPtr { void *p = nullptr; ~DevPtr() { if (p) hipFree(p); } };
 #define DALLOC(buf, bytes) do { hipError_t e__ = hipMalloc(&(buf).p, (bytes) ? (bytes) : 16); \
     if (e__ != hipSuccess) { fmd_set_hip_error(e__, "hipMalloc(" #buf ")"); return FMD_E_NOMEM; } } while (0)
@@ -269,6 +271,8 @@ template <class Text, class Sink>
 static int build_bucketed(hipStream_t st, Text text, uint64_t n, uint32_t max_len, int uniform_len, RemRagged rr, int depth, uint8_t *bwt_direct, Sink sink)
 {
     const int n_chunks = (int)((max_len + 1 + 20) / 21);
+    const bool tm = getenv("FMD_TIMING") != nullptr;     // phase times of the build (each phase synchronised: diagnostics only)
+    double t_alloc = 0, t_sel = 0, t_keys = 0, t_sort = 0, t_emit = 0, t0 = bt_now(st, tm), t1;
     std::vector<uint32_t> codes;
     prefix_codes(depth, codes);
     uint64_t done = 0, cap = 0;
@@ -305,10 +309,12 @@ static int build_bucketed(hipStream_t st, Text text, uint64_t n, uint32_t max_le
                                                           (uint64_t *)ids_b.p, (size_t)cap, 0, 63, st));
             DALLOC(stmp, sb);
         }
+        if (tm) { t1 = bt_now(st, tm); t_alloc += t1 - t0; t0 = t1; }
         k_tile_count<<<sel_grid, 256, 0, st>>>(text, n, depth, code, n_tiles, (uint64_t *)tile_cnt.p);
         FMD_HIP_TRY(fmd_exclusive_sum(tmp.p, tb, (uint64_t *)tile_cnt.p, (uint64_t *)tile_off.p, (size_t)n_tiles, st));
         k_tile_select<<<sel_grid, 256, 0, st>>>(text, n, depth, code, n_tiles, (const uint64_t *)tile_off.p, (uint64_t *)ids_a.p);
         uint64_t *cur = (uint64_t *)ids_a.p;
+        if (tm) { t1 = bt_now(st, tm); t_sel += t1 - t0; t0 = t1; }
         if (!has_end) {
             uint64_t *nxt = (uint64_t *)ids_b.p;
             size_t sb_m = 0;
@@ -319,8 +325,10 @@ static int build_bucketed(hipStream_t st, Text text, uint64_t n, uint32_t max_le
                 else k_chunk_keys64<<<nblk(m, 256), 256, 0, st>>>(text, n_wide, m, cur, ch, rr, (uint64_t *)keys_a.p);
                 // the first `depth` symbols are equal inside a bucket: chunk 0 sorts on the bits below them only
                 const int end_bit = ch == 0 ? 63 - 3 * (depth < 21 ? depth : 21) : 63;
+                if (tm) { t1 = bt_now(st, tm); t_keys += t1 - t0; t0 = t1; }
                 FMD_HIP_TRY(fmd_sort_pairs(stmp.p, sb_m, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, cur, nxt, (size_t)m, 0, end_bit, st));
                 uint64_t *t = cur; cur = nxt; nxt = t;
+                if (tm) { t1 = bt_now(st, tm); t_sort += t1 - t0; t0 = t1; }
             }
         }
         if (bwt_direct) k_emit_bwt64<<<nblk(m, 256), 256, 0, st>>>(text, cur, m, bwt_direct + done);
@@ -330,8 +338,11 @@ static int build_bucketed(hipStream_t st, Text text, uint64_t n, uint32_t max_le
             if (rc) return rc;
         }
         FMD_HIP_TRY(hipStreamSynchronize(st));
+        if (tm) { t1 = bt_now(st, tm); t_emit += t1 - t0; t0 = t1; }
         done += m;
     }
+    if (tm) fprintf(stderr, "[M::fmd_build] %llu symbols, depth %d: histogram + arrays (hipMalloc / hipFree) %.2f s, positions of the buckets %.2f s, keys %.2f s, sorts %.2f s, BWT out %.2f s\n",
+                    (unsigned long long)n, depth, t_alloc, t_sel, t_keys, t_sort, t_emit);
     return done == n ? FMD_OK : FMD_E_HIP;
 }
 struct NoSink { int operator()(const uint8_t *, uint64_t, uint64_t) const { return FMD_OK; } };

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU BWT construction (fmd_build_bwt_dev on device-resident reads, as bench.py's setup runs it) timed on N synthetic 100-bp reads, error-free and with
 1 % substitutions, with two checksums of the BWT each time.  FMD_BUILD_KEY_BYTES=1 (the A/B switch): the key kernels load byte by byte as through round 3.
-Usage: python tools/time_build_keys.py [n_reads=50000000]"""
+Usage: [FMD_TIMING=1] [BUILD_ERRS=0,0.01] [BUILD_MODES=1,0,1,0] python tools/time_build_keys.py [n_reads=50000000]"""
 import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,9 +12,9 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 lib = api.lib()
 hip = C.CDLL("libamdhip64.so")
-for err in (0.0, 0.01):
+for err in [float(x) for x in os.environ.get("BUILD_ERRS", "0,0.01").split(",")]:
     rd = workload.ReadsOnDevice.synth(n, 100, 30, err, dev)
-    for mode in ("1", "0", "1", "0"):
+    for mode in os.environ.get("BUILD_MODES", "1,0,1,0").split(","):
         os.environ["FMD_BUILD_KEY_BYTES"] = mode
         torch.cuda.synchronize(); t = time.time()
         d_bwt, n_sym = workload.build_bwt_on_device(rd, 0)
