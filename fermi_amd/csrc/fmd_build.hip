@@ -193,6 +193,43 @@ __global__ void k_tile_select(Text text, uint64_t n, int depth, uint32_t code, u
     }
 }
 
+// ---- FMD_BUILD_PARTITION=1 (off by default: tested on the fixtures only): the suffixes that have ENDED before a chunk -- distance to their '$' <= 21 * chunk,
+// key 0 -- keep their order in front of the others, which is all a stable sort would do with them; they are 83 % of a bucket of 100-bp reads in the last chunk
+// and 62 / 42 / 21 % in the ones before.  Two stable selections over tiles of the id array (count, scan, scatter by ballot prefix), then keys and sort for the rest.
+template <class Rem>
+__global__ void k_part_count(const uint64_t *__restrict__ ids, uint64_t m, Rem rem, uint32_t o0, uint64_t m_tiles, uint64_t *__restrict__ counts)
+{
+    const int lane = threadIdx.x & 63;
+    for (uint64_t tile = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < m_tiles; tile += (uint64_t)gridDim.x * (blockDim.x >> 6)) {
+        const uint64_t i0 = tile << SEL_TILE_SHIFT, i1 = i0 + (1ull << SEL_TILE_SHIFT) < m ? i0 + (1ull << SEL_TILE_SHIFT) : m;
+        uint32_t c = 0;
+        for (uint64_t i = i0 + (uint64_t)lane; i < i1; i += 64) c += rem(ids[i]) <= o0;
+        for (int o = 32; o; o >>= 1) c += __shfl_xor((int)c, o);
+        if (lane == 0) counts[tile] = c;
+    }
+}
+// ended[tile] = ended suffixes in front of the tile (exclusive scan of the counts), z = all of them: out[0, z) the ended ones, out[z, m) the others, both in order
+template <class Rem>
+__global__ void k_part_scatter(const uint64_t *__restrict__ ids, uint64_t m, Rem rem, uint32_t o0, uint64_t m_tiles, const uint64_t *__restrict__ ended, uint64_t z,
+                               uint64_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    for (uint64_t tile = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < m_tiles; tile += (uint64_t)gridDim.x * (blockDim.x >> 6)) {
+        const uint64_t i0 = tile << SEL_TILE_SHIFT, i1 = i0 + (1ull << SEL_TILE_SHIFT) < m ? i0 + (1ull << SEL_TILE_SHIFT) : m;
+        uint64_t bz = ended[tile], bn = z + (i0 - ended[tile]);
+        for (uint64_t ib = i0; ib < i1; ib += 64) {           // all 64 lanes take every turn: the ballots need them
+            const uint64_t i = ib + (uint64_t)lane;
+            const bool in = i < i1;
+            const uint64_t t = in ? ids[i] : 0;
+            const bool end = in && rem(t) <= o0;
+            const uint64_t mz = __ballot(end), mn = __ballot(in && !end), below = (1ull << lane) - 1;
+            if (end) out[bz + (uint64_t)__popcll(mz & below)] = t;
+            else if (in) out[bn + (uint64_t)__popcll(mn & below)] = t;
+            bz += (uint64_t)__popcll(mz); bn += (uint64_t)__popcll(mn);
+        }
+    }
+}
+
 template <class Text>
 __device__ __forceinline__ uint64_t text_key(Text text, uint64_t, uint64_t a, uint32_t mm)   // (4 bits per symbol: symbol by symbol)
 {
@@ -320,7 +357,34 @@ static int build_bucketed(hipStream_t st, Text text, uint64_t n, uint32_t max_le
             size_t sb_m = 0;
             FMD_HIP_TRY(fmd_sort_pairs(nullptr, sb_m, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, cur, nxt, (size_t)m, 0, 63, st));
             const uint64_t n_wide = getenv("FMD_BUILD_KEY_BYTES") && atoi(getenv("FMD_BUILD_KEY_BYTES")) ? 0 : n;   // A/B switch: 0 = every key byte by byte (round 3)
+            const bool part = getenv("FMD_BUILD_PARTITION") && atoi(getenv("FMD_BUILD_PARTITION"));
             for (int ch = n_chunks - 1; ch >= 0; --ch) {
+                if (part && ch > 0) {   // (chunk 0: nothing has ended before the first symbol of a bucket without a '$' in its prefix)
+                    const uint64_t m_tiles = (m + (1ull << SEL_TILE_SHIFT) - 1) >> SEL_TILE_SHIFT;
+                    const uint32_t o0 = 21u * (uint32_t)ch;
+                    const RemUniform ru{max_len + 1};
+                    if (uniform_len) k_part_count<<<sel_grid, 256, 0, st>>>(cur, m, ru, o0, m_tiles, (uint64_t *)tile_cnt.p);
+                    else k_part_count<<<sel_grid, 256, 0, st>>>(cur, m, rr, o0, m_tiles, (uint64_t *)tile_cnt.p);
+                    FMD_HIP_TRY(fmd_exclusive_sum(tmp.p, tb, (uint64_t *)tile_cnt.p, (uint64_t *)tile_off.p, (size_t)m_tiles, st));
+                    uint64_t last[2] = {0, 0};
+                    FMD_HIP_TRY(hipMemcpyAsync(&last[0], (uint64_t *)tile_off.p + (m_tiles - 1), 8, hipMemcpyDeviceToHost, st));
+                    FMD_HIP_TRY(hipMemcpyAsync(&last[1], (uint64_t *)tile_cnt.p + (m_tiles - 1), 8, hipMemcpyDeviceToHost, st));
+                    FMD_HIP_TRY(hipStreamSynchronize(st));
+                    const uint64_t z = last[0] + last[1];
+                    if (z == m) continue;                     // every suffix of the bucket ended before this chunk: the order stands
+                    if (z > 0) {
+                        if (uniform_len) k_part_scatter<<<sel_grid, 256, 0, st>>>(cur, m, ru, o0, m_tiles, (const uint64_t *)tile_off.p, z, nxt);
+                        else k_part_scatter<<<sel_grid, 256, 0, st>>>(cur, m, rr, o0, m_tiles, (const uint64_t *)tile_off.p, z, nxt);
+                        if (tm) { t1 = bt_now(st, tm); t_sel += t1 - t0; t0 = t1; }
+                        if (uniform_len) k_chunk_keys64<<<nblk(m - z, 256), 256, 0, st>>>(text, n_wide, m - z, nxt + z, ch, ru, (uint64_t *)keys_a.p);
+                        else k_chunk_keys64<<<nblk(m - z, 256), 256, 0, st>>>(text, n_wide, m - z, nxt + z, ch, rr, (uint64_t *)keys_a.p);
+                        if (tm) { t1 = bt_now(st, tm); t_keys += t1 - t0; t0 = t1; }
+                        FMD_HIP_TRY(fmd_sort_pairs(stmp.p, sb_m, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, nxt + z, cur + z, (size_t)(m - z), 0, 63, st));
+                        FMD_HIP_TRY(hipMemcpyAsync(cur, nxt, z * 8, hipMemcpyDeviceToDevice, st));   // (the result is in `cur` again: no swap)
+                        if (tm) { t1 = bt_now(st, tm); t_sort += t1 - t0; t0 = t1; }
+                        continue;
+                    }
+                }
                 if (uniform_len) k_chunk_keys64<<<nblk(m, 256), 256, 0, st>>>(text, n_wide, m, cur, ch, RemUniform{max_len + 1}, (uint64_t *)keys_a.p);
                 else k_chunk_keys64<<<nblk(m, 256), 256, 0, st>>>(text, n_wide, m, cur, ch, rr, (uint64_t *)keys_a.p);
                 // the first `depth` symbols are equal inside a bucket: chunk 0 sorts on the bits below them only

@@ -635,6 +635,34 @@ def test_inplace_builder_gives_the_same_index(gpu, monkeypatch, depth):
         a.close(); b.close()
 
 
+@pytest.mark.parametrize("depth", [1, 3])
+def test_builders_with_the_ended_suffixes_set_aside(gpu, gold, oracle_lib, monkeypatch, depth):
+    """FMD_BUILD_PARTITION=1 (off by default): before a chunk is sorted, the suffixes that ended in front of it keep their order at the head of
+    the bucket by two stable selections and only the rest gets keys and a sort.  The bucketed byte-BWT builder on the fixtures (uniform, ragged,
+    Ns) == `fermi build`; the in-place builder on reads of 100 bp (five chunks, buckets of several selection tiles) and 37 bp == the one-shot builder."""
+    from fermi_amd import hostlib
+    monkeypatch.setenv("FMD_BUILD_DEPTH", str(depth))
+    monkeypatch.setenv("FMD_BUILD_PARTITION", "1")
+    monkeypatch.setenv("FMD_BUILD_BUCKETED", "1")
+    for name in ("tiny", "special", "repeat"):
+        reads = gold.fastq_nt6(name + ".fq.gz")
+        reads = [r[:hostlib.trim_palindrome(r)] for r in reads]
+        o = orcbind.OrcIndex(gold.path(name + ".fmd"))
+        assert np.array_equal(gpu.build_bwt(reads), o.decode_all()), name
+        o.close()
+    monkeypatch.delenv("FMD_BUILD_BUCKETED")
+    for n, ln, err, seed in ((6000, 100, 0.01, 3), (3000, 37, 0.02, 1)):
+        reads = synth.reads(synth.DEFAULT_SEED + seed, n, ln, 20, err)
+        monkeypatch.setenv("FMD_BUILD_PARTITION", "1")
+        a = gpu.build_index_inplace(reads, pieces=3)
+        monkeypatch.setenv("FMD_BUILD_PARTITION", "0")
+        want = gpu.build_bwt(reads)
+        got = np.zeros(a.n, dtype=np.uint8)
+        gpu.check(gpu.lib().fmd_dev_export_bwt(a.h, 0, a.n, got.ctypes.data))
+        assert a.n == len(want) and np.array_equal(got, want), (n, ln)
+        a.close()
+
+
 @pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20), ("special", 20)])
 def test_seqsort_and_unitig_r_cli(gpu, gold, tmp_path, name, mm):
     """`fermi-amd seqsort` == `fermi seqsort` bytes; `fermi-amd unitig -r` == `fermi unitig -t1 -r` bytes."""
