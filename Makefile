@@ -8,7 +8,7 @@ CC        = gcc
 CFLAGS    = -O2 -g -Wall -fPIC -std=gnu11
 
 HIP_SRCS  = $(wildcard fermi_amd/csrc/*.hip)
-HIP_HDRS  = $(wildcard fermi_amd/csrc/*.h) include/fmd_hip.h
+HIP_HDRS  = $(wildcard fermi_amd/csrc/*.h) $(wildcard fermi_amd/csrc/*.inc) include/fmd_hip.h
 HIP_OBJS  = $(patsubst fermi_amd/csrc/%.hip,build/%.o,$(HIP_SRCS))
 HOST_SRCS = $(filter-out fermi_amd/host/main.c,$(wildcard fermi_amd/host/*.c))
 HOST_HDRS = $(wildcard fermi_amd/host/*.h) include/fmd_hip.h

@@ -45,29 +45,7 @@ struct RemRagged {   // binary search over sequence ends (position of each '$'),
 // builds of a bench run against 5.2 s: profiles/r4_final2/kernel_stats.csv) although a suffix lies in one or two 64-byte lines.  A byte text is
 // read as four aligned 8-byte words instead -- the 21 symbols start anywhere in the first -- and eight symbols at a time go from bytes to 3-bit
 // fields in registers.  (`n` = symbols of the text: a window that would reach past it takes the byte loop, as does a text that is not 8-byte aligned.)
-__device__ __forceinline__ uint64_t key_bytes(const uint8_t *text, uint64_t a, uint32_t mm)
-{
-    uint64_t key = 0;
-    for (uint32_t j = 0; j < mm; ++j) key |= (uint64_t)text[a + j] << (3 * (20 - j));
-    return key;
-}
-__device__ __forceinline__ uint64_t squeeze3(uint64_t w)   // 8 symbols, one per byte, the FIRST in the lowest byte -> 24 bits, the first highest
-{
-    uint64_t y = __builtin_bswap64(w) & 0x0707070707070707ull;
-    y = (y | (y >> 5)) & 0x003F003F003F003Full;
-    y = (y | (y >> 10)) & 0x00000FFF00000FFFull;
-    return (y | (y >> 20)) & 0xFFFFFFull;
-}
-__device__ __forceinline__ uint64_t chunk_key(const uint8_t *text, uint64_t n, uint64_t a, uint32_t mm)
-{
-    if (a + 32 > n || ((uintptr_t)text & 7)) return key_bytes(text, a, mm);
-    const uint64_t *q = (const uint64_t *)(text + (a & ~7ull));
-    const uint32_t sh = 8 * (uint32_t)(a & 7);
-    const uint64_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = sh ? q[3] : 0;
-    const uint64_t w0 = sh ? q0 >> sh | q1 << (64 - sh) : q0, w1 = sh ? q1 >> sh | q2 << (64 - sh) : q1, w2 = sh ? q2 >> sh | q3 << (64 - sh) : q2;
-    const uint64_t key = squeeze3(w0) << 39 | squeeze3(w1) << 15 | squeeze3(w2) >> 9;
-    return mm >= 21 ? key : key & ~((1ull << (3 * (21 - mm))) - 1);
-}
+#include "fmd_keys.inc"
 
 template <class Rem>
 __global__ void k_chunk_keys(const uint8_t *__restrict__ text, uint64_t n, uint64_t n_wide, const uint32_t *__restrict__ order, int chunk,
@@ -241,30 +219,7 @@ __device__ __forceinline__ uint64_t text_key(Text text, uint64_t, uint64_t a, ui
 __device__ __forceinline__ uint64_t text_key(Text8 text, uint64_t n, uint64_t a, uint32_t mm) { return chunk_key(text.p, n, a, mm); }
 // the same for the 4-bit text of the in-place builder (symbol t = nibble t & 1 of byte t >> 1: a little-endian stream of nibbles): 21 symbols are
 // 84 bits of three aligned 8-byte words; sixteen symbols at a time go from nibbles to 3-bit fields, the first highest
-__device__ __forceinline__ uint64_t squeeze4(uint64_t w)
-{
-    uint64_t x = __builtin_bswap64(w);
-    x = (x & 0x0F0F0F0F0F0F0F0Full) << 4 | ((x >> 4) & 0x0F0F0F0F0F0F0F0Full);      // nibbles reversed: the first symbol in the highest nibble
-    uint64_t y = x & 0x7777777777777777ull;
-    y = (y & 0x0707070707070707ull) | ((y >> 1) & 0x3838383838383838ull);
-    y = (y & 0x003F003F003F003Full) | ((y >> 2) & 0x0FC00FC00FC00FC0ull);
-    y = (y & 0x00000FFF00000FFFull) | ((y >> 4) & 0x00FFF00000FFF000ull);
-    return (y & 0x0000000000FFFFFFull) | ((y >> 8) & 0x0000FFFFFF000000ull);
-}
-__device__ __forceinline__ uint64_t text_key(Text4 text, uint64_t n, uint64_t a, uint32_t mm)
-{
-    if (a + 48 > n || ((uintptr_t)text.p & 7)) {
-        uint64_t key = 0;
-        for (uint32_t j = 0; j < mm; ++j) key |= (uint64_t)text[a + j] << (3 * (20 - j));
-        return key;
-    }
-    const uint64_t *q = (const uint64_t *)text.p + (a >> 4);
-    const uint32_t sh = 4 * (uint32_t)(a & 15);
-    const uint64_t q0 = q[0], q1 = q[1], q2 = sh ? q[2] : 0;
-    const uint64_t w0 = sh ? q0 >> sh | q1 << (64 - sh) : q0, w1 = sh ? q1 >> sh | q2 << (64 - sh) : q1;
-    const uint64_t key = squeeze4(w0) << 15 | squeeze4(w1) >> 33;
-    return mm >= 21 ? key : key & ~((1ull << (3 * (21 - mm))) - 1);
-}
+__device__ __forceinline__ uint64_t text_key(Text4 text, uint64_t n, uint64_t a, uint32_t mm) { return chunk_key4(text.p, n, a, mm); }
 template <class Text, class Rem>
 __global__ void k_chunk_keys64(Text text, uint64_t n_text, uint64_t m, const uint64_t *__restrict__ ids, int chunk, Rem rem, uint64_t *__restrict__ keys)
 {

@@ -33,3 +33,46 @@ def test_bruteforce_bwt_equals_fermi_build(oracle_lib, gold):
     o = orcbind.OrcIndex(gold.path("tiny.fmd"))
     assert np.array_equal(bwt, o.decode_all())
     o.close()
+
+
+def test_word_wide_sort_keys_equal_the_symbol_loops(tmp_path):
+    """fermi_amd/csrc/fmd_keys.inc (the sort keys of the GPU index build, compiled here for the host): the word-wide forms -- four aligned 8-byte loads
+    of a byte text, three of a 4-bit text, symbols packed to 3-bit fields in registers -- against the symbol-by-symbol loops, on every alignment, every
+    count of symbols 1..21 and windows at the very end of the text (where the loops take over)."""
+    import os, subprocess
+    src = tmp_path / "keys_test.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "fmd_keys.inc"
+int main(void)
+{
+    const uint64_t n = 1 << 16;
+    uint8_t *t8 = (uint8_t *)aligned_alloc(64, n + 64), *t4 = (uint8_t *)aligned_alloc(64, n / 2 + 64);
+    uint64_t x = 88172645463325252ull, bad = 0, wide8 = 0, wide4 = 0;
+    memset(t8, 0xee, n + 64); memset(t4, 0xee, n / 2 + 64);     /* what lies behind the text must not matter */
+    for (uint64_t i = 0; i < n; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; t8[i] = (uint8_t)(x % 6); }
+    for (uint64_t i = 0; i < n; i += 2) t4[i >> 1] = (uint8_t)(t8[i] | t8[i + 1] << 4);
+    for (uint64_t a = 0; a < n; ++a) {
+        const uint32_t room = n - a < 21 ? (uint32_t)(n - a) : 21;
+        for (uint32_t mm = 1; mm <= room; mm += (a & 63) < 40 || a + 64 > n ? 1 : 5) {
+            const uint64_t w8 = key_bytes(t8, a, mm);
+            bad += chunk_key(t8, n, a, mm) != w8;
+            bad += key_nibbles(t4, a, mm) != w8;                /* the two texts hold the same symbols */
+            bad += chunk_key4(t4, n, a, mm) != w8;
+        }
+        wide8 += a + 32 <= n; wide4 += a + 48 <= n;
+    }
+    bad += chunk_key(t8 + 1, n - 1, 5, 21) != key_bytes(t8 + 1, 5, 21);   /* an unaligned text takes the loop */
+    printf("%llu %llu %llu\n", (unsigned long long)bad, (unsigned long long)wide8, (unsigned long long)wide4);
+    return bad != 0;
+}
+""")
+    exe = tmp_path / "keys_test"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fermi_amd", "csrc")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-I", inc, str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    bad, wide8, wide4 = (int(v) for v in out.stdout.split())
+    assert out.returncode == 0 and bad == 0, out.stdout
+    assert wide8 > 65000 and wide4 > 65000      # (nearly every window took the word-wide form)
