@@ -773,11 +773,10 @@ void fmd_launch_nei_fast(int cls, int wide, int n_cu, int per_cu_cap, hipStream_
 #endif
 }
 
-// launcher used by fmd_ovlp.hip.  Grid = exactly the resident set (ask the runtime).  With the round-robin deal (DYN = false) that is a
-// must: a block that has to wait for a slot starts when the others are done and then works alone through a full share (11 blocks per CU
-// computed from 160 KiB / 14.25 KiB ran 17 % slower than 10: LDS is handed out in 1280-byte granules).  With the dealt-out lists a late
-// block would find the list dealt out and leave, so the resident set is simply the right number of waves; the first chunks (fmd_deal_first)
-// are sized for it.
+// launcher used by fmd_ovlp.hip.  The strands of a work list are dealt to the groups round-robin, so
+// the grid must be exactly the resident set: a block that has to wait for a slot starts when the others
+// are done and then works alone through a full share (11 blocks per CU computed from 160 KiB / 14.25 KiB
+// ran 17 % slower than 10: LDS is handed out in 1280-byte granules).  Ask the runtime.
 template <int G, bool DYN>
 static int grp_blocks_per_cu(void)
 {
