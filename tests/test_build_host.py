@@ -2,6 +2,7 @@
 definition the index constructors are checked against (sentinels sort by sequence id:
 ksa.c:54; text = read $ revcomp $ ..., cmd.c:457-469)."""
 import numpy as np
+import pytest
 
 import orcbind
 
@@ -76,3 +77,51 @@ int main(void)
     bad, wide8, wide4 = (int(v) for v in out.stdout.split())
     assert out.returncode == 0 and bad == 0, out.stdout
     assert wide8 > 65000 and wide4 > 65000      # (nearly every window took the word-wide form)
+
+
+def _chunk_keys(text, send_of, ids, ch):
+    """numpy restatement of k_chunk_keys64 (fmd_build.hip): symbols [21 ch, 21 ch + 21) of the suffix at ids[i], up to and including its '$', 3 bits each"""
+    r = send_of[ids] - ids                                   # distance to the '$' that closes the sequence
+    o0 = 21 * ch
+    keys = np.zeros(len(ids), dtype=np.uint64)
+    for j in range(21):
+        use = o0 + j <= r
+        t = np.minimum(ids + o0 + j, len(text) - 1)
+        keys |= np.where(use, text[t].astype(np.uint64), 0).astype(np.uint64) << np.uint64(3 * (20 - j))
+    return keys, r
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_setting_the_ended_suffixes_aside_is_the_stable_sort(ragged):
+    """The claim behind FMD_BUILD_PARTITION (fmd_build.hip, build_bucketed): in the LSD pass of chunk ch a suffix has key 0 exactly when it ended before the
+    chunk (distance to its '$' <= 21 ch), so [those, in their order] + [the rest, stably sorted by key] IS the stable sort of all -- restated in numpy
+    over one bucket-free text (reads with Ns, equal or ragged lengths up to 70: four chunks), pass by pass, and the final order against sorted suffixes."""
+    rng = np.random.default_rng(7 + ragged)
+    n_reads = 300
+    lens = rng.integers(1, 71, n_reads) if ragged else np.full(n_reads, 64)
+    parts, ends = [], []
+    for ln in lens:
+        r = rng.integers(1, 5, ln).astype(np.uint8)
+        r[rng.random(ln) < 0.02] = 5
+        for s in (r, np.where((r >= 1) & (r <= 4), 5 - r, r)[::-1]):
+            parts += [s, np.zeros(1, dtype=np.uint8)]
+            ends.append(sum(len(p) for p in parts) - 1)
+    text = np.concatenate(parts)
+    n = len(text)
+    send_of = np.array(ends, dtype=np.int64)[np.searchsorted(np.array(ends), np.arange(n))]
+    n_chunks = (int(lens.max()) + 1 + 20) // 21
+    plain = np.arange(n, dtype=np.int64)
+    aside = plain.copy()
+    for ch in range(n_chunks - 1, -1, -1):
+        k, _ = _chunk_keys(text, send_of, plain, ch)
+        plain = plain[np.argsort(k, kind="stable")]
+        k, r = _chunk_keys(text, send_of, aside, ch)
+        ended = r <= 21 * ch
+        assert np.array_equal(ended, k == 0) or ch == 0      # (chunk 0 of the whole text: the suffixes that ARE a '$' have key 0 too; a bucket has none)
+        if ch == 0:
+            ended = k == 0
+        rest = aside[~ended]
+        aside = np.concatenate([aside[ended], rest[np.argsort(k[~ended], kind="stable")]])
+        assert np.array_equal(aside, plain), ch
+    want = sorted(range(n), key=lambda t: (bytes(text[t:send_of[t] + 1]), t))      # a '$' ends the comparison; ties go by text order = sequence id
+    assert plain.tolist() == want
