@@ -182,7 +182,7 @@ static int pack_core(fmd_dev_t *h, hipStream_t st, size_t n, const uint32_t *d_r
                      const fmd_ovlp_rec_t *d_rec, const fmd_intv_t *d_nei, uint32_t max_nei, const uint8_t *d_seq, uint32_t seq_stride, uint32_t *d_pid,
                      fmd_ovlp_rec_t *d_prec, uint64_t *d_off, uint8_t *d_var, uint64_t var_cap, void *d_work, size_t work_bytes)
 {
-    if (!h || (n && (!d_rec || !d_nei || !d_seq || !d_prec || !d_off || !d_var || !d_work)) || max_nei == 0 || (seq_stride & 3)) return FMD_E_ARG;
+    if (!h || (n && (!d_rec || !d_nei || !d_seq || !d_prec || !d_off || !d_var || !d_work)) || max_nei == 0 || (seq_stride & 7)) return FMD_E_ARG;   /* the rows are read as aligned 8-byte words */
     if (work_bytes < fmd_ovlp_pack_work_bytes(n)) return FMD_E_ARG;
     FMD_HIP_TRY(hipSetDevice(h->device));
     if (n == 0) { FMD_HIP_TRY(hipMemsetAsync(d_off, 0, 8, st)); return FMD_OK; }

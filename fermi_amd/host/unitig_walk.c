@@ -406,7 +406,10 @@ static inline void st_set(walk_t *w, int which, uint64_t x)
     spec_t *sp = w->sp;
     if (!sp) { bit_set(st_map(w, which), x); return; }
     if (bit_get(st_map(w, which), x)) return;
-    { const uint64_t key = (uint64_t)which << 62 | x; if (ov_add(sp, key)) log_push(&sp->wlog, &sp->n_w, &sp->m_w, key, &sp->err); }
+    /* logged whether or not an earlier seed of the chunk put the bit into the overlay first: that seed may fail validation and not set it again when it is
+     * re-run, and this seed's log must then still carry the bit (a write without a read in front -- mark_used, the bend of a forward bifurcation -- is not
+     * caught by the read log).  A key logged twice is set twice. */
+    { const uint64_t key = (uint64_t)which << 62 | x; ov_add(sp, key); log_push(&sp->wlog, &sp->n_w, &sp->m_w, key, &sp->err); }
 }
 
 static void mark_used(walk_t *w, const uint64_t x[3]) /* set_bits, unitig.c:22-36 (sorted == NULL) */

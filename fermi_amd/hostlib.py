@@ -238,6 +238,8 @@ def read_records_parallel(path, threads, span):
     while L.fmdh_pseq_next(r, C.byref(parts), C.byref(n_parts)) == 1:
         for k in range(n_parts.value):
             p = parts[k]
+            if p.n == 0:   # a cut guess that ran into the end of its span: no records, len never allocated
+                continue
             lens = np.ctypeslib.as_array(C.cast(p.len, C.POINTER(C.c_uint32)), (max(p.n, 1),))[: p.n]
             seq = C.string_at(p.seq, p.bytes) if p.bytes else b""
             qual = C.string_at(p.qual, p.bytes) if p.bytes else b""

@@ -245,7 +245,7 @@ int fmd_ovlp_batch(fmd_dev_t *h, size_t n, const uint64_t *ids, int min_match, u
  *                      (base - 1) in 2 bits, first base in the low bits -- or nt6 codes 2 per byte with PACK4 --
  *                      padded to 8 bytes; empty for rows with status != 0 or FMD_OVLP_F_OVERFLOW
  * d_off has n + 1 entries; rows that would end past var_cap are not written (compare d_off[n] with var_cap;
- * fmd_ovlp_pack_max_bytes is always enough).  seq_stride must be a multiple of 4. */
+ * fmd_ovlp_pack_max_bytes is always enough).  seq_stride must be a multiple of 8 (FMD_E_ARG otherwise). */
 size_t fmd_ovlp_pack_max_bytes(size_t n, uint32_t max_nei, uint32_t seq_stride);
 size_t fmd_ovlp_pack_work_bytes(size_t n);
 int fmd_ovlp_pack_dev(fmd_dev_t *h, void *stream, size_t n, const fmd_ovlp_rec_t *d_rec, const fmd_intv_t *d_nei, uint32_t max_nei,
