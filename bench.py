@@ -23,7 +23,7 @@ needs far fewer bytes per query.  roofline.traffic = PMC bytes from profiles/pmc
 when that file was measured on these kernel sources (sha of the leg's files in fermi_amd/csrc) at this size.
 
 Knobs: FMD_BENCH_READS (50_000_000), FMD_BENCH_BSEARCH_READS (10_000_000), FMD_BENCH_LEGS
-(overlap,check_left,bsearch,smem,kmer), FMD_BENCH_CPU_SAMPLE* (bounded CPU samples).
+(overlap,check_left,bsearch,smem,kmer,ecfix), FMD_BENCH_CPU_SAMPLE* (bounded CPU samples).
 """
 import argparse
 import ctypes as C
@@ -50,7 +50,7 @@ def log(*a):
 
 # the sources a leg's kernels are compiled from (besides the headers and the index layout, which every kernel depends on)
 LEG_SOURCES = {"overlap": ("fmd_ovlp.hip", "fmd_ovlp_grp.hip", "fmd_ovlp_sort.hip"), "overlap_raw": ("fmd_ovlp.hip", "fmd_ovlp_grp.hip", "fmd_ovlp_sort.hip"),
-               "check_left": ("fmd_pack.hip", "fmd_ovlp.hip"), "k_bsearch": ("fmd_ops.hip",), "smem": ("fmd_smem.hip",), "kmer": ("fmd_kmer.hip",)}
+               "check_left": ("fmd_pack.hip", "fmd_ovlp.hip"), "k_bsearch": ("fmd_ops.hip",), "smem": ("fmd_smem.hip",), "kmer": ("fmd_kmer.hip",), "ecfix": ("fmd_ecfix.hip",)}
 
 
 def csrc_sha(leg=None, read=None):
@@ -69,11 +69,12 @@ PMC_LIVE = {}     # leg key -> (bytes per step, source): measured by THIS run (p
 PROBE = {}        # the bare random-gather probe of this run (64-byte lines over 8 GiB): the ceiling that applies to a path made of random lines
 
 
-def pmc_in_run(fmd_path, n_reads, steps=2):
+def pmc_in_run(fmd_path, n_reads, steps=2, leg="overlap"):
     """roofline.traffic measured in the run that prints it: when rocprofv3 is on the box, two short child processes run `steps` steps of
     the headline leg (tools/pmc_legs.py on the .fmd this run wrote) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate
     passes, counters only, as MI355X_MICROARCH.md prescribes), a third runs the gather probe for the FETCH_SIZE calibration (known byte
-    count, 64-byte lines).  -> PMC_LIVE["overlap@n"], PMC_LIVE["check_left@n"]; on any failure the tracked look-up stays in place."""
+    count, 64-byte lines).  -> PMC_LIVE["overlap@n"], PMC_LIVE["check_left@n"] (leg "overlap") or PMC_LIVE["ecfix@n"] (leg "ecfix": k_ecfix over the
+    raw-read set, table harvested by the child from the raw .fmd); on any failure the tracked look-up stays in place."""
     import csv, glob, shutil, subprocess
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not exe or os.environ.get("FMD_BENCH_PMC", "1") == "0":
@@ -82,12 +83,13 @@ def pmc_in_run(fmd_path, n_reads, steps=2):
         return "not run (this process is itself being profiled)"
     t0 = time.time()
     out = tempfile.mkdtemp(prefix="fmd_pmc_")
-    env = dict(os.environ, TMPDIR="/tmp", PMC_LEGS="overlap", PMC_FMD=fmd_path, FMD_BENCH_READS=str(n_reads), PROBE_LINE="64")
+    env = dict(os.environ, TMPDIR="/tmp", PMC_LEGS=leg, FMD_BENCH_READS=str(n_reads), PROBE_LINE="64")
+    env["PMC_FMD_RAW" if leg == "ecfix" else "PMC_FMD"] = fmd_path     # (ecfix: the .fmd of the raw-read set; the child harvests its table from it)
     legs, probe = os.path.join(ROOT, "tools", "pmc_legs.py"), os.path.join(ROOT, "tools", "probe_once.py")
     try:
         for sub, ctr, script, args in (("f", "FETCH_SIZE", legs, [str(steps)]), ("w", "WRITE_SIZE", legs, [str(steps)]), ("p", "FETCH_SIZE", probe, [])):
             r = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(out, sub), "-o", "x", "--", sys.executable, script] + args,
-                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=120)
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=180)
             if r.returncode != 0:
                 return "failed (%s pass: rc %d: %s)" % (ctr, r.returncode, r.stderr.decode(errors="replace")[-200:].replace("\n", " "))
 
@@ -105,7 +107,8 @@ def pmc_in_run(fmd_path, n_reads, steps=2):
         cal = 2 * (1 << 27) * 64 / (pr["k_probe"] * 1024.0)      # probe_once: warm-up + one launch, 2^27 lines of 64 bytes each
         src = "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over %d steps of the leg on the index this run built; KB units, FETCH_SIZE x %.4f (gather probe, 64-byte lines, same run)" % (steps, cal)
         OVL = ("k_ovl_head_adm", "k_ovl_walk", "k_ovl_park_keys", "k_ovl_seq_out", "k_ovl_classify", "k_ovl_nei_fast", "k_ovl_nei_grp", "k_ovl_nei", "k_ovl_fix")
-        for key, names in (("overlap@%d" % n_reads, OVL), ("check_left@%d" % n_reads, ("k_link_rows", "k_link_edges", "k_ovl_cls"))):
+        legs_of = {"overlap": (("overlap@%d" % n_reads, OVL), ("check_left@%d" % n_reads, ("k_link_rows", "k_link_edges", "k_ovl_cls"))), "ecfix": (("ecfix@%d" % n_reads, ("k_ecfix",)),)}
+        for key, names in legs_of[leg]:
             fk = sum(v for k, v in fetch.items() if k in names) / steps
             wk = sum(v for k, v in write.items() if k in names) / steps
             if fk:
@@ -978,7 +981,154 @@ def bench_kmer(torch, api, index, n_sym, fmd_path, dev, local_rank, n_reads, ste
     out["cpu_baseline"] = base
     out["parity_vs_cpu_on_sample"] = "bit-exact" if ok else "MISMATCH"
     out["speedup_vs_cpu_all_cores"] = out["value"] / base["value"]
-    return out
+    del work
+    return out, {"w": w, "suf_len": suf_len, "n": n_out, "bucket": ob, "key": ok_, "val": ov}    # the table of the correction pass (bench_ecfix), resident
+
+
+# ------------------------------------------------------------------------------------------ the correction pass of `fermi correct`
+NT6_OF_ASCII = np.full(256, 5, dtype=np.uint8)
+for _ch, _v in zip(b"ACGTacgt", [1, 2, 3, 4, 1, 2, 3, 4]):
+    NT6_OF_ASCII[_ch] = _v
+
+
+def mark_corrected(orig_nt6, fixed_nt6, quals, info, max_corr=0.3):
+    """What the reference does with a read after its two ec_fix1 passes (correct.c:247-252), on n x L arrays: corrected bases in lower case with
+    quality 36, bit 16 of info when more than max_corr of the read changed or the score difference is <= 10.  -> (ASCII text, quals, info)"""
+    changed = orig_nt6 != fixed_nt6
+    text = np.where(changed, np.frombuffer(b"$acgtn", dtype=np.uint8)[fixed_nt6], np.frombuffer(b"$ACGTN", dtype=np.uint8)[orig_nt6])
+    q = np.where(changed, np.uint8(36), quals)
+    inf = info.astype(np.int64)
+    inf = np.where(changed.sum(axis=1) / float(orig_nt6.shape[1]) > np.float32(max_corr).astype(np.float64), inf | (1 << 16), inf)
+    inf = np.where((inf >> 18) <= 10, inf | (1 << 16), inf)
+    return text, q, inf.astype(np.int32)
+
+
+def ref_ec_lib():
+    drv = os.path.join(ROOT, "oracle", "_ref", "libref_ec.so")
+    if not os.path.exists(drv) or os.environ.get("FMD_BENCH_FORCE_PORT"):
+        return None
+    Lb = C.CDLL(drv)
+    if not hasattr(Lb, "refec_fix"):
+        return None
+    Lb.refec_fix.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    return Lb
+
+
+def cpu_ecfix(w, suf_len, step, trip, reads_nt6, quals):
+    """ec_fix (correct.c:222-256) of n x L reads on the host cores: the reference's own static function through oracle/_ref/libref_ec.so (its tables
+    filled from `trip` = (bucket, key, val) sorted by bucket) when it travelled, else the oracle's port + the marking rule.
+    -> (text, quals, info) after correct.c:247-252, rate on all cores, rate on one, look-ups per read, kind"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    cores = usable_cpus()
+    n, L = reads_nt6.shape
+    n1 = min(n, max(1000, n // 20))
+    B, K, V = trip
+    Lb = ref_ec_lib()
+    if Lb:
+        def run(m, thr):
+            txt = np.ascontiguousarray(np.frombuffer(b"$ACGTN", dtype=np.uint8)[reads_nt6[:m]])
+            q = np.ascontiguousarray(quals[:m]).copy()
+            info = np.zeros(m, dtype=np.int32)
+            secs, nq = C.c_double(), C.c_uint64()
+            rc = Lb.refec_fix(w, suf_len, step, 0.3, len(B), B.ctypes.data, K.ctypes.data, V.ctypes.data, m, L, txt.ctypes.data, q.ctypes.data, info.ctypes.data, thr,
+                              C.byref(secs), C.byref(nq))
+            assert rc == 0, "refec_fix: %d" % rc
+            return txt, q, info, secs.value, nq.value
+        _, _, _, t1, _ = run(n1, 1)
+        txt, q, info, tall, nq = run(n, cores)
+        kind = "reference"
+    else:
+        import orcbind
+        t0 = time.time(); orcbind.ec_fix(w, B, K, V, list(reads_nt6[:n1]), list(quals[:n1]), step); t1 = time.time() - t0   # (the oracle's batch form runs on one thread)
+        t0 = time.time(); s, q, off, info = orcbind.ec_fix(w, B, K, V, list(reads_nt6), list(quals), step); tall = time.time() - t0
+        txt, q, info = mark_corrected(reads_nt6, s.reshape(n, L), q.reshape(n, L), info)
+        cores, nq, kind = 1, 0, "port"
+    return (txt, q, info), n / tall, n1 / t1, nq / float(n), kind, cores
+
+
+def bench_ecfix(torch, api, rd, tab, n_sym, dev, local_rank, n_reads, L, steps, warmup, raw_fmd_path):
+    """configs[2], the second half of `fermi correct`: ec_fix (correct.c:121-256) of every read of the raw-read set against the solid k-mer table the
+    harvest leg has just built (resident, fmd_ectab_build_dev), qualities 'I' (SURVEY 8(d)), step 5 (the CLI's default).  The kernel rewrites bases and
+    qualities in place, so every step (warm-up included) gets its own copy of the reads, made before the clock starts."""
+    lib = api.lib()
+    stream = torch.cuda.current_stream()
+    sh = C.c_void_p(stream.cuda_stream)
+    step_sz = int(os.environ.get("FMD_BENCH_EC_STEP", "5"))
+    trace_cap = int(os.environ.get("FMD_BENCH_EC_TRACE", "1024"))
+    t = C.c_void_p()
+    api.check(lib.fmd_ectab_build_dev(local_rank, sh, tab["w"], tab["suf_len"], tab["n"], tab["bucket"].data_ptr(), tab["key"].data_ptr(), tab["val"].data_ptr(), C.byref(t)))
+    torch.cuda.synchronize()
+    nb = n_reads * L
+    ncopy = steps + warmup
+    seqs = [rd.flat.clone() for _ in range(ncopy)]
+    quals = [torch.full((nb + 64,), ord("I"), dtype=torch.uint8, device=dev) for _ in range(ncopy)]
+    info = torch.zeros(n_reads, dtype=torch.int32, device=dev)
+    wb = lib.fmd_ecfix_work_bytes(t, n_reads, trace_cap)
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    turn = [0]
+
+    def step(Lb=None, tt=None):
+        k = turn[0] % ncopy
+        turn[0] += 1
+        api.check((Lb or lib).fmd_ecfix_dev(tt or t, sh, n_reads, seqs[k].data_ptr(), quals[k].data_ptr(), rd.off.data_ptr(), step_sz, trace_cap, info.data_ptr(), work.data_ptr(), wb))
+    try:
+        wall, kern_ms = timed(torch, None, dev, stream, step, steps, warmup)
+        last = (turn[0] - 1) % ncopy
+        g_info = info.cpu().numpy()
+        n_full = int((g_info == -2147483648).sum())
+        changed = int((seqs[last][:nb] != rd.flat[:nb]).sum().item())
+        out = {"metric": "reads/sec through ec_fix (the correction pass of fermi correct, correct.c:121-256), k=%d, step %d, reads with 1 %% substitutions, quality 'I'" % (tab["w"], step_sz),
+               "value": n_reads * steps / wall, "unit": "reads/s", "ms_per_step": wall / steps * 1e3, "solid_kmers_in_the_table": tab["n"], "bases_changed": changed,
+               "reads_flagged_unfixable_by_the_kernel_word": int(((g_info >> 16) & 1).sum()), "trace_cap": trace_cap,
+               "reads_whose_trace_overflowed": n_full,    # (the host form runs these again with a longer trace: fmd_ecfix_batch)
+               "table_bytes": int(8 * (1 << max(10, int(np.ceil(np.log2(max(2 * tab["n"], 1))))))), "work_bytes": int(wb)}
+        # ---- device bytes of one step: what the instrumented build counts (table slots probed, queue and trace entries moved) + the read / quality / info streams
+        counts = None
+        Lc = api.count_lib()
+        if Lc is not None:
+            tc = C.c_void_p()
+            if Lc.fmd_ectab_build_dev(local_rank, sh, tab["w"], tab["suf_len"], tab["n"], tab["bucket"].data_ptr(), tab["key"].data_ptr(), tab["val"].data_ptr(), C.byref(tc)) == 0:
+                buf, cnt = (C.c_uint64 * 3)(), C.c_int(0)
+                seqs[0].copy_(rd.flat); quals[0].fill_(ord("I")); turn[0] = 0
+                Lc.fmd_ectab_line_count(tc, buf, 1, C.byref(cnt))
+                step(Lc, tc)
+                if Lc.fmd_ectab_line_count(tc, buf, 1, C.byref(cnt)) == 0 and cnt.value:
+                    counts = [int(buf[0]), int(buf[1]), int(buf[2])]
+                Lc.fmd_ectab_free(tc)
+        io = n_reads * (2 * L + 8 + 4) + 2 * changed
+        dev_bytes = None if counts is None else counts[0] * 8 + counts[1] * 16 + counts[2] * 8 + io
+        # ---- the reference on a sample of the reads: bases, qualities and info after the marking of correct.c:247-252
+        ns = min(n_reads, int(os.environ.get("FMD_BENCH_CPU_SAMPLE_ECFIX", "400000")))
+        sel = np.sort(np.random.default_rng(8).choice(n_reads, ns, replace=False))
+        sel_d = torch.from_numpy(sel).to(dev)
+        orig = rd.flat[:nb].view(n_reads, L)[sel_d].cpu().numpy()
+        g_s = seqs[last][:nb].view(n_reads, L)[sel_d].cpu().numpy()
+        g_q = quals[last][:nb].view(n_reads, L)[sel_d].cpu().numpy()
+        keep = g_info[sel] != -2147483648
+        g_txt, g_q2, g_inf = mark_corrected(orig, g_s, g_q, g_info[sel])
+        order = torch.argsort(tab["bucket"][: tab["n"]].to(torch.int64), stable=True)
+        trip = (tab["bucket"][: tab["n"]][order].cpu().numpy().view(np.uint32), tab["key"][: tab["n"]][order].cpu().numpy().view(np.uint32), tab["val"][: tab["n"]][order].cpu().numpy())
+        del order
+        (r_txt, r_q, r_inf), rate, rate1, lpr, kind, cores = cpu_ecfix(tab["w"], tab["suf_len"], step_sz, trip, orig, np.full((ns, L), ord("I"), dtype=np.uint8))
+        ok = bool(np.array_equal(g_txt[keep], r_txt[keep]) and np.array_equal(g_q2[keep], r_q[keep]) and np.array_equal(g_inf[keep], r_inf[keep]))
+        out["cpu_baseline"] = baseline_obj(rate, "reads/s", cores, kind, "a random sample of %d reads of the set against the whole table (%d solid k-mers), %d host threads: the reference's own "
+                                           "ec_fix with its read k -> thread k mod n interleave" % (ns, tab["n"], cores), rate1)
+        out["parity_vs_cpu_on_sample"] = ("bit-exact (bases, qualities and info words of %d reads after the marking of correct.c:247-252; %d bases corrected among them, %d reads marked bad)"
+                                          % (int(keep.sum()), int((g_txt[keep] >= ord("a")).sum()), int(((g_inf[keep] >> 16) & 1).sum()))) if ok else "MISMATCH"
+        out["speedup_vs_cpu_all_cores"] = out["value"] / rate
+        lookups = lpr * n_reads if lpr else (counts[0] if counts else 0)
+        out["roofline"] = roofline("k_ecfix", kern_ms, dev_bytes,
+                                   {"table_slots_probed": counts and counts[0], "queue_entries_moved": counts and counts[1], "trace_entries_moved": counts and counts[2], "stream_bytes": io,
+                                    "streams": "8 B per slot probed, 16 B per queue entry read or written, 8 B per trace entry; reads + qualities read, changed bytes written, offsets, info"},
+                                   lookups * 2 * 8.0, "ecfix@%d" % n_reads,
+                                   {"table_lookups_per_read_in_the_reference": lpr or None,
+                                    "algorithmic_definition": "the reference's khash look-up is two dependent loads (flags word, key/value) per kh_get: 2 x 8 B x look-ups counted by the reference's own n_query on the sample; "
+                                                              "SURVEY 8(d) prices rank queries and this pass makes none",
+                                    "note": "one lane per read: a best-first search over <= 256 paths kept in the lane's slice of HBM; the table is one random 8-byte load per look-up"})
+        return out
+    finally:
+        lib.fmd_ectab_free(t)
 
 
 def bench_raw_reads(torch, api, workload, dev, local_rank, n_reads, L, steps, warmup, legs):
@@ -994,13 +1144,24 @@ def bench_raw_reads(torch, api, workload, dev, local_rank, n_reads, L, steps, wa
     index = api.DevIndex.from_bwt_dev(d_bwt, n_sym, local_rank)
     api.lib().fmd_dev_free(d_bwt)
     log("raw-read index: %d reads at e=%g, %d symbols, %.1fs" % (n_reads, err, n_sym, time.time() - t0))
-    sm = km = raw = None
+    sm = km = raw = ec = None
     try:
         if "smem" in legs:
             sm = bench_smem(torch, api, index, rd, err, n_sym, fmd_path, dev, local_rank, n_reads, L, steps, warmup)
             torch.cuda.empty_cache()
-        if "kmer" in legs:
-            km = bench_kmer(torch, api, index, n_sym, fmd_path, dev, local_rank, n_reads, steps, warmup)
+        if "kmer" in legs or "ecfix" in legs:
+            km, tab = bench_kmer(torch, api, index, n_sym, fmd_path, dev, local_rank, n_reads, steps, warmup)
+            torch.cuda.empty_cache()
+            if "ecfix" in legs:
+                ec = bench_ecfix(torch, api, rd, tab, n_sym, dev, local_rank, n_reads, L, steps, min(warmup, 1), fmd_path)
+                if os.environ.get("FMD_BENCH_PMC", "1") != "0" and "roofline" in ec:
+                    del tab
+                    torch.cuda.empty_cache()
+                    note = pmc_in_run(fmd_path, n_reads, leg="ecfix")
+                    log("in-run PMC pass (ecfix): %s" % note)
+                    apply_traffic(ec["roofline"])
+                    ec["pmc_in_run"] = note
+            tab = None
             torch.cuda.empty_cache()
         if "overlap" in legs and os.environ.get("FMD_BENCH_RAW_OVERLAP", "1") != "0":
             raw = bench_overlap_raw(torch, api, index, dev, n_reads, L, err, fmd_path)
@@ -1008,7 +1169,7 @@ def bench_raw_reads(torch, api, workload, dev, local_rank, n_reads, L, steps, wa
         if os.path.exists(fmd_path):
             os.remove(fmd_path)
         index.close()
-    return sm, km, raw
+    return sm, km, raw, ec
 
 
 def bench_overlap_raw(torch, api, index, dev, n_reads, L, err, fmd_path):
@@ -1147,6 +1308,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # launched plainly (`python bench.py --gpus N`): this process becomes the launcher -- N ranks of this same file through torch.distributed.run
+        # (one per GPU, rendezvous on 127.0.0.1 at a free port), their stdout (rank 0's one JSON line) and stderr passed through, its exit code returned:
+        # non-zero as soon as any rank fails (torch.distributed.run tears the others down)
+        import socket
+        import subprocess
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+        log("bench.py: --gpus %d without a launcher: %s" % (args.gpus, " ".join(cmd[1:])))
+        sys.exit(subprocess.call(cmd, env=env))
     import torch
     from fermi_amd import api, workload
 
@@ -1154,7 +1328,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        log("bench.py: --gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+        log("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
         sys.exit(2)
     dist = None
     if world > 1:
@@ -1178,7 +1352,7 @@ def main():
 
     n_reads = int(os.environ.get("FMD_BENCH_READS", "50000000"))
     L = 100
-    legs = os.environ.get("FMD_BENCH_LEGS", "overlap,check_left,bsearch,smem,kmer" if world == 1 else "overlap").split(",")
+    legs = os.environ.get("FMD_BENCH_LEGS", "overlap,check_left,bsearch,smem,kmer,ecfix" if world == 1 else "overlap").split(",")
 
     # ---- untimed set-up: synthetic reads in HBM -> GPU index build -> (rank 0, N = 1) .fmd -> drop-in loader.
     # Every rank builds the same index from the same reads: the full index is replicated, nothing is shared.
@@ -1234,14 +1408,14 @@ def main():
     if fmd_path and os.path.exists(fmd_path):
         os.remove(fmd_path)
 
-    bs = sm = km = raw_ovl = None
+    bs = sm = km = raw_ovl = ec = None
     if rank == 0 and world == 1:
         k2, w2 = max(1, min(args.steps, 5)), min(args.warmup, 1)
         if "bsearch" in legs:
             bs = bench_bsearch(torch, api, workload, dev, local_rank, k2, w2)
             torch.cuda.empty_cache()
-        if "smem" in legs or "kmer" in legs:
-            sm, km, raw_ovl = bench_raw_reads(torch, api, workload, dev, local_rank, n_reads, L, max(1, min(args.steps, 3)), w2, legs)
+        if "smem" in legs or "kmer" in legs or "ecfix" in legs:
+            sm, km, raw_ovl, ec = bench_raw_reads(torch, api, workload, dev, local_rank, n_reads, L, max(1, min(args.steps, 3)), w2, legs)
 
     if rank == 0:
         out = {
@@ -1276,6 +1450,8 @@ def main():
             out["smem"] = sm
         if km:
             out["kmer_harvest"] = km
+        if ec:
+            out["ec_fix"] = ec
         if raw_ovl:
             out["overlap_discovery_on_raw_reads"] = raw_ovl
         if pmc_note:

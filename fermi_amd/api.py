@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "fmd_dev_malloc", "fmd_memcpy_h2d", "fmd_memcpy_d2h",
     "fmd_smem_work_bytes", "fmd_smem_dev", "fmd_smem_batch", "fmd_smem_win_dev", "fmd_smem_win_batch", "fmd_reach_dev", "fmd_reach_batch", "fmd_dev_export_bwt", "fmd_dev_check_rank",
     "fmd_kmer_work_bytes", "fmd_kmer_collect_dev", "fmd_kmer_collect_part_dev", "fmd_kmer_collect", "fmd_kmer_collect_seeds",
-    "fmd_ectab_build_dev", "fmd_ectab_build", "fmd_ectab_free", "fmd_ecfix_work_bytes", "fmd_ecfix_dev", "fmd_ecfix_batch",
+    "fmd_ectab_build_dev", "fmd_ectab_build", "fmd_ectab_free", "fmd_ecfix_work_bytes", "fmd_ecfix_dev", "fmd_ecfix_batch", "fmd_ectab_line_count",
     "fmd_ovlp_work_bytes", "fmd_ovlp_dev", "fmd_ovlp_sorted_work_bytes", "fmd_ovlp_sorted_dev", "fmd_ovlp_batch", "fmd_ovlp_check_left_dev", "fmd_seqinfo_dev", "fmd_seqinfo_batch",
     "fmd_ovlp_pack_max_bytes", "fmd_ovlp_pack_work_bytes", "fmd_ovlp_pack_dev", "fmd_ovlp_packed_batch", "fmd_ovlp_packed_free", "fmd_table_alloc", "fmd_table_free", "fmd_ovlp_link_dev", "fmd_ovlp_packed_table",
     "fmd_ovlp_two_pass_ok", "fmd_ovlp_head_work_bytes", "fmd_ovlp_head_dev", "fmd_ovlp_tail_dev", "fmd_ovlp_pack_rows_dev",
@@ -126,6 +126,7 @@ def _configure(L):
     L.fmd_ecfix_work_bytes.restype = sz; L.fmd_ecfix_work_bytes.argtypes = [vp, sz, C.c_uint32]
     L.fmd_ecfix_dev.argtypes = [vp, vp, sz, vp, vp, u64p, C.c_int, C.c_uint32, vp, vp, sz]
     L.fmd_ecfix_batch.argtypes = [vp, sz, vp, vp, u64p, C.c_int, vp]
+    L.fmd_ectab_line_count.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
     L.fmd_ovlp_packed_batch.argtypes = [vp, vp, C.c_uint64, C.c_uint64, sz, C.c_int, C.c_uint32, C.c_uint32, C.c_int, vp, vp, C.c_uint32, vp]
     L.fmd_ovlp_link_dev.argtypes = [vp, vp, sz, vp, vp, C.c_uint32, vp, vp, vp, vp]
     L.fmd_ovlp_packed_table.argtypes = [vp, sz, C.c_int, C.c_uint32, C.c_uint32, vp, vp, C.c_uint32, vp, vp, vp, C.POINTER(vp), C.POINTER(C.c_uint64)]

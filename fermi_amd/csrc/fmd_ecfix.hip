@@ -42,6 +42,20 @@ struct fmd_ectab {
 // k_ectab_fill does not store it -- it would read as an empty slot and the solid k-mer as a miss -- but raises queue[EC_FULL_FLAG],
 // and a look-up of that k-mer that runs into an empty slot answers from the flag.
 #define EC_FULL_FLAG 1
+// queue + EC_STAT_U32 (as u64[3]): the instrumented build's counters (-DFMD_COUNT_LINES=1, libfmdhip_count.so; fmd_ectab_line_count): table slots
+// probed (8 bytes each), queue entries read or written (16 bytes each), trace entries read or written (8 bytes each)
+#define EC_STAT_U32 4
+struct EcCount {
+#if FMD_COUNT_LINES
+    unsigned long long c[3];
+    __device__ __forceinline__ EcCount() { c[0] = c[1] = c[2] = 0; }
+    __device__ __forceinline__ void add(int kind, int n = 1) { c[kind] += (unsigned long long)n; }
+    __device__ __forceinline__ void flush(uint32_t *queue) { for (int k = 0; k < 3; ++k) if (c[k]) atomicAdd((unsigned long long *)(queue + EC_STAT_U32) + k, c[k]); }
+#else
+    __device__ __forceinline__ void add(int, int = 1) {}
+    __device__ __forceinline__ void flush(uint32_t *) {}
+#endif
+};
 
 __device__ __forceinline__ uint64_t ec_hash(uint64_t x)   // splitmix64 finaliser: the k-mers of a genome are anything but uniform
 {
@@ -69,11 +83,12 @@ __global__ void k_ectab_fill(uint64_t n, int suf_len, const uint32_t *__restrict
 }
 
 // kh_get(solid, h, key) of correct.c:156-157: -1, or val << 2 | best base
-__device__ __forceinline__ int ec_lookup(const uint64_t *__restrict__ slots, uint64_t mask, uint64_t x, bool full)
+__device__ __forceinline__ int ec_lookup(const uint64_t *__restrict__ slots, uint64_t mask, uint64_t x, bool full, EcCount &C)
 {
     uint64_t p = ec_hash(x) & mask;
     for (;;) {
         const uint64_t e = slots[p];
+        C.add(0);
         if (e == EC_EMPTY) return (full && x == (EC_EMPTY >> 10)) ? 0x3ff : -1;
         if ((e >> 10) == x) return (int)(e & 0x3ff);
         p = (p + 1) & mask;
@@ -83,21 +98,25 @@ __device__ __forceinline__ int ec_lookup(const uint64_t *__restrict__ slots, uin
 struct EcNode { uint64_t x; int64_t y; };
 
 // binary min-heap on y in the lane's slice (any queue gives the reference's order: the keys are distinct)
-__device__ __forceinline__ void ec_push(uint4 *heap, uint32_t &hn, uint64_t x, int64_t y)
+__device__ __forceinline__ void ec_push(uint4 *heap, uint32_t &hn, uint64_t x, int64_t y, EcCount &C)
 {
     uint32_t k = hn++;
+    C.add(1);
     while (k) {
         const uint32_t p = (k - 1) >> 1;
         const uint4 v = heap[p];
+        C.add(1);
         const int64_t py = (int64_t)((uint64_t)v.w << 32 | v.z);
         if (py <= y) break;
         heap[k] = v; k = p;
+        C.add(1);
     }
     heap[k] = make_uint4((uint32_t)x, (uint32_t)(x >> 32), (uint32_t)(uint64_t)y, (uint32_t)((uint64_t)y >> 32));
 }
-__device__ __forceinline__ EcNode ec_pop(uint4 *heap, uint32_t &hn)
+__device__ __forceinline__ EcNode ec_pop(uint4 *heap, uint32_t &hn, EcCount &C)
 {
     const uint4 top = heap[0];
+    C.add(1, 3);    // the top, the last entry, the entry written back at the end
     EcNode r; r.x = (uint64_t)top.y << 32 | top.x; r.y = (int64_t)((uint64_t)top.w << 32 | top.z);
     const uint4 last = heap[--hn];
     const int64_t ly = (int64_t)((uint64_t)last.w << 32 | last.z);
@@ -107,13 +126,16 @@ __device__ __forceinline__ EcNode ec_pop(uint4 *heap, uint32_t &hn)
         if (c >= hn) break;
         uint4 cv = heap[c];
         int64_t cy = (int64_t)((uint64_t)cv.w << 32 | cv.z);
+        C.add(1);
         if (c + 1 < hn) {
             const uint4 dv = heap[c + 1];
+            C.add(1);
             const int64_t dy = (int64_t)((uint64_t)dv.w << 32 | dv.z);
             if (dy < cy) { cv = dv; cy = dy; ++c; }
         }
         if (ly <= cy) break;
         heap[i] = cv; i = c;
+        C.add(1);
     }
     if (hn) heap[i] = last;
     return r;
@@ -131,7 +153,7 @@ struct EcRead {
 
 // a new path: `par` extended by base code c (0..3; an N in the read is followed as A, correct.c:101) at a cost
 __device__ __forceinline__ bool ec_branch(uint4 *heap, uint32_t &hn, uint64_t *trace, uint32_t &tn, uint32_t trace_cap, const EcNode &par, int c, int cost,
-                                          int shift, int has_match)
+                                          int shift, int has_match, EcCount &C)
 {
     if (tn >= trace_cap) return false;
     if (cost < 0) cost = 0;
@@ -139,7 +161,8 @@ __device__ __forceinline__ bool ec_branch(uint4 *heap, uint32_t &hn, uint64_t *t
     const uint64_t py = (uint64_t)par.y, left = (py & 0xffff) - 1;
     const uint64_t y = ((py >> 48) + (uint64_t)cost) << 48 | (uint64_t)tn << 16 | left;
     trace[tn++] = left << 32 | (uint64_t)((uint32_t)c << 29 | (uint32_t)has_match << 28 | (uint32_t)(py >> 16)); // position | base | matched | parent
-    ec_push(heap, hn, (uint64_t)c << shift | par.x >> 2, (int64_t)y);
+    C.add(2);
+    ec_push(heap, hn, (uint64_t)c << shift | par.x >> 2, (int64_t)y, C);
     return true;
 }
 
@@ -165,7 +188,7 @@ struct EcSearch {
 };
 enum { EC_MORE = 0, EC_DONE = 1, EC_FULL = 2 };
 
-__device__ __forceinline__ bool ec_seed(const EcRead &r, int w, EcSearch &S, uint4 *heap, uint64_t *trace)   // false: ec_fix1 returns 0xffff
+__device__ __forceinline__ bool ec_seed(const EcRead &r, int w, EcSearch &S, uint4 *heap, uint64_t *trace, EcCount &C)   // false: ec_fix1 returns 0xffff
 {
     const int shift = (w - 1) << 1;
     if (r.len <= w) return false;
@@ -179,16 +202,17 @@ __device__ __forceinline__ bool ec_seed(const EcRead &r, int w, EcSearch &S, uin
     if (i == 0) return false;
     S.hn = 0; S.tn = 0; S.n_done = 0; S.no_hits = 1; S.done_y[0] = S.done_y[1] = 0;
     trace[S.tn++] = 0;
-    ec_push(heap, S.hn, x, (int64_t)(i + 1));
+    C.add(2);
+    ec_push(heap, S.hn, x, (int64_t)(i + 1), C);
     return true;
 }
 
 __device__ __forceinline__ int ec_expand(const EcRead &r, int w, int step, const uint64_t *__restrict__ slots, uint64_t mask, bool full, EcSearch &S, uint4 *heap,
-                                         uint64_t *trace, uint32_t trace_cap)
+                                         uint64_t *trace, uint32_t trace_cap, EcCount &C)
 {
     const int shift = (w - 1) << 1;
     if (S.hn == 0) return EC_DONE;
-    EcNode z = ec_pop(heap, S.hn);
+    EcNode z = ec_pop(heap, S.hn, C);
     const uint64_t zy = (uint64_t)z.y;
     if ((zy & 0xffff) == 0) {                                // a path that reached the start of the strand
         S.done_y[S.n_done++] = z.y;
@@ -200,16 +224,16 @@ __device__ __forceinline__ int ec_expand(const EcRead &r, int w, int step, const
     int q = r.qual(i) - 33;
     q = q < EC_MAX_QUAL ? q : EC_MAX_QUAL;
     q = q < 3 ? 3 : q;
-    const int hit = ec_lookup(slots, mask, z.x, full);
+    const int hit = ec_lookup(slots, mask, z.x, full, C);
     bool ok = true;
-    if (hit < 0) ok = ec_branch(heap, S.hn, trace, S.tn, trace_cap, z, b - 1, EC_MISS_PENALTY + (EC_MAX_QUAL - q), shift, 0);
+    if (hit < 0) ok = ec_branch(heap, S.hn, trace, S.tn, trace_cap, z, b - 1, EC_MISS_PENALTY + (EC_MAX_QUAL - q), shift, 0, C);
     else {
         const int best = (hit & 3) + 1, v = hit >> 2;
         S.no_hits = 0;
         if (b != best) {                                     // the table prefers another base: follow both, within the queue's budget
             const int pen = ec_swap_penalty(v);
-            if (b != 5 && (S.hn + 2 <= EC_MAX_HEAP || pen < q)) ok = ec_branch(heap, S.hn, trace, S.tn, trace_cap, z, b - 1, pen, shift, 1);
-            if (ok && (b == 5 || S.hn + 2 <= EC_MAX_HEAP || pen > q)) ok = ec_branch(heap, S.hn, trace, S.tn, trace_cap, z, best - 1, q, shift, 1);
+            if (b != 5 && (S.hn + 2 <= EC_MAX_HEAP || pen < q)) ok = ec_branch(heap, S.hn, trace, S.tn, trace_cap, z, b - 1, pen, shift, 1, C);
+            if (ok && (b == 5 || S.hn + 2 <= EC_MAX_HEAP || pen > q)) ok = ec_branch(heap, S.hn, trace, S.tn, trace_cap, z, best - 1, q, shift, 1, C);
         } else {                                             // agreement: hop `step` bases at a time while the k-mers stay deep and unambiguous
             EcNode keep = z;
             int keep_i = i, depth_last = ec_depth(v);
@@ -219,7 +243,7 @@ __device__ __forceinline__ int ec_expand(const EcRead &r, int w, int step, const
                         z.x = (uint64_t)(r.base(i) - 1) << shift | z.x >> 2;
                     const int bi = r.base(i);
                     if (bi == 5) break;
-                    const int h2 = ec_lookup(slots, mask, z.x, full);
+                    const int h2 = ec_lookup(slots, mask, z.x, full, C);
                     if (h2 < 0 || bi != (h2 & 3) + 1) break;
                     const int v2 = h2 >> 2, depth = ec_depth(v2);
                     if (!((v2 & 7) <= 1 && depth >= EC_MIN_OCC && (double)depth / depth_last >= EC_MIN_OCC_RATIO)) break;
@@ -227,13 +251,13 @@ __device__ __forceinline__ int ec_expand(const EcRead &r, int w, int step, const
                     keep = z; keep_i = i; depth_last = depth;
                 }
             }
-            ok = ec_branch(heap, S.hn, trace, S.tn, trace_cap, keep, r.base(keep_i) - 1, 0, shift, 1);
+            ok = ec_branch(heap, S.hn, trace, S.tn, trace_cap, keep, r.base(keep_i) - 1, 0, shift, 1, C);
         }
     }
     return ok ? EC_MORE : EC_FULL;
 }
 
-__device__ __forceinline__ int ec_close(EcRead &r, const EcSearch &S, const uint64_t *trace)   // ec_fix1's return value; the read is rewritten
+__device__ __forceinline__ int ec_close(EcRead &r, const EcSearch &S, const uint64_t *trace, EcCount &C)   // ec_fix1's return value; the read is rewritten
 {
     int score_diff = S.n_done == 1 ? EC_MAX_SC_DIFF : (int)((uint64_t)S.done_y[1] >> 48) - (int)((uint64_t)S.done_y[0] >> 48);
     if (score_diff >= EC_MAX_SC_DIFF) score_diff = EC_MAX_SC_DIFF;
@@ -241,6 +265,7 @@ __device__ __forceinline__ int ec_close(EcRead &r, const EcSearch &S, const uint
     int qsum = 0;
     for (uint32_t t = (uint32_t)((uint64_t)S.done_y[0] >> 16); t;) {       // apply the best path's choices
         const uint64_t e = trace[t];
+        C.add(2);
         const int pos = (int)(e >> 32);
         const uint32_t lo = (uint32_t)e, c = lo >> 29;
         if ((uint32_t)(r.base(pos) - 1) != c) { qsum += r.qual(pos) - 33; r.set_base(pos, (int)c + 1); }
@@ -266,6 +291,7 @@ __global__ __launch_bounds__(64) void k_ecfix(size_t n, uint8_t *__restrict__ se
     bool busy = false, drained = false;
     const bool full = queue[EC_FULL_FLAG] != 0;   // the one triple the table cannot hold (EC_FULL_FLAG)
     FmdTickets tk;
+    EcCount C;
     fmd_tickets_init(tk, queue);
     for (;;) {
         const size_t my = fmd_tickets_take(tk, queue, !busy && !drained);
@@ -273,20 +299,20 @@ __global__ __launch_bounds__(64) void k_ecfix(size_t n, uint8_t *__restrict__ se
             if (my < n) {
                 cur = my;
                 r.s = seqs + off[my]; r.q = quals + off[my]; r.len = (int)(off[my + 1] - off[my]); r.rc = true;
-                if (ec_seed(r, w, S, heap, trace)) busy = true;
+                if (ec_seed(r, w, S, heap, trace, C)) busy = true;
                 else info[my] = 0xffff;                                    // too short, or no clean k-mer (correct.c:242-246)
             } else drained = true;
         }
-        if (__ballot(busy) == 0) { if (__ballot(!drained) == 0) break; else continue; }
+        if (__ballot(busy) == 0) { if (__ballot(!drained) == 0) { C.flush(queue); break; } else continue; }
         if (!busy) continue;
-        const int st = ec_expand(r, w, step, slots, mask, full, S, heap, trace, trace_cap);
+        const int st = ec_expand(r, w, step, slots, mask, full, S, heap, trace, trace_cap, C);
         if (st == EC_MORE) continue;
         if (st == EC_FULL) { info[cur] = (int32_t)EC_INFO_TRACE_FULL; busy = false; continue; }
-        int ret = ec_close(r, S, trace);
+        int ret = ec_close(r, S, trace, C);
         if (r.rc) {                                                        // the reverse-complement strand is done: now the read as given
             ret0 = ret;
             r.rc = false;
-            if (ec_seed(r, w, S, heap, trace)) continue;
+            if (ec_seed(r, w, S, heap, trace, C)) continue;
             ret = 0xffff;                                                  // no clean k-mer at this end: ec_fix1 returns 0xffff and ec_fix combines it all the same
         }
         {
@@ -306,6 +332,21 @@ extern "C" void fmd_ectab_free(fmd_ectab_t *t)
     hipFree(t->slots); hipFree(t->queue);
     for (int i = 0; i < 5; ++i) if (t->buf[i]) hipFree(t->buf[i]);
     free(t);
+}
+
+// What the kernels launched on this table requested since the last reset -- {table slots probed, queue entries moved, trace entries moved} --
+// when the library is the instrumented build (*counting = 1; zeros otherwise).  Synchronises the device.
+extern "C" int fmd_ectab_line_count(fmd_ectab_t *t, uint64_t counts[3], int reset, int *counting)
+{
+    if (!t || !counts) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(t->device));
+    FMD_HIP_TRY(hipDeviceSynchronize());
+    uint32_t host[16];
+    FMD_HIP_TRY(hipMemcpy(host, t->queue, sizeof(host), hipMemcpyDeviceToHost));
+    memcpy(counts, host + EC_STAT_U32, 24);
+    if (reset) FMD_HIP_TRY(hipMemset(t->queue + EC_STAT_U32, 0, 24));
+    if (counting) *counting = FMD_COUNT_LINES;
+    return FMD_OK;
 }
 
 extern "C" int fmd_ectab_build_dev(int device, void *stream_, int w, int suf_len, uint64_t n, const uint32_t *d_bucket, const uint32_t *d_key,

@@ -437,6 +437,9 @@ size_t fmd_ecfix_work_bytes(const fmd_ectab_t *t, size_t n, uint32_t trace_cap);
 int fmd_ecfix_dev(fmd_ectab_t *t, void *stream, size_t n, uint8_t *d_seqs, uint8_t *d_quals, const uint64_t *d_off, int step, uint32_t trace_cap,
                   int32_t *d_info, void *d_work, size_t work_bytes);
 int fmd_ecfix_batch(fmd_ectab_t *t, size_t n, uint8_t *seqs, uint8_t *quals, const uint64_t *off, int step, int32_t *info);
+/* what the kernels launched on the table requested since the last reset: {table slots probed (8 B each), queue entries moved (16 B), trace entries
+ * moved (8 B)} -- counted by the instrumented build only (*counting = 1; the shipped library answers zeros and *counting = 0), like fmd_dev_line_count */
+int fmd_ectab_line_count(fmd_ectab_t *t, uint64_t counts[3], int reset, int *counting);
 
 /* ---- fm6_retrieve (exact.c:100-127) in bulk: rank, `$read$` bi-interval and containment of each
  * sequence id (rec.rank, rec.k[], rec.status = -3 when contained, rec.len); no length threshold,

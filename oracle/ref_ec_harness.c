@@ -108,3 +108,86 @@ int refec_range(const char *fn, int w, int min_occ, int suf_len, int b0, int b1,
     return 0;
 }
 void refec_free(void *p) { free(p); }
+
+/* Bench/parity driver for the correction pass: the reference's own ec_fix (correct.c:222-256, static) over n reads of len bases each, on n_threads
+ * threads with the reference's interleave (read k -> thread k % n_threads, correct.c:444-446).  The `solid` tables are filled from (bucket, key, val)
+ * triples SORTED BY BUCKET (what ec_collect would have put there, correct.c:71-75: the product's harvest, itself checked against ec_collect on a bucket
+ * sample) -- a look-up depends on the tables' content only, not on the insertion order.  seqs: ASCII bases, quals: phred + 33, both n x len, rewritten in
+ * place as ec_fix leaves them (corrected bases in lower case, their quality 36); info[n].  *secs = wall seconds of the ec_fix threads alone, *n_query =
+ * the table look-ups they made. */
+typedef struct { const fmecopt_t *opt; shash_t *const *solid; const uint32_t *B, *K; const uint8_t *V; uint64_t t0, t1; } rf_fill_t;
+static void *rf_fill(void *d)
+{
+    rf_fill_t *f = (rf_fill_t *)d;
+    uint64_t i;
+    for (i = f->t0; i < f->t1; ++i) {
+        int absent;
+        shash_t *h = (shash_t *)f->solid[f->B[i]];
+        khint_t k = kh_put(solid, h, f->K[i], &absent);
+        kh_val(h, k) = f->V[i];
+    }
+    return 0;
+}
+int refec_fix(int w, int suf_len, int step, double max_corr, uint64_t n_trip, const uint32_t *B, const uint32_t *K, const uint8_t *V,
+              int n, int len, char *seqs, char *quals, int *info, int n_threads, double *secs, uint64_t *n_query)
+{
+    fmecopt_t opt;
+    shash_t **solid;
+    pthread_t *tid;
+    worker2_t *w2;
+    rf_fill_t *ff;
+    int j, t;
+    uint64_t i;
+    double t0;
+    memset(&opt, 0, sizeof(opt));
+    opt.w = w; opt.min_occ = 3; opt.max_corr = (float)max_corr; opt.step = step;
+    compute_SUF(suf_len);
+    for (i = 1; i < n_trip; ++i) if (B[i] < B[i - 1]) return -2;                 /* not sorted by bucket */
+    if (n_trip && B[n_trip - 1] >= (uint32_t)SUF_NUM) return -3;
+    solid = calloc(SUF_NUM, sizeof(void *));
+    for (j = 0; j < SUF_NUM; ++j) solid[j] = kh_init(solid);
+    tid = calloc(n_threads, sizeof(pthread_t));
+    ff = calloc(n_threads, sizeof(rf_fill_t));
+    for (t = 0; t < n_threads; ++t) {                                             /* the fill, by ranges of whole buckets */
+        uint64_t a = n_trip * (uint64_t)t / n_threads, b = n_trip * (uint64_t)(t + 1) / n_threads;
+        while (a > 0 && a < n_trip && B[a] == B[a - 1]) ++a;
+        while (b > 0 && b < n_trip && B[b] == B[b - 1]) ++b;
+        ff[t].opt = &opt; ff[t].solid = solid; ff[t].B = B; ff[t].K = K; ff[t].V = V; ff[t].t0 = a; ff[t].t1 = b;
+        pthread_create(&tid[t], 0, rf_fill, &ff[t]);
+    }
+    for (t = 0; t < n_threads; ++t) pthread_join(tid[t], 0);
+    free(ff);
+    w2 = calloc(n_threads, sizeof(worker2_t));
+    for (t = 0; t < n_threads; ++t) {
+        int m = (n + n_threads - 1) / n_threads;
+        w2[t].e = 0; w2[t].solid = solid; w2[t].opt = &opt;
+        w2[t].seq = calloc(m, sizeof(void *)); w2[t].qual = calloc(m, sizeof(void *)); w2[t].info = calloc(m, sizeof(int));
+    }
+    {   /* ec_fix works on NUL-terminated strings: private copies, as the reference's batches are (correct.c:446-452) */
+        char *cs = malloc((size_t)n * (len + 1)), *cq = malloc((size_t)n * (len + 1));
+        for (j = 0; j < n; ++j) {
+            worker2_t *x = &w2[j % n_threads];
+            memcpy(cs + (size_t)j * (len + 1), seqs + (size_t)j * len, len); cs[(size_t)j * (len + 1) + len] = 0;
+            memcpy(cq + (size_t)j * (len + 1), quals + (size_t)j * len, len); cq[(size_t)j * (len + 1) + len] = 0;
+            x->seq[x->n_seqs] = cs + (size_t)j * (len + 1); x->qual[x->n_seqs] = cq + (size_t)j * (len + 1); ++x->n_seqs;
+        }
+        t0 = rr_now();
+        for (t = 0; t < n_threads; ++t) pthread_create(&tid[t], 0, worker2, &w2[t]);
+        for (t = 0; t < n_threads; ++t) pthread_join(tid[t], 0);
+        *secs = rr_now() - t0;
+        *n_query = 0;
+        for (t = 0; t < n_threads; ++t) { *n_query += w2[t].n_query; w2[t].n_seqs = 0; }
+        for (j = 0; j < n; ++j) {
+            worker2_t *x = &w2[j % n_threads];
+            memcpy(seqs + (size_t)j * len, cs + (size_t)j * (len + 1), len);
+            memcpy(quals + (size_t)j * len, cq + (size_t)j * (len + 1), len);
+            info[j] = x->info[x->n_seqs++];
+        }
+        free(cs); free(cq);
+    }
+    for (t = 0; t < n_threads; ++t) { free(w2[t].seq); free(w2[t].qual); free(w2[t].info); }
+    free(w2); free(tid);
+    for (j = 0; j < SUF_NUM; ++j) kh_destroy(solid, solid[j]);
+    free(solid);
+    return 0;
+}

@@ -3,7 +3,9 @@
 reference binary compiled in place (oracle/_ref/fermi): `fermi build` + `fermi unitig -l50 -t1` on error-free reads and
 `fermi build` + `fermi correct -t1` + `fermi unitig -l50 -t1` on reads with 1 % substitutions (qualities from a seeded generator).  Only the md5s
 are committed (tests/golden/md5_1m.json); tests/test_gpu_fullsize.py regenerates the same inputs on the GPU box.
-Usage: python tests/golden/make_md5_1m.py"""
+Usage: python tests/golden/make_md5_1m.py            -> md5_1m.json
+       python tests/golden/make_md5_1m.py 10000000   -> md5_10m.json  (the single-GPU size class of configs[1]; about two hours of the reference here,
+                                                        the error-free and the raw chain side by side)"""
 import hashlib, json, os, subprocess, sys, time
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
@@ -15,7 +17,8 @@ REF = os.path.join(ROOT, "oracle", "_ref", "fermi")
 N = 1_000_000
 
 
-def write_fastq(path, err, with_random_quals):
+def write_fastq(path, err, with_random_quals, n=None):
+    N = n or globals()["N"]
     lut = np.frombuffer(b"$ACGTN", dtype=np.uint8)
     rng = np.random.default_rng(5)
     with open(path, "wb") as fp:
@@ -35,20 +38,40 @@ def md5_of(cmd):
     return h.hexdigest(), n
 
 
-if __name__ == "__main__":
-    d = "/tmp/fmd_md5_1m"; os.makedirs(d, exist_ok=True)
-    out = {"n_reads": N, "seed": synth.DEFAULT_SEED, "made_with": "oracle/_ref/fermi (the reference compiled in place)"}
-    t = time.time()
-    write_fastq(d + "/clean.fq", 0.0, False)
+def clean_chain(d, n, out, t):
+    write_fastq(d + "/clean.fq", 0.0, False, n)
     subprocess.check_call([REF, "build", "-fo", d + "/clean.fmd", d + "/clean.fq"], stderr=subprocess.DEVNULL)
     out["clean_fmd"] = md5_of(["cat", d + "/clean.fmd"])
     out["unitig_l50_t1"] = md5_of([REF, "unitig", "-l50", "-t1", d + "/clean.fmd"])
     print("unitig done", time.time() - t, out["unitig_l50_t1"], flush=True)
-    write_fastq(d + "/raw.fq", 0.01, True)
+
+
+def raw_chain(d, n, out, t):
+    write_fastq(d + "/raw.fq", 0.01, True, n)
     subprocess.check_call([REF, "build", "-fo", d + "/raw.fmd", d + "/raw.fq"], stderr=subprocess.DEVNULL)
     out["raw_fmd"] = md5_of(["cat", d + "/raw.fmd"])
     out["correct_t1"] = md5_of([REF, "correct", "-t1", d + "/raw.fmd", d + "/raw.fq"])
     print("correct done", time.time() - t, out["correct_t1"], flush=True)
     out["unitig_raw_l50_t1"] = md5_of([REF, "unitig", "-l50", "-t1", d + "/raw.fmd"])   # reads with errors: forks, tips, back-bifurcations
     print("unitig on raw reads done", time.time() - t, out["unitig_raw_l50_t1"], flush=True)
-    json.dump(out, open(os.path.join(HERE, "md5_1m.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    import threading
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else N
+    assert n % 250_000 == 0
+    tag = "%dm" % (n // 1_000_000)
+    d = "/tmp/fmd_md5_" + tag; os.makedirs(d, exist_ok=True)
+    out = {"n_reads": n, "seed": synth.DEFAULT_SEED, "made_with": "oracle/_ref/fermi (the reference compiled in place)"}
+    t = time.time()
+    a, b = {}, {}
+    th = [threading.Thread(target=clean_chain, args=(d, n, a, t)), threading.Thread(target=raw_chain, args=(d, n, b, t))]   # (the work is in child processes)
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for k in ("clean_fmd", "unitig_l50_t1"):
+        out[k] = a[k]
+    for k in ("raw_fmd", "correct_t1", "unitig_raw_l50_t1"):
+        out[k] = b[k]
+    json.dump(out, open(os.path.join(HERE, "md5_%s.json" % tag), "w"), indent=1)

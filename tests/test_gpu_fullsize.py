@@ -34,7 +34,7 @@ def _md5_stream(cmd, env=None):
 
 def test_10m_reads_every_leg_bit_exact_on_random_samples(gpu):
     env = dict(os.environ, FMD_BENCH_READS="10000000", FMD_BENCH_BSEARCH_READS="10000000", FMD_BENCH_CPU_SAMPLE="200000",
-               FMD_BENCH_CPU_SAMPLE_OVLP="100000", FMD_BENCH_CPU_SAMPLE_SMEM="100000", FMD_BENCH_CPU_SAMPLE_KMER="2048", FMD_BENCH_PROBE="0", FMD_BENCH_PMC="0")
+               FMD_BENCH_CPU_SAMPLE_OVLP="100000", FMD_BENCH_CPU_SAMPLE_SMEM="100000", FMD_BENCH_CPU_SAMPLE_KMER="2048", FMD_BENCH_CPU_SAMPLE_ECFIX="100000", FMD_BENCH_PROBE="0", FMD_BENCH_PMC="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     d = json.loads(p.stdout.decode().strip().splitlines()[-1])
@@ -46,11 +46,13 @@ def test_10m_reads_every_leg_bit_exact_on_random_samples(gpu):
     assert d["backward_search"]["parity_vs_cpu_on_sample"] == "bit-exact" and d["backward_search"]["hits"] == 10_000_000
     assert d["smem"]["parity_vs_cpu_on_sample"] == "bit-exact" and d["smem"]["overflow_reads"] == 0
     assert d["kmer_harvest"]["parity_vs_cpu_on_sample"] == "bit-exact"
+    ec = d["ec_fix"]                                                                     # the correction pass on the table the harvest leg built: bases, qualities, info words
+    assert ec["parity_vs_cpu_on_sample"].startswith("bit-exact") and ec["bases_changed"] > 5_000_000 and ec["reads_whose_trace_overflowed"] < 1000
     raw = d["overlap_discovery_on_raw_reads"]                                            # reads with 1 % errors: forks, the general group kernels
     assert raw["parity_vs_cpu_on_sample"] == "bit-exact" and raw["same_results_both_ways"] and raw["forked"] > 0
     assert raw["overflow_records"] == 0 and raw["rows_completed_in_the_side_table"]["are_exactly_the_flagged_rows"]   # every row has its answer when the clock stops
     assert raw["check_left"]["parity_vs_oracle_on_sample"].startswith("bit-exact") and raw["check_left"]["back_bifurcations"] > 0
-    for leg in (d, d["check_left"], d["backward_search"], d["smem"], d["kmer_harvest"], raw):
+    for leg in (d, d["check_left"], d["backward_search"], d["smem"], d["kmer_harvest"], ec, raw):
         f = leg["roofline"]["frac"]
         assert f is None or 0 < f <= 1.0, leg["roofline"]                               # a fraction is a fraction
 
@@ -75,14 +77,13 @@ def test_1m_reads_cli_md5_equals_the_reference(gpu, tmp_path):
 
 
 def test_bench_n2_path_sharded_ids_and_gather_on_one_gpu(gpu):
-    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per GPU), here with both ranks on
-    GPU 0 and gloo instead of RCCL (FMD_BENCH_BACKEND / FMD_BENCH_SHARE_GPU): rank r computes the ids i = r (mod 2), the
-    packed rows are gathered on rank 0 inside the timed step, and rank 0 recomputes a sample of rank 1's rows."""
-    import socket
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    """`python bench.py --gpus 2` launched PLAINLY, as the driver's N = 1 command is: bench.py becomes its own launcher (N ranks of itself through
+    torch.distributed.run, one per GPU), here with both ranks on GPU 0 and gloo instead of RCCL (FMD_BENCH_BACKEND / FMD_BENCH_SHARE_GPU): rank r
+    computes the ids i = r (mod 2), the packed rows are gathered on rank 0 inside the timed step, and rank 0 recomputes a sample of rank 1's rows."""
     env = dict(os.environ, FMD_BENCH_READS="1000000", FMD_BENCH_BACKEND="gloo", FMD_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])

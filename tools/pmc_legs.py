@@ -42,6 +42,36 @@ if os.environ.get("PMC_LEGS") == "overlap_raw":
     ix.close()
     print("pmc_legs: %d steps of overlap discovery on the raw-read index of %d reads" % (K, n_reads))
     sys.exit(0)
+if os.environ.get("PMC_LEGS") == "ecfix":   # the correction pass: harvest (untimed, other kernel names) -> table -> K steps of k_ecfix, each on a fresh copy of the reads
+    fmd = os.environ.get("PMC_FMD_RAW")
+    rd = workload.ReadsOnDevice.synth(n_reads, L, 30, 0.01, dev)
+    if fmd:
+        ix = api.DevIndex.open(fmd, 0); n_sym = ix.n
+    else:
+        d_bwt, n_sym = workload.build_bwt_on_device(rd, 0)
+        ix = api.DevIndex.from_bwt_dev(d_bwt, n_sym, 0)
+        lib.fmd_dev_free(d_bwt)
+    w = min(27, int(math.log(n_sym) / math.log(4) + 8.499)); suf = w - 15 if w > 15 else 1
+    cap = max(1 << 22, 1 << int(math.ceil(math.log2(n_sym / 30.0 * 1.5))))
+    wb = lib.fmd_kmer_work_bytes(cap); work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    ob = torch.empty(cap, dtype=torch.int32, device=dev); ok_ = torch.empty(cap, dtype=torch.int32, device=dev); ov = torch.empty(cap, dtype=torch.uint8, device=dev)
+    st = torch.zeros(4, dtype=torch.int64, device=dev)
+    api.check(lib.fmd_kmer_collect_dev(ix.h, sh, w, 3, suf, work.data_ptr(), wb, cap, ob.data_ptr(), ok_.data_ptr(), ov.data_ptr(), st.data_ptr()))
+    torch.cuda.synchronize()
+    n_out = int(st.cpu().numpy().view("u8")[0])
+    ix.close(); del work; torch.cuda.empty_cache()
+    t = C.c_void_p()
+    api.check(lib.fmd_ectab_build_dev(0, sh, w, suf, n_out, ob.data_ptr(), ok_.data_ptr(), ov.data_ptr(), C.byref(t)))
+    cap_t = int(os.environ.get("FMD_BENCH_EC_TRACE", "1024"))
+    wb = lib.fmd_ecfix_work_bytes(t, n_reads, cap_t); work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    info = torch.zeros(n_reads, dtype=torch.int32, device=dev)
+    for _ in range(K):
+        s = rd.flat.clone(); q = torch.full((n_reads * L + 64,), ord("I"), dtype=torch.uint8, device=dev)
+        api.check(lib.fmd_ecfix_dev(t, sh, n_reads, s.data_ptr(), q.data_ptr(), rd.off.data_ptr(), int(os.environ.get("FMD_BENCH_EC_STEP", "5")), cap_t, info.data_ptr(), work.data_ptr(), wb))
+        torch.cuda.synchronize()
+    lib.fmd_ectab_free(t)
+    print("pmc_legs: %d steps of ec_fix over %d reads, table of %d solid k-mers" % (K, n_reads, n_out))
+    sys.exit(0)
 ONLY = os.environ.get("PMC_LEGS")   # e.g. PMC_LEGS=smem,kmer: a partial re-collection after one leg's kernels changed
 want = lambda leg: not ONLY or leg in ONLY.split(",")
 if want("overlap") or want("check_left"):   # overlap (+ check_left) at n_reads, e = 0
