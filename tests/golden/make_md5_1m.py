@@ -17,15 +17,47 @@ REF = os.path.join(ROOT, "oracle", "_ref", "fermi")
 N = 1_000_000
 
 
-def write_fastq(path, err, with_random_quals, n=None):
+def _records(first_id, r, q):
+    """the FASTQ text of reads first_id .. : b"@r%d\n%s\n+\n%s\n" per read, built as byte arrays (ids of equal digit count at a time)"""
+    n, L = r.shape
+    out = []
+    ids = np.arange(first_id, first_id + n, dtype=np.int64)
+    nd = np.where(ids == 0, 1, np.floor(np.log10(np.maximum(ids, 1))).astype(np.int64) + 1)
+    nd = np.where(10 ** (nd - 1) > ids, nd - 1, np.where(10 ** nd <= ids, nd + 1, nd))      # (log10 at the powers of ten)
+    nd = np.maximum(nd, 1)
+    lo = 0
+    while lo < n:
+        hi = lo + int(np.searchsorted(nd[lo:], nd[lo], side="right"))
+        d, m = int(nd[lo]), hi - lo
+        blk = np.empty((m, 2 + d + 1 + L + 3 + L + 1), dtype=np.uint8)
+        blk[:, 0] = ord("@"); blk[:, 1] = ord("r")
+        v = ids[lo:hi].copy()
+        for k in range(d - 1, -1, -1):
+            blk[:, 2 + k] = ord("0") + v % 10
+            v //= 10
+        blk[:, 2 + d] = 10
+        blk[:, 3 + d:3 + d + L] = r[lo:hi]
+        blk[:, 3 + d + L] = 10; blk[:, 4 + d + L] = ord("+"); blk[:, 5 + d + L] = 10
+        blk[:, 6 + d + L:6 + d + 2 * L] = q[lo:hi]
+        blk[:, 6 + d + 2 * L] = 10
+        out.append(blk.tobytes())
+        lo = hi
+    return b"".join(out)
+
+
+def write_fastq(path, err, with_random_quals, n=None, reads_of=None):
+    """reads_of(start, count) -> nt6 reads (count x 100) of the set: the numpy generator by default; a test on a GPU box passes the torch form"""
     N = n or globals()["N"]
     lut = np.frombuffer(b"$ACGTN", dtype=np.uint8)
     rng = np.random.default_rng(5)
+    if reads_of is None:
+        gen = synth.genome(synth.DEFAULT_SEED, N, 100, 30)
+        reads_of = lambda s, c: synth.reads(synth.DEFAULT_SEED, N, 100, 30, err, start=s, count=c, gen=gen)
     with open(path, "wb") as fp:
         for s in range(0, N, 250_000):
-            r = lut[synth.reads(synth.DEFAULT_SEED, N, 100, 30, err, start=s, count=250_000)]
+            r = lut[reads_of(s, 250_000)]
             q = rng.integers(33 + 5, 33 + 41, size=(250_000, 100)).astype(np.uint8) if with_random_quals else np.full((250_000, 100), ord("I"), dtype=np.uint8)
-            fp.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (s + i, r[i].tobytes(), q[i].tobytes()) for i in range(250_000)))
+            fp.write(_records(s, r, q))
 
 
 def md5_of(cmd):

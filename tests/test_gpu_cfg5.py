@@ -5,9 +5,10 @@ builders that only sizes beyond 2^32 symbols exercise, inside `pytest -m gpu` (V
     the rank self-check over all 1.4*10^11 positions, sampled reads hit themselves, overlap discovery of random ids checked by what
     the generator knows (sequences, the one neighbour and its overlap from the start positions, mutual edges, mirrored intervals),
     the four-part k-mer harvest cross-checked by backward search, and the share i = 0 (mod 8) of the discovery timed.  ~10 minutes.
-  * 1.3*10^8 reads (2.6*10^10 symbols): the bucketed byte-BWT builder, the .fmd written by the product and loaded by the REFERENCE
-    (oracle/_ref when it travelled, the oracle otherwise): backward search and overlap discovery of 20 000 random reads / ids
-    bit-exact, plus the same generator properties.  ~3 minutes.
+  * 1.3*10^8 reads WITH 1 % substitutions (2.6*10^10 symbols): the bucketed byte-BWT builder, the .fmd written by the product and loaded by the
+    REFERENCE (oracle/_ref when it travelled, the oracle otherwise): backward search and overlap discovery of 20 000 random reads / ids
+    bit-exact, the sorted job on 200 000 random ids (forks: the general group kernels and the 64-bit fast kernels beyond 2^32 symbols) bit-exact,
+    check_left against the oracle.  ~4 minutes.
 Both run tools/scale_check.py (the log goes to gpurun_out/ when that directory exists)."""
 import os
 import subprocess
@@ -39,7 +40,9 @@ def test_config5_700m_reads_index_in_place_and_one_gpus_share(gpu):
     assert "share 1/8 of the overlap discovery on this index: 175000000 strands" in txt and "(0 overflow records" in txt
 
 
-def test_130m_reads_bucketed_builder_fmd_and_reference(gpu):
-    txt = _scale_check("130M", ["130000000", "bwt", "20000", "8", "props"], 900)
-    assert "26260000000 positions: 0 bad" in txt and "properties on" in txt
-    assert "backward search vs" in txt and "overlap discovery vs" in txt and "MISMATCH" not in txt
+def test_130m_raw_reads_bucketed_builder_fmd_and_reference(gpu):
+    """2.6*10^10 symbols of reads WITH 1 % substitutions: beyond 2^32 symbols the forked path of fm6_get_nei (the general group kernels, the 64-bit fast kernels) meets the
+    reference -- config 5 and the 7*10^8-read case above are error-free, where no strand forks."""
+    txt = _scale_check("130M_raw", ["130000000", "bwt", "20000", "8", "raw"], 900)
+    assert "26260000000 positions: 0 bad" in txt
+    assert "backward search vs" in txt and "overlap discovery vs" in txt and "the sorted job vs the reference" in txt and "check_left_simple of" in txt and "MISMATCH" not in txt

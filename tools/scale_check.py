@@ -13,7 +13,10 @@ device layout; the only form that carries 1.4*10^11 symbols) --, then
     has exactly that read as its one neighbour with the overlap the two start positions give, and the edge is mutual (the
     successor's reverse strand is followed by the strand's reverse strand with the same overlap),
   * `kmer` with `noref`: the harvest's solid k-mers cross-checked by backward search on a sample.
-Usage: python tools/scale_check.py [n_reads=250000000] [bwt|inplace] [sample=20000] [share=8] [noref] [kmer] [props]"""
+  * `raw`: the reads carry 1 % substitutions (the forked path of fm6_get_nei: general group kernels, side table, 64-bit fast kernels beyond 2^32 symbols): the
+    discovery of the random ids runs through BOTH host forms (fmd_ovlp_batch in id order, the sorted job) with room for 16 neighbours, and check_left of a
+    sub-sample is compared with the oracle; `props` (which assume error-free reads) is ignored.
+Usage: python tools/scale_check.py [n_reads=250000000] [bwt|inplace] [sample=20000] [share=8] [noref] [kmer] [props] [raw]"""
 import ctypes as C, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -27,6 +30,9 @@ mode = sys.argv[2] if len(sys.argv) > 2 else "bwt"
 sample = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
 share = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 noref = "noref" in sys.argv[5:]
+raw = "raw" in sys.argv[5:]
+ERR = 0.01 if raw else 0.0
+PROPS = "props" in sys.argv[5:] and not raw
 L = 100
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
@@ -49,7 +55,7 @@ if mode == "inplace":
     api.check(lib.fmd_builder_new(0, n_reads, L, C.byref(b)))
     for s in range(0, n_reads, PIECE):
         c = min(PIECE, n_reads - s)
-        piece = synth.reads_torch(seed, n_reads, L, 30, 0.0, dev, start=s, count=c, gen=gen)
+        piece = synth.reads_torch(seed, n_reads, L, 30, ERR, dev, start=s, count=c, gen=gen)
         api.check(lib.fmd_builder_add_dev(b, None, c, piece.data_ptr()))
         torch.cuda.synchronize()
         del piece
@@ -77,7 +83,7 @@ else:
     rd.flat = torch.zeros(n_reads * L + 64, dtype=torch.uint8, device=dev)
     for s in range(0, n_reads, PIECE):
         c = min(PIECE, n_reads - s)
-        rd.flat[s * L:(s + c) * L].view(c, L).copy_(synth.reads_torch(seed, n_reads, L, 30, 0.0, dev, start=s, count=c, gen=gen))
+        rd.flat[s * L:(s + c) * L].view(c, L).copy_(synth.reads_torch(seed, n_reads, L, 30, ERR, dev, start=s, count=c, gen=gen))
     rd.off = torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * L
     rd.total = n_reads * L
     torch.cuda.synchronize()
@@ -105,8 +111,8 @@ print("rank self-check over all %d positions: %d bad (%.1f s)" % (n_sym, bad.val
 assert bad.value == 0
 # a spread sample of the reads: blocks of 1000 consecutive reads
 starts = np.sort(rng.choice(n_reads // 1000, max(1, sample // 1000), replace=False)) * 1000
-q = torch.cat([synth.reads_torch(seed, n_reads, L, 30, 0.0, dev, start=int(s), count=1000, gen=gen) for s in starts]).cpu().numpy()
-if "props" in sys.argv[5:]:
+q = torch.cat([synth.reads_torch(seed, n_reads, L, 30, ERR, dev, start=int(s), count=1000, gen=gen) for s in starts]).cpu().numpy()
+if PROPS:
     # ---- what the generator knows: where every read starts and which way round it is
     G = gen.shape[0]
     t0 = time.time()
@@ -144,10 +150,11 @@ cnt, beg, end = index.backward_search(q)
 assert (cnt >= 1).all() and np.array_equal(end - beg + 1, cnt), "a read of the set does not hit its own index"
 print("backward search: all %d sampled reads hit their own index (multiplicities 1..%d)" % (len(q), int(cnt.max())), flush=True)
 ids = np.sort(rng.choice(2 * n_reads, min(sample, 2 * n_reads), replace=False)).astype(np.uint64)
-rec, nei, seq = index.overlap(ids, 50, max_len=100, max_nei=4, check_left=False)
+MAX_NEI = 16 if raw else 4
+rec, nei, seq = index.overlap(ids, 50, max_len=100, max_nei=MAX_NEI, check_left=False)
 print("overlap discovery of %d random sequence ids: %d with a neighbour, %d contained, %d overflow" % (len(ids), int((rec["n_nei"] > 0).sum()), int((rec["status"] == -3).sum()),
       int(((rec["flags"] & api.OVLP_F_OVERFLOW) != 0).sum())), flush=True)
-if "props" in sys.argv[5:]:
+if PROPS:
     t0 = time.time()
     all_ids = np.unique(np.concatenate([A, A ^ np.uint64(1), B, B ^ np.uint64(1)]))
     prec, pnei, pseq = index.overlap(all_ids, 50, max_len=100, max_nei=4, check_left=False)
@@ -185,9 +192,31 @@ if not noref:
     base, ok = bench.cpu_bsearch(fmd_path, q, cnt, beg, end)
     print("backward search vs %s on the sample: %s (%.0f reads/s on %d host threads)" % (base["kind"], "bit-exact" if ok else "MISMATCH", base["value"], base["cores"]), flush=True)
     assert ok
-    base, ok = bench.cpu_overlap(fmd_path, ids, 50, rec, nei)
-    print("overlap discovery vs %s on %d random sequence ids: %s (reference %.0f reads/s on %d threads)" % (base["kind"], len(ids), "bit-exact" if ok else "MISMATCH", base["value"], base["cores"]), flush=True)
-    assert ok
+    keep = (rec["flags"] & api.OVLP_F_OVERFLOW) == 0
+    base, ok = bench.cpu_overlap(fmd_path, ids, 50, rec, nei, keep=keep)
+    print("overlap discovery vs %s on %d random sequence ids (%d of them without an answer at %d neighbour slots): %s (reference %.0f reads/s on %d threads)"
+          % (base["kind"], len(ids), int((~keep).sum()), MAX_NEI, "bit-exact" if ok else "MISMATCH", base["value"], base["cores"]), flush=True)
+    assert ok and keep.mean() > 0.99
+    if raw:   # the forked path beyond 2^32 symbols: the sorted job (walk passes, fast and general group kernels, 64-bit forms) on a larger sample, and check_left
+        ids2 = np.sort(rng.choice(2 * n_reads, min(10 * sample, 2 * n_reads), replace=False)).astype(np.uint64)
+        rec2, nei2, _ = index.overlap_sorted(ids2, 50, 100, MAX_NEI, 0)
+        keep2 = (rec2["flags"] & api.OVLP_F_OVERFLOW) == 0
+        forked = int(((rec2["flags"] & api.OVLP_F_FORKED) != 0).sum())
+        _, ok2 = bench.cpu_overlap(fmd_path, ids2, 50, rec2, nei2, keep=keep2)
+        print("the sorted job vs the reference on %d random sequence ids: %s (%d forked strands, %d with more than one neighbour, %d without an answer)"
+              % (len(ids2), "bit-exact" if ok2 else "MISMATCH", forked, int((rec2["n_nei"] > 1).sum()), int((~keep2).sum())), flush=True)
+        assert ok2 and keep2.mean() > 0.99 and forked > len(ids2) // 100
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orcbind
+        sub = ids2[:: max(1, len(ids2) // 4000)]
+        r_cl, _, _ = index.overlap_sorted(sub, 50, 100, MAX_NEI, 0, check_left=True)
+        o = orcbind.OrcIndex(fmd_path)
+        w_cl, _, _ = o.overlap_batch(sub, 50, 100, MAX_NEI, bench.usable_cpus(), check_left=True)
+        o.close()
+        k3 = (r_cl["flags"] & api.OVLP_F_OVERFLOW) == 0
+        same = np.array_equal(r_cl["reserved"][k3], w_cl["reserved"][k3])
+        print("check_left_simple of %d ids vs the oracle: %s (%d edges with a verdict, %d back-bifurcations)" % (len(sub), "bit-exact" if same else "MISMATCH", int((w_cl["reserved"] != 2).sum()), int((w_cl["reserved"] == 1).sum())), flush=True)
+        assert same and (w_cl["reserved"] == 1).sum() > 0
     if "kmer" in sys.argv[5:]:   # the harvest of `fermi correct` (fm6_traverse + ec_collect) over the whole index, host form (parts as the free HBM asks)
         import math
         w = min(27, int(math.log(n_sym) / math.log(4) + 8.499)); suf_len = w - 15 if w > 15 else 1
