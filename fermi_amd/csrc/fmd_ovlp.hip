@@ -204,6 +204,12 @@ __device__ __forceinline__ bool walk_lf_shares(uint64_t k, uint64_t x0, uint64_t
 // 4 bits each (FmdWalkPark::bases), and never stores
 #define WALK_PUT_BASE(cc)                                                                                  \
     do {                                                                                                   \
+        if (MODE == WALK_TAIL2) {   /* 2 bits per base, a word of 16 into the lane's LDS stash */          \
+            pack |= (((uint32_t)(cc) - 1u) & 3u) << (2 * (depth & 15));                                    \
+            if ((uint32_t)(cc) > 4u) flags |= WALK_F_HASN;                                                 \
+            ++depth;                                                                                       \
+            if ((depth & 15) == 0) { if (depth <= WALK_LS_BASES) walk_ls[((depth >> 4) - 1) * 64 + fmd_lane()] = pack; pack = 0; } \
+        } else                                                                                             \
         if (MODE == WALK_HEAD) {                                                                           \
             const uint32_t v_ = (uint32_t)(cc) << (4 * (depth & 7)), w_ = depth >> 3;                      \
             pk0 |= w_ == 0 ? v_ : 0u; pk1 |= w_ == 1 ? v_ : 0u; pk2 |= w_ == 2 ? v_ : 0u; pack |= w_ == 3 ? v_ : 0u; \
@@ -222,7 +228,58 @@ __device__ __forceinline__ bool walk_lf_shares(uint64_t k, uint64_t x0, uint64_t
 // those bases (k_ovl_park_keys), so that strands of one genomic window sit in neighbouring lanes; WALK_TAIL picks each strand up where
 // it was parked, in that order.  Nothing can be pushed before min_match >= FMD_WALK_SPLIT bases, so the two passes together make
 // exactly the steps of the one-pass walk and leave the same records, candidates and stash.
-enum { WALK_WHOLE = 0, WALK_HEAD = 1, WALK_TAIL = 2 };   // (FMD_WALK_SPLIT, FmdWalkPark: fmd_kernel_common.h)
+enum { WALK_WHOLE = 0, WALK_HEAD = 1, WALK_TAIL = 2, WALK_TAIL2 = 3 };   // (FMD_WALK_SPLIT, FmdWalkPark: fmd_kernel_common.h)
+
+// WALK_TAIL2 = WALK_TAIL for sequences of at most WALK_LS_BASES bases, without the stash in HBM and without k_ovl_seq_out behind it: the bases wait in
+// LDS, 2 bits each (code - 1; 7 words per lane: what is left of a CU's 160 KiB beside the gather's 8.25 KiB per wave at 16 waves), and the lane that
+// reaches its sequence's '$' writes the caller's row itself, in read order, from those words (walk_emit_row: ~250 instructions once per strand, where
+// the separate kernel read 112 + wrote 100 bytes per strand and cost the step 14 ms of its 272).  Reads of one length finish a wave together, so
+// nobody waits.  A sequence that holds an N (2 bits do not) is put on a list and k_ovl_seq_redo writes its row afterwards from what WALK_HEAD parked.
+#define WALK_LS_WORDS 7
+#define WALK_LS_BASES (16 * WALK_LS_WORDS)
+#define WALK_F_HASN 0x80000000u       // (in the walk's `flags` register only: never stored)
+struct __attribute__((packed, aligned(4))) WalkU4 { uint32_t x, y, z, w; };   // a 16-byte store at a 4-byte aligned address
+// four bases, 2 bits each, first found (= LAST in read order) in the low bits -> their nt6 codes as the four bytes of a word in read order
+__device__ __forceinline__ uint32_t walk_expand4(uint32_t win8)
+{
+    uint32_t y = (win8 | win8 << 12) & 0x000f000fu;
+    y = (y | y << 6) & 0x03030303u;
+    return __builtin_bswap32(y + 0x01010101u);
+}
+// eight bases as nibbles (nt6 codes 1..5) -> 2 bits each (code - 1) in the low 16 bits; bit 16 set when one of them is not A/C/G/T
+__device__ __forceinline__ uint32_t walk_nib_to_2bit(uint32_t v)
+{
+    const uint32_t t = v - 0x11111111u;
+    uint32_t x = t & 0x33333333u;
+    x = (x | x >> 2) & 0x0f0f0f0fu; x = (x | x >> 4) & 0x00ff00ffu; x = (x | x >> 8) & 0x0000ffffu;
+    return x | ((t & 0xccccccccu) ? 0x10000u : 0u);
+}
+// st[w * 64]: word w of this lane (bases 16w .. 16w + 15 in the order found, i.e. from the sequence's end); len <= WALK_LS_BASES; dst 4-byte aligned
+// with room for len + 3 bytes.  Output word w holds the bases found as [len - 4 - 4w, len - 4w): with r = len & 3 the words line up with the stash
+// shifted by r bases, 16 bases = four output words = one 16-byte store.  The word that holds the sequence's last bases (r of them) is padded with
+// zeros, bytes beyond it are not written (as k_ovl_seq_out leaves a row).
+__device__ __forceinline__ void walk_emit_row(const uint32_t *st, uint32_t len, uint8_t *dst)
+{
+    const uint32_t r = len & 3u, sh = 2u * r;
+    const int q = (int)(len >> 2);
+    uint32_t prev = 0;
+#pragma unroll
+    for (int t = 0; t <= WALK_LS_WORDS; ++t) {
+        const uint32_t cur = t < WALK_LS_WORDS ? st[t * 64] : 0u;
+        const uint32_t S = __builtin_amdgcn_alignbit(cur, prev, sh);      // bases found as [16 (t - 1) + r, 16 t + r)
+        prev = cur;
+        const int w0 = q - 4 * t;                                         // S >> 24 -> word w0, ..., S & 0xff -> word w0 + 3
+        if (t == 0) { if (r) *(uint32_t *)(dst + 4 * q) = walk_expand4(S >> 24) & ((1u << (8u * r)) - 1u); }
+        else if (w0 >= 0) {
+            WalkU4 v; v.x = walk_expand4(S >> 24); v.y = walk_expand4((S >> 16) & 0xffu); v.z = walk_expand4((S >> 8) & 0xffu); v.w = walk_expand4(S & 0xffu);
+            *(WalkU4 *)(dst + 4 * w0) = v;
+        } else if (w0 + 3 >= 0) {                                         // the sequence's first words: fewer than four
+            if (w0 + 1 >= 0) *(uint32_t *)(dst + 4 * (w0 + 1)) = walk_expand4((S >> 16) & 0xffu);
+            if (w0 + 2 >= 0) *(uint32_t *)(dst + 4 * (w0 + 2)) = walk_expand4((S >> 8) & 0xffu);
+            *(uint32_t *)(dst + 4 * (w0 + 3)) = walk_expand4(S & 0xffu);
+        }
+    }
+}
 
 // MODE = WALK_HEAD: item t = admission record t (k_ovl_head_adm: the strand's row in ids[], park[] and rec[] and where its walk stands
 // behind the tail table); the first 32 bases stay in registers and leave with the parked state in ONE 64-byte burst.
@@ -234,9 +291,11 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
                                                  fmd_intv_t *__restrict__ listA, fmd_ovlp_rec_t *__restrict__ rec,
                                                  uint8_t *__restrict__ seq_out, uint32_t seq_stride, uint32_t *__restrict__ queue,
                                                  int info_only, FmdWalkPark *__restrict__ park, const uint32_t *__restrict__ gidx,
-                                                 const uint4 *__restrict__ adm, uint32_t tchunk)
+                                                 const uint4 *__restrict__ adm, uint32_t tchunk, uint32_t *__restrict__ redo)
 {
     FMD_DECLARE_COMPACT_LDS();
+    __shared__ uint32_t walk_ls[MODE == WALK_TAIL2 ? 64 * WALK_LS_WORDS : 1];   // WALK_TAIL2: the lane's bases, word w of lane l at [w * 64 + l]
+    constexpr bool TAILM = MODE == WALK_TAIL || MODE == WALK_TAIL2;
     size_t sid = 0;
     size_t gs = 0;                        // the strand's row in rec[] (WALK_TAIL: gidx[sid], otherwise sid)
     int st = WK_IDLE, c_pend = 0, ret = 0;
@@ -260,7 +319,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
             // here and complete under the gather of the other lanes (WK_ADM1 / WK_ADM2 below).  A chain of dependent loads in front of
             // the gather -- id, tail-table entry, two prefix-table entries, as the one-pass walk does it -- stalls all 64 lanes of a wave
             // whose strands live 20 steps: k_ovl_head_adm resolves that chain for every strand beforehand, streaming.
-            if (MODE == WALK_TAIL) {
+            if (TAILM) {
                 if (my < n) { sid = my; gs = gidx[my]; st = WK_ADM1; }
                 else exhausted = true;
             } else if (MODE == WALK_HEAD) {
@@ -337,12 +396,23 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
             }
             continue;
         }
-        if (MODE == WALK_TAIL && st == WK_ADM1) {   // the strand's row is known: fetch what WALK_HEAD parked there, straight into the
+        if (TAILM && st == WK_ADM1) {   // the strand's row is known: fetch what WALK_HEAD parked there, straight into the
             const uint4 *pp = (const uint4 *)(park + gs);   // registers the state will live in (the loads land under the next gather)
             const uint4 a = pp[0], b = pp[1], cb = pp[2];
             k = (uint64_t)a.y << 32 | a.x; x0 = (uint64_t)a.w << 32 | a.z; x1 = (uint64_t)b.y << 32 | b.x; sz = (uint64_t)b.w << 32 | b.z;
             pk0 = cb.x; pk1 = cb.y; pk2 = cb.z; pack = cb.w;
             st = WK_ADM2;
+            continue;
+        }
+        if (MODE == WALK_TAIL2 && st == WK_ADM2) {
+            st = WK_IDLE;
+            if (k != ~0ull) {   // (~0: the sequence ended inside the head)
+                const uint32_t c0 = walk_nib_to_2bit(pk0), c1 = walk_nib_to_2bit(pk1), c2 = walk_nib_to_2bit(pk2), c3 = walk_nib_to_2bit(pack);
+                walk_ls[fmd_lane()] = (c0 & 0xffffu) | c1 << 16; walk_ls[64 + fmd_lane()] = (c2 & 0xffffu) | c3 << 16;
+                depth = FMD_WALK_SPLIT; npush = 0; pack = 0; pk0 = pk1 = pk2 = 0; ret = 0; tab = false;
+                flags = ((c0 | c1 | c2 | c3) & 0x10000u) ? WALK_F_HASN : 0u;
+                st = walk_lf_shares(k, x0, sz) ? WK_BOTH : WK_LF;
+            }
             continue;
         }
         if (MODE == WALK_TAIL && st == WK_ADM2) {
@@ -460,6 +530,9 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
                 x1 += before; sz = sc;
                 WALK_PUT_BASE(c);
             } else { // '$': the sequence is complete (len = depth); these ranks are the left test of fm6_is_contained
+                if (MODE == WALK_TAIL2) {
+                    if ((depth & 15) && depth <= WALK_LS_BASES) walk_ls[(depth >> 4) * 64 + fmd_lane()] = pack;   // the last, partial word
+                } else
                 if (MODE != WALK_HEAD && (depth & 15) && depth <= stride_r) // the last, partial group of 16 (stride_r is a multiple of 16)
                 {   // completed words of the group sit in pk0..2, a partial word in pack; everything past it is zero
                     const uint32_t wq = (depth >> 2) & 3;
@@ -471,7 +544,11 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
                 if (MODE == WALK_HEAD) park[gs].k = ~0ull;   // ended inside the head: shorter than min_match, the record below is final
                 if (depth > stride_r) { o->status = 0; o->flags = FMD_OVLP_F_OVERFLOW; st = WK_IDLE; continue; } // longer than max_len
                 if (!info_only && (int)depth <= min_match) { o->status = -1; o->flags = 0; st = WK_IDLE; continue; } // too short (unitig.c:288)
-                // (the caller's copy in read order is made by k_ovl_seq_out: a lane doing it here holds up the other 63)
+                // (the caller's copy in read order is made by k_ovl_seq_out: a lane doing it here, from a stash in HBM, holds up the other 63)
+                if (MODE == WALK_TAIL2) {          // ... from LDS it does not: every sequence with a complete record gets its row now (k_ovl_seq_out's conditions)
+                    if (flags & WALK_F_HASN) redo[1 + atomicAdd(redo, 1u)] = (uint32_t)sid;
+                    else walk_emit_row(walk_ls + fmd_lane(), depth, seq_out + gs * (size_t)seq_stride);
+                }
                 if (sz != s[0]) ret = -1;          // left-contained
                 x0 = tk[0]; sz = s[0];             // ok[0]: x[0] = cnt[0] + tk[0], x[1] unchanged
                 st = WK_RIGHT;
@@ -485,7 +562,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
             o->k[0] = x0; o->k[1] = t0k; o->k[2] = t0l - t0k;
             o->status = ret < 0 ? -3 : 0;
             o->n_ovlp = (int32_t)npush;
-            o->flags = flags;
+            o->flags = flags & ~WALK_F_HASN;
             st = WK_IDLE;
             continue;
         }
@@ -506,6 +583,34 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
 
 #undef WALK_STASH_WORD
 #undef WALK_PUT_BASE
+
+// WALK_TAIL2's strands with an N (redo[0] of them, slots redo[1 ..]): one lane per strand, the row byte by byte -- the 32 bases WALK_HEAD parked, then LF steps from
+// the parked row on, read straight from the index (no wave gather: a handful of strands per batch of real reads, none of synthetic ones).
+__global__ void k_ovl_seq_redo(FmdIndexView ix, const uint32_t *__restrict__ redo, const uint32_t *__restrict__ gidx, const FmdWalkPark *__restrict__ park,
+                               const fmd_ovlp_rec_t *__restrict__ rec, uint8_t *__restrict__ seq_out, uint32_t seq_stride)
+{
+    const uint32_t n = redo[0];
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const size_t g = gidx[redo[1 + j]];
+        const int len = rec[g].len;
+        uint8_t *dst = seq_out + g * (size_t)seq_stride;
+        const uint4 *pp = (const uint4 *)(park + g);
+        const uint4 a = pp[0], cb = pp[2];
+        const uint32_t nib[4] = {cb.x, cb.y, cb.z, cb.w};
+        uint64_t k = (uint64_t)a.y << 32 | a.x;
+        for (int f = 0; f < (int)FMD_WALK_SPLIT && f < len; ++f) dst[len - 1 - f] = (uint8_t)((nib[f >> 3] >> (4 * (f & 7))) & 0xfu);
+        for (int f = (int)FMD_WALK_SPLIT; f < len; ++f) {
+            uint32_t b, o;
+            fmd_split(k, b, o);
+            const uint4 *img = ix.blocks + (size_t)b * FMD_BLK_U4;
+            const uint4 v = img[o >> 5];
+            const uint32_t bit = o & 31;
+            const int c = (int)(((v.x >> bit) & 1) | ((v.y >> bit) & 1) << 1 | ((v.z >> bit) & 1) << 2);
+            dst[len - 1 - f] = (uint8_t)c;
+            k = ix.cnt[c] + fmd_block_rank1(img, 0, o + 1, c, b) - 1;
+        }
+    }
+}
 
 // The caller's copy of every sequence in read order: the stash holds it last base first.  One thread per 16 output bytes (four aligned
 // dwords of the stash, a fifth when the chunk starts between two, funnel-shifted and byte-swapped; the record's length is read once per
@@ -742,7 +847,7 @@ __global__ __launch_bounds__(64) void k_ovl_nei(FmdIndexView ix, size_t n, int m
                     if (cpend) st = ST_C; else { ++j; st = ST_PICK; }
                 }
             } else if (st == ST_FIX1) { // unitig.c:160-163
-                const int b = srev[sid * (size_t)stride_r + (ori_l - 1 - fix_i)];
+                const int b = seq_out[gs * (size_t)seq_stride + fix_i];   // (the caller's row holds the sequence in read order by now: the stash is the walk's own)
                 const int c = comp6(b);
                 o0 = pick5(c, k0, k1, k2, k3, k4);
                 if (c == 5) { o0.x0 = k1.x0 + s[1]; o0.x1 = ix.cnt[5] + tk[5]; o0.sz = s[5]; }
@@ -865,7 +970,7 @@ __global__ __launch_bounds__(64) void k_ovl_fix(FmdIndexView ix, const uint32_t 
         k1.x0 = k2.x0 + s[2];     k1.x1 = ix.cnt[1] + tk[1]; k1.sz = s[1];
         bool done = false;
         if (st == 1) { // unitig.c:160-163
-            const int b = srev[sid * (size_t)stride_r + (ori_l - 1 - fix_i)];
+            const int b = seq_out[gs * (size_t)seq_stride + fix_i];
             const int c = comp6(b);
             I3 n3 = pick5(c, k0, k1, k2, k3, k4);
             if (c == 5) { n3.x0 = k1.x0 + s[1]; n3.x1 = ix.cnt[5] + tk[5]; n3.sz = s[5]; }
@@ -1076,7 +1181,19 @@ static void ovl_phase_a(const OvlBatch &o, hipStream_t st, size_t b, size_t np, 
         int grid = fmd_grid_for_lds(o.h, np, FMD_COMPACT_LDS_U4 * 16);
         { const char *e = getenv("FMD_WALK_WAVES"); if (per_cu <= 0 && e && atoi(e) > 0) per_cu = atoi(e); }
         if (per_cu > 0 && grid > o.h->n_cu * per_cu) grid = o.h->n_cu * per_cu;
-        k_ovl_walk<WALK_TAIL><<<grid, 64, 0, st>>>(o.ix, np, nullptr, o.min_match, srev, o.stride_r, o.cap, listA, o.rec, seq, o.seq_stride, q0, 0, o.park, o.gidx + b, nullptr, walk_ticket_chunk("FMD_TAIL_TICKETS", 64, np, grid));
+        // sequences of at most WALK_LS_BASES bases: the rows in read order come from the walk itself (WALK_TAIL2: bases in LDS, no stash in HBM, no k_ovl_seq_out);
+        // FMD_WALK_TAIL2=0 is the A/B switch.  The stash area, idle then, holds the list of the strands with an N: [0] their number, [1 ..] their slots.
+        const char *e2 = getenv("FMD_WALK_TAIL2");
+        if (o.stride_r <= WALK_LS_BASES && o.seq_stride >= o.stride_r + 4 && (o.seq_stride & 3) == 0 && !(e2 && atoi(e2) == 0)) {
+            uint32_t *redo = (uint32_t *)srev;
+            (void)hipMemsetAsync(redo, 0, 4, st);
+            grid = fmd_grid_for_lds(o.h, np, FMD_COMPACT_LDS_U4 * 16 + 64 * WALK_LS_WORDS * 4);
+            if (per_cu > 0 && grid > o.h->n_cu * per_cu) grid = o.h->n_cu * per_cu;
+            k_ovl_walk<WALK_TAIL2><<<grid, 64, 0, st>>>(o.ix, np, nullptr, o.min_match, srev, o.stride_r, o.cap, listA, o.rec, seq, o.seq_stride, q0, 0, o.park, o.gidx + b, nullptr, walk_ticket_chunk("FMD_TAIL_TICKETS", 64, np, grid), redo);
+            k_ovl_seq_redo<<<64, 64, 0, st>>>(o.ix, redo, o.gidx + b, o.park, o.rec, seq, o.seq_stride);
+            return;
+        }
+        k_ovl_walk<WALK_TAIL><<<grid, 64, 0, st>>>(o.ix, np, nullptr, o.min_match, srev, o.stride_r, o.cap, listA, o.rec, seq, o.seq_stride, q0, 0, o.park, o.gidx + b, nullptr, walk_ticket_chunk("FMD_TAIL_TICKETS", 64, np, grid), nullptr);
         launch_seq_out(st, np, o.max_len, srev, o.stride_r, o.rec, o.min_match, 0, seq, o.seq_stride, o.gidx + b);
         return;
     }
@@ -1089,7 +1206,7 @@ static void ovl_phase_a(const OvlBatch &o, hipStream_t st, size_t b, size_t np, 
     int grid = fmd_grid_for_lds(o.h, np, FMD_COMPACT_LDS_U4 * 16);
     { const char *e = getenv("FMD_WALK_WAVES"); if (per_cu <= 0 && e && atoi(e) > 0) per_cu = atoi(e); }   // A/B knob: resident waves per CU
     if (per_cu > 0 && grid > o.h->n_cu * per_cu) grid = o.h->n_cu * per_cu;
-    k_ovl_walk<WALK_WHOLE><<<grid, 64, 0, st>>>(o.ix, np, o.ids + b, o.min_match, srev, o.stride_r, o.cap, listA, o.rec + b, seq, o.seq_stride, q0, 0, nullptr, nullptr, nullptr, walk_ticket_chunk("FMD_WALK_TICKETS", 64, np, grid));
+    k_ovl_walk<WALK_WHOLE><<<grid, 64, 0, st>>>(o.ix, np, o.ids + b, o.min_match, srev, o.stride_r, o.cap, listA, o.rec + b, seq, o.seq_stride, q0, 0, nullptr, nullptr, nullptr, walk_ticket_chunk("FMD_WALK_TICKETS", 64, np, grid), nullptr);
     launch_seq_out(st, np, o.max_len, srev, o.stride_r, o.rec + b, o.min_match, 0, seq, o.seq_stride);
 }
 
@@ -1407,7 +1524,7 @@ static int ovl_head(fmd_dev *h, hipStream_t st, size_t n, const uint64_t *d_ids,
         int grid = fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16);
         { const char *e = getenv("FMD_HEAD_WAVES"); if (e && atoi(e) > 0 && grid > h->n_cu * atoi(e)) grid = h->n_cu * atoi(e); }
         k_ovl_walk<WALK_HEAD><<<grid, 64, 0, st>>>(ix, n, d_ids, min_match, nullptr, (uint32_t)sizeof(FmdWalkPark), 0, nullptr, d_rec,
-                                                nullptr, seq_stride, q, 0, park, nullptr, adm, walk_ticket_chunk("FMD_HEAD_TICKETS", 256, n, grid));
+                                                nullptr, seq_stride, q, 0, park, nullptr, adm, walk_ticket_chunk("FMD_HEAD_TICKETS", 256, n, grid), nullptr);
     }
     // the order of pass 2: rows sorted by the minimizer of the bases each strand has shown so far
     return fmd_park_sort(st, n, park, keys_a, keys_sorted, vals_a, order, tmp, tmp_bytes);
@@ -1610,7 +1727,7 @@ extern "C" int fmd_seqinfo_dev(fmd_dev_t *h, void *stream_, size_t n, const uint
     fmd_intv_t *listA = (fmd_intv_t *)((uint8_t *)d_work + align_up(n * (size_t)stride_r, 256));
     uint32_t *q0 = fmd_next_queue(h, st);
     k_ovl_walk<WALK_WHOLE><<<fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16), 64, 0, st>>>(fmd_view(h), n, d_ids, 0, srev, stride_r, cap, listA, d_rec,
-                                                                                         d_seq, seq_stride, q0, 1, nullptr, nullptr, nullptr, FMD_TICKET_CHUNK);
+                                                                                         d_seq, seq_stride, q0, 1, nullptr, nullptr, nullptr, FMD_TICKET_CHUNK, nullptr);
     launch_seq_out(st, n, max_len, srev, stride_r, d_rec, 0, 1, d_seq, seq_stride);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "k_ovl_walk"); return FMD_E_HIP; }
