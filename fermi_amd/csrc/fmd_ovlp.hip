@@ -238,6 +238,11 @@ enum { WALK_WHOLE = 0, WALK_HEAD = 1, WALK_TAIL = 2, WALK_TAIL2 = 3 };   // (FMD
 #define WALK_LS_WORDS 7
 #define WALK_LS_BASES (16 * WALK_LS_WORDS)
 #define WALK_F_HASN 0x80000000u       // (in the walk's `flags` register only: never stored)
+// the strand's FIRST candidate (the widest: shortest overlap) as k_ovl_classify reads it back from listA -- size <= 63, narrow form, size > 31
+#define WALK_F_W63 0x40000000u
+#define WALK_F_WNARROW 0x20000000u
+#define WALK_F_W32 0x10000000u
+#define WALK_F_INTERNAL 0xf0000000u
 struct __attribute__((packed, aligned(4))) WalkU4 { uint32_t x, y, z, w; };   // a 16-byte store at a 4-byte aligned address
 // four bases, 2 bits each, first found (= LAST in read order) in the low bits -> their nt6 codes as the four bytes of a word in read order
 __device__ __forceinline__ uint32_t walk_expand4(uint32_t win8)
@@ -291,7 +296,8 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
                                                  fmd_intv_t *__restrict__ listA, fmd_ovlp_rec_t *__restrict__ rec,
                                                  uint8_t *__restrict__ seq_out, uint32_t seq_stride, uint32_t *__restrict__ queue,
                                                  int info_only, FmdWalkPark *__restrict__ park, const uint32_t *__restrict__ gidx,
-                                                 const uint4 *__restrict__ adm, uint32_t tchunk, uint32_t *__restrict__ redo)
+                                                 const uint4 *__restrict__ adm, uint32_t tchunk, uint32_t *__restrict__ redo,
+                                                 uint32_t *__restrict__ cls, int cls_cfg)
 {
     FMD_DECLARE_COMPACT_LDS();
     __shared__ uint32_t walk_ls[MODE == WALK_TAIL2 ? 64 * WALK_LS_WORDS : 1];   // WALK_TAIL2: the lane's bases, word w of lane l at [w * 64 + l]
@@ -299,6 +305,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
     size_t sid = 0;
     size_t gs = 0;                        // the strand's row in rec[] (WALK_TAIL: gidx[sid], otherwise sid)
     int st = WK_IDLE, c_pend = 0, ret = 0;
+    int fin_cls = -1;                     // WALK_TAIL2 with the work lists of get_nei made here (cls != nullptr): the list of the strand this lane has just finished
     uint32_t depth = 0, npush = 0, pack = 0, flags = 0;
     uint32_t pk0 = 0, pk1 = 0, pk2 = 0;   // the stash is written 16 bases at a time (one 16-byte store per lane instead of four words)
     uint64_t k = 0, x0 = 0, x1 = 0, sz = 0;
@@ -313,6 +320,37 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
     FmdTickets tk_;
     fmd_tickets_init(tk_, queue, tchunk & 0xffffffu, (MODE != WALK_WHOLE && (tchunk >> 24)) ? n : 0);   // (bit 24: guided chunks, the two passes of a sorted job)
     for (;;) {
+        if (MODE == WALK_TAIL2 && cls != nullptr) {
+            // k_ovl_classify's work, by the lanes that finished a strand in the last step (reads of one length: the whole wave): one returning atomic per
+            // list that gets entries, all of them issued at once (lane j reserves for the j-th distinct list), then every lane writes its entry.  The lists
+            // and counters are where ovl_phase_b expects them (FmdOvlClasses over `cls`); depth, npush and sid are still the finished strand's.
+            uint64_t rem = __ballot(fin_cls >= 0);
+            if (rem) {
+                const int lane = fmd_lane();
+                int my_c = 0, nc = 0;
+                uint32_t my_cnt = 0, my_slot = 0, my_rank = 0;
+                while (rem) {
+                    const int c = __builtin_amdgcn_readlane(fin_cls, __ffsll((unsigned long long)rem) - 1);
+                    const uint64_t mk = __ballot(fin_cls == c);
+                    if (lane == nc) { my_c = c; my_cnt = (uint32_t)__popcll(mk); }
+                    if (fin_cls == c) { my_slot = (uint32_t)nc; my_rank = (uint32_t)fmd_below(mk); }
+                    rem &= ~mk; ++nc;
+                }
+                uint32_t base = 0;
+                if (lane < nc) base = atomicAdd(cls + my_c * FMD_CLS_CNT_STRIDE, my_cnt);
+                base = (uint32_t)__shfl((int)base, (int)my_slot) + my_rank;
+                if (fin_cls >= 0) {
+                    const size_t gl = 2 * n + 2 * (size_t)FMD_FAST_RESERVE;           // words of a general list
+                    uint32_t *lslow = cls + FMD_CLS_HEADER_U32 + gl * FMD_GRP_CLASSES;
+                    if (fin_cls == FMD_GRP_CLASSES) lslow[base] = (uint32_t)sid;
+                    else {
+                        uint32_t *lst = fin_cls < FMD_GRP_CLASSES ? cls + FMD_CLS_HEADER_U32 + gl * fin_cls : lslow + n + 2 * n * (size_t)(fin_cls - FMD_GRP_CLASSES - 1);
+                        lst[2 * base] = (uint32_t)sid; lst[2 * base + 1] = npush | depth << 16;
+                    }
+                    fin_cls = -1;
+                }
+            }
+        }
         const size_t my = fmd_tickets_take(tk_, queue, st == WK_IDLE && !exhausted, (MODE != WALK_WHOLE && (tchunk >> 24)) ? n : 0);
         if (st == WK_IDLE && !exhausted) {
             // The two passes of a sorted job take a strand in over one (WALK_HEAD) or two (WALK_TAIL) wave steps: the loads are issued
@@ -517,6 +555,8 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
                         fmd_intv_t *e = listA + sid * (size_t)cap + (cap - 1 - npush);
                         if (narrow && depth < 65536u) cand_store_narrow(e, x0, x1, (uint32_t)sz, depth, wD, wr0);
                         else store_entry(e, x0, x1, sz, (uint64_t)depth);
+                        if (MODE == WALK_TAIL2 && npush == 0)
+                            flags |= (sz <= 63 ? WALK_F_W63 : 0u) | (narrow && depth < 65536u ? WALK_F_WNARROW : 0u) | (sz > 31 ? WALK_F_W32 : 0u);
                     } else flags |= FMD_OVLP_F_OVERFLOW;
                     ++npush;
                 }
@@ -562,7 +602,16 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
             o->k[0] = x0; o->k[1] = t0k; o->k[2] = t0l - t0k;
             o->status = ret < 0 ? -3 : 0;
             o->n_ovlp = (int32_t)npush;
-            o->flags = flags & ~WALK_F_HASN;
+            o->flags = flags & ~WALK_F_INTERNAL;
+            if (MODE == WALK_TAIL2 && cls != nullptr && ret >= 0 && npush > 0 && !(flags & FMD_OVLP_F_OVERFLOW)) {   // k_ovl_classify's rule (fmd_ovlp_grp.hip)
+                int c = FMD_GRP_CLASSES;
+                if ((flags & WALK_F_W63) && depth < 65535u) {
+#pragma unroll
+                    for (int kk = FMD_GRP_CLASSES - 1; kk >= 0; --kk) if (kk >= (cls_cfg >> 8) && npush <= (uint32_t)fmd_grp_size(kk)) c = kk;
+                    if (c < FMD_GRP_CLASSES && (flags & WALK_F_WNARROW) && (cls_cfg & 1)) c += FMD_GRP_CLASSES + 1 + ((flags & WALK_F_W32) ? FMD_GRP_CLASSES : 0);
+                }
+                fin_cls = c;
+            }
             st = WK_IDLE;
             continue;
         }
@@ -1169,6 +1218,21 @@ struct OvlBatch {
     const uint32_t *gidx; FmdWalkPark *park;
 };
 
+// The second pass of a sorted job through k_ovl_walk<WALK_TAIL2> (rows written by the walk, FMD_WALK_TAIL2=0: the A/B switch), and with the work
+// lists of get_nei made by the walk as well (FMD_WALK_CLS=0: k_ovl_classify behind it as before)?
+static bool ovl_tail2(const OvlBatch &o)
+{
+    const char *e = getenv("FMD_WALK_TAIL2");
+    return o.gidx && o.stride_r <= WALK_LS_BASES && o.seq_stride >= o.stride_r + 4 && (o.seq_stride & 3) == 0 && !(e && atoi(e) == 0);
+}
+static bool ovl_tail2_cls(const OvlBatch &o)
+{
+    const char *e = getenv("FMD_WALK_CLS");
+    return ovl_tail2(o) && !getenv("FMD_OVLP_SLOW_ONLY") && !(e && atoi(e) == 0);
+}
+static int ovl_use_fast(void) { const char *ef = getenv("FMD_OVLP_FAST"); return fmd_nei_fast_available() && !(ef && atoi(ef) == 0); }   // FMD_OVLP_FAST=0: A/B switch, every strand through the general group kernels
+static int ovl_min_cls(void) { const char *e = getenv("FMD_GRP4"); return e && atoi(e) == 0 ? 1 : 0; }                                  // FMD_GRP4=0: no groups of 4 (as fmd_launch_classify)
+
 // phase A: LF-walk + overlap_intv + fm6_is_contained, then the read-order copy.  per_cu > 0 bounds the
 // resident waves per CU (pipelined batches leave room for phase B of the previous part).
 static void ovl_phase_a(const OvlBatch &o, hipStream_t st, size_t b, size_t np, int per_cu)
@@ -1183,17 +1247,18 @@ static void ovl_phase_a(const OvlBatch &o, hipStream_t st, size_t b, size_t np, 
         if (per_cu > 0 && grid > o.h->n_cu * per_cu) grid = o.h->n_cu * per_cu;
         // sequences of at most WALK_LS_BASES bases: the rows in read order come from the walk itself (WALK_TAIL2: bases in LDS, no stash in HBM, no k_ovl_seq_out);
         // FMD_WALK_TAIL2=0 is the A/B switch.  The stash area, idle then, holds the list of the strands with an N: [0] their number, [1 ..] their slots.
-        const char *e2 = getenv("FMD_WALK_TAIL2");
-        if (o.stride_r <= WALK_LS_BASES && o.seq_stride >= o.stride_r + 4 && (o.seq_stride & 3) == 0 && !(e2 && atoi(e2) == 0)) {
+        if (ovl_tail2(o)) {
             uint32_t *redo = (uint32_t *)srev;
             (void)hipMemsetAsync(redo, 0, 4, st);
+            uint32_t *cls = nullptr;      // the work lists of phase B made here (part 0 of the batch: a sorted job's batches are not pipelined)
+            if (ovl_tail2_cls(o)) { cls = o.cls + b * FMD_CLS_WORDS_PER_STRAND; (void)hipMemsetAsync(cls, 0, 4 * FMD_CLS_HEADER_U32, st); }
             grid = fmd_grid_for_lds(o.h, np, FMD_COMPACT_LDS_U4 * 16 + 64 * WALK_LS_WORDS * 4);
             if (per_cu > 0 && grid > o.h->n_cu * per_cu) grid = o.h->n_cu * per_cu;
-            k_ovl_walk<WALK_TAIL2><<<grid, 64, 0, st>>>(o.ix, np, nullptr, o.min_match, srev, o.stride_r, o.cap, listA, o.rec, seq, o.seq_stride, q0, 0, o.park, o.gidx + b, nullptr, walk_ticket_chunk("FMD_TAIL_TICKETS", 64, np, grid), redo);
+            k_ovl_walk<WALK_TAIL2><<<grid, 64, 0, st>>>(o.ix, np, nullptr, o.min_match, srev, o.stride_r, o.cap, listA, o.rec, seq, o.seq_stride, q0, 0, o.park, o.gidx + b, nullptr, walk_ticket_chunk("FMD_TAIL_TICKETS", 64, np, grid), redo, cls, ovl_use_fast() | ovl_min_cls() << 8);
             k_ovl_seq_redo<<<64, 64, 0, st>>>(o.ix, redo, o.gidx + b, o.park, o.rec, seq, o.seq_stride);
             return;
         }
-        k_ovl_walk<WALK_TAIL><<<grid, 64, 0, st>>>(o.ix, np, nullptr, o.min_match, srev, o.stride_r, o.cap, listA, o.rec, seq, o.seq_stride, q0, 0, o.park, o.gidx + b, nullptr, walk_ticket_chunk("FMD_TAIL_TICKETS", 64, np, grid), nullptr);
+        k_ovl_walk<WALK_TAIL><<<grid, 64, 0, st>>>(o.ix, np, nullptr, o.min_match, srev, o.stride_r, o.cap, listA, o.rec, seq, o.seq_stride, q0, 0, o.park, o.gidx + b, nullptr, walk_ticket_chunk("FMD_TAIL_TICKETS", 64, np, grid), nullptr, nullptr, 0);
         launch_seq_out(st, np, o.max_len, srev, o.stride_r, o.rec, o.min_match, 0, seq, o.seq_stride, o.gidx + b);
         return;
     }
@@ -1206,7 +1271,7 @@ static void ovl_phase_a(const OvlBatch &o, hipStream_t st, size_t b, size_t np, 
     int grid = fmd_grid_for_lds(o.h, np, FMD_COMPACT_LDS_U4 * 16);
     { const char *e = getenv("FMD_WALK_WAVES"); if (per_cu <= 0 && e && atoi(e) > 0) per_cu = atoi(e); }   // A/B knob: resident waves per CU
     if (per_cu > 0 && grid > o.h->n_cu * per_cu) grid = o.h->n_cu * per_cu;
-    k_ovl_walk<WALK_WHOLE><<<grid, 64, 0, st>>>(o.ix, np, o.ids + b, o.min_match, srev, o.stride_r, o.cap, listA, o.rec + b, seq, o.seq_stride, q0, 0, nullptr, nullptr, nullptr, walk_ticket_chunk("FMD_WALK_TICKETS", 64, np, grid), nullptr);
+    k_ovl_walk<WALK_WHOLE><<<grid, 64, 0, st>>>(o.ix, np, o.ids + b, o.min_match, srev, o.stride_r, o.cap, listA, o.rec + b, seq, o.seq_stride, q0, 0, nullptr, nullptr, nullptr, walk_ticket_chunk("FMD_WALK_TICKETS", 64, np, grid), nullptr, nullptr, 0);
     launch_seq_out(st, np, o.max_len, srev, o.stride_r, o.rec + b, o.min_match, 0, seq, o.seq_stride);
 }
 
@@ -1237,11 +1302,11 @@ static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, i
     uint32_t *lslow_late = cl.lslow + np + 2 * np * (size_t)(2 * FMD_GRP_CLASSES);   // strands the fast / group kernels hand back (behind the fast lists)
     const size_t fix_off = np;                                                        // the fix-up list (fake forks the group kernels closed), behind that one
     uint32_t *n_slow = cl.cnt + FMD_GRP_CLASSES * FMD_CLS_CNT_STRIDE, *n_late = n_slow + FMD_CLS_LATE_CNT;
-    FMD_HIP_TRY(hipMemsetAsync(cls, 0, 4 * FMD_CLS_HEADER_U32, st));
-    // FMD_OVLP_FAST=0: A/B switch, every strand through the general group kernels
-    const char *ef = getenv("FMD_OVLP_FAST");
-    const int use_fast = fmd_nei_fast_available() && !(ef && atoi(ef) == 0);
-    fmd_launch_classify(st, np, rec, listA, o.cap, cl, use_fast, gidx);
+    const int use_fast = ovl_use_fast();
+    if (!(part == 0 && ovl_tail2_cls(o))) {   // (else: k_ovl_walk<WALK_TAIL2> has zeroed the header and filled the lists)
+        FMD_HIP_TRY(hipMemsetAsync(cls, 0, 4 * FMD_CLS_HEADER_U32, st));
+        fmd_launch_classify(st, np, rec, listA, o.cap, cl, use_fast, gidx);
+    }
     // what classification sets aside (more than 32 candidates, a candidate wider than 63) goes through the lane-per-strand kernel NOW, on a
     // side stream beside the group kernels: it is a handful of long dependent chains (10 ms per 2*10^7 strands of raw reads for 1 % of
     // them), latency from end to end
@@ -1524,7 +1589,7 @@ static int ovl_head(fmd_dev *h, hipStream_t st, size_t n, const uint64_t *d_ids,
         int grid = fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16);
         { const char *e = getenv("FMD_HEAD_WAVES"); if (e && atoi(e) > 0 && grid > h->n_cu * atoi(e)) grid = h->n_cu * atoi(e); }
         k_ovl_walk<WALK_HEAD><<<grid, 64, 0, st>>>(ix, n, d_ids, min_match, nullptr, (uint32_t)sizeof(FmdWalkPark), 0, nullptr, d_rec,
-                                                nullptr, seq_stride, q, 0, park, nullptr, adm, walk_ticket_chunk("FMD_HEAD_TICKETS", 256, n, grid), nullptr);
+                                                nullptr, seq_stride, q, 0, park, nullptr, adm, walk_ticket_chunk("FMD_HEAD_TICKETS", 256, n, grid), nullptr, nullptr, 0);
     }
     // the order of pass 2: rows sorted by the minimizer of the bases each strand has shown so far
     return fmd_park_sort(st, n, park, keys_a, keys_sorted, vals_a, order, tmp, tmp_bytes);
@@ -1727,7 +1792,7 @@ extern "C" int fmd_seqinfo_dev(fmd_dev_t *h, void *stream_, size_t n, const uint
     fmd_intv_t *listA = (fmd_intv_t *)((uint8_t *)d_work + align_up(n * (size_t)stride_r, 256));
     uint32_t *q0 = fmd_next_queue(h, st);
     k_ovl_walk<WALK_WHOLE><<<fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16), 64, 0, st>>>(fmd_view(h), n, d_ids, 0, srev, stride_r, cap, listA, d_rec,
-                                                                                         d_seq, seq_stride, q0, 1, nullptr, nullptr, nullptr, FMD_TICKET_CHUNK, nullptr);
+                                                                                         d_seq, seq_stride, q0, 1, nullptr, nullptr, nullptr, FMD_TICKET_CHUNK, nullptr, nullptr, 0);
     launch_seq_out(st, n, max_len, srev, stride_r, d_rec, 0, 1, d_seq, seq_stride);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fmd_set_hip_error(e, "k_ovl_walk"); return FMD_E_HIP; }
