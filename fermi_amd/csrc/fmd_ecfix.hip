@@ -64,105 +64,172 @@ __device__ __forceinline__ uint64_t ec_hash(uint64_t x)   // splitmix64 finalise
     return x ^ (x >> 31);
 }
 
+// The table is bucketed by 64-byte lines of eight slots: a k-mer goes into the first free slot of its home line, the next line when that one is full.
+// Nothing is ever removed, so a line with a free slot has never been full: a look-up that finds neither the k-mer nor a free slot in a line goes on to the
+// next, anything else ends there -- one line, fetched as four 16-byte loads in flight together, for all but the ~1 % of the look-ups whose home line is
+// full (load <= 1/2), where linear probing over single slots made 1.7 dependent round trips per look-up, and the slowest lane's chain is the wave's.
+#define EC_LINE 8
 __global__ void k_ectab_fill(uint64_t n, int suf_len, const uint32_t *__restrict__ bucket, const uint32_t *__restrict__ key, const uint8_t *__restrict__ val,
                              uint64_t *__restrict__ slots, uint64_t mask, uint32_t *__restrict__ full_flag)
 {
-    const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t step = (uint64_t)gridDim.x * blockDim.x, lmask = mask >> 3;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
         // the k-mer a look-up will present (correct.c:156-157): bucket = its low 2*suf_len bits, key >> 2 = the rest
         const uint64_t x = (uint64_t)(key[i] >> 2) << (2 * suf_len) | bucket[i];
         const uint64_t e = x << 10 | (uint64_t)val[i] << 2 | (key[i] & 3);
         if (e == EC_EMPTY) { *full_flag = 1u; continue; }
-        uint64_t p = ec_hash(x) & mask;
-        for (;;) {
-            const unsigned long long old = atomicCAS((unsigned long long *)(slots + p), (unsigned long long)EC_EMPTY, (unsigned long long)e);
-            if (old == EC_EMPTY) break;
-            p = (p + 1) & mask;
-        }
+        uint64_t ln = ec_hash(x) & lmask;
+        for (bool placed = false; !placed; ln = (ln + 1) & lmask)
+            for (int k = 0; k < EC_LINE && !placed; ++k)
+                placed = atomicCAS((unsigned long long *)(slots + ln * EC_LINE + k), (unsigned long long)EC_EMPTY, (unsigned long long)e) == EC_EMPTY;
     }
 }
 
 // kh_get(solid, h, key) of correct.c:156-157: -1, or val << 2 | best base
 __device__ __forceinline__ int ec_lookup(const uint64_t *__restrict__ slots, uint64_t mask, uint64_t x, bool full, EcCount &C)
 {
-    uint64_t p = ec_hash(x) & mask;
+    const uint64_t lmask = mask >> 3;
+    uint64_t ln = ec_hash(x) & lmask;
     for (;;) {
-        const uint64_t e = slots[p];
-        C.add(0);
-        if (e == EC_EMPTY) return (full && x == (EC_EMPTY >> 10)) ? 0x3ff : -1;
-        if ((e >> 10) == x) return (int)(e & 0x3ff);
-        p = (p + 1) & mask;
+        const uint4 *q = (const uint4 *)(slots + ln * EC_LINE);
+        const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+        C.add(0, EC_LINE);
+        const uint64_t e[EC_LINE] = {(uint64_t)a.y << 32 | a.x, (uint64_t)a.w << 32 | a.z, (uint64_t)b.y << 32 | b.x, (uint64_t)b.w << 32 | b.z,
+                                     (uint64_t)c.y << 32 | c.x, (uint64_t)c.w << 32 | c.z, (uint64_t)d.y << 32 | d.x, (uint64_t)d.w << 32 | d.z};
+        int hit = -2;
+        bool free_slot = false;
+#pragma unroll
+        for (int k = 0; k < EC_LINE; ++k) {
+            if ((e[k] >> 10) == x && e[k] != EC_EMPTY) hit = (int)(e[k] & 0x3ff);
+            free_slot |= e[k] == EC_EMPTY;
+        }
+        if (hit >= 0) return hit;
+        if (free_slot) return (full && x == (EC_EMPTY >> 10)) ? 0x3ff : -1;
+        ln = (ln + 1) & lmask;
     }
 }
 
 struct EcNode { uint64_t x; int64_t y; };
 
-// binary min-heap on y in the lane's slice (any queue gives the reference's order: the keys are distinct)
-__device__ __forceinline__ void ec_push(uint4 *heap, uint32_t &hn, uint64_t x, int64_t y, EcCount &C)
+// ---- where a lane keeps what it works on -------------------------------------------------------------------------------------------
+// The bases of a read of at most EC_LDS_BASES bases are staged in LDS when the lane takes it, 4 bits each, in read order (word w of lane l at
+// [w * 64 + l]: lanes side by side, no bank conflicts when they ask for the same word).  The first EC_LDS_H entries of the lane's queue -- a binary
+// heap: the top is what every expansion reads -- live in LDS as well; a read with a few errors never has more paths than that (per error: the path
+// that leaves the read there and the path that stays), so only error-ridden reads ever touch the slice of HBM behind it.  A quality is needed once
+// per expansion, of a position known before the table is asked: its byte is loaded beside the table's line, and it rides in the trace entry for the
+// walk back (correct.c:213-218 reads it again there).  What is left for HBM per turn: the table's line (the point of the exercise), that byte, one
+// 8-byte store to the trace.  Round 4's kernel kept all of it in HBM behind byte loads -- ~17 dependent round trips per expansion, 409 ms per 5*10^7 reads.
+#define EC_LDS_H 6
+#define EC_LDS_BASES 128
+#define EC_LDS_BW (EC_LDS_BASES / 8)          // words of bases per lane
+#define EC_LDS_BYTES (EC_LDS_H * 64 * 16 + EC_LDS_BW * 64 * 4)   // 10 KiB per wave: 16 waves per CU
+
+struct EcHeap {                                // entry k of the lane's queue
+    uint4 *lds; uint4 *hbm;                    // lds + k * 64 for k < EC_LDS_H, hbm + k beyond
+    __device__ __forceinline__ uint4 get(uint32_t k, EcCount &C) const { if (k < EC_LDS_H) return lds[k * 64]; C.add(1); return hbm[k]; }
+    __device__ __forceinline__ void put(uint32_t k, const uint4 v, EcCount &C) const { if (k < EC_LDS_H) lds[k * 64] = v; else { C.add(1); hbm[k] = v; } }
+};
+__device__ __forceinline__ int64_t ec_key(const uint4 v) { return (int64_t)((uint64_t)v.w << 32 | v.z); }
+
+// binary min-heap on y (any queue gives the reference's order: the keys are distinct)
+__device__ __forceinline__ void ec_push(const EcHeap &H, uint32_t &hn, uint64_t x, int64_t y, EcCount &C)
 {
     uint32_t k = hn++;
-    C.add(1);
     while (k) {
         const uint32_t p = (k - 1) >> 1;
-        const uint4 v = heap[p];
-        C.add(1);
-        const int64_t py = (int64_t)((uint64_t)v.w << 32 | v.z);
-        if (py <= y) break;
-        heap[k] = v; k = p;
-        C.add(1);
+        const uint4 v = H.get(p, C);
+        if (ec_key(v) <= y) break;
+        H.put(k, v, C); k = p;
     }
-    heap[k] = make_uint4((uint32_t)x, (uint32_t)(x >> 32), (uint32_t)(uint64_t)y, (uint32_t)((uint64_t)y >> 32));
+    H.put(k, make_uint4((uint32_t)x, (uint32_t)(x >> 32), (uint32_t)(uint64_t)y, (uint32_t)((uint64_t)y >> 32)), C);
 }
-__device__ __forceinline__ EcNode ec_pop(uint4 *heap, uint32_t &hn, EcCount &C)
+__device__ __forceinline__ EcNode ec_pop(const EcHeap &H, uint32_t &hn, EcCount &C)
 {
-    const uint4 top = heap[0];
-    C.add(1, 3);    // the top, the last entry, the entry written back at the end
-    EcNode r; r.x = (uint64_t)top.y << 32 | top.x; r.y = (int64_t)((uint64_t)top.w << 32 | top.z);
-    const uint4 last = heap[--hn];
-    const int64_t ly = (int64_t)((uint64_t)last.w << 32 | last.z);
+    const uint4 top = H.get(0, C);
+    EcNode r; r.x = (uint64_t)top.y << 32 | top.x; r.y = ec_key(top);
+    const uint4 last = H.get(--hn, C);
+    const int64_t ly = ec_key(last);
     uint32_t i = 0;
     for (;;) {
         uint32_t c = 2 * i + 1;
         if (c >= hn) break;
-        uint4 cv = heap[c];
-        int64_t cy = (int64_t)((uint64_t)cv.w << 32 | cv.z);
-        C.add(1);
+        uint4 cv = H.get(c, C);
+        int64_t cy = ec_key(cv);
         if (c + 1 < hn) {
-            const uint4 dv = heap[c + 1];
-            C.add(1);
-            const int64_t dy = (int64_t)((uint64_t)dv.w << 32 | dv.z);
+            const uint4 dv = H.get(c + 1, C);
+            const int64_t dy = ec_key(dv);
             if (dy < cy) { cv = dv; cy = dy; ++c; }
         }
         if (ly <= cy) break;
-        heap[i] = cv; i = c;
-        C.add(1);
+        H.put(i, cv, C); i = c;
     }
-    if (hn) heap[i] = last;
+    if (hn) H.put(i, last, C);
     return r;
 }
 
 // One read, seen from one strand.  Pass 0 works on the reverse complement with the qualities reversed (correct.c:237-238):
 // logical position i is byte len-1-i, bases complemented; pass 1 is the read as stored.
 struct EcRead {
-    uint8_t *s, *q; int len; bool rc;
-    __device__ __forceinline__ int base(int i) const { const int c = s[rc ? len - 1 - i : i]; return rc ? comp6(c) : c; }
-    __device__ __forceinline__ void set_base(int i, int c) { s[rc ? len - 1 - i : i] = (uint8_t)(rc ? comp6(c) : c); }
-    __device__ __forceinline__ int qual(int i) const { return q[rc ? len - 1 - i : i]; }
-    __device__ __forceinline__ void set_qual(int i, int v) { q[rc ? len - 1 - i : i] = (uint8_t)v; }
+    uint8_t *s, *q; int len; bool rc, staged;
+    uint32_t *lb;                              // the lane's words of bases in LDS (staged reads)
+    __device__ __forceinline__ int at(int i) const { return rc ? len - 1 - i : i; }
+    __device__ __forceinline__ int base(int i) const
+    {
+        const int j = at(i);
+        const int c = staged ? (int)((lb[(j >> 3) * 64] >> (4 * (j & 7))) & 0xfu) : (int)s[j];
+        return rc ? comp6(c) : c;
+    }
+    __device__ __forceinline__ void set_base(int i, int c)
+    {
+        const int j = at(i);
+        const uint32_t v = (uint32_t)(rc ? comp6(c) : c);
+        s[j] = (uint8_t)v;
+        if (staged) { uint32_t *w = lb + (j >> 3) * 64; *w = (*w & ~(0xfu << (4 * (j & 7)))) | v << (4 * (j & 7)); }
+    }
+    __device__ __forceinline__ int qual(int i) const { return (int)q[at(i)]; }
+    __device__ __forceinline__ void set_qual(int i, int v) { q[at(i)] = (uint8_t)v; }
 };
+// The read into the lane's LDS words: aligned 4-byte loads funnel-shifted into place, whatever the alignment of its first byte; a word is loaded only if
+// it holds a byte of the read (bytes past the read's end inside its last word: whatever follows, never looked at).
+__device__ __forceinline__ void ec_stage_words(const uint8_t *p, int len, uint32_t *dst, bool nibbles)
+{
+    const uint32_t *al = (const uint32_t *)((uintptr_t)p & ~(uintptr_t)3);
+    const uint32_t sh = 8u * (uint32_t)((uintptr_t)p & 3);
+    const uint32_t *last = (const uint32_t *)((uintptr_t)(p + len - 1) & ~(uintptr_t)3);   // the word of the read's last byte
+    const int nw = (len + 3) >> 2;
+    uint32_t carry = al[0], acc = 0;
+    for (int w = 0; w < nw; ++w) {
+        const uint32_t nxt = al + w + 1 <= last ? al[w + 1] : 0u;
+        const uint32_t d = sh ? __builtin_amdgcn_alignbit(nxt, carry, sh) : carry;
+        carry = nxt;
+        if (!nibbles) dst[w * 64] = d;
+        else {
+            uint32_t t = (d | d >> 4) & 0x00ff00ffu; t = (t | t >> 8) & 0xffffu;   // four bases -> four nibbles
+            if (w & 1) dst[(w >> 1) * 64] = acc | t << 16; else acc = t;
+        }
+    }
+    if (nibbles && (nw & 1)) dst[(nw >> 1) * 64] = acc;
+}
+__device__ __forceinline__ void ec_stage(EcRead &r)
+{
+    r.staged = r.len > 0 && r.len <= EC_LDS_BASES;
+    if (!r.staged) return;
+    ec_stage_words(r.s, r.len, r.lb, true);
+}
 
 // a new path: `par` extended by base code c (0..3; an N in the read is followed as A, correct.c:101) at a cost
-__device__ __forceinline__ bool ec_branch(uint4 *heap, uint32_t &hn, uint64_t *trace, uint32_t &tn, uint32_t trace_cap, const EcNode &par, int c, int cost,
-                                          int shift, int has_match, EcCount &C)
+// (qv: the quality byte of the position the path steps over -- the walk back wants it, correct.c:215-217, and takes it from the trace entry)
+__device__ __forceinline__ bool ec_branch(const EcHeap &H, uint32_t &hn, uint64_t *trace, uint32_t &tn, uint32_t trace_cap, const EcNode &par, int c, int cost,
+                                          int shift, int has_match, int qv, EcCount &C)
 {
     if (tn >= trace_cap) return false;
     if (cost < 0) cost = 0;
     if (c >= 4) c = 0;
     const uint64_t py = (uint64_t)par.y, left = (py & 0xffff) - 1;
     const uint64_t y = ((py >> 48) + (uint64_t)cost) << 48 | (uint64_t)tn << 16 | left;
-    trace[tn++] = left << 32 | (uint64_t)((uint32_t)c << 29 | (uint32_t)has_match << 28 | (uint32_t)(py >> 16)); // position | base | matched | parent
+    trace[tn++] = ((uint64_t)(uint32_t)qv << 16 | left) << 32 | (uint64_t)((uint32_t)c << 29 | (uint32_t)has_match << 28 | (uint32_t)(py >> 16)); // quality, position | base | matched | parent
     C.add(2);
-    ec_push(heap, hn, (uint64_t)c << shift | par.x >> 2, (int64_t)y, C);
+    ec_push(H, hn, (uint64_t)c << shift | par.x >> 2, (int64_t)y, C);
     return true;
 }
 
@@ -179,16 +246,14 @@ __device__ __forceinline__ int ec_swap_penalty(int v)
 }
 __device__ __forceinline__ int ec_depth(int v) { return (v & 7) ? (v & 7) * ((v >> 3) + 1) : v >> 3; }
 
-// ec_fix1 (correct.c:121-220) on the strand `r`, cut into the pieces a lane runs between two looks at the wave:
-// seed (the first path), one expansion of the best path, and the closing step (scores, trace applied to the read).
+// ec_fix1 (correct.c:121-220) on the strand `r`: the state of its best-first search
 struct EcSearch {
     uint32_t hn, tn;           // paths in the queue, trace entries
     int n_done, no_hits;
-    int64_t done_y[2];         // keys of the (up to two) best finished paths
+    int64_t done_y0, done_y1;  // keys of the (up to two) best finished paths
 };
-enum { EC_MORE = 0, EC_DONE = 1, EC_FULL = 2 };
 
-__device__ __forceinline__ bool ec_seed(const EcRead &r, int w, EcSearch &S, uint4 *heap, uint64_t *trace, EcCount &C)   // false: ec_fix1 returns 0xffff
+__device__ __forceinline__ bool ec_seed(const EcRead &r, int w, EcSearch &S, const EcHeap &H, uint64_t *trace, EcCount &C)   // false: ec_fix1 returns 0xffff
 {
     const int shift = (w - 1) << 1;
     if (r.len <= w) return false;
@@ -200,126 +265,153 @@ __device__ __forceinline__ bool ec_seed(const EcRead &r, int w, EcSearch &S, uin
         else { x = (uint64_t)(c - 1) << shift | x >> 2; ++l; }
     }
     if (i == 0) return false;
-    S.hn = 0; S.tn = 0; S.n_done = 0; S.no_hits = 1; S.done_y[0] = S.done_y[1] = 0;
+    S.hn = 0; S.tn = 0; S.n_done = 0; S.no_hits = 1; S.done_y0 = S.done_y1 = 0;
     trace[S.tn++] = 0;
     C.add(2);
-    ec_push(heap, S.hn, x, (int64_t)(i + 1), C);
+    ec_push(H, S.hn, x, (int64_t)(i + 1), C);
     return true;
 }
 
-__device__ __forceinline__ int ec_expand(const EcRead &r, int w, int step, const uint64_t *__restrict__ slots, uint64_t mask, bool full, EcSearch &S, uint4 *heap,
-                                         uint64_t *trace, uint32_t trace_cap, EcCount &C)
+// One lane = one read at a time.  The search of correct.c:141-206 and the walk back along the best path (:207-219) are cut into TURNS of the wave's loop, and
+// a turn asks memory for ONE thing per lane -- a table slot (EL_POP: the best path's k-mer; EL_JUMP: the k-mer `step` bases on, correct.c:182-196) or a trace
+// entry (EL_CLOSE) -- so that the 64 requests of a wave are in flight together whatever its lanes are doing: the reference's inner loops (up to 20 dependent
+// look-ups while a clean read hops along, up to 100 dependent trace entries at the end) are turns here, not loops inside a turn that 63 lanes wait for.
+// A lane whose read is finished draws the next one at once (reads with errors take 10-100x the expansions of clean ones: a wave never waits for its slowest read).
+enum { EL_IDLE = 0, EL_POP, EL_JUMP, EL_CLOSE };
+__global__ __launch_bounds__(64, 4) void k_ecfix(size_t n, uint8_t *__restrict__ seqs, uint8_t *__restrict__ quals, const uint64_t *__restrict__ off, int w, int step,
+                                                 const uint64_t *__restrict__ slots, uint64_t mask, int32_t *__restrict__ info, uint4 *heaps, uint64_t *traces,
+                                                 uint32_t trace_cap, uint32_t *__restrict__ queue)
 {
-    const int shift = (w - 1) << 1;
-    if (S.hn == 0) return EC_DONE;
-    EcNode z = ec_pop(heap, S.hn, C);
-    const uint64_t zy = (uint64_t)z.y;
-    if ((zy & 0xffff) == 0) {                                // a path that reached the start of the strand
-        S.done_y[S.n_done++] = z.y;
-        return S.n_done == 2 ? EC_DONE : EC_MORE;
-    }
-    if (S.n_done && (int)(zy >> 48) > (int)((uint64_t)S.done_y[0] >> 48) + EC_MAX_SC_DIFF) return EC_DONE;
-    int i = (int)(zy & 0xffff) - 1, l;
-    const int b = r.base(i);
-    int q = r.qual(i) - 33;
-    q = q < EC_MAX_QUAL ? q : EC_MAX_QUAL;
-    q = q < 3 ? 3 : q;
-    const int hit = ec_lookup(slots, mask, z.x, full, C);
-    bool ok = true;
-    if (hit < 0) ok = ec_branch(heap, S.hn, trace, S.tn, trace_cap, z, b - 1, EC_MISS_PENALTY + (EC_MAX_QUAL - q), shift, 0, C);
-    else {
-        const int best = (hit & 3) + 1, v = hit >> 2;
-        S.no_hits = 0;
-        if (b != best) {                                     // the table prefers another base: follow both, within the queue's budget
-            const int pen = ec_swap_penalty(v);
-            if (b != 5 && (S.hn + 2 <= EC_MAX_HEAP || pen < q)) ok = ec_branch(heap, S.hn, trace, S.tn, trace_cap, z, b - 1, pen, shift, 1, C);
-            if (ok && (b == 5 || S.hn + 2 <= EC_MAX_HEAP || pen > q)) ok = ec_branch(heap, S.hn, trace, S.tn, trace_cap, z, best - 1, q, shift, 1, C);
-        } else {                                             // agreement: hop `step` bases at a time while the k-mers stay deep and unambiguous
-            EcNode keep = z;
-            int keep_i = i, depth_last = ec_depth(v);
-            if ((v & 7) <= 0 && step > 1) {
-                while (keep_i > 0) {
-                    for (i = (int)((uint64_t)z.y & 0xffff) - 1, l = 0; i >= 1 && l < step && r.base(i) < 5; --i, ++l)
-                        z.x = (uint64_t)(r.base(i) - 1) << shift | z.x >> 2;
-                    const int bi = r.base(i);
-                    if (bi == 5) break;
-                    const int h2 = ec_lookup(slots, mask, z.x, full, C);
-                    if (h2 < 0 || bi != (h2 & 3) + 1) break;
-                    const int v2 = h2 >> 2, depth = ec_depth(v2);
-                    if (!((v2 & 7) <= 1 && depth >= EC_MIN_OCC && (double)depth / depth_last >= EC_MIN_OCC_RATIO)) break;
-                    z.y = (int64_t)((uint64_t)z.y >> 16 << 16 | (uint64_t)(i + 1));
-                    keep = z; keep_i = i; depth_last = depth;
-                }
-            }
-            ok = ec_branch(heap, S.hn, trace, S.tn, trace_cap, keep, r.base(keep_i) - 1, 0, shift, 1, C);
-        }
-    }
-    return ok ? EC_MORE : EC_FULL;
-}
-
-__device__ __forceinline__ int ec_close(EcRead &r, const EcSearch &S, const uint64_t *trace, EcCount &C)   // ec_fix1's return value; the read is rewritten
-{
-    int score_diff = S.n_done == 1 ? EC_MAX_SC_DIFF : (int)((uint64_t)S.done_y[1] >> 48) - (int)((uint64_t)S.done_y[0] >> 48);
-    if (score_diff >= EC_MAX_SC_DIFF) score_diff = EC_MAX_SC_DIFF;
-    if (((uint64_t)S.done_y[0] >> 48) == 0) return score_diff << 18;       // nothing to change
-    int qsum = 0;
-    for (uint32_t t = (uint32_t)((uint64_t)S.done_y[0] >> 16); t;) {       // apply the best path's choices
-        const uint64_t e = trace[t];
-        C.add(2);
-        const int pos = (int)(e >> 32);
-        const uint32_t lo = (uint32_t)e, c = lo >> 29;
-        if ((uint32_t)(r.base(pos) - 1) != c) { qsum += r.qual(pos) - 33; r.set_base(pos, (int)c + 1); }
-        else if ((lo >> 28 & 1) && r.qual(pos) < 37) r.set_qual(pos, 37);
-        t = lo << 4 >> 4;
-    }
-    return qsum | score_diff << 18 | S.no_hits << 17;
-}
-
-// One lane = one read at a time, one expansion per turn of the wave's loop; a lane whose read is finished draws the next
-// one at once (reads with errors take 10-100x the expansions of clean ones: a wave never waits for its slowest read).
-__global__ __launch_bounds__(64) void k_ecfix(size_t n, uint8_t *__restrict__ seqs, uint8_t *__restrict__ quals, const uint64_t *__restrict__ off, int w, int step,
-                                              const uint64_t *__restrict__ slots, uint64_t mask, int32_t *__restrict__ info, uint4 *heaps, uint64_t *traces,
-                                              uint32_t trace_cap, uint32_t *__restrict__ queue)
-{
+    __shared__ uint4 lds_heap[EC_LDS_H * 64];
+    __shared__ uint32_t lds_bases[EC_LDS_BW * 64];
+    const int lane = (int)threadIdx.x;
     const size_t slice = (size_t)blockIdx.x * 64 + threadIdx.x;
-    uint4 *heap = heaps + slice * EC_HEAP_SLOTS;
+    EcHeap H; H.lds = lds_heap + lane; H.hbm = heaps + slice * EC_HEAP_SLOTS;
     uint64_t *trace = traces + slice * (size_t)trace_cap;
-    EcRead r; r.s = nullptr; r.q = nullptr; r.len = 0; r.rc = true;
-    EcSearch S; S.hn = S.tn = 0; S.n_done = 0; S.no_hits = 1; S.done_y[0] = S.done_y[1] = 0;
+    const int shift = (w - 1) << 1;
+    EcRead r; r.s = nullptr; r.q = nullptr; r.len = 0; r.rc = true; r.staged = false; r.lb = lds_bases + lane;
+    EcSearch S; S.hn = S.tn = 0; S.n_done = 0; S.no_hits = 1; S.done_y0 = S.done_y1 = 0;
+    EcNode z, keep;                            // EL_JUMP: the path as the hop in progress leaves it, and as the last accepted hop left it
+    z.x = 0; z.y = 0; keep = z;
+    int keep_i = 0, keep_q = 0, depth_last = 0;
+    uint32_t ct = 0;                           // EL_CLOSE: the trace entry to apply next
+    int qsum = 0, score_diff = 0;
     size_t cur = 0;
-    int ret0 = 0;
-    bool busy = false, drained = false;
+    int ret0 = 0, st = EL_IDLE;
+    bool drained = false;
     const bool full = queue[EC_FULL_FLAG] != 0;   // the one triple the table cannot hold (EC_FULL_FLAG)
     FmdTickets tk;
     EcCount C;
     fmd_tickets_init(tk, queue);
     for (;;) {
-        const size_t my = fmd_tickets_take(tk, queue, !busy && !drained);
-        if (!busy && !drained) {
+        const size_t my = fmd_tickets_take(tk, queue, st == EL_IDLE && !drained);
+        if (st == EL_IDLE && !drained) {
             if (my < n) {
                 cur = my;
                 r.s = seqs + off[my]; r.q = quals + off[my]; r.len = (int)(off[my + 1] - off[my]); r.rc = true;
-                if (ec_seed(r, w, S, heap, trace, C)) busy = true;
+                ec_stage(r);
+                if (ec_seed(r, w, S, H, trace, C)) st = EL_POP;
                 else info[my] = 0xffff;                                    // too short, or no clean k-mer (correct.c:242-246)
             } else drained = true;
         }
-        if (__ballot(busy) == 0) { if (__ballot(!drained) == 0) { C.flush(queue); break; } else continue; }
-        if (!busy) continue;
-        const int st = ec_expand(r, w, step, slots, mask, full, S, heap, trace, trace_cap, C);
-        if (st == EC_MORE) continue;
-        if (st == EC_FULL) { info[cur] = (int32_t)EC_INFO_TRACE_FULL; busy = false; continue; }
-        int ret = ec_close(r, S, trace, C);
-        if (r.rc) {                                                        // the reverse-complement strand is done: now the read as given
-            ret0 = ret;
-            r.rc = false;
-            if (ec_seed(r, w, S, heap, trace, C)) continue;
-            ret = 0xffff;                                                  // no clean k-mer at this end: ec_fix1 returns 0xffff and ec_fix combines it all the same
+        if (__ballot(st != EL_IDLE) == 0) { if (__ballot(!drained) == 0) { C.flush(queue); break; } else continue; }
+
+        // ---- what the lane wants from memory this turn
+        bool want = false, pass_done = false, hop_end = false, overflow = false;
+        int i = 0, b = 0;
+        if (st == EL_POP) {
+            if (S.hn == 0) pass_done = true;
+            else {
+                z = ec_pop(H, S.hn, C);
+                const uint64_t zy = (uint64_t)z.y;
+                if ((zy & 0xffff) == 0) {                                  // a path that reached the start of the strand
+                    if (S.n_done == 0) S.done_y0 = z.y; else S.done_y1 = z.y;
+                    ++S.n_done;
+                    pass_done = S.n_done == 2;
+                } else if (S.n_done && (int)(zy >> 48) > (int)((uint64_t)S.done_y0 >> 48) + EC_MAX_SC_DIFF) pass_done = true;
+                else { i = (int)(zy & 0xffff) - 1; b = r.base(i); want = true; }
+            }
+        } else if (st == EL_JUMP) {                                        // `step` bases on (correct.c:183-185)
+            int l;
+            for (i = (int)((uint64_t)z.y & 0xffff) - 1, l = 0; i >= 1 && l < step; --i, ++l) {
+                const int c = r.base(i);
+                if (c >= 5) break;
+                z.x = (uint64_t)(c - 1) << shift | z.x >> 2;
+            }
+            b = r.base(i);
+            if (b == 5) hop_end = true; else want = true;
         }
-        {
+        if (pass_done) {                                                   // correct.c:207-212
+            score_diff = S.n_done == 1 ? EC_MAX_SC_DIFF : (int)((uint64_t)S.done_y1 >> 48) - (int)((uint64_t)S.done_y0 >> 48);
+            if (score_diff >= EC_MAX_SC_DIFF) score_diff = EC_MAX_SC_DIFF;
+            qsum = 0;
+            ct = ((uint64_t)S.done_y0 >> 48) == 0 ? 0u : (uint32_t)((uint64_t)S.done_y0 >> 16);   // nothing to change: no walk back
+            st = EL_CLOSE;
+        }
+        // ---- the turn's one request per lane
+        int hit = -1, qv = 0;
+        uint64_t te = 0;
+        if (want) { qv = r.qual(i); hit = ec_lookup(slots, mask, z.x, full, C); }   // (the byte's load is in flight beside the line's)
+        if (st == EL_CLOSE && ct) { te = trace[ct]; C.add(2); }
+        // ---- what came back
+        if (want && st == EL_POP) {
+            int q = qv - 33;
+            q = q < EC_MAX_QUAL ? q : EC_MAX_QUAL;
+            q = q < 3 ? 3 : q;
+            bool ok = true;
+            if (hit < 0) ok = ec_branch(H, S.hn, trace, S.tn, trace_cap, z, b - 1, EC_MISS_PENALTY + (EC_MAX_QUAL - q), shift, 0, qv, C);
+            else {
+                const int best = (hit & 3) + 1, v = hit >> 2;
+                S.no_hits = 0;
+                if (b != best) {                                     // the table prefers another base: follow both, within the queue's budget
+                    const int pen = ec_swap_penalty(v);
+                    if (b != 5 && (S.hn + 2 <= EC_MAX_HEAP || pen < q)) ok = ec_branch(H, S.hn, trace, S.tn, trace_cap, z, b - 1, pen, shift, 1, qv, C);
+                    if (ok && (b == 5 || S.hn + 2 <= EC_MAX_HEAP || pen > q)) ok = ec_branch(H, S.hn, trace, S.tn, trace_cap, z, best - 1, q, shift, 1, qv, C);
+                } else {                                             // agreement: hop `step` bases at a time while the k-mers stay deep and unambiguous
+                    keep = z; keep_i = i; keep_q = qv; depth_last = ec_depth(v);
+                    if ((v & 7) <= 0 && step > 1 && keep_i > 0) st = EL_JUMP;
+                    else hop_end = true;
+                }
+            }
+            overflow = !ok;
+        } else if (want) {                                                 // EL_JUMP: is the hop good?  (correct.c:186-195)
+            bool good = hit >= 0 && b == (hit & 3) + 1;
+            if (good) {
+                const int v2 = hit >> 2, depth = ec_depth(v2);
+                good = (v2 & 7) <= 1 && depth >= EC_MIN_OCC && (double)depth / depth_last >= EC_MIN_OCC_RATIO;
+                if (good) {
+                    z.y = (int64_t)((uint64_t)z.y >> 16 << 16 | (uint64_t)(i + 1));
+                    keep = z; keep_i = i; keep_q = qv; depth_last = depth;
+                }
+            }
+            if (!good || keep_i <= 0) hop_end = true;
+        }
+        if (hop_end) {                                                     // the path goes on from where the last good hop left it (correct.c:198)
+            overflow = !ec_branch(H, S.hn, trace, S.tn, trace_cap, keep, r.base(keep_i) - 1, 0, shift, 1, keep_q, C);
+            st = EL_POP;
+        }
+        if (overflow) { info[cur] = (int32_t)EC_INFO_TRACE_FULL; st = EL_IDLE; continue; }
+        if (st != EL_CLOSE) continue;
+        if (ct) {                                                          // one choice of the best path applied (correct.c:213-218)
+            const int pos = (int)((te >> 32) & 0xffffu), qq = (int)((te >> 48) & 0xffu);
+            const uint32_t lo = (uint32_t)te, c = lo >> 29;
+            if ((uint32_t)(r.base(pos) - 1) != c) { qsum += qq - 33; r.set_base(pos, (int)c + 1); }
+            else if ((lo >> 28 & 1) && qq < 37) r.set_qual(pos, 37);
+            ct = lo << 4 >> 4;
+            if (ct) continue;
+        }
+        {                                                                  // the strand is done
+            int ret = ((uint64_t)S.done_y0 >> 48) == 0 ? score_diff << 18 : (qsum | score_diff << 18 | S.no_hits << 17);
+            if (r.rc) {                                                    // the reverse-complement strand is done: now the read as given
+                ret0 = ret;
+                r.rc = false;
+                if (ec_seed(r, w, S, H, trace, C)) { st = EL_POP; continue; }
+                ret = 0xffff;                                              // no clean k-mer at this end: ec_fix1 returns 0xffff and ec_fix combines it all the same
+            }
             int out = ((ret0 & 0xffff) + (ret & 0xffff)) | ((ret0 >> 18 < ret >> 18 ? ret0 >> 18 : ret >> 18) << 18);
             if ((ret0 >> 17 & 1) && (ret >> 17 & 1)) out |= 1 << 16;
             info[cur] = out;
-            busy = false;
+            st = EL_IDLE;
         }
     }
 }
@@ -395,12 +487,13 @@ extern "C" int fmd_ectab_build(int device, int w, int suf_len, uint64_t n, const
     return rc;
 }
 
-static int ec_grid(int device, size_t n)
+static int ec_grid(int device, size_t n)   // the resident set: a workgroup (one wave) holds EC_LDS_BYTES of the CU's 160 KiB
 {
     hipDeviceProp_t prop;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
-    size_t waves = (size_t)cus * 16, need = (n + 63) / 64;
+    const size_t per_cu = (160 * 1024) / (((size_t)EC_LDS_BYTES + 1279) / 1280 * 1280);
+    size_t waves = (size_t)cus * per_cu, need = (n + 63) / 64;
     return (int)(need < waves ? (need ? need : 1) : waves);
 }
 

@@ -38,6 +38,7 @@ struct Rccl {
     ncclResult_t_ (*GetUniqueId)(ncclUniqueId_ *) = nullptr;
     ncclResult_t_ (*CommInitRank)(void **, int, ncclUniqueId_, int) = nullptr;
     ncclResult_t_ (*CommDestroy)(void *) = nullptr;
+    ncclResult_t_ (*CommCount)(void *, int *) = nullptr;
     ncclResult_t_ (*GroupStart)() = nullptr;
     ncclResult_t_ (*GroupEnd)() = nullptr;
     ncclResult_t_ (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
@@ -57,7 +58,7 @@ Rccl &rccl()
     for (const char *nm : names) { if (nm && *nm && (r.so = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break; }
     if (!r.so) return r;
 #define RSYM(f) *(void **)(&r.f) = dlsym(r.so, "nccl" #f)
-    RSYM(GetVersion); RSYM(GetUniqueId); RSYM(CommInitRank); RSYM(CommDestroy); RSYM(GroupStart); RSYM(GroupEnd); RSYM(Send); RSYM(Recv); RSYM(AllGather); RSYM(GetErrorString);
+    RSYM(GetVersion); RSYM(GetUniqueId); RSYM(CommInitRank); RSYM(CommDestroy); RSYM(CommCount); RSYM(GroupStart); RSYM(GroupEnd); RSYM(Send); RSYM(Recv); RSYM(AllGather); RSYM(GetErrorString);
 #undef RSYM
     r.ok = r.GetVersion && r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.AllGather;
     return r;
@@ -134,6 +135,13 @@ extern "C" int fmd_comm_rccl_init(int device, int rank, int world, const uint8_t
     c->allgather = rccl_allgather; c->exchange = rccl_exchange; c->destroy = rccl_destroy;
     *out = c;
     return FMD_OK;
+}
+// ncclCommCount of a communicator fmd_comm_rccl_init made: the number of ranks RCCL itself says it joined (-1: not such a communicator / no such symbol)
+extern "C" int fmd_comm_rccl_count(const fmd_comm_t *c)
+{
+    if (!c || c->destroy != rccl_destroy || !c->ctx || !rccl().CommCount) return -1;
+    int n = -1;
+    return rccl().CommCount(((RcclCtx *)c->ctx)->comm, &n) ? -1 : n;
 }
 extern "C" void fmd_comm_free(fmd_comm_t *c)
 {
@@ -242,6 +250,10 @@ struct DBuf {   // device memory owned by the job
     int need(size_t b) { if (b <= bytes) return FMD_OK; if (p) { hipFree(p); p = nullptr; bytes = 0; } if (hipMalloc(&p, b ? b : 16) != hipSuccess) { (void)hipGetLastError(); return FMD_E_NOMEM; } bytes = b; return FMD_OK; }
     void drop() { if (p) hipFree(p); p = nullptr; bytes = 0; }
 };
+// FMD_DIST_DRY=1: fmd_ovlp_dist_new says what it allocates (every buffer of a step, the root's table and -- what a step would only allocate as rows arrive -- the
+// arena of the variable parts at its usual size), so that the sizes of a configuration can be proven on ONE rank with a stand-in communicator of the
+// intended world size before N ranks try (tools/scale_check.py `dry`)
+static bool dist_dry() { static const bool v = getenv("FMD_DIST_DRY") && atoi(getenv("FMD_DIST_DRY")) != 0; return v; }
 struct HBuf {   // pinned host memory owned by the job
     void *p = nullptr; size_t bytes = 0;
     int need(size_t b) { if (b <= bytes) return FMD_OK; if (p) { hipHostFree(p); p = nullptr; bytes = 0; } if (hipHostMalloc(&p, b ? b : 16, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return FMD_E_NOMEM; } bytes = b; return FMD_OK; }
@@ -356,7 +368,12 @@ extern "C" int fmd_ovlp_dist_new(fmd_dev_t *h, fmd_comm_t *comm, const fmd_ovlp_
     }
     d->var_cap_piece = fmd_ovlp_pack_max_bytes(d->piece_max, cfg->max_nei, d->stride);
     int rc = FMD_OK;
-#define NEED(buf, bytes) do { if (rc == FMD_OK) rc = (buf).need(bytes); } while (0)
+    size_t dry_dev = 0, dry_host = 0;
+    const bool dry = dist_dry();
+#define NEED(buf, bytes) do { if (rc == FMD_OK) { const size_t b_ = (bytes); rc = (buf).need(b_); dry_dev += b_; \
+                              if (dry && (b_ >= ((size_t)1 << 28) || rc != FMD_OK)) fprintf(stderr, "[M::fmd_ovlp_dist_new] rank %d/%d: %-24s %8.2f GB of HBM%s\n", d->rank, d->world, #buf, b_ / 1e9, rc == FMD_OK ? "" : "  <- FAILED"); } } while (0)
+#define NEEDH(buf, bytes) do { if (rc == FMD_OK) { const size_t b_ = (bytes); rc = (buf).need(b_); dry_host += b_; \
+                               if (dry && (b_ >= ((size_t)1 << 28) || rc != FMD_OK)) fprintf(stderr, "[M::fmd_ovlp_dist_new] rank %d/%d: %-24s %8.2f GB of pinned host memory%s\n", d->rank, d->world, #buf, b_ / 1e9, rc == FMD_OK ? "" : "  <- FAILED"); } } while (0)
     NEED(d->ids_home, d->n_home * 8);
     NEED(d->rec, d->cap_rows * sizeof(fmd_ovlp_rec_t));
     NEED(d->nei, d->cap_rows * (size_t)cfg->max_nei * sizeof(fmd_intv_t));
@@ -379,9 +396,9 @@ extern "C" int fmd_ovlp_dist_new(fmd_dev_t *h, fmd_comm_t *comm, const fmd_ovlp_
     NEED(d->cnt_dev, (size_t)(d->world + 1) * 8 * (size_t)(d->world + 1));
     NEED(d->sizes_dev, 16 * (size_t)(d->world + 1));
     NEED(d->split_dev, 4 * ((size_t)d->world * (d->world + 2) + 2));
-    if (rc == FMD_OK) rc = d->split_host.need(4 * ((size_t)d->world * (d->world + 2) + 2));
-    if (rc == FMD_OK) rc = d->cnt_host.need((size_t)(d->world + 1) * 8 * (size_t)(d->world + 1));
-    if (rc == FMD_OK) rc = d->sizes_host.need(16 * (size_t)(d->world + 1));
+    NEEDH(d->split_host, 4 * ((size_t)d->world * (d->world + 2) + 2));
+    NEEDH(d->cnt_host, (size_t)(d->world + 1) * 8 * (size_t)(d->world + 1));
+    NEEDH(d->sizes_host, 16 * (size_t)(d->world + 1));
     // where the table lives at the root
     const bool root = d->rank == cfg->root;
     d->on_host = 0;
@@ -394,10 +411,10 @@ extern "C" int fmd_ovlp_dist_new(fmd_dev_t *h, fmd_comm_t *comm, const fmd_ovlp_
         NEED(d->t_row_of, n * 4);
         if (!d->on_host) { NEED(d->t_prec, n * sizeof(fmd_ovlp_rec_t)); NEED(d->t_ids, n * 4); NEED(d->t_vaddr, n * 8); NEED(d->t_off, (size_t)d->world * (d->piece_max + 1) * 8); }
         else {
-            if (rc == FMD_OK) rc = d->th_prec.need(n * sizeof(fmd_ovlp_rec_t));
-            if (rc == FMD_OK) rc = d->th_ids.need(n * 4);
-            if (rc == FMD_OK) rc = d->th_vaddr.need(n * 8);
-            if (rc == FMD_OK) rc = d->th_row_of.need(n * 4);
+            NEEDH(d->th_prec, n * sizeof(fmd_ovlp_rec_t));
+            NEEDH(d->th_ids, n * 4);
+            NEEDH(d->th_vaddr, n * 8);
+            NEEDH(d->th_row_of, n * 4);
             for (int k = 0; k < 2 && rc == FMD_OK; ++k) {
                 d->in[k].resize((size_t)d->world);
                 for (int q = 0; q < d->world && rc == FMD_OK; ++q) {
@@ -408,9 +425,26 @@ extern "C" int fmd_ovlp_dist_new(fmd_dev_t *h, fmd_comm_t *comm, const fmd_ovlp_
         }
         d->var.host = d->on_host != 0;
         d->var.chunk_bytes = d->var_cap_piece > ((size_t)256 << 20) ? up256(d->var_cap_piece) : ((size_t)256 << 20);
+        if (dry && rc == FMD_OK) {   // the arena as a whole step leaves it: the usual variable part (neighbours + bases, as table_dev above) of every row
+            const size_t want = (size_t)n * (size_t)(cfg->max_nei * 8 + 72);
+            size_t got = 0;
+            while (got < want) {
+                d->var.cur = d->var.chunks.size(); d->var.used = 0;
+                if (!d->var.take(d->var.chunk_bytes)) { rc = FMD_E_NOMEM; break; }
+                got += d->var.chunk_bytes;
+            }
+            d->var.reset();
+            (d->on_host ? dry_host : dry_dev) += got;
+            fprintf(stderr, "[M::fmd_ovlp_dist_new] rank %d/%d: %-24s %8.2f GB of %s in %zu chunks%s\n", d->rank, d->world, "variable parts (arena)", got / 1e9,
+                    d->on_host ? "pinned host memory" : "HBM", d->var.chunks.size(), rc == FMD_OK ? "" : "  <- FAILED");
+        }
     }
     for (int k = 0; k < (root && d->on_host ? 2 : (root ? 0 : 1)); ++k) { NEED(d->out[k].pid, d->piece_max * 4); NEED(d->out[k].prec, d->piece_max * sizeof(fmd_ovlp_rec_t)); NEED(d->out[k].off, (d->piece_max + 1) * 8); NEED(d->out[k].var, d->var_cap_piece); }
 #undef NEED
+#undef NEEDH
+    if (dry) fprintf(stderr, "[M::fmd_ovlp_dist_new] rank %d/%d of a job over %llu ids (%s, %d pieces of at most %zu rows, table %s): %.2f GB of HBM, %.2f GB of pinned host memory: %s\n", d->rank, d->world,
+                     (unsigned long long)cfg->n_ids, d->cfg.key_shard ? "key shard" : "id shard", d->pieces, d->piece_max, root ? (d->on_host ? "in pinned host memory" : "in HBM") : "elsewhere",
+                     dry_dev / 1e9, dry_host / 1e9, rc == FMD_OK ? "every allocation succeeded" : "OUT OF MEMORY");
     if (rc == FMD_OK) {
         int lo = 0, hi = 0;
         // the second stream at the compute stream's priority: measured on one GPU (tools/dist_one_rank.py), 10^8 strands, pass 2 takes 242 ms beside

@@ -429,6 +429,23 @@ class TorchComm:
         pass
 
 
+class DryComm:
+    """A stand-in fmd_comm_t of `world` ranks that carries nothing (both calls fail): what fmd_ovlp_dist_new needs to size and allocate one rank's buffers of an
+    N-rank job on a box with one GPU (FMD_DIST_DRY=1 makes it say what it allocates, the root's table and arena included).  Never step() such a job."""
+
+    def __init__(self, api, rank, world):
+        self._ag = ALLGATHER_FN(lambda ctx, stream, d_send, d_recv, nbytes: -6)
+        self._ex = EXCHANGE_FN(lambda ctx, stream, n_ops, ops: -6)
+        self._de = DESTROY_FN(lambda ctx: None)
+        self.c = Comm(rank, world, None, self._ag, self._ex, self._de)
+
+    def ptr(self):
+        return C.addressof(self.c)
+
+    def free(self):
+        pass
+
+
 class RcclComm:
     """fmd_comm_rccl_init on this rank's device: rank 0 makes the unique id (ncclGetUniqueId), torch.distributed carries it."""
 

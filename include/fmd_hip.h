@@ -353,6 +353,7 @@ typedef struct fmd_comm {
 int fmd_comm_rccl_unique_id(uint8_t id[FMD_COMM_ID_BYTES]);                       /* ncclGetUniqueId: rank 0 calls, the host carries it to the others */
 int fmd_comm_rccl_init(int device, int rank, int world, const uint8_t id[FMD_COMM_ID_BYTES], fmd_comm_t **out);   /* ncclCommInitRank */
 int fmd_comm_rccl_version(void);                                                 /* ncclGetVersion; 0 = librccl not loadable */
+int fmd_comm_rccl_count(const fmd_comm_t *c);                                    /* ncclCommCount of a communicator made by fmd_comm_rccl_init; -1 otherwise */
 void fmd_comm_free(fmd_comm_t *c);                                               /* calls destroy(ctx) and frees c if fmd_comm_rccl_init made it */
 
 /* One pass of overlap discovery over the sequence ids 0 .. n_ids-1 on `world` GPUs, rank r on its own replica of the index:

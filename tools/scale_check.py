@@ -16,7 +16,8 @@ device layout; the only form that carries 1.4*10^11 symbols) --, then
   * `raw`: the reads carry 1 % substitutions (the forked path of fm6_get_nei: general group kernels, side table, 64-bit fast kernels beyond 2^32 symbols): the
     discovery of the random ids runs through BOTH host forms (fmd_ovlp_batch in id order, the sorted job) with room for 16 neighbours, and check_left of a
     sub-sample is compared with the oracle; `props` (which assume error-free reads) is ignored.
-Usage: python tools/scale_check.py [n_reads=250000000] [bwt|inplace] [sample=20000] [share=8] [noref] [kmer] [props] [raw]"""
+  * `dry`: the allocations of one rank of the `share`-rank step (fmd_ovlp_dist_new with a stand-in communicator, FMD_DIST_DRY=1), as the root and as a peer.
+Usage: python tools/scale_check.py [n_reads=250000000] [bwt|inplace] [sample=20000] [share=8] [noref] [kmer] [props] [raw] [dry]"""
 import ctypes as C, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -244,5 +245,16 @@ ms = e0.elapsed_time(e1)
 g = job.rec.view(torch.int32).view(job.n, 16)
 print("share 1/%d of the overlap discovery on this index: %d strands in %.1f ms = %.3e strands/s = %.3e reads/s per GPU (%d overflow records, %d with a neighbour); HBM in use %.1f GB"
       % (share, job.n, ms, job.n / ms * 1e3, job.n / 2 / ms * 1e3, int(((g[:, 14] & 2) != 0).sum().item()), int((g[:, 13] > 0).sum().item()), hbm_used()), flush=True)
+if "dry" in sys.argv[5:]:   # one rank's allocations of the `share`-rank step on this index, at full size, beside the index: rank 0 (the root: table + arena) and a peer
+    from fermi_amd import dist as fdist
+    del job
+    torch.cuda.empty_cache()
+    os.environ["FMD_DIST_DRY"] = "1"
+    for r_ in (0, 1):
+        t0 = time.time()
+        dj = fdist.DistJob(api, index, fdist.DryComm(api, r_, share), 2 * n_reads, 50, L, 4, pieces=0, key_shard=1 if share >= 4 else 0, root=0, host_table=-1, batch=0)
+        print("dry run of rank %d of %d (fmd_ovlp_dist_new, every buffer of a step at full size, HBM in use %.1f GB): allocated in %.1f s" % (r_, share, hbm_used(), time.time() - t0), flush=True)
+        dj.free()
+        torch.cuda.empty_cache()
 index.close()
 print("scale check passed: %d reads, %d symbols, %s builder" % (n_reads, n_sym, mode))
