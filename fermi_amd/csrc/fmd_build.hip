@@ -313,10 +313,10 @@ static int build_bucketed(hipStream_t st, Text text, uint64_t n, uint32_t max_le
             size_t sb_m = 0;
             FMD_HIP_TRY(fmd_sort_pairs(nullptr, sb_m, (uint64_t *)keys_a.p, (uint64_t *)keys_b.p, cur, nxt, (size_t)m, 0, 63, st));
             const uint64_t n_wide = getenv("FMD_BUILD_KEY_BYTES") && atoi(getenv("FMD_BUILD_KEY_BYTES")) ? 0 : n;   // A/B switch: 0 = every key byte by byte (round 3)
-            // default: on where a whole build has been compared symbol for symbol with and without it (byte text, equal read lengths, depth 1: the
-            // 1.01*10^10 symbols of 5*10^7 reads, profiles/r4_build), off elsewhere until config 5 has run with it; FMD_BUILD_PARTITION=0 / 1 decides
+            // on everywhere (round 5: config 5's in-place build at depth 4 and the ragged 2*10^6-read set run with it under pytest -m gpu -- rank self-check over
+            // every position, md5 of the .fmd against fermi build); FMD_BUILD_PARTITION=0 is the A/B switch
             const char *pe = getenv("FMD_BUILD_PARTITION");
-            const bool part = pe ? atoi(pe) != 0 : (std::is_same<Text, Text8>::value && depth == 1 && uniform_len != 0);
+            const bool part = pe ? atoi(pe) != 0 : true;
             for (int ch = n_chunks - 1; ch >= 0; --ch) {
                 if (part && ch > 0) {   // (chunk 0: nothing has ended before the first symbol of a bucket without a '$' in its prefix)
                     const uint64_t m_tiles = (m + (1ull << SEL_TILE_SHIFT) - 1) >> SEL_TILE_SHIFT;

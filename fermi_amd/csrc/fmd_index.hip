@@ -161,11 +161,7 @@ __global__ void k_rld_scatter(const uint64_t *__restrict__ w, uint64_t n_rld_blo
 // sums are then taken one symbol at a time through ONE 8-byte-per-block buffer, so finishing an index
 // costs 20 (14) bytes per block on top of the index itself -- the 1.4e11-symbol index (1.5e9 blocks)
 // must fit next to its own 94 GB.
-#if FMD_BLK64
 typedef uint8_t fmd_bc_t;
-#else
-typedef uint16_t fmd_bc_t;
-#endif
 __global__ void k_block_counts(const uint4 *__restrict__ blocks, uint64_t n_blocks, fmd_bc_t *__restrict__ bc)
 {
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += (uint64_t)gridDim.x * blockDim.x) {
@@ -181,7 +177,6 @@ __global__ void k_block_counts(const uint4 *__restrict__ blocks, uint64_t n_bloc
         for (int s = 0; s < 6; ++s) bc[(uint64_t)s * n_blocks + b] = (fmd_bc_t)n[s];
     }
 }
-#if FMD_BLK_OVERLAP
 // overlapped blocks: the planes of the first chunk of block b + 1 repeated as the third chunk of block b (the transcoders write
 // every 32-position word once, into the block that owns it)
 __global__ void k_fill_lookahead(uint4 *__restrict__ blocks, uint64_t n_blocks)
@@ -193,25 +188,17 @@ __global__ void k_fill_lookahead(uint4 *__restrict__ blocks, uint64_t n_blocks)
         dst->x = v.x; dst->y = v.y; dst->z = v.z;
     }
 }
-#endif
 // the count of symbol s before each block into its place in the block's meta words (fmd_wave.h)
 __global__ void k_write_meta_sym(uint4 *__restrict__ blocks, uint64_t n_blocks, const uint64_t *__restrict__ acc, int s)
 {
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t a = acc[b];
         const uint32_t lo = (uint32_t)a, hi = (uint32_t)(a >> 32) & 0xff;
-    #if FMD_BLK64
         // meta_0..2 in the .w of the three plane chunks, meta_3..6 = the fourth uint4; N is not stored
         uint4 *m = blocks + b * 4;
         if (s < 3) m[s].w = lo; else if (s == 3) m[3].x = lo; else if (s == 4) m[3].y = lo;
         if (s < 4) m[3].z = (m[3].z & ~(0xffu << (8 * s))) | hi << (8 * s);
         else if (s == 4) m[3].w = hi;
-    #else
-        uint4 *m = blocks + b * 8;
-        m[s].w = lo;
-        if (s < 4) m[6].w = (m[6].w & ~(0xffu << (8 * s))) | hi << (8 * s);
-        else m[7].w = (m[7].w & ~(0xffu << (8 * (s - 4)))) | hi << (8 * (s - 4));
-    #endif
     }
 }
 
@@ -373,9 +360,7 @@ static int finish_index(fmd_dev *h)
     FMD_HIP_TRY(hipMalloc((void **)&bc, 6 * nb * sizeof(fmd_bc_t)));
     hipError_t e = hipMalloc((void **)&acc, nb * 8);
     if (e != hipSuccess) { hipFree(bc); fmd_set_hip_error(e, "hipMalloc(scan)"); return FMD_E_NOMEM; }
-#if FMD_BLK_OVERLAP
     k_fill_lookahead<<<nblk(nb, 256), 256>>>(h->blocks, nb);
-#endif
     k_block_counts<<<nblk(nb, 256), 256>>>(h->blocks, nb, bc);
     int rc = FMD_OK;
     uint64_t last[6] = {0, 0, 0, 0, 0, 0};

@@ -79,7 +79,6 @@ __device__ __forceinline__ void grp_window(const uint4 *img_k, int t_k, const ui
                                            bool has_k, bool has_l, uint32_t blk_p, uint32_t off_p, uint4 &a, uint4 &b, uint4 &c)
 {
     uint32_t blk = blk_p, ch = (off_p + 1) >> 5;
-#if FMD_BLK_OVERLAP
     // 32-position words counted from the start of block blk_p: words 0..2 are its chunks, word q >= 3 is chunk q - 2 of the next block
     if (ch >= FMD_BLK_CHUNKS) { ch -= FMD_BLK_OWN_CHUNKS; ++blk; }
     a = grp_pick(img_k, t_k, img_l, t_l, blk_k, blk_l, has_k, has_l, blk, ch);
@@ -87,14 +86,6 @@ __device__ __forceinline__ void grp_window(const uint4 *img_k, int t_k, const ui
     b = grp_pick(img_k, t_k, img_l, t_l, blk_k, blk_l, has_k, has_l, blk, ch);
     if (++ch == FMD_BLK_CHUNKS) { ch = FMD_BLK_CHUNKS - FMD_BLK_OWN_CHUNKS; ++blk; }
     c = grp_pick(img_k, t_k, img_l, t_l, blk_k, blk_l, has_k, has_l, blk, ch);
-#else
-    if (off_p + 1 == FMD_BLK_SYMS) { ++blk; ch = 0; }
-    a = grp_pick(img_k, t_k, img_l, t_l, blk_k, blk_l, has_k, has_l, blk, ch);
-    if (++ch == FMD_BLK_CHUNKS) { ch = 0; ++blk; }
-    b = grp_pick(img_k, t_k, img_l, t_l, blk_k, blk_l, has_k, has_l, blk, ch);
-    if (++ch == FMD_BLK_CHUNKS) { ch = 0; ++blk; }
-    c = grp_pick(img_k, t_k, img_l, t_l, blk_k, blk_l, has_k, has_l, blk, ch);
-#endif
 }
 __device__ __forceinline__ uint64_t win64(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t sh)
 {

@@ -2,9 +2,9 @@
 // of unitig1 (unitig.c:274-300) for a batch of sequence ids, one lane per read-strand:
 //     fm_retrieve (exact.c:59)  ->  fm6_is_contained / overlap_intv (unitig.c:38-91)
 //                               ->  fm6_get_nei (unitig.c:93-179, used = sorted = NULL)
-// Three phase-uniform persistent kernels on the wave engine (fmd_wave.h); candidate interval lists
-// travel between phases through an HBM work area.  Every lane free-runs its own search and posts
-// one rank2a request per wave step; finished lanes refill from a queue (ballot compaction).
+// Phase-uniform persistent kernels on the wave engine (fmd_wave.h): the fused LF-walk + overlap_intv (k_ovl_walk), then fm6_get_nei by group
+// kernels (fmd_ovlp_grp.hip) and, for what they set aside, one lane per strand (k_ovl_nei); candidate interval lists travel between the phases
+// through an HBM work area.  Every lane free-runs its own search and posts one rank2a request per wave step; finished lanes refill from a queue.
 #include <stdlib.h>
 #include <string.h>
 #include "fmd_kernel_common.h"
@@ -21,153 +21,6 @@ void fmd_launch_classify(hipStream_t st, size_t n, const fmd_ovlp_rec_t *rec, co
 // fmd_ovlp_sort.hip: minimizer keys of the parked strands, then their rows sorted by key (-> vals_b)
 size_t fmd_park_sort_temp_bytes(size_t n);
 int fmd_park_sort(hipStream_t st, size_t n, const FmdWalkPark *park, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, void *tmp, size_t tmp_bytes);
-
-// ---------------------------------------------------------------------------- phase 0: retrieve
-// fm_retrieve (exact.c:59-70); writes the sequence REVERSED into srev and rank/len into rec.
-__global__ __launch_bounds__(64) void k_ovl_retrieve(FmdIndexView ix, size_t n, const uint64_t *__restrict__ ids,
-                                                     uint8_t *__restrict__ srev, uint32_t stride_r,
-                                                     fmd_ovlp_rec_t *__restrict__ rec, uint32_t *__restrict__ queue)
-{
-    FMD_DECLARE_WAVE_LDS();
-    size_t sid = 0;
-    uint64_t k = 0;
-    uint32_t len = 0, pack = 0;
-    bool live = false, exhausted = false;
-    FmdTickets tk_;
-    fmd_tickets_init(tk_, queue);
-    for (;;) {
-        const size_t my = fmd_tickets_take(tk_, queue, !live && !exhausted);
-        if (!live && !exhausted) {
-            if (my < n) { sid = my; k = ids[my]; len = 0; pack = 0; live = true; }
-            else exhausted = true;
-        }
-        if (__ballot(live) == 0) break;
-        const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, live ? k : NONE64, NONE64);
-        if (live) {
-            uint64_t ok[6];
-            const int c = fmd_block_rank6<true>(r.bk, r.t, r.nk, ok, r.blk_k);
-            k = ix.cnt[c] + ok[c] - 1;
-            if (c == 0) {
-                if ((len & 3) && len < stride_r) *(uint32_t *)(srev + sid * (size_t)stride_r + (len & ~3u)) = pack;
-                fmd_ovlp_rec_t *o = rec + sid;
-                o->rank = k; o->k[0] = o->k[1] = o->k[2] = 0;
-                o->len = (int32_t)len; o->status = 0; o->n_ovlp = 0; o->rbeg = -1; o->ext_len = 0; o->n_nei = 0; o->flags = 0; o->reserved = 2; o->lfork = 0;
-                live = false;
-            } else {
-                pack |= (uint32_t)c << (8 * (len & 3));
-                ++len;
-                if ((len & 3) == 0) { // four bases per store
-                    if (len <= stride_r) *(uint32_t *)(srev + sid * (size_t)stride_r + len - 4) = pack;
-                    pack = 0;
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------- phase A: overlap_intv + fm6_is_contained
-// unitig.c:38-64 (at5 = 0, inc_sentinel = 0, j = len-1) then unitig.c:83-90.
-// The candidate list is written back to front so that it ends up in the reversed order the
-// reference produces with fm_reverse_fmivec (longest overlap first): entries [cap-n, cap).
-__global__ __launch_bounds__(64) void k_ovl_intv(FmdIndexView ix, size_t n, int min_match, const uint8_t *__restrict__ srev,
-                                                 uint32_t stride_r, uint32_t cap, fmd_intv_t *__restrict__ listA,
-                                                 fmd_ovlp_rec_t *__restrict__ rec, uint8_t *__restrict__ seq_out,
-                                                 uint32_t seq_stride, uint32_t *__restrict__ queue)
-{
-    FMD_DECLARE_WAVE_LDS();
-    size_t sid = 0;
-    int L = 0, jr = 0, depth = 0, phase = 0, ret = 0;
-    uint32_t npush = 0, cache = 0;
-    uint64_t x0 = 0, x1 = 0, sz = 0;
-    bool live = false, exhausted = false;
-    FmdTickets tk_;
-    fmd_tickets_init(tk_, queue);
-    for (;;) {
-        const size_t my = fmd_tickets_take(tk_, queue, !live && !exhausted);
-        if (!live && !exhausted) {
-            if (my < n) {
-                sid = my; L = rec[my].len;
-                if (L > (int)stride_r) { rec[my].flags |= FMD_OVLP_F_OVERFLOW; }     // longer than the caller's max_len
-                else if (L <= min_match) { rec[my].status = -1; }                      // too short (unitig.c:288)
-                else {
-                    const uint8_t *s = srev + sid * (size_t)stride_r;
-                    cache = *(const uint32_t *)s;
-                    const int c = cache & 0xff;
-                    x0 = ix.cnt[c]; x1 = ix.cnt[comp6(c)]; sz = ix.cnt[c + 1] - ix.cnt[c];
-                    {   // sequence in read order for the caller: one burst of dword stores (the row is
-                        // srev byte-reversed), so the line is written once instead of L partial writes
-                        uint8_t *dst = seq_out + sid * (size_t)seq_stride;
-                        const int nw = (L + 3) >> 2;
-                        for (int w = 0; w < nw; ++w) {
-                            // read-order bytes 4w..4w+3 = srev[L-1-4w], srev[L-2-4w], ...
-                            uint32_t v = 0;
-#pragma unroll
-                            for (int b = 0; b < 4; ++b) {
-                                const int i = 4 * w + b;
-                                if (i < L) v |= (uint32_t)s[L - 1 - i] << (8 * b);
-                            }
-                            if ((uint32_t)(4 * w + 3) < seq_stride) *(uint32_t *)(dst + 4 * w) = v;
-                        }
-                    }
-                    jr = 1; depth = 1; npush = 0; ret = 0; phase = L > 1 ? 0 : 1; live = true;
-                }
-            } else exhausted = true;
-        }
-        if (__ballot(live) == 0) break;
-        // request: backward extension in phases 0/1, forward in phase 2
-        uint64_t qk = NONE64, ql = NONE64;
-        if (live) { const uint64_t a = phase == 2 ? x1 : x0; qk = a - 1; ql = a - 1 + sz; }
-        const FmdRank2 r = fmd_wave_rank2_fetch(ix, fmd_lds, qk, ql);
-        if (live) {
-            uint64_t tk[6] = {0, 0, 0, 0, 0, 0}, tl[6] = {0, 0, 0, 0, 0, 0};
-            if (r.hk) fmd_block_rank6<false>(r.bk, r.t, r.nk, tk, r.blk_k);
-            if (r.hl) fmd_block_rank6<false>(r.bl, r.tl, r.nl, tl, r.blk_l);
-            uint64_t s[6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) s[c] = tl[c] - tk[c];
-            if (phase == 0) {
-                if ((jr & 3) == 0) cache = *(const uint32_t *)(srev + sid * (size_t)stride_r + jr);
-                const int c = (cache >> (8 * (jr & 3))) & 0xff;
-                const uint64_t sc = sel6(c, s[0], s[1], s[2], s[3], s[4], s[5]);
-                if (sc == 0) phase = 1; // cannot be extended (unitig.c:50)
-                else {
-                    if (depth >= min_match && s[0]) { // a read starts here: keep the current interval
-                        if (npush < cap) {
-                            fmd_intv_t *e = listA + sid * (size_t)cap + (cap - 1 - npush);
-                            uint4 *q = (uint4 *)e;
-                            q[0] = make_uint4((uint32_t)x0, (uint32_t)(x0 >> 32), (uint32_t)x1, (uint32_t)(x1 >> 32));
-                            q[1] = make_uint4((uint32_t)sz, (uint32_t)(sz >> 32), (uint32_t)depth, 0u); // info = depth; start = len - depth
-                        } else rec[sid].flags |= FMD_OVLP_F_OVERFLOW;
-                        ++npush;
-                    }
-                    // ik = ok[c] (backward): x0 from rank, x1 = running sum in the order $,T,G,C,A,N
-                    const uint64_t tkc = sel6(c, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
-                    x0 = sel6(c, ix.cnt[0], ix.cnt[1], ix.cnt[2], ix.cnt[3], ix.cnt[4], ix.cnt[5]) + tkc;
-                    uint64_t before = 0;             // sizes ordered before c: 0 <4 <3 <2 <1 <5
-                    if (c != 0) before += s[0];
-                    if (c == 3 || c == 2 || c == 1 || c == 5) before += s[4];
-                    if (c == 2 || c == 1 || c == 5) before += s[3];
-                    if (c == 1 || c == 5) before += s[2];
-                    if (c == 5) before += s[1];
-                    x1 += before; sz = sc;
-                    ++jr; ++depth;
-                    if (jr == L) phase = 1;
-                }
-            } else if (phase == 1) { // extend by '$' on the left: left-contained if the size shrinks
-                if (sz != s[0]) ret = -1;
-                x0 = tk[0]; sz = s[0]; // ok[0]: x[0] = cnt[0] + tk[0], x[1] unchanged
-                phase = 2;
-            } else {                 // extend by '$' on the right
-                if (sz != s[0]) ret = -1;
-                fmd_ovlp_rec_t *o = rec + sid;
-                o->k[0] = x0; o->k[1] = tk[0]; o->k[2] = s[0];
-                o->status = ret < 0 ? -3 : 0; // contained (unitig.c:292)
-                o->n_ovlp = (int32_t)npush;
-                live = false;
-            }
-        }
-    }
-}
 
 // ------------------------------------------------- phases 0+A fused: LF-walk + overlap_intv in one pass
 // fm_retrieve walks the rows k_i of the suffixes "last i bases $" of the sequence; overlap_intv
@@ -1240,7 +1093,7 @@ static void ovl_phase_a(const OvlBatch &o, hipStream_t st, size_t b, size_t np, 
     uint8_t *srev = o.srev + b * (size_t)o.stride_r;
     fmd_intv_t *listA = o.listA + b * (size_t)o.cap;
     uint8_t *seq = o.gidx ? o.seq : o.seq + b * (size_t)o.seq_stride;
-    uint32_t *q0 = fmd_next_queue(o.h, st), *q1 = fmd_next_queue(o.h, st);
+    uint32_t *q0 = fmd_next_queue(o.h, st);
     if (o.gidx) {   // the second pass of a sorted job: every strand of the batch from where WALK_HEAD parked it
         int grid = fmd_grid_for_lds(o.h, np, FMD_COMPACT_LDS_U4 * 16);
         { const char *e = getenv("FMD_WALK_WAVES"); if (per_cu <= 0 && e && atoi(e) > 0) per_cu = atoi(e); }
@@ -1260,12 +1113,6 @@ static void ovl_phase_a(const OvlBatch &o, hipStream_t st, size_t b, size_t np, 
         }
         k_ovl_walk<WALK_TAIL><<<grid, 64, 0, st>>>(o.ix, np, nullptr, o.min_match, srev, o.stride_r, o.cap, listA, o.rec, seq, o.seq_stride, q0, 0, o.park, o.gidx + b, nullptr, walk_ticket_chunk("FMD_TAIL_TICKETS", 64, np, grid), nullptr, nullptr, 0);
         launch_seq_out(st, np, o.max_len, srev, o.stride_r, o.rec, o.min_match, 0, seq, o.seq_stride, o.gidx + b);
-        return;
-    }
-    if (getenv("FMD_OVLP_UNFUSED")) { // A/B switch: separate LF-walk and overlap_intv passes
-        const int grid = fmd_grid_for(o.h, np);
-        k_ovl_retrieve<<<grid, 64, 0, st>>>(o.ix, np, o.ids + b, srev, o.stride_r, o.rec + b, q0);
-        k_ovl_intv<<<grid, 64, 0, st>>>(o.ix, np, o.min_match, srev, o.stride_r, o.cap, listA, o.rec + b, seq, o.seq_stride, q1);
         return;
     }
     int grid = fmd_grid_for_lds(o.h, np, FMD_COMPACT_LDS_U4 * 16);
@@ -1386,7 +1233,7 @@ static void ovl_pipe_config(size_t n, int &parts, int &walk_cu, int &grp_cu, int
         if (k >= 3 && c >= 1) grp_cu = c;
         if (k >= 4 && d >= 1) fast_cu = d;
     }
-    if (getenv("FMD_OVLP_UNFUSED") || getenv("FMD_OVLP_SLOW_ONLY")) parts = 1;
+    if (getenv("FMD_OVLP_SLOW_ONLY")) parts = 1;
 }
 static bool ovl_slow_acquire(fmd_dev *h)
 {
@@ -1547,7 +1394,7 @@ static bool sorted_eligible(const fmd_dev *h, size_t n, int min_match, uint32_t 
 {
     const char *e = getenv("FMD_OVLP_SORT");   // A/B switch: 0 = batches in id order through the one-pass walk
     if (e && atoi(e) == 0) return false;
-    return n < 0xffffff00ull && min_match >= (int)FMD_WALK_SPLIT && max_len >= FMD_WALK_SPLIT && h->ptab_d < (int)FMD_WALK_SPLIT && !getenv("FMD_OVLP_UNFUSED");
+    return n < 0xffffff00ull && min_match >= (int)FMD_WALK_SPLIT && max_len >= FMD_WALK_SPLIT && h->ptab_d < (int)FMD_WALK_SPLIT;
 }
 
 // ---- the two halves of the sorted job as entry points of their own: a caller may do something between them (hand finished rows on

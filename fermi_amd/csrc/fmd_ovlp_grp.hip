@@ -466,15 +466,10 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
 // The moment a strand leaves that regime (a second base or an N among the reads of any candidate, even one no read starts with;
 // a candidate in the wide form) it is appended to the general list of its class and k_ovl_nei_grp starts it over: nothing the fast
 // path wrote for it survives (records are written at the close only; neighbours and appended bases are rewritten).
-#if FMD_BLK64
 // uint4 index, in the two block images side by side (4 uint4 each), of the q-th 32-position word counted from the start of the first
 __device__ __forceinline__ uint32_t fast_word(uint32_t q)
 {
-#if FMD_BLK_OVERLAP
     return q < 3 ? q : q + 2;          // words 3, 4 = chunks 1, 2 of the next block (word 2 is in both)
-#else
-    return q < 3 ? q : q + 1;          // words 3.. = chunks 0.. of the next block
-#endif
 }
 template <typename M> struct FastW;
 template <> struct FastW<uint32_t> {
@@ -744,14 +739,12 @@ static int fast_blocks_per_cu(void)
     if (!cached) cached = fmd_resident_per_cu(k_ovl_nei_fast<G, M, DYN>, sizeof(uint4) * ((2 * (64 / G) + FMD_BLK_PER_INST - 1) / FMD_BLK_PER_INST * FMD_BLK_PER_INST + 2) * FMD_BLK_U4, 32, "k_ovl_nei_fast");
     return cached;
 }
-#endif
-int fmd_nei_fast_available(void) { return FMD_BLK64 ? 1 : 0; }
+int fmd_nei_fast_available(void) { return 1; }
 static inline int fast_grid(int waves) { return waves < FMD_FAST_MAX_WAVES ? waves : FMD_FAST_MAX_WAVES; }   // (the hand-over lists have room for this many waves' holes)
 void fmd_launch_nei_fast(int cls, int wide, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                          const fmd_intv_t *listA, fmd_intv_t *listB, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
                          uint32_t seq_stride, uint32_t *gen_list, uint32_t *gen_n, uint32_t *bail_n, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx)
 {
-#if FMD_BLK64
     const char *e = getenv("FMD_FAST_WAVES"); // A/B knob: resident waves per CU
     if (e && atoi(e) > 0 && (per_cu_cap <= 0 || atoi(e) < per_cu_cap)) per_cu_cap = atoi(e);
     const bool dyn = nei_dyn() != 0;
@@ -770,7 +763,6 @@ void fmd_launch_nei_fast(int cls, int wide, int n_cu, int per_cu_cap, hipStream_
 #undef FAST_LAUNCH2
 #undef FAST_LAUNCH
 #undef FAST_LAUNCH_
-#endif
 }
 
 // launcher used by fmd_ovlp.hip.  The strands of a work list are dealt to the groups round-robin, so

@@ -4,18 +4,27 @@
 // nt6 symbols of its run as three bit-planes per 32 positions plus the absolute symbol counts before
 // it, so rank(k) -- rld_rank1a in the reference (rld.c:424) -- is ONE aligned fetch of the block k
 // falls into plus masked popcounts: no frame lookup, no header walk (rld.c:352), no sequential
-// Elias-delta decode (rld.h:77).  Two geometries share all the code below (FMD_BLK64):
-//   * 64 bytes / 96 positions (shipped; described where FMD_BLK64 is defined), 5.33 bits/symbol;
-//   * 128 bytes / 256 positions, one L2 line, 4 bits/symbol: 8 chunks of 16 bytes,
-//       chunk j = { p0, p1, p2, meta_j }        bit i of p0/p1/p2 = bit 0/1/2 of symbol 32j+i
-//       meta_0..5 = low 32 bits of the absolute count of $,A,C,G,T,N before the block,
-//       meta_6 / meta_7 = bits 32..39 of those counts (one byte each).
-// 70-94 GB for the 1.4e11-symbol human-35x index, which is what 288 GB of HBM3E per GPU is for.
+// Elias-delta decode (rld.h:77).
+//
+// A block is 64 bytes (random 64-byte gathers run 30-36 % more lines per second than 128-byte ones on MI355X,
+// profiles/r1_bsearch/gather_probe.txt, and a line costs half the LDS landing space) = 4 x uint4:
+//     u4[j], j = 0..2 = { p0, p1, p2, meta_j } for 32 positions each: bit i of p0/p1/p2 = bit 0/1/2 of the symbol
+//     u4[3]           = { meta_3, meta_4, meta_5, meta_6 }
+//     meta_0..4 = low 32 bits of the absolute count of $,A,C,G,T before the block,
+//     meta_5 = bits 32..39 of the counts of $,A,C,G, meta_6 & 0xff = those of T; the count of N is what is left.
+// Blocks OVERLAP: a block STARTS every 64 positions and holds the symbols of 96 -- its third chunk repeats the first chunk of the
+// next block; the counts are those before position 64 b.  A rank pair (k, l) -- the two ends of an SA interval, l - k <= a few
+// dozen once a search is past its first bases -- is answered from the ONE block of k whenever l < 64 b + 96, i.e. always for
+// intervals up to 32 wide, where disjoint 96-position blocks needed a second line for a fraction size/96 of the steps (12-16 % of
+// all lines of backward search and overlap discovery at 30x); the block of a position is a shift.  8 bits per symbol: 141 GB for
+// the 1.4e11-symbol human-35x index, which is what 288 GB of HBM3E per GPU is for.  (Rounds 1-4 carried two more geometries behind
+// macros -- 128-byte blocks of 256 positions, disjoint 64-byte blocks of 96 -- measured against this one in profiles/r1_blk64,
+// r2_ab and r3_locality; they left the tree in round 5.)
 //
 // Wave engine: a wavefront owns 64 searches, one per lane.  Per step every lane posts up to two
 // block numbers (k-side, l-side).  The 64 lanes then fetch those blocks COOPERATIVELY: in round
-// r each 4-lane (8-lane) group g streams the block of its lane number r with one 16-byte
-// global_load_lds_dwordx4 per lane (16 or 8 whole blocks per wave instruction, fully coalesced,
+// r each 4-lane group g streams the block of its lane number r with one 16-byte
+// global_load_lds_dwordx4 per lane (16 whole blocks per wave instruction, fully coalesced,
 // LDS-DMA, no VGPR round trip).  After one s_waitcnt every lane reads ITS block back from LDS with
 // ds_read_b128 and counts the symbols itself.  LDS is the transpose between "coalesced by line"
 // and "one search per lane".
@@ -23,52 +32,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// Second geometry (-DFMD_BLK64=1): 64-byte rank blocks of 96 positions.  Random 64-byte gathers run
-// 30-36 % more lines per second than 128-byte ones on MI355X (profiles/r1_bsearch/gather_probe.txt)
-// and a line costs half the LDS landing space.  Block b = 4 x uint4 = BWT[96b, 96b+96):
-//     u4[j], j = 0..2 = { p0, p1, p2, meta_j } for positions [32j, 32j+32)
-//     u4[3]           = { meta_3, meta_4, meta_5, meta_6 }
-//     meta_0..4 = low 32 bits of the absolute count of $,A,C,G,T before the block,
-//     meta_5 = bits 32..39 of the counts of $,A,C,G, meta_6 & 0xff = those of T;
-//     the count of N is 96b minus the other five.
-// Still one aligned fetch per rank, self-contained (no superblock table); 5.33 bits/symbol.
-#ifndef FMD_BLK64
-#define FMD_BLK64 1   // the shipped geometry (A/B: make variant NAME=128 EXTRA=-DFMD_BLK64=0)
-#endif
-// Overlapped blocks (FMD_BLK_OVERLAP, the shipped form of the 64-byte geometry): a block STARTS every 64 positions and holds the
-// symbols of 96 -- its third chunk repeats the first chunk of the next block.  The counts are those before position 64 b.  A rank
-// pair (k, l) -- the two ends of an SA interval, l - k <= a few dozen once a search is past its first bases -- is answered from the
-// ONE block of k whenever l < 64 b + 96, i.e. always for intervals up to 32 wide, where disjoint 96-position blocks needed a second
-// line for a fraction size/96 of the steps (12-16 % of all lines of backward search and overlap discovery at 30x); the block of a
-// position is a shift instead of a division by 96.  8 bits per symbol instead of 5.33: 141 GB for the 1.4e11-symbol index.
-#ifndef FMD_BLK_OVERLAP
-#define FMD_BLK_OVERLAP 1   // round 2 (kernels bound by DRAM lines): 3-5 % for 1.5 x the HBM, not shipped.  Round 3 (the sorted walk is bound by the
-                            // fabric's REQUEST rate, every second line of a straddling pair a request of its own): overlap discovery -6 %, raw reads -3.5 %,
-                            // backward search -5.6 %, k-mer harvest -6 %, SMEM +-0 on one box (profiles/r3_locality/overlapped_blocks_all_legs.txt);
-                            // the index is 1.43 x the size (11.2 GB for 50 M reads, 141 GB for config 5: 288 GB of HBM are there to be used).
-                            // -DFMD_BLK_OVERLAP=0 builds the disjoint 96-position blocks (make variant NAME=disjoint EXTRA=-DFMD_BLK_OVERLAP=0)
-#endif
-#if FMD_BLK64
 #define FMD_BLK_SYMS 96u        // positions whose symbols a block holds
 #define FMD_BLK_U4 4            // uint4 per block
 #define FMD_BLK_CHUNKS 3        // 32-position plane chunks per block
 #define FMD_GRP_SHIFT 2         // 4 lanes x 16 B fetch one block
-#else
-#define FMD_BLK_SYMS 256u
-#define FMD_BLK_U4 8            // uint4 per block
-#define FMD_BLK_CHUNKS 8
-#define FMD_GRP_SHIFT 3         // 8 lanes x 16 B fetch one block
-#endif
-#if FMD_BLK_OVERLAP
-#if !FMD_BLK64
-#error "overlapped blocks are defined for the 64-byte geometry"
-#endif
 #define FMD_BLK_STRIDE 64u      // positions between the starts of consecutive blocks
 #define FMD_BLK_OWN_CHUNKS 2    // chunks a block counts as its own (the rest is look-ahead)
-#else
-#define FMD_BLK_STRIDE FMD_BLK_SYMS
-#define FMD_BLK_OWN_CHUNKS FMD_BLK_CHUNKS
-#endif
 #define FMD_BLK_BYTES (FMD_BLK_U4 * 16)
 #define FMD_GRP_MASK ((1 << FMD_GRP_SHIFT) - 1)
 #define FMD_BLK_PER_INST (64 >> FMD_GRP_SHIFT)   // blocks moved by one 64-lane global_load_lds
@@ -139,33 +108,8 @@ __device__ __forceinline__ void fmd_count_lane(const FmdIndexView &ix, int n, in
 }
 
 // position -> (block, offset inside the block)
-#if FMD_BLK_OVERLAP
 __device__ __forceinline__ void fmd_word_split(uint64_t w, uint32_t &blk, uint32_t &ch) { blk = (uint32_t)(w >> 1); ch = (uint32_t)w & 1; } // the OWN chunk of word w
 __device__ __forceinline__ void fmd_split(uint64_t k, uint32_t &blk, uint32_t &off) { blk = (uint32_t)(k >> 6); off = (uint32_t)k & 63; }
-#elif FMD_BLK64
-__device__ __forceinline__ uint64_t fmd_div3(uint64_t w) // w < 2^43 (32-position word index)
-{
-    // 2^32 = 3K + 1 with K = 0x55555555:  w = hi*2^32 + lo = 3*hi*K + (hi + lo);  hi + lo = c*2^32 + sl likewise
-    const uint32_t hi = (uint32_t)(w >> 32), lo = (uint32_t)w;
-    const uint64_t s = (uint64_t)hi + lo;
-    const uint32_t c = (uint32_t)(s >> 32), sl = (uint32_t)s;
-    return (uint64_t)(hi + c) * 0x55555555ull + (__umulhi(sl + c, 0xAAAAAAABu) >> 1);
-}
-__device__ __forceinline__ void fmd_word_split(uint64_t w, uint32_t &blk, uint32_t &ch) // 32-position word -> block, chunk
-{
-    const uint64_t q = fmd_div3(w);
-    blk = (uint32_t)q; ch = (uint32_t)(w - 3 * q);
-}
-__device__ __forceinline__ void fmd_split(uint64_t k, uint32_t &blk, uint32_t &off)
-{
-    uint32_t ch;
-    fmd_word_split(k >> 5, blk, ch);
-    off = ch * 32 + ((uint32_t)k & 31);
-}
-#else
-__device__ __forceinline__ void fmd_word_split(uint64_t w, uint32_t &blk, uint32_t &ch) { blk = (uint32_t)(w >> 3); ch = (uint32_t)w & 7; }
-__device__ __forceinline__ void fmd_split(uint64_t k, uint32_t &blk, uint32_t &off) { blk = (uint32_t)(k >> 8); off = (uint32_t)k & 255; }
-#endif
 __device__ __forceinline__ uint32_t fmd_blk_of(uint64_t k) { uint32_t b, o; fmd_split(k, b, o); return b; }
 // Can position p be read from the image of block blk (its own positions, or -- overlapped blocks -- the look-ahead chunk)?  off = its offset there.
 __device__ __forceinline__ bool fmd_in_block(uint64_t p, uint32_t blk, uint32_t &off)
@@ -181,20 +125,15 @@ __device__ __forceinline__ uint64_t fmd_word_u4(uint64_t w) { uint32_t b, c; fmd
 // lane-owned block are bank-conflict free (the b128 lane groups are {0-3,12-15,20-27}, ... --
 // MI355X_MICROARCH.md LDS table; lanes of one group whose blocks start on the same 128-B
 // half-row get distinct 16-byte slots).
-#if FMD_BLK64
 // 64-byte images: slot of chunk j of lane q = 4*((q>>2)&3) + (j ^ t) mod 16; the four quads of a b128
 // lane group have distinct (q>>2)&3, so t = q & 3 separates the lanes of a quad.
 __device__ __forceinline__ int fmd_chunk_xor(int q) { return q & 3; }
-#else
-__device__ __forceinline__ int fmd_chunk_xor(int q) { return (q & 3) | (((q >> 4) & 1) << 2); }
-#endif
 
 // One cooperative round: lane group g fetches the block of lane (g << FMD_GRP_SHIFT) + R for slot SLOT
 // (8 lanes x 16 B for a 128-byte block, 4 lanes for a 64-byte one).
 template <int SLOT, int R>
 __device__ __forceinline__ void fmd_fetch_round(const FmdIndexView &ix, uint4 *lds, uint32_t blk, uint64_t need_mask)
 {
-#if FMD_BLK64
     if ((need_mask >> R) & 0x1111111111111111ull) {          // wave-uniform: anybody in this round?
         const int lane = fmd_lane();
         const int j = lane & 3;
@@ -204,18 +143,6 @@ __device__ __forceinline__ void fmd_fetch_round(const FmdIndexView &ix, uint4 *l
             __builtin_amdgcn_global_load_lds((fmd_glb_void *)src, (fmd_lds_void *)(lds + SLOT * FMD_SLOT_U4 + R * 64), 16, 0, FMD_GLDS_AUX);
         }
     }
-#else
-    if ((need_mask >> R) & 0x0101010101010101ull) {          // wave-uniform: anybody in this round?
-        const int lane = fmd_lane();
-        const int g = lane >> 3, j = lane & 7;
-        const uint32_t sb = (uint32_t)__builtin_amdgcn_ds_swizzle((int)blk, (R << 5) | 0x18); // blk of lane 8g+R
-        if ((need_mask >> ((lane & ~7) | R)) & 1) {
-            const int t = (R & 3) | (((g >> 1) & 1) << 2);  // = fmd_chunk_xor(8g+R)
-            const uint4 *src = ix.blocks + (size_t)sb * FMD_BLK_U4 + (j ^ t);
-            __builtin_amdgcn_global_load_lds((fmd_glb_void *)src, (fmd_lds_void *)(lds + SLOT * FMD_SLOT_U4 + R * 64), 16, 0, FMD_GLDS_AUX);
-        }
-    }
-#endif
 }
 
 template <int SLOT>
@@ -226,10 +153,6 @@ __device__ __forceinline__ void fmd_fetch_slot(const FmdIndexView &ix, uint4 *ld
     fmd_count_lines(ix, __popcll(m));
     fmd_fetch_round<SLOT, 0>(ix, lds, blk, m); fmd_fetch_round<SLOT, 1>(ix, lds, blk, m);
     fmd_fetch_round<SLOT, 2>(ix, lds, blk, m); fmd_fetch_round<SLOT, 3>(ix, lds, blk, m);
-#if !FMD_BLK64
-    fmd_fetch_round<SLOT, 4>(ix, lds, blk, m); fmd_fetch_round<SLOT, 5>(ix, lds, blk, m);
-    fmd_fetch_round<SLOT, 6>(ix, lds, blk, m); fmd_fetch_round<SLOT, 7>(ix, lds, blk, m);
-#endif
 }
 
 __device__ __forceinline__ void fmd_fetch_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -241,11 +164,7 @@ __device__ __forceinline__ int fmd_lds_base(int q, int slot)
 }
 
 // chunk XOR of pool slot p: 16 consecutive slots use the 16 distinct (quad, chunk) 16-byte slot classes
-#if FMD_BLK64
 __device__ __forceinline__ int fmd_pool_xor(int p) { return (p ^ (p >> 2)) & 3; }
-#else
-__device__ __forceinline__ int fmd_pool_xor(int p) { return p & 7; }
-#endif
 
 // Pool of compacted blocks (ballot-prefix slots): `n` block ids in ids[], FMD_BLK_PER_INST per wave
 // instruction, written to pool; the lane that owns pool slot p reads pool + p * FMD_BLK_U4 with XOR fmd_pool_xor(p).
@@ -298,7 +217,6 @@ __device__ __forceinline__ int fmd_block_rank6(const uint4 *blk, int t, uint32_t
     }
     const uint32_t n5 = cxz, n4 = cz - cxz, n3 = cxy, n2 = cy - cxy, n1 = cx - cxy - cxz;
     const uint32_t n0 = npos - (n1 + n2 + n3 + n4 + n5); // positions past the BWT end are never counted
-#if FMD_BLK64
     {
         const uint4 mv = blk[3 ^ t];
         meta[3] = mv.x; meta[4] = mv.y; meta[5] = mv.z; meta[6] = mv.w;
@@ -308,15 +226,6 @@ __device__ __forceinline__ int fmd_block_rank6(const uint4 *blk, int t, uint32_t
     const uint64_t b4 = ((uint64_t)(meta[6] & 0xff) << 32 | meta[4]);
     out[0] = b0 + n0; out[1] = b1 + n1; out[2] = b2 + n2; out[3] = b3 + n3; out[4] = b4 + n4;
     out[5] = (uint64_t)blk_no * FMD_BLK_STRIDE - (b0 + b1 + b2 + b3 + b4) + n5;
-#else
-    (void)blk_no;
-    out[0] = ((uint64_t)(meta[6] & 0xff) << 32 | meta[0]) + n0;
-    out[1] = ((uint64_t)((meta[6] >> 8) & 0xff) << 32 | meta[1]) + n1;
-    out[2] = ((uint64_t)((meta[6] >> 16) & 0xff) << 32 | meta[2]) + n2;
-    out[3] = ((uint64_t)(meta[6] >> 24) << 32 | meta[3]) + n3;
-    out[4] = ((uint64_t)(meta[7] & 0xff) << 32 | meta[4]) + n4;
-    out[5] = ((uint64_t)((meta[7] >> 8) & 0xff) << 32 | meta[5]) + n5;
-#endif
     if (WANT_SYM) {
         const uint32_t bit = off & 31;
         return (int)(((s0 >> bit) & 1) | ((s1 >> bit) & 1) << 1 | ((s2 >> bit) & 1) << 2);
@@ -330,7 +239,6 @@ __device__ __forceinline__ uint64_t fmd_block_rank1(const uint4 *blk, int t, uin
 {
     const uint32_t x0 = (c & 1) ? 0u : ~0u, x1 = (c & 2) ? 0u : ~0u, x2 = (c & 4) ? 0u : ~0u;
     uint32_t n = 0, lo = 0, hi = 0;
-#if FMD_BLK64
     uint32_t m0 = 0, m1 = 0, m2 = 0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -349,25 +257,11 @@ __device__ __forceinline__ uint64_t fmd_block_rank1(const uint4 *blk, int t, uin
     const uint64_t five = ((uint64_t)(mv.z & 0xff) << 32 | m0) + ((uint64_t)((mv.z >> 8) & 0xff) << 32 | m1) +
                           ((uint64_t)((mv.z >> 16) & 0xff) << 32 | m2) + ((uint64_t)(mv.z >> 24) << 32 | mv.x) + ((uint64_t)(mv.w & 0xff) << 32 | mv.y);
     return (uint64_t)blk_no * FMD_BLK_STRIDE - five + n;
-#else
-    (void)blk_no;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const uint4 v = blk[j ^ t];
-        const uint32_t m = fmd_mask32((int)npos - 32 * j);
-        n += __builtin_popcount((v.x ^ x0) & (v.y ^ x1) & (v.z ^ x2) & m);
-        lo = (j == c) ? v.w : lo;
-        if (j == 6) hi = (c < 4) ? (v.w >> (8 * c)) & 0xff : hi;
-        if (j == 7) hi = (c >= 4) ? (v.w >> (8 * (c - 4))) & 0xff : hi;
-    }
-    return ((uint64_t)hi << 32 | lo) + n;
-#endif
 }
 
 // fmd_block_rank1 of symbol c AND of '$' from the same three chunk reads (the walk's window path and k_ovl_nei_fast want both).
 __device__ __forceinline__ uint64_t fmd_block_rank1z(const uint4 *blk, int t, uint32_t npos, int c, uint32_t blk_no, uint64_t &rz)
 {
-#if FMD_BLK64
     const uint32_t x0 = (c & 1) ? 0u : ~0u, x1 = (c & 2) ? 0u : ~0u, x2 = (c & 4) ? 0u : ~0u;
     uint32_t n = 0, nz = 0, lo = 0, hi = 0, m0 = 0, m1 = 0, m2 = 0;
 #pragma unroll
@@ -388,10 +282,6 @@ __device__ __forceinline__ uint64_t fmd_block_rank1z(const uint4 *blk, int t, ui
     const uint64_t five = ((uint64_t)(mv.z & 0xff) << 32 | m0) + ((uint64_t)((mv.z >> 8) & 0xff) << 32 | m1) +
                           ((uint64_t)((mv.z >> 16) & 0xff) << 32 | m2) + ((uint64_t)(mv.z >> 24) << 32 | mv.x) + ((uint64_t)(mv.w & 0xff) << 32 | mv.y);
     return (uint64_t)blk_no * FMD_BLK_STRIDE - five + n;
-#else
-    rz = fmd_block_rank1(blk, t, npos, 0, blk_no);
-    return fmd_block_rank1(blk, t, npos, c, blk_no);
-#endif
 }
 
 // ---- work queue of the persistent kernels --------------------------------------------------------
@@ -470,12 +360,8 @@ __device__ __forceinline__ size_t fmd_tickets_take(FmdTickets &t, uint32_t *queu
 // overlapped blocks: the l side of a rank pair is read from the block of the k side whenever that block reaches it
 __device__ __forceinline__ void fmd_l_from_k(bool both, uint64_t l, uint32_t blk_k, uint32_t &blk_l, uint32_t &off_l)
 {
-#if FMD_BLK_OVERLAP
     uint32_t o;
     if (both && blk_l != blk_k && fmd_in_block(l, blk_k, o)) { blk_l = blk_k; off_l = o; }
-#else
-    (void)both; (void)l; (void)blk_k; (void)blk_l; (void)off_l;
-#endif
 }
 
 struct FmdRank2 {
@@ -546,12 +432,6 @@ __device__ __forceinline__ FmdRank2c fmd_wave_rank2_fetch_compact(const FmdIndex
     r.hk = k != ~0ull; r.hl = l != ~0ull;
     uint32_t ok_, ol_;
     fmd_split(k, r.blk_k, ok_);
-#if !FMD_BLK_OVERLAP
-    if (r.hk && r.hl && l - k < FMD_BLK_SYMS) {   // the two ends of a narrow interval: one division, not two
-        ol_ = ok_ + (uint32_t)(l - k); r.blk_l = r.blk_k;
-        if (ol_ >= FMD_BLK_SYMS) { ol_ -= FMD_BLK_SYMS; ++r.blk_l; }
-    } else
-#endif
     fmd_split(l, r.blk_l, ol_);
     fmd_l_from_k(r.hk && r.hl, l, r.blk_k, r.blk_l, ol_);
     r.l_sep = r.hl && !(r.hk && r.blk_k == r.blk_l);

@@ -805,8 +805,7 @@ def test_large_index_properties(gpu):
       * overlap records: rank/len agree with retrieve, the `$read$` interval of a strand and of its
         reverse strand mirror each other (x[0] <-> x[1]), and unique irreducible overlaps are mutual:
         if b is the only right neighbour of a with overlap o, then a^1 follows b^1 with the same o;
-      * an indexed read is its own single, sentinel-closed SMEM with the multiplicity backward search reports;
-      * the table-free kernels (FMD_OVLP_UNFUSED path) give the same records."""
+      * an indexed read is its own single, sentinel-closed SMEM with the multiplicity backward search reports."""
     import os
     N, L = 300_000, 100
     reads = synth.reads(synth.DEFAULT_SEED, N)
@@ -845,12 +844,6 @@ def test_large_index_properties(gpu):
     m0 = np.concatenate(mems)
     assert (m0["info"] == np.uint64(1 << 63 | L)).all() and (m0["x"][:, 1] < np.uint64(2 * N)).all()
     assert np.array_equal(m0["x"][:, 2], cnt[:50_000])
-    os.environ["FMD_OVLP_UNFUSED"] = "1"
-    try:
-        rec2, nei2, seq2 = d.overlap(ids[:200_000], 50, L, 4, check_left=False)
-    finally:
-        del os.environ["FMD_OVLP_UNFUSED"]
-    assert rec2.tobytes() == rec[:200_000].tobytes() and nei2.tobytes() == nei[:200_000].tobytes() and seq2.tobytes() == seq[:200_000].tobytes()
     d.close()
 
 

@@ -11,7 +11,7 @@ ok, sym = d.rank1a(g['rank1a_k'])
 print("rank1a", np.array_equal(ok, g['rank1a_ok']), flush=True)
 ids = np.arange(0, 600, dtype=np.uint64)
 want = o.overlap_batch(ids, 50, 100, 4, 4, check_left=False)
-print("mode", os.environ.get("FMD_OVLP_UNFUSED"), os.environ.get("FMD_OVLP_SLOW_ONLY"), flush=True)
+print("mode", os.environ.get("FMD_OVLP_SLOW_ONLY"), flush=True)
 rec, nei, seq = d.overlap(ids, 50, 100, 4, check_left=False)
 print("overlap rec", rec.tobytes() == want[0].tobytes(), "nei", nei.tobytes() == want[1].tobytes(), "seq", seq.tobytes() == want[2].tobytes(), flush=True)
 if rec.tobytes() != want[0].tobytes():

@@ -251,10 +251,21 @@ if "dry" in sys.argv[5:]:   # one rank's allocations of the `share`-rank step on
     torch.cuda.empty_cache()
     os.environ["FMD_DIST_DRY"] = "1"
     for r_ in (0, 1):
-        t0 = time.time()
-        dj = fdist.DistJob(api, index, fdist.DryComm(api, r_, share), 2 * n_reads, 50, L, 4, pieces=0, key_shard=1 if share >= 4 else 0, root=0, host_table=-1, batch=0)
-        print("dry run of rank %d of %d (fmd_ovlp_dist_new, every buffer of a step at full size, HBM in use %.1f GB): allocated in %.1f s" % (r_, share, hbm_used(), time.time() - t0), flush=True)
-        dj.free()
-        torch.cuda.empty_cache()
+        for ks in ((1, 0) if share >= 4 else (0,)):   # both shardings of pass 2 (bench.py times both from four ranks up)
+            dj = None
+            for bt in (0, 10_000_000, 5_000_000, 2_500_000, 1_250_000):   # bench.py's ladder: smaller pieces until the rank has room beside the index
+                t0 = time.time()
+                try:
+                    dj = fdist.DistJob(api, index, fdist.DryComm(api, r_, share), 2 * n_reads, 50, L, 4, pieces=0, key_shard=ks, root=0, host_table=-1, batch=bt)
+                except api.FmdError as ex:
+                    print("dry run of rank %d of %d, %s, pieces of at most %s strands: %s" % (r_, share, "key shard" if ks else "id shard", bt or "2*10^7", ex), flush=True)
+                    torch.cuda.empty_cache()
+                    continue
+                print("dry run of rank %d of %d, %s: every buffer of a step at full size with pieces of at most %s strands (HBM in use %.1f GB), allocated in %.1f s"
+                      % (r_, share, "key shard" if ks else "id shard", bt or "2*10^7", hbm_used(), time.time() - t0), flush=True)
+                break
+            assert dj is not None, "no piece size leaves rank %d of %d room beside this index" % (r_, share)
+            dj.free()
+            torch.cuda.empty_cache()
 index.close()
 print("scale check passed: %d reads, %d symbols, %s builder" % (n_reads, n_sym, mode))
