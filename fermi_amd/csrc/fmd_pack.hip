@@ -250,28 +250,19 @@ __global__ void k_link_edges(size_t n, fmd_ovlp_rec_t *__restrict__ rec, const u
         fmd_ovlp_rec_t *r = rec + i;
         fmd_ovlp_link_t l; l.nxt = l.rev = 0xffffffffu;
         if (r->status == 0 && r->n_nei == 1 && r->rbeg >= 0 && !(r->flags & FMD_OVLP_F_OVERFLOW)) {
+            // (round 5 tried to spare the third random line of an edge -- the reverse strand of a neighbour that is the only read of its sequence is the row beside it,
+            // and its record, read for lfork anyway, can confirm that: 3.71 -> 4.33 ms per 2*10^7 rows and 9.9 -> 12.3 GB fetched, gpurun_out/b_cl_[01].json: the row
+            // map of 10^8 rows is 400 MB and mostly answers from the Infinity Cache, a dependent record line does not.  Reverted.)
             const uint64_t x0 = nei_x01[i * (size_t)nei_stride], x1 = nei_x01[i * (size_t)nei_stride + 1];
             if (x0 < n) l.nxt = row_of[x0];
-            // A neighbour that is the only read of its sequence (its `$N$` interval has size 1: no duplicate, no reverse-complement duplicate) has its reverse
-            // strand in the row beside it (ids 2r, 2r + 1): that record -- one random line, which the verdict needs anyway for lfork -- confirms it (k[0] == x1,
-            // nothing flagged), and row_of[x1], a third random line per edge, is asked only for the others (2.1 x the requested bytes were fetched here: three
-            // 64-byte lines for 4 + 4 + 2 bytes).
-            uint16_t lf_rev = 0;
-            bool have_lf = false;
-            if (x1 < n) {
-                if (l.nxt != 0xffffffffu && (size_t)(l.nxt ^ 1u) < n && nei_x01[i * (size_t)nei_stride + 2] == 1) {
-                    const fmd_ovlp_rec_t *q = rec + (l.nxt ^ 1u);
-                    if (q->k[0] == x1 && q->status == 0 && !(q->flags & FMD_OVLP_F_OVERFLOW)) { l.rev = l.nxt ^ 1u; lf_rev = q->lfork; have_lf = true; }
-                }
-                if (!have_lf) l.rev = row_of[x1];
-            }
+            if (x1 < n) l.rev = row_of[x1];
             // a neighbour without a row: its record is flagged (a capacity was exceeded) and the caller computes it again, larger -- the
             // edge is reported with the undecided ones, and the caller links it when that row is there (host/ovlp_table.c: table_patch_links)
             const bool miss = (x0 < n && l.nxt == 0xffffffffu) || (x1 < n && l.rev == 0xffffffffu);
             int d = 0;
             if (r->reserved == 2) {
                 d = 1;
-                if (l.rev != 0xffffffffu && !force_exact) d = lfork_decide_dev(have_lf ? lf_rev : rec[l.rev].lfork, r->rbeg);
+                if (l.rev != 0xffffffffu && !force_exact) d = lfork_decide_dev(rec[l.rev].lfork, r->rbeg);
                 if (d != 1) r->reserved = (uint16_t)(d < 0 ? 1 : 0);
             }
             if (d == 1 || miss) und[atomicAdd(n_und, 1ull)] = i;
