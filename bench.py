@@ -106,7 +106,7 @@ def pmc_in_run(fmd_path, n_reads, steps=2, leg="overlap"):
             return "failed (no counter rows)"
         cal = 2 * (1 << 27) * 64 / (pr["k_probe"] * 1024.0)      # probe_once: warm-up + one launch, 2^27 lines of 64 bytes each
         src = "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over %d steps of the leg on the index this run built; KB units, FETCH_SIZE x %.4f (gather probe, 64-byte lines, same run)" % (steps, cal)
-        OVL = ("k_ovl_head_adm", "k_ovl_walk", "k_ovl_park_keys", "k_ovl_seq_out", "k_ovl_classify", "k_ovl_nei_fast", "k_ovl_nei_grp", "k_ovl_nei", "k_ovl_fix")
+        OVL = ("k_ovl_head_adm", "k_ovl_walk", "k_ovl_park_keys", "k_ovl_seq_out", "k_ovl_seq_redo", "k_ovl_classify", "k_ovl_nei_fast", "k_ovl_nei_grp", "k_ovl_nei", "k_ovl_fix")
         legs_of = {"overlap": (("overlap@%d" % n_reads, OVL), ("check_left@%d" % n_reads, ("k_link_rows", "k_link_edges", "k_ovl_cls"))), "ecfix": (("ecfix@%d" % n_reads, ("k_ecfix",)),)}
         for key, names in legs_of[leg]:
             fk = sum(v for k, v in fetch.items() if k in names) / steps
@@ -720,17 +720,20 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
     n_neis = int(np.minimum(g_rec["n_nei"][ok_rows], job.max_nei).sum())
     n_ext = int(g_rec["ext_len"][ok_rows].sum())
     stride_r = (L + 15) // 16 * 16
-    streams = {"ids": 2 * 8 * n_loc, "tail_table": 0 if os.environ.get("FMD_TAIL_TABLE") == "0" else 2 * 8 * n_loc, "stash_write_and_read": 2 * stride_r * n_loc, "sequence_rows_out": L * n_loc + 32 * n_ext,
+    tail2 = os.environ.get("FMD_WALK_TAIL2") != "0" and stride_r <= 112     # k_ovl_walk<WALK_TAIL2>: rows written by the walk (no stash, no k_ovl_seq_out) ...
+    tail2_cls = tail2 and os.environ.get("FMD_WALK_CLS") != "0"               # ... and the work lists too (no k_ovl_classify)
+    streams = {"ids": 2 * 8 * n_loc, "tail_table": 0 if os.environ.get("FMD_TAIL_TABLE") == "0" else 2 * 8 * n_loc, "stash_write_and_read": 0 if tail2 else 2 * stride_r * n_loc, "sequence_rows_out": L * n_loc + 32 * n_ext,
                "head_admission_records_write_and_read": 2 * 32 * n_loc, "parked_strands_write_read_twice": 3 * 64 * n_loc,
                "two_sorts_keys_and_rows": 2 * (2 * 8 + 4 * 2 * 8) * n_loc, "slot_to_row_map_reads": 4 * 4 * n_loc,
-               "records_write_classify_read_result_write": 3 * 64 * n_loc, "work_lists": 16 * n_loc,
-               "candidates_write_and_read": 2 * 32 * n_cand, "classify_widest_candidate": 64 * n_loc, "neighbours": 32 * n_neis}
+               "records_write_classify_read_result_write": (2 if tail2_cls else 3) * 64 * n_loc, "work_lists": 16 * n_loc,
+               "candidates_write_and_read": 2 * 32 * n_cand, "classify_widest_candidate": 0 if tail2_cls else 64 * n_loc, "neighbours": 32 * n_neis}
     io = sum(streams.values())
     dev_bytes = None if lines is None else (lines[0] + lines[1]) * BLOCK_BYTES + io
     cn = oracle_counters(fmd_path, lambda o: o.overlap_batch(np.arange(4000, dtype=np.uint64), min_match, 100, 4, 1, check_left=False))
     qps = (cn["rank1a"] + cn["rank2a"] + cn["rank2a_spill"]) / 4000.0
-    out["roofline"] = roofline("k_ovl_head_adm + k_ovl_walk<HEAD> + 2 radix sorts + per batch: k_ovl_walk<TAIL> + k_ovl_seq_out + k_ovl_classify + k_ovl_nei_fast<G, M> + k_ovl_nei_grp<G> + k_ovl_nei (one step = one job of %d batches of %d strands)"
-                               % ((job.n + job.batch - 1) // job.batch, job.batch), kern_ms, dev_bytes,
+    out["roofline"] = roofline("k_ovl_head_adm + k_ovl_walk<HEAD> + k_ovl_park_keys + one radix sort + per batch: k_ovl_walk<%s> + k_ovl_nei_fast<G, M> + k_ovl_nei_grp<G> + k_ovl_nei (one step = one job of %d batches of %d strands)"
+                               % ("TAIL2> (rows and work lists written by the walk" if tail2_cls else ("TAIL2> + k_ovl_classify" if tail2 else "TAIL> + k_ovl_seq_out + k_ovl_classify"),
+                                  (job.n + job.batch - 1) // job.batch, job.batch), kern_ms, dev_bytes,
                                {"rank_blocks": lines and lines[0], "prefix_table_lines": lines and lines[1], "stream_bytes": io, "streams": streams},
                                qps * BYTES_PER_RANK_QUERY * n_loc, "overlap@%d" % n_reads if world == 1 else "overlap@%d/%d" % (n_reads, world),
                                {"rank_queries_per_strand": qps, "oracle_counters_on_sample": cn,
@@ -1309,7 +1312,9 @@ def bench_overlap_raw(torch, api, index, dev, n_reads, L, err, fmd_path):
     torch.cuda.synchronize()
     ok_rows = (g_rec["status"] == 0) & ((g_rec["flags"] & api.OVLP_F_OVERFLOW) == 0)
     n_cand = int(g_rec["n_ovlp"][ok_rows].sum())
-    io = n_ids * (16 + 16 + 2 * 112 + L + 3 * 64 + 16 + 64 + 64 + 3 * 64 + 80 + 16) + 2 * 32 * n_cand
+    tail2 = os.environ.get("FMD_WALK_TAIL2") != "0"                       # (as in the headline's model: no stash, no classification pass over the records)
+    tail2_cls = tail2 and os.environ.get("FMD_WALK_CLS") != "0"
+    io = n_ids * (16 + 16 + (0 if tail2 else 2 * 112) + L + 3 * 64 + 16 + (0 if tail2_cls else 64 + 64) + 3 * 64 + 80 + 16) + 2 * 32 * n_cand
     dev_bytes = None if lines is None else (lines[0] + lines[1]) * BLOCK_BYTES + io
     cn = oracle_counters(fmd_path, lambda oo: oo.overlap_batch(selc[:2000], 50, 100, 4, 1, check_left=False))
     qps = (cn["rank1a"] + cn["rank2a"] + cn["rank2a_spill"]) / 2000.0

@@ -14,6 +14,10 @@ if [ -z "$PMC_LEGS" ] || [[ ",$PMC_LEGS," == *",overlap_raw,"* ]]; then
 PMC_LEGS=overlap_raw timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/raw_fetch -o legs -- python tools/pmc_legs.py $K > $OUT/raw_fetch.log 2>&1
 PMC_LEGS=overlap_raw timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/raw_write -o legs -- python tools/pmc_legs.py $K > $OUT/raw_write.log 2>&1
 fi
+if [ -z "$PMC_LEGS" ] || [[ ",$PMC_LEGS," == *",ecfix,"* ]]; then   # the correction pass: harvest + table in the child, K steps of k_ecfix
+PMC_LEGS=ecfix timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/ec_fetch -o legs -- python tools/pmc_legs.py $K > $OUT/ec_fetch.log 2>&1
+PMC_LEGS=ecfix timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/ec_write -o legs -- python tools/pmc_legs.py $K > $OUT/ec_write.log 2>&1
+fi
 PROBE_LINE=64 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_probe -o probe -- python tools/probe_once.py > $OUT/probe_once.txt 2>&1
 python tools/pmc_to_json.py $OUT $K $NR $NB "profiles/${TAG}_pmc (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/pmc_legs.py, $K steps per leg)" > $OUT/pmc_traffic_summary.txt 2>&1
 cp profiles/pmc_traffic.json $OUT/pmc_traffic.json

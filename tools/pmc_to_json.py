@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 import bench
 
 d, steps, n_reads, n_bs, label = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-OVL = ("k_ovl_head_adm", "k_ovl_walk", "k_ovl_park_keys", "k_ovl_seq_out", "k_ovl_classify", "k_ovl_nei_fast", "k_ovl_nei_grp", "k_ovl_nei", "k_ovl_fix")
+OVL = ("k_ovl_head_adm", "k_ovl_walk", "k_ovl_park_keys", "k_ovl_seq_out", "k_ovl_seq_redo", "k_ovl_classify", "k_ovl_nei_fast", "k_ovl_nei_grp", "k_ovl_nei", "k_ovl_fix")
 # (the two 32-bit radix sorts of the sorted job -- ~10 GB of streaming per 10^8 strands -- run in rocprim kernels whose names they
 # share with the sorts of the index build in the same profile: not in these sums)
 LEGS = {"overlap@%d" % n_reads: OVL,
@@ -47,6 +47,10 @@ fk = sum(v for k, v in fr.items() if k in OVL) / steps
 if fk:
     out["overlap_raw@%d" % n_reads] = {"fetch_kb": fk, "write_kb": sum(v for k, v in wr.items() if k in OVL) / steps, "fetch_calibration": cal, "csrc_sha": bench.csrc_sha("overlap_raw"),
                                        "source": label, "per_kernel_fetch_kb": {k: v / steps for k, v in fr.items() if k in OVL}}
+fe, we = sums("ec_fetch", "FETCH_SIZE"), sums("ec_write", "WRITE_SIZE")     # the correction pass (PMC_LEGS=ecfix: a profile of its own)
+if fe.get("k_ecfix"):
+    out["ecfix@%d" % n_reads] = {"fetch_kb": fe["k_ecfix"] / steps, "write_kb": we.get("k_ecfix", 0.0) / steps, "fetch_calibration": cal, "csrc_sha": bench.csrc_sha("ecfix"),
+                                 "source": label, "per_kernel_fetch_kb": {"k_ecfix": fe["k_ecfix"] / steps}}
 dst = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 try:   # a partial collection (PMC_LEGS=...) keeps the other legs' entries; each is valid for the sha it carries
     old = json.load(open(dst))
