@@ -33,6 +33,7 @@ ABI_SYMBOLS = [
     "fmd_ectab_build_dev", "fmd_ectab_build", "fmd_ectab_free", "fmd_ecfix_work_bytes", "fmd_ecfix_dev", "fmd_ecfix_batch", "fmd_ectab_line_count",
     "fmd_ovlp_work_bytes", "fmd_ovlp_dev", "fmd_ovlp_sorted_work_bytes", "fmd_ovlp_sorted_dev", "fmd_ovlp_batch", "fmd_ovlp_check_left_dev", "fmd_seqinfo_dev", "fmd_seqinfo_batch",
     "fmd_ovlp_pack_max_bytes", "fmd_ovlp_pack_work_bytes", "fmd_ovlp_pack_dev", "fmd_ovlp_packed_batch", "fmd_ovlp_packed_free", "fmd_table_alloc", "fmd_table_free", "fmd_ovlp_link_dev", "fmd_ovlp_packed_table",
+    "fmd_ovlp_packed_stream", "fmd_ovlp_tabjob_rows", "fmd_ovlp_tabjob_patch", "fmd_ovlp_tabjob_link", "fmd_ovlp_tabjob_free",
     "fmd_ovlp_two_pass_ok", "fmd_ovlp_head_work_bytes", "fmd_ovlp_head_dev", "fmd_ovlp_tail_dev", "fmd_ovlp_pack_rows_dev",
     "fmd_comm_rccl_unique_id", "fmd_comm_rccl_init", "fmd_comm_rccl_version", "fmd_comm_rccl_count", "fmd_comm_free",
     "fmd_ovlp_side_work_bytes", "fmd_ovlp_rerun_overflow_dev",

@@ -402,22 +402,32 @@ __global__ void k_take_reserved(size_t n, const fmd_ovlp_rec_t *__restrict__ rec
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) out[i] = (uint8_t)rec[i].reserved;
 }
 
+// where the packed chunks go when the caller does not want them kept: a callback over two pinned staging sets (the streamed forms below)
+struct RowSink { fmd_ovlp_rows_fn fn; void *ctx; };
+struct PinnedBuf { // hipHostMalloc for a scope
+    void *p = nullptr;
+    int alloc(size_t bytes) { return hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault) == hipSuccess ? FMD_OK : FMD_E_NOMEM; }
+    ~PinnedBuf() { if (p) hipHostFree(p); }
+};
+
 static int packed_batch_core(fmd_dev_t *h, const uint64_t *ids, uint64_t first, uint64_t step, size_t n, int min_match, uint32_t max_len,
                              uint32_t max_nei, int with_check_left, fmd_ovlp_rec_t *rec, uint64_t *off, uint32_t chunk_shift, uint8_t **chunks,
-                             const KeepRows *keep, hipStream_t *stream_out)
+                             const KeepRows *keep, const RowSink *sink)
 {
-    if (!h || (n && (!rec || !off || !chunks)) || chunk_shift < 10 || chunk_shift > 26 || max_len == 0 || max_nei == 0) return FMD_E_ARG;
+    if (!h || (n && !sink && (!rec || !off || !chunks)) || chunk_shift < 10 || chunk_shift > 26 || max_len == 0 || max_nei == 0) return FMD_E_ARG;
     if (n == 0) return FMD_OK;
     FMD_HIP_TRY(hipSetDevice(h->device));
     const bool timing = getenv("FMD_TIMING") != nullptr;
     auto now = [] { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; };
     const double t_begin = now();
-    double t_alloc = 0, t_wait = 0, t_host = 0;
-    const size_t CH = (size_t)1 << chunk_shift, m = n < CH ? n : CH, n_chunks = (n + CH - 1) / CH;
+    double t_alloc = 0, t_wait = 0, t_host = 0, t_sink = 0;
+    // computed (and packed) in chunks of CH rows; a sink takes them in pieces of SUB <= CH rows (its staging buffers are SUB rows large)
+    const size_t SUB = (size_t)1 << chunk_shift;
+    const size_t CH = sink && chunk_shift < 22 ? (size_t)1 << 22 : SUB, m = n < CH ? n : CH, n_chunks = (n + CH - 1) / CH;
     const uint32_t stride = 2 * ((max_len + 3) / 4 * 4);
     const size_t wb0 = fmd_ovlp_work_bytes(m, max_len, min_match), wb1 = fmd_ovlp_pack_work_bytes(m), wb = wb0 > wb1 ? wb0 : wb1;
     const size_t cap = fmd_ovlp_pack_max_bytes(m, max_nei, stride);
-    for (size_t c = 0; c < n_chunks; ++c) chunks[c] = nullptr;
+    if (!sink) for (size_t c = 0; c < n_chunks; ++c) chunks[c] = nullptr;
     DevMem d_ids, d_rec, d_nei, d_seq, d_work, d_prec[2], d_off[2], d_var[2];
     Stream s_cmp, s_cpy;
     Event done[2], copied[2];
@@ -445,8 +455,20 @@ static int packed_batch_core(fmd_dev_t *h, const uint64_t *ids, uint64_t first, 
         if (d_prec[k].alloc(h, m * sizeof(fmd_ovlp_rec_t)) || d_off[k].alloc(h, (m + 1) * 8) || d_var[k].alloc(h, cap) || done[k].make() || copied[k].make()) return FMD_E_NOMEM;
     if (s_cmp.make() || s_cpy.make()) return FMD_E_HIP;
     Pinned pin_rec, pin_off;
-    pin_rec.pin(rec, n * sizeof(fmd_ovlp_rec_t));
-    pin_off.pin(off, n * 8);
+    PinnedBuf st_rec[2], st_adj[2], st_var[2], st_off;        // the sink's staging sets (pieces of SUB rows), and the offsets of a whole chunk
+    size_t st_var_cap[2] = {0, 0};
+    Event sub_done[2];
+    const size_t sub_m = m < SUB ? m : SUB;
+    if (!sink) {
+        pin_rec.pin(rec, n * sizeof(fmd_ovlp_rec_t));
+        pin_off.pin(off, n * 8);
+    } else {
+        if (st_off.alloc((m + 1) * 8)) return FMD_E_NOMEM;
+        for (int k = 0; k < 2; ++k) {
+            st_var_cap[k] = sub_m * 96 + 4096;     // (grown when a piece is larger: the worst case is max_nei * 32 + seq_stride / 2 + 8 per row, the usual 60-70)
+            if (st_rec[k].alloc(sub_m * sizeof(fmd_ovlp_rec_t)) || st_adj[k].alloc((sub_m + 1) * 8) || st_var[k].alloc(st_var_cap[k]) || sub_done[k].make()) return FMD_E_NOMEM;
+        }
+    }
     uint64_t *tot = nullptr;            // pinned landing place of the two chunk totals
     FMD_HIP_TRY(hipHostMalloc((void **)&tot, 2 * sizeof(uint64_t), hipHostMallocDefault));
     t_alloc = now() - t_begin;
@@ -492,7 +514,49 @@ static int packed_batch_core(fmd_dev_t *h, const uint64_t *ids, uint64_t first, 
             }
             if (hipMemcpyAsync(tot + k, (uint64_t *)d_off[k].p + nc, 8, hipMemcpyDeviceToHost, s_cmp.s) != hipSuccess || hipEventRecord(done[k].e, s_cmp.s) != hipSuccess) { fail(FMD_E_HIP); break; }
         }
-        if (c >= 1) { // copy chunk c - 1 out while chunk c runs
+        if (sink && c >= 1) { // chunk c - 1 to the caller, piece by piece, while chunk c is computed: piece j crosses PCIe while the caller has piece j - 1
+            const size_t p = c - 1, b = p * CH, np = n - b < CH ? n - b : CH;
+            const int k = (int)(p & 1);
+            double t0 = now();
+            if (hipEventSynchronize(done[k].e) != hipSuccess) { fail(FMD_E_HIP); break; }
+            t_wait += now() - t0; t0 = now();
+            if (tot[k] > cap) { fail(FMD_E_OVERFLOW); break; }
+            if (hipMemcpyAsync(st_off.p, d_off[k].p, (np + 1) * 8, hipMemcpyDeviceToHost, s_cpy.s) != hipSuccess || hipStreamSynchronize(s_cpy.s) != hipSuccess) { fail(FMD_E_HIP); break; }
+            const uint64_t *offs = (const uint64_t *)st_off.p;
+            const size_t n_sub = (np + SUB - 1) / SUB;
+            t_host += now() - t0;
+            for (size_t j = 0; j <= n_sub && rc == FMD_OK; ++j) {
+                if (j < n_sub) {
+                    const size_t r0 = j * SUB, nr = np - r0 < SUB ? np - r0 : SUB;
+                    const int ks = (int)(j & 1);
+                    const uint64_t b0 = offs[r0], bytes = offs[r0 + nr] - b0;
+                    t0 = now();
+                    if (bytes > st_var_cap[ks]) {   // (the caller finished with this set two pieces ago)
+                        hipHostFree(st_var[ks].p); st_var[ks].p = nullptr;
+                        st_var_cap[ks] = bytes + bytes / 4;
+                        if (st_var[ks].alloc(st_var_cap[ks])) { fail(FMD_E_NOMEM); break; }
+                    }
+                    if (hipMemcpyAsync(st_rec[ks].p, (const fmd_ovlp_rec_t *)d_prec[k].p + r0, nr * sizeof(fmd_ovlp_rec_t), hipMemcpyDeviceToHost, s_cpy.s) != hipSuccess ||
+                        (bytes && hipMemcpyAsync(st_var[ks].p, (const uint8_t *)d_var[k].p + b0, bytes, hipMemcpyDeviceToHost, s_cpy.s) != hipSuccess) ||
+                        hipEventRecord(sub_done[ks].e, s_cpy.s) != hipSuccess) { fail(FMD_E_HIP); break; }
+                    uint64_t *adj = (uint64_t *)st_adj[ks].p;
+                    for (size_t i = 0; i <= nr; ++i) adj[i] = offs[r0 + i] - b0;
+                    t_host += now() - t0;
+                }
+                if (j >= 1) {
+                    const size_t q = j - 1, r0 = q * SUB, nr = np - r0 < SUB ? np - r0 : SUB;
+                    const int ks = (int)(q & 1);
+                    t0 = now();
+                    if (hipEventSynchronize(sub_done[ks].e) != hipSuccess) { fail(FMD_E_HIP); break; }
+                    t_wait += now() - t0; t0 = now();
+                    const int src = sink->fn(sink->ctx, (uint64_t)(b + r0), nr, (const fmd_ovlp_rec_t *)st_rec[ks].p, (const uint64_t *)st_adj[ks].p, (const uint8_t *)st_var[ks].p, offs[r0 + nr] - offs[r0]);
+                    t_sink += now() - t0;
+                    if (src) { fail(src); break; }
+                }
+            }
+            if (rc == FMD_OK && hipEventRecord(copied[k].e, s_cpy.s) != hipSuccess) { fail(FMD_E_HIP); break; }
+        }
+        if (!sink && c >= 1) { // copy chunk c - 1 out while chunk c runs
             const size_t p = c - 1, b = p * CH, np = n - b < CH ? n - b : CH;
             const int k = (int)(p & 1);
             double t0 = now();
@@ -517,16 +581,15 @@ static int packed_batch_core(fmd_dev_t *h, const uint64_t *ids, uint64_t first, 
     hipStreamSynchronize(s_cmp.s);
     const double t_tail0 = now();
     hipStreamSynchronize(s_cpy.s);
-    if (timing) fprintf(stderr, "[M::%s] %zu rows in %zu chunks%s: device buffers + pinning %.3f s, sorted job %.3f s, waiting for kernels %.3f s, host allocation + copy issue %.3f s, last copy %.3f s, total %.3f s\n",
-                        __func__, n, n_chunks, sorted_batch ? " (all rows from one sorted job)" : " (chunk by chunk in id order)", t_alloc, t_job, t_wait, t_host, now() - t_tail0, now() - t_begin);
+    if (timing) fprintf(stderr, "[M::%s] %zu rows in %zu chunks%s: device buffers + pinning %.3f s, sorted job %.3f s, waiting for kernels / copies %.3f s, host allocation + copy issue %.3f s, the caller's sink %.3f s, last copy %.3f s, total %.3f s\n",
+                        __func__, n, n_chunks, sorted_batch ? " (all rows from one sorted job)" : " (chunk by chunk in id order)", t_alloc, t_job, t_wait, t_host, t_sink, now() - t_tail0, now() - t_begin);
     for (void *q : registered) hipHostUnregister(q);
     hipHostFree(tot);
     if (rc == FMD_OK) {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { fmd_set_hip_error(e, "packed overlap batch"); rc = FMD_E_HIP; }
     } else if (rc == FMD_E_HIP) fmd_set_hip_error(hipGetLastError(), "packed overlap batch");
-    if (rc != FMD_OK) fmd_ovlp_packed_free(chunks, n_chunks);
-    (void)stream_out;
+    if (rc != FMD_OK && !sink) fmd_ovlp_packed_free(chunks, n_chunks);
     return rc;
 }
 
@@ -574,5 +637,107 @@ extern "C" int fmd_ovlp_packed_table(fmd_dev_t *h, size_t n, int min_match, uint
         }
     }
     if (rc != FMD_OK) { fmd_ovlp_packed_free(chunks, n_chunks); if (rc == FMD_E_HIP) fmd_set_hip_error(hipGetLastError(), "packed table: link pass"); }
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Streamed forms: the packed chunks are handed to a callback from two pinned staging sets and nothing of the table stays in host
+// memory unless the callback keeps it (host/slim_table.c keeps ~58 bytes per row of the ~125 that cross PCIe).
+extern "C" int fmd_ovlp_packed_stream(fmd_dev_t *h, const uint64_t *ids, uint64_t first, uint64_t step, size_t n, int min_match, uint32_t max_len,
+                                      uint32_t max_nei, int with_check_left, uint32_t chunk_shift, fmd_ovlp_rows_fn fn, void *ctx)
+{
+    if (!fn) return FMD_E_ARG;
+    RowSink sink{fn, ctx};
+    return packed_batch_core(h, ids, first, step, n, min_match, max_len, max_nei, with_check_left, nullptr, nullptr, chunk_shift, nullptr, nullptr, &sink);
+}
+
+// The whole table (ids 0 .. n-1) on ONE device as a job in three steps: rows (streamed; the fixed-stride records and the first neighbour's
+// coordinates stay on the device), patch (rows the caller computed again: their records replace the flagged ones), link (fmd_ovlp_link_dev
+// over the records as they are THEN, its results streamed in pieces).
+struct fmd_ovlp_tabjob {
+    fmd_dev *h = nullptr;
+    size_t n = 0;
+    DevMem rec_all, nei01;
+};
+extern "C" void fmd_ovlp_tabjob_free(fmd_ovlp_tabjob_t *j) { delete j; }
+extern "C" int fmd_ovlp_tabjob_rows(fmd_dev_t *h, size_t n, int min_match, uint32_t max_len, uint32_t max_nei, uint32_t chunk_shift,
+                                    fmd_ovlp_rows_fn fn, void *ctx, fmd_ovlp_tabjob_t **job)
+{
+    if (!h || !fn || !job) return FMD_E_ARG;
+    *job = nullptr;
+    if (n >= 0xffffffffull) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    fmd_ovlp_tabjob *j = new (std::nothrow) fmd_ovlp_tabjob;
+    if (!j) return FMD_E_NOMEM;
+    j->h = h; j->n = n;
+    if (j->rec_all.alloc(h, (n ? n : 1) * sizeof(fmd_ovlp_rec_t)) || j->nei01.alloc(h, (n ? n : 1) * 16)) { delete j; return FMD_E_NOMEM; }
+    KeepRows keep{(fmd_ovlp_rec_t *)j->rec_all.p, (uint64_t *)j->nei01.p};
+    RowSink sink{fn, ctx};
+    const int rc = packed_batch_core(h, nullptr, 0, 1, n, min_match, max_len, max_nei, 0, nullptr, nullptr, chunk_shift, nullptr, &keep, &sink);
+    if (rc) { delete j; return rc; }
+    *job = j;
+    return FMD_OK;
+}
+__global__ void k_patch_rows(size_t m, const uint64_t *__restrict__ ids, const fmd_ovlp_rec_t *__restrict__ rec, const uint64_t *__restrict__ nei01, size_t n,
+                             fmd_ovlp_rec_t *__restrict__ rec_all, uint64_t *__restrict__ nei01_all)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += step) {
+        const uint64_t id = ids[i];
+        if (id >= n) continue;
+        rec_all[id] = rec[i];
+        nei01_all[2 * id] = nei01[2 * i]; nei01_all[2 * id + 1] = nei01[2 * i + 1];
+    }
+}
+extern "C" int fmd_ovlp_tabjob_patch(fmd_ovlp_tabjob_t *j, size_t m, const uint64_t *ids, const fmd_ovlp_rec_t *rec, const uint64_t *nei01)
+{
+    if (!j || (m && (!ids || !rec || !nei01))) return FMD_E_ARG;
+    if (m == 0) return FMD_OK;
+    FMD_HIP_TRY(hipSetDevice(j->h->device));
+    DevMem d_ids, d_rec, d_n01;
+    if (d_ids.alloc(j->h, m * 8) || d_rec.alloc(j->h, m * sizeof(fmd_ovlp_rec_t)) || d_n01.alloc(j->h, m * 16)) return FMD_E_NOMEM;
+    FMD_HIP_TRY(hipMemcpy(d_ids.p, ids, m * 8, hipMemcpyHostToDevice));
+    FMD_HIP_TRY(hipMemcpy(d_rec.p, rec, m * sizeof(fmd_ovlp_rec_t), hipMemcpyHostToDevice));
+    FMD_HIP_TRY(hipMemcpy(d_n01.p, nei01, m * 16, hipMemcpyHostToDevice));
+    size_t blocks = (m + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    k_patch_rows<<<(unsigned)blocks, 256>>>(m, (const uint64_t *)d_ids.p, (const fmd_ovlp_rec_t *)d_rec.p, (const uint64_t *)d_n01.p, j->n, (fmd_ovlp_rec_t *)j->rec_all.p, (uint64_t *)j->nei01.p);
+    FMD_HIP_TRY(hipDeviceSynchronize());
+    return FMD_OK;
+}
+extern "C" int fmd_ovlp_tabjob_link(fmd_ovlp_tabjob_t *j, fmd_ovlp_links_fn fn, void *ctx, uint64_t **undecided, uint64_t *n_undecided)
+{
+    if (!j || !fn || !undecided || !n_undecided) return FMD_E_ARG;
+    *undecided = nullptr; *n_undecided = 0;
+    const size_t n = j->n;
+    if (n == 0) return FMD_OK;
+    fmd_dev *h = j->h;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    DevMem d_row_of, d_link, d_und, d_nund, d_res;
+    if (d_row_of.alloc(h, n * 4) || d_link.alloc(h, n * sizeof(fmd_ovlp_link_t)) || d_und.alloc(h, n * 8) || d_nund.alloc(h, 8) || d_res.alloc(h, n)) return FMD_E_NOMEM;
+    int rc = fmd_ovlp_link_dev(h, nullptr, n, (fmd_ovlp_rec_t *)j->rec_all.p, (const uint64_t *)j->nei01.p, 2, (uint32_t *)d_row_of.p, (fmd_ovlp_link_t *)d_link.p,
+                               (uint64_t *)d_und.p, (uint64_t *)d_nund.p);
+    if (rc) return rc;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > (1u << 20)) blocks = 1u << 20;
+    k_take_reserved<<<(unsigned)blocks, 256>>>(n, (const fmd_ovlp_rec_t *)j->rec_all.p, (uint8_t *)d_res.p);
+    const size_t piece = (size_t)1 << 22;
+    PinnedBuf st_link, st_res;
+    if (st_link.alloc(piece * sizeof(fmd_ovlp_link_t)) || st_res.alloc(piece)) return FMD_E_NOMEM;
+    for (size_t b = 0; b < n && rc == FMD_OK; b += piece) {
+        const size_t m = n - b < piece ? n - b : piece;
+        if (hipMemcpy(st_link.p, (const fmd_ovlp_link_t *)d_link.p + b, m * sizeof(fmd_ovlp_link_t), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(st_res.p, (const uint8_t *)d_res.p + b, m, hipMemcpyDeviceToHost) != hipSuccess) { rc = FMD_E_HIP; break; }
+        rc = fn(ctx, (uint64_t)b, m, (const fmd_ovlp_link_t *)st_link.p, (const uint8_t *)st_res.p);
+    }
+    uint64_t nu = 0;
+    if (rc == FMD_OK && hipMemcpy(&nu, d_nund.p, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = FMD_E_HIP;
+    if (rc == FMD_OK && nu) {
+        uint64_t *u = (uint64_t *)malloc(nu * 8);
+        if (!u) rc = FMD_E_NOMEM;
+        else if (hipMemcpy(u, d_und.p, nu * 8, hipMemcpyDeviceToHost) != hipSuccess) { free(u); rc = FMD_E_HIP; }
+        else { std::sort(u, u + nu); *undecided = u; *n_undecided = nu; }
+    }
+    if (rc == FMD_E_HIP) fmd_set_hip_error(hipGetLastError(), "table job: link pass");
     return rc;
 }

@@ -63,7 +63,7 @@ int fmdh_api_unitig(int device, int min_match, int64_t l, char *seq, FILE *out)
     size_t n = 0;
     int64_t i;
     fmd_dev_t *dev = 0;
-    fmdh_ovlp_table_t t;
+    fmdh_slim_t *t = 0;
     int rc;
     if (l <= 0 || !seq || !out || seq[l - 1] != 0) return 1;
     if (min_match < 0) min_match = (int)(fmdh_api_seqlen(l, seq, .25) * .33 + .499);
@@ -72,11 +72,11 @@ int fmdh_api_unitig(int device, int min_match, int64_t l, char *seq, FILE *out)
     rc = open_index(device, n, bases, off, &dev);
     free(bases); free(off);
     if (rc) { fprintf(stderr, "[E::%s] index construction failed: %s\n", __func__, fmd_strerror(rc)); return 1; }
-    rc = fmdh_ovlp_table_build_dev(dev, min_match, &t, &n_seq);
+    rc = fmdh_slim_build_dev(dev, min_match, &t, &n_seq);
     fmd_dev_close(dev);
     if (rc) { fprintf(stderr, "[E::%s] cannot build the overlap table\n", __func__); return 1; }
-    rc = fmdh_unitig_walk_opt(&t, n_seq, min_match, 0, out, FMDH_WALK_FULL_RECORDS);   /* what mag_g_print(g) prints (example.c:42) */
-    fmdh_ovlp_table_free(&t);
+    rc = fmdh_unitig_walk_slim(t, n_seq, min_match, 0, out, FMDH_WALK_FULL_RECORDS);   /* what mag_g_print(g) prints (example.c:42) */
+    fmdh_slim_free(t);
     return rc ? 1 : 0;
 }
 

@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <stdio.h>
+#include <pthread.h>
 #include "fmd_hip.h"
 #ifdef __cplusplus
 extern "C" {
@@ -83,15 +84,159 @@ static inline void fmdh_row_bases(const fmdh_row_t *x, uint32_t from, uint32_t n
     }
     for (; j < n; ++j) dst[j] = (char)fmd_ovlp_row_base(x->rec, x->max_nei, x->var, from + j);
 }
-/* Build the table of all n_seq sequence ids on the GPUs devices[0..n_dev): one host thread and one replica of the index
- * per device, shard g = ids g, g + n_dev, ...; rows that overflow the capacities are recomputed (device 0) with the
- * capacities doubled until they fit.  A device may be listed more than once (two replicas on one GPU). */
+/* ---- the walk's own table (slim_table.c): 32 bytes per sequence id that a plain step of the walk reads as ONE line, and a short variable part.
+ * What `unitig` holds in host memory: ~58 bytes per id on 100-base reads where the packed rows above took 150-190. */
+#define FMDH_SLIM_CHUNK_SHIFT 22
+#define FMDH_W_ST_MASK 3u          /* bits & 3: 0 = a read the walk can extend, 1 = short (unitig.c:288), 2 = contained (:292), 3 = flagged (a capacity was exceeded) */
+#define FMDH_W_ST_SHORT 1
+#define FMDH_W_ST_CONTAINED 2
+#define FMDH_W_ST_INVALID 3
+#define FMDH_W_PLAIN 4u            /* one neighbour, check_left decided, the appended bases in the line, nothing wide: the step reads w[id] and w[nxt] only */
+#define FMDH_W_CL 8u               /* check_left (unitig.c:206-225) < 0 on the edge to the unique neighbour */
+#define FMDH_W_UNDEC 16u           /* that edge is not decided (or the neighbour has no row): the table is incomplete */
+#define FMDH_W_BIG 32u             /* the variable part is the record itself (64 bytes), its neighbours (32 each), all bases 4 bits each */
+#define FMDH_W_EXTVAR 64u          /* the appended bases are in the variable part, 4 bits each */
+#define FMDH_W_XVAR 128u           /* the variable part is in xvar (rows computed again), voff in units of 8 bytes */
+#define FMDH_W_EXT_INLINE 24
+typedef struct {
+    uint32_t nxt;                  /* id of the unique neighbour's row, 0xffffffff = none */
+    uint32_t far;                  /* the row eight accepted links on (a prefetch hint; 0xffffffff = none / not built) */
+    uint32_t k0, k1;               /* k[0], k[1] of the record: the `$read$` interval */
+    uint32_t voff;                 /* where the variable part starts in its chunk (bytes) */
+    uint16_t rbeg;                 /* 0xffff = fm6_get_nei returned -1 */
+    uint8_t ext[6];                /* the appended bases, (code - 1) in 2 bits each, first one lowest */
+    uint8_t ext_len, n_nei, k2, bits;
+} fmdh_wrec_t;                     /* 32 bytes */
+/* variable part of a row that is not W_BIG: rank u32, len u16, flags u8, the neighbours, [appended bases, 4 bits each: W_EXTVAR],
+ * [the sequence: 2 bits per base, or 4 with V_SEED_N: V_HAS_SEED -- even ids, and rows computed again].
+ * The neighbours (x[0], x[1] of `$neighbour$` and the overlap length): n_nei x {x0 u32, x1 u32, overlap u16} in a table that host threads
+ * will link (they need x0 and x1); in a table linked on the device n_nei x {x0 u32, overlap u16}, and for ONE neighbour the overlap alone --
+ * its x0 is k0 of the row the link leads to. */
+#define FMDH_V_HDR 7u
+#define FMDH_V_NEI 10u
+#define FMDH_V_HAS_OVLP 1u         /* overlap_intv found a candidate (rec.n_ovlp != 0) */
+#define FMDH_V_SEED_N 2u
+#define FMDH_V_HAS_SEED 4u
+#define FMDH_V_RES_SHIFT 3         /* rec.reserved (0 / 1 / 2) as it arrived */
+typedef struct fmdh_slim {
+    uint64_t n; int n_shards; uint32_t chunk_shift; uint64_t cps;   /* ids; variable parts are kept per shard (id % n_shards) in chunks of 2^chunk_shift rows, cps chunks per shard */
+    fmdh_wrec_t *w;
+    uint8_t **var; uint64_t *var_len;
+    uint8_t *xvar; uint64_t x_len, x_cap;
+    uint32_t max_nei;                     /* the longest neighbour list of any row */
+    uint64_t big_k2;                      /* widest k[2] a line holds (255) */
+    int host_link;                        /* 1: neighbours in the 10-byte form, lfork kept until the table is linked */
+    uint16_t *lfork; uint32_t *row_of;    /* until fmdh_slim_finalize: what fmdh_slim_link_host reads */
+    uint64_t *und; uint32_t *und_rev; uint64_t n_und, m_und;   /* rows whose check_left is open, ascending, and the row of the neighbour's reverse strand */
+    pthread_mutex_t mu;
+} fmdh_slim_t;
+fmdh_slim_t *fmdh_slim_new(uint64_t n, int n_shards, int host_link, uint32_t chunk_shift);
+void fmdh_slim_free(fmdh_slim_t *s);
+uint64_t fmdh_slim_bytes(const fmdh_slim_t *s);
+int fmdh_host_threads(void);       /* FMD_HOST_THREADS, default 16 */
+void fmdh_par_for(int nt, void (*fn)(void *ctx, int tid, int nt), void *ctx);   /* fn(ctx, tid, nt) on nt threads (at most 64), joined */
+/* rows (chunk << FMDH_SLIM_CHUNK_SHIFT) .. + nr of shard g (id = g + n_shards * row) from packed rows as fmd_ovlp_pack_dev writes them: rec[nr], off[nr]
+ * (offsets into var); the three buffers are the caller's and are not kept.  Chunks of different shards may be added concurrently. */
+int fmdh_slim_add(fmdh_slim_t *s, int g, uint64_t chunk, const fmd_ovlp_rec_t *rec, const uint64_t *off, const uint8_t *var, uint32_t max_nei, uint64_t nr, int n_threads);
+int fmdh_slim_replace(fmdh_slim_t *s, const uint64_t *ids, const fmd_ovlp_rec_t *rec, const uint64_t *off, const uint8_t *var, uint32_t max_nei, uint64_t n, int n_threads);
+int fmdh_slim_link_fold(fmdh_slim_t *s, uint64_t first, uint64_t n, const struct fmdh_link *link, const uint8_t *reserved);
+int fmdh_slim_link_host(fmdh_slim_t *s, int n_threads);
+void fmdh_slim_undecided(const fmdh_slim_t *s, const uint64_t **ids, uint64_t *n);
+int fmdh_slim_set_reserved(fmdh_slim_t *s, const uint64_t *ids, const uint16_t *vals, uint64_t n);
+int fmdh_slim_finalize(fmdh_slim_t *s, int n_threads);
+int fmdh_slim_from_table(const fmdh_ovlp_table_t *t, int n_threads, fmdh_slim_t **out);
+int fmdh_slim_stats(const fmdh_ovlp_table_t *t, uint64_t out[6]);
+
+static inline const uint8_t *fmdh_slim_var(const fmdh_slim_t *s, uint64_t id)
+{
+    const fmdh_wrec_t *w = &s->w[id];
+    if (w->bits & FMDH_W_XVAR) return s->xvar + (uint64_t)w->voff * 8;
+    if (s->n_shards == 1) return s->var[id >> s->chunk_shift] + w->voff;
+    return s->var[(id % (uint64_t)s->n_shards) * s->cps + ((id / (uint64_t)s->n_shards) >> s->chunk_shift)] + w->voff;
+}
+/* a row as the walk's general code reads it */
+typedef struct {
+    const uint8_t *var, *nei;      /* nei: the neighbour entries (FMDH_V_NEI bytes each; 32 in a W_BIG row) */
+    uint64_t rank, k[3];
+    int32_t len, rbeg, ext_len, n_nei, n_stored;
+    int status, has_ovlp, reserved, big, nei_bytes;   /* nei_bytes: of the whole neighbour block */
+    uint8_t bits, vflags;
+} fmdh_rowv_t;
+static inline void fmdh_slim_row(const fmdh_slim_t *s, uint64_t id, fmdh_rowv_t *v)
+{
+    const fmdh_wrec_t *w = &s->w[id];
+    const uint8_t *p = fmdh_slim_var(s, id);
+    v->var = p; v->bits = w->bits; v->status = (int)(w->bits & FMDH_W_ST_MASK); v->big = (w->bits & FMDH_W_BIG) != 0;
+    if (v->big) {
+        fmd_ovlp_rec_t r;
+        memcpy(&r, p, 64);
+        v->rank = r.rank; v->k[0] = r.k[0]; v->k[1] = r.k[1]; v->k[2] = r.k[2]; v->len = r.len; v->rbeg = r.rbeg; v->ext_len = r.ext_len; v->n_nei = r.n_nei;
+        v->has_ovlp = r.n_ovlp != 0; v->reserved = r.reserved; v->vflags = FMDH_V_HAS_SEED | FMDH_V_SEED_N;
+        v->nei = p + 64;
+    } else {
+        uint32_t rk; uint16_t ln;
+        memcpy(&rk, p, 4); memcpy(&ln, p + 4, 2);
+        v->rank = rk; v->len = ln; v->vflags = p[6]; v->has_ovlp = (p[6] & FMDH_V_HAS_OVLP) != 0; v->reserved = (p[6] >> FMDH_V_RES_SHIFT) & 3;
+        v->k[0] = w->k0; v->k[1] = w->k1; v->k[2] = w->k2; v->rbeg = w->rbeg == 0xffff ? -1 : (int32_t)w->rbeg; v->ext_len = w->ext_len; v->n_nei = w->n_nei;
+        v->nei = p + FMDH_V_HDR;
+    }
+    if (v->status != 0) { v->n_nei = 0; v->rbeg = -1; v->ext_len = 0; }
+    v->n_stored = v->n_nei;
+    v->nei_bytes = v->big ? v->n_stored * 32 : s->host_link ? v->n_stored * (int)FMDH_V_NEI : v->n_stored == 1 ? 2 : v->n_stored * 6;
+}
+/* neighbour k of row id: x[0] (and x[1] where the table keeps it, else ~0) of `$neighbour$`, the overlap length */
+static inline void fmdh_slim_nei(const fmdh_slim_t *s, uint64_t id, const fmdh_rowv_t *v, int k, uint64_t *x0, uint64_t *x1, uint64_t *info)
+{
+    if (v->big) { fmd_intv_t e; memcpy(&e, v->nei + (size_t)k * 32, 32); *x0 = e.x[0]; *x1 = e.x[1]; *info = e.info; }
+    else if (s->host_link) { uint32_t a, b; uint16_t c; const uint8_t *q = v->nei + (size_t)k * FMDH_V_NEI; memcpy(&a, q, 4); memcpy(&b, q + 4, 4); memcpy(&c, q + 8, 2); *x0 = a; *x1 = b; *info = c; }
+    else if (v->n_stored == 1) {
+        const uint32_t nxt = s->w[id].nxt;
+        uint16_t c;
+        memcpy(&c, v->nei, 2);
+        *info = c; *x1 = ~0ull; *x0 = ~0ull;
+        if (nxt != 0xffffffffu) {
+            if (s->w[nxt].bits & FMDH_W_BIG) { fmd_ovlp_rec_t r; memcpy(&r, fmdh_slim_var(s, nxt), 64); *x0 = r.k[0]; }
+            else *x0 = s->w[nxt].k0;
+        }
+    } else { uint32_t a; uint16_t c; const uint8_t *q = v->nei + (size_t)k * 6; memcpy(&a, q, 4); memcpy(&c, q + 4, 2); *x0 = a; *x1 = ~0ull; *info = c; }
+}
+/* the bases fm6_get_nei appended (unitig.c:139), nt6 codes */
+static inline void fmdh_slim_ext(const fmdh_slim_t *s, uint64_t id, const fmdh_rowv_t *v, char *dst)
+{
+    int j;
+    if (v->big) { const uint8_t *q = v->nei + v->nei_bytes; for (j = 0; j < v->ext_len; ++j) { const int z = v->len + j; dst[j] = (char)((q[z >> 1] >> (4 * (z & 1))) & 15); } }
+    else if (v->bits & FMDH_W_EXTVAR) { const uint8_t *q = v->nei + v->nei_bytes; for (j = 0; j < v->ext_len; ++j) dst[j] = (char)((q[j >> 1] >> (4 * (j & 1))) & 15); }
+    else { const uint8_t *q = s->w[id].ext; for (j = 0; j < v->ext_len; ++j) dst[j] = (char)(((q[j >> 2] >> (2 * (j & 3))) & 3) + 1); }
+}
+/* the sequence of a row that holds its own (V_HAS_SEED), nt6 codes; 0 = this row does not */
+static inline int fmdh_slim_own_seq(const fmdh_rowv_t *v, char *dst)
+{
+    const uint8_t *q;
+    int j;
+    if (!(v->vflags & FMDH_V_HAS_SEED) || v->status != 0) return 0;
+    if (v->big) { q = v->nei + v->nei_bytes; for (j = 0; j < v->len; ++j) dst[j] = (char)((q[j >> 1] >> (4 * (j & 1))) & 15); return 1; }
+    q = v->nei + v->nei_bytes + ((v->bits & FMDH_W_EXTVAR) ? (size_t)(v->ext_len + 1) / 2 : 0);
+    if (v->vflags & FMDH_V_SEED_N) for (j = 0; j < v->len; ++j) dst[j] = (char)((q[j >> 1] >> (4 * (j & 1))) & 15);
+    else {
+        for (j = 0; j + 4 <= v->len; j += 4) {
+            const uint32_t b = q[j >> 2], x = ((b & 3u) | (b & 0xcu) << 6 | (b & 0x30u) << 12 | (b & 0xc0u) << 18) + 0x01010101u;
+            memcpy(dst + j, &x, 4);
+        }
+        for (; j < v->len; ++j) dst[j] = (char)(((q[j >> 2] >> (2 * (j & 3))) & 3) + 1);
+    }
+    return 1;
+}
+
 /* One parallel pass over a complete table (n_threads host threads): row_of, link, and check_left_simple's verdict
  * (unitig.c:186-204) for every row with a unique neighbour, decided from the lfork of the neighbour's reverse strand
  * (include/fmd_hip.h) and written to rec.reserved (0 / 1).  Rows it cannot decide are returned in *undecided
  * (malloc'ed ids, *n_undecided of them; rec.reserved stays 2): the caller runs fmd_ovlp_check_left on those. */
 int fmdh_ovlp_table_link(fmdh_ovlp_table_t *t, int n_threads, uint64_t **undecided, uint64_t *n_undecided);
-int fmdh_ovlp_table_build(const char *fmd_path, int n_dev, const int *devices, int min_match, fmdh_ovlp_table_t *t, uint64_t *n_seq);
+/* Build the table of all n_seq sequence ids on the GPUs devices[0..n_dev): one host thread and one replica of the index
+ * per device, GPU g = the rows of ids g, g + n_dev, ..., streamed chunk by chunk into the slim table; rows that overflow the
+ * capacities are recomputed (device 0) with the capacities raised until they fit.  A device may be listed more than once (two
+ * replicas on one GPU).  *out is released with fmdh_slim_free. */
+int fmdh_slim_build(const char *fmd_path, int n_dev, const int *devices, int min_match, fmdh_slim_t **out, uint64_t *n_seq);
 void fmdh_ovlp_table_free(fmdh_ovlp_table_t *t);
 /* Replays the single-threaded walk and writes the MAG records `fermi unitig -t1` prints. */
 int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, const uint64_t *sorted /* or NULL */, FILE *out);
@@ -99,6 +244,8 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
  * a graph (mag.c:176-188, fwrite) -- `fermi unitig` cuts it at the NUL (unitig.c:354, fputs), which is the default here */
 #define FMDH_WALK_FULL_RECORDS 1
 int fmdh_unitig_walk_opt(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, const uint64_t *sorted /* or NULL */, FILE *out, int flags);
+/* the walk itself: over the slim table (writes the skip list into t->w[].far) */
+int fmdh_unitig_walk_slim(fmdh_slim_t *t, uint64_t n_seq, int min_match, const uint64_t *sorted /* or NULL */, FILE *out, int flags);
 /* Whole command: replicate the .fmd on the listed GPUs, build the table, walk, print.  `fermi unitig -l min_match <fn>`
  * (cmd.c:184-216); the reference's fm6_unitig gives seeds i = j (mod n_threads) to worker j (unitig.c:394-404), here
  * GPU g computes the rows of ids i = g (mod n_dev) and ONE deterministic walk consumes them (the output is that of -t1
@@ -162,7 +309,7 @@ uint64_t fmdh_remap_table_resets(const fmdh_remap_state_t *st);  /* how often th
 int fmdh_api_unitig(int device, int min_match, int64_t l, char *seq, FILE *out);
 int fmdh_api_correct(int device, int kmer, int step, int64_t l, char *seq, char *qual);
 int fmdh_api_seqlen(int64_t l, const char *seq, double quantile);   /* fm6_api_seqlen, seq.c:430-446 */
-int fmdh_ovlp_table_build_dev(fmd_dev_t *dev, int min_match, fmdh_ovlp_table_t *t, uint64_t *n_seq_out);
+int fmdh_slim_build_dev(fmd_dev_t *dev, int min_match, fmdh_slim_t **out, uint64_t *n_seq_out);
 
 /* `fermi build -o out.fmd <in.fa>` (cmd.c:378-484); no_fr = trim palindromes (default 1) */
 int fmdh_build(const char *fa_path, const char *out_path, int device, int max_len, int no_fr);

@@ -148,94 +148,90 @@ done:
     return rc;
 }
 
-/* One GPU linked the whole table (fmd_ovlp_packed_table) while the rows that exceeded a capacity were still flagged; they are in the side
- * table now.  Nothing else changed, so nothing else is linked again: the side rows enter row_of (identical reads overflow together, so no
- * entry that is there loses to one of them), and the rows of `ids` -- the side rows themselves and what the device reported: edges it could
- * not decide and edges into a row that was not there -- get their links and verdicts the way fmdh_ovlp_table_link gives them to every row.
- * (0.6 s of host threads over 10^8 rows for 6*10^5 that changed.)  ids: ascending, may repeat. */
-static int table_patch_links(fmdh_ovlp_table_t *t, const uint64_t *side_ids, uint64_t n_side, const uint64_t *dev_und, uint64_t n_dev_und, uint64_t **und_out, uint64_t *n_und_out)
-{
-    const int force_exact = getenv("FMD_CHECK_LEFT_EXACT") != NULL;
-    uint64_t a = 0, b = 0, last = ~0ull, n_und = 0, m_und = 0, *und = 0;
-    *und_out = 0; *n_und_out = 0;
-    for (a = 0; a < n_side; ++a) {
-        const fmd_ovlp_rec_t *r = &t->side.rec[a];
-        if (r->status == 0 && !(r->flags & FMD_OVLP_F_OVERFLOW) && r->k[0] < t->n && (uint32_t)side_ids[a] < t->row_of[r->k[0]]) t->row_of[r->k[0]] = (uint32_t)side_ids[a];
-    }
-    for (a = 0, b = 0; a < n_side || b < n_dev_und;) {   /* the two lists merged */
-        const uint64_t i = b >= n_dev_und || (a < n_side && side_ids[a] <= dev_und[b]) ? side_ids[a++] : dev_und[b++];
-        if (i == last) continue;
-        last = i;
-        if (link_row(t, i, force_exact)) {
-            if (n_und == m_und) { uint64_t m = m_und ? m_und << 1 : 1024, *q = (uint64_t *)realloc(und, m * 8); if (!q) { free(und); return -ENOMEM; } und = q; m_und = m; }
-            und[n_und++] = i;
-        }
-    }
-    *und_out = und; *n_und_out = n_und;
-    return 0;
-}
-
 /* ------------------------------------------------------------------------------------------------ build */
+/* The table `unitig` walks, built on n_dev GPUs and kept SLIM (slim_table.c): the packed chunks are staging buffers of the library
+ * (fmd_ovlp_tabjob_rows / fmd_ovlp_packed_stream) and every chunk is folded into 32 bytes per row + a short variable part as it
+ * arrives.  One GPU: the device links the table (fmd_ovlp_tabjob_link) after the rows that exceeded a capacity have been computed
+ * again and patched into its copy; several GPUs: GPU g streams the rows of ids i = g (mod n_dev), host threads link the slim rows. */
+#define STREAM_CHUNK_SHIFT 20   /* rows per streamed chunk: two pinned staging sets of ~340 MB at the default capacities */
 typedef struct {
     const char *fmd_path; int device, g, n_dev, min_match; uint32_t max_len, max_nei;
-    fmdh_ovlp_shard_t *shard; fmd_dev_t *dev; uint64_t n_seq; int rc; double t_load, t_rows;
-    fmdh_ovlp_table_t *whole;          /* one GPU: the table itself, linked on the device (fmd_ovlp_packed_table) */
-    uint64_t *und, n_und;
+    fmd_dev_t *dev; uint64_t n_seq; int rc; double t_load, t_rows;
+    fmdh_slim_t *slim; int conv_threads, one_gpu_job;
+    fmd_ovlp_tabjob_t *tabjob;
+    uint64_t *flagged, n_flagged, m_flagged; uint32_t longest; int too_long;   /* what the sink saw: rows that exceeded a capacity */
+    int sink_rc;
 } job_t;
 
-/* one GPU holds every row: the link pass runs there too */
-static int table_fill_linked(fmd_dev_t *d, fmdh_ovlp_table_t *t, uint64_t n, int min_match, uint32_t max_len, uint32_t max_nei, uint64_t **und, uint64_t *n_und)
+static int rows_sink(void *ctx, uint64_t first_row, size_t n_rows, const fmd_ovlp_rec_t *rec, const uint64_t *off, const uint8_t *var, uint64_t var_bytes)
 {
-    fmdh_ovlp_shard_t *s = &t->shard[0];
-    const size_t nc = (size_t)((n + ((uint64_t)1 << TABLE_CHUNK_SHIFT) - 1) >> TABLE_CHUNK_SHIFT);
-    memset(s, 0, sizeof(*s));
-    s->n = n; s->chunk_shift = TABLE_CHUNK_SHIFT; s->max_nei = max_nei; s->seq_stride = 2 * ((max_len + 3) / 4 * 4);
-    s->rec = (fmd_ovlp_rec_t *)fmdh_big_alloc((n ? n : 1) * sizeof(fmd_ovlp_rec_t));
-    s->off = (uint64_t *)fmdh_big_alloc((n ? n : 1) * 8);
-    s->chunk = (uint8_t **)calloc(nc ? nc : 1, sizeof(uint8_t *));
-    t->row_of = (uint32_t *)fmdh_big_alloc((n ? n : 1) * 4);
-    t->link = (fmdh_link_t *)fmdh_big_alloc((n ? n : 1) * sizeof(fmdh_link_t));
-    if (!s->rec || !s->off || !s->chunk || !t->row_of || !t->link) { shard_free(s); fmdh_big_free(t->row_of); fmdh_big_free(t->link); t->row_of = 0; t->link = 0; return FMD_E_NOMEM; }
-    {
-        const int rc = fmd_ovlp_packed_table(d, n, min_match, max_len, max_nei, s->rec, s->off, s->chunk_shift, s->chunk, t->row_of, (fmd_ovlp_link_t *)t->link, und, n_und);
-        if (rc) { shard_free(s); fmdh_big_free(t->row_of); fmdh_big_free(t->link); t->row_of = 0; t->link = 0; return rc; }
+    job_t *j = (job_t *)ctx;
+    size_t k;
+    int rc;
+    (void)var_bytes;
+    if (first_row & (((uint64_t)1 << STREAM_CHUNK_SHIFT) - 1)) return FMD_E_ARG;
+    rc = fmdh_slim_add(j->slim, j->g, first_row >> STREAM_CHUNK_SHIFT, rec, off, var, j->max_nei, n_rows, j->conv_threads);
+    if (rc) { j->sink_rc = rc; return FMD_E_NOMEM; }
+    for (k = 0; k < n_rows; ++k) if (rec[k].flags & FMD_OVLP_F_OVERFLOW) {
+        if (j->n_flagged == j->m_flagged) {
+            const uint64_t m = j->m_flagged ? 2 * j->m_flagged : 1 << 16;
+            uint64_t *q = (uint64_t *)realloc(j->flagged, m * 8);
+            if (!q) { j->sink_rc = -ENOMEM; return FMD_E_NOMEM; }
+            j->flagged = q; j->m_flagged = m;
+        }
+        j->flagged[j->n_flagged++] = (uint64_t)j->g + (uint64_t)j->n_dev * (first_row + k);
+        j->too_long |= (uint32_t)rec[k].len > j->max_len;
+        if (rec[k].len > 0 && (uint32_t)rec[k].len > j->longest) j->longest = (uint32_t)rec[k].len;
     }
-    return FMD_OK;
+    return 0;
+}
+static int links_sink(void *ctx, uint64_t first_row, size_t n_rows, const fmd_ovlp_link_t *link, const uint8_t *reserved)
+{
+    return fmdh_slim_link_fold((fmdh_slim_t *)ctx, first_row, n_rows, (const fmdh_link_t *)link, reserved) ? FMD_E_NOMEM : 0;
 }
 
+/* The capacity of the main pass follows the reads: the lengths of 8192 evenly spaced sequences (fm6_retrieve in bulk, a few ms), the
+ * longest of them rounded up to 32 -- 128 for reads of up to 128 bases.  A sequence longer than that is flagged by the main pass and
+ * computed in the overflow pass below, which costs a second look at the index: fine for stragglers, not for a third of the read set
+ * (reads of 70-150 bases under a fixed 128: 28 % of the rows went round again, and the ladder doubled their capacities out of memory). */
+static void probe_max_len(job_t *j)
+{
+    const uint64_t ns = j->n_seq < 8192 ? j->n_seq : 8192;
+    uint64_t *sid = (uint64_t *)malloc((ns ? ns : 1) * 8), k;
+    fmd_ovlp_rec_t *sr = (fmd_ovlp_rec_t *)malloc((ns ? ns : 1) * sizeof(fmd_ovlp_rec_t));
+    if (sid && sr && ns) {
+        int32_t mx = 0;
+        for (k = 0; k < ns; ++k) sid[k] = (uint64_t)((unsigned __int128)j->n_seq * k / ns);
+        if (fmd_seqinfo_batch(j->dev, (size_t)ns, sid, 1024, sr) == FMD_OK) {
+            for (k = 0; k < ns; ++k) if (sr[k].len > mx) mx = sr[k].len;
+            if (mx > 3000) mx = 3000;
+            if ((uint32_t)mx > j->max_len) j->max_len = ((uint32_t)mx + 31) / 32 * 32;
+        }
+    }
+    free(sid); free(sr);
+}
+static int job_open(job_t *j)
+{
+    fmd_info_t info;
+    const double t0 = now_s();
+    if (!j->dev) j->rc = fmd_dev_open_file(j->device, j->fmd_path, &j->dev);   /* (fmdh_slim_build_dev: the caller's handle) */
+    if (j->rc) return j->rc;
+    fmd_dev_info(j->dev, &info);
+    j->n_seq = info.mcnt[1];
+    j->t_load = now_s() - t0;
+    probe_max_len(j);
+    return 0;
+}
 static void *job_main(void *p)
 {
     job_t *j = (job_t *)p;
-    fmd_info_t info;
-    double t0 = now_s();
-    if (!j->dev) j->rc = fmd_dev_open_file(j->device, j->fmd_path, &j->dev);   /* (fmdh_ovlp_table_build_dev: the caller's handle) */
-    if (j->rc) return 0;
-    fmd_dev_info(j->dev, &info);
-    j->n_seq = info.mcnt[1];
-    j->t_load = now_s() - t0; t0 = now_s();
-    {   /* The capacity of the main pass follows the reads: the lengths of 8192 evenly spaced sequences (fm6_retrieve in bulk, a few ms), the
-         * longest of them rounded up to 32 -- 128 for reads of up to 128 bases.  A sequence longer than that is flagged by the main pass and
-         * computed in the overflow pass below, which costs a second look at the index: fine for stragglers, not for a third of the read set
-         * (reads of 70-150 bases under a fixed 128: 28 % of the rows went round again, and the ladder doubled their capacities out of memory). */
-        const uint64_t ns = j->n_seq < 8192 ? j->n_seq : 8192;
-        uint64_t *sid = (uint64_t *)malloc((ns ? ns : 1) * 8), k;
-        fmd_ovlp_rec_t *sr = (fmd_ovlp_rec_t *)malloc((ns ? ns : 1) * sizeof(fmd_ovlp_rec_t));
-        if (sid && sr && ns) {
-            int32_t mx = 0;
-            for (k = 0; k < ns; ++k) sid[k] = (uint64_t)((unsigned __int128)j->n_seq * k / ns);
-            if (fmd_seqinfo_batch(j->dev, (size_t)ns, sid, 1024, sr) == FMD_OK) {
-                for (k = 0; k < ns; ++k) if (sr[k].len > mx) mx = sr[k].len;
-                if (mx > 3000) mx = 3000;
-                if ((uint32_t)mx > j->max_len) j->max_len = ((uint32_t)mx + 31) / 32 * 32;
-            }
-        }
-        free(sid); free(sr);
-    }
-    if (j->whole && j->n_seq < 0xffffffffull && !getenv("FMD_HOST_LINK")) j->rc = table_fill_linked(j->dev, j->whole, j->n_seq, j->min_match, j->max_len, j->max_nei, &j->und, &j->n_und);
+    double t0;
+    if (!j->dev && job_open(j)) return 0;
+    t0 = now_s();
+    if (j->one_gpu_job) j->rc = fmd_ovlp_tabjob_rows(j->dev, j->n_seq, j->min_match, j->max_len, j->max_nei, STREAM_CHUNK_SHIFT, rows_sink, j, &j->tabjob);
     else {
         const uint64_t n = j->n_seq > (uint64_t)j->g ? (j->n_seq - (uint64_t)j->g + (uint64_t)j->n_dev - 1) / (uint64_t)j->n_dev : 0;
-        j->whole = 0;
-        j->rc = shard_fill(j->dev, j->shard, 0, (uint64_t)j->g, (uint64_t)j->n_dev, n, j->min_match, j->max_len, j->max_nei, 0);
+        j->rc = fmd_ovlp_packed_stream(j->dev, 0, (uint64_t)j->g, (uint64_t)j->n_dev, n, j->min_match, j->max_len, j->max_nei, 0, STREAM_CHUNK_SHIFT, rows_sink, j);
     }
     j->t_rows = now_s() - t0;
     if (j->g != 0) { fmd_dev_close(j->dev); j->dev = 0; }   /* replica 0 stays open for the overflow pass */
@@ -254,154 +250,188 @@ void fmdh_ovlp_table_free(fmdh_ovlp_table_t *t)
 }
 
 static int cmp_u64(const void *a, const void *b) { const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b; return x < y ? -1 : x > y; }
-static int table_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_dev, const int *devices, int min_match, fmdh_ovlp_table_t *t, uint64_t *n_seq_out);
-int fmdh_ovlp_table_build(const char *fmd_path, int n_dev, const int *devices, int min_match, fmdh_ovlp_table_t *t, uint64_t *n_seq_out)
+static int slim_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_dev, const int *devices, int min_match, fmdh_slim_t **out, uint64_t *n_seq_out);
+int fmdh_slim_build(const char *fmd_path, int n_dev, const int *devices, int min_match, fmdh_slim_t **out, uint64_t *n_seq_out)
 {
-    return table_build_core(fmd_path, 0, n_dev, devices, min_match, t, n_seq_out);
+    return slim_build_core(fmd_path, 0, n_dev, devices, min_match, out, n_seq_out);
 }
 /* the same table from an index that is already in a GPU's HBM (the in-memory API: no .fmd in between); the handle stays the caller's */
-int fmdh_ovlp_table_build_dev(fmd_dev_t *dev, int min_match, fmdh_ovlp_table_t *t, uint64_t *n_seq_out)
+int fmdh_slim_build_dev(fmd_dev_t *dev, int min_match, fmdh_slim_t **out, uint64_t *n_seq_out)
 {
     fmd_info_t info;
     int device;
     if (!dev || fmd_dev_info(dev, &info)) return 1;
     device = info.device;
-    return table_build_core("(memory)", dev, 1, &device, min_match, t, n_seq_out);
+    return slim_build_core("(memory)", dev, 1, &device, min_match, out, n_seq_out);
 }
-static int table_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_dev, const int *devices, int min_match, fmdh_ovlp_table_t *t, uint64_t *n_seq_out)
+/* a shard of packed rows computed for `ids` (the side pass, the exact check_left pass) into the slim rows, chunk by chunk */
+static int replace_from_shard(fmdh_slim_t *s, const uint64_t *ids, const fmdh_ovlp_shard_t *sh, int nt)
+{
+    uint64_t k;
+    int rc = 0;
+    for (k = 0; k < sh->n && !rc; k += (uint64_t)1 << sh->chunk_shift) {
+        const uint64_t nr = sh->n - k < ((uint64_t)1 << sh->chunk_shift) ? sh->n - k : (uint64_t)1 << sh->chunk_shift;
+        rc = fmdh_slim_replace(s, ids + k, sh->rec + k, sh->off + k, sh->chunk[k >> sh->chunk_shift], sh->max_nei, nr, nt);
+    }
+    return rc;
+}
+static int slim_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_dev, const int *devices, int min_match, fmdh_slim_t **out, uint64_t *n_seq_out)
 {
     const int timing = getenv("FMD_TIMING") != 0;
-    uint32_t max_len = 128, longest = 0;   /* (max_len: raised by the jobs' probe of the read lengths) */
+    const int nt = fmdh_host_threads();
+    uint32_t max_len = 128, longest = 0;   /* (max_len: raised by the probe of the read lengths) */
     const uint32_t max_nei = 4;
     job_t *jobs;
     pthread_t *tid;
     char *started;
+    fmdh_slim_t *s = 0;
     uint64_t *ids = 0, n_side = 0, n_seq, i;
-    int g, rc = 0, too_long_hint = 0;
+    int g, rc = 0, too_long_hint = 0, one_gpu;
     double t0 = now_s();
-    if (n_dev < 1 || !devices || !t) return 1;
-    memset(t, 0, sizeof(*t));
+    if (n_dev < 1 || !devices || !out) return 1;
+    *out = 0;
     jobs = (job_t *)calloc((size_t)n_dev, sizeof(job_t));
     tid = (pthread_t *)calloc((size_t)n_dev, sizeof(pthread_t));
     started = (char *)calloc((size_t)n_dev, 1);
-    t->shard = (fmdh_ovlp_shard_t *)calloc((size_t)n_dev, sizeof(fmdh_ovlp_shard_t));
-    if (!jobs || !tid || !started || !t->shard) { free(jobs); free(tid); free(started); free(t->shard); t->shard = 0; return 1; }
-    t->n_shards = n_dev;
+    if (!jobs || !tid || !started) { free(jobs); free(tid); free(started); return 1; }
+    one_gpu = n_dev == 1 && !getenv("FMD_HOST_LINK");
     for (g = 0; g < n_dev; ++g) {
-        job_t x = {fmd_path, devices[g], g, n_dev, min_match, max_len, max_nei, &t->shard[g], 0, 0, 0, 0, 0, n_dev == 1 ? t : 0, 0, 0};
+        job_t x;
+        memset(&x, 0, sizeof(x));
+        x.fmd_path = fmd_path; x.device = devices[g]; x.g = g; x.n_dev = n_dev; x.min_match = min_match; x.max_len = max_len; x.max_nei = max_nei;
+        x.conv_threads = nt / n_dev > 0 ? nt / n_dev : 1; x.one_gpu_job = one_gpu;
         jobs[g] = x;
-        if (g == 0 && preopened) jobs[g].dev = preopened;
-        if (g > 0) started[g] = pthread_create(&tid[g], 0, job_main, &jobs[g]) == 0;
     }
+    /* replica 0 first: the number of sequences sizes the table every job writes into */
+    if (preopened) jobs[0].dev = preopened;
+    if (job_open(&jobs[0])) { fprintf(stderr, "[E::%s] GPU %d: %s\n", __func__, devices[0], fmd_strerror(jobs[0].rc)); rc = 1; goto done; }
+    n_seq = jobs[0].n_seq;
+    if (n_seq_out) *n_seq_out = n_seq;
+    if (n_seq >= 0xffffffffull) { fprintf(stderr, "[E::%s] %llu sequences: the walk's rows hold 32-bit ids\n", __func__, (unsigned long long)n_seq); rc = 1; goto done; }
+    s = fmdh_slim_new(n_seq, n_dev, !one_gpu, STREAM_CHUNK_SHIFT);
+    if (!s) { fprintf(stderr, "[E::%s] out of memory (%llu rows)\n", __func__, (unsigned long long)n_seq); rc = 1; goto done; }
+    for (g = 0; g < n_dev; ++g) { jobs[g].slim = s; jobs[g].max_len = jobs[0].max_len; }
+    for (g = 1; g < n_dev; ++g) started[g] = pthread_create(&tid[g], 0, job_main, &jobs[g]) == 0;
     job_main(&jobs[0]);                                           /* shard 0 on the calling thread */
     for (g = 1; g < n_dev; ++g) { if (started[g]) pthread_join(tid[g], 0); else job_main(&jobs[g]); } /* no thread: do it here, afterwards */
     for (g = 0; g < n_dev; ++g) {
-        if (jobs[g].rc) { fprintf(stderr, "[E::%s] GPU %d: %s\n", __func__, devices[g], fmd_strerror(jobs[g].rc)); rc = 1; }
-        if (timing) fprintf(stderr, "[M::%s] GPU %d: index load + transcode %.3f s, %llu rows (GPU + copies) %.3f s\n", __func__, devices[g], jobs[g].t_load,
-                            (unsigned long long)t->shard[g].n, jobs[g].t_rows);
+        if (jobs[g].rc) { fprintf(stderr, "[E::%s] GPU %d: %s%s\n", __func__, devices[g], fmd_strerror(jobs[g].rc), jobs[g].sink_rc ? " (folding a chunk into the table)" : ""); rc = 1; }
+        if (timing) fprintf(stderr, "[M::%s] GPU %d: index load + transcode %.3f s, rows (GPU + copies + folding) %.3f s\n", __func__, devices[g], jobs[g].t_load, jobs[g].t_rows);
     }
     if (rc) goto done;
-    n_seq = jobs[0].n_seq;
     max_len = jobs[0].max_len;
-    for (g = 1; g < n_dev; ++g) if (jobs[g].max_len > max_len) max_len = jobs[g].max_len;
     for (g = 1; g < n_dev; ++g) if (jobs[g].n_seq != n_seq) { fprintf(stderr, "[E::%s] the replicas disagree\n", __func__); rc = 1; goto done; }
-    t->n = n_seq;
-    if (n_seq_out) *n_seq_out = n_seq;
-    if (n_seq >= 0xffffffffull) { fprintf(stderr, "[E::%s] %llu sequences: the walk's row map holds 32-bit ids\n", __func__, (unsigned long long)n_seq); rc = 1; goto done; }
     /* the rows that did not fit (longer sequences, more neighbours, longer lists): again, alone, with the capacities
-     * doubled until they do -- on the GPU; nothing falls back to the CPU */
-    {   /* one pass over the records: the flagged ids, and whether any of them is a sequence longer than max_len */
-        uint64_t cap_ids = 0;
-        int too_long = 0;
-        for (g = 0; g < n_dev; ++g) {
-            const fmd_ovlp_rec_t *r = t->shard[g].rec;
-            const uint64_t m = t->shard[g].n;
-            for (i = 0; i < m; ++i) if (r[i].flags & FMD_OVLP_F_OVERFLOW) {
-                if (n_side == cap_ids) { cap_ids = cap_ids ? 2 * cap_ids : 1 << 16; ids = (uint64_t *)realloc(ids, cap_ids * 8); if (!ids) { rc = 1; goto done; } }
-                ids[n_side++] = i * (uint64_t)n_dev + (uint64_t)g;
-                too_long |= (uint32_t)r[i].len > max_len;
-                if (r[i].len > 0 && (uint32_t)r[i].len > longest) longest = (uint32_t)r[i].len;
-            }
-        }
-        too_long_hint = too_long;
-    }
+     * raised until they do -- on the GPU; nothing falls back to the CPU */
+    for (g = 0; g < n_dev; ++g) { n_side += jobs[g].n_flagged; too_long_hint |= jobs[g].too_long; if (jobs[g].longest > longest) longest = jobs[g].longest; }
     if (n_side) {
+        fmdh_ovlp_shard_t side;
         uint32_t s_len = max_len, s_nei = max_nei;
         int attempt;
         double t1 = now_s();
-        t->side_of = (uint32_t *)malloc(n_seq * 4);
-        if (!ids || !t->side_of) { rc = 1; goto done; }
+        uint64_t o = 0;
+        memset(&side, 0, sizeof(side));
+        ids = (uint64_t *)malloc(n_side * 8);
+        if (!ids) { rc = 1; goto done; }
+        for (g = 0; g < n_dev; ++g) { memcpy(ids + o, jobs[g].flagged, jobs[g].n_flagged * 8); o += jobs[g].n_flagged; }
         if (n_dev > 1) qsort(ids, n_side, 8, cmp_u64);   /* (one shard: ascending already) */
         for (attempt = 0;; ++attempt) {
             uint64_t n_over = 0;
-            if (attempt == 12) { fprintf(stderr, "[E::%s] %llu rows still overflow at max_len %u, max_nei %u\n", __func__, (unsigned long long)n_side, s_len, s_nei); rc = 1; goto done; }
+            if (attempt == 12) { fprintf(stderr, "[E::%s] %llu rows still overflow at max_len %u, max_nei %u\n", __func__, (unsigned long long)n_side, s_len, s_nei); rc = 1; shard_free(&side); goto done; }
             /* what overflows in practice is the neighbour list of a strand in a fork-rich corner (more than max_nei irreducible overlaps): room for
              * four times as many at once, longer sequences / candidate lists only where a flagged record says so or the first attempt was not enough */
             if (attempt == 0) { s_nei *= 4; if (too_long_hint && longest > s_len) s_len = (longest + 31) / 32 * 32; }
             else { s_nei *= 2; s_len = (s_len + s_len / 2 + 31) / 32 * 32; }     /* (the candidate lists' capacity follows max_len: fmd_ovlp_list_cap) */
             if (s_len > 4000 + (uint32_t)min_match) s_len = 4000 + (uint32_t)min_match;   /* (lists of 4096 entries and more: not supported) */
-            shard_free(&t->side);
-            rc = shard_fill(jobs[0].dev, &t->side, ids, 0, 0, n_side, min_match, s_len, s_nei, 0);
+            shard_free(&side);
+            rc = shard_fill(jobs[0].dev, &side, ids, 0, 0, n_side, min_match, s_len, s_nei, 0);
             if (rc) { fprintf(stderr, "[E::%s] overflow pass: %s\n", __func__, fmd_strerror(rc)); rc = 1; goto done; }
-            for (i = 0; i < n_side; ++i) n_over += (t->side.rec[i].flags & FMD_OVLP_F_OVERFLOW) != 0;
+            for (i = 0; i < n_side; ++i) n_over += (side.rec[i].flags & FMD_OVLP_F_OVERFLOW) != 0;
             if (n_over == 0) break;
         }
-        memset(t->side_of, 0xff, n_seq * 4);
-        for (i = 0; i < n_side; ++i) t->side_of[ids[i]] = (uint32_t)i;
+        rc = replace_from_shard(s, ids, &side, nt);
+        if (!rc && jobs[0].tabjob) {   /* the device's copy of those rows, for its link pass */
+            uint64_t *n01 = (uint64_t *)malloc(n_side * 16);
+            if (!n01) rc = -ENOMEM;
+            else {
+                for (i = 0; i < n_side; ++i) {
+                    const fmd_ovlp_rec_t *r = &side.rec[i];
+                    const fmd_intv_t *ne = (const fmd_intv_t *)(side.chunk[i >> side.chunk_shift] + side.off[i]);
+                    const int has = fmd_ovlp_row_nei(r, side.max_nei) > 0;
+                    n01[2 * i] = has ? ne[0].x[0] : ~0ull; n01[2 * i + 1] = has ? ne[0].x[1] : ~0ull;
+                }
+                if (fmd_ovlp_tabjob_patch(jobs[0].tabjob, n_side, ids, side.rec, n01)) rc = -EIO;
+                free(n01);
+            }
+        }
+        shard_free(&side);
+        if (rc) { fprintf(stderr, "[E::%s] overflow pass: cannot replace the rows (%s)\n", __func__, strerror(-rc)); rc = 1; goto done; }
         if (timing) fprintf(stderr, "[M::%s] %llu rows again with capacities %u / %u: %.3f s\n", __func__, (unsigned long long)n_side, s_len, s_nei, now_s() - t1);
     }
-    /* check_left_simple (unitig.c:186-204) of every edge: decided on the host from the lfork of the neighbour's reverse
-     * strand; the edges that field does not decide go through the exact kernel (fmd_ovlp_check_left_dev), alone */
+    /* check_left_simple (unitig.c:186-204) of every edge: decided from the lfork of the neighbour's reverse strand, on the device that
+     * holds every record or by host threads; the edges that field does not decide go through the exact kernel (fmd_ovlp_check_left_dev), alone */
     {
-        uint64_t *und = 0, n_und = 0, k;
+        const uint64_t *und = 0;
+        uint64_t n_und = 0, k;
         double t1 = now_s();
-        int nt = 16;
-        { const char *e = getenv("FMD_HOST_THREADS"); if (e && atoi(e) > 0) nt = atoi(e); }
-        if (jobs[0].whole && n_side == 0) { /* linked on the device already */
-            und = jobs[0].und; n_und = jobs[0].n_und; jobs[0].und = 0;
-            if (timing) fprintf(stderr, "[M::%s] link pass on the GPU (inside the table pass), %llu edges left to the exact kernel\n", __func__, (unsigned long long)n_und);
-        } else if (jobs[0].whole && !getenv("FMD_HOST_RELINK")) {   /* linked on the device, and a few rows were replaced since: those, and what pointed at them */
-            rc = table_patch_links(t, ids, n_side, jobs[0].und, jobs[0].n_und, &und, &n_und);
-            fmd_host_free(jobs[0].und); jobs[0].und = 0;
-            if (rc) { fprintf(stderr, "[E::%s] link patch: %s\n", __func__, strerror(-rc)); rc = 1; goto done; }
-            if (timing) fprintf(stderr, "[M::%s] link pass on the GPU (inside the table pass) + %llu rows linked again here: %.3f s, %llu edges left to the exact kernel\n", __func__,
-                                (unsigned long long)n_side, now_s() - t1, (unsigned long long)n_und);
+        if (jobs[0].tabjob) {
+            uint64_t *dev_und = 0, n_dev_und = 0;
+            rc = fmd_ovlp_tabjob_link(jobs[0].tabjob, links_sink, s, &dev_und, &n_dev_und);
+            fmd_host_free(dev_und);                      /* (the folded rows list the same edges, with the rows of their reverse strands) */
+            fmd_ovlp_tabjob_free(jobs[0].tabjob); jobs[0].tabjob = 0;
+            if (rc) { fprintf(stderr, "[E::%s] link pass on the GPU: %s\n", __func__, fmd_strerror(rc)); rc = 1; goto done; }
         } else {
-            fmd_host_free(jobs[0].und); jobs[0].und = 0;    /* rows were replaced by the overflow pass: link again, here */
-            rc = fmdh_ovlp_table_link(t, nt, &und, &n_und);
-            if (rc) { fprintf(stderr, "[E::%s] link pass: %s\n", __func__, strerror(-rc)); rc = 1; free(und); goto done; }
-            if (timing) fprintf(stderr, "[M::%s] link pass (%d threads): %.3f s, %llu edges left to the exact kernel\n", __func__, nt, now_s() - t1, (unsigned long long)n_und);
+            rc = fmdh_slim_link_host(s, nt);
+            if (rc) { fprintf(stderr, "[E::%s] link pass: %s\n", __func__, strerror(-rc)); rc = 1; goto done; }
         }
+        fmdh_slim_undecided(s, &und, &n_und);
+        if (timing) fprintf(stderr, "[M::%s] link pass (%s): %.3f s, %llu edges left to the exact kernel\n", __func__, one_gpu ? "on the GPU, folded into the rows" : "host threads", now_s() - t1,
+                            (unsigned long long)n_und);
         if (n_und) {
             fmdh_ovlp_shard_t ex;
             uint32_t s_len = max_len > longest ? max_len : (longest + 31) / 32 * 32, s_nei = max_nei;
+            uint16_t *vals;
             int attempt;
             t1 = now_s();
             memset(&ex, 0, sizeof(ex));
-            for (attempt = 0;; ++attempt) {   /* same capacity ladder as above: a row of the side table needs its capacities here too */
+            for (attempt = 0;; ++attempt) {   /* same capacity ladder as above: a row that was computed again needs its capacities here too */
                 uint64_t n_over = 0;
                 rc = shard_fill(jobs[0].dev, &ex, und, 0, 0, n_und, min_match, s_len, s_nei, 1);
-                if (rc) { fprintf(stderr, "[E::%s] exact check_left pass: %s\n", __func__, fmd_strerror(rc)); rc = 1; free(und); goto done; }
+                if (rc) { fprintf(stderr, "[E::%s] exact check_left pass: %s\n", __func__, fmd_strerror(rc)); rc = 1; goto done; }
                 for (k = 0; k < n_und; ++k) n_over += (ex.rec[k].flags & FMD_OVLP_F_OVERFLOW) != 0;
                 if (n_over == 0) break;
                 if (attempt == 12) {   /* records that still overflow are invalid: their verdicts must not reach the table */
                     fprintf(stderr, "[E::%s] exact check_left pass: %llu rows still overflow at max_len %u, max_nei %u\n", __func__, (unsigned long long)n_over, s_len, s_nei);
-                    rc = 1; shard_free(&ex); free(und); goto done;
+                    rc = 1; shard_free(&ex); goto done;
                 }
                 s_nei *= 2; s_len = (s_len + s_len / 2 + 31) / 32 * 32;
                 if (s_len > 4000 + (uint32_t)min_match) s_len = 4000 + (uint32_t)min_match;
                 shard_free(&ex);
             }
-            for (k = 0; k < n_und; ++k) row_rec_mut(t, und[k])->reserved = ex.rec[k].reserved;
+            vals = (uint16_t *)malloc(n_und * 2);
+            if (!vals) { rc = 1; shard_free(&ex); goto done; }
+            for (k = 0; k < n_und; ++k) vals[k] = ex.rec[k].reserved;
+            rc = fmdh_slim_set_reserved(s, und, vals, n_und);
+            free(vals);
             shard_free(&ex);
+            if (rc) { fprintf(stderr, "[E::%s] exact check_left pass: %s\n", __func__, strerror(-rc)); rc = 1; goto done; }
             if (timing) fprintf(stderr, "[M::%s] exact check_left of %llu rows: %.3f s\n", __func__, (unsigned long long)n_und, now_s() - t1);
         }
-        free(und);
     }
-    if (timing) fprintf(stderr, "[M::%s] table of %llu sequences on %d GPU(s): %.3f s\n", __func__, (unsigned long long)n_seq, n_dev, now_s() - t0);
+    {
+        const double t1 = now_s();
+        if (fmdh_slim_finalize(s, nt)) { rc = 1; goto done; }
+        if (timing) fprintf(stderr, "[M::%s] plain steps marked: %.3f s\n", __func__, now_s() - t1);
+    }
+    if (timing) fprintf(stderr, "[M::%s] table of %llu sequences on %d GPU(s): %.3f s, %.1f bytes per row in host memory\n", __func__, (unsigned long long)n_seq, n_dev, now_s() - t0,
+                        n_seq ? (double)fmdh_slim_bytes(s) / (double)n_seq : 0.0);
 done:
-    for (g = 0; g < n_dev; ++g) if (jobs[g].dev && jobs[g].dev != preopened) fmd_dev_close(jobs[g].dev);
+    for (g = 0; g < n_dev; ++g) {
+        if (jobs[g].tabjob) fmd_ovlp_tabjob_free(jobs[g].tabjob);
+        if (jobs[g].dev && jobs[g].dev != preopened) fmd_dev_close(jobs[g].dev);
+        free(jobs[g].flagged);
+    }
     free(ids); free(jobs); free(tid); free(started);
-    if (rc) fmdh_ovlp_table_free(t);
+    if (rc) fmdh_slim_free(s); else *out = s;
     return rc;
 }

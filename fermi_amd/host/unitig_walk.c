@@ -59,225 +59,95 @@ typedef struct {
 } spec_t;
 
 typedef struct {
-    const fmdh_ovlp_table_t *t;
+    const fmdh_slim_t *t;       /* the table: 32 bytes per row the walk steps through, a short variable part for seeds and ends (slim_table.c) */
     uint64_t n_seq;
     int min_match;
     uint64_t *used, *bend, *visited;
     int full_records;           /* records written whole (mag_g_print, mag.c:176-188: fwrite) instead of cut at a NUL (unitig.c:354: fputs) */
     spec_t *sp;                 /* NULL: the maps are read and written directly (the sequential walk, and re-runs at commit) */
-    uint32_t *row_of;           /* `$read$` interval start -> a sequence id with that interval */
     const uint64_t *sorted;     /* optional rank -> (sequence id << 2 | flags) map of `unitig -r` (unitig.c:22-29) */
     /* the neighbour list left behind by the last try_right (unitig.c:181-184): that of row `last` */
     uint64_t last; int n_nei;
     int err;
-    uint32_t *jump;             /* row JUMP_DIST accepted links ahead of each row (prefetch hints only; 0 = not built) */
-    const struct hop *hop;      /* what a plain step of the walk reads, 32 bytes per row (hop_build below; 0 = not built) */
-    int seed_hints;             /* the seeds' first hops are prefetched (a linked table, unless FMD_WALK_NO_JUMP) */
+    int have_far;               /* w[].far is built: the row JUMP_DIST accepted links ahead of each row (prefetch hints only) */
+    int no_plain;               /* FMD_WALK_NO_HOP: every step through the general code (the A/B switch, and the tests' second opinion) */
+    int seed_hints;             /* the seeds' first hops are prefetched (unless FMD_WALK_NO_JUMP) */
     int timing;                 /* FMD_TIMING: the clock is read around the sections of a walk (four times per seed that walks: not for free at 4*10^7 seeds) */
     double t_uni, t_turn, t_text; uint64_t n_hops;   /* FMD_TIMING: seconds inside unidir, turning the string round, formatting the record; reads appended */
 } walk_t;
-/* one entry of walk_t.hop (see hop_build) */
-#define HOP_OK 1u
-#define HOP_CL 2u               /* check_left < 0: a backward bifurcation */
-#define HOP_MAX_EXT 21
-typedef struct hop {
-    uint32_t nxt, far;          /* the neighbour's row; the row JUMP_DIST links on (prefetch hint) */
-    uint32_t kx0, kx1;          /* k[0], k[1] of the neighbour's record: its `$read$` interval */
-    uint16_t rbeg; uint8_t ext_len, kx2;
-    uint8_t flags, pad[3];
-    uint64_t bases;             /* the appended bases (nt6 codes), 3 bits each, first one lowest */
-} hop_t;                        /* 32 bytes */
 
-/* The walk is a pointer chase: the next row is known when link[row] has arrived, one DRAM miss (~90 ns) per read and nothing
- * to overlap it with -- 1.8 s per 10^7 reads.  A chase cannot be prefetched, a chase with a skip list can: jump[row] = the
- * row 2^JUMP_LOG links further on (pointer doubling over link[].nxt, all host threads, ~0.1 s), and visiting a row prefetches
- * what the visit JUMP_DIST steps later will read (its record, offset, links, its own jump entry); half way there, when the
- * offset has arrived, the variable part.  Hints only: where the walk stops or turns, a prefetch was wasted, nothing else. */
+/* The walk is a pointer chase: the next row is known when w[row] has arrived, one DRAM miss (~90 ns) per read and nothing
+ * to overlap it with -- 1.8 s per 10^7 reads.  A chase cannot be prefetched, a chase with a skip list can: w[row].far = the
+ * row 2^JUMP_LOG links further on (pointer doubling over w[].nxt, all host threads), and visiting a row prefetches the line the
+ * visit JUMP_DIST steps later will read; half way there, when that line has arrived, the bitmap words its step will test and set.
+ * Hints only: where the walk stops or turns, a prefetch was wasted, nothing else.  The PLAIN step -- one neighbour, check_left decided,
+ * the appended bases in the line: all but the last step of every walk -- reads w[row] and the neighbour's w[] (its `$read$` interval),
+ * which is the line the next step starts from: one new line per read (rounds 2-4 read seven lines from seven arrays, then one of a
+ * 32-byte hop[] built beside the table; the table IS that array now). */
 #define JUMP_LOG 3
 #define JUMP_DIST (1 << JUMP_LOG)
 #define SEED_AHEAD 32           /* ids between a seed and the one whose first hop is prefetched */
-typedef struct { const fmdh_link_t *link; const uint32_t *src; uint32_t *dst; uint64_t n; int first, tid, nt; } jump_job_t;
-static void *jump_main(void *p)
+typedef struct { fmdh_slim_t *s; uint32_t *tmp; int lv; } far_job_t;
+static void far_main(void *p, int tid, int nt)
 {
-    jump_job_t *j = (jump_job_t *)p;
-    const uint64_t a = j->n * (uint64_t)j->tid / (uint64_t)j->nt, b = j->n * (uint64_t)(j->tid + 1) / (uint64_t)j->nt;
+    far_job_t *j = (far_job_t *)p;
+    fmdh_wrec_t *W = j->s->w;
+    const uint64_t n = j->s->n, a = n * (uint64_t)tid / (uint64_t)nt, b = n * (uint64_t)(tid + 1) / (uint64_t)nt;
     uint64_t i;
-    if (j->first) for (i = a; i < b; ++i) { const uint32_t x = j->link[i].nxt; j->dst[i] = x != 0xffffffffu ? j->link[x].nxt : x; }  /* two links */
-    else for (i = a; i < b; ++i) { const uint32_t x = j->src[i]; j->dst[i] = x != 0xffffffffu ? j->src[x] : x; }
-    return 0;
+    if (j->lv == 1) for (i = a; i < b; ++i) { const uint32_t x = W[i].nxt; j->tmp[i] = x != 0xffffffffu ? W[x].nxt : x; }                    /* two links */
+    else if (j->lv == 2) for (i = a; i < b; ++i) { const uint32_t x = j->tmp[i]; W[i].far = x != 0xffffffffu ? j->tmp[x] : x; }              /* four */
+    else if (j->lv == 3) for (i = a; i < b; ++i) { const uint32_t x = W[i].far; j->tmp[i] = x != 0xffffffffu ? W[x].far : x; }               /* eight */
+    else for (i = a; i < b; ++i) W[i].far = j->tmp[i];
 }
-static uint32_t *build_jump(const fmdh_link_t *link, uint64_t n)
+static int build_far(fmdh_slim_t *s)
 {
-    uint32_t *a = (uint32_t *)fmdh_big_alloc((n ? n : 1) * 4), *b = (uint32_t *)fmdh_big_alloc((n ? n : 1) * 4), *t;
-    int nt = 16, lv, k;
-    { const char *e = getenv("FMD_HOST_THREADS"); if (e && atoi(e) > 0) nt = atoi(e); }
-    if (nt > 64) nt = 64;
-    if (!a || !b) { fmdh_big_free(a); fmdh_big_free(b); return 0; }
-    for (lv = 1; lv <= JUMP_LOG; ++lv) {   /* after level lv, a[] holds the row 2^lv links on */
-        pthread_t tid[64];
-        jump_job_t job[64];
-        int started[64];
-        if (lv == 1) { for (k = 0; k < nt; ++k) { job[k] = (jump_job_t){link, 0, a, n, 1, k, nt}; } }
-        else { for (k = 0; k < nt; ++k) { job[k] = (jump_job_t){link, a, b, n, 0, k, nt}; } }
-        for (k = 1; k < nt; ++k) started[k] = pthread_create(&tid[k], 0, jump_main, &job[k]) == 0;
-        jump_main(&job[0]);
-        for (k = 1; k < nt; ++k) { if (started[k]) pthread_join(tid[k], 0); else jump_main(&job[k]); }
-        if (lv > 1) { t = a; a = b; b = t; }
-    }
-    fmdh_big_free(b);
-    return a;
+    far_job_t j = {s, (uint32_t *)fmdh_big_alloc((s->n ? s->n : 1) * 4), 0};
+    if (!j.tmp) return 0;
+    for (j.lv = 1; j.lv <= 4; ++j.lv) fmdh_par_for(fmdh_host_threads(), far_main, &j);
+    fmdh_big_free(j.tmp);
+    return 1;
 }
-/* the record of a row for a prefetch (side-table rows go to the old place: a wasted hint).  One shard -- one GPU computed the table -- is the usual case and
- * needs no division: two of them per hint, thirty hints per seed, were a third of the seed loop's time on reads with errors. */
-static inline const fmd_ovlp_rec_t *rec_addr(const fmdh_ovlp_table_t *t, uint32_t row)
+static inline void prefetch_var(const fmdh_slim_t *t, uint32_t row) { const uint8_t *p = fmdh_slim_var(t, row); __builtin_prefetch(p); __builtin_prefetch(p + 64); }
+static inline uint64_t row_rank(const fmdh_slim_t *t, uint64_t row)
 {
-    if (t->n_shards == 1) return &t->shard[0].rec[row];
-    return &t->shard[row % (uint32_t)t->n_shards].rec[row / (uint32_t)t->n_shards];
-}
-/* (a row that the overflow pass replaced lives in the side table: its prefetch goes to the old place and is wasted) */
-static inline void prefetch_row_head(const walk_t *w, uint32_t row) /* what a visit reads first */
-{
-    const fmdh_ovlp_table_t *t = w->t;
-    const int one = t->n_shards == 1;
-    const fmdh_ovlp_shard_t *s = one ? &t->shard[0] : &t->shard[row % (uint32_t)t->n_shards];
-    const uint32_t r = one ? row : row / (uint32_t)t->n_shards;
-    __builtin_prefetch(&s->rec[r]);
-    __builtin_prefetch(&s->off[r]);
-    if (t->link) __builtin_prefetch(&t->link[row]);
-    if (w->jump) __builtin_prefetch(&w->jump[row]);
-    if (t->side_of) __builtin_prefetch(&t->side_of[row]);
-    if (w->hop) __builtin_prefetch(&w->hop[row]);
-}
-
-static inline void prefetch_row_var(const walk_t *w, uint32_t row)  /* once its offset is there */
-{
-    const fmdh_ovlp_table_t *t = w->t;
-    const int one = t->n_shards == 1;
-    const fmdh_ovlp_shard_t *s = one ? &t->shard[0] : &t->shard[row % (uint32_t)t->n_shards];
-    const uint64_t r = one ? row : row / (uint32_t)t->n_shards;   /* (64 bits: a table in one chunk has a chunk_shift beyond 32) */
-    __builtin_prefetch(s->chunk[r >> s->chunk_shift] + s->off[r]);
-    __builtin_prefetch(s->chunk[r >> s->chunk_shift] + s->off[r] + 64);
-}
-
-static inline fmdh_row_t ROW(const walk_t *w, uint64_t row) { return fmdh_table_row(w->t, row); }
-
-/* A step of unidir() over the table reads the row's record, its offset, its link, its jump entry, two lines of its packed part (the appended
- * bases), the record of the neighbour's reverse strand (check_left): seven lines from seven places, and a core keeps about a dozen misses
- * in flight whatever the prefetch distance -- 61 ns per read on error-free reads (5*10^7 of them in a handful of unitigs: 3.05 s at the
- * commit of `unitig` on 5*10^7 reads).  The PLAIN step -- one neighbour, check_left decided, a few appended bases: all but the last step of
- * every walk -- needs 29 bytes of all that.  hop[row] holds them, written once by all host threads (the pass reads the table in row
- * order; only the neighbour's records are random), and the walk then touches ONE line per read.  Rows that are not plain (no / several
- * neighbours, an undecided edge, a row of the side table, more than 21 appended bases, intervals beyond 32 bits) have HOP_OK clear and
- * take the general code below, which is also what FMD_WALK_NO_HOP=1 leaves (the A/B switch, and the tests' second opinion). */
-typedef struct { const walk_t *w; hop_t *hop; uint64_t lo, hi; } hop_job_t;
-static inline const fmd_ovlp_rec_t *REC(const walk_t *w, uint64_t row);
-static void *hop_main(void *p)
-{
-    hop_job_t *j = (hop_job_t *)p;
-    const walk_t *w = j->w;
-    const fmdh_ovlp_table_t *t = w->t;
-    uint64_t i;
-    for (i = j->lo; i < j->hi; ++i) {
-        hop_t *h = &j->hop[i];
-        memset(h, 0, sizeof(*h));
-        h->nxt = t->link[i].nxt; h->far = w->jump ? w->jump[i] : 0xffffffffu;
-        if (i + 8 < j->hi && t->link[i + 8].nxt != 0xffffffffu) __builtin_prefetch(REC(w, t->link[i + 8].nxt));
-        if (i + 8 < j->hi && t->link[i + 8].rev != 0xffffffffu) __builtin_prefetch(REC(w, t->link[i + 8].rev));
-        if (t->side_of && t->side_of[i] != 0xffffffffu) continue;
-        const fmd_ovlp_rec_t *r = REC(w, i);
-        const uint32_t nxt = t->link[i].nxt, rev = t->link[i].rev;
-        if (r->status != 0 || r->rbeg < 0 || r->rbeg > 0xffff || r->n_nei != 1 || (r->flags & FMD_OVLP_F_OVERFLOW) || nxt == 0xffffffffu) continue;
-        if (r->ext_len < 0 || r->ext_len > HOP_MAX_EXT) continue;
-        const fmd_ovlp_rec_t *q = REC(w, nxt);
-        if (q->k[0] > 0xffffffffull || q->k[1] > 0xffffffffull || q->k[2] > 0xffull) continue;
-        int cl = r->reserved;                            /* check_left below, without its error exit: an undecided edge is not a plain step */
-        if (cl == 2) {
-            const int d = rev != 0xffffffffu ? fmd_lfork_decide(REC(w, rev)->lfork, r->rbeg) : 1;
-            if (d == 1) continue;
-            cl = d < 0;
-        }
-        if (cl != 0) cl = rev == 0xffffffffu ? 1 : REC(w, rev)->n_nei > 1;
-        {
-            char tmp[HOP_MAX_EXT + 3];
-            const fmdh_row_t x = ROW(w, i);
-            int k;
-            fmdh_row_bases(&x, (uint32_t)r->len, (uint32_t)r->ext_len, tmp);
-            for (k = 0; k < r->ext_len; ++k) h->bases |= (uint64_t)((unsigned char)tmp[k] & 7u) << (3 * k);
-        }
-        h->kx0 = (uint32_t)q->k[0]; h->kx1 = (uint32_t)q->k[1]; h->kx2 = (uint8_t)q->k[2];
-        h->rbeg = (uint16_t)r->rbeg; h->ext_len = (uint8_t)r->ext_len;
-        h->flags = (uint8_t)(HOP_OK | (cl ? HOP_CL : 0u));
-    }
-    return 0;
-}
-static hop_t *hop_build(const walk_t *w)
-{
-    const uint64_t n = w->t->n;
-    /* 32 bytes per row on top of a table of 140: only where that much memory is plainly there (twice over, unless the blocks are file pages) --
-     * the walk is the same without it */
-    if (!getenv("FMD_TABLE_DIR")) {
-        const long pg = sysconf(_SC_PAGESIZE), av = sysconf(_SC_AVPHYS_PAGES);
-        if (pg > 0 && av > 0 && (double)av * (double)pg < 2.0 * (double)n * sizeof(hop_t)) return 0;
-    }
-    hop_t *hop = (hop_t *)fmdh_big_alloc((n ? n : 1) * sizeof(hop_t));
-    int nt = 16, k;
-    pthread_t tid[64];
-    hop_job_t job[64];
-    int started[64];
-    { const char *e = getenv("FMD_HOST_THREADS"); if (e && atoi(e) > 0) nt = atoi(e); }
-    if (nt > 64) nt = 64;
-    if ((uint64_t)nt > n / 4096 + 1) nt = (int)(n / 4096 + 1);
-    if (!hop) return 0;
-    for (k = 0; k < nt; ++k) job[k] = (hop_job_t){w, hop, n * (uint64_t)k / (uint64_t)nt, n * (uint64_t)(k + 1) / (uint64_t)nt};
-    for (k = 1; k < nt; ++k) started[k] = pthread_create(&tid[k], 0, hop_main, &job[k]) == 0;
-    hop_main(&job[0]);
-    for (k = 1; k < nt; ++k) { if (started[k]) pthread_join(tid[k], 0); else hop_main(&job[k]); }
-    return hop;
+    const uint8_t *p = fmdh_slim_var(t, row);
+    if (t->w[row].bits & FMDH_W_BIG) { fmd_ovlp_rec_t r; memcpy(&r, p, 64); return r.rank; }
+    { uint32_t v; memcpy(&v, p, 4); return v; }
 }
 
 /* Short unitigs (reads with errors: 10^8 of them at 50 M reads) leave the skip list nothing to look ahead along; what a seed will
- * touch is known from the seeds' own links, which are read in id order.  Three stages, SEED_AHEAD ids apart, for the two first hops
- * of a seed to come (from the seed's strand and from its reverse): the hop's record, offset, links and the record of the hop's
- * reverse strand (check_left reads its lfork) -- then the hop's packed row and the heads of the SECOND hops -- then their rows. */
-static inline void seed_hint_head(const walk_t *w, uint32_t a)
-{
-    if (a == 0xffffffffu) return;
-    prefetch_row_head(w, a);
-}
+ * touch is known from the seeds' own lines, which are read in id order.  Three stages, SEED_AHEAD ids apart, for the two first hops
+ * of a seed to come (from the seed's strand and from its reverse): the hop's line -- then its variable part and the lines of the SECOND
+ * hops -- then their variable parts. */
 /* A seed that is `used` already returns at once (unitig.c:282, :289) and nothing of its rows is read: no hints for it.  On error-free reads that is
  * every seed but a handful -- the genome is one walk -- and thirty wasted line fetches per seed were most of the walk's time there (2*10^6 reads on
  * 8 cores: 1.26 s, of which 0.19 s inside walks).  The bit is read as it is NOW, without the speculative walk's logs: a hint decides nothing. */
-static inline const fmd_ovlp_rec_t *REC(const walk_t *w, uint64_t row);
 static inline int seed_is_used(const walk_t *w, uint64_t j)
 {
-    return w->sorted ? bit_get(w->used, j) : bit_get(w->used, REC(w, j)->rank);
+    return w->sorted ? bit_get(w->used, j) : bit_get(w->used, row_rank(w->t, j));
 }
 static inline void seed_hints(const walk_t *w, uint64_t i, int staged)
 {
-    const fmdh_ovlp_table_t *t = w->t;
+    const fmdh_slim_t *t = w->t;
+    const fmdh_wrec_t *W = t->w;
     int d;
-    if (!staged) {   /* (FMD_WALK_SEED_STAGES=0: the first hop's record only, as before) */
-        if (i + SEED_AHEAD < t->n) for (d = 0; d < 2; ++d) { const uint32_t a = t->link[i + SEED_AHEAD - (uint64_t)d].nxt; if (a != 0xffffffffu) __builtin_prefetch(rec_addr(t, a)); }
+    if (!staged) {   /* (FMD_WALK_SEED_STAGES=0: the first hop's line only) */
+        if (i + SEED_AHEAD < t->n) for (d = 0; d < 2; ++d) { const uint32_t a = W[i + SEED_AHEAD - (uint64_t)d].nxt; if (a != 0xffffffffu) __builtin_prefetch(&W[a]); }
         return;
     }
     if (i + 3 * SEED_AHEAD < t->n && !seed_is_used(w, i + 3 * SEED_AHEAD))
-        for (d = 0; d < 2; ++d) {
-            const fmdh_link_t *l = &t->link[i + 3 * SEED_AHEAD - (uint64_t)d];
-            seed_hint_head(w, l->nxt);
-            if (l->rev != 0xffffffffu) __builtin_prefetch(rec_addr(t, l->rev));
-        }
+        for (d = 0; d < 2; ++d) { const uint32_t a = W[i + 3 * SEED_AHEAD - (uint64_t)d].nxt; if (a != 0xffffffffu) __builtin_prefetch(&W[a]); }
     if (i + 2 * SEED_AHEAD < t->n && !seed_is_used(w, i + 2 * SEED_AHEAD))
         for (d = 0; d < 2; ++d) {
-            const uint32_t a = t->link[i + 2 * SEED_AHEAD - (uint64_t)d].nxt;
+            const uint32_t a = W[i + 2 * SEED_AHEAD - (uint64_t)d].nxt;
             if (a == 0xffffffffu) continue;
-            prefetch_row_var(w, a);
-            seed_hint_head(w, t->link[a].nxt);
-            if (t->link[a].rev != 0xffffffffu) __builtin_prefetch(rec_addr(t, t->link[a].rev));
+            prefetch_var(t, a);
+            if (W[a].nxt != 0xffffffffu) __builtin_prefetch(&W[W[a].nxt]);
         }
     if (i + SEED_AHEAD < t->n && !seed_is_used(w, i + SEED_AHEAD))
         for (d = 0; d < 2; ++d) {
-            const uint32_t a = t->link[i + SEED_AHEAD - (uint64_t)d].nxt;
-            if (a != 0xffffffffu && t->link[a].nxt != 0xffffffffu) prefetch_row_var(w, t->link[a].nxt);
+            const uint32_t a = W[i + SEED_AHEAD - (uint64_t)d].nxt;
+            if (a != 0xffffffffu && W[a].nxt != 0xffffffffu) prefetch_var(t, W[a].nxt);
         }
 }
 
@@ -478,34 +348,11 @@ static void cov_flush(cov_t *c, size_t l) /* materialise what is pending, keep [
     c->l = l; c->n_add = 0;
 }
 
-static inline const fmd_ovlp_rec_t *REC(const walk_t *w, uint64_t row)
-{
-    const fmdh_ovlp_table_t *t = w->t;
-    if (t->side_of && t->side_of[row] != 0xffffffffu) return &t->side.rec[t->side_of[row]];
-    if (t->n_shards == 1) return &t->shard[0].rec[row];
-    return &t->shard[row % (uint64_t)t->n_shards].rec[row / (uint64_t)t->n_shards];
-}
-
-/* check_left (unitig.c:206-225) for the edge row -> its unique neighbour; rev = row of the neighbour's reverse strand */
-static int check_left(walk_t *w, const fmd_ovlp_rec_t *r, uint32_t rev)
-{
-    int cl = r->reserved;
-    if (cl == 2) { /* check_left_simple was not run on this row: the rounds of the neighbour's reverse strand decide it (include/fmd_hip.h) */
-        const int d = rev != 0xffffffffu ? fmd_lfork_decide(REC(w, rev)->lfork, r->rbeg) : 1;
-        if (d == 1) { w->err = -EDOM; return -1; }        /* the table is incomplete: fmdh_ovlp_table_link leaves no such row */
-        cl = d < 0;
-    }
-    if (cl == 0) return 0;
-    /* the back fork may be due to a contained read: look right from the reverse strand of the
-     * neighbour; more than one irreducible overlap there confirms the bifurcation */
-    if (rev == 0xffffffffu) return -1;
-    return REC(w, rev)->n_nei > 1 ? -1 : 0;
-}
-
 /* unitig_unidir, unitig.c:227-262.  `cur` = table row of the read at the right end of s. */
 static int unidir(walk_t *w, uint64_t cur, str_t *s, cov_t *cov, int beg0, uint64_t k0, uint64_t *end, int *is_loop)
 {
-    const fmdh_link_t *link = w->t->link;
+    const fmdh_slim_t *t = w->t;
+    const fmdh_wrec_t *W = t->w;
     int beg = beg0, ori_l = (int)s->l, n_reads = 0;
     uint32_t ahead[JUMP_DIST];              /* ahead[i % JUMP_DIST] = the row step i + JUMP_DIST will visit, as far as known */
     uint64_t step = 0;
@@ -513,77 +360,72 @@ static int unidir(walk_t *w, uint64_t cur, str_t *s, cov_t *cov, int beg0, uint6
     for (q = 0; q < JUMP_DIST; ++q) ahead[q] = 0xffffffffu;
     *is_loop = 0;
     for (;; ++step) {
+        const fmdh_wrec_t *h = &W[cur];
         if (w->sp && w->sp->budget-- == 0) { w->err = -EAGAIN; return -1; }      /* too long to speculate on: this seed is walked at commit */
-        if (w->hop) {
-            const hop_t *h = &w->hop[cur];
-            {   /* hints: the line of the step JUMP_DIST links on; half way there, when that line has arrived, the bitmap words its step will test and set */
-                const uint32_t mid = ahead[(step + JUMP_DIST / 2) % JUMP_DIST];
-                if (h->far != 0xffffffffu) __builtin_prefetch(&w->hop[h->far]);
-                if (mid != 0xffffffffu) {
-                    const hop_t *m = &w->hop[mid];
-                    __builtin_prefetch(&w->bend[m->kx0 >> 6]);
-                    __builtin_prefetch(&w->used[m->kx0 >> 6]); __builtin_prefetch(&w->used[m->kx1 >> 6]);
-                }
-                ahead[step % JUMP_DIST] = h->far;
+        if (w->have_far) {   /* hints: the line of the step JUMP_DIST links on; half way there, when that line has arrived, the bitmap words its step will test and set */
+            const uint32_t far = h->far, mid = ahead[(step + JUMP_DIST / 2) % JUMP_DIST];
+            if (far != 0xffffffffu) __builtin_prefetch(&W[far]);
+            if (mid != 0xffffffffu) {
+                const fmdh_wrec_t *m = &W[mid];
+                __builtin_prefetch(&w->bend[m->k0 >> 6]);
+                __builtin_prefetch(&w->used[m->k0 >> 6]); __builtin_prefetch(&w->used[m->k1 >> 6]);
             }
-            if (h->flags & HOP_OK) {                                             /* the plain step, from one line (see hop_t) */
-                uint64_t kx[3] = {h->kx0, h->kx1, h->kx2}, bs = h->bases;
-                const int ext = h->ext_len, rbeg = beg + (int)h->rbeg;
-                int k;
-                w->last = cur; w->n_nei = 1;
-                if (str_reserve(s, (size_t)ori_l + (size_t)ext + 1)) return -1;
-                for (k = 0; k < ext; ++k, bs >>= 3) s->s[ori_l + k] = (char)(bs & 7u);
-                s->l = (size_t)ori_l + (size_t)ext;
-                if (kx[0] == *end) break;
-                if (st_get(w, ST_BEND, kx[0]) || (h->flags & HOP_CL)) { st_set(w, ST_BEND, kx[0]); break; }
-                if (kx[0] == k0) { *is_loop = 1; break; }
-                if (kx[1] == *end) { w->n_nei = 0; break; }
-                *end = kx[1];
-                mark_used(w, kx);
-                ++n_reads;
-                if (cov_add(cov, (size_t)rbeg, s->l)) return -1;
-                beg = rbeg; ori_l = (int)s->l;
-                cur = h->nxt;
-                continue;
-            }
-        }
-        if (w->jump) {
-            const uint32_t far = w->jump[cur], mid = ahead[(step + JUMP_DIST / 2) % JUMP_DIST];   /* mid: noted JUMP_DIST / 2 steps ago */
-            if (far != 0xffffffffu) prefetch_row_head(w, far);
-            if (mid != 0xffffffffu) prefetch_row_var(w, mid);
             ahead[step % JUMP_DIST] = far;
         }
-        const fmd_ovlp_rec_t *r = REC(w, cur);
-        uint64_t kx[3];
-        uint32_t nxt, rev;
-        int rbeg;
-        w->last = cur; w->n_nei = r->n_nei;                                      /* the list try_right leaves behind (unitig.c:181-184) */
-        if (r->status != 0 || r->rbeg < 0) { w->n_nei = r->status == 0 ? r->n_nei : 0; break; }   /* try_right < 0 */
-        rbeg = beg + r->rbeg;
-        if (r->n_nei > 1) { st_set(w, ST_BEND, *end); break; }                     /* forward bifurcation */
-        {
-            const fmdh_row_t x = ROW(w, cur);
-            if (link) { nxt = link[cur].nxt; rev = link[cur].rev; }
-            else { nxt = x.nei[0].x[0] < w->n_seq ? w->row_of[x.nei[0].x[0]] : 0xffffffffu; rev = x.nei[0].x[1] < w->n_seq ? w->row_of[x.nei[0].x[1]] : 0xffffffffu; }
-            /* the `$neighbour$` interval: the neighbour's own row has it (its record is the next one the walk reads anyway) */
-            if (nxt != 0xffffffffu) { const fmd_ovlp_rec_t *q = REC(w, nxt); kx[0] = q->k[0]; kx[1] = q->k[1]; kx[2] = q->k[2]; }
-            else { kx[0] = x.nei[0].x[0]; kx[1] = x.nei[0].x[1]; kx[2] = x.nei[0].x[2]; }
-            /* the bases fm6_get_nei appended (unitig.c:139) */
-            if (str_reserve(s, (size_t)ori_l + r->ext_len + 1)) return -1;
-            fmdh_row_bases(&x, (uint32_t)r->len, (uint32_t)r->ext_len, s->s + ori_l);
-            s->l = (size_t)ori_l + r->ext_len;
+        if ((h->bits & FMDH_W_PLAIN) && !w->no_plain) {                          /* the plain step, from one line (fmdh_wrec_t) and the neighbour's */
+            const fmdh_wrec_t *nb = &W[h->nxt];
+            const uint64_t kx[3] = {nb->k0, nb->k1, nb->k2};
+            const int ext = h->ext_len, rbeg = beg + (int)h->rbeg;
+            int k;
+            w->last = cur; w->n_nei = 1;
+            if (str_reserve(s, (size_t)ori_l + (size_t)ext + 1)) return -1;
+            for (k = 0; k < ext; ++k) s->s[ori_l + k] = (char)(((h->ext[k >> 2] >> (2 * (k & 3))) & 3) + 1);
+            s->l = (size_t)ori_l + (size_t)ext;
+            if (kx[0] == *end) break;
+            if (st_get(w, ST_BEND, kx[0]) || (h->bits & FMDH_W_CL)) { st_set(w, ST_BEND, kx[0]); break; }
+            if (kx[0] == k0) { *is_loop = 1; break; }
+            if (kx[1] == *end) { w->n_nei = 0; break; }
+            *end = kx[1];
+            mark_used(w, kx);
+            ++n_reads;
+            if (cov_add(cov, (size_t)rbeg, s->l)) return -1;
+            beg = rbeg; ori_l = (int)s->l;
+            cur = h->nxt;
+            continue;
         }
-        if (kx[0] == *end) break;                                                /* b>>c>>a><a */
-        if (st_get(w, ST_BEND, kx[0]) || check_left(w, r, rev) < 0) { if (w->err) return -1; st_set(w, ST_BEND, kx[0]); break; } /* backward bifurcation */
-        if (kx[0] == k0) { *is_loop = 1; break; }                                /* a>>b>>c>>a */
-        if (kx[1] == *end) { w->n_nei = 0; break; }                              /* b>>c>>a>>a: cut the last link */
-        *end = kx[1];
-        mark_used(w, kx);
-        ++n_reads;
-        if (cov_add(cov, (size_t)rbeg, s->l)) return -1;                          /* ++ over [rbeg, ori_l), '"' for the new bases */
-        beg = rbeg; ori_l = (int)s->l;
-        if (nxt == 0xffffffffu) break; /* cannot happen: a neighbour is a non-contained read */
-        cur = nxt;
+        {
+            fmdh_rowv_t r;
+            uint64_t kx[3];
+            const uint32_t nxt = h->nxt;
+            int rbeg;
+            fmdh_slim_row(t, cur, &r);
+            w->last = cur; w->n_nei = r.n_nei;                                       /* the list try_right leaves behind (unitig.c:181-184) */
+            if (r.status != 0 || r.rbeg < 0) { w->n_nei = r.status == 0 ? r.n_nei : 0; break; }   /* try_right < 0 */
+            rbeg = beg + r.rbeg;
+            if (r.n_nei > 1) { st_set(w, ST_BEND, *end); break; }                     /* forward bifurcation */
+            /* the `$neighbour$` interval: the neighbour's own row has it (the next one the walk reads anyway).  A row with one neighbour and no
+             * link to it is a row of an incomplete table (the neighbour is a non-contained read longer than min_match: it has a row) */
+            if (r.n_nei != 1 || nxt == 0xffffffffu) { w->err = -EDOM; return -1; }
+            if (W[nxt].bits & FMDH_W_BIG) { fmdh_rowv_t nb; fmdh_slim_row(t, nxt, &nb); kx[0] = nb.k[0]; kx[1] = nb.k[1]; kx[2] = nb.k[2]; }
+            else { kx[0] = W[nxt].k0; kx[1] = W[nxt].k1; kx[2] = W[nxt].k2; }
+            /* the bases fm6_get_nei appended (unitig.c:139) */
+            if (str_reserve(s, (size_t)ori_l + (size_t)r.ext_len + 1)) return -1;
+            fmdh_slim_ext(t, cur, &r, s->s + ori_l);
+            s->l = (size_t)ori_l + (size_t)r.ext_len;
+            if (kx[0] == *end) break;                                                /* b>>c>>a><a */
+            if (!st_get(w, ST_BEND, kx[0])) {                                        /* check_left (unitig.c:206-225), decided when the table was linked */
+                if (h->bits & FMDH_W_UNDEC) { w->err = -EDOM; return -1; }           /* the table is incomplete: the link passes leave no such row */
+                if (h->bits & FMDH_W_CL) { st_set(w, ST_BEND, kx[0]); break; }       /* backward bifurcation */
+            } else { st_set(w, ST_BEND, kx[0]); break; }
+            if (kx[0] == k0) { *is_loop = 1; break; }                                /* a>>b>>c>>a */
+            if (kx[1] == *end) { w->n_nei = 0; break; }                              /* b>>c>>a>>a: cut the last link */
+            *end = kx[1];
+            mark_used(w, kx);
+            ++n_reads;
+            if (cov_add(cov, (size_t)rbeg, s->l)) return -1;                          /* ++ over [rbeg, ori_l), '"' for the new bases */
+            beg = rbeg; ori_l = (int)s->l;
+            cur = nxt;
+        }
     }
     s->l = (size_t)ori_l;
     cov_flush(cov, (size_t)ori_l);
@@ -705,56 +547,76 @@ static int seedbuf_init(seedbuf_t *b, uint32_t cap_nei)
 }
 static void seedbuf_free(seedbuf_t *b) { free(b->nei[0]); free(b->nei[1]); free(b->s.s); free(b->o.s); free(b->cov.s); free(b->cov.d); }
 
+/* the sequence of row i: its own copy, or the reverse complement of the other strand's (the table keeps the bases of a read once) */
+static int seed_seq(const walk_t *w, uint64_t i, const fmdh_rowv_t *r, char *dst)
+{
+    fmdh_rowv_t p;
+    if (fmdh_slim_own_seq(r, dst)) return 0;
+    if ((i ^ 1) >= w->t->n) return -EDOM;
+    fmdh_slim_row(w->t, i ^ 1, &p);
+    if (p.len != r->len || !fmdh_slim_own_seq(&p, dst)) return -EDOM;
+    revcomp6((size_t)r->len, dst);
+    return 0;
+}
+/* the neighbours of row `last` as the MAG record lists them: x[0] of `$neighbour$` and the overlap length */
+static int end_list(const walk_t *w, int n, link_t *dst, uint32_t cap)
+{
+    fmdh_rowv_t lr;
+    int k;
+    if (n <= 0) return 0;
+    if ((uint32_t)n > cap) return -ERANGE;          /* more neighbours than any row of this table holds */
+    fmdh_slim_row(w->t, w->last, &lr);
+    if (n > lr.n_stored) return -ERANGE;
+    for (k = 0; k < n; ++k) { uint64_t x1; fmdh_slim_nei(w->t, w->last, &lr, k, &dst[k].x, &x1, &dst[k].y); }
+    return 0;
+}
+
 static int walk_seed(walk_t *w, uint64_t i, seedbuf_t *b, size_t *wl)
 {
-    const fmdh_ovlp_table_t *t = w->t;
     const uint64_t *sorted = w->sorted;
     const int min_match = w->min_match;
     str_t *s = &b->s, *o = &b->o;
     cov_t *cov = &b->cov;
     link_t **nei = b->nei;
-    const fmd_ovlp_rec_t *r = REC(w, i);
+    fmdh_rowv_t r;
     uint64_t end[2];
-    int n_nei[2] = {0, 0}, n_reads, is_loop = 0, seed_len, k, done_loop = 0;
-    if (r->flags & FMD_OVLP_F_OVERFLOW) return -ERANGE;
+    int n_nei[2] = {0, 0}, n_reads, is_loop = 0, seed_len, done_loop = 0, e;
+    fmdh_slim_row(w->t, i, &r);
+    if (r.status == FMDH_W_ST_INVALID) return -ERANGE;
     if (sorted && st_get(w, ST_USED, i)) return 0;              /* used (unitig.c:282: by sequence id with -r) */
-    if (r->len <= min_match) return 0;                          /* too short */
-    if (!sorted && st_get(w, ST_USED, r->rank)) return 0;       /* used (unitig.c:289: by rank) */
-    mark_used(w, r->k);
-    if (r->status != 0) return 0;                               /* contained */
-    seed_len = r->len;
+    if (r.len <= min_match) return 0;                           /* too short */
+    if (!sorted && st_get(w, ST_USED, r.rank)) return 0;        /* used (unitig.c:289: by rank) */
+    mark_used(w, r.k);
+    if (r.status != 0) return 0;                                /* contained */
+    seed_len = r.len;
     if (str_reserve(s, (size_t)seed_len + 1)) return -ENOMEM;
-    { const fmdh_row_t seed = fmdh_table_row(t, i); fmdh_row_bases(&seed, 0, (uint32_t)seed_len, s->s); }
+    if ((e = seed_seq(w, i, &r, s->s)) != 0) return e;
     s->l = (size_t)seed_len;
     cov_flush(cov, 0);
     if (cov_add(cov, 0, (size_t)seed_len)) return -ENOMEM;
     n_reads = 1;
-    end[0] = r->k[1]; end[1] = r->k[0];
+    end[0] = r.k[1]; end[1] = r.k[0];
     const int tm = w->timing;
     double p0 = tm ? wall_s() : 0, p1;
-    if (r->n_ovlp) { /* left-wards extension of the unitig = right-wards of this strand */
-        int m = unidir(w, i, s, cov, 0, r->k[0], &end[0], &is_loop);
+    if (r.has_ovlp) { /* left-wards extension of the unitig = right-wards of this strand */
+        int m = unidir(w, i, s, cov, 0, r.k[0], &end[0], &is_loop);
         if (tm) { p1 = wall_s(); w->t_uni += p1 - p0; p0 = p1; w->n_hops += m > 0 ? (uint64_t)m : 0; }
         if (m < 0) return w->err ? w->err : -ENOMEM;
         n_reads += m;
-        if ((uint32_t)w->n_nei > b->cap_nei) return -ERANGE;   /* more neighbours than any row of this table holds: the row should have been flagged and computed again */
-        { const fmd_intv_t *ln = fmdh_table_row(t, w->last).nei;
-          for (k = 0; k < w->n_nei; ++k) { nei[0][k].x = ln[k].x[0]; nei[0][k].y = ln[k].info; }
-          n_nei[0] = w->n_nei;
-          if (is_loop) { nei[1][0].x = end[0]; nei[1][0].y = ln[0].info; n_nei[1] = 1; done_loop = 1; } }
+        if ((e = end_list(w, w->n_nei, nei[0], b->cap_nei)) != 0) return e;
+        n_nei[0] = w->n_nei;
+        if (is_loop) { nei[1][0].x = end[0]; nei[1][0].y = nei[0][0].y; n_nei[1] = 1; done_loop = 1; }
     }
     if (!done_loop) { /* the other direction, from the reverse strand of the seed (unitig.c:310-315) */
         int m;
         cov_flush(cov, s->l);
         revcomp6(s->l, s->s); reverse(s->l, cov->s);
         if (tm) { p1 = wall_s(); w->t_turn += p1 - p0; p0 = p1; }
-        m = unidir(w, i ^ 1, s, cov, (int)s->l - seed_len, r->k[1], &end[1], &is_loop);
+        m = unidir(w, i ^ 1, s, cov, (int)s->l - seed_len, r.k[1], &end[1], &is_loop);
         if (tm) { p1 = wall_s(); w->t_uni += p1 - p0; p0 = p1; w->n_hops += m > 0 ? (uint64_t)m : 0; }
         if (m < 0) return w->err ? w->err : -ENOMEM;
         n_reads += m;
-        if ((uint32_t)w->n_nei > b->cap_nei) return -ERANGE;
-        { const fmd_intv_t *ln = fmdh_table_row(t, w->last).nei;
-          for (k = 0; k < w->n_nei; ++k) { nei[1][k].x = ln[k].x[0]; nei[1][k].y = ln[k].info; } }
+        if ((e = end_list(w, w->n_nei, nei[1], b->cap_nei)) != 0) return e;
         n_nei[1] = w->n_nei;
     }
     /* ---- unitig_core: keep each unitig once (unitig.c:336-339) */
@@ -1060,64 +922,65 @@ int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, 
 {
     return fmdh_unitig_walk_opt(t, n_seq, min_match, sorted, out, 0);
 }
+/* over a table of packed rows (the tests' tables; a caller that holds fmd_ovlp_packed_batch's output): made slim first, then the one walk there is */
 int fmdh_unitig_walk_opt(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, const uint64_t *sorted, FILE *out, int flags)
+{
+    fmdh_slim_t *s = 0;
+    int rc;
+    if (!t) return -EINVAL;
+    if (n_seq >= 0xffffffffull || t->n >= 0xffffffffull) return -ERANGE;   /* rows are 32-bit ids */
+    if ((rc = fmdh_slim_from_table(t, fmdh_host_threads(), &s)) != 0) return rc;
+    rc = fmdh_unitig_walk_slim(s, n_seq, min_match, sorted, out, flags);
+    fmdh_slim_free(s);
+    return rc;
+}
+int fmdh_unitig_walk_slim(fmdh_slim_t *t, uint64_t n_seq, int min_match, const uint64_t *sorted, FILE *out, int flags)
 {
     walk_t w;
     seedbuf_t b;
     uint64_t i, nw = (n_seq + 63) / 64;
     int rc = 0, b_ok = 0;
     double t_begin = wall_s();
+    outq_t oq;
+    int oq_open = 0;
+    uint32_t cap_nei;
+    if (!t) return -EINVAL;
+    cap_nei = t->max_nei > 1 ? t->max_nei : 1;
     memset(&w, 0, sizeof(w));
     w.t = t; w.n_seq = n_seq; w.min_match = min_match; w.sorted = sorted; w.full_records = (flags & FMDH_WALK_FULL_RECORDS) != 0;
     w.used = (uint64_t *)calloc(nw + 1, 8); w.bend = (uint64_t *)calloc(nw + 1, 8); w.visited = (uint64_t *)calloc(nw + 1, 8);
-    w.row_of = t->row_of ? t->row_of : (uint32_t *)fmdh_big_alloc((n_seq ? n_seq : 1) * 4);
-    uint32_t cap_nei = t->side_of ? t->side.max_nei : 1;
-    outq_t oq;
-    int oq_open = 0, g;
-    for (g = 0; g < t->n_shards; ++g) if (t->shard[g].max_nei > cap_nei) cap_nei = t->shard[g].max_nei;
-    if (!w.used || !w.bend || !w.visited || !w.row_of) { rc = -ENOMEM; goto done; }
-    if (n_seq >= 0xffffffffull || t->n >= 0xffffffffull) { rc = -ERANGE; goto done; }   /* row_of holds 32-bit ids */
-    if (!t->row_of) { /* not linked (fmdh_ovlp_table_link): build the row map here */
-        memset(w.row_of, 0xff, n_seq * 4);
-        for (i = t->n; i-- > 0;) { /* smallest id wins */
-            const fmd_ovlp_rec_t *r = REC(&w, i);
-            if (r->status == 0 && !(r->flags & FMD_OVLP_F_OVERFLOW) && r->k[0] < n_seq) w.row_of[r->k[0]] = (uint32_t)i;
-        }
-    }
-    const int hints = t->link && !getenv("FMD_WALK_NO_JUMP");
-    t_begin = wall_s();
+    if (!w.used || !w.bend || !w.visited) { rc = -ENOMEM; goto done; }
+    if (n_seq >= 0xffffffffull || t->n >= 0xffffffffull || n_seq > t->n) { rc = -ERANGE; goto done; }
+    const int hints = !getenv("FMD_WALK_NO_JUMP");
     w.seed_hints = hints;
+    w.no_plain = getenv("FMD_WALK_NO_HOP") != NULL;
     w.timing = getenv("FMD_TIMING") != NULL;
-    /* The skip list and hop[] serve LONG walks (error-free or corrected reads: unitigs of 10^3 .. 10^7 reads, walked by one thread); on raw reads a
-     * walk is one to three steps from its seed, the seeds' own hints cover those, and 0.15 + 0.43 s of building the two per 10^8 rows buy nothing
-     * (measured: walk 4.4-5.2 s with, 4.1-4.7 s without, box noise larger than the difference).  Which it is shows in the links: the plain steps in a row
-     * from 2048 evenly spaced rows, 64 at most each.  FMD_WALK_LONG=0 / 1 overrides the verdict (tests: both ways on the same fixture). */
+    /* The skip list serves LONG walks (error-free or corrected reads: unitigs of 10^3 .. 10^7 reads, walked by one thread); on raw reads a
+     * walk is one to three steps from its seed, the seeds' own hints cover those, and building it buys nothing.  Which it is shows in the
+     * links: the steps in a row from 2048 evenly spaced rows, 64 at most each.  FMD_WALK_LONG=0 / 1 overrides the verdict (tests: both ways
+     * on the same fixture). */
     int long_walks = 0;
-    if (t->link && t->n) {
+    if (t->n) {
         const uint64_t ns = t->n < 2048 ? t->n : 2048;
         uint64_t k, tot = 0;
         for (k = 0; k < ns; ++k) {
             uint64_t cur = (uint64_t)((unsigned __int128)t->n * k / ns);
             int len = 0;
             while (len < 64) {
-                const fmd_ovlp_rec_t *r = REC(&w, cur);
-                if (r->status != 0 || r->rbeg < 0 || r->n_nei != 1 || t->link[cur].nxt == 0xffffffffu) break;
-                cur = t->link[cur].nxt; ++len;
+                const fmdh_wrec_t *h = &t->w[cur];
+                if ((h->bits & FMDH_W_ST_MASK) != 0 || h->rbeg == 0xffff || h->n_nei != 1 || h->nxt == 0xffffffffu) break;
+                cur = h->nxt; ++len;
             }
             tot += (uint64_t)len;
         }
         long_walks = tot >= 16 * ns;
         { const char *e = getenv("FMD_WALK_LONG"); if (e) long_walks = atoi(e) != 0; }
-        if (getenv("FMD_TIMING")) fprintf(stderr, "[M::%s] %.1f plain steps in a row from a sampled row (of 64 at most): %s\n", __func__, (double)tot / (double)ns,
-                                          long_walks ? "long walks, skip list + one line per step" : "short walks, the seeds' hints only");
+        if (w.timing) fprintf(stderr, "[M::%s] %.1f steps in a row from a sampled row (of 64 at most): %s\n", __func__, (double)tot / (double)ns,
+                              long_walks ? "long walks, skip list" : "short walks, the seeds' hints only");
     }
-    if (hints && long_walks) w.jump = build_jump(t->link, t->n);   /* 0: the plain chase */
-    if (getenv("FMD_TIMING") && w.jump) fprintf(stderr, "[M::%s] skip list over the links: %.3f s\n", __func__, wall_s() - t_begin);
-    if (t->link && long_walks && !getenv("FMD_WALK_NO_HOP")) {
-        const double t0 = wall_s();
-        w.hop = hop_build(&w);                         /* 0: every step through the general code */
-        if (getenv("FMD_TIMING")) fprintf(stderr, "[M::%s] one line per plain step (hop[], %.1f GB): %.3f s\n", __func__, (double)t->n * sizeof(hop_t) / 1e9, wall_s() - t0);
-    }
+    t_begin = wall_s();
+    if (hints && long_walks) w.have_far = build_far(t);   /* 0: the plain chase */
+    if (w.timing && w.have_far) fprintf(stderr, "[M::%s] skip list over the links: %.3f s\n", __func__, wall_s() - t_begin);
     const int seed_stages = !(getenv("FMD_WALK_SEED_STAGES") && atoi(getenv("FMD_WALK_SEED_STAGES")) == 0);
     {
         const int nt = walk_threads();
@@ -1138,11 +1001,10 @@ int fmdh_unitig_walk_opt(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_mat
     }
 done:
     if (oq_open) { const int e = outq_close(&oq); if (!rc) rc = e; }
-    if (getenv("FMD_TIMING") && w.n_hops + (uint64_t)(w.t_uni > 0)) fprintf(stderr, "[M::%s] walks of the sequential loop: %llu reads appended in %.3f s, turning the strings round %.3f s, record text %.3f s\n", __func__,
-                                                                              (unsigned long long)w.n_hops, w.t_uni, w.t_turn, w.t_text);
-    if (getenv("FMD_TIMING")) fprintf(stderr, "[M::%s] walk of %llu sequences: %.3f s\n", __func__, (unsigned long long)n_seq, wall_s() - t_begin);
-    free(w.used); free(w.bend); free(w.visited); if (w.row_of != t->row_of) fmdh_big_free(w.row_of);
-    fmdh_big_free(w.jump); fmdh_big_free((void *)w.hop);
+    if (w.timing && w.n_hops + (uint64_t)(w.t_uni > 0)) fprintf(stderr, "[M::%s] walks of the sequential loop: %llu reads appended in %.3f s, turning the strings round %.3f s, record text %.3f s\n", __func__,
+                                                                (unsigned long long)w.n_hops, w.t_uni, w.t_turn, w.t_text);
+    if (w.timing) fprintf(stderr, "[M::%s] walk of %llu sequences: %.3f s\n", __func__, (unsigned long long)n_seq, wall_s() - t_begin);
+    free(w.used); free(w.bend); free(w.visited);
     if (b_ok) seedbuf_free(&b);
     return rc;
 }

@@ -30,6 +30,7 @@ def lib():
         L.Shard = Shard
         L.Table = Table
         L.fmdh_unitig_walk.argtypes = [C.POINTER(Table), C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+        L.fmdh_slim_stats.argtypes = [C.POINTER(Table), C.POINTER(C.c_uint64)]
         L.fmdh_unitig.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_void_p]
         class EcOpt(C.Structure):
             _fields_ = [("w", C.c_int), ("min_occ", C.c_int), ("keep_bad", C.c_int), ("is_paired", C.c_int), ("trim_l", C.c_int),
@@ -101,7 +102,7 @@ _libc.free.argtypes = [C.c_void_p]
 _libc.free.restype = None
 
 
-def unitig_walk(shards, n_seq, min_match, out_path, sorted_map=None, max_nei=4, seq_stride=256, link=0, resolve=None):
+def unitig_walk(shards, n_seq, min_match, out_path, sorted_map=None, max_nei=4, seq_stride=256, link=0, resolve=None, stats=None):
     """Replay the `fermi unitig -t1` walk over a packed per-id overlap table kept in len(shards) shards -- id i = row
     i // N of shard i % N; each shard = (prec[OVLP_DT], off[u64, n+1], var[u8]) as fmd_ovlp_pack_dev writes them.
     Writes MAG records to out_path."""
@@ -128,6 +129,10 @@ def unitig_walk(shards, n_seq, min_match, out_path, sorted_map=None, max_nei=4, 
             n_sh = len(shards)
             for i, v in zip(undecided, vals):
                 keep[4 * int(i % n_sh)]["reserved"][int(i // n_sh)] = v
+    if stats is not None:   # what the walk's own table (host/slim_table.c) makes of these rows
+        st = (C.c_uint64 * 6)()
+        _chk(L.fmdh_slim_stats(C.byref(t), st), "slim_stats")
+        stats.update(bytes=st[0], big=st[1], ext_in_var=st[2], plain=st[3], own_seq=st[4], undecided=st[5])
     fp = _libc.fopen(out_path.encode(), b"wb")
     try:
         sm = None if sorted_map is None else np.ascontiguousarray(sorted_map, dtype=np.uint64)

@@ -286,6 +286,27 @@ void fmd_table_free(void *p);
  * open come back in *undecided (malloc'ed: fmd_host_free; ascending) for a fmd_ovlp_packed_batch(ids, with_check_left = 1). */
 int fmd_ovlp_packed_table(fmd_dev_t *h, size_t n, int min_match, uint32_t max_len, uint32_t max_nei, fmd_ovlp_rec_t *rec, uint64_t *off,
                           uint32_t chunk_shift, uint8_t **chunks, uint32_t *row_of, fmd_ovlp_link_t *link, uint64_t **undecided, uint64_t *n_undecided);
+/* Streamed forms of the two entries above: the packed chunks (2^chunk_shift rows each, in the order of the ids) are handed to fn from
+ * pinned staging buffers -- first_row = the chunk's first row of the call, rec[n_rows], off[n_rows] (offsets into var), var_bytes of var --
+ * and are the library's again when fn returns (non-zero: the call stops and returns it).  fn runs on the calling thread while the next
+ * chunk is computed and the one after crosses PCIe.  Nothing of the table stays in host memory unless fn keeps it: `unitig` keeps
+ * ~58 bytes per row (host/slim_table.c) where the reference keeps three bitmaps (unitig.c:390-392) and recomputes. */
+typedef int (*fmd_ovlp_rows_fn)(void *ctx, uint64_t first_row, size_t n_rows, const fmd_ovlp_rec_t *rec, const uint64_t *off, const uint8_t *var, uint64_t var_bytes);
+int fmd_ovlp_packed_stream(fmd_dev_t *h, const uint64_t *ids, uint64_t first, uint64_t step, size_t n, int min_match, uint32_t max_len,
+                           uint32_t max_nei, int with_check_left, uint32_t chunk_shift, fmd_ovlp_rows_fn fn, void *ctx);
+/* fmd_ovlp_packed_table as a job in three steps, so that the link pass sees the rows as they are in the END:
+ *   rows   ids 0 .. n-1 streamed to fn; the job keeps the fixed-stride records and the first neighbour's coordinates on the device
+ *   patch  rows the caller has computed again since (flagged FMD_OVLP_F_OVERFLOW by the first step): rec[m], nei01[2 m] = x[0], x[1] of each
+ *          row's first neighbour, replace the job's copies at ids[m]
+ *   link   fmd_ovlp_link_dev over the job's records; link[n_rows] and reserved[n_rows] (0 / 1 / 2 as rec.reserved) go to fn in pieces of
+ *          2^22 rows; *undecided as fmd_ovlp_packed_table returns it */
+typedef struct fmd_ovlp_tabjob fmd_ovlp_tabjob_t;
+typedef int (*fmd_ovlp_links_fn)(void *ctx, uint64_t first_row, size_t n_rows, const fmd_ovlp_link_t *link, const uint8_t *reserved);
+int fmd_ovlp_tabjob_rows(fmd_dev_t *h, size_t n, int min_match, uint32_t max_len, uint32_t max_nei, uint32_t chunk_shift,
+                         fmd_ovlp_rows_fn fn, void *ctx, fmd_ovlp_tabjob_t **job);
+int fmd_ovlp_tabjob_patch(fmd_ovlp_tabjob_t *job, size_t m, const uint64_t *ids, const fmd_ovlp_rec_t *rec, const uint64_t *nei01);
+int fmd_ovlp_tabjob_link(fmd_ovlp_tabjob_t *job, fmd_ovlp_links_fn fn, void *ctx, uint64_t **undecided, uint64_t *n_undecided);
+void fmd_ovlp_tabjob_free(fmd_ovlp_tabjob_t *job);
 /* layout of a packed row's variable part, from its (packed) record */
 static inline uint32_t fmd_ovlp_row_nei(const fmd_ovlp_rec_t *r, uint32_t max_nei)
 {

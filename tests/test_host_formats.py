@@ -349,3 +349,37 @@ def test_walks_that_close_on_themselves(oracle_lib, gold, tmp_path, monkeypatch,
     hostlib.unitig_walk(_packed_shards(rec, nei, seq, 2), n_seq, 40, out, max_nei=8, seq_stride=seq.shape[1], link=3)
     got = open(out, "rb").read()
     assert got == gold.text_gz("circle.mag.gz") and got.count(b"\n@") + 1 == 3
+
+
+@pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20), ("special", 20), ("circle", 40)])
+@pytest.mark.parametrize("link", [0, 3])
+def test_slim_table_keeps_what_the_walk_reads(oracle_lib, gold, tmp_path, monkeypatch, name, mm, link):
+    """The walk runs over its own table (host/slim_table.c): 32 bytes per row + a short variable part instead of the packed rows (64-byte record, 32-byte
+    neighbours, both strands' bases).  Same MAG as the reference from both of its neighbour forms (link = 0: host threads link the slim rows, 10-byte
+    entries; link = 3: the links come with the table, one neighbour = its overlap alone), with the bases of a read kept once (odd rows take the reverse
+    complement of the even row's), and with records kept whole (W_BIG) where a field outgrows the line -- forced here by a narrow k[2] (FMD_SLIM_BIG_K2=1:
+    every interval of two or more identical reads)."""
+    o = orcbind.OrcIndex(gold.path(name + ".fmd"))
+    n_seq = int(o.mcnt[1])
+    rec, nei, seq = o.overlap_batch(np.arange(n_seq, dtype=np.uint64), mm, max_len=100, max_nei=8, n_threads=4)
+    want = gold.text_gz(name + ".mag.gz")
+    fat_bytes = None
+    for big in (False, True):
+        if big:
+            monkeypatch.setenv("FMD_SLIM_BIG_K2", "1")
+        st = {}
+        out = str(tmp_path / ("o%d.mag" % big))
+        shards = _packed_shards(rec.copy(), nei, seq, 2)
+        hostlib.unitig_walk(shards, n_seq, mm, out, max_nei=8, seq_stride=seq.shape[1], link=link, stats=st)
+        assert open(out, "rb").read() == want
+        ok = int(((rec["status"] == 0) & ((rec["flags"] & 2) == 0)).sum())
+        if not big:
+            fat_bytes = sum(p.nbytes + 8 * len(p) + len(v) for p, _, v in shards) + 12 * n_seq      # records, offsets, packed parts, row map + links
+            assert st["big"] == 0 and st["undecided"] == 0
+            assert st["own_seq"] == int(((rec["status"] == 0) & ((rec["flags"] & 2) == 0))[0::2].sum())       # the even rows only
+            assert st["plain"] > 0 and st["bytes"] < 0.5 * fat_bytes, (st, fat_bytes)
+        else:
+            dup = int(((rec["k"][:, 2] > 1) & (rec["status"] != -1) & ((rec["flags"] & 2) == 0)).sum())
+            assert st["big"] == dup and (dup > 0 or name not in ("tiny", "repeat")), (st, dup)
+        assert st["own_seq"] <= ok
+    o.close()

@@ -17,7 +17,8 @@ device layout; the only form that carries 1.4*10^11 symbols) --, then
     discovery of the random ids runs through BOTH host forms (fmd_ovlp_batch in id order, the sorted job) with room for 16 neighbours, and check_left of a
     sub-sample is compared with the oracle; `props` (which assume error-free reads) is ignored.
   * `dry`: the allocations of one rank of the `share`-rank step (fmd_ovlp_dist_new with a stand-in communicator, FMD_DIST_DRY=1), as the root and as a peer.
-Usage: python tools/scale_check.py [n_reads=250000000] [bwt|inplace] [sample=20000] [share=8] [noref] [kmer] [props] [raw] [dry]"""
+  * `unitig`: `fermi-amd unitig -l50` on the .fmd as its own process: time, peak resident set, md5 of the MAG (and the same by build/old/fermi-amd-old where present).
+Usage: python tools/scale_check.py [n_reads=250000000] [bwt|inplace] [sample=20000] [share=8] [noref] [kmer] [props] [raw] [dry] [unitig]"""
 import ctypes as C, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -233,7 +234,8 @@ if not noref:
         base, ok = bench.cpu_kmer(fmd_path, w, 3, suf_len, nb, trip)
         print("k-mer harvest vs %s on suffix buckets 0..%d (%d triples): %s" % (base["kind"], nb - 1, len(trip), "bit-exact" if ok else "MISMATCH"), flush=True)
         assert ok
-    os.remove(fmd_path)
+    if "unitig" not in sys.argv[5:]:
+        os.remove(fmd_path)
 # ---- one GPU's share of the sharded overlap discovery on this index (BASELINE configs[3] / [4]: ids i = 0 (mod share))
 job = bench.OverlapJob(torch, api, index, dev, 2 * n_reads, 0, share, L, 50)
 job.compute()                       # warm-up
@@ -268,4 +270,37 @@ if "dry" in sys.argv[5:]:   # one rank's allocations of the `share`-rank step on
             dj.free()
             torch.cuda.empty_cache()
 index.close()
+if "unitig" in sys.argv[5:] and not noref:
+    # `fermi-amd unitig -l50` on the .fmd written above, as its own process: wall time, phase times, the peak resident set (FMD_TIMING) and the md5 of the MAG.
+    # build/old/fermi-amd-old, where a builder put one (the CLI of an earlier tree linked against this libfmdhip.so), runs beside it: same MAG, its memory.
+    import hashlib, subprocess
+    try:
+        del job
+    except NameError:
+        pass
+    torch.cuda.empty_cache()
+    print("HBM in use by this process before the CLI starts: %.1f GB" % hbm_used(), flush=True)
+    seen = None
+    for name, exe in (("fermi-amd", os.path.join(ROOT, "fermi_amd", "bin", "fermi-amd")), ("the earlier CLI (build/old)", os.path.join(ROOT, "build", "old", "fermi-amd-old"))):
+        if not os.path.exists(exe):
+            continue
+        t0 = time.time()
+        h, nb = hashlib.md5(), 0
+        pr = subprocess.Popen([exe, "unitig", "-l50", fmd_path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, FMD_TIMING="1"))
+        import threading
+        errbuf = []
+        th = threading.Thread(target=lambda: errbuf.append(pr.stderr.read())); th.start()
+        for blk in iter(lambda: pr.stdout.read(1 << 24), b""):
+            h.update(blk); nb += len(blk)
+        rc = pr.wait(); th.join()
+        lines = [l for l in errbuf[0].decode().splitlines() if "M::" in l and "fmd_ovlp]" not in l]
+        rss = [l for l in lines if "peak resident set" in l]
+        print("unitig -l50 by %s: rc %d, %.1f s, MAG %d bytes md5 %s; %s" % (name, rc, time.time() - t0, nb, h.hexdigest(), rss[-1].split(": ", 1)[1] if rss else "no resident-set line"), flush=True)
+        print("\n".join("    " + l for l in lines if "slim_build_core" in l or "table_build_core" in l or "fmdh_unitig" in l or "packed_batch_core" in l), flush=True)
+        if rc != 0:
+            print(errbuf[0].decode()[-3000:], flush=True)
+        assert rc == 0
+        assert seen is None or seen == h.hexdigest(), "the two CLIs print different MAGs"
+        seen = h.hexdigest()
+    os.remove(fmd_path)
 print("scale check passed: %d reads, %d symbols, %s builder" % (n_reads, n_sym, mode))
