@@ -112,6 +112,7 @@ __device__ __host__ __forceinline__ constexpr int fmd_grp_size(int k) { return k
 #define FMD_FAST_CHUNK 16
 #define FMD_FAST_MAX_WAVES 8192
 #define FMD_LIST_HOLE 0xffffffffu
+#define FMD_DOWN_WORD 4                    // word of a fast list's counter line that counts the SECOND-PASS list of that class (strands k_ovl_nei_grp moved to a smaller group); its deal counter: + FMD_DEAL_WORD
 // A strand k_ovl_nei_fast hands on in the middle (a fork, an N: rounds only k_ovl_nei_grp does) travels with its state: bit 15 of the
 // list entry's second word, the number of live candidates in the bits below, and in the strand's row of listB (scratch of
 // k_ovl_nei, which these strands never reach without being started over from listA) one 32-byte entry per live candidate, in list

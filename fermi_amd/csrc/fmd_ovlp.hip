@@ -12,7 +12,7 @@
 // (gidx: slot of a sorted batch -> row of rec / nei_out / seq_out, fmd_ovlp_sorted_dev; nullptr = the slot is the row)
 void fmd_launch_nei_grp(int cls, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                         const fmd_intv_t *listA, fmd_intv_t *listB, const FmdOvlClasses &cl, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
-                        uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx, size_t fix_off);
+                        uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx, size_t fix_off, uint32_t down_cap, int second_pass);
 int fmd_nei_fast_available(void);
 void fmd_launch_nei_fast(int cls, int wide, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                          const fmd_intv_t *listA, fmd_intv_t *listB, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
@@ -1084,6 +1084,7 @@ static bool ovl_tail2_cls(const OvlBatch &o)
     return ovl_tail2(o) && !getenv("FMD_OVLP_SLOW_ONLY") && !(e && atoi(e) == 0);
 }
 static int ovl_use_fast(void) { const char *ef = getenv("FMD_OVLP_FAST"); return fmd_nei_fast_available() && !(ef && atoi(ef) == 0); }   // FMD_OVLP_FAST=0: A/B switch, every strand through the general group kernels
+static int ovl_grp_down(void) { const char *e = getenv("FMD_GRP_DOWN"); return !(e && atoi(e) == 0); }
 static int ovl_min_cls(void) { const char *e = getenv("FMD_GRP4"); return e && atoi(e) == 0 ? 1 : 0; }                                  // FMD_GRP4=0: no groups of 4 (as fmd_launch_classify)
 
 // phase A: LF-walk + overlap_intv + fm6_is_contained, then the read-order copy.  per_cu > 0 bounds the
@@ -1176,8 +1177,15 @@ static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, i
                                 o.seq_stride, cl.lst[kg], cl.cnt + kg * FMD_CLS_CNT_STRIDE, nk + 8, lslow_late, n_late, gidx);
         }
     // one lane per candidate interval, 64 / G strands per wave
+    // (second pass: the strands a group kernel moved to a smaller group when their candidates had died down to single reads -- reads with errors --, largest class first:
+    // a strand may move again; their lists live where the fast lists were.  FMD_GRP_DOWN=0: the A/B switch, every strand stays in the group it was admitted to)
+    const uint32_t down_cap = ovl_grp_down() && np > 2 * (size_t)FMD_FAST_CHUNK ? (uint32_t)np : 0u;
     for (int k = 0; k < FMD_GRP_CLASSES; ++k)
-        fmd_launch_nei_grp(k, o.h->n_cu, per_cu, st, o.ix, cl.lst[k], cl.cnt + k * FMD_CLS_CNT_STRIDE, o.cap, listA, listB, cl, rec, nei, o.max_nei, seq, o.seq_stride, lslow_late, n_late, gidx, fix_off);
+        fmd_launch_nei_grp(k, o.h->n_cu, per_cu, st, o.ix, cl.lst[k], cl.cnt + k * FMD_CLS_CNT_STRIDE, o.cap, listA, listB, cl, rec, nei, o.max_nei, seq, o.seq_stride, lslow_late, n_late, gidx, fix_off, down_cap, 0);
+    if (down_cap)
+        for (int k = FMD_GRP_CLASSES - 2; k >= 0; --k)
+            fmd_launch_nei_grp(k, o.h->n_cu, per_cu, st, o.ix, cl.fast[k], cl.cnt + (FMD_GRP_CLASSES + 1 + k) * FMD_CLS_CNT_STRIDE + FMD_DOWN_WORD, o.cap, listA, listB, cl, rec, nei, o.max_nei, seq, o.seq_stride,
+                               lslow_late, n_late, gidx, fix_off, down_cap, 1);
     // the rest (too many candidates, wide intervals, fake forks, neighbour overflow): lane per strand
     k_ovl_nei<<<grid, 64, 0, st>>>(o.ix, np, o.min_match, srev, o.stride_r, o.cap, listA, listB, rec, nei, o.max_nei, seq, o.seq_stride, q2, lslow_late, n_late, gidx);
     // fake forks among the strands the group kernels finished: the fix-up alone

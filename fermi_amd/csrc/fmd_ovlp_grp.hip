@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
                                                     fmd_ovlp_rec_t *__restrict__ rec,
                                                     fmd_intv_t *__restrict__ nei_out, uint32_t max_nei, uint8_t *__restrict__ seq_out,
                                                     uint32_t seq_stride, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_n,
-                                                    const uint32_t *__restrict__ gidx, size_t fix_off, uint32_t *__restrict__ deal)
+                                                    const uint32_t *__restrict__ gidx, size_t fix_off, uint32_t *__restrict__ deal, uint32_t down_cap, uint32_t n_max)
 {
     __shared__ uint4 lds[GRP_LDS_U4];
     uint4 *pool = lds + GRP_SLOTS_U4, *stage = pool;
@@ -164,7 +164,8 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
     constexpr int S = 64 / G;
     constexpr uint32_t GM = G == 32 ? 0xffffffffu : (1u << G) - 1;
     const int lane = fmd_lane(), g = lane / G, j = lane % G, gbase = g * G;
-    const uint32_t N = *list_n;
+    // (n_max: a second-pass list -- its counter also counts the chunks that were asked for when it was full; those entries do not exist)
+    const uint32_t N = n_max && *list_n > n_max ? n_max : *list_n;
     const uint32_t n_groups = gridDim.x * S;
     uint32_t idx = !DYN && g < S ? blockIdx.x * S + g : 0xffffffffu; // position of this group's next strand in the list (lanes past S * G idle)
     // DYN: the positions are dealt out instead (fmd_deal_next below) -- dealt round-robin, a group's share of the list is fixed at the launch and
@@ -191,8 +192,55 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
     int pf = 0;
     uint32_t d_sid = 0, d_meta = 0, d_gs = 0;
     uint4 pa = make_uint4(0, 0, 0, 0), pb = make_uint4(0, 0, 0, 0);
+    // A strand keeps the group it was admitted to while its candidates die (reads with errors: a read that differs from the others is a category
+    // of its own from that base to its end, up to 50 rounds on, one lane of the group's G: 39 % live lanes on 30x reads with 1 % errors).  The sum
+    // of the live candidates' interval sizes bounds the lanes the strand can EVER need again (every child takes at least one occurrence of its
+    // parent's with it), so a strand whose live candidates are all single occurrences and fit a smaller group moves there for good -- as it stands
+    // after the round (FMD_LIST_RESUME), to the second-pass list of that class (the storage of its fast list, idle by now; counter in word
+    // FMD_DOWN_WORD of that list's line), which the launcher runs after the first pass, largest class first.  Slots are reserved FMD_FAST_CHUNK at a
+    // time per wave and target class (one atomic per strand on one address serialises), unused ones stay holes.  down_cap = entries a second-pass
+    // list holds (0: strands stay where they are, the A/B switch FMD_GRP_DOWN=0).
+    constexpr int MYK = G == 4 ? 0 : G == 8 ? 1 : G == 12 ? 2 : G == 16 ? 3 : G == 21 ? 4 : 5;
+    constexpr int NT = !DYN ? 0 : MYK >= 2 ? 2 : MYK;   // target classes: MYK - 1 and MYK - 2 (further down in one more hop from there); not with the round-robin deal (FMD_NEI_DYN=0, an A/B form: its registers are full)
+    uint32_t mv = 0;                                    // group-uniform: 1 + t = this group's strand leaves for target t (class MYK - 1 - t)
+    uint32_t res_cur[NT > 0 ? NT : 1] = {0}, res_end[NT > 0 ? NT : 1] = {0};   // wave-uniform
 
     for (;;) {
+        if (NT > 0 && down_cap) {   // ---- strands that leave for a smaller group (set at the end of the previous step)
+            if (__ballot(mv != 0)) {
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    const uint64_t hm = __ballot(mv == (uint32_t)(tt + 1) && j == 0 && g < S);
+                    if (hm == 0) continue;
+                    const int k2 = MYK - 1 - tt;
+                    uint32_t *lst2 = cl.fast[k2], *cnt2 = cl.cnt + (FMD_GRP_CLASSES + 1 + k2) * FMD_CLS_CNT_STRIDE + FMD_DOWN_WORD;
+                    const uint32_t n = (uint32_t)__popcll(hm), room = res_end[tt] - res_cur[tt];   // n <= S <= FMD_FAST_CHUNK
+                    uint32_t base = 0;
+                    bool got = true;
+                    if (room < n) {
+                        if (lane == 0) base = atomicAdd(cnt2, (uint32_t)FMD_FAST_CHUNK);
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        got = base + FMD_FAST_CHUNK <= down_cap;                      // (a full list: the strands beyond `room` stay here)
+                        if (got) {
+                            if (lane < FMD_FAST_CHUNK) { lst2[2 * (size_t)(base + lane)] = FMD_LIST_HOLE; lst2[2 * (size_t)(base + lane) + 1] = 0; }
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the markers land before the entries that replace them
+                        }
+                    }
+                    const uint32_t q = (uint32_t)__popcll(hm & ((1ull << gbase) - 1));   // this group's place among those that leave for k2
+                    const bool mine = mv == (uint32_t)(tt + 1) && (q < room || got);
+                    if (mine) {
+                        const uint32_t k = q < room ? res_cur[tt] + q : base + (q - room);
+                        const uint32_t ag = (uint32_t)(__ballot(alive) >> gbase) & GM;    // (lanes j < the number of children: packed already)
+                        if (alive) fmd_resume_encode((uint4 *)(listB + sid * (size_t)cap + j), x1, sz, D, r0, pos, (uint32_t)round, n_nei, nei0_info, LF_GET(flags), (uint32_t)cat, flags & 0xffu);
+                        if (j == 0) { lst2[2 * (size_t)k] = sid; lst2[2 * (size_t)k + 1] = (uint32_t)__popc(ag) | FMD_LIST_RESUME | (uint32_t)ori_l << 16; }
+                        active = false; alive = false;
+                    }
+                    if (room < n) { if (got) { res_cur[tt] = base + (n - room); res_end[tt] = base + FMD_FAST_CHUNK; } else res_cur[tt] = res_end[tt]; }
+                    else res_cur[tt] += n;
+                }
+                mv = 0;
+            }
+        }
         // ---- admission
         if (!active && pf == 2) {
             const uint32_t m = d_meta & 0x7fffu;
@@ -430,6 +478,11 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
                     const uint4 a = stage[2 * (gbase + j)], b = stage[2 * (gbase + j) + 1];
                     x1 = (uint64_t)(a.y & 0xffu) << 32 | a.x; sz = (a.y >> 8) & 0xffu; cat = (int)(a.y >> 16);
                     D = (uint64_t)a.w << 32 | a.z; r0 = (uint64_t)b.y << 32 | b.x; pos = b.z;
+                }
+                if (NT > 0 && down_cap && n_new <= fmd_grp_size(MYK - 1)) {   // fits a smaller group: for good, if every live candidate is one occurrence
+                    const uint32_t wide_g = (uint32_t)(__ballot(alive && sz > 1) >> gbase) & GM;
+                    if (wide_g == 0 && (uint32_t)n_new <= cap && fmd_resume_fits((uint32_t)round, n_nei, nei0_info, 0u))
+                        mv = NT > 1 && n_new <= fmd_grp_size(MYK >= 2 ? MYK - 2 : 0) ? 2u : 1u;
                 }
             } else { // every path is closed (unitig.c:154-178)
                 if (j == 0) {
@@ -783,11 +836,12 @@ static int grp_blocks_per_cu(void)
 }
 void fmd_launch_nei_grp(int cls, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                         const fmd_intv_t *listA, fmd_intv_t *listB, const FmdOvlClasses &cl, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
-                        uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx, size_t fix_off)
+                        uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx, size_t fix_off, uint32_t down_cap, int second_pass)
 {
+    const uint32_t n_max = second_pass ? down_cap / FMD_FAST_CHUNK * FMD_FAST_CHUNK : 0u;
     const bool dyn = nei_dyn() != 0;
     uint32_t *deal = (uint32_t *)list_n + FMD_DEAL_WORD;
-#define GRP_LAUNCH_(K, DY) k_ovl_nei_grp<fmd_grp_size(K), DY><<<n_cu * grp_cap(grp_blocks_per_cu<fmd_grp_size(K), DY>(), per_cu_cap), 64, 0, st>>>(ix, list, list_n, cap, listA, listB, cl, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n, gidx, fix_off, deal)
+#define GRP_LAUNCH_(K, DY) k_ovl_nei_grp<fmd_grp_size(K), DY><<<n_cu * grp_cap(grp_blocks_per_cu<fmd_grp_size(K), DY>(), per_cu_cap), 64, 0, st>>>(ix, list, list_n, cap, listA, listB, cl, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n, gidx, fix_off, deal, down_cap, n_max)
 #define GRP_LAUNCH(K) do { if (dyn) GRP_LAUNCH_(K, true); else GRP_LAUNCH_(K, false); } while (0)
     switch (cls) {
     case 0: GRP_LAUNCH(0); break;
