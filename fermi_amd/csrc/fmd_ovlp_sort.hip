@@ -52,6 +52,16 @@ __global__ void k_ovl_park_keys(size_t n, const FmdWalkPark *__restrict__ park, 
     }
 }
 
+#ifndef FMD_PARK_SORT_FROM_DEFAULT
+#define FMD_PARK_SORT_FROM_DEFAULT 0
+#endif
+static unsigned park_sort_from(void)
+{
+    const char *e = getenv("FMD_PARK_SORT_FROM");
+    const int v = e ? atoi(e) : FMD_PARK_SORT_FROM_DEFAULT;
+    return v < 0 ? 0u : v > 31 ? 31u : (unsigned)v;
+}
+
 size_t fmd_park_sort_temp_bytes(size_t n)
 {
     size_t tb = 0;
@@ -67,6 +77,9 @@ int fmd_park_sort(hipStream_t st, size_t n, const FmdWalkPark *park, uint32_t *k
     size_t blocks = (n + 255) / 256;
     if (blocks > (1u << 20)) blocks = 1u << 20;
     k_ovl_park_keys<<<(unsigned)blocks, 256, 0, st>>>(n, park, keys_a, vals_a);
-    FMD_HIP_TRY(fmd_sort_pairs(tmp, tmp_bytes, (const uint32_t *)keys_a, keys_b, (const uint32_t *)vals_a, vals_b, n, 0, 32, st));
+    // All 32 bits: the order is for the caches only (any order gives the same rows), but dropping radix passes does not pay -- with the sort looking at
+    // key bits b .. 31 the whole job took 254.4 (b = 0), 259.5 (8), 274.1 (12), 276.2 (16), 292.7 (20), 322.5 (24) ms per 10^8 strands
+    // (profiles/r5_sortbits, FMD_PARK_SORT_FROM=b): already the five offset bits that put the strands of ONE minimizer in genome order are worth 2 %.
+    FMD_HIP_TRY(fmd_sort_pairs(tmp, tmp_bytes, (const uint32_t *)keys_a, keys_b, (const uint32_t *)vals_a, vals_b, n, park_sort_from(), 32, st));
     return FMD_OK;
 }
