@@ -134,7 +134,9 @@ __device__ __forceinline__ void fmd_resume_decode(const uint4 a, const uint4 b, 
     x1 = (uint64_t)(a.y & 0xffu) << 32 | a.x; round = (a.y >> 8) & 0xffffu; n_nei = a.y >> 24; D = (uint64_t)a.w << 32 | a.z;
     r0 = (uint64_t)(b.y & 0xffu) << 32 | b.x; nei0 = b.y >> 8; sz = b.z & 0xffffu; pos = b.z >> 16; lf = b.w & 0x1ffffu; cat = (b.w >> 17) & 31u; flags8 = (b.w >> 22) & 0xffu;
 }
-#define FMD_FAST_RESERVE (2 * FMD_FAST_MAX_WAVES * FMD_FAST_CHUNK)   // entries a general list may lose to holes (two fast kernels feed it)
+#define FMD_LANE_CHUNK 64                  // the same for k_ovl_nei_lane (fmd_ovlp_lane.hip): every lane of a wave may hand its strand on in one step
+#define FMD_DEAL_WORD_LANE 16              // word of a fast list's counter line that is k_ovl_nei_lane's ticket counter (the group form deals from the same word)
+#define FMD_FAST_RESERVE (2 * FMD_FAST_MAX_WAVES * FMD_LANE_CHUNK)   // entries a general list may lose to holes (two fast kernels feed it; a wave's last chunk keeps at most FMD_LANE_CHUNK - 1)
 #define FMD_CLS_PART_U32 (FMD_CLS_HEADER_U32 + 2 * FMD_GRP_CLASSES * FMD_FAST_RESERVE)   // per part of a pipelined batch: counters + that room
 static_assert((3 * FMD_GRP_CLASSES + 1) * FMD_CLS_CNT_STRIDE <= FMD_CLS_HEADER_U32, "one counter line per list");
 #define FMD_CLS_LISTS (3 * FMD_GRP_CLASSES + 1)                 // general lists, the slow list, fast lists (32-bit masks, 64-bit masks)

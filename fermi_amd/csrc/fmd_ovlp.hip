@@ -14,6 +14,11 @@ void fmd_launch_nei_grp(int cls, int n_cu, int per_cu_cap, hipStream_t st, const
                         const fmd_intv_t *listA, fmd_intv_t *listB, const FmdOvlClasses &cl, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
                         uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx, size_t fix_off, uint32_t down_cap, int second_pass);
 int fmd_nei_fast_available(void);
+int fmd_nei_lane_enabled(void);
+int fmd_nei_lane_class_ok(int cls, int wide);
+void fmd_launch_nei_lane(int cls, int wide, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
+                         const fmd_intv_t *listA, fmd_intv_t *listB, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
+                         uint32_t seq_stride, uint32_t *gen_list, uint32_t *gen_n, uint32_t *bail_n, const uint32_t *gidx);
 void fmd_launch_nei_fast(int cls, int wide, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                          const fmd_intv_t *listA, fmd_intv_t *listB, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
                          uint32_t seq_stride, uint32_t *gen_list, uint32_t *gen_n, uint32_t *bail_n, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx);
@@ -1173,6 +1178,11 @@ static int ovl_phase_b(const OvlBatch &o, hipStream_t st, size_t b, size_t np, i
         for (int k = 0; k < 2 * FMD_GRP_CLASSES; ++k) {
             uint32_t *nk = cl.cnt + (FMD_GRP_CLASSES + 1 + k) * FMD_CLS_CNT_STRIDE;
             const int kg = k % FMD_GRP_CLASSES;
+            // one lane per STRAND where its candidates fit a lane's registers (fmd_ovlp_lane.hip), one lane per candidate otherwise (FMD_NEI_LANE=0: always)
+            if (fmd_nei_lane_enabled() && fmd_nei_lane_class_ok(kg, k >= FMD_GRP_CLASSES))
+                fmd_launch_nei_lane(kg, k >= FMD_GRP_CLASSES, o.h->n_cu, fast_cu, st, o.ix, cl.fast[k], nk, o.cap, listA, listB, rec, nei, o.max_nei, seq,
+                                    o.seq_stride, cl.lst[kg], cl.cnt + kg * FMD_CLS_CNT_STRIDE, nk + 8, gidx);
+            else
             fmd_launch_nei_fast(kg, k >= FMD_GRP_CLASSES, o.h->n_cu, fast_cu, st, o.ix, cl.fast[k], nk, o.cap, listA, listB, rec, nei, o.max_nei, seq,
                                 o.seq_stride, cl.lst[kg], cl.cnt + kg * FMD_CLS_CNT_STRIDE, nk + 8, lslow_late, n_late, gidx);
         }
