@@ -49,7 +49,7 @@ def log(*a):
 
 
 # the sources a leg's kernels are compiled from (besides the headers and the index layout, which every kernel depends on)
-LEG_SOURCES = {"overlap": ("fmd_ovlp.hip", "fmd_ovlp_grp.hip", "fmd_ovlp_sort.hip"), "overlap_raw": ("fmd_ovlp.hip", "fmd_ovlp_grp.hip", "fmd_ovlp_sort.hip"),
+LEG_SOURCES = {"overlap": ("fmd_ovlp.hip", "fmd_ovlp_grp.hip", "fmd_ovlp_lane.hip", "fmd_ovlp_sort.hip"), "overlap_raw": ("fmd_ovlp.hip", "fmd_ovlp_grp.hip", "fmd_ovlp_lane.hip", "fmd_ovlp_sort.hip"),
                "check_left": ("fmd_pack.hip", "fmd_ovlp.hip"), "k_bsearch": ("fmd_ops.hip",), "smem": ("fmd_smem.hip",), "kmer": ("fmd_kmer.hip",), "ecfix": ("fmd_ecfix.hip",)}
 
 
@@ -106,7 +106,7 @@ def pmc_in_run(fmd_path, n_reads, steps=2, leg="overlap"):
             return "failed (no counter rows)"
         cal = 2 * (1 << 27) * 64 / (pr["k_probe"] * 1024.0)      # probe_once: warm-up + one launch, 2^27 lines of 64 bytes each
         src = "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over %d steps of the leg on the index this run built; KB units, FETCH_SIZE x %.4f (gather probe, 64-byte lines, same run)" % (steps, cal)
-        OVL = ("k_ovl_head_adm", "k_ovl_walk", "k_ovl_park_keys", "k_ovl_seq_out", "k_ovl_seq_redo", "k_ovl_classify", "k_ovl_nei_fast", "k_ovl_nei_grp", "k_ovl_nei", "k_ovl_fix")
+        OVL = ("k_ovl_head_adm", "k_ovl_walk", "k_ovl_park_keys", "k_ovl_seq_out", "k_ovl_seq_redo", "k_ovl_classify", "k_ovl_nei_fast", "k_ovl_nei_lane", "k_ovl_nei_grp", "k_ovl_nei", "k_ovl_fix")
         legs_of = {"overlap": (("overlap@%d" % n_reads, OVL), ("check_left@%d" % n_reads, ("k_link_rows", "k_link_edges", "k_ovl_cls"))), "ecfix": (("ecfix@%d" % n_reads, ("k_ecfix",)),)}
         for key, names in legs_of[leg]:
             fk = sum(v for k, v in fetch.items() if k in names) / steps
@@ -731,7 +731,7 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
     dev_bytes = None if lines is None else (lines[0] + lines[1]) * BLOCK_BYTES + io
     cn = oracle_counters(fmd_path, lambda o: o.overlap_batch(np.arange(4000, dtype=np.uint64), min_match, 100, 4, 1, check_left=False))
     qps = (cn["rank1a"] + cn["rank2a"] + cn["rank2a_spill"]) / 4000.0
-    out["roofline"] = roofline("k_ovl_head_adm + k_ovl_walk<HEAD> + k_ovl_park_keys + one radix sort + per batch: k_ovl_walk<%s> + k_ovl_nei_fast<G, M> + k_ovl_nei_grp<G> + k_ovl_nei (one step = one job of %d batches of %d strands)"
+    out["roofline"] = roofline("k_ovl_head_adm + k_ovl_walk<HEAD> + k_ovl_park_keys + one radix sort + per batch: k_ovl_walk<%s> + k_ovl_nei_lane<G, M> (k_ovl_nei_fast<32, M>) + k_ovl_nei_grp<G> + k_ovl_nei (one step = one job of %d batches of %d strands)"
                                % ("TAIL2> (rows and work lists written by the walk" if tail2_cls else ("TAIL2> + k_ovl_classify" if tail2 else "TAIL> + k_ovl_seq_out + k_ovl_classify"),
                                   (job.n + job.batch - 1) // job.batch, job.batch), kern_ms, dev_bytes,
                                {"rank_blocks": lines and lines[0], "prefix_table_lines": lines and lines[1], "stream_bytes": io, "streams": streams},

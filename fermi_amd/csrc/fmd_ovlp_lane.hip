@@ -10,7 +10,8 @@
 // Here a lane owns a strand: its candidates are 16-byte entries of the lane's own column of LDS (D, r0, packed offset / size / start; entry j of lane q at
 // [j][q]: a wave's ds_read_b128 of one j is conflict-free), the round is a loop over them (as registers -- unrolled over G -- they spilled: 515 VGPRs
 // at G = 16), the window comes from the lane's own block image (the wave engine's cooperative gather: 64 strands' blocks per wave instruction), and
-// 64 strands per wave x 6-13 waves per CU (LDS: G + 4 KiB per wave) are in flight instead of 80.  Same results by
+// 64 strands per wave x 8-13 waves per CU (LDS: G + 4 KiB per wave) are in flight instead of 80.  Classes of up to 16 candidates (21 is 4 VGPRs short of
+// holding an admission's raw entries beside the round's state: the group form).  Same results by
 // construction: the arithmetic of a round is k_ovl_nei_fast's, statement by statement; a strand that leaves the simple regime is handed to
 // k_ovl_nei_grp in the same FMD_LIST_RESUME form.  FMD_NEI_LANE=0 runs the group form instead (the A/B switch, and the tests' second opinion).
 #include "fmd_kernel_common.h"
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(64, FMD_LANE_LB) void k_ovl_nei_lane(FmdIndexView i
     int hand = 0;                                          // 1 = hand this strand on from round 0, 2 = with its state (FMD_LIST_RESUME)
     bool slow = false;                                     // the strand's round waits for the wave's next pass through the full round code, with what it saw of its window:
     M sX = 0, sY = 0, sZ = 0;
-    uint64_t sRc = 0, sRz = 0;
+    uint64_t sR0 = 0, sR1 = 0, sR2 = 0, sR3 = 0, sR4 = 0;    // ranks at X1 - 1 of '$', A, C, G, T (one base in the window: that base's in all four)
     int scs = 0;                                           // the base | 8 = more than one base among the reads of the window
     int st = 0;                                            // admission: 0 none in progress, 2 = (sid, meta) are known, the candidates are fetched in the next step
     bool drained = false;
@@ -186,45 +187,21 @@ __global__ __launch_bounds__(64, FMD_LANE_LB) void k_ovl_nei_lane(FmdIndexView i
             const M ends = ~(X | Y | Z) & mw;                        // reads of the window that end here
             int cs = (xa ? 1 : 0) | (ya ? 2 : 0) | (za ? 4 : 0);
             const bool mixed = go && ((xa && xa != any) || (ya && ya != any) || (za && za != any) || cs > 4);
-            bool bail = false;
-            if (mixed) {
-                const M m1 = X & ~Y & ~Z & mw, m2 = ~X & Y & ~Z & mw, m3 = X & Y & ~Z & mw, m4 = ~X & ~Y & Z & mw, m5 = X & ~Y & Z & mw;
-                // which bases does a read that STARTS inside some candidate go on with (a surviving child, unitig.c:126-134)?
-                uint32_t u = 0;
-                for (uint32_t j = 0; j < m_lane; ++j) {
-                    if ((am >> j) & 1u) {
-                        const uint4 e = mc[j * 64];
-                        const uint32_t d = LC_D(e.w), sz = LC_SZ(e.w);
-                        const M mine = W::below(sz) << d;
-                        const uint32_t nS = W::popc(ends & mine);
-                        const uint32_t s1 = W::popc(m1 & mine), s2 = W::popc(m2 & mine), s3 = W::popc(m3 & mine), s4 = W::popc(m4 & mine), s5 = W::popc(m5 & mine);
-                        const uint32_t o4 = nS, o3 = o4 + s4, o2 = o3 + s3, o1_ = o2 + s2, o5 = o1_ + s1;
-                        const M D = CD(e);
-                        if ((D >> o1_) & W::below(s1)) u |= 2u;
-                        if ((D >> o2) & W::below(s2)) u |= 4u;
-                        if ((D >> o3) & W::below(s3)) u |= 8u;
-                        if ((D >> o4) & W::below(s4)) u |= 16u;
-                        if ((D >> o5) & W::below(s5)) u |= 32u;
-                    }
-                }
-                bail = __popc(u) >= 2 || (u & 32u);                 // a fork (or an N to follow): the general kernel's business
-                cs = u ? __ffs((int)u) - 1 : 0;
-                if (cs > 4) cs = 0;
-            }
-            // absolute ranks at X1 - 1: of that base (children) and of '$' (x[1] of a neighbour)
-            uint64_t Rz;
-            const uint64_t Rc = fmd_block_rank1z(img_k, t_k, oke + 1, cs, bke, Rz);
+            // absolute ranks at X1 - 1: of the base the strand goes on with (children) and of '$' (x[1] of a neighbour); with more than one base in the window
+            // which one it is comes out of the candidates (the full round below), so all of them are taken while the block is here
+            uint64_t R[6] = {0, 0, 0, 0, 0, 0};
+            if (__ballot(mixed)) { if (mixed) fmd_block_rank6<false>(img_k, t_k, oke + 1, R, bke); }
+            if (!mixed) { uint64_t rz; const uint64_t rc = fmd_block_rank1z(img_k, t_k, oke + 1, cs, bke, rz); R[0] = rz; R[1] = R[2] = R[3] = R[4] = rc; }
             if (go) {
-                if (bail) { hand = 2; active = false; lane_flush_bases(seq_out, seq_stride, gs, meta >> 16, eb0, round, eb); }   // (the candidates stay as they are until the hand-over at the top of the next step)
-                else if (!mixed && ends == 0) {
+                if (!mixed && ends == 0) {
                     // the QUIET round -- no read of the window ends, all go on with one base: nothing ends, nothing is a neighbour, every candidate keeps
                     // its size, its offset in the window, its D (alive => D != 0: a read starts with it) and r0; the window moves by one LF step.
                     if (!(lf & 0x10000u)) lf = round + 1;
                     eb |= (uint64_t)(uint32_t)(4 - cs) << (2 * (round - eb0));
                     ++round;
                     if (round - eb0 == 32) { lane_flush_bases(seq_out, seq_stride, gs, meta >> 16, eb0, round, eb); eb = 0; eb0 = round; }
-                    X1 = (cs == 1 ? ix.cnt[1] : cs == 2 ? ix.cnt[2] : cs == 3 ? ix.cnt[3] : ix.cnt[4]) + Rc;
-                } else { slow = true; sX = X; sY = Y; sZ = Z; sRc = Rc; sRz = Rz; scs = cs | (mixed ? 8 : 0); }
+                    X1 = (cs == 1 ? ix.cnt[1] : cs == 2 ? ix.cnt[2] : cs == 3 ? ix.cnt[3] : ix.cnt[4]) + R[1];
+                } else { slow = true; sX = X; sY = Y; sZ = Z; sR0 = R[0]; sR1 = R[1]; sR2 = R[2]; sR3 = R[3]; sR4 = R[4]; scs = cs | (mixed ? 8 : 0); }
             }
         }
         // ---- the full round, for the lanes that wait for it, when enough of them do (its loops over the candidates are most of this kernel's instructions: a wave
@@ -234,14 +211,40 @@ __global__ __launch_bounds__(64, FMD_LANE_LB) void k_ovl_nei_lane(FmdIndexView i
             if (sm && ((uint32_t)__popcll(sm) >= slow_min || __ballot(active && !slow) == 0)) {
                 if (slow) {
                     const M X = sX, Y = sY, Z = sZ;
-                    const uint64_t Rc = sRc, Rz = sRz;
-                    const int cs = scs & 7;
+                    int cs = scs & 7;
                     const bool mixed = (scs & 8) != 0;
                     const M mw = W::below(szw), any = (X | Y | Z) & mw, ends = ~(X | Y | Z) & mw;
                     const M m1 = X & ~Y & ~Z & mw, m2 = ~X & Y & ~Z & mw, m3 = X & Y & ~Z & mw, m4 = ~X & ~Y & Z & mw;
+                    bool bail = false;
+                    if (mixed) {   // which bases does a read that STARTS inside some candidate go on with (a surviving child, unitig.c:126-134)?
+                        const M m5 = X & ~Y & Z & mw;
+                        uint32_t u = 0;
+                        for (uint32_t j = 0; j < m_lane; ++j) {
+                            if ((am >> j) & 1u) {
+                                const uint4 e = mc[j * 64];
+                                const uint32_t d = LC_D(e.w), sz = LC_SZ(e.w);
+                                const M mine = W::below(sz) << d;
+                                const uint32_t nS = W::popc(ends & mine);
+                                const uint32_t s1 = W::popc(m1 & mine), s2 = W::popc(m2 & mine), s3 = W::popc(m3 & mine), s4 = W::popc(m4 & mine), s5 = W::popc(m5 & mine);
+                                const uint32_t o4 = nS, o3 = o4 + s4, o2 = o3 + s3, o1_ = o2 + s2, o5 = o1_ + s1;
+                                const M D = CD(e);
+                                if ((D >> o1_) & W::below(s1)) u |= 2u;
+                                if ((D >> o2) & W::below(s2)) u |= 4u;
+                                if ((D >> o3) & W::below(s3)) u |= 8u;
+                                if ((D >> o4) & W::below(s4)) u |= 16u;
+                                if ((D >> o5) & W::below(s5)) u |= 32u;
+                            }
+                        }
+                        bail = __popc(u) >= 2 || (u & 32u);             // a fork (or an N to follow): the general kernel's business
+                        cs = u ? __ffs((int)u) - 1 : 0;
+                        if (cs > 4) cs = 0;
+                    }
+                    const uint64_t Rz = sR0, Rc = cs == 1 ? sR1 : cs == 2 ? sR2 : cs == 3 ? sR3 : cs == 4 ? sR4 : sR0;
                     const M Cw = !mixed ? any : cs == 1 ? m1 : cs == 2 ? m2 : cs == 3 ? m3 : cs == 4 ? m4 : (M)0;   // the positions of cs in the window
                     slow = false;
                     const uint32_t ori_l = meta >> 16;
+                    if (bail) { hand = 2; active = false; lane_flush_bases(seq_out, seq_stride, gs, ori_l, eb0, round, eb); }   // (the candidates stay as they are until the hand-over at the top of the next step)
+                    else {
                     // ---- every candidate of the strand: is it a neighbour (unitig.c:111-122), does a read that starts with it go on (unitig.c:129)?
                     uint32_t nei_m = 0, child_m = 0;
                     for (uint32_t j = 0; j < m_lane; ++j) {
@@ -313,6 +316,7 @@ __global__ __launch_bounds__(64, FMD_LANE_LB) void k_ovl_nei_lane(FmdIndexView i
                         o->n_nei = (int32_t)n_nei;
                         active = false; am = 0;
                     }
+                    }
                 }
             }
         }
@@ -357,7 +361,7 @@ int fmd_nei_lane_enabled(void)
     return !(e && atoi(e) == 0);
 }
 // classes whose candidates fit the registers of a lane: up to 21 (the larger group size is the group kernels' business)
-int fmd_nei_lane_class_ok(int cls, int wide) { return cls >= 0 && (wide ? cls <= 3 : cls <= 4); }
+int fmd_nei_lane_class_ok(int cls, int wide) { (void)wide; return cls >= 0 && cls <= 3; }   // up to 16 candidates: the 8 raw words per candidate of an admission are in registers beside the round's state (21: 4 VGPRs short)
 
 void fmd_launch_nei_lane(int cls, int wide, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                          const fmd_intv_t *listA, fmd_intv_t *listB, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
@@ -384,8 +388,7 @@ void fmd_launch_nei_lane(int cls, int wide, int n_cu, int per_cu_cap, hipStream_
     case 0: LANE_LAUNCH2(0); break;
     case 1: LANE_LAUNCH2(1); break;
     case 2: LANE_LAUNCH2(2); break;
-    case 3: LANE_LAUNCH2(3); break;
-    default: LANE_LAUNCH_(4, uint32_t); break;   // (21 candidates with 64-bit masks: the raw entries of an admission do not fit the registers beside them -- the group form, see fmd_nei_lane_class_ok)
+    default: LANE_LAUNCH2(3); break;
     }
 #undef LANE_LAUNCH2
 #undef LANE_LAUNCH_

@@ -922,7 +922,7 @@ def _same_overlap(a, b, max_nei):
 @pytest.mark.parametrize("L,cov,mm,err,N", [(100, 30, 50, 0.0, 20000), (100, 30, 50, 0.01, 20000), (100, 60, 40, 0.003, 8000), (151, 12, 31, 0.02, 6000),
                                             (100, 80, 45, 0.0, 6000), (100, 80, 45, 0.005, 6000)])   # the last two: widest candidates of 32..63 occurrences, the 64-bit masks
 def test_unforked_fast_path_equals_general_group_kernels(gpu, oracle_lib, monkeypatch, capfd, L, cov, mm, err, N):
-    """k_ovl_nei_fast (candidates in the narrow form, no x[0]-side fetch, one shared window per strand and round; hands a strand
+    """The unforked path (k_ovl_nei_lane / k_ovl_nei_fast: candidates in the narrow form, no x[0]-side fetch, one shared window per strand and round; hands a strand
     on to k_ovl_nei_grp the moment its reads show a second base) against the general group kernels alone (FMD_OVLP_FAST=0) and the
     oracle: records incl. lfork, neighbours, appended bases.  Also: the fast path really ran, and with errors in the reads really
     handed strands on."""
@@ -940,6 +940,17 @@ def test_unforked_fast_path_equals_general_group_kernels(gpu, oracle_lib, monkey
     general = d.overlap(ids, mm, L, 8, check_left=True)
     monkeypatch.delenv("FMD_OVLP_FAST")
     _same_overlap(general, fast, 8)
+    # the two forms of the unforked path: one lane per STRAND (k_ovl_nei_lane, what ran above for the classes up to 16 candidates: quiet rounds inline, full rounds
+    # and admissions in batches -- also with a batch of one lane and of a whole wave) and one lane per CANDIDATE (k_ovl_nei_fast, FMD_NEI_LANE=0)
+    for env in ({"FMD_NEI_LANE": "0"}, {"FMD_LANE_BATCH": "1"}, {"FMD_LANE_BATCH": "64", "FMD_LANE_TICKETS": "16"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        other = d.overlap(ids, mm, L, 8, check_left=True)
+        for k in env:
+            monkeypatch.delenv(k)
+        _same_overlap(other, fast, 8)
+        for f in ("lfork", "flags"):
+            assert np.array_equal(other[0][f], fast[0][f]), (env, f)
     took = [(int(a), int(b)) for a, b in re.findall(r"(\d+) to the unforked path \((\d+) of them handed on\)", msg)]
     assert took and sum(a for a, _ in took) > N // 2, msg
     if err > 0:
