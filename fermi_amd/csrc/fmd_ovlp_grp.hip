@@ -479,10 +479,17 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
                     x1 = (uint64_t)(a.y & 0xffu) << 32 | a.x; sz = (a.y >> 8) & 0xffu; cat = (int)(a.y >> 16);
                     D = (uint64_t)a.w << 32 | a.z; r0 = (uint64_t)b.y << 32 | b.x; pos = b.z;
                 }
-                if (NT > 0 && down_cap && n_new <= fmd_grp_size(MYK - 1)) {   // fits a smaller group: for good, if every live candidate is one occurrence
-                    const uint32_t wide_g = (uint32_t)(__ballot(alive && sz > 1) >> gbase) & GM;
-                    if (wide_g == 0 && (uint32_t)n_new <= cap && fmd_resume_fits((uint32_t)round, n_nei, nei0_info, 0u))
-                        mv = NT > 1 && n_new <= fmd_grp_size(MYK >= 2 ? MYK - 2 : 0) ? 2u : 1u;
+                if (NT > 0 && down_cap && n_new <= fmd_grp_size(MYK - 1)) {   // fits a smaller group: for good, if the sum of the live candidates' sizes does
+                    // W = n_new + sum (size - 1), from ballots (sizes of 5 and more: no move) -- the lanes the strand can ever need again
+                    const uint32_t b2 = (uint32_t)(__ballot(alive && sz >= 2) >> gbase) & GM, b5 = (uint32_t)(__ballot(alive && sz >= 5) >> gbase) & GM;
+                    if (b5 == 0 && (uint32_t)n_new <= cap && fmd_resume_fits((uint32_t)round, n_nei, nei0_info, 0u)) {
+                        uint32_t Wsum = (uint32_t)n_new;
+                        if (b2) {
+                            const uint32_t b3 = (uint32_t)(__ballot(alive && sz >= 3) >> gbase) & GM, b4 = (uint32_t)(__ballot(alive && sz >= 4) >> gbase) & GM;
+                            Wsum += (uint32_t)(__popc(b2) + __popc(b3) + __popc(b4));
+                        }
+                        if (Wsum <= (uint32_t)fmd_grp_size(MYK - 1)) mv = NT > 1 && Wsum <= (uint32_t)fmd_grp_size(MYK >= 2 ? MYK - 2 : 0) ? 2u : 1u;
+                    }
                 }
             } else { // every path is closed (unitig.c:154-178)
                 if (j == 0) {
