@@ -93,7 +93,9 @@ __global__ __launch_bounds__(64, FMD_LANE_LB) void k_ovl_nei_lane(FmdIndexView i
     M sX = 0, sY = 0, sZ = 0;
     uint64_t sR0 = 0, sR1 = 0, sR2 = 0, sR3 = 0, sR4 = 0;    // ranks at X1 - 1 of '$', A, C, G, T (one base in the window: that base's in all four)
     int scs = 0;                                           // the base | 8 = more than one base among the reads of the window
-    int st = 0;                                            // admission: 0 none in progress, 2 = (sid, meta) are known, the candidates are fetched in the next step
+    int st = 0;                                            // admission: 0 none in progress, 2 = (sid, meta) are known, the candidates [m / 2, m) are fetched next, 3 = then the others
+    bool adm_bad = false;
+    constexpr int HALVES = G > 8 ? 2 : 1, RAWN = (G + HALVES - 1) / HALVES;
     bool drained = false;
 
     for (;;) {
@@ -136,16 +138,18 @@ __global__ __launch_bounds__(64, FMD_LANE_LB) void k_ovl_nei_lane(FmdIndexView i
         // ---- admission, in two steps whose loads ride under the other lanes' gather (one s_waitcnt for all): (1) a ticket and the list entry of that
         // position; (2) the strand's candidates (overlap_intv's list, longest overlap first) -- m entries of 32 bytes from the lane's own row, issued at once
         // (a loop that waits for every entry in turn costs the wave m round trips: the first form of this kernel, 15 ms SLOWER than the group form)
-        uint4 raw[2 * G];
+        // (more than 8 candidates come in two parts, the widest half first: 8 raw words per candidate sit in registers from the loads to the s_waitcnt)
+        uint4 raw[2 * RAWN];
         uint32_t l0 = 0, l1 = 0, g_in = 0;
-        // (the candidates' decode is G x 40 instructions for the wave however many lanes take part: not before `slow_min` lanes wait for it, unless nobody has a round to do)
-        const bool ld2 = st == 2 && ((uint32_t)__popcll(__ballot(st == 2)) >= slow_min || __ballot(active) == 0);
+        // (the candidates' decode is RAWN x 40 instructions for the wave however many lanes take part: not before `slow_min` lanes wait for it, unless nobody has a round to do)
+        const bool ld2 = st >= 2 && ((uint32_t)__popcll(__ballot(st >= 2)) >= slow_min || __ballot(active) == 0);
+        const uint32_t adm_m = meta & 0xffffu, adm_h0 = HALVES == 2 ? adm_m / 2 : 0u;                 // the parts: [h0, m) first, then [0, h0)
+        const uint32_t adm_base = st == 2 ? adm_h0 : 0u, adm_cnt = st == 2 ? adm_m - adm_h0 : adm_h0;
         if (ld2) {
-            const uint32_t m = meta & 0xffffu;
-            const uint4 *q0 = (const uint4 *)(listA + sid * (size_t)cap + (cap - m));
+            const uint4 *q0 = (const uint4 *)(listA + sid * (size_t)cap + (cap - adm_m) + adm_base);
 #pragma unroll
-            for (int j = 0; j < G; ++j) if ((uint32_t)j < m) { raw[2 * j] = q0[2 * j]; raw[2 * j + 1] = q0[2 * j + 1]; }
-            g_in = gidx ? gidx[sid] : sid;
+            for (int t = 0; t < RAWN; ++t) if ((uint32_t)t < adm_cnt) { raw[2 * t] = q0[2 * t]; raw[2 * t + 1] = q0[2 * t + 1]; }
+            if (st == 2) g_in = gidx ? gidx[sid] : sid;
         }
         bool ld1 = false;
         {
@@ -322,28 +326,34 @@ __global__ __launch_bounds__(64, FMD_LANE_LB) void k_ovl_nei_lane(FmdIndexView i
         }
         // ---- what the admission loads of this step brought
         if (ld2) {
-            const uint32_t m = meta & 0xffffu, ori_l = meta >> 16;
-            gs = g_in;
-            round = 0; n_nei = 0; lf = 0; nei0 = 0; am = 0; eb = 0; eb0 = 0;
-            bool bad = m == 0 || m > (uint32_t)G || ori_l > LANE_MAX_LEN;
-            uint64_t x1w = 1; uint32_t szw_ = 1;
+            const uint32_t m = adm_m, ori_l = meta >> 16;
+            if (st == 2) {
+                gs = g_in;
+                round = 0; n_nei = 0; lf = 0; nei0 = 0; am = 0; eb = 0; eb0 = 0;
+                adm_bad = m == 0 || m > (uint32_t)G || ori_l > LANE_MAX_LEN;
+                uint64_t x1w = 1; uint32_t szw_ = 1;
 #pragma unroll
-            for (int j = 0; j < G; ++j) if ((uint32_t)j + 1 == m) { const FmdCand cw = cand_decode(raw[2 * j], raw[2 * j + 1]); x1w = cw.x1; szw_ = (uint32_t)cw.sz; }   // the widest candidate is the last: its range holds the others'
-            bad |= szw_ > W::MAXW || szw_ == 0;
-            m_lane = bad ? 0u : m;
+                for (int t = 0; t < RAWN; ++t) if ((uint32_t)t + 1 == adm_cnt) { const FmdCand cw = cand_decode(raw[2 * t], raw[2 * t + 1]); x1w = cw.x1; szw_ = (uint32_t)cw.sz; }   // the widest candidate is the last: its range holds the others'
+                adm_bad |= szw_ > W::MAXW || szw_ == 0;
+                X1 = x1w; szw = szw_;
+                m_lane = adm_bad ? 0u : m;
+            }
 #pragma unroll
-            for (int j = 0; j < G; ++j)
-                if ((uint32_t)j < m_lane) {
-                    const FmdCand cd = cand_decode(raw[2 * j], raw[2 * j + 1]);
-                    const uint64_t d = cd.x1 - x1w;
-                    bad |= !cd.narrow || cd.x1 < x1w || d + cd.sz > szw_ || cd.sz == 0 || cd.depth > ori_l;
+            for (int t = 0; t < RAWN; ++t)
+                if ((uint32_t)t < adm_cnt && !adm_bad) {
+                    const uint32_t j = adm_base + (uint32_t)t;
+                    const FmdCand cd = cand_decode(raw[2 * t], raw[2 * t + 1]);
+                    const uint64_t d = cd.x1 - X1;
+                    adm_bad |= !cd.narrow || cd.x1 < X1 || d + cd.sz > szw || cd.sz == 0 || cd.depth > ori_l;
                     mc[j * 64] = make_uint4((uint32_t)cd.D, (uint32_t)(cd.D >> 32), (uint32_t)cd.r0, LC_PACK(cd.r0, d & 63u, cd.sz & 63u, (ori_l - cd.depth) & 0xfffu));
                     am |= 1u << j;
                 }
-            X1 = x1w; szw = szw_;
-            if (bad) { hand = 1; am = 0; }     // (sid and meta stay until the hand-over at the top of the next step)
-            else active = true;
-            st = 0;
+            if (st == 2 && adm_h0 != 0 && !adm_bad) st = 3;        // the other half in the next admission pass
+            else {
+                if (adm_bad) { hand = 1; am = 0; }     // (sid and meta stay until the hand-over at the top of the next step)
+                else active = true;
+                st = 0;
+            }
         }
         if (ld1) { sid = l0; meta = l1; st = 2; }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the images are read before the next gather lands in the slots
@@ -361,7 +371,7 @@ int fmd_nei_lane_enabled(void)
     return !(e && atoi(e) == 0);
 }
 // classes whose candidates fit the registers of a lane: up to 21 (the larger group size is the group kernels' business)
-int fmd_nei_lane_class_ok(int cls, int wide) { (void)wide; return cls >= 0 && cls <= 3; }   // up to 16 candidates: the 8 raw words per candidate of an admission are in registers beside the round's state (21: 4 VGPRs short)
+int fmd_nei_lane_class_ok(int cls, int wide) { (void)wide; return cls >= 0 && cls <= 4; }   // up to 21 candidates (32: the group form)
 
 void fmd_launch_nei_lane(int cls, int wide, int n_cu, int per_cu_cap, hipStream_t st, const FmdIndexView &ix, const uint32_t *list, const uint32_t *list_n, uint32_t cap,
                          const fmd_intv_t *listA, fmd_intv_t *listB, fmd_ovlp_rec_t *rec, fmd_intv_t *nei_out, uint32_t max_nei, uint8_t *seq_out,
@@ -388,7 +398,8 @@ void fmd_launch_nei_lane(int cls, int wide, int n_cu, int per_cu_cap, hipStream_
     case 0: LANE_LAUNCH2(0); break;
     case 1: LANE_LAUNCH2(1); break;
     case 2: LANE_LAUNCH2(2); break;
-    default: LANE_LAUNCH2(3); break;
+    case 3: LANE_LAUNCH2(3); break;
+    default: LANE_LAUNCH2(4); break;
     }
 #undef LANE_LAUNCH2
 #undef LANE_LAUNCH_
