@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
                                                     fmd_ovlp_rec_t *__restrict__ rec,
                                                     fmd_intv_t *__restrict__ nei_out, uint32_t max_nei, uint8_t *__restrict__ seq_out,
                                                     uint32_t seq_stride, uint32_t *__restrict__ slow_list, uint32_t *__restrict__ slow_n,
-                                                    const uint32_t *__restrict__ gidx, size_t fix_off, uint32_t *__restrict__ deal, uint32_t down_cap, uint32_t n_max)
+                                                    const uint32_t *__restrict__ gidx, size_t fix_off, uint32_t *__restrict__ deal, uint32_t down_cap, uint32_t n_max, int quiet_on)
 {
     __shared__ uint4 lds[GRP_LDS_U4];
     uint4 *pool = lds + GRP_SLOTS_U4, *stage = pool;
@@ -203,10 +203,20 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
     constexpr int MYK = G == 4 ? 0 : G == 8 ? 1 : G == 12 ? 2 : G == 16 ? 3 : G == 21 ? 4 : 5;
     constexpr int NT = !DYN ? 0 : MYK >= 2 ? 2 : MYK;   // target classes: MYK - 1 and MYK - 2 (further down in one more hop from there); not with the round-robin deal (FMD_NEI_DYN=0, an A/B form: its registers are full)
     uint32_t mv = 0;                                    // group-uniform: 1 + t = this group's strand leaves for target t (class MYK - 1 - t)
+    bool chk_down = false;                              // group-uniform: a round has just ended, the strand goes on
     uint32_t res_cur[NT > 0 ? NT : 1] = {0}, res_end[NT > 0 ? NT : 1] = {0};   // wave-uniform
 
     for (;;) {
-        if (NT > 0 && down_cap) {   // ---- strands that leave for a smaller group (set at the end of the previous step)
+        if (NT > 0 && down_cap) {   // ---- strands that leave for a smaller group
+            if (__ballot(chk_down)) {   // after a round: does the strand fit a smaller group for good?  W = live candidates + sum (size - 1), from ballots (a size of 5 or more: no move)
+                const uint32_t ag = (uint32_t)(__ballot(alive) >> gbase) & GM, nl = (uint32_t)__popc(ag);
+                const uint32_t b2 = (uint32_t)(__ballot(alive && sz >= 2) >> gbase) & GM, b3 = (uint32_t)(__ballot(alive && sz >= 3) >> gbase) & GM;
+                const uint32_t b4 = (uint32_t)(__ballot(alive && sz >= 4) >> gbase) & GM, b5 = (uint32_t)(__ballot(alive && sz >= 5) >> gbase) & GM;
+                const uint32_t Wsum = nl + (uint32_t)(__popc(b2) + __popc(b3) + __popc(b4));
+                if (chk_down && active && nl > 0 && b5 == 0 && Wsum <= (uint32_t)fmd_grp_size(MYK - 1) && nl <= cap && fmd_resume_fits((uint32_t)round, n_nei, nei0_info, 0u))
+                    mv = NT > 1 && Wsum <= (uint32_t)fmd_grp_size(MYK >= 2 ? MYK - 2 : 0) ? 2u : 1u;
+                chk_down = false;
+            }
             if (__ballot(mv != 0)) {
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
@@ -376,6 +386,36 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
         // ---- the reference's sequential loop over the list, as prefix logic on group ballots
         const uint32_t alive_g = (uint32_t)(__ballot(live) >> gbase) & GM;
         const int ncur = __popc(alive_g);
+        // ---- the QUIET round (as in k_ovl_nei_lane): every live candidate of every strand of the wave goes on with exactly ONE base, all of its occurrences, and a read
+        // starts with that child -- nothing ends, nothing is a neighbour, nothing forks or dies: sizes, D, r0, order and categories stand, x[1] takes one LF step.
+        // On reads with errors the long-lived strands are single reads marching to their ends: most of their rounds.  (quiet_on = 0: FMD_GRP_QUIET=0, the A/B switch)
+        if (G <= 8 && quiet_on) {   // (the groups of 4 and 8: where the strands of reads with errors are; the larger instantiations have no registers to spare for it)
+            const int qc = cm ? __ffs((int)cm) - 1 : 0;
+            const uint32_t qs = qc == 1 ? s[1] : qc == 2 ? s[2] : qc == 3 ? s[3] : s[4];
+            const bool lane_q = !live || (cm != 0 && (cm & (cm - 1)) == 0 && qs == sz);
+            if (__ballot(!lane_q || (active && alive_g == 0)) == 0) {
+                if (active && !(LF_GET(flags) & 0x10000u)) { // check_left's rounds (as below): which bases do the reads that start inside X go on with?
+                    uint32_t u = 0;
+#pragma unroll
+                    for (int c = 1; c <= 4; ++c) if ((uint32_t)(__ballot((dm >> c) & 1) >> gbase) & GM) u |= 1u << c;
+                    if (__popc(u) >= 2) LF_SET(flags, LF_GET(flags) | 0x18000u);
+                    else LF_SET(flags, (uint32_t)(round + 1));   // (u != 0: every live lane has its child)
+                }
+                const uint64_t r = fmd_block_rank1(img_e, t, oke + 1, qc, bke);
+                if (live) x1 = (qc == 1 ? ix.cnt[1] : qc == 2 ? ix.cnt[2] : qc == 3 ? ix.cnt[3] : ix.cnt[4]) + r;
+                const uint32_t fk_g = (uint32_t)(__ballot(live && cat != 0) >> gbase) & GM;
+                const int qsrc = alive_g ? gbase + __ffs((int)alive_g) - 1 : lane;
+                const int first_c = (int)(uint32_t)__shfl((int)(uint32_t)qc, qsrc);   // base appended this round = base of the first child in push order (unitig.c:138-139)
+                if (active) {
+                    if (fk_g) flags |= FMD_OVLP_F_FORKED;
+                    if (j == 0 && (uint32_t)(ori_l + round) < seq_stride) seq_out[gs * (size_t)seq_stride + ori_l + round] = (uint8_t)comp6(first_c);
+                    ++round;
+                    chk_down = true;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the images are read before the next gather lands in the slots
+                continue;
+            }
+        }
         const uint32_t nei_g = (uint32_t)(__ballot(is_nei) >> gbase) & GM;
         const uint32_t head_g = (uint32_t)(__ballot(live && cat == j) >> gbase) & GM;   // first lane of each category
         const uint32_t in_cat_upto_j = (uint32_t)(bits_below(j + 1) & ~bits_below(cat));
@@ -479,18 +519,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_nei_grp(FmdIndexView ix, const ui
                     x1 = (uint64_t)(a.y & 0xffu) << 32 | a.x; sz = (a.y >> 8) & 0xffu; cat = (int)(a.y >> 16);
                     D = (uint64_t)a.w << 32 | a.z; r0 = (uint64_t)b.y << 32 | b.x; pos = b.z;
                 }
-                if (NT > 0 && down_cap && n_new <= fmd_grp_size(MYK - 1)) {   // fits a smaller group: for good, if the sum of the live candidates' sizes does
-                    // W = n_new + sum (size - 1), from ballots (sizes of 5 and more: no move) -- the lanes the strand can ever need again
-                    const uint32_t b2 = (uint32_t)(__ballot(alive && sz >= 2) >> gbase) & GM, b5 = (uint32_t)(__ballot(alive && sz >= 5) >> gbase) & GM;
-                    if (b5 == 0 && (uint32_t)n_new <= cap && fmd_resume_fits((uint32_t)round, n_nei, nei0_info, 0u)) {
-                        uint32_t Wsum = (uint32_t)n_new;
-                        if (b2) {
-                            const uint32_t b3 = (uint32_t)(__ballot(alive && sz >= 3) >> gbase) & GM, b4 = (uint32_t)(__ballot(alive && sz >= 4) >> gbase) & GM;
-                            Wsum += (uint32_t)(__popc(b2) + __popc(b3) + __popc(b4));
-                        }
-                        if (Wsum <= (uint32_t)fmd_grp_size(MYK - 1)) mv = NT > 1 && Wsum <= (uint32_t)fmd_grp_size(MYK >= 2 ? MYK - 2 : 0) ? 2u : 1u;
-                    }
-                }
+                chk_down = true;
             } else { // every path is closed (unitig.c:154-178)
                 if (j == 0) {
                     fmd_ovlp_rec_t *o = rec + gs;
@@ -846,9 +875,11 @@ void fmd_launch_nei_grp(int cls, int n_cu, int per_cu_cap, hipStream_t st, const
                         uint32_t seq_stride, uint32_t *slow_list, uint32_t *slow_n, const uint32_t *gidx, size_t fix_off, uint32_t down_cap, int second_pass)
 {
     const uint32_t n_max = second_pass ? down_cap / FMD_FAST_CHUNK * FMD_FAST_CHUNK : 0u;
+    const char *eq = getenv("FMD_GRP_QUIET");
+    const int quiet_on = !(eq && atoi(eq) == 0);
     const bool dyn = nei_dyn() != 0;
     uint32_t *deal = (uint32_t *)list_n + FMD_DEAL_WORD;
-#define GRP_LAUNCH_(K, DY) k_ovl_nei_grp<fmd_grp_size(K), DY><<<n_cu * grp_cap(grp_blocks_per_cu<fmd_grp_size(K), DY>(), per_cu_cap), 64, 0, st>>>(ix, list, list_n, cap, listA, listB, cl, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n, gidx, fix_off, deal, down_cap, n_max)
+#define GRP_LAUNCH_(K, DY) k_ovl_nei_grp<fmd_grp_size(K), DY><<<n_cu * grp_cap(grp_blocks_per_cu<fmd_grp_size(K), DY>(), per_cu_cap), 64, 0, st>>>(ix, list, list_n, cap, listA, listB, cl, rec, nei_out, max_nei, seq_out, seq_stride, slow_list, slow_n, gidx, fix_off, deal, down_cap, n_max, quiet_on)
 #define GRP_LAUNCH(K) do { if (dyn) GRP_LAUNCH_(K, true); else GRP_LAUNCH_(K, false); } while (0)
     switch (cls) {
     case 0: GRP_LAUNCH(0); break;

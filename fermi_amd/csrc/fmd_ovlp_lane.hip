@@ -10,8 +10,8 @@
 // Here a lane owns a strand: its candidates are 16-byte entries of the lane's own column of LDS (D, r0, packed offset / size / start; entry j of lane q at
 // [j][q]: a wave's ds_read_b128 of one j is conflict-free), the round is a loop over them (as registers -- unrolled over G -- they spilled: 515 VGPRs
 // at G = 16), the window comes from the lane's own block image (the wave engine's cooperative gather: 64 strands' blocks per wave instruction), and
-// 64 strands per wave x 8-13 waves per CU (LDS: G + 4 KiB per wave) are in flight instead of 80.  Classes of up to 16 candidates (21 is 4 VGPRs short of
-// holding an admission's raw entries beside the round's state: the group form).  Same results by
+// 64 strands per wave x 8-13 waves per CU (LDS: G + 4 KiB per wave) are in flight instead of 80.  Classes of up to 21 candidates: more than 8 are admitted in two parts, the widest half first (64-88 raw
+// words in registers beside the round's state instead of 128-168); the class of 32 keeps the group form.  Same results by
 // construction: the arithmetic of a round is k_ovl_nei_fast's, statement by statement; a strand that leaves the simple regime is handed to
 // k_ovl_nei_grp in the same FMD_LIST_RESUME form.  FMD_NEI_LANE=0 runs the group form instead (the A/B switch, and the tests' second opinion).
 #include "fmd_kernel_common.h"

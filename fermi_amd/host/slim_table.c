@@ -8,7 +8,9 @@
  *
  *   w[id]   32 bytes, ONE line per plain step of the walk: the unique neighbour's id, the id eight links on (prefetch hint), the
  *           `$read$` interval, rbeg, up to 24 appended bases, the verdict of check_left, the place of the variable part;
- *   var     per id: rank, length, the neighbours as (x0, x1, overlap) of 10 bytes, appended bases that did not fit the line, and
+ *   var     per id: rank, length, the neighbours -- device-linked tables: the overlap alone of a unique neighbour (its interval is
+ *           w[nxt]'s), (x0, overlap) of 6 bytes of several; host-linked tables: (x0, x1, overlap) of 10 bytes --, appended bases that
+ *           did not fit the line, and
  *           the bases of the READ -- 2 bits each, once per read: row 2i+1 is the reverse complement of row 2i (cmd.c:457-469) and
  *           the walk already relies on that (unitig.c:310: the seed's other direction is the reverse strand's extension);
  *   a record with a field beyond those widths (an interval of more than 255 identical reads, a sequence of 65 536 bases or more)
@@ -17,7 +19,7 @@
  * Rows arrive in chunks as the GPU finishes them (fmdh_slim_add: the fat chunk is a staging buffer that is reused), rows that
  * exceeded a capacity are replaced when they have been computed again (fmdh_slim_replace), links and check_left verdicts come from
  * the device's link pass piece by piece (fmdh_slim_link_fold) or from a host pass over the slim rows (fmdh_slim_link_host: several
- * GPUs, and the tests' tables), and fmdh_slim_finalize marks the plain steps.  ~58 bytes per id on 100-base reads.
+ * GPUs, and the tests' tables), and fmdh_slim_finalize marks the plain steps.  53.5 bytes per id on 100-base reads (device-linked).
  */
 #define _GNU_SOURCE
 #include <errno.h>
