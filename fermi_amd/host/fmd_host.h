@@ -85,39 +85,46 @@ static inline void fmdh_row_bases(const fmdh_row_t *x, uint32_t from, uint32_t n
     for (; j < n; ++j) dst[j] = (char)fmd_ovlp_row_base(x->rec, x->max_nei, x->var, from + j);
 }
 /* ---- the walk's own table (slim_table.c): 32 bytes per sequence id that a plain step of the walk reads as ONE line, and a short variable part.
- * What `unitig` holds in host memory: ~58 bytes per id on 100-base reads where the packed rows above took 150-190. */
+ * What `unitig` holds in host memory: 44.5 bytes per id on 100-base reads where the packed rows above took 150-190. */
 #define FMDH_SLIM_CHUNK_SHIFT 22
 #define FMDH_W_ST_MASK 3u          /* bits & 3: 0 = a read the walk can extend, 1 = short (unitig.c:288), 2 = contained (:292), 3 = flagged (a capacity was exceeded) */
 #define FMDH_W_ST_SHORT 1
 #define FMDH_W_ST_CONTAINED 2
 #define FMDH_W_ST_INVALID 3
-#define FMDH_W_PLAIN 4u            /* one neighbour, check_left decided, the appended bases in the line, nothing wide: the step reads w[id] and w[nxt] only */
+#define FMDH_W_PLAIN 4u            /* one neighbour, check_left decided, the appended bases in the line, nothing wide: the step reads w[id] and the line of w[nxt] only */
 #define FMDH_W_CL 8u               /* check_left (unitig.c:206-225) < 0 on the edge to the unique neighbour */
 #define FMDH_W_UNDEC 16u           /* that edge is not decided (or the neighbour has no row): the table is incomplete */
 #define FMDH_W_BIG 32u             /* the variable part is the record itself (64 bytes), its neighbours (32 each), all bases 4 bits each */
 #define FMDH_W_EXTVAR 64u          /* the appended bases are in the variable part, 4 bits each */
 #define FMDH_W_XVAR 128u           /* the variable part is in xvar (rows computed again), voff in units of 8 bytes */
 #define FMDH_W_EXT_INLINE 24
+/* What a line does NOT hold because another one does: k[1] of `$read$` is k[0] of the read's other strand (the bi-interval of a string is
+ * (interval, interval of its reverse complement, size) and '$' is its own complement: exact.c:72-88), and the other strand's row is id ^ 1 --
+ * the other half of the same 64 bytes; the rank fm_retrieve returns (exact.c:59-70: the place of the read's '$' among the sentinels) lies
+ * in [k[0], k[0] + k[2]), so one byte of it is new; the length is the table's common one unless the row says otherwise. */
 typedef struct {
     uint32_t nxt;                  /* id of the unique neighbour's row, 0xffffffff = none */
     uint32_t far;                  /* the row eight accepted links on (a prefetch hint; 0xffffffff = none / not built) */
-    uint32_t k0, k1;               /* k[0], k[1] of the record: the `$read$` interval */
+    uint32_t k0;                   /* k[0] of the record (every row that is not short or flagged, W_BIG ones included when it fits): k[1] of row id ^ 1 */
     uint32_t voff;                 /* where the variable part starts in its chunk (bytes) */
     uint16_t rbeg;                 /* 0xffff = fm6_get_nei returned -1 */
     uint8_t ext[6];                /* the appended bases, (code - 1) in 2 bits each, first one lowest */
     uint8_t ext_len, n_nei, k2, bits;
+    uint8_t dr;                    /* rank - k[0] */
+    uint8_t vfl;                   /* FMDH_V_* */
+    uint16_t ov;                   /* a table linked on the device, ONE neighbour: the overlap length (its x[0] is k0 of the row the link leads to) */
 } fmdh_wrec_t;                     /* 32 bytes */
-/* variable part of a row that is not W_BIG: rank u32, len u16, flags u8, the neighbours, [appended bases, 4 bits each: W_EXTVAR],
- * [the sequence: 2 bits per base, or 4 with V_SEED_N: V_HAS_SEED -- even ids, and rows computed again].
+/* variable part of a row that is not W_BIG: [len u16: V_LEN_VAR], the neighbours, [appended bases, 4 bits each: W_EXTVAR],
+ * [the sequence: 2 bits per base, or 4 with V_SEED_N: V_HAS_SEED -- even ids, and rows computed again].  On reads of one length with one
+ * neighbour each: the sequence of every other row and nothing else.
  * The neighbours (x[0], x[1] of `$neighbour$` and the overlap length): n_nei x {x0 u32, x1 u32, overlap u16} in a table that host threads
- * will link (they need x0 and x1); in a table linked on the device n_nei x {x0 u32, overlap u16}, and for ONE neighbour the overlap alone --
- * its x0 is k0 of the row the link leads to. */
-#define FMDH_V_HDR 7u
+ * will link (they need x0 and x1); in a table linked on the device n_nei x {x0 u32, overlap u16}, and nothing for ONE neighbour (w.ov). */
 #define FMDH_V_NEI 10u
 #define FMDH_V_HAS_OVLP 1u         /* overlap_intv found a candidate (rec.n_ovlp != 0) */
 #define FMDH_V_SEED_N 2u
 #define FMDH_V_HAS_SEED 4u
 #define FMDH_V_RES_SHIFT 3         /* rec.reserved (0 / 1 / 2) as it arrived */
+#define FMDH_V_LEN_VAR 32u         /* the length is not the table's len0: it leads the variable part */
 typedef struct fmdh_slim {
     uint64_t n; int n_shards; uint32_t chunk_shift; uint64_t cps;   /* ids; variable parts are kept per shard (id % n_shards) in chunks of 2^chunk_shift rows, cps chunks per shard */
     fmdh_wrec_t *w;
@@ -125,6 +132,7 @@ typedef struct fmdh_slim {
     uint8_t *xvar; uint64_t x_len, x_cap;
     uint32_t max_nei;                     /* the longest neighbour list of any row */
     uint64_t big_k2;                      /* widest k[2] a line holds (255) */
+    int32_t len0; int len0_set;           /* the length rows have unless they say otherwise (that of the first row that arrived) */
     int host_link;                        /* 1: neighbours in the 10-byte form, lfork kept until the table is linked */
     uint16_t *lfork; uint32_t *row_of;    /* until fmdh_slim_finalize: what fmdh_slim_link_host reads */
     uint64_t *und; uint32_t *und_rev; uint64_t n_und, m_und;   /* rows whose check_left is open, ascending, and the row of the neighbour's reverse strand */
@@ -174,15 +182,16 @@ static inline void fmdh_slim_row(const fmdh_slim_t *s, uint64_t id, fmdh_rowv_t 
         v->has_ovlp = r.n_ovlp != 0; v->reserved = r.reserved; v->vflags = FMDH_V_HAS_SEED | FMDH_V_SEED_N;
         v->nei = p + 64;
     } else {
-        uint32_t rk; uint16_t ln;
-        memcpy(&rk, p, 4); memcpy(&ln, p + 4, 2);
-        v->rank = rk; v->len = ln; v->vflags = p[6]; v->has_ovlp = (p[6] & FMDH_V_HAS_OVLP) != 0; v->reserved = (p[6] >> FMDH_V_RES_SHIFT) & 3;
-        v->k[0] = w->k0; v->k[1] = w->k1; v->k[2] = w->k2; v->rbeg = w->rbeg == 0xffff ? -1 : (int32_t)w->rbeg; v->ext_len = w->ext_len; v->n_nei = w->n_nei;
-        v->nei = p + FMDH_V_HDR;
+        const uint64_t other = id ^ 1;
+        v->vflags = w->vfl; v->has_ovlp = (w->vfl & FMDH_V_HAS_OVLP) != 0; v->reserved = (w->vfl >> FMDH_V_RES_SHIFT) & 3;
+        if (w->vfl & FMDH_V_LEN_VAR) { uint16_t ln; memcpy(&ln, p, 2); v->len = ln; p += 2; } else v->len = s->len0;
+        v->k[0] = w->k0; v->k[1] = other < s->n ? s->w[other].k0 : ~0ull; v->k[2] = w->k2; v->rank = (uint64_t)w->k0 + w->dr;
+        v->rbeg = w->rbeg == 0xffff ? -1 : (int32_t)w->rbeg; v->ext_len = w->ext_len; v->n_nei = w->n_nei;
+        v->nei = p;
     }
     if (v->status != 0) { v->n_nei = 0; v->rbeg = -1; v->ext_len = 0; }
     v->n_stored = v->n_nei;
-    v->nei_bytes = v->big ? v->n_stored * 32 : s->host_link ? v->n_stored * (int)FMDH_V_NEI : v->n_stored == 1 ? 2 : v->n_stored * 6;
+    v->nei_bytes = v->big ? v->n_stored * 32 : s->host_link ? v->n_stored * (int)FMDH_V_NEI : v->n_stored == 1 ? 0 : v->n_stored * 6;
 }
 /* neighbour k of row id: x[0] (and x[1] where the table keeps it, else ~0) of `$neighbour$`, the overlap length */
 static inline void fmdh_slim_nei(const fmdh_slim_t *s, uint64_t id, const fmdh_rowv_t *v, int k, uint64_t *x0, uint64_t *x1, uint64_t *info)
@@ -191,9 +200,7 @@ static inline void fmdh_slim_nei(const fmdh_slim_t *s, uint64_t id, const fmdh_r
     else if (s->host_link) { uint32_t a, b; uint16_t c; const uint8_t *q = v->nei + (size_t)k * FMDH_V_NEI; memcpy(&a, q, 4); memcpy(&b, q + 4, 4); memcpy(&c, q + 8, 2); *x0 = a; *x1 = b; *info = c; }
     else if (v->n_stored == 1) {
         const uint32_t nxt = s->w[id].nxt;
-        uint16_t c;
-        memcpy(&c, v->nei, 2);
-        *info = c; *x1 = ~0ull; *x0 = ~0ull;
+        *info = s->w[id].ov; *x1 = ~0ull; *x0 = ~0ull;
         if (nxt != 0xffffffffu) {
             if (s->w[nxt].bits & FMDH_W_BIG) { fmd_ovlp_rec_t r; memcpy(&r, fmdh_slim_var(s, nxt), 64); *x0 = r.k[0]; }
             else *x0 = s->w[nxt].k0;

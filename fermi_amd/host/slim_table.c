@@ -6,20 +6,21 @@
  * held the packed rows as they left the GPU: record 64 B + offset 8 + neighbours 32 each + bases + row map 4 + links 8 (+ 32 of
  * hop[] and 4 of the skip list on long walks), 150-190 bytes per id, 190 GB for BASELINE's 7*10^8 reads.  The walk needs less:
  *
- *   w[id]   32 bytes, ONE line per plain step of the walk: the unique neighbour's id, the id eight links on (prefetch hint), the
- *           `$read$` interval, rbeg, up to 24 appended bases, the verdict of check_left, the place of the variable part;
- *   var     per id: rank, length, the neighbours -- device-linked tables: the overlap alone of a unique neighbour (its interval is
- *           w[nxt]'s), (x0, overlap) of 6 bytes of several; host-linked tables: (x0, x1, overlap) of 10 bytes --, appended bases that
- *           did not fit the line, and
- *           the bases of the READ -- 2 bits each, once per read: row 2i+1 is the reverse complement of row 2i (cmd.c:457-469) and
- *           the walk already relies on that (unitig.c:310: the seed's other direction is the reverse strand's extension);
+ *   w[id]   32 bytes, ONE line per plain step of the walk: the unique neighbour's id and the overlap with it, the id eight links on
+ *           (prefetch hint), k[0] of the `$read$` interval (k[1] is k[0] of row id ^ 1, the other half of the same 64 bytes) and its size,
+ *           the rank as its distance from k[0], rbeg, up to 24 appended bases, the verdict of check_left, the place of the variable part;
+ *   var     per id: the length where it is not the table's common one; the neighbours where there are several -- device-linked tables:
+ *           (x0, overlap) of 6 bytes; host-linked tables: (x0, x1, overlap) of 10 bytes, a single one too --; appended bases that did not
+ *           fit the line; and the bases of the READ -- 2 bits each, once per read: row 2i+1 is the reverse complement of row 2i
+ *           (cmd.c:457-469) and the walk already relies on that (unitig.c:310: the seed's other direction is the reverse strand's extension);
  *   a record with a field beyond those widths (an interval of more than 255 identical reads, a sequence of 65 536 bases or more)
  *           is kept whole in its variable part (W_BIG).
  *
  * Rows arrive in chunks as the GPU finishes them (fmdh_slim_add: the fat chunk is a staging buffer that is reused), rows that
  * exceeded a capacity are replaced when they have been computed again (fmdh_slim_replace), links and check_left verdicts come from
  * the device's link pass piece by piece (fmdh_slim_link_fold) or from a host pass over the slim rows (fmdh_slim_link_host: several
- * GPUs, and the tests' tables), and fmdh_slim_finalize marks the plain steps.  53.5 bytes per id on 100-base reads (device-linked).
+ * GPUs, and the tests' tables), and fmdh_slim_finalize marks the plain steps.  44.5 bytes per id on 100-base reads (device-linked):
+ * the line and a quarter of a byte per base of every other row.
  */
 #define _GNU_SOURCE
 #include <errno.h>
@@ -66,6 +67,7 @@ fmdh_slim_t *fmdh_slim_new(uint64_t n, int n_shards, int host_link, uint32_t chu
     s = (fmdh_slim_t *)calloc(1, sizeof(*s));
     if (!s) return 0;
     s->n = n; s->n_shards = n_shards; s->chunk_shift = chunk_shift; s->host_link = host_link;
+    s->len0 = -1;                                                          /* (no row's length until one has arrived) */
     { const char *e = getenv("FMD_SLIM_BIG_K2"); s->big_k2 = e && atol(e) > 0 ? (uint64_t)atol(e) : 0xff; }   /* (tests lower the width of k[2] so that fixtures have W_BIG rows) */
     { const uint64_t per = (n + (uint64_t)n_shards - 1) / (uint64_t)n_shards; s->cps = (per >> s->chunk_shift) + 1; }
     s->w = (fmdh_wrec_t *)fmdh_big_alloc((n ? n : 1) * sizeof(fmdh_wrec_t));
@@ -123,14 +125,15 @@ static int row_is_big(const fmd_ovlp_rec_t *r, int st, uint32_t nn, const fmd_in
     if (r->len < 0 || r->len > 0xffff || r->rank > 0xffffffffull) return 1;
     if (st == FMDH_W_ST_SHORT) return 0;                                  /* nothing else of a short row is ever read */
     if (r->k[0] > 0xffffffffull || r->k[1] > 0xffffffffull || r->k[2] > k2_limit) return 1;
+    if (r->rank < r->k[0] || r->rank - r->k[0] > 0xff) return 1;                 /* (never: the read is one of the k[2] <= 255 of its interval) */
     if (st != 0) return 0;
     if (r->rbeg > 0xfffe || r->ext_len < 0 || r->ext_len > 0xff || r->n_nei < 0 || r->n_nei > 0xff) return 1;
     for (k = 0; k < nn; ++k) if (nei[k].x[0] > 0xffffffffull || nei[k].x[1] > 0xffffffffull || nei[k].info > 0xffffull) return 1;
     return 0;
 }
 /* bytes of the variable part; *inl = the appended bases fit the line (<= 24, all A/C/G/T) */
-static inline uint32_t nei_block(int full, uint32_t nn) { return full ? nn * FMDH_V_NEI : nn == 1 ? 2 : nn * 6; }
-static uint32_t row_var_bytes(const fmdh_row_t *x, int st, int big, int own_seed, int full, int *inl, char *tmp /* >= len + ext_len */)
+static inline uint32_t nei_block(int full, uint32_t nn) { return full ? nn * FMDH_V_NEI : nn == 1 ? 0 : nn * 6; }
+static uint32_t row_var_bytes(const fmdh_row_t *x, int st, int big, int own_seed, int full, int32_t len0, int *inl, char *tmp /* >= len + ext_len */)
 {
     const fmd_ovlp_rec_t *r = x->rec;
     *inl = 1;
@@ -139,10 +142,11 @@ static uint32_t row_var_bytes(const fmdh_row_t *x, int st, int big, int own_seed
         *inl = 0;
         return 64 + nn * 32 + (nb + 1) / 2;
     }
-    if (st != 0) return FMDH_V_HDR;
+    if (st == FMDH_W_ST_INVALID) return 0;
+    if (st != 0) return r->len != len0 ? 2 : 0;
     {
         const uint32_t nn = fmd_ovlp_row_nei(r, x->max_nei), len = (uint32_t)r->len, ext = (uint32_t)r->ext_len;
-        uint32_t b = FMDH_V_HDR + nei_block(full, nn), j;
+        uint32_t b = (r->len != len0 ? 2 : 0) + nei_block(full, nn), j;
         int seed_n = 0;
         if (ext > FMDH_W_EXT_INLINE) *inl = 0;
         if ((r->flags & FMD_OVLP_F_PACK4) && (ext || own_seed)) {              /* some base of the row is not A/C/G/T: which? */
@@ -156,7 +160,7 @@ static uint32_t row_var_bytes(const fmdh_row_t *x, int st, int big, int own_seed
     }
 }
 /* writes w (all but nxt / far / the link bits) and the variable part at v; returns the bytes written */
-static uint32_t row_write(const fmdh_row_t *x, int st, int big, int own_seed, int full, fmdh_wrec_t *w, uint8_t *v, char *tmp, uint16_t *lfork_out)
+static uint32_t row_write(const fmdh_row_t *x, int st, int big, int own_seed, int full, int32_t len0, fmdh_wrec_t *w, uint8_t *v, char *tmp, uint16_t *lfork_out)
 {
     const fmd_ovlp_rec_t *r = x->rec;
     const uint32_t nn = st == 0 ? fmd_ovlp_row_nei(r, x->max_nei) : 0;
@@ -166,7 +170,7 @@ static uint32_t row_write(const fmdh_row_t *x, int st, int big, int own_seed, in
     w->rbeg = 0xffff;
     w->bits = (uint8_t)st;
     if (lfork_out) *lfork_out = 0;
-    if (st != FMDH_W_ST_INVALID && st != FMDH_W_ST_SHORT) { w->k0 = (uint32_t)r->k[0]; w->k1 = (uint32_t)r->k[1]; w->k2 = (uint8_t)(r->k[2] > 0xff ? 0xff : r->k[2]); }
+    if (st != FMDH_W_ST_INVALID && st != FMDH_W_ST_SHORT) { w->k0 = (uint32_t)r->k[0]; w->k2 = (uint8_t)(r->k[2] > 0xff ? 0xff : r->k[2]); if (!big) w->dr = (uint8_t)(r->rank - r->k[0]); }
     if (st == 0) {
         w->n_nei = (uint8_t)(r->n_nei > 0xff ? 0xff : r->n_nei < 0 ? 0 : r->n_nei);
         if (r->rbeg >= 0 && r->rbeg <= 0xfffe) w->rbeg = (uint16_t)r->rbeg;
@@ -186,13 +190,13 @@ static uint32_t row_write(const fmdh_row_t *x, int st, int big, int own_seed, in
         }
         return 64 + nn * 32 + (nb + 1) / 2;
     }
-    st32(v, (uint32_t)r->rank);
-    st16(v + 4, (uint16_t)(r->len < 0 ? 0 : r->len));
-    v[6] = (uint8_t)((r->n_ovlp ? FMDH_V_HAS_OVLP : 0) | ((r->reserved > 2 ? 2 : r->reserved) << FMDH_V_RES_SHIFT));
-    if (st != 0) return FMDH_V_HDR;
-    b = FMDH_V_HDR;
+    if (st == FMDH_W_ST_INVALID) return 0;
+    w->vfl = (uint8_t)((r->n_ovlp ? FMDH_V_HAS_OVLP : 0) | ((r->reserved > 2 ? 2 : r->reserved) << FMDH_V_RES_SHIFT));
+    b = 0;
+    if (r->len != len0) { w->vfl |= FMDH_V_LEN_VAR; st16(v, (uint16_t)(r->len < 0 ? 0 : r->len)); b = 2; }
+    if (st != 0) return b;
     if (full) for (k = 0; k < nn; ++k, b += FMDH_V_NEI) { st32(v + b, (uint32_t)x->nei[k].x[0]); st32(v + b + 4, (uint32_t)x->nei[k].x[1]); st16(v + b + 8, (uint16_t)x->nei[k].info); }
-    else if (nn == 1) { st16(v + b, (uint16_t)x->nei[0].info); b += 2; }
+    else if (nn == 1) w->ov = (uint16_t)x->nei[0].info;
     else for (k = 0; k < nn; ++k, b += 6) { st32(v + b, (uint32_t)x->nei[k].x[0]); st16(v + b + 4, (uint16_t)x->nei[k].info); }
     {
         const uint32_t len = (uint32_t)r->len, ext = (uint32_t)r->ext_len;
@@ -214,9 +218,9 @@ static uint32_t row_write(const fmdh_row_t *x, int st, int big, int own_seed, in
             }
         }
         if (own_seed) {
-            v[6] |= FMDH_V_HAS_SEED;
+            w->vfl |= FMDH_V_HAS_SEED;
             if (seed_n) {
-                v[6] |= FMDH_V_SEED_N;
+                w->vfl |= FMDH_V_SEED_N;
                 memset(v + b, 0, (len + 1) / 2);
                 for (j = 0; j < len; ++j) v[b + (j >> 1)] |= (uint8_t)((tmp[j] & 15) << (4 * (j & 1)));
                 b += (len + 1) / 2;
@@ -266,12 +270,12 @@ static void add_main(void *ctx, int tid, int nt)
         int inl;
         if (!tmp || id >= a->s->n) { a->rc[tid] = tmp ? -ERANGE : -ENOMEM; break; }
         if (st == 0 && x.rec->n_nei > 0 && (uint32_t)x.rec->n_nei > mx) mx = (uint32_t)x.rec->n_nei;
-        if (!a->phase) at += (row_var_bytes(&x, st, big, own_seed, a->s->host_link, &inl, tmp) + unit - 1) / unit * unit;
+        if (!a->phase) at += (row_var_bytes(&x, st, big, own_seed, a->s->host_link, a->s->len0, &inl, tmp) + unit - 1) / unit * unit;
         else {
             fmdh_wrec_t *w = &a->s->w[id];
             const uint64_t start = at;
             if (start / unit > 0xffffffffull) { a->rc[tid] = -ERANGE; break; }
-            at += (row_write(&x, st, big, own_seed, a->s->host_link, w, a->dst + at, tmp, a->s->lfork ? &a->s->lfork[id] : 0) + unit - 1) / unit * unit;
+            at += (row_write(&x, st, big, own_seed, a->s->host_link, a->s->len0, w, a->dst + at, tmp, a->s->lfork ? &a->s->lfork[id] : 0) + unit - 1) / unit * unit;
             w->voff = (uint32_t)(start / unit);
             if (a->ids) w->bits |= FMDH_W_XVAR;
         }
@@ -287,6 +291,12 @@ static int add_run(add_t *a, int nt, uint8_t *(*alloc)(add_t *a, uint64_t bytes)
     if ((uint64_t)nt > a->nr / 1024 + 1) nt = (int)(a->nr / 1024 + 1);
     if (nt > 64) nt = 64;
     memset(a->rc, 0, sizeof(a->rc));
+    pthread_mutex_lock(&a->s->mu);          /* the common length: that of the first row that arrives with one (any value is correct: it decides bytes only) */
+    if (!a->s->len0_set) {
+        uint64_t j;
+        for (j = 0; j < a->nr; ++j) if (row_status(&a->f.rec[j]) != FMDH_W_ST_INVALID && a->f.rec[j].len > 0 && a->f.rec[j].len <= 0xffff) { a->s->len0 = a->f.rec[j].len; a->s->len0_set = 1; break; }
+    }
+    pthread_mutex_unlock(&a->s->mu);
     a->phase = 0;
     fmdh_par_for(nt, add_main, a);
     for (k = 0; k < nt; ++k) { if (a->rc[k]) return a->rc[k]; a->slice_off[k] = tot; tot += a->slice_bytes[k]; }

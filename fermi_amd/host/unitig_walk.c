@@ -110,9 +110,9 @@ static int build_far(fmdh_slim_t *s)
 static inline void prefetch_var(const fmdh_slim_t *t, uint32_t row) { const uint8_t *p = fmdh_slim_var(t, row); __builtin_prefetch(p); __builtin_prefetch(p + 64); }
 static inline uint64_t row_rank(const fmdh_slim_t *t, uint64_t row)
 {
-    const uint8_t *p = fmdh_slim_var(t, row);
-    if (t->w[row].bits & FMDH_W_BIG) { fmd_ovlp_rec_t r; memcpy(&r, p, 64); return r.rank; }
-    { uint32_t v; memcpy(&v, p, 4); return v; }
+    const fmdh_wrec_t *h = &t->w[row];
+    if (h->bits & FMDH_W_BIG) { fmd_ovlp_rec_t r; memcpy(&r, fmdh_slim_var(t, row), 64); return r.rank; }
+    return (uint64_t)h->k0 + h->dr;
 }
 
 /* Short unitigs (reads with errors: 10^8 of them at 50 M reads) leave the skip list nothing to look ahead along; what a seed will
@@ -124,6 +124,8 @@ static inline uint64_t row_rank(const fmdh_slim_t *t, uint64_t row)
  * 8 cores: 1.26 s, of which 0.19 s inside walks).  The bit is read as it is NOW, without the speculative walk's logs: a hint decides nothing. */
 static inline int seed_is_used(const walk_t *w, uint64_t j)
 {
+    const unsigned st = w->t->w[j].bits & FMDH_W_ST_MASK;
+    if (st == FMDH_W_ST_SHORT || st == FMDH_W_ST_INVALID) return 1;      /* (returns at once as well, and its line holds no rank) */
     return w->sorted ? bit_get(w->used, j) : bit_get(w->used, row_rank(w->t, j));
 }
 static inline void seed_hints(const walk_t *w, uint64_t i, int staged)
@@ -368,13 +370,13 @@ static int unidir(walk_t *w, uint64_t cur, str_t *s, cov_t *cov, int beg0, uint6
             if (mid != 0xffffffffu) {
                 const fmdh_wrec_t *m = &W[mid];
                 __builtin_prefetch(&w->bend[m->k0 >> 6]);
-                __builtin_prefetch(&w->used[m->k0 >> 6]); __builtin_prefetch(&w->used[m->k1 >> 6]);
+                __builtin_prefetch(&w->used[m->k0 >> 6]); __builtin_prefetch(&w->used[W[mid ^ 1].k0 >> 6]);   /* (k[1] = k[0] of the other strand: the same 64 bytes) */
             }
             ahead[step % JUMP_DIST] = far;
         }
         if ((h->bits & FMDH_W_PLAIN) && !w->no_plain) {                          /* the plain step, from one line (fmdh_wrec_t) and the neighbour's */
             const fmdh_wrec_t *nb = &W[h->nxt];
-            const uint64_t kx[3] = {nb->k0, nb->k1, nb->k2};
+            const uint64_t kx[3] = {nb->k0, W[h->nxt ^ 1].k0, nb->k2};
             const int ext = h->ext_len, rbeg = beg + (int)h->rbeg;
             int k;
             w->last = cur; w->n_nei = 1;
@@ -407,7 +409,7 @@ static int unidir(walk_t *w, uint64_t cur, str_t *s, cov_t *cov, int beg0, uint6
              * link to it is a row of an incomplete table (the neighbour is a non-contained read longer than min_match: it has a row) */
             if (r.n_nei != 1 || nxt == 0xffffffffu) { w->err = -EDOM; return -1; }
             if (W[nxt].bits & FMDH_W_BIG) { fmdh_rowv_t nb; fmdh_slim_row(t, nxt, &nb); kx[0] = nb.k[0]; kx[1] = nb.k[1]; kx[2] = nb.k[2]; }
-            else { kx[0] = W[nxt].k0; kx[1] = W[nxt].k1; kx[2] = W[nxt].k2; }
+            else { kx[0] = W[nxt].k0; kx[1] = ((uint64_t)nxt ^ 1) < t->n ? W[nxt ^ 1].k0 : ~0ull; kx[2] = W[nxt].k2; }
             /* the bases fm6_get_nei appended (unitig.c:139) */
             if (str_reserve(s, (size_t)ori_l + (size_t)r.ext_len + 1)) return -1;
             fmdh_slim_ext(t, cur, &r, s->s + ori_l);

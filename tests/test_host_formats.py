@@ -351,6 +351,26 @@ def test_walks_that_close_on_themselves(oracle_lib, gold, tmp_path, monkeypatch,
     assert got == gold.text_gz("circle.mag.gz") and got.count(b"\n@") + 1 == 3
 
 
+@pytest.mark.parametrize("name", ["tiny", "repeat", "special", "circle", "pairs", "dup32"])
+def test_what_a_line_of_the_slim_table_leaves_to_the_other_strand(oracle_lib, gold, name):
+    """The walk's 32-byte line (fmdh_wrec_t) keeps k[0] and ONE byte of the rank.  What it leaves out is in the record of the read's other strand, row id ^ 1:
+    the bi-interval of `$read$` is (interval, interval of the reverse complement, size) -- k[1] of a row is k[0] of its other strand, k[2] is shared, and the
+    two strands are short / not short together -- and the rank fm_retrieve returns (exact.c:59-70) is one of the k[2] sentinels of the interval."""
+    o = orcbind.OrcIndex(gold.path(name + ".fmd"))
+    n_seq = int(o.mcnt[1])
+    assert n_seq % 2 == 0
+    for mm in (10, 20, 30, 50):
+        rec, _, _ = o.overlap_batch(np.arange(n_seq, dtype=np.uint64), mm, max_len=300, max_nei=16, n_threads=4)
+        ok = (rec["status"] != -1) & ((rec["flags"] & 2) == 0)
+        assert (ok[0::2] == ok[1::2]).all()
+        k, m = rec["k"], ok[0::2]
+        assert m.any()
+        assert (k[0::2, 1] == k[1::2, 0])[m].all() and (k[0::2, 0] == k[1::2, 1])[m].all() and (k[0::2, 2] == k[1::2, 2])[m].all()
+        assert ((rec["rank"] >= k[:, 0]) & (rec["rank"] < k[:, 0] + k[:, 2]))[ok].all()
+        assert (rec["len"][0::2] == rec["len"][1::2]).all()
+    o.close()
+
+
 @pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20), ("special", 20), ("circle", 40)])
 @pytest.mark.parametrize("link", [0, 3])
 def test_slim_table_keeps_what_the_walk_reads(oracle_lib, gold, tmp_path, monkeypatch, name, mm, link):
