@@ -117,9 +117,8 @@ typedef struct {
 /* variable part of a row that is not W_BIG: [len u16: V_LEN_VAR], the neighbours, [appended bases, 4 bits each: W_EXTVAR],
  * [the sequence: 2 bits per base, or 4 with V_SEED_N: V_HAS_SEED -- even ids, and rows computed again].  On reads of one length with one
  * neighbour each: the sequence of every other row and nothing else.
- * The neighbours (x[0], x[1] of `$neighbour$` and the overlap length): n_nei x {x0 u32, x1 u32, overlap u16} in a table that host threads
- * will link (they need x0 and x1); in a table linked on the device n_nei x {x0 u32, overlap u16}, and nothing for ONE neighbour (w.ov). */
-#define FMDH_V_NEI 10u
+ * The neighbours: n_nei x {x[0] of `$neighbour$` u32, overlap u16} where there are several, and nothing for ONE (w.ov; its x[0] is k0 of the row the
+ * link leads to -- a table the host links carries it in w.nxt until then). */
 #define FMDH_V_HAS_OVLP 1u         /* overlap_intv found a candidate (rec.n_ovlp != 0) */
 #define FMDH_V_SEED_N 2u
 #define FMDH_V_HAS_SEED 4u
@@ -133,8 +132,8 @@ typedef struct fmdh_slim {
     uint32_t max_nei;                     /* the longest neighbour list of any row */
     uint64_t big_k2;                      /* widest k[2] a line holds (255) */
     int32_t len0; int len0_set;           /* the length rows have unless they say otherwise (that of the first row that arrived) */
-    int host_link;                        /* 1: neighbours in the 10-byte form, lfork kept until the table is linked */
-    uint16_t *lfork; uint32_t *row_of;    /* until fmdh_slim_finalize: what fmdh_slim_link_host reads */
+    int host_link, linked;                /* host_link: fmdh_slim_link_host will link the rows -- until it has (linked), w.nxt = x[0] of the unique neighbour, w.far = rec.lfork */
+    uint32_t *row_of;                     /* k[0] -> the smallest id with that interval; until fmdh_slim_finalize */
     uint64_t *und; uint32_t *und_rev; uint64_t n_und, m_und;   /* rows whose check_left is open, ascending, and the row of the neighbour's reverse strand */
     pthread_mutex_t mu;
 } fmdh_slim_t;
@@ -142,6 +141,7 @@ fmdh_slim_t *fmdh_slim_new(uint64_t n, int n_shards, int host_link, uint32_t chu
 void fmdh_slim_free(fmdh_slim_t *s);
 uint64_t fmdh_slim_bytes(const fmdh_slim_t *s);
 int fmdh_host_threads(void);       /* FMD_HOST_THREADS, default 16 */
+double fmdh_rss_gb(int peak);       /* resident set of this process now (/proc/self/statm), or its peak so far (getrusage), in GB: the FMD_TIMING lines */
 void fmdh_par_for(int nt, void (*fn)(void *ctx, int tid, int nt), void *ctx);   /* fn(ctx, tid, nt) on nt threads (at most 64), joined */
 /* rows (chunk << FMDH_SLIM_CHUNK_SHIFT) .. + nr of shard g (id = g + n_shards * row) from packed rows as fmd_ovlp_pack_dev writes them: rec[nr], off[nr]
  * (offsets into var); the three buffers are the caller's and are not kept.  Chunks of different shards may be added concurrently. */
@@ -164,7 +164,7 @@ static inline const uint8_t *fmdh_slim_var(const fmdh_slim_t *s, uint64_t id)
 }
 /* a row as the walk's general code reads it */
 typedef struct {
-    const uint8_t *var, *nei;      /* nei: the neighbour entries (FMDH_V_NEI bytes each; 32 in a W_BIG row) */
+    const uint8_t *var, *nei;      /* nei: the neighbour entries (6 bytes each where there are several; 32 in a W_BIG row) */
     uint64_t rank, k[3];
     int32_t len, rbeg, ext_len, n_nei, n_stored;
     int status, has_ovlp, reserved, big, nei_bytes;   /* nei_bytes: of the whole neighbour block */
@@ -191,13 +191,12 @@ static inline void fmdh_slim_row(const fmdh_slim_t *s, uint64_t id, fmdh_rowv_t 
     }
     if (v->status != 0) { v->n_nei = 0; v->rbeg = -1; v->ext_len = 0; }
     v->n_stored = v->n_nei;
-    v->nei_bytes = v->big ? v->n_stored * 32 : s->host_link ? v->n_stored * (int)FMDH_V_NEI : v->n_stored == 1 ? 0 : v->n_stored * 6;
+    v->nei_bytes = v->big ? v->n_stored * 32 : v->n_stored == 1 ? 0 : v->n_stored * 6;
 }
 /* neighbour k of row id: x[0] (and x[1] where the table keeps it, else ~0) of `$neighbour$`, the overlap length */
 static inline void fmdh_slim_nei(const fmdh_slim_t *s, uint64_t id, const fmdh_rowv_t *v, int k, uint64_t *x0, uint64_t *x1, uint64_t *info)
 {
     if (v->big) { fmd_intv_t e; memcpy(&e, v->nei + (size_t)k * 32, 32); *x0 = e.x[0]; *x1 = e.x[1]; *info = e.info; }
-    else if (s->host_link) { uint32_t a, b; uint16_t c; const uint8_t *q = v->nei + (size_t)k * FMDH_V_NEI; memcpy(&a, q, 4); memcpy(&b, q + 4, 4); memcpy(&c, q + 8, 2); *x0 = a; *x1 = b; *info = c; }
     else if (v->n_stored == 1) {
         const uint32_t nxt = s->w[id].nxt;
         *info = s->w[id].ov; *x1 = ~0ull; *x0 = ~0ull;

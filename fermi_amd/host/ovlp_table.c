@@ -317,6 +317,7 @@ static int slim_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_dev
     for (g = 0; g < n_dev; ++g) {
         if (jobs[g].rc) { fprintf(stderr, "[E::%s] GPU %d: %s%s\n", __func__, devices[g], fmd_strerror(jobs[g].rc), jobs[g].sink_rc ? " (folding a chunk into the table)" : ""); rc = 1; }
         if (timing) fprintf(stderr, "[M::%s] GPU %d: index load + transcode %.3f s, rows (GPU + copies + folding) %.3f s\n", __func__, devices[g], jobs[g].t_load, jobs[g].t_rows);
+        if (timing && g == 0) fprintf(stderr, "[M::%s] after the rows: resident set %.2f GB, peak so far %.2f GB\n", __func__, fmdh_rss_gb(0), fmdh_rss_gb(1));
     }
     if (rc) goto done;
     max_len = jobs[0].max_len;
@@ -423,8 +424,8 @@ static int slim_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_dev
         if (fmdh_slim_finalize(s, nt)) { rc = 1; goto done; }
         if (timing) fprintf(stderr, "[M::%s] plain steps marked: %.3f s\n", __func__, now_s() - t1);
     }
-    if (timing) fprintf(stderr, "[M::%s] table of %llu sequences on %d GPU(s): %.3f s, %.1f bytes per row in host memory\n", __func__, (unsigned long long)n_seq, n_dev, now_s() - t0,
-                        n_seq ? (double)fmdh_slim_bytes(s) / (double)n_seq : 0.0);
+    if (timing) fprintf(stderr, "[M::%s] table of %llu sequences on %d GPU(s): %.3f s, %.1f bytes per row in host memory (%.2f GB); resident set now %.2f GB, peak so far %.2f GB\n", __func__,
+                        (unsigned long long)n_seq, n_dev, now_s() - t0, n_seq ? (double)fmdh_slim_bytes(s) / (double)n_seq : 0.0, (double)fmdh_slim_bytes(s) / 1e9, fmdh_rss_gb(0), fmdh_rss_gb(1));
 done:
     for (g = 0; g < n_dev; ++g) {
         if (jobs[g].tabjob) fmd_ovlp_tabjob_free(jobs[g].tabjob);

@@ -28,6 +28,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/resource.h>
+#include <unistd.h>
 #include "fmd_host.h"
 
 /* ------------------------------------------------------------------------------------------------ a parallel for */
@@ -45,6 +47,18 @@ void fmdh_par_for(int nt, void (*fn)(void *ctx, int tid, int nt), void *ctx)
     for (k = 1; k < nt; ++k) started[k] = pthread_create(&tid[k], 0, par_main, &job[k]) == 0;
     par_main(&job[0]);
     for (k = 1; k < nt; ++k) { if (started[k]) pthread_join(tid[k], 0); else par_main(&job[k]); }   /* no thread: here, afterwards */
+}
+double fmdh_rss_gb(int peak)
+{
+    if (peak) { struct rusage ru; return getrusage(RUSAGE_SELF, &ru) == 0 ? (double)ru.ru_maxrss * 1024.0 / 1e9 : 0.0; }
+    {
+        FILE *f = fopen("/proc/self/statm", "r");
+        unsigned long long total = 0, res = 0;
+        if (!f) return 0.0;
+        if (fscanf(f, "%llu %llu", &total, &res) != 2) res = 0;
+        fclose(f);
+        return (double)res * (double)sysconf(_SC_PAGESIZE) / 1e9;
+    }
 }
 int fmdh_host_threads(void)
 {
@@ -73,16 +87,15 @@ fmdh_slim_t *fmdh_slim_new(uint64_t n, int n_shards, int host_link, uint32_t chu
     s->w = (fmdh_wrec_t *)fmdh_big_alloc((n ? n : 1) * sizeof(fmdh_wrec_t));
     s->var = (uint8_t **)calloc((size_t)n_shards * s->cps, sizeof(uint8_t *));
     s->var_len = (uint64_t *)calloc((size_t)n_shards * s->cps, 8);
-    if (host_link) s->lfork = (uint16_t *)fmdh_big_alloc((n ? n : 1) * 2);
     pthread_mutex_init(&s->mu, 0);
-    if (!s->w || !s->var || !s->var_len || (host_link && !s->lfork)) { fmdh_slim_free(s); return 0; }
+    if (!s->w || !s->var || !s->var_len) { fmdh_slim_free(s); return 0; }
     return s;
 }
 
 static void slim_free_transients(fmdh_slim_t *s)
 {
-    fmdh_big_free(s->lfork); fmdh_big_free(s->row_of);
-    s->lfork = 0; s->row_of = 0;
+    fmdh_big_free(s->row_of);
+    s->row_of = 0;
 }
 
 void fmdh_slim_free(fmdh_slim_t *s)
@@ -132,8 +145,8 @@ static int row_is_big(const fmd_ovlp_rec_t *r, int st, uint32_t nn, const fmd_in
     return 0;
 }
 /* bytes of the variable part; *inl = the appended bases fit the line (<= 24, all A/C/G/T) */
-static inline uint32_t nei_block(int full, uint32_t nn) { return full ? nn * FMDH_V_NEI : nn == 1 ? 0 : nn * 6; }
-static uint32_t row_var_bytes(const fmdh_row_t *x, int st, int big, int own_seed, int full, int32_t len0, int *inl, char *tmp /* >= len + ext_len */)
+static inline uint32_t nei_block(uint32_t nn) { return nn == 1 ? 0 : nn * 6; }
+static uint32_t row_var_bytes(const fmdh_row_t *x, int st, int big, int own_seed, int32_t len0, int *inl, char *tmp /* >= len + ext_len */)
 {
     const fmd_ovlp_rec_t *r = x->rec;
     *inl = 1;
@@ -146,7 +159,7 @@ static uint32_t row_var_bytes(const fmdh_row_t *x, int st, int big, int own_seed
     if (st != 0) return r->len != len0 ? 2 : 0;
     {
         const uint32_t nn = fmd_ovlp_row_nei(r, x->max_nei), len = (uint32_t)r->len, ext = (uint32_t)r->ext_len;
-        uint32_t b = (r->len != len0 ? 2 : 0) + nei_block(full, nn), j;
+        uint32_t b = (r->len != len0 ? 2 : 0) + nei_block(nn), j;
         int seed_n = 0;
         if (ext > FMDH_W_EXT_INLINE) *inl = 0;
         if ((r->flags & FMD_OVLP_F_PACK4) && (ext || own_seed)) {              /* some base of the row is not A/C/G/T: which? */
@@ -159,8 +172,9 @@ static uint32_t row_var_bytes(const fmdh_row_t *x, int st, int big, int own_seed
         return b;
     }
 }
-/* writes w (all but nxt / far / the link bits) and the variable part at v; returns the bytes written */
-static uint32_t row_write(const fmdh_row_t *x, int st, int big, int own_seed, int full, int32_t len0, fmdh_wrec_t *w, uint8_t *v, char *tmp, uint16_t *lfork_out)
+/* writes w (all but nxt / far / the link bits) and the variable part at v; returns the bytes written.  host_link: what the host's link pass needs of a row
+ * travels in the two fields that pass fills -- x[0] of the unique neighbour in w.nxt, rec.lfork in w.far (fmdh_slim_link_host) */
+static uint32_t row_write(const fmdh_row_t *x, int st, int big, int own_seed, int host_link, int32_t len0, fmdh_wrec_t *w, uint8_t *v, char *tmp)
 {
     const fmd_ovlp_rec_t *r = x->rec;
     const uint32_t nn = st == 0 ? fmd_ovlp_row_nei(r, x->max_nei) : 0;
@@ -169,13 +183,12 @@ static uint32_t row_write(const fmdh_row_t *x, int st, int big, int own_seed, in
     w->nxt = w->far = 0xffffffffu;
     w->rbeg = 0xffff;
     w->bits = (uint8_t)st;
-    if (lfork_out) *lfork_out = 0;
     if (st != FMDH_W_ST_INVALID && st != FMDH_W_ST_SHORT) { w->k0 = (uint32_t)r->k[0]; w->k2 = (uint8_t)(r->k[2] > 0xff ? 0xff : r->k[2]); if (!big) w->dr = (uint8_t)(r->rank - r->k[0]); }
     if (st == 0) {
         w->n_nei = (uint8_t)(r->n_nei > 0xff ? 0xff : r->n_nei < 0 ? 0 : r->n_nei);
         if (r->rbeg >= 0 && r->rbeg <= 0xfffe) w->rbeg = (uint16_t)r->rbeg;
         w->ext_len = (uint8_t)(r->ext_len > 0xff ? 0xff : r->ext_len < 0 ? 0 : r->ext_len);
-        if (lfork_out) *lfork_out = r->lfork;
+        if (host_link) w->far = r->lfork;
     }
     if (big) {
         const uint32_t nb = st == 0 ? (uint32_t)r->len + (uint32_t)r->ext_len : 0;
@@ -195,8 +208,7 @@ static uint32_t row_write(const fmdh_row_t *x, int st, int big, int own_seed, in
     b = 0;
     if (r->len != len0) { w->vfl |= FMDH_V_LEN_VAR; st16(v, (uint16_t)(r->len < 0 ? 0 : r->len)); b = 2; }
     if (st != 0) return b;
-    if (full) for (k = 0; k < nn; ++k, b += FMDH_V_NEI) { st32(v + b, (uint32_t)x->nei[k].x[0]); st32(v + b + 4, (uint32_t)x->nei[k].x[1]); st16(v + b + 8, (uint16_t)x->nei[k].info); }
-    else if (nn == 1) w->ov = (uint16_t)x->nei[0].info;
+    if (nn == 1) { w->ov = (uint16_t)x->nei[0].info; if (host_link) w->nxt = (uint32_t)x->nei[0].x[0]; }
     else for (k = 0; k < nn; ++k, b += 6) { st32(v + b, (uint32_t)x->nei[k].x[0]); st16(v + b + 4, (uint16_t)x->nei[k].info); }
     {
         const uint32_t len = (uint32_t)r->len, ext = (uint32_t)r->ext_len;
@@ -270,12 +282,12 @@ static void add_main(void *ctx, int tid, int nt)
         int inl;
         if (!tmp || id >= a->s->n) { a->rc[tid] = tmp ? -ERANGE : -ENOMEM; break; }
         if (st == 0 && x.rec->n_nei > 0 && (uint32_t)x.rec->n_nei > mx) mx = (uint32_t)x.rec->n_nei;
-        if (!a->phase) at += (row_var_bytes(&x, st, big, own_seed, a->s->host_link, a->s->len0, &inl, tmp) + unit - 1) / unit * unit;
+        if (!a->phase) at += (row_var_bytes(&x, st, big, own_seed, a->s->len0, &inl, tmp) + unit - 1) / unit * unit;
         else {
             fmdh_wrec_t *w = &a->s->w[id];
             const uint64_t start = at;
             if (start / unit > 0xffffffffull) { a->rc[tid] = -ERANGE; break; }
-            at += (row_write(&x, st, big, own_seed, a->s->host_link, a->s->len0, w, a->dst + at, tmp, a->s->lfork ? &a->s->lfork[id] : 0) + unit - 1) / unit * unit;
+            at += (row_write(&x, st, big, own_seed, a->s->host_link && !a->s->linked, a->s->len0, w, a->dst + at, tmp) + unit - 1) / unit * unit;
             w->voff = (uint32_t)(start / unit);
             if (a->ids) w->bits |= FMDH_W_XVAR;
         }
@@ -422,21 +434,34 @@ static void lk_main(void *ctx, int tid, int nt)
     }
     for (i = lo; i < hi; ++i) {
         fmdh_wrec_t *w = &s->w[i];
-        fmdh_rowv_t v;
-        uint64_t x0, x1;
+        uint64_t x0;
         uint32_t rev;
-        int res;
+        int res, reserved, rbeg;
         if (!has_edge(w)) continue;
-        fmdh_slim_row(s, i, &v);
-        { uint64_t info; fmdh_slim_nei(s, i, &v, 0, &x0, &x1, &info); }
+        /* x[0] of `$neighbour$`: where row_write left it (w.nxt), or in the record a W_BIG row keeps.  The neighbour's other strand is the row beside the
+         * neighbour's: x[1] of `$neighbour$` is k[0] of that strand (fmd_host.h), and where several identical reads share the interval (row_of = the
+         * smallest id) the smallest of the other strands' ids is its partner -- but for a read that is its own reverse complement, whose two rows
+         * are one record twice. */
+        if (w->bits & FMDH_W_BIG) {
+            fmd_ovlp_rec_t r; fmd_intv_t e;
+            const uint8_t *p = fmdh_slim_var(s, i);
+            memcpy(&r, p, 64); memcpy(&e, p + 64, 32);
+            x0 = e.x[0]; reserved = r.reserved > 2 ? 2 : r.reserved; rbeg = r.rbeg;
+        } else { x0 = w->nxt; reserved = (w->vfl >> FMDH_V_RES_SHIFT) & 3; rbeg = w->rbeg; }
         w->nxt = x0 < s->n ? s->row_of[x0] : 0xffffffffu;
-        rev = x1 < s->n ? s->row_of[x1] : 0xffffffffu;
         if (w->nxt == 0xffffffffu) { w->bits |= FMDH_W_UNDEC; continue; }
-        res = v.reserved;
+        rev = ((uint64_t)w->nxt ^ 1) < s->n ? (w->nxt ^ 1u) : 0xffffffffu;
+        res = reserved;
         if (res == 2 || L->force_exact) {     /* check_left_simple was not run on this row: the rounds of the neighbour's reverse strand decide it (include/fmd_hip.h) */
-            const int d = rev != 0xffffffffu && !L->force_exact && s->lfork ? fmd_lfork_decide(s->lfork[rev], v.rbeg) : 1;
+            int d = 1;
+            if (rev != 0xffffffffu && !L->force_exact) {
+                const fmdh_wrec_t *q = &s->w[rev];
+                uint16_t lf = (uint16_t)q->far;
+                if (q->bits & FMDH_W_BIG) { fmd_ovlp_rec_t r; memcpy(&r, fmdh_slim_var(s, rev), 64); lf = r.lfork; }
+                if ((q->bits & FMDH_W_ST_MASK) == 0) d = fmd_lfork_decide(lf, rbeg);
+            }
             res = d == 1 ? 2 : d < 0;
-            if (L->force_exact && v.reserved != 2) res = v.reserved;   /* (the exact answer is there already) */
+            if (L->force_exact && reserved != 2) res = reserved;   /* (the exact answer is there already) */
         }
         set_verdict(s, i, res, rev);
         if (w->bits & FMDH_W_UNDEC) {
@@ -468,6 +493,7 @@ int fmdh_slim_link_host(fmdh_slim_t *s, int n_threads)
     s->row_of = (uint32_t *)fmdh_big_alloc((s->n ? s->n : 1) * 4);
     if (!L || !s->row_of) { free(L); return -ENOMEM; }
     memset(s->row_of, 0xff, s->n * 4);
+    if (!s->host_link || s->linked) { free(L); return -EINVAL; }   /* (x[0] and lfork travel in w.nxt / w.far of a host_link table until this pass has run: once) */
     L->s = s; L->force_exact = getenv("FMD_CHECK_LEFT_EXACT") != NULL;
     s->n_und = 0;
     for (L->phase = 0; L->phase < 2; ++L->phase) fmdh_par_for(nt, lk_main, L);
@@ -478,6 +504,7 @@ int fmdh_slim_link_host(fmdh_slim_t *s, int n_threads)
     }
     for (k = 0; k < 64; ++k) { free(L->und[k]); free(L->rev[k]); }
     free(L);
+    s->linked = 1;
     return rc;
 }
 void fmdh_slim_undecided(const fmdh_slim_t *s, const uint64_t **ids, uint64_t *n) { *ids = s->und; *n = s->n_und; }
@@ -505,6 +532,7 @@ static void fin_main(void *ctx, int tid, int nt)
     for (i = lo; i < hi; ++i) {
         fmdh_wrec_t *w = &s->w[i];
         w->bits &= (uint8_t)~FMDH_W_PLAIN;
+        w->far = 0xffffffffu;                                  /* (lfork of a host_link table until now; the walk builds the skip list here) */
         if (i + 8 < hi && s->w[i + 8].nxt != 0xffffffffu) __builtin_prefetch(&s->w[s->w[i + 8].nxt]);
         if (!has_edge(w) || w->nxt == 0xffffffffu || (w->bits & (FMDH_W_EXTVAR | FMDH_W_UNDEC | FMDH_W_BIG))) continue;
         if (s->w[w->nxt].bits & FMDH_W_BIG) continue;

@@ -982,7 +982,7 @@ int fmdh_unitig_walk_slim(fmdh_slim_t *t, uint64_t n_seq, int min_match, const u
     }
     t_begin = wall_s();
     if (hints && long_walks) w.have_far = build_far(t);   /* 0: the plain chase */
-    if (w.timing && w.have_far) fprintf(stderr, "[M::%s] skip list over the links: %.3f s\n", __func__, wall_s() - t_begin);
+    if (w.timing && w.have_far) fprintf(stderr, "[M::%s] skip list over the links: %.3f s; resident set now %.2f GB, peak so far %.2f GB\n", __func__, wall_s() - t_begin, fmdh_rss_gb(0), fmdh_rss_gb(1));
     const int seed_stages = !(getenv("FMD_WALK_SEED_STAGES") && atoi(getenv("FMD_WALK_SEED_STAGES")) == 0);
     {
         const int nt = walk_threads();
@@ -1005,7 +1005,7 @@ done:
     if (oq_open) { const int e = outq_close(&oq); if (!rc) rc = e; }
     if (w.timing && w.n_hops + (uint64_t)(w.t_uni > 0)) fprintf(stderr, "[M::%s] walks of the sequential loop: %llu reads appended in %.3f s, turning the strings round %.3f s, record text %.3f s\n", __func__,
                                                                 (unsigned long long)w.n_hops, w.t_uni, w.t_turn, w.t_text);
-    if (w.timing) fprintf(stderr, "[M::%s] walk of %llu sequences: %.3f s\n", __func__, (unsigned long long)n_seq, wall_s() - t_begin);
+    if (w.timing) fprintf(stderr, "[M::%s] walk of %llu sequences: %.3f s; resident set now %.2f GB, peak so far %.2f GB\n", __func__, (unsigned long long)n_seq, wall_s() - t_begin, fmdh_rss_gb(0), fmdh_rss_gb(1));
     free(w.used); free(w.bend); free(w.visited);
     if (b_ok) seedbuf_free(&b);
     return rc;

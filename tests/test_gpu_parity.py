@@ -353,7 +353,7 @@ def test_smem_lists_and_refill_policies(gpu, oracle_lib, monkeypatch, sm):
     d.close(); o.close()
 
 
-@pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20)])
+@pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20), ("palin", 40)])
 def test_unitig_cli_equals_fermi_unitig_t1(gpu, gold, tmp_path, name, mm):
     """`fermi-amd unitig -l mm x.fmd` (GPU overlap table + host walk) == `fermi unitig -t1` bytes."""
     import subprocess, os
@@ -367,7 +367,7 @@ def test_unitig_cli_equals_fermi_unitig_t1(gpu, gold, tmp_path, name, mm):
         assert got == gold.text_gz(name + ".mag.gz")
 
 
-@pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20), ("special", 20)])
+@pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20), ("special", 20), ("palin", 40)])
 @pytest.mark.parametrize("n_rep", [2, 3])
 def test_unitig_sharded_over_replicas_equals_one_gpu(gpu, gold, tmp_path, name, mm, n_rep):
     """`fermi-amd unitig -g a,b[,c]`: the index replicated n_rep times, replica g computing the rows of the ids

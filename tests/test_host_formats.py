@@ -351,7 +351,7 @@ def test_walks_that_close_on_themselves(oracle_lib, gold, tmp_path, monkeypatch,
     assert got == gold.text_gz("circle.mag.gz") and got.count(b"\n@") + 1 == 3
 
 
-@pytest.mark.parametrize("name", ["tiny", "repeat", "special", "circle", "pairs", "dup32"])
+@pytest.mark.parametrize("name", ["tiny", "repeat", "special", "circle", "pairs", "dup32", "palin"])
 def test_what_a_line_of_the_slim_table_leaves_to_the_other_strand(oracle_lib, gold, name):
     """The walk's 32-byte line (fmdh_wrec_t) keeps k[0] and ONE byte of the rank.  What it leaves out is in the record of the read's other strand, row id ^ 1:
     the bi-interval of `$read$` is (interval, interval of the reverse complement, size) -- k[1] of a row is k[0] of its other strand, k[2] is shared, and the
@@ -371,7 +371,7 @@ def test_what_a_line_of_the_slim_table_leaves_to_the_other_strand(oracle_lib, go
     o.close()
 
 
-@pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20), ("special", 20), ("circle", 40)])
+@pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20), ("special", 20), ("circle", 40), ("palin", 40)])
 @pytest.mark.parametrize("link", [0, 3])
 def test_slim_table_keeps_what_the_walk_reads(oracle_lib, gold, tmp_path, monkeypatch, name, mm, link):
     """The walk runs over its own table (host/slim_table.c): 32 bytes per row + a short variable part instead of the packed rows (64-byte record, 32-byte
