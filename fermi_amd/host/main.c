@@ -271,10 +271,9 @@ int main(int argc, char *argv[])
     /* (what a caller's clock sees beyond this: 0.6 s at 10^7 reads for loading the runtime's libraries before main and for the kernel taking the process's
      * mappings and its GPU context down after it -- ending the process with _exit instead of the exit handlers changed nothing measurable) */
     if (timing) {
-        struct rusage ru;
         fflush(stdout);
         fprintf(stderr, "[M::main] %s: %.3f s from the start of the process\n", argv[1], main_now() - t_start);
-        if (getrusage(RUSAGE_SELF, &ru) == 0) fprintf(stderr, "[M::main] %s: peak resident set %.2f GB\n", argv[1], (double)ru.ru_maxrss * 1024.0 / 1e9);
+        fprintf(stderr, "[M::main] %s: peak resident set %.2f GB\n", argv[1], fmdh_rss_gb(1));   /* (VmHWM: of this program, not of what exec'ed it) */
     }
     return rc;
 }

@@ -171,6 +171,8 @@ static int rows_sink(void *ctx, uint64_t first_row, size_t n_rows, const fmd_ovl
     (void)var_bytes;
     if (first_row & (((uint64_t)1 << STREAM_CHUNK_SHIFT) - 1)) return FMD_E_ARG;
     rc = fmdh_slim_add(j->slim, j->g, first_row >> STREAM_CHUNK_SHIFT, rec, off, var, j->max_nei, n_rows, j->conv_threads);
+    if (j->g == 0 && getenv("FMD_TIMING") && ((first_row >> STREAM_CHUNK_SHIFT) & 31) == 0)    /* where the resident set stands as the rows arrive */
+        fprintf(stderr, "[M::%s] rows %llu ..: resident set %.2f GB (peak so far %.2f)\n", __func__, (unsigned long long)first_row, fmdh_rss_gb(0), fmdh_rss_gb(1));
     if (rc) { j->sink_rc = rc; return FMD_E_NOMEM; }
     for (k = 0; k < n_rows; ++k) if (rec[k].flags & FMD_OVLP_F_OVERFLOW) {
         if (j->n_flagged == j->m_flagged) {
@@ -307,6 +309,7 @@ static int slim_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_dev
     if (job_open(&jobs[0])) { fprintf(stderr, "[E::%s] GPU %d: %s\n", __func__, devices[0], fmd_strerror(jobs[0].rc)); rc = 1; goto done; }
     n_seq = jobs[0].n_seq;
     if (n_seq_out) *n_seq_out = n_seq;
+    if (timing) fprintf(stderr, "[M::%s] index in HBM: resident set %.2f GB, peak so far %.2f GB\n", __func__, fmdh_rss_gb(0), fmdh_rss_gb(1));
     if (n_seq >= 0xffffffffull) { fprintf(stderr, "[E::%s] %llu sequences: the walk's rows hold 32-bit ids\n", __func__, (unsigned long long)n_seq); rc = 1; goto done; }
     s = fmdh_slim_new(n_seq, n_dev, !one_gpu, STREAM_CHUNK_SHIFT);
     if (!s) { fprintf(stderr, "[E::%s] out of memory (%llu rows)\n", __func__, (unsigned long long)n_seq); rc = 1; goto done; }

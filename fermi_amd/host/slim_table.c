@@ -28,8 +28,6 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <sys/resource.h>
-#include <unistd.h>
 #include "fmd_host.h"
 
 /* ------------------------------------------------------------------------------------------------ a parallel for */
@@ -48,17 +46,19 @@ void fmdh_par_for(int nt, void (*fn)(void *ctx, int tid, int nt), void *ctx)
     par_main(&job[0]);
     for (k = 1; k < nt; ++k) { if (started[k]) pthread_join(tid[k], 0); else par_main(&job[k]); }   /* no thread: here, afterwards */
 }
+/* The resident set of THIS program: VmRSS / VmHWM of /proc/self/status.  (getrusage's ru_maxrss is not that: at execve the kernel folds the high-water mark
+ * of the address space that is being replaced into it, so a CLI started by fork + exec from a large process reports its parent's -- a 16 GB Python
+ * process made every `unitig` it started "peak at 16.0 GB".) */
 double fmdh_rss_gb(int peak)
 {
-    if (peak) { struct rusage ru; return getrusage(RUSAGE_SELF, &ru) == 0 ? (double)ru.ru_maxrss * 1024.0 / 1e9 : 0.0; }
-    {
-        FILE *f = fopen("/proc/self/statm", "r");
-        unsigned long long total = 0, res = 0;
-        if (!f) return 0.0;
-        if (fscanf(f, "%llu %llu", &total, &res) != 2) res = 0;
-        fclose(f);
-        return (double)res * (double)sysconf(_SC_PAGESIZE) / 1e9;
-    }
+    FILE *f = fopen("/proc/self/status", "r");
+    const char *key = peak ? "VmHWM:" : "VmRSS:";
+    char line[256];
+    double kb = 0.0;
+    if (!f) return 0.0;
+    while (fgets(line, sizeof(line), f)) if (strncmp(line, key, 6) == 0) { kb = atof(line + 6); break; }
+    fclose(f);
+    return kb * 1024.0 / 1e9;
 }
 int fmdh_host_threads(void)
 {

@@ -99,11 +99,40 @@ static void far_main(void *p, int tid, int nt)
     else if (j->lv == 3) for (i = a; i < b; ++i) { const uint32_t x = W[i].far; j->tmp[i] = x != 0xffffffffu ? W[x].far : x; }               /* eight */
     else for (i = a; i < b; ++i) W[i].far = j->tmp[i];
 }
+/* The same w[].far without the temporary array (4 bytes per id: 5.6 GB at BASELINE's 1.4*10^9 ids, on top of a table of 62 GB): every row follows its
+ * own eight links -- w[].nxt only, which nothing writes -- FAR_LANES rows at a time so that their misses overlap.  Eight random lines per row instead of
+ * the doubling's three: for tables whose temporary would be large (FMD_FAR_CHASE=0 / 1 overrides; the result is the same array). */
+#define FAR_LANES 32
+static void far_chase_main(void *p, int tid, int nt)
+{
+    fmdh_wrec_t *W = ((far_job_t *)p)->s->w;
+    const uint64_t n = ((far_job_t *)p)->s->n, a = n * (uint64_t)tid / (uint64_t)nt, b = n * (uint64_t)(tid + 1) / (uint64_t)nt;
+    uint64_t i;
+    for (i = a; i < b; i += FAR_LANES) {
+        const int m = b - i < FAR_LANES ? (int)(b - i) : FAR_LANES;
+        uint32_t cur[FAR_LANES];
+        int k, h;
+        for (k = 0; k < m; ++k) { cur[k] = W[i + k].nxt; if (cur[k] != 0xffffffffu) __builtin_prefetch(&W[cur[k]]); }
+        for (h = 1; h < JUMP_DIST; ++h)
+            for (k = 0; k < m; ++k) if (cur[k] != 0xffffffffu) { cur[k] = W[cur[k]].nxt; if (cur[k] != 0xffffffffu) __builtin_prefetch(&W[cur[k]]); }
+        for (k = 0; k < m; ++k) W[i + k].far = cur[k];
+    }
+}
 static int build_far(fmdh_slim_t *s)
 {
-    far_job_t j = {s, (uint32_t *)fmdh_big_alloc((s->n ? s->n : 1) * 4), 0};
-    if (!j.tmp) return 0;
+    far_job_t j = {s, 0, 0};
+    const char *e = getenv("FMD_FAR_CHASE");
+    if (e ? atoi(e) != 0 : s->n >= ((uint64_t)1 << 29)) { fmdh_par_for(fmdh_host_threads(), far_chase_main, &j); return 1; }
+    j.tmp = (uint32_t *)fmdh_big_alloc((s->n ? s->n : 1) * 4);
+    if (!j.tmp) { fmdh_par_for(fmdh_host_threads(), far_chase_main, &j); return 1; }    /* (no room for the temporary: the slower way) */
     for (j.lv = 1; j.lv <= 4; ++j.lv) fmdh_par_for(fmdh_host_threads(), far_main, &j);
+    if (getenv("FMD_FAR_CHECK")) {   /* tests: the other construction gives the same array */
+        uint64_t i, bad = 0;
+        for (i = 0; i < s->n; ++i) j.tmp[i] = s->w[i].far;
+        fmdh_par_for(fmdh_host_threads(), far_chase_main, &j);
+        for (i = 0; i < s->n; ++i) bad += j.tmp[i] != s->w[i].far;
+        if (bad) { fprintf(stderr, "[E::%s] the two constructions of the skip list differ in %llu rows\n", __func__, (unsigned long long)bad); fmdh_big_free(j.tmp); return -1; }
+    }
     fmdh_big_free(j.tmp);
     return 1;
 }
@@ -981,7 +1010,7 @@ int fmdh_unitig_walk_slim(fmdh_slim_t *t, uint64_t n_seq, int min_match, const u
                               long_walks ? "long walks, skip list" : "short walks, the seeds' hints only");
     }
     t_begin = wall_s();
-    if (hints && long_walks) w.have_far = build_far(t);   /* 0: the plain chase */
+    if (hints && long_walks) { w.have_far = build_far(t); if (w.have_far < 0) return -EDOM; }   /* 0: the plain chase */
     if (w.timing && w.have_far) fprintf(stderr, "[M::%s] skip list over the links: %.3f s; resident set now %.2f GB, peak so far %.2f GB\n", __func__, wall_s() - t_begin, fmdh_rss_gb(0), fmdh_rss_gb(1));
     const int seed_stages = !(getenv("FMD_WALK_SEED_STAGES") && atoi(getenv("FMD_WALK_SEED_STAGES")) == 0);
     {

@@ -101,14 +101,17 @@ def test_unitig_walk_prefetch_hints_change_nothing(oracle_lib, gold, tmp_path, m
     rec["reserved"] = 2
     outs = []
     monkeypatch.setenv("FMD_WALK_LONG", "1")
-    for no_jump in (False, True):
-        if no_jump:
+    monkeypatch.setenv("FMD_FAR_CHECK", "1")      # the skip list by pointer doubling (one temporary array) == by following eight links per row (none: large tables)
+    for no_jump in (False, True, "chase"):
+        if no_jump is True:
             monkeypatch.setenv("FMD_WALK_NO_JUMP", "1")
-        out = str(tmp_path / ("o%d.mag" % no_jump))
+        if no_jump == "chase":
+            monkeypatch.delenv("FMD_WALK_NO_JUMP"); monkeypatch.setenv("FMD_FAR_CHASE", "1")
+        out = str(tmp_path / ("o%s.mag" % no_jump))
         hostlib.unitig_walk(_packed_shards(rec.copy(), nei, seq, n_shards), n_seq, 50, out, max_nei=8, seq_stride=seq.shape[1], link=2,
                             resolve=lambda ids: exact[ids.astype(np.int64)])
         outs.append(open(out, "rb").read())
-    assert outs[0] == outs[1] == gold.text_gz("tiny.mag.gz")
+    assert outs[0] == outs[1] == outs[2] == gold.text_gz("tiny.mag.gz")
     o.close()
 
 
@@ -122,6 +125,7 @@ def test_one_line_per_plain_step_changes_nothing(oracle_lib, gold, tmp_path, mon
     monkeypatch.setenv("FMD_WALK_THREADS", str(threads))
     monkeypatch.setenv("FMD_WALK_CHUNK", "16")
     monkeypatch.setenv("FMD_WALK_LONG", "1")   # (the walk builds hop[] and the skip list where a sample of the links shows long walks: here, always)
+    monkeypatch.setenv("FMD_FAR_CHECK", "1")   # (and checks its two constructions of the skip list against each other: loops, forks, ends)
     o = orcbind.OrcIndex(gold.path(name + ".fmd"))
     n_seq = int(o.mcnt[1])
     rec, nei, seq = o.overlap_batch(np.arange(n_seq, dtype=np.uint64), mm, max_len=100, max_nei=8, n_threads=4)
