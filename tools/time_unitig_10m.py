@@ -35,3 +35,11 @@ p = subprocess.run([AMD, "unitig", "-l50", D + "/a.fmd"], stdout=open(D + "/c.ma
 print("unitig -l50 with FMD_TABLE_DIR=%s/pages (%s): %.1f s" % (D, subprocess.run(["df", "--output=fstype,avail", "-h", D + "/pages"], capture_output=True, text=True).stdout.split("\n")[1].strip(), time.time() - t),
       "md5", hashlib.md5(open(D + "/c.mag", "rb").read()).hexdigest())
 print("\n".join(l for l in p.stderr.decode().splitlines() if "M::" in l))
+# the host-linked form (several GPUs: here two replicas on GPU 0, and one GPU with FMD_HOST_LINK=1) and the skip list without its temporary array
+for label, cmd, e in (("-g 0,0 (two replicas, host threads link the rows)", [AMD, "unitig", "-l50", "-g", "0,0", D + "/a.fmd"], env),
+                      ("FMD_HOST_LINK=1", [AMD, "unitig", "-l50", D + "/a.fmd"], dict(env, FMD_HOST_LINK="1")),
+                      ("FMD_FAR_CHASE=1", [AMD, "unitig", "-l50", D + "/a.fmd"], dict(env, FMD_FAR_CHASE="1"))):
+    t = time.time()
+    p = subprocess.run(cmd, stdout=open(D + "/d.mag", "wb"), stderr=subprocess.PIPE, env=e)
+    print("unitig -l50 %s: %.1f s rc %d" % (label, time.time() - t, p.returncode), "md5", hashlib.md5(open(D + "/d.mag", "rb").read()).hexdigest())
+    print("\n".join(l for l in p.stderr.decode().splitlines() if "link pass" in l or "skip list" in l or "table of" in l or "peak resident" in l))
