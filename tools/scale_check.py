@@ -286,7 +286,7 @@ if "unitig" in sys.argv[5:] and not noref:
             continue
         t0 = time.time()
         h, nb = hashlib.md5(), 0
-        pr = subprocess.Popen([exe, "unitig", "-l50", fmd_path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, FMD_TIMING="1"))
+        pr = subprocess.Popen(os.environ.get("FMD_CLI_WRAP", "").split() + [exe, "unitig", "-l50", fmd_path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, FMD_TIMING="1"))   # (FMD_CLI_WRAP: e.g. a profiler in front of the CLI)
         import threading
         errbuf = []
         th = threading.Thread(target=lambda: errbuf.append(pr.stderr.read())); th.start()
