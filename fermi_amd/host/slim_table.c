@@ -9,9 +9,8 @@
  *   w[id]   32 bytes, ONE line per plain step of the walk: the unique neighbour's id and the overlap with it, the id eight links on
  *           (prefetch hint), k[0] of the `$read$` interval (k[1] is k[0] of row id ^ 1, the other half of the same 64 bytes) and its size,
  *           the rank as its distance from k[0], rbeg, up to 24 appended bases, the verdict of check_left, the place of the variable part;
- *   var     per id: the length where it is not the table's common one; the neighbours where there are several -- device-linked tables:
- *           (x0, overlap) of 6 bytes; host-linked tables: (x0, x1, overlap) of 10 bytes, a single one too --; appended bases that did not
- *           fit the line; and the bases of the READ -- 2 bits each, once per read: row 2i+1 is the reverse complement of row 2i
+ *   var     per id: the length where it is not the table's common one; the neighbours where there are several, (x0, overlap) of 6 bytes;
+ *           appended bases that did not fit the line; and the bases of the READ -- 2 bits each, once per read: row 2i+1 is the reverse complement of row 2i
  *           (cmd.c:457-469) and the walk already relies on that (unitig.c:310: the seed's other direction is the reverse strand's extension);
  *   a record with a field beyond those widths (an interval of more than 255 identical reads, a sequence of 65 536 bases or more)
  *           is kept whole in its variable part (W_BIG).
@@ -19,8 +18,9 @@
  * Rows arrive in chunks as the GPU finishes them (fmdh_slim_add: the fat chunk is a staging buffer that is reused), rows that
  * exceeded a capacity are replaced when they have been computed again (fmdh_slim_replace), links and check_left verdicts come from
  * the device's link pass piece by piece (fmdh_slim_link_fold) or from a host pass over the slim rows (fmdh_slim_link_host: several
- * GPUs, and the tests' tables), and fmdh_slim_finalize marks the plain steps.  44.5 bytes per id on 100-base reads (device-linked):
- * the line and a quarter of a byte per base of every other row.
+ * GPUs, and the tests' tables: until it has run, x[0] of a row's unique neighbour travels in w.nxt and rec.lfork in w.far, the fields it
+ * fills), and fmdh_slim_finalize marks the plain steps.  44.5 bytes per id on 100-base reads: the line and a quarter of a byte per base
+ * of every other row.
  */
 #define _GNU_SOURCE
 #include <errno.h>

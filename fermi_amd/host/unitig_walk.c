@@ -78,7 +78,7 @@ typedef struct {
 
 /* The walk is a pointer chase: the next row is known when w[row] has arrived, one DRAM miss (~90 ns) per read and nothing
  * to overlap it with -- 1.8 s per 10^7 reads.  A chase cannot be prefetched, a chase with a skip list can: w[row].far = the
- * row 2^JUMP_LOG links further on (pointer doubling over w[].nxt, all host threads), and visiting a row prefetches the line the
+ * row 2^JUMP_LOG links further on (build_far, all host threads), and visiting a row prefetches the line the
  * visit JUMP_DIST steps later will read; half way there, when that line has arrived, the bitmap words its step will test and set.
  * Hints only: where the walk stops or turns, a prefetch was wasted, nothing else.  The PLAIN step -- one neighbour, check_left decided,
  * the appended bases in the line: all but the last step of every walk -- reads w[row] and the neighbour's w[] (its `$read$` interval),
