@@ -131,6 +131,7 @@ typedef struct fmdh_slim {
     uint8_t *xvar; uint64_t x_len, x_cap;
     uint32_t max_nei;                     /* the longest neighbour list of any row */
     uint64_t big_k2;                      /* widest k[2] a line holds (255) */
+    double t_add[4];                      /* FMD_TIMING: seconds in fmdh_slim_add's sizes pass, allocation, rows pass; calls */
     int32_t len0; int len0_set;           /* the length rows have unless they say otherwise (that of the first row that arrived) */
     int host_link, linked;                /* host_link: fmdh_slim_link_host will link the rows -- until it has (linked), w.nxt = x[0] of the unique neighbour, w.far = rec.lfork */
     uint32_t *row_of;                     /* k[0] -> the smallest id with that interval; until fmdh_slim_finalize */

@@ -320,7 +320,8 @@ static int slim_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_dev
     for (g = 0; g < n_dev; ++g) {
         if (jobs[g].rc) { fprintf(stderr, "[E::%s] GPU %d: %s%s\n", __func__, devices[g], fmd_strerror(jobs[g].rc), jobs[g].sink_rc ? " (folding a chunk into the table)" : ""); rc = 1; }
         if (timing) fprintf(stderr, "[M::%s] GPU %d: index load + transcode %.3f s, rows (GPU + copies + folding) %.3f s\n", __func__, devices[g], jobs[g].t_load, jobs[g].t_rows);
-        if (timing && g == 0) fprintf(stderr, "[M::%s] after the rows: resident set %.2f GB, peak so far %.2f GB\n", __func__, fmdh_rss_gb(0), fmdh_rss_gb(1));
+        if (timing && g == 0) fprintf(stderr, "[M::%s] after the rows: resident set %.2f GB, peak so far %.2f GB; folding shard 0 (%d threads, %.0f pieces): sizes %.3f s, allocation %.3f s, rows %.3f s\n", __func__,
+                                      fmdh_rss_gb(0), fmdh_rss_gb(1), jobs[0].conv_threads, s->t_add[3], s->t_add[0], s->t_add[1], s->t_add[2]);
     }
     if (rc) goto done;
     max_len = jobs[0].max_len;

@@ -28,6 +28,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include "fmd_host.h"
 
 /* ------------------------------------------------------------------------------------------------ a parallel for */
@@ -296,10 +297,12 @@ static void add_main(void *ctx, int tid, int nt)
     if (!a->phase) { a->slice_bytes[tid] = at; a->max_nei[tid] = mx; }
 }
 /* sizes, then the rows; *bytes = the size of the variable parts, (*alloc)(ctx, bytes) = where they go */
+static double wall_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static int add_run(add_t *a, int nt, uint8_t *(*alloc)(add_t *a, uint64_t bytes))
 {
     uint64_t tot = 0;
     int k;
+    double t0, t1, t2, t3;
     if ((uint64_t)nt > a->nr / 1024 + 1) nt = (int)(a->nr / 1024 + 1);
     if (nt > 64) nt = 64;
     memset(a->rc, 0, sizeof(a->rc));
@@ -310,12 +313,17 @@ static int add_run(add_t *a, int nt, uint8_t *(*alloc)(add_t *a, uint64_t bytes)
     }
     pthread_mutex_unlock(&a->s->mu);
     a->phase = 0;
+    t0 = wall_now();
     fmdh_par_for(nt, add_main, a);
     for (k = 0; k < nt; ++k) { if (a->rc[k]) return a->rc[k]; a->slice_off[k] = tot; tot += a->slice_bytes[k]; }
+    t1 = wall_now();
     a->dst = alloc(a, tot);
     if (!a->dst) return -ENOMEM;
     a->phase = 1;
+    t2 = wall_now();
     fmdh_par_for(nt, add_main, a);
+    t3 = wall_now();
+    if (a->g == 0) { a->s->t_add[0] += t1 - t0; a->s->t_add[1] += t2 - t1; a->s->t_add[2] += t3 - t2; a->s->t_add[3] += 1; }   /* (shard 0's calls: one writer) */
     for (k = 0; k < nt; ++k) if (a->rc[k]) return a->rc[k];
     pthread_mutex_lock(&a->s->mu);
     for (k = 0; k < nt; ++k) if (a->max_nei[k] > a->s->max_nei) a->s->max_nei = a->max_nei[k];
