@@ -172,6 +172,109 @@ __global__ void k_tile_select(Text text, uint64_t n, int depth, uint32_t code, u
     }
 }
 
+// The same two sweeps over the 4-bit text of the in-place builder, sixteen positions per 64-bit word.  Symbol by symbol (above) a position costs ~25
+// instructions, and config 5 asks 341 buckets x 2 sweeps x 1.4*10^11 positions of them: ~140 of the 350 s of its build.  A prefix of `depth` <= 4
+// symbols is `depth` nibbles of the text: nibble j of the word shifted down by j symbols against symbol j of the code, all sixteen positions at once
+// (a nibble is zero where the exclusive-or with the replicated symbol is); a code with a '$' in it compares up to that '$' only, as prefix_code
+// does.  A lane owns one word of a turn (64 words = 1024 positions per wave instruction, 512 bytes coalesced) and the first symbols of the next;
+// the tile at the end of the text, where "the next" may lie outside it, goes symbol by symbol.
+struct Match4 { uint64_t pat[4]; int de; };
+static Match4 match4_of(uint32_t code, int depth)
+{
+    Match4 m; m.de = depth;
+    for (int j = 0; j < 4; ++j) m.pat[j] = 0;
+    for (int j = 0; j < depth; ++j) {
+        const uint64_t sy = (code >> (3 * (depth - 1 - j))) & 7u;
+        m.pat[j] = sy * 0x1111111111111111ull;
+        if (sy == 0) { m.de = j + 1; break; }
+    }
+    return m;
+}
+__device__ __forceinline__ uint64_t match16(uint64_t w, uint64_t nx, const Match4 &m)   // bit 4i = position i of the word starts the prefix
+{
+    const uint64_t ones = 0x1111111111111111ull;
+    uint64_t acc = ones;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j < m.de) {
+            const uint64_t y = j ? (w >> (4 * j)) | (nx << (64 - 4 * j)) : w, z = y ^ m.pat[j];
+            acc &= ~(z | z >> 1 | z >> 2 | z >> 3);
+        }
+    }
+    return acc & ones;
+}
+#define SEL_TILE_WORDS (1u << (SEL_TILE_SHIFT - 4))
+__global__ void k_tile_count4(Text4 text, uint64_t n, int depth, uint32_t code, Match4 m4, uint64_t n_tiles, uint64_t *__restrict__ counts)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t *__restrict__ p64 = (const uint64_t *)text.p;
+    for (uint64_t tile = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < n_tiles; tile += (uint64_t)gridDim.x * (blockDim.x >> 6)) {
+        const uint64_t t0 = tile << SEL_TILE_SHIFT, t1 = t0 + (1ull << SEL_TILE_SHIFT) < n ? t0 + (1ull << SEL_TILE_SHIFT) : n;
+        uint32_t c = 0;
+        if (t0 + (1ull << SEL_TILE_SHIFT) + 4 <= n) {
+            const uint64_t w0 = t0 >> 4;
+            for (uint32_t it = 0; it < SEL_TILE_WORDS; it += 64) { const uint64_t wi = w0 + it + (uint64_t)lane; c += (uint32_t)__popcll(match16(p64[wi], p64[wi + 1], m4)); }
+        } else for (uint64_t t = t0 + (uint64_t)lane; t < t1; t += 64) c += prefix_code(text, n, depth, t) == code;
+        for (int o = 32; o; o >>= 1) c += __shfl_xor((int)c, o);
+        if (lane == 0) counts[tile] = c;
+    }
+}
+__global__ void k_tile_select4(Text4 text, uint64_t n, int depth, uint32_t code, Match4 m4, uint64_t n_tiles, const uint64_t *__restrict__ offset, uint64_t *__restrict__ ids)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t *__restrict__ p64 = (const uint64_t *)text.p;
+    for (uint64_t tile = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < n_tiles; tile += (uint64_t)gridDim.x * (blockDim.x >> 6)) {
+        const uint64_t t0 = tile << SEL_TILE_SHIFT, t1 = t0 + (1ull << SEL_TILE_SHIFT) < n ? t0 + (1ull << SEL_TILE_SHIFT) : n;
+        uint64_t base = offset[tile];
+        if (t0 + (1ull << SEL_TILE_SHIFT) + 4 <= n) {
+            const uint64_t w0 = t0 >> 4;
+            for (uint32_t it = 0; it < SEL_TILE_WORDS; it += 64) {
+                const uint64_t wi = w0 + it + (uint64_t)lane;
+                uint64_t acc = match16(p64[wi], p64[wi + 1], m4);
+                const uint32_t cnt = (uint32_t)__popcll(acc);
+                if (__ballot(cnt != 0) == 0) continue;
+                uint32_t inc = cnt;                                 // matches of the lanes up to this one: the lanes' words are in text order
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += v; }
+                uint64_t at = base + inc - cnt;
+                while (acc) { const int b = __ffsll((long long)acc) - 1; ids[at++] = (wi << 4) + (uint64_t)(b >> 2); acc &= acc - 1; }
+                base += (uint64_t)(uint32_t)__shfl((int)inc, 63);
+            }
+        } else {
+            for (uint64_t tb = t0; tb < t1; tb += 64) {
+                const uint64_t t = tb + (uint64_t)lane;
+                const bool hit = t < t1 && prefix_code(text, n, depth, t) == code;
+                const uint64_t mk = __ballot(hit);
+                if (hit) ids[base + (uint64_t)__popcll(mk & ((1ull << lane) - 1))] = t;
+                base += (uint64_t)__popcll(mk);
+            }
+        }
+    }
+}
+// the two sweeps of a bucket: the word-parallel kernels for the 4-bit text (FMD_BUILD_SELECT_BYTES=1: symbol by symbol, the A/B switch), the generic ones otherwise
+template <class Text>
+static void launch_tile_count(hipStream_t st, unsigned grid, Text text, uint64_t n, int depth, uint32_t code, uint64_t n_tiles, uint64_t *counts)
+{
+    k_tile_count<<<grid, 256, 0, st>>>(text, n, depth, code, n_tiles, counts);
+}
+template <class Text>
+static void launch_tile_select(hipStream_t st, unsigned grid, Text text, uint64_t n, int depth, uint32_t code, uint64_t n_tiles, const uint64_t *offset, uint64_t *ids)
+{
+    k_tile_select<<<grid, 256, 0, st>>>(text, n, depth, code, n_tiles, offset, ids);
+}
+static bool select_words() { static const bool on = !(getenv("FMD_BUILD_SELECT_BYTES") && atoi(getenv("FMD_BUILD_SELECT_BYTES"))); return on; }
+template <>
+void launch_tile_count<Text4>(hipStream_t st, unsigned grid, Text4 text, uint64_t n, int depth, uint32_t code, uint64_t n_tiles, uint64_t *counts)
+{
+    if (depth <= 4 && select_words()) k_tile_count4<<<grid, 256, 0, st>>>(text, n, depth, code, match4_of(code, depth), n_tiles, counts);
+    else k_tile_count<<<grid, 256, 0, st>>>(text, n, depth, code, n_tiles, counts);
+}
+template <>
+void launch_tile_select<Text4>(hipStream_t st, unsigned grid, Text4 text, uint64_t n, int depth, uint32_t code, uint64_t n_tiles, const uint64_t *offset, uint64_t *ids)
+{
+    if (depth <= 4 && select_words()) k_tile_select4<<<grid, 256, 0, st>>>(text, n, depth, code, match4_of(code, depth), n_tiles, offset, ids);
+    else k_tile_select<<<grid, 256, 0, st>>>(text, n, depth, code, n_tiles, offset, ids);
+}
+
 // ---- FMD_BUILD_PARTITION=1 (off by default: tested on the fixtures only): the suffixes that have ENDED before a chunk -- distance to their '$' <= 21 * chunk,
 // key 0 -- keep their order in front of the others, which is all a stable sort would do with them; they are 83 % of a bucket of 100-bp reads in the last chunk
 // and 62 / 42 / 21 % in the ones before.  Two stable selections over tiles of the id array (count, scan, scatter by ballot prefix), then keys and sort for the rest.
@@ -303,9 +406,9 @@ static int build_bucketed(hipStream_t st, Text text, uint64_t n, uint32_t max_le
             DALLOC(stmp, sb);
         }
         if (tm) { t1 = bt_now(st, tm); t_alloc += t1 - t0; t0 = t1; }
-        k_tile_count<<<sel_grid, 256, 0, st>>>(text, n, depth, code, n_tiles, (uint64_t *)tile_cnt.p);
+        launch_tile_count(st, sel_grid, text, n, depth, code, n_tiles, (uint64_t *)tile_cnt.p);
         FMD_HIP_TRY(fmd_exclusive_sum(tmp.p, tb, (uint64_t *)tile_cnt.p, (uint64_t *)tile_off.p, (size_t)n_tiles, st));
-        k_tile_select<<<sel_grid, 256, 0, st>>>(text, n, depth, code, n_tiles, (const uint64_t *)tile_off.p, (uint64_t *)ids_a.p);
+        launch_tile_select(st, sel_grid, text, n, depth, code, n_tiles, (const uint64_t *)tile_off.p, (uint64_t *)ids_a.p);
         uint64_t *cur = (uint64_t *)ids_a.p;
         if (tm) { t1 = bt_now(st, tm); t_sel += t1 - t0; t0 = t1; }
         if (!has_end) {
