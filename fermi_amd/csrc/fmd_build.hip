@@ -173,7 +173,7 @@ __global__ void k_tile_select(Text text, uint64_t n, int depth, uint32_t code, u
 }
 
 // The same two sweeps over the 4-bit text of the in-place builder, sixteen positions per 64-bit word.  Symbol by symbol (above) a position costs ~25
-// instructions, and config 5 asks 341 buckets x 2 sweeps x 1.4*10^11 positions of them: ~140 of the 350 s of its build.  A prefix of `depth` <= 4
+// instructions, and config 5 asks 341 buckets x 2 sweeps x 1.4*10^11 positions of them: ~285 of the 350 s its build took.  A prefix of `depth` <= 4
 // symbols is `depth` nibbles of the text: nibble j of the word shifted down by j symbols against symbol j of the code, all sixteen positions at once
 // (a nibble is zero where the exclusive-or with the replicated symbol is); a code with a '$' in it compares up to that '$' only, as prefix_code
 // does.  A lane owns one word of a turn (64 words = 1024 positions per wave instruction, 512 bytes coalesced) and the first symbols of the next;
