@@ -1,5 +1,7 @@
+#define _GNU_SOURCE
 /* main.c -- `fermi-amd`: the sub-commands of fermi (main.c:101-124) that sit on the FMD hot path,
  * same argv surface as cmd.c, index work on MI355X.  No CPU fallback: without a GPU it says so. */
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -235,6 +237,41 @@ static int main_remap(int argc, char *argv[]) /* cmd.c:218-251 */
 
 #include <time.h>
 static double main_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+/* On a host with several NUMA nodes the process stays on the node it started on (FMD_NUMA=off: wherever the scheduler puts it; FMD_NUMA=n: node n): the
+ * tables of `unitig` and `correct` are filled by the host threads and then read at random by the thread that commits -- first touch puts a page on
+ * the toucher's node, and a walk that runs on the other one pays the remote latency on half of its steps.  The threads created afterwards, the
+ * runtime's included, inherit the mask.  Returns the node, -1 when nothing was done. */
+static int stay_on_one_node(void)
+{
+    const char *e = getenv("FMD_NUMA");
+    int node, n_nodes = 0, cpu = sched_getcpu(), found = -1;
+    char path[128], buf[4096];
+    cpu_set_t set;
+    if (e && strcmp(e, "off") == 0) return -1;
+    for (node = 0; node < 64; ++node) {
+        FILE *f;
+        char *q;
+        cpu_set_t cs;
+        int any = 0;
+        snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+        f = fopen(path, "r");
+        if (!f) break;
+        ++n_nodes;
+        if (!fgets(buf, sizeof(buf), f)) buf[0] = 0;
+        fclose(f);
+        CPU_ZERO(&cs);
+        for (q = buf; *q && *q != '\n';) {          /* "0-63,128-191" */
+            long a = strtol(q, &q, 10), b = a;
+            if (*q == '-') b = strtol(q + 1, &q, 10);
+            for (; a <= b && a < CPU_SETSIZE; ++a) { CPU_SET((int)a, &cs); any = 1; }
+            if (*q == ',') ++q;
+        }
+        if (any && ((e && atoi(e) == node && e[0] >= '0' && e[0] <= '9') || (!e && cpu >= 0 && cpu < CPU_SETSIZE && CPU_ISSET(cpu, &cs)))) { set = cs; found = node; }
+    }
+    if (n_nodes < 2 || found < 0) return -1;
+    return sched_setaffinity(0, sizeof(set), &set) == 0 ? found : -1;
+}
+
 int main(int argc, char *argv[])
 {
     if (argc < 2) {
@@ -254,6 +291,7 @@ int main(int argc, char *argv[])
     const int timing = getenv("FMD_TIMING") != 0;
     int rc;
     setvbuf(stdout, 0, _IOFBF, 4 << 20); /* the outputs are hundreds of MB of short lines */
+    { const int node = stay_on_one_node(); if (timing && node >= 0) fprintf(stderr, "[M::main] the process stays on NUMA node %d\n", node); }
     if (fmd_device_count() <= 0) {
         fprintf(stderr, "[E::main] %s\n", fmd_strerror(FMD_E_NODEV));
         return 1;

@@ -61,6 +61,18 @@ double fmdh_rss_gb(int peak)
     fclose(f);
     return kb * 1024.0 / 1e9;
 }
+/* anonymous memory of this process that sits in transparent huge pages (AnonHugePages of /proc/self/smaps_rollup), in GB: fmd_table_alloc asks for them
+ * (MADV_HUGEPAGE) and the walk's random reads of an 8 GB table miss the TLB on every step without */
+double fmdh_thp_gb(void)
+{
+    FILE *f = fopen("/proc/self/smaps_rollup", "r");
+    char line[256];
+    double kb = -1.0;
+    if (!f) return -1.0;
+    while (fgets(line, sizeof(line), f)) if (strncmp(line, "AnonHugePages:", 14) == 0) { kb = atof(line + 14); break; }
+    fclose(f);
+    return kb < 0 ? -1.0 : kb * 1024.0 / 1e9;
+}
 int fmdh_host_threads(void)
 {
     const char *e = getenv("FMD_HOST_THREADS");

@@ -1035,7 +1035,7 @@ done:
     if (oq_open) { const int e = outq_close(&oq); if (!rc) rc = e; }
     if (w.timing && w.n_hops + (uint64_t)(w.t_uni > 0)) fprintf(stderr, "[M::%s] walks of the sequential loop: %llu reads appended in %.3f s, turning the strings round %.3f s, record text %.3f s\n", __func__,
                                                                 (unsigned long long)w.n_hops, w.t_uni, w.t_turn, w.t_text);
-    if (w.timing) fprintf(stderr, "[M::%s] walk of %llu sequences: %.3f s; resident set now %.2f GB, peak so far %.2f GB\n", __func__, (unsigned long long)n_seq, wall_s() - t_begin, fmdh_rss_gb(0), fmdh_rss_gb(1));
+    if (w.timing) fprintf(stderr, "[M::%s] walk of %llu sequences: %.3f s; resident set now %.2f GB (%.2f GB of it in transparent huge pages), peak so far %.2f GB\n", __func__, (unsigned long long)n_seq, wall_s() - t_begin, fmdh_rss_gb(0), fmdh_thp_gb(), fmdh_rss_gb(1));
     free(w.used); free(w.bend); free(w.visited);
     if (b_ok) seedbuf_free(&b);
     return rc;
