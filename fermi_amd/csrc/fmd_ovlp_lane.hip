@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64, FMD_LANE_LB) void k_ovl_nei_lane(FmdIndexView i
                                                                 uint32_t cap, const fmd_intv_t *__restrict__ listA, fmd_intv_t *__restrict__ listB, fmd_ovlp_rec_t *__restrict__ rec,
                                                                 fmd_intv_t *__restrict__ nei_out, uint32_t max_nei, uint8_t *__restrict__ seq_out, uint32_t seq_stride,
                                                                 uint32_t *__restrict__ gen_list, uint32_t *__restrict__ gen_n, uint32_t *__restrict__ bail_n,
-                                                                const uint32_t *__restrict__ gidx, uint32_t *__restrict__ queue, uint32_t tk_chunk, uint32_t slow_min)
+                                                                const uint32_t *__restrict__ gidx, uint32_t *__restrict__ queue, uint32_t tk_chunk, uint32_t slow_min, uint32_t adm_min)
 {
     using W = LaneW<M>;
     constexpr bool WIDE = sizeof(M) == 8;
@@ -142,7 +142,10 @@ __global__ __launch_bounds__(64, FMD_LANE_LB) void k_ovl_nei_lane(FmdIndexView i
         uint4 raw[2 * RAWN];
         uint32_t l0 = 0, l1 = 0, g_in = 0;
         // (the candidates' decode is RAWN x 40 instructions for the wave however many lanes take part: not before `slow_min` lanes wait for it, unless nobody has a round to do)
-        const bool ld2 = st >= 2 && ((uint32_t)__popcll(__ballot(st >= 2)) >= slow_min || __ballot(active) == 0);
+        // (both ballots are taken by the WHOLE wave before the per-lane test: behind `st >= 2 &&` they would run with EXEC cut down to the waiting lanes,
+        // none of which is `active`, and the gate would always be open -- which is how rounds 5's numbers were taken; FMD_LANE_ADM_GATE=0 is that form)
+        const uint64_t adm_wait_m = __ballot(st >= 2), adm_act_m = __ballot(active);
+        const bool ld2 = st >= 2 && ((uint32_t)__popcll(adm_wait_m) >= adm_min || adm_act_m == 0);
         const uint32_t adm_m = meta & 0xffffu, adm_h0 = HALVES == 2 ? adm_m / 2 : 0u;                 // the parts: [h0, m) first, then [0, h0)
         const uint32_t adm_base = st == 2 ? adm_h0 : 0u, adm_cnt = st == 2 ? adm_m - adm_h0 : adm_h0;
         if (ld2) {
@@ -383,6 +386,8 @@ void fmd_launch_nei_lane(int cls, int wide, int n_cu, int per_cu_cap, hipStream_
     const uint32_t tk_chunk = et && atoi(et) >= 16 ? (uint32_t)atoi(et) : 256u;
     const char *es = getenv("FMD_LANE_BATCH");                      // lanes that must wait for the full round code (and for the candidates' decode) before the wave runs it
     const uint32_t slow_min = es && atoi(es) >= 1 ? (uint32_t)atoi(es) : 32u;
+    const char *ea = getenv("FMD_LANE_ADM_GATE");                   // lanes that must wait for the candidates' decode of an admission (1 = never held back: the form every number up to round 5 was taken with)
+    const uint32_t adm_min = ea && atoi(ea) >= 1 ? (uint32_t)atoi(ea) : 1u;
 #define LANE_LAUNCH_(K, MM) do { \
         static int cached = 0; \
         if (!cached) cached = lane_blocks_per_cu((const void *)k_ovl_nei_lane<fmd_grp_size(K), MM>, sizeof(uint4) * ((sizeof(MM) == 8 ? FMD_WAVE_LDS_U4 : FMD_SLOT_U4) + 64 * fmd_grp_size(K))); \
@@ -391,7 +396,7 @@ void fmd_launch_nei_lane(int cls, int wide, int n_cu, int per_cu_cap, hipStream_
         if (e && atoi(e) > 0 && atoi(e) < per) per = atoi(e); \
         int grid = n_cu * per; \
         if (grid > FMD_FAST_MAX_WAVES) grid = FMD_FAST_MAX_WAVES; \
-        k_ovl_nei_lane<fmd_grp_size(K), MM><<<grid, 64, 0, st>>>(ix, list, list_n, cap, listA, listB, rec, nei_out, max_nei, seq_out, seq_stride, gen_list, gen_n, bail_n, gidx, queue, tk_chunk, slow_min); \
+        k_ovl_nei_lane<fmd_grp_size(K), MM><<<grid, 64, 0, st>>>(ix, list, list_n, cap, listA, listB, rec, nei_out, max_nei, seq_out, seq_stride, gen_list, gen_n, bail_n, gidx, queue, tk_chunk, slow_min, adm_min); \
     } while (0)
 #define LANE_LAUNCH2(K) do { if (wide) LANE_LAUNCH_(K, uint64_t); else LANE_LAUNCH_(K, uint32_t); } while (0)
     switch (cls) {

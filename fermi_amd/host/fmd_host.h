@@ -143,7 +143,8 @@ void fmdh_slim_free(fmdh_slim_t *s);
 uint64_t fmdh_slim_bytes(const fmdh_slim_t *s);
 int fmdh_host_threads(void);       /* FMD_HOST_THREADS, default 16 */
 double fmdh_thp_gb(void);          /* anonymous memory in transparent huge pages, GB (-1: unknown) */
-double fmdh_rss_gb(int peak);       /* resident set of this process now (/proc/self/statm), or its peak so far (getrusage), in GB: the FMD_TIMING lines */
+double fmdh_rss_gb(int peak);       /* resident set of this process now (VmRSS of /proc/self/status) or its peak so far (VmHWM -- NOT ru_maxrss, which
+                                    * inherits the high-water mark of whatever exec'ed the program), in GB: the FMD_TIMING lines */
 void fmdh_par_for(int nt, void (*fn)(void *ctx, int tid, int nt), void *ctx);   /* fn(ctx, tid, nt) on nt threads (at most 64), joined */
 /* rows (chunk << FMDH_SLIM_CHUNK_SHIFT) .. + nr of shard g (id = g + n_shards * row) from packed rows as fmd_ovlp_pack_dev writes them: rec[nr], off[nr]
  * (offsets into var); the three buffers are the caller's and are not kept.  Chunks of different shards may be added concurrently. */

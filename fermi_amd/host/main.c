@@ -237,17 +237,25 @@ static int main_remap(int argc, char *argv[]) /* cmd.c:218-251 */
 
 #include <time.h>
 static double main_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
-/* On a host with several NUMA nodes the process stays on the node it started on (FMD_NUMA=off: wherever the scheduler puts it; FMD_NUMA=n: node n): the
- * tables of `unitig` and `correct` are filled by the host threads and then read at random by the thread that commits -- first touch puts a page on
- * the toucher's node, and a walk that runs on the other one pays the remote latency on half of its steps.  The threads created afterwards, the
- * runtime's included, inherit the mask.  Returns the node, -1 when nothing was done. */
-static int stay_on_one_node(void)
+/* On a host with several NUMA nodes `unitig` stays on the node it started on (FMD_NUMA=off: wherever the scheduler puts it; FMD_NUMA=n: node n; FMD_NUMA=all:
+ * every sub-command is pinned, not only `unitig`): its table is filled by the host threads and then read at random by the thread that commits -- first touch
+ * puts a page on the toucher's node, and a walk that runs on the other one pays the remote latency on half of its steps.  The threads created afterwards,
+ * the runtime's included, inherit the mask.  The new mask is the INHERITED one AND the node's CPUs: a binding the caller made (taskset, numactl, a batch
+ * system's cpuset) is never widened, and a caller that already bound the process to fewer than the online CPUs has decided -- nothing is done then unless
+ * FMD_NUMA names a node.  `correct -tN` and `build` keep every core they were given.  Returns the node, -1 when nothing was done. */
+static int stay_on_one_node(const char *cmd)
 {
     const char *e = getenv("FMD_NUMA");
-    int node, n_nodes = 0, cpu = sched_getcpu(), found = -1;
+    const int named = e && e[0] >= '0' && e[0] <= '9', all_cmds = e && strcmp(e, "all") == 0;
+    int node, n_nodes = 0, cpu = sched_getcpu(), found = -1, i, n_inherited, n_new = 0;
     char path[128], buf[4096];
-    cpu_set_t set;
+    cpu_set_t set, inherited;
     if (e && strcmp(e, "off") == 0) return -1;
+    if (!named && !all_cmds && strcmp(cmd, "unitig") != 0) return -1;
+    if (sched_getaffinity(0, sizeof(inherited), &inherited) != 0) return -1;
+    n_inherited = CPU_COUNT(&inherited);
+    if (!named && n_inherited < (int)sysconf(_SC_NPROCESSORS_ONLN)) return -1;   /* bound by the caller already */
+    CPU_ZERO(&set);
     for (node = 0; node < 64; ++node) {
         FILE *f;
         char *q;
@@ -265,10 +273,14 @@ static int stay_on_one_node(void)
             if (*q == '-') b = strtol(q + 1, &q, 10);
             for (; a <= b && a < CPU_SETSIZE; ++a) { CPU_SET((int)a, &cs); any = 1; }
             if (*q == ',') ++q;
+            else if (*q && *q != '\n') break;       /* not a cpulist */
         }
-        if (any && ((e && atoi(e) == node && e[0] >= '0' && e[0] <= '9') || (!e && cpu >= 0 && cpu < CPU_SETSIZE && CPU_ISSET(cpu, &cs)))) { set = cs; found = node; }
+        if (any && ((named && atoi(e) == node) || (!named && cpu >= 0 && cpu < CPU_SETSIZE && CPU_ISSET(cpu, &cs)))) { set = cs; found = node; }
     }
     if (n_nodes < 2 || found < 0) return -1;
+    for (i = 0; i < CPU_SETSIZE; ++i)
+        if (CPU_ISSET(i, &set)) { if (CPU_ISSET(i, &inherited)) ++n_new; else CPU_CLR(i, &set); }
+    if (n_new == 0 || n_new == n_inherited) return -1;      /* nothing of the node is ours / nothing would change */
     return sched_setaffinity(0, sizeof(set), &set) == 0 ? found : -1;
 }
 
@@ -285,13 +297,16 @@ int main(int argc, char *argv[])
         fprintf(stderr, "         chkbwt     print / check the BWT held on the GPU (fermi chkbwt)\n");
         fprintf(stderr, "         unpack     print the indexed sequences (fermi unpack)\n");
         fprintf(stderr, "         remap      coverage of contigs by the reads, paired-end breaks (fermi remap)\n\n");
+        fprintf(stderr, "Environment: FMD_NUMA=off|all|<node>  `unitig` keeps to the CPUs of the NUMA node it started on (never more than the\n");
+        fprintf(stderr, "                                      mask it inherited; nothing is done under taskset / numactl / a cpuset);\n");
+        fprintf(stderr, "                                      off = no pinning, all = every command, <node> = that node\n\n");
         return 1;
     }
     const double t_start = main_now();
     const int timing = getenv("FMD_TIMING") != 0;
     int rc;
     setvbuf(stdout, 0, _IOFBF, 4 << 20); /* the outputs are hundreds of MB of short lines */
-    { const int node = stay_on_one_node(); if (timing && node >= 0) fprintf(stderr, "[M::main] the process stays on NUMA node %d\n", node); }
+    { const int node = stay_on_one_node(argv[1]); if (timing && node >= 0) fprintf(stderr, "[M::main] the process stays on NUMA node %d\n", node); }
     if (fmd_device_count() <= 0) {
         fprintf(stderr, "[E::main] %s\n", fmd_strerror(FMD_E_NODEV));
         return 1;

@@ -409,9 +409,10 @@ static int und_push(fmdh_slim_t *s, uint64_t id, uint32_t rev)
 static inline void set_verdict(fmdh_slim_t *s, uint64_t id, int res, uint32_t rev)
 {
     fmdh_wrec_t *w = &s->w[id];
-    w->bits &= (uint8_t)~(FMDH_W_CL | FMDH_W_UNDEC);
-    if (res == 2) w->bits |= FMDH_W_UNDEC;
-    else if (res && (rev == 0xffffffffu || s->w[rev].n_nei > 1)) w->bits |= FMDH_W_CL;
+    uint8_t b = __atomic_load_n(&w->bits, __ATOMIC_RELAXED) & (uint8_t)~(FMDH_W_CL | FMDH_W_UNDEC);
+    if (res == 2) b |= FMDH_W_UNDEC;
+    else if (res && (rev == 0xffffffffu || s->w[rev].n_nei > 1)) b |= FMDH_W_CL;
+    __atomic_store_n(&w->bits, b, __ATOMIC_RELAXED);     /* one store of the final byte: other threads read this row's BIG / status bits meanwhile */
 }
 static inline int has_edge(const fmdh_wrec_t *w) { return (w->bits & FMDH_W_ST_MASK) == 0 && w->n_nei == 1 && w->rbeg != 0xffff; }
 
@@ -469,7 +470,7 @@ static void lk_main(void *ctx, int tid, int nt)
             x0 = e.x[0]; reserved = r.reserved > 2 ? 2 : r.reserved; rbeg = r.rbeg;
         } else { x0 = w->nxt; reserved = (w->vfl >> FMDH_V_RES_SHIFT) & 3; rbeg = w->rbeg; }
         w->nxt = x0 < s->n ? s->row_of[x0] : 0xffffffffu;
-        if (w->nxt == 0xffffffffu) { w->bits |= FMDH_W_UNDEC; continue; }
+        if (w->nxt == 0xffffffffu) { __atomic_store_n(&w->bits, (uint8_t)(w->bits | FMDH_W_UNDEC), __ATOMIC_RELAXED); continue; }
         rev = ((uint64_t)w->nxt ^ 1) < s->n ? (w->nxt ^ 1u) : 0xffffffffu;
         res = reserved;
         if (res == 2 || L->force_exact) {     /* check_left_simple was not run on this row: the rounds of the neighbour's reverse strand decide it (include/fmd_hip.h) */
@@ -477,8 +478,9 @@ static void lk_main(void *ctx, int tid, int nt)
             if (rev != 0xffffffffu && !L->force_exact) {
                 const fmdh_wrec_t *q = &s->w[rev];
                 uint16_t lf = (uint16_t)q->far;
-                if (q->bits & FMDH_W_BIG) { fmd_ovlp_rec_t r; memcpy(&r, fmdh_slim_var(s, rev), 64); lf = r.lfork; }
-                if ((q->bits & FMDH_W_ST_MASK) == 0) d = fmd_lfork_decide(lf, rbeg);
+                const uint8_t qb = __atomic_load_n(&q->bits, __ATOMIC_RELAXED);   /* (its owner may be storing its verdict bits: BIG and the status never change here) */
+                if (qb & FMDH_W_BIG) { fmd_ovlp_rec_t r; memcpy(&r, fmdh_slim_var(s, rev), 64); lf = r.lfork; }
+                if ((qb & FMDH_W_ST_MASK) == 0) d = fmd_lfork_decide(lf, rbeg);
             }
             res = d == 1 ? 2 : d < 0;
             if (L->force_exact && reserved != 2) res = reserved;   /* (the exact answer is there already) */
@@ -508,12 +510,12 @@ int fmdh_slim_link_host(fmdh_slim_t *s, int n_threads)
     if (nt < 1) nt = 1;
     if (nt > 64) nt = 64;
     if ((uint64_t)nt > s->n / 4096 + 1) nt = (int)(s->n / 4096 + 1);
+    if (!s->host_link || s->linked) return -EINVAL;   /* (x[0] and lfork travel in w.nxt / w.far of a host_link table until this pass has run: once) */
     L = (lk_t *)calloc(1, sizeof(lk_t));
     fmdh_big_free(s->row_of);
     s->row_of = (uint32_t *)fmdh_big_alloc((s->n ? s->n : 1) * 4);
     if (!L || !s->row_of) { free(L); return -ENOMEM; }
     memset(s->row_of, 0xff, s->n * 4);
-    if (!s->host_link || s->linked) { free(L); return -EINVAL; }   /* (x[0] and lfork travel in w.nxt / w.far of a host_link table until this pass has run: once) */
     L->s = s; L->force_exact = getenv("FMD_CHECK_LEFT_EXACT") != NULL;
     s->n_und = 0;
     for (L->phase = 0; L->phase < 2; ++L->phase) fmdh_par_for(nt, lk_main, L);
@@ -551,12 +553,23 @@ static void fin_main(void *ctx, int tid, int nt)
     uint64_t i;
     for (i = lo; i < hi; ++i) {
         fmdh_wrec_t *w = &s->w[i];
-        w->bits &= (uint8_t)~FMDH_W_PLAIN;
+        /* (another thread may be reading this row's bits -- its BIG bit and status, which this pass never changes -- as the neighbour of one of ITS
+         * rows: the byte is written once, whole, and read through relaxed atomics) */
+        const uint8_t b0 = __atomic_load_n(&w->bits, __ATOMIC_RELAXED) & (uint8_t)~FMDH_W_PLAIN;
+        uint8_t b1 = b0;
         w->far = 0xffffffffu;                                  /* (lfork of a host_link table until now; the walk builds the skip list here) */
         if (i + 8 < hi && s->w[i + 8].nxt != 0xffffffffu) __builtin_prefetch(&s->w[s->w[i + 8].nxt]);
-        if (!has_edge(w) || w->nxt == 0xffffffffu || (w->bits & (FMDH_W_EXTVAR | FMDH_W_UNDEC | FMDH_W_BIG))) continue;
-        if (s->w[w->nxt].bits & FMDH_W_BIG) continue;
-        w->bits |= FMDH_W_PLAIN;
+        if (has_edge(w) && w->nxt != 0xffffffffu && !(b0 & (FMDH_W_EXTVAR | FMDH_W_UNDEC | FMDH_W_BIG))) {
+            /* the plain step takes k[1] of the neighbour from k0 of the neighbour's OTHER strand (unitig_walk.c): that row must exist and must have
+             * been written with its interval (a short or flagged row carries k0 = 0) */
+            const uint64_t nx = w->nxt, ot = nx ^ 1;
+            if (ot < s->n && !(__atomic_load_n(&s->w[nx].bits, __ATOMIC_RELAXED) & FMDH_W_BIG)) {
+                const uint8_t bo = __atomic_load_n(&s->w[ot].bits, __ATOMIC_RELAXED);
+                const unsigned sto = bo & FMDH_W_ST_MASK;
+                if (!(bo & FMDH_W_BIG) && (sto == 0 || sto == FMDH_W_ST_CONTAINED)) b1 |= FMDH_W_PLAIN;
+            }
+        }
+        __atomic_store_n(&w->bits, b1, __ATOMIC_RELAXED);
     }
 }
 int fmdh_slim_finalize(fmdh_slim_t *s, int n_threads)

@@ -400,7 +400,7 @@ static int unidir(walk_t *w, uint64_t cur, str_t *s, cov_t *cov, int beg0, uint6
             if (mid != 0xffffffffu) {
                 const fmdh_wrec_t *m = &W[mid];
                 __builtin_prefetch(&w->bend[m->k0 >> 6]);
-                __builtin_prefetch(&w->used[m->k0 >> 6]); __builtin_prefetch(&w->used[W[mid ^ 1].k0 >> 6]);   /* (k[1] = k[0] of the other strand: the same 64 bytes) */
+                __builtin_prefetch(&w->used[m->k0 >> 6]); if (((uint64_t)mid ^ 1) < t->n) __builtin_prefetch(&w->used[W[mid ^ 1].k0 >> 6]);   /* (k[1] = k[0] of the other strand: the same 64 bytes) */
             }
             ahead[step % JUMP_DIST] = far;
         }
