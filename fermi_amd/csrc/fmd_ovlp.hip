@@ -35,6 +35,9 @@ int fmd_park_sort(hipStream_t st, size_t n, const FmdWalkPark *park, uint32_t *k
 // L2 -- the LF step takes a gather of its own).  The base found by the LF step is the base the
 // extension needs; when it is '$' the same ranks are fm6_is_contained's left test (unitig.c:83-85).
 // Candidates are pushed with info = depth (their start is len - depth, known only at the end).
+#ifndef FMD_HEAD_AUX
+#define FMD_HEAD_AUX 0
+#endif
 enum { WK_IDLE = 0, WK_LF, WK_EXT, WK_BOTH, WK_RIGHT, WK_ADM1, WK_ADM2 };
 // can the LF step at row k be read from a block the backward extension of [x0, x0 + sz) brings in anyway (the block of x0 - 1, or
 // the block of its other end when that one does not reach it)?
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
     FMD_DECLARE_COMPACT_LDS();
     __shared__ uint32_t walk_ls[MODE == WALK_TAIL2 ? 64 * WALK_LS_WORDS : 1];   // WALK_TAIL2: the lane's bases, word w of lane l at [w * 64 + l]
     constexpr bool TAILM = MODE == WALK_TAIL || MODE == WALK_TAIL2;
+    constexpr int WAUX = MODE == WALK_HEAD ? FMD_HEAD_AUX : FMD_GLDS_AUX;   // pass 1 never asks for a line twice (strands in id order: every gather is a DRAM miss)
     size_t sid = 0;
     size_t gs = 0;                        // the strand's row in rec[] (WALK_TAIL: gidx[sid], otherwise sid)
     int st = WK_IDLE, c_pend = 0, ret = 0;
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
         if (st == WK_LF) qk = k;
         else if (st == WK_EXT || st == WK_BOTH) { qk = x0 - 1; ql = x0 - 1 + sz; }
         else if (st == WK_RIGHT) { qk = x1 - 1; ql = x1 - 1 + sz; }
-        FmdRank2c r = fmd_wave_rank2_fetch_compact(ix, fmd_lds, qk, ql);
+        FmdRank2c r = fmd_wave_rank2_fetch_compact<WAUX>(ix, fmd_lds, qk, ql);
         // two-phase step (more than 32 lanes straddle: wide intervals): the k-side ranks are taken now,
         // the l-side after fmd_wave_l_ready(); a narrow lane whose window straddles sits this step out
         uint64_t tk2[6] = {0, 0, 0, 0, 0, 0};
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
                                                      // lanes straddle again next step)
         }
         const bool was_two_phase = r.two_phase;
-        fmd_wave_l_ready(ix, fmd_lds, r);
+        fmd_wave_l_ready<WAUX>(ix, fmd_lds, r);
         if (st == WK_IDLE || skip) continue;
         if (MODE == WALK_HEAD && st == WK_ADM1) {   // the admission record has arrived (FmdHeadAdm, k_ovl_head_adm)
             gs = adm_a.x;

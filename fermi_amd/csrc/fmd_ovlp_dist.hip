@@ -280,6 +280,25 @@ struct Arena {  // variable parts at the root: large chunks, allocated when firs
         used += bytes;
         return r;
     }
+    // Make sure `n_takes` takes of at most `each` bytes can follow without a new allocation failing: chunks are allocated NOW.  (Every take fits one
+    // chunk; a take that does not fit what is left of the current chunk moves on to the next one, so n_takes * each bytes need at most
+    // ceil(n_takes / floor(chunk_bytes / each)) chunks beyond the current one's rest.)
+    bool ensure(size_t n_takes, size_t each)
+    {
+        each = (each + 255) & ~(size_t)255;
+        if (each == 0 || n_takes == 0) return true;
+        if (each > chunk_bytes) return false;
+        const size_t per_chunk = chunk_bytes / each;
+        const size_t in_cur = cur < chunks.size() ? (chunk_bytes - used) / each : 0;
+        const size_t more = n_takes > in_cur ? (n_takes - in_cur + per_chunk - 1) / per_chunk : 0;
+        const size_t want = (cur < chunks.size() ? cur + 1 : chunks.size()) + more;
+        while (chunks.size() < want) {
+            void *p = nullptr;
+            if ((host ? hipHostMalloc(&p, chunk_bytes, hipHostMallocDefault) : hipMalloc(&p, chunk_bytes)) != hipSuccess) { (void)hipGetLastError(); return false; }
+            chunks.push_back(p);
+        }
+        return true;
+    }
     void shrink_last(size_t taken, size_t kept) { taken = (taken + 255) & ~(size_t)255; kept = (kept + 255) & ~(size_t)255; if (kept < taken && used >= taken - kept) used -= taken - kept; }
     void drop() { for (void *p : chunks) { if (host) hipHostFree(p); else hipFree(p); } chunks.clear(); reset(); }
 };
@@ -393,12 +412,12 @@ extern "C" int fmd_ovlp_dist_new(fmd_dev_t *h, fmd_comm_t *comm, const fmd_ovlp_
         NEED(d->work, wb);
     }
     NEED(d->pack_work, fmd_ovlp_pack_work_bytes(d->piece_max));
-    NEED(d->cnt_dev, (size_t)(d->world + 1) * 8 * (size_t)(d->world + 1));
-    NEED(d->sizes_dev, 16 * (size_t)(d->world + 1));
+    NEED(d->cnt_dev, (size_t)(d->world + 2) * 8 * (size_t)(d->world + 1));     // (a row of the key exchange's counts: W + 1 counts and a status word)
+    NEED(d->sizes_dev, 24 * (size_t)(d->world + 1));                           // (a piece: rows, variable bytes, status)
     NEED(d->split_dev, 4 * ((size_t)d->world * (d->world + 2) + 2));
     NEEDH(d->split_host, 4 * ((size_t)d->world * (d->world + 2) + 2));
-    NEEDH(d->cnt_host, (size_t)(d->world + 1) * 8 * (size_t)(d->world + 1));
-    NEEDH(d->sizes_host, 16 * (size_t)(d->world + 1));
+    NEEDH(d->cnt_host, (size_t)(d->world + 2) * 8 * (size_t)(d->world + 1));
+    NEEDH(d->sizes_host, 24 * (size_t)(d->world + 1));
     // where the table lives at the root
     const bool root = d->rank == cfg->root;
     d->on_host = 0;
@@ -467,21 +486,71 @@ extern "C" int fmd_ovlp_dist_new(fmd_dev_t *h, fmd_comm_t *comm, const fmd_ovlp_
     return FMD_OK;
 }
 
+// A failure that all ranks see (the reference's workers cannot fail apart: unitig.c:394-404 joins them).  A rank that fails on its own -- out of memory,
+// a capacity exceeded, a HIP error -- must not leave the step while its peers wait for it in the next collective: it carries the code in `lerr`, skips
+// its own work, keeps taking part, and the next all-gather delivers the code to everybody (a status word beside the counts of the key exchange, beside
+// the sizes of every piece).  All ranks then read the SAME gathered words and leave with the same code -- the first failing rank's, in rank order --
+// before anything further is posted.  (A transport that fails itself -- an error out of RCCL -- is beyond this: that code is returned as it comes.)
+// FMD_DIST_INJECT=<rank>:<where>[:<piece>] makes a rank fail on purpose (tests): where = head | keys | pack | arena.
+static int dist_inject(const fmd_ovlp_dist *d, const char *where, int piece)
+{
+    const char *e = getenv("FMD_DIST_INJECT");
+    if (!e) return FMD_OK;
+    int r = -1, pc = -1;
+    char w[16] = {0};
+    if (sscanf(e, "%d:%15[a-z]:%d", &r, w, &pc) < 2 || r != d->rank || strcmp(w, where) != 0) return FMD_OK;
+    if (pc >= 0 && piece >= 0 && pc != piece) return FMD_OK;
+    fprintf(stderr, "[W::fmd_ovlp_dist_step] rank %d fails on purpose at `%s' (FMD_DIST_INJECT)\n", d->rank, where);
+    return FMD_E_NOMEM;
+}
+// the verdict over `W` gathered status words (stride in u64 between ranks): the first failing rank's code, the same on every rank
+static int dist_verdict(const fmd_ovlp_dist *d, const uint64_t *words, size_t stride, const char *what, int piece)
+{
+    for (int q = 0; q < d->world; ++q) {
+        const int code = (int)(int64_t)words[(size_t)q * stride];
+        if (code != FMD_OK) {
+            if (piece >= 0) fprintf(stderr, "[E::fmd_ovlp_dist_step] rank %d: rank %d reports `%s' at %s, piece %d: every rank leaves the step with this code\n", d->rank, q, fmd_strerror(code), what, piece);
+            else fprintf(stderr, "[E::fmd_ovlp_dist_step] rank %d: rank %d reports `%s' at %s: every rank leaves the step with this code\n", d->rank, q, fmd_strerror(code), what);
+            return code;
+        }
+    }
+    return FMD_OK;
+}
+// one status word per rank, all-gathered on `st` (8 bytes each): used where no other collective is at hand to carry it
+static int dist_agree(fmd_ovlp_dist *d, hipStream_t st, int local, const char *what)
+{
+    if (d->world == 1) return local;
+    unsigned long long *dev = (unsigned long long *)d->sizes_dev.p;     // (free between the pieces: [3] mine, then [W][3])
+    uint64_t *host = (uint64_t *)d->sizes_host.p;
+    const unsigned long long mine = (unsigned long long)(int64_t)local;
+    if (hipMemcpyAsync(dev, &mine, 8, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); /* the all-gather still runs */ }
+    int rc = d->comm->allgather(d->comm->ctx, st, dev, dev + 3, 8);
+    if (rc != FMD_OK) return rc;
+    FMD_HIP_TRY(hipMemcpyAsync(host, dev + 3, (size_t)d->world * 8, hipMemcpyDeviceToHost, st));
+    FMD_HIP_TRY(hipStreamSynchronize(st));
+    return dist_verdict(d, host, 1, what, -1);
+}
+#define DIST_LOCAL(expr) do { if (lerr == FMD_OK && (expr) != hipSuccess) { fmd_set_hip_error(hipGetLastError(), "overlap job on N GPUs"); lerr = FMD_E_HIP; } } while (0)
+
 // the all-to-all of the parked strands; on return park_loc / ids_loc / keys / order describe the rows this rank computes.
 // *fell_back = 1: some rank's share would not fit (decided the same way on every rank): the step runs on the id shard.
-static int key_exchange(fmd_ovlp_dist *d, hipStream_t sc, uint64_t *rows_out, std::vector<uint64_t> &rows_of_rank, int *fell_back, uint64_t *sent_rows)
+// Returns a code EVERY rank returns (a rank's own failure before the exchange travels in the status slot of the counts), or -- *local_err -- a failure
+// of this rank alone after the last collective of the exchange, which the caller carries into the pieces' all-gathers.
+static int key_exchange(fmd_ovlp_dist *d, hipStream_t sc, uint64_t *rows_out, std::vector<uint64_t> &rows_of_rank, int *fell_back, uint64_t *sent_rows, int *local_err)
 {
     const int W = d->world, me = d->rank;
     const size_t n = d->n_home;
-    unsigned long long *cnt = (unsigned long long *)d->cnt_dev.p;           // [W + 1] mine, then [W][W + 1] everybody's
+    const size_t CW = (size_t)W + 2;                                         // a rank's row of counts: [W] to each rank, [1] special, [1] status
+    unsigned long long *cnt = (unsigned long long *)d->cnt_dev.p;           // [W + 2] mine, then [W][W + 2] everybody's
+    int lerr = FMD_OK;
     // the key ranges: everybody's quantiles, the median of each
     uint32_t *q_dev = (uint32_t *)d->split_dev.p, *q_all = q_dev + W, *split_dev = q_all + (size_t)W * W;   // [W] mine, [W][W] everybody's, [W + 1] the boundaries
     uint32_t *q_host = (uint32_t *)d->split_host.p, *split = q_host + (size_t)W * W;
     k_ks_quantiles<<<(W + 63) / 64, 64, 0, sc>>>(n, (const uint32_t *)d->keys.p, W, q_dev);
     int rc = d->comm->allgather(d->comm->ctx, sc, q_dev, q_all, (size_t)W * 4);
     if (rc != FMD_OK) return rc;
-    FMD_HIP_TRY(hipMemcpyAsync(q_host, q_all, (size_t)W * W * 4, hipMemcpyDeviceToHost, sc));
-    FMD_HIP_TRY(hipStreamSynchronize(sc));
+    DIST_LOCAL(hipMemcpyAsync(q_host, q_all, (size_t)W * W * 4, hipMemcpyDeviceToHost, sc));
+    DIST_LOCAL(hipStreamSynchronize(sc));
     split[0] = 0; split[W] = 0xfffffffeu;
     for (int p = 1; p < W; ++p) {
         std::vector<uint32_t> v((size_t)W);
@@ -492,56 +561,66 @@ static int key_exchange(fmd_ovlp_dist *d, hipStream_t sc, uint64_t *rows_out, st
         if (m_ > 0xfffffffeu) m_ = 0xfffffffeu;
         split[p] = m_;
     }
-    FMD_HIP_TRY(hipMemcpyAsync(split_dev, split, (size_t)(W + 1) * 4, hipMemcpyHostToDevice, sc));
+    DIST_LOCAL(hipMemcpyAsync(split_dev, split, (size_t)(W + 1) * 4, hipMemcpyHostToDevice, sc));
     k_ks_counts<<<(W + 1 + 63) / 64, 64, 0, sc>>>(n, (const uint32_t *)d->keys.p, W, split_dev, cnt);
-    rc = d->comm->allgather(d->comm->ctx, sc, cnt, cnt + (W + 1), (size_t)(W + 1) * 8);
+    if (lerr == FMD_OK) lerr = dist_inject(d, "keys", -1);
+    { const unsigned long long stw = (unsigned long long)(int64_t)lerr; if (hipMemcpyAsync(cnt + W + 1, &stw, 8, hipMemcpyHostToDevice, sc) != hipSuccess || hipStreamSynchronize(sc) != hipSuccess) (void)hipGetLastError(); }
+    rc = d->comm->allgather(d->comm->ctx, sc, cnt, cnt + CW, CW * 8);
     if (rc != FMD_OK) return rc;
     uint64_t *mat = (uint64_t *)d->cnt_host.p;
-    FMD_HIP_TRY(hipMemcpyAsync(mat, cnt + (W + 1), (size_t)W * (W + 1) * 8, hipMemcpyDeviceToHost, sc));
+    FMD_HIP_TRY(hipMemcpyAsync(mat, cnt + CW, (size_t)W * CW * 8, hipMemcpyDeviceToHost, sc));
     FMD_HIP_TRY(hipStreamSynchronize(sc));
+    rc = dist_verdict(d, mat + W + 1, CW, "the key exchange", -1);
+    if (rc != FMD_OK) return rc;
     // rows every rank ends up with
     *fell_back = 0;
     for (int q = 0; q < W; ++q) {
-        uint64_t m = mat[(size_t)q * (W + 1) + W];
-        for (int s = 0; s < W; ++s) m += mat[(size_t)s * (W + 1) + q];
+        uint64_t m = mat[(size_t)q * CW + W];
+        for (int s = 0; s < W; ++s) m += mat[(size_t)s * CW + q];
         rows_of_rank[(size_t)q] = m;
         const uint64_t nq = shard_size(d->cfg.n_ids, q, W), capq = nq + nq / 8 + 65536;
         if (m > capq || piece_begin(m, 1, d->pieces) + 1 > d->piece_max) *fell_back = 1;
     }
     if (*fell_back) return FMD_OK;
-    // my segments in park_send: [to 0 | to 1 | ... | to W-1 | special]; what I receive, in rank order, then my own special rows
+    // my segments in park_send: [to 0 | to 1 | ... | to W-1 | special]; what I receive, in rank order, then my own special rows.  Nothing that can fail
+    // on one rank alone stands between the verdict above and the exchange: the local copies follow it (they touch other parts of the buffers).
     std::vector<fmd_comm_op_t> ops;
     uint64_t soff = 0, roff = 0;
     FmdWalkPark *send = (FmdWalkPark *)d->park_send.p, *loc = (FmdWalkPark *)d->park_loc.p;
     *sent_rows = 0;
+    struct Own { uint64_t to, from, rows; };
+    std::vector<Own> own;
     for (int q = 0; q < W; ++q) {
-        const uint64_t sc_ = mat[(size_t)me * (W + 1) + q], rc_ = mat[(size_t)q * (W + 1) + me];
-        if (q == me) { if (sc_) FMD_HIP_TRY(hipMemcpyAsync(loc + roff, send + soff, sc_ * sizeof(FmdWalkPark), hipMemcpyDeviceToDevice, sc)); }
+        const uint64_t sc_ = mat[(size_t)me * CW + q], rc_ = mat[(size_t)q * CW + me];
+        if (q == me) { if (sc_) own.push_back(Own{roff, soff, sc_}); }
         else {
             if (sc_) { ops.push_back(fmd_comm_op_t{0, q, send + soff, (size_t)sc_ * sizeof(FmdWalkPark)}); *sent_rows += sc_; }
             if (rc_) ops.push_back(fmd_comm_op_t{1, q, loc + roff, (size_t)rc_ * sizeof(FmdWalkPark)});
         }
         soff += sc_; roff += rc_;
     }
-    { const uint64_t sp = mat[(size_t)me * (W + 1) + W]; if (sp) FMD_HIP_TRY(hipMemcpyAsync(loc + roff, send + soff, sp * sizeof(FmdWalkPark), hipMemcpyDeviceToDevice, sc)); roff += sp; }
+    { const uint64_t sp = mat[(size_t)me * CW + W]; if (sp) own.push_back(Own{roff, soff, sp}); roff += sp; }
     rc = d->comm->exchange(d->comm->ctx, sc, (int)ops.size(), ops.data());
     if (rc != FMD_OK) return rc;
+    for (const Own &o : own) DIST_LOCAL(hipMemcpyAsync(loc + o.to, send + o.from, o.rows * sizeof(FmdWalkPark), hipMemcpyDeviceToDevice, sc));
     const uint64_t m = roff;
     *rows_out = m;
-    if (m) {
+    if (m && lerr == FMD_OK) {
         // the order of pass 2 over the rows as they arrived (W sorted runs): the same sort again, then the rows into that order (the send
         // buffer is free again: the exchange precedes this on the stream)
         uint8_t *w = (uint8_t *)d->work.p;
         const size_t tb = fmd_park_sort_temp_bytes(m);
         uint32_t *keys_a = (uint32_t *)w, *vals_a = (uint32_t *)(w + up256(m * 4));
         void *tmp = w + 2 * up256(m * 4);
-        if (2 * up256(m * 4) + tb > d->work.bytes) return FMD_E_NOMEM;
-        rc = fmd_park_sort(sc, m, loc, keys_a, (uint32_t *)d->keys.p, vals_a, (uint32_t *)d->order.p, tmp, tb);
-        if (rc != FMD_OK) return rc;
-        k_park_permute<<<nblk(m, 64), 256, 0, sc>>>(m, (const uint32_t *)d->order.p, loc, send);
-        k_ks_unpack<<<nblk(m, 256), 256, 0, sc>>>(m, send, (uint64_t *)d->ids_loc.p, (fmd_ovlp_rec_t *)d->rec.p);
+        if (2 * up256(m * 4) + tb > d->work.bytes) lerr = FMD_E_NOMEM;
+        else lerr = fmd_park_sort(sc, m, loc, keys_a, (uint32_t *)d->keys.p, vals_a, (uint32_t *)d->order.p, tmp, tb);
+        if (lerr == FMD_OK) {
+            k_park_permute<<<nblk(m, 64), 256, 0, sc>>>(m, (const uint32_t *)d->order.p, loc, send);
+            k_ks_unpack<<<nblk(m, 256), 256, 0, sc>>>(m, send, (uint64_t *)d->ids_loc.p, (fmd_ovlp_rec_t *)d->rec.p);
+        }
     }
-    return rc;
+    *local_err = lerr;
+    return FMD_OK;
 }
 
 extern "C" int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream_, fmd_ovlp_dist_stats_t *stats)
@@ -557,6 +636,7 @@ extern "C" int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream_, fmd_ovlp_di
     S.pieces = P; S.on_host = d->on_host; S.two_pass = d->two_pass;
     const double t_begin = now_s();
     int rc = FMD_OK;
+    int lerr = FMD_OK;      // a failure of this rank alone: carried, not returned (see dist_verdict above)
     FMD_HIP_TRY(hipEventRecord(d->ev[0], sc));
     FMD_HIP_TRY(hipStreamWaitEvent(sm, d->ev[0], 0));
     // ---- pass 1 on the id shard
@@ -567,101 +647,126 @@ extern "C" int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream_, fmd_ovlp_di
     const uint64_t *row_ids = nullptr;          // nullptr: row j of this rank is id me + W * j
     int key_shard = 0;
     if (d->two_pass) {
-        if (d->n_home) rc = fmd_ovlp_head_dev(d->h, sc, (size_t)d->n_home, (const uint64_t *)d->ids_home.p, cfg.min_match, cfg.max_len, (fmd_ovlp_rec_t *)d->rec.p, park,
-                                              (uint32_t *)d->keys.p, (uint32_t *)d->order.p, d->work.p, d->work.bytes);
-        if (rc != FMD_OK) return rc;
-        FMD_HIP_TRY(hipEventRecord(d->ev[1], sc));
+        if (d->n_home) lerr = fmd_ovlp_head_dev(d->h, sc, (size_t)d->n_home, (const uint64_t *)d->ids_home.p, cfg.min_match, cfg.max_len, (fmd_ovlp_rec_t *)d->rec.p, park,
+                                                (uint32_t *)d->keys.p, (uint32_t *)d->order.p, d->work.p, d->work.bytes);
+        if (lerr == FMD_OK) lerr = dist_inject(d, "head", -1);
+        DIST_LOCAL(hipEventRecord(d->ev[1], sc));
         // the parked strands in key order, each with its id (and, if it ended inside the head, what its record needs): the send buffer of the
         // all-to-all, and -- without one -- already the rows of pass 2
-        if (d->n_home)
+        if (d->n_home && lerr == FMD_OK)
             k_ks_gather<<<nblk(d->n_home, 64), 256, 0, sc>>>((size_t)d->n_home, (const uint32_t *)d->order.p, (const FmdWalkPark *)d->park_home.p, (const uint64_t *)d->ids_home.p,
                                                              (const fmd_ovlp_rec_t *)d->rec.p, (FmdWalkPark *)d->park_send.p);
         int fell_back = 1;
         if (cfg.key_shard) {
+            // the exchange is made of collectives: nobody enters it unless everybody's pass 1 went through
+            rc = dist_agree(d, sc, lerr, "pass 1");
+            if (rc != FMD_OK) return rc;
             uint64_t m = 0, sent = 0;
-            rc = key_exchange(d, sc, &m, rows_of_rank, &fell_back, &sent);
+            rc = key_exchange(d, sc, &m, rows_of_rank, &fell_back, &sent, &lerr);
             if (rc != FMD_OK) return rc;
             if (!fell_back) { rows = m; key_shard = 1; S.key_rows_sent = sent; }
             else for (int q = 0; q < W; ++q) rows_of_rank[(size_t)q] = shard_size(cfg.n_ids, q, W);
         }
-        if (fell_back && d->n_home) k_ks_unpack<<<nblk(d->n_home, 256), 256, 0, sc>>>((size_t)d->n_home, (const FmdWalkPark *)d->park_send.p, (uint64_t *)d->ids_loc.p, (fmd_ovlp_rec_t *)d->rec.p);
+        if (fell_back && d->n_home && lerr == FMD_OK) k_ks_unpack<<<nblk(d->n_home, 256), 256, 0, sc>>>((size_t)d->n_home, (const FmdWalkPark *)d->park_send.p, (uint64_t *)d->ids_loc.p, (fmd_ovlp_rec_t *)d->rec.p);
         park = (FmdWalkPark *)d->park_send.p;
         row_ids = (const uint64_t *)d->ids_loc.p;
     } else {
-        FMD_HIP_TRY(hipEventRecord(d->ev[1], sc));
+        DIST_LOCAL(hipEventRecord(d->ev[1], sc));
     }
-    FMD_HIP_TRY(hipEventRecord(d->ev[2], sc));
+    DIST_LOCAL(hipEventRecord(d->ev[2], sc));
     S.key_shard = key_shard;
     d->n_rows = rows;
     d->loc_ids = row_ids ? row_ids : (const uint64_t *)d->ids_home.p;
     // ---- pass 2 + fm6_get_nei: every piece queued on the compute stream now; the loop below follows with pack + transfer
-    for (int p = 0; p < P && rc == FMD_OK; ++p) {
+    for (int p = 0; p < P && lerr == FMD_OK; ++p) {
         const uint64_t b = piece_begin(rows, p, P), np = piece_begin(rows, p + 1, P) - b;
         if (np) {
             if (d->two_pass)
-                rc = fmd_ovlp_tail_dev(d->h, sc, (size_t)np, (const uint32_t *)d->iota.p + b, park, cfg.min_match, cfg.max_len, cfg.max_nei, (fmd_ovlp_rec_t *)d->rec.p,
-                                       (fmd_intv_t *)d->nei.p, (uint8_t *)d->seq.p, d->stride, d->work.p, d->work.bytes);
+                lerr = fmd_ovlp_tail_dev(d->h, sc, (size_t)np, (const uint32_t *)d->iota.p + b, park, cfg.min_match, cfg.max_len, cfg.max_nei, (fmd_ovlp_rec_t *)d->rec.p,
+                                         (fmd_intv_t *)d->nei.p, (uint8_t *)d->seq.p, d->stride, d->work.p, d->work.bytes);
             else
-                rc = fmd_ovlp_dev(d->h, sc, (size_t)np, (const uint64_t *)d->ids_home.p + b, cfg.min_match, cfg.max_len, cfg.max_nei, (fmd_ovlp_rec_t *)d->rec.p + b,
-                                  (fmd_intv_t *)d->nei.p + b * cfg.max_nei, (uint8_t *)d->seq.p + b * (size_t)d->stride, d->stride, d->work.p, d->work.bytes);
+                lerr = fmd_ovlp_dev(d->h, sc, (size_t)np, (const uint64_t *)d->ids_home.p + b, cfg.min_match, cfg.max_len, cfg.max_nei, (fmd_ovlp_rec_t *)d->rec.p + b,
+                                    (fmd_intv_t *)d->nei.p + b * cfg.max_nei, (uint8_t *)d->seq.p + b * (size_t)d->stride, d->stride, d->work.p, d->work.bytes);
         }
-        if (rc == FMD_OK && hipEventRecord(d->done[(size_t)p], sc) != hipSuccess) rc = FMD_E_HIP;
+        DIST_LOCAL(hipEventRecord(d->done[(size_t)p], sc));
     }
-    if (rc != FMD_OK) return rc;
-    FMD_HIP_TRY(hipEventRecord(d->ev[3], sc));
+    DIST_LOCAL(hipEventRecord(d->ev[3], sc));
     // ---- the pieces leave
     std::vector<uint64_t> rowbase((size_t)W + 1, 0);
     for (int q = 0; q < W; ++q) rowbase[(size_t)q + 1] = rowbase[(size_t)q] + rows_of_rank[(size_t)q];
-    if (is_root) { d->var.reset(); FMD_HIP_TRY(hipMemsetAsync(d->t_row_of.p, 0xff, cfg.n_ids * 4, sm)); }
-    unsigned long long *sz_dev = (unsigned long long *)d->sizes_dev.p;   // [2] mine = {rows, variable bytes}, then [W][2]
+    if (is_root) { d->var.reset(); DIST_LOCAL(hipMemsetAsync(d->t_row_of.p, 0xff, cfg.n_ids * 4, sm)); }
+    unsigned long long *sz_dev = (unsigned long long *)d->sizes_dev.p;   // [3] mine = {rows, variable bytes, status}, then [W][3]
     uint64_t *sz_host = (uint64_t *)d->sizes_host.p;
     for (int p = 0; p < P && !(W == 1 && getenv("FMD_DIST_NO_PACK")); ++p) {   // (A/B knob: pass 2 alone)
         const uint64_t b = piece_begin(rows, p, P), np = piece_begin(rows, p + 1, P) - b;
         const int k = p & 1;
-        FMD_HIP_TRY(hipStreamWaitEvent(sm, d->done[(size_t)p], 0));
-        if (p == P - 1) FMD_HIP_TRY(hipEventRecord(d->ev[4], sm));
-        // where this rank's piece is packed to: straight into the table (root, table in HBM) or into the out buffers
-        uint32_t *o_pid; fmd_ovlp_rec_t *o_prec; uint64_t *o_off; uint8_t *o_var; uint64_t o_cap;
+        // ---- this rank's own part of piece p: everything in it that can fail comes BEFORE the all-gather of the sizes, which carries the outcome
+        uint32_t *o_pid = nullptr; fmd_ovlp_rec_t *o_prec = nullptr; uint64_t *o_off = nullptr; uint8_t *o_var = nullptr; uint64_t o_cap = 0;
         const uint64_t my_row0 = rowbase[(size_t)me] + b;
-        if (is_root && !d->on_host) {
-            o_pid = (uint32_t *)d->t_ids.p + my_row0; o_prec = (fmd_ovlp_rec_t *)d->t_prec.p + my_row0; o_off = (uint64_t *)d->t_off.p + (size_t)me * (d->piece_max + 1);
-            o_cap = fmd_ovlp_pack_max_bytes((size_t)np, cfg.max_nei, d->stride);
-            o_var = (uint8_t *)d->var.take(o_cap ? o_cap : 256);
-            if (!o_var) return FMD_E_NOMEM;
-        } else {
-            Stage &os = d->out[is_root ? k : 0];
-            if (is_root) FMD_HIP_TRY(hipStreamWaitEvent(sm, d->drained[k], 0));   // (host table: set k -- the root's own piece and the peers' staging -- has left for the host)
-            o_pid = (uint32_t *)os.pid.p; o_prec = (fmd_ovlp_rec_t *)os.prec.p; o_off = (uint64_t *)os.off.p; o_var = (uint8_t *)os.var.p; o_cap = d->var_cap_piece;
+        if (lerr == FMD_OK) lerr = dist_inject(d, "pack", p);
+        DIST_LOCAL(hipStreamWaitEvent(sm, d->done[(size_t)p], 0));
+        if (p == P - 1) DIST_LOCAL(hipEventRecord(d->ev[4], sm));
+        if (lerr == FMD_OK) {
+            // where this rank's piece is packed to: straight into the table (root, table in HBM) or into the out buffers
+            if (is_root && !d->on_host) {
+                o_pid = (uint32_t *)d->t_ids.p + my_row0; o_prec = (fmd_ovlp_rec_t *)d->t_prec.p + my_row0; o_off = (uint64_t *)d->t_off.p + (size_t)me * (d->piece_max + 1);
+                o_cap = fmd_ovlp_pack_max_bytes((size_t)np, cfg.max_nei, d->stride);
+                o_var = (uint8_t *)d->var.take(o_cap ? o_cap : 256);
+                if (!o_var) lerr = FMD_E_NOMEM;
+            } else {
+                Stage &os = d->out[is_root ? k : 0];
+                if (is_root) DIST_LOCAL(hipStreamWaitEvent(sm, d->drained[k], 0));   // (host table: set k -- the root's own piece and the peers' staging -- has left for the host)
+                o_pid = (uint32_t *)os.pid.p; o_prec = (fmd_ovlp_rec_t *)os.prec.p; o_off = (uint64_t *)os.off.p; o_var = (uint8_t *)os.var.p; o_cap = d->var_cap_piece;
+            }
         }
-        rc = fmd_ovlp_pack_rows_dev(d->h, sm, (size_t)np, (const uint32_t *)d->iota.p + b, row_ids, (uint64_t)me, (uint64_t)W, (const fmd_ovlp_rec_t *)d->rec.p, (const fmd_intv_t *)d->nei.p,
-                                    cfg.max_nei, (const uint8_t *)d->seq.p, d->stride, o_pid, o_prec, o_off, o_var, o_cap, d->pack_work.p, d->pack_work.bytes);
-        if (rc != FMD_OK) return rc;
-        // sizes of everybody's piece p
-        FMD_HIP_TRY(hipMemcpyAsync(sz_dev + 1, o_off + np, 8, hipMemcpyDeviceToDevice, sm));
-        { const unsigned long long npv = np; FMD_HIP_TRY(hipMemcpyAsync(sz_dev, &npv, 8, hipMemcpyHostToDevice, sm)); FMD_HIP_TRY(hipStreamSynchronize(sm)); }
+        if (lerr == FMD_OK)
+            lerr = fmd_ovlp_pack_rows_dev(d->h, sm, (size_t)np, (const uint32_t *)d->iota.p + b, row_ids, (uint64_t)me, (uint64_t)W, (const fmd_ovlp_rec_t *)d->rec.p, (const fmd_intv_t *)d->nei.p,
+                                          cfg.max_nei, (const uint8_t *)d->seq.p, d->stride, o_pid, o_prec, o_off, o_var, o_cap, d->pack_work.p, d->pack_work.bytes);
+        if (is_root && lerr == FMD_OK) {
+            // the root's arena must hold whatever the peers send: room for their worst case is made NOW, while a failure can still travel with the sizes
+            uint64_t np_max = 0;
+            for (int q = 0; q < W; ++q) { const uint64_t nq = piece_begin(rows_of_rank[(size_t)q], p + 1, P) - piece_begin(rows_of_rank[(size_t)q], p, P); if (q != me || d->on_host) np_max = nq > np_max ? nq : np_max; }
+            const size_t worst = fmd_ovlp_pack_max_bytes((size_t)np_max, cfg.max_nei, d->stride);
+            if (dist_inject(d, "arena", p) != FMD_OK || !d->var.ensure((size_t)(d->on_host ? W : W - 1), worst ? worst : 256)) lerr = FMD_E_NOMEM;
+        }
+        // sizes of everybody's piece p, and how everybody fared
+        if (lerr == FMD_OK) DIST_LOCAL(hipMemcpyAsync(sz_dev + 1, o_off + np, 8, hipMemcpyDeviceToDevice, sm));
+        {
+            const unsigned long long head[3] = {lerr == FMD_OK ? (unsigned long long)np : 0ull, 0ull, (unsigned long long)(int64_t)lerr};
+            bool ok = hipMemcpyAsync(sz_dev, &head[0], 8, hipMemcpyHostToDevice, sm) == hipSuccess && hipMemcpyAsync(sz_dev + 2, &head[2], 8, hipMemcpyHostToDevice, sm) == hipSuccess;
+            if (lerr != FMD_OK) ok = ok && hipMemcpyAsync(sz_dev + 1, &head[1], 8, hipMemcpyHostToDevice, sm) == hipSuccess;
+            ok = ok && hipStreamSynchronize(sm) == hipSuccess;
+            if (!ok) (void)hipGetLastError();      // (a device that cannot even take this is beyond the protocol: the all-gather below reports or hangs with it)
+        }
         if (W > 1) {
-            rc = d->comm->allgather(d->comm->ctx, sm, sz_dev, sz_dev + 2, 16);
+            rc = d->comm->allgather(d->comm->ctx, sm, sz_dev, sz_dev + 3, 24);
             if (rc != FMD_OK) return rc;
-            FMD_HIP_TRY(hipMemcpyAsync(sz_host, sz_dev + 2, (size_t)W * 16, hipMemcpyDeviceToHost, sm));
-        } else FMD_HIP_TRY(hipMemcpyAsync(sz_host, sz_dev, 16, hipMemcpyDeviceToHost, sm));
+            FMD_HIP_TRY(hipMemcpyAsync(sz_host, sz_dev + 3, (size_t)W * 24, hipMemcpyDeviceToHost, sm));
+        } else FMD_HIP_TRY(hipMemcpyAsync(sz_host, sz_dev, 24, hipMemcpyDeviceToHost, sm));
         FMD_HIP_TRY(hipStreamSynchronize(sm));
+        // ---- the verdict, from the same words on every rank; then -- also on every rank, from the same words -- the row counts
+        rc = dist_verdict(d, sz_host + 2, 3, "pass 2 / the pack", p);
+        if (rc != FMD_OK) return rc;
+        for (int q = 0; q < W; ++q) {
+            const uint64_t want = piece_begin(rows_of_rank[(size_t)q], p + 1, P) - piece_begin(rows_of_rank[(size_t)q], p, P);
+            if (sz_host[3 * q] != want) { fprintf(stderr, "[E::fmd_ovlp_dist_step] rank %d sends %llu rows in piece %d, %llu expected\n", q, (unsigned long long)sz_host[3 * q], p, (unsigned long long)want); return FMD_E_ARG; }
+        }
         S.rows_computed += np;
-        if (is_root && !d->on_host) d->var.shrink_last(o_cap ? o_cap : 256, sz_host[2 * me + 1] ? sz_host[2 * me + 1] : 256);   // (the worst case was reserved for the root's own piece)
+        if (is_root && !d->on_host) d->var.shrink_last(o_cap ? o_cap : 256, sz_host[3 * me + 1] ? sz_host[3 * me + 1] : 256);   // (the worst case was reserved for the root's own piece)
         if (!is_root) {
-            const uint64_t vb = sz_host[2 * me + 1];
+            const uint64_t vb = sz_host[3 * me + 1];
             fmd_comm_op_t ops[4] = {{0, root, o_pid, (size_t)np * 4}, {0, root, o_prec, (size_t)np * sizeof(fmd_ovlp_rec_t)}, {0, root, o_off, (size_t)(np + 1) * 8}, {0, root, o_var, (size_t)vb}};
             if (np) { rc = d->comm->exchange(d->comm->ctx, sm, 4, ops); if (rc != FMD_OK) return rc; }
             S.rows_sent += np; S.bytes_sent += np * (4 + sizeof(fmd_ovlp_rec_t)) + (np + 1) * 8 + vb;
             continue;
         }
-        // ---- root: receive every peer's piece p, place it
+        // ---- root: receive every peer's piece p, place it (the arena has the room: ensure() above)
         std::vector<fmd_comm_op_t> ops;
         struct Placed { const uint32_t *pid; const uint64_t *off; uint64_t var_base, row0, np; uint64_t *vaddr_dst; Stage *st; uint64_t vb; };
         std::vector<Placed> placed;
         for (int q = 0; q < W; ++q) {
-            const uint64_t nq = sz_host[2 * q], vb = sz_host[2 * q + 1];
+            const uint64_t nq = sz_host[3 * q], vb = sz_host[3 * q + 1];
             const uint64_t bq = piece_begin(rows_of_rank[(size_t)q], p, P);
-            if (nq != piece_begin(rows_of_rank[(size_t)q], p + 1, P) - bq) { fprintf(stderr, "[E::fmd_ovlp_dist_step] rank %d sends %llu rows in piece %d, %llu expected\n", q, (unsigned long long)nq, p, (unsigned long long)(piece_begin(rows_of_rank[(size_t)q], p + 1, P) - bq)); return FMD_E_ARG; }
             if (!nq) continue;
             const uint64_t row0 = rowbase[(size_t)q] + bq;
             if (!d->on_host) {
@@ -669,7 +774,7 @@ extern "C" int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream_, fmd_ovlp_di
                 uint8_t *vq = o_var;
                 if (q != me) {
                     vq = (uint8_t *)d->var.take(vb ? vb : 256);
-                    if (!vq) return FMD_E_NOMEM;
+                    if (!vq) return FMD_E_NOMEM;        // (cannot happen after ensure(): a peer's variable part is no larger than its worst case)
                     ops.push_back(fmd_comm_op_t{1, q, (uint32_t *)d->t_ids.p + row0, (size_t)nq * 4});
                     ops.push_back(fmd_comm_op_t{1, q, (fmd_ovlp_rec_t *)d->t_prec.p + row0, (size_t)nq * sizeof(fmd_ovlp_rec_t)});
                     ops.push_back(fmd_comm_op_t{1, q, offq, (size_t)(nq + 1) * 8});
@@ -680,7 +785,7 @@ extern "C" int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream_, fmd_ovlp_di
             } else {
                 Stage *st = &d->in[k][(size_t)q];
                 uint8_t *hv = (uint8_t *)d->var.take(vb ? vb : 256);   // the row's final place in pinned host memory
-                if (!hv) return FMD_E_NOMEM;
+                if (!hv) return FMD_E_NOMEM;            // (as above)
                 const uint32_t *pid_src; const uint64_t *off_src;
                 if (q != me) {
                     ops.push_back(fmd_comm_op_t{1, q, st->pid.p, (size_t)nq * 4});
@@ -710,6 +815,7 @@ extern "C" int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream_, fmd_ovlp_di
             FMD_HIP_TRY(hipEventRecord(d->drained[k], s3));
         }
     }
+    if (lerr != FMD_OK) return lerr;       // (W == 1 with FMD_DIST_NO_PACK: nobody to tell)
     if (W == 1 && getenv("FMD_DIST_NO_PACK")) { FMD_HIP_TRY(hipStreamWaitEvent(sm, d->done[(size_t)P - 1], 0)); FMD_HIP_TRY(hipEventRecord(d->ev[4], sm)); }
     FMD_HIP_TRY(hipEventRecord(d->ev[5], sm));
     // ---- the end of this rank's part in the gather (the end of its compute is ev[3] on the compute stream)

@@ -69,6 +69,11 @@ struct FmdIndexView {            // passed by value as a kernel argument (lives 
     // exactly these ptab_d dependent steps -- one DRAM line each, a ninth of all lines of overlap discovery -- for every
     // sequence, every time; they are taken once, when the index is loaded (8 bytes per sequence; nullptr = not built).
     const unsigned long long *tail;
+    // Two-base blocks (fmd_pair.hip; nullptr = not built): 128 bytes per 64 positions, for the steps of a walk below min_match -- nothing is pushed
+    // there, so a step may take TWO bases from one line (a 128-byte random line costs this memory system what a 64-byte one costs: profiles/r6_probe).
+    // pair_tab[(block >> FMD_PAIR_SB_SHIFT) * 16 + pair]: where the pair's range starts + the pairs before that superblock (see fmd_pair_step).
+    const uint4 *pair;
+    const unsigned long long *pair_tab;
     // 64 counters on separate 128-byte lines: rank blocks requested from the memory system by the gathers.
     // Only the instrumented build (-DFMD_COUNT_LINES=1, libfmdhip_count.so) adds to them; bench.py runs one step
     // of each leg through that build to price the shipped kernels in DEVICE bytes (64 bytes per block).
@@ -80,7 +85,7 @@ struct FmdIndexView {            // passed by value as a kernel argument (lives 
 #endif
 #define FMD_STAT_SLOTS 64
 #define FMD_STAT_STRIDE 16   // u64 per slot = 128 bytes
-// kind 0 = 64-byte rank blocks, kind 1 = other random lines (prefix-table look-ups)
+// kind 0 = 64-byte rank blocks, kind 1 = other random lines (prefix-table look-ups), kind 2 = 128-byte two-base blocks
 __device__ __forceinline__ void fmd_count_lines(const FmdIndexView &ix, int n, int kind = 0)
 {
 #if FMD_COUNT_LINES
@@ -131,7 +136,7 @@ __device__ __forceinline__ int fmd_chunk_xor(int q) { return q & 3; }
 
 // One cooperative round: lane group g fetches the block of lane (g << FMD_GRP_SHIFT) + R for slot SLOT
 // (8 lanes x 16 B for a 128-byte block, 4 lanes for a 64-byte one).
-template <int SLOT, int R>
+template <int SLOT, int R, int AUX = FMD_GLDS_AUX>
 __device__ __forceinline__ void fmd_fetch_round(const FmdIndexView &ix, uint4 *lds, uint32_t blk, uint64_t need_mask)
 {
     if ((need_mask >> R) & 0x1111111111111111ull) {          // wave-uniform: anybody in this round?
@@ -140,22 +145,66 @@ __device__ __forceinline__ void fmd_fetch_round(const FmdIndexView &ix, uint4 *l
         const uint32_t sb = (uint32_t)__builtin_amdgcn_ds_swizzle((int)blk, (R << 5) | 0x1C); // blk of lane 4g+R
         if ((need_mask >> ((lane & ~3) | R)) & 1) {
             const uint4 *src = ix.blocks + (size_t)sb * FMD_BLK_U4 + (j ^ R);  // R = fmd_chunk_xor(4g+R)
-            __builtin_amdgcn_global_load_lds((fmd_glb_void *)src, (fmd_lds_void *)(lds + SLOT * FMD_SLOT_U4 + R * 64), 16, 0, FMD_GLDS_AUX);
+            __builtin_amdgcn_global_load_lds((fmd_glb_void *)src, (fmd_lds_void *)(lds + SLOT * FMD_SLOT_U4 + R * 64), 16, 0, AUX);
         }
     }
 }
 
-template <int SLOT>
+// AUX = the cache-policy bits of this gather (a kernel whose lines are never asked for twice -- pass 1 of the sorted job -- may say nt: profiles/r6_probe)
+template <int SLOT, int AUX = FMD_GLDS_AUX>
 __device__ __forceinline__ void fmd_fetch_slot(const FmdIndexView &ix, uint4 *lds, uint32_t blk, bool need)
 {
     const uint64_t m = __ballot(need);
     if (m == 0) return;
     fmd_count_lines(ix, __popcll(m));
-    fmd_fetch_round<SLOT, 0>(ix, lds, blk, m); fmd_fetch_round<SLOT, 1>(ix, lds, blk, m);
-    fmd_fetch_round<SLOT, 2>(ix, lds, blk, m); fmd_fetch_round<SLOT, 3>(ix, lds, blk, m);
+    fmd_fetch_round<SLOT, 0, AUX>(ix, lds, blk, m); fmd_fetch_round<SLOT, 1, AUX>(ix, lds, blk, m);
+    fmd_fetch_round<SLOT, 2, AUX>(ix, lds, blk, m); fmd_fetch_round<SLOT, 3, AUX>(ix, lds, blk, m);
 }
 
 __device__ __forceinline__ void fmd_fetch_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// ---- two-base blocks ------------------------------------------------------------------------------------------------------------------
+// A pair block starts every 64 positions and describes 96, like a rank block; per position p it holds BWT[p] (as the rank block does) and
+// BWT[LF(p)] -- the base the walk would find one step later -- as three bit planes each, and for its 16 A/C/G/T pairs the number of positions
+// before the block with that pair, relative to its superblock of 2^28 positions (28 bits each):
+//     u4[j], j = 0..2     = { p0, p1, p2, s0 } of 32 positions: p = planes of BWT[p], s = planes of BWT[LF(p)] (0 where BWT[p] is not A/C/G/T)
+//     u4[3 + j], j = 0..2 = { s1, s2, cw[2j], cw[2j + 1] }
+//     u4[6], u4[7]        = cw[6 .. 13]
+//     cw[0 .. 13] as one string of 448 bits: count of pair i = 4 (c1 - 1) + (c2 - 1) at bits [28 i, 28 i + 28)
+// LF(LF(k)) for a row with BWT[k] = c1, BWT[LF(k)] = c2 is K2[c1][c2] + #{q <= k: pair(q) = (c1, c2)} - 1 with the constant
+// K2 = cnt[c2] + #{c2 in BWT[0, cnt[c1])}; pair_tab holds K2 + the pairs before the superblock, the block the rest.
+#define FMD_PAIR_U4 8
+#define FMD_PAIR_BYTES 128
+#define FMD_PAIR_SB_SHIFT 22                    // blocks per superblock: 2^22 (2^28 positions)
+#define FMD_PAIR_SLOT_U4 (64 * FMD_PAIR_U4)     // one image per lane: 8 KiB per wave
+// chunk XOR of lane q's image: the sixteen lanes of a ds_read_b128 service group ({0-3,12-15,20-27}, ...) get the sixteen 16-byte slots of a 256-byte row
+__device__ __forceinline__ int fmd_pair_xor(int q) { return (q & 3) | ((q >> 4) & 1) << 2; }
+__device__ __forceinline__ int fmd_pair_base(int q) { return (q & 7) * 64 + (q >> 3) * FMD_PAIR_U4; }   // uint4 index of lane q's image in the slot
+// round R: the 8-lane group g fetches the pair block of lane 8 g + R, 16 bytes per lane (8 blocks per wave instruction)
+template <int R, int AUX>
+__device__ __forceinline__ void fmd_pair_round(const FmdIndexView &ix, uint4 *slot, uint32_t blk, uint64_t need_mask)
+{
+    if ((need_mask >> R) & 0x0101010101010101ull) {
+        const int lane = fmd_lane();
+        const int j = lane & 7;
+        const uint32_t sb = (uint32_t)__builtin_amdgcn_ds_swizzle((int)blk, (R << 5) | 0x18);   // blk of lane 8 g + R (lanes of one half-wave: bits 3, 4 kept)
+        if ((need_mask >> ((lane & ~7) | R)) & 1) {
+            const int x = (R & 3) | ((lane >> 4) & 1) << 2;                                      // fmd_pair_xor(8 g + R)
+            const uint4 *src = ix.pair + (size_t)sb * FMD_PAIR_U4 + (j ^ x);
+            __builtin_amdgcn_global_load_lds((fmd_glb_void *)src, (fmd_lds_void *)(slot + R * 64), 16, 0, AUX);
+        }
+    }
+}
+// every lane that `need`s one posts its block; no wait (the caller's next fmd_fetch_wait covers these loads too)
+template <int AUX = FMD_GLDS_AUX>
+__device__ __forceinline__ void fmd_pair_fetch(const FmdIndexView &ix, uint4 *slot, uint32_t blk, bool need)
+{
+    const uint64_t m = __ballot(need);
+    if (m == 0) return;
+    fmd_count_lines(ix, __popcll(m), 2);
+    fmd_pair_round<0, AUX>(ix, slot, blk, m); fmd_pair_round<1, AUX>(ix, slot, blk, m); fmd_pair_round<2, AUX>(ix, slot, blk, m); fmd_pair_round<3, AUX>(ix, slot, blk, m);
+    fmd_pair_round<4, AUX>(ix, slot, blk, m); fmd_pair_round<5, AUX>(ix, slot, blk, m); fmd_pair_round<6, AUX>(ix, slot, blk, m); fmd_pair_round<7, AUX>(ix, slot, blk, m);
+}
 
 // uint4 index (inside the wave's LDS area) of chunk 0^t of the block fetched for lane q, slot s
 __device__ __forceinline__ int fmd_lds_base(int q, int slot)
@@ -168,6 +217,7 @@ __device__ __forceinline__ int fmd_pool_xor(int p) { return (p ^ (p >> 2)) & 3; 
 
 // Pool of compacted blocks (ballot-prefix slots): `n` block ids in ids[], FMD_BLK_PER_INST per wave
 // instruction, written to pool; the lane that owns pool slot p reads pool + p * FMD_BLK_U4 with XOR fmd_pool_xor(p).
+template <int AUX = FMD_GLDS_AUX>
 __device__ __forceinline__ void fmd_fetch_pool(const FmdIndexView &ix, uint4 *pool, const uint32_t *ids, int n)
 {
     const int q = fmd_lane();
@@ -176,7 +226,7 @@ __device__ __forceinline__ void fmd_fetch_pool(const FmdIndexView &ix, uint4 *po
         const int slot = rr * FMD_BLK_PER_INST + (q >> FMD_GRP_SHIFT);
         if (slot < n) {
             const uint4 *src = ix.blocks + (size_t)ids[slot] * FMD_BLK_U4 + ((q & FMD_GRP_MASK) ^ fmd_pool_xor(slot));
-            __builtin_amdgcn_global_load_lds((fmd_glb_void *)src, (fmd_lds_void *)(pool + rr * 64), 16, 0, FMD_GLDS_AUX);
+            __builtin_amdgcn_global_load_lds((fmd_glb_void *)src, (fmd_lds_void *)(pool + rr * 64), 16, 0, AUX);
         }
     }
 }
@@ -425,6 +475,7 @@ struct FmdRank2c {
     bool two_phase;        // wave-uniform: bl is not valid until fmd_wave_l_ready()
 };
 
+template <int AUX = FMD_GLDS_AUX>
 __device__ __forceinline__ FmdRank2c fmd_wave_rank2_fetch_compact(const FmdIndexView &ix, uint4 *lds, uint64_t k, uint64_t l)
 {
     const int q = fmd_lane();
@@ -435,7 +486,7 @@ __device__ __forceinline__ FmdRank2c fmd_wave_rank2_fetch_compact(const FmdIndex
     fmd_split(l, r.blk_l, ol_);
     fmd_l_from_k(r.hk && r.hl, l, r.blk_k, r.blk_l, ol_);
     r.l_sep = r.hl && !(r.hk && r.blk_k == r.blk_l);
-    fmd_fetch_slot<0>(ix, lds, r.blk_k, r.hk);
+    fmd_fetch_slot<0, AUX>(ix, lds, r.blk_k, r.hk);
     r.t = fmd_chunk_xor(q);
     r.bk = lds + fmd_lds_base(q, 0);
     r.bl = r.bk; r.tl = r.t;
@@ -449,7 +500,7 @@ __device__ __forceinline__ FmdRank2c fmd_wave_rank2_fetch_compact(const FmdIndex
             const int p = fmd_below(m);
             if (r.l_sep) ids[p] = r.blk_l;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            fmd_fetch_pool(ix, pool, ids, n_sep);
+            fmd_fetch_pool<AUX>(ix, pool, ids, n_sep);
             if (r.l_sep) { r.bl = pool + p * FMD_BLK_U4; r.tl = fmd_pool_xor(p); }
         } else r.two_phase = true;
     }
@@ -461,11 +512,12 @@ __device__ __forceinline__ FmdRank2c fmd_wave_rank2_fetch_compact(const FmdIndex
 // Second phase of a two-phase step (no-op otherwise).  All 64 lanes together, after every lane
 // has finished reading its k-side image: lanes whose l side lives in another block get it in the
 // dense slot; the others keep their k block, which is also their l block.
+template <int AUX = FMD_GLDS_AUX>
 __device__ __forceinline__ void fmd_wave_l_ready(const FmdIndexView &ix, uint4 *lds, FmdRank2c &r)
 {
     if (!r.two_phase) return;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // k-side LDS reads have returned
-    fmd_fetch_slot<0>(ix, lds, r.blk_l, r.l_sep);
+    fmd_fetch_slot<0, AUX>(ix, lds, r.blk_l, r.l_sep);
     fmd_fetch_wait();
     r.bl = r.bk; r.tl = r.t;
 }

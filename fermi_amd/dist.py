@@ -570,17 +570,40 @@ def key_shard_rows(torch, dist, rank, world, park, keys):
     return torch.cat(got), mat, split
 
 
+class DistStepFailed(RuntimeError):
+    """A rank failed inside the step; EVERY rank raises this, with the same (rank, code, piece), before anything further is posted."""
+
+    def __init__(self, rank, code, piece):
+        super().__init__("rank %d reports code %d in piece %d: every rank leaves the step" % (rank, code, piece))
+        self.failed_rank, self.code, self.piece = rank, code, piece
+
+
 def piecewise_exchange(torch, dist, rank, world, root, pieces, rows_of_rank, my_pieces):
     """The gather in pieces: my_pieces = list over p of (pid int32 [np], prec uint8 [np * 64], off int64 [np + 1], var uint8 [bytes]) of
-    this rank's rows piece_begin(rows, p) .. piece_begin(rows, p + 1) in its computing order.  Per piece: an all-gather of
-    (rows, variable bytes), then every peer's four arrays straight to the root.
+    this rank's rows piece_begin(rows, p) .. piece_begin(rows, p + 1) in its computing order -- or an int (a negative status code): this
+    rank FAILED on that piece (and on every later one).  Per piece: an all-gather of (rows, variable bytes, status), then every peer's four
+    arrays straight to the root.  The status word is how a failure reaches everybody (fmd_ovlp_dist_step, fmd_ovlp_dist.hip: the same three
+    words): all ranks read the same gathered words and raise DistStepFailed for the first failing rank BEFORE any send or receive of the piece.
     -> root: dict id -> (record bytes, variable-part bytes) of every row of the job; others: None."""
     table = {} if rank == root else None
+    failed = 0
     for p in range(pieces):
-        pid, prec, off, var = my_pieces[p]
-        mine = torch.tensor([len(pid), int(off[-1])], dtype=torch.int64)
-        sizes = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        if not isinstance(my_pieces[p], tuple):
+            failed = failed or int(my_pieces[p])
+        if failed:
+            pid = prec = off = var = None
+            mine = torch.tensor([0, 0, failed], dtype=torch.int64)
+        else:
+            pid, prec, off, var = my_pieces[p]
+            mine = torch.tensor([len(pid), int(off[-1]), 0], dtype=torch.int64)
+        sizes = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
         dist.all_gather(sizes, mine)
+        for q in range(world):
+            if int(sizes[q][2]):
+                raise DistStepFailed(q, int(sizes[q][2]), p)
+        for q in range(world):   # every rank checks every count: the same verdict everywhere
+            nq = int(sizes[q][0])
+            assert nq == piece_begin(rows_of_rank[q], p + 1, pieces) - piece_begin(rows_of_rank[q], p, pieces), "rank %d, piece %d: %d rows" % (q, p, nq)
         if rank != root:
             ops = []
             if len(pid):
@@ -593,7 +616,6 @@ def piecewise_exchange(torch, dist, rank, world, root, pieces, rows_of_rank, my_
         got, ops = {}, []
         for q in range(world):
             nq, vb = int(sizes[q][0]), int(sizes[q][1])
-            assert nq == piece_begin(rows_of_rank[q], p + 1, pieces) - piece_begin(rows_of_rank[q], p, pieces), "rank %d, piece %d: %d rows" % (q, p, nq)
             if q == root:
                 got[q] = (pid, prec, off, var[:vb])
                 continue

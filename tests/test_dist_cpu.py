@@ -201,6 +201,48 @@ def test_gather_in_pieces_and_key_shard_gloo(oracle_lib, world, pieces, key_shar
     assert ok
 
 
+def _failing_worker(rank, world, port, fmd, n_ids, min_match, pieces, bad_rank, bad_piece, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    own = fdist.shard_ids(n_ids, rank, world)
+    rows_of_rank = [fdist.shard_size(n_ids, r, world) for r in range(world)]
+    prec, off, var = _oracle_rows(fmd, own, min_match)
+    my = []
+    for p in range(pieces):
+        b, e = fdist.piece_begin(len(own), p, pieces), fdist.piece_begin(len(own), p + 1, pieces)
+        if rank == bad_rank and p >= bad_piece:
+            my.append(-5)                                # this rank ran out of memory packing piece p (FMD_E_NOMEM)
+            continue
+        o = off[b:e + 1].astype(np.int64) - int(off[b])
+        my.append((torch.from_numpy(own[b:e].astype(np.int32)), torch.from_numpy(prec[b:e].view(np.uint8).reshape(-1).copy()), torch.from_numpy(o),
+                   torch.from_numpy(var[int(off[b]):int(off[e])].copy())))
+    try:
+        fdist.piecewise_exchange(torch, dist, rank, world, 0, pieces, rows_of_rank, my)
+        q.put((rank, None))
+    except fdist.DistStepFailed as ex:
+        q.put((rank, (ex.failed_rank, ex.code, ex.piece)))
+    dist.barrier()                                       # nobody is left waiting in a send or a receive: all three get here
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bad_rank,bad_piece", [(1, 0), (2, 2), (0, 1)])
+def test_a_rank_that_fails_takes_every_rank_out_of_the_step_gloo(oracle_lib, bad_rank, bad_piece):
+    """world 3, one rank fails at piece `bad_piece` (a peer or the root): the status word of the per-piece all-gather reaches everybody, all three leave the
+    step with the same (rank, code, piece) and meet at the barrier behind it -- the protocol of fmd_ovlp_dist_step."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world, pieces = 3, 4
+    ps = [ctx.Process(target=_failing_worker, args=(r, world, port, os.path.join(GOLD, "tiny.fmd"), 601, 50, pieces, bad_rank, bad_piece, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == {r: (bad_rank, -5, bad_piece) for r in range(world)}
+
+
 def test_key_splitters_partition_the_key_space():
     for world in (1, 2, 3, 7, 8):
         split = np.array([0] + sorted(np.random.default_rng(world).integers(1, 0xfffffffe, world - 1).tolist()) + [0xfffffffe], dtype=np.uint64)

@@ -150,6 +150,68 @@ def test_dist_step_ranks_sharing_one_gpu(gpu, world, N, err, ragged, mm, pieces,
     assert ok
 
 
+def _failing_worker(rank, world, port, inject, key_shard, host_table, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from fermi_amd import api, dist as fdist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = api.DevIndex.from_bwt(api.build_bwt(_reads(12000, 0.0, False)))
+    n_ids = int(d.mcnt[1])
+    comm = fdist.TorchComm(api, dist, rank, world)
+    job = fdist.DistJob(api, d, comm, n_ids, 50, 100, 4, pieces=3, key_shard=key_shard, root=0, host_table=host_table)
+    job.step()                                                       # a good step first
+    os.environ["FMD_DIST_INJECT"] = inject                           # "<rank>:<where>[:<piece>]": that rank fails there, on its own
+    rc = api.lib().fmd_ovlp_dist_step(job.h, None, C.byref(job.stats))
+    del os.environ["FMD_DIST_INJECT"]
+    torch.cuda.synchronize()
+    q.put((rank, int(rc)))
+    dist.barrier()                                                   # every rank got out of the step: nobody hangs in a collective
+    st = job.step()                                                  # and the job is good for another step
+    ok = st.rows_computed > 0
+    if rank == 0:
+        t = job.table()
+        want_p, _, _ = _expected(api, d, n_ids, 50, 100, 4)
+        sample = np.arange(0, n_ids, 5)
+        got_rec, _ = _table_rows(api, t, n_ids, 4, 200, sample)
+        ok = ok and got_rec.tobytes() == want_p.tobytes()
+    q.put((100 + rank, bool(ok)))
+    dist.barrier()
+    job.free(); d.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("inject,key_shard,host_table", [
+    ("1:head", 0, 0),        # a peer's pass 1 fails; no collective until the first piece's sizes: they carry it
+    ("2:head", 1, 0),        # ... with the key exchange ahead: the agreement in front of it
+    ("1:keys", 1, 0),        # inside the key exchange: the status slot of the counts
+    ("2:pack:1", 0, 1),      # a peer cannot pack its second piece (the first one has been gathered already)
+    ("0:arena:2", 0, 0),     # the ROOT cannot make room for the last piece: the peers must not be left sending
+    ("0:pack:0", 1, 1),      # the root's own first piece
+])
+def test_a_failing_rank_takes_all_ranks_out_of_the_step_with_one_code(gpu, inject, key_shard, host_table):
+    """fmd_ovlp_dist_step used to return on a rank-local error while the peers sat in the matching collective.  Three ranks share
+    the GPU; one is made to fail (FMD_DIST_INJECT); all three must come out of the step with the same code (FMD_E_NOMEM), meet at a barrier behind
+    it, and run a correct step afterwards."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 3
+    ps = [ctx.Process(target=_failing_worker, args=(r, world, port, inject, key_shard, host_table, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(2 * world))
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [got[r] for r in range(world)] == [-5] * world, got
+    assert all(got[100 + r] for r in range(world)), got
+
+
 def test_head_and_tail_in_pieces_equal_the_sorted_job(gpu):
     """fmd_ovlp_head_dev + fmd_ovlp_tail_dev over slices of the order = fmd_ovlp_sorted_dev; fmd_ovlp_pack_rows_dev of a slice =
     the rows of that slice under their ids."""

@@ -10,11 +10,11 @@ def row(name, x, unit):
     cb = x.get("cpu_baseline")
     cpu = "%.3g %s on %d threads (1 thread: %.3g)" % (cb["value"], cb["unit"], cb["cores"], cb["one_thread"]) if cb else "—"
     sp = "%.0f×" % x["speedup_vs_cpu_all_cores"] if "speedup_vs_cpu_all_cores" in x else "—"
-    fr = "%.2f TB/s = **%.2f**" % (r["achieved"] / 1e3, r["frac"]) if r.get("frac") is not None else "—"
+    fr = "%.2f TB/s = %.2f" % (r["achieved_requested"] / 1e3, r["frac_requested"]) if r.get("frac_requested") is not None else "—"
     return "| %s | %.4g %s (%.1f ms) | %s | %s | %.1f TB/s | %s | %s |" % (name, x["value"], unit, r["kernel_ms"], fr, tr, r["algorithmic_equivalent_GBps"] / 1e3, cpu, sp)
 
 
-print("| leg | GPU (HIP-event ms per step) | requested device bytes ÷ time (`roofline.frac`) | HBM bytes from PMC ÷ time (`traffic_frac_of_peak`) | SURVEY 8(d) algorithmic equivalent | reference CPU, same box | ratio |")
+print("| leg | GPU (HIP-event ms per step) | requested device bytes ÷ time (`roofline.frac_requested`) | HBM bytes from PMC ÷ time (`roofline.frac`) | SURVEY 8(d) algorithmic equivalent | reference CPU, same box | ratio |")
 print("|---|---|---|---|---|---|---|")
 n = d["config"]["reads"]
 top = dict(d); top["value"] = d["value"]
