@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "fmd_retrieve_dev", "fmd_retrieve_batch", "fmd_probe_gather",
     "fmd_build_bwt", "fmd_build_bwt_dev", "fmd_dev_free", "fmd_builder_new", "fmd_builder_add_dev", "fmd_builder_finish", "fmd_builder_free", "fmd_bwt_to_rle6", "fmd_host_free",
     "fmd_dev_malloc", "fmd_memcpy_h2d", "fmd_memcpy_d2h",
-    "fmd_smem_work_bytes", "fmd_smem_dev", "fmd_smem_batch", "fmd_smem_win_dev", "fmd_smem_win_batch", "fmd_reach_dev", "fmd_reach_batch", "fmd_dev_export_bwt", "fmd_dev_check_rank",
+    "fmd_smem_work_bytes", "fmd_smem_dev", "fmd_smem_batch", "fmd_smem_win_dev", "fmd_smem_win_batch", "fmd_reach_dev", "fmd_reach_batch", "fmd_dev_export_bwt", "fmd_dev_check_rank", "fmd_dev_build_pairs", "fmd_dev_check_pairs",
     "fmd_kmer_work_bytes", "fmd_kmer_collect_dev", "fmd_kmer_collect_part_dev", "fmd_kmer_collect", "fmd_kmer_collect_seeds",
     "fmd_ectab_build_dev", "fmd_ectab_build", "fmd_ectab_free", "fmd_ecfix_work_bytes", "fmd_ecfix_dev", "fmd_ecfix_batch", "fmd_ectab_line_count",
     "fmd_ovlp_work_bytes", "fmd_ovlp_dev", "fmd_ovlp_sorted_work_bytes", "fmd_ovlp_sorted_dev", "fmd_ovlp_batch", "fmd_ovlp_check_left_dev", "fmd_seqinfo_dev", "fmd_seqinfo_batch",
@@ -111,6 +111,8 @@ def _configure(L):
     L.fmd_smem_batch.argtypes = [vp, sz, vp, u64p, C.c_int, C.c_uint32, C.c_uint32, vp, vp]
     L.fmd_dev_export_bwt.argtypes = [vp, C.c_uint64, C.c_uint64, vp]
     L.fmd_dev_check_rank.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.fmd_dev_build_pairs.argtypes = [vp, C.POINTER(C.c_int)]
+    L.fmd_dev_check_pairs.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.fmd_reach_dev.argtypes = [vp, vp, sz, vp, vp]
     L.fmd_reach_batch.argtypes = [vp, sz, vp, vp]
     L.fmd_smem_win_dev.argtypes = [vp, vp, sz, vp, vp, C.c_int, C.c_uint32, C.c_uint32, vp, vp, vp, sz]
@@ -252,6 +254,18 @@ class DevIndex:
         h = C.c_void_p()
         check(lib().fmd_dev_open_rle6(device, _ptr(runs), len(runs), C.byref(h)))
         return cls(h)
+
+    def build_pairs(self):
+        """the two-base blocks now (fmd_dev_build_pairs) -> True when the handle has them"""
+        b = C.c_int(0)
+        check(lib().fmd_dev_build_pairs(self.h, C.byref(b)))
+        return bool(b.value)
+
+    def check_pairs(self):
+        """every row's pair step against two single LF steps -> (number of bad rows, the first one)"""
+        bad, first = C.c_uint64(), C.c_uint64()
+        check(lib().fmd_dev_check_pairs(self.h, C.byref(bad), C.byref(first)))
+        return int(bad.value), int(first.value)
 
     def close(self):  # rld_destroy (rld.c:81)
         if self.h:

@@ -689,6 +689,8 @@ extern "C" void fmd_dev_close(fmd_dev_t *h)
     hipFree(h->blocks);
     hipFree(h->ptab);
     hipFree(h->tail);
+    hipFree(h->pair);
+    hipFree(h->pair_tab);
     hipFree(h->queues);
     hipFree(h->stat);
     for (size_t i = 0; i < sizeof(h->scratch) / sizeof(h->scratch[0]); ++i) if (h->scratch[i].p) hipFree(h->scratch[i].p);

@@ -17,6 +17,10 @@ struct fmd_dev {
     uint4 *ptab;              // device: intervals of all strings of ptab_d bases (FmdIndexView)
     int ptab_d;
     unsigned long long *tail;  // device: FmdIndexView::tail
+    uint4 *pair;               // device: two-base blocks (fmd_pair.hip), built on first use by the sorted overlap job; nullptr = none
+    unsigned long long *pair_tab;
+    uint64_t pair_bytes;
+    int pair_tried;
     uint32_t *queues;         // device ring of work-queue heads for the persistent kernels
     uint32_t queue_next;      // host-side ring cursor (atomic)
     unsigned long long *stat; // device: FMD_STAT_SLOTS x FMD_STAT_STRIDE line counters (written by the instrumented build only)
@@ -56,6 +60,7 @@ static inline FmdIndexView fmd_view(const fmd_dev *h)
     v.n_sym = h->mcnt[0];
     v.n_seq = h->mcnt[1];
     v.ptab = h->ptab; v.ptab_d = h->ptab_d; v.tail = h->tail;
+    v.pair = h->pair; v.pair_tab = h->pair_tab;
     v.stat = h->stat;
     return v;
 }
@@ -69,6 +74,9 @@ void fmd_scratch_release(fmd_dev *h, void *p);
 int fmd_index_alloc(int device, uint64_t n_sym, fmd_dev **out);
 int fmd_index_put_slice(fmd_dev *h, hipStream_t st, const uint8_t *d_slice, uint64_t first, uint64_t m);
 int fmd_index_finish(fmd_dev *h);
+
+// the two-base blocks (fmd_pair.hip): built if FMD_PAIR allows and they fit; FMD_OK either way (h->pair says)
+int fmd_pairs_ensure(fmd_dev *h);
 
 // next zeroed work-queue head for a persistent launch on `stream`
 uint32_t *fmd_next_queue(fmd_dev *h, hipStream_t stream);

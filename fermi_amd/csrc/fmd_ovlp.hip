@@ -38,7 +38,7 @@ int fmd_park_sort(hipStream_t st, size_t n, const FmdWalkPark *park, uint32_t *k
 #ifndef FMD_HEAD_AUX
 #define FMD_HEAD_AUX 0
 #endif
-enum { WK_IDLE = 0, WK_LF, WK_EXT, WK_BOTH, WK_RIGHT, WK_ADM1, WK_ADM2 };
+enum { WK_IDLE = 0, WK_LF, WK_EXT, WK_BOTH, WK_RIGHT, WK_ADM1, WK_ADM2, WK_PAIR };
 // can the LF step at row k be read from a block the backward extension of [x0, x0 + sz) brings in anyway (the block of x0 - 1, or
 // the block of its other end when that one does not reach it)?
 __device__ __forceinline__ bool walk_lf_shares(uint64_t k, uint64_t x0, uint64_t sz)
@@ -71,9 +71,13 @@ __device__ __forceinline__ bool walk_lf_shares(uint64_t k, uint64_t x0, uint64_t
             ++depth;                                                                                       \
             if ((depth & 15) == 0) { if (depth <= WALK_LS_BASES) walk_ls[((depth >> 4) - 1) * 64 + fmd_lane()] = pack; pack = 0; } \
         } else                                                                                             \
-        if (MODE == WALK_HEAD) {                                                                           \
+        if (MODE == WALK_HEAD || MODE == WALK_HEADP) {                                                     \
             const uint32_t v_ = (uint32_t)(cc) << (4 * (depth & 7)), w_ = depth >> 3;                      \
             pk0 |= w_ == 0 ? v_ : 0u; pk1 |= w_ == 1 ? v_ : 0u; pk2 |= w_ == 2 ? v_ : 0u; pack |= w_ == 3 ? v_ : 0u; \
+            if (MODE == WALK_HEADP && depth >= FMD_WALK_SPLIT) {   /* beyond the first park: 2 bits each */   \
+                const uint32_t e_ = depth - FMD_WALK_SPLIT, b_ = ((uint32_t)(cc) - 1u) & 3u;               \
+                ex0 |= e_ < 16 ? b_ << (2 * e_) : 0u; ex1 |= e_ >= 16 ? b_ << (2 * (e_ - 16)) : 0u;        \
+            }                                                                                              \
             ++depth;                                                                                       \
         } else {                                                                                           \
             pack |= (uint32_t)(cc) << (8 * (depth & 3));                                                   \
@@ -89,7 +93,16 @@ __device__ __forceinline__ bool walk_lf_shares(uint64_t k, uint64_t x0, uint64_t
 // those bases (k_ovl_park_keys), so that strands of one genomic window sit in neighbouring lanes; WALK_TAIL picks each strand up where
 // it was parked, in that order.  Nothing can be pushed before min_match >= FMD_WALK_SPLIT bases, so the two passes together make
 // exactly the steps of the one-pass walk and leave the same records, candidates and stash.
-enum { WALK_WHOLE = 0, WALK_HEAD = 1, WALK_TAIL = 2, WALK_TAIL2 = 3 };   // (FMD_WALK_SPLIT, FmdWalkPark: fmd_kernel_common.h)
+enum { WALK_WHOLE = 0, WALK_HEAD = 1, WALK_TAIL = 2, WALK_TAIL2 = 3, WALK_HEADP = 4 };   // (FMD_WALK_SPLIT, FmdWalkPark: fmd_kernel_common.h)
+// WALK_HEADP = WALK_HEAD over an index that has two-base blocks (FmdIndexView::pair, fmd_pair.hip): once the interval is narrow, a step takes TWO
+// bases from one 128-byte line (WK_PAIR), and the head goes on past FMD_WALK_SPLIT up to `split` <= min_match bases (nothing is pushed below
+// min_match) -- in pass 1 a base then costs half a request, in pass 2 a whole one.  The strand is parked TWICE: at FMD_WALK_SPLIT bases as ever (the
+// line written whole: row, interval, the 32 bases the order is made from), and at `split` the row and the interval are overwritten and the bases
+// in between (A/C/G/T, 2 bits each) + the depth go into pad.z / pad.w.  A strand that meets an N on the way stays parked where it was.
+#ifndef FMD_HEADP_WAVES
+#define FMD_HEADP_WAVES 2          // waves per SIMD the two-base head is compiled for (its 16.25 KiB of LDS allow nine per CU)
+#endif
+#define WALK_PARK_MAX 60u             // 28 more bases fit pad.z (16) and the low 24 bits of pad.w (12); pad.w >> 24 = the depth (0: FMD_WALK_SPLIT)
 
 // WALK_TAIL2 = WALK_TAIL for sequences of at most WALK_LS_BASES bases, without the stash in HBM and without k_ovl_seq_out behind it: the bases wait in
 // LDS, 2 bits each (code - 1; 7 words per lane: what is left of a CU's 160 KiB beside the gather's 8.25 KiB per wave at 16 waves), and the lane that
@@ -147,12 +160,49 @@ __device__ __forceinline__ void walk_emit_row(const uint32_t *st, uint32_t len, 
     }
 }
 
+// may the step at this depth take two bases from a two-base block?  Narrow interval that lies inside the 96 positions the block of x0 describes; neither
+// base may be one at which something is pushed or the strand is parked: both below `split`, and not across FMD_WALK_SPLIT (the first park)
+__device__ __forceinline__ bool walk_pair_ok(uint64_t x0, uint64_t sz, uint32_t depth, uint32_t split, bool nopair)
+{
+    return !nopair && sz <= 63 && ((uint32_t)x0 & 63u) + (uint32_t)sz <= FMD_BLK_SYMS && depth + 2 <= split && (depth + 2 <= FMD_WALK_SPLIT || depth >= FMD_WALK_SPLIT);
+}
+// the end of a step of k_ovl_walk: the state of the next one, and -- the heads -- the strand parked where it has to be
+#define WALK_NEXT_STATE_AND_PARK()                                                                                             \
+    do {                                                                                                                       \
+        st = walk_lf_shares(k, x0, sz) ? WK_BOTH : WK_LF;   /* can the LF step share the extension's gather? */               \
+        if (tab) st = WK_LF;                                /* inside the prefix table there is no extension to share one with */ \
+        if (MODE == WALK_HEADP && !tab && walk_pair_ok(x0, sz, depth, split, nopair)) st = WK_PAIR;                            \
+        if (HEADM && depth == FMD_WALK_SPLIT && !tab) {     /* park the strand: one 64-byte line, written whole */             \
+            uint4 *pp = (uint4 *)(park + gs);                                                                                  \
+            pp[0] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), (uint32_t)x0, (uint32_t)(x0 >> 32));                          \
+            pp[1] = make_uint4((uint32_t)x1, (uint32_t)(x1 >> 32), (uint32_t)sz, (uint32_t)(sz >> 32));                        \
+            pp[2] = make_uint4(pk0, pk1, pk2, pack); pp[3] = make_uint4(0, 0, 0, 0);                                           \
+            if (split == FMD_WALK_SPLIT) st = WK_IDLE;                                                                         \
+        } else if (MODE == WALK_HEADP && depth == split && !tab) {   /* ... and for good: row, interval, the bases since */    \
+            uint4 *pp = (uint4 *)(park + gs);                                                                                  \
+            pp[0] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), (uint32_t)x0, (uint32_t)(x0 >> 32));                          \
+            pp[1] = make_uint4((uint32_t)x1, (uint32_t)(x1 >> 32), (uint32_t)sz, (uint32_t)(sz >> 32));                        \
+            pp[3] = make_uint4(0, 0, ex0, ex1 | depth << 24);                                                                  \
+            st = WK_IDLE;                                                                                                      \
+        }                                                                                                                      \
+    } while (0)
+// WALK_TAIL / WALK_TAIL2 taking in a strand that was parked beyond FMD_WALK_SPLIT (adm_a = its pad): the bases in between into the stash, as the
+// steps would have put them
+#define WALK_PARKED_EXTRAS()                                                                                                   \
+    do {                                                                                                                       \
+        const uint32_t pd_ = adm_a.w >> 24;                                                                                    \
+        for (uint32_t e_ = 0; e_ + FMD_WALK_SPLIT < pd_; ++e_) {                                                               \
+            const uint32_t cc_ = (((e_ < 16 ? adm_a.z >> (2 * e_) : adm_a.w >> (2 * (e_ - 16))) & 3u) + 1u);                   \
+            WALK_PUT_BASE(cc_);                                                                                                \
+        }                                                                                                                      \
+    } while (0)
+
 // MODE = WALK_HEAD: item t = admission record t (k_ovl_head_adm: the strand's row in ids[], park[] and rec[] and where its walk stands
 // behind the tail table); the first 32 bases stay in registers and leave with the parked state in ONE 64-byte burst.
 // MODE = WALK_TAIL: item = slot of the batch (rows of srev, listA), gidx[slot] = its row in park[], rec[] (and, for the kernels
 // that follow, nei[] and seq[]).
 template <int MODE>
-__global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, const uint64_t *__restrict__ ids, int min_match,
+__global__ __launch_bounds__(64, MODE == WALK_HEADP ? FMD_HEADP_WAVES : 4) void k_ovl_walk(FmdIndexView ix, size_t n, const uint64_t *__restrict__ ids, int min_match,
                                                  uint8_t *__restrict__ srev, uint32_t stride_r, uint32_t cap,
                                                  fmd_intv_t *__restrict__ listA, fmd_ovlp_rec_t *__restrict__ rec,
                                                  uint8_t *__restrict__ seq_out, uint32_t seq_stride, uint32_t *__restrict__ queue,
@@ -162,8 +212,13 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
 {
     FMD_DECLARE_COMPACT_LDS();
     __shared__ uint32_t walk_ls[MODE == WALK_TAIL2 ? 64 * WALK_LS_WORDS : 1];   // WALK_TAIL2: the lane's bases, word w of lane l at [w * 64 + l]
+    __shared__ uint4 pair_lds[MODE == WALK_HEADP ? FMD_PAIR_SLOT_U4 : 1];       // WALK_HEADP: one two-base block image per lane (8 KiB)
     constexpr bool TAILM = MODE == WALK_TAIL || MODE == WALK_TAIL2;
-    constexpr int WAUX = MODE == WALK_HEAD ? FMD_HEAD_AUX : FMD_GLDS_AUX;   // pass 1 never asks for a line twice (strands in id order: every gather is a DRAM miss)
+    constexpr bool HEADM = MODE == WALK_HEAD || MODE == WALK_HEADP;
+    constexpr int WAUX = HEADM ? FMD_HEAD_AUX : FMD_GLDS_AUX;   // pass 1 never asks for a line twice (strands in id order: every gather is a DRAM miss)
+    const uint32_t split = MODE == WALK_HEADP ? (uint32_t)cls_cfg : FMD_WALK_SPLIT;   // WALK_HEADP: where the strand is parked for good (cls_cfg is free in the heads)
+    uint32_t ex0 = 0, ex1 = 0;            // WALK_HEADP: the bases beyond FMD_WALK_SPLIT, 2 bits each
+    bool nopair = false;                  // WALK_HEADP: the lane's last pair step met a base that is not A/C/G/T: one single step first
     size_t sid = 0;
     size_t gs = 0;                        // the strand's row in rec[] (WALK_TAIL: gidx[sid], otherwise sid)
     int st = WK_IDLE, c_pend = 0, ret = 0;
@@ -222,7 +277,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
             if (TAILM) {
                 if (my < n) { sid = my; gs = gidx[my]; st = WK_ADM1; }
                 else exhausted = true;
-            } else if (MODE == WALK_HEAD) {
+            } else if (HEADM) {
                 if (my < n) { sid = my; adm_a = adm[2 * my]; adm_b = adm[2 * my + 1]; st = WK_ADM1; }
                 else exhausted = true;
             } else
@@ -256,6 +311,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
         if (st == WK_LF) qk = k;
         else if (st == WK_EXT || st == WK_BOTH) { qk = x0 - 1; ql = x0 - 1 + sz; }
         else if (st == WK_RIGHT) { qk = x1 - 1; ql = x1 - 1 + sz; }
+        if (MODE == WALK_HEADP) fmd_pair_fetch<WAUX>(ix, pair_lds, (uint32_t)(x0 >> 6), st == WK_PAIR);   // (no wait of its own: the one below covers it)
         FmdRank2c r = fmd_wave_rank2_fetch_compact<WAUX>(ix, fmd_lds, qk, ql);
         // two-phase step (more than 32 lanes straddle: wide intervals): the k-side ranks are taken now,
         // the l-side after fmd_wave_l_ready(); a narrow lane whose window straddles sits this step out
@@ -274,9 +330,9 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
         const bool was_two_phase = r.two_phase;
         fmd_wave_l_ready<WAUX>(ix, fmd_lds, r);
         if (st == WK_IDLE || skip) continue;
-        if (MODE == WALK_HEAD && st == WK_ADM1) {   // the admission record has arrived (FmdHeadAdm, k_ovl_head_adm)
+        if (HEADM && st == WK_ADM1) {   // the admission record has arrived (FmdHeadAdm, k_ovl_head_adm)
             gs = adm_a.x;
-            depth = 0; npush = 0; pack = 0; pk0 = pk1 = pk2 = 0; flags = 0; ret = 0;
+            depth = 0; npush = 0; pack = 0; pk0 = pk1 = pk2 = 0; flags = 0; ret = 0; ex0 = ex1 = 0; nopair = false;
             if (adm_b.w & 1u) {   // no tail-table entry: from the sentinel, on the ordinary path
                 k = (uint64_t)(adm_b.y & 0xffu) << 32 | adm_a.y; st = WK_LF; tab = tab_ok;
             } else {
@@ -293,12 +349,69 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
                 pk1 = d > 8 ? (up + 0x11111111u) & (d >= 16 ? ~0u : (1u << (4 * (d - 8))) - 1u) : 0u;
                 depth = (uint32_t)d; tab = false;
                 st = walk_lf_shares(k, x0, sz) ? WK_BOTH : WK_LF;
+                if (MODE == WALK_HEADP && walk_pair_ok(x0, sz, depth, split, false)) st = WK_PAIR;
             }
+            continue;
+        }
+        if (MODE == WALK_HEADP && st == WK_PAIR) {
+            // ---- two bases from one line.  The lane's image holds, for the 96 positions from block(x0) on, BWT[p] and BWT[LF(p)] as bit planes; the
+            // interval [x0, x0 + sz) lies inside (walk_pair_ok), row k inside the interval.  The positions of the window with first symbol c1 are the
+            // interval one base on, in order; those among them with second symbol c2 are the interval two bases on: sizes, the x[1] sums of both
+            // extensions (fm6_extend's order 0 < 4 < 3 < 2 < 1 < 5, exact.c:81-86) and the rank of row k are popcounts, the start is one pair count.
+            const int q_ = fmd_lane(), px = fmd_pair_xor(q_);
+            const uint4 *img = pair_lds + fmd_pair_base(q_);
+            const uint32_t off = (uint32_t)x0 & 63u, hw = off >> 5, sh = off & 31u;
+            const uint4 A0 = img[0 ^ px], A1 = img[1 ^ px], A2 = img[2 ^ px], B0 = img[3 ^ px], B1 = img[4 ^ px], B2 = img[5 ^ px];
+#define WP_WIN(f0, f1, f2) win64(hw ? (f1) : (f0), hw ? (f2) : (f1), hw ? 0u : (f2), sh)
+            const uint64_t X = WP_WIN(A0.x, A1.x, A2.x), Y = WP_WIN(A0.y, A1.y, A2.y), Z = WP_WIN(A0.z, A1.z, A2.z);
+            const uint64_t S0 = WP_WIN(A0.w, A1.w, A2.w), S1 = WP_WIN(B0.x, B1.x, B2.x), S2 = WP_WIN(B0.y, B1.y, B2.y);
+#undef WP_WIN
+            const uint64_t m = bits_below((int)sz);
+            const uint32_t o = (uint32_t)(k - x0);
+            const int c1 = (int)(((X >> o) & 1) | ((Y >> o) & 1) << 1 | ((Z >> o) & 1) << 2);
+            const int c2 = (int)(((S0 >> o) & 1) | ((S1 >> o) & 1) << 1 | ((S2 >> o) & 1) << 2);
+            if (c1 < 1 || c1 > 4 || c2 < 1 || c2 > 4) {   // the sequence ends within two bases, or an N: this step again, one base at a time
+                nopair = true; st = WK_BOTH;
+                continue;
+            }
+            const uint64_t lo = ~Z & m, hi = Z & ~Y & m;
+            const uint64_t M0 = lo & ~Y & ~X, M1 = lo & ~Y & X, M2 = lo & Y & ~X, M3 = lo & Y & X, M4 = hi & ~X;
+            const uint64_t Mc = c1 == 1 ? M1 : c1 == 2 ? M2 : c1 == 3 ? M3 : M4;
+            const uint64_t lo2 = ~S2 & Mc, hi2 = S2 & ~S1 & Mc;
+            const uint64_t N0 = lo2 & ~S1 & ~S0, N1 = lo2 & ~S1 & S0, N2 = lo2 & S1 & ~S0, N3 = lo2 & S1 & S0, N4 = hi2 & ~S0;
+            const uint64_t Mp = c2 == 1 ? N1 : c2 == 2 ? N2 : c2 == 3 ? N3 : N4;
+            uint32_t before = (uint32_t)__popcll(M0) + (uint32_t)__popcll(N0);          // '$' sorts before every base
+            if (c1 != 4) before += (uint32_t)__popcll(M4);
+            if (c1 == 2 || c1 == 1) before += (uint32_t)__popcll(M3);
+            if (c1 == 1) before += (uint32_t)__popcll(M2);
+            if (c2 != 4) before += (uint32_t)__popcll(N4);
+            if (c2 == 2 || c2 == 1) before += (uint32_t)__popcll(N3);
+            if (c2 == 1) before += (uint32_t)__popcll(N2);
+            // pairs (c1, c2) before x0: the superblock's (+ K2: ix.pair_tab), the block's 28-bit count, positions [0, off) of the block
+            const uint32_t e0x = (c1 & 1) ? 0u : ~0u, e0y = (c1 & 2) ? 0u : ~0u, e0z = (c1 & 4) ? 0u : ~0u;
+            const uint32_t e1x = (c2 & 1) ? 0u : ~0u, e1y = (c2 & 2) ? 0u : ~0u, e1z = (c2 & 4) ? 0u : ~0u;
+            const uint32_t pm0 = (A0.x ^ e0x) & (A0.y ^ e0y) & (A0.z ^ e0z) & (A0.w ^ e1x) & (B0.x ^ e1y) & (B0.y ^ e1z);
+            const uint32_t pm1 = (A1.x ^ e0x) & (A1.y ^ e0y) & (A1.z ^ e0z) & (A1.w ^ e1x) & (B1.x ^ e1y) & (B1.y ^ e1z);
+            const uint32_t nb_ = (uint32_t)__builtin_popcount(pm0 & fmd_mask32((int)off)) + (uint32_t)__builtin_popcount(pm1 & fmd_mask32((int)off - 32));
+            const int pr = 4 * (c1 - 1) + (c2 - 1), bp = 28 * pr, tw = bp >> 5, tw1 = tw < 13 ? tw + 1 : 13;
+            const uint32_t *iw = (const uint32_t *)(pair_lds + fmd_pair_base(q_));
+#define WP_CW(t) iw[(((t) < 6 ? 3 + ((t) >> 1) : 6 + (((t) - 6) >> 2)) ^ px) * 4 + ((t) < 6 ? 2 + ((t) & 1) : (((t) - 6) & 3))]
+            const uint32_t cwl = WP_CW(tw), cwh = WP_CW(tw1);
+#undef WP_CW
+            const uint32_t rel = __builtin_amdgcn_alignbit(cwh, cwl, (uint32_t)bp & 31u) & 0x0fffffffu;
+            const uint64_t base = ix.pair_tab[(x0 >> (6 + FMD_PAIR_SB_SHIFT)) * 16 + (uint64_t)pr];
+            const uint64_t nx0 = base + rel + nb_;
+            k = nx0 + (uint64_t)__popcll(Mp & bits_below((int)o + 1)) - 1;
+            x0 = nx0; sz = (uint64_t)__popcll(Mp); x1 += before;
+            WALK_PUT_BASE(c1);
+            WALK_PUT_BASE(c2);
+            WALK_NEXT_STATE_AND_PARK();
             continue;
         }
         if (TAILM && st == WK_ADM1) {   // the strand's row is known: fetch what WALK_HEAD parked there, straight into the
             const uint4 *pp = (const uint4 *)(park + gs);   // registers the state will live in (the loads land under the next gather)
             const uint4 a = pp[0], b = pp[1], cb = pp[2];
+            adm_a = pp[3];                                  // pad.z / pad.w: the bases and the depth of a strand a WALK_HEADP parked beyond FMD_WALK_SPLIT
             k = (uint64_t)a.y << 32 | a.x; x0 = (uint64_t)a.w << 32 | a.z; x1 = (uint64_t)b.y << 32 | b.x; sz = (uint64_t)b.w << 32 | b.z;
             pk0 = cb.x; pk1 = cb.y; pk2 = cb.z; pack = cb.w;
             st = WK_ADM2;
@@ -311,6 +424,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
                 walk_ls[fmd_lane()] = (c0 & 0xffffu) | c1 << 16; walk_ls[64 + fmd_lane()] = (c2 & 0xffffu) | c3 << 16;
                 depth = FMD_WALK_SPLIT; npush = 0; pack = 0; pk0 = pk1 = pk2 = 0; ret = 0; tab = false;
                 flags = ((c0 | c1 | c2 | c3) & 0x10000u) ? WALK_F_HASN : 0u;
+                WALK_PARKED_EXTRAS();
                 st = walk_lf_shares(k, x0, sz) ? WK_BOTH : WK_LF;
             }
             continue;
@@ -324,6 +438,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
                 sr[1] = make_uint4(WALK_NIB4(pk2), WALK_NIB4(pk2 >> 16), WALK_NIB4(pack), WALK_NIB4(pack >> 16));
 #undef WALK_NIB4
                 depth = FMD_WALK_SPLIT; npush = 0; pack = 0; pk0 = pk1 = pk2 = 0; flags = 0; ret = 0; tab = false;
+                WALK_PARKED_EXTRAS();
                 st = walk_lf_shares(k, x0, sz) ? WK_BOTH : WK_LF;
             }
             continue;
@@ -386,7 +501,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
                 fmd_ovlp_rec_t *o = rec + gs;
                 o->rank = k; o->k[0] = o->k[1] = o->k[2] = 0; o->len = 0; o->status = -1; o->n_ovlp = 0; o->rbeg = -1;
                 o->ext_len = 0; o->n_nei = 0; o->flags = 0; o->reserved = 2; o->lfork = 0;
-                if (MODE == WALK_HEAD) park[gs].k = ~0ull;
+                if (HEADM) park[gs].k = ~0ull;
                 st = WK_IDLE;
                 continue;
             }
@@ -412,7 +527,8 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
             if (c != 0) { // one more base: overlap_intv's loop body (unitig.c:47-59)
                 const uint64_t sc = sel6(c, s[0], s[1], s[2], s[3], s[4], s[5]);
                 // (sc == 0 cannot happen: the sequence itself is in the index)
-                if (MODE != WALK_HEAD && !info_only && (int)depth >= min_match && s[0]) {
+                if (MODE == WALK_HEADP && depth >= FMD_WALK_SPLIT && c > 4) { st = WK_IDLE; continue; }   // an N beyond the first park: the strand stays parked there
+                if (!HEADM && !info_only && (int)depth >= min_match && s[0]) {
                     if (npush < cap) {
                         fmd_intv_t *e = listA + sid * (size_t)cap + (cap - 1 - npush);
                         if (narrow && depth < 65536u) cand_store_narrow(e, x0, x1, (uint32_t)sz, depth, wD, wr0);
@@ -435,7 +551,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
                 if (MODE == WALK_TAIL2) {
                     if ((depth & 15) && depth <= WALK_LS_BASES) walk_ls[(depth >> 4) * 64 + fmd_lane()] = pack;   // the last, partial word
                 } else
-                if (MODE != WALK_HEAD && (depth & 15) && depth <= stride_r) // the last, partial group of 16 (stride_r is a multiple of 16)
+                if (!HEADM && (depth & 15) && depth <= stride_r) // the last, partial group of 16 (stride_r is a multiple of 16)
                 {   // completed words of the group sit in pk0..2, a partial word in pack; everything past it is zero
                     const uint32_t wq = (depth >> 2) & 3;
                     *(uint4 *)(srev + sid * (size_t)stride_r + (depth & ~15u)) = make_uint4(wq == 0 ? pack : pk0, wq == 1 ? pack : pk1, wq == 2 ? pack : pk2, wq == 3 ? pack : 0u);
@@ -443,7 +559,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
                 fmd_ovlp_rec_t *o = rec + gs;
                 o->rank = k; o->len = (int32_t)depth; o->rbeg = -1; o->ext_len = 0; o->n_nei = 0; o->reserved = 2; o->lfork = 0;
                 o->k[0] = o->k[1] = o->k[2] = 0; o->n_ovlp = 0;
-                if (MODE == WALK_HEAD) park[gs].k = ~0ull;   // ended inside the head: shorter than min_match, the record below is final
+                if (HEADM) park[gs].k = ~0ull;   // ended inside the head: shorter than min_match, the record below is final
                 if (depth > stride_r) { o->status = 0; o->flags = FMD_OVLP_F_OVERFLOW; st = WK_IDLE; continue; } // longer than max_len
                 if (!info_only && (int)depth <= min_match) { o->status = -1; o->flags = 0; st = WK_IDLE; continue; } // too short (unitig.c:288)
                 // (the caller's copy in read order is made by k_ovl_seq_out: a lane doing it here, from a stash in HBM, holds up the other 63)
@@ -477,20 +593,12 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
             st = WK_IDLE;
             continue;
         }
-        // next base: can the LF step share the extension's gather?
-        {
-            st = walk_lf_shares(k, x0, sz) ? WK_BOTH : WK_LF;
-            if (tab) st = WK_LF;   // inside the prefix table there is no extension to share a gather with
-        }
-        if (MODE == WALK_HEAD && depth == FMD_WALK_SPLIT && !tab) {   // park the strand: one 64-byte line, written whole
-            uint4 *pp = (uint4 *)(park + gs);
-            pp[0] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), (uint32_t)x0, (uint32_t)(x0 >> 32));
-            pp[1] = make_uint4((uint32_t)x1, (uint32_t)(x1 >> 32), (uint32_t)sz, (uint32_t)(sz >> 32));
-            pp[2] = make_uint4(pk0, pk1, pk2, pack); pp[3] = make_uint4(0, 0, 0, 0);
-            st = WK_IDLE;
-        }
+        nopair = false;
+        WALK_NEXT_STATE_AND_PARK();
     }
 }
+#undef WALK_NEXT_STATE_AND_PARK
+#undef WALK_PARKED_EXTRAS
 
 #undef WALK_STASH_WORD
 #undef WALK_PUT_BASE
@@ -506,11 +614,16 @@ __global__ void k_ovl_seq_redo(FmdIndexView ix, const uint32_t *__restrict__ red
         const int len = rec[g].len;
         uint8_t *dst = seq_out + g * (size_t)seq_stride;
         const uint4 *pp = (const uint4 *)(park + g);
-        const uint4 a = pp[0], cb = pp[2];
+        const uint4 a = pp[0], cb = pp[2], pd = pp[3];
         const uint32_t nib[4] = {cb.x, cb.y, cb.z, cb.w};
         uint64_t k = (uint64_t)a.y << 32 | a.x;
+        const int parked = (int)(pd.w >> 24) > (int)FMD_WALK_SPLIT ? (int)(pd.w >> 24) : (int)FMD_WALK_SPLIT;   // (WALK_HEADP: the row stands `parked` bases in; those beyond the first 32 are in pad.z / pad.w, 2 bits each)
         for (int f = 0; f < (int)FMD_WALK_SPLIT && f < len; ++f) dst[len - 1 - f] = (uint8_t)((nib[f >> 3] >> (4 * (f & 7))) & 0xfu);
-        for (int f = (int)FMD_WALK_SPLIT; f < len; ++f) {
+        for (int f = (int)FMD_WALK_SPLIT; f < parked && f < len; ++f) {
+            const int e = f - (int)FMD_WALK_SPLIT;
+            dst[len - 1 - f] = (uint8_t)((((e < 16 ? pd.z >> (2 * e) : pd.w >> (2 * (e - 16))) & 3u)) + 1u);
+        }
+        for (int f = parked; f < len; ++f) {
             uint32_t b, o;
             fmd_split(k, b, o);
             const uint4 *img = ix.blocks + (size_t)b * FMD_BLK_U4;
@@ -1445,6 +1558,7 @@ extern "C" size_t fmd_ovlp_head_work_bytes(size_t n) { return head_layout(n).tot
 static int ovl_head(fmd_dev *h, hipStream_t st, size_t n, const uint64_t *d_ids, int min_match, uint32_t seq_stride, fmd_ovlp_rec_t *d_rec, FmdWalkPark *park,
                     uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_sorted, uint32_t *order, void *tmp, size_t tmp_bytes, uint4 *adm)
 {
+    (void)fmd_pairs_ensure(h);             // the two-base blocks, built on the first job of this handle where they fit (fmd_pair.hip)
     const FmdIndexView ix = fmd_view(h);
     // pass 1: every strand FMD_WALK_SPLIT bases in, in the caller's order.  (Taking the strands in the order of their last ptab_d bases --
     // the tail table has them, one more radix sort -- makes this pass 7 % faster and costs what it saves: profiles/r3_locality.)
@@ -1455,8 +1569,18 @@ static int ovl_head(fmd_dev *h, hipStream_t st, size_t n, const uint64_t *d_ids,
         if (blocks > (1u << 20)) blocks = 1u << 20;
         k_ovl_head_adm<<<(unsigned)blocks, 256, 0, st>>>(ix, n, d_ids, order1, use_tail, adm);
         uint32_t *q = fmd_next_queue(h, st);
-        int grid = fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16);
+        bool pairs = ix.pair != nullptr && ix.pair_tab != nullptr;
+        { const char *e = getenv("FMD_PAIR_USE"); if (e && atoi(e) == 0) pairs = false; }   // A/B switch on a handle that has the blocks
+        int grid = fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16 + (pairs ? FMD_PAIR_SLOT_U4 * 16 : 0));
         { const char *e = getenv("FMD_HEAD_WAVES"); if (e && atoi(e) > 0 && grid > h->n_cu * atoi(e)) grid = h->n_cu * atoi(e); }
+        if (pairs) {
+            // with two-base blocks a base of pass 1 costs half a request where a base of pass 2 costs a whole one: the head goes on up to min_match
+            // (nothing is pushed below it), as far as the parked line has room for the bases (WALK_PARK_MAX); FMD_HEAD_SPLIT is the A/B knob
+            int split = min_match < (int)WALK_PARK_MAX ? min_match : (int)WALK_PARK_MAX;
+            { const char *e = getenv("FMD_HEAD_SPLIT"); if (e && atoi(e) >= (int)FMD_WALK_SPLIT && atoi(e) <= split) split = atoi(e); }
+            k_ovl_walk<WALK_HEADP><<<grid, 64, 0, st>>>(ix, n, d_ids, min_match, nullptr, (uint32_t)sizeof(FmdWalkPark), 0, nullptr, d_rec,
+                                                     nullptr, seq_stride, q, 0, park, nullptr, adm, walk_ticket_chunk("FMD_HEAD_TICKETS", 256, n, grid), nullptr, nullptr, split);
+        } else
         k_ovl_walk<WALK_HEAD><<<grid, 64, 0, st>>>(ix, n, d_ids, min_match, nullptr, (uint32_t)sizeof(FmdWalkPark), 0, nullptr, d_rec,
                                                 nullptr, seq_stride, q, 0, park, nullptr, adm, walk_ticket_chunk("FMD_HEAD_TICKETS", 256, n, grid), nullptr, nullptr, 0);
     }

@@ -191,7 +191,7 @@ __global__ void k_ks_gather(size_t n, const uint32_t *__restrict__ order, const 
         uint4 v = ((const uint4 *)(park + row))[l4];
         const uint4 a = l4 == 0 ? v : ((const uint4 *)(park + row))[0];
         const bool ended = a.x == 0xffffffffu && a.y == 0xffffffffu;
-        if (l4 == 3) { const uint64_t id = ids[row]; v = make_uint4((uint32_t)id, (uint32_t)(id >> 32), 0u, 0u); }
+        if (l4 == 3) { const uint64_t id = ids[row]; v = make_uint4((uint32_t)id, (uint32_t)(id >> 32), v.z, v.w); }   // (pad.z / pad.w: the bases and the depth of a strand parked beyond 32 bases, fmd_ovlp.hip)
         if (ended && l4 == 0) { const uint64_t rk = rec[row].rank; v.z = (uint32_t)rk; v.w = (uint32_t)(rk >> 32); }
         if (ended && l4 == 1) { v.x = (uint32_t)rec[row].len; v.y = 0; }
         ((uint4 *)(send + t))[l4] = v;

@@ -121,14 +121,16 @@ __global__ void k_pair_k2(FmdIndexView ix, unsigned long long *__restrict__ k2)
 
 struct PairWiden { __host__ __device__ uint64_t operator()(uint8_t v) const { return (uint64_t)v; } };
 
-// Build the two-base blocks of `h` (idempotent).  FMD_PAIR=0: never; FMD_PAIR=1: whenever the allocation succeeds; default: when they fit with
-// room to spare (a job's buffers come after them).  Returns FMD_OK whether or not they were built: h->pair stays nullptr without them.
+// Build the two-base blocks of `h` (idempotent).  FMD_PAIR=1: whenever the allocation succeeds; FMD_PAIR=2: when they fit with room to spare (a job's
+// buffers come after them); otherwise -- the DEFAULT -- never: measured on 5*10^7 reads (profiles/r6_pair) the head that reads them takes 104 ms where
+// the single-step head takes 50.5 (it holds 8 KiB of LDS and 177 VGPRs per wave: 8 waves per CU against 16, and a wave step costs 6.5 us either
+// way), which the 18 ms it saves pass 2 do not pay for.  Returns FMD_OK whether or not they were built: h->pair stays nullptr without them.
 int fmd_pairs_ensure(fmd_dev *h)
 {
     if (h->pair || h->pair_tried) return FMD_OK;
     h->pair_tried = 1;
     const char *e = getenv("FMD_PAIR");
-    if (e && atoi(e) == 0) return FMD_OK;
+    if (!e || atoi(e) < 1) return FMD_OK;
     if (hipSetDevice(h->device) != hipSuccess) { (void)hipGetLastError(); return FMD_OK; }
     const uint64_t nb = h->n_blocks;
     const size_t need = (size_t)nb * FMD_PAIR_BYTES, temp = (size_t)nb * (16 + 8) + (64u << 20);

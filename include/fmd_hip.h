@@ -111,6 +111,13 @@ int fmd_retrieve_batch(fmd_dev_t *h, size_t n, const uint64_t *x, uint8_t *seqs,
  * at the last position, not the marginal counts); first_bad = the smallest of them. */
 int fmd_dev_export_bwt(fmd_dev_t *h, uint64_t first, uint64_t n, uint8_t *bwt);
 int fmd_dev_check_rank(fmd_dev_t *h, uint64_t *n_bad, uint64_t *first_bad);
+/* The two-base blocks (16 bits per symbol beside the index; fmd_pair.hip): what the sorted overlap job reads below min_match, two bases per
+ * 128-byte line where the rank blocks give one per 64-byte line -- same results, fewer requests.  The job builds them on first use where they fit
+ * (FMD_PAIR=0: never, FMD_PAIR=1: whenever the allocation succeeds); this call builds them now (*built = 1 when the handle has them).  The
+ * reference has nothing like it: rld_rank2a (rld.c:457) is asked once per base (unitig.c:47-59, exact.c:59-70).
+ * fmd_dev_check_pairs: every row's pair step against two single LF steps (FMD_E_ARG when the handle has no two-base blocks). */
+int fmd_dev_build_pairs(fmd_dev_t *h, int *built);
+int fmd_dev_check_pairs(fmd_dev_t *h, uint64_t *n_bad, uint64_t *first_bad);
 
 /* ---- forward reach ("matching statistics") --------------------------------------------------
  * seqs: n_bytes of nt6 sequences, each followed by at least one 0 byte (the _dev form: 4-byte

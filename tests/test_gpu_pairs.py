@@ -1,0 +1,104 @@
+"""GPU: the two-base blocks (fmd_pair.hip) and the head that reads them (k_ovl_walk<WALK_HEADP>).  A pair step is two exact LF / extension
+steps, so (a) every row's pair step must equal two single steps (fmd_dev_check_pairs, all rows of every fixture), and (b) the sorted job must
+leave the same bytes whether the handle has two-base blocks or not, wherever the head parks its strands (FMD_HEAD_SPLIT), on reads with
+errors, ragged lengths, Ns and sequences that end inside the head -- and those bytes are the id-order pass's, which the golden tests tie to
+the reference."""
+import os
+
+import numpy as np
+import pytest
+
+from fermi_amd import synth
+
+pytestmark = pytest.mark.gpu
+U64 = np.uint64
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _same(a, b, max_nei):
+    rec0, nei0, seq0 = a; rec1, nei1, seq1 = b
+    assert rec1.tobytes() == rec0.tobytes()
+    for j in range(max_nei):
+        mj = rec0["n_nei"] > j
+        assert nei1[mj, j].tobytes() == nei0[mj, j].tobytes(), j
+    used = (rec0["len"] + np.maximum(rec0["ext_len"], 0)).astype(np.int64)
+    m = (np.arange(seq0.shape[1])[None, :] < used[:, None]) & (rec0["status"] == 0)[:, None]
+    assert np.array_equal(seq1[m], seq0[m])
+
+
+@pytest.mark.parametrize("name", ["tiny", "special", "repeat", "dup32"])
+def test_pair_step_equals_two_single_steps_on_every_row(gpu, monkeypatch, name):
+    monkeypatch.setenv("FMD_PAIR", "1")
+    d = gpu.DevIndex.open(os.path.join(HERE, "golden", name + ".fmd"))
+    assert d.build_pairs()
+    assert d.check_pairs() == (0, 0)
+    d.close()
+
+
+def _ragged(rng, N, L, cov, err):
+    base = synth.reads(synth.DEFAULT_SEED + 77, N, L, cov, err)
+    reads = []
+    for i in range(N):
+        r = base[i].copy()
+        u = rng.random()
+        if u < 0.05:
+            r = r[: rng.integers(1, 62)]                     # ends inside the head, wherever it parks
+        elif u < 0.15:
+            r = r[rng.integers(0, 45):]
+        if rng.random() < 0.06:
+            r[rng.integers(0, len(r))] = 5                   # an N anywhere: among the first 32 bases, between the two parks, beyond
+        reads.append(r)
+    return reads + reads[:40]
+
+
+@pytest.mark.parametrize("mm,splits", [(50, (None, 32, 41, 50)), (60, (None, 33, 60)), (75, (None, 58)), (33, (None,))])
+def test_sorted_job_with_and_without_two_base_blocks(gpu, monkeypatch, mm, splits):
+    rng = np.random.default_rng(5 + mm)
+    reads = _ragged(rng, 14000, 100, 40, 0.004)
+    bwt = gpu.build_bwt(reads)
+    n_seq = 2 * len(reads)
+    ids = rng.permutation(n_seq)[: n_seq - 77].astype(U64)
+    monkeypatch.delenv("FMD_PAIR", raising=False)                     # the default: no two-base blocks
+    d0 = gpu.DevIndex.from_bwt(bwt)
+    want = d0.overlap(ids, mm, 100, 8, check_left=False)              # id order, the one-pass walk
+    plain = d0.overlap_sorted(ids, mm, 100, 8, 5000)
+    assert not d0.build_pairs()
+    _same(want, plain, 8)
+    d0.close()
+    monkeypatch.setenv("FMD_PAIR", "1")
+    d1 = gpu.DevIndex.from_bwt(bwt)
+    for sp in splits:
+        if sp is None:
+            monkeypatch.delenv("FMD_HEAD_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("FMD_HEAD_SPLIT", str(sp))
+        for batch in (0, 4097):
+            _same(want, d1.overlap_sorted(ids, mm, 100, 8, batch), 8)
+    assert d1.build_pairs() and d1.check_pairs() == (0, 0)            # (the job built them itself)
+    assert (want[0]["status"] == -1).sum() > 100 and (want[0]["n_nei"] > 0).sum() > 3000
+    d1.close()
+
+
+def test_two_base_head_on_a_repeat_rich_deep_set(gpu, monkeypatch):
+    """80-fold reads of a genome with repeats: intervals stay wider than a block for many bases (single steps between pair steps, windows
+    that do not fit a block's 96 positions), identical reads, forks."""
+    monkeypatch.setenv("FMD_PAIR", "1")
+    rng = np.random.default_rng(3)
+    unit = rng.integers(1, 5, 300).astype(np.uint8)
+    g = np.concatenate([rng.integers(1, 5, 3000).astype(np.uint8), unit, rng.integers(1, 5, 2000).astype(np.uint8), unit, unit, rng.integers(1, 5, 3000).astype(np.uint8)])
+    N, L = 9000, 100
+    pos = rng.integers(0, len(g) - L, N)
+    reads = []
+    for i in range(N):
+        r = g[pos[i]:pos[i] + L].copy()
+        if rng.random() < 0.5:
+            r = (5 - r)[::-1].copy()
+        e = rng.random(L) < 0.003
+        r[e] = (r[e] - 1 + rng.integers(1, 4, int(e.sum()))) % 4 + 1
+        reads.append(r)
+    d = gpu.DevIndex.from_bwt(gpu.build_bwt(reads))
+    ids = np.arange(2 * N, dtype=U64)
+    for mm in (40, 55):
+        _same(d.overlap(ids, mm, L, 16, check_left=False), d.overlap_sorted(ids, mm, L, 16, 6000), 16)
+    assert d.build_pairs() and d.check_pairs() == (0, 0)
+    d.close()
