@@ -73,8 +73,10 @@ def test_no_kernel_spills_to_scratch():
             seen += 1
             name = kr.demangle(k["name"])
             assert int(k.get("vgpr_spill_count", 0)) == 0, (os.path.basename(o), name, k)
-            if "rocprim" not in name:   # (the library sort's kernels keep small private arrays; ours have none)
-                assert int(k.get("private_segment_fixed_size", 0)) == 0, (os.path.basename(o), name, k)
+            if "rocprim" not in name and int(k.get("private_segment_fixed_size", 0)) != 0:   # (the library sort's kernels keep small private arrays; ours have none)
+                # a private segment in the metadata and not one instruction that reaches it: SGPR spill slots that were placed in VGPR lanes (k_ovl_walk<WALK_HEADP>,
+                # the opt-in two-base head: 106 SGPRs).  Anything that does reach scratch fails here.
+                assert kr.scratch_instructions(o, k["name"]) == 0, (os.path.basename(o), name, k)
     assert seen > 40
 
 

@@ -224,3 +224,31 @@ def test_oracle_ec_fix_reproduces_fermi_correct(oracle_lib, gold):
     quals = [np.frombuffer(r[2], dtype=np.uint8) for r in recs]
     s, q, off, info = orcbind.ec_fix(17, v["w17_o3_bucket"], v["w17_o3_key"], v["w17_o3_val"], nt6, quals)
     assert finish_correct(reads, s, q, off, info) == gold.text_gz("tiny.ec.fq.gz")
+
+
+def test_generator_rule_reproduces_the_reference_mag(tmp_path):
+    """tools/mag_vs_generator.py states what `unitig -l50` prints for error-free synthetic reads from the generator alone (runs of start positions at most
+    L - 50 apart: sequence, coverage string, number of reads, no neighbours) -- the exact check of `unitig` at sizes the reference cannot run (config 5,
+    tests/test_gpu_cfg5.py).  Here the rule is held against a MAG the REFERENCE printed (tests/golden/gen_rule_20k.mag.gz, made by make_gen_rule.py:
+    20 000 reads at 8-fold coverage, 346 unitigs, 8 of them single reads), and against MAGs it must reject."""
+    import gzip, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import mag_vs_generator as mg
+    mag = gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gen_rule_20k.mag.gz")).read()
+    p = str(tmp_path / "r.mag")
+    open(p, "wb").write(mag)
+    log = []
+    assert mg.check(p, 20000, 50, 100, 8, log=log.append), log
+    assert "346 runs expected, 346 matched exactly" in log[-1]
+    recs = mag.split(b"\n@")
+    bad = []
+    bad.append(b"\n@".join(recs[:100] + recs[101:]))                                             # a unitig missing
+    r = recs[5].split(b"\n"); r[3] = r[3][:40] + bytes([r[3][40] + 1]) + r[3][41:]               # one coverage character off by one
+    bad.append(b"\n@".join(recs[:5] + [b"\n".join(r)] + recs[6:]))
+    r = recs[7].split(b"\n"); r[1] = r[1][:-1] + (b"A" if r[1][-1:] != b"A" else b"C")             # one base
+    bad.append(b"\n@".join(recs[:7] + [b"\n".join(r)] + recs[8:]))
+    r = recs[9].split(b"\n"); h = r[0].split(b"\t"); h[1] = b"%d" % (int(h[1]) + 1); r[0] = b"\t".join(h)   # nsr
+    bad.append(b"\n@".join(recs[:9] + [b"\n".join(r)] + recs[10:]))
+    for m in bad:
+        open(p, "wb").write(m)
+        assert not mg.check(p, 20000, 50, 100, 8, log=lambda s: None)

@@ -33,6 +33,20 @@ def kernels_of(obj):
     return [k for k in out if "vgpr_count" in k]
 
 
+def scratch_instructions(obj, mangled):
+    """scratch_* / buffer_* (the two ways private memory is reached on gfx9) instructions in the code of one kernel of `obj`: a kernel whose metadata
+    names a private segment but whose code has none of them holds SGPR spill slots that ended up in VGPR lanes -- it never touches memory for them."""
+    with tempfile.TemporaryDirectory() as td:
+        fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "k.co")
+        subprocess.run([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.run([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dis = subprocess.run([LLVM + "/llvm-objdump", "-d", "--disassemble-symbols=" + mangled, co], check=True, capture_output=True, text=True).stdout
+    n_ins = sum(1 for ln in dis.splitlines() if "//" in ln)
+    assert n_ins > 50, "no disassembly of " + mangled
+    return sum(1 for ln in dis.splitlines() if re.search(r"\b(scratch_|buffer_)", ln))
+
+
 def demangle(sym):
     for tool in ("c++filt", LLVM + "/llvm-cxxfilt"):
         try:

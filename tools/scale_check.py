@@ -18,7 +18,9 @@ device layout; the only form that carries 1.4*10^11 symbols) --, then
     sub-sample is compared with the oracle; `props` (which assume error-free reads) is ignored.
   * `dry`: the allocations of one rank of the `share`-rank step (fmd_ovlp_dist_new with a stand-in communicator, FMD_DIST_DRY=1), as the root and as a peer.
   * `unitig`: `fermi-amd unitig -l50` on the .fmd as its own process: time, peak resident set, md5 of the MAG (and the same by build/old/fermi-amd-old where present).
-Usage: python tools/scale_check.py [n_reads=250000000] [bwt|inplace] [sample=20000] [share=8] [noref] [kmer] [props] [raw] [dry] [unitig]"""
+  * `genmag` (with `unitig`, error-free reads): the MAG of `fermi-amd unitig` checked EXACTLY against the generator (tools/mag_vs_generator.py: every unitig's
+    sequence, coverage string and number of reads, no other records) -- the check that needs no reference run; `noref fmd`: write the .fmd without the reference's checks.
+Usage: python tools/scale_check.py [n_reads=250000000] [bwt|inplace] [sample=20000] [share=8] [noref] [fmd] [kmer] [props] [raw] [dry] [unitig] [genmag]"""
 import ctypes as C, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -32,6 +34,7 @@ mode = sys.argv[2] if len(sys.argv) > 2 else "bwt"
 sample = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
 share = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 noref = "noref" in sys.argv[5:]
+WRITE_FMD = (not noref) or "fmd" in sys.argv[5:]      # `noref fmd`: the .fmd is written (for `unitig`), the comparisons with the reference are not run
 raw = "raw" in sys.argv[5:]
 ERR = 0.01 if raw else 0.0
 PROPS = "props" in sys.argv[5:] and not raw
@@ -70,7 +73,7 @@ if mode == "inplace":
     n_sym = index.n
     t_build = time.time() - t0
     print("index built in place: %d symbols in %.1f s (%.2e symbols/s), %.1f GB in HBM, HBM in use %.1f GB" % (n_sym, t_build, n_sym / t_build, index.hbm_bytes / 1e9, hbm_used()), flush=True)
-    if not noref:   # the reference reads fermi's file: decode the BWT back from the device layout, encode RLD on the host
+    if WRITE_FMD:   # the reference (and `fermi-amd unitig`) read fermi's file: decode the BWT back from the device layout, encode RLD on the host
         t0 = time.time()
         bwt = np.empty(n_sym, dtype=np.uint8)
         for o in range(0, n_sym, 1 << 30):
@@ -97,7 +100,7 @@ else:
     print("GPU BWT build: %d symbols in %.1f s (%.2e symbols/s); HBM in use after the build %.1f GB" % (n_sym, t_build, n_sym / t_build, hbm_used()), flush=True)
     del rd
     torch.cuda.empty_cache()
-    if not noref:
+    if WRITE_FMD:
         t0 = time.time()
         workload.write_fmd_from_device_bwt(d_bwt, n_sym, fmd_path, 0)
         print(".fmd written (GPU run-length pass + host RLD encoder): %.1f GB in %.1f s" % (os.path.getsize(fmd_path) / 1e9, time.time() - t0), flush=True)
@@ -236,6 +239,8 @@ if not noref:
         assert ok
     if "unitig" not in sys.argv[5:]:
         os.remove(fmd_path)
+elif WRITE_FMD and "unitig" not in sys.argv[5:]:
+    os.remove(fmd_path)
 # ---- one GPU's share of the sharded overlap discovery on this index (BASELINE configs[3] / [4]: ids i = 0 (mod share))
 job = bench.OverlapJob(torch, api, index, dev, 2 * n_reads, 0, share, L, 50)
 job.compute()                       # warm-up
@@ -270,7 +275,7 @@ if "dry" in sys.argv[5:]:   # one rank's allocations of the `share`-rank step on
             dj.free()
             torch.cuda.empty_cache()
 index.close()
-if "unitig" in sys.argv[5:] and not noref:
+if "unitig" in sys.argv[5:] and WRITE_FMD:
     # `fermi-amd unitig -l50` on the .fmd written above, as its own process: wall time, phase times, the peak resident set (FMD_TIMING) and the md5 of the MAG.
     # build/old/fermi-amd-old, where a builder put one (the CLI of an earlier tree linked against this libfmdhip.so), runs beside it: same MAG, its memory.
     import hashlib, subprocess
@@ -286,13 +291,19 @@ if "unitig" in sys.argv[5:] and not noref:
             continue
         t0 = time.time()
         h, nb = hashlib.md5(), 0
+        mag_path = os.path.join(tempfile.gettempdir(), "fmd_scale_%d.mag" % n_reads) if ("genmag" in sys.argv[5:] and name == "fermi-amd") else None
+        mag_fp = open(mag_path, "wb") if mag_path else None
         pr = subprocess.Popen(os.environ.get("FMD_CLI_WRAP", "").split() + [exe, "unitig", "-l50", fmd_path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, FMD_TIMING="1"))   # (FMD_CLI_WRAP: e.g. a profiler in front of the CLI)
         import threading
         errbuf = []
         th = threading.Thread(target=lambda: errbuf.append(pr.stderr.read())); th.start()
         for blk in iter(lambda: pr.stdout.read(1 << 24), b""):
             h.update(blk); nb += len(blk)
+            if mag_fp:
+                mag_fp.write(blk)
         rc = pr.wait(); th.join()
+        if mag_fp:
+            mag_fp.close()
         lines = [l for l in errbuf[0].decode().splitlines() if "M::" in l and "fmd_ovlp]" not in l]
         rss = [l for l in lines if "peak resident set" in l]
         print("unitig -l50 by %s: rc %d, %.1f s, MAG %d bytes md5 %s; %s" % (name, rc, time.time() - t0, nb, h.hexdigest(), rss[-1].split(": ", 1)[1] if rss else "no resident-set line"), flush=True)
@@ -302,5 +313,12 @@ if "unitig" in sys.argv[5:] and not noref:
         assert rc == 0
         assert seen is None or seen == h.hexdigest(), "the two CLIs print different MAGs"
         seen = h.hexdigest()
+        if mag_path:   # `genmag`: the MAG against what the generator knows -- exact, and possible where the reference cannot run (tools/mag_vs_generator.py)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import mag_vs_generator
+            ok_mag = mag_vs_generator.check(mag_path, n_reads, 50, L, 30, seed, log=lambda m_: print("    " + m_, flush=True))
+            print("unitig -l50 by %s against the generator (every unitig's sequence, coverage string and number of reads; no other records): %s" % (name, "EXACT" if ok_mag else "MISMATCH"), flush=True)
+            os.remove(mag_path)
+            assert ok_mag
     os.remove(fmd_path)
 print("scale check passed: %d reads, %d symbols, %s builder" % (n_reads, n_sym, mode))
