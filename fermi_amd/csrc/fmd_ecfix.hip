@@ -38,6 +38,26 @@ struct fmd_ectab {
     void *buf[5]; size_t buf_bytes[5]; int buf_busy;   // device buffers of fmd_ecfix_batch, kept between calls (EcBuf)
 };
 #define EC_EMPTY (~0ull)
+#ifndef EC_NT_TABLE
+#define EC_NT_TABLE 0
+#endif
+// What a lane keeps in LDS decides how many waves a CU holds (160 KiB), and this kernel lives on resident waves (profiles/r6_ecfix): three knobs.
+#ifndef EC_STAGE_QUAL  // 1: the qualities of a staged read wait in LDS beside its bases (8 KiB per wave)
+#define EC_STAGE_QUAL 0
+#endif
+#ifndef EC_TR_LINE     // trace entries per piece written / read at once through an LDS piece per lane: 0 = entry by entry, 4 = 32-byte pieces, 8 = whole 64-byte lines
+#define EC_TR_LINE 4
+#endif
+#ifndef EC_LDS_H       // entries of the lane's queue (a binary heap) that live in LDS, the rest in its slice of HBM
+#define EC_LDS_H 4
+#endif
+#ifndef EC_QWIN        // 1: the lane keeps the 16 aligned bytes of qualities around the last position it asked for in registers (a strand is searched position by position)
+#define EC_QWIN 1
+#endif
+#ifndef EC_HOP_BATCH   // 1: the bases a hop passes over are taken from the lane's LDS words in one piece, not one LDS read and one 64-bit shift per base
+#define EC_HOP_BATCH 1
+#endif
+#define EC_STAGE (EC_TR_LINE > 0)
 // One triple encodes to EC_EMPTY itself: the 27-mer of 27 Ts (54 one bits) with the largest packed depths (255) and best base T.
 // k_ectab_fill does not store it -- it would read as an empty slot and the solid k-mer as a miss -- but raises queue[EC_FULL_FLAG],
 // and a look-up of that k-mer that runs into an empty slot answers from the flag.
@@ -92,17 +112,21 @@ __device__ __forceinline__ int ec_lookup(const uint64_t *__restrict__ slots, uin
     uint64_t ln = ec_hash(x) & lmask;
     for (;;) {
         const uint4 *q = (const uint4 *)(slots + ln * EC_LINE);
+#if EC_NT_TABLE   // a table line is asked for once: "nt" keeps it from pushing the lanes' own reads out of the caches (profiles/r6_ecfix)
+        typedef uint32_t ec_u32x4 __attribute__((ext_vector_type(4)));
+        const ec_u32x4 a_ = __builtin_nontemporal_load((const ec_u32x4 *)q), b_ = __builtin_nontemporal_load((const ec_u32x4 *)q + 1),
+                       c_ = __builtin_nontemporal_load((const ec_u32x4 *)q + 2), d_ = __builtin_nontemporal_load((const ec_u32x4 *)q + 3);
+        const uint4 a = make_uint4(a_.x, a_.y, a_.z, a_.w), b = make_uint4(b_.x, b_.y, b_.z, b_.w), c = make_uint4(c_.x, c_.y, c_.z, c_.w), d = make_uint4(d_.x, d_.y, d_.z, d_.w);
+#else
         const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+#endif
         C.add(0, EC_LINE);
-        const uint64_t e[EC_LINE] = {(uint64_t)a.y << 32 | a.x, (uint64_t)a.w << 32 | a.z, (uint64_t)b.y << 32 | b.x, (uint64_t)b.w << 32 | b.z,
-                                     (uint64_t)c.y << 32 | c.x, (uint64_t)c.w << 32 | c.z, (uint64_t)d.y << 32 | d.x, (uint64_t)d.w << 32 | d.z};
         int hit = -2;
         bool free_slot = false;
-#pragma unroll
-        for (int k = 0; k < EC_LINE; ++k) {
-            if ((e[k] >> 10) == x && e[k] != EC_EMPTY) hit = (int)(e[k] & 0x3ff);
-            free_slot |= e[k] == EC_EMPTY;
-        }
+        // (slot by slot in registers: as an array of eight the compiler has put the line into scratch)
+#define EC_SLOT(lo_, hi_) do { const uint64_t e_ = (uint64_t)(hi_) << 32 | (lo_); if ((e_ >> 10) == x && e_ != EC_EMPTY) hit = (int)(e_ & 0x3ff); free_slot |= e_ == EC_EMPTY; } while (0)
+        EC_SLOT(a.x, a.y); EC_SLOT(a.z, a.w); EC_SLOT(b.x, b.y); EC_SLOT(b.z, b.w); EC_SLOT(c.x, c.y); EC_SLOT(c.z, c.w); EC_SLOT(d.x, d.y); EC_SLOT(d.z, d.w);
+#undef EC_SLOT
         if (hit >= 0) return hit;
         if (free_slot) return (full && x == (EC_EMPTY >> 10)) ? 0x3ff : -1;
         ln = (ln + 1) & lmask;
@@ -119,10 +143,10 @@ struct EcNode { uint64_t x; int64_t y; };
 // per expansion, of a position known before the table is asked: its byte is loaded beside the table's line, and it rides in the trace entry for the
 // walk back (correct.c:213-218 reads it again there).  What is left for HBM per turn: the table's line (the point of the exercise), that byte, one
 // 8-byte store to the trace.  Round 4's kernel kept all of it in HBM behind byte loads -- ~17 dependent round trips per expansion, 409 ms per 5*10^7 reads.
-#define EC_LDS_H 6
 #define EC_LDS_BASES 128
 #define EC_LDS_BW (EC_LDS_BASES / 8)          // words of bases per lane
-#define EC_LDS_BYTES (EC_LDS_H * 64 * 16 + EC_LDS_BW * 64 * 4)   // 10 KiB per wave: 16 waves per CU
+#define EC_LDS_QW (EC_LDS_BASES / 4)          // words of quality bytes per lane
+#define EC_LDS_BYTES (EC_LDS_H * 64 * 16 + EC_LDS_BW * 64 * 4 + (EC_STAGE_QUAL ? EC_LDS_QW * 64 * 4 : 0) + EC_TR_LINE * 64 * 8)   // 4 + 4 + 0 + 2 = 10 KiB per wave: 16 waves per CU
 
 struct EcHeap {                                // entry k of the lane's queue
     uint4 *lds; uint4 *hbm;                    // lds + k * 64 for k < EC_LDS_H, hbm + k beyond
@@ -172,6 +196,7 @@ __device__ __forceinline__ EcNode ec_pop(const EcHeap &H, uint32_t &hn, EcCount 
 struct EcRead {
     uint8_t *s, *q; int len; bool rc, staged;
     uint32_t *lb;                              // the lane's words of bases in LDS (staged reads)
+    uint32_t *lq;                              // EC_STAGE_QUAL: the lane's words of quality bytes in LDS, in read order
     __device__ __forceinline__ int at(int i) const { return rc ? len - 1 - i : i; }
     __device__ __forceinline__ int base(int i) const
     {
@@ -186,9 +211,40 @@ struct EcRead {
         s[j] = (uint8_t)v;
         if (staged) { uint32_t *w = lb + (j >> 3) * 64; *w = (*w & ~(0xfu << (4 * (j & 7)))) | v << (4 * (j & 7)); }
     }
+#if EC_STAGE_QUAL
+    __device__ __forceinline__ int qual(int i) const { const int j = at(i); return staged ? (int)((lq[(j >> 2) * 64] >> (8 * (j & 3))) & 0xffu) : (int)q[j]; }
+    __device__ __forceinline__ void set_qual(int i, int v)
+    {
+        const int j = at(i);
+        q[j] = (uint8_t)v;
+        if (staged) { uint32_t *w = lq + (j >> 2) * 64; *w = (*w & ~(0xffu << (8 * (j & 3)))) | (uint32_t)(v & 0xff) << (8 * (j & 3)); }
+    }
+#else
+#if EC_QWIN
+    // The quality of position i is asked for once per expansion, of a position a few bases from the last one: the 16 aligned bytes around it stay in four
+    // registers, and three accesses in four are answered from them.  (Byte by byte every access paid a 64-byte line that the table's lines had pushed out of
+    // the caches since the last one: 155 GB of table lines pass through them per 5*10^7 reads.  profiles/r6_ecfix.)
+    // (the window lives in the kernel's own registers, EcQwin: as members of this struct the whole struct went to scratch)
     __device__ __forceinline__ int qual(int i) const { return (int)q[at(i)]; }
     __device__ __forceinline__ void set_qual(int i, int v) { q[at(i)] = (uint8_t)v; }
+#else
+    __device__ __forceinline__ int qual(int i) const { return (int)q[at(i)]; }
+    __device__ __forceinline__ void set_qual(int i, int v) { q[at(i)] = (uint8_t)v; }
+#endif
+#endif
 };
+struct EcQwin { uint32_t w0, w1, w2, w3; uint64_t tag; };
+__device__ __forceinline__ int ec_qual(const EcRead &r, int i, EcQwin &W)
+{
+#if EC_QWIN && !EC_STAGE_QUAL
+    const uint64_t a = (uint64_t)(uintptr_t)(r.q + r.at(i)), t = a & ~15ull;
+    if (t != W.tag) { const uint4 v = *(const uint4 *)(uintptr_t)t; W.w0 = v.x; W.w1 = v.y; W.w2 = v.z; W.w3 = v.w; W.tag = t; }
+    const uint32_t o = (uint32_t)a & 15u, wv = (o >> 2) == 0 ? W.w0 : (o >> 2) == 1 ? W.w1 : (o >> 2) == 2 ? W.w2 : W.w3;
+    return (int)((wv >> (8 * (o & 3))) & 0xffu);
+#else
+    return r.qual(i);
+#endif
+}
 // The read into the lane's LDS words: aligned 4-byte loads funnel-shifted into place, whatever the alignment of its first byte; a word is loaded only if
 // it holds a byte of the read (bytes past the read's end inside its last word: whatever follows, never looked at).
 __device__ __forceinline__ void ec_stage_words(const uint8_t *p, int len, uint32_t *dst, bool nibbles)
@@ -215,11 +271,45 @@ __device__ __forceinline__ void ec_stage(EcRead &r)
     r.staged = r.len > 0 && r.len <= EC_LDS_BASES;
     if (!r.staged) return;
     ec_stage_words(r.s, r.len, r.lb, true);
+#if EC_STAGE_QUAL
+    ec_stage_words(r.q, r.len, r.lq, false);
+#endif
 }
+
+// The trace of a lane (correct.c:104: one entry per path, each naming its parent) is written in order and read back along ONE chain of parents.  Entry by
+// entry that is an 8-byte access to a line of the lane's own (64 lanes, 64 lines per wave instruction: every entry pays a 64-byte line -- 92 GB of traffic for
+// 11.5 GB of entries on 5*10^7 reads, profiles/r5_final).  EC_STAGE: the open line -- EC_TR_LINE entries -- waits in LDS (entry e of lane l at [e * 64 + l]) and
+// leaves whole; the walk back loads the line of the entry it wants into the same LDS line and takes every entry of its chain that the line holds.
+struct EcTrace {
+    uint64_t *hbm;                             // the lane's slice
+    uint64_t *ln;                              // its LDS line (lds + lane)
+    uint32_t tag;                              // walk back: the line of the slice the LDS line holds
+    __device__ __forceinline__ void put(uint32_t t, uint64_t v, EcCount &C)
+    {
+#if EC_STAGE
+        ln[(t & (EC_TR_LINE - 1)) * 64] = v;
+        if ((t & (EC_TR_LINE - 1)) == EC_TR_LINE - 1) flush(t, C);
+#else
+        hbm[t] = v; C.add(2);
+#endif
+    }
+    __device__ __forceinline__ void flush(uint32_t t, EcCount &C)     // the line that holds entry t, whole
+    {
+#if EC_STAGE
+        uint4 *dst = (uint4 *)(hbm + (t & ~(uint32_t)(EC_TR_LINE - 1)));
+#pragma unroll
+        for (int e = 0; e < (EC_TR_LINE > 0 ? EC_TR_LINE : 2); e += 2) {
+            const uint64_t a = ln[e * 64], b = ln[(e + 1) * 64];
+            dst[e >> 1] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+        }
+        C.add(2, EC_TR_LINE);
+#endif
+    }
+};
 
 // a new path: `par` extended by base code c (0..3; an N in the read is followed as A, correct.c:101) at a cost
 // (qv: the quality byte of the position the path steps over -- the walk back wants it, correct.c:215-217, and takes it from the trace entry)
-__device__ __forceinline__ bool ec_branch(const EcHeap &H, uint32_t &hn, uint64_t *trace, uint32_t &tn, uint32_t trace_cap, const EcNode &par, int c, int cost,
+__device__ __forceinline__ bool ec_branch(const EcHeap &H, uint32_t &hn, EcTrace &trace, uint32_t &tn, uint32_t trace_cap, const EcNode &par, int c, int cost,
                                           int shift, int has_match, int qv, EcCount &C)
 {
     if (tn >= trace_cap) return false;
@@ -227,8 +317,8 @@ __device__ __forceinline__ bool ec_branch(const EcHeap &H, uint32_t &hn, uint64_
     if (c >= 4) c = 0;
     const uint64_t py = (uint64_t)par.y, left = (py & 0xffff) - 1;
     const uint64_t y = ((py >> 48) + (uint64_t)cost) << 48 | (uint64_t)tn << 16 | left;
-    trace[tn++] = ((uint64_t)(uint32_t)qv << 16 | left) << 32 | (uint64_t)((uint32_t)c << 29 | (uint32_t)has_match << 28 | (uint32_t)(py >> 16)); // quality, position | base | matched | parent
-    C.add(2);
+    trace.put(tn, ((uint64_t)(uint32_t)qv << 16 | left) << 32 | (uint64_t)((uint32_t)c << 29 | (uint32_t)has_match << 28 | (uint32_t)(py >> 16)), C); // quality, position | base | matched | parent
+    ++tn;
     ec_push(H, hn, (uint64_t)c << shift | par.x >> 2, (int64_t)y, C);
     return true;
 }
@@ -253,7 +343,7 @@ struct EcSearch {
     int64_t done_y0, done_y1;  // keys of the (up to two) best finished paths
 };
 
-__device__ __forceinline__ bool ec_seed(const EcRead &r, int w, EcSearch &S, const EcHeap &H, uint64_t *trace, EcCount &C)   // false: ec_fix1 returns 0xffff
+__device__ __forceinline__ bool ec_seed(const EcRead &r, int w, EcSearch &S, const EcHeap &H, EcTrace &trace, EcCount &C)   // false: ec_fix1 returns 0xffff
 {
     const int shift = (w - 1) << 1;
     if (r.len <= w) return false;
@@ -266,8 +356,8 @@ __device__ __forceinline__ bool ec_seed(const EcRead &r, int w, EcSearch &S, con
     }
     if (i == 0) return false;
     S.hn = 0; S.tn = 0; S.n_done = 0; S.no_hits = 1; S.done_y0 = S.done_y1 = 0;
-    trace[S.tn++] = 0;
-    C.add(2);
+    trace.put(S.tn, 0, C);
+    ++S.tn;
     ec_push(H, S.hn, x, (int64_t)(i + 1), C);
     return true;
 }
@@ -284,12 +374,29 @@ __global__ __launch_bounds__(64, 4) void k_ecfix(size_t n, uint8_t *__restrict__
 {
     __shared__ uint4 lds_heap[EC_LDS_H * 64];
     __shared__ uint32_t lds_bases[EC_LDS_BW * 64];
+#if EC_STAGE_QUAL
+    __shared__ uint32_t lds_quals[EC_LDS_QW * 64];
+#endif
+#if EC_STAGE
+    __shared__ uint64_t lds_trace[EC_TR_LINE * 64];
+#endif
     const int lane = (int)threadIdx.x;
     const size_t slice = (size_t)blockIdx.x * 64 + threadIdx.x;
     EcHeap H; H.lds = lds_heap + lane; H.hbm = heaps + slice * EC_HEAP_SLOTS;
-    uint64_t *trace = traces + slice * (size_t)trace_cap;
+    EcTrace trace; trace.hbm = traces + slice * (size_t)trace_cap; trace.tag = 0;
+#if EC_STAGE
+    trace.ln = lds_trace + lane;
+#else
+    trace.ln = nullptr;
+#endif
     const int shift = (w - 1) << 1;
     EcRead r; r.s = nullptr; r.q = nullptr; r.len = 0; r.rc = true; r.staged = false; r.lb = lds_bases + lane;
+    EcQwin QW; QW.w0 = QW.w1 = QW.w2 = QW.w3 = 0; QW.tag = ~0ull;
+#if EC_STAGE_QUAL
+    r.lq = lds_quals + lane;
+#else
+    r.lq = nullptr;
+#endif
     EcSearch S; S.hn = S.tn = 0; S.n_done = 0; S.no_hits = 1; S.done_y0 = S.done_y1 = 0;
     EcNode z, keep;                            // EL_JUMP: the path as the hop in progress leaves it, and as the last accepted hop left it
     z.x = 0; z.y = 0; keep = z;
@@ -309,6 +416,7 @@ __global__ __launch_bounds__(64, 4) void k_ecfix(size_t n, uint8_t *__restrict__
             if (my < n) {
                 cur = my;
                 r.s = seqs + off[my]; r.q = quals + off[my]; r.len = (int)(off[my + 1] - off[my]); r.rc = true;
+                QW.tag = ~0ull;
                 ec_stage(r);
                 if (ec_seed(r, w, S, H, trace, C)) st = EL_POP;
                 else info[my] = 0xffff;                                    // too short, or no clean k-mer (correct.c:242-246)
@@ -333,7 +441,32 @@ __global__ __launch_bounds__(64, 4) void k_ecfix(size_t n, uint8_t *__restrict__
             }
         } else if (st == EL_JUMP) {                                        // `step` bases on (correct.c:183-185)
             int l;
-            for (i = (int)((uint64_t)z.y & 0xffff) - 1, l = 0; i >= 1 && l < step; --i, ++l) {
+            i = (int)((uint64_t)z.y & 0xffff) - 1;
+            const int nav = i < step ? (i < 0 ? 0 : i) : step;             // bases the loop below would take if none of them is an N (i >= 1, l < step)
+            bool batched = false;
+#if EC_HOP_BATCH
+            if (r.staged && nav > 0 && nav <= 8 && 2 * (nav - 1) <= shift) {
+                // all of them at once: their nibbles are one field of the lane's LDS words (positions i - nav + 1 .. i of the strand; on the reverse strand the
+                // bytes run the other way and the bases are complemented), A/C/G/T -> 2 bits each, into the k-mer in the order the loop shifts them in
+                const int jl = r.rc ? r.len - 1 - i : i - nav + 1;
+                const uint32_t wq = (uint32_t)jl >> 3, sh4 = 4u * ((uint32_t)jl & 7u);
+                const uint32_t lo_w = r.lb[wq * 64], hi_w = wq + 1 < EC_LDS_BW ? r.lb[(wq + 1) * 64] : 0u;
+                const uint32_t fm = nav == 8 ? ~0u : (1u << (4 * nav)) - 1u;
+                const uint32_t F = (uint32_t)(((uint64_t)hi_w << 32 | lo_w) >> sh4) & fm;
+                const uint32_t t = F - (0x11111111u & fm);                    // nibbles 0..3 for A/C/G/T, 4 for an N
+                if (((t >> 2) & 0x11111111u & fm) == 0) {                     // no N among them
+                    uint32_t y = (t | t >> 2) & 0x0f0f0f0fu;                  // pairs of bases per byte
+                    y = (y | y >> 4) & 0x00ff00ffu; y = (y | y >> 8) & 0xffffu;   // nav bases, 2 bits each, the one at the lowest byte address first
+                    if (r.rc) y ^= (1u << (2 * nav)) - 1u;                    // complemented; the loop's first base is the one at the lowest address
+                    else { uint32_t rv = __brev(y) >> (32 - 2 * nav); y = ((rv >> 1) & 0x55555555u) | ((rv & 0x55555555u) << 1); }   // ... at the highest address: the 2-bit groups reversed
+                    z.x = (uint64_t)y << (shift - 2 * (nav - 1)) | z.x >> (2 * nav);
+                    i -= nav;
+                    batched = true;
+                }
+            }
+#endif
+            if (!batched)
+            for (l = 0; i >= 1 && l < step; --i, ++l) {
                 const int c = r.base(i);
                 if (c >= 5) break;
                 z.x = (uint64_t)(c - 1) << shift | z.x >> 2;
@@ -347,12 +480,26 @@ __global__ __launch_bounds__(64, 4) void k_ecfix(size_t n, uint8_t *__restrict__
             qsum = 0;
             ct = ((uint64_t)S.done_y0 >> 48) == 0 ? 0u : (uint32_t)((uint64_t)S.done_y0 >> 16);   // nothing to change: no walk back
             st = EL_CLOSE;
+#if EC_STAGE
+            if (ct && S.tn) { trace.flush(S.tn - 1, C); trace.tag = (S.tn - 1) / EC_TR_LINE; }   // the open line leaves too (whole: what lies behind its last entry is never read); the LDS line still holds it
+#endif
         }
         // ---- the turn's one request per lane
         int hit = -1, qv = 0;
         uint64_t te = 0;
-        if (want) { qv = r.qual(i); hit = ec_lookup(slots, mask, z.x, full, C); }   // (the byte's load is in flight beside the line's)
-        if (st == EL_CLOSE && ct) { te = trace[ct]; C.add(2); }
+        if (want) { qv = ec_qual(r, i, QW); hit = ec_lookup(slots, mask, z.x, full, C); }   // (the byte's load is in flight beside the line's)
+#if EC_STAGE
+        uint4 tl[EC_TR_LINE / 2];
+        const bool tload = st == EL_CLOSE && ct && ct / EC_TR_LINE != trace.tag;
+        if (tload) {
+            const uint4 *src = (const uint4 *)(trace.hbm + (ct & ~(uint32_t)(EC_TR_LINE - 1)));
+#pragma unroll
+            for (int e = 0; e < EC_TR_LINE / 2; ++e) tl[e] = src[e];
+            C.add(2, EC_TR_LINE);
+        }
+#else
+        if (st == EL_CLOSE && ct) { te = trace.hbm[ct]; C.add(2); }
+#endif
         // ---- what came back
         if (want && st == EL_POP) {
             int q = qv - 33;
@@ -392,14 +539,29 @@ __global__ __launch_bounds__(64, 4) void k_ecfix(size_t n, uint8_t *__restrict__
         }
         if (overflow) { info[cur] = (int32_t)EC_INFO_TRACE_FULL; st = EL_IDLE; continue; }
         if (st != EL_CLOSE) continue;
+#if EC_STAGE
+        if (tload) {                                                       // the line of the chain's next entry into the lane's LDS line
+#pragma unroll
+            for (int e = 0; e < EC_TR_LINE / 2; ++e) { trace.ln[2 * e * 64] = (uint64_t)tl[e].y << 32 | tl[e].x; trace.ln[(2 * e + 1) * 64] = (uint64_t)tl[e].w << 32 | tl[e].z; }
+            trace.tag = ct / EC_TR_LINE;
+        }
+        while (ct && ct / EC_TR_LINE == trace.tag) {                       // every choice of the best path that this line holds (correct.c:213-218)
+            te = trace.ln[(ct & (EC_TR_LINE - 1)) * 64];
+#else
         if (ct) {                                                          // one choice of the best path applied (correct.c:213-218)
+#endif
             const int pos = (int)((te >> 32) & 0xffffu), qq = (int)((te >> 48) & 0xffu);
             const uint32_t lo = (uint32_t)te, c = lo >> 29;
             if ((uint32_t)(r.base(pos) - 1) != c) { qsum += qq - 33; r.set_base(pos, (int)c + 1); }
-            else if ((lo >> 28 & 1) && qq < 37) r.set_qual(pos, 37);
+            else if ((lo >> 28 & 1) && qq < 37) { r.set_qual(pos, 37); QW.tag = ~0ull; }
             ct = lo << 4 >> 4;
+#if !EC_STAGE
             if (ct) continue;
+#endif
         }
+#if EC_STAGE
+        if (ct) continue;
+#endif
         {                                                                  // the strand is done
             int ret = ((uint64_t)S.done_y0 >> 48) == 0 ? score_diff << 18 : (qsum | score_diff << 18 | S.no_hits << 17);
             if (r.rc) {                                                    // the reverse-complement strand is done: now the read as given
@@ -513,6 +675,7 @@ extern "C" int fmd_ecfix_dev(fmd_ectab_t *t, void *stream_, size_t n, uint8_t *d
     FMD_HIP_TRY(hipSetDevice(t->device));
     hipStream_t st = (hipStream_t)stream_;
     const int grid = ec_grid(t->device, n);
+    if (EC_TR_LINE > 0) trace_cap &= ~(uint32_t)((EC_TR_LINE > 0 ? EC_TR_LINE : 1) - 1);               // slices of whole 64-byte lines (the work area was sized by the caller's number: no smaller)
     uint4 *heaps = (uint4 *)(((uintptr_t)d_work + 255) & ~(uintptr_t)255);
     uint64_t *traces = (uint64_t *)(heaps + (size_t)grid * 64 * EC_HEAP_SLOTS);
     FMD_HIP_TRY(hipMemsetAsync(t->queue, 0, 4, st));
