@@ -1443,6 +1443,29 @@ def main():
         apply_traffic(ovl["roofline"])
         if cl and "roofline" in cl:
             apply_traffic(cl["roofline"])
+    # ---- what the PRODUCT does with N GPUs: `fermi-amd unitig -g 0,1,..` is ONE process with one index replica and one host thread per
+    # GPU, rows of ids i = g (mod N) streamed over each GPU's own PCIe link into the slim table, host threads linking -- no RCCL.  The step timed above is
+    # fmd_ovlp_dist_step (one process per GPU behind the C ABI); this is the other path's rate, host side included, on the same .fmd, once.  The ranks have
+    # closed their indexes; rank 0 opens the N replicas itself while the others wait at the barrier.
+    product = None
+    if world > 1 or os.environ.get("FMD_BENCH_PRODUCT_TABLE") == "1":
+        if rank == 0 and fmd_path and os.path.exists(fmd_path):
+            try:
+                from fermi_amd import hostlib
+                devs = tuple(0 if os.environ.get("FMD_BENCH_SHARE_GPU") == "1" else g for g in range(world))   # (a builder's box: the replicas share GPU 0, as the ranks did)
+                tb = hostlib.slim_build(fmd_path, ovl["min_match"] if ovl else 50, devs)
+                product = {"path": "`fermi-amd unitig -g %s`: fmdh_slim_build -- one process, %d index replica(s) and host thread(s), rows of ids i = g (mod %d) over each GPU's own PCIe link "
+                                   "into the slim table (host/slim_table.c), host threads fold and link; no RCCL" % (",".join(str(g) for g in devs), world, world),
+                           "rows": tb["n_seq"], "rows_phase_seconds": tb["rows_s"], "strands_per_s_rows_phase": tb["n_seq"] / max(tb["rows_s"], 1e-9),
+                           "reads_per_s_rows_phase": tb["n_seq"] / 2 / max(tb["rows_s"], 1e-9),
+                           "whole_table_seconds_without_index_load": tb["build_s"] - tb["index_load_s"], "index_load_seconds_slowest_replica": tb["index_load_s"],
+                           "reads_per_s_whole_table": tb["n_seq"] / 2 / max(tb["build_s"] - tb["index_load_s"], 1e-9),
+                           "table_bytes_per_row": tb["table_bytes"] / max(1, tb["n_seq"]),
+                           "note": "host side included (16 host threads fold the rows into 32-byte lines while they arrive); the walk itself is not part of either number"}
+            except Exception as ex:
+                product = {"failed": repr(ex)}
+        if dist is not None and world > 1:
+            dist.barrier()
     if fmd_path and os.path.exists(fmd_path):
         os.remove(fmd_path)
 
@@ -1480,6 +1503,8 @@ def main():
             r = out["roofline"]
             r["random_gather_ceiling"] = {"probe_GBps": probe["GB_per_s"], "requested_bytes_frac_of_it": (r["achieved_requested"] / probe["GB_per_s"]) if r.get("achieved_requested") else None,
                                           "traffic_frac_of_it": (r["traffic_GBps"] / probe["GB_per_s"]) if r.get("traffic_GBps") else None}
+        if product:
+            out["product_path_unitig_g"] = product
         if cl:
             out["check_left"] = cl
         if bs:

@@ -246,6 +246,7 @@ int fmdh_ovlp_table_link(fmdh_ovlp_table_t *t, int n_threads, uint64_t **undecid
  * capacities are recomputed (device 0) with the capacities raised until they fit.  A device may be listed more than once (two
  * replicas on one GPU).  *out is released with fmdh_slim_free. */
 int fmdh_slim_build(const char *fmd_path, int n_dev, const int *devices, int min_match, fmdh_slim_t **out, uint64_t *n_seq);
+void fmdh_slim_last_build(double out[4]);   /* seconds of the last build: slowest replica's load, slowest replica's rows, whole build; bytes of the table */
 void fmdh_ovlp_table_free(fmdh_ovlp_table_t *t);
 /* Replays the single-threaded walk and writes the MAG records `fermi unitig -t1` prints. */
 int fmdh_unitig_walk(const fmdh_ovlp_table_t *t, uint64_t n_seq, int min_match, const uint64_t *sorted /* or NULL */, FILE *out);

@@ -253,6 +253,11 @@ void fmdh_ovlp_table_free(fmdh_ovlp_table_t *t)
 
 static int cmp_u64(const void *a, const void *b) { const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b; return x < y ? -1 : x > y; }
 static int slim_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_dev, const int *devices, int min_match, fmdh_slim_t **out, uint64_t *n_seq_out);
+/* seconds of the last table build of this process: [0] the slowest replica's index load + transcode, [1] the slowest replica's rows (GPU + copies over PCIe +
+ * folding into the slim table), [2] the whole build (rows computed again, link pass, plain steps included), [3] bytes of the table.  What bench.py --gpus N
+ * reports beside the RCCL step as the rate of the path `fermi-amd unitig -g 0,1,..` takes. */
+static double g_last_build[4];
+void fmdh_slim_last_build(double out[4]) { memcpy(out, g_last_build, sizeof(g_last_build)); }
 int fmdh_slim_build(const char *fmd_path, int n_dev, const int *devices, int min_match, fmdh_slim_t **out, uint64_t *n_seq_out)
 {
     return slim_build_core(fmd_path, 0, n_dev, devices, min_match, out, n_seq_out);
@@ -340,9 +345,18 @@ static int slim_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_dev
         if (!ids) { rc = 1; goto done; }
         for (g = 0; g < n_dev; ++g) { memcpy(ids + o, jobs[g].flagged, jobs[g].n_flagged * 8); o += jobs[g].n_flagged; }
         if (n_dev > 1) qsort(ids, n_side, 8, cmp_u64);   /* (one shard: ascending already) */
+        uint64_t over_at_cap = 0;
+        int at_cap = 0;
         for (attempt = 0;; ++attempt) {
             uint64_t n_over = 0;
-            if (attempt == 12) { fprintf(stderr, "[E::%s] %llu rows still overflow at max_len %u, max_nei %u\n", __func__, (unsigned long long)n_side, s_len, s_nei); rc = 1; shard_free(&side); goto done; }
+            /* the ladder ends at sequences of 4000 + min_match bases (candidate lists of 4095 entries): two attempts there that leave the same rows flagged
+             * are rows it cannot hold -- said so, with status 1 and nothing printed, rather than a list cut short (tests/test_gpu_parity.py pins this edge,
+             * which the reference, whose vectors grow, does not have: kvec.h:76-82) */
+            if (attempt == 12 || at_cap >= 2) {
+                fprintf(stderr, "[E::%s] %llu rows still overflow at max_len %u, max_nei %u: sequences longer than %u bases and candidate lists of 4096 entries and more are not supported\n",
+                        __func__, (unsigned long long)(over_at_cap ? over_at_cap : n_side), s_len, s_nei, 4000u + (uint32_t)min_match);
+                rc = 1; shard_free(&side); goto done;
+            }
             /* what overflows in practice is the neighbour list of a strand in a fork-rich corner (more than max_nei irreducible overlaps): room for
              * four times as many at once, longer sequences / candidate lists only where a flagged record says so or the first attempt was not enough */
             if (attempt == 0) { s_nei *= 4; if (too_long_hint && longest > s_len) s_len = (longest + 31) / 32 * 32; }
@@ -353,6 +367,7 @@ static int slim_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_dev
             if (rc) { fprintf(stderr, "[E::%s] overflow pass: %s\n", __func__, fmd_strerror(rc)); rc = 1; goto done; }
             for (i = 0; i < n_side; ++i) n_over += (side.rec[i].flags & FMD_OVLP_F_OVERFLOW) != 0;
             if (n_over == 0) break;
+            if (s_len == 4000 + (uint32_t)min_match) { at_cap = n_over == over_at_cap ? at_cap + 1 : 1; over_at_cap = n_over; }
         }
         rc = replace_from_shard(s, ids, &side, nt);
         if (!rc && jobs[0].tabjob) {   /* the device's copy of those rows, for its link pass */
@@ -428,6 +443,9 @@ static int slim_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_dev
         if (fmdh_slim_finalize(s, nt)) { rc = 1; goto done; }
         if (timing) fprintf(stderr, "[M::%s] plain steps marked: %.3f s\n", __func__, now_s() - t1);
     }
+    g_last_build[0] = g_last_build[1] = 0;
+    for (g = 0; g < n_dev; ++g) { if (jobs[g].t_load > g_last_build[0]) g_last_build[0] = jobs[g].t_load; if (jobs[g].t_rows > g_last_build[1]) g_last_build[1] = jobs[g].t_rows; }
+    g_last_build[2] = now_s() - t0; g_last_build[3] = (double)fmdh_slim_bytes(s);
     if (timing) fprintf(stderr, "[M::%s] table of %llu sequences on %d GPU(s): %.3f s, %.1f bytes per row in host memory (%.2f GB); resident set now %.2f GB, peak so far %.2f GB\n", __func__,
                         (unsigned long long)n_seq, n_dev, now_s() - t0, n_seq ? (double)fmdh_slim_bytes(s) / (double)n_seq : 0.0, (double)fmdh_slim_bytes(s) / 1e9, fmdh_rss_gb(0), fmdh_rss_gb(1));
 done:

@@ -156,6 +156,23 @@ def unitig(fmd_path, min_match, out_path, devices=(0,)):
         raise RuntimeError("fmdh_unitig failed")
 
 
+def slim_build(fmd_path, min_match, devices=(0,)):
+    """The table `fermi-amd unitig -l min_match -g d0,d1,..` walks, built and freed again: one index replica + one host thread per GPU, rows of ids
+    i = g (mod G) streamed over each GPU's own PCIe link into the slim table, host threads link them.  -> dict of seconds / bytes (fmdh_slim_last_build)."""
+    L = lib()
+    dev = (C.c_int * len(devices))(*devices)
+    slim, n_seq = C.c_void_p(), C.c_uint64()
+    L.fmdh_slim_build.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.fmdh_slim_free.argtypes = [C.c_void_p]
+    rc = L.fmdh_slim_build(fmd_path.encode(), len(devices), dev, min_match, C.byref(slim), C.byref(n_seq))
+    if rc:
+        raise RuntimeError("fmdh_slim_build failed")
+    t = (C.c_double * 4)()
+    L.fmdh_slim_last_build(t)
+    L.fmdh_slim_free(slim)
+    return {"n_seq": int(n_seq.value), "index_load_s": t[0], "rows_s": t[1], "build_s": t[2], "table_bytes": t[3]}
+
+
 def correct_reads(w, min_occ, bucket, key, val, fq_path, out_path, step=5, max_corr=0.3, device=0):
     """ec_fix phase of `fermi correct` against a harvested solid-k-mer table (GPU correction pass + host marking/printing)."""
     L = lib()

@@ -135,6 +135,8 @@ def test_bench_n2_path_sharded_ids_and_gather_on_one_gpu(gpu):
     g = d["overlap_discovery"]["record_gather_rccl"]
     assert g["check"].startswith("ok"), g
     assert 64 < g["bytes_per_strand"] < 200
+    pp = d["product_path_unitig_g"]                                           # what `fermi-amd unitig -g 0,0` does with the same .fmd: two replicas -> slim table, host side included
+    assert pp["rows"] == 2_000_000 and pp["strands_per_s_rows_phase"] > 1e6 and 40 < pp["table_bytes_per_row"] < 50, pp
 
 
 def test_repeat_rich_ragged_2m_reads_md5_and_random_ids_vs_the_reference(gpu, oracle_lib, tmp_path):

@@ -1182,3 +1182,44 @@ def test_fuzz_cli_against_reference_binary(gpu, tmp_path, seed):
         compared += 1
     print("compared %d commands, reference gave up on %s" % (compared, skipped or "none"))
     assert compared >= 5
+
+
+def _long_read_set(path, G, L, cov, seed):
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(1, 5, G).astype(np.uint8)
+    tab = np.frombuffer(b"$ACGTN", dtype=np.uint8)
+    with open(path, "w") as f:
+        for i in range(G * cov // L):
+            p = int(rng.integers(0, G - L))
+            r = genome[p:p + L].copy()
+            if rng.random() < 0.5:
+                r = (5 - r)[::-1].copy()
+            f.write("@r%d\n%s\n+\n%s\n" % (i, tab[r].tobytes().decode(), "I" * L))
+
+
+def test_the_tested_ceiling_of_sequence_length(gpu, tmp_path):
+    """The reference's vectors grow without bound (kvec.h:76-82); here a candidate list holds at most 4095 entries, which caps a sequence at
+    4000 + min_match bases (host/ovlp_table.c: the capacity ladder stops there).  Pinned on both sides of the limit:
+      * reads of 3900 bases (lists of 3850 entries, the ladder's largest class): `unitig -l50` == the reference's bytes, through the re-run of the flagged rows;
+      * reads of 5000 bases: the reference assembles them; `fermi-amd unitig` REFUSES -- exit status 1, nothing on stdout, and a message that names the limit --
+        rather than truncating a list.  A hard edge the reference does not have, stated here so that it cannot move unnoticed."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref, amd = os.path.join(root, "oracle", "_ref", "fermi"), os.path.join(root, "fermi_amd", "bin", "fermi-amd")
+    have_ref = os.path.exists(ref)
+    for L, ok in ((3900, True), (5000, False)):
+        fq, fmd = str(tmp_path / ("l%d.fq" % L)), str(tmp_path / ("l%d.fmd" % L))
+        _long_read_set(fq, 40000, L, 12, 1000 + L)
+        subprocess.check_call([amd, "build", "-fo", fmd, fq], stderr=subprocess.DEVNULL)
+        p = subprocess.run([amd, "unitig", "-l50", fmd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        want = subprocess.run([ref, "unitig", "-l50", "-t1", fmd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600) if have_ref else None
+        if want is not None:
+            assert want.returncode == 0 and len(want.stdout) > 30000                 # the reference has no such limit
+        if ok:
+            assert p.returncode == 0, p.stderr.decode()[-2000:]
+            if want is not None:
+                assert p.stdout == want.stdout
+        else:
+            assert p.returncode == 1 and p.stdout == b"", (p.returncode, len(p.stdout))
+            err = p.stderr.decode()
+            assert "rows still overflow at max_len 4050" in err and "not supported" in err, err[-2000:]
