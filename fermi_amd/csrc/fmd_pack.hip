@@ -233,16 +233,26 @@ __device__ __forceinline__ int lfork_decide_dev(uint16_t lfork, int rbeg)   // f
     if (rbeg <= r || r == (int)FMD_LFORK_ALL) return 0;
     return (lfork & 0x8000) ? -1 : 1;
 }
-__global__ void k_link_rows(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, uint32_t *__restrict__ row_of)
+// Round 6: the row map carries each row's lfork.  An edge used to cost three random accesses: row_of[x0], row_of[x1] (4 bytes each, mostly from the
+// Infinity Cache: the map of 10^8 rows is 400 MB) and then -- DEPENDENT on the second -- the record of the neighbour's reverse strand for its lfork, two
+// bytes of a 64-byte line from DRAM (PMC: 2.13 x the bytes the kernel asks for, profiles/r5_final).  The map is now 8 bytes per position, row << 32 | lfork:
+// atomicMin on the whole word still elects the smallest row (the row sits in the high half), and the edge's second look-up brings the lfork with the row.
+// Two random 8-byte reads per edge, no dependent one; row_of[] as the ABI promises it is a streaming pass over the map.
+__global__ void k_link_rows(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, unsigned long long *__restrict__ map)
 {
     const size_t step = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
         const fmd_ovlp_rec_t *r = rec + i;
-        if (r->status == 0 && !(r->flags & FMD_OVLP_F_OVERFLOW) && r->k[0] < n) atomicMin(row_of + r->k[0], (uint32_t)i);
+        if (r->status == 0 && !(r->flags & FMD_OVLP_F_OVERFLOW) && r->k[0] < n) atomicMin(map + r->k[0], (unsigned long long)i << 32 | (unsigned long long)r->lfork);
     }
 }
+__global__ void k_link_row_of(size_t n, const unsigned long long *__restrict__ map, uint32_t *__restrict__ row_of)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) row_of[i] = (uint32_t)(map[i] >> 32);   // (~0 stays ~0)
+}
 __global__ void k_link_edges(size_t n, fmd_ovlp_rec_t *__restrict__ rec, const uint64_t *__restrict__ nei_x01, uint32_t nei_stride,
-                             const uint32_t *__restrict__ row_of, fmd_ovlp_link_t *__restrict__ link, uint64_t *__restrict__ und,
+                             const unsigned long long *__restrict__ map, fmd_ovlp_link_t *__restrict__ link, uint64_t *__restrict__ und,
                              unsigned long long *__restrict__ n_und, int force_exact)
 {
     const size_t step = (size_t)gridDim.x * blockDim.x;
@@ -251,18 +261,19 @@ __global__ void k_link_edges(size_t n, fmd_ovlp_rec_t *__restrict__ rec, const u
         fmd_ovlp_link_t l; l.nxt = l.rev = 0xffffffffu;
         if (r->status == 0 && r->n_nei == 1 && r->rbeg >= 0 && !(r->flags & FMD_OVLP_F_OVERFLOW)) {
             // (round 5 tried to spare the third random line of an edge -- the reverse strand of a neighbour that is the only read of its sequence is the row beside it,
-            // and its record, read for lfork anyway, can confirm that: 3.71 -> 4.33 ms per 2*10^7 rows and 9.9 -> 12.3 GB fetched, gpurun_out/b_cl_[01].json: the row
-            // map of 10^8 rows is 400 MB and mostly answers from the Infinity Cache, a dependent record line does not.  Reverted.)
+            // and its record, read for lfork anyway, can confirm that: 3.71 -> 4.33 ms per 2*10^7 rows and 9.9 -> 12.3 GB fetched: a dependent record line costs
+            // more than the look-up it spares.  Reverted; round 6 moved the lfork into the map instead.)
             const uint64_t x0 = nei_x01[i * (size_t)nei_stride], x1 = nei_x01[i * (size_t)nei_stride + 1];
-            if (x0 < n) l.nxt = row_of[x0];
-            if (x1 < n) l.rev = row_of[x1];
+            unsigned long long m1 = ~0ull;
+            if (x0 < n) l.nxt = (uint32_t)(map[x0] >> 32);
+            if (x1 < n) { m1 = map[x1]; l.rev = (uint32_t)(m1 >> 32); }
             // a neighbour without a row: its record is flagged (a capacity was exceeded) and the caller computes it again, larger -- the
             // edge is reported with the undecided ones, and the caller links it when that row is there (host/ovlp_table.c: table_patch_links)
             const bool miss = (x0 < n && l.nxt == 0xffffffffu) || (x1 < n && l.rev == 0xffffffffu);
             int d = 0;
             if (r->reserved == 2) {
                 d = 1;
-                if (l.rev != 0xffffffffu && !force_exact) d = lfork_decide_dev(rec[l.rev].lfork, r->rbeg);
+                if (l.rev != 0xffffffffu && !force_exact) d = lfork_decide_dev((uint16_t)m1, r->rbeg);
                 if (d != 1) r->reserved = (uint16_t)(d < 0 ? 1 : 0);
             }
             if (d == 1 || miss) und[atomicAdd(n_und, 1ull)] = i;
@@ -279,13 +290,19 @@ extern "C" int fmd_ovlp_link_dev(fmd_dev_t *h, void *stream_, size_t n, fmd_ovlp
     hipStream_t st = (hipStream_t)stream_;
     FMD_HIP_TRY(hipMemsetAsync(d_n_undecided, 0, 8, st));
     if (n == 0) return FMD_OK;
-    FMD_HIP_TRY(hipMemsetAsync(d_row_of, 0xff, n * 4, st));
+    unsigned long long *map = (unsigned long long *)fmd_scratch_acquire(h, n * 8);   // (kept by the handle between calls)
+    if (!map) return FMD_E_NOMEM;
+    if (hipMemsetAsync(map, 0xff, n * 8, st) != hipSuccess) { fmd_set_hip_error(hipGetLastError(), "link kernels"); fmd_scratch_release(h, map); return FMD_E_HIP; }
     size_t blocks = (n + 255) / 256;
     if (blocks > (1u << 20)) blocks = 1u << 20;
-    k_link_rows<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, d_row_of);
-    k_link_edges<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, d_nei_x01, nei_stride_u64, d_row_of, d_link, d_undecided, (unsigned long long *)d_n_undecided,
+    k_link_rows<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, map);
+    k_link_edges<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, d_nei_x01, nei_stride_u64, map, d_link, d_undecided, (unsigned long long *)d_n_undecided,
                                                   getenv("FMD_CHECK_LEFT_EXACT") != nullptr);
+    k_link_row_of<<<(unsigned)blocks, 256, 0, st>>>(n, map, d_row_of);
     hipError_t e = hipGetLastError();
+    // the map goes back to the handle's cache when the stream has passed the kernels that read it
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    fmd_scratch_release(h, map);
     if (e != hipSuccess) { fmd_set_hip_error(e, "link kernels"); return FMD_E_HIP; }
     return FMD_OK;
 }
