@@ -108,7 +108,7 @@ def pmc_in_run(fmd_path, n_reads, steps=2, leg="overlap"):
             return "failed (no counter rows)"
         cal = 2 * (1 << 27) * 64 / (pr["k_probe"] * 1024.0)      # probe_once: warm-up + one launch, 2^27 lines of 64 bytes each
         src = "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over %d steps of the leg on the index this run built; KB units, FETCH_SIZE x %.4f (gather probe, 64-byte lines, same run)" % (steps, cal)
-        OVL = ("k_ovl_head_adm", "k_ovl_walk", "k_ovl_park_keys", "k_ovl_seq_out", "k_ovl_seq_redo", "k_ovl_classify", "k_ovl_nei_fast", "k_ovl_nei_lane", "k_ovl_nei_grp", "k_ovl_nei", "k_ovl_fix")
+        OVL = ("k_ovl_head_adm", "k_ovl_walk", "k_ovl_pair", "k_ovl_strag_adm", "k_ovl_park_keys", "k_ovl_seq_out", "k_ovl_seq_redo", "k_ovl_classify", "k_ovl_nei_fast", "k_ovl_nei_lane", "k_ovl_nei_grp", "k_ovl_nei", "k_ovl_fix")
         legs_of = {"overlap": (("overlap@%d" % n_reads, OVL), ("check_left@%d" % n_reads, ("k_link_rows", "k_link_edges", "k_ovl_cls"))), "ecfix": (("ecfix@%d" % n_reads, ("k_ecfix",)),)}
         for key, names in legs_of[leg]:
             fk = sum(v for k, v in fetch.items() if k in names) / steps
@@ -193,6 +193,7 @@ class Counter:
     def __init__(self, api, fmd_path, device):
         self.L = api.count_lib()
         self.h = None
+        self.pair_lines = 0
         if self.L is None or not fmd_path:
             return
         h = C.c_void_p()
@@ -203,12 +204,13 @@ class Counter:
         """step(L, h) launches one step on library L / handle h; returns (rank blocks, other lines) or None."""
         if self.h is None:
             return None
-        buf = (C.c_uint64 * 2)()
+        buf = (C.c_uint64 * 3)()
         cnt = C.c_int(0)
-        self.L.fmd_dev_line_count(self.h, buf, 1, C.byref(cnt))
-        step(self.L, self.h)
-        if self.L.fmd_dev_line_count(self.h, buf, 1, C.byref(cnt)) != 0 or not cnt.value:
+        self.L.fmd_dev_line_count3(self.h, buf, 1, C.byref(cnt))
+        step(self.L, self.h)     # (with FMD_PAIR=1 in the environment the handle builds its two-base blocks inside this step, as the timed handle has them)
+        if self.L.fmd_dev_line_count3(self.h, buf, 1, C.byref(cnt)) != 0 or not cnt.value:
             return None
+        self.pair_lines = int(buf[2])      # 128-byte two-base blocks requested (k_ovl_pair)
         return int(buf[0]), int(buf[1])
 
     def close(self):
@@ -698,6 +700,26 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
             return out, job
     n_loc = job.n               # rows of this rank (all of them at N = 1); everything below is about rank 0's own shard
     ids_host = job.ids.cpu().numpy().astype(np.uint64)
+    # ---- the same job without the two-base blocks (FMD_PAIR_USE=0: pass 1 one base per request all the way), same box, same run: time and bytes
+    if os.environ.get("FMD_PAIR") == "1" and os.environ.get("FMD_BENCH_PAIR_AB", "1") != "0":
+        keep_rec = job.rec.clone()
+        os.environ["FMD_PAIR_USE"] = "0"
+        try:
+            job.compute()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(job.stream)
+            for _ in range(3):
+                job.compute()
+            e1.record(job.stream)
+            torch.cuda.synchronize()
+            out["without_two_base_blocks"] = {"ms_per_step": e0.elapsed_time(e1) / 3, "what": "the same job with FMD_PAIR_USE=0 (k_ovl_walk<WALK_HEAD> takes every strand to 32 bases alone), 3 passes right after the timed steps",
+                                              "same_records": bool(torch.equal(job.rec, keep_rec))}
+        finally:
+            del os.environ["FMD_PAIR_USE"]
+        job.compute()            # (the arrays as the timed steps left them)
+        torch.cuda.synchronize()
+        del keep_rec
     # ---- the same strands in id order (the one-pass walk of rounds 1-2), same box, same run: time and bytes
     if os.environ.get("FMD_BENCH_ID_ORDER_AB", "1") != "0":
         keep = (job.rec, job.nei, job.seq)
@@ -741,14 +763,17 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
                "two_sorts_keys_and_rows": 2 * (2 * 8 + 4 * 2 * 8) * n_loc, "slot_to_row_map_reads": 4 * 4 * n_loc,
                "records_write_classify_read_result_write": (2 if tail2_cls else 3) * 64 * n_loc, "work_lists": 16 * n_loc,
                "candidates_write_and_read": 2 * 32 * n_cand, "classify_widest_candidate": 0 if tail2_cls else 64 * n_loc, "neighbours": 32 * n_neis}
+    pair_lines = ctr.pair_lines
+    if pair_lines:   # the two-base pass: every strand's parked line read and written once more
+        streams["parked_strands_two_base_pass_read_write"] = 2 * 64 * n_loc
     io = sum(streams.values())
-    dev_bytes = None if lines is None else (lines[0] + lines[1]) * BLOCK_BYTES + io
+    dev_bytes = None if lines is None else (lines[0] + lines[1]) * BLOCK_BYTES + pair_lines * 128 + io
     cn = oracle_counters(fmd_path, lambda o: o.overlap_batch(np.arange(4000, dtype=np.uint64), min_match, 100, 4, 1, check_left=False))
     qps = (cn["rank1a"] + cn["rank2a"] + cn["rank2a_spill"]) / 4000.0
     out["roofline"] = roofline("k_ovl_head_adm + k_ovl_walk<HEAD> + k_ovl_park_keys + one radix sort + per batch: k_ovl_walk<%s> + k_ovl_nei_lane<G, M> (k_ovl_nei_fast<32, M>) + k_ovl_nei_grp<G> + k_ovl_nei (one step = one job of %d batches of %d strands)"
                                % ("TAIL2> (rows and work lists written by the walk" if tail2_cls else ("TAIL2> + k_ovl_classify" if tail2 else "TAIL> + k_ovl_seq_out + k_ovl_classify"),
                                   (job.n + job.batch - 1) // job.batch, job.batch), kern_ms, dev_bytes,
-                               {"rank_blocks": lines and lines[0], "prefix_table_lines": lines and lines[1], "stream_bytes": io, "streams": streams},
+                               {"rank_blocks": lines and lines[0], "prefix_table_lines": lines and lines[1], "two_base_blocks_128B": pair_lines, "stream_bytes": io, "streams": streams},
                                qps * BYTES_PER_RANK_QUERY * n_loc, "overlap@%d" % n_reads if world == 1 else "overlap@%d/%d" % (n_reads, world),
                                {"rank_queries_per_strand": qps, "oracle_counters_on_sample": cn,
                                 "scope": "rank 0's shard of %d strands, its discovery kernels alone" % n_loc if world > 1 else "all %d strands" % n_loc})
@@ -1414,6 +1439,22 @@ def main():
     del rd              # the overlap path needs only the index
     torch.cuda.empty_cache()
     t4 = time.time()
+    # The two-base blocks (fmd_pair.hip, round 6): an auxiliary structure of the resident index, like the prefix and tail tables -- 32 bits per symbol beside the
+    # index's 8, built once on the device; pass 1 of the sorted job then takes two bases per 128-byte request between depth 16 and 32 (k_ovl_pair).  They pay
+    # where an index serves many passes (this benchmark; a server) and never within one pass (`fermi-amd unitig` does not build them).  FMD_BENCH_PAIRS=0: without.
+    # FMD_PAIR=1 in the environment makes every OTHER handle of this run (the instrumented build's, the PMC child's) build them too, inside its first step.
+    pairs_info = None
+    if os.environ.get("FMD_BENCH_PAIRS", "1") != "0" and os.environ.get("FMD_PAIR", "1") != "0":
+        os.environ["FMD_PAIR"] = "1"
+        tp = time.time()
+        before = index.hbm_bytes
+        built = index.build_pairs()
+        index.refresh_info()
+        pairs_info = {"built": built, "build_seconds": time.time() - tp, "hbm_bytes": index.hbm_bytes - before,
+                      "what": "two-base blocks: BWT[p] and BWT[LF(p)] as bit planes + 16 pair counts, 128 bytes per 32 positions; same results (tests/test_gpu_pairs.py), "
+                              "the A/B without them is in overlap_discovery.without_two_base_blocks"}
+        if not built:
+            os.environ.pop("FMD_PAIR", None)
     if rank == 0:
         log("setup: synth in HBM %.1fs, GPU BWT build %.2fs (%d symbols), .fmd write %.1fs, index load+transcode %.2fs (%.2f GB in HBM)"
             % (t1 - t0, t2 - t1, n_sym, t3 - t2, t4 - t3, index.hbm_bytes / 1e9))
@@ -1492,6 +1533,8 @@ def main():
                             "fmd_write_seconds": t3 - t2, "fmd_load_transcode_seconds": t4 - t3, "hbm_bytes": hbm_index},
             "kernel_sources_sha": csrc_sha(),
         }
+        if pairs_info:
+            out["index_build"]["two_base_blocks"] = pairs_info
         for k in ("roofline", "cpu_baseline", "parity_vs_cpu_on_sample", "speedup_vs_cpu_all_cores"):
             if k in ovl:
                 out[k] = ovl.pop(k)

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "fmd_retrieve_dev", "fmd_retrieve_batch", "fmd_probe_gather",
     "fmd_build_bwt", "fmd_build_bwt_dev", "fmd_dev_free", "fmd_builder_new", "fmd_builder_add_dev", "fmd_builder_finish", "fmd_builder_free", "fmd_bwt_to_rle6", "fmd_host_free",
     "fmd_dev_malloc", "fmd_memcpy_h2d", "fmd_memcpy_d2h",
-    "fmd_smem_work_bytes", "fmd_smem_dev", "fmd_smem_batch", "fmd_smem_win_dev", "fmd_smem_win_batch", "fmd_reach_dev", "fmd_reach_batch", "fmd_dev_export_bwt", "fmd_dev_check_rank", "fmd_dev_build_pairs", "fmd_dev_check_pairs",
+    "fmd_smem_work_bytes", "fmd_smem_dev", "fmd_smem_batch", "fmd_smem_win_dev", "fmd_smem_win_batch", "fmd_reach_dev", "fmd_reach_batch", "fmd_dev_export_bwt", "fmd_dev_check_rank", "fmd_dev_build_pairs", "fmd_dev_check_pairs", "fmd_dev_line_count3",
     "fmd_kmer_work_bytes", "fmd_kmer_collect_dev", "fmd_kmer_collect_part_dev", "fmd_kmer_collect", "fmd_kmer_collect_seeds",
     "fmd_ectab_build_dev", "fmd_ectab_build", "fmd_ectab_free", "fmd_ecfix_work_bytes", "fmd_ecfix_dev", "fmd_ecfix_batch", "fmd_ectab_line_count",
     "fmd_ovlp_work_bytes", "fmd_ovlp_dev", "fmd_ovlp_sorted_work_bytes", "fmd_ovlp_sorted_dev", "fmd_ovlp_batch", "fmd_ovlp_check_left_dev", "fmd_seqinfo_dev", "fmd_seqinfo_batch",
@@ -121,6 +121,7 @@ def _configure(L):
     L.fmd_seqinfo_batch.argtypes = [vp, sz, u64p, C.c_uint32, vp]
     L.fmd_probe_gather.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_float)]
     L.fmd_dev_line_count.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
+    L.fmd_dev_line_count3.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
     L.fmd_ovlp_pack_max_bytes.restype = sz; L.fmd_ovlp_pack_max_bytes.argtypes = [sz, C.c_uint32, C.c_uint32]
     L.fmd_ovlp_pack_work_bytes.restype = sz; L.fmd_ovlp_pack_work_bytes.argtypes = [sz]
     L.fmd_ectab_build_dev.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_uint64, vp, vp, vp, C.POINTER(vp)]
@@ -254,6 +255,12 @@ class DevIndex:
         h = C.c_void_p()
         check(lib().fmd_dev_open_rle6(device, _ptr(runs), len(runs), C.byref(h)))
         return cls(h)
+
+    def refresh_info(self):
+        """cnt / mcnt / bytes again (the handle may have grown: fmd_dev_build_pairs)"""
+        info = Info()
+        check(lib().fmd_dev_info(self.h, C.byref(info)))
+        self.hbm_bytes = int(info.hbm_bytes)
 
     def build_pairs(self):
         """the two-base blocks now (fmd_dev_build_pairs) -> True when the handle has them"""

@@ -733,6 +733,21 @@ extern "C" int fmd_dev_line_count(fmd_dev_t *h, uint64_t lines[2], int reset, in
     return FMD_OK;
 }
 
+// the same with the 128-byte two-base blocks as a third number (fmd_pair.hip; lines[2])
+extern "C" int fmd_dev_line_count3(fmd_dev_t *h, uint64_t lines[3], int reset, int *counting)
+{
+    if (!h || !lines) return FMD_E_ARG;
+    FMD_HIP_TRY(hipSetDevice(h->device));
+    unsigned long long host[FMD_STAT_SLOTS * FMD_STAT_STRIDE];
+    FMD_HIP_TRY(hipDeviceSynchronize());
+    FMD_HIP_TRY(hipMemcpy(host, h->stat, sizeof(host), hipMemcpyDeviceToHost));
+    lines[0] = lines[1] = lines[2] = 0;
+    for (int i = 0; i < FMD_STAT_SLOTS; ++i) { lines[0] += host[i * FMD_STAT_STRIDE]; lines[1] += host[i * FMD_STAT_STRIDE + 1]; lines[2] += host[i * FMD_STAT_STRIDE + 2]; }
+    if (reset) FMD_HIP_TRY(hipMemset(h->stat, 0, sizeof(host)));
+    if (counting) *counting = FMD_COUNT_LINES;
+    return FMD_OK;
+}
+
 extern "C" int fmd_dev_malloc(int device, size_t bytes, void **d_ptr)
 {
     if (!d_ptr) return FMD_E_ARG;

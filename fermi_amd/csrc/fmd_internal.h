@@ -75,8 +75,8 @@ int fmd_index_alloc(int device, uint64_t n_sym, fmd_dev **out);
 int fmd_index_put_slice(fmd_dev *h, hipStream_t st, const uint8_t *d_slice, uint64_t first, uint64_t m);
 int fmd_index_finish(fmd_dev *h);
 
-// the two-base blocks (fmd_pair.hip): built if FMD_PAIR allows and they fit; FMD_OK either way (h->pair says)
-int fmd_pairs_ensure(fmd_dev *h);
+// the two-base blocks (fmd_pair.hip): built when forced (fmd_dev_build_pairs) or FMD_PAIR asks, and they fit; FMD_OK either way (h->pair says)
+int fmd_pairs_ensure(fmd_dev *h, int force);
 
 // next zeroed work-queue head for a persistent launch on `stream`
 uint32_t *fmd_next_queue(fmd_dev *h, hipStream_t stream);

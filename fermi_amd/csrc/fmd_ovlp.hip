@@ -38,7 +38,7 @@ int fmd_park_sort(hipStream_t st, size_t n, const FmdWalkPark *park, uint32_t *k
 #ifndef FMD_HEAD_AUX
 #define FMD_HEAD_AUX 0
 #endif
-enum { WK_IDLE = 0, WK_LF, WK_EXT, WK_BOTH, WK_RIGHT, WK_ADM1, WK_ADM2, WK_PAIR };
+enum { WK_IDLE = 0, WK_LF, WK_EXT, WK_BOTH, WK_RIGHT, WK_ADM1, WK_ADM2 };
 // can the LF step at row k be read from a block the backward extension of [x0, x0 + sz) brings in anyway (the block of x0 - 1, or
 // the block of its other end when that one does not reach it)?
 __device__ __forceinline__ bool walk_lf_shares(uint64_t k, uint64_t x0, uint64_t sz)
@@ -71,13 +71,9 @@ __device__ __forceinline__ bool walk_lf_shares(uint64_t k, uint64_t x0, uint64_t
             ++depth;                                                                                       \
             if ((depth & 15) == 0) { if (depth <= WALK_LS_BASES) walk_ls[((depth >> 4) - 1) * 64 + fmd_lane()] = pack; pack = 0; } \
         } else                                                                                             \
-        if (MODE == WALK_HEAD || MODE == WALK_HEADP) {                                                     \
+        if (MODE == WALK_HEAD) {                                                                           \
             const uint32_t v_ = (uint32_t)(cc) << (4 * (depth & 7)), w_ = depth >> 3;                      \
             pk0 |= w_ == 0 ? v_ : 0u; pk1 |= w_ == 1 ? v_ : 0u; pk2 |= w_ == 2 ? v_ : 0u; pack |= w_ == 3 ? v_ : 0u; \
-            if (MODE == WALK_HEADP && depth >= FMD_WALK_SPLIT) {   /* beyond the first park: 2 bits each */   \
-                const uint32_t e_ = depth - FMD_WALK_SPLIT, b_ = ((uint32_t)(cc) - 1u) & 3u;               \
-                ex0 |= e_ < 16 ? b_ << (2 * e_) : 0u; ex1 |= e_ >= 16 ? b_ << (2 * (e_ - 16)) : 0u;        \
-            }                                                                                              \
             ++depth;                                                                                       \
         } else {                                                                                           \
             pack |= (uint32_t)(cc) << (8 * (depth & 3));                                                   \
@@ -93,16 +89,7 @@ __device__ __forceinline__ bool walk_lf_shares(uint64_t k, uint64_t x0, uint64_t
 // those bases (k_ovl_park_keys), so that strands of one genomic window sit in neighbouring lanes; WALK_TAIL picks each strand up where
 // it was parked, in that order.  Nothing can be pushed before min_match >= FMD_WALK_SPLIT bases, so the two passes together make
 // exactly the steps of the one-pass walk and leave the same records, candidates and stash.
-enum { WALK_WHOLE = 0, WALK_HEAD = 1, WALK_TAIL = 2, WALK_TAIL2 = 3, WALK_HEADP = 4 };   // (FMD_WALK_SPLIT, FmdWalkPark: fmd_kernel_common.h)
-// WALK_HEADP = WALK_HEAD over an index that has two-base blocks (FmdIndexView::pair, fmd_pair.hip): once the interval is narrow, a step takes TWO
-// bases from one 128-byte line (WK_PAIR), and the head goes on past FMD_WALK_SPLIT up to `split` <= min_match bases (nothing is pushed below
-// min_match) -- in pass 1 a base then costs half a request, in pass 2 a whole one.  The strand is parked TWICE: at FMD_WALK_SPLIT bases as ever (the
-// line written whole: row, interval, the 32 bases the order is made from), and at `split` the row and the interval are overwritten and the bases
-// in between (A/C/G/T, 2 bits each) + the depth go into pad.z / pad.w.  A strand that meets an N on the way stays parked where it was.
-#ifndef FMD_HEADP_WAVES
-#define FMD_HEADP_WAVES 2          // waves per SIMD the two-base head is compiled for (its 16.25 KiB of LDS allow nine per CU)
-#endif
-#define WALK_PARK_MAX 60u             // 28 more bases fit pad.z (16) and the low 24 bits of pad.w (12); pad.w >> 24 = the depth (0: FMD_WALK_SPLIT)
+enum { WALK_WHOLE = 0, WALK_HEAD = 1, WALK_TAIL = 2, WALK_TAIL2 = 3 };   // (FMD_WALK_SPLIT, FmdWalkPark: fmd_kernel_common.h)
 
 // WALK_TAIL2 = WALK_TAIL for sequences of at most WALK_LS_BASES bases, without the stash in HBM and without k_ovl_seq_out behind it: the bases wait in
 // LDS, 2 bits each (code - 1; 7 words per lane: what is left of a CU's 160 KiB beside the gather's 8.25 KiB per wave at 16 waves), and the lane that
@@ -160,49 +147,12 @@ __device__ __forceinline__ void walk_emit_row(const uint32_t *st, uint32_t len, 
     }
 }
 
-// may the step at this depth take two bases from a two-base block?  Narrow interval that lies inside the 96 positions the block of x0 describes; neither
-// base may be one at which something is pushed or the strand is parked: both below `split`, and not across FMD_WALK_SPLIT (the first park)
-__device__ __forceinline__ bool walk_pair_ok(uint64_t x0, uint64_t sz, uint32_t depth, uint32_t split, bool nopair)
-{
-    return !nopair && sz <= 63 && ((uint32_t)x0 & 63u) + (uint32_t)sz <= FMD_BLK_SYMS && depth + 2 <= split && (depth + 2 <= FMD_WALK_SPLIT || depth >= FMD_WALK_SPLIT);
-}
-// the end of a step of k_ovl_walk: the state of the next one, and -- the heads -- the strand parked where it has to be
-#define WALK_NEXT_STATE_AND_PARK()                                                                                             \
-    do {                                                                                                                       \
-        st = walk_lf_shares(k, x0, sz) ? WK_BOTH : WK_LF;   /* can the LF step share the extension's gather? */               \
-        if (tab) st = WK_LF;                                /* inside the prefix table there is no extension to share one with */ \
-        if (MODE == WALK_HEADP && !tab && walk_pair_ok(x0, sz, depth, split, nopair)) st = WK_PAIR;                            \
-        if (HEADM && depth == FMD_WALK_SPLIT && !tab) {     /* park the strand: one 64-byte line, written whole */             \
-            uint4 *pp = (uint4 *)(park + gs);                                                                                  \
-            pp[0] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), (uint32_t)x0, (uint32_t)(x0 >> 32));                          \
-            pp[1] = make_uint4((uint32_t)x1, (uint32_t)(x1 >> 32), (uint32_t)sz, (uint32_t)(sz >> 32));                        \
-            pp[2] = make_uint4(pk0, pk1, pk2, pack); pp[3] = make_uint4(0, 0, 0, 0);                                           \
-            if (split == FMD_WALK_SPLIT) st = WK_IDLE;                                                                         \
-        } else if (MODE == WALK_HEADP && depth == split && !tab) {   /* ... and for good: row, interval, the bases since */    \
-            uint4 *pp = (uint4 *)(park + gs);                                                                                  \
-            pp[0] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), (uint32_t)x0, (uint32_t)(x0 >> 32));                          \
-            pp[1] = make_uint4((uint32_t)x1, (uint32_t)(x1 >> 32), (uint32_t)sz, (uint32_t)(sz >> 32));                        \
-            pp[3] = make_uint4(0, 0, ex0, ex1 | depth << 24);                                                                  \
-            st = WK_IDLE;                                                                                                      \
-        }                                                                                                                      \
-    } while (0)
-// WALK_TAIL / WALK_TAIL2 taking in a strand that was parked beyond FMD_WALK_SPLIT (adm_a = its pad): the bases in between into the stash, as the
-// steps would have put them
-#define WALK_PARKED_EXTRAS()                                                                                                   \
-    do {                                                                                                                       \
-        const uint32_t pd_ = adm_a.w >> 24;                                                                                    \
-        for (uint32_t e_ = 0; e_ + FMD_WALK_SPLIT < pd_; ++e_) {                                                               \
-            const uint32_t cc_ = (((e_ < 16 ? adm_a.z >> (2 * e_) : adm_a.w >> (2 * (e_ - 16))) & 3u) + 1u);                   \
-            WALK_PUT_BASE(cc_);                                                                                                \
-        }                                                                                                                      \
-    } while (0)
-
 // MODE = WALK_HEAD: item t = admission record t (k_ovl_head_adm: the strand's row in ids[], park[] and rec[] and where its walk stands
 // behind the tail table); the first 32 bases stay in registers and leave with the parked state in ONE 64-byte burst.
 // MODE = WALK_TAIL: item = slot of the batch (rows of srev, listA), gidx[slot] = its row in park[], rec[] (and, for the kernels
 // that follow, nei[] and seq[]).
 template <int MODE>
-__global__ __launch_bounds__(64, MODE == WALK_HEADP ? FMD_HEADP_WAVES : 4) void k_ovl_walk(FmdIndexView ix, size_t n, const uint64_t *__restrict__ ids, int min_match,
+__global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, const uint64_t *__restrict__ ids, int min_match,
                                                  uint8_t *__restrict__ srev, uint32_t stride_r, uint32_t cap,
                                                  fmd_intv_t *__restrict__ listA, fmd_ovlp_rec_t *__restrict__ rec,
                                                  uint8_t *__restrict__ seq_out, uint32_t seq_stride, uint32_t *__restrict__ queue,
@@ -212,13 +162,8 @@ __global__ __launch_bounds__(64, MODE == WALK_HEADP ? FMD_HEADP_WAVES : 4) void 
 {
     FMD_DECLARE_COMPACT_LDS();
     __shared__ uint32_t walk_ls[MODE == WALK_TAIL2 ? 64 * WALK_LS_WORDS : 1];   // WALK_TAIL2: the lane's bases, word w of lane l at [w * 64 + l]
-    __shared__ uint4 pair_lds[MODE == WALK_HEADP ? FMD_PAIR_SLOT_U4 : 1];       // WALK_HEADP: one two-base block image per lane (8 KiB)
     constexpr bool TAILM = MODE == WALK_TAIL || MODE == WALK_TAIL2;
-    constexpr bool HEADM = MODE == WALK_HEAD || MODE == WALK_HEADP;
-    constexpr int WAUX = HEADM ? FMD_HEAD_AUX : FMD_GLDS_AUX;   // pass 1 never asks for a line twice (strands in id order: every gather is a DRAM miss)
-    const uint32_t split = MODE == WALK_HEADP ? (uint32_t)cls_cfg : FMD_WALK_SPLIT;   // WALK_HEADP: where the strand is parked for good (cls_cfg is free in the heads)
-    uint32_t ex0 = 0, ex1 = 0;            // WALK_HEADP: the bases beyond FMD_WALK_SPLIT, 2 bits each
-    bool nopair = false;                  // WALK_HEADP: the lane's last pair step met a base that is not A/C/G/T: one single step first
+    constexpr int WAUX = MODE == WALK_HEAD ? FMD_HEAD_AUX : FMD_GLDS_AUX;   // pass 1 never asks for a line twice (strands in id order: every gather is a DRAM miss)
     size_t sid = 0;
     size_t gs = 0;                        // the strand's row in rec[] (WALK_TAIL: gidx[sid], otherwise sid)
     int st = WK_IDLE, c_pend = 0, ret = 0;
@@ -277,7 +222,7 @@ __global__ __launch_bounds__(64, MODE == WALK_HEADP ? FMD_HEADP_WAVES : 4) void 
             if (TAILM) {
                 if (my < n) { sid = my; gs = gidx[my]; st = WK_ADM1; }
                 else exhausted = true;
-            } else if (HEADM) {
+            } else if (MODE == WALK_HEAD) {
                 if (my < n) { sid = my; adm_a = adm[2 * my]; adm_b = adm[2 * my + 1]; st = WK_ADM1; }
                 else exhausted = true;
             } else
@@ -311,7 +256,6 @@ __global__ __launch_bounds__(64, MODE == WALK_HEADP ? FMD_HEADP_WAVES : 4) void 
         if (st == WK_LF) qk = k;
         else if (st == WK_EXT || st == WK_BOTH) { qk = x0 - 1; ql = x0 - 1 + sz; }
         else if (st == WK_RIGHT) { qk = x1 - 1; ql = x1 - 1 + sz; }
-        if (MODE == WALK_HEADP) fmd_pair_fetch<WAUX>(ix, pair_lds, (uint32_t)(x0 >> 6), st == WK_PAIR);   // (no wait of its own: the one below covers it)
         FmdRank2c r = fmd_wave_rank2_fetch_compact<WAUX>(ix, fmd_lds, qk, ql);
         // two-phase step (more than 32 lanes straddle: wide intervals): the k-side ranks are taken now,
         // the l-side after fmd_wave_l_ready(); a narrow lane whose window straddles sits this step out
@@ -330,9 +274,9 @@ __global__ __launch_bounds__(64, MODE == WALK_HEADP ? FMD_HEADP_WAVES : 4) void 
         const bool was_two_phase = r.two_phase;
         fmd_wave_l_ready<WAUX>(ix, fmd_lds, r);
         if (st == WK_IDLE || skip) continue;
-        if (HEADM && st == WK_ADM1) {   // the admission record has arrived (FmdHeadAdm, k_ovl_head_adm)
+        if (MODE == WALK_HEAD && st == WK_ADM1) {   // the admission record has arrived (FmdHeadAdm, k_ovl_head_adm)
             gs = adm_a.x;
-            depth = 0; npush = 0; pack = 0; pk0 = pk1 = pk2 = 0; flags = 0; ret = 0; ex0 = ex1 = 0; nopair = false;
+            depth = 0; npush = 0; pack = 0; pk0 = pk1 = pk2 = 0; flags = 0; ret = 0;
             if (adm_b.w & 1u) {   // no tail-table entry: from the sentinel, on the ordinary path
                 k = (uint64_t)(adm_b.y & 0xffu) << 32 | adm_a.y; st = WK_LF; tab = tab_ok;
             } else {
@@ -349,69 +293,12 @@ __global__ __launch_bounds__(64, MODE == WALK_HEADP ? FMD_HEADP_WAVES : 4) void 
                 pk1 = d > 8 ? (up + 0x11111111u) & (d >= 16 ? ~0u : (1u << (4 * (d - 8))) - 1u) : 0u;
                 depth = (uint32_t)d; tab = false;
                 st = walk_lf_shares(k, x0, sz) ? WK_BOTH : WK_LF;
-                if (MODE == WALK_HEADP && walk_pair_ok(x0, sz, depth, split, false)) st = WK_PAIR;
             }
-            continue;
-        }
-        if (MODE == WALK_HEADP && st == WK_PAIR) {
-            // ---- two bases from one line.  The lane's image holds, for the 96 positions from block(x0) on, BWT[p] and BWT[LF(p)] as bit planes; the
-            // interval [x0, x0 + sz) lies inside (walk_pair_ok), row k inside the interval.  The positions of the window with first symbol c1 are the
-            // interval one base on, in order; those among them with second symbol c2 are the interval two bases on: sizes, the x[1] sums of both
-            // extensions (fm6_extend's order 0 < 4 < 3 < 2 < 1 < 5, exact.c:81-86) and the rank of row k are popcounts, the start is one pair count.
-            const int q_ = fmd_lane(), px = fmd_pair_xor(q_);
-            const uint4 *img = pair_lds + fmd_pair_base(q_);
-            const uint32_t off = (uint32_t)x0 & 63u, hw = off >> 5, sh = off & 31u;
-            const uint4 A0 = img[0 ^ px], A1 = img[1 ^ px], A2 = img[2 ^ px], B0 = img[3 ^ px], B1 = img[4 ^ px], B2 = img[5 ^ px];
-#define WP_WIN(f0, f1, f2) win64(hw ? (f1) : (f0), hw ? (f2) : (f1), hw ? 0u : (f2), sh)
-            const uint64_t X = WP_WIN(A0.x, A1.x, A2.x), Y = WP_WIN(A0.y, A1.y, A2.y), Z = WP_WIN(A0.z, A1.z, A2.z);
-            const uint64_t S0 = WP_WIN(A0.w, A1.w, A2.w), S1 = WP_WIN(B0.x, B1.x, B2.x), S2 = WP_WIN(B0.y, B1.y, B2.y);
-#undef WP_WIN
-            const uint64_t m = bits_below((int)sz);
-            const uint32_t o = (uint32_t)(k - x0);
-            const int c1 = (int)(((X >> o) & 1) | ((Y >> o) & 1) << 1 | ((Z >> o) & 1) << 2);
-            const int c2 = (int)(((S0 >> o) & 1) | ((S1 >> o) & 1) << 1 | ((S2 >> o) & 1) << 2);
-            if (c1 < 1 || c1 > 4 || c2 < 1 || c2 > 4) {   // the sequence ends within two bases, or an N: this step again, one base at a time
-                nopair = true; st = WK_BOTH;
-                continue;
-            }
-            const uint64_t lo = ~Z & m, hi = Z & ~Y & m;
-            const uint64_t M0 = lo & ~Y & ~X, M1 = lo & ~Y & X, M2 = lo & Y & ~X, M3 = lo & Y & X, M4 = hi & ~X;
-            const uint64_t Mc = c1 == 1 ? M1 : c1 == 2 ? M2 : c1 == 3 ? M3 : M4;
-            const uint64_t lo2 = ~S2 & Mc, hi2 = S2 & ~S1 & Mc;
-            const uint64_t N0 = lo2 & ~S1 & ~S0, N1 = lo2 & ~S1 & S0, N2 = lo2 & S1 & ~S0, N3 = lo2 & S1 & S0, N4 = hi2 & ~S0;
-            const uint64_t Mp = c2 == 1 ? N1 : c2 == 2 ? N2 : c2 == 3 ? N3 : N4;
-            uint32_t before = (uint32_t)__popcll(M0) + (uint32_t)__popcll(N0);          // '$' sorts before every base
-            if (c1 != 4) before += (uint32_t)__popcll(M4);
-            if (c1 == 2 || c1 == 1) before += (uint32_t)__popcll(M3);
-            if (c1 == 1) before += (uint32_t)__popcll(M2);
-            if (c2 != 4) before += (uint32_t)__popcll(N4);
-            if (c2 == 2 || c2 == 1) before += (uint32_t)__popcll(N3);
-            if (c2 == 1) before += (uint32_t)__popcll(N2);
-            // pairs (c1, c2) before x0: the superblock's (+ K2: ix.pair_tab), the block's 28-bit count, positions [0, off) of the block
-            const uint32_t e0x = (c1 & 1) ? 0u : ~0u, e0y = (c1 & 2) ? 0u : ~0u, e0z = (c1 & 4) ? 0u : ~0u;
-            const uint32_t e1x = (c2 & 1) ? 0u : ~0u, e1y = (c2 & 2) ? 0u : ~0u, e1z = (c2 & 4) ? 0u : ~0u;
-            const uint32_t pm0 = (A0.x ^ e0x) & (A0.y ^ e0y) & (A0.z ^ e0z) & (A0.w ^ e1x) & (B0.x ^ e1y) & (B0.y ^ e1z);
-            const uint32_t pm1 = (A1.x ^ e0x) & (A1.y ^ e0y) & (A1.z ^ e0z) & (A1.w ^ e1x) & (B1.x ^ e1y) & (B1.y ^ e1z);
-            const uint32_t nb_ = (uint32_t)__builtin_popcount(pm0 & fmd_mask32((int)off)) + (uint32_t)__builtin_popcount(pm1 & fmd_mask32((int)off - 32));
-            const int pr = 4 * (c1 - 1) + (c2 - 1), bp = 28 * pr, tw = bp >> 5, tw1 = tw < 13 ? tw + 1 : 13;
-            const uint32_t *iw = (const uint32_t *)(pair_lds + fmd_pair_base(q_));
-#define WP_CW(t) iw[(((t) < 6 ? 3 + ((t) >> 1) : 6 + (((t) - 6) >> 2)) ^ px) * 4 + ((t) < 6 ? 2 + ((t) & 1) : (((t) - 6) & 3))]
-            const uint32_t cwl = WP_CW(tw), cwh = WP_CW(tw1);
-#undef WP_CW
-            const uint32_t rel = __builtin_amdgcn_alignbit(cwh, cwl, (uint32_t)bp & 31u) & 0x0fffffffu;
-            const uint64_t base = ix.pair_tab[(x0 >> (6 + FMD_PAIR_SB_SHIFT)) * 16 + (uint64_t)pr];
-            const uint64_t nx0 = base + rel + nb_;
-            k = nx0 + (uint64_t)__popcll(Mp & bits_below((int)o + 1)) - 1;
-            x0 = nx0; sz = (uint64_t)__popcll(Mp); x1 += before;
-            WALK_PUT_BASE(c1);
-            WALK_PUT_BASE(c2);
-            WALK_NEXT_STATE_AND_PARK();
             continue;
         }
         if (TAILM && st == WK_ADM1) {   // the strand's row is known: fetch what WALK_HEAD parked there, straight into the
             const uint4 *pp = (const uint4 *)(park + gs);   // registers the state will live in (the loads land under the next gather)
             const uint4 a = pp[0], b = pp[1], cb = pp[2];
-            adm_a = pp[3];                                  // pad.z / pad.w: the bases and the depth of a strand a WALK_HEADP parked beyond FMD_WALK_SPLIT
             k = (uint64_t)a.y << 32 | a.x; x0 = (uint64_t)a.w << 32 | a.z; x1 = (uint64_t)b.y << 32 | b.x; sz = (uint64_t)b.w << 32 | b.z;
             pk0 = cb.x; pk1 = cb.y; pk2 = cb.z; pack = cb.w;
             st = WK_ADM2;
@@ -424,7 +311,6 @@ __global__ __launch_bounds__(64, MODE == WALK_HEADP ? FMD_HEADP_WAVES : 4) void 
                 walk_ls[fmd_lane()] = (c0 & 0xffffu) | c1 << 16; walk_ls[64 + fmd_lane()] = (c2 & 0xffffu) | c3 << 16;
                 depth = FMD_WALK_SPLIT; npush = 0; pack = 0; pk0 = pk1 = pk2 = 0; ret = 0; tab = false;
                 flags = ((c0 | c1 | c2 | c3) & 0x10000u) ? WALK_F_HASN : 0u;
-                WALK_PARKED_EXTRAS();
                 st = walk_lf_shares(k, x0, sz) ? WK_BOTH : WK_LF;
             }
             continue;
@@ -438,7 +324,6 @@ __global__ __launch_bounds__(64, MODE == WALK_HEADP ? FMD_HEADP_WAVES : 4) void 
                 sr[1] = make_uint4(WALK_NIB4(pk2), WALK_NIB4(pk2 >> 16), WALK_NIB4(pack), WALK_NIB4(pack >> 16));
 #undef WALK_NIB4
                 depth = FMD_WALK_SPLIT; npush = 0; pack = 0; pk0 = pk1 = pk2 = 0; flags = 0; ret = 0; tab = false;
-                WALK_PARKED_EXTRAS();
                 st = walk_lf_shares(k, x0, sz) ? WK_BOTH : WK_LF;
             }
             continue;
@@ -501,7 +386,7 @@ __global__ __launch_bounds__(64, MODE == WALK_HEADP ? FMD_HEADP_WAVES : 4) void 
                 fmd_ovlp_rec_t *o = rec + gs;
                 o->rank = k; o->k[0] = o->k[1] = o->k[2] = 0; o->len = 0; o->status = -1; o->n_ovlp = 0; o->rbeg = -1;
                 o->ext_len = 0; o->n_nei = 0; o->flags = 0; o->reserved = 2; o->lfork = 0;
-                if (HEADM) park[gs].k = ~0ull;
+                if (MODE == WALK_HEAD) park[gs].k = ~0ull;
                 st = WK_IDLE;
                 continue;
             }
@@ -527,8 +412,7 @@ __global__ __launch_bounds__(64, MODE == WALK_HEADP ? FMD_HEADP_WAVES : 4) void 
             if (c != 0) { // one more base: overlap_intv's loop body (unitig.c:47-59)
                 const uint64_t sc = sel6(c, s[0], s[1], s[2], s[3], s[4], s[5]);
                 // (sc == 0 cannot happen: the sequence itself is in the index)
-                if (MODE == WALK_HEADP && depth >= FMD_WALK_SPLIT && c > 4) { st = WK_IDLE; continue; }   // an N beyond the first park: the strand stays parked there
-                if (!HEADM && !info_only && (int)depth >= min_match && s[0]) {
+                if (MODE != WALK_HEAD && !info_only && (int)depth >= min_match && s[0]) {
                     if (npush < cap) {
                         fmd_intv_t *e = listA + sid * (size_t)cap + (cap - 1 - npush);
                         if (narrow && depth < 65536u) cand_store_narrow(e, x0, x1, (uint32_t)sz, depth, wD, wr0);
@@ -551,7 +435,7 @@ __global__ __launch_bounds__(64, MODE == WALK_HEADP ? FMD_HEADP_WAVES : 4) void 
                 if (MODE == WALK_TAIL2) {
                     if ((depth & 15) && depth <= WALK_LS_BASES) walk_ls[(depth >> 4) * 64 + fmd_lane()] = pack;   // the last, partial word
                 } else
-                if (!HEADM && (depth & 15) && depth <= stride_r) // the last, partial group of 16 (stride_r is a multiple of 16)
+                if (MODE != WALK_HEAD && (depth & 15) && depth <= stride_r) // the last, partial group of 16 (stride_r is a multiple of 16)
                 {   // completed words of the group sit in pk0..2, a partial word in pack; everything past it is zero
                     const uint32_t wq = (depth >> 2) & 3;
                     *(uint4 *)(srev + sid * (size_t)stride_r + (depth & ~15u)) = make_uint4(wq == 0 ? pack : pk0, wq == 1 ? pack : pk1, wq == 2 ? pack : pk2, wq == 3 ? pack : 0u);
@@ -559,7 +443,7 @@ __global__ __launch_bounds__(64, MODE == WALK_HEADP ? FMD_HEADP_WAVES : 4) void 
                 fmd_ovlp_rec_t *o = rec + gs;
                 o->rank = k; o->len = (int32_t)depth; o->rbeg = -1; o->ext_len = 0; o->n_nei = 0; o->reserved = 2; o->lfork = 0;
                 o->k[0] = o->k[1] = o->k[2] = 0; o->n_ovlp = 0;
-                if (HEADM) park[gs].k = ~0ull;   // ended inside the head: shorter than min_match, the record below is final
+                if (MODE == WALK_HEAD) park[gs].k = ~0ull;   // ended inside the head: shorter than min_match, the record below is final
                 if (depth > stride_r) { o->status = 0; o->flags = FMD_OVLP_F_OVERFLOW; st = WK_IDLE; continue; } // longer than max_len
                 if (!info_only && (int)depth <= min_match) { o->status = -1; o->flags = 0; st = WK_IDLE; continue; } // too short (unitig.c:288)
                 // (the caller's copy in read order is made by k_ovl_seq_out: a lane doing it here, from a stash in HBM, holds up the other 63)
@@ -593,15 +477,146 @@ __global__ __launch_bounds__(64, MODE == WALK_HEADP ? FMD_HEADP_WAVES : 4) void 
             st = WK_IDLE;
             continue;
         }
-        nopair = false;
-        WALK_NEXT_STATE_AND_PARK();
+        // next base: can the LF step share the extension's gather?
+        {
+            st = walk_lf_shares(k, x0, sz) ? WK_BOTH : WK_LF;
+            if (tab) st = WK_LF;   // inside the prefix table there is no extension to share a gather with
+        }
+        // park the strand: one 64-byte line, written whole.  cls_cfg (free in this mode): a depth below FMD_WALK_SPLIT at which the head hands the strand to
+        // k_ovl_pair (two bases per request from there on; pad.w >> 24 = that depth), 0 = FMD_WALK_SPLIT, the strand parked for good
+        // (Handing a strand over at the first even depth at which its interval is narrow -- 63 % of the strands of 30-fold reads at 14, nearly all at 16 -- was
+        // measured and not kept: the head's time is its first two, wide, bases, and k_ovl_pair lost more than the head gained: 36.3 -> 39.3 ms, profiles/r6_pair.)
+        // A strand whose interval is still wider than 63 at the hand-over is not handed over: it goes on here, one base at a time, and is parked for good.
+        if (MODE == WALK_HEAD && !tab && (depth == FMD_WALK_SPLIT || (cls_cfg > 0 && depth == (uint32_t)cls_cfg && sz <= 63))) {
+            uint4 *pp = (uint4 *)(park + gs);
+            pp[0] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), (uint32_t)x0, (uint32_t)(x0 >> 32));
+            pp[1] = make_uint4((uint32_t)x1, (uint32_t)(x1 >> 32), (uint32_t)sz, (uint32_t)(sz >> 32));
+            pp[2] = make_uint4(pk0, pk1, pk2, pack); pp[3] = make_uint4(0, 0, 0, depth < FMD_WALK_SPLIT ? depth << 24 : 0u);
+            st = WK_IDLE;
+        }
     }
 }
-#undef WALK_NEXT_STATE_AND_PARK
-#undef WALK_PARKED_EXTRAS
 
 #undef WALK_STASH_WORD
 #undef WALK_PUT_BASE
+
+// ---- two bases per request (round 6; fmd_pair.hip, fmd_wave.h) -----------------------------------------------------------------------
+// Pass 1 of a sorted job below FMD_WALK_SPLIT, for an index that has two-base blocks: WALK_HEAD takes every strand to depth `from` (16: by then the
+// interval of a strand of 30-fold reads is narrower than 64) and parks it; this kernel takes it on to FMD_WALK_SPLIT two bases per gather and parks it
+// for good.  It does NOTHING else -- no single steps, no wide intervals, no sequence ends: a strand it cannot take all the way (an interval still wider than
+// 63, an N or the sequence's end within the next two bases) goes on a list, and WALK_HEAD walks those again from their admission records.  That is
+// what keeps it lean: one 8 KiB landing slot and ~70 registers per wave, so that a CU holds as many waves as the single-step head -- the first form of
+// this (k_ovl_walk<WALK_HEADP>, profiles/r6_pair) carried the whole single-step engine beside the pair step, held 8 waves per CU and lost.
+// A pair block starts every 32 positions and describes 96: an interval of up to 64 positions lies inside the block of its first position.
+// The step: the positions of the window with first symbol c1 are the interval one base on, in order; those among them with second symbol c2 the interval
+// two bases on: sizes, the x[1] sums of both extensions (fm6_extend's order 0 < 4 < 3 < 2 < 1 < 5, exact.c:81-86) and the rank of row k are popcounts,
+// the start is one pair count (block + superblock: ix.pair_tab, which also holds K2[c1][c2] = cnt[c2] + #{c2 in BWT[0, cnt[c1])}).
+enum { PK_IDLE = 0, PK_LOAD, PK_RUN };
+#ifndef FMD_PAIR_AUX
+#define FMD_PAIR_AUX FMD_HEAD_AUX      // cache-policy bits of the two-base gather (2 = nt: every line is asked for once)
+#endif
+#ifndef FMD_PAIR_LB
+#define FMD_PAIR_LB 4                  // waves per SIMD the kernel is compiled for
+#endif
+__global__ __launch_bounds__(64, FMD_PAIR_LB) void k_ovl_pair(FmdIndexView ix, size_t n, FmdWalkPark *__restrict__ park, uint32_t *__restrict__ queue, uint32_t tchunk,
+                                                  uint32_t *__restrict__ strag)
+{
+    __shared__ uint4 pair_lds[FMD_PAIR_SLOT_U4];
+    const int q_ = fmd_lane(), px = fmd_pair_xor(q_);
+    const uint4 *img = pair_lds + fmd_pair_base(q_);
+    const uint32_t *iw = (const uint32_t *)img;
+    size_t row = 0;
+    int st = PK_IDLE;
+    bool exhausted = false;
+    uint32_t depth = 0, pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0;
+    uint64_t k = 0, x0 = 0, x1 = 0, sz = 0;
+    uint4 la = make_uint4(0, 0, 0, 0), lb = la, lc = la, ld = la;
+    FmdTickets tk_;
+    fmd_tickets_init(tk_, queue, tchunk & 0xffffffu, (tchunk >> 24) ? n : 0);
+    for (;;) {
+        const size_t my = fmd_tickets_take(tk_, queue, st == PK_IDLE && !exhausted, (tchunk >> 24) ? n : 0);
+        if (st == PK_IDLE && !exhausted) {
+            if (my < n) {   // the parked line: its loads land under the gather of the other lanes
+                row = my;
+                const uint4 *pp = (const uint4 *)(park + row);
+                la = pp[0]; lb = pp[1]; lc = pp[2]; ld = pp[3];
+                st = PK_LOAD;
+            } else exhausted = true;
+        }
+        if (__ballot(st != PK_IDLE) == 0) break;
+        fmd_pair_fetch<FMD_PAIR_AUX>(ix, pair_lds, (uint32_t)(x0 >> 5), st == PK_RUN);
+        fmd_fetch_wait();
+        if (st == PK_LOAD) {
+            k = (uint64_t)la.y << 32 | la.x; x0 = (uint64_t)la.w << 32 | la.z; x1 = (uint64_t)lb.y << 32 | lb.x; sz = (uint64_t)lb.w << 32 | lb.z;
+            pk0 = lc.x; pk1 = lc.y; pk2 = lc.z; pk3 = lc.w;
+            depth = ld.w >> 24;
+            st = PK_RUN;
+            if (k == ~0ull || depth == 0) st = PK_IDLE;                        // the sequence ended inside the head / the strand is parked for good already
+            else if (sz > 63 || depth + 2 > FMD_WALK_SPLIT) { strag[1 + atomicAdd(strag, 1u)] = (uint32_t)row; st = PK_IDLE; }
+            continue;
+        }
+        if (st != PK_RUN) continue;
+        const uint32_t off = (uint32_t)x0 & 31u;
+        const uint4 A0 = img[0 ^ px], A1 = img[1 ^ px], A2 = img[2 ^ px], B0 = img[3 ^ px], B1 = img[4 ^ px], B2 = img[5 ^ px];
+        const uint64_t X = win64(A0.x, A1.x, A2.x, off), Y = win64(A0.y, A1.y, A2.y, off), Z = win64(A0.z, A1.z, A2.z, off);
+        const uint64_t S0 = win64(A0.w, A1.w, A2.w, off), S1 = win64(B0.x, B1.x, B2.x, off), S2 = win64(B0.y, B1.y, B2.y, off);
+        const uint64_t m = bits_below((int)sz);
+        const uint32_t o = (uint32_t)(k - x0);
+        const int c1 = (int)(((X >> o) & 1) | ((Y >> o) & 1) << 1 | ((Z >> o) & 1) << 2);
+        const int c2 = (int)(((S0 >> o) & 1) | ((S1 >> o) & 1) << 1 | ((S2 >> o) & 1) << 2);
+        if (c1 < 1 || c1 > 4 || c2 < 1 || c2 > 4) { strag[1 + atomicAdd(strag, 1u)] = (uint32_t)row; st = PK_IDLE; continue; }   // the sequence ends within two bases, or an N
+        const uint64_t lo = ~Z & m, hi = Z & ~Y & m;
+        const uint64_t M0 = lo & ~Y & ~X, M1 = lo & ~Y & X, M2 = lo & Y & ~X, M3 = lo & Y & X, M4 = hi & ~X;
+        const uint64_t Mc = c1 == 1 ? M1 : c1 == 2 ? M2 : c1 == 3 ? M3 : M4;
+        const uint64_t lo2 = ~S2 & Mc, hi2 = S2 & ~S1 & Mc;
+        const uint64_t N0 = lo2 & ~S1 & ~S0, N1 = lo2 & ~S1 & S0, N2 = lo2 & S1 & ~S0, N3 = lo2 & S1 & S0, N4 = hi2 & ~S0;
+        const uint64_t Mp = c2 == 1 ? N1 : c2 == 2 ? N2 : c2 == 3 ? N3 : N4;
+        uint32_t before = (uint32_t)__popcll(M0) + (uint32_t)__popcll(N0);          // '$' sorts before every base
+        if (c1 != 4) before += (uint32_t)__popcll(M4);
+        if (c1 == 2 || c1 == 1) before += (uint32_t)__popcll(M3);
+        if (c1 == 1) before += (uint32_t)__popcll(M2);
+        if (c2 != 4) before += (uint32_t)__popcll(N4);
+        if (c2 == 2 || c2 == 1) before += (uint32_t)__popcll(N3);
+        if (c2 == 1) before += (uint32_t)__popcll(N2);
+        // pairs (c1, c2) before x0: the superblock's (+ K2), the block's 28-bit count, positions [0, off) of the block's own chunk
+        const uint32_t e0x = (c1 & 1) ? 0u : ~0u, e0y = (c1 & 2) ? 0u : ~0u, e0z = (c1 & 4) ? 0u : ~0u;
+        const uint32_t e1x = (c2 & 1) ? 0u : ~0u, e1y = (c2 & 2) ? 0u : ~0u, e1z = (c2 & 4) ? 0u : ~0u;
+        const uint32_t pm0 = (A0.x ^ e0x) & (A0.y ^ e0y) & (A0.z ^ e0z) & (A0.w ^ e1x) & (B0.x ^ e1y) & (B0.y ^ e1z);
+        const uint32_t nb_ = (uint32_t)__builtin_popcount(pm0 & fmd_mask32((int)off));
+        const int pr = 4 * (c1 - 1) + (c2 - 1), bp = 28 * pr, tw = bp >> 5, tw1 = tw < 13 ? tw + 1 : 13;
+#define WP_CW(t) iw[(((t) < 6 ? 3 + ((t) >> 1) : 6 + (((t) - 6) >> 2)) ^ px) * 4 + ((t) < 6 ? 2 + ((t) & 1) : (((t) - 6) & 3))]
+        const uint32_t cwl = WP_CW(tw), cwh = WP_CW(tw1);
+#undef WP_CW
+        const uint32_t rel = __builtin_amdgcn_alignbit(cwh, cwl, (uint32_t)bp & 31u) & 0x0fffffffu;
+        const uint64_t base = ix.pair_tab[(x0 >> (5 + FMD_PAIR_SB_SHIFT)) * 16 + (uint64_t)pr];
+        const uint64_t nx0 = base + rel + nb_;
+        k = nx0 + (uint64_t)__popcll(Mp & bits_below((int)o + 1)) - 1;
+        x0 = nx0; sz = (uint64_t)__popcll(Mp); x1 += before;
+        {   // the two bases into the parked nibbles (FmdWalkPark::bases: 4 bits each, the sequence's last base first)
+            const uint32_t v1 = (uint32_t)c1 << (4 * (depth & 7)), w1 = depth >> 3;
+            pk0 |= w1 == 0 ? v1 : 0u; pk1 |= w1 == 1 ? v1 : 0u; pk2 |= w1 == 2 ? v1 : 0u; pk3 |= w1 == 3 ? v1 : 0u;
+            const uint32_t d2 = depth + 1, v2 = (uint32_t)c2 << (4 * (d2 & 7)), w2 = d2 >> 3;
+            pk0 |= w2 == 0 ? v2 : 0u; pk1 |= w2 == 1 ? v2 : 0u; pk2 |= w2 == 2 ? v2 : 0u; pk3 |= w2 == 3 ? v2 : 0u;
+            depth += 2;
+        }
+        if (depth >= FMD_WALK_SPLIT) {   // parked for good: the line WALK_HEAD would have written
+            uint4 *pp = (uint4 *)(park + row);
+            pp[0] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), (uint32_t)x0, (uint32_t)(x0 >> 32));
+            pp[1] = make_uint4((uint32_t)x1, (uint32_t)(x1 >> 32), (uint32_t)sz, (uint32_t)(sz >> 32));
+            pp[2] = make_uint4(pk0, pk1, pk2, pk3); pp[3] = make_uint4(0, 0, 0, 0);
+            st = PK_IDLE;
+        } else if (sz > 63 || depth + 2 > FMD_WALK_SPLIT) { strag[1 + atomicAdd(strag, 1u)] = (uint32_t)row; st = PK_IDLE; }   // (cannot happen from an even depth with a narrow interval: sizes only shrink)
+    }
+}
+// the admission records of the strands k_ovl_pair could not take all the way, for a second launch of WALK_HEAD
+__global__ void k_ovl_strag_adm(const uint32_t *__restrict__ strag, const uint4 *__restrict__ adm, uint4 *__restrict__ adm2)
+{
+    const uint32_t n = strag[0];
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const size_t r = strag[1 + j];
+        adm2[2 * (size_t)j] = adm[2 * r]; adm2[2 * (size_t)j + 1] = adm[2 * r + 1];
+    }
+}
 
 // WALK_TAIL2's strands with an N (redo[0] of them, slots redo[1 ..]): one lane per strand, the row byte by byte -- the 32 bases WALK_HEAD parked, then LF steps from
 // the parked row on, read straight from the index (no wave gather: a handful of strands per batch of real reads, none of synthetic ones).
@@ -614,16 +629,11 @@ __global__ void k_ovl_seq_redo(FmdIndexView ix, const uint32_t *__restrict__ red
         const int len = rec[g].len;
         uint8_t *dst = seq_out + g * (size_t)seq_stride;
         const uint4 *pp = (const uint4 *)(park + g);
-        const uint4 a = pp[0], cb = pp[2], pd = pp[3];
+        const uint4 a = pp[0], cb = pp[2];
         const uint32_t nib[4] = {cb.x, cb.y, cb.z, cb.w};
         uint64_t k = (uint64_t)a.y << 32 | a.x;
-        const int parked = (int)(pd.w >> 24) > (int)FMD_WALK_SPLIT ? (int)(pd.w >> 24) : (int)FMD_WALK_SPLIT;   // (WALK_HEADP: the row stands `parked` bases in; those beyond the first 32 are in pad.z / pad.w, 2 bits each)
         for (int f = 0; f < (int)FMD_WALK_SPLIT && f < len; ++f) dst[len - 1 - f] = (uint8_t)((nib[f >> 3] >> (4 * (f & 7))) & 0xfu);
-        for (int f = (int)FMD_WALK_SPLIT; f < parked && f < len; ++f) {
-            const int e = f - (int)FMD_WALK_SPLIT;
-            dst[len - 1 - f] = (uint8_t)((((e < 16 ? pd.z >> (2 * e) : pd.w >> (2 * (e - 16))) & 3u)) + 1u);
-        }
-        for (int f = parked; f < len; ++f) {
+        for (int f = (int)FMD_WALK_SPLIT; f < len; ++f) {
             uint32_t b, o;
             fmd_split(k, b, o);
             const uint4 *img = ix.blocks + (size_t)b * FMD_BLK_U4;
@@ -1558,7 +1568,7 @@ extern "C" size_t fmd_ovlp_head_work_bytes(size_t n) { return head_layout(n).tot
 static int ovl_head(fmd_dev *h, hipStream_t st, size_t n, const uint64_t *d_ids, int min_match, uint32_t seq_stride, fmd_ovlp_rec_t *d_rec, FmdWalkPark *park,
                     uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_sorted, uint32_t *order, void *tmp, size_t tmp_bytes, uint4 *adm)
 {
-    (void)fmd_pairs_ensure(h);             // the two-base blocks, built on the first job of this handle where they fit (fmd_pair.hip)
+    (void)fmd_pairs_ensure(h, 0);          // the two-base blocks: built here only where FMD_PAIR asks for it (fmd_pair.hip); a caller that keeps the index for many passes calls fmd_dev_build_pairs
     const FmdIndexView ix = fmd_view(h);
     // pass 1: every strand FMD_WALK_SPLIT bases in, in the caller's order.  (Taking the strands in the order of their last ptab_d bases --
     // the tail table has them, one more radix sort -- makes this pass 7 % faster and costs what it saves: profiles/r3_locality.)
@@ -1569,20 +1579,48 @@ static int ovl_head(fmd_dev *h, hipStream_t st, size_t n, const uint64_t *d_ids,
         if (blocks > (1u << 20)) blocks = 1u << 20;
         k_ovl_head_adm<<<(unsigned)blocks, 256, 0, st>>>(ix, n, d_ids, order1, use_tail, adm);
         uint32_t *q = fmd_next_queue(h, st);
-        bool pairs = ix.pair != nullptr && ix.pair_tab != nullptr;
-        { const char *e = getenv("FMD_PAIR_USE"); if (e && atoi(e) == 0) pairs = false; }   // A/B switch on a handle that has the blocks
-        int grid = fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16 + (pairs ? FMD_PAIR_SLOT_U4 * 16 : 0));
+        int grid = fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16);
         { const char *e = getenv("FMD_HEAD_WAVES"); if (e && atoi(e) > 0 && grid > h->n_cu * atoi(e)) grid = h->n_cu * atoi(e); }
-        if (pairs) {
-            // with two-base blocks a base of pass 1 costs half a request where a base of pass 2 costs a whole one: the head goes on up to min_match
-            // (nothing is pushed below it), as far as the parked line has room for the bases (WALK_PARK_MAX); FMD_HEAD_SPLIT is the A/B knob
-            int split = min_match < (int)WALK_PARK_MAX ? min_match : (int)WALK_PARK_MAX;
-            { const char *e = getenv("FMD_HEAD_SPLIT"); if (e && atoi(e) >= (int)FMD_WALK_SPLIT && atoi(e) <= split) split = atoi(e); }
-            k_ovl_walk<WALK_HEADP><<<grid, 64, 0, st>>>(ix, n, d_ids, min_match, nullptr, (uint32_t)sizeof(FmdWalkPark), 0, nullptr, d_rec,
-                                                     nullptr, seq_stride, q, 0, park, nullptr, adm, walk_ticket_chunk("FMD_HEAD_TICKETS", 256, n, grid), nullptr, nullptr, split);
-        } else
+        bool pairs = ix.pair != nullptr && ix.pair_tab != nullptr && n >= 4096 && n < 0xffffff00ull;
+        { const char *e = getenv("FMD_PAIR_USE"); if (e && atoi(e) == 0) pairs = false; }   // A/B switch on a handle that has the blocks
+        uint32_t *strag = pairs ? (uint32_t *)fmd_scratch_acquire(h, (n + 1) * 4) : nullptr;
+        if (pairs && strag) {
+            // single steps up to `from` (by then a strand's interval is narrow), two bases per request from there to FMD_WALK_SPLIT (k_ovl_pair), and
+            // the strands that kernel could not take all the way once more from their admission records, single steps all the way
+            int from = 16;
+            { const char *e = getenv("FMD_PAIR_FROM"); if (e && atoi(e) > ix.ptab_d && atoi(e) < (int)FMD_WALK_SPLIT && !(atoi(e) & 1)) from = atoi(e); }
+            if (from <= ix.ptab_d) from = (ix.ptab_d + 2) & ~1;
+            k_ovl_walk<WALK_HEAD><<<grid, 64, 0, st>>>(ix, n, d_ids, min_match, nullptr, (uint32_t)sizeof(FmdWalkPark), 0, nullptr, d_rec,
+                                                    nullptr, seq_stride, q, 0, park, nullptr, adm, walk_ticket_chunk("FMD_HEAD_TICKETS", 256, n, grid), nullptr, nullptr, from);
+            (void)hipMemsetAsync(strag, 0, 4, st);
+            uint32_t *q2 = fmd_next_queue(h, st);
+            int grid2 = h->n_cu * (FMD_PAIR_LB * 4 < 20 ? FMD_PAIR_LB * 4 : 20);      // (8 KiB of LDS per wave: twenty fit a CU)
+            if ((size_t)grid2 > (n + 63) / 64) grid2 = (int)((n + 63) / 64);
+            { const char *e = getenv("FMD_PAIR_WAVES"); if (e && atoi(e) > 0 && grid2 > h->n_cu * atoi(e)) grid2 = h->n_cu * atoi(e); }
+            k_ovl_pair<<<grid2, 64, 0, st>>>(ix, n, park, q2, walk_ticket_chunk("FMD_PAIR_TICKETS", 256, n, grid2), strag);
+            uint32_t n_strag = 0;
+            hipError_t e1 = hipMemcpyAsync(&n_strag, strag, 4, hipMemcpyDeviceToHost, st);
+            if (e1 == hipSuccess) e1 = hipStreamSynchronize(st);
+            if (e1 != hipSuccess) { fmd_set_hip_error(e1, "two-base pass"); fmd_scratch_release(h, strag); return FMD_E_HIP; }
+            if (n_strag) {
+                uint4 *adm2 = (uint4 *)fmd_scratch_acquire(h, (size_t)n_strag * 32);
+                if (!adm2) { fmd_scratch_release(h, strag); return FMD_E_NOMEM; }
+                k_ovl_strag_adm<<<(n_strag + 255) / 256 < 65536 ? (n_strag + 255) / 256 : 65536, 256, 0, st>>>(strag, adm, adm2);
+                uint32_t *q3 = fmd_next_queue(h, st);
+                int grid3 = fmd_grid_for_lds(h, n_strag, FMD_COMPACT_LDS_U4 * 16);
+                k_ovl_walk<WALK_HEAD><<<grid3, 64, 0, st>>>(ix, n_strag, d_ids, min_match, nullptr, (uint32_t)sizeof(FmdWalkPark), 0, nullptr, d_rec,
+                                                         nullptr, seq_stride, q3, 0, park, nullptr, adm2, walk_ticket_chunk("FMD_HEAD_TICKETS", 256, n_strag, grid3), nullptr, nullptr, 0);
+                e1 = hipStreamSynchronize(st);      // (adm2 goes back to the handle's cache)
+                fmd_scratch_release(h, adm2);
+                if (e1 != hipSuccess) { fmd_set_hip_error(e1, "two-base pass"); fmd_scratch_release(h, strag); return FMD_E_HIP; }
+            }
+            fmd_scratch_release(h, strag);
+            if (getenv("FMD_DEBUG_PAIR")) fprintf(stderr, "[M::ovl_head] two-base pass from depth %d: %u of %zu strands walked again one base at a time\n", from, n_strag, n);
+        } else {
+        if (strag) fmd_scratch_release(h, strag);
         k_ovl_walk<WALK_HEAD><<<grid, 64, 0, st>>>(ix, n, d_ids, min_match, nullptr, (uint32_t)sizeof(FmdWalkPark), 0, nullptr, d_rec,
                                                 nullptr, seq_stride, q, 0, park, nullptr, adm, walk_ticket_chunk("FMD_HEAD_TICKETS", 256, n, grid), nullptr, nullptr, 0);
+        }
     }
     // the order of pass 2: rows sorted by the minimizer of the bases each strand has shown so far
     return fmd_park_sort(st, n, park, keys_a, keys_sorted, vals_a, order, tmp, tmp_bytes);

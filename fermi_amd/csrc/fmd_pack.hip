@@ -246,6 +246,40 @@ __global__ void k_link_rows(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, un
         if (r->status == 0 && !(r->flags & FMD_OVLP_F_OVERFLOW) && r->k[0] < n) atomicMin(map + r->k[0], (unsigned long long)i << 32 | (unsigned long long)r->lfork);
     }
 }
+// The round-5 form, kept for tables beside which the 8-byte map does not fit (config 5: 1.4*10^9 rows beside a 153 GB index): a 4-byte row map in the
+// caller's row_of[], and the neighbour's reverse strand's record read for its lfork.
+__global__ void k_link_rows32(size_t n, const fmd_ovlp_rec_t *__restrict__ rec, uint32_t *__restrict__ row_of)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+        const fmd_ovlp_rec_t *r = rec + i;
+        if (r->status == 0 && !(r->flags & FMD_OVLP_F_OVERFLOW) && r->k[0] < n) atomicMin(row_of + r->k[0], (uint32_t)i);
+    }
+}
+__global__ void k_link_edges32(size_t n, fmd_ovlp_rec_t *__restrict__ rec, const uint64_t *__restrict__ nei_x01, uint32_t nei_stride,
+                               const uint32_t *__restrict__ row_of, fmd_ovlp_link_t *__restrict__ link, uint64_t *__restrict__ und,
+                               unsigned long long *__restrict__ n_und, int force_exact)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+        fmd_ovlp_rec_t *r = rec + i;
+        fmd_ovlp_link_t l; l.nxt = l.rev = 0xffffffffu;
+        if (r->status == 0 && r->n_nei == 1 && r->rbeg >= 0 && !(r->flags & FMD_OVLP_F_OVERFLOW)) {
+            const uint64_t x0 = nei_x01[i * (size_t)nei_stride], x1 = nei_x01[i * (size_t)nei_stride + 1];
+            if (x0 < n) l.nxt = row_of[x0];
+            if (x1 < n) l.rev = row_of[x1];
+            const bool miss = (x0 < n && l.nxt == 0xffffffffu) || (x1 < n && l.rev == 0xffffffffu);
+            int d = 0;
+            if (r->reserved == 2) {
+                d = 1;
+                if (l.rev != 0xffffffffu && !force_exact) d = lfork_decide_dev(rec[l.rev].lfork, r->rbeg);
+                if (d != 1) r->reserved = (uint16_t)(d < 0 ? 1 : 0);
+            }
+            if (d == 1 || miss) und[atomicAdd(n_und, 1ull)] = i;
+        }
+        link[i] = l;
+    }
+}
 __global__ void k_link_row_of(size_t n, const unsigned long long *__restrict__ map, uint32_t *__restrict__ row_of)
 {
     const size_t step = (size_t)gridDim.x * blockDim.x;
@@ -290,14 +324,22 @@ extern "C" int fmd_ovlp_link_dev(fmd_dev_t *h, void *stream_, size_t n, fmd_ovlp
     hipStream_t st = (hipStream_t)stream_;
     FMD_HIP_TRY(hipMemsetAsync(d_n_undecided, 0, 8, st));
     if (n == 0) return FMD_OK;
-    unsigned long long *map = (unsigned long long *)fmd_scratch_acquire(h, n * 8);   // (kept by the handle between calls)
-    if (!map) return FMD_E_NOMEM;
-    if (hipMemsetAsync(map, 0xff, n * 8, st) != hipSuccess) { fmd_set_hip_error(hipGetLastError(), "link kernels"); fmd_scratch_release(h, map); return FMD_E_HIP; }
     size_t blocks = (n + 255) / 256;
     if (blocks > (1u << 20)) blocks = 1u << 20;
+    const int force_exact = getenv("FMD_CHECK_LEFT_EXACT") != nullptr;
+    unsigned long long *map = getenv("FMD_LINK_MAP32") ? nullptr : (unsigned long long *)fmd_scratch_acquire(h, n * 8);   // (kept by the handle between calls; FMD_LINK_MAP32: the A/B switch)
+    if (!map) {   // no room for 8 bytes per position (or asked not to): the 4-byte map in the caller's array, three look-ups per edge
+        (void)hipGetLastError();
+        FMD_HIP_TRY(hipMemsetAsync(d_row_of, 0xff, n * 4, st));
+        k_link_rows32<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, d_row_of);
+        k_link_edges32<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, d_nei_x01, nei_stride_u64, d_row_of, d_link, d_undecided, (unsigned long long *)d_n_undecided, force_exact);
+        hipError_t e32 = hipGetLastError();
+        if (e32 != hipSuccess) { fmd_set_hip_error(e32, "link kernels"); return FMD_E_HIP; }
+        return FMD_OK;
+    }
+    if (hipMemsetAsync(map, 0xff, n * 8, st) != hipSuccess) { fmd_set_hip_error(hipGetLastError(), "link kernels"); fmd_scratch_release(h, map); return FMD_E_HIP; }
     k_link_rows<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, map);
-    k_link_edges<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, d_nei_x01, nei_stride_u64, map, d_link, d_undecided, (unsigned long long *)d_n_undecided,
-                                                  getenv("FMD_CHECK_LEFT_EXACT") != nullptr);
+    k_link_edges<<<(unsigned)blocks, 256, 0, st>>>(n, d_rec, d_nei_x01, nei_stride_u64, map, d_link, d_undecided, (unsigned long long *)d_n_undecided, force_exact);
     k_link_row_of<<<(unsigned)blocks, 256, 0, st>>>(n, map, d_row_of);
     hipError_t e = hipGetLastError();
     // the map goes back to the handle's cache when the stream has passed the kernels that read it

@@ -164,9 +164,10 @@ __device__ __forceinline__ void fmd_fetch_slot(const FmdIndexView &ix, uint4 *ld
 __device__ __forceinline__ void fmd_fetch_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---- two-base blocks ------------------------------------------------------------------------------------------------------------------
-// A pair block starts every 64 positions and describes 96, like a rank block; per position p it holds BWT[p] (as the rank block does) and
-// BWT[LF(p)] -- the base the walk would find one step later -- as three bit planes each, and for its 16 A/C/G/T pairs the number of positions
-// before the block with that pair, relative to its superblock of 2^28 positions (28 bits each):
+// A pair block starts every 32 positions and describes 96 (so that ANY interval of up to 64 positions lies inside the block of its first position: a
+// walk that has become narrow never needs a second line); per position p it holds BWT[p] (as the rank block does) and BWT[LF(p)] -- the base the
+// walk would find one step later -- as three bit planes each, and for its 16 A/C/G/T pairs the number of positions before the block with that
+// pair, relative to its superblock of 2^28 positions (28 bits each):
 //     u4[j], j = 0..2     = { p0, p1, p2, s0 } of 32 positions: p = planes of BWT[p], s = planes of BWT[LF(p)] (0 where BWT[p] is not A/C/G/T)
 //     u4[3 + j], j = 0..2 = { s1, s2, cw[2j], cw[2j + 1] }
 //     u4[6], u4[7]        = cw[6 .. 13]
@@ -175,7 +176,8 @@ __device__ __forceinline__ void fmd_fetch_wait() { asm volatile("s_waitcnt vmcnt
 // K2 = cnt[c2] + #{c2 in BWT[0, cnt[c1])}; pair_tab holds K2 + the pairs before the superblock, the block the rest.
 #define FMD_PAIR_U4 8
 #define FMD_PAIR_BYTES 128
-#define FMD_PAIR_SB_SHIFT 22                    // blocks per superblock: 2^22 (2^28 positions)
+#define FMD_PAIR_STRIDE 32u                     // positions between the starts of consecutive pair blocks
+#define FMD_PAIR_SB_SHIFT 23                    // blocks per superblock: 2^23 (2^28 positions)
 #define FMD_PAIR_SLOT_U4 (64 * FMD_PAIR_U4)     // one image per lane: 8 KiB per wave
 // chunk XOR of lane q's image: the sixteen lanes of a ds_read_b128 service group ({0-3,12-15,20-27}, ...) get the sixteen 16-byte slots of a 256-byte row
 __device__ __forceinline__ int fmd_pair_xor(int q) { return (q & 3) | ((q >> 4) & 1) << 2; }

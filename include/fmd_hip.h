@@ -72,6 +72,7 @@ int fmd_dev_sync(const fmd_dev_t *h, void *stream);
  * libfmdhip_count.so -- the same sources built with -DFMD_COUNT_LINES=1 -- counts (*counting = 1); the shipped
  * library returns zeros and *counting = 0.  Synchronises the device. */
 int fmd_dev_line_count(fmd_dev_t *h, uint64_t lines[2], int reset, int *counting);
+int fmd_dev_line_count3(fmd_dev_t *h, uint64_t lines[3], int reset, int *counting);   /* ... and lines[2] = 128-byte two-base blocks requested (fmd_dev_build_pairs) */
 
 /* ---- rank: rld_rank1a (rld.c:424) / rld_rank2a (rld.c:457) -------------------------------
  * ok/ol: n rows of 6 counts ($ACGTN) of BWT[0..k] inclusive; k == UINT64_MAX gives zeros.

@@ -1,8 +1,8 @@
-"""GPU: the two-base blocks (fmd_pair.hip) and the head that reads them (k_ovl_walk<WALK_HEADP>).  A pair step is two exact LF / extension
-steps, so (a) every row's pair step must equal two single steps (fmd_dev_check_pairs, all rows of every fixture), and (b) the sorted job must
-leave the same bytes whether the handle has two-base blocks or not, wherever the head parks its strands (FMD_HEAD_SPLIT), on reads with
-errors, ragged lengths, Ns and sequences that end inside the head -- and those bytes are the id-order pass's, which the golden tests tie to
-the reference."""
+"""GPU: the two-base blocks (fmd_pair.hip) and the kernel that reads them (k_ovl_pair: pass 1 of the sorted job between the depth at which the single-step
+head hands a strand over and the 32 bases at which it is parked).  A pair step is two exact LF / extension steps, so (a) every row's pair step must equal
+two single steps (fmd_dev_check_pairs, all rows of every fixture, the look-ahead chunks included), and (b) the sorted job must leave the same bytes whether
+the handle has two-base blocks or not, wherever the hand-over is (FMD_PAIR_FROM), on reads with errors, ragged lengths, Ns and sequences that end inside the
+head (all of which k_ovl_pair refuses and the head walks again) -- and those bytes are the id-order pass's, which the golden tests tie to the reference."""
 import os
 
 import numpy as np
@@ -42,23 +42,23 @@ def _ragged(rng, N, L, cov, err):
         r = base[i].copy()
         u = rng.random()
         if u < 0.05:
-            r = r[: rng.integers(1, 62)]                     # ends inside the head, wherever it parks
+            r = r[: rng.integers(1, 62)]                     # ends inside the head, before or after the hand-over
         elif u < 0.15:
             r = r[rng.integers(0, 45):]
         if rng.random() < 0.06:
-            r[rng.integers(0, len(r))] = 5                   # an N anywhere: among the first 32 bases, between the two parks, beyond
+            r[rng.integers(0, len(r))] = 5                   # an N anywhere: before the hand-over, among the bases k_ovl_pair would take, beyond
         reads.append(r)
     return reads + reads[:40]
 
 
-@pytest.mark.parametrize("mm,splits", [(50, (None, 32, 41, 50)), (60, (None, 33, 60)), (75, (None, 58)), (33, (None,))])
+@pytest.mark.parametrize("mm,splits", [(50, (None, 14, 20, 30)), (60, (None, 18)), (33, (None, 26))])
 def test_sorted_job_with_and_without_two_base_blocks(gpu, monkeypatch, mm, splits):
     rng = np.random.default_rng(5 + mm)
     reads = _ragged(rng, 14000, 100, 40, 0.004)
     bwt = gpu.build_bwt(reads)
     n_seq = 2 * len(reads)
     ids = rng.permutation(n_seq)[: n_seq - 77].astype(U64)
-    monkeypatch.delenv("FMD_PAIR", raising=False)                     # the default: no two-base blocks
+    monkeypatch.setenv("FMD_PAIR", "0")                               # never: not even when asked for through the ABI
     d0 = gpu.DevIndex.from_bwt(bwt)
     want = d0.overlap(ids, mm, 100, 8, check_left=False)              # id order, the one-pass walk
     plain = d0.overlap_sorted(ids, mm, 100, 8, 5000)
@@ -69,9 +69,9 @@ def test_sorted_job_with_and_without_two_base_blocks(gpu, monkeypatch, mm, split
     d1 = gpu.DevIndex.from_bwt(bwt)
     for sp in splits:
         if sp is None:
-            monkeypatch.delenv("FMD_HEAD_SPLIT", raising=False)
+            monkeypatch.delenv("FMD_PAIR_FROM", raising=False)
         else:
-            monkeypatch.setenv("FMD_HEAD_SPLIT", str(sp))
+            monkeypatch.setenv("FMD_PAIR_FROM", str(sp))
         for batch in (0, 4097):
             _same(want, d1.overlap_sorted(ids, mm, 100, 8, batch), 8)
     assert d1.build_pairs() and d1.check_pairs() == (0, 0)            # (the job built them itself)
@@ -80,8 +80,8 @@ def test_sorted_job_with_and_without_two_base_blocks(gpu, monkeypatch, mm, split
 
 
 def test_two_base_head_on_a_repeat_rich_deep_set(gpu, monkeypatch):
-    """80-fold reads of a genome with repeats: intervals stay wider than a block for many bases (single steps between pair steps, windows
-    that do not fit a block's 96 positions), identical reads, forks."""
+    """80-fold reads of a genome with repeats: intervals that are still wider than 63 at the hand-over (k_ovl_pair refuses the strand, the head walks it
+    again), identical reads, forks."""
     monkeypatch.setenv("FMD_PAIR", "1")
     rng = np.random.default_rng(3)
     unit = rng.integers(1, 5, 300).astype(np.uint8)
