@@ -109,7 +109,7 @@ def pmc_in_run(fmd_path, n_reads, steps=2, leg="overlap"):
         cal = 2 * (1 << 27) * 64 / (pr["k_probe"] * 1024.0)      # probe_once: warm-up + one launch, 2^27 lines of 64 bytes each
         src = "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over %d steps of the leg on the index this run built; KB units, FETCH_SIZE x %.4f (gather probe, 64-byte lines, same run)" % (steps, cal)
         OVL = ("k_ovl_head_adm", "k_ovl_walk", "k_ovl_pair", "k_ovl_strag_adm", "k_ovl_park_keys", "k_ovl_seq_out", "k_ovl_seq_redo", "k_ovl_classify", "k_ovl_nei_fast", "k_ovl_nei_lane", "k_ovl_nei_grp", "k_ovl_nei", "k_ovl_fix")
-        legs_of = {"overlap": (("overlap@%d" % n_reads, OVL), ("check_left@%d" % n_reads, ("k_link_rows", "k_link_edges", "k_ovl_cls"))), "ecfix": (("ecfix@%d" % n_reads, ("k_ecfix",)),)}
+        legs_of = {"overlap": (("overlap@%d" % n_reads, OVL), ("check_left@%d" % n_reads, ("k_link_rows", "k_link_edges", "k_link_row_of", "k_link_rows32", "k_link_edges32", "k_ovl_cls"))), "ecfix": (("ecfix@%d" % n_reads, ("k_ecfix",)),)}
         for key, names in legs_of[leg]:
             fk = sum(v for k, v in fetch.items() if k in names) / steps
             wk = sum(v for k, v in write.items() if k in names) / steps
@@ -306,7 +306,8 @@ def bench_bsearch(torch, api, workload, dev, local_rank, steps, warmup):
     workload.write_fmd_from_device_bwt(d_bwt, n_sym, fmd_path, local_rank)
     api.lib().fmd_dev_free(d_bwt)
     index = api.DevIndex.open(fmd_path, local_rank)      # the drop-in path: fermi's own file format
-    log("backward-search index: %d reads, build %.1fs, write+load %.1fs" % (n_reads, t1 - t0, time.time() - t1))
+    has_pairs = os.environ.get("FMD_PAIR") == "1" and index.build_pairs()     # (the two-base blocks, as the headline's index has them: main())
+    log("backward-search index: %d reads, build %.1fs, write+load %.1fs%s" % (n_reads, t1 - t0, time.time() - t1, ", two-base blocks" if has_pairs else ""))
     cnt = torch.zeros(n_reads, dtype=torch.int64, device=dev)
     beg = torch.zeros(n_reads, dtype=torch.int64, device=dev)
     end = torch.zeros(n_reads, dtype=torch.int64, device=dev)
@@ -323,14 +324,29 @@ def bench_bsearch(torch, api, workload, dev, local_rank, steps, warmup):
                "ms_per_step": wall / steps * 1e3, "hits": int((g_cnt > 0).sum()),
                "config": {"workload": "configs[1]: %dx%d bp synthetic reads (splitmix64 seed 20260928, 30x, e=0) against the FMD index of the same reads (%.2f GB in HBM)"
                                       % (n_reads, L, index.hbm_bytes / 1e9), "index_symbols": n_sym}}
+        if has_pairs:   # the same searches one base per request all the way (FMD_PAIR_USE=0), same box, same run
+            keep = cnt.clone()
+            os.environ["FMD_PAIR_USE"] = "0"
+            try:
+                step(); torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(5):
+                    step()
+                e1.record(stream)
+                torch.cuda.synchronize()
+                out["without_two_base_blocks"] = {"ms_per_step": e0.elapsed_time(e1) / 5, "same_counts": bool(torch.equal(cnt, keep))}
+            finally:
+                del os.environ["FMD_PAIR_USE"]
+            step(); torch.cuda.synchronize()
         ctr = Counter(api, fmd_path, local_rank)
         lines = ctr.run(step)
         ctr.close()
         qpr = 2.0 * (L - 1)   # closed form for hits (exact.c:13-19), checked against the instrumented oracle in tests
-        io = n_reads * (L + 24)
-        dev_bytes = None if lines is None else (lines[0] + lines[1]) * BLOCK_BYTES + io
-        out["roofline"] = roofline("k_bsearch", kern_ms, dev_bytes,
-                                   {"rank_blocks": lines and lines[0], "prefix_table_lines": lines and lines[1], "stream_bytes": io,
+        io = n_reads * (L + 24) + (2 * 24 * n_reads if has_pairs else 0)      # (+ the hand-over record written and read)
+        dev_bytes = None if lines is None else (lines[0] + lines[1]) * BLOCK_BYTES + ctr.pair_lines * 128 + io
+        out["roofline"] = roofline("k_bsearch" + (" + k_bsearch_pair" if has_pairs else ""), kern_ms, dev_bytes,
+                                   {"rank_blocks": lines and lines[0], "prefix_table_lines": lines and lines[1], "two_base_blocks_128B": ctr.pair_lines, "stream_bytes": io,
                                     "streams": "reads %d B + 3 x 8 B results per read" % L},
                                    qpr * BYTES_PER_RANK_QUERY * n_reads, "k_bsearch@%d" % n_reads,
                                    {"rank_queries_per_read": qpr})

@@ -4,7 +4,7 @@
 // Every kernel runs 64-thread workgroups (one wavefront, 16 KiB LDS); lane = one query/search.
 #include <stdlib.h>
 #include <string.h>
-#include "fmd_internal.h"
+#include "fmd_kernel_common.h"
 
 #define NONE64 (~0ull)
 
@@ -113,6 +113,12 @@ __global__ __launch_bounds__(64) void k_extend(FmdIndexView ix, size_t n, const 
 // exact.c:7-23.  Persistent waves; a lane that finishes its read (hit or early miss) pulls the
 // next read index from a global queue: ballot -> one atomicAdd per wave -> prefix popcount, so the
 // wave keeps 64 live SA intervals.
+// MODE 0: the whole search.  MODE 1 (an index with two-base blocks, fmd_pair.hip): a search is HANDED OVER to k_bsearch_pair as soon as its interval is
+// narrower than 65 and an even number of bases is left -- d_cnt = BS_HANDED, d_beg = k, d_end = bases left << 32 | size -- and goes on there two bases per
+// request.  MODE 2: only the reads k_bsearch_pair gave back (d_cnt = BS_AGAIN: a base that is not A/C/G/T among those left), the whole search.
+#define BS_HANDED (~0ull)
+#define BS_AGAIN (~1ull)
+template <int MODE>
 __global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const uint8_t *__restrict__ seqs,
                                                 const uint64_t *__restrict__ off, uint64_t *__restrict__ d_cnt,
                                                 uint64_t *__restrict__ d_beg, uint64_t *__restrict__ d_end,
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const
         {
             const size_t my = fmd_tickets_take(tk_, queue, !live && !exhausted, n);
             if (!live && !exhausted) {
-                if (my < n) {
+                if (my < n && !(MODE == 2 && d_cnt[my] != BS_AGAIN)) {
                     rid = my; sbase = off[my];
                     const int len = (int)(off[my + 1] - sbase);
                     if (len <= 0) { d_cnt[my] = 0; d_beg[my] = 0; d_end[my] = 0; }
@@ -184,15 +190,20 @@ __global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const
                         }
                         if (live && pos >= 0) BS_LOAD16(sbase + pos);
                     }
-                } else exhausted = true;
+                } else if (my >= n) exhausted = true;
             }
         }
-        if (__ballot(live) == 0) break;
+        if (__ballot(live) == 0) { if (__ballot(!exhausted) == 0) break; else continue; }   // (a wave whose lanes all drew reads that need nothing draws again)
 
         // ---- retire lanes that have consumed their whole read (len == 1 lands here directly)
         if (live && pos < 0) {
             const bool hit = k <= l;
             d_cnt[rid] = hit ? l - k + 1 : 0; d_beg[rid] = hit ? k : 0; d_end[rid] = hit ? l : 0;
+            live = false;
+        }
+        // ---- MODE 1: narrow, and an even number of bases left: the search goes on in k_bsearch_pair
+        if (MODE == 1 && live && pos >= 1 && (pos & 1) && l - k < 64) {
+            d_cnt[rid] = BS_HANDED; d_beg[rid] = k; d_end[rid] = (uint64_t)(uint32_t)(pos + 1) << 32 | (l - k + 1);
             live = false;
         }
         // ---- one backward step for every live lane: rank21(k-1, l, c)
@@ -222,6 +233,88 @@ __global__ __launch_bounds__(64) void k_bsearch(FmdIndexView ix, size_t n, const
         }
     }
 #undef BS_LOAD16
+}
+
+// fm_backward_search two bases per request (round 6): for a read handed over by k_bsearch<1>, the interval [k, k + size) and `left` bases (even) to go.
+// A step takes the read's next two bases (c1 nearest the interval, then c2): the rows of the interval with BWT[p] = c1 and BWT[LF(p)] = c2 are, in order,
+// the interval two bases on; its start is one pair count (fmd_wave.h: the block's 28 bits + ix.pair_tab, which holds K2[c1][c2] too), its size a
+// popcount.  A pair block starts every 32 positions and describes 96: an interval of up to 64 positions lies inside the block of its first position.
+// One 8 KiB landing slot, ~60 registers: twenty waves per CU.  A read with a base that is not A/C/G/T among those left is given back (BS_AGAIN).
+__global__ __launch_bounds__(64, 5) void k_bsearch_pair(FmdIndexView ix, size_t n, const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ off,
+                                                      uint64_t *__restrict__ d_cnt, uint64_t *__restrict__ d_beg, uint64_t *__restrict__ d_end, uint32_t *__restrict__ queue)
+{
+    __shared__ uint4 pair_lds[FMD_PAIR_SLOT_U4];
+    const int q_ = fmd_lane(), px = fmd_pair_xor(q_);
+    const uint4 *img = pair_lds + fmd_pair_base(q_);
+    const uint32_t *iw = (const uint32_t *)img;
+    size_t rid = 0;
+    uint64_t k = 0, sbase = 0, hk = 0, he = 0, hc = 0, ho = 0;
+    uint32_t size = 0;
+    int pos = -1, st = 0;                 // st: 0 idle, 1 the hand-over record on its way, 2 running
+    uint4 cq = make_uint4(0, 0, 0, 0), cp = cq;      // the 16 bases around pos, and the 16 below them
+    bool exhausted = false;
+#define BSP_LOAD16(dst_, at_, top_at_)                                                                           \
+    do {                                                                                                         \
+        const uint64_t b_ = (at_) & ~15ull, top_ = (top_at_) & ~3ull;                                            \
+        const uint32_t *w_ = (const uint32_t *)(seqs + b_);                                                      \
+        dst_.x = w_[0];                                                                                          \
+        dst_.y = b_ + 4 <= top_ ? w_[1] : 0u; dst_.z = b_ + 8 <= top_ ? w_[2] : 0u; dst_.w = b_ + 12 <= top_ ? w_[3] : 0u; \
+    } while (0)
+#define BSP_BASE(a_, win_) ({ const uint32_t wq_ = (uint32_t)((a_) >> 2) & 3u, cw_ = wq_ == 0 ? win_.x : wq_ == 1 ? win_.y : wq_ == 2 ? win_.z : win_.w; (int)((cw_ >> (8 * ((a_) & 3))) & 0xff); })
+    FmdTickets tk_;
+    fmd_tickets_init(tk_, queue, 64, n);
+    for (;;) {
+        const size_t my = fmd_tickets_take(tk_, queue, st == 0 && !exhausted, n);
+        if (st == 0 && !exhausted) {
+            if (my < n) { rid = my; hc = d_cnt[my]; hk = d_beg[my]; he = d_end[my]; ho = off[my]; st = 1; }
+            else exhausted = true;
+        }
+        if (__ballot(st != 0) == 0) break;
+        fmd_pair_fetch(ix, pair_lds, (uint32_t)(k >> 5), st == 2);
+        fmd_fetch_wait();
+        if (st == 1) {
+            st = 0;
+            if (hc == BS_HANDED) {
+                k = hk; size = (uint32_t)he; pos = (int)(he >> 32) - 1; sbase = ho;
+                const uint64_t a = sbase + (uint64_t)pos;
+                BSP_LOAD16(cq, a, a);
+                if ((a & ~15ull) > (sbase & ~15ull)) BSP_LOAD16(cp, (a & ~15ull) - 16, (a & ~15ull) - 1); // (never below the read's own first block)
+                st = 2;
+            }
+            continue;
+        }
+        if (st != 2) continue;
+        const uint64_t a1 = sbase + (uint64_t)pos, a2 = a1 - 1;
+        const int c1 = BSP_BASE(a1, cq);
+        const int c2 = (a2 & ~15ull) == (a1 & ~15ull) ? BSP_BASE(a2, cq) : BSP_BASE(a2, cp);
+        if (c1 < 1 || c1 > 4 || c2 < 1 || c2 > 4) { d_cnt[rid] = BS_AGAIN; st = 0; continue; }
+        const uint32_t offp = (uint32_t)k & 31u;
+        const uint4 A0 = img[0 ^ px], A1 = img[1 ^ px], A2 = img[2 ^ px], B0 = img[3 ^ px], B1 = img[4 ^ px], B2 = img[5 ^ px];
+        const uint32_t e0x = (c1 & 1) ? 0u : ~0u, e0y = (c1 & 2) ? 0u : ~0u, e0z = (c1 & 4) ? 0u : ~0u;
+        const uint32_t e1x = (c2 & 1) ? 0u : ~0u, e1y = (c2 & 2) ? 0u : ~0u, e1z = (c2 & 4) ? 0u : ~0u;
+        const uint32_t pm0 = (A0.x ^ e0x) & (A0.y ^ e0y) & (A0.z ^ e0z) & (A0.w ^ e1x) & (B0.x ^ e1y) & (B0.y ^ e1z);
+        const uint32_t pm1 = (A1.x ^ e0x) & (A1.y ^ e0y) & (A1.z ^ e0z) & (A1.w ^ e1x) & (B1.x ^ e1y) & (B1.y ^ e1z);
+        const uint32_t pm2 = (A2.x ^ e0x) & (A2.y ^ e0y) & (A2.z ^ e0z) & (A2.w ^ e1x) & (B2.x ^ e1y) & (B2.y ^ e1z);
+        const uint64_t Mp = win64(pm0, pm1, pm2, offp) & bits_below((int)size);
+        const uint32_t nsz = (uint32_t)__popcll(Mp);
+        if (nsz == 0) { d_cnt[rid] = 0; d_beg[rid] = 0; d_end[rid] = 0; st = 0; continue; }      // a miss (exact.c:17-18: the outputs of a miss are not defined; zeros, as k_bsearch)
+        const int pr = 4 * (c1 - 1) + (c2 - 1), bp = 28 * pr, tw = bp >> 5, tw1 = tw < 13 ? tw + 1 : 13;
+#define WP_CW(t) iw[(((t) < 6 ? 3 + ((t) >> 1) : 6 + (((t) - 6) >> 2)) ^ px) * 4 + ((t) < 6 ? 2 + ((t) & 1) : (((t) - 6) & 3))]
+        const uint32_t cwl = WP_CW(tw), cwh = WP_CW(tw1);
+#undef WP_CW
+        const uint32_t rel = __builtin_amdgcn_alignbit(cwh, cwl, (uint32_t)bp & 31u) & 0x0fffffffu;
+        k = ix.pair_tab[(k >> (5 + FMD_PAIR_SB_SHIFT)) * 16 + (uint64_t)pr] + rel + (uint32_t)__builtin_popcount(pm0 & fmd_mask32((int)offp));
+        size = nsz;
+        pos -= 2;
+        if (pos < 0) { d_cnt[rid] = size; d_beg[rid] = k; d_end[rid] = k + size - 1; st = 0; continue; }
+        if (((sbase + (uint64_t)pos) & ~15ull) != (a1 & ~15ull)) {   // into the block below: it is here already; the one below that is asked for now
+            cq = cp;
+            const uint64_t nb_ = (sbase + (uint64_t)pos) & ~15ull;
+            if (nb_ > (sbase & ~15ull)) BSP_LOAD16(cp, nb_ - 16, nb_ - 1);
+        }
+    }
+#undef BSP_LOAD16
+#undef BSP_BASE
 }
 
 // ------------------------------------------------------------------------------ forward reach
@@ -390,7 +483,23 @@ extern "C" int fmd_bsearch_dev(fmd_dev_t *h, void *stream, size_t n, const uint8
     if (n >= 0xffffff00ull) return FMD_E_ARG; // 32-bit queue head
     FMD_HIP_TRY(hipSetDevice(h->device));
     uint32_t *q = fmd_next_queue(h, S(stream));
-    k_bsearch<<<fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16), 64, 0, S(stream)>>>(fmd_view(h), n, d_seqs, d_off, d_cnt, d_beg, d_end, q);
+    (void)fmd_pairs_ensure(h, 0);          // (built here only where FMD_PAIR asks for it: fmd_pair.hip)
+    const FmdIndexView ix = fmd_view(h);
+    bool pairs = ix.pair != nullptr && ix.pair_tab != nullptr;
+    { const char *e = getenv("FMD_PAIR_USE"); if (e && atoi(e) == 0) pairs = false; }   // A/B switch on a handle that has the two-base blocks
+    const int grid = fmd_grid_for_lds(h, n, FMD_COMPACT_LDS_U4 * 16);
+    if (pairs) {
+        // the search one base at a time until the interval is narrow, then two bases per request (k_bsearch_pair), then -- one base at a time, whole -- the reads
+        // that kernel gave back (an N among the bases left).  All three on the stream, no host in between: the third finds nothing to do on real reads.
+        k_bsearch<1><<<grid, 64, 0, S(stream)>>>(ix, n, d_seqs, d_off, d_cnt, d_beg, d_end, q);
+        uint32_t *q2 = fmd_next_queue(h, S(stream));
+        int grid2 = h->n_cu * 20;
+        if ((size_t)grid2 > (n + 63) / 64) grid2 = (int)((n + 63) / 64);
+        k_bsearch_pair<<<grid2, 64, 0, S(stream)>>>(ix, n, d_seqs, d_off, d_cnt, d_beg, d_end, q2);
+        uint32_t *q3 = fmd_next_queue(h, S(stream));
+        k_bsearch<2><<<grid, 64, 0, S(stream)>>>(ix, n, d_seqs, d_off, d_cnt, d_beg, d_end, q3);
+    } else
+    k_bsearch<0><<<grid, 64, 0, S(stream)>>>(ix, n, d_seqs, d_off, d_cnt, d_beg, d_end, q);
     FMD_CHECK_LAUNCH();
     return FMD_OK;
 }

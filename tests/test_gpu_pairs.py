@@ -102,3 +102,41 @@ def test_two_base_head_on_a_repeat_rich_deep_set(gpu, monkeypatch):
         _same(d.overlap(ids, mm, L, 16, check_left=False), d.overlap_sorted(ids, mm, L, 16, 6000), 16)
     assert d.build_pairs() and d.check_pairs() == (0, 0)
     d.close()
+
+
+def test_backward_search_two_bases_per_request(gpu, monkeypatch):
+    """fm_backward_search (exact.c:7-23) with the two-base blocks: k_bsearch<1> hands a search over as soon as its interval is narrower than 65 and an even
+    number of bases is left, k_bsearch_pair takes two bases per request from there, k_bsearch<2> redoes the reads with an N among the bases left.  Same
+    counts and intervals as without the blocks: hits, early and late misses (reads with errors against an error-free index), ragged lengths from 1 base
+    on (odd and even), Ns anywhere, duplicates."""
+    rng = np.random.default_rng(17)
+    N = 20000
+    clean = synth.reads(synth.DEFAULT_SEED + 5, N, 100, 30, 0.0)
+    dirty = synth.reads(synth.DEFAULT_SEED + 5, N, 100, 30, 0.02)
+    q = []
+    for i in range(N):
+        r = (clean[i] if i % 3 else dirty[i]).copy()
+        u = rng.random()
+        if u < 0.2:
+            r = r[rng.integers(0, 99):]
+        elif u < 0.3:
+            r = r[: rng.integers(1, 100)]
+        if rng.random() < 0.05:
+            r[rng.integers(0, len(r))] = 5
+        q.append(r)
+    bwt = gpu.build_bwt(list(clean))
+    monkeypatch.setenv("FMD_PAIR", "0")
+    d0 = gpu.DevIndex.from_bwt(bwt)
+    want = d0.backward_search(q)
+    d0.close()
+    monkeypatch.setenv("FMD_PAIR", "1")
+    d1 = gpu.DevIndex.from_bwt(bwt)
+    assert d1.build_pairs()
+    got = d1.backward_search(q)
+    hit = want[0] > 0
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1][hit], want[1][hit]) and np.array_equal(got[2][hit], want[2][hit])
+    assert hit.sum() > N // 2 and (~hit).sum() > N // 10
+    monkeypatch.setenv("FMD_PAIR_USE", "0")
+    again = d1.backward_search(q)
+    assert np.array_equal(again[0], want[0])
+    d1.close()

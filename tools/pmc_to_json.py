@@ -11,11 +11,11 @@ sys.path.insert(0, ROOT)
 import bench
 
 d, steps, n_reads, n_bs, label = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-OVL = ("k_ovl_head_adm", "k_ovl_walk", "k_ovl_park_keys", "k_ovl_seq_out", "k_ovl_seq_redo", "k_ovl_classify", "k_ovl_nei_fast", "k_ovl_nei_lane", "k_ovl_nei_grp", "k_ovl_nei", "k_ovl_fix")
+OVL = ("k_ovl_head_adm", "k_ovl_walk", "k_ovl_pair", "k_ovl_strag_adm", "k_ovl_park_keys", "k_ovl_seq_out", "k_ovl_seq_redo", "k_ovl_classify", "k_ovl_nei_fast", "k_ovl_nei_lane", "k_ovl_nei_grp", "k_ovl_nei", "k_ovl_fix")
 # (the two 32-bit radix sorts of the sorted job -- ~10 GB of streaming per 10^8 strands -- run in rocprim kernels whose names they
 # share with the sorts of the index build in the same profile: not in these sums)
 LEGS = {"overlap@%d" % n_reads: OVL,
-        "check_left@%d" % n_reads: ("k_link_rows", "k_link_edges", "k_ovl_cls"), "k_bsearch@%d" % n_bs: ("k_bsearch",), "smem@%d" % n_reads: ("k_smem",),
+        "check_left@%d" % n_reads: ("k_link_rows", "k_link_edges", "k_link_row_of", "k_link_rows32", "k_link_edges32", "k_ovl_cls"), "k_bsearch@%d" % n_bs: ("k_bsearch", "k_bsearch_pair"), "smem@%d" % n_reads: ("k_smem",),
         "kmer@%d" % n_reads: ("k_kmer_level", "k_kmer_emit")}
 
 
