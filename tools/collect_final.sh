@@ -2,7 +2,7 @@
 # After tools/final_measure.sh <tag> ran on the GPU box and gpurun merged its output: copy what is to be judged from gpurun_out/ (scratch)
 # into profiles/<round>_final/ (tracked) -- the bench line, the traced run's kernel statistics, the test log, the PMC passes summed per
 # kernel -- and profiles/pmc_traffic.json.  Usage: tools/collect_final.sh <tag> [dest=profiles/r3_final]
-TAG=$1; DST=${2:-profiles/r5_final}
+TAG=$1; DST=${2:-profiles/r6_final}
 [ -d gpurun_out/$TAG ] || { echo "no gpurun_out/$TAG"; exit 1; }
 rm -rf $DST; mkdir -p $DST/pmc
 cp gpurun_out/$TAG/* $DST/

@@ -9,7 +9,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path\|amdgpu.ids" | tail -6 > $OUT/pytest.log; cat $OUT/pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1; tail -1 $OUT/smoke.txt
-tools/pmc_collect.sh $TAG 2 > $OUT/pmc_collect.log 2>&1; tail -3 $OUT/pmc_collect.log
+FMD_PAIR=1 tools/pmc_collect.sh $TAG 2 > $OUT/pmc_collect.log 2>&1; tail -3 $OUT/pmc_collect.log   # (FMD_PAIR=1: the legs on indexes with two-base blocks, as bench.py runs them)
 timeout 1800 python bench.py --steps $K --warmup $W > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 FMD_BENCH_PMC=0 timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/trace_$TAG -o bench -- python bench.py --steps 5 --warmup 2 > $OUT/bench_traced.json 2> $OUT/bench_traced.err
 cp $(find /tmp/trace_$TAG -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
