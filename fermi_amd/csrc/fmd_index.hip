@@ -230,10 +230,13 @@ __global__ void k_ptab_level(FmdIndexView ix, int d, const uint4 *__restrict__ p
 
 static int build_ptab(fmd_dev *h)
 {
-    // as deep as keeps the table well below the index: 4^d <= n/8, at most 12 (268 MB), at least 2
+    // as deep as keeps the table well below the index: 4^d <= n/8, at most 14 (4.3 GB; 12 = 268 MB until round 6), at least 2 -- and no deeper than the
+    // tail table can say: its 8-byte entry holds 2 d bits of bases beside the row (FmdIndexView::tail), so the index must have fewer than 2^(64 - 2 d) symbols.
+    // Every base the tables take is a base the head does not walk, and the first ones are the expensive ones -- the interval is still wider than a block,
+    // up to three lines and two wave steps a base: pass 1 of the sorted job 36 -> 27 ms per 10^8 strands from depth 12 to 14 (profiles/r6_ptab).
     int d = 2;
-    while (d < 12 && (1ull << (2 * (d + 1))) <= h->mcnt[0] / 8) ++d;
-    if (getenv("FMD_PTAB_DEPTH")) { d = atoi(getenv("FMD_PTAB_DEPTH")); if (d < 1) return FMD_OK; if (d > 13) d = 13; }
+    while (d < 14 && (1ull << (2 * (d + 1))) <= h->mcnt[0] / 8 && h->mcnt[0] < (1ull << (64 - 2 * (d + 1))) - 1) ++d;
+    if (getenv("FMD_PTAB_DEPTH")) { d = atoi(getenv("FMD_PTAB_DEPTH")); if (d < 1) return FMD_OK; if (d > 14) d = 14; while (d > 2 && (1ull << (2 * d)) > h->mcnt[0]) --d; }
     uint4 *a = nullptr, *b = nullptr;
     const uint64_t n = 1ull << (2 * d);
     FMD_HIP_TRY(hipMalloc((void **)&a, n * 16));
@@ -272,13 +275,13 @@ __global__ void k_tail_table(FmdIndexView ix, int d, unsigned long long *__restr
             k = ix.cnt[c] + r[c] - 1;
             tfw |= (uint64_t)(c - 1) << (2 * j);
         }
-        tail[id] = ok ? (k | tfw << 40) : FMD_TAIL_NONE;
+        tail[id] = ok ? (k | tfw << (64 - 2 * d)) : FMD_TAIL_NONE;      // (FmdIndexView::tail: the row in the low 64 - 2 d bits)
     }
 }
 static int build_tail(fmd_dev *h)
 {
     const char *e = getenv("FMD_TAIL_TABLE");
-    if ((e && atoi(e) == 0) || !h->ptab || h->ptab_d < 2 || h->ptab_d > 12 || h->mcnt[1] == 0) return FMD_OK;   // 24 bits of bases beside a 40-bit row
+    if ((e && atoi(e) == 0) || !h->ptab || h->ptab_d < 2 || h->ptab_d > 14 || h->mcnt[0] >= (1ull << (64 - 2 * h->ptab_d)) - 1 || h->mcnt[1] == 0) return FMD_OK;   // 2 d bits of bases beside a row of 64 - 2 d bits
     unsigned long long *t = nullptr;
     if (hipMalloc((void **)&t, h->mcnt[1] * 8) != hipSuccess) { (void)hipGetLastError(); return FMD_OK; }   // no room: the walk takes its steps itself
     k_tail_table<<<nblk(h->mcnt[1], 256), 256>>>(fmd_view(h), h->ptab_d, t);

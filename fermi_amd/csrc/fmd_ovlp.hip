@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
                 // the first ptab_d LF steps were taken when the index was loaded (FmdIndexView::tail): pick the walk up behind them
                 const unsigned long long te = (tab_ok && ix.tail && k < ix.n_seq) ? ix.tail[k] : ~0ull;
                 if (te != ~0ull) {
-                    tfw = (uint32_t)(te >> 40); k = te & 0xffffffffffull;
+                    tfw = (uint32_t)(te >> (64 - 2 * ix.ptab_d)); k = te & ((1ull << (64 - 2 * ix.ptab_d)) - 1);
                     for (int jb = 0; jb < ix.ptab_d; ++jb) {   // the bases into the stash, as the steps would have put them
                         WALK_PUT_BASE(((tfw >> (2 * jb)) & 3u) + 1u);
                     }
@@ -1492,8 +1492,8 @@ __global__ void k_ovl_head_adm(FmdIndexView ix, size_t n, const uint64_t *__rest
         const unsigned long long te = (use_tail && id < ix.n_seq) ? ix.tail[id] : ~0ull;
         uint4 a, b;
         if (te != ~0ull) {
-            const uint32_t tfw = (uint32_t)(te >> 40);
-            const uint64_t k = te & 0xffffffffffull;
+            const uint32_t tfw = (uint32_t)(te >> (64 - 2 * ix.ptab_d));
+            const uint64_t k = te & ((1ull << (64 - 2 * ix.ptab_d)) - 1);
             uint32_t r = __brev(~tfw) >> (32 - 2 * ix.ptab_d);   // reverse complement of the ptab index: the 2-bit groups in reverse order, complemented
             const uint32_t trv = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
             const uint4 ef = ix.ptab[tfw], er = ix.ptab[trv];

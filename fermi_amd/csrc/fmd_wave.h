@@ -65,7 +65,7 @@ struct FmdIndexView {            // passed by value as a kernel argument (lives 
     const uint4 *ptab;
     int ptab_d;
     // Where the LF-walk of every sequence stands after its last ptab_d bases (tail[id], id = the sequence's sentinel row):
-    // row | the bases as a ptab index << 40; ~0 = shorter than that, or not A/C/G/T.  fm_retrieve (exact.c:59) begins with
+    // row | the bases as a ptab index << (64 - 2 ptab_d) (40 at depth 12); ~0 = shorter than that, or not A/C/G/T.  fm_retrieve (exact.c:59) begins with
     // exactly these ptab_d dependent steps -- one DRAM line each, a ninth of all lines of overlap discovery -- for every
     // sequence, every time; they are taken once, when the index is loaded (8 bytes per sequence; nullptr = not built).
     const unsigned long long *tail;
