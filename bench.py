@@ -207,7 +207,21 @@ class Counter:
         buf = (C.c_uint64 * 3)()
         cnt = C.c_int(0)
         self.L.fmd_dev_line_count3(self.h, buf, 1, C.byref(cnt))
-        step(self.L, self.h)     # (with FMD_PAIR=1 in the environment the handle builds its two-base blocks inside this step, as the timed handle has them)
+        # The timed handle has its two-base blocks (FMD_PAIR=1); this one builds its own inside the step and must not be turned down by the "only where the
+        # job still finds its room" rule of fmd_pairs_ensure, or the step counted is not the step timed: torch's cached blocks back to the device, and FMD_PAIR=2.
+        was = os.environ.get("FMD_PAIR")
+        if was == "1":
+            try:
+                import torch
+                torch.cuda.empty_cache()
+            except Exception:
+                pass
+            os.environ["FMD_PAIR"] = "2"
+        try:
+            step(self.L, self.h)
+        finally:
+            if was == "1":
+                os.environ["FMD_PAIR"] = "1"
         if self.L.fmd_dev_line_count3(self.h, buf, 1, C.byref(cnt)) != 0 or not cnt.value:
             return None
         self.pair_lines = int(buf[2])      # 128-byte two-base blocks requested (k_ovl_pair)

@@ -236,7 +236,7 @@ static int build_ptab(fmd_dev *h)
     // up to three lines and two wave steps a base: pass 1 of the sorted job 36 -> 27 ms per 10^8 strands from depth 12 to 14 (profiles/r6_ptab).
     int d = 2;
     while (d < 14 && (1ull << (2 * (d + 1))) <= h->mcnt[0] / 8 && h->mcnt[0] < (1ull << (64 - 2 * (d + 1))) - 1) ++d;
-    if (getenv("FMD_PTAB_DEPTH")) { d = atoi(getenv("FMD_PTAB_DEPTH")); if (d < 1) return FMD_OK; if (d > 14) d = 14; while (d > 2 && (1ull << (2 * d)) > h->mcnt[0]) --d; }
+    if (getenv("FMD_PTAB_DEPTH")) { d = atoi(getenv("FMD_PTAB_DEPTH")); if (d < 1) return FMD_OK; if (d > 15) d = 15; while (d > 2 && ((1ull << (2 * d)) > h->mcnt[0] || h->mcnt[0] >= (1ull << (64 - 2 * d)) - 1)) --d; }   // (15: 17 GB, by request only)
     uint4 *a = nullptr, *b = nullptr;
     const uint64_t n = 1ull << (2 * d);
     FMD_HIP_TRY(hipMalloc((void **)&a, n * 16));
@@ -281,7 +281,7 @@ __global__ void k_tail_table(FmdIndexView ix, int d, unsigned long long *__restr
 static int build_tail(fmd_dev *h)
 {
     const char *e = getenv("FMD_TAIL_TABLE");
-    if ((e && atoi(e) == 0) || !h->ptab || h->ptab_d < 2 || h->ptab_d > 14 || h->mcnt[0] >= (1ull << (64 - 2 * h->ptab_d)) - 1 || h->mcnt[1] == 0) return FMD_OK;   // 2 d bits of bases beside a row of 64 - 2 d bits
+    if ((e && atoi(e) == 0) || !h->ptab || h->ptab_d < 2 || h->ptab_d > 15 || h->mcnt[0] >= (1ull << (64 - 2 * h->ptab_d)) - 1 || h->mcnt[1] == 0) return FMD_OK;   // 2 d bits of bases beside a row of 64 - 2 d bits
     unsigned long long *t = nullptr;
     if (hipMalloc((void **)&t, h->mcnt[1] * 8) != hipSuccess) { (void)hipGetLastError(); return FMD_OK; }   // no room: the walk takes its steps itself
     k_tail_table<<<nblk(h->mcnt[1], 256), 256>>>(fmd_view(h), h->ptab_d, t);

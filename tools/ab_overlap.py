@@ -96,7 +96,7 @@ for s in settings:
         job.rec.zero_(); job.nei.zero_(); job.seq.zero_()
         job.compute(); torch.cuda.synchronize()
         explain()
-    print("%-60s %8.1f ms per pass = %.3e strands/s   %s" % (s, ms, job.n / ms * 1e3, "same bytes" if dg == first else "DIFFERENT (%s vs %s)" % (dg, first)), flush=True)
+    print("%-60s %8.1f ms per pass = %.3e strands/s   %s" % (s, ms, job.n / ms * 1e3, ("same bytes" if dg == first else "DIFFERENT (%s vs %s)" % (dg, first)) + ("  digest " + dg if os.environ.get("AB_DIGEST") else "")), flush=True)
     for k, v in saved.items():
         if v is None:
             os.environ.pop(k, None)
