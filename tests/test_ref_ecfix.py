@@ -10,6 +10,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 import bench  # noqa: E402
+from benchlegs import ecfix as ecfix_leg  # noqa: E402
 import orcbind  # noqa: E402
 from test_oracle_golden import _fastq_records  # noqa: E402
 
@@ -35,7 +36,7 @@ def _kept_records(text):
 def test_refec_fix_prints_fermi_correct(gold, oracle_lib, threads, monkeypatch):
     if bench.ref_ec_lib() is None:
         pytest.skip("oracle/_ref/libref_ec.so not built here")
-    monkeypatch.setattr(bench, "usable_cpus", lambda: threads)
+    monkeypatch.setattr(ecfix_leg, "usable_cpus", lambda: threads)
     ids, nt6, q = _fixed_len(gold)
     (txt, q2, info), _, _, lpr, kind, cores = bench.cpu_ecfix(17, 2, 5, _sorted_trip(gold.npz("tiny_solid.npz")), nt6, q)
     assert kind == "reference" and cores == threads and lpr > 20
