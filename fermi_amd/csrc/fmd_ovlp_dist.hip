@@ -303,6 +303,7 @@ struct Arena {  // variable parts at the root: large chunks, allocated when firs
     void drop() { for (void *p : chunks) { if (host) hipHostFree(p); else hipFree(p); } chunks.clear(); reset(); }
 };
 struct Stage { DBuf pid, prec, off, var, vaddr; };   // one piece of one peer on its way through HBM (host table), or this rank's piece on its way out
+struct HStage { HBuf pid, prec, off, var; uint64_t rows = 0; };   // root with a row sink: where such a piece lands in pinned host memory, until the sink has had it
 }   // namespace
 
 struct fmd_ovlp_dist {
@@ -315,6 +316,8 @@ struct fmd_ovlp_dist {
     HBuf cnt_host, sizes_host, split_host;
     Stage out[2];                               // this rank's piece on its way out (non-root: set 0; root with a host table: set p & 1)
     std::vector<Stage> in[2];                   // root, host mode: staging per peer, two sets
+    int sink = 0;                               // root, cfg.host_table == 2: no table -- every piece goes to cfg.row_sink from ...
+    std::vector<HStage> hin[2];                 // ... these, set p & 1 (rows != 0: the sink has not had them yet)
     // the table at the root
     DBuf t_prec, t_ids, t_vaddr, t_row_of, t_off;   // (t_off: per peer (piece_max + 1) offsets of the piece being placed)
     HBuf th_prec, th_ids, th_vaddr, th_row_of;
@@ -345,6 +348,7 @@ extern "C" void fmd_ovlp_dist_free(fmd_ovlp_dist_t *d)
                   &d->sizes_dev, &d->t_prec, &d->t_ids, &d->t_vaddr, &d->t_row_of, &d->t_off, &d->out[0].pid, &d->out[0].prec, &d->out[0].off, &d->out[0].var, &d->out[0].vaddr, &d->out[1].pid, &d->out[1].prec, &d->out[1].off, &d->out[1].var, &d->out[1].vaddr};
     for (DBuf *b : bs) b->drop();
     for (int k = 0; k < 2; ++k) for (Stage &s : d->in[k]) { s.pid.drop(); s.prec.drop(); s.off.drop(); s.var.drop(); s.vaddr.drop(); }
+    for (int k = 0; k < 2; ++k) for (HStage &s : d->hin[k]) { s.pid.drop(); s.prec.drop(); s.off.drop(); s.var.drop(); }
     HBuf *hs[] = {&d->cnt_host, &d->sizes_host, &d->split_host, &d->th_prec, &d->th_ids, &d->th_vaddr, &d->th_row_of};
     for (HBuf *b : hs) b->drop();
     d->var.drop();
@@ -361,6 +365,7 @@ extern "C" int fmd_ovlp_dist_new(fmd_dev_t *h, fmd_comm_t *comm, const fmd_ovlp_
 {
     if (!h || !comm || !cfg || !out || !comm->allgather || !comm->exchange || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world) return FMD_E_ARG;
     if (cfg->n_ids == 0 || cfg->n_ids >= 0xffffff00ull || cfg->max_len == 0 || cfg->max_nei == 0 || cfg->min_match < 0 || cfg->root < 0 || cfg->root >= comm->world) return FMD_E_ARG;
+    if (cfg->host_table == 2 && comm->rank == cfg->root && !cfg->row_sink) return FMD_E_ARG;   // (a root that keeps no table must say where the rows go)
     *out = nullptr;
     FMD_HIP_TRY(hipSetDevice(h->device));
     fmd_ovlp_dist *d = new fmd_ovlp_dist();
@@ -427,13 +432,23 @@ extern "C" int fmd_ovlp_dist_new(fmd_dev_t *h, fmd_comm_t *comm, const fmd_ovlp_
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
         d->on_host = cfg->host_table > 0 || (cfg->host_table < 0 && table_dev + ((size_t)6 << 30) > free_b) ? 1 : 0;
+        d->sink = cfg->host_table == 2;
         NEED(d->t_row_of, n * 4);
         if (!d->on_host) { NEED(d->t_prec, n * sizeof(fmd_ovlp_rec_t)); NEED(d->t_ids, n * 4); NEED(d->t_vaddr, n * 8); NEED(d->t_off, (size_t)d->world * (d->piece_max + 1) * 8); }
         else {
-            NEEDH(d->th_prec, n * sizeof(fmd_ovlp_rec_t));
-            NEEDH(d->th_ids, n * 4);
-            NEEDH(d->th_vaddr, n * 8);
-            NEEDH(d->th_row_of, n * 4);
+            if (!d->sink) {
+                NEEDH(d->th_prec, n * sizeof(fmd_ovlp_rec_t));
+                NEEDH(d->th_ids, n * 4);
+                NEEDH(d->th_vaddr, n * 8);
+                NEEDH(d->th_row_of, n * 4);
+            } else   // no table: two sets of pinned landing buffers, a piece of every peer each; the sink folds set k while set k ^ 1 fills
+                for (int k = 0; k < 2 && rc == FMD_OK; ++k) {
+                    d->hin[k].resize((size_t)d->world);
+                    for (int q = 0; q < d->world && rc == FMD_OK; ++q) {
+                        HStage &s = d->hin[k][(size_t)q];
+                        NEEDH(s.pid, d->piece_max * 4); NEEDH(s.prec, d->piece_max * sizeof(fmd_ovlp_rec_t)); NEEDH(s.off, (d->piece_max + 1) * 8); NEEDH(s.var, d->var_cap_piece);
+                    }
+                }
             for (int k = 0; k < 2 && rc == FMD_OK; ++k) {
                 d->in[k].resize((size_t)d->world);
                 for (int q = 0; q < d->world && rc == FMD_OK; ++q) {
@@ -444,7 +459,7 @@ extern "C" int fmd_ovlp_dist_new(fmd_dev_t *h, fmd_comm_t *comm, const fmd_ovlp_
         }
         d->var.host = d->on_host != 0;
         d->var.chunk_bytes = d->var_cap_piece > ((size_t)256 << 20) ? up256(d->var_cap_piece) : ((size_t)256 << 20);
-        if (dry && rc == FMD_OK) {   // the arena as a whole step leaves it: the usual variable part (neighbours + bases, as table_dev above) of every row
+        if (dry && rc == FMD_OK && !d->sink) {   // the arena as a whole step leaves it: the usual variable part (neighbours + bases, as table_dev above) of every row
             const size_t want = (size_t)n * (size_t)(cfg->max_nei * 8 + 72);
             size_t got = 0;
             while (got < want) {
@@ -462,7 +477,7 @@ extern "C" int fmd_ovlp_dist_new(fmd_dev_t *h, fmd_comm_t *comm, const fmd_ovlp_
 #undef NEED
 #undef NEEDH
     if (dry) fprintf(stderr, "[M::fmd_ovlp_dist_new] rank %d/%d of a job over %llu ids (%s, %d pieces of at most %zu rows, table %s): %.2f GB of HBM, %.2f GB of pinned host memory: %s\n", d->rank, d->world,
-                     (unsigned long long)cfg->n_ids, d->cfg.key_shard ? "key shard" : "id shard", d->pieces, d->piece_max, root ? (d->on_host ? "in pinned host memory" : "in HBM") : "elsewhere",
+                     (unsigned long long)cfg->n_ids, d->cfg.key_shard ? "key shard" : "id shard", d->pieces, d->piece_max, root ? (d->sink ? "none: rows go to the sink" : d->on_host ? "in pinned host memory" : "in HBM") : "elsewhere",
                      dry_dev / 1e9, dry_host / 1e9, rc == FMD_OK ? "every allocation succeeded" : "OUT OF MEMORY");
     if (rc == FMD_OK) {
         int lo = 0, hi = 0;
@@ -633,7 +648,26 @@ extern "C" int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream_, fmd_ovlp_di
     const bool is_root = me == root;
     fmd_ovlp_dist_stats_t S;
     memset(&S, 0, sizeof(S));
-    S.pieces = P; S.on_host = d->on_host; S.two_pass = d->two_pass;
+    S.pieces = P; S.on_host = d->sink ? 2 : d->on_host; S.two_pass = d->two_pass;
+    // root with a row sink: the piece that sits in landing set k goes to the sink, peer by peer, on this thread (the sink has its own threads) -- while the
+    // GPUs compute and pack the next piece.  A sink that fails is a failure of this rank: it travels with the next status word like any other.
+    for (int k = 0; k < 2; ++k) for (HStage &hs : d->hin[k]) hs.rows = 0;
+    auto run_sink = [&](int k) -> int {
+        if (!d->sink) return FMD_OK;
+        bool any = false;
+        for (const HStage &hs : d->hin[k]) any = any || hs.rows != 0;
+        if (!any) return FMD_OK;
+        if (hipEventSynchronize(d->drained[k]) != hipSuccess) { fmd_set_hip_error(hipGetLastError(), "overlap job on N GPUs: a piece on its way to the sink"); return FMD_E_HIP; }
+        int src = FMD_OK;
+        for (HStage &hs : d->hin[k]) {
+            if (hs.rows && src == FMD_OK && d->cfg.row_sink(d->cfg.sink_ctx, hs.rows, (const uint32_t *)hs.pid.p, (const fmd_ovlp_rec_t *)hs.prec.p, (const uint64_t *)hs.off.p, (const uint8_t *)hs.var.p, d->cfg.max_nei) != 0) {
+                fprintf(stderr, "[E::fmd_ovlp_dist_step] rank %d: the row sink turned %llu rows down\n", d->rank, (unsigned long long)hs.rows);
+                src = FMD_E_IO;
+            }
+            hs.rows = 0;
+        }
+        return src;
+    };
     const double t_begin = now_s();
     int rc = FMD_OK;
     int lerr = FMD_OK;      // a failure of this rank alone: carried, not returned (see dist_verdict above)
@@ -722,12 +756,13 @@ extern "C" int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream_, fmd_ovlp_di
         if (lerr == FMD_OK)
             lerr = fmd_ovlp_pack_rows_dev(d->h, sm, (size_t)np, (const uint32_t *)d->iota.p + b, row_ids, (uint64_t)me, (uint64_t)W, (const fmd_ovlp_rec_t *)d->rec.p, (const fmd_intv_t *)d->nei.p,
                                           cfg.max_nei, (const uint8_t *)d->seq.p, d->stride, o_pid, o_prec, o_off, o_var, o_cap, d->pack_work.p, d->pack_work.bytes);
+        if (is_root && d->sink && p >= 1 && lerr == FMD_OK) lerr = run_sink(k ^ 1);   // piece p - 1, while piece p is being packed
         if (is_root && lerr == FMD_OK) {
             // the root's arena must hold whatever the peers send: room for their worst case is made NOW, while a failure can still travel with the sizes
             uint64_t np_max = 0;
             for (int q = 0; q < W; ++q) { const uint64_t nq = piece_begin(rows_of_rank[(size_t)q], p + 1, P) - piece_begin(rows_of_rank[(size_t)q], p, P); if (q != me || d->on_host) np_max = nq > np_max ? nq : np_max; }
             const size_t worst = fmd_ovlp_pack_max_bytes((size_t)np_max, cfg.max_nei, d->stride);
-            if (dist_inject(d, "arena", p) != FMD_OK || !d->var.ensure((size_t)(d->on_host ? W : W - 1), worst ? worst : 256)) lerr = FMD_E_NOMEM;
+            if (dist_inject(d, "arena", p) != FMD_OK || (!d->sink && !d->var.ensure((size_t)(d->on_host ? W : W - 1), worst ? worst : 256))) lerr = FMD_E_NOMEM;   // (a sink: the landing sets hold a worst case each)
         }
         // sizes of everybody's piece p, and how everybody fared
         if (lerr == FMD_OK) DIST_LOCAL(hipMemcpyAsync(sz_dev + 1, o_off + np, 8, hipMemcpyDeviceToDevice, sm));
@@ -762,7 +797,7 @@ extern "C" int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream_, fmd_ovlp_di
         }
         // ---- root: receive every peer's piece p, place it (the arena has the room: ensure() above)
         std::vector<fmd_comm_op_t> ops;
-        struct Placed { const uint32_t *pid; const uint64_t *off; uint64_t var_base, row0, np; uint64_t *vaddr_dst; Stage *st; uint64_t vb; };
+        struct Placed { const uint32_t *pid; const uint64_t *off; uint64_t var_base, row0, np; uint64_t *vaddr_dst; Stage *st; uint64_t vb; int q; };
         std::vector<Placed> placed;
         for (int q = 0; q < W; ++q) {
             const uint64_t nq = sz_host[3 * q], vb = sz_host[3 * q + 1];
@@ -781,10 +816,10 @@ extern "C" int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream_, fmd_ovlp_di
                     ops.push_back(fmd_comm_op_t{1, q, vq, (size_t)vb});
                     S.bytes_received += nq * (4 + sizeof(fmd_ovlp_rec_t)) + (nq + 1) * 8 + vb;
                 }
-                placed.push_back(Placed{(const uint32_t *)d->t_ids.p + row0, offq, (uint64_t)(uintptr_t)vq, row0, nq, (uint64_t *)d->t_vaddr.p + row0, nullptr, vb});
+                placed.push_back(Placed{(const uint32_t *)d->t_ids.p + row0, offq, (uint64_t)(uintptr_t)vq, row0, nq, (uint64_t *)d->t_vaddr.p + row0, nullptr, vb, q});
             } else {
                 Stage *st = &d->in[k][(size_t)q];
-                uint8_t *hv = (uint8_t *)d->var.take(vb ? vb : 256);   // the row's final place in pinned host memory
+                uint8_t *hv = d->sink ? (uint8_t *)d->hin[k][(size_t)q].var.p : (uint8_t *)d->var.take(vb ? vb : 256);   // the row's final place in pinned host memory (a sink: where it waits for the sink)
                 if (!hv) return FMD_E_NOMEM;            // (as above)
                 const uint32_t *pid_src; const uint64_t *off_src;
                 if (q != me) {
@@ -795,7 +830,7 @@ extern "C" int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream_, fmd_ovlp_di
                     S.bytes_received += nq * (4 + sizeof(fmd_ovlp_rec_t)) + (nq + 1) * 8 + vb;
                     pid_src = (const uint32_t *)st->pid.p; off_src = (const uint64_t *)st->off.p;
                 } else { pid_src = o_pid; off_src = o_off; }
-                placed.push_back(Placed{pid_src, off_src, (uint64_t)(uintptr_t)hv, row0, nq, (uint64_t *)st->vaddr.p, st, vb});
+                placed.push_back(Placed{pid_src, off_src, (uint64_t)(uintptr_t)hv, row0, nq, (uint64_t *)st->vaddr.p, st, vb, q});
             }
         }
         if (!ops.empty()) { rc = d->comm->exchange(d->comm->ctx, sm, (int)ops.size(), ops.data()); if (rc != FMD_OK) return rc; }
@@ -807,9 +842,17 @@ extern "C" int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream_, fmd_ovlp_di
             for (const Placed &pl : placed) {
                 const bool mine = pl.pid == o_pid;
                 const void *src_prec = mine ? (const void *)o_prec : pl.st->prec.p, *src_var = mine ? (const void *)o_var : pl.st->var.p;
+                if (d->sink) {   // ids, records and the offsets as they were packed (the sink reads a piece as fmd_ovlp_pack_rows_dev wrote it: off[] into var)
+                    HStage &hs = d->hin[k][(size_t)pl.q];
+                    FMD_HIP_TRY(hipMemcpyAsync(hs.pid.p, pl.pid, pl.np * 4, hipMemcpyDeviceToHost, s3));
+                    FMD_HIP_TRY(hipMemcpyAsync(hs.prec.p, src_prec, pl.np * sizeof(fmd_ovlp_rec_t), hipMemcpyDeviceToHost, s3));
+                    FMD_HIP_TRY(hipMemcpyAsync(hs.off.p, pl.off, (pl.np + 1) * 8, hipMemcpyDeviceToHost, s3));
+                    hs.rows = pl.np;
+                } else {
                 FMD_HIP_TRY(hipMemcpyAsync((uint32_t *)d->th_ids.p + pl.row0, pl.pid, pl.np * 4, hipMemcpyDeviceToHost, s3));
                 FMD_HIP_TRY(hipMemcpyAsync((fmd_ovlp_rec_t *)d->th_prec.p + pl.row0, src_prec, pl.np * sizeof(fmd_ovlp_rec_t), hipMemcpyDeviceToHost, s3));
                 FMD_HIP_TRY(hipMemcpyAsync((uint64_t *)d->th_vaddr.p + pl.row0, pl.vaddr_dst, pl.np * 8, hipMemcpyDeviceToHost, s3));
+                }
                 if (pl.vb) FMD_HIP_TRY(hipMemcpyAsync((void *)(uintptr_t)pl.var_base, src_var, pl.vb, hipMemcpyDeviceToHost, s3));
             }
             FMD_HIP_TRY(hipEventRecord(d->drained[k], s3));
@@ -820,9 +863,15 @@ extern "C" int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream_, fmd_ovlp_di
     FMD_HIP_TRY(hipEventRecord(d->ev[5], sm));
     // ---- the end of this rank's part in the gather (the end of its compute is ev[3] on the compute stream)
     FMD_HIP_TRY(hipStreamSynchronize(sm));
-    if (is_root && d->on_host) FMD_HIP_TRY(hipMemcpyAsync(d->th_row_of.p, d->t_row_of.p, cfg.n_ids * 4, hipMemcpyDeviceToHost, s3));
+    if (is_root && d->on_host && !d->sink) FMD_HIP_TRY(hipMemcpyAsync(d->th_row_of.p, d->t_row_of.p, cfg.n_ids * 4, hipMemcpyDeviceToHost, s3));
     FMD_HIP_TRY(hipEventRecord(d->ev[6], s3));
     FMD_HIP_TRY(hipStreamSynchronize(s3));
+    if (cfg.host_table == 2) {   // what is left in the landing sets (the last piece), and how the sink fared with it: one more status word, so that this too is everybody's code
+        int serr = FMD_OK;
+        if (is_root) { serr = run_sink(P & 1); if (serr == FMD_OK) serr = run_sink((P - 1) & 1); }
+        rc = dist_agree(d, sm, serr, "the row sink");
+        if (rc != FMD_OK) return rc;
+    }
     const double t_end = now_s();
     FMD_HIP_TRY(hipStreamWaitEvent(sc, d->ev[5], 0));   // the caller's stream owns the table
     float ms = 0;
@@ -847,6 +896,7 @@ extern "C" int fmd_ovlp_dist_table(fmd_ovlp_dist_t *d, fmd_ovlp_dist_table_t *t)
     if (!d || !t) return FMD_E_ARG;
     memset(t, 0, sizeof(*t));
     if (d->rank != d->cfg.root) return FMD_E_ARG;
+    if (d->sink) return FMD_E_ARG;       // (no table was kept: the rows went to cfg.row_sink)
     t->on_host = d->on_host;
     t->n_rows = d->cfg.n_ids;
     if (d->on_host) { t->prec = (const fmd_ovlp_rec_t *)d->th_prec.p; t->ids = (const uint32_t *)d->th_ids.p; t->vaddr = (const uint64_t *)d->th_vaddr.p; t->row_of_id = (const uint32_t *)d->th_row_of.p; }

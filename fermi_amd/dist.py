@@ -339,7 +339,8 @@ class Comm(C.Structure):       # fmd_comm_t
 
 class DistCfg(C.Structure):    # fmd_ovlp_dist_cfg_t
     _fields_ = [("n_ids", C.c_uint64), ("min_match", C.c_int), ("max_len", C.c_uint32), ("max_nei", C.c_uint32), ("pieces", C.c_uint32),
-                ("key_shard", C.c_int), ("root", C.c_int), ("host_table", C.c_int), ("batch", C.c_size_t)]
+                ("key_shard", C.c_int), ("root", C.c_int), ("host_table", C.c_int), ("batch", C.c_size_t),
+                ("row_sink", C.c_void_p), ("sink_ctx", C.c_void_p)]      # host_table = 2: the root hands every piece to row_sink(sink_ctx, ...) and keeps no table
 
 
 class DistStats(C.Structure):  # fmd_ovlp_dist_stats_t
@@ -477,9 +478,10 @@ class RcclComm:
 class DistJob:
     """fmd_ovlp_dist_t: one pass of overlap discovery over ids 0 .. n_ids-1 on `world` GPUs per step()."""
 
-    def __init__(self, api, index, comm, n_ids, min_match, max_len, max_nei=4, pieces=0, key_shard=0, root=0, host_table=-1, batch=0):
+    def __init__(self, api, index, comm, n_ids, min_match, max_len, max_nei=4, pieces=0, key_shard=0, root=0, host_table=-1, batch=0, row_sink=None, sink_ctx=None):
+        """row_sink / sink_ctx: with host_table = 2, the address of a C function (fmd_ovlp_dist_cfg_t.row_sink: e.g. fmdh_dist_root_sink of libfmdhost) and its context"""
         self.api, self.lib, self.comm = api, api.lib(), comm
-        self.cfg = DistCfg(n_ids, min_match, max_len, max_nei, pieces, key_shard, root, host_table, batch)
+        self.cfg = DistCfg(n_ids, min_match, max_len, max_nei, pieces, key_shard, root, host_table, batch, row_sink, sink_ctx)
         h = C.c_void_p()
         api.check(self.lib.fmd_ovlp_dist_new(index.h, comm.ptr(), C.byref(self.cfg), C.byref(h)))
         self.h = h

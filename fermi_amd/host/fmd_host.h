@@ -150,6 +150,7 @@ void fmdh_par_for(int nt, void (*fn)(void *ctx, int tid, int nt), void *ctx);   
  * (offsets into var); the three buffers are the caller's and are not kept.  Chunks of different shards may be added concurrently. */
 int fmdh_slim_add(fmdh_slim_t *s, int g, uint64_t chunk, const fmd_ovlp_rec_t *rec, const uint64_t *off, const uint8_t *var, uint32_t max_nei, uint64_t nr, int n_threads);
 int fmdh_slim_replace(fmdh_slim_t *s, const uint64_t *ids, const fmd_ovlp_rec_t *rec, const uint64_t *off, const uint8_t *var, uint32_t max_nei, uint64_t n, int n_threads);
+int fmdh_slim_add_ids(fmdh_slim_t *s, const uint64_t *ids, const fmd_ovlp_rec_t *rec, const uint64_t *off, const uint8_t *var, uint32_t max_nei, uint64_t n, int n_threads);
 int fmdh_slim_link_fold(fmdh_slim_t *s, uint64_t first, uint64_t n, const struct fmdh_link *link, const uint8_t *reserved);
 int fmdh_slim_link_host(fmdh_slim_t *s, int n_threads);
 void fmdh_slim_undecided(const fmdh_slim_t *s, const uint64_t **ids, uint64_t *n);
@@ -261,6 +262,19 @@ int fmdh_unitig_walk_slim(fmdh_slim_t *t, uint64_t n_seq, int min_match, const u
  * GPU g computes the rows of ids i = g (mod n_dev) and ONE deterministic walk consumes them (the output is that of -t1
  * whatever n_dev is). */
 int fmdh_unitig(const char *fmd_path, int n_dev, const int *devices, int min_match, const char *rank_file /* -r, or NULL */, FILE *out);
+
+/* ---- the root of an N-PROCESS overlap job (include/fmd_hip.h, fmd_ovlp_dist_*: one process per GPU, RCCL) as `unitig` needs it: the root keeps no packed
+ * table (fmd_ovlp_dist_cfg_t.host_table = 2) -- every piece of every peer is folded into the slim rows as it arrives (row_sink = fmdh_dist_root_sink,
+ * sink_ctx = the object), 44.5 bytes per id instead of 125 -- and when the step has returned, fmdh_dist_root_finish does on the root's own GPU what
+ * fmdh_slim_build does after its rows: the rows that exceeded a capacity again, links and check_left by host threads, the plain steps.  The table it hands
+ * over is the one fmdh_unitig_walk_slim walks (unitig.c:394-404: the reference joins its workers' vertices into one graph; here the graph is walked from
+ * the table).  (fermi_amd/host/ovlp_table.c) */
+typedef struct fmdh_dist_root fmdh_dist_root_t;
+fmdh_dist_root_t *fmdh_dist_root_new(uint64_t n_seq, uint32_t max_len);
+int fmdh_dist_root_sink(void *ctx, uint64_t n_rows, const uint32_t *ids, const fmd_ovlp_rec_t *prec, const uint64_t *off, const uint8_t *var, uint32_t max_nei);
+uint64_t fmdh_dist_root_rows(const fmdh_dist_root_t *r);       /* rows folded so far */
+int fmdh_dist_root_finish(fmdh_dist_root_t *r, fmd_dev_t *dev, int min_match, fmdh_slim_t **out);   /* 0 and *out (the caller's: fmdh_slim_free), or 1; frees r either way */
+void fmdh_dist_root_free(fmdh_dist_root_t *r);
 /* `fermi seqsort <reads.fmd>` (seqsort.c:37-70): *sorted is malloc'ed, n = mcnt[1] entries */
 int fmdh_seqsort(const char *fmd_path, int device, uint64_t **sorted, uint64_t *n);
 

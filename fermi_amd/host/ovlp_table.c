@@ -282,6 +282,126 @@ static int replace_from_shard(fmdh_slim_t *s, const uint64_t *ids, const fmdh_ov
     }
     return rc;
 }
+/* What follows the rows, on ONE GPU (`dev`: an open replica of the index): the rows that exceeded a capacity again (ids[n_side], ascending), links and
+ * check_left (by the device's table job if there is one, by host threads otherwise), the edges the lfork does not decide through the exact kernel, the
+ * plain steps.  0, or 1 with the reason on stderr; the table stays the caller's either way. */
+static int slim_finish(fmdh_slim_t *s, fmd_dev_t *dev, fmd_ovlp_tabjob_t **tabjob, const uint64_t *ids, uint64_t n_side, int too_long_hint, uint32_t longest,
+                       int min_match, uint32_t max_len, uint32_t max_nei, int nt, int timing)
+{
+    uint64_t i;
+    int rc = 0, had_tabjob = 0;
+    if (n_side && !dev) { fprintf(stderr, "[E::%s] %llu rows exceeded a capacity and there is no GPU to compute them again\n", __func__, (unsigned long long)n_side); return 1; }
+    /* the rows that did not fit (longer sequences, more neighbours, longer lists): again, alone, with the capacities
+     * raised until they do -- on the GPU; nothing falls back to the CPU */
+    if (n_side) {
+        fmdh_ovlp_shard_t side;
+        uint32_t s_len = max_len, s_nei = max_nei;
+        int attempt;
+        double t1 = now_s();
+        memset(&side, 0, sizeof(side));
+        uint64_t over_at_cap = 0;
+        int at_cap = 0;
+        for (attempt = 0;; ++attempt) {
+            uint64_t n_over = 0;
+            /* the ladder ends at sequences of 4000 + min_match bases (candidate lists of 4095 entries): two attempts there that leave the same rows flagged
+             * are rows it cannot hold -- said so, with status 1 and nothing printed, rather than a list cut short (tests/test_gpu_parity.py pins this edge,
+             * which the reference, whose vectors grow, does not have: kvec.h:76-82) */
+            if (attempt == 12 || at_cap >= 2) {
+                fprintf(stderr, "[E::%s] %llu rows still overflow at max_len %u, max_nei %u: sequences longer than %u bases and candidate lists of 4096 entries and more are not supported\n",
+                        __func__, (unsigned long long)(over_at_cap ? over_at_cap : n_side), s_len, s_nei, 4000u + (uint32_t)min_match);
+                rc = 1; shard_free(&side); return rc;
+            }
+            /* what overflows in practice is the neighbour list of a strand in a fork-rich corner (more than max_nei irreducible overlaps): room for
+             * four times as many at once, longer sequences / candidate lists only where a flagged record says so or the first attempt was not enough */
+            if (attempt == 0) { s_nei *= 4; if (too_long_hint && longest > s_len) s_len = (longest + 31) / 32 * 32; }
+            else { s_nei *= 2; s_len = (s_len + s_len / 2 + 31) / 32 * 32; }     /* (the candidate lists' capacity follows max_len: fmd_ovlp_list_cap) */
+            if (s_len > 4000 + (uint32_t)min_match) s_len = 4000 + (uint32_t)min_match;   /* (lists of 4096 entries and more: not supported) */
+            shard_free(&side);
+            rc = shard_fill(dev, &side, ids, 0, 0, n_side, min_match, s_len, s_nei, 0);
+            if (rc) { fprintf(stderr, "[E::%s] overflow pass: %s\n", __func__, fmd_strerror(rc)); rc = 1; return rc; }
+            for (i = 0; i < n_side; ++i) n_over += (side.rec[i].flags & FMD_OVLP_F_OVERFLOW) != 0;
+            if (n_over == 0) break;
+            if (s_len == 4000 + (uint32_t)min_match) { at_cap = n_over == over_at_cap ? at_cap + 1 : 1; over_at_cap = n_over; }
+        }
+        rc = replace_from_shard(s, ids, &side, nt);
+        if (!rc && (*tabjob)) {   /* the device's copy of those rows, for its link pass */
+            uint64_t *n01 = (uint64_t *)malloc(n_side * 16);
+            if (!n01) rc = -ENOMEM;
+            else {
+                for (i = 0; i < n_side; ++i) {
+                    const fmd_ovlp_rec_t *r = &side.rec[i];
+                    const fmd_intv_t *ne = (const fmd_intv_t *)(side.chunk[i >> side.chunk_shift] + side.off[i]);
+                    const int has = fmd_ovlp_row_nei(r, side.max_nei) > 0;
+                    n01[2 * i] = has ? ne[0].x[0] : ~0ull; n01[2 * i + 1] = has ? ne[0].x[1] : ~0ull;
+                }
+                if (fmd_ovlp_tabjob_patch((*tabjob), n_side, ids, side.rec, n01)) rc = -EIO;
+                free(n01);
+            }
+        }
+        shard_free(&side);
+        if (rc) { fprintf(stderr, "[E::%s] overflow pass: cannot replace the rows (%s)\n", __func__, strerror(-rc)); rc = 1; return rc; }
+        if (timing) fprintf(stderr, "[M::%s] %llu rows again with capacities %u / %u: %.3f s\n", __func__, (unsigned long long)n_side, s_len, s_nei, now_s() - t1);
+    }
+    /* check_left_simple (unitig.c:186-204) of every edge: decided from the lfork of the neighbour's reverse strand, on the device that
+     * holds every record or by host threads; the edges that field does not decide go through the exact kernel (fmd_ovlp_check_left_dev), alone */
+    {
+        const uint64_t *und = 0;
+        uint64_t n_und = 0, k;
+        double t1 = now_s();
+        if ((*tabjob)) {
+            uint64_t *dev_und = 0, n_dev_und = 0;
+            had_tabjob = 1;
+            rc = fmd_ovlp_tabjob_link((*tabjob), links_sink, s, &dev_und, &n_dev_und);
+            fmd_host_free(dev_und);                      /* (the folded rows list the same edges, with the rows of their reverse strands) */
+            fmd_ovlp_tabjob_free((*tabjob)); (*tabjob) = 0;
+            if (rc) { fprintf(stderr, "[E::%s] link pass on the GPU: %s\n", __func__, fmd_strerror(rc)); rc = 1; return rc; }
+        } else {
+            rc = fmdh_slim_link_host(s, nt);
+            if (rc) { fprintf(stderr, "[E::%s] link pass: %s\n", __func__, strerror(-rc)); rc = 1; return rc; }
+        }
+        fmdh_slim_undecided(s, &und, &n_und);
+        if (timing) fprintf(stderr, "[M::%s] link pass (%s): %.3f s, %llu edges left to the exact kernel\n", __func__, had_tabjob ? "on the GPU, folded into the rows" : "host threads", now_s() - t1,
+                            (unsigned long long)n_und);
+        if (n_und && !dev) { fprintf(stderr, "[E::%s] %llu edges need the exact check_left kernel and there is no GPU\n", __func__, (unsigned long long)n_und); return 1; }
+        if (n_und) {
+            fmdh_ovlp_shard_t ex;
+            uint32_t s_len = max_len > longest ? max_len : (longest + 31) / 32 * 32, s_nei = max_nei;
+            uint16_t *vals;
+            int attempt;
+            t1 = now_s();
+            memset(&ex, 0, sizeof(ex));
+            for (attempt = 0;; ++attempt) {   /* same capacity ladder as above: a row that was computed again needs its capacities here too */
+                uint64_t n_over = 0;
+                rc = shard_fill(dev, &ex, und, 0, 0, n_und, min_match, s_len, s_nei, 1);
+                if (rc) { fprintf(stderr, "[E::%s] exact check_left pass: %s\n", __func__, fmd_strerror(rc)); rc = 1; return rc; }
+                for (k = 0; k < n_und; ++k) n_over += (ex.rec[k].flags & FMD_OVLP_F_OVERFLOW) != 0;
+                if (n_over == 0) break;
+                if (attempt == 12) {   /* records that still overflow are invalid: their verdicts must not reach the table */
+                    fprintf(stderr, "[E::%s] exact check_left pass: %llu rows still overflow at max_len %u, max_nei %u\n", __func__, (unsigned long long)n_over, s_len, s_nei);
+                    rc = 1; shard_free(&ex); return rc;
+                }
+                s_nei *= 2; s_len = (s_len + s_len / 2 + 31) / 32 * 32;
+                if (s_len > 4000 + (uint32_t)min_match) s_len = 4000 + (uint32_t)min_match;
+                shard_free(&ex);
+            }
+            vals = (uint16_t *)malloc(n_und * 2);
+            if (!vals) { rc = 1; shard_free(&ex); return rc; }
+            for (k = 0; k < n_und; ++k) vals[k] = ex.rec[k].reserved;
+            rc = fmdh_slim_set_reserved(s, und, vals, n_und);
+            free(vals);
+            shard_free(&ex);
+            if (rc) { fprintf(stderr, "[E::%s] exact check_left pass: %s\n", __func__, strerror(-rc)); rc = 1; return rc; }
+            if (timing) fprintf(stderr, "[M::%s] exact check_left of %llu rows: %.3f s\n", __func__, (unsigned long long)n_und, now_s() - t1);
+        }
+    }
+    {
+        const double t1 = now_s();
+        if (fmdh_slim_finalize(s, nt)) { rc = 1; return rc; }
+        if (timing) fprintf(stderr, "[M::%s] plain steps marked: %.3f s\n", __func__, now_s() - t1);
+    }
+    return 0;
+}
+
 static int slim_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_dev, const int *devices, int min_match, fmdh_slim_t **out, uint64_t *n_seq_out)
 {
     const int timing = getenv("FMD_TIMING") != 0;
@@ -292,7 +412,7 @@ static int slim_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_dev
     pthread_t *tid;
     char *started;
     fmdh_slim_t *s = 0;
-    uint64_t *ids = 0, n_side = 0, n_seq, i;
+    uint64_t *ids = 0, n_side = 0, n_seq;
     int g, rc = 0, too_long_hint = 0, one_gpu;
     double t0 = now_s();
     if (n_dev < 1 || !devices || !out) return 1;
@@ -331,118 +451,17 @@ static int slim_build_core(const char *fmd_path, fmd_dev_t *preopened, int n_dev
     if (rc) goto done;
     max_len = jobs[0].max_len;
     for (g = 1; g < n_dev; ++g) if (jobs[g].n_seq != n_seq) { fprintf(stderr, "[E::%s] the replicas disagree\n", __func__); rc = 1; goto done; }
-    /* the rows that did not fit (longer sequences, more neighbours, longer lists): again, alone, with the capacities
-     * raised until they do -- on the GPU; nothing falls back to the CPU */
+    /* the rows that did not fit: gathered from the replicas, ascending; then everything that follows the rows (slim_finish) on replica 0 */
     for (g = 0; g < n_dev; ++g) { n_side += jobs[g].n_flagged; too_long_hint |= jobs[g].too_long; if (jobs[g].longest > longest) longest = jobs[g].longest; }
     if (n_side) {
-        fmdh_ovlp_shard_t side;
-        uint32_t s_len = max_len, s_nei = max_nei;
-        int attempt;
-        double t1 = now_s();
         uint64_t o = 0;
-        memset(&side, 0, sizeof(side));
         ids = (uint64_t *)malloc(n_side * 8);
         if (!ids) { rc = 1; goto done; }
         for (g = 0; g < n_dev; ++g) { memcpy(ids + o, jobs[g].flagged, jobs[g].n_flagged * 8); o += jobs[g].n_flagged; }
         if (n_dev > 1) qsort(ids, n_side, 8, cmp_u64);   /* (one shard: ascending already) */
-        uint64_t over_at_cap = 0;
-        int at_cap = 0;
-        for (attempt = 0;; ++attempt) {
-            uint64_t n_over = 0;
-            /* the ladder ends at sequences of 4000 + min_match bases (candidate lists of 4095 entries): two attempts there that leave the same rows flagged
-             * are rows it cannot hold -- said so, with status 1 and nothing printed, rather than a list cut short (tests/test_gpu_parity.py pins this edge,
-             * which the reference, whose vectors grow, does not have: kvec.h:76-82) */
-            if (attempt == 12 || at_cap >= 2) {
-                fprintf(stderr, "[E::%s] %llu rows still overflow at max_len %u, max_nei %u: sequences longer than %u bases and candidate lists of 4096 entries and more are not supported\n",
-                        __func__, (unsigned long long)(over_at_cap ? over_at_cap : n_side), s_len, s_nei, 4000u + (uint32_t)min_match);
-                rc = 1; shard_free(&side); goto done;
-            }
-            /* what overflows in practice is the neighbour list of a strand in a fork-rich corner (more than max_nei irreducible overlaps): room for
-             * four times as many at once, longer sequences / candidate lists only where a flagged record says so or the first attempt was not enough */
-            if (attempt == 0) { s_nei *= 4; if (too_long_hint && longest > s_len) s_len = (longest + 31) / 32 * 32; }
-            else { s_nei *= 2; s_len = (s_len + s_len / 2 + 31) / 32 * 32; }     /* (the candidate lists' capacity follows max_len: fmd_ovlp_list_cap) */
-            if (s_len > 4000 + (uint32_t)min_match) s_len = 4000 + (uint32_t)min_match;   /* (lists of 4096 entries and more: not supported) */
-            shard_free(&side);
-            rc = shard_fill(jobs[0].dev, &side, ids, 0, 0, n_side, min_match, s_len, s_nei, 0);
-            if (rc) { fprintf(stderr, "[E::%s] overflow pass: %s\n", __func__, fmd_strerror(rc)); rc = 1; goto done; }
-            for (i = 0; i < n_side; ++i) n_over += (side.rec[i].flags & FMD_OVLP_F_OVERFLOW) != 0;
-            if (n_over == 0) break;
-            if (s_len == 4000 + (uint32_t)min_match) { at_cap = n_over == over_at_cap ? at_cap + 1 : 1; over_at_cap = n_over; }
-        }
-        rc = replace_from_shard(s, ids, &side, nt);
-        if (!rc && jobs[0].tabjob) {   /* the device's copy of those rows, for its link pass */
-            uint64_t *n01 = (uint64_t *)malloc(n_side * 16);
-            if (!n01) rc = -ENOMEM;
-            else {
-                for (i = 0; i < n_side; ++i) {
-                    const fmd_ovlp_rec_t *r = &side.rec[i];
-                    const fmd_intv_t *ne = (const fmd_intv_t *)(side.chunk[i >> side.chunk_shift] + side.off[i]);
-                    const int has = fmd_ovlp_row_nei(r, side.max_nei) > 0;
-                    n01[2 * i] = has ? ne[0].x[0] : ~0ull; n01[2 * i + 1] = has ? ne[0].x[1] : ~0ull;
-                }
-                if (fmd_ovlp_tabjob_patch(jobs[0].tabjob, n_side, ids, side.rec, n01)) rc = -EIO;
-                free(n01);
-            }
-        }
-        shard_free(&side);
-        if (rc) { fprintf(stderr, "[E::%s] overflow pass: cannot replace the rows (%s)\n", __func__, strerror(-rc)); rc = 1; goto done; }
-        if (timing) fprintf(stderr, "[M::%s] %llu rows again with capacities %u / %u: %.3f s\n", __func__, (unsigned long long)n_side, s_len, s_nei, now_s() - t1);
     }
-    /* check_left_simple (unitig.c:186-204) of every edge: decided from the lfork of the neighbour's reverse strand, on the device that
-     * holds every record or by host threads; the edges that field does not decide go through the exact kernel (fmd_ovlp_check_left_dev), alone */
-    {
-        const uint64_t *und = 0;
-        uint64_t n_und = 0, k;
-        double t1 = now_s();
-        if (jobs[0].tabjob) {
-            uint64_t *dev_und = 0, n_dev_und = 0;
-            rc = fmd_ovlp_tabjob_link(jobs[0].tabjob, links_sink, s, &dev_und, &n_dev_und);
-            fmd_host_free(dev_und);                      /* (the folded rows list the same edges, with the rows of their reverse strands) */
-            fmd_ovlp_tabjob_free(jobs[0].tabjob); jobs[0].tabjob = 0;
-            if (rc) { fprintf(stderr, "[E::%s] link pass on the GPU: %s\n", __func__, fmd_strerror(rc)); rc = 1; goto done; }
-        } else {
-            rc = fmdh_slim_link_host(s, nt);
-            if (rc) { fprintf(stderr, "[E::%s] link pass: %s\n", __func__, strerror(-rc)); rc = 1; goto done; }
-        }
-        fmdh_slim_undecided(s, &und, &n_und);
-        if (timing) fprintf(stderr, "[M::%s] link pass (%s): %.3f s, %llu edges left to the exact kernel\n", __func__, one_gpu ? "on the GPU, folded into the rows" : "host threads", now_s() - t1,
-                            (unsigned long long)n_und);
-        if (n_und) {
-            fmdh_ovlp_shard_t ex;
-            uint32_t s_len = max_len > longest ? max_len : (longest + 31) / 32 * 32, s_nei = max_nei;
-            uint16_t *vals;
-            int attempt;
-            t1 = now_s();
-            memset(&ex, 0, sizeof(ex));
-            for (attempt = 0;; ++attempt) {   /* same capacity ladder as above: a row that was computed again needs its capacities here too */
-                uint64_t n_over = 0;
-                rc = shard_fill(jobs[0].dev, &ex, und, 0, 0, n_und, min_match, s_len, s_nei, 1);
-                if (rc) { fprintf(stderr, "[E::%s] exact check_left pass: %s\n", __func__, fmd_strerror(rc)); rc = 1; goto done; }
-                for (k = 0; k < n_und; ++k) n_over += (ex.rec[k].flags & FMD_OVLP_F_OVERFLOW) != 0;
-                if (n_over == 0) break;
-                if (attempt == 12) {   /* records that still overflow are invalid: their verdicts must not reach the table */
-                    fprintf(stderr, "[E::%s] exact check_left pass: %llu rows still overflow at max_len %u, max_nei %u\n", __func__, (unsigned long long)n_over, s_len, s_nei);
-                    rc = 1; shard_free(&ex); goto done;
-                }
-                s_nei *= 2; s_len = (s_len + s_len / 2 + 31) / 32 * 32;
-                if (s_len > 4000 + (uint32_t)min_match) s_len = 4000 + (uint32_t)min_match;
-                shard_free(&ex);
-            }
-            vals = (uint16_t *)malloc(n_und * 2);
-            if (!vals) { rc = 1; shard_free(&ex); goto done; }
-            for (k = 0; k < n_und; ++k) vals[k] = ex.rec[k].reserved;
-            rc = fmdh_slim_set_reserved(s, und, vals, n_und);
-            free(vals);
-            shard_free(&ex);
-            if (rc) { fprintf(stderr, "[E::%s] exact check_left pass: %s\n", __func__, strerror(-rc)); rc = 1; goto done; }
-            if (timing) fprintf(stderr, "[M::%s] exact check_left of %llu rows: %.3f s\n", __func__, (unsigned long long)n_und, now_s() - t1);
-        }
-    }
-    {
-        const double t1 = now_s();
-        if (fmdh_slim_finalize(s, nt)) { rc = 1; goto done; }
-        if (timing) fprintf(stderr, "[M::%s] plain steps marked: %.3f s\n", __func__, now_s() - t1);
-    }
+    rc = slim_finish(s, jobs[0].dev, &jobs[0].tabjob, ids, n_side, too_long_hint, longest, min_match, max_len, max_nei, nt, timing);
+    if (rc) goto done;
     g_last_build[0] = g_last_build[1] = 0;
     for (g = 0; g < n_dev; ++g) { if (jobs[g].t_load > g_last_build[0]) g_last_build[0] = jobs[g].t_load; if (jobs[g].t_rows > g_last_build[1]) g_last_build[1] = jobs[g].t_rows; }
     g_last_build[2] = now_s() - t0; g_last_build[3] = (double)fmdh_slim_bytes(s);
@@ -456,5 +475,77 @@ done:
     }
     free(ids); free(jobs); free(tid); free(started);
     if (rc) fmdh_slim_free(s); else *out = s;
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------ the root of an N-process job (fmd_host.h) */
+struct fmdh_dist_root {
+    fmdh_slim_t *s; uint64_t n_seq; uint32_t max_len, max_nei; int nt;
+    uint64_t *flagged, n_flagged, m_flagged; uint32_t longest; int too_long;    /* rows that exceeded a capacity, as they arrived */
+    uint64_t *ids64, m_ids64, rows;
+};
+fmdh_dist_root_t *fmdh_dist_root_new(uint64_t n_seq, uint32_t max_len)
+{
+    fmdh_dist_root_t *r;
+    if (n_seq == 0 || n_seq >= 0xffffffffull) return 0;
+    r = (fmdh_dist_root_t *)calloc(1, sizeof(*r));
+    if (!r) return 0;
+    r->n_seq = n_seq; r->max_len = max_len; r->nt = fmdh_host_threads();
+    r->s = fmdh_slim_new(n_seq, 1, 1, STREAM_CHUNK_SHIFT);     /* (one shard, unused: the rows arrive by id, fmdh_slim_add_ids; host threads link them) */
+    if (!r->s) { free(r); return 0; }
+    return r;
+}
+void fmdh_dist_root_free(fmdh_dist_root_t *r)
+{
+    if (!r) return;
+    fmdh_slim_free(r->s);
+    free(r->flagged); free(r->ids64); free(r);
+}
+uint64_t fmdh_dist_root_rows(const fmdh_dist_root_t *r) { return r ? r->rows : 0; }
+int fmdh_dist_root_sink(void *ctx, uint64_t n_rows, const uint32_t *ids, const fmd_ovlp_rec_t *prec, const uint64_t *off, const uint8_t *var, uint32_t max_nei)
+{
+    fmdh_dist_root_t *r = (fmdh_dist_root_t *)ctx;
+    uint64_t k;
+    if (!r || !r->s) return -EINVAL;
+    if (n_rows > r->m_ids64) {
+        uint64_t *q = (uint64_t *)realloc(r->ids64, n_rows * 8);
+        if (!q) return -ENOMEM;
+        r->ids64 = q; r->m_ids64 = n_rows;
+    }
+    for (k = 0; k < n_rows; ++k) {
+        if (ids[k] >= r->n_seq) return -ERANGE;
+        r->ids64[k] = ids[k];
+    }
+    r->max_nei = max_nei;
+    if (fmdh_slim_add_ids(r->s, r->ids64, prec, off, var, max_nei, n_rows, r->nt)) return -ENOMEM;
+    for (k = 0; k < n_rows; ++k) if (prec[k].flags & FMD_OVLP_F_OVERFLOW) {
+        if (r->n_flagged == r->m_flagged) {
+            const uint64_t m = r->m_flagged ? 2 * r->m_flagged : 1 << 16;
+            uint64_t *q = (uint64_t *)realloc(r->flagged, m * 8);
+            if (!q) return -ENOMEM;
+            r->flagged = q; r->m_flagged = m;
+        }
+        r->flagged[r->n_flagged++] = ids[k];
+        r->too_long |= (uint32_t)prec[k].len > r->max_len;
+        if (prec[k].len > 0 && (uint32_t)prec[k].len > r->longest) r->longest = (uint32_t)prec[k].len;
+    }
+    r->rows += n_rows;
+    return 0;
+}
+int fmdh_dist_root_finish(fmdh_dist_root_t *r, fmd_dev_t *dev, int min_match, fmdh_slim_t **out)
+{
+    fmd_ovlp_tabjob_t *none = 0;
+    int rc;
+    if (out) *out = 0;
+    if (!r || !out) { fmdh_dist_root_free(r); return 1; }      /* (dev may be NULL where no row needs the GPU again: the tests' tables) */
+    if (r->rows != r->n_seq) {
+        fprintf(stderr, "[E::%s] %llu of %llu rows have arrived\n", __func__, (unsigned long long)r->rows, (unsigned long long)r->n_seq);
+        fmdh_dist_root_free(r);
+        return 1;
+    }
+    if (r->n_flagged > 1) qsort(r->flagged, r->n_flagged, 8, cmp_u64);
+    rc = slim_finish(r->s, dev, &none, r->flagged, r->n_flagged, r->too_long, r->longest, min_match, r->max_len, r->max_nei ? r->max_nei : 4, r->nt, getenv("FMD_TIMING") != 0);
+    if (!rc) { *out = r->s; r->s = 0; }
+    fmdh_dist_root_free(r);
     return rc;
 }

@@ -273,7 +273,8 @@ static char *tmp_for(tmp_t *t, const fmd_ovlp_rec_t *r)
 typedef struct {
     fmdh_slim_t *s; fat_t f; uint64_t nr;
     int g; uint64_t chunk;              /* rows (chunk << shift) .. of shard g: id = g + n_shards * row; or */
-    const uint64_t *ids;                /* explicit ids (rows replaced: every row carries its own bases) */
+    const uint64_t *ids;                /* explicit ids (rows replaced: every row carries its own bases; rows_of_a_peer: the even ones do, as in a chunk) */
+    int even_seeds;
     uint64_t slice_bytes[64], slice_off[64]; uint32_t max_nei[64]; int rc[64];
     uint8_t *dst; uint64_t dst_unit;    /* voff = byte offset / dst_unit (rows start on multiples of it) */
     int phase;
@@ -290,7 +291,7 @@ static void add_main(void *ctx, int tid, int nt)
         const fmdh_row_t x = fat_row(&a->f, j);
         const uint64_t id = add_id(a, j);
         const int st = row_status(x.rec), nn = st == 0 ? (int)fmd_ovlp_row_nei(x.rec, x.max_nei) : 0;
-        const int big = row_is_big(x.rec, st, (uint32_t)nn, x.nei, a->s->big_k2), own_seed = st == 0 && (a->ids || !(id & 1) || big);
+        const int big = row_is_big(x.rec, st, (uint32_t)nn, x.nei, a->s->big_k2), own_seed = st == 0 && ((a->ids && !a->even_seeds) || !(id & 1) || big);
         char *tmp = tmp_for(&t, x.rec);
         int inl;
         if (!tmp || id >= a->s->n) { a->rc[tid] = tmp ? -ERANGE : -ENOMEM; break; }
@@ -384,6 +385,19 @@ int fmdh_slim_replace(fmdh_slim_t *s, const uint64_t *ids, const fmd_ovlp_rec_t 
     if (n == 0) return 0;
     memset(&a, 0, sizeof(a));
     a.s = s; a.f.rec = rec; a.f.off = off; a.f.var = var; a.f.max_nei = max_nei; a.nr = n; a.ids = ids; a.dst_unit = 8;
+    s->x_len = (s->x_len + 7) & ~(uint64_t)7;
+    return add_run(&a, n_threads, alloc_x);
+}
+
+/* rows in ANY order of ids, each once (a piece of a peer of an N-process job, fmd_ovlp_dist_cfg_t.row_sink: the rows of one piece are neighbours in the
+ * sorted order of their keys, not in id): as fmdh_slim_add keeps them -- the bases with the even row of a read only -- in the growing area fmdh_slim_replace uses */
+int fmdh_slim_add_ids(fmdh_slim_t *s, const uint64_t *ids, const fmd_ovlp_rec_t *rec, const uint64_t *off, const uint8_t *var, uint32_t max_nei, uint64_t n, int n_threads)
+{
+    add_t a;
+    if (!s || (n && !ids)) return -EINVAL;
+    if (n == 0) return 0;
+    memset(&a, 0, sizeof(a));
+    a.s = s; a.f.rec = rec; a.f.off = off; a.f.var = var; a.f.max_nei = max_nei; a.nr = n; a.ids = ids; a.dst_unit = 8; a.even_seeds = 1;
     s->x_len = (s->x_len + 7) & ~(uint64_t)7;
     return add_run(&a, n_threads, alloc_x);
 }

@@ -143,6 +143,62 @@ def unitig_walk(shards, n_seq, min_match, out_path, sorted_map=None, max_nei=4, 
     return undecided
 
 
+class DistRoot:
+    """fmdh_dist_root_t: the root of an N-process overlap job (fermi_amd.dist.DistJob with host_table = 2) keeps no packed table -- every piece is folded into
+    the rows `unitig` walks as it arrives.  sink / ctx go into the job (row_sink, sink_ctx); feed() is the same entry for callers that hold pieces themselves."""
+
+    def __init__(self, n_seq, max_len=128):
+        L = lib()
+        L.fmdh_dist_root_new.restype = C.c_void_p
+        L.fmdh_dist_root_new.argtypes = [C.c_uint64, C.c_uint32]
+        L.fmdh_dist_root_sink.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.fmdh_dist_root_rows.restype = C.c_uint64
+        L.fmdh_dist_root_rows.argtypes = [C.c_void_p]
+        L.fmdh_dist_root_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.fmdh_dist_root_free.argtypes = [C.c_void_p]
+        L.fmdh_dist_root_free.restype = None
+        L.fmdh_slim_free.argtypes = [C.c_void_p]
+        L.fmdh_slim_bytes.restype = C.c_uint64
+        L.fmdh_slim_bytes.argtypes = [C.c_void_p]
+        L.fmdh_unitig_walk_slim.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        self.L, self.n_seq = L, n_seq
+        self.ctx = L.fmdh_dist_root_new(n_seq, max_len)
+        if not self.ctx:
+            raise MemoryError("fmdh_dist_root_new")
+        self.sink = C.cast(L.fmdh_dist_root_sink, C.c_void_p).value
+        self.slim = None
+
+    def feed(self, ids, prec, off, var, max_nei):
+        ids = np.ascontiguousarray(ids, dtype=np.uint32); prec = np.ascontiguousarray(prec); off = np.ascontiguousarray(off, dtype=np.uint64)
+        var = np.ascontiguousarray(var, dtype=np.uint8) if len(var) else np.zeros(8, np.uint8)
+        _chk(self.L.fmdh_dist_root_sink(self.ctx, len(ids), ids.ctypes.data, prec.ctypes.data, off.ctypes.data, var.ctypes.data, max_nei), "dist_root_sink")
+
+    def rows(self):
+        return int(self.L.fmdh_dist_root_rows(self.ctx))
+
+    def finish(self, min_match, dev_handle=None):
+        """-> bytes of the table; the rows that exceeded a capacity and the edges lfork leaves open go through the GPU behind dev_handle (an api.DevIndex.h)"""
+        slim = C.c_void_p()
+        ctx, self.ctx = self.ctx, None
+        if self.L.fmdh_dist_root_finish(ctx, dev_handle, min_match, C.byref(slim)):
+            raise RuntimeError("fmdh_dist_root_finish failed")
+        self.slim = slim
+        return int(self.L.fmdh_slim_bytes(slim))
+
+    def walk(self, min_match, out_path):
+        fp = _libc.fopen(out_path.encode(), b"wb")
+        try:
+            _chk(self.L.fmdh_unitig_walk_slim(self.slim, self.n_seq, min_match, None, fp, 0), "unitig_walk_slim")
+        finally:
+            _libc.fclose(fp)
+
+    def close(self):
+        if self.ctx:
+            self.L.fmdh_dist_root_free(self.ctx); self.ctx = None
+        if self.slim:
+            self.L.fmdh_slim_free(self.slim); self.slim = None
+
+
 def unitig(fmd_path, min_match, out_path, devices=(0,)):
     """`fermi-amd unitig -l min_match -g d0,d1,.. fmd_path > out_path` (GPU)."""
     L = lib()

@@ -400,8 +400,15 @@ typedef struct {
     uint32_t pieces;        /* 0 = default (4, fewer for small shards) */
     int key_shard;          /* 0 / 1; where the two-pass form does not apply (fmd_ovlp_two_pass_ok) the shard is computed in id order */
     int root;
-    int host_table;         /* root: 0 = the table stays in HBM, 1 = in pinned host memory (pieces staged through HBM), -1 = by free HBM */
+    int host_table;         /* root: 0 = the table stays in HBM, 1 = in pinned host memory (pieces staged through HBM), -1 = by free HBM, 2 = no table: row_sink below */
     size_t batch;           /* 0 = a piece is one batch; else pieces are cut further so that no batch exceeds this many strands */
+    /* host_table = 2 (the same on every rank): the root keeps NO table.  Every piece of every peer, once it has landed in pinned host memory, is handed to
+     * row_sink -- n_rows packed rows as fmd_ovlp_pack_rows_dev writes them: ids[n_rows], prec[n_rows], off[n_rows + 1] into var -- on the thread that runs the
+     * step, while the GPUs compute and pack the next piece; the buffers are reused two pieces later.  What unitig.c:394-404 does by joining its workers into
+     * one graph: here the consumer (fermi_amd/host/dist_root.c folds the rows into the 44.5-byte rows `unitig` walks) takes them as they arrive, and the
+     * root's memory is what the consumer keeps.  A non-zero return fails the step on every rank (FMD_E_IO).  Only the root's row_sink / sink_ctx are read. */
+    int (*row_sink)(void *ctx, uint64_t n_rows, const uint32_t *ids, const fmd_ovlp_rec_t *prec, const uint64_t *off, const uint8_t *var, uint32_t max_nei);
+    void *sink_ctx;
 } fmd_ovlp_dist_cfg_t;
 typedef struct {            /* of the last step, this rank; milliseconds from HIP events / the host clock */
     double head_ms, key_exchange_ms, tail_ms;      /* compute stream: pass 1 + sort; the all-to-all and the re-sort; all pieces of pass 2 */
@@ -409,7 +416,7 @@ typedef struct {            /* of the last step, this rank; milliseconds from HI
     double gather_exposed_ms;                      /* HIP events: end of this rank's last compute kernel -> end of its part in the gather */
     double step_ms;                                /* host clock, whole step */
     uint64_t rows_computed, rows_sent, bytes_sent, bytes_received, key_rows_sent;
-    int pieces, on_host, key_shard, two_pass;
+    int pieces, on_host /* 2: rows went to cfg.row_sink */, key_shard, two_pass;
 } fmd_ovlp_dist_stats_t;
 typedef struct {            /* root only: the table of the last step */
     int on_host;                  /* the arrays below are device (0) or pinned host (1) memory */
@@ -421,7 +428,7 @@ typedef struct {            /* root only: the table of the last step */
 } fmd_ovlp_dist_table_t;
 int fmd_ovlp_dist_new(fmd_dev_t *h, fmd_comm_t *comm, const fmd_ovlp_dist_cfg_t *cfg, fmd_ovlp_dist_t **out);
 int fmd_ovlp_dist_step(fmd_ovlp_dist_t *d, void *stream, fmd_ovlp_dist_stats_t *stats);
-int fmd_ovlp_dist_table(fmd_ovlp_dist_t *d, fmd_ovlp_dist_table_t *t);
+int fmd_ovlp_dist_table(fmd_ovlp_dist_t *d, fmd_ovlp_dist_table_t *t);     /* FMD_E_ARG on a job whose rows went to a sink */
 /* this rank's own fixed-stride rows of the last step (tests, parity samples): row j describes sequence id ids[j] */
 int fmd_ovlp_dist_local(fmd_ovlp_dist_t *d, uint64_t *n_rows, const uint64_t **d_ids, const fmd_ovlp_rec_t **d_rec, const fmd_intv_t **d_nei, const uint8_t **d_seq, uint32_t *seq_stride);
 void fmd_ovlp_dist_free(fmd_ovlp_dist_t *d);

@@ -295,3 +295,79 @@ def test_rccl_transport_one_rank_talking_to_itself(gpu):
     for i in sample:
         assert got_var[int(i)] == want_v[int(want_o[i]):int(want_o[i + 1])].tobytes()
     job.free(); comm.free(); d.close()
+
+
+def _sink_worker(rank, world, port, N, err, ragged, key_shard, pieces, tmp, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import ctypes as C
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    from fermi_amd import api, dist as fdist, hostlib
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bwt = api.build_bwt(_reads(N, err, ragged))
+    d = api.DevIndex.from_bwt(bwt)
+    n_ids = int(d.mcnt[1])
+    comm = fdist.TorchComm(api, dist, rank, world)
+    root = hostlib.DistRoot(n_ids, 128) if rank == 0 else None
+    job = fdist.DistJob(api, d, comm, n_ids, 50, 100, 4, pieces=pieces, key_shard=key_shard, root=0, host_table=2,
+                        row_sink=root.sink if root else None, sink_ctx=root.ctx if root else None)
+    st = job.step()
+    assert st.pieces == pieces and (rank != 0 or st.on_host == 2)
+    if rank == 0:
+        assert root.rows() == n_ids
+        assert api.lib().fmd_ovlp_dist_table(job.h, C.byref(fdist.DistTable())) == -2       # no table was kept
+        nbytes = root.finish(50, d.h)               # rows beyond a capacity again and the open check_left edges: on this rank's GPU
+        out = os.path.join(tmp, "dist.mag")
+        root.walk(50, out)
+        fmd = os.path.join(tmp, "r.fmd")
+        hostlib.write_rld_from_bwt(bwt, fmd)
+        one = os.path.join(tmp, "one.mag")
+        hostlib.unitig(fmd, 50, one, devices=(0,))   # what `fermi-amd unitig -l50` prints from one process
+        a, b = open(out, "rb").read(), open(one, "rb").read()
+        q.put((0, hashlib.md5(a).hexdigest() == hashlib.md5(b).hexdigest() and len(a) > 1000, nbytes / n_ids))
+        root.close()
+    # a sink that turns rows down fails the step on EVERY rank with one code
+    bad = hostlib.DistRoot(n_ids, 128) if rank == 0 else None
+    job2 = fdist.DistJob(api, d, comm, n_ids, 50, 100, 4, pieces=pieces, key_shard=key_shard, root=0, host_table=2,
+                         row_sink=bad.sink if bad else None, sink_ctx=None)              # (no context: fmdh_dist_root_sink returns -EINVAL on the first piece)
+    rc = api.lib().fmd_ovlp_dist_step(job2.h, None, C.byref(job2.stats))
+    torch.cuda.synchronize()
+    q.put((10 + rank, int(rc), 0.0))
+    dist.barrier()
+    if bad:
+        bad.close()
+    job2.free(); job.free(); d.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,err,ragged,key_shard,pieces", [
+    (15000, 0.0, False, 0, 3),       # id shard, error-free reads
+    (15000, 0.01, True, 1, 4),       # key shard, reads with errors, ragged lengths, Ns: rows beyond max_nei = 4 are computed again on the root's GPU
+    (9000, 0.005, False, 0, 1),      # one piece: everything reaches the sink after the loop
+])
+def test_root_folds_arriving_pieces_into_the_rows_unitig_walks(gpu, tmp_path, N, err, ragged, key_shard, pieces):
+    """the root of the N-process step kept the packed rows (125 bytes per id) where the CLI holds 44.5.  With host_table = 2 it keeps no
+    table: every piece of every peer goes from its pinned landing buffers through cfg.row_sink (fmdh_dist_root_sink, libfmdhost) into the slim rows while
+    the next piece is computed; fmdh_dist_root_finish + the walk then print the MAG -- the bytes `fermi-amd unitig -l50` prints from one process.  Three
+    ranks share the GPU (gloo transport).  A sink that fails takes every rank out of the step with FMD_E_IO."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 3
+    ps = [ctx.Process(target=_sink_worker, args=(r, world, port, N, err, ragged, key_shard, pieces, str(tmp_path), q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = {}
+    for _ in range(1 + world):
+        k, v, x = q.get(timeout=300)
+        got[k] = (v, x)
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0][0] is True, got
+    assert got[0][1] < 70.0, got             # bytes per id at the root (packed rows: 125 and more)
+    assert [got[10 + r][0] for r in range(world)] == [-4] * world, got

@@ -407,3 +407,44 @@ def test_slim_table_keeps_what_the_walk_reads(oracle_lib, gold, tmp_path, monkey
             assert st["big"] == dup and (dup > 0 or name not in ("tiny", "repeat")), (st, dup)
         assert st["own_seq"] <= ok
     o.close()
+
+
+@pytest.mark.parametrize("name,mm", [("tiny", 50), ("repeat", 20), ("special", 20)])
+@pytest.mark.parametrize("n_pieces", [1, 7])
+def test_rows_folded_as_a_root_receives_them_walk_to_the_reference_mag(oracle_lib, gold, tmp_path, name, mm, n_pieces):
+    """The root of an N-process job keeps no packed table (fmd_ovlp_dist_cfg_t.host_table = 2): every piece of every peer goes through fmdh_dist_root_sink into
+    the slim rows -- ids in ANY order (a piece is a stretch of the sorted key order), bases with the even row of a read only -- and after the last one
+    fmdh_dist_root_finish links them.  Here the pieces come from the oracle's table cut at random; the MAG must be `fermi unitig -t1`'s, byte for byte, and
+    the table as small as the one the streamed chunks make."""
+    import packref
+    o = orcbind.OrcIndex(gold.path(name + ".fmd"))
+    n_seq = int(o.mcnt[1])
+    rec, nei, seq = o.overlap_batch(np.arange(n_seq, dtype=np.uint64), mm, max_len=100, max_nei=8, n_threads=4)
+    o.close()
+    order = np.random.default_rng(11 + n_pieces).permutation(n_seq)
+    root = hostlib.DistRoot(n_seq, 128)
+    try:
+        for part in np.array_split(order, n_pieces):
+            if len(part):
+                prec, off, var = packref.pack_rows(rec[part], nei[part], seq[part], nei.shape[1])
+                root.feed(part.astype(np.uint32), prec, off, var, nei.shape[1])
+        assert root.rows() == n_seq
+        nbytes = root.finish(mm)          # (no row exceeded a capacity, no edge is left to the exact kernel in these sets: no GPU needed)
+        out = str(tmp_path / "o.mag")
+        root.walk(mm, out)
+        assert open(out, "rb").read() == gold.text_gz(name + ".mag.gz")
+        st = {}
+        hostlib.unitig_walk(_packed_shards(rec.copy(), nei, seq, 1), n_seq, mm, str(tmp_path / "p.mag"), max_nei=8, seq_stride=seq.shape[1], stats=st)
+        assert nbytes <= st["bytes"] + 8 * n_seq + 4096, (nbytes, st)      # (rows by id start on multiples of 8 in the growing area)
+    finally:
+        root.close()
+
+
+def test_a_root_that_misses_rows_says_so(oracle_lib, gold):
+    o = orcbind.OrcIndex(gold.path("tiny.fmd"))
+    n_seq = int(o.mcnt[1])
+    o.close()
+    root = hostlib.DistRoot(n_seq, 128)
+    with pytest.raises(RuntimeError):
+        root.finish(50)
+    root.close()
