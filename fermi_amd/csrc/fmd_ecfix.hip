@@ -54,6 +54,18 @@ struct fmd_ectab {
 #ifndef EC_QWIN        // 1: the lane keeps the 16 aligned bytes of qualities around the last position it asked for in registers (a strand is searched position by position)
 #define EC_QWIN 1
 #endif
+#ifndef EC_HOP_LOOP
+#define EC_HOP_LOOP 1      // the hop chains in a loop of their own (below); 0: every hop a turn of the general form
+#endif
+#ifndef EC_HOP_MIN
+#define EC_HOP_MIN 16      // ... which runs (once at least, if anybody hops) while at least this many lanes of the wave are hopping: 1 -> 218 ms (a last hopping lane holds 63 up), 8 -> 173, 16 -> 160, 24 -> 162, 32 and more -> 172 (profiles/r6_hop)
+#endif
+#ifndef EC_HOP_ONLY
+#define EC_HOP_ONLY 1      // 1: the general turn holds no hop at all (a hopping lane sits it out; the loop gives every one of them a hop per turn at least)
+#endif
+#ifndef EC_PUSH_AB
+#define EC_PUSH_AB 1       // 1: a turn's pushes through two shared calls
+#endif
 #ifndef EC_HOP_BATCH   // 1: the bases a hop passes over are taken from the lane's LDS words in one piece, not one LDS read and one 64-bit shift per base
 #define EC_HOP_BATCH 1
 #endif
@@ -362,12 +374,64 @@ __device__ __forceinline__ bool ec_seed(const EcRead &r, int w, EcSearch &S, con
     return true;
 }
 
+// EL_JUMP: the path z `step` bases on (correct.c:183-185) -> the position of the base its next k-mer ends with
+__device__ __forceinline__ int ec_hop(const EcRead &r, EcNode &z, int step, int shift)
+{
+    int i;
+    int l;
+    i = (int)((uint64_t)z.y & 0xffff) - 1;
+    const int nav = i < step ? (i < 0 ? 0 : i) : step;             // bases the loop below would take if none of them is an N (i >= 1, l < step)
+    bool batched = false;
+#if EC_HOP_BATCH
+    if (r.staged && nav > 0 && nav <= 8 && 2 * (nav - 1) <= shift) {
+        // all of them at once: their nibbles are one field of the lane's LDS words (positions i - nav + 1 .. i of the strand; on the reverse strand the
+        // bytes run the other way and the bases are complemented), A/C/G/T -> 2 bits each, into the k-mer in the order the loop shifts them in
+        const int jl = r.rc ? r.len - 1 - i : i - nav + 1;
+        const uint32_t wq = (uint32_t)jl >> 3, sh4 = 4u * ((uint32_t)jl & 7u);
+        const uint32_t lo_w = r.lb[wq * 64], hi_w = wq + 1 < EC_LDS_BW ? r.lb[(wq + 1) * 64] : 0u;
+        const uint32_t fm = nav == 8 ? ~0u : (1u << (4 * nav)) - 1u;
+        const uint32_t F = (uint32_t)(((uint64_t)hi_w << 32 | lo_w) >> sh4) & fm;
+        const uint32_t t = F - (0x11111111u & fm);                    // nibbles 0..3 for A/C/G/T, 4 for an N
+        if (((t >> 2) & 0x11111111u & fm) == 0) {                     // no N among them
+            uint32_t y = (t | t >> 2) & 0x0f0f0f0fu;                  // pairs of bases per byte
+            y = (y | y >> 4) & 0x00ff00ffu; y = (y | y >> 8) & 0xffffu;   // nav bases, 2 bits each, the one at the lowest byte address first
+            if (r.rc) y ^= (1u << (2 * nav)) - 1u;                    // complemented; the loop's first base is the one at the lowest address
+            else { uint32_t rv = __brev(y) >> (32 - 2 * nav); y = ((rv >> 1) & 0x55555555u) | ((rv & 0x55555555u) << 1); }   // ... at the highest address: the 2-bit groups reversed
+            z.x = (uint64_t)y << (shift - 2 * (nav - 1)) | z.x >> (2 * nav);
+            i -= nav;
+            batched = true;
+        }
+    }
+#endif
+    if (!batched)
+    for (l = 0; i >= 1 && l < step; --i, ++l) {
+        const int c = r.base(i);
+        if (c >= 5) break;
+        z.x = (uint64_t)(c - 1) << shift | z.x >> 2;
+    }
+    return i;
+}
+// ... and the verdict on it (correct.c:186-195): the hop stands if the table agrees, unambiguously and deep enough; then the path is kept as it is now
+__device__ __forceinline__ bool ec_hop_good(int hit, int b, int i, int qv, EcNode &z, EcNode &keep, int &keep_i, int &keep_q, int &depth_last)
+{
+    bool good = hit >= 0 && b == (hit & 3) + 1;
+    if (good) {
+        const int v2 = hit >> 2, depth = ec_depth(v2);
+        good = (v2 & 7) <= 1 && depth >= EC_MIN_OCC && (double)depth / depth_last >= EC_MIN_OCC_RATIO;
+        if (good) {
+            z.y = (int64_t)((uint64_t)z.y >> 16 << 16 | (uint64_t)(i + 1));
+            keep = z; keep_i = i; keep_q = qv; depth_last = depth;
+        }
+    }
+    return good;
+}
+
 // One lane = one read at a time.  The search of correct.c:141-206 and the walk back along the best path (:207-219) are cut into TURNS of the wave's loop, and
 // a turn asks memory for ONE thing per lane -- a table slot (EL_POP: the best path's k-mer; EL_JUMP: the k-mer `step` bases on, correct.c:182-196) or a trace
 // entry (EL_CLOSE) -- so that the 64 requests of a wave are in flight together whatever its lanes are doing: the reference's inner loops (up to 20 dependent
 // look-ups while a clean read hops along, up to 100 dependent trace entries at the end) are turns here, not loops inside a turn that 63 lanes wait for.
 // A lane whose read is finished draws the next one at once (reads with errors take 10-100x the expansions of clean ones: a wave never waits for its slowest read).
-enum { EL_IDLE = 0, EL_POP, EL_JUMP, EL_CLOSE };
+enum { EL_IDLE = 0, EL_POP, EL_JUMP, EL_CLOSE, EL_HOPEND };
 __global__ __launch_bounds__(64, 4) void k_ecfix(size_t n, uint8_t *__restrict__ seqs, uint8_t *__restrict__ quals, const uint64_t *__restrict__ off, int w, int step,
                                                  const uint64_t *__restrict__ slots, uint64_t mask, int32_t *__restrict__ info, uint4 *heaps, uint64_t *traces,
                                                  uint32_t trace_cap, uint32_t *__restrict__ queue)
@@ -424,9 +488,35 @@ __global__ __launch_bounds__(64, 4) void k_ecfix(size_t n, uint8_t *__restrict__
         }
         if (__ballot(st != EL_IDLE) == 0) { if (__ballot(!drained) == 0) { C.flush(queue); break; } else continue; }
 
+#if EC_HOP_LOOP
+        // ---- hop chains first.  A strand in agreement with the table hops `step` bases at a time, one look-up per hop, up to (len - w) / step hops in a row
+        // (correct.c:182-196) -- three turns in four of an error-free read -- and a turn of the general form below costs the wave everything any lane might
+        // be doing: the queue's sift loops, the branches, the walk back.  So the lanes that are hopping hop on in a loop that holds nothing but the hop, its
+        // look-up and the verdict, until fewer than EC_HOP_MIN of them still are (the rest wait; a chain that ends leaves its strand in EL_HOPEND, and the
+        // turn below pushes the kept path and pops the next one as before).  Per lane the sequence of operations is the same as without the loop.
+        if (__ballot(st == EL_JUMP)) {
+            do {
+                if (st == EL_JUMP) {
+                    const int ih = ec_hop(r, z, step, shift);
+                    const int bh = r.base(ih);
+                    bool ends = bh == 5;
+                    if (!ends) {
+                        const int qh = ec_qual(r, ih, QW);
+                        const int hh = ec_lookup(slots, mask, z.x, full, C);
+                        ends = !ec_hop_good(hh, bh, ih, qh, z, keep, keep_i, keep_q, depth_last) || keep_i <= 0;
+                    }
+                    if (ends) st = EL_HOPEND;
+                }
+            } while (__popcll(__ballot(st == EL_JUMP)) >= EC_HOP_MIN);
+        }
+#endif
         // ---- what the lane wants from memory this turn
         bool want = false, pass_done = false, hop_end = false, overflow = false;
         int i = 0, b = 0;
+        if (st == EL_HOPEND) {                                             // the path goes on from where the last good hop left it (correct.c:198); then the queue's best
+            st = EL_POP;
+            if (!ec_branch(H, S.hn, trace, S.tn, trace_cap, keep, r.base(keep_i) - 1, 0, shift, 1, keep_q, C)) { info[cur] = (int32_t)EC_INFO_TRACE_FULL; st = EL_IDLE; }
+        }
         if (st == EL_POP) {
             if (S.hn == 0) pass_done = true;
             else {
@@ -439,41 +529,14 @@ __global__ __launch_bounds__(64, 4) void k_ecfix(size_t n, uint8_t *__restrict__
                 } else if (S.n_done && (int)(zy >> 48) > (int)((uint64_t)S.done_y0 >> 48) + EC_MAX_SC_DIFF) pass_done = true;
                 else { i = (int)(zy & 0xffff) - 1; b = r.base(i); want = true; }
             }
-        } else if (st == EL_JUMP) {                                        // `step` bases on (correct.c:183-185)
-            int l;
-            i = (int)((uint64_t)z.y & 0xffff) - 1;
-            const int nav = i < step ? (i < 0 ? 0 : i) : step;             // bases the loop below would take if none of them is an N (i >= 1, l < step)
-            bool batched = false;
-#if EC_HOP_BATCH
-            if (r.staged && nav > 0 && nav <= 8 && 2 * (nav - 1) <= shift) {
-                // all of them at once: their nibbles are one field of the lane's LDS words (positions i - nav + 1 .. i of the strand; on the reverse strand the
-                // bytes run the other way and the bases are complemented), A/C/G/T -> 2 bits each, into the k-mer in the order the loop shifts them in
-                const int jl = r.rc ? r.len - 1 - i : i - nav + 1;
-                const uint32_t wq = (uint32_t)jl >> 3, sh4 = 4u * ((uint32_t)jl & 7u);
-                const uint32_t lo_w = r.lb[wq * 64], hi_w = wq + 1 < EC_LDS_BW ? r.lb[(wq + 1) * 64] : 0u;
-                const uint32_t fm = nav == 8 ? ~0u : (1u << (4 * nav)) - 1u;
-                const uint32_t F = (uint32_t)(((uint64_t)hi_w << 32 | lo_w) >> sh4) & fm;
-                const uint32_t t = F - (0x11111111u & fm);                    // nibbles 0..3 for A/C/G/T, 4 for an N
-                if (((t >> 2) & 0x11111111u & fm) == 0) {                     // no N among them
-                    uint32_t y = (t | t >> 2) & 0x0f0f0f0fu;                  // pairs of bases per byte
-                    y = (y | y >> 4) & 0x00ff00ffu; y = (y | y >> 8) & 0xffffu;   // nav bases, 2 bits each, the one at the lowest byte address first
-                    if (r.rc) y ^= (1u << (2 * nav)) - 1u;                    // complemented; the loop's first base is the one at the lowest address
-                    else { uint32_t rv = __brev(y) >> (32 - 2 * nav); y = ((rv >> 1) & 0x55555555u) | ((rv & 0x55555555u) << 1); }   // ... at the highest address: the 2-bit groups reversed
-                    z.x = (uint64_t)y << (shift - 2 * (nav - 1)) | z.x >> (2 * nav);
-                    i -= nav;
-                    batched = true;
-                }
-            }
-#endif
-            if (!batched)
-            for (l = 0; i >= 1 && l < step; --i, ++l) {
-                const int c = r.base(i);
-                if (c >= 5) break;
-                z.x = (uint64_t)(c - 1) << shift | z.x >> 2;
-            }
+        }
+#if !(EC_HOP_LOOP && EC_HOP_ONLY)
+        else if (st == EL_JUMP) {                                          // `step` bases on (correct.c:183-185)
+            i = ec_hop(r, z, step, shift);
             b = r.base(i);
             if (b == 5) hop_end = true; else want = true;
         }
+#endif
         if (pass_done) {                                                   // correct.c:207-212
             score_diff = S.n_done == 1 ? EC_MAX_SC_DIFF : (int)((uint64_t)S.done_y1 >> 48) - (int)((uint64_t)S.done_y0 >> 48);
             if (score_diff >= EC_MAX_SC_DIFF) score_diff = EC_MAX_SC_DIFF;
@@ -501,6 +564,41 @@ __global__ __launch_bounds__(64, 4) void k_ecfix(size_t n, uint8_t *__restrict__
         if (st == EL_CLOSE && ct) { te = trace.hbm[ct]; C.add(2); }
 #endif
         // ---- what came back
+#if EC_PUSH_AB
+        // The paths a turn adds to the queue -- none, one (a miss; the kept path where a hop chain cannot start) or two (the read's base and the table's) -- are
+        // described first and pushed by TWO shared calls: four inlined copies of the push (trace entry + sift loop) cost the wave four of them per turn
+        // whenever its lanes disagree about which one they need.
+        bool pa = false, pb = false, a_keep = false;
+        int ac = 0, acost = 0, amatch = 1, bc = 0, bcost = 0;
+        if (want && st == EL_POP) {
+            int q = qv - 33;
+            q = q < EC_MAX_QUAL ? q : EC_MAX_QUAL;
+            q = q < 3 ? 3 : q;
+            if (hit < 0) { pa = true; ac = b - 1; acost = EC_MISS_PENALTY + (EC_MAX_QUAL - q); amatch = 0; }
+            else {
+                const int best = (hit & 3) + 1, v = hit >> 2;
+                S.no_hits = 0;
+                if (b != best) {                                     // the table prefers another base: follow both, within the queue's budget
+                    const int pen = ec_swap_penalty(v);
+                    if (b != 5 && (S.hn + 2 <= EC_MAX_HEAP || pen < q)) { pa = true; ac = b - 1; acost = pen; }
+                    if (b == 5 || S.hn + (pa ? 1u : 0u) + 2 <= EC_MAX_HEAP || pen > q) { pb = true; bc = best - 1; bcost = q; }   // (the budget as it stands after the first push)
+                } else {                                             // agreement: hop `step` bases at a time while the k-mers stay deep and unambiguous
+                    keep = z; keep_i = i; keep_q = qv; depth_last = ec_depth(v);
+                    if ((v & 7) <= 0 && step > 1 && keep_i > 0) st = EL_JUMP;
+                    else hop_end = true;
+                }
+            }
+        }
+#if !(EC_HOP_LOOP && EC_HOP_ONLY)
+        else if (want) {                                                   // EL_JUMP: is the hop good?  (correct.c:186-195)
+            const bool good = ec_hop_good(hit, b, i, qv, z, keep, keep_i, keep_q, depth_last);
+            if (!good || keep_i <= 0) hop_end = true;
+        }
+#endif
+        if (hop_end) { pa = true; a_keep = true; ac = r.base(keep_i) - 1; acost = 0; st = EL_POP; }   // the path goes on from where the last good hop left it (correct.c:198)
+        if (pa) overflow = !ec_branch(H, S.hn, trace, S.tn, trace_cap, a_keep ? keep : z, ac, acost, shift, amatch, a_keep ? keep_q : qv, C);
+        if (pb && !overflow) overflow = !ec_branch(H, S.hn, trace, S.tn, trace_cap, z, bc, bcost, shift, 1, qv, C);
+#else
         if (want && st == EL_POP) {
             int q = qv - 33;
             q = q < EC_MAX_QUAL ? q : EC_MAX_QUAL;
@@ -521,22 +619,18 @@ __global__ __launch_bounds__(64, 4) void k_ecfix(size_t n, uint8_t *__restrict__
                 }
             }
             overflow = !ok;
-        } else if (want) {                                                 // EL_JUMP: is the hop good?  (correct.c:186-195)
-            bool good = hit >= 0 && b == (hit & 3) + 1;
-            if (good) {
-                const int v2 = hit >> 2, depth = ec_depth(v2);
-                good = (v2 & 7) <= 1 && depth >= EC_MIN_OCC && (double)depth / depth_last >= EC_MIN_OCC_RATIO;
-                if (good) {
-                    z.y = (int64_t)((uint64_t)z.y >> 16 << 16 | (uint64_t)(i + 1));
-                    keep = z; keep_i = i; keep_q = qv; depth_last = depth;
-                }
-            }
+        }
+#if !(EC_HOP_LOOP && EC_HOP_ONLY)
+        else if (want) {                                                   // EL_JUMP: is the hop good?  (correct.c:186-195)
+            const bool good = ec_hop_good(hit, b, i, qv, z, keep, keep_i, keep_q, depth_last);
             if (!good || keep_i <= 0) hop_end = true;
         }
+#endif
         if (hop_end) {                                                     // the path goes on from where the last good hop left it (correct.c:198)
             overflow = !ec_branch(H, S.hn, trace, S.tn, trace_cap, keep, r.base(keep_i) - 1, 0, shift, 1, keep_q, C);
             st = EL_POP;
         }
+#endif
         if (overflow) { info[cur] = (int32_t)EC_INFO_TRACE_FULL; st = EL_IDLE; continue; }
         if (st != EL_CLOSE) continue;
 #if EC_STAGE
