@@ -66,6 +66,15 @@ struct fmd_ectab {
 #ifndef EC_PUSH_AB
 #define EC_PUSH_AB 1       // 1: a turn's pushes through two shared calls
 #endif
+#ifndef EC_GATE
+#define EC_GATE 1          // taking reads in / seeding strands / closing strands wait until EC_GATE_IN / EC_GATE_CL lanes of the wave want to (k_ecfix)
+#endif
+#ifndef EC_GATE_IN
+#define EC_GATE_IN 16      // 0 (no gates): 143.8 ms per 5*10^7 reads; 4: 130.4; 8: 117.9; 16: 114.2; 24: 122.1 (profiles/r6_hop/ab_gate.txt)
+#endif
+#ifndef EC_GATE_CL
+#define EC_GATE_CL 8
+#endif
 #ifndef EC_HOP_BATCH   // 1: the bases a hop passes over are taken from the lane's LDS words in one piece, not one LDS read and one 64-bit shift per base
 #define EC_HOP_BATCH 1
 #endif
@@ -374,6 +383,13 @@ __device__ __forceinline__ bool ec_seed(const EcRead &r, int w, EcSearch &S, con
     return true;
 }
 
+// ec_fix's word for a read from the two strands' (correct.c:247-252)
+__device__ __forceinline__ int ec_combine(int ret0, int ret)
+{
+    int out = ((ret0 & 0xffff) + (ret & 0xffff)) | ((ret0 >> 18 < ret >> 18 ? ret0 >> 18 : ret >> 18) << 18);
+    if ((ret0 >> 17 & 1) && (ret >> 17 & 1)) out |= 1 << 16;
+    return out;
+}
 // EL_JUMP: the path z `step` bases on (correct.c:183-185) -> the position of the base its next k-mer ends with
 __device__ __forceinline__ int ec_hop(const EcRead &r, EcNode &z, int step, int shift)
 {
@@ -431,7 +447,7 @@ __device__ __forceinline__ bool ec_hop_good(int hit, int b, int i, int qv, EcNod
 // entry (EL_CLOSE) -- so that the 64 requests of a wave are in flight together whatever its lanes are doing: the reference's inner loops (up to 20 dependent
 // look-ups while a clean read hops along, up to 100 dependent trace entries at the end) are turns here, not loops inside a turn that 63 lanes wait for.
 // A lane whose read is finished draws the next one at once (reads with errors take 10-100x the expansions of clean ones: a wave never waits for its slowest read).
-enum { EL_IDLE = 0, EL_POP, EL_JUMP, EL_CLOSE, EL_HOPEND };
+enum { EL_IDLE = 0, EL_POP, EL_JUMP, EL_CLOSE, EL_HOPEND, EL_SEED };
 __global__ __launch_bounds__(64, 4) void k_ecfix(size_t n, uint8_t *__restrict__ seqs, uint8_t *__restrict__ quals, const uint64_t *__restrict__ off, int w, int step,
                                                  const uint64_t *__restrict__ slots, uint64_t mask, int32_t *__restrict__ info, uint4 *heaps, uint64_t *traces,
                                                  uint32_t trace_cap, uint32_t *__restrict__ queue)
@@ -475,16 +491,36 @@ __global__ __launch_bounds__(64, 4) void k_ecfix(size_t n, uint8_t *__restrict__
     EcCount C;
     fmd_tickets_init(tk, queue);
     for (;;) {
-        const size_t my = fmd_tickets_take(tk, queue, st == EL_IDLE && !drained);
-        if (st == EL_IDLE && !drained) {
-            if (my < n) {
-                cur = my;
-                r.s = seqs + off[my]; r.q = quals + off[my]; r.len = (int)(off[my + 1] - off[my]); r.rc = true;
-                QW.tag = ~0ull;
-                ec_stage(r);
+#if EC_GATE
+        // ---- what a lane does ONCE per strand -- take a read and stage it, find the strand's seed k-mer; close a strand: walk its best path back, hand the
+        // result on -- costs the wave its whole code every turn in which ANY lane does it, and with 64 lanes and ~18 turns per strand some lane nearly always
+        // does.  So these wait for company: reads are taken in and strands seeded when EC_GATE_IN lanes want it, strands closed when EC_GATE_CL do -- or
+        // when no lane of the wave is searching (then everything goes ahead: nothing can wait for ever).  Per lane the sequence of operations is unchanged.
+        const uint64_t busy_m = __ballot(st == EL_POP || st == EL_JUMP || st == EL_HOPEND);
+        const bool gate_in = busy_m == 0 || __popcll(__ballot((st == EL_IDLE && !drained) || st == EL_SEED)) >= EC_GATE_IN;
+        const bool gate_cl = busy_m == 0 || __popcll(__ballot(st == EL_CLOSE)) >= EC_GATE_CL;
+#else
+        const bool gate_in = true, gate_cl = true;
+#endif
+        const size_t my = fmd_tickets_take(tk, queue, gate_in && st == EL_IDLE && !drained);
+        if (gate_in) {
+            if (st == EL_IDLE && !drained) {
+                if (my < n) {
+                    cur = my;
+                    r.s = seqs + off[my]; r.q = quals + off[my]; r.len = (int)(off[my + 1] - off[my]); r.rc = true;
+                    QW.tag = ~0ull;
+                    ec_stage(r);
+                    st = EL_SEED;
+                } else drained = true;
+            }
+            if (st == EL_SEED) {                                           // the reverse-complement strand of a new read, or (r.rc false) the read as given after it
                 if (ec_seed(r, w, S, H, trace, C)) st = EL_POP;
-                else info[my] = 0xffff;                                    // too short, or no clean k-mer (correct.c:242-246)
-            } else drained = true;
+                else {
+                    // first strand: too short, or no clean k-mer (correct.c:242-246); second: ec_fix1 returns 0xffff and ec_fix combines it all the same
+                    info[cur] = r.rc ? 0xffff : ec_combine(ret0, 0xffff);
+                    st = EL_IDLE;
+                }
+            }
         }
         if (__ballot(st != EL_IDLE) == 0) { if (__ballot(!drained) == 0) { C.flush(queue); break; } else continue; }
 
@@ -553,7 +589,7 @@ __global__ __launch_bounds__(64, 4) void k_ecfix(size_t n, uint8_t *__restrict__
         if (want) { qv = ec_qual(r, i, QW); hit = ec_lookup(slots, mask, z.x, full, C); }   // (the byte's load is in flight beside the line's)
 #if EC_STAGE
         uint4 tl[EC_TR_LINE / 2];
-        const bool tload = st == EL_CLOSE && ct && ct / EC_TR_LINE != trace.tag;
+        const bool tload = st == EL_CLOSE && gate_cl && ct && ct / EC_TR_LINE != trace.tag;
         if (tload) {
             const uint4 *src = (const uint4 *)(trace.hbm + (ct & ~(uint32_t)(EC_TR_LINE - 1)));
 #pragma unroll
@@ -561,7 +597,7 @@ __global__ __launch_bounds__(64, 4) void k_ecfix(size_t n, uint8_t *__restrict__
             C.add(2, EC_TR_LINE);
         }
 #else
-        if (st == EL_CLOSE && ct) { te = trace.hbm[ct]; C.add(2); }
+        if (st == EL_CLOSE && gate_cl && ct) { te = trace.hbm[ct]; C.add(2); }
 #endif
         // ---- what came back
 #if EC_PUSH_AB
@@ -632,7 +668,7 @@ __global__ __launch_bounds__(64, 4) void k_ecfix(size_t n, uint8_t *__restrict__
         }
 #endif
         if (overflow) { info[cur] = (int32_t)EC_INFO_TRACE_FULL; st = EL_IDLE; continue; }
-        if (st != EL_CLOSE) continue;
+        if (st != EL_CLOSE || !gate_cl) continue;
 #if EC_STAGE
         if (tload) {                                                       // the line of the chain's next entry into the lane's LDS line
 #pragma unroll
@@ -658,15 +694,8 @@ __global__ __launch_bounds__(64, 4) void k_ecfix(size_t n, uint8_t *__restrict__
 #endif
         {                                                                  // the strand is done
             int ret = ((uint64_t)S.done_y0 >> 48) == 0 ? score_diff << 18 : (qsum | score_diff << 18 | S.no_hits << 17);
-            if (r.rc) {                                                    // the reverse-complement strand is done: now the read as given
-                ret0 = ret;
-                r.rc = false;
-                if (ec_seed(r, w, S, H, trace, C)) { st = EL_POP; continue; }
-                ret = 0xffff;                                              // no clean k-mer at this end: ec_fix1 returns 0xffff and ec_fix combines it all the same
-            }
-            int out = ((ret0 & 0xffff) + (ret & 0xffff)) | ((ret0 >> 18 < ret >> 18 ? ret0 >> 18 : ret >> 18) << 18);
-            if ((ret0 >> 17 & 1) && (ret >> 17 & 1)) out |= 1 << 16;
-            info[cur] = out;
+            if (r.rc) { ret0 = ret; r.rc = false; st = EL_SEED; continue; }   // the reverse-complement strand is done: now the read as given (seeded at the top, in company)
+            info[cur] = ec_combine(ret0, ret);
             st = EL_IDLE;
         }
     }

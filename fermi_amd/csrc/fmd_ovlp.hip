@@ -158,9 +158,10 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
                                                  uint8_t *__restrict__ seq_out, uint32_t seq_stride, uint32_t *__restrict__ queue,
                                                  int info_only, FmdWalkPark *__restrict__ park, const uint32_t *__restrict__ gidx,
                                                  const uint4 *__restrict__ adm, uint32_t tchunk, uint32_t *__restrict__ redo,
-                                                 uint32_t *__restrict__ cls, int cls_cfg)
+                                                 uint32_t *__restrict__ cls, int cls_cfg_)
 {
     FMD_DECLARE_COMPACT_LDS();
+    const int cls_cfg = cls_cfg_ & 0xffff, gate_n = (cls_cfg_ >> 16) & 0xff;   // (bits 16-23: the admission gate, below)
     __shared__ uint32_t walk_ls[MODE == WALK_TAIL2 ? 64 * WALK_LS_WORDS : 1];   // WALK_TAIL2: the lane's bases, word w of lane l at [w * 64 + l]
     constexpr bool TAILM = MODE == WALK_TAIL || MODE == WALK_TAIL2;
     constexpr int WAUX = MODE == WALK_HEAD ? FMD_HEAD_AUX : FMD_GLDS_AUX;   // pass 1 never asks for a line twice (strands in id order: every gather is a DRAM miss)
@@ -213,8 +214,13 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
                 }
             }
         }
-        const size_t my = fmd_tickets_take(tk_, queue, st == WK_IDLE && !exhausted, (MODE != WALK_WHOLE && (tchunk >> 24)) ? n : 0);
-        if (st == WK_IDLE && !exhausted) {
+        // The admission gate (gate_n > 1): idle lanes take their next strand only when gate_n of them are idle (or nobody is walking).  What a lane does once per
+        // strand -- the parked state in, the record, the row and the work-list entry out -- costs the wave its whole code in every step in which ANY lane does
+        // it; lanes that start together finish within a few steps of each other (a step in which the LF step cannot share the extension's gather sets a lane
+        // back by one), lanes that refill one by one drift apart until some lane does it in every step.
+        const bool gate = gate_n <= 1 || __popcll(__ballot(st == WK_IDLE && !exhausted)) >= gate_n || __ballot(st != WK_IDLE) == 0;
+        const size_t my = fmd_tickets_take(tk_, queue, gate && st == WK_IDLE && !exhausted, (MODE != WALK_WHOLE && (tchunk >> 24)) ? n : 0);
+        if (gate && st == WK_IDLE && !exhausted) {
             // The two passes of a sorted job take a strand in over one (WALK_HEAD) or two (WALK_TAIL) wave steps: the loads are issued
             // here and complete under the gather of the other lanes (WK_ADM1 / WK_ADM2 below).  A chain of dependent loads in front of
             // the gather -- id, tail-table entry, two prefix-table entries, as the one-pass walk does it -- stalls all 64 lanes of a wave
@@ -1157,6 +1163,7 @@ __global__ __launch_bounds__(64) void k_ovl_cls(FmdIndexView ix, size_t n, int m
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // tickets per atomic of a walk launch (FmdTickets::chunk): `dflt` for large launches, never more than a 64th of a wave's share
 // (the last chunks of a launch are worked off by fewer and fewer waves); the environment variable is the A/B knob
+static int walk_gate(const char *env, int dflt) { const char *e = getenv(env); int g = e ? atoi(e) : dflt; return g < 0 ? 0 : g > 64 ? 64 : g; }   // lanes that must be idle before any takes a new strand (k_ovl_walk)
 static uint32_t walk_ticket_chunk(const char *env, uint32_t dflt, size_t n, int grid)
 {
     const char *e = getenv(env);
@@ -1240,7 +1247,7 @@ static void ovl_phase_a(const OvlBatch &o, hipStream_t st, size_t b, size_t np, 
             if (ovl_tail2_cls(o)) { cls = o.cls + b * FMD_CLS_WORDS_PER_STRAND; (void)hipMemsetAsync(cls, 0, 4 * FMD_CLS_HEADER_U32, st); }
             grid = fmd_grid_for_lds(o.h, np, FMD_COMPACT_LDS_U4 * 16 + 64 * WALK_LS_WORDS * 4);
             if (per_cu > 0 && grid > o.h->n_cu * per_cu) grid = o.h->n_cu * per_cu;
-            k_ovl_walk<WALK_TAIL2><<<grid, 64, 0, st>>>(o.ix, np, nullptr, o.min_match, srev, o.stride_r, o.cap, listA, o.rec, seq, o.seq_stride, q0, 0, o.park, o.gidx + b, nullptr, walk_ticket_chunk("FMD_TAIL_TICKETS", 64, np, grid), redo, cls, ovl_use_fast() | ovl_min_cls() << 8);
+            k_ovl_walk<WALK_TAIL2><<<grid, 64, 0, st>>>(o.ix, np, nullptr, o.min_match, srev, o.stride_r, o.cap, listA, o.rec, seq, o.seq_stride, q0, 0, o.park, o.gidx + b, nullptr, walk_ticket_chunk("FMD_TAIL_TICKETS", 64, np, grid), redo, cls, ovl_use_fast() | ovl_min_cls() << 8 | walk_gate("FMD_TAIL_GATE", 0) << 16);
             k_ovl_seq_redo<<<64, 64, 0, st>>>(o.ix, redo, o.gidx + b, o.park, o.rec, seq, o.seq_stride);
             return;
         }
@@ -1591,7 +1598,7 @@ static int ovl_head(fmd_dev *h, hipStream_t st, size_t n, const uint64_t *d_ids,
             { const char *e = getenv("FMD_PAIR_FROM"); if (e && atoi(e) > ix.ptab_d && atoi(e) < (int)FMD_WALK_SPLIT && !(atoi(e) & 1)) from = atoi(e); }
             if (from <= ix.ptab_d) from = (ix.ptab_d + 2) & ~1;
             k_ovl_walk<WALK_HEAD><<<grid, 64, 0, st>>>(ix, n, d_ids, min_match, nullptr, (uint32_t)sizeof(FmdWalkPark), 0, nullptr, d_rec,
-                                                    nullptr, seq_stride, q, 0, park, nullptr, adm, walk_ticket_chunk("FMD_HEAD_TICKETS", 256, n, grid), nullptr, nullptr, from);
+                                                    nullptr, seq_stride, q, 0, park, nullptr, adm, walk_ticket_chunk("FMD_HEAD_TICKETS", 256, n, grid), nullptr, nullptr, from | walk_gate("FMD_HEAD_GATE", 0) << 16);
             (void)hipMemsetAsync(strag, 0, 4, st);
             uint32_t *q2 = fmd_next_queue(h, st);
             int grid2 = h->n_cu * (FMD_PAIR_LB * 4 < 20 ? FMD_PAIR_LB * 4 : 20);      // (8 KiB of LDS per wave: twenty fit a CU)
@@ -1619,7 +1626,7 @@ static int ovl_head(fmd_dev *h, hipStream_t st, size_t n, const uint64_t *d_ids,
         } else {
         if (strag) fmd_scratch_release(h, strag);
         k_ovl_walk<WALK_HEAD><<<grid, 64, 0, st>>>(ix, n, d_ids, min_match, nullptr, (uint32_t)sizeof(FmdWalkPark), 0, nullptr, d_rec,
-                                                nullptr, seq_stride, q, 0, park, nullptr, adm, walk_ticket_chunk("FMD_HEAD_TICKETS", 256, n, grid), nullptr, nullptr, 0);
+                                                nullptr, seq_stride, q, 0, park, nullptr, adm, walk_ticket_chunk("FMD_HEAD_TICKETS", 256, n, grid), nullptr, nullptr, walk_gate("FMD_HEAD_GATE", 0) << 16);
         }
     }
     // the order of pass 2: rows sorted by the minimizer of the bases each strand has shown so far
