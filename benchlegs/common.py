@@ -162,15 +162,26 @@ def apply_traffic(r):
 class Counter:
     """One untimed step of a leg through libfmdhip_count.so (same sources, gathers instrumented)."""
 
-    def __init__(self, api, fmd_path, device):
+    def __init__(self, api, fmd_path, device, main=None):
+        """main: the timed handle -- the work areas it keeps between calls go back to the device first (fmd_dev_trim), the counting handle needs the room"""
         self.L = api.count_lib()
+        if main is not None:
+            api.lib().fmd_dev_trim.restype = C.c_uint64
+            api.lib().fmd_dev_trim(main.h)
         self.h = None
         self.pair_lines = 0
         if self.L is None or not fmd_path:
             return
         h = C.c_void_p()
-        if self.L.fmd_dev_open_file(device, fmd_path.encode(), C.byref(h)) == 0:
+        rc = self.L.fmd_dev_open_file(device, fmd_path.encode(), C.byref(h))
+        if rc == 0:
             self.h = h
+        else:
+            log("  counting handle: fmd_dev_open_file failed (%d): no requested-bytes figure for this leg" % rc)
+        if os.environ.get("FMD_BENCH_DEBUG_MEM"):
+            import torch
+            f, t = torch.cuda.mem_get_info()
+            log("  [mem] counter opened (rc %d): %.1f GB free of %.1f (torch: %.1f allocated, %.1f reserved)" % (rc, f / 1e9, t / 1e9, torch.cuda.memory_allocated() / 1e9, torch.cuda.memory_reserved() / 1e9))
 
     def run(self, step):
         """step(L, h) launches one step on library L / handle h; returns (rank blocks, other lines) or None."""
@@ -181,6 +192,12 @@ class Counter:
         self.L.fmd_dev_line_count3(self.h, buf, 1, C.byref(cnt))
         # The timed handle has its two-base blocks (FMD_PAIR=1); this one builds its own inside the step and must not be turned down by the "only where the
         # job still finds its room" rule of fmd_pairs_ensure, or the step counted is not the step timed: torch's cached blocks back to the device, and FMD_PAIR=2.
+        def mem(tag):
+            if os.environ.get("FMD_BENCH_DEBUG_MEM"):
+                import torch
+                f, t = torch.cuda.mem_get_info()
+                log("  [mem] %s: %.1f GB free of %.1f (torch: %.1f allocated, %.1f reserved)" % (tag, f / 1e9, t / 1e9, torch.cuda.memory_allocated() / 1e9, torch.cuda.memory_reserved() / 1e9))
+        mem("counter: before the step")
         was = os.environ.get("FMD_PAIR")
         if was == "1":
             try:
@@ -194,6 +211,7 @@ class Counter:
         finally:
             if was == "1":
                 os.environ["FMD_PAIR"] = "1"
+        mem("counter: after the step")
         if self.L.fmd_dev_line_count3(self.h, buf, 1, C.byref(cnt)) != 0 or not cnt.value:
             return None
         self.pair_lines = int(buf[2])      # 128-byte two-base blocks requested (k_ovl_pair)

@@ -84,7 +84,7 @@ def bench_kmer(torch, api, index, n_sym, fmd_path, dev, local_rank, n_reads, ste
            "value": n_out * steps / wall, "unit": "solid k-mers/s", "ms_per_step": wall / steps * 1e3,
            "solid_kmers": n_out, "informative": int(st[3]), "extensions": nodes, "extensions_per_s": nodes * steps / wall,
            "k": w, "suf_len": suf_len, "frontier_cap": cap}
-    ctr = Counter(api, fmd_path, local_rank)
+    ctr = Counter(api, fmd_path, local_rank, main=index)
     lines = ctr.run(step)
     ctr.close()
     cn = oracle_counters(fmd_path, lambda o: o.ec_range(w, min_occ, suf_len, 0, 16, 1))

@@ -377,7 +377,7 @@ def bench_overlap(torch, api, index, dev, n_reads, L, steps, warmup, dist, world
         out["id_order_one_pass_walk"] = {"ms_per_step": e0.elapsed_time(e1) / 2, "what": "fmd_ovlp_dev batch by batch over ids in input order (the step of rounds 1-2), 2 passes on this box right after the timed steps",
                                          "same_results": "identical (records, neighbours, sequences + appended bases of all %d strands)" % n_loc if same else "MISMATCH"}
         job.rec, job.nei, job.seq = keep
-    ctr = Counter(api, fmd_path, local_rank)
+    ctr = Counter(api, fmd_path, local_rank, main=job.index)
     lines = ctr.run(job.compute)
     cl_lines = None
     ctr.close()
@@ -477,7 +477,7 @@ def bench_check_left(torch, api, job, n_reads, steps, warmup, fmd_path, ovl, loc
                                          % (ns, int((rec_o["reserved"] != 2).sum()), int((rec_o["reserved"] == 1).sum()))) if same else "MISMATCH"
     # device bytes of the linked form: rec read twice + reserved written, neighbour x0/x1 read, row map written + read twice, links written
     io = job.n * (2 * 64 + 64 + 16 + 3 * 4 + 8) + n_und * 8
-    ctr = Counter(api, fmd_path, local_rank)
+    ctr = Counter(api, fmd_path, local_rank, main=job.index)
     lines = ctr.run(job.check_left_linked)
     ctr.close()
     dev_bytes = None if lines is None else (lines[0] + lines[1]) * BLOCK_BYTES + io
@@ -611,7 +611,7 @@ def bench_overlap_raw(torch, api, index, dev, n_reads, L, err, fmd_path):
                          "parity_vs_oracle_on_sample": ("bit-exact (check_left_simple of %d random ids: %d edges with a verdict, %d back-bifurcations among them)"
                                                         % (nc, int((rec_o["reserved"] != 2).sum()), int((rec_o["reserved"] == 1).sum()))) if same else "MISMATCH"}
     # ---- device bytes of one job (rank blocks counted by the instrumented build) over its time
-    ctr = Counter(api, fmd_path, index.device)
+    ctr = Counter(api, fmd_path, index.device, main=index)
     lines = ctr.run(job.compute)
     ctr.close()
     torch.cuda.synchronize()

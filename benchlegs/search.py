@@ -83,7 +83,7 @@ def bench_bsearch(torch, api, workload, dev, local_rank, steps, warmup):
             finally:
                 del os.environ["FMD_PAIR_USE"]
             step(); torch.cuda.synchronize()
-        ctr = Counter(api, fmd_path, local_rank)
+        ctr = Counter(api, fmd_path, local_rank, main=index)
         lines = ctr.run(step)
         ctr.close()
         qpr = 2.0 * (L - 1)   # closed form for hits (exact.c:13-19), checked against the instrumented oracle in tests

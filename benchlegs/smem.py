@@ -60,7 +60,7 @@ def bench_smem(torch, api, index, rd, err, n_sym, fmd_path, dev, local_rank, n_r
     out = {"metric": "reads/sec through fm6_smem (fermi exact), reads with %g substitutions against their own index" % err,
            "value": n_reads * steps / wall, "unit": "reads/s", "ms_per_step": wall / steps * 1e3,
            "smems": n_out, "overflow_reads": int((g_nmem >> 31).sum()), "index_symbols": n_sym}
-    ctr = Counter(api, fmd_path, local_rank)
+    ctr = Counter(api, fmd_path, local_rank, main=index)
     lines = ctr.run(step)
     ctr.close()
     ns = 4000

@@ -22,7 +22,7 @@ OVLP_F_FORKED, OVLP_F_OVERFLOW, OVLP_F_FIXED = 1, 2, 4
 ABI_SYMBOLS = [
     "fmd_strerror", "fmd_last_hip_error", "fmd_device_count",
     "fmd_dev_open_file", "fmd_dev_open_rld", "fmd_dev_open_rle6", "fmd_dev_open_bwt", "fmd_dev_open_bwt_dev",
-    "fmd_dev_close", "fmd_dev_info", "fmd_dev_sync", "fmd_dev_line_count",
+    "fmd_dev_close", "fmd_dev_trim", "fmd_dev_info", "fmd_dev_sync", "fmd_dev_line_count",
     "fmd_rank1a_dev", "fmd_rank2a_dev", "fmd_rank1a_batch", "fmd_rank2a_batch",
     "fmd_extend_dev", "fmd_extend_batch", "fmd_bsearch_dev", "fmd_bsearch_batch",
     "fmd_retrieve_dev", "fmd_retrieve_batch", "fmd_probe_gather",
@@ -71,6 +71,7 @@ def _configure(L):
     L.fmd_dev_open_bwt.argtypes = [C.c_int, vp, C.c_uint64, C.POINTER(vp)]
     L.fmd_dev_open_bwt_dev.argtypes = [C.c_int, vp, C.c_uint64, C.POINTER(vp)]
     L.fmd_dev_close.restype = None; L.fmd_dev_close.argtypes = [vp]
+    L.fmd_dev_trim.restype = C.c_uint64; L.fmd_dev_trim.argtypes = [vp]
     L.fmd_dev_info.argtypes = [vp, C.POINTER(Info)]
     L.fmd_dev_sync.argtypes = [vp, vp]
     L.fmd_rank1a_dev.argtypes = [vp, vp, sz, u64p, u64p, vp]

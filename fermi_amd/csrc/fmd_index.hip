@@ -16,6 +16,8 @@ static thread_local char g_hip_err[256] = "";
 void fmd_set_hip_error(hipError_t e, const char *what)
 {
     snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();   // the code travels in the return value and the text here: the runtime's own "last error" is not left set for the next HIP call of the process
+                               // (another library's launch check) to trip over -- a failed hipMalloc in fmd_dev_open_file ended a torch kernel launch minutes later
 }
 extern "C" const char *fmd_last_hip_error(void) { return g_hip_err; }
 extern "C" const char *fmd_strerror(int code)
@@ -239,8 +241,8 @@ static int build_ptab(fmd_dev *h)
     if (getenv("FMD_PTAB_DEPTH")) { d = atoi(getenv("FMD_PTAB_DEPTH")); if (d < 1) return FMD_OK; if (d > 15) d = 15; while (d > 2 && ((1ull << (2 * d)) > h->mcnt[0] || h->mcnt[0] >= (1ull << (64 - 2 * d)) - 1)) --d; }   // (15: 17 GB, by request only)
     uint4 *a = nullptr, *b = nullptr;
     const uint64_t n = 1ull << (2 * d);
-    FMD_HIP_TRY(hipMalloc((void **)&a, n * 16));
-    if (hipMalloc((void **)&b, (n / 4 ? n / 4 : 1) * 16) != hipSuccess) { hipFree(a); return FMD_E_NOMEM; }
+    if (hipMalloc((void **)&a, n * 16) != hipSuccess) { (void)hipGetLastError(); return FMD_E_NOMEM; }      // (the error is the caller's to report: none is left behind for the next HIP call of the process to trip over)
+    if (hipMalloc((void **)&b, (n / 4 ? n / 4 : 1) * 16) != hipSuccess) { (void)hipGetLastError(); hipFree(a); return FMD_E_NOMEM; }
     // levels alternate between b (odd distance from the last) and a, so that level d lands in a
     FmdIndexView ix = fmd_view(h);
     uint4 *cur = nullptr;
@@ -820,6 +822,22 @@ void fmd_scratch_release(fmd_dev *h, void *p)
     for (int i = 0; i < N; ++i) if (h->scratch[i].p == p) { h->scratch[i].busy = 0; scratch_unlock(h); return; }
     scratch_unlock(h);
     hipFree(p);
+}
+
+// The buffers the handle keeps between calls (the work areas of the host-buffer entries: fmd_*_batch, the table jobs) go back to the device; the next call
+// that needs one allocates it again.  Synchronises the device first.  -> bytes released.
+extern "C" uint64_t fmd_dev_trim(fmd_dev_t *h)
+{
+    if (!h || hipSetDevice(h->device) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    (void)hipDeviceSynchronize();
+    const int N = (int)(sizeof(h->scratch) / sizeof(h->scratch[0]));
+    uint64_t freed = 0;
+    scratch_lock(h);
+    for (int i = 0; i < N; ++i)
+        if (h->scratch[i].p && !h->scratch[i].busy) { hipFree(h->scratch[i].p); freed += h->scratch[i].bytes; h->scratch[i].p = nullptr; h->scratch[i].bytes = 0; }
+    scratch_unlock(h);
+    (void)hipGetLastError();
+    return freed;
 }
 
 uint32_t *fmd_next_queue(fmd_dev *h, hipStream_t stream)

@@ -65,6 +65,9 @@ int fmd_dev_open_rle6(int device, const uint8_t *runs, uint64_t n_bytes, fmd_dev
 int fmd_dev_open_bwt(int device, const uint8_t *bwt, uint64_t n, fmd_dev_t **out);          /* plain nt6 BWT string, host */
 int fmd_dev_open_bwt_dev(int device, const uint8_t *d_bwt, uint64_t n, fmd_dev_t **out);    /* same, already in HBM */
 void fmd_dev_close(fmd_dev_t *h);
+/* the work areas the handle keeps between calls of the host-buffer entries (fmd_*_batch, the table jobs) back to the device; -> bytes released.
+ * (The reference's per-call vectors are freed per call, e.g. unitig.c:321-325; the handle keeps them because allocating 10-100 GB per call costs more than the call.) */
+uint64_t fmd_dev_trim(fmd_dev_t *h);
 int fmd_dev_info(const fmd_dev_t *h, fmd_info_t *info);
 int fmd_dev_sync(const fmd_dev_t *h, void *stream);
 /* measurement aid (no reference counterpart): lines[0] = 64-byte rank blocks, lines[1] = other random lines

@@ -307,7 +307,7 @@ if "unitig" in sys.argv[5:] and WRITE_FMD:
         lines = [l for l in errbuf[0].decode().splitlines() if "M::" in l and "fmd_ovlp]" not in l]
         rss = [l for l in lines if "peak resident set" in l]
         print("unitig -l50 by %s: rc %d, %.1f s, MAG %d bytes md5 %s; %s" % (name, rc, time.time() - t0, nb, h.hexdigest(), rss[-1].split(": ", 1)[1] if rss else "no resident-set line"), flush=True)
-        print("\n".join("    " + l for l in lines if "slim_build_core" in l or "table_build_core" in l or "fmdh_unitig" in l or "packed_batch_core" in l), flush=True)
+        print("\n".join("    " + l for l in lines if "slim_build_core" in l or "slim_finish" in l or "table_build_core" in l or "fmdh_unitig" in l or "packed_batch_core" in l), flush=True)
         if rc != 0:
             print(errbuf[0].decode()[-3000:], flush=True)
         assert rc == 0
