@@ -75,6 +75,9 @@ struct fmd_ectab {
 #ifndef EC_GATE_CL
 #define EC_GATE_CL 8
 #endif
+#ifndef EC_HOP_WARM
+#define EC_HOP_WARM 0      // 1: the hop loop asks for the NEXT hop's table line beside this hop's (speculation: most hops stand)
+#endif
 #ifndef EC_HOP_BATCH   // 1: the bases a hop passes over are taken from the lane's LDS words in one piece, not one LDS read and one 64-bit shift per base
 #define EC_HOP_BATCH 1
 #endif
@@ -448,7 +451,10 @@ __device__ __forceinline__ bool ec_hop_good(int hit, int b, int i, int qv, EcNod
 // look-ups while a clean read hops along, up to 100 dependent trace entries at the end) are turns here, not loops inside a turn that 63 lanes wait for.
 // A lane whose read is finished draws the next one at once (reads with errors take 10-100x the expansions of clean ones: a wave never waits for its slowest read).
 enum { EL_IDLE = 0, EL_POP, EL_JUMP, EL_CLOSE, EL_HOPEND, EL_SEED };
-__global__ __launch_bounds__(64, 4) void k_ecfix(size_t n, uint8_t *__restrict__ seqs, uint8_t *__restrict__ quals, const uint64_t *__restrict__ off, int w, int step,
+#ifndef EC_LB
+#define EC_LB 4
+#endif
+__global__ __launch_bounds__(64, EC_LB) void k_ecfix(size_t n, uint8_t *__restrict__ seqs, uint8_t *__restrict__ quals, const uint64_t *__restrict__ off, int w, int step,
                                                  const uint64_t *__restrict__ slots, uint64_t mask, int32_t *__restrict__ info, uint4 *heaps, uint64_t *traces,
                                                  uint32_t trace_cap, uint32_t *__restrict__ queue)
 {
@@ -538,7 +544,20 @@ __global__ __launch_bounds__(64, 4) void k_ecfix(size_t n, uint8_t *__restrict__
                     bool ends = bh == 5;
                     if (!ends) {
                         const int qh = ec_qual(r, ih, QW);
+#if EC_HOP_WARM
+                        // most hops stand, and then the next look-up is the k-mer `step` bases further on: its line is asked for NOW, beside this hop's
+                        // (one word of it is loaded and never looked at: the line is in the caches by the time the next turn asks for it)
+                        if (ih > 0) {
+                            EcNode zs = z;
+                            zs.y = (int64_t)((uint64_t)z.y >> 16 << 16 | (uint64_t)(ih + 1));       // (as ec_hop_good leaves a hop that stands)
+                            (void)ec_hop(r, zs, step, shift);
+                            const uint32_t w_ = *(const volatile uint32_t *)(slots + (ec_hash(zs.x) & (mask >> 3)) * EC_LINE);
+                            (void)w_;
+                        }
                         const int hh = ec_lookup(slots, mask, z.x, full, C);
+#else
+                        const int hh = ec_lookup(slots, mask, z.x, full, C);
+#endif
                         ends = !ec_hop_good(hh, bh, ih, qh, z, keep, keep_i, keep_q, depth_last) || keep_i <= 0;
                     }
                     if (ends) st = EL_HOPEND;
