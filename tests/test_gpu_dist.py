@@ -343,12 +343,13 @@ def _sink_worker(rank, world, port, N, err, ragged, key_shard, pieces, tmp, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("N,err,ragged,key_shard,pieces", [
-    (15000, 0.0, False, 0, 3),       # id shard, error-free reads
-    (15000, 0.01, True, 1, 4),       # key shard, reads with errors, ragged lengths, Ns: rows beyond max_nei = 4 are computed again on the root's GPU
-    (9000, 0.005, False, 0, 1),      # one piece: everything reaches the sink after the loop
+@pytest.mark.parametrize("world,N,err,ragged,key_shard,pieces", [
+    (3, 15000, 0.0, False, 0, 3),       # id shard, error-free reads
+    (3, 15000, 0.01, True, 1, 4),       # key shard, reads with errors, ragged lengths, Ns: rows beyond max_nei = 4 are computed again on the root's GPU
+    (3, 9000, 0.005, False, 0, 1),      # one piece: everything reaches the sink after the loop
+    (1, 9000, 0.01, True, 0, 2),        # a world of one: the root's own pieces take the same way
 ])
-def test_root_folds_arriving_pieces_into_the_rows_unitig_walks(gpu, tmp_path, N, err, ragged, key_shard, pieces):
+def test_root_folds_arriving_pieces_into_the_rows_unitig_walks(gpu, tmp_path, world, N, err, ragged, key_shard, pieces):
     """the root of the N-process step kept the packed rows (125 bytes per id) where the CLI holds 44.5.  With host_table = 2 it keeps no
     table: every piece of every peer goes from its pinned landing buffers through cfg.row_sink (fmdh_dist_root_sink, libfmdhost) into the slim rows while
     the next piece is computed; fmdh_dist_root_finish + the walk then print the MAG -- the bytes `fermi-amd unitig -l50` prints from one process.  Three
@@ -357,7 +358,6 @@ def test_root_folds_arriving_pieces_into_the_rows_unitig_walks(gpu, tmp_path, N,
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    world = 3
     ps = [ctx.Process(target=_sink_worker, args=(r, world, port, N, err, ragged, key_shard, pieces, str(tmp_path), q)) for r in range(world)]
     for p in ps:
         p.start()
