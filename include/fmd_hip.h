@@ -409,7 +409,8 @@ typedef struct {
      * row_sink -- n_rows packed rows as fmd_ovlp_pack_rows_dev writes them: ids[n_rows], prec[n_rows], off[n_rows + 1] into var -- on the thread that runs the
      * step, while the GPUs compute and pack the next piece; the buffers are reused two pieces later.  What unitig.c:394-404 does by joining its workers into
      * one graph: here the consumer (fermi_amd/host/dist_root.c folds the rows into the 44.5-byte rows `unitig` walks) takes them as they arrive, and the
-     * root's memory is what the consumer keeps.  A non-zero return fails the step on every rank (FMD_E_IO).  Only the root's row_sink / sink_ctx are read. */
+     * root's memory is what the consumer keeps.  A non-zero return fails the step on every rank (FMD_E_IO).  Only the root's row_sink / sink_ctx are read.
+     * A step that fails (any rank, any reason) has handed the sink SOME of its pieces: what the consumer holds then is incomplete -- it starts over. */
     int (*row_sink)(void *ctx, uint64_t n_rows, const uint32_t *ids, const fmd_ovlp_rec_t *prec, const uint64_t *off, const uint8_t *var, uint32_t max_nei);
     void *sink_ctx;
 } fmd_ovlp_dist_cfg_t;
