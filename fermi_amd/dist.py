@@ -580,16 +580,32 @@ class DistStepFailed(RuntimeError):
         self.failed_rank, self.code, self.piece = rank, code, piece
 
 
-def piecewise_exchange(torch, dist, rank, world, root, pieces, rows_of_rank, my_pieces):
+def piecewise_exchange(torch, dist, rank, world, root, pieces, rows_of_rank, my_pieces, sink=None):
     """The gather in pieces: my_pieces = list over p of (pid int32 [np], prec uint8 [np * 64], off int64 [np + 1], var uint8 [bytes]) of
     this rank's rows piece_begin(rows, p) .. piece_begin(rows, p + 1) in its computing order -- or an int (a negative status code): this
     rank FAILED on that piece (and on every later one).  Per piece: an all-gather of (rows, variable bytes, status), then every peer's four
     arrays straight to the root.  The status word is how a failure reaches everybody (fmd_ovlp_dist_step, fmd_ovlp_dist.hip: the same three
     words): all ranks read the same gathered words and raise DistStepFailed for the first failing rank BEFORE any send or receive of the piece.
-    -> root: dict id -> (record bytes, variable-part bytes) of every row of the job; others: None."""
-    table = {} if rank == root else None
+    -> root: dict id -> (record bytes, variable-part bytes) of every row of the job; others: None.
+    sink (the same on every rank: a callable at the root, anything true elsewhere): the root keeps NO table -- every peer's piece goes to
+    sink(ids uint32 [n], prec uint8 [n * 64], off uint64 [n + 1], var uint8) as it has arrived (fmd_ovlp_dist_cfg_t.host_table = 2 / row_sink), a piece behind
+    the exchange as the C step does it; a sink that raises is a failure of the root (FMD_E_IO = -4) and reaches everybody with the next status word -- one
+    more is exchanged after the last piece."""
+    table = {} if rank == root and not sink else None
     failed = 0
+    waiting = []          # root with a sink: the piece that has arrived and not been handed on yet
+
+    def hand_on():
+        nonlocal failed
+        while waiting and not failed:
+            qpid, qprec, qoff, qvar = waiting.pop(0)
+            try:
+                sink(qpid.numpy().view(np.uint32), qprec.numpy(), qoff.numpy().astype(np.uint64), qvar.numpy())
+            except Exception:
+                failed = -4
     for p in range(pieces):
+        if rank == root and sink:
+            hand_on()                                    # piece p - 1, before this rank says how it fares
         if not isinstance(my_pieces[p], tuple):
             failed = failed or int(my_pieces[p])
         if failed:
@@ -631,8 +647,20 @@ def piecewise_exchange(torch, dist, rank, world, root, pieces, rows_of_rank, my_
             w.wait()
         for q in range(world):   # placement: what k_place does at the root
             qpid, qprec, qoff, qvar = got[q]
+            if sink:
+                if len(qpid):
+                    waiting.append((qpid, qprec, qoff, qvar))
+                continue
             for t in range(len(qpid)):
                 table[int(qpid[t])] = (qprec[t * 64:(t + 1) * 64].numpy().tobytes(), qvar[int(qoff[t]):int(qoff[t + 1])].numpy().tobytes())
+    if sink:   # the last piece, and how the sink fared with it: everybody's code
+        if rank == root:
+            hand_on()
+        words = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(words, torch.tensor([failed], dtype=torch.int64))
+        for q in range(world):
+            if int(words[q][0]):
+                raise DistStepFailed(q, int(words[q][0]), pieces)
     return table
 
 

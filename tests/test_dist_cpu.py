@@ -254,3 +254,75 @@ def test_key_splitters_partition_the_key_space():
             assert ((d == p) == ((ks >= split[p]) & (ks < split[p + 1]))).all()
         assert (fdist.key_dest(np.array([0xfffffffe, 0xffffffff], dtype=np.uint64), 5, split) == 5).all()
     assert list(fdist.local_quantiles(np.array([3, 5, 9, 11, 0xfffffffe, 0xffffffff], dtype=np.uint32), 2)) == [0, 9]
+
+
+def _sink_worker(rank, world, port, fmd, min_match, pieces, break_sink, tmp, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, HERE)
+    import orcbind
+    import packref
+    from fermi_amd import hostlib
+    o = orcbind.OrcIndex(fmd)
+    n_ids = int(o.mcnt[1])
+    own = fdist.shard_ids(n_ids, rank, world)
+    comp = own[np.random.default_rng(7 + rank).permutation(len(own))]          # the computing order of pass 2: not the id order
+    rec, nei, seq = o.overlap_batch(comp, min_match, max_len=100, max_nei=8, n_threads=2)
+    o.close()
+    prec, off, var = packref.pack_rows(rec, nei, seq, 8)
+    rows_of_rank = [fdist.shard_size(n_ids, r, world) for r in range(world)]
+    my = []
+    for p in range(pieces):
+        b, e = fdist.piece_begin(len(comp), p, pieces), fdist.piece_begin(len(comp), p + 1, pieces)
+        oo = off[b:e + 1].astype(np.int64) - int(off[b])
+        my.append((torch.from_numpy(comp[b:e].astype(np.int32)), torch.from_numpy(prec[b:e].view(np.uint8).reshape(-1).copy()), torch.from_numpy(oo),
+                   torch.from_numpy(var[int(off[b]):int(off[e])].copy())))
+    root = hostlib.DistRoot(n_ids, 128) if rank == 0 else None
+    fed = [0]
+
+    def sink(ids, prec_u8, off_u64, var_u8):
+        if break_sink and fed[0] >= 1:
+            raise MemoryError("the consumer is out of room")
+        fed[0] += 1
+        root.feed(ids, prec_u8, off_u64, var_u8, 8)            # (records as the 64 bytes they are)
+
+    try:
+        fdist.piecewise_exchange(torch, dist, rank, world, 0, pieces, rows_of_rank, my, sink=sink if rank == 0 else True)
+        if rank == 0:
+            assert root.rows() == n_ids
+            root.finish(min_match)
+            out = os.path.join(tmp, "sink.mag")
+            root.walk(min_match, out)
+            q.put((rank, open(out, "rb").read()))
+        else:
+            q.put((rank, None))
+    except fdist.DistStepFailed as ex:
+        q.put((rank, (ex.failed_rank, ex.code)))
+    if root:
+        root.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,pieces,break_sink", [(2, 3, False), (3, 4, False), (3, 1, False), (3, 4, True)])
+def test_root_folds_pieces_through_a_sink_gloo(oracle_lib, tmp_path, world, pieces, break_sink):
+    """The N > 1 step with a root that keeps no table (fmd_ovlp_dist_cfg_t.host_table = 2; here the Python twin of its protocol over gloo, the C folding code of
+    libfmdhost behind the sink): every peer's piece is folded into the rows `unitig` walks a piece behind the exchange, and the MAG the root prints is
+    `fermi unitig -t1`'s.  A sink that fails takes every rank out of the step with FMD_E_IO, the root named as the one that failed."""
+    import gzip
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_sink_worker, args=(r, world, port, os.path.join(GOLD, "tiny.fmd"), 50, pieces, break_sink, str(tmp_path), q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if break_sink:
+        assert got == {r: (0, -4) for r in range(world)}
+    else:
+        assert got[0] == gzip.open(os.path.join(GOLD, "tiny.mag.gz"), "rb").read()
+        assert all(got[r] is None for r in range(1, world))
