@@ -217,7 +217,9 @@ __global__ __launch_bounds__(64, 4) void k_ovl_walk(FmdIndexView ix, size_t n, c
         // The admission gate (gate_n > 1): idle lanes take their next strand only when gate_n of them are idle (or nobody is walking).  What a lane does once per
         // strand -- the parked state in, the record, the row and the work-list entry out -- costs the wave its whole code in every step in which ANY lane does
         // it; lanes that start together finish within a few steps of each other (a step in which the LF step cannot share the extension's gather sets a lane
-        // back by one), lanes that refill one by one drift apart until some lane does it in every step.
+        // back by one), lanes that refill one by one drift apart until some lane does it in every step.  MEASURED on reads of one length: no effect at 16 .. 64
+        // lanes (214.2 - 214.5 ms per 10^8 strands, profiles/r6_gate) -- such strands keep a wave's lanes in step by themselves; off by default
+        // (FMD_TAIL_GATE / FMD_HEAD_GATE), kept for read sets of mixed lengths, where it has not been measured.  (k_ecfix is where this halves the time.)
         const bool gate = gate_n <= 1 || __popcll(__ballot(st == WK_IDLE && !exhausted)) >= gate_n || __ballot(st != WK_IDLE) == 0;
         const size_t my = fmd_tickets_take(tk_, queue, gate && st == WK_IDLE && !exhausted, (MODE != WALK_WHOLE && (tchunk >> 24)) ? n : 0);
         if (gate && st == WK_IDLE && !exhausted) {
